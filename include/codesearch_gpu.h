@@ -1,0 +1,229 @@
+/*
+ * codesearch_gpu.h — C ABI of libcsgpu.so, the MI355X (gfx950) embedding + similarity
+ * hot path for flupkede/codesearch.
+ *
+ * The reference has no FFI/plugin seam for this path: callers use
+ * two concrete Rust structs directly.  Each entry point below therefore names the
+ * reference METHOD it stands in for (paths relative to /root/reference):
+ *
+ *   VectorStore  (src/vectordb/store.rs:94-102)   -> cs_index_*
+ *   FastEmbedder (src/embed/embedder.rs:201-322)  -> cs_embedder_*
+ *
+ * Conventions
+ *   - Plain C: pointers, sizes, opaque handles.  No C++/torch types cross the boundary.
+ *   - Every function returns a cs_status (0 = ok).  cs_last_error() returns a
+ *     thread-local UTF-8 message that reproduces the reference's anyhow! wording.
+ *   - The caller allocates every output buffer; inputs are borrowed for the call only.
+ *   - "host" pointers are ordinary process memory; "_device" variants take HBM pointers
+ *     on the handle's device and a hipStream_t passed as void* (NULL = the handle's
+ *     own stream), and do not synchronise.
+ *   - Threading mirrors the Rust receivers: functions standing in for `&mut self`
+ *     methods (add/remove/build/clear, all of cs_embedder_*) need external exclusion
+ *     per handle; cs_index_search* stands in for `&self` search and is re-entrant
+ *     (src/search/mod.rs:508-511 calls it from rayon threads).
+ *   - There is no CPU fallback: if no HIP device is usable, create() fails with
+ *     CS_ERR_HIP.
+ */
+#ifndef CODESEARCH_GPU_H
+#define CODESEARCH_GPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum cs_status {
+    CS_OK = 0,
+    CS_ERR_BAD_ARG = 1,
+    CS_ERR_DIM_MISMATCH = 2, /* store.rs:349-353, :433-437, :667-671 */
+    CS_ERR_NOT_BUILT = 3,    /* store.rs:440-444 */
+    CS_ERR_CANCELLED = 4,    /* embedder.rs:280-282 */
+    CS_ERR_OOM = 5,
+    CS_ERR_HIP = 6,
+    CS_ERR_UNSUPPORTED = 7
+} cs_status;
+
+/* Largest k a single search call accepts.  The reference asks for at most
+ * max(5*max_results, 200) (src/search/mod.rs:494-502). */
+#define CS_MAX_K 256u
+/* Largest number of queries per search call. */
+#define CS_MAX_QUERIES 4096u
+
+const char* cs_last_error(void);
+/* ABI version of this header; bumped on any signature change. */
+uint32_t cs_abi_version(void);
+/* Number of visible HIP devices (0 if none / no driver). */
+int32_t cs_device_count(void);
+
+/* ------------------------------------------------------------------------------------
+ * Vector index  — the vector half of VectorStore.  Chunk metadata (store.rs:19-85) stays
+ * host-side with the caller, keyed by the u32 ids this index hands out.
+ * Rows live in one row-major [capacity, dim] f32 matrix in HBM; id == id_base + row.
+ * ---------------------------------------------------------------------------------- */
+typedef struct cs_index cs_index;
+
+/* VectorStore::new(path, dimensions) — store.rs:110-176.  `capacity_rows` is a
+ * reservation hint (the matrix grows by doubling); `device` is the HIP ordinal;
+ * `id_base` is the first id this shard hands out (0 for a single-GPU store; the row
+ * offset of the shard for a row-sharded store). */
+int32_t cs_index_create(uint32_t dim, uint64_t capacity_rows, int32_t device,
+                        uint32_t id_base, cs_index** out);
+void cs_index_destroy(cs_index* h);
+
+/* insert_chunks_with_ids — store.rs:618-686 (vector half: writer.add_item, :674).
+ * Appends n rows of `dim` floats (host memory); ids are contiguous from next_id
+ * (store.rs:659-685).  dim != index dim -> CS_ERR_DIM_MISMATCH with the reference text
+ * "Embedding dimension mismatch: expected {}, got {}".  Marks the index not-built
+ * (store.rs:682).  out_ids may be NULL. */
+int32_t cs_index_add(cs_index* h, const float* rows, uint64_t n, uint32_t dim,
+                     uint32_t* out_ids);
+/* Same, rows already in HBM on the index's device (zero-copy hand-off from the
+ * encoder's pooled+normalised output). */
+int32_t cs_index_add_device(cs_index* h, const float* d_rows, uint64_t n, uint32_t dim,
+                            uint32_t* out_ids, void* stream);
+/* Appends n rows produced in place by the counter-based generator of
+ * include/cs_synth.h (row r, col c -> cs_synth_value(seed, (first_row + r)*dim + c)).
+ * Exists so 10M..80M-row corpora never cross PCIe; not a reference method. */
+int32_t cs_index_add_synthetic(cs_index* h, uint64_t n, uint64_t seed, uint64_t first_row,
+                               uint32_t* out_first_id);
+
+/* delete_chunks — store.rs:548-610.  Tombstones the ids (a deleted row can never be
+ * returned again); *removed counts ids that were live.  Unknown ids are ignored like
+ * `del_item(..).is_ok()` failing (store.rs:594).  Marks not-built if any was removed
+ * (store.rs:604-606). */
+int32_t cs_index_remove(cs_index* h, const uint32_t* ids, uint64_t n, uint64_t* removed);
+
+/* build_index — store.rs:386-430.  The exact scan needs no tree; this publishes the
+ * appended rows to searchers and sets `indexed` (store.rs:428). */
+int32_t cs_index_build(cs_index* h);
+/* clear — store.rs:690-707. */
+int32_t cs_index_clear(cs_index* h);
+
+/* is_indexed (store.rs:745), stats().total_chunks (store.rs:488-523), next_id, dims. */
+int32_t cs_index_is_built(const cs_index* h);
+uint64_t cs_index_len(const cs_index* h);      /* live rows (appended - removed) */
+uint32_t cs_index_next_id(const cs_index* h);  /* store.rs:101 */
+uint32_t cs_index_dim(const cs_index* h);
+int32_t cs_index_device(const cs_index* h);
+
+/* search — store.rs:431-486, for nq queries at once (the caller's par_iter over query
+ * variants, src/search/mod.rs:508-511, becomes one call).
+ *   queries : [nq, dim] f32 row-major
+ *   out_cos : [nq, k] raw cosine, best first; order is (cosine desc, id asc)
+ *   out_ids : [nq, k] u32
+ *   out_counts : [nq] number of valid results per query (< k when fewer live rows)
+ * Errors: dim mismatch -> "Query embedding dimension mismatch: expected {}, got {}"
+ * (store.rs:432-438); not built -> "Index not built. Call build_index() after
+ * inserting chunks." (store.rs:440-444).  The reference's distance/score pair is
+ * derived from the cosine by cs_cos_to_distance()/cs_cos_to_score(). */
+int32_t cs_index_search(cs_index* h, const float* queries, uint32_t nq, uint32_t dim,
+                        uint32_t k, float* out_cos, uint32_t* out_ids,
+                        uint32_t* out_counts);
+/* Same with queries and outputs in HBM; asynchronous on `stream`.  out_keys receives
+ * [nq, k] packed 64-bit sort keys (see cs_key_* below; 0 = empty slot), best first —
+ * the form the shard merge consumes.  out_cos / out_ids / out_counts may be NULL. */
+int32_t cs_index_search_device(cs_index* h, const float* d_queries, uint32_t nq,
+                               uint32_t dim, uint32_t k, uint64_t* d_out_keys,
+                               float* d_out_cos, uint32_t* d_out_ids,
+                               uint32_t* d_out_counts, void* stream);
+
+/* Shard merge: given `nlists` per-shard key lists [nlists, nq, k]
+ * (as all-gathered over RCCL), write the merged best-k per query.  Device pointers. */
+int32_t cs_merge_topk_device(int32_t device, const uint64_t* d_keys, uint32_t nlists,
+                             uint32_t nq, uint32_t k, uint64_t* d_out_keys,
+                             float* d_out_cos, uint32_t* d_out_ids,
+                             uint32_t* d_out_counts, void* stream);
+
+/* Copy rows [first_row, first_row + n) of the matrix back to host memory (test and
+ * persistence aid; VectorStore has no direct counterpart). */
+int32_t cs_index_read_rows(cs_index* h, uint64_t first_row, uint64_t n, float* out_rows);
+
+/* Kernel timing for bench.py: when enabled, every scan launch is bracketed by HIP
+ * events on the launching stream.  read() synchronises and returns accumulated
+ * milliseconds and launch count since the last reset. */
+int32_t cs_index_profile(cs_index* h, int32_t enable);
+int32_t cs_index_profile_read(cs_index* h, double* scan_ms, uint64_t* scan_launches,
+                              double* merge_ms, int32_t reset);
+
+/* Score mapping.  store.rs:477-478: score = 1 - distance, distance = arroy 0.5.0
+ * Cosine = (1 - cos) / 2  (third-party). */
+static inline float cs_cos_to_distance(float c) { return (1.0f - c) * 0.5f; }
+static inline float cs_cos_to_score(float c) { return 1.0f - (1.0f - c) * 0.5f; }
+
+/* Packed sort key: high 32 bits = order-preserving image of the f32 cosine, low 32 =
+ * ~id, so that a larger key is a better result under (cosine desc, id asc). */
+static inline uint64_t cs_key_pack(float c, uint32_t id) {
+    union { float f; uint32_t u; } v; v.f = c + 0.0f; /* -0 -> +0 */
+    uint32_t o = (v.u & 0x80000000u) ? ~v.u : (v.u | 0x80000000u);
+    return ((uint64_t)o << 32) | (uint64_t)(~id);
+}
+static inline float cs_key_cos(uint64_t key) {
+    uint32_t o = (uint32_t)(key >> 32);
+    union { float f; uint32_t u; } v;
+    v.u = (o & 0x80000000u) ? (o & 0x7fffffffu) : ~o;
+    return v.f;
+}
+static inline uint32_t cs_key_id(uint64_t key) { return ~(uint32_t)key; }
+
+/* ------------------------------------------------------------------------------------
+ * Embedder — FastEmbedder.  The device side starts from token ids (the tokenizer is a
+ * host concern).  Architecture = HF BertModel without pooler.
+ * ---------------------------------------------------------------------------------- */
+typedef struct cs_embedder cs_embedder;
+
+typedef enum cs_pooling { CS_POOL_CLS = 0, CS_POOL_MEAN = 1 } cs_pooling;
+
+typedef struct cs_bert_config {
+    uint32_t vocab_size;        /* 30522 for bge-small-en-v1.5 */
+    uint32_t hidden;            /* 384  (== ModelType::dimensions, embedder.rs:76-96) */
+    uint32_t layers;            /* 12 */
+    uint32_t heads;             /* 12 */
+    uint32_t intermediate;      /* 1536 */
+    uint32_t max_position;      /* 512 */
+    uint32_t type_vocab_size;   /* 2 */
+    float layer_norm_eps;       /* 1e-12 */
+    int32_t pooling;            /* cs_pooling */
+} cs_bert_config;
+
+/* Fills *cfg with the BAAI/bge-small-en-v1.5 architecture (CLS pooling). */
+void cs_bert_config_bge_small(cs_bert_config* cfg);
+/* Number of f32 parameters a config needs, in the flat order documented in
+ * codesearch_amd/csrc/bert_params.h (HF BertModel tensor order). */
+uint64_t cs_bert_param_count(const cs_bert_config* cfg);
+
+/* FastEmbedder::with_cache_dir — embedder.rs:218-245.  `params` = flat f32 parameter
+ * block (host memory, cs_bert_param_count floats); NULL => weights are generated on the
+ * device from `seed` by the counter-based generator of include/cs_synth.h (synthetic-weight mode). */
+int32_t cs_embedder_create(const cs_bert_config* cfg, const float* params, uint64_t seed,
+                           int32_t device, cs_embedder** out);
+void cs_embedder_destroy(cs_embedder* h);
+uint32_t cs_embedder_dim(const cs_embedder* h);   /* dimensions(), embedder.rs:307 */
+
+/* embed_batch_chunked — embedder.rs:266-295, from token ids.
+ *   ids, mask : [n, seq_len] i32 row-major (mask 1 = token, 0 = pad)
+ *   batch     : mini-batch size (embed_batch's 256/128/64 policy, embedder.rs:251-261;
+ *               0 = that policy, honouring CODESEARCH_BATCH_SIZE)
+ *   out       : [n, dim] f32 — L2-normalised pooled embeddings
+ *   cancel    : optional flag polled between mini-batches (embedder.rs:280); non-zero
+ *               -> CS_ERR_CANCELLED "Embedding interrupted by shutdown request". */
+int32_t cs_embedder_embed_ids(cs_embedder* h, const int32_t* ids, const int32_t* mask,
+                              uint64_t n, uint32_t seq_len, uint32_t batch, float* out,
+                              const volatile int32_t* cancel);
+/* Same, but leaves the [n, dim] result in HBM at d_out (e.g. to feed
+ * cs_index_add_device without a PCIe round trip). */
+int32_t cs_embedder_embed_ids_device(cs_embedder* h, const int32_t* ids,
+                                     const int32_t* mask, uint64_t n, uint32_t seq_len,
+                                     uint32_t batch, float* d_out,
+                                     const volatile int32_t* cancel);
+/* Debug/parity aid: last_hidden_state [n*seq_len, hidden] of the most recent
+ * mini-batch (n <= batch), copied to host. */
+int32_t cs_embedder_last_hidden(cs_embedder* h, float* out, uint64_t n_tokens);
+int32_t cs_embedder_profile_read(cs_embedder* h, double* forward_ms, uint64_t* forwards,
+                                 int32_t reset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CODESEARCH_GPU_H */
