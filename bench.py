@@ -1,0 +1,208 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the hot path (BASELINE.json): brute-force cosine
+top-10 over a 10M x 384 fp32 corpus resident in HBM, one MI355X per rank.
+
+A "step" = one pass of the hot path over one batch of synthetic input: the query batch
+(already in HBM) is scored against every row of the rank's shard by the fused scan +
+top-k kernel, block partials are merged, and for N > 1 the per-shard top-k lists are
+all-gathered over RCCL and merged.  `value` = corpus rows ("chunks") searched per second
+over all ranks = N * rows_per_gpu * nq * K / t.
+
+  python bench.py                      # N=1, 10M x 384, Q=1, k=10
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N
+
+Adds to the JSON line:
+  roofline     — the scan kernel against the 8 TB/s HBM peak: algorithmic bytes per launch
+                 (rows*dim*4) / HIP-event duration of that kernel, measured live.
+  cpu_baseline — the CPU oracle's tuned port timed on this box's host cores over a bounded
+                 sample (reported baseline, not the target).
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+SEED = 0xC0DE5EA
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--rows", type=int, default=10_000_000, help="corpus rows per GPU")
+    ap.add_argument("--dim", type=int, default=384)
+    ap.add_argument("--nq", type=int, default=1, help="queries per step")
+    ap.add_argument("--k", type=int, default=10)
+    ap.add_argument("--cpu-sample-rows", type=int, default=1_000_000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(oracle, sample_rows, dim, k, store_cls):
+    """Time the oracle's tuned CPU port (and the literal scalar loop on a smaller slice) on
+    a bounded sample of the same workload; also returns recall@k of the HIP path against
+    the CPU result on that sample (BASELINE.json configs[1]: 1 query over 1M x 384)."""
+    import numpy as np
+
+    from codesearch_amd.synth import synth_rows
+
+    corpus = oracle.synth_rows(SEED, 0, sample_rows, dim)
+    q = synth_rows(SEED + 1, 0, 1, dim)[0]
+    threads = oracle.num_threads()
+    oracle.scan_topk(corpus[: min(sample_rows, 50_000)], q, k, mode="omp")  # warm threads
+    reps, t_total, res = 0, 0.0, None
+    while t_total < 8.0 and reps < 64:
+        t0 = time.perf_counter()
+        res = oracle.scan_topk(corpus, q, k, mode="omp")
+        t_total += time.perf_counter() - t0
+        reps += 1
+    omp_rate = sample_rows * reps / t_total
+    lit_rows = min(sample_rows, 200_000)
+    t0 = time.perf_counter()
+    oracle.scan_topk(corpus[:lit_rows], q, k, mode="literal")
+    lit_rate = lit_rows / (time.perf_counter() - t0)
+    # recall@k of the HIP path vs the CPU result on the same sample
+    st = store_cls(None, dim, device=0)
+    st.insert_synthetic(sample_rows, SEED, 0)
+    st.build_index()
+    cos, ids, _ = st.search_raw(q, k)
+    st.close()
+    recall = len(set(ids[0].tolist()) & set(res[1].tolist())) / float(k)
+    max_err = float(np.abs(cos[0] - res[0]).max())
+    return {
+        "value": omp_rate, "unit": "chunks/s", "cores": threads, "kind": "port",
+        "sample": f"{sample_rows} x {dim} fp32 rows of the same synthetic corpus, 1 query, top-{k}, "
+                  f"{reps} passes of oracle/scan_oracle.c cs_oracle_scan_topk_omp ({threads} threads)",
+        "literal_1thread_chunks_per_s": lit_rate,
+        "literal_sample_rows": lit_rows,
+    }, recall, max_err
+
+
+def main():
+    args = parse_args()
+    import torch
+
+    from codesearch_amd import VectorStore
+    from codesearch_amd.sharded import ShardedVectorStore
+    from codesearch_amd.synth import synth_rows
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    shard = ShardedVectorStore(args.dim, args.rows, rank, world, local_rank)
+    shard.fill_synthetic(SEED)
+    q_host = synth_rows(SEED + 1, 0, args.nq, args.dim)  # same queries on every rank
+    d_q = torch.from_numpy(q_host).to(f"cuda:{local_rank}")
+    torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        shard.search_device(d_q, args.nq, args.k)
+    torch.cuda.synchronize()
+    shard.store.profile(True)
+    shard.store.profile_read(reset=True)
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = shard.search_device(d_q, args.nq, args.k)
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    scan_ms, launches, merge_ms = shard.store.profile_read(reset=True)
+    shard.store.profile(False)
+
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    ids0 = out["ids"].cpu().numpy().astype("uint32").reshape(args.nq, args.k)
+    cos0 = out["cos"].cpu().numpy().reshape(args.nq, args.k)
+
+    if rank == 0:
+        total_rows = args.rows * world
+        value = total_rows * args.nq * args.steps / elapsed
+        scan_us = scan_ms * 1e3 / max(launches, 1)
+        alg_bytes = args.rows * args.dim * 4  # per launch: every row of the shard read once
+        achieved = alg_bytes / (scan_us * 1e-6) / 1e9
+        line = {
+            "metric": "chunks searched/sec, brute-force cosine top-10 over 10M x 384 fp32 corpus per GPU",
+            "value": value,
+            "unit": "chunks/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed * 1e3 / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"brute-force cosine top-{args.k}, {args.nq} query/step over "
+                            f"{args.rows} x {args.dim} fp32 rows per GPU (BASELINE.json north-star target; "
+                            f"rows generated in HBM by include/cs_synth.h, seed {SEED:#x})",
+                "rows_per_gpu": args.rows, "dim": args.dim, "queries_per_step": args.nq, "k": args.k,
+                "parallelism": f"row-sharded x{world}, all-gather of per-shard top-k" if world > 1 else "single GPU",
+            },
+            "roofline": {
+                "kernel": "cs::scan_topk_kernel<3,4,1,true>" if args.dim == 384 and args.nq == 1 else "cs::scan_topk_kernel",
+                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBPS,
+                "traffic": None,
+                "algorithmic_bytes_per_launch": alg_bytes,
+                "avg_launch_us": scan_us, "launches_timed": launches,
+                "merge_avg_us": merge_ms * 1e3 / max(launches, 1),
+            },
+            "top1": {"id": int(ids0[0][0]), "cos": float(cos0[0][0])},
+        }
+        traffic_file = os.path.join(ROOT, "profiles", "scan_traffic.json")
+        if os.path.exists(traffic_file):
+            try:
+                tr = json.load(open(traffic_file))
+                if tr.get("rows") == args.rows and tr.get("dim") == args.dim:
+                    line["roofline"]["traffic"] = tr.get("hbm_bytes_per_launch")
+                    line["roofline"]["traffic_source"] = tr.get("source")
+            except Exception:
+                pass
+        if world == 1 and not args.no_cpu_baseline:
+            from tests.oracle_lib import load_oracle
+
+            base, recall, err = cpu_baseline(load_oracle(), args.cpu_sample_rows, args.dim, args.k, VectorStore)
+            line["cpu_baseline"] = base
+            line["recall_at_10"] = recall
+            line["max_abs_cos_err_vs_cpu"] = err
+        print(json.dumps(line), flush=True)
+
+    barrier()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

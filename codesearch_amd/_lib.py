@@ -1,0 +1,118 @@
+"""ctypes binding of libcsgpu.so (include/codesearch_gpu.h).
+
+There is no CPU fallback: if the HIP library is missing or cannot be loaded this module
+raises, and every product entry point goes through it.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(PKG_DIR, "libcsgpu.so")
+
+CS_OK, CS_ERR_BAD_ARG, CS_ERR_DIM_MISMATCH, CS_ERR_NOT_BUILT = 0, 1, 2, 3
+CS_ERR_CANCELLED, CS_ERR_OOM, CS_ERR_HIP, CS_ERR_UNSUPPORTED = 4, 5, 6, 7
+CS_MAX_K = 256
+CS_MAX_QUERIES = 4096
+
+f32p = C.POINTER(C.c_float)
+u32p = C.POINTER(C.c_uint32)
+i32p = C.POINTER(C.c_int32)
+u64p = C.POINTER(C.c_uint64)
+f64p = C.POINTER(C.c_double)
+vp = C.c_void_p
+
+
+class BertConfig(C.Structure):
+    _fields_ = [
+        ("vocab_size", C.c_uint32),
+        ("hidden", C.c_uint32),
+        ("layers", C.c_uint32),
+        ("heads", C.c_uint32),
+        ("intermediate", C.c_uint32),
+        ("max_position", C.c_uint32),
+        ("type_vocab_size", C.c_uint32),
+        ("layer_norm_eps", C.c_float),
+        ("pooling", C.c_int32),
+    ]
+
+
+class CsError(RuntimeError):
+    """A non-zero cs_status; .code is the status, str() the reference-worded message."""
+
+    def __init__(self, code: int, message: str):
+        super().__init__(message)
+        self.code = code
+
+
+# name -> (restype, argtypes); every symbol include/codesearch_gpu.h declares.
+SIGNATURES = {
+    "cs_last_error": (C.c_char_p, []),
+    "cs_abi_version": (C.c_uint32, []),
+    "cs_device_count": (C.c_int32, []),
+    "cs_index_create": (C.c_int32, [C.c_uint32, C.c_uint64, C.c_int32, C.c_uint32, C.POINTER(vp)]),
+    "cs_index_destroy": (None, [vp]),
+    "cs_index_add": (C.c_int32, [vp, f32p, C.c_uint64, C.c_uint32, u32p]),
+    "cs_index_add_device": (C.c_int32, [vp, vp, C.c_uint64, C.c_uint32, u32p, vp]),
+    "cs_index_add_synthetic": (C.c_int32, [vp, C.c_uint64, C.c_uint64, C.c_uint64, u32p]),
+    "cs_index_remove": (C.c_int32, [vp, u32p, C.c_uint64, u64p]),
+    "cs_index_build": (C.c_int32, [vp]),
+    "cs_index_clear": (C.c_int32, [vp]),
+    "cs_index_is_built": (C.c_int32, [vp]),
+    "cs_index_len": (C.c_uint64, [vp]),
+    "cs_index_next_id": (C.c_uint32, [vp]),
+    "cs_index_dim": (C.c_uint32, [vp]),
+    "cs_index_device": (C.c_int32, [vp]),
+    "cs_index_search": (C.c_int32, [vp, f32p, C.c_uint32, C.c_uint32, C.c_uint32, f32p, u32p, u32p]),
+    "cs_index_search_device": (C.c_int32, [vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, vp, vp, vp]),
+    "cs_merge_topk_device": (C.c_int32, [C.c_int32, vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, vp, vp, vp]),
+    "cs_index_read_rows": (C.c_int32, [vp, C.c_uint64, C.c_uint64, f32p]),
+    "cs_index_profile": (C.c_int32, [vp, C.c_int32]),
+    "cs_index_profile_read": (C.c_int32, [vp, f64p, u64p, f64p, C.c_int32]),
+    "cs_bert_config_bge_small": (None, [C.POINTER(BertConfig)]),
+    "cs_bert_param_count": (C.c_uint64, [C.POINTER(BertConfig)]),
+    "cs_embedder_create": (C.c_int32, [C.POINTER(BertConfig), f32p, C.c_uint64, C.c_int32, C.POINTER(vp)]),
+    "cs_embedder_destroy": (None, [vp]),
+    "cs_embedder_dim": (C.c_uint32, [vp]),
+    "cs_embedder_embed_ids": (C.c_int32, [vp, i32p, i32p, C.c_uint64, C.c_uint32, C.c_uint32, f32p, i32p]),
+    "cs_embedder_embed_ids_device": (C.c_int32, [vp, i32p, i32p, C.c_uint64, C.c_uint32, C.c_uint32, vp, i32p]),
+    "cs_embedder_last_hidden": (C.c_int32, [vp, f32p, C.c_uint64]),
+    "cs_embedder_profile_read": (C.c_int32, [vp, f64p, u64p, C.c_int32]),
+}
+
+_LIB = None
+
+
+def load() -> C.CDLL:
+    """Load libcsgpu.so once; raise loudly when it is absent (run __graft_entry__.build())."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise FileNotFoundError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(make -C codesearch_amd/csrc). There is no CPU fallback."
+        )
+    # torch bundles its own libamdhip64.so.7; importing it first makes both share ONE HIP
+    # runtime in processes that also use torch.distributed (bench.py, multi-GPU tests).
+    try:
+        import torch  # noqa: F401
+    except Exception:  # pragma: no cover - torch is optional plumbing
+        pass
+    lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError => ABI drift, fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    _LIB = lib
+    return lib
+
+
+def last_error() -> str:
+    return load().cs_last_error().decode("utf-8", "replace")
+
+
+def check(status: int) -> None:
+    if status != CS_OK:
+        raise CsError(status, last_error())

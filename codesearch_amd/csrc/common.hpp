@@ -1,0 +1,76 @@
+// common.hpp — shared host/device helpers of libcsgpu (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <string>
+
+#include "../../include/codesearch_gpu.h"
+
+namespace cs {
+
+// ---- error plumbing: status code + thread-local message (cs_last_error) ---------------
+std::string& last_error_ref();
+int32_t fail(int32_t code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
+
+#define CS_HIP(expr)                                                                      \
+    do {                                                                                  \
+        hipError_t _e = (expr);                                                           \
+        if (_e != hipSuccess)                                                             \
+            return ::cs::fail(_e == hipErrorOutOfMemory ? CS_ERR_OOM : CS_ERR_HIP,        \
+                              "HIP error %d (%s) at %s:%d: %s", (int)_e,                  \
+                              hipGetErrorString(_e), __FILE__, __LINE__, #expr);          \
+    } while (0)
+
+#define CS_TRY(expr)                      \
+    do {                                  \
+        int32_t _s = (expr);              \
+        if (_s != CS_OK) return _s;       \
+    } while (0)
+
+// RAII: make `device` current for the calling thread, restore on scope exit.
+struct DeviceGuard {
+    int prev = -1;
+    bool changed = false;
+    explicit DeviceGuard(int device) {
+        if (hipGetDevice(&prev) == hipSuccess && prev != device) {
+            changed = (hipSetDevice(device) == hipSuccess);
+        }
+    }
+    ~DeviceGuard() {
+        if (changed) (void)hipSetDevice(prev);
+    }
+};
+
+// ---- packed sort key (mirrors cs_key_* in the public header) ------------------------------
+__host__ __device__ __forceinline__ uint64_t key_pack(float c, uint32_t id) {
+    c = c + 0.0f;  // -0 -> +0
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t u = __float_as_uint(c);
+#else
+    union { float f; uint32_t u; } v; v.f = c; uint32_t u = v.u;
+#endif
+    uint32_t o = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+    return ((uint64_t)o << 32) | (uint64_t)(~id);
+}
+__host__ __device__ __forceinline__ float key_cos(uint64_t key) {
+    uint32_t o = (uint32_t)(key >> 32);
+    uint32_t u = (o & 0x80000000u) ? (o & 0x7fffffffu) : ~o;
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __uint_as_float(u);
+#else
+    union { float f; uint32_t u; } v; v.u = u; return v.f;
+#endif
+}
+__host__ __device__ __forceinline__ uint32_t key_id(uint64_t key) { return ~(uint32_t)key; }
+
+inline uint32_t next_pow2(uint32_t v) {
+    uint32_t p = 1;
+    while (p < v) p <<= 1;
+    return p;
+}
+
+}  // namespace cs

@@ -1,0 +1,538 @@
+// index.hip — cs_index_*: the vector half of the reference's VectorStore
+// (/root/reference/src/vectordb/store.rs:94-750) as a device-resident row-major matrix
+// searched by the exact scan of scan.hip.  Metadata (store.rs:19-85) stays with the caller.
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <vector>
+
+#include "scan.hpp"
+
+namespace cs {
+
+std::string& last_error_ref() {
+    static thread_local std::string msg;
+    return msg;
+}
+
+int32_t fail(int32_t code, const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    last_error_ref() = buf;
+    return code;
+}
+
+struct EventTriple {
+    hipEvent_t e0, e1, e2;
+};
+
+// Per-call scratch.  Host-API calls borrow one from the pool (own stream); device-API
+// calls use the one bound to the caller's stream (stream order makes reuse safe).
+struct Workspace {
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    uint64_t* d_partial = nullptr; size_t partial_cap = 0;
+    uint64_t* d_tmp_a = nullptr; uint64_t* d_tmp_b = nullptr; size_t tmp_cap = 0;
+    float* d_queries = nullptr; size_t q_cap = 0;
+    uint64_t* d_keys = nullptr; float* d_cos = nullptr; uint32_t* d_ids = nullptr; size_t out_cap = 0;
+    uint32_t* d_counts = nullptr; size_t cnt_cap = 0;
+    float* h_cos = nullptr; uint32_t* h_ids = nullptr; uint32_t* h_counts = nullptr;
+    size_t h_out_cap = 0, h_cnt_cap = 0;
+    std::vector<EventTriple> free_events;
+
+    int32_t reserve(const ScanPlan& p, uint32_t nq, uint32_t dim, uint32_t k, bool host_io) {
+        if (p.partial_keys > partial_cap) {
+            if (d_partial) (void)hipFree(d_partial);
+            d_partial = nullptr; partial_cap = 0;
+            CS_HIP(hipMalloc(&d_partial, p.partial_keys * sizeof(uint64_t)));
+            partial_cap = p.partial_keys;
+        }
+        if (p.merge_keys > tmp_cap) {
+            if (d_tmp_a) (void)hipFree(d_tmp_a);
+            if (d_tmp_b) (void)hipFree(d_tmp_b);
+            d_tmp_a = d_tmp_b = nullptr; tmp_cap = 0;
+            CS_HIP(hipMalloc(&d_tmp_a, p.merge_keys * sizeof(uint64_t)));
+            CS_HIP(hipMalloc(&d_tmp_b, p.merge_keys * sizeof(uint64_t)));
+            tmp_cap = p.merge_keys;
+        }
+        if (!host_io) return CS_OK;
+        const size_t qn = (size_t)nq * dim, on = (size_t)nq * k;
+        if (qn > q_cap) {
+            if (d_queries) (void)hipFree(d_queries);
+            d_queries = nullptr; q_cap = 0;
+            CS_HIP(hipMalloc(&d_queries, qn * sizeof(float)));
+            q_cap = qn;
+        }
+        if (on > out_cap) {
+            if (d_keys) (void)hipFree(d_keys);
+            if (d_cos) (void)hipFree(d_cos);
+            if (d_ids) (void)hipFree(d_ids);
+            d_keys = nullptr; d_cos = nullptr; d_ids = nullptr; out_cap = 0;
+            CS_HIP(hipMalloc(&d_keys, on * sizeof(uint64_t)));
+            CS_HIP(hipMalloc(&d_cos, on * sizeof(float)));
+            CS_HIP(hipMalloc(&d_ids, on * sizeof(uint32_t)));
+            out_cap = on;
+        }
+        if (nq > cnt_cap) {
+            if (d_counts) (void)hipFree(d_counts);
+            d_counts = nullptr; cnt_cap = 0;
+            CS_HIP(hipMalloc(&d_counts, nq * sizeof(uint32_t)));
+            cnt_cap = nq;
+        }
+        if (on > h_out_cap) {
+            if (h_cos) (void)hipHostFree(h_cos);
+            if (h_ids) (void)hipHostFree(h_ids);
+            h_cos = nullptr; h_ids = nullptr; h_out_cap = 0;
+            CS_HIP(hipHostMalloc(&h_cos, on * sizeof(float)));
+            CS_HIP(hipHostMalloc(&h_ids, on * sizeof(uint32_t)));
+            h_out_cap = on;
+        }
+        if (nq > h_cnt_cap) {
+            if (h_counts) (void)hipHostFree(h_counts);
+            h_counts = nullptr; h_cnt_cap = 0;
+            CS_HIP(hipHostMalloc(&h_counts, nq * sizeof(uint32_t)));
+            h_cnt_cap = nq;
+        }
+        return CS_OK;
+    }
+
+    void release_all() {
+        if (d_partial) (void)hipFree(d_partial);
+        if (d_tmp_a) (void)hipFree(d_tmp_a);
+        if (d_tmp_b) (void)hipFree(d_tmp_b);
+        if (d_queries) (void)hipFree(d_queries);
+        if (d_keys) (void)hipFree(d_keys);
+        if (d_cos) (void)hipFree(d_cos);
+        if (d_ids) (void)hipFree(d_ids);
+        if (d_counts) (void)hipFree(d_counts);
+        if (h_cos) (void)hipHostFree(h_cos);
+        if (h_ids) (void)hipHostFree(h_ids);
+        if (h_counts) (void)hipHostFree(h_counts);
+        for (auto& t : free_events) {
+            (void)hipEventDestroy(t.e0); (void)hipEventDestroy(t.e1); (void)hipEventDestroy(t.e2);
+        }
+        if (own_stream && stream) (void)hipStreamDestroy(stream);
+    }
+};
+
+}  // namespace cs
+
+using namespace cs;
+
+struct cs_index {
+    int device = 0;
+    int num_cus = 256;
+    uint32_t dim = 0;
+    uint32_t id_base = 0;
+    uint64_t capacity = 0;   // rows allocated
+    uint64_t n_rows = 0;     // rows appended (next_id - id_base)
+    uint64_t n_removed = 0;
+    float* d_corpus = nullptr;
+    uint32_t* d_dead = nullptr;  // bitmap over rows, sized for `capacity`
+    std::vector<uint32_t> h_dead;
+    bool built = false;
+
+    std::mutex mu;  // guards the pools below (search is re-entrant)
+    std::vector<Workspace*> pool;
+    std::map<hipStream_t, Workspace*> by_stream;
+    bool profile = false;
+    std::vector<EventTriple> pending;
+    double scan_ms = 0.0, merge_ms = 0.0;
+    uint64_t scan_launches = 0;
+};
+
+namespace {
+
+int32_t grow(cs_index* h, uint64_t need_rows) {
+    if (need_rows <= h->capacity) return CS_OK;
+    uint64_t cap = h->capacity ? h->capacity * 2 : 1024;
+    if (cap < need_rows) cap = need_rows;
+    float* nc = nullptr;
+    uint32_t* nd = nullptr;
+    const size_t words = (size_t)((cap + 31) / 32);
+    CS_HIP(hipMalloc(&nc, (size_t)cap * h->dim * sizeof(float)));
+    hipError_t e = hipMalloc(&nd, words * sizeof(uint32_t));
+    if (e != hipSuccess) {
+        (void)hipFree(nc);
+        return fail(CS_ERR_OOM, "hipMalloc(dead bitmap) failed: %s", hipGetErrorString(e));
+    }
+    CS_HIP(hipMemset(nd, 0, words * sizeof(uint32_t)));
+    if (h->n_rows) {
+        CS_HIP(hipMemcpy(nc, h->d_corpus, (size_t)h->n_rows * h->dim * sizeof(float),
+                         hipMemcpyDeviceToDevice));
+        CS_HIP(hipMemcpy(nd, h->h_dead.data(), h->h_dead.size() * sizeof(uint32_t),
+                         hipMemcpyHostToDevice));
+    }
+    if (h->d_corpus) (void)hipFree(h->d_corpus);
+    if (h->d_dead) (void)hipFree(h->d_dead);
+    h->d_corpus = nc;
+    h->d_dead = nd;
+    h->capacity = cap;
+    return CS_OK;
+}
+
+int32_t check_append(cs_index* h, uint64_t n, uint32_t dim) {
+    if (!h) return fail(CS_ERR_BAD_ARG, "null index handle");
+    if (dim != h->dim)  // store.rs:667-671
+        return fail(CS_ERR_DIM_MISMATCH, "Embedding dimension mismatch: expected %u, got %u",
+                    h->dim, dim);
+    if ((uint64_t)h->id_base + h->n_rows + n > 0xffffffffull)
+        return fail(CS_ERR_BAD_ARG, "id space exhausted: ids are u32 (store.rs:97)");
+    return CS_OK;
+}
+
+void finish_append(cs_index* h, uint64_t n, uint32_t* out_ids) {
+    const uint32_t start = h->id_base + (uint32_t)h->n_rows;
+    if (out_ids)
+        for (uint64_t i = 0; i < n; ++i) out_ids[i] = start + (uint32_t)i;  // store.rs:684
+    h->n_rows += n;
+    h->h_dead.resize((size_t)((h->n_rows + 31) / 32), 0u);
+    if (n) h->built = false;  // store.rs:682
+}
+
+Workspace* acquire_pooled(cs_index* h) {
+    std::lock_guard<std::mutex> lk(h->mu);
+    if (!h->pool.empty()) {
+        Workspace* w = h->pool.back();
+        h->pool.pop_back();
+        return w;
+    }
+    Workspace* w = new Workspace();
+    if (hipStreamCreateWithFlags(&w->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete w;
+        return nullptr;
+    }
+    w->own_stream = true;
+    return w;
+}
+
+void release_pooled(cs_index* h, Workspace* w) {
+    std::lock_guard<std::mutex> lk(h->mu);
+    h->pool.push_back(w);
+}
+
+Workspace* for_stream(cs_index* h, hipStream_t s) {
+    std::lock_guard<std::mutex> lk(h->mu);
+    auto it = h->by_stream.find(s);
+    if (it != h->by_stream.end()) return it->second;
+    Workspace* w = new Workspace();
+    w->stream = s;
+    h->by_stream[s] = w;
+    return w;
+}
+
+bool take_events(cs_index* h, Workspace* w, EventTriple* t) {
+    if (!h->profile) return false;
+    if (!w->free_events.empty()) {
+        *t = w->free_events.back();
+        w->free_events.pop_back();
+        return true;
+    }
+    if (hipEventCreate(&t->e0) != hipSuccess) return false;
+    if (hipEventCreate(&t->e1) != hipSuccess) return false;
+    if (hipEventCreate(&t->e2) != hipSuccess) return false;
+    return true;
+}
+
+// scan + merge on `stream`; outputs are device pointers (any may be null).
+int32_t run_search(cs_index* h, Workspace* w, const ScanPlan& plan, const float* d_queries,
+                   uint32_t nq, uint32_t k, uint64_t* d_keys, float* d_cos, uint32_t* d_ids,
+                   uint32_t* d_counts, hipStream_t stream) {
+    EventTriple ev{};
+    const bool timed = take_events(h, w, &ev);
+    if (timed) CS_HIP(hipEventRecord(ev.e0, stream));
+    CS_TRY(launch_scan(plan, h->d_corpus, h->n_rows, h->dim, d_queries, nq, k,
+                       h->n_removed ? h->d_dead : nullptr, h->id_base, w->d_partial, stream));
+    if (timed) CS_HIP(hipEventRecord(ev.e1, stream));
+    CS_TRY(launch_merge(w->d_partial, plan.blocks, nq, k, false, w->d_tmp_a, w->d_tmp_b, d_keys, d_cos,
+                        d_ids, d_counts, stream));
+    if (timed) {
+        CS_HIP(hipEventRecord(ev.e2, stream));
+        std::lock_guard<std::mutex> lk(h->mu);
+        h->pending.push_back(ev);
+    }
+    return CS_OK;
+}
+
+int32_t check_search(const cs_index* h, uint32_t nq, uint32_t dim, uint32_t k) {
+    if (!h) return fail(CS_ERR_BAD_ARG, "null index handle");
+    if (dim != h->dim)  // store.rs:432-438
+        return fail(CS_ERR_DIM_MISMATCH,
+                    "Query embedding dimension mismatch: expected %u, got %u", h->dim, dim);
+    if (!h->built)  // store.rs:440-444
+        return fail(CS_ERR_NOT_BUILT,
+                    "Index not built. Call build_index() after inserting chunks.");
+    if (nq == 0 || nq > CS_MAX_QUERIES)
+        return fail(CS_ERR_BAD_ARG, "nq must be in 1..%u, got %u", CS_MAX_QUERIES, nq);
+    if (k == 0 || k > CS_MAX_K)
+        return fail(CS_ERR_BAD_ARG, "k must be in 1..%u, got %u", CS_MAX_K, k);
+    return CS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* cs_last_error(void) { return last_error_ref().c_str(); }
+uint32_t cs_abi_version(void) { return 1; }
+
+int32_t cs_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int32_t cs_index_create(uint32_t dim, uint64_t capacity_rows, int32_t device, uint32_t id_base,
+                        cs_index** out) {
+    if (!out) return fail(CS_ERR_BAD_ARG, "out is null");
+    *out = nullptr;
+    if (dim == 0 || dim > 8192) return fail(CS_ERR_BAD_ARG, "dim must be in 1..8192, got %u", dim);
+    int ndev = 0;
+    CS_HIP(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev)
+        return fail(CS_ERR_HIP, "HIP device %d not available (%d visible); there is no CPU fallback",
+                    device, ndev);
+    DeviceGuard g(device);
+    hipDeviceProp_t prop;
+    CS_HIP(hipGetDeviceProperties(&prop, device));
+    cs_index* h = new cs_index();
+    h->device = device;
+    h->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    h->dim = dim;
+    h->id_base = id_base;
+    if (capacity_rows) {
+        int32_t s = grow(h, capacity_rows);
+        if (s != CS_OK) { delete h; return s; }
+    }
+    *out = h;
+    return CS_OK;
+}
+
+void cs_index_destroy(cs_index* h) {
+    if (!h) return;
+    DeviceGuard g(h->device);
+    (void)hipDeviceSynchronize();
+    for (auto* w : h->pool) { w->release_all(); delete w; }
+    for (auto& kv : h->by_stream) { kv.second->release_all(); delete kv.second; }
+    for (auto& t : h->pending) {
+        (void)hipEventDestroy(t.e0); (void)hipEventDestroy(t.e1); (void)hipEventDestroy(t.e2);
+    }
+    if (h->d_corpus) (void)hipFree(h->d_corpus);
+    if (h->d_dead) (void)hipFree(h->d_dead);
+    delete h;
+}
+
+int32_t cs_index_add(cs_index* h, const float* rows, uint64_t n, uint32_t dim, uint32_t* out_ids) {
+    CS_TRY(check_append(h, n, dim));
+    if (n == 0) return CS_OK;  // store.rs:655-657
+    if (!rows) return fail(CS_ERR_BAD_ARG, "rows is null");
+    DeviceGuard g(h->device);
+    CS_TRY(grow(h, h->n_rows + n));
+    CS_HIP(hipMemcpy(h->d_corpus + (size_t)h->n_rows * h->dim, rows,
+                     (size_t)n * h->dim * sizeof(float), hipMemcpyHostToDevice));
+    finish_append(h, n, out_ids);
+    return CS_OK;
+}
+
+int32_t cs_index_add_device(cs_index* h, const float* d_rows, uint64_t n, uint32_t dim,
+                            uint32_t* out_ids, void* stream) {
+    CS_TRY(check_append(h, n, dim));
+    if (n == 0) return CS_OK;
+    if (!d_rows) return fail(CS_ERR_BAD_ARG, "d_rows is null");
+    DeviceGuard g(h->device);
+    CS_TRY(grow(h, h->n_rows + n));
+    CS_HIP(hipMemcpyAsync(h->d_corpus + (size_t)h->n_rows * h->dim, d_rows,
+                          (size_t)n * h->dim * sizeof(float), hipMemcpyDeviceToDevice,
+                          (hipStream_t)stream));
+    finish_append(h, n, out_ids);
+    return CS_OK;
+}
+
+int32_t cs_index_add_synthetic(cs_index* h, uint64_t n, uint64_t seed, uint64_t first_row,
+                               uint32_t* out_first_id) {
+    CS_TRY(check_append(h, n, h ? h->dim : 0));
+    DeviceGuard g(h->device);
+    CS_TRY(grow(h, h->n_rows + n));
+    CS_TRY(launch_synth_fill(h->d_corpus + (size_t)h->n_rows * h->dim, n, h->dim, seed, first_row,
+                             nullptr));
+    CS_HIP(hipStreamSynchronize(nullptr));
+    if (out_first_id) *out_first_id = h->id_base + (uint32_t)h->n_rows;
+    finish_append(h, n, nullptr);
+    return CS_OK;
+}
+
+int32_t cs_index_remove(cs_index* h, const uint32_t* ids, uint64_t n, uint64_t* removed) {
+    if (!h) return fail(CS_ERR_BAD_ARG, "null index handle");
+    if (removed) *removed = 0;
+    if (n == 0) return CS_OK;  // store.rs:585-587
+    if (!ids) return fail(CS_ERR_BAD_ARG, "ids is null");
+    uint64_t cnt = 0;
+    for (uint64_t i = 0; i < n; ++i) {
+        if (ids[i] < h->id_base) continue;
+        const uint64_t row = (uint64_t)ids[i] - h->id_base;
+        if (row >= h->n_rows) continue;  // del_item fails -> not counted (store.rs:594)
+        uint32_t& w = h->h_dead[(size_t)(row >> 5)];
+        const uint32_t bit = 1u << (row & 31);
+        if (w & bit) continue;
+        w |= bit;
+        ++cnt;
+    }
+    if (cnt) {
+        DeviceGuard g(h->device);
+        CS_HIP(hipMemcpy(h->d_dead, h->h_dead.data(), h->h_dead.size() * sizeof(uint32_t),
+                         hipMemcpyHostToDevice));
+        h->n_removed += cnt;
+        h->built = false;  // store.rs:604-606
+    }
+    if (removed) *removed = cnt;
+    return CS_OK;
+}
+
+int32_t cs_index_build(cs_index* h) {
+    if (!h) return fail(CS_ERR_BAD_ARG, "null index handle");
+    DeviceGuard g(h->device);
+    CS_HIP(hipDeviceSynchronize());  // appended rows (incl. async device appends) are now visible
+    h->built = true;                 // store.rs:428
+    return CS_OK;
+}
+
+int32_t cs_index_clear(cs_index* h) {
+    if (!h) return fail(CS_ERR_BAD_ARG, "null index handle");
+    DeviceGuard g(h->device);
+    CS_HIP(hipDeviceSynchronize());
+    if (h->d_dead && h->capacity)
+        CS_HIP(hipMemset(h->d_dead, 0, (size_t)((h->capacity + 31) / 32) * sizeof(uint32_t)));
+    h->n_rows = 0;  // store.rs:701 next_id = 0
+    h->n_removed = 0;
+    h->h_dead.clear();
+    h->built = false;  // store.rs:702
+    return CS_OK;
+}
+
+int32_t cs_index_is_built(const cs_index* h) { return h && h->built ? 1 : 0; }
+uint64_t cs_index_len(const cs_index* h) { return h ? h->n_rows - h->n_removed : 0; }
+uint32_t cs_index_next_id(const cs_index* h) { return h ? h->id_base + (uint32_t)h->n_rows : 0; }
+uint32_t cs_index_dim(const cs_index* h) { return h ? h->dim : 0; }
+int32_t cs_index_device(const cs_index* h) { return h ? h->device : -1; }
+
+int32_t cs_index_search(cs_index* h, const float* queries, uint32_t nq, uint32_t dim, uint32_t k,
+                        float* out_cos, uint32_t* out_ids, uint32_t* out_counts) {
+    CS_TRY(check_search(h, nq, dim, k));
+    if (!queries || !out_cos || !out_ids || !out_counts)
+        return fail(CS_ERR_BAD_ARG, "null buffer");
+    DeviceGuard g(h->device);
+    const ScanPlan plan = plan_scan(h->n_rows, h->dim, nq, k, h->num_cus);
+    Workspace* w = acquire_pooled(h);
+    if (!w) return fail(CS_ERR_HIP, "could not create a HIP stream");
+    int32_t s = w->reserve(plan, nq, h->dim, k, true);
+    if (s == CS_OK) {
+        const size_t on = (size_t)nq * k;
+        s = [&]() -> int32_t {
+            CS_HIP(hipMemcpyAsync(w->d_queries, queries, (size_t)nq * h->dim * sizeof(float),
+                                  hipMemcpyHostToDevice, w->stream));
+            CS_TRY(run_search(h, w, plan, w->d_queries, nq, k, w->d_keys, w->d_cos, w->d_ids,
+                              w->d_counts, w->stream));
+            CS_HIP(hipMemcpyAsync(w->h_cos, w->d_cos, on * sizeof(float), hipMemcpyDeviceToHost, w->stream));
+            CS_HIP(hipMemcpyAsync(w->h_ids, w->d_ids, on * sizeof(uint32_t), hipMemcpyDeviceToHost, w->stream));
+            CS_HIP(hipMemcpyAsync(w->h_counts, w->d_counts, nq * sizeof(uint32_t), hipMemcpyDeviceToHost, w->stream));
+            CS_HIP(hipStreamSynchronize(w->stream));
+            memcpy(out_cos, w->h_cos, on * sizeof(float));
+            memcpy(out_ids, w->h_ids, on * sizeof(uint32_t));
+            memcpy(out_counts, w->h_counts, nq * sizeof(uint32_t));
+            return CS_OK;
+        }();
+    }
+    release_pooled(h, w);
+    return s;
+}
+
+int32_t cs_index_search_device(cs_index* h, const float* d_queries, uint32_t nq, uint32_t dim,
+                               uint32_t k, uint64_t* d_out_keys, float* d_out_cos,
+                               uint32_t* d_out_ids, uint32_t* d_out_counts, void* stream) {
+    CS_TRY(check_search(h, nq, dim, k));
+    if (!d_queries) return fail(CS_ERR_BAD_ARG, "d_queries is null");
+    DeviceGuard g(h->device);
+    const ScanPlan plan = plan_scan(h->n_rows, h->dim, nq, k, h->num_cus);
+    Workspace* w = for_stream(h, (hipStream_t)stream);
+    CS_TRY(w->reserve(plan, nq, h->dim, k, false));
+    return run_search(h, w, plan, d_queries, nq, k, d_out_keys, d_out_cos, d_out_ids, d_out_counts,
+                      (hipStream_t)stream);
+}
+
+int32_t cs_merge_topk_device(int32_t device, const uint64_t* d_keys, uint32_t nlists, uint32_t nq,
+                             uint32_t k, uint64_t* d_out_keys, float* d_out_cos,
+                             uint32_t* d_out_ids, uint32_t* d_out_counts, void* stream) {
+    if (!d_keys || nlists == 0 || nq == 0 || k == 0 || k > CS_MAX_K)
+        return fail(CS_ERR_BAD_ARG, "bad merge arguments");
+    DeviceGuard g(device);
+    const size_t tmp = merge_tmp_keys(nlists, nq, k);
+    uint64_t *ta = nullptr, *tb = nullptr;
+    if (tmp) {  // more than 2048 keys per query: rare (8 shards x k<=256 fits one pass)
+        CS_HIP(hipMalloc(&ta, tmp * sizeof(uint64_t)));
+        CS_HIP(hipMalloc(&tb, tmp * sizeof(uint64_t)));
+    }
+    int32_t s = launch_merge(d_keys, nlists, nq, k, true, ta, tb, d_out_keys, d_out_cos, d_out_ids,
+                             d_out_counts, (hipStream_t)stream);
+    if (tmp) {
+        (void)hipStreamSynchronize((hipStream_t)stream);
+        (void)hipFree(ta);
+        (void)hipFree(tb);
+    }
+    return s;
+}
+
+int32_t cs_index_read_rows(cs_index* h, uint64_t first_row, uint64_t n, float* out_rows) {
+    if (!h || !out_rows) return fail(CS_ERR_BAD_ARG, "null argument");
+    if (first_row + n > h->n_rows)
+        return fail(CS_ERR_BAD_ARG, "rows [%llu, %llu) out of range (have %llu)",
+                    (unsigned long long)first_row, (unsigned long long)(first_row + n),
+                    (unsigned long long)h->n_rows);
+    if (n == 0) return CS_OK;
+    DeviceGuard g(h->device);
+    CS_HIP(hipDeviceSynchronize());
+    CS_HIP(hipMemcpy(out_rows, h->d_corpus + (size_t)first_row * h->dim,
+                     (size_t)n * h->dim * sizeof(float), hipMemcpyDeviceToHost));
+    return CS_OK;
+}
+
+int32_t cs_index_profile(cs_index* h, int32_t enable) {
+    if (!h) return fail(CS_ERR_BAD_ARG, "null index handle");
+    std::lock_guard<std::mutex> lk(h->mu);
+    h->profile = enable != 0;
+    return CS_OK;
+}
+
+int32_t cs_index_profile_read(cs_index* h, double* scan_ms, uint64_t* scan_launches,
+                              double* merge_ms, int32_t reset) {
+    if (!h) return fail(CS_ERR_BAD_ARG, "null index handle");
+    DeviceGuard g(h->device);
+    std::vector<EventTriple> pend;
+    {
+        std::lock_guard<std::mutex> lk(h->mu);
+        pend.swap(h->pending);
+    }
+    double s_ms = 0.0, m_ms = 0.0;
+    for (auto& t : pend) {
+        CS_HIP(hipEventSynchronize(t.e2));
+        float a = 0.f, b = 0.f;
+        CS_HIP(hipEventElapsedTime(&a, t.e0, t.e1));
+        CS_HIP(hipEventElapsedTime(&b, t.e1, t.e2));
+        s_ms += a;
+        m_ms += b;
+        (void)hipEventDestroy(t.e0); (void)hipEventDestroy(t.e1); (void)hipEventDestroy(t.e2);
+    }
+    std::lock_guard<std::mutex> lk(h->mu);
+    h->scan_ms += s_ms;
+    h->merge_ms += m_ms;
+    h->scan_launches += pend.size();
+    if (scan_ms) *scan_ms = h->scan_ms;
+    if (merge_ms) *merge_ms = h->merge_ms;
+    if (scan_launches) *scan_launches = h->scan_launches;
+    if (reset) { h->scan_ms = 0.0; h->merge_ms = 0.0; h->scan_launches = 0; }
+    return CS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,469 @@
+// scan.hip — brute-force cosine scan with fused streaming top-k,
+// the cross-block / cross-shard key merge (S2/S4) and the in-place corpus generator.
+//
+// Replaces, in /root/reference:
+//   examples/benchmark_models.rs:155-165 + :323-328  (linear scan + cosine_similarity)
+//   src/vectordb/store.rs:446-459                    (arroy nns().by_vector(): ANN there,
+//                                                     exact here)
+//
+// HBM-bound: each corpus row is read exactly once per query tile as 16 B/lane
+// coalesced loads (32 lanes x float4 = one 512 B row segment per half-wave), both
+// dot(q,x) and |x|^2 are accumulated from the same registers, and selection happens in
+// registers/LDS, so the only HBM traffic besides the matrix is k keys per block.
+// Algorithmic bytes per row = dim*4 (1536 B at dim 384).
+#include "scan.hpp"
+
+#include "../../include/cs_synth.h"
+
+namespace cs {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kBlock = 256;   // 4 waves
+constexpr int kWaves = kBlock / 64;
+constexpr int kMergeBlock = 1024;
+constexpr int kMergeCap = 2048;  // keys sorted per merge block
+
+// ---- wave helpers ---------------------------------------------------------------------
+
+// Sum over the 32 lanes of each half-wave; every lane of the half receives the total.
+__device__ __forceinline__ float half_allreduce_sum(float v) {
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 8, 64);
+    v += __shfl_xor(v, 4, 64);
+    v += __shfl_xor(v, 2, 64);
+    v += __shfl_xor(v, 1, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_allreduce_sum(float v) {
+    v += __shfl_xor(v, 32, 64);
+    return half_allreduce_sum(v);
+}
+
+__device__ __forceinline__ uint64_t shfl_xor_u64(uint64_t v, int m) {
+    uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+    lo = __shfl_xor(lo, m, 64);
+    hi = __shfl_xor(hi, m, 64);
+    return ((uint64_t)hi << 32) | lo;
+}
+
+// Per-wave candidate list: k live slots (of kpad) in LDS holding packed keys, 0 = empty.
+// State kept by the caller: `thr` = cosine of the current worst slot (-inf while any slot
+// is empty) and `wpos` = that slot's index.  Rows are streamed in ascending id, so a row
+// that ties the worst cosine loses to it (id asc) and `c > thr` is the whole test — the
+// `>` of benchmark_models.rs:160.
+__device__ __forceinline__ void wave_list_insert(volatile uint64_t* list, uint32_t k, int lane,
+                                                 float c, uint32_t id, float& thr,
+                                                 uint32_t& wpos) {
+    if (lane == 0) list[wpos] = key_pack(c, id);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    uint64_t mk = ~0ull;
+    uint32_t mp = 0xffffffffu;
+    for (uint32_t i = lane; i < k; i += 64) {
+        uint64_t v = list[i];
+        if (v < mk) { mk = v; mp = i; }
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        uint64_t ok = shfl_xor_u64(mk, m);
+        uint32_t op = __shfl_xor(mp, m, 64);
+        if (ok < mk || (ok == mk && op < mp)) { mk = ok; mp = op; }
+    }
+    wpos = mp;
+    thr = (mk == 0ull) ? -__builtin_huge_valf() : key_cos(mk);
+}
+
+// Bitonic sort, descending, of a[0..n) (n a power of two) by all threads of the block.
+template <int T>
+__device__ __forceinline__ void block_bitonic_desc(uint64_t* a, uint32_t n, int tid) {
+    for (uint32_t size = 2; size <= n; size <<= 1) {
+        for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+            __syncthreads();
+            for (uint32_t t = tid; t < (n >> 1); t += T) {
+                uint32_t i = 2 * t - (t & (stride - 1));
+                uint32_t j = i + stride;
+                uint64_t x = a[i], y = a[j];
+                bool desc = ((i & size) == 0);
+                if ((x < y) == desc) { a[i] = y; a[j] = x; }
+            }
+        }
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ bool row_is_dead(const uint32_t* dead, uint64_t row) {
+    if (!dead) return false;
+    return (dead[row >> 5] >> (row & 31)) & 1u;
+}
+
+// ---- S1+S2: the streaming scan ----------------------------------------------------------
+//
+// J  = float4 chunks per lane per row (dim = 128*J);  U = row pairs in flight per wave
+// (a wave tile is 2U consecutive rows: half-wave h takes row 2u+h);  QT = queries scored
+// per pass from registers;  NT = non-temporal corpus loads.
+template <int J, int U, int QT, bool NT>
+__global__ void __launch_bounds__(kBlock)
+scan_topk_kernel(const float* __restrict__ corpus, uint64_t n_rows,
+                 const float* __restrict__ queries, uint32_t nq, uint32_t k, uint32_t kpad,
+                 const uint32_t* __restrict__ dead, uint32_t id_base,
+                 uint64_t* __restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) uint64_t lds_keys[];  // [QT][kWaves][kpad]
+    constexpr int DIM = 128 * J;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int half = lane >> 5;
+    const int l32 = lane & 31;
+    const uint32_t q0 = blockIdx.y * QT;
+
+    for (uint32_t i = tid; i < QT * kWaves * kpad; i += kBlock) lds_keys[i] = 0ull;
+
+    // query fragments + magnitudes (mag_a of benchmark_models.rs:325)
+    f32x4 qf[QT][J];
+    float qmag[QT];
+#pragma unroll
+    for (int qi = 0; qi < QT; ++qi) {
+        const uint32_t q = (q0 + qi < nq) ? (q0 + qi) : (nq - 1);
+        const f32x4* qp = reinterpret_cast<const f32x4*>(queries + (size_t)q * DIM) + l32;
+        float s = 0.0f;
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            qf[qi][j] = qp[j * 32];
+            s = fmaf(qf[qi][j].x, qf[qi][j].x, s);
+            s = fmaf(qf[qi][j].y, qf[qi][j].y, s);
+            s = fmaf(qf[qi][j].z, qf[qi][j].z, s);
+            s = fmaf(qf[qi][j].w, qf[qi][j].w, s);
+        }
+        qmag[qi] = sqrtf(half_allreduce_sum(s));
+    }
+    float thr[QT];
+    uint32_t wpos[QT];
+#pragma unroll
+    for (int qi = 0; qi < QT; ++qi) { thr[qi] = -__builtin_huge_valf(); wpos[qi] = 0; }
+    __syncthreads();
+
+    const uint64_t gw = (uint64_t)blockIdx.x * kWaves + wave;
+    const uint64_t nw = (uint64_t)gridDim.x * kWaves;
+    const uint64_t ntiles = (n_rows + 2 * U - 1) / (2 * U);
+
+    for (uint64_t tile = gw; tile < ntiles; tile += nw) {
+        const uint64_t row0 = tile * (2 * U);
+        f32x4 x[U][J];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            uint64_t r = row0 + 2 * u + half;
+            r = r < n_rows ? r : n_rows - 1;  // tail rows re-read the last row, masked below
+            const f32x4* p = reinterpret_cast<const f32x4*>(corpus + r * DIM) + l32;
+#pragma unroll
+            for (int j = 0; j < J; ++j) {
+                if constexpr (NT) x[u][j] = __builtin_nontemporal_load(p + j * 32);
+                else x[u][j] = p[j * 32];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            float ss = 0.0f;
+            float dot[QT];
+#pragma unroll
+            for (int qi = 0; qi < QT; ++qi) dot[qi] = 0.0f;
+#pragma unroll
+            for (int j = 0; j < J; ++j) {
+                const f32x4 v = x[u][j];
+                ss = fmaf(v.x, v.x, ss);
+                ss = fmaf(v.y, v.y, ss);
+                ss = fmaf(v.z, v.z, ss);
+                ss = fmaf(v.w, v.w, ss);
+#pragma unroll
+                for (int qi = 0; qi < QT; ++qi) {
+                    dot[qi] = fmaf(v.x, qf[qi][j].x, dot[qi]);
+                    dot[qi] = fmaf(v.y, qf[qi][j].y, dot[qi]);
+                    dot[qi] = fmaf(v.z, qf[qi][j].z, dot[qi]);
+                    dot[qi] = fmaf(v.w, qf[qi][j].w, dot[qi]);
+                }
+            }
+            const float xmag = sqrtf(half_allreduce_sum(ss));  // mag_b
+            const uint64_t r = row0 + 2 * u + half;
+            const bool valid = r < n_rows;
+#pragma unroll
+            for (int qi = 0; qi < QT; ++qi) {
+                const float d = half_allreduce_sum(dot[qi]);
+                // batch.rs:320-323: zero magnitude -> 0.0, else dot / (mag_a * mag_b)
+                const float c = (qmag[qi] == 0.0f || xmag == 0.0f) ? 0.0f : d / (qmag[qi] * xmag);
+                unsigned long long m = __ballot(valid && l32 == 0 && c > thr[qi]);
+                if (m) {  // rare: wave-uniform slow path
+                    volatile uint64_t* list = lds_keys + ((size_t)qi * kWaves + wave) * kpad;
+                    while (m) {
+                        const int src = __ffsll((long long)m) - 1;
+                        m &= m - 1;
+                        const float cc = __shfl(c, src, 64);
+                        const uint64_t rr = row0 + 2 * u + (src >> 5);
+                        if (cc > thr[qi] && !row_is_dead(dead, rr))
+                            wave_list_insert(list, k, lane, cc, id_base + (uint32_t)rr, thr[qi],
+                                             wpos[qi]);
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    // block merge: the 4 wave lists of each query -> best k, sorted, to HBM
+    const uint32_t nsort = kWaves * kpad;
+#pragma unroll 1
+    for (int qi = 0; qi < QT; ++qi) {
+        if (q0 + qi >= nq) break;
+        uint64_t* a = lds_keys + (size_t)qi * nsort;
+        block_bitonic_desc<kBlock>(a, nsort, tid);
+        uint64_t* out = partial + ((size_t)(q0 + qi) * gridDim.x + blockIdx.x) * k;
+        for (uint32_t i = tid; i < k; i += kBlock) out[i] = a[i];
+    }
+}
+
+// Any-dim fallback (e.g. the reference's own 4-d unit test, store.rs:846-893): one wave
+// per row, lanes stride over columns.  Not a tuned path.
+__global__ void __launch_bounds__(kBlock)
+scan_topk_generic_kernel(const float* __restrict__ corpus, uint64_t n_rows, uint32_t dim,
+                         const float* __restrict__ queries, uint32_t nq, uint32_t k,
+                         uint32_t kpad, const uint32_t* __restrict__ dead, uint32_t id_base,
+                         uint64_t* __restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) uint64_t lds_keys[];  // [kWaves][kpad]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t q = blockIdx.y;
+    for (uint32_t i = tid; i < kWaves * kpad; i += kBlock) lds_keys[i] = 0ull;
+    const float* qp = queries + (size_t)q * dim;
+    float s = 0.0f;
+    for (uint32_t c = lane; c < dim; c += 64) s = fmaf(qp[c], qp[c], s);
+    const float qmag = sqrtf(wave_allreduce_sum(s));
+    float thr = -__builtin_huge_valf();
+    uint32_t wpos = 0;
+    __syncthreads();
+    volatile uint64_t* list = lds_keys + (size_t)wave * kpad;
+    const uint64_t gw = (uint64_t)blockIdx.x * kWaves + wave;
+    const uint64_t nw = (uint64_t)gridDim.x * kWaves;
+    for (uint64_t r = gw; r < n_rows; r += nw) {
+        const float* xp = corpus + r * dim;
+        float ss = 0.0f, dot = 0.0f;
+        for (uint32_t c = lane; c < dim; c += 64) {
+            const float v = xp[c];
+            ss = fmaf(v, v, ss);
+            dot = fmaf(v, qp[c], dot);
+        }
+        const float xmag = sqrtf(wave_allreduce_sum(ss));
+        const float d = wave_allreduce_sum(dot);
+        const float c = (qmag == 0.0f || xmag == 0.0f) ? 0.0f : d / (qmag * xmag);
+        if (c > thr && !row_is_dead(dead, r))  // wave-uniform
+            wave_list_insert(list, k, lane, c, id_base + (uint32_t)r, thr, wpos);
+    }
+    __syncthreads();
+    const uint32_t nsort = kWaves * kpad;
+    block_bitonic_desc<kBlock>(lds_keys, nsort, tid);
+    uint64_t* out = partial + ((size_t)q * gridDim.x + blockIdx.x) * k;
+    for (uint32_t i = tid; i < k; i += kBlock) out[i] = lds_keys[i];
+}
+
+// ---- S2/S4: key-list merge ----------------------------------------------------------------
+// in: list l of query q starts at in + q*q_stride + l*l_stride ([nq][nlists][k] for the
+// scan partials, [nlists][nq][k] for all-gathered shard results); block (g, q) sorts lists [g*G, min(nlists,(g+1)*G)) and writes its
+// best k to out_keys[q][g][k].  When gridDim.x == 1 the result is final and is also
+// decoded to cos / ids / counts.
+__global__ void __launch_bounds__(kMergeBlock)
+merge_topk_kernel(const uint64_t* __restrict__ in, uint32_t nlists, uint32_t k, uint32_t G,
+                  uint64_t q_stride, uint64_t l_stride, uint64_t* __restrict__ out_keys, float* __restrict__ out_cos,
+                  uint32_t* __restrict__ out_ids, uint32_t* __restrict__ out_counts) {
+    __shared__ __attribute__((aligned(16))) uint64_t a[kMergeCap];
+    __shared__ uint32_t live;
+    const int tid = threadIdx.x;
+    const uint32_t g = blockIdx.x, q = blockIdx.y, ngroups = gridDim.x;
+    const uint32_t lo = g * G;
+    const uint32_t hi = (lo + G < nlists) ? lo + G : nlists;
+    const uint32_t ncand = (hi - lo) * k;
+    uint32_t nsort = 64;
+    while (nsort < ncand) nsort <<= 1;
+    const uint64_t* src = in + (size_t)q * q_stride + (size_t)lo * l_stride;
+    for (uint32_t i = tid; i < nsort; i += kMergeBlock) {
+        const uint32_t l = i / k, e = i - l * k;
+        a[i] = (i < ncand) ? src[(size_t)l * l_stride + e] : 0ull;
+    }
+    if (tid == 0) live = 0;
+    block_bitonic_desc<kMergeBlock>(a, nsort, tid);
+    const bool final_pass = (ngroups == 1);
+    for (uint32_t i = tid; i < k; i += kMergeBlock) {
+        const uint64_t key = (i < nsort) ? a[i] : 0ull;
+        if (out_keys) out_keys[((size_t)q * ngroups + g) * k + i] = key;
+        if (final_pass) {
+            if (key) atomicAdd(&live, 1u);
+            if (out_cos) out_cos[(size_t)q * k + i] = key ? key_cos(key) : 0.0f;
+            if (out_ids) out_ids[(size_t)q * k + i] = key ? key_id(key) : 0xffffffffu;
+        }
+    }
+    __syncthreads();
+    if (final_pass && out_counts && tid == 0) out_counts[q] = live;
+}
+
+// ---- synthetic corpus, generated in HBM ---------------------------------------------------
+__global__ void synth_fill_kernel(float* __restrict__ out, uint64_t total, uint64_t seed,
+                                  uint64_t first_flat) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x * 4;
+    for (uint64_t i = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < total; i += stride) {
+        if (i + 4 <= total) {
+            f32x4 v;
+            v.x = cs_synth_value(seed, first_flat + i);
+            v.y = cs_synth_value(seed, first_flat + i + 1);
+            v.z = cs_synth_value(seed, first_flat + i + 2);
+            v.w = cs_synth_value(seed, first_flat + i + 3);
+            *reinterpret_cast<f32x4*>(out + i) = v;
+        } else {
+            for (uint64_t j = i; j < total; ++j) out[j] = cs_synth_value(seed, first_flat + j);
+        }
+    }
+}
+
+// ---- host side ----------------------------------------------------------------------------
+
+static uint32_t kpad_for(uint32_t k) {
+    uint32_t p = 64;
+    while (p < k) p <<= 1;
+    return p;
+}
+
+static bool fast_dim(uint32_t dim) { return dim == 384 || dim == 768 || dim == 1024; }
+
+template <int J, int U, int QT>
+static int occupancy_of(size_t lds) {
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, scan_topk_kernel<J, U, QT, true>, kBlock,
+                                                     lds) != hipSuccess || nb < 1)
+        nb = 2;
+    return nb;
+}
+
+// Resident blocks per CU of the kernel instance a plan selects (the grid is sized to be
+// fully resident: a grid-stride scan with a second wave of blocks would idle CUs).
+static int blocks_per_cu(uint32_t dim, uint32_t qtile, uint32_t kpad) {
+    const size_t lds = (size_t)qtile * kWaves * kpad * sizeof(uint64_t);
+    int nb;
+    if (dim == 384) nb = qtile == 4 ? occupancy_of<3, 4, 4>(lds) : qtile == 2 ? occupancy_of<3, 4, 2>(lds) : occupancy_of<3, 4, 1>(lds);
+    else if (dim == 768) nb = qtile == 4 ? occupancy_of<6, 2, 4>(lds) : qtile == 2 ? occupancy_of<6, 2, 2>(lds) : occupancy_of<6, 2, 1>(lds);
+    else nb = qtile == 4 ? occupancy_of<8, 2, 4>(lds) : qtile == 2 ? occupancy_of<8, 2, 2>(lds) : occupancy_of<8, 2, 1>(lds);
+    return nb > 8 ? 8 : nb;
+}
+
+ScanPlan plan_scan(uint64_t n_rows, uint32_t dim, uint32_t nq, uint32_t k, int num_cus) {
+    ScanPlan p{};
+    p.kpad = kpad_for(k);
+    if (fast_dim(dim)) {
+        p.qtile = nq >= 4 ? 4 : (nq >= 2 ? 2 : 1);
+        // LDS per block = qtile * 4 waves * kpad * 8 B; stay at >= 2 blocks per CU
+        while (p.qtile > 1 && (size_t)p.qtile * kWaves * p.kpad * 8 > 64 * 1024) p.qtile >>= 1;
+        const uint32_t rows_per_tile = (dim == 384) ? 8 : 4;
+        const uint64_t ntiles = (n_rows + rows_per_tile - 1) / rows_per_tile;
+        const uint64_t blocks = (ntiles + kWaves - 1) / kWaves;
+        const uint64_t cap = (uint64_t)num_cus * blocks_per_cu(dim, p.qtile, p.kpad);
+        p.blocks = (uint32_t)(blocks < 1 ? 1 : (blocks > cap ? cap : blocks));
+    } else {
+        p.qtile = 1;
+        const uint64_t blocks = (n_rows + kWaves - 1) / kWaves;
+        const uint64_t cap = (uint64_t)num_cus * 8;
+        p.blocks = (uint32_t)(blocks < 1 ? 1 : (blocks > cap ? cap : blocks));
+    }
+    p.passes = (nq + p.qtile - 1) / p.qtile;
+    p.partial_keys = (size_t)nq * p.blocks * k;
+    p.merge_keys = merge_tmp_keys(p.blocks, nq, k);
+    return p;
+}
+
+template <int J, int U, int QT>
+static void launch_fast(const ScanPlan& plan, const float* d_corpus, uint64_t n_rows,
+                        const float* d_queries, uint32_t nq, uint32_t k, const uint32_t* d_dead,
+                        uint32_t id_base, uint64_t* d_partial, hipStream_t stream) {
+    const size_t lds = (size_t)QT * kWaves * plan.kpad * sizeof(uint64_t);
+    dim3 grid(plan.blocks, plan.passes);
+    hipLaunchKernelGGL((scan_topk_kernel<J, U, QT, true>), grid, dim3(kBlock), lds, stream,
+                       d_corpus, n_rows, d_queries, nq, k, plan.kpad, d_dead, id_base, d_partial);
+}
+
+template <int J, int U>
+static void launch_fast_q(const ScanPlan& plan, const float* d_corpus, uint64_t n_rows,
+                          const float* d_queries, uint32_t nq, uint32_t k,
+                          const uint32_t* d_dead, uint32_t id_base, uint64_t* d_partial,
+                          hipStream_t stream) {
+    switch (plan.qtile) {
+        case 4: launch_fast<J, U, 4>(plan, d_corpus, n_rows, d_queries, nq, k, d_dead, id_base, d_partial, stream); break;
+        case 2: launch_fast<J, U, 2>(plan, d_corpus, n_rows, d_queries, nq, k, d_dead, id_base, d_partial, stream); break;
+        default: launch_fast<J, U, 1>(plan, d_corpus, n_rows, d_queries, nq, k, d_dead, id_base, d_partial, stream); break;
+    }
+}
+
+int32_t launch_scan(const ScanPlan& plan, const float* d_corpus, uint64_t n_rows, uint32_t dim,
+                    const float* d_queries, uint32_t nq, uint32_t k, const uint32_t* d_dead,
+                    uint32_t id_base, uint64_t* d_partial, hipStream_t stream) {
+    if (n_rows == 0) {  // nothing to score: all-empty partial lists
+        CS_HIP(hipMemsetAsync(d_partial, 0, plan.partial_keys * sizeof(uint64_t), stream));
+        return CS_OK;
+    }
+    if (dim == 384) launch_fast_q<3, 4>(plan, d_corpus, n_rows, d_queries, nq, k, d_dead, id_base, d_partial, stream);
+    else if (dim == 768) launch_fast_q<6, 2>(plan, d_corpus, n_rows, d_queries, nq, k, d_dead, id_base, d_partial, stream);
+    else if (dim == 1024) launch_fast_q<8, 2>(plan, d_corpus, n_rows, d_queries, nq, k, d_dead, id_base, d_partial, stream);
+    else {
+        const size_t lds = (size_t)kWaves * plan.kpad * sizeof(uint64_t);
+        hipLaunchKernelGGL(scan_topk_generic_kernel, dim3(plan.blocks, nq), dim3(kBlock), lds,
+                           stream, d_corpus, n_rows, dim, d_queries, nq, k, plan.kpad, d_dead,
+                           id_base, d_partial);
+    }
+    CS_HIP(hipGetLastError());
+    return CS_OK;
+}
+
+static uint32_t merge_group(uint32_t k) {
+    uint32_t g = kMergeCap / k;
+    return g < 2 ? 2 : g;  // k <= 256 -> g >= 8
+}
+
+size_t merge_tmp_keys(uint32_t nlists, uint32_t nq, uint32_t k) {
+    const uint32_t G = merge_group(k);
+    const uint32_t ngroups = (nlists + G - 1) / G;
+    return ngroups > 1 ? (size_t)nq * ngroups * k : 0;
+}
+
+int32_t launch_merge(const uint64_t* d_lists, uint32_t nlists, uint32_t nq, uint32_t k,
+                     bool list_major, uint64_t* d_tmp_a, uint64_t* d_tmp_b, uint64_t* d_out_keys, float* d_out_cos,
+                     uint32_t* d_out_ids, uint32_t* d_out_counts, hipStream_t stream) {
+    const uint32_t G = merge_group(k);
+    const uint64_t* in = d_lists;
+    uint64_t* bufs[2] = {d_tmp_a, d_tmp_b};
+    int flip = 0;
+    uint64_t q_stride = list_major ? k : (uint64_t)nlists * k;
+    uint64_t l_stride = list_major ? (uint64_t)nq * k : k;
+    for (;;) {
+        const uint32_t ngroups = (nlists + G - 1) / G;
+        const bool final_pass = ngroups == 1;
+        uint64_t* out = final_pass ? d_out_keys : bufs[flip];
+        if (!final_pass && !out) return fail(CS_ERR_BAD_ARG, "merge scratch missing");
+        hipLaunchKernelGGL(merge_topk_kernel, dim3(ngroups, nq), dim3(kMergeBlock), 0, stream, in,
+                           nlists, k, G, q_stride, l_stride, out, d_out_cos, d_out_ids, d_out_counts);
+        CS_HIP(hipGetLastError());
+        if (final_pass) break;
+        in = out;
+        nlists = ngroups;
+        q_stride = (uint64_t)nlists * k;
+        l_stride = k;
+        flip ^= 1;
+    }
+    return CS_OK;
+}
+
+int32_t launch_synth_fill(float* d_rows, uint64_t n, uint32_t dim, uint64_t seed,
+                          uint64_t first_row, hipStream_t stream) {
+    if (n == 0) return CS_OK;
+    const uint64_t total = n * dim;
+    uint64_t blocks = (total / 4 + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(synth_fill_kernel, dim3((uint32_t)blocks), dim3(256), 0, stream, d_rows,
+                       total, seed, first_row * dim);
+    CS_HIP(hipGetLastError());
+    return CS_OK;
+}
+
+}  // namespace cs

@@ -1,0 +1,39 @@
+// scan.hpp — launch interface of the cosine scan + top-k kernels (scan.hip).
+#pragma once
+
+#include "common.hpp"
+
+namespace cs {
+
+struct ScanPlan {
+    uint32_t blocks;     // scan grid.x
+    uint32_t kpad;       // per-wave list capacity (power of two >= k, >= 64)
+    uint32_t qtile;      // queries handled per scan pass
+    uint32_t passes;     // ceil(nq / qtile)  (grid.y)
+    size_t partial_keys; // u64 count needed for the scan's partial buffer
+    size_t merge_keys;   // u64 count needed for the merge ping-pong buffer
+};
+
+// Geometry for a search of nq queries / top-k over n_rows rows of `dim` floats.
+ScanPlan plan_scan(uint64_t n_rows, uint32_t dim, uint32_t nq, uint32_t k, int num_cus);
+
+// Scores every live row of corpus[0..n_rows) against each query and leaves, per
+// (query, block), the block's best k as packed keys in d_partial[q][block][k].
+int32_t launch_scan(const ScanPlan& plan, const float* d_corpus, uint64_t n_rows, uint32_t dim,
+                    const float* d_queries, uint32_t nq, uint32_t k, const uint32_t* d_dead,
+                    uint32_t id_base, uint64_t* d_partial, hipStream_t stream);
+
+// Reduces nlists lists of k keys per query ([nq][nlists][k], or [nlists][nq][k] when
+// list_major) to the best k per query,
+// writing keys / decoded cosines / ids / counts (each optional).  d_tmp: ping-pong
+// scratch of plan.merge_keys (may be null when nlists*k <= 2048).
+int32_t launch_merge(const uint64_t* d_lists, uint32_t nlists, uint32_t nq, uint32_t k,
+                     bool list_major, uint64_t* d_tmp_a, uint64_t* d_tmp_b, uint64_t* d_out_keys, float* d_out_cos,
+                     uint32_t* d_out_ids, uint32_t* d_out_counts, hipStream_t stream);
+size_t merge_tmp_keys(uint32_t nlists, uint32_t nq, uint32_t k);
+
+// corpus[(first_out_row + r) * dim + c] = cs_synth_value(seed, (first_row + r) * dim + c)
+int32_t launch_synth_fill(float* d_rows, uint64_t n, uint32_t dim, uint64_t seed,
+                          uint64_t first_row, hipStream_t stream);
+
+}  // namespace cs

@@ -1,0 +1,107 @@
+"""Row-sharded store: one process per GPU, one exchange step.
+
+Shard g owns the contiguous id range [g*rows_per_shard, (g+1)*rows_per_shard): ids are
+global (`cs_index_create(..., id_base)`), so no translation happens after the exchange.
+A search is: every rank scans its shard -> [nq, k] packed keys -> ONE all-gather of
+nq*k*8 bytes per rank (RCCL over xGMI; `nccl` backend) -> every rank merges the
+world_size lists with the same HIP merge kernel.  top-k of a union = top-k of the
+per-shard top-ks, so the result equals a single-GPU scan of the whole corpus.
+
+The key helpers below are pure numpy so the N>1 data path can be exercised on CPU with
+the gloo backend (tests/test_sharded_gloo.py).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+import numpy as np
+
+
+def shard_range(rank: int, world: int, total_rows: int) -> Tuple[int, int]:
+    """Contiguous, balanced row range of a shard (first rows get the remainder)."""
+    base, rem = divmod(total_rows, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def key_pack(cos: np.ndarray, ids: np.ndarray) -> np.ndarray:
+    """cs_key_pack: order-preserving f32 image in the high word, ~id in the low word."""
+    c = (np.asarray(cos, np.float32) + np.float32(0.0)).view(np.uint32).astype(np.uint64)
+    o = np.where(c & np.uint64(0x80000000), (~c) & np.uint64(0xFFFFFFFF), c | np.uint64(0x80000000))
+    return (o << np.uint64(32)) | ((~np.asarray(ids, np.uint32)).astype(np.uint64))
+
+
+def key_unpack(keys: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
+    """cs_key_cos / cs_key_id."""
+    keys = np.asarray(keys, np.uint64)
+    o = (keys >> np.uint64(32)).astype(np.uint32)
+    u = np.where(o & np.uint32(0x80000000), o & np.uint32(0x7FFFFFFF), ~o)
+    return u.astype(np.uint32).view(np.float32), ~(keys & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+
+
+def merge_keys_host(gathered: np.ndarray, k: int) -> np.ndarray:
+    """Host statement of the shard merge: gathered [world, nq, k] keys (0 = empty) ->
+    [nq, k] best-first.  Used by the gloo tests; the product path is cs_merge_topk_device."""
+    world, nq, kk = gathered.shape
+    flat = np.transpose(gathered, (1, 0, 2)).reshape(nq, world * kk)
+    return np.sort(flat, axis=1)[:, ::-1][:, :k].copy()
+
+
+class ShardedVectorStore:
+    """One rank's shard plus the exchange.  Device buffers are torch tensors (plumbing);
+    kernels are libcsgpu's, launched on torch's current stream so RCCL orders after them."""
+
+    def __init__(self, dim: int, rows_per_shard: int, rank: int, world: int, device: int, group=None):
+        import torch
+
+        from . import _lib
+        from .vector_store import VectorStore
+
+        self.torch = torch
+        self._lib = _lib.load()
+        self._check = _lib.check
+        self.dim, self.rank, self.world, self.device = dim, rank, world, device
+        self.rows_per_shard = rows_per_shard
+        self.group = group
+        self.store = VectorStore(None, dim, device=device, capacity=rows_per_shard,
+                                 id_base=rank * rows_per_shard)
+        self._bufs = {}
+
+    def fill_synthetic(self, seed: int) -> None:
+        self.store.insert_synthetic(self.rows_per_shard, seed, self.rank * self.rows_per_shard)
+        self.store.build_index()
+
+    def _buffers(self, nq: int, k: int):
+        key = (nq, k)
+        if key not in self._bufs:
+            t, dev = self.torch, f"cuda:{self.device}"
+            self._bufs[key] = dict(
+                local=t.zeros(nq * k, dtype=t.int64, device=dev),
+                gathered=t.zeros(self.world * nq * k, dtype=t.int64, device=dev),
+                keys=t.zeros(nq * k, dtype=t.int64, device=dev),
+                cos=t.zeros(nq * k, dtype=t.float32, device=dev),
+                ids=t.zeros(nq * k, dtype=t.int32, device=dev),
+                counts=t.zeros(nq, dtype=t.int32, device=dev),
+            )
+        return self._bufs[key]
+
+    def search_device(self, d_queries, nq: int, k: int):
+        """d_queries: torch f32 tensor [nq, dim] on this rank's GPU (same on every rank).
+        Asynchronous; returns the dict of device result tensors (cos/ids/counts/keys)."""
+        t = self.torch
+        b = self._buffers(nq, k)
+        stream = C.c_void_p(t.cuda.current_stream().cuda_stream)
+        vp = lambda x: C.c_void_p(x.data_ptr())
+        if self.world == 1:
+            self._check(self._lib.cs_index_search_device(self.store.handle, vp(d_queries), nq, self.dim, k,
+                                                         vp(b["keys"]), vp(b["cos"]), vp(b["ids"]),
+                                                         vp(b["counts"]), stream))
+            return b
+        self._check(self._lib.cs_index_search_device(self.store.handle, vp(d_queries), nq, self.dim, k,
+                                                     vp(b["local"]), None, None, None, stream))
+        t.distributed.all_gather_into_tensor(b["gathered"], b["local"], group=self.group)
+        self._check(self._lib.cs_merge_topk_device(self.device, vp(b["gathered"]), self.world, nq, k,
+                                                   vp(b["keys"]), vp(b["cos"]), vp(b["ids"]),
+                                                   vp(b["counts"]), stream))
+        return b

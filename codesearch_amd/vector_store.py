@@ -1,0 +1,312 @@
+"""Host-side mirror of the reference's VectorStore over the C ABI.
+
+Same method names, argument meaning and error behaviour as
+/root/reference/src/vectordb/store.rs:94-750, so tests read like the reference's own
+(`store.rs:833-1028`).  The vectors live in HBM behind `cs_index_*`; chunk metadata
+(`ChunkMetadata`, store.rs:19-85) stays in host memory keyed by the u32 id, where the
+reference keeps it in a second LMDB database.  LMDB persistence, MDB_MAP_FULL resizing
+and page statistics are storage-engine concerns and out of scope.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import hashlib
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+
+from . import _lib
+from ._lib import CsError, f32p, u32p, u64p
+
+
+# ---- carrier types ---------------------------------------------------------------------------
+
+@dataclass
+class Chunk:
+    """src/chunker/mod.rs:22-62 (fields the hot path and its metadata need)."""
+
+    content: str
+    start_line: int
+    end_line: int
+    kind: str  # ChunkKind Debug name, e.g. "Function"
+    path: str
+    context: List[str] = field(default_factory=list)
+    signature: Optional[str] = None
+    docstring: Optional[str] = None
+    is_complete: bool = True
+    split_index: Optional[int] = None
+    hash: str = ""
+    context_prev: Optional[str] = None
+    context_next: Optional[str] = None
+
+    def __post_init__(self):
+        if not self.hash:  # Chunk::compute_hash, mod.rs:93-97
+            self.hash = hashlib.sha256(self.content.encode("utf-8")).hexdigest()
+
+
+@dataclass
+class EmbeddedChunk:
+    """src/embed/batch.rs:47-57."""
+
+    chunk: Chunk
+    embedding: Sequence[float]
+
+
+@dataclass
+class ChunkMetadata:
+    """store.rs:19-85."""
+
+    content: str
+    path: str
+    start_line: int
+    end_line: int
+    kind: str
+    signature: Optional[str]
+    docstring: Optional[str]
+    context: Optional[str]
+    hash: str
+    context_prev: Optional[str] = None
+    context_next: Optional[str] = None
+    searchable_text: str = ""
+
+    @staticmethod
+    def from_embedded_chunk(ec: EmbeddedChunk) -> "ChunkMetadata":
+        ch = ec.chunk
+        parts = [p for p in (ch.signature, ch.docstring) if p is not None]
+        parts += [ch.kind, ch.content]
+        return ChunkMetadata(
+            content=ch.content, path=ch.path, start_line=ch.start_line, end_line=ch.end_line,
+            kind=ch.kind, signature=ch.signature, docstring=ch.docstring,
+            context=" > ".join(ch.context) if ch.context else None, hash=ch.hash,
+            context_prev=ch.context_prev, context_next=ch.context_next,
+            searchable_text="\n".join(parts),
+        )
+
+
+@dataclass
+class SearchResult:
+    """store.rs:753-772."""
+
+    id: int
+    content: str
+    path: str
+    start_line: int
+    end_line: int
+    kind: str
+    signature: Optional[str]
+    docstring: Optional[str]
+    context: Optional[str]
+    hash: str
+    distance: float
+    score: float
+    context_prev: Optional[str] = None
+    context_next: Optional[str] = None
+
+
+@dataclass
+class StoreStats:
+    """store.rs:784-792."""
+
+    total_chunks: int
+    total_files: int
+    indexed: bool
+    dimensions: int
+    max_chunk_id: int
+
+
+def cos_to_distance(cos):
+    """arroy 0.5.0 Cosine distance (1 - cos)/2 (third-party)."""
+    return (np.float32(1.0) - np.asarray(cos, np.float32)) * np.float32(0.5)
+
+
+def cos_to_score(cos):
+    """store.rs:478: score = 1.0 - distance."""
+    return np.float32(1.0) - cos_to_distance(cos)
+
+
+# ---- the store ---------------------------------------------------------------------------------
+
+class VectorStore:
+    """`VectorStore::new(db_path, dimensions)` — store.rs:110-176.
+
+    `db_path` is accepted for signature parity and ignored: nothing is persisted.
+    `device`, `capacity` and `id_base` are the GPU-side additions (shard placement).
+    """
+
+    def __init__(self, db_path, dimensions: int, device: int = 0, capacity: int = 0, id_base: int = 0):
+        self._lib = _lib.load()
+        self.db_path = db_path
+        self.dimensions = int(dimensions)
+        handle = C.c_void_p()
+        _lib.check(self._lib.cs_index_create(self.dimensions, capacity, device, id_base, C.byref(handle)))
+        self._h = handle
+        self._meta: Dict[int, ChunkMetadata] = {}
+
+    # -- lifecycle
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.cs_index_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # -- writes (`&mut self` in the reference)
+    def insert_chunks_with_ids(self, chunks: Sequence[EmbeddedChunk]) -> List[int]:
+        """store.rs:618-686 -> assigned ids (contiguous from next_id)."""
+        if not chunks:
+            return []
+        for ch in chunks:  # store.rs:666-672: first bad row aborts the transaction
+            if len(ch.embedding) != self.dimensions:
+                raise CsError(_lib.CS_ERR_DIM_MISMATCH,
+                              f"Embedding dimension mismatch: expected {self.dimensions}, got {len(ch.embedding)}")
+        rows = np.ascontiguousarray([ch.embedding for ch in chunks], dtype=np.float32)
+        ids = np.zeros(len(chunks), np.uint32)
+        _lib.check(self._lib.cs_index_add(self._h, rows.ctypes.data_as(f32p), len(chunks), self.dimensions,
+                                          ids.ctypes.data_as(u32p)))
+        for i, ch in zip(ids.tolist(), chunks):
+            self._meta[i] = ChunkMetadata.from_embedded_chunk(ch)
+        return ids.tolist()
+
+    def insert_chunks(self, chunks: Sequence[EmbeddedChunk]) -> int:
+        """store.rs:334-379 -> number inserted."""
+        return len(self.insert_chunks_with_ids(chunks))
+
+    def insert_embeddings(self, rows: np.ndarray) -> np.ndarray:
+        """Vector-only append (no metadata) for bulk/bench use -> ids."""
+        rows = np.ascontiguousarray(rows, np.float32)
+        if rows.ndim != 2:
+            raise ValueError("rows must be [n, dim]")
+        ids = np.zeros(rows.shape[0], np.uint32)
+        _lib.check(self._lib.cs_index_add(self._h, rows.ctypes.data_as(f32p), rows.shape[0], rows.shape[1],
+                                          ids.ctypes.data_as(u32p)))
+        return ids
+
+    def insert_synthetic(self, n: int, seed: int, first_row: int = 0) -> int:
+        """Generate n rows in HBM with include/cs_synth.h -> first id."""
+        first = C.c_uint32()
+        _lib.check(self._lib.cs_index_add_synthetic(self._h, n, seed, first_row, C.byref(first)))
+        return int(first.value)
+
+    def delete_chunks(self, chunk_ids: Sequence[int]) -> int:
+        """store.rs:548-610 -> number deleted."""
+        ids = np.ascontiguousarray(chunk_ids, np.uint32)
+        removed = C.c_uint64()
+        _lib.check(self._lib.cs_index_remove(self._h, ids.ctypes.data_as(u32p), ids.size, C.byref(removed)))
+        for i in ids.tolist():
+            self._meta.pop(i, None)  # store.rs:598
+        return int(removed.value)
+
+    def build_index(self) -> None:
+        """store.rs:386-430."""
+        _lib.check(self._lib.cs_index_build(self._h))
+
+    def clear(self) -> None:
+        """store.rs:690-707."""
+        _lib.check(self._lib.cs_index_clear(self._h))
+        self._meta.clear()
+
+    # -- reads (`&self`)
+    def is_indexed(self) -> bool:
+        return bool(self._lib.cs_index_is_built(self._h))
+
+    def next_id(self) -> int:
+        return int(self._lib.cs_index_next_id(self._h))
+
+    def __len__(self) -> int:
+        return int(self._lib.cs_index_len(self._h))
+
+    def search_raw(self, queries, limit: int):
+        """-> (cos [nq, limit] f32, ids [nq, limit] u32, counts [nq] u32); rows best-first."""
+        q = np.ascontiguousarray(queries, np.float32)
+        if q.ndim == 1:
+            q = q[None, :]
+        nq, dim = q.shape
+        cos = np.zeros((nq, max(limit, 1)), np.float32)
+        ids = np.zeros((nq, max(limit, 1)), np.uint32)
+        counts = np.zeros(nq, np.uint32)
+        _lib.check(self._lib.cs_index_search(self._h, q.ctypes.data_as(f32p), nq, dim, limit,
+                                             cos.ctypes.data_as(f32p), ids.ctypes.data_as(u32p),
+                                             counts.ctypes.data_as(u32p)))
+        return cos, ids, counts
+
+    def search(self, query_embedding, limit: int) -> List[SearchResult]:
+        """store.rs:431-486.  Results whose metadata is missing are skipped (store.rs:465)."""
+        cos, ids, counts = self.search_raw(query_embedding, limit)
+        return self._results(cos[0], ids[0], int(counts[0]))
+
+    def search_batch(self, query_embeddings, limit: int) -> List[List[SearchResult]]:
+        """One call for all query variants (the par_iter of src/search/mod.rs:508-511)."""
+        cos, ids, counts = self.search_raw(query_embeddings, limit)
+        return [self._results(cos[i], ids[i], int(counts[i])) for i in range(len(counts))]
+
+    def _results(self, cos, ids, count) -> List[SearchResult]:
+        out = []
+        dist = cos_to_distance(cos[:count])
+        for i in range(count):
+            m = self._meta.get(int(ids[i]))
+            if m is None:
+                continue
+            d = float(dist[i])
+            out.append(SearchResult(
+                id=int(ids[i]), content=m.content, path=m.path, start_line=m.start_line,
+                end_line=m.end_line, kind=m.kind, signature=m.signature, docstring=m.docstring,
+                context=m.context, hash=m.hash, distance=d, score=float(np.float32(1.0) - np.float32(d)),
+                context_prev=m.context_prev, context_next=m.context_next))
+        return out
+
+    def get_chunk(self, chunk_id: int) -> Optional[ChunkMetadata]:
+        """store.rs:709-713."""
+        return self._meta.get(int(chunk_id))
+
+    def get_chunk_as_result(self, chunk_id: int) -> Optional[SearchResult]:
+        """store.rs:715-738 (distance/score 0.0, set by caller)."""
+        m = self._meta.get(int(chunk_id))
+        if m is None:
+            return None
+        return SearchResult(id=int(chunk_id), content=m.content, path=m.path, start_line=m.start_line,
+                            end_line=m.end_line, kind=m.kind, signature=m.signature, docstring=m.docstring,
+                            context=m.context, hash=m.hash, distance=0.0, score=0.0,
+                            context_prev=m.context_prev, context_next=m.context_next)
+
+    def get_chunks_by_file(self) -> Dict[str, List[int]]:
+        """store.rs:529-543: path -> chunk ids."""
+        out: Dict[str, List[int]] = {}
+        for i, m in self._meta.items():
+            out.setdefault(m.path, []).append(i)
+        return out
+
+    def stats(self) -> StoreStats:
+        """store.rs:488-523."""
+        files = {m.path for m in self._meta.values()}
+        return StoreStats(total_chunks=len(self._meta), total_files=len(files), indexed=self.is_indexed(),
+                          dimensions=self.dimensions, max_chunk_id=max(self._meta.keys(), default=0))
+
+    def read_rows(self, first_row: int, n: int) -> np.ndarray:
+        out = np.empty((n, self.dimensions), np.float32)
+        _lib.check(self._lib.cs_index_read_rows(self._h, first_row, n, out.ctypes.data_as(f32p)))
+        return out
+
+    # -- kernel timing (bench.py)
+    def profile(self, enable: bool) -> None:
+        _lib.check(self._lib.cs_index_profile(self._h, 1 if enable else 0))
+
+    def profile_read(self, reset: bool = True):
+        """-> (scan_ms_total, scan_launches, merge_ms_total)."""
+        s, m, n = C.c_double(), C.c_double(), C.c_uint64()
+        _lib.check(self._lib.cs_index_profile_read(self._h, C.byref(s), C.byref(n), C.byref(m), 1 if reset else 0))
+        return s.value, int(n.value), m.value
+
+    @property
+    def handle(self):
+        return self._h
