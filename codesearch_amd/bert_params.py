@@ -1,0 +1,132 @@
+"""Python mirror of include/cs_bert_params.h: flat parameter layout of the encoder, the
+synthetic-weight rule, and the mapping to/from HF `BertModel` state-dict names (used to
+load real checkpoints and to build golden vectors with transformers)."""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Dict, List, Tuple
+
+import numpy as np
+
+from .synth import synth_below, synth_int
+
+POOL_CLS, POOL_MEAN = 0, 1
+
+# kind -> (shift, base); cs_bert_synth_rule
+_RULE = {
+    "emb": (2, 0.0), "ln_g": (3, 1.0), "ln_b": (3, 0.0), "qk_w": (3, 0.0), "v_w": (4, 0.0),
+    "ao_w": (4, 0.0), "up_w": (4, 0.0), "down_w": (5, 0.0), "bias": (4, 0.0),
+}
+
+
+@dataclass
+class BertConfig:
+    vocab_size: int = 30522
+    hidden: int = 384
+    layers: int = 12
+    heads: int = 12
+    intermediate: int = 1536
+    max_position: int = 512
+    type_vocab_size: int = 2
+    layer_norm_eps: float = 1e-12
+    pooling: int = POOL_CLS
+
+    @staticmethod
+    def bge_small() -> "BertConfig":
+        """BAAI/bge-small-en-v1.5 architecture; CLS pooling (fastembed's choice for BGE)."""
+        return BertConfig()
+
+    def to_c(self):
+        from ._lib import BertConfig as CBert
+
+        return CBert(self.vocab_size, self.hidden, self.layers, self.heads, self.intermediate,
+                     self.max_position, self.type_vocab_size, self.layer_norm_eps, self.pooling)
+
+
+def tensor_table(cfg: BertConfig) -> List[Tuple[str, Tuple[int, ...], str]]:
+    """[(hf_name, shape, kind)] in flat order (= BertModel(add_pooling_layer=False).state_dict())."""
+    H, I = cfg.hidden, cfg.intermediate
+    t = [
+        ("embeddings.word_embeddings.weight", (cfg.vocab_size, H), "emb"),
+        ("embeddings.position_embeddings.weight", (cfg.max_position, H), "emb"),
+        ("embeddings.token_type_embeddings.weight", (cfg.type_vocab_size, H), "emb"),
+        ("embeddings.LayerNorm.weight", (H,), "ln_g"),
+        ("embeddings.LayerNorm.bias", (H,), "ln_b"),
+    ]
+    for l in range(cfg.layers):
+        p = f"encoder.layer.{l}."
+        t += [
+            (p + "attention.self.query.weight", (H, H), "qk_w"), (p + "attention.self.query.bias", (H,), "bias"),
+            (p + "attention.self.key.weight", (H, H), "qk_w"), (p + "attention.self.key.bias", (H,), "bias"),
+            (p + "attention.self.value.weight", (H, H), "v_w"), (p + "attention.self.value.bias", (H,), "bias"),
+            (p + "attention.output.dense.weight", (H, H), "ao_w"), (p + "attention.output.dense.bias", (H,), "bias"),
+            (p + "attention.output.LayerNorm.weight", (H,), "ln_g"), (p + "attention.output.LayerNorm.bias", (H,), "ln_b"),
+            (p + "intermediate.dense.weight", (I, H), "up_w"), (p + "intermediate.dense.bias", (I,), "bias"),
+            (p + "output.dense.weight", (H, I), "down_w"), (p + "output.dense.bias", (H,), "bias"),
+            (p + "output.LayerNorm.weight", (H,), "ln_g"), (p + "output.LayerNorm.bias", (H,), "ln_b"),
+        ]
+    return t
+
+
+def param_count(cfg: BertConfig) -> int:
+    return sum(int(np.prod(s)) for _, s, _ in tensor_table(cfg))
+
+
+def synth_params(cfg: BertConfig, seed: int) -> np.ndarray:
+    """cs_bert_synth_param for the whole block -> float32 [param_count]."""
+    out = np.empty(param_count(cfg), np.float32)
+    off = 0
+    for _, shape, kind in tensor_table(cfg):
+        n = int(np.prod(shape))
+        shift, base = _RULE[kind]
+        idx = np.arange(off, off + n, dtype=np.uint64)
+        v = synth_int(seed, idx).astype(np.float32) * np.float32(1.0 / 65536.0) * np.float32(1.0 / (1 << shift))
+        out[off:off + n] = np.float32(base) + v
+        off += n
+    return out
+
+
+def to_state_dict(cfg: BertConfig, flat: np.ndarray) -> Dict[str, np.ndarray]:
+    sd, off = {}, 0
+    for name, shape, _ in tensor_table(cfg):
+        n = int(np.prod(shape))
+        sd[name] = flat[off:off + n].reshape(shape)
+        off += n
+    return sd
+
+
+def from_state_dict(cfg: BertConfig, sd) -> np.ndarray:
+    """Flatten a HF state dict (numpy arrays or tensors; an optional 'bert.' prefix and
+    pooler/position_ids entries are ignored) into the flat block."""
+    out = np.empty(param_count(cfg), np.float32)
+    off = 0
+    for name, shape, _ in tensor_table(cfg):
+        key = name if name in sd else ("bert." + name)
+        a = sd[key]
+        a = a.detach().cpu().numpy() if hasattr(a, "detach") else np.asarray(a)
+        if tuple(a.shape) != tuple(shape):
+            raise ValueError(f"{name}: expected {shape}, got {a.shape}")
+        n = int(np.prod(shape))
+        out[off:off + n] = a.astype(np.float32).reshape(-1)
+        off += n
+    return out
+
+
+def synth_token_batch(cfg: BertConfig, seed: int, B: int, L: int, ragged: bool):
+    """Synthetic token ids + mask: ids uniform in [1000, vocab), [CLS]=101 first, [SEP]=102
+    last valid, [PAD]=0 after; lengths U[L/8, L] when ragged else L.  """
+    lo = min(1000, cfg.vocab_size // 2)
+    idx = np.arange(B * L, dtype=np.uint64)
+    ids = (synth_below(seed, idx, cfg.vocab_size - lo) + lo).astype(np.int32).reshape(B, L)
+    if ragged:
+        mn = max(2, L // 8)
+        lens = (synth_below(seed + 1, np.arange(B, dtype=np.uint64), L - mn + 1) + mn).astype(np.int64)
+        lens[0] = L  # batch-longest padding: at least one full row
+    else:
+        lens = np.full(B, L, np.int64)
+    mask = (np.arange(L)[None, :] < lens[:, None]).astype(np.int32)
+    ids[:, 0] = 101 % cfg.vocab_size
+    for b in range(B):
+        ids[b, lens[b] - 1] = 102 % cfg.vocab_size
+    ids = ids * mask
+    return ids, mask

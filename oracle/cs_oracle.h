@@ -68,6 +68,18 @@ uint32_t cs_oracle_merge_topk(const float* cos, const uint32_t* ids, const uint3
                               uint32_t* out_ids);
 int cs_oracle_num_threads(void);
 
+/* ---- encoder (bert_oracle.c) ------------------------------------------------------- */
+struct cs_bert_config; /* include/codesearch_gpu.h */
+/* fp32 BertModel forward + pooling + L2 normalise.  ids/mask [B,L] i32; hidden_out
+ * (optional) [B*L*H]; pooled_out (optional) [B,H]; layer_hidden_out (optional)
+ * [(layers+1)*B*L*H]: embedding output followed by each layer's output. */
+void cs_oracle_bert_forward(const struct cs_bert_config* cfg, const float* params,
+                            const int32_t* ids, const int32_t* mask, uint32_t B, uint32_t L,
+                            float* hidden_out, float* pooled_out, float* layer_hidden_out);
+/* Flat parameter block from the synthetic rule of include/cs_bert_params.h. */
+void cs_oracle_bert_synth_params(const struct cs_bert_config* cfg, uint64_t seed, float* out);
+uint64_t cs_oracle_bert_param_count(const struct cs_bert_config* cfg);
+
 /* ---- synthetic data (include/cs_synth.h) ------------------------------------------ */
 void cs_oracle_synth_rows(uint64_t seed, uint64_t first_row, uint64_t n, uint32_t dim,
                           float* out);
