@@ -45,6 +45,12 @@ class Oracle:
         lib.cs_oracle_merge_topk.restype = C.c_uint32
         lib.cs_oracle_merge_topk.argtypes = [c_f32p, c_u32p, c_u32p, C.c_uint32, C.c_uint32, c_f32p, c_u32p]
         lib.cs_oracle_num_threads.restype = C.c_int
+        lib.cs_oracle_bert_forward.restype = None
+        lib.cs_oracle_bert_forward.argtypes = [C.c_void_p, c_f32p, c_i32p, c_i32p, C.c_uint32, C.c_uint32, c_f32p, c_f32p, c_f32p]
+        lib.cs_oracle_bert_synth_params.restype = None
+        lib.cs_oracle_bert_synth_params.argtypes = [C.c_void_p, C.c_uint64, c_f32p]
+        lib.cs_oracle_bert_param_count.restype = C.c_uint64
+        lib.cs_oracle_bert_param_count.argtypes = [C.c_void_p]
         lib.cs_oracle_synth_rows.restype = None
         lib.cs_oracle_synth_rows.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, c_f32p]
         lib.cs_oracle_synth_planted.restype = None
@@ -95,6 +101,32 @@ class Oracle:
 
     def num_threads(self) -> int:
         return int(self.lib.cs_oracle_num_threads())
+
+    # ---- encoder ------------------------------------------------------------------
+    def bert_param_count(self, cfg) -> int:
+        c = cfg.to_c()
+        return int(self.lib.cs_oracle_bert_param_count(C.byref(c)))
+
+    def bert_synth_params(self, cfg, seed):
+        c = cfg.to_c()
+        out = np.empty(self.bert_param_count(cfg), np.float32)
+        self.lib.cs_oracle_bert_synth_params(C.byref(c), seed, _ptr(out, c_f32p))
+        return out
+
+    def bert_forward(self, cfg, params, ids, mask, want_hidden=False, want_layers=False):
+        """-> dict(pooled [B,H], hidden [B,L,H]?, layers [layers+1,B,L,H]?)"""
+        c = cfg.to_c()
+        params = np.ascontiguousarray(params, np.float32)
+        ids = np.ascontiguousarray(ids, np.int32)
+        mask = np.ascontiguousarray(mask, np.int32)
+        B, L = ids.shape
+        H = cfg.hidden
+        pooled = np.empty((B, H), np.float32)
+        hidden = np.empty((B, L, H), np.float32) if want_hidden else None
+        layers = np.empty((cfg.layers + 1, B, L, H), np.float32) if want_layers else None
+        self.lib.cs_oracle_bert_forward(C.byref(c), _ptr(params, c_f32p), _ptr(ids, c_i32p), _ptr(mask, c_i32p),
+                                        B, L, _ptr(hidden, c_f32p), _ptr(pooled, c_f32p), _ptr(layers, c_f32p))
+        return {"pooled": pooled, "hidden": hidden, "layers": layers}
 
     # ---- synthetic data --------------------------------------------------------
     def synth_rows(self, seed, first_row, n, dim):
