@@ -1,0 +1,430 @@
+// encoder.hip — the BERT forward pass of the embedding path as hand-written gfx950 kernels
+// (SURVEY.md §8a E1-E8).  Replaces what /root/reference reaches through
+// `self.model.embed(text_refs, None)` (src/embed/embedder.rs:286-289): fastembed -> ONNX
+// Runtime CPU executing the BAAI/bge-small-en-v1.5 graph, then pooling + L2 normalise.
+//
+//   E1  embed_ln_kernel      word + type + position gather, LayerNorm            (HBM)
+//   E2/E4/E5/E6 gemm_f32_kernel  y = x W^T + b [+gelu | +residual]; exact-f32 MFMA
+//                            v_mfma_f32_32x32x2_f32, 128x128x32 tiles through LDS  (MFMA)
+//   E3  attention_kernel     per (batch, head, 128 queries): S^T = K Q^T and O^T = V^T P on
+//                            the f32 MFMA with the query on the lane, so the online
+//                            softmax is in-lane; K/V of the head staged in LDS    (MFMA/LDS)
+//   E4/E6 layernorm_kernel   in-place row LayerNorm (bias + residual already added)  (HBM)
+//   E7/E8 pool_normalize_kernel  CLS or masked-mean pooling, v / (|v| + 1e-12)      (HBM)
+//
+// All arithmetic is fp32: the f32-input MFMA is bit-for-bit an fmaf chain
+// (cdna_hip_programming.md §3), which keeps the 1e-4 embedding tolerance with margin.
+#include "encoder.hpp"
+
+namespace cs {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr float kMaskMin = -3.4028234663852886e38f;  // HF get_extended_attention_mask
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+
+// ---- E1: embeddings + LayerNorm; E4/E6: LayerNorm -------------------------------------------
+// One wave per token row; NPL = H / 64 values per lane (lane + 64*i).
+template <int NPL>
+__device__ __forceinline__ void ln_row(float (&v)[NPL], const float* __restrict__ g,
+                                       const float* __restrict__ b, float eps, int lane,
+                                       float* __restrict__ out) {
+    constexpr float invH = 1.0f / (64.0f * NPL);
+    float s = 0.0f;
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) s += v[i];
+    const float mean = wave_sum(s) * invH;
+    float q = 0.0f;
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) { const float d = v[i] - mean; q = fmaf(d, d, q); }
+    const float var = wave_sum(q) * invH;
+    const float inv = 1.0f / sqrtf(var + eps);
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) {
+        const int c = lane + 64 * i;
+        out[c] = (v[i] - mean) * inv * g[c] + b[c];
+    }
+}
+
+template <int NPL>
+__global__ void __launch_bounds__(256)
+embed_ln_kernel(const int32_t* __restrict__ ids, const float* __restrict__ word,
+                const float* __restrict__ pos, const float* __restrict__ type0,
+                const float* __restrict__ g, const float* __restrict__ b, float eps, uint32_t T,
+                uint32_t L, uint32_t vocab, float* __restrict__ x) {
+    constexpr int H = 64 * NPL;
+    const int lane = threadIdx.x & 63;
+    const uint32_t t = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= T) return;
+    uint32_t id = (uint32_t)ids[t];
+    if (id >= vocab) id = 0;  // host validates; never index out of the table
+    const float* we = word + (size_t)id * H;
+    const float* pe = pos + (size_t)(t % L) * H;
+    float v[NPL];
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) {
+        const int c = lane + 64 * i;
+        v[i] = (we[c] + type0[c]) + pe[c];  // BertEmbeddings: (inputs + token_type) + position
+    }
+    ln_row<NPL>(v, g, b, eps, lane, x + (size_t)t * H);
+}
+
+template <int NPL>
+__global__ void __launch_bounds__(256)
+layernorm_kernel(float* __restrict__ x, const float* __restrict__ g, const float* __restrict__ b,
+                 float eps, uint32_t T) {
+    constexpr int H = 64 * NPL;
+    const int lane = threadIdx.x & 63;
+    const uint32_t t = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= T) return;
+    float* row = x + (size_t)t * H;
+    float v[NPL];
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) v[i] = row[lane + 64 * i];
+    ln_row<NPL>(v, g, b, eps, lane, row);
+}
+
+// ---- E2/E4/E5/E6: C[M,N] = A[M,K] W[N,K]^T + bias (+ epilogue) --------------------------------
+// 128x128 block tile, BK = 32, 4 waves as 2x2, each wave 64x64 = 2x2 MFMA tiles of 32x32.
+// LDS rows are padded to 36 floats so the ds_read_b128 fragment reads (16-lane groups reading
+// 16 distinct rows) are bank-conflict free.  Fragment k order: lane half h holds
+// k = 16h .. 16h+15 of the stage for BOTH operands, MFMA step s pairs k = s with k = 16 + s;
+// the sum over k is the same set in a fixed order.
+enum { EPI_BIAS = 0, EPI_GELU = 1, EPI_RESID = 2 };
+constexpr int GBM = 128, GBN = 128, GBK = 32, GLS = 36;
+
+__device__ __forceinline__ float gelu_erf(float v) {
+    return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+}
+
+template <int EPI>
+__global__ void __launch_bounds__(256, 2)
+gemm_f32_kernel(const float* __restrict__ A, const float* __restrict__ W,
+                const float* __restrict__ bias, const float* __restrict__ resid,
+                float* __restrict__ C, uint32_t M, uint32_t N, uint32_t K) {
+    __shared__ __attribute__((aligned(16))) float lds[2 * GBM * GLS];
+    float* As = lds;
+    float* Ws = lds + GBM * GLS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int l31 = lane & 31, h = lane >> 5;
+    const uint32_t m0 = blockIdx.y * GBM, n0 = blockIdx.x * GBN;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    // global -> register staging: 4 float4 of A and 4 of W per thread per stage
+    f32x4 ga[4], gw[4];
+    auto load_stage = [&](uint32_t k0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = tid + 256 * i;
+            const int row = idx >> 3, c4 = idx & 7;
+            const uint32_t m = m0 + row;
+            ga[i] = (m < M) ? *reinterpret_cast<const f32x4*>(A + (size_t)m * K + k0 + c4 * 4)
+                            : f32x4{0.f, 0.f, 0.f, 0.f};
+            gw[i] = *reinterpret_cast<const f32x4*>(W + (size_t)(n0 + row) * K + k0 + c4 * 4);
+        }
+    };
+    auto store_stage = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = tid + 256 * i;
+            const int row = idx >> 3, c4 = idx & 7;
+            *reinterpret_cast<f32x4*>(As + row * GLS + c4 * 4) = ga[i];
+            *reinterpret_cast<f32x4*>(Ws + row * GLS + c4 * 4) = gw[i];
+        }
+    };
+
+    load_stage(0);
+    store_stage();
+    __syncthreads();
+    for (uint32_t k0 = 0; k0 < K; k0 += GBK) {
+        const bool more = (k0 + GBK) < K;
+        if (more) load_stage(k0 + GBK);  // in flight while this stage computes
+        f32x4 a[2][4], b[2][4];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                a[t][c] = *reinterpret_cast<const f32x4*>(As + (wr * 64 + t * 32 + l31) * GLS + 16 * h + 4 * c);
+                b[t][c] = *reinterpret_cast<const f32x4*>(Ws + (wc * 64 + t * 32 + l31) * GLS + 16 * h + 4 * c);
+            }
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][c][e], b[j][c][e], acc[i][j], 0, 0, 0);
+        __syncthreads();
+        if (more) {
+            store_stage();
+            __syncthreads();
+        }
+    }
+
+    // epilogue: C/D map col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const uint32_t col = n0 + wc * 64 + j * 32 + l31;
+        const float bv = bias[col];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const uint32_t row = m0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (row < M) {
+                    float v = acc[i][j][r] + bv;
+                    if (EPI == EPI_GELU) v = gelu_erf(v);
+                    if (EPI == EPI_RESID) v = v + resid[(size_t)row * N + col];
+                    C[(size_t)row * N + col] = v;
+                }
+            }
+        }
+    }
+}
+
+// ---- E3: attention, head_dim 32 ---------------------------------------------------------------
+// Block = (query block of 128, head, batch); wave w owns queries qb*128 + w*32 + (lane&31).
+// S^T tile (keys x queries) = K_tile (A: [key][d]) x Q^T (B: [d][query]); then
+// O^T (d x queries) += V_tile^T (A: [d][key]) x P^T (B: [key][query]) where P^T is the S^T
+// accumulator itself: its row (key) index sits on (register, half) exactly as the A/B k index
+// of the next MFMA needs, so probabilities never leave registers.
+constexpr int AKS = 36;  // padded K row (floats)
+
+__global__ void __launch_bounds__(256)
+attention_kernel(const float* __restrict__ qkv, const int32_t* __restrict__ mask,
+                 float* __restrict__ ctx, uint32_t L, uint32_t H, float scale) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const uint32_t Lp = (L + 31) & ~31u;
+    float* Ks = smem;                 // [Lp][36]
+    float* Vs = Ks + (size_t)Lp * AKS;  // [Lp][32]
+    float* madd = Vs + (size_t)Lp * 32; // [Lp]
+    int& last_valid = *reinterpret_cast<int*>(madd + Lp);  // all LDS in the one dynamic region
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const uint32_t qb = blockIdx.x, head = blockIdx.y, b = blockIdx.z;
+    const size_t row3 = (size_t)3 * H;
+    const float* base = qkv + (size_t)b * L * row3 + head * 32;
+
+    if (tid == 0) last_valid = 0;
+    __syncthreads();
+    for (uint32_t idx = tid; idx < Lp * 8; idx += 256) {
+        const uint32_t key = idx >> 3, c4 = idx & 7;
+        f32x4 kv = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
+        if (key < L) {
+            kv = *reinterpret_cast<const f32x4*>(base + key * row3 + H + c4 * 4);
+            vv = *reinterpret_cast<const f32x4*>(base + key * row3 + 2 * H + c4 * 4);
+        }
+        *reinterpret_cast<f32x4*>(Ks + key * AKS + c4 * 4) = kv;
+        *reinterpret_cast<f32x4*>(Vs + key * 32 + c4 * 4) = vv;
+    }
+    for (uint32_t key = tid; key < Lp; key += 256) {
+        const bool ok = key < L && mask[(size_t)b * L + key] != 0;
+        madd[key] = ok ? 0.0f : kMaskMin;
+        if (ok) atomicMax(&last_valid, (int)key);
+    }
+    __syncthreads();
+    const uint32_t ntiles = (uint32_t)last_valid / 32 + 1;  // trailing all-masked tiles add exp(min - m) = 0
+
+    const uint32_t query = qb * 128 + wave * 32 + l31;
+    float qf[16];
+    {
+        const bool ok = query < L;
+        const float* qp = base + (size_t)(ok ? query : 0) * row3 + 16 * h;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const f32x4 t = *reinterpret_cast<const f32x4*>(qp + 4 * c);
+            qf[4 * c + 0] = ok ? t.x : 0.f; qf[4 * c + 1] = ok ? t.y : 0.f;
+            qf[4 * c + 2] = ok ? t.z : 0.f; qf[4 * c + 3] = ok ? t.w : 0.f;
+        }
+    }
+    f32x16 ot;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ot[r] = 0.0f;
+    float m = -__builtin_huge_valf(), lsum = 0.0f;
+
+    for (uint32_t kt = 0; kt < ntiles; ++kt) {
+        const float* kr = Ks + (size_t)(kt * 32 + l31) * AKS + 16 * h;
+        f32x4 ka[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) ka[c] = *reinterpret_cast<const f32x4*>(kr + 4 * c);
+        f32x16 st;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) st[r] = 0.0f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                st = __builtin_amdgcn_mfma_f32_32x32x2f32(ka[c][e], qf[4 * c + e], st, 0, 0, 0);
+        // st[r] = S^T[key = kt*32 + (r&3) + 8*(r>>2) + 4h][query = lane&31]
+        float tmax = -__builtin_huge_valf();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const uint32_t key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            st[r] = st[r] * scale + madd[key];
+            tmax = fmaxf(tmax, st[r]);
+        }
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        const float mnew = fmaxf(m, tmax);
+        const float alpha = expf(m - mnew);
+        float psum = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            st[r] = expf(st[r] - mnew);
+            psum += st[r];
+        }
+        lsum = lsum * alpha + psum;
+        m = mnew;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ot[r] *= alpha;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const uint32_t key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            const float vt = Vs[(size_t)key * 32 + l31];  // A = V^T[d = lane&31][key]
+            ot = __builtin_amdgcn_mfma_f32_32x32x2f32(vt, st[r], ot, 0, 0, 0);
+        }
+    }
+    lsum += __shfl_xor(lsum, 32, 64);
+    const float inv = 1.0f / lsum;
+    // ot[r] = O^T[d = (r&3) + 8*(r>>2) + 4h][query]; 4 consecutive d per register quad
+    if (query < L) {
+        float* op = ctx + ((size_t)b * L + query) * H + head * 32 + 4 * h;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            f32x4 o = {ot[4 * g] * inv, ot[4 * g + 1] * inv, ot[4 * g + 2] * inv, ot[4 * g + 3] * inv};
+            *reinterpret_cast<f32x4*>(op + 8 * g) = o;
+        }
+    }
+}
+
+// ---- E7/E8: pooling + L2 normalise ------------------------------------------------------------
+// One wave per sequence.  CLS: row 0.  Mean: sum(mask*h) / max(sum mask, 1e-9).
+template <int NPL>
+__global__ void __launch_bounds__(256)
+pool_normalize_kernel(const float* __restrict__ x, const int32_t* __restrict__ mask, uint32_t B,
+                      uint32_t L, int pooling, float* __restrict__ out) {
+    constexpr int H = 64 * NPL;
+    const int lane = threadIdx.x & 63;
+    const uint32_t b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= B) return;
+    float v[NPL];
+    if (pooling == CS_POOL_CLS) {
+        const float* r = x + (size_t)b * L * H;
+#pragma unroll
+        for (int i = 0; i < NPL; ++i) v[i] = r[lane + 64 * i];
+    } else {
+#pragma unroll
+        for (int i = 0; i < NPL; ++i) v[i] = 0.0f;
+        float cnt = 0.0f;
+        for (uint32_t t = 0; t < L; ++t) {
+            if (!mask[(size_t)b * L + t]) continue;  // wave-uniform
+            cnt += 1.0f;
+            const float* r = x + ((size_t)b * L + t) * H;
+#pragma unroll
+            for (int i = 0; i < NPL; ++i) v[i] += r[lane + 64 * i];
+        }
+        cnt = fmaxf(cnt, 1e-9f);
+#pragma unroll
+        for (int i = 0; i < NPL; ++i) v[i] /= cnt;
+    }
+    float ss = 0.0f;
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) ss = fmaf(v[i], v[i], ss);
+    const float den = sqrtf(wave_sum(ss)) + 1e-12f;
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) out[(size_t)b * H + lane + 64 * i] = v[i] / den;
+}
+
+// ---- synthetic parameters, generated in HBM ---------------------------------------------------
+__global__ void synth_params_kernel(float* __restrict__ out, cs_bert_config cfg, cs_bert_offsets off,
+                                    uint64_t seed) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < off.total; e += stride)
+        out[e] = cs_bert_synth_param(&cfg, &off, seed, e);
+}
+
+// ---- launchers --------------------------------------------------------------------------------
+
+template <int NPL>
+static void launch_rows(int which, const EncoderLaunch& a, hipStream_t s) {
+    const uint32_t T = a.T;
+    if (which == 0)
+        hipLaunchKernelGGL(embed_ln_kernel<NPL>, dim3((T + 3) / 4), dim3(256), 0, s, a.ids, a.word, a.pos,
+                           a.type0, a.g, a.b, a.eps, T, a.L, a.vocab, a.x);
+    else if (which == 1)
+        hipLaunchKernelGGL(layernorm_kernel<NPL>, dim3((T + 3) / 4), dim3(256), 0, s, a.x, a.g, a.b, a.eps, T);
+    else
+        hipLaunchKernelGGL(pool_normalize_kernel<NPL>, dim3((a.B + 3) / 4), dim3(256), 0, s, a.x, a.mask, a.B,
+                           a.L, a.pooling, a.out);
+}
+
+int32_t launch_row_kernel(int which, const EncoderLaunch& a, uint32_t H, hipStream_t s) {
+    switch (H) {
+        case 384: launch_rows<6>(which, a, s); break;
+        case 768: launch_rows<12>(which, a, s); break;
+        case 1024: launch_rows<16>(which, a, s); break;
+        default: return fail(CS_ERR_UNSUPPORTED, "hidden size %u not supported (384/768/1024)", H);
+    }
+    CS_HIP(hipGetLastError());
+    return CS_OK;
+}
+
+int32_t launch_gemm(int epi, const float* A, const float* W, const float* bias, const float* resid,
+                    float* C, uint32_t M, uint32_t N, uint32_t K, hipStream_t s) {
+    if (N % GBN || K % GBK) return fail(CS_ERR_UNSUPPORTED, "GEMM N=%u K=%u must be multiples of 128/32", N, K);
+    dim3 grid(N / GBN, (M + GBM - 1) / GBM);
+    if (epi == EPI_BIAS) hipLaunchKernelGGL(gemm_f32_kernel<EPI_BIAS>, grid, dim3(256), 0, s, A, W, bias, resid, C, M, N, K);
+    else if (epi == EPI_GELU) hipLaunchKernelGGL(gemm_f32_kernel<EPI_GELU>, grid, dim3(256), 0, s, A, W, bias, resid, C, M, N, K);
+    else hipLaunchKernelGGL(gemm_f32_kernel<EPI_RESID>, grid, dim3(256), 0, s, A, W, bias, resid, C, M, N, K);
+    CS_HIP(hipGetLastError());
+    return CS_OK;
+}
+
+size_t attention_lds_bytes(uint32_t L) {
+    const uint32_t Lp = (L + 31) & ~31u;
+    return (size_t)Lp * (AKS + 32 + 1) * sizeof(float) + 16;
+}
+
+int32_t launch_attention(const float* qkv, const int32_t* mask, float* ctx, uint32_t B, uint32_t L,
+                         uint32_t H, uint32_t heads, hipStream_t s) {
+    if (H / heads != 32 || H % heads)
+        return fail(CS_ERR_UNSUPPORTED, "head_dim %u not supported (32 only in this round)", heads ? H / heads : 0);
+    const size_t lds = attention_lds_bytes(L);
+    if (lds > 160 * 1024 - 64) return fail(CS_ERR_UNSUPPORTED, "sequence length %u exceeds the LDS-resident K/V limit", L);
+    static bool attr_set = false;
+    if (!attr_set) {
+        CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attention_kernel),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
+        attr_set = true;
+    }
+    dim3 grid((L + 127) / 128, heads, B);
+    hipLaunchKernelGGL(attention_kernel, grid, dim3(256), lds, s, qkv, mask, ctx, L, H,
+                       1.0f / sqrtf(32.0f));
+    CS_HIP(hipGetLastError());
+    return CS_OK;
+}
+
+int32_t launch_synth_params(float* d_out, const cs_bert_config& cfg, uint64_t seed, hipStream_t s) {
+    cs_bert_offsets off;
+    cs_bert_layout(&cfg, &off);
+    hipLaunchKernelGGL(synth_params_kernel, dim3(2048), dim3(256), 0, s, d_out, cfg, off, seed);
+    CS_HIP(hipGetLastError());
+    return CS_OK;
+}
+
+}  // namespace cs

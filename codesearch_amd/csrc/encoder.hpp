@@ -1,0 +1,39 @@
+// encoder.hpp — launch interface of the encoder kernels (encoder.hip).
+#pragma once
+
+#include "common.hpp"
+
+#include "../../include/cs_bert_params.h"
+
+namespace cs {
+
+// Arguments of the row-wise kernels (which: 0 = embeddings+LN, 1 = LN in place,
+// 2 = pool + L2-normalise).
+struct EncoderLaunch {
+    const int32_t* ids = nullptr;
+    const int32_t* mask = nullptr;
+    const float* word = nullptr;
+    const float* pos = nullptr;
+    const float* type0 = nullptr;
+    const float* g = nullptr;
+    const float* b = nullptr;
+    float eps = 1e-12f;
+    uint32_t T = 0, L = 0, B = 0, vocab = 0;
+    int pooling = CS_POOL_CLS;
+    float* x = nullptr;
+    float* out = nullptr;
+};
+
+enum { GEMM_BIAS = 0, GEMM_GELU = 1, GEMM_RESID = 2 };
+
+int32_t launch_row_kernel(int which, const EncoderLaunch& a, uint32_t H, hipStream_t s);
+// C[M,N] = A[M,K] W[N,K]^T + bias, then epilogue (GEMM_*); resid is [M,N].
+int32_t launch_gemm(int epi, const float* A, const float* W, const float* bias, const float* resid,
+                    float* C, uint32_t M, uint32_t N, uint32_t K, hipStream_t s);
+// qkv [B*L, 3H] (Q | K | V), mask [B, L] -> ctx [B*L, H]
+int32_t launch_attention(const float* qkv, const int32_t* mask, float* ctx, uint32_t B, uint32_t L,
+                         uint32_t H, uint32_t heads, hipStream_t s);
+size_t attention_lds_bytes(uint32_t L);
+int32_t launch_synth_params(float* d_out, const cs_bert_config& cfg, uint64_t seed, hipStream_t s);
+
+}  // namespace cs

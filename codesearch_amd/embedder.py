@@ -1,0 +1,260 @@
+"""Host-side mirror of the reference's FastEmbedder / ModelType over the C ABI.
+
+Same method names and behaviour as /root/reference/src/embed/embedder.rs:7-322:
+`with_cache_dir`, `embed_batch` (adaptive mini-batch 256/128/64, `CODESEARCH_BATCH_SIZE`),
+`embed_batch_chunked` (shutdown poll between mini-batches), `embed_one`, `dimensions`,
+`model_name`, `model_type`.  The device side starts from token ids; texts go through a
+tokenizer object supplied by the caller (the host text path is SURVEY.md §8f-1).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import enum
+import os
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+from . import _lib
+from ._lib import CsError, f32p, i32p
+from .bert_params import POOL_CLS, POOL_MEAN, BertConfig
+
+
+class ModelType(enum.Enum):
+    """embedder.rs:7-198.  value = (short_name, HF name, dimensions, quantized)."""
+
+    AllMiniLML6V2 = ("minilm-l6", "sentence-transformers/all-MiniLM-L6-v2", 384, False)
+    AllMiniLML6V2Q = ("minilm-l6-q", "sentence-transformers/all-MiniLM-L6-v2 (quantized)", 384, True)
+    AllMiniLML12V2 = ("minilm-l12", "sentence-transformers/all-MiniLM-L12-v2", 384, False)
+    AllMiniLML12V2Q = ("minilm-l12-q", "sentence-transformers/all-MiniLM-L12-v2 (quantized)", 384, True)
+    ParaphraseMLMiniLML12V2 = ("paraphrase-minilm", "sentence-transformers/paraphrase-MiniLM-L6-v2", 384, False)
+    BGESmallENV15 = ("bge-small", "BAAI/bge-small-en-v1.5", 384, False)
+    BGESmallENV15Q = ("bge-small-q", "BAAI/bge-small-en-v1.5 (quantized)", 384, True)
+    BGEBaseENV15 = ("bge-base", "BAAI/bge-base-en-v1.5", 768, False)
+    BGELargeENV15 = ("bge-large", "BAAI/bge-large-en-v1.5", 1024, False)
+    NomicEmbedTextV1 = ("nomic-v1", "nomic-ai/nomic-embed-text-v1", 768, False)
+    NomicEmbedTextV15 = ("nomic-v1.5", "nomic-ai/nomic-embed-text-v1.5", 768, False)
+    NomicEmbedTextV15Q = ("nomic-v1.5-q", "nomic-ai/nomic-embed-text-v1.5 (quantized)", 768, True)
+    JinaEmbeddingsV2BaseCode = ("jina-code", "jinaai/jina-embeddings-v2-base-code", 768, False)
+    MultilingualE5Small = ("e5-multilingual", "intfloat/multilingual-e5-small", 384, False)
+    MxbaiEmbedLargeV1 = ("mxbai-large", "mixedbread-ai/mxbai-embed-large-v1", 1024, False)
+    ModernBertEmbedLarge = ("modernbert-large", "lightonai/modernbert-embed-large", 1024, False)
+
+    @classmethod
+    def default(cls) -> "ModelType":
+        return cls.AllMiniLML6V2Q  # embedder.rs:12-13 (#[default])
+
+    def dimensions(self) -> int:  # embedder.rs:76-96
+        return self.value[2]
+
+    def name_str(self) -> str:  # embedder.rs:98-117 (`name`)
+        return self.value[1]
+
+    def short_name(self) -> str:  # embedder.rs:132-151
+        return self.value[0]
+
+    def is_quantized(self) -> bool:  # embedder.rs:121-129
+        return self.value[3]
+
+    @classmethod
+    def all(cls) -> List["ModelType"]:  # embedder.rs:155-174
+        return list(cls)
+
+    @classmethod
+    def parse(cls, s: str) -> Optional["ModelType"]:
+        """embedder.rs:177-197: short name or lower-cased enum name."""
+        s = s.lower()
+        for m in cls:
+            if s == m.short_name() or s == _PARSE_ALIASES.get(m.name):
+                return m
+        return None
+
+    def bert_config(self) -> BertConfig:
+        """Encoder architecture this build can run on the GPU for the model (BERT family,
+        head_dim 32).  Pooling = fastembed's default for the family (CLS for BGE, mean for
+        MiniLM/E5), SURVEY.md §0 #4."""
+        if self in (ModelType.BGESmallENV15, ModelType.BGESmallENV15Q):
+            return BertConfig(pooling=POOL_CLS)
+        if self in (ModelType.AllMiniLML6V2, ModelType.AllMiniLML6V2Q, ModelType.ParaphraseMLMiniLML12V2):
+            return BertConfig(layers=6, pooling=POOL_MEAN)
+        if self in (ModelType.AllMiniLML12V2, ModelType.AllMiniLML12V2Q):
+            return BertConfig(layers=12, pooling=POOL_MEAN)
+        raise CsError(_lib.CS_ERR_UNSUPPORTED,
+                      f"Failed to initialize embedding model: {self.name_str()} is not a head_dim-32 BERT "
+                      "encoder; this round builds the 384-d BERT family only")
+
+
+# second spellings accepted by ModelType::parse (embedder.rs:178-195), verbatim
+_PARSE_ALIASES = {
+    "AllMiniLML6V2": "allminiml6v2", "AllMiniLML6V2Q": "allminiml6v2q",
+    "AllMiniLML12V2": "allminiml12v2", "AllMiniLML12V2Q": "allminiml12v2q",
+    "BGESmallENV15": "bgesmallenv15", "BGESmallENV15Q": "bgesmallenv15q",
+    "BGEBaseENV15": "bgebaseenv15", "BGELargeENV15": "bgelargeenv15",
+    "NomicEmbedTextV1": "nomicembedtextv1", "NomicEmbedTextV15": "nomicembedtextv15",
+    "NomicEmbedTextV15Q": "nomicembedtextv15q", "JinaEmbeddingsV2BaseCode": "jinaembeddingsv2basecode",
+    "MultilingualE5Small": "multilinguale5small", "MxbaiEmbedLargeV1": "mxbaiembedlargev1",
+    "ModernBertEmbedLarge": "modernbertembedlarge",
+}
+
+_SHUTDOWN = C.c_int32(0)  # constants.rs:17-33 global shutdown flag
+
+
+def request_shutdown(value: bool = True) -> None:
+    _SHUTDOWN.value = 1 if value else 0
+
+
+def is_shutdown_requested() -> bool:
+    return bool(_SHUTDOWN.value)
+
+
+class FastEmbedder:
+    """embedder.rs:201-322.  `params` = flat f32 block in include/cs_bert_params.h order
+    (see bert_params.from_state_dict for real checkpoints); None => synthetic weights from
+    `seed`, generated on the device."""
+
+    def __init__(self, model_type: ModelType = None, cache_dir=None, *, config: BertConfig = None,
+                 params: np.ndarray = None, seed: int = 0, device: int = 0, tokenizer=None):
+        self._lib = _lib.load()
+        self._model_type = model_type or ModelType.default()
+        self.config = config or self._model_type.bert_config()
+        if cache_dir is not None:  # embedder.rs:224-229
+            os.environ["FASTEMBED_CACHE_DIR"] = str(cache_dir)
+        self.tokenizer = tokenizer
+        ccfg = self.config.to_c()
+        pptr = None
+        if params is not None:
+            params = np.ascontiguousarray(params, np.float32)
+            need = int(self._lib.cs_bert_param_count(C.byref(ccfg)))
+            if params.size != need:
+                raise CsError(_lib.CS_ERR_BAD_ARG,
+                              f"Failed to initialize embedding model: expected {need} parameters, got {params.size}")
+            pptr = params.ctypes.data_as(f32p)
+        h = C.c_void_p()
+        _lib.check(self._lib.cs_embedder_create(C.byref(ccfg), pptr, seed, device, C.byref(h)))
+        self._h = h
+
+    # constructors named as in the reference
+    @classmethod
+    def new(cls, **kw) -> "FastEmbedder":
+        return cls.with_model(ModelType.default(), **kw)
+
+    @classmethod
+    def with_model(cls, model_type: ModelType, **kw) -> "FastEmbedder":
+        return cls.with_cache_dir(model_type, None, **kw)
+
+    @classmethod
+    def with_cache_dir(cls, model_type: ModelType, cache_dir, **kw) -> "FastEmbedder":
+        return cls(model_type, cache_dir, **kw)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.cs_embedder_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- token-id entry points (what the device consumes) ---------------------------------
+    def embed_ids(self, ids, mask, batch_size: int = 0) -> np.ndarray:
+        """ids/mask [n, L] int32 -> [n, dim] float32 (pooled, L2-normalised)."""
+        ids = np.ascontiguousarray(ids, np.int32)
+        mask = np.ascontiguousarray(mask, np.int32)
+        if ids.ndim != 2 or ids.shape != mask.shape:
+            raise ValueError("ids and mask must both be [n, seq_len]")
+        n, L = ids.shape
+        out = np.empty((n, self.dimensions()), np.float32)
+        _lib.check(self._lib.cs_embedder_embed_ids(self._h, ids.ctypes.data_as(i32p), mask.ctypes.data_as(i32p),
+                                                   n, L, batch_size, out.ctypes.data_as(f32p),
+                                                   C.cast(C.byref(_SHUTDOWN), i32p)))
+        return out
+
+    def embed_ids_to_device(self, ids, mask, d_out_ptr: int, batch_size: int = 0) -> None:
+        """Same, leaving the [n, dim] result at the device address d_out_ptr."""
+        ids = np.ascontiguousarray(ids, np.int32)
+        mask = np.ascontiguousarray(mask, np.int32)
+        n, L = ids.shape
+        _lib.check(self._lib.cs_embedder_embed_ids_device(self._h, ids.ctypes.data_as(i32p),
+                                                          mask.ctypes.data_as(i32p), n, L, batch_size,
+                                                          C.c_void_p(d_out_ptr), C.cast(C.byref(_SHUTDOWN), i32p)))
+
+    def last_hidden(self, n_tokens: int) -> np.ndarray:
+        out = np.empty((n_tokens, self.dimensions()), np.float32)
+        _lib.check(self._lib.cs_embedder_last_hidden(self._h, out.ctypes.data_as(f32p), n_tokens))
+        return out
+
+    # ---- text entry points (embedder.rs:249-304) --------------------------------------------
+    def _tokenize(self, texts: Sequence[str]):
+        if self.tokenizer is None:
+            raise CsError(_lib.CS_ERR_UNSUPPORTED,
+                          "Failed to generate embeddings: no tokenizer attached (pass tokenizer=...)")
+        return self.tokenizer.encode_batch(list(texts), self.config.max_position)
+
+    def embed_batch(self, texts: Sequence[str]) -> List[np.ndarray]:
+        """embedder.rs:249-263: mini-batch from CODESEARCH_BATCH_SIZE or 256/128/64 by dims."""
+        env = os.environ.get("CODESEARCH_BATCH_SIZE")
+        if env is not None:
+            try:
+                batch_size = int(env)
+                if batch_size <= 0:
+                    batch_size = 256
+            except ValueError:
+                batch_size = 256
+        else:
+            d = self.dimensions()
+            batch_size = 256 if d <= 384 else (128 if d <= 768 else 64)
+        return self.embed_batch_chunked(texts, batch_size)
+
+    def embed_batch_chunked(self, texts: Sequence[str], batch_size: int) -> List[np.ndarray]:
+        """embedder.rs:266-295: tokenise and run each mini-batch (padded batch-longest, as
+        fastembed does), polling the shutdown flag between mini-batches."""
+        texts = list(texts)
+        if not texts:
+            return []
+        out: List[np.ndarray] = []
+        for lo in range(0, len(texts), batch_size):
+            if is_shutdown_requested():
+                raise CsError(_lib.CS_ERR_CANCELLED, "Embedding interrupted by shutdown request")
+            ids, mask = self._tokenize(texts[lo:lo + batch_size])
+            emb = self.embed_ids(ids, mask, batch_size)
+            out.extend(emb[i] for i in range(emb.shape[0]))
+        return out
+
+    def embed_one(self, text: str) -> np.ndarray:
+        """embedder.rs:298-304."""
+        r = self.embed_batch([text])
+        if not r:
+            raise CsError(_lib.CS_ERR_BAD_ARG, "No embedding generated")
+        return r[0]
+
+    def dimensions(self) -> int:
+        return int(self._lib.cs_embedder_dim(self._h))
+
+    def model_name(self) -> str:
+        return self._model_type.name_str()
+
+    def model_type(self) -> ModelType:
+        return self._model_type
+
+    def profile_read(self, reset: bool = True):
+        """-> (forward_ms_total, forwards)"""
+        ms, n = C.c_double(), C.c_uint64()
+        _lib.check(self._lib.cs_embedder_profile_read(self._h, C.byref(ms), C.byref(n), 1 if reset else 0))
+        return ms.value, int(n.value)
+
+
+def smoke(oracle) -> None:
+    """Tiny encoder batch on device 0 vs the CPU oracle (called by __graft_entry__.smoke)."""
+    from .bert_params import synth_token_batch
+
+    cfg = BertConfig(vocab_size=512, layers=2, pooling=POOL_CLS)
+    emb = FastEmbedder(ModelType.BGESmallENV15, config=cfg, seed=101, device=0)
+    ids, mask = synth_token_batch(cfg, 151, 4, 16, True)
+    got = emb.embed_ids(ids, mask)
+    exp = oracle.bert_forward(cfg, oracle.bert_synth_params(cfg, 101), ids, mask)["pooled"]
+    err = float(np.abs(got - exp).max())
+    assert err < 1e-4, err
+    emb.close()
+    print(f"smoke ok: encoder parity on cuda:0, max |gpu - oracle| = {err:.2e}")

@@ -1,0 +1,55 @@
+"""The C-ABI library loads without a GPU and exports every symbol include/codesearch_gpu.h
+declares; the Python binding table covers exactly that set.  CPU only (no compute calls)."""
+import ctypes
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "codesearch_gpu.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    names = set(re.findall(r"\b(cs_[a-z0-9_]+)\s*\(", text))
+    inline = set(re.findall(r"static inline [a-z0-9_ ]+?\b(cs_[a-z0-9_]+)\s*\(", text))
+    return names - inline
+
+
+def test_library_exports_every_declared_symbol(gpu_lib):
+    from codesearch_amd import _lib
+
+    syms = declared_symbols()
+    assert len(syms) >= 30
+    raw = ctypes.CDLL(_lib.LIB_PATH)
+    for s in sorted(syms):
+        assert hasattr(raw, s), f"{s} declared in include/codesearch_gpu.h but not exported"
+    assert syms == set(_lib.SIGNATURES), syms ^ set(_lib.SIGNATURES)
+
+
+def test_no_gpu_means_loud_failure_not_fallback(gpu_lib):
+    """Without a device the product refuses to run (CS_ERR_HIP); it never computes on the CPU."""
+    from codesearch_amd import CsError, VectorStore, _lib
+
+    if gpu_lib.cs_device_count() > 0:
+        return  # on the GPU box this path is covered by the -m gpu tests
+    try:
+        VectorStore(None, 384)
+    except CsError as e:
+        assert e.code in (_lib.CS_ERR_HIP, _lib.CS_ERR_OOM)
+    else:
+        raise AssertionError("VectorStore was created without a GPU")
+
+
+def test_inline_key_helpers_match_python_mirror():
+    import numpy as np
+
+    from codesearch_amd.sharded import key_pack, key_unpack
+
+    cos = np.array([1.0, 0.5, 0.0, -0.0, -0.25, 3e-8, -1.0], np.float32)
+    ids = np.array([0, 1, 2, 3, 4, 0xFFFFFFFE, 7], np.uint32)
+    keys = key_pack(cos, ids)
+    c2, i2 = key_unpack(keys)
+    assert np.array_equal(c2, np.abs(cos) * np.sign(cos) + np.float32(0)) and np.array_equal(i2, ids)
+    order = np.argsort(keys)[::-1]
+    assert order.tolist() == [0, 1, 5, 2, 3, 4, 6]  # cos desc, then id asc on the tie at 0.0
+    assert (keys != 0).all()

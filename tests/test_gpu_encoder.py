@@ -1,0 +1,162 @@
+"""Parity tests proper for the encoder: HIP kernels through the C ABI vs the CPU oracle and
+the committed HF-transformers golden vectors.  Needs an MI355X.
+
+Bar (BASELINE.json north_star): embeddings within 1e-4 of the reference path; asserted at
+2e-5 against the fp32 oracle and 3e-5 against the float64 golden vectors."""
+import os
+
+import numpy as np
+import pytest
+
+from codesearch_amd.bert_params import POOL_CLS, POOL_MEAN, BertConfig, synth_params, synth_token_batch
+
+pytestmark = pytest.mark.gpu
+
+GOLD = np.load(os.path.join(os.path.dirname(__file__), "golden", "encoder_golden.npz"))
+TOL_ORACLE = 2e-5
+TOL_GOLDEN = 3e-5
+
+
+def case_cfg(name):
+    m = GOLD[name + "/meta"]
+    cfg = BertConfig(vocab_size=int(m[0]), hidden=int(m[1]), layers=int(m[2]), heads=int(m[3]),
+                     intermediate=int(m[4]), max_position=int(m[5]))
+    return cfg, int(m[6]), int(m[7]), int(m[8]), int(m[9]), bool(m[10])
+
+
+@pytest.fixture(scope="module")
+def FE(gpu_lib):
+    from codesearch_amd import FastEmbedder, ModelType
+
+    assert gpu_lib.cs_device_count() >= 1
+    return lambda cfg, **kw: FastEmbedder(ModelType.BGESmallENV15, config=cfg, **kw)
+
+
+def test_device_generated_params_match_host(FE, oracle):
+    """Synthetic weights generated in HBM == the C / numpy generators: a model built from
+    an uploaded block and one built from the seed give identical embeddings."""
+    cfg = BertConfig(vocab_size=512, layers=2)
+    ids, mask = synth_token_batch(cfg, 3, 4, 16, True)
+    a = FE(cfg, seed=7).embed_ids(ids, mask)
+    b = FE(cfg, params=synth_params(cfg, 7)).embed_ids(ids, mask)
+    assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("name", [str(n) for n in GOLD["names"] if str(n).startswith("tiny")])
+def test_tiny_cases_vs_golden_and_oracle(FE, oracle, name):
+    cfg, wseed, iseed, B, L, ragged = case_cfg(name)
+    ids, mask = synth_token_batch(cfg, iseed, B, L, ragged)
+    params = synth_params(cfg, wseed)
+    for pooling, key in ((POOL_CLS, "cls"), (POOL_MEAN, "mean")):
+        cfg.pooling = pooling
+        emb = FE(cfg, seed=wseed)
+        got = emb.embed_ids(ids, mask)
+        ref = oracle.bert_forward(cfg, params, ids, mask, want_hidden=True)
+        np.testing.assert_allclose(got, ref["pooled"], atol=TOL_ORACLE)
+        np.testing.assert_allclose(got, GOLD[f"{name}/{key}"], atol=TOL_GOLDEN)
+        np.testing.assert_allclose(np.linalg.norm(got, axis=1), 1.0, atol=1e-5)  # embedder.rs:460-463
+        # full last_hidden_state of the valid tokens (pad rows are don't-care)
+        hid = emb.last_hidden(B * L).reshape(B, L, cfg.hidden)
+        valid = mask.astype(bool)
+        np.testing.assert_allclose(hid[valid], ref["hidden"][valid], atol=1e-4)
+        emb.close()
+
+
+def test_full_bge_small_shape_vs_golden_and_oracle(FE, oracle):
+    """12 layers, hidden 384, 12 heads, FFN 1536, vocab 30522 (BAAI/bge-small-en-v1.5)."""
+    for name in ("full_dense", "full_ragged"):
+        cfg, wseed, iseed, B, L, ragged = case_cfg(name)
+        ids, mask = synth_token_batch(cfg, iseed, B, L, ragged)
+        params = oracle.bert_synth_params(cfg, wseed)
+        for pooling, key in ((POOL_CLS, "cls"), (POOL_MEAN, "mean")):
+            cfg.pooling = pooling
+            emb = FE(cfg, seed=wseed)
+            got = emb.embed_ids(ids, mask)
+            ref = oracle.bert_forward(cfg, params, ids, mask, want_hidden=True)
+            np.testing.assert_allclose(got, ref["pooled"], atol=TOL_ORACLE)
+            np.testing.assert_allclose(got, GOLD[f"{name}/{key}"], atol=TOL_GOLDEN)
+            hid = emb.last_hidden(B * L).reshape(B, L, cfg.hidden)
+            valid = mask.astype(bool)
+            np.testing.assert_allclose(hid[valid], ref["hidden"][valid], atol=2e-4)
+            emb.close()
+
+
+@pytest.mark.parametrize("L", [1, 5, 31, 32, 33, 100, 129, 257, 512])
+def test_sequence_length_edges(FE, oracle, L):
+    cfg = BertConfig(vocab_size=512, layers=1)
+    ids, mask = synth_token_batch(cfg, 40 + L, 3, L, L > 2)
+    emb = FE(cfg, seed=9)
+    got = emb.embed_ids(ids, mask)
+    ref = oracle.bert_forward(cfg, synth_params(cfg, 9), ids, mask)["pooled"]
+    np.testing.assert_allclose(got, ref, atol=TOL_ORACLE)
+
+
+def test_minibatching_and_padding_invariance(FE, oracle):
+    """embed_batch_chunked semantics: results do not depend on the mini-batch size, and
+    batch-longest padding does not leak into a sequence's embedding."""
+    cfg = BertConfig(vocab_size=512, layers=2, pooling=POOL_MEAN)
+    ids, mask = synth_token_batch(cfg, 77, 37, 48, True)
+    emb = FE(cfg, seed=5)
+    whole = emb.embed_ids(ids, mask, batch_size=64)
+    parts = emb.embed_ids(ids, mask, batch_size=8)
+    np.testing.assert_allclose(whole, parts, atol=1e-6)
+    n1 = int(mask[3].sum())
+    alone = emb.embed_ids(ids[3:4, :n1], mask[3:4, :n1])
+    np.testing.assert_allclose(whole[3], alone[0], atol=2e-6)
+    ref = oracle.bert_forward(cfg, synth_params(cfg, 5), ids, mask)["pooled"]
+    np.testing.assert_allclose(whole, ref, atol=TOL_ORACLE)
+
+
+def test_cancel_and_errors(FE):
+    from codesearch_amd import CsError, FastEmbedder, ModelType
+    from codesearch_amd import embedder as E
+
+    cfg = BertConfig(vocab_size=512, layers=1)
+    emb = FE(cfg, seed=1)
+    ids, mask = synth_token_batch(cfg, 1, 4, 8, False)
+    E.request_shutdown(True)
+    try:
+        with pytest.raises(CsError) as e:  # embedder.rs:280-282
+            emb.embed_ids(ids, mask)
+        assert str(e.value) == "Embedding interrupted by shutdown request" and e.value.code == 4
+    finally:
+        E.request_shutdown(False)
+    bad = ids.copy()
+    bad[0, 1] = 512
+    with pytest.raises(CsError) as e:
+        emb.embed_ids(bad, mask)
+    assert str(e.value).startswith("Failed to generate embeddings:")  # embedder.rs:289
+    with pytest.raises(CsError):
+        emb.embed_ids(np.zeros((1, 513), np.int32), np.ones((1, 513), np.int32))
+    assert emb.embed_ids(ids[:0], mask[:0]).shape == (0, 384)  # embedder.rs:271-273
+    assert emb.dimensions() == 384 and emb.model_name() == "BAAI/bge-small-en-v1.5"
+    with pytest.raises(CsError):  # a model family this round does not build
+        FastEmbedder(ModelType.BGEBaseENV15)
+
+
+def test_reference_semantic_ordering_sanity(FE):
+    """embedder.rs:487-506 asserts only an ordering: similar inputs embed closer than
+    dissimilar ones.  With synthetic weights: a sequence vs a one-token edit vs a random one."""
+    cfg = BertConfig(vocab_size=512, layers=2)
+    ids, mask = synth_token_batch(cfg, 5, 3, 32, False)
+    ids[1] = ids[0]
+    ids[1, 7] = (ids[0, 7] + 1) % 512
+    e = FE(cfg, seed=3).embed_ids(ids, mask)
+    assert float(e[0] @ e[1]) > float(e[0] @ e[2])
+
+
+def test_config3_shape_b256_l256_property(FE, oracle):
+    """BASELINE.json configs[2]: B=256, L=256 on the full model.  The oracle would need
+    minutes at this size, so check size-independent properties: unit norms, batch-position
+    invariance (row i alone == row i in the batch) and 8 sampled rows against the oracle."""
+    cfg = BertConfig.bge_small()
+    B, L = 256, 256
+    ids, mask = synth_token_batch(cfg, 999, B, L, True)
+    emb = FE(cfg, seed=202)
+    got = emb.embed_ids(ids, mask)
+    np.testing.assert_allclose(np.linalg.norm(got, axis=1), 1.0, atol=1e-5)
+    rows = [0, 1, 77, 128, 200, 255]
+    sub = emb.embed_ids(ids[rows], mask[rows])
+    np.testing.assert_allclose(sub, got[rows], atol=2e-6)
+    ref = oracle.bert_forward(cfg, oracle.bert_synth_params(cfg, 202), ids[rows], mask[rows])["pooled"]
+    np.testing.assert_allclose(got[rows], ref, atol=TOL_ORACLE)
