@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""Encoder throughput at BASELINE.json configs[2]: BGE-small shape, batch 256, seq 256.
+Prints one JSON line: sequences ("chunks") embedded per second, ms per batch, achieved
+TFLOP/s against the fp32 MFMA peak (157.3 TF, MI355X_MICROARCH.md)."""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--seq", type=int, default=256)
+    ap.add_argument("--iters", type=int, default=5)
+    ap.add_argument("--ragged", action="store_true")
+    args = ap.parse_args()
+    import numpy as np
+
+    from codesearch_amd import BertConfig, FastEmbedder, ModelType
+    from codesearch_amd.bert_params import synth_token_batch
+
+    cfg = BertConfig.bge_small()
+    emb = FastEmbedder(ModelType.BGESmallENV15, config=cfg, seed=202)
+    ids, mask = synth_token_batch(cfg, 999, args.batch, args.seq, args.ragged)
+    emb.embed_ids(ids, mask)  # warm-up (allocates the workspace)
+    emb.profile_read(reset=True)
+    t0 = time.perf_counter()
+    for _ in range(args.iters):
+        out = emb.embed_ids(ids, mask)
+    wall = (time.perf_counter() - t0) / args.iters
+    ms, n = emb.profile_read()
+    ms /= max(n, 1)
+    L, H, I, layers = args.seq, cfg.hidden, cfg.intermediate, cfg.layers
+    flops_tok = layers * (2 * (4 * H * H + 2 * H * I) + 4 * L * H)
+    flops = flops_tok * args.batch * args.seq
+    print(json.dumps({
+        "workload": f"BGE-small-en-v1.5 shape, batch {args.batch} x seq {args.seq}, {'ragged' if args.ragged else 'full'} mask, fp32",
+        "device_ms_per_batch": ms, "wall_ms_per_batch_incl_pcie": wall * 1e3,
+        "chunks_per_s_device": args.batch / (ms * 1e-3), "tokens_per_s_device": args.batch * args.seq / (ms * 1e-3),
+        "algorithmic_tflop_per_batch": flops / 1e12, "achieved_tflops": flops / (ms * 1e-3) / 1e12,
+        "peak_tflops_f32_mfma": 157.3, "frac": flops / (ms * 1e-3) / 1e12 / 157.3,
+        "norm0": float(np.linalg.norm(out[0])),
+    }))
+
+
+if __name__ == "__main__":
+    main()

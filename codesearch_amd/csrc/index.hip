@@ -42,6 +42,36 @@ struct Workspace {
     float* h_cos = nullptr; uint32_t* h_ids = nullptr; uint32_t* h_counts = nullptr;
     size_t h_out_cap = 0, h_cnt_cap = 0;
     std::vector<EventTriple> free_events;
+    BatchedState bs;
+    size_t bs_nq = 0, bs_cand = 0, bs_carry = 0;
+    uint32_t* h_overflow = nullptr;
+
+    int32_t reserve_batched(uint32_t nq, uint32_t k) {
+        const size_t cand = (size_t)nq * batched_cap(k), carry = (size_t)nq * k;
+        if (!h_overflow) CS_HIP(hipHostMalloc(&h_overflow, sizeof(uint32_t)));
+        if (!bs.d_overflow) CS_HIP(hipMalloc(&bs.d_overflow, sizeof(uint32_t)));
+        if (nq > bs_nq) {
+            if (bs.d_cnt) (void)hipFree(bs.d_cnt);
+            if (bs.d_tau) (void)hipFree(bs.d_tau);
+            bs.d_cnt = nullptr; bs.d_tau = nullptr; bs_nq = 0;
+            CS_HIP(hipMalloc(&bs.d_cnt, nq * sizeof(uint32_t)));
+            CS_HIP(hipMalloc(&bs.d_tau, nq * sizeof(float)));
+            bs_nq = nq;
+        }
+        if (cand > bs_cand) {
+            if (bs.d_cand) (void)hipFree(bs.d_cand);
+            bs.d_cand = nullptr; bs_cand = 0;
+            CS_HIP(hipMalloc(&bs.d_cand, cand * sizeof(uint64_t)));
+            bs_cand = cand;
+        }
+        if (carry > bs_carry) {
+            if (bs.d_carry) (void)hipFree(bs.d_carry);
+            bs.d_carry = nullptr; bs_carry = 0;
+            CS_HIP(hipMalloc(&bs.d_carry, carry * sizeof(uint64_t)));
+            bs_carry = carry;
+        }
+        return CS_OK;
+    }
 
     int32_t reserve(const ScanPlan& p, uint32_t nq, uint32_t dim, uint32_t k, bool host_io) {
         if (p.partial_keys > partial_cap) {
@@ -111,6 +141,12 @@ struct Workspace {
         if (h_cos) (void)hipHostFree(h_cos);
         if (h_ids) (void)hipHostFree(h_ids);
         if (h_counts) (void)hipHostFree(h_counts);
+        if (h_overflow) (void)hipHostFree(h_overflow);
+        if (bs.d_cand) (void)hipFree(bs.d_cand);
+        if (bs.d_cnt) (void)hipFree(bs.d_cnt);
+        if (bs.d_tau) (void)hipFree(bs.d_tau);
+        if (bs.d_carry) (void)hipFree(bs.d_carry);
+        if (bs.d_overflow) (void)hipFree(bs.d_overflow);
         for (auto& t : free_events) {
             (void)hipEventDestroy(t.e0); (void)hipEventDestroy(t.e1); (void)hipEventDestroy(t.e2);
         }
@@ -132,6 +168,9 @@ struct cs_index {
     uint64_t n_removed = 0;
     float* d_corpus = nullptr;
     uint32_t* d_dead = nullptr;  // bitmap over rows, sized for `capacity`
+    float* d_norms = nullptr;    // |row| for rows [0, normed_rows) (batched-query path)
+    uint64_t normed_rows = 0;
+    uint64_t batched_searches = 0, batched_fallbacks = 0;
     std::vector<uint32_t> h_dead;
     bool built = false;
 
@@ -159,7 +198,18 @@ int32_t grow(cs_index* h, uint64_t need_rows) {
         (void)hipFree(nc);
         return fail(CS_ERR_OOM, "hipMalloc(dead bitmap) failed: %s", hipGetErrorString(e));
     }
+    float* nn = nullptr;
+    e = hipMalloc(&nn, (size_t)cap * sizeof(float));
+    if (e != hipSuccess) {
+        (void)hipFree(nc);
+        (void)hipFree(nd);
+        return fail(CS_ERR_OOM, "hipMalloc(row norms) failed: %s", hipGetErrorString(e));
+    }
     CS_HIP(hipMemset(nd, 0, words * sizeof(uint32_t)));
+    if (h->normed_rows)
+        CS_HIP(hipMemcpy(nn, h->d_norms, (size_t)h->normed_rows * sizeof(float), hipMemcpyDeviceToDevice));
+    if (h->d_norms) (void)hipFree(h->d_norms);
+    h->d_norms = nn;
     if (h->n_rows) {
         CS_HIP(hipMemcpy(nc, h->d_corpus, (size_t)h->n_rows * h->dim * sizeof(float),
                          hipMemcpyDeviceToDevice));
@@ -244,6 +294,36 @@ int32_t run_search(cs_index* h, Workspace* w, const ScanPlan& plan, const float*
     EventTriple ev{};
     const bool timed = take_events(h, w, &ev);
     if (timed) CS_HIP(hipEventRecord(ev.e0, stream));
+    // >= 5 queries: MFMA scoring + phased candidate selection (scan_mfma.hip)
+    if (nq >= 5 && h->n_rows > 0 && batched_supported(h->dim) && h->normed_rows >= h->n_rows) {
+        CS_TRY(w->reserve_batched(nq, k));
+        CS_TRY(launch_scan_batched(w->bs, h->d_corpus, h->d_norms, h->n_rows, h->dim, d_queries, nq, k,
+                                   h->n_removed ? h->d_dead : nullptr, h->id_base, h->num_cus, d_keys, d_cos,
+                                   d_ids, d_counts, stream));
+        if (timed) CS_HIP(hipEventRecord(ev.e1, stream));
+        CS_HIP(hipMemcpyAsync(w->h_overflow, w->bs.d_overflow, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+        CS_HIP(hipStreamSynchronize(stream));
+        bool overflow = *w->h_overflow != 0;
+        {
+            std::lock_guard<std::mutex> lk(h->mu);
+            h->batched_searches++;
+            if (overflow) h->batched_fallbacks++;
+            if (timed) {
+                CS_HIP(hipEventRecord(ev.e2, stream));
+                h->pending.push_back(ev);
+            }
+        }
+        if (!overflow) return CS_OK;
+        // candidate buffer overflowed (adversarial row order): exact list-based rerun below
+        EventTriple none{};
+        ev = none;
+        return [&]() -> int32_t {
+            CS_TRY(launch_scan(plan, h->d_corpus, h->n_rows, h->dim, d_queries, nq, k,
+                               h->n_removed ? h->d_dead : nullptr, h->id_base, w->d_partial, stream));
+            return launch_merge(w->d_partial, plan.blocks, nq, k, false, w->d_tmp_a, w->d_tmp_b, d_keys, d_cos,
+                                d_ids, d_counts, stream);
+        }();
+    }
     CS_TRY(launch_scan(plan, h->d_corpus, h->n_rows, h->dim, d_queries, nq, k,
                        h->n_removed ? h->d_dead : nullptr, h->id_base, w->d_partial, stream));
     if (timed) CS_HIP(hipEventRecord(ev.e1, stream));
@@ -322,6 +402,7 @@ void cs_index_destroy(cs_index* h) {
     }
     if (h->d_corpus) (void)hipFree(h->d_corpus);
     if (h->d_dead) (void)hipFree(h->d_dead);
+    if (h->d_norms) (void)hipFree(h->d_norms);
     delete h;
 }
 
@@ -395,6 +476,12 @@ int32_t cs_index_build(cs_index* h) {
     if (!h) return fail(CS_ERR_BAD_ARG, "null index handle");
     DeviceGuard g(h->device);
     CS_HIP(hipDeviceSynchronize());  // appended rows (incl. async device appends) are now visible
+    if (batched_supported(h->dim) && h->normed_rows < h->n_rows) {
+        CS_TRY(launch_row_norms(h->d_corpus, h->normed_rows, h->n_rows - h->normed_rows, h->dim,
+                                h->d_norms, nullptr));
+        CS_HIP(hipDeviceSynchronize());
+        h->normed_rows = h->n_rows;
+    }
     h->built = true;                 // store.rs:428
     return CS_OK;
 }
@@ -406,6 +493,7 @@ int32_t cs_index_clear(cs_index* h) {
     if (h->d_dead && h->capacity)
         CS_HIP(hipMemset(h->d_dead, 0, (size_t)((h->capacity + 31) / 32) * sizeof(uint32_t)));
     h->n_rows = 0;  // store.rs:701 next_id = 0
+    h->normed_rows = 0;
     h->n_removed = 0;
     h->h_dead.clear();
     h->built = false;  // store.rs:702
@@ -495,6 +583,14 @@ int32_t cs_index_read_rows(cs_index* h, uint64_t first_row, uint64_t n, float* o
     CS_HIP(hipDeviceSynchronize());
     CS_HIP(hipMemcpy(out_rows, h->d_corpus + (size_t)first_row * h->dim,
                      (size_t)n * h->dim * sizeof(float), hipMemcpyDeviceToHost));
+    return CS_OK;
+}
+
+int32_t cs_index_debug_counters(cs_index* h, uint64_t* batched_searches, uint64_t* batched_fallbacks) {
+    if (!h) return fail(CS_ERR_BAD_ARG, "null index handle");
+    std::lock_guard<std::mutex> lk(h->mu);
+    if (batched_searches) *batched_searches = h->batched_searches;
+    if (batched_fallbacks) *batched_fallbacks = h->batched_fallbacks;
     return CS_OK;
 }
 

@@ -36,4 +36,23 @@ size_t merge_tmp_keys(uint32_t nlists, uint32_t nq, uint32_t k);
 int32_t launch_synth_fill(float* d_rows, uint64_t n, uint32_t dim, uint64_t seed,
                           uint64_t first_row, hipStream_t stream);
 
+// ---- batched-query (MFMA) path, scan_mfma.hip ---------------------------------------------
+struct BatchedState {
+    uint64_t* d_cand = nullptr;   // [nq][cap] candidate keys
+    uint32_t* d_cnt = nullptr;    // [nq]
+    float* d_tau = nullptr;       // [nq]
+    uint64_t* d_carry = nullptr;  // [nq][k]
+    uint32_t* d_overflow = nullptr;
+};
+bool batched_supported(uint32_t dim);
+uint32_t batched_cap(uint32_t k);
+int32_t launch_row_norms(const float* d_corpus, uint64_t first, uint64_t n, uint32_t dim,
+                         float* d_norms, hipStream_t stream);
+// Exact unless *st.d_overflow != 0 afterwards (then rerun on the list-based scan).
+int32_t launch_scan_batched(const BatchedState& st, const float* d_corpus, const float* d_norms,
+                            uint64_t n_rows, uint32_t dim, const float* d_queries, uint32_t nq, uint32_t k,
+                            const uint32_t* d_dead, uint32_t id_base, int num_cus, uint64_t* d_out_keys,
+                            float* d_out_cos, uint32_t* d_out_ids, uint32_t* d_out_counts,
+                            hipStream_t stream);
+
 }  // namespace cs

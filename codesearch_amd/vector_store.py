@@ -307,6 +307,12 @@ class VectorStore:
         _lib.check(self._lib.cs_index_profile_read(self._h, C.byref(s), C.byref(n), C.byref(m), 1 if reset else 0))
         return s.value, int(n.value), m.value
 
+    def debug_counters(self):
+        """-> (batched_searches, batched_fallbacks)"""
+        a, b = C.c_uint64(), C.c_uint64()
+        _lib.check(self._lib.cs_index_debug_counters(self._h, C.byref(a), C.byref(b)))
+        return int(a.value), int(b.value)
+
     @property
     def handle(self):
         return self._h

@@ -147,6 +147,11 @@ int32_t cs_index_profile(cs_index* h, int32_t enable);
 int32_t cs_index_profile_read(cs_index* h, double* scan_ms, uint64_t* scan_launches,
                               double* merge_ms, int32_t reset);
 
+/* Diagnostics: how many searches took the batched-query (MFMA) path, and how many of those
+ * overflowed their candidate buffers and were rerun on the exact list-based scan. */
+int32_t cs_index_debug_counters(cs_index* h, uint64_t* batched_searches,
+                                uint64_t* batched_fallbacks);
+
 /* Score mapping.  store.rs:477-478: score = 1 - distance, distance = arroy 0.5.0
  * Cosine = (1 - cos) / 2  (third-party). */
 static inline float cs_cos_to_distance(float c) { return (1.0f - c) * 0.5f; }

@@ -313,3 +313,68 @@ def test_full_size_10m_against_oracle_slices(VS, oracle):
         ecos, eids = oracle.merge_topk(pc[i], pi[i], np.full(nsl, k, np.uint32), k)
         assert ids[i].tolist() == eids.tolist()
         np.testing.assert_allclose(cos[i], ecos, atol=COS_TOL)
+
+
+# ---- batched queries: the MFMA scoring + phased selection path (scan_mfma.hip) ------------------
+
+@pytest.mark.parametrize("dim,n,nq,k", [(384, 100, 5, 10), (384, 5000, 33, 25), (384, 200_003, 64, 10),
+                                        (384, 70_001, 100, 200), (768, 30_000, 40, 10), (384, 31, 7, 256)])
+def test_mfma_batched_path_vs_oracle(VS, oracle, dim, n, nq, k):
+    corpus = oracle.synth_rows(900 + nq, 0, n, dim)
+    st = VS(None, dim)
+    st.insert_embeddings(corpus)
+    dead_ids = [3, n // 2, n - 1] if n > 50 else []
+    dead = None
+    if dead_ids:
+        st.delete_chunks(dead_ids)
+        dead = np.zeros((n + 31) // 32, np.uint32)
+        for d in dead_ids:
+            dead[d >> 5] |= np.uint32(1 << (d & 31))
+    st.build_index()
+    qs = np.concatenate([synth_rows(901 + nq, 0, nq - 2, dim),
+                         synth_planted(900 + nq, 77, [n // 3, (2 * n) // 3], dim)])
+    cos, ids, counts = st.search_raw(qs, k)
+    assert st.debug_counters() == (1, 0)  # took the batched path, no overflow rerun
+    for i in range(nq):
+        ecos, eids = oracle.scan_topk(corpus, qs[i], k, dead=dead, mode="omp")
+        assert counts[i] == len(eids)
+        assert_topk_equal(cos[i][: counts[i]], ids[i][: counts[i]], ecos, eids, corpus, qs[i], oracle)
+    assert ids[nq - 2][0] == n // 3 and ids[nq - 1][0] == (2 * n) // 3
+
+
+def test_mfma_batched_overflow_falls_back_to_exact(VS, oracle):
+    """Rows ordered so every later row beats all earlier ones for query 0: the candidate
+    buffer overflows, the search is rerun on the list-based kernel, and is still exact."""
+    n, dim, k, nq = 300_000, 384, 10, 8
+    q = synth_rows(5, 0, nq, dim)
+    u = synth_rows(6, 0, 1, dim)[0]
+    u = u - (u @ q[0]) / (q[0] @ q[0]) * q[0]
+    w = np.linspace(3.0, 0.5, n, dtype=np.float32)[:, None]
+    corpus = (q[0][None, :] + w * u[None, :]).astype(np.float32)  # cos(q0, row_i) increases with i
+    st = VS(None, dim)
+    st.insert_embeddings(corpus)
+    st.build_index()
+    cos, ids, counts = st.search_raw(q, k)
+    assert st.debug_counters() == (1, 1)
+    for i in range(nq):
+        ecos, eids = oracle.scan_topk(corpus, q[i], k, mode="omp")
+        assert_topk_equal(cos[i], ids[i], ecos, eids, corpus, q[i], oracle)
+
+
+def test_mfma_batched_10m_equals_single_query_scans(VS):
+    """BASELINE configs 4/5 shape on one GPU: 64 (and 100) batched queries over 10M rows must
+    equal 64 independent single-query scans (which are checked against the oracle above)."""
+    n, dim, k, seed = 10_000_000, 384, 10, 0xC0DE5EA
+    st = VS(None, dim, capacity=n)
+    st.insert_synthetic(n, seed, 0)
+    st.build_index()
+    for nq in (64, 100):
+        qs = synth_rows(seed + 5, 0, nq, dim)
+        cos, ids, counts = st.search_raw(qs, k)
+        assert (counts == k).all()
+        for i in list(range(0, nq, 9)) + [nq - 1]:
+            c1, i1, _ = st.search_raw(qs[i], k)
+            assert ids[i].tolist() == i1[0].tolist()
+            np.testing.assert_allclose(cos[i], c1[0], atol=COS_TOL)
+    b, f = st.debug_counters()
+    assert b == 2 and f == 0
