@@ -1,0 +1,230 @@
+// codesearch_gpu.hpp — header-only C++ mirror of the reference's VectorStore / FastEmbedder
+// over the C ABI (include/codesearch_gpu.h), for compiled callers.  Same method names,
+// argument meaning and error texts as /root/reference/src/vectordb/store.rs:94-750 and
+// src/embed/embedder.rs:201-322; `anyhow::Result<T>` becomes a thrown cs::Error carrying
+// the cs_status and the reference-worded message.
+#pragma once
+
+#include <cstdint>
+#include <cstdlib>
+#include <map>
+#include <optional>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/codesearch_gpu.h"
+
+namespace cs {
+
+struct Error : std::runtime_error {
+    int32_t code;
+    Error(int32_t c, const std::string& m) : std::runtime_error(m), code(c) {}
+};
+
+inline void check(int32_t status) {
+    if (status != CS_OK) throw Error(status, cs_last_error());
+}
+
+// src/chunker/mod.rs:22-62 (fields that cross into the hot path / its metadata)
+struct Chunk {
+    std::string content;
+    size_t start_line = 0, end_line = 0;
+    std::string kind;  // ChunkKind Debug name
+    std::string path;
+    std::vector<std::string> context;
+    std::optional<std::string> signature, docstring;
+    std::string hash;
+    std::optional<std::string> context_prev, context_next;
+};
+
+// src/embed/batch.rs:47-57
+struct EmbeddedChunk {
+    Chunk chunk;
+    std::vector<float> embedding;
+};
+
+// store.rs:19-85 (searchable_text omitted: FTS is out of scope)
+struct ChunkMetadata {
+    std::string content, path;
+    size_t start_line = 0, end_line = 0;
+    std::string kind;
+    std::optional<std::string> signature, docstring, context;
+    std::string hash;
+    std::optional<std::string> context_prev, context_next;
+
+    static ChunkMetadata from_embedded_chunk(const EmbeddedChunk& ec) {
+        ChunkMetadata m;
+        const Chunk& c = ec.chunk;
+        m.content = c.content; m.path = c.path; m.start_line = c.start_line; m.end_line = c.end_line;
+        m.kind = c.kind; m.signature = c.signature; m.docstring = c.docstring; m.hash = c.hash;
+        m.context_prev = c.context_prev; m.context_next = c.context_next;
+        if (!c.context.empty()) {
+            std::string j;
+            for (size_t i = 0; i < c.context.size(); ++i) j += (i ? " > " : "") + c.context[i];
+            m.context = j;
+        }
+        return m;
+    }
+};
+
+// store.rs:753-772
+struct SearchResult {
+    uint32_t id = 0;
+    ChunkMetadata meta;
+    float distance = 0.f;  // arroy Cosine: (1 - cos) / 2
+    float score = 0.f;     // 1 - distance (store.rs:478)
+};
+
+// store.rs:784-792
+struct StoreStats {
+    size_t total_chunks = 0, total_files = 0;
+    bool indexed = false;
+    size_t dimensions = 0;
+    uint32_t max_chunk_id = 0;
+};
+
+class VectorStore {
+  public:
+    // VectorStore::new(db_path, dimensions) — store.rs:110-176 (db_path unused: nothing persists)
+    VectorStore(const std::string& /*db_path*/, size_t dimensions, int device = 0, uint64_t capacity = 0,
+                uint32_t id_base = 0)
+        : dimensions_(dimensions) {
+        check(cs_index_create((uint32_t)dimensions, capacity, device, id_base, &h_));
+    }
+    ~VectorStore() { cs_index_destroy(h_); }
+    VectorStore(const VectorStore&) = delete;
+    VectorStore& operator=(const VectorStore&) = delete;
+
+    // store.rs:618-686
+    std::vector<uint32_t> insert_chunks_with_ids(const std::vector<EmbeddedChunk>& chunks) {
+        if (chunks.empty()) return {};
+        std::vector<float> rows;
+        rows.reserve(chunks.size() * dimensions_);
+        for (const auto& c : chunks) {
+            if (c.embedding.size() != dimensions_)  // store.rs:666-672
+                throw Error(CS_ERR_DIM_MISMATCH, "Embedding dimension mismatch: expected " +
+                                                     std::to_string(dimensions_) + ", got " +
+                                                     std::to_string(c.embedding.size()));
+            rows.insert(rows.end(), c.embedding.begin(), c.embedding.end());
+        }
+        std::vector<uint32_t> ids(chunks.size());
+        check(cs_index_add(h_, rows.data(), chunks.size(), (uint32_t)dimensions_, ids.data()));
+        for (size_t i = 0; i < chunks.size(); ++i) meta_[ids[i]] = ChunkMetadata::from_embedded_chunk(chunks[i]);
+        return ids;
+    }
+    // store.rs:334-379
+    size_t insert_chunks(const std::vector<EmbeddedChunk>& chunks) { return insert_chunks_with_ids(chunks).size(); }
+    // store.rs:386-430
+    void build_index() { check(cs_index_build(h_)); }
+    // store.rs:548-610
+    size_t delete_chunks(const std::vector<uint32_t>& ids) {
+        uint64_t removed = 0;
+        check(cs_index_remove(h_, ids.data(), ids.size(), &removed));
+        for (uint32_t id : ids) meta_.erase(id);
+        return (size_t)removed;
+    }
+    // store.rs:690-707
+    void clear() { check(cs_index_clear(h_)); meta_.clear(); }
+    // store.rs:745
+    bool is_indexed() const { return cs_index_is_built(h_) != 0; }
+
+    // store.rs:431-486
+    std::vector<SearchResult> search(const std::vector<float>& query_embedding, size_t limit) const {
+        auto all = search_batch({query_embedding}, limit);
+        return all.empty() ? std::vector<SearchResult>{} : all[0];
+    }
+    // all query variants in one call (src/search/mod.rs:508-511)
+    std::vector<std::vector<SearchResult>> search_batch(const std::vector<std::vector<float>>& queries,
+                                                        size_t limit) const {
+        const size_t nq = queries.size();
+        if (nq == 0) return {};
+        const size_t qdim = queries[0].size();
+        std::vector<float> q;
+        for (const auto& v : queries) {
+            if (v.size() != qdim) throw Error(CS_ERR_BAD_ARG, "queries of unequal length");
+            q.insert(q.end(), v.begin(), v.end());
+        }
+        std::vector<float> cos(nq * limit);
+        std::vector<uint32_t> ids(nq * limit), counts(nq);
+        check(cs_index_search(h_, q.data(), (uint32_t)nq, (uint32_t)qdim, (uint32_t)limit, cos.data(), ids.data(),
+                              counts.data()));
+        std::vector<std::vector<SearchResult>> out(nq);
+        for (size_t i = 0; i < nq; ++i)
+            for (uint32_t j = 0; j < counts[i]; ++j) {
+                auto it = meta_.find(ids[i * limit + j]);
+                if (it == meta_.end()) continue;  // store.rs:465
+                SearchResult r;
+                r.id = ids[i * limit + j];
+                r.meta = it->second;
+                r.distance = cs_cos_to_distance(cos[i * limit + j]);
+                r.score = 1.0f - r.distance;
+                out[i].push_back(std::move(r));
+            }
+        return out;
+    }
+    std::optional<ChunkMetadata> get_chunk(uint32_t id) const {  // store.rs:709-713
+        auto it = meta_.find(id);
+        return it == meta_.end() ? std::nullopt : std::optional<ChunkMetadata>(it->second);
+    }
+    std::map<std::string, std::vector<uint32_t>> get_chunks_by_file() const {  // store.rs:529-543
+        std::map<std::string, std::vector<uint32_t>> m;
+        for (const auto& kv : meta_) m[kv.second.path].push_back(kv.first);
+        return m;
+    }
+    StoreStats stats() const {  // store.rs:501-523
+        StoreStats s;
+        s.total_chunks = meta_.size();
+        s.total_files = get_chunks_by_file().size();
+        s.indexed = is_indexed();
+        s.dimensions = dimensions_;
+        s.max_chunk_id = meta_.empty() ? 0 : meta_.rbegin()->first;
+        return s;
+    }
+    size_t dimensions() const { return dimensions_; }
+    cs_index* handle() const { return h_; }
+
+  private:
+    cs_index* h_ = nullptr;
+    size_t dimensions_;
+    std::map<uint32_t, ChunkMetadata> meta_;
+};
+
+// FastEmbedder from token ids (tokenisation stays with the caller).
+class FastEmbedder {
+  public:
+    // with_cache_dir — embedder.rs:218-245; params == nullptr => synthetic weights from seed
+    FastEmbedder(const cs_bert_config& cfg, const float* params, uint64_t seed = 0, int device = 0) {
+        check(cs_embedder_create(&cfg, params, seed, device, &h_));
+    }
+    ~FastEmbedder() { cs_embedder_destroy(h_); }
+    FastEmbedder(const FastEmbedder&) = delete;
+    FastEmbedder& operator=(const FastEmbedder&) = delete;
+
+    // embed_batch — embedder.rs:249-263 (batch 0 = CODESEARCH_BATCH_SIZE or 256/128/64)
+    std::vector<std::vector<float>> embed_batch(const std::vector<int32_t>& ids, const std::vector<int32_t>& mask,
+                                                size_t n, size_t seq_len,
+                                                const volatile int32_t* shutdown = nullptr) {
+        return embed_batch_chunked(ids, mask, n, seq_len, 0, shutdown);
+    }
+    // embed_batch_chunked — embedder.rs:266-295
+    std::vector<std::vector<float>> embed_batch_chunked(const std::vector<int32_t>& ids,
+                                                        const std::vector<int32_t>& mask, size_t n,
+                                                        size_t seq_len, size_t batch_size,
+                                                        const volatile int32_t* shutdown = nullptr) {
+        const size_t d = dimensions();
+        std::vector<float> flat(n * d);
+        check(cs_embedder_embed_ids(h_, ids.data(), mask.data(), n, (uint32_t)seq_len, (uint32_t)batch_size,
+                                    flat.data(), shutdown));
+        std::vector<std::vector<float>> out(n);
+        for (size_t i = 0; i < n; ++i) out[i].assign(flat.begin() + i * d, flat.begin() + (i + 1) * d);
+        return out;
+    }
+    size_t dimensions() const { return cs_embedder_dim(h_); }  // embedder.rs:307
+    cs_embedder* handle() const { return h_; }
+
+  private:
+    cs_embedder* h_ = nullptr;
+};
+
+}  // namespace cs
