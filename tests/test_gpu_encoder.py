@@ -160,3 +160,35 @@ def test_config3_shape_b256_l256_property(FE, oracle):
     np.testing.assert_allclose(sub, got[rows], atol=2e-6)
     ref = oracle.bert_forward(cfg, oracle.bert_synth_params(cfg, 202), ids[rows], mask[rows])["pooled"]
     np.testing.assert_allclose(got[rows], ref, atol=TOL_ORACLE)
+
+
+def test_end_to_end_index_then_search_vs_oracle_pipeline(FE, oracle):
+    """BASELINE configs[3] at reduced size: chunks embedded on the GPU, appended to the
+    device-resident matrix without leaving HBM, batched queries, top-10 — against the same
+    pipeline built from the two oracles (encoder oracle -> scan oracle)."""
+    from codesearch_amd import VectorStore
+    from codesearch_amd.pipeline import index_token_chunks, search_token_queries
+
+    cfg = BertConfig(vocab_size=2048, layers=2, pooling=POOL_CLS)
+    n, L, nq, k = 1500, 32, 7, 10
+    ids, mask = synth_token_batch(cfg, 4321, n, L, True)
+    targets = [(i * 211) % n for i in range(nq)]
+    q_ids, q_mask = ids[targets].copy(), mask[targets].copy()
+    q_ids[:, 3] = (q_ids[:, 3] + 1) % cfg.vocab_size
+    emb = FE(cfg, seed=17)
+    store = VectorStore(None, cfg.hidden)
+    index_token_chunks(emb, store, ids, mask, batch_size=256)
+    assert store.is_indexed() and len(store) == n
+    cos, rid, counts, _ = search_token_queries(emb, store, q_ids, q_mask, k)
+    params = synth_params(cfg, 17)
+    corpus = oracle.bert_forward(cfg, params, ids, mask)["pooled"]
+    np.testing.assert_allclose(store.read_rows(0, n), corpus, atol=TOL_ORACLE)
+    qv = oracle.bert_forward(cfg, params, q_ids, q_mask)["pooled"]
+    for i in range(nq):
+        ecos, eids = oracle.scan_topk(corpus, qv[i], k, mode="omp")
+        assert counts[i] == k
+        np.testing.assert_allclose(cos[i], ecos, atol=1e-4)  # north_star tolerance on scores
+        if rid[i].tolist() != eids.tolist():  # ids may differ only where embeddings tie within tolerance
+            for a, b in zip(rid[i], eids):
+                if a != b:
+                    assert abs(float(corpus[a] @ qv[i]) - float(corpus[b] @ qv[i])) < 5e-5
