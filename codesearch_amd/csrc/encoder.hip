@@ -16,6 +16,8 @@
 // (cdna_hip_programming.md §3), which keeps the 1e-4 embedding tolerance with margin.
 #include "encoder.hpp"
 
+#include <cstdlib>
+
 namespace cs {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -103,6 +105,52 @@ __device__ __forceinline__ float gelu_erf(float v) {
     return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
 }
 
+// Epilogue of both GEMM kernels.  C/D map: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+// Full tiles take a branch-free path: residuals are loaded 16 at a time before use (a
+// per-element `if (row < M)` makes hipcc wait on every load separately).
+template <int EPI>
+__device__ __forceinline__ void gemm_epilogue(const f32x16 (&acc)[2][2], const float* __restrict__ bias,
+                                              const float* __restrict__ resid, float* __restrict__ C,
+                                              uint32_t M, uint32_t N, uint32_t m0, uint32_t n0, int wr,
+                                              int wc, int l31, int h) {
+    const bool full = (m0 + GBM) <= M;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const uint32_t col = n0 + wc * 64 + j * 32 + l31;
+        const float bv = bias[col];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const uint32_t rbase = m0 + wr * 64 + i * 32 + 4 * h;
+            if (full) {
+                float rs[16];
+                if (EPI == EPI_RESID) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        rs[r] = resid[(size_t)(rbase + (r & 3) + 8 * (r >> 2)) * N + col];
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float v = acc[i][j][r] + bv;
+                    if (EPI == EPI_GELU) v = gelu_erf(v);
+                    if (EPI == EPI_RESID) v = v + rs[r];
+                    C[(size_t)(rbase + (r & 3) + 8 * (r >> 2)) * N + col] = v;
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const uint32_t row = rbase + (r & 3) + 8 * (r >> 2);
+                    if (row < M) {
+                        float v = acc[i][j][r] + bv;
+                        if (EPI == EPI_GELU) v = gelu_erf(v);
+                        if (EPI == EPI_RESID) v = v + resid[(size_t)row * N + col];
+                        C[(size_t)row * N + col] = v;
+                    }
+                }
+            }
+        }
+    }
+}
+
 template <int EPI>
 __global__ void __launch_bounds__(256, 2)
 gemm_f32_kernel(const float* __restrict__ A, const float* __restrict__ W,
@@ -131,9 +179,9 @@ gemm_f32_kernel(const float* __restrict__ A, const float* __restrict__ W,
         for (int i = 0; i < 4; ++i) {
             const int idx = tid + 256 * i;
             const int row = idx >> 3, c4 = idx & 7;
-            const uint32_t m = m0 + row;
-            ga[i] = (m < M) ? *reinterpret_cast<const f32x4*>(A + (size_t)m * K + k0 + c4 * 4)
-                            : f32x4{0.f, 0.f, 0.f, 0.f};
+            // rows past M re-read row M-1: they only feed output rows that are never stored
+            const uint32_t m = (m0 + row < M) ? m0 + row : M - 1;
+            ga[i] = *reinterpret_cast<const f32x4*>(A + (size_t)m * K + k0 + c4 * 4);
             gw[i] = *reinterpret_cast<const f32x4*>(W + (size_t)(n0 + row) * K + k0 + c4 * 4);
         }
     };
@@ -177,25 +225,108 @@ gemm_f32_kernel(const float* __restrict__ A, const float* __restrict__ W,
         }
     }
 
-    // epilogue: C/D map col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    gemm_epilogue<EPI>(acc, bias, resid, C, M, N, m0, n0, wr, wc, l31, h);
+}
+
+// Software-pipelined variant: two LDS stage buffers, ONE barrier per K-step, and the fragments
+// of the next 8-k chunk are read from LDS while the current chunk's 16 MFMAs run, so a wave
+// has no MFMA-free window between stages (blocks on a CU run in lock-step, so such windows
+// coincide and idle the matrix pipe: 29 % on the plain kernel per SQ_VALU_MFMA_BUSY_CYCLES).
+// Stage s+1 goes global -> registers during stage s-1.. s, is written to the other buffer in
+// the middle of stage s, and the barrier sits before the first read of that buffer.
+template <int EPI>
+__global__ void __launch_bounds__(256, 2)
+gemm_f32_pipe_kernel(const float* __restrict__ A, const float* __restrict__ W,
+                     const float* __restrict__ bias, const float* __restrict__ resid,
+                     float* __restrict__ C, uint32_t M, uint32_t N, uint32_t K) {
+    extern __shared__ __attribute__((aligned(16))) float plds[];  // [2][A 128x36 | W 128x36]
+    constexpr int STAGE = 2 * GBM * GLS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int l31 = lane & 31, h = lane >> 5;
+    const uint32_t m0 = blockIdx.y * GBM, n0 = blockIdx.x * GBN;
+
+    f32x16 acc[2][2];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const uint32_t col = n0 + wc * 64 + j * 32 + l31;
-        const float bv = bias[col];
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const uint32_t row = m0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (row < M) {
-                    float v = acc[i][j][r] + bv;
-                    if (EPI == EPI_GELU) v = gelu_erf(v);
-                    if (EPI == EPI_RESID) v = v + resid[(size_t)row * N + col];
-                    C[(size_t)row * N + col] = v;
-                }
-            }
-        }
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    f32x4 ga[4], gw[4];
+    const float* asrc[4];
+    const float* wsrc[4];
+    int soff[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int idx = tid + 256 * i;
+        const int row = idx >> 3, c4 = idx & 7;
+        // rows past M re-read row M-1: they only feed output rows that are never stored
+        const uint32_t m = (m0 + row < M) ? m0 + row : M - 1;
+        asrc[i] = A + (size_t)m * K + c4 * 4;
+        wsrc[i] = W + (size_t)(n0 + row) * K + c4 * 4;
+        soff[i] = row * GLS + c4 * 4;
     }
+    auto load_stage = [&](uint32_t k0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            ga[i] = *reinterpret_cast<const f32x4*>(asrc[i] + k0);
+            gw[i] = *reinterpret_cast<const f32x4*>(wsrc[i] + k0);
+        }
+    };
+    auto store_stage = [&](float* buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *reinterpret_cast<f32x4*>(buf + soff[i]) = ga[i];
+            *reinterpret_cast<f32x4*>(buf + GBM * GLS + soff[i]) = gw[i];
+        }
+    };
+    const int aoff = (wr * 64 + l31) * GLS + 16 * h;
+    const int boff = GBM * GLS + (wc * 64 + l31) * GLS + 16 * h;
+    auto frags = [&](const float* buf, int c, f32x4 (&a)[2], f32x4 (&b)[2]) {
+        a[0] = *reinterpret_cast<const f32x4*>(buf + aoff + 4 * c);
+        a[1] = *reinterpret_cast<const f32x4*>(buf + aoff + 32 * GLS + 4 * c);
+        b[0] = *reinterpret_cast<const f32x4*>(buf + boff + 4 * c);
+        b[1] = *reinterpret_cast<const f32x4*>(buf + boff + 32 * GLS + 4 * c);
+    };
+    auto mfma_chunk = [&](const f32x4 (&a)[2], const f32x4 (&b)[2]) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
+    };
+
+    const uint32_t nstages = K / GBK;
+    load_stage(0);
+    store_stage(plds);
+    __syncthreads();
+    if (nstages > 1) load_stage(GBK);
+    f32x4 fa0[2], fb0[2], fa1[2], fb1[2];
+    frags(plds, 0, fa0, fb0);
+    for (uint32_t s = 0; s < nstages; ++s) {
+        float* cur = plds + (s & 1) * STAGE;
+        float* nxt = plds + ((s + 1) & 1) * STAGE;
+        const bool more = s + 1 < nstages;
+        frags(cur, 1, fa1, fb1);
+        mfma_chunk(fa0, fb0);
+        frags(cur, 2, fa0, fb0);
+        mfma_chunk(fa1, fb1);
+        if (more) {
+            store_stage(nxt);                              // stage s+1 -> the other buffer
+            if (s + 2 < nstages) load_stage((s + 2) * GBK);  // stage s+2 -> registers
+        }
+        frags(cur, 3, fa1, fb1);
+        mfma_chunk(fa0, fb0);
+        __syncthreads();                                   // nxt complete; cur fully consumed
+        if (more) frags(nxt, 0, fa0, fb0);
+        mfma_chunk(fa1, fb1);
+    }
+
+    gemm_epilogue<EPI>(acc, bias, resid, C, M, N, m0, n0, wr, wc, l31, h);
 }
 
 // ---- E3: attention, head_dim 32 ---------------------------------------------------------------
@@ -384,13 +515,36 @@ int32_t launch_row_kernel(int which, const EncoderLaunch& a, uint32_t H, hipStre
     return CS_OK;
 }
 
+static int gemm_variant() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = std::getenv("CS_GEMM_VARIANT");  // 0 = plain, 1 = pipelined (default)
+        v = e ? std::atoi(e) : 1;
+    }
+    return v;
+}
+
 int32_t launch_gemm(int epi, const float* A, const float* W, const float* bias, const float* resid,
                     float* C, uint32_t M, uint32_t N, uint32_t K, hipStream_t s) {
     if (N % GBN || K % GBK) return fail(CS_ERR_UNSUPPORTED, "GEMM N=%u K=%u must be multiples of 128/32", N, K);
     dim3 grid(N / GBN, (M + GBM - 1) / GBM);
-    if (epi == EPI_BIAS) hipLaunchKernelGGL(gemm_f32_kernel<EPI_BIAS>, grid, dim3(256), 0, s, A, W, bias, resid, C, M, N, K);
-    else if (epi == EPI_GELU) hipLaunchKernelGGL(gemm_f32_kernel<EPI_GELU>, grid, dim3(256), 0, s, A, W, bias, resid, C, M, N, K);
-    else hipLaunchKernelGGL(gemm_f32_kernel<EPI_RESID>, grid, dim3(256), 0, s, A, W, bias, resid, C, M, N, K);
+    if (gemm_variant() == 0) {
+        if (epi == EPI_BIAS) hipLaunchKernelGGL(gemm_f32_kernel<EPI_BIAS>, grid, dim3(256), 0, s, A, W, bias, resid, C, M, N, K);
+        else if (epi == EPI_GELU) hipLaunchKernelGGL(gemm_f32_kernel<EPI_GELU>, grid, dim3(256), 0, s, A, W, bias, resid, C, M, N, K);
+        else hipLaunchKernelGGL(gemm_f32_kernel<EPI_RESID>, grid, dim3(256), 0, s, A, W, bias, resid, C, M, N, K);
+    } else {
+        constexpr size_t lds = 2 * 2 * GBM * GLS * sizeof(float);  // 73,728 B
+        static bool attr_set = false;
+        if (!attr_set) {
+            CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_pipe_kernel<EPI_BIAS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_pipe_kernel<EPI_GELU>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_pipe_kernel<EPI_RESID>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr_set = true;
+        }
+        if (epi == EPI_BIAS) hipLaunchKernelGGL(gemm_f32_pipe_kernel<EPI_BIAS>, grid, dim3(256), lds, s, A, W, bias, resid, C, M, N, K);
+        else if (epi == EPI_GELU) hipLaunchKernelGGL(gemm_f32_pipe_kernel<EPI_GELU>, grid, dim3(256), lds, s, A, W, bias, resid, C, M, N, K);
+        else hipLaunchKernelGGL(gemm_f32_pipe_kernel<EPI_RESID>, grid, dim3(256), lds, s, A, W, bias, resid, C, M, N, K);
+    }
     CS_HIP(hipGetLastError());
     return CS_OK;
 }
