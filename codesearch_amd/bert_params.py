@@ -130,3 +130,33 @@ def synth_token_batch(cfg: BertConfig, seed: int, B: int, L: int, ragged: bool):
         ids[b, lens[b] - 1] = 102 % cfg.vocab_size
     ids = ids * mask
     return ids, mask
+
+
+# ---- real checkpoints ----------------------------------------------------------
+
+def config_from_hf(cfg_json: dict, pooling: int = POOL_CLS) -> BertConfig:
+    """HF config.json -> BertConfig (BERT family only)."""
+    if cfg_json.get("model_type", "bert") != "bert":
+        raise ValueError(f"model_type {cfg_json.get('model_type')!r} is not a BERT encoder")
+    if cfg_json.get("hidden_act", "gelu") != "gelu":
+        raise ValueError("only erf-GELU encoders are supported")
+    return BertConfig(vocab_size=cfg_json["vocab_size"], hidden=cfg_json["hidden_size"],
+                      layers=cfg_json["num_hidden_layers"], heads=cfg_json["num_attention_heads"],
+                      intermediate=cfg_json["intermediate_size"],
+                      max_position=cfg_json["max_position_embeddings"],
+                      type_vocab_size=cfg_json.get("type_vocab_size", 2),
+                      layer_norm_eps=cfg_json.get("layer_norm_eps", 1e-12), pooling=pooling)
+
+
+def load_checkpoint(path: str, cfg: BertConfig) -> np.ndarray:
+    """Read a `.safetensors` (or `.npz`) BertModel checkpoint into the flat block.  Tensor
+    names may carry a `bert.` prefix; pooler / position_ids / extra heads are ignored."""
+    if path.endswith(".safetensors"):
+        from safetensors.numpy import load_file
+
+        sd = load_file(path)
+    elif path.endswith(".npz"):
+        sd = dict(np.load(path))
+    else:
+        raise ValueError("expected a .safetensors or .npz checkpoint")
+    return from_state_dict(cfg, sd)

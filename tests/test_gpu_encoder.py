@@ -192,3 +192,30 @@ def test_end_to_end_index_then_search_vs_oracle_pipeline(FE, oracle):
             for a, b in zip(rid[i], eids):
                 if a != b:
                     assert abs(float(corpus[a] @ qv[i]) - float(corpus[b] @ qv[i])) < 5e-5
+
+
+def test_text_entry_points_with_tokenizer(FE, oracle):
+    """embed_batch / embed_one (embedder.rs:249-304) from strings: WordPiece on the host,
+    batch-longest padding, encoder on the GPU — against tokenizer + encoder oracle."""
+    import json
+
+    from codesearch_amd.batch import BatchEmbedder, prepare_text
+    from codesearch_amd.tokenizer import BertWordPieceTokenizer
+    from codesearch_amd.vector_store import Chunk
+
+    G = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "tokenizer_golden.json")))
+    tok = BertWordPieceTokenizer(G["vocab"])
+    cfg = BertConfig(vocab_size=len(G["vocab"]), layers=2, pooling=POOL_MEAN)
+    emb = FE(cfg, seed=23, tokenizer=tok)
+    texts = ["fn main() { println!(\"hello world\"); }", "def calculate(a, b): return a", "struct"]
+    got = emb.embed_batch(texts)
+    ids, mask = tok.encode_batch(texts)
+    ref = oracle.bert_forward(cfg, synth_params(cfg, 23), ids, mask)["pooled"]
+    np.testing.assert_allclose(np.stack(got), ref, atol=TOL_ORACLE)
+    one = emb.embed_one(texts[2])
+    np.testing.assert_allclose(one, ref[2], atol=TOL_ORACLE)  # padding-invariant
+    chunks = [Chunk(t, 0, 1, "Function", "a.rs", signature="fn main()") for t in texts]
+    ecs = BatchEmbedder(emb).embed_chunks(chunks)
+    ids2, mask2 = tok.encode_batch([prepare_text(c) for c in chunks])
+    ref2 = oracle.bert_forward(cfg, synth_params(cfg, 23), ids2, mask2)["pooled"]
+    np.testing.assert_allclose(np.stack([e.embedding for e in ecs]), ref2, atol=TOL_ORACLE)

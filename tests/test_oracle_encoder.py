@@ -76,3 +76,27 @@ def test_padding_does_not_leak(oracle):
     n1 = int(mask[1].sum())
     alone = oracle.bert_forward(cfg, params, ids[1:2, :n1], mask[1:2, :n1])["pooled"]
     np.testing.assert_allclose(full[1], alone[0], atol=1e-6)
+
+
+def test_checkpoint_loader_roundtrip(tmp_path):
+    """Real-weight path: a safetensors BertModel checkpoint (with `bert.` prefix and the extra
+    tensors HF exports) loads into the same flat block."""
+    import json
+
+    from safetensors.numpy import save_file
+
+    from codesearch_amd.bert_params import config_from_hf, load_checkpoint
+
+    hf = {"model_type": "bert", "vocab_size": 300, "hidden_size": 384, "num_hidden_layers": 2,
+          "num_attention_heads": 12, "intermediate_size": 1536, "max_position_embeddings": 64,
+          "type_vocab_size": 2, "layer_norm_eps": 1e-12, "hidden_act": "gelu"}
+    cfg = config_from_hf(json.loads(json.dumps(hf)))
+    flat = synth_params(cfg, 11)
+    sd = {"bert." + k: np.ascontiguousarray(v) for k, v in to_state_dict(cfg, flat).items()}
+    sd["bert.pooler.dense.weight"] = np.zeros((384, 384), np.float32)
+    sd["bert.embeddings.position_ids"] = np.arange(64, dtype=np.int64)[None]
+    path = str(tmp_path / "model.safetensors")
+    save_file(sd, path)
+    assert np.array_equal(load_checkpoint(path, cfg), flat)
+    with pytest.raises(ValueError):
+        config_from_hf({**hf, "model_type": "nomic_bert"})
