@@ -106,16 +106,19 @@ def main():
         args.gpus = world
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    # CS_BENCH_FORCE_DIST=1 (under torch.distributed.run) exercises the RCCL exchange at world 1
+    force_dist = os.environ.get("CS_BENCH_FORCE_DIST") == "1" and "MASTER_ADDR" in os.environ
+    if world > 1 or force_dist:
         import torch.distributed as dist
 
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device(f"cuda:{local_rank}"))
 
     def barrier():
         if dist is not None:
             dist.barrier()
 
-    shard = ShardedVectorStore(args.dim, args.rows, rank, world, local_rank)
+    shard = ShardedVectorStore(args.dim, args.rows, rank, world, local_rank, force_exchange=force_dist)
     shard.fill_synthetic(SEED)
     q_host = synth_rows(SEED + 1, 0, args.nq, args.dim)  # same queries on every rank
     d_q = torch.from_numpy(q_host).to(f"cuda:{local_rank}")

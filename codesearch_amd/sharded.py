@@ -52,7 +52,8 @@ class ShardedVectorStore:
     """One rank's shard plus the exchange.  Device buffers are torch tensors (plumbing);
     kernels are libcsgpu's, launched on torch's current stream so RCCL orders after them."""
 
-    def __init__(self, dim: int, rows_per_shard: int, rank: int, world: int, device: int, group=None):
+    def __init__(self, dim: int, rows_per_shard: int, rank: int, world: int, device: int, group=None,
+                 force_exchange: bool = False):
         import torch
 
         from . import _lib
@@ -64,6 +65,7 @@ class ShardedVectorStore:
         self.dim, self.rank, self.world, self.device = dim, rank, world, device
         self.rows_per_shard = rows_per_shard
         self.group = group
+        self.force_exchange = force_exchange  # run the all-gather + merge even when world == 1
         self.store = VectorStore(None, dim, device=device, capacity=rows_per_shard,
                                  id_base=rank * rows_per_shard)
         self._bufs = {}
@@ -93,7 +95,7 @@ class ShardedVectorStore:
         b = self._buffers(nq, k)
         stream = C.c_void_p(t.cuda.current_stream().cuda_stream)
         vp = lambda x: C.c_void_p(x.data_ptr())
-        if self.world == 1:
+        if self.world == 1 and not self.force_exchange:
             self._check(self._lib.cs_index_search_device(self.store.handle, vp(d_queries), nq, self.dim, k,
                                                          vp(b["keys"]), vp(b["cos"]), vp(b["ids"]),
                                                          vp(b["counts"]), stream))
