@@ -13,6 +13,7 @@ LIB_PATH = os.path.join(PKG_DIR, "libcsgpu.so")
 
 CS_OK, CS_ERR_BAD_ARG, CS_ERR_DIM_MISMATCH, CS_ERR_NOT_BUILT = 0, 1, 2, 3
 CS_ERR_CANCELLED, CS_ERR_OOM, CS_ERR_HIP, CS_ERR_UNSUPPORTED = 4, 5, 6, 7
+CS_GEMM_F32, CS_GEMM_SPLIT_F16 = 0, 1
 CS_MAX_K = 256
 CS_MAX_QUERIES = 4096
 
@@ -80,6 +81,10 @@ SIGNATURES = {
     "cs_embedder_embed_ids_device": (C.c_int32, [vp, i32p, i32p, C.c_uint64, C.c_uint32, C.c_uint32, vp, i32p]),
     "cs_embedder_last_hidden": (C.c_int32, [vp, f32p, C.c_uint64]),
     "cs_embedder_profile_read": (C.c_int32, [vp, f64p, u64p, C.c_int32]),
+    "cs_embedder_set_gemm_mode": (C.c_int32, [vp, C.c_int32]),
+    "cs_embedder_debug_counters": (C.c_int32, [vp, u64p, u64p, u64p]),
+    "cs_debug_gemm": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32, f32p, f32p, f32p, f32p, f32p,
+                                  C.c_uint32, C.c_uint32, C.c_uint32, u32p]),
 }
 
 _LIB = None

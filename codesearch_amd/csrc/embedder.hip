@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "encoder.hpp"
+#include "split_f16.hpp"
 
 using namespace cs;
 
@@ -18,14 +19,19 @@ struct cs_embedder {
     float* d_params = nullptr;
     float* d_wqkv = nullptr;  // [layers][3H][H]  (query | key | value rows)
     float* d_bqkv = nullptr;  // [layers][3H]
+    _Float16* d_wsplit = nullptr;  // per layer: wqkv | attention-out | ffn-up | ffn-down, split-f16 rows
+    uint32_t* d_flag = nullptr;    // split-f16 range flag
+    int gemm_mode = CS_GEMM_SPLIT_F16;
+    uint64_t split_forwards = 0, f32_forwards = 0, range_fallbacks = 0;
     hipStream_t stream = nullptr;
     size_t cap_tokens = 0, cap_seqs = 0;
     int32_t* d_ids = nullptr;
     int32_t* d_mask = nullptr;
     float* d_x = nullptr;       // [T, H]
+    float* d_xs = nullptr;      // [T, H/32, 64] f16: x in split form (same bytes as f32)
     float* d_qkv = nullptr;     // [T, 3H]
-    float* d_ctx = nullptr;     // [T, H]
-    float* d_mid = nullptr;     // [T, I]
+    float* d_ctx = nullptr;     // [T, H]   (f32, or split form: same bytes)
+    float* d_mid = nullptr;     // [T, I]   (f32, or split form: same bytes)
     float* d_pooled = nullptr;  // [B, H]
     uint32_t last_B = 0, last_L = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -39,12 +45,13 @@ void free_workspace(cs_embedder* h) {
     if (h->d_ids) (void)hipFree(h->d_ids);
     if (h->d_mask) (void)hipFree(h->d_mask);
     if (h->d_x) (void)hipFree(h->d_x);
+    if (h->d_xs) (void)hipFree(h->d_xs);
     if (h->d_qkv) (void)hipFree(h->d_qkv);
     if (h->d_ctx) (void)hipFree(h->d_ctx);
     if (h->d_mid) (void)hipFree(h->d_mid);
     if (h->d_pooled) (void)hipFree(h->d_pooled);
     h->d_ids = h->d_mask = nullptr;
-    h->d_x = h->d_qkv = h->d_ctx = h->d_mid = h->d_pooled = nullptr;
+    h->d_x = h->d_xs = h->d_qkv = h->d_ctx = h->d_mid = h->d_pooled = nullptr;
     h->cap_tokens = h->cap_seqs = 0;
 }
 
@@ -55,6 +62,7 @@ int32_t reserve(cs_embedder* h, size_t seqs, size_t tokens) {
     CS_HIP(hipMalloc(&h->d_ids, tokens * sizeof(int32_t)));
     CS_HIP(hipMalloc(&h->d_mask, tokens * sizeof(int32_t)));
     CS_HIP(hipMalloc(&h->d_x, tokens * H * sizeof(float)));
+    CS_HIP(hipMalloc(&h->d_xs, tokens * H * sizeof(float)));
     CS_HIP(hipMalloc(&h->d_qkv, tokens * 3 * H * sizeof(float)));
     CS_HIP(hipMalloc(&h->d_ctx, tokens * H * sizeof(float)));
     CS_HIP(hipMalloc(&h->d_mid, tokens * I * sizeof(float)));
@@ -64,34 +72,68 @@ int32_t reserve(cs_embedder* h, size_t seqs, size_t tokens) {
     return CS_OK;
 }
 
+// Offsets (in f16 elements) of one layer's split weights inside d_wsplit.
+struct SplitLayer { size_t qkv, ao, up, down, total; };
+SplitLayer split_layer(const cs_bert_config& c) {
+    const size_t H = c.hidden, I = c.intermediate;
+    SplitLayer o;
+    o.qkv = 0;
+    o.ao = o.qkv + 3 * H * H * 2;
+    o.up = o.ao + H * H * 2;
+    o.down = o.up + I * H * 2;
+    o.total = o.down + H * I * 2;
+    return o;
+}
+
 // One mini-batch already on the device (d_ids/d_mask) -> d_pooled [B, H].
-int32_t forward(cs_embedder* h, uint32_t B, uint32_t L) {
+int32_t forward(cs_embedder* h, uint32_t B, uint32_t L, int mode) {
     const cs_bert_config& c = h->cfg;
     const uint32_t H = c.hidden, I = c.intermediate, T = B * L;
     const float* P = h->d_params;
     hipStream_t s = h->stream;
+    const bool split = mode == CS_GEMM_SPLIT_F16;
     CS_HIP(hipEventRecord(h->ev0, s));
+    if (split) CS_HIP(hipMemsetAsync(h->d_flag, 0, sizeof(uint32_t), s));
     EncoderLaunch a;
     a.ids = h->d_ids; a.mask = h->d_mask;
     a.word = P + h->off.word; a.pos = P + h->off.pos; a.type0 = P + h->off.type;
     a.g = P + h->off.emb_ln_g; a.b = P + h->off.emb_ln_b;
     a.eps = c.layer_norm_eps; a.T = T; a.L = L; a.B = B; a.vocab = c.vocab_size;
     a.pooling = c.pooling; a.x = h->d_x; a.out = h->d_pooled;
+    a.xs = split ? h->d_xs : nullptr;
+    a.flag = h->d_flag;
+    _Float16* xs = reinterpret_cast<_Float16*>(h->d_xs);
+    _Float16* ctxs = reinterpret_cast<_Float16*>(h->d_ctx);
+    _Float16* mids = reinterpret_cast<_Float16*>(h->d_mid);
+    const SplitLayer sl = split_layer(c);
     CS_TRY(launch_row_kernel(0, a, H, s));  // E1
     for (uint32_t l = 0; l < c.layers; ++l) {
         cs_bert_layer_offsets lo;
         cs_bert_layer_layout(&c, &h->off, l, &lo);
-        const float* wqkv = h->d_wqkv + (size_t)l * 3 * H * H;
         const float* bqkv = h->d_bqkv + (size_t)l * 3 * H;
-        CS_TRY(launch_gemm(GEMM_BIAS, h->d_x, wqkv, bqkv, nullptr, h->d_qkv, T, 3 * H, H, s));        // E2
-        CS_TRY(launch_attention(h->d_qkv, h->d_mask, h->d_ctx, B, L, H, c.heads, s));                 // E3
-        CS_TRY(launch_gemm(GEMM_RESID, h->d_ctx, P + lo.ao_w, P + lo.ao_b, h->d_x, h->d_x, T, H, H, s)); // E4
-        a.g = P + lo.ao_ln_g; a.b = P + lo.ao_ln_b;
-        CS_TRY(launch_row_kernel(1, a, H, s));
-        CS_TRY(launch_gemm(GEMM_GELU, h->d_x, P + lo.up_w, P + lo.up_b, nullptr, h->d_mid, T, I, H, s)); // E5
-        CS_TRY(launch_gemm(GEMM_RESID, h->d_mid, P + lo.down_w, P + lo.down_b, h->d_x, h->d_x, T, H, I, s)); // E6
-        a.g = P + lo.out_ln_g; a.b = P + lo.out_ln_b;
-        CS_TRY(launch_row_kernel(1, a, H, s));
+        if (split) {
+            const _Float16* ws = h->d_wsplit + (size_t)l * sl.total;
+            CS_TRY(launch_gemm_split(SH_OUT_F32, xs, ws + sl.qkv, bqkv, nullptr, h->d_qkv, nullptr, T, 3 * H, H, h->d_flag, s));   // E2
+            CS_TRY(launch_attention_split(h->d_qkv, h->d_mask, ctxs, h->d_flag, B, L, H, c.heads, s));                            // E3
+            CS_TRY(launch_gemm_split(SH_OUT_F32_RESID, ctxs, ws + sl.ao, P + lo.ao_b, h->d_x, h->d_x, nullptr, T, H, H, h->d_flag, s));  // E4
+            a.g = P + lo.ao_ln_g; a.b = P + lo.ao_ln_b;
+            CS_TRY(launch_row_kernel(1, a, H, s));
+            CS_TRY(launch_gemm_split(SH_OUT_SPLIT_GELU, xs, ws + sl.up, P + lo.up_b, nullptr, nullptr, mids, T, I, H, h->d_flag, s));    // E5
+            CS_TRY(launch_gemm_split(SH_OUT_F32_RESID, mids, ws + sl.down, P + lo.down_b, h->d_x, h->d_x, nullptr, T, H, I, h->d_flag, s)); // E6
+            a.g = P + lo.out_ln_g; a.b = P + lo.out_ln_b;
+            CS_TRY(launch_row_kernel(1, a, H, s));
+        } else {
+            const float* wqkv = h->d_wqkv + (size_t)l * 3 * H * H;
+            CS_TRY(launch_gemm(GEMM_BIAS, h->d_x, wqkv, bqkv, nullptr, h->d_qkv, T, 3 * H, H, s));        // E2
+            CS_TRY(launch_attention(h->d_qkv, h->d_mask, h->d_ctx, B, L, H, c.heads, s));                 // E3
+            CS_TRY(launch_gemm(GEMM_RESID, h->d_ctx, P + lo.ao_w, P + lo.ao_b, h->d_x, h->d_x, T, H, H, s)); // E4
+            a.g = P + lo.ao_ln_g; a.b = P + lo.ao_ln_b;
+            CS_TRY(launch_row_kernel(1, a, H, s));
+            CS_TRY(launch_gemm(GEMM_GELU, h->d_x, P + lo.up_w, P + lo.up_b, nullptr, h->d_mid, T, I, H, s)); // E5
+            CS_TRY(launch_gemm(GEMM_RESID, h->d_mid, P + lo.down_w, P + lo.down_b, h->d_x, h->d_x, T, H, I, s)); // E6
+            a.g = P + lo.out_ln_g; a.b = P + lo.out_ln_b;
+            CS_TRY(launch_row_kernel(1, a, H, s));
+        }
     }
     CS_TRY(launch_row_kernel(2, a, H, s));  // E7 + E8
     CS_HIP(hipEventRecord(h->ev1, s));
@@ -139,7 +181,20 @@ int32_t embed_impl(cs_embedder* h, const int32_t* ids, const int32_t* mask, uint
         CS_HIP(hipMemcpyAsync(h->d_ids, bi, tok * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
         CS_HIP(hipMemcpyAsync(h->d_mask, mask + done * seq_len, tok * sizeof(int32_t),
                               hipMemcpyHostToDevice, h->stream));
-        CS_TRY(forward(h, B, seq_len));
+        int mode = h->gemm_mode;
+        CS_TRY(forward(h, B, seq_len, mode));
+        if (mode == CS_GEMM_SPLIT_F16) {
+            uint32_t flag = 0;
+            CS_HIP(hipMemcpyAsync(&flag, h->d_flag, sizeof(flag), hipMemcpyDeviceToHost, h->stream));
+            CS_HIP(hipStreamSynchronize(h->stream));
+            h->split_forwards += 1;
+            if (flag) {  // an activation left the f16 range: redo this mini-batch on the exact-f32 MFMA
+                h->range_fallbacks += 1;
+                mode = CS_GEMM_F32;
+                CS_TRY(forward(h, B, seq_len, mode));
+            }
+        }
+        if (mode == CS_GEMM_F32) h->f32_forwards += 1;
         CS_HIP(hipMemcpyAsync(out + done * H, h->d_pooled, (size_t)B * H * sizeof(float),
                               out_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, h->stream));
         CS_HIP(hipStreamSynchronize(h->stream));
@@ -226,6 +281,31 @@ int32_t cs_embedder_create(const cs_bert_config* cfg, const float* params, uint6
                 s = fail(CS_ERR_HIP, "QKV packing failed");
         }
     }
+    // split-f16 copies of the four dense weights of every layer (split_f16.hpp)
+    if (s == CS_OK) {
+        const SplitLayer sl = split_layer(*cfg);
+        const size_t I = cfg->intermediate;
+        if (hipMalloc(&h->d_wsplit, (size_t)cfg->layers * sl.total * sizeof(_Float16)) != hipSuccess ||
+            hipMalloc(&h->d_flag, sizeof(uint32_t)) != hipSuccess)
+            return cleanup(fail(CS_ERR_OOM, "hipMalloc(split weights) failed"));
+        if (hipMemsetAsync(h->d_flag, 0, sizeof(uint32_t), h->stream) != hipSuccess) s = fail(CS_ERR_HIP, "memset failed");
+        for (uint32_t l = 0; l < cfg->layers && s == CS_OK; ++l) {
+            cs_bert_layer_offsets lo;
+            cs_bert_layer_layout(cfg, &h->off, l, &lo);
+            _Float16* ws = h->d_wsplit + (size_t)l * sl.total;
+            s = launch_split_rows(h->d_wqkv + (size_t)l * 3 * H * H, ws + sl.qkv, 3 * H, (uint32_t)H, h->d_flag, h->stream);
+            if (s == CS_OK) s = launch_split_rows(h->d_params + lo.ao_w, ws + sl.ao, H, (uint32_t)H, h->d_flag, h->stream);
+            if (s == CS_OK) s = launch_split_rows(h->d_params + lo.up_w, ws + sl.up, I, (uint32_t)H, h->d_flag, h->stream);
+            if (s == CS_OK) s = launch_split_rows(h->d_params + lo.down_w, ws + sl.down, H, (uint32_t)I, h->d_flag, h->stream);
+        }
+        uint32_t wflag = 0;
+        if (s == CS_OK && (hipMemcpyAsync(&wflag, h->d_flag, sizeof(wflag), hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
+                           hipStreamSynchronize(h->stream) != hipSuccess))
+            s = fail(CS_ERR_HIP, "parameter setup failed");
+        if (const char* env = std::getenv("CS_ENCODER_GEMM"))
+            h->gemm_mode = (std::strcmp(env, "f32") == 0) ? CS_GEMM_F32 : CS_GEMM_SPLIT_F16;
+        if (wflag) h->gemm_mode = CS_GEMM_F32;  // a weight outside the f16 range: exact path only
+    }
     if (s == CS_OK && hipStreamSynchronize(h->stream) != hipSuccess) s = fail(CS_ERR_HIP, "parameter setup failed");
     if (s != CS_OK) return cleanup(s);
     *out = h;
@@ -240,6 +320,8 @@ void cs_embedder_destroy(cs_embedder* h) {
     if (h->d_params) (void)hipFree(h->d_params);
     if (h->d_wqkv) (void)hipFree(h->d_wqkv);
     if (h->d_bqkv) (void)hipFree(h->d_bqkv);
+    if (h->d_wsplit) (void)hipFree(h->d_wsplit);
+    if (h->d_flag) (void)hipFree(h->d_flag);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -276,6 +358,84 @@ int32_t cs_embedder_profile_read(cs_embedder* h, double* forward_ms, uint64_t* f
     if (forwards) *forwards = h->forwards;
     if (reset) { h->forward_ms = 0.0; h->forwards = 0; }
     return CS_OK;
+}
+
+int32_t cs_embedder_set_gemm_mode(cs_embedder* h, int32_t mode) {
+    if (!h) return fail(CS_ERR_BAD_ARG, "null embedder handle");
+    if (mode != CS_GEMM_F32 && mode != CS_GEMM_SPLIT_F16) return fail(CS_ERR_BAD_ARG, "unknown gemm mode %d", mode);
+    h->gemm_mode = mode;
+    return CS_OK;
+}
+
+int32_t cs_embedder_debug_counters(cs_embedder* h, uint64_t* split_forwards, uint64_t* f32_forwards,
+                                   uint64_t* range_fallbacks) {
+    if (!h) return fail(CS_ERR_BAD_ARG, "null embedder handle");
+    if (split_forwards) *split_forwards = h->split_forwards;
+    if (f32_forwards) *f32_forwards = h->f32_forwards;
+    if (range_fallbacks) *range_fallbacks = h->range_fallbacks;
+    return CS_OK;
+}
+
+int32_t cs_debug_gemm(int32_t device, int32_t mode, int32_t epilogue, const float* A, const float* W,
+                      const float* bias, const float* resid, float* C, uint32_t M, uint32_t N, uint32_t K,
+                      uint32_t* range_flag) {
+    if (!A || !W || !bias || !C || (epilogue == 2 && !resid)) return fail(CS_ERR_BAD_ARG, "null buffer");
+    if (epilogue < 0 || epilogue > 2 || (mode != CS_GEMM_F32 && mode != CS_GEMM_SPLIT_F16))
+        return fail(CS_ERR_BAD_ARG, "unknown epilogue/mode");
+    if (M == 0 || N % 128 || K % 32 || K == 0) return fail(CS_ERR_UNSUPPORTED, "cs_debug_gemm needs M > 0, N %% 128 == 0, K %% 32 == 0");
+    int ndev = 0;
+    CS_HIP(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) return fail(CS_ERR_HIP, "HIP device %d not available (%d visible)", device, ndev);
+    DeviceGuard g(device);
+    const size_t a_n = (size_t)M * K, w_n = (size_t)N * K, c_n = (size_t)M * N;
+    float *dA = nullptr, *dW = nullptr, *dB = nullptr, *dR = nullptr, *dC = nullptr;
+    _Float16 *sA = nullptr, *sW = nullptr, *sC = nullptr;
+    uint32_t* dF = nullptr;
+    int32_t st = CS_OK;
+    auto run = [&]() -> int32_t {
+        CS_HIP(hipMalloc(&dA, a_n * 4)); CS_HIP(hipMalloc(&dW, w_n * 4)); CS_HIP(hipMalloc(&dB, (size_t)N * 4));
+        CS_HIP(hipMalloc(&dC, c_n * 4)); CS_HIP(hipMalloc(&dF, 4));
+        CS_HIP(hipMemcpy(dA, A, a_n * 4, hipMemcpyHostToDevice));
+        CS_HIP(hipMemcpy(dW, W, w_n * 4, hipMemcpyHostToDevice));
+        CS_HIP(hipMemcpy(dB, bias, (size_t)N * 4, hipMemcpyHostToDevice));
+        CS_HIP(hipMemset(dF, 0, 4));
+        if (epilogue == 2) {
+            CS_HIP(hipMalloc(&dR, c_n * 4));
+            CS_HIP(hipMemcpy(dR, resid, c_n * 4, hipMemcpyHostToDevice));
+        }
+        if (mode == CS_GEMM_F32) {
+            CS_TRY(launch_gemm(epilogue, dA, dW, dB, dR, dC, M, N, K, nullptr));
+        } else {
+            CS_HIP(hipMalloc(&sA, a_n * 4)); CS_HIP(hipMalloc(&sW, w_n * 4));
+            CS_TRY(launch_split_rows(dA, sA, M, K, dF, nullptr));
+            CS_TRY(launch_split_rows(dW, sW, N, K, dF, nullptr));
+            if (epilogue == 1) {  // the GELU epilogue writes split form: read it back through hi + lo / 2048
+                CS_HIP(hipMalloc(&sC, c_n * 4));
+                CS_TRY(launch_gemm_split(SH_OUT_SPLIT_GELU, sA, sW, dB, nullptr, nullptr, sC, M, N, K, dF, nullptr));
+            } else {
+                CS_TRY(launch_gemm_split(epilogue == 2 ? SH_OUT_F32_RESID : SH_OUT_F32, sA, sW, dB, dR, dC, nullptr, M, N, K, dF, nullptr));
+            }
+        }
+        CS_HIP(hipDeviceSynchronize());
+        if (sC) {
+            std::vector<_Float16> hs(c_n * 2);
+            CS_HIP(hipMemcpy(hs.data(), sC, c_n * 4, hipMemcpyDeviceToHost));
+            const size_t nch = N / 32;
+            for (size_t m = 0; m < M; ++m)
+                for (size_t n = 0; n < N; ++n) {
+                    const _Float16* line = hs.data() + (m * nch + n / 32) * 64;
+                    C[m * N + n] = (float)line[n % 32] + (float)line[32 + n % 32] * (1.0f / 2048.0f);
+                }
+        } else {
+            CS_HIP(hipMemcpy(C, dC, c_n * 4, hipMemcpyDeviceToHost));
+        }
+        if (range_flag) CS_HIP(hipMemcpy(range_flag, dF, 4, hipMemcpyDeviceToHost));
+        return CS_OK;
+    };
+    st = run();
+    for (void* p : {(void*)dA, (void*)dW, (void*)dB, (void*)dR, (void*)dC, (void*)sA, (void*)sW, (void*)sC, (void*)dF})
+        if (p) (void)hipFree(p);
+    return st;
 }
 
 }  // extern "C"

@@ -15,6 +15,7 @@
 // All arithmetic is fp32: the f32-input MFMA is bit-for-bit an fmaf chain
 // (cdna_hip_programming.md §3), which keeps the 1e-4 embedding tolerance with margin.
 #include "encoder.hpp"
+#include "split_f16.hpp"
 
 #include <cstdlib>
 
@@ -32,11 +33,15 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 
 // ---- E1: embeddings + LayerNorm; E4/E6: LayerNorm -------------------------------------------
-// One wave per token row; NPL = H / 64 values per lane (lane + 64*i).
+// One wave per token row; NPL = H / 64 values per lane, held as pairs of consecutive columns
+// (v[2p], v[2p+1] = columns 2*lane + 128*p + {0,1}) so the row can also be written in split-f16
+// form (split_f16.hpp) with one 4-byte store per pair and plane.
+__device__ __forceinline__ int ln_col(int lane, int i) { return 2 * lane + 128 * (i >> 1) + (i & 1); }
+
 template <int NPL>
-__device__ __forceinline__ void ln_row(float (&v)[NPL], const float* __restrict__ g,
+__device__ __forceinline__ bool ln_row(float (&v)[NPL], const float* __restrict__ g,
                                        const float* __restrict__ b, float eps, int lane,
-                                       float* __restrict__ out) {
+                                       float* __restrict__ out, _Float16* __restrict__ outs) {
     constexpr float invH = 1.0f / (64.0f * NPL);
     float s = 0.0f;
 #pragma unroll
@@ -47,11 +52,27 @@ __device__ __forceinline__ void ln_row(float (&v)[NPL], const float* __restrict_
     for (int i = 0; i < NPL; ++i) { const float d = v[i] - mean; q = fmaf(d, d, q); }
     const float var = wave_sum(q) * invH;
     const float inv = 1.0f / sqrtf(var + eps);
+    bool ovf = false;
 #pragma unroll
-    for (int i = 0; i < NPL; ++i) {
-        const int c = lane + 64 * i;
-        out[c] = (v[i] - mean) * inv * g[c] + b[c];
+    for (int p = 0; p < NPL / 2; ++p) {
+        const int c = ln_col(lane, 2 * p);
+        const float2 gv = *reinterpret_cast<const float2*>(g + c);
+        const float2 bv = *reinterpret_cast<const float2*>(b + c);
+        float2 o;
+        o.x = (v[2 * p] - mean) * inv * gv.x + bv.x;
+        o.y = (v[2 * p + 1] - mean) * inv * gv.y + bv.y;
+        *reinterpret_cast<float2*>(out + c) = o;
+        if (outs) {
+            f16x2 hi, lo;
+            _Float16 a, bb;
+            ovf |= sh_split(o.x, a, bb); hi[0] = a; lo[0] = bb;
+            ovf |= sh_split(o.y, a, bb); hi[1] = a; lo[1] = bb;
+            _Float16* d = outs + (c >> 5) * 64 + (c & 31);
+            *reinterpret_cast<f16x2*>(d) = hi;
+            *reinterpret_cast<f16x2*>(d + 32) = lo;
+        }
     }
+    return ovf;
 }
 
 template <int NPL>
@@ -59,7 +80,8 @@ __global__ void __launch_bounds__(256)
 embed_ln_kernel(const int32_t* __restrict__ ids, const float* __restrict__ word,
                 const float* __restrict__ pos, const float* __restrict__ type0,
                 const float* __restrict__ g, const float* __restrict__ b, float eps, uint32_t T,
-                uint32_t L, uint32_t vocab, float* __restrict__ x) {
+                uint32_t L, uint32_t vocab, float* __restrict__ x, _Float16* __restrict__ xs,
+                uint32_t* __restrict__ flag) {
     constexpr int H = 64 * NPL;
     const int lane = threadIdx.x & 63;
     const uint32_t t = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -70,17 +92,22 @@ embed_ln_kernel(const int32_t* __restrict__ ids, const float* __restrict__ word,
     const float* pe = pos + (size_t)(t % L) * H;
     float v[NPL];
 #pragma unroll
-    for (int i = 0; i < NPL; ++i) {
-        const int c = lane + 64 * i;
-        v[i] = (we[c] + type0[c]) + pe[c];  // BertEmbeddings: (inputs + token_type) + position
+    for (int p = 0; p < NPL / 2; ++p) {
+        const int c = ln_col(lane, 2 * p);
+        const float2 w2 = *reinterpret_cast<const float2*>(we + c);
+        const float2 t2 = *reinterpret_cast<const float2*>(type0 + c);
+        const float2 p2 = *reinterpret_cast<const float2*>(pe + c);
+        v[2 * p] = (w2.x + t2.x) + p2.x;  // BertEmbeddings: (inputs + token_type) + position
+        v[2 * p + 1] = (w2.y + t2.y) + p2.y;
     }
-    ln_row<NPL>(v, g, b, eps, lane, x + (size_t)t * H);
+    const bool ovf = ln_row<NPL>(v, g, b, eps, lane, x + (size_t)t * H, xs ? xs + (size_t)t * H * 2 : nullptr);
+    if (ovf && flag) atomicOr(flag, 1u);
 }
 
 template <int NPL>
 __global__ void __launch_bounds__(256)
 layernorm_kernel(float* __restrict__ x, const float* __restrict__ g, const float* __restrict__ b,
-                 float eps, uint32_t T) {
+                 float eps, uint32_t T, _Float16* __restrict__ xs, uint32_t* __restrict__ flag) {
     constexpr int H = 64 * NPL;
     const int lane = threadIdx.x & 63;
     const uint32_t t = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -88,8 +115,13 @@ layernorm_kernel(float* __restrict__ x, const float* __restrict__ g, const float
     float* row = x + (size_t)t * H;
     float v[NPL];
 #pragma unroll
-    for (int i = 0; i < NPL; ++i) v[i] = row[lane + 64 * i];
-    ln_row<NPL>(v, g, b, eps, lane, row);
+    for (int p = 0; p < NPL / 2; ++p) {
+        const float2 r2 = *reinterpret_cast<const float2*>(row + ln_col(lane, 2 * p));
+        v[2 * p] = r2.x;
+        v[2 * p + 1] = r2.y;
+    }
+    const bool ovf = ln_row<NPL>(v, g, b, eps, lane, row, xs ? xs + (size_t)t * H * 2 : nullptr);
+    if (ovf && flag) atomicOr(flag, 1u);
 }
 
 // ---- E2/E4/E5/E6: C[M,N] = A[M,K] W[N,K]^T + bias (+ epilogue) --------------------------------
@@ -337,9 +369,11 @@ gemm_f32_pipe_kernel(const float* __restrict__ A, const float* __restrict__ W,
 // of the next MFMA needs, so probabilities never leave registers.
 constexpr int AKS = 36;  // padded K row (floats)
 
+template <bool SPLIT>
 __global__ void __launch_bounds__(256)
 attention_kernel(const float* __restrict__ qkv, const int32_t* __restrict__ mask,
-                 float* __restrict__ ctx, uint32_t L, uint32_t H, float scale) {
+                 float* __restrict__ ctx, _Float16* __restrict__ ctxs, uint32_t* __restrict__ flag,
+                 uint32_t L, uint32_t H, float scale) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const uint32_t Lp = (L + 31) & ~31u;
     float* Ks = smem;                 // [Lp][36]
@@ -434,11 +468,30 @@ attention_kernel(const float* __restrict__ qkv, const int32_t* __restrict__ mask
     const float inv = 1.0f / lsum;
     // ot[r] = O^T[d = (r&3) + 8*(r>>2) + 4h][query]; 4 consecutive d per register quad
     if (query < L) {
-        float* op = ctx + ((size_t)b * L + query) * H + head * 32 + 4 * h;
+        if (SPLIT) {
+            // head_dim 32 = one k-chunk of the output projection: [row][head][32 hi | 32 lo]
+            _Float16* op = ctxs + (((size_t)b * L + query) * (H / 32) + head) * 64 + 4 * h;
+            bool ovf = false;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            f32x4 o = {ot[4 * g] * inv, ot[4 * g + 1] * inv, ot[4 * g + 2] * inv, ot[4 * g + 3] * inv};
-            *reinterpret_cast<f32x4*>(op + 8 * g) = o;
+            for (int g = 0; g < 4; ++g) {
+                f16x4 hi, lo;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    _Float16 a, bb;
+                    ovf |= sh_split(ot[4 * g + e] * inv, a, bb);
+                    hi[e] = a; lo[e] = bb;
+                }
+                *reinterpret_cast<f16x4*>(op + 8 * g) = hi;
+                *reinterpret_cast<f16x4*>(op + 32 + 8 * g) = lo;
+            }
+            if (ovf && flag) atomicOr(flag, 1u);
+        } else {
+            float* op = ctx + ((size_t)b * L + query) * H + head * 32 + 4 * h;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 o = {ot[4 * g] * inv, ot[4 * g + 1] * inv, ot[4 * g + 2] * inv, ot[4 * g + 3] * inv};
+                *reinterpret_cast<f32x4*>(op + 8 * g) = o;
+            }
         }
     }
 }
@@ -496,9 +549,10 @@ static void launch_rows(int which, const EncoderLaunch& a, hipStream_t s) {
     const uint32_t T = a.T;
     if (which == 0)
         hipLaunchKernelGGL(embed_ln_kernel<NPL>, dim3((T + 3) / 4), dim3(256), 0, s, a.ids, a.word, a.pos,
-                           a.type0, a.g, a.b, a.eps, T, a.L, a.vocab, a.x);
+                           a.type0, a.g, a.b, a.eps, T, a.L, a.vocab, a.x, static_cast<_Float16*>(a.xs), a.flag);
     else if (which == 1)
-        hipLaunchKernelGGL(layernorm_kernel<NPL>, dim3((T + 3) / 4), dim3(256), 0, s, a.x, a.g, a.b, a.eps, T);
+        hipLaunchKernelGGL(layernorm_kernel<NPL>, dim3((T + 3) / 4), dim3(256), 0, s, a.x, a.g, a.b, a.eps, T,
+                           static_cast<_Float16*>(a.xs), a.flag);
     else
         hipLaunchKernelGGL(pool_normalize_kernel<NPL>, dim3((a.B + 3) / 4), dim3(256), 0, s, a.x, a.mask, a.B,
                            a.L, a.pooling, a.out);
@@ -554,23 +608,37 @@ size_t attention_lds_bytes(uint32_t L) {
     return (size_t)Lp * (AKS + 32 + 1) * sizeof(float) + 16;
 }
 
-int32_t launch_attention(const float* qkv, const int32_t* mask, float* ctx, uint32_t B, uint32_t L,
-                         uint32_t H, uint32_t heads, hipStream_t s) {
+static int32_t launch_attention_impl(const float* qkv, const int32_t* mask, float* ctx, _Float16* ctxs,
+                                     uint32_t* flag, uint32_t B, uint32_t L, uint32_t H, uint32_t heads,
+                                     hipStream_t s) {
     if (H / heads != 32 || H % heads)
         return fail(CS_ERR_UNSUPPORTED, "head_dim %u not supported (32 only in this round)", heads ? H / heads : 0);
     const size_t lds = attention_lds_bytes(L);
     if (lds > 160 * 1024 - 64) return fail(CS_ERR_UNSUPPORTED, "sequence length %u exceeds the LDS-resident K/V limit", L);
     static bool attr_set = false;
     if (!attr_set) {
-        CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attention_kernel),
+        CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attention_kernel<false>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
+        CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attention_kernel<true>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
         attr_set = true;
     }
     dim3 grid((L + 127) / 128, heads, B);
-    hipLaunchKernelGGL(attention_kernel, grid, dim3(256), lds, s, qkv, mask, ctx, L, H,
-                       1.0f / sqrtf(32.0f));
+    const float scale = 1.0f / sqrtf(32.0f);
+    if (ctxs) hipLaunchKernelGGL(attention_kernel<true>, grid, dim3(256), lds, s, qkv, mask, ctx, ctxs, flag, L, H, scale);
+    else hipLaunchKernelGGL(attention_kernel<false>, grid, dim3(256), lds, s, qkv, mask, ctx, ctxs, flag, L, H, scale);
     CS_HIP(hipGetLastError());
     return CS_OK;
+}
+
+int32_t launch_attention(const float* qkv, const int32_t* mask, float* ctx, uint32_t B, uint32_t L,
+                         uint32_t H, uint32_t heads, hipStream_t s) {
+    return launch_attention_impl(qkv, mask, ctx, nullptr, nullptr, B, L, H, heads, s);
+}
+
+int32_t launch_attention_split(const float* qkv, const int32_t* mask, void* ctx_split, uint32_t* flag, uint32_t B,
+                               uint32_t L, uint32_t H, uint32_t heads, hipStream_t s) {
+    return launch_attention_impl(qkv, mask, nullptr, static_cast<_Float16*>(ctx_split), flag, B, L, H, heads, s);
 }
 
 int32_t launch_synth_params(float* d_out, const cs_bert_config& cfg, uint64_t seed, hipStream_t s) {

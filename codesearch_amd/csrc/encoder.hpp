@@ -22,6 +22,8 @@ struct EncoderLaunch {
     int pooling = CS_POOL_CLS;
     float* x = nullptr;
     float* out = nullptr;
+    void* xs = nullptr;         // optional: the row also in split-f16 form (split_f16.hpp), [T][H/32][64] f16
+    uint32_t* flag = nullptr;   // split-f16 overflow flag (device)
 };
 
 enum { GEMM_BIAS = 0, GEMM_GELU = 1, GEMM_RESID = 2 };
@@ -33,7 +35,16 @@ int32_t launch_gemm(int epi, const float* A, const float* W, const float* bias, 
 // qkv [B*L, 3H] (Q | K | V), mask [B, L] -> ctx [B*L, H]
 int32_t launch_attention(const float* qkv, const int32_t* mask, float* ctx, uint32_t B, uint32_t L,
                          uint32_t H, uint32_t heads, hipStream_t s);
+// ctx_split (optional, instead of ctx): the context in split-f16 form for the output projection
+int32_t launch_attention_split(const float* qkv, const int32_t* mask, void* ctx_split, uint32_t* flag, uint32_t B,
+                               uint32_t L, uint32_t H, uint32_t heads, hipStream_t s);
 size_t attention_lds_bytes(uint32_t L);
+
+// Split-f16 GEMM (gemm_split.hip): A [M][K/32][64] f16, W [N][K/32][64] f16 (split_f16.hpp).
+enum { SH_OUT_F32 = 0, SH_OUT_F32_RESID = 1, SH_OUT_SPLIT_GELU = 2 };
+int32_t launch_gemm_split(int epi, const _Float16* A, const _Float16* W, const float* bias, const float* resid,
+                          float* C, _Float16* Cs, uint32_t M, uint32_t N, uint32_t K, uint32_t* d_flag,
+                          hipStream_t s);
 int32_t launch_synth_params(float* d_out, const cs_bert_config& cfg, uint64_t seed, hipStream_t s);
 
 }  // namespace cs

@@ -1,0 +1,158 @@
+// gemm_split.hip — the encoder's dense layers on the f16 MFMA with split-f16 operands
+// (split_f16.hpp), SURVEY.md §8a E2/E4/E5/E6:  C[M,N] = A[M,K] W[N,K]^T + bias, then
+//   SH_OUT_F32        store f32                                  (QKV projection)
+//   SH_OUT_F32_RESID  + residual, store f32 (may be in place)    (attention output / FFN down)
+//   SH_OUT_SPLIT_GELU erf-GELU, store in split form              (FFN up; only a GEMM reads it)
+// 128x128x32 tiles by LDS-DMA, three v_mfma_f32_32x32x16_f16 per f32 product block, C tile
+// staged through LDS so every global access of the epilogue is a full 16 B per lane on
+// consecutive lanes.  Replaces the fp32 arithmetic ONNX Runtime does for
+// /root/reference/src/embed/embedder.rs:286-289 to within ~3 * 2^-22 per product.
+#include "encoder.hpp"
+#include "split_f16.hpp"
+
+namespace cs {
+
+__device__ __forceinline__ float sh_gelu_erf(float v) {
+    return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+}
+
+template <int EPI, bool FULL>
+__device__ __forceinline__ void gemm_sh_epilogue(const float* ctile, const float* __restrict__ bias,
+                                                 const float* resid, float* C, _Float16* __restrict__ Cs,
+                                                 uint32_t M, uint32_t N, uint32_t m0, uint32_t n0,
+                                                 uint32_t* __restrict__ flag) {
+    const int tid = threadIdx.x;
+    if (EPI == SH_OUT_SPLIT_GELU) {
+        bool ovf = false;
+        const int c8 = tid & 15;  // 8 consecutive n per thread
+        const sh_f32x4 b0 = *reinterpret_cast<const sh_f32x4*>(bias + n0 + c8 * 8);
+        const sh_f32x4 b1 = *reinterpret_cast<const sh_f32x4*>(bias + n0 + c8 * 8 + 4);
+        const size_t nchunks = N / 32;
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int row = (tid >> 4) + 16 * it;
+            const sh_f32x4 v0 = *reinterpret_cast<const sh_f32x4*>(ctile + row * 128 + c8 * 8);
+            const sh_f32x4 v1 = *reinterpret_cast<const sh_f32x4*>(ctile + row * 128 + c8 * 8 + 4);
+            f16x8 hi, lo;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                _Float16 a, b;
+                ovf |= sh_split(sh_gelu_erf(v0[e] + b0[e]), a, b);
+                hi[e] = a; lo[e] = b;
+                ovf |= sh_split(sh_gelu_erf(v1[e] + b1[e]), a, b);
+                hi[4 + e] = a; lo[4 + e] = b;
+            }
+            if (FULL || m0 + row < M) {
+                _Float16* dst = Cs + ((size_t)(m0 + row) * nchunks + (n0 >> 5) + (c8 >> 2)) * 64 + (c8 & 3) * 8;
+                *reinterpret_cast<f16x8*>(dst) = hi;
+                *reinterpret_cast<f16x8*>(dst + 32) = lo;
+            }
+        }
+        if (ovf && flag) atomicOr(flag, 1u);
+    } else {
+        const int c4 = tid & 31;
+        const sh_f32x4 bv = *reinterpret_cast<const sh_f32x4*>(bias + n0 + c4 * 4);
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            sh_f32x4 rs[8];
+            if (EPI == SH_OUT_F32_RESID) {
+#pragma unroll
+                for (int it = 0; it < 8; ++it) {
+                    const uint32_t row = m0 + (tid >> 5) + 8 * (half * 8 + it);
+                    rs[it] = *reinterpret_cast<const sh_f32x4*>(resid + (size_t)((FULL || row < M) ? row : M - 1) * N + n0 + c4 * 4);
+                }
+            }
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int row = (tid >> 5) + 8 * (half * 8 + it);
+                sh_f32x4 v = *reinterpret_cast<const sh_f32x4*>(ctile + row * 128 + c4 * 4);
+                v += bv;
+                if (EPI == SH_OUT_F32_RESID) v += rs[it];
+                if (FULL || m0 + row < M) *reinterpret_cast<sh_f32x4*>(C + (size_t)(m0 + row) * N + n0 + c4 * 4) = v;
+            }
+        }
+    }
+}
+
+template <int EPI>
+__global__ void __launch_bounds__(256, 2)
+gemm_sh_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ W,
+               const float* __restrict__ bias, const float* resid, float* C,
+               _Float16* __restrict__ Cs, uint32_t M, uint32_t N, uint32_t kchunks,
+               uint32_t* __restrict__ flag) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    uint32_t mt, nt;
+    if (!sh_tile_of_block(blockIdx.x, (M + SH_BM - 1) / SH_BM, N / SH_BN, mt, nt)) return;
+    const uint32_t m0 = mt * SH_BM, n0 = nt * SH_BN;
+    ShAcc acc;
+    sh_acc_zero(acc);
+    sh_mainloop(A, M, m0, W, N, n0, kchunks, lds, acc);
+    float* ctile = reinterpret_cast<float*>(lds);
+    sh_acc_to_lds(acc, ctile);
+
+    // Full tiles take a branch-free path (a per-row `if (row < M)` makes hipcc drain vmcnt
+    // around every store); the ragged last m-tile takes the guarded one.
+    if (m0 + SH_BM <= M) gemm_sh_epilogue<EPI, true>(ctile, bias, resid, C, Cs, M, N, m0, n0, flag);
+    else gemm_sh_epilogue<EPI, false>(ctile, bias, resid, C, Cs, M, N, m0, n0, flag);
+}
+
+// rows x K f32 -> split layout; one thread per 8 consecutive k.
+__global__ void __launch_bounds__(256)
+split_rows_kernel(const float* __restrict__ src, _Float16* __restrict__ dst, uint64_t n8, uint32_t K,
+                  uint32_t* __restrict__ flag) {
+    bool ovf = false;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    const uint32_t k8 = K / 8;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += stride) {
+        const uint64_t row = i / k8;
+        const uint32_t c = (uint32_t)(i % k8);  // 8-element group within the row
+        const sh_f32x4 v0 = *reinterpret_cast<const sh_f32x4*>(src + i * 8);
+        const sh_f32x4 v1 = *reinterpret_cast<const sh_f32x4*>(src + i * 8 + 4);
+        f16x8 hi, lo;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            _Float16 a, b;
+            ovf |= sh_split(v0[e], a, b); hi[e] = a; lo[e] = b;
+            ovf |= sh_split(v1[e], a, b); hi[4 + e] = a; lo[4 + e] = b;
+        }
+        _Float16* d = dst + (row * (K / 32) + (c >> 2)) * 64 + (c & 3) * 8;
+        *reinterpret_cast<f16x8*>(d) = hi;
+        *reinterpret_cast<f16x8*>(d + 32) = lo;
+    }
+    if (ovf && flag) atomicOr(flag, 1u);
+}
+
+int32_t launch_split_rows(const float* d_src, _Float16* d_dst, uint64_t rows, uint32_t K, uint32_t* d_flag,
+                          hipStream_t s) {
+    if (K % 32) return fail(CS_ERR_UNSUPPORTED, "split-f16 layout needs K %% 32 == 0 (K = %u)", K);
+    const uint64_t n8 = rows * (K / 8);
+    if (n8 == 0) return CS_OK;
+    const uint64_t want = (n8 + 255) / 256;
+    hipLaunchKernelGGL(split_rows_kernel, dim3((uint32_t)(want < 8192 ? want : 8192)), dim3(256), 0, s, d_src,
+                       d_dst, n8, K, d_flag);
+    CS_HIP(hipGetLastError());
+    return CS_OK;
+}
+
+int32_t launch_gemm_split(int epi, const _Float16* A, const _Float16* W, const float* bias, const float* resid,
+                          float* C, _Float16* Cs, uint32_t M, uint32_t N, uint32_t K, uint32_t* d_flag,
+                          hipStream_t s) {
+    if (N % SH_BN || K % 32) return fail(CS_ERR_UNSUPPORTED, "split GEMM N=%u K=%u must be multiples of 128/32", N, K);
+    if (M == 0) return CS_OK;
+    static bool attr_set = false;
+    if (!attr_set) {
+        CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_sh_kernel<SH_OUT_F32>), hipFuncAttributeMaxDynamicSharedMemorySize, SH_LDS_BYTES));
+        CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_sh_kernel<SH_OUT_F32_RESID>), hipFuncAttributeMaxDynamicSharedMemorySize, SH_LDS_BYTES));
+        CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_sh_kernel<SH_OUT_SPLIT_GELU>), hipFuncAttributeMaxDynamicSharedMemorySize, SH_LDS_BYTES));
+        attr_set = true;
+    }
+    const dim3 grid(sh_grid_blocks((M + SH_BM - 1) / SH_BM, N / SH_BN));
+    const uint32_t kc = K / 32;
+    if (epi == SH_OUT_F32) hipLaunchKernelGGL(gemm_sh_kernel<SH_OUT_F32>, grid, dim3(256), SH_LDS_BYTES, s, A, W, bias, resid, C, Cs, M, N, kc, d_flag);
+    else if (epi == SH_OUT_F32_RESID) hipLaunchKernelGGL(gemm_sh_kernel<SH_OUT_F32_RESID>, grid, dim3(256), SH_LDS_BYTES, s, A, W, bias, resid, C, Cs, M, N, kc, d_flag);
+    else hipLaunchKernelGGL(gemm_sh_kernel<SH_OUT_SPLIT_GELU>, grid, dim3(256), SH_LDS_BYTES, s, A, W, bias, resid, C, Cs, M, N, kc, d_flag);
+    CS_HIP(hipGetLastError());
+    return CS_OK;
+}
+
+}  // namespace cs

@@ -1,0 +1,186 @@
+// split_f16.hpp — the "split-f16" operand format and the shared MFMA main loop built on it.
+//
+// gfx950 has no reduced-precision fast path for f32 matmul inputs (no xf32): the exact-f32
+// MFMA runs at 1/16 of the f16/bf16 MFMA rate (MI355X_MICROARCH.md § Matrix cores).  The dense
+// products of this path (the encoder's QKV/FFN GEMMs, the batched query x corpus scan) therefore
+// run on v_mfma_f32_32x32x16_f16 with every f32 operand x stored as TWO f16 values
+//
+//     x  =  hi  +  lo / 2048  +  e,     hi = rn_f16(x) (0 when |x| < 2^-14, so no f16 subnormal
+//     lo =  rn_f16((x - hi) * 2048)     is ever the high part of an MFMA input)
+//     |e| <= 2^-22 |x|  for |x| >= 2^-14;   |e| <= 2^-11 |x| <= 2^-25  below (lo alone carries x)
+//
+// and a product sum  sum a*w  evaluated as  sum a_hi*w_hi  +  2^-11 * sum (a_hi*w_lo + a_lo*w_hi)
+// with both sums accumulated in f32 by the MFMA (three f16 MFMAs in place of sixteen-cycles-each
+// f32 ones: 3/16 of the matrix-pipe time).  Dropped: a_lo*w_lo <= 2^-22 |a w|.  Per-product error
+// is <= ~3 * 2^-22 |a w| (+ 2^-25 |w| for a tiny a), the same order as the rounding of an f32
+// fmaf chain at K ~ 10^3; LayerNorm'd / GELU'd activations and BERT weights are O(1e-2..1e1).
+// Values with |x| > 65504 do not fit: producers raise an overflow flag that the host checks
+// (cs_embedder falls back to the exact-f32 kernels; the scan uses the result only as a filter).
+//
+// Memory layout of a logical [rows, K] f32 matrix in split form ("sh" layout), K % 32 == 0:
+//     [rows][K/32][64] f16  —  per 32-element k-chunk one 128-B line: 32 hi, then 32 lo
+// so a row is K*4 bytes (the f32 size) and every k-chunk of a row is one full cache line.
+#pragma once
+
+#include "common.hpp"
+
+namespace cs {
+
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float sh_f32x4 __attribute__((ext_vector_type(4)));
+typedef float sh_f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr float kShLoScale = 2048.0f;
+constexpr float kShLoInv = 1.0f / 2048.0f;
+constexpr float kShMinNormal = 6.103515625e-05f;  // 2^-14
+constexpr float kShMax = 65504.0f;
+
+// One value -> (hi, lo).  Returns true when the value does not fit the format.
+__device__ __forceinline__ bool sh_split(float x, _Float16& hi, _Float16& lo) {
+    const float xs = fabsf(x) < kShMinNormal ? 0.0f : x;
+    hi = (_Float16)xs;
+    lo = (_Float16)((x - (float)hi) * kShLoScale);  // x - hi is exact in f32
+    return !(fabsf(x) <= kShMax);                    // also true for NaN
+}
+
+// ---- 128 x 128 x 32 tile main loop --------------------------------------------------------
+// Block = 256 threads = 4 waves as 2 (m) x 2 (n); a wave owns 64 x 64 = 2 x 2 MFMA tiles of
+// 32 x 32.  Stage = one k-chunk (32 k) of 128 A rows and 128 W rows = 2 x 16 KiB, brought in
+// by global_load_lds_dwordx4 (no VGPR round trip, no ds_write); two stage buffers = 64 KiB,
+// two blocks per CU.  LDS image: row r of a tile = 128 B = eight 16-B slots, logical slot c
+// (c = 0..3: hi k 8c..8c+7; c = 4..7: lo) stored at physical slot c ^ ((r >> 1) & 7): the
+// 16-lane groups of ds_read_b128 then touch 16 distinct 4-bank slots (conflict-free).  The
+// LDS-DMA destination is lane-linear, so the permutation is applied to the per-lane SOURCE
+// address (cdna_hip_programming.md §5.4 rule 21).
+constexpr int SH_BM = 128, SH_BN = 128;
+constexpr int SH_TILE_BYTES = 128 * 128;          // one operand tile of one stage
+constexpr int SH_STAGE_BYTES = 2 * SH_TILE_BYTES; // A tile | W tile
+constexpr int SH_LDS_BYTES = 2 * SH_STAGE_BYTES;  // 65,536
+
+struct ShAcc {
+    sh_f32x16 hh[2][2];  // sum a_hi * w_hi
+    sh_f32x16 xx[2][2];  // sum a_hi * w_lo' + a_lo' * w_hi   (primes: scaled by 2048)
+};
+
+__device__ __forceinline__ void sh_glds16(const void* gsrc, void* lds_dst) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+}
+
+// A: split rows [m0, m0+128) of a [M][kc][64] matrix (rows >= M re-read row M-1: they only feed
+// outputs that are never stored); W likewise with N rows.  acc must be zero-initialised by the
+// caller or carry a previous partial sum.  All 256 threads must call.
+__device__ __forceinline__ void sh_mainloop(const _Float16* __restrict__ A, uint32_t M, uint32_t m0,
+                                            const _Float16* __restrict__ W, uint32_t N, uint32_t n0,
+                                            uint32_t kchunks, char* lds, ShAcc& acc) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    const int l31 = lane & 31, h = lane >> 5;
+
+    // staging: wave w moves tile rows [32w, 32w+32) of both operands, 8 rows per instruction
+    const _Float16* asrc[4];
+    const _Float16* wsrc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = wave * 32 + i * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((row >> 1) & 7);
+        const uint32_t am = (m0 + row < M) ? m0 + row : M - 1;
+        const uint32_t wn = (n0 + row < N) ? n0 + row : N - 1;
+        asrc[i] = A + (size_t)am * kchunks * 64 + c * 8;
+        wsrc[i] = W + (size_t)wn * kchunks * 64 + c * 8;
+    }
+    auto stage = [&](uint32_t kc, char* buf) {
+        char* dst = buf + wave * 32 * 128;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            sh_glds16(asrc[i] + (size_t)kc * 64, dst + i * 1024);
+            sh_glds16(wsrc[i] + (size_t)kc * 64, dst + SH_TILE_BYTES + i * 1024);
+        }
+    };
+
+    // fragment addresses: MFMA step s (k 16s..16s+15), lane half h -> logical slot 2s + h (hi), 4 + 2s + h (lo)
+    const int swz = (l31 >> 1) & 7;
+    const int arow = (wr * 64 + l31) * 128, wrow = SH_TILE_BYTES + (wc * 64 + l31) * 128;
+    int sl_hi[2], sl_lo[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        sl_hi[s] = ((2 * s + h) ^ swz) * 16;
+        sl_lo[s] = ((4 + 2 * s + h) ^ swz) * 16;
+    }
+
+    stage(0, lds);
+    __syncthreads();
+    for (uint32_t kc = 0; kc < kchunks; ++kc) {
+        char* cur = lds + (kc & 1) * SH_STAGE_BYTES;
+        if (kc + 1 < kchunks) stage(kc + 1, lds + ((kc + 1) & 1) * SH_STAGE_BYTES);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            f16x8 ah[2], al[2], wh[2], wl[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                ah[t] = *reinterpret_cast<const f16x8*>(cur + arow + t * 32 * 128 + sl_hi[s]);
+                al[t] = *reinterpret_cast<const f16x8*>(cur + arow + t * 32 * 128 + sl_lo[s]);
+                wh[t] = *reinterpret_cast<const f16x8*>(cur + wrow + t * 32 * 128 + sl_hi[s]);
+                wl[t] = *reinterpret_cast<const f16x8*>(cur + wrow + t * 32 * 128 + sl_lo[s]);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    acc.hh[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], wh[j], acc.hh[i][j], 0, 0, 0);
+                    acc.xx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], wl[j], acc.xx[i][j], 0, 0, 0);
+                    acc.xx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], wh[j], acc.xx[i][j], 0, 0, 0);
+                }
+        }
+        __syncthreads();  // stage kc+1 has landed (vmcnt(0) precedes the barrier); cur is free
+    }
+}
+
+__device__ __forceinline__ void sh_acc_zero(ShAcc& acc) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc.hh[i][j][r] = 0.0f; acc.xx[i][j][r] = 0.0f; }
+}
+
+// The tile's f32 values into LDS as [128 m][128 n] (64 KiB, reusing the stage buffers; the main
+// loop's final barrier has retired every read of them).  C/D map of the 32x32 MFMA:
+// n = lane & 31, m = (r & 3) + 8 (r >> 2) + 4 (lane >> 5).  Followed by a barrier.
+__device__ __forceinline__ void sh_acc_to_lds(const ShAcc& acc, float* ctile) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1, l31 = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                ctile[m * 128 + wc * 64 + j * 32 + l31] = fmaf(acc.xx[i][j][r], kShLoInv, acc.hh[i][j][r]);
+            }
+    __syncthreads();
+}
+
+// XCD-aware tile order (cdna_hip_programming.md T1): blocks b and b + 8 share an XCD's L2, so
+// each XCD walks its own m-tiles with the n-tiles of one m-tile back to back (the A tile is
+// fetched into one L2; W is small and resident in all eight).  Returns false for padding blocks.
+__device__ __forceinline__ bool sh_tile_of_block(uint32_t b, uint32_t mtiles, uint32_t ntiles,
+                                                 uint32_t& mt, uint32_t& nt) {
+    const uint32_t xcd = b & 7, q = b >> 3;
+    mt = (q / ntiles) * 8 + xcd;
+    nt = q % ntiles;
+    return mt < mtiles;
+}
+inline uint32_t sh_grid_blocks(uint32_t mtiles, uint32_t ntiles) { return ((mtiles + 7) / 8) * 8 * ntiles; }
+
+// ---- host-visible launchers (gemm_split.hip) ----------------------------------------------
+// rows x K f32 -> split layout; flag (device u32, may be null) is OR-ed with 1 on overflow.
+int32_t launch_split_rows(const float* d_src, _Float16* d_dst, uint64_t rows, uint32_t K, uint32_t* d_flag,
+                          hipStream_t s);
+
+}  // namespace cs

@@ -113,7 +113,8 @@ class FastEmbedder:
     `seed`, generated on the device."""
 
     def __init__(self, model_type: ModelType = None, cache_dir=None, *, config: BertConfig = None,
-                 params: np.ndarray = None, seed: int = 0, device: int = 0, tokenizer=None):
+                 params: np.ndarray = None, seed: int = 0, device: int = 0, tokenizer=None,
+                 gemm_mode: Optional[str] = None):
         self._lib = _lib.load()
         self._model_type = model_type or ModelType.default()
         self.config = config or self._model_type.bert_config()
@@ -132,6 +133,19 @@ class FastEmbedder:
         h = C.c_void_p()
         _lib.check(self._lib.cs_embedder_create(C.byref(ccfg), pptr, seed, device, C.byref(h)))
         self._h = h
+        if gemm_mode is not None:
+            self.set_gemm_mode(gemm_mode)
+
+    def set_gemm_mode(self, mode: str) -> None:
+        """"split" (default: split-f16 operands on the f16 MFMA) or "f32" (exact-f32 MFMA)."""
+        m = {"f32": _lib.CS_GEMM_F32, "split": _lib.CS_GEMM_SPLIT_F16}[mode]
+        _lib.check(self._lib.cs_embedder_set_gemm_mode(self._h, m))
+
+    def debug_counters(self):
+        """-> (split_forwards, f32_forwards, range_fallbacks)"""
+        a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        _lib.check(self._lib.cs_embedder_debug_counters(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return int(a.value), int(b.value), int(c.value)
 
     # constructors named as in the reference
     @classmethod

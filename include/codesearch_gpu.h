@@ -228,6 +228,26 @@ int32_t cs_embedder_last_hidden(cs_embedder* h, float* out, uint64_t n_tokens);
 int32_t cs_embedder_profile_read(cs_embedder* h, double* forward_ms, uint64_t* forwards,
                                  int32_t reset);
 
+/* Arithmetic of the dense layers.  CS_GEMM_SPLIT_F16 (default): every f32 operand as two f16
+ * values on the f16 MFMA, three MFMAs per product block, f32 accumulation — error per product
+ * <= ~3 * 2^-22, the order of f32 rounding itself (codesearch_amd/csrc/split_f16.hpp).
+ * CS_GEMM_F32: the exact-f32 MFMA (bit-for-bit an fmaf chain), 16/3 x the matrix-pipe time.
+ * A mini-batch whose activations leave the f16 range (|x| > 65504) is recomputed with
+ * CS_GEMM_F32 automatically; cs_embedder_debug_counters reports how often.
+ * The environment variable CS_ENCODER_GEMM=f32|split sets the default at create time. */
+typedef enum cs_gemm_mode { CS_GEMM_F32 = 0, CS_GEMM_SPLIT_F16 = 1 } cs_gemm_mode;
+int32_t cs_embedder_set_gemm_mode(cs_embedder* h, int32_t mode);
+int32_t cs_embedder_debug_counters(cs_embedder* h, uint64_t* split_forwards,
+                                   uint64_t* f32_forwards, uint64_t* range_fallbacks);
+
+/* Diagnostics: one dense layer of the encoder on host buffers, for unit parity tests of the
+ * GEMM kernels (E2/E4/E5/E6).  C[M,N] = A[M,K] W[N,K]^T + bias, epilogue 0 = none,
+ * 1 = erf-GELU, 2 = + resid[M,N]; mode = cs_gemm_mode.  N % 128 == 0, K % 32 == 0.
+ * *range_flag (optional) is set when a split-f16 operand left the f16 range. */
+int32_t cs_debug_gemm(int32_t device, int32_t mode, int32_t epilogue, const float* A,
+                      const float* W, const float* bias, const float* resid, float* C,
+                      uint32_t M, uint32_t N, uint32_t K, uint32_t* range_flag);
+
 #ifdef __cplusplus
 }
 #endif
