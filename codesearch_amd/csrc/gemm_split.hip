@@ -96,18 +96,27 @@ gemm_sh_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ W,
     else gemm_sh_epilogue<EPI, false>(ctile, bias, resid, C, Cs, M, N, m0, n0, flag);
 }
 
-// rows x K f32 -> split layout; one thread per 8 consecutive k.
+// rows x K f32 -> split layout; one thread per 8 consecutive k.  With row_norm, row r is divided
+// by row_norm[r] first (a zero norm gives a zero row): unit rows for the scan's filter operand.
 __global__ void __launch_bounds__(256)
 split_rows_kernel(const float* __restrict__ src, _Float16* __restrict__ dst, uint64_t n8, uint32_t K,
-                  uint32_t* __restrict__ flag) {
+                  const float* __restrict__ row_norm, uint32_t* __restrict__ flag) {
     bool ovf = false;
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     const uint32_t k8 = K / 8;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += stride) {
         const uint64_t row = i / k8;
         const uint32_t c = (uint32_t)(i % k8);  // 8-element group within the row
-        const sh_f32x4 v0 = *reinterpret_cast<const sh_f32x4*>(src + i * 8);
-        const sh_f32x4 v1 = *reinterpret_cast<const sh_f32x4*>(src + i * 8 + 4);
+        sh_f32x4 v0 = *reinterpret_cast<const sh_f32x4*>(src + i * 8);
+        sh_f32x4 v1 = *reinterpret_cast<const sh_f32x4*>(src + i * 8 + 4);
+        if (row_norm) {
+            const float nrm = row_norm[row];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v0[e] = nrm == 0.0f ? 0.0f : v0[e] / nrm;
+                v1[e] = nrm == 0.0f ? 0.0f : v1[e] / nrm;
+            }
+        }
         f16x8 hi, lo;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -123,13 +132,13 @@ split_rows_kernel(const float* __restrict__ src, _Float16* __restrict__ dst, uin
 }
 
 int32_t launch_split_rows(const float* d_src, _Float16* d_dst, uint64_t rows, uint32_t K, uint32_t* d_flag,
-                          hipStream_t s) {
+                          hipStream_t s, const float* d_row_norm) {
     if (K % 32) return fail(CS_ERR_UNSUPPORTED, "split-f16 layout needs K %% 32 == 0 (K = %u)", K);
     const uint64_t n8 = rows * (K / 8);
     if (n8 == 0) return CS_OK;
     const uint64_t want = (n8 + 255) / 256;
     hipLaunchKernelGGL(split_rows_kernel, dim3((uint32_t)(want < 8192 ? want : 8192)), dim3(256), 0, s, d_src,
-                       d_dst, n8, K, d_flag);
+                       d_dst, n8, K, d_row_norm, d_flag);
     CS_HIP(hipGetLastError());
     return CS_OK;
 }

@@ -6,6 +6,8 @@
 #include <mutex>
 #include <vector>
 
+#include <cstdlib>
+
 #include "scan.hpp"
 
 namespace cs {
@@ -44,7 +46,26 @@ struct Workspace {
     std::vector<EventTriple> free_events;
     BatchedState bs;
     size_t bs_nq = 0, bs_cand = 0, bs_carry = 0;
+    SplitQueryWs qw;
+    size_t qw_elems = 0, qw_nq = 0;
     uint32_t* h_overflow = nullptr;
+
+    int32_t reserve_split_queries(uint32_t nq, uint32_t dim) {
+        const size_t elems = (size_t)nq * dim * 2;
+        if (elems > qw_elems) {
+            if (qw.d_qsplit) (void)hipFree(qw.d_qsplit);
+            qw.d_qsplit = nullptr; qw_elems = 0;
+            CS_HIP(hipMalloc(&qw.d_qsplit, elems * sizeof(_Float16)));
+            qw_elems = elems;
+        }
+        if (nq > qw_nq) {
+            if (qw.d_qmag) (void)hipFree(qw.d_qmag);
+            qw.d_qmag = nullptr; qw_nq = 0;
+            CS_HIP(hipMalloc(&qw.d_qmag, nq * sizeof(float)));
+            qw_nq = nq;
+        }
+        return CS_OK;
+    }
 
     int32_t reserve_batched(uint32_t nq, uint32_t k) {
         const size_t cand = (size_t)nq * batched_cap(k), carry = (size_t)nq * k;
@@ -147,6 +168,8 @@ struct Workspace {
         if (bs.d_tau) (void)hipFree(bs.d_tau);
         if (bs.d_carry) (void)hipFree(bs.d_carry);
         if (bs.d_overflow) (void)hipFree(bs.d_overflow);
+        if (qw.d_qsplit) (void)hipFree(qw.d_qsplit);
+        if (qw.d_qmag) (void)hipFree(qw.d_qmag);
         for (auto& t : free_events) {
             (void)hipEventDestroy(t.e0); (void)hipEventDestroy(t.e1); (void)hipEventDestroy(t.e2);
         }
@@ -170,6 +193,9 @@ struct cs_index {
     uint32_t* d_dead = nullptr;  // bitmap over rows, sized for `capacity`
     float* d_norms = nullptr;    // |row| for rows [0, normed_rows) (batched-query path)
     uint64_t normed_rows = 0;
+    _Float16* d_split = nullptr;  // rows [0, split_rows) in split-f16 form (filter operand of the batched path)
+    uint64_t split_rows = 0;
+    bool use_split = false;
     uint64_t batched_searches = 0, batched_fallbacks = 0;
     std::vector<uint32_t> h_dead;
     bool built = false;
@@ -204,6 +230,24 @@ int32_t grow(cs_index* h, uint64_t need_rows) {
         (void)hipFree(nc);
         (void)hipFree(nd);
         return fail(CS_ERR_OOM, "hipMalloc(row norms) failed: %s", hipGetErrorString(e));
+    }
+    if (h->use_split) {
+        // filter copy of the batched path (same bytes as the f32 matrix); without room for it the
+        // batched path stays on the exact-f32 MFMA kernels (scan_mfma.hip)
+        _Float16* ns = nullptr;
+        if (hipMalloc(&ns, (size_t)cap * h->dim * 2 * sizeof(_Float16)) != hipSuccess) {
+            (void)hipGetLastError();
+            h->use_split = false;
+            if (h->d_split) (void)hipFree(h->d_split);
+            h->d_split = nullptr;
+            h->split_rows = 0;
+        } else {
+            if (h->split_rows)
+                CS_HIP(hipMemcpy(ns, h->d_split, (size_t)h->split_rows * h->dim * 2 * sizeof(_Float16),
+                                 hipMemcpyDeviceToDevice));
+            if (h->d_split) (void)hipFree(h->d_split);
+            h->d_split = ns;
+        }
     }
     CS_HIP(hipMemset(nd, 0, words * sizeof(uint32_t)));
     if (h->normed_rows)
@@ -295,11 +339,19 @@ int32_t run_search(cs_index* h, Workspace* w, const ScanPlan& plan, const float*
     const bool timed = take_events(h, w, &ev);
     if (timed) CS_HIP(hipEventRecord(ev.e0, stream));
     // >= 5 queries: MFMA scoring + phased candidate selection (scan_mfma.hip)
-    if (nq >= 5 && h->n_rows > 0 && batched_supported(h->dim) && h->normed_rows >= h->n_rows) {
+    const bool split_ready = h->use_split && h->split_rows >= h->n_rows;
+    if (nq >= 5 && h->n_rows > 0 && h->normed_rows >= h->n_rows && (split_ready || batched_supported(h->dim))) {
         CS_TRY(w->reserve_batched(nq, k));
-        CS_TRY(launch_scan_batched(w->bs, h->d_corpus, h->d_norms, h->n_rows, h->dim, d_queries, nq, k,
-                                   h->n_removed ? h->d_dead : nullptr, h->id_base, h->num_cus, d_keys, d_cos,
-                                   d_ids, d_counts, stream));
+        if (split_ready) {
+            CS_TRY(w->reserve_split_queries(nq, h->dim));
+            CS_TRY(launch_scan_split(w->bs, w->qw, h->d_corpus, h->d_split, h->n_rows, h->dim,
+                                     d_queries, nq, k, h->n_removed ? h->d_dead : nullptr, h->id_base, d_keys,
+                                     d_cos, d_ids, d_counts, stream));
+        } else {
+            CS_TRY(launch_scan_batched(w->bs, h->d_corpus, h->d_norms, h->n_rows, h->dim, d_queries, nq, k,
+                                       h->n_removed ? h->d_dead : nullptr, h->id_base, h->num_cus, d_keys, d_cos,
+                                       d_ids, d_counts, stream));
+        }
         if (timed) CS_HIP(hipEventRecord(ev.e1, stream));
         CS_HIP(hipMemcpyAsync(w->h_overflow, w->bs.d_overflow, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
         CS_HIP(hipStreamSynchronize(stream));
@@ -383,6 +435,10 @@ int32_t cs_index_create(uint32_t dim, uint64_t capacity_rows, int32_t device, ui
     h->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     h->dim = dim;
     h->id_base = id_base;
+    {
+        const char* env = std::getenv("CS_INDEX_SPLIT");  // "0": keep the batched path on the exact-f32 MFMA
+        h->use_split = split_scan_supported(dim) && !(env && env[0] == '0');
+    }
     if (capacity_rows) {
         int32_t s = grow(h, capacity_rows);
         if (s != CS_OK) { delete h; return s; }
@@ -403,6 +459,7 @@ void cs_index_destroy(cs_index* h) {
     if (h->d_corpus) (void)hipFree(h->d_corpus);
     if (h->d_dead) (void)hipFree(h->d_dead);
     if (h->d_norms) (void)hipFree(h->d_norms);
+    if (h->d_split) (void)hipFree(h->d_split);
     delete h;
 }
 
@@ -476,11 +533,17 @@ int32_t cs_index_build(cs_index* h) {
     if (!h) return fail(CS_ERR_BAD_ARG, "null index handle");
     DeviceGuard g(h->device);
     CS_HIP(hipDeviceSynchronize());  // appended rows (incl. async device appends) are now visible
-    if (batched_supported(h->dim) && h->normed_rows < h->n_rows) {
+    if ((batched_supported(h->dim) || h->use_split) && h->normed_rows < h->n_rows) {
         CS_TRY(launch_row_norms(h->d_corpus, h->normed_rows, h->n_rows - h->normed_rows, h->dim,
                                 h->d_norms, nullptr));
         CS_HIP(hipDeviceSynchronize());
         h->normed_rows = h->n_rows;
+    }
+    if (h->use_split && h->split_rows < h->n_rows) {
+        CS_TRY(launch_corpus_split(h->d_corpus, h->d_norms, h->d_split, h->split_rows, h->n_rows - h->split_rows, h->dim,
+                                   nullptr));
+        CS_HIP(hipDeviceSynchronize());
+        h->split_rows = h->n_rows;
     }
     h->built = true;                 // store.rs:428
     return CS_OK;
@@ -494,6 +557,7 @@ int32_t cs_index_clear(cs_index* h) {
         CS_HIP(hipMemset(h->d_dead, 0, (size_t)((h->capacity + 31) / 32) * sizeof(uint32_t)));
     h->n_rows = 0;  // store.rs:701 next_id = 0
     h->normed_rows = 0;
+    h->split_rows = 0;
     h->n_removed = 0;
     h->h_dead.clear();
     h->built = false;  // store.rs:702

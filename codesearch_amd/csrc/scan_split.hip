@@ -1,0 +1,268 @@
+// scan_split.hip — batched-query cosine scan, filter-and-refine:
+//
+//   filter   score_split_kernel: [rows, dim] x [dim, Q] on the f16 MFMA with split-f16 operands
+//            (split_f16.hpp; 3/16 of the exact-f32 MFMA's matrix-pipe time), 128 rows x 128
+//            queries per block, never materialised.  Both operands are the UNIT vectors x/|x|,
+//            q/|q| (built once per build_index / per search), so the product is the approximate
+//            cosine itself whatever the rows' magnitudes; an element within kSplitMargin of the
+//            query's running k-th best (tau) is appended, as a row index, to that query's
+//            candidate buffer.
+//   refine   rescore_select_kernel: every candidate is re-scored from the f32 corpus row with the
+//            arithmetic of the single-query scan (scan.hip: 32 lanes x float4 partial fmaf
+//            chains, half-wave butterfly, correctly rounded sqrt and divide) and folded into the
+//            running best-k; tau becomes the exact k-th best of the rows scanned so far.
+//
+// The filter's error (split <= ~2e-6, normalisation ~1e-7, f32 accumulation order <= 2.3e-5 worst
+// case at dim 384) is inside the margin, so every row whose exact cosine beats tau is a candidate and the result
+// equals the exact scan's bit for bit — ids and cosines — at a fraction of its MFMA cost.
+// Phases (row-ordered, geometrically growing) and the overflow escape hatch are those of
+// scan_mfma.hip.  Serves `variants.par_iter().map(|e| store.search(e, limit))`
+// (/root/reference/src/search/mod.rs:508-511) and BASELINE.json configs 4/5.
+#include "scan.hpp"
+#include "split_f16.hpp"
+
+namespace cs {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr float kSplitMargin = 1.0e-4f;  // cosine units; filter error bound ~3e-5 worst case
+constexpr int RS_THREADS = 1024;
+constexpr int RS_CAP = 2048;
+
+__device__ __forceinline__ float half_sum_s(float v) {
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 8, 64);
+    v += __shfl_xor(v, 4, 64);
+    v += __shfl_xor(v, 2, 64);
+    v += __shfl_xor(v, 1, 64);
+    return v;
+}
+
+// |q| per query with the single-query scan's arithmetic (scan.hip, "query fragments + magnitudes").
+template <int J>
+__global__ void __launch_bounds__(256)
+query_mag_kernel(const float* __restrict__ queries, uint32_t nq, float* __restrict__ qmag) {
+    constexpr int DIM = 128 * J;
+    const int lane = threadIdx.x & 63, half = lane >> 5, l32 = lane & 31;
+    const uint32_t q = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 2 + half;
+    const uint32_t qq = q < nq ? q : nq - 1;
+    const f32x4* qp = reinterpret_cast<const f32x4*>(queries + (size_t)qq * DIM) + l32;
+    float s = 0.0f;
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        const f32x4 v = qp[j * 32];
+        s = fmaf(v.x, v.x, s); s = fmaf(v.y, v.y, s); s = fmaf(v.z, v.z, s); s = fmaf(v.w, v.w, s);
+    }
+    const float m = sqrtf(half_sum_s(s));
+    if (q < nq && l32 == 0) qmag[q] = m;
+}
+
+// grid = sh_grid_blocks(row tiles of the phase, query tiles); dynamic LDS = SH_LDS_BYTES.
+__global__ void __launch_bounds__(256, 2)
+score_split_kernel(const _Float16* __restrict__ corpus_s, uint64_t row_lo, uint64_t row_hi, uint32_t kchunks,
+                   const _Float16* __restrict__ queries_s, uint32_t nq, const float* __restrict__ tau, const uint32_t* __restrict__ dead,
+                   uint32_t* __restrict__ cand, uint32_t* __restrict__ cnt, uint32_t cap) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const uint32_t M = (uint32_t)(row_hi - row_lo);
+    uint32_t mt, nt;
+    if (!sh_tile_of_block(blockIdx.x, (M + SH_BM - 1) / SH_BM, (nq + SH_BN - 1) / SH_BN, mt, nt)) return;
+    const uint32_t m0 = mt * SH_BM, n0 = nt * SH_BN;
+    ShAcc acc;
+    sh_acc_zero(acc);
+    sh_mainloop(corpus_s + row_lo * kchunks * 64, M, m0, queries_s, nq, n0, kchunks, lds, acc);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1, l31 = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const uint32_t q = n0 + wc * 64 + j * 32 + l31;
+        const bool qok = q < nq;
+        // candidate <=> approx_cos > tau - margin, written so that NaN (a row holding NaN/Inf)
+        // counts as a candidate: refine decides
+        const float tq = qok ? tau[q] - kSplitMargin : 0.0f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const uint32_t m = m0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const float c = fmaf(acc.xx[i][j][r], kShLoInv, acc.hh[i][j][r]);
+                if (qok && m < M && !(c <= tq)) {  // rare, divergent, short
+                    const uint64_t row = row_lo + m;
+                    if (!dead || !((dead[row >> 5] >> (row & 31)) & 1u)) {
+                        const uint32_t pos = atomicAdd(&cnt[q], 1u);
+                        if (pos < cap) cand[(size_t)q * cap + pos] = (uint32_t)row;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// One block per query: exact cosines of its candidates (one half-wave per row, the layout and
+// operation order of scan_topk_kernel), folded into carry[q][k]; tau[q] = exact k-th best.
+template <int J>
+__global__ void __launch_bounds__(RS_THREADS)
+rescore_select_kernel(const float* __restrict__ corpus, const float* __restrict__ queries,
+                      const float* __restrict__ qmag, const uint32_t* __restrict__ cand,
+                      uint32_t* __restrict__ cnt, uint32_t cap, uint32_t k, uint32_t id_base,
+                      uint64_t* __restrict__ carry, float* __restrict__ tau,
+                      uint32_t* __restrict__ overflow, int final_out, uint64_t* __restrict__ out_keys,
+                      float* __restrict__ out_cos, uint32_t* __restrict__ out_ids,
+                      uint32_t* __restrict__ out_counts) {
+    constexpr int DIM = 128 * J;
+    __shared__ __attribute__((aligned(16))) uint64_t a[RS_CAP];
+    __shared__ uint32_t live;
+    const int tid = threadIdx.x, lane = tid & 63, l32 = lane & 31;
+    const uint32_t hw = tid >> 5;  // half-wave index, 0..31
+    const uint32_t q = blockIdx.x;
+    uint32_t n = cnt[q];
+    if (n > cap) {
+        if (tid == 0) atomicOr(overflow, 1u);
+        n = cap;
+    }
+    f32x4 qf[J];
+    {
+        const f32x4* qp = reinterpret_cast<const f32x4*>(queries + (size_t)q * DIM) + l32;
+#pragma unroll
+        for (int j = 0; j < J; ++j) qf[j] = qp[j * 32];
+    }
+    const float qm = qmag[q];
+    const uint32_t* src = cand + (size_t)q * cap;
+    for (uint32_t i = tid; i < RS_CAP; i += RS_THREADS) a[i] = (i < k) ? carry[(size_t)q * k + i] : 0ull;
+    if (tid == 0) live = 0;
+    __syncthreads();
+    const uint32_t room = RS_CAP - k;
+    for (uint32_t done = 0; done < n || done == 0; done += room) {
+        const uint32_t take = (n - done) < room ? (n - done) : room;
+        for (uint32_t i0 = 0; i0 < room; i0 += RS_THREADS / 32) {  // one candidate per half-wave per round
+            const uint32_t i = i0 + hw;
+            uint64_t key = 0ull;
+            if (i < take) {  // half-wave uniform (xor masks <= 16 stay inside the half)
+                const uint32_t row = src[done + i];
+                const f32x4* p = reinterpret_cast<const f32x4*>(corpus + (size_t)row * DIM) + l32;
+                float ss = 0.0f, dot = 0.0f;
+#pragma unroll
+                for (int j = 0; j < J; ++j) {
+                    const f32x4 v = p[j * 32];
+                    ss = fmaf(v.x, v.x, ss); ss = fmaf(v.y, v.y, ss);
+                    ss = fmaf(v.z, v.z, ss); ss = fmaf(v.w, v.w, ss);
+                    dot = fmaf(v.x, qf[j].x, dot); dot = fmaf(v.y, qf[j].y, dot);
+                    dot = fmaf(v.z, qf[j].z, dot); dot = fmaf(v.w, qf[j].w, dot);
+                }
+                const float xmag = sqrtf(half_sum_s(ss));
+                const float d = half_sum_s(dot);
+                const float c = (qm == 0.0f || xmag == 0.0f) ? 0.0f : d / (qm * xmag);  // batch.rs:320-323
+                // NaN/Inf scores are never returned
+                key = (c > -__builtin_huge_valf() && c < __builtin_huge_valf()) ? key_pack(c, id_base + row) : 0ull;
+            }
+            if (i < room && l32 == 0) a[k + i] = key;  // slots past `take` are cleared
+        }
+        // bitonic sort, descending, of the 2048 slots
+        for (uint32_t size = 2; size <= RS_CAP; size <<= 1)
+            for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+                __syncthreads();
+                for (uint32_t t = tid; t < RS_CAP / 2; t += RS_THREADS) {
+                    const uint32_t i = 2 * t - (t & (stride - 1)), jx = i + stride;
+                    const uint64_t x = a[i], y = a[jx];
+                    if ((x < y) == ((i & size) == 0)) { a[i] = y; a[jx] = x; }
+                }
+            }
+        __syncthreads();
+        if (n == 0) break;
+    }
+    for (uint32_t i = tid; i < k; i += RS_THREADS) {
+        const uint64_t key = a[i];
+        carry[(size_t)q * k + i] = key;
+        if (final_out) {
+            if (key) atomicAdd(&live, 1u);
+            if (out_keys) out_keys[(size_t)q * k + i] = key;
+            if (out_cos) out_cos[(size_t)q * k + i] = key ? key_cos(key) : 0.0f;
+            if (out_ids) out_ids[(size_t)q * k + i] = key ? key_id(key) : 0xffffffffu;
+        }
+    }
+    if (tid == 0) {
+        const uint64_t kth = a[k - 1];
+        tau[q] = kth ? key_cos(kth) : -__builtin_huge_valf();
+        cnt[q] = 0;
+    }
+    __syncthreads();
+    if (final_out && out_counts && tid == 0) out_counts[q] = live;
+}
+
+__global__ void init_split_state_kernel(float* tau, uint32_t* cnt, uint64_t* carry, uint32_t nq, uint32_t k,
+                                        uint32_t* overflow) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nq) { tau[i] = -__builtin_huge_valf(); cnt[i] = 0; }
+    if (i < nq * k) carry[i] = 0ull;
+    if (i == 0) *overflow = 0;
+}
+
+// ---- host side ----------------------------------------------------------------------------
+
+bool split_scan_supported(uint32_t dim) { return dim == 384 || dim == 768 || dim == 1024; }
+
+int32_t launch_corpus_split(const float* d_corpus, const float* d_norms, _Float16* d_split, uint64_t first,
+                            uint64_t n, uint32_t dim, hipStream_t stream) {
+    return launch_split_rows(d_corpus + first * dim, d_split + first * dim * 2, n, dim, nullptr, stream,
+                             d_norms + first);
+}
+
+template <int J>
+static int32_t scan_split_impl(const BatchedState& st, const SplitQueryWs& qw, const float* d_corpus,
+                               const _Float16* d_split, uint64_t n_rows, const float* d_queries, uint32_t nq, uint32_t k, const uint32_t* d_dead,
+                               uint32_t id_base, uint64_t* d_out_keys, float* d_out_cos,
+                               uint32_t* d_out_ids, uint32_t* d_out_counts, hipStream_t stream) {
+    constexpr uint32_t dim = 128 * J;
+    const uint32_t cap = batched_cap(k);
+    static bool attr_set = false;
+    if (!attr_set) {
+        CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(score_split_kernel),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, SH_LDS_BYTES));
+        attr_set = true;
+    }
+    {
+        const uint32_t n = nq * k > nq ? nq * k : nq;
+        hipLaunchKernelGGL(init_split_state_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, st.d_tau, st.d_cnt,
+                           st.d_carry, nq, k, st.d_overflow);
+    }
+    hipLaunchKernelGGL(query_mag_kernel<J>, dim3((nq + 7) / 8), dim3(256), 0, stream, d_queries, nq, qw.d_qmag);
+    CS_TRY(launch_split_rows(d_queries, qw.d_qsplit, nq, dim, nullptr, stream, qw.d_qmag));
+    uint32_t* cand = reinterpret_cast<uint32_t*>(st.d_cand);
+    const uint32_t ntiles = (nq + SH_BN - 1) / SH_BN;
+    uint64_t done = 0;
+    uint64_t phase = n_rows < 1024 ? n_rows : 1024;  // phase 0: tau = -inf, every row is a candidate
+    const uint32_t growth = 16;
+    do {
+        const uint64_t lo = done, hi = done + phase;
+        if (hi > lo) {
+            const uint32_t mtiles = (uint32_t)((hi - lo + SH_BM - 1) / SH_BM);
+            hipLaunchKernelGGL(score_split_kernel, dim3(sh_grid_blocks(mtiles, ntiles)), dim3(256), SH_LDS_BYTES, stream,
+                               d_split, lo, hi, dim / 32, qw.d_qsplit, nq, st.d_tau, d_dead, cand, st.d_cnt, cap);
+            CS_HIP(hipGetLastError());
+        }
+        done = hi;
+        const bool last = done >= n_rows;
+        hipLaunchKernelGGL(rescore_select_kernel<J>, dim3(nq), dim3(RS_THREADS), 0, stream, d_corpus, d_queries,
+                           qw.d_qmag, cand, st.d_cnt, cap, k, id_base, st.d_carry, st.d_tau, st.d_overflow,
+                           last ? 1 : 0, d_out_keys, d_out_cos, d_out_ids, d_out_counts);
+        CS_HIP(hipGetLastError());
+        phase = done * growth;
+        if (phase > n_rows - done) phase = n_rows - done;
+    } while (done < n_rows);
+    return CS_OK;
+}
+
+int32_t launch_scan_split(const BatchedState& st, const SplitQueryWs& qw, const float* d_corpus,
+                          const _Float16* d_split, uint64_t n_rows, uint32_t dim, const float* d_queries, uint32_t nq, uint32_t k, const uint32_t* d_dead,
+                          uint32_t id_base, uint64_t* d_out_keys, float* d_out_cos, uint32_t* d_out_ids,
+                          uint32_t* d_out_counts, hipStream_t stream) {
+#define CS_SPLIT_ARGS st, qw, d_corpus, d_split, n_rows, d_queries, nq, k, d_dead, id_base, d_out_keys, \
+                      d_out_cos, d_out_ids, d_out_counts, stream
+    if (dim == 384) return scan_split_impl<3>(CS_SPLIT_ARGS);
+    if (dim == 768) return scan_split_impl<6>(CS_SPLIT_ARGS);
+    if (dim == 1024) return scan_split_impl<8>(CS_SPLIT_ARGS);
+#undef CS_SPLIT_ARGS
+    return fail(CS_ERR_UNSUPPORTED, "split scan supports dim 384/768/1024, got %u", dim);
+}
+
+}  // namespace cs

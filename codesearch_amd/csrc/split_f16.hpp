@@ -179,8 +179,9 @@ __device__ __forceinline__ bool sh_tile_of_block(uint32_t b, uint32_t mtiles, ui
 inline uint32_t sh_grid_blocks(uint32_t mtiles, uint32_t ntiles) { return ((mtiles + 7) / 8) * 8 * ntiles; }
 
 // ---- host-visible launchers (gemm_split.hip) ----------------------------------------------
-// rows x K f32 -> split layout; flag (device u32, may be null) is OR-ed with 1 on overflow.
+// rows x K f32 -> split layout; flag (device u32, may be null) is OR-ed with 1 on overflow;
+// d_row_norm (may be null): row r is divided by d_row_norm[r] first (zero norm -> zero row).
 int32_t launch_split_rows(const float* d_src, _Float16* d_dst, uint64_t rows, uint32_t K, uint32_t* d_flag,
-                          hipStream_t s);
+                          hipStream_t s, const float* d_row_norm = nullptr);
 
 }  // namespace cs

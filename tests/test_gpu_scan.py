@@ -375,6 +375,73 @@ def test_mfma_batched_10m_equals_single_query_scans(VS):
         for i in list(range(0, nq, 9)) + [nq - 1]:
             c1, i1, _ = st.search_raw(qs[i], k)
             assert ids[i].tolist() == i1[0].tolist()
-            np.testing.assert_allclose(cos[i], c1[0], atol=COS_TOL)
+            assert cos[i].tobytes() == c1[0].tobytes()  # refine = the single-query arithmetic
     b, f = st.debug_counters()
     assert b == 2 and f == 0
+
+
+# ---- batched queries: filter (split-f16 MFMA) + exact refine (scan_split.hip) ---------------------
+
+@pytest.mark.parametrize("dim,n,nq,k", [(384, 50_000, 130, 10), (768, 20_001, 9, 25), (1024, 10_000, 33, 10),
+                                        (384, 1000, 5, 256)])
+def test_split_batched_path_is_bit_identical_to_single_query_scan(VS, dim, n, nq, k):
+    """The refine step re-scores candidates with the single-query scan's arithmetic, so a batched
+    search returns the same bits — ids AND cosines — as nq independent searches."""
+    st = VS(None, dim)
+    st.insert_synthetic(n, 4242 + dim, 0)
+    st.delete_chunks([1, n // 2])
+    st.build_index()
+    qs = np.concatenate([synth_rows(77 + nq, 0, nq - 1, dim), synth_planted(4242 + dim, 5, [n // 4], dim)])
+    cos, ids, counts = st.search_raw(qs, k)
+    assert st.debug_counters() == (1, 0)
+    for i in range(nq):
+        c1, i1, n1 = st.search_raw(qs[i], k)
+        assert counts[i] == n1[0]
+        assert ids[i].tolist() == i1[0].tolist()
+        assert cos[i].tobytes() == c1[0].tobytes()
+    assert ids[nq - 1][0] == n // 4
+
+
+def test_split_batched_path_any_row_magnitude(VS, oracle):
+    """The filter works on unit vectors, so rows far outside the f16 range (1e6), far below it
+    (1e-9), zero rows and NaN/Inf rows are all handled exactly as by the single-query scan."""
+    dim, n, nq, k = 384, 4000, 6, 12
+    corpus = oracle.synth_rows(31, 0, n, dim).copy()
+    scale = np.ones(n, np.float32)
+    scale[0::7] = 1e6
+    scale[1::7] = 1e-9
+    scale[2::7] = 3e-5
+    corpus *= scale[:, None]
+    corpus[10] = 0.0
+    corpus[11, 5] = np.nan
+    corpus[12, 6] = np.inf
+    st = VS(None, dim)
+    st.insert_embeddings(corpus)
+    st.build_index()
+    qs = synth_rows(32, 0, nq, dim) * np.float32(250.0)
+    qs[1] *= np.float32(1e-7)
+    cos, ids, counts = st.search_raw(qs, k)
+    assert st.debug_counters() == (1, 0)
+    for i in range(nq):
+        c1, i1, n1 = st.search_raw(qs[i], k)
+        assert counts[i] == n1[0] and ids[i].tolist() == i1[0].tolist() and cos[i].tobytes() == c1[0].tobytes()
+        ok = [r for r in range(n) if r not in (11, 12)]
+        ecos, eids = oracle.scan_topk(corpus[ok], qs[i], k, mode="omp")
+        assert_topk_equal(cos[i], ids[i], ecos, np.asarray(ok)[eids], corpus, qs[i], oracle)
+
+
+def test_f32_mfma_batched_path_still_available(VS, oracle, monkeypatch):
+    """CS_INDEX_SPLIT=0 keeps the batched path on the exact-f32 MFMA kernels (no second copy of
+    the corpus in HBM)."""
+    monkeypatch.setenv("CS_INDEX_SPLIT", "0")
+    dim, n, nq, k = 384, 5000, 33, 25
+    corpus = oracle.synth_rows(933, 0, n, dim)
+    st = VS(None, dim)
+    st.insert_embeddings(corpus)
+    st.build_index()
+    qs = synth_rows(934, 0, nq, dim)
+    cos, ids, counts = st.search_raw(qs, k)
+    assert st.debug_counters() == (1, 0)
+    for i in range(nq):
+        ecos, eids = oracle.scan_topk(corpus, qs[i], k, mode="omp")
+        assert_topk_equal(cos[i], ids[i], ecos, eids, corpus, qs[i], oracle)
