@@ -638,7 +638,7 @@ int32_t launch_attention(const float* qkv, const int32_t* mask, float* ctx, uint
 
 int32_t launch_attention_split(const float* qkv, const int32_t* mask, void* ctx_split, uint32_t* flag, uint32_t B,
                                uint32_t L, uint32_t H, uint32_t heads, hipStream_t s) {
-    return launch_attention_impl(qkv, mask, nullptr, static_cast<_Float16*>(ctx_split), flag, B, L, H, heads, s);
+    return launch_attention_sh(qkv, mask, nullptr, ctx_split, flag, B, L, H, heads, s);
 }
 
 int32_t launch_synth_params(float* d_out, const cs_bert_config& cfg, uint64_t seed, hipStream_t s) {

@@ -39,6 +39,11 @@ int32_t launch_attention(const float* qkv, const int32_t* mask, float* ctx, uint
 int32_t launch_attention_split(const float* qkv, const int32_t* mask, void* ctx_split, uint32_t* flag, uint32_t B,
                                uint32_t L, uint32_t H, uint32_t heads, hipStream_t s);
 size_t attention_lds_bytes(uint32_t L);
+// attention_split.hip: the same attention on the f16 MFMA with split-f16 operands; writes ctx (f32)
+// or, when ctx_split is given, the split form.
+int32_t launch_attention_sh(const float* qkv, const int32_t* mask, float* ctx, void* ctx_split, uint32_t* flag,
+                            uint32_t B, uint32_t L, uint32_t H, uint32_t heads, hipStream_t s);
+size_t attention_sh_lds_bytes(uint32_t L);
 
 // Split-f16 GEMM (gemm_split.hip): A [M][K/32][64] f16, W [N][K/32][64] f16 (split_f16.hpp).
 enum { SH_OUT_F32 = 0, SH_OUT_F32_RESID = 1, SH_OUT_SPLIT_GELU = 2 };
