@@ -24,6 +24,9 @@ struct cs_embedder {
     int gemm_mode = CS_GEMM_SPLIT_F16;
     uint64_t split_forwards = 0, f32_forwards = 0, range_fallbacks = 0;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;     // second half of a mini-batch runs here (see forward())
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    int n_streams = 2;
     size_t cap_tokens = 0, cap_seqs = 0;
     int32_t* d_ids = nullptr;
     int32_t* d_mask = nullptr;
@@ -85,26 +88,31 @@ SplitLayer split_layer(const cs_bert_config& c) {
     return o;
 }
 
-// One mini-batch already on the device (d_ids/d_mask) -> d_pooled [B, H].
-int32_t forward(cs_embedder* h, uint32_t B, uint32_t L, int mode) {
+// Sequences [b0, b0 + nb) of the mini-batch on stream s.  Every kernel but attention is local to
+// a token row and attention is local to a sequence, so a range of sequences is an independent job
+// on the same buffers at a token offset.
+int32_t forward_range(cs_embedder* h, hipStream_t s, uint32_t b0, uint32_t nb, uint32_t L, int mode) {
     const cs_bert_config& c = h->cfg;
-    const uint32_t H = c.hidden, I = c.intermediate, T = B * L;
+    const uint32_t H = c.hidden, I = c.intermediate, T = nb * L;
+    const size_t t0 = (size_t)b0 * L;
     const float* P = h->d_params;
-    hipStream_t s = h->stream;
     const bool split = mode == CS_GEMM_SPLIT_F16;
-    CS_HIP(hipEventRecord(h->ev0, s));
-    if (split) CS_HIP(hipMemsetAsync(h->d_flag, 0, sizeof(uint32_t), s));
+    float* x = h->d_x + t0 * H;
+    float* qkv = h->d_qkv + t0 * 3 * H;
+    float* ctx = h->d_ctx + t0 * H;
+    float* mid = h->d_mid + t0 * I;
+    const int32_t* mask = h->d_mask + t0;
     EncoderLaunch a;
-    a.ids = h->d_ids; a.mask = h->d_mask;
+    a.ids = h->d_ids + t0; a.mask = mask;
     a.word = P + h->off.word; a.pos = P + h->off.pos; a.type0 = P + h->off.type;
     a.g = P + h->off.emb_ln_g; a.b = P + h->off.emb_ln_b;
-    a.eps = c.layer_norm_eps; a.T = T; a.L = L; a.B = B; a.vocab = c.vocab_size;
-    a.pooling = c.pooling; a.x = h->d_x; a.out = h->d_pooled;
-    a.xs = split ? h->d_xs : nullptr;
+    a.eps = c.layer_norm_eps; a.T = T; a.L = L; a.B = nb; a.vocab = c.vocab_size;
+    a.pooling = c.pooling; a.x = x; a.out = h->d_pooled + (size_t)b0 * H;
+    a.xs = split ? (void*)(h->d_xs + t0 * H) : nullptr;
     a.flag = h->d_flag;
-    _Float16* xs = reinterpret_cast<_Float16*>(h->d_xs);
-    _Float16* ctxs = reinterpret_cast<_Float16*>(h->d_ctx);
-    _Float16* mids = reinterpret_cast<_Float16*>(h->d_mid);
+    _Float16* xs = reinterpret_cast<_Float16*>(h->d_xs + t0 * H);
+    _Float16* ctxs = reinterpret_cast<_Float16*>(ctx);
+    _Float16* mids = reinterpret_cast<_Float16*>(mid);
     const SplitLayer sl = split_layer(c);
     CS_TRY(launch_row_kernel(0, a, H, s));  // E1
     for (uint32_t l = 0; l < c.layers; ++l) {
@@ -113,29 +121,51 @@ int32_t forward(cs_embedder* h, uint32_t B, uint32_t L, int mode) {
         const float* bqkv = h->d_bqkv + (size_t)l * 3 * H;
         if (split) {
             const _Float16* ws = h->d_wsplit + (size_t)l * sl.total;
-            CS_TRY(launch_gemm_split(SH_OUT_F32, xs, ws + sl.qkv, bqkv, nullptr, h->d_qkv, nullptr, T, 3 * H, H, h->d_flag, s));   // E2
-            CS_TRY(launch_attention_split(h->d_qkv, h->d_mask, ctxs, h->d_flag, B, L, H, c.heads, s));                            // E3
-            CS_TRY(launch_gemm_split(SH_OUT_F32_RESID, ctxs, ws + sl.ao, P + lo.ao_b, h->d_x, h->d_x, nullptr, T, H, H, h->d_flag, s));  // E4
+            CS_TRY(launch_gemm_split(SH_OUT_F32, xs, ws + sl.qkv, bqkv, nullptr, qkv, nullptr, T, 3 * H, H, h->d_flag, s));   // E2
+            CS_TRY(launch_attention_split(qkv, mask, ctxs, h->d_flag, nb, L, H, c.heads, s));                              // E3
+            CS_TRY(launch_gemm_split(SH_OUT_F32_RESID, ctxs, ws + sl.ao, P + lo.ao_b, x, x, nullptr, T, H, H, h->d_flag, s));  // E4
             a.g = P + lo.ao_ln_g; a.b = P + lo.ao_ln_b;
             CS_TRY(launch_row_kernel(1, a, H, s));
             CS_TRY(launch_gemm_split(SH_OUT_SPLIT_GELU, xs, ws + sl.up, P + lo.up_b, nullptr, nullptr, mids, T, I, H, h->d_flag, s));    // E5
-            CS_TRY(launch_gemm_split(SH_OUT_F32_RESID, mids, ws + sl.down, P + lo.down_b, h->d_x, h->d_x, nullptr, T, H, I, h->d_flag, s)); // E6
+            CS_TRY(launch_gemm_split(SH_OUT_F32_RESID, mids, ws + sl.down, P + lo.down_b, x, x, nullptr, T, H, I, h->d_flag, s)); // E6
             a.g = P + lo.out_ln_g; a.b = P + lo.out_ln_b;
             CS_TRY(launch_row_kernel(1, a, H, s));
         } else {
             const float* wqkv = h->d_wqkv + (size_t)l * 3 * H * H;
-            CS_TRY(launch_gemm(GEMM_BIAS, h->d_x, wqkv, bqkv, nullptr, h->d_qkv, T, 3 * H, H, s));        // E2
-            CS_TRY(launch_attention(h->d_qkv, h->d_mask, h->d_ctx, B, L, H, c.heads, s));                 // E3
-            CS_TRY(launch_gemm(GEMM_RESID, h->d_ctx, P + lo.ao_w, P + lo.ao_b, h->d_x, h->d_x, T, H, H, s)); // E4
+            CS_TRY(launch_gemm(GEMM_BIAS, x, wqkv, bqkv, nullptr, qkv, T, 3 * H, H, s));        // E2
+            CS_TRY(launch_attention(qkv, mask, ctx, nb, L, H, c.heads, s));                     // E3
+            CS_TRY(launch_gemm(GEMM_RESID, ctx, P + lo.ao_w, P + lo.ao_b, x, x, T, H, H, s));   // E4
             a.g = P + lo.ao_ln_g; a.b = P + lo.ao_ln_b;
             CS_TRY(launch_row_kernel(1, a, H, s));
-            CS_TRY(launch_gemm(GEMM_GELU, h->d_x, P + lo.up_w, P + lo.up_b, nullptr, h->d_mid, T, I, H, s)); // E5
-            CS_TRY(launch_gemm(GEMM_RESID, h->d_mid, P + lo.down_w, P + lo.down_b, h->d_x, h->d_x, T, H, I, s)); // E6
+            CS_TRY(launch_gemm(GEMM_GELU, x, P + lo.up_w, P + lo.up_b, nullptr, mid, T, I, H, s)); // E5
+            CS_TRY(launch_gemm(GEMM_RESID, mid, P + lo.down_w, P + lo.down_b, x, x, T, H, I, s));  // E6
             a.g = P + lo.out_ln_g; a.b = P + lo.out_ln_b;
             CS_TRY(launch_row_kernel(1, a, H, s));
         }
     }
     CS_TRY(launch_row_kernel(2, a, H, s));  // E7 + E8
+    return CS_OK;
+}
+
+// One mini-batch already on the device (d_ids/d_mask) -> d_pooled [B, H].  The batch is cut into
+// two halves on two streams: each kernel alternates an MFMA-bound main loop with an HBM-bound
+// epilogue (and attention / LayerNorm are memory-heavy throughout), so blocks of two different
+// kernels sharing a CU keep both the matrix pipe and the memory system busy.
+int32_t forward(cs_embedder* h, uint32_t B, uint32_t L, int mode) {
+    hipStream_t s = h->stream;
+    CS_HIP(hipEventRecord(h->ev0, s));
+    if (mode == CS_GEMM_SPLIT_F16) CS_HIP(hipMemsetAsync(h->d_flag, 0, sizeof(uint32_t), s));
+    if (h->n_streams >= 2 && B >= 2) {
+        const uint32_t b1 = B / 2;
+        CS_HIP(hipEventRecord(h->ev_fork, s));
+        CS_HIP(hipStreamWaitEvent(h->stream2, h->ev_fork, 0));
+        CS_TRY(forward_range(h, h->stream2, b1, B - b1, L, mode));
+        CS_HIP(hipEventRecord(h->ev_join, h->stream2));
+        CS_TRY(forward_range(h, s, 0, b1, L, mode));
+        CS_HIP(hipStreamWaitEvent(s, h->ev_join, 0));
+    } else {
+        CS_TRY(forward_range(h, s, 0, B, L, mode));
+    }
     CS_HIP(hipEventRecord(h->ev1, s));
     h->last_B = B;
     h->last_L = L;
@@ -254,6 +284,9 @@ int32_t cs_embedder_create(const cs_bert_config* cfg, const float* params, uint6
     const size_t H = cfg->hidden;
     auto cleanup = [&](int32_t s) { cs_embedder_destroy(h); return s; };
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess ||
         hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess)
         return cleanup(fail(CS_ERR_HIP, "could not create stream/events"));
     if (hipMalloc(&h->d_params, h->off.total * sizeof(float)) != hipSuccess ||
@@ -305,6 +338,7 @@ int32_t cs_embedder_create(const cs_bert_config* cfg, const float* params, uint6
         if (const char* env = std::getenv("CS_ENCODER_GEMM"))
             h->gemm_mode = (std::strcmp(env, "f32") == 0) ? CS_GEMM_F32 : CS_GEMM_SPLIT_F16;
         if (wflag) h->gemm_mode = CS_GEMM_F32;  // a weight outside the f16 range: exact path only
+        if (const char* env = std::getenv("CS_ENCODER_STREAMS")) h->n_streams = std::atoi(env) >= 2 ? 2 : 1;
     }
     if (s == CS_OK && hipStreamSynchronize(h->stream) != hipSuccess) s = fail(CS_ERR_HIP, "parameter setup failed");
     if (s != CS_OK) return cleanup(s);
@@ -316,6 +350,7 @@ void cs_embedder_destroy(cs_embedder* h) {
     if (!h) return;
     DeviceGuard g(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
+    if (h->stream2) (void)hipStreamSynchronize(h->stream2);
     free_workspace(h);
     if (h->d_params) (void)hipFree(h->d_params);
     if (h->d_wqkv) (void)hipFree(h->d_wqkv);
@@ -324,6 +359,9 @@ void cs_embedder_destroy(cs_embedder* h) {
     if (h->d_flag) (void)hipFree(h->d_flag);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
+    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+    if (h->ev_join) (void)hipEventDestroy(h->ev_join);
+    if (h->stream2) (void)hipStreamDestroy(h->stream2);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }

@@ -7,8 +7,16 @@
 // staged through LDS so every global access of the epilogue is a full 16 B per lane on
 // consecutive lanes.  Replaces the fp32 arithmetic ONNX Runtime does for
 // /root/reference/src/embed/embedder.rs:286-289 to within ~3 * 2^-22 per product.
+#include <cstdlib>
+
 #include "encoder.hpp"
 #include "split_f16.hpp"
+
+// Diagnostic builds (benchmarks/gemm_probe.hip) define SH_STAMP to record s_memtime at five points
+// of a block's life; the product build compiles it to nothing.
+#ifndef SH_STAMP
+#define SH_STAMP(i)
+#endif
 
 namespace cs {
 
@@ -16,7 +24,7 @@ __device__ __forceinline__ float sh_gelu_erf(float v) {
     return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
 }
 
-template <int EPI, bool FULL>
+template <int EPI, bool FULL, int WM>
 __device__ __forceinline__ void gemm_sh_epilogue(const float* ctile, const float* __restrict__ bias,
                                                  const float* resid, float* C, _Float16* __restrict__ Cs,
                                                  uint32_t M, uint32_t N, uint32_t m0, uint32_t n0,
@@ -30,7 +38,7 @@ __device__ __forceinline__ void gemm_sh_epilogue(const float* ctile, const float
         const size_t nchunks = N / 32;
 #pragma unroll
         for (int it = 0; it < 8; ++it) {
-            const int row = (tid >> 4) + 16 * it;
+            const int row = (tid >> 4) + 8 * WM * it;
             const sh_f32x4 v0 = *reinterpret_cast<const sh_f32x4*>(ctile + row * 128 + c8 * 8);
             const sh_f32x4 v1 = *reinterpret_cast<const sh_f32x4*>(ctile + row * 128 + c8 * 8 + 4);
             f16x8 hi, lo;
@@ -58,13 +66,13 @@ __device__ __forceinline__ void gemm_sh_epilogue(const float* ctile, const float
             if (EPI == SH_OUT_F32_RESID) {
 #pragma unroll
                 for (int it = 0; it < 8; ++it) {
-                    const uint32_t row = m0 + (tid >> 5) + 8 * (half * 8 + it);
+                    const uint32_t row = m0 + (tid >> 5) + 4 * WM * (half * 8 + it);
                     rs[it] = *reinterpret_cast<const sh_f32x4*>(resid + (size_t)((FULL || row < M) ? row : M - 1) * N + n0 + c4 * 4);
                 }
             }
 #pragma unroll
             for (int it = 0; it < 8; ++it) {
-                const int row = (tid >> 5) + 8 * (half * 8 + it);
+                const int row = (tid >> 5) + 4 * WM * (half * 8 + it);
                 sh_f32x4 v = *reinterpret_cast<const sh_f32x4*>(ctile + row * 128 + c4 * 4);
                 v += bv;
                 if (EPI == SH_OUT_F32_RESID) v += rs[it];
@@ -84,16 +92,41 @@ gemm_sh_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ W,
     uint32_t mt, nt;
     if (!sh_tile_of_block(blockIdx.x, (M + SH_BM - 1) / SH_BM, N / SH_BN, mt, nt)) return;
     const uint32_t m0 = mt * SH_BM, n0 = nt * SH_BN;
+    SH_STAMP(0);
     ShAcc acc;
     sh_acc_zero(acc);
     sh_mainloop(A, M, m0, W, N, n0, kchunks, lds, acc);
+    SH_STAMP(1);
     float* ctile = reinterpret_cast<float*>(lds);
     sh_acc_to_lds(acc, ctile);
+    SH_STAMP(2);
 
     // Full tiles take a branch-free path (a per-row `if (row < M)` makes hipcc drain vmcnt
     // around every store); the ragged last m-tile takes the guarded one.
-    if (m0 + SH_BM <= M) gemm_sh_epilogue<EPI, true>(ctile, bias, resid, C, Cs, M, N, m0, n0, flag);
-    else gemm_sh_epilogue<EPI, false>(ctile, bias, resid, C, Cs, M, N, m0, n0, flag);
+    if (m0 + SH_BM <= M) gemm_sh_epilogue<EPI, true, 2>(ctile, bias, resid, C, Cs, M, N, m0, n0, flag);
+    else gemm_sh_epilogue<EPI, false, 2>(ctile, bias, resid, C, Cs, M, N, m0, n0, flag);
+    SH_STAMP(3);
+}
+
+// 256 x 128 tiles, 8 waves, 3-stage LDS-DMA ring (sh_mainloop3<4>), one block per CU.
+template <int EPI>
+__global__ void __launch_bounds__(512, 2)
+gemm_sh3_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ W,
+                const float* __restrict__ bias, const float* resid, float* C,
+                _Float16* __restrict__ Cs, uint32_t M, uint32_t N, uint32_t kchunks,
+                uint32_t* __restrict__ flag) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    using G = ShGeom<4>;
+    uint32_t mt, nt;
+    if (!sh_tile_of_block(blockIdx.x, (M + G::BM - 1) / G::BM, N / SH_BN, mt, nt)) return;
+    const uint32_t m0 = mt * G::BM, n0 = nt * SH_BN;
+    ShAcc acc;
+    sh_acc_zero(acc);
+    sh_mainloop3<4>(A, M, m0, W, N, n0, kchunks, lds, acc);
+    float* ctile = reinterpret_cast<float*>(lds);  // [256][128] f32 = 128 KiB of the 144 KiB ring
+    sh_acc_to_lds(acc, ctile);
+    if (m0 + G::BM <= M) gemm_sh_epilogue<EPI, true, 4>(ctile, bias, resid, C, Cs, M, N, m0, n0, flag);
+    else gemm_sh_epilogue<EPI, false, 4>(ctile, bias, resid, C, Cs, M, N, m0, n0, flag);
 }
 
 // rows x K f32 -> split layout; one thread per 8 consecutive k.  With row_norm, row r is divided
@@ -155,8 +188,29 @@ int32_t launch_gemm_split(int epi, const _Float16* A, const _Float16* W, const f
         CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_sh_kernel<SH_OUT_SPLIT_GELU>), hipFuncAttributeMaxDynamicSharedMemorySize, SH_LDS_BYTES));
         attr_set = true;
     }
-    const dim3 grid(sh_grid_blocks((M + SH_BM - 1) / SH_BM, N / SH_BN));
     const uint32_t kc = K / 32;
+    static int tile = -1;
+    if (tile < 0) {
+        const char* e = std::getenv("CS_GEMM_TILE");  // 128 (default): 128x128 tiles, 2 blocks/CU; 256: 256x128, 3-stage ring
+        tile = (e && std::atoi(e) == 256) ? 256 : 128;
+    }
+    if (tile == 256) {
+        using G = ShGeom<4>;
+        static bool attr3 = false;
+        if (!attr3) {
+            CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_sh3_kernel<SH_OUT_F32>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
+            CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_sh3_kernel<SH_OUT_F32_RESID>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
+            CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_sh3_kernel<SH_OUT_SPLIT_GELU>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
+            attr3 = true;
+        }
+        const dim3 grid3(sh_grid_blocks((M + G::BM - 1) / G::BM, N / SH_BN));
+        if (epi == SH_OUT_F32) hipLaunchKernelGGL(gemm_sh3_kernel<SH_OUT_F32>, grid3, dim3(G::THREADS), G::LDS, s, A, W, bias, resid, C, Cs, M, N, kc, d_flag);
+        else if (epi == SH_OUT_F32_RESID) hipLaunchKernelGGL(gemm_sh3_kernel<SH_OUT_F32_RESID>, grid3, dim3(G::THREADS), G::LDS, s, A, W, bias, resid, C, Cs, M, N, kc, d_flag);
+        else hipLaunchKernelGGL(gemm_sh3_kernel<SH_OUT_SPLIT_GELU>, grid3, dim3(G::THREADS), G::LDS, s, A, W, bias, resid, C, Cs, M, N, kc, d_flag);
+        CS_HIP(hipGetLastError());
+        return CS_OK;
+    }
+    const dim3 grid(sh_grid_blocks((M + SH_BM - 1) / SH_BM, N / SH_BN));
     if (epi == SH_OUT_F32) hipLaunchKernelGGL(gemm_sh_kernel<SH_OUT_F32>, grid, dim3(256), SH_LDS_BYTES, s, A, W, bias, resid, C, Cs, M, N, kc, d_flag);
     else if (epi == SH_OUT_F32_RESID) hipLaunchKernelGGL(gemm_sh_kernel<SH_OUT_F32_RESID>, grid, dim3(256), SH_LDS_BYTES, s, A, W, bias, resid, C, Cs, M, N, kc, d_flag);
     else hipLaunchKernelGGL(gemm_sh_kernel<SH_OUT_SPLIT_GELU>, grid, dim3(256), SH_LDS_BYTES, s, A, W, bias, resid, C, Cs, M, N, kc, d_flag);

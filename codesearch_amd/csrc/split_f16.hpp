@@ -139,6 +139,150 @@ __device__ __forceinline__ void sh_mainloop(const _Float16* __restrict__ A, uint
     }
 }
 
+// ---- 3-stage variant: (64*WM) x 128 x 32 tiles, 2*WM waves, up to 3 stages in flight ----------
+// WM = 4: 256 x 128 tile, 8 waves (two per SIMD), one block per CU: 1.33x the MFMA work per byte
+// staged into LDS of the 128 x 128 tile, and the LDS-DMA of stages k+1 and k+2 stays in flight
+// under the MFMAs of stage k (counted vmcnt, raw s_barrier: cdna_hip_programming.md §5
+// "Pipelining across barriers").  One barrier per k-step: it publishes stage k (each wave has
+// waited for its own pieces) and retires every read of stage k-1, whose buffer the loads issued
+// right after it overwrite.
+template <int WM>
+struct ShGeom {
+    static constexpr int WAVES = 2 * WM;
+    static constexpr int THREADS = 64 * WAVES;
+    static constexpr int BM = 64 * WM;
+    static constexpr int A_BYTES = BM * 128;
+    static constexpr int W_BYTES = 128 * 128;
+    static constexpr int STAGE = A_BYTES + W_BYTES;
+    static constexpr int NSTAGE = 3;
+    static constexpr int LDS = NSTAGE * STAGE;
+    static constexpr int A_PER_WAVE = (BM / 8) / WAVES;   // glds instructions per wave per stage
+    static constexpr int W_PER_WAVE = 16 / WAVES;
+    static constexpr int NL = A_PER_WAVE + W_PER_WAVE;
+};
+
+template <int N>
+__device__ __forceinline__ void sh_wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int WM>
+__device__ __forceinline__ void sh_mainloop3(const _Float16* __restrict__ A, uint32_t M, uint32_t m0,
+                                             const _Float16* __restrict__ W, uint32_t N, uint32_t n0,
+                                             uint32_t kchunks, char* lds, ShAcc& acc) {
+    using G = ShGeom<WM>;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    const int l31 = lane & 31, h = lane >> 5;
+
+    const _Float16* asrc[G::A_PER_WAVE];
+    const _Float16* wsrc[G::W_PER_WAVE];
+#pragma unroll
+    for (int i = 0; i < G::A_PER_WAVE; ++i) {
+        const int row = (wave * G::A_PER_WAVE + i) * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((row >> 1) & 7);
+        const uint32_t am = (m0 + row < M) ? m0 + row : M - 1;
+        asrc[i] = A + (size_t)am * kchunks * 64 + c * 8;
+    }
+#pragma unroll
+    for (int i = 0; i < G::W_PER_WAVE; ++i) {
+        const int row = (wave * G::W_PER_WAVE + i) * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((row >> 1) & 7);
+        const uint32_t wn = (n0 + row < N) ? n0 + row : N - 1;
+        wsrc[i] = W + (size_t)wn * kchunks * 64 + c * 8;
+    }
+    auto stage = [&](uint32_t kc, char* buf) {
+#pragma unroll
+        for (int i = 0; i < G::A_PER_WAVE; ++i)
+            sh_glds16(asrc[i] + (size_t)kc * 64, buf + (wave * G::A_PER_WAVE + i) * 1024);
+#pragma unroll
+        for (int i = 0; i < G::W_PER_WAVE; ++i)
+            sh_glds16(wsrc[i] + (size_t)kc * 64, buf + G::A_BYTES + (wave * G::W_PER_WAVE + i) * 1024);
+    };
+
+    const int swz = (l31 >> 1) & 7;
+    const int arow = (wr * 64 + l31) * 128, wrow = G::A_BYTES + (wc * 64 + l31) * 128;
+    int sl_hi[2], sl_lo[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        sl_hi[s] = ((2 * s + h) ^ swz) * 16;
+        sl_lo[s] = ((4 + 2 * s + h) ^ swz) * 16;
+    }
+
+    // Fragment sets are double-buffered in registers: the reads of the next k16-step are in
+    // flight under the 12 MFMAs of the current one, and the k-step barrier sits between the two
+    // MFMA groups of a stage, so a wave never parks on LDS latency with its matrix pipe idle.
+    // The reads are inline asm with hand-counted lgkmcnt (hipcc's own bookkeeping waits
+    // lgkmcnt(0) for loop-carried LDS loads, which would expose the whole latency every k-step;
+    // cdna_hip_programming.md §5.7 form (iii): "=v" loads, wait-only statement, sched_barrier).
+    struct Frags { f16x8 ah[2], al[2], wh[2], wl[2]; };
+    const uint32_t lds_base = (uint32_t)(uintptr_t)lds;  // LDS byte address (shared aperture low bits)
+    auto load_frags = [&](uint32_t buf_off, int s, Frags& f) {
+        const uint32_t a_hi = lds_base + buf_off + arow + sl_hi[s], a_lo = lds_base + buf_off + arow + sl_lo[s];
+        const uint32_t w_hi = lds_base + buf_off + wrow + sl_hi[s], w_lo = lds_base + buf_off + wrow + sl_lo[s];
+        asm volatile("ds_read_b128 %0, %1" : "=v"(f.ah[0]) : "v"(a_hi));
+        asm volatile("ds_read_b128 %0, %1" : "=v"(f.wh[0]) : "v"(w_hi));
+        asm volatile("ds_read_b128 %0, %1" : "=v"(f.wl[0]) : "v"(w_lo));
+        asm volatile("ds_read_b128 %0, %1" : "=v"(f.al[0]) : "v"(a_lo));
+        asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(f.wh[1]) : "v"(w_hi));
+        asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(f.wl[1]) : "v"(w_lo));
+        asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(f.ah[1]) : "v"(a_hi));
+        asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(f.al[1]) : "v"(a_lo));
+    };
+    auto mfma_group = [&](const Frags& f) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                acc.hh[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[i], f.wh[j], acc.hh[i][j], 0, 0, 0);
+                acc.xx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[i], f.wl[j], acc.xx[i][j], 0, 0, 0);
+                acc.xx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al[i], f.wh[j], acc.xx[i][j], 0, 0, 0);
+            }
+    };
+#define SH_LGKM_WAIT(N)                                            \
+    do {                                                           \
+        asm volatile("s_waitcnt lgkmcnt(" #N ")" ::: "memory");    \
+        __builtin_amdgcn_sched_barrier(0);                         \
+    } while (0)
+
+    stage(0, lds);
+    if (kchunks > 1) stage(1, lds + G::STAGE);
+    if (kchunks > 2) stage(2, lds + 2 * G::STAGE);
+    if (kchunks > 2) sh_wait_vmcnt<2 * G::NL>();
+    else if (kchunks > 1) sh_wait_vmcnt<G::NL>();
+    else sh_wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    Frags f0, f1;
+    load_frags(0, 0, f0);
+    uint32_t cur = 0;  // buffer index of stage kc
+    for (uint32_t kc = 0; kc + 1 < kchunks; ++kc) {  // (the last stage is peeled)
+        load_frags(cur * G::STAGE, 1, f1);
+        SH_LGKM_WAIT(8);  // f0 (the older 8 reads) is back; f1 stays in flight under the MFMAs
+        mfma_group(f0);
+        __builtin_amdgcn_sched_barrier(0);
+        const uint32_t nxt = cur + 1 == 3 ? 0 : cur + 1;
+        if (kc + 2 < kchunks) sh_wait_vmcnt<G::NL>();  // stage kc+1 landed; kc+2 may still fly
+        else sh_wait_vmcnt<0>();
+        SH_LGKM_WAIT(0);  // f1 is back = this wave's last reads of stage kc
+        __builtin_amdgcn_s_barrier();
+        if (kc + 3 < kchunks) stage(kc + 3, lds + cur * G::STAGE);  // overwrite stage kc's buffer
+        load_frags(nxt * G::STAGE, 0, f0);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_group(f1);
+        __builtin_amdgcn_sched_barrier(0);
+        cur = nxt;
+    }
+    load_frags(cur * G::STAGE, 1, f1);
+    SH_LGKM_WAIT(8);
+    mfma_group(f0);
+    __builtin_amdgcn_sched_barrier(0);
+    SH_LGKM_WAIT(0);
+    mfma_group(f1);
+#undef SH_LGKM_WAIT
+    __syncthreads();  // every wave is done reading the stage buffers (callers reuse them)
+}
+
 __device__ __forceinline__ void sh_acc_zero(ShAcc& acc) {
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -151,6 +295,7 @@ __device__ __forceinline__ void sh_acc_zero(ShAcc& acc) {
 // The tile's f32 values into LDS as [128 m][128 n] (64 KiB, reusing the stage buffers; the main
 // loop's final barrier has retired every read of them).  C/D map of the 32x32 MFMA:
 // n = lane & 31, m = (r & 3) + 8 (r >> 2) + 4 (lane >> 5).  Followed by a barrier.
+// (with 2*WM waves the tile is [64*WM m][128 n]: the same code, wr = wave >> 1 runs to WM-1)
 __device__ __forceinline__ void sh_acc_to_lds(const ShAcc& acc, float* ctile) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1, l31 = lane & 31, h = lane >> 5;
