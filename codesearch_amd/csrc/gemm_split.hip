@@ -76,7 +76,11 @@ __device__ __forceinline__ void gemm_sh_epilogue(const float* ctile, const float
                 sh_f32x4 v = *reinterpret_cast<const sh_f32x4*>(ctile + row * 128 + c4 * 4);
                 v += bv;
                 if (EPI == SH_OUT_F32_RESID) v += rs[it];
+#ifdef SH_ABLATE_NO_STORE
+                asm volatile("" ::"v"(v));
+#else
                 if (FULL || m0 + row < M) *reinterpret_cast<sh_f32x4*>(C + (size_t)(m0 + row) * N + n0 + c4 * 4) = v;
+#endif
             }
         }
     }
@@ -95,7 +99,7 @@ gemm_sh_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ W,
     SH_STAMP(0);
     ShAcc acc;
     sh_acc_zero(acc);
-    sh_mainloop(A, M, m0, W, N, n0, kchunks, lds, acc);
+    sh_mainloop(A, M, m0, W, N, n0, kchunks, lds, acc, sh_kc_rot(nt, N / SH_BN, kchunks));
     SH_STAMP(1);
     float* ctile = reinterpret_cast<float*>(lds);
     sh_acc_to_lds(acc, ctile);
@@ -120,13 +124,17 @@ gemm_sh3_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ W,
     uint32_t mt, nt;
     if (!sh_tile_of_block(blockIdx.x, (M + G::BM - 1) / G::BM, N / SH_BN, mt, nt)) return;
     const uint32_t m0 = mt * G::BM, n0 = nt * SH_BN;
+    SH_STAMP(0);
     ShAcc acc;
     sh_acc_zero(acc);
-    sh_mainloop3<4>(A, M, m0, W, N, n0, kchunks, lds, acc);
+    sh_mainloop3<4>(A, M, m0, W, N, n0, kchunks, lds, acc, sh_kc_rot(nt, N / SH_BN, kchunks));
+    SH_STAMP(1);
     float* ctile = reinterpret_cast<float*>(lds);  // [256][128] f32 = 128 KiB of the 144 KiB ring
     sh_acc_to_lds(acc, ctile);
+    SH_STAMP(2);
     if (m0 + G::BM <= M) gemm_sh_epilogue<EPI, true, 4>(ctile, bias, resid, C, Cs, M, N, m0, n0, flag);
     else gemm_sh_epilogue<EPI, false, 4>(ctile, bias, resid, C, Cs, M, N, m0, n0, flag);
+    SH_STAMP(3);
 }
 
 // rows x K f32 -> split layout; one thread per 8 consecutive k.  With row_norm, row r is divided

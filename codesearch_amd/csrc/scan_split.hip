@@ -69,7 +69,8 @@ score_split_kernel(const _Float16* __restrict__ corpus_s, uint64_t row_lo, uint6
     const uint32_t m0 = mt * SH_BM, n0 = nt * SH_BN;
     ShAcc acc;
     sh_acc_zero(acc);
-    sh_mainloop(corpus_s + row_lo * kchunks * 64, M, m0, queries_s, nq, n0, kchunks, lds, acc);
+    sh_mainloop(corpus_s + row_lo * kchunks * 64, M, m0, queries_s, nq, n0, kchunks, lds, acc,
+                sh_kc_rot(nt, (nq + SH_BN - 1) / SH_BN, kchunks));
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1, l31 = lane & 31, h = lane >> 5;

@@ -72,9 +72,14 @@ __device__ __forceinline__ void sh_glds16(const void* gsrc, void* lds_dst) {
 // A: split rows [m0, m0+128) of a [M][kc][64] matrix (rows >= M re-read row M-1: they only feed
 // outputs that are never stored); W likewise with N rows.  acc must be zero-initialised by the
 // caller or carry a previous partial sum.  All 256 threads must call.
+// kc_rot: the block walks the k-chunks starting at chunk kc_rot (mod kchunks).  Blocks that share an
+// A tile (the n-tiles of one m-tile run concurrently on one XCD) are given different rotations, so
+// at any moment they read DIFFERENT lines of the tile: one of them misses to HBM, the others hit
+// the XCD's L2 a stage later.  In lockstep they would all miss on the same lines at the same time
+// (measured: the L2 does not merge them; fill rate 2x lower).
 __device__ __forceinline__ void sh_mainloop(const _Float16* __restrict__ A, uint32_t M, uint32_t m0,
                                             const _Float16* __restrict__ W, uint32_t N, uint32_t n0,
-                                            uint32_t kchunks, char* lds, ShAcc& acc) {
+                                            uint32_t kchunks, char* lds, ShAcc& acc, uint32_t kc_rot = 0) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 1, wc = wave & 1;
@@ -86,19 +91,29 @@ __device__ __forceinline__ void sh_mainloop(const _Float16* __restrict__ A, uint
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int row = wave * 32 + i * 8 + (lane >> 3);
+#ifdef SH_ABLATE_LINEAR
+        const int c = (lane & 7);
+#else
         const int c = (lane & 7) ^ ((row >> 1) & 7);
+#endif
+#ifdef SH_ABLATE_SAMEA
+        const uint32_t am = row;
+#else
         const uint32_t am = (m0 + row < M) ? m0 + row : M - 1;
+#endif
         const uint32_t wn = (n0 + row < N) ? n0 + row : N - 1;
         asrc[i] = A + (size_t)am * kchunks * 64 + c * 8;
         wsrc[i] = W + (size_t)wn * kchunks * 64 + c * 8;
     }
     auto stage = [&](uint32_t kc, char* buf) {
+#ifndef SH_ABLATE_NO_LOAD  // (diagnostic builds only: benchmarks/gemm_probe.hip)
         char* dst = buf + wave * 32 * 128;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             sh_glds16(asrc[i] + (size_t)kc * 64, dst + i * 1024);
             sh_glds16(wsrc[i] + (size_t)kc * 64, dst + SH_TILE_BYTES + i * 1024);
         }
+#endif
     };
 
     // fragment addresses: MFMA step s (k 16s..16s+15), lane half h -> logical slot 2s + h (hi), 4 + 2s + h (lo)
@@ -111,14 +126,20 @@ __device__ __forceinline__ void sh_mainloop(const _Float16* __restrict__ A, uint
         sl_lo[s] = ((4 + 2 * s + h) ^ swz) * 16;
     }
 
-    stage(0, lds);
+    uint32_t kr = kc_rot % kchunks;  // chunk index of the stage being issued
+    auto next_chunk = [&]() { const uint32_t c = kr; kr = kr + 1 == kchunks ? 0 : kr + 1; return c; };
+    stage(next_chunk(), lds);
     __syncthreads();
     for (uint32_t kc = 0; kc < kchunks; ++kc) {
         char* cur = lds + (kc & 1) * SH_STAGE_BYTES;
-        if (kc + 1 < kchunks) stage(kc + 1, lds + ((kc + 1) & 1) * SH_STAGE_BYTES);
+        if (kc + 1 < kchunks) stage(next_chunk(), lds + ((kc + 1) & 1) * SH_STAGE_BYTES);
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             f16x8 ah[2], al[2], wh[2], wl[2];
+#ifdef SH_ABLATE_NO_LDSREAD
+#pragma unroll
+            for (int t = 0; t < 2; ++t) { ah[t] = al[t] = wh[t] = wl[t] = f16x8{}; }
+#else
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 ah[t] = *reinterpret_cast<const f16x8*>(cur + arow + t * 32 * 128 + sl_hi[s]);
@@ -126,6 +147,11 @@ __device__ __forceinline__ void sh_mainloop(const _Float16* __restrict__ A, uint
                 wh[t] = *reinterpret_cast<const f16x8*>(cur + wrow + t * 32 * 128 + sl_hi[s]);
                 wl[t] = *reinterpret_cast<const f16x8*>(cur + wrow + t * 32 * 128 + sl_lo[s]);
             }
+#endif
+#ifdef SH_ABLATE_NO_MFMA
+#pragma unroll
+            for (int t = 0; t < 2; ++t) asm volatile("" ::"v"(ah[t]), "v"(al[t]), "v"(wh[t]), "v"(wl[t]));
+#else
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -134,6 +160,7 @@ __device__ __forceinline__ void sh_mainloop(const _Float16* __restrict__ A, uint
                     acc.xx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], wl[j], acc.xx[i][j], 0, 0, 0);
                     acc.xx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], wh[j], acc.xx[i][j], 0, 0, 0);
                 }
+#endif
         }
         __syncthreads();  // stage kc+1 has landed (vmcnt(0) precedes the barrier); cur is free
     }
@@ -169,7 +196,7 @@ __device__ __forceinline__ void sh_wait_vmcnt() {
 template <int WM>
 __device__ __forceinline__ void sh_mainloop3(const _Float16* __restrict__ A, uint32_t M, uint32_t m0,
                                              const _Float16* __restrict__ W, uint32_t N, uint32_t n0,
-                                             uint32_t kchunks, char* lds, ShAcc& acc) {
+                                             uint32_t kchunks, char* lds, ShAcc& acc, uint32_t kc_rot = 0) {
     using G = ShGeom<WM>;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -246,9 +273,11 @@ __device__ __forceinline__ void sh_mainloop3(const _Float16* __restrict__ A, uin
         __builtin_amdgcn_sched_barrier(0);                         \
     } while (0)
 
-    stage(0, lds);
-    if (kchunks > 1) stage(1, lds + G::STAGE);
-    if (kchunks > 2) stage(2, lds + 2 * G::STAGE);
+    uint32_t kr = kc_rot % kchunks;  // chunk index of the stage being issued (see sh_mainloop)
+    auto next_chunk = [&]() { const uint32_t c = kr; kr = kr + 1 == kchunks ? 0 : kr + 1; return c; };
+    stage(next_chunk(), lds);
+    if (kchunks > 1) stage(next_chunk(), lds + G::STAGE);
+    if (kchunks > 2) stage(next_chunk(), lds + 2 * G::STAGE);
     if (kchunks > 2) sh_wait_vmcnt<2 * G::NL>();
     else if (kchunks > 1) sh_wait_vmcnt<G::NL>();
     else sh_wait_vmcnt<0>();
@@ -266,7 +295,7 @@ __device__ __forceinline__ void sh_mainloop3(const _Float16* __restrict__ A, uin
         else sh_wait_vmcnt<0>();
         SH_LGKM_WAIT(0);  // f1 is back = this wave's last reads of stage kc
         __builtin_amdgcn_s_barrier();
-        if (kc + 3 < kchunks) stage(kc + 3, lds + cur * G::STAGE);  // overwrite stage kc's buffer
+        if (kc + 3 < kchunks) stage(next_chunk(), lds + cur * G::STAGE);  // overwrite stage kc's buffer
         load_frags(nxt * G::STAGE, 0, f0);
         __builtin_amdgcn_sched_barrier(0);
         mfma_group(f1);
@@ -320,6 +349,11 @@ __device__ __forceinline__ bool sh_tile_of_block(uint32_t b, uint32_t mtiles, ui
     mt = (q / ntiles) * 8 + xcd;
     nt = q % ntiles;
     return mt < mtiles;
+}
+// Rotation of n-tile nt's k-walk: spread the n-tiles of an m-tile evenly over the k-chunks.
+__device__ __forceinline__ uint32_t sh_kc_rot(uint32_t nt, uint32_t ntiles, uint32_t kchunks) {
+    const uint32_t stride = kchunks / ntiles > 0 ? kchunks / ntiles : 1;
+    return (nt * stride) % kchunks;
 }
 inline uint32_t sh_grid_blocks(uint32_t mtiles, uint32_t ntiles) { return ((mtiles + 7) / 8) * 8 * ntiles; }
 
