@@ -209,32 +209,35 @@ def main():
         alg_bytes = args.rows * args.dim * 4  # per launch: every row of the shard read once
         achieved = alg_bytes / (scan_us * 1e-6) / 1e9
         # the scan is HBM-bound below ~39 queries per pass and fp32-MFMA-bound above
-        split_path = args.nq >= 5 and args.dim in (384, 768, 1024) and os.environ.get("CS_INDEX_SPLIT", "1")[0] != "0"
-        if args.nq >= 40:
-            # filter = [rows, dim] x [dim, nq] on the f16 MFMA, 3 MFMAs per f32 product block, in
-            # 128-query tiles (padding executed too); priced against the dense f16 MFMA peak
-            alg_flops = 2.0 * args.rows * args.nq * args.dim
-            if split_path:
-                tiles = (args.nq + 127) // 128
-                exe = 3 * 2.0 * args.rows * tiles * 128 * args.dim
-                roof = {"kernel": "cs::score_split_kernel (+ rescore_select_kernel between phases)",
-                        "bound": "mfma", "achieved": exe / (scan_us * 1e-6) / 1e12, "peak": MFMA_F16_PEAK_TFLOPS,
-                        "unit": "TFLOP/s", "frac": exe / (scan_us * 1e-6) / 1e12 / MFMA_F16_PEAK_TFLOPS,
-                        "traffic": None, "executed_f16_flops_per_launch": exe,
-                        "algorithmic_flops_per_launch": alg_flops,
-                        "algorithmic_tflops_f32_equivalent": alg_flops / (scan_us * 1e-6) / 1e12,
-                        "f32_mfma_peak_for_information": MFMA_F32_PEAK_TFLOPS,
-                        "hbm_GBps_for_information": achieved}
-            else:
-                roof = {"kernel": "cs::score_append_kernel (+ select_candidates_kernel between phases)",
-                        "bound": "mfma", "achieved": alg_flops / (scan_us * 1e-6) / 1e12, "peak": MFMA_F32_PEAK_TFLOPS,
-                        "unit": "TFLOP/s", "frac": alg_flops / (scan_us * 1e-6) / 1e12 / MFMA_F32_PEAK_TFLOPS,
-                        "traffic": None, "algorithmic_flops_per_launch": alg_flops,
-                        "hbm_GBps_for_information": achieved}
+        filter_path = args.nq >= 5 and args.dim in (384, 768, 1024) and os.environ.get("CS_INDEX_SPLIT", "1")[0] != "0"
+        alg_flops = 2.0 * args.rows * args.nq * args.dim
+        if filter_path:
+            # scan_filter.hip: the filter streams the f16 unit-vector copy of the corpus (rows*dim*2 B)
+            # once per 128-query tile through the f16 MFMA; candidates are re-scored exactly in f32.
+            tiles = (args.nq + 127) // 128
+            f16_bytes = args.rows * args.dim * 2
+            exe = 2.0 * args.rows * tiles * 128 * args.dim
+            hbm = {"kernel": "cs::score_filter_kernel (+ rescore_select_kernel between phases)",
+                   "bound": "hbm", "achieved": f16_bytes / (scan_us * 1e-6) / 1e9, "peak": HBM_PEAK_GBPS,
+                   "unit": "GB/s", "frac": f16_bytes / (scan_us * 1e-6) / 1e9 / HBM_PEAK_GBPS, "traffic": None,
+                   "algorithmic_bytes_per_launch": f16_bytes,
+                   "note": "bytes = the f16 filter copy, read once when all queries fit one 128-query tile"}
+            mfma = {"kernel": "cs::score_filter_kernel (+ rescore_select_kernel between phases)",
+                    "bound": "mfma", "achieved": exe / (scan_us * 1e-6) / 1e12, "peak": MFMA_F16_PEAK_TFLOPS,
+                    "unit": "TFLOP/s", "frac": exe / (scan_us * 1e-6) / 1e12 / MFMA_F16_PEAK_TFLOPS,
+                    "traffic": None, "executed_f16_flops_per_launch": exe,
+                    "algorithmic_flops_per_launch": alg_flops,
+                    "hbm_GBps_for_information": f16_bytes * tiles / (scan_us * 1e-6) / 1e9}
+            roof = hbm if tiles == 1 else mfma
+        elif args.nq >= 40:
+            roof = {"kernel": "cs::score_append_kernel (+ select_candidates_kernel between phases)",
+                    "bound": "mfma", "achieved": alg_flops / (scan_us * 1e-6) / 1e12, "peak": MFMA_F32_PEAK_TFLOPS,
+                    "unit": "TFLOP/s", "frac": alg_flops / (scan_us * 1e-6) / 1e12 / MFMA_F32_PEAK_TFLOPS,
+                    "traffic": None, "algorithmic_flops_per_launch": alg_flops,
+                    "hbm_GBps_for_information": achieved}
         else:
             roof = {"kernel": "cs::scan_topk_kernel<3,4,1,true>" if args.dim == 384 and args.nq == 1
-                    else (("cs::score_split_kernel" if split_path else "cs::score_append_kernel") if args.nq >= 5
-                          else "cs::scan_topk_kernel"),
+                    else ("cs::score_append_kernel" if args.nq >= 5 else "cs::scan_topk_kernel"),
                     "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
                     "algorithmic_bytes_per_launch": alg_bytes}

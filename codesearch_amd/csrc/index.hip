@@ -51,7 +51,7 @@ struct Workspace {
     uint32_t* h_overflow = nullptr;
 
     int32_t reserve_split_queries(uint32_t nq, uint32_t dim) {
-        const size_t elems = (size_t)nq * dim * 2;
+        const size_t elems = (size_t)nq * dim;
         if (elems > qw_elems) {
             if (qw.d_qsplit) (void)hipFree(qw.d_qsplit);
             qw.d_qsplit = nullptr; qw_elems = 0;
@@ -193,7 +193,7 @@ struct cs_index {
     uint32_t* d_dead = nullptr;  // bitmap over rows, sized for `capacity`
     float* d_norms = nullptr;    // |row| for rows [0, normed_rows) (batched-query path)
     uint64_t normed_rows = 0;
-    _Float16* d_split = nullptr;  // rows [0, split_rows) in split-f16 form (filter operand of the batched path)
+    _Float16* d_split = nullptr;  // unit rows [0, split_rows) as f16 [row][dim]: filter operand of the batched path
     uint64_t split_rows = 0;
     bool use_split = false;
     uint64_t batched_searches = 0, batched_fallbacks = 0;
@@ -232,10 +232,10 @@ int32_t grow(cs_index* h, uint64_t need_rows) {
         return fail(CS_ERR_OOM, "hipMalloc(row norms) failed: %s", hipGetErrorString(e));
     }
     if (h->use_split) {
-        // filter copy of the batched path (same bytes as the f32 matrix); without room for it the
+        // filter copy of the batched path (half the bytes of the f32 matrix); without room for it the
         // batched path stays on the exact-f32 MFMA kernels (scan_mfma.hip)
         _Float16* ns = nullptr;
-        if (hipMalloc(&ns, (size_t)cap * h->dim * 2 * sizeof(_Float16)) != hipSuccess) {
+        if (hipMalloc(&ns, (size_t)cap * h->dim * sizeof(_Float16)) != hipSuccess) {
             (void)hipGetLastError();
             h->use_split = false;
             if (h->d_split) (void)hipFree(h->d_split);
@@ -243,7 +243,7 @@ int32_t grow(cs_index* h, uint64_t need_rows) {
             h->split_rows = 0;
         } else {
             if (h->split_rows)
-                CS_HIP(hipMemcpy(ns, h->d_split, (size_t)h->split_rows * h->dim * 2 * sizeof(_Float16),
+                CS_HIP(hipMemcpy(ns, h->d_split, (size_t)h->split_rows * h->dim * sizeof(_Float16),
                                  hipMemcpyDeviceToDevice));
             if (h->d_split) (void)hipFree(h->d_split);
             h->d_split = ns;

@@ -55,13 +55,14 @@ int32_t launch_scan_batched(const BatchedState& st, const float* d_corpus, const
                             float* d_out_cos, uint32_t* d_out_ids, uint32_t* d_out_counts,
                             hipStream_t stream);
 
-// ---- batched-query filter-and-refine path on split-f16 operands, scan_split.hip ---------------
+// ---- batched-query filter-and-refine path (f16 unit-vector filter + exact refine), scan_filter.hip
 struct SplitQueryWs {
-    _Float16* d_qsplit = nullptr;  // [nq][dim/32][64] f16
+    _Float16* d_qsplit = nullptr;  // [nq][dim] f16: q / |q|
     float* d_qmag = nullptr;       // [nq]
 };
 bool split_scan_supported(uint32_t dim);
-// rows [first, first+n) of the f32 corpus, divided by their norms -> the split copy (same row order)
+// rows [first, first+n) of the f32 corpus, divided by their norms, as f16 -> the filter copy
+// [rows][dim] (same row order; half the bytes of the f32 matrix)
 int32_t launch_corpus_split(const float* d_corpus, const float* d_norms, _Float16* d_split, uint64_t first,
                             uint64_t n, uint32_t dim, hipStream_t stream);
 // Exact (bit-identical to launch_scan + launch_merge) unless *st.d_overflow != 0 afterwards.

@@ -1,20 +1,25 @@
-// scan_split.hip — batched-query cosine scan, filter-and-refine:
+// scan_filter.hip — batched-query cosine scan, filter-and-refine:
 //
-//   filter   score_split_kernel: [rows, dim] x [dim, Q] on the f16 MFMA with split-f16 operands
-//            (split_f16.hpp; 3/16 of the exact-f32 MFMA's matrix-pipe time), 128 rows x 128
-//            queries per block, never materialised.  Both operands are the UNIT vectors x/|x|,
-//            q/|q| (built once per build_index / per search), so the product is the approximate
-//            cosine itself whatever the rows' magnitudes; an element within kSplitMargin of the
-//            query's running k-th best (tau) is appended, as a row index, to that query's
-//            candidate buffer.
+//   filter   score_filter_kernel: [rows, dim] x [dim, Q] on the f16 MFMA (v_mfma_f32_32x32x16_f16,
+//            1/16 of the exact-f32 MFMA's matrix-pipe time), 128 rows x 128 queries per block,
+//            never materialised.  Both operands are the UNIT vectors x/|x| and q/|q| rounded to
+//            f16 — a second, half-size copy of the corpus built at build_index (2 bytes per
+//            element: the filter also reads half the bytes of the f32 scan) — so the product is
+//            the cosine to within kFilterMargin whatever the rows' magnitudes.  An element within
+//            the margin of the query's running k-th best (tau) is appended, as a row index, to that
+//            query's candidate buffer.
 //   refine   rescore_select_kernel: every candidate is re-scored from the f32 corpus row with the
 //            arithmetic of the single-query scan (scan.hip: 32 lanes x float4 partial fmaf
 //            chains, half-wave butterfly, correctly rounded sqrt and divide) and folded into the
 //            running best-k; tau becomes the exact k-th best of the rows scanned so far.
 //
-// The filter's error (split <= ~2e-6, normalisation ~1e-7, f32 accumulation order <= 2.3e-5 worst
-// case at dim 384) is inside the margin, so every row whose exact cosine beats tau is a candidate and the result
-// equals the exact scan's bit for bit — ids and cosines — at a fraction of its MFMA cost.
+// Error of the filter, for unit vectors: rounding both operands to f16 costs at most
+// (2 * 2^-11 + 2^-22) * sum|q_i||x_i| <= 9.8e-4; elements below the f16 normal range add at most
+// 2^-14 * sum|q_i| <= 1.2e-3 at dim 384 even if the matrix pipe flushed them; f32 accumulation
+// order <= 2.3e-5.  kFilterMargin = 2.6e-3 covers the sum, so every row whose exact cosine beats
+// tau is a candidate and the result equals the exact scan's bit for bit — ids and cosines.  The
+// price of the margin is a handful of extra candidates per query (rows whose cosine lies within
+// 2.6e-3 below the k-th best), each one 1.5 KB re-read.
 // Phases (row-ordered, geometrically growing) and the overflow escape hatch are those of
 // scan_mfma.hip.  Serves `variants.par_iter().map(|e| store.search(e, limit))`
 // (/root/reference/src/search/mod.rs:508-511) and BASELINE.json configs 4/5.
@@ -25,7 +30,7 @@ namespace cs {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr float kSplitMargin = 1.0e-4f;  // cosine units; filter error bound ~3e-5 worst case
+constexpr float kFilterMargin = 2.6e-3f;  // cosine units; bound derived in the header comment
 constexpr int RS_THREADS = 1024;
 constexpr int RS_CAP = 2048;
 
@@ -57,20 +62,108 @@ query_mag_kernel(const float* __restrict__ queries, uint32_t nq, float* __restri
     if (q < nq && l32 == 0) qmag[q] = m;
 }
 
+// rows [first, first+n) of the f32 matrix, each divided by its norm (zero norm -> zero row), as f16
+// [rows][dim]; one thread per 8 consecutive elements.
+__global__ void __launch_bounds__(256)
+unit_f16_rows_kernel(const float* __restrict__ src, const float* __restrict__ row_norm,
+                     _Float16* __restrict__ dst, uint64_t n8, uint32_t dim) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    const uint32_t d8 = dim / 8;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += stride) {
+        const float nrm = row_norm[i / d8];
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(src + i * 8);
+        const f32x4 v1 = *reinterpret_cast<const f32x4*>(src + i * 8 + 4);
+        f16x8 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            o[e] = (_Float16)(nrm == 0.0f ? 0.0f : v0[e] / nrm);
+            o[4 + e] = (_Float16)(nrm == 0.0f ? 0.0f : v1[e] / nrm);
+        }
+        *reinterpret_cast<f16x8*>(dst + i * 8) = o;
+    }
+}
+
+// 128 x 128 x 64 tile main loop on plain f16 operands: the staging, LDS image and swizzle of
+// sh_mainloop (split_f16.hpp) — a stage is one 128-B line per row — but the line holds 64
+// consecutive k of one f16 plane, so a stage is four MFMA k-steps into ONE accumulator set.
+__device__ __forceinline__ void uf_mainloop(const _Float16* __restrict__ A, uint32_t M, uint32_t m0,
+                                            const _Float16* __restrict__ W, uint32_t N, uint32_t n0,
+                                            uint32_t kchunks, char* lds, sh_f32x16 (&acc)[2][2], uint32_t kc_rot) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    const int l31 = lane & 31, h = lane >> 5;
+    const _Float16* asrc[4];
+    const _Float16* wsrc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = wave * 32 + i * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((row >> 1) & 7);
+        const uint32_t am = (m0 + row < M) ? m0 + row : M - 1;
+        const uint32_t wn = (n0 + row < N) ? n0 + row : N - 1;
+        asrc[i] = A + (size_t)am * kchunks * 64 + c * 8;
+        wsrc[i] = W + (size_t)wn * kchunks * 64 + c * 8;
+    }
+    auto stage = [&](uint32_t kc, char* buf) {
+        char* dst = buf + wave * 32 * 128;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            sh_glds16(asrc[i] + (size_t)kc * 64, dst + i * 1024);
+            sh_glds16(wsrc[i] + (size_t)kc * 64, dst + SH_TILE_BYTES + i * 1024);
+        }
+    };
+    const int swz = (l31 >> 1) & 7;
+    const int arow = (wr * 64 + l31) * 128, wrow = SH_TILE_BYTES + (wc * 64 + l31) * 128;
+    int sl[4];  // MFMA step s (k 16s..16s+15), lane half h -> logical 16-B slot 2s + h
+#pragma unroll
+    for (int s = 0; s < 4; ++s) sl[s] = ((2 * s + h) ^ swz) * 16;
+
+    uint32_t kr = kc_rot % kchunks;
+    auto next_chunk = [&]() { const uint32_t c = kr; kr = kr + 1 == kchunks ? 0 : kr + 1; return c; };
+    stage(next_chunk(), lds);
+    __syncthreads();
+    for (uint32_t kc = 0; kc < kchunks; ++kc) {
+        char* cur = lds + (kc & 1) * SH_STAGE_BYTES;
+        if (kc + 1 < kchunks) stage(next_chunk(), lds + ((kc + 1) & 1) * SH_STAGE_BYTES);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            f16x8 a[2], w[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                a[t] = *reinterpret_cast<const f16x8*>(cur + arow + t * 32 * 128 + sl[s]);
+                w[t] = *reinterpret_cast<const f16x8*>(cur + wrow + t * 32 * 128 + sl[s]);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i], w[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+}
+
 // grid = sh_grid_blocks(row tiles of the phase, query tiles); dynamic LDS = SH_LDS_BYTES.
 __global__ void __launch_bounds__(256, 2)
-score_split_kernel(const _Float16* __restrict__ corpus_s, uint64_t row_lo, uint64_t row_hi, uint32_t kchunks,
-                   const _Float16* __restrict__ queries_s, uint32_t nq, const float* __restrict__ tau, const uint32_t* __restrict__ dead,
-                   uint32_t* __restrict__ cand, uint32_t* __restrict__ cnt, uint32_t cap) {
+score_filter_kernel(const _Float16* __restrict__ corpus_h, uint64_t row_lo, uint64_t row_hi, uint32_t kchunks,
+                    const _Float16* __restrict__ queries_h, uint32_t nq, const float* __restrict__ tau,
+                    const uint32_t* __restrict__ dead, uint32_t* __restrict__ cand, uint32_t* __restrict__ cnt,
+                    uint32_t cap) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const uint32_t M = (uint32_t)(row_hi - row_lo);
+    const uint32_t ntiles = (nq + SH_BN - 1) / SH_BN;
     uint32_t mt, nt;
-    if (!sh_tile_of_block(blockIdx.x, (M + SH_BM - 1) / SH_BM, (nq + SH_BN - 1) / SH_BN, mt, nt)) return;
+    if (!sh_tile_of_block(blockIdx.x, (M + SH_BM - 1) / SH_BM, ntiles, mt, nt)) return;
     const uint32_t m0 = mt * SH_BM, n0 = nt * SH_BN;
-    ShAcc acc;
-    sh_acc_zero(acc);
-    sh_mainloop(corpus_s + row_lo * kchunks * 64, M, m0, queries_s, nq, n0, kchunks, lds, acc,
-                sh_kc_rot(nt, (nq + SH_BN - 1) / SH_BN, kchunks));
+    sh_f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+    uf_mainloop(corpus_h + row_lo * kchunks * 64, M, m0, queries_h, nq, n0, kchunks, lds, acc,
+                sh_kc_rot(nt, ntiles, kchunks));
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1, l31 = lane & 31, h = lane >> 5;
@@ -80,14 +173,13 @@ score_split_kernel(const _Float16* __restrict__ corpus_s, uint64_t row_lo, uint6
         const bool qok = q < nq;
         // candidate <=> approx_cos > tau - margin, written so that NaN (a row holding NaN/Inf)
         // counts as a candidate: refine decides
-        const float tq = qok ? tau[q] - kSplitMargin : 0.0f;
+        const float tq = qok ? tau[q] - kFilterMargin : 0.0f;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const uint32_t m = m0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                const float c = fmaf(acc.xx[i][j][r], kShLoInv, acc.hh[i][j][r]);
-                if (qok && m < M && !(c <= tq)) {  // rare, divergent, short
+                if (qok && m < M && !(acc[i][j][r] <= tq)) {  // rare, divergent, short
                     const uint64_t row = row_lo + m;
                     if (!dead || !((dead[row >> 5] >> (row & 31)) & 1u)) {
                         const uint32_t pos = atomicAdd(&cnt[q], 1u);
@@ -202,10 +294,20 @@ __global__ void init_split_state_kernel(float* tau, uint32_t* cnt, uint64_t* car
 
 bool split_scan_supported(uint32_t dim) { return dim == 384 || dim == 768 || dim == 1024; }
 
+static int32_t launch_unit_f16(const float* d_src, const float* d_norm, _Float16* d_dst, uint64_t rows, uint32_t dim,
+                               hipStream_t stream) {
+    const uint64_t n8 = rows * (dim / 8);
+    if (n8 == 0) return CS_OK;
+    const uint64_t want = (n8 + 255) / 256;
+    hipLaunchKernelGGL(unit_f16_rows_kernel, dim3((uint32_t)(want < 8192 ? want : 8192)), dim3(256), 0, stream, d_src,
+                       d_norm, d_dst, n8, dim);
+    CS_HIP(hipGetLastError());
+    return CS_OK;
+}
+
 int32_t launch_corpus_split(const float* d_corpus, const float* d_norms, _Float16* d_split, uint64_t first,
                             uint64_t n, uint32_t dim, hipStream_t stream) {
-    return launch_split_rows(d_corpus + first * dim, d_split + first * dim * 2, n, dim, nullptr, stream,
-                             d_norms + first);
+    return launch_unit_f16(d_corpus + first * dim, d_norms + first, d_split + first * dim, n, dim, stream);
 }
 
 template <int J>
@@ -217,7 +319,7 @@ static int32_t scan_split_impl(const BatchedState& st, const SplitQueryWs& qw, c
     const uint32_t cap = batched_cap(k);
     static bool attr_set = false;
     if (!attr_set) {
-        CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(score_split_kernel),
+        CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(score_filter_kernel),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, SH_LDS_BYTES));
         attr_set = true;
     }
@@ -227,7 +329,7 @@ static int32_t scan_split_impl(const BatchedState& st, const SplitQueryWs& qw, c
                            st.d_carry, nq, k, st.d_overflow);
     }
     hipLaunchKernelGGL(query_mag_kernel<J>, dim3((nq + 7) / 8), dim3(256), 0, stream, d_queries, nq, qw.d_qmag);
-    CS_TRY(launch_split_rows(d_queries, qw.d_qsplit, nq, dim, nullptr, stream, qw.d_qmag));
+    CS_TRY(launch_unit_f16(d_queries, qw.d_qmag, qw.d_qsplit, nq, dim, stream));
     uint32_t* cand = reinterpret_cast<uint32_t*>(st.d_cand);
     const uint32_t ntiles = (nq + SH_BN - 1) / SH_BN;
     uint64_t done = 0;
@@ -237,8 +339,8 @@ static int32_t scan_split_impl(const BatchedState& st, const SplitQueryWs& qw, c
         const uint64_t lo = done, hi = done + phase;
         if (hi > lo) {
             const uint32_t mtiles = (uint32_t)((hi - lo + SH_BM - 1) / SH_BM);
-            hipLaunchKernelGGL(score_split_kernel, dim3(sh_grid_blocks(mtiles, ntiles)), dim3(256), SH_LDS_BYTES, stream,
-                               d_split, lo, hi, dim / 32, qw.d_qsplit, nq, st.d_tau, d_dead, cand, st.d_cnt, cap);
+            hipLaunchKernelGGL(score_filter_kernel, dim3(sh_grid_blocks(mtiles, ntiles)), dim3(256), SH_LDS_BYTES, stream,
+                               d_split, lo, hi, dim / 64, qw.d_qsplit, nq, st.d_tau, d_dead, cand, st.d_cnt, cap);
             CS_HIP(hipGetLastError());
         }
         done = hi;
