@@ -23,6 +23,8 @@
 // Phases (row-ordered, geometrically growing) and the overflow escape hatch are those of
 // scan_mfma.hip.  Serves `variants.par_iter().map(|e| store.search(e, limit))`
 // (/root/reference/src/search/mod.rs:508-511) and BASELINE.json configs 4/5.
+#include <cstdlib>
+
 #include "scan.hpp"
 #include "split_f16.hpp"
 
@@ -191,6 +193,108 @@ score_filter_kernel(const _Float16* __restrict__ corpus_h, uint64_t row_lo, uint
     }
 }
 
+// ---- 256 x 256 x 64 tiles for more than 128 queries -------------------------------------------
+// 8 waves as 4 (rows) x 2 (queries), a wave owns 64 rows x 128 queries = 2 x 4 MFMA tiles (128
+// accumulator registers): per byte staged into LDS twice the MFMA work of the 128 x 128 tile —
+// the global -> LDS fill path (~10 TB/s chip-wide with operands coming partly from HBM) is what
+// bounds these kernels, not the matrix pipe.  One block per CU (2 x 64 KiB stages).
+constexpr int UF2_BM = 256, UF2_BN = 256, UF2_TILE = 256 * 128, UF2_STAGE = 2 * UF2_TILE, UF2_LDS = 2 * UF2_STAGE;
+
+__global__ void __launch_bounds__(512, 2)
+score_filter256_kernel(const _Float16* __restrict__ corpus_h, uint64_t row_lo, uint64_t row_hi, uint32_t kchunks,
+                       const _Float16* __restrict__ queries_h, uint32_t nq, const float* __restrict__ tau,
+                       const uint32_t* __restrict__ dead, uint32_t* __restrict__ cand,
+                       uint32_t* __restrict__ cnt, uint32_t cap) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const uint32_t M = (uint32_t)(row_hi - row_lo);
+    const uint32_t ntiles = (nq + UF2_BN - 1) / UF2_BN;
+    uint32_t mt, nt;
+    if (!sh_tile_of_block(blockIdx.x, (M + UF2_BM - 1) / UF2_BM, ntiles, mt, nt)) return;
+    const uint32_t m0 = mt * UF2_BM, n0 = nt * UF2_BN;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    const int l31 = lane & 31, h = lane >> 5;
+    const _Float16* A = corpus_h + row_lo * kchunks * 64;
+
+    const _Float16* asrc[4];
+    const _Float16* wsrc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = wave * 32 + i * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((row >> 1) & 7);
+        const uint32_t am = (m0 + row < M) ? m0 + row : M - 1;
+        const uint32_t wn = (n0 + row < nq) ? n0 + row : nq - 1;
+        asrc[i] = A + (size_t)am * kchunks * 64 + c * 8;
+        wsrc[i] = queries_h + (size_t)wn * kchunks * 64 + c * 8;
+    }
+    auto stage = [&](uint32_t kc, char* buf) {
+        char* dst = buf + wave * 32 * 128;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            sh_glds16(asrc[i] + (size_t)kc * 64, dst + i * 1024);
+            sh_glds16(wsrc[i] + (size_t)kc * 64, dst + UF2_TILE + i * 1024);
+        }
+    };
+    const int swz = (l31 >> 1) & 7;
+    const int arow = (wr * 64 + l31) * 128, wrow = UF2_TILE + (wc * 128 + l31) * 128;
+    int sl[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) sl[s] = ((2 * s + h) ^ swz) * 16;
+
+    sh_f32x16 acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    uint32_t kr = sh_kc_rot(nt, ntiles, kchunks);
+    auto next_chunk = [&]() { const uint32_t c = kr; kr = kr + 1 == kchunks ? 0 : kr + 1; return c; };
+    stage(next_chunk(), lds);
+    __syncthreads();
+    for (uint32_t kc = 0; kc < kchunks; ++kc) {
+        char* cur = lds + (kc & 1) * UF2_STAGE;
+        if (kc + 1 < kchunks) stage(next_chunk(), lds + ((kc + 1) & 1) * UF2_STAGE);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            f16x8 a[2], w[4];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) a[t] = *reinterpret_cast<const f16x8*>(cur + arow + t * 32 * 128 + sl[s]);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) w[t] = *reinterpret_cast<const f16x8*>(cur + wrow + t * 32 * 128 + sl[s]);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i], w[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t q = n0 + wc * 128 + j * 32 + l31;
+        const bool qok = q < nq;
+        const float tq = qok ? tau[q] - kFilterMargin : 0.0f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const uint32_t m = m0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (qok && m < M && !(acc[i][j][r] <= tq)) {
+                    const uint64_t row = row_lo + m;
+                    if (!dead || !((dead[row >> 5] >> (row & 31)) & 1u)) {
+                        const uint32_t pos = atomicAdd(&cnt[q], 1u);
+                        if (pos < cap) cand[(size_t)q * cap + pos] = (uint32_t)row;
+                    }
+                }
+            }
+        }
+    }
+}
+
 // One block per query: exact cosines of its candidates (one half-wave per row, the layout and
 // operation order of scan_topk_kernel), folded into carry[q][k]; tau[q] = exact k-th best.
 template <int J>
@@ -321,6 +425,8 @@ static int32_t scan_split_impl(const BatchedState& st, const SplitQueryWs& qw, c
     if (!attr_set) {
         CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(score_filter_kernel),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, SH_LDS_BYTES));
+        CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(score_filter256_kernel),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, UF2_LDS));
         attr_set = true;
     }
     {
@@ -332,15 +438,28 @@ static int32_t scan_split_impl(const BatchedState& st, const SplitQueryWs& qw, c
     CS_TRY(launch_unit_f16(d_queries, qw.d_qmag, qw.d_qsplit, nq, dim, stream));
     uint32_t* cand = reinterpret_cast<uint32_t*>(st.d_cand);
     const uint32_t ntiles = (nq + SH_BN - 1) / SH_BN;
+    static int wide_min = -1;  // query count from which the 256 x 256 tile kernel is used
+    if (wide_min < 0) {
+        const char* e = std::getenv("CS_FILTER_WIDE_MIN_Q");
+        wide_min = e ? std::atoi(e) : 129;
+    }
+    const bool wide = (int)nq >= wide_min;
     uint64_t done = 0;
     uint64_t phase = n_rows < 1024 ? n_rows : 1024;  // phase 0: tau = -inf, every row is a candidate
     const uint32_t growth = 16;
     do {
         const uint64_t lo = done, hi = done + phase;
         if (hi > lo) {
-            const uint32_t mtiles = (uint32_t)((hi - lo + SH_BM - 1) / SH_BM);
-            hipLaunchKernelGGL(score_filter_kernel, dim3(sh_grid_blocks(mtiles, ntiles)), dim3(256), SH_LDS_BYTES, stream,
-                               d_split, lo, hi, dim / 64, qw.d_qsplit, nq, st.d_tau, d_dead, cand, st.d_cnt, cap);
+            if (wide) {
+                const uint32_t mt2 = (uint32_t)((hi - lo + UF2_BM - 1) / UF2_BM), nt2 = (nq + UF2_BN - 1) / UF2_BN;
+                hipLaunchKernelGGL(score_filter256_kernel, dim3(sh_grid_blocks(mt2, nt2)), dim3(512), UF2_LDS, stream,
+                                   d_split, lo, hi, dim / 64, qw.d_qsplit, nq, st.d_tau, d_dead, cand, st.d_cnt, cap);
+            } else {
+                const uint32_t mtiles = (uint32_t)((hi - lo + SH_BM - 1) / SH_BM);
+                hipLaunchKernelGGL(score_filter_kernel, dim3(sh_grid_blocks(mtiles, ntiles)), dim3(256), SH_LDS_BYTES,
+                                   stream, d_split, lo, hi, dim / 64, qw.d_qsplit, nq, st.d_tau, d_dead, cand, st.d_cnt,
+                                   cap);
+            }
             CS_HIP(hipGetLastError());
         }
         done = hi;

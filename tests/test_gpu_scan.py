@@ -445,3 +445,21 @@ def test_f32_mfma_batched_path_still_available(VS, oracle, monkeypatch):
     for i in range(nq):
         ecos, eids = oracle.scan_topk(corpus, qs[i], k, mode="omp")
         assert_topk_equal(cos[i], ids[i], ecos, eids, corpus, qs[i], oracle)
+
+
+@pytest.mark.parametrize("nq", [129, 300, 1000])
+def test_wide_filter_tiles_bit_identical(VS, nq):
+    """More than 128 queries take the 256 x 256 filter tiles; results stay those of the
+    single-query scan, bit for bit (sampled queries)."""
+    dim, n, k = 384, 300_001, 10
+    st = VS(None, dim)
+    st.insert_synthetic(n, 515, 0)
+    st.delete_chunks([7, n - 1])
+    st.build_index()
+    qs = np.concatenate([synth_rows(600 + nq, 0, nq - 1, dim), synth_planted(515, 6, [n - 2], dim)])
+    cos, ids, counts = st.search_raw(qs, k)
+    assert st.debug_counters() == (1, 0)
+    for i in list(range(0, nq, max(1, nq // 16))) + [nq - 2, nq - 1]:
+        c1, i1, n1 = st.search_raw(qs[i], k)
+        assert counts[i] == n1[0] and ids[i].tolist() == i1[0].tolist() and cos[i].tobytes() == c1[0].tobytes()
+    assert ids[nq - 1][0] == n - 2
