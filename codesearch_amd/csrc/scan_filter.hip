@@ -427,6 +427,7 @@ static int32_t scan_split_impl(const BatchedState& st, const SplitQueryWs& qw, c
                                    hipFuncAttributeMaxDynamicSharedMemorySize, SH_LDS_BYTES));
         CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(score_filter256_kernel),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, UF2_LDS));
+
         attr_set = true;
     }
     {
@@ -444,6 +445,7 @@ static int32_t scan_split_impl(const BatchedState& st, const SplitQueryWs& qw, c
         wide_min = e ? std::atoi(e) : 129;
     }
     const bool wide = (int)nq >= wide_min;
+
     uint64_t done = 0;
     uint64_t phase = n_rows < 1024 ? n_rows : 1024;  // phase 0: tau = -inf, every row is a candidate
     const uint32_t growth = 16;
