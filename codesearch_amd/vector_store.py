@@ -4,13 +4,17 @@ Same method names, argument meaning and error behaviour as
 /root/reference/src/vectordb/store.rs:94-750, so tests read like the reference's own
 (`store.rs:833-1028`).  The vectors live in HBM behind `cs_index_*`; chunk metadata
 (`ChunkMetadata`, store.rs:19-85) stays in host memory keyed by the u32 id, where the
-reference keeps it in a second LMDB database.  LMDB persistence, MDB_MAP_FULL resizing
-and page statistics are storage-engine concerns and out of scope.
+reference keeps it in a second LMDB database.  A store opened with a path persists itself in a
+flat form (vectors.f32 + sidecars); LMDB itself, MDB_MAP_FULL resizing and
+page statistics are storage-engine concerns and out of scope.
 """
 from __future__ import annotations
 
 import ctypes as C
+import dataclasses
 import hashlib
+import json
+import os
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Sequence
 
@@ -130,18 +134,111 @@ def cos_to_score(cos):
 class VectorStore:
     """`VectorStore::new(db_path, dimensions)` — store.rs:110-176.
 
-    `db_path` is accepted for signature parity and ignored: nothing is persisted.
+    `db_path = None`: a purely HBM-resident store.  With a path the store is persistent the way the
+    reference's is across process restarts (it reopens its LMDB environment, `next_id = last_key + 1`,
+    `indexed` = a built index exists, store.rs:139-170), in a flat form the GPU can ingest at full
+    PCIe rate, written at `build_index()` next to where the reference keeps its
+    `data.mdb`:
+        <db_path>/vectors.f32         rows [next_id - id_base, dim] f32 little-endian, row = id - id_base
+        <db_path>/vectors.meta.json   {"format", "dimensions", "id_base", "next_id", "removed": [ids], "built"}
+        <db_path>/chunks.jsonl        one ChunkMetadata per line (the `chunks` database, store.rs:98)
+    Rows appended after the last `build_index()` are in HBM only (the reference commits each insert
+    to LMDB but cannot search it before the next build either).
     `device`, `capacity` and `id_base` are the GPU-side additions (shard placement).
     """
 
+    FORMAT = 1
+
     def __init__(self, db_path, dimensions: int, device: int = 0, capacity: int = 0, id_base: int = 0):
         self._lib = _lib.load()
-        self.db_path = db_path
+        self.db_path = None if db_path is None else str(db_path)
         self.dimensions = int(dimensions)
+        self.id_base = int(id_base)
+        self.readonly = False
         handle = C.c_void_p()
         _lib.check(self._lib.cs_index_create(self.dimensions, capacity, device, id_base, C.byref(handle)))
         self._h = handle
         self._meta: Dict[int, ChunkMetadata] = {}
+        self._removed: set = set()
+        self._persisted_rows = 0
+        if self.db_path is not None:
+            os.makedirs(self.db_path, exist_ok=True)  # store.rs:113
+            self._load()
+
+    @classmethod
+    def open_readonly(cls, db_path, dimensions: int, **kw) -> "VectorStore":
+        """store.rs:183-250: same data, mutators refuse."""
+        st = cls(db_path, dimensions, **kw)
+        st.readonly = True
+        return st
+
+    # -- persistence (SURVEY.md §8f-4)
+    def _paths(self):
+        j = os.path.join
+        return j(self.db_path, "vectors.f32"), j(self.db_path, "vectors.meta.json"), j(self.db_path, "chunks.jsonl")
+
+    def _load(self) -> None:
+        vec, meta, chunks = self._paths()
+        if not (os.path.exists(vec) and os.path.exists(meta)):
+            return
+        m = json.load(open(meta))
+        if m.get("format") != self.FORMAT:
+            raise CsError(_lib.CS_ERR_BAD_ARG, f"unknown vector file format {m.get('format')!r} in {meta}")
+        if int(m["dimensions"]) != self.dimensions:  # the reference would fail at the first insert/search
+            raise CsError(_lib.CS_ERR_DIM_MISMATCH,
+                          f"Embedding dimension mismatch: expected {self.dimensions}, got {m['dimensions']}")
+        if int(m["id_base"]) != self.id_base:
+            raise CsError(_lib.CS_ERR_BAD_ARG, f"store was written with id_base {m['id_base']}, opened with {self.id_base}")
+        n = int(m["next_id"]) - self.id_base
+        rows = np.memmap(vec, dtype="<f4", mode="r", shape=(n, self.dimensions)) if n else np.zeros((0, self.dimensions), np.float32)
+        step = max(1, (256 << 20) // (4 * self.dimensions))  # 256 MB host pieces
+        for lo in range(0, n, step):
+            piece = np.ascontiguousarray(rows[lo:lo + step], np.float32)
+            _lib.check(self._lib.cs_index_add(self._h, piece.ctypes.data_as(f32p), piece.shape[0], self.dimensions, None))
+        self._persisted_rows = n
+        removed = [int(i) for i in m.get("removed", [])]
+        if removed:
+            ids = np.ascontiguousarray(removed, np.uint32)
+            _lib.check(self._lib.cs_index_remove(self._h, ids.ctypes.data_as(u32p), ids.size, None))
+            self._removed = set(removed)
+        if os.path.exists(chunks):
+            for line in open(chunks):
+                d = json.loads(line)
+                cid = int(d.pop("id"))
+                self._meta[cid] = ChunkMetadata(**d)
+        if m.get("built"):
+            _lib.check(self._lib.cs_index_build(self._h))
+
+    def _persist(self) -> None:
+        vec, meta, chunks = self._paths()
+        n = self.next_id() - self.id_base
+        with open(vec, "r+b" if os.path.exists(vec) else "w+b") as f:
+            f.truncate(self._persisted_rows * self.dimensions * 4)  # drop anything past the last consistent state
+            f.seek(0, 2)
+            step = max(1, (256 << 20) // (4 * self.dimensions))
+            for lo in range(self._persisted_rows, n, step):
+                f.write(self.read_rows(lo, min(step, n - lo)).astype("<f4").tobytes())
+        with open(chunks + ".tmp", "w") as f:
+            for cid in sorted(self._meta):
+                d = dataclasses.asdict(self._meta[cid])
+                d["id"] = cid
+                f.write(json.dumps(d) + "\n")
+        os.replace(chunks + ".tmp", chunks)
+        with open(meta + ".tmp", "w") as f:
+            json.dump({"format": self.FORMAT, "dimensions": self.dimensions, "id_base": self.id_base,
+                       "next_id": self.next_id(), "removed": sorted(self._removed), "built": True}, f)
+        os.replace(meta + ".tmp", meta)  # the meta file is the commit point
+        self._persisted_rows = n
+
+    def db_size(self) -> int:
+        """store.rs:741-749: bytes on disk."""
+        if self.db_path is None:
+            return 0
+        return sum(os.path.getsize(p) for p in self._paths() if os.path.exists(p))
+
+    def _writable(self):
+        if self.readonly:
+            raise CsError(_lib.CS_ERR_BAD_ARG, "store opened read-only (open_readonly)")
 
     # -- lifecycle
     def close(self):
@@ -164,6 +261,7 @@ class VectorStore:
     # -- writes (`&mut self` in the reference)
     def insert_chunks_with_ids(self, chunks: Sequence[EmbeddedChunk]) -> List[int]:
         """store.rs:618-686 -> assigned ids (contiguous from next_id)."""
+        self._writable()
         if not chunks:
             return []
         for ch in chunks:  # store.rs:666-672: first bad row aborts the transaction
@@ -184,6 +282,7 @@ class VectorStore:
 
     def insert_embeddings(self, rows: np.ndarray) -> np.ndarray:
         """Vector-only append (no metadata) for bulk/bench use -> ids."""
+        self._writable()
         rows = np.ascontiguousarray(rows, np.float32)
         if rows.ndim != 2:
             raise ValueError("rows must be [n, dim]")
@@ -200,21 +299,35 @@ class VectorStore:
 
     def delete_chunks(self, chunk_ids: Sequence[int]) -> int:
         """store.rs:548-610 -> number deleted."""
+        self._writable()
         ids = np.ascontiguousarray(chunk_ids, np.uint32)
         removed = C.c_uint64()
         _lib.check(self._lib.cs_index_remove(self._h, ids.ctypes.data_as(u32p), ids.size, C.byref(removed)))
+        nxt = self.next_id()
         for i in ids.tolist():
             self._meta.pop(i, None)  # store.rs:598
+            if self.id_base <= i < nxt:
+                self._removed.add(i)
         return int(removed.value)
 
     def build_index(self) -> None:
-        """store.rs:386-430."""
+        """store.rs:386-430 (+ the flat vector file when the store has a path)."""
+        self._writable()
         _lib.check(self._lib.cs_index_build(self._h))
+        if self.db_path is not None:
+            self._persist()
 
     def clear(self) -> None:
         """store.rs:690-707."""
+        self._writable()
         _lib.check(self._lib.cs_index_clear(self._h))
         self._meta.clear()
+        self._removed.clear()
+        self._persisted_rows = 0
+        if self.db_path is not None:
+            for p in self._paths():
+                if os.path.exists(p):
+                    os.remove(p)
 
     # -- reads (`&self`)
     def is_indexed(self) -> bool:
@@ -316,3 +429,23 @@ class VectorStore:
     @property
     def handle(self):
         return self._h
+
+
+# ---- embedding-cache value format --------------------------------------------------
+
+def encode_cached_embedding(vec) -> bytes:
+    """The value bytes of the reference's persistent embedding cache
+    (`Database<Str, SerdeBincode<Vec<f32>>>`, /root/reference/src/embed/cache.rs:283-285):
+    bincode 1.x of a Vec<f32> = u64 little-endian length, then the f32 little-endian elements."""
+    v = np.ascontiguousarray(vec, "<f4")
+    return int(v.size).to_bytes(8, "little") + v.tobytes()
+
+
+def decode_cached_embedding(buf: bytes) -> np.ndarray:
+    """Inverse of encode_cached_embedding; raises on a length/size mismatch."""
+    if len(buf) < 8:
+        raise ValueError("bincode Vec<f32>: missing length prefix")
+    n = int.from_bytes(buf[:8], "little")
+    if len(buf) != 8 + 4 * n:
+        raise ValueError(f"bincode Vec<f32>: length {n} does not match {len(buf) - 8} payload bytes")
+    return np.frombuffer(buf, "<f4", count=n, offset=8).astype(np.float32)

@@ -463,3 +463,47 @@ def test_wide_filter_tiles_bit_identical(VS, nq):
         c1, i1, n1 = st.search_raw(qs[i], k)
         assert counts[i] == n1[0] and ids[i].tolist() == i1[0].tolist() and cos[i].tobytes() == c1[0].tobytes()
     assert ids[nq - 1][0] == n - 2
+
+
+# ---- persistence interop: a store with a path survives a restart ---------------
+
+def test_persistent_store_round_trip(VS, oracle, tmp_path):
+    from codesearch_amd import CsError
+    from codesearch_amd.vector_store import Chunk, EmbeddedChunk
+
+    dim, n = 384, 300
+    rows = oracle.synth_rows(88, 0, n, dim)
+    chunks = [EmbeddedChunk(Chunk(f"fn f{i}() {{}}", i, i + 1, "Function", f"src/m{i % 7}.rs", hash=f"h{i}"), rows[i])
+              for i in range(n)]
+    db = tmp_path / "vectors.db"
+    st = VS(db, dim)
+    ids = st.insert_chunks_with_ids(chunks[:200])
+    assert ids == list(range(200))
+    st.build_index()
+    st.delete_chunks([5, 17])
+    st.insert_chunks_with_ids(chunks[200:])
+    st.build_index()                      # second build appends rows 200..299 to the flat file
+    q = rows[123] + 0.01 * rows[124]
+    want = [(r.id, r.score, r.path) for r in st.search(q, 10)]
+    size = st.db_size()
+    assert size >= n * dim * 4
+    st.close()
+
+    st2 = VS(db, dim)                     # VectorStore::new on an existing directory, store.rs:139-170
+    assert st2.is_indexed() and st2.next_id() == n and len(st2) == n - 2
+    assert [(r.id, r.score, r.path) for r in st2.search(q, 10)] == want
+    assert st2.get_chunk(5) is None and st2.get_chunk(6).hash == "h6"
+    assert np.array_equal(st2.read_rows(0, n), rows)
+    assert st2.stats().total_chunks == n - 2 and st2.db_size() == size
+    new_id = st2.insert_chunks_with_ids([EmbeddedChunk(Chunk("x", 1, 2, "Function", "a.rs"), rows[0])])
+    assert new_id == [n]                  # ids are never reused (store.rs:101)
+    st2.close()
+
+    ro = VS.open_readonly(db, dim)        # store.rs:183-250
+    assert [(r.id, r.score, r.path) for r in ro.search(q, 10)] == want
+    with pytest.raises(CsError):
+        ro.insert_chunks_with_ids(chunks[:1])
+    ro.close()
+    with pytest.raises(CsError) as e:     # a store written at 384 dims opened at 768
+        VS(db, 768)
+    assert "dimension mismatch" in str(e.value)
