@@ -209,7 +209,8 @@ def main():
         alg_bytes = args.rows * args.dim * 4  # per launch: every row of the shard read once
         achieved = alg_bytes / (scan_us * 1e-6) / 1e9
         # the scan is HBM-bound below ~39 queries per pass and fp32-MFMA-bound above
-        filter_path = args.nq >= 5 and args.dim in (384, 768, 1024) and os.environ.get("CS_INDEX_SPLIT", "1")[0] != "0"
+        filter_path = (args.nq >= int(os.environ.get("CS_FILTER_MIN_Q", "2")) and args.dim in (384, 768, 1024)
+                       and os.environ.get("CS_INDEX_SPLIT", "1")[0] != "0")
         alg_flops = 2.0 * args.rows * args.nq * args.dim
         if filter_path:
             # scan_filter.hip: the filter streams the f16 unit-vector copy of the corpus (rows*dim*2 B)
@@ -217,7 +218,8 @@ def main():
             tiles = (args.nq + 127) // 128
             f16_bytes = args.rows * args.dim * 2
             exe = 2.0 * args.rows * tiles * 128 * args.dim
-            hbm = {"kernel": "cs::score_filter_kernel (+ rescore_select_kernel between phases)",
+            hbm = {"kernel": ("cs::score_filter_rw_kernel" if args.nq <= 64 and args.dim == 384 else "cs::score_filter_kernel")
+                             + " (+ rescore_select_kernel between phases)",
                    "bound": "hbm", "achieved": f16_bytes / (scan_us * 1e-6) / 1e9, "peak": HBM_PEAK_GBPS,
                    "unit": "GB/s", "frac": f16_bytes / (scan_us * 1e-6) / 1e9 / HBM_PEAK_GBPS, "traffic": None,
                    "algorithmic_bytes_per_launch": f16_bytes,

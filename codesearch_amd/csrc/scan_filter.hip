@@ -295,6 +295,153 @@ score_filter256_kernel(const _Float16* __restrict__ corpus_h, uint64_t row_lo, u
     }
 }
 
+// ---- up to 64 queries: resident queries, deep corpus ring ---------------------------------------
+// With few queries the filter is a pure stream of the f16 corpus copy, and what limits a
+// tile-at-a-time kernel is bytes in flight per CU (one 16 KB corpus stage per block) against HBM
+// latency.  Here one persistent block per CU keeps its 32*NQT unit queries in LDS for its whole
+// life and gives ALL remaining LDS to the corpus: each of the 4 waves owns 32 rows of a 128-row
+// tile and a private ring of R 4-KiB slots filled by LDS-DMA, R-1 stages (7 x 16 KB per CU at
+// NQT = 1) in flight across tile boundaries under counted vmcnt — no barrier in the loop, since a
+// wave only reads rows it loaded itself.
+template <int NQT>
+struct RwGeom {
+    static constexpr int QROWS = 32 * NQT;
+    static constexpr int WBYTES = QROWS * 768;                 // 6 chunks x QROWS x 128 B (dim 384)
+    static constexpr int R = NQT == 1 ? 8 : 6;                 // ring slots (16 KiB each, 4 KiB per wave)
+    static constexpr int LDS = WBYTES + R * 16384;             // 155,648 / 147,456 B
+};
+
+template <int N>
+__device__ __forceinline__ void uf_wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int NQT>
+__global__ void __launch_bounds__(256)
+score_filter_rw_kernel(const _Float16* __restrict__ corpus_h, uint64_t row_lo, uint64_t row_hi,
+                       const _Float16* __restrict__ queries_h, uint32_t nq, const float* __restrict__ tau,
+                       const uint32_t* __restrict__ dead, uint32_t* __restrict__ cand,
+                       uint32_t* __restrict__ cnt, uint32_t cap) {
+    using G = RwGeom<NQT>;
+    constexpr int KC = 6, R = G::R;
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    char* Wl = lds;                 // [KC][QROWS][128 B], slots swizzled as in uf_mainloop
+    char* ring = lds + G::WBYTES;   // [R][4 waves][32 rows][128 B]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, h = lane >> 5;
+    const uint64_t M = row_hi - row_lo;
+    const uint64_t ntile = (M + 127) / 128;
+    const _Float16* base = corpus_h + row_lo * 384;
+
+    // resident queries: 8 rows x 128 B per instruction, 6*NQT instructions per wave
+#pragma unroll
+    for (int i = 0; i < 6 * NQT; ++i) {
+        const int g8 = wave * 6 * NQT + i;               // group of 8 (chunk, row) lines
+        const int c = g8 / (4 * NQT), r8 = g8 % (4 * NQT);
+        const int row = r8 * 8 + (lane >> 3);
+        const int pc = (lane & 7) ^ ((row >> 1) & 7);
+        const uint32_t q = (uint32_t)row < nq ? row : nq - 1;
+        sh_glds16(queries_h + (size_t)q * 384 + c * 64 + pc * 8, Wl + (c * G::QROWS + r8 * 8) * 128);
+    }
+    uf_wait_vmcnt<0>();
+    __syncthreads();
+
+    float tq[NQT];
+    bool qok[NQT];
+#pragma unroll
+    for (int t = 0; t < NQT; ++t) {
+        const uint32_t q = 32 * t + l31;
+        qok[t] = q < nq;
+        tq[t] = qok[t] ? tau[q] - kFilterMargin : 0.0f;
+    }
+
+    // this wave's staging: 4 instructions of 8 rows per stage; lane -> (row 8i + lane/8, slot lane%8)
+    const int swz = (l31 >> 1) & 7;
+    int a_sl[4], w_off[4];
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+        a_sl[st] = l31 * 128 + (((2 * st + h) ^ swz) * 16);
+        w_off[st] = l31 * 128 + (((2 * st + h) ^ swz) * 16);
+    }
+    char* myring = ring + wave * 4096;
+    auto issue = [&](uint64_t tile, int c, int slot) {  // stage (tile, chunk c) -> ring slot
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = i * 8 + (lane >> 3);
+            const int pc = (lane & 7) ^ ((row >> 1) & 7);
+            uint64_t r = tile * 128 + wave * 32 + row;
+            r = r < M ? r : M - 1;  // tail rows re-read the last row; masked at append
+            sh_glds16(base + r * 384 + c * 64 + pc * 8, myring + slot * 16384 + i * 1024);
+        }
+    };
+
+    const uint64_t t0 = blockIdx.x, tstep = gridDim.x;
+    if (t0 >= ntile) return;
+    // flattened stage sequence g = n*KC + c over this block's tiles; ring slot = g % R
+    const uint64_t my_tiles = (ntile - t0 + tstep - 1) / tstep;
+    const uint64_t nstage = my_tiles * KC;
+    uint64_t gi = 0;              // next stage to issue = (tile i_tile, chunk i_c) -> slot i_slot
+    uint64_t i_tile = t0;
+    int i_c = 0, i_slot = 0;
+    auto issue_next = [&]() {
+        issue(i_tile, i_c, i_slot);
+        ++gi;
+        if (++i_c == KC) { i_c = 0; i_tile += tstep; }
+        if (++i_slot == R) i_slot = 0;
+    };
+    for (int p = 0; p < R - 1; ++p)
+        if (gi < nstage) issue_next();
+
+    sh_f32x16 acc[NQT];
+    int c_slot = 0;  // ring slot of the stage being consumed
+    for (uint64_t n = 0; n < my_tiles; ++n) {
+        const uint64_t tile = t0 + n * tstep;
+#pragma unroll
+        for (int t = 0; t < NQT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+#pragma unroll
+        for (int c = 0; c < KC; ++c) {
+            // the slot refilled now was read in the previous iteration: its ds_reads are back
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (gi < nstage) {
+                issue_next();
+                uf_wait_vmcnt<4 * (R - 1)>();  // all but the R-1 youngest stages have landed: stage g is in
+            } else {
+                uf_wait_vmcnt<0>();            // tail: nothing younger to keep in flight
+            }
+            const char* slot = myring + c_slot * 16384;
+            if (++c_slot == R) c_slot = 0;
+            const char* wc = Wl + c * G::QROWS * 128;
+#pragma unroll
+            for (int st = 0; st < 4; ++st) {
+                const f16x8 a = *reinterpret_cast<const f16x8*>(slot + a_sl[st]);
+#pragma unroll
+                for (int t = 0; t < NQT; ++t) {
+                    const f16x8 w = *reinterpret_cast<const f16x8*>(wc + t * 32 * 128 + w_off[st]);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, w, acc[t], 0, 0, 0);
+                }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < NQT; ++t) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const uint64_t m = tile * 128 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (qok[t] && m < M && !(acc[t][r] <= tq[t])) {  // rare, divergent, short
+                    const uint64_t row = row_lo + m;
+                    if (!dead || !((dead[row >> 5] >> (row & 31)) & 1u)) {
+                        const uint32_t q = 32 * t + l31;
+                        const uint32_t pos = atomicAdd(&cnt[q], 1u);
+                        if (pos < cap) cand[(size_t)q * cap + pos] = (uint32_t)row;
+                    }
+                }
+            }
+        }
+    }
+}
+
 // One block per query: exact cosines of its candidates (one half-wave per row, the layout and
 // operation order of scan_topk_kernel), folded into carry[q][k]; tau[q] = exact k-th best.
 template <int J>
@@ -331,7 +478,9 @@ rescore_select_kernel(const float* __restrict__ corpus, const float* __restrict_
     const uint32_t room = RS_CAP - k;
     for (uint32_t done = 0; done < n || done == 0; done += room) {
         const uint32_t take = (n - done) < room ? (n - done) : room;
-        for (uint32_t i0 = 0; i0 < room; i0 += RS_THREADS / 32) {  // one candidate per half-wave per round
+        uint32_t fill = 64;  // slots [k, fill) must hold this chunk's keys or zeros (fill = the sort size)
+        while (fill < k + take) fill <<= 1;
+        for (uint32_t i0 = 0; i0 + k < fill; i0 += RS_THREADS / 32) {  // one candidate per half-wave per round
             const uint32_t i = i0 + hw;
             uint64_t key = 0ull;
             if (i < take) {  // half-wave uniform (xor masks <= 16 stay inside the half)
@@ -352,13 +501,16 @@ rescore_select_kernel(const float* __restrict__ corpus, const float* __restrict_
                 // NaN/Inf scores are never returned
                 key = (c > -__builtin_huge_valf() && c < __builtin_huge_valf()) ? key_pack(c, id_base + row) : 0ull;
             }
-            if (i < room && l32 == 0) a[k + i] = key;  // slots past `take` are cleared
+            if (k + i < fill && l32 == 0) a[k + i] = key;  // slots past `take` are cleared
         }
-        // bitonic sort, descending, of the 2048 slots
-        for (uint32_t size = 2; size <= RS_CAP; size <<= 1)
+        // bitonic sort, descending, of the live prefix (k carried + `take` new keys, padded with the
+        // zero keys already there to a power of two): a few dozen candidates sort in 64..256 slots
+        uint32_t nsort = 64;
+        while (nsort < k + take) nsort <<= 1;
+        for (uint32_t size = 2; size <= nsort; size <<= 1)
             for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
                 __syncthreads();
-                for (uint32_t t = tid; t < RS_CAP / 2; t += RS_THREADS) {
+                for (uint32_t t = tid; t < nsort / 2; t += RS_THREADS) {
                     const uint32_t i = 2 * t - (t & (stride - 1)), jx = i + stride;
                     const uint64_t x = a[i], y = a[jx];
                     if ((x < y) == ((i & size) == 0)) { a[i] = y; a[jx] = x; }
@@ -427,6 +579,10 @@ static int32_t scan_split_impl(const BatchedState& st, const SplitQueryWs& qw, c
                                    hipFuncAttributeMaxDynamicSharedMemorySize, SH_LDS_BYTES));
         CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(score_filter256_kernel),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, UF2_LDS));
+        CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(score_filter_rw_kernel<1>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, RwGeom<1>::LDS));
+        CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(score_filter_rw_kernel<2>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, RwGeom<2>::LDS));
 
         attr_set = true;
     }
@@ -445,6 +601,12 @@ static int32_t scan_split_impl(const BatchedState& st, const SplitQueryWs& qw, c
         wide_min = e ? std::atoi(e) : 129;
     }
     const bool wide = (int)nq >= wide_min;
+    static int rw_mode = -1;  // resident-query / deep-ring kernel for <= 64 queries (dim 384)
+    if (rw_mode < 0) {
+        const char* e = std::getenv("CS_FILTER_RW");
+        rw_mode = e ? std::atoi(e) : 1;
+    }
+    const bool small = rw_mode && dim == 384 && nq <= 64;
 
     uint64_t done = 0;
     uint64_t phase = n_rows < 1024 ? n_rows : 1024;  // phase 0: tau = -inf, every row is a candidate
@@ -452,7 +614,16 @@ static int32_t scan_split_impl(const BatchedState& st, const SplitQueryWs& qw, c
     do {
         const uint64_t lo = done, hi = done + phase;
         if (hi > lo) {
-            if (wide) {
+            if (small) {
+                const uint64_t tiles = (hi - lo + 127) / 128;
+                const uint32_t blocks = (uint32_t)(tiles < 256 ? tiles : 256);
+                if (nq <= 32)
+                    hipLaunchKernelGGL(score_filter_rw_kernel<1>, dim3(blocks), dim3(256), RwGeom<1>::LDS, stream, d_split,
+                                       lo, hi, qw.d_qsplit, nq, st.d_tau, d_dead, cand, st.d_cnt, cap);
+                else
+                    hipLaunchKernelGGL(score_filter_rw_kernel<2>, dim3(blocks), dim3(256), RwGeom<2>::LDS, stream, d_split,
+                                       lo, hi, qw.d_qsplit, nq, st.d_tau, d_dead, cand, st.d_cnt, cap);
+            } else if (wide) {
                 const uint32_t mt2 = (uint32_t)((hi - lo + UF2_BM - 1) / UF2_BM), nt2 = (nq + UF2_BN - 1) / UF2_BN;
                 hipLaunchKernelGGL(score_filter256_kernel, dim3(sh_grid_blocks(mt2, nt2)), dim3(512), UF2_LDS, stream,
                                    d_split, lo, hi, dim / 64, qw.d_qsplit, nq, st.d_tau, d_dead, cand, st.d_cnt, cap);
