@@ -616,7 +616,16 @@ static int32_t scan_split_impl(const BatchedState& st, const SplitQueryWs& qw, c
         if (hi > lo) {
             if (small) {
                 const uint64_t tiles = (hi - lo + 127) / 128;
-                const uint32_t blocks = (uint32_t)(tiles < 256 ? tiles : 256);
+                static int cus = 0;  // one persistent block per CU
+                if (!cus) {
+                    int dev = 0, n = 0;
+                    if (hipGetDevice(&dev) == hipSuccess &&
+                        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0)
+                        cus = n;
+                    else
+                        cus = 256;
+                }
+                const uint32_t blocks = (uint32_t)(tiles < (uint64_t)cus ? tiles : (uint64_t)cus);
                 if (nq <= 32)
                     hipLaunchKernelGGL(score_filter_rw_kernel<1>, dim3(blocks), dim3(256), RwGeom<1>::LDS, stream, d_split,
                                        lo, hi, qw.d_qsplit, nq, st.d_tau, d_dead, cand, st.d_cnt, cap);

@@ -102,16 +102,26 @@ __device__ __forceinline__ void sh_mainloop(const _Float16* __restrict__ A, uint
         const uint32_t am = (m0 + row < M) ? m0 + row : M - 1;
 #endif
         const uint32_t wn = (n0 + row < N) ? n0 + row : N - 1;
+#ifdef SH_ABLATE_TILED  // timing-only address pattern: the 8 rows of one instruction contiguous (1 KiB)
+        asrc[i] = A + ((size_t)(am >> 3) * kchunks * 8 + (am & 7)) * 64 + c * 8;
+        wsrc[i] = W + ((size_t)(wn >> 3) * kchunks * 8 + (wn & 7)) * 64 + c * 8;
+#else
         asrc[i] = A + (size_t)am * kchunks * 64 + c * 8;
         wsrc[i] = W + (size_t)wn * kchunks * 64 + c * 8;
+#endif
     }
     auto stage = [&](uint32_t kc, char* buf) {
 #ifndef SH_ABLATE_NO_LOAD  // (diagnostic builds only: benchmarks/gemm_probe.hip)
         char* dst = buf + wave * 32 * 128;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
+#ifdef SH_ABLATE_TILED
+            sh_glds16(asrc[i] + (size_t)kc * 512, dst + i * 1024);
+            sh_glds16(wsrc[i] + (size_t)kc * 512, dst + SH_TILE_BYTES + i * 1024);
+#else
             sh_glds16(asrc[i] + (size_t)kc * 64, dst + i * 1024);
             sh_glds16(wsrc[i] + (size_t)kc * 64, dst + SH_TILE_BYTES + i * 1024);
+#endif
         }
 #endif
     };
