@@ -235,7 +235,9 @@ int32_t grow(cs_index* h, uint64_t need_rows) {
         // filter copy of the batched path (half the bytes of the f32 matrix); without room for it the
         // batched path stays on the exact-f32 MFMA kernels (scan_mfma.hip)
         _Float16* ns = nullptr;
-        if (hipMalloc(&ns, (size_t)cap * h->dim * sizeof(_Float16)) != hipSuccess) {
+        // whole 128-row tiles (scan_filter.hip layout), an even number of them (256-row blocks)
+        const size_t cap256 = ((size_t)cap + 255) / 256 * 256;
+        if (hipMalloc(&ns, cap256 * h->dim * sizeof(_Float16)) != hipSuccess) {
             (void)hipGetLastError();
             h->use_split = false;
             if (h->d_split) (void)hipFree(h->d_split);
@@ -243,7 +245,7 @@ int32_t grow(cs_index* h, uint64_t need_rows) {
             h->split_rows = 0;
         } else {
             if (h->split_rows)
-                CS_HIP(hipMemcpy(ns, h->d_split, (size_t)h->split_rows * h->dim * sizeof(_Float16),
+                CS_HIP(hipMemcpy(ns, h->d_split, ((size_t)h->split_rows + 127) / 128 * 128 * h->dim * sizeof(_Float16),
                                  hipMemcpyDeviceToDevice));
             if (h->d_split) (void)hipFree(h->d_split);
             h->d_split = ns;

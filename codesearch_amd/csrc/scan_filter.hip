@@ -13,6 +13,11 @@
 //            chains, half-wave butterfly, correctly rounded sqrt and divide) and folded into the
 //            running best-k; tau becomes the exact k-th best of the rows scanned so far.
 //
+// Layout of the filter copy: 128-row tiles, chunk-major inside a tile — [tile][k-chunk of 64][row][128 B]
+// — so the 16 KB a stage needs (one k-chunk of 128 rows) and the 96 KB of a whole tile are
+// contiguous, every LDS-DMA instruction reads 1 KiB of consecutive lines, and the scan walks HBM
+// sequentially (row-major rows would be visited as 128 B every 768 B, six times over).
+//
 // Error of the filter, for unit vectors: rounding both operands to f16 costs at most
 // (2 * 2^-11 + 2^-22) * sum|q_i||x_i| <= 9.8e-4; elements below the f16 normal range add at most
 // 2^-14 * sum|q_i| <= 1.2e-3 at dim 384 even if the matrix pipe flushed them; f32 accumulation
@@ -64,15 +69,23 @@ query_mag_kernel(const float* __restrict__ queries, uint32_t nq, float* __restri
     if (q < nq && l32 == 0) qmag[q] = m;
 }
 
-// rows [first, first+n) of the f32 matrix, each divided by its norm (zero norm -> zero row), as f16
-// [rows][dim]; one thread per 8 consecutive elements.
+// Offset (in f16 elements) of (row, k-chunk c) in the tiled filter copy; + 8 * piece for the 16-B pieces.
+__host__ __device__ __forceinline__ size_t uf_tiled_off(uint64_t row, uint32_t c, uint32_t kchunks) {
+    return (((row >> 7) * kchunks + c) * 128 + (row & 127)) * 64;
+}
+
+// rows of an f32 matrix, each divided by its norm (zero norm -> zero row), as f16; one thread per 8
+// consecutive elements.  tiled: destination row index dst_row0 + r in the layout above (the corpus
+// copy); otherwise plain row-major [rows][dim] (the queries).
 __global__ void __launch_bounds__(256)
 unit_f16_rows_kernel(const float* __restrict__ src, const float* __restrict__ row_norm,
-                     _Float16* __restrict__ dst, uint64_t n8, uint32_t dim) {
+                     _Float16* __restrict__ dst, uint64_t n8, uint32_t dim, int tiled, uint64_t dst_row0) {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     const uint32_t d8 = dim / 8;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += stride) {
-        const float nrm = row_norm[i / d8];
+        const uint64_t r = i / d8;
+        const uint32_t p = (uint32_t)(i % d8);  // 8-element piece within the row
+        const float nrm = row_norm[r];
         const f32x4 v0 = *reinterpret_cast<const f32x4*>(src + i * 8);
         const f32x4 v1 = *reinterpret_cast<const f32x4*>(src + i * 8 + 4);
         f16x8 o;
@@ -81,7 +94,8 @@ unit_f16_rows_kernel(const float* __restrict__ src, const float* __restrict__ ro
             o[e] = (_Float16)(nrm == 0.0f ? 0.0f : v0[e] / nrm);
             o[4 + e] = (_Float16)(nrm == 0.0f ? 0.0f : v1[e] / nrm);
         }
-        *reinterpret_cast<f16x8*>(dst + i * 8) = o;
+        _Float16* d = tiled ? dst + uf_tiled_off(dst_row0 + r, p >> 3, dim / 64) + (p & 7) * 8 : dst + i * 8;
+        *reinterpret_cast<f16x8*>(d) = o;
     }
 }
 
@@ -101,16 +115,17 @@ __device__ __forceinline__ void uf_mainloop(const _Float16* __restrict__ A, uint
     for (int i = 0; i < 4; ++i) {
         const int row = wave * 32 + i * 8 + (lane >> 3);
         const int c = (lane & 7) ^ ((row >> 1) & 7);
-        const uint32_t am = (m0 + row < M) ? m0 + row : M - 1;
+        // A is the tiled filter copy (rows past M exist in its padded last tile and are masked at
+        // append); m0 is a multiple of 128, so the block's rows are one tile
         const uint32_t wn = (n0 + row < N) ? n0 + row : N - 1;
-        asrc[i] = A + (size_t)am * kchunks * 64 + c * 8;
+        asrc[i] = A + uf_tiled_off(m0 + row, 0, kchunks) + c * 8;
         wsrc[i] = W + (size_t)wn * kchunks * 64 + c * 8;
     }
     auto stage = [&](uint32_t kc, char* buf) {
         char* dst = buf + wave * 32 * 128;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            sh_glds16(asrc[i] + (size_t)kc * 64, dst + i * 1024);
+            sh_glds16(asrc[i] + (size_t)kc * 128 * 64, dst + i * 1024);
             sh_glds16(wsrc[i] + (size_t)kc * 64, dst + SH_TILE_BYTES + i * 1024);
         }
     };
@@ -164,7 +179,7 @@ score_filter_kernel(const _Float16* __restrict__ corpus_h, uint64_t row_lo, uint
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-    uf_mainloop(corpus_h + row_lo * kchunks * 64, M, m0, queries_h, nq, n0, kchunks, lds, acc,
+    uf_mainloop(corpus_h + uf_tiled_off(row_lo, 0, kchunks), M, m0, queries_h, nq, n0, kchunks, lds, acc,
                 sh_kc_rot(nt, ntiles, kchunks));
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -215,7 +230,7 @@ score_filter256_kernel(const _Float16* __restrict__ corpus_h, uint64_t row_lo, u
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 1, wc = wave & 1;
     const int l31 = lane & 31, h = lane >> 5;
-    const _Float16* A = corpus_h + row_lo * kchunks * 64;
+    const _Float16* A = corpus_h + uf_tiled_off(row_lo, 0, kchunks);  // row_lo is a multiple of 128
 
     const _Float16* asrc[4];
     const _Float16* wsrc[4];
@@ -223,16 +238,15 @@ score_filter256_kernel(const _Float16* __restrict__ corpus_h, uint64_t row_lo, u
     for (int i = 0; i < 4; ++i) {
         const int row = wave * 32 + i * 8 + (lane >> 3);
         const int c = (lane & 7) ^ ((row >> 1) & 7);
-        const uint32_t am = (m0 + row < M) ? m0 + row : M - 1;
         const uint32_t wn = (n0 + row < nq) ? n0 + row : nq - 1;
-        asrc[i] = A + (size_t)am * kchunks * 64 + c * 8;
+        asrc[i] = A + uf_tiled_off(m0 + row, 0, kchunks) + c * 8;  // padded tiles: no row clamp needed
         wsrc[i] = queries_h + (size_t)wn * kchunks * 64 + c * 8;
     }
     auto stage = [&](uint32_t kc, char* buf) {
         char* dst = buf + wave * 32 * 128;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            sh_glds16(asrc[i] + (size_t)kc * 64, dst + i * 1024);
+            sh_glds16(asrc[i] + (size_t)kc * 128 * 64, dst + i * 1024);
             sh_glds16(wsrc[i] + (size_t)kc * 64, dst + UF2_TILE + i * 1024);
         }
     };
@@ -332,7 +346,7 @@ score_filter_rw_kernel(const _Float16* __restrict__ corpus_h, uint64_t row_lo, u
     const int l31 = lane & 31, h = lane >> 5;
     const uint64_t M = row_hi - row_lo;
     const uint64_t ntile = (M + 127) / 128;
-    const _Float16* base = corpus_h + row_lo * 384;
+    const _Float16* base = corpus_h + uf_tiled_off(row_lo, 0, 6);  // row_lo is a multiple of 128
 
     // resident queries: 8 rows x 128 B per instruction, 6*NQT instructions per wave
 #pragma unroll
@@ -370,9 +384,8 @@ score_filter_rw_kernel(const _Float16* __restrict__ corpus_h, uint64_t row_lo, u
         for (int i = 0; i < 4; ++i) {
             const int row = i * 8 + (lane >> 3);
             const int pc = (lane & 7) ^ ((row >> 1) & 7);
-            uint64_t r = tile * 128 + wave * 32 + row;
-            r = r < M ? r : M - 1;  // tail rows re-read the last row; masked at append
-            sh_glds16(base + r * 384 + c * 64 + pc * 8, myring + slot * 16384 + i * 1024);
+            // 8 consecutive rows of chunk c = 1 KiB of consecutive lines (rows past M: padded tile, masked at append)
+            sh_glds16(base + ((tile * 6 + c) * 128 + wave * 32 + row) * 64 + pc * 8, myring + slot * 16384 + i * 1024);
         }
     };
 
@@ -551,19 +564,19 @@ __global__ void init_split_state_kernel(float* tau, uint32_t* cnt, uint64_t* car
 bool split_scan_supported(uint32_t dim) { return dim == 384 || dim == 768 || dim == 1024; }
 
 static int32_t launch_unit_f16(const float* d_src, const float* d_norm, _Float16* d_dst, uint64_t rows, uint32_t dim,
-                               hipStream_t stream) {
+                               hipStream_t stream, int tiled = 0, uint64_t dst_row0 = 0) {
     const uint64_t n8 = rows * (dim / 8);
     if (n8 == 0) return CS_OK;
     const uint64_t want = (n8 + 255) / 256;
     hipLaunchKernelGGL(unit_f16_rows_kernel, dim3((uint32_t)(want < 8192 ? want : 8192)), dim3(256), 0, stream, d_src,
-                       d_norm, d_dst, n8, dim);
+                       d_norm, d_dst, n8, dim, tiled, dst_row0);
     CS_HIP(hipGetLastError());
     return CS_OK;
 }
 
 int32_t launch_corpus_split(const float* d_corpus, const float* d_norms, _Float16* d_split, uint64_t first,
                             uint64_t n, uint32_t dim, hipStream_t stream) {
-    return launch_unit_f16(d_corpus + first * dim, d_norms + first, d_split + first * dim, n, dim, stream);
+    return launch_unit_f16(d_corpus + first * dim, d_norms + first, d_split, n, dim, stream, 1, first);
 }
 
 template <int J>
