@@ -284,6 +284,28 @@ def main():
             line["cpu_baseline"] = base
             line["recall_at_10"] = recall
             line["max_abs_cos_err_vs_cpu"] = err
+        if world == 1 and args.nq == 1:
+            # for information: the same exact search routed through the f16 filter + f32 refine path
+            # (bit-identical result; reads the half-size filter copy instead of the f32 matrix)
+            shard.store.set_filter_min_queries(1)
+            for _ in range(3):
+                shard.search_device(d_q, 1, args.k)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            reps = 50
+            for _ in range(reps):
+                alt = shard.search_device(d_q, 1, args.k)
+            torch.cuda.synchronize()
+            alt_ms = (time.perf_counter() - t1) * 1e3 / reps
+            same = bool((alt["ids"].cpu().numpy().astype("uint32").reshape(-1) == ids0.reshape(-1)).all()
+                        and (alt["cos"].cpu().numpy().reshape(-1) == cos0.reshape(-1)).all())
+            shard.store.set_filter_min_queries(2)
+            line["single_query_via_filter"] = {
+                "ms_per_search": alt_ms, "chunks_per_s": args.rows / (alt_ms * 1e-3),
+                "bit_identical_to_streaming_scan": same,
+                "note": "cs_index_set_filter_min_queries(1): f16 MFMA filter over the 7.68 GB unit-vector copy, "
+                        "then exact f32 re-score of the candidates; not used for `value`",
+            }
         if world == 1 and not args.no_encoder:
             line.update(encoder_legs(shard, args.k, local_rank))
         print(json.dumps(line), flush=True)

@@ -196,6 +196,7 @@ struct cs_index {
     _Float16* d_split = nullptr;  // unit rows [0, split_rows) as f16 [row][dim]: filter operand of the batched path
     uint64_t split_rows = 0;
     bool use_split = false;
+    int filter_min_q = 2;  // query count from which the f16 filter + exact refine path is used
     uint64_t batched_searches = 0, batched_fallbacks = 0;
     std::vector<uint32_t> h_dead;
     bool built = false;
@@ -346,13 +347,7 @@ int32_t run_search(cs_index* h, Workspace* w, const ScanPlan& plan, const float*
     // queries (1.85 ms vs 2.5 ms for two passes-in-one of the streaming scan over 10M x 384) and
     // the refine step keeps the result bit-identical.  One query stays on the streaming f32 scan
     // (the north-star kernel).  Without the filter copy, >= 5 queries use the exact-f32 MFMA path.
-    static int filter_min_q = -1;
-    if (filter_min_q < 0) {
-        const char* e = std::getenv("CS_FILTER_MIN_Q");
-        filter_min_q = e ? std::atoi(e) : 2;
-        if (filter_min_q < 1) filter_min_q = 1;
-    }
-    const bool use_filter = split_ready && (int)nq >= filter_min_q;
+    const bool use_filter = split_ready && (int)nq >= h->filter_min_q;
     if (h->n_rows > 0 && h->normed_rows >= h->n_rows && (use_filter || (nq >= 5 && batched_supported(h->dim)))) {
         CS_TRY(w->reserve_batched(nq, k));
         if (use_filter) {
@@ -451,6 +446,10 @@ int32_t cs_index_create(uint32_t dim, uint64_t capacity_rows, int32_t device, ui
     {
         const char* env = std::getenv("CS_INDEX_SPLIT");  // "0": keep the batched path on the exact-f32 MFMA
         h->use_split = split_scan_supported(dim) && !(env && env[0] == '0');
+        if (const char* e = std::getenv("CS_FILTER_MIN_Q")) {
+            h->filter_min_q = std::atoi(e);
+            if (h->filter_min_q < 1) h->filter_min_q = 1;
+        }
     }
     if (capacity_rows) {
         int32_t s = grow(h, capacity_rows);
@@ -660,6 +659,12 @@ int32_t cs_index_read_rows(cs_index* h, uint64_t first_row, uint64_t n, float* o
     CS_HIP(hipDeviceSynchronize());
     CS_HIP(hipMemcpy(out_rows, h->d_corpus + (size_t)first_row * h->dim,
                      (size_t)n * h->dim * sizeof(float), hipMemcpyDeviceToHost));
+    return CS_OK;
+}
+
+int32_t cs_index_set_filter_min_queries(cs_index* h, uint32_t min_queries) {
+    if (!h) return fail(CS_ERR_BAD_ARG, "null index handle");
+    h->filter_min_q = min_queries < 1 ? 1 : (int)min_queries;
     return CS_OK;
 }
 

@@ -420,6 +420,10 @@ class VectorStore:
         _lib.check(self._lib.cs_index_profile_read(self._h, C.byref(s), C.byref(n), C.byref(m), 1 if reset else 0))
         return s.value, int(n.value), m.value
 
+    def set_filter_min_queries(self, n: int) -> None:
+        """Searches of >= n queries use the f16 filter + exact refine path (default 2; 1 = always)."""
+        _lib.check(self._lib.cs_index_set_filter_min_queries(self._h, int(n)))
+
     def debug_counters(self):
         """-> (batched_searches, batched_fallbacks)"""
         a, b = C.c_uint64(), C.c_uint64()

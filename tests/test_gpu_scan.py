@@ -507,3 +507,19 @@ def test_persistent_store_round_trip(VS, oracle, tmp_path):
     with pytest.raises(CsError) as e:     # a store written at 384 dims opened at 768
         VS(db, 768)
     assert "dimension mismatch" in str(e.value)
+
+
+def test_single_query_through_filter_is_bit_identical(VS):
+    """cs_index_set_filter_min_queries(1): even one query may take filter + refine; same bits."""
+    dim, n, k = 384, 200_000, 10
+    st = VS(None, dim)
+    st.insert_synthetic(n, 99, 0)
+    st.build_index()
+    qs = synth_rows(1234, 0, 5, dim)
+    base = [st.search_raw(q, k) for q in qs]
+    assert st.debug_counters() == (0, 0)
+    st.set_filter_min_queries(1)
+    for q, (c0, i0, n0) in zip(qs, base):
+        c1, i1, n1 = st.search_raw(q, k)
+        assert n1[0] == n0[0] and i1.tolist() == i0.tolist() and c1.tobytes() == c0.tobytes()
+    assert st.debug_counters() == (5, 0)
