@@ -321,8 +321,8 @@ template <int NQT>
 struct RwGeom {
     static constexpr int QROWS = 32 * NQT;
     static constexpr int WBYTES = QROWS * 768;                 // 6 chunks x QROWS x 128 B (dim 384)
-    static constexpr int R = NQT == 1 ? 8 : 6;                 // ring slots (16 KiB each, 4 KiB per wave)
-    static constexpr int LDS = WBYTES + R * 16384;             // 155,648 / 147,456 B
+    static constexpr int R = NQT == 1 ? 8 : NQT == 2 ? 6 : 3;  // ring slots (16 KiB each, 4 KiB per wave)
+    static constexpr int LDS = WBYTES + R * 16384;             // 155,648 / 147,456 / 147,456 B
 };
 
 template <int N>
@@ -335,7 +335,7 @@ __global__ void __launch_bounds__(256)
 score_filter_rw_kernel(const _Float16* __restrict__ corpus_h, uint64_t row_lo, uint64_t row_hi,
                        const _Float16* __restrict__ queries_h, uint32_t nq, const float* __restrict__ tau,
                        const uint32_t* __restrict__ dead, uint32_t* __restrict__ cand,
-                       uint32_t* __restrict__ cnt, uint32_t cap) {
+                       uint32_t* __restrict__ cnt, uint32_t cap, uint32_t qtiles) {
     using G = RwGeom<NQT>;
     constexpr int KC = 6, R = G::R;
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -347,6 +347,13 @@ score_filter_rw_kernel(const _Float16* __restrict__ corpus_h, uint64_t row_lo, u
     const uint64_t M = row_hi - row_lo;
     const uint64_t ntile = (M + 127) / 128;
     const _Float16* base = corpus_h + uf_tiled_off(row_lo, 0, 6);  // row_lo is a multiple of 128
+    // Several query tiles: blocks of one XCD (blockIdx % 8) that hold different query tiles share a
+    // row group and walk its corpus tiles in the same order, so a tile comes from HBM once per XCD
+    // group and from that XCD's L2 for the other query tiles.
+    const uint32_t xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const uint32_t qt = slot % qtiles, rg = slot / qtiles, rgn = (gridDim.x >> 3) / qtiles;
+    if (rg >= rgn) return;  // spare slot when qtiles does not divide the slots of an XCD
+    const uint32_t q0 = qt * G::QROWS;
 
     // resident queries: 8 rows x 128 B per instruction, 6*NQT instructions per wave
 #pragma unroll
@@ -355,7 +362,7 @@ score_filter_rw_kernel(const _Float16* __restrict__ corpus_h, uint64_t row_lo, u
         const int c = g8 / (4 * NQT), r8 = g8 % (4 * NQT);
         const int row = r8 * 8 + (lane >> 3);
         const int pc = (lane & 7) ^ ((row >> 1) & 7);
-        const uint32_t q = (uint32_t)row < nq ? row : nq - 1;
+        const uint32_t q = q0 + row < nq ? q0 + row : nq - 1;
         sh_glds16(queries_h + (size_t)q * 384 + c * 64 + pc * 8, Wl + (c * G::QROWS + r8 * 8) * 128);
     }
     uf_wait_vmcnt<0>();
@@ -365,7 +372,7 @@ score_filter_rw_kernel(const _Float16* __restrict__ corpus_h, uint64_t row_lo, u
     bool qok[NQT];
 #pragma unroll
     for (int t = 0; t < NQT; ++t) {
-        const uint32_t q = 32 * t + l31;
+        const uint32_t q = q0 + 32 * t + l31;
         qok[t] = q < nq;
         tq[t] = qok[t] ? tau[q] - kFilterMargin : 0.0f;
     }
@@ -389,7 +396,7 @@ score_filter_rw_kernel(const _Float16* __restrict__ corpus_h, uint64_t row_lo, u
         }
     };
 
-    const uint64_t t0 = blockIdx.x, tstep = gridDim.x;
+    const uint64_t t0 = (uint64_t)rg * 8 + xcd, tstep = (uint64_t)rgn * 8;
     if (t0 >= ntile) return;
     // flattened stage sequence g = n*KC + c over this block's tiles; ring slot = g % R
     const uint64_t my_tiles = (ntile - t0 + tstep - 1) / tstep;
@@ -445,7 +452,7 @@ score_filter_rw_kernel(const _Float16* __restrict__ corpus_h, uint64_t row_lo, u
                 if (qok[t] && m < M && !(acc[t][r] <= tq[t])) {  // rare, divergent, short
                     const uint64_t row = row_lo + m;
                     if (!dead || !((dead[row >> 5] >> (row & 31)) & 1u)) {
-                        const uint32_t q = 32 * t + l31;
+                        const uint32_t q = q0 + 32 * t + l31;
                         const uint32_t pos = atomicAdd(&cnt[q], 1u);
                         if (pos < cap) cand[(size_t)q * cap + pos] = (uint32_t)row;
                     }
@@ -596,6 +603,8 @@ static int32_t scan_split_impl(const BatchedState& st, const SplitQueryWs& qw, c
                                    hipFuncAttributeMaxDynamicSharedMemorySize, RwGeom<1>::LDS));
         CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(score_filter_rw_kernel<2>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, RwGeom<2>::LDS));
+        CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(score_filter_rw_kernel<4>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, RwGeom<4>::LDS));
 
         attr_set = true;
     }
@@ -619,7 +628,8 @@ static int32_t scan_split_impl(const BatchedState& st, const SplitQueryWs& qw, c
         const char* e = std::getenv("CS_FILTER_RW");
         rw_mode = e ? std::atoi(e) : 1;
     }
-    const bool small = rw_mode && dim == 384 && nq <= 64;
+    // resident-query kernel: up to 64 queries always; above that when CS_FILTER_RW=2 (128-query tiles)
+    const bool small = rw_mode && dim == 384 && (nq <= 64 || (rw_mode >= 2 && (nq + 127) / 128 <= 32));
 
     uint64_t done = 0;
     uint64_t phase = n_rows < 1024 ? n_rows : 1024;  // phase 0: tau = -inf, every row is a candidate
@@ -628,23 +638,30 @@ static int32_t scan_split_impl(const BatchedState& st, const SplitQueryWs& qw, c
         const uint64_t lo = done, hi = done + phase;
         if (hi > lo) {
             if (small) {
-                const uint64_t tiles = (hi - lo + 127) / 128;
-                static int cus = 0;  // one persistent block per CU
+                static int cus = 0;  // one persistent block per CU (grid rounded down to whole XCD octets)
                 if (!cus) {
                     int dev = 0, n = 0;
                     if (hipGetDevice(&dev) == hipSuccess &&
-                        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0)
-                        cus = n;
+                        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n >= 8)
+                        cus = n / 8 * 8;
                     else
                         cus = 256;
                 }
-                const uint32_t blocks = (uint32_t)(tiles < (uint64_t)cus ? tiles : (uint64_t)cus);
-                if (nq <= 32)
-                    hipLaunchKernelGGL(score_filter_rw_kernel<1>, dim3(blocks), dim3(256), RwGeom<1>::LDS, stream, d_split,
-                                       lo, hi, qw.d_qsplit, nq, st.d_tau, d_dead, cand, st.d_cnt, cap);
-                else
-                    hipLaunchKernelGGL(score_filter_rw_kernel<2>, dim3(blocks), dim3(256), RwGeom<2>::LDS, stream, d_split,
-                                       lo, hi, qw.d_qsplit, nq, st.d_tau, d_dead, cand, st.d_cnt, cap);
+                const uint32_t per = nq <= 32 ? 32 : nq <= 64 ? 64 : 128;
+                const uint32_t qtiles = (nq + per - 1) / per;
+                const uint64_t tiles = (hi - lo + 127) / 128;
+                // row groups needed: one per corpus tile at most
+                uint64_t slots = (tiles + 7) / 8 * qtiles;  // per XCD
+                if (slots > (uint64_t)cus / 8) slots = (uint64_t)cus / 8;
+                if (slots < qtiles) slots = qtiles;
+                const uint32_t blocks = (uint32_t)slots * 8;
+#define CS_RW_LAUNCH(NQT_)                                                                                   \
+    hipLaunchKernelGGL(score_filter_rw_kernel<NQT_>, dim3(blocks), dim3(256), RwGeom<NQT_>::LDS, stream, d_split, lo, \
+                       hi, qw.d_qsplit, nq, st.d_tau, d_dead, cand, st.d_cnt, cap, qtiles)
+                if (per == 32) CS_RW_LAUNCH(1);
+                else if (per == 64) CS_RW_LAUNCH(2);
+                else CS_RW_LAUNCH(4);
+#undef CS_RW_LAUNCH
             } else if (wide) {
                 const uint32_t mt2 = (uint32_t)((hi - lo + UF2_BM - 1) / UF2_BM), nt2 = (nq + UF2_BN - 1) / UF2_BN;
                 hipLaunchKernelGGL(score_filter256_kernel, dim3(sh_grid_blocks(mt2, nt2)), dim3(512), UF2_LDS, stream,

@@ -44,11 +44,11 @@ def assert_topk_equal(got_cos, got_ids, exp_cos, exp_ids, corpus=None, q=None, o
 
 # ---- the reference's own tests, re-expressed (store.rs:833-1028) --------------------------------
 
-def test_reference_insert_and_search(VS):
-    """store.rs:846-893 test_insert_and_search, 4-d vectors, k=2."""
+def test_reference_insert_and_search(VS, tmp_path):
+    """store.rs:846-893 test_insert_and_search, 4-d vectors, k=2 (TempDir + test.db as there)."""
     from codesearch_amd import Chunk, EmbeddedChunk
 
-    store = VS("test.db", 4)
+    store = VS(tmp_path / "test.db", 4)
     assert store.dimensions == 4 and not store.is_indexed()  # store.rs:834-844
     chunks = [
         EmbeddedChunk(Chunk("fn authenticate() {}", 0, 1, "Function", "auth.rs"), [1.0, 0.0, 0.0, 0.0]),
@@ -74,7 +74,7 @@ def test_reference_insert_and_search(VS):
 def test_reference_error_texts(VS):
     from codesearch_amd import Chunk, CsError, EmbeddedChunk
 
-    store = VS("t.db", 4)
+    store = VS(None, 4)
     with pytest.raises(CsError) as e:  # store.rs:440-444
         store.search([1, 0, 0, 0], 1)
     assert str(e.value) == "Index not built. Call build_index() after inserting chunks."
