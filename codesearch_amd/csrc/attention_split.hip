@@ -16,6 +16,12 @@
 #include "encoder.hpp"
 #include "split_f16.hpp"
 
+// Diagnostic builds (benchmarks/attn_probe.hip) define AT_STAMP to record s_memtime at points of a
+// block's life; the product build compiles it to nothing.
+#ifndef AT_STAMP
+#define AT_STAMP(i)
+#endif
+
 namespace cs {
 
 typedef __fp16 h16x2 __attribute__((ext_vector_type(2)));
@@ -62,38 +68,59 @@ attention_sh_kernel(const float* __restrict__ qkv, const int32_t* __restrict__ m
     const float* base = qkv + (size_t)b * L * row3 + head * 32;
     bool ovf = false;
 
+    AT_STAMP(0);
     if (tid == 0) *last_valid_p = 0;
     __syncthreads();
-    // K: thread -> (key, 4 consecutive d)
-    for (uint32_t idx = tid; idx < Lp * 8; idx += 256) {
-        const uint32_t key = idx >> 3, c4 = idx & 7;
-        sh_f32x4 kv = {0.f, 0.f, 0.f, 0.f};
-        if (key < L) kv = *reinterpret_cast<const sh_f32x4*>(base + key * row3 + H + c4 * 4);
-        f16x4 hi, lo;
+    // K: thread -> (key, 4 consecutive d).  Loads are issued four iterations at a time before any
+    // of them is converted: one HBM round trip per batch instead of one per iteration.
+    for (uint32_t idx0 = tid; idx0 < Lp * 8; idx0 += 256 * 4) {
+        sh_f32x4 kv[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            _Float16 a, bb;
-            ovf |= sh_split(kv[e], a, bb);
-            hi[e] = a; lo[e] = bb;
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t idx = idx0 + 256 * u, key = idx >> 3, c4 = idx & 7;
+            kv[u] = sh_f32x4{0.f, 0.f, 0.f, 0.f};
+            if (key < L) kv[u] = *reinterpret_cast<const sh_f32x4*>(base + key * row3 + H + c4 * 4);
         }
-        *reinterpret_cast<f16x4*>(Kh + key * AT_KROW + c4 * 8) = hi;
-        *reinterpret_cast<f16x4*>(Kl + key * AT_KROW + c4 * 8) = lo;
-    }
-    // V^T: thread -> (key pair, 4 consecutive d); one 4-byte store per (d, plane)
-    for (uint32_t idx = tid; idx < (Lp / 2) * 8; idx += 256) {
-        const uint32_t kp = idx >> 3, c4 = idx & 7, key = 2 * kp;
-        sh_f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = {0.f, 0.f, 0.f, 0.f};
-        if (key < L) v0 = *reinterpret_cast<const sh_f32x4*>(base + key * row3 + 2 * H + c4 * 4);
-        if (key + 1 < L) v1 = *reinterpret_cast<const sh_f32x4*>(base + (key + 1) * row3 + 2 * H + c4 * 4);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            f16x2 hi, lo;
-            _Float16 a, bb;
-            ovf |= sh_split(v0[e], a, bb); hi[0] = a; lo[0] = bb;
-            ovf |= sh_split(v1[e], a, bb); hi[1] = a; lo[1] = bb;
-            const uint32_t d = c4 * 4 + e;
-            *reinterpret_cast<f16x2*>(Vth + d * VS + key * 2) = hi;
-            *reinterpret_cast<f16x2*>(Vtl + d * VS + key * 2) = lo;
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t idx = idx0 + 256 * u, key = idx >> 3, c4 = idx & 7;
+            if (idx >= Lp * 8) break;
+            f16x4 hi, lo;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                _Float16 a, bb;
+                ovf |= sh_split(kv[u][e], a, bb);
+                hi[e] = a; lo[e] = bb;
+            }
+            *reinterpret_cast<f16x4*>(Kh + key * AT_KROW + c4 * 8) = hi;
+            *reinterpret_cast<f16x4*>(Kl + key * AT_KROW + c4 * 8) = lo;
+        }
+    }
+    // V^T: thread -> (key pair, 4 consecutive d); one 4-byte store per (d, plane); batched likewise
+    for (uint32_t idx0 = tid; idx0 < (Lp / 2) * 8; idx0 += 256 * 2) {
+        sh_f32x4 v0[2], v1[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const uint32_t idx = idx0 + 256 * u, key = 2 * (idx >> 3), c4 = idx & 7;
+            v0[u] = sh_f32x4{0.f, 0.f, 0.f, 0.f};
+            v1[u] = sh_f32x4{0.f, 0.f, 0.f, 0.f};
+            if (key < L) v0[u] = *reinterpret_cast<const sh_f32x4*>(base + key * row3 + 2 * H + c4 * 4);
+            if (key + 1 < L) v1[u] = *reinterpret_cast<const sh_f32x4*>(base + (key + 1) * row3 + 2 * H + c4 * 4);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const uint32_t idx = idx0 + 256 * u, key = 2 * (idx >> 3), c4 = idx & 7;
+            if (idx >= (Lp / 2) * 8) break;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                f16x2 hi, lo;
+                _Float16 a, bb;
+                ovf |= sh_split(v0[u][e], a, bb); hi[0] = a; lo[0] = bb;
+                ovf |= sh_split(v1[u][e], a, bb); hi[1] = a; lo[1] = bb;
+                const uint32_t d = c4 * 4 + e;
+                *reinterpret_cast<f16x2*>(Vth + d * VS + key * 2) = hi;
+                *reinterpret_cast<f16x2*>(Vtl + d * VS + key * 2) = lo;
+            }
         }
     }
     for (uint32_t key = tid; key < Lp; key += 256) {
@@ -103,6 +130,7 @@ attention_sh_kernel(const float* __restrict__ qkv, const int32_t* __restrict__ m
     }
     __syncthreads();
     const uint32_t ntiles = (uint32_t)(*last_valid_p) / 32 + 1;  // trailing all-masked tiles contribute exp2(-3e38 - m) = 0
+    AT_STAMP(1);
 
     const char* kh_lane = Kh + l31 * AT_KROW + 16 * h;
     const char* kl_lane = Kl + l31 * AT_KROW + 16 * h;
@@ -227,7 +255,206 @@ attention_sh_kernel(const float* __restrict__ qkv, const int32_t* __restrict__ m
             }
         }
     }
+    AT_STAMP(2);
     if (ovf && flag) atomicOr(flag, 1u);
+}
+
+// ---- the same attention on a split-f16 qkv (the QKV GEMM's SH_OUT_SPLIT output) ------------------
+// head_dim 32 = one k-chunk, so K and V of a (token, head) are one 128-B line [32 hi | 32 lo] each,
+// exactly the layout the matrix pipe wants for K: the prologue is pure LDS-DMA (no conversion, no
+// ds_write; it was 36 % of a block's life when it split f32 K/V itself).  V stays [key][d] in LDS
+// and is consumed as the A operand V^T through the transposing read ds_read_b64_tr_b16: per
+// 16-lane group it turns a 4-key x 16-d block into "lane d holds its 4 keys" (verified on the
+// hardware with benchmarks/tr_probe).  LDS images: K pieces (16 B) at c ^ ((key >> 1) & 7) for
+// conflict-free ds_read_b128; V pieces at c ^ (4 * ((key >> 1) & 1)) so the four key rows and
+// four pieces a half-wave's transposing read touches cover all 64 banks once.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+union FragTr {
+    f16x8 v;
+    s16x4 q[2];
+};
+
+// Two probabilities -> packed (hi, hi) and (lo, lo), no subnormal guard (the f16 MFMA keeps
+// subnormal inputs; cs_embedder_create verifies that once per device).
+__device__ __forceinline__ void split_pair_rtz_ng(float a, float b, uint32_t& hi, uint32_t& lo) {
+    const h16x2 h = __builtin_amdgcn_cvt_pkrtz(a, b);
+    const h16x2 l = __builtin_amdgcn_cvt_pkrtz((a - (float)h[0]) * kShLoScale, (b - (float)h[1]) * kShLoScale);
+    hi = __builtin_bit_cast(uint32_t, h);
+    lo = __builtin_bit_cast(uint32_t, l);
+}
+
+__global__ void __launch_bounds__(256, 2)
+attention_sh2_kernel(const _Float16* __restrict__ qkvs, const int32_t* __restrict__ mask,
+                     _Float16* __restrict__ ctxs, uint32_t* __restrict__ flag, uint32_t L, uint32_t H,
+                     float scale_log2e) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const uint32_t Lp = (L + 31) & ~31u;
+    char* Kt = smem;                            // [Lp][128 B]
+    char* Vt = Kt + (size_t)Lp * 128;           // [Lp][128 B]
+    float* madd = reinterpret_cast<float*>(Vt + (size_t)Lp * 128);  // [Lp]
+    int* last_valid_p = reinterpret_cast<int*>(madd + Lp);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, h = lane >> 5;
+    const uint32_t head = blockIdx.x, b = blockIdx.y;
+    const uint32_t nh = H / 32, nch = 3 * nh;  // chunks per token row: Q heads | K heads | V heads
+    const _Float16* base = qkvs + (size_t)b * L * nch * 64;
+    bool ovf = false;
+
+    AT_STAMP(0);
+    if (tid == 0) *last_valid_p = 0;
+    for (uint32_t ii = wave; ii < Lp / 8; ii += 4) {  // 8 keys x 128 B per instruction and operand
+        const uint32_t row = ii * 8 + (lane >> 3);
+        const uint32_t key = row < L ? row : L - 1;   // keys past L are masked; read a valid line
+        const uint32_t ck = (lane & 7) ^ ((row >> 1) & 7);
+        const uint32_t cv = (lane & 7) ^ (4 * ((row >> 1) & 1));
+        sh_glds16(base + ((size_t)key * nch + nh + head) * 64 + ck * 8, Kt + ii * 1024);
+        sh_glds16(base + ((size_t)key * nch + 2 * nh + head) * 64 + cv * 8, Vt + ii * 1024);
+    }
+    __syncthreads();  // (last_valid_p initialised)
+    for (uint32_t key = tid; key < Lp; key += 256) {
+        const bool ok = key < L && mask[(size_t)b * L + key] != 0;
+        madd[key] = ok ? 0.0f : kMaskedLog2;
+        if (ok) atomicMax(last_valid_p, (int)key);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const uint32_t ntiles = (uint32_t)(*last_valid_p) / 32 + 1;
+    AT_STAMP(1);
+
+    const int kswz = (l31 >> 1) & 7;
+    const char* k_lane = Kt + l31 * 128;
+    int k_hi[2], k_lo[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        k_hi[s] = ((2 * s + h) ^ kswz) * 16;
+        k_lo[s] = ((4 + 2 * s + h) ^ kswz) * 16;
+    }
+    // transposing read of V: lane 4q+p of a 16-lane group supplies row q, columns 4p..4p+3 of the
+    // group's 4-key x 16-d block; group G = lane>>4: d0 = 16 (G&1), keys 4h + q (h = G>>1 = lane>>5)
+    const int vq = (lane & 15) >> 2, vp = lane & 3, vg = (lane >> 4) & 1;
+    const int vfv = 4 * ((vq >> 1) & 1);
+    const int v_hi = (4 * h + vq) * 128 + (((2 * vg + (vp >> 1)) ^ vfv) * 16) + 8 * (vp & 1);
+    const int v_lo = v_hi ^ 64;  // logical piece + 4 (the lo half of the line) under the same XOR
+
+    for (uint32_t qb = 0; qb * 128 < L; ++qb) {
+        if (qb * 128 + wave * 32 >= L) break;  // wave-uniform: no query of this wave's tile exists
+        const uint32_t query = qb * 128 + wave * 32 + l31;
+        const uint32_t qsrc = query < L ? query : L - 1;
+        // Q^T fragments (B operand): element j of step s = d 16s + 8h + j, straight from the split line
+        const _Float16* qp = base + ((size_t)qsrc * nch + head) * 64 + 8 * h;
+        f16x8 qh[2], ql[2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            qh[s] = *reinterpret_cast<const f16x8*>(qp + 16 * s);
+            ql[s] = *reinterpret_cast<const f16x8*>(qp + 32 + 16 * s);
+        }
+        sh_f32x16 ohh, oxx;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { ohh[r] = 0.0f; oxx[r] = 0.0f; }
+        float m = -__builtin_huge_valf(), lsum = 0.0f;
+
+        for (uint32_t kt = 0; kt < ntiles; ++kt) {
+            sh_f32x16 hh, xx;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { hh[r] = 0.0f; xx[r] = 0.0f; }
+            const char* kr = k_lane + (size_t)kt * 32 * 128;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const f16x8 kh = *reinterpret_cast<const f16x8*>(kr + k_hi[s]);
+                const f16x8 kl = *reinterpret_cast<const f16x8*>(kr + k_lo[s]);
+                hh = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[s], hh, 0, 0, 0);
+                xx = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[s], xx, 0, 0, 0);
+                xx = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[s], xx, 0, 0, 0);
+            }
+            float tmax = -__builtin_huge_valf();
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const sh_f32x4 ma = *reinterpret_cast<const sh_f32x4*>(madd + kt * 32 + 8 * g + 4 * h);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int r = 4 * g + e;
+                    hh[r] = fmaf(fmaf(xx[r], kShLoInv, hh[r]), scale_log2e, ma[e]);
+                    tmax = fmaxf(tmax, hh[r]);
+                }
+            }
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+            if (__any(tmax > m)) {
+                const float mnew = fmaxf(m, tmax);
+                const float alpha = __builtin_amdgcn_exp2f(m - mnew);
+                lsum *= alpha;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { ohh[r] *= alpha; oxx[r] *= alpha; }
+                m = mnew;
+            }
+            float psum = 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                hh[r] = __builtin_amdgcn_exp2f(hh[r] - m);
+                psum += hh[r];
+            }
+            lsum += psum;
+            Frag8 ph[2], pl[2];
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int w2 = 0; w2 < 4; ++w2)
+                    split_pair_rtz_ng(hh[8 * s + 2 * w2], hh[8 * s + 2 * w2 + 1], ph[s].u[w2], pl[s].u[w2]);
+            typedef __attribute__((address_space(3))) s16x4* lds_s16x4_p;
+            const char* vr = Vt + (size_t)kt * 32 * 128;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                // element j of the V^T fragment = key 16s + 8 (j>>2) + 4h + (j&3): two 4-key blocks
+                FragTr vh, vl;
+                vh.q[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(vr + s * 16 * 128 + v_hi));
+                vh.q[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(vr + s * 16 * 128 + 8 * 128 + v_hi));
+                vl.q[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(vr + s * 16 * 128 + v_lo));
+                vl.q[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(vr + s * 16 * 128 + 8 * 128 + v_lo));
+                ohh = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh.v, ph[s].v, ohh, 0, 0, 0);
+                oxx = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh.v, pl[s].v, oxx, 0, 0, 0);
+                oxx = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl.v, ph[s].v, oxx, 0, 0, 0);
+            }
+        }
+        lsum += __shfl_xor(lsum, 32, 64);
+        const float inv = 1.0f / lsum;
+        if (query < L) {
+            _Float16* op = ctxs + (((size_t)b * L + query) * nh + head) * 64 + 4 * h;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f16x4 hi, lo;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    _Float16 a, bb;
+                    ovf |= sh_split(fmaf(oxx[4 * g + e], kShLoInv, ohh[4 * g + e]) * inv, a, bb);
+                    hi[e] = a; lo[e] = bb;
+                }
+                *reinterpret_cast<f16x4*>(op + 8 * g) = hi;
+                *reinterpret_cast<f16x4*>(op + 32 + 8 * g) = lo;
+            }
+        }
+    }
+    AT_STAMP(2);
+    if (ovf && flag) atomicOr(flag, 1u);
+}
+
+int32_t launch_attention_sh2(const _Float16* qkv_split, const int32_t* mask, void* ctx_split, uint32_t* flag,
+                             uint32_t B, uint32_t L, uint32_t H, uint32_t heads, hipStream_t s) {
+    if (H / heads != 32 || H % heads)
+        return fail(CS_ERR_UNSUPPORTED, "head_dim %u not supported (32 only in this round)", heads ? H / heads : 0);
+    const size_t Lp = (L + 31) & ~31u;
+    const size_t lds = 2 * Lp * 128 + Lp * sizeof(float) + 16;
+    if (lds > 160 * 1024 - 64) return fail(CS_ERR_UNSUPPORTED, "sequence length %u exceeds the LDS-resident K/V limit", L);
+    static bool attr_set = false;
+    if (!attr_set) {
+        CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attention_sh2_kernel),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(attention_sh2_kernel, dim3(heads, B), dim3(256), lds, s, qkv_split, mask,
+                       static_cast<_Float16*>(ctx_split), flag, L, H, (1.0f / sqrtf(32.0f)) * kLog2e);
+    CS_HIP(hipGetLastError());
+    return CS_OK;
 }
 
 size_t attention_sh_lds_bytes(uint32_t L) {

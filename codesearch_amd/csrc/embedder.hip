@@ -22,6 +22,7 @@ struct cs_embedder {
     _Float16* d_wsplit = nullptr;  // per layer: wqkv | attention-out | ffn-up | ffn-down, split-f16 rows
     uint32_t* d_flag = nullptr;    // split-f16 range flag
     int gemm_mode = CS_GEMM_SPLIT_F16;
+    bool split_unavailable = false;  // device flushes f16 subnormals in the MFMA: exact-f32 kernels only
     uint64_t split_forwards = 0, f32_forwards = 0, range_fallbacks = 0;
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;     // second half of a mini-batch runs here (see forward())
@@ -121,8 +122,15 @@ int32_t forward_range(cs_embedder* h, hipStream_t s, uint32_t b0, uint32_t nb, u
         const float* bqkv = h->d_bqkv + (size_t)l * 3 * H;
         if (split) {
             const _Float16* ws = h->d_wsplit + (size_t)l * sl.total;
-            CS_TRY(launch_gemm_split(SH_OUT_F32, xs, ws + sl.qkv, bqkv, nullptr, qkv, nullptr, T, 3 * H, H, h->d_flag, s));   // E2
-            CS_TRY(launch_attention_split(qkv, mask, ctxs, h->d_flag, nb, L, H, c.heads, s));                              // E3
+            static const bool attn_v1 = std::getenv("CS_ATTN_V1") != nullptr;  // A/B: f32 qkv + converting prologue
+            if (attn_v1) {
+                CS_TRY(launch_gemm_split(SH_OUT_F32, xs, ws + sl.qkv, bqkv, nullptr, qkv, nullptr, T, 3 * H, H, h->d_flag, s));
+                CS_TRY(launch_attention_split(qkv, mask, ctxs, h->d_flag, nb, L, H, c.heads, s));
+            } else {
+                _Float16* qkvs = reinterpret_cast<_Float16*>(qkv);  // [T][3H/32][64] f16: same bytes as the f32 qkv
+                CS_TRY(launch_gemm_split(SH_OUT_SPLIT, xs, ws + sl.qkv, bqkv, nullptr, nullptr, qkvs, T, 3 * H, H, h->d_flag, s));  // E2
+                CS_TRY(launch_attention_sh2(qkvs, mask, ctxs, h->d_flag, nb, L, H, c.heads, s));                                 // E3
+            }
             CS_TRY(launch_gemm_split(SH_OUT_F32_RESID, ctxs, ws + sl.ao, P + lo.ao_b, x, x, nullptr, T, H, H, h->d_flag, s));  // E4
             a.g = P + lo.ao_ln_g; a.b = P + lo.ao_ln_b;
             CS_TRY(launch_row_kernel(1, a, H, s));
@@ -338,6 +346,9 @@ int32_t cs_embedder_create(const cs_bert_config* cfg, const float* params, uint6
         if (const char* env = std::getenv("CS_ENCODER_GEMM"))
             h->gemm_mode = (std::strcmp(env, "f32") == 0) ? CS_GEMM_F32 : CS_GEMM_SPLIT_F16;
         if (wflag) h->gemm_mode = CS_GEMM_F32;  // a weight outside the f16 range: exact path only
+        bool denorm_ok = false;  // the split format relies on exact f16-subnormal MFMA inputs
+        if (s == CS_OK) s = sh_denorm_selftest(&denorm_ok, h->stream);
+        if (s == CS_OK && !denorm_ok) { h->gemm_mode = CS_GEMM_F32; h->split_unavailable = true; }
         if (const char* env = std::getenv("CS_ENCODER_STREAMS")) h->n_streams = std::atoi(env) >= 2 ? 2 : 1;
     }
     if (s == CS_OK && hipStreamSynchronize(h->stream) != hipSuccess) s = fail(CS_ERR_HIP, "parameter setup failed");
@@ -401,6 +412,8 @@ int32_t cs_embedder_profile_read(cs_embedder* h, double* forward_ms, uint64_t* f
 int32_t cs_embedder_set_gemm_mode(cs_embedder* h, int32_t mode) {
     if (!h) return fail(CS_ERR_BAD_ARG, "null embedder handle");
     if (mode != CS_GEMM_F32 && mode != CS_GEMM_SPLIT_F16) return fail(CS_ERR_BAD_ARG, "unknown gemm mode %d", mode);
+    if (mode == CS_GEMM_SPLIT_F16 && h->split_unavailable)
+        return fail(CS_ERR_UNSUPPORTED, "split-f16 mode needs exact f16-subnormal MFMA inputs, which this device/mode lacks");
     h->gemm_mode = mode;
     return CS_OK;
 }

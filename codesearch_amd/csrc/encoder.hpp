@@ -44,9 +44,13 @@ size_t attention_lds_bytes(uint32_t L);
 int32_t launch_attention_sh(const float* qkv, const int32_t* mask, float* ctx, void* ctx_split, uint32_t* flag,
                             uint32_t B, uint32_t L, uint32_t H, uint32_t heads, hipStream_t s);
 size_t attention_sh_lds_bytes(uint32_t L);
+// attention on a split-f16 qkv [T][3H/32][64] (the QKV GEMM's SH_OUT_SPLIT output): K/V go to LDS by
+// LDS-DMA with no conversion, V is consumed through the transposing LDS read; writes ctx in split form.
+int32_t launch_attention_sh2(const _Float16* qkv_split, const int32_t* mask, void* ctx_split, uint32_t* flag,
+                             uint32_t B, uint32_t L, uint32_t H, uint32_t heads, hipStream_t s);
 
 // Split-f16 GEMM (gemm_split.hip): A [M][K/32][64] f16, W [N][K/32][64] f16 (split_f16.hpp).
-enum { SH_OUT_F32 = 0, SH_OUT_F32_RESID = 1, SH_OUT_SPLIT_GELU = 2 };
+enum { SH_OUT_F32 = 0, SH_OUT_F32_RESID = 1, SH_OUT_SPLIT_GELU = 2, SH_OUT_SPLIT = 3 };
 int32_t launch_gemm_split(int epi, const _Float16* A, const _Float16* W, const float* bias, const float* resid,
                           float* C, _Float16* Cs, uint32_t M, uint32_t N, uint32_t K, uint32_t* d_flag,
                           hipStream_t s);

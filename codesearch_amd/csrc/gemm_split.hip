@@ -30,7 +30,7 @@ __device__ __forceinline__ void gemm_sh_epilogue(const float* ctile, const float
                                                  uint32_t M, uint32_t N, uint32_t m0, uint32_t n0,
                                                  uint32_t* __restrict__ flag) {
     const int tid = threadIdx.x;
-    if (EPI == SH_OUT_SPLIT_GELU) {
+    if (EPI == SH_OUT_SPLIT_GELU || EPI == SH_OUT_SPLIT) {
         bool ovf = false;
         const int c8 = tid & 15;  // 8 consecutive n per thread
         const sh_f32x4 b0 = *reinterpret_cast<const sh_f32x4*>(bias + n0 + c8 * 8);
@@ -45,9 +45,9 @@ __device__ __forceinline__ void gemm_sh_epilogue(const float* ctile, const float
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 _Float16 a, b;
-                ovf |= sh_split(sh_gelu_erf(v0[e] + b0[e]), a, b);
+                ovf |= sh_split(EPI == SH_OUT_SPLIT_GELU ? sh_gelu_erf(v0[e] + b0[e]) : v0[e] + b0[e], a, b);
                 hi[e] = a; lo[e] = b;
-                ovf |= sh_split(sh_gelu_erf(v1[e] + b1[e]), a, b);
+                ovf |= sh_split(EPI == SH_OUT_SPLIT_GELU ? sh_gelu_erf(v1[e] + b1[e]) : v1[e] + b1[e], a, b);
                 hi[4 + e] = a; lo[4 + e] = b;
             }
             if (FULL || m0 + row < M) {
@@ -172,6 +172,40 @@ split_rows_kernel(const float* __restrict__ src, _Float16* __restrict__ dst, uin
     if (ovf && flag) atomicOr(flag, 1u);
 }
 
+// a = 2^-24 (the smallest f16 subnormal) at k = 0 of every row, b = 1024: every output must be 2^-14
+// (x2: both lane halves hold a k = 0 element of their own 8-k group).
+__global__ void denorm_selftest_kernel(uint32_t* ok) {
+    f16x8 a, b;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { a[j] = (_Float16)0.0f; b[j] = (_Float16)0.0f; }
+    a[0] = (_Float16)5.9604645e-08f;
+    b[0] = (_Float16)1024.0f;
+    sh_f32x16 c;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) c[r] = 0.0f;
+    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+    bool good = true;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) good &= c[r] == 2.0f * 1024.0f * 5.9604645e-08f;
+    if (!good) atomicAnd(ok, 0u);
+}
+
+int32_t sh_denorm_selftest(bool* ok, hipStream_t s) {
+    uint32_t* d = nullptr;
+    uint32_t hv = 1;
+    CS_HIP(hipMalloc(&d, sizeof(uint32_t)));
+    hipError_t e = hipMemcpyAsync(d, &hv, sizeof hv, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(denorm_selftest_kernel, dim3(1), dim3(64), 0, s, d);
+        e = hipMemcpyAsync(&hv, d, sizeof hv, hipMemcpyDeviceToHost, s);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(CS_ERR_HIP, "f16 subnormal self-test failed to run: %s", hipGetErrorString(e));
+    *ok = hv == 1;
+    return CS_OK;
+}
+
 int32_t launch_split_rows(const float* d_src, _Float16* d_dst, uint64_t rows, uint32_t K, uint32_t* d_flag,
                           hipStream_t s, const float* d_row_norm) {
     if (K % 32) return fail(CS_ERR_UNSUPPORTED, "split-f16 layout needs K %% 32 == 0 (K = %u)", K);
@@ -194,6 +228,7 @@ int32_t launch_gemm_split(int epi, const _Float16* A, const _Float16* W, const f
         CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_sh_kernel<SH_OUT_F32>), hipFuncAttributeMaxDynamicSharedMemorySize, SH_LDS_BYTES));
         CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_sh_kernel<SH_OUT_F32_RESID>), hipFuncAttributeMaxDynamicSharedMemorySize, SH_LDS_BYTES));
         CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_sh_kernel<SH_OUT_SPLIT_GELU>), hipFuncAttributeMaxDynamicSharedMemorySize, SH_LDS_BYTES));
+        CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_sh_kernel<SH_OUT_SPLIT>), hipFuncAttributeMaxDynamicSharedMemorySize, SH_LDS_BYTES));
         attr_set = true;
     }
     const uint32_t kc = K / 32;
@@ -209,11 +244,13 @@ int32_t launch_gemm_split(int epi, const _Float16* A, const _Float16* W, const f
             CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_sh3_kernel<SH_OUT_F32>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
             CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_sh3_kernel<SH_OUT_F32_RESID>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
             CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_sh3_kernel<SH_OUT_SPLIT_GELU>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
+            CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_sh3_kernel<SH_OUT_SPLIT>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
             attr3 = true;
         }
         const dim3 grid3(sh_grid_blocks((M + G::BM - 1) / G::BM, N / SH_BN));
         if (epi == SH_OUT_F32) hipLaunchKernelGGL(gemm_sh3_kernel<SH_OUT_F32>, grid3, dim3(G::THREADS), G::LDS, s, A, W, bias, resid, C, Cs, M, N, kc, d_flag);
         else if (epi == SH_OUT_F32_RESID) hipLaunchKernelGGL(gemm_sh3_kernel<SH_OUT_F32_RESID>, grid3, dim3(G::THREADS), G::LDS, s, A, W, bias, resid, C, Cs, M, N, kc, d_flag);
+        else if (epi == SH_OUT_SPLIT) hipLaunchKernelGGL(gemm_sh3_kernel<SH_OUT_SPLIT>, grid3, dim3(G::THREADS), G::LDS, s, A, W, bias, resid, C, Cs, M, N, kc, d_flag);
         else hipLaunchKernelGGL(gemm_sh3_kernel<SH_OUT_SPLIT_GELU>, grid3, dim3(G::THREADS), G::LDS, s, A, W, bias, resid, C, Cs, M, N, kc, d_flag);
         CS_HIP(hipGetLastError());
         return CS_OK;
@@ -221,6 +258,7 @@ int32_t launch_gemm_split(int epi, const _Float16* A, const _Float16* W, const f
     const dim3 grid(sh_grid_blocks((M + SH_BM - 1) / SH_BM, N / SH_BN));
     if (epi == SH_OUT_F32) hipLaunchKernelGGL(gemm_sh_kernel<SH_OUT_F32>, grid, dim3(256), SH_LDS_BYTES, s, A, W, bias, resid, C, Cs, M, N, kc, d_flag);
     else if (epi == SH_OUT_F32_RESID) hipLaunchKernelGGL(gemm_sh_kernel<SH_OUT_F32_RESID>, grid, dim3(256), SH_LDS_BYTES, s, A, W, bias, resid, C, Cs, M, N, kc, d_flag);
+    else if (epi == SH_OUT_SPLIT) hipLaunchKernelGGL(gemm_sh_kernel<SH_OUT_SPLIT>, grid, dim3(256), SH_LDS_BYTES, s, A, W, bias, resid, C, Cs, M, N, kc, d_flag);
     else hipLaunchKernelGGL(gemm_sh_kernel<SH_OUT_SPLIT_GELU>, grid, dim3(256), SH_LDS_BYTES, s, A, W, bias, resid, C, Cs, M, N, kc, d_flag);
     CS_HIP(hipGetLastError());
     return CS_OK;

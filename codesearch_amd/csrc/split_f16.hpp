@@ -5,15 +5,14 @@
 // products of this path (the encoder's QKV/FFN GEMMs, the batched query x corpus scan) therefore
 // run on v_mfma_f32_32x32x16_f16 with every f32 operand x stored as TWO f16 values
 //
-//     x  =  hi  +  lo / 2048  +  e,     hi = rn_f16(x) (0 when |x| < 2^-14, so no f16 subnormal
-//     lo =  rn_f16((x - hi) * 2048)     is ever the high part of an MFMA input)
-//     |e| <= 2^-22 |x|  for |x| >= 2^-14;   |e| <= 2^-11 |x| <= 2^-25  below (lo alone carries x)
+//     x  =  hi  +  lo / 2048  +  e,     hi = rn_f16(x),  lo = rn_f16((x - hi) * 2048)
+//     |e| <= 2^-22 |x|  for |x| >= 2^-14;   |e| <= 2^-36 below (hi and lo are then f16 subnormals,
+//     which the f16 MFMA consumes exactly: verified at cs_embedder_create, sh_denorm_selftest)
 //
 // and a product sum  sum a*w  evaluated as  sum a_hi*w_hi  +  2^-11 * sum (a_hi*w_lo + a_lo*w_hi)
 // with both sums accumulated in f32 by the MFMA (three f16 MFMAs in place of sixteen-cycles-each
 // f32 ones: 3/16 of the matrix-pipe time).  Dropped: a_lo*w_lo <= 2^-22 |a w|.  Per-product error
-// is <= ~3 * 2^-22 |a w| (+ 2^-25 |w| for a tiny a), the same order as the rounding of an f32
-// fmaf chain at K ~ 10^3; LayerNorm'd / GELU'd activations and BERT weights are O(1e-2..1e1).
+// is <= ~3 * 2^-22 |a w|, the same order as the rounding of an f32 fmaf chain at K ~ 10^3.
 // Values with |x| > 65504 do not fit: producers raise an overflow flag that the host checks
 // (cs_embedder falls back to the exact-f32 kernels; the scan uses the result only as a filter).
 //
@@ -37,10 +36,18 @@ constexpr float kShLoInv = 1.0f / 2048.0f;
 constexpr float kShMinNormal = 6.103515625e-05f;  // 2^-14
 constexpr float kShMax = 65504.0f;
 
-// One value -> (hi, lo).  Returns true when the value does not fit the format.
+// One value -> (hi, lo).  Returns true when the value does not fit the format.  hi may be an f16
+// subnormal: the f16 MFMA takes subnormal inputs at full precision under the kernels' default
+// denormal mode (measured: benchmarks/denorm_probe; cs_embedder_create re-checks it on the device
+// with sh_denorm_selftest and otherwise stays on the exact-f32 kernels).
 __device__ __forceinline__ bool sh_split(float x, _Float16& hi, _Float16& lo) {
-    const float xs = fabsf(x) < kShMinNormal ? 0.0f : x;
-    hi = (_Float16)xs;
+    hi = (_Float16)x;
+    // The stored bits must be the ONLY source of the value lo is computed against.  When x is the
+    // result of a multiply (GELU's last product), hipcc may produce the stored hi with
+    // v_fma_mixlo_f16 — f16(a*b) rounded once from the exact product — while `(float)hi` below is
+    // derived from a separate conversion of the f32-rounded x; for x within an f32 ulp of an f16
+    // rounding tie (1 element in 4096) the two differ and the pair is off by a whole f16 ulp.
+    asm volatile("" : "+v"(hi));
     lo = (_Float16)((x - (float)hi) * kShLoScale);  // x - hi is exact in f32
     return !(fabsf(x) <= kShMax);                    // also true for NaN
 }
@@ -368,6 +375,8 @@ __device__ __forceinline__ uint32_t sh_kc_rot(uint32_t nt, uint32_t ntiles, uint
 inline uint32_t sh_grid_blocks(uint32_t mtiles, uint32_t ntiles) { return ((mtiles + 7) / 8) * 8 * ntiles; }
 
 // ---- host-visible launchers (gemm_split.hip) ----------------------------------------------
+// True when the f16 MFMA on the current device multiplies f16 subnormal inputs exactly.
+int32_t sh_denorm_selftest(bool* ok, hipStream_t s);
 // rows x K f32 -> split layout; flag (device u32, may be null) is OR-ed with 1 on overflow;
 // d_row_norm (may be null): row r is divided by d_row_norm[r] first (zero norm -> zero row).
 int32_t launch_split_rows(const float* d_src, _Float16* d_dst, uint64_t rows, uint32_t K, uint32_t* d_flag,
