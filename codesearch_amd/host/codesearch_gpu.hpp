@@ -183,6 +183,8 @@ class VectorStore {
     }
     size_t dimensions() const { return dimensions_; }
     cs_index* handle() const { return h_; }
+    // searches of >= n queries take the f16 filter + exact f32 refine path (default 2; 1 = always)
+    void set_filter_min_queries(uint32_t n) { check(cs_index_set_filter_min_queries(h_, n)); }
 
   private:
     cs_index* h_ = nullptr;
@@ -222,6 +224,8 @@ class FastEmbedder {
     }
     size_t dimensions() const { return cs_embedder_dim(h_); }  // embedder.rs:307
     cs_embedder* handle() const { return h_; }
+    // CS_GEMM_SPLIT_F16 (default) or CS_GEMM_F32 (exact-f32 MFMA), include/codesearch_gpu.h
+    void set_gemm_mode(cs_gemm_mode mode) { check(cs_embedder_set_gemm_mode(h_, (int32_t)mode)); }
 
   private:
     cs_embedder* h_ = nullptr;
