@@ -84,6 +84,15 @@ SIGNATURES = {
     "cs_embedder_profile_read": (C.c_int32, [vp, f64p, u64p, C.c_int32]),
     "cs_embedder_set_gemm_mode": (C.c_int32, [vp, C.c_int32]),
     "cs_embedder_debug_counters": (C.c_int32, [vp, u64p, u64p, u64p]),
+    "cs_tokenizer_create": (C.c_int32, [C.c_char_p, C.c_uint64, C.c_int32, C.c_uint32, C.POINTER(vp)]),
+    "cs_tokenizer_create_from_file": (C.c_int32, [C.c_char_p, C.c_int32, C.c_uint32, C.POINTER(vp)]),
+    "cs_tokenizer_destroy": (None, [vp]),
+    "cs_tokenizer_vocab_size": (C.c_uint32, [vp]),
+    "cs_tokenizer_token_to_id": (C.c_int32, [vp, C.c_char_p]),
+    "cs_tokenizer_encode_batch": (C.c_int32, [vp, C.c_char_p, u64p, C.c_uint32, C.c_uint32, i32p, i32p,
+                                              C.c_uint32, u32p]),
+    "cs_embedder_embed_texts": (C.c_int32, [vp, vp, C.c_char_p, u64p, C.c_uint64, C.c_uint32, f32p, i32p]),
+    "cs_embedder_embed_texts_device": (C.c_int32, [vp, vp, C.c_char_p, u64p, C.c_uint64, C.c_uint32, vp, i32p]),
     "cs_debug_gemm": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32, f32p, f32p, f32p, f32p, f32p,
                                   C.c_uint32, C.c_uint32, C.c_uint32, u32p]),
 }

@@ -7,6 +7,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <string>
+#include <vector>
 
 #include "../../include/codesearch_gpu.h"
 
@@ -66,6 +67,10 @@ __host__ __device__ __forceinline__ float key_cos(uint64_t key) {
 #endif
 }
 __host__ __device__ __forceinline__ uint32_t key_id(uint64_t key) { return ~(uint32_t)key; }
+
+// tokenizer.cpp: per-text id lists ([CLS] ... [SEP], truncated to max_length), texts in parallel
+void tokenize_texts(const cs_tokenizer* t, const char* utf8, const uint64_t* offsets, uint32_t n,
+                    uint32_t max_length, std::vector<std::vector<int32_t>>& out);
 
 inline uint32_t next_pow2(uint32_t v) {
     uint32_t p = 1;

@@ -3,8 +3,10 @@
 // host concern); runs the encoder kernels of encoder.hip; returns pooled, L2-normalised
 // embeddings.  Mini-batching and the shutdown poll follow embed_batch_chunked
 // (embedder.rs:266-295).
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <thread>
 #include <vector>
 
 #include "encoder.hpp"
@@ -245,6 +247,63 @@ int32_t embed_impl(cs_embedder* h, const int32_t* ids, const int32_t* mask, uint
     return CS_OK;
 }
 
+
+// embed_batch_chunked from strings (embedder.rs:266-295): tokenise mini-batch i+1 on host threads
+// while the device runs mini-batch i; each mini-batch is padded to its own longest sequence.
+struct TokenBatch {
+    std::vector<int32_t> ids, mask;
+    uint32_t B = 0, L = 0;
+};
+
+void tokenize_batch(const cs_tokenizer* t, const char* utf8, const uint64_t* offsets, uint32_t B,
+                    uint32_t max_length, int32_t pad, TokenBatch* out) {
+    std::vector<std::vector<int32_t>> enc;
+    cs::tokenize_texts(t, utf8, offsets, B, max_length, enc);
+    uint32_t L = 1;
+    for (const auto& e : enc) L = std::max<uint32_t>(L, (uint32_t)e.size());
+    out->B = B;
+    out->L = L;
+    out->ids.assign((size_t)B * L, pad);
+    out->mask.assign((size_t)B * L, 0);
+    for (uint32_t i = 0; i < B; ++i)
+        for (size_t j = 0; j < enc[i].size(); ++j) {
+            out->ids[(size_t)i * L + j] = enc[i][j];
+            out->mask[(size_t)i * L + j] = 1;
+        }
+}
+
+int32_t embed_texts_impl(cs_embedder* h, const cs_tokenizer* t, const char* utf8, const uint64_t* offsets,
+                         uint64_t n, uint32_t batch, float* out, bool out_on_device,
+                         const volatile int32_t* cancel) {
+    if (!h) return fail(CS_ERR_BAD_ARG, "null embedder handle");
+    if (!t) return fail(CS_ERR_BAD_ARG, "Failed to generate embeddings: no tokenizer attached");
+    if (n == 0) return CS_OK;  // embedder.rs:271-273
+    if (!utf8 || !offsets || !out) return fail(CS_ERR_BAD_ARG, "null buffer");
+    for (uint64_t i = 0; i < n; ++i)
+        if (offsets[i + 1] < offsets[i]) return fail(CS_ERR_BAD_ARG, "text offsets must be non-decreasing");
+    if (batch == 0) batch = default_batch(h);
+    const uint32_t max_length = h->cfg.max_position;
+    const int32_t pad = cs_tokenizer_token_to_id(t, "[PAD]");
+    const uint32_t H = h->cfg.hidden;
+    TokenBatch cur, nxt;
+    auto span = [&](uint64_t lo) { return (uint32_t)std::min<uint64_t>(batch, n - lo); };
+    tokenize_batch(t, utf8, offsets, span(0), max_length, pad, &cur);
+    for (uint64_t done = 0; done < n; done += batch) {
+        if (cancel && *cancel)  // embedder.rs:280-282
+            return fail(CS_ERR_CANCELLED, "Embedding interrupted by shutdown request");
+        const uint64_t next_lo = done + batch;
+        std::thread ahead;
+        if (next_lo < n)
+            ahead = std::thread(tokenize_batch, t, utf8, offsets + next_lo, span(next_lo), max_length, pad, &nxt);
+        const int32_t st = embed_impl(h, cur.ids.data(), cur.mask.data(), cur.B, cur.L, cur.B, out + done * H,
+                                      out_on_device, nullptr);
+        if (ahead.joinable()) ahead.join();
+        if (st != CS_OK) return st;
+        std::swap(cur, nxt);
+    }
+    return CS_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -389,6 +448,18 @@ int32_t cs_embedder_embed_ids_device(cs_embedder* h, const int32_t* ids, const i
                                      uint64_t n, uint32_t seq_len, uint32_t batch, float* d_out,
                                      const volatile int32_t* cancel) {
     return embed_impl(h, ids, mask, n, seq_len, batch, d_out, true, cancel);
+}
+
+int32_t cs_embedder_embed_texts(cs_embedder* h, const cs_tokenizer* t, const char* utf8,
+                                const uint64_t* offsets, uint64_t n, uint32_t batch, float* out,
+                                const volatile int32_t* cancel) {
+    return embed_texts_impl(h, t, utf8, offsets, n, batch, out, false, cancel);
+}
+
+int32_t cs_embedder_embed_texts_device(cs_embedder* h, const cs_tokenizer* t, const char* utf8,
+                                       const uint64_t* offsets, uint64_t n, uint32_t batch, float* d_out,
+                                       const volatile int32_t* cancel) {
+    return embed_texts_impl(h, t, utf8, offsets, n, batch, d_out, true, cancel);
 }
 
 int32_t cs_embedder_last_hidden(cs_embedder* h, float* out, uint64_t n_tokens) {

@@ -3,8 +3,9 @@
 Same method names and behaviour as /root/reference/src/embed/embedder.rs:7-322:
 `with_cache_dir`, `embed_batch` (adaptive mini-batch 256/128/64, `CODESEARCH_BATCH_SIZE`),
 `embed_batch_chunked` (shutdown poll between mini-batches), `embed_one`, `dimensions`,
-`model_name`, `model_type`.  The device side starts from token ids; texts go through a
-tokenizer object supplied by the caller (the host text path is SURVEY.md §8f-1).
+`model_name`, `model_type`.  The device side starts from token ids; texts go through
+cs_embedder_embed_texts with the WordPieceTokenizer (cs_tokenizer, csrc/tokenizer.cpp) the
+caller attaches (the model's vocab.txt).
 """
 from __future__ import annotations
 
@@ -18,6 +19,7 @@ import numpy as np
 from . import _lib
 from ._lib import CsError, f32p, i32p
 from .bert_params import POOL_CLS, POOL_MEAN, BertConfig
+from .tokenizer import pack_texts
 
 
 class ModelType(enum.Enum):
@@ -200,41 +202,42 @@ class FastEmbedder:
         return out
 
     # ---- text entry points (embedder.rs:249-304) --------------------------------------------
-    def _tokenize(self, texts: Sequence[str]):
+    def _require_tokenizer(self):
         if self.tokenizer is None:
             raise CsError(_lib.CS_ERR_UNSUPPORTED,
                           "Failed to generate embeddings: no tokenizer attached (pass tokenizer=...)")
-        return self.tokenizer.encode_batch(list(texts), self.config.max_position)
+        return self.tokenizer
 
     def embed_batch(self, texts: Sequence[str]) -> List[np.ndarray]:
-        """embedder.rs:249-263: mini-batch from CODESEARCH_BATCH_SIZE or 256/128/64 by dims."""
-        env = os.environ.get("CODESEARCH_BATCH_SIZE")
-        if env is not None:
-            try:
-                batch_size = int(env)
-                if batch_size <= 0:
-                    batch_size = 256
-            except ValueError:
-                batch_size = 256
-        else:
-            d = self.dimensions()
-            batch_size = 256 if d <= 384 else (128 if d <= 768 else 64)
-        return self.embed_batch_chunked(texts, batch_size)
+        """embedder.rs:249-263: mini-batch from CODESEARCH_BATCH_SIZE or 256/128/64 by dims
+        (batch 0 = that policy, applied inside cs_embedder_embed_texts)."""
+        return self.embed_batch_chunked(texts, 0)
 
     def embed_batch_chunked(self, texts: Sequence[str], batch_size: int) -> List[np.ndarray]:
-        """embedder.rs:266-295: tokenise and run each mini-batch (padded batch-longest, as
-        fastembed does), polling the shutdown flag between mini-batches."""
+        """embedder.rs:266-295 through cs_embedder_embed_texts: each mini-batch tokenised on the
+        host (padded batch-longest, as fastembed does) and run on the device, the shutdown flag
+        polled between mini-batches."""
         texts = list(texts)
         if not texts:
             return []
-        out: List[np.ndarray] = []
-        for lo in range(0, len(texts), batch_size):
-            if is_shutdown_requested():
-                raise CsError(_lib.CS_ERR_CANCELLED, "Embedding interrupted by shutdown request")
-            ids, mask = self._tokenize(texts[lo:lo + batch_size])
-            emb = self.embed_ids(ids, mask, batch_size)
-            out.extend(emb[i] for i in range(emb.shape[0]))
-        return out
+        tok = self._require_tokenizer()
+        blob, offsets = pack_texts(texts)
+        emb = np.empty((len(texts), self.dimensions()), np.float32)
+        _lib.check(self._lib.cs_embedder_embed_texts(self._h, tok.handle, blob, offsets.ctypes.data_as(_lib.u64p),
+                                                     len(texts), batch_size, emb.ctypes.data_as(f32p),
+                                                     C.cast(C.byref(_SHUTDOWN), i32p)))
+        return [emb[i] for i in range(emb.shape[0])]
+
+    def embed_texts_to_device(self, texts: Sequence[str], d_out_ptr: int, batch_size: int = 0) -> None:
+        """Same, leaving the [n, dim] result at the device address d_out_ptr."""
+        texts = list(texts)
+        if not texts:
+            return
+        tok = self._require_tokenizer()
+        blob, offsets = pack_texts(texts)
+        _lib.check(self._lib.cs_embedder_embed_texts_device(self._h, tok.handle, blob,
+                                                            offsets.ctypes.data_as(_lib.u64p), len(texts), batch_size,
+                                                            C.c_void_p(d_out_ptr), C.cast(C.byref(_SHUTDOWN), i32p)))
 
     def embed_one(self, text: str) -> np.ndarray:
         """embedder.rs:298-304."""

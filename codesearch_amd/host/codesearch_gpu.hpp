@@ -192,7 +192,53 @@ class VectorStore {
     std::map<uint32_t, ChunkMetadata> meta_;
 };
 
-// FastEmbedder from token ids (tokenisation stays with the caller).
+// The tokenizer fastembed builds from the model's tokenizer.json (tokenizers 0.22.2): vocab.txt in,
+// [CLS] ... [SEP] ids out (csrc/tokenizer.cpp).
+class Tokenizer {
+  public:
+    explicit Tokenizer(const std::string& vocab_path, bool lowercase = true, uint32_t max_length = 512) {
+        check(cs_tokenizer_create_from_file(vocab_path.c_str(), lowercase ? 1 : 0, max_length, &h_));
+    }
+    Tokenizer(const char* vocab_txt, size_t bytes, bool lowercase = true, uint32_t max_length = 512) {
+        check(cs_tokenizer_create(vocab_txt, bytes, lowercase ? 1 : 0, max_length, &h_));
+    }
+    ~Tokenizer() { cs_tokenizer_destroy(h_); }
+    Tokenizer(const Tokenizer&) = delete;
+    Tokenizer& operator=(const Tokenizer&) = delete;
+
+    // encode_batch: ids/mask [n, L] row-major, L = the batch's longest sequence
+    size_t encode_batch(const std::vector<std::string>& texts, std::vector<int32_t>& ids, std::vector<int32_t>& mask,
+                        uint32_t max_length = 0) const {
+        std::string blob;
+        std::vector<uint64_t> off;
+        pack(texts, blob, off);
+        uint32_t L = 0;
+        check(cs_tokenizer_encode_batch(h_, blob.data(), off.data(), (uint32_t)texts.size(), max_length, nullptr,
+                                        nullptr, 0, &L));
+        ids.assign(texts.size() * L, 0);
+        mask.assign(texts.size() * L, 0);
+        if (!texts.empty())
+            check(cs_tokenizer_encode_batch(h_, blob.data(), off.data(), (uint32_t)texts.size(), max_length,
+                                            ids.data(), mask.data(), L, nullptr));
+        return L;
+    }
+    int32_t token_to_id(const std::string& token) const { return cs_tokenizer_token_to_id(h_, token.c_str()); }
+    size_t vocab_size() const { return cs_tokenizer_vocab_size(h_); }
+    const cs_tokenizer* handle() const { return h_; }
+
+    static void pack(const std::vector<std::string>& texts, std::string& blob, std::vector<uint64_t>& off) {
+        off.assign(1, 0);
+        for (const auto& t : texts) {
+            blob += t;
+            off.push_back(blob.size());
+        }
+    }
+
+  private:
+    cs_tokenizer* h_ = nullptr;
+};
+
+// FastEmbedder: from strings when a Tokenizer is attached (embed_batch(Vec<String>)), or from token ids.
 class FastEmbedder {
   public:
     // with_cache_dir — embedder.rs:218-245; params == nullptr => synthetic weights from seed
@@ -222,6 +268,32 @@ class FastEmbedder {
         for (size_t i = 0; i < n; ++i) out[i].assign(flat.begin() + i * d, flat.begin() + (i + 1) * d);
         return out;
     }
+    // embed_batch(texts) — embedder.rs:249-263, from strings
+    void attach_tokenizer(const Tokenizer* t) { tok_ = t; }
+    std::vector<std::vector<float>> embed_batch(const std::vector<std::string>& texts,
+                                                const volatile int32_t* shutdown = nullptr) {
+        return embed_batch_chunked(texts, 0, shutdown);
+    }
+    std::vector<std::vector<float>> embed_batch_chunked(const std::vector<std::string>& texts, size_t batch_size,
+                                                        const volatile int32_t* shutdown = nullptr) {
+        if (!tok_) throw Error(CS_ERR_UNSUPPORTED, "Failed to generate embeddings: no tokenizer attached");
+        std::string blob;
+        std::vector<uint64_t> off;
+        Tokenizer::pack(texts, blob, off);
+        const size_t d = dimensions(), n = texts.size();
+        std::vector<float> flat(n * d);
+        check(cs_embedder_embed_texts(h_, tok_->handle(), blob.data(), off.data(), n, (uint32_t)batch_size,
+                                      flat.data(), shutdown));
+        std::vector<std::vector<float>> out(n);
+        for (size_t i = 0; i < n; ++i) out[i].assign(flat.begin() + i * d, flat.begin() + (i + 1) * d);
+        return out;
+    }
+    // embed_one — embedder.rs:298-304
+    std::vector<float> embed_one(const std::string& text) {
+        auto r = embed_batch(std::vector<std::string>{text});
+        if (r.empty()) throw Error(CS_ERR_BAD_ARG, "No embedding generated");
+        return r[0];
+    }
     size_t dimensions() const { return cs_embedder_dim(h_); }  // embedder.rs:307
     cs_embedder* handle() const { return h_; }
     // CS_GEMM_SPLIT_F16 (default) or CS_GEMM_F32 (exact-f32 MFMA), include/codesearch_gpu.h
@@ -229,6 +301,7 @@ class FastEmbedder {
 
   private:
     cs_embedder* h_ = nullptr;
+    const Tokenizer* tok_ = nullptr;
 };
 
 }  // namespace cs

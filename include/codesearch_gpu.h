@@ -233,6 +233,48 @@ int32_t cs_embedder_last_hidden(cs_embedder* h, float* out, uint64_t n_tokens);
 int32_t cs_embedder_profile_read(cs_embedder* h, double* forward_ms, uint64_t* forwards,
                                  int32_t reset);
 
+/* ------------------------------------------------------------------------------------
+ * Text entry points — what FastEmbedder::embed_batch(Vec<String>) takes (embedder.rs:249-295).
+ * fastembed tokenises with the `tokenizers` crate 0.22.2 configured from the model's
+ * tokenizer.json; cs_tokenizer restates that BERT pipeline on the host in C++ (special tokens
+ * cut out verbatim -> BertNormalizer -> BertPreTokenizer -> WordPiece("##", [UNK], 100) ->
+ * [CLS] A [SEP] -> truncation -> batch-longest padding).  Pure host code: usable without a GPU.
+ * ---------------------------------------------------------------------------------- */
+typedef struct cs_tokenizer cs_tokenizer;
+
+/* `vocab` = the bytes of a vocab.txt (one token per line, id = line number).  `lowercase`
+ * is BertNormalizer's flag (strip_accents follows it, as in tokenizer.json's null);
+ * `max_length` the truncation length (512 for bge-small).  The vocabulary must hold
+ * [PAD] [UNK] [CLS] [SEP]. */
+int32_t cs_tokenizer_create(const char* vocab, uint64_t vocab_bytes, int32_t lowercase,
+                            uint32_t max_length, cs_tokenizer** out);
+int32_t cs_tokenizer_create_from_file(const char* vocab_path, int32_t lowercase,
+                                      uint32_t max_length, cs_tokenizer** out);
+void cs_tokenizer_destroy(cs_tokenizer* t);
+uint32_t cs_tokenizer_vocab_size(const cs_tokenizer* t);
+int32_t cs_tokenizer_token_to_id(const cs_tokenizer* t, const char* token); /* -1 = absent */
+/* Tokenizer::encode_batch.  Text i is utf8[offsets[i] .. offsets[i+1]) (n+1 offsets).
+ * max_length 0 = the handle's.  *out_len = the batch's longest sequence L (<= max_length).
+ * ids/mask: [n, row_stride] i32 with row_stride >= L, padded with [PAD] / 0; pass both NULL
+ * to query L only.  Re-entrant. */
+int32_t cs_tokenizer_encode_batch(const cs_tokenizer* t, const char* utf8,
+                                  const uint64_t* offsets, uint32_t n, uint32_t max_length,
+                                  int32_t* ids, int32_t* mask, uint32_t row_stride,
+                                  uint32_t* out_len);
+
+/* embed_batch / embed_batch_chunked from strings — embedder.rs:249-295.  Mini-batches of
+ * `batch` texts (0 = the 256/128/64 policy, CODESEARCH_BATCH_SIZE honoured), each tokenised
+ * and padded to ITS longest sequence as fastembed does (truncation at the model's
+ * max_position), the next mini-batch tokenised on host threads while the device runs the
+ * current one; `cancel` polled between mini-batches.  out: [n, dim] f32 host memory. */
+int32_t cs_embedder_embed_texts(cs_embedder* h, const cs_tokenizer* t, const char* utf8,
+                                const uint64_t* offsets, uint64_t n, uint32_t batch,
+                                float* out, const volatile int32_t* cancel);
+/* Same, result left in HBM at d_out. */
+int32_t cs_embedder_embed_texts_device(cs_embedder* h, const cs_tokenizer* t, const char* utf8,
+                                       const uint64_t* offsets, uint64_t n, uint32_t batch,
+                                       float* d_out, const volatile int32_t* cancel);
+
 /* Arithmetic of the dense layers.  CS_GEMM_SPLIT_F16 (default): every f32 operand as two f16
  * values on the f16 MFMA, three MFMAs per product block, f32 accumulation — error per product
  * <= ~3 * 2^-22, the order of f32 rounding itself (codesearch_amd/csrc/split_f16.hpp).

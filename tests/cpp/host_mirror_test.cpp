@@ -56,6 +56,20 @@ int main() {
     double n = 0;
     for (float v : e[1]) n += (double)v * v;
     REQUIRE(std::fabs(std::sqrt(n) - 1.0) < 1e-5);
+    // embed_batch(Vec<String>): vocab.txt built in memory, ids 0..: [PAD] [UNK] [CLS] [SEP] fn main ( ) ##s
+    const std::string vocab = "[PAD]\n[UNK]\n[CLS]\n[SEP]\nfn\nmain\n(\n)\n##s\n";
+    Tokenizer tok(vocab.data(), vocab.size());
+    std::vector<int32_t> tid, tmask;
+    REQUIRE(tok.encode_batch({"fn mains()", "FN"}, tid, tmask) == 7);
+    REQUIRE((tid == std::vector<int32_t>{2, 4, 5, 8, 6, 7, 3, 2, 4, 3, 0, 0, 0, 0}));
+    emb.attach_tokenizer(&tok);
+    auto te = emb.embed_batch(std::vector<std::string>{"fn mains()", "FN"});
+    auto ti = emb.embed_batch(tid, tmask, 2, 7);
+    REQUIRE(te.size() == 2);
+    for (size_t i = 0; i < 2; ++i)
+        for (size_t j = 0; j < 384; ++j) REQUIRE(te[i][j] == ti[i][j]);
+    auto one = emb.embed_one("FN");
+    for (size_t j = 0; j < 384; ++j) REQUIRE(std::fabs(one[j] - te[1][j]) < 1e-5);  // padding-invariant
     std::printf("host mirror ok\n");
     return 0;
 }

@@ -88,5 +88,67 @@ def main():
     print("wrote", path, os.path.getsize(path), "bytes; vocab", len(vocab))
 
 
+# ---- second fixture: the tokenizer as fastembed configures it (special tokens registered as
+# added tokens, so a literal "[SEP]" in the text becomes id 102), seeded random Unicode text that
+# exercises every table of csrc/unicode_tables.inc, cased and uncased, two truncation lengths.
+EXTRA_TOKENS = ["σ", "ς", "ω", "한", "ᄒ", "ᅡ", "##ᆫ", "##̇", "ǆ", "ss", "##ss", "😀", "ı", "к", "##к",
+                "д", "я", "##я", "豈", "ᄀ", "Hello", "##World", "İ", "É"]
+POOLS = [list(range(0x20, 0x7F)), list(range(0xA0, 0x250)), list(range(0x370, 0x400)), list(range(0x400, 0x460)),
+         [0x9, 0xA, 0xD, 0x85, 0xA0, 0x2003, 0x200B, 0x3000, 0xFFFD, 0, 7, 0xAD, 0xFEFF, 0xE000],
+         list(range(0x300, 0x370)), list(range(0x4E00, 0x4E20)) + [0xF900, 0xFA0E, 0x3400, 0x20000, 0x2F800],
+         list(range(0xAC00, 0xAC40)) + [0xD7A3], list(range(0x2000, 0x2070)),
+         list(range(0x1F600, 0x1F610)) + [0x1FAE0, 0x378], list(range(0x1E00, 0x2000)),
+         [0x130, 0x131, 0x3A3, 0x3C2, 0x1C4, 0x1C5, 0xDF, 0x1E9E, 0x37E, 0x1FEF, 0x212A, 0x212B, 0x2126]]
+
+
+def random_text(rng, words):
+    parts = []
+    for _ in range(rng.randint(0, 30)):
+        r = rng.random()
+        if r < 0.4:
+            parts.append(rng.choice(words))
+        elif r < 0.5:
+            parts.append(rng.choice(words).upper())
+        else:
+            pool = rng.choice(POOLS)
+            parts.append("".join(chr(rng.choice(pool)) for _ in range(rng.randint(1, 6))))
+        parts.append(rng.choice(["", " ", " ", "\n", "_", "."]))
+    return "".join(parts)
+
+
+def main_special():
+    import random
+
+    from tokenizers import AddedToken
+
+    vocab = build_vocab()
+    for t in EXTRA_TOKENS:
+        vocab.setdefault(t, len(vocab))
+    words = list(vocab) + ["[CLS", "CLS]", "[[SEP]]", "[mask]"]
+    rng = random.Random(20260227)
+    out = {"library": "tokenizers 0.22.2", "vocab": vocab, "cases": []}
+    for lowercase in (True, False):
+        for max_len in (512, 24):
+            tok = Tokenizer(WordPiece(vocab, unk_token="[UNK]", max_input_chars_per_word=100))
+            tok.normalizer = BertNormalizer(clean_text=True, handle_chinese_chars=True, strip_accents=None,
+                                            lowercase=lowercase)
+            tok.pre_tokenizer = BertPreTokenizer()
+            tok.post_processor = BertProcessing(("[SEP]", vocab["[SEP]"]), ("[CLS]", vocab["[CLS]"]))
+            tok.add_special_tokens([AddedToken(t, special=True, normalized=False)
+                                    for t in ("[PAD]", "[UNK]", "[CLS]", "[SEP]", "[MASK]")])
+            tok.enable_truncation(max_len)
+            tok.enable_padding(pad_id=vocab["[PAD]"], pad_token="[PAD]")
+            for _ in range(6):
+                batch = [random_text(rng, words) for _ in range(6)]
+                enc = tok.encode_batch(batch)
+                out["cases"].append({"lowercase": lowercase, "max_length": max_len, "texts": batch,
+                                     "ids": [e.ids for e in enc], "mask": [e.attention_mask for e in enc]})
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tokenizer_golden_special.json")
+    with open(path, "w") as f:
+        json.dump(out, f)
+    print("wrote", path, os.path.getsize(path), "bytes; vocab", len(vocab), "cases", len(out["cases"]))
+
+
 if __name__ == "__main__":
     main()
+    main_special()

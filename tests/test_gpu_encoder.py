@@ -219,3 +219,26 @@ def test_text_entry_points_with_tokenizer(FE, oracle):
     ids2, mask2 = tok.encode_batch([prepare_text(c) for c in chunks])
     ref2 = oracle.bert_forward(cfg, synth_params(cfg, 23), ids2, mask2)["pooled"]
     np.testing.assert_allclose(np.stack([e.embedding for e in ecs]), ref2, atol=TOL_ORACLE)
+    # mini-batches of 2 (cs_embedder_embed_texts tokenises batch i+1 while batch i runs): each is
+    # padded to its own longest sequence, results are the same embeddings
+    many = texts + ["Café naïve [SEP] résumé", "", "x" * 150, "中文 mixed"]
+    chunked = np.stack(emb.embed_batch_chunked(many, 2))
+    for lo in range(0, len(many), 2):
+        i2, m2 = tok.encode_batch(many[lo:lo + 2])
+        r2 = oracle.bert_forward(cfg, synth_params(cfg, 23), i2, m2)["pooled"]
+        np.testing.assert_allclose(chunked[lo:lo + 2], r2, atol=TOL_ORACLE)
+    np.testing.assert_allclose(np.stack(emb.embed_batch(many)), chunked, atol=2e-5)
+    assert emb.embed_batch([]) == []
+    from codesearch_amd import embedder as E
+    from codesearch_amd._lib import CS_ERR_CANCELLED, CS_ERR_UNSUPPORTED, CsError
+    E.request_shutdown(True)
+    try:
+        with pytest.raises(CsError) as ei:
+            emb.embed_batch(many)
+        assert ei.value.code == CS_ERR_CANCELLED and str(ei.value) == "Embedding interrupted by shutdown request"
+    finally:
+        E.request_shutdown(False)
+    bare = FE(cfg, seed=23)
+    with pytest.raises(CsError) as ei:
+        bare.embed_batch(["a"])
+    assert ei.value.code == CS_ERR_UNSUPPORTED

@@ -12,6 +12,7 @@ from codesearch_amd.tokenizer import BertWordPieceTokenizer
 from codesearch_amd.vector_store import Chunk, SearchResult
 
 GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "tokenizer_golden.json")))
+GOLD_SPECIAL = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "tokenizer_golden_special.json")))
 
 
 def test_clean_docstring_reference_cases():
@@ -49,6 +50,9 @@ def test_embedding_stats_reference_case():
 
 
 def test_wordpiece_matches_tokenizers_library():
+    """cs_tokenizer_* (csrc/tokenizer.cpp, host-only C++) against outputs of the `tokenizers` 0.22.2
+    wheel: the plain BERT pipeline, then the pipeline as fastembed configures it (special tokens as
+    added tokens), cased and uncased, two truncation lengths, seeded random Unicode text."""
     for case in GOLD["cases"]:
         tok = BertWordPieceTokenizer(GOLD["vocab"], max_length=case["max_length"])
         ids, mask = tok.encode_batch(case["texts"])
@@ -56,6 +60,100 @@ def test_wordpiece_matches_tokenizers_library():
         assert ids.shape[1] <= case["max_length"]
     tok = BertWordPieceTokenizer(GOLD["vocab"])
     assert tok.encode("")[0] == 101 and tok.encode("")[-1] == 102  # BERT's [CLS]/[SEP] ids kept
+    assert tok.vocab_size() == len(GOLD["vocab"]) and tok.token_to_id("[MASK]") == 103
+    assert tok.token_to_id("no such token") == -1
+    for case in GOLD_SPECIAL["cases"]:
+        tok = BertWordPieceTokenizer(GOLD_SPECIAL["vocab"], lowercase=case["lowercase"], max_length=case["max_length"])
+        ids, mask = tok.encode_batch(case["texts"])
+        assert ids.tolist() == case["ids"] and mask.tolist() == case["mask"], case["texts"]
+        # max_length passed per call overrides the handle's
+        tok512 = BertWordPieceTokenizer(GOLD_SPECIAL["vocab"], lowercase=case["lowercase"])
+        ids2, _ = tok512.encode_batch(case["texts"], case["max_length"])
+        assert ids2.tolist() == case["ids"]
+
+
+def test_tokenizer_abi_edges(tmp_path):
+    from codesearch_amd._lib import CsError
+
+    tok = BertWordPieceTokenizer(GOLD["vocab"])
+    ids, mask = tok.encode_batch([])
+    assert ids.shape == (0, 0)
+    ids, mask = tok.encode_batch(["", "a"])
+    assert ids.tolist() == [[101, 102, 0], [101, tok.token_to_id("a"), 102]] and mask.tolist() == [[1, 1, 0], [1, 1, 1]]
+    # ill-formed UTF-8 reaches the tokenizer as U+FFFD, which clean_text drops
+    import ctypes as C
+
+    import numpy as np
+
+    from codesearch_amd import _lib
+    raw = b"a\xff\xe2\x82b \xf0\x9f"
+    off = np.array([0, len(raw)], np.uint64)
+    L = C.c_uint32()
+    out = np.zeros((1, 8), np.int32)
+    _lib.check(tok._lib.cs_tokenizer_encode_batch(tok.handle, raw, off.ctypes.data_as(_lib.u64p), 1, 0,
+                                                  out.ctypes.data_as(_lib.i32p), None, 8, C.byref(L)))
+    assert out[0, :L.value].tolist() == tok.encode("ab")
+    # vocab.txt from a file, CRLF tolerated
+    toks = sorted(GOLD["vocab"], key=GOLD["vocab"].get)
+    path = tmp_path / "vocab.txt"
+    path.write_bytes("\r\n".join(toks).encode("utf-8"))
+    tf = BertWordPieceTokenizer.from_vocab_file(str(path))
+    text = GOLD["cases"][0]["texts"][0]
+    assert tf.encode(text) == tok.encode(text) and tf.vocab_size() == len(toks)
+    for bad in ({"a": 0, "b": 1}, ):
+        try:
+            BertWordPieceTokenizer(bad)
+            raise AssertionError("vocabulary without special tokens accepted")
+        except CsError as e:
+            assert "[PAD] [UNK] [CLS] [SEP]" in str(e)
+    try:
+        BertWordPieceTokenizer(GOLD["vocab"], max_length=1)
+        raise AssertionError("max_length 1 accepted")
+    except CsError:
+        pass
+
+
+def test_tokenizer_live_against_wheel_when_present():
+    """Where the `tokenizers` wheel is importable (this image), a short seeded fuzz against it."""
+    import random
+
+    import pytest
+    tk = pytest.importorskip("tokenizers")
+    from tokenizers import AddedToken, Tokenizer
+    from tokenizers.models import WordPiece
+    from tokenizers.normalizers import BertNormalizer
+    from tokenizers.pre_tokenizers import BertPreTokenizer
+    from tokenizers.processors import BertProcessing
+
+    vocab = GOLD_SPECIAL["vocab"]
+    ref = Tokenizer(WordPiece(vocab, unk_token="[UNK]", max_input_chars_per_word=100))
+    ref.normalizer = BertNormalizer(clean_text=True, handle_chinese_chars=True, strip_accents=None, lowercase=True)
+    ref.pre_tokenizer = BertPreTokenizer()
+    ref.post_processor = BertProcessing(("[SEP]", vocab["[SEP]"]), ("[CLS]", vocab["[CLS]"]))
+    ref.add_special_tokens([AddedToken(t, special=True, normalized=False)
+                            for t in ("[PAD]", "[UNK]", "[CLS]", "[SEP]", "[MASK]")])
+    ref.enable_truncation(64)
+    ref.enable_padding(pad_id=0, pad_token="[PAD]")
+    mine = BertWordPieceTokenizer(vocab, max_length=64)
+    rng = random.Random(7)
+    words = list(vocab)
+    for _ in range(60):
+        texts = []
+        for _ in range(rng.randint(1, 12)):
+            parts = []
+            for _ in range(rng.randint(0, 40)):
+                if rng.random() < 0.5:
+                    parts.append(rng.choice(words))
+                else:
+                    parts.append("".join(chr(rng.choice((rng.randint(0x20, 0x24F), rng.randint(0x250, 0x2FFF),
+                                                         rng.randint(0x3000, 0xD7FF), rng.randint(0xE000, 0x2FFFF))))
+                                         for _ in range(rng.randint(1, 5))))
+                parts.append(rng.choice(["", " ", "\t", "-"]))
+            texts.append("".join(parts))
+        enc = ref.encode_batch(texts)
+        ids, mask = mine.encode_batch(texts)
+        assert ids.tolist() == [e.ids for e in enc], texts
+        assert mask.tolist() == [e.attention_mask for e in enc]
 
 
 class _FakeEmbedder:
