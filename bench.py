@@ -103,6 +103,31 @@ def encoder_legs(shard, k, device):
     }
 
 
+def hbm_reference(device, nbytes=2 << 30, reps=10):
+    """a measured device copy / fill bandwidth beside the 8 TB/s spec figure, so the
+    scan's fraction can be read against both.  torch's copy_ and zero_ kernels on `nbytes`."""
+    import torch
+
+    src = torch.empty(nbytes // 4, dtype=torch.float32, device=device).normal_()
+    dst = torch.empty_like(src)
+    out = {}
+    for name, fn, moved in (("copy", lambda: dst.copy_(src), 2 * nbytes), ("fill", lambda: dst.zero_(), nbytes)):
+        for _ in range(2):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        out[name + "_GBps"] = moved / (e0.elapsed_time(e1) * 1e-3 / reps) / 1e9
+    out["note"] = (f"torch copy_ (read + write bytes counted) and zero_ over {nbytes >> 20} MiB on this device; "
+                   "MI355X_MICROARCH.md quotes 6.29 TB/s for a float4 copy")
+    del src, dst
+    torch.cuda.empty_cache()
+    return out
+
+
 def cpu_baseline(oracle, sample_rows, dim, k, store_cls):
     """Time the oracle's tuned CPU port (and the literal scalar loop on a smaller slice) on
     a bounded sample of the same workload; also returns recall@k of the HIP path against
@@ -306,6 +331,11 @@ def main():
                 "note": "cs_index_set_filter_min_queries(1): f16 MFMA filter over the 7.68 GB unit-vector copy, "
                         "then exact f32 re-score of the candidates; not used for `value`",
             }
+        if world == 1:
+            ref = hbm_reference(f"cuda:{local_rank}")
+            line["hbm_reference"] = ref
+            if line["roofline"]["bound"] == "hbm":
+                line["roofline"]["frac_of_measured_copy"] = line["roofline"]["achieved"] / ref["copy_GBps"]
         if world == 1 and not args.no_encoder:
             line.update(encoder_legs(shard, args.k, local_rank))
         print(json.dumps(line), flush=True)

@@ -18,6 +18,11 @@
 #define SH_STAMP(i)
 #endif
 
+// Diagnostic builds may pad the dynamic LDS request (-DSH_LDS_LAUNCH_BYTES=...) to force one block per CU.
+#ifndef SH_LDS_LAUNCH_BYTES
+#define SH_LDS_LAUNCH_BYTES SH_LDS_BYTES
+#endif
+
 namespace cs {
 
 // erf-GELU.  ocml's erff costs ~34 VALU instructions per element with both of its branches taken in
@@ -134,7 +139,7 @@ gemm_sh_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ W,
 }
 
 // 256 x 128 tiles, 8 waves, 3-stage LDS-DMA ring (sh_mainloop3<4>), one block per CU.
-template <int EPI>
+template <int EPI, bool IL = false>
 __global__ void __launch_bounds__(512, 2)
 gemm_sh3_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ W,
                 const float* __restrict__ bias, const float* resid, float* C,
@@ -148,7 +153,8 @@ gemm_sh3_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ W,
     SH_STAMP(0);
     ShAcc acc;
     sh_acc_zero(acc);
-    sh_mainloop3<4>(A, M, m0, W, N, n0, kchunks, lds, acc, sh_kc_rot(nt, N / SH_BN, kchunks));
+    if (IL) sh_mainloop3i<4>(A, M, m0, W, N, n0, kchunks, lds, acc, sh_kc_rot(nt, N / SH_BN, kchunks));
+    else sh_mainloop3<4>(A, M, m0, W, N, n0, kchunks, lds, acc, sh_kc_rot(nt, N / SH_BN, kchunks));
     SH_STAMP(1);
     float* ctile = reinterpret_cast<float*>(lds);  // [256][128] f32 = 128 KiB of the 144 KiB ring
     sh_acc_to_lds(acc, ctile);
@@ -246,17 +252,35 @@ int32_t launch_gemm_split(int epi, const _Float16* A, const _Float16* W, const f
     if (M == 0) return CS_OK;
     static bool attr_set = false;
     if (!attr_set) {
-        CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_sh_kernel<SH_OUT_F32>), hipFuncAttributeMaxDynamicSharedMemorySize, SH_LDS_BYTES));
-        CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_sh_kernel<SH_OUT_F32_RESID>), hipFuncAttributeMaxDynamicSharedMemorySize, SH_LDS_BYTES));
-        CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_sh_kernel<SH_OUT_SPLIT_GELU>), hipFuncAttributeMaxDynamicSharedMemorySize, SH_LDS_BYTES));
-        CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_sh_kernel<SH_OUT_SPLIT>), hipFuncAttributeMaxDynamicSharedMemorySize, SH_LDS_BYTES));
+        CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_sh_kernel<SH_OUT_F32>), hipFuncAttributeMaxDynamicSharedMemorySize, SH_LDS_LAUNCH_BYTES));
+        CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_sh_kernel<SH_OUT_F32_RESID>), hipFuncAttributeMaxDynamicSharedMemorySize, SH_LDS_LAUNCH_BYTES));
+        CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_sh_kernel<SH_OUT_SPLIT_GELU>), hipFuncAttributeMaxDynamicSharedMemorySize, SH_LDS_LAUNCH_BYTES));
+        CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_sh_kernel<SH_OUT_SPLIT>), hipFuncAttributeMaxDynamicSharedMemorySize, SH_LDS_LAUNCH_BYTES));
         attr_set = true;
     }
     const uint32_t kc = K / 32;
     static int tile = -1;
     if (tile < 0) {
-        const char* e = std::getenv("CS_GEMM_TILE");  // 128 (default): 128x128 tiles, 2 blocks/CU; 256: 256x128, 3-stage ring
-        tile = (e && std::atoi(e) == 256) ? 256 : 128;
+        const char* e = std::getenv("CS_GEMM_TILE");  // 128 (default): 128x128 tiles, 2 blocks/CU; 256: 256x128, 3-stage ring; 257: the same with the DMA issue interleaved
+        tile = (e && std::atoi(e) == 256) ? 256 : (e && std::atoi(e) == 257) ? 257 : 128;
+    }
+    if (tile == 257) {  // 256 x 128 tiles, 3-stage ring, LDS-DMA issue spread through the MFMA stream
+        using G = ShGeom<4>;
+        static bool attr3i = false;
+        if (!attr3i) {
+            CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_sh3_kernel<SH_OUT_F32, true>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
+            CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_sh3_kernel<SH_OUT_F32_RESID, true>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
+            CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_sh3_kernel<SH_OUT_SPLIT_GELU, true>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
+            CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_sh3_kernel<SH_OUT_SPLIT, true>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
+            attr3i = true;
+        }
+        const dim3 grid3(sh_grid_blocks((M + G::BM - 1) / G::BM, N / SH_BN));
+        if (epi == SH_OUT_F32) hipLaunchKernelGGL((gemm_sh3_kernel<SH_OUT_F32, true>), grid3, dim3(G::THREADS), G::LDS, s, A, W, bias, resid, C, Cs, M, N, kc, d_flag);
+        else if (epi == SH_OUT_F32_RESID) hipLaunchKernelGGL((gemm_sh3_kernel<SH_OUT_F32_RESID, true>), grid3, dim3(G::THREADS), G::LDS, s, A, W, bias, resid, C, Cs, M, N, kc, d_flag);
+        else if (epi == SH_OUT_SPLIT) hipLaunchKernelGGL((gemm_sh3_kernel<SH_OUT_SPLIT, true>), grid3, dim3(G::THREADS), G::LDS, s, A, W, bias, resid, C, Cs, M, N, kc, d_flag);
+        else hipLaunchKernelGGL((gemm_sh3_kernel<SH_OUT_SPLIT_GELU, true>), grid3, dim3(G::THREADS), G::LDS, s, A, W, bias, resid, C, Cs, M, N, kc, d_flag);
+        CS_HIP(hipGetLastError());
+        return CS_OK;
     }
     if (tile == 256) {
         using G = ShGeom<4>;
@@ -277,10 +301,10 @@ int32_t launch_gemm_split(int epi, const _Float16* A, const _Float16* W, const f
         return CS_OK;
     }
     const dim3 grid(sh_grid_blocks((M + SH_BM - 1) / SH_BM, N / SH_BN));
-    if (epi == SH_OUT_F32) hipLaunchKernelGGL(gemm_sh_kernel<SH_OUT_F32>, grid, dim3(256), SH_LDS_BYTES, s, A, W, bias, resid, C, Cs, M, N, kc, d_flag);
-    else if (epi == SH_OUT_F32_RESID) hipLaunchKernelGGL(gemm_sh_kernel<SH_OUT_F32_RESID>, grid, dim3(256), SH_LDS_BYTES, s, A, W, bias, resid, C, Cs, M, N, kc, d_flag);
-    else if (epi == SH_OUT_SPLIT) hipLaunchKernelGGL(gemm_sh_kernel<SH_OUT_SPLIT>, grid, dim3(256), SH_LDS_BYTES, s, A, W, bias, resid, C, Cs, M, N, kc, d_flag);
-    else hipLaunchKernelGGL(gemm_sh_kernel<SH_OUT_SPLIT_GELU>, grid, dim3(256), SH_LDS_BYTES, s, A, W, bias, resid, C, Cs, M, N, kc, d_flag);
+    if (epi == SH_OUT_F32) hipLaunchKernelGGL(gemm_sh_kernel<SH_OUT_F32>, grid, dim3(256), SH_LDS_LAUNCH_BYTES, s, A, W, bias, resid, C, Cs, M, N, kc, d_flag);
+    else if (epi == SH_OUT_F32_RESID) hipLaunchKernelGGL(gemm_sh_kernel<SH_OUT_F32_RESID>, grid, dim3(256), SH_LDS_LAUNCH_BYTES, s, A, W, bias, resid, C, Cs, M, N, kc, d_flag);
+    else if (epi == SH_OUT_SPLIT) hipLaunchKernelGGL(gemm_sh_kernel<SH_OUT_SPLIT>, grid, dim3(256), SH_LDS_LAUNCH_BYTES, s, A, W, bias, resid, C, Cs, M, N, kc, d_flag);
+    else hipLaunchKernelGGL(gemm_sh_kernel<SH_OUT_SPLIT_GELU>, grid, dim3(256), SH_LDS_LAUNCH_BYTES, s, A, W, bias, resid, C, Cs, M, N, kc, d_flag);
     CS_HIP(hipGetLastError());
     return CS_OK;
 }

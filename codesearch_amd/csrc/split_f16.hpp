@@ -329,6 +329,145 @@ __device__ __forceinline__ void sh_mainloop3(const _Float16* __restrict__ A, uin
     __syncthreads();  // every wave is done reading the stage buffers (callers reuse them)
 }
 
+// ---- sh_mainloop3 with the LDS-DMA issue spread through the MFMA stream -----------------------------
+// Measured (benchmarks/gemm_probe ablations, QKV shape): the CU's address path accepts one 1-KiB
+// LDS-DMA instruction per ~35 cycles even when every line hits, i.e. a 128x128x32 stage costs ~1100
+// cycles of it against 768 cycles of MFMA, and a wave that issues its DMAs back to back right after the
+// k-step barrier (as sh_mainloop and sh_mainloop3 do, all waves at the same moment) sits in instruction
+// issue for that long with the matrix pipe idle: load time and MFMA time ADD (loads only 146 us, MFMA +
+// LDS reads only 125 us, kernel 253 us).  Here each wave issues ONE DMA after every third MFMA, half of
+// a stage's pieces behind the barrier and half in front of the next one, so the address path works
+// while the matrix pipe does.  Ring protocol and vmcnt counts as in sh_mainloop3 (a stage is still
+// complete one full k-step before the barrier that publishes it).
+template <int WM>
+__device__ __forceinline__ void sh_mainloop3i(const _Float16* __restrict__ A, uint32_t M, uint32_t m0,
+                                              const _Float16* __restrict__ W, uint32_t N, uint32_t n0,
+                                              uint32_t kchunks, char* lds, ShAcc& acc, uint32_t kc_rot = 0) {
+    using G = ShGeom<WM>;
+    static_assert(G::A_PER_WAVE == 4 && G::W_PER_WAVE == 2, "DMA interleave below is written for 256 x 128 tiles");
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    const int l31 = lane & 31, h = lane >> 5;
+
+    // this wave's six pieces of a stage: p = 0..3 A rows, p = 4,5 W rows; LDS offsets inside a stage
+    const _Float16* src[6];
+    uint32_t dst[6];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = (wave * 4 + i) * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((row >> 1) & 7);
+        const uint32_t am = (m0 + row < M) ? m0 + row : M - 1;
+        src[i] = A + (size_t)am * kchunks * 64 + c * 8;
+        dst[i] = (wave * 4 + i) * 1024;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = (wave * 2 + i) * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((row >> 1) & 7);
+        const uint32_t wn = (n0 + row < N) ? n0 + row : N - 1;
+        src[4 + i] = W + (size_t)wn * kchunks * 64 + c * 8;
+        dst[4 + i] = G::A_BYTES + (wave * 2 + i) * 1024;
+    }
+    // piece order of a stage: first half {A0, W0, A1}, second half {A2, W1, A3}
+    constexpr int kOrder[6] = {0, 4, 1, 2, 5, 3};
+    auto dma = [&](int q, uint32_t kc, uint32_t slot) {
+        const int p = kOrder[q];
+        sh_glds16(src[p] + (size_t)kc * 64, lds + slot * G::STAGE + dst[p]);
+    };
+
+    const int swz = (l31 >> 1) & 7;
+    const int arow = (wr * 64 + l31) * 128, wrow = G::A_BYTES + (wc * 64 + l31) * 128;
+    int sl_hi[2], sl_lo[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        sl_hi[s] = ((2 * s + h) ^ swz) * 16;
+        sl_lo[s] = ((4 + 2 * s + h) ^ swz) * 16;
+    }
+    struct Frags { f16x8 ah[2], al[2], wh[2], wl[2]; };
+    const uint32_t lds_base = (uint32_t)(uintptr_t)lds;
+    auto load_frags = [&](uint32_t buf_off, int s, Frags& f) {
+        const uint32_t a_hi = lds_base + buf_off + arow + sl_hi[s], a_lo = lds_base + buf_off + arow + sl_lo[s];
+        const uint32_t w_hi = lds_base + buf_off + wrow + sl_hi[s], w_lo = lds_base + buf_off + wrow + sl_lo[s];
+        asm volatile("ds_read_b128 %0, %1" : "=v"(f.ah[0]) : "v"(a_hi));
+        asm volatile("ds_read_b128 %0, %1" : "=v"(f.wh[0]) : "v"(w_hi));
+        asm volatile("ds_read_b128 %0, %1" : "=v"(f.wl[0]) : "v"(w_lo));
+        asm volatile("ds_read_b128 %0, %1" : "=v"(f.al[0]) : "v"(a_lo));
+        asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(f.wh[1]) : "v"(w_hi));
+        asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(f.wl[1]) : "v"(w_lo));
+        asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(f.ah[1]) : "v"(a_hi));
+        asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(f.al[1]) : "v"(a_lo));
+    };
+    // 12 MFMAs; when `issue`, DMA pieces q0, q0+1, q0+2 of (kc, slot) go out after MFMAs 3, 6 and 9
+    auto mfma_group = [&](const Frags& f, bool issue, int q0, uint32_t kc, uint32_t slot) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                acc.hh[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[i], f.wh[j], acc.hh[i][j], 0, 0, 0);
+                acc.xx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[i], f.wl[j], acc.xx[i][j], 0, 0, 0);
+                acc.xx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al[i], f.wh[j], acc.xx[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (issue && (i * 2 + j) < 3) dma(q0 + i * 2 + j, kc, slot);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+    };
+#define SH_LGKM_WAIT(N)                                            \
+    do {                                                           \
+        asm volatile("s_waitcnt lgkmcnt(" #N ")" ::: "memory");    \
+        __builtin_amdgcn_sched_barrier(0);                         \
+    } while (0)
+
+    uint32_t kr = kc_rot % kchunks;
+    auto next_chunk = [&]() { const uint32_t c = kr; kr = kr + 1 == kchunks ? 0 : kr + 1; return c; };
+    // prologue: stages 0..2 whole
+    for (uint32_t st = 0; st < 3 && st < kchunks; ++st) {
+        const uint32_t c = next_chunk();
+#pragma unroll
+        for (int q = 0; q < 6; ++q) dma(q, c, st);
+    }
+    if (kchunks > 2) sh_wait_vmcnt<2 * G::NL>();
+    else if (kchunks > 1) sh_wait_vmcnt<G::NL>();
+    else sh_wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    Frags f0, f1;
+    load_frags(0, 0, f0);
+    uint32_t cur = 0;        // slot of stage kc
+    uint32_t half_kc = 0;    // chunk of the stage whose second half is still to be issued
+    bool half_open = false;  // ... and whether there is one
+    for (uint32_t kc = 0; kc + 1 < kchunks; ++kc) {  // (the last stage is peeled)
+        load_frags(cur * G::STAGE, 1, f1);
+        SH_LGKM_WAIT(8);  // f0 is back; f1 stays in flight under the MFMAs
+        // second half of stage kc+2 into the slot stage kc-1 used (free since the previous barrier)
+        const uint32_t prv = cur == 0 ? 2 : cur - 1;
+        mfma_group(f0, half_open, 3, half_kc, prv);
+        half_open = false;
+        __builtin_amdgcn_sched_barrier(0);
+        const uint32_t nxt = cur + 1 == 3 ? 0 : cur + 1;
+        if (kc + 2 < kchunks) sh_wait_vmcnt<G::NL>();  // stage kc+1 landed; kc+2 may still fly
+        else sh_wait_vmcnt<0>();
+        SH_LGKM_WAIT(0);  // f1 is back = this wave's last reads of stage kc
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        load_frags(nxt * G::STAGE, 0, f0);
+        __builtin_amdgcn_sched_barrier(0);
+        // first half of stage kc+3 into stage kc's slot
+        const bool more = kc + 3 < kchunks;
+        if (more) { half_kc = next_chunk(); half_open = true; }
+        mfma_group(f1, more, 0, half_kc, cur);
+        __builtin_amdgcn_sched_barrier(0);
+        cur = nxt;
+    }
+    load_frags(cur * G::STAGE, 1, f1);
+    SH_LGKM_WAIT(8);
+    mfma_group(f0, false, 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    SH_LGKM_WAIT(0);
+    mfma_group(f1, false, 0, 0, 0);
+#undef SH_LGKM_WAIT
+    __syncthreads();  // every wave is done reading the stage buffers (callers reuse them)
+}
+
 __device__ __forceinline__ void sh_acc_zero(ShAcc& acc) {
 #pragma unroll
     for (int i = 0; i < 2; ++i)
