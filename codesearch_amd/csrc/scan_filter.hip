@@ -215,6 +215,7 @@ score_filter_kernel(const _Float16* __restrict__ corpus_h, uint64_t row_lo, uint
 // bounds these kernels, not the matrix pipe.  One block per CU (2 x 64 KiB stages).
 constexpr int UF2_BM = 256, UF2_BN = 256, UF2_TILE = 256 * 128, UF2_STAGE = 2 * UF2_TILE, UF2_LDS = 2 * UF2_STAGE;
 
+template <bool LEGACY>
 __global__ void __launch_bounds__(512, 2)
 score_filter256_kernel(const _Float16* __restrict__ corpus_h, uint64_t row_lo, uint64_t row_hi, uint32_t kchunks,
                        const _Float16* __restrict__ queries_h, uint32_t nq, const float* __restrict__ tau,
@@ -268,6 +269,7 @@ score_filter256_kernel(const _Float16* __restrict__ corpus_h, uint64_t row_lo, u
     auto next_chunk = [&]() { const uint32_t c = kr; kr = kr + 1 == kchunks ? 0 : kr + 1; return c; };
     stage(next_chunk(), lds);
     __syncthreads();
+    if (LEGACY) {  // A/B (CS_FILTER256_LEGACY): every DMA of the next stage issued back to back at the top of the step
     for (uint32_t kc = 0; kc < kchunks; ++kc) {
         char* cur = lds + (kc & 1) * UF2_STAGE;
         if (kc + 1 < kchunks) stage(next_chunk(), lds + ((kc + 1) & 1) * UF2_STAGE);
@@ -285,6 +287,72 @@ score_filter256_kernel(const _Float16* __restrict__ corpus_h, uint64_t row_lo, u
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i], w[j], acc[i][j], 0, 0, 0);
         }
         __syncthreads();
+    }
+    } else {
+    // The wave's eight LDS-DMA instructions of the NEXT stage go out one at a time between the MFMAs of
+    // the first two k16 sub-steps of this one (an LDS-DMA costs its wave ~35+ cycles of issue while the
+    // CU's address path accepts it: issued back to back at the top of the step, with all eight waves doing
+    // the same, they hold the matrix pipe idle for about as long as the step's MFMAs take; see the ablation
+    // table in DESIGN.md §3.3).  Fragment reads are explicit asm with counted lgkmcnt, double-buffered
+    // across the sub-steps of a stage.
+    const uint32_t lds_base = (uint32_t)(uintptr_t)lds;
+    struct Frags { f16x8 a[2], w[4]; };
+    auto load_frags = [&](uint32_t stage_off, int s, Frags& f) {
+        const uint32_t aa = lds_base + stage_off + arow + sl[s], ww = lds_base + stage_off + wrow + sl[s];
+        asm volatile("ds_read_b128 %0, %1" : "=v"(f.a[0]) : "v"(aa));
+        asm volatile("ds_read_b128 %0, %1" : "=v"(f.w[0]) : "v"(ww));
+        asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(f.w[1]) : "v"(ww));
+        asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(f.a[1]) : "v"(aa));
+        asm volatile("ds_read_b128 %0, %1 offset:8192" : "=v"(f.w[2]) : "v"(ww));
+        asm volatile("ds_read_b128 %0, %1 offset:12288" : "=v"(f.w[3]) : "v"(ww));
+    };
+#define UF2_LGKM_WAIT(N)                                           \
+    do {                                                           \
+        asm volatile("s_waitcnt lgkmcnt(" #N ")" ::: "memory");    \
+        __builtin_amdgcn_sched_barrier(0);                         \
+    } while (0)
+    // eight MFMAs of one k16 sub-step; with `issue`, DMA pieces q0..q0+3 of the next stage after MFMAs 2, 4, 6, 8
+    auto mfma8 = [&](const Frags& f, bool issue, int q0, uint32_t kcn, char* nbuf) {
+        char* dst = nbuf + wave * 32 * 128;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int i = p >> 1, j0 = (p & 1) * 2;
+            acc[i][j0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.a[i], f.w[j0], acc[i][j0], 0, 0, 0);
+            acc[i][j0 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.a[i], f.w[j0 + 1], acc[i][j0 + 1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (issue) {
+                const int q = q0 + p;  // pieces 0..3: corpus rows, 4..7: queries
+                if (q < 4) sh_glds16(asrc[q] + (size_t)kcn * 128 * 64, dst + q * 1024);
+                else sh_glds16(wsrc[q - 4] + (size_t)kcn * 64, dst + UF2_TILE + (q - 4) * 1024);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    Frags f0, f1;
+    load_frags(0, 0, f0);
+    for (uint32_t kc = 0; kc < kchunks; ++kc) {
+        const uint32_t so = (kc & 1) * UF2_STAGE;
+        char* nbuf = lds + ((kc + 1) & 1) * UF2_STAGE;
+        const bool more = kc + 1 < kchunks;
+        const uint32_t kcn = more ? next_chunk() : 0;
+        load_frags(so, 1, f1);
+        UF2_LGKM_WAIT(6);
+        mfma8(f0, more, 0, kcn, nbuf);
+        load_frags(so, 2, f0);
+        UF2_LGKM_WAIT(6);
+        mfma8(f1, more, 4, kcn, nbuf);
+        load_frags(so, 3, f1);
+        UF2_LGKM_WAIT(6);
+        mfma8(f0, false, 0, 0, nbuf);
+        UF2_LGKM_WAIT(0);  // this wave's last reads of the stage are back
+        sh_wait_vmcnt<0>();  // ... and its pieces of the next stage have landed
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) load_frags(so ^ UF2_STAGE, 0, f0);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma8(f1, false, 0, 0, nbuf);
+    }
+#undef UF2_LGKM_WAIT
     }
 
 #pragma unroll
@@ -597,7 +665,9 @@ static int32_t scan_split_impl(const BatchedState& st, const SplitQueryWs& qw, c
     if (!attr_set) {
         CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(score_filter_kernel),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, SH_LDS_BYTES));
-        CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(score_filter256_kernel),
+        CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(score_filter256_kernel<false>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, UF2_LDS));
+        CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(score_filter256_kernel<true>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, UF2_LDS));
         CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(score_filter_rw_kernel<1>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, RwGeom<1>::LDS));
@@ -675,8 +745,15 @@ static int32_t scan_split_impl(const BatchedState& st, const SplitQueryWs& qw, c
 #undef CS_RW_LAUNCH
             } else if (wide) {
                 const uint32_t mt2 = (uint32_t)((hi - lo + UF2_BM - 1) / UF2_BM), nt2 = (nq + UF2_BN - 1) / UF2_BN;
-                hipLaunchKernelGGL(score_filter256_kernel, dim3(sh_grid_blocks(mt2, nt2)), dim3(512), UF2_LDS, stream,
-                                   d_split, lo, hi, dim / 64, qw.d_qsplit, nq, st.d_tau, d_dead, cand, st.d_cnt, cap);
+                static const bool legacy256 = std::getenv("CS_FILTER256_LEGACY") != nullptr;
+                if (legacy256)
+                    hipLaunchKernelGGL(score_filter256_kernel<true>, dim3(sh_grid_blocks(mt2, nt2)), dim3(512), UF2_LDS,
+                                       stream, d_split, lo, hi, dim / 64, qw.d_qsplit, nq, st.d_tau, d_dead, cand,
+                                       st.d_cnt, cap);
+                else
+                    hipLaunchKernelGGL(score_filter256_kernel<false>, dim3(sh_grid_blocks(mt2, nt2)), dim3(512), UF2_LDS,
+                                       stream, d_split, lo, hi, dim / 64, qw.d_qsplit, nq, st.d_tau, d_dead, cand,
+                                       st.d_cnt, cap);
             } else {
                 const uint32_t mtiles = (uint32_t)((hi - lo + SH_BM - 1) / SH_BM);
                 hipLaunchKernelGGL(score_filter_kernel, dim3(sh_grid_blocks(mtiles, ntiles)), dim3(256), SH_LDS_BYTES,
