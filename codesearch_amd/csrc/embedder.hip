@@ -39,6 +39,8 @@ struct cs_embedder {
     float* d_ctx = nullptr;     // [T, H]   (f32, or split form: same bytes)
     float* d_mid = nullptr;     // [T, I]   (f32, or split form: same bytes)
     float* d_pooled = nullptr;  // [B, H]
+    uint32_t* d_perm = nullptr; // [B] destination row of each pooled row (length-sorted text mini-batches)
+    std::vector<float> h_pooled; // host staging of a mini-batch's rows when they are scattered
     uint32_t last_B = 0, last_L = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     double forward_ms = 0.0;
@@ -46,6 +48,16 @@ struct cs_embedder {
 };
 
 namespace {
+
+// dst[perm[r]] = src[r] for r < rows: one float4 per thread (H % 4 == 0)
+__global__ void __launch_bounds__(256)
+scatter_rows_kernel(const float* __restrict__ src, const uint32_t* __restrict__ perm, float* __restrict__ dst,
+                    uint32_t rows, uint32_t h4) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * h4) return;
+    const uint32_t r = i / h4, c = i % h4;
+    reinterpret_cast<float4*>(dst)[(size_t)perm[r] * h4 + c] = reinterpret_cast<const float4*>(src)[(size_t)r * h4 + c];
+}
 
 void free_workspace(cs_embedder* h) {
     if (h->d_ids) (void)hipFree(h->d_ids);
@@ -56,6 +68,8 @@ void free_workspace(cs_embedder* h) {
     if (h->d_ctx) (void)hipFree(h->d_ctx);
     if (h->d_mid) (void)hipFree(h->d_mid);
     if (h->d_pooled) (void)hipFree(h->d_pooled);
+    if (h->d_perm) (void)hipFree(h->d_perm);
+    h->d_perm = nullptr;
     h->d_ids = h->d_mask = nullptr;
     h->d_x = h->d_xs = h->d_qkv = h->d_ctx = h->d_mid = h->d_pooled = nullptr;
     h->cap_tokens = h->cap_seqs = 0;
@@ -73,6 +87,7 @@ int32_t reserve(cs_embedder* h, size_t seqs, size_t tokens) {
     CS_HIP(hipMalloc(&h->d_ctx, tokens * H * sizeof(float)));
     CS_HIP(hipMalloc(&h->d_mid, tokens * I * sizeof(float)));
     CS_HIP(hipMalloc(&h->d_pooled, seqs * H * sizeof(float)));
+    CS_HIP(hipMalloc(&h->d_perm, seqs * sizeof(uint32_t)));
     h->cap_tokens = tokens;
     h->cap_seqs = seqs;
     return CS_OK;
@@ -194,9 +209,10 @@ uint32_t default_batch(const cs_embedder* h) {
     return d <= 384 ? 256 : (d <= 768 ? 128 : 64);
 }
 
+// perm (optional, only with n <= batch): pooled row r of the mini-batch goes to out row perm[r].
 int32_t embed_impl(cs_embedder* h, const int32_t* ids, const int32_t* mask, uint64_t n,
                    uint32_t seq_len, uint32_t batch, float* out, bool out_on_device,
-                   const volatile int32_t* cancel) {
+                   const volatile int32_t* cancel, const uint32_t* perm = nullptr) {
     if (!h) return fail(CS_ERR_BAD_ARG, "null embedder handle");
     if (n == 0) return CS_OK;  // embedder.rs:271-273
     if (!ids || !mask || !out) return fail(CS_ERR_BAD_ARG, "null buffer");
@@ -235,9 +251,25 @@ int32_t embed_impl(cs_embedder* h, const int32_t* ids, const int32_t* mask, uint
             }
         }
         if (mode == CS_GEMM_F32) h->f32_forwards += 1;
-        CS_HIP(hipMemcpyAsync(out + done * H, h->d_pooled, (size_t)B * H * sizeof(float),
-                              out_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, h->stream));
-        CS_HIP(hipStreamSynchronize(h->stream));
+        if (!perm) {
+            CS_HIP(hipMemcpyAsync(out + done * H, h->d_pooled, (size_t)B * H * sizeof(float),
+                                  out_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, h->stream));
+            CS_HIP(hipStreamSynchronize(h->stream));
+        } else if (out_on_device) {
+            CS_HIP(hipMemcpyAsync(h->d_perm, perm, B * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
+            const uint32_t h4 = H / 4;
+            hipLaunchKernelGGL(scatter_rows_kernel, dim3((B * h4 + 255) / 256), dim3(256), 0, h->stream, h->d_pooled,
+                               h->d_perm, out, B, h4);
+            CS_HIP(hipGetLastError());
+            CS_HIP(hipStreamSynchronize(h->stream));
+        } else {
+            h->h_pooled.resize((size_t)B * H);
+            CS_HIP(hipMemcpyAsync(h->h_pooled.data(), h->d_pooled, (size_t)B * H * sizeof(float),
+                                  hipMemcpyDeviceToHost, h->stream));
+            CS_HIP(hipStreamSynchronize(h->stream));
+            for (uint32_t r = 0; r < B; ++r)
+                std::memcpy(out + (size_t)perm[r] * H, h->h_pooled.data() + (size_t)r * H, H * sizeof(float));
+        }
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, h->ev0, h->ev1) == hipSuccess) {
             h->forward_ms += ms;
@@ -248,28 +280,21 @@ int32_t embed_impl(cs_embedder* h, const int32_t* ids, const int32_t* mask, uint
 }
 
 
-// embed_batch_chunked from strings (embedder.rs:266-295): tokenise mini-batch i+1 on host threads
-// while the device runs mini-batch i; each mini-batch is padded to its own longest sequence.
-struct TokenBatch {
-    std::vector<int32_t> ids, mask;
-    uint32_t B = 0, L = 0;
+// embed_batch_chunked from strings (embedder.rs:266-295).  Texts are taken in WINDOWS of 16 mini-batches:
+// window w+1 is tokenised on host threads while the device runs window w, and inside a window the
+// texts are grouped into mini-batches BY TOKEN COUNT (stable sort), each padded to its own longest
+// sequence.  fastembed pads every mini-batch of consecutive texts to its longest member; padding is
+// masked out of attention and pooling, so an embedding does not depend on what it was batched with
+// beyond f32 rounding (asserted in tests/test_gpu_encoder.py), and on code chunks of mixed length the
+// grouping removes ~1/3 of the padded tokens the device would otherwise compute.
+// CS_EMBED_LENGTH_SORT=0 keeps the caller's order (mini-batches of consecutive texts, as fastembed).
+struct TokenWindow {
+    std::vector<std::vector<int32_t>> enc;
 };
 
-void tokenize_batch(const cs_tokenizer* t, const char* utf8, const uint64_t* offsets, uint32_t B,
-                    uint32_t max_length, int32_t pad, TokenBatch* out) {
-    std::vector<std::vector<int32_t>> enc;
-    cs::tokenize_texts(t, utf8, offsets, B, max_length, enc);
-    uint32_t L = 1;
-    for (const auto& e : enc) L = std::max<uint32_t>(L, (uint32_t)e.size());
-    out->B = B;
-    out->L = L;
-    out->ids.assign((size_t)B * L, pad);
-    out->mask.assign((size_t)B * L, 0);
-    for (uint32_t i = 0; i < B; ++i)
-        for (size_t j = 0; j < enc[i].size(); ++j) {
-            out->ids[(size_t)i * L + j] = enc[i][j];
-            out->mask[(size_t)i * L + j] = 1;
-        }
+void tokenize_window(const cs_tokenizer* t, const char* utf8, const uint64_t* offsets, uint32_t n,
+                     uint32_t max_length, TokenWindow* out) {
+    cs::tokenize_texts(t, utf8, offsets, n, max_length, out->enc);
 }
 
 int32_t embed_texts_impl(cs_embedder* h, const cs_tokenizer* t, const char* utf8, const uint64_t* offsets,
@@ -282,23 +307,57 @@ int32_t embed_texts_impl(cs_embedder* h, const cs_tokenizer* t, const char* utf8
     for (uint64_t i = 0; i < n; ++i)
         if (offsets[i + 1] < offsets[i]) return fail(CS_ERR_BAD_ARG, "text offsets must be non-decreasing");
     if (batch == 0) batch = default_batch(h);
+    static const bool length_sort = [] {
+        const char* e = std::getenv("CS_EMBED_LENGTH_SORT");
+        return !(e && e[0] == '0');
+    }();
     const uint32_t max_length = h->cfg.max_position;
     const int32_t pad = cs_tokenizer_token_to_id(t, "[PAD]");
     const uint32_t H = h->cfg.hidden;
-    TokenBatch cur, nxt;
-    auto span = [&](uint64_t lo) { return (uint32_t)std::min<uint64_t>(batch, n - lo); };
-    tokenize_batch(t, utf8, offsets, span(0), max_length, pad, &cur);
-    for (uint64_t done = 0; done < n; done += batch) {
-        if (cancel && *cancel)  // embedder.rs:280-282
-            return fail(CS_ERR_CANCELLED, "Embedding interrupted by shutdown request");
-        const uint64_t next_lo = done + batch;
+    const uint64_t window = (uint64_t)batch * 16;
+    auto span = [&](uint64_t lo) { return (uint32_t)std::min<uint64_t>(window, n - lo); };
+    TokenWindow cur, nxt;
+    tokenize_window(t, utf8, offsets, span(0), max_length, &cur);
+    std::vector<uint32_t> order;
+    std::vector<int32_t> ids, mask;
+    for (uint64_t lo = 0; lo < n; lo += window) {
+        const uint32_t wn = span(lo);
         std::thread ahead;
-        if (next_lo < n)
-            ahead = std::thread(tokenize_batch, t, utf8, offsets + next_lo, span(next_lo), max_length, pad, &nxt);
-        const int32_t st = embed_impl(h, cur.ids.data(), cur.mask.data(), cur.B, cur.L, cur.B, out + done * H,
-                                      out_on_device, nullptr);
+        if (lo + window < n)
+            ahead = std::thread(tokenize_window, t, utf8, offsets + lo + window, span(lo + window), max_length, &nxt);
+        struct Joiner {
+            std::thread& th;
+            ~Joiner() { if (th.joinable()) th.join(); }
+        } joiner{ahead};
+        {   // workspace for the window's longest sequence once, not once per (growing) mini-batch
+            size_t longest = 1;
+            for (const auto& e : cur.enc) longest = std::max(longest, e.size());
+            const size_t bmax = std::min<size_t>(batch, wn);
+            DeviceGuard g(h->device);
+            CS_TRY(reserve(h, std::max(bmax, h->cap_seqs), std::max(bmax * longest, h->cap_tokens)));
+        }
+        order.resize(wn);
+        for (uint32_t i = 0; i < wn; ++i) order[i] = i;
+        if (length_sort && wn > batch)
+            std::stable_sort(order.begin(), order.end(),
+                             [&](uint32_t a, uint32_t b) { return cur.enc[a].size() < cur.enc[b].size(); });
+        for (uint32_t b0 = 0; b0 < wn; b0 += batch) {
+            if (cancel && *cancel)  // embedder.rs:280-282
+                return fail(CS_ERR_CANCELLED, "Embedding interrupted by shutdown request");
+            const uint32_t B = std::min<uint32_t>(batch, wn - b0);
+            uint32_t L = 1;
+            for (uint32_t r = 0; r < B; ++r) L = std::max<uint32_t>(L, (uint32_t)cur.enc[order[b0 + r]].size());
+            ids.assign((size_t)B * L, pad);
+            mask.assign((size_t)B * L, 0);
+            for (uint32_t r = 0; r < B; ++r) {
+                const std::vector<int32_t>& e = cur.enc[order[b0 + r]];
+                std::copy(e.begin(), e.end(), ids.begin() + (size_t)r * L);
+                std::fill(mask.begin() + (size_t)r * L, mask.begin() + (size_t)r * L + e.size(), 1);
+            }
+            CS_TRY(embed_impl(h, ids.data(), mask.data(), B, L, B, out + lo * H, out_on_device, nullptr,
+                              order.data() + b0));
+        }
         if (ahead.joinable()) ahead.join();
-        if (st != CS_OK) return st;
         std::swap(cur, nxt);
     }
     return CS_OK;

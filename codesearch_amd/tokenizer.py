@@ -82,12 +82,12 @@ class WordPieceTokenizer:
         ml = int(max_length or 0)
         L = C.c_uint32()
         op = offsets.ctypes.data_as(_lib.u64p)
-        _lib.check(self._lib.cs_tokenizer_encode_batch(self._h, blob, op, n, ml, None, None, 0, C.byref(L)))
-        ids = np.empty((n, L.value), np.int32)
-        mask = np.empty((n, L.value), np.int32)
-        if n:
-            _lib.check(self._lib.cs_tokenizer_encode_batch(self._h, blob, op, n, ml, ids.ctypes.data_as(_lib.i32p),
-                                                           mask.ctypes.data_as(_lib.i32p), L.value, None))
+        stride = ml or self.max_length  # one pass: rows at the truncation length, then cut to the longest
+        ids = np.empty((n, stride), np.int32)
+        mask = np.empty((n, stride), np.int32)
+        _lib.check(self._lib.cs_tokenizer_encode_batch(self._h, blob, op, n, ml, ids.ctypes.data_as(_lib.i32p),
+                                                       mask.ctypes.data_as(_lib.i32p), stride, C.byref(L)))
+        ids, mask = np.ascontiguousarray(ids[:, :L.value]), np.ascontiguousarray(mask[:, :L.value])
         return ids, mask
 
     def encode(self, text: str) -> List[int]:

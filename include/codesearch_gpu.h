@@ -263,10 +263,14 @@ int32_t cs_tokenizer_encode_batch(const cs_tokenizer* t, const char* utf8,
                                   uint32_t* out_len);
 
 /* embed_batch / embed_batch_chunked from strings — embedder.rs:249-295.  Mini-batches of
- * `batch` texts (0 = the 256/128/64 policy, CODESEARCH_BATCH_SIZE honoured), each tokenised
- * and padded to ITS longest sequence as fastembed does (truncation at the model's
- * max_position), the next mini-batch tokenised on host threads while the device runs the
- * current one; `cancel` polled between mini-batches.  out: [n, dim] f32 host memory. */
+ * `batch` texts (0 = the 256/128/64 policy, CODESEARCH_BATCH_SIZE honoured), each padded to
+ * ITS longest sequence as fastembed does (truncation at the model's max_position).  Texts are
+ * taken in windows of 16 mini-batches: the next window is tokenised on host threads while the
+ * device runs the current one, and inside a window texts are grouped into mini-batches by token
+ * count (padding is masked out of attention and pooling, so an embedding does not depend on its
+ * batch-mates beyond f32 rounding; CS_EMBED_LENGTH_SORT=0 keeps consecutive texts together).
+ * Row i of `out` is always text i.  `cancel` is polled between mini-batches.
+ * out: [n, dim] f32 host memory. */
 int32_t cs_embedder_embed_texts(cs_embedder* h, const cs_tokenizer* t, const char* utf8,
                                 const uint64_t* offsets, uint64_t n, uint32_t batch,
                                 float* out, const volatile int32_t* cancel);

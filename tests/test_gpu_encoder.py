@@ -242,3 +242,32 @@ def test_text_entry_points_with_tokenizer(FE, oracle):
     with pytest.raises(CsError) as ei:
         bare.embed_batch(["a"])
     assert ei.value.code == CS_ERR_UNSUPPORTED
+
+
+def test_text_pipeline_index_and_search(FE):
+    """pipeline.index_text_chunks / search_text_queries: strings -> cs_embedder_embed_texts_device ->
+    cs_index_add_device -> batched search; a prefix of a chunk must retrieve that chunk, and the result
+    must equal the token-id pipeline on the same tokenisation."""
+    from codesearch_amd import VectorStore
+    from codesearch_amd.pipeline import (index_text_chunks, index_token_chunks, search_text_queries,
+                                         synth_code_texts, synth_vocab)
+    from codesearch_amd.tokenizer import WordPieceTokenizer
+
+    vocab = synth_vocab(2048)
+    tok = WordPieceTokenizer(vocab, max_length=64)
+    cfg = BertConfig(vocab_size=2048, layers=2, max_position=64, pooling=POOL_MEAN)
+    emb = FE(cfg, seed=5, tokenizer=tok)
+    texts = synth_code_texts(vocab, 300, 9, mean_words=24)
+    store = VectorStore(None, cfg.hidden)
+    index_text_chunks(emb, store, texts, batch_size=128)
+    assert store.stats().total_chunks == 0 and len(store) == 300  # vectors only: metadata is the caller's
+    queries = [texts[i][: len(texts[i]) * 3 // 4] for i in (3, 150, 299)]
+    cos, ids, counts, _ = search_text_queries(emb, store, queries, 5)
+    assert ids[:, 0].tolist() == [3, 150, 299] and (counts == 5).all()
+    # same rows as embedding consecutive mini-batches of token ids: cs_embedder_embed_texts groups a
+    # window's texts by token count, and an embedding does not depend on its batch-mates or its padding
+    store2 = VectorStore(None, cfg.hidden)
+    for lo in range(0, 300, 128):
+        i, m = tok.encode_batch(texts[lo:lo + 128])
+        index_token_chunks(emb, store2, i, m)
+    assert np.abs(store.read_rows(0, 300) - store2.read_rows(0, 300)).max() <= 1e-6
