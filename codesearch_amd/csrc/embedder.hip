@@ -297,6 +297,53 @@ void tokenize_window(const cs_tokenizer* t, const char* utf8, const uint64_t* of
     cs::tokenize_texts(t, utf8, offsets, n, max_length, out->enc);
 }
 
+bool length_sort_enabled() {
+    static const bool on = [] {
+        const char* e = std::getenv("CS_EMBED_LENGTH_SORT");
+        return !(e && e[0] == '0');
+    }();
+    return on;
+}
+
+// One window of sequences, each a (ids, mask, length) view with every position >= length padding:
+// group them into mini-batches by length, pad each mini-batch to ITS longest member, run it, and put
+// row r of the result at out[order[r]].  mask == nullptr means "ones up to length".
+struct SeqView { const int32_t* ids; const int32_t* mask; uint32_t len; };
+
+int32_t run_window(cs_embedder* h, const std::vector<SeqView>& seqs, uint32_t batch, int32_t pad, float* out,
+                   bool out_on_device, const volatile int32_t* cancel, std::vector<uint32_t>& order,
+                   std::vector<int32_t>& ids, std::vector<int32_t>& mask) {
+    const uint32_t wn = (uint32_t)seqs.size();
+    {   // workspace for the window's longest sequence once, not once per (growing) mini-batch
+        size_t longest = 1;
+        for (const SeqView& v : seqs) longest = std::max<size_t>(longest, v.len);
+        const size_t bmax = std::min<size_t>(batch, wn);
+        DeviceGuard g(h->device);
+        CS_TRY(reserve(h, std::max(bmax, h->cap_seqs), std::max(bmax * longest, h->cap_tokens)));
+    }
+    order.resize(wn);
+    for (uint32_t i = 0; i < wn; ++i) order[i] = i;
+    if (length_sort_enabled() && wn > batch)
+        std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return seqs[a].len < seqs[b].len; });
+    for (uint32_t b0 = 0; b0 < wn; b0 += batch) {
+        if (cancel && *cancel)  // embedder.rs:280-282
+            return fail(CS_ERR_CANCELLED, "Embedding interrupted by shutdown request");
+        const uint32_t B = std::min<uint32_t>(batch, wn - b0);
+        uint32_t L = 1;
+        for (uint32_t r = 0; r < B; ++r) L = std::max(L, seqs[order[b0 + r]].len);
+        ids.assign((size_t)B * L, pad);
+        mask.assign((size_t)B * L, 0);
+        for (uint32_t r = 0; r < B; ++r) {
+            const SeqView& v = seqs[order[b0 + r]];
+            std::copy(v.ids, v.ids + v.len, ids.begin() + (size_t)r * L);
+            if (v.mask) std::copy(v.mask, v.mask + v.len, mask.begin() + (size_t)r * L);
+            else std::fill(mask.begin() + (size_t)r * L, mask.begin() + (size_t)r * L + v.len, 1);
+        }
+        CS_TRY(embed_impl(h, ids.data(), mask.data(), B, L, B, out, out_on_device, nullptr, order.data() + b0));
+    }
+    return CS_OK;
+}
+
 int32_t embed_texts_impl(cs_embedder* h, const cs_tokenizer* t, const char* utf8, const uint64_t* offsets,
                          uint64_t n, uint32_t batch, float* out, bool out_on_device,
                          const volatile int32_t* cancel) {
@@ -307,10 +354,6 @@ int32_t embed_texts_impl(cs_embedder* h, const cs_tokenizer* t, const char* utf8
     for (uint64_t i = 0; i < n; ++i)
         if (offsets[i + 1] < offsets[i]) return fail(CS_ERR_BAD_ARG, "text offsets must be non-decreasing");
     if (batch == 0) batch = default_batch(h);
-    static const bool length_sort = [] {
-        const char* e = std::getenv("CS_EMBED_LENGTH_SORT");
-        return !(e && e[0] == '0');
-    }();
     const uint32_t max_length = h->cfg.max_position;
     const int32_t pad = cs_tokenizer_token_to_id(t, "[PAD]");
     const uint32_t H = h->cfg.hidden;
@@ -320,8 +363,8 @@ int32_t embed_texts_impl(cs_embedder* h, const cs_tokenizer* t, const char* utf8
     tokenize_window(t, utf8, offsets, span(0), max_length, &cur);
     std::vector<uint32_t> order;
     std::vector<int32_t> ids, mask;
+    std::vector<SeqView> seqs;
     for (uint64_t lo = 0; lo < n; lo += window) {
-        const uint32_t wn = span(lo);
         std::thread ahead;
         if (lo + window < n)
             ahead = std::thread(tokenize_window, t, utf8, offsets + lo + window, span(lo + window), max_length, &nxt);
@@ -329,38 +372,48 @@ int32_t embed_texts_impl(cs_embedder* h, const cs_tokenizer* t, const char* utf8
             std::thread& th;
             ~Joiner() { if (th.joinable()) th.join(); }
         } joiner{ahead};
-        {   // workspace for the window's longest sequence once, not once per (growing) mini-batch
-            size_t longest = 1;
-            for (const auto& e : cur.enc) longest = std::max(longest, e.size());
-            const size_t bmax = std::min<size_t>(batch, wn);
-            DeviceGuard g(h->device);
-            CS_TRY(reserve(h, std::max(bmax, h->cap_seqs), std::max(bmax * longest, h->cap_tokens)));
-        }
-        order.resize(wn);
-        for (uint32_t i = 0; i < wn; ++i) order[i] = i;
-        if (length_sort && wn > batch)
-            std::stable_sort(order.begin(), order.end(),
-                             [&](uint32_t a, uint32_t b) { return cur.enc[a].size() < cur.enc[b].size(); });
-        for (uint32_t b0 = 0; b0 < wn; b0 += batch) {
-            if (cancel && *cancel)  // embedder.rs:280-282
-                return fail(CS_ERR_CANCELLED, "Embedding interrupted by shutdown request");
-            const uint32_t B = std::min<uint32_t>(batch, wn - b0);
-            uint32_t L = 1;
-            for (uint32_t r = 0; r < B; ++r) L = std::max<uint32_t>(L, (uint32_t)cur.enc[order[b0 + r]].size());
-            ids.assign((size_t)B * L, pad);
-            mask.assign((size_t)B * L, 0);
-            for (uint32_t r = 0; r < B; ++r) {
-                const std::vector<int32_t>& e = cur.enc[order[b0 + r]];
-                std::copy(e.begin(), e.end(), ids.begin() + (size_t)r * L);
-                std::fill(mask.begin() + (size_t)r * L, mask.begin() + (size_t)r * L + e.size(), 1);
-            }
-            CS_TRY(embed_impl(h, ids.data(), mask.data(), B, L, B, out + lo * H, out_on_device, nullptr,
-                              order.data() + b0));
-        }
+        seqs.clear();
+        for (const auto& e : cur.enc) seqs.push_back(SeqView{e.data(), nullptr, (uint32_t)e.size()});
+        CS_TRY(run_window(h, seqs, batch, pad, out + lo * H, out_on_device, cancel, order, ids, mask));
         if (ahead.joinable()) ahead.join();
         std::swap(cur, nxt);
     }
     return CS_OK;
+}
+
+// cs_embedder_embed_ids with more than one mini-batch: the same windows over the caller's padded rows.
+// A row's length is the position after its last mask bit; mini-batches are cut to their longest member
+// (the columns dropped hold padding in every row of the mini-batch) and grouped by length.
+int32_t embed_ids_windowed(cs_embedder* h, const int32_t* ids_in, const int32_t* mask_in, uint64_t n,
+                           uint32_t seq_len, uint32_t batch, float* out, bool out_on_device,
+                           const volatile int32_t* cancel) {
+    const uint32_t H = h->cfg.hidden;
+    const uint64_t window = (uint64_t)batch * 16;
+    std::vector<uint32_t> order;
+    std::vector<int32_t> ids, mask;
+    std::vector<SeqView> seqs;
+    for (uint64_t lo = 0; lo < n; lo += window) {
+        const uint32_t wn = (uint32_t)std::min<uint64_t>(window, n - lo);
+        seqs.clear();
+        for (uint32_t i = 0; i < wn; ++i) {
+            const int32_t* m = mask_in + (lo + i) * seq_len;
+            uint32_t len = seq_len;
+            while (len > 1 && m[len - 1] == 0) --len;
+            seqs.push_back(SeqView{ids_in + (lo + i) * seq_len, m, len});
+        }
+        CS_TRY(run_window(h, seqs, batch, 0, out + lo * H, out_on_device, cancel, order, ids, mask));
+    }
+    return CS_OK;
+}
+
+int32_t embed_ids_entry(cs_embedder* h, const int32_t* ids, const int32_t* mask, uint64_t n, uint32_t seq_len,
+                        uint32_t batch, float* out, bool out_on_device, const volatile int32_t* cancel) {
+    if (!h) return fail(CS_ERR_BAD_ARG, "null embedder handle");
+    const uint32_t b = batch ? batch : default_batch(h);
+    // a single mini-batch runs exactly as given (cs_embedder_last_hidden then has the caller's [n, seq_len] layout)
+    if (n <= b || !ids || !mask || !out || seq_len == 0 || seq_len > h->cfg.max_position || !length_sort_enabled())
+        return embed_impl(h, ids, mask, n, seq_len, batch, out, out_on_device, cancel);
+    return embed_ids_windowed(h, ids, mask, n, seq_len, b, out, out_on_device, cancel);
 }
 
 }  // namespace
@@ -500,13 +553,13 @@ uint32_t cs_embedder_dim(const cs_embedder* h) { return h ? h->cfg.hidden : 0; }
 int32_t cs_embedder_embed_ids(cs_embedder* h, const int32_t* ids, const int32_t* mask, uint64_t n,
                               uint32_t seq_len, uint32_t batch, float* out,
                               const volatile int32_t* cancel) {
-    return embed_impl(h, ids, mask, n, seq_len, batch, out, false, cancel);
+    return embed_ids_entry(h, ids, mask, n, seq_len, batch, out, false, cancel);
 }
 
 int32_t cs_embedder_embed_ids_device(cs_embedder* h, const int32_t* ids, const int32_t* mask,
                                      uint64_t n, uint32_t seq_len, uint32_t batch, float* d_out,
                                      const volatile int32_t* cancel) {
-    return embed_impl(h, ids, mask, n, seq_len, batch, d_out, true, cancel);
+    return embed_ids_entry(h, ids, mask, n, seq_len, batch, d_out, true, cancel);
 }
 
 int32_t cs_embedder_embed_texts(cs_embedder* h, const cs_tokenizer* t, const char* utf8,
