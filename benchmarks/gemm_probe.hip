@@ -4,14 +4,21 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <map>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
 
 __device__ unsigned long long* g_stamps = nullptr;  // [blocks][4]
+__device__ unsigned int* g_where = nullptr;         // [blocks]: HW_ID | XCC_ID << 16 of the block's first wave
 #define SH_STAMP(i)                                                                       \
     do {                                                                                  \
-        if (threadIdx.x == 0 && g_stamps) g_stamps[(size_t)blockIdx.x * 4 + (i)] = __builtin_readcyclecounter(); \
+        if (threadIdx.x == 0 && g_stamps) {                                               \
+            g_stamps[(size_t)blockIdx.x * 4 + (i)] = __builtin_readcyclecounter();        \
+            if ((i) == 0 && g_where)                                                      \
+                g_where[blockIdx.x] = (__builtin_amdgcn_s_getreg((4) | (0 << 6) | (15 << 11)) & 0xffffu) | \
+                                      ((__builtin_amdgcn_s_getreg((20) | (0 << 6) | (3 << 11)) & 0xfu) << 16);  \
+        }                                                                                 \
     } while (0)
 
 #include "../codesearch_amd/csrc/gemm_split.hip"
@@ -46,6 +53,10 @@ int main(int argc, char** argv) {
     unsigned long long* d_st;
     hipMalloc(&d_st, (size_t)blocks * 4 * 8);
     hipMemset(d_st, 0, (size_t)blocks * 4 * 8);
+    unsigned int* d_wh;
+    hipMalloc(&d_wh, (size_t)blocks * 4);
+    hipMemset(d_wh, 0, (size_t)blocks * 4);
+    hipMemcpyToSymbol(HIP_SYMBOL(g_where), &d_wh, sizeof(d_wh));
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
     for (int pass = 0; pass < 2; ++pass) {
@@ -74,6 +85,37 @@ int main(int argc, char** argv) {
         tmin = std::min(tmin, s[0]); tmax = std::max(tmax, s[3]);
         life.push_back((double)(s[3] - s[0]));
         ++nb;
+    }
+    {   // per-CU timeline of the LAST stamped launch: how much of a CU's span is covered by resident blocks?
+        std::vector<unsigned int> wh(blocks);
+        hipMemcpy(wh.data(), d_wh, wh.size() * 4, hipMemcpyDeviceToHost);
+        struct Ev { unsigned long long t0, t1; };
+        std::map<unsigned int, std::vector<Ev>> cu;
+        for (uint32_t b = 0; b < blocks; ++b) {
+            const unsigned long long* s4 = &st[(size_t)b * 4];
+            if (!s4[3]) continue;
+            const unsigned int key = (wh[b] >> 16) << 16 | (wh[b] & 0xff00u);  // xcc | se, sh, cu
+            cu[key].push_back({s4[0], s4[3]});
+        }
+        double busy = 0, span = 0, gap_sum = 0;
+        size_t gaps = 0, maxb = 0;
+        for (auto& kv : cu) {
+            auto& v = kv.second;
+            std::sort(v.begin(), v.end(), [](const Ev& a, const Ev& b) { return a.t0 < b.t0; });
+            unsigned long long lo = v.front().t0, hi = 0;
+            for (auto& e : v) { busy += (double)(e.t1 - e.t0); hi = std::max(hi, e.t1); }
+            span += (double)(hi - lo);
+            maxb = std::max(maxb, v.size());
+            // replacement latency: for each block end, the next block start on this CU at or after it
+            for (auto& e : v) {
+                unsigned long long best = ~0ull;
+                for (auto& f : v) if (f.t0 >= e.t1 && f.t0 < best) best = f.t0;
+                if (best != ~0ull) { gap_sum += (double)(best - e.t1); ++gaps; }
+            }
+        }
+        printf("CUs seen %zu (max %zu blocks on one); sum(block life)/sum(CU span) = %.2f resident blocks per CU on average; "
+               "mean CU span %.0f ticks; mean end->next-start on the same CU %.0f ticks\n",
+               cu.size(), maxb, busy / span, span / cu.size(), gaps ? gap_sum / gaps : 0.0);
     }
     std::sort(life.begin(), life.end());
     printf("blocks %zu: mainloop %.0f  acc->lds %.0f  epilogue %.0f cycles (avg per block; s_memtime ticks)\n", nb, seg[0] / nb,
