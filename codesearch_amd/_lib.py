@@ -76,6 +76,9 @@ SIGNATURES = {
     "cs_bert_config_bge_small": (None, [C.POINTER(BertConfig)]),
     "cs_bert_param_count": (C.c_uint64, [C.POINTER(BertConfig)]),
     "cs_embedder_create": (C.c_int32, [C.POINTER(BertConfig), f32p, C.c_uint64, C.c_int32, C.POINTER(vp)]),
+    "cs_bert_config_from_dir": (C.c_int32, [C.c_char_p, C.c_int32, C.POINTER(BertConfig)]),
+    "cs_bert_params_from_safetensors": (C.c_int32, [C.c_char_p, C.POINTER(BertConfig), f32p, C.c_uint64]),
+    "cs_embedder_create_from_dir": (C.c_int32, [C.c_char_p, C.c_int32, C.c_int32, C.POINTER(vp)]),
     "cs_embedder_destroy": (None, [vp]),
     "cs_embedder_dim": (C.c_uint32, [vp]),
     "cs_embedder_embed_ids": (C.c_int32, [vp, i32p, i32p, C.c_uint64, C.c_uint32, C.c_uint32, f32p, i32p]),

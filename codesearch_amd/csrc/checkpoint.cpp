@@ -1,0 +1,360 @@
+// checkpoint.cpp — real-weight loading behind the C ABI: a HF model directory
+// (config.json + model.safetensors, what `hf-hub` leaves in fastembed's cache dir for
+// BAAI/bge-small-en-v1.5 and its BERT siblings) -> cs_bert_config + the flat f32 parameter block of
+// include/cs_bert_params.h.  Stands in for the model-loading half of FastEmbedder::with_cache_dir
+// (/root/reference/src/embed/embedder.rs:218-245; fastembed itself reads an ONNX export of the same
+// tensors).  Host-only C++; no GPU needed for the two loaders.
+//
+// safetensors file = u64 LE header length N | N bytes of JSON {"name": {"dtype": "F32"|"F16"|"BF16",
+// "shape": [...], "data_offsets": [begin, end]}, ..., "__metadata__": {...}} | tensor bytes.
+// Tensor names are HF BertModel state-dict names, optionally prefixed "bert."; pooler, position_ids
+// and any other extra tensors are ignored.
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/cs_bert_params.h"
+#include "common.hpp"
+
+namespace {
+
+using cs::fail;
+
+// ---- a small JSON reader: just enough for config.json and a safetensors header --------------------
+struct Json {
+    enum Kind { Null, Bool, Num, Str, Arr, Obj } kind = Null;
+    double num = 0.0;
+    bool b = false;
+    std::string str;
+    std::vector<Json> arr;
+    std::vector<std::pair<std::string, Json>> obj;
+
+    const Json* get(const char* key) const {
+        for (const auto& kv : obj)
+            if (kv.first == key) return &kv.second;
+        return nullptr;
+    }
+};
+
+struct JsonParser {
+    const char* p;
+    const char* end;
+    bool ok = true;
+
+    void ws() {
+        while (p < end && (*p == ' ' || *p == '\n' || *p == '\t' || *p == '\r')) ++p;
+    }
+    bool lit(const char* s) {
+        const size_t n = std::strlen(s);
+        if ((size_t)(end - p) >= n && std::memcmp(p, s, n) == 0) { p += n; return true; }
+        return false;
+    }
+    std::string string() {
+        std::string out;
+        if (p >= end || *p != '"') { ok = false; return out; }
+        ++p;
+        while (p < end && *p != '"') {
+            if (*p == '\\' && p + 1 < end) {
+                ++p;
+                switch (*p) {
+                    case 'n': out.push_back('\n'); break;
+                    case 't': out.push_back('\t'); break;
+                    case 'r': out.push_back('\r'); break;
+                    case 'b': out.push_back('\b'); break;
+                    case 'f': out.push_back('\f'); break;
+                    case 'u': {  // keep BMP escapes as UTF-8; names we look up are ASCII
+                        if (end - p < 5) { ok = false; return out; }
+                        unsigned cp = (unsigned)std::strtoul(std::string(p + 1, p + 5).c_str(), nullptr, 16);
+                        p += 4;
+                        if (cp < 0x80) out.push_back((char)cp);
+                        else if (cp < 0x800) { out.push_back((char)(0xC0 | (cp >> 6))); out.push_back((char)(0x80 | (cp & 0x3F))); }
+                        else { out.push_back((char)(0xE0 | (cp >> 12))); out.push_back((char)(0x80 | ((cp >> 6) & 0x3F))); out.push_back((char)(0x80 | (cp & 0x3F))); }
+                        break;
+                    }
+                    default: out.push_back(*p);
+                }
+                ++p;
+            } else {
+                out.push_back(*p++);
+            }
+        }
+        if (p >= end) { ok = false; return out; }
+        ++p;
+        return out;
+    }
+    Json value(int depth = 0) {
+        Json j;
+        ws();
+        if (p >= end || depth > 64) { ok = false; return j; }
+        if (*p == '{') {
+            j.kind = Json::Obj;
+            ++p;
+            ws();
+            if (p < end && *p == '}') { ++p; return j; }
+            while (ok) {
+                ws();
+                std::string k = string();
+                ws();
+                if (!ok || p >= end || *p != ':') { ok = false; break; }
+                ++p;
+                j.obj.emplace_back(std::move(k), value(depth + 1));
+                ws();
+                if (p < end && *p == ',') { ++p; continue; }
+                if (p < end && *p == '}') { ++p; break; }
+                ok = false;
+            }
+        } else if (*p == '[') {
+            j.kind = Json::Arr;
+            ++p;
+            ws();
+            if (p < end && *p == ']') { ++p; return j; }
+            while (ok) {
+                j.arr.push_back(value(depth + 1));
+                ws();
+                if (p < end && *p == ',') { ++p; continue; }
+                if (p < end && *p == ']') { ++p; break; }
+                ok = false;
+            }
+        } else if (*p == '"') {
+            j.kind = Json::Str;
+            j.str = string();
+        } else if (lit("true")) { j.kind = Json::Bool; j.b = true; }
+        else if (lit("false")) { j.kind = Json::Bool; }
+        else if (lit("null")) { j.kind = Json::Null; }
+        else {
+            char* e = nullptr;
+            const std::string tmp(p, (size_t)std::min<ptrdiff_t>(end - p, 64));
+            j.num = std::strtod(tmp.c_str(), &e);
+            if (e == tmp.c_str()) { ok = false; return j; }
+            j.kind = Json::Num;
+            p += e - tmp.c_str();
+        }
+        return j;
+    }
+};
+
+bool read_file(const std::string& path, std::string& out, uint64_t max_bytes = ~0ull) {
+    FILE* f = std::fopen(path.c_str(), "rb");
+    if (!f) return false;
+    char tmp[1 << 16];
+    size_t got;
+    while (out.size() < max_bytes && (got = std::fread(tmp, 1, sizeof(tmp), f)) > 0) out.append(tmp, got);
+    std::fclose(f);
+    return true;
+}
+
+float half_to_float(uint16_t h) {
+    const uint32_t sign = (uint32_t)(h & 0x8000u) << 16;
+    uint32_t exp = (h >> 10) & 0x1Fu, man = h & 0x3FFu, bits;
+    if (exp == 0) {
+        if (man == 0) bits = sign;
+        else {  // subnormal
+            int e = -1;
+            do { man <<= 1; ++e; } while (!(man & 0x400u));
+            bits = sign | ((uint32_t)(127 - 15 - e) << 23) | ((man & 0x3FFu) << 13);
+        }
+    } else if (exp == 31) bits = sign | 0x7F800000u | (man << 13);
+    else bits = sign | ((exp + 112) << 23) | (man << 13);
+    float f;
+    std::memcpy(&f, &bits, 4);
+    return f;
+}
+
+struct TensorRef { std::string dtype; std::vector<uint64_t> shape; uint64_t begin = 0, end = 0; };
+
+// name -> (shape, offset in the flat block) for every tensor of the layout, in layout order
+struct Want { std::string name; std::vector<uint64_t> shape; uint64_t off; };
+std::vector<Want> layout_table(const cs_bert_config& c) {
+    cs_bert_offsets o;
+    cs_bert_layout(&c, &o);
+    const uint64_t H = c.hidden, I = c.intermediate;
+    std::vector<Want> t = {
+        {"embeddings.word_embeddings.weight", {c.vocab_size, H}, o.word},
+        {"embeddings.position_embeddings.weight", {c.max_position, H}, o.pos},
+        {"embeddings.token_type_embeddings.weight", {c.type_vocab_size, H}, o.type},
+        {"embeddings.LayerNorm.weight", {H}, o.emb_ln_g},
+        {"embeddings.LayerNorm.bias", {H}, o.emb_ln_b},
+    };
+    for (uint32_t l = 0; l < c.layers; ++l) {
+        cs_bert_layer_offsets lo;
+        cs_bert_layer_layout(&c, &o, l, &lo);
+        const std::string p = "encoder.layer." + std::to_string(l) + ".";
+        t.push_back({p + "attention.self.query.weight", {H, H}, lo.q_w});
+        t.push_back({p + "attention.self.query.bias", {H}, lo.q_b});
+        t.push_back({p + "attention.self.key.weight", {H, H}, lo.k_w});
+        t.push_back({p + "attention.self.key.bias", {H}, lo.k_b});
+        t.push_back({p + "attention.self.value.weight", {H, H}, lo.v_w});
+        t.push_back({p + "attention.self.value.bias", {H}, lo.v_b});
+        t.push_back({p + "attention.output.dense.weight", {H, H}, lo.ao_w});
+        t.push_back({p + "attention.output.dense.bias", {H}, lo.ao_b});
+        t.push_back({p + "attention.output.LayerNorm.weight", {H}, lo.ao_ln_g});
+        t.push_back({p + "attention.output.LayerNorm.bias", {H}, lo.ao_ln_b});
+        t.push_back({p + "intermediate.dense.weight", {I, H}, lo.up_w});
+        t.push_back({p + "intermediate.dense.bias", {I}, lo.up_b});
+        t.push_back({p + "output.dense.weight", {H, I}, lo.down_w});
+        t.push_back({p + "output.dense.bias", {H}, lo.down_b});
+        t.push_back({p + "output.LayerNorm.weight", {H}, lo.out_ln_g});
+        t.push_back({p + "output.LayerNorm.bias", {H}, lo.out_ln_b});
+    }
+    return t;
+}
+
+bool json_u32(const Json& root, const char* key, uint32_t& out) {
+    const Json* j = root.get(key);
+    if (!j || j->kind != Json::Num || j->num < 0 || j->num > 4294967295.0) return false;
+    out = (uint32_t)j->num;
+    return true;
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t cs_bert_config_from_dir(const char* model_dir, int32_t pooling, cs_bert_config* cfg) {
+    if (!model_dir || !cfg) return fail(CS_ERR_BAD_ARG, "null argument");
+    if (pooling != CS_POOL_CLS && pooling != CS_POOL_MEAN) return fail(CS_ERR_BAD_ARG, "unknown pooling %d", pooling);
+    const std::string path = std::string(model_dir) + "/config.json";
+    std::string text;
+    if (!read_file(path, text, 1 << 24))
+        return fail(CS_ERR_BAD_ARG, "Failed to initialize embedding model: cannot open %s", path.c_str());
+    JsonParser jp{text.data(), text.data() + text.size()};
+    const Json root = jp.value();
+    if (!jp.ok || root.kind != Json::Obj)
+        return fail(CS_ERR_BAD_ARG, "Failed to initialize embedding model: %s is not a JSON object", path.c_str());
+    if (const Json* mt = root.get("model_type"))
+        if (mt->kind == Json::Str && mt->str != "bert")
+            return fail(CS_ERR_UNSUPPORTED, "Failed to initialize embedding model: model_type \"%s\" is not a BERT encoder",
+                        mt->str.c_str());
+    if (const Json* act = root.get("hidden_act"))
+        if (act->kind == Json::Str && act->str != "gelu")
+            return fail(CS_ERR_UNSUPPORTED, "Failed to initialize embedding model: hidden_act \"%s\" (only erf-GELU)",
+                        act->str.c_str());
+    if (const Json* pe = root.get("position_embedding_type"))
+        if (pe->kind == Json::Str && pe->str != "absolute")
+            return fail(CS_ERR_UNSUPPORTED, "Failed to initialize embedding model: position_embedding_type \"%s\"",
+                        pe->str.c_str());
+    cs_bert_config c{};
+    if (!json_u32(root, "vocab_size", c.vocab_size) || !json_u32(root, "hidden_size", c.hidden) ||
+        !json_u32(root, "num_hidden_layers", c.layers) || !json_u32(root, "num_attention_heads", c.heads) ||
+        !json_u32(root, "intermediate_size", c.intermediate) ||
+        !json_u32(root, "max_position_embeddings", c.max_position))
+        return fail(CS_ERR_BAD_ARG, "Failed to initialize embedding model: %s lacks a BERT size field", path.c_str());
+    if (!json_u32(root, "type_vocab_size", c.type_vocab_size)) c.type_vocab_size = 2;
+    const Json* eps = root.get("layer_norm_eps");
+    c.layer_norm_eps = (eps && eps->kind == Json::Num) ? (float)eps->num : 1e-12f;
+    c.pooling = pooling;
+    *cfg = c;
+    return CS_OK;
+}
+
+int32_t cs_bert_params_from_safetensors(const char* path, const cs_bert_config* cfg, float* params,
+                                        uint64_t n_params) {
+    if (!path || !cfg || !params) return fail(CS_ERR_BAD_ARG, "null argument");
+    cs_bert_offsets o;
+    cs_bert_layout(cfg, &o);
+    if (n_params != o.total)
+        return fail(CS_ERR_BAD_ARG, "Failed to initialize embedding model: expected %llu parameters, got %llu",
+                    (unsigned long long)o.total, (unsigned long long)n_params);
+    FILE* f = std::fopen(path, "rb");
+    if (!f) return fail(CS_ERR_BAD_ARG, "Failed to initialize embedding model: cannot open %s", path);
+    struct Closer { FILE* f; ~Closer() { std::fclose(f); } } closer{f};
+    unsigned char lenb[8];
+    if (std::fread(lenb, 1, 8, f) != 8)
+        return fail(CS_ERR_BAD_ARG, "Failed to initialize embedding model: %s is not a safetensors file", path);
+    uint64_t hlen = 0;
+    for (int i = 7; i >= 0; --i) hlen = (hlen << 8) | lenb[i];
+    if (hlen < 2 || hlen > (100ull << 20))
+        return fail(CS_ERR_BAD_ARG, "Failed to initialize embedding model: %s has an implausible header length", path);
+    std::string header(hlen, '\0');
+    if (std::fread(&header[0], 1, hlen, f) != hlen)
+        return fail(CS_ERR_BAD_ARG, "Failed to initialize embedding model: %s is truncated", path);
+    JsonParser jp{header.data(), header.data() + header.size()};
+    const Json root = jp.value();
+    if (!jp.ok || root.kind != Json::Obj)
+        return fail(CS_ERR_BAD_ARG, "Failed to initialize embedding model: %s has a malformed header", path);
+    std::map<std::string, TensorRef> have;
+    for (const auto& kv : root.obj) {
+        if (kv.first == "__metadata__" || kv.second.kind != Json::Obj) continue;
+        const Json *dt = kv.second.get("dtype"), *sh = kv.second.get("shape"), *off = kv.second.get("data_offsets");
+        if (!dt || dt->kind != Json::Str || !sh || sh->kind != Json::Arr || !off || off->kind != Json::Arr ||
+            off->arr.size() != 2)
+            continue;
+        TensorRef t;
+        t.dtype = dt->str;
+        for (const Json& d : sh->arr) t.shape.push_back((uint64_t)d.num);
+        t.begin = (uint64_t)off->arr[0].num;
+        t.end = (uint64_t)off->arr[1].num;
+        have[kv.first] = std::move(t);
+    }
+    const uint64_t data0 = 8 + hlen;
+    std::vector<unsigned char> raw;
+    for (const Want& w : layout_table(*cfg)) {
+        auto it = have.find(w.name);
+        if (it == have.end()) it = have.find("bert." + w.name);
+        if (it == have.end())
+            return fail(CS_ERR_BAD_ARG, "Failed to initialize embedding model: tensor %s is missing from %s",
+                        w.name.c_str(), path);
+        const TensorRef& t = it->second;
+        if (t.shape != w.shape) {
+            std::string got, exp;
+            for (uint64_t d : t.shape) got += (got.empty() ? "" : ", ") + std::to_string(d);
+            for (uint64_t d : w.shape) exp += (exp.empty() ? "" : ", ") + std::to_string(d);
+            return fail(CS_ERR_DIM_MISMATCH, "Failed to initialize embedding model: %s has shape [%s], config.json implies [%s]",
+                        w.name.c_str(), got.c_str(), exp.c_str());
+        }
+        uint64_t count = 1;
+        for (uint64_t d : w.shape) count *= d;
+        const uint32_t esz = t.dtype == "F32" ? 4 : (t.dtype == "F16" || t.dtype == "BF16") ? 2 : 0;
+        if (!esz)
+            return fail(CS_ERR_UNSUPPORTED, "Failed to initialize embedding model: %s has dtype %s (F32, F16, BF16 only)",
+                        w.name.c_str(), t.dtype.c_str());
+        if (t.end < t.begin || t.end - t.begin != count * esz)
+            return fail(CS_ERR_BAD_ARG, "Failed to initialize embedding model: %s has inconsistent data_offsets", w.name.c_str());
+        if (fseeko(f, (off_t)(data0 + t.begin), SEEK_SET) != 0)
+            return fail(CS_ERR_BAD_ARG, "Failed to initialize embedding model: %s is truncated", path);
+        float* dst = params + w.off;
+        if (esz == 4) {
+            if (std::fread(dst, 4, count, f) != count)
+                return fail(CS_ERR_BAD_ARG, "Failed to initialize embedding model: %s is truncated", path);
+        } else {
+            raw.resize(count * 2);
+            if (std::fread(raw.data(), 2, count, f) != count)
+                return fail(CS_ERR_BAD_ARG, "Failed to initialize embedding model: %s is truncated", path);
+            const bool bf = t.dtype == "BF16";
+            for (uint64_t i = 0; i < count; ++i) {
+                const uint16_t v = (uint16_t)(raw[2 * i] | (raw[2 * i + 1] << 8));
+                if (bf) {
+                    const uint32_t bits = (uint32_t)v << 16;
+                    std::memcpy(dst + i, &bits, 4);
+                } else {
+                    dst[i] = half_to_float(v);
+                }
+            }
+        }
+    }
+    return CS_OK;
+}
+
+int32_t cs_embedder_create_from_dir(const char* model_dir, int32_t pooling, int32_t device, cs_embedder** out) {
+    if (!out) return fail(CS_ERR_BAD_ARG, "null out pointer");
+    *out = nullptr;
+    cs_bert_config cfg;
+    CS_TRY(cs_bert_config_from_dir(model_dir, pooling, &cfg));
+    const uint64_t n = cs_bert_param_count(&cfg);
+    std::vector<float> params;
+    try {
+        params.resize(n);
+    } catch (const std::bad_alloc&) {
+        return fail(CS_ERR_OOM, "out of host memory for %llu parameters", (unsigned long long)n);
+    }
+    const std::string path = std::string(model_dir) + "/model.safetensors";
+    CS_TRY(cs_bert_params_from_safetensors(path.c_str(), &cfg, params.data(), n));
+    return cs_embedder_create(&cfg, params.data(), 0, device, out);
+}
+
+}  // extern "C"

@@ -149,6 +149,31 @@ class FastEmbedder:
         _lib.check(self._lib.cs_embedder_debug_counters(self._h, C.byref(a), C.byref(b), C.byref(c)))
         return int(a.value), int(b.value), int(c.value)
 
+    @classmethod
+    def from_dir(cls, model_dir: str, model_type: ModelType = None, pooling: int = POOL_CLS, device: int = 0,
+                 lowercase: bool = True) -> "FastEmbedder":
+        """A HF snapshot directory (config.json, model.safetensors, vocab.txt), as hf-hub leaves it in
+        fastembed's cache: cs_embedder_create_from_dir + cs_tokenizer_create_from_file."""
+        from .tokenizer import WordPieceTokenizer
+
+        self = cls.__new__(cls)
+        self._lib = _lib.load()
+        self._model_type = model_type or ModelType.default()
+        ccfg = _lib.BertConfig()
+        _lib.check(self._lib.cs_bert_config_from_dir(str(model_dir).encode(), pooling, C.byref(ccfg)))
+        self.config = BertConfig(vocab_size=ccfg.vocab_size, hidden=ccfg.hidden, layers=ccfg.layers, heads=ccfg.heads,
+                                 intermediate=ccfg.intermediate, max_position=ccfg.max_position,
+                                 type_vocab_size=ccfg.type_vocab_size, layer_norm_eps=ccfg.layer_norm_eps,
+                                 pooling=ccfg.pooling)
+        h = C.c_void_p()
+        _lib.check(self._lib.cs_embedder_create_from_dir(str(model_dir).encode(), pooling, device, C.byref(h)))
+        self._h = h
+        vocab = os.path.join(str(model_dir), "vocab.txt")
+        self.tokenizer = (WordPieceTokenizer.from_vocab_file(vocab, lowercase=lowercase,
+                                                             max_length=self.config.max_position)
+                          if os.path.exists(vocab) else None)
+        return self
+
     # constructors named as in the reference
     @classmethod
     def new(cls, **kw) -> "FastEmbedder":

@@ -245,6 +245,10 @@ class FastEmbedder {
     FastEmbedder(const cs_bert_config& cfg, const float* params, uint64_t seed = 0, int device = 0) {
         check(cs_embedder_create(&cfg, params, seed, device, &h_));
     }
+    // with_cache_dir from a HF snapshot directory (config.json + model.safetensors)
+    explicit FastEmbedder(const std::string& model_dir, cs_pooling pooling = CS_POOL_CLS, int device = 0) {
+        check(cs_embedder_create_from_dir(model_dir.c_str(), (int32_t)pooling, device, &h_));
+    }
     ~FastEmbedder() { cs_embedder_destroy(h_); }
     FastEmbedder(const FastEmbedder&) = delete;
     FastEmbedder& operator=(const FastEmbedder&) = delete;

@@ -208,6 +208,17 @@ uint64_t cs_bert_param_count(const cs_bert_config* cfg);
  * device from `seed` by the counter-based generator of include/cs_synth.h (synthetic-weight mode). */
 int32_t cs_embedder_create(const cs_bert_config* cfg, const float* params, uint64_t seed,
                            int32_t device, cs_embedder** out);
+/* Real checkpoints (the model-loading half of with_cache_dir).  `model_dir` is a HF snapshot
+ * directory as hf-hub caches it: config.json (BERT family, erf-GELU, absolute positions) and
+ * model.safetensors (HF BertModel tensor names, optional "bert." prefix; F32, F16 or BF16;
+ * pooler / position_ids / other extras ignored).  The two loaders are host-only. */
+int32_t cs_bert_config_from_dir(const char* model_dir, int32_t pooling, cs_bert_config* cfg);
+int32_t cs_bert_params_from_safetensors(const char* path, const cs_bert_config* cfg,
+                                        float* params, uint64_t n_params);
+/* config.json + model.safetensors -> embedder on `device` (vocab.txt of the same directory goes to
+ * cs_tokenizer_create_from_file). */
+int32_t cs_embedder_create_from_dir(const char* model_dir, int32_t pooling, int32_t device,
+                                    cs_embedder** out);
 void cs_embedder_destroy(cs_embedder* h);
 uint32_t cs_embedder_dim(const cs_embedder* h);   /* dimensions(), embedder.rs:307 */
 

@@ -271,3 +271,40 @@ def test_text_pipeline_index_and_search(FE):
         i, m = tok.encode_batch(texts[lo:lo + 128])
         index_token_chunks(emb, store2, i, m)
     assert np.abs(store.read_rows(0, 300) - store2.read_rows(0, 300)).max() <= 1e-6
+
+
+def test_embedder_from_hf_snapshot_directory(FE, oracle, tmp_path):
+    """FastEmbedder.from_dir = cs_embedder_create_from_dir + vocab.txt tokenizer: a HF snapshot written here
+    (config.json, bf16-free f32 model.safetensors with the `bert.` prefix, vocab.txt) embeds texts exactly
+    like an embedder handed the same flat parameter block."""
+    import json
+
+    from safetensors.numpy import save_file
+
+    from codesearch_amd import FastEmbedder
+    from codesearch_amd.bert_params import to_state_dict
+    from codesearch_amd.pipeline import synth_code_texts, synth_vocab
+    from codesearch_amd.tokenizer import WordPieceTokenizer
+
+    vocab = synth_vocab(1024)
+    cfg = BertConfig(vocab_size=1024, layers=2, max_position=64, pooling=POOL_CLS)
+    flat = synth_params(cfg, 77)
+    d = tmp_path / "snapshot"
+    d.mkdir()
+    (d / "config.json").write_text(json.dumps({
+        "model_type": "bert", "vocab_size": 1024, "hidden_size": 384, "num_hidden_layers": 2,
+        "num_attention_heads": 12, "intermediate_size": 1536, "max_position_embeddings": 64,
+        "type_vocab_size": 2, "layer_norm_eps": 1e-12, "hidden_act": "gelu"}))
+    save_file({"bert." + k: np.ascontiguousarray(v) for k, v in to_state_dict(cfg, flat).items()},
+              str(d / "model.safetensors"))
+    (d / "vocab.txt").write_text("\n".join(sorted(vocab, key=vocab.get)) + "\n")
+    emb = FastEmbedder.from_dir(str(d))
+    assert emb.dimensions() == 384 and emb.config.layers == 2 and emb.tokenizer.vocab_size() == 1024
+    texts = synth_code_texts(vocab, 9, 3, mean_words=20)
+    got = np.stack(emb.embed_batch(texts))
+    ref_emb = FE(cfg, params=flat, tokenizer=WordPieceTokenizer(vocab, max_length=64))
+    assert np.array_equal(got, np.stack(ref_emb.embed_batch(texts)))
+    ids, mask = emb.tokenizer.encode_batch(texts)
+    exp = oracle.bert_forward(cfg, flat, ids, mask)["pooled"]
+    np.testing.assert_allclose(got, exp, atol=TOL_ORACLE)
+    emb.close()

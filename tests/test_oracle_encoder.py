@@ -100,3 +100,80 @@ def test_checkpoint_loader_roundtrip(tmp_path):
     assert np.array_equal(load_checkpoint(path, cfg), flat)
     with pytest.raises(ValueError):
         config_from_hf({**hf, "model_type": "nomic_bert"})
+
+
+def test_c_abi_checkpoint_loaders(tmp_path, gpu_lib):
+    """cs_bert_config_from_dir / cs_bert_params_from_safetensors (csrc/checkpoint.cpp, host-only): a HF
+    snapshot directory -> the same config and flat block as the Python loader, for F32, F16 and BF16
+    files, with and without the `bert.` prefix; error texts for the usual failures."""
+    import ctypes as C
+    import json
+
+    import torch
+    from safetensors.numpy import save_file
+    from safetensors.torch import save_file as save_torch
+
+    from codesearch_amd import _lib
+    from codesearch_amd.bert_params import config_from_hf
+
+    hf = {"model_type": "bert", "vocab_size": 300, "hidden_size": 384, "num_hidden_layers": 2,
+          "num_attention_heads": 12, "intermediate_size": 1536, "max_position_embeddings": 64,
+          "type_vocab_size": 2, "layer_norm_eps": 1e-12, "hidden_act": "gelu",
+          "architectures": ["BertModel"], "id2label": {"0": "LABEL_0"}, "torch_dtype": "float32",
+          "note": "escapes \\ \" \u00e9 and nested {\"a\": [1, 2.5e3, true, null]}"}
+    cfg = config_from_hf(hf)
+    flat = synth_params(cfg, 11)
+    sd = to_state_dict(cfg, flat)
+
+    def load(d):
+        c = _lib.BertConfig()
+        _lib.check(gpu_lib.cs_bert_config_from_dir(str(d).encode(), POOL_MEAN, C.byref(c)))
+        n = int(gpu_lib.cs_bert_param_count(C.byref(c)))
+        out = np.empty(n, np.float32)
+        _lib.check(gpu_lib.cs_bert_params_from_safetensors(str(d / "model.safetensors").encode(), C.byref(c),
+                                                          out.ctypes.data_as(_lib.f32p), n))
+        return c, out
+
+    d32 = tmp_path / "f32"
+    d32.mkdir()
+    (d32 / "config.json").write_text(json.dumps(hf, indent=2))
+    extra = {"bert." + k: np.ascontiguousarray(v) for k, v in sd.items()}
+    extra["bert.pooler.dense.weight"] = np.zeros((384, 384), np.float32)
+    extra["bert.embeddings.position_ids"] = np.arange(64, dtype=np.int64)[None]
+    save_file(extra, str(d32 / "model.safetensors"), metadata={"format": "pt"})
+    c, got = load(d32)
+    assert (c.vocab_size, c.hidden, c.layers, c.heads, c.intermediate, c.max_position, c.type_vocab_size,
+            c.pooling) == (300, 384, 2, 12, 1536, 64, 2, POOL_MEAN)
+    assert abs(c.layer_norm_eps - 1e-12) < 1e-18 and np.array_equal(got, flat)
+
+    for name, dt in (("f16", torch.float16), ("bf16", torch.bfloat16)):
+        d = tmp_path / name
+        d.mkdir()
+        (d / "config.json").write_text(json.dumps(hf))
+        save_torch({k: torch.from_numpy(np.ascontiguousarray(v)).to(dt) for k, v in sd.items()},
+                   str(d / "model.safetensors"))
+        _, got = load(d)
+        exp = torch.from_numpy(flat).to(dt).to(torch.float32).numpy()
+        assert np.array_equal(got, exp), name
+
+    def expect(fn, code, text):
+        try:
+            fn()
+        except _lib.CsError as e:
+            assert e.code == code and text in str(e), str(e)
+        else:
+            raise AssertionError("expected " + text)
+
+    bad = tmp_path / "bad"
+    bad.mkdir()
+    expect(lambda: load(bad), _lib.CS_ERR_BAD_ARG, "cannot open")
+    (bad / "config.json").write_text(json.dumps({**hf, "model_type": "nomic_bert"}))
+    expect(lambda: load(bad), _lib.CS_ERR_UNSUPPORTED, "is not a BERT encoder")
+    (bad / "config.json").write_text(json.dumps({**hf, "num_hidden_layers": 3}))
+    save_file({k: np.ascontiguousarray(v) for k, v in sd.items()}, str(bad / "model.safetensors"))
+    expect(lambda: load(bad), _lib.CS_ERR_BAD_ARG, "encoder.layer.2.attention.self.query.weight is missing")
+    (bad / "config.json").write_text(json.dumps({**hf, "intermediate_size": 1024}))
+    expect(lambda: load(bad), _lib.CS_ERR_DIM_MISMATCH, "has shape [1536, 384], config.json implies [1024, 384]")
+    (bad / "model.safetensors").write_bytes(b"\x10\x00\x00\x00\x00\x00\x00\x00not json at all!")
+    (bad / "config.json").write_text(json.dumps(hf))
+    expect(lambda: load(bad), _lib.CS_ERR_BAD_ARG, "malformed header")
