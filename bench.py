@@ -103,6 +103,55 @@ def encoder_legs(shard, k, device):
     }
 
 
+def scan_1m_leg(dim, k, device, store_cls):
+    """BASELINE.json configs[1] for information: 1 query over 1,000,000 x 384 fp32 rows (1.536 GB per launch:
+    launch ramp and tail weigh ~10x more than at 10M rows).  Kernel time from the library's HIP events."""
+    import ctypes as C
+
+    import torch
+
+    from codesearch_amd import _lib
+    from codesearch_amd.synth import synth_rows
+
+    rows = 1_000_000
+    st = store_cls(None, dim, device=device, capacity=rows)
+    st.insert_synthetic(rows, SEED, 0)
+    st.build_index()
+    lib = _lib.load()
+    dev = f"cuda:{device}"
+    d_q = torch.from_numpy(synth_rows(SEED + 1, 0, 1, dim)).to(dev)
+    keys = torch.zeros(k, dtype=torch.int64, device=dev)
+    cos = torch.zeros(k, dtype=torch.float32, device=dev)
+    ids = torch.zeros(k, dtype=torch.int32, device=dev)
+    cnt = torch.zeros(1, dtype=torch.int32, device=dev)
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    vp = lambda x: C.c_void_p(x.data_ptr())
+
+    def search():
+        _lib.check(lib.cs_index_search_device(st.handle, vp(d_q), 1, dim, k, vp(keys), vp(cos), vp(ids), vp(cnt), stream))
+
+    for _ in range(20):
+        search()
+    torch.cuda.synchronize()
+    st.profile(True)
+    st.profile_read(reset=True)
+    reps = 200
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        search()
+    torch.cuda.synchronize()
+    wall = (time.perf_counter() - t0) / reps
+    scan_ms, launches, _ = st.profile_read(reset=True)
+    st.profile(False)
+    us = scan_ms * 1e3 / max(launches, 1)
+    gbps = rows * dim * 4 / (us * 1e-6) / 1e9
+    out = {"workload": f"brute-force cosine top-{k}, 1 query over {rows} x {dim} fp32 rows (BASELINE.json configs[1])",
+           "ms_per_search": wall * 1e3, "chunks_per_s": rows / wall, "scan_kernel_us": us,
+           "hbm_GBps": gbps, "frac_of_hbm_peak": gbps / HBM_PEAK_GBPS}
+    del st
+    return out
+
+
 def hbm_reference(device, nbytes=2 << 30, reps=10):
     """a measured device copy / fill bandwidth beside the 8 TB/s spec figure, so the
     scan's fraction can be read against both.  torch's copy_ and zero_ kernels on `nbytes`."""
@@ -331,6 +380,8 @@ def main():
                 "note": "cs_index_set_filter_min_queries(1): f16 MFMA filter over the 7.68 GB unit-vector copy, "
                         "then exact f32 re-score of the candidates; not used for `value`",
             }
+        if world == 1 and args.nq == 1 and args.dim == 384:
+            line["config_1m"] = scan_1m_leg(args.dim, args.k, local_rank, VectorStore)
         if world == 1:
             ref = hbm_reference(f"cuda:{local_rank}")
             line["hbm_reference"] = ref

@@ -377,6 +377,182 @@ score_filter256_kernel(const _Float16* __restrict__ corpus_h, uint64_t row_lo, u
     }
 }
 
+// ---- the 256 x 256 tiles as a persistent kernel with cross-tile prefetch ------------------------------
+// dim 384 is only six 64-k stages per tile, and with one block per CU (128 KiB of LDS) nothing covers a
+// tile's first stage (an HBM round trip when the corpus rows are cold) or its epilogue.  Here a block
+// walks tiles b, b + grid, ... (same XCD, consecutive tile slots: the XCD-shared walk of
+// sh_tile_of_block is kept) and issues stage 0 of its NEXT tile between the MFMAs of the current
+// tile's last stage, into the buffer that stage leaves free; the threshold epilogue then runs under
+// that load.  Main loop as in score_filter256_kernel<false> (DMA issue spread through the MFMAs).
+__global__ void __launch_bounds__(512, 2)
+score_filter256p_kernel(const _Float16* __restrict__ corpus_h, uint64_t row_lo, uint64_t row_hi, uint32_t kchunks,
+                        const _Float16* __restrict__ queries_h, uint32_t nq, const float* __restrict__ tau,
+                        const uint32_t* __restrict__ dead, uint32_t* __restrict__ cand,
+                        uint32_t* __restrict__ cnt, uint32_t cap, uint32_t total_slots) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const uint32_t M = (uint32_t)(row_hi - row_lo);
+    const uint32_t mtiles = (M + UF2_BM - 1) / UF2_BM, ntiles = (nq + UF2_BN - 1) / UF2_BN;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    const int l31 = lane & 31, h = lane >> 5;
+    const _Float16* A = corpus_h + uf_tiled_off(row_lo, 0, kchunks);  // row_lo is a multiple of 128
+
+    // first live tile slot of this block at or after `slot` (slots of padding m-tiles are skipped)
+    auto next_live = [&](uint32_t slot, uint32_t& mt, uint32_t& nt) {
+        for (; slot < total_slots; slot += gridDim.x)
+            if (sh_tile_of_block(slot, mtiles, ntiles, mt, nt)) return slot;
+        return total_slots;
+    };
+    // per-lane source pointers of a tile's stage pieces (4 corpus pieces, 4 query pieces per wave)
+    auto tile_ptrs = [&](uint32_t mt, uint32_t nt, const _Float16* (&ap)[4], const _Float16* (&wp)[4]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = wave * 32 + i * 8 + (lane >> 3);
+            const int c = (lane & 7) ^ ((row >> 1) & 7);
+            const uint32_t wn = (nt * UF2_BN + row < nq) ? nt * UF2_BN + row : nq - 1;
+            ap[i] = A + uf_tiled_off(mt * UF2_BM + row, 0, kchunks) + c * 8;  // padded tiles: no row clamp needed
+            wp[i] = queries_h + (size_t)wn * kchunks * 64 + c * 8;
+        }
+    };
+    const int swz = (l31 >> 1) & 7;
+    const int arow = (wr * 64 + l31) * 128, wrow = UF2_TILE + (wc * 128 + l31) * 128;
+    int sl[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) sl[s] = ((2 * s + h) ^ swz) * 16;
+    const uint32_t lds_base = (uint32_t)(uintptr_t)lds;
+    struct Frags { f16x8 a[2], w[4]; };
+    auto load_frags = [&](uint32_t stage_off, int s, Frags& f) {
+        const uint32_t aa = lds_base + stage_off + arow + sl[s], ww = lds_base + stage_off + wrow + sl[s];
+        asm volatile("ds_read_b128 %0, %1" : "=v"(f.a[0]) : "v"(aa));
+        asm volatile("ds_read_b128 %0, %1" : "=v"(f.w[0]) : "v"(ww));
+        asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(f.w[1]) : "v"(ww));
+        asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(f.a[1]) : "v"(aa));
+        asm volatile("ds_read_b128 %0, %1 offset:8192" : "=v"(f.w[2]) : "v"(ww));
+        asm volatile("ds_read_b128 %0, %1 offset:12288" : "=v"(f.w[3]) : "v"(ww));
+    };
+#define UF2_LGKM_WAIT(N)                                           \
+    do {                                                           \
+        asm volatile("s_waitcnt lgkmcnt(" #N ")" ::: "memory");    \
+        __builtin_amdgcn_sched_barrier(0);                         \
+    } while (0)
+
+    uint32_t mt, nt, mtn = 0, ntn = 0;
+    uint32_t slot = next_live(blockIdx.x, mt, nt);
+    if (slot >= total_slots) return;
+    const _Float16 *a_cur[4], *w_cur[4], *a_nxt[4], *w_nxt[4];
+    tile_ptrs(mt, nt, a_cur, w_cur);
+    uint32_t kr = sh_kc_rot(nt, ntiles, kchunks);  // chunk of the next stage to issue for the current tile
+    uint32_t par = 0;                              // buffer of the current tile's stage 0
+    {   // stage 0 of the first tile
+        char* dst = lds + wave * 32 * 128;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            sh_glds16(a_cur[i] + (size_t)kr * 128 * 64, dst + i * 1024);
+            sh_glds16(w_cur[i] + (size_t)kr * 64, dst + UF2_TILE + i * 1024);
+        }
+        kr = kr + 1 == kchunks ? 0 : kr + 1;
+    }
+    for (;;) {
+        const uint32_t slot_n = next_live(slot + gridDim.x, mtn, ntn);
+        const bool have_next = slot_n < total_slots;
+        uint32_t krn = 0;
+        if (have_next) {
+            tile_ptrs(mtn, ntn, a_nxt, w_nxt);
+            krn = sh_kc_rot(ntn, ntiles, kchunks);
+        }
+        sh_f32x16 acc[2][4];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+        // eight MFMAs of one k16 sub-step; with `issue`, DMA pieces q0..q0+3 (0..3 corpus, 4..7 queries) of
+        // chunk kcn — of this tile, or of the next tile's stage 0 when `from_next` — after MFMAs 2, 4, 6, 8
+        auto mfma8 = [&](const Frags& f, bool issue, bool from_next, int q0, uint32_t kcn, char* nbuf) {
+            char* dst = nbuf + wave * 32 * 128;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const int i = p >> 1, j0 = (p & 1) * 2;
+                acc[i][j0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.a[i], f.w[j0], acc[i][j0], 0, 0, 0);
+                acc[i][j0 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.a[i], f.w[j0 + 1], acc[i][j0 + 1], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (issue) {
+                    const int q = q0 + p;
+                    if (q < 4) sh_glds16((from_next ? a_nxt[q] : a_cur[q]) + (size_t)kcn * 128 * 64, dst + q * 1024);
+                    else sh_glds16((from_next ? w_nxt[q - 4] : w_cur[q - 4]) + (size_t)kcn * 64, dst + UF2_TILE + (q - 4) * 1024);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        sh_wait_vmcnt<0>();             // this wave's pieces of the tile's stage 0 (and the last epilogue's stores)
+        __builtin_amdgcn_s_barrier();   // ... and everybody else's
+        __builtin_amdgcn_sched_barrier(0);
+        Frags f0, f1;
+        load_frags(par * UF2_STAGE, 0, f0);
+        for (uint32_t kc = 0; kc < kchunks; ++kc) {
+            const uint32_t b = (par + kc) & 1;
+            const uint32_t so = b * UF2_STAGE;
+            char* nbuf = lds + (b ^ 1) * UF2_STAGE;
+            const bool last = kc + 1 == kchunks;
+            const bool issue = !last || have_next;
+            uint32_t kcn;
+            if (!last) { kcn = kr; kr = kr + 1 == kchunks ? 0 : kr + 1; }
+            else kcn = krn;
+            load_frags(so, 1, f1);
+            UF2_LGKM_WAIT(6);
+            mfma8(f0, issue, last, 0, kcn, nbuf);
+            load_frags(so, 2, f0);
+            UF2_LGKM_WAIT(6);
+            mfma8(f1, issue, last, 4, kcn, nbuf);
+            load_frags(so, 3, f1);
+            UF2_LGKM_WAIT(6);
+            mfma8(f0, false, false, 0, 0, nbuf);
+            UF2_LGKM_WAIT(0);  // this wave's last reads of the stage are back
+            if (!last) {
+                sh_wait_vmcnt<0>();  // its pieces of the next stage have landed
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                load_frags(so ^ UF2_STAGE, 0, f0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            mfma8(f1, false, false, 0, 0, nbuf);
+        }
+        // threshold epilogue of (mt, nt) while the next tile's stage 0 is in flight
+        const uint32_t m0 = mt * UF2_BM, n0 = nt * UF2_BN;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t q = n0 + wc * 128 + j * 32 + l31;
+            const bool qok = q < nq;
+            const float tq = qok ? tau[q] - kFilterMargin : 0.0f;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const uint32_t m = m0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    if (qok && m < M && !(acc[i][j][r] <= tq)) {
+                        const uint64_t row = row_lo + m;
+                        if (!dead || !((dead[row >> 5] >> (row & 31)) & 1u)) {
+                            const uint32_t pos = atomicAdd(&cnt[q], 1u);
+                            if (pos < cap) cand[(size_t)q * cap + pos] = (uint32_t)row;
+                        }
+                    }
+                }
+            }
+        }
+        if (!have_next) break;
+        par = (par + kchunks) & 1;
+        slot = slot_n;
+        mt = mtn;
+        nt = ntn;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { a_cur[i] = a_nxt[i]; w_cur[i] = w_nxt[i]; }
+        kr = krn + 1 == kchunks ? 0 : krn + 1;  // stage 0 (chunk krn) is already on its way
+    }
+#undef UF2_LGKM_WAIT
+}
+
 // ---- up to 64 queries: resident queries, deep corpus ring ---------------------------------------
 // With few queries the filter is a pure stream of the f16 corpus copy, and what limits a
 // tile-at-a-time kernel is bytes in flight per CU (one 16 KB corpus stage per block) against HBM
@@ -669,6 +845,8 @@ static int32_t scan_split_impl(const BatchedState& st, const SplitQueryWs& qw, c
                                    hipFuncAttributeMaxDynamicSharedMemorySize, UF2_LDS));
         CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(score_filter256_kernel<true>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, UF2_LDS));
+        CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(score_filter256p_kernel),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, UF2_LDS));
         CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(score_filter_rw_kernel<1>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, RwGeom<1>::LDS));
         CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(score_filter_rw_kernel<2>),
@@ -746,7 +924,21 @@ static int32_t scan_split_impl(const BatchedState& st, const SplitQueryWs& qw, c
             } else if (wide) {
                 const uint32_t mt2 = (uint32_t)((hi - lo + UF2_BM - 1) / UF2_BM), nt2 = (nq + UF2_BN - 1) / UF2_BN;
                 static const bool legacy256 = std::getenv("CS_FILTER256_LEGACY") != nullptr;
-                if (legacy256)
+                static const bool tile256 = std::getenv("CS_FILTER256_TILEWISE") != nullptr;  // A/B: one block per tile
+                if (!legacy256 && !tile256) {
+                    static int cus = 0;
+                    if (!cus) {
+                        int dev = 0;
+                        hipDeviceProp_t prop;
+                        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+                            cus = prop.multiProcessorCount;
+                        if (cus <= 0) cus = 256;
+                    }
+                    const uint32_t slots = sh_grid_blocks(mt2, nt2);
+                    const uint32_t grid = std::min<uint32_t>(slots, ((uint32_t)cus + 7) / 8 * 8);  // a multiple of 8: a block stays on its XCD slot
+                    hipLaunchKernelGGL(score_filter256p_kernel, dim3(grid), dim3(512), UF2_LDS, stream, d_split, lo, hi,
+                                       dim / 64, qw.d_qsplit, nq, st.d_tau, d_dead, cand, st.d_cnt, cap, slots);
+                } else if (legacy256)
                     hipLaunchKernelGGL(score_filter256_kernel<true>, dim3(sh_grid_blocks(mt2, nt2)), dim3(512), UF2_LDS,
                                        stream, d_split, lo, hi, dim / 64, qw.d_qsplit, nq, st.d_tau, d_dead, cand,
                                        st.d_cnt, cap);
