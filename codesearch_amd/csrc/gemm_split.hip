@@ -138,6 +138,30 @@ gemm_sh_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ W,
     SH_STAMP(3);
 }
 
+// 128 x 128 tiles on v_mfma_f32_16x16x32_f16 (sh_mainloop16), two blocks per CU.
+template <int EPI>
+__global__ void __launch_bounds__(256, 2)
+gemm_sh16_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ W,
+                 const float* __restrict__ bias, const float* resid, float* C,
+                 _Float16* __restrict__ Cs, uint32_t M, uint32_t N, uint32_t kchunks,
+                 uint32_t* __restrict__ flag) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    uint32_t mt, nt;
+    if (!sh_tile_of_block(blockIdx.x, (M + SH_BM - 1) / SH_BM, N / SH_BN, mt, nt)) return;
+    const uint32_t m0 = mt * SH_BM, n0 = nt * SH_BN;
+    SH_STAMP(0);
+    ShAcc16 acc;
+    sh_acc16_zero(acc);
+    sh_mainloop16(A, M, m0, W, N, n0, kchunks, lds, acc, sh_kc_rot(nt, N / SH_BN, kchunks));
+    SH_STAMP(1);
+    float* ctile = reinterpret_cast<float*>(lds);
+    sh_acc16_to_lds(acc, ctile);
+    SH_STAMP(2);
+    if (m0 + SH_BM <= M) gemm_sh_epilogue<EPI, true, 2>(ctile, bias, resid, C, Cs, M, N, m0, n0, flag);
+    else gemm_sh_epilogue<EPI, false, 2>(ctile, bias, resid, C, Cs, M, N, m0, n0, flag);
+    SH_STAMP(3);
+}
+
 // 256 x 128 tiles, 8 waves, 3-stage LDS-DMA ring (sh_mainloop3<4>), one block per CU.
 template <int EPI, bool IL = false>
 __global__ void __launch_bounds__(512, 2)
@@ -261,8 +285,28 @@ int32_t launch_gemm_split(int epi, const _Float16* A, const _Float16* W, const f
     const uint32_t kc = K / 32;
     static int tile = -1;
     if (tile < 0) {
-        const char* e = std::getenv("CS_GEMM_TILE");  // 128 (default): 128x128 tiles, 2 blocks/CU; 256: 256x128, 3-stage ring; 257: the same with the DMA issue interleaved
-        tile = (e && std::atoi(e) == 256) ? 256 : (e && std::atoi(e) == 257) ? 257 : 128;
+        // 16 (default): 128x128 tiles on v_mfma_f32_16x16x32_f16, 2 blocks/CU; 128: the same tiles on the 32x32x16
+        // MFMA; 256: 256x128, 3-stage ring; 257: the same with the DMA issue interleaved
+        const char* e = std::getenv("CS_GEMM_TILE");
+        const int v = e ? std::atoi(e) : 16;
+        tile = (v == 256 || v == 257 || v == 128) ? v : 16;
+    }
+    if (tile == 16) {  // 128 x 128 tiles on the 16x16x32 MFMA
+        static bool attr16 = false;
+        if (!attr16) {
+            CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_sh16_kernel<SH_OUT_F32>), hipFuncAttributeMaxDynamicSharedMemorySize, SH_LDS_BYTES));
+            CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_sh16_kernel<SH_OUT_F32_RESID>), hipFuncAttributeMaxDynamicSharedMemorySize, SH_LDS_BYTES));
+            CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_sh16_kernel<SH_OUT_SPLIT_GELU>), hipFuncAttributeMaxDynamicSharedMemorySize, SH_LDS_BYTES));
+            CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_sh16_kernel<SH_OUT_SPLIT>), hipFuncAttributeMaxDynamicSharedMemorySize, SH_LDS_BYTES));
+            attr16 = true;
+        }
+        const dim3 grid16(sh_grid_blocks((M + SH_BM - 1) / SH_BM, N / SH_BN));
+        if (epi == SH_OUT_F32) hipLaunchKernelGGL(gemm_sh16_kernel<SH_OUT_F32>, grid16, dim3(256), SH_LDS_BYTES, s, A, W, bias, resid, C, Cs, M, N, kc, d_flag);
+        else if (epi == SH_OUT_F32_RESID) hipLaunchKernelGGL(gemm_sh16_kernel<SH_OUT_F32_RESID>, grid16, dim3(256), SH_LDS_BYTES, s, A, W, bias, resid, C, Cs, M, N, kc, d_flag);
+        else if (epi == SH_OUT_SPLIT) hipLaunchKernelGGL(gemm_sh16_kernel<SH_OUT_SPLIT>, grid16, dim3(256), SH_LDS_BYTES, s, A, W, bias, resid, C, Cs, M, N, kc, d_flag);
+        else hipLaunchKernelGGL(gemm_sh16_kernel<SH_OUT_SPLIT_GELU>, grid16, dim3(256), SH_LDS_BYTES, s, A, W, bias, resid, C, Cs, M, N, kc, d_flag);
+        CS_HIP(hipGetLastError());
+        return CS_OK;
     }
     if (tile == 257) {  // 256 x 128 tiles, 3-stage ring, LDS-DMA issue spread through the MFMA stream
         using G = ShGeom<4>;

@@ -183,6 +183,104 @@ __device__ __forceinline__ void sh_mainloop(const _Float16* __restrict__ A, uint
     }
 }
 
+// ---- sh_mainloop on v_mfma_f32_16x16x32_f16 -------------------------------------------------------------
+// Same tiles, staging, LDS image and barrier protocol as sh_mainloop; a wave's 64 x 64 tile is 4 x 4 MFMA
+// tiles of 16 x 16 and one MFMA consumes the whole 32-k line of a row (A/B operand: lane = row | col
+// (lane & 15), k-group lane >> 4 of 8 values = 16-B piece g (hi) or 4 + g (lo) of the line).  Same MFMA
+// cycles and the same LDS read bytes per flop as the 32 x 32 x 16 form; MI355X_MICROARCH.md (DVFS
+// give-back, item 7) measures ~1.12-1.15x the FLOP/s for this shape on random data because the chip
+// holds a higher clock under it.  Accumulator layout: 4 registers per tile, n = lane & 15,
+// m = 4 (lane >> 4) + r.
+typedef float sh_f32x4v __attribute__((ext_vector_type(4)));
+struct ShAcc16 {
+    sh_f32x4v hh[4][4];
+    sh_f32x4v xx[4][4];
+};
+
+__device__ __forceinline__ void sh_acc16_zero(ShAcc16& acc) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { acc.hh[i][j][r] = 0.0f; acc.xx[i][j][r] = 0.0f; }
+}
+
+__device__ __forceinline__ void sh_mainloop16(const _Float16* __restrict__ A, uint32_t M, uint32_t m0,
+                                              const _Float16* __restrict__ W, uint32_t N, uint32_t n0,
+                                              uint32_t kchunks, char* lds, ShAcc16& acc, uint32_t kc_rot = 0) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    const int l15 = lane & 15, g = lane >> 4;
+    const _Float16* asrc[4];
+    const _Float16* wsrc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = wave * 32 + i * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((row >> 1) & 7);
+        const uint32_t am = (m0 + row < M) ? m0 + row : M - 1;
+        const uint32_t wn = (n0 + row < N) ? n0 + row : N - 1;
+        asrc[i] = A + (size_t)am * kchunks * 64 + c * 8;
+        wsrc[i] = W + (size_t)wn * kchunks * 64 + c * 8;
+    }
+    auto stage = [&](uint32_t kc, char* buf) {
+        char* dst = buf + wave * 32 * 128;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            sh_glds16(asrc[i] + (size_t)kc * 64, dst + i * 1024);
+            sh_glds16(wsrc[i] + (size_t)kc * 64, dst + SH_TILE_BYTES + i * 1024);
+        }
+    };
+    // rows wr*64 + 16 i + l15: (row >> 1) & 7 = (l15 >> 1) for every i (16 i, 64 wr are multiples of 16)
+    const int swz = (l15 >> 1) & 7;
+    const int arow = (wr * 64 + l15) * 128, wrow = SH_TILE_BYTES + (wc * 64 + l15) * 128;
+    const int s_hi = (g ^ swz) * 16, s_lo = ((4 + g) ^ swz) * 16;
+
+    uint32_t kr = kc_rot % kchunks;
+    auto next_chunk = [&]() { const uint32_t c = kr; kr = kr + 1 == kchunks ? 0 : kr + 1; return c; };
+    stage(next_chunk(), lds);
+    __syncthreads();
+    for (uint32_t kc = 0; kc < kchunks; ++kc) {
+        char* cur = lds + (kc & 1) * SH_STAGE_BYTES;
+        if (kc + 1 < kchunks) stage(next_chunk(), lds + ((kc + 1) & 1) * SH_STAGE_BYTES);
+        f16x8 ah[4], al[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            ah[i] = *reinterpret_cast<const f16x8*>(cur + arow + i * 16 * 128 + s_hi);
+            al[i] = *reinterpret_cast<const f16x8*>(cur + arow + i * 16 * 128 + s_lo);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const f16x8 wh = *reinterpret_cast<const f16x8*>(cur + wrow + j * 16 * 128 + s_hi);
+            const f16x8 wl = *reinterpret_cast<const f16x8*>(cur + wrow + j * 16 * 128 + s_lo);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                acc.hh[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], wh, acc.hh[i][j], 0, 0, 0);
+                acc.xx[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], wl, acc.xx[i][j], 0, 0, 0);
+                acc.xx[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], wh, acc.xx[i][j], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// C tile to LDS as [128 m][128 n] f32 (see sh_acc_to_lds).  Followed by a barrier.
+__device__ __forceinline__ void sh_acc16_to_lds(const ShAcc16& acc, float* ctile) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1, l15 = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = wr * 64 + i * 16 + 4 * g + r;
+                ctile[m * 128 + wc * 64 + j * 16 + l15] = fmaf(acc.xx[i][j][r], kShLoInv, acc.hh[i][j][r]);
+            }
+    __syncthreads();
+}
+
 // ---- 3-stage variant: (64*WM) x 128 x 32 tiles, 2*WM waves, up to 3 stages in flight ----------
 // WM = 4: 256 x 128 tile, 8 waves (two per SIMD), one block per CU: 1.33x the MFMA work per byte
 // staged into LDS of the 128 x 128 tile, and the LDS-DMA of stages k+1 and k+2 stays in flight
