@@ -90,7 +90,7 @@ def encoder_legs(shard, k, device):
                         "synthetic weights, CLS pool + L2 normalise",
             "ms_per_batch": ms, "chunks_per_s": B / (ms * 1e-3),
             "algorithmic_tflops": (gemm_flops + attn_flops) / (ms * 1e-3) / 1e12,
-            "dense_layers": "split-f16 operands on v_mfma_f32_32x32x16_f16, 3 MFMAs per f32 product block",
+            "dense_layers": "split-f16 operands on v_mfma_f32_16x16x32_f16, 3 MFMAs per f32 product block",
             "executed_f16_mfma_tflops": 3 * gemm_flops / (ms * 1e-3) / 1e12,
             "f16_mfma_peak_tflops": MFMA_F16_PEAK_TFLOPS,
             "split_forwards": split, "f32_fallbacks": fb,
