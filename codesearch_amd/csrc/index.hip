@@ -41,8 +41,10 @@ struct Workspace {
     float* d_queries = nullptr; size_t q_cap = 0;
     uint64_t* d_keys = nullptr; float* d_cos = nullptr; uint32_t* d_ids = nullptr; size_t out_cap = 0;
     uint32_t* d_counts = nullptr; size_t cnt_cap = 0;
-    float* h_cos = nullptr; uint32_t* h_ids = nullptr; uint32_t* h_counts = nullptr;
-    size_t h_out_cap = 0, h_cnt_cap = 0;
+    // pinned staging of the host-buffer API: queries in, packed keys out (ONE copy each way; the host
+    // unpacks cosine / id / count from the keys — three more small D2H copies cost ~8 us apiece)
+    float* h_queries = nullptr; size_t h_q_cap = 0;
+    uint64_t* h_keys = nullptr; size_t h_out_cap = 0;
     std::vector<EventTriple> free_events;
     BatchedState bs;
     size_t bs_nq = 0, bs_cand = 0, bs_carry = 0;
@@ -134,18 +136,16 @@ struct Workspace {
             cnt_cap = nq;
         }
         if (on > h_out_cap) {
-            if (h_cos) (void)hipHostFree(h_cos);
-            if (h_ids) (void)hipHostFree(h_ids);
-            h_cos = nullptr; h_ids = nullptr; h_out_cap = 0;
-            CS_HIP(hipHostMalloc(&h_cos, on * sizeof(float)));
-            CS_HIP(hipHostMalloc(&h_ids, on * sizeof(uint32_t)));
+            if (h_keys) (void)hipHostFree(h_keys);
+            h_keys = nullptr; h_out_cap = 0;
+            CS_HIP(hipHostMalloc(&h_keys, on * sizeof(uint64_t)));
             h_out_cap = on;
         }
-        if (nq > h_cnt_cap) {
-            if (h_counts) (void)hipHostFree(h_counts);
-            h_counts = nullptr; h_cnt_cap = 0;
-            CS_HIP(hipHostMalloc(&h_counts, nq * sizeof(uint32_t)));
-            h_cnt_cap = nq;
+        if ((size_t)nq * dim > h_q_cap) {
+            if (h_queries) (void)hipHostFree(h_queries);
+            h_queries = nullptr; h_q_cap = 0;
+            CS_HIP(hipHostMalloc(&h_queries, (size_t)nq * dim * sizeof(float)));
+            h_q_cap = (size_t)nq * dim;
         }
         return CS_OK;
     }
@@ -159,9 +159,8 @@ struct Workspace {
         if (d_cos) (void)hipFree(d_cos);
         if (d_ids) (void)hipFree(d_ids);
         if (d_counts) (void)hipFree(d_counts);
-        if (h_cos) (void)hipHostFree(h_cos);
-        if (h_ids) (void)hipHostFree(h_ids);
-        if (h_counts) (void)hipHostFree(h_counts);
+        if (h_keys) (void)hipHostFree(h_keys);
+        if (h_queries) (void)hipHostFree(h_queries);
         if (h_overflow) (void)hipHostFree(h_overflow);
         if (bs.d_cand) (void)hipFree(bs.d_cand);
         if (bs.d_cnt) (void)hipFree(bs.d_cnt);
@@ -595,17 +594,22 @@ int32_t cs_index_search(cs_index* h, const float* queries, uint32_t nq, uint32_t
     if (s == CS_OK) {
         const size_t on = (size_t)nq * k;
         s = [&]() -> int32_t {
-            CS_HIP(hipMemcpyAsync(w->d_queries, queries, (size_t)nq * h->dim * sizeof(float),
+            memcpy(w->h_queries, queries, (size_t)nq * h->dim * sizeof(float));
+            CS_HIP(hipMemcpyAsync(w->d_queries, w->h_queries, (size_t)nq * h->dim * sizeof(float),
                                   hipMemcpyHostToDevice, w->stream));
-            CS_TRY(run_search(h, w, plan, w->d_queries, nq, k, w->d_keys, w->d_cos, w->d_ids,
-                              w->d_counts, w->stream));
-            CS_HIP(hipMemcpyAsync(w->h_cos, w->d_cos, on * sizeof(float), hipMemcpyDeviceToHost, w->stream));
-            CS_HIP(hipMemcpyAsync(w->h_ids, w->d_ids, on * sizeof(uint32_t), hipMemcpyDeviceToHost, w->stream));
-            CS_HIP(hipMemcpyAsync(w->h_counts, w->d_counts, nq * sizeof(uint32_t), hipMemcpyDeviceToHost, w->stream));
+            CS_TRY(run_search(h, w, plan, w->d_queries, nq, k, w->d_keys, nullptr, nullptr, nullptr, w->stream));
+            CS_HIP(hipMemcpyAsync(w->h_keys, w->d_keys, on * sizeof(uint64_t), hipMemcpyDeviceToHost, w->stream));
             CS_HIP(hipStreamSynchronize(w->stream));
-            memcpy(out_cos, w->h_cos, on * sizeof(float));
-            memcpy(out_ids, w->h_ids, on * sizeof(uint32_t));
-            memcpy(out_counts, w->h_counts, nq * sizeof(uint32_t));
+            for (uint32_t q = 0; q < nq; ++q) {  // keys are best-first, 0 = empty slot
+                uint32_t c = 0;
+                for (uint32_t j = 0; j < k; ++j) {
+                    const uint64_t key = w->h_keys[(size_t)q * k + j];
+                    if (key) ++c;
+                    out_cos[(size_t)q * k + j] = key ? key_cos(key) : 0.0f;
+                    out_ids[(size_t)q * k + j] = key ? key_id(key) : 0xFFFFFFFFu;
+                }
+                out_counts[q] = c;
+            }
             return CS_OK;
         }();
     }
