@@ -177,6 +177,33 @@ def hbm_reference(device, nbytes=2 << 30, reps=10):
     return out
 
 
+def host_cpu_share(visible):
+    """Threads the CPU baseline may really use: the cgroup CPU quota of this container (a GPU box hands a
+    one-GPU job a share of its host cores) and the affinity mask, not the number of cores the host shows."""
+    import math
+
+    n = visible
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, math.ceil(int(txt[0]) / int(txt[1]))))
+            else:
+                quota = int(txt[0])
+                period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if quota > 0:
+                    n = min(n, max(1, math.ceil(quota / period)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return max(1, n)
+
+
 def cpu_baseline(oracle, sample_rows, dim, k, store_cls):
     """Time the oracle's tuned CPU port (and the literal scalar loop on a smaller slice) on
     a bounded sample of the same workload; also returns recall@k of the HIP path against
@@ -187,12 +214,12 @@ def cpu_baseline(oracle, sample_rows, dim, k, store_cls):
 
     corpus = oracle.synth_rows(SEED, 0, sample_rows, dim)
     q = synth_rows(SEED + 1, 0, 1, dim)[0]
-    threads = oracle.num_threads()
-    oracle.scan_topk(corpus[: min(sample_rows, 50_000)], q, k, mode="omp")  # warm threads
+    threads = host_cpu_share(oracle.num_threads())
+    oracle.scan_topk(corpus[: min(sample_rows, 50_000)], q, k, mode="omp", threads=threads)  # warm threads
     reps, t_total, res = 0, 0.0, None
     while t_total < 8.0 and reps < 64:
         t0 = time.perf_counter()
-        res = oracle.scan_topk(corpus, q, k, mode="omp")
+        res = oracle.scan_topk(corpus, q, k, mode="omp", threads=threads)
         t_total += time.perf_counter() - t0
         reps += 1
     omp_rate = sample_rows * reps / t_total
@@ -211,7 +238,8 @@ def cpu_baseline(oracle, sample_rows, dim, k, store_cls):
     return {
         "value": omp_rate, "unit": "chunks/s", "cores": threads, "kind": "port",
         "sample": f"{sample_rows} x {dim} fp32 rows of the same synthetic corpus, 1 query, top-{k}, "
-                  f"{reps} passes of oracle/scan_oracle.c cs_oracle_scan_topk_omp ({threads} threads)",
+                  f"{reps} passes of oracle/scan_oracle.c cs_oracle_scan_topk_omp ({threads} threads = this job's CPU "
+                  f"share; the host shows {oracle.num_threads()})",
         "literal_1thread_chunks_per_s": lit_rate,
         "literal_sample_rows": lit_rows,
     }, recall, max_err
