@@ -29,6 +29,8 @@ struct cs_embedder {
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;     // second half of a mini-batch runs here (see forward())
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipStream_t xstreams[2] = {nullptr, nullptr};  // CS_ENCODER_STREAMS=3|4: further slices of the mini-batch
+    hipEvent_t xjoin[2] = {nullptr, nullptr};
     int n_streams = 2;
     size_t cap_tokens = 0, cap_seqs = 0;
     int32_t* d_ids = nullptr;
@@ -180,14 +182,18 @@ int32_t forward(cs_embedder* h, uint32_t B, uint32_t L, int mode) {
     hipStream_t s = h->stream;
     CS_HIP(hipEventRecord(h->ev0, s));
     if (mode == CS_GEMM_SPLIT_F16) CS_HIP(hipMemsetAsync(h->d_flag, 0, sizeof(uint32_t), s));
-    if (h->n_streams >= 2 && B >= 2) {
-        const uint32_t b1 = B / 2;
+    if (h->n_streams >= 2 && B >= (uint32_t)h->n_streams) {
+        const uint32_t ns = (uint32_t)h->n_streams;
+        hipStream_t st[4] = {s, h->stream2, h->xstreams[0], h->xstreams[1]};
+        hipEvent_t jn[4] = {nullptr, h->ev_join, h->xjoin[0], h->xjoin[1]};
         CS_HIP(hipEventRecord(h->ev_fork, s));
-        CS_HIP(hipStreamWaitEvent(h->stream2, h->ev_fork, 0));
-        CS_TRY(forward_range(h, h->stream2, b1, B - b1, L, mode));
-        CS_HIP(hipEventRecord(h->ev_join, h->stream2));
-        CS_TRY(forward_range(h, s, 0, b1, L, mode));
-        CS_HIP(hipStreamWaitEvent(s, h->ev_join, 0));
+        for (uint32_t i = ns; i-- > 0;) {  // slice 0 last, on the caller-visible stream
+            const uint32_t lo = (uint32_t)((uint64_t)B * i / ns), hi = (uint32_t)((uint64_t)B * (i + 1) / ns);
+            if (i) CS_HIP(hipStreamWaitEvent(st[i], h->ev_fork, 0));
+            CS_TRY(forward_range(h, st[i], lo, hi - lo, L, mode));
+            if (i) CS_HIP(hipEventRecord(jn[i], st[i]));
+        }
+        for (uint32_t i = 1; i < ns; ++i) CS_HIP(hipStreamWaitEvent(s, jn[i], 0));
     } else {
         CS_TRY(forward_range(h, s, 0, B, L, mode));
     }
@@ -520,7 +526,16 @@ int32_t cs_embedder_create(const cs_bert_config* cfg, const float* params, uint6
         bool denorm_ok = false;  // the split format relies on exact f16-subnormal MFMA inputs
         if (s == CS_OK) s = sh_denorm_selftest(&denorm_ok, h->stream);
         if (s == CS_OK && !denorm_ok) { h->gemm_mode = CS_GEMM_F32; h->split_unavailable = true; }
-        if (const char* env = std::getenv("CS_ENCODER_STREAMS")) h->n_streams = std::atoi(env) >= 2 ? 2 : 1;
+        if (const char* env = std::getenv("CS_ENCODER_STREAMS")) {
+            const int v = std::atoi(env);
+            h->n_streams = v >= 4 ? 4 : (v >= 1 ? v : 1);
+        }
+        for (int i = 0; i + 2 < h->n_streams; ++i)
+            if (hipStreamCreateWithFlags(&h->xstreams[i], hipStreamNonBlocking) != hipSuccess ||
+                hipEventCreateWithFlags(&h->xjoin[i], hipEventDisableTiming) != hipSuccess) {
+                h->n_streams = 2;
+                break;
+            }
     }
     if (s == CS_OK && hipStreamSynchronize(h->stream) != hipSuccess) s = fail(CS_ERR_HIP, "parameter setup failed");
     if (s != CS_OK) return cleanup(s);
@@ -533,6 +548,10 @@ void cs_embedder_destroy(cs_embedder* h) {
     DeviceGuard g(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->stream2) (void)hipStreamSynchronize(h->stream2);
+    for (int i = 0; i < 2; ++i) {
+        if (h->xstreams[i]) { (void)hipStreamSynchronize(h->xstreams[i]); (void)hipStreamDestroy(h->xstreams[i]); }
+        if (h->xjoin[i]) (void)hipEventDestroy(h->xjoin[i]);
+    }
     free_workspace(h);
     if (h->d_params) (void)hipFree(h->d_params);
     if (h->d_wqkv) (void)hipFree(h->d_wqkv);
