@@ -4,6 +4,9 @@
 #include <cmath>
 #include <cstdio>
 
+#include <cstring>
+
+#include "../../codesearch_amd/host/codesearch_callers.hpp"
 #include "../../codesearch_amd/host/codesearch_gpu.hpp"
 
 #define REQUIRE(c)                                                          \
@@ -11,8 +14,92 @@
         if (!(c)) { std::printf("FAILED %s:%d: %s\n", __FILE__, __LINE__, #c); return 1; } \
     } while (0)
 
-int main() {
+// The reference's own known answers for the callers either side of the hot path (no GPU involved):
+// batch.rs:238-314 (stats, clean_docstring, prepare_text), rerank/mod.rs:273-337 (fusion), search/mod.rs:494-611.
+static int cpu_checks() {
     using namespace cs;
+    EmbeddingStats st;  // batch.rs:238-251
+    st.total_chunks = 100; st.embedded_chunks = 80; st.cached_chunks = 20; st.total_time_ms = 1000;
+    REQUIRE(st.cache_hit_rate() == 0.2 && st.success_rate() == 0.8 && st.chunks_per_second() == 80.0);
+    // batch.rs:253-274
+    REQUIRE(clean_docstring("/// This is a doc comment\n/// with multiple lines") == "This is a doc comment with multiple lines");
+    REQUIRE(clean_docstring("\"\"\"This is a Python docstring\"\"\"") == "\"\"This is a Python docstring\"\"");
+    REQUIRE(clean_docstring("/**\n * JSDoc comment\n * with multiple lines\n */") == "JSDoc comment with multiple lines");
+    REQUIRE(clean_docstring("\"This is a quoted docstring\"") == "This is a quoted docstring");
+    REQUIRE(clean_docstring("") == "" && clean_docstring("//! inner\r\n// plain") == "inner plain");
+    REQUIRE(clean_docstring("  \xc2\xa0/// nbsp-indented\xe3\x80\x80") == "nbsp-indented");  // Unicode trim
+    // batch.rs:276-314
+    Chunk c;
+    c.content = "fn test() { println!(\"test\"); }"; c.kind = "Function"; c.path = "test.rs";
+    c.context = {"File: test.rs", "Function: test"};
+    c.signature = "fn test()"; c.docstring = "/// Test function";
+    REQUIRE(prepare_text(c) == "Context: File: test.rs > Function: test\nSignature: fn test()\nName: test\n"
+                               "Documentation: Test function\nCode:\nfn test() { println!(\"test\"); }");
+    Chunk g2;
+    g2.content = "x"; g2.signature = "fn sort<T: Ord>(items: Vec<T>) -> Vec<T>";
+    REQUIRE(prepare_text(g2).find("Name: sort\n") != std::string::npos);
+    Chunk bare;
+    bare.content = "body";
+    REQUIRE(prepare_text(bare) == "Code:\nbody");
+    bare.signature = "lonely";
+    REQUIRE(prepare_text(bare).find("Name:") == std::string::npos);
+    // BatchEmbedder slices of 32 (batch.rs:94) over any embedder with embed_batch(vector<string>)
+    struct Fake {
+        std::vector<size_t> calls;
+        std::vector<std::vector<float>> embed_batch(const std::vector<std::string>& t) {
+            calls.push_back(t.size());
+            std::vector<std::vector<float>> o;
+            for (const auto& x : t) o.push_back({(float)x.size()});
+            return o;
+        }
+        std::vector<float> embed_one(const std::string& t) { return embed_batch({t})[0]; }
+        size_t dimensions() const { return 1; }
+    } fake;
+    std::vector<Chunk> chunks(70);
+    for (size_t i = 0; i < chunks.size(); ++i) chunks[i].content = "content " + std::to_string(i);
+    BatchEmbedder<Fake> be(fake);
+    auto ecs = be.embed_chunks(chunks);
+    REQUIRE((fake.calls == std::vector<size_t>{32, 32, 6}) && ecs.size() == 70);
+    REQUIRE(ecs[69].embedding[0] == (float)std::strlen("Code:\ncontent 69") && ecs[5].chunk.content == "content 5");
+
+    auto vres = [](uint32_t id, float score) { SearchResult r; r.id = id; r.score = score; r.distance = 1.0f - score; return r; };
+    // search/mod.rs:494-611
+    REQUIRE(retrieval_limit(25, true, false) == 25 && retrieval_limit(25, false, true) == 100);
+    REQUIRE(retrieval_limit(50, false, true) == 150 && retrieval_limit(25, false, false) == 200 && retrieval_limit(60, false, false) == 300);
+    auto merged = merge_variant_results({{vres(1, 0.9f), vres(2, 0.8f), vres(3, 0.7f)}, {vres(2, 0.95f), vres(4, 0.6f), vres(1, 0.85f)}}, 3);
+    REQUIRE(merged.size() == 3 && merged[0].id == 2 && merged[0].score == 0.95f && merged[1].id == 1 && merged[2].id == 3);
+    std::vector<SearchResult> hi;
+    for (uint32_t i = 0; i < 6; ++i) hi.push_back(vres(i, 0.9f));
+    REQUIRE(should_use_vector_only(hi, false) && !should_use_vector_only(hi, true) && !should_use_vector_only({}, false));
+    hi[4] = vres(9, 0.8f);  // distance 0.2 inside the top five
+    REQUIRE(!should_use_vector_only(hi, false));
+    // rerank/mod.rs:273-306
+    auto fused = rrf_fusion({vres(1, 0.9f), vres(2, 0.8f), vres(3, 0.7f)}, {{2, 10.0f}, {1, 8.0f}, {4, 6.0f}}, 20.0f);
+    REQUIRE(fused.size() == 4);
+    std::map<uint32_t, FusedResult> by;
+    for (const auto& f : fused) by[f.chunk_id] = f;
+    REQUIRE(by[1].vector_rank && by[1].fts_rank && by[2].vector_rank && by[2].fts_rank);
+    REQUIRE(!by[4].vector_rank && by[4].fts_rank);
+    REQUIRE((fused[0].chunk_id == 1 || fused[0].chunk_id == 2) && (fused[1].chunk_id == 1 || fused[1].chunk_id == 2));
+    for (size_t i = 0; i + 1 < fused.size(); ++i) REQUIRE(fused[i].rrf_score >= fused[i + 1].rrf_score);
+    // rerank/mod.rs:308-324 (f32 arithmetic)
+    auto one = rrf_fusion({vres(1, 0.9f)}, {{1, 10.0f}}, 20.0f);
+    REQUIRE(one.size() == 1 && one[0].rrf_score == 1.0f / 21.0f + 1.0f / 21.0f);
+    // rerank/mod.rs:326-336
+    auto vo = vector_only({vres(1, 0.9f), vres(2, 0.8f)});
+    REQUIRE(vo.size() == 2 && vo[0].chunk_id == 1 && vo[0].rrf_score == 0.9f && !vo[0].fts_score);
+    // three-way (rerank/mod.rs:139-241): exact rank 1 with k = 5 outweighs a rank-1 vector hit
+    auto tw = rrf_fusion_with_exact({vres(1, 0.9f), vres(2, 0.8f)}, {{2, 4.0f}, {3, 2.0f}}, {{3, 9.0f}});
+    REQUIRE(tw[0].chunk_id == 3 && std::fabs(tw[0].rrf_score - (1.0f / 6 + 1.0f / 22)) < 1e-6f);
+    REQUIRE(*tw[0].fts_score == 5.5f && *tw[0].fts_rank == 2);
+    std::printf("host callers ok\n");
+    return 0;
+}
+
+int main(int argc, char** argv) {
+    using namespace cs;
+    if (int rc = cpu_checks()) return rc;
+    if (argc > 1 && std::string(argv[1]) == "cpu") return 0;
     if (cs_device_count() < 1) { std::printf("no HIP device\n"); return 77; }
     VectorStore store("test.db", 4);
     REQUIRE(store.dimensions() == 4 && !store.is_indexed());

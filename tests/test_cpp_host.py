@@ -21,6 +21,15 @@ def test_cpp_host_mirror_compiles_and_links(gpu_lib):
     assert os.path.exists(EXE)
 
 
+def test_cpp_host_callers_reference_known_answers(gpu_lib):
+    """codesearch_callers.hpp (prepare_text, clean_docstring, BatchEmbedder, variant merge, RRF fusion)
+    against the reference's own unit-test cases; no GPU involved."""
+    build()
+    r = subprocess.run([EXE, "cpu"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "host callers ok" in r.stdout
+
+
 @pytest.mark.gpu
 def test_cpp_host_mirror_runs_reference_test():
     build()
