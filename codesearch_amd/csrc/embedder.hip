@@ -182,7 +182,8 @@ int32_t forward(cs_embedder* h, uint32_t B, uint32_t L, int mode) {
     hipStream_t s = h->stream;
     CS_HIP(hipEventRecord(h->ev0, s));
     if (mode == CS_GEMM_SPLIT_F16) CS_HIP(hipMemsetAsync(h->d_flag, 0, sizeof(uint32_t), s));
-    if (h->n_streams >= 2 && B >= (uint32_t)h->n_streams) {
+    // (a few short sequences are launch-bound: slicing them would only double the launches)
+    if (h->n_streams >= 2 && B >= (uint32_t)h->n_streams && (uint64_t)B * L >= 8192) {
         const uint32_t ns = (uint32_t)h->n_streams;
         hipStream_t st[4] = {s, h->stream2, h->xstreams[0], h->xstreams[1]};
         hipEvent_t jn[4] = {nullptr, h->ev_join, h->xjoin[0], h->xjoin[1]};

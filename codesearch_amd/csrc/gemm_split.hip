@@ -8,6 +8,7 @@
 // consecutive lanes.  Replaces the fp32 arithmetic ONNX Runtime does for
 // /root/reference/src/embed/embedder.rs:286-289 to within ~3 * 2^-22 per product.
 #include <cstdlib>
+#include <type_traits>
 
 #include "encoder.hpp"
 #include "split_f16.hpp"
@@ -188,6 +189,99 @@ gemm_sh3_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ W,
     SH_STAMP(3);
 }
 
+// ---- small M (query-side batches: a few short sequences) -------------------------------------------------
+// The tiled kernels above are throughput kernels: with a handful of 128-row tiles they leave 95 % of the
+// chip idle and walk K one exposed memory latency per stage (FFN-down: 48 stages), ~1 ms per forward of a
+// single short query.  Here a block owns ONE 16 x 16 output tile and its four waves split K between them
+// (wave w takes k-chunks w, w+4, ...): operands go global -> VGPR straight into the 16x16x32 MFMA fragment
+// layout (a row's 128-B line per 32 k is exactly four lanes' hi pieces + four lanes' lo pieces), every load
+// of a wave is in flight at once, and the four partial tiles meet in 4 KiB of LDS.  Weights are read once
+// per 16 rows of activations; grid = (N / 16) x ceil(M / 16) blocks.
+template <int EPI, int MT>
+__global__ void __launch_bounds__(256)
+gemm_sh_skinny_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ W,
+                      const float* __restrict__ bias, const float* resid, float* C,
+                      _Float16* __restrict__ Cs, uint32_t M, uint32_t N, uint32_t kchunks,
+                      uint32_t* __restrict__ flag) {
+    // MT row groups of 16 per block share the block's weight fragments (MT = 4 from 65 rows up)
+    __shared__ float red[4][MT][16][17];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, g = lane >> 4;
+    const uint32_t n0 = blockIdx.x * 16, m0 = blockIdx.y * 16 * MT;
+    const _Float16* ap[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+        const uint32_t r = m0 + 16 * t + l15;
+        ap[t] = A + (size_t)(r < M ? r : M - 1) * kchunks * 64 + 8 * g;  // rows past M re-read row M-1 (never stored)
+    }
+    const _Float16* wp = W + (size_t)(n0 + l15) * kchunks * 64 + 8 * g;
+    sh_f32x4v hh[MT], xx[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) { hh[t] = sh_f32x4v{0.f, 0.f, 0.f, 0.f}; xx[t] = sh_f32x4v{0.f, 0.f, 0.f, 0.f}; }
+    // groups of U of this wave's chunks: every 16-B load of a group in flight before its MFMAs.  K = 384 is
+    // three chunks per wave (one group of 4), K = 1536 twelve (one group of 12): one memory latency per GEMM.
+    const uint32_t mine = kchunks > (uint32_t)wave ? (kchunks - wave + 3) / 4 : 0;  // chunks wave, wave+4, ...
+    auto run_groups = [&](auto ucount) {
+        constexpr int U = decltype(ucount)::value;
+        for (uint32_t i0 = 0; i0 < mine; i0 += U) {
+            f16x8 ah[U][MT], al[U][MT], wh[U], wl[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint32_t i = i0 + u < mine ? i0 + u : mine - 1;  // past the end: reload the last one (unused)
+                const size_t off = (size_t)(wave + 4 * i) * 64;
+                wh[u] = *reinterpret_cast<const f16x8*>(wp + off);
+                wl[u] = *reinterpret_cast<const f16x8*>(wp + off + 32);
+#pragma unroll
+                for (int t = 0; t < MT; ++t) {
+                    ah[u][t] = *reinterpret_cast<const f16x8*>(ap[t] + off);
+                    al[u][t] = *reinterpret_cast<const f16x8*>(ap[t] + off + 32);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (i0 + u < mine) {  // wave-uniform
+#pragma unroll
+                    for (int t = 0; t < MT; ++t) {
+                        hh[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[u][t], wh[u], hh[t], 0, 0, 0);
+                        xx[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[u][t], wl[u], xx[t], 0, 0, 0);
+                        xx[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[u][t], wh[u], xx[t], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    };
+    if (MT == 1 && kchunks > 16) run_groups(std::integral_constant<int, 12>{});
+    else run_groups(std::integral_constant<int, (MT == 1 ? 4 : 2)>{});
+    // C/D layout of the 16x16 MFMA: n = lane & 15, m = 4 (lane >> 4) + r
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[wave][t][4 * g + r][l15] = fmaf(xx[t][r], kShLoInv, hh[t][r]);
+    __syncthreads();
+    const int m = tid >> 4, n = tid & 15;
+    const float bn = bias[n0 + n];
+    bool ovf = false;
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+        float v = (red[0][t][m][n] + red[1][t][m][n]) + (red[2][t][m][n] + red[3][t][m][n]) + bn;
+        const uint32_t row = m0 + 16 * t + m;
+        if (row >= M) break;
+        if (EPI == SH_OUT_F32 || EPI == SH_OUT_F32_RESID) {
+            if (EPI == SH_OUT_F32_RESID) v += resid[(size_t)row * N + n0 + n];
+            C[(size_t)row * N + n0 + n] = v;
+        } else {
+            if (EPI == SH_OUT_SPLIT_GELU) v = sh_gelu_erf(v);
+            _Float16 hi, lo;
+            ovf |= sh_split(v, hi, lo);
+            _Float16* dst = Cs + ((size_t)row * (N / 32) + ((n0 + n) >> 5)) * 64 + ((n0 + n) & 31);
+            dst[0] = hi;
+            dst[32] = lo;
+        }
+    }
+    if (ovf && flag) atomicOr(flag, 1u);
+}
+
 // rows x K f32 -> split layout; one thread per 8 consecutive k.  With row_norm, row r is divided
 // by row_norm[r] first (a zero norm gives a zero row): unit rows for the scan's filter operand.
 __global__ void __launch_bounds__(256)
@@ -283,6 +377,25 @@ int32_t launch_gemm_split(int epi, const _Float16* A, const _Float16* W, const f
         attr_set = true;
     }
     const uint32_t kc = K / 32;
+    static int skinny_max_m = -1;
+    if (skinny_max_m < 0) {
+        const char* e = std::getenv("CS_GEMM_SKINNY_MAX_M");  // 0 disables the small-M kernel
+        skinny_max_m = e ? std::atoi(e) : 1024;
+    }
+    if ((int64_t)M <= skinny_max_m) {
+#define CS_SKINNY(MT_)                                                                                                     \
+    do {                                                                                                                   \
+        const dim3 gs(N / 16, (M + 16 * MT_ - 1) / (16 * MT_));                                                            \
+        if (epi == SH_OUT_F32) hipLaunchKernelGGL((gemm_sh_skinny_kernel<SH_OUT_F32, MT_>), gs, dim3(256), 0, s, A, W, bias, resid, C, Cs, M, N, kc, d_flag); \
+        else if (epi == SH_OUT_F32_RESID) hipLaunchKernelGGL((gemm_sh_skinny_kernel<SH_OUT_F32_RESID, MT_>), gs, dim3(256), 0, s, A, W, bias, resid, C, Cs, M, N, kc, d_flag); \
+        else if (epi == SH_OUT_SPLIT) hipLaunchKernelGGL((gemm_sh_skinny_kernel<SH_OUT_SPLIT, MT_>), gs, dim3(256), 0, s, A, W, bias, resid, C, Cs, M, N, kc, d_flag); \
+        else hipLaunchKernelGGL((gemm_sh_skinny_kernel<SH_OUT_SPLIT_GELU, MT_>), gs, dim3(256), 0, s, A, W, bias, resid, C, Cs, M, N, kc, d_flag); \
+    } while (0)
+        CS_SKINNY(1);  // (4 row groups per block sharing the weight fragments measured slower: fewer, longer blocks)
+#undef CS_SKINNY
+        CS_HIP(hipGetLastError());
+        return CS_OK;
+    }
     static int tile = -1;
     if (tile < 0) {
         // 16 (default): 128x128 tiles on v_mfma_f32_16x16x32_f16, 2 blocks/CU; 128: the same tiles on the 32x32x16
