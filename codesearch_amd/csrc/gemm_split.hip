@@ -197,43 +197,52 @@ gemm_sh3_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ W,
 // layout (a row's 128-B line per 32 k is exactly four lanes' hi pieces + four lanes' lo pieces), every load
 // of a wave is in flight at once, and the four partial tiles meet in 4 KiB of LDS.  Weights are read once
 // per 16 rows of activations; grid = (N / 16) x ceil(M / 16) blocks.
-template <int EPI, int MT>
+template <int EPI, int RT, int CT>
 __global__ void __launch_bounds__(256)
 gemm_sh_skinny_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ W,
                       const float* __restrict__ bias, const float* resid, float* C,
                       _Float16* __restrict__ Cs, uint32_t M, uint32_t N, uint32_t kchunks,
                       uint32_t* __restrict__ flag) {
-    // MT row groups of 16 per block share the block's weight fragments (MT = 4 from 65 rows up)
-    __shared__ float red[4][MT][16][17];
+    // a block owns RT x CT output tiles of 16 x 16 (1 x 1 up to 64 rows; 2 x 2 above: half the operand
+    // bytes per flop); each of its four waves computes all of them over a quarter of K
+    __shared__ float red[4][RT][CT][16][17];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l15 = lane & 15, g = lane >> 4;
-    const uint32_t n0 = blockIdx.x * 16, m0 = blockIdx.y * 16 * MT;
-    const _Float16* ap[MT];
+    const uint32_t n0 = blockIdx.x * 16 * CT, m0 = blockIdx.y * 16 * RT;
+    const _Float16* ap[RT];
+    const _Float16* wp[CT];
 #pragma unroll
-    for (int t = 0; t < MT; ++t) {
+    for (int t = 0; t < RT; ++t) {
         const uint32_t r = m0 + 16 * t + l15;
         ap[t] = A + (size_t)(r < M ? r : M - 1) * kchunks * 64 + 8 * g;  // rows past M re-read row M-1 (never stored)
     }
-    const _Float16* wp = W + (size_t)(n0 + l15) * kchunks * 64 + 8 * g;
-    sh_f32x4v hh[MT], xx[MT];
 #pragma unroll
-    for (int t = 0; t < MT; ++t) { hh[t] = sh_f32x4v{0.f, 0.f, 0.f, 0.f}; xx[t] = sh_f32x4v{0.f, 0.f, 0.f, 0.f}; }
-    // groups of U of this wave's chunks: every 16-B load of a group in flight before its MFMAs.  K = 384 is
-    // three chunks per wave (one group of 4), K = 1536 twelve (one group of 12): one memory latency per GEMM.
+    for (int t = 0; t < CT; ++t) wp[t] = W + (size_t)(n0 + 16 * t + l15) * kchunks * 64 + 8 * g;
+    sh_f32x4v hh[RT][CT], xx[RT][CT];
+#pragma unroll
+    for (int i = 0; i < RT; ++i)
+#pragma unroll
+        for (int j = 0; j < CT; ++j) { hh[i][j] = sh_f32x4v{0.f, 0.f, 0.f, 0.f}; xx[i][j] = sh_f32x4v{0.f, 0.f, 0.f, 0.f}; }
+    // groups of U of this wave's chunks: every 16-B load of a group in flight before its MFMAs.  With one
+    // tile per block K = 384 is one group of 3 chunks per wave and K = 1536 one group of 12: one memory
+    // latency per GEMM.
     const uint32_t mine = kchunks > (uint32_t)wave ? (kchunks - wave + 3) / 4 : 0;  // chunks wave, wave+4, ...
     auto run_groups = [&](auto ucount) {
         constexpr int U = decltype(ucount)::value;
         for (uint32_t i0 = 0; i0 < mine; i0 += U) {
-            f16x8 ah[U][MT], al[U][MT], wh[U], wl[U];
+            f16x8 ah[U][RT], al[U][RT], wh[U][CT], wl[U][CT];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const uint32_t i = i0 + u < mine ? i0 + u : mine - 1;  // past the end: reload the last one (unused)
                 const size_t off = (size_t)(wave + 4 * i) * 64;
-                wh[u] = *reinterpret_cast<const f16x8*>(wp + off);
-                wl[u] = *reinterpret_cast<const f16x8*>(wp + off + 32);
 #pragma unroll
-                for (int t = 0; t < MT; ++t) {
+                for (int t = 0; t < CT; ++t) {
+                    wh[u][t] = *reinterpret_cast<const f16x8*>(wp[t] + off);
+                    wl[u][t] = *reinterpret_cast<const f16x8*>(wp[t] + off + 32);
+                }
+#pragma unroll
+                for (int t = 0; t < RT; ++t) {
                     ah[u][t] = *reinterpret_cast<const f16x8*>(ap[t] + off);
                     al[u][t] = *reinterpret_cast<const f16x8*>(ap[t] + off + 32);
                 }
@@ -242,41 +251,48 @@ gemm_sh_skinny_kernel(const _Float16* __restrict__ A, const _Float16* __restrict
             for (int u = 0; u < U; ++u) {
                 if (i0 + u < mine) {  // wave-uniform
 #pragma unroll
-                    for (int t = 0; t < MT; ++t) {
-                        hh[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[u][t], wh[u], hh[t], 0, 0, 0);
-                        xx[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[u][t], wl[u], xx[t], 0, 0, 0);
-                        xx[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[u][t], wh[u], xx[t], 0, 0, 0);
-                    }
+                    for (int i = 0; i < RT; ++i)
+#pragma unroll
+                        for (int j = 0; j < CT; ++j) {
+                            hh[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[u][i], wh[u][j], hh[i][j], 0, 0, 0);
+                            xx[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[u][i], wl[u][j], xx[i][j], 0, 0, 0);
+                            xx[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[u][i], wh[u][j], xx[i][j], 0, 0, 0);
+                        }
                 }
             }
         }
     };
-    if (MT == 1 && kchunks > 16) run_groups(std::integral_constant<int, 12>{});
-    else run_groups(std::integral_constant<int, (MT == 1 ? 4 : 2)>{});
+    if (RT * CT == 1 && kchunks > 16) run_groups(std::integral_constant<int, 12>{});
+    else run_groups(std::integral_constant<int, (RT * CT == 1 ? 4 : 3)>{});
     // C/D layout of the 16x16 MFMA: n = lane & 15, m = 4 (lane >> 4) + r
 #pragma unroll
-    for (int t = 0; t < MT; ++t)
+    for (int i = 0; i < RT; ++i)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) red[wave][t][4 * g + r][l15] = fmaf(xx[t][r], kShLoInv, hh[t][r]);
+        for (int j = 0; j < CT; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[wave][i][j][4 * g + r][l15] = fmaf(xx[i][j][r], kShLoInv, hh[i][j][r]);
     __syncthreads();
     const int m = tid >> 4, n = tid & 15;
-    const float bn = bias[n0 + n];
     bool ovf = false;
 #pragma unroll
-    for (int t = 0; t < MT; ++t) {
-        float v = (red[0][t][m][n] + red[1][t][m][n]) + (red[2][t][m][n] + red[3][t][m][n]) + bn;
-        const uint32_t row = m0 + 16 * t + m;
+    for (int i = 0; i < RT; ++i) {
+        const uint32_t row = m0 + 16 * i + m;
         if (row >= M) break;
-        if (EPI == SH_OUT_F32 || EPI == SH_OUT_F32_RESID) {
-            if (EPI == SH_OUT_F32_RESID) v += resid[(size_t)row * N + n0 + n];
-            C[(size_t)row * N + n0 + n] = v;
-        } else {
-            if (EPI == SH_OUT_SPLIT_GELU) v = sh_gelu_erf(v);
-            _Float16 hi, lo;
-            ovf |= sh_split(v, hi, lo);
-            _Float16* dst = Cs + ((size_t)row * (N / 32) + ((n0 + n) >> 5)) * 64 + ((n0 + n) & 31);
-            dst[0] = hi;
-            dst[32] = lo;
+#pragma unroll
+        for (int j = 0; j < CT; ++j) {
+            const uint32_t col = n0 + 16 * j + n;
+            float v = (red[0][i][j][m][n] + red[1][i][j][m][n]) + (red[2][i][j][m][n] + red[3][i][j][m][n]) + bias[col];
+            if (EPI == SH_OUT_F32 || EPI == SH_OUT_F32_RESID) {
+                if (EPI == SH_OUT_F32_RESID) v += resid[(size_t)row * N + col];
+                C[(size_t)row * N + col] = v;
+            } else {
+                if (EPI == SH_OUT_SPLIT_GELU) v = sh_gelu_erf(v);
+                _Float16 hi, lo;
+                ovf |= sh_split(v, hi, lo);
+                _Float16* dst = Cs + ((size_t)row * (N / 32) + (col >> 5)) * 64 + (col & 31);
+                dst[0] = hi;
+                dst[32] = lo;
+            }
         }
     }
     if (ovf && flag) atomicOr(flag, 1u);
@@ -380,18 +396,27 @@ int32_t launch_gemm_split(int epi, const _Float16* A, const _Float16* W, const f
     static int skinny_max_m = -1;
     if (skinny_max_m < 0) {
         const char* e = std::getenv("CS_GEMM_SKINNY_MAX_M");  // 0 disables the small-M kernel
-        skinny_max_m = e ? std::atoi(e) : 1024;
+        skinny_max_m = e ? std::atoi(e) : 1100;
     }
     if ((int64_t)M <= skinny_max_m) {
-#define CS_SKINNY(MT_)                                                                                                     \
+#define CS_SKINNY(RT_, CT_)                                                                                                \
     do {                                                                                                                   \
-        const dim3 gs(N / 16, (M + 16 * MT_ - 1) / (16 * MT_));                                                            \
-        if (epi == SH_OUT_F32) hipLaunchKernelGGL((gemm_sh_skinny_kernel<SH_OUT_F32, MT_>), gs, dim3(256), 0, s, A, W, bias, resid, C, Cs, M, N, kc, d_flag); \
-        else if (epi == SH_OUT_F32_RESID) hipLaunchKernelGGL((gemm_sh_skinny_kernel<SH_OUT_F32_RESID, MT_>), gs, dim3(256), 0, s, A, W, bias, resid, C, Cs, M, N, kc, d_flag); \
-        else if (epi == SH_OUT_SPLIT) hipLaunchKernelGGL((gemm_sh_skinny_kernel<SH_OUT_SPLIT, MT_>), gs, dim3(256), 0, s, A, W, bias, resid, C, Cs, M, N, kc, d_flag); \
-        else hipLaunchKernelGGL((gemm_sh_skinny_kernel<SH_OUT_SPLIT_GELU, MT_>), gs, dim3(256), 0, s, A, W, bias, resid, C, Cs, M, N, kc, d_flag); \
+        const dim3 gs(N / (16 * CT_), (M + 16 * RT_ - 1) / (16 * RT_));                                                    \
+        if (epi == SH_OUT_F32) hipLaunchKernelGGL((gemm_sh_skinny_kernel<SH_OUT_F32, RT_, CT_>), gs, dim3(256), 0, s, A, W, bias, resid, C, Cs, M, N, kc, d_flag); \
+        else if (epi == SH_OUT_F32_RESID) hipLaunchKernelGGL((gemm_sh_skinny_kernel<SH_OUT_F32_RESID, RT_, CT_>), gs, dim3(256), 0, s, A, W, bias, resid, C, Cs, M, N, kc, d_flag); \
+        else if (epi == SH_OUT_SPLIT) hipLaunchKernelGGL((gemm_sh_skinny_kernel<SH_OUT_SPLIT, RT_, CT_>), gs, dim3(256), 0, s, A, W, bias, resid, C, Cs, M, N, kc, d_flag); \
+        else hipLaunchKernelGGL((gemm_sh_skinny_kernel<SH_OUT_SPLIT_GELU, RT_, CT_>), gs, dim3(256), 0, s, A, W, bias, resid, C, Cs, M, N, kc, d_flag); \
     } while (0)
-        CS_SKINNY(1);  // (4 row groups per block sharing the weight fragments measured slower: fewer, longer blocks)
+        // measured per forward (device us), tiled / 1x1 / 2x2 tiles per block: 144 rows 1096 / 520 / 559, 256 rows
+        // 1152 / 748 / 660, 512 rows 1160 / 1096 / 711, 1024 rows 1209 / 1883 / 1072, 2048 rows 1248 / 3450 / 1601
+        // (4 x 4 tiles per block: 1017 at 512 rows, 1297 at 1024: never the fastest)
+        static int wide_from = -1;
+        if (wide_from < 0) {
+            const char* e = std::getenv("CS_GEMM_SKINNY_WIDE_M");  // rows from which a block owns 2 x 2 tiles
+            wide_from = e ? std::atoi(e) : 200;
+        }
+        if ((int64_t)M < wide_from) CS_SKINNY(1, 1);
+        else CS_SKINNY(2, 2);
 #undef CS_SKINNY
         CS_HIP(hipGetLastError());
         return CS_OK;
