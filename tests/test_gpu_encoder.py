@@ -308,3 +308,18 @@ def test_embedder_from_hf_snapshot_directory(FE, oracle, tmp_path):
     exp = oracle.bert_forward(cfg, flat, ids, mask)["pooled"]
     np.testing.assert_allclose(got, exp, atol=TOL_ORACLE)
     emb.close()
+
+
+def test_multi_minibatch_id_calls_group_by_length(FE, oracle):
+    """cs_embedder_embed_ids over several mini-batches: rows are grouped by mask length inside a window and
+    each mini-batch is cut to its longest member; row i of the result is still sequence i, equal (to f32
+    rounding) to the single-mini-batch result and to the oracle; masks with holes keep their columns."""
+    cfg = BertConfig(vocab_size=512, layers=2, pooling=POOL_MEAN)
+    emb = FE(cfg, seed=31)
+    ids, mask = synth_token_batch(cfg, 77, 21, 48, True)  # ragged prefix masks
+    mask[3, 5] = 0                                        # a hole: the row's length stays its last set bit
+    one = emb.embed_ids(ids, mask, batch_size=32)         # one mini-batch, as given
+    many = emb.embed_ids(ids, mask, batch_size=4)         # six mini-batches, grouped by length
+    assert np.abs(one - many).max() <= 1e-6
+    ref = oracle.bert_forward(cfg, synth_params(cfg, 31), ids, mask)["pooled"]
+    np.testing.assert_allclose(many, ref, atol=TOL_ORACLE)
