@@ -300,3 +300,19 @@ def smoke(oracle) -> None:
     assert err < 1e-4, err
     emb.close()
     print(f"smoke ok: encoder parity on cuda:0, max |gpu - oracle| = {err:.2e}")
+    # the text entry point: C++ WordPiece -> cs_embedder_embed_texts, against tokenizer + encoder oracle
+    from .pipeline import synth_code_texts, synth_vocab
+    from .tokenizer import WordPieceTokenizer
+
+    vocab = synth_vocab(512)
+    tok = WordPieceTokenizer(vocab, max_length=64)
+    cfg = BertConfig(vocab_size=512, layers=2, max_position=64, pooling=POOL_MEAN)
+    emb = FastEmbedder(ModelType.BGESmallENV15, config=cfg, seed=102, device=0, tokenizer=tok)
+    texts = synth_code_texts(vocab, 5, 7, mean_words=12) + ["fn main() { [SEP] }", ""]
+    got = np.stack(emb.embed_batch(texts))
+    ids, mask = tok.encode_batch(texts)
+    exp = oracle.bert_forward(cfg, oracle.bert_synth_params(cfg, 102), ids, mask)["pooled"]
+    err = float(np.abs(got - exp).max())
+    assert err < 1e-4, err
+    emb.close()
+    print(f"smoke ok: text path (tokenizer + encoder) on cuda:0, max |gpu - oracle| = {err:.2e}")
