@@ -104,7 +104,8 @@ unit_f16_rows_kernel(const float* __restrict__ src, const float* __restrict__ ro
 // consecutive k of one f16 plane, so a stage is four MFMA k-steps into ONE accumulator set.
 __device__ __forceinline__ void uf_mainloop(const _Float16* __restrict__ A, uint32_t M, uint32_t m0,
                                             const _Float16* __restrict__ W, uint32_t N, uint32_t n0,
-                                            uint32_t kchunks, char* lds, sh_f32x16 (&acc)[2][2], uint32_t kc_rot) {
+                                            uint32_t kchunks, char* lds, sh_f32x16 (&acc)[2][2], uint32_t kc_rot,
+                                            bool nt_corpus) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 1, wc = wave & 1;
@@ -125,7 +126,8 @@ __device__ __forceinline__ void uf_mainloop(const _Float16* __restrict__ A, uint
         char* dst = buf + wave * 32 * 128;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            sh_glds16(asrc[i] + (size_t)kc * 128 * 64, dst + i * 1024);
+            if (nt_corpus) sh_glds16_nt(asrc[i] + (size_t)kc * 128 * 64, dst + i * 1024);
+            else sh_glds16(asrc[i] + (size_t)kc * 128 * 64, dst + i * 1024);
             sh_glds16(wsrc[i] + (size_t)kc * 64, dst + SH_TILE_BYTES + i * 1024);
         }
     };
@@ -180,7 +182,7 @@ score_filter_kernel(const _Float16* __restrict__ corpus_h, uint64_t row_lo, uint
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
     uf_mainloop(corpus_h + uf_tiled_off(row_lo, 0, kchunks), M, m0, queries_h, nq, n0, kchunks, lds, acc,
-                sh_kc_rot(nt, ntiles, kchunks));
+                sh_kc_rot(nt, ntiles, kchunks), /*nt_corpus=*/ntiles == 1);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1, l31 = lane & 31, h = lane >> 5;
@@ -446,6 +448,8 @@ score_filter256p_kernel(const _Float16* __restrict__ corpus_h, uint64_t row_lo, 
         __builtin_amdgcn_sched_barrier(0);                         \
     } while (0)
 
+    // one query tile: a corpus tile is read by exactly one block, once — stream it past the caches
+    const bool nt_corpus = ntiles == 1;
     uint32_t mt, nt, mtn = 0, ntn = 0;
     uint32_t slot = next_live(blockIdx.x, mt, nt);
     if (slot >= total_slots) return;
@@ -457,7 +461,8 @@ score_filter256p_kernel(const _Float16* __restrict__ corpus_h, uint64_t row_lo, 
         char* dst = lds + wave * 32 * 128;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            sh_glds16(a_cur[i] + (size_t)kr * 128 * 64, dst + i * 1024);
+            if (nt_corpus) sh_glds16_nt(a_cur[i] + (size_t)kr * 128 * 64, dst + i * 1024);
+            else sh_glds16(a_cur[i] + (size_t)kr * 128 * 64, dst + i * 1024);
             sh_glds16(w_cur[i] + (size_t)kr * 64, dst + UF2_TILE + i * 1024);
         }
         kr = kr + 1 == kchunks ? 0 : kr + 1;
@@ -491,8 +496,13 @@ score_filter256p_kernel(const _Float16* __restrict__ corpus_h, uint64_t row_lo, 
                 __builtin_amdgcn_sched_barrier(0);
                 if (issue) {
                     const int q = q0 + j;
-                    if (q < 4) sh_glds16((from_next ? a_nxt[q] : a_cur[q]) + (size_t)kcn * 128 * 64, dst + q * 1024);
-                    else sh_glds16((from_next ? w_nxt[q - 4] : w_cur[q - 4]) + (size_t)kcn * 64, dst + UF2_TILE + (q - 4) * 1024);
+                    if (q < 4) {
+                        const _Float16* src = (from_next ? a_nxt[q] : a_cur[q]) + (size_t)kcn * 128 * 64;
+                        if (nt_corpus) sh_glds16_nt(src, dst + q * 1024);
+                        else sh_glds16(src, dst + q * 1024);
+                    } else {
+                        sh_glds16((from_next ? w_nxt[q - 4] : w_cur[q - 4]) + (size_t)kcn * 64, dst + UF2_TILE + (q - 4) * 1024);
+                    }
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -594,8 +604,11 @@ __global__ void __launch_bounds__(256)
 score_filter_rw_kernel(const _Float16* __restrict__ corpus_h, uint64_t row_lo, uint64_t row_hi,
                        const _Float16* __restrict__ queries_h, uint32_t nq, const float* __restrict__ tau,
                        const uint32_t* __restrict__ dead, uint32_t* __restrict__ cand,
-                       uint32_t* __restrict__ cnt, uint32_t cap, uint32_t qtiles) {
+                       uint32_t* __restrict__ cnt, uint32_t cap, uint32_t qtiles, uint32_t nt_stream) {
     using G = RwGeom<NQT>;
+    // one query tile: every corpus byte is read by exactly one CU, once — stream it past the caches (with
+    // several query tiles the blocks of an XCD share tiles through its L2: default policy)
+    const bool NT = nt_stream != 0 && qtiles == 1;
     constexpr int KC = 6, R = G::R;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     char* Wl = lds;                 // [KC][QROWS][128 B], slots swizzled as in uf_mainloop
@@ -651,7 +664,8 @@ score_filter_rw_kernel(const _Float16* __restrict__ corpus_h, uint64_t row_lo, u
             const int row = i * 8 + (lane >> 3);
             const int pc = (lane & 7) ^ ((row >> 1) & 7);
             // 8 consecutive rows of chunk c = 1 KiB of consecutive lines (rows past M: padded tile, masked at append)
-            sh_glds16(base + ((tile * 6 + c) * 128 + wave * 32 + row) * 64 + pc * 8, myring + slot * 16384 + i * 1024);
+            if (NT) sh_glds16_nt(base + ((tile * 6 + c) * 128 + wave * 32 + row) * 64 + pc * 8, myring + slot * 16384 + i * 1024);
+            else sh_glds16(base + ((tile * 6 + c) * 128 + wave * 32 + row) * 64 + pc * 8, myring + slot * 16384 + i * 1024);
         }
     };
 
@@ -929,9 +943,13 @@ static int32_t scan_split_impl(const BatchedState& st, const SplitQueryWs& qw, c
                 if (slots > (uint64_t)cus / 8) slots = (uint64_t)cus / 8;
                 if (slots < qtiles) slots = qtiles;
                 const uint32_t blocks = (uint32_t)slots * 8;
+                static const uint32_t nt_stream = [] {
+                    const char* e = std::getenv("CS_FILTER_NT");  // "0": default cache policy on the corpus stream
+                    return (uint32_t)!(e && e[0] == '0');
+                }();
 #define CS_RW_LAUNCH(NQT_)                                                                                   \
     hipLaunchKernelGGL(score_filter_rw_kernel<NQT_>, dim3(blocks), dim3(256), RwGeom<NQT_>::LDS, stream, d_split, lo, \
-                       hi, qw.d_qsplit, nq, st.d_tau, d_dead, cand, st.d_cnt, cap, qtiles)
+                       hi, qw.d_qsplit, nq, st.d_tau, d_dead, cand, st.d_cnt, cap, qtiles, nt_stream)
                 if (per == 32) CS_RW_LAUNCH(1);
                 else if (per == 64) CS_RW_LAUNCH(2);
                 else CS_RW_LAUNCH(4);

@@ -75,6 +75,12 @@ __device__ __forceinline__ void sh_glds16(const void* gsrc, void* lds_dst) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
                                      (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
 }
+// The same with the non-temporal cache policy (aux = 2): for bytes ONE CU reads once (a streamed corpus);
+// never for operands other CUs re-read from L2 (MI355X_MICROARCH.md, price list row nt-weights).
+__device__ __forceinline__ void sh_glds16_nt(const void* gsrc, void* lds_dst) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 2);
+}
 
 // A: split rows [m0, m0+128) of a [M][kc][64] matrix (rows >= M re-read row M-1: they only feed
 // outputs that are never stored); W likewise with N rows.  acc must be zero-initialised by the
