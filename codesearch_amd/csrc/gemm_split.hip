@@ -51,11 +51,12 @@ __device__ __forceinline__ float sh_gelu_erf(float v) {
     return 0.5f * v * (1.0f + sh_erf_fast(v * 0.70710678118654752440f));
 }
 
-// The split-form outputs (300-400 MB per launch) and the residual read are non-temporal: each byte is
-// touched once by this block, while the XCD's L2 is holding the weights and the A tiles its sibling n-tile
-// blocks are about to read (all accesses non-temporal, kernel alone: QKV -6.6 %, out-proj -10.6 %, FFN-up
-// -10.4 %, FFN-down -0.7 %; whole encoder 12.97 -> 12.60 ms on one box).  The same policy on LayerNorm's and
-// attention's accesses costs +10 %: their 100 MB tensors are served from the Infinity Cache otherwise.
+// The split-form outputs (300-400 MB per launch) are stored non-temporal: each byte is touched once by this
+// block, while the XCD's L2 is holding the weights and the A tiles its sibling n-tile blocks are about to
+// read (QKV 193 -> 181 us, FFN-up 284 -> 270 us in the encoder).  The 100 MB f32 tensors keep the default
+// policy on both sides: they are served from the Infinity Cache (a non-temporal residual load made the
+// LayerNorm that follows 8.5 us slower for 2 us gained here; the policy on LayerNorm's and attention's own
+// accesses cost the encoder +10 %).
 template <int EPI, bool FULL, int WM>
 __device__ __forceinline__ void gemm_sh_epilogue(const float* ctile, const float* __restrict__ bias,
                                                  const float* resid, float* C, _Float16* __restrict__ Cs,
@@ -99,7 +100,7 @@ __device__ __forceinline__ void gemm_sh_epilogue(const float* ctile, const float
 #pragma unroll
                 for (int it = 0; it < 8; ++it) {
                     const uint32_t row = m0 + (tid >> 5) + 4 * WM * (half * 8 + it);
-                    rs[it] = __builtin_nontemporal_load(reinterpret_cast<const sh_f32x4*>(resid + (size_t)((FULL || row < M) ? row : M - 1) * N + n0 + c4 * 4));
+                    rs[it] = *reinterpret_cast<const sh_f32x4*>(resid + (size_t)((FULL || row < M) ? row : M - 1) * N + n0 + c4 * 4);
                 }
             }
 #pragma unroll
