@@ -182,8 +182,14 @@ int32_t forward(cs_embedder* h, uint32_t B, uint32_t L, int mode) {
     hipStream_t s = h->stream;
     CS_HIP(hipEventRecord(h->ev0, s));
     if (mode == CS_GEMM_SPLIT_F16) CS_HIP(hipMemsetAsync(h->d_flag, 0, sizeof(uint32_t), s));
-    // (a few short sequences are launch-bound: slicing them would only double the launches)
-    if (h->n_streams >= 2 && B >= (uint32_t)h->n_streams && (uint64_t)B * L >= 8192) {
+    // Slicing pays from ~20,000 tokens (device us per forward, one stream / two: 16,384 tokens 3505 / 3542,
+    // 24,576 5267 / 4916, 32,768 6517 / 6275, 49,152 9568 / 9437); below that it only multiplies launches
+    // of kernels that already leave the chip part-empty.
+    static const uint64_t stream_min_tokens = [] {
+        const char* e = std::getenv("CS_ENCODER_STREAM_MIN_TOKENS");
+        return e ? (uint64_t)std::atoll(e) : (uint64_t)20000;
+    }();
+    if (h->n_streams >= 2 && B >= (uint32_t)h->n_streams && (uint64_t)B * L >= stream_min_tokens) {
         const uint32_t ns = (uint32_t)h->n_streams;
         hipStream_t st[4] = {s, h->stream2, h->xstreams[0], h->xstreams[1]};
         hipEvent_t jn[4] = {nullptr, h->ev_join, h->xjoin[0], h->xjoin[1]};
