@@ -134,6 +134,11 @@ int32_t forward_range(cs_embedder* h, hipStream_t s, uint32_t b0, uint32_t nb, u
     _Float16* ctxs = reinterpret_cast<_Float16*>(ctx);
     _Float16* mids = reinterpret_cast<_Float16*>(mid);
     const SplitLayer sl = split_layer(c);
+    static const uint32_t split_k_min = [] { const char* e = std::getenv("CS_GEMM_SPLITK_MIN_M"); return e ? (uint32_t)std::atoi(e) : 1100u; }();
+    static const uint32_t split_k_max = [] { const char* e = std::getenv("CS_GEMM_SPLITK_MAX_M"); return e ? (uint32_t)std::atoi(e) : 6144u; }();
+    // device us per forward, fused / FFN-down in 3 K slices / out-proj too: 1,280 rows 1320 / 1020 / 971, 2,048
+    // 1331 / 1052 / 1021, 4,096 1538 / 1311 / 1328, 6,144 1841 / 1619 / 1654, 8,192 2210 / 2264 / -
+    static const uint32_t split_k_ao_max = [] { const char* e = std::getenv("CS_GEMM_SPLITK_AO_MAX_M"); return e ? (uint32_t)std::atoi(e) : 2560u; }();
     CS_TRY(launch_row_kernel(0, a, H, s));  // E1
     for (uint32_t l = 0; l < c.layers; ++l) {
         cs_bert_layer_offsets lo;
@@ -150,13 +155,28 @@ int32_t forward_range(cs_embedder* h, hipStream_t s, uint32_t b0, uint32_t nb, u
                 CS_TRY(launch_gemm_split(SH_OUT_SPLIT, xs, ws + sl.qkv, bqkv, nullptr, nullptr, qkvs, T, 3 * H, H, h->d_flag, s));  // E2
                 CS_TRY(launch_attention_sh2(qkvs, mask, ctxs, h->d_flag, nb, L, H, c.heads, s));                                 // E3
             }
-            CS_TRY(launch_gemm_split(SH_OUT_F32_RESID, ctxs, ws + sl.ao, P + lo.ao_b, x, x, nullptr, T, H, H, h->d_flag, s));  // E4
             a.g = P + lo.ao_ln_g; a.b = P + lo.ao_ln_b;
-            CS_TRY(launch_row_kernel(1, a, H, s));
+            if (T > split_k_min && T <= split_k_max && T <= split_k_ao_max) {
+                CS_TRY(launch_gemm_split_partial(ctxs, ws + sl.ao, qkv, T, H, H, 3, s));  // E4, K slices as for E6 below
+                a.parts = qkv; a.nparts = 3; a.bias = P + lo.ao_b;
+                CS_TRY(launch_row_kernel(3, a, H, s));
+            } else {
+                CS_TRY(launch_gemm_split(SH_OUT_F32_RESID, ctxs, ws + sl.ao, P + lo.ao_b, x, x, nullptr, T, H, H, h->d_flag, s));  // E4
+                CS_TRY(launch_row_kernel(1, a, H, s));
+            }
             CS_TRY(launch_gemm_split(SH_OUT_SPLIT_GELU, xs, ws + sl.up, P + lo.up_b, nullptr, nullptr, mids, T, I, H, h->d_flag, s));    // E5
-            CS_TRY(launch_gemm_split(SH_OUT_F32_RESID, mids, ws + sl.down, P + lo.down_b, x, x, nullptr, T, H, I, h->d_flag, s)); // E6
             a.g = P + lo.out_ln_g; a.b = P + lo.out_ln_b;
-            CS_TRY(launch_row_kernel(1, a, H, s));
+            if (T > split_k_min && T <= split_k_max) {
+                // a few thousand token rows: FFN-down is 3 x T / 128 blocks walking 48 K stages one exposed
+                // latency each; three K slices per tile (partial slabs in the qkv buffer, free by now),
+                // summed with bias and residual by the LayerNorm that follows
+                CS_TRY(launch_gemm_split_partial(mids, ws + sl.down, qkv, T, H, I, 3, s));  // E6
+                a.parts = qkv; a.nparts = 3; a.bias = P + lo.down_b;
+                CS_TRY(launch_row_kernel(3, a, H, s));
+            } else {
+                CS_TRY(launch_gemm_split(SH_OUT_F32_RESID, mids, ws + sl.down, P + lo.down_b, x, x, nullptr, T, H, I, h->d_flag, s)); // E6
+                CS_TRY(launch_row_kernel(1, a, H, s));
+            }
         } else {
             const float* wqkv = h->d_wqkv + (size_t)l * 3 * H * H;
             CS_TRY(launch_gemm(GEMM_BIAS, x, wqkv, bqkv, nullptr, qkv, T, 3 * H, H, s));        // E2

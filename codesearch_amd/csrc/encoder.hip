@@ -124,6 +124,37 @@ layernorm_kernel(float* __restrict__ x, const float* __restrict__ g, const float
     if (ovf && flag) atomicOr(flag, 1u);
 }
 
+// LayerNorm over x + bias + sum of the split-K partial slabs (the epilogue of a launch_gemm_split_partial
+// GEMM moved here: slab order is fixed, so the sum is deterministic).
+template <int NPL>
+__global__ void __launch_bounds__(256)
+layernorm_sum_kernel(float* __restrict__ x, const float* __restrict__ parts, uint32_t nparts,
+                     const float* __restrict__ bias, const float* __restrict__ g, const float* __restrict__ b,
+                     float eps, uint32_t T, _Float16* __restrict__ xs, uint32_t* __restrict__ flag) {
+    constexpr int H = 64 * NPL;
+    const int lane = threadIdx.x & 63;
+    const uint32_t t = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= T) return;
+    float* row = x + (size_t)t * H;
+    float v[NPL];
+#pragma unroll
+    for (int p = 0; p < NPL / 2; ++p) {
+        const int c = ln_col(lane, 2 * p);
+        float2 acc = *reinterpret_cast<const float2*>(parts + (size_t)t * H + c);
+        for (uint32_t s = 1; s < nparts; ++s) {
+            const float2 q = *reinterpret_cast<const float2*>(parts + ((size_t)s * T + t) * H + c);
+            acc.x += q.x;
+            acc.y += q.y;
+        }
+        const float2 bv = *reinterpret_cast<const float2*>(bias + c);
+        const float2 r2 = *reinterpret_cast<const float2*>(row + c);
+        v[2 * p] = (acc.x + bv.x) + r2.x;      // (A W^T + bias) + residual, as the fused epilogue computes it
+        v[2 * p + 1] = (acc.y + bv.y) + r2.y;
+    }
+    const bool ovf = ln_row<NPL>(v, g, b, eps, lane, row, xs ? xs + (size_t)t * H * 2 : nullptr);
+    if (ovf && flag) atomicOr(flag, 1u);
+}
+
 // ---- E2/E4/E5/E6: C[M,N] = A[M,K] W[N,K]^T + bias (+ epilogue) --------------------------------
 // 128x128 block tile, BK = 32, 4 waves as 2x2, each wave 64x64 = 2x2 MFMA tiles of 32x32.
 // LDS rows are padded to 36 floats so the ds_read_b128 fragment reads (16-lane groups reading
@@ -553,6 +584,9 @@ static void launch_rows(int which, const EncoderLaunch& a, hipStream_t s) {
     else if (which == 1)
         hipLaunchKernelGGL(layernorm_kernel<NPL>, dim3((T + 3) / 4), dim3(256), 0, s, a.x, a.g, a.b, a.eps, T,
                            static_cast<_Float16*>(a.xs), a.flag);
+    else if (which == 3)
+        hipLaunchKernelGGL(layernorm_sum_kernel<NPL>, dim3((T + 3) / 4), dim3(256), 0, s, a.x, a.parts, a.nparts,
+                           a.bias, a.g, a.b, a.eps, T, static_cast<_Float16*>(a.xs), a.flag);
     else
         hipLaunchKernelGGL(pool_normalize_kernel<NPL>, dim3((a.B + 3) / 4), dim3(256), 0, s, a.x, a.mask, a.B,
                            a.L, a.pooling, a.out);

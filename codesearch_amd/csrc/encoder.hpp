@@ -23,6 +23,9 @@ struct EncoderLaunch {
     float* x = nullptr;
     float* out = nullptr;
     void* xs = nullptr;         // optional: the row also in split-f16 form (split_f16.hpp), [T][H/32][64] f16
+    const float* parts = nullptr;  // which == 3: [nparts][T][H] partial sums of a split-K GEMM
+    const float* bias = nullptr;   //             the layer's bias ([H])
+    uint32_t nparts = 0;
     uint32_t* flag = nullptr;   // split-f16 overflow flag (device)
 };
 
@@ -50,7 +53,10 @@ int32_t launch_attention_sh2(const _Float16* qkv_split, const int32_t* mask, voi
                              uint32_t B, uint32_t L, uint32_t H, uint32_t heads, hipStream_t s);
 
 // Split-f16 GEMM (gemm_split.hip): A [M][K/32][64] f16, W [N][K/32][64] f16 (split_f16.hpp).
-enum { SH_OUT_F32 = 0, SH_OUT_F32_RESID = 1, SH_OUT_SPLIT_GELU = 2, SH_OUT_SPLIT = 3 };
+enum { SH_OUT_F32 = 0, SH_OUT_F32_RESID = 1, SH_OUT_SPLIT_GELU = 2, SH_OUT_SPLIT = 3,
+       SH_OUT_PARTIAL = 4 /* raw f32 partial sums of a K slice, no bias: slab blockIdx-slice of C */ };
+int32_t launch_gemm_split_partial(const _Float16* A, const _Float16* W, float* Cpart, uint32_t M, uint32_t N,
+                                  uint32_t K, uint32_t ksplit, hipStream_t s);
 int32_t launch_gemm_split(int epi, const _Float16* A, const _Float16* W, const float* bias, const float* resid,
                           float* C, _Float16* Cs, uint32_t M, uint32_t N, uint32_t K, uint32_t* d_flag,
                           hipStream_t s);

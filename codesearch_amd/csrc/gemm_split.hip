@@ -92,7 +92,8 @@ __device__ __forceinline__ void gemm_sh_epilogue(const float* ctile, const float
         if (ovf && flag) atomicOr(flag, 1u);
     } else {
         const int c4 = tid & 31;
-        const sh_f32x4 bv = *reinterpret_cast<const sh_f32x4*>(bias + n0 + c4 * 4);
+        sh_f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+        if (EPI != SH_OUT_PARTIAL) bv = *reinterpret_cast<const sh_f32x4*>(bias + n0 + c4 * 4);
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
             sh_f32x4 rs[8];
@@ -155,15 +156,21 @@ __global__ void __launch_bounds__(256, 2)
 gemm_sh16_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ W,
                  const float* __restrict__ bias, const float* resid, float* C,
                  _Float16* __restrict__ Cs, uint32_t M, uint32_t N, uint32_t kchunks,
-                 uint32_t* __restrict__ flag) {
+                 uint32_t* __restrict__ flag, uint32_t ksplit) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     uint32_t mt, nt;
-    if (!sh_tile_of_block(blockIdx.x, (M + SH_BM - 1) / SH_BM, N / SH_BN, mt, nt)) return;
+    // split-K (SH_OUT_PARTIAL): gridDim.x = tile slots x ksplit; slice s takes chunks [s, s+1) * kchunks / ksplit
+    // and writes its raw partial tile into slab s of C ([ksplit][M][N])
+    const uint32_t slots = gridDim.x / ksplit, slice = blockIdx.x / slots;
+    if (!sh_tile_of_block(blockIdx.x % slots, (M + SH_BM - 1) / SH_BM, N / SH_BN, mt, nt)) return;
     const uint32_t m0 = mt * SH_BM, n0 = nt * SH_BN;
     SH_STAMP(0);
     ShAcc16 acc;
     sh_acc16_zero(acc);
-    sh_mainloop16(A, M, m0, W, N, n0, kchunks, lds, acc, sh_kc_rot(nt, N / SH_BN, kchunks));
+    const uint32_t kc_begin = (uint32_t)((uint64_t)kchunks * slice / ksplit);
+    const uint32_t kc_count = (uint32_t)((uint64_t)kchunks * (slice + 1) / ksplit) - kc_begin;
+    if (EPI == SH_OUT_PARTIAL) C += (size_t)slice * M * N;
+    sh_mainloop16(A, M, m0, W, N, n0, kchunks, lds, acc, sh_kc_rot(nt, N / SH_BN, kc_count), kc_begin, kc_count);
     SH_STAMP(1);
     float* ctile = reinterpret_cast<float*>(lds);
     sh_acc16_to_lds(acc, ctile);
@@ -449,10 +456,10 @@ int32_t launch_gemm_split(int epi, const _Float16* A, const _Float16* W, const f
             attr16 = true;
         }
         const dim3 grid16(sh_grid_blocks((M + SH_BM - 1) / SH_BM, N / SH_BN));
-        if (epi == SH_OUT_F32) hipLaunchKernelGGL(gemm_sh16_kernel<SH_OUT_F32>, grid16, dim3(256), SH_LDS_BYTES, s, A, W, bias, resid, C, Cs, M, N, kc, d_flag);
-        else if (epi == SH_OUT_F32_RESID) hipLaunchKernelGGL(gemm_sh16_kernel<SH_OUT_F32_RESID>, grid16, dim3(256), SH_LDS_BYTES, s, A, W, bias, resid, C, Cs, M, N, kc, d_flag);
-        else if (epi == SH_OUT_SPLIT) hipLaunchKernelGGL(gemm_sh16_kernel<SH_OUT_SPLIT>, grid16, dim3(256), SH_LDS_BYTES, s, A, W, bias, resid, C, Cs, M, N, kc, d_flag);
-        else hipLaunchKernelGGL(gemm_sh16_kernel<SH_OUT_SPLIT_GELU>, grid16, dim3(256), SH_LDS_BYTES, s, A, W, bias, resid, C, Cs, M, N, kc, d_flag);
+        if (epi == SH_OUT_F32) hipLaunchKernelGGL(gemm_sh16_kernel<SH_OUT_F32>, grid16, dim3(256), SH_LDS_BYTES, s, A, W, bias, resid, C, Cs, M, N, kc, d_flag, 1u);
+        else if (epi == SH_OUT_F32_RESID) hipLaunchKernelGGL(gemm_sh16_kernel<SH_OUT_F32_RESID>, grid16, dim3(256), SH_LDS_BYTES, s, A, W, bias, resid, C, Cs, M, N, kc, d_flag, 1u);
+        else if (epi == SH_OUT_SPLIT) hipLaunchKernelGGL(gemm_sh16_kernel<SH_OUT_SPLIT>, grid16, dim3(256), SH_LDS_BYTES, s, A, W, bias, resid, C, Cs, M, N, kc, d_flag, 1u);
+        else hipLaunchKernelGGL(gemm_sh16_kernel<SH_OUT_SPLIT_GELU>, grid16, dim3(256), SH_LDS_BYTES, s, A, W, bias, resid, C, Cs, M, N, kc, d_flag, 1u);
         CS_HIP(hipGetLastError());
         return CS_OK;
     }
@@ -497,6 +504,26 @@ int32_t launch_gemm_split(int epi, const _Float16* A, const _Float16* W, const f
     else if (epi == SH_OUT_F32_RESID) hipLaunchKernelGGL(gemm_sh_kernel<SH_OUT_F32_RESID>, grid, dim3(256), SH_LDS_LAUNCH_BYTES, s, A, W, bias, resid, C, Cs, M, N, kc, d_flag);
     else if (epi == SH_OUT_SPLIT) hipLaunchKernelGGL(gemm_sh_kernel<SH_OUT_SPLIT>, grid, dim3(256), SH_LDS_LAUNCH_BYTES, s, A, W, bias, resid, C, Cs, M, N, kc, d_flag);
     else hipLaunchKernelGGL(gemm_sh_kernel<SH_OUT_SPLIT_GELU>, grid, dim3(256), SH_LDS_LAUNCH_BYTES, s, A, W, bias, resid, C, Cs, M, N, kc, d_flag);
+    CS_HIP(hipGetLastError());
+    return CS_OK;
+}
+
+// Split-K form of C = A W^T for layers whose K walk is what bounds them (FFN-down at a few thousand token
+// rows: 48 stages per block, too few blocks to overlap them): `ksplit` K slices per output tile, raw f32
+// partial tiles into Cpart[ksplit][M][N]; bias, residual and the sum are LayerNorm's (launch_row_kernel 3).
+int32_t launch_gemm_split_partial(const _Float16* A, const _Float16* W, float* Cpart, uint32_t M, uint32_t N,
+                                  uint32_t K, uint32_t ksplit, hipStream_t s) {
+    if (N % SH_BN || K % 32 || ksplit == 0 || K / 32 < ksplit)
+        return fail(CS_ERR_UNSUPPORTED, "split-K GEMM N=%u K=%u ksplit=%u", N, K, ksplit);
+    if (M == 0) return CS_OK;
+    static bool attr = false;
+    if (!attr) {
+        CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_sh16_kernel<SH_OUT_PARTIAL>), hipFuncAttributeMaxDynamicSharedMemorySize, SH_LDS_BYTES));
+        attr = true;
+    }
+    const dim3 grid(sh_grid_blocks((M + SH_BM - 1) / SH_BM, N / SH_BN) * ksplit);
+    hipLaunchKernelGGL(gemm_sh16_kernel<SH_OUT_PARTIAL>, grid, dim3(256), SH_LDS_BYTES, s, A, W, nullptr, nullptr, Cpart,
+                       nullptr, M, N, K / 32, nullptr, ksplit);
     CS_HIP(hipGetLastError());
     return CS_OK;
 }

@@ -212,9 +212,12 @@ __device__ __forceinline__ void sh_acc16_zero(ShAcc16& acc) {
             for (int r = 0; r < 4; ++r) { acc.hh[i][j][r] = 0.0f; acc.xx[i][j][r] = 0.0f; }
 }
 
+// kc_begin / kc_count: the block's share of the k-chunks (split-K launches); rows are always kchunks long.
 __device__ __forceinline__ void sh_mainloop16(const _Float16* __restrict__ A, uint32_t M, uint32_t m0,
                                               const _Float16* __restrict__ W, uint32_t N, uint32_t n0,
-                                              uint32_t kchunks, char* lds, ShAcc16& acc, uint32_t kc_rot = 0) {
+                                              uint32_t kchunks, char* lds, ShAcc16& acc, uint32_t kc_rot = 0,
+                                              uint32_t kc_begin = 0, uint32_t kc_count = 0) {
+    if (kc_count == 0) kc_count = kchunks;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 1, wc = wave & 1;
@@ -243,13 +246,13 @@ __device__ __forceinline__ void sh_mainloop16(const _Float16* __restrict__ A, ui
     const int arow = (wr * 64 + l15) * 128, wrow = SH_TILE_BYTES + (wc * 64 + l15) * 128;
     const int s_hi = (g ^ swz) * 16, s_lo = ((4 + g) ^ swz) * 16;
 
-    uint32_t kr = kc_rot % kchunks;
-    auto next_chunk = [&]() { const uint32_t c = kr; kr = kr + 1 == kchunks ? 0 : kr + 1; return c; };
+    uint32_t kr = kc_rot % kc_count;  // position inside the block's share
+    auto next_chunk = [&]() { const uint32_t c = kc_begin + kr; kr = kr + 1 == kc_count ? 0 : kr + 1; return c; };
     stage(next_chunk(), lds);
     __syncthreads();
-    for (uint32_t kc = 0; kc < kchunks; ++kc) {
+    for (uint32_t kc = 0; kc < kc_count; ++kc) {
         char* cur = lds + (kc & 1) * SH_STAGE_BYTES;
-        if (kc + 1 < kchunks) stage(next_chunk(), lds + ((kc + 1) & 1) * SH_STAGE_BYTES);
+        if (kc + 1 < kc_count) stage(next_chunk(), lds + ((kc + 1) & 1) * SH_STAGE_BYTES);
         f16x8 ah[4], al[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {

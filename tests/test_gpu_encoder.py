@@ -323,3 +323,18 @@ def test_multi_minibatch_id_calls_group_by_length(FE, oracle):
     assert np.abs(one - many).max() <= 1e-6
     ref = oracle.bert_forward(cfg, synth_params(cfg, 31), ids, mask)["pooled"]
     np.testing.assert_allclose(many, ref, atol=TOL_ORACLE)
+
+
+@pytest.mark.parametrize("B,L", [(12, 128), (20, 160), (40, 128)])
+def test_mid_size_batches_split_k_layers(FE, oracle, B, L):
+    """1,100 < tokens <= 6,144: FFN-down (and out-proj up to 2,560 tokens) run as three K slices whose partial
+    slabs LayerNorm sums with bias and residual (launch_gemm_split_partial + layernorm_sum_kernel): same
+    embeddings as the oracle, and the same run to run (fixed summation order)."""
+    cfg = BertConfig(vocab_size=512, layers=2, pooling=POOL_MEAN)
+    emb = FE(cfg, seed=41)
+    ids, mask = synth_token_batch(cfg, 19, B, L, True)
+    got = emb.embed_ids(ids, mask, batch_size=B)
+    again = emb.embed_ids(ids, mask, batch_size=B)
+    assert np.array_equal(got, again)
+    ref = oracle.bert_forward(cfg, synth_params(cfg, 41), ids, mask)["pooled"]
+    np.testing.assert_allclose(got, ref, atol=TOL_ORACLE)
