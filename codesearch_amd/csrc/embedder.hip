@@ -138,6 +138,8 @@ int32_t forward_range(cs_embedder* h, hipStream_t s, uint32_t b0, uint32_t nb, u
     static const uint32_t split_k_max = [] { const char* e = std::getenv("CS_GEMM_SPLITK_MAX_M"); return e ? (uint32_t)std::atoi(e) : 6144u; }();
     // device us per forward, fused / FFN-down in 3 K slices / out-proj too: 1,280 rows 1320 / 1020 / 971, 2,048
     // 1331 / 1052 / 1021, 4,096 1538 / 1311 / 1328, 6,144 1841 / 1619 / 1654, 8,192 2210 / 2264 / -
+    // two slices up to 10,240 rows: 7,168 rows 2048 -> 1891 us, 8,192 2203 -> 2060, 10,240 2443 -> 2369, 12,288 3034 -> 3167
+    static const uint32_t split_k_max2 = [] { const char* e = std::getenv("CS_GEMM_SPLITK_MAX2_M"); return e ? (uint32_t)std::atoi(e) : 10240u; }();
     static const uint32_t split_k_ao_max = [] { const char* e = std::getenv("CS_GEMM_SPLITK_AO_MAX_M"); return e ? (uint32_t)std::atoi(e) : 2560u; }();
     CS_TRY(launch_row_kernel(0, a, H, s));  // E1
     for (uint32_t l = 0; l < c.layers; ++l) {
@@ -166,12 +168,13 @@ int32_t forward_range(cs_embedder* h, hipStream_t s, uint32_t b0, uint32_t nb, u
             }
             CS_TRY(launch_gemm_split(SH_OUT_SPLIT_GELU, xs, ws + sl.up, P + lo.up_b, nullptr, nullptr, mids, T, I, H, h->d_flag, s));    // E5
             a.g = P + lo.out_ln_g; a.b = P + lo.out_ln_b;
-            if (T > split_k_min && T <= split_k_max) {
+            if (T > split_k_min && T <= split_k_max2) {
                 // a few thousand token rows: FFN-down is 3 x T / 128 blocks walking 48 K stages one exposed
-                // latency each; three K slices per tile (partial slabs in the qkv buffer, free by now),
-                // summed with bias and residual by the LayerNorm that follows
-                CS_TRY(launch_gemm_split_partial(mids, ws + sl.down, qkv, T, H, I, 3, s));  // E6
-                a.parts = qkv; a.nparts = 3; a.bias = P + lo.down_b;
+                // latency each; three K slices per tile (two from 6,144 rows: still one round of blocks), partial
+                // slabs in the qkv buffer (free by now), summed with bias and residual by the LayerNorm that follows
+                const uint32_t ks = T <= split_k_max ? 3 : 2;
+                CS_TRY(launch_gemm_split_partial(mids, ws + sl.down, qkv, T, H, I, ks, s));  // E6
+                a.parts = qkv; a.nparts = ks; a.bias = P + lo.down_b;
                 CS_TRY(launch_row_kernel(3, a, H, s));
             } else {
                 CS_TRY(launch_gemm_split(SH_OUT_F32_RESID, mids, ws + sl.down, P + lo.down_b, x, x, nullptr, T, H, I, h->d_flag, s)); // E6

@@ -325,9 +325,9 @@ def test_multi_minibatch_id_calls_group_by_length(FE, oracle):
     np.testing.assert_allclose(many, ref, atol=TOL_ORACLE)
 
 
-@pytest.mark.parametrize("B,L", [(12, 128), (20, 160), (40, 128)])
+@pytest.mark.parametrize("B,L", [(12, 128), (20, 160), (40, 128), (40, 200)])
 def test_mid_size_batches_split_k_layers(FE, oracle, B, L):
-    """1,100 < tokens <= 6,144: FFN-down (and out-proj up to 2,560 tokens) run as three K slices whose partial
+    """1,100 < tokens <= 10,240: FFN-down (and out-proj up to 2,560 tokens) run as three (two from 6,144) K slices whose partial
     slabs LayerNorm sums with bias and residual (launch_gemm_split_partial + layernorm_sum_kernel): same
     embeddings as the oracle, and the same run to run (fixed summation order)."""
     cfg = BertConfig(vocab_size=512, layers=2, pooling=POOL_MEAN)
