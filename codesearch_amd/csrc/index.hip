@@ -592,13 +592,13 @@ int32_t cs_index_search(cs_index* h, const float* queries, uint32_t nq, uint32_t
     if (!w) return fail(CS_ERR_HIP, "could not create a HIP stream");
     int32_t s = w->reserve(plan, nq, h->dim, k, true);
     if (s == CS_OK) {
-        const size_t on = (size_t)nq * k;
         s = [&]() -> int32_t {
             memcpy(w->h_queries, queries, (size_t)nq * h->dim * sizeof(float));
             CS_HIP(hipMemcpyAsync(w->d_queries, w->h_queries, (size_t)nq * h->dim * sizeof(float),
                                   hipMemcpyHostToDevice, w->stream));
-            CS_TRY(run_search(h, w, plan, w->d_queries, nq, k, w->d_keys, nullptr, nullptr, nullptr, w->stream));
-            CS_HIP(hipMemcpyAsync(w->h_keys, w->d_keys, on * sizeof(uint64_t), hipMemcpyDeviceToHost, w->stream));
+            // the last kernel of the search writes the packed keys straight into the pinned host buffer
+            // (device-addressable, coherent): no D2H copy call, one stream sync
+            CS_TRY(run_search(h, w, plan, w->d_queries, nq, k, w->h_keys, nullptr, nullptr, nullptr, w->stream));
             CS_HIP(hipStreamSynchronize(w->stream));
             for (uint32_t q = 0; q < nq; ++q) {  // keys are best-first, 0 = empty slot
                 uint32_t c = 0;
