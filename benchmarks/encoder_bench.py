@@ -18,14 +18,18 @@ def main():
     ap.add_argument("--seq", type=int, default=256)
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--ragged", action="store_true")
+    ap.add_argument("--model", default="bge-small", help="registry short name: bge-small, bge-base, bge-large, minilm-l6, ...")
     args = ap.parse_args()
     import numpy as np
 
     from codesearch_amd import BertConfig, FastEmbedder, ModelType
     from codesearch_amd.bert_params import synth_token_batch
 
-    cfg = BertConfig.bge_small()
-    emb = FastEmbedder(ModelType.BGESmallENV15, config=cfg, seed=202)
+    mt = ModelType.parse(args.model)
+    if mt is None:
+        raise SystemExit(f"unknown model {args.model!r}")
+    cfg = mt.bert_config()
+    emb = FastEmbedder(mt, config=cfg, seed=202)
     ids, mask = synth_token_batch(cfg, 999, args.batch, args.seq, args.ragged)
     emb.embed_ids(ids, mask)  # warm-up (allocates the workspace)
     emb.profile_read(reset=True)
@@ -34,12 +38,12 @@ def main():
         out = emb.embed_ids(ids, mask)
     wall = (time.perf_counter() - t0) / args.iters
     ms, n = emb.profile_read()
-    ms /= max(n, 1)
+    ms /= max(args.iters, 1)  # device time per BATCH (the reference's mini-batch policy cuts 768-d models at 128, 1024-d at 64)
     L, H, I, layers = args.seq, cfg.hidden, cfg.intermediate, cfg.layers
     flops_tok = layers * (2 * (4 * H * H + 2 * H * I) + 4 * L * H)
     flops = flops_tok * args.batch * args.seq
     print(json.dumps({
-        "workload": f"BGE-small-en-v1.5 shape, batch {args.batch} x seq {args.seq}, {'ragged' if args.ragged else 'full'} mask, fp32",
+        "workload": f"{mt.name_str()} shape ({cfg.layers} x hidden {cfg.hidden}, {cfg.heads} heads), batch {args.batch} x seq {args.seq}, {'ragged' if args.ragged else 'full'} mask, fp32",
         "device_ms_per_batch": ms, "wall_ms_per_batch_incl_pcie": wall * 1e3,
         "chunks_per_s_device": args.batch / (ms * 1e-3), "tokens_per_s_device": args.batch * args.seq / (ms * 1e-3),
         "algorithmic_tflop_per_batch": flops / 1e12, "achieved_tflops": flops / (ms * 1e-3) / 1e12,

@@ -438,11 +438,205 @@ attention_sh2_kernel(const _Float16* __restrict__ qkvs, const int32_t* __restric
     if (ovf && flag) atomicOr(flag, 1u);
 }
 
+// ---- head_dim 32 * NC (NC = 2: BGE-base / BGE-large / mxbai-large): keys in super-tiles of 128 ------------
+// A (token, head) is NC 128-B lines [32 hi | 32 lo] of the split qkv row.  Each line of K and of V gets its
+// own LDS image with exactly the layout of attention_sh2_kernel (K pieces at c ^ ((key >> 1) & 7), V pieces
+// at c ^ (4 * ((key >> 1) & 1)) for the transposing read), so S sums NC images and O^T has NC 32-row tiles of
+// d.  At 512 B per key (NC = 2) a whole 512-token sequence no longer fits LDS: keys are staged 128 at a time
+// (64 KiB, two blocks per CU), the online softmax state carrying over.  Block = (head, sequence, 128 queries).
+template <int NC>
+__global__ void __launch_bounds__(256, 2)
+attention_shx_kernel(const _Float16* __restrict__ qkvs, const int32_t* __restrict__ mask,
+                     _Float16* __restrict__ ctxs, uint32_t* __restrict__ flag, uint32_t L, uint32_t H,
+                     float scale_log2e) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int KT = 128;                        // keys per super-tile
+    const uint32_t Lp = (L + 31) & ~31u;
+    char* Kt = smem;                               // [NC][KT][128 B]
+    char* Vt = Kt + (size_t)NC * KT * 128;         // [NC][KT][128 B]
+    float* madd = reinterpret_cast<float*>(Vt + (size_t)NC * KT * 128);  // [Lp]
+    int* last_valid_p = reinterpret_cast<int*>(madd + Lp);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, h = lane >> 5;
+    const uint32_t head = blockIdx.x, b = blockIdx.y, qb = blockIdx.z;
+    const uint32_t nh = H / (32 * NC), nch = 3 * nh * NC;  // chunks per token row: Q heads | K heads | V heads
+    const _Float16* base = qkvs + (size_t)b * L * nch * 64;
+    bool ovf = false;
+
+    if (tid == 0) *last_valid_p = 0;
+    __syncthreads();
+    for (uint32_t key = tid; key < Lp; key += 256) {
+        const bool ok = key < L && mask[(size_t)b * L + key] != 0;
+        madd[key] = ok ? 0.0f : kMaskedLog2;
+        if (ok) atomicMax(last_valid_p, (int)key);
+    }
+    __syncthreads();
+    const uint32_t ntiles = (uint32_t)(*last_valid_p) / 32 + 1;  // 32-key tiles that hold a valid key
+
+    const int kswz = (l31 >> 1) & 7;
+    int k_hi[2], k_lo[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        k_hi[s] = ((2 * s + h) ^ kswz) * 16;
+        k_lo[s] = ((4 + 2 * s + h) ^ kswz) * 16;
+    }
+    const int vq = (lane & 15) >> 2, vp = lane & 3, vg = (lane >> 4) & 1;
+    const int vfv = 4 * ((vq >> 1) & 1);
+    const int v_hi = (4 * h + vq) * 128 + (((2 * vg + (vp >> 1)) ^ vfv) * 16) + 8 * (vp & 1);
+    const int v_lo = v_hi ^ 64;
+
+    const bool wave_live = qb * 128 + wave * 32 < L;  // wave-uniform: some query of this wave's tile exists
+    const uint32_t query = qb * 128 + wave * 32 + l31;
+    const uint32_t qsrc = query < L ? query : L - 1;
+    f16x8 qh[NC][2], ql[NC][2];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const _Float16* qp = base + ((size_t)qsrc * nch + head * NC + c) * 64 + 8 * h;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            qh[c][s] = *reinterpret_cast<const f16x8*>(qp + 16 * s);
+            ql[c][s] = *reinterpret_cast<const f16x8*>(qp + 32 + 16 * s);
+        }
+    }
+    sh_f32x16 ohh[NC], oxx[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { ohh[c][r] = 0.0f; oxx[c][r] = 0.0f; }
+    float m = -__builtin_huge_valf(), lsum = 0.0f;
+
+    for (uint32_t st = 0; st * 4 < ntiles; ++st) {
+        __syncthreads();  // every wave is done with the previous super-tile
+        // stage keys [128 st, 128 st + 128): 8 keys x 128 B per instruction and image
+        for (uint32_t ii = wave; ii < (uint32_t)(KT / 8); ii += 4) {
+            const uint32_t row = ii * 8 + (lane >> 3);            // key inside the super-tile
+            const uint32_t gk = st * KT + row;
+            const uint32_t key = gk < L ? gk : L - 1;             // keys past L are masked; read a valid line
+            const uint32_t ck = (lane & 7) ^ ((row >> 1) & 7);
+            const uint32_t cv = (lane & 7) ^ (4 * ((row >> 1) & 1));
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                sh_glds16(base + ((size_t)key * nch + (nh + head) * NC + c) * 64 + ck * 8, Kt + (size_t)c * KT * 128 + ii * 1024);
+                sh_glds16(base + ((size_t)key * nch + (2 * nh + head) * NC + c) * 64 + cv * 8, Vt + (size_t)c * KT * 128 + ii * 1024);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (!wave_live) continue;  // (still takes part in the staging and the barriers)
+        const uint32_t kt_end = ntiles - st * 4 < 4 ? ntiles - st * 4 : 4;
+        for (uint32_t kl = 0; kl < kt_end; ++kl) {
+            const uint32_t kt = st * 4 + kl;  // global 32-key tile
+            sh_f32x16 hh, xx;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { hh[r] = 0.0f; xx[r] = 0.0f; }
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const char* kr = Kt + (size_t)c * KT * 128 + (size_t)(kl * 32 + l31) * 128;
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const f16x8 kh = *reinterpret_cast<const f16x8*>(kr + k_hi[s]);
+                    const f16x8 kl8 = *reinterpret_cast<const f16x8*>(kr + k_lo[s]);
+                    hh = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[c][s], hh, 0, 0, 0);
+                    xx = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[c][s], xx, 0, 0, 0);
+                    xx = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl8, qh[c][s], xx, 0, 0, 0);
+                }
+            }
+            float tmax = -__builtin_huge_valf();
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const sh_f32x4 ma = *reinterpret_cast<const sh_f32x4*>(madd + kt * 32 + 8 * g + 4 * h);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int r = 4 * g + e;
+                    hh[r] = fmaf(fmaf(xx[r], kShLoInv, hh[r]), scale_log2e, ma[e]);
+                    tmax = fmaxf(tmax, hh[r]);
+                }
+            }
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+            if (__any(tmax > m)) {
+                const float mnew = fmaxf(m, tmax);
+                const float alpha = __builtin_amdgcn_exp2f(m - mnew);
+                lsum *= alpha;
+#pragma unroll
+                for (int c = 0; c < NC; ++c)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) { ohh[c][r] *= alpha; oxx[c][r] *= alpha; }
+                m = mnew;
+            }
+            float psum = 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                hh[r] = __builtin_amdgcn_exp2f(hh[r] - m);
+                psum += hh[r];
+            }
+            lsum += psum;
+            Frag8 ph[2], pl[2];
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int w2 = 0; w2 < 4; ++w2)
+                    split_pair_rtz_ng(hh[8 * s + 2 * w2], hh[8 * s + 2 * w2 + 1], ph[s].u[w2], pl[s].u[w2]);
+            typedef __attribute__((address_space(3))) s16x4* lds_s16x4_p;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const char* vr = Vt + (size_t)c * KT * 128 + (size_t)kl * 32 * 128;
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    FragTr vh, vl;
+                    vh.q[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(vr + s * 16 * 128 + v_hi));
+                    vh.q[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(vr + s * 16 * 128 + 8 * 128 + v_hi));
+                    vl.q[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(vr + s * 16 * 128 + v_lo));
+                    vl.q[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(vr + s * 16 * 128 + 8 * 128 + v_lo));
+                    ohh[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh.v, ph[s].v, ohh[c], 0, 0, 0);
+                    oxx[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh.v, pl[s].v, oxx[c], 0, 0, 0);
+                    oxx[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl.v, ph[s].v, oxx[c], 0, 0, 0);
+                }
+            }
+        }
+    }
+    lsum += __shfl_xor(lsum, 32, 64);
+    const float inv = 1.0f / lsum;
+    if (wave_live && query < L) {
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            _Float16* op = ctxs + (((size_t)b * L + query) * nh + head) * NC * 64 + c * 64 + 4 * h;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f16x4 hi, lo;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    _Float16 a, bb;
+                    ovf |= sh_split(fmaf(oxx[c][4 * g + e], kShLoInv, ohh[c][4 * g + e]) * inv, a, bb);
+                    hi[e] = a; lo[e] = bb;
+                }
+                *reinterpret_cast<f16x4*>(op + 8 * g) = hi;
+                *reinterpret_cast<f16x4*>(op + 32 + 8 * g) = lo;
+            }
+        }
+    }
+    if (ovf && flag) atomicOr(flag, 1u);
+}
+
 int32_t launch_attention_sh2(const _Float16* qkv_split, const int32_t* mask, void* ctx_split, uint32_t* flag,
                              uint32_t B, uint32_t L, uint32_t H, uint32_t heads, hipStream_t s) {
-    if (H / heads != 32 || H % heads)
-        return fail(CS_ERR_UNSUPPORTED, "head_dim %u not supported (32 only in this round)", heads ? H / heads : 0);
+    const uint32_t dh = heads ? H / heads : 0;
+    if ((dh != 32 && dh != 64) || H % heads)
+        return fail(CS_ERR_UNSUPPORTED, "head_dim %u not supported (32 or 64)", dh);
     const size_t Lp = (L + 31) & ~31u;
+    if (dh == 64) {  // two 128-B lines per (token, head): keys staged 128 at a time
+        const size_t lds = 2 * 2 * 128 * 128 + Lp * sizeof(float) + 16;
+        static bool attr64 = false;
+        if (!attr64) {
+            CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attention_shx_kernel<2>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+            attr64 = true;
+        }
+        hipLaunchKernelGGL(attention_shx_kernel<2>, dim3(heads, B, (L + 127) / 128), dim3(256), lds, s, qkv_split, mask,
+                           static_cast<_Float16*>(ctx_split), flag, L, H, (1.0f / sqrtf(64.0f)) * kLog2e);
+        CS_HIP(hipGetLastError());
+        return CS_OK;
+    }
     const size_t lds = 2 * Lp * 128 + Lp * sizeof(float) + 16;
     if (lds > 160 * 1024 - 64) return fail(CS_ERR_UNSUPPORTED, "sequence length %u exceeds the LDS-resident K/V limit", L);
     static bool attr_set = false;

@@ -73,7 +73,7 @@ class ModelType(enum.Enum):
 
     def bert_config(self) -> BertConfig:
         """Encoder architecture this build can run on the GPU for the model (BERT family,
-        head_dim 32).  Pooling = fastembed's default for the family (CLS for BGE, mean for
+        head_dim 32 or 64).  Pooling = fastembed's default for the family (CLS for BGE, mean for
         MiniLM/E5), SURVEY.md §0 #4."""
         if self in (ModelType.BGESmallENV15, ModelType.BGESmallENV15Q):
             return BertConfig(pooling=POOL_CLS)
@@ -81,9 +81,13 @@ class ModelType(enum.Enum):
             return BertConfig(layers=6, pooling=POOL_MEAN)
         if self in (ModelType.AllMiniLML12V2, ModelType.AllMiniLML12V2Q):
             return BertConfig(layers=12, pooling=POOL_MEAN)
+        if self is ModelType.BGEBaseENV15:     # BERT-base: 12 x 768, 12 heads of 64
+            return BertConfig(hidden=768, layers=12, heads=12, intermediate=3072, pooling=POOL_CLS)
+        if self in (ModelType.BGELargeENV15, ModelType.MxbaiEmbedLargeV1):  # BERT-large: 24 x 1024, 16 heads of 64
+            return BertConfig(hidden=1024, layers=24, heads=16, intermediate=4096, pooling=POOL_CLS)
         raise CsError(_lib.CS_ERR_UNSUPPORTED,
-                      f"Failed to initialize embedding model: {self.name_str()} is not a head_dim-32 BERT "
-                      "encoder; this round builds the 384-d BERT family only")
+                      f"Failed to initialize embedding model: {self.name_str()} is not a BERT encoder with absolute "
+                      "positions (rotary / ALiBi / XLM-R families are not built)")
 
 
 # second spellings accepted by ModelType::parse (embedder.rs:178-195), verbatim

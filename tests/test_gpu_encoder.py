@@ -338,3 +338,23 @@ def test_mid_size_batches_split_k_layers(FE, oracle, B, L):
     assert np.array_equal(got, again)
     ref = oracle.bert_forward(cfg, synth_params(cfg, 41), ids, mask)["pooled"]
     np.testing.assert_allclose(got, ref, atol=TOL_ORACLE)
+
+
+@pytest.mark.parametrize("hidden,heads,inter,L", [(768, 12, 3072, 40), (768, 12, 3072, 300), (1024, 16, 4096, 130)])
+def test_head_dim_64_models(FE, oracle, hidden, heads, inter, L):
+    """BERT-base / BERT-large shapes (BGE-base, BGE-large, mxbai-large in the registry, embedder.rs:7-96): 64-wide
+    heads on attention_shx_kernel<2> (two K/V images per head, keys staged 128 at a time), ragged masks, more
+    than one key super-tile and more than one query block — against the oracle."""
+    cfg = BertConfig(vocab_size=512, hidden=hidden, layers=2, heads=heads, intermediate=inter, max_position=512,
+                     pooling=POOL_MEAN)
+    emb = FE(cfg, seed=53)
+    B = 5
+    ids, mask = synth_token_batch(cfg, 29, B, L, True)
+    got = emb.embed_ids(ids, mask)
+    assert got.shape == (B, hidden)
+    ref = oracle.bert_forward(cfg, synth_params(cfg, 53), ids, mask)["pooled"]
+    np.testing.assert_allclose(got, ref, atol=TOL_ORACLE)
+    from codesearch_amd._lib import CS_ERR_UNSUPPORTED, CsError
+    with pytest.raises(CsError) as ei:
+        emb.set_gemm_mode("f32")
+    assert ei.value.code == CS_ERR_UNSUPPORTED
