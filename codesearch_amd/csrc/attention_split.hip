@@ -1,4 +1,4 @@
-// attention_split.hip — multi-head self-attention (head_dim 32) on the f16 MFMA with split-f16
+// attention_split.hip — multi-head self-attention (head_dim 32; 64 in attention_shx_kernel) on the f16 MFMA with split-f16
 // operands (split_f16.hpp), SURVEY.md §8a E3.  Replaces the MHA nodes of the ONNX graph that
 // /root/reference/src/embed/embedder.rs:286-289 runs through fastembed/ort.
 //

@@ -480,8 +480,7 @@ int32_t cs_embedder_create(const cs_bert_config* cfg, const float* params, uint6
         return fail(CS_ERR_BAD_ARG, "Failed to initialize embedding model: inconsistent config");
     if (cfg->hidden != 384 && cfg->hidden != 768 && cfg->hidden != 1024)
         return fail(CS_ERR_UNSUPPORTED, "Failed to initialize embedding model: hidden size %u not supported", cfg->hidden);
-    // head_dim 64 (BGE-base / BGE-large / mxbai-large) runs on the split-f16 kernels only: the exact-f32
-    // attention kernel keeps K/V of a whole sequence in LDS, which 64-wide heads outgrow
+    // head_dim 64: BGE-base / BGE-large / mxbai-large
     if (cfg->hidden / cfg->heads != 32 && cfg->hidden / cfg->heads != 64)
         return fail(CS_ERR_UNSUPPORTED, "Failed to initialize embedding model: head_dim %u not supported (32 or 64)",
                     cfg->hidden / cfg->heads);
@@ -646,9 +645,6 @@ int32_t cs_embedder_profile_read(cs_embedder* h, double* forward_ms, uint64_t* f
 int32_t cs_embedder_set_gemm_mode(cs_embedder* h, int32_t mode) {
     if (!h) return fail(CS_ERR_BAD_ARG, "null embedder handle");
     if (mode != CS_GEMM_F32 && mode != CS_GEMM_SPLIT_F16) return fail(CS_ERR_BAD_ARG, "unknown gemm mode %d", mode);
-    if (mode == CS_GEMM_F32 && h->cfg.hidden / h->cfg.heads != 32)
-        return fail(CS_ERR_UNSUPPORTED, "the exact-f32 kernels support head_dim 32 only (this model: %u)",
-                    h->cfg.hidden / h->cfg.heads);
     if (mode == CS_GEMM_SPLIT_F16 && h->split_unavailable)
         return fail(CS_ERR_UNSUPPORTED, "split-f16 mode needs exact f16-subnormal MFMA inputs, which this device/mode lacks");
     h->gemm_mode = mode;

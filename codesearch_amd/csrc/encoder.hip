@@ -527,6 +527,132 @@ attention_kernel(const float* __restrict__ qkv, const int32_t* __restrict__ mask
     }
 }
 
+// ---- E3 for head_dim 64 (exact f32): the kernel above with keys staged 128 at a time ---------------------------
+// K rows of 64 + 4 floats and V rows of 64 floats for a whole 512-token sequence would need 270 KB of LDS; a
+// super-tile of 128 keys needs 67.6 KB.  The online softmax state and the two 32-row tiles of O^T carry over.
+constexpr int AKS64 = 68;  // padded K row (floats)
+constexpr int AKT64 = 128; // keys per super-tile
+
+__global__ void __launch_bounds__(256)
+attention64_kernel(const float* __restrict__ qkv, const int32_t* __restrict__ mask, float* __restrict__ ctx,
+                   uint32_t L, uint32_t H, float scale) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const uint32_t Lp = (L + 31) & ~31u;
+    float* Ks = smem;                          // [128][68]
+    float* Vs = Ks + (size_t)AKT64 * AKS64;    // [128][64]
+    float* madd = Vs + (size_t)AKT64 * 64;     // [Lp]
+    int& last_valid = *reinterpret_cast<int*>(madd + Lp);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const uint32_t qb = blockIdx.x, head = blockIdx.y, b = blockIdx.z;
+    const size_t row3 = (size_t)3 * H;
+    const float* base = qkv + (size_t)b * L * row3 + head * 64;
+
+    if (tid == 0) last_valid = 0;
+    __syncthreads();
+    for (uint32_t key = tid; key < Lp; key += 256) {
+        const bool ok = key < L && mask[(size_t)b * L + key] != 0;
+        madd[key] = ok ? 0.0f : kMaskMin;
+        if (ok) atomicMax(&last_valid, (int)key);
+    }
+    __syncthreads();
+    const uint32_t ntiles = (uint32_t)last_valid / 32 + 1;
+
+    const uint32_t query = qb * 128 + wave * 32 + l31;
+    float qf[32];  // d = 32 h + j  (the same permutation of d as the K fragments below)
+    {
+        const bool ok = query < L;
+        const float* qp = base + (size_t)(ok ? query : 0) * row3 + 32 * h;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const f32x4 t = *reinterpret_cast<const f32x4*>(qp + 4 * c);
+            qf[4 * c + 0] = ok ? t.x : 0.f; qf[4 * c + 1] = ok ? t.y : 0.f;
+            qf[4 * c + 2] = ok ? t.z : 0.f; qf[4 * c + 3] = ok ? t.w : 0.f;
+        }
+    }
+    f32x16 ot[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ot[c][r] = 0.0f;
+    float m = -__builtin_huge_valf(), lsum = 0.0f;
+
+    for (uint32_t st = 0; st * 4 < ntiles; ++st) {
+        __syncthreads();  // the previous super-tile is consumed
+        for (uint32_t idx = tid; idx < (uint32_t)AKT64 * 16; idx += 256) {
+            const uint32_t row = idx >> 4, c4 = idx & 15, key = st * AKT64 + row;
+            f32x4 kv = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
+            if (key < L) {
+                kv = *reinterpret_cast<const f32x4*>(base + key * row3 + H + c4 * 4);
+                vv = *reinterpret_cast<const f32x4*>(base + key * row3 + 2 * H + c4 * 4);
+            }
+            *reinterpret_cast<f32x4*>(Ks + row * AKS64 + c4 * 4) = kv;
+            *reinterpret_cast<f32x4*>(Vs + row * 64 + c4 * 4) = vv;
+        }
+        __syncthreads();
+        const uint32_t kt_end = ntiles - st * 4 < 4 ? ntiles - st * 4 : 4;
+        for (uint32_t kl = 0; kl < kt_end; ++kl) {
+            const uint32_t kt = st * 4 + kl;
+            const float* kr = Ks + (size_t)(kl * 32 + l31) * AKS64 + 32 * h;
+            f32x16 stt;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) stt[r] = 0.0f;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const f32x4 ka = *reinterpret_cast<const f32x4*>(kr + 4 * c);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    stt = __builtin_amdgcn_mfma_f32_32x32x2f32(ka[e], qf[4 * c + e], stt, 0, 0, 0);
+            }
+            float tmax = -__builtin_huge_valf();
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const uint32_t key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                stt[r] = stt[r] * scale + madd[key];
+                tmax = fmaxf(tmax, stt[r]);
+            }
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+            const float mnew = fmaxf(m, tmax);
+            const float alpha = expf(m - mnew);
+            float psum = 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                stt[r] = expf(stt[r] - mnew);
+                psum += stt[r];
+            }
+            lsum = lsum * alpha + psum;
+            m = mnew;
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) ot[c][r] *= alpha;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const uint32_t krow = kl * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;  // key inside the super-tile
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    const float vt = Vs[(size_t)krow * 64 + 32 * c + l31];  // A = V^T[d = 32 c + (lane & 31)][key]
+                    ot[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(vt, stt[r], ot[c], 0, 0, 0);
+                }
+            }
+        }
+    }
+    lsum += __shfl_xor(lsum, 32, 64);
+    const float inv = 1.0f / lsum;
+    // ot[c][r] = O^T[d = 32 c + (r&3) + 8*(r>>2) + 4h][query]
+    if (query < L) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            float* op = ctx + ((size_t)b * L + query) * H + head * 64 + 32 * c + 4 * h;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 o = {ot[c][4 * g] * inv, ot[c][4 * g + 1] * inv, ot[c][4 * g + 2] * inv, ot[c][4 * g + 3] * inv};
+                *reinterpret_cast<f32x4*>(op + 8 * g) = o;
+            }
+        }
+    }
+}
+
 // ---- E7/E8: pooling + L2 normalise ------------------------------------------------------------
 // One wave per sequence.  CLS: row 0.  Mean: sum(mask*h) / max(sum mask, 1e-9).
 template <int NPL>
@@ -645,8 +771,22 @@ size_t attention_lds_bytes(uint32_t L) {
 static int32_t launch_attention_impl(const float* qkv, const int32_t* mask, float* ctx, _Float16* ctxs,
                                      uint32_t* flag, uint32_t B, uint32_t L, uint32_t H, uint32_t heads,
                                      hipStream_t s) {
+    if (heads && H % heads == 0 && H / heads == 64 && !ctxs) {  // exact-f32 mode, 64-wide heads
+        const size_t Lp = (L + 31) & ~31u;
+        const size_t lds64 = ((size_t)AKT64 * (AKS64 + 64) + Lp + 4) * sizeof(float);
+        static bool attr64 = false;
+        if (!attr64) {
+            CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attention64_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+            attr64 = true;
+        }
+        hipLaunchKernelGGL(attention64_kernel, dim3((L + 127) / 128, heads, B), dim3(256), lds64, s, qkv, mask, ctx, L, H,
+                           1.0f / sqrtf(64.0f));
+        CS_HIP(hipGetLastError());
+        return CS_OK;
+    }
     if (H / heads != 32 || H % heads)
-        return fail(CS_ERR_UNSUPPORTED, "head_dim %u not supported (32 only in this round)", heads ? H / heads : 0);
+        return fail(CS_ERR_UNSUPPORTED, "head_dim %u not supported (32 or 64)", heads ? H / heads : 0);
     const size_t lds = attention_lds_bytes(L);
     if (lds > 160 * 1024 - 64) return fail(CS_ERR_UNSUPPORTED, "sequence length %u exceeds the LDS-resident K/V limit", L);
     static bool attr_set = false;
