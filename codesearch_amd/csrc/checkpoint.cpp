@@ -217,6 +217,20 @@ extern "C" {
 
 int32_t cs_bert_config_from_dir(const char* model_dir, int32_t pooling, cs_bert_config* cfg) {
     if (!model_dir || !cfg) return fail(CS_ERR_BAD_ARG, "null argument");
+    if (pooling == -1) {  // auto: the sentence-transformers pooling module of the snapshot, CLS when there is none
+        pooling = CS_POOL_CLS;
+        std::string ptext;
+        if (read_file(std::string(model_dir) + "/1_Pooling/config.json", ptext, 1 << 20)) {
+            JsonParser pj{ptext.data(), ptext.data() + ptext.size()};
+            const Json proot = pj.value();
+            if (pj.ok && proot.kind == Json::Obj) {
+                const Json* mean = proot.get("pooling_mode_mean_tokens");
+                const Json* cls = proot.get("pooling_mode_cls_token");
+                if (mean && mean->kind == Json::Bool && mean->b && !(cls && cls->kind == Json::Bool && cls->b))
+                    pooling = CS_POOL_MEAN;
+            }
+        }
+    }
     if (pooling != CS_POOL_CLS && pooling != CS_POOL_MEAN) return fail(CS_ERR_BAD_ARG, "unknown pooling %d", pooling);
     const std::string path = std::string(model_dir) + "/config.json";
     std::string text;

@@ -154,10 +154,11 @@ class FastEmbedder:
         return int(a.value), int(b.value), int(c.value)
 
     @classmethod
-    def from_dir(cls, model_dir: str, model_type: ModelType = None, pooling: int = POOL_CLS, device: int = 0,
+    def from_dir(cls, model_dir: str, model_type: ModelType = None, pooling: int = -1, device: int = 0,
                  lowercase: bool = True) -> "FastEmbedder":
         """A HF snapshot directory (config.json, model.safetensors, vocab.txt), as hf-hub leaves it in
-        fastembed's cache: cs_embedder_create_from_dir + cs_tokenizer_create_from_file."""
+        fastembed's cache: cs_embedder_create_from_dir + cs_tokenizer_create_from_file.  pooling -1 = what
+        the snapshot's 1_Pooling/config.json says (CLS when absent)."""
         from .tokenizer import WordPieceTokenizer
 
         self = cls.__new__(cls)

@@ -212,6 +212,8 @@ int32_t cs_embedder_create(const cs_bert_config* cfg, const float* params, uint6
  * directory as hf-hub caches it: config.json (BERT family, erf-GELU, absolute positions) and
  * model.safetensors (HF BertModel tensor names, optional "bert." prefix; F32, F16 or BF16;
  * pooler / position_ids / other extras ignored).  The two loaders are host-only. */
+/* pooling: CS_POOL_CLS, CS_POOL_MEAN, or -1 = what <model_dir>/1_Pooling/config.json says (the
+ * sentence-transformers module: mean for MiniLM / E5, CLS for BGE), CLS when that file is absent. */
 int32_t cs_bert_config_from_dir(const char* model_dir, int32_t pooling, cs_bert_config* cfg);
 int32_t cs_bert_params_from_safetensors(const char* path, const cs_bert_config* cfg,
                                         float* params, uint64_t n_params);

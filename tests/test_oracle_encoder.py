@@ -174,6 +174,19 @@ def test_c_abi_checkpoint_loaders(tmp_path, gpu_lib):
     expect(lambda: load(bad), _lib.CS_ERR_BAD_ARG, "encoder.layer.2.attention.self.query.weight is missing")
     (bad / "config.json").write_text(json.dumps({**hf, "intermediate_size": 1024}))
     expect(lambda: load(bad), _lib.CS_ERR_DIM_MISMATCH, "has shape [1536, 384], config.json implies [1024, 384]")
+    # pooling -1: the sentence-transformers pooling module of the snapshot decides
+    def auto_pooling(d):
+        c = _lib.BertConfig()
+        _lib.check(gpu_lib.cs_bert_config_from_dir(str(d).encode(), -1, C.byref(c)))
+        return c.pooling
+
+    assert auto_pooling(d32) == POOL_CLS
+    (d32 / "1_Pooling").mkdir()
+    (d32 / "1_Pooling" / "config.json").write_text(json.dumps({"word_embedding_dimension": 384, "pooling_mode_cls_token": False,
+                                                              "pooling_mode_mean_tokens": True}))
+    assert auto_pooling(d32) == POOL_MEAN
+    (d32 / "1_Pooling" / "config.json").write_text(json.dumps({"pooling_mode_cls_token": True, "pooling_mode_mean_tokens": False}))
+    assert auto_pooling(d32) == POOL_CLS
     (bad / "model.safetensors").write_bytes(b"\x10\x00\x00\x00\x00\x00\x00\x00not json at all!")
     (bad / "config.json").write_text(json.dumps(hf))
     expect(lambda: load(bad), _lib.CS_ERR_BAD_ARG, "malformed header")
