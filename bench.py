@@ -344,7 +344,9 @@ def main():
                     else ("cs::score_append_kernel" if args.nq >= 5 else "cs::scan_topk_kernel"),
                     "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
-                    "algorithmic_bytes_per_launch": alg_bytes}
+                    "algorithmic_bytes_per_launch": alg_bytes,
+                    "note": "avg_launch_us is the HIP-event span of the prime pass (scan_topk_kernel<..,false,true> "
+                            "over the first n/256 <= 16384 rows, ~10 us) plus the scan kernel; bytes count the scan only"}
         roof.update({"avg_launch_us": scan_us, "launches_timed": launches,
                      "merge_avg_us": merge_ms * 1e3 / max(launches, 1)})
         line = {

@@ -38,6 +38,7 @@ struct Workspace {
     bool own_stream = false;
     uint64_t* d_partial = nullptr; size_t partial_cap = 0;
     uint64_t* d_tmp_a = nullptr; uint64_t* d_tmp_b = nullptr; size_t tmp_cap = 0;
+    ScanPrime prime; size_t prime_max_cap = 0, prime_nq_cap = 0;
     float* d_queries = nullptr; size_t q_cap = 0;
     uint64_t* d_keys = nullptr; float* d_cos = nullptr; uint32_t* d_ids = nullptr; size_t out_cap = 0;
     uint32_t* d_counts = nullptr; size_t cnt_cap = 0;
@@ -65,6 +66,26 @@ struct Workspace {
             qw.d_qmag = nullptr; qw_nq = 0;
             CS_HIP(hipMalloc(&qw.d_qmag, nq * sizeof(float)));
             qw_nq = nq;
+        }
+        return CS_OK;
+    }
+
+    int32_t reserve_prime(const ScanPlan& pp, uint32_t nq) {
+        const size_t nmax = (size_t)nq * pp.blocks * 4;
+        if (nmax > prime_max_cap) {
+            if (prime.d_wave_max) (void)hipFree(prime.d_wave_max);
+            prime.d_wave_max = nullptr; prime_max_cap = 0;
+            CS_HIP(hipMalloc(&prime.d_wave_max, nmax * sizeof(float)));
+            prime_max_cap = nmax;
+        }
+        if (nq > prime_nq_cap) {  // passes <= nq
+            if (prime.d_done) (void)hipFree(prime.d_done);
+            if (prime.d_floor) (void)hipFree(prime.d_floor);
+            prime.d_done = nullptr; prime.d_floor = nullptr; prime_nq_cap = 0;
+            CS_HIP(hipMalloc(&prime.d_done, nq * sizeof(uint32_t)));
+            CS_HIP(hipMalloc(&prime.d_floor, nq * sizeof(float)));
+            CS_HIP(hipMemset(prime.d_done, 0, nq * sizeof(uint32_t)));
+            prime_nq_cap = nq;
         }
         return CS_OK;
     }
@@ -152,6 +173,9 @@ struct Workspace {
 
     void release_all() {
         if (d_partial) (void)hipFree(d_partial);
+        if (prime.d_wave_max) (void)hipFree(prime.d_wave_max);
+        if (prime.d_done) (void)hipFree(prime.d_done);
+        if (prime.d_floor) (void)hipFree(prime.d_floor);
         if (d_tmp_a) (void)hipFree(d_tmp_a);
         if (d_tmp_b) (void)hipFree(d_tmp_b);
         if (d_queries) (void)hipFree(d_queries);
@@ -196,6 +220,13 @@ struct cs_index {
     uint64_t split_rows = 0;
     bool use_split = false;
     int filter_min_q = 2;  // query count from which the f16 filter + exact refine path is used
+    // primed streaming scan (scan.hip PRIME mode): from this k and this many rows on, a pass over
+    // the first prime_rows rows bounds the list inserts of the full scan
+    // (measured, 1 query x 384-d: 10M rows k=10 2.37 -> 2.31 ms, k=200 2.62 -> 2.41 ms; 1M rows
+    // k=200 382 -> 279 us).  prime_rows 0 = n_rows / 256 clamped to [4096, 16384]; prime_min_rows 0 =
+    // 500,000 rows below k = 48 and 100,000 from there on.
+    uint32_t prime_min_k = 1;
+    uint64_t prime_min_rows = 0, prime_rows = 0;
     uint64_t batched_searches = 0, batched_fallbacks = 0;
     std::vector<uint32_t> h_dead;
     bool built = false;
@@ -383,8 +414,24 @@ int32_t run_search(cs_index* h, Workspace* w, const ScanPlan& plan, const float*
                                 d_ids, d_counts, stream);
         }();
     }
-    CS_TRY(launch_scan(plan, h->d_corpus, h->n_rows, h->dim, d_queries, nq, k,
-                       h->n_removed ? h->d_dead : nullptr, h->id_base, w->d_partial, stream));
+    const uint32_t* d_dead = h->n_removed ? h->d_dead : nullptr;
+    const ScanPrime* prime = nullptr;
+    uint64_t prime_rows = h->prime_rows;
+    if (!prime_rows) {
+        prime_rows = (h->n_rows / 256) & ~(uint64_t)63;
+        prime_rows = prime_rows < 4096 ? 4096 : (prime_rows > 16384 ? 16384 : prime_rows);
+    }
+    const uint64_t prime_min_rows = h->prime_min_rows ? h->prime_min_rows : (k >= 48 ? 100000 : 500000);
+    if (h->prime_min_k && k >= h->prime_min_k && h->n_rows >= prime_min_rows &&
+        h->n_rows >= 4 * prime_rows && scan_prime_supported(h->dim)) {
+        const ScanPlan pp = plan_prime(prime_rows, h->dim, nq, k, h->num_cus);
+        CS_TRY(w->reserve_prime(pp, nq));
+        CS_TRY(launch_scan(pp, h->d_corpus, prime_rows, h->dim, d_queries, nq, k, d_dead, h->id_base,
+                           nullptr, stream, &w->prime, true));
+        prime = &w->prime;
+    }
+    CS_TRY(launch_scan(plan, h->d_corpus, h->n_rows, h->dim, d_queries, nq, k, d_dead, h->id_base,
+                       w->d_partial, stream, prime));
     if (timed) CS_HIP(hipEventRecord(ev.e1, stream));
     CS_TRY(launch_merge(w->d_partial, plan.blocks, nq, k, false, w->d_tmp_a, w->d_tmp_b, d_keys, d_cos,
                         d_ids, d_counts, stream));
@@ -449,6 +496,9 @@ int32_t cs_index_create(uint32_t dim, uint64_t capacity_rows, int32_t device, ui
             h->filter_min_q = std::atoi(e);
             if (h->filter_min_q < 1) h->filter_min_q = 1;
         }
+        if (const char* e = std::getenv("CS_SCAN_PRIME_MIN_K")) h->prime_min_k = (uint32_t)std::atol(e);  // 0 = off
+        if (const char* e = std::getenv("CS_SCAN_PRIME_MIN_ROWS")) h->prime_min_rows = (uint64_t)std::atoll(e);
+        if (const char* e = std::getenv("CS_SCAN_PRIME_ROWS")) h->prime_rows = (uint64_t)std::atoll(e);
     }
     if (capacity_rows) {
         int32_t s = grow(h, capacity_rows);

@@ -51,10 +51,12 @@ __device__ __forceinline__ uint64_t shfl_xor_u64(uint64_t v, int m) {
 // State kept by the caller: `thr` = cosine of the current worst slot (-inf while any slot
 // is empty) and `wpos` = that slot's index.  Rows are streamed in ascending id, so a row
 // that ties the worst cosine loses to it (id asc) and `c > thr` is the whole test — the
-// `>` of benchmark_models.rs:160.
+// `>` of benchmark_models.rs:160.  `floor` is what thr falls back to while a slot is empty:
+// -inf, or the primed lower bound (see scan_topk_kernel's PRIME mode).
 __device__ __forceinline__ void wave_list_insert(volatile uint64_t* list, uint32_t k, int lane,
                                                  float c, uint32_t id, float& thr,
-                                                 uint32_t& wpos) {
+                                                 uint32_t& wpos,
+                                                 float floor = -__builtin_huge_valf()) {
     if (lane == 0) list[wpos] = key_pack(c, id);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -71,7 +73,7 @@ __device__ __forceinline__ void wave_list_insert(volatile uint64_t* list, uint32
         if (ok < mk || (ok == mk && op < mp)) { mk = ok; mp = op; }
     }
     wpos = mp;
-    thr = (mk == 0ull) ? -__builtin_huge_valf() : key_cos(mk);
+    thr = (mk == 0ull) ? floor : key_cos(mk);
 }
 
 // Bitonic sort, descending, of a[0..n) (n a power of two) by all threads of the block.
@@ -102,12 +104,26 @@ __device__ __forceinline__ bool row_is_dead(const uint32_t* dead, uint64_t row) 
 // J  = float4 chunks per lane per row (dim = 128*J);  U = row pairs in flight per wave
 // (a wave tile is 2U consecutive rows: half-wave h takes row 2u+h);  QT = queries scored
 // per pass from registers;  NT = non-temporal corpus loads.
-template <int J, int U, int QT, bool NT>
+//
+// Primed scans (large k).  A k=200 list costs ~450 cycles per insert (the 64-lane search for
+// the new worst slot) and a wave that sees 2,000 rows makes ~650 of them: 10 % of the scan.
+// Nearly all of those rows are nowhere near the global top-k.  PRIME = true is a cheap pass of
+// the SAME arithmetic over a prefix of the corpus that keeps one number per wave and query, the
+// best live cosine it saw; the waves' chunks are disjoint, so the k-th largest of those maxima
+// is attained by k different rows and is a lower bound of the corpus' k-th best cosine.  The
+// last block to finish selects it and writes floor_out[q] = the float just below it (rows
+// EQUAL to the bound must still pass the `>`; a bound in the denormal range becomes -FLT_MIN so
+// the test never depends on the denormal mode).  The full scan then starts every list with
+// thr = floor instead of -inf and inserts ~10 rows per wave instead of ~650; results are
+// bit-identical because only rows that cannot be among the best k are skipped.
+template <int J, int U, int QT, bool NT, bool PRIME = false>
 __global__ void __launch_bounds__(kBlock)
 scan_topk_kernel(const float* __restrict__ corpus, uint64_t n_rows,
                  const float* __restrict__ queries, uint32_t nq, uint32_t k, uint32_t kpad,
                  const uint32_t* __restrict__ dead, uint32_t id_base,
-                 uint64_t* __restrict__ partial) {
+                 uint64_t* __restrict__ partial, const float* __restrict__ floor_in,
+                 float* __restrict__ wave_max, uint32_t* __restrict__ done_ctr,
+                 float* __restrict__ floor_out) {
     extern __shared__ __attribute__((aligned(16))) uint64_t lds_keys[];  // [QT][kWaves][kpad]
     constexpr int DIM = 128 * J;
     const int tid = threadIdx.x;
@@ -137,10 +153,15 @@ scan_topk_kernel(const float* __restrict__ corpus, uint64_t n_rows,
         }
         qmag[qi] = sqrtf(half_allreduce_sum(s));
     }
-    float thr[QT];
+    float thr[QT], floor[QT];
     uint32_t wpos[QT];
 #pragma unroll
-    for (int qi = 0; qi < QT; ++qi) { thr[qi] = -__builtin_huge_valf(); wpos[qi] = 0; }
+    for (int qi = 0; qi < QT; ++qi) {
+        floor[qi] = (!PRIME && floor_in) ? floor_in[(q0 + qi < nq) ? (q0 + qi) : (nq - 1)]
+                                         : -__builtin_huge_valf();
+        thr[qi] = floor[qi];  // PRIME: the lane's running maximum
+        wpos[qi] = 0;
+    }
     __syncthreads();
 
     const uint64_t gw = (uint64_t)blockIdx.x * kWaves + wave;
@@ -190,6 +211,10 @@ scan_topk_kernel(const float* __restrict__ corpus, uint64_t n_rows,
                 const float d = half_allreduce_sum(dot[qi]);
                 // batch.rs:320-323: zero magnitude -> 0.0, else dot / (mag_a * mag_b)
                 const float c = (qmag[qi] == 0.0f || xmag == 0.0f) ? 0.0f : d / (qmag[qi] * xmag);
+                if constexpr (PRIME) {
+                    if (valid && c > thr[qi] && !row_is_dead(dead, r)) thr[qi] = c;
+                    continue;
+                }
                 unsigned long long m = __ballot(valid && l32 == 0 && c > thr[qi]);
                 if (m) {  // rare: wave-uniform slow path
                     volatile uint64_t* list = lds_keys + ((size_t)qi * kWaves + wave) * kpad;
@@ -200,11 +225,60 @@ scan_topk_kernel(const float* __restrict__ corpus, uint64_t n_rows,
                         const uint64_t rr = row0 + 2 * u + (src >> 5);
                         if (cc > thr[qi] && !row_is_dead(dead, rr))
                             wave_list_insert(list, k, lane, cc, id_base + (uint32_t)rr, thr[qi],
-                                             wpos[qi]);
+                                             wpos[qi], floor[qi]);
                     }
                 }
             }
         }
+    }
+    if constexpr (PRIME) {
+        // wave maxima -> HBM; the last block of this pass selects the k-th largest per query
+        const uint32_t nwaves = gridDim.x * kWaves;
+#pragma unroll
+        for (int qi = 0; qi < QT; ++qi) {
+            const float m = fmaxf(__shfl(thr[qi], 0, 64), __shfl(thr[qi], 32, 64));
+            if (lane == 0 && q0 + qi < nq)
+                __hip_atomic_store(wave_max + (size_t)(q0 + qi) * nwaves + gw, m, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __shared__ uint32_t is_last;
+        __threadfence();
+        __syncthreads();
+        if (tid == 0) {
+            const uint32_t prev = __hip_atomic_fetch_add(done_ctr + blockIdx.y, 1u, __ATOMIC_ACQ_REL,
+                                                         __HIP_MEMORY_SCOPE_AGENT);
+            is_last = (prev == gridDim.x - 1);
+        }
+        __syncthreads();
+        if (!is_last) return;
+        __threadfence();
+        uint32_t nsort = 64;
+        while (nsort < nwaves) nsort <<= 1;  // host keeps nsort <= kWaves * kpad (the LDS size)
+#pragma unroll 1
+        for (int qi = 0; qi < QT; ++qi) {
+            if (q0 + qi >= nq) break;
+            __syncthreads();
+            for (uint32_t i = tid; i < nsort; i += kBlock) {
+                float m = -__builtin_huge_valf();
+                if (i < nwaves)
+                    m = __hip_atomic_load(wave_max + (size_t)(q0 + qi) * nwaves + i, __ATOMIC_RELAXED,
+                                          __HIP_MEMORY_SCOPE_AGENT);
+                lds_keys[i] = (m == -__builtin_huge_valf()) ? 0ull : key_pack(m, 0u);
+            }
+            block_bitonic_desc<kBlock>(lds_keys, nsort, tid);
+            if (tid == 0) {
+                const uint64_t key = (k <= nsort) ? lds_keys[k - 1] : 0ull;
+                float t = -__builtin_huge_valf();
+                if (key) {
+                    const uint32_t o = (uint32_t)(key >> 32) - 1u;  // next float below the bound
+                    t = key_cos((uint64_t)o << 32);
+                    if (fabsf(t) < 1.17549435e-38f) t = -1.17549435e-38f;
+                }
+                floor_out[q0 + qi] = t;
+            }
+        }
+        if (tid == 0) __hip_atomic_store(done_ctr + blockIdx.y, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
     }
     __syncthreads();
 
@@ -373,38 +447,62 @@ ScanPlan plan_scan(uint64_t n_rows, uint32_t dim, uint32_t nq, uint32_t k, int n
     return p;
 }
 
+bool scan_prime_supported(uint32_t dim) { return fast_dim(dim); }
+
+// Prime pass geometry: one block per CU at most and never more waves than the LDS of the
+// selecting block holds keys (kWaves * kpad), so the k-th largest wave maximum exists.
+ScanPlan plan_prime(uint64_t sample_rows, uint32_t dim, uint32_t nq, uint32_t k, int num_cus) {
+    ScanPlan p = plan_scan(sample_rows, dim, nq, k, num_cus);
+    uint32_t cap = (uint32_t)num_cus;
+    if (cap > p.kpad) cap = p.kpad;  // waves = 4 * blocks <= 4 * kpad
+    if (p.blocks > cap) p.blocks = cap;
+    p.partial_keys = 0;
+    p.merge_keys = 0;
+    return p;
+}
+
 template <int J, int U, int QT>
 static void launch_fast(const ScanPlan& plan, const float* d_corpus, uint64_t n_rows,
                         const float* d_queries, uint32_t nq, uint32_t k, const uint32_t* d_dead,
-                        uint32_t id_base, uint64_t* d_partial, hipStream_t stream) {
+                        uint32_t id_base, uint64_t* d_partial, const ScanPrime* prime,
+                        bool prime_pass, hipStream_t stream) {
     const size_t lds = (size_t)QT * kWaves * plan.kpad * sizeof(uint64_t);
     dim3 grid(plan.blocks, plan.passes);
-    hipLaunchKernelGGL((scan_topk_kernel<J, U, QT, true>), grid, dim3(kBlock), lds, stream,
-                       d_corpus, n_rows, d_queries, nq, k, plan.kpad, d_dead, id_base, d_partial);
+    if (prime_pass)  // cached loads: the full scan re-reads these rows right after
+        hipLaunchKernelGGL((scan_topk_kernel<J, U, QT, false, true>), grid, dim3(kBlock), lds, stream,
+                           d_corpus, n_rows, d_queries, nq, k, plan.kpad, d_dead, id_base, nullptr,
+                           nullptr, prime->d_wave_max, prime->d_done, prime->d_floor);
+    else
+        hipLaunchKernelGGL((scan_topk_kernel<J, U, QT, true>), grid, dim3(kBlock), lds, stream,
+                           d_corpus, n_rows, d_queries, nq, k, plan.kpad, d_dead, id_base, d_partial,
+                           prime ? prime->d_floor : nullptr, nullptr, nullptr, nullptr);
 }
 
 template <int J, int U>
 static void launch_fast_q(const ScanPlan& plan, const float* d_corpus, uint64_t n_rows,
                           const float* d_queries, uint32_t nq, uint32_t k,
                           const uint32_t* d_dead, uint32_t id_base, uint64_t* d_partial,
-                          hipStream_t stream) {
+                          const ScanPrime* prime, bool prime_pass, hipStream_t stream) {
     switch (plan.qtile) {
-        case 4: launch_fast<J, U, 4>(plan, d_corpus, n_rows, d_queries, nq, k, d_dead, id_base, d_partial, stream); break;
-        case 2: launch_fast<J, U, 2>(plan, d_corpus, n_rows, d_queries, nq, k, d_dead, id_base, d_partial, stream); break;
-        default: launch_fast<J, U, 1>(plan, d_corpus, n_rows, d_queries, nq, k, d_dead, id_base, d_partial, stream); break;
+        case 4: launch_fast<J, U, 4>(plan, d_corpus, n_rows, d_queries, nq, k, d_dead, id_base, d_partial, prime, prime_pass, stream); break;
+        case 2: launch_fast<J, U, 2>(plan, d_corpus, n_rows, d_queries, nq, k, d_dead, id_base, d_partial, prime, prime_pass, stream); break;
+        default: launch_fast<J, U, 1>(plan, d_corpus, n_rows, d_queries, nq, k, d_dead, id_base, d_partial, prime, prime_pass, stream); break;
     }
 }
 
 int32_t launch_scan(const ScanPlan& plan, const float* d_corpus, uint64_t n_rows, uint32_t dim,
                     const float* d_queries, uint32_t nq, uint32_t k, const uint32_t* d_dead,
-                    uint32_t id_base, uint64_t* d_partial, hipStream_t stream) {
+                    uint32_t id_base, uint64_t* d_partial, hipStream_t stream,
+                    const ScanPrime* prime, bool prime_pass) {
+    if (prime_pass && (!prime || !fast_dim(dim) || n_rows == 0))
+        return fail(CS_ERR_BAD_ARG, "prime pass needs a 384/768/1024-d corpus prefix and its buffers");
     if (n_rows == 0) {  // nothing to score: all-empty partial lists
         CS_HIP(hipMemsetAsync(d_partial, 0, plan.partial_keys * sizeof(uint64_t), stream));
         return CS_OK;
     }
-    if (dim == 384) launch_fast_q<3, 4>(plan, d_corpus, n_rows, d_queries, nq, k, d_dead, id_base, d_partial, stream);
-    else if (dim == 768) launch_fast_q<6, 2>(plan, d_corpus, n_rows, d_queries, nq, k, d_dead, id_base, d_partial, stream);
-    else if (dim == 1024) launch_fast_q<8, 2>(plan, d_corpus, n_rows, d_queries, nq, k, d_dead, id_base, d_partial, stream);
+    if (dim == 384) launch_fast_q<3, 4>(plan, d_corpus, n_rows, d_queries, nq, k, d_dead, id_base, d_partial, prime, prime_pass, stream);
+    else if (dim == 768) launch_fast_q<6, 2>(plan, d_corpus, n_rows, d_queries, nq, k, d_dead, id_base, d_partial, prime, prime_pass, stream);
+    else if (dim == 1024) launch_fast_q<8, 2>(plan, d_corpus, n_rows, d_queries, nq, k, d_dead, id_base, d_partial, prime, prime_pass, stream);
     else {
         const size_t lds = (size_t)kWaves * plan.kpad * sizeof(uint64_t);
         hipLaunchKernelGGL(scan_topk_generic_kernel, dim3(plan.blocks, nq), dim3(kBlock), lds,

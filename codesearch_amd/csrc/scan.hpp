@@ -17,11 +17,24 @@ struct ScanPlan {
 // Geometry for a search of nq queries / top-k over n_rows rows of `dim` floats.
 ScanPlan plan_scan(uint64_t n_rows, uint32_t dim, uint32_t nq, uint32_t k, int num_cus);
 
+// Buffers of a primed scan (scan.hip, PRIME mode): a pass over a corpus prefix leaves in
+// d_floor[q] a lower bound of query q's k-th best cosine, which the full scan starts from.
+struct ScanPrime {
+    float* d_wave_max = nullptr;  // [nq][4 * plan_prime().blocks]
+    uint32_t* d_done = nullptr;   // [passes], zero between launches
+    float* d_floor = nullptr;     // [nq]
+};
+bool scan_prime_supported(uint32_t dim);
+ScanPlan plan_prime(uint64_t sample_rows, uint32_t dim, uint32_t nq, uint32_t k, int num_cus);
+
 // Scores every live row of corpus[0..n_rows) against each query and leaves, per
 // (query, block), the block's best k as packed keys in d_partial[q][block][k].
+// prime + prime_pass: run the prime pass over these rows instead (plan from plan_prime, no
+// partial lists written);  prime alone: start the lists from prime->d_floor.
 int32_t launch_scan(const ScanPlan& plan, const float* d_corpus, uint64_t n_rows, uint32_t dim,
                     const float* d_queries, uint32_t nq, uint32_t k, const uint32_t* d_dead,
-                    uint32_t id_base, uint64_t* d_partial, hipStream_t stream);
+                    uint32_t id_base, uint64_t* d_partial, hipStream_t stream,
+                    const ScanPrime* prime = nullptr, bool prime_pass = false);
 
 // Reduces nlists lists of k keys per query ([nq][nlists][k], or [nlists][nq][k] when
 // list_major) to the best k per query,

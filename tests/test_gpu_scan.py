@@ -523,3 +523,47 @@ def test_single_query_through_filter_is_bit_identical(VS):
         c1, i1, n1 = st.search_raw(q, k)
         assert n1[0] == n0[0] and i1.tolist() == i0.tolist() and c1.tobytes() == c0.tobytes()
     assert st.debug_counters() == (5, 0)
+
+
+@pytest.mark.parametrize("dim", [384, 768, 1024])
+def test_primed_scan_is_bit_identical(VS, oracle, dim, monkeypatch):
+    """Large-k streaming scans start from a lower bound of the k-th best cosine taken from a
+    pass over a corpus prefix (scan.hip, PRIME mode).  Forced on at test sizes; must equal the
+    unprimed scan bit for bit — ties at the bound, a bound of exactly 0 (zero rows), tombstones
+    inside the sample, and samples with fewer than k waves (no bound) included."""
+    n = 12000
+    rows = synth_rows(77, 0, n, dim)
+    rows[5] = rows[2]; rows[900] = rows[2]; rows[4000] = rows[2] * 3.0   # exact ties, in and out of the sample
+    rows[10:200] = 0.0                                                    # cosine exactly 0 inside the sample
+    rows[3000:3300] = 0.0
+    rows[300:2400:7] = 0.0
+    qs = np.stack([rows[2], synth_rows(78, 0, 1, dim)[0], -rows[2], synth_rows(78, 5, 1, dim)[0]])
+
+    def run(primed):
+        monkeypatch.setenv("CS_INDEX_SPLIT", "0")          # 2..4 queries stay on the streaming scan
+        monkeypatch.setenv("CS_SCAN_PRIME_MIN_K", "1" if primed else "0")
+        monkeypatch.setenv("CS_SCAN_PRIME_MIN_ROWS", "1")
+        monkeypatch.setenv("CS_SCAN_PRIME_ROWS", "2400")
+        st = VS(None, dim)
+        st.insert_embeddings(rows)
+        st.build_index()
+        out = []
+        for dead in (False, True):
+            if dead:
+                assert st.delete_chunks(list(range(0, 120)) + [900, 5000]) == 122
+                st.build_index()
+            for k in (1, 10, 64, 200, 256):
+                for nq in (1, 2, 4):
+                    out.append((k, nq, dead) + tuple(st.search_raw(qs[:nq], k)))
+        return out
+
+    got, want = run(True), run(False)
+    for (k, nq, dead, c1, i1, n1), (_, _, _, c0, i0, n0) in zip(got, want):
+        assert n1.tolist() == n0.tolist(), (k, nq, dead)
+        assert i1.tolist() == i0.tolist(), (k, nq, dead)
+        assert c1.tobytes() == c0.tobytes(), (k, nq, dead)
+    # and the unprimed result is the oracle's
+    k, nq, dead, c0, i0, _ = want[3 * 3]  # k=200, nq=1, no tombstones
+    assert (k, nq, dead) == (200, 1, False)
+    ecos, eids = oracle.scan_topk(rows, qs[0], 200, mode="omp")
+    assert_topk_equal(c0[0], i0[0], ecos, eids, rows, qs[0], oracle)
