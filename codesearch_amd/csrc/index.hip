@@ -98,7 +98,7 @@ struct Workspace {
             if (bs.d_cnt) (void)hipFree(bs.d_cnt);
             if (bs.d_tau) (void)hipFree(bs.d_tau);
             bs.d_cnt = nullptr; bs.d_tau = nullptr; bs_nq = 0;
-            CS_HIP(hipMalloc(&bs.d_cnt, nq * sizeof(uint32_t)));
+            CS_HIP(hipMalloc(&bs.d_cnt, (size_t)nq * kCntStride * sizeof(uint32_t)));
             CS_HIP(hipMalloc(&bs.d_tau, nq * sizeof(float)));
             bs_nq = nq;
         }

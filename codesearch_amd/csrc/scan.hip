@@ -77,11 +77,23 @@ __device__ __forceinline__ void wave_list_insert(volatile uint64_t* list, uint32
 }
 
 // Bitonic sort, descending, of a[0..n) (n a power of two) by all threads of the block.
+// Pair t of a stage is handled by thread t % T, i.e. by wave (t / 64) % (T / 64), and for strides
+// <= 64 it lies inside the 128-key segment [128 (t / 64), +128): such a stage reads only what the
+// same wave wrote in the stage before, so it needs the wave's own LDS ordering, not a block
+// barrier.  Only stages with stride >= 128, and the stage right after one, synchronise the block
+// (20 of the 78 stages of a 4096-key sort).
 template <int T>
 __device__ __forceinline__ void block_bitonic_desc(uint64_t* a, uint32_t n, int tid) {
+    uint32_t prev_stride = 128;  // whatever filled a[] was another wave
     for (uint32_t size = 2; size <= n; size <<= 1) {
         for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
-            __syncthreads();
+            if (stride >= 128 || prev_stride >= 128) {
+                __syncthreads();
+            } else {
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+            prev_stride = stride;
             for (uint32_t t = tid; t < (n >> 1); t += T) {
                 uint32_t i = 2 * t - (t & (stride - 1));
                 uint32_t j = i + stride;

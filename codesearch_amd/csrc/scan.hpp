@@ -50,13 +50,22 @@ int32_t launch_synth_fill(float* d_rows, uint64_t n, uint32_t dim, uint64_t seed
                           uint64_t first_row, hipStream_t stream);
 
 // ---- batched-query (MFMA) path, scan_mfma.hip ---------------------------------------------
+// Candidate counters sit one per 128-byte line: appends are device-scope atomics, and ops on one
+// line serialise at ~40 ns apiece whichever word they hit (measured: nine queries' counters in one
+// line made the k=200 filter phases 50-190 us longer).
+constexpr uint32_t kCntStride = 32;
 struct BatchedState {
     uint64_t* d_cand = nullptr;   // [nq][cap] candidate keys
-    uint32_t* d_cnt = nullptr;    // [nq]
+    uint32_t* d_cnt = nullptr;    // [nq][kCntStride], word 0 of each line used
     float* d_tau = nullptr;       // [nq]
     uint64_t* d_carry = nullptr;  // [nq][k]
     uint32_t* d_overflow = nullptr;
 };
+// One block per query folds st.d_cand[q][0..cnt[q]) (packed keys) into st.d_carry[q][k], sets
+// tau[q] to the k-th best cosine and resets cnt[q]; with `last` it also writes the outputs.
+int32_t launch_select_candidates(const BatchedState& st, uint32_t nq, uint32_t cap, uint32_t k, bool last,
+                                 uint64_t* d_out_keys, float* d_out_cos, uint32_t* d_out_ids,
+                                 uint32_t* d_out_counts, hipStream_t stream);
 bool batched_supported(uint32_t dim);
 uint32_t batched_cap(uint32_t k);
 int32_t launch_row_norms(const float* d_corpus, uint64_t first, uint64_t n, uint32_t dim,

@@ -8,10 +8,11 @@
 //            the cosine to within kFilterMargin whatever the rows' magnitudes.  An element within
 //            the margin of the query's running k-th best (tau) is appended, as a row index, to that
 //            query's candidate buffer.
-//   refine   rescore_select_kernel: every candidate is re-scored from the f32 corpus row with the
+//   refine   rescore_keys_kernel: every candidate is re-scored from the f32 corpus row with the
 //            arithmetic of the single-query scan (scan.hip: 32 lanes x float4 partial fmaf
-//            chains, half-wave butterfly, correctly rounded sqrt and divide) and folded into the
-//            running best-k; tau becomes the exact k-th best of the rows scanned so far.
+//            chains, half-wave butterfly, correctly rounded sqrt and divide), a query's rows spread
+//            over up to 32 CUs;  select_candidates_kernel (scan_mfma.hip) folds the keys into the
+//            running best-k, and tau becomes the exact k-th best of the rows scanned so far.
 //
 // Layout of the filter copy: 128-row tiles, chunk-major inside a tile — [tile][k-chunk of 64][row][128 B]
 // — so the 16 KB a stage needs (one k-chunk of 128 rows) and the 96 KB of a whole tile are
@@ -38,8 +39,6 @@ namespace cs {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr float kFilterMargin = 2.6e-3f;  // cosine units; bound derived in the header comment
-constexpr int RS_THREADS = 1024;
-constexpr int RS_CAP = 2048;
 
 __device__ __forceinline__ float half_sum_s(float v) {
     v += __shfl_xor(v, 16, 64);
@@ -201,8 +200,8 @@ score_filter_kernel(const _Float16* __restrict__ corpus_h, uint64_t row_lo, uint
                 if (qok && m < M && !(acc[i][j][r] <= tq)) {  // rare, divergent, short
                     const uint64_t row = row_lo + m;
                     if (!dead || !((dead[row >> 5] >> (row & 31)) & 1u)) {
-                        const uint32_t pos = atomicAdd(&cnt[q], 1u);
-                        if (pos < cap) cand[(size_t)q * cap + pos] = (uint32_t)row;
+                        const uint32_t pos = atomicAdd(&cnt[(size_t)q * kCntStride], 1u);
+                        if (pos < cap) cand[2 * ((size_t)q * cap + pos)] = (uint32_t)row;  // low word of the 8-byte slot
                     }
                 }
             }
@@ -370,8 +369,8 @@ score_filter256_kernel(const _Float16* __restrict__ corpus_h, uint64_t row_lo, u
                 if (qok && m < M && !(acc[i][j][r] <= tq)) {
                     const uint64_t row = row_lo + m;
                     if (!dead || !((dead[row >> 5] >> (row & 31)) & 1u)) {
-                        const uint32_t pos = atomicAdd(&cnt[q], 1u);
-                        if (pos < cap) cand[(size_t)q * cap + pos] = (uint32_t)row;
+                        const uint32_t pos = atomicAdd(&cnt[(size_t)q * kCntStride], 1u);
+                        if (pos < cap) cand[2 * ((size_t)q * cap + pos)] = (uint32_t)row;  // low word of the 8-byte slot
                     }
                 }
             }
@@ -559,8 +558,8 @@ score_filter256p_kernel(const _Float16* __restrict__ corpus_h, uint64_t row_lo, 
                     if (qok && m < M && !(acc[i][j][r] <= tq)) {
                         const uint64_t row = row_lo + m;
                         if (!dead || !((dead[row >> 5] >> (row & 31)) & 1u)) {
-                            const uint32_t pos = atomicAdd(&cnt[q], 1u);
-                            if (pos < cap) cand[(size_t)q * cap + pos] = (uint32_t)row;
+                            const uint32_t pos = atomicAdd(&cnt[(size_t)q * kCntStride], 1u);
+                            if (pos < cap) cand[2 * ((size_t)q * cap + pos)] = (uint32_t)row;  // low word of the 8-byte slot
                         }
                     }
                 }
@@ -726,8 +725,8 @@ score_filter_rw_kernel(const _Float16* __restrict__ corpus_h, uint64_t row_lo, u
                     const uint64_t row = row_lo + m;
                     if (!dead || !((dead[row >> 5] >> (row & 31)) & 1u)) {
                         const uint32_t q = q0 + 32 * t + l31;
-                        const uint32_t pos = atomicAdd(&cnt[q], 1u);
-                        if (pos < cap) cand[(size_t)q * cap + pos] = (uint32_t)row;
+                        const uint32_t pos = atomicAdd(&cnt[(size_t)q * kCntStride], 1u);
+                        if (pos < cap) cand[2 * ((size_t)q * cap + pos)] = (uint32_t)row;  // low word of the 8-byte slot
                     }
                 }
             }
@@ -735,28 +734,28 @@ score_filter_rw_kernel(const _Float16* __restrict__ corpus_h, uint64_t row_lo, u
     }
 }
 
-// One block per query: exact cosines of its candidates (one half-wave per row, the layout and
-// operation order of scan_topk_kernel), folded into carry[q][k]; tau[q] = exact k-th best.
+// Refine, step 1: exact cosines of the candidates, in place.  A candidate is an 8-byte slot of
+// cand[q][cap] whose low word the filter set to the row number; this kernel overwrites the slot
+// with the packed (cosine, id) key (0 for a NaN/Inf score), one half-wave per row with the layout
+// and operation order of scan_topk_kernel.  Step 2 is select_candidates_kernel (scan_mfma.hip).
+// The rows of ONE query are spread over gridDim.x blocks: a CU pulls ~50 GB/s of scattered 1.5-KB
+// rows, so the ~500 candidates a k = 200 phase brings per query took 32 us on one CU (9 queries:
+// 9 CUs busy, 247 idle) and take ~3 us on 32.
+constexpr int RK_THREADS = 256;
 template <int J>
-__global__ void __launch_bounds__(RS_THREADS)
-rescore_select_kernel(const float* __restrict__ corpus, const float* __restrict__ queries,
-                      const float* __restrict__ qmag, const uint32_t* __restrict__ cand,
-                      uint32_t* __restrict__ cnt, uint32_t cap, uint32_t k, uint32_t id_base,
-                      uint64_t* __restrict__ carry, float* __restrict__ tau,
-                      uint32_t* __restrict__ overflow, int final_out, uint64_t* __restrict__ out_keys,
-                      float* __restrict__ out_cos, uint32_t* __restrict__ out_ids,
-                      uint32_t* __restrict__ out_counts) {
+__global__ void __launch_bounds__(RK_THREADS)
+rescore_keys_kernel(const float* __restrict__ corpus, const float* __restrict__ queries,
+                    const float* __restrict__ qmag, uint64_t* __restrict__ cand,
+                    const uint32_t* __restrict__ cnt, uint32_t cap, uint32_t id_base) {
     constexpr int DIM = 128 * J;
-    __shared__ __attribute__((aligned(16))) uint64_t a[RS_CAP];
-    __shared__ uint32_t live;
-    const int tid = threadIdx.x, lane = tid & 63, l32 = lane & 31;
-    const uint32_t hw = tid >> 5;  // half-wave index, 0..31
-    const uint32_t q = blockIdx.x;
-    uint32_t n = cnt[q];
-    if (n > cap) {
-        if (tid == 0) atomicOr(overflow, 1u);
-        n = cap;
-    }
+    constexpr int RU = J <= 3 ? 4 : 2;          // rows per half-wave per round, loads issued together
+    constexpr int PER = RU * (RK_THREADS / 32);  // candidates per block per round
+    const int tid = threadIdx.x, l32 = tid & 31;
+    const uint32_t hw = tid >> 5;
+    const uint32_t q = blockIdx.y;
+    uint32_t n = cnt[(size_t)q * kCntStride];
+    if (n > cap) n = cap;  // select_candidates_kernel raises the overflow flag
+    if (blockIdx.x * PER >= n) return;
     f32x4 qf[J];
     {
         const f32x4* qp = reinterpret_cast<const f32x4*>(queries + (size_t)q * DIM) + l32;
@@ -764,77 +763,51 @@ rescore_select_kernel(const float* __restrict__ corpus, const float* __restrict_
         for (int j = 0; j < J; ++j) qf[j] = qp[j * 32];
     }
     const float qm = qmag[q];
-    const uint32_t* src = cand + (size_t)q * cap;
-    for (uint32_t i = tid; i < RS_CAP; i += RS_THREADS) a[i] = (i < k) ? carry[(size_t)q * k + i] : 0ull;
-    if (tid == 0) live = 0;
-    __syncthreads();
-    const uint32_t room = RS_CAP - k;
-    for (uint32_t done = 0; done < n || done == 0; done += room) {
-        const uint32_t take = (n - done) < room ? (n - done) : room;
-        uint32_t fill = 64;  // slots [k, fill) must hold this chunk's keys or zeros (fill = the sort size)
-        while (fill < k + take) fill <<= 1;
-        for (uint32_t i0 = 0; i0 + k < fill; i0 += RS_THREADS / 32) {  // one candidate per half-wave per round
-            const uint32_t i = i0 + hw;
-            uint64_t key = 0ull;
-            if (i < take) {  // half-wave uniform (xor masks <= 16 stay inside the half)
-                const uint32_t row = src[done + i];
-                const f32x4* p = reinterpret_cast<const f32x4*>(corpus + (size_t)row * DIM) + l32;
+    uint64_t* slots = cand + (size_t)q * cap;
+    for (uint32_t i0 = blockIdx.x * PER; i0 < n; i0 += gridDim.x * PER) {
+        f32x4 v[RU][J];
+        uint32_t row[RU];
+#pragma unroll
+        for (int u = 0; u < RU; ++u) {
+            const uint32_t i = i0 + u * (RK_THREADS / 32) + hw;  // half-wave uniform
+            row[u] = (i < n) ? (uint32_t)slots[i] : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < RU; ++u) {
+            const uint32_t i = i0 + u * (RK_THREADS / 32) + hw;
+            if (i < n) {
+                const f32x4* p = reinterpret_cast<const f32x4*>(corpus + (size_t)row[u] * DIM) + l32;
+#pragma unroll
+                for (int j = 0; j < J; ++j) v[u][j] = p[j * 32];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < RU; ++u) {
+            const uint32_t i = i0 + u * (RK_THREADS / 32) + hw;
+            if (i < n) {  // xor masks <= 16 stay inside the half-wave
                 float ss = 0.0f, dot = 0.0f;
 #pragma unroll
                 for (int j = 0; j < J; ++j) {
-                    const f32x4 v = p[j * 32];
-                    ss = fmaf(v.x, v.x, ss); ss = fmaf(v.y, v.y, ss);
-                    ss = fmaf(v.z, v.z, ss); ss = fmaf(v.w, v.w, ss);
-                    dot = fmaf(v.x, qf[j].x, dot); dot = fmaf(v.y, qf[j].y, dot);
-                    dot = fmaf(v.z, qf[j].z, dot); dot = fmaf(v.w, qf[j].w, dot);
+                    ss = fmaf(v[u][j].x, v[u][j].x, ss); ss = fmaf(v[u][j].y, v[u][j].y, ss);
+                    ss = fmaf(v[u][j].z, v[u][j].z, ss); ss = fmaf(v[u][j].w, v[u][j].w, ss);
+                    dot = fmaf(v[u][j].x, qf[j].x, dot); dot = fmaf(v[u][j].y, qf[j].y, dot);
+                    dot = fmaf(v[u][j].z, qf[j].z, dot); dot = fmaf(v[u][j].w, qf[j].w, dot);
                 }
                 const float xmag = sqrtf(half_sum_s(ss));
                 const float d = half_sum_s(dot);
                 const float c = (qm == 0.0f || xmag == 0.0f) ? 0.0f : d / (qm * xmag);  // batch.rs:320-323
                 // NaN/Inf scores are never returned
-                key = (c > -__builtin_huge_valf() && c < __builtin_huge_valf()) ? key_pack(c, id_base + row) : 0ull;
+                if (l32 == 0)
+                    slots[i] = (c > -__builtin_huge_valf() && c < __builtin_huge_valf()) ? key_pack(c, id_base + row[u]) : 0ull;
             }
-            if (k + i < fill && l32 == 0) a[k + i] = key;  // slots past `take` are cleared
-        }
-        // bitonic sort, descending, of the live prefix (k carried + `take` new keys, padded with the
-        // zero keys already there to a power of two): a few dozen candidates sort in 64..256 slots
-        uint32_t nsort = 64;
-        while (nsort < k + take) nsort <<= 1;
-        for (uint32_t size = 2; size <= nsort; size <<= 1)
-            for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
-                __syncthreads();
-                for (uint32_t t = tid; t < nsort / 2; t += RS_THREADS) {
-                    const uint32_t i = 2 * t - (t & (stride - 1)), jx = i + stride;
-                    const uint64_t x = a[i], y = a[jx];
-                    if ((x < y) == ((i & size) == 0)) { a[i] = y; a[jx] = x; }
-                }
-            }
-        __syncthreads();
-        if (n == 0) break;
-    }
-    for (uint32_t i = tid; i < k; i += RS_THREADS) {
-        const uint64_t key = a[i];
-        carry[(size_t)q * k + i] = key;
-        if (final_out) {
-            if (key) atomicAdd(&live, 1u);
-            if (out_keys) out_keys[(size_t)q * k + i] = key;
-            if (out_cos) out_cos[(size_t)q * k + i] = key ? key_cos(key) : 0.0f;
-            if (out_ids) out_ids[(size_t)q * k + i] = key ? key_id(key) : 0xffffffffu;
         }
     }
-    if (tid == 0) {
-        const uint64_t kth = a[k - 1];
-        tau[q] = kth ? key_cos(kth) : -__builtin_huge_valf();
-        cnt[q] = 0;
-    }
-    __syncthreads();
-    if (final_out && out_counts && tid == 0) out_counts[q] = live;
 }
 
 __global__ void init_split_state_kernel(float* tau, uint32_t* cnt, uint64_t* carry, uint32_t nq, uint32_t k,
                                         uint32_t* overflow) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < nq) { tau[i] = -__builtin_huge_valf(); cnt[i] = 0; }
+    if (i < nq) { tau[i] = -__builtin_huge_valf(); cnt[(size_t)i * kCntStride] = 0; }
     if (i < nq * k) carry[i] = 0ull;
     if (i == 0) *overflow = 0;
 }
@@ -908,6 +881,7 @@ static int32_t scan_split_impl(const BatchedState& st, const SplitQueryWs& qw, c
     // resident-query kernel: up to 64 queries always; above that when CS_FILTER_RW=2 (128-query tiles)
     const bool small = rw_mode && dim == 384 && (nq <= 64 || (rw_mode >= 2 && (nq + 127) / 128 <= 32));
 
+    const uint32_t rk_blocks = nq >= 256 ? 2 : nq >= 16 ? 512 / nq : 32;
     uint64_t done = 0;
     uint64_t phase = n_rows < 1024 ? n_rows : 1024;  // phase 0: tau = -inf, every row is a candidate
     // A phase over (growth - 1) x the rows scanned so far yields about k (growth - 1) candidates per
@@ -989,10 +963,11 @@ static int32_t scan_split_impl(const BatchedState& st, const SplitQueryWs& qw, c
         }
         done = hi;
         const bool last = done >= n_rows;
-        hipLaunchKernelGGL(rescore_select_kernel<J>, dim3(nq), dim3(RS_THREADS), 0, stream, d_corpus, d_queries,
-                           qw.d_qmag, cand, st.d_cnt, cap, k, id_base, st.d_carry, st.d_tau, st.d_overflow,
-                           last ? 1 : 0, d_out_keys, d_out_cos, d_out_ids, d_out_counts);
+        // refine: exact keys in place (each query's rows spread over rk_blocks CUs), then the select
+        hipLaunchKernelGGL(rescore_keys_kernel<J>, dim3(rk_blocks, nq), dim3(RK_THREADS), 0, stream, d_corpus, d_queries,
+                           qw.d_qmag, st.d_cand, st.d_cnt, cap, id_base);
         CS_HIP(hipGetLastError());
+        CS_TRY(launch_select_candidates(st, nq, cap, k, last, d_out_keys, d_out_cos, d_out_ids, d_out_counts, stream));
         phase = done * growth;
         if (phase > n_rows - done) phase = n_rows - done;
     } while (done < n_rows);

@@ -185,7 +185,7 @@ score_append_kernel(const float* __restrict__ corpus, const float* __restrict__ 
                 const float c = (qmag[t] == 0.0f || xm[r] == 0.0f) ? 0.0f : acc[t][r] / (qmag[t] * xm[r]);
                 if (c > thr[t] && row < row_hi) {  // rare, divergent, short
                     if (!dead || !((dead[row >> 5] >> (row & 31)) & 1u)) {
-                        const uint32_t pos = atomicAdd(&cnt[q], 1u);
+                        const uint32_t pos = atomicAdd(&cnt[(size_t)q * kCntStride], 1u);
                         if (pos < cap) cand[(size_t)q * cap + pos] = key_pack(c, id_base + (uint32_t)row);
                     }
                 }
@@ -209,7 +209,7 @@ select_candidates_kernel(const uint64_t* __restrict__ cand, uint32_t* __restrict
     __shared__ uint32_t live;
     const int tid = threadIdx.x;
     const uint32_t q = blockIdx.x;
-    uint32_t n = cnt[q];
+    uint32_t n = cnt[(size_t)q * kCntStride];
     if (n > cap) {
         if (tid == 0) atomicOr(overflow, 1u);
         n = cap;
@@ -221,12 +221,22 @@ select_candidates_kernel(const uint64_t* __restrict__ cand, uint32_t* __restrict
     const uint32_t room = MB_SEL_CAP - k;
     for (uint32_t done = 0; done < n || done == 0; done += room) {
         const uint32_t take = (n - done) < room ? (n - done) : room;
-        for (uint32_t i = tid; i < room; i += MB_SEL_THREADS) a[k + i] = (i < take) ? src[done + i] : 0ull;
-        // bitonic sort, descending, of the 2048 slots
-        for (uint32_t size = 2; size <= MB_SEL_CAP; size <<= 1)
+        // sort size: the k carried keys + this chunk, padded with zero keys to a power of two (a few
+        // dozen candidates sort in 64..256 slots, a k = 200 phase in 1024)
+        uint32_t nsort = 64;
+        while (nsort < k + take) nsort <<= 1;
+        for (uint32_t i = tid; k + i < nsort; i += MB_SEL_THREADS) a[k + i] = (i < take) ? src[done + i] : 0ull;
+        uint32_t prev_stride = 128;  // block barrier only around cross-segment stages (block_bitonic_desc, scan.hip)
+        for (uint32_t size = 2; size <= nsort; size <<= 1)
             for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
-                __syncthreads();
-                for (uint32_t t = tid; t < MB_SEL_CAP / 2; t += MB_SEL_THREADS) {
+                if (stride >= 128 || prev_stride >= 128) {
+                    __syncthreads();
+                } else {
+                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                }
+                prev_stride = stride;
+                for (uint32_t t = tid; t < nsort / 2; t += MB_SEL_THREADS) {
                     const uint32_t i = 2 * t - (t & (stride - 1)), j = i + stride;
                     const uint64_t x = a[i], y = a[j];
                     if ((x < y) == ((i & size) == 0)) { a[i] = y; a[j] = x; }
@@ -248,16 +258,26 @@ select_candidates_kernel(const uint64_t* __restrict__ cand, uint32_t* __restrict
     if (tid == 0) {
         const uint64_t kth = a[k - 1];
         tau[q] = kth ? key_cos(kth) : -__builtin_huge_valf();
-        cnt[q] = 0;
+        cnt[(size_t)q * kCntStride] = 0;
     }
     __syncthreads();
     if (final_out && out_counts && tid == 0) out_counts[q] = live;
 }
 
+int32_t launch_select_candidates(const BatchedState& st, uint32_t nq, uint32_t cap, uint32_t k, bool last,
+                                 uint64_t* d_out_keys, float* d_out_cos, uint32_t* d_out_ids,
+                                 uint32_t* d_out_counts, hipStream_t stream) {
+    hipLaunchKernelGGL(select_candidates_kernel, dim3(nq), dim3(MB_SEL_THREADS), 0, stream, st.d_cand, st.d_cnt,
+                       cap, k, st.d_carry, st.d_tau, st.d_overflow, last ? 1 : 0, d_out_keys, d_out_cos, d_out_ids,
+                       d_out_counts);
+    CS_HIP(hipGetLastError());
+    return CS_OK;
+}
+
 __global__ void init_batched_state_kernel(float* tau, uint32_t* cnt, uint64_t* carry, uint32_t nq,
                                           uint32_t k, uint32_t* overflow) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < nq) { tau[i] = -__builtin_huge_valf(); cnt[i] = 0; }
+    if (i < nq) { tau[i] = -__builtin_huge_valf(); cnt[(size_t)i * kCntStride] = 0; }
     if (i < nq * k) carry[i] = 0ull;
     if (i == 0) *overflow = 0;
 }
@@ -339,10 +359,7 @@ int32_t launch_scan_batched(const BatchedState& st, const float* d_corpus, const
         }
         done = hi;
         const bool last = done >= n_rows;
-        hipLaunchKernelGGL(select_candidates_kernel, dim3(nq), dim3(MB_SEL_THREADS), 0, stream, st.d_cand,
-                           st.d_cnt, cap, k, st.d_carry, st.d_tau, st.d_overflow, last ? 1 : 0, d_out_keys,
-                           d_out_cos, d_out_ids, d_out_counts);
-        CS_HIP(hipGetLastError());
+        CS_TRY(launch_select_candidates(st, nq, cap, k, last, d_out_keys, d_out_cos, d_out_ids, d_out_counts, stream));
         phase = done * growth;
         if (phase > n_rows - done) phase = n_rows - done;
     } while (done < n_rows);
