@@ -591,6 +591,8 @@ struct RwGeom {
     static constexpr int WBYTES = QROWS * 768;                 // 6 chunks x QROWS x 128 B (dim 384)
     static constexpr int R = NQT == 1 ? 8 : NQT == 2 ? 6 : 3;  // ring slots (16 KiB each, 4 KiB per wave)
     static constexpr int LDS = WBYTES + R * 16384;             // 155,648 / 147,456 / 147,456 B
+    static constexpr int PEND = 128;                           // pending candidates per wave (8 B each)
+    static constexpr int LDS_ALL = LDS + 4 * PEND * 8;         // + 4 KiB
 };
 
 template <int N>
@@ -685,6 +687,23 @@ score_filter_rw_kernel(const _Float16* __restrict__ corpus_h, uint64_t row_lo, u
     for (int p = 0; p < R - 1; ++p)
         if (gi < nstage) issue_next();
 
+    // this wave's pending candidates: (query << 32 | row), appended by flush()
+    volatile uint64_t* pend = reinterpret_cast<volatile uint64_t*>(lds + G::LDS) + wave * G::PEND;
+    uint32_t npend = 0;  // wave-uniform
+    auto flush = [&]() {
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (uint32_t i = lane; i < npend; i += 64) {
+            const uint64_t e = pend[i];
+            const uint32_t q = (uint32_t)(e >> 32);
+            const uint32_t pos = atomicAdd(&cnt[(size_t)q * kCntStride], 1u);
+            if (pos < cap) cand[2 * ((size_t)q * cap + pos)] = (uint32_t)e;  // low word of the 8-byte slot
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        npend = 0;
+    };
+
     sh_f32x16 acc[NQT];
     int c_slot = 0;  // ring slot of the stage being consumed
     for (uint64_t n = 0; n < my_tiles; ++n) {
@@ -716,22 +735,32 @@ score_filter_rw_kernel(const _Float16* __restrict__ corpus_h, uint64_t row_lo, u
                 }
             }
         }
+        // Candidates are parked in the wave's LDS list and appended in batches: the append is a
+        // device-scope atomic WITH return (~2 us round trip during which the wave issues no corpus
+        // loads), and at k = 200 one tile in ten holds a candidate — one stall per batch, not per row.
 #pragma unroll
         for (int t = 0; t < NQT; ++t) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const uint64_t m = tile * 128 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (qok[t] && m < M && !(acc[t][r] <= tq[t])) {  // rare, divergent, short
-                    const uint64_t row = row_lo + m;
-                    if (!dead || !((dead[row >> 5] >> (row & 31)) & 1u)) {
-                        const uint32_t q = q0 + 32 * t + l31;
-                        const uint32_t pos = atomicAdd(&cnt[(size_t)q * kCntStride], 1u);
-                        if (pos < cap) cand[2 * ((size_t)q * cap + pos)] = (uint32_t)row;  // low word of the 8-byte slot
+                const uint64_t row = row_lo + m;
+                bool hit = qok[t] && m < M && !(acc[t][r] <= tq[t]);
+                unsigned long long mask = __ballot(hit);
+                if (mask) {  // wave-uniform, rare
+                    if (dead) {
+                        if (hit) hit = !((dead[row >> 5] >> (row & 31)) & 1u);
+                        mask = __ballot(hit);
                     }
+                    const uint32_t before =
+                        __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+                    if (hit) pend[npend + before] = ((uint64_t)(q0 + 32 * t + l31) << 32) | (uint32_t)row;
+                    npend += (uint32_t)__popcll(mask);
+                    if (npend > G::PEND - 64) flush();
                 }
             }
         }
     }
+    flush();
 }
 
 // Refine, step 1: exact cosines of the candidates, in place.  A candidate is an 8-byte slot of
@@ -850,11 +879,11 @@ static int32_t scan_split_impl(const BatchedState& st, const SplitQueryWs& qw, c
         CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(score_filter256p_kernel),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, UF2_LDS));
         CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(score_filter_rw_kernel<1>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, RwGeom<1>::LDS));
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, RwGeom<1>::LDS_ALL));
         CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(score_filter_rw_kernel<2>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, RwGeom<2>::LDS));
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, RwGeom<2>::LDS_ALL));
         CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(score_filter_rw_kernel<4>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, RwGeom<4>::LDS));
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, RwGeom<4>::LDS_ALL));
 
         attr_set = true;
     }
@@ -892,10 +921,12 @@ static int32_t scan_split_impl(const BatchedState& st, const SplitQueryWs& qw, c
     static int growth_env = -1;
     if (growth_env < 0) {
         const char* e = std::getenv("CS_FILTER_GROWTH");
-        growth_env = e ? std::atoi(e) : 4;
-        if (growth_env < 2) growth_env = 2;
+        growth_env = e ? std::atoi(e) : 0;
+        if (growth_env == 1) growth_env = 2;
     }
-    const uint32_t growth = (uint32_t)growth_env;
+    // default: 4 from k = 48 on, 8 below (re-measured with the spread refine: 8 queries k=10 1.330 ->
+    // 1.310 ms at growth 8; 9 queries k=200 1.571 -> 1.630)
+    const uint32_t growth = growth_env > 0 ? (uint32_t)growth_env : (k >= 48 ? 4u : 8u);
     do {
         const uint64_t lo = done, hi = done + phase;
         if (hi > lo) {
@@ -922,7 +953,7 @@ static int32_t scan_split_impl(const BatchedState& st, const SplitQueryWs& qw, c
                     return (uint32_t)!(e && e[0] == '0');
                 }();
 #define CS_RW_LAUNCH(NQT_)                                                                                   \
-    hipLaunchKernelGGL(score_filter_rw_kernel<NQT_>, dim3(blocks), dim3(256), RwGeom<NQT_>::LDS, stream, d_split, lo, \
+    hipLaunchKernelGGL(score_filter_rw_kernel<NQT_>, dim3(blocks), dim3(256), RwGeom<NQT_>::LDS_ALL, stream, d_split, lo, \
                        hi, qw.d_qsplit, nq, st.d_tau, d_dead, cand, st.d_cnt, cap, qtiles, nt_stream)
                 if (per == 32) CS_RW_LAUNCH(1);
                 else if (per == 64) CS_RW_LAUNCH(2);
