@@ -775,14 +775,17 @@ template <int J>
 __global__ void __launch_bounds__(RK_THREADS)
 rescore_keys_kernel(const float* __restrict__ corpus, const float* __restrict__ queries,
                     const float* __restrict__ qmag, uint64_t* __restrict__ cand,
-                    const uint32_t* __restrict__ cnt, uint32_t cap, uint32_t id_base) {
+                    const uint32_t* __restrict__ cnt, uint32_t cap, uint32_t id_base,
+                    uint32_t first_rows, const uint32_t* __restrict__ dead) {
     constexpr int DIM = 128 * J;
     constexpr int RU = J <= 3 ? 4 : 2;          // rows per half-wave per round, loads issued together
     constexpr int PER = RU * (RK_THREADS / 32);  // candidates per block per round
     const int tid = threadIdx.x, l32 = tid & 31;
     const uint32_t hw = tid >> 5;
     const uint32_t q = blockIdx.y;
-    uint32_t n = cnt[(size_t)q * kCntStride];
+    // first_rows != 0: phase 0 — candidate i IS row i (tau is still -inf, the filter would append
+    // every row: a million atomics at 1,000 queries); tombstoned rows become empty keys
+    uint32_t n = first_rows ? first_rows : cnt[(size_t)q * kCntStride];
     if (n > cap) n = cap;  // select_candidates_kernel raises the overflow flag
     if (blockIdx.x * PER >= n) return;
     f32x4 qf[J];
@@ -799,7 +802,7 @@ rescore_keys_kernel(const float* __restrict__ corpus, const float* __restrict__ 
 #pragma unroll
         for (int u = 0; u < RU; ++u) {
             const uint32_t i = i0 + u * (RK_THREADS / 32) + hw;  // half-wave uniform
-            row[u] = (i < n) ? (uint32_t)slots[i] : 0u;
+            row[u] = (i < n) ? (first_rows ? i : (uint32_t)slots[i]) : 0u;
         }
 #pragma unroll
         for (int u = 0; u < RU; ++u) {
@@ -826,17 +829,18 @@ rescore_keys_kernel(const float* __restrict__ corpus, const float* __restrict__ 
                 const float d = half_sum_s(dot);
                 const float c = (qm == 0.0f || xmag == 0.0f) ? 0.0f : d / (qm * xmag);  // batch.rs:320-323
                 // NaN/Inf scores are never returned
+                const bool live = !(first_rows && dead) || !((dead[row[u] >> 5] >> (row[u] & 31)) & 1u);
                 if (l32 == 0)
-                    slots[i] = (c > -__builtin_huge_valf() && c < __builtin_huge_valf()) ? key_pack(c, id_base + row[u]) : 0ull;
+                    slots[i] = (live && c > -__builtin_huge_valf() && c < __builtin_huge_valf()) ? key_pack(c, id_base + row[u]) : 0ull;
             }
         }
     }
 }
 
 __global__ void init_split_state_kernel(float* tau, uint32_t* cnt, uint64_t* carry, uint32_t nq, uint32_t k,
-                                        uint32_t* overflow) {
+                                        uint32_t* overflow, uint32_t first_rows) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < nq) { tau[i] = -__builtin_huge_valf(); cnt[(size_t)i * kCntStride] = 0; }
+    if (i < nq) { tau[i] = -__builtin_huge_valf(); cnt[(size_t)i * kCntStride] = first_rows; }
     if (i < nq * k) carry[i] = 0ull;
     if (i == 0) *overflow = 0;
 }
@@ -890,7 +894,7 @@ static int32_t scan_split_impl(const BatchedState& st, const SplitQueryWs& qw, c
     {
         const uint32_t n = nq * k > nq ? nq * k : nq;
         hipLaunchKernelGGL(init_split_state_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, st.d_tau, st.d_cnt,
-                           st.d_carry, nq, k, st.d_overflow);
+                           st.d_carry, nq, k, st.d_overflow, (uint32_t)(n_rows < 1024 ? n_rows : 1024));
     }
     hipLaunchKernelGGL(query_mag_kernel<J>, dim3((nq + 7) / 8), dim3(256), 0, stream, d_queries, nq, qw.d_qmag);
     CS_TRY(launch_unit_f16(d_queries, qw.d_qmag, qw.d_qsplit, nq, dim, stream));
@@ -929,7 +933,8 @@ static int32_t scan_split_impl(const BatchedState& st, const SplitQueryWs& qw, c
     const uint32_t growth = growth_env > 0 ? (uint32_t)growth_env : (k >= 48 ? 4u : 8u);
     do {
         const uint64_t lo = done, hi = done + phase;
-        if (hi > lo) {
+        const bool first = lo == 0;  // phase 0 goes straight to the refine (rescore_keys_kernel, first_rows)
+        if (hi > lo && !first) {
             if (small) {
                 static int cus = 0;  // one persistent block per CU (grid rounded down to whole XCD octets)
                 if (!cus) {
@@ -996,7 +1001,7 @@ static int32_t scan_split_impl(const BatchedState& st, const SplitQueryWs& qw, c
         const bool last = done >= n_rows;
         // refine: exact keys in place (each query's rows spread over rk_blocks CUs), then the select
         hipLaunchKernelGGL(rescore_keys_kernel<J>, dim3(rk_blocks, nq), dim3(RK_THREADS), 0, stream, d_corpus, d_queries,
-                           qw.d_qmag, st.d_cand, st.d_cnt, cap, id_base);
+                           qw.d_qmag, st.d_cand, st.d_cnt, cap, id_base, first ? (uint32_t)hi : 0u, d_dead);
         CS_HIP(hipGetLastError());
         CS_TRY(launch_select_candidates(st, nq, cap, k, last, d_out_keys, d_out_cos, d_out_ids, d_out_counts, stream));
         phase = done * growth;
