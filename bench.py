@@ -321,12 +321,12 @@ def main():
             f16_bytes = args.rows * args.dim * 2
             exe = 2.0 * args.rows * tiles * 128 * args.dim
             hbm = {"kernel": ("cs::score_filter_rw_kernel" if args.nq <= 64 and args.dim == 384 else "cs::score_filter_kernel")
-                             + " (+ rescore_select_kernel between phases)",
+                             + " (+ rescore_keys_kernel / select_candidates_kernel between phases)",
                    "bound": "hbm", "achieved": f16_bytes / (scan_us * 1e-6) / 1e9, "peak": HBM_PEAK_GBPS,
                    "unit": "GB/s", "frac": f16_bytes / (scan_us * 1e-6) / 1e9 / HBM_PEAK_GBPS, "traffic": None,
                    "algorithmic_bytes_per_launch": f16_bytes,
                    "note": "bytes = the f16 filter copy, read once when all queries fit one 128-query tile"}
-            mfma = {"kernel": "cs::score_filter_kernel (+ rescore_select_kernel between phases)",
+            mfma = {"kernel": "cs::score_filter256p_kernel (+ rescore_keys_kernel / select_candidates_kernel between phases)",
                     "bound": "mfma", "achieved": exe / (scan_us * 1e-6) / 1e12, "peak": MFMA_F16_PEAK_TFLOPS,
                     "unit": "TFLOP/s", "frac": exe / (scan_us * 1e-6) / 1e12 / MFMA_F16_PEAK_TFLOPS,
                     "traffic": None, "executed_f16_flops_per_launch": exe,
