@@ -914,7 +914,9 @@ static int32_t scan_split_impl(const BatchedState& st, const SplitQueryWs& qw, c
     // resident-query kernel: up to 64 queries always; above that when CS_FILTER_RW=2 (128-query tiles)
     const bool small = rw_mode && dim == 384 && (nq <= 64 || (rw_mode >= 2 && (nq + 127) / 128 <= 32));
 
-    const uint32_t rk_blocks = nq >= 256 ? 2 : nq >= 16 ? 512 / nq : 32;
+    // refine blocks per query (blocks past a query's candidate count exit at once): enough that a
+    // k = 200 phase (~500 rows per query) is one or two rounds of 32 rows per block
+    const uint32_t rk_blocks = nq <= 128 ? 32 : (4096 / nq < 4 ? 4 : 4096 / nq);
     uint64_t done = 0;
     uint64_t phase = n_rows < 1024 ? n_rows : 1024;  // phase 0: tau = -inf, every row is a candidate
     // A phase over (growth - 1) x the rows scanned so far yields about k (growth - 1) candidates per
