@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(PKG_DIR, "libcsgpu.so")
 CS_OK, CS_ERR_BAD_ARG, CS_ERR_DIM_MISMATCH, CS_ERR_NOT_BUILT = 0, 1, 2, 3
 CS_ERR_CANCELLED, CS_ERR_OOM, CS_ERR_HIP, CS_ERR_UNSUPPORTED = 4, 5, 6, 7
 CS_GEMM_F32, CS_GEMM_SPLIT_F16 = 0, 1
-CS_MAX_K = 256
+CS_MAX_K = 1024
 CS_MAX_QUERIES = 4096
 
 f32p = C.POINTER(C.c_float)

@@ -420,6 +420,8 @@ int32_t run_search(cs_index* h, Workspace* w, const ScanPlan& plan, const float*
     if (!prime_rows) {
         prime_rows = (h->n_rows / 256) & ~(uint64_t)63;
         prime_rows = prime_rows < 4096 ? 4096 : (prime_rows > 16384 ? 16384 : prime_rows);
+        const uint64_t big = prime_sample_rows(prime_rows, k, h->num_cus);  // k > 256: more waves, 32 rows each
+        if (h->n_rows >= 4 * big) prime_rows = big;
     }
     const uint64_t prime_min_rows = h->prime_min_rows ? h->prime_min_rows : (k >= 48 ? 100000 : 500000);
     if (h->prime_min_k && k >= h->prime_min_k && h->n_rows >= prime_min_rows &&

@@ -22,7 +22,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int kBlock = 256;   // 4 waves
 constexpr int kWaves = kBlock / 64;
 constexpr int kMergeBlock = 1024;
-constexpr int kMergeCap = 2048;  // keys sorted per merge block
+constexpr int kMergeCap = 4096;  // keys a merge block can sort (2048 used up to k = 512, see merge_group)
 
 // ---- wave helpers ---------------------------------------------------------------------
 
@@ -461,12 +461,28 @@ ScanPlan plan_scan(uint64_t n_rows, uint32_t dim, uint32_t nq, uint32_t k, int n
 
 bool scan_prime_supported(uint32_t dim) { return fast_dim(dim); }
 
-// Prime pass geometry: one block per CU at most and never more waves than the LDS of the
-// selecting block holds keys (kWaves * kpad), so the k-th largest wave maximum exists.
+// Prime pass geometry.  The bound is the k-th largest of W wave maxima, so W must exceed k by a
+// good factor and every wave should see a few tiles: up to k = 256 one block per CU (W <= 1024
+// waves); above, four per CU (W <= 4096, the most keys the selecting block's LDS holds) — with
+// W = 1024 a k = 1024 bound is the smallest of all maxima, a third of the rows pass it and the scan
+// takes 4.9 ms instead of 2.5.  Never more blocks than kpad (waves = 4 * blocks <= 4 * kpad).
+static uint32_t prime_block_cap(uint32_t k, int num_cus) {
+    const uint32_t kpad = kpad_for(k);
+    uint32_t cap = (uint32_t)num_cus * (k > 256 ? 4u : 1u);
+    if (cap > 1024) cap = 1024;
+    return cap > kpad ? kpad : cap;
+}
+
+// Rows of the prime sample: the caller's default, raised to 32 rows per wave when k > 256.
+uint64_t prime_sample_rows(uint64_t default_rows, uint32_t k, int num_cus) {
+    if (k <= 256) return default_rows;
+    const uint64_t want = (uint64_t)prime_block_cap(k, num_cus) * kWaves * 32;
+    return want > default_rows ? want : default_rows;
+}
+
 ScanPlan plan_prime(uint64_t sample_rows, uint32_t dim, uint32_t nq, uint32_t k, int num_cus) {
     ScanPlan p = plan_scan(sample_rows, dim, nq, k, num_cus);
-    uint32_t cap = (uint32_t)num_cus;
-    if (cap > p.kpad) cap = p.kpad;  // waves = 4 * blocks <= 4 * kpad
+    const uint32_t cap = prime_block_cap(k, num_cus);
     if (p.blocks > cap) p.blocks = cap;
     p.partial_keys = 0;
     p.merge_keys = 0;
@@ -526,8 +542,10 @@ int32_t launch_scan(const ScanPlan& plan, const float* d_corpus, uint64_t n_rows
 }
 
 static uint32_t merge_group(uint32_t k) {
-    uint32_t g = kMergeCap / k;
-    return g < 2 ? 2 : g;  // k <= 256 -> g >= 8
+    // lists merged per block: 2048 keys per sort up to k = 512 (k = 10 -> 204 lists, k = 200 -> 10),
+    // 4096 above (k = 1024 -> 4), never fewer than 2
+    const uint32_t g = (k <= 512 ? 2048u : (uint32_t)kMergeCap) / k;
+    return g < 2 ? 2 : g;
 }
 
 size_t merge_tmp_keys(uint32_t nlists, uint32_t nq, uint32_t k) {

@@ -25,6 +25,7 @@ struct ScanPrime {
     float* d_floor = nullptr;     // [nq]
 };
 bool scan_prime_supported(uint32_t dim);
+uint64_t prime_sample_rows(uint64_t default_rows, uint32_t k, int num_cus);
 ScanPlan plan_prime(uint64_t sample_rows, uint32_t dim, uint32_t nq, uint32_t k, int num_cus);
 
 // Scores every live row of corpus[0..n_rows) against each query and leaves, per

@@ -29,7 +29,7 @@ constexpr int MB_THREADS = MB_WAVES * 64;
 constexpr int MB_KC = 32;               // K chunk (floats) staged per step
 constexpr int MB_RS = 36;               // padded row stride of the staged chunk (floats)
 constexpr int MB_SEL_THREADS = 1024;
-constexpr int MB_SEL_CAP = 2048;
+constexpr int MB_SEL_CAP = 4096;  // keys sorted per chunk: k carried (<= 1024) + up to 4096 - k new
 
 __device__ __forceinline__ float half_sum32(float v) {
     v += __shfl_xor(v, 16, 64);

@@ -45,9 +45,10 @@ typedef enum cs_status {
     CS_ERR_UNSUPPORTED = 7
 } cs_status;
 
-/* Largest k a single search call accepts.  The reference asks for at most
- * max(5*max_results, 200) (src/search/mod.rs:494-502). */
-#define CS_MAX_K 256u
+/* Largest k a single search call accepts.  The reference asks for
+ * max(5*max_results, 200) per query variant (src/search/mod.rs:494-502): 200 at the default
+ * max_results, 1024 covers max_results up to 204. */
+#define CS_MAX_K 1024u
 /* Largest number of queries per search call. */
 #define CS_MAX_QUERIES 4096u
 

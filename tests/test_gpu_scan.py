@@ -567,3 +567,55 @@ def test_primed_scan_is_bit_identical(VS, oracle, dim, monkeypatch):
     assert (k, nq, dead) == (200, 1, False)
     ecos, eids = oracle.scan_topk(rows, qs[0], 200, mode="omp")
     assert_topk_equal(c0[0], i0[0], ecos, eids, rows, qs[0], oracle)
+
+
+@pytest.mark.parametrize("dim", [384, 768, 100])
+def test_large_k_up_to_cs_max_k(VS, oracle, dim, monkeypatch):
+    """retrieval_limit = max(5 * max_results, 200) (src/search/mod.rs:494-502) passes 200 at the
+    default and 500 at max_results = 100: every k up to CS_MAX_K = 1024 is served, by the streaming
+    scan (primed and not), by filter + refine for several queries, by the exact-f32 MFMA path and
+    by the any-dim kernel — all equal to the oracle; k = 1025 is refused."""
+    from codesearch_amd import CsError, _lib
+
+    assert _lib.CS_MAX_K == 1024
+    n = 20_000
+    corpus = oracle.synth_rows(4242, 0, n, dim)
+    corpus[7] = corpus[3]; corpus[11_000] = corpus[3]
+    qs = np.stack([corpus[3], synth_rows(4243, 0, 1, dim)[0], synth_rows(4243, 9, 1, dim)[0]])
+    monkeypatch.setenv("CS_SCAN_PRIME_MIN_ROWS", "1")
+    monkeypatch.setenv("CS_SCAN_PRIME_ROWS", "4096")
+    st = VS(None, dim)
+    st.insert_embeddings(corpus)
+    st.build_index()
+    for k in (257, 500, 1000, 1024):
+        want = [oracle.scan_topk(corpus, q, k, mode="omp") for q in qs]
+        c1, i1, n1 = st.search_raw(qs[0], k)                    # one query: streaming scan
+        assert n1[0] == k
+        assert_topk_equal(c1[0], i1[0], want[0][0], want[0][1], corpus, qs[0], oracle)
+        c3, i3, n3 = st.search_raw(qs, k)                       # three: filter + refine where the dim has it
+        assert n3.tolist() == [k] * 3
+        for j in range(3):
+            assert_topk_equal(c3[j], i3[j], want[j][0], want[j][1], corpus, qs[j], oracle)
+        assert i3[0].tolist() == i1[0].tolist() and c3[0].tobytes() == c1[0].tobytes()
+    with pytest.raises(CsError) as e:
+        st.search_raw(qs[0], 1025)
+    assert "k must be in 1..1024" in str(e.value)
+    # k larger than the corpus: every live row once, the rest marked empty
+    small = VS(None, dim)
+    small.insert_embeddings(corpus[:300])
+    small.build_index()
+    c, i, cnt = small.search_raw(qs, 1024)
+    assert cnt.tolist() == [300] * 3 and (i[:, 300:] == 0xFFFFFFFF).all()
+    for j in range(3):
+        ecos, eids = oracle.scan_topk(corpus[:300], qs[j], 1024, mode="omp")
+        assert_topk_equal(c[j][:300], i[j][:300], ecos, eids, corpus[:300], qs[j], oracle)
+    if dim == 384:  # exact-f32 MFMA path (no filter copy) at 5+ queries
+        monkeypatch.setenv("CS_INDEX_SPLIT", "0")
+        st2 = VS(None, dim)
+        st2.insert_embeddings(corpus)
+        st2.build_index()
+        q5 = np.concatenate([qs, synth_rows(4244, 0, 2, dim)])
+        c5, i5, n5 = st2.search_raw(q5, 600)
+        for j in range(5):
+            ecos, eids = oracle.scan_topk(corpus, q5[j], 600, mode="omp")
+            assert_topk_equal(c5[j], i5[j], ecos, eids, corpus, q5[j], oracle)
