@@ -585,14 +585,17 @@ score_filter256p_kernel(const _Float16* __restrict__ corpus_h, uint64_t row_lo, 
 // tile and a private ring of R 4-KiB slots filled by LDS-DMA, R-1 stages (7 x 16 KB per CU at
 // NQT = 1) in flight across tile boundaries under counted vmcnt — no barrier in the loop, since a
 // wave only reads rows it loaded itself.
-template <int NQT>
+template <int NQT, int KC = 6>  // KC = dim / 64 k-chunks per row: 6 / 12 / 16 for dim 384 / 768 / 1024
 struct RwGeom {
     static constexpr int QROWS = 32 * NQT;
-    static constexpr int WBYTES = QROWS * 768;                 // 6 chunks x QROWS x 128 B (dim 384)
-    static constexpr int R = NQT == 1 ? 8 : NQT == 2 ? 6 : 3;  // ring slots (16 KiB each, 4 KiB per wave)
-    static constexpr int LDS = WBYTES + R * 16384;             // 155,648 / 147,456 / 147,456 B
+    static constexpr int WBYTES = KC * QROWS * 128;            // resident queries: KC chunks x QROWS x 128 B
     static constexpr int PEND = 128;                           // pending candidates per wave (8 B each)
+    static constexpr int RMAX = (160 * 1024 - 4 * PEND * 8 - WBYTES) / 16384;
+    static constexpr int R = RMAX > 8 ? 8 : RMAX;              // ring slots (16 KiB each, 4 KiB per wave):
+                                                               // dim 384: 8 / 6 / 3 at NQT 1 / 2 / 4; 768: 6 / 3; 1024: 5
+    static constexpr int LDS = WBYTES + R * 16384;             // dim 384: 155,648 / 147,456 / 147,456 B
     static constexpr int LDS_ALL = LDS + 4 * PEND * 8;         // + 4 KiB
+    static_assert(R >= 3, "the ring needs at least two stages in flight");
 };
 
 template <int N>
@@ -600,17 +603,17 @@ __device__ __forceinline__ void uf_wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int NQT>
+template <int NQT, int KC>
 __global__ void __launch_bounds__(256)
 score_filter_rw_kernel(const _Float16* __restrict__ corpus_h, uint64_t row_lo, uint64_t row_hi,
                        const _Float16* __restrict__ queries_h, uint32_t nq, const float* __restrict__ tau,
                        const uint32_t* __restrict__ dead, uint32_t* __restrict__ cand,
                        uint32_t* __restrict__ cnt, uint32_t cap, uint32_t qtiles, uint32_t nt_stream) {
-    using G = RwGeom<NQT>;
+    using G = RwGeom<NQT, KC>;
     // one query tile: every corpus byte is read by exactly one CU, once — stream it past the caches (with
     // several query tiles the blocks of an XCD share tiles through its L2: default policy)
     const bool NT = nt_stream != 0 && qtiles == 1;
-    constexpr int KC = 6, R = G::R;
+    constexpr int R = G::R;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     char* Wl = lds;                 // [KC][QROWS][128 B], slots swizzled as in uf_mainloop
     char* ring = lds + G::WBYTES;   // [R][4 waves][32 rows][128 B]
@@ -619,7 +622,7 @@ score_filter_rw_kernel(const _Float16* __restrict__ corpus_h, uint64_t row_lo, u
     const int l31 = lane & 31, h = lane >> 5;
     const uint64_t M = row_hi - row_lo;
     const uint64_t ntile = (M + 127) / 128;
-    const _Float16* base = corpus_h + uf_tiled_off(row_lo, 0, 6);  // row_lo is a multiple of 128
+    const _Float16* base = corpus_h + uf_tiled_off(row_lo, 0, KC);  // row_lo is a multiple of 128
     // Several query tiles: blocks of one XCD (blockIdx % 8) that hold different query tiles share a
     // row group and walk its corpus tiles in the same order, so a tile comes from HBM once per XCD
     // group and from that XCD's L2 for the other query tiles.
@@ -628,15 +631,15 @@ score_filter_rw_kernel(const _Float16* __restrict__ corpus_h, uint64_t row_lo, u
     if (rg >= rgn) return;  // spare slot when qtiles does not divide the slots of an XCD
     const uint32_t q0 = qt * G::QROWS;
 
-    // resident queries: 8 rows x 128 B per instruction, 6*NQT instructions per wave
+    // resident queries: 8 rows x 128 B per instruction, KC*NQT instructions per wave
 #pragma unroll
-    for (int i = 0; i < 6 * NQT; ++i) {
-        const int g8 = wave * 6 * NQT + i;               // group of 8 (chunk, row) lines
+    for (int i = 0; i < KC * NQT; ++i) {
+        const int g8 = wave * KC * NQT + i;              // group of 8 (chunk, row) lines
         const int c = g8 / (4 * NQT), r8 = g8 % (4 * NQT);
         const int row = r8 * 8 + (lane >> 3);
         const int pc = (lane & 7) ^ ((row >> 1) & 7);
         const uint32_t q = q0 + row < nq ? q0 + row : nq - 1;
-        sh_glds16(queries_h + (size_t)q * 384 + c * 64 + pc * 8, Wl + (c * G::QROWS + r8 * 8) * 128);
+        sh_glds16(queries_h + (size_t)q * (KC * 64) + c * 64 + pc * 8, Wl + (c * G::QROWS + r8 * 8) * 128);
     }
     uf_wait_vmcnt<0>();
     __syncthreads();
@@ -665,8 +668,8 @@ score_filter_rw_kernel(const _Float16* __restrict__ corpus_h, uint64_t row_lo, u
             const int row = i * 8 + (lane >> 3);
             const int pc = (lane & 7) ^ ((row >> 1) & 7);
             // 8 consecutive rows of chunk c = 1 KiB of consecutive lines (rows past M: padded tile, masked at append)
-            if (NT) sh_glds16_nt(base + ((tile * 6 + c) * 128 + wave * 32 + row) * 64 + pc * 8, myring + slot * 16384 + i * 1024);
-            else sh_glds16(base + ((tile * 6 + c) * 128 + wave * 32 + row) * 64 + pc * 8, myring + slot * 16384 + i * 1024);
+            if (NT) sh_glds16_nt(base + ((tile * KC + c) * 128 + wave * 32 + row) * 64 + pc * 8, myring + slot * 16384 + i * 1024);
+            else sh_glds16(base + ((tile * KC + c) * 128 + wave * 32 + row) * 64 + pc * 8, myring + slot * 16384 + i * 1024);
         }
     };
 
@@ -882,12 +885,22 @@ static int32_t scan_split_impl(const BatchedState& st, const SplitQueryWs& qw, c
                                    hipFuncAttributeMaxDynamicSharedMemorySize, UF2_LDS));
         CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(score_filter256p_kernel),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, UF2_LDS));
-        CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(score_filter_rw_kernel<1>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, RwGeom<1>::LDS_ALL));
-        CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(score_filter_rw_kernel<2>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, RwGeom<2>::LDS_ALL));
-        CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(score_filter_rw_kernel<4>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, RwGeom<4>::LDS_ALL));
+        if constexpr (J == 3) {
+            CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(score_filter_rw_kernel<1, 6>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, RwGeom<1, 6>::LDS_ALL));
+            CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(score_filter_rw_kernel<2, 6>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, RwGeom<2, 6>::LDS_ALL));
+            CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(score_filter_rw_kernel<4, 6>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, RwGeom<4, 6>::LDS_ALL));
+        } else if constexpr (J == 6) {
+            CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(score_filter_rw_kernel<1, 12>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, RwGeom<1, 12>::LDS_ALL));
+            CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(score_filter_rw_kernel<2, 12>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, RwGeom<2, 12>::LDS_ALL));
+        } else {
+            CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(score_filter_rw_kernel<1, 16>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, RwGeom<1, 16>::LDS_ALL));
+        }
 
         attr_set = true;
     }
@@ -906,13 +919,14 @@ static int32_t scan_split_impl(const BatchedState& st, const SplitQueryWs& qw, c
         wide_min = e ? std::atoi(e) : 129;
     }
     const bool wide = (int)nq >= wide_min;
-    static int rw_mode = -1;  // resident-query / deep-ring kernel for <= 64 queries (dim 384)
+    static int rw_mode = -1;  // resident-query / deep-ring kernel: <= 64 queries at dim 384 / 768, <= 32 at 1024
     if (rw_mode < 0) {
         const char* e = std::getenv("CS_FILTER_RW");
         rw_mode = e ? std::atoi(e) : 1;
     }
     // resident-query kernel: up to 64 queries always; above that when CS_FILTER_RW=2 (128-query tiles)
-    const bool small = rw_mode && dim == 384 && (nq <= 64 || (rw_mode >= 2 && (nq + 127) / 128 <= 32));
+    const bool small = rw_mode && (dim == 384 ? (nq <= 64 || (rw_mode >= 2 && (nq + 127) / 128 <= 32))
+                                              : nq <= (dim == 768 ? 64u : 32u));
 
     // refine blocks per query (blocks past a query's candidate count exit at once): enough that a
     // k = 200 phase (~500 rows per query) is one or two rounds of 32 rows per block
@@ -960,11 +974,22 @@ static int32_t scan_split_impl(const BatchedState& st, const SplitQueryWs& qw, c
                     return (uint32_t)!(e && e[0] == '0');
                 }();
 #define CS_RW_LAUNCH(NQT_)                                                                                   \
-    hipLaunchKernelGGL(score_filter_rw_kernel<NQT_>, dim3(blocks), dim3(256), RwGeom<NQT_>::LDS_ALL, stream, d_split, lo, \
-                       hi, qw.d_qsplit, nq, st.d_tau, d_dead, cand, st.d_cnt, cap, qtiles, nt_stream)
-                if (per == 32) CS_RW_LAUNCH(1);
-                else if (per == 64) CS_RW_LAUNCH(2);
-                else CS_RW_LAUNCH(4);
+    do {                                                                                                     \
+        using RwG = RwGeom<NQT_, 2 * J>;                                                                     \
+        constexpr size_t rw_lds = RwG::LDS_ALL;                                                              \
+        hipLaunchKernelGGL((score_filter_rw_kernel<NQT_, 2 * J>), dim3(blocks), dim3(256), rw_lds, stream, d_split, lo, \
+                           hi, qw.d_qsplit, nq, st.d_tau, d_dead, cand, st.d_cnt, cap, qtiles, nt_stream);   \
+    } while (0)
+                if constexpr (J == 3) {
+                    if (per == 32) CS_RW_LAUNCH(1);
+                    else if (per == 64) CS_RW_LAUNCH(2);
+                    else CS_RW_LAUNCH(4);
+                } else if constexpr (J == 6) {
+                    if (per == 32) CS_RW_LAUNCH(1);
+                    else CS_RW_LAUNCH(2);
+                } else {
+                    CS_RW_LAUNCH(1);
+                }
 #undef CS_RW_LAUNCH
             } else if (wide) {
                 const uint32_t mt2 = (uint32_t)((hi - lo + UF2_BM - 1) / UF2_BM), nt2 = (nq + UF2_BN - 1) / UF2_BN;

@@ -383,7 +383,10 @@ def test_mfma_batched_10m_equals_single_query_scans(VS):
 # ---- batched queries: filter (split-f16 MFMA) + exact refine (scan_split.hip) ---------------------
 
 @pytest.mark.parametrize("dim,n,nq,k", [(384, 50_000, 130, 10), (768, 20_001, 9, 25), (1024, 10_000, 33, 10),
-                                        (384, 1000, 5, 256)])
+                                        (384, 1000, 5, 256),
+                                        # resident-query filter kernel at the wider models' dims: <1,12>, <2,12>, <1,16>
+                                        (768, 60_000, 32, 10), (768, 30_003, 40, 200), (768, 40_000, 64, 10),
+                                        (1024, 30_000, 8, 200), (1024, 50_001, 32, 10)])
 def test_split_batched_path_is_bit_identical_to_single_query_scan(VS, dim, n, nq, k):
     """The refine step re-scores candidates with the single-query scan's arithmetic, so a batched
     search returns the same bits — ids AND cosines — as nq independent searches."""
