@@ -40,6 +40,48 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr float kFilterMargin = 2.6e-3f;  // cosine units; bound derived in the header comment
 
+// ---- candidate append, batched per wave ---------------------------------------------------------
+// An append is a device-scope atomic WITH return on the query's counter: a ~2 us round trip during
+// which the wave does nothing else, and at k = 200 one tile in ten holds a candidate.  So hits are
+// first parked in a wave-private LDS list — ballot + mbcnt give each hit its slot, no atomics — and
+// the list is appended in one go (all lanes' atomics in flight together: one round trip per batch).
+// Used by the resident-query kernel, a pure HBM stream; in the MFMA-bound tile kernels the ballot per
+// accumulator element costs more than the stalls it saves (100 queries 1.98 -> 2.10 ms, 1000 queries
+// 9.0 -> 9.8 ms), so they append directly.
+// kPend entries of (query << 32 | row); a push adds at most 64, so the list is flushed above kPend - 64.
+constexpr uint32_t kPend = 128;
+
+__device__ __forceinline__ void cand_flush(volatile uint64_t* pend, uint32_t& npend, int lane,
+                                           uint32_t* __restrict__ cand, uint32_t* __restrict__ cnt, uint32_t cap) {
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (uint32_t i = lane; i < npend; i += 64) {
+        const uint64_t e = pend[i];
+        const uint32_t q = (uint32_t)(e >> 32);
+        const uint32_t pos = atomicAdd(&cnt[(size_t)q * kCntStride], 1u);
+        if (pos < cap) cand[2 * ((size_t)q * cap + pos)] = (uint32_t)e;  // low word of the 8-byte slot
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    npend = 0;
+}
+
+// All 64 lanes call this together; `hit` lanes park (q, row).  Tombstoned rows are dropped here.
+__device__ __forceinline__ void cand_push(bool hit, uint32_t q, uint64_t row, const uint32_t* __restrict__ dead,
+                                          volatile uint64_t* pend, uint32_t& npend, int lane,
+                                          uint32_t* __restrict__ cand, uint32_t* __restrict__ cnt, uint32_t cap) {
+    unsigned long long mask = __ballot(hit);
+    if (!mask) return;  // wave-uniform; the common case
+    if (dead) {
+        if (hit) hit = !((dead[row >> 5] >> (row & 31)) & 1u);
+        mask = __ballot(hit);
+    }
+    const uint32_t before = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+    if (hit) pend[npend + before] = ((uint64_t)q << 32) | (uint32_t)row;
+    npend += (uint32_t)__popcll(mask);
+    if (npend > kPend - 64) cand_flush(pend, npend, lane, cand, cnt, cap);
+}
+
 __device__ __forceinline__ float half_sum_s(float v) {
     v += __shfl_xor(v, 16, 64);
     v += __shfl_xor(v, 8, 64);
@@ -589,7 +631,7 @@ template <int NQT, int KC = 6>  // KC = dim / 64 k-chunks per row: 6 / 12 / 16 f
 struct RwGeom {
     static constexpr int QROWS = 32 * NQT;
     static constexpr int WBYTES = KC * QROWS * 128;            // resident queries: KC chunks x QROWS x 128 B
-    static constexpr int PEND = 128;                           // pending candidates per wave (8 B each)
+    static constexpr int PEND = (int)kPend;                    // pending candidates per wave (8 B each)
     static constexpr int RMAX = (160 * 1024 - 4 * PEND * 8 - WBYTES) / 16384;
     static constexpr int R = RMAX > 8 ? 8 : RMAX;              // ring slots (16 KiB each, 4 KiB per wave):
                                                                // dim 384: 8 / 6 / 3 at NQT 1 / 2 / 4; 768: 6 / 3; 1024: 5
@@ -690,22 +732,9 @@ score_filter_rw_kernel(const _Float16* __restrict__ corpus_h, uint64_t row_lo, u
     for (int p = 0; p < R - 1; ++p)
         if (gi < nstage) issue_next();
 
-    // this wave's pending candidates: (query << 32 | row), appended by flush()
-    volatile uint64_t* pend = reinterpret_cast<volatile uint64_t*>(lds + G::LDS) + wave * G::PEND;
+    // this wave's pending candidates (cand_push / cand_flush)
+    volatile uint64_t* pend = reinterpret_cast<volatile uint64_t*>(lds + G::LDS) + wave * kPend;
     uint32_t npend = 0;  // wave-uniform
-    auto flush = [&]() {
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        for (uint32_t i = lane; i < npend; i += 64) {
-            const uint64_t e = pend[i];
-            const uint32_t q = (uint32_t)(e >> 32);
-            const uint32_t pos = atomicAdd(&cnt[(size_t)q * kCntStride], 1u);
-            if (pos < cap) cand[2 * ((size_t)q * cap + pos)] = (uint32_t)e;  // low word of the 8-byte slot
-        }
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        npend = 0;
-    };
 
     sh_f32x16 acc[NQT];
     int c_slot = 0;  // ring slot of the stage being consumed
@@ -738,32 +767,17 @@ score_filter_rw_kernel(const _Float16* __restrict__ corpus_h, uint64_t row_lo, u
                 }
             }
         }
-        // Candidates are parked in the wave's LDS list and appended in batches: the append is a
-        // device-scope atomic WITH return (~2 us round trip during which the wave issues no corpus
-        // loads), and at k = 200 one tile in ten holds a candidate — one stall per batch, not per row.
 #pragma unroll
         for (int t = 0; t < NQT; ++t) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const uint64_t m = tile * 128 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                const uint64_t row = row_lo + m;
-                bool hit = qok[t] && m < M && !(acc[t][r] <= tq[t]);
-                unsigned long long mask = __ballot(hit);
-                if (mask) {  // wave-uniform, rare
-                    if (dead) {
-                        if (hit) hit = !((dead[row >> 5] >> (row & 31)) & 1u);
-                        mask = __ballot(hit);
-                    }
-                    const uint32_t before =
-                        __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-                    if (hit) pend[npend + before] = ((uint64_t)(q0 + 32 * t + l31) << 32) | (uint32_t)row;
-                    npend += (uint32_t)__popcll(mask);
-                    if (npend > G::PEND - 64) flush();
-                }
+                cand_push(qok[t] && m < M && !(acc[t][r] <= tq[t]), q0 + 32 * t + l31, row_lo + m, dead, pend, npend,
+                          lane, cand, cnt, cap);
             }
         }
     }
-    flush();
+    cand_flush(pend, npend, lane, cand, cnt, cap);
 }
 
 // Refine, step 1: exact cosines of the candidates, in place.  A candidate is an 8-byte slot of
