@@ -25,5 +25,9 @@ for n in (592, 10_000, 100_000, 1_000_000):
     st.insert_synthetic(n, 1234, 0)
     st.build_index()
     q1, q9 = synth_rows(99, 0, 1, 384), synth_rows(99, 0, 9, 384)
+    # the HIP runtime stalls once for ~36 ms a few hundred calls into a process (seen at call ~345 of a plain
+    # loop of searches): get past it before timing
+    for q, k in ((q1, 10), (q9, 10), (q9, 200)) * 3:
+        timed(st, q, k, reps=60)
     print(f"rows {n}: 1 query k=10 {timed(st, q1, 10):.1f} us; 9 queries k=10 {timed(st, q9, 10):.1f} us; "
           f"9 queries k=200 {timed(st, q9, 200):.1f} us", flush=True)
