@@ -365,14 +365,21 @@ bool take_events(cs_index* h, Workspace* w, EventTriple* t) {
 }
 
 // scan + merge on `stream`; outputs are device pointers (any may be null).
+// h_queries_pinned != null: the queries are still in that pinned host buffer and d_queries is empty;
+// the filter path lets its prep kernel bring them over, every other path copies them first.
 int32_t run_search(cs_index* h, Workspace* w, const ScanPlan& plan, const float* d_queries,
                    uint32_t nq, uint32_t k, uint64_t* d_keys, float* d_cos, uint32_t* d_ids,
-                   uint32_t* d_counts, hipStream_t stream) {
+                   uint32_t* d_counts, hipStream_t stream, const float* h_queries_pinned = nullptr) {
     EventTriple ev{};
     const bool timed = take_events(h, w, &ev);
     if (timed) CS_HIP(hipEventRecord(ev.e0, stream));
     // >= 5 queries: MFMA scoring + phased candidate selection (scan_mfma.hip)
     const bool split_ready = h->use_split && h->split_rows >= h->n_rows;
+    const bool filter_path = split_ready && (int)nq >= h->filter_min_q && h->n_rows > 0 && h->normed_rows >= h->n_rows;
+    w->qw.q_pinned = filter_path ? h_queries_pinned : nullptr;
+    if (h_queries_pinned && !filter_path)
+        CS_HIP(hipMemcpyAsync(const_cast<float*>(d_queries), h_queries_pinned, (size_t)nq * h->dim * sizeof(float),
+                              hipMemcpyHostToDevice, stream));
     // Two or more queries: the f16 filter reads half the bytes of the f32 scan once for up to 128
     // queries (1.85 ms vs 2.5 ms for two passes-in-one of the streaming scan over 10M x 384) and
     // the refine step keeps the result bit-identical.  One query stays on the streaming f32 scan
@@ -646,11 +653,10 @@ int32_t cs_index_search(cs_index* h, const float* queries, uint32_t nq, uint32_t
     if (s == CS_OK) {
         s = [&]() -> int32_t {
             memcpy(w->h_queries, queries, (size_t)nq * h->dim * sizeof(float));
-            CS_HIP(hipMemcpyAsync(w->d_queries, w->h_queries, (size_t)nq * h->dim * sizeof(float),
-                                  hipMemcpyHostToDevice, w->stream));
             // the last kernel of the search writes the packed keys straight into the pinned host buffer
             // (device-addressable, coherent): no D2H copy call, one stream sync
-            CS_TRY(run_search(h, w, plan, w->d_queries, nq, k, w->h_keys, nullptr, nullptr, nullptr, w->stream));
+            CS_TRY(run_search(h, w, plan, w->d_queries, nq, k, w->h_keys, nullptr, nullptr, nullptr, w->stream,
+                              w->h_queries));
             CS_HIP(hipStreamSynchronize(w->stream));
             for (uint32_t q = 0; q < nq; ++q) {  // keys are best-first, 0 = empty slot
                 uint32_t c = 0;

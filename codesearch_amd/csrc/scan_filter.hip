@@ -91,23 +91,49 @@ __device__ __forceinline__ float half_sum_s(float v) {
     return v;
 }
 
-// |q| per query with the single-query scan's arithmetic (scan.hip, "query fragments + magnitudes").
+// Everything a batched search needs before its first phase, in one launch (three kernels of ~2 us
+// each cost ~12 us of launch gaps — a quarter of a search over the reference's own 592-chunk index):
+// per query, one half-wave computes |q| with the single-query scan's arithmetic (scan.hip, "query
+// fragments + magnitudes"), writes q/|q| as f16 row-major (the arithmetic of unit_f16_rows_kernel)
+// and resets the query's search state.
 template <int J>
 __global__ void __launch_bounds__(256)
-query_mag_kernel(const float* __restrict__ queries, uint32_t nq, float* __restrict__ qmag) {
+prep_queries_kernel(const float* __restrict__ queries, float* __restrict__ qcopy, uint32_t nq,
+                    float* __restrict__ qmag, _Float16* __restrict__ qunit, float* __restrict__ tau, uint32_t* __restrict__ cnt,
+                    uint64_t* __restrict__ carry, uint32_t k, uint32_t* __restrict__ overflow, uint32_t first_rows) {
     constexpr int DIM = 128 * J;
     const int lane = threadIdx.x & 63, half = lane >> 5, l32 = lane & 31;
     const uint32_t q = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 2 + half;
     const uint32_t qq = q < nq ? q : nq - 1;
     const f32x4* qp = reinterpret_cast<const f32x4*>(queries + (size_t)qq * DIM) + l32;
+    f32x4 v[J];
     float s = 0.0f;
 #pragma unroll
     for (int j = 0; j < J; ++j) {
-        const f32x4 v = qp[j * 32];
-        s = fmaf(v.x, v.x, s); s = fmaf(v.y, v.y, s); s = fmaf(v.z, v.z, s); s = fmaf(v.w, v.w, s);
+        v[j] = qp[j * 32];
+        s = fmaf(v[j].x, v[j].x, s); s = fmaf(v[j].y, v[j].y, s); s = fmaf(v[j].z, v[j].z, s); s = fmaf(v[j].w, v[j].w, s);
     }
     const float m = sqrtf(half_sum_s(s));
-    if (q < nq && l32 == 0) qmag[q] = m;
+    if (q >= nq) return;  // after the half-wave reduction
+    typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+    if (qcopy) {  // queries came from pinned host memory: leave a device copy for the refine kernels
+#pragma unroll
+        for (int j = 0; j < J; ++j) reinterpret_cast<f32x4*>(qcopy + (size_t)q * DIM)[l32 + 32 * j] = v[j];
+    }
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        f16x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (_Float16)(m == 0.0f ? 0.0f : v[j][e] / m);
+        *reinterpret_cast<f16x4*>(qunit + (size_t)q * DIM + (l32 + 32 * j) * 4) = o;
+    }
+    for (uint32_t i = l32; i < k; i += 32) carry[(size_t)q * k + i] = 0ull;
+    if (l32 == 0) {
+        qmag[q] = m;
+        tau[q] = -__builtin_huge_valf();
+        cnt[(size_t)q * kCntStride] = first_rows;
+        if (q == 0) *overflow = 0;
+    }
 }
 
 // Offset (in f16 elements) of (row, k-chunk c) in the tiled filter copy; + 8 * piece for the 16-B pieces.
@@ -854,14 +880,6 @@ rescore_keys_kernel(const float* __restrict__ corpus, const float* __restrict__ 
     }
 }
 
-__global__ void init_split_state_kernel(float* tau, uint32_t* cnt, uint64_t* carry, uint32_t nq, uint32_t k,
-                                        uint32_t* overflow, uint32_t first_rows) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < nq) { tau[i] = -__builtin_huge_valf(); cnt[(size_t)i * kCntStride] = first_rows; }
-    if (i < nq * k) carry[i] = 0ull;
-    if (i == 0) *overflow = 0;
-}
-
 // ---- host side ----------------------------------------------------------------------------
 
 bool split_scan_supported(uint32_t dim) { return dim == 384 || dim == 768 || dim == 1024; }
@@ -918,13 +936,11 @@ static int32_t scan_split_impl(const BatchedState& st, const SplitQueryWs& qw, c
 
         attr_set = true;
     }
-    {
-        const uint32_t n = nq * k > nq ? nq * k : nq;
-        hipLaunchKernelGGL(init_split_state_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, st.d_tau, st.d_cnt,
-                           st.d_carry, nq, k, st.d_overflow, (uint32_t)(n_rows < 1024 ? n_rows : 1024));
-    }
-    hipLaunchKernelGGL(query_mag_kernel<J>, dim3((nq + 7) / 8), dim3(256), 0, stream, d_queries, nq, qw.d_qmag);
-    CS_TRY(launch_unit_f16(d_queries, qw.d_qmag, qw.d_qsplit, nq, dim, stream));
+    hipLaunchKernelGGL(prep_queries_kernel<J>, dim3((nq + 7) / 8), dim3(256), 0, stream,
+                       qw.q_pinned ? qw.q_pinned : d_queries, qw.q_pinned ? const_cast<float*>(d_queries) : nullptr, nq,
+                       qw.d_qmag, qw.d_qsplit, st.d_tau, st.d_cnt, st.d_carry, k, st.d_overflow,
+                       (uint32_t)(n_rows < 1024 ? n_rows : 1024));
+    CS_HIP(hipGetLastError());
     uint32_t* cand = reinterpret_cast<uint32_t*>(st.d_cand);
     const uint32_t ntiles = (nq + SH_BN - 1) / SH_BN;
     static int wide_min = -1;  // query count from which the 256 x 256 tile kernel is used
