@@ -13,6 +13,7 @@
 // P^T is the S^T accumulator itself: its key index sits on (register, lane half) in exactly the
 // order the next MFMA's k index wants (cdna_hip_programming.md §3, "An accumulator tile as the next
 // MFMA's operand"), so probabilities are split to f16 pairs in registers and never touch LDS.
+#include <cstdlib>
 #include "encoder.hpp"
 #include "split_f16.hpp"
 
@@ -634,6 +635,18 @@ int32_t launch_attention_sh2(const _Float16* qkv_split, const int32_t* mask, voi
         }
         hipLaunchKernelGGL(attention_shx_kernel<2>, dim3(heads, B, (L + 127) / 128), dim3(256), lds, s, qkv_split, mask,
                            static_cast<_Float16*>(ctx_split), flag, L, H, (1.0f / sqrtf(64.0f)) * kLog2e);
+        CS_HIP(hipGetLastError());
+        return CS_OK;
+    }
+    // head_dim 32 also runs on the 128-key super-tile kernel by default: 32 KiB of LDS per block instead of
+    // 64 (four blocks per CU, one per 128 queries, so K/V staging of one block hides behind the softmax of
+    // the others) — 256 x 256 tokens 12.75 -> 12.54 ms per forward although K/V are staged once per query
+    // block.  CS_ATTN_SHX1=0 selects the whole-sequence kernel (attention_sh2_kernel) for A/B.
+    static const bool shx1 = [] { const char* e = std::getenv("CS_ATTN_SHX1"); return !(e && e[0] == '0'); }();
+    if (shx1) {
+        const size_t lds1 = 2 * 1 * 128 * 128 + Lp * sizeof(float) + 16;
+        hipLaunchKernelGGL(attention_shx_kernel<1>, dim3(heads, B, (L + 127) / 128), dim3(256), lds1, s, qkv_split, mask,
+                           static_cast<_Float16*>(ctx_split), flag, L, H, (1.0f / sqrtf(32.0f)) * kLog2e);
         CS_HIP(hipGetLastError());
         return CS_OK;
     }
