@@ -7,7 +7,7 @@ f = glob.glob(sys.argv[1] + "/*/*_kernel_trace.csv")[0]
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 17
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-names = ("rescore", "select_candidates", "score_filter", "init_split", "query_mag", "unit_f16", "scan_topk", "merge_topk")
+names = ("rescore", "select_candidates", "score_filter", "prep_queries", "scan_topk", "merge_topk")
 sel = [r for r in rows if any(s in r["Kernel_Name"] for s in names)]
 tail = sel[-n:]
 t0 = int(tail[0]["Start_Timestamp"])

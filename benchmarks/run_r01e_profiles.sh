@@ -13,7 +13,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/filter_q9_k200 -- pyt
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/scan_q1_k200 -- python3 $R/bench.py --k 200 --steps 50 --warmup 5 --no-cpu-baseline --no-encoder > $O/scan_q1_k200.log 2>&1
 echo "profiles done"
 cd $R
-python3 benchmarks/phase_timeline.py $O/filter_q9_k200 24 > $O/filter_q9_k200_timeline.log
+python3 benchmarks/phase_timeline.py $O/filter_q9_k200 22 > $O/filter_q9_k200_timeline.log
 python3 benchmarks/phase_timeline.py $O/scan_q1_k200 4 > $O/scan_q1_k200_timeline.log
 : > $O/search_nq_k_table.log
 for k in 10 200; do for nq in 1 2 8 9 32 64 128 256 1000; do
