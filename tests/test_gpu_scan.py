@@ -622,3 +622,55 @@ def test_large_k_up_to_cs_max_k(VS, oracle, dim, monkeypatch):
         for j in range(5):
             ecos, eids = oracle.scan_topk(corpus, q5[j], 600, mode="omp")
             assert_topk_equal(c5[j], i5[j], ecos, eids, corpus, q5[j], oracle)
+
+
+def test_randomised_paths_agree(VS, oracle, monkeypatch):
+    """Seeded sweep over corpus size, query count, k, width and tombstones: the batched paths (filter + refine,
+    phase 0 scored directly, candidates appended in batches) and the primed streaming scan must return the
+    same bits as the unprimed single-query scan, which is checked against the oracle."""
+    rng = np.random.default_rng(20261003)
+    monkeypatch.setenv("CS_SCAN_PRIME_MIN_ROWS", "1")
+    monkeypatch.setenv("CS_SCAN_PRIME_ROWS", "2048")
+    for case in range(36):
+        dim = int(rng.choice([384, 384, 768, 1024]))
+        n = int(rng.choice([1, 33, 700, 1024, 1025, 3000, 9000, 25_000]))
+        nq = int(rng.choice([2, 3, 9, 31, 33, 64, 70]))
+        k = int(rng.choice([1, 7, 10, 100, 200, 300, 1024]))
+        rows = synth_rows(5000 + case, 0, n, dim)
+        if n > 40:
+            rows[n // 3] = rows[1]                       # exact tie
+            rows[n // 2] = 0.0                           # zero row
+            rows[5] *= 1e-6; rows[7] *= 1e5              # magnitudes the unit-vector filter must not care about
+        qs = synth_rows(6000 + case, 0, nq, dim)
+        qs[0] = rows[1] if n > 1 else qs[0]
+        monkeypatch.setenv("CS_SCAN_PRIME_MIN_K", "1")
+        st = VS(None, dim)
+        st.insert_embeddings(rows)
+        if n > 40 and case % 2:
+            dead_ids = sorted(set(int(x) for x in rng.integers(0, n, size=n // 10)))
+            assert st.delete_chunks(dead_ids) == len(dead_ids)
+        st.build_index()
+        cb, ib, nb = st.search_raw(qs, k)                # batched: filter + refine
+        singles = [st.search_raw(q, k) for q in qs[:4]]  # primed streaming scan (prime forced on where n allows)
+        monkeypatch.setenv("CS_SCAN_PRIME_MIN_K", "0")
+        ref = VS(None, dim)                              # unprimed streaming scan
+        ref.insert_embeddings(rows)
+        if n > 40 and case % 2:
+            ref.delete_chunks(dead_ids)
+        ref.build_index()
+        for j in range(min(4, nq)):
+            c0, i0, n0 = ref.search_raw(qs[j], k)
+            tag = (case, dim, n, nq, k, j)
+            assert nb[j] == n0[0] == singles[j][2][0], tag
+            assert ib[j].tolist() == i0[0].tolist() == singles[j][1][0].tolist(), tag
+            assert cb[j].tobytes() == c0[0].tobytes() == singles[j][0][0].tobytes(), tag
+        if case % 6 == 0:
+            dead = None
+            if n > 40 and case % 2:
+                dead = np.zeros((n + 31) // 32, np.uint32)
+                for d in dead_ids:
+                    dead[d >> 5] |= np.uint32(1 << (d & 31))
+            c0, i0, n0 = ref.search_raw(qs[0], k)
+            ecos, eids = oracle.scan_topk(rows, qs[0], k, dead=dead, mode="omp")
+            assert_topk_equal(c0[0][: n0[0]], i0[0][: n0[0]], ecos, eids, rows, qs[0], oracle)
+        st.close(); ref.close()
