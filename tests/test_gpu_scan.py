@@ -674,3 +674,48 @@ def test_randomised_paths_agree(VS, oracle, monkeypatch):
             ecos, eids = oracle.scan_topk(rows, qs[0], k, dead=dead, mode="omp")
             assert_topk_equal(c0[0][: n0[0]], i0[0][: n0[0]], ecos, eids, rows, qs[0], oracle)
         st.close(); ref.close()
+
+
+@pytest.mark.parametrize("world,nq,k", [(8, 1, 10), (8, 9, 200), (8, 64, 10), (2, 5, 1), (8, 3, 1024), (4, 2, 700),
+                                        (3, 1000, 10)])
+def test_device_shard_merge_matches_host_statement(gpu_lib, world, nq, k):
+    """cs_merge_topk_device (S4: what every rank runs on the all-gathered [world][nq][k] keys) against the
+    host statement of the merge, with empty slots, duplicates across shards excluded by construction (ids are
+    shard-disjoint) and the multi-level path (world * k > one sort: k = 700, 1024)."""
+    import ctypes as C
+
+    import torch
+
+    from codesearch_amd import _lib
+    from codesearch_amd.sharded import key_pack, key_unpack, merge_keys_host
+
+    rng = np.random.default_rng(world * 1000 + nq + k)
+    lists = np.zeros((world, nq, k), np.uint64)
+    for w in range(world):
+        for q in range(nq):
+            live = int(rng.integers(0, k + 1)) if (w + q) % 3 else k      # some lists only partly filled
+            cos = np.sort(rng.uniform(-1, 1, size=live).astype(np.float32))[::-1]
+            if live > 2:
+                cos[1] = cos[0]                                            # equal cosines: id order decides
+            ids = (w * 1_000_000 + np.sort(rng.choice(900_000, size=live, replace=False))).astype(np.uint32)
+            keys = np.sort(key_pack(cos, ids))[::-1]
+            lists[w, q, :live] = keys
+    want = merge_keys_host(lists, k)
+    dev = "cuda:0"
+    d_in = torch.from_numpy(lists.view(np.int64)).to(dev)
+    d_keys = torch.zeros((nq, k), dtype=torch.int64, device=dev)
+    d_cos = torch.zeros((nq, k), dtype=torch.float32, device=dev)
+    d_ids = torch.zeros((nq, k), dtype=torch.int32, device=dev)
+    d_cnt = torch.zeros((nq,), dtype=torch.int32, device=dev)
+    vp = lambda t: C.c_void_p(t.data_ptr())
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    _lib.check(gpu_lib.cs_merge_topk_device(0, vp(d_in), world, nq, k, vp(d_keys), vp(d_cos), vp(d_ids), vp(d_cnt), stream))
+    torch.cuda.synchronize()
+    got = d_keys.cpu().numpy().view(np.uint64)
+    assert (got == want).all()
+    wc, wi = key_unpack(want)
+    live = want != 0
+    assert (d_cnt.cpu().numpy().astype(np.uint32) == live.sum(axis=1)).all()
+    assert (d_cos.cpu().numpy()[live] == wc[live]).all()
+    assert (d_ids.cpu().numpy().view(np.uint32)[live] == wi[live]).all()
+    assert (d_ids.cpu().numpy().view(np.uint32)[~live] == 0xFFFFFFFF).all()
