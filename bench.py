@@ -160,7 +160,8 @@ def hbm_reference(device, nbytes=2 << 30, reps=10):
     src = torch.empty(nbytes // 4, dtype=torch.float32, device=device).normal_()
     dst = torch.empty_like(src)
     out = {}
-    for name, fn, moved in (("copy", lambda: dst.copy_(src), 2 * nbytes), ("fill", lambda: dst.zero_(), nbytes)):
+    for name, fn, moved in (("copy", lambda: dst.copy_(src), 2 * nbytes), ("fill", lambda: dst.zero_(), nbytes),
+                            ("read", lambda: torch.sum(src), nbytes)):
         for _ in range(2):
             fn()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -170,7 +171,8 @@ def hbm_reference(device, nbytes=2 << 30, reps=10):
         e1.record()
         torch.cuda.synchronize()
         out[name + "_GBps"] = moved / (e0.elapsed_time(e1) * 1e-3 / reps) / 1e9
-    out["note"] = (f"torch copy_ (read + write bytes counted) and zero_ over {nbytes >> 20} MiB on this device; "
+    out["note"] = (f"torch copy_ (read + write bytes counted), zero_ and sum (a read-only pass, the scan's own traffic "
+                   f"shape) over {nbytes >> 20} MiB on this device; "
                    "MI355X_MICROARCH.md quotes 6.29 TB/s for a float4 copy")
     del src, dst
     torch.cuda.empty_cache()
