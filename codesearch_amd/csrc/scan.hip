@@ -432,7 +432,19 @@ static int blocks_per_cu(uint32_t dim, uint32_t qtile, uint32_t kpad) {
     if (dim == 384) nb = qtile == 4 ? occupancy_of<3, 4, 4>(lds) : qtile == 2 ? occupancy_of<3, 4, 2>(lds) : occupancy_of<3, 4, 1>(lds);
     else if (dim == 768) nb = qtile == 4 ? occupancy_of<6, 2, 4>(lds) : qtile == 2 ? occupancy_of<6, 2, 2>(lds) : occupancy_of<6, 2, 1>(lds);
     else nb = qtile == 4 ? occupancy_of<8, 2, 4>(lds) : qtile == 2 ? occupancy_of<8, 2, 2>(lds) : occupancy_of<8, 2, 1>(lds);
-    return nb > 8 ? 8 : nb;
+    // One or two queries per pass: TWO resident blocks per CU (8 waves, 96 KiB of loads in flight), not the 5 the
+    // occupancy allows.  A read-only stream of the scan's shape reaches 6.96 TB/s with 2 blocks per CU and 6.82
+    // with 5 (benchmarks/hbm_read_probe.hip), and the scan follows: 10M x 384, same box, 2.344 -> 2.237 ms at
+    // k = 10, 2.399 -> 2.305 at k = 200, two queries per pass 2.62 -> 2.29 ms; 1024-d 3.05 -> 2.97; 768-d within
+    // 1 %; 3 and 4 blocks are no better than 5, 1 block is 6 % worse.  Four queries per pass are VALU-heavy and
+    // keep the full occupancy (2.67 vs 3.22 ms).  CS_SCAN_BLOCKS_PER_CU overrides (A/B).
+    static const int forced = [] {
+        const char* e = std::getenv("CS_SCAN_BLOCKS_PER_CU");
+        return e ? std::atoi(e) : 0;
+    }();
+    nb = nb > 8 ? 8 : nb;
+    const int cap = forced > 0 ? forced : (qtile <= 2 ? 2 : 8);
+    return nb > cap ? cap : nb;
 }
 
 ScanPlan plan_scan(uint64_t n_rows, uint32_t dim, uint32_t nq, uint32_t k, int num_cus) {
