@@ -44,7 +44,7 @@ static double run(const f32x4* d, size_t bytes, int blocks, float* d_out, int re
 
 int main(int argc, char** argv) {
     const double gib = argc > 1 ? atof(argv[1]) : 14.3;  // 15.36 GB = the scan's corpus
-    const size_t bytes = (size_t)(gib * (1ull << 30)) / (12 * 64 * 16) * (12 * 64 * 16);
+    const size_t bytes = (size_t)(gib * (1ull << 30)) / (144 * 64 * 16) * (144 * 64 * 16);  // a multiple of every tile size tried
     hipDeviceProp_t prop;
     hipGetDeviceProperties(&prop, 0);
     const int cus = prop.multiProcessorCount;
@@ -52,11 +52,13 @@ int main(int argc, char** argv) {
     float* d_out = nullptr;
     if (hipMalloc(&d, bytes) != hipSuccess || hipMalloc(&d_out, 1 << 22) != hipSuccess) { printf("alloc failed\n"); return 1; }
     hipMemset(d, 0, bytes);
-    for (int bpc : {2, 4, 5, 8}) {
+    for (int bpc : {1, 2, 4, 5, 8}) {
         const int blocks = cus * bpc;
-        printf("%.2f GB, %d blocks/CU: 12 loads nt %.3f TB/s, 12 loads cached %.3f TB/s, 6 loads nt %.3f TB/s, 24 loads nt %.3f TB/s\n",
+        printf("%.2f GB, %d blocks/CU: 12 loads nt %.3f TB/s, 12 loads cached %.3f TB/s, 6 loads nt %.3f TB/s, 24 loads nt %.3f TB/s, "
+               "36 loads nt %.3f TB/s, 48 loads nt %.3f TB/s\n",
                bytes / 1e9, bpc, run<12, true>(d, bytes, blocks, d_out, 10), run<12, false>(d, bytes, blocks, d_out, 10),
-               run<6, true>(d, bytes, blocks, d_out, 10), run<24, true>(d, bytes, blocks, d_out, 10));
+               run<6, true>(d, bytes, blocks, d_out, 10), run<24, true>(d, bytes, blocks, d_out, 10),
+               run<36, true>(d, bytes, blocks, d_out, 10), run<48, true>(d, bytes, blocks, d_out, 10));
     }
     hipFree(d);
     hipFree(d_out);

@@ -180,9 +180,11 @@ scan_topk_kernel(const float* __restrict__ corpus, uint64_t n_rows,
     const uint64_t nw = (uint64_t)gridDim.x * kWaves;
     const uint64_t ntiles = (n_rows + 2 * U - 1) / (2 * U);
 
-    for (uint64_t tile = gw; tile < ntiles; tile += nw) {
+    // One tile = 2U consecutive rows.  load_tile issues the tile's loads; score_tile consumes them.  (Issuing the
+    // NEXT tile's loads before scoring the current one — two register sets, loop unrolled by two — was measured
+    // and is slower at every depth: 10M x 384, one block per CU, U = 8: 2.146 -> 2.200 ms, U = 4: 2.33 ms.)
+    auto load_tile = [&](f32x4 (&x)[U][J], uint64_t tile) {
         const uint64_t row0 = tile * (2 * U);
-        f32x4 x[U][J];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             uint64_t r = row0 + 2 * u + half;
@@ -194,6 +196,9 @@ scan_topk_kernel(const float* __restrict__ corpus, uint64_t n_rows,
                 else x[u][j] = p[j * 32];
             }
         }
+    };
+    auto score_tile = [&](const f32x4 (&x)[U][J], uint64_t tile) {
+        const uint64_t row0 = tile * (2 * U);
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             float ss = 0.0f;
@@ -242,6 +247,11 @@ scan_topk_kernel(const float* __restrict__ corpus, uint64_t n_rows,
                 }
             }
         }
+    };
+    for (uint64_t tile = gw; tile < ntiles; tile += nw) {
+        f32x4 x[U][J];
+        load_tile(x, tile);
+        score_tile(x, tile);
     }
     if constexpr (PRIME) {
         // wave maxima -> HBM; the last block of this pass selects the k-th largest per query
@@ -426,7 +436,7 @@ static int occupancy_of(size_t lds) {
 
 // Resident blocks per CU of the kernel instance a plan selects (the grid is sized to be
 // fully resident: a grid-stride scan with a second wave of blocks would idle CUs).
-static int blocks_per_cu(uint32_t dim, uint32_t qtile, uint32_t kpad) {
+static int blocks_per_cu(uint32_t dim, uint32_t qtile, uint32_t kpad, bool deep) {
     const size_t lds = (size_t)qtile * kWaves * kpad * sizeof(uint64_t);
     int nb;
     if (dim == 384) nb = qtile == 4 ? occupancy_of<3, 4, 4>(lds) : qtile == 2 ? occupancy_of<3, 4, 2>(lds) : occupancy_of<3, 4, 1>(lds);
@@ -443,8 +453,24 @@ static int blocks_per_cu(uint32_t dim, uint32_t qtile, uint32_t kpad) {
         return e ? std::atoi(e) : 0;
     }();
     nb = nb > 8 ? 8 : nb;
-    const int cap = forced > 0 ? forced : (qtile <= 2 ? 2 : 8);
+    const int cap = forced > 0 ? forced : (deep ? 1 : qtile <= 2 ? 2 : 8);
     return nb > cap ? cap : nb;
+}
+
+// One query and a short list (k <= 64): ONE block per CU whose waves keep twice the rows in flight (24 x 16-B
+// loads per lane: the same 96 KiB per CU from half the waves).  Fewer concurrent streams is what the memory
+// system rewards: 10M x 384, same box, k = 10 2.236 -> 2.165 ms (88.7 % of HBM peak with the prime pass
+// included), k = 64 2.267 -> 2.199, 1M rows 254 -> 246 us.  Longer lists lose (one wave per SIMD cannot hide the
+// inserts: k = 200 2.305 -> 2.336 ms, k = 1024 2.45 -> 3.27), two queries per pass lose badly (2.23 -> 3.55).
+// CS_SCAN_DEEP=0 disables, CS_SCAN_DEEP_MAX_K moves the limit.
+static bool scan_deep(uint32_t dim, uint32_t qtile, uint32_t k) {
+    static const int max_k = [] {
+        const char* off = std::getenv("CS_SCAN_DEEP");
+        if (off && off[0] == '0') return 0;
+        const char* e = std::getenv("CS_SCAN_DEEP_MAX_K");
+        return e ? std::atoi(e) : 64;
+    }();
+    return fast_dim(dim) && qtile == 1 && (int)k <= max_k;
 }
 
 ScanPlan plan_scan(uint64_t n_rows, uint32_t dim, uint32_t nq, uint32_t k, int num_cus) {
@@ -454,10 +480,11 @@ ScanPlan plan_scan(uint64_t n_rows, uint32_t dim, uint32_t nq, uint32_t k, int n
         p.qtile = nq >= 4 ? 4 : (nq >= 2 ? 2 : 1);
         // LDS per block = qtile * 4 waves * kpad * 8 B; stay at >= 2 blocks per CU
         while (p.qtile > 1 && (size_t)p.qtile * kWaves * p.kpad * 8 > 64 * 1024) p.qtile >>= 1;
-        const uint32_t rows_per_tile = (dim == 384) ? 8 : 4;
+        p.deep = scan_deep(dim, p.qtile, k);
+        const uint32_t rows_per_tile = p.deep ? (dim == 384 ? 16 : dim == 768 ? 8 : 6) : (dim == 384) ? 8 : 4;
         const uint64_t ntiles = (n_rows + rows_per_tile - 1) / rows_per_tile;
         const uint64_t blocks = (ntiles + kWaves - 1) / kWaves;
-        const uint64_t cap = (uint64_t)num_cus * blocks_per_cu(dim, p.qtile, p.kpad);
+        const uint64_t cap = (uint64_t)num_cus * blocks_per_cu(dim, p.qtile, p.kpad, p.deep);
         p.blocks = (uint32_t)(blocks < 1 ? 1 : (blocks > cap ? cap : blocks));
     } else {
         p.qtile = 1;
@@ -540,7 +567,11 @@ int32_t launch_scan(const ScanPlan& plan, const float* d_corpus, uint64_t n_rows
         CS_HIP(hipMemsetAsync(d_partial, 0, plan.partial_keys * sizeof(uint64_t), stream));
         return CS_OK;
     }
-    if (dim == 384) launch_fast_q<3, 4>(plan, d_corpus, n_rows, d_queries, nq, k, d_dead, id_base, d_partial, prime, prime_pass, stream);
+    if (plan.deep && plan.qtile == 1) {
+        if (dim == 384) launch_fast<3, 8, 1>(plan, d_corpus, n_rows, d_queries, nq, k, d_dead, id_base, d_partial, prime, prime_pass, stream);
+        else if (dim == 768) launch_fast<6, 4, 1>(plan, d_corpus, n_rows, d_queries, nq, k, d_dead, id_base, d_partial, prime, prime_pass, stream);
+        else launch_fast<8, 3, 1>(plan, d_corpus, n_rows, d_queries, nq, k, d_dead, id_base, d_partial, prime, prime_pass, stream);
+    } else if (dim == 384) launch_fast_q<3, 4>(plan, d_corpus, n_rows, d_queries, nq, k, d_dead, id_base, d_partial, prime, prime_pass, stream);
     else if (dim == 768) launch_fast_q<6, 2>(plan, d_corpus, n_rows, d_queries, nq, k, d_dead, id_base, d_partial, prime, prime_pass, stream);
     else if (dim == 1024) launch_fast_q<8, 2>(plan, d_corpus, n_rows, d_queries, nq, k, d_dead, id_base, d_partial, prime, prime_pass, stream);
     else {

@@ -10,6 +10,7 @@ struct ScanPlan {
     uint32_t kpad;       // per-wave list capacity (power of two >= k, >= 64)
     uint32_t qtile;      // queries handled per scan pass
     uint32_t passes;     // ceil(nq / qtile)  (grid.y)
+    bool deep;           // one block per CU with twice the rows in flight per wave (one query, k <= 64)
     size_t partial_keys; // u64 count needed for the scan's partial buffer
     size_t merge_keys;   // u64 count needed for the merge ping-pong buffer
 };
