@@ -649,19 +649,24 @@ score_filter256p_kernel(const _Float16* __restrict__ corpus_h, uint64_t row_lo, 
 // With few queries the filter is a pure stream of the f16 corpus copy, and what limits a
 // tile-at-a-time kernel is bytes in flight per CU (one 16 KB corpus stage per block) against HBM
 // latency.  Here one persistent block per CU keeps its 32*NQT unit queries in LDS for its whole
-// life and gives ALL remaining LDS to the corpus: each of the 4 waves owns 32 rows of a 128-row
-// tile and a private ring of R 4-KiB slots filled by LDS-DMA, R-1 stages (7 x 16 KB per CU at
-// NQT = 1) in flight across tile boundaries under counted vmcnt — no barrier in the loop, since a
-// wave only reads rows it loaded itself.
+// life and gives the corpus a ring in the remaining LDS: each of the 4 waves owns 32 rows of a 128-row
+// tile and a private ring of R 4-KiB slots filled by LDS-DMA, R-1 stages (3 x 16 KB per CU at
+// NQT = 1, see RCAP) in flight across tile boundaries under counted vmcnt — no barrier in the loop,
+// since a wave only reads rows it loaded itself.
 template <int NQT, int KC = 6>  // KC = dim / 64 k-chunks per row: 6 / 12 / 16 for dim 384 / 768 / 1024
 struct RwGeom {
     static constexpr int QROWS = 32 * NQT;
     static constexpr int WBYTES = KC * QROWS * 128;            // resident queries: KC chunks x QROWS x 128 B
     static constexpr int PEND = (int)kPend;                    // pending candidates per wave (8 B each)
     static constexpr int RMAX = (160 * 1024 - 4 * PEND * 8 - WBYTES) / 16384;
-    static constexpr int R = RMAX > 8 ? 8 : RMAX;              // ring slots (16 KiB each, 4 KiB per wave):
-                                                               // dim 384: 8 / 6 / 3 at NQT 1 / 2 / 4; 768: 6 / 3; 1024: 5
-    static constexpr int LDS = WBYTES + R * 16384;             // dim 384: 155,648 / 147,456 / 147,456 B
+    // Up to 32 queries the ring stops at 4 slots (3 stages = 48 KiB in flight per CU) although LDS would hold 8:
+    // the memory system rewards fewer outstanding requests (benchmarks/hbm_read_probe.hip; 8 queries over
+    // 10M x 384: 1.284 -> 1.270 ms, 9 queries k = 200: 1.420 -> 1.413; 3 slots measure the same, 768 / 1024-d
+    // within 0.5 % either way).
+    static constexpr int RCAP = NQT == 1 ? 4 : 8;
+    static constexpr int R = RMAX > RCAP ? RCAP : RMAX;              // ring slots (16 KiB each, 4 KiB per wave):
+                                                               // dim 384: 4 / 6 / 3 at NQT 1 / 2 / 4; 768: 4 / 3; 1024: 4
+    static constexpr int LDS = WBYTES + R * 16384;             // dim 384: 90,112 / 147,456 / 147,456 B
     static constexpr int LDS_ALL = LDS + 4 * PEND * 8;         // + 4 KiB
     static_assert(R >= 3, "the ring needs at least two stages in flight");
 };
