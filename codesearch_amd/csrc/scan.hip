@@ -585,9 +585,16 @@ int32_t launch_scan(const ScanPlan& plan, const float* d_corpus, uint64_t n_rows
 }
 
 static uint32_t merge_group(uint32_t k) {
-    // lists merged per block: 2048 keys per sort up to k = 512 (k = 10 -> 204 lists, k = 200 -> 10),
-    // 4096 above (k = 1024 -> 4), never fewer than 2
-    const uint32_t g = (k <= 512 ? 2048u : (uint32_t)kMergeCap) / k;
+    // lists merged per block.  Short lists (k <= 32): 512 keys per sort — 256 block lists x k = 10 become six
+    // 512-key sorts and a final 64-key one, 20 us for the two launches against 28 us with two 2048-key sorts
+    // (a single 4096-key sort: 36 us); up to k = 512: 2048 keys per sort (k = 200 -> 10 lists); 4096 above
+    // (k = 1024 -> 4); never fewer than 2.  CS_MERGE_SMALL_CAP overrides the first figure (A/B).
+    static const uint32_t small_cap = [] {
+        const char* e = std::getenv("CS_MERGE_SMALL_CAP");
+        const int v = e ? std::atoi(e) : 0;
+        return v >= 64 ? (uint32_t)v : 512u;
+    }();
+    const uint32_t g = (k <= 32 ? small_cap : k <= 512 ? 2048u : (uint32_t)kMergeCap) / k;
     return g < 2 ? 2 : g;
 }
 
