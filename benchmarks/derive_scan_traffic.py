@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""profiles/scan_traffic.json from two rocprofv3 PMC passes over bench.py (FETCH_SIZE, WRITE_SIZE; separate runs,
+--kernel-trace only).  usage: derive_scan_traffic.py FETCH_counter_collection.csv WRITE_counter_collection.csv TAG
+Keeps the first 40 scan / prime / merge dispatches of each pass as profiles/TAG_scan_pmc_{fetch,write}.csv."""
+import csv
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+fetch_csv, write_csv, tag = sys.argv[1:4]
+
+
+def rows(f):
+    return sorted(csv.DictReader(open(f)), key=lambda r: int(r["Dispatch_Id"]))
+
+
+def scans(rs):  # (prime, scan) dispatch pairs of the full-corpus scan
+    out = []
+    for i, r in enumerate(rs):
+        k = r["Kernel_Name"]
+        if "scan_topk_kernel" in k and "false, true" not in k and i > 0 and "false, true" in rs[i - 1]["Kernel_Name"]:
+            out.append((rs[i - 1], r))
+    return out
+
+
+F, W = scans(rows(fetch_csv)), scans(rows(write_csv))
+big = [i for i, t in enumerate(F) if float(t[1]["Counter_Value"]) > 5e6]  # 10M-row launches (7.5 M KB raw)
+fetch = sum(float(F[i][1]["Counter_Value"]) for i in big) / len(big)
+write = sum(float(W[i][1]["Counter_Value"]) for i in big) / len(big)
+pf = sum(float(F[i][0]["Counter_Value"]) for i in big) / len(big)
+pw = sum(float(W[i][0]["Counter_Value"]) for i in big) / len(big)
+name = F[big[0]][1]["Kernel_Name"].split("(")[0].replace("void ", "")
+doc = {"rows": 10000000, "dim": 384, "hbm_bytes_per_launch": (fetch * 2 + write) * 1024,
+       "fetch_size_kb_raw": fetch, "write_size_kb_raw": write, "prime_pass_hbm_bytes": (pf * 2 + pw) * 1024,
+       "source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only), "
+                 f"profiles/{tag}_scan_pmc_fetch.csv and {tag}_scan_pmc_write.csv, {name} over 10M rows "
+                 f"({len(big)} launches); FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports 1/2 of a 16 B/lane "
+                 f"coalesced stream); KB -> bytes x1024; the prime pass adds prime_pass_hbm_bytes"}
+json.dump(doc, open(os.path.join(ROOT, "profiles", "scan_traffic.json"), "w"), indent=1)
+cols = ["Dispatch_Id", "Kernel_Name", "Grid_Size", "Workgroup_Size", "LDS_Block_Size", "VGPR_Count", "Counter_Name",
+        "Counter_Value", "Start_Timestamp", "End_Timestamp"]
+for src, kind in ((fetch_csv, "fetch"), (write_csv, "write")):
+    keep = [r for r in rows(src) if "scan_topk" in r["Kernel_Name"] or "merge_topk" in r["Kernel_Name"]][:40]
+    with open(os.path.join(ROOT, "profiles", f"{tag}_scan_pmc_{kind}.csv"), "w", newline="") as f:
+        w = csv.DictWriter(f, fieldnames=cols, extrasaction="ignore")
+        w.writeheader()
+        w.writerows(keep)
+print(json.dumps(doc, indent=1))
