@@ -463,14 +463,17 @@ static int blocks_per_cu(uint32_t dim, uint32_t qtile, uint32_t kpad, bool deep)
 // included), k = 64 2.267 -> 2.199, 1M rows 254 -> 246 us.  Longer lists lose (one wave per SIMD cannot hide the
 // inserts: k = 200 2.305 -> 2.336 ms, k = 1024 2.45 -> 3.27), two queries per pass lose badly (2.23 -> 3.55).
 // CS_SCAN_DEEP=0 disables, CS_SCAN_DEEP_MAX_K moves the limit.
-static bool scan_deep(uint32_t dim, uint32_t qtile, uint32_t k) {
+// Between k = 65 and 128 it is still ahead over multi-million-row corpora (10M rows, k = 100: 2.228 vs 2.265 ms,
+// k = 128: 2.250 vs 2.270) and behind at 1M rows (330 vs 320 us), hence the second limit.
+static bool scan_deep(uint32_t dim, uint32_t qtile, uint32_t k, uint64_t n_rows) {
     static const int max_k = [] {
         const char* off = std::getenv("CS_SCAN_DEEP");
         if (off && off[0] == '0') return 0;
         const char* e = std::getenv("CS_SCAN_DEEP_MAX_K");
         return e ? std::atoi(e) : 64;
     }();
-    return fast_dim(dim) && qtile == 1 && (int)k <= max_k;
+    if (!fast_dim(dim) || qtile != 1 || max_k == 0) return false;
+    return (int)k <= max_k || ((int)k <= 2 * max_k && n_rows >= 4000000);
 }
 
 ScanPlan plan_scan(uint64_t n_rows, uint32_t dim, uint32_t nq, uint32_t k, int num_cus) {
@@ -480,7 +483,7 @@ ScanPlan plan_scan(uint64_t n_rows, uint32_t dim, uint32_t nq, uint32_t k, int n
         p.qtile = nq >= 4 ? 4 : (nq >= 2 ? 2 : 1);
         // LDS per block = qtile * 4 waves * kpad * 8 B; stay at >= 2 blocks per CU
         while (p.qtile > 1 && (size_t)p.qtile * kWaves * p.kpad * 8 > 64 * 1024) p.qtile >>= 1;
-        p.deep = scan_deep(dim, p.qtile, k);
+        p.deep = scan_deep(dim, p.qtile, k, n_rows);
         const uint32_t rows_per_tile = p.deep ? (dim == 384 ? 16 : dim == 768 ? 8 : 6) : (dim == 384) ? 8 : 4;
         const uint64_t ntiles = (n_rows + rows_per_tile - 1) / rows_per_tile;
         const uint64_t blocks = (ntiles + kWaves - 1) / kWaves;
