@@ -313,8 +313,10 @@ def main():
         alg_bytes = args.rows * args.dim * 4  # per launch: every row of the shard read once
         achieved = alg_bytes / (scan_us * 1e-6) / 1e9
         # the scan is HBM-bound below ~39 queries per pass and fp32-MFMA-bound above
-        filter_path = (args.nq >= int(os.environ.get("CS_FILTER_MIN_Q", "2")) and args.dim in (384, 768, 1024)
-                       and os.environ.get("CS_INDEX_SPLIT", "1")[0] != "0")
+        single_min_k = int(os.environ.get("CS_FILTER_SINGLE_MIN_K", "129"))  # index.hip run_search: one query, long list
+        wants_filter = (args.nq >= int(os.environ.get("CS_FILTER_MIN_Q", "2"))
+                        or (args.nq == 1 and single_min_k and args.k >= single_min_k and args.rows >= 2_000_000))
+        filter_path = wants_filter and args.dim in (384, 768, 1024) and os.environ.get("CS_INDEX_SPLIT", "1")[0] != "0"
         alg_flops = 2.0 * args.rows * args.nq * args.dim
         if filter_path:
             # scan_filter.hip: the filter streams the f16 unit-vector copy of the corpus (rows*dim*2 B)
@@ -342,7 +344,9 @@ def main():
                     "traffic": None, "algorithmic_flops_per_launch": alg_flops,
                     "hbm_GBps_for_information": achieved}
         else:
-            roof = {"kernel": "cs::scan_topk_kernel<3,4,1,true>" if args.dim == 384 and args.nq == 1
+            deep = args.k <= 64 or (args.k <= 128 and args.rows >= 4_000_000)  # scan.hip scan_deep()
+            roof = {"kernel": ("cs::scan_topk_kernel<3,8,1,true,false>" if deep else "cs::scan_topk_kernel<3,4,1,true,false>")
+                    if args.dim == 384 and args.nq == 1
                     else ("cs::score_append_kernel" if args.nq >= 5 else "cs::scan_topk_kernel"),
                     "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBPS, "traffic": None,

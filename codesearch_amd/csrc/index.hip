@@ -220,6 +220,7 @@ struct cs_index {
     uint64_t split_rows = 0;
     bool use_split = false;
     int filter_min_q = 2;  // query count from which the f16 filter + exact refine path is used
+    uint32_t single_filter_min_k = 129;  // ... and one query too from this k on, over >= 2M rows (0 = never)
     // primed streaming scan (scan.hip PRIME mode): from this k and this many rows on, a pass over
     // the first prime_rows rows bounds the list inserts of the full scan
     // (measured, 1 query x 384-d: 10M rows k=10 2.37 -> 2.31 ms, k=200 2.62 -> 2.41 ms; 1M rows
@@ -375,7 +376,13 @@ int32_t run_search(cs_index* h, Workspace* w, const ScanPlan& plan, const float*
     if (timed) CS_HIP(hipEventRecord(ev.e0, stream));
     // >= 5 queries: MFMA scoring + phased candidate selection (scan_mfma.hip)
     const bool split_ready = h->use_split && h->split_rows >= h->n_rows;
-    const bool filter_path = split_ready && (int)nq >= h->filter_min_q && h->n_rows > 0 && h->normed_rows >= h->n_rows;
+    // One query normally stays on the exact f32 streaming scan (the north-star kernel).  With a long list over a
+    // multi-million-row index — the reference's own retrieval_limit of 200 when a search has no query variants —
+    // the filter + refine path is taken instead: same bits, 1.40 vs 2.36 ms at k = 200 over 10M x 384, because
+    // the scan's list inserts need a second block per CU there and the filter reads half the bytes.
+    const bool wants_filter = (int)nq >= h->filter_min_q ||
+                              (nq == 1 && h->single_filter_min_k && k >= h->single_filter_min_k && h->n_rows >= 2000000);
+    const bool filter_path = split_ready && wants_filter && h->n_rows > 0 && h->normed_rows >= h->n_rows;
     w->qw.q_pinned = filter_path ? h_queries_pinned : nullptr;
     if (h_queries_pinned && !filter_path)
         CS_HIP(hipMemcpyAsync(const_cast<float*>(d_queries), h_queries_pinned, (size_t)nq * h->dim * sizeof(float),
@@ -384,7 +391,7 @@ int32_t run_search(cs_index* h, Workspace* w, const ScanPlan& plan, const float*
     // queries (1.85 ms vs 2.5 ms for two passes-in-one of the streaming scan over 10M x 384) and
     // the refine step keeps the result bit-identical.  One query stays on the streaming f32 scan
     // (the north-star kernel).  Without the filter copy, >= 5 queries use the exact-f32 MFMA path.
-    const bool use_filter = split_ready && (int)nq >= h->filter_min_q;
+    const bool use_filter = split_ready && wants_filter;
     if (h->n_rows > 0 && h->normed_rows >= h->n_rows && (use_filter || (nq >= 5 && batched_supported(h->dim)))) {
         CS_TRY(w->reserve_batched(nq, k));
         if (use_filter) {
@@ -505,6 +512,7 @@ int32_t cs_index_create(uint32_t dim, uint64_t capacity_rows, int32_t device, ui
             h->filter_min_q = std::atoi(e);
             if (h->filter_min_q < 1) h->filter_min_q = 1;
         }
+        if (const char* e = std::getenv("CS_FILTER_SINGLE_MIN_K")) h->single_filter_min_k = (uint32_t)std::atol(e);
         if (const char* e = std::getenv("CS_SCAN_PRIME_MIN_K")) h->prime_min_k = (uint32_t)std::atol(e);  // 0 = off
         if (const char* e = std::getenv("CS_SCAN_PRIME_MIN_ROWS")) h->prime_min_rows = (uint64_t)std::atoll(e);
         if (const char* e = std::getenv("CS_SCAN_PRIME_ROWS")) h->prime_rows = (uint64_t)std::atoll(e);
