@@ -313,7 +313,7 @@ def main():
         alg_bytes = args.rows * args.dim * 4  # per launch: every row of the shard read once
         achieved = alg_bytes / (scan_us * 1e-6) / 1e9
         # the scan is HBM-bound below ~39 queries per pass and fp32-MFMA-bound above
-        single_min_k = int(os.environ.get("CS_FILTER_SINGLE_MIN_K", "129"))  # index.hip run_search: one query, long list
+        single_min_k = int(os.environ.get("CS_FILTER_SINGLE_MIN_K", "100"))  # index.hip run_search: one query, long list
         wants_filter = (args.nq >= int(os.environ.get("CS_FILTER_MIN_Q", "2"))
                         or (args.nq == 1 and single_min_k and args.k >= single_min_k and args.rows >= 2_000_000))
         filter_path = wants_filter and args.dim in (384, 768, 1024) and os.environ.get("CS_INDEX_SPLIT", "1")[0] != "0"

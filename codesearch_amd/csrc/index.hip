@@ -220,7 +220,7 @@ struct cs_index {
     uint64_t split_rows = 0;
     bool use_split = false;
     int filter_min_q = 2;  // query count from which the f16 filter + exact refine path is used
-    uint32_t single_filter_min_k = 129;  // ... and one query too from this k on, over >= 2M rows (0 = never)
+    uint32_t single_filter_min_k = 100;  // ... and one query too from this k on, over >= 2M rows (0 = never)
     // primed streaming scan (scan.hip PRIME mode): from this k and this many rows on, a pass over
     // the first prime_rows rows bounds the list inserts of the full scan
     // (measured, 1 query x 384-d: 10M rows k=10 2.37 -> 2.31 ms, k=200 2.62 -> 2.41 ms; 1M rows
@@ -377,7 +377,7 @@ int32_t run_search(cs_index* h, Workspace* w, const ScanPlan& plan, const float*
     // >= 5 queries: MFMA scoring + phased candidate selection (scan_mfma.hip)
     const bool split_ready = h->use_split && h->split_rows >= h->n_rows;
     // One query normally stays on the exact f32 streaming scan (the north-star kernel).  With a long list over a
-    // multi-million-row index — the reference's own retrieval_limit of 200 when a search has no query variants —
+    // multi-million-row index — the reference's own retrieval_limit (100 or 200) when a search has no query variants —
     // the filter + refine path is taken instead: same bits, 1.40 vs 2.36 ms at k = 200 over 10M x 384, because
     // the scan's list inserts need a second block per CU there and the filter reads half the bytes.
     const bool wants_filter = (int)nq >= h->filter_min_q ||
