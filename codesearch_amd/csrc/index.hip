@@ -219,6 +219,7 @@ struct cs_index {
     _Float16* d_split = nullptr;  // unit rows [0, split_rows) as f16 [row][dim]: filter operand of the batched path
     uint64_t split_rows = 0;
     bool use_split = false;
+    float filter_margin = 0.0f;  // scan_filter.hip: bound of the f16 filter's error for this dim
     int filter_min_q = 2;  // query count from which the f16 filter + exact refine path is used
     uint32_t single_filter_min_k = 100;  // ... and one query too from this k on, over >= 2M rows (0 = never)
     // primed streaming scan (scan.hip PRIME mode): from this k and this many rows on, a pass over
@@ -245,6 +246,10 @@ namespace {
 
 int32_t grow(cs_index* h, uint64_t need_rows) {
     if (need_rows <= h->capacity) return CS_OK;
+    // Appends through cs_index_add_device may still be in flight on caller streams that do not order
+    // against the null stream (hipStreamNonBlocking, torch side streams): drain the device before the
+    // old buffers are copied and freed, or rows of an unfinished append would be lost.
+    if (h->n_rows) CS_HIP(hipDeviceSynchronize());
     uint64_t cap = h->capacity ? h->capacity * 2 : 1024;
     if (cap < need_rows) cap = need_rows;
     float* nc = nullptr;
@@ -398,7 +403,7 @@ int32_t run_search(cs_index* h, Workspace* w, const ScanPlan& plan, const float*
             CS_TRY(w->reserve_split_queries(nq, h->dim));
             CS_TRY(launch_scan_split(w->bs, w->qw, h->d_corpus, h->d_split, h->n_rows, h->dim,
                                      d_queries, nq, k, h->n_removed ? h->d_dead : nullptr, h->id_base, d_keys,
-                                     d_cos, d_ids, d_counts, stream));
+                                     d_cos, d_ids, d_counts, stream, h->filter_margin));
         } else {
             CS_TRY(launch_scan_batched(w->bs, h->d_corpus, h->d_norms, h->n_rows, h->dim, d_queries, nq, k,
                                        h->n_removed ? h->d_dead : nullptr, h->id_base, h->num_cus, d_keys, d_cos,
@@ -516,6 +521,20 @@ int32_t cs_index_create(uint32_t dim, uint64_t capacity_rows, int32_t device, ui
         if (const char* e = std::getenv("CS_SCAN_PRIME_MIN_K")) h->prime_min_k = (uint32_t)std::atol(e);  // 0 = off
         if (const char* e = std::getenv("CS_SCAN_PRIME_MIN_ROWS")) h->prime_min_rows = (uint64_t)std::atoll(e);
         if (const char* e = std::getenv("CS_SCAN_PRIME_ROWS")) h->prime_rows = (uint64_t)std::atoll(e);
+    }
+    if (h->use_split) {
+        // does the f16 MFMA take subnormal inputs exactly?  One one-wave launch per device per process.
+        static std::mutex mu;
+        static std::map<int, bool> known;
+        std::lock_guard<std::mutex> lk(mu);
+        auto it = known.find(device);
+        if (it == known.end()) {
+            bool ok = false;
+            int32_t s = sh_denorm_selftest(&ok, nullptr);
+            if (s != CS_OK) { delete h; return s; }
+            it = known.emplace(device, ok).first;
+        }
+        h->filter_margin = filter_margin(dim, it->second);
     }
     if (capacity_rows) {
         int32_t s = grow(h, capacity_rows);

@@ -97,6 +97,10 @@ int32_t launch_corpus_split(const float* d_corpus, const float* d_norms, _Float1
 int32_t launch_scan_split(const BatchedState& st, const SplitQueryWs& qw, const float* d_corpus,
                           const _Float16* d_split, uint64_t n_rows, uint32_t dim, const float* d_queries, uint32_t nq, uint32_t k, const uint32_t* d_dead,
                           uint32_t id_base, uint64_t* d_out_keys, float* d_out_cos, uint32_t* d_out_ids,
-                          uint32_t* d_out_counts, hipStream_t stream);
+                          uint32_t* d_out_counts, hipStream_t stream, float margin);
+// Proven bound of |filter cosine - exact cosine| for unit vectors of this width (scan_filter.hip header);
+// `subnormals_exact` = the f16 MFMA consumes subnormal inputs exactly (sh_denorm_selftest).
+float filter_margin(uint32_t dim, bool subnormals_exact);
+int32_t sh_denorm_selftest(bool* ok, hipStream_t s);  // gemm_split.hip
 
 }  // namespace cs

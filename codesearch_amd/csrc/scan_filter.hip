@@ -5,7 +5,7 @@
 //            never materialised.  Both operands are the UNIT vectors x/|x| and q/|q| rounded to
 //            f16 — a second, half-size copy of the corpus built at build_index (2 bytes per
 //            element: the filter also reads half the bytes of the f32 scan) — so the product is
-//            the cosine to within kFilterMargin whatever the rows' magnitudes.  An element within
+//            the cosine to within filter_margin(dim) whatever the rows' magnitudes.  An element within
 //            the margin of the query's running k-th best (tau) is appended, as a row index, to that
 //            query's candidate buffer.
 //   refine   rescore_keys_kernel: every candidate is re-scored from the f32 corpus row with the
@@ -19,13 +19,20 @@
 // contiguous, every LDS-DMA instruction reads 1 KiB of consecutive lines, and the scan walks HBM
 // sequentially (row-major rows would be visited as 128 B every 768 B, six times over).
 //
-// Error of the filter, for unit vectors: rounding both operands to f16 costs at most
-// (2 * 2^-11 + 2^-22) * sum|q_i||x_i| <= 9.8e-4; elements below the f16 normal range add at most
-// 2^-14 * sum|q_i| <= 1.2e-3 at dim 384 even if the matrix pipe flushed them; f32 accumulation
-// order <= 2.3e-5.  kFilterMargin = 2.6e-3 covers the sum, so every row whose exact cosine beats
-// tau is a candidate and the result equals the exact scan's bit for bit — ids and cosines.  The
-// price of the margin is a handful of extra candidates per query (rows whose cosine lies within
-// 2.6e-3 below the k-th best), each one 1.5 KB re-read.
+// Error of the filter, for unit vectors (filter_margin() below, per model width):
+//   * rounding both operands to f16: <= (2 * 2^-11 + 2^-22) * sum|q_i||x_i| <= 9.8e-4 (Cauchy-Schwarz);
+//   * f32 accumulation order: <= dim * 2^-24 (2.3e-5 at 384, 6.1e-5 at 1024);
+//   * elements below the f16 normal range (|v| < 2^-14): kept as f16 subnormals, absolute rounding error
+//     2^-25 each, <= 2^-24 * sqrt(dim) over both operands — IF the matrix pipe consumes f16 subnormals
+//     exactly, which cs_index_create checks once per device with the one-wave self-test the encoder uses
+//     (sh_denorm_selftest, same v_mfma_f32_32x32x16_f16); if it ever did not, both operands' small
+//     elements could be flushed: <= 2 * 2^-14 * sqrt(dim) (2.4e-3 at 384, 3.4e-3 at 768, 3.9e-3 at 1024);
+//   * 2e-5 of slack for the f32 rounding of the unit vectors and of tau itself.
+// Margin: 1.02e-3 / 1.05e-3 / 1.08e-3 at dim 384 / 768 / 1024 on hardware that passes the self-test
+// (MI355X does), 3.4e-3 / 4.4e-3 / 5.0e-3 otherwise.  Every row whose exact cosine beats tau is therefore
+// a candidate and the result equals the exact scan's bit for bit — ids and cosines.  The price of the
+// margin is a handful of extra candidates per query (rows whose cosine lies within it below the k-th
+// best), each one a 1.5 KB re-read.  CS_FILTER_MARGIN overrides (A/B only).
 // Phases (row-ordered, growing 5x: 1 K, 5 K, 25 K ... rows) and the overflow escape hatch are those
 // of scan_mfma.hip.  Serves `variants.par_iter().map(|e| store.search(e, limit))`
 // (/root/reference/src/search/mod.rs:508-511) and BASELINE.json configs 4/5.
@@ -38,7 +45,17 @@ namespace cs {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr float kFilterMargin = 2.6e-3f;  // cosine units; bound derived in the header comment
+// cosine units; bound derived in the header comment
+float filter_margin(uint32_t dim, bool subnormals_exact) {
+    static const float forced = [] {
+        const char* e = std::getenv("CS_FILTER_MARGIN");
+        return e ? (float)std::atof(e) : 0.0f;
+    }();
+    if (forced > 0.0f) return forced;
+    const float sq = sqrtf((float)dim);
+    const float small = subnormals_exact ? 5.9604645e-08f * sq : 2.0f * 6.1035156e-05f * sq;
+    return 9.8e-4f + (float)dim * 5.9604645e-08f + small + 2.0e-5f;
+}
 
 // ---- candidate append, batched per wave ---------------------------------------------------------
 // An append is a device-scope atomic WITH return on the query's counter: a ~2 us round trip during
@@ -234,7 +251,7 @@ __global__ void __launch_bounds__(256, 2)
 score_filter_kernel(const _Float16* __restrict__ corpus_h, uint64_t row_lo, uint64_t row_hi, uint32_t kchunks,
                     const _Float16* __restrict__ queries_h, uint32_t nq, const float* __restrict__ tau,
                     const uint32_t* __restrict__ dead, uint32_t* __restrict__ cand, uint32_t* __restrict__ cnt,
-                    uint32_t cap) {
+                    uint32_t cap, float margin) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const uint32_t M = (uint32_t)(row_hi - row_lo);
     const uint32_t ntiles = (nq + SH_BN - 1) / SH_BN;
@@ -259,7 +276,7 @@ score_filter_kernel(const _Float16* __restrict__ corpus_h, uint64_t row_lo, uint
         const bool qok = q < nq;
         // candidate <=> approx_cos > tau - margin, written so that NaN (a row holding NaN/Inf)
         // counts as a candidate: refine decides
-        const float tq = qok ? tau[q] - kFilterMargin : 0.0f;
+        const float tq = qok ? tau[q] - margin : 0.0f;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
 #pragma unroll
@@ -289,7 +306,7 @@ __global__ void __launch_bounds__(512, 2)
 score_filter256_kernel(const _Float16* __restrict__ corpus_h, uint64_t row_lo, uint64_t row_hi, uint32_t kchunks,
                        const _Float16* __restrict__ queries_h, uint32_t nq, const float* __restrict__ tau,
                        const uint32_t* __restrict__ dead, uint32_t* __restrict__ cand,
-                       uint32_t* __restrict__ cnt, uint32_t cap) {
+                       uint32_t* __restrict__ cnt, uint32_t cap, float margin) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const uint32_t M = (uint32_t)(row_hi - row_lo);
     const uint32_t ntiles = (nq + UF2_BN - 1) / UF2_BN;
@@ -428,7 +445,7 @@ score_filter256_kernel(const _Float16* __restrict__ corpus_h, uint64_t row_lo, u
     for (int j = 0; j < 4; ++j) {
         const uint32_t q = n0 + wc * 128 + j * 32 + l31;
         const bool qok = q < nq;
-        const float tq = qok ? tau[q] - kFilterMargin : 0.0f;
+        const float tq = qok ? tau[q] - margin : 0.0f;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
 #pragma unroll
@@ -457,7 +474,7 @@ __global__ void __launch_bounds__(512, 2)
 score_filter256p_kernel(const _Float16* __restrict__ corpus_h, uint64_t row_lo, uint64_t row_hi, uint32_t kchunks,
                         const _Float16* __restrict__ queries_h, uint32_t nq, const float* __restrict__ tau,
                         const uint32_t* __restrict__ dead, uint32_t* __restrict__ cand,
-                        uint32_t* __restrict__ cnt, uint32_t cap, uint32_t total_slots) {
+                        uint32_t* __restrict__ cnt, uint32_t cap, uint32_t total_slots, float margin) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const uint32_t M = (uint32_t)(row_hi - row_lo);
     const uint32_t mtiles = (M + UF2_BM - 1) / UF2_BM, ntiles = (nq + UF2_BN - 1) / UF2_BN;
@@ -617,7 +634,7 @@ score_filter256p_kernel(const _Float16* __restrict__ corpus_h, uint64_t row_lo, 
         for (int j = 0; j < 8; ++j) {
             const uint32_t q = n0 + wc * 128 + j * 16 + l15;
             const bool qok = q < nq;
-            const float tq = qok ? tau[q] - kFilterMargin : 0.0f;
+            const float tq = qok ? tau[q] - margin : 0.0f;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
 #pragma unroll
@@ -681,7 +698,7 @@ __global__ void __launch_bounds__(256)
 score_filter_rw_kernel(const _Float16* __restrict__ corpus_h, uint64_t row_lo, uint64_t row_hi,
                        const _Float16* __restrict__ queries_h, uint32_t nq, const float* __restrict__ tau,
                        const uint32_t* __restrict__ dead, uint32_t* __restrict__ cand,
-                       uint32_t* __restrict__ cnt, uint32_t cap, uint32_t qtiles, uint32_t nt_stream) {
+                       uint32_t* __restrict__ cnt, uint32_t cap, uint32_t qtiles, uint32_t nt_stream, float margin) {
     using G = RwGeom<NQT, KC>;
     // one query tile: every corpus byte is read by exactly one CU, once — stream it past the caches (with
     // several query tiles the blocks of an XCD share tiles through its L2: default policy)
@@ -723,7 +740,7 @@ score_filter_rw_kernel(const _Float16* __restrict__ corpus_h, uint64_t row_lo, u
     for (int t = 0; t < NQT; ++t) {
         const uint32_t q = q0 + 32 * t + l31;
         qok[t] = q < nq;
-        tq[t] = qok[t] ? tau[q] - kFilterMargin : 0.0f;
+        tq[t] = qok[t] ? tau[q] - margin : 0.0f;
     }
 
     // this wave's staging: 4 instructions of 8 rows per stage; lane -> (row 8i + lane/8, slot lane%8)
@@ -909,7 +926,7 @@ template <int J>
 static int32_t scan_split_impl(const BatchedState& st, const SplitQueryWs& qw, const float* d_corpus,
                                const _Float16* d_split, uint64_t n_rows, const float* d_queries, uint32_t nq, uint32_t k, const uint32_t* d_dead,
                                uint32_t id_base, uint64_t* d_out_keys, float* d_out_cos,
-                               uint32_t* d_out_ids, uint32_t* d_out_counts, hipStream_t stream) {
+                               uint32_t* d_out_ids, uint32_t* d_out_counts, hipStream_t stream, float margin) {
     constexpr uint32_t dim = 128 * J;
     const uint32_t cap = batched_cap(k);
     static bool attr_set = false;
@@ -1013,7 +1030,7 @@ static int32_t scan_split_impl(const BatchedState& st, const SplitQueryWs& qw, c
         using RwG = RwGeom<NQT_, 2 * J>;                                                                     \
         constexpr size_t rw_lds = RwG::LDS_ALL;                                                              \
         hipLaunchKernelGGL((score_filter_rw_kernel<NQT_, 2 * J>), dim3(blocks), dim3(256), rw_lds, stream, d_split, lo, \
-                           hi, qw.d_qsplit, nq, st.d_tau, d_dead, cand, st.d_cnt, cap, qtiles, nt_stream);   \
+                           hi, qw.d_qsplit, nq, st.d_tau, d_dead, cand, st.d_cnt, cap, qtiles, nt_stream, margin); \
     } while (0)
                 if constexpr (J == 3) {
                     if (per == 32) CS_RW_LAUNCH(1);
@@ -1042,20 +1059,20 @@ static int32_t scan_split_impl(const BatchedState& st, const SplitQueryWs& qw, c
                     const uint32_t slots = sh_grid_blocks(mt2, nt2);
                     const uint32_t grid = std::min<uint32_t>(slots, ((uint32_t)cus + 7) / 8 * 8);  // a multiple of 8: a block stays on its XCD slot
                     hipLaunchKernelGGL(score_filter256p_kernel, dim3(grid), dim3(512), UF2_LDS, stream, d_split, lo, hi,
-                                       dim / 64, qw.d_qsplit, nq, st.d_tau, d_dead, cand, st.d_cnt, cap, slots);
+                                       dim / 64, qw.d_qsplit, nq, st.d_tau, d_dead, cand, st.d_cnt, cap, slots, margin);
                 } else if (legacy256)
                     hipLaunchKernelGGL(score_filter256_kernel<true>, dim3(sh_grid_blocks(mt2, nt2)), dim3(512), UF2_LDS,
                                        stream, d_split, lo, hi, dim / 64, qw.d_qsplit, nq, st.d_tau, d_dead, cand,
-                                       st.d_cnt, cap);
+                                       st.d_cnt, cap, margin);
                 else
                     hipLaunchKernelGGL(score_filter256_kernel<false>, dim3(sh_grid_blocks(mt2, nt2)), dim3(512), UF2_LDS,
                                        stream, d_split, lo, hi, dim / 64, qw.d_qsplit, nq, st.d_tau, d_dead, cand,
-                                       st.d_cnt, cap);
+                                       st.d_cnt, cap, margin);
             } else {
                 const uint32_t mtiles = (uint32_t)((hi - lo + SH_BM - 1) / SH_BM);
                 hipLaunchKernelGGL(score_filter_kernel, dim3(sh_grid_blocks(mtiles, ntiles)), dim3(256), SH_LDS_BYTES,
                                    stream, d_split, lo, hi, dim / 64, qw.d_qsplit, nq, st.d_tau, d_dead, cand, st.d_cnt,
-                                   cap);
+                                   cap, margin);
             }
             CS_HIP(hipGetLastError());
         }
@@ -1075,9 +1092,9 @@ static int32_t scan_split_impl(const BatchedState& st, const SplitQueryWs& qw, c
 int32_t launch_scan_split(const BatchedState& st, const SplitQueryWs& qw, const float* d_corpus,
                           const _Float16* d_split, uint64_t n_rows, uint32_t dim, const float* d_queries, uint32_t nq, uint32_t k, const uint32_t* d_dead,
                           uint32_t id_base, uint64_t* d_out_keys, float* d_out_cos, uint32_t* d_out_ids,
-                          uint32_t* d_out_counts, hipStream_t stream) {
+                          uint32_t* d_out_counts, hipStream_t stream, float margin) {
 #define CS_SPLIT_ARGS st, qw, d_corpus, d_split, n_rows, d_queries, nq, k, d_dead, id_base, d_out_keys, \
-                      d_out_cos, d_out_ids, d_out_counts, stream
+                      d_out_cos, d_out_ids, d_out_counts, stream, margin
     if (dim == 384) return scan_split_impl<3>(CS_SPLIT_ARGS);
     if (dim == 768) return scan_split_impl<6>(CS_SPLIT_ARGS);
     if (dim == 1024) return scan_split_impl<8>(CS_SPLIT_ARGS);

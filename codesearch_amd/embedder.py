@@ -77,8 +77,15 @@ class ModelType(enum.Enum):
         MiniLM/E5), SURVEY.md §0 #4."""
         if self in (ModelType.BGESmallENV15, ModelType.BGESmallENV15Q):
             return BertConfig(pooling=POOL_CLS)
-        if self in (ModelType.AllMiniLML6V2, ModelType.AllMiniLML6V2Q, ModelType.ParaphraseMLMiniLML12V2):
+        if self in (ModelType.AllMiniLML6V2, ModelType.AllMiniLML6V2Q):
             return BertConfig(layers=6, pooling=POOL_MEAN)
+        if self is ModelType.ParaphraseMLMiniLML12V2:
+            # embedder.rs:58 maps this entry to fastembed's ParaphraseMLMiniLML12V2 = paraphrase-multilingual-
+            # MiniLM-L12-v2 (12 layers, a ~250k-entry SentencePiece/unigram vocabulary) whatever name() says
+            # (embedder.rs:103): a WordPiece tokenizer would embed a different model.
+            raise CsError(_lib.CS_ERR_UNSUPPORTED,
+                          f"Failed to initialize embedding model: {self.name_str()} needs a unigram (SentencePiece) "
+                          "tokenizer, which is not built")
         if self in (ModelType.AllMiniLML12V2, ModelType.AllMiniLML12V2Q):
             return BertConfig(layers=12, pooling=POOL_MEAN)
         if self is ModelType.BGEBaseENV15:     # BERT-base: 12 x 768, 12 heads of 64
@@ -299,33 +306,3 @@ class FastEmbedder:
         _lib.check(self._lib.cs_embedder_profile_read(self._h, C.byref(ms), C.byref(n), 1 if reset else 0))
         return ms.value, int(n.value)
 
-
-def smoke(oracle) -> None:
-    """Tiny encoder batch on device 0 vs the CPU oracle (called by __graft_entry__.smoke)."""
-    from .bert_params import synth_token_batch
-
-    cfg = BertConfig(vocab_size=512, layers=2, pooling=POOL_CLS)
-    emb = FastEmbedder(ModelType.BGESmallENV15, config=cfg, seed=101, device=0)
-    ids, mask = synth_token_batch(cfg, 151, 4, 16, True)
-    got = emb.embed_ids(ids, mask)
-    exp = oracle.bert_forward(cfg, oracle.bert_synth_params(cfg, 101), ids, mask)["pooled"]
-    err = float(np.abs(got - exp).max())
-    assert err < 1e-4, err
-    emb.close()
-    print(f"smoke ok: encoder parity on cuda:0, max |gpu - oracle| = {err:.2e}")
-    # the text entry point: C++ WordPiece -> cs_embedder_embed_texts, against tokenizer + encoder oracle
-    from .pipeline import synth_code_texts, synth_vocab
-    from .tokenizer import WordPieceTokenizer
-
-    vocab = synth_vocab(512)
-    tok = WordPieceTokenizer(vocab, max_length=64)
-    cfg = BertConfig(vocab_size=512, layers=2, max_position=64, pooling=POOL_MEAN)
-    emb = FastEmbedder(ModelType.BGESmallENV15, config=cfg, seed=102, device=0, tokenizer=tok)
-    texts = synth_code_texts(vocab, 5, 7, mean_words=12) + ["fn main() { [SEP] }", ""]
-    got = np.stack(emb.embed_batch(texts))
-    ids, mask = tok.encode_batch(texts)
-    exp = oracle.bert_forward(cfg, oracle.bert_synth_params(cfg, 102), ids, mask)["pooled"]
-    err = float(np.abs(got - exp).max())
-    assert err < 1e-4, err
-    emb.close()
-    print(f"smoke ok: text path (tokenizer + encoder) on cuda:0, max |gpu - oracle| = {err:.2e}")

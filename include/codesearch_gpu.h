@@ -81,7 +81,9 @@ void cs_index_destroy(cs_index* h);
 int32_t cs_index_add(cs_index* h, const float* rows, uint64_t n, uint32_t dim,
                      uint32_t* out_ids);
 /* Same, rows already in HBM on the index's device (zero-copy hand-off from the
- * encoder's pooled+normalised output). */
+ * encoder's pooled+normalised output).  The copy is asynchronous on `stream`: d_rows must stay
+ * alive and unmodified until that stream has passed this point (cs_index_build drains the
+ * device, and so does a later append that has to grow the matrix). */
 int32_t cs_index_add_device(cs_index* h, const float* d_rows, uint64_t n, uint32_t dim,
                             uint32_t* out_ids, void* stream);
 /* Appends n rows produced in place by the counter-based generator of

@@ -29,17 +29,24 @@ def VS(gpu_lib):
 
 
 def assert_topk_equal(got_cos, got_ids, exp_cos, exp_ids, corpus=None, q=None, oracle=None):
+    """ids exact; a differing id is accepted only as an fp32 summation-order tie: at every differing
+    position the two rows' float64 cosines are within 1e-6, no id is returned twice, and an id present
+    in only one of the lists (a tie across the k-th place) ties with the expected k-th cosine."""
     got_ids = list(map(int, got_ids))
     exp_ids = list(map(int, exp_ids))
     assert len(got_ids) == len(exp_ids)
     np.testing.assert_allclose(np.asarray(got_cos, np.float64), np.asarray(exp_cos, np.float64), atol=COS_TOL)
     if got_ids != exp_ids:
         assert corpus is not None, (got_ids, exp_ids)
+        assert len(set(got_ids)) == len(got_ids), got_ids
         for a, b in zip(got_ids, exp_ids):
             if a != b:  # only an fp32-order tie may swap ids
                 ca, cb = oracle.cosine_f64(q, corpus[a]), oracle.cosine_f64(q, corpus[b])
                 assert abs(ca - cb) < 1e-6, (a, b, ca, cb)
-        assert sorted(got_ids) == sorted(exp_ids) or len(set(got_ids)) == len(got_ids)
+        edge = oracle.cosine_f64(q, corpus[exp_ids[-1]])
+        for x in set(got_ids) ^ set(exp_ids):
+            cx = oracle.cosine_f64(q, corpus[x])
+            assert abs(cx - edge) < 1e-6, (x, cx, edge)
 
 
 # ---- the reference's own tests, re-expressed (store.rs:833-1028) --------------------------------
@@ -280,39 +287,108 @@ def test_concurrent_searches_are_reentrant(VS, oracle):
 
 # ---- full size (BASELINE.json target: 10M x 384, top-10) ----------------------------------------
 
-def test_full_size_10m_against_oracle_slices(VS, oracle):
-    """10M x 384 generated in HBM.  (a) planted queries: top-1 is the planted row at any
-    size; (b) exactness: the corpus is pulled back in 1M-row slices, each slice scanned by
-    the CPU oracle, slice results merged (top-k of a union = top-k of the per-slice
-    top-ks) and compared with the single GPU scan of all 10M rows."""
-    n, dim, k, seed = 10_000_000, 384, 10, 0xC0DE5EA
-    st = VS(None, dim, capacity=n)
-    st.insert_synthetic(n, seed, 0)
-    st.build_index()
-    planted_rows = [123_456, 9_999_999, 0, 5_000_001]
-    qs = np.concatenate([synth_planted(seed, seed + 2, planted_rows, dim), synth_rows(seed + 1, 0, 2, dim)])
-    cos, ids, counts = st.search_raw(qs, k)
-    assert (counts == k).all()
-    for i, r in enumerate(planted_rows):
-        assert ids[i][0] == r and cos[i][0] > 0.85
-    for i in range(len(qs)):
-        assert (np.diff(cos[i]) <= 0).all() and len(set(ids[i].tolist())) == k
-    slice_rows = 1_000_000
+def _oracle_topk_by_slices(st, oracle, qs, n, kmax, seed, dim, slice_rows=1_000_000):
+    """Exhaustive CPU answer for a corpus that only exists in HBM: pull it back in slices, scan each with
+    the oracle at kmax, merge (top-k of a union = top-k of the per-slice top-ks).  The merged list is
+    totally ordered (cosine desc, id asc), so its first k entries are the answer for every k <= kmax."""
     nsl = n // slice_rows
-    pc = np.zeros((len(qs), nsl, k), np.float32)
-    pi = np.zeros((len(qs), nsl, k), np.uint32)
+    pc = np.zeros((len(qs), nsl, kmax), np.float32)
+    pi = np.zeros((len(qs), nsl, kmax), np.uint32)
     for s in range(nsl):
         rows = st.read_rows(s * slice_rows, slice_rows)
         if s in (0, 7):  # the slice really is what the host generator says
             assert np.array_equal(rows[:1000], synth_rows(seed, s * slice_rows, 1000, dim))
         for i in range(len(qs)):
-            c, ii = oracle.scan_topk(rows, qs[i], k, id_base=s * slice_rows, mode="omp")
+            c, ii = oracle.scan_topk(rows, qs[i], kmax, id_base=s * slice_rows, mode="omp")
             pc[i, s], pi[i, s] = c, ii
         del rows
+    return [oracle.merge_topk(pc[i], pi[i], np.full(nsl, kmax, np.uint32), kmax) for i in range(len(qs))]
+
+
+def test_full_size_10m_against_oracle_slices(VS, oracle, monkeypatch):
+    """BASELINE's target: 10M x 384 generated in HBM, every search path against the exhaustive CPU oracle
+    (examples/benchmark_models.rs:155-165 generalised to top-k).
+    (a) planted queries: top-1 is the planted row at any size;
+    (b) six queries in ONE call (filter + refine path) at k = 10;
+    (c) the HEADLINE path — one query per call, k = 10: the primed one-block streaming f32 scan
+        scan_topk_kernel<3,8,1,true,false> + prime pass — for every query;
+    (d) one query per call at k = 100 and 200 (the reference's retrieval limits, src/search/mod.rs:494-502):
+        routed through filter + refine by default, and through the streaming scan on a second store
+        created with CS_FILTER_SINGLE_MIN_K=0."""
+    n, dim, seed, kmax = 10_000_000, 384, 0xC0DE5EA, 200
+    st = VS(None, dim, capacity=n)
+    st.insert_synthetic(n, seed, 0)
+    st.build_index()
+    planted_rows = [123_456, 9_999_999, 0, 5_000_001]
+    qs = np.concatenate([synth_planted(seed, seed + 2, planted_rows, dim), synth_rows(seed + 1, 0, 2, dim)])
+    k = 10
+    cos, ids, counts = st.search_raw(qs, k)
+    assert st.debug_counters() == (1, 0)
+    assert (counts == k).all()
+    for i, r in enumerate(planted_rows):
+        assert ids[i][0] == r and cos[i][0] > 0.85
     for i in range(len(qs)):
-        ecos, eids = oracle.merge_topk(pc[i], pi[i], np.full(nsl, k, np.uint32), k)
-        assert ids[i].tolist() == eids.tolist()
-        np.testing.assert_allclose(cos[i], ecos, atol=COS_TOL)
+        assert (np.diff(cos[i]) <= 0).all() and len(set(ids[i].tolist())) == k
+    expect = _oracle_topk_by_slices(st, oracle, qs, n, kmax, seed, dim)
+    for i in range(len(qs)):  # (b)
+        ecos, eids = expect[i]
+        assert ids[i].tolist() == eids[:k].tolist()
+        np.testing.assert_allclose(cos[i], ecos[:k], atol=COS_TOL)
+    for i in range(len(qs)):  # (c): the north-star kernel
+        c1, i1, n1 = st.search_raw(qs[i], 10)
+        assert n1[0] == 10 and i1[0].tolist() == expect[i][1][:10].tolist()
+        np.testing.assert_allclose(c1[0], expect[i][0][:10], atol=COS_TOL)
+        assert c1[0].tobytes() == cos[i].tobytes()  # and the two paths agree bit for bit
+    assert st.debug_counters() == (1, 0)  # none of those took the batched path
+    b = 1
+    for kk in (100, 200):  # (d) default routing: filter + refine for one long-list query
+        for i in (0, 4, 5):
+            c1, i1, n1 = st.search_raw(qs[i], kk)
+            b += 1
+            assert n1[0] == kk and i1[0].tolist() == expect[i][1][:kk].tolist()
+            np.testing.assert_allclose(c1[0], expect[i][0][:kk], atol=COS_TOL)
+    assert st.debug_counters() == (b, 0)
+    st.close()
+    monkeypatch.setenv("CS_FILTER_SINGLE_MIN_K", "0")
+    st2 = VS(None, dim, capacity=n)
+    st2.insert_synthetic(n, seed, 0)
+    st2.build_index()
+    for kk in (100, 200):  # (d) streaming f32 scan with long lists (two blocks per CU from k = 129)
+        for i in (1, 5):
+            c1, i1, n1 = st2.search_raw(qs[i], kk)
+            assert n1[0] == kk and i1[0].tolist() == expect[i][1][:kk].tolist()
+            np.testing.assert_allclose(c1[0], expect[i][0][:kk], atol=COS_TOL)
+    assert st2.debug_counters() == (0, 0)
+    st2.close()
+
+
+def test_config1_1m_single_query_against_oracle(VS, oracle):
+    """BASELINE configs[1]: one query, top-10 over 1M x 384 — the primed streaming scan at the size where
+    the prime pass and the merge are 9 % of a search — and k = 100 / 200, all against the oracle on the
+    whole corpus; then the same queries in one batched call."""
+    n, dim, seed = 1_000_000, 384, 0xC0DE5EA
+    st = VS(None, dim, capacity=n)
+    st.insert_synthetic(n, seed, 0)
+    st.delete_chunks([17, 999_999])
+    st.build_index()
+    corpus = st.read_rows(0, n)
+    assert np.array_equal(corpus[-500:], synth_rows(seed, n - 500, 500, dim))
+    dead = np.zeros((n + 31) // 32, np.uint32)
+    for d in (17, 999_999):
+        dead[d >> 5] |= np.uint32(1 << (d & 31))
+    qs = np.concatenate([synth_rows(seed + 1, 0, 3, dim), synth_planted(seed, seed + 2, [999_998], dim)])
+    expect = [oracle.scan_topk(corpus, q, 200, dead=dead, mode="omp") for q in qs]
+    for kk in (10, 100, 200):
+        for i in range(len(qs)):
+            c1, i1, n1 = st.search_raw(qs[i], kk)
+            assert n1[0] == kk
+            assert_topk_equal(c1[0], i1[0], expect[i][0][:kk], expect[i][1][:kk], corpus, qs[i], oracle)
+    assert st.debug_counters() == (0, 0)  # below 2M rows one query always streams
+    assert st.search_raw(qs[3], 10)[1][0][0] == 999_998
+    cos, ids, counts = st.search_raw(qs, 10)
+    assert st.debug_counters() == (1, 0)
+    for i in range(len(qs)):
+        assert_topk_equal(cos[i], ids[i], expect[i][0][:10], expect[i][1][:10], corpus, qs[i], oracle)
 
 
 # ---- batched queries: the MFMA scoring + phased selection path (scan_mfma.hip) ------------------
@@ -451,20 +527,27 @@ def test_f32_mfma_batched_path_still_available(VS, oracle, monkeypatch):
 
 
 @pytest.mark.parametrize("nq", [129, 300, 1000])
-def test_wide_filter_tiles_bit_identical(VS, nq):
-    """More than 128 queries take the 256 x 256 filter tiles; results stay those of the
+def test_wide_filter_tiles_bit_identical(VS, oracle, nq):
+    """More than 128 queries take the 256 x 256 filter tiles; results are the oracle's and those of the
     single-query scan, bit for bit (sampled queries)."""
     dim, n, k = 384, 300_001, 10
     st = VS(None, dim)
     st.insert_synthetic(n, 515, 0)
-    st.delete_chunks([7, n - 1])
+    dead_ids = [7, n - 1]
+    st.delete_chunks(dead_ids)
     st.build_index()
     qs = np.concatenate([synth_rows(600 + nq, 0, nq - 1, dim), synth_planted(515, 6, [n - 2], dim)])
     cos, ids, counts = st.search_raw(qs, k)
     assert st.debug_counters() == (1, 0)
+    corpus = oracle.synth_rows(515, 0, n, dim)
+    dead = np.zeros((n + 31) // 32, np.uint32)
+    for d in dead_ids:
+        dead[d >> 5] |= np.uint32(1 << (d & 31))
     for i in list(range(0, nq, max(1, nq // 16))) + [nq - 2, nq - 1]:
         c1, i1, n1 = st.search_raw(qs[i], k)
         assert counts[i] == n1[0] and ids[i].tolist() == i1[0].tolist() and cos[i].tobytes() == c1[0].tobytes()
+        ecos, eids = oracle.scan_topk(corpus, qs[i], k, dead=dead, mode="omp")
+        assert_topk_equal(cos[i], ids[i], ecos, eids, corpus, qs[i], oracle)
     assert ids[nq - 1][0] == n - 2
 
 
