@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(PKG_DIR, "libcsgpu.so")
+# CS_LIBCSGPU: another build of the same library (A/B scripts under benchmarks/)
+LIB_PATH = os.environ.get("CS_LIBCSGPU") or os.path.join(PKG_DIR, "libcsgpu.so")
 
 CS_OK, CS_ERR_BAD_ARG, CS_ERR_DIM_MISMATCH, CS_ERR_NOT_BUILT = 0, 1, 2, 3
 CS_ERR_CANCELLED, CS_ERR_OOM, CS_ERR_HIP, CS_ERR_UNSUPPORTED = 4, 5, 6, 7
@@ -67,7 +68,24 @@ SIGNATURES = {
     "cs_index_device": (C.c_int32, [vp]),
     "cs_index_search": (C.c_int32, [vp, f32p, C.c_uint32, C.c_uint32, C.c_uint32, f32p, u32p, u32p]),
     "cs_index_search_device": (C.c_int32, [vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, vp, vp, vp]),
+    "cs_index_search_status": (C.c_int32, [vp, vp, u32p]),
     "cs_merge_topk_device": (C.c_int32, [C.c_int32, vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, vp, vp, vp]),
+    "cs_shards_create": (C.c_int32, [C.c_uint32, C.c_uint32, i32p, C.c_uint64, C.c_uint64, C.POINTER(vp)]),
+    "cs_shards_destroy": (None, [vp]),
+    "cs_shards_add": (C.c_int32, [vp, f32p, C.c_uint64, C.c_uint32, u32p]),
+    "cs_shards_add_synthetic": (C.c_int32, [vp, C.c_uint64, C.c_uint64, C.c_uint64, u32p]),
+    "cs_shards_remove": (C.c_int32, [vp, u32p, C.c_uint64, u64p]),
+    "cs_shards_build": (C.c_int32, [vp]),
+    "cs_shards_clear": (C.c_int32, [vp]),
+    "cs_shards_is_built": (C.c_int32, [vp]),
+    "cs_shards_len": (C.c_uint64, [vp]),
+    "cs_shards_next_id": (C.c_uint32, [vp]),
+    "cs_shards_dim": (C.c_uint32, [vp]),
+    "cs_shards_count": (C.c_uint32, [vp]),
+    "cs_shards_shard_len": (C.c_uint64, [vp, C.c_uint32]),
+    "cs_shards_direct_gather": (C.c_int32, [vp]),
+    "cs_shards_search": (C.c_int32, [vp, f32p, C.c_uint32, C.c_uint32, C.c_uint32, f32p, u32p, u32p]),
+    "cs_shards_read_rows": (C.c_int32, [vp, C.c_uint64, C.c_uint64, f32p]),
     "cs_index_read_rows": (C.c_int32, [vp, C.c_uint64, C.c_uint64, f32p]),
     "cs_index_debug_counters": (C.c_int32, [vp, u64p, u64p]),
     "cs_index_set_filter_min_queries": (C.c_int32, [vp, C.c_uint32]),
@@ -85,6 +103,8 @@ SIGNATURES = {
     "cs_embedder_embed_ids_device": (C.c_int32, [vp, i32p, i32p, C.c_uint64, C.c_uint32, C.c_uint32, vp, i32p]),
     "cs_embedder_last_hidden": (C.c_int32, [vp, f32p, C.c_uint64]),
     "cs_embedder_profile_read": (C.c_int32, [vp, f64p, u64p, C.c_int32]),
+    "cs_embedder_profile_stages": (C.c_int32, [vp, C.c_int32]),
+    "cs_embedder_profile_stages_read": (C.c_int32, [vp, f64p, u64p, C.c_int32]),
     "cs_embedder_set_gemm_mode": (C.c_int32, [vp, C.c_int32]),
     "cs_embedder_debug_counters": (C.c_int32, [vp, u64p, u64p, u64p]),
     "cs_tokenizer_create": (C.c_int32, [C.c_char_p, C.c_uint64, C.c_int32, C.c_uint32, C.POINTER(vp)]),

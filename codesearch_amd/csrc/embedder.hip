@@ -47,6 +47,13 @@ struct cs_embedder {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     double forward_ms = 0.0;
     uint64_t forwards = 0;
+    // cs_embedder_profile_stages: one HIP event after every kernel of a forward (single stream), durations
+    // summed per kernel class
+    bool stage_profile = false;
+    std::vector<hipEvent_t> stage_ev;      // pool; stage_ev[0] precedes the first kernel
+    std::vector<int> stage_tag;            // tag of the kernel that ends at stage_ev[i + 1]
+    double stage_us[CS_ENCODER_STAGES] = {};
+    uint64_t stage_forwards = 0;
 };
 
 namespace {
@@ -141,7 +148,23 @@ int32_t forward_range(cs_embedder* h, hipStream_t s, uint32_t b0, uint32_t nb, u
     // two slices up to 10,240 rows: 7,168 rows 2048 -> 1891 us, 8,192 2203 -> 2060, 10,240 2443 -> 2369, 12,288 3034 -> 3167
     static const uint32_t split_k_max2 = [] { const char* e = std::getenv("CS_GEMM_SPLITK_MAX2_M"); return e ? (uint32_t)std::atoi(e) : 10240u; }();
     static const uint32_t split_k_ao_max = [] { const char* e = std::getenv("CS_GEMM_SPLITK_AO_MAX_M"); return e ? (uint32_t)std::atoi(e) : 2560u; }();
+    // stage profile: an event after each kernel (only on the one-stream path, see forward())
+    auto mark = [&](int tag) -> int32_t {
+        if (!h->stage_profile) return CS_OK;
+        const size_t i = h->stage_tag.size() + 1;
+        while (h->stage_ev.size() <= i) {
+            hipEvent_t e;
+            CS_HIP(hipEventCreate(&e));
+            h->stage_ev.push_back(e);
+        }
+        if (tag < 0) { CS_HIP(hipEventRecord(h->stage_ev[0], s)); return CS_OK; }
+        CS_HIP(hipEventRecord(h->stage_ev[i], s));
+        h->stage_tag.push_back(tag);
+        return CS_OK;
+    };
+    CS_TRY(mark(-1));
     CS_TRY(launch_row_kernel(0, a, H, s));  // E1
+    CS_TRY(mark(CS_STAGE_EMBED_LN));
     for (uint32_t l = 0; l < c.layers; ++l) {
         cs_bert_layer_offsets lo;
         cs_bert_layer_layout(&c, &h->off, l, &lo);
@@ -151,22 +174,30 @@ int32_t forward_range(cs_embedder* h, hipStream_t s, uint32_t b0, uint32_t nb, u
             static const bool attn_v1 = std::getenv("CS_ATTN_V1") != nullptr;  // A/B: f32 qkv + converting prologue
             if (attn_v1) {
                 CS_TRY(launch_gemm_split(SH_OUT_F32, xs, ws + sl.qkv, bqkv, nullptr, qkv, nullptr, T, 3 * H, H, h->d_flag, s));
+                CS_TRY(mark(CS_STAGE_QKV));
                 CS_TRY(launch_attention_split(qkv, mask, ctxs, h->d_flag, nb, L, H, c.heads, s));
+                CS_TRY(mark(CS_STAGE_ATTENTION));
             } else {
                 _Float16* qkvs = reinterpret_cast<_Float16*>(qkv);  // [T][3H/32][64] f16: same bytes as the f32 qkv
                 CS_TRY(launch_gemm_split(SH_OUT_SPLIT, xs, ws + sl.qkv, bqkv, nullptr, nullptr, qkvs, T, 3 * H, H, h->d_flag, s));  // E2
+                CS_TRY(mark(CS_STAGE_QKV));
                 CS_TRY(launch_attention_sh2(qkvs, mask, ctxs, h->d_flag, nb, L, H, c.heads, s));                                 // E3
+                CS_TRY(mark(CS_STAGE_ATTENTION));
             }
             a.g = P + lo.ao_ln_g; a.b = P + lo.ao_ln_b;
             if (T > split_k_min && T <= split_k_max && T <= split_k_ao_max) {
                 CS_TRY(launch_gemm_split_partial(ctxs, ws + sl.ao, qkv, T, H, H, 3, s));  // E4, K slices as for E6 below
+                CS_TRY(mark(CS_STAGE_OUT_PROJ));
                 a.parts = qkv; a.nparts = 3; a.bias = P + lo.ao_b;
                 CS_TRY(launch_row_kernel(3, a, H, s));
             } else {
                 CS_TRY(launch_gemm_split(SH_OUT_F32_RESID, ctxs, ws + sl.ao, P + lo.ao_b, x, x, nullptr, T, H, H, h->d_flag, s));  // E4
+                CS_TRY(mark(CS_STAGE_OUT_PROJ));
                 CS_TRY(launch_row_kernel(1, a, H, s));
             }
+            CS_TRY(mark(CS_STAGE_LN_ATTN));
             CS_TRY(launch_gemm_split(SH_OUT_SPLIT_GELU, xs, ws + sl.up, P + lo.up_b, nullptr, nullptr, mids, T, I, H, h->d_flag, s));    // E5
+            CS_TRY(mark(CS_STAGE_FFN_UP));
             a.g = P + lo.out_ln_g; a.b = P + lo.out_ln_b;
             if (T > split_k_min && T <= split_k_max2) {
                 // a few thousand token rows: FFN-down is 3 x T / 128 blocks walking 48 K stages one exposed
@@ -174,26 +205,37 @@ int32_t forward_range(cs_embedder* h, hipStream_t s, uint32_t b0, uint32_t nb, u
                 // slabs in the qkv buffer (free by now), summed with bias and residual by the LayerNorm that follows
                 const uint32_t ks = T <= split_k_max ? 3 : 2;
                 CS_TRY(launch_gemm_split_partial(mids, ws + sl.down, qkv, T, H, I, ks, s));  // E6
+                CS_TRY(mark(CS_STAGE_FFN_DOWN));
                 a.parts = qkv; a.nparts = ks; a.bias = P + lo.down_b;
                 CS_TRY(launch_row_kernel(3, a, H, s));
             } else {
                 CS_TRY(launch_gemm_split(SH_OUT_F32_RESID, mids, ws + sl.down, P + lo.down_b, x, x, nullptr, T, H, I, h->d_flag, s)); // E6
+                CS_TRY(mark(CS_STAGE_FFN_DOWN));
                 CS_TRY(launch_row_kernel(1, a, H, s));
             }
+            CS_TRY(mark(CS_STAGE_LN_FFN));
         } else {
             const float* wqkv = h->d_wqkv + (size_t)l * 3 * H * H;
             CS_TRY(launch_gemm(GEMM_BIAS, x, wqkv, bqkv, nullptr, qkv, T, 3 * H, H, s));        // E2
+            CS_TRY(mark(CS_STAGE_QKV));
             CS_TRY(launch_attention(qkv, mask, ctx, nb, L, H, c.heads, s));                     // E3
+            CS_TRY(mark(CS_STAGE_ATTENTION));
             CS_TRY(launch_gemm(GEMM_RESID, ctx, P + lo.ao_w, P + lo.ao_b, x, x, T, H, H, s));   // E4
+            CS_TRY(mark(CS_STAGE_OUT_PROJ));
             a.g = P + lo.ao_ln_g; a.b = P + lo.ao_ln_b;
             CS_TRY(launch_row_kernel(1, a, H, s));
+            CS_TRY(mark(CS_STAGE_LN_ATTN));
             CS_TRY(launch_gemm(GEMM_GELU, x, P + lo.up_w, P + lo.up_b, nullptr, mid, T, I, H, s)); // E5
+            CS_TRY(mark(CS_STAGE_FFN_UP));
             CS_TRY(launch_gemm(GEMM_RESID, mid, P + lo.down_w, P + lo.down_b, x, x, T, H, I, s));  // E6
+            CS_TRY(mark(CS_STAGE_FFN_DOWN));
             a.g = P + lo.out_ln_g; a.b = P + lo.out_ln_b;
             CS_TRY(launch_row_kernel(1, a, H, s));
+            CS_TRY(mark(CS_STAGE_LN_FFN));
         }
     }
     CS_TRY(launch_row_kernel(2, a, H, s));  // E7 + E8
+    CS_TRY(mark(CS_STAGE_POOL));
     return CS_OK;
 }
 
@@ -212,7 +254,8 @@ int32_t forward(cs_embedder* h, uint32_t B, uint32_t L, int mode) {
         const char* e = std::getenv("CS_ENCODER_STREAM_MIN_TOKENS");
         return e ? (uint64_t)std::atoll(e) : (uint64_t)20000;
     }();
-    if (h->n_streams >= 2 && B >= (uint32_t)h->n_streams && (uint64_t)B * L >= stream_min_tokens) {
+    h->stage_tag.clear();
+    if (!h->stage_profile && h->n_streams >= 2 && B >= (uint32_t)h->n_streams && (uint64_t)B * L >= stream_min_tokens) {
         const uint32_t ns = (uint32_t)h->n_streams;
         hipStream_t st[4] = {s, h->stream2, h->xstreams[0], h->xstreams[1]};
         hipEvent_t jn[4] = {nullptr, h->ev_join, h->xjoin[0], h->xjoin[1]};
@@ -310,6 +353,14 @@ int32_t embed_impl(cs_embedder* h, const int32_t* ids, const int32_t* mask, uint
         if (hipEventElapsedTime(&ms, h->ev0, h->ev1) == hipSuccess) {
             h->forward_ms += ms;
             h->forwards += 1;
+        }
+        if (h->stage_profile && !h->stage_tag.empty()) {  // the stream is idle here (synchronised above)
+            for (size_t i = 0; i < h->stage_tag.size(); ++i) {
+                float us = 0.f;
+                if (hipEventElapsedTime(&us, h->stage_ev[i], h->stage_ev[i + 1]) == hipSuccess)
+                    h->stage_us[h->stage_tag[i]] += (double)us * 1e3;
+            }
+            h->stage_forwards += 1;
         }
     }
     return CS_OK;
@@ -589,6 +640,7 @@ void cs_embedder_destroy(cs_embedder* h) {
     if (h->d_bqkv) (void)hipFree(h->d_bqkv);
     if (h->d_wsplit) (void)hipFree(h->d_wsplit);
     if (h->d_flag) (void)hipFree(h->d_flag);
+    for (hipEvent_t e : h->stage_ev) (void)hipEventDestroy(e);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
@@ -639,6 +691,24 @@ int32_t cs_embedder_profile_read(cs_embedder* h, double* forward_ms, uint64_t* f
     if (forward_ms) *forward_ms = h->forward_ms;
     if (forwards) *forwards = h->forwards;
     if (reset) { h->forward_ms = 0.0; h->forwards = 0; }
+    return CS_OK;
+}
+
+int32_t cs_embedder_profile_stages(cs_embedder* h, int32_t enable) {
+    if (!h) return fail(CS_ERR_BAD_ARG, "null embedder handle");
+    h->stage_profile = enable != 0;
+    return CS_OK;
+}
+
+int32_t cs_embedder_profile_stages_read(cs_embedder* h, double* us_per_stage, uint64_t* forwards, int32_t reset) {
+    if (!h) return fail(CS_ERR_BAD_ARG, "null embedder handle");
+    if (us_per_stage)
+        for (int i = 0; i < CS_ENCODER_STAGES; ++i) us_per_stage[i] = h->stage_us[i];
+    if (forwards) *forwards = h->stage_forwards;
+    if (reset) {
+        for (int i = 0; i < CS_ENCODER_STAGES; ++i) h->stage_us[i] = 0.0;
+        h->stage_forwards = 0;
+    }
     return CS_OK;
 }
 

@@ -4,6 +4,9 @@
 #include <cstring>
 #include <map>
 #include <mutex>
+#include <thread>
+#include <tuple>
+#include <utility>
 #include <vector>
 
 #include <cstdlib>
@@ -92,8 +95,11 @@ struct Workspace {
 
     int32_t reserve_batched(uint32_t nq, uint32_t k) {
         const size_t cand = (size_t)nq * batched_cap(k), carry = (size_t)nq * k;
-        if (!h_overflow) CS_HIP(hipHostMalloc(&h_overflow, sizeof(uint32_t)));
-        if (!bs.d_overflow) CS_HIP(hipMalloc(&bs.d_overflow, sizeof(uint32_t)));
+        if (!h_overflow) CS_HIP(hipHostMalloc(&h_overflow, 4 * sizeof(uint32_t)));
+        if (!bs.d_overflow) {  // [0] this search, [1] sticky, [2] overflowed searches so far (scan.hpp BatchedState)
+            CS_HIP(hipMalloc(&bs.d_overflow, 4 * sizeof(uint32_t)));
+            CS_HIP(hipMemset(bs.d_overflow, 0, 4 * sizeof(uint32_t)));
+        }
         if (nq > bs_nq) {
             if (bs.d_cnt) (void)hipFree(bs.d_cnt);
             if (bs.d_tau) (void)hipFree(bs.d_tau);
@@ -235,7 +241,9 @@ struct cs_index {
 
     std::mutex mu;  // guards the pools below (search is re-entrant)
     std::vector<Workspace*> pool;
-    std::map<hipStream_t, Workspace*> by_stream;
+    // device-API scratch: one set per (stream, calling thread) — stream order makes reuse safe within a
+    // thread, and two threads sharing a stream (e.g. both on the null stream) never share a set
+    std::map<std::pair<hipStream_t, std::thread::id>, Workspace*> by_stream;
     bool profile = false;
     std::vector<EventTriple> pending;
     double scan_ms = 0.0, merge_ms = 0.0;
@@ -243,6 +251,8 @@ struct cs_index {
 };
 
 namespace {
+
+constexpr uint32_t kGatedMaxQ = 16;  // device-API searches of up to this many queries carry a gated exact rerun
 
 int32_t grow(cs_index* h, uint64_t need_rows) {
     if (need_rows <= h->capacity) return CS_OK;
@@ -349,11 +359,12 @@ void release_pooled(cs_index* h, Workspace* w) {
 
 Workspace* for_stream(cs_index* h, hipStream_t s) {
     std::lock_guard<std::mutex> lk(h->mu);
-    auto it = h->by_stream.find(s);
+    const auto key = std::make_pair(s, std::this_thread::get_id());
+    auto it = h->by_stream.find(key);
     if (it != h->by_stream.end()) return it->second;
     Workspace* w = new Workspace();
     w->stream = s;
-    h->by_stream[s] = w;
+    h->by_stream[key] = w;
     return w;
 }
 
@@ -375,7 +386,8 @@ bool take_events(cs_index* h, Workspace* w, EventTriple* t) {
 // the filter path lets its prep kernel bring them over, every other path copies them first.
 int32_t run_search(cs_index* h, Workspace* w, const ScanPlan& plan, const float* d_queries,
                    uint32_t nq, uint32_t k, uint64_t* d_keys, float* d_cos, uint32_t* d_ids,
-                   uint32_t* d_counts, hipStream_t stream, const float* h_queries_pinned = nullptr) {
+                   uint32_t* d_counts, hipStream_t stream, const float* h_queries_pinned = nullptr,
+                   bool may_sync = true) {
     EventTriple ev{};
     const bool timed = take_events(h, w, &ev);
     if (timed) CS_HIP(hipEventRecord(ev.e0, stream));
@@ -410,9 +422,38 @@ int32_t run_search(cs_index* h, Workspace* w, const ScanPlan& plan, const float*
                                        d_ids, d_counts, stream));
         }
         if (timed) CS_HIP(hipEventRecord(ev.e1, stream));
-        CS_HIP(hipMemcpyAsync(w->h_overflow, w->bs.d_overflow, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-        CS_HIP(hipStreamSynchronize(stream));
-        bool overflow = *w->h_overflow != 0;
+        // A candidate buffer holds batched_cap(k) entries and a phase appends at most one per row: it can
+        // only overflow over more rows than that (adversarial row order; thousands of near-duplicate rows).
+        const bool can_overflow = h->n_rows > batched_cap(k);
+        if (!may_sync) {
+            // Device API: never wait for the device.  Up to kGatedMaxQ queries, the exact list-based scan and
+            // its merge are enqueued right behind the search with the overflow word as their gate: every
+            // block exits at once unless the search overflowed (then they overwrite its outputs), so what
+            // the caller's stream delivers is exact either way; cost when not taken ~3 near-empty launches.
+            // Above that (hundreds of query passes would be enqueued) the sticky word is left for
+            // cs_index_search_status().
+            if (can_overflow && nq <= kGatedMaxQ) {
+                const uint32_t* gate = w->bs.d_overflow;
+                CS_TRY(launch_scan(plan, h->d_corpus, h->n_rows, h->dim, d_queries, nq, k,
+                                   h->n_removed ? h->d_dead : nullptr, h->id_base, w->d_partial, stream, nullptr, false,
+                                   gate));
+                CS_TRY(launch_merge(w->d_partial, plan.blocks, nq, k, false, w->d_tmp_a, w->d_tmp_b, d_keys, d_cos, d_ids,
+                                    d_counts, stream, gate));
+            }
+            std::lock_guard<std::mutex> lk(h->mu);
+            h->batched_searches++;
+            if (timed) {
+                CS_HIP(hipEventRecord(ev.e2, stream));
+                h->pending.push_back(ev);
+            }
+            return CS_OK;
+        }
+        bool overflow = false;
+        if (can_overflow) {  // host-buffer API: it synchronises for its results anyway
+            CS_HIP(hipMemcpyAsync(w->h_overflow, w->bs.d_overflow, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+            CS_HIP(hipStreamSynchronize(stream));
+            overflow = *w->h_overflow != 0;
+        }
         {
             std::lock_guard<std::mutex> lk(h->mu);
             h->batched_searches++;
@@ -423,7 +464,7 @@ int32_t run_search(cs_index* h, Workspace* w, const ScanPlan& plan, const float*
             }
         }
         if (!overflow) return CS_OK;
-        // candidate buffer overflowed (adversarial row order): exact list-based rerun below
+        // candidate buffer overflowed: exact list-based rerun below
         EventTriple none{};
         ev = none;
         return [&]() -> int32_t {
@@ -484,7 +525,7 @@ int32_t check_search(const cs_index* h, uint32_t nq, uint32_t dim, uint32_t k) {
 extern "C" {
 
 const char* cs_last_error(void) { return last_error_ref().c_str(); }
-uint32_t cs_abi_version(void) { return 3; }
+uint32_t cs_abi_version(void) { return 4; }
 
 int32_t cs_device_count(void) {
     int n = 0;
@@ -712,30 +753,70 @@ int32_t cs_index_search_device(cs_index* h, const float* d_queries, uint32_t nq,
     Workspace* w = for_stream(h, (hipStream_t)stream);
     CS_TRY(w->reserve(plan, nq, h->dim, k, false));
     return run_search(h, w, plan, d_queries, nq, k, d_out_keys, d_out_cos, d_out_ids, d_out_counts,
-                      (hipStream_t)stream);
+                      (hipStream_t)stream, nullptr, /*may_sync=*/false);
+}
+
+int32_t cs_index_search_status(cs_index* h, void* stream, uint32_t* overflowed) {
+    if (!h || !overflowed) return fail(CS_ERR_BAD_ARG, "null argument");
+    *overflowed = 0;
+    DeviceGuard g(h->device);
+    Workspace* w = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(h->mu);
+        auto it = h->by_stream.find(std::make_pair((hipStream_t)stream, std::this_thread::get_id()));
+        if (it != h->by_stream.end()) w = it->second;
+    }
+    if (!w || !w->bs.d_overflow) return CS_OK;  // no batched search was issued here
+    CS_HIP(hipMemcpyAsync(w->h_overflow, w->bs.d_overflow, 3 * sizeof(uint32_t), hipMemcpyDeviceToHost,
+                          (hipStream_t)stream));
+    CS_HIP(hipMemsetAsync(w->bs.d_overflow + 1, 0, sizeof(uint32_t), (hipStream_t)stream));
+    CS_HIP(hipStreamSynchronize((hipStream_t)stream));
+    *overflowed = w->h_overflow[1];
+    return CS_OK;
 }
 
 int32_t cs_merge_topk_device(int32_t device, const uint64_t* d_keys, uint32_t nlists, uint32_t nq,
                              uint32_t k, uint64_t* d_out_keys, float* d_out_cos,
                              uint32_t* d_out_ids, uint32_t* d_out_counts, void* stream) {
+    return cs::merge_topk_device_impl(device, d_keys, nlists, nq, k, d_out_keys, d_out_cos, d_out_ids, d_out_counts,
+                                      (hipStream_t)stream, 0, 0);
+}
+
+}  // extern "C"
+
+int32_t cs::merge_topk_device_impl(int32_t device, const uint64_t* d_keys, uint32_t nlists, uint32_t nq, uint32_t k,
+                                   uint64_t* d_out_keys, float* d_out_cos, uint32_t* d_out_ids, uint32_t* d_out_counts,
+                                   hipStream_t stream, uint32_t remap_stripe, uint32_t remap_shards) {
     if (!d_keys || nlists == 0 || nq == 0 || k == 0 || k > CS_MAX_K)
         return fail(CS_ERR_BAD_ARG, "bad merge arguments");
     DeviceGuard g(device);
     const size_t tmp = merge_tmp_keys(nlists, nq, k);
     uint64_t *ta = nullptr, *tb = nullptr;
-    if (tmp) {  // more than 2048 keys per query: rare (8 shards x k<=256 fits one pass)
-        CS_HIP(hipMalloc(&ta, tmp * sizeof(uint64_t)));
-        CS_HIP(hipMalloc(&tb, tmp * sizeof(uint64_t)));
-    }
-    int32_t s = launch_merge(d_keys, nlists, nq, k, true, ta, tb, d_out_keys, d_out_cos, d_out_ids,
-                             d_out_counts, (hipStream_t)stream);
     if (tmp) {
-        (void)hipStreamSynchronize((hipStream_t)stream);
-        (void)hipFree(ta);
-        (void)hipFree(tb);
+        // More than one merge level (over 2048 keys per query; 8 shards x k <= 256 fit one): ping-pong scratch
+        // kept per (device, stream, calling thread) and grown on demand — never freed or synchronised per call, so
+        // the merge stays asynchronous between the all-gather and whatever the caller enqueues next.
+        struct Scratch { uint64_t* a = nullptr; uint64_t* b = nullptr; size_t cap = 0; };
+        static std::mutex mu;
+        static std::map<std::tuple<int, hipStream_t, std::thread::id>, Scratch> pool;
+        std::lock_guard<std::mutex> lk(mu);
+        Scratch& sc = pool[std::make_tuple(device, (hipStream_t)stream, std::this_thread::get_id())];
+        if (tmp > sc.cap) {
+            // the old pair may still be in use by merges already enqueued on this stream: let them finish
+            if (sc.a) { CS_HIP(hipStreamSynchronize((hipStream_t)stream)); (void)hipFree(sc.a); (void)hipFree(sc.b); }
+            sc = Scratch();
+            CS_HIP(hipMalloc(&sc.a, tmp * sizeof(uint64_t)));
+            CS_HIP(hipMalloc(&sc.b, tmp * sizeof(uint64_t)));
+            sc.cap = tmp;
+        }
+        ta = sc.a;
+        tb = sc.b;
     }
-    return s;
+    return launch_merge(d_keys, nlists, nq, k, true, ta, tb, d_out_keys, d_out_cos, d_out_ids, d_out_counts,
+                        (hipStream_t)stream, nullptr, remap_stripe, remap_shards);
 }
+
+extern "C" {
 
 int32_t cs_index_read_rows(cs_index* h, uint64_t first_row, uint64_t n, float* out_rows) {
     if (!h || !out_rows) return fail(CS_ERR_BAD_ARG, "null argument");
@@ -759,9 +840,24 @@ int32_t cs_index_set_filter_min_queries(cs_index* h, uint32_t min_queries) {
 
 int32_t cs_index_debug_counters(cs_index* h, uint64_t* batched_searches, uint64_t* batched_fallbacks) {
     if (!h) return fail(CS_ERR_BAD_ARG, "null index handle");
+    DeviceGuard g(h->device);
+    // device-API searches count their overflows on the device (no host round trip per search): drain and read
+    uint64_t dev_fallbacks = 0;
+    std::vector<Workspace*> ws;
+    {
+        std::lock_guard<std::mutex> lk(h->mu);
+        for (auto& kv : h->by_stream) ws.push_back(kv.second);
+    }
+    for (Workspace* w : ws) {
+        if (!w->bs.d_overflow) continue;
+        uint32_t v[3] = {0, 0, 0};
+        CS_HIP(hipStreamSynchronize(w->stream));
+        CS_HIP(hipMemcpy(v, w->bs.d_overflow, sizeof v, hipMemcpyDeviceToHost));
+        dev_fallbacks += (uint64_t)v[2] + (v[0] ? 1 : 0);
+    }
     std::lock_guard<std::mutex> lk(h->mu);
     if (batched_searches) *batched_searches = h->batched_searches;
-    if (batched_fallbacks) *batched_fallbacks = h->batched_fallbacks;
+    if (batched_fallbacks) *batched_fallbacks = h->batched_fallbacks + dev_fallbacks;
     return CS_OK;
 }
 

@@ -135,7 +135,10 @@ scan_topk_kernel(const float* __restrict__ corpus, uint64_t n_rows,
                  const uint32_t* __restrict__ dead, uint32_t id_base,
                  uint64_t* __restrict__ partial, const float* __restrict__ floor_in,
                  float* __restrict__ wave_max, uint32_t* __restrict__ done_ctr,
-                 float* __restrict__ floor_out) {
+                 float* __restrict__ floor_out, const uint32_t* __restrict__ gate) {
+    // gate != null: this launch is the exact rerun enqueued behind a batched (filter + refine) search on the
+    // device API; it runs only if that search overflowed a candidate buffer (index.hip run_search)
+    if (gate && *gate == 0u) return;
     extern __shared__ __attribute__((aligned(16))) uint64_t lds_keys[];  // [QT][kWaves][kpad]
     constexpr int DIM = 128 * J;
     const int tid = threadIdx.x;
@@ -322,7 +325,8 @@ __global__ void __launch_bounds__(kBlock)
 scan_topk_generic_kernel(const float* __restrict__ corpus, uint64_t n_rows, uint32_t dim,
                          const float* __restrict__ queries, uint32_t nq, uint32_t k,
                          uint32_t kpad, const uint32_t* __restrict__ dead, uint32_t id_base,
-                         uint64_t* __restrict__ partial) {
+                         uint64_t* __restrict__ partial, const uint32_t* __restrict__ gate) {
+    if (gate && *gate == 0u) return;
     extern __shared__ __attribute__((aligned(16))) uint64_t lds_keys[];  // [kWaves][kpad]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t q = blockIdx.y;
@@ -366,7 +370,9 @@ scan_topk_generic_kernel(const float* __restrict__ corpus, uint64_t n_rows, uint
 __global__ void __launch_bounds__(kMergeBlock)
 merge_topk_kernel(const uint64_t* __restrict__ in, uint32_t nlists, uint32_t k, uint32_t G,
                   uint64_t q_stride, uint64_t l_stride, uint64_t* __restrict__ out_keys, float* __restrict__ out_cos,
-                  uint32_t* __restrict__ out_ids, uint32_t* __restrict__ out_counts) {
+                  uint32_t* __restrict__ out_ids, uint32_t* __restrict__ out_counts,
+                  const uint32_t* __restrict__ gate, uint32_t remap_stripe, uint32_t remap_shards) {
+    if (gate && *gate == 0u) return;  // see scan_topk_kernel
     __shared__ __attribute__((aligned(16))) uint64_t a[kMergeCap];
     __shared__ uint32_t live;
     const int tid = threadIdx.x;
@@ -379,7 +385,16 @@ merge_topk_kernel(const uint64_t* __restrict__ in, uint32_t nlists, uint32_t k, 
     const uint64_t* src = in + (size_t)q * q_stride + (size_t)lo * l_stride;
     for (uint32_t i = tid; i < nsort; i += kMergeBlock) {
         const uint32_t l = i / k, e = i - l * k;
-        a[i] = (i < ncand) ? src[(size_t)l * l_stride + e] : 0ull;
+        uint64_t key = (i < ncand) ? src[(size_t)l * l_stride + e] : 0ull;
+        if (remap_stripe && key) {
+            // striped shards (shards.hip): list lo + l comes from shard lo + l and carries that shard's LOCAL row
+            // numbers; global id = ((row / stripe) * shards + shard) * stripe + row % stripe — monotone in the
+            // row within a shard, so each list stays sorted under (cosine desc, id asc)
+            const uint32_t row = key_id(key);
+            const uint32_t gid = ((row / remap_stripe) * remap_shards + (lo + l)) * remap_stripe + row % remap_stripe;
+            key = (key & 0xffffffff00000000ull) | (uint64_t)(~gid);
+        }
+        a[i] = key;
     }
     if (tid == 0) live = 0;
     block_bitonic_desc<kMergeBlock>(a, nsort, tid);
@@ -535,53 +550,54 @@ template <int J, int U, int QT>
 static void launch_fast(const ScanPlan& plan, const float* d_corpus, uint64_t n_rows,
                         const float* d_queries, uint32_t nq, uint32_t k, const uint32_t* d_dead,
                         uint32_t id_base, uint64_t* d_partial, const ScanPrime* prime,
-                        bool prime_pass, hipStream_t stream) {
+                        bool prime_pass, hipStream_t stream, const uint32_t* gate) {
     const size_t lds = (size_t)QT * kWaves * plan.kpad * sizeof(uint64_t);
     dim3 grid(plan.blocks, plan.passes);
     if (prime_pass)  // cached loads: the full scan re-reads these rows right after
         hipLaunchKernelGGL((scan_topk_kernel<J, U, QT, false, true>), grid, dim3(kBlock), lds, stream,
                            d_corpus, n_rows, d_queries, nq, k, plan.kpad, d_dead, id_base, nullptr,
-                           nullptr, prime->d_wave_max, prime->d_done, prime->d_floor);
+                           nullptr, prime->d_wave_max, prime->d_done, prime->d_floor, nullptr);
     else
         hipLaunchKernelGGL((scan_topk_kernel<J, U, QT, true>), grid, dim3(kBlock), lds, stream,
                            d_corpus, n_rows, d_queries, nq, k, plan.kpad, d_dead, id_base, d_partial,
-                           prime ? prime->d_floor : nullptr, nullptr, nullptr, nullptr);
+                           prime ? prime->d_floor : nullptr, nullptr, nullptr, nullptr, gate);
 }
 
 template <int J, int U>
 static void launch_fast_q(const ScanPlan& plan, const float* d_corpus, uint64_t n_rows,
                           const float* d_queries, uint32_t nq, uint32_t k,
                           const uint32_t* d_dead, uint32_t id_base, uint64_t* d_partial,
-                          const ScanPrime* prime, bool prime_pass, hipStream_t stream) {
+                          const ScanPrime* prime, bool prime_pass, hipStream_t stream, const uint32_t* gate) {
     switch (plan.qtile) {
-        case 4: launch_fast<J, U, 4>(plan, d_corpus, n_rows, d_queries, nq, k, d_dead, id_base, d_partial, prime, prime_pass, stream); break;
-        case 2: launch_fast<J, U, 2>(plan, d_corpus, n_rows, d_queries, nq, k, d_dead, id_base, d_partial, prime, prime_pass, stream); break;
-        default: launch_fast<J, U, 1>(plan, d_corpus, n_rows, d_queries, nq, k, d_dead, id_base, d_partial, prime, prime_pass, stream); break;
+        case 4: launch_fast<J, U, 4>(plan, d_corpus, n_rows, d_queries, nq, k, d_dead, id_base, d_partial, prime, prime_pass, stream, gate); break;
+        case 2: launch_fast<J, U, 2>(plan, d_corpus, n_rows, d_queries, nq, k, d_dead, id_base, d_partial, prime, prime_pass, stream, gate); break;
+        default: launch_fast<J, U, 1>(plan, d_corpus, n_rows, d_queries, nq, k, d_dead, id_base, d_partial, prime, prime_pass, stream, gate); break;
     }
 }
 
 int32_t launch_scan(const ScanPlan& plan, const float* d_corpus, uint64_t n_rows, uint32_t dim,
                     const float* d_queries, uint32_t nq, uint32_t k, const uint32_t* d_dead,
                     uint32_t id_base, uint64_t* d_partial, hipStream_t stream,
-                    const ScanPrime* prime, bool prime_pass) {
+                    const ScanPrime* prime, bool prime_pass, const uint32_t* gate) {
     if (prime_pass && (!prime || !fast_dim(dim) || n_rows == 0))
         return fail(CS_ERR_BAD_ARG, "prime pass needs a 384/768/1024-d corpus prefix and its buffers");
     if (n_rows == 0) {  // nothing to score: all-empty partial lists
+        if (gate) return CS_OK;  // a gated rerun follows a batched search, which needs rows
         CS_HIP(hipMemsetAsync(d_partial, 0, plan.partial_keys * sizeof(uint64_t), stream));
         return CS_OK;
     }
     if (plan.deep && plan.qtile == 1) {
-        if (dim == 384) launch_fast<3, 8, 1>(plan, d_corpus, n_rows, d_queries, nq, k, d_dead, id_base, d_partial, prime, prime_pass, stream);
-        else if (dim == 768) launch_fast<6, 4, 1>(plan, d_corpus, n_rows, d_queries, nq, k, d_dead, id_base, d_partial, prime, prime_pass, stream);
-        else launch_fast<8, 3, 1>(plan, d_corpus, n_rows, d_queries, nq, k, d_dead, id_base, d_partial, prime, prime_pass, stream);
-    } else if (dim == 384) launch_fast_q<3, 4>(plan, d_corpus, n_rows, d_queries, nq, k, d_dead, id_base, d_partial, prime, prime_pass, stream);
-    else if (dim == 768) launch_fast_q<6, 2>(plan, d_corpus, n_rows, d_queries, nq, k, d_dead, id_base, d_partial, prime, prime_pass, stream);
-    else if (dim == 1024) launch_fast_q<8, 2>(plan, d_corpus, n_rows, d_queries, nq, k, d_dead, id_base, d_partial, prime, prime_pass, stream);
+        if (dim == 384) launch_fast<3, 8, 1>(plan, d_corpus, n_rows, d_queries, nq, k, d_dead, id_base, d_partial, prime, prime_pass, stream, gate);
+        else if (dim == 768) launch_fast<6, 4, 1>(plan, d_corpus, n_rows, d_queries, nq, k, d_dead, id_base, d_partial, prime, prime_pass, stream, gate);
+        else launch_fast<8, 3, 1>(plan, d_corpus, n_rows, d_queries, nq, k, d_dead, id_base, d_partial, prime, prime_pass, stream, gate);
+    } else if (dim == 384) launch_fast_q<3, 4>(plan, d_corpus, n_rows, d_queries, nq, k, d_dead, id_base, d_partial, prime, prime_pass, stream, gate);
+    else if (dim == 768) launch_fast_q<6, 2>(plan, d_corpus, n_rows, d_queries, nq, k, d_dead, id_base, d_partial, prime, prime_pass, stream, gate);
+    else if (dim == 1024) launch_fast_q<8, 2>(plan, d_corpus, n_rows, d_queries, nq, k, d_dead, id_base, d_partial, prime, prime_pass, stream, gate);
     else {
         const size_t lds = (size_t)kWaves * plan.kpad * sizeof(uint64_t);
         hipLaunchKernelGGL(scan_topk_generic_kernel, dim3(plan.blocks, nq), dim3(kBlock), lds,
                            stream, d_corpus, n_rows, dim, d_queries, nq, k, plan.kpad, d_dead,
-                           id_base, d_partial);
+                           id_base, d_partial, gate);
     }
     CS_HIP(hipGetLastError());
     return CS_OK;
@@ -609,7 +625,8 @@ size_t merge_tmp_keys(uint32_t nlists, uint32_t nq, uint32_t k) {
 
 int32_t launch_merge(const uint64_t* d_lists, uint32_t nlists, uint32_t nq, uint32_t k,
                      bool list_major, uint64_t* d_tmp_a, uint64_t* d_tmp_b, uint64_t* d_out_keys, float* d_out_cos,
-                     uint32_t* d_out_ids, uint32_t* d_out_counts, hipStream_t stream) {
+                     uint32_t* d_out_ids, uint32_t* d_out_counts, hipStream_t stream, const uint32_t* gate,
+                     uint32_t remap_stripe, uint32_t remap_shards) {
     const uint32_t G = merge_group(k);
     const uint64_t* in = d_lists;
     uint64_t* bufs[2] = {d_tmp_a, d_tmp_b};
@@ -622,8 +639,10 @@ int32_t launch_merge(const uint64_t* d_lists, uint32_t nlists, uint32_t nq, uint
         uint64_t* out = final_pass ? d_out_keys : bufs[flip];
         if (!final_pass && !out) return fail(CS_ERR_BAD_ARG, "merge scratch missing");
         hipLaunchKernelGGL(merge_topk_kernel, dim3(ngroups, nq), dim3(kMergeBlock), 0, stream, in,
-                           nlists, k, G, q_stride, l_stride, out, d_out_cos, d_out_ids, d_out_counts);
+                           nlists, k, G, q_stride, l_stride, out, d_out_cos, d_out_ids, d_out_counts, gate,
+                           remap_stripe, remap_shards);
         CS_HIP(hipGetLastError());
+        remap_stripe = 0;  // ids are global after the first level
         if (final_pass) break;
         in = out;
         nlists = ngroups;

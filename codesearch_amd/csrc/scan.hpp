@@ -36,7 +36,9 @@ ScanPlan plan_prime(uint64_t sample_rows, uint32_t dim, uint32_t nq, uint32_t k,
 int32_t launch_scan(const ScanPlan& plan, const float* d_corpus, uint64_t n_rows, uint32_t dim,
                     const float* d_queries, uint32_t nq, uint32_t k, const uint32_t* d_dead,
                     uint32_t id_base, uint64_t* d_partial, hipStream_t stream,
-                    const ScanPrime* prime = nullptr, bool prime_pass = false);
+                    const ScanPrime* prime = nullptr, bool prime_pass = false, const uint32_t* gate = nullptr);
+// `gate` (launch_scan and launch_merge): device word; when non-null every block of the launch exits at
+// once unless *gate != 0 — the exact rerun enqueued behind a batched search on the device API.
 
 // Reduces nlists lists of k keys per query ([nq][nlists][k], or [nlists][nq][k] when
 // list_major) to the best k per query,
@@ -44,8 +46,15 @@ int32_t launch_scan(const ScanPlan& plan, const float* d_corpus, uint64_t n_rows
 // scratch of plan.merge_keys (may be null when nlists*k <= 2048).
 int32_t launch_merge(const uint64_t* d_lists, uint32_t nlists, uint32_t nq, uint32_t k,
                      bool list_major, uint64_t* d_tmp_a, uint64_t* d_tmp_b, uint64_t* d_out_keys, float* d_out_cos,
-                     uint32_t* d_out_ids, uint32_t* d_out_counts, hipStream_t stream);
+                     uint32_t* d_out_ids, uint32_t* d_out_counts, hipStream_t stream,
+                     const uint32_t* gate = nullptr, uint32_t remap_stripe = 0, uint32_t remap_shards = 0);
+// remap_stripe != 0: list l holds shard l's local row numbers; they become global ids while the lists are
+// read (striped row sharding, shards.hip).
 size_t merge_tmp_keys(uint32_t nlists, uint32_t nq, uint32_t k);
+// cs_merge_topk_device with the striped-shard id remap of launch_merge (index.hip; pooled scratch, asynchronous)
+int32_t merge_topk_device_impl(int32_t device, const uint64_t* d_keys, uint32_t nlists, uint32_t nq, uint32_t k,
+                               uint64_t* d_out_keys, float* d_out_cos, uint32_t* d_out_ids, uint32_t* d_out_counts,
+                               hipStream_t stream, uint32_t remap_stripe, uint32_t remap_shards);
 
 // corpus[(first_out_row + r) * dim + c] = cs_synth_value(seed, (first_row + r) * dim + c)
 int32_t launch_synth_fill(float* d_rows, uint64_t n, uint32_t dim, uint64_t seed,
@@ -61,6 +70,9 @@ struct BatchedState {
     uint32_t* d_cnt = nullptr;    // [nq][kCntStride], word 0 of each line used
     float* d_tau = nullptr;       // [nq]
     uint64_t* d_carry = nullptr;  // [nq][k]
+    // [0] = a candidate buffer overflowed during the current search (reset by the search's first kernel);
+    // [1] = sticky: set with [0], cleared only by cs_index_search_status; [2] = overflowed searches counted so far
+    // (the first kernel of the NEXT search folds [0] into it)
     uint32_t* d_overflow = nullptr;
 };
 // One block per query folds st.d_cand[q][0..cnt[q]) (packed keys) into st.d_carry[q][k], sets

@@ -149,7 +149,7 @@ prep_queries_kernel(const float* __restrict__ queries, float* __restrict__ qcopy
         qmag[q] = m;
         tau[q] = -__builtin_huge_valf();
         cnt[(size_t)q * kCntStride] = first_rows;
-        if (q == 0) *overflow = 0;
+        if (q == 0) { overflow[2] += overflow[0]; overflow[0] = 0; }
     }
 }
 

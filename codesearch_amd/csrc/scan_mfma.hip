@@ -211,7 +211,7 @@ select_candidates_kernel(const uint64_t* __restrict__ cand, uint32_t* __restrict
     const uint32_t q = blockIdx.x;
     uint32_t n = cnt[(size_t)q * kCntStride];
     if (n > cap) {
-        if (tid == 0) atomicOr(overflow, 1u);
+        if (tid == 0) { atomicOr(overflow, 1u); atomicOr(overflow + 1, 1u); }
         n = cap;
     }
     const uint64_t* src = cand + (size_t)q * cap;
@@ -279,7 +279,7 @@ __global__ void init_batched_state_kernel(float* tau, uint32_t* cnt, uint64_t* c
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < nq) { tau[i] = -__builtin_huge_valf(); cnt[(size_t)i * kCntStride] = 0; }
     if (i < nq * k) carry[i] = 0ull;
-    if (i == 0) *overflow = 0;
+    if (i == 0) { overflow[2] += overflow[0]; overflow[0] = 0; }
 }
 
 // ---- host side ----------------------------------------------------------------------------

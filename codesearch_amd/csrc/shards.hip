@@ -1,0 +1,392 @@
+// shards.hip — cs_shards_*: the vector half of the reference's VectorStore
+// (/root/reference/src/vectordb/store.rs:94-750) over SEVERAL GPUs of one node, owned by ONE
+// process — what a Rust `VectorStore` behind `codesearch search` can call: the reference calls
+// `store.search` from a single process (src/search/mod.rs:508-511).  SURVEY.md §8e.
+//
+// Layout: the corpus is row-sharded in stripes of `stripe` consecutive ids, dealt round-robin:
+//     stripe t = id / stripe,  shard = t % N,  local row = (t / N) * stripe + id % stripe.
+// With stripe = rows per GPU and a corpus of up to N * stripe rows this is the contiguous-range layout of
+// BASELINE.json config 5 (shard g holds ids [g * stripe, (g + 1) * stripe)); with a smaller stripe a corpus
+// of any size is spread over all GPUs while ids stay contiguous from next_id as in the reference
+// (store.rs:659-685).  Every shard is a plain cs_index with id_base 0.
+//
+// One search = ONE exchange step over xGMI:
+//   1. the queries ([nq, dim] f32, pinned host memory) go to every shard's device on that shard's stream
+//      (the broadcast: nq * dim * 4 bytes per GPU);
+//   2. every shard runs cs_index_search_device on its own stream — the single-query streaming scan or the
+//      batched filter + refine path, unchanged — and leaves its [nq, k] packed keys DIRECTLY in its slot
+//      of the root GPU's gather buffer when peer access is enabled (nq * k * 8 bytes per shard written
+//      over xGMI by the last kernel of the search: a one-step direct gather, no ring), or
+//      in a local buffer followed by one hipMemcpyPeerAsync otherwise (CS_SHARDS_DIRECT=0 forces this);
+//   3. the root stream waits for one event per shard and runs the key merge (scan.hip merge_topk_kernel),
+//      which turns local row numbers into global ids while it reads the lists; the merged keys land in
+//      pinned host memory.
+// top-k of a union = top-k of the per-shard top-ks and a shard's local order is its global order, so the
+// result equals the single-index search of the whole corpus bit for bit.
+// The multi-process variant (one rank per GPU, RCCL all-gather) is codesearch_amd/sharded.py.
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <vector>
+
+#include "scan.hpp"
+
+using namespace cs;
+
+namespace {
+
+struct ShardCtx {               // per shard, inside one search context
+    hipStream_t stream = nullptr;
+    hipEvent_t done = nullptr;
+    float* d_queries = nullptr; size_t q_cap = 0;     // on the shard's device
+    uint64_t* d_keys = nullptr; size_t key_cap = 0;   // local result buffer (copy path only)
+};
+
+struct SearchCtx {              // one in-flight search; pooled (search is `&self`: concurrent callers)
+    std::vector<ShardCtx> sh;
+    hipStream_t root_stream = nullptr;
+    uint64_t* d_gathered = nullptr; size_t gathered_cap = 0;  // [N][nq][k] on the root device
+    float* h_queries = nullptr; size_t h_q_cap = 0;           // pinned, visible to every device
+    uint64_t* h_keys = nullptr; size_t h_key_cap = 0;         // pinned: merged [nq][k]
+};
+
+}  // namespace
+
+struct cs_shards {
+    uint32_t dim = 0, n = 0;
+    uint64_t stripe = 0;
+    std::vector<int> devices;
+    std::vector<cs_index*> idx;
+    int root = 0;          // device of shard 0: gathers and merges
+    bool direct = false;   // shards write their keys straight into the root's gather buffer
+    uint64_t next = 0;     // rows appended so far == next_id
+    bool built = false;
+    std::mutex mu;
+    std::vector<SearchCtx*> pool;
+};
+
+namespace {
+
+struct Piece { uint32_t shard; uint64_t local_row, count, offset; };
+
+// ids [first, first + n) as runs that stay inside one stripe
+std::vector<Piece> pieces_of(const cs_shards* h, uint64_t first, uint64_t n) {
+    std::vector<Piece> out;
+    uint64_t id = first, off = 0;
+    while (off < n) {
+        const uint64_t t = id / h->stripe, in = id % h->stripe;
+        const uint64_t cnt = std::min<uint64_t>(h->stripe - in, n - off);
+        out.push_back(Piece{(uint32_t)(t % h->n), (t / h->n) * h->stripe + in, cnt, off});
+        id += cnt;
+        off += cnt;
+    }
+    return out;
+}
+
+void free_ctx(cs_shards* h, SearchCtx* c) {
+    for (uint32_t s = 0; s < c->sh.size(); ++s) {
+        DeviceGuard g(h->devices[s]);
+        ShardCtx& x = c->sh[s];
+        if (x.stream) (void)hipStreamSynchronize(x.stream);
+        if (x.d_queries) (void)hipFree(x.d_queries);
+        if (x.d_keys) (void)hipFree(x.d_keys);
+        if (x.done) (void)hipEventDestroy(x.done);
+        if (x.stream) (void)hipStreamDestroy(x.stream);
+    }
+    DeviceGuard g(h->root);
+    if (c->root_stream) { (void)hipStreamSynchronize(c->root_stream); (void)hipStreamDestroy(c->root_stream); }
+    if (c->d_gathered) (void)hipFree(c->d_gathered);
+    if (c->h_queries) (void)hipHostFree(c->h_queries);
+    if (c->h_keys) (void)hipHostFree(c->h_keys);
+    delete c;
+}
+
+int32_t new_ctx(cs_shards* h, SearchCtx** out) {
+    SearchCtx* c = new SearchCtx();
+    c->sh.resize(h->n);
+    auto bail = [&](int32_t s) { free_ctx(h, c); return s; };
+    for (uint32_t s = 0; s < h->n; ++s) {
+        DeviceGuard g(h->devices[s]);
+        if (hipStreamCreateWithFlags(&c->sh[s].stream, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&c->sh[s].done, hipEventDisableTiming) != hipSuccess)
+            return bail(fail(CS_ERR_HIP, "could not create a stream/event on device %d", h->devices[s]));
+    }
+    DeviceGuard g(h->root);
+    if (hipStreamCreateWithFlags(&c->root_stream, hipStreamNonBlocking) != hipSuccess)
+        return bail(fail(CS_ERR_HIP, "could not create the root stream"));
+    *out = c;
+    return CS_OK;
+}
+
+int32_t reserve_ctx(cs_shards* h, SearchCtx* c, uint32_t nq, uint32_t k) {
+    const size_t qn = (size_t)nq * h->dim, kn = (size_t)nq * k;
+    if (qn > c->h_q_cap) {
+        if (c->h_queries) (void)hipHostFree(c->h_queries);
+        c->h_queries = nullptr; c->h_q_cap = 0;
+        CS_HIP(hipHostMalloc(&c->h_queries, qn * sizeof(float), hipHostMallocPortable | hipHostMallocMapped));
+        c->h_q_cap = qn;
+    }
+    if (kn > c->h_key_cap) {
+        if (c->h_keys) (void)hipHostFree(c->h_keys);
+        c->h_keys = nullptr; c->h_key_cap = 0;
+        CS_HIP(hipHostMalloc(&c->h_keys, kn * sizeof(uint64_t), hipHostMallocPortable | hipHostMallocMapped));
+        c->h_key_cap = kn;
+    }
+    {
+        DeviceGuard g(h->root);
+        if (kn * h->n > c->gathered_cap) {
+            if (c->d_gathered) { CS_HIP(hipStreamSynchronize(c->root_stream)); (void)hipFree(c->d_gathered); }
+            c->d_gathered = nullptr; c->gathered_cap = 0;
+            CS_HIP(hipMalloc(&c->d_gathered, kn * h->n * sizeof(uint64_t)));
+            c->gathered_cap = kn * h->n;
+        }
+    }
+    for (uint32_t s = 0; s < h->n; ++s) {
+        DeviceGuard g(h->devices[s]);
+        ShardCtx& x = c->sh[s];
+        if (qn > x.q_cap) {
+            if (x.d_queries) (void)hipFree(x.d_queries);
+            x.d_queries = nullptr; x.q_cap = 0;
+            CS_HIP(hipMalloc(&x.d_queries, qn * sizeof(float)));
+            x.q_cap = qn;
+        }
+        if (!h->direct && kn > x.key_cap) {
+            if (x.d_keys) (void)hipFree(x.d_keys);
+            x.d_keys = nullptr; x.key_cap = 0;
+            CS_HIP(hipMalloc(&x.d_keys, kn * sizeof(uint64_t)));
+            x.key_cap = kn;
+        }
+    }
+    return CS_OK;
+}
+
+// Enqueue the search of queries [q0, q0 + qn) on shard s; its keys go to gathered[s][q0 ..][k]
+// (row stride of the gather buffer is the FULL nq).
+int32_t enqueue_shard(cs_shards* h, SearchCtx* c, uint32_t s, uint32_t q0, uint32_t qn, uint32_t nq, uint32_t k,
+                      bool copy_queries) {
+    DeviceGuard g(h->devices[s]);
+    ShardCtx& x = c->sh[s];
+    if (copy_queries)
+        CS_HIP(hipMemcpyAsync(x.d_queries, c->h_queries, (size_t)nq * h->dim * sizeof(float), hipMemcpyHostToDevice,
+                              x.stream));
+    uint64_t* slot = c->d_gathered + ((size_t)s * nq + q0) * k;
+    uint64_t* dst = h->direct ? slot : x.d_keys + (size_t)q0 * k;
+    CS_TRY(cs_index_search_device(h->idx[s], x.d_queries + (size_t)q0 * h->dim, qn, h->dim, k, dst, nullptr, nullptr,
+                                  nullptr, x.stream));
+    if (!h->direct)
+        CS_HIP(hipMemcpyPeerAsync(slot, h->root, dst, h->devices[s], (size_t)qn * k * sizeof(uint64_t), x.stream));
+    return CS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t cs_shards_create(uint32_t dim, uint32_t nshards, const int32_t* devices, uint64_t rows_per_stripe,
+                         uint64_t capacity_rows, cs_shards** out) {
+    if (!out) return fail(CS_ERR_BAD_ARG, "out is null");
+    *out = nullptr;
+    if (nshards == 0 || nshards > 64 || !devices) return fail(CS_ERR_BAD_ARG, "nshards must be in 1..64 with a device list");
+    if (rows_per_stripe == 0) return fail(CS_ERR_BAD_ARG, "rows_per_stripe must be > 0");
+    if (rows_per_stripe > 0xffffffffull) return fail(CS_ERR_BAD_ARG, "rows_per_stripe must fit u32 (ids are u32, store.rs:97)");
+    cs_shards* h = new cs_shards();
+    h->dim = dim;
+    h->n = nshards;
+    h->stripe = rows_per_stripe;
+    h->devices.assign(devices, devices + nshards);
+    h->root = devices[0];
+    const uint64_t per_shard = (capacity_rows + nshards - 1) / nshards;
+    for (uint32_t s = 0; s < nshards; ++s) {
+        cs_index* ix = nullptr;
+        // whole stripes, so a shard never grows in the middle of a bulk append that was sized up front
+        const uint64_t cap = per_shard ? (per_shard + rows_per_stripe - 1) / rows_per_stripe * rows_per_stripe : 0;
+        const int32_t st = cs_index_create(dim, cap, devices[s], 0, &ix);
+        if (st != CS_OK) { cs_shards_destroy(h); return st; }
+        h->idx.push_back(ix);
+    }
+    // direct gather: every shard's device must be able to write the root's memory
+    bool direct = true;
+    if (const char* e = std::getenv("CS_SHARDS_DIRECT")) direct = !(e[0] == '0');
+    for (uint32_t s = 0; s < nshards && direct; ++s) {
+        if (devices[s] == h->root) continue;
+        int can = 0;
+        if (hipDeviceCanAccessPeer(&can, devices[s], h->root) != hipSuccess || !can) { direct = false; break; }
+        DeviceGuard g(devices[s]);
+        const hipError_t e = hipDeviceEnablePeerAccess(h->root, 0);
+        if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) { direct = false; }
+        (void)hipGetLastError();
+    }
+    h->direct = direct;
+    *out = h;
+    return CS_OK;
+}
+
+void cs_shards_destroy(cs_shards* h) {
+    if (!h) return;
+    for (SearchCtx* c : h->pool) free_ctx(h, c);
+    for (cs_index* ix : h->idx) cs_index_destroy(ix);
+    delete h;
+}
+
+int32_t cs_shards_add(cs_shards* h, const float* rows, uint64_t n, uint32_t dim, uint32_t* out_ids) {
+    if (!h) return fail(CS_ERR_BAD_ARG, "null shards handle");
+    if (dim != h->dim)  // store.rs:667-671
+        return fail(CS_ERR_DIM_MISMATCH, "Embedding dimension mismatch: expected %u, got %u", h->dim, dim);
+    if (n == 0) return CS_OK;
+    if (!rows) return fail(CS_ERR_BAD_ARG, "rows is null");
+    if (h->next + n > 0xffffffffull) return fail(CS_ERR_BAD_ARG, "id space exhausted: ids are u32 (store.rs:97)");
+    for (const Piece& p : pieces_of(h, h->next, n))
+        CS_TRY(cs_index_add(h->idx[p.shard], rows + (size_t)p.offset * dim, p.count, dim, nullptr));
+    if (out_ids)
+        for (uint64_t i = 0; i < n; ++i) out_ids[i] = (uint32_t)(h->next + i);  // store.rs:684
+    h->next += n;
+    h->built = false;  // store.rs:682
+    return CS_OK;
+}
+
+int32_t cs_shards_add_synthetic(cs_shards* h, uint64_t n, uint64_t seed, uint64_t first_row, uint32_t* out_first_id) {
+    if (!h) return fail(CS_ERR_BAD_ARG, "null shards handle");
+    if (h->next + n > 0xffffffffull) return fail(CS_ERR_BAD_ARG, "id space exhausted: ids are u32 (store.rs:97)");
+    for (const Piece& p : pieces_of(h, h->next, n))
+        CS_TRY(cs_index_add_synthetic(h->idx[p.shard], p.count, seed, first_row + p.offset, nullptr));
+    if (out_first_id) *out_first_id = (uint32_t)h->next;
+    h->next += n;
+    if (n) h->built = false;
+    return CS_OK;
+}
+
+int32_t cs_shards_remove(cs_shards* h, const uint32_t* ids, uint64_t n, uint64_t* removed) {
+    if (!h) return fail(CS_ERR_BAD_ARG, "null shards handle");
+    if (removed) *removed = 0;
+    if (n == 0) return CS_OK;
+    if (!ids) return fail(CS_ERR_BAD_ARG, "ids is null");
+    std::vector<std::vector<uint32_t>> local(h->n);
+    for (uint64_t i = 0; i < n; ++i) {
+        if (ids[i] >= h->next) continue;  // unknown id: ignored (store.rs:594)
+        const uint64_t t = ids[i] / h->stripe;
+        local[t % h->n].push_back((uint32_t)((t / h->n) * h->stripe + ids[i] % h->stripe));
+    }
+    uint64_t total = 0;
+    for (uint32_t s = 0; s < h->n; ++s) {
+        if (local[s].empty()) continue;
+        uint64_t r = 0;
+        CS_TRY(cs_index_remove(h->idx[s], local[s].data(), local[s].size(), &r));
+        total += r;
+    }
+    if (total) h->built = false;  // store.rs:604-606
+    if (removed) *removed = total;
+    return CS_OK;
+}
+
+int32_t cs_shards_build(cs_shards* h) {
+    if (!h) return fail(CS_ERR_BAD_ARG, "null shards handle");
+    for (cs_index* ix : h->idx) CS_TRY(cs_index_build(ix));
+    h->built = true;  // store.rs:428
+    return CS_OK;
+}
+
+int32_t cs_shards_clear(cs_shards* h) {
+    if (!h) return fail(CS_ERR_BAD_ARG, "null shards handle");
+    for (cs_index* ix : h->idx) CS_TRY(cs_index_clear(ix));
+    h->next = 0;
+    h->built = false;
+    return CS_OK;
+}
+
+int32_t cs_shards_is_built(const cs_shards* h) { return h && h->built ? 1 : 0; }
+uint64_t cs_shards_len(const cs_shards* h) {
+    uint64_t n = 0;
+    if (h) for (cs_index* ix : h->idx) n += cs_index_len(ix);
+    return n;
+}
+uint32_t cs_shards_next_id(const cs_shards* h) { return h ? (uint32_t)h->next : 0; }
+uint32_t cs_shards_dim(const cs_shards* h) { return h ? h->dim : 0; }
+uint32_t cs_shards_count(const cs_shards* h) { return h ? h->n : 0; }
+int32_t cs_shards_direct_gather(const cs_shards* h) { return h && h->direct ? 1 : 0; }
+uint64_t cs_shards_shard_len(const cs_shards* h, uint32_t shard) {
+    return h && shard < h->n ? cs_index_len(h->idx[shard]) : 0;
+}
+
+int32_t cs_shards_read_rows(cs_shards* h, uint64_t first_id, uint64_t n, float* out_rows) {
+    if (!h || !out_rows) return fail(CS_ERR_BAD_ARG, "null argument");
+    if (first_id + n > h->next)
+        return fail(CS_ERR_BAD_ARG, "rows [%llu, %llu) out of range (have %llu)", (unsigned long long)first_id,
+                    (unsigned long long)(first_id + n), (unsigned long long)h->next);
+    for (const Piece& p : pieces_of(h, first_id, n))
+        CS_TRY(cs_index_read_rows(h->idx[p.shard], p.local_row, p.count, out_rows + (size_t)p.offset * h->dim));
+    return CS_OK;
+}
+
+int32_t cs_shards_search(cs_shards* h, const float* queries, uint32_t nq, uint32_t dim, uint32_t k, float* out_cos,
+                         uint32_t* out_ids, uint32_t* out_counts) {
+    if (!h) return fail(CS_ERR_BAD_ARG, "null shards handle");
+    if (dim != h->dim)  // store.rs:432-438
+        return fail(CS_ERR_DIM_MISMATCH, "Query embedding dimension mismatch: expected %u, got %u", h->dim, dim);
+    if (!h->built)  // store.rs:440-444
+        return fail(CS_ERR_NOT_BUILT, "Index not built. Call build_index() after inserting chunks.");
+    if (nq == 0 || nq > CS_MAX_QUERIES) return fail(CS_ERR_BAD_ARG, "nq must be in 1..%u, got %u", CS_MAX_QUERIES, nq);
+    if (k == 0 || k > CS_MAX_K) return fail(CS_ERR_BAD_ARG, "k must be in 1..%u, got %u", CS_MAX_K, k);
+    if (!queries || !out_cos || !out_ids || !out_counts) return fail(CS_ERR_BAD_ARG, "null buffer");
+    SearchCtx* c = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(h->mu);
+        if (!h->pool.empty()) { c = h->pool.back(); h->pool.pop_back(); }
+    }
+    if (!c) CS_TRY(new_ctx(h, &c));
+    const int32_t st = [&]() -> int32_t {
+        CS_TRY(reserve_ctx(h, c, nq, k));
+        memcpy(c->h_queries, queries, (size_t)nq * h->dim * sizeof(float));
+        for (uint32_t s = 0; s < h->n; ++s) {
+            CS_TRY(enqueue_shard(h, c, s, 0, nq, nq, k, true));
+            DeviceGuard g(h->devices[s]);
+            CS_HIP(hipEventRecord(c->sh[s].done, c->sh[s].stream));
+        }
+        auto merge = [&]() -> int32_t {
+            DeviceGuard g(h->root);
+            for (uint32_t s = 0; s < h->n; ++s) CS_HIP(hipStreamWaitEvent(c->root_stream, c->sh[s].done, 0));
+            CS_TRY(merge_topk_device_impl(h->root, c->d_gathered, h->n, nq, k, c->h_keys, nullptr, nullptr, nullptr,
+                                          c->root_stream, (uint32_t)h->stripe, h->n));
+            CS_HIP(hipStreamSynchronize(c->root_stream));
+            return CS_OK;
+        };
+        CS_TRY(merge());
+        if (nq > 16) {
+            // cs_index_search_device reports candidate-buffer overflows of > 16-query searches instead of
+            // rerunning them: redo an overflowed shard in slices of 16 queries (always exact), merge again
+            bool again = false;
+            for (uint32_t s = 0; s < h->n; ++s) {
+                uint32_t ov = 0;
+                CS_TRY(cs_index_search_status(h->idx[s], c->sh[s].stream, &ov));
+                if (!ov) continue;
+                again = true;
+                for (uint32_t q0 = 0; q0 < nq; q0 += 16)
+                    CS_TRY(enqueue_shard(h, c, s, q0, std::min<uint32_t>(16, nq - q0), nq, k, false));
+                DeviceGuard g(h->devices[s]);
+                CS_HIP(hipEventRecord(c->sh[s].done, c->sh[s].stream));
+            }
+            if (again) CS_TRY(merge());
+        }
+        for (uint32_t q = 0; q < nq; ++q) {  // keys are best-first, 0 = empty slot
+            uint32_t cnt = 0;
+            for (uint32_t j = 0; j < k; ++j) {
+                const uint64_t key = c->h_keys[(size_t)q * k + j];
+                if (key) ++cnt;
+                out_cos[(size_t)q * k + j] = key ? key_cos(key) : 0.0f;
+                out_ids[(size_t)q * k + j] = key ? key_id(key) : 0xFFFFFFFFu;
+            }
+            out_counts[q] = cnt;
+        }
+        return CS_OK;
+    }();
+    if (st != CS_OK) {  // leave nothing in flight behind a failed call
+        for (uint32_t s = 0; s < h->n; ++s) { DeviceGuard g(h->devices[s]); (void)hipStreamSynchronize(c->sh[s].stream); }
+        DeviceGuard g(h->root);
+        (void)hipStreamSynchronize(c->root_stream);
+    }
+    std::lock_guard<std::mutex> lk(h->mu);
+    h->pool.push_back(c);
+    return st;
+}
+
+}  // extern "C"

@@ -306,3 +306,17 @@ class FastEmbedder:
         _lib.check(self._lib.cs_embedder_profile_read(self._h, C.byref(ms), C.byref(n), 1 if reset else 0))
         return ms.value, int(n.value)
 
+    STAGES = ("embed_ln", "qkv_gemm", "attention", "out_proj_gemm", "layernorm_attn", "ffn_up_gemm",
+              "ffn_down_gemm", "layernorm_ffn", "pool_normalize")  # CS_STAGE_* of codesearch_gpu.h
+
+    def profile_stages(self, enable: bool) -> None:
+        """While on, a forward runs on one stream with a HIP event after every kernel."""
+        _lib.check(self._lib.cs_embedder_profile_stages(self._h, 1 if enable else 0))
+
+    def profile_stages_read(self, reset: bool = True):
+        """-> ({stage: microseconds per forward}, forwards)"""
+        us = (C.c_double * len(self.STAGES))()
+        n = C.c_uint64()
+        _lib.check(self._lib.cs_embedder_profile_stages_read(self._h, us, C.byref(n), 1 if reset else 0))
+        f = max(int(n.value), 1)
+        return {name: us[i] / f for i, name in enumerate(self.STAGES)}, int(n.value)

@@ -48,36 +48,66 @@ def merge_keys_host(gathered: np.ndarray, k: int) -> np.ndarray:
     return np.sort(flat, axis=1)[:, ::-1][:, :k].copy()
 
 
-class ShardedVectorStore:
-    """One rank's shard plus the exchange.  Device buffers are torch tensors (plumbing);
-    kernels are libcsgpu's, launched on torch's current stream so RCCL orders after them."""
+class HipShardBackend:
+    """The product backend of ShardedVectorStore: this rank's shard is a cs_index in HBM, buffers are torch
+    CUDA tensors (plumbing), kernels are libcsgpu's, launched on torch's current stream so RCCL orders
+    after them."""
 
-    def __init__(self, dim: int, rows_per_shard: int, rank: int, world: int, device: int, group=None,
-                 force_exchange: bool = False):
+    def __init__(self, dim: int, rows_per_shard: int, rank: int, device: int):
         import torch
 
         from . import _lib
         from .vector_store import VectorStore
 
+        self.torch, self._lib, self._check = torch, _lib.load(), _lib.check
+        self.dim, self.device = dim, device
+        self.tensor_device = f"cuda:{device}"
+        self.store = VectorStore(None, dim, device=device, capacity=rows_per_shard, id_base=rank * rows_per_shard)
+
+    def _stream(self):
+        return C.c_void_p(self.torch.cuda.current_stream().cuda_stream)
+
+    def fill_synthetic(self, n: int, seed: int, first_row: int) -> None:
+        self.store.insert_synthetic(n, seed, first_row)
+        self.store.build_index()
+
+    def search_local(self, d_queries, nq: int, k: int, keys, cos=None, ids=None, counts=None) -> None:
+        vp = lambda x: None if x is None else C.c_void_p(x.data_ptr())
+        self._check(self._lib.cs_index_search_device(self.store.handle, vp(d_queries), nq, self.dim, k, vp(keys),
+                                                     vp(cos), vp(ids), vp(counts), self._stream()))
+
+    def merge(self, gathered, world: int, nq: int, k: int, keys, cos, ids, counts) -> None:
+        vp = lambda x: C.c_void_p(x.data_ptr())
+        self._check(self._lib.cs_merge_topk_device(self.device, vp(gathered), world, nq, k, vp(keys), vp(cos), vp(ids),
+                                                   vp(counts), self._stream()))
+
+
+class ShardedVectorStore:
+    """One rank's shard plus the exchange: (optional) query broadcast -> local search -> ONE all-gather of
+    nq*k*8 bytes per rank -> merge on every rank.  `backend` supplies the local search and the merge:
+    HipShardBackend (default; needs a GPU) or, in the CPU tests, a stand-in built on the oracle — the
+    exchange sequence below is the same code either way."""
+
+    def __init__(self, dim: int, rows_per_shard: int, rank: int, world: int, device: int, group=None,
+                 force_exchange: bool = False, backend=None):
+        import torch
+
         self.torch = torch
-        self._lib = _lib.load()
-        self._check = _lib.check
         self.dim, self.rank, self.world, self.device = dim, rank, world, device
         self.rows_per_shard = rows_per_shard
         self.group = group
         self.force_exchange = force_exchange  # run the all-gather + merge even when world == 1
-        self.store = VectorStore(None, dim, device=device, capacity=rows_per_shard,
-                                 id_base=rank * rows_per_shard)
+        self.backend = backend if backend is not None else HipShardBackend(dim, rows_per_shard, rank, device)
+        self.store = getattr(self.backend, "store", None)
         self._bufs = {}
 
     def fill_synthetic(self, seed: int) -> None:
-        self.store.insert_synthetic(self.rows_per_shard, seed, self.rank * self.rows_per_shard)
-        self.store.build_index()
+        self.backend.fill_synthetic(self.rows_per_shard, seed, self.rank * self.rows_per_shard)
 
     def _buffers(self, nq: int, k: int):
         key = (nq, k)
         if key not in self._bufs:
-            t, dev = self.torch, f"cuda:{self.device}"
+            t, dev = self.torch, self.backend.tensor_device
             self._bufs[key] = dict(
                 local=t.zeros(nq * k, dtype=t.int64, device=dev),
                 gathered=t.zeros(self.world * nq * k, dtype=t.int64, device=dev),
@@ -88,22 +118,21 @@ class ShardedVectorStore:
             )
         return self._bufs[key]
 
-    def search_device(self, d_queries, nq: int, k: int):
-        """d_queries: torch f32 tensor [nq, dim] on this rank's GPU (same on every rank).
-        Asynchronous; returns the dict of device result tensors (cos/ids/counts/keys)."""
+    def search_device(self, d_queries, nq: int, k: int, broadcast_src: Optional[int] = None):
+        """d_queries: torch f32 tensor [nq, dim] on this rank's device.  With broadcast_src = r the queries
+        are those of rank r, sent to every shard first (RCCL broadcast of nq*dim*4 bytes: the caller of
+        VectorStore::search lives in one process, SURVEY.md §8e); otherwise every rank must already
+        hold the same queries.  Asynchronous; returns the dict of device result tensors
+        (cos/ids/counts/keys)."""
         t = self.torch
         b = self._buffers(nq, k)
-        stream = C.c_void_p(t.cuda.current_stream().cuda_stream)
-        vp = lambda x: C.c_void_p(x.data_ptr())
-        if self.world == 1 and not self.force_exchange:
-            self._check(self._lib.cs_index_search_device(self.store.handle, vp(d_queries), nq, self.dim, k,
-                                                         vp(b["keys"]), vp(b["cos"]), vp(b["ids"]),
-                                                         vp(b["counts"]), stream))
+        exchange = self.world > 1 or self.force_exchange
+        if broadcast_src is not None and exchange:
+            t.distributed.broadcast(d_queries, src=broadcast_src, group=self.group)
+        if not exchange:
+            self.backend.search_local(d_queries, nq, k, b["keys"], b["cos"], b["ids"], b["counts"])
             return b
-        self._check(self._lib.cs_index_search_device(self.store.handle, vp(d_queries), nq, self.dim, k,
-                                                     vp(b["local"]), None, None, None, stream))
+        self.backend.search_local(d_queries, nq, k, b["local"])
         t.distributed.all_gather_into_tensor(b["gathered"], b["local"], group=self.group)
-        self._check(self._lib.cs_merge_topk_device(self.device, vp(b["gathered"]), self.world, nq, k,
-                                                   vp(b["keys"]), vp(b["cos"]), vp(b["ids"]),
-                                                   vp(b["counts"]), stream))
+        self.backend.merge(b["gathered"], self.world, nq, k, b["keys"], b["cos"], b["ids"], b["counts"])
         return b

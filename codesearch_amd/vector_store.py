@@ -149,14 +149,27 @@ class VectorStore:
 
     FORMAT = 1
 
-    def __init__(self, db_path, dimensions: int, device: int = 0, capacity: int = 0, id_base: int = 0):
+    def __init__(self, db_path, dimensions: int, device: int = 0, capacity: int = 0, id_base: int = 0,
+                 devices: Optional[Sequence[int]] = None, rows_per_stripe: int = 65536):
+        """devices=[d0, d1, ...]: the store is row-sharded over those GPUs inside this one process
+        (cs_shards_*: ids stay contiguous, rows dealt in stripes of `rows_per_stripe`; a search broadcasts
+        the queries, scans every shard and merges on d0).  Otherwise one cs_index on `device`."""
         self._lib = _lib.load()
         self.db_path = None if db_path is None else str(db_path)
         self.dimensions = int(dimensions)
         self.id_base = int(id_base)
         self.readonly = False
         handle = C.c_void_p()
-        _lib.check(self._lib.cs_index_create(self.dimensions, capacity, device, id_base, C.byref(handle)))
+        if devices is not None:
+            if id_base:
+                raise CsError(_lib.CS_ERR_BAD_ARG, "a sharded store hands out ids from 0")
+            devs = (C.c_int32 * len(devices))(*[int(d) for d in devices])
+            _lib.check(self._lib.cs_shards_create(self.dimensions, len(devices), devs, int(rows_per_stripe), capacity,
+                                                  C.byref(handle)))
+            self._pfx = "cs_shards_"
+        else:
+            _lib.check(self._lib.cs_index_create(self.dimensions, capacity, device, id_base, C.byref(handle)))
+            self._pfx = "cs_index_"
         self._h = handle
         self._meta: Dict[int, ChunkMetadata] = {}
         self._removed: set = set()
@@ -194,12 +207,12 @@ class VectorStore:
         step = max(1, (256 << 20) // (4 * self.dimensions))  # 256 MB host pieces
         for lo in range(0, n, step):
             piece = np.ascontiguousarray(rows[lo:lo + step], np.float32)
-            _lib.check(self._lib.cs_index_add(self._h, piece.ctypes.data_as(f32p), piece.shape[0], self.dimensions, None))
+            _lib.check(self._fn("add")(self._h, piece.ctypes.data_as(f32p), piece.shape[0], self.dimensions, None))
         self._persisted_rows = n
         removed = [int(i) for i in m.get("removed", [])]
         if removed:
             ids = np.ascontiguousarray(removed, np.uint32)
-            _lib.check(self._lib.cs_index_remove(self._h, ids.ctypes.data_as(u32p), ids.size, None))
+            _lib.check(self._fn("remove")(self._h, ids.ctypes.data_as(u32p), ids.size, None))
             self._removed = set(removed)
         if os.path.exists(chunks):
             for line in open(chunks):
@@ -207,7 +220,7 @@ class VectorStore:
                 cid = int(d.pop("id"))
                 self._meta[cid] = ChunkMetadata(**d)
         if m.get("built"):
-            _lib.check(self._lib.cs_index_build(self._h))
+            _lib.check(self._fn("build")(self._h))
 
     def _persist(self) -> None:
         vec, meta, chunks = self._paths()
@@ -236,6 +249,20 @@ class VectorStore:
             return 0
         return sum(os.path.getsize(p) for p in self._paths() if os.path.exists(p))
 
+    def _fn(self, name: str):
+        """cs_index_<name> or, for a store sharded over several GPUs, cs_shards_<name> (same signature)."""
+        return getattr(self._lib, self._pfx + name)
+
+    @property
+    def sharded(self) -> bool:
+        return self._pfx == "cs_shards_"
+
+    def shard_lens(self) -> List[int]:
+        """Live rows per shard (sharded stores only)."""
+        if not self.sharded:
+            return [len(self)]
+        return [int(self._lib.cs_shards_shard_len(self._h, i)) for i in range(int(self._lib.cs_shards_count(self._h)))]
+
     def _writable(self):
         if self.readonly:
             raise CsError(_lib.CS_ERR_BAD_ARG, "store opened read-only (open_readonly)")
@@ -243,7 +270,7 @@ class VectorStore:
     # -- lifecycle
     def close(self):
         if getattr(self, "_h", None):
-            self._lib.cs_index_destroy(self._h)
+            self._fn("destroy")(self._h)
             self._h = None
 
     def __del__(self):
@@ -270,7 +297,7 @@ class VectorStore:
                               f"Embedding dimension mismatch: expected {self.dimensions}, got {len(ch.embedding)}")
         rows = np.ascontiguousarray([ch.embedding for ch in chunks], dtype=np.float32)
         ids = np.zeros(len(chunks), np.uint32)
-        _lib.check(self._lib.cs_index_add(self._h, rows.ctypes.data_as(f32p), len(chunks), self.dimensions,
+        _lib.check(self._fn("add")(self._h, rows.ctypes.data_as(f32p), len(chunks), self.dimensions,
                                           ids.ctypes.data_as(u32p)))
         for i, ch in zip(ids.tolist(), chunks):
             self._meta[i] = ChunkMetadata.from_embedded_chunk(ch)
@@ -287,14 +314,14 @@ class VectorStore:
         if rows.ndim != 2:
             raise ValueError("rows must be [n, dim]")
         ids = np.zeros(rows.shape[0], np.uint32)
-        _lib.check(self._lib.cs_index_add(self._h, rows.ctypes.data_as(f32p), rows.shape[0], rows.shape[1],
+        _lib.check(self._fn("add")(self._h, rows.ctypes.data_as(f32p), rows.shape[0], rows.shape[1],
                                           ids.ctypes.data_as(u32p)))
         return ids
 
     def insert_synthetic(self, n: int, seed: int, first_row: int = 0) -> int:
         """Generate n rows in HBM with include/cs_synth.h -> first id."""
         first = C.c_uint32()
-        _lib.check(self._lib.cs_index_add_synthetic(self._h, n, seed, first_row, C.byref(first)))
+        _lib.check(self._fn("add_synthetic")(self._h, n, seed, first_row, C.byref(first)))
         return int(first.value)
 
     def delete_chunks(self, chunk_ids: Sequence[int]) -> int:
@@ -302,7 +329,7 @@ class VectorStore:
         self._writable()
         ids = np.ascontiguousarray(chunk_ids, np.uint32)
         removed = C.c_uint64()
-        _lib.check(self._lib.cs_index_remove(self._h, ids.ctypes.data_as(u32p), ids.size, C.byref(removed)))
+        _lib.check(self._fn("remove")(self._h, ids.ctypes.data_as(u32p), ids.size, C.byref(removed)))
         nxt = self.next_id()
         for i in ids.tolist():
             self._meta.pop(i, None)  # store.rs:598
@@ -313,14 +340,14 @@ class VectorStore:
     def build_index(self) -> None:
         """store.rs:386-430 (+ the flat vector file when the store has a path)."""
         self._writable()
-        _lib.check(self._lib.cs_index_build(self._h))
+        _lib.check(self._fn("build")(self._h))
         if self.db_path is not None:
             self._persist()
 
     def clear(self) -> None:
         """store.rs:690-707."""
         self._writable()
-        _lib.check(self._lib.cs_index_clear(self._h))
+        _lib.check(self._fn("clear")(self._h))
         self._meta.clear()
         self._removed.clear()
         self._persisted_rows = 0
@@ -331,13 +358,13 @@ class VectorStore:
 
     # -- reads (`&self`)
     def is_indexed(self) -> bool:
-        return bool(self._lib.cs_index_is_built(self._h))
+        return bool(self._fn("is_built")(self._h))
 
     def next_id(self) -> int:
-        return int(self._lib.cs_index_next_id(self._h))
+        return int(self._fn("next_id")(self._h))
 
     def __len__(self) -> int:
-        return int(self._lib.cs_index_len(self._h))
+        return int(self._fn("len")(self._h))
 
     def search_raw(self, queries, limit: int):
         """-> (cos [nq, limit] f32, ids [nq, limit] u32, counts [nq] u32); rows best-first."""
@@ -348,7 +375,7 @@ class VectorStore:
         cos = np.zeros((nq, max(limit, 1)), np.float32)
         ids = np.zeros((nq, max(limit, 1)), np.uint32)
         counts = np.zeros(nq, np.uint32)
-        _lib.check(self._lib.cs_index_search(self._h, q.ctypes.data_as(f32p), nq, dim, limit,
+        _lib.check(self._fn("search")(self._h, q.ctypes.data_as(f32p), nq, dim, limit,
                                              cos.ctypes.data_as(f32p), ids.ctypes.data_as(u32p),
                                              counts.ctypes.data_as(u32p)))
         return cos, ids, counts
@@ -407,7 +434,7 @@ class VectorStore:
 
     def read_rows(self, first_row: int, n: int) -> np.ndarray:
         out = np.empty((n, self.dimensions), np.float32)
-        _lib.check(self._lib.cs_index_read_rows(self._h, first_row, n, out.ctypes.data_as(f32p)))
+        _lib.check(self._fn("read_rows")(self._h, first_row, n, out.ctypes.data_as(f32p)))
         return out
 
     # -- kernel timing (bench.py)

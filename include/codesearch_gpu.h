@@ -124,13 +124,27 @@ int32_t cs_index_device(const cs_index* h);
 int32_t cs_index_search(cs_index* h, const float* queries, uint32_t nq, uint32_t dim,
                         uint32_t k, float* out_cos, uint32_t* out_ids,
                         uint32_t* out_counts);
-/* Same with queries and outputs in HBM; asynchronous on `stream`.  out_keys receives
- * [nq, k] packed 64-bit sort keys (see cs_key_* below; 0 = empty slot), best first —
- * the form the shard merge consumes.  out_cos / out_ids / out_counts may be NULL. */
+/* Same with queries and outputs in HBM; asynchronous on `stream`: the call only enqueues work and
+ * never waits for the device.  out_keys receives [nq, k] packed 64-bit sort keys (see cs_key_* below;
+ * 0 = empty slot), best first — the form the shard merge consumes.  out_cos / out_ids / out_counts
+ * may be NULL.  Scratch is kept per (stream, calling thread), so concurrent callers are safe on any
+ * mix of streams.
+ * Exactness: searches of two or more queries run a filter + refine pipeline whose per-query candidate
+ * buffers (max(4096, 64 k) rows) can overflow on adversarial row orders.  Up to 16 queries per call the
+ * exact list-based scan is enqueued behind the search, gated on the overflow word, so the outputs are
+ * exact with no host involvement.  Calls with more than 16 queries over more than max(4096, 64 k) rows
+ * report an overflow through cs_index_search_status() instead: check it once the results are needed and
+ * rerun an overflowed search (in slices of <= 16 queries, or through cs_index_search, which reruns by
+ * itself). */
 int32_t cs_index_search_device(cs_index* h, const float* d_queries, uint32_t nq,
                                uint32_t dim, uint32_t k, uint64_t* d_out_keys,
                                float* d_out_cos, uint32_t* d_out_ids,
                                uint32_t* d_out_counts, void* stream);
+
+/* Synchronises `stream` and reports in *overflowed whether any cs_index_search_device call of more
+ * than 16 queries issued by this thread on it since the previous status call overflowed a candidate buffer
+ * (its results are then incomplete); clears the condition. */
+int32_t cs_index_search_status(cs_index* h, void* stream, uint32_t* overflowed);
 
 /* Shard merge: given `nlists` per-shard key lists [nlists, nq, k]
  * (as all-gathered over RCCL), write the merged best-k per query.  Device pointers. */
@@ -138,6 +152,40 @@ int32_t cs_merge_topk_device(int32_t device, const uint64_t* d_keys, uint32_t nl
                              uint32_t nq, uint32_t k, uint64_t* d_out_keys,
                              float* d_out_cos, uint32_t* d_out_ids,
                              uint32_t* d_out_counts, void* stream);
+/* (asynchronous like cs_index_search_device: scratch for multi-level merges is pooled per stream) */
+
+/* ------------------------------------------------------------------------------------
+ * Row-sharded index over several GPUs of one node, owned by ONE process — what a Rust VectorStore
+ * can call from `codesearch search` (store.rs:431-486 is called from a single process,
+ * src/search/mod.rs:508-511).  SURVEY.md §8e; codesearch_amd/csrc/shards.hip.
+ * Ids stay contiguous from next_id (store.rs:659-685); rows are dealt to the shards in stripes of
+ * `rows_per_stripe` consecutive ids, round-robin (stripe = rows per GPU gives the contiguous ranges of
+ * BASELINE.json config 5: shard g holds ids [g*stripe, (g+1)*stripe)).  A search broadcasts the queries,
+ * runs every shard's cs_index search on its own stream, gathers nq*k*8 bytes per shard on the first
+ * device (written there directly over xGMI when peer access is available) and merges them: the result
+ * is the single-index result bit for bit.  Same error texts, threading rules and entry-point meaning as
+ * cs_index_* (add/remove/build/clear need external exclusion; search is re-entrant).
+ * ---------------------------------------------------------------------------------- */
+typedef struct cs_shards cs_shards;
+int32_t cs_shards_create(uint32_t dim, uint32_t nshards, const int32_t* devices, uint64_t rows_per_stripe,
+                         uint64_t capacity_rows /* whole store, reservation hint */, cs_shards** out);
+void cs_shards_destroy(cs_shards* h);
+int32_t cs_shards_add(cs_shards* h, const float* rows, uint64_t n, uint32_t dim, uint32_t* out_ids);
+int32_t cs_shards_add_synthetic(cs_shards* h, uint64_t n, uint64_t seed, uint64_t first_row,
+                                uint32_t* out_first_id);
+int32_t cs_shards_remove(cs_shards* h, const uint32_t* ids, uint64_t n, uint64_t* removed);
+int32_t cs_shards_build(cs_shards* h);
+int32_t cs_shards_clear(cs_shards* h);
+int32_t cs_shards_is_built(const cs_shards* h);
+uint64_t cs_shards_len(const cs_shards* h);
+uint32_t cs_shards_next_id(const cs_shards* h);
+uint32_t cs_shards_dim(const cs_shards* h);
+uint32_t cs_shards_count(const cs_shards* h);                        /* number of shards */
+uint64_t cs_shards_shard_len(const cs_shards* h, uint32_t shard);    /* live rows on one shard */
+int32_t cs_shards_direct_gather(const cs_shards* h);                 /* 1 = shards write into the root's buffer */
+int32_t cs_shards_search(cs_shards* h, const float* queries, uint32_t nq, uint32_t dim, uint32_t k,
+                         float* out_cos, uint32_t* out_ids, uint32_t* out_counts);
+int32_t cs_shards_read_rows(cs_shards* h, uint64_t first_id, uint64_t n, float* out_rows);
 
 /* Copy rows [first_row, first_row + n) of the matrix back to host memory (test and
  * persistence aid; VectorStore has no direct counterpart). */
@@ -248,6 +296,24 @@ int32_t cs_embedder_embed_ids_device(cs_embedder* h, const int32_t* ids,
 int32_t cs_embedder_last_hidden(cs_embedder* h, float* out, uint64_t n_tokens);
 int32_t cs_embedder_profile_read(cs_embedder* h, double* forward_ms, uint64_t* forwards,
                                  int32_t reset);
+/* Per-kernel-class timing for bench.py's encoder roofline: while enabled, a forward runs on ONE
+ * stream with a HIP event after every kernel.  read() returns the summed
+ * microseconds per class since the last reset and the number of forwards they cover. */
+enum {
+    CS_STAGE_EMBED_LN = 0,  /* E1 */
+    CS_STAGE_QKV = 1,       /* E2 */
+    CS_STAGE_ATTENTION = 2, /* E3 */
+    CS_STAGE_OUT_PROJ = 3,  /* E4 GEMM */
+    CS_STAGE_LN_ATTN = 4,   /* E4 LayerNorm */
+    CS_STAGE_FFN_UP = 5,    /* E5 */
+    CS_STAGE_FFN_DOWN = 6,  /* E6 GEMM */
+    CS_STAGE_LN_FFN = 7,    /* E6 LayerNorm */
+    CS_STAGE_POOL = 8,      /* E7 + E8 */
+    CS_ENCODER_STAGES = 9
+};
+int32_t cs_embedder_profile_stages(cs_embedder* h, int32_t enable);
+int32_t cs_embedder_profile_stages_read(cs_embedder* h, double* us_per_stage /*[CS_ENCODER_STAGES]*/,
+                                        uint64_t* forwards, int32_t reset);
 
 /* ------------------------------------------------------------------------------------
  * Text entry points — what FastEmbedder::embed_batch(Vec<String>) takes (embedder.rs:249-295).

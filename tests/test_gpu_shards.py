@@ -1,0 +1,195 @@
+"""cs_shards_* — the row-sharded VectorStore inside ONE process (what a Rust caller of
+`VectorStore::search`, /root/reference/src/vectordb/store.rs:431-486, can reach) — and the non-blocking device
+search it is built on.  One GPU is enough: N shards placed on device 0 run the same code as N devices
+(streams, gather slots, event waits, id remap in the merge); the answer must be the single-index answer bit
+for bit.  Needs an MI355X."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from codesearch_amd.synth import synth_planted, synth_rows
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def VS(gpu_lib):
+    from codesearch_amd import VectorStore
+
+    assert gpu_lib.cs_device_count() >= 1, "no HIP device visible"
+    return VectorStore
+
+
+@pytest.mark.parametrize("n,stripe,direct", [(80_000, 10_000, "1"),   # contiguous ranges: shard g = ids [g*S, (g+1)*S)
+                                             (50_001, 1_000, "1"),    # seven rounds of stripes, ragged tail
+                                             (50_001, 1_000, "0"),    # gather through hipMemcpyPeerAsync
+                                             (3_000, 4_096, "1")])    # everything on shard 0, seven empty shards
+def test_eight_shards_equal_the_single_index(VS, oracle, monkeypatch, n, stripe, direct):
+    monkeypatch.setenv("CS_SHARDS_DIRECT", direct)
+    dim, seed, shards = 384, 9090, 8
+    single = VS(None, dim)
+    single.insert_synthetic(n, seed, 0)
+    sh = VS(None, dim, devices=[0] * shards, rows_per_stripe=stripe, capacity=n)
+    assert sh.sharded and bool(sh._lib.cs_shards_direct_gather(sh.handle)) == (direct == "1")
+    first = sh.insert_synthetic(n // 2, seed, 0)                      # two appends: the second starts mid-stripe
+    rest = oracle.synth_rows(seed, n // 2, n - n // 2, dim)
+    ids = sh.insert_embeddings(rest)                                  # host rows, ids contiguous (store.rs:659-685)
+    assert first == 0 and ids.tolist() == list(range(n // 2, n)) and sh.next_id() == n
+    lens = sh.shard_lens()
+    assert sum(lens) == n and (stripe * shards > n or max(lens) - min(lens) <= stripe)
+    assert np.array_equal(sh.read_rows(n // 2 - 3, 700), single.read_rows(n // 2 - 3, 700))
+    dead = [5, n // 3, n - 1, stripe, stripe - 1] if n > 2 * stripe else [5, n - 1]
+    assert sh.delete_chunks(dead + [n + 10]) == len(dead) == single.delete_chunks(dead + [n + 10])
+    assert len(sh) == n - len(dead) and not sh.is_indexed()
+    from codesearch_amd import CsError
+    with pytest.raises(CsError) as e:
+        sh.search_raw(synth_rows(1, 0, 1, dim), 10)
+    assert str(e.value) == "Index not built. Call build_index() after inserting chunks."
+    sh.build_index()
+    single.build_index()
+    planted = [0, n - 2, n // 2, min(n - 3, stripe + 1)]
+    for nq in (1, 9, 1000):
+        qs = np.concatenate([synth_rows(seed + nq, 0, nq - 1, dim), synth_planted(seed, 3, [planted[nq % 4]], dim)]) \
+            if nq > 1 else synth_planted(seed, 3, [planted[1]], dim)
+        for k in (10, 200):
+            c1, i1, n1 = single.search_raw(qs, k)
+            c8, i8, n8 = sh.search_raw(qs, k)
+            assert n8.tolist() == n1.tolist()
+            assert i8.tolist() == i1.tolist()          # global ids, (cosine desc, id asc)
+            assert c8.tobytes() == c1.tobytes()
+        assert i8[-1][0] == planted[nq % 4 if nq > 1 else 1]
+    bitmap = np.zeros((n + 31) // 32, np.uint32)
+    for d in dead:
+        bitmap[d >> 5] |= np.uint32(1 << (d & 31))
+    ecos, eids = oracle.scan_topk(single.read_rows(0, n), qs[0], 10, mode="omp", dead=bitmap)
+    c8, i8, _ = sh.search_raw(qs[0], 10)
+    assert i8[0].tolist() == eids.tolist() and np.abs(c8[0] - ecos).max() < 2e-6
+    sh.clear()
+    assert sh.next_id() == 0 and len(sh) == 0 and sum(sh.shard_lens()) == 0
+    sh.close(); single.close()
+
+
+def test_sharded_store_keeps_the_reference_surface(VS, tmp_path):
+    """store.rs:846-893 on a store spread over four shards, with metadata and persistence."""
+    from codesearch_amd import Chunk, EmbeddedChunk
+
+    st = VS(tmp_path / "sh.db", 4, devices=[0, 0, 0, 0], rows_per_stripe=1)
+    chunks = [EmbeddedChunk(Chunk("fn authenticate() {}", 0, 1, "Function", "auth.rs"), [1.0, 0.0, 0.0, 0.0]),
+              EmbeddedChunk(Chunk("fn calculate() {}", 2, 3, "Function", "math.rs"), [0.0, 1.0, 0.0, 0.0]),
+              EmbeddedChunk(Chunk("fn other() {}", 4, 5, "Function", "o.rs"), [0.0, 0.0, 1.0, 0.0])]
+    assert st.insert_chunks_with_ids(chunks) == [0, 1, 2] and st.shard_lens() == [1, 1, 1, 0]
+    st.build_index()
+    res = st.search([0.9, 0.1, 0.0, 0.0], 2)
+    assert [r.id for r in res] == [0, 1] and "authenticate" in res[0].content and res[0].score > res[1].score
+    st.close()
+    st2 = VS(tmp_path / "sh.db", 4, devices=[0, 0], rows_per_stripe=2)   # reopened over a different shard count
+    assert st2.is_indexed() and [r.id for r in st2.search([0.0, 0.2, 0.9, 0.0], 3)] == [2, 1, 0]
+    st2.close()
+
+
+def test_device_search_never_waits_and_gated_rerun_is_exact(VS, oracle, gpu_lib):
+    """cs_index_search_device only enqueues: (a) up to 16 queries the exact rerun is enqueued behind the
+    filter path, gated on its overflow word, so an adversarial row order still yields the exact answer on the
+    caller's stream with no host round trip; (b) above 16 queries the overflow is reported by
+    cs_index_search_status, and a search that did not overflow reports nothing."""
+    import torch
+
+    from codesearch_amd import _lib
+
+    n, dim, k, nq = 300_000, 384, 10, 8
+    q = synth_rows(5, 0, 24, dim)
+    u = synth_rows(6, 0, 1, dim)[0]
+    u = u - (u @ q[0]) / (q[0] @ q[0]) * q[0]
+    w = np.linspace(3.0, 0.5, n, dtype=np.float32)[:, None]
+    corpus = (q[0][None, :] + w * u[None, :]).astype(np.float32)   # cos(q0, row_i) increases with i: overflow
+    st = VS(None, dim)
+    st.insert_embeddings(corpus)
+    st.build_index()
+    dev = "cuda:0"
+    vp = lambda t: C.c_void_p(t.data_ptr())
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def device_search(queries, kk):
+        d_q = torch.from_numpy(np.ascontiguousarray(queries)).to(dev)
+        m = len(queries)
+        keys = torch.zeros((m, kk), dtype=torch.int64, device=dev)
+        cos = torch.zeros((m, kk), dtype=torch.float32, device=dev)
+        ids = torch.zeros((m, kk), dtype=torch.int32, device=dev)
+        cnt = torch.zeros((m,), dtype=torch.int32, device=dev)
+        _lib.check(gpu_lib.cs_index_search_device(st.handle, vp(d_q), m, dim, kk, vp(keys), vp(cos), vp(ids), vp(cnt), stream))
+        torch.cuda.synchronize()
+        return cos.cpu().numpy(), ids.cpu().numpy().astype(np.uint32), cnt.cpu().numpy()
+
+    cos, ids, cnt = device_search(q[:nq], k)                       # (a)
+    assert st.debug_counters() == (1, 1)
+    for i in range(nq):
+        ecos, eids = oracle.scan_topk(corpus, q[i], k, mode="omp")
+        assert cnt[i] == k and ids[i].tolist() == eids.tolist() and np.abs(cos[i] - ecos).max() < 2e-6
+    ov = C.c_uint32(7)
+    _lib.check(gpu_lib.cs_index_search_status(st.handle, stream, C.byref(ov)))
+    assert ov.value == 1                                           # sticky word: the overflow is also reported
+    _lib.check(gpu_lib.cs_index_search_status(st.handle, stream, C.byref(ov)))
+    assert ov.value == 0                                           # ... once
+    cos, ids, cnt = device_search(q, k)                            # (b) 24 queries: no gated rerun
+    _lib.check(gpu_lib.cs_index_search_status(st.handle, stream, C.byref(ov)))
+    assert ov.value == 1
+    ecos, eids = oracle.scan_topk(corpus, q[5], k, mode="omp")     # queries that did not overflow are still exact
+    assert ids[5].tolist() == eids.tolist()
+    hc, hi, hn = st.search_raw(q, k)                               # the host-buffer API reruns by itself
+    ecos, eids = oracle.scan_topk(corpus, q[0], k, mode="omp")
+    assert hi[0].tolist() == eids.tolist()
+    st.close()
+    # a benign corpus: nothing to report, and the device result is the host-API result bit for bit
+    st = VS(None, dim)
+    st.insert_synthetic(200_000, 31, 0)
+    st.build_index()
+    qs = synth_rows(32, 0, 40, dim)
+    for m in (2, 16, 40):
+        cos, ids, cnt = device_search(qs[:m], 25)
+        hc, hi, hn = st.search_raw(qs[:m], 25)
+        assert ids.tolist() == hi.tolist() and cos.tobytes() == hc.tobytes()
+    _lib.check(gpu_lib.cs_index_search_status(st.handle, stream, C.byref(ov)))
+    assert ov.value == 0 and st.debug_counters()[1] == 0
+    st.close()
+
+
+def test_concurrent_device_searches_on_one_stream_do_not_share_scratch(VS, oracle, gpu_lib):
+    """Scratch is keyed by (stream, calling thread): threads that all pass the NULL stream stay independent."""
+    import threading
+
+    import torch
+
+    from codesearch_amd import _lib
+
+    n, dim, k = 60_000, 384, 10
+    st = VS(None, dim)
+    st.insert_synthetic(n, 77, 0)
+    st.build_index()
+    corpus = oracle.synth_rows(77, 0, n, dim)
+    qs = synth_rows(78, 0, 12, dim)
+    expect = [oracle.scan_topk(corpus, qs[i], k, mode="omp") for i in range(12)]
+    errors = []
+    vp = lambda t: C.c_void_p(t.data_ptr())
+
+    def worker(t):
+        try:
+            torch.cuda.set_device(0)
+            sub = qs[3 * t: 3 * t + 3]
+            d_q = torch.from_numpy(np.ascontiguousarray(sub)).to("cuda:0")
+            ids = torch.zeros((3, k), dtype=torch.int32, device="cuda:0")
+            for _ in range(10):
+                keys = torch.zeros((3, k), dtype=torch.int64, device="cuda:0")
+                _lib.check(gpu_lib.cs_index_search_device(st.handle, vp(d_q), 3, dim, k, vp(keys), None, vp(ids), None, None))
+                torch.cuda.synchronize()
+                got = ids.cpu().numpy().astype(np.uint32)
+                for j in range(3):
+                    assert got[j].tolist() == expect[3 * t + j][1].tolist()
+        except Exception as e:  # pragma: no cover
+            errors.append(e)
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(4)]
+    [t.start() for t in threads]
+    [t.join() for t in threads]
+    assert not errors, errors
+    st.close()
