@@ -96,6 +96,7 @@ SIGNATURES = {
     "cs_embedder_create": (C.c_int32, [C.POINTER(BertConfig), f32p, C.c_uint64, C.c_int32, C.POINTER(vp)]),
     "cs_bert_config_from_dir": (C.c_int32, [C.c_char_p, C.c_int32, C.POINTER(BertConfig)]),
     "cs_bert_params_from_safetensors": (C.c_int32, [C.c_char_p, C.POINTER(BertConfig), f32p, C.c_uint64]),
+    "cs_bert_params_from_onnx": (C.c_int32, [C.c_char_p, C.POINTER(BertConfig), f32p, C.c_uint64]),
     "cs_embedder_create_from_dir": (C.c_int32, [C.c_char_p, C.c_int32, C.c_int32, C.POINTER(vp)]),
     "cs_embedder_destroy": (None, [vp]),
     "cs_embedder_dim": (C.c_uint32, [vp]),
@@ -109,8 +110,11 @@ SIGNATURES = {
     "cs_embedder_debug_counters": (C.c_int32, [vp, u64p, u64p, u64p]),
     "cs_tokenizer_create": (C.c_int32, [C.c_char_p, C.c_uint64, C.c_int32, C.c_uint32, C.POINTER(vp)]),
     "cs_tokenizer_create_from_file": (C.c_int32, [C.c_char_p, C.c_int32, C.c_uint32, C.POINTER(vp)]),
+    "cs_tokenizer_create_from_json": (C.c_int32, [C.c_char_p, C.c_uint32, C.POINTER(vp)]),
+    "cs_tokenizer_create_from_dir": (C.c_int32, [C.c_char_p, C.c_uint32, C.POINTER(vp)]),
     "cs_tokenizer_destroy": (None, [vp]),
     "cs_tokenizer_vocab_size": (C.c_uint32, [vp]),
+    "cs_tokenizer_max_length": (C.c_uint32, [vp]),
     "cs_tokenizer_token_to_id": (C.c_int32, [vp, C.c_char_p]),
     "cs_tokenizer_encode_batch": (C.c_int32, [vp, C.c_char_p, u64p, C.c_uint32, C.c_uint32, i32p, i32p,
                                               C.c_uint32, u32p]),

@@ -2,14 +2,17 @@
 // (config.json + model.safetensors, what `hf-hub` leaves in fastembed's cache dir for
 // BAAI/bge-small-en-v1.5 and its BERT siblings) -> cs_bert_config + the flat f32 parameter block of
 // include/cs_bert_params.h.  Stands in for the model-loading half of FastEmbedder::with_cache_dir
-// (/root/reference/src/embed/embedder.rs:218-245; fastembed itself reads an ONNX export of the same
-// tensors).  Host-only C++; no GPU needed for the two loaders.
+// (/root/reference/src/embed/embedder.rs:218-245).  fastembed's own cache holds the ONNX export of the same
+// tensors and a tokenizer.json instead: cs_embedder_create_from_dir takes either (ONNX: onnx_reader.cpp), and
+// cs_tokenizer_create_from_json / _from_dir below read tokenizer.json.  Host-only C++; no GPU needed for the
+// loaders.
 //
 // safetensors file = u64 LE header length N | N bytes of JSON {"name": {"dtype": "F32"|"F16"|"BF16",
 // "shape": [...], "data_offsets": [begin, end]}, ..., "__metadata__": {...}} | tensor bytes.
 // Tensor names are HF BertModel state-dict names, optionally prefixed "bert."; pooler, position_ids
 // and any other extra tensors are ignored.
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -67,13 +70,21 @@ struct JsonParser {
                     case 'r': out.push_back('\r'); break;
                     case 'b': out.push_back('\b'); break;
                     case 'f': out.push_back('\f'); break;
-                    case 'u': {  // keep BMP escapes as UTF-8; names we look up are ASCII
+                    case 'u': {  // \uXXXX (and surrogate pairs) -> UTF-8
                         if (end - p < 5) { ok = false; return out; }
                         unsigned cp = (unsigned)std::strtoul(std::string(p + 1, p + 5).c_str(), nullptr, 16);
                         p += 4;
+                        if (cp >= 0xD800 && cp < 0xDC00 && end - p >= 7 && p[1] == '\\' && p[2] == 'u') {
+                            const unsigned lo = (unsigned)std::strtoul(std::string(p + 3, p + 7).c_str(), nullptr, 16);
+                            if (lo >= 0xDC00 && lo < 0xE000) {
+                                cp = 0x10000 + ((cp - 0xD800) << 10) + (lo - 0xDC00);
+                                p += 6;
+                            }
+                        }
                         if (cp < 0x80) out.push_back((char)cp);
                         else if (cp < 0x800) { out.push_back((char)(0xC0 | (cp >> 6))); out.push_back((char)(0x80 | (cp & 0x3F))); }
-                        else { out.push_back((char)(0xE0 | (cp >> 12))); out.push_back((char)(0x80 | ((cp >> 6) & 0x3F))); out.push_back((char)(0x80 | (cp & 0x3F))); }
+                        else if (cp < 0x10000) { out.push_back((char)(0xE0 | (cp >> 12))); out.push_back((char)(0x80 | ((cp >> 6) & 0x3F))); out.push_back((char)(0x80 | (cp & 0x3F))); }
+                        else { out.push_back((char)(0xF0 | (cp >> 18))); out.push_back((char)(0x80 | ((cp >> 12) & 0x3F))); out.push_back((char)(0x80 | ((cp >> 6) & 0x3F))); out.push_back((char)(0x80 | (cp & 0x3F))); }
                         break;
                     }
                     default: out.push_back(*p);
@@ -144,6 +155,13 @@ bool read_file(const std::string& path, std::string& out, uint64_t max_bytes = ~
     char tmp[1 << 16];
     size_t got;
     while (out.size() < max_bytes && (got = std::fread(tmp, 1, sizeof(tmp), f)) > 0) out.append(tmp, got);
+    std::fclose(f);
+    return true;
+}
+
+bool file_exists(const std::string& path) {
+    FILE* f = std::fopen(path.c_str(), "rb");
+    if (!f) return false;
     std::fclose(f);
     return true;
 }
@@ -366,9 +384,134 @@ int32_t cs_embedder_create_from_dir(const char* model_dir, int32_t pooling, int3
     } catch (const std::bad_alloc&) {
         return fail(CS_ERR_OOM, "out of host memory for %llu parameters", (unsigned long long)n);
     }
-    const std::string path = std::string(model_dir) + "/model.safetensors";
-    CS_TRY(cs_bert_params_from_safetensors(path.c_str(), &cfg, params.data(), n));
+    // hf-hub snapshot of the PyTorch model (model.safetensors) or fastembed's cache of the ONNX export
+    // (onnx/model.onnx for Xenova/bge-small-en-v1.5; model.onnx / model_optimized.onnx for other entries)
+    const std::string dir(model_dir);
+    const std::string st_path = dir + "/model.safetensors";
+    if (file_exists(st_path)) {
+        CS_TRY(cs_bert_params_from_safetensors(st_path.c_str(), &cfg, params.data(), n));
+    } else {
+        std::string onnx;
+        for (const char* rel : {"/onnx/model.onnx", "/model.onnx", "/model_optimized.onnx", "/onnx/model_optimized.onnx"})
+            if (file_exists(dir + rel)) { onnx = dir + rel; break; }
+        if (onnx.empty())
+            return fail(CS_ERR_BAD_ARG, "Failed to initialize embedding model: %s holds neither model.safetensors nor "
+                        "onnx/model.onnx, model.onnx or model_optimized.onnx", model_dir);
+        CS_TRY(cs_bert_params_from_onnx(onnx.c_str(), &cfg, params.data(), n));
+    }
     return cs_embedder_create(&cfg, params.data(), 0, device, out);
+}
+
+// ---- tokenizer.json (the `tokenizers` crate's serialisation; what fastembed loads) ------------------
+// Read: model.type == "WordPiece", model.vocab {token: id}, model.unk_token / continuing_subword_prefix /
+// max_input_chars_per_word (must be the BERT values cs_tokenizer implements), normalizer BertNormalizer
+// .lowercase (strip_accents null or equal to it), truncation.max_length.  The vocabulary is handed to
+// cs_tokenizer_create in vocab.txt form (one token per line, id = line number).
+int32_t cs_tokenizer_create_from_json(const char* json_path, uint32_t max_length, cs_tokenizer** out) {
+    if (!out) return fail(CS_ERR_BAD_ARG, "null out pointer");
+    *out = nullptr;
+    if (!json_path) return fail(CS_ERR_BAD_ARG, "null tokenizer.json path");
+    std::string text;
+    if (!read_file(json_path, text, 1ull << 30))
+        return fail(CS_ERR_BAD_ARG, "Failed to initialize embedding model: cannot open %s", json_path);
+    JsonParser jp{text.data(), text.data() + text.size()};
+    const Json root = jp.value();
+    if (!jp.ok || root.kind != Json::Obj)
+        return fail(CS_ERR_BAD_ARG, "Failed to initialize embedding model: %s is not a JSON object", json_path);
+    const Json* model = root.get("model");
+    if (!model || model->kind != Json::Obj)
+        return fail(CS_ERR_BAD_ARG, "Failed to initialize embedding model: %s has no \"model\" object", json_path);
+    const Json* type = model->get("type");
+    if (type && type->kind == Json::Str && type->str != "WordPiece")
+        return fail(CS_ERR_UNSUPPORTED, "Failed to initialize embedding model: tokenizer model \"%s\" (only WordPiece is built)",
+                    type->str.c_str());
+    const Json* vocab = model->get("vocab");
+    if (!vocab || vocab->kind != Json::Obj || vocab->obj.empty())
+        return fail(CS_ERR_BAD_ARG, "Failed to initialize embedding model: %s has no WordPiece vocabulary", json_path);
+    if (const Json* j = model->get("unk_token"))
+        if (j->kind == Json::Str && j->str != "[UNK]")
+            return fail(CS_ERR_UNSUPPORTED, "Failed to initialize embedding model: unk_token \"%s\" (expected [UNK])", j->str.c_str());
+    if (const Json* j = model->get("continuing_subword_prefix"))
+        if (j->kind == Json::Str && j->str != "##")
+            return fail(CS_ERR_UNSUPPORTED, "Failed to initialize embedding model: continuing_subword_prefix \"%s\" (expected ##)",
+                        j->str.c_str());
+    if (const Json* j = model->get("max_input_chars_per_word"))
+        if (j->kind == Json::Num && j->num != 100.0)
+            return fail(CS_ERR_UNSUPPORTED, "Failed to initialize embedding model: max_input_chars_per_word %g (expected 100)", j->num);
+    int lowercase = 1;
+    if (const Json* nz = root.get("normalizer")) {
+        if (nz->kind == Json::Obj) {
+            const Json* nt = nz->get("type");
+            if (nt && nt->kind == Json::Str && nt->str != "BertNormalizer")
+                return fail(CS_ERR_UNSUPPORTED, "Failed to initialize embedding model: normalizer \"%s\" (only BertNormalizer)",
+                            nt->str.c_str());
+            const Json* lc = nz->get("lowercase");
+            if (lc && lc->kind == Json::Bool) lowercase = lc->b ? 1 : 0;
+            const Json* sa = nz->get("strip_accents");
+            if (sa && sa->kind == Json::Bool && (int)sa->b != lowercase)
+                return fail(CS_ERR_UNSUPPORTED, "Failed to initialize embedding model: strip_accents differs from lowercase");
+            for (const char* key : {"clean_text", "handle_chinese_chars"}) {
+                const Json* v = nz->get(key);
+                if (v && v->kind == Json::Bool && !v->b)
+                    return fail(CS_ERR_UNSUPPORTED, "Failed to initialize embedding model: normalizer.%s = false is not built", key);
+            }
+        }
+    }
+    if (max_length == 0) {
+        max_length = 512;  // fastembed's default truncation length
+        if (const Json* tr = root.get("truncation"))
+            if (tr->kind == Json::Obj)
+                if (const Json* ml = tr->get("max_length"))
+                    if (ml->kind == Json::Num && ml->num >= 2 && ml->num <= 1e6) max_length = (uint32_t)ml->num;
+    }
+    uint64_t max_id = 0;
+    for (const auto& kv : vocab->obj) {
+        if (kv.second.kind != Json::Num || kv.second.num < 0 || kv.second.num > 16777216.0)
+            return fail(CS_ERR_BAD_ARG, "Failed to initialize embedding model: vocabulary id of \"%s\" is not a small integer",
+                        kv.first.c_str());
+        max_id = std::max<uint64_t>(max_id, (uint64_t)kv.second.num);
+    }
+    std::vector<const std::string*> by_id(max_id + 1, nullptr);
+    for (const auto& kv : vocab->obj) {
+        if (kv.first.find('\n') != std::string::npos)
+            return fail(CS_ERR_UNSUPPORTED, "Failed to initialize embedding model: a vocabulary entry contains a line break");
+        by_id[(size_t)kv.second.num] = &kv.first;
+    }
+    std::string lines;
+    for (size_t i = 0; i <= max_id; ++i) {
+        if (by_id[i]) lines += *by_id[i];
+        else lines += "[unused-id-" + std::to_string(i) + "]";  // a hole in the id space: never produced
+        lines.push_back('\n');
+    }
+    return cs_tokenizer_create(lines.data(), lines.size(), lowercase, max_length, out);
+}
+
+// What fastembed builds its tokenizer from, in a model directory: tokenizer.json when present (truncation at
+// min(max_length or 512, tokenizer_config.json's model_max_length)), otherwise vocab.txt with
+// tokenizer_config.json's do_lower_case (default true).
+int32_t cs_tokenizer_create_from_dir(const char* model_dir, uint32_t max_length, cs_tokenizer** out) {
+    if (!out) return fail(CS_ERR_BAD_ARG, "null out pointer");
+    *out = nullptr;
+    if (!model_dir) return fail(CS_ERR_BAD_ARG, "null model directory");
+    const std::string dir(model_dir);
+    int lowercase = 1;
+    uint32_t cap = 0;
+    std::string ctext;
+    if (read_file(dir + "/tokenizer_config.json", ctext, 1 << 24)) {
+        JsonParser jp{ctext.data(), ctext.data() + ctext.size()};
+        const Json root = jp.value();
+        if (jp.ok && root.kind == Json::Obj) {
+            const Json* lc = root.get("do_lower_case");
+            if (lc && lc->kind == Json::Bool) lowercase = lc->b ? 1 : 0;
+            const Json* mm = root.get("model_max_length");
+            if (mm && mm->kind == Json::Num && mm->num >= 2 && mm->num <= 1e6) cap = (uint32_t)mm->num;
+        }
+    }
+    uint32_t want = max_length ? max_length : 512;
+    if (cap && cap < want) want = cap;
+    if (file_exists(dir + "/tokenizer.json")) return cs_tokenizer_create_from_json((dir + "/tokenizer.json").c_str(), want, out);
+    if (file_exists(dir + "/vocab.txt")) return cs_tokenizer_create_from_file((dir + "/vocab.txt").c_str(), lowercase, want, out);
+    return fail(CS_ERR_BAD_ARG, "Failed to initialize embedding model: %s holds neither tokenizer.json nor vocab.txt", model_dir);
 }
 
 }  // extern "C"

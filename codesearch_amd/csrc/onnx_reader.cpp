@@ -1,0 +1,400 @@
+// onnx_reader.cpp — the weights fastembed actually caches: FastEmbedder::with_cache_dir
+// (/root/reference/src/embed/embedder.rs:218-245) points fastembed at a cache directory in which hf-hub
+// leaves the model's ONNX export (onnx/model.onnx for Xenova/bge-small-en-v1.5, model.onnx or
+// model_optimized.onnx for other registry entries) beside config.json and tokenizer.json — not
+// model.safetensors.  This file reads the BERT parameters out of such an ONNX file into the flat f32 block
+// of include/cs_bert_params.h.  Host-only C++; protobuf wire format decoded by hand (no protobuf library,
+// no onnxruntime): only the handful of messages and fields below are interpreted, the rest is skipped.
+//
+//   ModelProto   { graph = 7 }
+//   GraphProto   { node = 1 (repeated NodeProto), initializer = 5 (repeated TensorProto) }
+//   NodeProto    { input = 1, output = 2, name = 3, op_type = 4, attribute = 5 }
+//   AttributeProto { name = 1, i = 3 }
+//   TensorProto  { dims = 1, data_type = 2 (1 FLOAT, 10 FLOAT16, 16 BFLOAT16), float_data = 4, name = 8,
+//                  raw_data = 9, external_data = 13, data_location = 14 }
+//
+// Where the tensors are.  An exporter (torch.onnx / optimum) keeps the state-dict name of every parameter an
+// op consumes as it is — embeddings, LayerNorm weights, all biases — but folds the transpose of a Linear
+// weight into a constant, so `encoder.layer.N.….dense.weight` [out, in] arrives as an anonymous
+// initializer (`onnx::MatMul_1234`) of shape [in, out].  Those are found through the graph: the Add that
+// consumes the layer's bias, the MatMul feeding that Add, the MatMul's second input.  Gemm nodes (weight as
+// input 1, transB) and the fused com.microsoft Attention node of ORT-optimised files (packed [H, 3H] QKV
+// weight as input 1, packed [3H] bias as input 2) are understood as well.
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/cs_bert_params.h"
+#include "common.hpp"
+
+namespace {
+
+using cs::fail;
+
+struct Span { const uint8_t* p = nullptr; const uint8_t* end = nullptr; };
+
+bool varint(Span& s, uint64_t& v) {
+    v = 0;
+    for (int shift = 0; shift < 64 && s.p < s.end; shift += 7) {
+        const uint8_t b = *s.p++;
+        v |= (uint64_t)(b & 0x7f) << shift;
+        if (!(b & 0x80)) return true;
+    }
+    return false;
+}
+
+// One field of a message: key, then (for wire type 2) the payload span, (for 0) the value.
+struct Field { uint32_t num = 0, wire = 0; uint64_t val = 0; Span sub; };
+
+bool next_field(Span& s, Field& f) {
+    uint64_t key;
+    if (!varint(s, key)) return false;
+    f.num = (uint32_t)(key >> 3);
+    f.wire = (uint32_t)(key & 7);
+    switch (f.wire) {
+        case 0: return varint(s, f.val);
+        case 1: if (s.end - s.p < 8) return false; std::memcpy(&f.val, s.p, 8); s.p += 8; return true;
+        case 5: if (s.end - s.p < 4) return false; f.val = 0; std::memcpy(&f.val, s.p, 4); s.p += 4; return true;
+        case 2: {
+            uint64_t n;
+            if (!varint(s, n) || (uint64_t)(s.end - s.p) < n) return false;
+            f.sub = Span{s.p, s.p + n};
+            s.p += n;
+            return true;
+        }
+        default: return false;  // groups (3, 4) do not occur in ONNX files
+    }
+}
+
+std::string str_of(const Span& s) { return std::string(reinterpret_cast<const char*>(s.p), (size_t)(s.end - s.p)); }
+
+struct Tensor {
+    std::string name;
+    std::vector<uint64_t> dims;
+    int dtype = 0;
+    Span raw;          // raw_data
+    Span float_data;   // packed float_data (dtype 1 only)
+    bool external = false;
+    uint64_t count() const { uint64_t c = 1; for (uint64_t d : dims) c *= d; return c; }
+};
+
+struct Node {
+    std::string op;
+    std::vector<std::string> in, out;
+    int64_t transB = 0;
+};
+
+bool parse_tensor(Span s, Tensor& t) {
+    Field f;
+    while (s.p < s.end) {
+        if (!next_field(s, f)) return false;
+        if (f.num == 1 && f.wire == 0) t.dims.push_back(f.val);
+        else if (f.num == 1 && f.wire == 2) {  // packed dims
+            Span d = f.sub;
+            uint64_t v;
+            while (d.p < d.end) { if (!varint(d, v)) return false; t.dims.push_back(v); }
+        } else if (f.num == 2 && f.wire == 0) t.dtype = (int)f.val;
+        else if (f.num == 4 && f.wire == 2) t.float_data = f.sub;
+        else if (f.num == 4 && f.wire == 5) return false;  // unpacked float_data: not produced by any exporter we know
+        else if (f.num == 8 && f.wire == 2) t.name = str_of(f.sub);
+        else if (f.num == 9 && f.wire == 2) t.raw = f.sub;
+        else if (f.num == 13) t.external = true;
+        else if (f.num == 14 && f.wire == 0 && f.val == 1) t.external = true;
+    }
+    return true;
+}
+
+bool parse_node(Span s, Node& n) {
+    Field f;
+    while (s.p < s.end) {
+        if (!next_field(s, f)) return false;
+        if (f.num == 1 && f.wire == 2) n.in.push_back(str_of(f.sub));
+        else if (f.num == 2 && f.wire == 2) n.out.push_back(str_of(f.sub));
+        else if (f.num == 4 && f.wire == 2) n.op = str_of(f.sub);
+        else if (f.num == 5 && f.wire == 2) {  // attribute: only transB matters
+            Span a = f.sub;
+            Field g;
+            std::string an;
+            int64_t iv = 0;
+            while (a.p < a.end) {
+                if (!next_field(a, g)) return false;
+                if (g.num == 1 && g.wire == 2) an = str_of(g.sub);
+                else if (g.num == 3 && g.wire == 0) iv = (int64_t)g.val;
+            }
+            if (an == "transB") n.transB = iv;
+        }
+    }
+    return true;
+}
+
+float half_to_float(uint16_t h) {
+    const uint32_t sign = (uint32_t)(h & 0x8000u) << 16;
+    uint32_t exp = (h >> 10) & 0x1Fu, man = h & 0x3FFu, bits;
+    if (exp == 0) {
+        if (man == 0) bits = sign;
+        else {
+            int e = -1;
+            do { man <<= 1; ++e; } while (!(man & 0x400u));
+            bits = sign | ((uint32_t)(127 - 15 - e) << 23) | ((man & 0x3FFu) << 13);
+        }
+    } else if (exp == 31) bits = sign | 0x7F800000u | (man << 13);
+    else bits = sign | ((exp + 112) << 23) | (man << 13);
+    float f;
+    std::memcpy(&f, &bits, 4);
+    return f;
+}
+
+// element i of a tensor as f32 (FLOAT, FLOAT16, BFLOAT16)
+struct Reader {
+    const Tensor* t;
+    const uint8_t* base;
+    int esz;
+    bool ok;
+    explicit Reader(const Tensor& tt) : t(&tt), base(nullptr), esz(0), ok(false) {
+        const uint64_t n = tt.count();
+        if (tt.dtype == 1) {
+            esz = 4;
+            if ((uint64_t)(tt.raw.end - tt.raw.p) == n * 4) base = tt.raw.p;
+            else if ((uint64_t)(tt.float_data.end - tt.float_data.p) == n * 4) base = tt.float_data.p;
+        } else if (tt.dtype == 10 || tt.dtype == 16) {
+            esz = 2;
+            if ((uint64_t)(tt.raw.end - tt.raw.p) == n * 2) base = tt.raw.p;
+        }
+        ok = base != nullptr;
+    }
+    float at(uint64_t i) const {
+        if (esz == 4) { float f; std::memcpy(&f, base + i * 4, 4); return f; }
+        uint16_t v;
+        std::memcpy(&v, base + i * 2, 2);
+        if (t->dtype == 16) { const uint32_t b = (uint32_t)v << 16; float f; std::memcpy(&f, &b, 4); return f; }
+        return half_to_float(v);
+    }
+};
+
+struct Model {
+    std::map<std::string, Tensor> init;
+    std::vector<Node> nodes;
+    std::map<std::string, size_t> producer;                 // output name -> node
+    std::multimap<std::string, size_t> consumers;           // input name -> nodes
+
+    const Tensor* tensor(const std::string& name) const {
+        auto it = init.find(name);
+        return it == init.end() ? nullptr : &it->second;
+    }
+    // initializers sometimes reach an op through Identity / Cast nodes
+    const Tensor* resolve(const std::string& name, int depth = 0) const {
+        if (const Tensor* t = tensor(name)) return t;
+        if (depth > 4) return nullptr;
+        auto it = producer.find(name);
+        if (it == producer.end()) return nullptr;
+        const Node& n = nodes[it->second];
+        if ((n.op == "Identity" || n.op == "Cast") && n.in.size() == 1) return resolve(n.in[0], depth + 1);
+        return nullptr;
+    }
+};
+
+int32_t parse_model(Span file, Model& m, const char* path) {
+    Field f;
+    Span graph;
+    while (file.p < file.end) {
+        if (!next_field(file, f)) return fail(CS_ERR_BAD_ARG, "Failed to initialize embedding model: %s is not an ONNX file (bad protobuf)", path);
+        if (f.num == 7 && f.wire == 2) graph = f.sub;
+    }
+    if (!graph.p) return fail(CS_ERR_BAD_ARG, "Failed to initialize embedding model: %s holds no graph", path);
+    while (graph.p < graph.end) {
+        if (!next_field(graph, f)) return fail(CS_ERR_BAD_ARG, "Failed to initialize embedding model: %s has a malformed graph", path);
+        if (f.num == 5 && f.wire == 2) {
+            Tensor t;
+            if (!parse_tensor(f.sub, t)) return fail(CS_ERR_BAD_ARG, "Failed to initialize embedding model: %s has a malformed initializer", path);
+            std::string nm = t.name;
+            m.init.emplace(std::move(nm), std::move(t));
+        } else if (f.num == 1 && f.wire == 2) {
+            Node n;
+            if (!parse_node(f.sub, n)) return fail(CS_ERR_BAD_ARG, "Failed to initialize embedding model: %s has a malformed node", path);
+            m.nodes.push_back(std::move(n));
+        }
+    }
+    for (size_t i = 0; i < m.nodes.size(); ++i) {
+        for (const auto& o : m.nodes[i].out) m.producer[o] = i;
+        for (const auto& in : m.nodes[i].in) m.consumers.emplace(in, i);
+    }
+    return CS_OK;
+}
+
+// dst[r * cols + c] = src, where src is [rows, cols] (direct) or [cols, rows] (transposed)
+int32_t copy_matrix(const Tensor& t, uint64_t rows, uint64_t cols, bool transposed, float* dst, const char* what) {
+    if (t.external)
+        return fail(CS_ERR_UNSUPPORTED, "Failed to initialize embedding model: %s keeps its data in an external file", what);
+    Reader r(t);
+    if (!r.ok)
+        return fail(CS_ERR_UNSUPPORTED, "Failed to initialize embedding model: %s has data type %d or a truncated payload "
+                    "(FLOAT, FLOAT16, BFLOAT16 only)", what, t.dtype);
+    if (!transposed) {
+        for (uint64_t i = 0; i < rows * cols; ++i) dst[i] = r.at(i);
+    } else {
+        for (uint64_t c = 0; c < cols; ++c)
+            for (uint64_t rr = 0; rr < rows; ++rr) dst[rr * cols + c] = r.at(c * rows + rr);
+    }
+    return CS_OK;
+}
+
+bool shape_is(const Tensor& t, std::initializer_list<uint64_t> want) {
+    return t.dims == std::vector<uint64_t>(want);
+}
+
+// The [out, in] weight that belongs to `bias_name` (see the header comment).  -> tensor + whether it is [in, out].
+const Tensor* weight_of_bias(const Model& m, const std::string& bias_name, uint64_t out, uint64_t in, bool& transposed) {
+    auto range = m.consumers.equal_range(bias_name);
+    for (auto it = range.first; it != range.second; ++it) {
+        const Node& n = m.nodes[it->second];
+        if (n.op == "Gemm" && n.in.size() >= 3 && n.in[2] == bias_name) {
+            const Tensor* w = m.resolve(n.in[1]);
+            if (!w) continue;
+            if (n.transB && shape_is(*w, {out, in})) { transposed = false; return w; }
+            if (!n.transB && shape_is(*w, {in, out})) { transposed = true; return w; }
+        } else if (n.op == "Add" && n.in.size() == 2) {
+            const std::string& other = n.in[0] == bias_name ? n.in[1] : n.in[0];
+            auto p = m.producer.find(other);
+            if (p == m.producer.end()) continue;
+            const Node& mm = m.nodes[p->second];
+            if (mm.op != "MatMul" || mm.in.size() != 2) continue;
+            const Tensor* w = m.resolve(mm.in[1]);
+            if (w && shape_is(*w, {in, out})) { transposed = true; return w; }
+        }
+    }
+    return nullptr;
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t cs_bert_params_from_onnx(const char* path, const cs_bert_config* cfg, float* params, uint64_t n_params) {
+    if (!path || !cfg || !params) return fail(CS_ERR_BAD_ARG, "null argument");
+    cs_bert_offsets o;
+    cs_bert_layout(cfg, &o);
+    if (n_params != o.total)
+        return fail(CS_ERR_BAD_ARG, "Failed to initialize embedding model: expected %llu parameters, got %llu",
+                    (unsigned long long)o.total, (unsigned long long)n_params);
+    const int fd = open(path, O_RDONLY);
+    if (fd < 0) return fail(CS_ERR_BAD_ARG, "Failed to initialize embedding model: cannot open %s", path);
+    struct stat sb;
+    if (fstat(fd, &sb) != 0 || sb.st_size <= 0) {
+        close(fd);
+        return fail(CS_ERR_BAD_ARG, "Failed to initialize embedding model: %s is empty", path);
+    }
+    void* map = mmap(nullptr, (size_t)sb.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+    close(fd);
+    if (map == MAP_FAILED) return fail(CS_ERR_OOM, "Failed to initialize embedding model: cannot map %s", path);
+    struct Unmap { void* p; size_t n; ~Unmap() { munmap(p, n); } } unmap{map, (size_t)sb.st_size};
+
+    Model m;
+    CS_TRY(parse_model(Span{(const uint8_t*)map, (const uint8_t*)map + sb.st_size}, m, path));
+    const uint64_t H = cfg->hidden, I = cfg->intermediate;
+
+    // a tensor whose state-dict name survived the export, under whatever module prefix the exported model was
+    // wrapped in ("", "bert.", "0.auto_model.", ...): the prefix is what precedes the word-embedding table's name
+    std::string mod_prefix;
+    {
+        static const std::string anchor = "embeddings.word_embeddings.weight";
+        for (const auto& kv : m.init) {
+            const std::string& nm = kv.first;
+            if (nm.size() >= anchor.size() && nm.compare(nm.size() - anchor.size(), anchor.size(), anchor) == 0) {
+                mod_prefix = nm.substr(0, nm.size() - anchor.size());
+                break;
+            }
+        }
+    }
+    auto named = [&](const std::string& name) -> const Tensor* { return m.tensor(mod_prefix + name); };
+    auto vec = [&](const std::string& name, uint64_t n, float* dst) -> int32_t {
+        const Tensor* t = named(name);
+        if (!t) return fail(CS_ERR_BAD_ARG, "Failed to initialize embedding model: tensor %s is missing from %s", name.c_str(), path);
+        if (t->count() != n || t->dims.size() > 2)
+            return fail(CS_ERR_DIM_MISMATCH, "Failed to initialize embedding model: %s has %llu elements, config.json implies %llu",
+                        name.c_str(), (unsigned long long)t->count(), (unsigned long long)n);
+        return copy_matrix(*t, 1, n, false, dst, name.c_str());
+    };
+    auto table = [&](const std::string& name, uint64_t rows, float* dst) -> int32_t {
+        const Tensor* t = named(name);
+        if (!t) return fail(CS_ERR_BAD_ARG, "Failed to initialize embedding model: tensor %s is missing from %s", name.c_str(), path);
+        if (!shape_is(*t, {rows, H}))
+            return fail(CS_ERR_DIM_MISMATCH, "Failed to initialize embedding model: %s does not have shape [%llu, %llu]",
+                        name.c_str(), (unsigned long long)rows, (unsigned long long)H);
+        return copy_matrix(*t, rows, H, false, dst, name.c_str());
+    };
+    // a Linear layer: weight [out, in] + bias [out]
+    auto linear = [&](const std::string& prefix, uint64_t out, uint64_t in, float* w_dst, float* b_dst) -> int32_t {
+        const std::string bname = prefix + ".bias", wname = prefix + ".weight";
+        CS_TRY(vec(bname, out, b_dst));
+        if (const Tensor* w = named(wname)) {  // name kept (Gemm exports, hand-built files)
+            if (shape_is(*w, {out, in})) return copy_matrix(*w, out, in, false, w_dst, wname.c_str());
+            return fail(CS_ERR_DIM_MISMATCH, "Failed to initialize embedding model: %s does not have shape [%llu, %llu]",
+                        wname.c_str(), (unsigned long long)out, (unsigned long long)in);
+        }
+        bool tr = false;
+        const Tensor* w = weight_of_bias(m, mod_prefix + bname, out, in, tr);
+        if (!w)
+            return fail(CS_ERR_BAD_ARG, "Failed to initialize embedding model: no MatMul/Gemm weight of shape [%llu, %llu] feeds "
+                        "the Add of %s in %s", (unsigned long long)in, (unsigned long long)out, bname.c_str(), path);
+        return copy_matrix(*w, out, in, tr, w_dst, wname.c_str());
+    };
+
+    CS_TRY(table("embeddings.word_embeddings.weight", cfg->vocab_size, params + o.word));
+    CS_TRY(table("embeddings.position_embeddings.weight", cfg->max_position, params + o.pos));
+    CS_TRY(table("embeddings.token_type_embeddings.weight", cfg->type_vocab_size, params + o.type));
+    CS_TRY(vec("embeddings.LayerNorm.weight", H, params + o.emb_ln_g));
+    CS_TRY(vec("embeddings.LayerNorm.bias", H, params + o.emb_ln_b));
+
+    // ORT-optimised files: one fused Attention node per layer, in layer order
+    std::vector<const Node*> fused;
+    for (const Node& n : m.nodes)
+        if (n.op == "Attention" && n.in.size() >= 3) fused.push_back(&n);
+    for (uint32_t l = 0; l < cfg->layers; ++l) {
+        cs_bert_layer_offsets lo;
+        cs_bert_layer_layout(cfg, &o, l, &lo);
+        const std::string p = "encoder.layer." + std::to_string(l) + ".";
+        if (named(p + "attention.self.query.bias")) {
+            CS_TRY(linear(p + "attention.self.query", H, H, params + lo.q_w, params + lo.q_b));
+            CS_TRY(linear(p + "attention.self.key", H, H, params + lo.k_w, params + lo.k_b));
+            CS_TRY(linear(p + "attention.self.value", H, H, params + lo.v_w, params + lo.v_b));
+        } else if (fused.size() == cfg->layers) {
+            const Tensor* w = m.resolve(fused[l]->in[1]);
+            const Tensor* b = m.resolve(fused[l]->in[2]);
+            if (!w || !b || !shape_is(*w, {H, 3 * H}) || b->count() != 3 * H)
+                return fail(CS_ERR_BAD_ARG, "Failed to initialize embedding model: layer %u's fused Attention node lacks a "
+                            "[%llu, %llu] weight and [%llu] bias", l, (unsigned long long)H, (unsigned long long)(3 * H),
+                            (unsigned long long)(3 * H));
+            Reader rw(*w), rb(*b);
+            if (!rw.ok || !rb.ok || w->external || b->external)
+                return fail(CS_ERR_UNSUPPORTED, "Failed to initialize embedding model: layer %u's fused QKV weight has an "
+                            "unsupported data type (quantised exports are not read)", l);
+            float* wd[3] = {params + lo.q_w, params + lo.k_w, params + lo.v_w};
+            float* bd[3] = {params + lo.q_b, params + lo.k_b, params + lo.v_b};
+            for (int part = 0; part < 3; ++part) {
+                for (uint64_t out = 0; out < H; ++out) {
+                    bd[part][out] = rb.at(part * H + out);
+                    for (uint64_t in = 0; in < H; ++in) wd[part][out * H + in] = rw.at(in * 3 * H + part * H + out);
+                }
+            }
+        } else {
+            return fail(CS_ERR_BAD_ARG, "Failed to initialize embedding model: %s has neither %sattention.self.query.bias nor "
+                        "one fused Attention node per layer", path, p.c_str());
+        }
+        CS_TRY(linear(p + "attention.output.dense", H, H, params + lo.ao_w, params + lo.ao_b));
+        CS_TRY(vec(p + "attention.output.LayerNorm.weight", H, params + lo.ao_ln_g));
+        CS_TRY(vec(p + "attention.output.LayerNorm.bias", H, params + lo.ao_ln_b));
+        CS_TRY(linear(p + "intermediate.dense", I, H, params + lo.up_w, params + lo.up_b));
+        CS_TRY(linear(p + "output.dense", H, I, params + lo.down_w, params + lo.down_b));
+        CS_TRY(vec(p + "output.LayerNorm.weight", H, params + lo.out_ln_g));
+        CS_TRY(vec(p + "output.LayerNorm.bias", H, params + lo.out_ln_b));
+    }
+    return CS_OK;
+}
+
+}  // extern "C"

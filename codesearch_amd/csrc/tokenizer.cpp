@@ -424,6 +424,7 @@ int32_t cs_tokenizer_create_from_file(const char* vocab_path, int32_t lowercase,
 void cs_tokenizer_destroy(cs_tokenizer* t) { delete t; }
 
 uint32_t cs_tokenizer_vocab_size(const cs_tokenizer* t) { return t ? t->size : 0; }
+uint32_t cs_tokenizer_max_length(const cs_tokenizer* t) { return t ? t->max_length : 0; }
 
 int32_t cs_tokenizer_token_to_id(const cs_tokenizer* t, const char* token) {
     return (t && token) ? t->find(std::string(token)) : -1;

@@ -163,9 +163,11 @@ class FastEmbedder:
     @classmethod
     def from_dir(cls, model_dir: str, model_type: ModelType = None, pooling: int = -1, device: int = 0,
                  lowercase: Optional[bool] = None) -> "FastEmbedder":
-        """A HF snapshot directory (config.json, model.safetensors, vocab.txt), as hf-hub leaves it in
-        fastembed's cache: cs_embedder_create_from_dir + cs_tokenizer_create_from_file.  pooling -1 = what
-        the snapshot's 1_Pooling/config.json says (CLS when absent)."""
+        """A model directory as hf-hub leaves it in fastembed's cache — config.json, the weights as
+        onnx/model.onnx | model.onnx | model_optimized.onnx (what fastembed downloads) or model.safetensors
+        (the PyTorch snapshot), tokenizer.json or vocab.txt: cs_embedder_create_from_dir +
+        cs_tokenizer_create_from_dir.  pooling -1 = what 1_Pooling/config.json says (CLS when absent);
+        lowercase overrides the directory's own setting (vocab.txt route only)."""
         from .tokenizer import WordPieceTokenizer
 
         self = cls.__new__(cls)
@@ -180,18 +182,15 @@ class FastEmbedder:
         h = C.c_void_p()
         _lib.check(self._lib.cs_embedder_create_from_dir(str(model_dir).encode(), pooling, device, C.byref(h)))
         self._h = h
-        vocab = os.path.join(str(model_dir), "vocab.txt")
-        if lowercase is None:  # tokenizer_config.json's do_lower_case (BERT's default: true)
-            lowercase = True
-            tc = os.path.join(str(model_dir), "tokenizer_config.json")
-            if os.path.exists(tc):
-                import json
-
-                with open(tc, encoding="utf-8") as f:
-                    lowercase = bool(json.load(f).get("do_lower_case", True))
-        self.tokenizer = (WordPieceTokenizer.from_vocab_file(vocab, lowercase=lowercase,
-                                                             max_length=self.config.max_position)
-                          if os.path.exists(vocab) else None)
+        d = str(model_dir)
+        vocab = os.path.join(d, "vocab.txt")
+        if os.path.exists(os.path.join(d, "tokenizer.json")) or (os.path.exists(vocab) and lowercase is None):
+            self.tokenizer = WordPieceTokenizer.from_dir(d, max_length=self.config.max_position)
+        elif os.path.exists(vocab):
+            self.tokenizer = WordPieceTokenizer.from_vocab_file(vocab, lowercase=lowercase,
+                                                                max_length=self.config.max_position)
+        else:
+            self.tokenizer = None
         return self
 
     # constructors named as in the reference

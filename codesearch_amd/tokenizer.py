@@ -34,10 +34,16 @@ class WordPieceTokenizer:
     {token: id} dict with contiguous ids, or use from_vocab_file for a vocab.txt."""
 
     def __init__(self, vocab: Dict[str, int] = None, lowercase: bool = True, max_length: int = 512,
-                 vocab_file: str = None):
+                 vocab_file: str = None, tokenizer_json: str = None, model_dir: str = None):
         self._lib = _lib.load()
         h = C.c_void_p()
-        if vocab_file is not None:
+        if tokenizer_json is not None:   # the file fastembed loads; max_length 0 = the file's truncation length
+            _lib.check(self._lib.cs_tokenizer_create_from_json(str(tokenizer_json).encode(), int(max_length or 0), C.byref(h)))
+            max_length = 0
+        elif model_dir is not None:      # tokenizer.json, else vocab.txt + tokenizer_config.json
+            _lib.check(self._lib.cs_tokenizer_create_from_dir(str(model_dir).encode(), int(max_length or 0), C.byref(h)))
+            max_length = 0
+        elif vocab_file is not None:
             _lib.check(self._lib.cs_tokenizer_create_from_file(vocab_file.encode(), int(lowercase), max_length,
                                                                C.byref(h)))
         else:
@@ -47,12 +53,22 @@ class WordPieceTokenizer:
             blob = "\n".join(toks).encode("utf-8") + b"\n"
             _lib.check(self._lib.cs_tokenizer_create(blob, len(blob), int(lowercase), max_length, C.byref(h)))
         self._h = h
+        if not max_length:  # the handle's own truncation length (from the json / directory)
+            max_length = int(self._lib.cs_tokenizer_max_length(h))
         self.max_length = max_length
         self.pad_id = self.token_to_id("[PAD]")
 
     @classmethod
     def from_vocab_file(cls, path: str, **kw) -> "WordPieceTokenizer":
         return cls(vocab_file=path, **kw)
+
+    @classmethod
+    def from_tokenizer_json(cls, path: str, max_length: int = 0) -> "WordPieceTokenizer":
+        return cls(tokenizer_json=path, max_length=max_length)
+
+    @classmethod
+    def from_dir(cls, model_dir: str, max_length: int = 0) -> "WordPieceTokenizer":
+        return cls(model_dir=model_dir, max_length=max_length)
 
     def close(self):
         if getattr(self, "_h", None):

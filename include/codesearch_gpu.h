@@ -259,17 +259,24 @@ uint64_t cs_bert_param_count(const cs_bert_config* cfg);
  * device from `seed` by the counter-based generator of include/cs_synth.h (synthetic-weight mode). */
 int32_t cs_embedder_create(const cs_bert_config* cfg, const float* params, uint64_t seed,
                            int32_t device, cs_embedder** out);
-/* Real checkpoints (the model-loading half of with_cache_dir).  `model_dir` is a HF snapshot
- * directory as hf-hub caches it: config.json (BERT family, erf-GELU, absolute positions) and
- * model.safetensors (HF BertModel tensor names, optional "bert." prefix; F32, F16 or BF16;
- * pooler / position_ids / other extras ignored).  The two loaders are host-only. */
+/* Real checkpoints (the model-loading half of with_cache_dir).  `model_dir` is a model directory as hf-hub
+ * caches it: config.json (BERT family, erf-GELU, absolute positions) and the weights as EITHER
+ *   - model.safetensors (the PyTorch snapshot: HF BertModel tensor names, optional "bert." prefix), or
+ *   - the ONNX export fastembed itself downloads and runs — onnx/model.onnx (Xenova/bge-small-en-v1.5),
+ *     model.onnx or model_optimized.onnx: the graph's initialisers are read by hand (no protobuf library):
+ *     named parameters directly, Linear weights through the MatMul/Gemm feeding each bias's Add, the packed
+ *     QKV of ORT-optimised files through their fused Attention nodes.
+ * F32, F16 or BF16; pooler / position_ids / other extras ignored; quantised (int8) exports are refused.
+ * All loaders are host-only. */
 /* pooling: CS_POOL_CLS, CS_POOL_MEAN, or -1 = what <model_dir>/1_Pooling/config.json says (the
  * sentence-transformers module: mean for MiniLM / E5, CLS for BGE), CLS when that file is absent. */
 int32_t cs_bert_config_from_dir(const char* model_dir, int32_t pooling, cs_bert_config* cfg);
 int32_t cs_bert_params_from_safetensors(const char* path, const cs_bert_config* cfg,
                                         float* params, uint64_t n_params);
-/* config.json + model.safetensors -> embedder on `device` (vocab.txt of the same directory goes to
- * cs_tokenizer_create_from_file). */
+int32_t cs_bert_params_from_onnx(const char* path, const cs_bert_config* cfg, float* params,
+                                 uint64_t n_params);
+/* config.json + weights -> embedder on `device` (the tokenizer of the same directory comes from
+ * cs_tokenizer_create_from_dir). */
 int32_t cs_embedder_create_from_dir(const char* model_dir, int32_t pooling, int32_t device,
                                     cs_embedder** out);
 void cs_embedder_destroy(cs_embedder* h);
@@ -332,8 +339,18 @@ int32_t cs_tokenizer_create(const char* vocab, uint64_t vocab_bytes, int32_t low
                             uint32_t max_length, cs_tokenizer** out);
 int32_t cs_tokenizer_create_from_file(const char* vocab_path, int32_t lowercase,
                                       uint32_t max_length, cs_tokenizer** out);
+/* tokenizer.json of the `tokenizers` crate — the file fastembed builds its tokenizer from: WordPiece
+ * model.vocab, BertNormalizer.lowercase, truncation.max_length.  max_length 0 = the file's truncation
+ * length, 512 (fastembed's default) when it has none.  Anything that is not the BERT pipeline
+ * cs_tokenizer implements (another model type, prefix, unk token or normalizer) is refused. */
+int32_t cs_tokenizer_create_from_json(const char* tokenizer_json_path, uint32_t max_length,
+                                      cs_tokenizer** out);
+/* A model directory: tokenizer.json when present, else vocab.txt with tokenizer_config.json's
+ * do_lower_case; truncation at min(max_length or 512, tokenizer_config.json's model_max_length). */
+int32_t cs_tokenizer_create_from_dir(const char* model_dir, uint32_t max_length, cs_tokenizer** out);
 void cs_tokenizer_destroy(cs_tokenizer* t);
 uint32_t cs_tokenizer_vocab_size(const cs_tokenizer* t);
+uint32_t cs_tokenizer_max_length(const cs_tokenizer* t);  /* the handle's truncation length */
 int32_t cs_tokenizer_token_to_id(const cs_tokenizer* t, const char* token); /* -1 = absent */
 /* Tokenizer::encode_batch.  Text i is utf8[offsets[i] .. offsets[i+1]) (n+1 offsets).
  * max_length 0 = the handle's.  *out_len = the batch's longest sequence L (<= max_length).

@@ -1,0 +1,114 @@
+"""A minimal ONNX (protobuf wire format) WRITER for tests: just enough of ModelProto / GraphProto / NodeProto /
+TensorProto to lay a BERT state dict out the way exporters do, so cs_bert_params_from_onnx can be exercised at
+any size without the `onnx` package.  Test infrastructure only — the product reads ONNX, it never writes it.
+(The fixture tests/golden/bert_tiny_export.onnx comes from torch's own exporter, not from this file.)"""
+import numpy as np
+
+FLOAT, FLOAT16, BFLOAT16 = 1, 10, 16
+
+
+def _varint(v: int) -> bytes:
+    out = bytearray()
+    while True:
+        b = v & 0x7F
+        v >>= 7
+        out.append(b | (0x80 if v else 0))
+        if not v:
+            return bytes(out)
+
+
+def _key(num: int, wire: int) -> bytes:
+    return _varint((num << 3) | wire)
+
+
+def _ld(num: int, payload: bytes) -> bytes:
+    return _key(num, 2) + _varint(len(payload)) + payload
+
+
+def tensor(name: str, arr: np.ndarray, dtype: int = FLOAT, packed_float_data: bool = False) -> bytes:
+    arr = np.ascontiguousarray(arr, np.float32)
+    body = b"".join(_key(1, 0) + _varint(int(d)) for d in arr.shape)
+    body += _key(2, 0) + _varint(dtype)
+    if dtype == FLOAT:
+        payload = arr.astype("<f4").tobytes()
+    elif dtype == FLOAT16:
+        payload = arr.astype("<f2").tobytes()
+    else:  # bfloat16: the high half of the f32 (round to nearest even)
+        u = arr.view(np.uint32).astype(np.uint64)
+        payload = (((u + 0x7FFF + ((u >> 16) & 1)) >> 16).astype("<u2")).tobytes()
+    body += _ld(8, name.encode())
+    body += _ld(4, payload) if (packed_float_data and dtype == FLOAT) else _ld(9, payload)
+    return body
+
+
+def node(op: str, inputs, outputs, name: str = "", attrs=()) -> bytes:
+    body = b"".join(_ld(1, i.encode()) for i in inputs) + b"".join(_ld(2, o.encode()) for o in outputs)
+    if name:
+        body += _ld(3, name.encode())
+    body += _ld(4, op.encode())
+    for an, iv in attrs:  # integer attributes only
+        body += _ld(5, _ld(1, an.encode()) + _key(3, 0) + _varint(iv) + _key(20, 0) + _varint(2))
+    return body
+
+
+def model(nodes, initializers, producer: str = "tests/onnx_writer.py") -> bytes:
+    graph = b"".join(_ld(1, n) for n in nodes) + _ld(2, b"main_graph") + b"".join(_ld(5, t) for t in initializers)
+    return _key(1, 0) + _varint(8) + _ld(2, producer.encode()) + _ld(7, graph)
+
+
+def bert_onnx(sd: dict, layers: int, style: str = "matmul", dtype: int = FLOAT, prefix: str = "") -> bytes:
+    """sd: HF BertModel state dict (numpy).  style:
+       "matmul" — the torch.onnx / optimum shape: biases and other directly-consumed parameters keep their names,
+                  Linear weights are transposed anonymous `onnx::MatMul_N` initialisers feeding MatMul -> Add(bias);
+       "gemm"   — Gemm(x, W [out, in], bias, transB = 1) with the weight's own name;
+       "fused"  — ORT-optimised: one com.microsoft Attention node per layer with a packed [H, 3H] weight and [3H] bias."""
+    inits, nodes, counter = [], [], [1000]
+
+    def keep(name):
+        inits.append(tensor(prefix + name, sd[name], dtype))
+
+    def linear(base, x):
+        w, b = sd[base + ".weight"], base + ".bias"
+        keep(b)
+        y = "/" + base + "/out"
+        if style == "gemm":
+            keep(base + ".weight")
+            nodes.append(node("Gemm", [x, prefix + base + ".weight", prefix + b], [y], attrs=[("transB", 1)]))
+        else:
+            counter[0] += 1
+            anon = f"onnx::MatMul_{counter[0]}"
+            inits.append(tensor(anon, w.T, dtype, packed_float_data=(counter[0] % 2 == 0)))
+            mm = "/" + base + "/MatMul_output_0"
+            nodes.append(node("MatMul", [x, anon], [mm]))
+            nodes.append(node("Add", [prefix + b, mm] if counter[0] % 3 else [mm, prefix + b], [y]))
+        return y
+
+    for n in ("embeddings.word_embeddings.weight", "embeddings.position_embeddings.weight",
+              "embeddings.token_type_embeddings.weight", "embeddings.LayerNorm.weight", "embeddings.LayerNorm.bias"):
+        keep(n)
+    nodes.append(node("Gather", [prefix + "embeddings.word_embeddings.weight", "input_ids"], ["/emb"]))
+    x = "/emb"
+    for l in range(layers):
+        p = f"encoder.layer.{l}."
+        if style == "fused":
+            wq, wk, wv = (sd[p + f"attention.self.{n}.weight"] for n in ("query", "key", "value"))
+            bq, bk, bv = (sd[p + f"attention.self.{n}.bias"] for n in ("query", "key", "value"))
+            inits.append(tensor(f"Attention_{l}_qkv_weight", np.concatenate([wq.T, wk.T, wv.T], axis=1), dtype))
+            inits.append(tensor(f"Attention_{l}_qkv_bias", np.concatenate([bq, bk, bv]), dtype))
+            nodes.append(node("Attention", [x, f"Attention_{l}_qkv_weight", f"Attention_{l}_qkv_bias", "mask_index"],
+                              [f"/att{l}"], attrs=[("num_heads", 12)]))
+            ctx = f"/att{l}"
+        else:
+            q = linear(p + "attention.self.query", x)
+            k = linear(p + "attention.self.key", x)
+            v = linear(p + "attention.self.value", x)
+            nodes.append(node("Softmax", [q, k, v], [f"/ctx{l}"]))
+            ctx = f"/ctx{l}"
+        x = linear(p + "attention.output.dense", ctx)
+        keep(p + "attention.output.LayerNorm.weight")
+        keep(p + "attention.output.LayerNorm.bias")
+        x = linear(p + "intermediate.dense", x)
+        x = linear(p + "output.dense", x)
+        keep(p + "output.LayerNorm.weight")
+        keep(p + "output.LayerNorm.bias")
+    return model(nodes, inits)

@@ -311,6 +311,62 @@ def test_embedder_from_hf_snapshot_directory(FE, oracle, tmp_path):
     emb.close()
 
 
+def test_embedder_from_fastembed_cache_layout(FE, oracle, tmp_path):
+    """What `with_cache_dir` (embedder.rs:218-245) really finds in fastembed's cache: config.json, the ONNX
+    export under onnx/model.onnx (exporter layout: anonymous transposed MatMul weights) and tokenizer.json as
+    the `tokenizers` library serialises it.  FastEmbedder.from_dir on that directory must embed texts
+    bit-identically to the safetensors + vocab.txt snapshot of the same model, and agree with the oracle."""
+    import json
+
+    pytest.importorskip("tokenizers")
+    from safetensors.numpy import save_file
+    from tokenizers import Tokenizer, models, normalizers, pre_tokenizers, processors
+
+    from codesearch_amd import FastEmbedder
+    from codesearch_amd.bert_params import to_state_dict
+    from codesearch_amd.pipeline import synth_code_texts, synth_vocab
+    from tests import onnx_writer
+
+    vocab = synth_vocab(1024)
+    cfg = BertConfig(vocab_size=1024, layers=2, max_position=64, pooling=POOL_MEAN)
+    flat = synth_params(cfg, 79)
+    sd = to_state_dict(cfg, flat)
+    config = {"model_type": "bert", "vocab_size": 1024, "hidden_size": 384, "num_hidden_layers": 2,
+              "num_attention_heads": 12, "intermediate_size": 1536, "max_position_embeddings": 64,
+              "type_vocab_size": 2, "layer_norm_eps": 1e-12, "hidden_act": "gelu"}
+    cache = tmp_path / "models--Xenova--bge-small-en-v1.5" / "snapshots" / "abc"
+    (cache / "onnx").mkdir(parents=True)
+    (cache / "config.json").write_text(json.dumps(config))
+    (cache / "onnx" / "model.onnx").write_bytes(onnx_writer.bert_onnx(sd, cfg.layers, "matmul"))
+    tk = Tokenizer(models.WordPiece(vocab, unk_token="[UNK]", max_input_chars_per_word=100))
+    tk.normalizer = normalizers.BertNormalizer(clean_text=True, handle_chinese_chars=True, strip_accents=None, lowercase=True)
+    tk.pre_tokenizer = pre_tokenizers.BertPreTokenizer()
+    tk.post_processor = processors.TemplateProcessing(single="[CLS] $A [SEP]", pair="[CLS] $A [SEP] $B:1 [SEP]:1",
+                                                      special_tokens=[("[CLS]", vocab["[CLS]"]), ("[SEP]", vocab["[SEP]"])])
+    tk.add_special_tokens(["[PAD]", "[UNK]", "[CLS]", "[SEP]", "[MASK]"])
+    tk.save(str(cache / "tokenizer.json"))
+    tk.enable_truncation(max_length=64)  # for the comparison below; the saved file carries no truncation
+    (cache / "tokenizer_config.json").write_text(json.dumps({"do_lower_case": True, "model_max_length": 512}))
+    snap = tmp_path / "snapshot"
+    snap.mkdir()
+    (snap / "config.json").write_text(json.dumps(config))
+    save_file({k: np.ascontiguousarray(v) for k, v in sd.items()}, str(snap / "model.safetensors"))
+    (snap / "vocab.txt").write_text("\n".join(sorted(vocab, key=vocab.get)) + "\n")
+
+    a = FastEmbedder.from_dir(str(cache), pooling=POOL_MEAN)
+    b = FastEmbedder.from_dir(str(snap), pooling=POOL_MEAN)
+    assert a.tokenizer.max_length == 64 == b.tokenizer.max_length  # min(512, model_max_length, max_position)
+    texts = synth_code_texts(vocab, 11, 4, mean_words=25) + ["fn main() { [SEP] }"]
+    ga, gb = np.stack(a.embed_batch(texts)), np.stack(b.embed_batch(texts))
+    assert np.array_equal(ga, gb)
+    ids, mask = a.tokenizer.encode_batch(texts)
+    for t, row, m in zip(texts, ids, mask):
+        assert row[: int(m.sum())].tolist() == tk.encode(t).ids
+    exp = oracle.bert_forward(cfg, flat, ids, mask)["pooled"]
+    np.testing.assert_allclose(ga, exp, atol=TOL_ORACLE)
+    a.close(); b.close()
+
+
 def test_multi_minibatch_id_calls_group_by_length(FE, oracle):
     """cs_embedder_embed_ids over several mini-batches: rows are grouped by mask length inside a window and
     each mini-batch is cut to its longest member; row i of the result is still sequence i, equal (to f32
