@@ -68,6 +68,8 @@ SIGNATURES = {
     "cs_index_device": (C.c_int32, [vp]),
     "cs_index_search": (C.c_int32, [vp, f32p, C.c_uint32, C.c_uint32, C.c_uint32, f32p, u32p, u32p]),
     "cs_index_search_device": (C.c_int32, [vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, vp, vp, vp]),
+    "cs_index_search_variants": (C.c_int32, [vp, f32p, C.c_uint32, C.c_uint32, C.c_uint32, f32p, u32p, u32p, i32p]),
+    "cs_merge_variants_device": (C.c_int32, [C.c_int32, vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, vp, vp, vp, vp]),
     "cs_index_search_status": (C.c_int32, [vp, vp, u32p]),
     "cs_merge_topk_device": (C.c_int32, [C.c_int32, vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, vp, vp, vp]),
     "cs_shards_create": (C.c_int32, [C.c_uint32, C.c_uint32, i32p, C.c_uint64, C.c_uint64, C.POINTER(vp)]),

@@ -49,6 +49,7 @@ struct Workspace {
     // unpacks cosine / id / count from the keys — three more small D2H copies cost ~8 us apiece)
     float* h_queries = nullptr; size_t h_q_cap = 0;
     uint64_t* h_keys = nullptr; size_t h_out_cap = 0;
+    uint32_t* h_variant_meta = nullptr;  // pinned: [0] count, [1] high-confidence flag (cs_index_search_variants)
     std::vector<EventTriple> free_events;
     BatchedState bs;
     size_t bs_nq = 0, bs_cand = 0, bs_carry = 0;
@@ -192,6 +193,7 @@ struct Workspace {
         if (h_keys) (void)hipHostFree(h_keys);
         if (h_queries) (void)hipHostFree(h_queries);
         if (h_overflow) (void)hipHostFree(h_overflow);
+        if (h_variant_meta) (void)hipHostFree(h_variant_meta);
         if (bs.d_cand) (void)hipFree(bs.d_cand);
         if (bs.d_cnt) (void)hipFree(bs.d_cnt);
         if (bs.d_tau) (void)hipFree(bs.d_tau);
@@ -754,6 +756,53 @@ int32_t cs_index_search_device(cs_index* h, const float* d_queries, uint32_t nq,
     CS_TRY(w->reserve(plan, nq, h->dim, k, false));
     return run_search(h, w, plan, d_queries, nq, k, d_out_keys, d_out_cos, d_out_ids, d_out_counts,
                       (hipStream_t)stream, nullptr, /*may_sync=*/false);
+}
+
+int32_t cs_index_search_variants(cs_index* h, const float* queries, uint32_t nq, uint32_t dim, uint32_t k,
+                                 float* out_cos, uint32_t* out_ids, uint32_t* out_count,
+                                 int32_t* out_high_confidence) {
+    CS_TRY(check_search(h, nq, dim, k));
+    if (nq > CS_MAX_VARIANTS)
+        return fail(CS_ERR_BAD_ARG, "at most %u query variants per call, got %u", CS_MAX_VARIANTS, nq);
+    if (!queries || !out_cos || !out_ids || !out_count) return fail(CS_ERR_BAD_ARG, "null buffer");
+    DeviceGuard g(h->device);
+    const ScanPlan plan = plan_scan(h->n_rows, h->dim, nq, k, h->num_cus);
+    Workspace* w = acquire_pooled(h);
+    if (!w) return fail(CS_ERR_HIP, "could not create a HIP stream");
+    int32_t s = w->reserve(plan, nq, h->dim, k, true);
+    if (s == CS_OK) {
+        s = [&]() -> int32_t {
+            if (!w->h_variant_meta) CS_HIP(hipHostMalloc(&w->h_variant_meta, 2 * sizeof(uint32_t)));
+            memcpy(w->h_queries, queries, (size_t)nq * h->dim * sizeof(float));
+            // per-variant lists stay in HBM (exact without a host round trip: <= 16 queries carry the gated rerun),
+            // the merge kernel writes the <= k survivors and the two scalars straight into pinned host memory
+            CS_TRY(run_search(h, w, plan, w->d_queries, nq, k, w->d_keys, nullptr, nullptr, nullptr, w->stream,
+                              w->h_queries, /*may_sync=*/false));
+            CS_TRY(launch_merge_variants(w->d_keys, nq, k, k, w->h_keys, nullptr, nullptr, w->h_variant_meta,
+                                         w->h_variant_meta + 1, w->stream));
+            CS_HIP(hipStreamSynchronize(w->stream));
+            for (uint32_t j = 0; j < k; ++j) {
+                const uint64_t key = w->h_keys[j];
+                out_cos[j] = key ? key_cos(key) : 0.0f;
+                out_ids[j] = key ? key_id(key) : 0xFFFFFFFFu;
+            }
+            *out_count = w->h_variant_meta[0];
+            if (out_high_confidence) *out_high_confidence = (int32_t)w->h_variant_meta[1];
+            return CS_OK;
+        }();
+    }
+    release_pooled(h, w);
+    return s;
+}
+
+int32_t cs_merge_variants_device(int32_t device, const uint64_t* d_keys, uint32_t nv, uint32_t k, uint32_t limit,
+                                 uint64_t* d_out_keys, float* d_out_cos, uint32_t* d_out_ids, uint32_t* d_out_count,
+                                 uint32_t* d_out_high_confidence, void* stream) {
+    if (!d_keys || nv == 0 || nv > CS_MAX_VARIANTS || k == 0 || k > CS_MAX_K || limit == 0 || limit > CS_MAX_K)
+        return fail(CS_ERR_BAD_ARG, "bad variant-merge arguments");
+    DeviceGuard g(device);
+    return launch_merge_variants(d_keys, nv, k, limit, d_out_keys, d_out_cos, d_out_ids, d_out_count,
+                                 d_out_high_confidence, (hipStream_t)stream);
 }
 
 int32_t cs_index_search_status(cs_index* h, void* stream, uint32_t* overflowed) {

@@ -412,6 +412,83 @@ merge_topk_kernel(const uint64_t* __restrict__ in, uint32_t nlists, uint32_t k, 
     if (final_pass && out_counts && tid == 0) out_counts[q] = live;
 }
 
+// ---- variant merge --------------------------------------------------------
+// The step right after the per-variant searches in search::search (/root/reference/src/search/mod.rs:513-611):
+// the <= 9 query variants' result lists are unioned, a chunk id found by several variants keeps its best score
+// (mod.rs:547-566), the best `limit` survive, sorted best-first (mod.rs:570-590), and the search skips its
+// text-search leg when the top five all have distance < 0.15 (mod.rs:595-611).  One block: keys [nv][k] ->
+// sort by (id, cosine) to find duplicates -> zero all but the best key of every id -> sort by key -> top
+// `limit`.  Scores are monotone in the cosine, so "best score" = largest key; equal scores fall back to
+// (cosine desc, id asc) where the reference's HashMap order is unspecified.
+__global__ void __launch_bounds__(kMergeBlock)
+merge_variants_kernel(const uint64_t* __restrict__ keys, uint32_t nkeys, uint32_t nsort, uint32_t limit,
+                      uint64_t* __restrict__ out_keys, float* __restrict__ out_cos, uint32_t* __restrict__ out_ids,
+                      uint32_t* __restrict__ out_count, uint32_t* __restrict__ out_high_confidence,
+                      float max_distance, uint32_t top_n) {
+    extern __shared__ __attribute__((aligned(16))) uint64_t va[];  // [nsort]
+    __shared__ uint32_t live, confident;
+    const int tid = threadIdx.x;
+    // (id, order-preserving cosine image): equal ids become neighbours, the best cosine of an id first
+    for (uint32_t i = tid; i < nsort; i += kMergeBlock) {
+        const uint64_t key = i < nkeys ? keys[i] : 0ull;
+        va[i] = key ? (((uint64_t)key_id(key) << 32) | (key >> 32)) : 0ull;
+    }
+    if (tid == 0) { live = 0; confident = 0; }
+    block_bitonic_desc<kMergeBlock>(va, nsort, tid);
+    constexpr int PER = kMergeCap * 4 / kMergeBlock;  // up to 16384 keys: 16 per thread
+    uint64_t mine[PER];
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        const uint32_t i = tid + j * kMergeBlock;
+        uint64_t v = i < nsort ? va[i] : 0ull;
+        if (v && i > 0 && (va[i - 1] >> 32) == (v >> 32)) v = 0ull;  // same id, better or equal cosine just before
+        mine[j] = v ? ((v << 32) | (uint64_t)(~(uint32_t)(v >> 32))) : 0ull;  // back to (cosine image, ~id)
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        const uint32_t i = tid + j * kMergeBlock;
+        if (i < nsort) va[i] = mine[j];
+    }
+    block_bitonic_desc<kMergeBlock>(va, nsort, tid);
+    for (uint32_t i = tid; i < limit; i += kMergeBlock) {
+        const uint64_t key = i < nsort ? va[i] : 0ull;
+        if (key) atomicAdd(&live, 1u);
+        if (out_keys) out_keys[i] = key;
+        if (out_cos) out_cos[i] = key ? key_cos(key) : 0.0f;
+        if (out_ids) out_ids[i] = key ? key_id(key) : 0xffffffffu;
+        // mod.rs:601-611 on the reference's own scale: distance = (1 - cos) / 2 (cs_cos_to_distance)
+        if (key && i < top_n && (1.0f - key_cos(key)) * 0.5f < max_distance) atomicAdd(&confident, 1u);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        if (out_count) *out_count = live;
+        const uint32_t want = live < top_n ? live : top_n;
+        if (out_high_confidence) *out_high_confidence = (live > 0 && confident == want) ? 1u : 0u;
+    }
+}
+
+int32_t launch_merge_variants(const uint64_t* d_keys, uint32_t nv, uint32_t k, uint32_t limit, uint64_t* d_out_keys,
+                              float* d_out_cos, uint32_t* d_out_ids, uint32_t* d_out_count,
+                              uint32_t* d_out_high_confidence, hipStream_t stream) {
+    const uint32_t nkeys = nv * k;
+    if (nkeys == 0 || nkeys > (uint32_t)kMergeCap * 4)
+        return fail(CS_ERR_BAD_ARG, "variant merge takes 1..%d keys, got %u", kMergeCap * 4, nkeys);
+    uint32_t nsort = 64;
+    while (nsort < nkeys) nsort <<= 1;
+    const size_t lds = (size_t)nsort * sizeof(uint64_t);
+    static bool attr_set = false;
+    if (!attr_set) {
+        CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(merge_variants_kernel),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, kMergeCap * 4 * sizeof(uint64_t)));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(merge_variants_kernel, dim3(1), dim3(kMergeBlock), lds, stream, d_keys, nkeys, nsort, limit,
+                       d_out_keys, d_out_cos, d_out_ids, d_out_count, d_out_high_confidence, 0.15f, 5u);
+    CS_HIP(hipGetLastError());
+    return CS_OK;
+}
+
 // ---- synthetic corpus, generated in HBM ---------------------------------------------------
 __global__ void synth_fill_kernel(float* __restrict__ out, uint64_t total, uint64_t seed,
                                   uint64_t first_flat) {

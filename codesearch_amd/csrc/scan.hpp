@@ -56,6 +56,12 @@ int32_t merge_topk_device_impl(int32_t device, const uint64_t* d_keys, uint32_t 
                                uint64_t* d_out_keys, float* d_out_cos, uint32_t* d_out_ids, uint32_t* d_out_counts,
                                hipStream_t stream, uint32_t remap_stripe, uint32_t remap_shards);
 
+// Variant merge of search::search (src/search/mod.rs:513-611): keys [nv][k] -> the best `limit` distinct ids
+// (a chunk keeps its best key), best-first, + count + the "top five all within distance 0.15" predicate.
+int32_t launch_merge_variants(const uint64_t* d_keys, uint32_t nv, uint32_t k, uint32_t limit, uint64_t* d_out_keys,
+                              float* d_out_cos, uint32_t* d_out_ids, uint32_t* d_out_count,
+                              uint32_t* d_out_high_confidence, hipStream_t stream);
+
 // corpus[(first_out_row + r) * dim + c] = cs_synth_value(seed, (first_row + r) * dim + c)
 int32_t launch_synth_fill(float* d_rows, uint64_t n, uint32_t dim, uint64_t seed,
                           uint64_t first_row, hipStream_t stream);

@@ -51,6 +51,9 @@ typedef enum cs_status {
 #define CS_MAX_K 1024u
 /* Largest number of queries per search call. */
 #define CS_MAX_QUERIES 4096u
+/* Largest number of query variants cs_index_search_variants merges (the reference expands a query into at
+ * most 9, src/search/mod.rs:263-388). */
+#define CS_MAX_VARIANTS 16u
 
 const char* cs_last_error(void);
 /* ABI version of this header; bumped on any signature change. */
@@ -140,6 +143,22 @@ int32_t cs_index_search_device(cs_index* h, const float* d_queries, uint32_t nq,
                                uint32_t dim, uint32_t k, uint64_t* d_out_keys,
                                float* d_out_cos, uint32_t* d_out_ids,
                                uint32_t* d_out_counts, void* stream);
+
+/* search::search's vector leg in one call — src/search/mod.rs:508-611: every query variant is searched for
+ * its k = retrieval_limit best rows (:508-511), the lists are unioned with a chunk id keeping its best score
+ * (:547-566), the best k distinct ids are returned best-first (:570-590) and *out_high_confidence tells whether
+ * the top five all have distance < 0.15 — the reference then skips its text-search leg (:595-611).  The merge
+ * runs on the device behind the searches (scan.hip merge_variants_kernel): k results and two scalars cross
+ * PCIe instead of nq lists.  out_cos / out_ids: [k]; *out_count <= k valid entries.  nq <= CS_MAX_VARIANTS.
+ * Equal scores are ordered (cosine desc, id asc), where the reference's HashMap order is unspecified. */
+int32_t cs_index_search_variants(cs_index* h, const float* queries, uint32_t nq, uint32_t dim, uint32_t k,
+                                 float* out_cos, uint32_t* out_ids, uint32_t* out_count,
+                                 int32_t* out_high_confidence);
+/* The merge alone, on device buffers: d_keys [nv, k] packed keys as cs_index_search_device (or the shard
+ * merge) leaves them -> the best `limit` distinct ids.  Asynchronous on `stream`; outputs optional. */
+int32_t cs_merge_variants_device(int32_t device, const uint64_t* d_keys, uint32_t nv, uint32_t k, uint32_t limit,
+                                 uint64_t* d_out_keys, float* d_out_cos, uint32_t* d_out_ids,
+                                 uint32_t* d_out_count, uint32_t* d_out_high_confidence, void* stream);
 
 /* Synchronises `stream` and reports in *overflowed whether any cs_index_search_device call of more
  * than 16 queries issued by this thread on it since the previous status call overflowed a candidate buffer
