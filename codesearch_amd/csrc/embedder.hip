@@ -25,6 +25,7 @@ struct cs_embedder {
     uint32_t* d_flag = nullptr;    // split-f16 range flag
     int gemm_mode = CS_GEMM_SPLIT_F16;
     bool split_unavailable = false;  // device flushes f16 subnormals in the MFMA: exact-f32 kernels only
+    bool wide_ok = false;            // every |w| < 31.98: the one-accumulator 128 x 384 kernels may run (gemm_wide.hip)
     uint64_t split_forwards = 0, f32_forwards = 0, range_fallbacks = 0;
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;     // second half of a mini-batch runs here (see forward())
@@ -162,6 +163,15 @@ int32_t forward_range(cs_embedder* h, hipStream_t s, uint32_t b0, uint32_t nb, u
         h->stage_tag.push_back(tag);
         return CS_OK;
     };
+    // dense layer: the persistent 128 x 384 one-accumulator kernel from wide_min_m token rows on (gemm_wide.hip),
+    // else the 128 x 128 / skinny kernels of gemm_split.hip
+    static const uint32_t wide_min_m = [] { const char* e = std::getenv("CS_GEMM_WIDE_MIN_M"); return e ? (uint32_t)std::atoll(e) : 12288u; }();
+    auto dense = [&](int epi, const _Float16* Ain, const _Float16* Wt, const float* bias, const float* resid, float* Cf,
+                     _Float16* Csp, uint32_t Mr, uint32_t Nn, uint32_t Kk) -> int32_t {
+        if (h->wide_ok && wide_min_m && Mr >= wide_min_m && gemm_wide_supported(Nn, Kk))
+            return launch_gemm_wide(epi, Ain, Wt, bias, resid, Cf, Csp, Mr, Nn, Kk, h->d_flag, s);
+        return launch_gemm_split(epi, Ain, Wt, bias, resid, Cf, Csp, Mr, Nn, Kk, h->d_flag, s);
+    };
     CS_TRY(mark(-1));
     CS_TRY(launch_row_kernel(0, a, H, s));  // E1
     CS_TRY(mark(CS_STAGE_EMBED_LN));
@@ -179,7 +189,7 @@ int32_t forward_range(cs_embedder* h, hipStream_t s, uint32_t b0, uint32_t nb, u
                 CS_TRY(mark(CS_STAGE_ATTENTION));
             } else {
                 _Float16* qkvs = reinterpret_cast<_Float16*>(qkv);  // [T][3H/32][64] f16: same bytes as the f32 qkv
-                CS_TRY(launch_gemm_split(SH_OUT_SPLIT, xs, ws + sl.qkv, bqkv, nullptr, nullptr, qkvs, T, 3 * H, H, h->d_flag, s));  // E2
+                CS_TRY(dense(SH_OUT_SPLIT, xs, ws + sl.qkv, bqkv, nullptr, nullptr, qkvs, T, 3 * H, H));  // E2
                 CS_TRY(mark(CS_STAGE_QKV));
                 CS_TRY(launch_attention_sh2(qkvs, mask, ctxs, h->d_flag, nb, L, H, c.heads, s));                                 // E3
                 CS_TRY(mark(CS_STAGE_ATTENTION));
@@ -191,12 +201,12 @@ int32_t forward_range(cs_embedder* h, hipStream_t s, uint32_t b0, uint32_t nb, u
                 a.parts = qkv; a.nparts = 3; a.bias = P + lo.ao_b;
                 CS_TRY(launch_row_kernel(3, a, H, s));
             } else {
-                CS_TRY(launch_gemm_split(SH_OUT_F32_RESID, ctxs, ws + sl.ao, P + lo.ao_b, x, x, nullptr, T, H, H, h->d_flag, s));  // E4
+                CS_TRY(dense(SH_OUT_F32_RESID, ctxs, ws + sl.ao, P + lo.ao_b, x, x, nullptr, T, H, H));  // E4
                 CS_TRY(mark(CS_STAGE_OUT_PROJ));
                 CS_TRY(launch_row_kernel(1, a, H, s));
             }
             CS_TRY(mark(CS_STAGE_LN_ATTN));
-            CS_TRY(launch_gemm_split(SH_OUT_SPLIT_GELU, xs, ws + sl.up, P + lo.up_b, nullptr, nullptr, mids, T, I, H, h->d_flag, s));    // E5
+            CS_TRY(dense(SH_OUT_SPLIT_GELU, xs, ws + sl.up, P + lo.up_b, nullptr, nullptr, mids, T, I, H));    // E5
             CS_TRY(mark(CS_STAGE_FFN_UP));
             a.g = P + lo.out_ln_g; a.b = P + lo.out_ln_b;
             if (T > split_k_min && T <= split_k_max2) {
@@ -209,7 +219,7 @@ int32_t forward_range(cs_embedder* h, hipStream_t s, uint32_t b0, uint32_t nb, u
                 a.parts = qkv; a.nparts = ks; a.bias = P + lo.down_b;
                 CS_TRY(launch_row_kernel(3, a, H, s));
             } else {
-                CS_TRY(launch_gemm_split(SH_OUT_F32_RESID, mids, ws + sl.down, P + lo.down_b, x, x, nullptr, T, H, I, h->d_flag, s)); // E6
+                CS_TRY(dense(SH_OUT_F32_RESID, mids, ws + sl.down, P + lo.down_b, x, x, nullptr, T, H, I)); // E6
                 CS_TRY(mark(CS_STAGE_FFN_DOWN));
                 CS_TRY(launch_row_kernel(1, a, H, s));
             }
@@ -605,6 +615,12 @@ int32_t cs_embedder_create(const cs_bert_config* cfg, const float* params, uint6
         if (const char* env = std::getenv("CS_ENCODER_GEMM"))
             h->gemm_mode = (std::strcmp(env, "f32") == 0) ? CS_GEMM_F32 : CS_GEMM_SPLIT_F16;
         if (wflag) h->gemm_mode = CS_GEMM_F32;  // a weight outside the f16 range: exact path only
+        if (s == CS_OK && !wflag) {  // may the one-accumulator kernels scale w_hi by 2^11 in f16?
+            bool fit = false;
+            s = sh_weights_fit_wide(h->d_wsplit, (uint64_t)cfg->layers * sl.total, h->d_flag, &fit, h->stream);
+            const char* e = std::getenv("CS_GEMM_WIDE");  // "0": never
+            h->wide_ok = fit && !(e && e[0] == '0');
+        }
         bool denorm_ok = false;  // the split format relies on exact f16-subnormal MFMA inputs
         if (s == CS_OK) s = sh_denorm_selftest(&denorm_ok, h->stream);
         if (s == CS_OK && !denorm_ok) { h->gemm_mode = CS_GEMM_F32; h->split_unavailable = true; }
@@ -734,8 +750,11 @@ int32_t cs_debug_gemm(int32_t device, int32_t mode, int32_t epilogue, const floa
                       const float* bias, const float* resid, float* C, uint32_t M, uint32_t N, uint32_t K,
                       uint32_t* range_flag) {
     if (!A || !W || !bias || !C || (epilogue == 2 && !resid)) return fail(CS_ERR_BAD_ARG, "null buffer");
+    const bool wide = mode == 2;  // diagnostics only: the 128 x 384 one-accumulator kernel whatever M is
+    if (wide) mode = CS_GEMM_SPLIT_F16;
     if (epilogue < 0 || epilogue > 2 || (mode != CS_GEMM_F32 && mode != CS_GEMM_SPLIT_F16))
         return fail(CS_ERR_BAD_ARG, "unknown epilogue/mode");
+    if (wide && !gemm_wide_supported(N, K)) return fail(CS_ERR_UNSUPPORTED, "wide kernel needs N %% 384 == 0");
     if (M == 0 || N % 128 || K % 32 || K == 0) return fail(CS_ERR_UNSUPPORTED, "cs_debug_gemm needs M > 0, N %% 128 == 0, K %% 32 == 0");
     int ndev = 0;
     CS_HIP(hipGetDeviceCount(&ndev));
@@ -763,11 +782,12 @@ int32_t cs_debug_gemm(int32_t device, int32_t mode, int32_t epilogue, const floa
             CS_HIP(hipMalloc(&sA, a_n * 4)); CS_HIP(hipMalloc(&sW, w_n * 4));
             CS_TRY(launch_split_rows(dA, sA, M, K, dF, nullptr));
             CS_TRY(launch_split_rows(dW, sW, N, K, dF, nullptr));
+            auto run_gemm = wide ? launch_gemm_wide : launch_gemm_split;
             if (epilogue == 1) {  // the GELU epilogue writes split form: read it back through hi + lo / 2048
                 CS_HIP(hipMalloc(&sC, c_n * 4));
-                CS_TRY(launch_gemm_split(SH_OUT_SPLIT_GELU, sA, sW, dB, nullptr, nullptr, sC, M, N, K, dF, nullptr));
+                CS_TRY(run_gemm(SH_OUT_SPLIT_GELU, sA, sW, dB, nullptr, nullptr, sC, M, N, K, dF, nullptr));
             } else {
-                CS_TRY(launch_gemm_split(epilogue == 2 ? SH_OUT_F32_RESID : SH_OUT_F32, sA, sW, dB, dR, dC, nullptr, M, N, K, dF, nullptr));
+                CS_TRY(run_gemm(epilogue == 2 ? SH_OUT_F32_RESID : SH_OUT_F32, sA, sW, dB, dR, dC, nullptr, M, N, K, dF, nullptr));
             }
         }
         CS_HIP(hipDeviceSynchronize());

@@ -60,6 +60,12 @@ int32_t launch_gemm_split_partial(const _Float16* A, const _Float16* W, float* C
 int32_t launch_gemm_split(int epi, const _Float16* A, const _Float16* W, const float* bias, const float* resid,
                           float* C, _Float16* Cs, uint32_t M, uint32_t N, uint32_t K, uint32_t* d_flag,
                           hipStream_t s);
+// gemm_wide.hip: the same product as a persistent kernel over 128 x 384 tiles with one accumulator per output
+// (w_hi scaled by 2^11 in registers).  N % 384 == 0; weights must pass sh_weights_fit_wide (|w| < 31.98).
+bool gemm_wide_supported(uint32_t N, uint32_t K);
+int32_t launch_gemm_wide(int epi, const _Float16* A, const _Float16* W, const float* bias, const float* resid, float* C,
+                         _Float16* Cs, uint32_t M, uint32_t N, uint32_t K, uint32_t* d_flag, hipStream_t s);
+int32_t sh_weights_fit_wide(const _Float16* d_wsplit, uint64_t n_f16, uint32_t* d_scratch_flag, bool* ok, hipStream_t s);
 int32_t launch_synth_params(float* d_out, const cs_bert_config& cfg, uint64_t seed, hipStream_t s);
 
 }  // namespace cs

@@ -1,0 +1,319 @@
+// gemm_wide.hip — the encoder's dense layers at indexing batch sizes:
+// C[M,N] = A[M,K] W[N,K]^T + bias on the f16 MFMA with split-f16 operands (split_f16.hpp), as a PERSISTENT
+// kernel over 128 x 384 output tiles with ONE accumulator per output.
+//
+// Why another GEMM.  The 128 x 128 kernels of gemm_split.hip are bound by operand delivery, not by the matrix
+// pipe (a stage costs ~1100 cycles of the CU's global->LDS address path against 768 cycles of
+// MFMA, and the two add because every wave issues its LDS-DMAs back to back after the k-step barrier).  Two
+// changes remove that bound:
+//   * One accumulator instead of two.  sum a*w = sum a_hi*w_hi + 2^-11 sum (a_hi*w_lo' + a_lo'*w_hi) needed a
+//     second accumulator set only because the two sums carry different scales.  Multiplying the w_hi fragment
+//     by 2^11 IN REGISTERS (exact: a power of two; four v_pk_mul_f16 per fragment) puts all three products on
+//     the scale 2^11, so they accumulate into one f32 tile and C = acc * 2^-11.  Same three MFMAs per product,
+//     same per-product error bound (~3 * 2^-22), half the accumulator registers.  Needs |w_hi| * 2^11 to stay
+//     finite in f16, i.e. |w| < 31.98: checked once per model (sh_weights_fit_wide), else the 128 x 128
+//     kernels run.
+//   * With 64 accumulator registers freed, a block of 8 waves owns 128 x 384 outputs (wave tile 64 x 96 =
+//     4 x 6 MFMA tiles of 16 x 16): a k-step stages 16 KiB of A + 48 KiB of W for 576 MFMAs — 0.83 address-path
+//     cycles per MFMA cycle instead of 1.46 — and every N of a BERT encoder whose hidden size is a multiple of
+//     384 (384, 1152, 1536; 768, 2304, 3072) is a whole number of tiles, N = 384 a single one.
+// The LDS-DMAs of stage k+1 are issued one at a time between the MFMA groups of stage k (eight per wave, all
+// within the first two thirds of the step), so the address path works while the matrix pipe does.  The
+// kernel is persistent (one block per CU): the first stage of a block's NEXT tile is in flight while the current
+// tile's epilogue runs, in the stage buffer the epilogue does not use.
+// LDS: two stages of 64 KiB; the epilogue stages the C tile through one of them in three passes of 128
+// columns so that every global access is 16 B per lane on consecutive lanes.
+#include <cstdlib>
+
+#include "encoder.hpp"
+#include "split_f16.hpp"
+
+namespace cs {
+
+constexpr int GW_BM = 128, GW_BN = 384;
+constexpr int GW_A_BYTES = GW_BM * 128;            // one k-chunk (32 k, hi + lo) of 128 A rows
+constexpr int GW_W_BYTES = GW_BN * 128;            // ... of 384 W rows
+constexpr int GW_STAGE = GW_A_BYTES + GW_W_BYTES;  // 65,536
+constexpr int GW_LDS = 2 * GW_STAGE;               // 131,072
+constexpr int GW_THREADS = 512;
+
+namespace {
+
+__device__ __forceinline__ float gw_erf_fast(float x) {  // gemm_split.hip sh_erf_fast
+    const float t = fminf(fabsf(x), 4.0f);
+    float q = 7.569788067485206e-07f;
+    q = fmaf(q, t, -1.6365151168429293e-05f);
+    q = fmaf(q, t, 0.00015192339196801186f);
+    q = fmaf(q, t, -0.0007679605041630566f);
+    q = fmaf(q, t, 0.002005203627049923f);
+    q = fmaf(q, t, 0.0003252939786761999f);
+    q = fmaf(q, t, -0.028044508770108223f);
+    q = fmaf(q, t, 0.1484302133321762f);
+    q = fmaf(q, t, 0.9184240698814392f);
+    q = fmaf(q, t, 1.6279078722000122f);
+    const float e = 1.0f - __builtin_amdgcn_exp2f(-(q * t));
+    return __builtin_copysignf(e, x);
+}
+__device__ __forceinline__ float gw_gelu(float v) { return 0.5f * v * (1.0f + gw_erf_fast(v * 0.70710678118654752440f)); }
+
+struct GwAcc { sh_f32x4v c[4][6]; };
+
+// this wave's eight LDS-DMA pieces of a stage: p = 0, 1 -> A rows, p = 2..7 -> W rows
+struct GwSrc {
+    const _Float16* a[2];
+    const _Float16* w[6];
+};
+
+}  // namespace
+
+template <int EPI>
+__global__ void __launch_bounds__(GW_THREADS, 2)
+gemm_wide_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ W, const float* __restrict__ bias,
+                 const float* resid, float* C, _Float16* __restrict__ Cs, uint32_t M, uint32_t N, uint32_t kchunks,
+                 uint32_t* __restrict__ flag, uint32_t total_slots) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int l15 = lane & 15, g = lane >> 4;
+    const uint32_t mtiles = (M + GW_BM - 1) / GW_BM, ntiles = N / GW_BN;
+
+    // LDS image of a stage: row r of a tile = one 128-B line, logical 16-B slot c at physical slot c ^ ((r >> 1) & 7)
+    // (split_f16.hpp); the LDS-DMA destination is lane-linear, so the permutation goes into the source address.
+    const int drow = lane >> 3;                  // row of a piece (8 rows x 128 B) this lane fetches
+    auto src_of = [&](const _Float16* base, uint32_t row_in_tile, uint32_t grow) {
+        const int c = (lane & 7) ^ ((row_in_tile >> 1) & 7);
+        return base + (size_t)grow * kchunks * 64 + c * 8;
+    };
+    auto tile_src = [&](uint32_t m0, uint32_t n0, GwSrc& s) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const uint32_t r = (wave * 2 + p) * 8 + drow;
+            s.a[p] = src_of(A, r, (m0 + r < M) ? m0 + r : M - 1);  // rows past M re-read row M-1 (never stored)
+        }
+#pragma unroll
+        for (int p = 0; p < 6; ++p) {
+            const uint32_t r = (wave * 6 + p) * 8 + drow;
+            s.w[p] = src_of(W, r, n0 + r);
+        }
+    };
+    auto dma = [&](const GwSrc& s, int p, uint32_t kc, uint32_t bufoff) {
+        if (p < 2) sh_glds16(s.a[p] + (size_t)kc * 64, lds + bufoff + (wave * 2 + p) * 1024);
+        else sh_glds16(s.w[p - 2] + (size_t)kc * 64, lds + bufoff + GW_A_BYTES + (wave * 6 + (p - 2)) * 1024);
+    };
+
+    const int swz = (l15 >> 1) & 7;
+    const uint32_t a_off = (wr * 64 + l15) * 128, w_off = GW_A_BYTES + (wc * 96 + l15) * 128;
+    const uint32_t s_hi = (g ^ swz) * 16, s_lo = ((4 + g) ^ swz) * 16;
+
+    auto valid = [&](uint32_t slot, uint32_t& mt, uint32_t& nt) { return sh_tile_of_block(slot, mtiles, ntiles, mt, nt); };
+    auto next_valid = [&](uint32_t slot, uint32_t& mt, uint32_t& nt) {
+        while (slot < total_slots && !valid(slot, mt, nt)) slot += gridDim.x;
+        return slot;
+    };
+
+    uint32_t mt = 0, nt = 0;
+    uint32_t slot = next_valid(blockIdx.x, mt, nt);
+    if (slot >= total_slots) return;
+    GwSrc src;
+    tile_src(mt * GW_BM, nt * GW_BN, src);
+    uint32_t buf = 0;  // stage buffer (0 | 1) that holds stage 0 of the current tile
+#pragma unroll
+    for (int p = 0; p < 8; ++p) dma(src, p, sh_kc_rot(nt, ntiles, kchunks), 0);
+
+    while (slot < total_slots) {
+        const uint32_t m0 = mt * GW_BM, n0 = nt * GW_BN;
+        const uint32_t rot = sh_kc_rot(nt, ntiles, kchunks);  // see sh_mainloop: n-tiles of an m-tile walk K out of phase
+        GwAcc acc;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 6; ++j) acc.c[i][j] = sh_f32x4v{0.f, 0.f, 0.f, 0.f};
+        __syncthreads();  // stage 0 has landed (vmcnt(0) precedes the barrier)
+
+        for (uint32_t kc = 0; kc < kchunks; ++kc) {
+            const char* cur = lds + ((buf + kc) & 1) * GW_STAGE;
+            const uint32_t nb = ((buf + kc + 1) & 1) * GW_STAGE;
+            const bool more = kc + 1 < kchunks;
+            uint32_t kn = rot + kc + 1;
+            kn = kn >= kchunks ? kn - kchunks : kn;
+            f16x8 ah[4], al[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                ah[i] = *reinterpret_cast<const f16x8*>(cur + a_off + i * 2048 + s_hi);
+                al[i] = *reinterpret_cast<const f16x8*>(cur + a_off + i * 2048 + s_lo);
+            }
+            f16x8 wh = *reinterpret_cast<const f16x8*>(cur + w_off + s_hi);
+            f16x8 wl = *reinterpret_cast<const f16x8*>(cur + w_off + s_lo);
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                f16x8 whn = wh, wln = wl;
+                if (j < 5) {
+                    whn = *reinterpret_cast<const f16x8*>(cur + w_off + (j + 1) * 2048 + s_hi);
+                    wln = *reinterpret_cast<const f16x8*>(cur + w_off + (j + 1) * 2048 + s_lo);
+                }
+                const f16x8 whs = wh * (_Float16)2048.0f;  // exact: |w_hi| < 32 (sh_weights_fit_wide)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    acc.c[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], whs, acc.c[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (more && j < 4) dma(src, 2 * j, kn, nb);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    acc.c[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], wl, acc.c[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (more && j < 4) dma(src, 2 * j + 1, kn, nb);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    acc.c[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], wh, acc.c[i][j], 0, 0, 0);
+                wh = whn;
+                wl = wln;
+            }
+            __syncthreads();  // stage kc+1 has landed; every wave is done reading stage kc
+        }
+
+        // next tile of this block: its first stage flies into the buffer the epilogue does not use
+        const uint32_t ebuf = (buf + kchunks - 1) & 1;  // buffer of the last stage: free now, stages the C tile
+        uint32_t nmt = 0, nnt = 0;
+        const uint32_t nslot = next_valid(slot + gridDim.x, nmt, nnt);
+        if (nslot < total_slots) {
+            tile_src(nmt * GW_BM, nnt * GW_BN, src);
+#pragma unroll
+            for (int p = 0; p < 8; ++p) dma(src, p, sh_kc_rot(nnt, ntiles, kchunks), (ebuf ^ 1) * GW_STAGE);
+        }
+
+        // ---- epilogue: three passes of 128 columns through the free stage buffer --------------------------------
+        float* ctile = reinterpret_cast<float*>(lds + ebuf * GW_STAGE);  // [128 m][128 n] f32, 16-col blocks XOR-swizzled by (m >> 2) & 3
+        const bool full = m0 + GW_BM <= M;
+        bool ovf = false;
+#pragma unroll 1
+        for (int p = 0; p < 3; ++p) {
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                const int col = wc * 96 + 16 * j;
+                if ((col >> 7) == p) {  // wave-uniform
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int m = wr * 64 + 16 * i + 4 * g + r;  // (m >> 2) & 3 == g
+                            ctile[m * 128 + (((col & 127) + l15) ^ (g << 4))] = acc.c[i][j][r] * kShLoInv;
+                        }
+                }
+            }
+            __syncthreads();
+            const uint32_t nbase = n0 + 128 * p;
+            if (EPI == SH_OUT_SPLIT || EPI == SH_OUT_SPLIT_GELU) {
+                const int c8 = tid & 15;  // 8 consecutive n per thread
+                const sh_f32x4 b0 = *reinterpret_cast<const sh_f32x4*>(bias + nbase + c8 * 8);
+                const sh_f32x4 b1 = *reinterpret_cast<const sh_f32x4*>(bias + nbase + c8 * 8 + 4);
+                const size_t nchunks = N / 32;
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    const int row = (tid >> 4) + 32 * it;
+                    const int pc = (c8 * 8) ^ (((row >> 2) & 3) << 4);
+                    const sh_f32x4 v0 = *reinterpret_cast<const sh_f32x4*>(ctile + row * 128 + pc);
+                    const sh_f32x4 v1 = *reinterpret_cast<const sh_f32x4*>(ctile + row * 128 + pc + 4);
+                    f16x8 hi, lo;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        _Float16 a, b;
+                        ovf |= sh_split(EPI == SH_OUT_SPLIT_GELU ? gw_gelu(v0[e] + b0[e]) : v0[e] + b0[e], a, b);
+                        hi[e] = a; lo[e] = b;
+                        ovf |= sh_split(EPI == SH_OUT_SPLIT_GELU ? gw_gelu(v1[e] + b1[e]) : v1[e] + b1[e], a, b);
+                        hi[4 + e] = a; lo[4 + e] = b;
+                    }
+                    if (full || m0 + row < M) {
+                        _Float16* dst = Cs + ((size_t)(m0 + row) * nchunks + (nbase >> 5) + (c8 >> 2)) * 64 + (c8 & 3) * 8;
+                        __builtin_nontemporal_store(hi, reinterpret_cast<f16x8*>(dst));
+                        __builtin_nontemporal_store(lo, reinterpret_cast<f16x8*>(dst + 32));
+                    }
+                }
+            } else {
+                const int c4 = tid & 31;  // 4 consecutive n per thread
+                const sh_f32x4 bv = *reinterpret_cast<const sh_f32x4*>(bias + nbase + c4 * 4);
+#pragma unroll
+                for (int it = 0; it < 8; ++it) {
+                    const int row = (tid >> 5) + 16 * it;
+                    const int pc = (c4 * 4) ^ (((row >> 2) & 3) << 4);
+                    sh_f32x4 v = *reinterpret_cast<const sh_f32x4*>(ctile + row * 128 + pc);
+                    v += bv;
+                    if (full || m0 + row < M) {
+                        const size_t o = (size_t)(m0 + row) * N + nbase + c4 * 4;
+                        if (EPI == SH_OUT_F32_RESID) v += *reinterpret_cast<const sh_f32x4*>(resid + o);
+                        *reinterpret_cast<sh_f32x4*>(C + o) = v;
+                    }
+                }
+            }
+            __syncthreads();  // the pass has been read: the buffer takes the next one (or the next tile's stages)
+        }
+        if (ovf && flag) atomicOr(flag, 1u);
+        buf = ebuf ^ 1;
+        slot = nslot;
+        mt = nmt;
+        nt = nnt;
+    }
+}
+
+// true when every w_hi of a split weight matrix times 2^11 stays finite in f16 (|w_hi| <= 31.98)
+__global__ void __launch_bounds__(256)
+gw_weight_range_kernel(const _Float16* __restrict__ w, uint64_t nlines, uint32_t* __restrict__ bad) {
+    bool b = false;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nlines * 4; i += (uint64_t)gridDim.x * blockDim.x) {
+        const f16x8 hi = *reinterpret_cast<const f16x8*>(w + (i >> 2) * 64 + (i & 3) * 8);  // the 32 hi values of a line
+#pragma unroll
+        for (int e = 0; e < 8; ++e) b |= !(fabsf((float)hi[e]) <= 31.98f);
+    }
+    if (b) atomicOr(bad, 1u);
+}
+
+int32_t sh_weights_fit_wide(const _Float16* d_wsplit, uint64_t n_f16, uint32_t* d_scratch_flag, bool* ok, hipStream_t s) {
+    CS_HIP(hipMemsetAsync(d_scratch_flag, 0, sizeof(uint32_t), s));
+    const uint64_t nlines = n_f16 / 64;
+    hipLaunchKernelGGL(gw_weight_range_kernel, dim3(1024), dim3(256), 0, s, d_wsplit, nlines, d_scratch_flag);
+    CS_HIP(hipGetLastError());
+    uint32_t v = 1;
+    CS_HIP(hipMemcpyAsync(&v, d_scratch_flag, sizeof v, hipMemcpyDeviceToHost, s));
+    CS_HIP(hipStreamSynchronize(s));
+    CS_HIP(hipMemsetAsync(d_scratch_flag, 0, sizeof(uint32_t), s));
+    *ok = v == 0;
+    return CS_OK;
+}
+
+bool gemm_wide_supported(uint32_t N, uint32_t K) { return N % GW_BN == 0 && K % 32 == 0 && N > 0 && K > 0; }
+
+int32_t launch_gemm_wide(int epi, const _Float16* A, const _Float16* W, const float* bias, const float* resid, float* C,
+                         _Float16* Cs, uint32_t M, uint32_t N, uint32_t K, uint32_t* d_flag, hipStream_t s) {
+    if (!gemm_wide_supported(N, K)) return fail(CS_ERR_UNSUPPORTED, "wide split GEMM needs N %% 384 == 0 and K %% 32 == 0 (N=%u K=%u)", N, K);
+    if (M == 0) return CS_OK;
+    static bool attr_set = false;
+    static int cus = 256;
+    if (!attr_set) {
+        CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wide_kernel<SH_OUT_F32>), hipFuncAttributeMaxDynamicSharedMemorySize, GW_LDS));
+        CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wide_kernel<SH_OUT_F32_RESID>), hipFuncAttributeMaxDynamicSharedMemorySize, GW_LDS));
+        CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wide_kernel<SH_OUT_SPLIT_GELU>), hipFuncAttributeMaxDynamicSharedMemorySize, GW_LDS));
+        CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wide_kernel<SH_OUT_SPLIT>), hipFuncAttributeMaxDynamicSharedMemorySize, GW_LDS));
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) == hipSuccess &&
+            hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n >= 8)
+            cus = n / 8 * 8;  // whole XCD octets: slot -> XCD mapping survives the persistent stride
+        attr_set = true;
+    }
+    const uint32_t mtiles = (M + GW_BM - 1) / GW_BM, ntiles = N / GW_BN;
+    const uint32_t slots = sh_grid_blocks(mtiles, ntiles);
+    const uint32_t grid = slots < (uint32_t)cus ? slots : (uint32_t)cus;
+    const uint32_t kc = K / 32;
+#define GW_LAUNCH(E) hipLaunchKernelGGL(gemm_wide_kernel<E>, dim3(grid), dim3(GW_THREADS), GW_LDS, s, A, W, bias, resid, C, Cs, M, N, kc, d_flag, slots)
+    if (epi == SH_OUT_F32) GW_LAUNCH(SH_OUT_F32);
+    else if (epi == SH_OUT_F32_RESID) GW_LAUNCH(SH_OUT_F32_RESID);
+    else if (epi == SH_OUT_SPLIT) GW_LAUNCH(SH_OUT_SPLIT);
+    else if (epi == SH_OUT_SPLIT_GELU) GW_LAUNCH(SH_OUT_SPLIT_GELU);
+    else return fail(CS_ERR_BAD_ARG, "unknown epilogue %d", epi);
+#undef GW_LAUNCH
+    CS_HIP(hipGetLastError());
+    return CS_OK;
+}
+
+}  // namespace cs

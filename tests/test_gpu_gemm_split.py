@@ -12,7 +12,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-F32, SPLIT = 0, 1
+F32, SPLIT, WIDE = 0, 1, 2  # WIDE: split-f16 on the persistent 128 x 384 one-accumulator kernel (gemm_wide.hip)
 
 
 def run_gemm(lib, mode, epi, A, W, bias, resid=None):
@@ -59,6 +59,52 @@ def test_split_gemm_matches_float64_like_f32_does(gpu_lib, M, N, K, epi):
     assert err_s.max() < 6e-7, (err_s.max(), err_f.max())
     # and the two kernels agree with each other far inside the 1e-4 bar on the embeddings
     assert np.abs(got_s - got_f).max() < 2e-5 * max(1.0, np.abs(ref).max())
+
+
+@pytest.mark.parametrize("M,N,K", [(1, 384, 32), (130, 384, 64), (128, 384, 384), (257, 1536, 384), (1000, 384, 1536),
+                                   (4096 + 77, 1152, 384),
+                                   (128 * 300 + 5, 384, 96),     # 301 tiles over <= 256 persistent blocks
+                                   (128 * 70, 1536, 384)])       # 280 tiles, four n-tiles per m-tile
+@pytest.mark.parametrize("epi", [0, 1, 2])
+def test_wide_gemm_matches_float64_and_the_two_accumulator_kernels(gpu_lib, M, N, K, epi):
+    """gemm_wide.hip: one accumulator (w_hi scaled by 2^11 in registers), 128 x 384 tiles, persistent blocks,
+    next tile's first stage prefetched under the epilogue — same bar as the 128 x 128 split kernels."""
+    rng = np.random.default_rng(M * 11 + N * 5 + K + epi)
+    A = rng.standard_normal((M, K)).astype(np.float32)
+    W = (rng.standard_normal((N, K)) * 0.05).astype(np.float32)
+    bias = (rng.standard_normal(N) * 0.1).astype(np.float32)
+    resid = rng.standard_normal((M, N)).astype(np.float32) if epi == 2 else None
+    got_w, flag = run_gemm(gpu_lib, WIDE, epi, A, W, bias, resid)
+    got_s, _ = run_gemm(gpu_lib, SPLIT, epi, A, W, bias, resid)
+    assert flag == 0
+    if M * N * K <= 4096 * 1536 * 384:  # float64 reference where numpy finishes in seconds
+        ref = reference(epi, A, W, bias, resid)
+        scale = np.abs(A).astype(np.float64) @ np.abs(W).astype(np.float64).T + 1.0
+        err = np.abs(got_w - ref) / scale
+        assert err.max() < 6e-7, err.max()
+    assert np.abs(got_w - got_s).max() < 2e-5 * max(1.0, np.abs(got_s).max())
+    rows = rng.integers(0, M, 64)  # sampled rows against float64 at every size
+    ref_rows = reference(epi, A[rows], W, bias, None if resid is None else resid[rows])
+    sc = np.abs(A[rows]).astype(np.float64) @ np.abs(W).astype(np.float64).T + 1.0
+    assert (np.abs(got_w[rows] - ref_rows) / sc).max() < 6e-7
+
+
+def test_wide_gemm_exact_and_range(gpu_lib):
+    """Integer data exact through the scaled accumulator; |w| up to 31 still inside the f16 range after the
+    2^11 scaling; the activation range flag still raised by the epilogue's split."""
+    rng = np.random.default_rng(6)
+    M, N, K = 200, 384, 96
+    A = rng.integers(-4, 5, (M, K)).astype(np.float32)
+    W = rng.integers(-3, 4, (N, K)).astype(np.float32)
+    W[:, 0] += np.arange(N, dtype=np.float32) % 7
+    W[5, 7] = 31.0
+    bias = np.arange(N, dtype=np.float32)
+    ref = (A.astype(np.int64) @ W.astype(np.int64).T + bias.astype(np.int64)).astype(np.float32)
+    got, flag = run_gemm(gpu_lib, WIDE, 0, A, W, bias)
+    assert flag == 0 and np.array_equal(got, ref)
+    bias[3] = 9.0e4  # GELU(x + 9e4) leaves the f16 range: the split-form epilogue must say so
+    _, flag = run_gemm(gpu_lib, WIDE, 1, A, W, bias)
+    assert flag == 1
 
 
 def test_split_gemm_exact_on_f16_representable_data(gpu_lib):
