@@ -18,6 +18,7 @@ def main():
     ap.add_argument("--seq", type=int, default=256)
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--ragged", action="store_true")
+    ap.add_argument("--stages", action="store_true", help="also print per-kernel-class microseconds per layer (one stream)")
     ap.add_argument("--model", default="bge-small", help="registry short name: bge-small, bge-base, bge-large, minilm-l6, ...")
     args = ap.parse_args()
     import numpy as np
@@ -39,6 +40,19 @@ def main():
     wall = (time.perf_counter() - t0) / args.iters
     ms, n = emb.profile_read()
     ms /= max(args.iters, 1)  # device time per BATCH (the reference's mini-batch policy cuts 768-d models at 128, 1024-d at 64)
+    stages = None
+    if args.stages:
+        emb.profile_stages(True)
+        emb.embed_ids(ids, mask)
+        emb.profile_stages_read(reset=True)
+        emb.profile_read(reset=True)
+        for _ in range(3):
+            emb.embed_ids(ids, mask)
+        st, nf = emb.profile_stages_read()
+        ms1, n1 = emb.profile_read()
+        emb.profile_stages(False)
+        stages = {k: round(v / (cfg.layers if k not in ("embed_ln", "pool_normalize") else 1), 1) for k, v in st.items()}
+        stages["one_stream_ms_per_forward"] = round(ms1 / max(n1, 1), 3)
     L, H, I, layers = args.seq, cfg.hidden, cfg.intermediate, cfg.layers
     flops_tok = layers * (2 * (4 * H * H + 2 * H * I) + 4 * L * H)
     flops = flops_tok * args.batch * args.seq
@@ -48,7 +62,7 @@ def main():
         "chunks_per_s_device": args.batch / (ms * 1e-3), "tokens_per_s_device": args.batch * args.seq / (ms * 1e-3),
         "algorithmic_tflop_per_batch": flops / 1e12, "achieved_tflops": flops / (ms * 1e-3) / 1e12,
         "peak_tflops_f32_mfma": 157.3, "frac": flops / (ms * 1e-3) / 1e12 / 157.3,
-        "norm0": float(np.linalg.norm(out[0])),
+        "norm0": float(np.linalg.norm(out[0])), "stages_us_per_layer": stages,
     }))
 
 

@@ -195,7 +195,13 @@ int32_t forward_range(cs_embedder* h, hipStream_t s, uint32_t b0, uint32_t nb, u
                 CS_TRY(mark(CS_STAGE_ATTENTION));
             }
             a.g = P + lo.ao_ln_g; a.b = P + lo.ao_ln_b;
-            if (T > split_k_min && T <= split_k_max && T <= split_k_ao_max) {
+            // N = 384 at indexing batch sizes: dense layer + residual + LayerNorm in one kernel (gemm_wide.hip)
+            static const bool ln_fuse_on = [] { const char* e = std::getenv("CS_GEMM_WIDE_LN"); return !(e && e[0] == '0'); }();
+            const bool fuse_ln = ln_fuse_on && h->wide_ok && wide_min_m && T >= wide_min_m && H == 384;
+            if (fuse_ln) {
+                CS_TRY(launch_gemm_wide_ln(ctxs, ws + sl.ao, P + lo.ao_b, x, a.g, a.b, c.layer_norm_eps, x, xs, T, H, h->d_flag, s));  // E4
+                CS_TRY(mark(CS_STAGE_OUT_PROJ));
+            } else if (T > split_k_min && T <= split_k_max && T <= split_k_ao_max) {
                 CS_TRY(launch_gemm_split_partial(ctxs, ws + sl.ao, qkv, T, H, H, 3, s));  // E4, K slices as for E6 below
                 CS_TRY(mark(CS_STAGE_OUT_PROJ));
                 a.parts = qkv; a.nparts = 3; a.bias = P + lo.ao_b;
@@ -209,7 +215,10 @@ int32_t forward_range(cs_embedder* h, hipStream_t s, uint32_t b0, uint32_t nb, u
             CS_TRY(dense(SH_OUT_SPLIT_GELU, xs, ws + sl.up, P + lo.up_b, nullptr, nullptr, mids, T, I, H));    // E5
             CS_TRY(mark(CS_STAGE_FFN_UP));
             a.g = P + lo.out_ln_g; a.b = P + lo.out_ln_b;
-            if (T > split_k_min && T <= split_k_max2) {
+            if (fuse_ln) {
+                CS_TRY(launch_gemm_wide_ln(mids, ws + sl.down, P + lo.down_b, x, a.g, a.b, c.layer_norm_eps, x, xs, T, I, h->d_flag, s));  // E6
+                CS_TRY(mark(CS_STAGE_FFN_DOWN));
+            } else if (T > split_k_min && T <= split_k_max2) {
                 // a few thousand token rows: FFN-down is 3 x T / 128 blocks walking 48 K stages one exposed
                 // latency each; three K slices per tile (two from 6,144 rows: still one round of blocks), partial
                 // slabs in the qkv buffer (free by now), summed with bias and residual by the LayerNorm that follows
@@ -749,10 +758,13 @@ int32_t cs_embedder_debug_counters(cs_embedder* h, uint64_t* split_forwards, uin
 int32_t cs_debug_gemm(int32_t device, int32_t mode, int32_t epilogue, const float* A, const float* W,
                       const float* bias, const float* resid, float* C, uint32_t M, uint32_t N, uint32_t K,
                       uint32_t* range_flag) {
-    if (!A || !W || !bias || !C || (epilogue == 2 && !resid)) return fail(CS_ERR_BAD_ARG, "null buffer");
+    if (!A || !W || !bias || !C || ((epilogue == 2 || epilogue == 3) && !resid)) return fail(CS_ERR_BAD_ARG, "null buffer");
     const bool wide = mode == 2;  // diagnostics only: the 128 x 384 one-accumulator kernel whatever M is
     if (wide) mode = CS_GEMM_SPLIT_F16;
-    if (epilogue < 0 || epilogue > 2 || (mode != CS_GEMM_F32 && mode != CS_GEMM_SPLIT_F16))
+    // epilogue 3 (wide only, N = 384): + resid, LayerNorm with gamma = bias + 1, beta = -bias, eps 1e-12; C receives
+    // the f32 output re-assembled from the SPLIT output (hi + lo / 2048), so both stores are exercised
+    if (epilogue == 3 && !(wide && N == 384)) return fail(CS_ERR_UNSUPPORTED, "epilogue 3 needs mode 2 and N = 384");
+    if (epilogue < 0 || epilogue > 3 || (mode != CS_GEMM_F32 && mode != CS_GEMM_SPLIT_F16))
         return fail(CS_ERR_BAD_ARG, "unknown epilogue/mode");
     if (wide && !gemm_wide_supported(N, K)) return fail(CS_ERR_UNSUPPORTED, "wide kernel needs N %% 384 == 0");
     if (M == 0 || N % 128 || K % 32 || K == 0) return fail(CS_ERR_UNSUPPORTED, "cs_debug_gemm needs M > 0, N %% 128 == 0, K %% 32 == 0");
@@ -772,7 +784,7 @@ int32_t cs_debug_gemm(int32_t device, int32_t mode, int32_t epilogue, const floa
         CS_HIP(hipMemcpy(dW, W, w_n * 4, hipMemcpyHostToDevice));
         CS_HIP(hipMemcpy(dB, bias, (size_t)N * 4, hipMemcpyHostToDevice));
         CS_HIP(hipMemset(dF, 0, 4));
-        if (epilogue == 2) {
+        if (epilogue == 2 || epilogue == 3) {
             CS_HIP(hipMalloc(&dR, c_n * 4));
             CS_HIP(hipMemcpy(dR, resid, c_n * 4, hipMemcpyHostToDevice));
         }
@@ -783,7 +795,32 @@ int32_t cs_debug_gemm(int32_t device, int32_t mode, int32_t epilogue, const floa
             CS_TRY(launch_split_rows(dA, sA, M, K, dF, nullptr));
             CS_TRY(launch_split_rows(dW, sW, N, K, dF, nullptr));
             auto run_gemm = wide ? launch_gemm_wide : launch_gemm_split;
-            if (epilogue == 1) {  // the GELU epilogue writes split form: read it back through hi + lo / 2048
+            if (epilogue == 3) {
+                std::vector<float> gam(N), bet(N);
+                for (uint32_t n = 0; n < N; ++n) { gam[n] = bias[n] + 1.0f; bet[n] = -bias[n]; }
+                float *dG = nullptr, *dBe = nullptr;
+                CS_HIP(hipMalloc(&dG, (size_t)N * 4)); CS_HIP(hipMalloc(&dBe, (size_t)N * 4));
+                CS_HIP(hipMemcpy(dG, gam.data(), (size_t)N * 4, hipMemcpyHostToDevice));
+                CS_HIP(hipMemcpy(dBe, bet.data(), (size_t)N * 4, hipMemcpyHostToDevice));
+                CS_HIP(hipMalloc(&sC, c_n * 4));
+                const int32_t st3 = launch_gemm_wide_ln(sA, sW, dB, dR, dG, dBe, 1e-12f, dR, sC, M, K, dF, nullptr);  // in place over resid
+                CS_HIP(hipDeviceSynchronize());
+                std::vector<float> f32out(c_n);
+                CS_HIP(hipMemcpy(f32out.data(), dR, c_n * 4, hipMemcpyDeviceToHost));
+                (void)hipFree(dG); (void)hipFree(dBe);
+                CS_TRY(st3);
+                // the two outputs must describe the same values: checked here, the split one is what C receives below
+                std::vector<_Float16> hs(c_n * 2);
+                CS_HIP(hipMemcpy(hs.data(), sC, c_n * 4, hipMemcpyDeviceToHost));
+                for (size_t m = 0; m < M; ++m)
+                    for (size_t n = 0; n < N; ++n) {
+                        const _Float16* line = hs.data() + (m * (N / 32) + n / 32) * 64;
+                        const float v = (float)line[n % 32] + (float)line[32 + n % 32] * (1.0f / 2048.0f);
+                        if (!(fabsf(v - f32out[m * N + n]) <= 1e-6f * fmaxf(1.0f, fabsf(v))))
+                            return fail(CS_ERR_HIP, "LayerNorm epilogue: f32 and split outputs disagree at (%zu, %zu): %g vs %g", m, n,
+                                        (double)f32out[m * N + n], (double)v);
+                    }
+            } else if (epilogue == 1) {  // the GELU epilogue writes split form: read it back through hi + lo / 2048
                 CS_HIP(hipMalloc(&sC, c_n * 4));
                 CS_TRY(run_gemm(SH_OUT_SPLIT_GELU, sA, sW, dB, nullptr, nullptr, sC, M, N, K, dF, nullptr));
             } else {

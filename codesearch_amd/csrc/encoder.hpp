@@ -65,6 +65,10 @@ int32_t launch_gemm_split(int epi, const _Float16* A, const _Float16* W, const f
 bool gemm_wide_supported(uint32_t N, uint32_t K);
 int32_t launch_gemm_wide(int epi, const _Float16* A, const _Float16* W, const float* bias, const float* resid, float* C,
                          _Float16* Cs, uint32_t M, uint32_t N, uint32_t K, uint32_t* d_flag, hipStream_t s);
+// N = 384 only: dense layer + bias + residual + LayerNorm in one kernel; X (f32, may alias resid) and Xs (split form)
+int32_t launch_gemm_wide_ln(const _Float16* A, const _Float16* W, const float* bias, const float* resid, const float* gamma,
+                            const float* beta, float eps, float* X, _Float16* Xs, uint32_t M, uint32_t K, uint32_t* d_flag,
+                            hipStream_t s);
 int32_t sh_weights_fit_wide(const _Float16* d_wsplit, uint64_t n_f16, uint32_t* d_scratch_flag, bool* ok, hipStream_t s);
 int32_t launch_synth_params(float* d_out, const cs_bert_config& cfg, uint64_t seed, hipStream_t s);
 

@@ -34,8 +34,10 @@ constexpr int GW_BM = 128, GW_BN = 384;
 constexpr int GW_A_BYTES = GW_BM * 128;            // one k-chunk (32 k, hi + lo) of 128 A rows
 constexpr int GW_W_BYTES = GW_BN * 128;            // ... of 384 W rows
 constexpr int GW_STAGE = GW_A_BYTES + GW_W_BYTES;  // 65,536
-constexpr int GW_LDS = 2 * GW_STAGE;               // 131,072
+constexpr int GW_STATS = 5 * GW_BM * 4;            // LayerNorm epilogue: [4 column groups][128 rows] f32 partial sums + [128] row statistic
+constexpr int GW_LDS = 2 * GW_STAGE + GW_STATS;    // 135,168
 constexpr int GW_THREADS = 512;
+constexpr int GW_OUT_LN = 16;  // epilogue: + bias + residual, LayerNorm over the 384 columns, store f32 AND split form
 
 namespace {
 
@@ -59,9 +61,9 @@ __device__ __forceinline__ float gw_gelu(float v) { return 0.5f * v * (1.0f + gw
 struct GwAcc { sh_f32x4v c[4][6]; };
 
 // this wave's eight LDS-DMA pieces of a stage: p = 0, 1 -> A rows, p = 2..7 -> W rows
-struct GwSrc {
-    const _Float16* a[2];
-    const _Float16* w[6];
+struct GwSrc {  // element offsets from A / W (32 bits: a [65536, 1536] operand is 2^27.6 elements)
+    uint32_t a[2];
+    uint32_t w[6];
 };
 
 }  // namespace
@@ -70,7 +72,8 @@ template <int EPI>
 __global__ void __launch_bounds__(GW_THREADS, 2)
 gemm_wide_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ W, const float* __restrict__ bias,
                  const float* resid, float* C, _Float16* __restrict__ Cs, uint32_t M, uint32_t N, uint32_t kchunks,
-                 uint32_t* __restrict__ flag, uint32_t total_slots) {
+                 uint32_t* __restrict__ flag, uint32_t total_slots, const float* __restrict__ ln_g,
+                 const float* __restrict__ ln_b, float ln_eps) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -81,25 +84,25 @@ gemm_wide_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ W,
     // LDS image of a stage: row r of a tile = one 128-B line, logical 16-B slot c at physical slot c ^ ((r >> 1) & 7)
     // (split_f16.hpp); the LDS-DMA destination is lane-linear, so the permutation goes into the source address.
     const int drow = lane >> 3;                  // row of a piece (8 rows x 128 B) this lane fetches
-    auto src_of = [&](const _Float16* base, uint32_t row_in_tile, uint32_t grow) {
+    auto src_of = [&](uint32_t row_in_tile, uint32_t grow) {
         const int c = (lane & 7) ^ ((row_in_tile >> 1) & 7);
-        return base + (size_t)grow * kchunks * 64 + c * 8;
+        return grow * kchunks * 64 + c * 8;
     };
     auto tile_src = [&](uint32_t m0, uint32_t n0, GwSrc& s) {
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
             const uint32_t r = (wave * 2 + p) * 8 + drow;
-            s.a[p] = src_of(A, r, (m0 + r < M) ? m0 + r : M - 1);  // rows past M re-read row M-1 (never stored)
+            s.a[p] = src_of(r, (m0 + r < M) ? m0 + r : M - 1);  // rows past M re-read row M-1 (never stored)
         }
 #pragma unroll
         for (int p = 0; p < 6; ++p) {
             const uint32_t r = (wave * 6 + p) * 8 + drow;
-            s.w[p] = src_of(W, r, n0 + r);
+            s.w[p] = src_of(r, n0 + r);
         }
     };
     auto dma = [&](const GwSrc& s, int p, uint32_t kc, uint32_t bufoff) {
-        if (p < 2) sh_glds16(s.a[p] + (size_t)kc * 64, lds + bufoff + (wave * 2 + p) * 1024);
-        else sh_glds16(s.w[p - 2] + (size_t)kc * 64, lds + bufoff + GW_A_BYTES + (wave * 6 + (p - 2)) * 1024);
+        if (p < 2) sh_glds16(A + (s.a[p] + kc * 64), lds + bufoff + (wave * 2 + p) * 1024);
+        else sh_glds16(W + (s.w[p - 2] + kc * 64), lds + bufoff + GW_A_BYTES + (wave * 6 + (p - 2)) * 1024);
     };
 
     const int swz = (l15 >> 1) & 7;
@@ -125,10 +128,32 @@ gemm_wide_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ W,
         const uint32_t m0 = mt * GW_BM, n0 = nt * GW_BN;
         const uint32_t rot = sh_kc_rot(nt, ntiles, kchunks);  // see sh_mainloop: n-tiles of an m-tile walk K out of phase
         GwAcc acc;
+        if (EPI == GW_OUT_LN) {
+            // the accumulators START at (bias + residual) * 2^11, the scale the products arrive on: the residual is
+            // read while stage 0 is in flight and the epilogue needs no registers for it
+            float bj[6];
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+            for (int j = 0; j < 6; ++j) bj[j] = bias[wc * 96 + 16 * j + l15];
+            const char* rbase = reinterpret_cast<const char*>(resid);
 #pragma unroll
-            for (int j = 0; j < 6; ++j) acc.c[i][j] = sh_f32x4v{0.f, 0.f, 0.f, 0.f};
+            for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const uint32_t row = m0 + wr * 64 + 16 * i + 4 * g + r;
+                    // 32-bit byte offset from a uniform base (a [65536, 384] f32 tensor is 100 MB): one VGPR per row
+                    const uint32_t off = ((row < M ? row : M - 1) * GW_BN + wc * 96 + l15) * 4u;
+#pragma unroll
+                    for (int j = 0; j < 6; ++j)
+                        acc.c[i][j][r] = (bj[j] + *reinterpret_cast<const float*>(rbase + (size_t)(off + 64u * j))) * kShLoScale;
+                }
+                __builtin_amdgcn_sched_barrier(0);  // 24 loads in flight at a time
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 6; ++j) acc.c[i][j] = sh_f32x4v{0.f, 0.f, 0.f, 0.f};
+        }
         __syncthreads();  // stage 0 has landed (vmcnt(0) precedes the barrier)
 
         for (uint32_t kc = 0; kc < kchunks; ++kc) {
@@ -188,6 +213,63 @@ gemm_wide_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ W,
         float* ctile = reinterpret_cast<float*>(lds + ebuf * GW_STAGE);  // [128 m][128 n] f32, 16-col blocks XOR-swizzled by (m >> 2) & 3
         const bool full = m0 + GW_BM <= M;
         bool ovf = false;
+        if (EPI == GW_OUT_LN) {
+            // One n-tile = whole rows: v = acc / 2^11 (bias and residual are in there), then LayerNorm over the 384 columns
+            // (two passes like encoder.hip ln_row: mean, then the variance of the deviations), all in the
+            // accumulator registers.  A row's columns sit in 4 waves (wc) x 6 tiles (j) x 16 lanes (l15).
+            float* stats = reinterpret_cast<float*>(lds + 2 * GW_STAGE);  // [4][128] partial sums, [128] row statistic
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 6; ++j) acc.c[i][j] *= kShLoInv;
+            constexpr float invN = 1.0f / (float)GW_BN;
+            float* rowstat = stats + 4 * GW_BM;  // [128] per-row mean, then per-row 1 / sqrt(var + eps)
+            sh_f32x4v mean[4];
+            // partial sums of this wave's 96 columns -> stats[wc][row]; rows 4g..4g+3 of tile i are one float4
+            auto reduce_rows = [&](bool second) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    sh_f32x4v t = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) {
+                        if (second) { const sh_f32x4v d = acc.c[i][j] - mean[i]; t += d * d; }
+                        else t += acc.c[i][j];
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        t[r] += __shfl_xor(t[r], 8, 64);
+                        t[r] += __shfl_xor(t[r], 4, 64);
+                        t[r] += __shfl_xor(t[r], 2, 64);
+                        t[r] += __shfl_xor(t[r], 1, 64);
+                    }
+                    if (l15 == 0) *reinterpret_cast<sh_f32x4v*>(stats + wc * GW_BM + wr * 64 + 16 * i + 4 * g) = t;
+                }
+                __syncthreads();
+                if (tid < GW_BM) {
+                    const float tot = (stats[tid] + stats[GW_BM + tid]) + (stats[2 * GW_BM + tid] + stats[3 * GW_BM + tid]);
+                    rowstat[tid] = second ? 1.0f / sqrtf(tot * invN + ln_eps) : tot * invN;
+                }
+                __syncthreads();
+            };
+            reduce_rows(false);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) mean[i] = *reinterpret_cast<const sh_f32x4v*>(rowstat + wr * 64 + 16 * i + 4 * g);
+            reduce_rows(true);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const sh_f32x4v inv = *reinterpret_cast<const sh_f32x4v*>(rowstat + wr * 64 + 16 * i + 4 * g);
+#pragma unroll
+                for (int j = 0; j < 6; ++j) acc.c[i][j] = (acc.c[i][j] - mean[i]) * inv;
+            }
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                const float gj = ln_g[wc * 96 + 16 * j + l15], tj = ln_b[wc * 96 + 16 * j + l15];
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc.c[i][j][r] = fmaf(acc.c[i][j][r], gj, tj);
+            }
+        }
 #pragma unroll 1
         for (int p = 0; p < 3; ++p) {
 #pragma unroll
@@ -199,13 +281,39 @@ gemm_wide_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ W,
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             const int m = wr * 64 + 16 * i + 4 * g + r;  // (m >> 2) & 3 == g
-                            ctile[m * 128 + (((col & 127) + l15) ^ (g << 4))] = acc.c[i][j][r] * kShLoInv;
+                            ctile[m * 128 + (((col & 127) + l15) ^ (g << 4))] =
+                                EPI == GW_OUT_LN ? acc.c[i][j][r] : acc.c[i][j][r] * kShLoInv;
                         }
                 }
             }
             __syncthreads();
             const uint32_t nbase = n0 + 128 * p;
-            if (EPI == SH_OUT_SPLIT || EPI == SH_OUT_SPLIT_GELU) {
+            if (EPI == GW_OUT_LN) {
+                const int c8 = tid & 15;  // 8 consecutive n per thread: two 16-B f32 stores, one 16-B store per f16 plane
+                const size_t nchunks = GW_BN / 32;
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    const int row = (tid >> 4) + 32 * it;
+                    const int pc = (c8 * 8) ^ (((row >> 2) & 3) << 4);
+                    const sh_f32x4 v0 = *reinterpret_cast<const sh_f32x4*>(ctile + row * 128 + pc);
+                    const sh_f32x4 v1 = *reinterpret_cast<const sh_f32x4*>(ctile + row * 128 + pc + 4);
+                    f16x8 hi, lo;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        _Float16 a, b;
+                        ovf |= sh_split(v0[e], a, b); hi[e] = a; lo[e] = b;
+                        ovf |= sh_split(v1[e], a, b); hi[4 + e] = a; lo[4 + e] = b;
+                    }
+                    if (full || m0 + row < M) {
+                        float* xd = C + (size_t)(m0 + row) * GW_BN + nbase + c8 * 8;
+                        *reinterpret_cast<sh_f32x4*>(xd) = v0;
+                        *reinterpret_cast<sh_f32x4*>(xd + 4) = v1;
+                        _Float16* dst = Cs + ((size_t)(m0 + row) * nchunks + (nbase >> 5) + (c8 >> 2)) * 64 + (c8 & 3) * 8;
+                        *reinterpret_cast<f16x8*>(dst) = hi;
+                        *reinterpret_cast<f16x8*>(dst + 32) = lo;
+                    }
+                }
+            } else if (EPI == SH_OUT_SPLIT || EPI == SH_OUT_SPLIT_GELU) {
                 const int c8 = tid & 15;  // 8 consecutive n per thread
                 const sh_f32x4 b0 = *reinterpret_cast<const sh_f32x4*>(bias + nbase + c8 * 8);
                 const sh_f32x4 b1 = *reinterpret_cast<const sh_f32x4*>(bias + nbase + c8 * 8 + 4);
@@ -284,8 +392,9 @@ int32_t sh_weights_fit_wide(const _Float16* d_wsplit, uint64_t n_f16, uint32_t* 
 
 bool gemm_wide_supported(uint32_t N, uint32_t K) { return N % GW_BN == 0 && K % 32 == 0 && N > 0 && K > 0; }
 
-int32_t launch_gemm_wide(int epi, const _Float16* A, const _Float16* W, const float* bias, const float* resid, float* C,
-                         _Float16* Cs, uint32_t M, uint32_t N, uint32_t K, uint32_t* d_flag, hipStream_t s) {
+static int32_t gemm_wide_impl(int epi, const _Float16* A, const _Float16* W, const float* bias, const float* resid, float* C,
+                              _Float16* Cs, uint32_t M, uint32_t N, uint32_t K, uint32_t* d_flag, hipStream_t s,
+                              const float* ln_g, const float* ln_b, float ln_eps) {
     if (!gemm_wide_supported(N, K)) return fail(CS_ERR_UNSUPPORTED, "wide split GEMM needs N %% 384 == 0 and K %% 32 == 0 (N=%u K=%u)", N, K);
     if (M == 0) return CS_OK;
     static bool attr_set = false;
@@ -295,6 +404,7 @@ int32_t launch_gemm_wide(int epi, const _Float16* A, const _Float16* W, const fl
         CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wide_kernel<SH_OUT_F32_RESID>), hipFuncAttributeMaxDynamicSharedMemorySize, GW_LDS));
         CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wide_kernel<SH_OUT_SPLIT_GELU>), hipFuncAttributeMaxDynamicSharedMemorySize, GW_LDS));
         CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wide_kernel<SH_OUT_SPLIT>), hipFuncAttributeMaxDynamicSharedMemorySize, GW_LDS));
+        CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wide_kernel<GW_OUT_LN>), hipFuncAttributeMaxDynamicSharedMemorySize, GW_LDS));
         int dev = 0, n = 0;
         if (hipGetDevice(&dev) == hipSuccess &&
             hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n >= 8)
@@ -305,15 +415,30 @@ int32_t launch_gemm_wide(int epi, const _Float16* A, const _Float16* W, const fl
     const uint32_t slots = sh_grid_blocks(mtiles, ntiles);
     const uint32_t grid = slots < (uint32_t)cus ? slots : (uint32_t)cus;
     const uint32_t kc = K / 32;
-#define GW_LAUNCH(E) hipLaunchKernelGGL(gemm_wide_kernel<E>, dim3(grid), dim3(GW_THREADS), GW_LDS, s, A, W, bias, resid, C, Cs, M, N, kc, d_flag, slots)
+#define GW_LAUNCH(E) hipLaunchKernelGGL(gemm_wide_kernel<E>, dim3(grid), dim3(GW_THREADS), GW_LDS, s, A, W, bias, resid, C, Cs, M, N, kc, d_flag, slots, ln_g, ln_b, ln_eps)
     if (epi == SH_OUT_F32) GW_LAUNCH(SH_OUT_F32);
     else if (epi == SH_OUT_F32_RESID) GW_LAUNCH(SH_OUT_F32_RESID);
     else if (epi == SH_OUT_SPLIT) GW_LAUNCH(SH_OUT_SPLIT);
     else if (epi == SH_OUT_SPLIT_GELU) GW_LAUNCH(SH_OUT_SPLIT_GELU);
+    else if (epi == GW_OUT_LN) GW_LAUNCH(GW_OUT_LN);
     else return fail(CS_ERR_BAD_ARG, "unknown epilogue %d", epi);
 #undef GW_LAUNCH
     CS_HIP(hipGetLastError());
     return CS_OK;
+}
+
+int32_t launch_gemm_wide(int epi, const _Float16* A, const _Float16* W, const float* bias, const float* resid, float* C,
+                         _Float16* Cs, uint32_t M, uint32_t N, uint32_t K, uint32_t* d_flag, hipStream_t s) {
+    if (epi == GW_OUT_LN) return fail(CS_ERR_BAD_ARG, "the LayerNorm epilogue goes through launch_gemm_wide_ln");
+    return gemm_wide_impl(epi, A, W, bias, resid, C, Cs, M, N, K, d_flag, s, nullptr, nullptr, 0.0f);
+}
+
+// X[M,384] = LayerNorm(A W^T + bias + resid) * gamma + beta, written as f32 (X; may alias resid) and in split
+// form (Xs): a dense layer with N = 384, its residual add and the LayerNorm behind it (E4 / E6) in one kernel.
+int32_t launch_gemm_wide_ln(const _Float16* A, const _Float16* W, const float* bias, const float* resid, const float* gamma,
+                            const float* beta, float eps, float* X, _Float16* Xs, uint32_t M, uint32_t K, uint32_t* d_flag,
+                            hipStream_t s) {
+    return gemm_wide_impl(GW_OUT_LN, A, W, bias, resid, X, Xs, M, GW_BN, K, d_flag, s, gamma, beta, eps);
 }
 
 }  // namespace cs

@@ -89,6 +89,27 @@ def test_wide_gemm_matches_float64_and_the_two_accumulator_kernels(gpu_lib, M, N
     assert (np.abs(got_w[rows] - ref_rows) / sc).max() < 6e-7
 
 
+@pytest.mark.parametrize("M,K", [(1, 32), (130, 384), (1000, 1536), (128 * 300 + 5, 96)])
+def test_wide_gemm_with_fused_layernorm(gpu_lib, M, K):
+    """N = 384: dense layer + bias + residual + LayerNorm in one kernel (accumulators start at (bias + resid) * 2^11;
+    row statistics across the block's four column waves).  cs_debug_gemm epilogue 3 runs it in place over the
+    residual with gamma = bias + 1, beta = -bias, checks that its f32 and split outputs agree, and returns the split one."""
+    N = 384
+    rng = np.random.default_rng(M + K)
+    A = rng.standard_normal((M, K)).astype(np.float32)
+    W = (rng.standard_normal((N, K)) * 0.05).astype(np.float32)
+    bias = (rng.standard_normal(N) * 0.1).astype(np.float32)
+    resid = rng.standard_normal((M, N)).astype(np.float32)
+    got, flag = run_gemm(gpu_lib, WIDE, 3, A, W, bias, resid)
+    assert flag == 0
+    rows = np.arange(M) if M <= 1000 else rng.integers(0, M, 256)
+    v = A[rows].astype(np.float64) @ W.astype(np.float64).T + bias.astype(np.float64) + resid[rows].astype(np.float64)
+    mu = v.mean(axis=1, keepdims=True)
+    var = ((v - mu) ** 2).mean(axis=1, keepdims=True)
+    ref = (v - mu) / np.sqrt(var + 1e-12) * (bias.astype(np.float64) + 1.0) - bias.astype(np.float64)
+    assert np.abs(got[rows] - ref).max() < 5e-6, np.abs(got[rows] - ref).max()
+
+
 def test_wide_gemm_exact_and_range(gpu_lib):
     """Integer data exact through the scaled accumulator; |w| up to 31 still inside the f16 range after the
     2^11 scaling; the activation range flag still raised by the epilogue's split."""
