@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""Device time of the encoder's dense layers, one kernel at a time, through cs_debug_gemm_time (operands resident
+in HBM): the 128 x 128 split kernels vs the persistent 128 x 384 one-accumulator kernel, and the wide kernel's
+ablation builds (no LDS-DMA / no MFMA / DMAs at the step start)."""
+import ctypes as C
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    from codesearch_amd import _lib
+
+    lib = _lib.load()
+    M = int(os.environ.get("M", 65536))
+
+    def t(mode, epi, N, K, abl=0, iters=20):
+        ms = C.c_double()
+        _lib.check(lib.cs_debug_gemm_time(0, mode, epi, M, N, K, iters, abl, C.byref(ms)))
+        return ms.value * 1e3
+
+    shapes = [("qkv      (N=1152, K=384,  bias -> split)", 4, 1152, 384), ("ffn_up   (N=1536, K=384,  GELU -> split)", 1, 1536, 384),
+              ("out_proj (N=384,  K=384,  + resid f32)", 2, 384, 384), ("ffn_down (N=384,  K=1536, + resid f32)", 2, 384, 1536)]
+    for name, epi, N, K in shapes:
+        tf = 3 * 2.0 * M * N * K / 1e12
+        a, b = t(1, epi, N, K), t(2, epi, N, K)
+        print(f"{name}: 128x128 {a:7.1f} us ({tf / a * 1e6:6.0f} TF/s executed)   wide {b:7.1f} us ({tf / b * 1e6:6.0f} TF/s)", flush=True)
+    for K in (384, 1536):
+        print(f"N=384 K={K} LayerNorm-fused wide: {t(2, 3, 384, K):7.1f} us", flush=True)
+    for name, abl in (("full", 0), ("no LDS-DMA", 1), ("no MFMA", 2), ("DMAs at step start", 3)):
+        print(f"wide qkv ablation {name:20s}: {t(2, 4, 1152, 384, abl):7.1f} us", flush=True)
+
+
+if __name__ == "__main__":
+    main()

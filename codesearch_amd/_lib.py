@@ -122,6 +122,8 @@ SIGNATURES = {
                                               C.c_uint32, u32p]),
     "cs_embedder_embed_texts": (C.c_int32, [vp, vp, C.c_char_p, u64p, C.c_uint64, C.c_uint32, f32p, i32p]),
     "cs_embedder_embed_texts_device": (C.c_int32, [vp, vp, C.c_char_p, u64p, C.c_uint64, C.c_uint32, vp, i32p]),
+    "cs_debug_gemm_time": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                       C.c_int32, f64p]),
     "cs_debug_gemm": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32, f32p, f32p, f32p, f32p, f32p,
                                   C.c_uint32, C.c_uint32, C.c_uint32, u32p]),
 }

@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "encoder.hpp"
+#include "scan.hpp"  // launch_synth_fill (cs_debug_gemm_time)
 #include "split_f16.hpp"
 
 using namespace cs;
@@ -846,6 +847,64 @@ int32_t cs_debug_gemm(int32_t device, int32_t mode, int32_t epilogue, const floa
     st = run();
     for (void* p : {(void*)dA, (void*)dW, (void*)dB, (void*)dR, (void*)dC, (void*)sA, (void*)sW, (void*)sC, (void*)dF})
         if (p) (void)hipFree(p);
+    return st;
+}
+
+// Diagnostics: device time of one dense layer on synthetic operands already in HBM (no PCIe, no allocation inside the
+// timed region).  mode as cs_debug_gemm (0 f32 MFMA, 1 split-f16 128 x 128 / skinny kernels, 2 split-f16 wide kernel);
+// epilogue 0 f32 store, 1 GELU -> split store, 2 + residual, 3 LayerNorm-fused (mode 2, N = 384), 4 bias -> split store
+// (the QKV projection).  `ablation` (mode 2, epilogue 4 only): 1 no LDS-DMA, 2 no MFMA, 3 DMAs issued at the step start.
+int32_t cs_debug_gemm_time(int32_t device, int32_t mode, int32_t epilogue, uint32_t M, uint32_t N, uint32_t K,
+                           uint32_t iters, int32_t ablation, double* ms_per_launch) {
+    if (!ms_per_launch || iters == 0 || M == 0 || N % 128 || K % 32 || K == 0) return fail(CS_ERR_BAD_ARG, "bad arguments");
+    int ndev = 0;
+    CS_HIP(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) return fail(CS_ERR_HIP, "HIP device %d not available (%d visible)", device, ndev);
+    DeviceGuard g(device);
+    const size_t a_n = (size_t)M * K, w_n = (size_t)N * K, c_n = (size_t)M * N;
+    float *dA = nullptr, *dW = nullptr, *dB = nullptr, *dR = nullptr, *dC = nullptr;
+    _Float16 *sA = nullptr, *sW = nullptr, *sC = nullptr;
+    uint32_t* dF = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    auto run = [&]() -> int32_t {
+        CS_HIP(hipMalloc(&dA, a_n * 4)); CS_HIP(hipMalloc(&dW, w_n * 4)); CS_HIP(hipMalloc(&dB, (size_t)N * 4));
+        CS_HIP(hipMalloc(&dC, c_n * 4)); CS_HIP(hipMalloc(&dR, c_n * 4)); CS_HIP(hipMalloc(&dF, 4));
+        CS_HIP(hipMalloc(&sA, a_n * 4)); CS_HIP(hipMalloc(&sW, w_n * 4)); CS_HIP(hipMalloc(&sC, c_n * 4));
+        // operands from the counter-based generator: unit-scale activations, weights / 20
+        CS_TRY(launch_synth_fill(dA, M, K, 11, 0, nullptr));
+        CS_TRY(launch_synth_fill(dW, N, K, 12, 0, nullptr));
+        CS_TRY(launch_synth_fill(dR, M, N, 13, 0, nullptr));
+        CS_HIP(hipMemset(dB, 0, (size_t)N * 4));
+        CS_HIP(hipMemset(dF, 0, 4));
+        CS_TRY(launch_split_rows(dA, sA, M, K, dF, nullptr));
+        CS_TRY(launch_split_rows(dW, sW, N, K, dF, nullptr));
+        CS_HIP(hipEventCreate(&e0)); CS_HIP(hipEventCreate(&e1));
+        auto once = [&]() -> int32_t {
+            if (mode == CS_GEMM_F32)
+                return launch_gemm(epilogue == 1 ? GEMM_GELU : epilogue == 2 ? GEMM_RESID : GEMM_BIAS, dA, dW, dB, dR, dC, M, N, K, nullptr);
+            if (epilogue == 3) return launch_gemm_wide_ln(sA, sW, dB, dR, dB, dB, 1e-12f, dR, sC, M, K, dF, nullptr);
+            const int epi = epilogue == 0 ? SH_OUT_F32 : epilogue == 1 ? SH_OUT_SPLIT_GELU : epilogue == 2 ? SH_OUT_F32_RESID : SH_OUT_SPLIT;
+            auto fn = mode == 2 ? launch_gemm_wide : launch_gemm_split;
+            return fn(epi, sA, sW, dB, dR, dC, sC, M, N, K, dF, nullptr);
+        };
+        cs::g_gemm_wide_ablation = (mode == 2 && epilogue == 4) ? ablation : 0;
+        for (int i = 0; i < 3; ++i) CS_TRY(once());
+        CS_HIP(hipEventRecord(e0, nullptr));
+        for (uint32_t i = 0; i < iters; ++i) CS_TRY(once());
+        CS_HIP(hipEventRecord(e1, nullptr));
+        CS_HIP(hipEventSynchronize(e1));
+        float ms = 0.f;
+        CS_HIP(hipEventElapsedTime(&ms, e0, e1));
+        *ms_per_launch = (double)ms / iters;
+        return CS_OK;
+    };
+    const int32_t st = run();
+    cs::g_gemm_wide_ablation = 0;
+    (void)hipDeviceSynchronize();
+    for (void* p : {(void*)dA, (void*)dW, (void*)dB, (void*)dR, (void*)dC, (void*)sA, (void*)sW, (void*)sC, (void*)dF})
+        if (p) (void)hipFree(p);
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
     return st;
 }
 

@@ -68,7 +68,10 @@ struct GwSrc {  // element offsets from A / W (32 bits: a [65536, 1536] operand 
 
 }  // namespace
 
-template <int EPI>
+// ABL (diagnostics, cs_debug_gemm_time): 0 = the product kernel; 1 = no LDS-DMA after a tile's first stage (the MFMA +
+// LDS-read ceiling); 2 = no MFMA (fill + LDS reads only); 3 = the eight DMAs of a stage issued back to back at the
+// start of the step instead of between the MFMA groups.
+template <int EPI, int ABL = 0>
 __global__ void __launch_bounds__(GW_THREADS, 2)
 gemm_wide_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ W, const float* __restrict__ bias,
                  const float* resid, float* C, _Float16* __restrict__ Cs, uint32_t M, uint32_t N, uint32_t kchunks,
@@ -170,6 +173,10 @@ gemm_wide_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ W,
             }
             f16x8 wh = *reinterpret_cast<const f16x8*>(cur + w_off + s_hi);
             f16x8 wl = *reinterpret_cast<const f16x8*>(cur + w_off + s_lo);
+            if (ABL == 3 && more) {
+#pragma unroll
+                for (int p = 0; p < 8; ++p) dma(src, p, kn, nb);
+            }
 #pragma unroll
             for (int j = 0; j < 6; ++j) {
                 f16x8 whn = wh, wln = wl;
@@ -178,21 +185,26 @@ gemm_wide_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ W,
                     wln = *reinterpret_cast<const f16x8*>(cur + w_off + (j + 1) * 2048 + s_lo);
                 }
                 const f16x8 whs = wh * (_Float16)2048.0f;  // exact: |w_hi| < 32 (sh_weights_fit_wide)
+                if (ABL == 2) {
+                    asm volatile("" ::"v"(whs), "v"(wl), "v"(wh));
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(ah[i]), "v"(al[i]));
+                }
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
-                    acc.c[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], whs, acc.c[i][j], 0, 0, 0);
+                    if (ABL != 2) acc.c[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], whs, acc.c[i][j], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
-                if (more && j < 4) dma(src, 2 * j, kn, nb);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    acc.c[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], wl, acc.c[i][j], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-                if (more && j < 4) dma(src, 2 * j + 1, kn, nb);
+                if ((ABL == 0 || ABL == 2) && more && j < 4) dma(src, 2 * j, kn, nb);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
-                    acc.c[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], wh, acc.c[i][j], 0, 0, 0);
+                    if (ABL != 2) acc.c[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], wl, acc.c[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if ((ABL == 0 || ABL == 2) && more && j < 4) dma(src, 2 * j + 1, kn, nb);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (ABL != 2) acc.c[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], wh, acc.c[i][j], 0, 0, 0);
                 wh = whn;
                 wl = wln;
             }
@@ -392,6 +404,8 @@ int32_t sh_weights_fit_wide(const _Float16* d_wsplit, uint64_t n_f16, uint32_t* 
 
 bool gemm_wide_supported(uint32_t N, uint32_t K) { return N % GW_BN == 0 && K % 32 == 0 && N > 0 && K > 0; }
 
+int g_gemm_wide_ablation = 0;  // diagnostics only (cs_debug_gemm_time)
+
 static int32_t gemm_wide_impl(int epi, const _Float16* A, const _Float16* W, const float* bias, const float* resid, float* C,
                               _Float16* Cs, uint32_t M, uint32_t N, uint32_t K, uint32_t* d_flag, hipStream_t s,
                               const float* ln_g, const float* ln_b, float ln_eps) {
@@ -416,6 +430,22 @@ static int32_t gemm_wide_impl(int epi, const _Float16* A, const _Float16* W, con
     const uint32_t grid = slots < (uint32_t)cus ? slots : (uint32_t)cus;
     const uint32_t kc = K / 32;
 #define GW_LAUNCH(E) hipLaunchKernelGGL(gemm_wide_kernel<E>, dim3(grid), dim3(GW_THREADS), GW_LDS, s, A, W, bias, resid, C, Cs, M, N, kc, d_flag, slots, ln_g, ln_b, ln_eps)
+    if (g_gemm_wide_ablation && epi == SH_OUT_SPLIT) {
+        static bool abl_attr = false;
+        if (!abl_attr) {
+            CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wide_kernel<SH_OUT_SPLIT, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, GW_LDS));
+            CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wide_kernel<SH_OUT_SPLIT, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, GW_LDS));
+            CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wide_kernel<SH_OUT_SPLIT, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, GW_LDS));
+            abl_attr = true;
+        }
+#define GW_LAUNCH_ABL(V) hipLaunchKernelGGL((gemm_wide_kernel<SH_OUT_SPLIT, V>), dim3(grid), dim3(GW_THREADS), GW_LDS, s, A, W, bias, resid, C, Cs, M, N, kc, d_flag, slots, ln_g, ln_b, ln_eps)
+        if (g_gemm_wide_ablation == 1) GW_LAUNCH_ABL(1);
+        else if (g_gemm_wide_ablation == 2) GW_LAUNCH_ABL(2);
+        else GW_LAUNCH_ABL(3);
+#undef GW_LAUNCH_ABL
+        CS_HIP(hipGetLastError());
+        return CS_OK;
+    }
     if (epi == SH_OUT_F32) GW_LAUNCH(SH_OUT_F32);
     else if (epi == SH_OUT_F32_RESID) GW_LAUNCH(SH_OUT_F32_RESID);
     else if (epi == SH_OUT_SPLIT) GW_LAUNCH(SH_OUT_SPLIT);
