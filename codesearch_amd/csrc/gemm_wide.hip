@@ -21,8 +21,9 @@
 // within the first two thirds of the step), so the address path works while the matrix pipe does.  The
 // kernel is persistent (one block per CU): the first stage of a block's NEXT tile is in flight while the current
 // tile's epilogue runs, in the stage buffer the epilogue does not use.
-// LDS: two stages of 64 KiB; the epilogue stages the C tile through one of them in three passes of 128
-// columns so that every global access is 16 B per lane on consecutive lanes.
+// LDS: two stages of 64 KiB.  The MFMAs take the weight fragment as their FIRST operand, so the accumulator of a
+// 16 x 16 tile holds four consecutive columns of one row per lane and the epilogue stores straight from registers
+// (16 B of f32 or 8 B per f16 plane per lane): no LDS pass, no barrier.
 #include <cstdlib>
 
 #include "encoder.hpp"
@@ -134,22 +135,18 @@ gemm_wide_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ W,
         if (EPI == GW_OUT_LN) {
             // the accumulators START at (bias + residual) * 2^11, the scale the products arrive on: the residual is
             // read while stage 0 is in flight and the epilogue needs no registers for it
-            float bj[6];
-#pragma unroll
-            for (int j = 0; j < 6; ++j) bj[j] = bias[wc * 96 + 16 * j + l15];
             const char* rbase = reinterpret_cast<const char*>(resid);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
+                const uint32_t row = m0 + wr * 64 + 16 * i + l15;
+                // 32-bit byte offset from a uniform base (a [65536, 384] f32 tensor is 100 MB): one VGPR per row
+                const uint32_t off = ((row < M ? row : M - 1) * GW_BN + wc * 96 + 4 * g) * 4u;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const uint32_t row = m0 + wr * 64 + 16 * i + 4 * g + r;
-                    // 32-bit byte offset from a uniform base (a [65536, 384] f32 tensor is 100 MB): one VGPR per row
-                    const uint32_t off = ((row < M ? row : M - 1) * GW_BN + wc * 96 + l15) * 4u;
-#pragma unroll
-                    for (int j = 0; j < 6; ++j)
-                        acc.c[i][j][r] = (bj[j] + *reinterpret_cast<const float*>(rbase + (size_t)(off + 64u * j))) * kShLoScale;
+                for (int j = 0; j < 6; ++j) {
+                    const sh_f32x4 bv = *reinterpret_cast<const sh_f32x4*>(bias + wc * 96 + 16 * j + 4 * g);
+                    const sh_f32x4 rv = *reinterpret_cast<const sh_f32x4*>(rbase + (size_t)(off + 64u * j));
+                    acc.c[i][j] = (bv + rv) * kShLoScale;
                 }
-                __builtin_amdgcn_sched_barrier(0);  // 24 loads in flight at a time
             }
         } else {
 #pragma unroll
@@ -192,19 +189,19 @@ gemm_wide_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ W,
                 }
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
-                    if (ABL != 2) acc.c[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], whs, acc.c[i][j], 0, 0, 0);
+                    if (ABL != 2) acc.c[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(whs, ah[i], acc.c[i][j], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
                 if ((ABL == 0 || ABL == 2) && more && j < 4) dma(src, 2 * j, kn, nb);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
-                    if (ABL != 2) acc.c[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], wl, acc.c[i][j], 0, 0, 0);
+                    if (ABL != 2) acc.c[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, ah[i], acc.c[i][j], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
                 if ((ABL == 0 || ABL == 2) && more && j < 4) dma(src, 2 * j + 1, kn, nb);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
-                    if (ABL != 2) acc.c[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], wh, acc.c[i][j], 0, 0, 0);
+                    if (ABL != 2) acc.c[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, al[i], acc.c[i][j], 0, 0, 0);
                 wh = whn;
                 wl = wln;
             }
@@ -212,7 +209,7 @@ gemm_wide_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ W,
         }
 
         // next tile of this block: its first stage flies into the buffer the epilogue does not use
-        const uint32_t ebuf = (buf + kchunks - 1) & 1;  // buffer of the last stage: free now, stages the C tile
+        const uint32_t ebuf = (buf + kchunks - 1) & 1;  // buffer of the last stage
         uint32_t nmt = 0, nnt = 0;
         const uint32_t nslot = next_valid(slot + gridDim.x, nmt, nnt);
         if (nslot < total_slots) {
@@ -221,40 +218,39 @@ gemm_wide_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ W,
             for (int p = 0; p < 8; ++p) dma(src, p, sh_kc_rot(nnt, ntiles, kchunks), (ebuf ^ 1) * GW_STAGE);
         }
 
-        // ---- epilogue: three passes of 128 columns through the free stage buffer --------------------------------
-        float* ctile = reinterpret_cast<float*>(lds + ebuf * GW_STAGE);  // [128 m][128 n] f32, 16-col blocks XOR-swizzled by (m >> 2) & 3
+        // ---- epilogue: straight from the accumulator registers ------------------------------------------------------
+        // The MFMAs take the WEIGHT fragment as their first operand, so a lane holds, per 16 x 16 tile, FOUR CONSECUTIVE
+        // COLUMNS n = 16 j + 4 g + r of ONE ROW m = 16 i + l15: 16 bytes of f32, or 8 bytes of each f16 plane of the
+        // split form — stored directly, no LDS pass, no barrier (the three staged passes this replaces cost a
+        // quarter of a tile's time: nothing overlaps them at one block per CU).
         const bool full = m0 + GW_BM <= M;
         bool ovf = false;
+        const uint32_t cbase = n0 + wc * 96 + 4 * g;  // first column of this lane in tile j = 0
         if (EPI == GW_OUT_LN) {
-            // One n-tile = whole rows: v = acc / 2^11 (bias and residual are in there), then LayerNorm over the 384 columns
-            // (two passes like encoder.hip ln_row: mean, then the variance of the deviations), all in the
-            // accumulator registers.  A row's columns sit in 4 waves (wc) x 6 tiles (j) x 16 lanes (l15).
+            // One n-tile = whole rows: v = acc / 2^11 (bias and residual are in there), then LayerNorm over the 384
+            // columns (two passes like encoder.hip ln_row).  A row's columns sit in 4 waves (wc) x 6 tiles x 4 lanes (g).
+            constexpr float invN = 1.0f / (float)GW_BN;
             float* stats = reinterpret_cast<float*>(lds + 2 * GW_STAGE);  // [4][128] partial sums, [128] row statistic
+            float* rowstat = stats + 4 * GW_BM;
+            float mean[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 6; ++j) acc.c[i][j] *= kShLoInv;
-            constexpr float invN = 1.0f / (float)GW_BN;
-            float* rowstat = stats + 4 * GW_BM;  // [128] per-row mean, then per-row 1 / sqrt(var + eps)
-            sh_f32x4v mean[4];
-            // partial sums of this wave's 96 columns -> stats[wc][row]; rows 4g..4g+3 of tile i are one float4
             auto reduce_rows = [&](bool second) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    sh_f32x4v t = {0.f, 0.f, 0.f, 0.f};
+                    float t = 0.0f;
 #pragma unroll
-                    for (int j = 0; j < 6; ++j) {
-                        if (second) { const sh_f32x4v d = acc.c[i][j] - mean[i]; t += d * d; }
-                        else t += acc.c[i][j];
-                    }
+                    for (int j = 0; j < 6; ++j)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        t[r] += __shfl_xor(t[r], 8, 64);
-                        t[r] += __shfl_xor(t[r], 4, 64);
-                        t[r] += __shfl_xor(t[r], 2, 64);
-                        t[r] += __shfl_xor(t[r], 1, 64);
-                    }
-                    if (l15 == 0) *reinterpret_cast<sh_f32x4v*>(stats + wc * GW_BM + wr * 64 + 16 * i + 4 * g) = t;
+                        for (int r = 0; r < 4; ++r) {
+                            const float d = second ? acc.c[i][j][r] - mean[i] : acc.c[i][j][r];
+                            t = second ? fmaf(d, d, t) : t + d;
+                        }
+                    t += __shfl_xor(t, 16, 64);
+                    t += __shfl_xor(t, 32, 64);
+                    if (g == 0) stats[wc * GW_BM + wr * 64 + 16 * i + l15] = t;
                 }
                 __syncthreads();
                 if (tid < GW_BM) {
@@ -265,109 +261,76 @@ gemm_wide_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ W,
             };
             reduce_rows(false);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) mean[i] = *reinterpret_cast<const sh_f32x4v*>(rowstat + wr * 64 + 16 * i + 4 * g);
+            for (int i = 0; i < 4; ++i) mean[i] = rowstat[wr * 64 + 16 * i + l15];
             reduce_rows(true);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const sh_f32x4v inv = *reinterpret_cast<const sh_f32x4v*>(rowstat + wr * 64 + 16 * i + 4 * g);
-#pragma unroll
-                for (int j = 0; j < 6; ++j) acc.c[i][j] = (acc.c[i][j] - mean[i]) * inv;
-            }
+            const size_t nchunks = GW_BN / 32;
 #pragma unroll
             for (int j = 0; j < 6; ++j) {
-                const float gj = ln_g[wc * 96 + 16 * j + l15], tj = ln_b[wc * 96 + 16 * j + l15];
+                const sh_f32x4 gv = *reinterpret_cast<const sh_f32x4*>(ln_g + wc * 96 + 16 * j + 4 * g);
+                const sh_f32x4 tv = *reinterpret_cast<const sh_f32x4*>(ln_b + wc * 96 + 16 * j + 4 * g);
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < 4; ++i) {
+                    const uint32_t m = wr * 64 + 16 * i + l15;
+                    const float inv = rowstat[m];
+                    sh_f32x4 y;
+                    f16x4 hi, lo;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) acc.c[i][j][r] = fmaf(acc.c[i][j][r], gj, tj);
+                    for (int r = 0; r < 4; ++r) {
+                        y[r] = (acc.c[i][j][r] - mean[i]) * inv * gv[r] + tv[r];
+                        _Float16 a, b;
+                        ovf |= sh_split(y[r], a, b);
+                        hi[r] = a; lo[r] = b;
+                    }
+                    if (full || m0 + m < M) {
+                        const uint32_t col = wc * 96 + 16 * j + 4 * g;
+                        *reinterpret_cast<sh_f32x4*>(C + (size_t)(m0 + m) * GW_BN + col) = y;
+                        _Float16* dst = Cs + ((size_t)(m0 + m) * nchunks + (col >> 5)) * 64 + (col & 31);
+                        *reinterpret_cast<f16x4*>(dst) = hi;
+                        *reinterpret_cast<f16x4*>(dst + 32) = lo;
+                    }
+                }
             }
-        }
-#pragma unroll 1
-        for (int p = 0; p < 3; ++p) {
+        } else if (EPI == SH_OUT_SPLIT || EPI == SH_OUT_SPLIT_GELU) {
+            const size_t nchunks = N / 32;
 #pragma unroll
             for (int j = 0; j < 6; ++j) {
-                const int col = wc * 96 + 16 * j;
-                if ((col >> 7) == p) {  // wave-uniform
+                const sh_f32x4 bv = *reinterpret_cast<const sh_f32x4*>(bias + cbase + 16 * j);
 #pragma unroll
-                    for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < 4; ++i) {
+                    const uint32_t m = wr * 64 + 16 * i + l15;
+                    f16x4 hi, lo;
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const int m = wr * 64 + 16 * i + 4 * g + r;  // (m >> 2) & 3 == g
-                            ctile[m * 128 + (((col & 127) + l15) ^ (g << 4))] =
-                                EPI == GW_OUT_LN ? acc.c[i][j][r] : acc.c[i][j][r] * kShLoInv;
-                        }
+                    for (int r = 0; r < 4; ++r) {
+                        const float v = fmaf(acc.c[i][j][r], kShLoInv, bv[r]);
+                        _Float16 a, b;
+                        ovf |= sh_split(EPI == SH_OUT_SPLIT_GELU ? gw_gelu(v) : v, a, b);
+                        hi[r] = a; lo[r] = b;
+                    }
+                    if (full || m0 + m < M) {
+                        const uint32_t col = cbase + 16 * j;
+                        _Float16* dst = Cs + ((size_t)(m0 + m) * nchunks + (col >> 5)) * 64 + (col & 31);
+                        __builtin_nontemporal_store(hi, reinterpret_cast<f16x4*>(dst));
+                        __builtin_nontemporal_store(lo, reinterpret_cast<f16x4*>(dst + 32));
+                    }
                 }
             }
-            __syncthreads();
-            const uint32_t nbase = n0 + 128 * p;
-            if (EPI == GW_OUT_LN) {
-                const int c8 = tid & 15;  // 8 consecutive n per thread: two 16-B f32 stores, one 16-B store per f16 plane
-                const size_t nchunks = GW_BN / 32;
+        } else {
 #pragma unroll
-                for (int it = 0; it < 4; ++it) {
-                    const int row = (tid >> 4) + 32 * it;
-                    const int pc = (c8 * 8) ^ (((row >> 2) & 3) << 4);
-                    const sh_f32x4 v0 = *reinterpret_cast<const sh_f32x4*>(ctile + row * 128 + pc);
-                    const sh_f32x4 v1 = *reinterpret_cast<const sh_f32x4*>(ctile + row * 128 + pc + 4);
-                    f16x8 hi, lo;
+            for (int j = 0; j < 6; ++j) {
+                const sh_f32x4 bv = *reinterpret_cast<const sh_f32x4*>(bias + cbase + 16 * j);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        _Float16 a, b;
-                        ovf |= sh_split(v0[e], a, b); hi[e] = a; lo[e] = b;
-                        ovf |= sh_split(v1[e], a, b); hi[4 + e] = a; lo[4 + e] = b;
-                    }
-                    if (full || m0 + row < M) {
-                        float* xd = C + (size_t)(m0 + row) * GW_BN + nbase + c8 * 8;
-                        *reinterpret_cast<sh_f32x4*>(xd) = v0;
-                        *reinterpret_cast<sh_f32x4*>(xd + 4) = v1;
-                        _Float16* dst = Cs + ((size_t)(m0 + row) * nchunks + (nbase >> 5) + (c8 >> 2)) * 64 + (c8 & 3) * 8;
-                        *reinterpret_cast<f16x8*>(dst) = hi;
-                        *reinterpret_cast<f16x8*>(dst + 32) = lo;
-                    }
-                }
-            } else if (EPI == SH_OUT_SPLIT || EPI == SH_OUT_SPLIT_GELU) {
-                const int c8 = tid & 15;  // 8 consecutive n per thread
-                const sh_f32x4 b0 = *reinterpret_cast<const sh_f32x4*>(bias + nbase + c8 * 8);
-                const sh_f32x4 b1 = *reinterpret_cast<const sh_f32x4*>(bias + nbase + c8 * 8 + 4);
-                const size_t nchunks = N / 32;
+                for (int i = 0; i < 4; ++i) {
+                    const uint32_t m = wr * 64 + 16 * i + l15;
+                    if (full || m0 + m < M) {
+                        const size_t o = (size_t)(m0 + m) * N + cbase + 16 * j;
+                        sh_f32x4 v;
 #pragma unroll
-                for (int it = 0; it < 4; ++it) {
-                    const int row = (tid >> 4) + 32 * it;
-                    const int pc = (c8 * 8) ^ (((row >> 2) & 3) << 4);
-                    const sh_f32x4 v0 = *reinterpret_cast<const sh_f32x4*>(ctile + row * 128 + pc);
-                    const sh_f32x4 v1 = *reinterpret_cast<const sh_f32x4*>(ctile + row * 128 + pc + 4);
-                    f16x8 hi, lo;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        _Float16 a, b;
-                        ovf |= sh_split(EPI == SH_OUT_SPLIT_GELU ? gw_gelu(v0[e] + b0[e]) : v0[e] + b0[e], a, b);
-                        hi[e] = a; lo[e] = b;
-                        ovf |= sh_split(EPI == SH_OUT_SPLIT_GELU ? gw_gelu(v1[e] + b1[e]) : v1[e] + b1[e], a, b);
-                        hi[4 + e] = a; lo[4 + e] = b;
-                    }
-                    if (full || m0 + row < M) {
-                        _Float16* dst = Cs + ((size_t)(m0 + row) * nchunks + (nbase >> 5) + (c8 >> 2)) * 64 + (c8 & 3) * 8;
-                        __builtin_nontemporal_store(hi, reinterpret_cast<f16x8*>(dst));
-                        __builtin_nontemporal_store(lo, reinterpret_cast<f16x8*>(dst + 32));
-                    }
-                }
-            } else {
-                const int c4 = tid & 31;  // 4 consecutive n per thread
-                const sh_f32x4 bv = *reinterpret_cast<const sh_f32x4*>(bias + nbase + c4 * 4);
-#pragma unroll
-                for (int it = 0; it < 8; ++it) {
-                    const int row = (tid >> 5) + 16 * it;
-                    const int pc = (c4 * 4) ^ (((row >> 2) & 3) << 4);
-                    sh_f32x4 v = *reinterpret_cast<const sh_f32x4*>(ctile + row * 128 + pc);
-                    v += bv;
-                    if (full || m0 + row < M) {
-                        const size_t o = (size_t)(m0 + row) * N + nbase + c4 * 4;
+                        for (int r = 0; r < 4; ++r) v[r] = fmaf(acc.c[i][j][r], kShLoInv, bv[r]);
                         if (EPI == SH_OUT_F32_RESID) v += *reinterpret_cast<const sh_f32x4*>(resid + o);
                         *reinterpret_cast<sh_f32x4*>(C + o) = v;
                     }
                 }
             }
-            __syncthreads();  // the pass has been read: the buffer takes the next one (or the next tile's stages)
         }
         if (ovf && flag) atomicOr(flag, 1u);
         buf = ebuf ^ 1;
