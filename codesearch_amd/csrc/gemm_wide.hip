@@ -22,8 +22,9 @@
 // kernel is persistent (one block per CU): the first stage of a block's NEXT tile is in flight while the current
 // tile's epilogue runs, in the stage buffer the epilogue does not use.
 // LDS: two stages of 64 KiB.  The MFMAs take the weight fragment as their FIRST operand, so the accumulator of a
-// 16 x 16 tile holds four consecutive columns of one row per lane and the epilogue stores straight from registers
-// (16 B of f32 or 8 B per f16 plane per lane): no LDS pass, no barrier.
+// 16 x 16 tile holds four consecutive columns of one row per lane, and a wave's 64 x 96 tile is whole 128-byte
+// output lines: each wave finishes its own rows through a private 6.4 KB patch of the free stage buffer — no block
+// barrier in the epilogue (the staged three-pass epilogue this replaces cost a quarter of a tile's time).
 #include <cstdlib>
 
 #include "encoder.hpp"
@@ -218,21 +219,26 @@ gemm_wide_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ W,
             for (int p = 0; p < 8; ++p) dma(src, p, sh_kc_rot(nnt, ntiles, kchunks), (ebuf ^ 1) * GW_STAGE);
         }
 
-        // ---- epilogue: straight from the accumulator registers ------------------------------------------------------
+        // ---- epilogue: per wave, through a private LDS patch — no block barrier ------------------------------------
         // The MFMAs take the WEIGHT fragment as their first operand, so a lane holds, per 16 x 16 tile, FOUR CONSECUTIVE
-        // COLUMNS n = 16 j + 4 g + r of ONE ROW m = 16 i + l15: 16 bytes of f32, or 8 bytes of each f16 plane of the
-        // split form — stored directly, no LDS pass, no barrier (the three staged passes this replaces cost a
-        // quarter of a tile's time: nothing overlaps them at one block per CU).
+        // COLUMNS n = 16 j + 4 g + r of ONE ROW m = 16 i + l15.  A wave's 64 x 96 tile is whole 128-byte lines of the
+        // output (96 columns = three 32-column chunks of the split form, or three lines of f32), so each wave finishes
+        // its own rows alone: per strip of 16 rows it writes its values into a private 6.4 KB patch of the free stage
+        // buffer (ds_write_b128, rows padded to 400 B: conflict-free) and reads them back in line order, 8 consecutive
+        // columns per lane, so every global store is 16 B per lane on consecutive lanes of a line.  (Storing straight
+        // from the accumulators, 8 B per lane and plane, was measured: 2.4x slower — partial-line writes.)
         const bool full = m0 + GW_BM <= M;
         bool ovf = false;
         const uint32_t cbase = n0 + wc * 96 + 4 * g;  // first column of this lane in tile j = 0
+        float* patch = reinterpret_cast<float*>(lds + ebuf * GW_STAGE + wave * 8192);  // [16 rows][100 floats]
+        constexpr int PS = 100;
+        float mean[4] = {0.f, 0.f, 0.f, 0.f};
+        float* rowstat = reinterpret_cast<float*>(lds + 2 * GW_STAGE) + 4 * GW_BM;
         if (EPI == GW_OUT_LN) {
             // One n-tile = whole rows: v = acc / 2^11 (bias and residual are in there), then LayerNorm over the 384
             // columns (two passes like encoder.hip ln_row).  A row's columns sit in 4 waves (wc) x 6 tiles x 4 lanes (g).
             constexpr float invN = 1.0f / (float)GW_BN;
             float* stats = reinterpret_cast<float*>(lds + 2 * GW_STAGE);  // [4][128] partial sums, [128] row statistic
-            float* rowstat = stats + 4 * GW_BM;
-            float mean[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -263,74 +269,82 @@ gemm_wide_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ W,
 #pragma unroll
             for (int i = 0; i < 4; ++i) mean[i] = rowstat[wr * 64 + 16 * i + l15];
             reduce_rows(true);
-            const size_t nchunks = GW_BN / 32;
+        }
+        sh_f32x4 bv[6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j)
+            if (EPI != GW_OUT_LN) bv[j] = *reinterpret_cast<const sh_f32x4*>(bias + cbase + 16 * j);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            // final values of strip i into the patch (row l15, columns 16 j + 4 g .. + 3)
+            float inv = 1.0f;
+            if (EPI == GW_OUT_LN) inv = rowstat[wr * 64 + 16 * i + l15];
 #pragma unroll
             for (int j = 0; j < 6; ++j) {
-                const sh_f32x4 gv = *reinterpret_cast<const sh_f32x4*>(ln_g + wc * 96 + 16 * j + 4 * g);
-                const sh_f32x4 tv = *reinterpret_cast<const sh_f32x4*>(ln_b + wc * 96 + 16 * j + 4 * g);
+                sh_f32x4 v;
+                if (EPI == GW_OUT_LN) {
+                    // gamma / beta re-read per strip (volatile: not hoisted out of the strip loop — 48 registers the
+                    // accumulators need); they sit in L1
+                    const sh_f32x4 gj = *reinterpret_cast<const volatile sh_f32x4*>(ln_g + wc * 96 + 16 * j + 4 * g);
+                    const sh_f32x4 bj = *reinterpret_cast<const volatile sh_f32x4*>(ln_b + wc * 96 + 16 * j + 4 * g);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const uint32_t m = wr * 64 + 16 * i + l15;
-                    const float inv = rowstat[m];
-                    sh_f32x4 y;
-                    f16x4 hi, lo;
+                    for (int r = 0; r < 4; ++r) v[r] = (acc.c[i][j][r] - mean[i]) * inv * gj[r] + bj[r];
+                } else {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        y[r] = (acc.c[i][j][r] - mean[i]) * inv * gv[r] + tv[r];
+                        v[r] = fmaf(acc.c[i][j][r], kShLoInv, bv[j][r]);
+                        if (EPI == SH_OUT_SPLIT_GELU) v[r] = gw_gelu(v[r]);
+                    }
+                }
+                *reinterpret_cast<sh_f32x4*>(patch + l15 * PS + 16 * j + 4 * g) = v;
+            }
+            // wave-local: the writes above are visible to this wave's reads below once lgkmcnt drains
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            // 16 rows x 12 pieces of 8 columns = 192 pieces, three per lane
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                const int pidx = lane + 64 * t;
+                const int prow = pidx / 12, q = pidx - prow * 12;  // row of the strip, 8-column piece of the 96
+                const sh_f32x4 v0 = *reinterpret_cast<const sh_f32x4*>(patch + prow * PS + q * 8);
+                const sh_f32x4 v1 = *reinterpret_cast<const sh_f32x4*>(patch + prow * PS + q * 8 + 4);
+                const uint32_t m = wr * 64 + 16 * i + prow;
+                const uint32_t col = n0 + wc * 96 + q * 8;
+                const bool live = full || m0 + m < M;
+                if (EPI == SH_OUT_F32 || EPI == SH_OUT_F32_RESID || EPI == GW_OUT_LN) {
+                    if (live) {
+                        float* o = C + (size_t)(m0 + m) * N + col;
+                        sh_f32x4 o0 = v0, o1 = v1;
+                        if (EPI == SH_OUT_F32_RESID) {
+                            o0 += *reinterpret_cast<const sh_f32x4*>(resid + (size_t)(m0 + m) * N + col);
+                            o1 += *reinterpret_cast<const sh_f32x4*>(resid + (size_t)(m0 + m) * N + col + 4);
+                        }
+                        *reinterpret_cast<sh_f32x4*>(o) = o0;
+                        *reinterpret_cast<sh_f32x4*>(o + 4) = o1;
+                    }
+                }
+                if (EPI == SH_OUT_SPLIT || EPI == SH_OUT_SPLIT_GELU || EPI == GW_OUT_LN) {
+                    f16x8 hi, lo;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
                         _Float16 a, b;
-                        ovf |= sh_split(y[r], a, b);
-                        hi[r] = a; lo[r] = b;
+                        ovf |= sh_split(v0[e], a, b); hi[e] = a; lo[e] = b;
+                        ovf |= sh_split(v1[e], a, b); hi[4 + e] = a; lo[4 + e] = b;
                     }
-                    if (full || m0 + m < M) {
-                        const uint32_t col = wc * 96 + 16 * j + 4 * g;
-                        *reinterpret_cast<sh_f32x4*>(C + (size_t)(m0 + m) * GW_BN + col) = y;
-                        _Float16* dst = Cs + ((size_t)(m0 + m) * nchunks + (col >> 5)) * 64 + (col & 31);
-                        *reinterpret_cast<f16x4*>(dst) = hi;
-                        *reinterpret_cast<f16x4*>(dst + 32) = lo;
-                    }
-                }
-            }
-        } else if (EPI == SH_OUT_SPLIT || EPI == SH_OUT_SPLIT_GELU) {
-            const size_t nchunks = N / 32;
-#pragma unroll
-            for (int j = 0; j < 6; ++j) {
-                const sh_f32x4 bv = *reinterpret_cast<const sh_f32x4*>(bias + cbase + 16 * j);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const uint32_t m = wr * 64 + 16 * i + l15;
-                    f16x4 hi, lo;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float v = fmaf(acc.c[i][j][r], kShLoInv, bv[r]);
-                        _Float16 a, b;
-                        ovf |= sh_split(EPI == SH_OUT_SPLIT_GELU ? gw_gelu(v) : v, a, b);
-                        hi[r] = a; lo[r] = b;
-                    }
-                    if (full || m0 + m < M) {
-                        const uint32_t col = cbase + 16 * j;
-                        _Float16* dst = Cs + ((size_t)(m0 + m) * nchunks + (col >> 5)) * 64 + (col & 31);
-                        __builtin_nontemporal_store(hi, reinterpret_cast<f16x4*>(dst));
-                        __builtin_nontemporal_store(lo, reinterpret_cast<f16x4*>(dst + 32));
+                    if (live) {
+                        _Float16* dst = Cs + ((size_t)(m0 + m) * (N / 32) + (col >> 5)) * 64 + (col & 31);
+                        if (EPI == GW_OUT_LN) {  // the next GEMM reads it from L2 / MALL: default policy
+                            *reinterpret_cast<f16x8*>(dst) = hi;
+                            *reinterpret_cast<f16x8*>(dst + 32) = lo;
+                        } else {
+                            __builtin_nontemporal_store(hi, reinterpret_cast<f16x8*>(dst));
+                            __builtin_nontemporal_store(lo, reinterpret_cast<f16x8*>(dst + 32));
+                        }
                     }
                 }
             }
-        } else {
-#pragma unroll
-            for (int j = 0; j < 6; ++j) {
-                const sh_f32x4 bv = *reinterpret_cast<const sh_f32x4*>(bias + cbase + 16 * j);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const uint32_t m = wr * 64 + 16 * i + l15;
-                    if (full || m0 + m < M) {
-                        const size_t o = (size_t)(m0 + m) * N + cbase + 16 * j;
-                        sh_f32x4 v;
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] = fmaf(acc.c[i][j][r], kShLoInv, bv[r]);
-                        if (EPI == SH_OUT_F32_RESID) v += *reinterpret_cast<const sh_f32x4*>(resid + o);
-                        *reinterpret_cast<sh_f32x4*>(C + o) = v;
-                    }
-                }
-            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            __builtin_amdgcn_wave_barrier();  // the patch is rewritten by the next strip
         }
         if (ovf && flag) atomicOr(flag, 1u);
         buf = ebuf ^ 1;
