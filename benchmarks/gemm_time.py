@@ -23,13 +23,15 @@ def main():
 
     shapes = [("qkv      (N=1152, K=384,  bias -> split)", 4, 1152, 384), ("ffn_up   (N=1536, K=384,  GELU -> split)", 1, 1536, 384),
               ("out_proj (N=384,  K=384,  + resid f32)", 2, 384, 384), ("ffn_down (N=384,  K=1536, + resid f32)", 2, 384, 1536)]
+    shape = os.environ.get("CS_GEMM_WIDE_SHAPE", "192")
     for name, epi, N, K in shapes:
         tf = 3 * 2.0 * M * N * K / 1e12
         a, b = t(1, epi, N, K), t(2, epi, N, K)
-        print(f"{name}: 128x128 {a:7.1f} us ({tf / a * 1e6:6.0f} TF/s executed)   wide {b:7.1f} us ({tf / b * 1e6:6.0f} TF/s)", flush=True)
+        print(f"{name}: 128x128 {a:7.1f} us ({tf / a * 1e6:6.0f} TF/s executed)   wide(128x{shape}) {b:7.1f} us ({tf / b * 1e6:6.0f} TF/s)", flush=True)
     for K in (384, 1536):
         print(f"N=384 K={K} LayerNorm-fused wide: {t(2, 3, 384, K):7.1f} us", flush=True)
-    for name, abl in (("full", 0), ("no LDS-DMA", 1), ("no MFMA", 2), ("DMAs at step start", 3)):
+    for name, abl in (("full", 0), ("no LDS-DMA", 1), ("no MFMA", 2), ("DMAs at step start", 3), ("no DMA, no barrier", 4),
+                      ("no DMA/barrier/LDS reads", 5), ("no DMA, no epilogue", 6)):
         print(f"wide qkv ablation {name:20s}: {t(2, 4, 1152, 384, abl):7.1f} us", flush=True)
 
 

@@ -34,11 +34,22 @@ namespace cs {
 
 constexpr int GW_BM = 128, GW_BN = 384;
 constexpr int GW_A_BYTES = GW_BM * 128;            // one k-chunk (32 k, hi + lo) of 128 A rows
-constexpr int GW_W_BYTES = GW_BN * 128;            // ... of 384 W rows
-constexpr int GW_STAGE = GW_A_BYTES + GW_W_BYTES;  // 65,536
 constexpr int GW_STATS = 5 * GW_BM * 4;            // LayerNorm epilogue: [4 column groups][128 rows] f32 partial sums + [128] row statistic
-constexpr int GW_LDS = 2 * GW_STAGE + GW_STATS;    // 135,168
-constexpr int GW_THREADS = 512;
+// Two block shapes share the kernel: WCN = 4 column waves -> 8 waves, 128 x 384 outputs, one block per CU (whole rows
+// at N = 384: the LayerNorm epilogue); WCN = 2 -> 4 waves, 128 x 192 outputs, 80 KiB of LDS, TWO blocks per CU, so
+// one block's epilogue (VALU conversions + stores) runs under the other's MFMAs.
+template <int WCN>
+struct GwGeom {
+    static constexpr int BN = 96 * WCN;
+    static constexpr int WAVES = 2 * WCN;
+    static constexpr int THREADS = 64 * WAVES;
+    static constexpr int W_BYTES = BN * 128;
+    static constexpr int STAGE = GW_A_BYTES + W_BYTES;           // 65,536 | 40,960
+    static constexpr int LDS = 2 * STAGE + (WCN == 4 ? GW_STATS : 0);
+    static constexpr int A_PIECES = 16 / WAVES;                  // LDS-DMA pieces (8 rows x 128 B) of A per wave and stage: 2 | 4
+    static constexpr int W_PIECES = (BN / 8) / WAVES;            // ... of W: 6
+    static constexpr int PIECES = A_PIECES + W_PIECES;           // 8 | 10
+};
 constexpr int GW_OUT_LN = 16;  // epilogue: + bias + residual, LayerNorm over the 384 columns, store f32 AND split form
 
 namespace {
@@ -63,26 +74,31 @@ __device__ __forceinline__ float gw_gelu(float v) { return 0.5f * v * (1.0f + gw
 struct GwAcc { sh_f32x4v c[4][6]; };
 
 // this wave's eight LDS-DMA pieces of a stage: p = 0, 1 -> A rows, p = 2..7 -> W rows
+template <int WCN>
 struct GwSrc {  // element offsets from A / W (32 bits: a [65536, 1536] operand is 2^27.6 elements)
-    uint32_t a[2];
-    uint32_t w[6];
+    uint32_t a[GwGeom<WCN>::A_PIECES];
+    uint32_t w[GwGeom<WCN>::W_PIECES];
 };
 
 }  // namespace
 
 // ABL (diagnostics, cs_debug_gemm_time): 0 = the product kernel; 1 = no LDS-DMA after a tile's first stage (the MFMA +
 // LDS-read ceiling); 2 = no MFMA (fill + LDS reads only); 3 = the eight DMAs of a stage issued back to back at the
-// start of the step instead of between the MFMA groups.
-template <int EPI, int ABL = 0>
-__global__ void __launch_bounds__(GW_THREADS, 2)
+// start of the step instead of between the MFMA groups; 4 = 1 without the k-step barrier; 5 = 4 with the fragment
+// reads hoisted out of the k loop (the pure MFMA rate); 6 = 1 without the epilogue's stores.
+template <int EPI, int ABL = 0, int WCN = 4>
+__global__ void __launch_bounds__(GwGeom<WCN>::THREADS, 2)
 gemm_wide_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ W, const float* __restrict__ bias,
                  const float* resid, float* C, _Float16* __restrict__ Cs, uint32_t M, uint32_t N, uint32_t kchunks,
                  uint32_t* __restrict__ flag, uint32_t total_slots, const float* __restrict__ ln_g,
-                 const float* __restrict__ ln_b, float ln_eps) {
+                 const float* __restrict__ ln_b, float ln_eps, uint32_t stagger_cycles) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
+    using G = GwGeom<WCN>;
+    static_assert(EPI != GW_OUT_LN || WCN == 4, "the LayerNorm epilogue needs whole rows in one block");
+    constexpr int GW_BN = G::BN, GW_STAGE = G::STAGE, AP = G::A_PIECES, WP = G::W_PIECES, NP = G::PIECES;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave >> 2, wc = wave & 3;
+    const int wr = wave / WCN, wc = wave % WCN;
     const int l15 = lane & 15, g = lane >> 4;
     const uint32_t mtiles = (M + GW_BM - 1) / GW_BM, ntiles = N / GW_BN;
 
@@ -93,21 +109,21 @@ gemm_wide_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ W,
         const int c = (lane & 7) ^ ((row_in_tile >> 1) & 7);
         return grow * kchunks * 64 + c * 8;
     };
-    auto tile_src = [&](uint32_t m0, uint32_t n0, GwSrc& s) {
+    auto tile_src = [&](uint32_t m0, uint32_t n0, GwSrc<WCN>& s) {
 #pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            const uint32_t r = (wave * 2 + p) * 8 + drow;
+        for (int p = 0; p < AP; ++p) {
+            const uint32_t r = (wave * AP + p) * 8 + drow;
             s.a[p] = src_of(r, (m0 + r < M) ? m0 + r : M - 1);  // rows past M re-read row M-1 (never stored)
         }
 #pragma unroll
-        for (int p = 0; p < 6; ++p) {
-            const uint32_t r = (wave * 6 + p) * 8 + drow;
+        for (int p = 0; p < WP; ++p) {
+            const uint32_t r = (wave * WP + p) * 8 + drow;
             s.w[p] = src_of(r, n0 + r);
         }
     };
-    auto dma = [&](const GwSrc& s, int p, uint32_t kc, uint32_t bufoff) {
-        if (p < 2) sh_glds16(A + (s.a[p] + kc * 64), lds + bufoff + (wave * 2 + p) * 1024);
-        else sh_glds16(W + (s.w[p - 2] + kc * 64), lds + bufoff + GW_A_BYTES + (wave * 6 + (p - 2)) * 1024);
+    auto dma = [&](const GwSrc<WCN>& s, int p, uint32_t kc, uint32_t bufoff) {
+        if (p < AP) sh_glds16(A + (s.a[p < AP ? p : 0] + kc * 64), lds + bufoff + (wave * AP + p) * 1024);
+        else sh_glds16(W + (s.w[p >= AP ? p - AP : 0] + kc * 64), lds + bufoff + GW_A_BYTES + (wave * WP + (p - AP)) * 1024);
     };
 
     const int swz = (l15 >> 1) & 7;
@@ -123,12 +139,23 @@ gemm_wide_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ W,
     uint32_t mt = 0, nt = 0;
     uint32_t slot = next_valid(blockIdx.x, mt, nt);
     if (slot >= total_slots) return;
-    GwSrc src;
+    GwSrc<WCN> src;
     tile_src(mt * GW_BM, nt * GW_BN, src);
     uint32_t buf = 0;  // stage buffer (0 | 1) that holds stage 0 of the current tile
 #pragma unroll
-    for (int p = 0; p < 8; ++p) dma(src, p, sh_kc_rot(nt, ntiles, kchunks), 0);
+    for (int p = 0; p < NP; ++p) dma(src, p, sh_kc_rot(nt, ntiles, kchunks), 0);
 
+    // Stagger.  Every tile of a launch costs the same, so the blocks of a persistent grid stay in lockstep and their
+    // epilogues hit HBM together: 300-400 MB of split-form output written in bursts at the write roofline while no
+    // matrix pipe runs, then nothing written while they all compute (measured on the QKV shape: epilogue 63 of
+    // 172 us).  Blocks therefore start in four phases a quarter of a tile's main loop apart (neighbouring CUs of
+    // an XCD in different phases) and stay that far apart: at any moment a quarter of the chip stores while the
+    // rest computes.
+    if (stagger_cycles) {
+        const uint32_t phase = (blockIdx.x >> 3) & 3;
+        const uint64_t t0 = __builtin_amdgcn_s_memtime();
+        while (__builtin_amdgcn_s_memtime() - t0 < (uint64_t)phase * stagger_cycles) __builtin_amdgcn_s_sleep(16);
+    }
     while (slot < total_slots) {
         const uint32_t m0 = mt * GW_BM, n0 = nt * GW_BN;
         const uint32_t rot = sh_kc_rot(nt, ntiles, kchunks);  // see sh_mainloop: n-tiles of an m-tile walk K out of phase
@@ -163,6 +190,7 @@ gemm_wide_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ W,
             const bool more = kc + 1 < kchunks;
             uint32_t kn = rot + kc + 1;
             kn = kn >= kchunks ? kn - kchunks : kn;
+            if (ABL == 5) cur = lds;  // same addresses every step: the reads hoist out of the loop (pure MFMA rate)
             f16x8 ah[4], al[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -173,7 +201,7 @@ gemm_wide_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ W,
             f16x8 wl = *reinterpret_cast<const f16x8*>(cur + w_off + s_lo);
             if (ABL == 3 && more) {
 #pragma unroll
-                for (int p = 0; p < 8; ++p) dma(src, p, kn, nb);
+                for (int p = 0; p < NP; ++p) dma(src, p, kn, nb);
             }
 #pragma unroll
             for (int j = 0; j < 6; ++j) {
@@ -192,13 +220,13 @@ gemm_wide_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ W,
                 for (int i = 0; i < 4; ++i)
                     if (ABL != 2) acc.c[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(whs, ah[i], acc.c[i][j], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
-                if ((ABL == 0 || ABL == 2) && more && j < 4) dma(src, 2 * j, kn, nb);
+                if ((ABL == 0 || ABL == 2) && more && 2 * j < NP) dma(src, 2 * j, kn, nb);  // ABL 1, 4, 5, 6: no DMA
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
                     if (ABL != 2) acc.c[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, ah[i], acc.c[i][j], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
-                if ((ABL == 0 || ABL == 2) && more && j < 4) dma(src, 2 * j + 1, kn, nb);
+                if ((ABL == 0 || ABL == 2) && more && 2 * j + 1 < NP) dma(src, 2 * j + 1, kn, nb);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
@@ -206,8 +234,9 @@ gemm_wide_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ W,
                 wh = whn;
                 wl = wln;
             }
-            __syncthreads();  // stage kc+1 has landed; every wave is done reading stage kc
+            if (ABL != 4 && ABL != 5) __syncthreads();  // stage kc+1 has landed; every wave is done reading stage kc
         }
+        if (ABL == 4 || ABL == 5) __syncthreads();
 
         // next tile of this block: its first stage flies into the buffer the epilogue does not use
         const uint32_t ebuf = (buf + kchunks - 1) & 1;  // buffer of the last stage
@@ -216,7 +245,7 @@ gemm_wide_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ W,
         if (nslot < total_slots) {
             tile_src(nmt * GW_BM, nnt * GW_BN, src);
 #pragma unroll
-            for (int p = 0; p < 8; ++p) dma(src, p, sh_kc_rot(nnt, ntiles, kchunks), (ebuf ^ 1) * GW_STAGE);
+            for (int p = 0; p < NP; ++p) dma(src, p, sh_kc_rot(nnt, ntiles, kchunks), (ebuf ^ 1) * GW_STAGE);
         }
 
         // ---- epilogue: per wave, through a private LDS patch — no block barrier ------------------------------------
@@ -275,7 +304,7 @@ gemm_wide_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ W,
         for (int j = 0; j < 6; ++j)
             if (EPI != GW_OUT_LN) bv[j] = *reinterpret_cast<const sh_f32x4*>(bias + cbase + 16 * j);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < (ABL == 6 ? 0 : 4); ++i) {
             // final values of strip i into the patch (row l15, columns 16 j + 4 g .. + 3)
             float inv = 1.0f;
             if (EPI == GW_OUT_LN) inv = rowstat[wr * 64 + 16 * i + l15];
@@ -346,6 +375,12 @@ gemm_wide_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ W,
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             __builtin_amdgcn_wave_barrier();  // the patch is rewritten by the next strip
         }
+        if (ABL == 6) {  // keep the accumulators alive without storing them
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 6; ++j) asm volatile("" ::"v"(acc.c[i][j]));
+        }
         if (ovf && flag) atomicOr(flag, 1u);
         buf = ebuf ^ 1;
         slot = nslot;
@@ -379,59 +414,87 @@ int32_t sh_weights_fit_wide(const _Float16* d_wsplit, uint64_t n_f16, uint32_t* 
     return CS_OK;
 }
 
-bool gemm_wide_supported(uint32_t N, uint32_t K) { return N % GW_BN == 0 && K % 32 == 0 && N > 0 && K > 0; }
+bool gemm_wide_supported(uint32_t N, uint32_t K) { return N % 192 == 0 && K % 32 == 0 && N > 0 && K > 0; }
 
 int g_gemm_wide_ablation = 0;  // diagnostics only (cs_debug_gemm_time)
 
-static int32_t gemm_wide_impl(int epi, const _Float16* A, const _Float16* W, const float* bias, const float* resid, float* C,
-                              _Float16* Cs, uint32_t M, uint32_t N, uint32_t K, uint32_t* d_flag, hipStream_t s,
-                              const float* ln_g, const float* ln_b, float ln_eps) {
-    if (!gemm_wide_supported(N, K)) return fail(CS_ERR_UNSUPPORTED, "wide split GEMM needs N %% 384 == 0 and K %% 32 == 0 (N=%u K=%u)", N, K);
-    if (M == 0) return CS_OK;
+template <int WCN>
+static int32_t gemm_wide_launch(int epi, const _Float16* A, const _Float16* W, const float* bias, const float* resid, float* C,
+                                _Float16* Cs, uint32_t M, uint32_t N, uint32_t K, uint32_t* d_flag, hipStream_t s,
+                                const float* ln_g, const float* ln_b, float ln_eps) {
+    using G = GwGeom<WCN>;
     static bool attr_set = false;
     static int cus = 256;
     if (!attr_set) {
-        CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wide_kernel<SH_OUT_F32>), hipFuncAttributeMaxDynamicSharedMemorySize, GW_LDS));
-        CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wide_kernel<SH_OUT_F32_RESID>), hipFuncAttributeMaxDynamicSharedMemorySize, GW_LDS));
-        CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wide_kernel<SH_OUT_SPLIT_GELU>), hipFuncAttributeMaxDynamicSharedMemorySize, GW_LDS));
-        CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wide_kernel<SH_OUT_SPLIT>), hipFuncAttributeMaxDynamicSharedMemorySize, GW_LDS));
-        CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wide_kernel<GW_OUT_LN>), hipFuncAttributeMaxDynamicSharedMemorySize, GW_LDS));
+        CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wide_kernel<SH_OUT_F32, 0, WCN>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
+        CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wide_kernel<SH_OUT_F32_RESID, 0, WCN>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
+        CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wide_kernel<SH_OUT_SPLIT_GELU, 0, WCN>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
+        CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wide_kernel<SH_OUT_SPLIT, 0, WCN>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
+        if constexpr (WCN == 4)
+            CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wide_kernel<GW_OUT_LN, 0, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
         int dev = 0, n = 0;
         if (hipGetDevice(&dev) == hipSuccess &&
             hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n >= 8)
             cus = n / 8 * 8;  // whole XCD octets: slot -> XCD mapping survives the persistent stride
         attr_set = true;
     }
-    const uint32_t mtiles = (M + GW_BM - 1) / GW_BM, ntiles = N / GW_BN;
+    const uint32_t mtiles = (M + GW_BM - 1) / GW_BM, ntiles = N / G::BN;
     const uint32_t slots = sh_grid_blocks(mtiles, ntiles);
-    const uint32_t grid = slots < (uint32_t)cus ? slots : (uint32_t)cus;
+    const uint32_t resident = (uint32_t)cus * (WCN == 4 ? 1u : 2u);  // persistent grid: every block resident
+    const uint32_t grid = slots < resident ? slots : resident;
     const uint32_t kc = K / 32;
-#define GW_LAUNCH(E) hipLaunchKernelGGL(gemm_wide_kernel<E>, dim3(grid), dim3(GW_THREADS), GW_LDS, s, A, W, bias, resid, C, Cs, M, N, kc, d_flag, slots, ln_g, ln_b, ln_eps)
-    if (g_gemm_wide_ablation && epi == SH_OUT_SPLIT) {
-        static bool abl_attr = false;
-        if (!abl_attr) {
-            CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wide_kernel<SH_OUT_SPLIT, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, GW_LDS));
-            CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wide_kernel<SH_OUT_SPLIT, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, GW_LDS));
-            CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wide_kernel<SH_OUT_SPLIT, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, GW_LDS));
-            abl_attr = true;
+    // a quarter of a tile's main loop in shader cycles; 0 = off (measured: no gain, kept for A/B)
+    static const int stagger_env = [] { const char* e = std::getenv("CS_GEMM_WIDE_STAGGER"); return e ? std::atoi(e) : 0; }();
+    const uint32_t stagger = (slots >= 2 * grid && stagger_env > 0) ? kc * (uint32_t)stagger_env : 0u;
+#define GW_LAUNCH(E, V) hipLaunchKernelGGL((gemm_wide_kernel<E, V, WCN>), dim3(grid), dim3(G::THREADS), G::LDS, s, A, W, bias, resid, C, Cs, M, N, kc, d_flag, slots, ln_g, ln_b, ln_eps, stagger)
+    if constexpr (WCN == 4) {
+        if (g_gemm_wide_ablation && epi == SH_OUT_SPLIT) {
+            static bool abl_attr = false;
+            if (!abl_attr) {
+                CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wide_kernel<SH_OUT_SPLIT, 1, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
+                CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wide_kernel<SH_OUT_SPLIT, 2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
+                CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wide_kernel<SH_OUT_SPLIT, 3, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
+                CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wide_kernel<SH_OUT_SPLIT, 4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
+                CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wide_kernel<SH_OUT_SPLIT, 5, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
+                CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wide_kernel<SH_OUT_SPLIT, 6, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
+                abl_attr = true;
+            }
+            switch (g_gemm_wide_ablation) {
+                case 1: GW_LAUNCH(SH_OUT_SPLIT, 1); break;
+                case 2: GW_LAUNCH(SH_OUT_SPLIT, 2); break;
+                case 4: GW_LAUNCH(SH_OUT_SPLIT, 4); break;
+                case 5: GW_LAUNCH(SH_OUT_SPLIT, 5); break;
+                case 6: GW_LAUNCH(SH_OUT_SPLIT, 6); break;
+                default: GW_LAUNCH(SH_OUT_SPLIT, 3); break;
+            }
+            CS_HIP(hipGetLastError());
+            return CS_OK;
         }
-#define GW_LAUNCH_ABL(V) hipLaunchKernelGGL((gemm_wide_kernel<SH_OUT_SPLIT, V>), dim3(grid), dim3(GW_THREADS), GW_LDS, s, A, W, bias, resid, C, Cs, M, N, kc, d_flag, slots, ln_g, ln_b, ln_eps)
-        if (g_gemm_wide_ablation == 1) GW_LAUNCH_ABL(1);
-        else if (g_gemm_wide_ablation == 2) GW_LAUNCH_ABL(2);
-        else GW_LAUNCH_ABL(3);
-#undef GW_LAUNCH_ABL
-        CS_HIP(hipGetLastError());
-        return CS_OK;
     }
-    if (epi == SH_OUT_F32) GW_LAUNCH(SH_OUT_F32);
-    else if (epi == SH_OUT_F32_RESID) GW_LAUNCH(SH_OUT_F32_RESID);
-    else if (epi == SH_OUT_SPLIT) GW_LAUNCH(SH_OUT_SPLIT);
-    else if (epi == SH_OUT_SPLIT_GELU) GW_LAUNCH(SH_OUT_SPLIT_GELU);
-    else if (epi == GW_OUT_LN) GW_LAUNCH(GW_OUT_LN);
-    else return fail(CS_ERR_BAD_ARG, "unknown epilogue %d", epi);
+    if (epi == SH_OUT_F32) GW_LAUNCH(SH_OUT_F32, 0);
+    else if (epi == SH_OUT_F32_RESID) GW_LAUNCH(SH_OUT_F32_RESID, 0);
+    else if (epi == SH_OUT_SPLIT) GW_LAUNCH(SH_OUT_SPLIT, 0);
+    else if (epi == SH_OUT_SPLIT_GELU) GW_LAUNCH(SH_OUT_SPLIT_GELU, 0);
+    else if (epi == GW_OUT_LN) {
+        if constexpr (WCN == 4) GW_LAUNCH(GW_OUT_LN, 0);
+        else return fail(CS_ERR_BAD_ARG, "the LayerNorm epilogue needs the 128 x 384 block");
+    } else return fail(CS_ERR_BAD_ARG, "unknown epilogue %d", epi);
 #undef GW_LAUNCH
     CS_HIP(hipGetLastError());
     return CS_OK;
+}
+
+// Block shape: 128 x 384 / one block per CU when asked for (LayerNorm epilogue; CS_GEMM_WIDE_SHAPE=384), else
+// 128 x 192 / two blocks per CU.
+static int32_t gemm_wide_impl(int epi, const _Float16* A, const _Float16* W, const float* bias, const float* resid, float* C,
+                              _Float16* Cs, uint32_t M, uint32_t N, uint32_t K, uint32_t* d_flag, hipStream_t s,
+                              const float* ln_g, const float* ln_b, float ln_eps) {
+    if (!gemm_wide_supported(N, K)) return fail(CS_ERR_UNSUPPORTED, "wide split GEMM needs N %% 192 == 0 and K %% 32 == 0 (N=%u K=%u)", N, K);
+    if (M == 0) return CS_OK;
+    static const int shape_env = [] { const char* e = std::getenv("CS_GEMM_WIDE_SHAPE"); return e ? std::atoi(e) : 192; }();
+    const bool big = epi == GW_OUT_LN || g_gemm_wide_ablation || (shape_env == 384 && N % 384 == 0);
+    if (big) return gemm_wide_launch<4>(epi, A, W, bias, resid, C, Cs, M, N, K, d_flag, s, ln_g, ln_b, ln_eps);
+    return gemm_wide_launch<2>(epi, A, W, bias, resid, C, Cs, M, N, K, d_flag, s, ln_g, ln_b, ln_eps);
 }
 
 int32_t launch_gemm_wide(int epi, const _Float16* A, const _Float16* W, const float* bias, const float* resid, float* C,
