@@ -145,16 +145,14 @@ gemm_wide_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ W,
 #pragma unroll
     for (int p = 0; p < NP; ++p) dma(src, p, sh_kc_rot(nt, ntiles, kchunks), 0);
 
-    // Stagger.  Every tile of a launch costs the same, so the blocks of a persistent grid stay in lockstep and their
-    // epilogues hit HBM together: 300-400 MB of split-form output written in bursts at the write roofline while no
-    // matrix pipe runs, then nothing written while they all compute (measured on the QKV shape: epilogue 63 of
-    // 172 us).  Blocks therefore start in four phases a quarter of a tile's main loop apart (neighbouring CUs of
-    // an XCD in different phases) and stay that far apart: at any moment a quarter of the chip stores while the
-    // rest computes.
-    if (stagger_cycles) {
-        const uint32_t phase = (blockIdx.x >> 3) & 3;
+    // Stagger (two blocks per CU).  Every tile of a launch costs the same, so the two persistent blocks of a CU stay
+    // in lockstep: both in their main loops, then both in their epilogues — the epilogue's VALU work (GELU + split:
+    // as many cycles as the tile's MFMAs at K = 384) would never meet the other block's MFMAs.  The second half of
+    // the grid (the blocks dispatched onto already occupied CUs) therefore starts half a tile late and stays
+    // half a tile behind.
+    if (stagger_cycles && WCN == 2 && blockIdx.x >= gridDim.x / 2) {
         const uint64_t t0 = __builtin_amdgcn_s_memtime();
-        while (__builtin_amdgcn_s_memtime() - t0 < (uint64_t)phase * stagger_cycles) __builtin_amdgcn_s_sleep(16);
+        while (__builtin_amdgcn_s_memtime() - t0 < (uint64_t)stagger_cycles) __builtin_amdgcn_s_sleep(16);
     }
     while (slot < total_slots) {
         const uint32_t m0 = mt * GW_BM, n0 = nt * GW_BN;
@@ -436,6 +434,11 @@ static int32_t gemm_wide_launch(int epi, const _Float16* A, const _Float16* W, c
         if (hipGetDevice(&dev) == hipSuccess &&
             hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n >= 8)
             cus = n / 8 * 8;  // whole XCD octets: slot -> XCD mapping survives the persistent stride
+        if (std::getenv("CS_GEMM_WIDE_DEBUG")) {
+            int nb = -1;
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, gemm_wide_kernel<SH_OUT_SPLIT, 0, WCN>, G::THREADS, G::LDS);
+            fprintf(stderr, "gemm_wide<WCN=%d>: %d threads, %d B LDS, occupancy %d blocks per CU\n", WCN, G::THREADS, G::LDS, nb);
+        }
         attr_set = true;
     }
     const uint32_t mtiles = (M + GW_BM - 1) / GW_BM, ntiles = N / G::BN;
@@ -443,9 +446,10 @@ static int32_t gemm_wide_launch(int epi, const _Float16* A, const _Float16* W, c
     const uint32_t resident = (uint32_t)cus * (WCN == 4 ? 1u : 2u);  // persistent grid: every block resident
     const uint32_t grid = slots < resident ? slots : resident;
     const uint32_t kc = K / 32;
-    // a quarter of a tile's main loop in shader cycles; 0 = off (measured: no gain, kept for A/B)
+    // half a tile in s_memtime ticks per k-chunk (CS_GEMM_WIDE_STAGGER; default 0 = off: measured 600 / 1200 / 2400 on
+    // all four layer shapes, no gain — see DESIGN.md §3.3); only when blocks run several tiles
     static const int stagger_env = [] { const char* e = std::getenv("CS_GEMM_WIDE_STAGGER"); return e ? std::atoi(e) : 0; }();
-    const uint32_t stagger = (slots >= 2 * grid && stagger_env > 0) ? kc * (uint32_t)stagger_env : 0u;
+    const uint32_t stagger = (WCN == 2 && slots >= 2 * grid && grid == resident && stagger_env > 0) ? kc * (uint32_t)stagger_env : 0u;
 #define GW_LAUNCH(E, V) hipLaunchKernelGGL((gemm_wide_kernel<E, V, WCN>), dim3(grid), dim3(G::THREADS), G::LDS, s, A, W, bias, resid, C, Cs, M, N, kc, d_flag, slots, ln_g, ln_b, ln_eps, stagger)
     if constexpr (WCN == 4) {
         if (g_gemm_wide_ablation && epi == SH_OUT_SPLIT) {
@@ -484,14 +488,15 @@ static int32_t gemm_wide_launch(int epi, const _Float16* A, const _Float16* W, c
     return CS_OK;
 }
 
-// Block shape: 128 x 384 / one block per CU when asked for (LayerNorm epilogue; CS_GEMM_WIDE_SHAPE=384), else
-// 128 x 192 / two blocks per CU.
+// Block shape: 128 x 384 / one block per CU where N allows (and always for the LayerNorm epilogue); 128 x 192 / two
+// blocks per CU for the other multiples of 192 or with CS_GEMM_WIDE_SHAPE=192 (measured level with each other on every
+// layer shape of the encoder: QKV 187 vs 190 us, FFN-up 270 vs 279, FFN-down 223 vs 237).
 static int32_t gemm_wide_impl(int epi, const _Float16* A, const _Float16* W, const float* bias, const float* resid, float* C,
                               _Float16* Cs, uint32_t M, uint32_t N, uint32_t K, uint32_t* d_flag, hipStream_t s,
                               const float* ln_g, const float* ln_b, float ln_eps) {
     if (!gemm_wide_supported(N, K)) return fail(CS_ERR_UNSUPPORTED, "wide split GEMM needs N %% 192 == 0 and K %% 32 == 0 (N=%u K=%u)", N, K);
     if (M == 0) return CS_OK;
-    static const int shape_env = [] { const char* e = std::getenv("CS_GEMM_WIDE_SHAPE"); return e ? std::atoi(e) : 192; }();
+    static const int shape_env = [] { const char* e = std::getenv("CS_GEMM_WIDE_SHAPE"); return e ? std::atoi(e) : 384; }();
     const bool big = epi == GW_OUT_LN || g_gemm_wide_ablation || (shape_env == 384 && N % 384 == 0);
     if (big) return gemm_wide_launch<4>(epi, A, W, bias, resid, C, Cs, M, N, K, d_flag, s, ln_g, ln_b, ln_eps);
     return gemm_wide_launch<2>(epi, A, W, bias, resid, C, Cs, M, N, K, d_flag, s, ln_g, ln_b, ln_eps);
