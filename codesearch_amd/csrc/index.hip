@@ -383,32 +383,6 @@ bool take_events(cs_index* h, Workspace* w, EventTriple* t) {
     return true;
 }
 
-// The list-based exact search: scan (+ prime floors) then the merge of the block lists — in the scan's last block
-// when the plan allows (plan.fuse), else by launch_merge.
-int32_t scan_and_merge(Workspace* w, const ScanPlan& plan, const float* d_corpus, uint64_t n_rows, uint32_t dim,
-                       const float* d_queries, uint32_t nq, uint32_t k, const uint32_t* d_dead, uint32_t id_base,
-                       uint64_t* d_keys, float* d_cos, uint32_t* d_ids, uint32_t* d_counts, hipStream_t stream,
-                       const ScanPrime* prime, const uint32_t* gate, hipEvent_t after_scan) {
-    if (plan.fuse) {
-        if (!w->prime.d_done || w->prime_nq_cap < nq) {  // the pass counters (shared with the prime pass, which has ended)
-            ScanPlan pp = plan;
-            pp.blocks = 1;
-            CS_TRY(w->reserve_prime(pp, nq));
-        }
-        ScanFuse f;
-        f.d_done = w->prime.d_done;
-        f.d_out_keys = d_keys; f.d_out_cos = d_cos; f.d_out_ids = d_ids; f.d_out_counts = d_counts;
-        CS_TRY(launch_scan(plan, d_corpus, n_rows, dim, d_queries, nq, k, d_dead, id_base, w->d_partial, stream, prime, false,
-                           gate, &f));
-        if (after_scan) CS_HIP(hipEventRecord(after_scan, stream));
-        return CS_OK;
-    }
-    CS_TRY(launch_scan(plan, d_corpus, n_rows, dim, d_queries, nq, k, d_dead, id_base, w->d_partial, stream, prime, false, gate));
-    if (after_scan) CS_HIP(hipEventRecord(after_scan, stream));
-    return launch_merge(w->d_partial, plan.blocks, nq, k, false, w->d_tmp_a, w->d_tmp_b, d_keys, d_cos, d_ids, d_counts,
-                        stream, gate);
-}
-
 // scan + merge on `stream`; outputs are device pointers (any may be null).
 // h_queries_pinned != null: the queries are still in that pinned host buffer and d_queries is empty;
 // the filter path lets its prep kernel bring them over, every other path copies them first.
@@ -461,9 +435,12 @@ int32_t run_search(cs_index* h, Workspace* w, const ScanPlan& plan, const float*
             // Above that (hundreds of query passes would be enqueued) the sticky word is left for
             // cs_index_search_status().
             if (can_overflow && nq <= kGatedMaxQ) {
-                CS_TRY(scan_and_merge(w, plan, h->d_corpus, h->n_rows, h->dim, d_queries, nq, k,
-                                      h->n_removed ? h->d_dead : nullptr, h->id_base, d_keys, d_cos, d_ids, d_counts, stream,
-                                      nullptr, w->bs.d_overflow, nullptr));
+                const uint32_t* gate = w->bs.d_overflow;
+                CS_TRY(launch_scan(plan, h->d_corpus, h->n_rows, h->dim, d_queries, nq, k,
+                                   h->n_removed ? h->d_dead : nullptr, h->id_base, w->d_partial, stream, nullptr, false,
+                                   gate));
+                CS_TRY(launch_merge(w->d_partial, plan.blocks, nq, k, false, w->d_tmp_a, w->d_tmp_b, d_keys, d_cos, d_ids,
+                                    d_counts, stream, gate));
             }
             std::lock_guard<std::mutex> lk(h->mu);
             h->batched_searches++;
@@ -492,9 +469,12 @@ int32_t run_search(cs_index* h, Workspace* w, const ScanPlan& plan, const float*
         // candidate buffer overflowed: exact list-based rerun below
         EventTriple none{};
         ev = none;
-        return scan_and_merge(w, plan, h->d_corpus, h->n_rows, h->dim, d_queries, nq, k,
-                              h->n_removed ? h->d_dead : nullptr, h->id_base, d_keys, d_cos, d_ids, d_counts, stream, nullptr,
-                              nullptr, nullptr);
+        return [&]() -> int32_t {
+            CS_TRY(launch_scan(plan, h->d_corpus, h->n_rows, h->dim, d_queries, nq, k,
+                               h->n_removed ? h->d_dead : nullptr, h->id_base, w->d_partial, stream));
+            return launch_merge(w->d_partial, plan.blocks, nq, k, false, w->d_tmp_a, w->d_tmp_b, d_keys, d_cos,
+                                d_ids, d_counts, stream);
+        }();
     }
     const uint32_t* d_dead = h->n_removed ? h->d_dead : nullptr;
     const ScanPrime* prime = nullptr;
@@ -514,8 +494,11 @@ int32_t run_search(cs_index* h, Workspace* w, const ScanPlan& plan, const float*
                            nullptr, stream, &w->prime, true));
         prime = &w->prime;
     }
-    CS_TRY(scan_and_merge(w, plan, h->d_corpus, h->n_rows, h->dim, d_queries, nq, k, d_dead, h->id_base, d_keys, d_cos, d_ids,
-                          d_counts, stream, prime, nullptr, timed ? ev.e1 : nullptr));
+    CS_TRY(launch_scan(plan, h->d_corpus, h->n_rows, h->dim, d_queries, nq, k, d_dead, h->id_base,
+                       w->d_partial, stream, prime));
+    if (timed) CS_HIP(hipEventRecord(ev.e1, stream));
+    CS_TRY(launch_merge(w->d_partial, plan.blocks, nq, k, false, w->d_tmp_a, w->d_tmp_b, d_keys, d_cos,
+                        d_ids, d_counts, stream));
     if (timed) {
         CS_HIP(hipEventRecord(ev.e2, stream));
         std::lock_guard<std::mutex> lk(h->mu);

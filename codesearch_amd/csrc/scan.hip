@@ -128,21 +128,14 @@ __device__ __forceinline__ bool row_is_dead(const uint32_t* dead, uint64_t row) 
 // the test never depends on the denormal mode).  The full scan then starts every list with
 // thr = floor instead of -inf and inserts ~10 rows per wave instead of ~650; results are
 // bit-identical because only rows that cannot be among the best k are skipped.
-//
-// FUSE = true (short searches: grid blocks x k <= 4096 keys): the last block of a pass to finish (agent-scope
-// counter, the PRIME mode's pattern) merges the block lists itself and writes the final result — no merge_topk_kernel
-// launches behind the scan (two for k = 10: ~20 us of a 267-us search over 1M rows, most of a 47-us search over
-// the 592 rows of the reference's own benchmark index).
-template <int J, int U, int QT, bool NT, bool PRIME = false, bool FUSE = false>
+template <int J, int U, int QT, bool NT, bool PRIME = false>
 __global__ void __launch_bounds__(kBlock)
 scan_topk_kernel(const float* __restrict__ corpus, uint64_t n_rows,
                  const float* __restrict__ queries, uint32_t nq, uint32_t k, uint32_t kpad,
                  const uint32_t* __restrict__ dead, uint32_t id_base,
                  uint64_t* __restrict__ partial, const float* __restrict__ floor_in,
                  float* __restrict__ wave_max, uint32_t* __restrict__ done_ctr,
-                 float* __restrict__ floor_out, const uint32_t* __restrict__ gate,
-                 uint64_t* __restrict__ out_keys, float* __restrict__ out_cos, uint32_t* __restrict__ out_ids,
-                 uint32_t* __restrict__ out_counts) {
+                 float* __restrict__ floor_out, const uint32_t* __restrict__ gate) {
     // gate != null: this launch is the exact rerun enqueued behind a batched (filter + refine) search on the
     // device API; it runs only if that search overflowed a candidate buffer (index.hip run_search)
     if (gate && *gate == 0u) return;
@@ -323,42 +316,6 @@ scan_topk_kernel(const float* __restrict__ corpus, uint64_t n_rows,
         block_bitonic_desc<kBlock>(a, nsort, tid);
         uint64_t* out = partial + ((size_t)(q0 + qi) * gridDim.x + blockIdx.x) * k;
         for (uint32_t i = tid; i < k; i += kBlock) out[i] = a[i];
-    }
-    if constexpr (FUSE) {
-        __shared__ uint32_t is_last_f, live;
-        __threadfence();
-        __syncthreads();
-        if (tid == 0) {
-            const uint32_t prev = __hip_atomic_fetch_add(done_ctr + blockIdx.y, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-            is_last_f = (prev == gridDim.x - 1);
-        }
-        __syncthreads();
-        if (!is_last_f) return;
-        __threadfence();
-        const uint32_t nkeys = gridDim.x * k;  // host: nkeys <= 4096 and the LDS request covers next_pow2(nkeys)
-        uint32_t nm = 64;
-        while (nm < nkeys) nm <<= 1;
-#pragma unroll 1
-        for (int qi = 0; qi < QT; ++qi) {
-            if (q0 + qi >= nq) break;
-            __syncthreads();
-            const uint64_t* src = partial + (size_t)(q0 + qi) * gridDim.x * k;  // [blocks][k], written by other CUs
-            for (uint32_t i = tid; i < nm; i += kBlock)
-                lds_keys[i] = i < nkeys ? __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
-            if (tid == 0) live = 0;
-            block_bitonic_desc<kBlock>(lds_keys, nm, tid);
-            const uint32_t q = q0 + qi;
-            for (uint32_t i = tid; i < k; i += kBlock) {
-                const uint64_t key = i < nm ? lds_keys[i] : 0ull;
-                if (key) atomicAdd(&live, 1u);
-                if (out_keys) out_keys[(size_t)q * k + i] = key;
-                if (out_cos) out_cos[(size_t)q * k + i] = key ? key_cos(key) : 0.0f;
-                if (out_ids) out_ids[(size_t)q * k + i] = key ? key_id(key) : 0xffffffffu;
-            }
-            __syncthreads();
-            if (out_counts && tid == 0) out_counts[q] = live;
-        }
-        if (tid == 0) __hip_atomic_store(done_ctr + blockIdx.y, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -633,9 +590,6 @@ ScanPlan plan_scan(uint64_t n_rows, uint32_t dim, uint32_t nq, uint32_t k, int n
     p.passes = (nq + p.qtile - 1) / p.qtile;
     p.partial_keys = (size_t)nq * p.blocks * k;
     p.merge_keys = merge_tmp_keys(p.blocks, nq, k);
-    // short searches: the last scan block merges (scan_topk_kernel FUSE); CS_SCAN_FUSE=0 keeps the separate merge
-    static const bool fuse_on = [] { const char* e = std::getenv("CS_SCAN_FUSE"); return !(e && e[0] == '0'); }();
-    p.fuse = fuse_on && fast_dim(dim) && (uint64_t)p.blocks * k <= (uint64_t)kMergeCap && n_rows > 0;
     return p;
 }
 
@@ -673,47 +627,35 @@ template <int J, int U, int QT>
 static void launch_fast(const ScanPlan& plan, const float* d_corpus, uint64_t n_rows,
                         const float* d_queries, uint32_t nq, uint32_t k, const uint32_t* d_dead,
                         uint32_t id_base, uint64_t* d_partial, const ScanPrime* prime,
-                        bool prime_pass, hipStream_t stream, const uint32_t* gate, const ScanFuse* fuse) {
-    size_t lds = (size_t)QT * kWaves * plan.kpad * sizeof(uint64_t);
+                        bool prime_pass, hipStream_t stream, const uint32_t* gate) {
+    const size_t lds = (size_t)QT * kWaves * plan.kpad * sizeof(uint64_t);
     dim3 grid(plan.blocks, plan.passes);
     if (prime_pass)  // cached loads: the full scan re-reads these rows right after
         hipLaunchKernelGGL((scan_topk_kernel<J, U, QT, false, true>), grid, dim3(kBlock), lds, stream,
                            d_corpus, n_rows, d_queries, nq, k, plan.kpad, d_dead, id_base, nullptr,
-                           nullptr, prime->d_wave_max, prime->d_done, prime->d_floor, nullptr, nullptr, nullptr, nullptr,
-                           nullptr);
-    else if (fuse) {
-        const size_t need = (size_t)next_pow2(plan.blocks * k < 64 ? 64 : plan.blocks * k) * sizeof(uint64_t);
-        if (need > lds) lds = need;
-        hipLaunchKernelGGL((scan_topk_kernel<J, U, QT, true, false, true>), grid, dim3(kBlock), lds, stream,
-                           d_corpus, n_rows, d_queries, nq, k, plan.kpad, d_dead, id_base, d_partial,
-                           prime ? prime->d_floor : nullptr, nullptr, fuse->d_done, nullptr, gate, fuse->d_out_keys,
-                           fuse->d_out_cos, fuse->d_out_ids, fuse->d_out_counts);
-    } else
+                           nullptr, prime->d_wave_max, prime->d_done, prime->d_floor, nullptr);
+    else
         hipLaunchKernelGGL((scan_topk_kernel<J, U, QT, true>), grid, dim3(kBlock), lds, stream,
                            d_corpus, n_rows, d_queries, nq, k, plan.kpad, d_dead, id_base, d_partial,
-                           prime ? prime->d_floor : nullptr, nullptr, nullptr, nullptr, gate, nullptr, nullptr, nullptr,
-                           nullptr);
+                           prime ? prime->d_floor : nullptr, nullptr, nullptr, nullptr, gate);
 }
 
 template <int J, int U>
 static void launch_fast_q(const ScanPlan& plan, const float* d_corpus, uint64_t n_rows,
                           const float* d_queries, uint32_t nq, uint32_t k,
                           const uint32_t* d_dead, uint32_t id_base, uint64_t* d_partial,
-                          const ScanPrime* prime, bool prime_pass, hipStream_t stream, const uint32_t* gate,
-                          const ScanFuse* fuse) {
+                          const ScanPrime* prime, bool prime_pass, hipStream_t stream, const uint32_t* gate) {
     switch (plan.qtile) {
-        case 4: launch_fast<J, U, 4>(plan, d_corpus, n_rows, d_queries, nq, k, d_dead, id_base, d_partial, prime, prime_pass, stream, gate, fuse); break;
-        case 2: launch_fast<J, U, 2>(plan, d_corpus, n_rows, d_queries, nq, k, d_dead, id_base, d_partial, prime, prime_pass, stream, gate, fuse); break;
-        default: launch_fast<J, U, 1>(plan, d_corpus, n_rows, d_queries, nq, k, d_dead, id_base, d_partial, prime, prime_pass, stream, gate, fuse); break;
+        case 4: launch_fast<J, U, 4>(plan, d_corpus, n_rows, d_queries, nq, k, d_dead, id_base, d_partial, prime, prime_pass, stream, gate); break;
+        case 2: launch_fast<J, U, 2>(plan, d_corpus, n_rows, d_queries, nq, k, d_dead, id_base, d_partial, prime, prime_pass, stream, gate); break;
+        default: launch_fast<J, U, 1>(plan, d_corpus, n_rows, d_queries, nq, k, d_dead, id_base, d_partial, prime, prime_pass, stream, gate); break;
     }
 }
 
 int32_t launch_scan(const ScanPlan& plan, const float* d_corpus, uint64_t n_rows, uint32_t dim,
                     const float* d_queries, uint32_t nq, uint32_t k, const uint32_t* d_dead,
                     uint32_t id_base, uint64_t* d_partial, hipStream_t stream,
-                    const ScanPrime* prime, bool prime_pass, const uint32_t* gate, const ScanFuse* fuse) {
-    if (fuse && (!plan.fuse || !fast_dim(dim) || prime_pass))
-        return fail(CS_ERR_BAD_ARG, "fused merge needs a plan with fuse set on a 384/768/1024-d scan");
+                    const ScanPrime* prime, bool prime_pass, const uint32_t* gate) {
     if (prime_pass && (!prime || !fast_dim(dim) || n_rows == 0))
         return fail(CS_ERR_BAD_ARG, "prime pass needs a 384/768/1024-d corpus prefix and its buffers");
     if (n_rows == 0) {  // nothing to score: all-empty partial lists
@@ -722,12 +664,12 @@ int32_t launch_scan(const ScanPlan& plan, const float* d_corpus, uint64_t n_rows
         return CS_OK;
     }
     if (plan.deep && plan.qtile == 1) {
-        if (dim == 384) launch_fast<3, 8, 1>(plan, d_corpus, n_rows, d_queries, nq, k, d_dead, id_base, d_partial, prime, prime_pass, stream, gate, fuse);
-        else if (dim == 768) launch_fast<6, 4, 1>(plan, d_corpus, n_rows, d_queries, nq, k, d_dead, id_base, d_partial, prime, prime_pass, stream, gate, fuse);
-        else launch_fast<8, 3, 1>(plan, d_corpus, n_rows, d_queries, nq, k, d_dead, id_base, d_partial, prime, prime_pass, stream, gate, fuse);
-    } else if (dim == 384) launch_fast_q<3, 4>(plan, d_corpus, n_rows, d_queries, nq, k, d_dead, id_base, d_partial, prime, prime_pass, stream, gate, fuse);
-    else if (dim == 768) launch_fast_q<6, 2>(plan, d_corpus, n_rows, d_queries, nq, k, d_dead, id_base, d_partial, prime, prime_pass, stream, gate, fuse);
-    else if (dim == 1024) launch_fast_q<8, 2>(plan, d_corpus, n_rows, d_queries, nq, k, d_dead, id_base, d_partial, prime, prime_pass, stream, gate, fuse);
+        if (dim == 384) launch_fast<3, 8, 1>(plan, d_corpus, n_rows, d_queries, nq, k, d_dead, id_base, d_partial, prime, prime_pass, stream, gate);
+        else if (dim == 768) launch_fast<6, 4, 1>(plan, d_corpus, n_rows, d_queries, nq, k, d_dead, id_base, d_partial, prime, prime_pass, stream, gate);
+        else launch_fast<8, 3, 1>(plan, d_corpus, n_rows, d_queries, nq, k, d_dead, id_base, d_partial, prime, prime_pass, stream, gate);
+    } else if (dim == 384) launch_fast_q<3, 4>(plan, d_corpus, n_rows, d_queries, nq, k, d_dead, id_base, d_partial, prime, prime_pass, stream, gate);
+    else if (dim == 768) launch_fast_q<6, 2>(plan, d_corpus, n_rows, d_queries, nq, k, d_dead, id_base, d_partial, prime, prime_pass, stream, gate);
+    else if (dim == 1024) launch_fast_q<8, 2>(plan, d_corpus, n_rows, d_queries, nq, k, d_dead, id_base, d_partial, prime, prime_pass, stream, gate);
     else {
         const size_t lds = (size_t)kWaves * plan.kpad * sizeof(uint64_t);
         hipLaunchKernelGGL(scan_topk_generic_kernel, dim3(plan.blocks, nq), dim3(kBlock), lds,

@@ -11,7 +11,6 @@ struct ScanPlan {
     uint32_t qtile;      // queries handled per scan pass
     uint32_t passes;     // ceil(nq / qtile)  (grid.y)
     bool deep;           // one block per CU with twice the rows in flight per wave (one query, k <= 64)
-    bool fuse;           // blocks * k <= 4096: the last scan block may merge the block lists itself (ScanFuse)
     size_t partial_keys; // u64 count needed for the scan's partial buffer
     size_t merge_keys;   // u64 count needed for the merge ping-pong buffer
 };
@@ -30,15 +29,6 @@ bool scan_prime_supported(uint32_t dim);
 uint64_t prime_sample_rows(uint64_t default_rows, uint32_t k, int num_cus);
 ScanPlan plan_prime(uint64_t sample_rows, uint32_t dim, uint32_t nq, uint32_t k, int num_cus);
 
-// Fused merge (plan.fuse): the scan's last block per pass writes the final result; no launch_merge behind it.
-struct ScanFuse {
-    uint32_t* d_done = nullptr;  // [passes], zero between launches (ScanPrime::d_done may be shared: the prime pass has ended)
-    uint64_t* d_out_keys = nullptr;
-    float* d_out_cos = nullptr;
-    uint32_t* d_out_ids = nullptr;
-    uint32_t* d_out_counts = nullptr;
-};
-
 // Scores every live row of corpus[0..n_rows) against each query and leaves, per
 // (query, block), the block's best k as packed keys in d_partial[q][block][k].
 // prime + prime_pass: run the prime pass over these rows instead (plan from plan_prime, no
@@ -46,8 +36,7 @@ struct ScanFuse {
 int32_t launch_scan(const ScanPlan& plan, const float* d_corpus, uint64_t n_rows, uint32_t dim,
                     const float* d_queries, uint32_t nq, uint32_t k, const uint32_t* d_dead,
                     uint32_t id_base, uint64_t* d_partial, hipStream_t stream,
-                    const ScanPrime* prime = nullptr, bool prime_pass = false, const uint32_t* gate = nullptr,
-                    const ScanFuse* fuse = nullptr);
+                    const ScanPrime* prime = nullptr, bool prime_pass = false, const uint32_t* gate = nullptr);
 // `gate` (launch_scan and launch_merge): device word; when non-null every block of the launch exits at
 // once unless *gate != 0 — the exact rerun enqueued behind a batched search on the device API.
 
