@@ -255,7 +255,7 @@ gemm_wide_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ W,
         // columns per lane, so every global store is 16 B per lane on consecutive lanes of a line.  (Storing straight
         // from the accumulators, 8 B per lane and plane, was measured: 2.4x slower — partial-line writes.)
         const bool full = m0 + GW_BM <= M;
-        bool ovf = false;
+        uint32_t mx = 0;  // packed maximum of |hi| bit patterns (sh_split8)
         const uint32_t cbase = n0 + wc * 96 + 4 * g;  // first column of this lane in tile j = 0
         float* patch = reinterpret_cast<float*>(lds + ebuf * GW_STAGE + wave * 8192);  // [16 rows][100 floats]
         constexpr int PS = 100;
@@ -352,12 +352,7 @@ gemm_wide_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ W,
                 }
                 if (EPI == SH_OUT_SPLIT || EPI == SH_OUT_SPLIT_GELU || EPI == GW_OUT_LN) {
                     f16x8 hi, lo;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        _Float16 a, b;
-                        ovf |= sh_split(v0[e], a, b); hi[e] = a; lo[e] = b;
-                        ovf |= sh_split(v1[e], a, b); hi[4 + e] = a; lo[4 + e] = b;
-                    }
+                    sh_split8(v0, v1, hi, lo, mx);
                     if (live) {
                         _Float16* dst = Cs + ((size_t)(m0 + m) * (N / 32) + (col >> 5)) * 64 + (col & 31);
                         if (EPI == GW_OUT_LN) {  // the next GEMM reads it from L2 / MALL: default policy
@@ -379,7 +374,7 @@ gemm_wide_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ W,
 #pragma unroll
                 for (int j = 0; j < 6; ++j) asm volatile("" ::"v"(acc.c[i][j]));
         }
-        if (ovf && flag) atomicOr(flag, 1u);
+        if (flag && sh_split_overflowed(mx)) atomicOr(flag, 1u);
         buf = ebuf ^ 1;
         slot = nslot;
         mt = nmt;

@@ -52,6 +52,32 @@ __device__ __forceinline__ bool sh_split(float x, _Float16& hi, _Float16& lo) {
     return !(fabsf(x) <= kShMax);                    // also true for NaN
 }
 
+// Eight values at once, same results bit for bit: packed conversions (v_cvt_pk_f16_f32) and packed f32 arithmetic
+// (v_pk_add_f32 / v_pk_mul_f32) take the split from ~7 VALU instructions per value to ~3.5 — the dense layers'
+// epilogues are VALU-bound on it.  Range check: `mx` accumulates the packed unsigned maximum of
+// |hi| bit patterns (as integers |f16| orders inf = 0x7C00 below every NaN); sh_split_overflowed(mx) at the end.
+typedef float sh_f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned short sh_u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void sh_split8(sh_f32x4 v0, sh_f32x4 v1, f16x8& hi, f16x8& lo, uint32_t& mx) {
+    asm volatile("" : "+v"(v0), "+v"(v1));  // the f32 values are the only source of hi (see sh_split)
+    uint32_t* hw = reinterpret_cast<uint32_t*>(&hi);
+    uint32_t* lw = reinterpret_cast<uint32_t*>(&lo);
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const sh_f32x2 x = p < 2 ? sh_f32x2{v0[2 * p], v0[2 * p + 1]} : sh_f32x2{v1[2 * p - 4], v1[2 * p - 3]};
+        f16x2 h = __builtin_convertvector(x, f16x2);
+        asm volatile("" : "+v"(h));
+        const sh_f32x2 hf = {(float)h[0], (float)h[1]};
+        const sh_f32x2 t = (x - hf) * kShLoScale;  // x - hi is exact in f32
+        const f16x2 l = __builtin_convertvector(t, f16x2);
+        hw[p] = __builtin_bit_cast(uint32_t, h);
+        lw[p] = __builtin_bit_cast(uint32_t, l);
+        const sh_u16x2 a = __builtin_bit_cast(sh_u16x2, hw[p] & 0x7fff7fffu), b = __builtin_bit_cast(sh_u16x2, mx);
+        mx = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(a, b));
+    }
+}
+__device__ __forceinline__ bool sh_split_overflowed(uint32_t mx) { return (mx & 0xffffu) >= 0x7c00u || (mx >> 16) >= 0x7c00u; }
+
 // ---- 128 x 128 x 32 tile main loop --------------------------------------------------------
 // Block = 256 threads = 4 waves as 2 (m) x 2 (n); a wave owns 64 x 64 = 2 x 2 MFMA tiles of
 // 32 x 32.  Stage = one k-chunk (32 k) of 128 A rows and 128 W rows = 2 x 16 KiB, brought in
