@@ -27,6 +27,7 @@ struct cs_embedder {
     int gemm_mode = CS_GEMM_SPLIT_F16;
     bool split_unavailable = false;  // device flushes f16 subnormals in the MFMA: exact-f32 kernels only
     bool wide_ok = false;            // every |w| < 31.98: the one-accumulator 128 x 384 kernels may run (gemm_wide.hip)
+    int streams_in_flight = 1;       // slices of the current mini-batch running side by side (forward())
     uint64_t split_forwards = 0, f32_forwards = 0, range_fallbacks = 0;
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;     // second half of a mini-batch runs here (see forward())
@@ -166,11 +167,20 @@ int32_t forward_range(cs_embedder* h, hipStream_t s, uint32_t b0, uint32_t nb, u
     };
     // dense layer: the persistent 128 x 384 one-accumulator kernel from wide_min_m token rows on (gemm_wide.hip),
     // else the 128 x 128 / skinny kernels of gemm_split.hip
+    // A persistent block owns whole 128 x 384 tiles, so a launch needs about one tile per CU to fill the chip: the wide
+    // kernel takes a layer when its tiles cover >= 85 % of the CUs, or from wide_min_m rows when the other half-batch
+    // runs beside it on the second stream (measured, device ms per forward, wide / 128 x 128: 32 x 256 tokens 2.67 /
+    // 2.08, 64 x 256 4.01 / 3.57 — one stream, N = 384 layers leave half the chip idle — 128 x 256 5.95 / 6.40,
+    // 256 x 256 11.4 / 12.5).
     static const uint32_t wide_min_m = [] { const char* e = std::getenv("CS_GEMM_WIDE_MIN_M"); return e ? (uint32_t)std::atoll(e) : 12288u; }();
+    auto takes_wide = [&](uint32_t Mr, uint32_t Nn, uint32_t Kk) {
+        if (!h->wide_ok || !wide_min_m || !gemm_wide_supported(Nn, Kk) || Nn % 384) return false;
+        const uint32_t tiles = ((Mr + 127) / 128) * (Nn / 384);
+        return tiles >= 218 || (h->streams_in_flight >= 2 && Mr >= wide_min_m);
+    };
     auto dense = [&](int epi, const _Float16* Ain, const _Float16* Wt, const float* bias, const float* resid, float* Cf,
                      _Float16* Csp, uint32_t Mr, uint32_t Nn, uint32_t Kk) -> int32_t {
-        if (h->wide_ok && wide_min_m && Mr >= wide_min_m && gemm_wide_supported(Nn, Kk))
-            return launch_gemm_wide(epi, Ain, Wt, bias, resid, Cf, Csp, Mr, Nn, Kk, h->d_flag, s);
+        if (takes_wide(Mr, Nn, Kk)) return launch_gemm_wide(epi, Ain, Wt, bias, resid, Cf, Csp, Mr, Nn, Kk, h->d_flag, s);
         return launch_gemm_split(epi, Ain, Wt, bias, resid, Cf, Csp, Mr, Nn, Kk, h->d_flag, s);
     };
     CS_TRY(mark(-1));
@@ -198,7 +208,7 @@ int32_t forward_range(cs_embedder* h, hipStream_t s, uint32_t b0, uint32_t nb, u
             a.g = P + lo.ao_ln_g; a.b = P + lo.ao_ln_b;
             // N = 384 at indexing batch sizes: dense layer + residual + LayerNorm in one kernel (gemm_wide.hip)
             static const bool ln_fuse_on = [] { const char* e = std::getenv("CS_GEMM_WIDE_LN"); return !(e && e[0] == '0'); }();
-            const bool fuse_ln = ln_fuse_on && h->wide_ok && wide_min_m && T >= wide_min_m && H == 384;
+            const bool fuse_ln = ln_fuse_on && H == 384 && takes_wide(T, H, H);
             if (fuse_ln) {
                 CS_TRY(launch_gemm_wide_ln(ctxs, ws + sl.ao, P + lo.ao_b, x, a.g, a.b, c.layer_norm_eps, x, xs, T, H, h->d_flag, s));  // E4
                 CS_TRY(mark(CS_STAGE_OUT_PROJ));
@@ -277,6 +287,7 @@ int32_t forward(cs_embedder* h, uint32_t B, uint32_t L, int mode) {
     h->stage_tag.clear();
     if (!h->stage_profile && h->n_streams >= 2 && B >= (uint32_t)h->n_streams && (uint64_t)B * L >= stream_min_tokens) {
         const uint32_t ns = (uint32_t)h->n_streams;
+        h->streams_in_flight = (int)ns;
         hipStream_t st[4] = {s, h->stream2, h->xstreams[0], h->xstreams[1]};
         hipEvent_t jn[4] = {nullptr, h->ev_join, h->xjoin[0], h->xjoin[1]};
         CS_HIP(hipEventRecord(h->ev_fork, s));
@@ -288,6 +299,7 @@ int32_t forward(cs_embedder* h, uint32_t B, uint32_t L, int mode) {
         }
         for (uint32_t i = 1; i < ns; ++i) CS_HIP(hipStreamWaitEvent(s, jn[i], 0));
     } else {
+        h->streams_in_flight = 1;
         CS_TRY(forward_range(h, s, 0, B, L, mode));
     }
     CS_HIP(hipEventRecord(h->ev1, s));
