@@ -14,6 +14,34 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+def _cpu_share() -> int:
+    """Threads this job may really use: the cgroup CPU quota and the affinity mask, not the cores the host shows (a
+    one-GPU box shows 128 and grants 16: an OpenMP oracle started with 128 threads runs 3-8x slower)."""
+    import math
+
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, math.ceil(int(q) / int(p))))
+    except (OSError, ValueError, IndexError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, math.ceil(q / p)))
+        except (OSError, ValueError):
+            pass
+    return max(1, n)
+
+
+os.environ.setdefault("OMP_NUM_THREADS", str(_cpu_share()))  # before liboracle.so (OpenMP) is loaded
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
