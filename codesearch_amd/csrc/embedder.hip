@@ -178,9 +178,19 @@ int32_t forward_range(cs_embedder* h, hipStream_t s, uint32_t b0, uint32_t nb, u
         const uint32_t tiles = ((Mr + 127) / 128) * (Nn / 384);
         return tiles >= 218 || (h->streams_in_flight >= 2 && Mr >= wide_min_m);
     };
+    // Mid-size launches (the reference's 32-chunk calls: 8,192 token rows): the 128 x 128 grid is 1.1 rounds of
+    // blocks for QKV (576 tiles on 512 slots); 128 x 192 tiles at two blocks per CU make it ONE round (384 tiles for
+    // QKV, 512 for FFN-up).  Taken when that single round is at least 70 % full.
+    static const bool mid192 = [] { const char* e = std::getenv("CS_GEMM_WIDE_MID"); return !(e && e[0] == '0'); }();
+    auto takes_192 = [&](uint32_t Mr, uint32_t Nn, uint32_t Kk) {
+        if (!mid192 || !h->wide_ok || !gemm_wide_supported(Nn, Kk) || h->streams_in_flight >= 2) return false;
+        const uint32_t tiles = ((Mr + 127) / 128) * (Nn / 192);
+        return tiles >= 358 && tiles <= 512;
+    };
     auto dense = [&](int epi, const _Float16* Ain, const _Float16* Wt, const float* bias, const float* resid, float* Cf,
                      _Float16* Csp, uint32_t Mr, uint32_t Nn, uint32_t Kk) -> int32_t {
         if (takes_wide(Mr, Nn, Kk)) return launch_gemm_wide(epi, Ain, Wt, bias, resid, Cf, Csp, Mr, Nn, Kk, h->d_flag, s);
+        if (takes_192(Mr, Nn, Kk)) return launch_gemm_wide(epi, Ain, Wt, bias, resid, Cf, Csp, Mr, Nn, Kk, h->d_flag, s, 192);
         return launch_gemm_split(epi, Ain, Wt, bias, resid, Cf, Csp, Mr, Nn, Kk, h->d_flag, s);
     };
     CS_TRY(mark(-1));
@@ -807,7 +817,10 @@ int32_t cs_debug_gemm(int32_t device, int32_t mode, int32_t epilogue, const floa
             CS_HIP(hipMalloc(&sA, a_n * 4)); CS_HIP(hipMalloc(&sW, w_n * 4));
             CS_TRY(launch_split_rows(dA, sA, M, K, dF, nullptr));
             CS_TRY(launch_split_rows(dW, sW, N, K, dF, nullptr));
-            auto run_gemm = wide ? launch_gemm_wide : launch_gemm_split;
+            auto run_gemm = [&](int e, const _Float16* a_, const _Float16* w_, const float* b_, const float* r_, float* c_, _Float16* cs_,
+                                uint32_t m_, uint32_t n_, uint32_t k_, uint32_t* f_, hipStream_t st_) {
+                return wide ? launch_gemm_wide(e, a_, w_, b_, r_, c_, cs_, m_, n_, k_, f_, st_, 0) : launch_gemm_split(e, a_, w_, b_, r_, c_, cs_, m_, n_, k_, f_, st_);
+            };
             if (epilogue == 3) {
                 std::vector<float> gam(N), bet(N);
                 for (uint32_t n = 0; n < N; ++n) { gam[n] = bias[n] + 1.0f; bet[n] = -bias[n]; }
@@ -896,8 +909,8 @@ int32_t cs_debug_gemm_time(int32_t device, int32_t mode, int32_t epilogue, uint3
                 return launch_gemm(epilogue == 1 ? GEMM_GELU : epilogue == 2 ? GEMM_RESID : GEMM_BIAS, dA, dW, dB, dR, dC, M, N, K, nullptr);
             if (epilogue == 3) return launch_gemm_wide_ln(sA, sW, dB, dR, dB, dB, 1e-12f, dR, sC, M, K, dF, nullptr);
             const int epi = epilogue == 0 ? SH_OUT_F32 : epilogue == 1 ? SH_OUT_SPLIT_GELU : epilogue == 2 ? SH_OUT_F32_RESID : SH_OUT_SPLIT;
-            auto fn = mode == 2 ? launch_gemm_wide : launch_gemm_split;
-            return fn(epi, sA, sW, dB, dR, dC, sC, M, N, K, dF, nullptr);
+            if (mode == 2) return launch_gemm_wide(epi, sA, sW, dB, dR, dC, sC, M, N, K, dF, nullptr, 0);
+            return launch_gemm_split(epi, sA, sW, dB, dR, dC, sC, M, N, K, dF, nullptr);
         };
         cs::g_gemm_wide_ablation = (mode == 2 && epilogue == 4) ? ablation : 0;
         for (int i = 0; i < 3; ++i) CS_TRY(once());

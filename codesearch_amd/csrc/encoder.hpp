@@ -63,8 +63,9 @@ int32_t launch_gemm_split(int epi, const _Float16* A, const _Float16* W, const f
 // gemm_wide.hip: the same product as a persistent kernel over 128 x 384 tiles with one accumulator per output
 // (w_hi scaled by 2^11 in registers).  N % 384 == 0; weights must pass sh_weights_fit_wide (|w| < 31.98).
 bool gemm_wide_supported(uint32_t N, uint32_t K);
+// shape: 0 = CS_GEMM_WIDE_SHAPE / default (128 x 384 where N allows), 192 = the 128 x 192 two-blocks-per-CU shape, 384
 int32_t launch_gemm_wide(int epi, const _Float16* A, const _Float16* W, const float* bias, const float* resid, float* C,
-                         _Float16* Cs, uint32_t M, uint32_t N, uint32_t K, uint32_t* d_flag, hipStream_t s);
+                         _Float16* Cs, uint32_t M, uint32_t N, uint32_t K, uint32_t* d_flag, hipStream_t s, int shape = 0);
 // N = 384 only: dense layer + bias + residual + LayerNorm in one kernel; X (f32, may alias resid) and Xs (split form)
 int32_t launch_gemm_wide_ln(const _Float16* A, const _Float16* W, const float* bias, const float* resid, const float* gamma,
                             const float* beta, float eps, float* X, _Float16* Xs, uint32_t M, uint32_t K, uint32_t* d_flag,

@@ -488,19 +488,19 @@ static int32_t gemm_wide_launch(int epi, const _Float16* A, const _Float16* W, c
 // layer shape of the encoder: QKV 187 vs 190 us, FFN-up 270 vs 279, FFN-down 223 vs 237).
 static int32_t gemm_wide_impl(int epi, const _Float16* A, const _Float16* W, const float* bias, const float* resid, float* C,
                               _Float16* Cs, uint32_t M, uint32_t N, uint32_t K, uint32_t* d_flag, hipStream_t s,
-                              const float* ln_g, const float* ln_b, float ln_eps) {
+                              const float* ln_g, const float* ln_b, float ln_eps, int shape = 0) {
     if (!gemm_wide_supported(N, K)) return fail(CS_ERR_UNSUPPORTED, "wide split GEMM needs N %% 192 == 0 and K %% 32 == 0 (N=%u K=%u)", N, K);
     if (M == 0) return CS_OK;
     static const int shape_env = [] { const char* e = std::getenv("CS_GEMM_WIDE_SHAPE"); return e ? std::atoi(e) : 384; }();
-    const bool big = epi == GW_OUT_LN || g_gemm_wide_ablation || (shape_env == 384 && N % 384 == 0);
+    const bool big = epi == GW_OUT_LN || g_gemm_wide_ablation || ((shape ? shape : shape_env) == 384 && N % 384 == 0);
     if (big) return gemm_wide_launch<4>(epi, A, W, bias, resid, C, Cs, M, N, K, d_flag, s, ln_g, ln_b, ln_eps);
     return gemm_wide_launch<2>(epi, A, W, bias, resid, C, Cs, M, N, K, d_flag, s, ln_g, ln_b, ln_eps);
 }
 
 int32_t launch_gemm_wide(int epi, const _Float16* A, const _Float16* W, const float* bias, const float* resid, float* C,
-                         _Float16* Cs, uint32_t M, uint32_t N, uint32_t K, uint32_t* d_flag, hipStream_t s) {
+                         _Float16* Cs, uint32_t M, uint32_t N, uint32_t K, uint32_t* d_flag, hipStream_t s, int shape) {
     if (epi == GW_OUT_LN) return fail(CS_ERR_BAD_ARG, "the LayerNorm epilogue goes through launch_gemm_wide_ln");
-    return gemm_wide_impl(epi, A, W, bias, resid, C, Cs, M, N, K, d_flag, s, nullptr, nullptr, 0.0f);
+    return gemm_wide_impl(epi, A, W, bias, resid, C, Cs, M, N, K, d_flag, s, nullptr, nullptr, 0.0f, shape);
 }
 
 // X[M,384] = LayerNorm(A W^T + bias + resid) * gamma + beta, written as f32 (X; may alias resid) and in split
