@@ -159,6 +159,12 @@ class VectorStore:
         self.dimensions = int(dimensions)
         self.id_base = int(id_base)
         self.readonly = False
+        if self.db_path is not None:  # reopening: reserve the persisted row count at once instead of growing by doubling
+            try:
+                with open(os.path.join(self.db_path, "vectors.meta.json")) as f:
+                    capacity = max(int(capacity), int(json.load(f)["next_id"]) - self.id_base)
+            except (OSError, ValueError, KeyError):
+                pass
         handle = C.c_void_p()
         if devices is not None:
             if id_base:
@@ -174,6 +180,8 @@ class VectorStore:
         self._meta: Dict[int, ChunkMetadata] = {}
         self._removed: set = set()
         self._persisted_rows = 0
+        self._persisted_meta_ids: set = set()   # ids whose line is already in chunks.jsonl
+        self._chunks_rewrite = False            # a persisted line was deleted: rewrite the file instead of appending
         if self.db_path is not None:
             os.makedirs(self.db_path, exist_ok=True)  # store.rs:113
             self._load()
@@ -216,9 +224,20 @@ class VectorStore:
             self._removed = set(removed)
         if os.path.exists(chunks):
             for line in open(chunks):
-                d = json.loads(line)
+                try:
+                    d = json.loads(line)
+                except ValueError:
+                    self._chunks_rewrite = True  # a torn last line of an interrupted append
+                    continue
                 cid = int(d.pop("id"))
+                if cid >= int(m["next_id"]):  # appended after the last commit point
+                    self._chunks_rewrite = True
+                    continue
                 self._meta[cid] = ChunkMetadata(**d)
+            self._persisted_meta_ids = set(self._meta)
+        for cid in self._removed:  # deletes committed after the last build (delete_chunks) win over older lines
+            if self._meta.pop(cid, None) is not None:
+                self._chunks_rewrite = True
         if m.get("built"):
             _lib.check(self._fn("build")(self._h))
 
@@ -231,17 +250,38 @@ class VectorStore:
             step = max(1, (256 << 20) // (4 * self.dimensions))
             for lo in range(self._persisted_rows, n, step):
                 f.write(self.read_rows(lo, min(step, n - lo)).astype("<f4").tobytes())
-        with open(chunks + ".tmp", "w") as f:
-            for cid in sorted(self._meta):
-                d = dataclasses.asdict(self._meta[cid])
-                d["id"] = cid
-                f.write(json.dumps(d) + "\n")
-        os.replace(chunks + ".tmp", chunks)
+        self._write_chunks(chunks)
+        self._write_meta(meta, built=True)  # the meta file is the commit point
+        self._persisted_rows = n
+
+    def _write_chunks(self, chunks: str) -> None:
+        """chunks.jsonl: appended to when only new chunks arrived (the reference builds per file: rewriting N lines per
+        build would be O(N) per file), rewritten atomically when a persisted line was deleted."""
+        def line(cid):
+            d = dataclasses.asdict(self._meta[cid])
+            d["id"] = cid
+            return json.dumps(d) + "\n"
+
+        if self._chunks_rewrite or not os.path.exists(chunks):
+            with open(chunks + ".tmp", "w") as f:
+                for cid in sorted(self._meta):
+                    f.write(line(cid))
+            os.replace(chunks + ".tmp", chunks)
+        else:
+            new = sorted(set(self._meta) - self._persisted_meta_ids)
+            if new:
+                with open(chunks, "a") as f:
+                    for cid in new:
+                        f.write(line(cid))
+        self._persisted_meta_ids = set(self._meta)
+        self._chunks_rewrite = False
+
+    def _write_meta(self, meta: str, built: bool) -> None:
         with open(meta + ".tmp", "w") as f:
             json.dump({"format": self.FORMAT, "dimensions": self.dimensions, "id_base": self.id_base,
-                       "next_id": self.next_id(), "removed": sorted(self._removed), "built": True}, f)
-        os.replace(meta + ".tmp", meta)  # the meta file is the commit point
-        self._persisted_rows = n
+                       "next_id": self.id_base + self._persisted_rows if not built else self.next_id(),
+                       "removed": sorted(self._removed), "built": built}, f)
+        os.replace(meta + ".tmp", meta)
 
     def db_size(self) -> int:
         """store.rs:741-749: bytes on disk."""
@@ -332,9 +372,21 @@ class VectorStore:
         _lib.check(self._fn("remove")(self._h, ids.ctypes.data_as(u32p), ids.size, C.byref(removed)))
         nxt = self.next_id()
         for i in ids.tolist():
-            self._meta.pop(i, None)  # store.rs:598
+            if self._meta.pop(i, None) is not None and i in self._persisted_meta_ids:  # store.rs:598
+                self._chunks_rewrite = True
             if self.id_base <= i < nxt:
                 self._removed.add(i)
+        # The reference commits a delete to LMDB at once (store.rs:584-610).  Here the removed list of the persisted
+        # state is committed at once too (atomic rewrite of the small meta file): a process that dies before the next
+        # build_index() reopens without the deleted chunks.  Rows appended since the last build stay HBM-only until
+        # that build, as arroy's tree does.
+        if self.db_path is not None and os.path.exists(self._paths()[1]):
+            m = json.load(open(self._paths()[1]))
+            keep = int(m["next_id"])
+            with open(self._paths()[1] + ".tmp", "w") as f:
+                m["removed"] = sorted(i for i in self._removed if i < keep)
+                json.dump(m, f)
+            os.replace(self._paths()[1] + ".tmp", self._paths()[1])
         return int(removed.value)
 
     def build_index(self) -> None:

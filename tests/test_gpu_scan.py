@@ -585,6 +585,24 @@ def test_persistent_store_round_trip(VS, oracle, tmp_path):
     assert new_id == [n]                  # ids are never reused (store.rs:101)
     st2.close()
 
+    st3 = VS(db, dim)                     # a delete is committed at once (store.rs:584-610), not at the next build
+    assert st3.delete_chunks([6, 123]) == 2
+    st3.close()                           # ... so a process that ends here
+    st3 = VS(db, dim)
+    assert st3.get_chunk(6) is None and st3.get_chunk(7).hash == "h7" and len(st3) == n - 4 and st3.next_id() == n
+    assert all(r.id not in (6, 123) for r in st3.search(q, 10))
+    st3.build_index()                     # rewrites chunks.jsonl without the deleted lines, appends nothing
+    lines = [__import__("json").loads(l)["id"] for l in open(db / "chunks.jsonl")]
+    assert 6 not in lines and 123 not in lines and len(lines) == len(set(lines)) == n - 4
+    st3.insert_chunks_with_ids([EmbeddedChunk(Chunk("y", 1, 2, "Function", "b.rs"), rows[1])])
+    st3.build_index()                     # only the new chunk is appended
+    assert sum(1 for _ in open(db / "chunks.jsonl")) == len(lines) + 1
+    st3.delete_chunks([n])
+    st3.build_index()
+    want = [(r.id, r.score, r.path) for r in st3.search(q, 10)]
+    assert all(w[0] not in (5, 17, 6, 123, n) for w in want)
+    st3.close()
+
     ro = VS.open_readonly(db, dim)        # store.rs:183-250
     assert [(r.id, r.score, r.path) for r in ro.search(q, 10)] == want
     with pytest.raises(CsError):
