@@ -87,6 +87,7 @@ SIGNATURES = {
     "cs_shards_shard_len": (C.c_uint64, [vp, C.c_uint32]),
     "cs_shards_direct_gather": (C.c_int32, [vp]),
     "cs_shards_search": (C.c_int32, [vp, f32p, C.c_uint32, C.c_uint32, C.c_uint32, f32p, u32p, u32p]),
+    "cs_shards_search_variants": (C.c_int32, [vp, f32p, C.c_uint32, C.c_uint32, C.c_uint32, f32p, u32p, u32p, i32p]),
     "cs_shards_read_rows": (C.c_int32, [vp, C.c_uint64, C.c_uint64, f32p]),
     "cs_index_read_rows": (C.c_int32, [vp, C.c_uint64, C.c_uint64, f32p]),
     "cs_index_debug_counters": (C.c_int32, [vp, u64p, u64p]),

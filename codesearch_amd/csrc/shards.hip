@@ -49,6 +49,7 @@ struct SearchCtx {              // one in-flight search; pooled (search is `&sel
     uint64_t* d_gathered = nullptr; size_t gathered_cap = 0;  // [N][nq][k] on the root device
     float* h_queries = nullptr; size_t h_q_cap = 0;           // pinned, visible to every device
     uint64_t* h_keys = nullptr; size_t h_key_cap = 0;         // pinned: merged [nq][k]
+    uint32_t* h_meta = nullptr;                               // pinned: variant merge count + high-confidence flag
 };
 
 }  // namespace
@@ -99,6 +100,7 @@ void free_ctx(cs_shards* h, SearchCtx* c) {
     if (c->d_gathered) (void)hipFree(c->d_gathered);
     if (c->h_queries) (void)hipHostFree(c->h_queries);
     if (c->h_keys) (void)hipHostFree(c->h_keys);
+    if (c->h_meta) (void)hipHostFree(c->h_meta);
     delete c;
 }
 
@@ -135,12 +137,13 @@ int32_t reserve_ctx(cs_shards* h, SearchCtx* c, uint32_t nq, uint32_t k) {
     }
     {
         DeviceGuard g(h->root);
-        if (kn * h->n > c->gathered_cap) {
+        if (kn * (h->n + 1) > c->gathered_cap) {  // [N][nq][k] shard slots + one merged [nq][k] block (variant searches)
             if (c->d_gathered) { CS_HIP(hipStreamSynchronize(c->root_stream)); (void)hipFree(c->d_gathered); }
             c->d_gathered = nullptr; c->gathered_cap = 0;
-            CS_HIP(hipMalloc(&c->d_gathered, kn * h->n * sizeof(uint64_t)));
-            c->gathered_cap = kn * h->n;
+            CS_HIP(hipMalloc(&c->d_gathered, kn * (h->n + 1) * sizeof(uint64_t)));
+            c->gathered_cap = kn * (h->n + 1);
         }
+        if (!c->h_meta) CS_HIP(hipHostMalloc(&c->h_meta, 2 * sizeof(uint32_t), hipHostMallocPortable | hipHostMallocMapped));
     }
     for (uint32_t s = 0; s < h->n; ++s) {
         DeviceGuard g(h->devices[s]);
@@ -177,6 +180,102 @@ int32_t enqueue_shard(cs_shards* h, SearchCtx* c, uint32_t s, uint32_t q0, uint3
     if (!h->direct)
         CS_HIP(hipMemcpyPeerAsync(slot, h->root, dst, h->devices[s], (size_t)qn * k * sizeof(uint64_t), x.stream));
     return CS_OK;
+}
+
+}  // namespace
+
+namespace {
+
+// variants != null: after the shard merge the nq lists are merged as query variants (scan.hip merge_variants_kernel) and
+// out_cos / out_ids hold ONE list of k; variants[0] = count, variants[1] = high-confidence flag.
+int32_t shards_search_impl(cs_shards* h, const float* queries, uint32_t nq, uint32_t dim, uint32_t k, float* out_cos,
+                           uint32_t* out_ids, uint32_t* out_counts, uint32_t* variants) {
+    if (!h) return fail(CS_ERR_BAD_ARG, "null shards handle");
+    if (dim != h->dim)  // store.rs:432-438
+        return fail(CS_ERR_DIM_MISMATCH, "Query embedding dimension mismatch: expected %u, got %u", h->dim, dim);
+    if (!h->built)  // store.rs:440-444
+        return fail(CS_ERR_NOT_BUILT, "Index not built. Call build_index() after inserting chunks.");
+    if (nq == 0 || nq > CS_MAX_QUERIES) return fail(CS_ERR_BAD_ARG, "nq must be in 1..%u, got %u", CS_MAX_QUERIES, nq);
+    if (k == 0 || k > CS_MAX_K) return fail(CS_ERR_BAD_ARG, "k must be in 1..%u, got %u", CS_MAX_K, k);
+    if (!queries || !out_cos || !out_ids || !out_counts) return fail(CS_ERR_BAD_ARG, "null buffer");
+    SearchCtx* c = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(h->mu);
+        if (!h->pool.empty()) { c = h->pool.back(); h->pool.pop_back(); }
+    }
+    if (!c) CS_TRY(new_ctx(h, &c));
+    const int32_t st = [&]() -> int32_t {
+        CS_TRY(reserve_ctx(h, c, nq, k));
+        memcpy(c->h_queries, queries, (size_t)nq * h->dim * sizeof(float));
+        for (uint32_t s = 0; s < h->n; ++s) {
+            CS_TRY(enqueue_shard(h, c, s, 0, nq, nq, k, true));
+            DeviceGuard g(h->devices[s]);
+            CS_HIP(hipEventRecord(c->sh[s].done, c->sh[s].stream));
+        }
+        auto merge = [&]() -> int32_t {
+            DeviceGuard g(h->root);
+            for (uint32_t s = 0; s < h->n; ++s) CS_HIP(hipStreamWaitEvent(c->root_stream, c->sh[s].done, 0));
+            if (variants) {
+                // shard merge into the spare block behind the shard slots, then the variant merge into pinned memory
+                uint64_t* d_merged = c->d_gathered + (size_t)h->n * nq * k;
+                CS_TRY(merge_topk_device_impl(h->root, c->d_gathered, h->n, nq, k, d_merged, nullptr, nullptr, nullptr,
+                                              c->root_stream, (uint32_t)h->stripe, h->n));
+                CS_TRY(launch_merge_variants(d_merged, nq, k, k, c->h_keys, nullptr, nullptr, c->h_meta, c->h_meta + 1,
+                                             c->root_stream));
+            } else {
+                CS_TRY(merge_topk_device_impl(h->root, c->d_gathered, h->n, nq, k, c->h_keys, nullptr, nullptr, nullptr,
+                                              c->root_stream, (uint32_t)h->stripe, h->n));
+            }
+            CS_HIP(hipStreamSynchronize(c->root_stream));
+            return CS_OK;
+        };
+        CS_TRY(merge());
+        if (nq > 16) {
+            // cs_index_search_device reports candidate-buffer overflows of > 16-query searches instead of
+            // rerunning them: redo an overflowed shard in slices of 16 queries (always exact), merge again
+            bool again = false;
+            for (uint32_t s = 0; s < h->n; ++s) {
+                uint32_t ov = 0;
+                CS_TRY(cs_index_search_status(h->idx[s], c->sh[s].stream, &ov));
+                if (!ov) continue;
+                again = true;
+                for (uint32_t q0 = 0; q0 < nq; q0 += 16)
+                    CS_TRY(enqueue_shard(h, c, s, q0, std::min<uint32_t>(16, nq - q0), nq, k, false));
+                DeviceGuard g(h->devices[s]);
+                CS_HIP(hipEventRecord(c->sh[s].done, c->sh[s].stream));
+            }
+            if (again) CS_TRY(merge());
+        }
+        if (variants) {
+            for (uint32_t j = 0; j < k; ++j) {
+                const uint64_t key = c->h_keys[j];
+                out_cos[j] = key ? key_cos(key) : 0.0f;
+                out_ids[j] = key ? key_id(key) : 0xFFFFFFFFu;
+            }
+            variants[0] = c->h_meta[0];
+            variants[1] = c->h_meta[1];
+            return CS_OK;
+        }
+        for (uint32_t q = 0; q < nq; ++q) {  // keys are best-first, 0 = empty slot
+            uint32_t cnt = 0;
+            for (uint32_t j = 0; j < k; ++j) {
+                const uint64_t key = c->h_keys[(size_t)q * k + j];
+                if (key) ++cnt;
+                out_cos[(size_t)q * k + j] = key ? key_cos(key) : 0.0f;
+                out_ids[(size_t)q * k + j] = key ? key_id(key) : 0xFFFFFFFFu;
+            }
+            out_counts[q] = cnt;
+        }
+        return CS_OK;
+    }();
+    if (st != CS_OK) {  // leave nothing in flight behind a failed call
+        for (uint32_t s = 0; s < h->n; ++s) { DeviceGuard g(h->devices[s]); (void)hipStreamSynchronize(c->sh[s].stream); }
+        DeviceGuard g(h->root);
+        (void)hipStreamSynchronize(c->root_stream);
+    }
+    std::lock_guard<std::mutex> lk(h->mu);
+    h->pool.push_back(c);
+    return st;
 }
 
 }  // namespace
@@ -320,73 +419,21 @@ int32_t cs_shards_read_rows(cs_shards* h, uint64_t first_id, uint64_t n, float* 
 
 int32_t cs_shards_search(cs_shards* h, const float* queries, uint32_t nq, uint32_t dim, uint32_t k, float* out_cos,
                          uint32_t* out_ids, uint32_t* out_counts) {
-    if (!h) return fail(CS_ERR_BAD_ARG, "null shards handle");
-    if (dim != h->dim)  // store.rs:432-438
-        return fail(CS_ERR_DIM_MISMATCH, "Query embedding dimension mismatch: expected %u, got %u", h->dim, dim);
-    if (!h->built)  // store.rs:440-444
-        return fail(CS_ERR_NOT_BUILT, "Index not built. Call build_index() after inserting chunks.");
-    if (nq == 0 || nq > CS_MAX_QUERIES) return fail(CS_ERR_BAD_ARG, "nq must be in 1..%u, got %u", CS_MAX_QUERIES, nq);
-    if (k == 0 || k > CS_MAX_K) return fail(CS_ERR_BAD_ARG, "k must be in 1..%u, got %u", CS_MAX_K, k);
-    if (!queries || !out_cos || !out_ids || !out_counts) return fail(CS_ERR_BAD_ARG, "null buffer");
-    SearchCtx* c = nullptr;
-    {
-        std::lock_guard<std::mutex> lk(h->mu);
-        if (!h->pool.empty()) { c = h->pool.back(); h->pool.pop_back(); }
-    }
-    if (!c) CS_TRY(new_ctx(h, &c));
-    const int32_t st = [&]() -> int32_t {
-        CS_TRY(reserve_ctx(h, c, nq, k));
-        memcpy(c->h_queries, queries, (size_t)nq * h->dim * sizeof(float));
-        for (uint32_t s = 0; s < h->n; ++s) {
-            CS_TRY(enqueue_shard(h, c, s, 0, nq, nq, k, true));
-            DeviceGuard g(h->devices[s]);
-            CS_HIP(hipEventRecord(c->sh[s].done, c->sh[s].stream));
-        }
-        auto merge = [&]() -> int32_t {
-            DeviceGuard g(h->root);
-            for (uint32_t s = 0; s < h->n; ++s) CS_HIP(hipStreamWaitEvent(c->root_stream, c->sh[s].done, 0));
-            CS_TRY(merge_topk_device_impl(h->root, c->d_gathered, h->n, nq, k, c->h_keys, nullptr, nullptr, nullptr,
-                                          c->root_stream, (uint32_t)h->stripe, h->n));
-            CS_HIP(hipStreamSynchronize(c->root_stream));
-            return CS_OK;
-        };
-        CS_TRY(merge());
-        if (nq > 16) {
-            // cs_index_search_device reports candidate-buffer overflows of > 16-query searches instead of
-            // rerunning them: redo an overflowed shard in slices of 16 queries (always exact), merge again
-            bool again = false;
-            for (uint32_t s = 0; s < h->n; ++s) {
-                uint32_t ov = 0;
-                CS_TRY(cs_index_search_status(h->idx[s], c->sh[s].stream, &ov));
-                if (!ov) continue;
-                again = true;
-                for (uint32_t q0 = 0; q0 < nq; q0 += 16)
-                    CS_TRY(enqueue_shard(h, c, s, q0, std::min<uint32_t>(16, nq - q0), nq, k, false));
-                DeviceGuard g(h->devices[s]);
-                CS_HIP(hipEventRecord(c->sh[s].done, c->sh[s].stream));
-            }
-            if (again) CS_TRY(merge());
-        }
-        for (uint32_t q = 0; q < nq; ++q) {  // keys are best-first, 0 = empty slot
-            uint32_t cnt = 0;
-            for (uint32_t j = 0; j < k; ++j) {
-                const uint64_t key = c->h_keys[(size_t)q * k + j];
-                if (key) ++cnt;
-                out_cos[(size_t)q * k + j] = key ? key_cos(key) : 0.0f;
-                out_ids[(size_t)q * k + j] = key ? key_id(key) : 0xFFFFFFFFu;
-            }
-            out_counts[q] = cnt;
-        }
-        return CS_OK;
-    }();
-    if (st != CS_OK) {  // leave nothing in flight behind a failed call
-        for (uint32_t s = 0; s < h->n; ++s) { DeviceGuard g(h->devices[s]); (void)hipStreamSynchronize(c->sh[s].stream); }
-        DeviceGuard g(h->root);
-        (void)hipStreamSynchronize(c->root_stream);
-    }
-    std::lock_guard<std::mutex> lk(h->mu);
-    h->pool.push_back(c);
-    return st;
+    return shards_search_impl(h, queries, nq, dim, k, out_cos, out_ids, out_counts, nullptr);
+}
+
+// search::search's vector leg over the sharded store (cs_index_search_variants' counterpart): per-variant searches on
+// every shard, shard merge, then the variant merge (dedup by id keeping the best key, top k, early-termination
+// predicate) on the first device.  out_cos / out_ids: [k]; *out_count valid entries.
+int32_t cs_shards_search_variants(cs_shards* h, const float* queries, uint32_t nq, uint32_t dim, uint32_t k, float* out_cos,
+                                  uint32_t* out_ids, uint32_t* out_count, int32_t* out_high_confidence) {
+    if (nq > CS_MAX_VARIANTS) return fail(CS_ERR_BAD_ARG, "at most %u query variants per call, got %u", CS_MAX_VARIANTS, nq);
+    if (!out_count) return fail(CS_ERR_BAD_ARG, "null buffer");
+    uint32_t meta[2] = {0, 0};
+    CS_TRY(shards_search_impl(h, queries, nq, dim, k, out_cos, out_ids, out_count, meta));
+    *out_count = meta[0];
+    if (out_high_confidence) *out_high_confidence = (int32_t)meta[1];
+    return CS_OK;
 }
 
 }  // extern "C"

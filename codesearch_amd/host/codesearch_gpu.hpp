@@ -92,9 +92,18 @@ class VectorStore {
         : dimensions_(dimensions) {
         check(cs_index_create((uint32_t)dimensions, capacity, device, id_base, &h_));
     }
-    ~VectorStore() { cs_index_destroy(h_); }
+    // The same store row-sharded over several GPUs of the node inside this process (cs_shards_*):
+    // ids stay contiguous, rows are dealt in stripes of rows_per_stripe ids, a search scans every shard and merges
+    // on devices[0].
+    VectorStore(const std::string& /*db_path*/, size_t dimensions, const std::vector<int32_t>& devices,
+                uint64_t rows_per_stripe = 65536, uint64_t capacity = 0)
+        : dimensions_(dimensions) {
+        check(cs_shards_create((uint32_t)dimensions, (uint32_t)devices.size(), devices.data(), rows_per_stripe, capacity, &sh_));
+    }
+    ~VectorStore() { if (sh_) cs_shards_destroy(sh_); else cs_index_destroy(h_); }
     VectorStore(const VectorStore&) = delete;
     VectorStore& operator=(const VectorStore&) = delete;
+    bool sharded() const { return sh_ != nullptr; }
 
     // store.rs:618-686
     std::vector<uint32_t> insert_chunks_with_ids(const std::vector<EmbeddedChunk>& chunks) {
@@ -109,25 +118,26 @@ class VectorStore {
             rows.insert(rows.end(), c.embedding.begin(), c.embedding.end());
         }
         std::vector<uint32_t> ids(chunks.size());
-        check(cs_index_add(h_, rows.data(), chunks.size(), (uint32_t)dimensions_, ids.data()));
+        check(sh_ ? cs_shards_add(sh_, rows.data(), chunks.size(), (uint32_t)dimensions_, ids.data())
+                  : cs_index_add(h_, rows.data(), chunks.size(), (uint32_t)dimensions_, ids.data()));
         for (size_t i = 0; i < chunks.size(); ++i) meta_[ids[i]] = ChunkMetadata::from_embedded_chunk(chunks[i]);
         return ids;
     }
     // store.rs:334-379
     size_t insert_chunks(const std::vector<EmbeddedChunk>& chunks) { return insert_chunks_with_ids(chunks).size(); }
     // store.rs:386-430
-    void build_index() { check(cs_index_build(h_)); }
+    void build_index() { check(sh_ ? cs_shards_build(sh_) : cs_index_build(h_)); }
     // store.rs:548-610
     size_t delete_chunks(const std::vector<uint32_t>& ids) {
         uint64_t removed = 0;
-        check(cs_index_remove(h_, ids.data(), ids.size(), &removed));
+        check(sh_ ? cs_shards_remove(sh_, ids.data(), ids.size(), &removed) : cs_index_remove(h_, ids.data(), ids.size(), &removed));
         for (uint32_t id : ids) meta_.erase(id);
         return (size_t)removed;
     }
     // store.rs:690-707
-    void clear() { check(cs_index_clear(h_)); meta_.clear(); }
+    void clear() { check(sh_ ? cs_shards_clear(sh_) : cs_index_clear(h_)); meta_.clear(); }
     // store.rs:745
-    bool is_indexed() const { return cs_index_is_built(h_) != 0; }
+    bool is_indexed() const { return (sh_ ? cs_shards_is_built(sh_) : cs_index_is_built(h_)) != 0; }
 
     // store.rs:431-486
     std::vector<SearchResult> search(const std::vector<float>& query_embedding, size_t limit) const {
@@ -147,8 +157,10 @@ class VectorStore {
         }
         std::vector<float> cos(nq * limit);
         std::vector<uint32_t> ids(nq * limit), counts(nq);
-        check(cs_index_search(h_, q.data(), (uint32_t)nq, (uint32_t)qdim, (uint32_t)limit, cos.data(), ids.data(),
-                              counts.data()));
+        check(sh_ ? cs_shards_search(sh_, q.data(), (uint32_t)nq, (uint32_t)qdim, (uint32_t)limit, cos.data(), ids.data(),
+                                     counts.data())
+                  : cs_index_search(h_, q.data(), (uint32_t)nq, (uint32_t)qdim, (uint32_t)limit, cos.data(), ids.data(),
+                                    counts.data()));
         std::vector<std::vector<SearchResult>> out(nq);
         for (size_t i = 0; i < nq; ++i)
             for (uint32_t j = 0; j < counts[i]; ++j) {
@@ -161,6 +173,41 @@ class VectorStore {
                 r.score = 1.0f - r.distance;
                 out[i].push_back(std::move(r));
             }
+        return out;
+    }
+    // search::search's vector leg in one call (src/search/mod.rs:508-611): every variant searched for `limit` rows, a
+    // chunk found by several variants keeps its best score, the best `limit` distinct chunks best-first — merged on the
+    // device; *high_confidence = the top five all have distance < 0.15 (the reference then skips its FTS leg).
+    std::vector<SearchResult> search_variants(const std::vector<std::vector<float>>& variants, size_t limit,
+                                              bool* high_confidence = nullptr) const {
+        const size_t nq = variants.size();
+        if (nq == 0) return {};
+        const size_t qdim = variants[0].size();
+        std::vector<float> q;
+        for (const auto& v : variants) {
+            if (v.size() != qdim) throw Error(CS_ERR_BAD_ARG, "queries of unequal length");
+            q.insert(q.end(), v.begin(), v.end());
+        }
+        std::vector<float> cos(limit);
+        std::vector<uint32_t> ids(limit);
+        uint32_t count = 0;
+        int32_t flag = 0;
+        check(sh_ ? cs_shards_search_variants(sh_, q.data(), (uint32_t)nq, (uint32_t)qdim, (uint32_t)limit, cos.data(),
+                                              ids.data(), &count, &flag)
+                  : cs_index_search_variants(h_, q.data(), (uint32_t)nq, (uint32_t)qdim, (uint32_t)limit, cos.data(),
+                                             ids.data(), &count, &flag));
+        if (high_confidence) *high_confidence = flag != 0;
+        std::vector<SearchResult> out;
+        for (uint32_t j = 0; j < count; ++j) {
+            auto it = meta_.find(ids[j]);
+            if (it == meta_.end()) continue;
+            SearchResult r;
+            r.id = ids[j];
+            r.meta = it->second;
+            r.distance = cs_cos_to_distance(cos[j]);
+            r.score = 1.0f - r.distance;
+            out.push_back(std::move(r));
+        }
         return out;
     }
     std::optional<ChunkMetadata> get_chunk(uint32_t id) const {  // store.rs:709-713
@@ -184,10 +231,11 @@ class VectorStore {
     size_t dimensions() const { return dimensions_; }
     cs_index* handle() const { return h_; }
     // searches of >= n queries take the f16 filter + exact f32 refine path (default 2; 1 = always)
-    void set_filter_min_queries(uint32_t n) { check(cs_index_set_filter_min_queries(h_, n)); }
+    void set_filter_min_queries(uint32_t n) { if (h_) check(cs_index_set_filter_min_queries(h_, n)); }
 
   private:
     cs_index* h_ = nullptr;
+    cs_shards* sh_ = nullptr;
     size_t dimensions_;
     std::map<uint32_t, ChunkMetadata> meta_;
 };

@@ -446,20 +446,15 @@ class VectorStore:
         """search::search's vector leg (src/search/mod.rs:508-611) in one call: every variant searched for `limit`
         rows, union with a chunk keeping its best score, best `limit` distinct chunks best-first, merged on
         the device.  -> (results, high_confidence) where high_confidence is the early-termination predicate
-        (top five all distance < 0.15).  Single-GPU stores; a sharded store merges on the host (search.py)."""
+        (top five all distance < 0.15)."""
         q = np.ascontiguousarray(query_embeddings, np.float32)
         if q.ndim == 1:
             q = q[None, :]
-        if self.sharded:
-            from .search import merge_variant_results, should_use_vector_only
-
-            merged = merge_variant_results(self.search_batch(q, limit), limit)
-            return merged, should_use_vector_only(merged, False)
         nq, dim = q.shape
         cos = np.zeros(max(limit, 1), np.float32)
         ids = np.zeros(max(limit, 1), np.uint32)
         count, flag = C.c_uint32(), C.c_int32()
-        _lib.check(self._lib.cs_index_search_variants(self._h, q.ctypes.data_as(f32p), nq, dim, limit,
+        _lib.check(self._fn("search_variants")(self._h, q.ctypes.data_as(f32p), nq, dim, limit,
                                                       cos.ctypes.data_as(f32p), ids.ctypes.data_as(u32p),
                                                       C.byref(count), C.byref(flag)))
         return self._results(cos, ids, int(count.value)), bool(flag.value)

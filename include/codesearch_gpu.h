@@ -204,6 +204,10 @@ uint64_t cs_shards_shard_len(const cs_shards* h, uint32_t shard);    /* live row
 int32_t cs_shards_direct_gather(const cs_shards* h);                 /* 1 = shards write into the root's buffer */
 int32_t cs_shards_search(cs_shards* h, const float* queries, uint32_t nq, uint32_t dim, uint32_t k,
                          float* out_cos, uint32_t* out_ids, uint32_t* out_counts);
+/* cs_index_search_variants over the sharded store: per-variant searches on every shard, the shard merge, then the
+ * variant merge (src/search/mod.rs:513-611) on the first device. */
+int32_t cs_shards_search_variants(cs_shards* h, const float* queries, uint32_t nq, uint32_t dim, uint32_t k,
+                                  float* out_cos, uint32_t* out_ids, uint32_t* out_count, int32_t* out_high_confidence);
 int32_t cs_shards_read_rows(cs_shards* h, uint64_t first_id, uint64_t n, float* out_rows);
 
 /* Copy rows [first_row, first_row + n) of the matrix back to host memory (test and

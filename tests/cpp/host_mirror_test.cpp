@@ -133,6 +133,40 @@ int main(int argc, char** argv) {
     REQUIRE(store.search({0.9f, 0.1f, 0.f, 0.f}, 2).size() == 1);
     REQUIRE(store.stats().total_chunks == 1);
 
+    {   // the same store over three shards inside this process (cs_shards_*), and the variant merge on the device
+        VectorStore one("one.db", 8), three("three.db", 8, std::vector<int32_t>{0, 0, 0}, /*rows_per_stripe=*/2);
+        std::vector<EmbeddedChunk> cs;
+        for (int i = 0; i < 11; ++i) {
+            EmbeddedChunk c;
+            c.chunk.content = "fn f" + std::to_string(i) + "() {}"; c.chunk.kind = "Function"; c.chunk.path = "m" + std::to_string(i % 3) + ".rs";
+            c.embedding.assign(8, 0.05f * (float)((i * 7) % 5));
+            c.embedding[i % 8] = 1.0f; c.embedding[(i * 3 + 1) % 8] += 0.4f;
+            cs.push_back(c);
+        }
+        auto ids1 = one.insert_chunks_with_ids(cs), ids3 = three.insert_chunks_with_ids(cs);
+        REQUIRE(ids1 == ids3 && ids3.front() == 0 && ids3.back() == 10 && three.sharded());
+        REQUIRE(one.delete_chunks({4}) == 1 && three.delete_chunks({4}) == 1);
+        one.build_index(); three.build_index();
+        std::vector<std::vector<float>> variants = {cs[2].embedding, cs[9].embedding, cs[2].embedding};
+        variants[2][5] += 0.3f;
+        auto r1 = one.search_batch(variants, 5), r3 = three.search_batch(variants, 5);
+        REQUIRE(r1.size() == 3 && r3.size() == 3);
+        for (size_t v = 0; v < 3; ++v) {
+            REQUIRE(r1[v].size() == r3[v].size() && r1[v].size() == 5);
+            for (size_t j = 0; j < r1[v].size(); ++j) REQUIRE(r1[v][j].id == r3[v][j].id && r1[v][j].score == r3[v][j].score);
+        }
+        REQUIRE(r1[0][0].id == 2 && r1[1][0].id == 9);
+        bool conf1 = true, conf3 = true;
+        auto m1 = one.search_variants(variants, 5, &conf1), m3 = three.search_variants(variants, 5, &conf3);
+        auto want = merge_variant_results(r1, 5);  // codesearch_callers.hpp: the host statement of mod.rs:513-590
+        REQUIRE(m1.size() == want.size() && m3.size() == want.size() && conf1 == conf3);
+        REQUIRE(conf1 == should_use_vector_only(want, false));
+        for (size_t j = 0; j < want.size(); ++j) {
+            REQUIRE(m1[j].score == want[j].score && m3[j].score == want[j].score);
+            REQUIRE(m1[j].id == m3[j].id);
+        }
+    }
+
     cs_bert_config cfg;
     cs_bert_config_bge_small(&cfg);
     cfg.vocab_size = 512; cfg.layers = 1;

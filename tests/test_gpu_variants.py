@@ -133,6 +133,13 @@ def test_search_variants_end_to_end(gpu_lib, oracle):
             best[int(ii)] = max(best.get(int(ii), -2.0), float(cc))
     top = sorted(best.items(), key=lambda t: (-t[1], t[0]))[:k]
     np.testing.assert_allclose([1.0 - 2.0 * r.distance for r in got], [c for _, c in top], atol=2e-6)
+    sh = VectorStore(None, dim, devices=[0, 0, 0, 0], rows_per_stripe=4096)   # the same through four shards
+    sh.insert_chunks_with_ids([EmbeddedChunk(Chunk(f"fn f{i}() {{}}", i, i + 1, "Function", f"m{i % 13}.rs"), rows[i])
+                               for i in range(n)])
+    sh.build_index()
+    got4, flag4 = sh.search_variants(variants, k)
+    assert [(r.id, r.score) for r in got4] == [(r.id, r.score) for r in got] and flag4 == flag
+    sh.close()
     single, flag1 = st.search_variants(variants[0], 10)               # one variant: the plain search
     assert [r.id for r in single] == [r.id for r in st.search(variants[0], 10)] and flag1 is False
     from codesearch_amd import CsError
