@@ -154,39 +154,9 @@ gemm_wide_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ W,
         const uint64_t t0 = __builtin_amdgcn_s_memtime();
         while (__builtin_amdgcn_s_memtime() - t0 < (uint64_t)stagger_cycles) __builtin_amdgcn_s_sleep(16);
     }
-    float touch_sink = 0.0f;  // destination of the L2 touches below (never read as data)
     while (slot < total_slots) {
         const uint32_t m0 = mt * GW_BM, n0 = nt * GW_BN;
         const uint32_t rot = sh_kc_rot(nt, ntiles, kchunks);  // see sh_mainloop: n-tiles of an m-tile walk K out of phase
-        uint32_t nmt = 0, nnt = 0;
-        const uint32_t nslot = next_valid(slot + gridDim.x, nmt, nnt);  // this block's next tile (prefetch + first stage)
-        const uint32_t nrot = sh_kc_rot(nnt, ntiles, kchunks);
-        // L2 touch of A, PF stages ahead.  Two stage buffers keep ONE stage (16 KiB of A) per CU in flight: 4 MB across the
-        // chip, ~2 TB/s at HBM latency — measured on the FFN-down shape (A = 403 MB straight from HBM): fill alone 173 us,
-        // compute alone 170, together 243.  Waves 0 and 1 therefore touch the A lines of stage kc + PF with one dword load
-        // per lane (64 lines = 8 KiB per instruction, 1/8 of an LDS-DMA's address-path cost per byte): the lines are in L2
-        // when their LDS-DMA is issued two steps later.  The touch is issued after the step's DMAs and loads return in
-        // order, so `vmcnt(1)` at the step barrier still means "this step's DMAs have landed".
-        constexpr uint32_t PF = 3;
-        const bool toucher = wave < 2 && ABL == 0;
-        auto touch = [&](uint32_t step) {  // step: k-step index counted from this tile's stage 0, may run into the next tile
-            uint32_t tm0 = m0, chunk = rot + step;
-            if (step >= kchunks) {
-                if (nslot >= total_slots) return;
-                tm0 = nmt * GW_BM;
-                chunk = nrot + (step - kchunks);
-            }
-            chunk = chunk >= kchunks ? chunk - kchunks : chunk;
-            const uint32_t row = tm0 + wave * 64 + lane;
-            const _Float16* pl = A + ((size_t)(row < M ? row : M - 1) * kchunks + chunk) * 64;
-            asm volatile("global_load_dword %0, %1, off" : "+v"(touch_sink) : "v"(pl) : "memory");
-        };
-        auto step_barrier = [&]() {  // this step's LDS-DMAs have landed and every wave has finished reading the stage
-            if (toucher) asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-        };
         GwAcc acc;
         if (EPI == GW_OUT_LN) {
             // the accumulators START at (bias + residual) * 2^11, the scale the products arrive on: the residual is
@@ -210,9 +180,7 @@ gemm_wide_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ W,
 #pragma unroll
                 for (int j = 0; j < 6; ++j) acc.c[i][j] = sh_f32x4v{0.f, 0.f, 0.f, 0.f};
         }
-        // stage 0 has landed — vmcnt(0): the previous tile's epilogue stores complete out of order with respect to loads, so
-        // a counted wait could pass with a stage-0 DMA still in flight
-        __syncthreads();
+        __syncthreads();  // stage 0 has landed (vmcnt(0) precedes the barrier)
 
         for (uint32_t kc = 0; kc < kchunks; ++kc) {
             const char* cur = lds + ((buf + kc) & 1) * GW_STAGE;
@@ -263,15 +231,15 @@ gemm_wide_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ W,
                     if (ABL != 2) acc.c[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, al[i], acc.c[i][j], 0, 0, 0);
                 wh = whn;
                 wl = wln;
-                if (j == 4 && toucher) touch(kc + PF);  // after the step's last DMA (issued at j <= 3 / 4)
             }
-            if (ABL == 0) step_barrier();  // stage kc+1 has landed; every wave is done reading stage kc
-            else if (ABL != 4 && ABL != 5) __syncthreads();
+            if (ABL != 4 && ABL != 5) __syncthreads();  // stage kc+1 has landed; every wave is done reading stage kc
         }
         if (ABL == 4 || ABL == 5) __syncthreads();
 
         // next tile of this block: its first stage flies into the buffer the epilogue does not use
         const uint32_t ebuf = (buf + kchunks - 1) & 1;  // buffer of the last stage
+        uint32_t nmt = 0, nnt = 0;
+        const uint32_t nslot = next_valid(slot + gridDim.x, nmt, nnt);
         if (nslot < total_slots) {
             tile_src(nmt * GW_BM, nnt * GW_BN, src);
 #pragma unroll
@@ -412,8 +380,6 @@ gemm_wide_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ W,
         mt = nmt;
         nt = nnt;
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    asm volatile("" ::"v"(touch_sink));
 }
 
 // true when every w_hi of a split weight matrix times 2^11 stays finite in f16 (|w_hi| <= 31.98)
