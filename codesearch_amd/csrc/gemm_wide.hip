@@ -32,6 +32,10 @@
 
 namespace cs {
 
+// volatile loads that stay global_load (a volatile generic pointer compiles to flat_load, which also counts on lgkmcnt)
+typedef volatile sh_f32x4 __attribute__((address_space(1))) gw_vglobal_f32x4;
+
+
 constexpr int GW_BM = 128, GW_BN = 384;
 constexpr int GW_A_BYTES = GW_BM * 128;            // one k-chunk (32 k, hi + lo) of 128 A rows
 constexpr int GW_STATS = 5 * GW_BM * 4;            // LayerNorm epilogue: [4 column groups][128 rows] f32 partial sums + [128] row statistic
@@ -312,8 +316,8 @@ gemm_wide_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ W,
                 if (EPI == GW_OUT_LN) {
                     // gamma / beta re-read per strip (volatile: not hoisted out of the strip loop — 48 registers the
                     // accumulators need); they sit in L1
-                    const sh_f32x4 gj = *reinterpret_cast<const volatile sh_f32x4*>(ln_g + wc * 96 + 16 * j + 4 * g);
-                    const sh_f32x4 bj = *reinterpret_cast<const volatile sh_f32x4*>(ln_b + wc * 96 + 16 * j + 4 * g);
+                    const sh_f32x4 gj = *(const gw_vglobal_f32x4*)(ln_g + wc * 96 + 16 * j + 4 * g);
+                    const sh_f32x4 bj = *(const gw_vglobal_f32x4*)(ln_b + wc * 96 + 16 * j + 4 * g);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = (acc.c[i][j][r] - mean[i]) * inv * gj[r] + bj[r];
                 } else {

@@ -403,7 +403,14 @@ int32_t run_search(cs_index* h, Workspace* w, const ScanPlan& plan, const float*
                               (nq == 1 && h->single_filter_min_k && k >= h->single_filter_min_k && h->n_rows >= 2000000);
     const bool filter_path = split_ready && wants_filter && h->n_rows > 0 && h->normed_rows >= h->n_rows;
     w->qw.q_pinned = filter_path ? h_queries_pinned : nullptr;
-    if (h_queries_pinned && !filter_path)
+    // A streaming scan of a few blocks (a corpus of the reference's own size: hundreds to thousands of chunks) reads
+    // the queries straight from the pinned buffer too: a copy launch costs more than <= 64 blocks' reads over the link.
+    const bool streaming = !filter_path && !(h->n_rows > 0 && h->normed_rows >= h->n_rows &&
+                                             ((split_ready && wants_filter) || (nq >= 5 && batched_supported(h->dim))));
+    if (h_queries_pinned && streaming && scan_prime_supported(h->dim) /* queries go to registers once */ &&
+        (uint64_t)plan.blocks * plan.passes <= 64)
+        d_queries = h_queries_pinned;
+    else if (h_queries_pinned && !filter_path)
         CS_HIP(hipMemcpyAsync(const_cast<float*>(d_queries), h_queries_pinned, (size_t)nq * h->dim * sizeof(float),
                               hipMemcpyHostToDevice, stream));
     // Two or more queries: the f16 filter reads half the bytes of the f32 scan once for up to 128

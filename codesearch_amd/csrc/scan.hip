@@ -53,11 +53,26 @@ __device__ __forceinline__ uint64_t shfl_xor_u64(uint64_t v, int m) {
 // that ties the worst cosine loses to it (id asc) and `c > thr` is the whole test — the
 // `>` of benchmark_models.rs:160.  `floor` is what thr falls back to while a slot is empty:
 // -inf, or the primed lower bound (see scan_topk_kernel's PRIME mode).
-__device__ __forceinline__ void wave_list_insert(volatile uint64_t* list, uint32_t k, int lane,
+__device__ __forceinline__ void wave_list_insert(volatile uint64_t* list_generic, uint32_t k, int lane,
                                                  float c, uint32_t id, float& thr,
                                                  uint32_t& wpos,
                                                  float floor = -__builtin_huge_valf()) {
-    if (lane == 0) list[wpos] = key_pack(c, id);
+    // While the list still has empty slots they are filled in index order (the search below picks the lowest
+    // empty slot), thr stays at the floor and nothing needs searching: wpos < kListFull counts the filled slots.
+    // A k = 200 list over a small corpus never leaves this phase; the 64-lane search (~1,000 cycles) starts with
+    // the insert that fills the last slot.
+    constexpr uint32_t kListFull = 0x80000000u;
+    const uint32_t slot = wpos & ~kListFull;
+    // The list is LDS; say so.  Through the generic pointer these were flat_store / flat_load, which count on vmcnt
+    // as well and return out of order with the corpus loads in flight: every `s_waitcnt vmcnt(N)` of the scan loop
+    // after a possible insert degraded to vmcnt(0).
+    typedef volatile uint64_t __attribute__((address_space(3))) lds_vu64;
+    lds_vu64* const list = (lds_vu64*)list_generic;
+    if (lane == 0) list[slot] = key_pack(c, id);
+    if (!(wpos & kListFull) && slot + 1 < k) {
+        wpos = slot + 1;
+        return;
+    }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     uint64_t mk = ~0ull;
@@ -72,7 +87,7 @@ __device__ __forceinline__ void wave_list_insert(volatile uint64_t* list, uint32
         uint32_t op = __shfl_xor(mp, m, 64);
         if (ok < mk || (ok == mk && op < mp)) { mk = ok; mp = op; }
     }
-    wpos = mp;
+    wpos = mp | kListFull;
     thr = (mk == 0ull) ? floor : key_cos(mk);
 }
 

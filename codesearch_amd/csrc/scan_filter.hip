@@ -68,8 +68,14 @@ float filter_margin(uint32_t dim, bool subnormals_exact) {
 // kPend entries of (query << 32 | row); a push adds at most 64, so the list is flushed above kPend - 64.
 constexpr uint32_t kPend = 128;
 
-__device__ __forceinline__ void cand_flush(volatile uint64_t* pend, uint32_t& npend, int lane,
+// The parking list is LDS and is addressed as such: through a generic pointer the accesses become flat_store /
+// flat_load, which count on vmcnt too and return out of order with the corpus loads in flight, and every counted
+// `s_waitcnt vmcnt(N)` of the streaming loop behind a possible push degrades to vmcnt(0).
+typedef volatile uint64_t __attribute__((address_space(3))) lds_vu64;
+
+__device__ __forceinline__ void cand_flush(volatile uint64_t* pend_generic, uint32_t& npend, int lane,
                                            uint32_t* __restrict__ cand, uint32_t* __restrict__ cnt, uint32_t cap) {
+    lds_vu64* const pend = (lds_vu64*)pend_generic;
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     __builtin_amdgcn_wave_barrier();
     for (uint32_t i = lane; i < npend; i += 64) {
@@ -85,8 +91,9 @@ __device__ __forceinline__ void cand_flush(volatile uint64_t* pend, uint32_t& np
 
 // All 64 lanes call this together; `hit` lanes park (q, row).  Tombstoned rows are dropped here.
 __device__ __forceinline__ void cand_push(bool hit, uint32_t q, uint64_t row, const uint32_t* __restrict__ dead,
-                                          volatile uint64_t* pend, uint32_t& npend, int lane,
+                                          volatile uint64_t* pend_generic, uint32_t& npend, int lane,
                                           uint32_t* __restrict__ cand, uint32_t* __restrict__ cnt, uint32_t cap) {
+    lds_vu64* const pend = (lds_vu64*)pend_generic;
     unsigned long long mask = __ballot(hit);
     if (!mask) return;  // wave-uniform; the common case
     if (dead) {
@@ -96,7 +103,7 @@ __device__ __forceinline__ void cand_push(bool hit, uint32_t q, uint64_t row, co
     const uint32_t before = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
     if (hit) pend[npend + before] = ((uint64_t)q << 32) | (uint32_t)row;
     npend += (uint32_t)__popcll(mask);
-    if (npend > kPend - 64) cand_flush(pend, npend, lane, cand, cnt, cap);
+    if (npend > kPend - 64) cand_flush(pend_generic, npend, lane, cand, cnt, cap);
 }
 
 __device__ __forceinline__ float half_sum_s(float v) {
