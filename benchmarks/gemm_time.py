@@ -28,11 +28,17 @@ def main():
         tf = 3 * 2.0 * M * N * K / 1e12
         a, b = t(1, epi, N, K), t(2, epi, N, K)
         print(f"{name}: 128x128 {a:7.1f} us ({tf / a * 1e6:6.0f} TF/s executed)   wide(128x{shape}) {b:7.1f} us ({tf / b * 1e6:6.0f} TF/s)", flush=True)
+    if os.environ.get("GEMM_TIME_SHAPES_ONLY"):
+        return
     for K in (384, 1536):
         print(f"N=384 K={K} LayerNorm-fused wide: {t(2, 3, 384, K):7.1f} us", flush=True)
     for name, abl in (("full", 0), ("no LDS-DMA", 1), ("no MFMA", 2), ("DMAs at step start", 3), ("no DMA, no barrier", 4),
-                      ("no DMA/barrier/LDS reads", 5), ("no DMA, no epilogue", 6)):
+                      ("no DMA/barrier/LDS reads", 5), ("no DMA, no epilogue", 6), ("full, no global stores", 8),
+                      ("full, default-policy stores", 9)):
         print(f"wide qkv ablation {name:20s}: {t(2, 4, 1152, 384, abl):7.1f} us", flush=True)
+    # stamped build (s_memtime / s_memrealtime per block) after > 2 s of back-to-back launches: the clock the chip
+    # holds under this kernel (the library prints it on stderr)
+    print(f"wide qkv stamped build, 12000 launches: {t(2, 4, 1152, 384, 7, iters=12000):7.1f} us", flush=True)
 
 
 if __name__ == "__main__":

@@ -46,6 +46,32 @@ __global__ void __launch_bounds__(256) write_epilogue(char* __restrict__ dst, ui
     }
 }
 
+// the same patch written as half lines: an instruction covers 16 rows x 64 B (4 lanes x 16 B per row), the hi half of
+// a 128-B line, and the next instruction the lo half — what a register-to-register transpose (no LDS pass) could emit
+template <bool NT>
+__global__ void __launch_bounds__(256) write_half_lines(char* __restrict__ dst, uint64_t rows, uint32_t pitch, float seed) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint64_t gw = (uint64_t)blockIdx.x * 4 + wave, nw = (uint64_t)gridDim.x * 4;
+    const uint32_t patches_per_row = pitch / 384;
+    const uint64_t npatches = (rows / 64) * patches_per_row;
+    const f32x4 v = {seed, seed + lane, seed, seed};
+    const uint32_t r16 = lane & 15, g = lane >> 4;
+    for (uint64_t p = gw; p < npatches; p += nw) {
+        const uint64_t r0 = (p / patches_per_row) * 64;
+        const uint32_t c0 = (uint32_t)(p % patches_per_row) * 384;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)        // strips of 16 rows
+#pragma unroll
+            for (int l = 0; l < 3; ++l)    // the three lines of a row
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {  // hi half, lo half
+                    f32x4* q = reinterpret_cast<f32x4*>(dst + (r0 + 16 * i + r16) * pitch + c0 + 128 * l + 64 * h + 16 * g);
+                    if (NT) __builtin_nontemporal_store(v, q);
+                    else *q = v;
+                }
+    }
+}
+
 template <typename F>
 static double timed(F launch, size_t bytes, int reps) {
     hipEvent_t e0, e1;
@@ -78,6 +104,9 @@ int main(int argc, char** argv) {
         const double b = timed([&] { hipLaunchKernelGGL(write_contiguous<true>, dim3(blocks), dim3(256), 0, 0, (f32x4*)d, bytes / 1024, 1.0f); }, bytes, 20);
         const double c = timed([&] { hipLaunchKernelGGL(write_epilogue<false>, dim3(blocks), dim3(256), 0, 0, d, rows, pitch, 1.0f); }, bytes, 20);
         const double e = timed([&] { hipLaunchKernelGGL(write_epilogue<true>, dim3(blocks), dim3(256), 0, 0, d, rows, pitch, 1.0f); }, bytes, 20);
+        const double f = timed([&] { hipLaunchKernelGGL(write_half_lines<false>, dim3(blocks), dim3(256), 0, 0, d, rows, pitch, 1.0f); }, bytes, 20);
+        const double h = timed([&] { hipLaunchKernelGGL(write_half_lines<true>, dim3(blocks), dim3(256), 0, 0, d, rows, pitch, 1.0f); }, bytes, 20);
+        printf("%.1f MB, %d blocks/CU: half-line instructions (16 rows x 64 B) %.3f TB/s (nt %.3f)\n", bytes / 1e6, bpc, f, h);
         printf("%.1f MB, %d blocks/CU: contiguous %.3f TB/s (nt %.3f), epilogue-shaped %.3f TB/s (nt %.3f)  -> %.1f us per %.0f MB at the best\n",
                bytes / 1e6, bpc, a, b, c, e, bytes / 1e6 / (a > b ? (a > c ? (a > e ? a : e) : (c > e ? c : e)) : (b > c ? (b > e ? b : e) : (c > e ? c : e))), bytes / 1e6);
     }

@@ -921,6 +921,13 @@ int32_t cs_debug_gemm_time(int32_t device, int32_t mode, int32_t epilogue, uint3
         float ms = 0.f;
         CS_HIP(hipEventElapsedTime(&ms, e0, e1));
         *ms_per_launch = (double)ms / iters;
+        if (cs::g_gemm_wide_ablation == 7)  // stamped build: the clock the blocks of the LAST launch ran at
+        {
+            double mc = 0.0, ec = 0.0;
+            const double ghz = cs::gemm_wide_read_clock_ghz(&mc, &ec);
+            fprintf(stderr, "gemm_wide in-kernel clock: %.3f GHz (median over blocks, last of %u launches, %.1f us each); per tile: "
+                            "k loop %.0f cycles, epilogue %.0f cycles\n", ghz, iters, (double)ms / iters * 1e3, mc, ec);
+        }
         return CS_OK;
     };
     const int32_t st = run();

@@ -71,6 +71,7 @@ int32_t launch_gemm_wide_ln(const _Float16* A, const _Float16* W, const float* b
                             const float* beta, float eps, float* X, _Float16* Xs, uint32_t M, uint32_t K, uint32_t* d_flag,
                             hipStream_t s);
 extern int g_gemm_wide_ablation;  // diagnostics (cs_debug_gemm_time)
+double gemm_wide_read_clock_ghz(double* main_cycles, double* epi_cycles);  // after an ablation-7 launch: median in-kernel clock
 int32_t sh_weights_fit_wide(const _Float16* d_wsplit, uint64_t n_f16, uint32_t* d_scratch_flag, bool* ok, hipStream_t s);
 int32_t launch_synth_params(float* d_out, const cs_bert_config& cfg, uint64_t seed, hipStream_t s);
 

@@ -28,6 +28,9 @@
 #include <cstdlib>
 
 #include "encoder.hpp"
+
+#include <algorithm>
+#include <vector>
 #include "split_f16.hpp"
 
 namespace cs {
@@ -90,6 +93,10 @@ struct GwSrc {  // element offsets from A / W (32 bits: a [65536, 1536] operand 
 // LDS-read ceiling); 2 = no MFMA (fill + LDS reads only); 3 = the eight DMAs of a stage issued back to back at the
 // start of the step instead of between the MFMA groups; 4 = 1 without the k-step barrier; 5 = 4 with the fragment
 // reads hoisted out of the k loop (the pure MFMA rate); 6 = 1 without the epilogue's stores.
+// ABL 7: the product kernel plus one (s_memtime, s_memrealtime) pair per block at its first and after its last tile,
+// written to a buffer nothing else reads: the in-kernel clock (MI355X_MICROARCH.md, DVFS give-back item 6).
+__device__ uint64_t g_gw_stamps[8 * 512];  // per block: clk0, real0, clk1, real1, main-loop cycles, epilogue cycles, tiles
+
 template <int EPI, int ABL = 0, int WCN = 4>
 __global__ void __launch_bounds__(GwGeom<WCN>::THREADS, 2)
 gemm_wide_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ W, const float* __restrict__ bias,
@@ -154,10 +161,14 @@ gemm_wide_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ W,
     // as many cycles as the tile's MFMAs at K = 384) would never meet the other block's MFMAs.  The second half of
     // the grid (the blocks dispatched onto already occupied CUs) therefore starts half a tile late and stays
     // half a tile behind.
+    const bool use_prio = (stagger_cycles >> 31) != 0;  // experiment: main loop at wave priority 2, epilogue at 0
+    stagger_cycles &= 0x7fffffffu;
     if (stagger_cycles && WCN == 2 && blockIdx.x >= gridDim.x / 2) {
         const uint64_t t0 = __builtin_amdgcn_s_memtime();
         while (__builtin_amdgcn_s_memtime() - t0 < (uint64_t)stagger_cycles) __builtin_amdgcn_s_sleep(16);
     }
+    uint64_t t_clk = 0, t_real = 0, t_main = 0, t_epi = 0, t_mark = 0, n_tiles = 0;
+    if (ABL == 7) { t_clk = __builtin_amdgcn_s_memtime(); t_real = __builtin_amdgcn_s_memrealtime(); t_mark = t_clk; }
     while (slot < total_slots) {
         const uint32_t m0 = mt * GW_BM, n0 = nt * GW_BN;
         const uint32_t rot = sh_kc_rot(nt, ntiles, kchunks);  // see sh_mainloop: n-tiles of an m-tile walk K out of phase
@@ -185,6 +196,7 @@ gemm_wide_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ W,
                 for (int j = 0; j < 6; ++j) acc.c[i][j] = sh_f32x4v{0.f, 0.f, 0.f, 0.f};
         }
         __syncthreads();  // stage 0 has landed (vmcnt(0) precedes the barrier)
+        if (use_prio) __builtin_amdgcn_s_setprio(2);
 
         for (uint32_t kc = 0; kc < kchunks; ++kc) {
             const char* cur = lds + ((buf + kc) & 1) * GW_STAGE;
@@ -222,13 +234,13 @@ gemm_wide_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ W,
                 for (int i = 0; i < 4; ++i)
                     if (ABL != 2) acc.c[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(whs, ah[i], acc.c[i][j], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
-                if ((ABL == 0 || ABL == 2) && more && 2 * j < NP) dma(src, 2 * j, kn, nb);  // ABL 1, 4, 5, 6: no DMA
+                if ((ABL == 0 || ABL == 2 || ABL >= 7) && more && 2 * j < NP) dma(src, 2 * j, kn, nb);  // ABL 1, 4, 5, 6: no DMA
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
                     if (ABL != 2) acc.c[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, ah[i], acc.c[i][j], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
-                if ((ABL == 0 || ABL == 2) && more && 2 * j + 1 < NP) dma(src, 2 * j + 1, kn, nb);
+                if ((ABL == 0 || ABL == 2 || ABL >= 7) && more && 2 * j + 1 < NP) dma(src, 2 * j + 1, kn, nb);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
@@ -240,6 +252,8 @@ gemm_wide_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ W,
         }
         if (ABL == 4 || ABL == 5) __syncthreads();
 
+        if (use_prio) __builtin_amdgcn_s_setprio(0);
+        if (ABL == 7) { const uint64_t t = __builtin_amdgcn_s_memtime(); t_main += t - t_mark; t_mark = t; }
         // next tile of this block: its first stage flies into the buffer the epilogue does not use
         const uint32_t ebuf = (buf + kchunks - 1) & 1;  // buffer of the last stage
         uint32_t nmt = 0, nnt = 0;
@@ -359,7 +373,9 @@ gemm_wide_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ W,
                     sh_split8(v0, v1, hi, lo, mx);
                     if (live) {
                         _Float16* dst = Cs + ((size_t)(m0 + m) * (N / 32) + (col >> 5)) * 64 + (col & 31);
-                        if (EPI == GW_OUT_LN) {  // the next GEMM reads it from L2 / MALL: default policy
+                        if (ABL == 8) {  // epilogue arithmetic and LDS passes, no global stores
+                            asm volatile("" ::"v"(hi), "v"(lo));
+                        } else if (EPI == GW_OUT_LN || ABL == 9) {  // the next GEMM reads it from L2 / MALL: default policy
                             *reinterpret_cast<f16x8*>(dst) = hi;
                             *reinterpret_cast<f16x8*>(dst + 32) = lo;
                         } else {
@@ -379,11 +395,43 @@ gemm_wide_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ W,
                 for (int j = 0; j < 6; ++j) asm volatile("" ::"v"(acc.c[i][j]));
         }
         if (flag && sh_split_overflowed(mx)) atomicOr(flag, 1u);
+        if (ABL == 7) { const uint64_t t = __builtin_amdgcn_s_memtime(); t_epi += t - t_mark; t_mark = t; ++n_tiles; }
         buf = ebuf ^ 1;
         slot = nslot;
         mt = nmt;
         nt = nnt;
     }
+    if (ABL == 7 && tid == 0 && blockIdx.x < 512) {
+        g_gw_stamps[8 * blockIdx.x + 0] = t_clk;
+        g_gw_stamps[8 * blockIdx.x + 1] = t_real;
+        g_gw_stamps[8 * blockIdx.x + 2] = __builtin_amdgcn_s_memtime();
+        g_gw_stamps[8 * blockIdx.x + 3] = __builtin_amdgcn_s_memrealtime();
+        g_gw_stamps[8 * blockIdx.x + 4] = t_main;
+        g_gw_stamps[8 * blockIdx.x + 5] = t_epi;
+        g_gw_stamps[8 * blockIdx.x + 6] = n_tiles;
+    }
+}
+
+// median over blocks of (shader cycles) / (100 MHz reference ticks) of the last ABL 7 launch, in GHz; main_cycles /
+// epi_cycles: wave 0's cycles per tile in the k loop (first barrier to last) and in the epilogue (next tile's first
+// DMAs + conversions + stores), medians over blocks
+double gemm_wide_read_clock_ghz(double* main_cycles, double* epi_cycles) {
+    static uint64_t h[8 * 512];
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_gw_stamps), sizeof h) != hipSuccess) return 0.0;
+    std::vector<double> v, m, e;
+    for (int b = 0; b < 512; ++b) {
+        const uint64_t* p = h + 8 * b;
+        if (p[3] > p[1] && p[6] > 0) {
+            v.push_back((double)(p[2] - p[0]) / (double)(p[3] - p[1]) * 0.1);
+            m.push_back((double)p[4] / (double)p[6]);
+            e.push_back((double)p[5] / (double)p[6]);
+        }
+    }
+    if (v.empty()) return 0.0;
+    std::sort(v.begin(), v.end()); std::sort(m.begin(), m.end()); std::sort(e.begin(), e.end());
+    if (main_cycles) *main_cycles = m[m.size() / 2];
+    if (epi_cycles) *epi_cycles = e[e.size() / 2];
+    return v[v.size() / 2];
 }
 
 // true when every w_hi of a split weight matrix times 2^11 stays finite in f16 (|w_hi| <= 31.98)
@@ -448,7 +496,9 @@ static int32_t gemm_wide_launch(int epi, const _Float16* A, const _Float16* W, c
     // half a tile in s_memtime ticks per k-chunk (CS_GEMM_WIDE_STAGGER; default 0 = off: measured 600 / 1200 / 2400 on
     // all four layer shapes, no gain — see DESIGN.md §3.3); only when blocks run several tiles
     static const int stagger_env = [] { const char* e = std::getenv("CS_GEMM_WIDE_STAGGER"); return e ? std::atoi(e) : 0; }();
-    const uint32_t stagger = (WCN == 2 && slots >= 2 * grid && grid == resident && stagger_env > 0) ? kc * (uint32_t)stagger_env : 0u;
+    static const bool prio_env = [] { const char* e = std::getenv("CS_GEMM_WIDE_PRIO"); return e && e[0] == '1'; }();
+    const uint32_t stagger = ((WCN == 2 && slots >= 2 * grid && grid == resident && stagger_env > 0) ? kc * (uint32_t)stagger_env : 0u) |
+                             (prio_env ? 0x80000000u : 0u);
 #define GW_LAUNCH(E, V) hipLaunchKernelGGL((gemm_wide_kernel<E, V, WCN>), dim3(grid), dim3(G::THREADS), G::LDS, s, A, W, bias, resid, C, Cs, M, N, kc, d_flag, slots, ln_g, ln_b, ln_eps, stagger)
     if constexpr (WCN == 4) {
         if (g_gemm_wide_ablation && epi == SH_OUT_SPLIT) {
@@ -460,6 +510,9 @@ static int32_t gemm_wide_launch(int epi, const _Float16* A, const _Float16* W, c
                 CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wide_kernel<SH_OUT_SPLIT, 4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
                 CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wide_kernel<SH_OUT_SPLIT, 5, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
                 CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wide_kernel<SH_OUT_SPLIT, 6, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
+                CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wide_kernel<SH_OUT_SPLIT, 7, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
+                CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wide_kernel<SH_OUT_SPLIT, 8, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
+                CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wide_kernel<SH_OUT_SPLIT, 9, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
                 abl_attr = true;
             }
             switch (g_gemm_wide_ablation) {
@@ -468,6 +521,9 @@ static int32_t gemm_wide_launch(int epi, const _Float16* A, const _Float16* W, c
                 case 4: GW_LAUNCH(SH_OUT_SPLIT, 4); break;
                 case 5: GW_LAUNCH(SH_OUT_SPLIT, 5); break;
                 case 6: GW_LAUNCH(SH_OUT_SPLIT, 6); break;
+                case 7: GW_LAUNCH(SH_OUT_SPLIT, 7); break;
+                case 8: GW_LAUNCH(SH_OUT_SPLIT, 8); break;
+                case 9: GW_LAUNCH(SH_OUT_SPLIT, 9); break;
                 default: GW_LAUNCH(SH_OUT_SPLIT, 3); break;
             }
             CS_HIP(hipGetLastError());
