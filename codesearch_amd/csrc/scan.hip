@@ -435,8 +435,9 @@ merge_topk_kernel(const uint64_t* __restrict__ in, uint32_t nlists, uint32_t k, 
 // sort by (id, cosine) to find duplicates -> zero all but the best key of every id -> sort by key -> top
 // `limit`.  Scores are monotone in the cosine, so "best score" = largest key; equal scores fall back to
 // (cosine desc, id asc) where the reference's HashMap order is unspecified.
+// More than kVariantHashMax keys (the table would not fit in LDS): duplicates found by a sort on (id, cosine image).
 __global__ void __launch_bounds__(kMergeBlock)
-merge_variants_kernel(const uint64_t* __restrict__ keys, uint32_t nkeys, uint32_t nsort, uint32_t limit,
+merge_variants_sort2_kernel(const uint64_t* __restrict__ keys, uint32_t nkeys, uint32_t nsort, uint32_t limit,
                       uint64_t* __restrict__ out_keys, float* __restrict__ out_cos, uint32_t* __restrict__ out_ids,
                       uint32_t* __restrict__ out_count, uint32_t* __restrict__ out_high_confidence,
                       float max_distance, uint32_t top_n) {
@@ -483,6 +484,65 @@ merge_variants_kernel(const uint64_t* __restrict__ keys, uint32_t nkeys, uint32_
     }
 }
 
+__global__ void __launch_bounds__(kMergeBlock)
+merge_variants_kernel(const uint64_t* __restrict__ keys, uint32_t nkeys, uint32_t nsort, uint32_t limit,
+                      uint64_t* __restrict__ out_keys, float* __restrict__ out_cos, uint32_t* __restrict__ out_ids,
+                      uint32_t* __restrict__ out_count, uint32_t* __restrict__ out_high_confidence,
+                      float max_distance, uint32_t top_n) {
+    // Duplicates first, through an LDS hash table keyed by chunk id (open addressing, 2 * nsort slots, at most half
+    // full): an entry is (id + 1) << 32 | cosine image, so entries of one id compare by cosine and a 64-bit LDS
+    // atomic max keeps the best.  One sort of the survivors then orders them.  (The first version sorted twice — by
+    // (id, cosine) to find duplicates, then by key: two 2,048-key sorts on one CU are LDS-bandwidth-bound, 38 us for
+    // nine lists of 200.)
+    extern __shared__ __attribute__((aligned(16))) uint64_t va[];  // [nsort] sort buffer, then [2 * nsort] table
+    __shared__ uint32_t live, confident, nuniq;
+    unsigned long long* table = reinterpret_cast<unsigned long long*>(va + nsort);
+    const int tid = threadIdx.x;
+    const uint32_t tmask = 2 * nsort - 1;
+    for (uint32_t i = tid; i < 2 * nsort; i += kMergeBlock) table[i] = 0ull;
+    if (tid == 0) { live = 0; confident = 0; nuniq = 0; }
+    __syncthreads();
+    for (uint32_t i = tid; i < nkeys; i += kMergeBlock) {
+        const uint64_t key = keys[i];
+        if (!key) continue;
+        const uint32_t id = key_id(key);
+        const unsigned long long mine = ((unsigned long long)(id + 1u) << 32) | (key >> 32);  // ids stop at 2^32 - 2
+        uint32_t slot = (id * 2654435761u) & tmask;
+        for (;;) {
+            unsigned long long cur = table[slot];
+            if (cur == 0ull) cur = atomicCAS(&table[slot], 0ull, mine);
+            if (cur == 0ull) break;                                              // claimed an empty slot
+            if ((uint32_t)(cur >> 32) == id + 1u) { atomicMax(&table[slot], mine); break; }  // same chunk: best cosine
+            slot = (slot + 1) & tmask;
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = tid; i < 2 * nsort; i += kMergeBlock) {
+        const unsigned long long e = table[i];
+        if (e) va[atomicAdd(&nuniq, 1u)] = (e << 32) | (uint64_t)(~((uint32_t)(e >> 32) - 1u));  // back to (image, ~id)
+    }
+    __syncthreads();
+    uint32_t ns = 64;
+    while (ns < nuniq) ns <<= 1;
+    for (uint32_t i = nuniq + tid; i < ns; i += kMergeBlock) va[i] = 0ull;
+    block_bitonic_desc<kMergeBlock>(va, ns, tid);
+    for (uint32_t i = tid; i < limit; i += kMergeBlock) {
+        const uint64_t key = i < ns ? va[i] : 0ull;
+        if (key) atomicAdd(&live, 1u);
+        if (out_keys) out_keys[i] = key;
+        if (out_cos) out_cos[i] = key ? key_cos(key) : 0.0f;
+        if (out_ids) out_ids[i] = key ? key_id(key) : 0xffffffffu;
+        // mod.rs:601-611 on the reference's own scale: distance = (1 - cos) / 2 (cs_cos_to_distance)
+        if (key && i < top_n && (1.0f - key_cos(key)) * 0.5f < max_distance) atomicAdd(&confident, 1u);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        if (out_count) *out_count = live;
+        const uint32_t want = live < top_n ? live : top_n;
+        if (out_high_confidence) *out_high_confidence = (live > 0 && confident == want) ? 1u : 0u;
+    }
+}
+
 int32_t launch_merge_variants(const uint64_t* d_keys, uint32_t nv, uint32_t k, uint32_t limit, uint64_t* d_out_keys,
                               float* d_out_cos, uint32_t* d_out_ids, uint32_t* d_out_count,
                               uint32_t* d_out_high_confidence, hipStream_t stream) {
@@ -491,15 +551,23 @@ int32_t launch_merge_variants(const uint64_t* d_keys, uint32_t nv, uint32_t k, u
         return fail(CS_ERR_BAD_ARG, "variant merge takes 1..%d keys, got %u", kMergeCap * 4, nkeys);
     uint32_t nsort = 64;
     while (nsort < nkeys) nsort <<= 1;
-    const size_t lds = (size_t)nsort * sizeof(uint64_t);
+    constexpr uint32_t kVariantHashMax = 4096;  // 3 * 4096 * 8 B = 96 KiB of LDS
     static bool attr_set = false;
     if (!attr_set) {
-        CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(merge_variants_kernel),
+        CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(merge_variants_sort2_kernel),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, kMergeCap * 4 * sizeof(uint64_t)));
+        CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(merge_variants_kernel),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, kVariantHashMax * 3 * sizeof(uint64_t)));
         attr_set = true;
     }
-    hipLaunchKernelGGL(merge_variants_kernel, dim3(1), dim3(kMergeBlock), lds, stream, d_keys, nkeys, nsort, limit,
-                       d_out_keys, d_out_cos, d_out_ids, d_out_count, d_out_high_confidence, 0.15f, 5u);
+    if (nsort <= kVariantHashMax)
+        hipLaunchKernelGGL(merge_variants_kernel, dim3(1), dim3(kMergeBlock), (size_t)nsort * 3 * sizeof(uint64_t), stream,
+                           d_keys, nkeys, nsort, limit, d_out_keys, d_out_cos, d_out_ids, d_out_count,
+                           d_out_high_confidence, 0.15f, 5u);
+    else
+        hipLaunchKernelGGL(merge_variants_sort2_kernel, dim3(1), dim3(kMergeBlock), (size_t)nsort * sizeof(uint64_t), stream,
+                           d_keys, nkeys, nsort, limit, d_out_keys, d_out_cos, d_out_ids, d_out_count,
+                           d_out_high_confidence, 0.15f, 5u);
     CS_HIP(hipGetLastError());
     return CS_OK;
 }
