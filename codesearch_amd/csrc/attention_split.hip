@@ -465,6 +465,7 @@ attention_shx_kernel(const _Float16* __restrict__ qkvs, const int32_t* __restric
     const _Float16* base = qkvs + (size_t)b * L * nch * 64;
     bool ovf = false;
 
+    AT_STAMP(0);
     if (tid == 0) *last_valid_p = 0;
     __syncthreads();
     for (uint32_t key = tid; key < Lp; key += 256) {
@@ -616,6 +617,7 @@ attention_shx_kernel(const _Float16* __restrict__ qkvs, const int32_t* __restric
             }
         }
     }
+    AT_STAMP(2);
     if (ovf && flag) atomicOr(flag, 1u);
 }
 
