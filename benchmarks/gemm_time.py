@@ -34,7 +34,7 @@ def main():
         print(f"N=384 K={K} LayerNorm-fused wide: {t(2, 3, 384, K):7.1f} us", flush=True)
     for name, abl in (("full", 0), ("no LDS-DMA", 1), ("no MFMA", 2), ("DMAs at step start", 3), ("no DMA, no barrier", 4),
                       ("no DMA/barrier/LDS reads", 5), ("no DMA, no epilogue", 6), ("full, no global stores", 8),
-                      ("full, default-policy stores", 9)):
+                      ("full, default-policy stores", 9), ("full, line-ordered stores (timing only)", 10)):
         print(f"wide qkv ablation {name:20s}: {t(2, 4, 1152, 384, abl):7.1f} us", flush=True)
     # stamped build (s_memtime / s_memrealtime per block) after > 2 s of back-to-back launches: the clock the chip
     # holds under this kernel (the library prints it on stderr)

@@ -219,8 +219,13 @@ int32_t forward_range(cs_embedder* h, hipStream_t s, uint32_t b0, uint32_t nb, u
             // N = 384 at indexing batch sizes: dense layer + residual + LayerNorm in one kernel (gemm_wide.hip)
             static const bool ln_fuse_on = [] { const char* e = std::getenv("CS_GEMM_WIDE_LN"); return !(e && e[0] == '0'); }();
             const bool fuse_ln = ln_fuse_on && H == 384 && takes_wide(T, H, H);
+            static const bool split_resid_on = [] { const char* e = std::getenv("CS_GEMM_WIDE_LN_SPLIT_RESID"); return !(e && e[0] == '0'); }();
+            const bool split_resid = fuse_ln && split_resid_on;  // every N = 384 layer of this forward is fused or none is
             if (fuse_ln) {
-                CS_TRY(launch_gemm_wide_ln(ctxs, ws + sl.ao, P + lo.ao_b, x, a.g, a.b, c.layer_norm_eps, x, xs, T, H, h->d_flag, s));  // E4
+                // the residual stream is carried in split form alone between the fused layers (read from xs, no f32
+                // copy written: 100 MB less per layer and 65,536 rows); the last layer writes x for the pooling
+                CS_TRY(launch_gemm_wide_ln(ctxs, ws + sl.ao, P + lo.ao_b, x, a.g, a.b, c.layer_norm_eps,
+                                           split_resid ? nullptr : x, xs, T, H, h->d_flag, s, split_resid ? xs : nullptr));  // E4
                 CS_TRY(mark(CS_STAGE_OUT_PROJ));
             } else if (T > split_k_min && T <= split_k_max && T <= split_k_ao_max) {
                 CS_TRY(launch_gemm_split_partial(ctxs, ws + sl.ao, qkv, T, H, H, 3, s));  // E4, K slices as for E6 below
@@ -237,7 +242,9 @@ int32_t forward_range(cs_embedder* h, hipStream_t s, uint32_t b0, uint32_t nb, u
             CS_TRY(mark(CS_STAGE_FFN_UP));
             a.g = P + lo.out_ln_g; a.b = P + lo.out_ln_b;
             if (fuse_ln) {
-                CS_TRY(launch_gemm_wide_ln(mids, ws + sl.down, P + lo.down_b, x, a.g, a.b, c.layer_norm_eps, x, xs, T, I, h->d_flag, s));  // E6
+                CS_TRY(launch_gemm_wide_ln(mids, ws + sl.down, P + lo.down_b, x, a.g, a.b, c.layer_norm_eps,
+                                           (split_resid && l + 1 < c.layers) ? nullptr : x, xs, T, I, h->d_flag, s,
+                                           split_resid ? xs : nullptr));  // E6
                 CS_TRY(mark(CS_STAGE_FFN_DOWN));
             } else if (T > split_k_min && T <= split_k_max2) {
                 // a few thousand token rows: FFN-down is 3 x T / 128 blocks walking 48 K stages one exposed
@@ -787,7 +794,7 @@ int32_t cs_debug_gemm(int32_t device, int32_t mode, int32_t epilogue, const floa
     // epilogue 3 (wide only, N = 384): + resid, LayerNorm with gamma = bias + 1, beta = -bias, eps 1e-12; C receives
     // the f32 output re-assembled from the SPLIT output (hi + lo / 2048), so both stores are exercised
     if (epilogue == 3 && !(wide && N == 384)) return fail(CS_ERR_UNSUPPORTED, "epilogue 3 needs mode 2 and N = 384");
-    if (epilogue < 0 || epilogue > 3 || (mode != CS_GEMM_F32 && mode != CS_GEMM_SPLIT_F16))
+    if (epilogue < 0 || epilogue > 4 || (mode != CS_GEMM_F32 && mode != CS_GEMM_SPLIT_F16))
         return fail(CS_ERR_BAD_ARG, "unknown epilogue/mode");
     if (wide && !gemm_wide_supported(N, K)) return fail(CS_ERR_UNSUPPORTED, "wide kernel needs N %% 384 == 0");
     if (M == 0 || N % 128 || K % 32 || K == 0) return fail(CS_ERR_UNSUPPORTED, "cs_debug_gemm needs M > 0, N %% 128 == 0, K %% 32 == 0");
@@ -807,7 +814,7 @@ int32_t cs_debug_gemm(int32_t device, int32_t mode, int32_t epilogue, const floa
         CS_HIP(hipMemcpy(dW, W, w_n * 4, hipMemcpyHostToDevice));
         CS_HIP(hipMemcpy(dB, bias, (size_t)N * 4, hipMemcpyHostToDevice));
         CS_HIP(hipMemset(dF, 0, 4));
-        if (epilogue == 2 || epilogue == 3) {
+        if (epilogue >= 2) {
             CS_HIP(hipMalloc(&dR, c_n * 4));
             CS_HIP(hipMemcpy(dR, resid, c_n * 4, hipMemcpyHostToDevice));
         }
@@ -821,7 +828,20 @@ int32_t cs_debug_gemm(int32_t device, int32_t mode, int32_t epilogue, const floa
                                 uint32_t m_, uint32_t n_, uint32_t k_, uint32_t* f_, hipStream_t st_) {
                 return wide ? launch_gemm_wide(e, a_, w_, b_, r_, c_, cs_, m_, n_, k_, f_, st_, 0) : launch_gemm_split(e, a_, w_, b_, r_, c_, cs_, m_, n_, k_, f_, st_);
             };
-            if (epilogue == 3) {
+            if (epilogue == 4) {  // LayerNorm epilogue, residual given (and overwritten) in split form, no f32 output
+                std::vector<float> gam(N), bet(N);
+                for (uint32_t n = 0; n < N; ++n) { gam[n] = bias[n] + 1.0f; bet[n] = -bias[n]; }
+                float *dG = nullptr, *dBe = nullptr;
+                CS_HIP(hipMalloc(&dG, (size_t)N * 4)); CS_HIP(hipMalloc(&dBe, (size_t)N * 4));
+                CS_HIP(hipMemcpy(dG, gam.data(), (size_t)N * 4, hipMemcpyHostToDevice));
+                CS_HIP(hipMemcpy(dBe, bet.data(), (size_t)N * 4, hipMemcpyHostToDevice));
+                CS_HIP(hipMalloc(&sC, c_n * 4));
+                CS_TRY(launch_split_rows(dR, sC, M, N, dF, nullptr));
+                const int32_t st4 = launch_gemm_wide_ln(sA, sW, dB, nullptr, dG, dBe, 1e-12f, nullptr, sC, M, K, dF, nullptr, sC);
+                CS_HIP(hipDeviceSynchronize());
+                (void)hipFree(dG); (void)hipFree(dBe);
+                CS_TRY(st4);
+            } else if (epilogue == 3) {
                 std::vector<float> gam(N), bet(N);
                 for (uint32_t n = 0; n < N; ++n) { gam[n] = bias[n] + 1.0f; bet[n] = -bias[n]; }
                 float *dG = nullptr, *dBe = nullptr;

@@ -66,10 +66,11 @@ bool gemm_wide_supported(uint32_t N, uint32_t K);
 // shape: 0 = CS_GEMM_WIDE_SHAPE / default (128 x 384 where N allows), 192 = the 128 x 192 two-blocks-per-CU shape, 384
 int32_t launch_gemm_wide(int epi, const _Float16* A, const _Float16* W, const float* bias, const float* resid, float* C,
                          _Float16* Cs, uint32_t M, uint32_t N, uint32_t K, uint32_t* d_flag, hipStream_t s, int shape = 0);
-// N = 384 only: dense layer + bias + residual + LayerNorm in one kernel; X (f32, may alias resid) and Xs (split form)
+// N = 384 only: dense layer + bias + residual + LayerNorm in one kernel; X (f32, may alias resid; null = not written)
+// and Xs (split form).  resid_split (optional): the residual in split form instead of `resid` (may be Xs).
 int32_t launch_gemm_wide_ln(const _Float16* A, const _Float16* W, const float* bias, const float* resid, const float* gamma,
                             const float* beta, float eps, float* X, _Float16* Xs, uint32_t M, uint32_t K, uint32_t* d_flag,
-                            hipStream_t s);
+                            hipStream_t s, const _Float16* resid_split = nullptr);
 extern int g_gemm_wide_ablation;  // diagnostics (cs_debug_gemm_time)
 double gemm_wide_read_clock_ghz(double* main_cycles, double* epi_cycles);  // after an ablation-7 launch: median in-kernel clock
 int32_t sh_weights_fit_wide(const _Float16* d_wsplit, uint64_t n_f16, uint32_t* d_scratch_flag, bool* ok, hipStream_t s);

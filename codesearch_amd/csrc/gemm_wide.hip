@@ -35,8 +35,6 @@
 
 namespace cs {
 
-// volatile loads that stay global_load (a volatile generic pointer compiles to flat_load, which also counts on lgkmcnt)
-typedef volatile sh_f32x4 __attribute__((address_space(1))) gw_vglobal_f32x4;
 
 
 constexpr int GW_BM = 128, GW_BN = 384;
@@ -57,6 +55,7 @@ struct GwGeom {
     static constexpr int W_PIECES = (BN / 8) / WAVES;            // ... of W: 6
     static constexpr int PIECES = A_PIECES + W_PIECES;           // 8 | 10
 };
+constexpr uint32_t GW_LN_RESID_SPLIT = 1u, GW_LN_NO_F32 = 2u;  // ln_flags of the LayerNorm epilogue (launch_gemm_wide_ln)
 constexpr int GW_OUT_LN = 16;  // epilogue: + bias + residual, LayerNorm over the 384 columns, store f32 AND split form
 
 namespace {
@@ -102,7 +101,7 @@ __global__ void __launch_bounds__(GwGeom<WCN>::THREADS, 2)
 gemm_wide_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ W, const float* __restrict__ bias,
                  const float* resid, float* C, _Float16* __restrict__ Cs, uint32_t M, uint32_t N, uint32_t kchunks,
                  uint32_t* __restrict__ flag, uint32_t total_slots, const float* __restrict__ ln_g,
-                 const float* __restrict__ ln_b, float ln_eps, uint32_t stagger_cycles) {
+                 const float* __restrict__ ln_b, float ln_eps, uint32_t stagger_cycles, uint32_t ln_flags) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     using G = GwGeom<WCN>;
     static_assert(EPI != GW_OUT_LN || WCN == 4, "the LayerNorm epilogue needs whole rows in one block");
@@ -185,8 +184,20 @@ gemm_wide_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ W,
 #pragma unroll
                 for (int j = 0; j < 6; ++j) {
                     const sh_f32x4 bv = *reinterpret_cast<const sh_f32x4*>(bias + wc * 96 + 16 * j + 4 * g);
-                    const sh_f32x4 rv = *reinterpret_cast<const sh_f32x4*>(rbase + (size_t)(off + 64u * j));
-                    acc.c[i][j] = (bv + rv) * kShLoScale;
+                    if (ln_flags & GW_LN_RESID_SPLIT) {
+                        // the residual stream in split form only (same 4 B per element: the row's line [32 hi | 32 lo] of
+                        // the 32-column chunk): hi * 2^11 + lo' is exact in f32 and already on the accumulators' scale
+                        const uint32_t col = wc * 96 + 16 * j + 4 * g;
+                        const char* lp = rbase + (size_t)(((row < M ? row : M - 1) * (GW_BN / 32) + (col >> 5)) * 128u + (col & 31) * 2u);
+                        const f16x4 rh = *reinterpret_cast<const f16x4*>(lp);
+                        const f16x4 rl = *reinterpret_cast<const f16x4*>(lp + 64);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            acc.c[i][j][r] = fmaf((float)rh[r], kShLoScale, (float)rl[r]) + bv[r] * kShLoScale;
+                    } else {
+                        const sh_f32x4 rv = *reinterpret_cast<const sh_f32x4*>(rbase + (size_t)(off + 64u * j));
+                        acc.c[i][j] = (bv + rv) * kShLoScale;
+                    }
                 }
             }
         } else {
@@ -324,14 +335,18 @@ gemm_wide_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ W,
             // final values of strip i into the patch (row l15, columns 16 j + 4 g .. + 3)
             float inv = 1.0f;
             if (EPI == GW_OUT_LN) inv = rowstat[wr * 64 + 16 * i + l15];
+            // gamma / beta are re-read per strip (held across the strips they would cost the 48 registers the
+            // accumulators need); they sit in L1.  The strip's offset goes through an opaque zero so the loads of
+            // different strips cannot be merged — and are still ORDINARY loads, twelve in flight: as `volatile` they
+            // were system-scope (sc0 sc1) loads with a vmcnt(0) behind each, 48 round trips per tile and wave.
+            uint32_t strip_zero = 0;
+            if (EPI == GW_OUT_LN) asm volatile("" : "+s"(strip_zero));
 #pragma unroll
             for (int j = 0; j < 6; ++j) {
                 sh_f32x4 v;
                 if (EPI == GW_OUT_LN) {
-                    // gamma / beta re-read per strip (volatile: not hoisted out of the strip loop — 48 registers the
-                    // accumulators need); they sit in L1
-                    const sh_f32x4 gj = *(const gw_vglobal_f32x4*)(ln_g + wc * 96 + 16 * j + 4 * g);
-                    const sh_f32x4 bj = *(const gw_vglobal_f32x4*)(ln_b + wc * 96 + 16 * j + 4 * g);
+                    const sh_f32x4 gj = *reinterpret_cast<const sh_f32x4*>(ln_g + strip_zero + wc * 96 + 16 * j + 4 * g);
+                    const sh_f32x4 bj = *reinterpret_cast<const sh_f32x4*>(ln_b + strip_zero + wc * 96 + 16 * j + 4 * g);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = (acc.c[i][j][r] - mean[i]) * inv * gj[r] + bj[r];
                 } else {
@@ -364,8 +379,10 @@ gemm_wide_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ W,
                             o0 += *reinterpret_cast<const sh_f32x4*>(resid + (size_t)(m0 + m) * N + col);
                             o1 += *reinterpret_cast<const sh_f32x4*>(resid + (size_t)(m0 + m) * N + col + 4);
                         }
-                        *reinterpret_cast<sh_f32x4*>(o) = o0;
-                        *reinterpret_cast<sh_f32x4*>(o + 4) = o1;
+                        if (!(EPI == GW_OUT_LN && (ln_flags & GW_LN_NO_F32))) {
+                            *reinterpret_cast<sh_f32x4*>(o) = o0;
+                            *reinterpret_cast<sh_f32x4*>(o + 4) = o1;
+                        }
                     }
                 }
                 if (EPI == SH_OUT_SPLIT || EPI == SH_OUT_SPLIT_GELU || EPI == GW_OUT_LN) {
@@ -373,7 +390,13 @@ gemm_wide_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ W,
                     sh_split8(v0, v1, hi, lo, mx);
                     if (live) {
                         _Float16* dst = Cs + ((size_t)(m0 + m) * (N / 32) + (col >> 5)) * 64 + (col & 31);
-                        if (ABL == 8) {  // epilogue arithmetic and LDS passes, no global stores
+                        if (ABL == 10) {
+                            // timing only (wrong addresses, same bytes): every store instruction writes 64 consecutive
+                            // 16-B chunks = eight whole 128-B lines, what a line-ordered patch would give
+                            const size_t chunk = ((((size_t)(mt * ntiles + nt) * G::WAVES + wave) * 4 + i) * 6 + 2 * t) * 64 + lane;
+                            __builtin_nontemporal_store(hi, reinterpret_cast<f16x8*>(Cs + chunk * 8));
+                            __builtin_nontemporal_store(lo, reinterpret_cast<f16x8*>(Cs + (chunk + 64) * 8));
+                        } else if (ABL == 8) {  // epilogue arithmetic and LDS passes, no global stores
                             asm volatile("" ::"v"(hi), "v"(lo));
                         } else if (EPI == GW_OUT_LN || ABL == 9) {  // the next GEMM reads it from L2 / MALL: default policy
                             *reinterpret_cast<f16x8*>(dst) = hi;
@@ -466,7 +489,7 @@ int g_gemm_wide_ablation = 0;  // diagnostics only (cs_debug_gemm_time)
 template <int WCN>
 static int32_t gemm_wide_launch(int epi, const _Float16* A, const _Float16* W, const float* bias, const float* resid, float* C,
                                 _Float16* Cs, uint32_t M, uint32_t N, uint32_t K, uint32_t* d_flag, hipStream_t s,
-                                const float* ln_g, const float* ln_b, float ln_eps) {
+                                const float* ln_g, const float* ln_b, float ln_eps, uint32_t ln_flags) {
     using G = GwGeom<WCN>;
     static bool attr_set = false;
     static int cus = 256;
@@ -499,7 +522,7 @@ static int32_t gemm_wide_launch(int epi, const _Float16* A, const _Float16* W, c
     static const bool prio_env = [] { const char* e = std::getenv("CS_GEMM_WIDE_PRIO"); return e && e[0] == '1'; }();
     const uint32_t stagger = ((WCN == 2 && slots >= 2 * grid && grid == resident && stagger_env > 0) ? kc * (uint32_t)stagger_env : 0u) |
                              (prio_env ? 0x80000000u : 0u);
-#define GW_LAUNCH(E, V) hipLaunchKernelGGL((gemm_wide_kernel<E, V, WCN>), dim3(grid), dim3(G::THREADS), G::LDS, s, A, W, bias, resid, C, Cs, M, N, kc, d_flag, slots, ln_g, ln_b, ln_eps, stagger)
+#define GW_LAUNCH(E, V) hipLaunchKernelGGL((gemm_wide_kernel<E, V, WCN>), dim3(grid), dim3(G::THREADS), G::LDS, s, A, W, bias, resid, C, Cs, M, N, kc, d_flag, slots, ln_g, ln_b, ln_eps, stagger, ln_flags)
     if constexpr (WCN == 4) {
         if (g_gemm_wide_ablation && epi == SH_OUT_SPLIT) {
             static bool abl_attr = false;
@@ -513,6 +536,7 @@ static int32_t gemm_wide_launch(int epi, const _Float16* A, const _Float16* W, c
                 CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wide_kernel<SH_OUT_SPLIT, 7, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
                 CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wide_kernel<SH_OUT_SPLIT, 8, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
                 CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wide_kernel<SH_OUT_SPLIT, 9, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
+                CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wide_kernel<SH_OUT_SPLIT, 10, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
                 abl_attr = true;
             }
             switch (g_gemm_wide_ablation) {
@@ -524,6 +548,7 @@ static int32_t gemm_wide_launch(int epi, const _Float16* A, const _Float16* W, c
                 case 7: GW_LAUNCH(SH_OUT_SPLIT, 7); break;
                 case 8: GW_LAUNCH(SH_OUT_SPLIT, 8); break;
                 case 9: GW_LAUNCH(SH_OUT_SPLIT, 9); break;
+                case 10: GW_LAUNCH(SH_OUT_SPLIT, 10); break;
                 default: GW_LAUNCH(SH_OUT_SPLIT, 3); break;
             }
             CS_HIP(hipGetLastError());
@@ -548,13 +573,13 @@ static int32_t gemm_wide_launch(int epi, const _Float16* A, const _Float16* W, c
 // layer shape of the encoder: QKV 187 vs 190 us, FFN-up 270 vs 279, FFN-down 223 vs 237).
 static int32_t gemm_wide_impl(int epi, const _Float16* A, const _Float16* W, const float* bias, const float* resid, float* C,
                               _Float16* Cs, uint32_t M, uint32_t N, uint32_t K, uint32_t* d_flag, hipStream_t s,
-                              const float* ln_g, const float* ln_b, float ln_eps, int shape = 0) {
+                              const float* ln_g, const float* ln_b, float ln_eps, int shape = 0, uint32_t ln_flags = 0) {
     if (!gemm_wide_supported(N, K)) return fail(CS_ERR_UNSUPPORTED, "wide split GEMM needs N %% 192 == 0 and K %% 32 == 0 (N=%u K=%u)", N, K);
     if (M == 0) return CS_OK;
     static const int shape_env = [] { const char* e = std::getenv("CS_GEMM_WIDE_SHAPE"); return e ? std::atoi(e) : 384; }();
     const bool big = epi == GW_OUT_LN || g_gemm_wide_ablation || ((shape ? shape : shape_env) == 384 && N % 384 == 0);
-    if (big) return gemm_wide_launch<4>(epi, A, W, bias, resid, C, Cs, M, N, K, d_flag, s, ln_g, ln_b, ln_eps);
-    return gemm_wide_launch<2>(epi, A, W, bias, resid, C, Cs, M, N, K, d_flag, s, ln_g, ln_b, ln_eps);
+    if (big) return gemm_wide_launch<4>(epi, A, W, bias, resid, C, Cs, M, N, K, d_flag, s, ln_g, ln_b, ln_eps, ln_flags);
+    return gemm_wide_launch<2>(epi, A, W, bias, resid, C, Cs, M, N, K, d_flag, s, ln_g, ln_b, ln_eps, ln_flags);
 }
 
 int32_t launch_gemm_wide(int epi, const _Float16* A, const _Float16* W, const float* bias, const float* resid, float* C,
@@ -565,10 +590,16 @@ int32_t launch_gemm_wide(int epi, const _Float16* A, const _Float16* W, const fl
 
 // X[M,384] = LayerNorm(A W^T + bias + resid) * gamma + beta, written as f32 (X; may alias resid) and in split
 // form (Xs): a dense layer with N = 384, its residual add and the LayerNorm behind it (E4 / E6) in one kernel.
+// resid_split != null: the residual is read from that split-form tensor instead of `resid` (it may be Xs itself: a
+// block reads its own rows before it writes them); X == null: no f32 copy is written — the residual stream then lives
+// in split form only (hi + lo / 2048 carries x to 2^-22 relative) and the layer writes 100 MB less per 65,536 rows.
 int32_t launch_gemm_wide_ln(const _Float16* A, const _Float16* W, const float* bias, const float* resid, const float* gamma,
                             const float* beta, float eps, float* X, _Float16* Xs, uint32_t M, uint32_t K, uint32_t* d_flag,
-                            hipStream_t s) {
-    return gemm_wide_impl(GW_OUT_LN, A, W, bias, resid, X, Xs, M, GW_BN, K, d_flag, s, gamma, beta, eps);
+                            hipStream_t s, const _Float16* resid_split) {
+    if (!resid && !resid_split) return fail(CS_ERR_BAD_ARG, "the LayerNorm epilogue needs a residual");
+    const uint32_t flags = (resid_split ? GW_LN_RESID_SPLIT : 0u) | (X ? 0u : GW_LN_NO_F32);
+    const float* r = resid_split ? reinterpret_cast<const float*>(resid_split) : resid;
+    return gemm_wide_impl(GW_OUT_LN, A, W, bias, r, X, Xs, M, GW_BN, K, d_flag, s, gamma, beta, eps, 0, flags);
 }
 
 }  // namespace cs

@@ -415,8 +415,10 @@ int32_t cs_embedder_debug_counters(cs_embedder* h, uint64_t* split_forwards,
 
 /* Diagnostics: one dense layer of the encoder on host buffers, for unit parity tests of the
  * GEMM kernels (E2/E4/E5/E6).  C[M,N] = A[M,K] W[N,K]^T + bias, epilogue 0 = none,
- * 1 = erf-GELU, 2 = + resid[M,N]; mode = cs_gemm_mode.  N % 128 == 0, K % 32 == 0.
- * *range_flag (optional) is set when a split-f16 operand left the f16 range. */
+ * 1 = erf-GELU, 2 = + resid[M,N]; mode = cs_gemm_mode (| 2: the persistent wide kernel).  N % 128 == 0, K % 32 == 0.
+ * Wide kernel, N = 384 only: 3 = + resid, then LayerNorm (gamma = bias + 1, beta = -bias) in the same kernel, f32 and
+ * split outputs; 4 = the same with the residual handed over in split form in the output buffer and no f32 output (how
+ * the encoder runs it).  *range_flag (optional) is set when a split-f16 operand left the f16 range. */
 int32_t cs_debug_gemm(int32_t device, int32_t mode, int32_t epilogue, const float* A,
                       const float* W, const float* bias, const float* resid, float* C,
                       uint32_t M, uint32_t N, uint32_t K, uint32_t* range_flag);

@@ -102,6 +102,10 @@ def test_wide_gemm_with_fused_layernorm(gpu_lib, M, K):
     resid = rng.standard_normal((M, N)).astype(np.float32)
     got, flag = run_gemm(gpu_lib, WIDE, 3, A, W, bias, resid)
     assert flag == 0
+    # the encoder's form: the residual arrives in split form (hi + lo / 2048, 2^-22 relative) in the buffer the
+    # result overwrites, and no f32 copy is written (cs_debug_gemm epilogue 4)
+    got_split_resid, flag4 = run_gemm(gpu_lib, WIDE, 4, A, W, bias, resid)
+    assert flag4 == 0 and np.abs(got_split_resid - got).max() < 2e-6
     rows = np.arange(M) if M <= 1000 else rng.integers(0, M, 256)
     v = A[rows].astype(np.float64) @ W.astype(np.float64).T + bias.astype(np.float64) + resid[rows].astype(np.float64)
     mu = v.mean(axis=1, keepdims=True)
