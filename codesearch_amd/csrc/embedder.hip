@@ -35,6 +35,7 @@ struct cs_embedder {
     hipStream_t xstreams[2] = {nullptr, nullptr};  // CS_ENCODER_STREAMS=3|4: further slices of the mini-batch
     hipEvent_t xjoin[2] = {nullptr, nullptr};
     int n_streams = 2;
+    bool streams_forced = false;       // CS_ENCODER_STREAMS given: forward() does not second-guess it
     size_t cap_tokens = 0, cap_seqs = 0;
     int32_t* d_ids = nullptr;
     int32_t* d_mask = nullptr;
@@ -302,7 +303,20 @@ int32_t forward(cs_embedder* h, uint32_t B, uint32_t L, int mode) {
         return e ? (uint64_t)std::atoll(e) : (uint64_t)20000;
     }();
     h->stage_tag.clear();
-    if (!h->stage_profile && h->n_streams >= 2 && B >= (uint32_t)h->n_streams && (uint64_t)B * L >= stream_min_tokens) {
+    // The persistent wide kernels give every CU a whole number of tiles when the tile counts of the three layer shapes
+    // (T/128 x {1, 3, 4}) are multiples of the CU count; then one stream is as good or better (256 x 256 tokens: 11.05
+    // vs 11.20 ms) and the second stream only helps where a last round of tiles would leave CUs idle (160 x 256: 8.08
+    // one stream, 7.07 two).  CS_ENCODER_STREAMS forces the count either way.
+    bool whole_rounds = false;
+    if (mode == CS_GEMM_SPLIT_F16 && h->wide_ok && !h->streams_forced) {
+        int cus = 0;
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device);
+        const uint64_t mt = ((uint64_t)B * L + 127) / 128;
+        auto eff = [&](uint64_t tiles) { return cus > 0 ? (double)tiles / (double)(((tiles + cus - 1) / cus) * cus) : 0.0; };
+        whole_rounds = h->cfg.hidden == 384 && mt >= 218 && eff(mt) >= 0.96 && eff(3 * mt) >= 0.96 && eff(4 * mt) >= 0.96;
+    }
+    if (!h->stage_profile && !whole_rounds && h->n_streams >= 2 && B >= (uint32_t)h->n_streams &&
+        (uint64_t)B * L >= stream_min_tokens) {
         const uint32_t ns = (uint32_t)h->n_streams;
         h->streams_in_flight = (int)ns;
         hipStream_t st[4] = {s, h->stream2, h->xstreams[0], h->xstreams[1]};
@@ -664,6 +678,7 @@ int32_t cs_embedder_create(const cs_bert_config* cfg, const float* params, uint6
         if (s == CS_OK) s = sh_denorm_selftest(&denorm_ok, h->stream);
         if (s == CS_OK && !denorm_ok) { h->gemm_mode = CS_GEMM_F32; h->split_unavailable = true; }
         if (const char* env = std::getenv("CS_ENCODER_STREAMS")) {
+            h->streams_forced = true;
             const int v = std::atoi(env);
             h->n_streams = v >= 4 ? 4 : (v >= 1 ? v : 1);
         }
