@@ -189,11 +189,12 @@ def encoder_legs(shard, k, device, with_cpu=True):
             "frac_algorithmic_of_f32_mfma_peak": (gemm_flops + attn_flops) / sec / 1e12 / MFMA_F32_PEAK_TFLOPS,
             "traffic": None,
             "note": "achieved = executed f16-MFMA flops (3 per f32 product: hi*hi + the two cross terms) / device time of "
-                    "the whole forward (HIP events on the encoder's stream, two half-batches on two streams)",
+                    "the whole forward (HIP events on the encoder's stream; one stream at this shape, whose tile rounds are whole — "
+                    "ragged shapes run as two half-batches on two streams)",
             "per_kernel_us_per_layer": per_layer,
             "per_kernel_us_per_forward": {"embed_ln": stages["embed_ln"], "pool_normalize": stages["pool_normalize"]},
             "per_kernel_note": f"one stream, a HIP event after every kernel ({sf} forwards, {ms1 / max(n1, 1):.3f} ms each "
-                               "in that mode); the default two-stream forward overlaps kernels of the two half-batches",
+                               "in that mode)",
             "per_kernel_executed_tflops": {
                 "qkv_gemm": 3 * 2 * 3 * cfg.hidden * cfg.hidden * B * L / (per_layer["qkv_gemm"] * 1e-6) / 1e12,
                 "out_proj_gemm": 3 * 2 * cfg.hidden * cfg.hidden * B * L / (per_layer["out_proj_gemm"] * 1e-6) / 1e12,
