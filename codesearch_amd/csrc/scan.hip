@@ -12,6 +12,7 @@
 // registers/LDS, so the only HBM traffic besides the matrix is k keys per block.
 // Algorithmic bytes per row = dim*4 (1536 B at dim 384).
 #include "scan.hpp"
+#include "block_select.hpp"
 
 #include "../../include/cs_synth.h"
 
@@ -525,6 +526,11 @@ merge_variants_kernel(const uint64_t* __restrict__ keys, uint32_t nkeys, uint32_
     uint32_t ns = 64;
     while (ns < nuniq) ns <<= 1;
     for (uint32_t i = nuniq + tid; i < ns; i += kMergeBlock) va[i] = 0ull;
+    if (ns > 256 && limit < nuniq) {  // bracket the limit-th key, sort only what is above it (block_select.hpp)
+        __shared__ uint32_t sel_slots[66];
+        __syncthreads();
+        ns = block_select_topk<kMergeBlock, 4>(va, nuniq, limit, tid, sel_slots);  // nuniq <= 4096 on this path
+    }
     block_bitonic_desc<kMergeBlock>(va, ns, tid);
     for (uint32_t i = tid; i < limit; i += kMergeBlock) {
         const uint64_t key = i < ns ? va[i] : 0ull;

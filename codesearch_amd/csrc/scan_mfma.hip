@@ -18,6 +18,7 @@
 // is exact.  Expected candidates per phase are ~ k * growth; if a buffer still overflows
 // (adversarially ordered data) the caller reruns those queries on the list-based kernel.
 #include "scan.hpp"
+#include "block_select.hpp"
 
 namespace cs {
 
@@ -207,6 +208,7 @@ select_candidates_kernel(const uint64_t* __restrict__ cand, uint32_t* __restrict
                          uint32_t* __restrict__ out_ids, uint32_t* __restrict__ out_counts) {
     __shared__ __attribute__((aligned(16))) uint64_t a[MB_SEL_CAP];
     __shared__ uint32_t live;
+    __shared__ uint32_t sel_slots[66];
     const int tid = threadIdx.x;
     const uint32_t q = blockIdx.x;
     uint32_t n = cnt[(size_t)q * kCntStride];
@@ -226,6 +228,10 @@ select_candidates_kernel(const uint64_t* __restrict__ cand, uint32_t* __restrict
         uint32_t nsort = 64;
         while (nsort < k + take) nsort <<= 1;
         for (uint32_t i = tid; k + i < nsort; i += MB_SEL_THREADS) a[k + i] = (i < take) ? src[done + i] : 0ull;
+        if (nsort > 256) {  // hundreds of candidates: bracket the k-th key first, sort only what is above it
+            __syncthreads();
+            nsort = block_select_topk<MB_SEL_THREADS, MB_SEL_CAP / MB_SEL_THREADS>(a, k + take, k, tid, sel_slots);
+        }
         uint32_t prev_stride = 128;  // block barrier only around cross-segment stages (block_bitonic_desc, scan.hip)
         for (uint32_t size = 2; size <= nsort; size <<= 1)
             for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
