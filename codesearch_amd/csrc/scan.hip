@@ -413,6 +413,11 @@ merge_topk_kernel(const uint64_t* __restrict__ in, uint32_t nlists, uint32_t k, 
         a[i] = key;
     }
     if (tid == 0) live = 0;
+    if (nsort > 256) {  // thousands of keys, k wanted: bracket the k-th first and sort only what is above it
+        __shared__ uint32_t sel_slots[66];
+        __syncthreads();
+        nsort = block_select_topk<kMergeBlock, kMergeCap / kMergeBlock>(a, ncand, k, tid, sel_slots);
+    }
     block_bitonic_desc<kMergeBlock>(a, nsort, tid);
     const bool final_pass = (ngroups == 1);
     for (uint32_t i = tid; i < k; i += kMergeBlock) {
@@ -770,16 +775,16 @@ int32_t launch_scan(const ScanPlan& plan, const float* d_corpus, uint64_t n_rows
 }
 
 static uint32_t merge_group(uint32_t k) {
-    // lists merged per block.  Short lists (k <= 32): 512 keys per sort — 256 block lists x k = 10 become six
-    // 512-key sorts and a final 64-key one, 20 us for the two launches against 28 us with two 2048-key sorts
-    // (a single 4096-key sort: 36 us); up to k = 512: 2048 keys per sort (k = 200 -> 10 lists); 4096 above
-    // (k = 1024 -> 4); never fewer than 2.  CS_MERGE_SMALL_CAP overrides the first figure (A/B).
-    static const uint32_t small_cap = [] {
-        const char* e = std::getenv("CS_MERGE_SMALL_CAP");
+    // lists merged per block: as many as kMergeCap (4,096) keys hold — the block brackets the k-th key by bisection
+    // and sorts only the keys above it (block_select.hpp), so 256 block lists x k = 10 are ONE launch.  (When the block
+    // sorted everything it loaded, short lists went through 512-key groups and a second level: 20 us for the two
+    // launches against 36 us for one 4,096-key sort.)  Never fewer than 2.  CS_MERGE_GROUP_KEYS overrides (A/B).
+    static const uint32_t cap = [] {
+        const char* e = std::getenv("CS_MERGE_GROUP_KEYS");
         const int v = e ? std::atoi(e) : 0;
-        return v >= 64 ? (uint32_t)v : 512u;
+        return (v >= 64 && v <= kMergeCap) ? (uint32_t)v : (uint32_t)kMergeCap;
     }();
-    const uint32_t g = (k <= 32 ? small_cap : k <= 512 ? 2048u : (uint32_t)kMergeCap) / k;
+    const uint32_t g = cap / k;
     return g < 2 ? 2 : g;
 }
 
