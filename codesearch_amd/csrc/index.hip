@@ -488,7 +488,11 @@ int32_t run_search(cs_index* h, Workspace* w, const ScanPlan& plan, const float*
     uint64_t prime_rows = h->prime_rows;
     if (!prime_rows) {
         prime_rows = (h->n_rows / 256) & ~(uint64_t)63;
-        prime_rows = prime_rows < 4096 ? 4096 : (prime_rows > 16384 ? 16384 : prime_rows);
+        // short lists need fewer wave maxima for a useful bound: 8,192 rows (512 waves of 16) up to k = 16 — over 10M
+        // rows the pass costs 18 instead of 26 us and the scan the same (k = 10: 2,122 -> 2,114 us; k = 64 and 99 lose
+        // 5 and 17 us with the smaller sample and keep 16,384)
+        const uint64_t prime_cap = k <= 16 ? 8192 : 16384;
+        prime_rows = prime_rows < 4096 ? 4096 : (prime_rows > prime_cap ? prime_cap : prime_rows);
         const uint64_t big = prime_sample_rows(prime_rows, k, h->num_cus);  // k > 256: more waves, 32 rows each
         if (h->n_rows >= 4 * big) prime_rows = big;
     }
