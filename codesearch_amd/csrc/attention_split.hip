@@ -629,12 +629,12 @@ int32_t launch_attention_sh2(const _Float16* qkv_split, const int32_t* mask, voi
     const size_t Lp = (L + 31) & ~31u;
     if (dh == 64) {  // two 128-B lines per (token, head): keys staged 128 at a time
         const size_t lds = 2 * 2 * 128 * 128 + Lp * sizeof(float) + 16;
-        static bool attr64 = false;
-        if (!attr64) {
+        static PerDeviceOnce attr64;  // function attributes are per device
+        CS_TRY(attr64.run([&]() -> int32_t {
             CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attention_shx_kernel<2>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
-            attr64 = true;
-        }
+            return CS_OK;
+        }));
         hipLaunchKernelGGL(attention_shx_kernel<2>, dim3(heads, B, (L + 127) / 128), dim3(256), lds, s, qkv_split, mask,
                            static_cast<_Float16*>(ctx_split), flag, L, H, (1.0f / sqrtf(64.0f)) * kLog2e);
         CS_HIP(hipGetLastError());
@@ -654,12 +654,12 @@ int32_t launch_attention_sh2(const _Float16* qkv_split, const int32_t* mask, voi
     }
     const size_t lds = 2 * Lp * 128 + Lp * sizeof(float) + 16;
     if (lds > 160 * 1024 - 64) return fail(CS_ERR_UNSUPPORTED, "sequence length %u exceeds the LDS-resident K/V limit", L);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDeviceOnce attr_set;  // function attributes are per device
+    CS_TRY(attr_set.run([&]() -> int32_t {
         CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attention_sh2_kernel),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
-        attr_set = true;
-    }
+        return CS_OK;
+    }));
     hipLaunchKernelGGL(attention_sh2_kernel, dim3(heads, B), dim3(256), lds, s, qkv_split, mask,
                        static_cast<_Float16*>(ctx_split), flag, L, H, (1.0f / sqrtf(32.0f)) * kLog2e);
     CS_HIP(hipGetLastError());
@@ -677,14 +677,14 @@ int32_t launch_attention_sh(const float* qkv, const int32_t* mask, float* ctx, v
         return fail(CS_ERR_UNSUPPORTED, "head_dim %u not supported (32 only in this round)", heads ? H / heads : 0);
     const size_t lds = attention_sh_lds_bytes(L);
     if (lds > 160 * 1024 - 64) return fail(CS_ERR_UNSUPPORTED, "sequence length %u exceeds the LDS-resident K/V limit", L);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDeviceOnce attr_set;  // function attributes are per device
+    CS_TRY(attr_set.run([&]() -> int32_t {
         CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attention_sh_kernel<false>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
         CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attention_sh_kernel<true>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
-        attr_set = true;
-    }
+        return CS_OK;
+    }));
     dim3 grid(heads, B);
     const float scale_log2e = (1.0f / sqrtf(32.0f)) * kLog2e;
     if (ctx_split)

@@ -6,6 +6,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -31,6 +32,24 @@ int32_t fail(int32_t code, const char* fmt, ...) __attribute__((format(printf, 2
         int32_t _s = (expr);              \
         if (_s != CS_OK) return _s;       \
     } while (0)
+
+// Runs `f` once per device (the current one), under a lock: kernel function attributes such as the dynamic-LDS limit
+// belong to the device they were set on, and one process may drive several (cs_shards_*, one embedder per GPU).
+struct PerDeviceOnce {
+    std::mutex mu;
+    uint64_t done = 0;
+    template <class F>
+    int32_t run(F&& f) {
+        int d = 0;
+        if (hipGetDevice(&d) != hipSuccess) d = 0;
+        const uint64_t bit = 1ull << (d & 63);
+        std::lock_guard<std::mutex> lk(mu);
+        if (done & bit) return CS_OK;
+        const int32_t s = f();
+        if (s == CS_OK) done |= bit;
+        return s;
+    }
+};
 
 // RAII: make `device` current for the calling thread, restore on scope exit.
 struct DeviceGuard {

@@ -748,13 +748,13 @@ int32_t launch_gemm(int epi, const float* A, const float* W, const float* bias, 
         else hipLaunchKernelGGL(gemm_f32_kernel<EPI_RESID>, grid, dim3(256), 0, s, A, W, bias, resid, C, M, N, K);
     } else {
         constexpr size_t lds = 2 * 2 * GBM * GLS * sizeof(float);  // 73,728 B
-        static bool attr_set = false;
-        if (!attr_set) {
+        static PerDeviceOnce attr_set;  // function attributes are per device
+        CS_TRY(attr_set.run([&]() -> int32_t {
             CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_pipe_kernel<EPI_BIAS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_pipe_kernel<EPI_GELU>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_pipe_kernel<EPI_RESID>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            attr_set = true;
-        }
+            return CS_OK;
+        }));
         if (epi == EPI_BIAS) hipLaunchKernelGGL(gemm_f32_pipe_kernel<EPI_BIAS>, grid, dim3(256), lds, s, A, W, bias, resid, C, M, N, K);
         else if (epi == EPI_GELU) hipLaunchKernelGGL(gemm_f32_pipe_kernel<EPI_GELU>, grid, dim3(256), lds, s, A, W, bias, resid, C, M, N, K);
         else hipLaunchKernelGGL(gemm_f32_pipe_kernel<EPI_RESID>, grid, dim3(256), lds, s, A, W, bias, resid, C, M, N, K);
@@ -774,12 +774,12 @@ static int32_t launch_attention_impl(const float* qkv, const int32_t* mask, floa
     if (heads && H % heads == 0 && H / heads == 64 && !ctxs) {  // exact-f32 mode, 64-wide heads
         const size_t Lp = (L + 31) & ~31u;
         const size_t lds64 = ((size_t)AKT64 * (AKS64 + 64) + Lp + 4) * sizeof(float);
-        static bool attr64 = false;
-        if (!attr64) {
+        static PerDeviceOnce attr64;  // function attributes are per device
+        CS_TRY(attr64.run([&]() -> int32_t {
             CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attention64_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
-            attr64 = true;
-        }
+            return CS_OK;
+        }));
         hipLaunchKernelGGL(attention64_kernel, dim3((L + 127) / 128, heads, B), dim3(256), lds64, s, qkv, mask, ctx, L, H,
                            1.0f / sqrtf(64.0f));
         CS_HIP(hipGetLastError());
@@ -789,14 +789,14 @@ static int32_t launch_attention_impl(const float* qkv, const int32_t* mask, floa
         return fail(CS_ERR_UNSUPPORTED, "head_dim %u not supported (32 or 64)", heads ? H / heads : 0);
     const size_t lds = attention_lds_bytes(L);
     if (lds > 160 * 1024 - 64) return fail(CS_ERR_UNSUPPORTED, "sequence length %u exceeds the LDS-resident K/V limit", L);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDeviceOnce attr_set;  // function attributes are per device
+    CS_TRY(attr_set.run([&]() -> int32_t {
         CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attention_kernel<false>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
         CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attention_kernel<true>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
-        attr_set = true;
-    }
+        return CS_OK;
+    }));
     dim3 grid((L + 127) / 128, heads, B);
     const float scale = 1.0f / sqrtf(32.0f);
     if (ctxs) hipLaunchKernelGGL(attention_kernel<true>, grid, dim3(256), lds, s, qkv, mask, ctx, ctxs, flag, L, H, scale);

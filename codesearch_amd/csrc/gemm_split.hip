@@ -401,14 +401,14 @@ int32_t launch_gemm_split(int epi, const _Float16* A, const _Float16* W, const f
                           hipStream_t s) {
     if (N % SH_BN || K % 32) return fail(CS_ERR_UNSUPPORTED, "split GEMM N=%u K=%u must be multiples of 128/32", N, K);
     if (M == 0) return CS_OK;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDeviceOnce attr_set;  // function attributes are per device
+    CS_TRY(attr_set.run([&]() -> int32_t {
         CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_sh_kernel<SH_OUT_F32>), hipFuncAttributeMaxDynamicSharedMemorySize, SH_LDS_LAUNCH_BYTES));
         CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_sh_kernel<SH_OUT_F32_RESID>), hipFuncAttributeMaxDynamicSharedMemorySize, SH_LDS_LAUNCH_BYTES));
         CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_sh_kernel<SH_OUT_SPLIT_GELU>), hipFuncAttributeMaxDynamicSharedMemorySize, SH_LDS_LAUNCH_BYTES));
         CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_sh_kernel<SH_OUT_SPLIT>), hipFuncAttributeMaxDynamicSharedMemorySize, SH_LDS_LAUNCH_BYTES));
-        attr_set = true;
-    }
+        return CS_OK;
+    }));
     const uint32_t kc = K / 32;
     static int skinny_max_m = -1;
     if (skinny_max_m < 0) {
@@ -447,14 +447,14 @@ int32_t launch_gemm_split(int epi, const _Float16* A, const _Float16* W, const f
         tile = (v == 256 || v == 257 || v == 128) ? v : 16;
     }
     if (tile == 16) {  // 128 x 128 tiles on the 16x16x32 MFMA
-        static bool attr16 = false;
-        if (!attr16) {
+        static PerDeviceOnce attr16;  // function attributes are per device
+        CS_TRY(attr16.run([&]() -> int32_t {
             CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_sh16_kernel<SH_OUT_F32>), hipFuncAttributeMaxDynamicSharedMemorySize, SH_LDS_BYTES));
             CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_sh16_kernel<SH_OUT_F32_RESID>), hipFuncAttributeMaxDynamicSharedMemorySize, SH_LDS_BYTES));
             CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_sh16_kernel<SH_OUT_SPLIT_GELU>), hipFuncAttributeMaxDynamicSharedMemorySize, SH_LDS_BYTES));
             CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_sh16_kernel<SH_OUT_SPLIT>), hipFuncAttributeMaxDynamicSharedMemorySize, SH_LDS_BYTES));
-            attr16 = true;
-        }
+            return CS_OK;
+        }));
         const dim3 grid16(sh_grid_blocks((M + SH_BM - 1) / SH_BM, N / SH_BN));
         if (epi == SH_OUT_F32) hipLaunchKernelGGL(gemm_sh16_kernel<SH_OUT_F32>, grid16, dim3(256), SH_LDS_BYTES, s, A, W, bias, resid, C, Cs, M, N, kc, d_flag, 1u);
         else if (epi == SH_OUT_F32_RESID) hipLaunchKernelGGL(gemm_sh16_kernel<SH_OUT_F32_RESID>, grid16, dim3(256), SH_LDS_BYTES, s, A, W, bias, resid, C, Cs, M, N, kc, d_flag, 1u);
@@ -465,14 +465,14 @@ int32_t launch_gemm_split(int epi, const _Float16* A, const _Float16* W, const f
     }
     if (tile == 257) {  // 256 x 128 tiles, 3-stage ring, LDS-DMA issue spread through the MFMA stream
         using G = ShGeom<4>;
-        static bool attr3i = false;
-        if (!attr3i) {
+        static PerDeviceOnce attr3i;  // function attributes are per device
+        CS_TRY(attr3i.run([&]() -> int32_t {
             CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_sh3_kernel<SH_OUT_F32, true>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
             CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_sh3_kernel<SH_OUT_F32_RESID, true>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
             CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_sh3_kernel<SH_OUT_SPLIT_GELU, true>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
             CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_sh3_kernel<SH_OUT_SPLIT, true>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
-            attr3i = true;
-        }
+            return CS_OK;
+        }));
         const dim3 grid3(sh_grid_blocks((M + G::BM - 1) / G::BM, N / SH_BN));
         if (epi == SH_OUT_F32) hipLaunchKernelGGL((gemm_sh3_kernel<SH_OUT_F32, true>), grid3, dim3(G::THREADS), G::LDS, s, A, W, bias, resid, C, Cs, M, N, kc, d_flag);
         else if (epi == SH_OUT_F32_RESID) hipLaunchKernelGGL((gemm_sh3_kernel<SH_OUT_F32_RESID, true>), grid3, dim3(G::THREADS), G::LDS, s, A, W, bias, resid, C, Cs, M, N, kc, d_flag);
@@ -483,14 +483,14 @@ int32_t launch_gemm_split(int epi, const _Float16* A, const _Float16* W, const f
     }
     if (tile == 256) {
         using G = ShGeom<4>;
-        static bool attr3 = false;
-        if (!attr3) {
+        static PerDeviceOnce attr3;  // function attributes are per device
+        CS_TRY(attr3.run([&]() -> int32_t {
             CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_sh3_kernel<SH_OUT_F32>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
             CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_sh3_kernel<SH_OUT_F32_RESID>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
             CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_sh3_kernel<SH_OUT_SPLIT_GELU>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
             CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_sh3_kernel<SH_OUT_SPLIT>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
-            attr3 = true;
-        }
+            return CS_OK;
+        }));
         const dim3 grid3(sh_grid_blocks((M + G::BM - 1) / G::BM, N / SH_BN));
         if (epi == SH_OUT_F32) hipLaunchKernelGGL(gemm_sh3_kernel<SH_OUT_F32>, grid3, dim3(G::THREADS), G::LDS, s, A, W, bias, resid, C, Cs, M, N, kc, d_flag);
         else if (epi == SH_OUT_F32_RESID) hipLaunchKernelGGL(gemm_sh3_kernel<SH_OUT_F32_RESID>, grid3, dim3(G::THREADS), G::LDS, s, A, W, bias, resid, C, Cs, M, N, kc, d_flag);
@@ -516,11 +516,11 @@ int32_t launch_gemm_split_partial(const _Float16* A, const _Float16* W, float* C
     if (N % SH_BN || K % 32 || ksplit == 0 || K / 32 < ksplit)
         return fail(CS_ERR_UNSUPPORTED, "split-K GEMM N=%u K=%u ksplit=%u", N, K, ksplit);
     if (M == 0) return CS_OK;
-    static bool attr = false;
-    if (!attr) {
+    static PerDeviceOnce attr;  // function attributes are per device
+    CS_TRY(attr.run([&]() -> int32_t {
         CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_sh16_kernel<SH_OUT_PARTIAL>), hipFuncAttributeMaxDynamicSharedMemorySize, SH_LDS_BYTES));
-        attr = true;
-    }
+        return CS_OK;
+    }));
     const dim3 grid(sh_grid_blocks((M + SH_BM - 1) / SH_BM, N / SH_BN) * ksplit);
     hipLaunchKernelGGL(gemm_sh16_kernel<SH_OUT_PARTIAL>, grid, dim3(256), SH_LDS_BYTES, s, A, W, nullptr, nullptr, Cpart,
                        nullptr, M, N, K / 32, nullptr, ksplit);

@@ -491,9 +491,9 @@ static int32_t gemm_wide_launch(int epi, const _Float16* A, const _Float16* W, c
                                 _Float16* Cs, uint32_t M, uint32_t N, uint32_t K, uint32_t* d_flag, hipStream_t s,
                                 const float* ln_g, const float* ln_b, float ln_eps, uint32_t ln_flags) {
     using G = GwGeom<WCN>;
-    static bool attr_set = false;
+    static PerDeviceOnce attr_set;  // function attributes are per device
     static int cus = 256;
-    if (!attr_set) {
+    CS_TRY(attr_set.run([&]() -> int32_t {
         CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wide_kernel<SH_OUT_F32, 0, WCN>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
         CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wide_kernel<SH_OUT_F32_RESID, 0, WCN>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
         CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wide_kernel<SH_OUT_SPLIT_GELU, 0, WCN>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
@@ -509,8 +509,8 @@ static int32_t gemm_wide_launch(int epi, const _Float16* A, const _Float16* W, c
             (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, gemm_wide_kernel<SH_OUT_SPLIT, 0, WCN>, G::THREADS, G::LDS);
             fprintf(stderr, "gemm_wide<WCN=%d>: %d threads, %d B LDS, occupancy %d blocks per CU\n", WCN, G::THREADS, G::LDS, nb);
         }
-        attr_set = true;
-    }
+        return CS_OK;
+    }));
     const uint32_t mtiles = (M + GW_BM - 1) / GW_BM, ntiles = N / G::BN;
     const uint32_t slots = sh_grid_blocks(mtiles, ntiles);
     const uint32_t resident = (uint32_t)cus * (WCN == 4 ? 1u : 2u);  // persistent grid: every block resident
@@ -525,8 +525,8 @@ static int32_t gemm_wide_launch(int epi, const _Float16* A, const _Float16* W, c
 #define GW_LAUNCH(E, V) hipLaunchKernelGGL((gemm_wide_kernel<E, V, WCN>), dim3(grid), dim3(G::THREADS), G::LDS, s, A, W, bias, resid, C, Cs, M, N, kc, d_flag, slots, ln_g, ln_b, ln_eps, stagger, ln_flags)
     if constexpr (WCN == 4) {
         if (g_gemm_wide_ablation && epi == SH_OUT_SPLIT) {
-            static bool abl_attr = false;
-            if (!abl_attr) {
+            static PerDeviceOnce abl_attr;  // function attributes are per device
+            CS_TRY(abl_attr.run([&]() -> int32_t {
                 CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wide_kernel<SH_OUT_SPLIT, 1, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
                 CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wide_kernel<SH_OUT_SPLIT, 2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
                 CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wide_kernel<SH_OUT_SPLIT, 3, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
@@ -537,8 +537,8 @@ static int32_t gemm_wide_launch(int epi, const _Float16* A, const _Float16* W, c
                 CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wide_kernel<SH_OUT_SPLIT, 8, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
                 CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wide_kernel<SH_OUT_SPLIT, 9, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
                 CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wide_kernel<SH_OUT_SPLIT, 10, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
-                abl_attr = true;
-            }
+                return CS_OK;
+            }));
             switch (g_gemm_wide_ablation) {
                 case 1: GW_LAUNCH(SH_OUT_SPLIT, 1); break;
                 case 2: GW_LAUNCH(SH_OUT_SPLIT, 2); break;

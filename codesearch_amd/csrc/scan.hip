@@ -563,14 +563,14 @@ int32_t launch_merge_variants(const uint64_t* d_keys, uint32_t nv, uint32_t k, u
     uint32_t nsort = 64;
     while (nsort < nkeys) nsort <<= 1;
     constexpr uint32_t kVariantHashMax = 4096;  // 3 * 4096 * 8 B = 96 KiB of LDS
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDeviceOnce attr_set;  // function attributes are per device
+    CS_TRY(attr_set.run([&]() -> int32_t {
         CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(merge_variants_sort2_kernel),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, kMergeCap * 4 * sizeof(uint64_t)));
         CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(merge_variants_kernel),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, kVariantHashMax * 3 * sizeof(uint64_t)));
-        attr_set = true;
-    }
+        return CS_OK;
+    }));
     if (nsort <= kVariantHashMax)
         hipLaunchKernelGGL(merge_variants_kernel, dim3(1), dim3(kMergeBlock), (size_t)nsort * 3 * sizeof(uint64_t), stream,
                            d_keys, nkeys, nsort, limit, d_out_keys, d_out_cos, d_out_ids, d_out_count,

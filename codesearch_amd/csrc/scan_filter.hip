@@ -936,8 +936,8 @@ static int32_t scan_split_impl(const BatchedState& st, const SplitQueryWs& qw, c
                                uint32_t* d_out_ids, uint32_t* d_out_counts, hipStream_t stream, float margin) {
     constexpr uint32_t dim = 128 * J;
     const uint32_t cap = batched_cap(k);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDeviceOnce attr_set;  // function attributes are per device
+    CS_TRY(attr_set.run([&]() -> int32_t {
         CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(score_filter_kernel),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, SH_LDS_BYTES));
         CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(score_filter256_kernel<false>),
@@ -963,8 +963,8 @@ static int32_t scan_split_impl(const BatchedState& st, const SplitQueryWs& qw, c
                                        hipFuncAttributeMaxDynamicSharedMemorySize, RwGeom<1, 16>::LDS_ALL));
         }
 
-        attr_set = true;
-    }
+        return CS_OK;
+    }));
     hipLaunchKernelGGL(prep_queries_kernel<J>, dim3((nq + 7) / 8), dim3(256), 0, stream,
                        qw.q_pinned ? qw.q_pinned : d_queries, qw.q_pinned ? const_cast<float*>(d_queries) : nullptr, nq,
                        qw.d_qmag, qw.d_qsplit, st.d_tau, st.d_cnt, st.d_carry, k, st.d_overflow,

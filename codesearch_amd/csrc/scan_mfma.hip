@@ -325,16 +325,16 @@ int32_t launch_scan_batched(const BatchedState& st, const float* d_corpus, const
     if (batched_lds_bytes(dim, nqt) > 160 * 1024 - 256) nqt = 1;
     const uint32_t qtiles = (nq + 32 * nqt - 1) / (32 * nqt);
     const size_t lds = batched_lds_bytes(dim, nqt);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDeviceOnce attr_set;  // function attributes are per device
+    CS_TRY(attr_set.run([&]() -> int32_t {
         const void* fns[4] = {reinterpret_cast<const void*>(score_append_kernel<1, true>),
                               reinterpret_cast<const void*>(score_append_kernel<1, false>),
                               reinterpret_cast<const void*>(score_append_kernel<2, true>),
                               reinterpret_cast<const void*>(score_append_kernel<2, false>)};
         for (const void* f : fns)
             CS_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
-        attr_set = true;
-    }
+        return CS_OK;
+    }));
     if (lds > 160 * 1024 - 256) return fail(CS_ERR_UNSUPPORTED, "query tile does not fit LDS at dim %u", dim);
     {
         const uint32_t n = nq * k > nq ? nq * k : nq;
