@@ -5,6 +5,7 @@
 //   g++ -O2 -std=c++17 benchmarks/search_latency.cpp -o benchmarks/search_latency_cpp -Lcodesearch_amd -lcsgpu -Wl,-rpath,$PWD/codesearch_amd
 #include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 
 #include "../include/codesearch_gpu.h"
@@ -26,9 +27,11 @@ static double timed(cs_index* h, const std::vector<float>& q, uint32_t nq, uint3
     return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / reps;
 }
 
-int main() {
+int main(int argc, char** argv) {
     if (cs_device_count() < 1) { std::printf("no HIP device\n"); return 77; }
-    for (uint64_t n : {592ull, 10000ull, 100000ull, 1000000ull}) {
+    std::vector<uint64_t> sizes = {592ull, 10000ull, 100000ull, 1000000ull};
+    if (argc > 1) { sizes.clear(); for (int i = 1; i < argc; ++i) sizes.push_back(strtoull(argv[i], nullptr, 10)); }
+    for (uint64_t n : sizes) {
         cs_index* h = nullptr;
         if (cs_index_create(384, n, 0, 0, &h) != CS_OK || cs_index_add_synthetic(h, n, 1234, 0, nullptr) != CS_OK ||
             cs_index_build(h) != CS_OK) { std::printf("error: %s\n", cs_last_error()); return 1; }

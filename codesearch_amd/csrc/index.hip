@@ -230,6 +230,7 @@ struct cs_index {
     float filter_margin = 0.0f;  // scan_filter.hip: bound of the f16 filter's error for this dim
     int filter_min_q = 2;  // query count from which the f16 filter + exact refine path is used
     uint32_t single_filter_min_k = 100;  // ... and one query too from this k on, over >= 2M rows (0 = never)
+    uint64_t single_batched_max_rows = 1024;  // ... and one query over at most this many rows (0 = never; CS_SINGLE_BATCHED_MAX_ROWS)
     // primed streaming scan (scan.hip PRIME mode): from this k and this many rows on, a pass over
     // the first prime_rows rows bounds the list inserts of the full scan
     // (measured, 1 query x 384-d: 10M rows k=10 2.37 -> 2.31 ms, k=200 2.62 -> 2.41 ms; 1M rows
@@ -399,8 +400,13 @@ int32_t run_search(cs_index* h, Workspace* w, const ScanPlan& plan, const float*
     // multi-million-row index — the reference's own retrieval_limit (100 or 200) when a search has no query variants —
     // the filter + refine path is taken instead: same bits, 1.40 vs 2.36 ms at k = 200 over 10M x 384, because
     // the scan's list inserts need a second block per CU there and the filter reads half the bytes.
+    // ... and over a corpus of the reference's own size (hundreds of chunks) the batched path — prep, direct scoring of
+    // every row, select: three small launches, no filter involved below a candidate buffer's worth of rows — answers one
+    // query faster than the streaming scan's per-wave lists do (592 rows: 30 vs 41 us; 1,000: 33 vs 46; from 2,000
+    // rows on the scan is ahead: 43 vs 48 us).
     const bool wants_filter = (int)nq >= h->filter_min_q ||
-                              (nq == 1 && h->single_filter_min_k && k >= h->single_filter_min_k && h->n_rows >= 2000000);
+                              (nq == 1 && h->single_filter_min_k && k >= h->single_filter_min_k && h->n_rows >= 2000000) ||
+                              (nq == 1 && h->n_rows <= h->single_batched_max_rows);
     const bool filter_path = split_ready && wants_filter && h->n_rows > 0 && h->normed_rows >= h->n_rows;
     w->qw.q_pinned = filter_path ? h_queries_pinned : nullptr;
     // A streaming scan of a few blocks (a corpus of the reference's own size: hundreds to thousands of chunks) reads
@@ -572,6 +578,7 @@ int32_t cs_index_create(uint32_t dim, uint64_t capacity_rows, int32_t device, ui
             if (h->filter_min_q < 1) h->filter_min_q = 1;
         }
         if (const char* e = std::getenv("CS_FILTER_SINGLE_MIN_K")) h->single_filter_min_k = (uint32_t)std::atol(e);
+        if (const char* e = std::getenv("CS_SINGLE_BATCHED_MAX_ROWS")) h->single_batched_max_rows = (uint64_t)std::atoll(e);
         if (const char* e = std::getenv("CS_SCAN_PRIME_MIN_K")) h->prime_min_k = (uint32_t)std::atol(e);  // 0 = off
         if (const char* e = std::getenv("CS_SCAN_PRIME_MIN_ROWS")) h->prime_min_rows = (uint64_t)std::atoll(e);
         if (const char* e = std::getenv("CS_SCAN_PRIME_ROWS")) h->prime_rows = (uint64_t)std::atoll(e);

@@ -732,6 +732,7 @@ def test_randomised_paths_agree(VS, oracle, monkeypatch):
     rng = np.random.default_rng(20261003)
     monkeypatch.setenv("CS_SCAN_PRIME_MIN_ROWS", "1")
     monkeypatch.setenv("CS_SCAN_PRIME_ROWS", "2048")
+    monkeypatch.setenv("CS_SINGLE_BATCHED_MAX_ROWS", "0")  # single queries stay on the streaming scan at every size
     for case in range(36):
         dim = int(rng.choice([384, 384, 768, 1024]))
         n = int(rng.choice([1, 33, 700, 1024, 1025, 3000, 9000, 25_000]))
@@ -775,6 +776,45 @@ def test_randomised_paths_agree(VS, oracle, monkeypatch):
             ecos, eids = oracle.scan_topk(rows, qs[0], k, dead=dead, mode="omp")
             assert_topk_equal(c0[0][: n0[0]], i0[0][: n0[0]], ecos, eids, rows, qs[0], oracle)
         st.close(); ref.close()
+
+
+@pytest.mark.parametrize("n", [1, 9, 592, 1024, 1025, 3000])
+def test_small_corpus_single_query_both_routes(VS, oracle, monkeypatch, n):
+    """One query over a corpus of the reference's own size takes the batched path (prep + direct scoring + select) up to
+    1,024 rows and the streaming scan above; CS_SINGLE_BATCHED_MAX_ROWS=0 keeps it on the scan.  Both routes must
+    return the oracle's answer and the same bits, with tombstones, an exact tie and a zero row in the corpus."""
+    dim = 384
+    rows = synth_rows(4242 + n, 0, n, dim)
+    if n > 40:
+        rows[n // 3] = rows[1]
+        rows[n // 2] = 0.0
+    q = synth_planted(4242 + n, 3, [min(1, n - 1)], dim)[0]
+    dead_ids = [0, n // 5] if n > 40 else []
+    stores = []
+    for max_rows in ("0", None):
+        if max_rows is None:
+            monkeypatch.delenv("CS_SINGLE_BATCHED_MAX_ROWS", raising=False)
+        else:
+            monkeypatch.setenv("CS_SINGLE_BATCHED_MAX_ROWS", max_rows)
+        st = VS(None, dim)
+        st.insert_embeddings(rows)
+        if dead_ids:
+            assert st.delete_chunks(dead_ids) == len(set(dead_ids))
+        st.build_index()
+        stores.append(st)
+    dead = None
+    if dead_ids:
+        dead = np.zeros((n + 31) // 32, np.uint32)
+        for d in dead_ids:
+            dead[d >> 5] |= np.uint32(1 << (d & 31))
+    for k in (1, 10, 200):
+        ecos, eids = oracle.scan_topk(rows, q, k, dead=dead, mode="omp")
+        (c0, i0, n0), (c1, i1, n1) = stores[0].search_raw(q, k), stores[1].search_raw(q, k)
+        assert n0[0] == n1[0] == len(eids)
+        assert i0[0].tolist() == i1[0].tolist() and c0[0].tobytes() == c1[0].tobytes()
+        assert_topk_equal(c1[0][: n1[0]], i1[0][: n1[0]], ecos, eids, rows, q, oracle)
+    for st in stores:
+        st.close()
 
 
 @pytest.mark.parametrize("world,nq,k", [(8, 1, 10), (8, 9, 200), (8, 64, 10), (2, 5, 1), (8, 3, 1024), (4, 2, 700),
