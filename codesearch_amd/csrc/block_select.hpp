@@ -14,7 +14,7 @@
 namespace cs {
 
 // a[0 .. n): keys (0 = empty), n <= R * T.  On return a[0 .. c) holds every key >= the bound found (c >= min(k, number
-// of non-zero keys); usually c <= max(64, next_pow2(k))), a[c .. ns) is zero, and ns (returned) is the power of two
+// of non-zero keys); usually c <= max(64, next_pow2(k)), twice that from k = 512), a[c .. ns) is zero, and ns (returned) is the power of two
 // >= max(c, k, 64) the caller should sort.  slots: 66 words of LDS scratch.  All T threads must call it.
 template <int T, int R>
 __device__ __forceinline__ uint32_t block_select_topk(uint64_t* a, uint32_t n, uint32_t k, int tid, uint32_t* slots) {
@@ -36,6 +36,7 @@ __device__ __forceinline__ uint32_t block_select_topk(uint64_t* a, uint32_t n, u
     };
     uint32_t want = 64;
     while (want < k) want <<= 1;
+    if (k >= 512) want <<= 1;  // long lists: an exact bracket would cost all 64 bits; a 2k-key sort is cheaper than that
     uint32_t c = count_ge(1ull, 64);
     uint64_t lo = 1ull;
     if (c > want) {  // more live keys than the small sort takes: raise the bound bit by bit while >= k keys stay above it
