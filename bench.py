@@ -9,7 +9,10 @@ all-gathered over RCCL and merged.  `value` = corpus rows ("chunks") searched pe
 over all ranks = N * rows_per_gpu * nq * K / t.
 
   python bench.py                      # N=1, 10M x 384, Q=1, k=10
+  python bench.py --gpus N             # ONE process drives N GPUs through cs_shards_* (what a Rust VectorStore
+                                       # inside `codesearch search` would call): shard g = rows [g*10M, (g+1)*10M)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N
+                                       # one rank per GPU, RCCL broadcast + all-gather (codesearch_amd/sharded.py)
 
 Adds to the JSON line:
   roofline     — the scan kernel against the 8 TB/s HBM peak: algorithmic bytes per launch
@@ -404,8 +407,150 @@ def cpu_baseline(oracle, sample_rows, dim, k, store_cls):
     }, recall, max_err
 
 
+def main_one_process(args):
+    """`python bench.py --gpus N` without a launcher: this process owns all N GPUs through the C ABI's row-sharded
+    store (cs_shards_*, csrc/shards.hip) — the form the reference's single-process `VectorStore::search`
+    (src/vectordb/store.rs:431-486, called at src/search/mod.rs:508-511) maps to.  Weak scaling: shard g holds rows
+    [g * rows, (g + 1) * rows).  A step = cs_shards_search_device: queries in HBM of GPU 0, fetched by every shard
+    over xGMI, per-shard scan + top-k, nq*k*8 bytes per shard sent back, one merge on GPU 0; nothing waits for the
+    host inside the timed region."""
+    import numpy as np
+    import torch
+
+    from codesearch_amd import VectorStore, _lib
+    from codesearch_amd.synth import synth_planted, synth_rows
+
+    lib = _lib.load()
+    N = args.gpus
+    ndev = int(lib.cs_device_count())
+    # CS_BENCH_SHARD_DEVICES=0,0: rehearse the N-shard code path on a box with fewer GPUs (not a scaling measurement)
+    devices = [int(x) for x in os.environ["CS_BENCH_SHARD_DEVICES"].split(",")] if os.environ.get("CS_BENCH_SHARD_DEVICES") \
+        else list(range(N))
+    if len(devices) != N or max(devices) >= ndev:
+        raise SystemExit(f"--gpus {N}: only {ndev} HIP device(s) visible")
+    dim, rows, nq, k = args.dim, args.rows, args.nq, args.k
+    st = VectorStore(None, dim, devices=devices, rows_per_stripe=rows, capacity=N * rows)
+    st.insert_synthetic(N * rows, SEED, 0)
+    st.build_index()
+    assert st.shard_lens() == [rows] * N
+    root = st.root_device()
+    torch.cuda.set_device(root)
+    dev = f"cuda:{root}"
+    q_host = synth_rows(SEED + 1, 0, nq, dim)
+    d_q = torch.from_numpy(q_host).to(dev)
+    keys = torch.zeros(nq * k, dtype=torch.int64, device=dev)
+    cos = torch.zeros(nq * k, dtype=torch.float32, device=dev)
+    ids = torch.zeros(nq * k, dtype=torch.int32, device=dev)
+    cnt = torch.zeros(nq, dtype=torch.int32, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step(q=d_q, m=nq):
+        st.search_device(q.data_ptr(), m, k, keys.data_ptr(), cos.data_ptr(), ids.data_ptr(), cnt.data_ptr(), stream)
+
+    def sync_all():
+        for d in sorted(set(devices)):
+            torch.cuda.synchronize(d)
+
+    # every shard must answer for its own rows: one planted query per shard (a noisy copy of a row living there)
+    planted_rows = [g * rows + (4242 + 1013 * g) % rows for g in range(N)]
+    planted = synth_planted(SEED, SEED + 7, planted_rows, dim)
+    planted_ok = []
+    for g in range(N):
+        pq = torch.from_numpy(planted[g:g + 1].copy()).to(dev)
+        step(pq, 1)
+        sync_all()
+        planted_ok.append(int(ids[0].item()) & 0xFFFFFFFF == planted_rows[g])
+    # and the gather form not in use must give the same bits (first hardware evidence for CS_SHARDS_DIRECT)
+    step()
+    sync_all()
+    ref_keys = keys.clone()
+    other = "0" if bool(lib.cs_shards_direct_gather(st.handle)) else "1"
+    os.environ["CS_SHARDS_DIRECT"], prev = other, os.environ.get("CS_SHARDS_DIRECT")
+    alt_same, alt_direct = None, None
+    try:
+        st2 = VectorStore(None, dim, devices=devices, rows_per_stripe=1 << 16, capacity=N << 16)
+        st2.insert_synthetic(N << 16, SEED, 0)
+        st2.build_index()
+        alt_direct = bool(lib.cs_shards_direct_gather(st2.handle))
+        c_alt, i_alt, _ = st2.search_raw(q_host, k)
+    finally:
+        if prev is None:
+            del os.environ["CS_SHARDS_DIRECT"]
+        else:
+            os.environ["CS_SHARDS_DIRECT"] = prev
+    st3 = VectorStore(None, dim, devices=devices, rows_per_stripe=1 << 16, capacity=N << 16)
+    st3.insert_synthetic(N << 16, SEED, 0)
+    st3.build_index()
+    c_def, i_def, _ = st3.search_raw(q_host, k)
+    alt_same = bool(np.array_equal(i_alt, i_def) and c_alt.tobytes() == c_def.tobytes())
+    st2.close()
+    st3.close()
+
+    for _ in range(args.warmup):
+        step()
+    sync_all()
+    sh0 = st.shard_handle(0)
+    _lib.check(lib.cs_index_profile(sh0, 1))
+    s_ms, m_ms, n_l = C.c_double(), C.c_double(), C.c_uint64()
+    _lib.check(lib.cs_index_profile_read(sh0, C.byref(s_ms), C.byref(n_l), C.byref(m_ms), 1))
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    _lib.check(lib.cs_index_profile_read(sh0, C.byref(s_ms), C.byref(n_l), C.byref(m_ms), 1))
+    _lib.check(lib.cs_index_profile(sh0, 0))
+    assert torch.equal(keys, ref_keys), "timed searches disagree with the first one"
+    scan_us = s_ms.value * 1e3 / max(n_l.value, 1)
+    alg_bytes = rows * dim * 4
+    achieved = alg_bytes / (scan_us * 1e-6) / 1e9 if scan_us else 0.0
+    total_rows = rows * N
+    line = {
+        "metric": "chunks embedded+searched/sec over 10M×384 corpus; recall@10 vs CPU ref",
+        "value_is": f"chunks searched/sec: brute-force cosine top-{k}, {nq} query/step over {rows} x {dim} fp32 rows "
+                    f"per GPU, {N} GPUs driven by one process",
+        "value": total_rows * nq * args.steps / elapsed,
+        "unit": "chunks/s", "n_gpus": len(set(devices)), "shards": N, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {
+            "workload": f"brute-force cosine top-{k}, {nq} query/step over {rows} x {dim} fp32 rows per GPU "
+                        f"(BASELINE.json north-star target / configs[4] layout; rows generated in HBM by "
+                        f"include/cs_synth.h, seed {SEED:#x})",
+            "rows_per_gpu": rows, "dim": dim, "queries_per_step": nq, "k": k,
+            "parallelism": f"one process, cs_shards over {N} GPUs: queries fetched from GPU {root} over xGMI, per-shard "
+                           f"scan + top-k, {nq * k * 8} B per shard gathered on GPU {root} "
+                           f"({'written by the search kernel' if lib.cs_shards_direct_gather(st.handle) else 'one peer copy per shard'}), "
+                           "one merge; no host synchronisation inside the timed region",
+        },
+        "roofline": {
+            "kernel": "cs::scan_topk_kernel (shard 0's launches; every shard runs the same kernel on its own rows)",
+            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBPS, "traffic": None, "algorithmic_bytes_per_launch": alg_bytes,
+            "avg_launch_us": scan_us, "launches_timed": int(n_l.value),
+            "merge_avg_us": m_ms.value * 1e3 / max(n_l.value, 1),
+            "note": "per GPU: HIP-event span of the prime pass + scan kernel on shard 0's stream; bytes = that shard's rows",
+        },
+        "top1": {"id": int(ids[0].item()) & 0xFFFFFFFF, "cos": float(cos[0].item())},
+        "multi_gpu_checks": {
+            "planted_query_per_shard_returns_its_row": planted_ok,
+            "gather_modes_agree": alt_same,
+            "gather_mode_compared": "direct" if alt_direct else "copy",
+        },
+    }
+    if not all(planted_ok):
+        line["error"] = "a shard did not return its planted row"
+    print(json.dumps(line), flush=True)
+    st.close()
+    if not all(planted_ok) or alt_same is False:
+        raise SystemExit(3)
+
+
 def main():
     args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return main_one_process(args)
     import torch
 
     from codesearch_amd import VectorStore
@@ -415,10 +560,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
-        args.gpus = world
+    args.gpus = world  # under a launcher the world decides
     torch.cuda.set_device(local_rank)
     dist = None
     # CS_BENCH_FORCE_DIST=1 (under torch.distributed.run) exercises the RCCL exchange at world 1

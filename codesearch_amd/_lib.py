@@ -71,10 +71,12 @@ SIGNATURES = {
     "cs_index_search_variants": (C.c_int32, [vp, f32p, C.c_uint32, C.c_uint32, C.c_uint32, f32p, u32p, u32p, i32p]),
     "cs_merge_variants_device": (C.c_int32, [C.c_int32, vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, vp, vp, vp, vp]),
     "cs_index_search_status": (C.c_int32, [vp, vp, u32p]),
+    "cs_index_release_stream": (C.c_int32, [vp, vp]),
     "cs_merge_topk_device": (C.c_int32, [C.c_int32, vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, vp, vp, vp]),
     "cs_shards_create": (C.c_int32, [C.c_uint32, C.c_uint32, i32p, C.c_uint64, C.c_uint64, C.POINTER(vp)]),
     "cs_shards_destroy": (None, [vp]),
     "cs_shards_add": (C.c_int32, [vp, f32p, C.c_uint64, C.c_uint32, u32p]),
+    "cs_shards_add_device": (C.c_int32, [vp, vp, C.c_int32, C.c_uint64, C.c_uint32, u32p, vp]),
     "cs_shards_add_synthetic": (C.c_int32, [vp, C.c_uint64, C.c_uint64, C.c_uint64, u32p]),
     "cs_shards_remove": (C.c_int32, [vp, u32p, C.c_uint64, u64p]),
     "cs_shards_build": (C.c_int32, [vp]),
@@ -87,6 +89,11 @@ SIGNATURES = {
     "cs_shards_shard_len": (C.c_uint64, [vp, C.c_uint32]),
     "cs_shards_direct_gather": (C.c_int32, [vp]),
     "cs_shards_search": (C.c_int32, [vp, f32p, C.c_uint32, C.c_uint32, C.c_uint32, f32p, u32p, u32p]),
+    "cs_shards_search_device": (C.c_int32, [vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, vp, vp, vp]),
+    "cs_shards_search_status": (C.c_int32, [vp, vp, u32p]),
+    "cs_shards_root_device": (C.c_int32, [vp]),
+    "cs_shards_shard_device": (C.c_int32, [vp, C.c_uint32]),
+    "cs_shards_shard_index": (vp, [vp, C.c_uint32]),
     "cs_shards_search_variants": (C.c_int32, [vp, f32p, C.c_uint32, C.c_uint32, C.c_uint32, f32p, u32p, u32p, i32p]),
     "cs_shards_read_rows": (C.c_int32, [vp, C.c_uint64, C.c_uint64, f32p]),
     "cs_index_read_rows": (C.c_int32, [vp, C.c_uint64, C.c_uint64, f32p]),

@@ -1,6 +1,7 @@
 // index.hip — cs_index_*: the vector half of the reference's VectorStore
 // (/root/reference/src/vectordb/store.rs:94-750) as a device-resident row-major matrix
 // searched by the exact scan of scan.hip.  Metadata (store.rs:19-85) stays with the caller.
+#include <algorithm>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -241,6 +242,9 @@ struct cs_index {
     uint64_t batched_searches = 0, batched_fallbacks = 0;
     std::vector<uint32_t> h_dead;
     bool built = false;
+    // streams of OTHER devices that carry unfinished appends into this corpus (index_append_from: an encoder replica on
+    // another GPU writing its rows over xGMI); hipDeviceSynchronize on this device does not wait for them
+    std::vector<std::pair<int, hipStream_t>> foreign_appends;
 
     std::mutex mu;  // guards the pools below (search is re-entrant)
     std::vector<Workspace*> pool;
@@ -255,14 +259,22 @@ struct cs_index {
 
 namespace {
 
-constexpr uint32_t kGatedMaxQ = 16;  // device-API searches of up to this many queries carry a gated exact rerun
+// Appends through cs_index_add_device / index_append_from may still be in flight on caller streams that do not
+// order against the null stream (hipStreamNonBlocking, torch side streams) or that belong to another device.
+int32_t drain_appends(cs_index* h) {
+    for (const auto& fs : h->foreign_appends) {
+        DeviceGuard g(fs.first);
+        CS_HIP(hipStreamSynchronize(fs.second));
+    }
+    h->foreign_appends.clear();
+    CS_HIP(hipDeviceSynchronize());
+    return CS_OK;
+}
 
 int32_t grow(cs_index* h, uint64_t need_rows) {
     if (need_rows <= h->capacity) return CS_OK;
-    // Appends through cs_index_add_device may still be in flight on caller streams that do not order
-    // against the null stream (hipStreamNonBlocking, torch side streams): drain the device before the
-    // old buffers are copied and freed, or rows of an unfinished append would be lost.
-    if (h->n_rows) CS_HIP(hipDeviceSynchronize());
+    // drain the device before the old buffers are copied and freed, or rows of an unfinished append would be lost
+    if (h->n_rows) CS_TRY(drain_appends(h));
     uint64_t cap = h->capacity ? h->capacity * 2 : 1024;
     if (cap < need_rows) cap = need_rows;
     float* nc = nullptr;
@@ -608,7 +620,7 @@ int32_t cs_index_create(uint32_t dim, uint64_t capacity_rows, int32_t device, ui
 void cs_index_destroy(cs_index* h) {
     if (!h) return;
     DeviceGuard g(h->device);
-    (void)hipDeviceSynchronize();
+    (void)drain_appends(h);
     for (auto* w : h->pool) { w->release_all(); delete w; }
     for (auto& kv : h->by_stream) { kv.second->release_all(); delete kv.second; }
     for (auto& t : h->pending) {
@@ -690,7 +702,7 @@ int32_t cs_index_remove(cs_index* h, const uint32_t* ids, uint64_t n, uint64_t* 
 int32_t cs_index_build(cs_index* h) {
     if (!h) return fail(CS_ERR_BAD_ARG, "null index handle");
     DeviceGuard g(h->device);
-    CS_HIP(hipDeviceSynchronize());  // appended rows (incl. async device appends) are now visible
+    CS_TRY(drain_appends(h));  // appended rows (incl. async device appends) are now visible
     if ((batched_supported(h->dim) || h->use_split) && h->normed_rows < h->n_rows) {
         CS_TRY(launch_row_norms(h->d_corpus, h->normed_rows, h->n_rows - h->normed_rows, h->dim,
                                 h->d_norms, nullptr));
@@ -710,7 +722,7 @@ int32_t cs_index_build(cs_index* h) {
 int32_t cs_index_clear(cs_index* h) {
     if (!h) return fail(CS_ERR_BAD_ARG, "null index handle");
     DeviceGuard g(h->device);
-    CS_HIP(hipDeviceSynchronize());
+    CS_TRY(drain_appends(h));
     if (h->d_dead && h->capacity)
         CS_HIP(hipMemset(h->d_dead, 0, (size_t)((h->capacity + 31) / 32) * sizeof(uint32_t)));
     h->n_rows = 0;  // store.rs:701 next_id = 0
@@ -842,6 +854,35 @@ int32_t cs_index_search_status(cs_index* h, void* stream, uint32_t* overflowed) 
     return CS_OK;
 }
 
+int32_t cs_index_release_stream(cs_index* h, void* stream) {
+    if (!h) return fail(CS_ERR_BAD_ARG, "null index handle");
+    DeviceGuard g(h->device);
+    std::vector<Workspace*> gone;
+    {
+        std::lock_guard<std::mutex> lk(h->mu);
+        for (auto it = h->by_stream.begin(); it != h->by_stream.end();) {
+            if (it->first.first == (hipStream_t)stream) { gone.push_back(it->second); it = h->by_stream.erase(it); }
+            else ++it;
+        }
+    }
+    if (gone.empty()) return CS_OK;
+    CS_HIP(hipStreamSynchronize((hipStream_t)stream));  // searches still using the scratch
+    uint64_t fallbacks = 0;
+    for (Workspace* w : gone) {
+        if (w->bs.d_overflow) {  // overflows counted on the device so far stay in the handle's totals
+            uint32_t v[3] = {0, 0, 0};
+            CS_HIP(hipMemcpy(v, w->bs.d_overflow, sizeof v, hipMemcpyDeviceToHost));
+            fallbacks += (uint64_t)v[2] + (v[0] ? 1 : 0);
+        }
+        w->release_all();
+        delete w;
+    }
+    cs::merge_scratch_release(h->device, (hipStream_t)stream);
+    std::lock_guard<std::mutex> lk(h->mu);
+    h->batched_fallbacks += fallbacks;
+    return CS_OK;
+}
+
 int32_t cs_merge_topk_device(int32_t device, const uint64_t* d_keys, uint32_t nlists, uint32_t nq,
                              uint32_t k, uint64_t* d_out_keys, float* d_out_cos,
                              uint32_t* d_out_ids, uint32_t* d_out_counts, void* stream) {
@@ -850,6 +891,50 @@ int32_t cs_merge_topk_device(int32_t device, const uint64_t* d_keys, uint32_t nl
 }
 
 }  // extern "C"
+
+namespace {
+struct MergeScratch { uint64_t* a = nullptr; uint64_t* b = nullptr; size_t cap = 0; };
+std::mutex g_merge_mu;
+std::map<std::tuple<int, hipStream_t, std::thread::id>, MergeScratch> g_merge_pool;
+}  // namespace
+
+// the caller has synchronised `stream`
+void cs::merge_scratch_release(int device, hipStream_t stream) {
+    std::lock_guard<std::mutex> lk(g_merge_mu);
+    for (auto it = g_merge_pool.begin(); it != g_merge_pool.end();) {
+        if (std::get<0>(it->first) == device && std::get<1>(it->first) == stream) {
+            if (it->second.a) { (void)hipFree(it->second.a); (void)hipFree(it->second.b); }
+            it = g_merge_pool.erase(it);
+        } else ++it;
+    }
+}
+
+int32_t cs::index_reserve(cs_index* h, uint64_t rows) {
+    if (!h) return fail(CS_ERR_BAD_ARG, "null index handle");
+    DeviceGuard g(h->device);
+    return grow(h, rows);
+}
+
+int32_t cs::index_append_from(cs_index* h, const float* d_rows, int src_device, uint64_t n, hipStream_t stream) {
+    CS_TRY(check_append(h, n, h ? h->dim : 0));
+    if (n == 0) return CS_OK;
+    {
+        DeviceGuard g(h->device);
+        CS_TRY(grow(h, h->n_rows + n));
+    }
+    float* dst = h->d_corpus + (size_t)h->n_rows * h->dim;
+    const size_t bytes = (size_t)n * h->dim * sizeof(float);
+    DeviceGuard g(src_device);  // `stream` belongs to the source device
+    if (src_device == h->device) CS_HIP(hipMemcpyAsync(dst, d_rows, bytes, hipMemcpyDeviceToDevice, stream));
+    else {
+        CS_HIP(hipMemcpyPeerAsync(dst, h->device, d_rows, src_device, bytes, stream));
+        const auto fs = std::make_pair(src_device, stream);
+        if (std::find(h->foreign_appends.begin(), h->foreign_appends.end(), fs) == h->foreign_appends.end())
+            h->foreign_appends.push_back(fs);
+    }
+    finish_append(h, n, nullptr);
+    return CS_OK;
+}
 
 int32_t cs::merge_topk_device_impl(int32_t device, const uint64_t* d_keys, uint32_t nlists, uint32_t nq, uint32_t k,
                                    uint64_t* d_out_keys, float* d_out_cos, uint32_t* d_out_ids, uint32_t* d_out_counts,
@@ -863,15 +948,12 @@ int32_t cs::merge_topk_device_impl(int32_t device, const uint64_t* d_keys, uint3
         // More than one merge level (over 2048 keys per query; 8 shards x k <= 256 fit one): ping-pong scratch
         // kept per (device, stream, calling thread) and grown on demand — never freed or synchronised per call, so
         // the merge stays asynchronous between the all-gather and whatever the caller enqueues next.
-        struct Scratch { uint64_t* a = nullptr; uint64_t* b = nullptr; size_t cap = 0; };
-        static std::mutex mu;
-        static std::map<std::tuple<int, hipStream_t, std::thread::id>, Scratch> pool;
-        std::lock_guard<std::mutex> lk(mu);
-        Scratch& sc = pool[std::make_tuple(device, (hipStream_t)stream, std::this_thread::get_id())];
+        std::lock_guard<std::mutex> lk(g_merge_mu);
+        MergeScratch& sc = g_merge_pool[std::make_tuple(device, (hipStream_t)stream, std::this_thread::get_id())];
         if (tmp > sc.cap) {
             // the old pair may still be in use by merges already enqueued on this stream: let them finish
             if (sc.a) { CS_HIP(hipStreamSynchronize((hipStream_t)stream)); (void)hipFree(sc.a); (void)hipFree(sc.b); }
-            sc = Scratch();
+            sc = MergeScratch();
             CS_HIP(hipMalloc(&sc.a, tmp * sizeof(uint64_t)));
             CS_HIP(hipMalloc(&sc.b, tmp * sizeof(uint64_t)));
             sc.cap = tmp;
@@ -893,7 +975,7 @@ int32_t cs_index_read_rows(cs_index* h, uint64_t first_row, uint64_t n, float* o
                     (unsigned long long)h->n_rows);
     if (n == 0) return CS_OK;
     DeviceGuard g(h->device);
-    CS_HIP(hipDeviceSynchronize());
+    CS_TRY(drain_appends(h));
     CS_HIP(hipMemcpy(out_rows, h->d_corpus + (size_t)first_row * h->dim,
                      (size_t)n * h->dim * sizeof(float), hipMemcpyDeviceToHost));
     return CS_OK;
@@ -918,7 +1000,9 @@ int32_t cs_index_debug_counters(cs_index* h, uint64_t* batched_searches, uint64_
     for (Workspace* w : ws) {
         if (!w->bs.d_overflow) continue;
         uint32_t v[3] = {0, 0, 0};
-        CS_HIP(hipStreamSynchronize(w->stream));
+        // a caller's stream may have been destroyed since (cs_index_release_stream is the orderly way): the blocking
+        // copy below orders against everything still running on the device either way
+        if (hipStreamSynchronize(w->stream) != hipSuccess) (void)hipGetLastError();
         CS_HIP(hipMemcpy(v, w->bs.d_overflow, sizeof v, hipMemcpyDeviceToHost));
         dev_fallbacks += (uint64_t)v[2] + (v[0] ? 1 : 0);
     }

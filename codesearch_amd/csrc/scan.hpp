@@ -56,6 +56,12 @@ int32_t merge_topk_device_impl(int32_t device, const uint64_t* d_keys, uint32_t 
                                uint64_t* d_out_keys, float* d_out_cos, uint32_t* d_out_ids, uint32_t* d_out_counts,
                                hipStream_t stream, uint32_t remap_stripe, uint32_t remap_shards);
 
+void merge_scratch_release(int device, hipStream_t stream);  // frees the pooled multi-level merge scratch of a stream
+// shards.hip: make room for `rows` rows in all (the only step of an append that can run out of memory), and append
+// rows resident on `src_device` with one asynchronous copy on `stream` (a stream of src_device).
+int32_t index_reserve(cs_index* h, uint64_t rows);
+int32_t index_append_from(cs_index* h, const float* d_rows, int src_device, uint64_t n, hipStream_t stream);
+
 // Variant merge of search::search (src/search/mod.rs:513-611): keys [nv][k] -> the best `limit` distinct ids
 // (a chunk keeps its best key), best-first, + count + the "top five all within distance 0.15" predicate.
 int32_t launch_merge_variants(const uint64_t* d_keys, uint32_t nv, uint32_t k, uint32_t limit, uint64_t* d_out_keys,
@@ -71,6 +77,9 @@ int32_t launch_synth_fill(float* d_rows, uint64_t n, uint32_t dim, uint64_t seed
 // line serialise at ~40 ns apiece whichever word they hit (measured: nine queries' counters in one
 // line made the k=200 filter phases 50-190 us longer).
 constexpr uint32_t kCntStride = 32;
+// Device-API searches of up to this many queries carry a gated exact rerun behind the filter path (index.hip
+// run_search); above it an overflowed candidate buffer is reported through the sticky word of BatchedState.
+constexpr uint32_t kGatedMaxQ = 16;
 struct BatchedState {
     uint64_t* d_cand = nullptr;   // [nq][cap] candidate keys
     uint32_t* d_cnt = nullptr;    // [nq][kCntStride], word 0 of each line used

@@ -213,7 +213,9 @@ select_candidates_kernel(const uint64_t* __restrict__ cand, uint32_t* __restrict
     const uint32_t q = blockIdx.x;
     uint32_t n = cnt[(size_t)q * kCntStride];
     if (n > cap) {
-        if (tid == 0) { atomicOr(overflow, 1u); atomicOr(overflow + 1, 1u); }
+        // [1] is the sticky word cs_index_search_status reports: only searches of more than kGatedMaxQ queries (one
+        // block per query here) rely on it — smaller ones carry the gated exact rerun and repair themselves
+        if (tid == 0) { atomicOr(overflow, 1u); if (gridDim.x > kGatedMaxQ) atomicOr(overflow + 1, 1u); }
         n = cap;
     }
     const uint64_t* src = cand + (size_t)q * cap;

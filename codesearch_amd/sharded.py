@@ -71,10 +71,28 @@ class HipShardBackend:
         self.store.insert_synthetic(n, seed, first_row)
         self.store.build_index()
 
+    GATED_MAX_Q = 16  # csrc/scan.hpp kGatedMaxQ: up to this many queries a device search repairs itself
+
     def search_local(self, d_queries, nq: int, k: int, keys, cos=None, ids=None, counts=None) -> None:
-        vp = lambda x: None if x is None else C.c_void_p(x.data_ptr())
+        """Exact on return-to-stream: searches of more than 16 queries report a candidate-buffer overflow (adversarial
+        row orders) through cs_index_search_status instead of rerunning on the device; it is asked here, BEFORE the
+        keys enter the all-gather, and an overflowed search is redone in slices of 16 queries, which always are exact.
+        The status call waits for this rank's search — one stream synchronisation per > 16-query search."""
+        vp = lambda x, off=0: None if x is None else C.c_void_p(x.data_ptr() + off)
         self._check(self._lib.cs_index_search_device(self.store.handle, vp(d_queries), nq, self.dim, k, vp(keys),
                                                      vp(cos), vp(ids), vp(counts), self._stream()))
+        if nq <= self.GATED_MAX_Q:
+            return
+        ov = C.c_uint32(0)
+        self._check(self._lib.cs_index_search_status(self.store.handle, self._stream(), C.byref(ov)))
+        if not ov.value:
+            return
+        self.overflow_reruns = getattr(self, "overflow_reruns", 0) + 1
+        for q0 in range(0, nq, self.GATED_MAX_Q):
+            m = min(self.GATED_MAX_Q, nq - q0)
+            self._check(self._lib.cs_index_search_device(
+                self.store.handle, vp(d_queries, q0 * self.dim * 4), m, self.dim, k, vp(keys, q0 * k * 8),
+                vp(cos, q0 * k * 4), vp(ids, q0 * k * 4), vp(counts, q0 * 4), self._stream()))
 
     def merge(self, gathered, world: int, nq: int, k: int, keys, cos, ids, counts) -> None:
         vp = lambda x: C.c_void_p(x.data_ptr())

@@ -303,6 +303,43 @@ class VectorStore:
             return [len(self)]
         return [int(self._lib.cs_shards_shard_len(self._h, i)) for i in range(int(self._lib.cs_shards_count(self._h)))]
 
+    def root_device(self) -> int:
+        """The device whose HBM holds queries and results of the device-pointer search API."""
+        return int(self._lib.cs_shards_root_device(self._h)) if self.sharded else int(self._lib.cs_index_device(self._h))
+
+    def shard_handle(self, shard: int):
+        """Borrowed cs_index of one shard (diagnostics: profile, counters)."""
+        return C.c_void_p(self._lib.cs_shards_shard_index(self._h, shard)) if self.sharded else self._h
+
+    def search_device(self, d_queries: int, nq: int, limit: int, d_keys: int = 0, d_cos: int = 0, d_ids: int = 0,
+                      d_counts: int = 0, stream: int = 0) -> None:
+        """cs_index_search_device / cs_shards_search_device: raw HBM pointers on root_device(), asynchronous on
+        `stream`; never waits for the device."""
+        p = lambda a: C.c_void_p(a) if a else None
+        _lib.check(self._fn("search_device")(self._h, p(d_queries), nq, self.dimensions, limit, p(d_keys), p(d_cos),
+                                             p(d_ids), p(d_counts), p(stream)))
+
+    def search_status(self, stream: int = 0) -> bool:
+        """True when a device search of more than 16 queries issued on `stream` overflowed a candidate buffer since
+        the last call (rerun it in slices of <= 16 queries or through search_raw)."""
+        ov = C.c_uint32(0)
+        _lib.check(self._fn("search_status")(self._h, C.c_void_p(stream) if stream else None, C.byref(ov)))
+        return bool(ov.value)
+
+    def insert_device(self, d_rows: int, n: int, src_device: Optional[int] = None, stream: int = 0) -> np.ndarray:
+        """Append n rows already in HBM (cs_index_add_device / cs_shards_add_device) -> ids."""
+        self._writable()
+        ids = np.zeros(n, np.uint32)
+        st = C.c_void_p(stream) if stream else None
+        if self.sharded:
+            src = self.root_device() if src_device is None else int(src_device)
+            _lib.check(self._lib.cs_shards_add_device(self._h, C.c_void_p(d_rows), src, n, self.dimensions,
+                                                      ids.ctypes.data_as(u32p), st))
+        else:
+            _lib.check(self._lib.cs_index_add_device(self._h, C.c_void_p(d_rows), n, self.dimensions,
+                                                     ids.ctypes.data_as(u32p), st))
+        return ids
+
     def _writable(self):
         if self.readonly:
             raise CsError(_lib.CS_ERR_BAD_ARG, "store opened read-only (open_readonly)")

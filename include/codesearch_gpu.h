@@ -164,6 +164,11 @@ int32_t cs_merge_variants_device(int32_t device, const uint64_t* d_keys, uint32_
  * than 16 queries issued by this thread on it since the previous status call overflowed a candidate buffer
  * (its results are then incomplete); clears the condition. */
 int32_t cs_index_search_status(cs_index* h, void* stream, uint32_t* overflowed);
+/* Frees the device-API scratch (partial lists, candidate buffers, split queries, merge ping-pong) the handle keeps
+ * per (stream, calling thread) for `stream`, for every thread that used it; synchronises the stream first.  Call it
+ * before destroying a stream that searched, or from a request thread that is about to exit: scratch is otherwise
+ * kept for the life of the index (cs_index_destroy frees all of it). */
+int32_t cs_index_release_stream(cs_index* h, void* stream);
 
 /* Shard merge: given `nlists` per-shard key lists [nlists, nq, k]
  * (as all-gathered over RCCL), write the merged best-k per query.  Device pointers. */
@@ -181,8 +186,8 @@ int32_t cs_merge_topk_device(int32_t device, const uint64_t* d_keys, uint32_t nl
  * `rows_per_stripe` consecutive ids, round-robin (stripe = rows per GPU gives the contiguous ranges of
  * BASELINE.json config 5: shard g holds ids [g*stripe, (g+1)*stripe)).  A search broadcasts the queries,
  * runs every shard's cs_index search on its own stream, gathers nq*k*8 bytes per shard on the first
- * device (written there directly over xGMI when peer access is available) and merges them: the result
- * is the single-index result bit for bit.  Same error texts, threading rules and entry-point meaning as
+ * device (one peer copy per shard over xGMI; CS_SHARDS_DIRECT=1: written there by the search's last kernel)
+ * and merges them: the result is the single-index result bit for bit.  Same error texts, threading rules and entry-point meaning as
  * cs_index_* (add/remove/build/clear need external exclusion; search is re-entrant).
  * ---------------------------------------------------------------------------------- */
 typedef struct cs_shards cs_shards;
@@ -190,6 +195,12 @@ int32_t cs_shards_create(uint32_t dim, uint32_t nshards, const int32_t* devices,
                          uint64_t capacity_rows /* whole store, reservation hint */, cs_shards** out);
 void cs_shards_destroy(cs_shards* h);
 int32_t cs_shards_add(cs_shards* h, const float* rows, uint64_t n, uint32_t dim, uint32_t* out_ids);
+/* Same with the rows in HBM of device `src_device` (an encoder replica's output): each run of rows goes to its
+ * shard by one asynchronous copy on `stream` (a stream of src_device; in place when the shard lives there, over
+ * xGMI otherwise) — the multi-GPU form of cs_index_add_device, src/index/mod.rs:692-723.  Appends are
+ * all-or-nothing: capacity is reserved on every touched shard before any row moves. */
+int32_t cs_shards_add_device(cs_shards* h, const float* d_rows, int32_t src_device, uint64_t n, uint32_t dim,
+                             uint32_t* out_ids, void* stream);
 int32_t cs_shards_add_synthetic(cs_shards* h, uint64_t n, uint64_t seed, uint64_t first_row,
                                 uint32_t* out_first_id);
 int32_t cs_shards_remove(cs_shards* h, const uint32_t* ids, uint64_t n, uint64_t* removed);
@@ -201,9 +212,24 @@ uint32_t cs_shards_next_id(const cs_shards* h);
 uint32_t cs_shards_dim(const cs_shards* h);
 uint32_t cs_shards_count(const cs_shards* h);                        /* number of shards */
 uint64_t cs_shards_shard_len(const cs_shards* h, uint32_t shard);    /* live rows on one shard */
-int32_t cs_shards_direct_gather(const cs_shards* h);                 /* 1 = shards write into the root's buffer */
+int32_t cs_shards_direct_gather(const cs_shards* h);                 /* 1 = shards write into the root's buffer (CS_SHARDS_DIRECT=1) */
 int32_t cs_shards_search(cs_shards* h, const float* queries, uint32_t nq, uint32_t dim, uint32_t k,
                          float* out_cos, uint32_t* out_ids, uint32_t* out_counts);
+/* Device-pointer form (cs_index_search_device's counterpart): d_queries [nq, dim] and the outputs live in HBM of the
+ * store's FIRST device (cs_shards_root_device); asynchronous on `stream`, a stream of that device — the call only
+ * enqueues: the shard streams wait for an event of `stream`, fetch the queries over xGMI, search, send their keys
+ * back, and `stream` waits for one event per shard before the merge.  Nothing waits for the host, so consecutive
+ * searches overlap their launch cost with the previous scan.  Exactness above 16 queries per call as for
+ * cs_index_search_device: ask cs_shards_search_status once the results are needed. */
+int32_t cs_shards_search_device(cs_shards* h, const float* d_queries, uint32_t nq, uint32_t dim, uint32_t k,
+                                uint64_t* d_out_keys, float* d_out_cos, uint32_t* d_out_ids, uint32_t* d_out_counts,
+                                void* stream);
+int32_t cs_shards_search_status(cs_shards* h, void* stream, uint32_t* overflowed);
+int32_t cs_shards_root_device(const cs_shards* h);
+int32_t cs_shards_shard_device(const cs_shards* h, uint32_t shard);
+/* Borrowed handle of one shard's cs_index, for diagnostics only (cs_index_profile*, cs_index_debug_counters,
+ * cs_index_search* of that shard alone: local row numbers, not ids).  Never mutate or destroy it. */
+cs_index* cs_shards_shard_index(cs_shards* h, uint32_t shard);
 /* cs_index_search_variants over the sharded store: per-variant searches on every shard, the shard merge, then the
  * variant merge (src/search/mod.rs:513-611) on the first device. */
 int32_t cs_shards_search_variants(cs_shards* h, const float* queries, uint32_t nq, uint32_t dim, uint32_t k,

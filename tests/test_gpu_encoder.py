@@ -9,6 +9,7 @@ import numpy as np
 import pytest
 
 from codesearch_amd.bert_params import POOL_CLS, POOL_MEAN, BertConfig, synth_params, synth_token_batch
+from tests.test_gpu_scan import assert_topk_equal
 
 pytestmark = pytest.mark.gpu
 
@@ -193,6 +194,46 @@ def test_end_to_end_index_then_search_vs_oracle_pipeline(FE, oracle):
             for a, b in zip(rid[i], eids):
                 if a != b:
                     assert abs(float(corpus[a] @ qv[i]) - float(corpus[b] @ qv[i])) < 5e-5
+
+
+def test_config3_full_size_100k_chunks_64_queries(FE, oracle):
+    """BASELINE.json configs[3] AT FULL SIZE: 100,000 synthetic chunks x 256 tokens embedded by the full 12-layer
+    BGE-small-shaped encoder, appended to the device-resident matrix without leaving HBM, then 64 batched queries
+    top-10.  Checked through what does not depend on size: every stored row is a unit vector; 8 sampled rows and 4
+    query embeddings against the encoder oracle; every query — a one-token edit of a known chunk — retrieves its
+    source chunk; and the 64 result lists against the scan oracle run over the stored matrix itself."""
+    from codesearch_amd import VectorStore
+    from codesearch_amd.pipeline import index_token_chunks
+
+    cfg = BertConfig.bge_small()
+    n, L, nq, k = 100_000, 256, 64, 10
+    ids, mask = synth_token_batch(cfg, 31337, n, L, False)
+    targets = [(i * 7919) % n for i in range(nq)]
+    q_ids, q_mask = ids[targets].copy(), mask[targets].copy()
+    q_ids[:, 5] = (q_ids[:, 5] + 1) % cfg.vocab_size
+    emb = FE(cfg, seed=202)
+    store = VectorStore(None, cfg.hidden, capacity=n)
+    index_token_chunks(emb, store, ids, mask)
+    assert store.is_indexed() and len(store) == n and store.next_id() == n
+    corpus = store.read_rows(0, n)
+    np.testing.assert_allclose(np.linalg.norm(corpus, axis=1), 1.0, atol=1e-5)
+    params = oracle.bert_synth_params(cfg, 202)
+    rows = [0, 255, 256, 31_337, 50_000, 65_535, 99_744, n - 1]   # first / last of mini-batches, the ragged last one
+    ref = oracle.bert_forward(cfg, params, ids[rows], mask[rows])["pooled"]
+    np.testing.assert_allclose(corpus[rows], ref, atol=TOL_ORACLE)
+    qv = emb.embed_ids(q_ids, q_mask)
+    qref = oracle.bert_forward(cfg, params, q_ids[:4], q_mask[:4])["pooled"]
+    np.testing.assert_allclose(qv[:4], qref, atol=TOL_ORACLE)
+    cos, rid, counts = store.search_raw(qv, k)
+    assert (counts == k).all()
+    assert rid[:, 0].tolist() == targets and (cos[:, 0] > 0.9).all()
+    for i in range(nq):  # the search itself: exact against the oracle over the very rows the store holds
+        ecos, eids = oracle.scan_topk(corpus, qv[i], k, mode="omp")
+        assert_topk_equal(cos[i], rid[i], ecos, eids, corpus, qv[i], oracle)
+    split, f32n, fallbacks = emb.debug_counters()
+    assert split >= n // 256 and fallbacks == 0
+    emb.close()
+    store.close()
 
 
 def test_text_entry_points_with_tokenizer(FE, oracle):

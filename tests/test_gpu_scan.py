@@ -305,7 +305,27 @@ def _oracle_topk_by_slices(st, oracle, qs, n, kmax, seed, dim, slice_rows=1_000_
     return [oracle.merge_topk(pc[i], pi[i], np.full(nsl, kmax, np.uint32), kmax) for i in range(len(qs))]
 
 
-def test_full_size_10m_against_oracle_slices(VS, oracle, monkeypatch):
+@pytest.fixture(scope="module")
+def full10m(VS, oracle):
+    """BASELINE's target corpus — 10M x 384 generated in HBM — with the exhaustive CPU answer (oracle over 1M-row slices
+    pulled back from HBM, one pass of 15 GB) for every query the full-size tests use: four planted + two random
+    queries, and 16 of the 1,000 queries of configs[4]'s per-GPU workload."""
+    n, dim, seed, kmax = 10_000_000, 384, 0xC0DE5EA, 200
+    st = VS(None, dim, capacity=n)
+    st.insert_synthetic(n, seed, 0)
+    st.build_index()
+    planted_rows = [123_456, 9_999_999, 0, 5_000_001]
+    qs = np.concatenate([synth_planted(seed, seed + 2, planted_rows, dim), synth_rows(seed + 1, 0, 2, dim)])
+    q1000 = synth_rows(seed + 9, 0, 1000, dim)
+    sample = list(range(0, 1000, 67)) + [999]
+    assert len(sample) == 16
+    expect = _oracle_topk_by_slices(st, oracle, np.concatenate([qs, q1000[sample]]), n, kmax, seed, dim)
+    yield dict(st=st, n=n, dim=dim, seed=seed, planted_rows=planted_rows, qs=qs, expect=expect[:len(qs)],
+               q1000=q1000, sample=sample, expect1000=expect[len(qs):])
+    st.close()
+
+
+def test_full_size_10m_against_oracle_slices(VS, oracle, monkeypatch, full10m):
     """BASELINE's target: 10M x 384 generated in HBM, every search path against the exhaustive CPU oracle
     (examples/benchmark_models.rs:155-165 generalised to top-k).
     (a) planted queries: top-1 is the planted row at any size;
@@ -315,21 +335,17 @@ def test_full_size_10m_against_oracle_slices(VS, oracle, monkeypatch):
     (d) one query per call at k = 100 and 200 (the reference's retrieval limits, src/search/mod.rs:494-502):
         routed through filter + refine by default, and through the streaming scan on a second store
         created with CS_FILTER_SINGLE_MIN_K=0."""
-    n, dim, seed, kmax = 10_000_000, 384, 0xC0DE5EA, 200
-    st = VS(None, dim, capacity=n)
-    st.insert_synthetic(n, seed, 0)
-    st.build_index()
-    planted_rows = [123_456, 9_999_999, 0, 5_000_001]
-    qs = np.concatenate([synth_planted(seed, seed + 2, planted_rows, dim), synth_rows(seed + 1, 0, 2, dim)])
+    st, n, dim, seed = full10m["st"], full10m["n"], full10m["dim"], full10m["seed"]
+    planted_rows, qs, expect = full10m["planted_rows"], full10m["qs"], full10m["expect"]
+    b0, f0 = st.debug_counters()
     k = 10
     cos, ids, counts = st.search_raw(qs, k)
-    assert st.debug_counters() == (1, 0)
+    assert st.debug_counters() == (b0 + 1, f0)
     assert (counts == k).all()
     for i, r in enumerate(planted_rows):
         assert ids[i][0] == r and cos[i][0] > 0.85
     for i in range(len(qs)):
         assert (np.diff(cos[i]) <= 0).all() and len(set(ids[i].tolist())) == k
-    expect = _oracle_topk_by_slices(st, oracle, qs, n, kmax, seed, dim)
     for i in range(len(qs)):  # (b)
         ecos, eids = expect[i]
         assert ids[i].tolist() == eids[:k].tolist()
@@ -339,16 +355,15 @@ def test_full_size_10m_against_oracle_slices(VS, oracle, monkeypatch):
         assert n1[0] == 10 and i1[0].tolist() == expect[i][1][:10].tolist()
         np.testing.assert_allclose(c1[0], expect[i][0][:10], atol=COS_TOL)
         assert c1[0].tobytes() == cos[i].tobytes()  # and the two paths agree bit for bit
-    assert st.debug_counters() == (1, 0)  # none of those took the batched path
-    b = 1
+    assert st.debug_counters() == (b0 + 1, f0)  # none of those took the batched path
+    b = b0 + 1
     for kk in (100, 200):  # (d) default routing: filter + refine for one long-list query
         for i in (0, 4, 5):
             c1, i1, n1 = st.search_raw(qs[i], kk)
             b += 1
             assert n1[0] == kk and i1[0].tolist() == expect[i][1][:kk].tolist()
             np.testing.assert_allclose(c1[0], expect[i][0][:kk], atol=COS_TOL)
-    assert st.debug_counters() == (b, 0)
-    st.close()
+    assert st.debug_counters() == (b, f0)
     monkeypatch.setenv("CS_FILTER_SINGLE_MIN_K", "0")
     st2 = VS(None, dim, capacity=n)
     st2.insert_synthetic(n, seed, 0)
@@ -360,6 +375,37 @@ def test_full_size_10m_against_oracle_slices(VS, oracle, monkeypatch):
             np.testing.assert_allclose(c1[0], expect[i][0][:kk], atol=COS_TOL)
     assert st2.debug_counters() == (0, 0)
     st2.close()
+
+
+def test_config5_per_gpu_workload_1000_queries_over_10m_rows(full10m):
+    """BASELINE.json configs[4], one GPU's share: 1,000 batched queries, top-10, over that GPU's 10M x 384 rows (the
+    256 x 256 f16 filter tiles + exact f32 refine).  16 sampled queries against the exhaustive CPU oracle; every query
+    bit-equal — ids and cosines — to the single-query streaming scan, itself checked against the oracle above; the
+    device-pointer call the sharded store issues (cs_index_search_device, > 16 queries) gives the same keys and
+    reports no overflow."""
+    import torch
+
+    from codesearch_amd.sharded import key_unpack
+
+    st, dim, q1000, sample = full10m["st"], full10m["dim"], full10m["q1000"], full10m["sample"]
+    k = 10
+    b0, f0 = st.debug_counters()
+    cos, ids, counts = st.search_raw(q1000, k)
+    assert st.debug_counters() == (b0 + 1, f0) and (counts == k).all()
+    for j, i in enumerate(sample):
+        ecos, eids = full10m["expect1000"][j]
+        assert ids[i].tolist() == eids[:k].tolist()
+        np.testing.assert_allclose(cos[i], ecos[:k], atol=COS_TOL)
+    for i in range(len(q1000)):
+        c1, i1, n1 = st.search_raw(q1000[i], k)  # scan_topk_kernel<3,8,1,true,false>
+        assert n1[0] == k and i1[0].tolist() == ids[i].tolist() and c1[0].tobytes() == cos[i].tobytes(), i
+    assert st.debug_counters() == (b0 + 1, f0)
+    d_q = torch.from_numpy(q1000).to("cuda:0")
+    keys = torch.zeros((1000, k), dtype=torch.int64, device="cuda:0")
+    st.search_device(d_q.data_ptr(), 1000, k, d_keys=keys.data_ptr())
+    assert st.search_status() is False
+    kc, ki = key_unpack(keys.cpu().numpy().view(np.uint64))
+    assert ki.tolist() == ids.tolist() and kc.tobytes() == cos.tobytes()
 
 
 def test_config1_1m_single_query_against_oracle(VS, oracle):
@@ -437,13 +483,11 @@ def test_mfma_batched_overflow_falls_back_to_exact(VS, oracle):
         assert_topk_equal(cos[i], ids[i], ecos, eids, corpus, q[i], oracle)
 
 
-def test_mfma_batched_10m_equals_single_query_scans(VS):
+def test_mfma_batched_10m_equals_single_query_scans(full10m):
     """BASELINE configs 4/5 shape on one GPU: 64 (and 100) batched queries over 10M rows must
     equal 64 independent single-query scans (which are checked against the oracle above)."""
-    n, dim, k, seed = 10_000_000, 384, 10, 0xC0DE5EA
-    st = VS(None, dim, capacity=n)
-    st.insert_synthetic(n, seed, 0)
-    st.build_index()
+    st, dim, k, seed = full10m["st"], full10m["dim"], 10, full10m["seed"]
+    b0, f0 = st.debug_counters()
     for nq in (64, 100):
         qs = synth_rows(seed + 5, 0, nq, dim)
         cos, ids, counts = st.search_raw(qs, k)
@@ -452,8 +496,7 @@ def test_mfma_batched_10m_equals_single_query_scans(VS):
             c1, i1, _ = st.search_raw(qs[i], k)
             assert ids[i].tolist() == i1[0].tolist()
             assert cos[i].tobytes() == c1[0].tobytes()  # refine = the single-query arithmetic
-    b, f = st.debug_counters()
-    assert b == 2 and f == 0
+    assert st.debug_counters() == (b0 + 2, f0)
 
 
 # ---- batched queries: filter (split-f16 MFMA) + exact refine (scan_split.hip) ---------------------

@@ -24,10 +24,14 @@ def VS(gpu_lib):
 
 @pytest.mark.parametrize("n,stripe,direct", [(80_000, 10_000, "1"),   # contiguous ranges: shard g = ids [g*S, (g+1)*S)
                                              (50_001, 1_000, "1"),    # seven rounds of stripes, ragged tail
-                                             (50_001, 1_000, "0"),    # gather through hipMemcpyPeerAsync
+                                             (50_001, 1_000, "0"),    # gather through hipMemcpyPeerAsync, forced
+                                             (50_001, 1_000, ""),     # default: copy across devices, in place on the root
                                              (3_000, 4_096, "1")])    # everything on shard 0, seven empty shards
 def test_eight_shards_equal_the_single_index(VS, oracle, monkeypatch, n, stripe, direct):
-    monkeypatch.setenv("CS_SHARDS_DIRECT", direct)
+    if direct:
+        monkeypatch.setenv("CS_SHARDS_DIRECT", direct)
+    else:
+        monkeypatch.delenv("CS_SHARDS_DIRECT", raising=False)
     dim, seed, shards = 384, 9090, 8
     single = VS(None, dim)
     single.insert_synthetic(n, seed, 0)
@@ -131,12 +135,12 @@ def test_device_search_never_waits_and_gated_rerun_is_exact(VS, oracle, gpu_lib)
     assert ids[0].min() >= n - 12                                  # query 0: the last rows, which the filter overflowed on
     ov = C.c_uint32(7)
     _lib.check(gpu_lib.cs_index_search_status(st.handle, stream, C.byref(ov)))
-    assert ov.value == 1                                           # sticky word: the overflow is also reported
-    _lib.check(gpu_lib.cs_index_search_status(st.handle, stream, C.byref(ov)))
-    assert ov.value == 0                                           # ... once
+    assert ov.value == 0                                           # a gated call repaired itself: nothing to report
     cos, ids, cnt = device_search(q, k)                            # (b) 24 queries: no gated rerun
     _lib.check(gpu_lib.cs_index_search_status(st.handle, stream, C.byref(ov)))
     assert ov.value == 1
+    _lib.check(gpu_lib.cs_index_search_status(st.handle, stream, C.byref(ov)))
+    assert ov.value == 0                                           # reported once
     hc, hi, hn = st.search_raw(q, k)                               # the host-buffer API reruns by itself
     for i in (0, 5, 23):
         ecos, eids = oracle.scan_topk(corpus, q[i], k, mode="omp")
@@ -194,4 +198,120 @@ def test_concurrent_device_searches_on_one_stream_do_not_share_scratch(VS, oracl
     [t.start() for t in threads]
     [t.join() for t in threads]
     assert not errors, errors
+    st.close()
+
+
+def test_shards_over_distinct_devices(VS, oracle, gpu_lib, monkeypatch):
+    """cs_shards over min(8, cs_device_count()) DISTINCT devices (one shard on a one-GPU box): peer copies of the
+    queries and keys, cross-device event waits, appends from another device's HBM.  1 / 9 / 1000 queries through the
+    host API and through the asynchronous device-pointer API must equal the single index bit for bit, in both gather
+    modes where a second device exists; rows appended with cs_shards_add_device from every device read back exactly."""
+    import torch
+
+    from codesearch_amd.sharded import key_unpack
+
+    ndev = min(8, int(gpu_lib.cs_device_count()))
+    devices = list(range(ndev))
+    n, dim, seed, stripe = 120_000, 384, 555, 4_096
+    corpus = oracle.synth_rows(seed, 0, n, dim)
+    single = VS(None, dim)
+    single.insert_embeddings(corpus)
+    single.build_index()
+    modes = ["", "1"] if ndev > 1 else [""]
+    for mode in modes:
+        if mode:
+            monkeypatch.setenv("CS_SHARDS_DIRECT", mode)
+        else:
+            monkeypatch.delenv("CS_SHARDS_DIRECT", raising=False)
+        sh = VS(None, dim, devices=devices, rows_per_stripe=stripe, capacity=n)
+        assert sh.root_device() == 0 and bool(gpu_lib.cs_shards_direct_gather(sh.handle)) == (mode == "1")
+        # appends: a third from the host, the rest from the HBM of each device in turn (cs_shards_add_device)
+        third = n // 3
+        assert sh.insert_embeddings(corpus[:third]).tolist() == list(range(third))
+        lo, d = third, 0
+        while lo < n:
+            m = min(17_001, n - lo)
+            t = torch.from_numpy(corpus[lo:lo + m]).to(f"cuda:{devices[d % ndev]}")
+            with torch.cuda.device(devices[d % ndev]):
+                ids = sh.insert_device(t.data_ptr(), m, src_device=devices[d % ndev],
+                                       stream=torch.cuda.current_stream().cuda_stream)
+                torch.cuda.synchronize()
+            assert ids.tolist() == list(range(lo, lo + m))
+            lo, d = lo + m, d + 1
+        assert sh.next_id() == n and sum(sh.shard_lens()) == n
+        assert np.array_equal(sh.read_rows(third - 5, 40_000), corpus[third - 5: third - 5 + 40_000])
+        dead = [7, third + 1, n - 1]
+        assert sh.delete_chunks(dead) == 3 == (single.delete_chunks(dead) if mode == modes[0] else 3)
+        sh.build_index()
+        if mode == modes[0]:
+            single.build_index()
+        torch.cuda.set_device(0)
+        stream = torch.cuda.current_stream().cuda_stream
+        for nq in (1, 9, 1000):
+            qs = np.concatenate([synth_rows(seed + nq, 0, nq - 1, dim), synth_planted(seed, 3, [n - 2], dim)]) \
+                if nq > 1 else synth_planted(seed, 3, [n - 2], dim)
+            for k in (10, 200):
+                c1, i1, n1 = single.search_raw(qs, k)
+                c8, i8, n8 = sh.search_raw(qs, k)
+                assert n8.tolist() == n1.tolist() and i8.tolist() == i1.tolist() and c8.tobytes() == c1.tobytes()
+                # the same search enqueued three times back to back on the device-pointer API (no host waits between)
+                d_q = torch.from_numpy(qs).to("cuda:0")
+                outs = [torch.zeros((nq, k), dtype=torch.int64, device="cuda:0") for _ in range(3)]
+                for o in outs:
+                    sh.search_device(d_q.data_ptr(), nq, k, d_keys=o.data_ptr(), stream=stream)
+                assert sh.search_status(stream) is False
+                for o in outs:
+                    kc, ki = key_unpack(o.cpu().numpy().view(np.uint64))
+                    live = o.cpu().numpy() != 0
+                    assert np.array_equal(ki[live], i1[live]) and np.array_equal(kc[live], c1[live])
+            assert i8[-1][0] == n - 2
+        sh.close()
+    single.close()
+
+
+def test_failed_append_leaves_the_sharded_store_consistent(VS, gpu_lib):
+    """An append is all-or-nothing across the shards: a dimension mismatch or an id-space overflow is refused before
+    any shard moved, and the stripe map (next_id, rows per shard, row contents) is what it was."""
+    from codesearch_amd import CsError
+
+    dim = 384
+    sh = VS(None, dim, devices=[0, 0, 0], rows_per_stripe=100, capacity=1000)
+    rows = synth_rows(9, 0, 450, dim)
+    sh.insert_embeddings(rows)
+    lens = sh.shard_lens()
+    with pytest.raises(CsError) as e:
+        sh.insert_embeddings(np.zeros((50, dim + 1), np.float32))
+    assert str(e.value) == f"Embedding dimension mismatch: expected {dim}, got {dim + 1}"
+    assert sh.next_id() == 450 and sh.shard_lens() == lens
+    more = synth_rows(10, 0, 333, dim)
+    assert sh.insert_embeddings(more).tolist() == list(range(450, 783))
+    assert np.array_equal(sh.read_rows(0, 783), np.concatenate([rows, more]))
+    sh.close()
+
+
+def test_release_stream_frees_device_api_scratch(VS, gpu_lib):
+    """cs_index_release_stream: the (stream, thread) scratch of a stream that is about to be destroyed is freed, and
+    the handle keeps working — on that stream value again (new scratch) and on others."""
+    import torch
+
+    from codesearch_amd import _lib
+
+    n, dim, k = 50_000, 384, 10
+    st = VS(None, dim)
+    st.insert_synthetic(n, 5, 0)
+    st.build_index()
+    qs = synth_rows(6, 0, 4, dim)
+    want = st.search_raw(qs, k)[1]
+    d_q = torch.from_numpy(qs).to("cuda:0")
+    free0 = torch.cuda.mem_get_info()[0]
+    for _ in range(3):
+        s = torch.cuda.Stream()
+        ids = torch.zeros((4, k), dtype=torch.int32, device="cuda:0")
+        s.wait_stream(torch.cuda.current_stream())
+        st.search_device(d_q.data_ptr(), 4, k, d_ids=ids.data_ptr(), stream=s.cuda_stream)
+        _lib.check(gpu_lib.cs_index_release_stream(st.handle, C.c_void_p(s.cuda_stream)))   # synchronises s
+        assert ids.cpu().numpy().astype(np.uint32).tolist() == want.tolist()
+        del s
+    assert st.debug_counters()[1] == 0
+    assert torch.cuda.mem_get_info()[0] >= free0 - (8 << 20)   # nothing of three workspaces is left behind
     st.close()
