@@ -169,6 +169,20 @@ def encoder_legs(shard, k, device, with_cpu=True):
     wall32 = (time.perf_counter() - t0) / 10
     ms32, n32 = emb.profile_read()
     ms32 /= max(n32, 1)
+    # the same call shape through the submission queue: eight slices of 32 submitted, then collected — the library
+    # packs them into one 256-row device batch (cs_embedder_submit_ids / cs_embedder_wait)
+    def queued_round():
+        ts = [emb.submit_ids(ids[lo:lo + 32], mask[lo:lo + 32]) for lo in range(0, B, 32)]
+        return [emb.wait(t) for t in ts]
+
+    queued_round()
+    emb.profile_read(reset=True)
+    t0 = time.perf_counter()
+    q_reps = 5
+    for _ in range(q_reps):
+        q_rows = queued_round()
+    wall_q = (time.perf_counter() - t0) / q_reps
+    ms_q, n_q = emb.profile_read()
     gemm_flops, attn_flops = _encoder_flops(cfg, B, L)
     split, f32n, fb = emb.debug_counters()
     emb.close()
@@ -209,6 +223,12 @@ def encoder_legs(shard, k, device, with_cpu=True):
         "reference_call_shape": {
             "workload": "32 chunks x 256 tokens per call (BatchEmbedder slices by 32, src/embed/batch.rs:70,94)",
             "device_ms_per_call": ms32, "wall_ms_per_call_incl_h2d": wall32 * 1e3, "chunks_per_s": 32 / (ms32 * 1e-3),
+            "queued": {
+                "workload": "eight such calls submitted (cs_embedder_submit_ids), then collected (cs_embedder_wait, host "
+                            "buffers): the library embeds the 256 queued rows as one device batch",
+                "wall_ms_per_8_calls": wall_q * 1e3, "chunks_per_s": B / wall_q,
+                "device_ms_per_8_calls": ms_q / max(q_reps, 1), "device_batches_per_8_calls": n_q / max(q_reps, 1),
+            },
         },
     }
     if with_cpu:

@@ -16,4 +16,4 @@ from .vector_store import (  # noqa: F401
     cos_to_score,
 )
 from .bert_params import POOL_CLS, POOL_MEAN, BertConfig  # noqa: F401
-from .embedder import FastEmbedder, ModelType  # noqa: F401
+from .embedder import EmbedderReplicas, FastEmbedder, ModelType  # noqa: F401

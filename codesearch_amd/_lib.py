@@ -130,6 +130,25 @@ SIGNATURES = {
                                               C.c_uint32, u32p]),
     "cs_embedder_embed_texts": (C.c_int32, [vp, vp, C.c_char_p, u64p, C.c_uint64, C.c_uint32, f32p, i32p]),
     "cs_embedder_embed_texts_device": (C.c_int32, [vp, vp, C.c_char_p, u64p, C.c_uint64, C.c_uint32, vp, i32p]),
+    "cs_embedder_submit_texts": (C.c_int32, [vp, vp, C.c_char_p, u64p, C.c_uint64, u64p]),
+    "cs_embedder_submit_ids": (C.c_int32, [vp, i32p, i32p, C.c_uint64, C.c_uint32, u64p]),
+    "cs_embedder_wait": (C.c_int32, [vp, C.c_uint64, f32p, i32p]),
+    "cs_embedder_wait_device": (C.c_int32, [vp, C.c_uint64, vp, i32p]),
+    "cs_embedder_discard": (C.c_int32, [vp, C.c_uint64]),
+    "cs_embedder_queued_rows": (C.c_uint64, [vp]),
+    "cs_shards_plan_append": (C.c_int32, [vp, C.c_uint64, C.c_uint32, u32p, u64p, u64p, u32p]),
+    "cs_shards_add_device_parts": (C.c_int32, [vp, C.c_uint32, C.POINTER(vp), i32p, u64p, C.c_uint32, u32p]),
+    "cs_embedders_create": (C.c_int32, [C.POINTER(BertConfig), f32p, C.c_uint64, i32p, C.c_uint32, C.POINTER(vp)]),
+    "cs_embedders_create_from_dir": (C.c_int32, [C.c_char_p, C.c_int32, i32p, C.c_uint32, C.POINTER(vp)]),
+    "cs_embedders_destroy": (None, [vp]),
+    "cs_embedders_count": (C.c_uint32, [vp]),
+    "cs_embedders_dim": (C.c_uint32, [vp]),
+    "cs_embedders_replica": (vp, [vp, C.c_uint32]),
+    "cs_embedders_device": (C.c_int32, [vp, C.c_uint32]),
+    "cs_embedders_embed_texts": (C.c_int32, [vp, vp, C.c_char_p, u64p, C.c_uint64, C.c_uint32, f32p, i32p]),
+    "cs_embedders_embed_ids": (C.c_int32, [vp, i32p, i32p, C.c_uint64, C.c_uint32, C.c_uint32, f32p, i32p]),
+    "cs_embedders_index_texts": (C.c_int32, [vp, vp, vp, C.c_char_p, u64p, C.c_uint64, C.c_uint32, u32p, i32p]),
+    "cs_embedders_index_ids": (C.c_int32, [vp, vp, i32p, i32p, C.c_uint64, C.c_uint32, C.c_uint32, u32p, i32p]),
     "cs_debug_gemm_time": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                        C.c_int32, f64p]),
     "cs_debug_gemm": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32, f32p, f32p, f32p, f32p, f32p,

@@ -109,9 +109,28 @@ class BatchEmbedder:
     prepare_text = staticmethod(prepare_text)
 
     def embed_chunks(self, chunks: Sequence[Chunk]) -> List[EmbeddedChunk]:
+        """batch.rs:84-115: the chunks go to the embedder in slices of `batch_size` (32).  On the GPU embedder every
+        slice is SUBMITTED first and collected afterwards (cs_embedder_submit_texts / cs_embedder_wait): the first
+        wait embeds all queued slices as full device batches, so the reference's call shape keeps the large-batch
+        rate.  An embedder without a queue (any object with embed_batch) is called slice by slice as the reference
+        does."""
         out: List[EmbeddedChunk] = []
-        for lo in range(0, len(chunks), self.batch_size):
-            part = chunks[lo:lo + self.batch_size]
+        slices = [chunks[lo:lo + self.batch_size] for lo in range(0, len(chunks), self.batch_size)]
+        if hasattr(self.embedder, "submit_texts") and len(slices) > 1:
+            tickets = [self.embedder.submit_texts([prepare_text(c) for c in part]) for part in slices]
+            try:
+                for part in slices:
+                    embs = self.embedder.wait(tickets[0])
+                    tickets.pop(0)
+                    out.extend(EmbeddedChunk(c, e) for c, e in zip(part, embs))
+            finally:
+                for t in tickets:  # a failed or interrupted wait: nothing of this call stays queued
+                    try:
+                        self.embedder.discard(t)
+                    except Exception:
+                        pass
+            return out
+        for part in slices:
             embs = self.embedder.embed_batch([prepare_text(c) for c in part])
             out.extend(EmbeddedChunk(c, e) for c, e in zip(part, embs))
         return out

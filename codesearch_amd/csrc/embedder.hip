@@ -6,6 +6,9 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <memory>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -15,7 +18,34 @@
 
 using namespace cs;
 
+// ---- submission queue (cs_embedder_submit_* / cs_embedder_wait*) -------------------------------------------------
+// One flush embeds everything queued; its rows stay in one device buffer until every ticket of the flush has been
+// collected.
+struct QueueFlush {
+    int device = 0;
+    float* d_rows = nullptr;
+    ~QueueFlush() {
+        if (!d_rows) return;
+        cs::DeviceGuard g(device);
+        (void)hipFree(d_rows);
+    }
+};
+struct QueueEntry {
+    uint64_t ticket = 0;
+    std::vector<std::vector<int32_t>> ids;   // per row: token ids up to its length
+    std::vector<std::vector<int32_t>> mask;  // per row, only for submit_ids rows whose mask has holes; else empty
+    enum { QUEUED, COMPUTING, DONE, FAILED } state = QUEUED;
+    std::shared_ptr<QueueFlush> flush;       // DONE: rows [first_row, first_row + ids.size()) of flush->d_rows
+    uint64_t first_row = 0;
+    int32_t error = 0;
+    std::string error_text;
+};
+
 struct cs_embedder {
+    std::mutex qmu;                 // the queue below
+    std::mutex cmu;                 // one flush at a time (and excludes nothing else: embed_* keep `&mut self` rules)
+    std::map<uint64_t, std::shared_ptr<QueueEntry>> queue;  // by ticket = submission order
+    uint64_t next_ticket = 1;
     int device = 0;
     cs_bert_config cfg{};
     cs_bert_offsets off{};
@@ -566,6 +596,93 @@ int32_t embed_ids_entry(cs_embedder* h, const int32_t* ids, const int32_t* mask,
     return embed_ids_windowed(h, ids, mask, n, seq_len, b, out, out_on_device, cancel);
 }
 
+// ---- submission queue ---------------------------------------------------------------------------------------------
+// The reference feeds its embedder 32 chunks per call, one file at a time, under a mutex
+// (/root/reference/src/embed/batch.rs:70,84-115; src/embed/mod.rs:41): at that shape a device batch is an eighth of
+// what fills the chip.  submit() only queues token rows; the first wait() that needs an unfinished ticket embeds
+// EVERYTHING queued so far as length-grouped mini-batches of the embed_batch size (256 for 384-d models), so eight
+// slices of 32 run as one 256-row forward; rows come back per ticket, in submission order.
+
+int32_t queue_push(cs_embedder* h, std::shared_ptr<QueueEntry> e, uint64_t* ticket) {
+    std::lock_guard<std::mutex> lk(h->qmu);
+    e->ticket = h->next_ticket++;
+    h->queue[e->ticket] = e;
+    *ticket = e->ticket;
+    return CS_OK;
+}
+
+// Embeds every QUEUED entry.  Caller holds h->cmu.
+int32_t flush_queue(cs_embedder* h, const volatile int32_t* cancel) {
+    std::vector<std::shared_ptr<QueueEntry>> todo;
+    {
+        std::lock_guard<std::mutex> lk(h->qmu);
+        for (auto& kv : h->queue)
+            if (kv.second->state == QueueEntry::QUEUED) { kv.second->state = QueueEntry::COMPUTING; todo.push_back(kv.second); }
+    }
+    if (todo.empty()) return CS_OK;
+    const uint32_t H = h->cfg.hidden, batch = default_batch(h);
+    std::vector<SeqView> seqs;
+    for (auto& e : todo)
+        for (size_t r = 0; r < e->ids.size(); ++r)
+            seqs.push_back(SeqView{e->ids[r].data(), e->mask.empty() || e->mask[r].empty() ? nullptr : e->mask[r].data(),
+                                   (uint32_t)e->ids[r].size()});
+    auto fl = std::make_shared<QueueFlush>();
+    fl->device = h->device;
+    const int32_t st = [&]() -> int32_t {
+        DeviceGuard g(h->device);
+        CS_HIP(hipMalloc(&fl->d_rows, seqs.size() * H * sizeof(float)));
+        const size_t window = (size_t)batch * 16;
+        std::vector<uint32_t> order;
+        std::vector<int32_t> ids, mask;
+        for (size_t lo = 0; lo < seqs.size(); lo += window) {
+            const std::vector<SeqView> win(seqs.begin() + lo, seqs.begin() + std::min(seqs.size(), lo + window));
+            CS_TRY(run_window(h, win, batch, 0, fl->d_rows + lo * H, true, cancel, order, ids, mask));
+        }
+        return CS_OK;
+    }();
+    std::lock_guard<std::mutex> lk(h->qmu);
+    uint64_t row = 0;
+    for (auto& e : todo) {
+        if (st == CS_OK) { e->state = QueueEntry::DONE; e->flush = fl; e->first_row = row; }
+        else if (st == CS_ERR_CANCELLED) e->state = QueueEntry::QUEUED;  // embedder.rs:280-282: nothing is lost, a later wait retries
+        else { e->state = QueueEntry::FAILED; e->error = st; e->error_text = last_error_ref(); }
+        row += e->ids.size();
+    }
+    return st;
+}
+
+int32_t queue_wait(cs_embedder* h, uint64_t ticket, float* out, bool out_on_device, const volatile int32_t* cancel) {
+    if (!h) return fail(CS_ERR_BAD_ARG, "null embedder handle");
+    if (!out) return fail(CS_ERR_BAD_ARG, "null buffer");
+    std::shared_ptr<QueueEntry> e;
+    {
+        std::lock_guard<std::mutex> lk(h->qmu);
+        auto it = h->queue.find(ticket);
+        if (it == h->queue.end()) return fail(CS_ERR_BAD_ARG, "unknown or already collected ticket %llu", (unsigned long long)ticket);
+        e = it->second;
+    }
+    int32_t flush_st = CS_OK;
+    {
+        std::lock_guard<std::mutex> lk(h->cmu);  // waits for a flush another caller is running (it may cover this ticket)
+        bool queued;
+        {
+            std::lock_guard<std::mutex> q(h->qmu);
+            queued = e->state == QueueEntry::QUEUED;
+        }
+        if (queued) flush_st = flush_queue(h, cancel);
+    }
+    std::lock_guard<std::mutex> lk(h->qmu);
+    if (e->state == QueueEntry::QUEUED) return flush_st != CS_OK ? flush_st : fail(CS_ERR_HIP, "ticket was not embedded");
+    h->queue.erase(ticket);
+    if (e->state == QueueEntry::FAILED) return fail(e->error, "%s", e->error_text.c_str());
+    const size_t n = e->ids.size(), H = h->cfg.hidden;
+    if (n == 0) return CS_OK;
+    DeviceGuard g(h->device);
+    CS_HIP(hipMemcpy(out, e->flush->d_rows + e->first_row * H, n * H * sizeof(float),
+                     out_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost));
+    return CS_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -744,6 +861,78 @@ int32_t cs_embedder_embed_texts_device(cs_embedder* h, const cs_tokenizer* t, co
                                        const uint64_t* offsets, uint64_t n, uint32_t batch, float* d_out,
                                        const volatile int32_t* cancel) {
     return embed_texts_impl(h, t, utf8, offsets, n, batch, d_out, true, cancel);
+}
+
+int32_t cs_embedder_submit_texts(cs_embedder* h, const cs_tokenizer* t, const char* utf8, const uint64_t* offsets,
+                                 uint64_t n, uint64_t* ticket) {
+    if (!h) return fail(CS_ERR_BAD_ARG, "null embedder handle");
+    if (!ticket) return fail(CS_ERR_BAD_ARG, "ticket is null");
+    if (!t) return fail(CS_ERR_BAD_ARG, "Failed to generate embeddings: no tokenizer attached");
+    if (n && (!utf8 || !offsets)) return fail(CS_ERR_BAD_ARG, "null buffer");
+    if (n > 0xffffffffull) return fail(CS_ERR_BAD_ARG, "too many texts in one submission");
+    for (uint64_t i = 0; i < n; ++i)
+        if (offsets[i + 1] < offsets[i]) return fail(CS_ERR_BAD_ARG, "text offsets must be non-decreasing");
+    auto e = std::make_shared<QueueEntry>();
+    if (n) cs::tokenize_texts(t, utf8, offsets, (uint32_t)n, h->cfg.max_position, e->ids);  // on the caller's thread
+    for (const auto& row : e->ids)
+        for (int32_t id : row)
+            if (id < 0 || (uint32_t)id >= h->cfg.vocab_size)
+                return fail(CS_ERR_BAD_ARG, "Failed to generate embeddings: token id %d outside vocabulary of %u", id,
+                            h->cfg.vocab_size);
+    return queue_push(h, e, ticket);
+}
+
+int32_t cs_embedder_submit_ids(cs_embedder* h, const int32_t* ids, const int32_t* mask, uint64_t n, uint32_t seq_len,
+                               uint64_t* ticket) {
+    if (!h) return fail(CS_ERR_BAD_ARG, "null embedder handle");
+    if (!ticket) return fail(CS_ERR_BAD_ARG, "ticket is null");
+    if (n && (!ids || !mask)) return fail(CS_ERR_BAD_ARG, "null buffer");
+    if (n && (seq_len == 0 || seq_len > h->cfg.max_position))
+        return fail(CS_ERR_BAD_ARG, "seq_len %u outside 1..%u (max_position_embeddings)", seq_len, h->cfg.max_position);
+    auto e = std::make_shared<QueueEntry>();
+    e->ids.resize(n);
+    e->mask.resize(n);
+    for (uint64_t r = 0; r < n; ++r) {
+        const int32_t* m = mask + r * seq_len;
+        const int32_t* v = ids + r * seq_len;
+        uint32_t len = seq_len;
+        while (len > 1 && m[len - 1] == 0) --len;  // a row's length = the position after its last mask bit
+        bool prefix = true;
+        for (uint32_t i = 0; i < len; ++i) {
+            if (v[i] < 0 || (uint32_t)v[i] >= h->cfg.vocab_size)
+                return fail(CS_ERR_BAD_ARG, "Failed to generate embeddings: token id %d outside vocabulary of %u", v[i],
+                            h->cfg.vocab_size);
+            prefix = prefix && m[i] != 0;
+        }
+        e->ids[r].assign(v, v + len);
+        if (!prefix) e->mask[r].assign(m, m + len);
+    }
+    return queue_push(h, e, ticket);
+}
+
+int32_t cs_embedder_wait(cs_embedder* h, uint64_t ticket, float* out, const volatile int32_t* cancel) {
+    return queue_wait(h, ticket, out, false, cancel);
+}
+
+int32_t cs_embedder_wait_device(cs_embedder* h, uint64_t ticket, float* d_out, const volatile int32_t* cancel) {
+    return queue_wait(h, ticket, d_out, true, cancel);
+}
+
+int32_t cs_embedder_discard(cs_embedder* h, uint64_t ticket) {
+    if (!h) return fail(CS_ERR_BAD_ARG, "null embedder handle");
+    std::lock_guard<std::mutex> c(h->cmu);  // not while a flush holds pointers into the entry
+    std::lock_guard<std::mutex> lk(h->qmu);
+    if (!h->queue.erase(ticket)) return fail(CS_ERR_BAD_ARG, "unknown or already collected ticket %llu", (unsigned long long)ticket);
+    return CS_OK;
+}
+
+uint64_t cs_embedder_queued_rows(cs_embedder* h) {
+    if (!h) return 0;
+    std::lock_guard<std::mutex> lk(h->qmu);
+    uint64_t n = 0;
+    for (auto& kv : h->queue)
+        if (kv.second->state == QueueEntry::QUEUED) n += kv.second->ids.size();
+    return n;
 }
 
 int32_t cs_embedder_last_hidden(cs_embedder* h, float* out, uint64_t n_tokens) {

@@ -492,6 +492,43 @@ int32_t cs_shards_add_device(cs_shards* h, const float* d_rows, int32_t src_devi
     return CS_OK;
 }
 
+// Where the next n rows will live: run i = rows [first[i], first[i] + count[i]) of the append, all on shard[i]; runs
+// ascend and cover [0, n).  *n_runs = the number of runs; the arrays are filled when max_runs holds them all.
+int32_t cs_shards_plan_append(const cs_shards* h, uint64_t n, uint32_t max_runs, uint32_t* shard, uint64_t* first,
+                              uint64_t* count, uint32_t* n_runs) {
+    if (!h || !n_runs) return fail(CS_ERR_BAD_ARG, "null argument");
+    const std::vector<Piece> pieces = pieces_of(h, h->next, n);
+    *n_runs = (uint32_t)pieces.size();
+    if (max_runs < pieces.size() || !shard || !first || !count) return CS_OK;
+    for (size_t i = 0; i < pieces.size(); ++i) { shard[i] = pieces[i].shard; first[i] = pieces[i].offset; count[i] = pieces[i].count; }
+    return CS_OK;
+}
+
+// cs_shards_add_device for rows that sit in several buffers: part i = the next counts[i] rows, in HBM of
+// src_devices[i] at d_rows[i] (encoder replicas on several GPUs, each holding the rows of its own shards).  The parts
+// must be the runs cs_shards_plan_append reports for their total, in that order.  Copies are asynchronous on the null
+// stream of each source device.
+int32_t cs_shards_add_device_parts(cs_shards* h, uint32_t nparts, const float* const* d_rows, const int32_t* src_devices,
+                                   const uint64_t* counts, uint32_t dim, uint32_t* out_ids) {
+    if (nparts && (!d_rows || !src_devices || !counts)) return fail(CS_ERR_BAD_ARG, "null argument");
+    uint64_t n = 0;
+    for (uint32_t i = 0; i < nparts; ++i) n += counts[i];
+    CS_TRY(check_shards_append(h, n, dim));
+    if (n == 0) return CS_OK;
+    const std::vector<Piece> pieces = pieces_of(h, h->next, n);
+    if (pieces.size() != nparts) return fail(CS_ERR_BAD_ARG, "parts do not match the append plan (%zu runs, got %u)", pieces.size(), nparts);
+    for (uint32_t i = 0; i < nparts; ++i)
+        if (pieces[i].count != counts[i] || !d_rows[i])
+            return fail(CS_ERR_BAD_ARG, "part %u does not match the append plan", i);
+    CS_TRY(reserve_pieces(h, pieces));
+    for (uint32_t i = 0; i < nparts; ++i) {
+        const int32_t st = index_append_from(h->idx[pieces[i].shard], d_rows[i], src_devices[i], counts[i], nullptr);
+        if (st != CS_OK) { h->poisoned = true; return st; }
+    }
+    finish_shards_append(h, n, out_ids);
+    return CS_OK;
+}
+
 int32_t cs_shards_add_synthetic(cs_shards* h, uint64_t n, uint64_t seed, uint64_t first_row, uint32_t* out_first_id) {
     CS_TRY(check_shards_append(h, n, h ? h->dim : 0));
     const std::vector<Piece> pieces = pieces_of(h, h->next, n);

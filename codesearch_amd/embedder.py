@@ -283,6 +283,53 @@ class FastEmbedder:
                                                             offsets.ctypes.data_as(_lib.u64p), len(texts), batch_size,
                                                             C.c_void_p(d_out_ptr), C.cast(C.byref(_SHUTDOWN), i32p)))
 
+    # ---- queueing entry points: the reference's 32-chunk call shape packed into full device batches ----
+    def submit_texts(self, texts: Sequence[str]) -> int:
+        """Queue a slice of texts (tokenised now, on this thread) -> ticket.  Nothing runs on the device until a
+        wait needs it; then everything queued is embedded as full length-grouped mini-batches."""
+        texts = list(texts)
+        tok = self._require_tokenizer()
+        blob, offsets = pack_texts(texts) if texts else (b"", np.zeros(1, np.uint64))
+        t = C.c_uint64()
+        _lib.check(self._lib.cs_embedder_submit_texts(self._h, tok.handle, blob, offsets.ctypes.data_as(_lib.u64p),
+                                                      len(texts), C.byref(t)))
+        self._ticket_rows = getattr(self, "_ticket_rows", {})
+        self._ticket_rows[int(t.value)] = len(texts)
+        return int(t.value)
+
+    def submit_ids(self, ids, mask) -> int:
+        ids = np.ascontiguousarray(ids, np.int32)
+        mask = np.ascontiguousarray(mask, np.int32)
+        if ids.ndim != 2 or ids.shape != mask.shape:
+            raise ValueError("ids and mask must both be [n, seq_len]")
+        t = C.c_uint64()
+        _lib.check(self._lib.cs_embedder_submit_ids(self._h, ids.ctypes.data_as(i32p), mask.ctypes.data_as(i32p),
+                                                    ids.shape[0], ids.shape[1], C.byref(t)))
+        self._ticket_rows = getattr(self, "_ticket_rows", {})
+        self._ticket_rows[int(t.value)] = ids.shape[0]
+        return int(t.value)
+
+    def wait(self, ticket: int) -> np.ndarray:
+        """-> the ticket's [n, dim] embeddings, rows in submission order."""
+        n = getattr(self, "_ticket_rows", {}).get(int(ticket), 0)
+        out = np.empty((n, self.dimensions()), np.float32)
+        _lib.check(self._lib.cs_embedder_wait(self._h, int(ticket), out.ctypes.data_as(f32p),
+                                              C.cast(C.byref(_SHUTDOWN), i32p)))
+        self._ticket_rows.pop(int(ticket), None)
+        return out
+
+    def wait_to_device(self, ticket: int, d_out_ptr: int) -> None:
+        _lib.check(self._lib.cs_embedder_wait_device(self._h, int(ticket), C.c_void_p(d_out_ptr),
+                                                     C.cast(C.byref(_SHUTDOWN), i32p)))
+        getattr(self, "_ticket_rows", {}).pop(int(ticket), None)
+
+    def discard(self, ticket: int) -> None:
+        _lib.check(self._lib.cs_embedder_discard(self._h, int(ticket)))
+        getattr(self, "_ticket_rows", {}).pop(int(ticket), None)
+
+    def queued_rows(self) -> int:
+        return int(self._lib.cs_embedder_queued_rows(self._h))
+
     def embed_one(self, text: str) -> np.ndarray:
         """embedder.rs:298-304."""
         r = self.embed_batch([text])
@@ -319,3 +366,100 @@ class FastEmbedder:
         _lib.check(self._lib.cs_embedder_profile_stages_read(self._h, us, C.byref(n), 1 if reset else 0))
         f = max(int(n.value), 1)
         return {name: us[i] / f for i, name in enumerate(self.STAGES)}, int(n.value)
+
+
+class EmbedderReplicas:
+    """cs_embedders_*: one encoder replica per GPU inside this process (replicas only, no
+    collective), with the reference's index loop — embed_chunks then insert_chunks_with_ids,
+    /root/reference/src/index/mod.rs:692-723 — over a row-sharded VectorStore: every replica embeds the chunks whose
+    ids fall on the shards of its own device and the rows are appended without leaving HBM."""
+
+    def __init__(self, devices: Sequence[int], model_type: ModelType = None, *, config: BertConfig = None,
+                 params: np.ndarray = None, seed: int = 0, tokenizer=None, model_dir: str = None, pooling: int = -1):
+        self._lib = _lib.load()
+        self._model_type = model_type or ModelType.default()
+        self.tokenizer = tokenizer
+        devs = (C.c_int32 * len(devices))(*[int(d) for d in devices])
+        h = C.c_void_p()
+        if model_dir is not None:
+            _lib.check(self._lib.cs_embedders_create_from_dir(str(model_dir).encode(), pooling, devs, len(devices),
+                                                              C.byref(h)))
+            self.config = None
+        else:
+            self.config = config or self._model_type.bert_config()
+            ccfg = self.config.to_c()
+            pptr = None
+            if params is not None:
+                params = np.ascontiguousarray(params, np.float32)
+                pptr = params.ctypes.data_as(f32p)
+            _lib.check(self._lib.cs_embedders_create(C.byref(ccfg), pptr, seed, devs, len(devices), C.byref(h)))
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.cs_embedders_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __len__(self) -> int:
+        return int(self._lib.cs_embedders_count(self._h))
+
+    def dimensions(self) -> int:
+        return int(self._lib.cs_embedders_dim(self._h))
+
+    def replica_counters(self):
+        """-> [(split_forwards, f32_forwards, range_fallbacks)] per replica."""
+        out = []
+        for i in range(len(self)):
+            a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
+            r = C.c_void_p(self._lib.cs_embedders_replica(self._h, i))
+            _lib.check(self._lib.cs_embedder_debug_counters(r, C.byref(a), C.byref(b), C.byref(c)))
+            out.append((int(a.value), int(b.value), int(c.value)))
+        return out
+
+    def embed_ids(self, ids, mask, batch_size: int = 0) -> np.ndarray:
+        ids = np.ascontiguousarray(ids, np.int32)
+        mask = np.ascontiguousarray(mask, np.int32)
+        n, L = ids.shape
+        out = np.empty((n, self.dimensions()), np.float32)
+        _lib.check(self._lib.cs_embedders_embed_ids(self._h, ids.ctypes.data_as(i32p), mask.ctypes.data_as(i32p), n, L,
+                                                    batch_size, out.ctypes.data_as(f32p), C.cast(C.byref(_SHUTDOWN), i32p)))
+        return out
+
+    def embed_batch(self, texts: Sequence[str], batch_size: int = 0) -> List[np.ndarray]:
+        texts = list(texts)
+        if not texts:
+            return []
+        blob, offsets = pack_texts(texts)
+        emb = np.empty((len(texts), self.dimensions()), np.float32)
+        _lib.check(self._lib.cs_embedders_embed_texts(self._h, self.tokenizer.handle, blob,
+                                                      offsets.ctypes.data_as(_lib.u64p), len(texts), batch_size,
+                                                      emb.ctypes.data_as(f32p), C.cast(C.byref(_SHUTDOWN), i32p)))
+        return [emb[i] for i in range(emb.shape[0])]
+
+    def index_ids(self, store, ids, mask, batch_size: int = 0) -> np.ndarray:
+        """Embed [n, L] token chunks and append them to the sharded `store` -> the assigned ids."""
+        ids = np.ascontiguousarray(ids, np.int32)
+        mask = np.ascontiguousarray(mask, np.int32)
+        n, L = ids.shape
+        out = np.zeros(n, np.uint32)
+        _lib.check(self._lib.cs_embedders_index_ids(self._h, store.handle, ids.ctypes.data_as(i32p),
+                                                    mask.ctypes.data_as(i32p), n, L, batch_size,
+                                                    out.ctypes.data_as(_lib.u32p), C.cast(C.byref(_SHUTDOWN), i32p)))
+        return out
+
+    def index_texts(self, store, texts: Sequence[str], batch_size: int = 0) -> np.ndarray:
+        texts = list(texts)
+        out = np.zeros(len(texts), np.uint32)
+        if not texts:
+            return out
+        blob, offsets = pack_texts(texts)
+        _lib.check(self._lib.cs_embedders_index_texts(self._h, self.tokenizer.handle, store.handle, blob,
+                                                      offsets.ctypes.data_as(_lib.u64p), len(texts), batch_size,
+                                                      out.ctypes.data_as(_lib.u32p), C.cast(C.byref(_SHUTDOWN), i32p)))
+        return out

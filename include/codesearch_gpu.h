@@ -201,6 +201,16 @@ int32_t cs_shards_add(cs_shards* h, const float* rows, uint64_t n, uint32_t dim,
  * all-or-nothing: capacity is reserved on every touched shard before any row moves. */
 int32_t cs_shards_add_device(cs_shards* h, const float* d_rows, int32_t src_device, uint64_t n, uint32_t dim,
                              uint32_t* out_ids, void* stream);
+/* Where the next n appended rows will live (ids are contiguous from next_id, so this is known before the rows exist):
+ * run i = rows [first[i], first[i] + count[i]) of the append, all on shard[i]; runs ascend and cover [0, n).
+ * *n_runs = the number of runs; the arrays are filled only when max_runs >= *n_runs (call with 0 to size them). */
+int32_t cs_shards_plan_append(const cs_shards* h, uint64_t n, uint32_t max_runs, uint32_t* shard, uint64_t* first,
+                              uint64_t* count, uint32_t* n_runs);
+/* cs_shards_add_device with the rows in several buffers: part i = the next counts[i] rows, at d_rows[i] in HBM of
+ * src_devices[i]; the parts must be the runs of cs_shards_plan_append for their total, in order.  One asynchronous
+ * copy per part on the null stream of its source device. */
+int32_t cs_shards_add_device_parts(cs_shards* h, uint32_t nparts, const float* const* d_rows,
+                                   const int32_t* src_devices, const uint64_t* counts, uint32_t dim, uint32_t* out_ids);
 int32_t cs_shards_add_synthetic(cs_shards* h, uint64_t n, uint64_t seed, uint64_t first_row,
                                 uint32_t* out_first_id);
 int32_t cs_shards_remove(cs_shards* h, const uint32_t* ids, uint64_t n, uint64_t* removed);
@@ -426,6 +436,63 @@ int32_t cs_embedder_embed_texts(cs_embedder* h, const cs_tokenizer* t, const cha
 int32_t cs_embedder_embed_texts_device(cs_embedder* h, const cs_tokenizer* t, const char* utf8,
                                        const uint64_t* offsets, uint64_t n, uint32_t batch,
                                        float* d_out, const volatile int32_t* cancel);
+
+/* Queueing entry points for callers that keep the reference's call shape.  BatchEmbedder::embed_chunks hands the
+ * embedder slices of 32 chunks, one file at a time, under a mutex (src/embed/batch.rs:70,84-115; src/embed/mod.rs:41;
+ * src/index/mod.rs:692): a 32-row device batch leaves seven eighths of the chip idle.  submit_* copies the rows into the
+ * library (texts are tokenised on the calling thread; inputs are borrowed for the call only) and returns a ticket;
+ * wait* returns that ticket's [n, dim] embeddings.  The first wait that needs an unfinished ticket embeds EVERYTHING
+ * queued so far, packed into length-grouped mini-batches of the embed_batch size (256/128/64, embedder.rs:251-261), so
+ * eight queued slices of 32 run as one 256-row forward; every ticket gets its own rows back in its own order, and a
+ * row's value does not depend on what it was batched with beyond f32 rounding (as cs_embedder_embed_texts).
+ * submit / wait / discard are safe from several threads on one handle (the reference's callers are rayon workers
+ * behind an Arc<Mutex<..>>); they must not overlap the handle's other entry points.  A wait interrupted through
+ * `cancel` returns CS_ERR_CANCELLED and leaves the queue intact; a ticket is consumed by the wait that returns its
+ * rows (or its error) and by discard. */
+int32_t cs_embedder_submit_texts(cs_embedder* h, const cs_tokenizer* t, const char* utf8, const uint64_t* offsets,
+                                 uint64_t n, uint64_t* ticket);
+int32_t cs_embedder_submit_ids(cs_embedder* h, const int32_t* ids, const int32_t* mask, uint64_t n, uint32_t seq_len,
+                               uint64_t* ticket);
+int32_t cs_embedder_wait(cs_embedder* h, uint64_t ticket, float* out, const volatile int32_t* cancel);
+int32_t cs_embedder_wait_device(cs_embedder* h, uint64_t ticket, float* d_out, const volatile int32_t* cancel);
+int32_t cs_embedder_discard(cs_embedder* h, uint64_t ticket);
+uint64_t cs_embedder_queued_rows(cs_embedder* h);   /* rows submitted and not yet embedded */
+
+/* ------------------------------------------------------------------------------------
+ * Encoder replicas: one cs_embedder per GPU inside ONE process, and the reference's index loop
+ * (src/index/mod.rs:626-762: embed_chunks :692 -> insert_chunks_with_ids :723) over a row-sharded store.
+ * replicas only — weights replicated, every GPU embeds the chunks destined for its own shard and
+ * the rows are written in place; no collective.  codesearch_amd/csrc/embedders.hip.
+ * One caller at a time per handle (`&mut self`), as cs_embedder_*.
+ * ---------------------------------------------------------------------------------- */
+typedef struct cs_embedders cs_embedders;
+/* One replica per entry of `devices` (a device may appear twice: two replicas share it). */
+int32_t cs_embedders_create(const cs_bert_config* cfg, const float* params, uint64_t seed, const int32_t* devices,
+                            uint32_t n, cs_embedders** out);
+int32_t cs_embedders_create_from_dir(const char* model_dir, int32_t pooling, const int32_t* devices, uint32_t n,
+                                     cs_embedders** out);
+void cs_embedders_destroy(cs_embedders* e);
+uint32_t cs_embedders_count(const cs_embedders* e);
+uint32_t cs_embedders_dim(const cs_embedders* e);
+cs_embedder* cs_embedders_replica(cs_embedders* e, uint32_t i);   /* borrowed: never destroy it */
+int32_t cs_embedders_device(const cs_embedders* e, uint32_t i);
+/* embed_batch over all replicas: the inputs are cut into one contiguous range of whole mini-batches per replica, each
+ * embedded on its own device by its own host thread; row i of `out` (host memory) is input i. */
+int32_t cs_embedders_embed_texts(cs_embedders* e, const cs_tokenizer* t, const char* utf8, const uint64_t* offsets,
+                                 uint64_t n, uint32_t batch, float* out, const volatile int32_t* cancel);
+int32_t cs_embedders_embed_ids(cs_embedders* e, const int32_t* ids, const int32_t* mask, uint64_t n, uint32_t seq_len,
+                               uint32_t batch, float* out, const volatile int32_t* cancel);
+/* Embed and append in one call: every replica embeds the inputs whose ids fall on the shards it serves (the shards on
+ * its own device; a shard whose device has no replica is served by replica shard %% count, its rows crossing xGMI
+ * once), leaving them in its own HBM; when all replicas are done the runs are appended in id order
+ * (cs_shards_add_device_parts).  out_ids (optional): the n assigned ids, contiguous from next_id (store.rs:659-685).
+ * An error or a shutdown request leaves the store as it was.  Use a stripe of one mini-batch (256 rows) or a few
+ * for an even spread of one call's inputs over the GPUs. */
+int32_t cs_embedders_index_texts(cs_embedders* e, const cs_tokenizer* t, cs_shards* store, const char* utf8,
+                                 const uint64_t* offsets, uint64_t n, uint32_t batch, uint32_t* out_ids,
+                                 const volatile int32_t* cancel);
+int32_t cs_embedders_index_ids(cs_embedders* e, cs_shards* store, const int32_t* ids, const int32_t* mask, uint64_t n,
+                               uint32_t seq_len, uint32_t batch, uint32_t* out_ids, const volatile int32_t* cancel);
 
 /* Arithmetic of the dense layers.  CS_GEMM_SPLIT_F16 (default): every f32 operand as two f16
  * values on the f16 MFMA, three MFMAs per product block, f32 accumulation — error per product

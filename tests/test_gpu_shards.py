@@ -315,3 +315,41 @@ def test_release_stream_frees_device_api_scratch(VS, gpu_lib):
     assert st.debug_counters()[1] == 0
     assert torch.cuda.mem_get_info()[0] >= free0 - (8 << 20)   # nothing of three workspaces is left behind
     st.close()
+
+
+def test_rank_backend_repairs_an_overflowed_batch_before_the_exchange(VS, oracle):
+    """codesearch_amd/sharded.py (one process per GPU, BASELINE configs[4]): HipShardBackend.search_local asks
+    cs_index_search_status after a > 16-query search and reruns an overflowed one in 16-query slices BEFORE its keys
+    enter the all-gather.  Adversarial row order (cosine rising with the row number) with 24 queries; a benign corpus
+    must not trigger a rerun."""
+    import torch
+
+    from codesearch_amd.sharded import ShardedVectorStore, key_unpack
+
+    n, dim, k, nq = 300_000, 384, 10, 24
+    q = synth_rows(5, 0, nq, dim)
+    u = synth_rows(6, 0, 1, dim)[0]
+    u = u - (u @ q[0]) / (q[0] @ q[0]) * q[0]
+    w = np.linspace(3.0, 0.5, n, dtype=np.float32)[:, None]
+    corpus = (q[0][None, :] + w * u[None, :]).astype(np.float32)
+    sh = ShardedVectorStore(dim, n, rank=0, world=1, device=0)
+    sh.store.insert_embeddings(corpus)
+    sh.store.build_index()
+    out = sh.search_device(torch.from_numpy(q).to("cuda:0"), nq, k)
+    torch.cuda.synchronize()
+    assert sh.backend.overflow_reruns == 1
+    ids = out["ids"].cpu().numpy().astype(np.uint32).reshape(nq, k)
+    cos = out["cos"].cpu().numpy().reshape(nq, k)
+    kc, ki = key_unpack(out["keys"].cpu().numpy().view(np.uint64).reshape(nq, k))
+    assert np.array_equal(ki, ids) and kc.tobytes() == cos.tobytes()
+    for i in (0, 1, 15, 16, 23):
+        ecos, eids = oracle.scan_topk(corpus, q[i], k, mode="omp")
+        assert_topk_equal(cos[i], ids[i], ecos, eids, corpus, q[i], oracle)
+    assert ids[0].min() >= n - 12
+    sh.store.close()
+    sh2 = ShardedVectorStore(dim, 100_000, rank=0, world=1, device=0)
+    sh2.fill_synthetic(77)
+    sh2.search_device(torch.from_numpy(q).to("cuda:0"), nq, k)
+    torch.cuda.synchronize()
+    assert getattr(sh2.backend, "overflow_reruns", 0) == 0
+    sh2.store.close()
