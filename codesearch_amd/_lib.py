@@ -149,6 +149,9 @@ SIGNATURES = {
     "cs_embedders_embed_ids": (C.c_int32, [vp, i32p, i32p, C.c_uint64, C.c_uint32, C.c_uint32, f32p, i32p]),
     "cs_embedders_index_texts": (C.c_int32, [vp, vp, vp, C.c_char_p, u64p, C.c_uint64, C.c_uint32, u32p, i32p]),
     "cs_embedders_index_ids": (C.c_int32, [vp, vp, i32p, i32p, C.c_uint64, C.c_uint32, C.c_uint32, u32p, i32p]),
+    "cs_debug_ffn": (C.c_int32, [C.c_int32, C.c_int32, f32p, f32p, f32p, f32p, f32p, f32p, f32p, C.c_float, f32p,
+                                 C.c_uint32, C.c_uint32, u32p]),
+    "cs_debug_ffn_time": (C.c_int32, [C.c_int32, C.c_int32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int32, f64p]),
     "cs_debug_gemm_time": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                        C.c_int32, f64p]),
     "cs_debug_gemm": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32, f32p, f32p, f32p, f32p, f32p,

@@ -71,6 +71,13 @@ int32_t launch_gemm_wide(int epi, const _Float16* A, const _Float16* W, const fl
 int32_t launch_gemm_wide_ln(const _Float16* A, const _Float16* W, const float* bias, const float* resid, const float* gamma,
                             const float* beta, float eps, float* X, _Float16* Xs, uint32_t M, uint32_t K, uint32_t* d_flag,
                             hipStream_t s, const _Float16* resid_split = nullptr);
+// ffn_fused.hip: X_out = LayerNorm(GELU(A W1^T + b1) W2^T + b2 + A) * gamma + beta in ONE persistent kernel per 128 rows
+// (hidden 384, intermediate % 128 == 0); A / Xs split form (Xs may be A), X optional f32 copy of the output.
+bool ffn_fused_supported(uint32_t hidden, uint32_t intermediate);
+int32_t launch_ffn_fused(const _Float16* A, const _Float16* W1, const float* b1, const _Float16* W2, const float* b2,
+                         const float* gamma, const float* beta, float eps, float* X, _Float16* Xs, uint32_t M,
+                         uint32_t intermediate, uint32_t* d_flag, hipStream_t s);
+extern int g_ffn_fused_ablation;  // diagnostics (cs_debug_ffn_time)
 extern int g_gemm_wide_ablation;  // diagnostics (cs_debug_gemm_time)
 double gemm_wide_read_clock_ghz(double* main_cycles, double* epi_cycles);  // after an ablation-7 launch: median in-kernel clock
 int32_t sh_weights_fit_wide(const _Float16* d_wsplit, uint64_t n_f16, uint32_t* d_scratch_flag, bool* ok, hipStream_t s);

@@ -523,6 +523,18 @@ int32_t cs_debug_gemm(int32_t device, int32_t mode, int32_t epilogue, const floa
 int32_t cs_debug_gemm_time(int32_t device, int32_t mode, int32_t epilogue, uint32_t M, uint32_t N, uint32_t K,
                            uint32_t iters, int32_t ablation, double* ms_per_launch);
 
+/* Diagnostics: the encoder's feed-forward block (E5 + E6) of a 384-d model on host buffers,
+ * out[M, 384] = LayerNorm(GELU(A W1^T + b1) W2^T + b2 + A) * gamma + beta with A [M, 384], W1 [I, 384], W2 [384, I].
+ * fused = 1: ONE persistent kernel per 128 rows whose [M, I] intermediate never leaves the CU (ffn_fused.hip);
+ * fused = 0: the two kernels it replaces.  For unit parity tests against float64. */
+int32_t cs_debug_ffn(int32_t device, int32_t fused, const float* A, const float* W1, const float* b1, const float* W2,
+                     const float* b2, const float* gamma, const float* beta, float eps, float* out, uint32_t M,
+                     uint32_t intermediate, uint32_t* range_flag);
+/* ... and its device milliseconds per launch on synthetic operands (ablation, fused only: 0 none, 1 no GELU
+ * arithmetic, 2 no LDS-DMA after a tile's first stage). */
+int32_t cs_debug_ffn_time(int32_t device, int32_t fused, uint32_t M, uint32_t intermediate, uint32_t iters,
+                          int32_t ablation, double* ms_per_launch);
+
 #ifdef __cplusplus
 }
 #endif
