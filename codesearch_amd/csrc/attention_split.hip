@@ -577,8 +577,15 @@ attention_shx_kernel(const _Float16* __restrict__ qkvs, const int32_t* __restric
 #pragma unroll
             for (int s = 0; s < 2; ++s)
 #pragma unroll
-                for (int w2 = 0; w2 < 4; ++w2)
+                for (int w2 = 0; w2 < 4; ++w2) {
+#ifdef CS_ATTN_P_HI_ONLY  // experiment (VERDICT r2 #4 ii): P as ONE f16, round to nearest; no p_lo * v_hi product
+                    const f16x2 pr = __builtin_convertvector(sh_f32x2{hh[8 * s + 2 * w2], hh[8 * s + 2 * w2 + 1]}, f16x2);
+                    ph[s].u[w2] = __builtin_bit_cast(uint32_t, pr);
+                    pl[s].u[w2] = 0u;
+#else
                     split_pair_rtz_ng(hh[8 * s + 2 * w2], hh[8 * s + 2 * w2 + 1], ph[s].u[w2], pl[s].u[w2]);
+#endif
+                }
             typedef __attribute__((address_space(3))) s16x4* lds_s16x4_p;
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
@@ -591,7 +598,9 @@ attention_shx_kernel(const _Float16* __restrict__ qkvs, const int32_t* __restric
                     vl.q[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(vr + s * 16 * 128 + v_lo));
                     vl.q[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(vr + s * 16 * 128 + 8 * 128 + v_lo));
                     ohh[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh.v, ph[s].v, ohh[c], 0, 0, 0);
+#ifndef CS_ATTN_P_HI_ONLY
                     oxx[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh.v, pl[s].v, oxx[c], 0, 0, 0);
+#endif
                     oxx[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl.v, ph[s].v, oxx[c], 0, 0, 0);
                 }
             }

@@ -224,7 +224,7 @@ std::vector<Want> layout_table(const cs_bert_config& c) {
 
 bool json_u32(const Json& root, const char* key, uint32_t& out) {
     const Json* j = root.get(key);
-    if (!j || j->kind != Json::Num || j->num < 0 || j->num > 4294967295.0) return false;
+    if (!j || j->kind != Json::Num || !(j->num >= 0 && j->num <= 4294967295.0)) return false;
     out = (uint32_t)j->num;
     return true;
 }
@@ -318,9 +318,17 @@ int32_t cs_bert_params_from_safetensors(const char* path, const cs_bert_config* 
             continue;
         TensorRef t;
         t.dtype = dt->str;
-        for (const Json& d : sh->arr) t.shape.push_back((uint64_t)d.num);
-        t.begin = (uint64_t)off->arr[0].num;
-        t.end = (uint64_t)off->arr[1].num;
+        // numbers of the header become integers only inside [0, 2^53]: a negative, huge or non-numeric entry makes the
+        // tensor unusable (it then counts as missing) instead of an undefined double -> integer conversion
+        bool sane = off->arr[0].kind == Json::Num && off->arr[1].kind == Json::Num;
+        auto as_u64 = [&](const Json& j) -> uint64_t {
+            if (j.kind != Json::Num || !(j.num >= 0.0 && j.num <= 9007199254740992.0)) { sane = false; return 0; }
+            return (uint64_t)j.num;
+        };
+        for (const Json& d : sh->arr) t.shape.push_back(as_u64(d));
+        t.begin = as_u64(off->arr[0]);
+        t.end = as_u64(off->arr[1]);
+        if (!sane) continue;
         have[kv.first] = std::move(t);
     }
     const uint64_t data0 = 8 + hlen;
@@ -466,7 +474,7 @@ int32_t cs_tokenizer_create_from_json(const char* json_path, uint32_t max_length
     }
     uint64_t max_id = 0;
     for (const auto& kv : vocab->obj) {
-        if (kv.second.kind != Json::Num || kv.second.num < 0 || kv.second.num > 16777216.0)
+        if (kv.second.kind != Json::Num || !(kv.second.num >= 0 && kv.second.num <= 16777216.0))
             return fail(CS_ERR_BAD_ARG, "Failed to initialize embedding model: vocabulary id of \"%s\" is not a small integer",
                         kv.first.c_str());
         max_id = std::max<uint64_t>(max_id, (uint64_t)kv.second.num);

@@ -25,6 +25,7 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <cstdint>
 #include <cstring>
 #include <map>
 #include <string>
@@ -81,7 +82,15 @@ struct Tensor {
     Span raw;          // raw_data
     Span float_data;   // packed float_data (dtype 1 only)
     bool external = false;
-    uint64_t count() const { uint64_t c = 1; for (uint64_t d : dims) c *= d; return c; }
+    // product of the dims, saturating: dims come from the file (a 2^40 x 2^40 "tensor" must not wrap to a small count)
+    uint64_t count() const {
+        uint64_t c = 1;
+        for (uint64_t d : dims) {
+            if (d != 0 && c > UINT64_MAX / d) return UINT64_MAX;
+            c *= d;
+        }
+        return c;
+    }
 };
 
 struct Node {
@@ -158,13 +167,18 @@ struct Reader {
     bool ok;
     explicit Reader(const Tensor& tt) : t(&tt), base(nullptr), esz(0), ok(false) {
         const uint64_t n = tt.count();
+        // byte lengths are compared by division: n * esz could wrap for a count taken from the file
+        auto holds = [&](const Span& sp, uint64_t e) {
+            const uint64_t bytes = (uint64_t)(sp.end - sp.p);
+            return bytes % e == 0 && bytes / e == n;
+        };
         if (tt.dtype == 1) {
             esz = 4;
-            if ((uint64_t)(tt.raw.end - tt.raw.p) == n * 4) base = tt.raw.p;
-            else if ((uint64_t)(tt.float_data.end - tt.float_data.p) == n * 4) base = tt.float_data.p;
+            if (holds(tt.raw, 4)) base = tt.raw.p;
+            else if (holds(tt.float_data, 4)) base = tt.float_data.p;
         } else if (tt.dtype == 10 || tt.dtype == 16) {
             esz = 2;
-            if ((uint64_t)(tt.raw.end - tt.raw.p) == n * 2) base = tt.raw.p;
+            if (holds(tt.raw, 2)) base = tt.raw.p;
         }
         ok = base != nullptr;
     }

@@ -139,8 +139,9 @@ struct cs_tokenizer {
         for (uint32_t i = (uint32_t)h & slot_mask;; i = (i + 1) & slot_mask) {
             const Slot& s = slots[i];
             if (s.id < 0) return -1;
-            if (s.hash == h && s.len == alen + blen && std::memcmp(pool.data() + s.off, a, alen) == 0 &&
-                std::memcmp(pool.data() + s.off + alen, b, blen) == 0)
+            // (a / b may be null with a zero length: memcmp's arguments must not be, whatever the length)
+            if (s.hash == h && s.len == alen + blen && (alen == 0 || std::memcmp(pool.data() + s.off, a, alen) == 0) &&
+                (blen == 0 || std::memcmp(pool.data() + s.off + alen, b, blen) == 0))
                 return s.id;
         }
     }

@@ -1,0 +1,83 @@
+"""The hand-written readers of untrusted model files — codesearch_amd/csrc/onnx_reader.cpp (protobuf wire format),
+checkpoint.cpp (config.json, safetensors header + payload, tokenizer.json) and tokenizer.cpp (vocab.txt) — under
+AddressSanitizer + UBSan on the CPU build (tests/cpp/parser_fuzz.cpp, `make -C tests/cpp asan`): every prefix
+truncation and 1,000 seeded mutations of each kind of file must come back as CS_OK or as a CS_ERR_* with a message,
+never as a crash, a sanitizer report or an unbounded allocation.  These are what FastEmbedder::with_cache_dir
+(/root/reference/src/embed/embedder.rs:218-245) points the library at: files downloaded from a model hub."""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CPP = os.path.join(ROOT, "tests", "cpp")
+GOLD = os.path.join(ROOT, "tests", "golden")
+TINY = "48 64 2 2 128 16"  # vocab hidden layers heads intermediate max_position of tests/golden/bert_tiny_export.onnx
+
+
+@pytest.fixture(scope="module")
+def fuzz():
+    subprocess.run(["make", "-s", "-C", CPP, "asan"], check=True)
+    exe = os.path.join(CPP, "parser_fuzz_asan")
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=1:allocator_may_return_null=1:max_allocation_size_mb=4096",
+               UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1")
+
+    def run(kind, path, seed=1, flips=1000, aux=TINY):
+        r = subprocess.run([exe, kind, str(path), str(seed), str(flips), aux], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, (r.returncode, r.stdout[-2000:], r.stderr[-4000:])
+        assert "intact file: accepted" in r.stdout, r.stdout
+        return r.stdout
+
+    return run
+
+
+def test_onnx_reader_survives_truncations_and_mutations(fuzz):
+    out = fuzz("onnx", os.path.join(GOLD, "bert_tiny_export.onnx"), seed=11)
+    assert "0 crashes" in out
+
+
+def test_safetensors_reader_survives_truncations_and_mutations(fuzz, tmp_path):
+    from safetensors.numpy import save_file
+
+    st = np.load(os.path.join(GOLD, "bert_tiny_export_state.npz"))
+    tensors = {k: np.ascontiguousarray(st[k]) for k in st.files if st[k].dtype == np.float32}
+    p = tmp_path / "model.safetensors"
+    save_file(tensors, str(p))
+    fuzz("safetensors", p, seed=12)
+    # the same payload as F16 and with a "bert." prefix: the other branches of the reader
+    save_file({"bert." + k: v.astype(np.float16) for k, v in tensors.items()}, str(p))
+    fuzz("safetensors", p, seed=13, flips=300)
+
+
+def test_tokenizer_json_and_vocab_readers_survive(fuzz, tmp_path):
+    from tokenizers import Tokenizer, models, normalizers, pre_tokenizers, processors
+
+    from codesearch_amd.pipeline import synth_vocab
+
+    vocab = synth_vocab(600)
+    tk = Tokenizer(models.WordPiece(vocab, unk_token="[UNK]", max_input_chars_per_word=100))
+    tk.normalizer = normalizers.BertNormalizer(lowercase=True)
+    tk.pre_tokenizer = pre_tokenizers.BertPreTokenizer()
+    tk.post_processor = processors.TemplateProcessing(single="[CLS] $A [SEP]", special_tokens=[("[CLS]", vocab["[CLS]"]), ("[SEP]", vocab["[SEP]"])])
+    tk.enable_truncation(max_length=64)
+    p = tmp_path / "tokenizer.json"
+    tk.save(str(p))
+    fuzz("tokenizer_json", p, seed=14)
+    # the \\u-escaped form of the same document (surrogate pairs, escapes inside keys)
+    esc = tmp_path / "escaped.json"
+    esc.write_text(json.dumps(json.load(open(p, encoding="utf-8")), ensure_ascii=True))
+    fuzz("tokenizer_json", esc, seed=15, flips=300)
+    v = tmp_path / "vocab.txt"
+    v.write_text("\n".join(t for t, _ in sorted(vocab.items(), key=lambda kv: kv[1])) + "\n", encoding="utf-8")
+    fuzz("vocab", v, seed=16)
+
+
+def test_config_json_reader_survives(fuzz, tmp_path):
+    cfg = {"model_type": "bert", "hidden_act": "gelu", "vocab_size": 48, "hidden_size": 384, "num_hidden_layers": 2,
+           "num_attention_heads": 12, "intermediate_size": 1536, "max_position_embeddings": 16, "type_vocab_size": 2,
+           "layer_norm_eps": 1e-12, "position_embedding_type": "absolute", "architectures": ["BertModel"]}
+    p = tmp_path / "config.json"
+    p.write_text(json.dumps(cfg, indent=1))
+    fuzz("config_dir", p, seed=17)
