@@ -10,8 +10,8 @@
 //   GraphProto   { node = 1 (repeated NodeProto), initializer = 5 (repeated TensorProto) }
 //   NodeProto    { input = 1, output = 2, name = 3, op_type = 4, attribute = 5 }
 //   AttributeProto { name = 1, i = 3 }
-//   TensorProto  { dims = 1, data_type = 2 (1 FLOAT, 10 FLOAT16, 16 BFLOAT16), float_data = 4, name = 8,
-//                  raw_data = 9, external_data = 13, data_location = 14 }
+//   TensorProto  { dims = 1, data_type = 2 (1 FLOAT, 10 FLOAT16, 16 BFLOAT16; 2 UINT8 / 3 INT8 with a scale), float_data = 4,
+//                  name = 8, raw_data = 9, external_data = 13, data_location = 14 }
 //
 // Where the tensors are.  An exporter (torch.onnx / optimum) keeps the state-dict name of every parameter an
 // op consumes as it is — embeddings, LayerNorm weights, all biases — but folds the transpose of a Linear
@@ -20,6 +20,15 @@
 // consumes the layer's bias, the MatMul feeding that Add, the MatMul's second input.  Gemm nodes (weight as
 // input 1, transB) and the fused com.microsoft Attention node of ORT-optimised files (packed [H, 3H] QKV
 // weight as input 1, packed [3H] bias as input 2) are understood as well.
+//
+// Quantised exports (the reference's DEFAULT model is one: ModelType::AllMiniLML6V2Q, embedder.rs:12-13,367-372 — fastembed
+// downloads its model_quantized.onnx, written by onnxruntime's dynamic quantiser): every Linear weight W is stored as
+// W_quantized (INT8 / UINT8, [in, out]) + W_scale + W_zero_point — per tensor or per channel — and consumed by
+// DynamicQuantizeLinear -> MatMulInteger -> Cast -> Mul(scales) -> Add(bias); Gather tables may be quantised in place the
+// same way.  They are read as w = (q - zero_point) * scale into the f32 block: the encoder then runs the f32 GRAPH OF THE
+// QUANTISED WEIGHTS.  It does not re-quantise activations to 8 bits per call as ORT's MatMulInteger path does, so its
+// embeddings differ from the reference's by that activation-rounding noise (the weights, the dominant quantisation
+// error, are bit-for-bit the file's).
 #include <fcntl.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
@@ -159,12 +168,48 @@ float half_to_float(uint16_t h) {
     return f;
 }
 
-// element i of a tensor as f32 (FLOAT, FLOAT16, BFLOAT16)
+// How an INT8 / UINT8 initialiser turns back into numbers: w = (q - zero_point) * scale, one pair for the whole tensor
+// or one per slice along `axis` (onnxruntime's quantize_dynamic / optimum's ORTQuantizer write both forms).
+struct Quant {
+    const Tensor* scale = nullptr;
+    const Tensor* zp = nullptr;   // may be null: zero point 0
+};
+
+// element i of a tensor as f32 (FLOAT, FLOAT16, BFLOAT16; INT8 / UINT8 through a Quant)
 struct Reader {
     const Tensor* t;
     const uint8_t* base;
     int esz;
     bool ok;
+    // quantised payloads: per-element scale index = (i / q_inner) % q_n  (q_n == 1: per tensor)
+    std::vector<float> q_scale;
+    std::vector<int32_t> q_zp;
+    uint64_t q_inner = 1, q_n = 1;
+    // rows x cols matrix quantised per tensor, per column (scale count == cols) or per row (== rows)
+    Reader(const Tensor& tt, const Quant& q, uint64_t rows, uint64_t cols) : t(&tt), base(nullptr), esz(0), ok(false) {
+        if ((tt.dtype != 2 && tt.dtype != 3) || !q.scale || tt.count() != (uint64_t)(tt.raw.end - tt.raw.p)) return;
+        Reader rs(*q.scale);
+        if (!rs.ok) return;
+        const uint64_t ns = q.scale->count();
+        if (ns == 1) { q_n = 1; q_inner = 1; }
+        else if (ns == cols) { q_n = cols; q_inner = 1; }
+        else if (ns == rows) { q_n = rows; q_inner = cols; }
+        else return;
+        q_scale.resize(ns);
+        for (uint64_t i = 0; i < ns; ++i) q_scale[i] = rs.at(i);
+        q_zp.assign(ns, 0);
+        if (q.zp) {
+            const uint64_t nz = q.zp->count();
+            if ((q.zp->dtype != 2 && q.zp->dtype != 3) || (nz != 1 && nz != ns) || nz != (uint64_t)(q.zp->raw.end - q.zp->raw.p)) return;
+            for (uint64_t i = 0; i < ns; ++i) {
+                const uint8_t b = q.zp->raw.p[nz == 1 ? 0 : i];
+                q_zp[i] = q.zp->dtype == 3 ? (int32_t)(int8_t)b : (int32_t)b;
+            }
+        }
+        base = tt.raw.p;
+        esz = 1;
+        ok = true;
+    }
     explicit Reader(const Tensor& tt) : t(&tt), base(nullptr), esz(0), ok(false) {
         const uint64_t n = tt.count();
         // byte lengths are compared by division: n * esz could wrap for a count taken from the file
@@ -183,6 +228,11 @@ struct Reader {
         ok = base != nullptr;
     }
     float at(uint64_t i) const {
+        if (esz == 1) {
+            const uint64_t c = q_n == 1 ? 0 : (i / q_inner) % q_n;
+            const int32_t v = t->dtype == 3 ? (int32_t)(int8_t)base[i] : (int32_t)base[i];
+            return (float)(v - q_zp[c]) * q_scale[c];
+        }
         if (esz == 4) { float f; std::memcpy(&f, base + i * 4, 4); return f; }
         uint16_t v;
         std::memcpy(&v, base + i * 2, 2);
@@ -242,13 +292,16 @@ int32_t parse_model(Span file, Model& m, const char* path) {
 }
 
 // dst[r * cols + c] = src, where src is [rows, cols] (direct) or [cols, rows] (transposed)
-int32_t copy_matrix(const Tensor& t, uint64_t rows, uint64_t cols, bool transposed, float* dst, const char* what) {
+// `q` (optional): the tensor is INT8 / UINT8 and dequantised while it is copied; its stored shape is [rows, cols]
+// (direct) or [cols, rows] (transposed).
+int32_t copy_matrix(const Tensor& t, uint64_t rows, uint64_t cols, bool transposed, float* dst, const char* what,
+                    const Quant* q = nullptr) {
     if (t.external)
         return fail(CS_ERR_UNSUPPORTED, "Failed to initialize embedding model: %s keeps its data in an external file", what);
-    Reader r(t);
+    Reader r = q ? (transposed ? Reader(t, *q, cols, rows) : Reader(t, *q, rows, cols)) : Reader(t);
     if (!r.ok)
-        return fail(CS_ERR_UNSUPPORTED, "Failed to initialize embedding model: %s has data type %d or a truncated payload "
-                    "(FLOAT, FLOAT16, BFLOAT16 only)", what, t.dtype);
+        return fail(CS_ERR_UNSUPPORTED, "Failed to initialize embedding model: %s has data type %d, a truncated payload or "
+                    "(quantised) no usable scale / zero point (FLOAT, FLOAT16, BFLOAT16; INT8 / UINT8 with a scale)", what, t.dtype);
     if (!transposed) {
         for (uint64_t i = 0; i < rows * cols; ++i) dst[i] = r.at(i);
     } else {
@@ -262,8 +315,22 @@ bool shape_is(const Tensor& t, std::initializer_list<uint64_t> want) {
     return t.dims == std::vector<uint64_t>(want);
 }
 
+// onnxruntime's quantizer names the pieces of a quantised initialiser W as W_quantized, W_scale, W_zero_point.
+bool quant_of(const Model& m, const Tensor& wq, Quant& q) {
+    static const std::string suf = "_quantized";
+    if (wq.name.size() <= suf.size() || wq.name.compare(wq.name.size() - suf.size(), suf.size(), suf) != 0) return false;
+    const std::string stem = wq.name.substr(0, wq.name.size() - suf.size());
+    q.scale = m.tensor(stem + "_scale");
+    q.zp = m.tensor(stem + "_zero_point");
+    return q.scale != nullptr;
+}
+
 // The [out, in] weight that belongs to `bias_name` (see the header comment).  -> tensor + whether it is [in, out].
-const Tensor* weight_of_bias(const Model& m, const std::string& bias_name, uint64_t out, uint64_t in, bool& transposed) {
+// Dynamic quantisation (the *Q models of the registry, e.g. Xenova/all-MiniLM-L6-v2's model_quantized.onnx) replaces
+// MatMul by DynamicQuantizeLinear -> MatMulInteger(x_q, W_quantized, x_zp, W_zero_point) -> Cast -> Mul(scales) before the
+// bias Add: the weight is then the INT8 / UINT8 second input of that MatMulInteger and *quant says how to read it.
+const Tensor* weight_of_bias(const Model& m, const std::string& bias_name, uint64_t out, uint64_t in, bool& transposed,
+                             Quant* quant = nullptr) {
     auto range = m.consumers.equal_range(bias_name);
     for (auto it = range.first; it != range.second; ++it) {
         const Node& n = m.nodes[it->second];
@@ -276,9 +343,27 @@ const Tensor* weight_of_bias(const Model& m, const std::string& bias_name, uint6
             const std::string& other = n.in[0] == bias_name ? n.in[1] : n.in[0];
             auto p = m.producer.find(other);
             if (p == m.producer.end()) continue;
-            const Node& mm = m.nodes[p->second];
-            if (mm.op != "MatMul" || mm.in.size() != 2) continue;
-            const Tensor* w = m.resolve(mm.in[1]);
+            const Node* mm = &m.nodes[p->second];
+            // quantised layers: Add(bias, Mul(Cast(MatMulInteger(..)), Mul(x_scale, W_scale))) — walk back to the product
+            for (int hop = 0; hop < 4 && mm && (mm->op == "Mul" || mm->op == "Cast"); ++hop) {
+                const Node* next = nullptr;
+                for (const std::string& inp : mm->in) {
+                    auto pp = m.producer.find(inp);
+                    if (pp == m.producer.end()) continue;
+                    const Node& cand = m.nodes[pp->second];
+                    if (cand.op == "MatMulInteger" || cand.op == "Cast") { next = &cand; break; }
+                    if (cand.op == "Mul" && !next) next = &cand;  // (the scale product is a Mul too: only if nothing better)
+                }
+                mm = next;
+            }
+            if (!mm) continue;
+            if (mm->op == "MatMulInteger" && mm->in.size() >= 2 && quant) {
+                const Tensor* w = m.tensor(mm->in[1]);
+                if (w && shape_is(*w, {in, out}) && quant_of(m, *w, *quant)) { transposed = true; return w; }
+                continue;
+            }
+            if (mm->op != "MatMul" || mm->in.size() != 2) continue;
+            const Tensor* w = m.resolve(mm->in[1]);
             if (w && shape_is(*w, {in, out})) { transposed = true; return w; }
         }
     }
@@ -316,13 +401,18 @@ int32_t cs_bert_params_from_onnx(const char* path, const cs_bert_config* cfg, fl
     // wrapped in ("", "bert.", "0.auto_model.", ...): the prefix is what precedes the word-embedding table's name
     std::string mod_prefix;
     {
-        static const std::string anchor = "embeddings.word_embeddings.weight";
-        for (const auto& kv : m.init) {
-            const std::string& nm = kv.first;
-            if (nm.size() >= anchor.size() && nm.compare(nm.size() - anchor.size(), anchor.size(), anchor) == 0) {
-                mod_prefix = nm.substr(0, nm.size() - anchor.size());
-                break;
+        static const std::string anchors[2] = {"embeddings.word_embeddings.weight", "embeddings.word_embeddings.weight_quantized"};
+        for (const std::string& anchor : anchors) {
+            bool found = false;
+            for (const auto& kv : m.init) {
+                const std::string& nm = kv.first;
+                if (nm.size() >= anchor.size() && nm.compare(nm.size() - anchor.size(), anchor.size(), anchor) == 0) {
+                    mod_prefix = nm.substr(0, nm.size() - anchor.size());
+                    found = true;
+                    break;
+                }
             }
+            if (found) break;
         }
     }
     auto named = [&](const std::string& name) -> const Tensor* { return m.tensor(mod_prefix + name); };
@@ -336,6 +426,15 @@ int32_t cs_bert_params_from_onnx(const char* path, const cs_bert_config* cfg, fl
     };
     auto table = [&](const std::string& name, uint64_t rows, float* dst) -> int32_t {
         const Tensor* t = named(name);
+        if (!t) {  // a Gather table quantised in place: name_quantized + name_scale (+ name_zero_point)
+            if (const Tensor* tq = named(name + "_quantized")) {
+                Quant q;
+                if (!shape_is(*tq, {rows, H}) || !quant_of(m, *tq, q))
+                    return fail(CS_ERR_DIM_MISMATCH, "Failed to initialize embedding model: %s_quantized does not have shape [%llu, %llu] "
+                                "with a scale", name.c_str(), (unsigned long long)rows, (unsigned long long)H);
+                return copy_matrix(*tq, rows, H, false, dst, name.c_str(), &q);
+            }
+        }
         if (!t) return fail(CS_ERR_BAD_ARG, "Failed to initialize embedding model: tensor %s is missing from %s", name.c_str(), path);
         if (!shape_is(*t, {rows, H}))
             return fail(CS_ERR_DIM_MISMATCH, "Failed to initialize embedding model: %s does not have shape [%llu, %llu]",
@@ -352,11 +451,12 @@ int32_t cs_bert_params_from_onnx(const char* path, const cs_bert_config* cfg, fl
                         wname.c_str(), (unsigned long long)out, (unsigned long long)in);
         }
         bool tr = false;
-        const Tensor* w = weight_of_bias(m, mod_prefix + bname, out, in, tr);
+        Quant q;
+        const Tensor* w = weight_of_bias(m, mod_prefix + bname, out, in, tr, &q);
         if (!w)
-            return fail(CS_ERR_BAD_ARG, "Failed to initialize embedding model: no MatMul/Gemm weight of shape [%llu, %llu] feeds "
-                        "the Add of %s in %s", (unsigned long long)in, (unsigned long long)out, bname.c_str(), path);
-        return copy_matrix(*w, out, in, tr, w_dst, wname.c_str());
+            return fail(CS_ERR_BAD_ARG, "Failed to initialize embedding model: no MatMul/Gemm/MatMulInteger weight of shape [%llu, %llu] "
+                        "feeds the Add of %s in %s", (unsigned long long)in, (unsigned long long)out, bname.c_str(), path);
+        return copy_matrix(*w, out, in, tr, w_dst, wname.c_str(), q.scale ? &q : nullptr);
     };
 
     CS_TRY(table("embeddings.word_embeddings.weight", cfg->vocab_size, params + o.word));

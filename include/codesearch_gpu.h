@@ -325,8 +325,10 @@ int32_t cs_embedder_create(const cs_bert_config* cfg, const float* params, uint6
  *     model.onnx or model_optimized.onnx: the graph's initialisers are read by hand (no protobuf library):
  *     named parameters directly, Linear weights through the MatMul/Gemm feeding each bias's Add, the packed
  *     QKV of ORT-optimised files through their fused Attention nodes.
- * F32, F16 or BF16; pooler / position_ids / other extras ignored; quantised (int8) exports are refused.
- * All loaders are host-only. */
+ * F32, F16 or BF16; pooler / position_ids / other extras ignored.  Dynamically quantised exports (the *Q models of
+ * the registry, among them the reference's default AllMiniLML6V2Q, embedder.rs:12-13: INT8 / UINT8 weights with scale and
+ * zero point behind MatMulInteger) are read as (q - zero_point) * scale: the encoder runs the f32 graph of the quantised
+ * weights and does not re-quantise activations per call as ORT does.  All loaders are host-only. */
 /* pooling: CS_POOL_CLS, CS_POOL_MEAN, or -1 = what <model_dir>/1_Pooling/config.json says (the
  * sentence-transformers module: mean for MiniLM / E5, CLS for BGE), CLS when that file is absent. */
 int32_t cs_bert_config_from_dir(const char* model_dir, int32_t pooling, cs_bert_config* cfg);

@@ -5,6 +5,34 @@ any size without the `onnx` package.  Test infrastructure only — the product r
 import numpy as np
 
 FLOAT, FLOAT16, BFLOAT16 = 1, 10, 16
+UINT8, INT8 = 2, 3
+
+
+def raw_tensor(name: str, arr: np.ndarray, dtype: int) -> bytes:
+    """An integer initialiser (UINT8 / INT8) exactly as given."""
+    arr = np.ascontiguousarray(arr, np.uint8 if dtype == UINT8 else np.int8)
+    body = b"".join(_key(1, 0) + _varint(int(d)) for d in arr.shape)
+    body += _key(2, 0) + _varint(dtype)
+    body += _ld(8, name.encode())
+    return body + _ld(9, arr.tobytes())
+
+
+def quantize(w: np.ndarray, dtype: int, axis=None):
+    """onnxruntime-style affine quantisation of a float matrix -> (q, scale, zero_point): per tensor, or per slice along
+    `axis`; INT8 symmetric (zero point 0), UINT8 asymmetric."""
+    w = np.asarray(w, np.float32)
+    red = None if axis is None else tuple(i for i in range(w.ndim) if i != axis)
+    lo = np.minimum(w.min(axis=red, keepdims=axis is not None), 0.0)
+    hi = np.maximum(w.max(axis=red, keepdims=axis is not None), 0.0)
+    if dtype == INT8:
+        scale = np.maximum(np.maximum(-lo, hi) / 127.0, 1e-12).astype(np.float32)
+        zp = np.zeros_like(scale, dtype=np.int8)
+        q = np.clip(np.rint(w / scale), -127, 127).astype(np.int8)
+    else:
+        scale = np.maximum((hi - lo) / 255.0, 1e-12).astype(np.float32)
+        zp = np.clip(np.rint(-lo / scale), 0, 255).astype(np.uint8)
+        q = np.clip(np.rint(w / scale) + zp.astype(np.float32), 0, 255).astype(np.uint8)
+    return q, scale.reshape(-1) if axis is not None else scale.reshape(()), zp.reshape(-1) if axis is not None else zp.reshape(())
 
 
 def _varint(v: int) -> bytes:
@@ -56,12 +84,17 @@ def model(nodes, initializers, producer: str = "tests/onnx_writer.py") -> bytes:
     return _key(1, 0) + _varint(8) + _ld(2, producer.encode()) + _ld(7, graph)
 
 
-def bert_onnx(sd: dict, layers: int, style: str = "matmul", dtype: int = FLOAT, prefix: str = "") -> bytes:
+def bert_onnx(sd: dict, layers: int, style: str = "matmul", dtype: int = FLOAT, prefix: str = "", qdtype: int = INT8,
+              per_channel: bool = False, quantize_tables: bool = False, dequantized: dict = None) -> bytes:
     """sd: HF BertModel state dict (numpy).  style:
        "matmul" — the torch.onnx / optimum shape: biases and other directly-consumed parameters keep their names,
                   Linear weights are transposed anonymous `onnx::MatMul_N` initialisers feeding MatMul -> Add(bias);
        "gemm"   — Gemm(x, W [out, in], bias, transB = 1) with the weight's own name;
-       "fused"  — ORT-optimised: one com.microsoft Attention node per layer with a packed [H, 3H] weight and [3H] bias."""
+       "fused"  — ORT-optimised: one com.microsoft Attention node per layer with a packed [H, 3H] weight and [3H] bias;
+       "quantized" — onnxruntime's dynamic quantisation of the "matmul" shape: W_quantized (qdtype, per tensor or per
+                  output channel) + W_scale + W_zero_point consumed by DynamicQuantizeLinear -> MatMulInteger -> Cast ->
+                  Mul(Mul(x_scale, W_scale)) -> Add(bias); with quantize_tables the word-embedding Gather table too.
+                  `dequantized` (a dict) receives name -> the f32 values a reader must reproduce."""
     inits, nodes, counter = [], [], [1000]
 
     def keep(name):
@@ -74,6 +107,23 @@ def bert_onnx(sd: dict, layers: int, style: str = "matmul", dtype: int = FLOAT, 
         if style == "gemm":
             keep(base + ".weight")
             nodes.append(node("Gemm", [x, prefix + base + ".weight", prefix + b], [y], attrs=[("transB", 1)]))
+        elif style == "quantized":
+            counter[0] += 1
+            anon = f"onnx::MatMul_{counter[0]}"
+            q, sc, zp = quantize(w.T, qdtype, axis=1 if per_channel else None)   # stored [in, out]; channels = outputs
+            inits.append(raw_tensor(anon + "_quantized", q, qdtype))
+            inits.append(tensor(anon + "_scale", sc))
+            inits.append(raw_tensor(anon + "_zero_point", zp, qdtype))
+            if dequantized is not None:
+                dequantized[base + ".weight"] = ((q.astype(np.float32) - zp.astype(np.float32)) * sc).T.astype(np.float32)
+            xq, xs, xz = (f"/{base}/x_{t}" for t in ("quantized", "scale", "zero_point"))
+            nodes.append(node("DynamicQuantizeLinear", [x], [xq, xs, xz]))
+            nodes.append(node("MatMulInteger", [xq, anon + "_quantized", xz, anon + "_zero_point"], [f"/{base}/mmi"]))
+            nodes.append(node("Cast", [f"/{base}/mmi"], [f"/{base}/mmi_f"], attrs=[("to", 1)]))
+            nodes.append(node("Mul", [xs, anon + "_scale"], [f"/{base}/scales"]))
+            nodes.append(node("Mul", [f"/{base}/mmi_f", f"/{base}/scales"] if counter[0] % 2 else [f"/{base}/scales", f"/{base}/mmi_f"],
+                              [f"/{base}/mm"]))
+            nodes.append(node("Add", [prefix + b, f"/{base}/mm"] if counter[0] % 3 else [f"/{base}/mm", prefix + b], [y]))
         else:
             counter[0] += 1
             anon = f"onnx::MatMul_{counter[0]}"
@@ -85,6 +135,14 @@ def bert_onnx(sd: dict, layers: int, style: str = "matmul", dtype: int = FLOAT, 
 
     for n in ("embeddings.word_embeddings.weight", "embeddings.position_embeddings.weight",
               "embeddings.token_type_embeddings.weight", "embeddings.LayerNorm.weight", "embeddings.LayerNorm.bias"):
+        if style == "quantized" and quantize_tables and n == "embeddings.word_embeddings.weight":
+            q, sc, zp = quantize(sd[n], UINT8)
+            inits.append(raw_tensor(prefix + n + "_quantized", q, UINT8))
+            inits.append(tensor(prefix + n + "_scale", sc))
+            inits.append(raw_tensor(prefix + n + "_zero_point", zp, UINT8))
+            if dequantized is not None:
+                dequantized[n] = ((q.astype(np.float32) - zp.astype(np.float32)) * sc).astype(np.float32)
+            continue
         keep(n)
     nodes.append(node("Gather", [prefix + "embeddings.word_embeddings.weight", "input_ids"], ["/emb"]))
     x = "/emb"

@@ -62,6 +62,39 @@ def test_exporter_layouts_and_dtypes(gpu_lib, tmp_path, style, dtype, prefix):
     assert np.array_equal(got, exp)
 
 
+@pytest.mark.parametrize("qdtype,per_channel,tables,prefix", [(onnx_writer.INT8, False, False, ""),
+                                                               (onnx_writer.UINT8, False, True, ""),
+                                                               (onnx_writer.INT8, True, True, "0.auto_model.")])
+def test_dynamically_quantised_export(gpu_lib, tmp_path, qdtype, per_channel, tables, prefix):
+    """The layout of the reference's DEFAULT model (ModelType::AllMiniLML6V2Q, embedder.rs:12-13: fastembed's
+    model_quantized.onnx, written by onnxruntime's dynamic quantiser): W_quantized (INT8 symmetric / UINT8 asymmetric,
+    per tensor or per output channel) + W_scale + W_zero_point behind DynamicQuantizeLinear -> MatMulInteger -> Cast ->
+    Mul -> Add(bias), optionally a quantised word-embedding table.  The loader must hand back exactly
+    (q - zero_point) * scale for those tensors and every other parameter bit for bit."""
+    cfg = BertConfig(vocab_size=300, layers=2, max_position=64, pooling=POOL_MEAN)
+    flat = synth_params(cfg, 78)
+    sd = to_state_dict(cfg, flat)
+    deq = {}
+    path = tmp_path / "model_quantized.onnx"
+    path.write_bytes(onnx_writer.bert_onnx(sd, cfg.layers, "quantized", prefix=prefix, qdtype=qdtype, per_channel=per_channel,
+                                           quantize_tables=tables, dequantized=deq))
+    got = to_state_dict(cfg, load_onnx(gpu_lib, path, cfg))
+    assert len(deq) == 6 * cfg.layers + (1 if tables else 0)
+    for name, want in sd.items():
+        if name in deq:
+            assert np.array_equal(got[name], deq[name]), name
+            rel = np.abs(deq[name] - want).max() / np.abs(want).max()
+            assert 0 < rel < (0.02 if not per_channel else 0.01), (name, rel)   # it IS quantised, and sanely so
+        else:
+            assert np.array_equal(got[name], want), name
+    # a quantised weight whose scale is missing is refused with a message, not read as garbage
+    broken = onnx_writer.bert_onnx(sd, cfg.layers, "quantized", qdtype=qdtype).replace(b"onnx::MatMul_1001_scale", b"onnx::MatMul_1001_scalX")
+    (tmp_path / "broken.onnx").write_bytes(broken)
+    with pytest.raises(_lib.CsError) as e:
+        load_onnx(gpu_lib, tmp_path / "broken.onnx", cfg)
+    assert "MatMulInteger weight" in str(e.value) or "scale" in str(e.value)
+
+
 def test_onnx_errors(gpu_lib, tmp_path):
     cfg = BertConfig(vocab_size=300, layers=2, max_position=64)
     sd = to_state_dict(cfg, synth_params(cfg, 78))

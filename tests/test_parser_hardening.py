@@ -38,6 +38,18 @@ def test_onnx_reader_survives_truncations_and_mutations(fuzz):
     assert "0 crashes" in out
 
 
+def test_quantised_onnx_survives_truncations_and_mutations(fuzz, tmp_path):
+    """The dynamically quantised layout (INT8 / UINT8 weights + scales + zero points, the reference's default model)."""
+    from codesearch_amd.bert_params import BertConfig, synth_params, to_state_dict
+    from tests import onnx_writer
+
+    cfg = BertConfig(vocab_size=64, hidden=128, heads=4, intermediate=256, layers=1, max_position=16)
+    sd = to_state_dict(cfg, synth_params(cfg, 5))
+    p = tmp_path / "model_quantized.onnx"
+    p.write_bytes(onnx_writer.bert_onnx(sd, 1, "quantized", qdtype=onnx_writer.UINT8, per_channel=True, quantize_tables=True))
+    fuzz("onnx", p, seed=21, flips=600, aux="64 128 1 4 256 16")
+
+
 def test_safetensors_reader_survives_truncations_and_mutations(fuzz, tmp_path):
     from safetensors.numpy import save_file
 
