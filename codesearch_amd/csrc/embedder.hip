@@ -243,6 +243,37 @@ int32_t forward_range(cs_embedder* h, hipStream_t s, uint32_t b0, uint32_t nb, u
                 _Float16* qkvs = reinterpret_cast<_Float16*>(qkv);  // [T][3H/32][64] f16: same bytes as the f32 qkv
                 CS_TRY(dense(SH_OUT_SPLIT, xs, ws + sl.qkv, bqkv, nullptr, nullptr, qkvs, T, 3 * H, H));  // E2
                 CS_TRY(mark(CS_STAGE_QKV));
+                // CLS pooling reads ONE row per sequence of the last layer: its attention needs every key and value but
+                // only the CLS query, and everything behind it runs on nb rows instead of nb * L (cls_tail.hip).  Same
+                // embedding, 1/12 less work at 12 layers.  Compact rows live in the (idle) intermediate buffer of the slice.
+                static const bool cls_tail_on = [] { const char* e = std::getenv("CS_ENCODER_CLS_TAIL"); return !(e && e[0] == '0'); }();
+                static const uint32_t cls_tail_min = [] { const char* e = std::getenv("CS_ENCODER_CLS_TAIL_MIN_TOKENS"); return e ? (uint32_t)std::atoll(e) : 4096u; }();
+                if (cls_tail_on && c.pooling == CS_POOL_CLS && l + 1 == c.layers && T >= cls_tail_min && L >= 16) {
+                    float* x_cls = mid;                                            // [nb, H] f32
+                    _Float16* xs_cls = reinterpret_cast<_Float16*>(mid + (size_t)nb * H);       // [nb][H/32][64]
+                    _Float16* ctxs_cls = reinterpret_cast<_Float16*>(mid + (size_t)2 * nb * H);
+                    _Float16* mids_cls = reinterpret_cast<_Float16*>(mid + (size_t)3 * nb * H);  // [nb][I/32][64]
+                    CS_TRY(launch_attention_cls(qkvs, mask, ctxs_cls, h->d_flag, nb, L, H, c.heads, s));   // E3, one query per sequence
+                    CS_TRY(mark(CS_STAGE_ATTENTION));
+                    CS_TRY(launch_gather_cls(xs, x_cls, xs_cls, nb, L, H, s));
+                    EncoderLaunch t = a;
+                    t.x = x_cls; t.xs = xs_cls; t.T = nb; t.L = 1; t.B = nb;
+                    CS_TRY(launch_gemm_split(SH_OUT_F32_RESID, ctxs_cls, ws + sl.ao, P + lo.ao_b, x_cls, x_cls, nullptr, nb, H, H, h->d_flag, s));  // E4
+                    CS_TRY(mark(CS_STAGE_OUT_PROJ));
+                    t.g = P + lo.ao_ln_g; t.b = P + lo.ao_ln_b;
+                    CS_TRY(launch_row_kernel(1, t, H, s));
+                    CS_TRY(mark(CS_STAGE_LN_ATTN));
+                    CS_TRY(launch_gemm_split(SH_OUT_SPLIT_GELU, xs_cls, ws + sl.up, P + lo.up_b, nullptr, nullptr, mids_cls, nb, I, H, h->d_flag, s));  // E5
+                    CS_TRY(mark(CS_STAGE_FFN_UP));
+                    CS_TRY(launch_gemm_split(SH_OUT_F32_RESID, mids_cls, ws + sl.down, P + lo.down_b, x_cls, x_cls, nullptr, nb, H, I, h->d_flag, s));  // E6
+                    CS_TRY(mark(CS_STAGE_FFN_DOWN));
+                    t.g = P + lo.out_ln_g; t.b = P + lo.out_ln_b;
+                    CS_TRY(launch_row_kernel(1, t, H, s));
+                    CS_TRY(mark(CS_STAGE_LN_FFN));
+                    CS_TRY(launch_row_kernel(2, t, H, s));  // E7 + E8 on the compact rows (L = 1: row b IS the CLS row)
+                    CS_TRY(mark(CS_STAGE_POOL));
+                    return CS_OK;
+                }
                 CS_TRY(launch_attention_sh2(qkvs, mask, ctxs, h->d_flag, nb, L, H, c.heads, s));                                 // E3
                 CS_TRY(mark(CS_STAGE_ATTENTION));
             }

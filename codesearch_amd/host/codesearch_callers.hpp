@@ -15,6 +15,8 @@
 #include <map>
 #include <optional>
 #include <string>
+#include <type_traits>
+#include <utility>
 #include <vector>
 
 #include "codesearch_gpu.hpp"
@@ -161,6 +163,10 @@ struct EmbeddingStats {
 
 // batch.rs:60-194.  batch_size defaults to the reference's 32; on the GPU hand over whole mini-batches
 // (256) or everything at once: cs_embedder_embed_texts forms its own mini-batches.
+template <class E, class = void> struct has_queue : std::false_type {};
+template <class E>
+struct has_queue<E, std::void_t<decltype(std::declval<E&>().submit(std::declval<const std::vector<std::string>&>()))>> : std::true_type {};
+
 template <class Embedder>
 class BatchEmbedder {
   public:
@@ -168,9 +174,35 @@ class BatchEmbedder {
     static BatchEmbedder with_batch_size(Embedder& embedder, size_t batch_size) {
         return BatchEmbedder(embedder, batch_size);
     }
+    // batch.rs:84-115.  An embedder with a submission queue (cs::FastEmbedder: submit / wait) gets every slice SUBMITTED
+    // first and collected afterwards — the first wait embeds all queued slices as full device batches — so the
+    // reference's slice size of 32 keeps the large-batch rate; any other embedder is called slice by slice.
     std::vector<EmbeddedChunk> embed_chunks(const std::vector<Chunk>& chunks) {
         std::vector<EmbeddedChunk> out;
         out.reserve(chunks.size());
+        if constexpr (has_queue<Embedder>::value) {
+            if (chunks.size() > batch_size_) {
+                std::vector<std::pair<uint64_t, size_t>> tickets;  // (ticket, first chunk)
+                try {
+                    for (size_t lo = 0; lo < chunks.size(); lo += batch_size_) {
+                        const size_t hi = std::min(chunks.size(), lo + batch_size_);
+                        std::vector<std::string> texts;
+                        for (size_t i = lo; i < hi; ++i) texts.push_back(prepare_text(chunks[i]));
+                        tickets.emplace_back(embedder_.submit(texts), lo);
+                    }
+                    while (!tickets.empty()) {
+                        const size_t lo = tickets.front().second, hi = std::min(chunks.size(), lo + batch_size_);
+                        auto embs = embedder_.wait(tickets.front().first, hi - lo);
+                        tickets.erase(tickets.begin());
+                        for (size_t i = lo; i < hi; ++i) out.push_back(EmbeddedChunk{chunks[i], std::move(embs[i - lo])});
+                    }
+                } catch (...) {
+                    for (auto& t : tickets) { try { embedder_.discard(t.first); } catch (...) {} }
+                    throw;
+                }
+                return out;
+            }
+        }
         for (size_t lo = 0; lo < chunks.size(); lo += batch_size_) {
             const size_t hi = std::min(chunks.size(), lo + batch_size_);
             std::vector<std::string> texts;

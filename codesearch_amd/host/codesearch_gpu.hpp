@@ -104,6 +104,15 @@ class VectorStore {
     VectorStore(const VectorStore&) = delete;
     VectorStore& operator=(const VectorStore&) = delete;
     bool sharded() const { return sh_ != nullptr; }
+    cs_shards* shards_handle() const { return sh_; }
+    // metadata of chunks whose vectors were appended by EmbedderReplicas::index_texts (ids assigned there)
+    void put_metadata(const std::vector<uint32_t>& ids, const std::vector<Chunk>& chunks) {
+        for (size_t i = 0; i < ids.size() && i < chunks.size(); ++i) {
+            EmbeddedChunk ec;
+            ec.chunk = chunks[i];
+            meta_[ids[i]] = ChunkMetadata::from_embedded_chunk(ec);
+        }
+    }
 
     // store.rs:618-686
     std::vector<uint32_t> insert_chunks_with_ids(const std::vector<EmbeddedChunk>& chunks) {
@@ -346,6 +355,27 @@ class FastEmbedder {
         if (r.empty()) throw Error(CS_ERR_BAD_ARG, "No embedding generated");
         return r[0];
     }
+    // The reference's call shape on a queue (src/embed/batch.rs:84-115: slices of 32 under a mutex): submit() tokenises
+    // and queues a slice, wait() returns its rows; the first wait embeds everything queued as full device batches.
+    // Safe from several threads on one embedder.
+    uint64_t submit(const std::vector<std::string>& texts) {
+        if (!tok_) throw Error(CS_ERR_UNSUPPORTED, "Failed to generate embeddings: no tokenizer attached");
+        std::string blob;
+        std::vector<uint64_t> off;
+        Tokenizer::pack(texts, blob, off);
+        uint64_t ticket = 0;
+        check(cs_embedder_submit_texts(h_, tok_->handle(), blob.data(), off.data(), texts.size(), &ticket));
+        return ticket;
+    }
+    std::vector<std::vector<float>> wait(uint64_t ticket, size_t n, const volatile int32_t* shutdown = nullptr) {
+        const size_t d = dimensions();
+        std::vector<float> flat(n * d + 1);
+        check(cs_embedder_wait(h_, ticket, flat.data(), shutdown));
+        std::vector<std::vector<float>> out(n);
+        for (size_t i = 0; i < n; ++i) out[i].assign(flat.begin() + i * d, flat.begin() + (i + 1) * d);
+        return out;
+    }
+    void discard(uint64_t ticket) { check(cs_embedder_discard(h_, ticket)); }
     size_t dimensions() const { return cs_embedder_dim(h_); }  // embedder.rs:307
     cs_embedder* handle() const { return h_; }
     // CS_GEMM_SPLIT_F16 (default) or CS_GEMM_F32 (exact-f32 MFMA), include/codesearch_gpu.h
@@ -353,6 +383,54 @@ class FastEmbedder {
 
   private:
     cs_embedder* h_ = nullptr;
+    const Tokenizer* tok_ = nullptr;
+};
+
+// One encoder replica per GPU inside this process and the index loop of src/index/mod.rs:626-762 over a sharded
+// VectorStore: every replica embeds the chunks whose ids fall on the shards of its own GPU, rows are appended without
+// leaving HBM, no collective (cs_embedders_*).
+class EmbedderReplicas {
+  public:
+    EmbedderReplicas(const cs_bert_config& cfg, const float* params, uint64_t seed, const std::vector<int32_t>& devices) {
+        check(cs_embedders_create(&cfg, params, seed, devices.data(), (uint32_t)devices.size(), &h_));
+    }
+    EmbedderReplicas(const std::string& model_dir, cs_pooling pooling, const std::vector<int32_t>& devices) {
+        check(cs_embedders_create_from_dir(model_dir.c_str(), (int32_t)pooling, devices.data(), (uint32_t)devices.size(), &h_));
+    }
+    ~EmbedderReplicas() { cs_embedders_destroy(h_); }
+    EmbedderReplicas(const EmbedderReplicas&) = delete;
+    EmbedderReplicas& operator=(const EmbedderReplicas&) = delete;
+    void attach_tokenizer(const Tokenizer* t) { tok_ = t; }
+    size_t dimensions() const { return cs_embedders_dim(h_); }
+    size_t size() const { return cs_embedders_count(h_); }
+    // embed_batch over all replicas: row i = text i
+    std::vector<std::vector<float>> embed_batch(const std::vector<std::string>& texts, const volatile int32_t* shutdown = nullptr) {
+        if (!tok_) throw Error(CS_ERR_UNSUPPORTED, "Failed to generate embeddings: no tokenizer attached");
+        std::string blob;
+        std::vector<uint64_t> off;
+        Tokenizer::pack(texts, blob, off);
+        const size_t d = dimensions(), n = texts.size();
+        std::vector<float> flat(n * d + 1);
+        check(cs_embedders_embed_texts(h_, tok_->handle(), blob.data(), off.data(), n, 0, flat.data(), shutdown));
+        std::vector<std::vector<float>> out(n);
+        for (size_t i = 0; i < n; ++i) out[i].assign(flat.begin() + i * d, flat.begin() + (i + 1) * d);
+        return out;
+    }
+    // embed_chunks + insert_chunks_with_ids in one call on a SHARDED store -> the assigned ids (metadata: the caller's)
+    std::vector<uint32_t> index_texts(cs_shards* store, const std::vector<std::string>& texts,
+                                      const volatile int32_t* shutdown = nullptr) {
+        if (!tok_) throw Error(CS_ERR_UNSUPPORTED, "Failed to generate embeddings: no tokenizer attached");
+        std::string blob;
+        std::vector<uint64_t> off;
+        Tokenizer::pack(texts, blob, off);
+        std::vector<uint32_t> ids(texts.size());
+        check(cs_embedders_index_texts(h_, tok_->handle(), store, blob.data(), off.data(), texts.size(), 0, ids.data(), shutdown));
+        return ids;
+    }
+    cs_embedders* handle() const { return h_; }
+
+  private:
+    cs_embedders* h_ = nullptr;
     const Tokenizer* tok_ = nullptr;
 };
 

@@ -191,6 +191,40 @@ int main(int argc, char** argv) {
         for (size_t j = 0; j < 384; ++j) REQUIRE(te[i][j] == ti[i][j]);
     auto one = emb.embed_one("FN");
     for (size_t j = 0; j < 384; ++j) REQUIRE(std::fabs(one[j] - te[1][j]) < 1e-5);  // padding-invariant
+    {   // BatchEmbedder on the queue (batch.rs:84-115 with its slices of 32): same vectors as one embed_batch call
+        std::vector<Chunk> chunks;
+        for (int i = 0; i < 75; ++i) {
+            Chunk c;
+            c.content = (i % 3 ? "fn mains() fn" : "main ( )"); c.kind = "Function"; c.path = "q.rs";
+            for (int r = 0; r < i % 5; ++r) c.content += " fn main";
+            chunks.push_back(c);
+        }
+        BatchEmbedder<FastEmbedder> be(emb);
+        auto got = be.embed_chunks(chunks);
+        std::vector<std::string> texts;
+        for (const auto& c : chunks) texts.push_back(prepare_text(c));
+        auto want = emb.embed_batch(texts);
+        REQUIRE(got.size() == 75 && want.size() == 75);
+        for (size_t i = 0; i < 75; ++i) {
+            REQUIRE(got[i].chunk.content == chunks[i].content);
+            for (size_t j = 0; j < 384; ++j) REQUIRE(std::fabs(got[i].embedding[j] - want[i][j]) < 2e-6);
+        }
+        // replicas + sharded store: embed and append in one call, ids contiguous, rows searchable
+        EmbedderReplicas reps(cfg, nullptr, 7, std::vector<int32_t>{0, 0});
+        reps.attach_tokenizer(&tok);
+        VectorStore sharded("s.db", 384, std::vector<int32_t>{0, 0, 0, 0}, /*rows_per_stripe=*/8);
+        auto ids_a = reps.index_texts(sharded.shards_handle(), std::vector<std::string>(texts.begin(), texts.begin() + 30));
+        auto ids_b = reps.index_texts(sharded.shards_handle(), std::vector<std::string>(texts.begin() + 30, texts.end()));
+        REQUIRE(ids_a.size() == 30 && ids_a.front() == 0 && ids_a.back() == 29 && ids_b.front() == 30 && ids_b.back() == 74);
+        ids_a.insert(ids_a.end(), ids_b.begin(), ids_b.end());
+        sharded.put_metadata(ids_a, chunks);
+        sharded.build_index();
+        auto hit = sharded.search(want[41], 3);
+        REQUIRE(!hit.empty() && hit[0].score > 0.9999f);
+        REQUIRE(hit[0].meta.content == chunks[hit[0].id].content);   // several chunks share a text: any of them may lead
+        auto both = reps.embed_batch(texts);
+        for (size_t j = 0; j < 384; ++j) REQUIRE(std::fabs(both[41][j] - want[41][j]) < 2e-6);
+    }
     std::printf("host mirror ok\n");
     return 0;
 }

@@ -164,6 +164,37 @@ def test_config3_shape_b256_l256_property(FE, oracle):
     np.testing.assert_allclose(got[rows], ref, atol=TOL_ORACLE)
 
 
+@pytest.mark.parametrize("hidden,heads,inter,layers,B,L", [(384, 12, 1536, 2, 40, 128),    # 5,120 tokens: just over the threshold
+                                                          (384, 12, 1536, 3, 256, 16),    # shortest rows the tail takes
+                                                          (384, 12, 1536, 2, 9, 512),     # longest rows
+                                                          (768, 12, 3072, 1, 20, 256)])   # head_dim 64
+def test_cls_tail_equals_the_full_last_layer(FE, oracle, hidden, heads, inter, layers, B, L):
+    """CLS-pooled models: from 4,096 tokens per mini-batch the LAST layer runs only what the embedding reads (one query
+    per sequence against every key, then B compact rows through the dense layers: cls_tail.hip).  Same embedding as the
+    full layer: compared with the same rows embedded in slices below the threshold (the full last layer) and with the
+    oracle; ragged masks, so padded keys are masked in the one-query attention too; mean pooling never takes the tail."""
+    cfg = BertConfig(vocab_size=2048, hidden=hidden, heads=heads, intermediate=inter, layers=layers, max_position=512,
+                     pooling=POOL_CLS)
+    ids, mask = synth_token_batch(cfg, 100 + L, B, L, True)
+    mask[1, 5:] = 0                                     # a very short row
+    ids[1, 5:] = 0
+    emb = FE(cfg, seed=9)
+    got = emb.embed_ids(ids, mask, batch_size=B)        # one mini-batch of B x L >= 4,096 tokens: the tail
+    step = max(1, 2048 // L)
+    small = np.concatenate([emb.embed_ids(ids[i:i + step], mask[i:i + step], batch_size=step) for i in range(0, B, step)])
+    np.testing.assert_allclose(got, small, atol=3e-6)
+    rows = [0, 1, B // 2, B - 1]
+    ref = oracle.bert_forward(cfg, oracle.bert_synth_params(cfg, 9), ids[rows], mask[rows])["pooled"]
+    np.testing.assert_allclose(got[rows], ref, atol=TOL_ORACLE)
+    emb.close()
+    cfg.pooling = POOL_MEAN
+    emb = FE(cfg, seed=9)
+    gm = emb.embed_ids(ids, mask, batch_size=B)
+    refm = oracle.bert_forward(cfg, oracle.bert_synth_params(cfg, 9), ids[rows], mask[rows])["pooled"]
+    np.testing.assert_allclose(gm[rows], refm, atol=TOL_ORACLE)
+    emb.close()
+
+
 def test_end_to_end_index_then_search_vs_oracle_pipeline(FE, oracle):
     """BASELINE configs[3] at reduced size: chunks embedded on the GPU, appended to the
     device-resident matrix without leaving HBM, batched queries, top-10 — against the same
