@@ -7,6 +7,8 @@
 // the same embedding — not an approximation — for 1/12 less work at 12 layers (measured: DESIGN.md §3.6b).
 // Mean-pooled models (MiniLM family) read every row and keep the full layer.
 //
+// Even the query projection shrinks: the last layer's big GEMM computes K and V only (N = 2H); the B CLS queries come from
+// a small GEMM over the gathered rows.
 //   attention_cls_kernel : one wave per (sequence, head): scores of the CLS query against all keys, softmax, P V —
 //                          plain f32 arithmetic on the split operands (hi + lo / 2048 is exact in f32), 16-byte loads:
 //                          a pass covers 8 keys (head_dim 32) or 4 (head_dim 64), lane = (key slot, 16-byte chunk).
@@ -23,19 +25,21 @@ constexpr float kClsMasked = -3.0e38f;
 
 template <int NC>  // head_dim = 32 * NC
 __global__ void __launch_bounds__(64)
-attention_cls_kernel(const _Float16* __restrict__ qkvs, const int32_t* __restrict__ mask, _Float16* __restrict__ ctxs_cls,
-                     uint32_t* __restrict__ flag, uint32_t L, uint32_t H, float scale_log2e) {
+attention_cls_kernel(const _Float16* __restrict__ q_cls, const _Float16* __restrict__ kvs, const int32_t* __restrict__ mask,
+                     _Float16* __restrict__ ctxs_cls, uint32_t* __restrict__ flag, uint32_t L, uint32_t H, float scale_log2e) {
     __shared__ float q_s[64];
     __shared__ float p_s[512];
     constexpr int CH = 8 * NC;        // 16-byte chunks of one key (hi and lo of every 8 dims)
     constexpr int KP = 64 / CH;       // keys per pass
     const int lane = threadIdx.x;
     const uint32_t head = blockIdx.x, b = blockIdx.y;
-    const uint32_t nh = H / (32 * NC), nch = 3 * nh * NC;
-    const _Float16* base = qkvs + (size_t)b * L * nch * 64;
+    // kvs: [T][2H/32][64] — per token the K lines of every head, then the V lines (the last layer projects K and V only;
+    // the CLS queries come from a GEMM over the B compact rows: q_cls [B][H/32][64])
+    const uint32_t nh = H / (32 * NC), nch = 2 * nh * NC;
+    const _Float16* base = kvs + (size_t)b * L * nch * 64;
     // the CLS query (token 0 of the sequence) as f32, pre-multiplied by log2(e) / sqrt(d)
     if (lane < 32 * NC) {
-        const _Float16* qp = base + (size_t)(head * NC + lane / 32) * 64;
+        const _Float16* qp = q_cls + ((size_t)b * (H / 32) + head * NC + lane / 32) * 64;
         q_s[lane] = fmaf((float)qp[32 + lane % 32], kShLoInv, (float)qp[lane % 32]) * scale_log2e;
     }
     __syncthreads();
@@ -56,7 +60,7 @@ attention_cls_kernel(const _Float16* __restrict__ qkvs, const int32_t* __restric
         for (int u = 0; u < U; ++u) {
             jx[u] = j0 + u * KP + ks;
             const uint32_t jj = jx[u] < L ? jx[u] : L - 1;
-            kv[u] = *reinterpret_cast<const f16x8*>(base + ((size_t)jj * nch + (nh + head) * NC + line) * 64 + slot * 8);
+            kv[u] = *reinterpret_cast<const f16x8*>(base + ((size_t)jj * nch + head * NC + line) * 64 + slot * 8);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -95,7 +99,7 @@ attention_cls_kernel(const _Float16* __restrict__ qkvs, const int32_t* __restric
         for (int u = 0; u < U; ++u) {
             const uint32_t j = j0 + u * KP + ks;
             const uint32_t jj = j < L ? j : L - 1;
-            vv[u] = *reinterpret_cast<const f16x8*>(base + ((size_t)jj * nch + (2 * nh + head) * NC + line) * 64 + slot * 8);
+            vv[u] = *reinterpret_cast<const f16x8*>(base + ((size_t)jj * nch + (nh + head) * NC + line) * 64 + slot * 8);
             pu[u] = j < L ? p_s[jj] : 0.0f;
         }
 #pragma unroll
@@ -151,17 +155,17 @@ gather_cls_kernel(const _Float16* __restrict__ xs, float* __restrict__ x_cls, _F
 
 }  // namespace
 
-int32_t launch_attention_cls(const _Float16* qkv_split, const int32_t* mask, _Float16* ctxs_cls, uint32_t* flag, uint32_t B,
-                             uint32_t L, uint32_t H, uint32_t heads, hipStream_t s) {
+int32_t launch_attention_cls(const _Float16* q_cls, const _Float16* kv_split, const int32_t* mask, _Float16* ctxs_cls,
+                             uint32_t* flag, uint32_t B, uint32_t L, uint32_t H, uint32_t heads, hipStream_t s) {
     const uint32_t dh = heads ? H / heads : 0;
     if ((dh != 32 && dh != 64) || H % heads || L == 0 || L > 512)
         return fail(CS_ERR_UNSUPPORTED, "CLS attention: head_dim %u / length %u not supported", dh, L);
     constexpr float kLog2e = 1.4426950408889634f;
     if (dh == 32)
-        hipLaunchKernelGGL(attention_cls_kernel<1>, dim3(heads, B), dim3(64), 0, s, qkv_split, mask, ctxs_cls, flag, L, H,
+        hipLaunchKernelGGL(attention_cls_kernel<1>, dim3(heads, B), dim3(64), 0, s, q_cls, kv_split, mask, ctxs_cls, flag, L, H,
                            (1.0f / sqrtf(32.0f)) * kLog2e);
     else
-        hipLaunchKernelGGL(attention_cls_kernel<2>, dim3(heads, B), dim3(64), 0, s, qkv_split, mask, ctxs_cls, flag, L, H,
+        hipLaunchKernelGGL(attention_cls_kernel<2>, dim3(heads, B), dim3(64), 0, s, q_cls, kv_split, mask, ctxs_cls, flag, L, H,
                            (1.0f / sqrtf(64.0f)) * kLog2e);
     CS_HIP(hipGetLastError());
     return CS_OK;

@@ -241,8 +241,6 @@ int32_t forward_range(cs_embedder* h, hipStream_t s, uint32_t b0, uint32_t nb, u
                 CS_TRY(mark(CS_STAGE_ATTENTION));
             } else {
                 _Float16* qkvs = reinterpret_cast<_Float16*>(qkv);  // [T][3H/32][64] f16: same bytes as the f32 qkv
-                CS_TRY(dense(SH_OUT_SPLIT, xs, ws + sl.qkv, bqkv, nullptr, nullptr, qkvs, T, 3 * H, H));  // E2
-                CS_TRY(mark(CS_STAGE_QKV));
                 // CLS pooling reads ONE row per sequence of the last layer: its attention needs every key and value but
                 // only the CLS query, and everything behind it runs on nb rows instead of nb * L (cls_tail.hip).  Same
                 // embedding, 1/12 less work at 12 layers.  Compact rows live in the (idle) intermediate buffer of the slice.
@@ -252,10 +250,15 @@ int32_t forward_range(cs_embedder* h, hipStream_t s, uint32_t b0, uint32_t nb, u
                     float* x_cls = mid;                                            // [nb, H] f32
                     _Float16* xs_cls = reinterpret_cast<_Float16*>(mid + (size_t)nb * H);       // [nb][H/32][64]
                     _Float16* ctxs_cls = reinterpret_cast<_Float16*>(mid + (size_t)2 * nb * H);
-                    _Float16* mids_cls = reinterpret_cast<_Float16*>(mid + (size_t)3 * nb * H);  // [nb][I/32][64]
-                    CS_TRY(launch_attention_cls(qkvs, mask, ctxs_cls, h->d_flag, nb, L, H, c.heads, s));   // E3, one query per sequence
-                    CS_TRY(mark(CS_STAGE_ATTENTION));
+                    _Float16* q_cls = reinterpret_cast<_Float16*>(mid + (size_t)3 * nb * H);
+                    _Float16* mids_cls = reinterpret_cast<_Float16*>(mid + (size_t)4 * nb * H);  // [nb][I/32][64]
+                    // E2: K and V for every token (the packed weight's rows H .. 3H: [T][2H/32][64]), Q for the CLS rows only
+                    CS_TRY(dense(SH_OUT_SPLIT, xs, ws + sl.qkv + (size_t)H * H * 2, bqkv + H, nullptr, nullptr, qkvs, T, 2 * H, H));
                     CS_TRY(launch_gather_cls(xs, x_cls, xs_cls, nb, L, H, s));
+                    CS_TRY(launch_gemm_split(SH_OUT_SPLIT, xs_cls, ws + sl.qkv, bqkv, nullptr, nullptr, q_cls, nb, H, H, h->d_flag, s));
+                    CS_TRY(mark(CS_STAGE_QKV));
+                    CS_TRY(launch_attention_cls(q_cls, qkvs, mask, ctxs_cls, h->d_flag, nb, L, H, c.heads, s));   // E3, one query per sequence
+                    CS_TRY(mark(CS_STAGE_ATTENTION));
                     EncoderLaunch t = a;
                     t.x = x_cls; t.xs = xs_cls; t.T = nb; t.L = 1; t.B = nb;
                     CS_TRY(launch_gemm_split(SH_OUT_F32_RESID, ctxs_cls, ws + sl.ao, P + lo.ao_b, x_cls, x_cls, nullptr, nb, H, H, h->d_flag, s));  // E4
@@ -274,6 +277,8 @@ int32_t forward_range(cs_embedder* h, hipStream_t s, uint32_t b0, uint32_t nb, u
                     CS_TRY(mark(CS_STAGE_POOL));
                     return CS_OK;
                 }
+                CS_TRY(dense(SH_OUT_SPLIT, xs, ws + sl.qkv, bqkv, nullptr, nullptr, qkvs, T, 3 * H, H));  // E2
+                CS_TRY(mark(CS_STAGE_QKV));
                 CS_TRY(launch_attention_sh2(qkvs, mask, ctxs, h->d_flag, nb, L, H, c.heads, s));                                 // E3
                 CS_TRY(mark(CS_STAGE_ATTENTION));
             }

@@ -72,10 +72,10 @@ int32_t launch_gemm_wide_ln(const _Float16* A, const _Float16* W, const float* b
                             const float* beta, float eps, float* X, _Float16* Xs, uint32_t M, uint32_t K, uint32_t* d_flag,
                             hipStream_t s, const _Float16* resid_split = nullptr);
 // cls_tail.hip: the last layer of a CLS-pooled model restricted to the B rows the embedding reads — attention of the CLS
-// query against every key (plain f32 on the split operands) -> ctxs_cls [B][H/32][64], and the gather of the residual
+// query q_cls [B][H/32][64] against every key of kv_split [T][2H/32][64] (plain f32 on the split operands) -> ctxs_cls, and the gather of the residual
 // stream's CLS rows -> x_cls [B, H] f32 + xs_cls split.
-int32_t launch_attention_cls(const _Float16* qkv_split, const int32_t* mask, _Float16* ctxs_cls, uint32_t* flag, uint32_t B,
-                             uint32_t L, uint32_t H, uint32_t heads, hipStream_t s);
+int32_t launch_attention_cls(const _Float16* q_cls, const _Float16* kv_split, const int32_t* mask, _Float16* ctxs_cls,
+                             uint32_t* flag, uint32_t B, uint32_t L, uint32_t H, uint32_t heads, hipStream_t s);
 int32_t launch_gather_cls(const _Float16* xs, float* x_cls, _Float16* xs_cls, uint32_t B, uint32_t L, uint32_t H, hipStream_t s);
 // ffn_fused.hip: X_out = LayerNorm(GELU(A W1^T + b1) W2^T + b2 + A) * gamma + beta in ONE persistent kernel per 128 rows
 // (hidden 384, intermediate % 128 == 0); A / Xs split form (Xs may be A), X optional f32 copy of the output.
