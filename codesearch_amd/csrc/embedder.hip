@@ -21,13 +21,25 @@ using namespace cs;
 // ---- submission queue (cs_embedder_submit_* / cs_embedder_wait*) -------------------------------------------------
 // One flush embeds everything queued; its rows stay in one device buffer until every ticket of the flush has been
 // collected.
-struct QueueFlush {
+// Result buffers are recycled through a small grow-only pool owned by the embedder (hipFree waits for the whole device:
+// freeing one per flush would stall every stream of the process between files).
+struct QueuePool {
+    std::mutex mu;
+    std::vector<std::pair<float*, size_t>> free_bufs;  // (pointer, capacity in floats)
     int device = 0;
+    ~QueuePool() {
+        cs::DeviceGuard g(device);
+        for (auto& b : free_bufs) (void)hipFree(b.first);
+    }
+};
+struct QueueFlush {
+    std::shared_ptr<QueuePool> pool;
     float* d_rows = nullptr;
+    size_t cap = 0;
     ~QueueFlush() {
         if (!d_rows) return;
-        cs::DeviceGuard g(device);
-        (void)hipFree(d_rows);
+        std::lock_guard<std::mutex> lk(pool->mu);
+        pool->free_bufs.emplace_back(d_rows, cap);
     }
 };
 struct QueueEntry {
@@ -45,6 +57,7 @@ struct cs_embedder {
     std::mutex qmu;                 // the queue below
     std::mutex cmu;                 // one flush at a time (and excludes nothing else: embed_* keep `&mut self` rules)
     std::map<uint64_t, std::shared_ptr<QueueEntry>> queue;  // by ticket = submission order
+    std::shared_ptr<QueuePool> qpool;
     uint64_t next_ticket = 1;
     int device = 0;
     cs_bert_config cfg{};
@@ -675,10 +688,27 @@ int32_t flush_queue(cs_embedder* h, const volatile int32_t* cancel) {
             seqs.push_back(SeqView{e->ids[r].data(), e->mask.empty() || e->mask[r].empty() ? nullptr : e->mask[r].data(),
                                    (uint32_t)e->ids[r].size()});
     auto fl = std::make_shared<QueueFlush>();
-    fl->device = h->device;
+    {
+        std::lock_guard<std::mutex> lk(h->qmu);
+        if (!h->qpool) { h->qpool = std::make_shared<QueuePool>(); h->qpool->device = h->device; }
+        fl->pool = h->qpool;
+    }
     const int32_t st = [&]() -> int32_t {
         DeviceGuard g(h->device);
-        CS_HIP(hipMalloc(&fl->d_rows, seqs.size() * H * sizeof(float)));
+        const size_t need = seqs.size() * H;
+        {   // smallest pooled buffer that fits, else a new one
+            std::lock_guard<std::mutex> lk(fl->pool->mu);
+            auto& fb = fl->pool->free_bufs;
+            size_t best = fb.size();
+            for (size_t i = 0; i < fb.size(); ++i)
+                if (fb[i].second >= need && (best == fb.size() || fb[i].second < fb[best].second)) best = i;
+            if (best < fb.size()) { fl->d_rows = fb[best].first; fl->cap = fb[best].second; fb.erase(fb.begin() + best); }
+        }
+        if (!fl->d_rows) {
+            const size_t cap = std::max<size_t>(need, (size_t)default_batch(h) * H);
+            CS_HIP(hipMalloc(&fl->d_rows, cap * sizeof(float)));
+            fl->cap = cap;
+        }
         const size_t window = (size_t)batch * 16;
         std::vector<uint32_t> order;
         std::vector<int32_t> ids, mask;

@@ -330,8 +330,48 @@ gemm_wide_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ W,
 #pragma unroll
         for (int j = 0; j < 6; ++j)
             if (EPI != GW_OUT_LN) bv[j] = *reinterpret_cast<const sh_f32x4*>(bias + cbase + 16 * j);
+        // ABL 11 — the split-form epilogues WITHOUT the LDS patch: a lane holds four consecutive columns of
+        // tiles j and j + 1 of its row; after the split, v_permlane16_swap exchanges tile j + 1 of the even 16-lane rows
+        // with tile j of the odd ones, so every lane owns 8 consecutive columns = one 16-byte chunk of the row's 128-byte
+        // line (lane g -> chunk (g >> 1) + 2 (g & 1)) and stores it: 16 rows x 64 B per instruction, default cache policy.
+        constexpr bool SWAP_EPI = ABL == 11 && (EPI == SH_OUT_SPLIT || EPI == SH_OUT_SPLIT_GELU);
+        if constexpr (SWAP_EPI) {
+            const int chunk = (g >> 1) + 2 * (g & 1);
 #pragma unroll
-        for (int i = 0; i < (ABL == 6 ? 0 : 4); ++i) {
+            for (int i = 0; i < 4; ++i) {
+                const uint32_t m = wr * 64 + 16 * i + l15;
+                const bool live = full || m0 + m < M;
+#pragma unroll
+                for (int jp = 0; jp < 3; ++jp) {
+                    sh_f32x4 v0, v1;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        v0[r] = fmaf(acc.c[i][2 * jp][r], kShLoInv, bv[2 * jp][r]);
+                        v1[r] = fmaf(acc.c[i][2 * jp + 1][r], kShLoInv, bv[2 * jp + 1][r]);
+                        if (EPI == SH_OUT_SPLIT_GELU) { v0[r] = gw_gelu(v0[r]); v1[r] = gw_gelu(v1[r]); }
+                    }
+                    f16x8 hi, lo;
+                    sh_split8(v0, v1, hi, lo, mx);
+                    uint32_t* hw = reinterpret_cast<uint32_t*>(&hi);
+                    uint32_t* lw = reinterpret_cast<uint32_t*>(&lo);
+#pragma unroll
+                    for (int w2 = 0; w2 < 2; ++w2) {
+                        const auto sh = __builtin_amdgcn_permlane16_swap(hw[w2], hw[2 + w2], false, false);
+                        hw[w2] = sh[0]; hw[2 + w2] = sh[1];
+                        const auto sl = __builtin_amdgcn_permlane16_swap(lw[w2], lw[2 + w2], false, false);
+                        lw[w2] = sl[0]; lw[2 + w2] = sl[1];
+                    }
+                    if (live) {
+                        const uint32_t col = n0 + wc * 96 + 32 * jp;  // first column of the line
+                        _Float16* dst = Cs + ((size_t)(m0 + m) * (N / 32) + (col >> 5)) * 64 + chunk * 8;
+                        *reinterpret_cast<f16x8*>(dst) = hi;
+                        *reinterpret_cast<f16x8*>(dst + 32) = lo;
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < ((ABL == 6 || SWAP_EPI) ? 0 : 4); ++i) {
             // final values of strip i into the patch (row l15, columns 16 j + 4 g .. + 3)
             float inv = 1.0f;
             if (EPI == GW_OUT_LN) inv = rowstat[wr * 64 + 16 * i + l15];
@@ -554,6 +594,19 @@ static int32_t gemm_wide_launch(int epi, const _Float16* A, const _Float16* W, c
             CS_HIP(hipGetLastError());
             return CS_OK;
         }
+    }
+    static const bool epi_swap = [] { const char* e = std::getenv("CS_GEMM_WIDE_EPI_SWAP"); return e && e[0] == '1'; }();
+    if (epi_swap && (epi == SH_OUT_SPLIT || epi == SH_OUT_SPLIT_GELU)) {
+        static PerDeviceOnce swap_attr;
+        CS_TRY(swap_attr.run([&]() -> int32_t {
+            CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wide_kernel<SH_OUT_SPLIT, 11, WCN>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
+            CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wide_kernel<SH_OUT_SPLIT_GELU, 11, WCN>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
+            return CS_OK;
+        }));
+        if (epi == SH_OUT_SPLIT) GW_LAUNCH(SH_OUT_SPLIT, 11);
+        else GW_LAUNCH(SH_OUT_SPLIT_GELU, 11);
+        CS_HIP(hipGetLastError());
+        return CS_OK;
     }
     if (epi == SH_OUT_F32) GW_LAUNCH(SH_OUT_F32, 0);
     else if (epi == SH_OUT_F32_RESID) GW_LAUNCH(SH_OUT_F32_RESID, 0);
