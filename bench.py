@@ -633,6 +633,20 @@ def main():
     bsrc = 0 if dist is not None else None
     torch.cuda.synchronize()
 
+    # N > 1: every shard must answer for its own rows before anything is timed — one planted query per shard (a noisy copy
+    # of a row living there; known on rank 0 only, broadcast like every query): the merged top-1 must be that row's global id
+    planted_ok = None
+    if dist is not None and world > 1:
+        from codesearch_amd.synth import synth_planted
+
+        planted_rows = [g * args.rows + (4242 + 1013 * g) % args.rows for g in range(world)]
+        planted = synth_planted(SEED, SEED + 7, planted_rows, args.dim)
+        planted_ok = []
+        for g in range(world):
+            pq = torch.from_numpy(planted[g:g + 1].copy()).to(dev) if rank == 0 else torch.zeros((1, args.dim), dtype=torch.float32, device=dev)
+            r = shard.search_device(pq, 1, args.k, broadcast_src=0)
+            torch.cuda.synchronize()
+            planted_ok.append(int(r["ids"][0].item()) & 0xFFFFFFFF == planted_rows[g])
     for _ in range(args.warmup):
         shard.search_device(d_q, args.nq, args.k, broadcast_src=bsrc)
     torch.cuda.synchronize()
@@ -737,6 +751,10 @@ def main():
             "roofline": roof,
             "top1": {"id": int(ids0[0][0]), "cos": float(cos0[0][0])},
         }
+        if planted_ok is not None:
+            line["multi_gpu_checks"] = {"planted_query_per_shard_returns_its_row": planted_ok}
+            if not all(planted_ok):
+                line["error"] = "a shard did not return its planted row"
         traffic_file = os.path.join(ROOT, "profiles", "scan_traffic.json")
         if os.path.exists(traffic_file):
             try:
