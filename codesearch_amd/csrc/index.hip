@@ -55,7 +55,7 @@ struct Workspace {
     BatchedState bs;
     size_t bs_nq = 0, bs_cand = 0, bs_carry = 0;
     SplitQueryWs qw;
-    size_t qw_elems = 0, qw_nq = 0;
+    size_t qw_elems = 0, qw_nq = 0, q8_elems = 0;
     uint32_t* h_overflow = nullptr;
 
     int32_t reserve_split_queries(uint32_t nq, uint32_t dim) {
@@ -66,10 +66,18 @@ struct Workspace {
             CS_HIP(hipMalloc(&qw.d_qsplit, elems * sizeof(_Float16)));
             qw_elems = elems;
         }
+        if (elems > q8_elems) {
+            if (qw.d_q8q) (void)hipFree(qw.d_q8q);
+            qw.d_q8q = nullptr; q8_elems = 0;
+            CS_HIP(hipMalloc(&qw.d_q8q, elems));
+            q8_elems = elems;
+        }
         if (nq > qw_nq) {
             if (qw.d_qmag) (void)hipFree(qw.d_qmag);
-            qw.d_qmag = nullptr; qw_nq = 0;
+            if (qw.d_qmeta) (void)hipFree(qw.d_qmeta);
+            qw.d_qmag = nullptr; qw.d_qmeta = nullptr; qw_nq = 0;
             CS_HIP(hipMalloc(&qw.d_qmag, nq * sizeof(float)));
+            CS_HIP(hipMalloc(&qw.d_qmeta, nq * sizeof(float2)));
             qw_nq = nq;
         }
         return CS_OK;
@@ -202,6 +210,8 @@ struct Workspace {
         if (bs.d_overflow) (void)hipFree(bs.d_overflow);
         if (qw.d_qsplit) (void)hipFree(qw.d_qsplit);
         if (qw.d_qmag) (void)hipFree(qw.d_qmag);
+        if (qw.d_q8q) (void)hipFree(qw.d_q8q);
+        if (qw.d_qmeta) (void)hipFree(qw.d_qmeta);
         for (auto& t : free_events) {
             (void)hipEventDestroy(t.e0); (void)hipEventDestroy(t.e1); (void)hipEventDestroy(t.e2);
         }
@@ -228,6 +238,11 @@ struct cs_index {
     _Float16* d_split = nullptr;  // unit rows [0, split_rows) as f16 [row][dim]: filter operand of the batched path
     uint64_t split_rows = 0;
     bool use_split = false;
+    // int8 filter copy (scan_filter.hip): complete 128-row tiles [0, q8_rows / 128), a quarter of the f32 bytes
+    int8_t* d_q8 = nullptr;
+    float2* d_tmeta = nullptr;
+    uint64_t q8_rows = 0;
+    bool use_q8 = false;
     float filter_margin = 0.0f;  // scan_filter.hip: bound of the f16 filter's error for this dim
     int filter_min_q = 2;  // query count from which the f16 filter + exact refine path is used
     uint32_t single_filter_min_k = 100;  // ... and one query too from this k on, over >= 2M rows (0 = never)
@@ -305,6 +320,7 @@ int32_t grow(cs_index* h, uint64_t need_rows) {
             if (h->d_split) (void)hipFree(h->d_split);
             h->d_split = nullptr;
             h->split_rows = 0;
+            h->q8_rows = 0;
         } else {
             if (h->split_rows)
                 CS_HIP(hipMemcpy(ns, h->d_split, ((size_t)h->split_rows + 127) / 128 * 128 * h->dim * sizeof(_Float16),
@@ -312,6 +328,26 @@ int32_t grow(cs_index* h, uint64_t need_rows) {
             if (h->d_split) (void)hipFree(h->d_split);
             h->d_split = ns;
         }
+    }
+    if (h->use_split && h->use_q8) {
+        int8_t* n8 = nullptr;
+        float2* nm = nullptr;
+        const size_t tiles = ((size_t)cap + 127) / 128;
+        if (hipMalloc(&n8, tiles * 128 * h->dim) != hipSuccess || hipMalloc(&nm, tiles * sizeof(float2)) != hipSuccess) {
+            (void)hipGetLastError();  // no room: the filter stays on the f16 copy
+            if (n8) (void)hipFree(n8);
+            h->use_q8 = false;
+            h->q8_rows = 0;
+        } else {
+            if (h->q8_rows) {
+                CS_HIP(hipMemcpy(n8, h->d_q8, (size_t)h->q8_rows * h->dim, hipMemcpyDeviceToDevice));
+                CS_HIP(hipMemcpy(nm, h->d_tmeta, (size_t)(h->q8_rows / 128) * sizeof(float2), hipMemcpyDeviceToDevice));
+            }
+        }
+        if (h->d_q8) (void)hipFree(h->d_q8);
+        if (h->d_tmeta) (void)hipFree(h->d_tmeta);
+        h->d_q8 = h->use_q8 ? n8 : nullptr;
+        h->d_tmeta = h->use_q8 ? nm : nullptr;
     }
     CS_HIP(hipMemset(nd, 0, words * sizeof(uint32_t)));
     if (h->normed_rows)
@@ -440,9 +476,11 @@ int32_t run_search(cs_index* h, Workspace* w, const ScanPlan& plan, const float*
         CS_TRY(w->reserve_batched(nq, k));
         if (use_filter) {
             CS_TRY(w->reserve_split_queries(nq, h->dim));
+            Q8View q8;
+            if (h->use_q8 && h->d_q8) { q8.d_q8 = h->d_q8; q8.d_tmeta = h->d_tmeta; q8.rows = h->q8_rows; }
             CS_TRY(launch_scan_split(w->bs, w->qw, h->d_corpus, h->d_split, h->n_rows, h->dim,
                                      d_queries, nq, k, h->n_removed ? h->d_dead : nullptr, h->id_base, d_keys,
-                                     d_cos, d_ids, d_counts, stream, h->filter_margin));
+                                     d_cos, d_ids, d_counts, stream, h->filter_margin, &q8));
         } else {
             CS_TRY(launch_scan_batched(w->bs, h->d_corpus, h->d_norms, h->n_rows, h->dim, d_queries, nq, k,
                                        h->n_removed ? h->d_dead : nullptr, h->id_base, h->num_cus, d_keys, d_cos,
@@ -585,6 +623,8 @@ int32_t cs_index_create(uint32_t dim, uint64_t capacity_rows, int32_t device, ui
     {
         const char* env = std::getenv("CS_INDEX_SPLIT");  // "0": keep the batched path on the exact-f32 MFMA
         h->use_split = split_scan_supported(dim) && !(env && env[0] == '0');
+        const char* e8 = std::getenv("CS_FILTER_INT8");  // "0": filter on the f16 copy only
+        h->use_q8 = h->use_split && !(e8 && e8[0] == '0');
         if (const char* e = std::getenv("CS_FILTER_MIN_Q")) {
             h->filter_min_q = std::atoi(e);
             if (h->filter_min_q < 1) h->filter_min_q = 1;
@@ -630,6 +670,8 @@ void cs_index_destroy(cs_index* h) {
     if (h->d_dead) (void)hipFree(h->d_dead);
     if (h->d_norms) (void)hipFree(h->d_norms);
     if (h->d_split) (void)hipFree(h->d_split);
+    if (h->d_q8) (void)hipFree(h->d_q8);
+    if (h->d_tmeta) (void)hipFree(h->d_tmeta);
     delete h;
 }
 
@@ -715,6 +757,12 @@ int32_t cs_index_build(cs_index* h) {
         CS_HIP(hipDeviceSynchronize());
         h->split_rows = h->n_rows;
     }
+    if (h->use_q8 && h->d_q8 && h->q8_rows / 128 < h->n_rows / 128) {  // tiles that became complete
+        CS_TRY(launch_corpus_q8(h->d_corpus, h->d_norms, h->d_q8, h->d_tmeta, h->q8_rows / 128,
+                                h->n_rows / 128 - h->q8_rows / 128, h->dim, nullptr));
+        CS_HIP(hipDeviceSynchronize());
+        h->q8_rows = h->n_rows / 128 * 128;
+    }
     h->built = true;                 // store.rs:428
     return CS_OK;
 }
@@ -728,6 +776,7 @@ int32_t cs_index_clear(cs_index* h) {
     h->n_rows = 0;  // store.rs:701 next_id = 0
     h->normed_rows = 0;
     h->split_rows = 0;
+    h->q8_rows = 0;
     h->n_removed = 0;
     h->h_dead.clear();
     h->built = false;  // store.rs:702

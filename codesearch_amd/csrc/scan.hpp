@@ -114,8 +114,19 @@ struct SplitQueryWs {
     // d_queries is an empty device buffer — the prep kernel reads them from here and fills it,
     // which saves the H2D copy call (~6 us of a 45-us search over a small corpus).  Null otherwise.
     const float* q_pinned = nullptr;
+    int8_t* d_q8q = nullptr;       // [nq][dim] int8: q / |q| on the query's own scale (int8 filter copy)
+    float2* d_qmeta = nullptr;     // [nq] {127 / max |q_i / |q||, 0.5001 sum |b_i| + 0.2501 dim + guard}
+};
+// int8 filter copy of the corpus (scan_filter.hip, "int8 filter copy"): complete 128-row tiles [0, rows / 128)
+struct Q8View {
+    const int8_t* d_q8 = nullptr;    // [tile][dim / 128][128 rows][128 B]
+    const float2* d_tmeta = nullptr; // [tile] {127 / max |u|, 0.5001 max row sum |a_i|}; x = NaN: every row is a candidate
+    uint64_t rows = 0;               // multiple of 128
 };
 bool split_scan_supported(uint32_t dim);
+// rows [first_tile * 128, (first_tile + ntiles) * 128) of the f32 corpus -> int8 tiles + their scales
+int32_t launch_corpus_q8(const float* d_corpus, const float* d_norms, int8_t* d_q8, float2* d_tmeta, uint64_t first_tile,
+                         uint64_t ntiles, uint32_t dim, hipStream_t stream);
 // rows [first, first+n) of the f32 corpus, divided by their norms, as f16 -> the filter copy
 // [rows][dim] (same row order; half the bytes of the f32 matrix)
 int32_t launch_corpus_split(const float* d_corpus, const float* d_norms, _Float16* d_split, uint64_t first,
@@ -124,7 +135,7 @@ int32_t launch_corpus_split(const float* d_corpus, const float* d_norms, _Float1
 int32_t launch_scan_split(const BatchedState& st, const SplitQueryWs& qw, const float* d_corpus,
                           const _Float16* d_split, uint64_t n_rows, uint32_t dim, const float* d_queries, uint32_t nq, uint32_t k, const uint32_t* d_dead,
                           uint32_t id_base, uint64_t* d_out_keys, float* d_out_cos, uint32_t* d_out_ids,
-                          uint32_t* d_out_counts, hipStream_t stream, float margin);
+                          uint32_t* d_out_counts, hipStream_t stream, float margin, const Q8View* q8 = nullptr);
 // Proven bound of |filter cosine - exact cosine| for unit vectors of this width (scan_filter.hip header);
 // `subnormals_exact` = the f16 MFMA consumes subnormal inputs exactly (sh_denorm_selftest).
 float filter_margin(uint32_t dim, bool subnormals_exact);

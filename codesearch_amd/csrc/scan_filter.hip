@@ -115,6 +115,42 @@ __device__ __forceinline__ float half_sum_s(float v) {
     return v;
 }
 
+// int8 filter operands (section "int8 filter copy" below)
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x16 __attribute__((ext_vector_type(16)));
+constexpr float kQ8Half = 0.5001f, kQ8Quarter = 0.2501f, kQ8Guard = 4.0f;
+__host__ __device__ __forceinline__ float q8_slack(uint32_t dim) { return (float)dim * 1.1920929e-07f + 4.0e-5f; }
+
+__device__ __forceinline__ int half_sum_i(int v) {
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 8, 64);
+    v += __shfl_xor(v, 4, 64);
+    v += __shfl_xor(v, 2, 64);
+    v += __shfl_xor(v, 1, 64);
+    return v;
+}
+__device__ __forceinline__ float half_max_q8(float v) {
+    v = fmaxf(v, __shfl_xor(v, 16, 64));
+    v = fmaxf(v, __shfl_xor(v, 8, 64));
+    v = fmaxf(v, __shfl_xor(v, 4, 64));
+    v = fmaxf(v, __shfl_xor(v, 2, 64));
+    v = fmaxf(v, __shfl_xor(v, 1, 64));
+    return v;
+}
+// four unit values -> four int8 in one dword (element 0 in the low byte), and the sum of their magnitudes
+__device__ __forceinline__ uint32_t q8_pack4(const f32x4 u, float inv, int& abs_sum) {
+    uint32_t w = 0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        float r = rintf(u[e] * inv);
+        r = fminf(fmaxf(r, -127.0f), 127.0f);  // NaN -> -127 (fmaxf drops it): such a tile is flagged anyway
+        const int a = (int)r;
+        abs_sum += a < 0 ? -a : a;
+        w |= ((uint32_t)a & 0xffu) << (8 * e);
+    }
+    return w;
+}
+
 // Everything a batched search needs before its first phase, in one launch (three kernels of ~2 us
 // each cost ~12 us of launch gaps — a quarter of a search over the reference's own 592-chunk index):
 // per query, one half-wave computes |q| with the single-query scan's arithmetic (scan.hip, "query
@@ -124,7 +160,8 @@ template <int J>
 __global__ void __launch_bounds__(256)
 prep_queries_kernel(const float* __restrict__ queries, float* __restrict__ qcopy, uint32_t nq,
                     float* __restrict__ qmag, _Float16* __restrict__ qunit, float* __restrict__ tau, uint32_t* __restrict__ cnt,
-                    uint64_t* __restrict__ carry, uint32_t k, uint32_t* __restrict__ overflow, uint32_t first_rows) {
+                    uint64_t* __restrict__ carry, uint32_t k, uint32_t* __restrict__ overflow, uint32_t first_rows,
+                    int8_t* __restrict__ q8q, float2* __restrict__ qmeta) {
     constexpr int DIM = 128 * J;
     const int lane = threadIdx.x & 63, half = lane >> 5, l32 = lane & 31;
     const uint32_t q = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 2 + half;
@@ -150,6 +187,25 @@ prep_queries_kernel(const float* __restrict__ queries, float* __restrict__ qcopy
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] = (_Float16)(m == 0.0f ? 0.0f : v[j][e] / m);
         *reinterpret_cast<f16x4*>(qunit + (size_t)q * DIM + (l32 + 32 * j) * 4) = o;
+    }
+    if (q8q) {  // int8 filter operand ("int8 filter copy" below): q / |q| on the query's own scale
+        float mx = 0.0f;
+#pragma unroll
+        for (int j = 0; j < J; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) mx = fmaxf(mx, fabsf(m == 0.0f ? 0.0f : v[j][e] / m));
+        mx = half_max_q8(mx);
+        const float inv = (mx > 0.0f && mx < __builtin_huge_valf()) ? 127.0f / mx : 1.0f;
+        int abs_sum = 0;
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            f32x4 u;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) u[e] = m == 0.0f ? 0.0f : v[j][e] / m;
+            *reinterpret_cast<uint32_t*>(q8q + (size_t)q * DIM + (l32 + 32 * j) * 4) = q8_pack4(u, inv, abs_sum);
+        }
+        abs_sum = half_sum_i(abs_sum);
+        if (l32 == 0) qmeta[q] = make_float2(inv, kQ8Half * (float)abs_sum + kQ8Quarter * (float)DIM + kQ8Guard);
     }
     for (uint32_t i = l32; i < k; i += 32) carry[(size_t)q * k + i] = 0ull;
     if (l32 == 0) {
@@ -677,7 +733,7 @@ score_filter256p_kernel(const _Float16* __restrict__ corpus_h, uint64_t row_lo, 
 // tile and a private ring of R 4-KiB slots filled by LDS-DMA, R-1 stages (3 x 16 KB per CU at
 // NQT = 1, see RCAP) in flight across tile boundaries under counted vmcnt — no barrier in the loop,
 // since a wave only reads rows it loaded itself.
-template <int NQT, int KC = 6>  // KC = dim / 64 k-chunks per row: 6 / 12 / 16 for dim 384 / 768 / 1024
+template <int NQT, int KC = 6, int RCAP_ = (NQT == 1 ? 4 : 8)>  // KC = dim / 64 k-chunks per row: 6 / 12 / 16 for dim 384 / 768 / 1024
 struct RwGeom {
     static constexpr int QROWS = 32 * NQT;
     static constexpr int WBYTES = KC * QROWS * 128;            // resident queries: KC chunks x QROWS x 128 B
@@ -687,7 +743,7 @@ struct RwGeom {
     // the memory system rewards fewer outstanding requests (benchmarks/hbm_read_probe.hip; 8 queries over
     // 10M x 384: 1.284 -> 1.270 ms, 9 queries k = 200: 1.420 -> 1.413; 3 slots measure the same, 768 / 1024-d
     // within 0.5 % either way).
-    static constexpr int RCAP = NQT == 1 ? 4 : 8;
+    static constexpr int RCAP = RCAP_;
     static constexpr int R = RMAX > RCAP ? RCAP : RMAX;              // ring slots (16 KiB each, 4 KiB per wave):
                                                                // dim 384: 4 / 6 / 3 at NQT 1 / 2 / 4; 768: 4 / 3; 1024: 4
     static constexpr int LDS = WBYTES + R * 16384;             // dim 384: 90,112 / 147,456 / 147,456 B
@@ -909,6 +965,261 @@ rescore_keys_kernel(const float* __restrict__ corpus, const float* __restrict__ 
     }
 }
 
+// ---- int8 filter copy -----------------------------------------------------------------------------
+// A third, quarter-size copy of the corpus for the resident-query kernel: unit rows quantised to int8 with one
+// scale per 128-row tile, scored on v_mfma_i32_32x32x32_i8 (exact integer dot products), the same 16-KiB stages,
+// LDS image and ring as score_filter_rw_kernel — a 128-B line now holds 128 k instead of 64, so a 384-d tile
+// is 3 stages instead of 6 and the filter streams 1 byte per element.
+//
+//   u_i = x_i / |x|  (f32, the arithmetic of unit_f16_rows_kernel);  inv_t = 127 / max |u_i| over the tile;
+//   a_i = rint(u_i * inv_t)  in [-127, 127];   queries the same with their own inv_q, b_i = rint(v_i * inv_q).
+//
+// Bound.  With s_t = 1 / inv_t, s_q = 1 / inv_q:  u_i = s_t (a_i + e_i),  v_i = s_q (b_i + d_i),  |e_i|, |d_i| <=
+// 0.5 + 127 * 2^-24 (the f32 rounding of the product before rint), so
+//   sum u_i v_i = s_t s_q (I + sum b_i e_i + sum a_i d_i + sum e_i d_i),   I = sum a_i b_i  (the MFMA's output, exact)
+//   |sum u_i v_i - s_t s_q I| <= s_t s_q (0.5001 (A_q + B_t) + 0.2501 dim),   A_q = sum |b_i|,  B_t = max over the tile's rows of sum |a_i|.
+// The refine's cosine differs from sum u_i v_i by f32 rounding only (<= dim * 2^-23 + 4e-5, kQ8Slack).  A row whose
+// exact cosine beats tau therefore has
+//   I > (tau - slack) * inv_q * inv_t - 0.5001 (A_q + B_t) - 0.2501 dim
+// and the kernel appends every row above that line lowered by 4 more units (rounding of the f32 expression itself:
+// its terms stay below 2^23, inv <= 127 sqrt(dim)).  In cosine units the band is ~0.024 at 384-d for Gaussian-like
+// rows (the f16 copy: 0.001): a few dozen extra candidates per query at k = 10 over 10M random rows, a few thousand per
+// phase at k = 200 — against half the bytes streamed.  A tile holding a non-finite value has inv_t = NaN and all its
+// rows become candidates (the refine decides).  Only complete tiles are quantised (a tile is written once, when
+// cs_index_build first sees it full: a search running beside a build never reads a tile being rewritten); the rows
+// behind the last complete tile are appended as candidates outright (tail_candidates_kernel, < 128 rows).
+// One block per 128-row tile (tiles tile0 .. tile0 + gridDim.x - 1): pass 1 finds the tile's largest unit magnitude,
+// pass 2 (the tile is in L2 now) quantises.  A half-wave per row; lane l32 holds float4 l32 + 32 j of the row, i.e.
+// bytes 4 l32 .. 4 l32 + 3 of the row's line in k-chunk j of [tile][chunk of 128 k][row][128 B].
+template <int J>
+__global__ void __launch_bounds__(256)
+corpus_q8_kernel(const float* __restrict__ corpus, const float* __restrict__ row_norm, int8_t* __restrict__ q8,
+                 float2* __restrict__ tmeta, uint64_t tile0) {
+    constexpr int DIM = 128 * J;
+    __shared__ float s_max[8];
+    __shared__ int s_bad[8], s_abs[8];
+    const uint64_t tile = tile0 + blockIdx.x;
+    const int tid = threadIdx.x, l32 = tid & 31, hw = tid >> 5;
+    float mx = 0.0f;
+    int bad = 0;
+    for (int r = hw; r < 128; r += 8) {
+        const uint64_t row = tile * 128 + r;
+        const float nrm = row_norm[row];
+        const f32x4* p = reinterpret_cast<const f32x4*>(corpus + row * DIM) + l32;
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            const f32x4 v = p[j * 32];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float u = fabsf(nrm == 0.0f ? 0.0f : v[e] / nrm);
+                if (!(u < __builtin_huge_valf())) bad = 1;
+                mx = fmaxf(mx, u);
+            }
+        }
+    }
+    mx = half_max_q8(mx);
+    bad = half_sum_i(bad);
+    if (l32 == 0) { s_max[hw] = mx; s_bad[hw] = bad; }
+    __syncthreads();
+    mx = 0.0f;
+    bad = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { mx = fmaxf(mx, s_max[i]); bad |= s_bad[i]; }
+    const float inv = mx > 0.0f ? 127.0f / mx : 1.0f;
+    int bmax = 0;
+    for (int r = hw; r < 128; r += 8) {
+        const uint64_t row = tile * 128 + r;
+        const float nrm = row_norm[row];
+        const f32x4* p = reinterpret_cast<const f32x4*>(corpus + row * DIM) + l32;
+        int abs_sum = 0;
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            const f32x4 v = p[j * 32];
+            f32x4 u;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) u[e] = nrm == 0.0f ? 0.0f : v[e] / nrm;
+            const uint32_t w = q8_pack4(u, inv, abs_sum);
+            *reinterpret_cast<uint32_t*>(q8 + ((tile * J + j) * 128 + r) * 128 + l32 * 4) = w;
+        }
+        abs_sum = half_sum_i(abs_sum);
+        bmax = abs_sum > bmax ? abs_sum : bmax;
+    }
+    if (l32 == 0) s_abs[hw] = bmax;
+    __syncthreads();
+    if (tid == 0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) bmax = s_abs[i] > bmax ? s_abs[i] : bmax;
+        tmeta[tile] = make_float2(bad ? __builtin_nanf("") : inv, kQ8Half * (float)bmax);
+    }
+}
+
+// rows [lo, hi) (fewer than 128: the incomplete last tile) become candidates of every query
+__global__ void __launch_bounds__(128)
+tail_candidates_kernel(uint64_t lo, uint64_t hi, const uint32_t* __restrict__ dead, uint32_t* __restrict__ cand,
+                       uint32_t* __restrict__ cnt, uint32_t cap) {
+    const uint32_t q = blockIdx.x;
+    const uint64_t row = lo + threadIdx.x;
+    if (row >= hi) return;
+    if (dead && ((dead[row >> 5] >> (row & 31)) & 1u)) return;
+    const uint32_t pos = atomicAdd(&cnt[(size_t)q * kCntStride], 1u);
+    if (pos < cap) cand[2 * ((size_t)q * cap + pos)] = (uint32_t)row;
+}
+
+// Ring depth of the int8 kernel (slots of 16 KiB; R - 1 stages in flight per CU).  Up to 32 queries: 3 — 8 queries
+// k = 10 over 10M x 384: 0.687 ms at 3, 0.704 at 4, 0.698 / 0.704 at 6 / 8 (the f16 kernel's finding, one step further).
+#ifndef CS_RW8_RCAP1
+#define CS_RW8_RCAP1 3
+#endif
+#ifndef CS_RW8_RCAP2
+#define CS_RW8_RCAP2 8
+#endif
+template <int NQT, int KC>
+using Rw8Geom = RwGeom<NQT, KC, (NQT == 1 ? CS_RW8_RCAP1 : CS_RW8_RCAP2)>;
+
+// score_filter_rw_kernel over the int8 copy.  KC = dim / 128 stages per tile; rows [row_lo, row_hi) are whole tiles.
+template <int NQT, int KC>
+__global__ void __launch_bounds__(256)
+score_filter_rw8_kernel(const int8_t* __restrict__ corpus_q8, const float2* __restrict__ tmeta, uint64_t row_lo,
+                        uint64_t row_hi, const int8_t* __restrict__ queries_q8, const float2* __restrict__ qmeta,
+                        uint32_t nq, const float* __restrict__ tau, const uint32_t* __restrict__ dead,
+                        uint32_t* __restrict__ cand, uint32_t* __restrict__ cnt, uint32_t cap, uint32_t qtiles,
+                        uint32_t nt_stream, float slack) {
+    using G = Rw8Geom<NQT, KC>;
+    const bool NT = nt_stream != 0 && qtiles == 1;
+    constexpr int R = G::R;
+    constexpr int DIM = 128 * KC;
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    char* Wl = lds;                 // [KC][QROWS][128 B], slots swizzled as in uf_mainloop
+    char* ring = lds + G::WBYTES;   // [R][4 waves][32 rows][128 B]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, h = lane >> 5;
+    const uint64_t tile_lo = row_lo >> 7;  // row_lo, row_hi are multiples of 128
+    const uint64_t ntile = (row_hi - row_lo) >> 7;
+    const int8_t* base = corpus_q8 + tile_lo * KC * 128 * 128;
+    const float2* tm = tmeta + tile_lo;
+    const uint32_t xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const uint32_t qt = slot % qtiles, rg = slot / qtiles, rgn = (gridDim.x >> 3) / qtiles;
+    if (rg >= rgn) return;
+    const uint32_t q0 = qt * G::QROWS;
+
+#pragma unroll
+    for (int i = 0; i < KC * NQT; ++i) {
+        const int g8 = wave * KC * NQT + i;
+        const int c = g8 / (4 * NQT), r8 = g8 % (4 * NQT);
+        const int row = r8 * 8 + (lane >> 3);
+        const int pc = (lane & 7) ^ ((row >> 1) & 7);
+        const uint32_t q = q0 + row < nq ? q0 + row : nq - 1;
+        sh_glds16(reinterpret_cast<const _Float16*>(queries_q8 + (size_t)q * DIM + c * 128 + pc * 16),
+                  Wl + (c * G::QROWS + r8 * 8) * 128);
+    }
+    uf_wait_vmcnt<0>();
+    __syncthreads();
+
+    // per query (lane & 31): tqs = (tau - slack) * inv_q and cq = 0.5001 A_q + 0.2501 dim + guard
+    float tqs[NQT], cq[NQT];
+    bool qok[NQT];
+#pragma unroll
+    for (int t = 0; t < NQT; ++t) {
+        const uint32_t q = q0 + 32 * t + l31;
+        qok[t] = q < nq;
+        const float2 m = qmeta[qok[t] ? q : 0];
+        tqs[t] = (tau[qok[t] ? q : 0] - slack) * m.x;
+        cq[t] = m.y;
+    }
+
+    const int swz = (l31 >> 1) & 7;
+    int a_sl[4];
+#pragma unroll
+    for (int st = 0; st < 4; ++st) a_sl[st] = l31 * 128 + (((2 * st + h) ^ swz) * 16);
+    char* myring = ring + wave * 4096;
+    auto issue = [&](uint64_t tile, int c, int slot) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = i * 8 + (lane >> 3);
+            const int pc = (lane & 7) ^ ((row >> 1) & 7);
+            const _Float16* src = reinterpret_cast<const _Float16*>(base + ((tile * KC + c) * 128 + wave * 32 + row) * 128 + pc * 16);
+            if (NT) sh_glds16_nt(src, myring + slot * 16384 + i * 1024);
+            else sh_glds16(src, myring + slot * 16384 + i * 1024);
+        }
+    };
+
+    const uint64_t t0 = (uint64_t)rg * 8 + xcd, tstep = (uint64_t)rgn * 8;
+    if (t0 >= ntile) return;
+    const uint64_t my_tiles = (ntile - t0 + tstep - 1) / tstep;
+    const uint64_t nstage = my_tiles * KC;
+    uint64_t gi = 0;
+    uint64_t i_tile = t0;
+    int i_c = 0, i_slot = 0;
+    auto issue_next = [&]() {
+        issue(i_tile, i_c, i_slot);
+        ++gi;
+        if (++i_c == KC) { i_c = 0; i_tile += tstep; }
+        if (++i_slot == R) i_slot = 0;
+    };
+    for (int p = 0; p < R - 1; ++p)
+        if (gi < nstage) issue_next();
+
+    volatile uint64_t* pend = reinterpret_cast<volatile uint64_t*>(lds + G::LDS) + wave * kPend;
+    uint32_t npend = 0;  // wave-uniform
+
+    i32x16 acc[NQT];
+    int c_slot = 0;
+    // tile scales: scalar loads (uniform address, read-only data) — they count on lgkmcnt, not on the vmcnt the ring
+    // is paced by — fetched one tile ahead
+    float2 tm_next = tm[t0];
+    for (uint64_t n = 0; n < my_tiles; ++n) {
+        const uint64_t tile = t0 + n * tstep;
+        const float2 tmv = tm_next;
+        tm_next = tm[n + 1 < my_tiles ? tile + tstep : tile];
+#pragma unroll
+        for (int t = 0; t < NQT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][r] = 0;
+#pragma unroll
+        for (int c = 0; c < KC; ++c) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (gi < nstage) {
+                issue_next();
+                uf_wait_vmcnt<4 * (R - 1)>();
+            } else {
+                uf_wait_vmcnt<0>();
+            }
+            const char* slot = myring + c_slot * 16384;
+            if (++c_slot == R) c_slot = 0;
+            const char* wc = Wl + c * G::QROWS * 128;
+#pragma unroll
+            for (int st = 0; st < 4; ++st) {
+                const i32x4 a = *reinterpret_cast<const i32x4*>(slot + a_sl[st]);
+#pragma unroll
+                for (int t = 0; t < NQT; ++t) {
+                    const i32x4 w = *reinterpret_cast<const i32x4*>(wc + t * 32 * 128 + a_sl[st]);
+                    acc[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, w, acc[t], 0, 0, 0);
+                }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < NQT; ++t) {
+            // I > T  <=>  I > floor(T) for an integer I; NaN (flagged tile or query) -> every row
+            const float T = floorf(fmaf(tqs[t], tmv.x, -(tmv.y + cq[t])));
+            const int Ti = (T == T) ? (T < -2.0e9f ? (int)0x80000000 : (T > 2.0e9f ? 0x7fffffff : (int)T)) : (int)0x80000000;
+            const bool all = !(T == T) || T < -2.0e9f;
+            // most tiles hold no candidate for anybody: one test of the lane's largest product instead of sixteen
+            int top = acc[t][0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) top = acc[t][r] > top ? acc[t][r] : top;
+            if (!__ballot(qok[t] && (all || top > Ti))) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const uint64_t m = tile * 128 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                cand_push(qok[t] && (all || acc[t][r] > Ti), q0 + 32 * t + l31, row_lo + m, dead, pend, npend, lane, cand,
+                          cnt, cap);
+            }
+        }
+    }
+    cand_flush(pend, npend, lane, cand, cnt, cap);
+}
+
 // ---- host side ----------------------------------------------------------------------------
 
 bool split_scan_supported(uint32_t dim) { return dim == 384 || dim == 768 || dim == 1024; }
@@ -929,11 +1240,26 @@ int32_t launch_corpus_split(const float* d_corpus, const float* d_norms, _Float1
     return launch_unit_f16(d_corpus + first * dim, d_norms + first, d_split, n, dim, stream, 1, first);
 }
 
+int32_t launch_corpus_q8(const float* d_corpus, const float* d_norms, int8_t* d_q8, float2* d_tmeta, uint64_t first_tile,
+                         uint64_t ntiles, uint32_t dim, hipStream_t stream) {
+    for (uint64_t t = 0; t < ntiles;) {  // grid.x stays below 2^31
+        const uint32_t n = (uint32_t)std::min<uint64_t>(ntiles - t, 1u << 30);
+        if (dim == 384) hipLaunchKernelGGL(corpus_q8_kernel<3>, dim3(n), dim3(256), 0, stream, d_corpus, d_norms, d_q8, d_tmeta, first_tile + t);
+        else if (dim == 768) hipLaunchKernelGGL(corpus_q8_kernel<6>, dim3(n), dim3(256), 0, stream, d_corpus, d_norms, d_q8, d_tmeta, first_tile + t);
+        else if (dim == 1024) hipLaunchKernelGGL(corpus_q8_kernel<8>, dim3(n), dim3(256), 0, stream, d_corpus, d_norms, d_q8, d_tmeta, first_tile + t);
+        else return fail(CS_ERR_UNSUPPORTED, "int8 filter copy supports dim 384/768/1024, got %u", dim);
+        CS_HIP(hipGetLastError());
+        t += n;
+    }
+    return CS_OK;
+}
+
 template <int J>
 static int32_t scan_split_impl(const BatchedState& st, const SplitQueryWs& qw, const float* d_corpus,
                                const _Float16* d_split, uint64_t n_rows, const float* d_queries, uint32_t nq, uint32_t k, const uint32_t* d_dead,
                                uint32_t id_base, uint64_t* d_out_keys, float* d_out_cos,
-                               uint32_t* d_out_ids, uint32_t* d_out_counts, hipStream_t stream, float margin) {
+                               uint32_t* d_out_ids, uint32_t* d_out_counts, hipStream_t stream, float margin,
+                               const Q8View* q8) {
     constexpr uint32_t dim = 128 * J;
     const uint32_t cap = batched_cap(k);
     static PerDeviceOnce attr_set;  // function attributes are per device
@@ -962,13 +1288,28 @@ static int32_t scan_split_impl(const BatchedState& st, const SplitQueryWs& qw, c
             CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(score_filter_rw_kernel<1, 16>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, RwGeom<1, 16>::LDS_ALL));
         }
+        CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(score_filter_rw8_kernel<1, J>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, Rw8Geom<1, J>::LDS_ALL));
+        CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(score_filter_rw8_kernel<2, J>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, Rw8Geom<2, J>::LDS_ALL));
+        if constexpr (J <= 6)
+            CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(score_filter_rw8_kernel<4, J>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, Rw8Geom<4, J>::LDS_ALL));
 
         return CS_OK;
     }));
+    // int8 copy: the resident-query kernel's operand whenever one exists (up to 64 queries; up to 128 at dim <= 768,
+    // where the f16 path would switch to its 128-row tile kernel) and covers at least one tile behind phase 0
+    static const uint32_t q8_max_env = [] {
+        const char* e = std::getenv("CS_FILTER_INT8_MAX_Q");  // A/B: query count up to which the int8 copy is the operand
+        return e ? (uint32_t)std::atoi(e) : 0u;
+    }();
+    const uint32_t q8_max_q = q8_max_env ? std::min(q8_max_env, dim <= 768 ? 128u : 64u) : (dim <= 768 ? 128u : 64u);
+    const bool use_q8 = q8 && q8->d_q8 && q8->rows > 1024 && nq <= q8_max_q && qw.d_q8q && qw.d_qmeta;
     hipLaunchKernelGGL(prep_queries_kernel<J>, dim3((nq + 7) / 8), dim3(256), 0, stream,
                        qw.q_pinned ? qw.q_pinned : d_queries, qw.q_pinned ? const_cast<float*>(d_queries) : nullptr, nq,
                        qw.d_qmag, qw.d_qsplit, st.d_tau, st.d_cnt, st.d_carry, k, st.d_overflow,
-                       (uint32_t)(n_rows < 1024 ? n_rows : 1024));
+                       (uint32_t)(n_rows < 1024 ? n_rows : 1024), use_q8 ? qw.d_q8q : nullptr, qw.d_qmeta);
     CS_HIP(hipGetLastError());
     uint32_t* cand = reinterpret_cast<uint32_t*>(st.d_cand);
     const uint32_t ntiles = (nq + SH_BN - 1) / SH_BN;
@@ -1010,7 +1351,43 @@ static int32_t scan_split_impl(const BatchedState& st, const SplitQueryWs& qw, c
         const uint64_t lo = done, hi = done + phase;
         const bool first = lo == 0;  // phase 0 goes straight to the refine (rescore_keys_kernel, first_rows)
         if (hi > lo && !first) {
-            if (small) {
+            if (use_q8) {
+                static int cus8 = 0;  // one persistent block per CU (grid rounded down to whole XCD octets)
+                if (!cus8) {
+                    int dev = 0, n = 0;
+                    if (hipGetDevice(&dev) == hipSuccess &&
+                        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n >= 8)
+                        cus8 = n / 8 * 8;
+                    else
+                        cus8 = 256;
+                }
+                const uint64_t q_hi = hi < q8->rows ? hi : q8->rows;  // lo is a multiple of 1024
+                if (q_hi > lo) {
+                    const uint32_t per = nq <= 32 ? 32 : nq <= 64 ? 64 : 128;
+                    const uint32_t qtiles = (nq + per - 1) / per;
+                    const uint64_t tiles = (q_hi - lo) / 128;
+                    uint64_t slots = (tiles + 7) / 8 * qtiles;  // per XCD
+                    if (slots > (uint64_t)cus8 / 8) slots = (uint64_t)cus8 / 8;
+                    if (slots < qtiles) slots = qtiles;
+                    const uint32_t blocks = (uint32_t)slots * 8;
+                    static const uint32_t nt_stream8 = [] {
+                        const char* e = std::getenv("CS_FILTER_NT");
+                        return (uint32_t)!(e && e[0] == '0');
+                    }();
+#define CS_RW8_LAUNCH(NQT_)                                                                                        \
+    hipLaunchKernelGGL((score_filter_rw8_kernel<NQT_, J>), dim3(blocks), dim3(256), (Rw8Geom<NQT_, J>::LDS_ALL), stream, \
+                       q8->d_q8, q8->d_tmeta, lo, q_hi, qw.d_q8q, qw.d_qmeta, nq, st.d_tau, d_dead, cand, st.d_cnt, cap, \
+                       qtiles, nt_stream8, q8_slack(dim))
+                    if (per == 32) CS_RW8_LAUNCH(1);
+                    else if (per == 64) CS_RW8_LAUNCH(2);
+                    else if constexpr (J <= 6) CS_RW8_LAUNCH(4);
+#undef CS_RW8_LAUNCH
+                    CS_HIP(hipGetLastError());
+                }
+                const uint64_t t_lo = lo > q8->rows ? lo : q8->rows;
+                if (hi > t_lo)  // fewer than 128 rows behind the last complete tile
+                    hipLaunchKernelGGL(tail_candidates_kernel, dim3(nq), dim3(128), 0, stream, t_lo, hi, d_dead, cand, st.d_cnt, cap);
+            } else if (small) {
                 static int cus = 0;  // one persistent block per CU (grid rounded down to whole XCD octets)
                 if (!cus) {
                     int dev = 0, n = 0;
@@ -1099,9 +1476,9 @@ static int32_t scan_split_impl(const BatchedState& st, const SplitQueryWs& qw, c
 int32_t launch_scan_split(const BatchedState& st, const SplitQueryWs& qw, const float* d_corpus,
                           const _Float16* d_split, uint64_t n_rows, uint32_t dim, const float* d_queries, uint32_t nq, uint32_t k, const uint32_t* d_dead,
                           uint32_t id_base, uint64_t* d_out_keys, float* d_out_cos, uint32_t* d_out_ids,
-                          uint32_t* d_out_counts, hipStream_t stream, float margin) {
+                          uint32_t* d_out_counts, hipStream_t stream, float margin, const Q8View* q8) {
 #define CS_SPLIT_ARGS st, qw, d_corpus, d_split, n_rows, d_queries, nq, k, d_dead, id_base, d_out_keys, \
-                      d_out_cos, d_out_ids, d_out_counts, stream, margin
+                      d_out_cos, d_out_ids, d_out_counts, stream, margin, q8
     if (dim == 384) return scan_split_impl<3>(CS_SPLIT_ARGS);
     if (dim == 768) return scan_split_impl<6>(CS_SPLIT_ARGS);
     if (dim == 1024) return scan_split_impl<8>(CS_SPLIT_ARGS);

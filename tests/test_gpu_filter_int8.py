@@ -1,0 +1,150 @@
+"""The int8 filter copy (scan_filter.hip, "int8 filter copy"): a quarter-size quantised copy of the corpus feeds the
+filter of batched searches of up to 128 queries; the refine step re-scores its candidates from the f32 rows, so the
+results must stay bit-identical to the single-query exact scan — whatever the data does to the quantiser.  Needs an
+MI355X.  The same shapes run with CS_FILTER_INT8=0 so that the f16 resident-query kernel stays covered."""
+import numpy as np
+import pytest
+
+from codesearch_amd.synth import synth_planted, synth_rows
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def VS(gpu_lib):
+    from codesearch_amd import VectorStore
+
+    assert gpu_lib.cs_device_count() >= 1, "no HIP device visible"
+    return VectorStore
+
+
+def _same_as_single_query_scans(st, qs, k):
+    cos, ids, counts = st.search_raw(qs, k)
+    assert st.debug_counters()[1] == 0, "candidate buffer overflowed: the filter path was not what answered"
+    for i in range(len(qs)):
+        c1, i1, n1 = st.search_raw(qs[i], k)
+        assert counts[i] == n1[0]
+        assert ids[i].tolist() == i1[0].tolist(), i
+        assert cos[i].tobytes() == c1[0].tobytes(), i
+    return cos, ids, counts
+
+
+@pytest.mark.parametrize("int8", ["1", "0"])
+@pytest.mark.parametrize("dim,n,nq,k", [(384, 300_000, 2, 10), (384, 200_003, 9, 200), (384, 150_000, 33, 10),
+                                        (384, 100_100, 64, 25), (384, 120_000, 100, 10), (384, 90_000, 128, 40),
+                                        (768, 60_000, 9, 200), (768, 50_001, 64, 10), (768, 40_000, 96, 10),
+                                        (1024, 50_001, 32, 10), (1024, 40_000, 64, 100)])
+def test_filter_copy_choice_does_not_change_a_bit(VS, monkeypatch, int8, dim, n, nq, k):
+    monkeypatch.setenv("CS_FILTER_INT8", int8)
+    # keep single queries on the streaming f32 scan: it is the yardstick here
+    monkeypatch.setenv("CS_FILTER_SINGLE_MIN_K", "0")
+    st = VS(None, dim)
+    st.insert_synthetic(n, 99 + dim, 0)
+    st.delete_chunks([3, n // 2, n - 1])
+    st.build_index()
+    qs = np.concatenate([synth_rows(7 + nq, 0, nq - 1, dim), synth_planted(99 + dim, 5, [n // 3], dim)])
+    cos, ids, _ = _same_as_single_query_scans(st, qs, k)
+    assert ids[nq - 1][0] == n // 3
+
+
+def test_rows_that_stress_the_quantiser(VS, oracle, monkeypatch):
+    """Outlier elements (one huge coordinate: the tile's scale collapses for everyone else), sparse rows, rows of
+    wildly different magnitudes, zero rows, NaN / Inf rows inside a tile, thousands of near-duplicates of the query
+    (cosines inside the quantisation band of each other around every k-th place)."""
+    monkeypatch.setenv("CS_FILTER_SINGLE_MIN_K", "0")
+    dim, n, nq, k = 384, 40_000, 12, 50
+    rng = np.random.default_rng(2024)
+    corpus = oracle.synth_rows(515, 0, n, dim).copy()
+    corpus[5::97, 17] = 40.0            # outlier coordinate: unit vector ~ e_17
+    corpus[7::101] = 0.0
+    corpus[7::101, ::64] = 1.0          # sparse rows
+    corpus[11::53] *= np.float32(1e6)
+    corpus[13::59] *= np.float32(1e-12)
+    corpus[300] = 0.0
+    corpus[301, 9] = np.nan
+    corpus[302, 10] = np.inf
+    corpus[303, 11] = -np.inf
+    base = oracle.synth_rows(516, 0, 1, dim)[0]
+    dup = np.arange(2000, 6000)         # 4,000 rows within ~1e-3 of each other in cosine to query 0
+    corpus[dup] = base[None, :] + rng.normal(0, 2e-3, (len(dup), dim)).astype(np.float32)
+    st = VS(None, dim)
+    st.insert_embeddings(corpus)
+    st.delete_chunks([2500, 2501, 39_999])
+    st.build_index()
+    qs = synth_rows(517, 0, nq, dim).copy()
+    qs[0] = base
+    qs[1] = 0.0
+    qs[1, 17] = 1.0                      # a one-hot query: its own scale is as coarse as it gets
+    qs[2] *= np.float32(1e-7)
+    qs[3] = corpus[5] * np.float32(3.0)
+    cos, ids, counts = st.search_raw(qs, k)
+    for i in range(nq):
+        c1, i1, n1 = st.search_raw(qs[i], k)
+        assert counts[i] == n1[0] and ids[i].tolist() == i1[0].tolist() and cos[i].tobytes() == c1[0].tobytes(), i
+    bad = {301, 302, 303}
+    assert not (set(ids[0][: counts[0]].tolist()) & bad)
+    # and against the CPU oracle for the near-duplicate query
+    ok = np.array([r for r in range(n) if r not in bad and r not in (2500, 2501, 39_999)])
+    ecos, eids = oracle.scan_topk(corpus[ok], qs[0], k, mode="omp")
+    np.testing.assert_allclose(cos[0], ecos, atol=2e-6)
+    assert set(ids[0].tolist()) <= set(dup.tolist())
+
+
+@pytest.mark.parametrize("n", [1025, 1100, 1151, 1152, 1153, 2047, 2048, 2049, 9_999])
+def test_tail_rows_behind_the_last_complete_tile(VS, monkeypatch, n):
+    """Only complete 128-row tiles are quantised; the rows behind them are candidates outright — planted best
+    matches sit in the tail, in the last complete tile and right behind phase 0."""
+    monkeypatch.setenv("CS_FILTER_SINGLE_MIN_K", "0")
+    dim, nq, k = 384, 5, 7
+    st = VS(None, dim)
+    st.insert_synthetic(n, 31, 0)
+    st.delete_chunks([n - 2])
+    st.build_index()
+    plant = [n - 1, n // 128 * 128 - 1, 1024, 0, n - 2]  # tail, last complete tile, first row behind phase 0, ...
+    qs = synth_planted(31, 5, plant, dim)
+    cos, ids, counts = _same_as_single_query_scans(st, qs, k)
+    for i, p in enumerate(plant):
+        if p != n - 2:
+            assert ids[i][0] == p
+        else:
+            assert p not in ids[i].tolist()  # tombstoned in the tail
+
+
+def test_tiles_are_quantised_as_they_fill_up(VS, monkeypatch):
+    """Appends after a build: the partial tile of the first build is quantised by the build that sees it full;
+    rows in between are served from the tail path; clear() starts over; growth keeps the copy."""
+    monkeypatch.setenv("CS_FILTER_SINGLE_MIN_K", "0")
+    dim, nq, k = 384, 9, 20
+    st = VS(None, dim)
+    total = 0
+    for step, add in enumerate([1500, 37, 91, 4000, 128, 1, 20_000]):
+        st.insert_synthetic(add, 77, total)
+        total += add
+        st.build_index()
+        qs = np.concatenate([synth_rows(5 + step, 0, nq - 2, dim), synth_planted(77, 5, [total - 1, total // 2], dim)])
+        cos, ids, _ = _same_as_single_query_scans(st, qs, k)
+        assert ids[nq - 2][0] == total - 1 and ids[nq - 1][0] == total // 2
+    st.clear()
+    st.insert_synthetic(5000, 78, 0)
+    st.build_index()
+    qs = np.concatenate([synth_rows(55, 0, nq - 1, dim), synth_planted(78, 5, [4999], dim)])
+    cos, ids, _ = _same_as_single_query_scans(st, qs, k)
+    assert ids[nq - 1][0] == 4999
+
+
+def test_int8_filter_over_10m_rows_k10_and_k200(VS, monkeypatch):
+    """BASELINE's 10M x 384 through the int8 copy: 8 queries k = 10 and the reference's default hybrid shape
+    (9 variants, retrieval limit 200) — bit-identical to the f16 copy's answers, no overflow."""
+    monkeypatch.setenv("CS_FILTER_SINGLE_MIN_K", "0")
+    dim, n = 384, 10_000_000
+    st = VS(None, dim)
+    st.insert_synthetic(n, 4242, 0)
+    st.build_index()
+    for nq, k in ((8, 10), (9, 200), (64, 10), (128, 10)):
+        qs = np.concatenate([synth_rows(1000 + nq, 0, nq - 1, dim), synth_planted(4242, 5, [n - 5], dim)])
+        cos, ids, counts = st.search_raw(qs, k)
+        assert st.debug_counters()[1] == 0
+        assert ids[nq - 1][0] == n - 5
+        for i in (0, nq - 1):
+            c1, i1, n1 = st.search_raw(qs[i], k)
+            assert ids[i].tolist() == i1[0].tolist() and cos[i].tobytes() == c1[0].tobytes()
