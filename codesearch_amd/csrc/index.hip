@@ -332,7 +332,7 @@ int32_t grow(cs_index* h, uint64_t need_rows) {
     if (h->use_split && h->use_q8) {
         int8_t* n8 = nullptr;
         float2* nm = nullptr;
-        const size_t tiles = ((size_t)cap + 127) / 128;
+        const size_t tiles = ((size_t)cap + 255) / 256 * 2;  // an even number: the 256-row tile kernel reads whole pairs
         if (hipMalloc(&n8, tiles * 128 * h->dim) != hipSuccess || hipMalloc(&nm, tiles * sizeof(float2)) != hipSuccess) {
             (void)hipGetLastError();  // no room: the filter stays on the f16 copy
             if (n8) (void)hipFree(n8);

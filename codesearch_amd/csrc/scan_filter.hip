@@ -37,6 +37,7 @@
 // of scan_mfma.hip.  Serves `variants.par_iter().map(|e| store.search(e, limit))`
 // (/root/reference/src/search/mod.rs:508-511) and BASELINE.json configs 4/5.
 #include <cstdlib>
+#include <type_traits>
 
 #include "scan.hpp"
 #include "split_f16.hpp"
@@ -533,11 +534,21 @@ score_filter256_kernel(const _Float16* __restrict__ corpus_h, uint64_t row_lo, u
 // sh_tile_of_block is kept) and issues stage 0 of its NEXT tile between the MFMAs of the current
 // tile's last stage, into the buffer that stage leaves free; the threshold epilogue then runs under
 // that load.  Main loop as in score_filter256_kernel<false> (DMA issue spread through the MFMAs).
+//
+// I8: the same kernel over the int8 copy ("int8 filter copy" above).  A 128-B line is 128 k instead of 64, the MFMA is
+// v_mfma_i32_16x16x64_i8 on the same 16-B fragments — every address below is unchanged, with kchunks = dim / 128 and
+// the int8 buffers passed as if they were f16 (64 two-byte elements per line) — at twice the f16 rate per matrix
+// instruction.  A wave's 64 rows lie in ONE 128-row corpus tile (tile 2 mt + (wr >> 1)), so its scale is a scalar;
+// `margin` carries the slack and tmeta / qmeta the scales (see score_filter_rw8_kernel for the threshold).
+template <bool I8>
 __global__ void __launch_bounds__(512, 2)
 score_filter256p_kernel(const _Float16* __restrict__ corpus_h, uint64_t row_lo, uint64_t row_hi, uint32_t kchunks,
                         const _Float16* __restrict__ queries_h, uint32_t nq, const float* __restrict__ tau,
                         const uint32_t* __restrict__ dead, uint32_t* __restrict__ cand,
-                        uint32_t* __restrict__ cnt, uint32_t cap, uint32_t total_slots, float margin) {
+                        uint32_t* __restrict__ cnt, uint32_t cap, uint32_t total_slots, float margin,
+                        const float2* __restrict__ tmeta, const float2* __restrict__ qmeta) {
+    using Frag = typename std::conditional<I8, i32x4, f16x8>::type;
+    using Acc = typename std::conditional<I8, i32x4, sh_f32x4v>::type;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const uint32_t M = (uint32_t)(row_hi - row_lo);
     const uint32_t mtiles = (M + UF2_BM - 1) / UF2_BM, ntiles = (nq + UF2_BN - 1) / UF2_BN;
@@ -575,14 +586,14 @@ score_filter256p_kernel(const _Float16* __restrict__ corpus_h, uint64_t row_lo, 
     for (int s = 0; s < 2; ++s) sl[s] = ((4 * s + g) ^ swz) * 16;
     const uint32_t lds_base = (uint32_t)(uintptr_t)lds;
     // fragments of a k32 step s: 4 corpus row groups (load_a), and 4 of the 8 query groups (load_w, qh = 0, 1)
-    auto load_a = [&](uint32_t stage_off, int s, f16x8 (&f)[4]) {
+    auto load_a = [&](uint32_t stage_off, int s, Frag (&f)[4]) {
         const uint32_t aa = lds_base + stage_off + arow + sl[s];
         asm volatile("ds_read_b128 %0, %1" : "=v"(f[0]) : "v"(aa));
         asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(f[1]) : "v"(aa));
         asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(f[2]) : "v"(aa));
         asm volatile("ds_read_b128 %0, %1 offset:6144" : "=v"(f[3]) : "v"(aa));
     };
-    auto load_w = [&](uint32_t stage_off, int s, int qh, f16x8 (&f)[4]) {
+    auto load_w = [&](uint32_t stage_off, int s, int qh, Frag (&f)[4]) {
         const uint32_t ww = lds_base + stage_off + wrow + sl[s] + qh * 8192;
         asm volatile("ds_read_b128 %0, %1" : "=v"(f[0]) : "v"(ww));
         asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(f[1]) : "v"(ww));
@@ -622,24 +633,25 @@ score_filter256p_kernel(const _Float16* __restrict__ corpus_h, uint64_t row_lo, 
             tile_ptrs(mtn, ntn, a_nxt, w_nxt);
             krn = sh_kc_rot(ntn, ntiles, kchunks);
         }
-        sh_f32x4v acc[4][8];
+        Acc acc[4][8];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 8; ++j)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.0f;
+                for (int r = 0; r < 4; ++r) acc[i][j][r] = 0;
         // sixteen MFMAs (4 row groups x 4 query groups jb..jb+3) of half a k32 step; with `issue`, DMA pieces
         // q0..q0+3 (0..3 corpus, 4..7 queries) of chunk kcn — of this tile, or of the next tile's stage 0
         // when `from_next` — after MFMAs 4, 8, 12, 16
-        auto mfma16 = [&](const f16x8 (&fa)[4], const f16x8 (&fw)[4], int jb, bool issue, bool from_next, int q0,
+        auto mfma16 = [&](const Frag (&fa)[4], const Frag (&fw)[4], int jb, bool issue, bool from_next, int q0,
                           uint32_t kcn, char* nbuf) {
             char* dst = nbuf + wave * 32 * 128;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
-                    acc[i][jb + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[i], fw[j], acc[i][jb + j], 0, 0, 0);
+                    if constexpr (I8) acc[i][jb + j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[i], fw[j], acc[i][jb + j], 0, 0, 0);
+                    else acc[i][jb + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[i], fw[j], acc[i][jb + j], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
                 if (issue) {
                     const int q = q0 + j;
@@ -657,7 +669,7 @@ score_filter256p_kernel(const _Float16* __restrict__ corpus_h, uint64_t row_lo, 
         sh_wait_vmcnt<0>();             // this wave's pieces of the tile's stage 0 (and the last epilogue's stores)
         __builtin_amdgcn_s_barrier();   // ... and everybody else's
         __builtin_amdgcn_sched_barrier(0);
-        f16x8 a0[4], a1[4], w0[4], w1[4];
+        Frag a0[4], a1[4], w0[4], w1[4];
         load_a(par * UF2_STAGE, 0, a0);
         load_w(par * UF2_STAGE, 0, 0, w0);
         for (uint32_t kc = 0; kc < kchunks; ++kc) {
@@ -693,17 +705,34 @@ score_filter256p_kernel(const _Float16* __restrict__ corpus_h, uint64_t row_lo, 
         // threshold epilogue of (mt, nt) while the next tile's stage 0 is in flight
         // (C/D of the 16x16 MFMA: query = lane & 15, row = 4 (lane >> 4) + r)
         const uint32_t m0 = mt * UF2_BM, n0 = nt * UF2_BN;
+        float2 tmv = make_float2(0.0f, 0.0f);
+        if constexpr (I8) tmv = tmeta[(row_lo >> 7) + 2 * mt + (wr >> 1)];  // uniform: a scalar load (rows past M: masked)
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const uint32_t q = n0 + wc * 128 + j * 16 + l15;
             const bool qok = q < nq;
-            const float tq = qok ? tau[q] - margin : 0.0f;
+            // f16: score > tau - margin.  int8: I > floor((tau - slack) inv_q inv_t - 0.5001 (A_q + B_t) - ...), as an
+            // integer compare; a NaN threshold (flagged tile) or tau = -inf takes every row
+            float tq = 0.0f;
+            int ti = 0;
+            bool all = false;
+            if constexpr (I8) {
+                const float2 qm = qmeta[qok ? q : 0];
+                const float T = floorf(fmaf((tau[qok ? q : 0] - margin) * qm.x, tmv.x, -(tmv.y + qm.y)));
+                all = !(T == T) || T < -2.0e9f;
+                ti = T > 2.0e9f ? 0x7fffffff : (int)T;
+            } else {
+                tq = qok ? tau[q] - margin : 0.0f;
+            }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const uint32_t m = m0 + wr * 64 + i * 16 + 4 * g + r;
-                    if (qok && m < M && !(acc[i][j][r] <= tq)) {
+                    bool hit;
+                    if constexpr (I8) hit = all || acc[i][j][r] > ti;
+                    else hit = !(acc[i][j][r] <= tq);
+                    if (qok && m < M && hit) {
                         const uint64_t row = row_lo + m;
                         if (!dead || !((dead[row >> 5] >> (row & 31)) & 1u)) {
                             const uint32_t pos = atomicAdd(&cnt[(size_t)q * kCntStride], 1u);
@@ -1270,7 +1299,9 @@ static int32_t scan_split_impl(const BatchedState& st, const SplitQueryWs& qw, c
                                    hipFuncAttributeMaxDynamicSharedMemorySize, UF2_LDS));
         CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(score_filter256_kernel<true>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, UF2_LDS));
-        CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(score_filter256p_kernel),
+        CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(score_filter256p_kernel<false>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, UF2_LDS));
+        CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(score_filter256p_kernel<true>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, UF2_LDS));
         if constexpr (J == 3) {
             CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(score_filter_rw_kernel<1, 6>),
@@ -1295,17 +1326,28 @@ static int32_t scan_split_impl(const BatchedState& st, const SplitQueryWs& qw, c
         if constexpr (J <= 6)
             CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(score_filter_rw8_kernel<4, J>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, Rw8Geom<4, J>::LDS_ALL));
+        if constexpr (J == 3)
+            CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(score_filter_rw8_kernel<8, J>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, Rw8Geom<8, J>::LDS_ALL));
 
         return CS_OK;
     }));
-    // int8 copy: the resident-query kernel's operand whenever one exists (up to 64 queries; up to 128 at dim <= 768,
-    // where the f16 path would switch to its 128-row tile kernel) and covers at least one tile behind phase 0
+    // int8 copy: the filter's operand whenever one exists and covers at least one tile behind phase 0
     static const uint32_t q8_max_env = [] {
         const char* e = std::getenv("CS_FILTER_INT8_MAX_Q");  // A/B: query count up to which the int8 copy is the operand
         return e ? (uint32_t)std::atoi(e) : 0u;
     }();
-    const uint32_t q8_max_q = q8_max_env ? std::min(q8_max_env, dim <= 768 ? 128u : 64u) : (dim <= 768 ? 128u : 64u);
-    const bool use_q8 = q8 && q8->d_q8 && q8->rows > 1024 && nq <= q8_max_q && qw.d_q8q && qw.d_qmeta;
+    static const uint32_t q8_rw_env = [] {
+        const char* e = std::getenv("CS_FILTER_INT8_RW_MAX_Q");  // A/B: ... and up to which its resident-query kernel runs
+        return e ? (uint32_t)std::atoi(e) : 0u;
+    }();
+    // one persistent block per (query tile, row group) slot of an XCD: at most 32 query tiles
+    const uint32_t q8_rw_limit = dim <= 768 ? 32u * 128u : 32u * 64u;
+    // Measured over 10M x 384, k = 10, 129 / 256 / 512 / 1,000 queries: f16 256 x 256 tiles 2.79 / 2.88 / 5.12 / 8.92 ms,
+    // the same tile kernel on int8 2.30 / 2.45 / 4.36 / 7.98 (LDS traffic, not MFMA rate, paces it), the resident-query
+    // kernel on int8 1.61 / 1.82 / 3.20 / 5.95 — so the tile kernel only takes what exceeds 32 query tiles.
+    const uint32_t q8_rw_max = q8_rw_env ? std::min(q8_rw_env, q8_rw_limit) : q8_rw_limit;
+    const bool use_q8 = q8 && q8->d_q8 && q8->rows > 1024 && (!q8_max_env || nq <= q8_max_env) && qw.d_q8q && qw.d_qmeta;
     hipLaunchKernelGGL(prep_queries_kernel<J>, dim3((nq + 7) / 8), dim3(256), 0, stream,
                        qw.q_pinned ? qw.q_pinned : d_queries, qw.q_pinned ? const_cast<float*>(d_queries) : nullptr, nq,
                        qw.d_qmag, qw.d_qsplit, st.d_tau, st.d_cnt, st.d_carry, k, st.d_overflow,
@@ -1362,8 +1404,23 @@ static int32_t scan_split_impl(const BatchedState& st, const SplitQueryWs& qw, c
                         cus8 = 256;
                 }
                 const uint64_t q_hi = hi < q8->rows ? hi : q8->rows;  // lo is a multiple of 1024
-                if (q_hi > lo) {
-                    const uint32_t per = nq <= 32 ? 32 : nq <= 64 ? 64 : 128;
+                if (q_hi > lo && nq > q8_rw_max) {
+                    const uint32_t mt2 = (uint32_t)((q_hi - lo + UF2_BM - 1) / UF2_BM), nt2 = (nq + UF2_BN - 1) / UF2_BN;
+                    const uint32_t slots = sh_grid_blocks(mt2, nt2);
+                    const uint32_t grid = std::min<uint32_t>(slots, (uint32_t)cus8);  // a multiple of 8: a block stays on its XCD slot
+                    hipLaunchKernelGGL(score_filter256p_kernel<true>, dim3(grid), dim3(512), UF2_LDS, stream,
+                                       reinterpret_cast<const _Float16*>(q8->d_q8), lo, q_hi, dim / 128,
+                                       reinterpret_cast<const _Float16*>(qw.d_q8q), nq, st.d_tau, d_dead, cand, st.d_cnt, cap,
+                                       slots, q8_slack(dim), q8->d_tmeta, qw.d_qmeta);
+                    CS_HIP(hipGetLastError());
+                } else if (q_hi > lo) {
+                    // above 128 queries at dim 384: 256 resident queries per block — half the query tiles re-reading the
+                    // corpus through L2 (1,000 queries over 10M rows: 7.21 -> 5.95 ms; 129: 1.97 -> 1.61); "0" = A/B
+                    static const bool rw8_256 = [] {
+                        const char* e = std::getenv("CS_FILTER_INT8_RW256");
+                        return !(e && e[0] == '0');
+                    }();
+                    const uint32_t per = nq <= 32 ? 32 : (nq <= 64 || J > 6) ? 64 : (J == 3 && rw8_256 && nq > 128) ? 256 : 128;
                     const uint32_t qtiles = (nq + per - 1) / per;
                     const uint64_t tiles = (q_hi - lo) / 128;
                     uint64_t slots = (tiles + 7) / 8 * qtiles;  // per XCD
@@ -1380,6 +1437,7 @@ static int32_t scan_split_impl(const BatchedState& st, const SplitQueryWs& qw, c
                        qtiles, nt_stream8, q8_slack(dim))
                     if (per == 32) CS_RW8_LAUNCH(1);
                     else if (per == 64) CS_RW8_LAUNCH(2);
+                    else if constexpr (J == 3) { if (per == 256) CS_RW8_LAUNCH(8); else CS_RW8_LAUNCH(4); }
                     else if constexpr (J <= 6) CS_RW8_LAUNCH(4);
 #undef CS_RW8_LAUNCH
                     CS_HIP(hipGetLastError());
@@ -1442,8 +1500,9 @@ static int32_t scan_split_impl(const BatchedState& st, const SplitQueryWs& qw, c
                     }
                     const uint32_t slots = sh_grid_blocks(mt2, nt2);
                     const uint32_t grid = std::min<uint32_t>(slots, ((uint32_t)cus + 7) / 8 * 8);  // a multiple of 8: a block stays on its XCD slot
-                    hipLaunchKernelGGL(score_filter256p_kernel, dim3(grid), dim3(512), UF2_LDS, stream, d_split, lo, hi,
-                                       dim / 64, qw.d_qsplit, nq, st.d_tau, d_dead, cand, st.d_cnt, cap, slots, margin);
+                    hipLaunchKernelGGL(score_filter256p_kernel<false>, dim3(grid), dim3(512), UF2_LDS, stream, d_split, lo, hi,
+                                       dim / 64, qw.d_qsplit, nq, st.d_tau, d_dead, cand, st.d_cnt, cap, slots, margin,
+                                       (const float2*)nullptr, (const float2*)nullptr);
                 } else if (legacy256)
                     hipLaunchKernelGGL(score_filter256_kernel<true>, dim3(sh_grid_blocks(mt2, nt2)), dim3(512), UF2_LDS,
                                        stream, d_split, lo, hi, dim / 64, qw.d_qsplit, nq, st.d_tau, d_dead, cand,

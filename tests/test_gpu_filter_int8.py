@@ -33,7 +33,11 @@ def _same_as_single_query_scans(st, qs, k):
 @pytest.mark.parametrize("dim,n,nq,k", [(384, 300_000, 2, 10), (384, 200_003, 9, 200), (384, 150_000, 33, 10),
                                         (384, 100_100, 64, 25), (384, 120_000, 100, 10), (384, 90_000, 128, 40),
                                         (768, 60_000, 9, 200), (768, 50_001, 64, 10), (768, 40_000, 96, 10),
-                                        (1024, 50_001, 32, 10), (1024, 40_000, 64, 100)])
+                                        (1024, 50_001, 32, 10), (1024, 40_000, 64, 100),
+                                        # several query tiles per row group (int8: 256 / 128 / 64 resident queries per
+                                        # block at 384 / 768 / 1024; f16: the 256 x 256 tile kernel)
+                                        (384, 50_000, 300, 10), (384, 40_000, 1000, 10), (384, 30_000, 129, 100),
+                                        (768, 30_000, 200, 25), (1024, 20_000, 130, 10)])
 def test_filter_copy_choice_does_not_change_a_bit(VS, monkeypatch, int8, dim, n, nq, k):
     monkeypatch.setenv("CS_FILTER_INT8", int8)
     # keep single queries on the streaming f32 scan: it is the yardstick here
@@ -45,6 +49,27 @@ def test_filter_copy_choice_does_not_change_a_bit(VS, monkeypatch, int8, dim, n,
     qs = np.concatenate([synth_rows(7 + nq, 0, nq - 1, dim), synth_planted(99 + dim, 5, [n // 3], dim)])
     cos, ids, _ = _same_as_single_query_scans(st, qs, k)
     assert ids[nq - 1][0] == n // 3
+
+
+@pytest.mark.parametrize("dim,n,nq,k", [(384, 50_000, 300, 10), (384, 33_000, 1000, 10), (768, 20_100, 260, 25),
+                                        (1024, 10_000, 257, 10)])
+def test_int8_tile_kernel_for_query_counts_past_the_resident_limit(VS, monkeypatch, dim, n, nq, k):
+    """Past 32 query tiles the int8 copy goes through the 256 x 256 tile kernel (score_filter256p_kernel<true>);
+    CS_FILTER_INT8_RW_MAX_Q lowers the switch-over so that a few hundred queries reach it.  Odd tile counts: the last
+    256-row block holds one real 128-row tile."""
+    monkeypatch.setenv("CS_FILTER_INT8_RW_MAX_Q", "128")
+    monkeypatch.setenv("CS_FILTER_SINGLE_MIN_K", "0")
+    st = VS(None, dim)
+    st.insert_synthetic(n, 12 + dim, 0)
+    st.delete_chunks([7, n // 2])
+    st.build_index()
+    qs = np.concatenate([synth_rows(70 + nq, 0, nq - 1, dim), synth_planted(12 + dim, 5, [n - 1], dim)])
+    cos, ids, counts = st.search_raw(qs, k)
+    assert st.debug_counters()[1] == 0
+    for i in list(range(0, nq, 37)) + [nq - 1]:
+        c1, i1, n1 = st.search_raw(qs[i], k)
+        assert counts[i] == n1[0] and ids[i].tolist() == i1[0].tolist() and cos[i].tobytes() == c1[0].tobytes(), i
+    assert ids[nq - 1][0] == n - 1
 
 
 def test_rows_that_stress_the_quantiser(VS, oracle, monkeypatch):
@@ -140,7 +165,7 @@ def test_int8_filter_over_10m_rows_k10_and_k200(VS, monkeypatch):
     st = VS(None, dim)
     st.insert_synthetic(n, 4242, 0)
     st.build_index()
-    for nq, k in ((8, 10), (9, 200), (64, 10), (128, 10)):
+    for nq, k in ((8, 10), (9, 200), (64, 10), (128, 10), (300, 10)):
         qs = np.concatenate([synth_rows(1000 + nq, 0, nq - 1, dim), synth_planted(4242, 5, [n - 5], dim)])
         cos, ids, counts = st.search_raw(qs, k)
         assert st.debug_counters()[1] == 0
