@@ -42,6 +42,7 @@ if ROOT not in sys.path:
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: f32-input MFMA peak
 MFMA_F16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense f16/bf16 MFMA peak
+MFMA_I8_PEAK_TOPS = 5000.0  # MI355X_MICROARCH.md MFMA table: I8 32x32x32 / 16x16x64 = 2x the BF16 rate per clock
 SEED = 0xC0DE5EA
 
 
@@ -202,6 +203,21 @@ def encoder_legs(shard, k, device, with_cpu=True):
     gemm_exec, attn_exec, cls_tail = _encoder_flops_executed(cfg, B, L)
     split, f32n, fb = emb.debug_counters()
     emb.close()
+    # BASELINE.json words configs[2] as "mean-pool + L2-norm"; the reference's BGE model pools CLS (SURVEY.md §0 #4:
+    # fastembed's default for the BGE family), which is what `ms_per_batch` above times.  The same weights and shape
+    # with mean pooling (all 12 layers run whole; no CLS tail), for the record:
+    import dataclasses
+
+    from codesearch_amd.bert_params import POOL_MEAN
+    emb_mean = FastEmbedder(ModelType.BGESmallENV15, config=dataclasses.replace(cfg, pooling=POOL_MEAN), seed=202, device=device)
+    emb_mean.embed_ids_to_device(ids, mask, d_q.data_ptr())
+    emb_mean.profile_read(reset=True)
+    for _ in range(iters):
+        emb_mean.embed_ids_to_device(ids, mask, d_q.data_ptr())
+    torch.cuda.synchronize()
+    ms_mean, n_mean = emb_mean.profile_read()
+    ms_mean /= max(n_mean, 1)
+    emb_mean.close()
     sec = ms * 1e-3
     # split-f16: three f16 MFMAs per f32 product block, dense layers AND attention; with the CLS tail the last layer's
     # one-query attention runs in plain f32 on the vector unit (counted once, it is 0.002 % of the total)
@@ -223,6 +239,9 @@ def encoder_legs(shard, k, device, with_cpu=True):
         "workload": f"BGE-small-en-v1.5 shape (12 x [MHA, GELU FFN, LN], hidden 384), batch {B} x seq {L}, "
                     "synthetic weights, CLS pool + L2 normalise (BASELINE.json configs[2])",
         "ms_per_batch": ms, "chunks_per_s": B / sec,
+        "mean_pool_variant": {"ms_per_batch": ms_mean, "chunks_per_s": B / (ms_mean * 1e-3),
+                              "note": "same weights and shape with mask-weighted mean pooling: every layer runs whole "
+                                      "(BASELINE.json's wording of configs[2]; the reference's BGE model pools CLS)"},
         "algorithmic_tflops": (gemm_flops + attn_flops) / sec / 1e12,
         "dense_layers": "split-f16 operands on v_mfma_f32_16x16x32_f16, 3 MFMAs per f32 product block",
         "split_forwards": split, "f32_fallbacks": fb,
@@ -685,7 +704,31 @@ def main():
                         or (args.nq == 1 and single_min_k and args.k >= single_min_k and args.rows >= 2_000_000))
         filter_path = wants_filter and args.dim in (384, 768, 1024) and os.environ.get("CS_INDEX_SPLIT", "1")[0] != "0"
         alg_flops = 2.0 * args.rows * args.nq * args.dim
-        if filter_path:
+        int8_path = filter_path and os.environ.get("CS_FILTER_INT8", "1")[0] != "0"
+        if int8_path:
+            # scan_filter.hip "int8 filter copy": the filter streams the int8 copy of the unit rows (rows*dim B) once per
+            # query tile through the i8 MFMA (exact integer products, proven band); candidates are re-scored exactly in f32.
+            per = 32 if args.nq <= 32 else 64 if (args.nq <= 64 or args.dim == 1024) else \
+                256 if (args.dim == 384 and args.nq > 128) else 128
+            tiles = (args.nq + per - 1) // per
+            i8_bytes = args.rows * args.dim
+            exe = 2.0 * args.rows * tiles * per * args.dim
+            kern = f"cs::score_filter_rw8_kernel<{per // 32},{args.dim // 128}> (+ rescore_keys_kernel / select_candidates_kernel between phases)"
+            hbm = {"kernel": kern, "bound": "hbm", "achieved": i8_bytes / (scan_us * 1e-6) / 1e9, "peak": HBM_PEAK_GBPS,
+                   "unit": "GB/s", "frac": i8_bytes / (scan_us * 1e-6) / 1e9 / HBM_PEAK_GBPS, "traffic": None,
+                   "algorithmic_bytes_per_launch": i8_bytes,
+                   "f32_bytes_equivalent_frac": alg_bytes / (scan_us * 1e-6) / 1e9 / HBM_PEAK_GBPS,
+                   "note": "bytes = the int8 filter copy (a quarter of the f32 matrix), read once when all queries fit "
+                           "one query tile; avg_launch_us spans every phase's filter, re-score and select kernels"}
+            mfma = {"kernel": kern, "bound": "mfma", "achieved": exe / (scan_us * 1e-6) / 1e12, "peak": MFMA_I8_PEAK_TOPS,
+                    "unit": "TOP/s", "frac": exe / (scan_us * 1e-6) / 1e12 / MFMA_I8_PEAK_TOPS,
+                    "traffic": None, "executed_i8_ops_per_launch": exe,
+                    "algorithmic_flops_per_launch": alg_flops,
+                    "l2_GBps_for_information": i8_bytes * tiles / (scan_us * 1e-6) / 1e9,
+                    "note": "every query tile re-reads the int8 copy through its XCD's L2; the kernel is paced by that "
+                            "stream and by LDS reads, not by the matrix pipe (DESIGN.md §3.1c)"}
+            roof = hbm if tiles == 1 else mfma
+        elif filter_path:
             # scan_filter.hip: the filter streams the f16 unit-vector copy of the corpus (rows*dim*2 B)
             # once per 128-query tile through the f16 MFMA; candidates are re-scored exactly in f32.
             tiles = (args.nq + 127) // 128
@@ -809,9 +852,11 @@ def main():
                 "ms_per_search": alt_ms, "chunks_per_s": args.rows / (alt_ms * 1e-3),
                 "took_filter_path": took_filter,
                 "bit_identical_to_streaming_scan": same,
-                "note": "cs_index_set_filter_min_queries(1): f16 MFMA filter over the f16 unit-vector copy "
-                        f"({args.rows * args.dim * 2 / 1e9:.2f} GB), then exact f32 re-score of the candidates; "
-                        "compared with the streaming f32 scan's ids and cosines; not used for `value`",
+                "filter_copy": "int8" if os.environ.get("CS_FILTER_INT8", "1")[0] != "0" else "f16",
+                "note": "cs_index_set_filter_min_queries(1): MFMA filter over the quantised copy of the unit rows "
+                        f"(int8: {args.rows * args.dim / 1e9:.2f} GB; CS_FILTER_INT8=0: f16, {args.rows * args.dim * 2 / 1e9:.2f} GB), "
+                        "then exact f32 re-score of the candidates; compared with the streaming f32 scan's ids and "
+                        "cosines; not used for `value`",
             }
         if world == 1 and args.nq == 1 and args.dim == 384 and not args.no_1m:
             line["config_1m"] = scan_1m_leg(args.dim, args.k, local_rank, VectorStore)
