@@ -42,6 +42,11 @@ if ROOT not in sys.path:
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: f32-input MFMA peak
 MFMA_F16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense f16/bf16 MFMA peak
+# benchmarks/mfma_rate_probe.hip (profiles/r03_mfma_rate_probe.log): what a loop of nothing but independent MFMAs sustains
+# chip-wide when every instruction gets different pseudo-random operands (constant operands reach 2,040 / 4,810): the chip is
+# power-limited under toggling data.  Reported beside the data-sheet peaks, never instead of them.
+MFMA_F16_16x16x32_SUSTAINED_TFLOPS = 1490.0
+MFMA_I8_32x32x32_SUSTAINED_TOPS = 3430.0
 MFMA_I8_PEAK_TOPS = 5000.0  # MI355X_MICROARCH.md MFMA table: I8 32x32x32 / 16x16x64 = 2x the BF16 rate per clock
 SEED = 0xC0DE5EA
 
@@ -251,6 +256,11 @@ def encoder_legs(shard, k, device, with_cpu=True):
             "executed_flops_per_batch": executed, "algorithmic_flops_per_batch": gemm_flops + attn_flops,
             "algorithmic_tflops": (gemm_flops + attn_flops) / sec / 1e12,
             "frac_algorithmic_of_f32_mfma_peak": (gemm_flops + attn_flops) / sec / 1e12 / MFMA_F32_PEAK_TFLOPS,
+            "sustained_mfma_stream_tflops": MFMA_F16_16x16x32_SUSTAINED_TFLOPS,
+            "frac_of_sustained_mfma_stream": executed / sec / 1e12 / MFMA_F16_16x16x32_SUSTAINED_TFLOPS,
+            "sustained_note": "benchmarks/mfma_rate_probe.hip: a loop of independent v_mfma_f32_16x16x32_f16 alone, one wave per "
+                              "SIMD on every CU, sustains 1,490 TFLOP/s on pseudo-random operands (2,040 on constant ones): "
+                              "the ceiling a kernel with real data can approach on this power-limited part",
             "traffic": None,
             "cls_tail": cls_tail,
             "cls_tail_note": "CLS pooling reads one row per sequence of the last layer: that layer computes K and V for every token, "
@@ -725,6 +735,7 @@ def main():
                     "traffic": None, "executed_i8_ops_per_launch": exe,
                     "algorithmic_flops_per_launch": alg_flops,
                     "l2_GBps_for_information": i8_bytes * tiles / (scan_us * 1e-6) / 1e9,
+                    "frac_of_sustained_mfma_stream": exe / (scan_us * 1e-6) / 1e12 / MFMA_I8_32x32x32_SUSTAINED_TOPS,
                     "note": "every query tile re-reads the int8 copy through its XCD's L2; the kernel is paced by that "
                             "stream and by LDS reads, not by the matrix pipe (DESIGN.md §3.1c)"}
             roof = hbm if tiles == 1 else mfma
