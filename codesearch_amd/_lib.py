@@ -98,6 +98,7 @@ SIGNATURES = {
     "cs_shards_read_rows": (C.c_int32, [vp, C.c_uint64, C.c_uint64, f32p]),
     "cs_index_read_rows": (C.c_int32, [vp, C.c_uint64, C.c_uint64, f32p]),
     "cs_index_debug_counters": (C.c_int32, [vp, u64p, u64p]),
+    "cs_index_filter_state": (C.c_int32, [vp, C.POINTER(C.c_int32), C.POINTER(C.c_float), u64p]),
     "cs_index_set_filter_min_queries": (C.c_int32, [vp, C.c_uint32]),
     "cs_index_profile": (C.c_int32, [vp, C.c_int32]),
     "cs_index_profile_read": (C.c_int32, [vp, f64p, u64p, f64p, C.c_int32]),

@@ -2,6 +2,7 @@
 // (/root/reference/src/vectordb/store.rs:94-750) as a device-resident row-major matrix
 // searched by the exact scan of scan.hip.  Metadata (store.rs:19-85) stays with the caller.
 #include <algorithm>
+#include <atomic>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -57,6 +58,7 @@ struct Workspace {
     SplitQueryWs qw;
     size_t qw_elems = 0, qw_nq = 0, q8_elems = 0;
     uint32_t* h_overflow = nullptr;
+    uint32_t mirror_seen = 0;  // value of h_overflow[3] already accounted for
 
     int32_t reserve_split_queries(uint32_t nq, uint32_t dim) {
         const size_t elems = (size_t)nq * dim;
@@ -77,7 +79,7 @@ struct Workspace {
             if (qw.d_qmeta) (void)hipFree(qw.d_qmeta);
             qw.d_qmag = nullptr; qw.d_qmeta = nullptr; qw_nq = 0;
             CS_HIP(hipMalloc(&qw.d_qmag, nq * sizeof(float)));
-            CS_HIP(hipMalloc(&qw.d_qmeta, nq * sizeof(float2)));
+            CS_HIP(hipMalloc(&qw.d_qmeta, nq * sizeof(float4)));
             qw_nq = nq;
         }
         return CS_OK;
@@ -105,7 +107,11 @@ struct Workspace {
 
     int32_t reserve_batched(uint32_t nq, uint32_t k) {
         const size_t cand = (size_t)nq * batched_cap(k), carry = (size_t)nq * k;
-        if (!h_overflow) CS_HIP(hipHostMalloc(&h_overflow, 4 * sizeof(uint32_t)));
+        if (!h_overflow) {
+            CS_HIP(hipHostMalloc(&h_overflow, 4 * sizeof(uint32_t)));
+            h_overflow[3] = 0;
+            bs.h_mirror = h_overflow + 3;  // written by the device (scan.hpp BatchedState::h_mirror)
+        }
         if (!bs.d_overflow) {  // [0] this search, [1] sticky, [2] overflowed searches so far (scan.hpp BatchedState)
             CS_HIP(hipMalloc(&bs.d_overflow, 4 * sizeof(uint32_t)));
             CS_HIP(hipMemset(bs.d_overflow, 0, 4 * sizeof(uint32_t)));
@@ -241,8 +247,21 @@ struct cs_index {
     // int8 filter copy (scan_filter.hip): complete 128-row tiles [0, q8_rows / 128), a quarter of the f32 bytes
     int8_t* d_q8 = nullptr;
     float2* d_tmeta = nullptr;
+    float* d_mu = nullptr;   // [dim] mean unit row of the first build: the copy holds u - mu (fixed until clear())
     uint64_t q8_rows = 0;
     bool use_q8 = false;
+    // The int8 copy stops being the filter operand (the f16 copy takes over, results unchanged) when the data defeat its
+    // error band: at build, when the tiles' scales say so (outlier coordinates: q8_spread), and at run time after two
+    // searches through it overflowed a candidate buffer.  clear() resets both.
+    std::atomic<bool> q8_active{true};
+    std::atomic<uint32_t> q8_strikes{0}, q8_searches{0};
+    // a strike; the copy is retired once there are two and they are more than one in sixteen of its searches
+    void q8_strike() {
+        const uint32_t s = q8_strikes.fetch_add(1) + 1;
+        if (s >= 2 && (uint64_t)s * 16 >= q8_searches.load()) q8_active.store(false);
+    }
+    float q8_spread = 0.0f;      // median over tiles of max |u - mu| * sqrt(dim) at the last build (isotropic rows: ~4.4)
+    float q8_max_spread = 7.0f;  // CS_FILTER_INT8_MAX_SPREAD
     float filter_margin = 0.0f;  // scan_filter.hip: bound of the f16 filter's error for this dim
     int filter_min_q = 2;  // query count from which the f16 filter + exact refine path is used
     uint32_t single_filter_min_k = 100;  // ... and one query too from this k on, over >= 2M rows (0 = never)
@@ -254,7 +273,7 @@ struct cs_index {
     // 500,000 rows below k = 48 and 100,000 from there on.
     uint32_t prime_min_k = 1;
     uint64_t prime_min_rows = 0, prime_rows = 0;
-    uint64_t batched_searches = 0, batched_fallbacks = 0;
+    uint64_t batched_searches = 0, batched_fallbacks = 0, q8_reruns = 0;
     std::vector<uint32_t> h_dead;
     bool built = false;
     // streams of OTHER devices that carry unfinished appends into this corpus (index_append_from: an encoder replica on
@@ -474,10 +493,23 @@ int32_t run_search(cs_index* h, Workspace* w, const ScanPlan& plan, const float*
     const bool use_filter = split_ready && wants_filter;
     if (h->n_rows > 0 && h->normed_rows >= h->n_rows && (use_filter || (nq >= 5 && batched_supported(h->dim)))) {
         CS_TRY(w->reserve_batched(nq, k));
+        bool via_q8 = false;
         if (use_filter) {
             CS_TRY(w->reserve_split_queries(nq, h->dim));
             Q8View q8;
-            if (h->use_q8 && h->d_q8) { q8.d_q8 = h->d_q8; q8.d_tmeta = h->d_tmeta; q8.rows = h->q8_rows; }
+            // overflowed searches the device has reported since this workspace last looked: strikes against the int8 copy
+            if (w->bs.h_mirror) {
+                const uint32_t seen = *reinterpret_cast<volatile uint32_t*>(w->bs.h_mirror);
+                if (seen != w->mirror_seen) {
+                    w->mirror_seen = seen;
+                    if (h->q8_active.load()) h->q8_strike();
+                }
+            }
+            via_q8 = h->use_q8 && h->d_q8 && h->q8_active.load();
+            if (via_q8) {
+                q8.d_q8 = h->d_q8; q8.d_tmeta = h->d_tmeta; q8.d_mu = h->d_mu; q8.rows = h->q8_rows;
+                h->q8_searches.fetch_add(1);
+            }
             CS_TRY(launch_scan_split(w->bs, w->qw, h->d_corpus, h->d_split, h->n_rows, h->dim,
                                      d_queries, nq, k, h->n_removed ? h->d_dead : nullptr, h->id_base, d_keys,
                                      d_cos, d_ids, d_counts, stream, h->filter_margin, &q8));
@@ -518,6 +550,21 @@ int32_t run_search(cs_index* h, Workspace* w, const ScanPlan& plan, const float*
             CS_HIP(hipMemcpyAsync(w->h_overflow, w->bs.d_overflow, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
             CS_HIP(hipStreamSynchronize(stream));
             overflow = *w->h_overflow != 0;
+            if (overflow && via_q8) {
+                // the int8 copy's band let too many rows through: a strike against it, and the f16 copy (band 0.001)
+                // answers this search before the exact list-based scan is asked to
+                h->q8_strike();
+                CS_TRY(launch_scan_split(w->bs, w->qw, h->d_corpus, h->d_split, h->n_rows, h->dim, d_queries, nq, k,
+                                         h->n_removed ? h->d_dead : nullptr, h->id_base, d_keys, d_cos, d_ids, d_counts,
+                                         stream, h->filter_margin, nullptr));
+                CS_HIP(hipMemcpyAsync(w->h_overflow, w->bs.d_overflow, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+                CS_HIP(hipStreamSynchronize(stream));
+                overflow = *w->h_overflow != 0;
+                // the rerun's first kernel has mirrored the count of overflowed searches, this one included: seen
+                w->mirror_seen = *reinterpret_cast<volatile uint32_t*>(w->bs.h_mirror);
+                std::lock_guard<std::mutex> lk(h->mu);
+                h->q8_reruns++;
+            }
         }
         {
             std::lock_guard<std::mutex> lk(h->mu);
@@ -625,6 +672,7 @@ int32_t cs_index_create(uint32_t dim, uint64_t capacity_rows, int32_t device, ui
         h->use_split = split_scan_supported(dim) && !(env && env[0] == '0');
         const char* e8 = std::getenv("CS_FILTER_INT8");  // "0": filter on the f16 copy only
         h->use_q8 = h->use_split && !(e8 && e8[0] == '0');
+        if (const char* e = std::getenv("CS_FILTER_INT8_MAX_SPREAD")) h->q8_max_spread = (float)std::atof(e);
         if (const char* e = std::getenv("CS_FILTER_MIN_Q")) {
             h->filter_min_q = std::atoi(e);
             if (h->filter_min_q < 1) h->filter_min_q = 1;
@@ -672,6 +720,7 @@ void cs_index_destroy(cs_index* h) {
     if (h->d_split) (void)hipFree(h->d_split);
     if (h->d_q8) (void)hipFree(h->d_q8);
     if (h->d_tmeta) (void)hipFree(h->d_tmeta);
+    if (h->d_mu) (void)hipFree(h->d_mu);
     delete h;
 }
 
@@ -758,10 +807,30 @@ int32_t cs_index_build(cs_index* h) {
         h->split_rows = h->n_rows;
     }
     if (h->use_q8 && h->d_q8 && h->q8_rows / 128 < h->n_rows / 128) {  // tiles that became complete
+        if (!h->d_mu) CS_HIP(hipMalloc(&h->d_mu, h->dim * sizeof(float)));
+        if (h->q8_rows == 0)  // first tiles of this copy: centre it on the mean unit row of what is there now
+            CS_TRY(launch_unit_mean(h->d_corpus, h->d_norms, std::min<uint64_t>(h->n_rows, 1u << 20), h->dim, h->d_mu, nullptr));
         CS_TRY(launch_corpus_q8(h->d_corpus, h->d_norms, h->d_q8, h->d_tmeta, h->q8_rows / 128,
-                                h->n_rows / 128 - h->q8_rows / 128, h->dim, nullptr));
+                                h->n_rows / 128 - h->q8_rows / 128, h->dim, h->d_mu, nullptr));
         CS_HIP(hipDeviceSynchronize());
         h->q8_rows = h->n_rows / 128 * 128;
+        // outlier coordinates: the tile scale is the tile's largest |u - mu|; where the typical tile's is far above what
+        // evenly spread coordinates give (4.3 / sqrt(dim) for Gaussian rows), the band (it grows with the square) lets
+        // through more rows than the candidate buffers hold — the f16 copy serves the filter then
+        {
+            const uint64_t nt = std::min<uint64_t>(h->q8_rows / 128, 4096);
+            std::vector<float2> tm((size_t)nt);
+            CS_HIP(hipMemcpy(tm.data(), h->d_tmeta, (size_t)nt * sizeof(float2), hipMemcpyDeviceToHost));
+            std::vector<float> sp;
+            sp.reserve((size_t)nt);
+            for (const float2& t : tm)
+                if (t.x == t.x && t.x > 0.0f) sp.push_back(127.0f / t.x * std::sqrt((float)h->dim));
+            if (!sp.empty()) {
+                std::nth_element(sp.begin(), sp.begin() + sp.size() / 2, sp.end());
+                h->q8_spread = sp[sp.size() / 2];
+                if (h->q8_spread > h->q8_max_spread) h->q8_active.store(false);
+            }
+        }
     }
     h->built = true;                 // store.rs:428
     return CS_OK;
@@ -777,6 +846,9 @@ int32_t cs_index_clear(cs_index* h) {
     h->normed_rows = 0;
     h->split_rows = 0;
     h->q8_rows = 0;
+    h->q8_active.store(true);
+    h->q8_strikes.store(0);
+    h->q8_searches.store(0);
     h->n_removed = 0;
     h->h_dead.clear();
     h->built = false;  // store.rs:702
@@ -1058,6 +1130,17 @@ int32_t cs_index_debug_counters(cs_index* h, uint64_t* batched_searches, uint64_
     std::lock_guard<std::mutex> lk(h->mu);
     if (batched_searches) *batched_searches = h->batched_searches;
     if (batched_fallbacks) *batched_fallbacks = h->batched_fallbacks + dev_fallbacks;
+    return CS_OK;
+}
+
+int32_t cs_index_filter_state(cs_index* h, int32_t* copy, float* spread, uint64_t* int8_reruns) {
+    if (!h) return fail(CS_ERR_BAD_ARG, "null index handle");
+    std::lock_guard<std::mutex> lk(h->mu);
+    const bool f16 = h->use_split && h->d_split;
+    const bool i8 = f16 && h->use_q8 && h->d_q8 && h->q8_active.load() && h->q8_rows > 1024;
+    if (copy) *copy = i8 ? 2 : f16 ? 1 : 0;
+    if (spread) *spread = h->q8_spread;
+    if (int8_reruns) *int8_reruns = h->q8_reruns;
     return CS_OK;
 }
 

@@ -162,7 +162,8 @@ __global__ void __launch_bounds__(256)
 prep_queries_kernel(const float* __restrict__ queries, float* __restrict__ qcopy, uint32_t nq,
                     float* __restrict__ qmag, _Float16* __restrict__ qunit, float* __restrict__ tau, uint32_t* __restrict__ cnt,
                     uint64_t* __restrict__ carry, uint32_t k, uint32_t* __restrict__ overflow, uint32_t first_rows,
-                    int8_t* __restrict__ q8q, float2* __restrict__ qmeta) {
+                    int8_t* __restrict__ q8q, float4* __restrict__ qmeta, const float* __restrict__ mu,
+                    uint32_t* __restrict__ overflow_mirror) {
     constexpr int DIM = 128 * J;
     const int lane = threadIdx.x & 63, half = lane >> 5, l32 = lane & 31;
     const uint32_t q = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 2 + half;
@@ -206,14 +207,31 @@ prep_queries_kernel(const float* __restrict__ queries, float* __restrict__ qcopy
             *reinterpret_cast<uint32_t*>(q8q + (size_t)q * DIM + (l32 + 32 * j) * 4) = q8_pack4(u, inv, abs_sum);
         }
         abs_sum = half_sum_i(abs_sum);
-        if (l32 == 0) qmeta[q] = make_float2(inv, kQ8Half * (float)abs_sum + kQ8Quarter * (float)DIM + kQ8Guard);
+        // the corpus copy holds u - mu (mu: the mean unit row at the first build): q.u = q.(u - mu) + q.mu, the second
+        // term exact per query
+        float qmu = 0.0f;
+        if (mu) {
+#pragma unroll
+            for (int j = 0; j < J; ++j) {
+                const f32x4 mv = *reinterpret_cast<const f32x4*>(mu + (l32 + 32 * j) * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) qmu = fmaf(m == 0.0f ? 0.0f : v[j][e] / m, mv[e], qmu);
+            }
+            qmu = half_sum_s(qmu);
+        }
+        if (l32 == 0)
+            qmeta[q] = make_float4(inv, kQ8Half * (float)abs_sum + kQ8Quarter * (float)DIM + kQ8Guard, qmu, 0.0f);
     }
     for (uint32_t i = l32; i < k; i += 32) carry[(size_t)q * k + i] = 0ull;
     if (l32 == 0) {
         qmag[q] = m;
         tau[q] = -__builtin_huge_valf();
         cnt[(size_t)q * kCntStride] = first_rows;
-        if (q == 0) { overflow[2] += overflow[0]; overflow[0] = 0; }
+        if (q == 0) {
+            overflow[2] += overflow[0];
+            overflow[0] = 0;
+            if (overflow_mirror) *overflow_mirror = overflow[2];
+        }
     }
 }
 
@@ -546,7 +564,7 @@ score_filter256p_kernel(const _Float16* __restrict__ corpus_h, uint64_t row_lo, 
                         const _Float16* __restrict__ queries_h, uint32_t nq, const float* __restrict__ tau,
                         const uint32_t* __restrict__ dead, uint32_t* __restrict__ cand,
                         uint32_t* __restrict__ cnt, uint32_t cap, uint32_t total_slots, float margin,
-                        const float2* __restrict__ tmeta, const float2* __restrict__ qmeta) {
+                        const float2* __restrict__ tmeta, const float4* __restrict__ qmeta) {
     using Frag = typename std::conditional<I8, i32x4, f16x8>::type;
     using Acc = typename std::conditional<I8, i32x4, sh_f32x4v>::type;
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -717,8 +735,8 @@ score_filter256p_kernel(const _Float16* __restrict__ corpus_h, uint64_t row_lo, 
             int ti = 0;
             bool all = false;
             if constexpr (I8) {
-                const float2 qm = qmeta[qok ? q : 0];
-                const float T = floorf(fmaf((tau[qok ? q : 0] - margin) * qm.x, tmv.x, -(tmv.y + qm.y)));
+                const float4 qm = qmeta[qok ? q : 0];
+                const float T = floorf(fmaf((tau[qok ? q : 0] - margin - qm.z) * qm.x, tmv.x, -(tmv.y + qm.y)));
                 all = !(T == T) || T < -2.0e9f;
                 ti = T > 2.0e9f ? 0x7fffffff : (int)T;
             } else {
@@ -1017,18 +1035,56 @@ rescore_keys_kernel(const float* __restrict__ corpus, const float* __restrict__ 
 // rows become candidates (the refine decides).  Only complete tiles are quantised (a tile is written once, when
 // cs_index_build first sees it full: a search running beside a build never reads a tile being rewritten); the rows
 // behind the last complete tile are appended as candidates outright (tail_candidates_kernel, < 128 rows).
+// mu[c] = mean over rows [0, n) of x[c] / |x| (rows of zero or non-finite norm count as zero rows): column sums per
+// block in registers (thread t owns columns t, t + 256, ...: a row is read coalesced), one atomicAdd per column per
+// block into `sum`; mean_finish_kernel divides.  Summation order varies run to run: mu only has to be the SAME vector
+// for the quantiser and the queries, any vector keeps the filter exact.
+__global__ void __launch_bounds__(256)
+unit_mean_kernel(const float* __restrict__ corpus, const float* __restrict__ row_norm, uint64_t n, uint32_t dim,
+                 float* __restrict__ sum) {
+    float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};  // dim <= 1024
+    for (uint64_t r = blockIdx.x; r < n; r += gridDim.x) {
+        const float nrm = row_norm[r];
+        if (!(nrm > 0.0f && nrm < __builtin_huge_valf())) continue;
+        const float inv = 1.0f / nrm;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t c = threadIdx.x + 256 * i;
+            if (c < dim) {
+                const float u = corpus[r * dim + c] * inv;
+                if (u == u) acc[i] += u;
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t c = threadIdx.x + 256 * i;
+        if (c < dim) atomicAdd(&sum[c], acc[i]);
+    }
+}
+__global__ void mean_finish_kernel(float* __restrict__ mu, uint32_t dim, float inv_n) {
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < dim) {
+        const float m = mu[c] * inv_n;
+        mu[c] = (m == m && fabsf(m) <= 1.0f) ? m : 0.0f;
+    }
+}
+
 // One block per 128-row tile (tiles tile0 .. tile0 + gridDim.x - 1): pass 1 finds the tile's largest unit magnitude,
 // pass 2 (the tile is in L2 now) quantises.  A half-wave per row; lane l32 holds float4 l32 + 32 j of the row, i.e.
 // bytes 4 l32 .. 4 l32 + 3 of the row's line in k-chunk j of [tile][chunk of 128 k][row][128 B].
 template <int J>
 __global__ void __launch_bounds__(256)
 corpus_q8_kernel(const float* __restrict__ corpus, const float* __restrict__ row_norm, int8_t* __restrict__ q8,
-                 float2* __restrict__ tmeta, uint64_t tile0) {
+                 float2* __restrict__ tmeta, uint64_t tile0, const float* __restrict__ mu) {
     constexpr int DIM = 128 * J;
     __shared__ float s_max[8];
     __shared__ int s_bad[8], s_abs[8];
     const uint64_t tile = tile0 + blockIdx.x;
     const int tid = threadIdx.x, l32 = tid & 31, hw = tid >> 5;
+    f32x4 mv[J];
+#pragma unroll
+    for (int j = 0; j < J; ++j) mv[j] = *reinterpret_cast<const f32x4*>(mu + (l32 + 32 * j) * 4);
     float mx = 0.0f;
     int bad = 0;
     for (int r = hw; r < 128; r += 8) {
@@ -1040,7 +1096,7 @@ corpus_q8_kernel(const float* __restrict__ corpus, const float* __restrict__ row
             const f32x4 v = p[j * 32];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const float u = fabsf(nrm == 0.0f ? 0.0f : v[e] / nrm);
+                const float u = fabsf((nrm == 0.0f ? 0.0f : v[e] / nrm) - mv[j][e]);
                 if (!(u < __builtin_huge_valf())) bad = 1;
                 mx = fmaxf(mx, u);
             }
@@ -1066,7 +1122,7 @@ corpus_q8_kernel(const float* __restrict__ corpus, const float* __restrict__ row
             const f32x4 v = p[j * 32];
             f32x4 u;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) u[e] = nrm == 0.0f ? 0.0f : v[e] / nrm;
+            for (int e = 0; e < 4; ++e) u[e] = (nrm == 0.0f ? 0.0f : v[e] / nrm) - mv[j][e];
             const uint32_t w = q8_pack4(u, inv, abs_sum);
             *reinterpret_cast<uint32_t*>(q8 + ((tile * J + j) * 128 + r) * 128 + l32 * 4) = w;
         }
@@ -1109,7 +1165,7 @@ using Rw8Geom = RwGeom<NQT, KC, (NQT == 1 ? CS_RW8_RCAP1 : CS_RW8_RCAP2)>;
 template <int NQT, int KC>
 __global__ void __launch_bounds__(256)
 score_filter_rw8_kernel(const int8_t* __restrict__ corpus_q8, const float2* __restrict__ tmeta, uint64_t row_lo,
-                        uint64_t row_hi, const int8_t* __restrict__ queries_q8, const float2* __restrict__ qmeta,
+                        uint64_t row_hi, const int8_t* __restrict__ queries_q8, const float4* __restrict__ qmeta,
                         uint32_t nq, const float* __restrict__ tau, const uint32_t* __restrict__ dead,
                         uint32_t* __restrict__ cand, uint32_t* __restrict__ cnt, uint32_t cap, uint32_t qtiles,
                         uint32_t nt_stream, float slack) {
@@ -1152,8 +1208,8 @@ score_filter_rw8_kernel(const int8_t* __restrict__ corpus_q8, const float2* __re
     for (int t = 0; t < NQT; ++t) {
         const uint32_t q = q0 + 32 * t + l31;
         qok[t] = q < nq;
-        const float2 m = qmeta[qok[t] ? q : 0];
-        tqs[t] = (tau[qok[t] ? q : 0] - slack) * m.x;
+        const float4 m = qmeta[qok[t] ? q : 0];
+        tqs[t] = (tau[qok[t] ? q : 0] - slack - m.z) * m.x;
         cq[t] = m.y;
     }
 
@@ -1269,13 +1325,26 @@ int32_t launch_corpus_split(const float* d_corpus, const float* d_norms, _Float1
     return launch_unit_f16(d_corpus + first * dim, d_norms + first, d_split, n, dim, stream, 1, first);
 }
 
+int32_t launch_unit_mean(const float* d_corpus, const float* d_norms, uint64_t n, uint32_t dim, float* d_mu,
+                         hipStream_t stream) {
+    if (dim > 1024) return fail(CS_ERR_UNSUPPORTED, "int8 filter copy supports dim <= 1024, got %u", dim);
+    CS_HIP(hipMemsetAsync(d_mu, 0, dim * sizeof(float), stream));
+    if (n == 0) return CS_OK;
+    const uint32_t blocks = (uint32_t)std::min<uint64_t>(n, 4096);
+    hipLaunchKernelGGL(unit_mean_kernel, dim3(blocks), dim3(256), 0, stream, d_corpus, d_norms, n, dim, d_mu);
+    CS_HIP(hipGetLastError());
+    hipLaunchKernelGGL(mean_finish_kernel, dim3((dim + 255) / 256), dim3(256), 0, stream, d_mu, dim, 1.0f / (float)n);
+    CS_HIP(hipGetLastError());
+    return CS_OK;
+}
+
 int32_t launch_corpus_q8(const float* d_corpus, const float* d_norms, int8_t* d_q8, float2* d_tmeta, uint64_t first_tile,
-                         uint64_t ntiles, uint32_t dim, hipStream_t stream) {
+                         uint64_t ntiles, uint32_t dim, const float* d_mu, hipStream_t stream) {
     for (uint64_t t = 0; t < ntiles;) {  // grid.x stays below 2^31
         const uint32_t n = (uint32_t)std::min<uint64_t>(ntiles - t, 1u << 30);
-        if (dim == 384) hipLaunchKernelGGL(corpus_q8_kernel<3>, dim3(n), dim3(256), 0, stream, d_corpus, d_norms, d_q8, d_tmeta, first_tile + t);
-        else if (dim == 768) hipLaunchKernelGGL(corpus_q8_kernel<6>, dim3(n), dim3(256), 0, stream, d_corpus, d_norms, d_q8, d_tmeta, first_tile + t);
-        else if (dim == 1024) hipLaunchKernelGGL(corpus_q8_kernel<8>, dim3(n), dim3(256), 0, stream, d_corpus, d_norms, d_q8, d_tmeta, first_tile + t);
+        if (dim == 384) hipLaunchKernelGGL(corpus_q8_kernel<3>, dim3(n), dim3(256), 0, stream, d_corpus, d_norms, d_q8, d_tmeta, first_tile + t, d_mu);
+        else if (dim == 768) hipLaunchKernelGGL(corpus_q8_kernel<6>, dim3(n), dim3(256), 0, stream, d_corpus, d_norms, d_q8, d_tmeta, first_tile + t, d_mu);
+        else if (dim == 1024) hipLaunchKernelGGL(corpus_q8_kernel<8>, dim3(n), dim3(256), 0, stream, d_corpus, d_norms, d_q8, d_tmeta, first_tile + t, d_mu);
         else return fail(CS_ERR_UNSUPPORTED, "int8 filter copy supports dim 384/768/1024, got %u", dim);
         CS_HIP(hipGetLastError());
         t += n;
@@ -1351,7 +1420,8 @@ static int32_t scan_split_impl(const BatchedState& st, const SplitQueryWs& qw, c
     hipLaunchKernelGGL(prep_queries_kernel<J>, dim3((nq + 7) / 8), dim3(256), 0, stream,
                        qw.q_pinned ? qw.q_pinned : d_queries, qw.q_pinned ? const_cast<float*>(d_queries) : nullptr, nq,
                        qw.d_qmag, qw.d_qsplit, st.d_tau, st.d_cnt, st.d_carry, k, st.d_overflow,
-                       (uint32_t)(n_rows < 1024 ? n_rows : 1024), use_q8 ? qw.d_q8q : nullptr, qw.d_qmeta);
+                       (uint32_t)(n_rows < 1024 ? n_rows : 1024), use_q8 ? qw.d_q8q : nullptr, qw.d_qmeta,
+                       use_q8 ? q8->d_mu : nullptr, st.h_mirror);
     CS_HIP(hipGetLastError());
     uint32_t* cand = reinterpret_cast<uint32_t*>(st.d_cand);
     const uint32_t ntiles = (nq + SH_BN - 1) / SH_BN;
@@ -1502,7 +1572,7 @@ static int32_t scan_split_impl(const BatchedState& st, const SplitQueryWs& qw, c
                     const uint32_t grid = std::min<uint32_t>(slots, ((uint32_t)cus + 7) / 8 * 8);  // a multiple of 8: a block stays on its XCD slot
                     hipLaunchKernelGGL(score_filter256p_kernel<false>, dim3(grid), dim3(512), UF2_LDS, stream, d_split, lo, hi,
                                        dim / 64, qw.d_qsplit, nq, st.d_tau, d_dead, cand, st.d_cnt, cap, slots, margin,
-                                       (const float2*)nullptr, (const float2*)nullptr);
+                                       (const float2*)nullptr, (const float4*)nullptr);
                 } else if (legacy256)
                     hipLaunchKernelGGL(score_filter256_kernel<true>, dim3(sh_grid_blocks(mt2, nt2)), dim3(512), UF2_LDS,
                                        stream, d_split, lo, hi, dim / 64, qw.d_qsplit, nq, st.d_tau, d_dead, cand,

@@ -563,6 +563,15 @@ class VectorStore:
         _lib.check(self._lib.cs_index_debug_counters(self._h, C.byref(a), C.byref(b)))
         return int(a.value), int(b.value)
 
+    def filter_state(self):
+        """-> (copy, spread, int8_reruns): which copy feeds the batched filter (0 none, 1 f16, 2 int8), the spread statistic
+        of the last build and the searches the f16 copy answered after the int8 copy overflowed (cs_index_filter_state)."""
+        if self.sharded:
+            raise ValueError("filter_state is per index: use shard_handle()")
+        c, sp, n = C.c_int32(), C.c_float(), C.c_uint64()
+        _lib.check(self._lib.cs_index_filter_state(self._h, C.byref(c), C.byref(sp), C.byref(n)))
+        return int(c.value), float(sp.value), int(n.value)
+
     @property
     def handle(self):
         return self._h

@@ -266,6 +266,14 @@ int32_t cs_index_profile_read(cs_index* h, double* scan_ms, uint64_t* scan_launc
 int32_t cs_index_set_filter_min_queries(cs_index* h, uint32_t min_queries);
 int32_t cs_index_debug_counters(cs_index* h, uint64_t* batched_searches,
                                 uint64_t* batched_fallbacks);
+/* Diagnostics: which copy of the corpus feeds the filter of batched searches right now — 0 none (no filter copy:
+ * CS_INDEX_SPLIT=0 or unsupported width), 1 the f16 unit rows, 2 the int8 unit rows — the spread
+ * statistic of the last build (median over tiles of max |u - mu| sqrt(dim): ~4.4 for evenly spread coordinates; above
+ * CS_FILTER_INT8_MAX_SPREAD = 7 the int8 copy is not used) and how many host-API searches through the int8 copy
+ * overflowed and were answered by the f16 copy instead (the int8 copy is retired until cs_index_clear once two searches
+ * through it have overflowed and they are more than one in sixteen of its searches).
+ * Results are exact and bit-identical whichever copy filters. */
+int32_t cs_index_filter_state(cs_index* h, int32_t* copy, float* spread, uint64_t* int8_reruns);
 
 /* Score mapping.  store.rs:477-478: score = 1 - distance, distance = arroy 0.5.0
  * Cosine = (1 - cos) / 2  (third-party). */

@@ -19,8 +19,9 @@ def VS(gpu_lib):
 
 
 def _same_as_single_query_scans(st, qs, k):
+    before = st.debug_counters()[1]
     cos, ids, counts = st.search_raw(qs, k)
-    assert st.debug_counters()[1] == 0, "candidate buffer overflowed: the filter path was not what answered"
+    assert st.debug_counters()[1] == before, "candidate buffer overflowed: the filter path was not what answered"
     for i in range(len(qs)):
         c1, i1, n1 = st.search_raw(qs[i], k)
         assert counts[i] == n1[0]
@@ -173,3 +174,112 @@ def test_int8_filter_over_10m_rows_k10_and_k200(VS, monkeypatch):
         for i in (0, nq - 1):
             c1, i1, n1 = st.search_raw(qs[i], k)
             assert ids[i].tolist() == i1[0].tolist() and cos[i].tobytes() == c1[0].tobytes()
+
+
+def _shared_rows(rng, n, dim, c=1.2):
+    """Rows with a large common component (mean pairwise cosine ~0.59): the shape of real sentence embeddings."""
+    mu = rng.normal(size=(1, dim)).astype(np.float32)
+    mu /= np.linalg.norm(mu)
+    x = rng.normal(size=(n, dim)).astype(np.float32) / np.sqrt(dim) + np.float32(c) * mu
+    return x / np.linalg.norm(x, axis=1, keepdims=True)
+
+
+def test_common_component_is_centred_out(VS, monkeypatch):
+    """The int8 copy holds u - mu (mu = the mean unit row at the first build) and q . mu is added back per query: rows
+    that share most of their norm — scores squeezed into a few hundredths around 0.6 — still filter without an overflow
+    and bit-identically.  Appended tiles are centred on the SAME mu; clear() takes a new one."""
+    monkeypatch.setenv("CS_FILTER_SINGLE_MIN_K", "0")
+    dim, n, nq = 384, 300_000, 9
+    rng = np.random.default_rng(77)
+    x = _shared_rows(rng, n + 40_000, dim)
+    st = VS(None, dim)
+    st.insert_embeddings(x[:n])
+    st.build_index()
+    assert st.filter_state()[0] == 2
+    qs = _shared_rows(np.random.default_rng(78), nq, dim)
+    qs[0] = x[12345] * np.float32(2.0)
+    for k in (10, 200):
+        cos, ids, _ = _same_as_single_query_scans(st, qs, k)
+        assert ids[0][0] == 12345
+    st.insert_embeddings(x[n:])           # more of the same, centred on the first build's mu
+    st.build_index()
+    qs[1] = x[n + 777]
+    cos, ids, _ = _same_as_single_query_scans(st, qs, 50)
+    assert ids[1][0] == n + 777 and st.filter_state()[0] == 2 and st.filter_state()[2] == 0
+    # rows pointing the other way (tiles at -2 mu after the centring: a coarser scale) that are ALSO the best matches
+    # of a query and come last: the phase that meets them holds more candidates than a buffer — the f16 copy answers
+    st.insert_embeddings(-x[:30_000])
+    st.build_index()
+    qs[3] = -x[5]
+    cos, ids, counts = st.search_raw(qs, 50)
+    for i in range(nq):
+        c1, i1, n1 = st.search_raw(qs[i], 50)
+        assert ids[i].tolist() == i1[0].tolist() and cos[i].tobytes() == c1[0].tobytes(), i
+    assert ids[3][0] == n + 40_000 + 5
+    st.clear()
+    st.insert_embeddings(-x[:50_000])
+    st.build_index()
+    qs[2] = -x[4242]
+    cos, ids, _ = _same_as_single_query_scans(st, qs, 20)
+    assert ids[2][0] == 4242
+
+
+def test_outlier_coordinates_retire_the_int8_copy_at_build(VS, monkeypatch):
+    """Three coordinates eight times the others' size: a tile's scale is set by them and the band would let a tenth of
+    the corpus through.  The build measures that (spread statistic) and leaves the filter on the f16 copy."""
+    monkeypatch.setenv("CS_FILTER_SINGLE_MIN_K", "0")
+    dim, n, nq, k = 384, 100_000, 8, 10
+    rng = np.random.default_rng(5)
+    x = rng.normal(size=(n, dim)).astype(np.float32)
+    x[:, [7, 100, 333]] *= np.float32(8.0)
+    st = VS(None, dim)
+    st.insert_embeddings(x)
+    st.build_index()
+    copy, spread, reruns = st.filter_state()
+    assert copy == 1 and spread > 7.0, (copy, spread)
+    qs = rng.normal(size=(nq, dim)).astype(np.float32)
+    qs[:, [7, 100, 333]] *= np.float32(8.0)
+    qs[0] = x[999]
+    cos, ids, _ = _same_as_single_query_scans(st, qs, k)
+    assert ids[0][0] == 999
+    iso = VS(None, dim)
+    iso.insert_synthetic(50_000, 3, 0)
+    iso.build_index()
+    copy, spread, _ = iso.filter_state()
+    assert copy == 2 and 2.5 < spread < 5.5, (copy, spread)
+
+
+def test_two_overflows_through_the_int8_copy_retire_it(VS, oracle, monkeypatch):
+    """Scores crowded inside the int8 band (thousands of near-duplicates of the query) overflow a candidate buffer: the
+    host API answers that search from the f16 copy (band 0.001) instead of the list-based scan, counts a strike, and
+    after two strikes the index filters on the f16 copy by itself.  Every answer stays exact."""
+    monkeypatch.setenv("CS_FILTER_SINGLE_MIN_K", "0")
+    monkeypatch.setenv("CS_FILTER_INT8_MAX_SPREAD", "1000")   # keep the build-time check out of this test
+    dim, n, nq, k = 384, 60_000, 4, 10
+    rng = np.random.default_rng(11)
+    corpus = oracle.synth_rows(41, 0, n, dim).copy()
+    base = oracle.synth_rows(42, 0, 1, dim)[0]
+    # 12,000 rows at cosines spread over 0.98 .. 1.0 to the query: all of them inside the int8 band of the 10th best (a
+    # buffer holds 4,096), a few hundred inside the f16 copy's
+    # (200 of them among the first 1,000 rows: phase 0 then leaves a bound near the top, and what a later phase lets
+    # through is decided by the band, not by a bound that has not met these rows yet)
+    dup = np.concatenate([np.arange(100, 300), np.arange(20_000, 31_800)])
+    amp = rng.uniform(0.0, 0.2, (len(dup), 1)).astype(np.float32) * np.linalg.norm(base) / np.sqrt(dim)
+    corpus[dup] = base[None, :] + amp * rng.normal(0, 1, (len(dup), dim)).astype(np.float32)
+    st = VS(None, dim)
+    st.insert_embeddings(corpus)
+    st.build_index()
+    assert st.filter_state()[0] == 2
+    qs = synth_rows(43, 0, nq, dim).copy()
+    qs[0] = base
+    for round_ in range(3):
+        cos, ids, counts = st.search_raw(qs, k)
+        ecos, eids = oracle.scan_topk(corpus, qs[0], k, mode="omp")
+        np.testing.assert_allclose(cos[0], ecos, atol=2e-6)
+        assert set(ids[0].tolist()) <= set(dup.tolist())
+        for i in range(1, nq):
+            c1, i1, _ = st.search_raw(qs[i], k)
+            assert ids[i].tolist() == i1[0].tolist() and cos[i].tobytes() == c1[0].tobytes()
+    copy, _, reruns = st.filter_state()
+    assert copy == 1 and reruns == 2, (copy, reruns)   # strikes 2 of 3 searches: more than one in sixteen
+    assert st.debug_counters()[1] == 0   # the f16 copy coped every time: no list-based rerun
