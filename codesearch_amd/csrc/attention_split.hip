@@ -544,6 +544,55 @@ attention_shx_kernel(const _Float16* __restrict__ qkvs, const int32_t* __restric
                     xx = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl8, qh[c][s], xx, 0, 0, 0);
                 }
             }
+#ifndef CS_ATTN_SCALAR_SOFTMAX
+            // The softmax of a tile is 172 VALU instructions per wave against 12 MFMAs when written element by element
+            // — the kernel is VALU-bound (2.3 x the MFMAs' cycles) — so everything that is the same operation on two
+            // neighbouring keys is a packed-f32 instruction (v_pk_fma_f32 / v_pk_add_f32 / v_pk_mul_f32): 124.
+            // Same operations, same roundings; only the order of the row sum changes (two partial sums).
+            sh_f32x2 p2[8];
+            float tmax = -__builtin_huge_valf();
+            const sh_f32x2 lo_inv2 = {kShLoInv, kShLoInv}, scale2 = {scale_log2e, scale_log2e};
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const sh_f32x4 ma = *reinterpret_cast<const sh_f32x4*>(madd + kt * 32 + 8 * g + 4 * h);
+#pragma unroll
+                for (int e2 = 0; e2 < 2; ++e2) {
+                    const int r = 4 * g + 2 * e2;
+                    const sh_f32x2 x2 = {xx[r], xx[r + 1]}, h2 = {hh[r], hh[r + 1]}, m2 = {ma[2 * e2], ma[2 * e2 + 1]};
+                    const sh_f32x2 s2 = __builtin_elementwise_fma(__builtin_elementwise_fma(x2, lo_inv2, h2), scale2, m2);
+                    p2[r / 2] = s2;
+                    tmax = fmaxf(tmax, fmaxf(s2[0], s2[1]));
+                }
+            }
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+            if (__any(tmax > m)) {
+                const float mnew = fmaxf(m, tmax);
+                const float alpha = __builtin_amdgcn_exp2f(m - mnew);
+                lsum *= alpha;
+#pragma unroll
+                for (int c = 0; c < NC; ++c)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) { ohh[c][r] *= alpha; oxx[c][r] *= alpha; }
+                m = mnew;
+            }
+            const sh_f32x2 m2v = {m, m};
+            sh_f32x2 ps2 = {0.0f, 0.0f};
+            Frag8 ph[2], pl[2];
+            const sh_f32x2 lo_scale2 = {kShLoScale, kShLoScale};
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const sh_f32x2 d2 = p2[i] - m2v;
+                const sh_f32x2 e2 = {__builtin_amdgcn_exp2f(d2[0]), __builtin_amdgcn_exp2f(d2[1])};
+                ps2 += e2;
+                const h16x2 hi = __builtin_amdgcn_cvt_pkrtz(e2[0], e2[1]);
+                const sh_f32x2 back = {(float)hi[0], (float)hi[1]};
+                const sh_f32x2 r2 = (e2 - back) * lo_scale2;
+                const h16x2 lo = __builtin_amdgcn_cvt_pkrtz(r2[0], r2[1]);
+                ph[i >> 2].u[i & 3] = __builtin_bit_cast(uint32_t, hi);
+                pl[i >> 2].u[i & 3] = __builtin_bit_cast(uint32_t, lo);
+            }
+            lsum += ps2[0] + ps2[1];
+#else
             float tmax = -__builtin_huge_valf();
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
@@ -586,6 +635,7 @@ attention_shx_kernel(const _Float16* __restrict__ qkvs, const int32_t* __restric
                     split_pair_rtz_ng(hh[8 * s + 2 * w2], hh[8 * s + 2 * w2 + 1], ph[s].u[w2], pl[s].u[w2]);
 #endif
                 }
+#endif
             typedef __attribute__((address_space(3))) s16x4* lds_s16x4_p;
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
