@@ -555,21 +555,35 @@ int32_t run_window(cs_embedder* h, const std::vector<SeqView>& seqs, uint32_t ba
                    bool out_on_device, const volatile int32_t* cancel, std::vector<uint32_t>& order,
                    std::vector<int32_t>& ids, std::vector<int32_t>& mask) {
     const uint32_t wn = (uint32_t)seqs.size();
+    // Length-grouped mini-batches are cut by TOKENS, not by rows: a mini-batch of `batch` short sequences is a fraction
+    // of the token rows the dense layers are tuned on (256 x 256 = 65,536 for the 384-d models: whole tile rounds on
+    // 256 CUs), so short sequences fill the same budget with more rows (up to 8 x batch).  Sorted ascending, the row
+    // that would join next is also the new longest.  CS_EMBED_TOKEN_BATCH=0: `batch` rows whatever their length.
+    static const bool token_batches = [] {
+        const char* e = std::getenv("CS_EMBED_TOKEN_BATCH");
+        return !(e && e[0] == '0');
+    }();
+    const bool sorted = length_sort_enabled() && wn > batch;
+    const uint64_t budget = (uint64_t)batch * std::min<uint32_t>(256, h->cfg.max_position);
+    const uint32_t max_rows = sorted && token_batches ? batch * 8 : batch;
     {   // workspace for the window's longest sequence once, not once per (growing) mini-batch
         size_t longest = 1;
         for (const SeqView& v : seqs) longest = std::max<size_t>(longest, v.len);
-        const size_t bmax = std::min<size_t>(batch, wn);
+        const size_t bmax = std::min<size_t>(max_rows, wn);
+        const size_t tokens = std::max<size_t>(std::min<size_t>(batch, wn) * longest, max_rows > batch ? (size_t)budget : 0);
         DeviceGuard g(h->device);
-        CS_TRY(reserve(h, std::max(bmax, h->cap_seqs), std::max(bmax * longest, h->cap_tokens)));
+        CS_TRY(reserve(h, std::max(bmax, h->cap_seqs), std::max(tokens, h->cap_tokens)));
     }
     order.resize(wn);
     for (uint32_t i = 0; i < wn; ++i) order[i] = i;
-    if (length_sort_enabled() && wn > batch)
+    if (sorted)
         std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return seqs[a].len < seqs[b].len; });
-    for (uint32_t b0 = 0; b0 < wn; b0 += batch) {
+    uint32_t B = 0;
+    for (uint32_t b0 = 0; b0 < wn; b0 += B) {
         if (cancel && *cancel)  // embedder.rs:280-282
             return fail(CS_ERR_CANCELLED, "Embedding interrupted by shutdown request");
-        const uint32_t B = std::min<uint32_t>(batch, wn - b0);
+        B = std::min<uint32_t>(batch, wn - b0);
+        while (b0 + B < wn && B < max_rows && (uint64_t)(B + 1) * seqs[order[b0 + B]].len <= budget) ++B;
         uint32_t L = 1;
         for (uint32_t r = 0; r < B; ++r) L = std::max(L, seqs[order[b0 + r]].len);
         ids.assign((size_t)B * L, pad);

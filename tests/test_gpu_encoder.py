@@ -454,6 +454,30 @@ def test_multi_minibatch_id_calls_group_by_length(FE, oracle):
     np.testing.assert_allclose(many, ref, atol=TOL_ORACLE)
 
 
+def test_minibatches_are_cut_by_tokens_not_rows(FE, oracle):
+    """Inside a window the length-sorted rows are cut into mini-batches that hold the token budget of `batch` rows of 256
+    tokens: short rows travel in mini-batches of up to 8 x batch rows (run_window, embedder.hip).  700 rows of 3 .. 200
+    tokens at batch 16: fewer forwards than rows / batch, every row still its own embedding."""
+    cfg = BertConfig(vocab_size=512, layers=2, pooling=POOL_CLS)
+    emb = FE(cfg, seed=33)
+    n, Lmax = 700, 200
+    ids, mask = synth_token_batch(cfg, 79, n, Lmax, False)
+    lens = np.random.default_rng(5).integers(3, Lmax + 1, n)
+    lens[:40] = 3
+    for i, ln in enumerate(lens):
+        mask[i, ln:] = 0
+        ids[i, ln:] = 0
+    emb.profile_read(reset=True)
+    got = emb.embed_ids(ids, mask, batch_size=16)
+    _, forwards = emb.profile_read()
+    assert forwards < (n + 15) // 16 * 0.8, forwards   # 44 mini-batches by rows; the 4,096-token budget needs ~25
+    pick = np.concatenate([np.arange(0, 45), np.arange(100, n, 37)])
+    ref = oracle.bert_forward(cfg, synth_params(cfg, 33), ids[pick], mask[pick])["pooled"]
+    np.testing.assert_allclose(got[pick], ref, atol=TOL_ORACLE)
+    alone = emb.embed_ids(ids[pick[:8]], mask[pick[:8]], batch_size=32)
+    assert np.abs(alone - got[pick[:8]]).max() <= 2e-6
+
+
 @pytest.mark.parametrize("B,L", [(12, 128), (20, 160), (40, 128), (40, 200)])
 def test_mid_size_batches_split_k_layers(FE, oracle, B, L):
     """1,100 < tokens <= 10,240: FFN-down (and out-proj up to 2,560 tokens) run as three (two from 6,144) K slices whose partial
