@@ -449,7 +449,7 @@ template <int NC>
 __global__ void __launch_bounds__(256, 2)
 attention_shx_kernel(const _Float16* __restrict__ qkvs, const int32_t* __restrict__ mask,
                      _Float16* __restrict__ ctxs, uint32_t* __restrict__ flag, uint32_t L, uint32_t H,
-                     float scale_log2e) {
+                     float scale_log2e, uint32_t HB) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int KT = 128;                        // keys per super-tile
     const uint32_t Lp = (L + 31) & ~31u;
@@ -460,21 +460,20 @@ attention_shx_kernel(const _Float16* __restrict__ qkvs, const int32_t* __restric
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, h = lane >> 5;
-    const uint32_t head = blockIdx.x, b = blockIdx.y, qb = blockIdx.z;
+    // Short sequences: a block of four waves serves HB heads (4 up to 32 tokens, 2 up to 64, else 1), wq = 4 / HB query
+    // tiles each — one head per block left three (one) of the four waves without a query tile, and the per-block
+    // overheads set the rate (2,048 x 32 tokens took 144 us per layer where the flops of 256 x 256 take 150).  Each
+    // head has KT / HB rows of the K and V images, staged by its own waves.
+    const uint32_t wq = 4 / HB, hsub = (uint32_t)wave / wq, qt = (uint32_t)wave % wq;
+    const uint32_t head = blockIdx.x * HB + hsub, b = blockIdx.y, qb = blockIdx.z;
+    Kt += (size_t)hsub * (KT / HB) * 128;
+    Vt += (size_t)hsub * (KT / HB) * 128;
     const uint32_t nh = H / (32 * NC), nch = 3 * nh * NC;  // chunks per token row: Q heads | K heads | V heads
     const _Float16* base = qkvs + (size_t)b * L * nch * 64;
     bool ovf = false;
 
     AT_STAMP(0);
     if (tid == 0) *last_valid_p = 0;
-    __syncthreads();
-    for (uint32_t key = tid; key < Lp; key += 256) {
-        const bool ok = key < L && mask[(size_t)b * L + key] != 0;
-        madd[key] = ok ? 0.0f : kMaskedLog2;
-        if (ok) atomicMax(last_valid_p, (int)key);
-    }
-    __syncthreads();
-    const uint32_t ntiles = (uint32_t)(*last_valid_p) / 32 + 1;  // 32-key tiles that hold a valid key
 
     const int kswz = (l31 >> 1) & 7;
     int k_hi[2], k_lo[2];
@@ -488,8 +487,8 @@ attention_shx_kernel(const _Float16* __restrict__ qkvs, const int32_t* __restric
     const int v_hi = (4 * h + vq) * 128 + (((2 * vg + (vp >> 1)) ^ vfv) * 16) + 8 * (vp & 1);
     const int v_lo = v_hi ^ 64;
 
-    const bool wave_live = qb * 128 + wave * 32 < L;  // wave-uniform: some query of this wave's tile exists
-    const uint32_t query = qb * 128 + wave * 32 + l31;
+    const bool wave_live = qb * 128 + qt * 32 < L;  // wave-uniform: some query of this wave's tile exists
+    const uint32_t query = qb * 128 + qt * 32 + l31;
     const uint32_t qsrc = query < L ? query : L - 1;
     f16x8 qh[NC][2], ql[NC][2];
 #pragma unroll
@@ -508,10 +507,11 @@ attention_shx_kernel(const _Float16* __restrict__ qkvs, const int32_t* __restric
         for (int r = 0; r < 16; ++r) { ohh[c][r] = 0.0f; oxx[c][r] = 0.0f; }
     float m = -__builtin_huge_valf(), lsum = 0.0f;
 
-    for (uint32_t st = 0; st * 4 < ntiles; ++st) {
-        __syncthreads();  // every wave is done with the previous super-tile
-        // stage keys [128 st, 128 st + 128): 8 keys x 128 B per instruction and image
-        for (uint32_t ii = wave; ii < (uint32_t)(KT / 8); ii += 4) {
+    // stage keys [128 st, 128 st + 128): 8 keys x 128 B per instruction and image
+    auto stage = [&](uint32_t st) {
+        // only the groups of 8 keys that exist (padded to whole 32-key tiles): a 32-token sequence stages 4 of the 16
+        const uint32_t live = Lp - st * KT < (uint32_t)KT ? Lp - st * KT : (uint32_t)KT;  // <= KT / HB when HB > 1
+        for (uint32_t ii = qt; ii < live / 8; ii += wq) {
             const uint32_t row = ii * 8 + (lane >> 3);            // key inside the super-tile
             const uint32_t gk = st * KT + row;
             const uint32_t key = gk < L ? gk : L - 1;             // keys past L are masked; read a valid line
@@ -523,8 +523,28 @@ attention_shx_kernel(const _Float16* __restrict__ qkvs, const int32_t* __restric
                 sh_glds16(base + ((size_t)key * nch + (2 * nh + head) * NC + c) * 64 + cv * 8, Vt + (size_t)c * KT * 128 + ii * 1024);
             }
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+    };
+    // A block's first round trips all leave together: the query fragments (above), the first super-tile's K / V, and the
+    // mask — waiting for the mask before the staging was issued put two memory latencies in front of every block
+    // (63 of the kernel's 150 us per layer were per-block overhead: 107 us at 128 tokens per sequence against 150 at 256).
+    stage(0);
+    __syncthreads();  // last_valid_p = 0 is visible
+    for (uint32_t key = tid; key < Lp; key += 256) {
+        const bool ok = key < L && mask[(size_t)b * L + key] != 0;
+        madd[key] = ok ? 0.0f : kMaskedLog2;
+        if (ok) atomicMax(last_valid_p, (int)key);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const uint32_t ntiles = (uint32_t)(*last_valid_p) / 32 + 1;  // 32-key tiles that hold a valid key
+
+    for (uint32_t st = 0; st * 4 < ntiles; ++st) {
+        if (st > 0) {
+            __syncthreads();  // every wave is done with the previous super-tile
+            stage(st);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
         if (!wave_live) continue;  // (still takes part in the staging and the barriers)
         const uint32_t kt_end = ntiles - st * 4 < 4 ? ntiles - st * 4 : 4;
         for (uint32_t kl = 0; kl < kt_end; ++kl) {
@@ -695,7 +715,7 @@ int32_t launch_attention_sh2(const _Float16* qkv_split, const int32_t* mask, voi
             return CS_OK;
         }));
         hipLaunchKernelGGL(attention_shx_kernel<2>, dim3(heads, B, (L + 127) / 128), dim3(256), lds, s, qkv_split, mask,
-                           static_cast<_Float16*>(ctx_split), flag, L, H, (1.0f / sqrtf(64.0f)) * kLog2e);
+                           static_cast<_Float16*>(ctx_split), flag, L, H, (1.0f / sqrtf(64.0f)) * kLog2e, 1u);
         CS_HIP(hipGetLastError());
         return CS_OK;
     }
@@ -706,8 +726,11 @@ int32_t launch_attention_sh2(const _Float16* qkv_split, const int32_t* mask, voi
     static const bool shx1 = [] { const char* e = std::getenv("CS_ATTN_SHX1"); return !(e && e[0] == '0'); }();
     if (shx1) {
         const size_t lds1 = 2 * 1 * 128 * 128 + Lp * sizeof(float) + 16;
-        hipLaunchKernelGGL(attention_shx_kernel<1>, dim3(heads, B, (L + 127) / 128), dim3(256), lds1, s, qkv_split, mask,
-                           static_cast<_Float16*>(ctx_split), flag, L, H, (1.0f / sqrtf(32.0f)) * kLog2e);
+        static const bool pack_heads = [] { const char* e = std::getenv("CS_ATTN_PACK_HEADS"); return !(e && e[0] == '0'); }();
+        uint32_t hb = !pack_heads ? 1u : (Lp <= 32 ? 4u : (Lp <= 64 ? 2u : 1u));  // heads per block (kernel comment)
+        while (heads % hb) hb >>= 1;
+        hipLaunchKernelGGL(attention_shx_kernel<1>, dim3(heads / hb, B, (L + 127) / 128), dim3(256), lds1, s, qkv_split, mask,
+                           static_cast<_Float16*>(ctx_split), flag, L, H, (1.0f / sqrtf(32.0f)) * kLog2e, hb);
         CS_HIP(hipGetLastError());
         return CS_OK;
     }
