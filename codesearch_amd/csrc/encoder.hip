@@ -691,6 +691,70 @@ pool_normalize_kernel(const float* __restrict__ x, const int32_t* __restrict__ m
     for (int i = 0; i < NPL; ++i) out[(size_t)b * H + lane + 64 * i] = v[i] / den;
 }
 
+// Mean pooling with a block per sequence (the kernel above walks a sequence with ONE wave and a mask load in front of
+// every row: 145 us for 128 x 256 tokens, all of it latency).  Wave w takes tokens 64 w .. 64 w + 63 of every 256: one
+// load of their 64 mask words, a ballot, then the rows that count in batches of four independent loads; the four waves'
+// partial sums are added in wave order (a fixed order: the result does not depend on timing).
+template <int NPL>
+__global__ void __launch_bounds__(256)
+mean_pool_normalize_kernel(const float* __restrict__ x, const int32_t* __restrict__ mask, uint32_t L,
+                           float* __restrict__ out) {
+    constexpr int H = 64 * NPL;
+    __shared__ float part[4][H];
+    __shared__ float pcnt[4];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t b = blockIdx.x;
+    float v[NPL];
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) v[i] = 0.0f;
+    float cnt = 0.0f;
+    for (uint32_t t0 = wave * 64; t0 < L; t0 += 256) {
+        const uint32_t t = t0 + lane;
+        unsigned long long live = __ballot(t < L && mask[(size_t)b * L + t] != 0);
+        cnt += (float)__popcll(live);
+        while (live) {
+            uint32_t tok[4];
+            int n = 0;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                tok[u] = 0;
+                if (live) { tok[u] = t0 + (uint32_t)__builtin_ctzll(live); live &= live - 1; n = u + 1; }
+            }
+            float r[4][NPL];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (u < n) {
+                    const float* p = x + ((size_t)b * L + tok[u]) * H;
+#pragma unroll
+                    for (int i = 0; i < NPL; ++i) r[u][i] = p[lane + 64 * i];
+                }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (u < n) {
+#pragma unroll
+                    for (int i = 0; i < NPL; ++i) v[i] += r[u][i];
+                }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) part[wave][lane + 64 * i] = v[i];
+    if (lane == 0) pcnt[wave] = cnt;
+    __syncthreads();
+    if (wave != 0) return;
+    cnt = fmaxf(pcnt[0] + pcnt[1] + pcnt[2] + pcnt[3], 1e-9f);
+    float ss = 0.0f;
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) {
+        const int c = lane + 64 * i;
+        v[i] = (((part[0][c] + part[1][c]) + part[2][c]) + part[3][c]) / cnt;
+        ss = fmaf(v[i], v[i], ss);
+    }
+    const float den = sqrtf(wave_sum(ss)) + 1e-12f;
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) out[(size_t)b * H + lane + 64 * i] = v[i] / den;
+}
+
 // ---- synthetic parameters, generated in HBM ---------------------------------------------------
 __global__ void synth_params_kernel(float* __restrict__ out, cs_bert_config cfg, cs_bert_offsets off,
                                     uint64_t seed) {
@@ -713,6 +777,8 @@ static void launch_rows(int which, const EncoderLaunch& a, hipStream_t s) {
     else if (which == 3)
         hipLaunchKernelGGL(layernorm_sum_kernel<NPL>, dim3((T + 3) / 4), dim3(256), 0, s, a.x, a.parts, a.nparts,
                            a.bias, a.g, a.b, a.eps, T, static_cast<_Float16*>(a.xs), a.flag);
+    else if (a.pooling != CS_POOL_CLS && a.L >= 16)
+        hipLaunchKernelGGL(mean_pool_normalize_kernel<NPL>, dim3(a.B), dim3(256), 0, s, a.x, a.mask, a.L, a.out);
     else
         hipLaunchKernelGGL(pool_normalize_kernel<NPL>, dim3((a.B + 3) / 4), dim3(256), 0, s, a.x, a.mask, a.B,
                            a.L, a.pooling, a.out);
