@@ -723,7 +723,10 @@ def main():
             tiles = (args.nq + per - 1) // per
             i8_bytes = args.rows * args.dim
             exe = 2.0 * args.rows * tiles * per * args.dim
-            kern = f"cs::score_filter_rw8_kernel<{per // 32},{args.dim // 128}> (+ rescore_keys_kernel / select_candidates_kernel between phases)"
+            rq8 = args.dim == 384 and args.nq > 128 and os.environ.get("CS_FILTER_INT8_RQ", "1")[0] != "0"
+            kern = (f"cs::score_filter_rq8_kernel<8,3> (eight waves per block, corpus fragments through registers)" if rq8 else
+                    f"cs::score_filter_rw8_kernel<{per // 32},{args.dim // 128}>") + \
+                " (+ rescore_keys_kernel / select_candidates_kernel between phases)"
             hbm = {"kernel": kern, "bound": "hbm", "achieved": i8_bytes / (scan_us * 1e-6) / 1e9, "peak": HBM_PEAK_GBPS,
                    "unit": "GB/s", "frac": i8_bytes / (scan_us * 1e-6) / 1e9 / HBM_PEAK_GBPS, "traffic": None,
                    "algorithmic_bytes_per_launch": i8_bytes,

@@ -1305,6 +1305,161 @@ score_filter_rw8_kernel(const int8_t* __restrict__ corpus_q8, const float2* __re
     cand_flush(pend, npend, lane, cand, cnt, cap);
 }
 
+// ---- many queries over the int8 copy: two waves per SIMD ---------------------------------------------
+// With 256 resident queries score_filter_rw8_kernel<8, 3> runs ONE wave per SIMD (its ring and the query image fill
+// the LDS, its accumulators half the registers), and a wave issues in order: the 1-KiB LDS read behind every MFMA, the
+// MFMAs and the threshold epilogue add up instead of overlapping (ablations in DESIGN.md 9.0c: ~2 us of LDS reads + ~2
+// us of MFMAs + 0.9 us of epilogue per 128 rows x 256 queries).  Here a block is EIGHT waves — two per SIMD, 256
+// registers each: 128 accumulators + at most 128 others — over one query image: a wave's corpus fragments never
+// touch LDS (lane (row l31, half h) loads its 16 B of MFMA step st — bytes (2 st + h) * 16 of the row's 128-B line, the
+// k order of the query image — with plain global loads, one unit ahead), so LDS holds only the queries and while one
+// wave of a SIMD waits for its query fragments or works through an epilogue the other one feeds the matrix pipe.
+// A unit is 256 rows (two corpus tiles): wave w owns rows 32 w .. 32 w + 31 of it.  1,000 queries over 10M rows:
+// 5.9 -> 4.8 ms per search (512: 3.2 -> 2.5; 129: 1.6 -> 1.45).  Ablations of the last phase (3.81 ms): 3.08 without
+// the epilogue, 1.68 with one MFMA in eight — the MFMAs' share (4.2 us per unit) is close to what the matrix pipe
+// sustains on such operands (3.8), and what is left (LDS reads, epilogue, loads: 3.3 us) still adds to it rather
+// than hiding under it: the part is power-limited, and time follows the energy of everything a kernel does.
+template <int I, int N, typename F>
+__device__ __forceinline__ void cs_static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        cs_static_for<I + 1, N>(f);
+    }
+}
+
+template <int NQT, int KC>
+constexpr int kRq8Lds = KC * 32 * NQT * 128 + 8 * (int)kPend * 8;  // the query image + eight pending-candidate lists
+
+template <int NQT, int KC, bool NT>
+__global__ void __launch_bounds__(512)
+score_filter_rq8_kernel(const int8_t* __restrict__ corpus_q8, const float2* __restrict__ tmeta, uint64_t row_lo,
+                        uint64_t row_hi, const int8_t* __restrict__ queries_q8, const float4* __restrict__ qmeta,
+                        uint32_t nq, const float* __restrict__ tau, const uint32_t* __restrict__ dead,
+                        uint32_t* __restrict__ cand, uint32_t* __restrict__ cnt, uint32_t cap, uint32_t qtiles,
+                        float slack) {
+    constexpr int DIM = 128 * KC;
+    constexpr int QROWS = 32 * NQT;
+    constexpr int WBYTES = KC * QROWS * 128;
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    char* Wl = lds;  // [KC][QROWS][128 B], slots swizzled as in uf_mainloop
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // 0 .. 7
+    const int l31 = lane & 31, h = lane >> 5;
+    const uint64_t M = row_hi - row_lo;            // a multiple of 128 (whole corpus tiles)
+    const uint64_t nunit = (M + 255) / 256;        // the last unit may hold one real tile: its second tile is
+                                                   // allocated (even tile count) and its rows are masked
+    const uint64_t tile_lo = row_lo >> 7;
+    const uint32_t xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const uint32_t qt = slot % qtiles, rg = slot / qtiles, rgn = (gridDim.x >> 3) / qtiles;
+    if (rg >= rgn) return;
+    const uint32_t q0 = qt * QROWS;
+
+    // resident queries: 8 rows x 128 B per instruction, KC * NQT * 4 instructions over eight waves
+    for (int g8 = wave; g8 < KC * NQT * 4; g8 += 8) {
+        const int c = g8 / (4 * NQT), r8 = g8 % (4 * NQT);
+        const int row = r8 * 8 + (lane >> 3);
+        const int pc = (lane & 7) ^ ((row >> 1) & 7);
+        const uint32_t q = q0 + row < nq ? q0 + row : nq - 1;
+        sh_glds16(queries_q8 + (size_t)q * DIM + c * 128 + pc * 16, Wl + (c * QROWS + r8 * 8) * 128);
+    }
+    uf_wait_vmcnt<0>();
+    __syncthreads();
+
+    float tqs[NQT], cq[NQT];
+    bool qok[NQT];
+#pragma unroll
+    for (int t = 0; t < NQT; ++t) {
+        const uint32_t q = q0 + 32 * t + l31;
+        qok[t] = q < nq;
+        const float4 m = qmeta[qok[t] ? q : 0];
+        tqs[t] = (tau[qok[t] ? q : 0] - slack - m.z) * m.x;
+        cq[t] = m.y;
+    }
+    const int swz = (l31 >> 1) & 7;
+    int w_sl[4];
+#pragma unroll
+    for (int st = 0; st < 4; ++st) w_sl[st] = l31 * 128 + (((2 * st + h) ^ swz) * 16);
+
+    const uint64_t u0 = (uint64_t)rg * 8 + xcd, ustep = (uint64_t)rgn * 8;
+    if (u0 >= nunit) return;
+    const uint64_t my_units = (nunit - u0 + ustep - 1) / ustep;
+    // this wave's rows of unit u: corpus tile 2 u + (wave >> 2), rows 32 (wave & 3) + l31 of it
+    const uint32_t wtile = (uint32_t)wave >> 2, wrow = ((uint32_t)wave & 3) * 32;
+    const int8_t* lane_base = corpus_q8 + ((tile_lo + wtile) * KC * 128 + wrow + l31) * 128 + h * 16;
+    // (Hand-counted waits on loads the compiler does not track were measured here too: within 1 % — with two waves per
+    // SIMD the compiler's conservative vmcnt(0) at the loop header costs nothing measurable.)
+    auto frag = [&](uint64_t u, int c, int st) {
+        const i32x4* p = reinterpret_cast<const i32x4*>(lane_base + ((u * 2 * KC + c) * 128) * 128 + st * 32);
+        return NT ? __builtin_nontemporal_load(p) : *p;
+    };
+    i32x4 a[KC][4];
+#pragma unroll
+    for (int c = 0; c < KC; ++c)
+#pragma unroll
+        for (int st = 0; st < 4; ++st) a[c][st] = frag(u0, c, st);
+
+    volatile uint64_t* pend = reinterpret_cast<volatile uint64_t*>(lds + WBYTES) + wave * kPend;
+    uint32_t npend = 0;  // wave-uniform
+    const float2* tm = tmeta + tile_lo + wtile;
+    float2 tm_next = tm[u0 * 2];
+    i32x16 acc[NQT];
+    for (uint64_t n = 0; n < my_units; ++n) {
+        const uint64_t u = u0 + n * ustep;
+        const uint64_t un = n + 1 < my_units ? u + ustep : u;  // the last unit re-reads itself (discarded)
+        const float2 tmv = tm_next;
+        tm_next = tm[un * 2];
+#pragma unroll
+        for (int t = 0; t < NQT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][r] = 0;
+        cs_static_for<0, KC>([&](auto CC) {
+            constexpr int c = decltype(CC)::value;
+            const char* wc = Wl + c * QROWS * 128;
+#pragma unroll
+            for (int st = 0; st < 4; ++st) {
+                i32x4 w[NQT];
+#pragma unroll
+                for (int t = 0; t < NQT; ++t) w[t] = *reinterpret_cast<const i32x4*>(wc + t * 32 * 128 + w_sl[st]);
+#pragma unroll
+                for (int t = 0; t < NQT; ++t) acc[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[c][st], w[t], acc[t], 0, 0, 0);
+            }
+            // the registers of stage c are free: the same stage of the next unit (fenced: hoisted above the MFMAs the
+            // loads would need registers of their own)
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int st = 0; st < 4; ++st) a[c][st] = frag(un, c, st);
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        // the last MFMAs' results are read below through inline asm the hazard recogniser does not see into
+        asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+        cs_static_for<0, NQT>([&](auto TC) {
+            constexpr int t = decltype(TC)::value;
+            // I > T  <=>  I > floor(T) for an integer I; NaN (flagged tile or query) -> every row
+            const float T = floorf(fmaf(tqs[t], tmv.x, -(tmv.y + cq[t])));
+            const int Ti = (T == T) ? (T < -2.0e9f ? (int)0x80000000 : (T > 2.0e9f ? 0x7fffffff : (int)T)) : (int)0x80000000;
+            const bool all = !(T == T) || T < -2.0e9f;
+            // explicit reads: left to itself the compiler copies every accumulator out of the AGPRs in one block
+            int v[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(v[r]) : "a"(acc[t][r]));
+            int top = v[0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) top = v[r] > top ? v[r] : top;
+            if (!__ballot(qok[t] && (all || top > Ti))) return;
+            uint32_t hm = 0;  // a tile with a candidate (rare): sixteen pushes as ONE rolled loop over a hit mask
+#pragma unroll
+            for (int r = 0; r < 16; ++r) hm |= (uint32_t)(all || v[r] > Ti) << r;
+#pragma nounroll
+            for (int r = 0; r < 16; ++r) {
+                const uint64_t m = u * 256 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                cand_push(qok[t] && m < M && ((hm >> r) & 1u), q0 + 32 * t + l31, row_lo + m, dead, pend, npend, lane, cand,
+                          cnt, cap);
+            }
+        });
+    }
+    cand_flush(pend, npend, lane, cand, cnt, cap);
+}
+
 // ---- host side ----------------------------------------------------------------------------
 
 bool split_scan_supported(uint32_t dim) { return dim == 384 || dim == 768 || dim == 1024; }
@@ -1395,9 +1550,14 @@ static int32_t scan_split_impl(const BatchedState& st, const SplitQueryWs& qw, c
         if constexpr (J <= 6)
             CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(score_filter_rw8_kernel<4, J>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, Rw8Geom<4, J>::LDS_ALL));
-        if constexpr (J == 3)
+        if constexpr (J == 3) {
             CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(score_filter_rw8_kernel<8, J>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, Rw8Geom<8, J>::LDS_ALL));
+            CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(score_filter_rq8_kernel<8, 3, true>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, kRq8Lds<8, 3>));
+            CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(score_filter_rq8_kernel<8, 3, false>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, kRq8Lds<8, 3>));
+        }
 
         return CS_OK;
     }));
@@ -1416,6 +1576,7 @@ static int32_t scan_split_impl(const BatchedState& st, const SplitQueryWs& qw, c
     // the same tile kernel on int8 2.30 / 2.45 / 4.36 / 7.98 (LDS traffic, not MFMA rate, paces it), the resident-query
     // kernel on int8 1.61 / 1.82 / 3.20 / 5.95 — so the tile kernel only takes what exceeds 32 query tiles.
     const uint32_t q8_rw_max = q8_rw_env ? std::min(q8_rw_env, q8_rw_limit) : q8_rw_limit;
+    static const bool rq8_on = [] { const char* e = std::getenv("CS_FILTER_INT8_RQ"); return !(e && e[0] == '0'); }();
     const bool use_q8 = q8 && q8->d_q8 && q8->rows > 1024 && (!q8_max_env || nq <= q8_max_env) && qw.d_q8q && qw.d_qmeta;
     hipLaunchKernelGGL(prep_queries_kernel<J>, dim3((nq + 7) / 8), dim3(256), 0, stream,
                        qw.q_pinned ? qw.q_pinned : d_queries, qw.q_pinned ? const_cast<float*>(d_queries) : nullptr, nq,
@@ -1483,6 +1644,25 @@ static int32_t scan_split_impl(const BatchedState& st, const SplitQueryWs& qw, c
                                        reinterpret_cast<const _Float16*>(qw.d_q8q), nq, st.d_tau, d_dead, cand, st.d_cnt, cap,
                                        slots, q8_slack(dim), q8->d_tmeta, qw.d_qmeta);
                     CS_HIP(hipGetLastError());
+                } else if (q_hi > lo && J == 3 && nq > 128 && rq8_on) {
+                    // many queries at dim 384: eight waves over 256 resident queries, corpus fragments through registers
+                    if constexpr (J == 3) {
+                        const uint32_t qtiles = (nq + 255) / 256;
+                        const uint64_t units = ((q_hi - lo) / 128 + 1) / 2;
+                        uint64_t slots = (units + 7) / 8 * qtiles;  // per XCD
+                        if (slots > (uint64_t)cus8 / 8) slots = (uint64_t)cus8 / 8;
+                        if (slots < qtiles) slots = qtiles;
+                        const uint32_t blocks = (uint32_t)slots * 8;
+                        if (qtiles == 1)
+                            hipLaunchKernelGGL((score_filter_rq8_kernel<8, 3, true>), dim3(blocks), dim3(512), (kRq8Lds<8, 3>), stream,
+                                               q8->d_q8, q8->d_tmeta, lo, q_hi, qw.d_q8q, qw.d_qmeta, nq, st.d_tau, d_dead, cand,
+                                               st.d_cnt, cap, qtiles, q8_slack(dim));
+                        else
+                            hipLaunchKernelGGL((score_filter_rq8_kernel<8, 3, false>), dim3(blocks), dim3(512), (kRq8Lds<8, 3>), stream,
+                                               q8->d_q8, q8->d_tmeta, lo, q_hi, qw.d_q8q, qw.d_qmeta, nq, st.d_tau, d_dead, cand,
+                                               st.d_cnt, cap, qtiles, q8_slack(dim));
+                        CS_HIP(hipGetLastError());
+                    }
                 } else if (q_hi > lo) {
                     // above 128 queries at dim 384: 256 resident queries per block — half the query tiles re-reading the
                     // corpus through L2 (1,000 queries over 10M rows: 7.21 -> 5.95 ms; 129: 1.97 -> 1.61); "0" = A/B

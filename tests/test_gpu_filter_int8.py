@@ -73,6 +73,28 @@ def test_int8_tile_kernel_for_query_counts_past_the_resident_limit(VS, monkeypat
     assert ids[nq - 1][0] == n - 1
 
 
+@pytest.mark.parametrize("rq", ["1", "0"])
+@pytest.mark.parametrize("n,nq,k", [(70_000, 129, 10), (50_000, 257, 64), (33_000, 700, 10)])
+def test_many_queries_both_resident_query_kernels(VS, monkeypatch, rq, n, nq, k):
+    """Above 128 queries at dim 384 the int8 copy is scored by score_filter_rq8_kernel (eight waves per block, corpus
+    fragments through registers); CS_FILTER_INT8_RQ=0 keeps score_filter_rw8_kernel<8, 3>.  Odd tile counts: the last
+    256-row unit holds one real 128-row tile."""
+    monkeypatch.setenv("CS_FILTER_INT8_RQ", rq)
+    monkeypatch.setenv("CS_FILTER_SINGLE_MIN_K", "0")
+    st = VS(None, 384)
+    st.insert_synthetic(n, 1234, 0)
+    st.delete_chunks([5, n // 2, n - 3])
+    st.build_index()
+    qs = np.concatenate([synth_rows(80 + nq, 0, nq - 2, 384), synth_planted(1234, 5, [n - 1, n // 128 * 128 - 1], 384)])
+    before = st.debug_counters()[1]
+    cos, ids, counts = st.search_raw(qs, k)
+    assert st.debug_counters()[1] == before
+    for i in list(range(0, nq, 41)) + [nq - 2, nq - 1]:
+        c1, i1, n1 = st.search_raw(qs[i], k)
+        assert counts[i] == n1[0] and ids[i].tolist() == i1[0].tolist() and cos[i].tobytes() == c1[0].tobytes(), i
+    assert ids[nq - 2][0] == n - 1 and ids[nq - 1][0] == n // 128 * 128 - 1
+
+
 def test_rows_that_stress_the_quantiser(VS, oracle, monkeypatch):
     """Outlier elements (one huge coordinate: the tile's scale collapses for everyone else), sparse rows, rows of
     wildly different magnitudes, zero rows, NaN / Inf rows inside a tile, thousands of near-duplicates of the query
