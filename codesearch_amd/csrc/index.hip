@@ -79,7 +79,7 @@ struct Workspace {
             if (qw.d_qmeta) (void)hipFree(qw.d_qmeta);
             qw.d_qmag = nullptr; qw.d_qmeta = nullptr; qw_nq = 0;
             CS_HIP(hipMalloc(&qw.d_qmag, nq * sizeof(float)));
-            CS_HIP(hipMalloc(&qw.d_qmeta, nq * sizeof(float4)));
+            CS_HIP(hipMalloc(&qw.d_qmeta, 2 * (size_t)nq * sizeof(float4)));
             qw_nq = nq;
         }
         return CS_OK;
@@ -246,7 +246,7 @@ struct cs_index {
     bool use_split = false;
     // int8 filter copy (scan_filter.hip): complete 128-row tiles [0, q8_rows / 128), a quarter of the f32 bytes
     int8_t* d_q8 = nullptr;
-    float2* d_tmeta = nullptr;
+    float4* d_tmeta = nullptr;
     float* d_mu = nullptr;   // [dim] mean unit row of the first build: the copy holds u - mu (fixed until clear())
     uint64_t q8_rows = 0;
     bool use_q8 = false;
@@ -350,9 +350,9 @@ int32_t grow(cs_index* h, uint64_t need_rows) {
     }
     if (h->use_split && h->use_q8) {
         int8_t* n8 = nullptr;
-        float2* nm = nullptr;
+        float4* nm = nullptr;
         const size_t tiles = ((size_t)cap + 255) / 256 * 2;  // an even number: the 256-row tile kernel reads whole pairs
-        if (hipMalloc(&n8, tiles * 128 * h->dim) != hipSuccess || hipMalloc(&nm, tiles * sizeof(float2)) != hipSuccess) {
+        if (hipMalloc(&n8, tiles * 128 * h->dim) != hipSuccess || hipMalloc(&nm, tiles * sizeof(float4)) != hipSuccess) {
             (void)hipGetLastError();  // no room: the filter stays on the f16 copy
             if (n8) (void)hipFree(n8);
             h->use_q8 = false;
@@ -360,7 +360,7 @@ int32_t grow(cs_index* h, uint64_t need_rows) {
         } else {
             if (h->q8_rows) {
                 CS_HIP(hipMemcpy(n8, h->d_q8, (size_t)h->q8_rows * h->dim, hipMemcpyDeviceToDevice));
-                CS_HIP(hipMemcpy(nm, h->d_tmeta, (size_t)(h->q8_rows / 128) * sizeof(float2), hipMemcpyDeviceToDevice));
+                CS_HIP(hipMemcpy(nm, h->d_tmeta, (size_t)(h->q8_rows / 128) * sizeof(float4), hipMemcpyDeviceToDevice));
             }
         }
         if (h->d_q8) (void)hipFree(h->d_q8);
@@ -819,11 +819,11 @@ int32_t cs_index_build(cs_index* h) {
         // through more rows than the candidate buffers hold — the f16 copy serves the filter then
         {
             const uint64_t nt = std::min<uint64_t>(h->q8_rows / 128, 4096);
-            std::vector<float2> tm((size_t)nt);
-            CS_HIP(hipMemcpy(tm.data(), h->d_tmeta, (size_t)nt * sizeof(float2), hipMemcpyDeviceToHost));
+            std::vector<float4> tm((size_t)nt);
+            CS_HIP(hipMemcpy(tm.data(), h->d_tmeta, (size_t)nt * sizeof(float4), hipMemcpyDeviceToHost));
             std::vector<float> sp;
             sp.reserve((size_t)nt);
-            for (const float2& t : tm)
+            for (const float4& t : tm)
                 if (t.x == t.x && t.x > 0.0f) sp.push_back(127.0f / t.x * std::sqrt((float)h->dim));
             if (!sp.empty()) {
                 std::nth_element(sp.begin(), sp.begin() + sp.size() / 2, sp.end());

@@ -118,18 +118,20 @@ struct SplitQueryWs {
     // which saves the H2D copy call (~6 us of a 45-us search over a small corpus).  Null otherwise.
     const float* q_pinned = nullptr;
     int8_t* d_q8q = nullptr;       // [nq][dim] int8: q / |q| on the query's own scale (int8 filter copy)
-    float4* d_qmeta = nullptr;     // [nq] {127 / max |q_i / |q||, 0.5001 sum |b_i| + 0.2501 dim + guard, q / |q| . mu, 0}
+    float4* d_qmeta = nullptr;     // [2 nq]: [q] = {127 / max |q_i / |q||, 0.5001 sum |b_i|, q / |q| . mu, sqrt(sum b_i^2)},
+                                   // [nq + q].x = sqrt(sum d_i^2), d = the query's rounding errors (q8_threshold)
 };
 // int8 filter copy of the corpus (scan_filter.hip, "int8 filter copy"): complete 128-row tiles [0, rows / 128)
 struct Q8View {
     const int8_t* d_q8 = nullptr;    // [tile][dim / 128][128 rows][128 B]
-    const float2* d_tmeta = nullptr; // [tile] {127 / max |u|, 0.5001 max row sum |a_i|}; x = NaN: every row is a candidate
+    const float4* d_tmeta = nullptr; // [tile] {127 / max |u - mu|, 0.5001 max row sum |a_i|, max row error norm, max row norm of a};
+                                     // x = NaN: every row is a candidate
     const float* d_mu = nullptr;     // [dim] the mean unit row the copy is centred on (q.u = q.(u - mu) + q.mu)
     uint64_t rows = 0;               // multiple of 128
 };
 bool split_scan_supported(uint32_t dim);
 // rows [first_tile * 128, (first_tile + ntiles) * 128) of the f32 corpus -> int8 tiles + their scales
-int32_t launch_corpus_q8(const float* d_corpus, const float* d_norms, int8_t* d_q8, float2* d_tmeta, uint64_t first_tile,
+int32_t launch_corpus_q8(const float* d_corpus, const float* d_norms, int8_t* d_q8, float4* d_tmeta, uint64_t first_tile,
                          uint64_t ntiles, uint32_t dim, const float* d_mu, hipStream_t stream);
 // d_mu[dim] = mean over rows [0, n) of x / |x|
 int32_t launch_unit_mean(const float* d_corpus, const float* d_norms, uint64_t n, uint32_t dim, float* d_mu,

@@ -139,17 +139,33 @@ __device__ __forceinline__ float half_max_q8(float v) {
     return v;
 }
 // four unit values -> four int8 in one dword (element 0 in the low byte), and the sum of their magnitudes
-__device__ __forceinline__ uint32_t q8_pack4(const f32x4 u, float inv, int& abs_sum) {
+// ... and of their squares (sq_sum) and of the squared rounding errors (err_sum): the Cauchy-Schwarz side of the bound
+__device__ __forceinline__ uint32_t q8_pack4(const f32x4 u, float inv, int& abs_sum, float& sq_sum, float& err_sum) {
     uint32_t w = 0;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-        float r = rintf(u[e] * inv);
+        const float t = u[e] * inv;
+        float r = rintf(t);
         r = fminf(fmaxf(r, -127.0f), 127.0f);  // NaN -> -127 (fmaxf drops it): such a tile is flagged anyway
         const int a = (int)r;
         abs_sum += a < 0 ? -a : a;
+        sq_sum = fmaf(r, r, sq_sum);
+        err_sum = fmaf(t - r, t - r, err_sum);
         w |= ((uint32_t)a & 0xffu) << (8 * e);
     }
     return w;
+}
+// The threshold of the int8 filter for one (tile, query): a row can beat tau only if its integer product I exceeds it.
+//   tile  {inv_t, 0.5001 B_t, E_t, N_t}:  B_t / E_t / N_t = the largest sum |a_i| / error norm sqrt(sum e_i^2) / norm
+//                                         sqrt(sum a_i^2) of the tile's rows
+//   query tqs = (tau - slack - q.mu) inv_q,  hA = 0.5001 sum |b_i|,  nb = sqrt(sum b_i^2),  Dq = sqrt(sum d_i^2)
+// |sum b_i e_i| <= min(max|e| sum|b_i|, |b| |e|) and likewise for the other two error terms: whichever side is tighter
+// (the L1 side for sparse or one-hot vectors, the Cauchy-Schwarz side — ~0.7 of it — for evenly spread ones).
+__device__ __forceinline__ float q8_threshold(float tqs, float hA, float nb, float Dq, const float4 tm, float dimq) {
+    const float tA = fminf(hA, nb * tm.z);
+    const float tB = fminf(tm.y, tm.w * Dq);
+    const float tC = fminf(dimq, tm.z * Dq);
+    return floorf(fmaf(tqs, tm.x, -(tA + tB + tC + kQ8Guard)));
 }
 
 // Everything a batched search needs before its first phase, in one launch (three kernels of ~2 us
@@ -199,14 +215,17 @@ prep_queries_kernel(const float* __restrict__ queries, float* __restrict__ qcopy
         mx = half_max_q8(mx);
         const float inv = (mx > 0.0f && mx < __builtin_huge_valf()) ? 127.0f / mx : 1.0f;
         int abs_sum = 0;
+        float sq_sum = 0.0f, err_sum = 0.0f;
 #pragma unroll
         for (int j = 0; j < J; ++j) {
             f32x4 u;
 #pragma unroll
             for (int e = 0; e < 4; ++e) u[e] = m == 0.0f ? 0.0f : v[j][e] / m;
-            *reinterpret_cast<uint32_t*>(q8q + (size_t)q * DIM + (l32 + 32 * j) * 4) = q8_pack4(u, inv, abs_sum);
+            *reinterpret_cast<uint32_t*>(q8q + (size_t)q * DIM + (l32 + 32 * j) * 4) = q8_pack4(u, inv, abs_sum, sq_sum, err_sum);
         }
         abs_sum = half_sum_i(abs_sum);
+        sq_sum = half_sum_s(sq_sum);
+        err_sum = half_sum_s(err_sum);
         // the corpus copy holds u - mu (mu: the mean unit row at the first build): q.u = q.(u - mu) + q.mu, the second
         // term exact per query
         float qmu = 0.0f;
@@ -219,8 +238,10 @@ prep_queries_kernel(const float* __restrict__ queries, float* __restrict__ qcopy
             }
             qmu = half_sum_s(qmu);
         }
-        if (l32 == 0)
-            qmeta[q] = make_float4(inv, kQ8Half * (float)abs_sum + kQ8Quarter * (float)DIM + kQ8Guard, qmu, 0.0f);
+        if (l32 == 0) {  // (norms a hair up: their own f32 rounding)
+            qmeta[q] = make_float4(inv, kQ8Half * (float)abs_sum, qmu, sqrtf(sq_sum) * 1.0001f);
+            qmeta[nq + q] = make_float4(sqrtf(err_sum) * 1.001f + 1.0e-3f, 0.0f, 0.0f, 0.0f);
+        }
     }
     for (uint32_t i = l32; i < k; i += 32) carry[(size_t)q * k + i] = 0ull;
     if (l32 == 0) {
@@ -564,7 +585,7 @@ score_filter256p_kernel(const _Float16* __restrict__ corpus_h, uint64_t row_lo, 
                         const _Float16* __restrict__ queries_h, uint32_t nq, const float* __restrict__ tau,
                         const uint32_t* __restrict__ dead, uint32_t* __restrict__ cand,
                         uint32_t* __restrict__ cnt, uint32_t cap, uint32_t total_slots, float margin,
-                        const float2* __restrict__ tmeta, const float4* __restrict__ qmeta) {
+                        const float4* __restrict__ tmeta, const float4* __restrict__ qmeta) {
     using Frag = typename std::conditional<I8, i32x4, f16x8>::type;
     using Acc = typename std::conditional<I8, i32x4, sh_f32x4v>::type;
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -723,7 +744,7 @@ score_filter256p_kernel(const _Float16* __restrict__ corpus_h, uint64_t row_lo, 
         // threshold epilogue of (mt, nt) while the next tile's stage 0 is in flight
         // (C/D of the 16x16 MFMA: query = lane & 15, row = 4 (lane >> 4) + r)
         const uint32_t m0 = mt * UF2_BM, n0 = nt * UF2_BN;
-        float2 tmv = make_float2(0.0f, 0.0f);
+        float4 tmv = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         if constexpr (I8) tmv = tmeta[(row_lo >> 7) + 2 * mt + (wr >> 1)];  // uniform: a scalar load (rows past M: masked)
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -736,7 +757,8 @@ score_filter256p_kernel(const _Float16* __restrict__ corpus_h, uint64_t row_lo, 
             bool all = false;
             if constexpr (I8) {
                 const float4 qm = qmeta[qok ? q : 0];
-                const float T = floorf(fmaf((tau[qok ? q : 0] - margin - qm.z) * qm.x, tmv.x, -(tmv.y + qm.y)));
+                const float T = q8_threshold((tau[qok ? q : 0] - margin - qm.z) * qm.x, qm.y, qm.w, qmeta[nq + (qok ? q : 0)].x, tmv,
+                                             kQ8Quarter * 128.0f * (float)kchunks);
                 all = !(T == T) || T < -2.0e9f;
                 ti = T > 2.0e9f ? 0x7fffffff : (int)T;
             } else {
@@ -1025,13 +1047,17 @@ rescore_keys_kernel(const float* __restrict__ corpus, const float* __restrict__ 
 // 0.5 + 127 * 2^-24 (the f32 rounding of the product before rint), so
 //   sum u_i v_i = s_t s_q (I + sum b_i e_i + sum a_i d_i + sum e_i d_i),   I = sum a_i b_i  (the MFMA's output, exact)
 //   |sum u_i v_i - s_t s_q I| <= s_t s_q (0.5001 (A_q + B_t) + 0.2501 dim),   A_q = sum |b_i|,  B_t = max over the tile's rows of sum |a_i|.
+// Each of the three error sums is also bounded by Cauchy-Schwarz — |sum b_i e_i| <= |b| |e| with the rows' ACTUAL
+// error norms, which the quantiser measures (sqrt(dim / 12) per unit of scale for evenly spread values, against the
+// worst case 0.5 sqrt(dim)) — and the kernels take whichever side is smaller per (tile, query) (q8_threshold): the
+// L1 side for sparse or one-hot vectors, the Cauchy-Schwarz side (~0.7 of it) for evenly spread ones.
 // The refine's cosine differs from sum u_i v_i by f32 rounding only (<= dim * 2^-23 + 4e-5, kQ8Slack).  A row whose
 // exact cosine beats tau therefore has
-//   I > (tau - slack) * inv_q * inv_t - 0.5001 (A_q + B_t) - 0.2501 dim
+//   I > (tau - slack) * inv_q * inv_t - min(0.5001 A_q, |b| E_t) - min(0.5001 B_t, N_t |d|) - min(0.2501 dim, E_t |d|)
 // and the kernel appends every row above that line lowered by 4 more units (rounding of the f32 expression itself:
-// its terms stay below 2^23, inv <= 127 sqrt(dim)).  In cosine units the band is ~0.024 at 384-d for Gaussian-like
-// rows (the f16 copy: 0.001): a few dozen extra candidates per query at k = 10 over 10M random rows, a few thousand per
-// phase at k = 200 — against half the bytes streamed.  A tile holding a non-finite value has inv_t = NaN and all its
+// its terms stay below 2^23, inv <= 127 sqrt(dim)).  In cosine units the band is ~0.017 at 384-d for Gaussian-like
+// rows (0.024 on the L1 side alone; the f16 copy: 0.001): a few dozen extra candidates per query at k = 10 over 10M
+// random rows, a couple of thousand per phase at k = 200 — against half the bytes streamed.  A tile holding a non-finite value has inv_t = NaN and all its
 // rows become candidates (the refine decides).  Only complete tiles are quantised (a tile is written once, when
 // cs_index_build first sees it full: a search running beside a build never reads a tile being rewritten); the rows
 // behind the last complete tile are appended as candidates outright (tail_candidates_kernel, < 128 rows).
@@ -1076,9 +1102,9 @@ __global__ void mean_finish_kernel(float* __restrict__ mu, uint32_t dim, float i
 template <int J>
 __global__ void __launch_bounds__(256)
 corpus_q8_kernel(const float* __restrict__ corpus, const float* __restrict__ row_norm, int8_t* __restrict__ q8,
-                 float2* __restrict__ tmeta, uint64_t tile0, const float* __restrict__ mu) {
+                 float4* __restrict__ tmeta, uint64_t tile0, const float* __restrict__ mu) {
     constexpr int DIM = 128 * J;
-    __shared__ float s_max[8];
+    __shared__ float s_max[8], s_err[8], s_sq[8];
     __shared__ int s_bad[8], s_abs[8];
     const uint64_t tile = tile0 + blockIdx.x;
     const int tid = threadIdx.x, l32 = tid & 31, hw = tid >> 5;
@@ -1112,29 +1138,38 @@ corpus_q8_kernel(const float* __restrict__ corpus, const float* __restrict__ row
     for (int i = 0; i < 8; ++i) { mx = fmaxf(mx, s_max[i]); bad |= s_bad[i]; }
     const float inv = mx > 0.0f ? 127.0f / mx : 1.0f;
     int bmax = 0;
+    float emax = 0.0f, smax = 0.0f;  // largest squared error norm / squared norm of a row
     for (int r = hw; r < 128; r += 8) {
         const uint64_t row = tile * 128 + r;
         const float nrm = row_norm[row];
         const f32x4* p = reinterpret_cast<const f32x4*>(corpus + row * DIM) + l32;
         int abs_sum = 0;
+        float sq_sum = 0.0f, err_sum = 0.0f;
 #pragma unroll
         for (int j = 0; j < J; ++j) {
             const f32x4 v = p[j * 32];
             f32x4 u;
 #pragma unroll
             for (int e = 0; e < 4; ++e) u[e] = (nrm == 0.0f ? 0.0f : v[e] / nrm) - mv[j][e];
-            const uint32_t w = q8_pack4(u, inv, abs_sum);
+            const uint32_t w = q8_pack4(u, inv, abs_sum, sq_sum, err_sum);
             *reinterpret_cast<uint32_t*>(q8 + ((tile * J + j) * 128 + r) * 128 + l32 * 4) = w;
         }
         abs_sum = half_sum_i(abs_sum);
         bmax = abs_sum > bmax ? abs_sum : bmax;
+        emax = fmaxf(emax, half_sum_s(err_sum));
+        smax = fmaxf(smax, half_sum_s(sq_sum));
     }
-    if (l32 == 0) s_abs[hw] = bmax;
+    if (l32 == 0) { s_abs[hw] = bmax; s_err[hw] = emax; s_sq[hw] = smax; }
     __syncthreads();
     if (tid == 0) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) bmax = s_abs[i] > bmax ? s_abs[i] : bmax;
-        tmeta[tile] = make_float2(bad ? __builtin_nanf("") : inv, kQ8Half * (float)bmax);
+        for (int i = 0; i < 8; ++i) {
+            bmax = s_abs[i] > bmax ? s_abs[i] : bmax;
+            emax = fmaxf(emax, s_err[i]);
+            smax = fmaxf(smax, s_sq[i]);
+        }
+        tmeta[tile] = make_float4(bad ? __builtin_nanf("") : inv, kQ8Half * (float)bmax, sqrtf(emax) * 1.001f + 1.0e-3f,
+                                  sqrtf(smax) * 1.0001f);
     }
 }
 
@@ -1164,7 +1199,7 @@ using Rw8Geom = RwGeom<NQT, KC, (NQT == 1 ? CS_RW8_RCAP1 : CS_RW8_RCAP2)>;
 // score_filter_rw_kernel over the int8 copy.  KC = dim / 128 stages per tile; rows [row_lo, row_hi) are whole tiles.
 template <int NQT, int KC>
 __global__ void __launch_bounds__(256)
-score_filter_rw8_kernel(const int8_t* __restrict__ corpus_q8, const float2* __restrict__ tmeta, uint64_t row_lo,
+score_filter_rw8_kernel(const int8_t* __restrict__ corpus_q8, const float4* __restrict__ tmeta, uint64_t row_lo,
                         uint64_t row_hi, const int8_t* __restrict__ queries_q8, const float4* __restrict__ qmeta,
                         uint32_t nq, const float* __restrict__ tau, const uint32_t* __restrict__ dead,
                         uint32_t* __restrict__ cand, uint32_t* __restrict__ cnt, uint32_t cap, uint32_t qtiles,
@@ -1182,7 +1217,7 @@ score_filter_rw8_kernel(const int8_t* __restrict__ corpus_q8, const float2* __re
     const uint64_t tile_lo = row_lo >> 7;  // row_lo, row_hi are multiples of 128
     const uint64_t ntile = (row_hi - row_lo) >> 7;
     const int8_t* base = corpus_q8 + tile_lo * KC * 128 * 128;
-    const float2* tm = tmeta + tile_lo;
+    const float4* tm = tmeta + tile_lo;
     const uint32_t xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     const uint32_t qt = slot % qtiles, rg = slot / qtiles, rgn = (gridDim.x >> 3) / qtiles;
     if (rg >= rgn) return;
@@ -1201,8 +1236,8 @@ score_filter_rw8_kernel(const int8_t* __restrict__ corpus_q8, const float2* __re
     uf_wait_vmcnt<0>();
     __syncthreads();
 
-    // per query (lane & 31): tqs = (tau - slack) * inv_q and cq = 0.5001 A_q + 0.2501 dim + guard
-    float tqs[NQT], cq[NQT];
+    // per query (lane & 31): tqs = (tau - slack - q.mu) * inv_q and the three constants of q8_threshold
+    float tqs[NQT], hA[NQT], nb[NQT], Dq[NQT];
     bool qok[NQT];
 #pragma unroll
     for (int t = 0; t < NQT; ++t) {
@@ -1210,7 +1245,9 @@ score_filter_rw8_kernel(const int8_t* __restrict__ corpus_q8, const float2* __re
         qok[t] = q < nq;
         const float4 m = qmeta[qok[t] ? q : 0];
         tqs[t] = (tau[qok[t] ? q : 0] - slack - m.z) * m.x;
-        cq[t] = m.y;
+        hA[t] = m.y;
+        nb[t] = m.w;
+        Dq[t] = qmeta[nq + (qok[t] ? q : 0)].x;
     }
 
     const int swz = (l31 >> 1) & 7;
@@ -1252,10 +1289,10 @@ score_filter_rw8_kernel(const int8_t* __restrict__ corpus_q8, const float2* __re
     int c_slot = 0;
     // tile scales: scalar loads (uniform address, read-only data) — they count on lgkmcnt, not on the vmcnt the ring
     // is paced by — fetched one tile ahead
-    float2 tm_next = tm[t0];
+    float4 tm_next = tm[t0];
     for (uint64_t n = 0; n < my_tiles; ++n) {
         const uint64_t tile = t0 + n * tstep;
-        const float2 tmv = tm_next;
+        const float4 tmv = tm_next;
         tm_next = tm[n + 1 < my_tiles ? tile + tstep : tile];
 #pragma unroll
         for (int t = 0; t < NQT; ++t)
@@ -1286,7 +1323,7 @@ score_filter_rw8_kernel(const int8_t* __restrict__ corpus_q8, const float2* __re
 #pragma unroll
         for (int t = 0; t < NQT; ++t) {
             // I > T  <=>  I > floor(T) for an integer I; NaN (flagged tile or query) -> every row
-            const float T = floorf(fmaf(tqs[t], tmv.x, -(tmv.y + cq[t])));
+            const float T = q8_threshold(tqs[t], hA[t], nb[t], Dq[t], tmv, kQ8Quarter * (float)DIM);
             const int Ti = (T == T) ? (T < -2.0e9f ? (int)0x80000000 : (T > 2.0e9f ? 0x7fffffff : (int)T)) : (int)0x80000000;
             const bool all = !(T == T) || T < -2.0e9f;
             // most tiles hold no candidate for anybody: one test of the lane's largest product instead of sixteen
@@ -1328,11 +1365,12 @@ __device__ __forceinline__ void cs_static_for(F&& f) {
 }
 
 template <int NQT, int KC>
-constexpr int kRq8Lds = KC * 32 * NQT * 128 + 8 * (int)kPend * 8;  // the query image + eight pending-candidate lists
+constexpr int kRq8Lds = KC * 32 * NQT * 128 + 8 * (int)kPend * 8 + 32 * NQT * 16;  // the query image + eight pending-candidate
+                                                                                   // lists + the queries' threshold constants
 
 template <int NQT, int KC, bool NT>
 __global__ void __launch_bounds__(512)
-score_filter_rq8_kernel(const int8_t* __restrict__ corpus_q8, const float2* __restrict__ tmeta, uint64_t row_lo,
+score_filter_rq8_kernel(const int8_t* __restrict__ corpus_q8, const float4* __restrict__ tmeta, uint64_t row_lo,
                         uint64_t row_hi, const int8_t* __restrict__ queries_q8, const float4* __restrict__ qmeta,
                         uint32_t nq, const float* __restrict__ tau, const uint32_t* __restrict__ dead,
                         uint32_t* __restrict__ cand, uint32_t* __restrict__ cnt, uint32_t cap, uint32_t qtiles,
@@ -1365,16 +1403,18 @@ score_filter_rq8_kernel(const int8_t* __restrict__ corpus_q8, const float2* __re
     uf_wait_vmcnt<0>();
     __syncthreads();
 
-    float tqs[NQT], cq[NQT];
+    // per resident query {tqs, hA, nb, Dq} (q8_threshold) in LDS: four registers per query tile would cost the
+    // second wave per SIMD
+    float4* qv = reinterpret_cast<float4*>(lds + WBYTES + 8 * kPend * 8);  // [QROWS]
     bool qok[NQT];
 #pragma unroll
-    for (int t = 0; t < NQT; ++t) {
-        const uint32_t q = q0 + 32 * t + l31;
-        qok[t] = q < nq;
-        const float4 m = qmeta[qok[t] ? q : 0];
-        tqs[t] = (tau[qok[t] ? q : 0] - slack - m.z) * m.x;
-        cq[t] = m.y;
+    for (int t = 0; t < NQT; ++t) qok[t] = q0 + 32 * t + l31 < nq;
+    for (int i = tid; i < QROWS; i += 512) {
+        const uint32_t q = q0 + i < nq ? q0 + i : 0;
+        const float4 m = qmeta[q];
+        qv[i] = make_float4((tau[q] - slack - m.z) * m.x, m.y, m.w, qmeta[nq + q].x);
     }
+    __syncthreads();
     const int swz = (l31 >> 1) & 7;
     int w_sl[4];
 #pragma unroll
@@ -1400,13 +1440,13 @@ score_filter_rq8_kernel(const int8_t* __restrict__ corpus_q8, const float2* __re
 
     volatile uint64_t* pend = reinterpret_cast<volatile uint64_t*>(lds + WBYTES) + wave * kPend;
     uint32_t npend = 0;  // wave-uniform
-    const float2* tm = tmeta + tile_lo + wtile;
-    float2 tm_next = tm[u0 * 2];
+    const float4* tm = tmeta + tile_lo + wtile;
+    float4 tm_next = tm[u0 * 2];
     i32x16 acc[NQT];
     for (uint64_t n = 0; n < my_units; ++n) {
         const uint64_t u = u0 + n * ustep;
         const uint64_t un = n + 1 < my_units ? u + ustep : u;  // the last unit re-reads itself (discarded)
-        const float2 tmv = tm_next;
+        const float4 tmv = tm_next;
         tm_next = tm[un * 2];
 #pragma unroll
         for (int t = 0; t < NQT; ++t)
@@ -1435,7 +1475,8 @@ score_filter_rq8_kernel(const int8_t* __restrict__ corpus_q8, const float2* __re
         cs_static_for<0, NQT>([&](auto TC) {
             constexpr int t = decltype(TC)::value;
             // I > T  <=>  I > floor(T) for an integer I; NaN (flagged tile or query) -> every row
-            const float T = floorf(fmaf(tqs[t], tmv.x, -(tmv.y + cq[t])));
+            const float4 qm = qv[32 * t + l31];
+            const float T = q8_threshold(qm.x, qm.y, qm.z, qm.w, tmv, kQ8Quarter * (float)DIM);
             const int Ti = (T == T) ? (T < -2.0e9f ? (int)0x80000000 : (T > 2.0e9f ? 0x7fffffff : (int)T)) : (int)0x80000000;
             const bool all = !(T == T) || T < -2.0e9f;
             // explicit reads: left to itself the compiler copies every accumulator out of the AGPRs in one block
@@ -1493,7 +1534,7 @@ int32_t launch_unit_mean(const float* d_corpus, const float* d_norms, uint64_t n
     return CS_OK;
 }
 
-int32_t launch_corpus_q8(const float* d_corpus, const float* d_norms, int8_t* d_q8, float2* d_tmeta, uint64_t first_tile,
+int32_t launch_corpus_q8(const float* d_corpus, const float* d_norms, int8_t* d_q8, float4* d_tmeta, uint64_t first_tile,
                          uint64_t ntiles, uint32_t dim, const float* d_mu, hipStream_t stream) {
     for (uint64_t t = 0; t < ntiles;) {  // grid.x stays below 2^31
         const uint32_t n = (uint32_t)std::min<uint64_t>(ntiles - t, 1u << 30);
@@ -1752,7 +1793,7 @@ static int32_t scan_split_impl(const BatchedState& st, const SplitQueryWs& qw, c
                     const uint32_t grid = std::min<uint32_t>(slots, ((uint32_t)cus + 7) / 8 * 8);  // a multiple of 8: a block stays on its XCD slot
                     hipLaunchKernelGGL(score_filter256p_kernel<false>, dim3(grid), dim3(512), UF2_LDS, stream, d_split, lo, hi,
                                        dim / 64, qw.d_qsplit, nq, st.d_tau, d_dead, cand, st.d_cnt, cap, slots, margin,
-                                       (const float2*)nullptr, (const float4*)nullptr);
+                                       (const float4*)nullptr, (const float4*)nullptr);
                 } else if (legacy256)
                     hipLaunchKernelGGL(score_filter256_kernel<true>, dim3(sh_grid_blocks(mt2, nt2)), dim3(512), UF2_LDS,
                                        stream, d_split, lo, hi, dim / 64, qw.d_qsplit, nq, st.d_tau, d_dead, cand,
