@@ -72,6 +72,10 @@ struct Workspace {
             if (qw.d_q8q) (void)hipFree(qw.d_q8q);
             qw.d_q8q = nullptr; q8_elems = 0;
             CS_HIP(hipMalloc(&qw.d_q8q, elems));
+            if (qw.d_q8q_hi) (void)hipFree(qw.d_q8q_hi);
+            qw.d_q8q_hi = qw.d_q8q_lo = nullptr;
+            CS_HIP(hipMalloc(&qw.d_q8q_hi, 2 * elems));
+            qw.d_q8q_lo = qw.d_q8q_hi + elems;
             q8_elems = elems;
         }
         if (nq > qw_nq) {
@@ -79,7 +83,7 @@ struct Workspace {
             if (qw.d_qmeta) (void)hipFree(qw.d_qmeta);
             qw.d_qmag = nullptr; qw.d_qmeta = nullptr; qw_nq = 0;
             CS_HIP(hipMalloc(&qw.d_qmag, nq * sizeof(float)));
-            CS_HIP(hipMalloc(&qw.d_qmeta, 2 * (size_t)nq * sizeof(float4)));
+            CS_HIP(hipMalloc(&qw.d_qmeta, 4 * (size_t)nq * sizeof(float4)));
             qw_nq = nq;
         }
         return CS_OK;
@@ -217,6 +221,7 @@ struct Workspace {
         if (qw.d_qsplit) (void)hipFree(qw.d_qsplit);
         if (qw.d_qmag) (void)hipFree(qw.d_qmag);
         if (qw.d_q8q) (void)hipFree(qw.d_q8q);
+        if (qw.d_q8q_hi) (void)hipFree(qw.d_q8q_hi);
         if (qw.d_qmeta) (void)hipFree(qw.d_qmeta);
         for (auto& t : free_events) {
             (void)hipEventDestroy(t.e0); (void)hipEventDestroy(t.e1); (void)hipEventDestroy(t.e2);

@@ -118,8 +118,11 @@ struct SplitQueryWs {
     // which saves the H2D copy call (~6 us of a 45-us search over a small corpus).  Null otherwise.
     const float* q_pinned = nullptr;
     int8_t* d_q8q = nullptr;       // [nq][dim] int8: q / |q| on the query's own scale (int8 filter copy)
-    float4* d_qmeta = nullptr;     // [2 nq]: [q] = {127 / max |q_i / |q||, 0.5001 sum |b_i|, q / |q| . mu, sqrt(sum b_i^2)},
-                                   // [nq + q].x = sqrt(sum d_i^2), d = the query's rounding errors (q8_threshold)
+    float4* d_qmeta = nullptr;     // [4 nq]: [q] = {127 / max |q_i / |q||, 0.5001 sum |b_i|, q / |q| . mu, sqrt(sum b_i^2)},
+                                   // [nq + q].x = sqrt(sum d_i^2), d = the query's rounding errors (q8_threshold);
+                                   // [2 nq + q], [3 nq + q]: the same for the two-plane (128 times finer) quantisation
+    int8_t* d_q8q_hi = nullptr;    // [nq][dim] x 2: the query as 128 hi + lo, both int8 (up to 64 queries)
+    int8_t* d_q8q_lo = nullptr;
 };
 // int8 filter copy of the corpus (scan_filter.hip, "int8 filter copy"): complete 128-row tiles [0, rows / 128)
 struct Q8View {

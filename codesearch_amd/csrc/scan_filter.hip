@@ -165,7 +165,9 @@ __device__ __forceinline__ float q8_threshold(float tqs, float hA, float nb, flo
     const float tA = fminf(hA, nb * tm.z);
     const float tB = fminf(tm.y, tm.w * Dq);
     const float tC = fminf(dimq, tm.z * Dq);
-    return floorf(fmaf(tqs, tm.x, -(tA + tB + tC + kQ8Guard)));
+    // the f32 evaluation of the line itself: a relative term (with two-plane queries |T| reaches 1e9: an ulp is 64)
+    const float lead = tqs * tm.x;
+    return floorf(lead - (tA + tB + tC + kQ8Guard + fabsf(lead) * 4.0e-7f));
 }
 
 // Everything a batched search needs before its first phase, in one launch (three kernels of ~2 us
@@ -179,7 +181,7 @@ prep_queries_kernel(const float* __restrict__ queries, float* __restrict__ qcopy
                     float* __restrict__ qmag, _Float16* __restrict__ qunit, float* __restrict__ tau, uint32_t* __restrict__ cnt,
                     uint64_t* __restrict__ carry, uint32_t k, uint32_t* __restrict__ overflow, uint32_t first_rows,
                     int8_t* __restrict__ q8q, float4* __restrict__ qmeta, const float* __restrict__ mu,
-                    uint32_t* __restrict__ overflow_mirror) {
+                    uint32_t* __restrict__ overflow_mirror, int8_t* __restrict__ q8q_hi, int8_t* __restrict__ q8q_lo) {
     constexpr int DIM = 128 * J;
     const int lane = threadIdx.x & 63, half = lane >> 5, l32 = lane & 31;
     const uint32_t q = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 2 + half;
@@ -241,6 +243,40 @@ prep_queries_kernel(const float* __restrict__ queries, float* __restrict__ qcopy
         if (l32 == 0) {  // (norms a hair up: their own f32 rounding)
             qmeta[q] = make_float4(inv, kQ8Half * (float)abs_sum, qmu, sqrtf(sq_sum) * 1.0001f);
             qmeta[nq + q] = make_float4(sqrtf(err_sum) * 1.001f + 1.0e-3f, 0.0f, 0.0f, 0.0f);
+        }
+        if (q8q_hi) {
+            // The same query 128 times finer, in TWO int8 planes: B_i = rint(v_i * 128 inv) = 128 hi_i + lo_i with hi in
+            // [-127, 127] and lo in [-64, 64], so sum a_i B_i = 128 (a . hi) + (a . lo): two MFMAs per step, where the
+            // matrix pipe has room (up to 64 queries the filter is a stream).  The query's rounding error — half the band
+            // for evenly spread vectors — shrinks 128-fold; the constants below are in the finer unit.
+            const float inv2 = inv * 128.0f;
+            float abs2 = 0.0f, sq2 = 0.0f, err2 = 0.0f;
+#pragma unroll
+            for (int j = 0; j < J; ++j) {
+                uint32_t whi = 0, wlo = 0;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float t = (m == 0.0f ? 0.0f : v[j][e] / m) * inv2;
+                    float B = rintf(t);
+                    B = fminf(fmaxf(B, -16256.0f), 16256.0f);
+                    const float hi = rintf(B * 0.0078125f);
+                    const float lo = B - 128.0f * hi;   // exact: |lo| <= 64
+                    abs2 += fabsf(B);
+                    sq2 = fmaf(B, B, sq2);
+                    err2 = fmaf(t - B, t - B, err2);
+                    whi |= ((uint32_t)(int)hi & 0xffu) << (8 * e);
+                    wlo |= ((uint32_t)(int)lo & 0xffu) << (8 * e);
+                }
+                *reinterpret_cast<uint32_t*>(q8q_hi + (size_t)q * DIM + (l32 + 32 * j) * 4) = whi;
+                *reinterpret_cast<uint32_t*>(q8q_lo + (size_t)q * DIM + (l32 + 32 * j) * 4) = wlo;
+            }
+            abs2 = half_sum_s(abs2);
+            sq2 = half_sum_s(sq2);
+            err2 = half_sum_s(err2);
+            if (l32 == 0) {
+                qmeta[2 * nq + q] = make_float4(inv2, kQ8Half * abs2 * 1.0001f, qmu, sqrtf(sq2) * 1.0001f);
+                qmeta[3 * nq + q] = make_float4(sqrtf(err2) * 1.001f + 1.0e-3f, 0.0f, 0.0f, 0.0f);
+            }
         }
     }
     for (uint32_t i = l32; i < k; i += 32) carry[(size_t)q * k + i] = 0ull;
@@ -1197,19 +1233,27 @@ template <int NQT, int KC>
 using Rw8Geom = RwGeom<NQT, KC, (NQT == 1 ? CS_RW8_RCAP1 : CS_RW8_RCAP2)>;
 
 // score_filter_rw_kernel over the int8 copy.  KC = dim / 128 stages per tile; rows [row_lo, row_hi) are whole tiles.
-template <int NQT, int KC>
+// TWO: the queries in two int8 planes (prep_queries_kernel: 128 hi + lo, a 128 times finer query scale) — a second
+// query image in LDS and a second MFMA per step into a second accumulator set, combined as 128 I_hi + I_lo in the
+// epilogue; queries_q8 is the hi plane, queries_lo the lo plane, and the query constants are the finer unit's.
+template <int NQT, int KC, bool TWO>
+using Rw8GeomT = typename std::conditional<TWO, RwGeom<2 * NQT, KC, (NQT == 1 ? CS_RW8_RCAP1 : CS_RW8_RCAP2)>, Rw8Geom<NQT, KC>>::type;
+
+template <int NQT, int KC, bool TWO = false>
 __global__ void __launch_bounds__(256)
 score_filter_rw8_kernel(const int8_t* __restrict__ corpus_q8, const float4* __restrict__ tmeta, uint64_t row_lo,
                         uint64_t row_hi, const int8_t* __restrict__ queries_q8, const float4* __restrict__ qmeta,
                         uint32_t nq, const float* __restrict__ tau, const uint32_t* __restrict__ dead,
                         uint32_t* __restrict__ cand, uint32_t* __restrict__ cnt, uint32_t cap, uint32_t qtiles,
-                        uint32_t nt_stream, float slack) {
-    using G = Rw8Geom<NQT, KC>;
+                        uint32_t nt_stream, float slack, const int8_t* __restrict__ queries_lo = nullptr) {
+    using G = Rw8GeomT<NQT, KC, TWO>;
+    constexpr int QROWS = 32 * NQT;              // (G::QROWS counts both planes when TWO)
+    constexpr int WB1 = KC * QROWS * 128;        // one plane of the query image
     const bool NT = nt_stream != 0 && qtiles == 1;
     constexpr int R = G::R;
     constexpr int DIM = 128 * KC;
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    char* Wl = lds;                 // [KC][QROWS][128 B], slots swizzled as in uf_mainloop
+    char* Wl = lds;                 // [KC][QROWS][128 B], slots swizzled as in uf_mainloop (TWO: the lo plane behind it)
     char* ring = lds + G::WBYTES;   // [R][4 waves][32 rows][128 B]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1221,7 +1265,7 @@ score_filter_rw8_kernel(const int8_t* __restrict__ corpus_q8, const float4* __re
     const uint32_t xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     const uint32_t qt = slot % qtiles, rg = slot / qtiles, rgn = (gridDim.x >> 3) / qtiles;
     if (rg >= rgn) return;
-    const uint32_t q0 = qt * G::QROWS;
+    const uint32_t q0 = qt * QROWS;
 
 #pragma unroll
     for (int i = 0; i < KC * NQT; ++i) {
@@ -1231,7 +1275,10 @@ score_filter_rw8_kernel(const int8_t* __restrict__ corpus_q8, const float4* __re
         const int pc = (lane & 7) ^ ((row >> 1) & 7);
         const uint32_t q = q0 + row < nq ? q0 + row : nq - 1;
         sh_glds16(reinterpret_cast<const _Float16*>(queries_q8 + (size_t)q * DIM + c * 128 + pc * 16),
-                  Wl + (c * G::QROWS + r8 * 8) * 128);
+                  Wl + (c * QROWS + r8 * 8) * 128);
+        if (TWO)
+            sh_glds16(reinterpret_cast<const _Float16*>(queries_lo + (size_t)q * DIM + c * 128 + pc * 16),
+                      Wl + WB1 + (c * QROWS + r8 * 8) * 128);
     }
     uf_wait_vmcnt<0>();
     __syncthreads();
@@ -1243,11 +1290,11 @@ score_filter_rw8_kernel(const int8_t* __restrict__ corpus_q8, const float4* __re
     for (int t = 0; t < NQT; ++t) {
         const uint32_t q = q0 + 32 * t + l31;
         qok[t] = q < nq;
-        const float4 m = qmeta[qok[t] ? q : 0];
+        const float4 m = qmeta[(TWO ? 2 * nq : 0) + (qok[t] ? q : 0)];
         tqs[t] = (tau[qok[t] ? q : 0] - slack - m.z) * m.x;
         hA[t] = m.y;
         nb[t] = m.w;
-        Dq[t] = qmeta[nq + (qok[t] ? q : 0)].x;
+        Dq[t] = qmeta[(TWO ? 3 * nq : nq) + (qok[t] ? q : 0)].x;
     }
 
     const int swz = (l31 >> 1) & 7;
@@ -1285,7 +1332,7 @@ score_filter_rw8_kernel(const int8_t* __restrict__ corpus_q8, const float4* __re
     volatile uint64_t* pend = reinterpret_cast<volatile uint64_t*>(lds + G::LDS) + wave * kPend;
     uint32_t npend = 0;  // wave-uniform
 
-    i32x16 acc[NQT];
+    i32x16 acc[NQT], acc_lo[TWO ? NQT : 1];
     int c_slot = 0;
     // tile scales: scalar loads (uniform address, read-only data) — they count on lgkmcnt, not on the vmcnt the ring
     // is paced by — fetched one tile ahead
@@ -1297,7 +1344,10 @@ score_filter_rw8_kernel(const int8_t* __restrict__ corpus_q8, const float4* __re
 #pragma unroll
         for (int t = 0; t < NQT; ++t)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[t][r] = 0;
+            for (int r = 0; r < 16; ++r) {
+                acc[t][r] = 0;
+                if (TWO) acc_lo[t][r] = 0;
+            }
 #pragma unroll
         for (int c = 0; c < KC; ++c) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1309,7 +1359,7 @@ score_filter_rw8_kernel(const int8_t* __restrict__ corpus_q8, const float4* __re
             }
             const char* slot = myring + c_slot * 16384;
             if (++c_slot == R) c_slot = 0;
-            const char* wc = Wl + c * G::QROWS * 128;
+            const char* wc = Wl + c * QROWS * 128;
 #pragma unroll
             for (int st = 0; st < 4; ++st) {
                 const i32x4 a = *reinterpret_cast<const i32x4*>(slot + a_sl[st]);
@@ -1317,6 +1367,10 @@ score_filter_rw8_kernel(const int8_t* __restrict__ corpus_q8, const float4* __re
                 for (int t = 0; t < NQT; ++t) {
                     const i32x4 w = *reinterpret_cast<const i32x4*>(wc + t * 32 * 128 + a_sl[st]);
                     acc[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, w, acc[t], 0, 0, 0);
+                    if (TWO) {
+                        const i32x4 wl = *reinterpret_cast<const i32x4*>(wc + WB1 + t * 32 * 128 + a_sl[st]);
+                        acc_lo[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, wl, acc_lo[t], 0, 0, 0);
+                    }
                 }
             }
         }
@@ -1326,6 +1380,10 @@ score_filter_rw8_kernel(const int8_t* __restrict__ corpus_q8, const float4* __re
             const float T = q8_threshold(tqs[t], hA[t], nb[t], Dq[t], tmv, kQ8Quarter * (float)DIM);
             const int Ti = (T == T) ? (T < -2.0e9f ? (int)0x80000000 : (T > 2.0e9f ? 0x7fffffff : (int)T)) : (int)0x80000000;
             const bool all = !(T == T) || T < -2.0e9f;
+            if (TWO) {  // I = 128 I_hi + I_lo (|I| <= 127 * 16,256 * dim < 2^31 up to dim 768)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[t][r] = acc[t][r] * 128 + acc_lo[t][r];
+            }
             // most tiles hold no candidate for anybody: one test of the lane's largest product instead of sixteen
             int top = acc[t][0];
 #pragma unroll
@@ -1586,6 +1644,12 @@ static int32_t scan_split_impl(const BatchedState& st, const SplitQueryWs& qw, c
         }
         CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(score_filter_rw8_kernel<1, J>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, Rw8Geom<1, J>::LDS_ALL));
+        if constexpr (J <= 6) {
+            CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(score_filter_rw8_kernel<1, J, true>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (Rw8GeomT<1, J, true>::LDS_ALL)));
+            CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(score_filter_rw8_kernel<2, J, true>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (Rw8GeomT<2, J, true>::LDS_ALL)));
+        }
         CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(score_filter_rw8_kernel<2, J>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, Rw8Geom<2, J>::LDS_ALL));
         if constexpr (J <= 6)
@@ -1619,11 +1683,20 @@ static int32_t scan_split_impl(const BatchedState& st, const SplitQueryWs& qw, c
     const uint32_t q8_rw_max = q8_rw_env ? std::min(q8_rw_env, q8_rw_limit) : q8_rw_limit;
     static const bool rq8_on = [] { const char* e = std::getenv("CS_FILTER_INT8_RQ"); return !(e && e[0] == '0'); }();
     const bool use_q8 = q8 && q8->d_q8 && q8->rows > 1024 && (!q8_max_env || nq <= q8_max_env) && qw.d_q8q && qw.d_qmeta;
+    // Long lists for up to 32 queries (dim <= 768) take the queries in two int8 planes: a 128 times finer query scale
+    // (band ~0.010 instead of ~0.017 for evenly spread vectors: the k-th best of a long list sits where scores are dense,
+    // and the band decides how many rows pass) for a second MFMA per step (score_filter_rw8_kernel<.., true>).  The
+    // second MFMA is not free even where the kernel streams — same-box A/B over 10M rows: 9 x 200 0.877 -> 0.863 ms,
+    // 1 x 200 0.836 -> 0.811, but 8 x 10 0.681 -> 0.712 and 64 x 10 0.81 -> 1.04 — so short lists and more than 32
+    // queries keep one plane.  CS_FILTER_INT8_Q2=0: never; =2: whenever the kernel exists (<= 64 queries).
+    static const int q2_mode = [] { const char* e = std::getenv("CS_FILTER_INT8_Q2"); return e ? std::atoi(e) : 1; }();
+    const bool two_planes = use_q8 && q2_mode > 0 && J <= 6 && qw.d_q8q_hi && qw.d_q8q_lo &&
+                            (q2_mode >= 2 ? nq <= 64 : (nq <= 32 && k >= 48));
     hipLaunchKernelGGL(prep_queries_kernel<J>, dim3((nq + 7) / 8), dim3(256), 0, stream,
                        qw.q_pinned ? qw.q_pinned : d_queries, qw.q_pinned ? const_cast<float*>(d_queries) : nullptr, nq,
                        qw.d_qmag, qw.d_qsplit, st.d_tau, st.d_cnt, st.d_carry, k, st.d_overflow,
                        (uint32_t)(n_rows < 1024 ? n_rows : 1024), use_q8 ? qw.d_q8q : nullptr, qw.d_qmeta,
-                       use_q8 ? q8->d_mu : nullptr, st.h_mirror);
+                       use_q8 ? q8->d_mu : nullptr, st.h_mirror, two_planes ? qw.d_q8q_hi : nullptr, qw.d_q8q_lo);
     CS_HIP(hipGetLastError());
     uint32_t* cand = reinterpret_cast<uint32_t*>(st.d_cand);
     const uint32_t ntiles = (nq + SH_BN - 1) / SH_BN;
@@ -1726,11 +1799,18 @@ static int32_t scan_split_impl(const BatchedState& st, const SplitQueryWs& qw, c
     hipLaunchKernelGGL((score_filter_rw8_kernel<NQT_, J>), dim3(blocks), dim3(256), (Rw8Geom<NQT_, J>::LDS_ALL), stream, \
                        q8->d_q8, q8->d_tmeta, lo, q_hi, qw.d_q8q, qw.d_qmeta, nq, st.d_tau, d_dead, cand, st.d_cnt, cap, \
                        qtiles, nt_stream8, q8_slack(dim))
-                    if (per == 32) CS_RW8_LAUNCH(1);
+#define CS_RW8_LAUNCH2(NQT_)                                                                                       \
+    hipLaunchKernelGGL((score_filter_rw8_kernel<NQT_, J, true>), dim3(blocks), dim3(256), (Rw8GeomT<NQT_, J, true>::LDS_ALL), \
+                       stream, q8->d_q8, q8->d_tmeta, lo, q_hi, qw.d_q8q_hi, qw.d_qmeta, nq, st.d_tau, d_dead, cand, st.d_cnt, \
+                       cap, qtiles, nt_stream8, q8_slack(dim), qw.d_q8q_lo)
+                    if (per <= 64 && two_planes) {
+                        if constexpr (J <= 6) { if (per == 32) CS_RW8_LAUNCH2(1); else CS_RW8_LAUNCH2(2); }
+                    } else if (per == 32) CS_RW8_LAUNCH(1);
                     else if (per == 64) CS_RW8_LAUNCH(2);
                     else if constexpr (J == 3) { if (per == 256) CS_RW8_LAUNCH(8); else CS_RW8_LAUNCH(4); }
                     else if constexpr (J <= 6) CS_RW8_LAUNCH(4);
 #undef CS_RW8_LAUNCH
+#undef CS_RW8_LAUNCH2
                     CS_HIP(hipGetLastError());
                 }
                 const uint64_t t_lo = lo > q8->rows ? lo : q8->rows;

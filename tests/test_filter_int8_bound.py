@@ -33,6 +33,21 @@ def _quantise_query(q, mu):
             F(np.sqrt(((t - b) ** 2).sum(dtype=F))) * F(1.001) + F(1e-3), F((v * mu).sum(dtype=F)))
 
 
+def _quantise_query_two_planes(q, mu):
+    """prep_queries_kernel's second quantisation: B = rint(v * 128 inv) = 128 hi + lo; the MFMAs compute a . hi and a . lo."""
+    m = F(np.sqrt((q.astype(F) ** 2).sum(dtype=F)))
+    v = (q / m).astype(F) if m > 0 else np.zeros_like(q, F)
+    mx = np.abs(v).max()
+    inv = (F(127.0) / mx if (mx > 0 and np.isfinite(mx)) else F(1.0)) * F(128.0)
+    t = (v * inv).astype(F)
+    B = np.clip(np.rint(t), -16256, 16256).astype(F)
+    hi = np.rint(B * F(0.0078125)).astype(F)
+    lo = (B - F(128.0) * hi).astype(F)
+    assert np.abs(hi).max() <= 127 and np.abs(lo).max() <= 64
+    return (hi, lo, inv, F(0.5001) * np.abs(B).sum(dtype=F) * F(1.0001), F(np.sqrt((B * B).sum(dtype=F))) * F(1.0001),
+            F(np.sqrt(((t - B) ** 2).sum(dtype=F))) * F(1.001) + F(1e-3), F((v * mu).sum(dtype=F)))
+
+
 def _check(rows, queries, dim):
     n = rows.shape[0] // 128 * 128
     rows = rows[:n]
@@ -44,6 +59,7 @@ def _check(rows, queries, dim):
     worst = -np.inf
     for q in queries:
         b, inv_q, hA, nb, Dq, qmu = _quantise_query(q, mu)
+        planes = _quantise_query_two_planes(q, mu)
         qn = np.linalg.norm(q.astype(np.float64))
         for t0 in range(0, n, 128):
             a, inv_t, hB, E, N = _quantise_tile(rows[t0:t0 + 128], mu)
@@ -55,6 +71,13 @@ def _check(rows, queries, dim):
             lhs = (cos - float(slack) - float(qmu)) * float(inv_q) * float(inv_t) - float(band_units)
             worst = max(worst, float((lhs - I).max()))
             assert (lhs < I).all(), (t0, float((lhs - I).max()))
+            # ... and with the query in two planes (the finer unit; q8_threshold's relative guard included)
+            hi, lo, inv2, hA2, nb2, Dq2, _ = planes
+            I2 = 128.0 * (a.astype(np.float64) @ hi.astype(np.float64)) + a.astype(np.float64) @ lo.astype(np.float64)
+            assert np.abs(I2).max() < 2 ** 31
+            lead = (cos - float(slack) - float(qmu)) * float(inv2) * float(inv_t)
+            band2 = min(hA2, nb2 * E) + min(hB, N * Dq2) + min(F(0.2501) * F(dim), E * Dq2) + F(4.0)
+            assert (lead - float(band2) - np.abs(lead) * 4.0e-7 < I2).all(), t0
     return worst
 
 

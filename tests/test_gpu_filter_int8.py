@@ -95,6 +95,26 @@ def test_many_queries_both_resident_query_kernels(VS, monkeypatch, rq, n, nq, k)
     assert ids[nq - 2][0] == n - 1 and ids[nq - 1][0] == n // 128 * 128 - 1
 
 
+@pytest.mark.parametrize("q2", ["2", "0"])
+@pytest.mark.parametrize("dim,n,nq,k", [(384, 200_000, 9, 200), (384, 150_000, 33, 10), (384, 120_000, 64, 100),
+                                        (768, 60_000, 8, 200), (768, 50_000, 40, 25)])
+def test_two_plane_queries_do_not_change_a_bit(VS, monkeypatch, q2, dim, n, nq, k):
+    """CS_FILTER_INT8_Q2=2 takes every search of up to 64 queries through the two-plane query kernels (default: long
+    lists of up to 32 queries only), =0 none: same bits either way; adversarial magnitudes ride along."""
+    monkeypatch.setenv("CS_FILTER_INT8_Q2", q2)
+    monkeypatch.setenv("CS_FILTER_SINGLE_MIN_K", "0")
+    st = VS(None, dim)
+    st.insert_synthetic(n, 321 + dim, 0)
+    st.delete_chunks([9, n // 3])
+    st.build_index()
+    qs = np.concatenate([synth_rows(17 + nq, 0, nq - 1, dim), synth_planted(321 + dim, 5, [n - 2], dim)])
+    qs[0] *= np.float32(1e5)
+    qs[1] = 0.0
+    qs[1, 3] = -2.0        # one-hot: hi plane +-127, lo plane 0
+    cos, ids, _ = _same_as_single_query_scans(st, qs, k)
+    assert ids[nq - 1][0] == n - 2
+
+
 def test_rows_that_stress_the_quantiser(VS, oracle, monkeypatch):
     """Outlier elements (one huge coordinate: the tile's scale collapses for everyone else), sparse rows, rows of
     wildly different magnitudes, zero rows, NaN / Inf rows inside a tile, thousands of near-duplicates of the query
