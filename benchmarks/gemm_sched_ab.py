@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""A/B of the wide GEMM's DMA issue schedules (gemm_wide.hip gw_dma_slot) on the encoder's four dense-layer shapes:
+schedules interleaved over rounds in ONE process (cdna_hip_programming.md rule 24), median and min per schedule."""
+import ctypes as C
+import os
+import statistics
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    from codesearch_amd import _lib
+
+    lib = _lib.load()
+    M = int(os.environ.get("M", 65536))
+    rounds = int(os.environ.get("ROUNDS", 5))
+    iters = int(os.environ.get("ITERS", 30))
+    # codes of cs_debug_gemm_time's `ablation`: 100 + s = DMA schedule s of the 128 x 384 kernel; 1000 + c = the 128 x 192
+    # two-blocks-per-CU shape with the CU's second block c cycles per k-chunk late (1000: no stagger)
+    scheds = [int(x) for x in os.environ.get("CODES", "100,101,102,103,104").split(",")]
+
+    def t(epi, N, K, code):
+        ms = C.c_double()
+        _lib.check(lib.cs_debug_gemm_time(0, 2, epi, M, N, K, iters, code, C.byref(ms)))
+        return ms.value * 1e3
+
+    shapes = [("qkv      N=1152 K=384  bias->split", 4, 1152, 384), ("ffn_up   N=1536 K=384  GELU->split", 1, 1536, 384),
+              ("out+LN   N=384  K=384  LayerNorm  ", 3, 384, 384), ("down+LN  N=384  K=1536 LayerNorm  ", 3, 384, 1536)]
+    only = os.environ.get("SHAPES")
+    for name, epi, N, K in shapes:
+        if only and name.split()[0] not in only.split(","):
+            continue
+        res = {s: [] for s in scheds}
+        for _ in range(rounds):
+            for s in scheds:
+                res[s].append(t(epi, N, K, s))
+        line = "  ".join(f"{s}: {statistics.median(v):6.1f} (min {min(v):6.1f})" for s, v in res.items())
+        print(f"{name}: {line}", flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -99,7 +99,9 @@ SIGNATURES = {
     "cs_index_read_rows": (C.c_int32, [vp, C.c_uint64, C.c_uint64, f32p]),
     "cs_index_debug_counters": (C.c_int32, [vp, u64p, u64p]),
     "cs_index_filter_state": (C.c_int32, [vp, C.POINTER(C.c_int32), C.POINTER(C.c_float), u64p]),
+    "cs_index_filter_copies": (C.c_int32, [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), u64p]),
     "cs_index_set_filter_min_queries": (C.c_int32, [vp, C.c_uint32]),
+    "cs_index_set_single_query_route": (C.c_int32, [vp, C.c_int32]),
     "cs_index_profile": (C.c_int32, [vp, C.c_int32]),
     "cs_index_profile_read": (C.c_int32, [vp, f64p, u64p, f64p, C.c_int32]),
     "cs_bert_config_bge_small": (None, [C.POINTER(BertConfig)]),
@@ -150,9 +152,6 @@ SIGNATURES = {
     "cs_embedders_embed_ids": (C.c_int32, [vp, i32p, i32p, C.c_uint64, C.c_uint32, C.c_uint32, f32p, i32p]),
     "cs_embedders_index_texts": (C.c_int32, [vp, vp, vp, C.c_char_p, u64p, C.c_uint64, C.c_uint32, u32p, i32p]),
     "cs_embedders_index_ids": (C.c_int32, [vp, vp, i32p, i32p, C.c_uint64, C.c_uint32, C.c_uint32, u32p, i32p]),
-    "cs_debug_ffn": (C.c_int32, [C.c_int32, C.c_int32, f32p, f32p, f32p, f32p, f32p, f32p, f32p, C.c_float, f32p,
-                                 C.c_uint32, C.c_uint32, u32p]),
-    "cs_debug_ffn_time": (C.c_int32, [C.c_int32, C.c_int32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int32, f64p]),
     "cs_debug_gemm_time": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                        C.c_int32, f64p]),
     "cs_debug_gemm": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32, f32p, f32p, f32p, f32p, f32p,

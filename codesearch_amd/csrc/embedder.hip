@@ -319,18 +319,6 @@ int32_t forward_range(cs_embedder* h, hipStream_t s, uint32_t b0, uint32_t nb, u
             }
             CS_TRY(mark(CS_STAGE_LN_ATTN));
             a.g = P + lo.out_ln_g; a.b = P + lo.out_ln_b;
-            // E5 + E6 in one kernel: the [T, I] intermediate never leaves the CU (ffn_fused.hip)
-            // Opt-in (CS_FFN_FUSED=1): measured 537 us per layer at 65,536 rows against 255 + 241 for the two kernels
-            // (X is re-streamed once per 128-column chunk and an up step is only 24 MFMAs per wave).
-            static const bool ffn_fused_on = [] { const char* e = std::getenv("CS_FFN_FUSED"); return e && e[0] == '1'; }();
-            if (ffn_fused_on && fuse_ln && split_resid && ffn_fused_supported(H, I)) {
-                CS_TRY(launch_ffn_fused(xs, ws + sl.up, P + lo.up_b, ws + sl.down, P + lo.down_b, a.g, a.b, c.layer_norm_eps,
-                                        l + 1 < c.layers ? nullptr : x, xs, T, I, h->d_flag, s));
-                CS_TRY(mark(CS_STAGE_FFN_UP));
-                CS_TRY(mark(CS_STAGE_FFN_DOWN));
-                CS_TRY(mark(CS_STAGE_LN_FFN));
-                continue;
-            }
             CS_TRY(dense(SH_OUT_SPLIT_GELU, xs, ws + sl.up, P + lo.up_b, nullptr, nullptr, mids, T, I, H));    // E5
             CS_TRY(mark(CS_STAGE_FFN_UP));
             if (fuse_ln) {
@@ -1191,120 +1179,6 @@ int32_t cs_debug_gemm(int32_t device, int32_t mode, int32_t epilogue, const floa
     return st;
 }
 
-// Diagnostics: the feed-forward block on host buffers — out[M, 384] = LayerNorm(GELU(A W1^T + b1) W2^T + b2 + A) * gamma
-// + beta.  fused = 1: ffn_fused.hip; 0: the two wide kernels it replaces (GELU epilogue, then LayerNorm epilogue).  The
-// output is re-assembled from the split-form result (hi + lo / 2048).
-int32_t cs_debug_ffn(int32_t device, int32_t fused, const float* A, const float* W1, const float* b1, const float* W2,
-                     const float* b2, const float* gamma, const float* beta, float eps, float* out, uint32_t M,
-                     uint32_t intermediate, uint32_t* range_flag) {
-    if (!A || !W1 || !b1 || !W2 || !b2 || !gamma || !beta || !out || M == 0) return fail(CS_ERR_BAD_ARG, "null buffer");
-    const uint32_t H = 384, I = intermediate;
-    if (!ffn_fused_supported(H, I)) return fail(CS_ERR_UNSUPPORTED, "intermediate size must be a multiple of 128");
-    int ndev = 0;
-    CS_HIP(hipGetDeviceCount(&ndev));
-    if (device < 0 || device >= ndev) return fail(CS_ERR_HIP, "HIP device %d not available (%d visible)", device, ndev);
-    DeviceGuard g(device);
-    float *dA = nullptr, *dW1 = nullptr, *dW2 = nullptr, *dv = nullptr;
-    _Float16 *sA = nullptr, *sW1 = nullptr, *sW2 = nullptr, *sMid = nullptr;
-    uint32_t* dF = nullptr;
-    auto run = [&]() -> int32_t {
-        const size_t an = (size_t)M * H, w1n = (size_t)I * H, w2n = (size_t)H * I, vn = (size_t)I + 3 * H;
-        CS_HIP(hipMalloc(&dA, an * 4)); CS_HIP(hipMalloc(&dW1, w1n * 4)); CS_HIP(hipMalloc(&dW2, w2n * 4));
-        CS_HIP(hipMalloc(&dv, vn * 4)); CS_HIP(hipMalloc(&dF, 4));
-        CS_HIP(hipMalloc(&sA, an * 4)); CS_HIP(hipMalloc(&sW1, w1n * 4)); CS_HIP(hipMalloc(&sW2, w2n * 4));
-        CS_HIP(hipMemcpy(dA, A, an * 4, hipMemcpyHostToDevice));
-        CS_HIP(hipMemcpy(dW1, W1, w1n * 4, hipMemcpyHostToDevice));
-        CS_HIP(hipMemcpy(dW2, W2, w2n * 4, hipMemcpyHostToDevice));
-        float *db1 = dv, *db2 = dv + I, *dg = dv + I + H, *dbe = dv + I + 2 * H;
-        CS_HIP(hipMemcpy(db1, b1, (size_t)I * 4, hipMemcpyHostToDevice));
-        CS_HIP(hipMemcpy(db2, b2, (size_t)H * 4, hipMemcpyHostToDevice));
-        CS_HIP(hipMemcpy(dg, gamma, (size_t)H * 4, hipMemcpyHostToDevice));
-        CS_HIP(hipMemcpy(dbe, beta, (size_t)H * 4, hipMemcpyHostToDevice));
-        CS_HIP(hipMemset(dF, 0, 4));
-        CS_TRY(launch_split_rows(dA, sA, M, H, dF, nullptr));
-        CS_TRY(launch_split_rows(dW1, sW1, I, H, dF, nullptr));
-        CS_TRY(launch_split_rows(dW2, sW2, H, I, dF, nullptr));
-        if (fused) {
-            CS_TRY(launch_ffn_fused(sA, sW1, db1, sW2, db2, dg, dbe, eps, nullptr, sA, M, I, dF, nullptr));
-        } else {
-            CS_HIP(hipMalloc(&sMid, (size_t)M * I * 4));
-            CS_TRY(launch_gemm_wide(SH_OUT_SPLIT_GELU, sA, sW1, db1, nullptr, nullptr, sMid, M, I, H, dF, nullptr, 0));
-            CS_TRY(launch_gemm_wide_ln(sMid, sW2, db2, nullptr, dg, dbe, eps, nullptr, sA, M, I, dF, nullptr, sA));
-        }
-        CS_HIP(hipDeviceSynchronize());
-        std::vector<_Float16> hs(an * 2);
-        CS_HIP(hipMemcpy(hs.data(), sA, an * 4, hipMemcpyDeviceToHost));
-        for (size_t m = 0; m < M; ++m)
-            for (size_t n = 0; n < H; ++n) {
-                const _Float16* line = hs.data() + (m * (H / 32) + n / 32) * 64;
-                out[m * H + n] = (float)line[n % 32] + (float)line[32 + n % 32] * (1.0f / 2048.0f);
-            }
-        if (range_flag) CS_HIP(hipMemcpy(range_flag, dF, 4, hipMemcpyDeviceToHost));
-        return CS_OK;
-    };
-    const int32_t st = run();
-    (void)hipDeviceSynchronize();
-    for (void* p : {(void*)dA, (void*)dW1, (void*)dW2, (void*)dv, (void*)sA, (void*)sW1, (void*)sW2, (void*)sMid, (void*)dF})
-        if (p) (void)hipFree(p);
-    return st;
-}
-
-// Diagnostics: device milliseconds per feed-forward block (fused = 1: one kernel; 0: the two wide kernels) on synthetic
-// operands resident in HBM.  ablation (fused only): 0 none, 1 no GELU arithmetic, 2 no LDS-DMA after a tile's first stage.
-int32_t cs_debug_ffn_time(int32_t device, int32_t fused, uint32_t M, uint32_t intermediate, uint32_t iters, int32_t ablation,
-                          double* ms_per_launch) {
-    const uint32_t H = 384, I = intermediate;
-    if (!ms_per_launch || iters == 0 || M == 0 || !ffn_fused_supported(H, I)) return fail(CS_ERR_BAD_ARG, "bad arguments");
-    int ndev = 0;
-    CS_HIP(hipGetDeviceCount(&ndev));
-    if (device < 0 || device >= ndev) return fail(CS_ERR_HIP, "HIP device %d not available (%d visible)", device, ndev);
-    DeviceGuard g(device);
-    float *dA = nullptr, *dW1 = nullptr, *dW2 = nullptr, *dv = nullptr;
-    _Float16 *sA = nullptr, *sX = nullptr, *sW1 = nullptr, *sW2 = nullptr, *sMid = nullptr;
-    uint32_t* dF = nullptr;
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    auto run = [&]() -> int32_t {
-        const size_t an = (size_t)M * H, w1n = (size_t)I * H, w2n = (size_t)H * I;
-        CS_HIP(hipMalloc(&dA, an * 4)); CS_HIP(hipMalloc(&dW1, w1n * 4)); CS_HIP(hipMalloc(&dW2, w2n * 4));
-        CS_HIP(hipMalloc(&dv, ((size_t)I + 3 * H) * 4)); CS_HIP(hipMalloc(&dF, 4));
-        CS_HIP(hipMalloc(&sA, an * 4)); CS_HIP(hipMalloc(&sX, an * 4)); CS_HIP(hipMalloc(&sW1, w1n * 4)); CS_HIP(hipMalloc(&sW2, w2n * 4));
-        CS_HIP(hipMalloc(&sMid, (size_t)M * I * 4));
-        CS_TRY(launch_synth_fill(dA, M, H, 11, 0, nullptr));
-        CS_TRY(launch_synth_fill(dW1, I, H, 12, 0, nullptr));
-        CS_TRY(launch_synth_fill(dW2, H, I, 13, 0, nullptr));
-        CS_HIP(hipMemset(dv, 0, ((size_t)I + 3 * H) * 4));
-        CS_HIP(hipMemset(dF, 0, 4));
-        CS_TRY(launch_split_rows(dA, sA, M, H, dF, nullptr));
-        CS_TRY(launch_split_rows(dW1, sW1, I, H, dF, nullptr));
-        CS_TRY(launch_split_rows(dW2, sW2, H, I, dF, nullptr));
-        float *db1 = dv, *db2 = dv + I, *dg = dv + I + H, *dbe = dv + I + 2 * H;
-        CS_HIP(hipEventCreate(&e0)); CS_HIP(hipEventCreate(&e1));
-        auto once = [&]() -> int32_t {  // out of place (sA -> sX): every launch sees the same inputs
-            if (fused) return launch_ffn_fused(sA, sW1, db1, sW2, db2, dg, dbe, 1e-12f, nullptr, sX, M, I, dF, nullptr);
-            CS_TRY(launch_gemm_wide(SH_OUT_SPLIT_GELU, sA, sW1, db1, nullptr, nullptr, sMid, M, I, H, dF, nullptr, 0));
-            return launch_gemm_wide_ln(sMid, sW2, db2, nullptr, dg, dbe, 1e-12f, nullptr, sX, M, I, dF, nullptr, sA);
-        };
-        cs::g_ffn_fused_ablation = fused ? ablation : 0;
-        for (int i = 0; i < 3; ++i) CS_TRY(once());
-        CS_HIP(hipEventRecord(e0, nullptr));
-        for (uint32_t i = 0; i < iters; ++i) CS_TRY(once());
-        CS_HIP(hipEventRecord(e1, nullptr));
-        CS_HIP(hipEventSynchronize(e1));
-        float ms = 0.f;
-        CS_HIP(hipEventElapsedTime(&ms, e0, e1));
-        *ms_per_launch = (double)ms / iters;
-        return CS_OK;
-    };
-    const int32_t st = run();
-    cs::g_ffn_fused_ablation = 0;
-    (void)hipDeviceSynchronize();
-    for (void* p : {(void*)dA, (void*)dW1, (void*)dW2, (void*)dv, (void*)sA, (void*)sX, (void*)sW1, (void*)sW2, (void*)sMid, (void*)dF})
-        if (p) (void)hipFree(p);
-    if (e0) (void)hipEventDestroy(e0);
-    if (e1) (void)hipEventDestroy(e1);
-    return st;
-}
-
 // Diagnostics: device time of one dense layer on synthetic operands already in HBM (no PCIe, no allocation inside the
 // timed region).  mode as cs_debug_gemm (0 f32 MFMA, 1 split-f16 128 x 128 / skinny kernels, 2 split-f16 wide kernel);
 // epilogue 0 f32 store, 1 GELU -> split store, 2 + residual, 3 LayerNorm-fused (mode 2, N = 384), 4 bias -> split store
@@ -1342,7 +1216,12 @@ int32_t cs_debug_gemm_time(int32_t device, int32_t mode, int32_t epilogue, uint3
             if (mode == 2) return launch_gemm_wide(epi, sA, sW, dB, dR, dC, sC, M, N, K, dF, nullptr, 0);
             return launch_gemm_split(epi, sA, sW, dB, dR, dC, sC, M, N, K, dF, nullptr);
         };
-        cs::g_gemm_wide_ablation = (mode == 2 && epilogue == 4) ? ablation : 0;
+        // ablation >= 100: DMA schedule ablation - 100 of the product kernel (gemm_wide.hip gw_dma_slot), any epilogue
+        // ablation >= 1000: the 128 x 192 two-blocks-per-CU shape with the CU's second block (ablation - 1000) cycles per
+        // k-chunk late (pairing by HW_ID)
+        if (mode == 2 && ablation >= 1000) { cs::g_gemm_wide_shape = 192; cs::g_gemm_wide_stagger = ablation - 1000; ablation = 0; }
+        cs::g_gemm_wide_sched = (mode == 2 && ablation >= 100) ? ablation - 100 : -1;
+        cs::g_gemm_wide_ablation = (mode == 2 && epilogue == 4 && ablation < 100) ? ablation : 0;
         for (int i = 0; i < 3; ++i) CS_TRY(once());
         CS_HIP(hipEventRecord(e0, nullptr));
         for (uint32_t i = 0; i < iters; ++i) CS_TRY(once());
@@ -1362,6 +1241,9 @@ int32_t cs_debug_gemm_time(int32_t device, int32_t mode, int32_t epilogue, uint3
     };
     const int32_t st = run();
     cs::g_gemm_wide_ablation = 0;
+    cs::g_gemm_wide_sched = -1;
+    cs::g_gemm_wide_shape = 0;
+    cs::g_gemm_wide_stagger = -1;
     (void)hipDeviceSynchronize();
     for (void* p : {(void*)dA, (void*)dW, (void*)dB, (void*)dR, (void*)dC, (void*)sA, (void*)sW, (void*)sC, (void*)dF})
         if (p) (void)hipFree(p);

@@ -77,14 +77,9 @@ int32_t launch_gemm_wide_ln(const _Float16* A, const _Float16* W, const float* b
 int32_t launch_attention_cls(const _Float16* q_cls, const _Float16* kv_split, const int32_t* mask, _Float16* ctxs_cls,
                              uint32_t* flag, uint32_t B, uint32_t L, uint32_t H, uint32_t heads, hipStream_t s);
 int32_t launch_gather_cls(const _Float16* xs, float* x_cls, _Float16* xs_cls, uint32_t B, uint32_t L, uint32_t H, hipStream_t s);
-// ffn_fused.hip: X_out = LayerNorm(GELU(A W1^T + b1) W2^T + b2 + A) * gamma + beta in ONE persistent kernel per 128 rows
-// (hidden 384, intermediate % 128 == 0); A / Xs split form (Xs may be A), X optional f32 copy of the output.
-bool ffn_fused_supported(uint32_t hidden, uint32_t intermediate);
-int32_t launch_ffn_fused(const _Float16* A, const _Float16* W1, const float* b1, const _Float16* W2, const float* b2,
-                         const float* gamma, const float* beta, float eps, float* X, _Float16* Xs, uint32_t M,
-                         uint32_t intermediate, uint32_t* d_flag, hipStream_t s);
-extern int g_ffn_fused_ablation;  // diagnostics (cs_debug_ffn_time)
 extern int g_gemm_wide_ablation;  // diagnostics (cs_debug_gemm_time)
+extern int g_gemm_wide_shape, g_gemm_wide_stagger;  // diagnostics: block shape / two-blocks-per-CU stagger overrides
+extern int g_gemm_wide_sched;     // diagnostics: DMA schedule override (gemm_wide.hip gw_dma_slot), -1 = environment
 double gemm_wide_read_clock_ghz(double* main_cycles, double* epi_cycles);  // after an ablation-7 launch: median in-kernel clock
 int32_t sh_weights_fit_wide(const _Float16* d_wsplit, uint64_t n_f16, uint32_t* d_scratch_flag, bool* ok, hipStream_t s);
 int32_t launch_synth_params(float* d_out, const cs_bert_config& cfg, uint64_t seed, hipStream_t s);

@@ -30,6 +30,7 @@
 #include "encoder.hpp"
 
 #include <algorithm>
+#include <type_traits>
 #include <vector>
 #include "split_f16.hpp"
 
@@ -39,6 +40,7 @@ namespace cs {
 
 constexpr int GW_BM = 128, GW_BN = 384;
 constexpr int GW_A_BYTES = GW_BM * 128;            // one k-chunk (32 k, hi + lo) of 128 A rows
+constexpr int GW_PARAM_FLOATS = 4096;                // bias of up to 4,096 columns (LayerNorm: bias | gamma | beta of 384)
 constexpr int GW_STATS = 5 * GW_BM * 4;            // LayerNorm epilogue: [4 column groups][128 rows] f32 partial sums + [128] row statistic
 // Two block shapes share the kernel: WCN = 4 column waves -> 8 waves, 128 x 384 outputs, one block per CU (whole rows
 // at N = 384: the LayerNorm epilogue); WCN = 2 -> 4 waves, 128 x 192 outputs, 80 KiB of LDS, TWO blocks per CU, so
@@ -50,11 +52,16 @@ struct GwGeom {
     static constexpr int THREADS = 64 * WAVES;
     static constexpr int W_BYTES = BN * 128;
     static constexpr int STAGE = GW_A_BYTES + W_BYTES;           // 65,536 | 40,960
-    static constexpr int LDS = 2 * STAGE + (WCN == 4 ? GW_STATS : 0);
+    // WCN == 4 keeps the layer's bias (and the LayerNorm's gamma / beta) in LDS for the block's lifetime: the epilogue then
+    // issues no global LOAD, so nothing in it waits on vmcnt (which retires in issue order: a load issued behind the
+    // previous strip's stores, or behind the next tile's first DMAs, waits for all of them)
+    static constexpr int PARAMS = WCN == 4 ? GW_PARAM_FLOATS * 4 : 0;
+    static constexpr int LDS = 2 * STAGE + (WCN == 4 ? GW_STATS : 0) + PARAMS;
     static constexpr int A_PIECES = 16 / WAVES;                  // LDS-DMA pieces (8 rows x 128 B) of A per wave and stage: 2 | 4
     static constexpr int W_PIECES = (BN / 8) / WAVES;            // ... of W: 6
     static constexpr int PIECES = A_PIECES + W_PIECES;           // 8 | 10
 };
+constexpr uint32_t GW_STAGGER_BY_CU = 4u;  // (ln_flags bit) the late block of a CU is found from HW_ID, not from blockIdx
 constexpr uint32_t GW_LN_RESID_SPLIT = 1u, GW_LN_NO_F32 = 2u;  // ln_flags of the LayerNorm epilogue (launch_gemm_wide_ln)
 constexpr int GW_OUT_LN = 16;  // epilogue: + bias + residual, LayerNorm over the 384 columns, store f32 AND split form
 
@@ -94,9 +101,30 @@ struct GwSrc {  // element offsets from A / W (32 bits: a [65536, 1536] operand 
 // reads hoisted out of the k loop (the pure MFMA rate); 6 = 1 without the epilogue's stores.
 // ABL 7: the product kernel plus one (s_memtime, s_memrealtime) pair per block at its first and after its last tile,
 // written to a buffer nothing else reads: the in-kernel clock (MI355X_MICROARCH.md, DVFS give-back item 6).
+__device__ uint32_t g_gw_cu_arrivals[2048];  // per CU: blocks that have started there (stagger pairing)
 __device__ uint64_t g_gw_stamps[8 * 512];  // per block: clk0, real0, clk1, real1, main-loop cycles, epilogue cycles, tiles
 
-template <int EPI, int ABL = 0, int WCN = 4>
+// DMA issue schedule of a k-step.  A k-step of a wave is 18 groups of four MFMAs (6 weight fragments x {w_hi * 2^11 . a_hi,
+// w_lo . a_hi, w_hi . a_lo}); "slot s" is the point right after group s (slot -1: before the first group).  All eight waves
+// of the block run the same program between the same barriers, so under SCH 0 they all reach their DMAs at the same
+// slots: the two waves of a SIMD stall in DMA issue together (MI355X_MICROARCH.md, Two waves per SIMD, item 9) and the CU's
+// one address path sees eight 1-KiB requests at once, then none.  SCH >= 1 gives waves 4-7 (the SIMD partners of 0-3)
+// other slots than waves 0-3.
+template <int SCH>
+__device__ constexpr int gw_dma_slot(int half, int p) {
+    // SCH 0: every wave, pieces 2j and 2j+1 after the first and second group of fragment j (the round-2 schedule)
+    if (SCH == 0) return 3 * (p / 2) + (p & 1);
+    // SCH 1: waves 0-3 on even slots 0..14, waves 4-7 on odd slots 1..15
+    if (SCH == 1) return 2 * p + half;
+    // SCH 2: twelve MFMAs, then two DMAs; waves 4-7 open the step with their first two (half a period out of phase)
+    if (SCH == 2) return half == 0 ? 3 * (p / 2) + 2 : 3 * (p / 2) - 1;
+    // SCH 3: one DMA per six MFMAs... waves 0-3 slots 0,1,3,4,6,7,9,10 (as SCH 0), waves 4-7 one group later
+    if (SCH == 3) return 3 * (p / 2) + (p & 1) + half;
+    // SCH 4: as SCH 1 but waves 4-7 lead: odd slots for waves 0-3
+    return 2 * p + (1 - half);
+}
+
+template <int EPI, int ABL = 0, int WCN = 4, int SCH = 0>
 __global__ void __launch_bounds__(GwGeom<WCN>::THREADS, 2)
 gemm_wide_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ W, const float* __restrict__ bias,
                  const float* resid, float* C, _Float16* __restrict__ Cs, uint32_t M, uint32_t N, uint32_t kchunks,
@@ -149,12 +177,31 @@ gemm_wide_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ W,
     uint32_t mt = 0, nt = 0;
     uint32_t slot = next_valid(blockIdx.x, mt, nt);
     if (slot >= total_slots) return;
+    float* const pbias = reinterpret_cast<float*>(lds + 2 * GW_STAGE + GW_STATS);  // (WCN == 4) [N] bias, LayerNorm: + gamma, beta
+    constexpr bool lds_params = WCN == 4;  // the launcher sends N > GW_PARAM_FLOATS to the 128 x 192 shape
+    if constexpr (lds_params) {
+        for (uint32_t i = tid; i < N / 4; i += G::THREADS) {
+            reinterpret_cast<sh_f32x4*>(pbias)[i] = reinterpret_cast<const sh_f32x4*>(bias)[i];
+            if (EPI == GW_OUT_LN) {
+                reinterpret_cast<sh_f32x4*>(pbias + N)[i] = reinterpret_cast<const sh_f32x4*>(ln_g)[i];
+                reinterpret_cast<sh_f32x4*>(pbias + 2 * N)[i] = reinterpret_cast<const sh_f32x4*>(ln_b)[i];
+            }
+        }
+        __syncthreads();
+    }
+    // the bias of this lane's four columns of tile j (n0: first column of the block's n-tile)
+    auto bias_of = [&](uint32_t n0, int j) -> sh_f32x4 {
+        const uint32_t c = n0 + wc * 96 + 16 * j + 4 * g;
+        // (a compile-time choice: a runtime select between an LDS and a global pointer becomes a FLAT load, which counts
+        // on vmcnt AND lgkmcnt and is waited for with both at zero)
+        if constexpr (lds_params) return *reinterpret_cast<const sh_f32x4*>(pbias + c);
+        else return *reinterpret_cast<const sh_f32x4*>(bias + c);
+    };
     GwSrc<WCN> src;
     tile_src(mt * GW_BM, nt * GW_BN, src);
     uint32_t buf = 0;  // stage buffer (0 | 1) that holds stage 0 of the current tile
-#pragma unroll
-    for (int p = 0; p < NP; ++p) dma(src, p, sh_kc_rot(nt, ntiles, kchunks), 0);
-
+    constexpr bool GRACE = SCH >= 10 && (EPI == SH_OUT_SPLIT || EPI == SH_OUT_SPLIT_GELU) && ABL == 0;
+    bool prev_full = false;
     // Stagger (two blocks per CU).  Every tile of a launch costs the same, so the two persistent blocks of a CU stay
     // in lockstep: both in their main loops, then both in their epilogues — the epilogue's VALU work (GELU + split:
     // as many cycles as the tile's MFMAs at K = 384) would never meet the other block's MFMAs.  The second half of
@@ -162,104 +209,181 @@ gemm_wide_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ W,
     // half a tile behind.
     const bool use_prio = (stagger_cycles >> 31) != 0;  // experiment: main loop at wave priority 2, epilogue at 0
     stagger_cycles &= 0x7fffffffu;
-    if (stagger_cycles && WCN == 2 && blockIdx.x >= gridDim.x / 2) {
+    bool late = blockIdx.x >= gridDim.x / 2;
+    if (stagger_cycles && WCN == 2 && (ln_flags & GW_STAGGER_BY_CU)) {
+        // which of a CU's two resident blocks am I?  The dispatcher's block -> CU order is not specified (two
+        // consecutive blocks may share a CU), so the pairing is taken from the hardware: (XCC, SE, SH, CU) from the wave's
+        // HW_ID names the CU, and the parity of an arrival count kept per CU (never reset: two blocks arrive per launch)
+        // says whether a partner is already there.
+        if (tid == 0) {
+            const uint32_t hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20);
+            const uint32_t key = ((xcc & 7u) << 8) | (((hw >> 13) & 7u) << 5) | (((hw >> 12) & 1u) << 4) | ((hw >> 8) & 15u);
+            *reinterpret_cast<volatile uint32_t*>(lds) = atomicAdd(&g_gw_cu_arrivals[key], 1u) & 1u;
+        }
+        __syncthreads();
+        late = *reinterpret_cast<volatile uint32_t*>(lds) != 0;
+        __syncthreads();  // the word is overwritten by the first stage
+    }
+    if (stagger_cycles && WCN == 2 && late) {
         const uint64_t t0 = __builtin_amdgcn_s_memtime();
         while (__builtin_amdgcn_s_memtime() - t0 < (uint64_t)stagger_cycles) __builtin_amdgcn_s_sleep(16);
     }
+#pragma unroll
+    for (int p = 0; p < NP; ++p) dma(src, p, sh_kc_rot(nt, ntiles, kchunks), 0);
+
     uint64_t t_clk = 0, t_real = 0, t_main = 0, t_epi = 0, t_mark = 0, n_tiles = 0;
     if (ABL == 7) { t_clk = __builtin_amdgcn_s_memtime(); t_real = __builtin_amdgcn_s_memrealtime(); t_mark = t_clk; }
     while (slot < total_slots) {
         const uint32_t m0 = mt * GW_BM, n0 = nt * GW_BN;
         const uint32_t rot = sh_kc_rot(nt, ntiles, kchunks);  // see sh_mainloop: n-tiles of an m-tile walk K out of phase
         GwAcc acc;
+        // The accumulators START at bias * 2^11 (LayerNorm: (bias + residual) * 2^11), the scale the products arrive on: the
+        // epilogue needs neither registers nor loads for them.
         if (EPI == GW_OUT_LN) {
-            // the accumulators START at (bias + residual) * 2^11, the scale the products arrive on: the residual is
-            // read while stage 0 is in flight and the epilogue needs no registers for it
+            // The residual is read while stage 0 is in flight.  The form (f32 | split) is decided ONCE, outside the unrolled
+            // loops, and every load of a half tile is issued before the first is used: with the choice inside the loops hipcc
+            // branches around each load and waits vmcnt(0) behind it — 24 dependent round trips per tile and wave
+            // (cdna_hip_programming.md §5, Projection GEMM item 4(c)).
             const char* rbase = reinterpret_cast<const char*>(resid);
+            if (ln_flags & GW_LN_RESID_SPLIT) {
+                // the residual stream in split form only (same 4 B per element: the row's line [32 hi | 32 lo] of the
+                // 32-column chunk): hi * 2^11 + lo' is exact in f32 and already on the accumulators' scale
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const uint32_t row = m0 + wr * 64 + 16 * i + l15;
-                // 32-bit byte offset from a uniform base (a [65536, 384] f32 tensor is 100 MB): one VGPR per row
-                const uint32_t off = ((row < M ? row : M - 1) * GW_BN + wc * 96 + 4 * g) * 4u;
+                for (int ih = 0; ih < 2; ++ih) {
+                    f16x4 rh[2][6], rl[2][6];
 #pragma unroll
-                for (int j = 0; j < 6; ++j) {
-                    const sh_f32x4 bv = *reinterpret_cast<const sh_f32x4*>(bias + wc * 96 + 16 * j + 4 * g);
-                    if (ln_flags & GW_LN_RESID_SPLIT) {
-                        // the residual stream in split form only (same 4 B per element: the row's line [32 hi | 32 lo] of
-                        // the 32-column chunk): hi * 2^11 + lo' is exact in f32 and already on the accumulators' scale
-                        const uint32_t col = wc * 96 + 16 * j + 4 * g;
-                        const char* lp = rbase + (size_t)(((row < M ? row : M - 1) * (GW_BN / 32) + (col >> 5)) * 128u + (col & 31) * 2u);
-                        const f16x4 rh = *reinterpret_cast<const f16x4*>(lp);
-                        const f16x4 rl = *reinterpret_cast<const f16x4*>(lp + 64);
+                    for (int ii = 0; ii < 2; ++ii) {
+                        const uint32_t row = m0 + wr * 64 + 16 * (2 * ih + ii) + l15;
+                        const uint32_t rrow = (row < M ? row : M - 1) * (GW_BN / 32);
 #pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                            acc.c[i][j][r] = fmaf((float)rh[r], kShLoScale, (float)rl[r]) + bv[r] * kShLoScale;
-                    } else {
-                        const sh_f32x4 rv = *reinterpret_cast<const sh_f32x4*>(rbase + (size_t)(off + 64u * j));
-                        acc.c[i][j] = (bv + rv) * kShLoScale;
+                        for (int j = 0; j < 6; ++j) {
+                            const uint32_t col = wc * 96 + 16 * j + 4 * g;
+                            const char* lp = rbase + (size_t)((rrow + (col >> 5)) * 128u + (col & 31) * 2u);
+                            rh[ii][j] = *reinterpret_cast<const f16x4*>(lp);
+                            rl[ii][j] = *reinterpret_cast<const f16x4*>(lp + 64);
+                        }
                     }
+#pragma unroll
+                    for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+                        for (int j = 0; j < 6; ++j) {
+                            const sh_f32x4 bv = bias_of(0, j);
+#pragma unroll
+                            for (int r = 0; r < 4; ++r)
+                                acc.c[2 * ih + ii][j][r] = fmaf((float)rh[ii][j][r], kShLoScale, (float)rl[ii][j][r]) + bv[r] * kShLoScale;
+                        }
                 }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const uint32_t row = m0 + wr * 64 + 16 * i + l15;
+                    // 32-bit byte offset from a uniform base (a [65536, 384] f32 tensor is 100 MB): one VGPR per row
+                    const uint32_t off = ((row < M ? row : M - 1) * GW_BN + wc * 96 + 4 * g) * 4u;
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) acc.c[i][j] = *reinterpret_cast<const sh_f32x4*>(rbase + (size_t)(off + 64u * j));
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) acc.c[i][j] = (bias_of(0, j) + acc.c[i][j]) * kShLoScale;
             }
         } else {
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int j = 0; j < 6; ++j) {
+                const sh_f32x4 bv = bias_of(n0, j) * kShLoScale;
 #pragma unroll
-                for (int j = 0; j < 6; ++j) acc.c[i][j] = sh_f32x4v{0.f, 0.f, 0.f, 0.f};
+                for (int i = 0; i < 4; ++i) acc.c[i][j] = bv;
+            }
         }
-        __syncthreads();  // stage 0 has landed (vmcnt(0) precedes the barrier)
+        // SCH >= 10 ("grace"): this tile's stage-0 DMAs were issued BEFORE the previous tile's epilogue stores; vmcnt retires
+        // in issue order, so waiting until only those 24 stores are outstanding proves stage 0 has landed and lets the
+        // stores drain under the first k-step's MFMAs (the step's own barrier waits for them).  Only after a full tile
+        // (every store instruction issued by every wave) and for the split-store epilogues.
+        if (GRACE && prev_full) {
+            asm volatile("s_waitcnt vmcnt(24) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        } else {
+            __syncthreads();  // stage 0 has landed (vmcnt(0) precedes the barrier)
+        }
         if (use_prio) __builtin_amdgcn_s_setprio(2);
 
-        for (uint32_t kc = 0; kc < kchunks; ++kc) {
-            const char* cur = lds + ((buf + kc) & 1) * GW_STAGE;
-            const uint32_t nb = ((buf + kc + 1) & 1) * GW_STAGE;
-            const bool more = kc + 1 < kchunks;
-            uint32_t kn = rot + kc + 1;
-            kn = kn >= kchunks ? kn - kchunks : kn;
-            if (ABL == 5) cur = lds;  // same addresses every step: the reads hoist out of the loop (pure MFMA rate)
-            f16x8 ah[4], al[4];
+        // the k loop, instantiated per SIMD half (waves 0-3 | 4-7) when the schedule differs between them
+        auto kloop = [&](auto half_c) __attribute__((always_inline)) {
+            constexpr int HALF = decltype(half_c)::value;
+            constexpr bool DMA_ON = ABL == 0 || ABL == 2 || ABL >= 7;  // ABL 1, 4, 5, 6: no DMA after a tile's first stage
+            for (uint32_t kc = 0; kc < kchunks; ++kc) {
+                const char* cur = lds + ((buf + kc) & 1) * GW_STAGE;
+                const uint32_t nb = ((buf + kc + 1) & 1) * GW_STAGE;
+                const bool more = kc + 1 < kchunks;
+                uint32_t kn = rot + kc + 1;
+                kn = kn >= kchunks ? kn - kchunks : kn;
+                if (ABL == 5) cur = lds;  // same addresses every step: the reads hoist out of the loop (pure MFMA rate)
+                auto issue = [&](int slot) __attribute__((always_inline)) {
+                    if (!DMA_ON || !more) return;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                ah[i] = *reinterpret_cast<const f16x8*>(cur + a_off + i * 2048 + s_hi);
-                al[i] = *reinterpret_cast<const f16x8*>(cur + a_off + i * 2048 + s_lo);
-            }
-            f16x8 wh = *reinterpret_cast<const f16x8*>(cur + w_off + s_hi);
-            f16x8 wl = *reinterpret_cast<const f16x8*>(cur + w_off + s_lo);
-            if (ABL == 3 && more) {
+                    for (int p = 0; p < NP; ++p)
+                        if (gw_dma_slot<WCN == 4 ? SCH % 10 : 0>(HALF, p) == slot) dma(src, p, kn, nb);
+                };
+                f16x8 ah[4], al[4];
 #pragma unroll
-                for (int p = 0; p < NP; ++p) dma(src, p, kn, nb);
-            }
-#pragma unroll
-            for (int j = 0; j < 6; ++j) {
-                f16x8 whn = wh, wln = wl;
-                if (j < 5) {
-                    whn = *reinterpret_cast<const f16x8*>(cur + w_off + (j + 1) * 2048 + s_hi);
-                    wln = *reinterpret_cast<const f16x8*>(cur + w_off + (j + 1) * 2048 + s_lo);
+                for (int i = 0; i < 4; ++i) {
+                    ah[i] = *reinterpret_cast<const f16x8*>(cur + a_off + i * 2048 + s_hi);
+                    al[i] = *reinterpret_cast<const f16x8*>(cur + a_off + i * 2048 + s_lo);
                 }
-                const f16x8 whs = wh * (_Float16)2048.0f;  // exact: |w_hi| < 32 (sh_weights_fit_wide)
-                if (ABL == 2) {
-                    asm volatile("" ::"v"(whs), "v"(wl), "v"(wh));
+                f16x8 wh = *reinterpret_cast<const f16x8*>(cur + w_off + s_hi);
+                f16x8 wl = *reinterpret_cast<const f16x8*>(cur + w_off + s_lo);
+                if (ABL == 3 && more) {
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(ah[i]), "v"(al[i]));
+                    for (int p = 0; p < NP; ++p) dma(src, p, kn, nb);
+                }
+                if (WCN == 4 && SCH % 10 != 0) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    issue(-1);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    if (ABL != 2) acc.c[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(whs, ah[i], acc.c[i][j], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-                if ((ABL == 0 || ABL == 2 || ABL >= 7) && more && 2 * j < NP) dma(src, 2 * j, kn, nb);  // ABL 1, 4, 5, 6: no DMA
-                __builtin_amdgcn_sched_barrier(0);
+                for (int j = 0; j < 6; ++j) {
+                    f16x8 whn = wh, wln = wl;
+                    if (j < 5) {
+                        whn = *reinterpret_cast<const f16x8*>(cur + w_off + (j + 1) * 2048 + s_hi);
+                        wln = *reinterpret_cast<const f16x8*>(cur + w_off + (j + 1) * 2048 + s_lo);
+                    }
+                    const f16x8 whs = wh * (_Float16)2048.0f;  // exact: |w_hi| < 32 (sh_weights_fit_wide)
+                    if (ABL == 2) {
+                        asm volatile("" ::"v"(whs), "v"(wl), "v"(wh));
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    if (ABL != 2) acc.c[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, ah[i], acc.c[i][j], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-                if ((ABL == 0 || ABL == 2 || ABL >= 7) && more && 2 * j + 1 < NP) dma(src, 2 * j + 1, kn, nb);
-                __builtin_amdgcn_sched_barrier(0);
+                        for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(ah[i]), "v"(al[i]));
+                    }
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    if (ABL != 2) acc.c[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, al[i], acc.c[i][j], 0, 0, 0);
-                wh = whn;
-                wl = wln;
+                    for (int i = 0; i < 4; ++i)
+                        if (ABL != 2) acc.c[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(whs, ah[i], acc.c[i][j], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    issue(3 * j);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        if (ABL != 2) acc.c[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, ah[i], acc.c[i][j], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    issue(3 * j + 1);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        if (ABL != 2) acc.c[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, al[i], acc.c[i][j], 0, 0, 0);
+                    if (WCN == 4 && SCH % 10 != 0) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        issue(3 * j + 2);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    wh = whn;
+                    wl = wln;
+                }
+                if (ABL != 4 && ABL != 5) __syncthreads();  // stage kc+1 has landed; every wave is done reading stage kc
             }
-            if (ABL != 4 && ABL != 5) __syncthreads();  // stage kc+1 has landed; every wave is done reading stage kc
+        };
+        if constexpr (WCN == 4 && SCH % 10 != 0) {
+            if (wave < 4) kloop(std::integral_constant<int, 0>{});
+            else kloop(std::integral_constant<int, 1>{});
+        } else {
+            kloop(std::integral_constant<int, 0>{});
         }
         if (ABL == 4 || ABL == 5) __syncthreads();
 
@@ -285,7 +409,6 @@ gemm_wide_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ W,
         // from the accumulators, 8 B per lane and plane, was measured: 2.4x slower — partial-line writes.)
         const bool full = m0 + GW_BM <= M;
         uint32_t mx = 0;  // packed maximum of |hi| bit patterns (sh_split8)
-        const uint32_t cbase = n0 + wc * 96 + 4 * g;  // first column of this lane in tile j = 0
         float* patch = reinterpret_cast<float*>(lds + ebuf * GW_STAGE + wave * 8192);  // [16 rows][100 floats]
         constexpr int PS = 100;
         float mean[4] = {0.f, 0.f, 0.f, 0.f};
@@ -326,73 +449,27 @@ gemm_wide_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ W,
             for (int i = 0; i < 4; ++i) mean[i] = rowstat[wr * 64 + 16 * i + l15];
             reduce_rows(true);
         }
-        sh_f32x4 bv[6];
 #pragma unroll
-        for (int j = 0; j < 6; ++j)
-            if (EPI != GW_OUT_LN) bv[j] = *reinterpret_cast<const sh_f32x4*>(bias + cbase + 16 * j);
-        // ABL 11 — the split-form epilogues WITHOUT the LDS patch: a lane holds four consecutive columns of
-        // tiles j and j + 1 of its row; after the split, v_permlane16_swap exchanges tile j + 1 of the even 16-lane rows
-        // with tile j of the odd ones, so every lane owns 8 consecutive columns = one 16-byte chunk of the row's 128-byte
-        // line (lane g -> chunk (g >> 1) + 2 (g & 1)) and stores it: 16 rows x 64 B per instruction, default cache policy.
-        constexpr bool SWAP_EPI = ABL == 11 && (EPI == SH_OUT_SPLIT || EPI == SH_OUT_SPLIT_GELU);
-        if constexpr (SWAP_EPI) {
-            const int chunk = (g >> 1) + 2 * (g & 1);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const uint32_t m = wr * 64 + 16 * i + l15;
-                const bool live = full || m0 + m < M;
-#pragma unroll
-                for (int jp = 0; jp < 3; ++jp) {
-                    sh_f32x4 v0, v1;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        v0[r] = fmaf(acc.c[i][2 * jp][r], kShLoInv, bv[2 * jp][r]);
-                        v1[r] = fmaf(acc.c[i][2 * jp + 1][r], kShLoInv, bv[2 * jp + 1][r]);
-                        if (EPI == SH_OUT_SPLIT_GELU) { v0[r] = gw_gelu(v0[r]); v1[r] = gw_gelu(v1[r]); }
-                    }
-                    f16x8 hi, lo;
-                    sh_split8(v0, v1, hi, lo, mx);
-                    uint32_t* hw = reinterpret_cast<uint32_t*>(&hi);
-                    uint32_t* lw = reinterpret_cast<uint32_t*>(&lo);
-#pragma unroll
-                    for (int w2 = 0; w2 < 2; ++w2) {
-                        const auto sh = __builtin_amdgcn_permlane16_swap(hw[w2], hw[2 + w2], false, false);
-                        hw[w2] = sh[0]; hw[2 + w2] = sh[1];
-                        const auto sl = __builtin_amdgcn_permlane16_swap(lw[w2], lw[2 + w2], false, false);
-                        lw[w2] = sl[0]; lw[2 + w2] = sl[1];
-                    }
-                    if (live) {
-                        const uint32_t col = n0 + wc * 96 + 32 * jp;  // first column of the line
-                        _Float16* dst = Cs + ((size_t)(m0 + m) * (N / 32) + (col >> 5)) * 64 + chunk * 8;
-                        *reinterpret_cast<f16x8*>(dst) = hi;
-                        *reinterpret_cast<f16x8*>(dst + 32) = lo;
-                    }
-                }
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < ((ABL == 6 || SWAP_EPI) ? 0 : 4); ++i) {
+        for (int i = 0; i < (ABL == 6 ? 0 : 4); ++i) {
             // final values of strip i into the patch (row l15, columns 16 j + 4 g .. + 3)
             float inv = 1.0f;
             if (EPI == GW_OUT_LN) inv = rowstat[wr * 64 + 16 * i + l15];
-            // gamma / beta are re-read per strip (held across the strips they would cost the 48 registers the
-            // accumulators need); they sit in L1.  The strip's offset goes through an opaque zero so the loads of
-            // different strips cannot be merged — and are still ORDINARY loads, twelve in flight: as `volatile` they
-            // were system-scope (sc0 sc1) loads with a vmcnt(0) behind each, 48 round trips per tile and wave.
-            uint32_t strip_zero = 0;
-            if (EPI == GW_OUT_LN) asm volatile("" : "+s"(strip_zero));
+            // gamma / beta per strip from the block's LDS copy (held in registers across the strips they would cost the 48
+            // registers the accumulators need; as global loads each strip's would sit behind the previous strip's stores
+            // in the vmcnt queue and wait for them)
 #pragma unroll
             for (int j = 0; j < 6; ++j) {
                 sh_f32x4 v;
-                if (EPI == GW_OUT_LN) {
-                    const sh_f32x4 gj = *reinterpret_cast<const sh_f32x4*>(ln_g + strip_zero + wc * 96 + 16 * j + 4 * g);
-                    const sh_f32x4 bj = *reinterpret_cast<const sh_f32x4*>(ln_b + strip_zero + wc * 96 + 16 * j + 4 * g);
+                if constexpr (EPI == GW_OUT_LN) {
+                    const uint32_t c = wc * 96 + 16 * j + 4 * g;
+                    const sh_f32x4 gj = *reinterpret_cast<const sh_f32x4*>(pbias + GW_BN + c);
+                    const sh_f32x4 bj = *reinterpret_cast<const sh_f32x4*>(pbias + 2 * GW_BN + c);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = (acc.c[i][j][r] - mean[i]) * inv * gj[r] + bj[r];
                 } else {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        v[r] = fmaf(acc.c[i][j][r], kShLoInv, bv[j][r]);
+                        v[r] = acc.c[i][j][r] * kShLoInv;  // the bias is in there (accumulator start)
                         if (EPI == SH_OUT_SPLIT_GELU) v[r] = gw_gelu(v[r]);
                     }
                 }
@@ -459,6 +536,7 @@ gemm_wide_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ W,
         }
         if (flag && sh_split_overflowed(mx)) atomicOr(flag, 1u);
         if (ABL == 7) { const uint64_t t = __builtin_amdgcn_s_memtime(); t_epi += t - t_mark; t_mark = t; ++n_tiles; }
+        prev_full = full;
         buf = ebuf ^ 1;
         slot = nslot;
         mt = nmt;
@@ -525,6 +603,9 @@ int32_t sh_weights_fit_wide(const _Float16* d_wsplit, uint64_t n_f16, uint32_t* 
 bool gemm_wide_supported(uint32_t N, uint32_t K) { return N % 192 == 0 && K % 32 == 0 && N > 0 && K > 0; }
 
 int g_gemm_wide_ablation = 0;  // diagnostics only (cs_debug_gemm_time)
+int g_gemm_wide_sched = -1;    // diagnostics only: >= 0 overrides CS_GEMM_WIDE_SCH
+int g_gemm_wide_shape = 0;     // diagnostics only: 192 / 384 overrides CS_GEMM_WIDE_SHAPE
+int g_gemm_wide_stagger = -1;  // diagnostics only: >= 0 = cycles per k-chunk the late block of a CU waits (pairing by HW_ID)
 
 template <int WCN>
 static int32_t gemm_wide_launch(int epi, const _Float16* A, const _Float16* W, const float* bias, const float* resid, float* C,
@@ -558,7 +639,10 @@ static int32_t gemm_wide_launch(int epi, const _Float16* A, const _Float16* W, c
     const uint32_t kc = K / 32;
     // half a tile in s_memtime ticks per k-chunk (CS_GEMM_WIDE_STAGGER; default 0 = off: measured 600 / 1200 / 2400 on
     // all four layer shapes, no gain — see DESIGN.md §3.3); only when blocks run several tiles
-    static const int stagger_env = [] { const char* e = std::getenv("CS_GEMM_WIDE_STAGGER"); return e ? std::atoi(e) : 0; }();
+    static const int stagger_env0 = [] { const char* e = std::getenv("CS_GEMM_WIDE_STAGGER"); return e ? std::atoi(e) : 0; }();
+    static const bool stagger_cu_env = [] { const char* e = std::getenv("CS_GEMM_WIDE_STAGGER_BY_CU"); return e && e[0] == '1'; }();
+    const int stagger_env = g_gemm_wide_stagger >= 0 ? g_gemm_wide_stagger : stagger_env0;
+    if (WCN == 2 && stagger_env > 0 && (stagger_cu_env || g_gemm_wide_stagger >= 0)) ln_flags |= GW_STAGGER_BY_CU;
     static const bool prio_env = [] { const char* e = std::getenv("CS_GEMM_WIDE_PRIO"); return e && e[0] == '1'; }();
     const uint32_t stagger = ((WCN == 2 && slots >= 2 * grid && grid == resident && stagger_env > 0) ? kc * (uint32_t)stagger_env : 0u) |
                              (prio_env ? 0x80000000u : 0u);
@@ -595,18 +679,33 @@ static int32_t gemm_wide_launch(int epi, const _Float16* A, const _Float16* W, c
             return CS_OK;
         }
     }
-    static const bool epi_swap = [] { const char* e = std::getenv("CS_GEMM_WIDE_EPI_SWAP"); return e && e[0] == '1'; }();
-    if (epi_swap && (epi == SH_OUT_SPLIT || epi == SH_OUT_SPLIT_GELU)) {
-        static PerDeviceOnce swap_attr;
-        CS_TRY(swap_attr.run([&]() -> int32_t {
-            CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wide_kernel<SH_OUT_SPLIT, 11, WCN>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
-            CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wide_kernel<SH_OUT_SPLIT_GELU, 11, WCN>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
+    if constexpr (WCN == 4) {
+        // DMA schedule (gw_dma_slot): CS_GEMM_WIDE_SCH, or ablation ids 12..15 = schedules 1..4 on the product kernel
+        static const int sch_env = [] { const char* e = std::getenv("CS_GEMM_WIDE_SCH"); return e ? std::atoi(e) : 0; }();
+        const int sch = (g_gemm_wide_sched >= 0) ? g_gemm_wide_sched : sch_env;
+        if (((sch >= 1 && sch <= 4) || (sch >= 10 && sch <= 12)) && epi != SH_OUT_F32) {
+#define GW_SCH_ATTR(E, S) CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wide_kernel<E, 0, 4, S>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS))
+#define GW_SCH_ATTR4(E) GW_SCH_ATTR(E, 1); GW_SCH_ATTR(E, 2); GW_SCH_ATTR(E, 3); GW_SCH_ATTR(E, 4); GW_SCH_ATTR(E, 10); GW_SCH_ATTR(E, 11); GW_SCH_ATTR(E, 12)
+            static PerDeviceOnce sch_attr;
+            auto set_attrs = [&]() -> int32_t {
+                GW_SCH_ATTR4(SH_OUT_SPLIT); GW_SCH_ATTR4(SH_OUT_SPLIT_GELU); GW_SCH_ATTR4(GW_OUT_LN); GW_SCH_ATTR4(SH_OUT_F32_RESID);
+                return CS_OK;
+            };
+            CS_TRY(sch_attr.run(set_attrs));
+#undef GW_SCH_ATTR4
+#undef GW_SCH_ATTR
+#define GW_LAUNCH_S(E, S) hipLaunchKernelGGL((gemm_wide_kernel<E, 0, 4, S>), dim3(grid), dim3(G::THREADS), G::LDS, s, A, W, bias, resid, C, Cs, M, N, kc, d_flag, slots, ln_g, ln_b, ln_eps, stagger, ln_flags)
+#define GW_LAUNCH_E(E) do { switch (sch) { case 1: GW_LAUNCH_S(E, 1); break; case 2: GW_LAUNCH_S(E, 2); break; case 3: GW_LAUNCH_S(E, 3); break; case 4: GW_LAUNCH_S(E, 4); break; case 10: GW_LAUNCH_S(E, 10); break; case 11: GW_LAUNCH_S(E, 11); break; default: GW_LAUNCH_S(E, 12); break; } } while (0)
+            if (epi == SH_OUT_SPLIT) GW_LAUNCH_E(SH_OUT_SPLIT);
+            else if (epi == SH_OUT_SPLIT_GELU) GW_LAUNCH_E(SH_OUT_SPLIT_GELU);
+            else if (epi == GW_OUT_LN) GW_LAUNCH_E(GW_OUT_LN);
+            else if (epi == SH_OUT_F32_RESID) GW_LAUNCH_E(SH_OUT_F32_RESID);
+            else return fail(CS_ERR_BAD_ARG, "unknown epilogue %d", epi);
+#undef GW_LAUNCH_E
+#undef GW_LAUNCH_S
+            CS_HIP(hipGetLastError());
             return CS_OK;
-        }));
-        if (epi == SH_OUT_SPLIT) GW_LAUNCH(SH_OUT_SPLIT, 11);
-        else GW_LAUNCH(SH_OUT_SPLIT_GELU, 11);
-        CS_HIP(hipGetLastError());
-        return CS_OK;
+        }
     }
     if (epi == SH_OUT_F32) GW_LAUNCH(SH_OUT_F32, 0);
     else if (epi == SH_OUT_F32_RESID) GW_LAUNCH(SH_OUT_F32_RESID, 0);
@@ -630,7 +729,7 @@ static int32_t gemm_wide_impl(int epi, const _Float16* A, const _Float16* W, con
     if (!gemm_wide_supported(N, K)) return fail(CS_ERR_UNSUPPORTED, "wide split GEMM needs N %% 192 == 0 and K %% 32 == 0 (N=%u K=%u)", N, K);
     if (M == 0) return CS_OK;
     static const int shape_env = [] { const char* e = std::getenv("CS_GEMM_WIDE_SHAPE"); return e ? std::atoi(e) : 384; }();
-    const bool big = epi == GW_OUT_LN || g_gemm_wide_ablation || ((shape ? shape : shape_env) == 384 && N % 384 == 0);
+    const bool big = epi == GW_OUT_LN || g_gemm_wide_ablation || ((shape ? shape : g_gemm_wide_shape ? g_gemm_wide_shape : shape_env) == 384 && N % 384 == 0 && N <= (uint32_t)GW_PARAM_FLOATS);
     if (big) return gemm_wide_launch<4>(epi, A, W, bias, resid, C, Cs, M, N, K, d_flag, s, ln_g, ln_b, ln_eps, ln_flags);
     return gemm_wide_launch<2>(epi, A, W, bias, resid, C, Cs, M, N, K, d_flag, s, ln_g, ln_b, ln_eps, ln_flags);
 }

@@ -59,25 +59,33 @@ struct Workspace {
     size_t qw_elems = 0, qw_nq = 0, q8_elems = 0;
     uint32_t* h_overflow = nullptr;
     uint32_t mirror_seen = 0;  // value of h_overflow[3] already accounted for
+    bool last_via_q8 = false;  // the previous filter search on this workspace read the int8 copy (strike bookkeeping)
 
-    int32_t reserve_split_queries(uint32_t nq, uint32_t dim) {
+    // want_q8: the int8 copy is this search's filter operand — its three query planes are allocated only then, and
+    // *q8_ok = false (never an error) when they do not fit: the caller filters on the f16 copy instead
+    int32_t reserve_split_queries(uint32_t nq, uint32_t dim, bool want_q8, bool* q8_ok) {
         const size_t elems = (size_t)nq * dim;
+        *q8_ok = false;
         if (elems > qw_elems) {
             if (qw.d_qsplit) (void)hipFree(qw.d_qsplit);
             qw.d_qsplit = nullptr; qw_elems = 0;
             CS_HIP(hipMalloc(&qw.d_qsplit, elems * sizeof(_Float16)));
             qw_elems = elems;
         }
-        if (elems > q8_elems) {
+        if (want_q8 && elems > q8_elems) {
             if (qw.d_q8q) (void)hipFree(qw.d_q8q);
-            qw.d_q8q = nullptr; q8_elems = 0;
-            CS_HIP(hipMalloc(&qw.d_q8q, elems));
             if (qw.d_q8q_hi) (void)hipFree(qw.d_q8q_hi);
-            qw.d_q8q_hi = qw.d_q8q_lo = nullptr;
-            CS_HIP(hipMalloc(&qw.d_q8q_hi, 2 * elems));
-            qw.d_q8q_lo = qw.d_q8q_hi + elems;
-            q8_elems = elems;
+            qw.d_q8q = qw.d_q8q_hi = qw.d_q8q_lo = nullptr; q8_elems = 0;
+            if (hipMalloc(&qw.d_q8q, elems) != hipSuccess || hipMalloc(&qw.d_q8q_hi, 2 * elems) != hipSuccess) {
+                (void)hipGetLastError();
+                if (qw.d_q8q) (void)hipFree(qw.d_q8q);
+                qw.d_q8q = nullptr;
+            } else {
+                qw.d_q8q_lo = qw.d_q8q_hi + elems;
+                q8_elems = elems;
+            }
         }
+        *q8_ok = want_q8 && elems <= q8_elems;
         if (nq > qw_nq) {
             if (qw.d_qmag) (void)hipFree(qw.d_qmag);
             if (qw.d_qmeta) (void)hipFree(qw.d_qmeta);
@@ -246,9 +254,15 @@ struct cs_index {
     uint32_t* d_dead = nullptr;  // bitmap over rows, sized for `capacity`
     float* d_norms = nullptr;    // |row| for rows [0, normed_rows) (batched-query path)
     uint64_t normed_rows = 0;
-    _Float16* d_split = nullptr;  // unit rows [0, split_rows) as f16 [row][dim]: filter operand of the batched path
-    uint64_t split_rows = 0;
+    // unit rows [0, split_rows) as f16 [row][dim]: the filter operand of the batched path WHEN the int8 copy does not
+    // serve (no int8 copy, retired by its spread or by strikes, <= 1024 rows).  Built on demand (ensure_f16): an index
+    // whose int8 copy serves holds 5 bytes per element (f32 + int8), not 7, and its builds skip the conversion.
+    _Float16* d_split = nullptr;
+    uint64_t split_rows = 0, split_cap = 0;
     bool use_split = false;
+    bool f16_eager = false;    // CS_FILTER_F16_EAGER=1 (or an A/B knob that needs both copies): build it at every cs_index_build
+    bool f16_failed = false;   // no room for it: searches stay on the int8 copy / the exact paths (reset by clear())
+    std::mutex filter_mu;      // guards the on-demand build (searches are re-entrant)
     // int8 filter copy (scan_filter.hip): complete 128-row tiles [0, q8_rows / 128), a quarter of the f32 bytes
     int8_t* d_q8 = nullptr;
     float4* d_tmeta = nullptr;
@@ -270,6 +284,12 @@ struct cs_index {
     float filter_margin = 0.0f;  // scan_filter.hip: bound of the f16 filter's error for this dim
     int filter_min_q = 2;  // query count from which the f16 filter + exact refine path is used
     uint32_t single_filter_min_k = 100;  // ... and one query too from this k on, over >= 2M rows (0 = never)
+    // One query over >= single_filter_min_rows rows: CS_ROUTE_COST (default) takes the filter whenever the int8 copy
+    // serves (same bits, 0.66 vs 2.16 ms over 10M x 384 at k = 10: the filter streams a quarter of the bytes), and from
+    // single_filter_min_k on with the f16 copy; CS_ROUTE_STREAM always runs the f32 streaming scan (the north-star
+    // kernel: bench.py selects it for `value`); CS_ROUTE_FILTER takes the filter whenever a copy can serve.
+    int single_route = CS_ROUTE_COST;
+    uint64_t single_filter_min_rows = 2000000;
     uint64_t single_batched_max_rows = 1024;  // ... and one query over at most this many rows (0 = never; CS_SINGLE_BATCHED_MAX_ROWS)
     // primed streaming scan (scan.hip PRIME mode): from this k and this many rows on, a pass over
     // the first prime_rows rows bounds the list inserts of the full scan
@@ -283,7 +303,8 @@ struct cs_index {
     bool built = false;
     // streams of OTHER devices that carry unfinished appends into this corpus (index_append_from: an encoder replica on
     // another GPU writing its rows over xGMI); hipDeviceSynchronize on this device does not wait for them
-    std::vector<std::pair<int, hipStream_t>> foreign_appends;
+    // (an EVENT recorded on that stream behind the copy, not the stream handle: the caller may destroy its stream)
+    std::vector<std::pair<int, hipEvent_t>> foreign_appends;
 
     std::mutex mu;  // guards the pools below (search is re-entrant)
     std::vector<Workspace*> pool;
@@ -301,11 +322,15 @@ namespace {
 // Appends through cs_index_add_device / index_append_from may still be in flight on caller streams that do not
 // order against the null stream (hipStreamNonBlocking, torch side streams) or that belong to another device.
 int32_t drain_appends(cs_index* h) {
-    for (const auto& fs : h->foreign_appends) {
-        DeviceGuard g(fs.first);
-        CS_HIP(hipStreamSynchronize(fs.second));
+    int32_t st = CS_OK;
+    for (const auto& fe : h->foreign_appends) {
+        DeviceGuard g(fe.first);
+        if (hipEventSynchronize(fe.second) != hipSuccess && st == CS_OK)
+            st = fail(CS_ERR_HIP, "a peer append into the index did not complete: %s", hipGetErrorString(hipGetLastError()));
+        (void)hipEventDestroy(fe.second);
     }
     h->foreign_appends.clear();
+    CS_TRY(st);
     CS_HIP(hipDeviceSynchronize());
     return CS_OK;
 }
@@ -332,46 +357,47 @@ int32_t grow(cs_index* h, uint64_t need_rows) {
         (void)hipFree(nd);
         return fail(CS_ERR_OOM, "hipMalloc(row norms) failed: %s", hipGetErrorString(e));
     }
-    if (h->use_split) {
-        // filter copy of the batched path (half the bytes of the f32 matrix); without room for it the
-        // batched path stays on the exact-f32 MFMA kernels (scan_mfma.hip)
+    if (h->d_split) {
+        // the f16 copy exists (the int8 copy does not serve): it grows with the corpus.  Without room for it, it is
+        // dropped — searches then build it again on demand or stay on the exact paths; the int8 copy below does not
+        // depend on it (whole 128-row tiles, an even number of them: 256-row blocks)
         _Float16* ns = nullptr;
-        // whole 128-row tiles (scan_filter.hip layout), an even number of them (256-row blocks)
         const size_t cap256 = ((size_t)cap + 255) / 256 * 256;
         if (hipMalloc(&ns, cap256 * h->dim * sizeof(_Float16)) != hipSuccess) {
             (void)hipGetLastError();
-            h->use_split = false;
-            if (h->d_split) (void)hipFree(h->d_split);
+            (void)hipFree(h->d_split);
             h->d_split = nullptr;
             h->split_rows = 0;
-            h->q8_rows = 0;
+            h->split_cap = 0;
         } else {
             if (h->split_rows)
                 CS_HIP(hipMemcpy(ns, h->d_split, ((size_t)h->split_rows + 127) / 128 * 128 * h->dim * sizeof(_Float16),
                                  hipMemcpyDeviceToDevice));
-            if (h->d_split) (void)hipFree(h->d_split);
+            (void)hipFree(h->d_split);
             h->d_split = ns;
+            h->split_cap = cap256;
         }
     }
-    if (h->use_split && h->use_q8) {
+    if (h->use_q8) {
         int8_t* n8 = nullptr;
         float4* nm = nullptr;
         const size_t tiles = ((size_t)cap + 255) / 256 * 2;  // an even number: the 256-row tile kernel reads whole pairs
-        if (hipMalloc(&n8, tiles * 128 * h->dim) != hipSuccess || hipMalloc(&nm, tiles * sizeof(float4)) != hipSuccess) {
-            (void)hipGetLastError();  // no room: the filter stays on the f16 copy
+        const bool fault = std::getenv("CS_FAULT_INT8_ALLOC") != nullptr && h->capacity != 0;  // tests: the failure path
+        if (fault || hipMalloc(&n8, tiles * 128 * h->dim) != hipSuccess || hipMalloc(&nm, tiles * sizeof(float4)) != hipSuccess) {
+            (void)hipGetLastError();  // no room: no int8 copy from here on (the f16 copy, or the exact paths, serve)
             if (n8) (void)hipFree(n8);
+            n8 = nullptr; nm = nullptr;
             h->use_q8 = false;
             h->q8_rows = 0;
-        } else {
-            if (h->q8_rows) {
-                CS_HIP(hipMemcpy(n8, h->d_q8, (size_t)h->q8_rows * h->dim, hipMemcpyDeviceToDevice));
-                CS_HIP(hipMemcpy(nm, h->d_tmeta, (size_t)(h->q8_rows / 128) * sizeof(float4), hipMemcpyDeviceToDevice));
-            }
+        } else if (h->q8_rows) {
+            CS_HIP(hipMemcpy(n8, h->d_q8, (size_t)h->q8_rows * h->dim, hipMemcpyDeviceToDevice));
+            CS_HIP(hipMemcpy(nm, h->d_tmeta, (size_t)(h->q8_rows / 128) * sizeof(float4), hipMemcpyDeviceToDevice));
         }
+        // the old, smaller buffers never survive a grow: a build that found them would convert tiles past their end
         if (h->d_q8) (void)hipFree(h->d_q8);
         if (h->d_tmeta) (void)hipFree(h->d_tmeta);
-        h->d_q8 = h->use_q8 ? n8 : nullptr;
-        h->d_tmeta = h->use_q8 ? nm : nullptr;
+        h->d_q8 = n8;
+        h->d_tmeta = nm;
     }
     CS_HIP(hipMemset(nd, 0, words * sizeof(uint32_t)));
     if (h->normed_rows)
@@ -390,6 +416,41 @@ int32_t grow(cs_index* h, uint64_t need_rows) {
     h->d_dead = nd;
     h->capacity = cap;
     return CS_OK;
+}
+
+// the int8 copy is the filter's operand: it exists, was not retired, and reaches past phase 0's 1,024 rows
+bool q8_serves(const cs_index* h) {
+    return h->use_q8 && h->d_q8 && h->d_tmeta && h->q8_active.load() && h->q8_rows > 1024;
+}
+
+// The f16 copy, complete for the rows of the last build — built now if it is not there (allocation + one conversion pass
+// over the missing rows on the null stream, waited for: 7.68 GB and ~4.7 ms per 10M x 384, paid once, by the first
+// search that needs it).  false: no room (remembered until clear()).
+bool ensure_f16(cs_index* h) {
+    if (!h->use_split) return false;
+    std::lock_guard<std::mutex> lk(h->filter_mu);
+    if (h->d_split && h->split_rows >= h->n_rows) return true;
+    if (h->f16_failed || h->normed_rows < h->n_rows) return false;
+    const size_t cap256 = ((size_t)h->capacity + 255) / 256 * 256;
+    if (!h->d_split || h->split_cap < cap256) {
+        if (h->d_split) (void)hipFree(h->d_split);
+        h->d_split = nullptr; h->split_rows = 0; h->split_cap = 0;
+        if (std::getenv("CS_FAULT_F16_ALLOC") != nullptr || hipMalloc(&h->d_split, cap256 * h->dim * sizeof(_Float16)) != hipSuccess) {
+            (void)hipGetLastError();
+            h->d_split = nullptr;
+            h->f16_failed = true;
+            return false;
+        }
+        h->split_cap = cap256;
+    }
+    if (launch_corpus_split(h->d_corpus, h->d_norms, h->d_split, h->split_rows, h->n_rows - h->split_rows, h->dim, nullptr) != CS_OK ||
+        hipStreamSynchronize(nullptr) != hipSuccess) {
+        (void)hipGetLastError();
+        h->f16_failed = true;
+        return false;
+    }
+    h->split_rows = h->n_rows;
+    return true;
 }
 
 int32_t check_append(cs_index* h, uint64_t n, uint32_t dim) {
@@ -467,7 +528,6 @@ int32_t run_search(cs_index* h, Workspace* w, const ScanPlan& plan, const float*
     const bool timed = take_events(h, w, &ev);
     if (timed) CS_HIP(hipEventRecord(ev.e0, stream));
     // >= 5 queries: MFMA scoring + phased candidate selection (scan_mfma.hip)
-    const bool split_ready = h->use_split && h->split_rows >= h->n_rows;
     // One query normally stays on the exact f32 streaming scan (the north-star kernel).  With a long list over a
     // multi-million-row index — the reference's own retrieval_limit (100 or 200) when a search has no query variants —
     // the filter + refine path is taken instead: same bits, 1.40 vs 2.36 ms at k = 200 over 10M x 384, because
@@ -476,41 +536,54 @@ int32_t run_search(cs_index* h, Workspace* w, const ScanPlan& plan, const float*
     // every row, select: three small launches, no filter involved below a candidate buffer's worth of rows — answers one
     // query faster than the streaming scan's per-wave lists do (592 rows: 30 vs 41 us; 1,000: 33 vs 46; from 2,000
     // rows on the scan is ahead: 43 vs 48 us).
-    const bool wants_filter = (int)nq >= h->filter_min_q ||
-                              (nq == 1 && h->single_filter_min_k && k >= h->single_filter_min_k && h->n_rows >= 2000000) ||
+    const bool single_filter =
+        nq == 1 && h->single_route != CS_ROUTE_STREAM &&
+        (h->single_route == CS_ROUTE_FILTER ||
+         (h->n_rows >= h->single_filter_min_rows &&
+          (q8_serves(h) || (h->single_filter_min_k && k >= h->single_filter_min_k))));
+    const bool wants_filter = (int)nq >= h->filter_min_q || single_filter ||
                               (nq == 1 && h->n_rows <= h->single_batched_max_rows);
-    const bool filter_path = split_ready && wants_filter && h->n_rows > 0 && h->normed_rows >= h->n_rows;
+    const bool normed = h->n_rows > 0 && h->normed_rows >= h->n_rows;
+    // Which copy filters: the int8 one when it serves; else the f16 one, built here, once, if it is not there yet; with
+    // neither (no room) the search takes the exact paths below.
+    bool via_q8 = false, use_filter = false;
+    if (h->use_split && wants_filter && normed) {
+        CS_TRY(w->reserve_batched(nq, k));
+        // overflowed searches the device has reported since this workspace last looked: a strike against the int8 copy
+        // only when the search that overflowed read it (the exact-f32 batched path and the f16 filter share the word).
+        // A strike can retire the copy: the choice is made after it.
+        if (w->bs.h_mirror) {
+            const uint32_t seen = *reinterpret_cast<volatile uint32_t*>(w->bs.h_mirror);
+            if (seen != w->mirror_seen) {
+                w->mirror_seen = seen;
+                if (w->last_via_q8 && h->q8_active.load()) h->q8_strike();
+            }
+        }
+        via_q8 = q8_serves(h);
+        bool planes = false;
+        CS_TRY(w->reserve_split_queries(nq, h->dim, via_q8, &planes));
+        if (via_q8 && !planes) via_q8 = false;  // no room for the int8 query planes
+        use_filter = via_q8 || ensure_f16(h);
+    }
+    const bool filter_path = use_filter;
     w->qw.q_pinned = filter_path ? h_queries_pinned : nullptr;
     // A streaming scan of a few blocks (a corpus of the reference's own size: hundreds to thousands of chunks) reads
     // the queries straight from the pinned buffer too: a copy launch costs more than <= 64 blocks' reads over the link.
-    const bool streaming = !filter_path && !(h->n_rows > 0 && h->normed_rows >= h->n_rows &&
-                                             ((split_ready && wants_filter) || (nq >= 5 && batched_supported(h->dim))));
+    const bool streaming = !filter_path && !(normed && nq >= 5 && batched_supported(h->dim));
     if (h_queries_pinned && streaming && scan_prime_supported(h->dim) /* queries go to registers once */ &&
         (uint64_t)plan.blocks * plan.passes <= 64)
         d_queries = h_queries_pinned;
     else if (h_queries_pinned && !filter_path)
         CS_HIP(hipMemcpyAsync(const_cast<float*>(d_queries), h_queries_pinned, (size_t)nq * h->dim * sizeof(float),
                               hipMemcpyHostToDevice, stream));
-    // Two or more queries: the f16 filter reads half the bytes of the f32 scan once for up to 128
-    // queries (1.85 ms vs 2.5 ms for two passes-in-one of the streaming scan over 10M x 384) and
-    // the refine step keeps the result bit-identical.  One query stays on the streaming f32 scan
-    // (the north-star kernel).  Without the filter copy, >= 5 queries use the exact-f32 MFMA path.
-    const bool use_filter = split_ready && wants_filter;
-    if (h->n_rows > 0 && h->normed_rows >= h->n_rows && (use_filter || (nq >= 5 && batched_supported(h->dim)))) {
+    // Two or more queries: the filter reads a quarter (int8) or half (f16) of the bytes of the f32 scan once for up to
+    // 128 queries and the refine step keeps the result bit-identical.  One query stays on the streaming f32 scan
+    // (the north-star kernel).  Without a filter copy, >= 5 queries use the exact-f32 MFMA path.
+    if (normed && (use_filter || (nq >= 5 && batched_supported(h->dim)))) {
         CS_TRY(w->reserve_batched(nq, k));
-        bool via_q8 = false;
         if (use_filter) {
-            CS_TRY(w->reserve_split_queries(nq, h->dim));
             Q8View q8;
-            // overflowed searches the device has reported since this workspace last looked: strikes against the int8 copy
-            if (w->bs.h_mirror) {
-                const uint32_t seen = *reinterpret_cast<volatile uint32_t*>(w->bs.h_mirror);
-                if (seen != w->mirror_seen) {
-                    w->mirror_seen = seen;
-                    if (h->q8_active.load()) h->q8_strike();
-                }
-            }
-            via_q8 = h->use_q8 && h->d_q8 && h->q8_active.load();
+            w->last_via_q8 = via_q8;
             if (via_q8) {
                 q8.d_q8 = h->d_q8; q8.d_tmeta = h->d_tmeta; q8.d_mu = h->d_mu; q8.rows = h->q8_rows;
                 h->q8_searches.fetch_add(1);
@@ -519,6 +592,7 @@ int32_t run_search(cs_index* h, Workspace* w, const ScanPlan& plan, const float*
                                      d_queries, nq, k, h->n_removed ? h->d_dead : nullptr, h->id_base, d_keys,
                                      d_cos, d_ids, d_counts, stream, h->filter_margin, &q8));
         } else {
+            w->last_via_q8 = false;
             CS_TRY(launch_scan_batched(w->bs, h->d_corpus, h->d_norms, h->n_rows, h->dim, d_queries, nq, k,
                                        h->n_removed ? h->d_dead : nullptr, h->id_base, h->num_cus, d_keys, d_cos,
                                        d_ids, d_counts, stream));
@@ -555,10 +629,11 @@ int32_t run_search(cs_index* h, Workspace* w, const ScanPlan& plan, const float*
             CS_HIP(hipMemcpyAsync(w->h_overflow, w->bs.d_overflow, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
             CS_HIP(hipStreamSynchronize(stream));
             overflow = *w->h_overflow != 0;
-            if (overflow && via_q8) {
-                // the int8 copy's band let too many rows through: a strike against it, and the f16 copy (band 0.001)
-                // answers this search before the exact list-based scan is asked to
-                h->q8_strike();
+            if (overflow && via_q8) h->q8_strike();  // the int8 copy's band let too many rows through
+            if (overflow && via_q8 && ensure_f16(h)) {
+                // ... and the f16 copy (band 0.001; built now if this is the first time it is needed) answers this search
+                // before the exact list-based scan is asked to
+                w->last_via_q8 = false;
                 CS_TRY(launch_scan_split(w->bs, w->qw, h->d_corpus, h->d_split, h->n_rows, h->dim, d_queries, nq, k,
                                          h->n_removed ? h->d_dead : nullptr, h->id_base, d_keys, d_cos, d_ids, d_counts,
                                          stream, h->filter_margin, nullptr));
@@ -677,12 +752,18 @@ int32_t cs_index_create(uint32_t dim, uint64_t capacity_rows, int32_t device, ui
         h->use_split = split_scan_supported(dim) && !(env && env[0] == '0');
         const char* e8 = std::getenv("CS_FILTER_INT8");  // "0": filter on the f16 copy only
         h->use_q8 = h->use_split && !(e8 && e8[0] == '0');
+        const char* ee = std::getenv("CS_FILTER_F16_EAGER");  // "1": keep the f16 copy beside a serving int8 copy
+        h->f16_eager = (ee && ee[0] == '1') || std::getenv("CS_FILTER_INT8_MAX_Q") != nullptr;
         if (const char* e = std::getenv("CS_FILTER_INT8_MAX_SPREAD")) h->q8_max_spread = (float)std::atof(e);
         if (const char* e = std::getenv("CS_FILTER_MIN_Q")) {
             h->filter_min_q = std::atoi(e);
             if (h->filter_min_q < 1) h->filter_min_q = 1;
         }
-        if (const char* e = std::getenv("CS_FILTER_SINGLE_MIN_K")) h->single_filter_min_k = (uint32_t)std::atol(e);
+        if (const char* e = std::getenv("CS_FILTER_SINGLE_MIN_K")) {  // "0": one query never takes the filter (= CS_ROUTE_STREAM)
+            h->single_filter_min_k = (uint32_t)std::atol(e);
+            if (h->single_filter_min_k == 0) h->single_route = CS_ROUTE_STREAM;
+        }
+        if (const char* e = std::getenv("CS_FILTER_SINGLE_MIN_ROWS")) h->single_filter_min_rows = (uint64_t)std::atoll(e);
         if (const char* e = std::getenv("CS_SINGLE_BATCHED_MAX_ROWS")) h->single_batched_max_rows = (uint64_t)std::atoll(e);
         if (const char* e = std::getenv("CS_SCAN_PRIME_MIN_K")) h->prime_min_k = (uint32_t)std::atol(e);  // 0 = off
         if (const char* e = std::getenv("CS_SCAN_PRIME_MIN_ROWS")) h->prime_min_rows = (uint64_t)std::atoll(e);
@@ -805,12 +886,6 @@ int32_t cs_index_build(cs_index* h) {
         CS_HIP(hipDeviceSynchronize());
         h->normed_rows = h->n_rows;
     }
-    if (h->use_split && h->split_rows < h->n_rows) {
-        CS_TRY(launch_corpus_split(h->d_corpus, h->d_norms, h->d_split, h->split_rows, h->n_rows - h->split_rows, h->dim,
-                                   nullptr));
-        CS_HIP(hipDeviceSynchronize());
-        h->split_rows = h->n_rows;
-    }
     if (h->use_q8 && h->d_q8 && h->q8_rows / 128 < h->n_rows / 128) {  // tiles that became complete
         if (!h->d_mu) CS_HIP(hipMalloc(&h->d_mu, h->dim * sizeof(float)));
         if (h->q8_rows == 0)  // first tiles of this copy: centre it on the mean unit row of what is there now
@@ -837,6 +912,20 @@ int32_t cs_index_build(cs_index* h) {
             }
         }
     }
+    if (h->use_split) {
+        // The f16 copy is kept only where the int8 copy does not serve (none, retired, <= 1024 rows) or on request: an
+        // index the int8 copy serves holds f32 + int8 = 5 bytes per element and its builds skip the conversion pass.
+        // Should the int8 copy be retired later (two overflowed searches), the first search after that builds it.
+        if (h->f16_eager || !q8_serves(h)) {
+            (void)ensure_f16(h);  // no room: not an error — searches take the exact paths
+        } else if (h->d_split) {
+            std::lock_guard<std::mutex> lk(h->filter_mu);
+            (void)hipFree(h->d_split);
+            h->d_split = nullptr;
+            h->split_rows = 0;
+            h->split_cap = 0;
+        }
+    }
     h->built = true;                 // store.rs:428
     return CS_OK;
 }
@@ -850,6 +939,7 @@ int32_t cs_index_clear(cs_index* h) {
     h->n_rows = 0;  // store.rs:701 next_id = 0
     h->normed_rows = 0;
     h->split_rows = 0;
+    h->f16_failed = false;
     h->q8_rows = 0;
     h->q8_active.store(true);
     h->q8_strikes.store(0);
@@ -1054,9 +1144,15 @@ int32_t cs::index_append_from(cs_index* h, const float* d_rows, int src_device, 
     if (src_device == h->device) CS_HIP(hipMemcpyAsync(dst, d_rows, bytes, hipMemcpyDeviceToDevice, stream));
     else {
         CS_HIP(hipMemcpyPeerAsync(dst, h->device, d_rows, src_device, bytes, stream));
-        const auto fs = std::make_pair(src_device, stream);
-        if (std::find(h->foreign_appends.begin(), h->foreign_appends.end(), fs) == h->foreign_appends.end())
-            h->foreign_appends.push_back(fs);
+        hipEvent_t done = nullptr;
+        CS_HIP(hipEventCreateWithFlags(&done, hipEventDisableTiming));
+        if (hipEventRecord(done, stream) != hipSuccess) {
+            (void)hipEventDestroy(done);
+            return fail(CS_ERR_HIP, "hipEventRecord on the peer stream failed");
+        }
+        // one event per source device is enough: a later record on the same stream covers the earlier copies only if
+        // it is the same stream, which the index cannot know — so every append keeps its own event until the next drain
+        h->foreign_appends.emplace_back(src_device, done);
     }
     finish_append(h, n, nullptr);
     return CS_OK;
@@ -1113,6 +1209,14 @@ int32_t cs_index_set_filter_min_queries(cs_index* h, uint32_t min_queries) {
     return CS_OK;
 }
 
+int32_t cs_index_set_single_query_route(cs_index* h, int32_t route) {
+    if (!h) return fail(CS_ERR_BAD_ARG, "null index handle");
+    if (route != CS_ROUTE_COST && route != CS_ROUTE_STREAM && route != CS_ROUTE_FILTER)
+        return fail(CS_ERR_BAD_ARG, "route must be CS_ROUTE_COST, CS_ROUTE_STREAM or CS_ROUTE_FILTER, got %d", route);
+    h->single_route = route;
+    return CS_OK;
+}
+
 int32_t cs_index_debug_counters(cs_index* h, uint64_t* batched_searches, uint64_t* batched_fallbacks) {
     if (!h) return fail(CS_ERR_BAD_ARG, "null index handle");
     DeviceGuard g(h->device);
@@ -1141,11 +1245,22 @@ int32_t cs_index_debug_counters(cs_index* h, uint64_t* batched_searches, uint64_
 int32_t cs_index_filter_state(cs_index* h, int32_t* copy, float* spread, uint64_t* int8_reruns) {
     if (!h) return fail(CS_ERR_BAD_ARG, "null index handle");
     std::lock_guard<std::mutex> lk(h->mu);
-    const bool f16 = h->use_split && h->d_split;
-    const bool i8 = f16 && h->use_q8 && h->d_q8 && h->q8_active.load() && h->q8_rows > 1024;
-    if (copy) *copy = i8 ? 2 : f16 ? 1 : 0;
+    const bool i8 = q8_serves(h);
+    if (copy) *copy = i8 ? 2 : h->use_split ? 1 : 0;
     if (spread) *spread = h->q8_spread;
     if (int8_reruns) *int8_reruns = h->q8_reruns;
+    return CS_OK;
+}
+
+int32_t cs_index_filter_copies(cs_index* h, int32_t* has_int8, int32_t* has_f16, uint64_t* filter_bytes) {
+    if (!h) return fail(CS_ERR_BAD_ARG, "null index handle");
+    std::lock_guard<std::mutex> lk(h->filter_mu);
+    const bool i8 = h->d_q8 && h->q8_rows > 0, f16 = h->d_split && h->split_rows > 0;
+    if (has_int8) *has_int8 = i8 ? 1 : 0;
+    if (has_f16) *has_f16 = f16 ? 1 : 0;
+    if (filter_bytes)
+        *filter_bytes = (h->d_q8 ? ((uint64_t)h->capacity + 255) / 256 * 256 * h->dim : 0) +
+                        (h->d_split ? (uint64_t)h->split_cap * h->dim * 2 : 0);
     return CS_OK;
 }
 

@@ -241,6 +241,7 @@ class VectorStore {
     cs_index* handle() const { return h_; }
     // searches of >= n queries take the f16 filter + exact f32 refine path (default 2; 1 = always)
     void set_filter_min_queries(uint32_t n) { if (h_) check(cs_index_set_filter_min_queries(h_, n)); }
+    void set_single_query_route(int32_t route) { if (h_) check(cs_index_set_single_query_route(h_, route)); }
 
   private:
     cs_index* h_ = nullptr;

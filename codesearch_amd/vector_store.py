@@ -557,6 +557,17 @@ class VectorStore:
         """Searches of >= n queries use the f16 filter + exact refine path (default 2; 1 = always)."""
         _lib.check(self._lib.cs_index_set_filter_min_queries(self._h, int(n)))
 
+    ROUTE_COST, ROUTE_STREAM, ROUTE_FILTER = 0, 1, 2
+
+    def set_single_query_route(self, route: int) -> None:
+        """How one query over a large index is answered (cs_index_set_single_query_route): ROUTE_COST (default: the int8
+        filter + exact refine over >= 2M rows), ROUTE_STREAM (always the f32 streaming scan), ROUTE_FILTER.  Same bits."""
+        if self.sharded:
+            for g in range(self.n_shards):
+                _lib.check(self._lib.cs_index_set_single_query_route(self.shard_handle(g), int(route)))
+        else:
+            _lib.check(self._lib.cs_index_set_single_query_route(self._h, int(route)))
+
     def debug_counters(self):
         """-> (batched_searches, batched_fallbacks)"""
         a, b = C.c_uint64(), C.c_uint64()
@@ -571,6 +582,16 @@ class VectorStore:
         c, sp, n = C.c_int32(), C.c_float(), C.c_uint64()
         _lib.check(self._lib.cs_index_filter_state(self._h, C.byref(c), C.byref(sp), C.byref(n)))
         return int(c.value), float(sp.value), int(n.value)
+
+    def filter_copies(self):
+        """-> (has_int8, has_f16, bytes): which filter copies of the corpus exist in HBM right now and what they occupy
+        (cs_index_filter_copies).  An index whose int8 copy serves holds no f16 copy: it is built by the first search
+        that needs it (the int8 copy retired) or at a build whose int8 copy does not serve."""
+        if self.sharded:
+            raise ValueError("filter_copies is per index: use shard_handle()")
+        a, b, n = C.c_int32(), C.c_int32(), C.c_uint64()
+        _lib.check(self._lib.cs_index_filter_copies(self._h, C.byref(a), C.byref(b), C.byref(n)))
+        return bool(a.value), bool(b.value), int(n.value)
 
     @property
     def handle(self):

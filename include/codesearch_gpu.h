@@ -264,6 +264,17 @@ int32_t cs_index_profile_read(cs_index* h, double* scan_ms, uint64_t* scan_launc
  * candidates: results bit-identical to the streaming f32 scan).  Default 2 (CS_FILTER_MIN_Q); 1
  * routes single queries through it too (1.45 ms instead of 2.26 ms over 10M x 384). */
 int32_t cs_index_set_filter_min_queries(cs_index* h, uint32_t min_queries);
+/* How ONE query is answered over a large index.  The reference's commonest searches are exactly that shape: MCP
+ * (src/mcp/mod.rs:252: one query, k = limit * 3) and the HTTP handler (src/server/mod.rs:547: k = 25).  Every route
+ * returns the same bits (exact f32 re-score of the filter's candidates; tests/test_gpu_scan.py).
+ *   CS_ROUTE_COST   (default) over >= 2,000,000 rows (CS_FILTER_SINGLE_MIN_ROWS) the filter + refine path whenever the
+ *                   int8 copy serves (it streams 1 byte per element instead of 4: 0.66 vs 2.16 ms over 10M x 384 at
+ *                   k = 10), and from k = 100 on (CS_FILTER_SINGLE_MIN_K) when only the f16 copy does; else the scan;
+ *   CS_ROUTE_STREAM always the f32 streaming scan (scan.hip — the kernel BASELINE.json's roofline target is quoted
+ *                   on; bench.py selects it for `value`);  CS_FILTER_SINGLE_MIN_K=0 makes it a handle's default;
+ *   CS_ROUTE_FILTER the filter path whenever a filter copy can serve, whatever the row count. */
+enum { CS_ROUTE_COST = 0, CS_ROUTE_STREAM = 1, CS_ROUTE_FILTER = 2 };
+int32_t cs_index_set_single_query_route(cs_index* h, int32_t route);
 int32_t cs_index_debug_counters(cs_index* h, uint64_t* batched_searches,
                                 uint64_t* batched_fallbacks);
 /* Diagnostics: which copy of the corpus feeds the filter of batched searches right now — 0 none (no filter copy:
@@ -274,6 +285,13 @@ int32_t cs_index_debug_counters(cs_index* h, uint64_t* batched_searches,
  * through it have overflowed and they are more than one in sixteen of its searches).
  * Results are exact and bit-identical whichever copy filters. */
 int32_t cs_index_filter_state(cs_index* h, int32_t* copy, float* spread, uint64_t* int8_reruns);
+/* Which filter copies exist in HBM right now, and the bytes they occupy.  The int8 copy (1 byte per element) is kept by
+ * every index of a supported width; the f16 copy (2 bytes per element) only where the int8 copy does not serve — no int8
+ * copy (CS_FILTER_INT8=0, no room), retired at a build by its spread or later by two overflowed searches, or at most
+ * 1,024 rows — and is then built by cs_index_build, or by the first search after a retirement (that one search waits
+ * ~5 ms per 10M x 384 for the conversion; if there is no room for it the search takes the exact paths, no error).
+ * CS_FILTER_F16_EAGER=1 keeps both at every build (round 3's behaviour: 7 bytes per element instead of 5). */
+int32_t cs_index_filter_copies(cs_index* h, int32_t* has_int8, int32_t* has_f16, uint64_t* filter_bytes);
 
 /* Score mapping.  store.rs:477-478: score = 1 - distance, distance = arroy 0.5.0
  * Cosine = (1 - cos) / 2  (third-party). */
@@ -534,18 +552,6 @@ int32_t cs_debug_gemm(int32_t device, int32_t mode, int32_t epilogue, const floa
  * ablation (mode 2, epilogue 4): 0 none, 1 no LDS-DMA, 2 no MFMA, 3 DMAs issued at the start of a k-step. */
 int32_t cs_debug_gemm_time(int32_t device, int32_t mode, int32_t epilogue, uint32_t M, uint32_t N, uint32_t K,
                            uint32_t iters, int32_t ablation, double* ms_per_launch);
-
-/* Diagnostics: the encoder's feed-forward block (E5 + E6) of a 384-d model on host buffers,
- * out[M, 384] = LayerNorm(GELU(A W1^T + b1) W2^T + b2 + A) * gamma + beta with A [M, 384], W1 [I, 384], W2 [384, I].
- * fused = 1: ONE persistent kernel per 128 rows whose [M, I] intermediate never leaves the CU (ffn_fused.hip);
- * fused = 0: the two kernels it replaces.  For unit parity tests against float64. */
-int32_t cs_debug_ffn(int32_t device, int32_t fused, const float* A, const float* W1, const float* b1, const float* W2,
-                     const float* b2, const float* gamma, const float* beta, float eps, float* out, uint32_t M,
-                     uint32_t intermediate, uint32_t* range_flag);
-/* ... and its device milliseconds per launch on synthetic operands (ablation, fused only: 0 none, 1 no GELU
- * arithmetic, 2 no LDS-DMA after a tile's first stage). */
-int32_t cs_debug_ffn_time(int32_t device, int32_t fused, uint32_t M, uint32_t intermediate, uint32_t iters,
-                          int32_t ablation, double* ms_per_launch);
 
 #ifdef __cplusplus
 }

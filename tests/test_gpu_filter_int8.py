@@ -279,6 +279,7 @@ def test_outlier_coordinates_retire_the_int8_copy_at_build(VS, monkeypatch):
     st.build_index()
     copy, spread, reruns = st.filter_state()
     assert copy == 1 and spread > 7.0, (copy, spread)
+    assert st.filter_copies()[1]          # the build found the int8 copy unfit and made the f16 one
     qs = rng.normal(size=(nq, dim)).astype(np.float32)
     qs[:, [7, 100, 333]] *= np.float32(8.0)
     qs[0] = x[999]
@@ -289,6 +290,8 @@ def test_outlier_coordinates_retire_the_int8_copy_at_build(VS, monkeypatch):
     iso.build_index()
     copy, spread, _ = iso.filter_state()
     assert copy == 2 and 2.5 < spread < 5.5, (copy, spread)
+    has8, has16, nbytes = iso.filter_copies()   # the int8 copy serves: no f16 copy is built (5 bytes per element, not 7)
+    assert has8 and not has16 and nbytes < 50_000 * dim * 2, (has8, has16, nbytes)
 
 
 def test_two_overflows_through_the_int8_copy_retire_it(VS, oracle, monkeypatch):
@@ -311,7 +314,7 @@ def test_two_overflows_through_the_int8_copy_retire_it(VS, oracle, monkeypatch):
     st = VS(None, dim)
     st.insert_embeddings(corpus)
     st.build_index()
-    assert st.filter_state()[0] == 2
+    assert st.filter_state()[0] == 2 and st.filter_copies()[:2] == (True, False)
     qs = synth_rows(43, 0, nq, dim).copy()
     qs[0] = base
     for round_ in range(3):
@@ -325,3 +328,41 @@ def test_two_overflows_through_the_int8_copy_retire_it(VS, oracle, monkeypatch):
     copy, _, reruns = st.filter_state()
     assert copy == 1 and reruns == 2, (copy, reruns)   # strikes 2 of 3 searches: more than one in sixteen
     assert st.debug_counters()[1] == 0   # the f16 copy coped every time: no list-based rerun
+    assert st.filter_copies()[1]         # ... built by the first search that overflowed
+
+
+def test_filter_copy_allocation_failures_fall_back_without_corruption(VS, monkeypatch):
+    """ADVICE r3 (index.hip grow): when a filter copy cannot be (re)allocated while the corpus grows, the stale smaller
+    buffer must not survive.  CS_FAULT_INT8_ALLOC makes the int8 reallocation of a grow fail: the index drops the int8
+    copy, the next build makes the f16 one, answers stay bit-identical to the single-query scans.  With the f16 allocation
+    failing too (CS_FAULT_F16_ALLOC) searches take the exact paths — still the same bits, no error."""
+    monkeypatch.setenv("CS_FILTER_SINGLE_MIN_K", "0")
+    dim, nq, k = 384, 6, 10
+    st = VS(None, dim)
+    st.insert_synthetic(3_000, 9, 0)
+    st.build_index()
+    assert st.filter_state()[0] == 2 and st.filter_copies()[:2] == (True, False)
+    monkeypatch.setenv("CS_FAULT_INT8_ALLOC", "1")
+    st.insert_synthetic(120_000, 9, 3_000)            # grows past the first capacity: the int8 reallocation "fails"
+    monkeypatch.delenv("CS_FAULT_INT8_ALLOC")
+    st.build_index()
+    assert st.filter_state()[0] == 1 and st.filter_copies()[:2] == (False, True)
+    qs = synth_rows(10, 0, nq, dim).copy()
+    qs[0] = synth_rows(9, 100_000, 1, dim)[0]
+    cos, ids, _ = _same_as_single_query_scans(st, qs, k)
+    assert ids[0][0] == 100_000
+    # neither copy: a fresh index whose int8 copy is switched off and whose f16 copy cannot be allocated
+    monkeypatch.setenv("CS_FILTER_INT8", "0")
+    monkeypatch.setenv("CS_FAULT_F16_ALLOC", "1")
+    bare = VS(None, dim)
+    bare.insert_synthetic(50_000, 9, 0)
+    bare.build_index()
+    assert bare.filter_copies()[:2] == (False, False)
+    qs[1] = synth_rows(9, 40_000, 1, dim)[0]
+    # (the exact-f32 MFMA path sums in another order than the streaming scan: same ids, cosines to an ulp or two)
+    cos, ids, counts = bare.search_raw(qs, k)
+    assert ids[1][0] == 40_000
+    for i in range(nq):
+        c1, i1, _ = bare.search_raw(qs[i], k)
+        assert ids[i].tolist() == i1[0].tolist(), i
+        np.testing.assert_allclose(cos[i], c1[0], atol=1e-6)

@@ -211,74 +211,3 @@ def test_encoder_split_vs_f32_mode_and_fallback(gpu_lib, oracle):
     np.testing.assert_allclose(ec, refc, atol=2e-5)
     s, f, fb = c.debug_counters()
     assert fb == 1 and f == 1 and s == 1
-
-
-def run_ffn(lib, fused, A, W1, b1, W2, b2, gamma, beta, eps=1e-12):
-    from codesearch_amd import _lib
-
-    M, I = A.shape[0], W1.shape[0]
-    out = np.empty((M, 384), np.float32)
-    flag = C.c_uint32(0)
-    p = lambda a: a.ctypes.data_as(_lib.f32p)
-    _lib.check(lib.cs_debug_ffn(0, fused, p(A), p(W1), p(b1), p(W2), p(b2), p(gamma), p(beta), eps, p(out), M, I,
-                                C.byref(flag)))
-    return out, int(flag.value)
-
-
-@pytest.mark.parametrize("M,I", [(1, 128), (130, 256), (1000, 1536), (128 * 300 + 5, 384), (4096, 1536)])
-def test_fused_ffn_matches_float64_and_the_two_kernel_path(gpu_lib, M, I):
-    """ffn_fused.hip: X_out = LayerNorm(GELU(X W1^T + b1) W2^T + b2 + X) gamma + beta in one persistent kernel per 128
-    rows (the intermediate lives in LDS) against float64 numpy and against the two wide kernels it replaces.
-    Shapes: one row, a ragged tile, the BGE-small FFN, more tiles than persistent blocks, whole tiles."""
-    H = 384
-    rng = np.random.default_rng(M * 3 + I)
-    A = rng.standard_normal((M, H)).astype(np.float32)
-    W1 = (rng.standard_normal((I, H)) * 0.05).astype(np.float32)
-    b1 = (rng.standard_normal(I) * 0.1).astype(np.float32)
-    W2 = (rng.standard_normal((H, I)) * 0.05).astype(np.float32)
-    b2 = (rng.standard_normal(H) * 0.1).astype(np.float32)
-    gamma = (1.0 + 0.1 * rng.standard_normal(H)).astype(np.float32)
-    beta = (0.1 * rng.standard_normal(H)).astype(np.float32)
-    got, flag = run_ffn(gpu_lib, 1, A, W1, b1, W2, b2, gamma, beta)
-    assert flag == 0
-    if I % 384 == 0:  # the wide kernels' tile width
-        two, flag2 = run_ffn(gpu_lib, 0, A, W1, b1, W2, b2, gamma, beta)
-        assert flag2 == 0 and np.abs(got - two).max() < 3e-6, np.abs(got - two).max()
-    rows = np.arange(M) if M <= 1000 else rng.integers(0, M, 200)
-    x = A[rows].astype(np.float64)
-    h = x @ W1.astype(np.float64).T + b1.astype(np.float64)
-    erf = np.vectorize(math.erf)
-    h = 0.5 * h * (1.0 + erf(h / math.sqrt(2.0)))
-    v = h @ W2.astype(np.float64).T + b2.astype(np.float64) + x
-    mu = v.mean(axis=1, keepdims=True)
-    var = ((v - mu) ** 2).mean(axis=1, keepdims=True)
-    ref = (v - mu) / np.sqrt(var + 1e-12) * gamma.astype(np.float64) + beta.astype(np.float64)
-    assert np.abs(got[rows] - ref).max() < 1e-5, np.abs(got[rows] - ref).max()
-
-
-def test_fused_ffn_exact_data_and_range_flag(gpu_lib):
-    """Small integers are exact through both products (catches any fragment / k-order / swizzle slip between the GELU
-    image and the down product: W2 is asymmetric); an intermediate that leaves the f16 range raises the flag."""
-    H, I, M = 384, 256, 200
-    rng = np.random.default_rng(8)
-    A = rng.integers(-2, 3, (M, H)).astype(np.float32)
-    W1 = np.zeros((I, H), np.float32)
-    W1[np.arange(I), (np.arange(I) * 7) % H] = 1.0           # h[m, n] = x[m, 7n mod 384]: ReLU-like after GELU on integers
-    b1 = np.zeros(I, np.float32)
-    W2 = rng.integers(-3, 4, (H, I)).astype(np.float32)
-    W2[:, 0] += np.arange(H, dtype=np.float32) % 5
-    b2 = np.arange(H, dtype=np.float32) % 3
-    gamma, beta = np.ones(H, np.float32), np.zeros(H, np.float32)
-    got, flag = run_ffn(gpu_lib, 1, A, W1, b1, W2, b2, gamma, beta)
-    assert flag == 0
-    x = A.astype(np.float64)
-    h = x @ W1.astype(np.float64).T
-    erf = np.vectorize(math.erf)
-    h = 0.5 * h * (1.0 + erf(h / math.sqrt(2.0)))
-    v = h @ W2.astype(np.float64).T + b2 + x
-    mu = v.mean(axis=1, keepdims=True)
-    ref = (v - mu) / np.sqrt(((v - mu) ** 2).mean(axis=1, keepdims=True) + 1e-12)
-    assert np.abs(got - ref).max() < 2e-6, np.abs(got - ref).max()
-    b1[5] = 9.0e4
-    _, flag = run_ffn(gpu_lib, 1, A, W1, b1, W2, b2, gamma, beta)
-    assert flag == 1

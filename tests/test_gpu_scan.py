@@ -330,8 +330,10 @@ def test_full_size_10m_against_oracle_slices(VS, oracle, monkeypatch, full10m):
     (examples/benchmark_models.rs:155-165 generalised to top-k).
     (a) planted queries: top-1 is the planted row at any size;
     (b) six queries in ONE call (filter + refine path) at k = 10;
-    (c) the HEADLINE path — one query per call, k = 10: the primed one-block streaming f32 scan
-        scan_topk_kernel<3,8,1,true,false> + prime pass — for every query;
+    (c) the HEADLINE path — one query per call, k = 10 (and 25, 75): the primed one-block streaming f32 scan
+        scan_topk_kernel<3,8,1,true,false> + prime pass, selected with CS_ROUTE_STREAM — for every query;
+    (c') the DEFAULT route for the same searches (CS_ROUTE_COST): int8 filter + exact refine, proven by the
+        debug counters, bit-identical to (c) at k = 10 / 25 / 75;
     (d) one query per call at k = 100 and 200 (the reference's retrieval limits, src/search/mod.rs:494-502):
         routed through filter + refine by default, and through the streaming scan on a second store
         created with CS_FILTER_SINGLE_MIN_K=0."""
@@ -350,13 +352,33 @@ def test_full_size_10m_against_oracle_slices(VS, oracle, monkeypatch, full10m):
         ecos, eids = expect[i]
         assert ids[i].tolist() == eids[:k].tolist()
         np.testing.assert_allclose(cos[i], ecos[:k], atol=COS_TOL)
-    for i in range(len(qs)):  # (c): the north-star kernel
+    # (c): the north-star kernel — selected explicitly (CS_ROUTE_STREAM): by default one query over this many rows goes
+    # through the int8 filter (c')
+    st.set_single_query_route(st.ROUTE_STREAM)
+    streamed = {}
+    for i in range(len(qs)):
         c1, i1, n1 = st.search_raw(qs[i], 10)
         assert n1[0] == 10 and i1[0].tolist() == expect[i][1][:10].tolist()
         np.testing.assert_allclose(c1[0], expect[i][0][:10], atol=COS_TOL)
         assert c1[0].tobytes() == cos[i].tobytes()  # and the two paths agree bit for bit
+        streamed[(i, 10)] = (c1[0].copy(), i1[0].copy())
+    for kk in (25, 75):
+        for i in (0, 3, 5):
+            c1, i1, n1 = st.search_raw(qs[i], kk)
+            assert n1[0] == kk and i1[0].tolist() == expect[i][1][:kk].tolist()
+            streamed[(i, kk)] = (c1[0].copy(), i1[0].copy())
     assert st.debug_counters() == (b0 + 1, f0)  # none of those took the batched path
     b = b0 + 1
+    # (c') default routing (CS_ROUTE_COST): the reference's commonest searches — one query, k = 25 (src/server/mod.rs:547)
+    # or limit * 3 (src/mcp/mod.rs:252) — take the int8 filter + exact refine over an index this large: same bits
+    st.set_single_query_route(st.ROUTE_COST)
+    assert st.filter_state()[0] == 2
+    for (i, kk), (sc, si) in sorted(streamed.items()):
+        c1, i1, n1 = st.search_raw(qs[i], kk)
+        b += 1
+        assert n1[0] == kk and i1[0].tolist() == si.tolist(), (i, kk)
+        assert c1[0].tobytes() == sc.tobytes(), (i, kk)
+    assert st.debug_counters() == (b, f0)   # every one of them went through filter + refine, none overflowed
     for kk in (100, 200):  # (d) default routing: filter + refine for one long-list query
         for i in (0, 4, 5):
             c1, i1, n1 = st.search_raw(qs[i], kk)
@@ -389,6 +411,7 @@ def test_config5_per_gpu_workload_1000_queries_over_10m_rows(full10m):
 
     st, dim, q1000, sample = full10m["st"], full10m["dim"], full10m["q1000"], full10m["sample"]
     k = 10
+    st.set_single_query_route(st.ROUTE_STREAM)  # the single-query searches below are the streaming-scan reference
     b0, f0 = st.debug_counters()
     cos, ids, counts = st.search_raw(q1000, k)
     assert st.debug_counters() == (b0 + 1, f0) and (counts == k).all()
@@ -406,6 +429,7 @@ def test_config5_per_gpu_workload_1000_queries_over_10m_rows(full10m):
     assert st.search_status() is False
     kc, ki = key_unpack(keys.cpu().numpy().view(np.uint64))
     assert ki.tolist() == ids.tolist() and kc.tobytes() == cos.tobytes()
+    st.set_single_query_route(st.ROUTE_COST)
 
 
 def test_config1_1m_single_query_against_oracle(VS, oracle):
@@ -487,6 +511,7 @@ def test_mfma_batched_10m_equals_single_query_scans(full10m):
     """BASELINE configs 4/5 shape on one GPU: 64 (and 100) batched queries over 10M rows must
     equal 64 independent single-query scans (which are checked against the oracle above)."""
     st, dim, k, seed = full10m["st"], full10m["dim"], 10, full10m["seed"]
+    st.set_single_query_route(st.ROUTE_STREAM)  # the single-query searches below are the streaming-scan reference
     b0, f0 = st.debug_counters()
     for nq in (64, 100):
         qs = synth_rows(seed + 5, 0, nq, dim)
@@ -497,6 +522,7 @@ def test_mfma_batched_10m_equals_single_query_scans(full10m):
             assert ids[i].tolist() == i1[0].tolist()
             assert cos[i].tobytes() == c1[0].tobytes()  # refine = the single-query arithmetic
     assert st.debug_counters() == (b0 + 2, f0)
+    st.set_single_query_route(st.ROUTE_COST)
 
 
 # ---- batched queries: filter (split-f16 MFMA) + exact refine (scan_split.hip) ---------------------
