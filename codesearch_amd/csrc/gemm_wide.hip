@@ -553,6 +553,208 @@ gemm_wide_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ W,
     }
 }
 
+// ---- the split-store layers (QKV, FFN-up) with the block's waves in two roles ----------------------------------------
+// What the ablations of the kernel above say (profiles/r04_gemm_time_and_ablations.log, QKV shape): with the global
+// stores removed it runs 150 instead of 179 us, although 302 MB in 179 us is a fifth of the write bandwidth.  The stores
+// are not slow, they are WAITED for: every CU reaches its epilogue at the same time, the burst (50 MB per round) takes
+// ~8 us to drain, and `vmcnt` retires in issue order — the first `s_waitcnt vmcnt(0)` that a wave needs for the NEXT
+// tile's LDS-DMAs also waits for its own stores.  Here no wave both loads and stores:
+//   * waves 0-3 (one per SIMD) issue ALL the LDS-DMAs (16 per k-step each) and never store: their vmcnt holds DMAs only;
+//   * waves 4-7 issue no DMA and store EVERYTHING — their SIMD partner's strip too, through the LDS patches the
+//     epilogue already uses for its transposition — and never wait on vmcnt: a block barrier (after the loaders' wait)
+//     publishes a stage to them.  Their stores drain under the next tile's MFMAs.
+// Same tiles, fragments, MFMA order, conversions and therefore the same bits as gemm_wide_kernel<SH_OUT_SPLIT[_GELU]>.
+template <bool VM>
+__device__ __forceinline__ void gw_barrier() {
+    // raw barrier (no fence: __syncthreads() would emit vmcnt(0) for every wave); LDS traffic of this wave has retired
+    if (VM) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+template <int EPI>
+__global__ void __launch_bounds__(512, 2)
+gemm_wide_roles_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ W, const float* __restrict__ bias,
+                       _Float16* __restrict__ Cs, uint32_t M, uint32_t N, uint32_t kchunks, uint32_t* __restrict__ flag,
+                       uint32_t total_slots) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    using G = GwGeom<4>;
+    static_assert(EPI == SH_OUT_SPLIT || EPI == SH_OUT_SPLIT_GELU, "split-store epilogues only");
+    constexpr int GW_BN = G::BN, GW_STAGE = G::STAGE;
+    constexpr int LA = 4, LW = 12, LP = LA + LW;  // a loader wave's LDS-DMA pieces of a stage: 4 of A, 12 of W
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave / 4, wc = wave % 4;
+    const bool loader = wave < 4;
+    const int l15 = lane & 15, g = lane >> 4;
+    const uint32_t mtiles = (M + GW_BM - 1) / GW_BM, ntiles = N / GW_BN;
+
+    const int drow = lane >> 3;
+    auto src_of = [&](uint32_t row_in_tile, uint32_t grow) {
+        const int c = (lane & 7) ^ ((row_in_tile >> 1) & 7);
+        return grow * kchunks * 64 + c * 8;
+    };
+    uint32_t sa[LA], sw[LW];  // element offsets of this loader wave's pieces (unused by waves 4-7)
+    auto tile_src = [&](uint32_t m0, uint32_t n0) {
+        const int lw = wave & 3;
+#pragma unroll
+        for (int p = 0; p < LA; ++p) {
+            const uint32_t r = (lw * LA + p) * 8 + drow;
+            sa[p] = src_of(r, (m0 + r < M) ? m0 + r : M - 1);
+        }
+#pragma unroll
+        for (int p = 0; p < LW; ++p) {
+            const uint32_t r = (lw * LW + p) * 8 + drow;
+            sw[p] = src_of(r, n0 + r);
+        }
+    };
+    auto dma = [&](int p, uint32_t kc, uint32_t bufoff) {
+        const int lw = wave & 3;
+        if (p < LA) sh_glds16(A + (sa[p < LA ? p : 0] + kc * 64), lds + bufoff + (lw * LA + p) * 1024);
+        else sh_glds16(W + (sw[p >= LA ? p - LA : 0] + kc * 64), lds + bufoff + GW_A_BYTES + (lw * LW + (p - LA)) * 1024);
+    };
+
+    const int swz = (l15 >> 1) & 7;
+    const uint32_t a_off = (wr * 64 + l15) * 128, w_off = GW_A_BYTES + (wc * 96 + l15) * 128;
+    const uint32_t s_hi = (g ^ swz) * 16, s_lo = ((4 + g) ^ swz) * 16;
+
+    auto next_valid = [&](uint32_t slot, uint32_t& mt, uint32_t& nt) {
+        while (slot < total_slots && !sh_tile_of_block(slot, mtiles, ntiles, mt, nt)) slot += gridDim.x;
+        return slot;
+    };
+    uint32_t mt = 0, nt = 0;
+    uint32_t slot = next_valid(blockIdx.x, mt, nt);
+    if (slot >= total_slots) return;
+    float* const pbias = reinterpret_cast<float*>(lds + 2 * GW_STAGE + GW_STATS);
+    for (uint32_t i = tid; i < N / 4; i += G::THREADS)
+        reinterpret_cast<sh_f32x4*>(pbias)[i] = reinterpret_cast<const sh_f32x4*>(bias)[i];
+    __syncthreads();  // (the only vmcnt wait of waves 4-7)
+    tile_src(mt * GW_BM, nt * GW_BN);
+    uint32_t buf = 0;
+    if (loader) {
+#pragma unroll
+        for (int p = 0; p < LP; ++p) dma(p, sh_kc_rot(nt, ntiles, kchunks), 0);
+    }
+    uint32_t mx = 0;
+    while (slot < total_slots) {
+        const uint32_t m0 = mt * GW_BM, n0 = nt * GW_BN;
+        const uint32_t rot = sh_kc_rot(nt, ntiles, kchunks);
+        GwAcc acc;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const sh_f32x4 bv = *reinterpret_cast<const sh_f32x4*>(pbias + n0 + wc * 96 + 16 * j + 4 * g) * kShLoScale;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc.c[i][j] = bv;
+        }
+        auto kloop = [&](auto role_c) __attribute__((always_inline)) {
+            constexpr bool LOADER = decltype(role_c)::value;
+            gw_barrier<LOADER>();  // stage 0 has landed (the loaders waited for their DMAs before arriving)
+            for (uint32_t kc = 0; kc < kchunks; ++kc) {
+                const char* cur = lds + ((buf + kc) & 1) * GW_STAGE;
+                const uint32_t nb = ((buf + kc + 1) & 1) * GW_STAGE;
+                const bool more = kc + 1 < kchunks;
+                uint32_t kn = rot + kc + 1;
+                kn = kn >= kchunks ? kn - kchunks : kn;
+                f16x8 ah[4], al[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    ah[i] = *reinterpret_cast<const f16x8*>(cur + a_off + i * 2048 + s_hi);
+                    al[i] = *reinterpret_cast<const f16x8*>(cur + a_off + i * 2048 + s_lo);
+                }
+                f16x8 wh = *reinterpret_cast<const f16x8*>(cur + w_off + s_hi);
+                f16x8 wl = *reinterpret_cast<const f16x8*>(cur + w_off + s_lo);
+#pragma unroll
+                for (int j = 0; j < 6; ++j) {
+                    f16x8 whn = wh, wln = wl;
+                    if (j < 5) {
+                        whn = *reinterpret_cast<const f16x8*>(cur + w_off + (j + 1) * 2048 + s_hi);
+                        wln = *reinterpret_cast<const f16x8*>(cur + w_off + (j + 1) * 2048 + s_lo);
+                    }
+                    const f16x8 whs = wh * (_Float16)2048.0f;  // exact: |w_hi| < 32 (sh_weights_fit_wide)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc.c[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(whs, ah[i], acc.c[i][j], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (LOADER && more && 3 * j < LP) dma(3 * j, kn, nb);  // one piece after every group of four MFMAs
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc.c[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, ah[i], acc.c[i][j], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (LOADER && more && 3 * j + 1 < LP) dma(3 * j + 1, kn, nb);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc.c[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, al[i], acc.c[i][j], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (LOADER && more && 3 * j + 2 < LP) dma(3 * j + 2, kn, nb);
+                    __builtin_amdgcn_sched_barrier(0);
+                    wh = whn;
+                    wl = wln;
+                }
+                gw_barrier<LOADER>();  // stage kc+1 has landed; every wave is done reading stage kc
+            }
+        };
+        if (loader) kloop(std::integral_constant<bool, true>{});
+        else kloop(std::integral_constant<bool, false>{});
+
+        const uint32_t ebuf = (buf + kchunks - 1) & 1;  // buffer of the last stage: the patches live there
+        uint32_t nmt = 0, nnt = 0;
+        const uint32_t nslot = next_valid(slot + gridDim.x, nmt, nnt);
+        if (nslot < total_slots) {
+            tile_src(nmt * GW_BM, nnt * GW_BN);
+            if (loader) {
+#pragma unroll
+                for (int p = 0; p < LP; ++p) dma(p, sh_kc_rot(nnt, ntiles, kchunks), (ebuf ^ 1) * GW_STAGE);
+            }
+        }
+
+        // ---- epilogue: every wave converts its strip into its LDS patch (gemm_wide_kernel's [16 rows][100 floats]); the
+        // storing wave of the SIMD pair (wr = 1) reads both patches of its column group back in line order and stores
+        const bool full = m0 + GW_BM <= M;
+        constexpr int PS = 100;
+        float* patch = reinterpret_cast<float*>(lds + ebuf * GW_STAGE + wave * 8192);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                sh_f32x4 v;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    v[r] = acc.c[i][j][r] * kShLoInv;  // the bias is in there (accumulator start)
+                    if (EPI == SH_OUT_SPLIT_GELU) v[r] = gw_gelu(v[r]);
+                }
+                *reinterpret_cast<sh_f32x4*>(patch + l15 * PS + 16 * j + 4 * g) = v;
+            }
+            gw_barrier<false>();  // the patches of strip i are written
+            if (!loader) {
+#pragma unroll
+                for (int sr = 0; sr < 2; ++sr) {
+                    const float* src = reinterpret_cast<const float*>(lds + ebuf * GW_STAGE + (sr * 4 + wc) * 8192);
+#pragma unroll
+                    for (int t = 0; t < 3; ++t) {
+                        const int pidx = lane + 64 * t;
+                        const int prow = pidx / 12, q = pidx - prow * 12;  // row of the strip, 8-column piece of the 96
+                        const sh_f32x4 v0 = *reinterpret_cast<const sh_f32x4*>(src + prow * PS + q * 8);
+                        const sh_f32x4 v1 = *reinterpret_cast<const sh_f32x4*>(src + prow * PS + q * 8 + 4);
+                        const uint32_t m = sr * 64 + 16 * i + prow;
+                        const uint32_t col = n0 + wc * 96 + q * 8;
+                        f16x8 hi, lo;
+                        sh_split8(v0, v1, hi, lo, mx);
+                        if (full || m0 + m < M) {
+                            _Float16* dst = Cs + ((size_t)(m0 + m) * (N / 32) + (col >> 5)) * 64 + (col & 31);
+                            __builtin_nontemporal_store(hi, reinterpret_cast<f16x8*>(dst));
+                            __builtin_nontemporal_store(lo, reinterpret_cast<f16x8*>(dst + 32));
+                        }
+                    }
+                }
+            }
+            gw_barrier<false>();  // ... and read: the next strip may overwrite them
+        }
+        buf = ebuf ^ 1;
+        slot = nslot;
+        mt = nmt;
+        nt = nnt;
+    }
+    if (flag && sh_split_overflowed(mx)) atomicOr(flag, 1u);
+}
+
 // median over blocks of (shader cycles) / (100 MHz reference ticks) of the last ABL 7 launch, in GHz; main_cycles /
 // epi_cycles: wave 0's cycles per tile in the k loop (first barrier to last) and in the epilogue (next tile's first
 // DMAs + conversions + stores), medians over blocks
@@ -675,6 +877,24 @@ static int32_t gemm_wide_launch(int epi, const _Float16* A, const _Float16* W, c
                 case 10: GW_LAUNCH(SH_OUT_SPLIT, 10); break;
                 default: GW_LAUNCH(SH_OUT_SPLIT, 3); break;
             }
+            CS_HIP(hipGetLastError());
+            return CS_OK;
+        }
+    }
+    static const bool roles_env = [] { const char* e = std::getenv("CS_GEMM_WIDE_ROLES"); return e && e[0] == '1'; }();
+    if constexpr (WCN == 4) {
+        if ((roles_env || g_gemm_wide_sched == 20) && !g_gemm_wide_ablation && (epi == SH_OUT_SPLIT || epi == SH_OUT_SPLIT_GELU)) {
+            static PerDeviceOnce roles_attr;
+            auto set_roles = [&]() -> int32_t {
+                CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wide_roles_kernel<SH_OUT_SPLIT>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
+                CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wide_roles_kernel<SH_OUT_SPLIT_GELU>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
+                return CS_OK;
+            };
+            CS_TRY(roles_attr.run(set_roles));
+            if (epi == SH_OUT_SPLIT)
+                hipLaunchKernelGGL(gemm_wide_roles_kernel<SH_OUT_SPLIT>, dim3(grid), dim3(G::THREADS), G::LDS, s, A, W, bias, Cs, M, N, kc, d_flag, slots);
+            else
+                hipLaunchKernelGGL(gemm_wide_roles_kernel<SH_OUT_SPLIT_GELU>, dim3(grid), dim3(G::THREADS), G::LDS, s, A, W, bias, Cs, M, N, kc, d_flag, slots);
             CS_HIP(hipGetLastError());
             return CS_OK;
         }
