@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
-"""A/B of the wide GEMM's DMA issue schedules (gemm_wide.hip gw_dma_slot) on the encoder's four dense-layer shapes:
-schedules interleaved over rounds in ONE process (cdna_hip_programming.md rule 24), median and min per schedule."""
+"""A/B of the wide GEMM's block shapes (128 x 384, one block per CU | 128 x 192, two per CU) on the encoder's dense-layer
+shapes: variants interleaved over rounds in ONE process (cdna_hip_programming.md rule 24), median and min per variant.
+(Round 4 also ran DMA schedules, a store-grace wait, a CU-paired stagger and a role-split kernel through this script:
+commit "Wide GEMM experiments", logs profiles/r04_gemm_*_ab.log.)"""
 import ctypes as C
 import os
 import statistics
@@ -17,9 +19,8 @@ def main():
     M = int(os.environ.get("M", 65536))
     rounds = int(os.environ.get("ROUNDS", 5))
     iters = int(os.environ.get("ITERS", 30))
-    # codes of cs_debug_gemm_time's `ablation`: 100 + s = DMA schedule s of the 128 x 384 kernel; 1000 + c = the 128 x 192
-    # two-blocks-per-CU shape with the CU's second block c cycles per k-chunk late (1000: no stagger)
-    scheds = [int(x) for x in os.environ.get("CODES", "100,101,102,103,104").split(",")]
+    # codes of cs_debug_gemm_time's `ablation`: 384 / 192 = that block shape of the product kernel
+    scheds = [int(x) for x in os.environ.get("CODES", "384,192").split(",")]
 
     def t(epi, N, K, code):
         ms = C.c_double()

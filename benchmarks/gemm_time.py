@@ -23,7 +23,7 @@ def main():
 
     shapes = [("qkv      (N=1152, K=384,  bias -> split)", 4, 1152, 384), ("ffn_up   (N=1536, K=384,  GELU -> split)", 1, 1536, 384),
               ("out_proj (N=384,  K=384,  + resid f32)", 2, 384, 384), ("ffn_down (N=384,  K=1536, + resid f32)", 2, 384, 1536)]
-    shape = os.environ.get("CS_GEMM_WIDE_SHAPE", "384")
+    shape = os.environ.get("CS_GEMM_WIDE_SHAPE", "384; QKV 192")
     for name, epi, N, K in shapes:
         tf = 3 * 2.0 * M * N * K / 1e12
         a, b = t(1, epi, N, K), t(2, epi, N, K)

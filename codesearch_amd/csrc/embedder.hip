@@ -1220,10 +1220,8 @@ int32_t cs_debug_gemm_time(int32_t device, int32_t mode, int32_t epilogue, uint3
             return launch_gemm_split(epi, sA, sW, dB, dR, dC, sC, M, N, K, dF, nullptr);
         };
         // ablation >= 100: DMA schedule ablation - 100 of the product kernel (gemm_wide.hip gw_dma_slot), any epilogue
-        // ablation >= 1000: the 128 x 192 two-blocks-per-CU shape with the CU's second block (ablation - 1000) cycles per
-        // k-chunk late (pairing by HW_ID)
-        if (mode == 2 && ablation >= 1000) { cs::g_gemm_wide_shape = 192; cs::g_gemm_wide_stagger = ablation - 1000; ablation = 0; }
-        cs::g_gemm_wide_sched = (mode == 2 && ablation >= 100) ? ablation - 100 : -1;
+        // ablation 192 / 384: that block shape of the product kernel, any epilogue
+        cs::g_gemm_wide_shape = (mode == 2 && (ablation == 192 || ablation == 384)) ? ablation : 0;
         cs::g_gemm_wide_ablation = (mode == 2 && epilogue == 4 && ablation < 100) ? ablation : 0;
         for (int i = 0; i < 3; ++i) CS_TRY(once());
         CS_HIP(hipEventRecord(e0, nullptr));
@@ -1244,9 +1242,7 @@ int32_t cs_debug_gemm_time(int32_t device, int32_t mode, int32_t epilogue, uint3
     };
     const int32_t st = run();
     cs::g_gemm_wide_ablation = 0;
-    cs::g_gemm_wide_sched = -1;
     cs::g_gemm_wide_shape = 0;
-    cs::g_gemm_wide_stagger = -1;
     (void)hipDeviceSynchronize();
     for (void* p : {(void*)dA, (void*)dW, (void*)dB, (void*)dR, (void*)dC, (void*)sA, (void*)sW, (void*)sC, (void*)dF})
         if (p) (void)hipFree(p);

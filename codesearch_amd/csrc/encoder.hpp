@@ -78,8 +78,7 @@ int32_t launch_attention_cls(const _Float16* q_cls, const _Float16* kv_split, co
                              uint32_t* flag, uint32_t B, uint32_t L, uint32_t H, uint32_t heads, hipStream_t s);
 int32_t launch_gather_cls(const _Float16* xs, float* x_cls, _Float16* xs_cls, uint32_t B, uint32_t L, uint32_t H, hipStream_t s);
 extern int g_gemm_wide_ablation;  // diagnostics (cs_debug_gemm_time)
-extern int g_gemm_wide_shape, g_gemm_wide_stagger;  // diagnostics: block shape / two-blocks-per-CU stagger overrides
-extern int g_gemm_wide_sched;     // diagnostics: DMA schedule override (gemm_wide.hip gw_dma_slot), -1 = environment
+extern int g_gemm_wide_shape;      // diagnostics: block shape override (192 | 384), 0 = default
 double gemm_wide_read_clock_ghz(double* main_cycles, double* epi_cycles);  // after an ablation-7 launch: median in-kernel clock
 int32_t sh_weights_fit_wide(const _Float16* d_wsplit, uint64_t n_f16, uint32_t* d_scratch_flag, bool* ok, hipStream_t s);
 int32_t launch_synth_params(float* d_out, const cs_bert_config& cfg, uint64_t seed, hipStream_t s);

@@ -61,7 +61,6 @@ struct GwGeom {
     static constexpr int W_PIECES = (BN / 8) / WAVES;            // ... of W: 6
     static constexpr int PIECES = A_PIECES + W_PIECES;           // 8 | 10
 };
-constexpr uint32_t GW_STAGGER_BY_CU = 4u;  // (ln_flags bit) the late block of a CU is found from HW_ID, not from blockIdx
 constexpr uint32_t GW_LN_RESID_SPLIT = 1u, GW_LN_NO_F32 = 2u;  // ln_flags of the LayerNorm epilogue (launch_gemm_wide_ln)
 constexpr int GW_OUT_LN = 16;  // epilogue: + bias + residual, LayerNorm over the 384 columns, store f32 AND split form
 
@@ -101,35 +100,22 @@ struct GwSrc {  // element offsets from A / W (32 bits: a [65536, 1536] operand 
 // reads hoisted out of the k loop (the pure MFMA rate); 6 = 1 without the epilogue's stores.
 // ABL 7: the product kernel plus one (s_memtime, s_memrealtime) pair per block at its first and after its last tile,
 // written to a buffer nothing else reads: the in-kernel clock (MI355X_MICROARCH.md, DVFS give-back item 6).
-__device__ uint32_t g_gw_cu_arrivals[2048];  // per CU: blocks that have started there (stagger pairing)
 __device__ uint64_t g_gw_stamps[8 * 512];  // per block: clk0, real0, clk1, real1, main-loop cycles, epilogue cycles, tiles
 
-// DMA issue schedule of a k-step.  A k-step of a wave is 18 groups of four MFMAs (6 weight fragments x {w_hi * 2^11 . a_hi,
-// w_lo . a_hi, w_hi . a_lo}); "slot s" is the point right after group s (slot -1: before the first group).  All eight waves
-// of the block run the same program between the same barriers, so under SCH 0 they all reach their DMAs at the same
-// slots: the two waves of a SIMD stall in DMA issue together (MI355X_MICROARCH.md, Two waves per SIMD, item 9) and the CU's
-// one address path sees eight 1-KiB requests at once, then none.  SCH >= 1 gives waves 4-7 (the SIMD partners of 0-3)
-// other slots than waves 0-3.
-template <int SCH>
-__device__ constexpr int gw_dma_slot(int half, int p) {
-    // SCH 0: every wave, pieces 2j and 2j+1 after the first and second group of fragment j (the round-2 schedule)
-    if (SCH == 0) return 3 * (p / 2) + (p & 1);
-    // SCH 1: waves 0-3 on even slots 0..14, waves 4-7 on odd slots 1..15
-    if (SCH == 1) return 2 * p + half;
-    // SCH 2: twelve MFMAs, then two DMAs; waves 4-7 open the step with their first two (half a period out of phase)
-    if (SCH == 2) return half == 0 ? 3 * (p / 2) + 2 : 3 * (p / 2) - 1;
-    // SCH 3: one DMA per six MFMAs... waves 0-3 slots 0,1,3,4,6,7,9,10 (as SCH 0), waves 4-7 one group later
-    if (SCH == 3) return 3 * (p / 2) + (p & 1) + half;
-    // SCH 4: as SCH 1 but waves 4-7 lead: odd slots for waves 0-3
-    return 2 * p + (1 - half);
-}
-
-template <int EPI, int ABL = 0, int WCN = 4, int SCH = 0>
+// Round 4 measured, and did not keep, three re-arrangements of WHEN this kernel's memory instructions issue (diagnostic
+// builds of commit "Wide GEMM experiments", logs profiles/r04_gemm_dma_schedule_ab.log, r04_gemm_stagger_by_cu_ab.log,
+// r04_gemm_role_split_ab.log): other DMA slots for waves 4-7 than for their SIMD partners 0-3 (four schedules: 0 ... +5 %),
+// the next tile's first barrier waiting with vmcnt(24) so the epilogue's stores drain under the first k-step (0 %), the
+// two blocks of a CU half a tile out of phase with the pair taken from HW_ID (0 ... +4 %), and loader waves that never
+// store beside storing waves that never wait on vmcnt (+7 %).  The no-DMA ablation already runs as fast as the full
+// kernel; on all-zero operands the same instruction stream is 15-20 % faster (r04_gemm_zero_vs_random.log): the rest
+// is the clock the chip holds under this load, not the schedule.
+template <int EPI, int ABL = 0, int WCN = 4>
 __global__ void __launch_bounds__(GwGeom<WCN>::THREADS, 2)
 gemm_wide_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ W, const float* __restrict__ bias,
                  const float* resid, float* C, _Float16* __restrict__ Cs, uint32_t M, uint32_t N, uint32_t kchunks,
                  uint32_t* __restrict__ flag, uint32_t total_slots, const float* __restrict__ ln_g,
-                 const float* __restrict__ ln_b, float ln_eps, uint32_t stagger_cycles, uint32_t ln_flags) {
+                 const float* __restrict__ ln_b, float ln_eps, uint32_t ln_flags) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     using G = GwGeom<WCN>;
     static_assert(EPI != GW_OUT_LN || WCN == 4, "the LayerNorm epilogue needs whole rows in one block");
@@ -200,34 +186,6 @@ gemm_wide_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ W,
     GwSrc<WCN> src;
     tile_src(mt * GW_BM, nt * GW_BN, src);
     uint32_t buf = 0;  // stage buffer (0 | 1) that holds stage 0 of the current tile
-    constexpr bool GRACE = SCH >= 10 && (EPI == SH_OUT_SPLIT || EPI == SH_OUT_SPLIT_GELU) && ABL == 0;
-    bool prev_full = false;
-    // Stagger (two blocks per CU).  Every tile of a launch costs the same, so the two persistent blocks of a CU stay
-    // in lockstep: both in their main loops, then both in their epilogues — the epilogue's VALU work (GELU + split:
-    // as many cycles as the tile's MFMAs at K = 384) would never meet the other block's MFMAs.  The second half of
-    // the grid (the blocks dispatched onto already occupied CUs) therefore starts half a tile late and stays
-    // half a tile behind.
-    const bool use_prio = (stagger_cycles >> 31) != 0;  // experiment: main loop at wave priority 2, epilogue at 0
-    stagger_cycles &= 0x7fffffffu;
-    bool late = blockIdx.x >= gridDim.x / 2;
-    if (stagger_cycles && WCN == 2 && (ln_flags & GW_STAGGER_BY_CU)) {
-        // which of a CU's two resident blocks am I?  The dispatcher's block -> CU order is not specified (two
-        // consecutive blocks may share a CU), so the pairing is taken from the hardware: (XCC, SE, SH, CU) from the wave's
-        // HW_ID names the CU, and the parity of an arrival count kept per CU (never reset: two blocks arrive per launch)
-        // says whether a partner is already there.
-        if (tid == 0) {
-            const uint32_t hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20);
-            const uint32_t key = ((xcc & 7u) << 8) | (((hw >> 13) & 7u) << 5) | (((hw >> 12) & 1u) << 4) | ((hw >> 8) & 15u);
-            *reinterpret_cast<volatile uint32_t*>(lds) = atomicAdd(&g_gw_cu_arrivals[key], 1u) & 1u;
-        }
-        __syncthreads();
-        late = *reinterpret_cast<volatile uint32_t*>(lds) != 0;
-        __syncthreads();  // the word is overwritten by the first stage
-    }
-    if (stagger_cycles && WCN == 2 && late) {
-        const uint64_t t0 = __builtin_amdgcn_s_memtime();
-        while (__builtin_amdgcn_s_memtime() - t0 < (uint64_t)stagger_cycles) __builtin_amdgcn_s_sleep(16);
-    }
 #pragma unroll
     for (int p = 0; p < NP; ++p) dma(src, p, sh_kc_rot(nt, ntiles, kchunks), 0);
 
@@ -295,20 +253,9 @@ gemm_wide_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ W,
                 for (int i = 0; i < 4; ++i) acc.c[i][j] = bv;
             }
         }
-        // SCH >= 10 ("grace"): this tile's stage-0 DMAs were issued BEFORE the previous tile's epilogue stores; vmcnt retires
-        // in issue order, so waiting until only those 24 stores are outstanding proves stage 0 has landed and lets the
-        // stores drain under the first k-step's MFMAs (the step's own barrier waits for them).  Only after a full tile
-        // (every store instruction issued by every wave) and for the split-store epilogues.
-        if (GRACE && prev_full) {
-            asm volatile("s_waitcnt vmcnt(24) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        } else {
-            __syncthreads();  // stage 0 has landed (vmcnt(0) precedes the barrier)
-        }
-        if (use_prio) __builtin_amdgcn_s_setprio(2);
+        __syncthreads();  // stage 0 has landed (vmcnt(0) precedes the barrier)
 
-        // the k loop, instantiated per SIMD half (waves 0-3 | 4-7) when the schedule differs between them
-        auto kloop = [&](auto half_c) __attribute__((always_inline)) {
-            constexpr int HALF = decltype(half_c)::value;
+        {
             constexpr bool DMA_ON = ABL == 0 || ABL == 2 || ABL >= 7;  // ABL 1, 4, 5, 6: no DMA after a tile's first stage
             for (uint32_t kc = 0; kc < kchunks; ++kc) {
                 const char* cur = lds + ((buf + kc) & 1) * GW_STAGE;
@@ -317,12 +264,6 @@ gemm_wide_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ W,
                 uint32_t kn = rot + kc + 1;
                 kn = kn >= kchunks ? kn - kchunks : kn;
                 if (ABL == 5) cur = lds;  // same addresses every step: the reads hoist out of the loop (pure MFMA rate)
-                auto issue = [&](int slot) __attribute__((always_inline)) {
-                    if (!DMA_ON || !more) return;
-#pragma unroll
-                    for (int p = 0; p < NP; ++p)
-                        if (gw_dma_slot<WCN == 4 ? SCH % 10 : 0>(HALF, p) == slot) dma(src, p, kn, nb);
-                };
                 f16x8 ah[4], al[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
@@ -334,11 +275,6 @@ gemm_wide_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ W,
                 if (ABL == 3 && more) {
 #pragma unroll
                     for (int p = 0; p < NP; ++p) dma(src, p, kn, nb);
-                }
-                if (WCN == 4 && SCH % 10 != 0) {
-                    __builtin_amdgcn_sched_barrier(0);
-                    issue(-1);
-                    __builtin_amdgcn_sched_barrier(0);
                 }
 #pragma unroll
                 for (int j = 0; j < 6; ++j) {
@@ -357,37 +293,25 @@ gemm_wide_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ W,
                     for (int i = 0; i < 4; ++i)
                         if (ABL != 2) acc.c[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(whs, ah[i], acc.c[i][j], 0, 0, 0);
                     __builtin_amdgcn_sched_barrier(0);
-                    issue(3 * j);
+                    if (DMA_ON && more && 2 * j < NP) dma(src, 2 * j, kn, nb);
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
                         if (ABL != 2) acc.c[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, ah[i], acc.c[i][j], 0, 0, 0);
                     __builtin_amdgcn_sched_barrier(0);
-                    issue(3 * j + 1);
+                    if (DMA_ON && more && 2 * j + 1 < NP) dma(src, 2 * j + 1, kn, nb);
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
                         if (ABL != 2) acc.c[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, al[i], acc.c[i][j], 0, 0, 0);
-                    if (WCN == 4 && SCH % 10 != 0) {
-                        __builtin_amdgcn_sched_barrier(0);
-                        issue(3 * j + 2);
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
                     wh = whn;
                     wl = wln;
                 }
                 if (ABL != 4 && ABL != 5) __syncthreads();  // stage kc+1 has landed; every wave is done reading stage kc
             }
-        };
-        if constexpr (WCN == 4 && SCH % 10 != 0) {
-            if (wave < 4) kloop(std::integral_constant<int, 0>{});
-            else kloop(std::integral_constant<int, 1>{});
-        } else {
-            kloop(std::integral_constant<int, 0>{});
         }
         if (ABL == 4 || ABL == 5) __syncthreads();
 
-        if (use_prio) __builtin_amdgcn_s_setprio(0);
         if (ABL == 7) { const uint64_t t = __builtin_amdgcn_s_memtime(); t_main += t - t_mark; t_mark = t; }
         // next tile of this block: its first stage flies into the buffer the epilogue does not use
         const uint32_t ebuf = (buf + kchunks - 1) & 1;  // buffer of the last stage
@@ -536,7 +460,6 @@ gemm_wide_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ W,
         }
         if (flag && sh_split_overflowed(mx)) atomicOr(flag, 1u);
         if (ABL == 7) { const uint64_t t = __builtin_amdgcn_s_memtime(); t_epi += t - t_mark; t_mark = t; ++n_tiles; }
-        prev_full = full;
         buf = ebuf ^ 1;
         slot = nslot;
         mt = nmt;
@@ -551,208 +474,6 @@ gemm_wide_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ W,
         g_gw_stamps[8 * blockIdx.x + 5] = t_epi;
         g_gw_stamps[8 * blockIdx.x + 6] = n_tiles;
     }
-}
-
-// ---- the split-store layers (QKV, FFN-up) with the block's waves in two roles ----------------------------------------
-// What the ablations of the kernel above say (profiles/r04_gemm_time_and_ablations.log, QKV shape): with the global
-// stores removed it runs 150 instead of 179 us, although 302 MB in 179 us is a fifth of the write bandwidth.  The stores
-// are not slow, they are WAITED for: every CU reaches its epilogue at the same time, the burst (50 MB per round) takes
-// ~8 us to drain, and `vmcnt` retires in issue order — the first `s_waitcnt vmcnt(0)` that a wave needs for the NEXT
-// tile's LDS-DMAs also waits for its own stores.  Here no wave both loads and stores:
-//   * waves 0-3 (one per SIMD) issue ALL the LDS-DMAs (16 per k-step each) and never store: their vmcnt holds DMAs only;
-//   * waves 4-7 issue no DMA and store EVERYTHING — their SIMD partner's strip too, through the LDS patches the
-//     epilogue already uses for its transposition — and never wait on vmcnt: a block barrier (after the loaders' wait)
-//     publishes a stage to them.  Their stores drain under the next tile's MFMAs.
-// Same tiles, fragments, MFMA order, conversions and therefore the same bits as gemm_wide_kernel<SH_OUT_SPLIT[_GELU]>.
-template <bool VM>
-__device__ __forceinline__ void gw_barrier() {
-    // raw barrier (no fence: __syncthreads() would emit vmcnt(0) for every wave); LDS traffic of this wave has retired
-    if (VM) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-}
-
-template <int EPI>
-__global__ void __launch_bounds__(512, 2)
-gemm_wide_roles_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ W, const float* __restrict__ bias,
-                       _Float16* __restrict__ Cs, uint32_t M, uint32_t N, uint32_t kchunks, uint32_t* __restrict__ flag,
-                       uint32_t total_slots) {
-    extern __shared__ __attribute__((aligned(16))) char lds[];
-    using G = GwGeom<4>;
-    static_assert(EPI == SH_OUT_SPLIT || EPI == SH_OUT_SPLIT_GELU, "split-store epilogues only");
-    constexpr int GW_BN = G::BN, GW_STAGE = G::STAGE;
-    constexpr int LA = 4, LW = 12, LP = LA + LW;  // a loader wave's LDS-DMA pieces of a stage: 4 of A, 12 of W
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave / 4, wc = wave % 4;
-    const bool loader = wave < 4;
-    const int l15 = lane & 15, g = lane >> 4;
-    const uint32_t mtiles = (M + GW_BM - 1) / GW_BM, ntiles = N / GW_BN;
-
-    const int drow = lane >> 3;
-    auto src_of = [&](uint32_t row_in_tile, uint32_t grow) {
-        const int c = (lane & 7) ^ ((row_in_tile >> 1) & 7);
-        return grow * kchunks * 64 + c * 8;
-    };
-    uint32_t sa[LA], sw[LW];  // element offsets of this loader wave's pieces (unused by waves 4-7)
-    auto tile_src = [&](uint32_t m0, uint32_t n0) {
-        const int lw = wave & 3;
-#pragma unroll
-        for (int p = 0; p < LA; ++p) {
-            const uint32_t r = (lw * LA + p) * 8 + drow;
-            sa[p] = src_of(r, (m0 + r < M) ? m0 + r : M - 1);
-        }
-#pragma unroll
-        for (int p = 0; p < LW; ++p) {
-            const uint32_t r = (lw * LW + p) * 8 + drow;
-            sw[p] = src_of(r, n0 + r);
-        }
-    };
-    auto dma = [&](int p, uint32_t kc, uint32_t bufoff) {
-        const int lw = wave & 3;
-        if (p < LA) sh_glds16(A + (sa[p < LA ? p : 0] + kc * 64), lds + bufoff + (lw * LA + p) * 1024);
-        else sh_glds16(W + (sw[p >= LA ? p - LA : 0] + kc * 64), lds + bufoff + GW_A_BYTES + (lw * LW + (p - LA)) * 1024);
-    };
-
-    const int swz = (l15 >> 1) & 7;
-    const uint32_t a_off = (wr * 64 + l15) * 128, w_off = GW_A_BYTES + (wc * 96 + l15) * 128;
-    const uint32_t s_hi = (g ^ swz) * 16, s_lo = ((4 + g) ^ swz) * 16;
-
-    auto next_valid = [&](uint32_t slot, uint32_t& mt, uint32_t& nt) {
-        while (slot < total_slots && !sh_tile_of_block(slot, mtiles, ntiles, mt, nt)) slot += gridDim.x;
-        return slot;
-    };
-    uint32_t mt = 0, nt = 0;
-    uint32_t slot = next_valid(blockIdx.x, mt, nt);
-    if (slot >= total_slots) return;
-    float* const pbias = reinterpret_cast<float*>(lds + 2 * GW_STAGE + GW_STATS);
-    for (uint32_t i = tid; i < N / 4; i += G::THREADS)
-        reinterpret_cast<sh_f32x4*>(pbias)[i] = reinterpret_cast<const sh_f32x4*>(bias)[i];
-    __syncthreads();  // (the only vmcnt wait of waves 4-7)
-    tile_src(mt * GW_BM, nt * GW_BN);
-    uint32_t buf = 0;
-    if (loader) {
-#pragma unroll
-        for (int p = 0; p < LP; ++p) dma(p, sh_kc_rot(nt, ntiles, kchunks), 0);
-    }
-    uint32_t mx = 0;
-    while (slot < total_slots) {
-        const uint32_t m0 = mt * GW_BM, n0 = nt * GW_BN;
-        const uint32_t rot = sh_kc_rot(nt, ntiles, kchunks);
-        GwAcc acc;
-#pragma unroll
-        for (int j = 0; j < 6; ++j) {
-            const sh_f32x4 bv = *reinterpret_cast<const sh_f32x4*>(pbias + n0 + wc * 96 + 16 * j + 4 * g) * kShLoScale;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) acc.c[i][j] = bv;
-        }
-        auto kloop = [&](auto role_c) __attribute__((always_inline)) {
-            constexpr bool LOADER = decltype(role_c)::value;
-            gw_barrier<LOADER>();  // stage 0 has landed (the loaders waited for their DMAs before arriving)
-            for (uint32_t kc = 0; kc < kchunks; ++kc) {
-                const char* cur = lds + ((buf + kc) & 1) * GW_STAGE;
-                const uint32_t nb = ((buf + kc + 1) & 1) * GW_STAGE;
-                const bool more = kc + 1 < kchunks;
-                uint32_t kn = rot + kc + 1;
-                kn = kn >= kchunks ? kn - kchunks : kn;
-                f16x8 ah[4], al[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    ah[i] = *reinterpret_cast<const f16x8*>(cur + a_off + i * 2048 + s_hi);
-                    al[i] = *reinterpret_cast<const f16x8*>(cur + a_off + i * 2048 + s_lo);
-                }
-                f16x8 wh = *reinterpret_cast<const f16x8*>(cur + w_off + s_hi);
-                f16x8 wl = *reinterpret_cast<const f16x8*>(cur + w_off + s_lo);
-#pragma unroll
-                for (int j = 0; j < 6; ++j) {
-                    f16x8 whn = wh, wln = wl;
-                    if (j < 5) {
-                        whn = *reinterpret_cast<const f16x8*>(cur + w_off + (j + 1) * 2048 + s_hi);
-                        wln = *reinterpret_cast<const f16x8*>(cur + w_off + (j + 1) * 2048 + s_lo);
-                    }
-                    const f16x8 whs = wh * (_Float16)2048.0f;  // exact: |w_hi| < 32 (sh_weights_fit_wide)
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) acc.c[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(whs, ah[i], acc.c[i][j], 0, 0, 0);
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (LOADER && more && 3 * j < LP) dma(3 * j, kn, nb);  // one piece after every group of four MFMAs
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) acc.c[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, ah[i], acc.c[i][j], 0, 0, 0);
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (LOADER && more && 3 * j + 1 < LP) dma(3 * j + 1, kn, nb);
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) acc.c[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, al[i], acc.c[i][j], 0, 0, 0);
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (LOADER && more && 3 * j + 2 < LP) dma(3 * j + 2, kn, nb);
-                    __builtin_amdgcn_sched_barrier(0);
-                    wh = whn;
-                    wl = wln;
-                }
-                gw_barrier<LOADER>();  // stage kc+1 has landed; every wave is done reading stage kc
-            }
-        };
-        if (loader) kloop(std::integral_constant<bool, true>{});
-        else kloop(std::integral_constant<bool, false>{});
-
-        const uint32_t ebuf = (buf + kchunks - 1) & 1;  // buffer of the last stage: the patches live there
-        uint32_t nmt = 0, nnt = 0;
-        const uint32_t nslot = next_valid(slot + gridDim.x, nmt, nnt);
-        if (nslot < total_slots) {
-            tile_src(nmt * GW_BM, nnt * GW_BN);
-            if (loader) {
-#pragma unroll
-                for (int p = 0; p < LP; ++p) dma(p, sh_kc_rot(nnt, ntiles, kchunks), (ebuf ^ 1) * GW_STAGE);
-            }
-        }
-
-        // ---- epilogue: every wave converts its strip into its LDS patch (gemm_wide_kernel's [16 rows][100 floats]); the
-        // storing wave of the SIMD pair (wr = 1) reads both patches of its column group back in line order and stores
-        const bool full = m0 + GW_BM <= M;
-        constexpr int PS = 100;
-        float* patch = reinterpret_cast<float*>(lds + ebuf * GW_STAGE + wave * 8192);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-#pragma unroll
-            for (int j = 0; j < 6; ++j) {
-                sh_f32x4 v;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    v[r] = acc.c[i][j][r] * kShLoInv;  // the bias is in there (accumulator start)
-                    if (EPI == SH_OUT_SPLIT_GELU) v[r] = gw_gelu(v[r]);
-                }
-                *reinterpret_cast<sh_f32x4*>(patch + l15 * PS + 16 * j + 4 * g) = v;
-            }
-            gw_barrier<false>();  // the patches of strip i are written
-            if (!loader) {
-#pragma unroll
-                for (int sr = 0; sr < 2; ++sr) {
-                    const float* src = reinterpret_cast<const float*>(lds + ebuf * GW_STAGE + (sr * 4 + wc) * 8192);
-#pragma unroll
-                    for (int t = 0; t < 3; ++t) {
-                        const int pidx = lane + 64 * t;
-                        const int prow = pidx / 12, q = pidx - prow * 12;  // row of the strip, 8-column piece of the 96
-                        const sh_f32x4 v0 = *reinterpret_cast<const sh_f32x4*>(src + prow * PS + q * 8);
-                        const sh_f32x4 v1 = *reinterpret_cast<const sh_f32x4*>(src + prow * PS + q * 8 + 4);
-                        const uint32_t m = sr * 64 + 16 * i + prow;
-                        const uint32_t col = n0 + wc * 96 + q * 8;
-                        f16x8 hi, lo;
-                        sh_split8(v0, v1, hi, lo, mx);
-                        if (full || m0 + m < M) {
-                            _Float16* dst = Cs + ((size_t)(m0 + m) * (N / 32) + (col >> 5)) * 64 + (col & 31);
-                            __builtin_nontemporal_store(hi, reinterpret_cast<f16x8*>(dst));
-                            __builtin_nontemporal_store(lo, reinterpret_cast<f16x8*>(dst + 32));
-                        }
-                    }
-                }
-            }
-            gw_barrier<false>();  // ... and read: the next strip may overwrite them
-        }
-        buf = ebuf ^ 1;
-        slot = nslot;
-        mt = nmt;
-        nt = nnt;
-    }
-    if (flag && sh_split_overflowed(mx)) atomicOr(flag, 1u);
 }
 
 // median over blocks of (shader cycles) / (100 MHz reference ticks) of the last ABL 7 launch, in GHz; main_cycles /
@@ -805,9 +526,7 @@ int32_t sh_weights_fit_wide(const _Float16* d_wsplit, uint64_t n_f16, uint32_t* 
 bool gemm_wide_supported(uint32_t N, uint32_t K) { return N % 192 == 0 && K % 32 == 0 && N > 0 && K > 0; }
 
 int g_gemm_wide_ablation = 0;  // diagnostics only (cs_debug_gemm_time)
-int g_gemm_wide_sched = -1;    // diagnostics only: >= 0 overrides CS_GEMM_WIDE_SCH
 int g_gemm_wide_shape = 0;     // diagnostics only: 192 / 384 overrides CS_GEMM_WIDE_SHAPE
-int g_gemm_wide_stagger = -1;  // diagnostics only: >= 0 = cycles per k-chunk the late block of a CU waits (pairing by HW_ID)
 
 template <int WCN>
 static int32_t gemm_wide_launch(int epi, const _Float16* A, const _Float16* W, const float* bias, const float* resid, float* C,
@@ -839,16 +558,7 @@ static int32_t gemm_wide_launch(int epi, const _Float16* A, const _Float16* W, c
     const uint32_t resident = (uint32_t)cus * (WCN == 4 ? 1u : 2u);  // persistent grid: every block resident
     const uint32_t grid = slots < resident ? slots : resident;
     const uint32_t kc = K / 32;
-    // half a tile in s_memtime ticks per k-chunk (CS_GEMM_WIDE_STAGGER; default 0 = off: measured 600 / 1200 / 2400 on
-    // all four layer shapes, no gain — see DESIGN.md §3.3); only when blocks run several tiles
-    static const int stagger_env0 = [] { const char* e = std::getenv("CS_GEMM_WIDE_STAGGER"); return e ? std::atoi(e) : 0; }();
-    static const bool stagger_cu_env = [] { const char* e = std::getenv("CS_GEMM_WIDE_STAGGER_BY_CU"); return e && e[0] == '1'; }();
-    const int stagger_env = g_gemm_wide_stagger >= 0 ? g_gemm_wide_stagger : stagger_env0;
-    if (WCN == 2 && stagger_env > 0 && (stagger_cu_env || g_gemm_wide_stagger >= 0)) ln_flags |= GW_STAGGER_BY_CU;
-    static const bool prio_env = [] { const char* e = std::getenv("CS_GEMM_WIDE_PRIO"); return e && e[0] == '1'; }();
-    const uint32_t stagger = ((WCN == 2 && slots >= 2 * grid && grid == resident && stagger_env > 0) ? kc * (uint32_t)stagger_env : 0u) |
-                             (prio_env ? 0x80000000u : 0u);
-#define GW_LAUNCH(E, V) hipLaunchKernelGGL((gemm_wide_kernel<E, V, WCN>), dim3(grid), dim3(G::THREADS), G::LDS, s, A, W, bias, resid, C, Cs, M, N, kc, d_flag, slots, ln_g, ln_b, ln_eps, stagger, ln_flags)
+#define GW_LAUNCH(E, V) hipLaunchKernelGGL((gemm_wide_kernel<E, V, WCN>), dim3(grid), dim3(G::THREADS), G::LDS, s, A, W, bias, resid, C, Cs, M, N, kc, d_flag, slots, ln_g, ln_b, ln_eps, ln_flags)
     if constexpr (WCN == 4) {
         if (g_gemm_wide_ablation && epi == SH_OUT_SPLIT) {
             static PerDeviceOnce abl_attr;  // function attributes are per device
@@ -881,52 +591,6 @@ static int32_t gemm_wide_launch(int epi, const _Float16* A, const _Float16* W, c
             return CS_OK;
         }
     }
-    static const bool roles_env = [] { const char* e = std::getenv("CS_GEMM_WIDE_ROLES"); return e && e[0] == '1'; }();
-    if constexpr (WCN == 4) {
-        if ((roles_env || g_gemm_wide_sched == 20) && !g_gemm_wide_ablation && (epi == SH_OUT_SPLIT || epi == SH_OUT_SPLIT_GELU)) {
-            static PerDeviceOnce roles_attr;
-            auto set_roles = [&]() -> int32_t {
-                CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wide_roles_kernel<SH_OUT_SPLIT>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
-                CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wide_roles_kernel<SH_OUT_SPLIT_GELU>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
-                return CS_OK;
-            };
-            CS_TRY(roles_attr.run(set_roles));
-            if (epi == SH_OUT_SPLIT)
-                hipLaunchKernelGGL(gemm_wide_roles_kernel<SH_OUT_SPLIT>, dim3(grid), dim3(G::THREADS), G::LDS, s, A, W, bias, Cs, M, N, kc, d_flag, slots);
-            else
-                hipLaunchKernelGGL(gemm_wide_roles_kernel<SH_OUT_SPLIT_GELU>, dim3(grid), dim3(G::THREADS), G::LDS, s, A, W, bias, Cs, M, N, kc, d_flag, slots);
-            CS_HIP(hipGetLastError());
-            return CS_OK;
-        }
-    }
-    if constexpr (WCN == 4) {
-        // DMA schedule (gw_dma_slot): CS_GEMM_WIDE_SCH, or ablation ids 12..15 = schedules 1..4 on the product kernel
-        static const int sch_env = [] { const char* e = std::getenv("CS_GEMM_WIDE_SCH"); return e ? std::atoi(e) : 0; }();
-        const int sch = (g_gemm_wide_sched >= 0) ? g_gemm_wide_sched : sch_env;
-        if (((sch >= 1 && sch <= 4) || (sch >= 10 && sch <= 12)) && epi != SH_OUT_F32) {
-#define GW_SCH_ATTR(E, S) CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wide_kernel<E, 0, 4, S>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS))
-#define GW_SCH_ATTR4(E) GW_SCH_ATTR(E, 1); GW_SCH_ATTR(E, 2); GW_SCH_ATTR(E, 3); GW_SCH_ATTR(E, 4); GW_SCH_ATTR(E, 10); GW_SCH_ATTR(E, 11); GW_SCH_ATTR(E, 12)
-            static PerDeviceOnce sch_attr;
-            auto set_attrs = [&]() -> int32_t {
-                GW_SCH_ATTR4(SH_OUT_SPLIT); GW_SCH_ATTR4(SH_OUT_SPLIT_GELU); GW_SCH_ATTR4(GW_OUT_LN); GW_SCH_ATTR4(SH_OUT_F32_RESID);
-                return CS_OK;
-            };
-            CS_TRY(sch_attr.run(set_attrs));
-#undef GW_SCH_ATTR4
-#undef GW_SCH_ATTR
-#define GW_LAUNCH_S(E, S) hipLaunchKernelGGL((gemm_wide_kernel<E, 0, 4, S>), dim3(grid), dim3(G::THREADS), G::LDS, s, A, W, bias, resid, C, Cs, M, N, kc, d_flag, slots, ln_g, ln_b, ln_eps, stagger, ln_flags)
-#define GW_LAUNCH_E(E) do { switch (sch) { case 1: GW_LAUNCH_S(E, 1); break; case 2: GW_LAUNCH_S(E, 2); break; case 3: GW_LAUNCH_S(E, 3); break; case 4: GW_LAUNCH_S(E, 4); break; case 10: GW_LAUNCH_S(E, 10); break; case 11: GW_LAUNCH_S(E, 11); break; default: GW_LAUNCH_S(E, 12); break; } } while (0)
-            if (epi == SH_OUT_SPLIT) GW_LAUNCH_E(SH_OUT_SPLIT);
-            else if (epi == SH_OUT_SPLIT_GELU) GW_LAUNCH_E(SH_OUT_SPLIT_GELU);
-            else if (epi == GW_OUT_LN) GW_LAUNCH_E(GW_OUT_LN);
-            else if (epi == SH_OUT_F32_RESID) GW_LAUNCH_E(SH_OUT_F32_RESID);
-            else return fail(CS_ERR_BAD_ARG, "unknown epilogue %d", epi);
-#undef GW_LAUNCH_E
-#undef GW_LAUNCH_S
-            CS_HIP(hipGetLastError());
-            return CS_OK;
-        }
-    }
     if (epi == SH_OUT_F32) GW_LAUNCH(SH_OUT_F32, 0);
     else if (epi == SH_OUT_F32_RESID) GW_LAUNCH(SH_OUT_F32_RESID, 0);
     else if (epi == SH_OUT_SPLIT) GW_LAUNCH(SH_OUT_SPLIT, 0);
@@ -948,8 +612,12 @@ static int32_t gemm_wide_impl(int epi, const _Float16* A, const _Float16* W, con
                               const float* ln_g, const float* ln_b, float ln_eps, int shape = 0, uint32_t ln_flags = 0) {
     if (!gemm_wide_supported(N, K)) return fail(CS_ERR_UNSUPPORTED, "wide split GEMM needs N %% 192 == 0 and K %% 32 == 0 (N=%u K=%u)", N, K);
     if (M == 0) return CS_OK;
-    static const int shape_env = [] { const char* e = std::getenv("CS_GEMM_WIDE_SHAPE"); return e ? std::atoi(e) : 384; }();
-    const bool big = epi == GW_OUT_LN || g_gemm_wide_ablation || ((shape ? shape : g_gemm_wide_shape ? g_gemm_wide_shape : shape_env) == 384 && N % 384 == 0 && N <= (uint32_t)GW_PARAM_FLOATS);
+    static const int shape_env = [] { const char* e = std::getenv("CS_GEMM_WIDE_SHAPE"); return e ? std::atoi(e) : 0; }();
+    // default: 128 x 384, except the bias -> split-store layer (the QKV projection), which four boxes measured 3-4 % faster
+    // as 128 x 192 tiles, two blocks per CU (169-173 vs 175-181 us at 65,536 x 1,152 x 384; FFN-up level: profiles/
+    // r04_gemm_stagger_by_cu_ab.log code 1000, r04_gemm_role_split_ab.log)
+    const int want = shape ? shape : g_gemm_wide_shape ? g_gemm_wide_shape : shape_env ? shape_env : (epi == SH_OUT_SPLIT ? 192 : 384);
+    const bool big = epi == GW_OUT_LN || g_gemm_wide_ablation || (want == 384 && N % 384 == 0 && N <= (uint32_t)GW_PARAM_FLOATS);
     if (big) return gemm_wide_launch<4>(epi, A, W, bias, resid, C, Cs, M, N, K, d_flag, s, ln_g, ln_b, ln_eps, ln_flags);
     return gemm_wide_launch<2>(epi, A, W, bias, resid, C, Cs, M, N, K, d_flag, s, ln_g, ln_b, ln_eps, ln_flags);
 }

@@ -549,7 +549,9 @@ int32_t cs_debug_gemm(int32_t device, int32_t mode, int32_t epilogue, const floa
 /* Diagnostics: device milliseconds per launch of one dense layer on synthetic operands resident in HBM.
  * mode 0 exact-f32 MFMA, 1 split-f16 (128 x 128 / skinny kernels), 2 split-f16 wide kernel (N % 384 == 0);
  * epilogue 0 f32, 1 GELU -> split, 2 + residual, 3 LayerNorm-fused (mode 2, N = 384), 4 bias -> split (QKV);
- * ablation (mode 2, epilogue 4): 0 none, 1 no LDS-DMA, 2 no MFMA, 3 DMAs issued at the start of a k-step. */
+ * ablation (mode 2): 0 none; epilogue 4 only: 1 no LDS-DMA, 2 no MFMA, 3 DMAs issued at the start of a k-step, 4-10 see
+ * gemm_wide.hip; any epilogue: 192 / 384 = that block shape of the product kernel.  CS_DEBUG_GEMM_ZERO=1: all-zero operands
+ * (the same instruction stream at the clock the chip holds on trivial data). */
 int32_t cs_debug_gemm_time(int32_t device, int32_t mode, int32_t epilogue, uint32_t M, uint32_t N, uint32_t K,
                            uint32_t iters, int32_t ablation, double* ms_per_launch);
 
