@@ -66,6 +66,9 @@ def parse_args():
     ap.add_argument("--no-1m", action="store_true", help="skip the configs[1] leg (1M rows)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the configs[3] leg (100k chunks indexed, 64 queries)")
     ap.add_argument("--e2e-chunks", type=int, default=100_000)
+    ap.add_argument("--route", choices=("stream", "cost", "filter"), default="stream",
+                    help="one query per step: stream = the f32 streaming scan (the north-star kernel `value` is quoted on; "
+                         "default), cost = the library's default route (int8 filter + exact refine over >= 2M rows), filter")
     ap.add_argument("--no-rccl-child", action="store_true",
                     help="--gpus N without a launcher: do not run the one-rank-per-GPU RCCL form as child processes first")
     ap.add_argument("--no-config5", action="store_true", help="--gpus N without a launcher: skip the 1,000-query leg")
@@ -874,7 +877,8 @@ def main():
     # `value` is quoted on the f32 streaming scan (the north-star kernel) when a step is one query: selected explicitly —
     # by default such a search takes the int8 filter + exact refine (same bits), timed below as `default_routing`
     if args.nq == 1:
-        shard.store.set_single_query_route(shard.store.ROUTE_STREAM)
+        shard.store.set_single_query_route({"stream": shard.store.ROUTE_STREAM, "cost": shard.store.ROUTE_COST,
+                                            "filter": shard.store.ROUTE_FILTER}[args.route])
     # the queries arrive on rank 0 (the process a caller of VectorStore::search talks to); for N > 1 every
     # step broadcasts them to the other shards inside the timed region
     q_host = synth_rows(SEED + 1, 0, args.nq, args.dim)
@@ -930,7 +934,8 @@ def main():
         alg_bytes = args.rows * args.dim * 4  # per launch: every row of the shard read once
         achieved = alg_bytes / (scan_us * 1e-6) / 1e9
         # the scan is HBM-bound below ~39 queries per pass and fp32-MFMA-bound above
-        wants_filter = args.nq >= int(os.environ.get("CS_FILTER_MIN_Q", "2"))  # one query: CS_ROUTE_STREAM selected above
+        wants_filter = (args.nq >= int(os.environ.get("CS_FILTER_MIN_Q", "2"))  # one query: --route (default: streaming scan)
+                        or (args.nq == 1 and args.route != "stream" and (args.route == "filter" or args.rows >= 2_000_000)))
         filter_path = wants_filter and args.dim in (384, 768, 1024) and os.environ.get("CS_INDEX_SPLIT", "1")[0] != "0"
         alg_flops = 2.0 * args.rows * args.nq * args.dim
         int8_path = filter_path and os.environ.get("CS_FILTER_INT8", "1")[0] != "0"
@@ -1050,7 +1055,7 @@ def main():
             line["cpu_baseline"] = base
             line["recall_at_10"] = recall
             line["max_abs_cos_err_vs_cpu"] = err
-        if world == 1 and args.nq == 1 and not args.only_scan:
+        if world == 1 and args.nq == 1 and args.route == "stream" and not args.only_scan:
             # The DEFAULT route of the same search (CS_ROUTE_COST, index.hip run_search): one query over >= 2M rows goes
             # through the MFMA filter over the int8 copy (a quarter of the f32 bytes) + exact f32 re-score — the shape of the
             # reference's MCP and HTTP searches (src/mcp/mod.rs:252, src/server/mod.rs:547).  Same bits as the streaming scan.

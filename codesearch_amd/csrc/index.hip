@@ -418,9 +418,9 @@ int32_t grow(cs_index* h, uint64_t need_rows) {
     return CS_OK;
 }
 
-// the int8 copy is the filter's operand: it exists, was not retired, and reaches past phase 0's 1,024 rows
+// the int8 copy is the filter's operand: it exists, was not retired, and reaches past phase 0's rows
 bool q8_serves(const cs_index* h) {
-    return h->use_q8 && h->d_q8 && h->d_tmeta && h->q8_active.load() && h->q8_rows > 1024;
+    return h->use_q8 && h->d_q8 && h->d_tmeta && h->q8_active.load() && h->q8_rows > kFilterPhase0;
 }
 
 // The f16 copy, complete for the rows of the last build — built now if it is not there (allocation + one conversion pass

@@ -80,6 +80,11 @@ constexpr uint32_t kCntStride = 32;
 // Device-API searches of up to this many queries carry a gated exact rerun behind the filter path (index.hip
 // run_search); above it an overflowed candidate buffer is reported through the sticky word of BatchedState.
 constexpr uint32_t kGatedMaxQ = 16;
+// Phase 0 of the filter searches (scan_filter.hip): tau is still -inf, so the first rows are not filtered at all — every
+// one of them is re-scored exactly and folded into the running best-k.  3,072 = a multiple of the filter kernels' 1,024
+// row granule that, with the k <= 1,024 carried keys, still sorts as ONE 4,096-key chunk of select_candidates_kernel;
+// round 3 used 1,024, which cost one more phase (filter + re-score + select: ~45 us of launches) on a 10M-row index.
+constexpr uint32_t kFilterPhase0 = 3072;
 struct BatchedState {
     uint64_t* d_cand = nullptr;   // [nq][cap] candidate keys
     uint32_t* d_cnt = nullptr;    // [nq][kCntStride], word 0 of each line used

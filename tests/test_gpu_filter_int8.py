@@ -339,11 +339,11 @@ def test_filter_copy_allocation_failures_fall_back_without_corruption(VS, monkey
     monkeypatch.setenv("CS_FILTER_SINGLE_MIN_K", "0")
     dim, nq, k = 384, 6, 10
     st = VS(None, dim)
-    st.insert_synthetic(3_000, 9, 0)
+    st.insert_synthetic(5_000, 9, 0)
     st.build_index()
     assert st.filter_state()[0] == 2 and st.filter_copies()[:2] == (True, False)
     monkeypatch.setenv("CS_FAULT_INT8_ALLOC", "1")
-    st.insert_synthetic(120_000, 9, 3_000)            # grows past the first capacity: the int8 reallocation "fails"
+    st.insert_synthetic(120_000, 9, 5_000)            # grows past the first capacity: the int8 reallocation "fails"
     monkeypatch.delenv("CS_FAULT_INT8_ALLOC")
     st.build_index()
     assert st.filter_state()[0] == 1 and st.filter_copies()[:2] == (False, True)
