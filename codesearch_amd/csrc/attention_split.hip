@@ -725,7 +725,18 @@ int32_t launch_attention_sh2(const _Float16* qkv_split, const int32_t* mask, voi
     // block.  CS_ATTN_SHX1=0 selects the whole-sequence kernel (attention_sh2_kernel) for A/B.
     static const bool shx1 = [] { const char* e = std::getenv("CS_ATTN_SHX1"); return !(e && e[0] == '0'); }();
     if (shx1) {
-        const size_t lds1 = 2 * 1 * 128 * 128 + Lp * sizeof(float) + 16;
+        // CS_ATTN_LDS_PAD (diagnostics): extra dynamic LDS per block, i.e. fewer co-resident blocks per CU — how the kernel's
+        // time moves with occupancy says whether a tile's dependent chain (latency) or issue slots bound it
+        static const size_t lds_pad = [] { const char* e = std::getenv("CS_ATTN_LDS_PAD"); return e ? (size_t)std::atol(e) : (size_t)0; }();
+        const size_t lds1 = 2 * 1 * 128 * 128 + Lp * sizeof(float) + 16 + lds_pad;
+        if (lds_pad) {
+            static PerDeviceOnce pad_attr;
+            CS_TRY(pad_attr.run([&]() -> int32_t {
+                CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attention_shx_kernel<1>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
+                return CS_OK;
+            }));
+        }
         static const bool pack_heads = [] { const char* e = std::getenv("CS_ATTN_PACK_HEADS"); return !(e && e[0] == '0'); }();
         uint32_t hb = !pack_heads ? 1u : (Lp <= 32 ? 4u : (Lp <= 64 ? 2u : 1u));  // heads per block (kernel comment)
         while (heads % hb) hb >>= 1;
