@@ -68,7 +68,7 @@ def parse_args():
     ap.add_argument("--e2e-chunks", type=int, default=100_000)
     ap.add_argument("--route", choices=("stream", "cost", "filter"), default="stream",
                     help="one query per step: stream = the f32 streaming scan (the north-star kernel `value` is quoted on; "
-                         "default), cost = the library's default route (int8 filter + exact refine over >= 2M rows), filter")
+                         "default), cost = the library's default route (int8 filter + exact refine from 150,000 rows on), filter")
     ap.add_argument("--no-rccl-child", action="store_true",
                     help="--gpus N without a launcher: do not run the one-rank-per-GPU RCCL form as child processes first")
     ap.add_argument("--no-config5", action="store_true", help="--gpus N without a launcher: skip the 1,000-query leg")
@@ -430,6 +430,7 @@ def scan_1m_leg(dim, k, device, store_cls):
     st = store_cls(None, dim, device=device, capacity=rows)
     st.insert_synthetic(rows, SEED, 0)
     st.build_index()
+    st.set_single_query_route(st.ROUTE_STREAM)  # configs[1] names the scan kernel; the default route is timed below
     lib = _lib.load()
     dev = f"cuda:{device}"
     d_q = torch.from_numpy(synth_rows(SEED + 1, 0, 1, dim)).to(dev)
@@ -458,9 +459,24 @@ def scan_1m_leg(dim, k, device, store_cls):
     st.profile(False)
     us = scan_ms * 1e3 / max(launches, 1)
     gbps = rows * dim * 4 / (us * 1e-6) / 1e9
+    ref_keys = keys.clone()
+    st.set_single_query_route(st.ROUTE_COST)
+    for _ in range(20):
+        search()
+    torch.cuda.synchronize()
+    same = bool(torch.equal(keys, ref_keys))
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        search()
+    torch.cuda.synchronize()
+    wall_def = (time.perf_counter() - t0) / reps
     out = {"workload": f"brute-force cosine top-{k}, 1 query over {rows} x {dim} fp32 rows (BASELINE.json configs[1])",
            "ms_per_search": wall * 1e3, "chunks_per_s": rows / wall, "scan_kernel_us": us,
-           "hbm_GBps": gbps, "frac_of_hbm_peak": gbps / HBM_PEAK_GBPS}
+           "hbm_GBps": gbps, "frac_of_hbm_peak": gbps / HBM_PEAK_GBPS,
+           "default_routing": {"ms_per_search": wall_def * 1e3, "chunks_per_s": rows / wall_def,
+                               "bit_identical_to_streaming_scan": same,
+                               "note": "CS_ROUTE_COST: int8 filter + exact refine from 150,000 rows on; the figures above "
+                                       "select CS_ROUTE_STREAM (the HIP scan kernel configs[1] names)"}}
     del st
     return out
 
@@ -935,7 +951,7 @@ def main():
         achieved = alg_bytes / (scan_us * 1e-6) / 1e9
         # the scan is HBM-bound below ~39 queries per pass and fp32-MFMA-bound above
         wants_filter = (args.nq >= int(os.environ.get("CS_FILTER_MIN_Q", "2"))  # one query: --route (default: streaming scan)
-                        or (args.nq == 1 and args.route != "stream" and (args.route == "filter" or args.rows >= 2_000_000)))
+                        or (args.nq == 1 and args.route != "stream" and (args.route == "filter" or args.rows >= 150_000)))
         filter_path = wants_filter and args.dim in (384, 768, 1024) and os.environ.get("CS_INDEX_SPLIT", "1")[0] != "0"
         alg_flops = 2.0 * args.rows * args.nq * args.dim
         int8_path = filter_path and os.environ.get("CS_FILTER_INT8", "1")[0] != "0"

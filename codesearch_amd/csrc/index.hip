@@ -284,12 +284,16 @@ struct cs_index {
     float filter_margin = 0.0f;  // scan_filter.hip: bound of the f16 filter's error for this dim
     int filter_min_q = 2;  // query count from which the f16 filter + exact refine path is used
     uint32_t single_filter_min_k = 100;  // ... and one query too from this k on, over >= 2M rows (0 = never)
-    // One query over >= single_filter_min_rows rows: CS_ROUTE_COST (default) takes the filter whenever the int8 copy
-    // serves (same bits, 0.66 vs 2.16 ms over 10M x 384 at k = 10: the filter streams a quarter of the bytes), and from
-    // single_filter_min_k on with the f16 copy; CS_ROUTE_STREAM always runs the f32 streaming scan (the north-star
+    // One query: CS_ROUTE_COST (default) takes the filter over >= single_int8_min_rows rows whenever the int8 copy serves
+    // (same bits, 0.66 vs 2.16 ms over 10M x 384 at k = 10: the filter streams a quarter of the bytes), and from
+    // single_filter_min_k on over >= single_filter_min_rows rows with the f16 copy; CS_ROUTE_STREAM always runs the f32 streaming scan (the north-star
     // kernel: bench.py selects it for `value`); CS_ROUTE_FILTER takes the filter whenever a copy can serve.
     int single_route = CS_ROUTE_COST;
-    uint64_t single_filter_min_rows = 2000000;
+    uint64_t single_filter_min_rows = 2000000;  // ... with the f16 copy (and k >= single_filter_min_k)
+    // ... with the int8 copy: measured crossover of the two routes at k = 10 / 25 (profiles/r04_route_crossover.log,
+    // us per search, stream / filter): 50k rows 67 / 80, 100k 83 / 81-87, 200k 109 / 90, 400k 158 / 100, 1M 263 / 154,
+    // 2M 473 / 210, 4M 889 / 320 — the filter's fixed rounds cost ~80 us, then it streams a quarter of the bytes
+    uint64_t single_int8_min_rows = 150000;
     uint64_t single_batched_max_rows = 1024;  // ... and one query over at most this many rows (0 = never; CS_SINGLE_BATCHED_MAX_ROWS)
     // primed streaming scan (scan.hip PRIME mode): from this k and this many rows on, a pass over
     // the first prime_rows rows bounds the list inserts of the full scan
@@ -539,8 +543,8 @@ int32_t run_search(cs_index* h, Workspace* w, const ScanPlan& plan, const float*
     const bool single_filter =
         nq == 1 && h->single_route != CS_ROUTE_STREAM &&
         (h->single_route == CS_ROUTE_FILTER ||
-         (h->n_rows >= h->single_filter_min_rows &&
-          (q8_serves(h) || (h->single_filter_min_k && k >= h->single_filter_min_k))));
+         (q8_serves(h) && h->n_rows >= h->single_int8_min_rows) ||
+         (h->n_rows >= h->single_filter_min_rows && h->single_filter_min_k && k >= h->single_filter_min_k));
     const bool wants_filter = (int)nq >= h->filter_min_q || single_filter ||
                               (nq == 1 && h->n_rows <= h->single_batched_max_rows);
     const bool normed = h->n_rows > 0 && h->normed_rows >= h->n_rows;
@@ -763,7 +767,7 @@ int32_t cs_index_create(uint32_t dim, uint64_t capacity_rows, int32_t device, ui
             h->single_filter_min_k = (uint32_t)std::atol(e);
             if (h->single_filter_min_k == 0) h->single_route = CS_ROUTE_STREAM;
         }
-        if (const char* e = std::getenv("CS_FILTER_SINGLE_MIN_ROWS")) h->single_filter_min_rows = (uint64_t)std::atoll(e);
+        if (const char* e = std::getenv("CS_FILTER_SINGLE_MIN_ROWS")) h->single_int8_min_rows = (uint64_t)std::atoll(e);
         if (const char* e = std::getenv("CS_SINGLE_BATCHED_MAX_ROWS")) h->single_batched_max_rows = (uint64_t)std::atoll(e);
         if (const char* e = std::getenv("CS_SCAN_PRIME_MIN_K")) h->prime_min_k = (uint32_t)std::atol(e);  // 0 = off
         if (const char* e = std::getenv("CS_SCAN_PRIME_MIN_ROWS")) h->prime_min_rows = (uint64_t)std::atoll(e);

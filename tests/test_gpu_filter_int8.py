@@ -19,6 +19,7 @@ def VS(gpu_lib):
 
 
 def _same_as_single_query_scans(st, qs, k):
+    st.set_single_query_route(st.ROUTE_STREAM)  # the single-query searches below are the streaming-scan reference
     before = st.debug_counters()[1]
     cos, ids, counts = st.search_raw(qs, k)
     assert st.debug_counters()[1] == before, "candidate buffer overflowed: the filter path was not what answered"

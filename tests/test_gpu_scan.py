@@ -435,7 +435,7 @@ def test_config5_per_gpu_workload_1000_queries_over_10m_rows(full10m):
 def test_config1_1m_single_query_against_oracle(VS, oracle):
     """BASELINE configs[1]: one query, top-10 over 1M x 384 — the primed streaming scan at the size where
     the prime pass and the merge are 9 % of a search — and k = 100 / 200, all against the oracle on the
-    whole corpus; then the same queries in one batched call."""
+    whole corpus; the same searches on the default route (filter + refine), bit for bit; then one batched call."""
     n, dim, seed = 1_000_000, 384, 0xC0DE5EA
     st = VS(None, dim, capacity=n)
     st.insert_synthetic(n, seed, 0)
@@ -448,15 +448,25 @@ def test_config1_1m_single_query_against_oracle(VS, oracle):
         dead[d >> 5] |= np.uint32(1 << (d & 31))
     qs = np.concatenate([synth_rows(seed + 1, 0, 3, dim), synth_planted(seed, seed + 2, [999_998], dim)])
     expect = [oracle.scan_topk(corpus, q, 200, dead=dead, mode="omp") for q in qs]
+    st.set_single_query_route(st.ROUTE_STREAM)   # configs[1] names the scan kernel: selected explicitly
+    streamed = {}
     for kk in (10, 100, 200):
         for i in range(len(qs)):
             c1, i1, n1 = st.search_raw(qs[i], kk)
             assert n1[0] == kk
             assert_topk_equal(c1[0], i1[0], expect[i][0][:kk], expect[i][1][:kk], corpus, qs[i], oracle)
-    assert st.debug_counters() == (0, 0)  # below 2M rows one query always streams
+            streamed[(kk, i)] = (c1[0].copy(), i1[0].copy())
+    assert st.debug_counters() == (0, 0)
     assert st.search_raw(qs[3], 10)[1][0][0] == 999_998
+    # the default route at this size (CS_ROUTE_COST: the int8 filter from 150,000 rows on): same bits, 0.15 vs 0.26 ms
+    st.set_single_query_route(st.ROUTE_COST)
+    for (kk, i), (sc, si) in sorted(streamed.items()):
+        c1, i1, n1 = st.search_raw(qs[i], kk)
+        assert i1[0].tolist() == si.tolist() and c1[0].tobytes() == sc.tobytes(), (kk, i)
+    assert st.debug_counters() == (len(streamed), 0)
+    b_before = st.debug_counters()[0]
     cos, ids, counts = st.search_raw(qs, 10)
-    assert st.debug_counters() == (1, 0)
+    assert st.debug_counters() == (b_before + 1, 0)
     for i in range(len(qs)):
         assert_topk_equal(cos[i], ids[i], expect[i][0][:10], expect[i][1][:10], corpus, qs[i], oracle)
 
@@ -683,19 +693,37 @@ def test_persistent_store_round_trip(VS, oracle, tmp_path):
 
 
 def test_single_query_through_filter_is_bit_identical(VS):
-    """cs_index_set_filter_min_queries(1): even one query may take filter + refine; same bits."""
+    """One query may take filter + refine — by default (CS_ROUTE_COST) from 150,000 rows on when the int8 copy serves, at
+    any size with CS_ROUTE_FILTER or cs_index_set_filter_min_queries(1); CS_ROUTE_STREAM pins the streaming scan.  Same
+    bits on every route; the debug counters prove which route ran."""
     dim, n, k = 384, 200_000, 10
     st = VS(None, dim)
     st.insert_synthetic(n, 99, 0)
     st.build_index()
     qs = synth_rows(1234, 0, 5, dim)
+    st.set_single_query_route(st.ROUTE_STREAM)
     base = [st.search_raw(q, k) for q in qs]
     assert st.debug_counters() == (0, 0)
-    st.set_filter_min_queries(1)
+    st.set_single_query_route(st.ROUTE_COST)      # the default: 200,000 rows are past the crossover
     for q, (c0, i0, n0) in zip(qs, base):
         c1, i1, n1 = st.search_raw(q, k)
         assert n1[0] == n0[0] and i1.tolist() == i0.tolist() and c1.tobytes() == c0.tobytes()
     assert st.debug_counters() == (5, 0)
+    small = VS(None, dim)
+    small.insert_synthetic(60_000, 99, 0)         # below the crossover the default route streams ...
+    small.build_index()
+    sbase = [small.search_raw(q, k) for q in qs]
+    assert small.debug_counters() == (0, 0)
+    small.set_single_query_route(small.ROUTE_FILTER)   # ... unless told otherwise
+    for q, (c0, i0, n0) in zip(qs, sbase):
+        c1, i1, n1 = small.search_raw(q, k)
+        assert n1[0] == n0[0] and i1.tolist() == i0.tolist() and c1.tobytes() == c0.tobytes()
+    assert small.debug_counters() == (5, 0)
+    small.set_single_query_route(small.ROUTE_COST)
+    small.set_filter_min_queries(1)                    # round 2's knob still does the same
+    c1, i1, n1 = small.search_raw(qs[0], k)
+    assert i1.tolist() == sbase[0][1].tolist() and c1.tobytes() == sbase[0][0].tobytes()
+    assert small.debug_counters() == (6, 0)
 
 
 @pytest.mark.parametrize("dim", [384, 768, 1024])
