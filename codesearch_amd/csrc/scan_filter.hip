@@ -1728,8 +1728,8 @@ static int32_t scan_split_impl(const BatchedState& st, const SplitQueryWs& qw, c
     // refine work (re-scoring + sorting grow with it), large growth on launches: a phase is three kernels (filter,
     // re-score, select) and the early ones are launch-bound whatever their size.  Measured over 10M rows (r01-r03):
     // g = 5 from k = 48 on, g = 9 ... 16 below.  Round 4 plans the boundaries as ONE geometric sequence from phase 0 to
-    // the last row with the fewest phases whose ratio stays within that growth (5.5 / 15): 10M rows take 5 filter
-    // phases at k = 200 (was 6) and 3 at k = 10 (was 4).  CS_FILTER_GROWTH / CS_FILTER_GROWTH1 restore fixed growth.
+    // the last row with the fewest phases whose ratio stays within that growth (5.5 from k = 48, up to 24 below): 10M rows
+    // take 5 filter phases at k = 200 (was 6) and 3 at k = 10 (was 4), 1M rows 2 at k = 10.  CS_FILTER_GROWTH / CS_FILTER_GROWTH1 restore fixed growth.
     static int growth_env = -1;
     if (growth_env < 0) {
         const char* e = std::getenv("CS_FILTER_GROWTH");
@@ -1744,7 +1744,13 @@ static int32_t scan_split_impl(const BatchedState& st, const SplitQueryWs& qw, c
     const uint32_t growth = growth_env > 0 ? (uint32_t)growth_env : (k >= 48 ? 4u : 8u);
     double ratio = 0.0;  // planned D_next / D
     if (!fixed_growth && n_rows > phase) {
-        const double gmax = k >= 48 ? 5.5 : 15.0, span = (double)n_rows / (double)phase;
+        static const double gmax_env = [] { const char* e = std::getenv("CS_FILTER_GMAX"); return e ? std::atof(e) : 0.0; }();
+        // Short lists: a round from D to r D rows brings ~k r candidates times the band's factor (the tail just below tau:
+        // exp(z band / sigma) = 3.3 at the 25th best of 175k isotropic rows) into a 4,096-slot buffer — r = 57 overflowed
+        // at k = 25 and fell back to the exact scan (profiles/r04_filter_gmax_ab.log); 24, capped by 900 / k, keeps a
+        // factor of 4.5 in hand and lets 1M rows take two rounds instead of three (153 -> 138 us at k = 10)
+        const double gshort = std::min(24.0, 900.0 / (double)k);
+        const double gmax = gmax_env > 1.0 ? gmax_env : (k >= 48 ? 5.5 : gshort), span = (double)n_rows / (double)phase;
         const double nph = std::ceil(std::log(span) / std::log(gmax) - 1e-9);
         ratio = std::pow(span, 1.0 / (nph < 1.0 ? 1.0 : nph));
     }
