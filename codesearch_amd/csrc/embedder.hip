@@ -1221,7 +1221,7 @@ int32_t cs_debug_gemm_time(int32_t device, int32_t mode, int32_t epilogue, uint3
         };
         // ablation >= 100: DMA schedule ablation - 100 of the product kernel (gemm_wide.hip gw_dma_slot), any epilogue
         // ablation 192 / 384: that block shape of the product kernel, any epilogue
-        cs::g_gemm_wide_shape = (mode == 2 && (ablation == 192 || ablation == 384 || ablation == 1384)) ? ablation : 0;
+        cs::g_gemm_wide_shape = (mode == 2 && (ablation == 192 || ablation == 384)) ? ablation : 0;
         cs::g_gemm_wide_ablation = (mode == 2 && epilogue == 4 && ablation < 100) ? ablation : 0;
         for (int i = 0; i < 3; ++i) CS_TRY(once());
         CS_HIP(hipEventRecord(e0, nullptr));

@@ -47,25 +47,19 @@ constexpr int GW_STATS = 5 * GW_BM * 4;            // LayerNorm epilogue: [4 col
 // one block's epilogue (VALU conversions + stores) runs under the other's MFMAs.
 template <int WCN>
 struct GwGeom {
-    // WCN = 4: 2 x 4 waves, wave tile 64 x 96; WCN = 2: 2 x 2 waves, 128 x 192 block; WCN = 8 (round 4):
-    // 1 x 4 waves of 128 x 96 wave tiles (192 accumulators, one wave per SIMD) over the same 128 x 384 block
-    static constexpr int CW = WCN == 8 ? 4 : WCN;                // column waves
-    static constexpr int RW = WCN == 8 ? 1 : 2;                  // row waves
-    static constexpr int IT = 8 / RW;                            // 16-row MFMA tiles per wave: 4 | 8
-    static constexpr int BN = 96 * CW;
-    static constexpr int WAVES = RW * CW;
+    static constexpr int BN = 96 * WCN;
+    static constexpr int WAVES = 2 * WCN;
     static constexpr int THREADS = 64 * WAVES;
     static constexpr int W_BYTES = BN * 128;
     static constexpr int STAGE = GW_A_BYTES + W_BYTES;           // 65,536 | 40,960
-    // CW == 4 keeps the layer's bias (and the LayerNorm's gamma / beta) in LDS for the block's lifetime: the epilogue then
+    // WCN == 4 keeps the layer's bias (and the LayerNorm's gamma / beta) in LDS for the block's lifetime: the epilogue then
     // issues no global LOAD, so nothing in it waits on vmcnt (which retires in issue order: a load issued behind the
     // previous strip's stores, or behind the next tile's first DMAs, waits for all of them)
-    static constexpr int PARAMS = CW == 4 ? GW_PARAM_FLOATS * 4 : 0;
-    static constexpr int LDS = 2 * STAGE + (CW == 4 ? GW_STATS : 0) + PARAMS;
-    static constexpr int A_PIECES = 16 / WAVES;                  // LDS-DMA pieces (8 rows x 128 B) of A per wave and stage: 2 | 4 | 4
-    static constexpr int W_PIECES = (BN / 8) / WAVES;            // ... of W: 6 | 6 | 12
-    static constexpr int PIECES = A_PIECES + W_PIECES;           // 8 | 10 | 16
-    static constexpr int PPJ = (PIECES + 5) / 6;                 // DMA pieces issued per weight fragment (six per k-step)
+    static constexpr int PARAMS = WCN == 4 ? GW_PARAM_FLOATS * 4 : 0;
+    static constexpr int LDS = 2 * STAGE + (WCN == 4 ? GW_STATS : 0) + PARAMS;
+    static constexpr int A_PIECES = 16 / WAVES;                  // LDS-DMA pieces (8 rows x 128 B) of A per wave and stage: 2 | 4
+    static constexpr int W_PIECES = (BN / 8) / WAVES;            // ... of W: 6
+    static constexpr int PIECES = A_PIECES + W_PIECES;           // 8 | 10
 };
 constexpr uint32_t GW_LN_RESID_SPLIT = 1u, GW_LN_NO_F32 = 2u;  // ln_flags of the LayerNorm epilogue (launch_gemm_wide_ln)
 constexpr int GW_OUT_LN = 16;  // epilogue: + bias + residual, LayerNorm over the 384 columns, store f32 AND split form
@@ -89,8 +83,7 @@ __device__ __forceinline__ float gw_erf_fast(float x) {  // gemm_split.hip sh_er
 }
 __device__ __forceinline__ float gw_gelu(float v) { return 0.5f * v * (1.0f + gw_erf_fast(v * 0.70710678118654752440f)); }
 
-template <int IT>
-struct GwAcc { sh_f32x4v c[IT][6]; };
+struct GwAcc { sh_f32x4v c[4][6]; };
 
 // this wave's eight LDS-DMA pieces of a stage: p = 0, 1 -> A rows, p = 2..7 -> W rows
 template <int WCN>
@@ -118,19 +111,18 @@ __device__ uint64_t g_gw_stamps[8 * 512];  // per block: clk0, real0, clk1, real
 // kernel; on all-zero operands the same instruction stream is 15-20 % faster (r04_gemm_zero_vs_random.log): the rest
 // is the clock the chip holds under this load, not the schedule.
 template <int EPI, int ABL = 0, int WCN = 4>
-__global__ void __launch_bounds__(GwGeom<WCN>::THREADS, (WCN == 8 ? 1 : 2))
+__global__ void __launch_bounds__(GwGeom<WCN>::THREADS, 2)
 gemm_wide_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ W, const float* __restrict__ bias,
                  const float* resid, float* C, _Float16* __restrict__ Cs, uint32_t M, uint32_t N, uint32_t kchunks,
                  uint32_t* __restrict__ flag, uint32_t total_slots, const float* __restrict__ ln_g,
                  const float* __restrict__ ln_b, float ln_eps, uint32_t ln_flags) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     using G = GwGeom<WCN>;
-    static_assert(EPI != GW_OUT_LN || G::CW == 4, "the LayerNorm epilogue needs whole rows in one block");
-    constexpr int IT = G::IT, CW = G::CW;
+    static_assert(EPI != GW_OUT_LN || WCN == 4, "the LayerNorm epilogue needs whole rows in one block");
     constexpr int GW_BN = G::BN, GW_STAGE = G::STAGE, AP = G::A_PIECES, WP = G::W_PIECES, NP = G::PIECES;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave / CW, wc = wave % CW;
+    const int wr = wave / WCN, wc = wave % WCN;
     const int l15 = lane & 15, g = lane >> 4;
     const uint32_t mtiles = (M + GW_BM - 1) / GW_BM, ntiles = N / GW_BN;
 
@@ -159,7 +151,7 @@ gemm_wide_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ W,
     };
 
     const int swz = (l15 >> 1) & 7;
-    const uint32_t a_off = (wr * 16 * IT + l15) * 128, w_off = GW_A_BYTES + (wc * 96 + l15) * 128;
+    const uint32_t a_off = (wr * 64 + l15) * 128, w_off = GW_A_BYTES + (wc * 96 + l15) * 128;
     const uint32_t s_hi = (g ^ swz) * 16, s_lo = ((4 + g) ^ swz) * 16;
 
     auto valid = [&](uint32_t slot, uint32_t& mt, uint32_t& nt) { return sh_tile_of_block(slot, mtiles, ntiles, mt, nt); };
@@ -172,7 +164,7 @@ gemm_wide_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ W,
     uint32_t slot = next_valid(blockIdx.x, mt, nt);
     if (slot >= total_slots) return;
     float* const pbias = reinterpret_cast<float*>(lds + 2 * GW_STAGE + GW_STATS);  // (WCN == 4) [N] bias, LayerNorm: + gamma, beta
-    constexpr bool lds_params = CW == 4;  // the launcher sends N > GW_PARAM_FLOATS to the 128 x 192 shape
+    constexpr bool lds_params = WCN == 4;  // the launcher sends N > GW_PARAM_FLOATS to the 128 x 192 shape
     if constexpr (lds_params) {
         for (uint32_t i = tid; i < N / 4; i += G::THREADS) {
             reinterpret_cast<sh_f32x4*>(pbias)[i] = reinterpret_cast<const sh_f32x4*>(bias)[i];
@@ -202,7 +194,7 @@ gemm_wide_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ W,
     while (slot < total_slots) {
         const uint32_t m0 = mt * GW_BM, n0 = nt * GW_BN;
         const uint32_t rot = sh_kc_rot(nt, ntiles, kchunks);  // see sh_mainloop: n-tiles of an m-tile walk K out of phase
-        GwAcc<IT> acc;
+        GwAcc acc;
         // The accumulators START at bias * 2^11 (LayerNorm: (bias + residual) * 2^11), the scale the products arrive on: the
         // epilogue needs neither registers nor loads for them.
         if (EPI == GW_OUT_LN) {
@@ -215,11 +207,11 @@ gemm_wide_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ W,
                 // the residual stream in split form only (same 4 B per element: the row's line [32 hi | 32 lo] of the
                 // 32-column chunk): hi * 2^11 + lo' is exact in f32 and already on the accumulators' scale
 #pragma unroll
-                for (int ih = 0; ih < IT / 2; ++ih) {
+                for (int ih = 0; ih < 2; ++ih) {
                     f16x4 rh[2][6], rl[2][6];
 #pragma unroll
                     for (int ii = 0; ii < 2; ++ii) {
-                        const uint32_t row = m0 + wr * 16 * IT + 16 * (2 * ih + ii) + l15;
+                        const uint32_t row = m0 + wr * 64 + 16 * (2 * ih + ii) + l15;
                         const uint32_t rrow = (row < M ? row : M - 1) * (GW_BN / 32);
 #pragma unroll
                         for (int j = 0; j < 6; ++j) {
@@ -241,15 +233,15 @@ gemm_wide_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ W,
                 }
             } else {
 #pragma unroll
-                for (int i = 0; i < IT; ++i) {
-                    const uint32_t row = m0 + wr * 16 * IT + 16 * i + l15;
+                for (int i = 0; i < 4; ++i) {
+                    const uint32_t row = m0 + wr * 64 + 16 * i + l15;
                     // 32-bit byte offset from a uniform base (a [65536, 384] f32 tensor is 100 MB): one VGPR per row
                     const uint32_t off = ((row < M ? row : M - 1) * GW_BN + wc * 96 + 4 * g) * 4u;
 #pragma unroll
                     for (int j = 0; j < 6; ++j) acc.c[i][j] = *reinterpret_cast<const sh_f32x4*>(rbase + (size_t)(off + 64u * j));
                 }
 #pragma unroll
-                for (int i = 0; i < IT; ++i)
+                for (int i = 0; i < 4; ++i)
 #pragma unroll
                     for (int j = 0; j < 6; ++j) acc.c[i][j] = (bias_of(0, j) + acc.c[i][j]) * kShLoScale;
             }
@@ -258,7 +250,7 @@ gemm_wide_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ W,
             for (int j = 0; j < 6; ++j) {
                 const sh_f32x4 bv = bias_of(n0, j) * kShLoScale;
 #pragma unroll
-                for (int i = 0; i < IT; ++i) acc.c[i][j] = bv;
+                for (int i = 0; i < 4; ++i) acc.c[i][j] = bv;
             }
         }
         __syncthreads();  // stage 0 has landed (vmcnt(0) precedes the barrier)
@@ -272,9 +264,9 @@ gemm_wide_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ W,
                 uint32_t kn = rot + kc + 1;
                 kn = kn >= kchunks ? kn - kchunks : kn;
                 if (ABL == 5) cur = lds;  // same addresses every step: the reads hoist out of the loop (pure MFMA rate)
-                f16x8 ah[IT], al[IT];
+                f16x8 ah[4], al[4];
 #pragma unroll
-                for (int i = 0; i < IT; ++i) {
+                for (int i = 0; i < 4; ++i) {
                     ah[i] = *reinterpret_cast<const f16x8*>(cur + a_off + i * 2048 + s_hi);
                     al[i] = *reinterpret_cast<const f16x8*>(cur + a_off + i * 2048 + s_lo);
                 }
@@ -295,28 +287,23 @@ gemm_wide_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ W,
                     if (ABL == 2) {
                         asm volatile("" ::"v"(whs), "v"(wl), "v"(wh));
 #pragma unroll
-                        for (int i = 0; i < IT; ++i) asm volatile("" ::"v"(ah[i]), "v"(al[i]));
+                        for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(ah[i]), "v"(al[i]));
                     }
 #pragma unroll
-                    for (int i = 0; i < IT; ++i)
+                    for (int i = 0; i < 4; ++i)
                         if (ABL != 2) acc.c[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(whs, ah[i], acc.c[i][j], 0, 0, 0);
                     __builtin_amdgcn_sched_barrier(0);
-                    if (DMA_ON && more && G::PPJ * j < NP) dma(src, G::PPJ * j, kn, nb);
+                    if (DMA_ON && more && 2 * j < NP) dma(src, 2 * j, kn, nb);
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int i = 0; i < IT; ++i)
+                    for (int i = 0; i < 4; ++i)
                         if (ABL != 2) acc.c[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, ah[i], acc.c[i][j], 0, 0, 0);
                     __builtin_amdgcn_sched_barrier(0);
-                    if (DMA_ON && more && G::PPJ * j + 1 < NP) dma(src, G::PPJ * j + 1, kn, nb);
+                    if (DMA_ON && more && 2 * j + 1 < NP) dma(src, 2 * j + 1, kn, nb);
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int i = 0; i < IT; ++i)
+                    for (int i = 0; i < 4; ++i)
                         if (ABL != 2) acc.c[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, al[i], acc.c[i][j], 0, 0, 0);
-                    if (G::PPJ > 2) {
-                        __builtin_amdgcn_sched_barrier(0);
-                        if (DMA_ON && more && G::PPJ * j + 2 < NP) dma(src, G::PPJ * j + 2, kn, nb);
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
                     wh = whn;
                     wl = wln;
                 }
@@ -348,9 +335,7 @@ gemm_wide_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ W,
         uint32_t mx = 0;  // packed maximum of |hi| bit patterns (sh_split8)
         float* patch = reinterpret_cast<float*>(lds + ebuf * GW_STAGE + wave * 8192);  // [16 rows][100 floats]
         constexpr int PS = 100;
-        float mean[IT];
-#pragma unroll
-        for (int i = 0; i < IT; ++i) mean[i] = 0.f;
+        float mean[4] = {0.f, 0.f, 0.f, 0.f};
         float* rowstat = reinterpret_cast<float*>(lds + 2 * GW_STAGE) + 4 * GW_BM;
         if (EPI == GW_OUT_LN) {
             // One n-tile = whole rows: v = acc / 2^11 (bias and residual are in there), then LayerNorm over the 384
@@ -358,12 +343,12 @@ gemm_wide_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ W,
             constexpr float invN = 1.0f / (float)GW_BN;
             float* stats = reinterpret_cast<float*>(lds + 2 * GW_STAGE);  // [4][128] partial sums, [128] row statistic
 #pragma unroll
-            for (int i = 0; i < IT; ++i)
+            for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 6; ++j) acc.c[i][j] *= kShLoInv;
             auto reduce_rows = [&](bool second) {
 #pragma unroll
-                for (int i = 0; i < IT; ++i) {
+                for (int i = 0; i < 4; ++i) {
                     float t = 0.0f;
 #pragma unroll
                     for (int j = 0; j < 6; ++j)
@@ -374,7 +359,7 @@ gemm_wide_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ W,
                         }
                     t += __shfl_xor(t, 16, 64);
                     t += __shfl_xor(t, 32, 64);
-                    if (g == 0) stats[wc * GW_BM + wr * 16 * IT + 16 * i + l15] = t;
+                    if (g == 0) stats[wc * GW_BM + wr * 64 + 16 * i + l15] = t;
                 }
                 __syncthreads();
                 if (tid < GW_BM) {
@@ -385,14 +370,14 @@ gemm_wide_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ W,
             };
             reduce_rows(false);
 #pragma unroll
-            for (int i = 0; i < IT; ++i) mean[i] = rowstat[wr * 16 * IT + 16 * i + l15];
+            for (int i = 0; i < 4; ++i) mean[i] = rowstat[wr * 64 + 16 * i + l15];
             reduce_rows(true);
         }
 #pragma unroll
-        for (int i = 0; i < (ABL == 6 ? 0 : IT); ++i) {
+        for (int i = 0; i < (ABL == 6 ? 0 : 4); ++i) {
             // final values of strip i into the patch (row l15, columns 16 j + 4 g .. + 3)
             float inv = 1.0f;
-            if (EPI == GW_OUT_LN) inv = rowstat[wr * 16 * IT + 16 * i + l15];
+            if (EPI == GW_OUT_LN) inv = rowstat[wr * 64 + 16 * i + l15];
             // gamma / beta per strip from the block's LDS copy (held in registers across the strips they would cost the 48
             // registers the accumulators need; as global loads each strip's would sit behind the previous strip's stores
             // in the vmcnt queue and wait for them)
@@ -424,7 +409,7 @@ gemm_wide_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ W,
                 const int prow = pidx / 12, q = pidx - prow * 12;  // row of the strip, 8-column piece of the 96
                 const sh_f32x4 v0 = *reinterpret_cast<const sh_f32x4*>(patch + prow * PS + q * 8);
                 const sh_f32x4 v1 = *reinterpret_cast<const sh_f32x4*>(patch + prow * PS + q * 8 + 4);
-                const uint32_t m = wr * 16 * IT + 16 * i + prow;
+                const uint32_t m = wr * 64 + 16 * i + prow;
                 const uint32_t col = n0 + wc * 96 + q * 8;
                 const bool live = full || m0 + m < M;
                 if (EPI == SH_OUT_F32 || EPI == SH_OUT_F32_RESID || EPI == GW_OUT_LN) {
@@ -449,7 +434,7 @@ gemm_wide_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ W,
                         if (ABL == 10) {
                             // timing only (wrong addresses, same bytes): every store instruction writes 64 consecutive
                             // 16-B chunks = eight whole 128-B lines, what a line-ordered patch would give
-                            const size_t chunk = ((((size_t)(mt * ntiles + nt) * G::WAVES + wave) * IT + i) * 6 + 2 * t) * 64 + lane;
+                            const size_t chunk = ((((size_t)(mt * ntiles + nt) * G::WAVES + wave) * 4 + i) * 6 + 2 * t) * 64 + lane;
                             __builtin_nontemporal_store(hi, reinterpret_cast<f16x8*>(Cs + chunk * 8));
                             __builtin_nontemporal_store(lo, reinterpret_cast<f16x8*>(Cs + (chunk + 64) * 8));
                         } else if (ABL == 8) {  // epilogue arithmetic and LDS passes, no global stores
@@ -469,7 +454,7 @@ gemm_wide_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ W,
         }
         if (ABL == 6) {  // keep the accumulators alive without storing them
 #pragma unroll
-            for (int i = 0; i < IT; ++i)
+            for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 6; ++j) asm volatile("" ::"v"(acc.c[i][j]));
         }
@@ -555,8 +540,8 @@ static int32_t gemm_wide_launch(int epi, const _Float16* A, const _Float16* W, c
         CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wide_kernel<SH_OUT_F32_RESID, 0, WCN>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
         CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wide_kernel<SH_OUT_SPLIT_GELU, 0, WCN>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
         CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wide_kernel<SH_OUT_SPLIT, 0, WCN>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
-        if constexpr (G::CW == 4)
-            CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wide_kernel<GW_OUT_LN, 0, WCN>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
+        if constexpr (WCN == 4)
+            CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wide_kernel<GW_OUT_LN, 0, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
         int dev = 0, n = 0;
         if (hipGetDevice(&dev) == hipSuccess &&
             hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n >= 8)
@@ -570,7 +555,7 @@ static int32_t gemm_wide_launch(int epi, const _Float16* A, const _Float16* W, c
     }));
     const uint32_t mtiles = (M + GW_BM - 1) / GW_BM, ntiles = N / G::BN;
     const uint32_t slots = sh_grid_blocks(mtiles, ntiles);
-    const uint32_t resident = (uint32_t)cus * (G::CW == 4 ? 1u : 2u);  // persistent grid: every block resident
+    const uint32_t resident = (uint32_t)cus * (WCN == 4 ? 1u : 2u);  // persistent grid: every block resident
     const uint32_t grid = slots < resident ? slots : resident;
     const uint32_t kc = K / 32;
 #define GW_LAUNCH(E, V) hipLaunchKernelGGL((gemm_wide_kernel<E, V, WCN>), dim3(grid), dim3(G::THREADS), G::LDS, s, A, W, bias, resid, C, Cs, M, N, kc, d_flag, slots, ln_g, ln_b, ln_eps, ln_flags)
@@ -611,7 +596,7 @@ static int32_t gemm_wide_launch(int epi, const _Float16* A, const _Float16* W, c
     else if (epi == SH_OUT_SPLIT) GW_LAUNCH(SH_OUT_SPLIT, 0);
     else if (epi == SH_OUT_SPLIT_GELU) GW_LAUNCH(SH_OUT_SPLIT_GELU, 0);
     else if (epi == GW_OUT_LN) {
-        if constexpr (G::CW == 4) GW_LAUNCH(GW_OUT_LN, 0);
+        if constexpr (WCN == 4) GW_LAUNCH(GW_OUT_LN, 0);
         else return fail(CS_ERR_BAD_ARG, "the LayerNorm epilogue needs the 128 x 384 block");
     } else return fail(CS_ERR_BAD_ARG, "unknown epilogue %d", epi);
 #undef GW_LAUNCH
@@ -633,10 +618,6 @@ static int32_t gemm_wide_impl(int epi, const _Float16* A, const _Float16* W, con
     // r04_gemm_stagger_by_cu_ab.log code 1000, r04_gemm_role_split_ab.log)
     const int want = shape ? shape : g_gemm_wide_shape ? g_gemm_wide_shape : shape_env ? shape_env : (epi == SH_OUT_SPLIT ? 192 : 384);
     const bool big = epi == GW_OUT_LN || g_gemm_wide_ablation || (want == 384 && N % 384 == 0 && N <= (uint32_t)GW_PARAM_FLOATS);
-    // shape 1384 (diagnostics / A-B): the 128 x 384 block as FOUR waves of 128 x 96 wave tiles (GwGeom<8>)
-    if ((want == 1384 || (epi == GW_OUT_LN && (g_gemm_wide_shape == 1384 || shape_env == 1384))) && !g_gemm_wide_ablation &&
-        N % 384 == 0 && N <= (uint32_t)GW_PARAM_FLOATS)
-        return gemm_wide_launch<8>(epi, A, W, bias, resid, C, Cs, M, N, K, d_flag, s, ln_g, ln_b, ln_eps, ln_flags);
     if (big) return gemm_wide_launch<4>(epi, A, W, bias, resid, C, Cs, M, N, K, d_flag, s, ln_g, ln_b, ln_eps, ln_flags);
     return gemm_wide_launch<2>(epi, A, W, bias, resid, C, Cs, M, N, K, d_flag, s, ln_g, ln_b, ln_eps, ln_flags);
 }
