@@ -294,6 +294,7 @@ struct cs_index {
     // us per search, stream / filter): 50k rows 67 / 80, 100k 83 / 81-87, 200k 109 / 90, 400k 158 / 100, 1M 263 / 154,
     // 2M 473 / 210, 4M 889 / 320 — the filter's fixed rounds cost ~80 us, then it streams a quarter of the bytes
     uint64_t single_int8_min_rows = 150000;
+    uint64_t few_queries_min_rows = 50000;  // 2-4 queries: rows from which they take the filter (CS_FILTER_FEW_MIN_ROWS)
     uint64_t single_batched_max_rows = 1024;  // ... and one query over at most this many rows (0 = never; CS_SINGLE_BATCHED_MAX_ROWS)
     // primed streaming scan (scan.hip PRIME mode): from this k and this many rows on, a pass over
     // the first prime_rows rows bounds the list inserts of the full scan
@@ -545,7 +546,12 @@ int32_t run_search(cs_index* h, Workspace* w, const ScanPlan& plan, const float*
         (h->single_route == CS_ROUTE_FILTER ||
          (q8_serves(h) && h->n_rows >= h->single_int8_min_rows) ||
          (h->n_rows >= h->single_filter_min_rows && h->single_filter_min_k && k >= h->single_filter_min_k));
-    const bool wants_filter = (int)nq >= h->filter_min_q || single_filter ||
+    // Two to four queries over a corpus between one phase 0 and ~50,000 rows: the streaming scan (one pass per query
+    // tile) is ahead of the filter's fixed rounds (profiles/r04_batched_route_by_size.log, us per search at nq = 2, k = 25,
+    // filter / stream: 2,000 rows 37 / 45; 5,000 63 / 45; 20,000 71 / 60; 100,000 97 / 117); from five queries on the filter
+    // wins at every size (9 x 200: 41 ... 277 us against 81 ... 600 on the exact-f32 MFMA path).
+    const bool few_small = nq >= 2 && nq <= 4 && h->filter_min_q == 2 && h->n_rows > kFilterPhase0 && h->n_rows < h->few_queries_min_rows;
+    const bool wants_filter = ((int)nq >= h->filter_min_q && !few_small) || single_filter ||
                               (nq == 1 && h->n_rows <= h->single_batched_max_rows);
     const bool normed = h->n_rows > 0 && h->normed_rows >= h->n_rows;
     // Which copy filters: the int8 one when it serves; else the f16 one, built here, once, if it is not there yet; with
@@ -768,6 +774,7 @@ int32_t cs_index_create(uint32_t dim, uint64_t capacity_rows, int32_t device, ui
             if (h->single_filter_min_k == 0) h->single_route = CS_ROUTE_STREAM;
         }
         if (const char* e = std::getenv("CS_FILTER_SINGLE_MIN_ROWS")) h->single_int8_min_rows = (uint64_t)std::atoll(e);
+        if (const char* e = std::getenv("CS_FILTER_FEW_MIN_ROWS")) h->few_queries_min_rows = (uint64_t)std::atoll(e);
         if (const char* e = std::getenv("CS_SINGLE_BATCHED_MAX_ROWS")) h->single_batched_max_rows = (uint64_t)std::atoll(e);
         if (const char* e = std::getenv("CS_SCAN_PRIME_MIN_K")) h->prime_min_k = (uint32_t)std::atol(e);  // 0 = off
         if (const char* e = std::getenv("CS_SCAN_PRIME_MIN_ROWS")) h->prime_min_rows = (uint64_t)std::atoll(e);
