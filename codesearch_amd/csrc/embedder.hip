@@ -91,6 +91,7 @@ struct cs_embedder {
     uint32_t* d_perm = nullptr; // [B] destination row of each pooled row (length-sorted text mini-batches)
     std::vector<float> h_pooled; // host staging of a mini-batch's rows when they are scattered
     uint32_t last_B = 0, last_L = 0;
+    bool last_hidden_partial = false;  // the last forward ran the CLS tail: d_x holds the previous layer outside the CLS rows
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     double forward_ms = 0.0;
     uint64_t forwards = 0;
@@ -259,7 +260,15 @@ int32_t forward_range(cs_embedder* h, hipStream_t s, uint32_t b0, uint32_t nb, u
                 // embedding, 1/12 less work at 12 layers.  Compact rows live in the (idle) intermediate buffer of the slice.
                 static const bool cls_tail_on = [] { const char* e = std::getenv("CS_ENCODER_CLS_TAIL"); return !(e && e[0] == '0'); }();
                 static const uint32_t cls_tail_min = [] { const char* e = std::getenv("CS_ENCODER_CLS_TAIL_MIN_TOKENS"); return e ? (uint32_t)std::atoll(e) : 4096u; }();
-                if (cls_tail_on && c.pooling == CS_POOL_CLS && l + 1 == c.layers && T >= cls_tail_min && L >= 16) {
+                // ... where the tail's kernels and scratch fit (else the full layer, never an error): attention_cls_kernel
+                // takes <= 512 keys and head_dim 32 | 64; the compact rows (4 nb H + nb I floats) live in the slice's
+                // [T, I] intermediate buffer
+                const uint32_t dh_tail = c.heads ? H / c.heads : 0;
+                const bool cls_tail_fits = L <= 512 && (dh_tail == 32 || dh_tail == 64) && H % c.heads == 0 &&
+                                           (uint64_t)(L - 1) * I >= (uint64_t)4 * H;
+                if (l + 1 == c.layers) h->last_hidden_partial = false;
+                if (cls_tail_on && cls_tail_fits && c.pooling == CS_POOL_CLS && l + 1 == c.layers && T >= cls_tail_min && L >= 16) {
+                    h->last_hidden_partial = true;
                     float* x_cls = mid;                                            // [nb, H] f32
                     _Float16* xs_cls = reinterpret_cast<_Float16*>(mid + (size_t)nb * H);       // [nb][H/32][64]
                     _Float16* ctxs_cls = reinterpret_cast<_Float16*>(mid + (size_t)2 * nb * H);
@@ -751,15 +760,23 @@ int32_t queue_wait(cs_embedder* h, uint64_t ticket, float* out, bool out_on_devi
         }
         if (queued) flush_st = flush_queue(h, cancel);
     }
-    std::lock_guard<std::mutex> lk(h->qmu);
-    if (e->state == QueueEntry::QUEUED) return flush_st != CS_OK ? flush_st : fail(CS_ERR_HIP, "ticket was not embedded");
-    h->queue.erase(ticket);
-    if (e->state == QueueEntry::FAILED) return fail(e->error, "%s", e->error_text.c_str());
+    {
+        // the entry leaves the queue under the lock; the copy below runs WITHOUT it (a blocking copy under qmu stalled
+        // every submit / wait of other threads for its duration: ADVICE r3)
+        std::lock_guard<std::mutex> lk(h->qmu);
+        if (e->state == QueueEntry::QUEUED) return flush_st != CS_OK ? flush_st : fail(CS_ERR_HIP, "ticket was not embedded");
+        h->queue.erase(ticket);
+        if (e->state == QueueEntry::FAILED) return fail(e->error, "%s", e->error_text.c_str());
+    }
     const size_t n = e->ids.size(), H = h->cfg.hidden;
     if (n == 0) return CS_OK;
     DeviceGuard g(h->device);
-    CS_HIP(hipMemcpy(out, e->flush->d_rows + e->first_row * H, n * H * sizeof(float),
-                     out_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost));
+    // On the embedder's own stream, and waited for: the flush buffer goes back to the pool when `e` drops its reference at
+    // return, and the next flush writes it on this (non-blocking) stream — a null-stream device-to-device copy is neither
+    // ordered against that stream nor waited for by the host.
+    CS_HIP(hipMemcpyAsync(out, e->flush->d_rows + e->first_row * H, n * H * sizeof(float),
+                          out_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, h->stream));
+    CS_HIP(hipStreamSynchronize(h->stream));
     return CS_OK;
 }
 
@@ -1019,6 +1036,9 @@ int32_t cs_embedder_last_hidden(cs_embedder* h, float* out, uint64_t n_tokens) {
     if (!h || !out) return fail(CS_ERR_BAD_ARG, "null argument");
     if (n_tokens > (uint64_t)h->last_B * h->last_L)
         return fail(CS_ERR_BAD_ARG, "only %u tokens in the last mini-batch", h->last_B * h->last_L);
+    if (h->last_hidden_partial)
+        return fail(CS_ERR_UNSUPPORTED, "the last forward computed its final layer for the CLS rows only (cls_tail.hip): "
+                                        "set CS_ENCODER_CLS_TAIL=0 to read every token's last hidden state");
     DeviceGuard g(h->device);
     CS_HIP(hipStreamSynchronize(h->stream));
     CS_HIP(hipMemcpy(out, h->d_x, n_tokens * h->cfg.hidden * sizeof(float), hipMemcpyDeviceToHost));

@@ -195,6 +195,29 @@ def test_cls_tail_equals_the_full_last_layer(FE, oracle, hidden, heads, inter, l
     emb.close()
 
 
+def test_cls_tail_falls_back_to_the_full_layer_and_guards_last_hidden(FE, oracle):
+    """a CLS-pooled model whose rows are longer than the one-query attention kernel takes (512 keys) must run
+    its last layer whole instead of failing the forward; and after a forward that DID take the tail, cs_embedder_last_hidden
+    says so instead of returning the previous layer's rows."""
+    from codesearch_amd._lib import CsError
+
+    cfg = BertConfig(vocab_size=2048, layers=2, max_position=640, pooling=POOL_CLS)
+    B, L = 8, 600                                       # 4,800 tokens: above the tail's threshold, L above its limit
+    ids, mask = synth_token_batch(cfg, 77, B, L, True)
+    emb = FE(cfg, seed=12)
+    got = emb.embed_ids(ids, mask, batch_size=B)
+    ref = oracle.bert_forward(cfg, oracle.bert_synth_params(cfg, 12), ids, mask)["pooled"]
+    np.testing.assert_allclose(got, ref, atol=TOL_ORACLE)
+    hid = emb.last_hidden(B * L)                        # the full layer ran: every token's last hidden state is there
+    assert np.isfinite(hid).all()
+    ids2, mask2 = synth_token_batch(cfg, 78, 32, 256, False)   # 8,192 tokens of 256: the tail runs
+    emb.embed_ids(ids2, mask2, batch_size=32)
+    with pytest.raises(CsError) as ei:
+        emb.last_hidden(32 * 256)
+    assert "CLS rows only" in str(ei.value)
+    emb.close()
+
+
 def test_end_to_end_index_then_search_vs_oracle_pipeline(FE, oracle):
     """BASELINE configs[3] at reduced size: chunks embedded on the GPU, appended to the
     device-resident matrix without leaving HBM, batched queries, top-10 — against the same
