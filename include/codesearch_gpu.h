@@ -388,8 +388,9 @@ int32_t cs_embedder_embed_ids_device(cs_embedder* h, const int32_t* ids,
                                      const volatile int32_t* cancel);
 /* Debug/parity aid: last_hidden_state [n*seq_len, hidden] of the most recent
  * mini-batch (n <= batch), copied to host.  A CLS-pooled model whose mini-batch holds at least 4,096 tokens computes
- * only the CLS rows of its LAST layer (the only rows the embedding reads; csrc/cls_tail.hip): the other rows of this
- * buffer are then those of the layer before.  CS_ENCODER_CLS_TAIL=0 in the environment restores the full last layer. */
+ * only the CLS rows of its LAST layer (the only rows the embedding reads; csrc/cls_tail.hip): this call then returns
+ * CS_ERR_UNSUPPORTED (the buffer holds the layer before outside the CLS rows).  CS_ENCODER_CLS_TAIL=0 in the environment
+ * restores the full last layer; rows longer than 512 tokens always run it. */
 int32_t cs_embedder_last_hidden(cs_embedder* h, float* out, uint64_t n_tokens);
 int32_t cs_embedder_profile_read(cs_embedder* h, double* forward_ms, uint64_t* forwards,
                                  int32_t reset);
