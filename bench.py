@@ -1072,7 +1072,7 @@ def main():
             line["recall_at_10"] = recall
             line["max_abs_cos_err_vs_cpu"] = err
         if world == 1 and args.nq == 1 and args.route == "stream" and not args.only_scan:
-            # The DEFAULT route of the same search (CS_ROUTE_COST, index.hip run_search): one query over >= 2M rows goes
+            # The DEFAULT route of the same search (CS_ROUTE_COST, index.hip run_search): one query over >= 150,000 rows goes
             # through the MFMA filter over the int8 copy (a quarter of the f32 bytes) + exact f32 re-score — the shape of the
             # reference's MCP and HTTP searches (src/mcp/mod.rs:252, src/server/mod.rs:547).  Same bits as the streaming scan.
             def timed_single(kk, reps=50):
@@ -1104,7 +1104,7 @@ def main():
             has8, has16, fbytes = shard.store.filter_copies()
             line["default_routing_ms_per_search"] = route[f"k{args.k}"]["default_ms_per_search"]
             line["default_routing"] = {
-                "route": "CS_ROUTE_COST (default): int8 filter + exact f32 refine for one query over >= 2,000,000 rows",
+                "route": "CS_ROUTE_COST (default): int8 filter + exact f32 refine for one query over >= 150,000 rows",
                 "per_k": route,
                 "chunks_per_s": args.rows / (route[f"k{args.k}"]["default_ms_per_search"] * 1e-3),
                 "filter_copy": {2: "int8", 1: "f16", 0: "none"}[copy], "copies_in_hbm": {"int8": has8, "f16": has16},

@@ -1,4 +1,5 @@
 #!/bin/bash
+# (round 3 script, kept for the record: the fused FFN kernel and benchmarks/ffn_time.py it profiles were removed in round 4)
 # Round-3 evidence set (profiles/r03_*): run from the repo root on the GPU box; results land in gpurun_out/r03/.
 # Every rocprofv3 pass profiles ONE kernel population (bench.py --only-scan = the timed loop alone); counters are
 # collected in their own passes with --kernel-trace only.

@@ -561,7 +561,7 @@ class VectorStore:
 
     def set_single_query_route(self, route: int) -> None:
         """How one query over a large index is answered (cs_index_set_single_query_route): ROUTE_COST (default: the int8
-        filter + exact refine over >= 2M rows), ROUTE_STREAM (always the f32 streaming scan), ROUTE_FILTER.  Same bits."""
+        filter + exact refine from 150,000 rows on), ROUTE_STREAM (always the f32 streaming scan), ROUTE_FILTER.  Same bits."""
         if self.sharded:
             for g in range(int(self._lib.cs_shards_count(self._h))):
                 _lib.check(self._lib.cs_index_set_single_query_route(self.shard_handle(g), int(route)))
