@@ -942,6 +942,17 @@ def main():
 
     ids0 = out["ids"].cpu().numpy().astype("uint32").reshape(args.nq, args.k)
     cos0 = out["cos"].cpu().numpy().reshape(args.nq, args.k)
+    # N > 1: the device merge of the last timed step against a HOST merge of the keys the all-gather delivered (every
+    # rank holds all of them): the exchange and the merge kernel checked on the real data, beside the planted rows
+    merged_ok = None
+    if dist is not None and (world > 1 or force_dist):
+        import numpy as np
+
+        from codesearch_amd.sharded import merge_keys_host
+
+        gathered = out["gathered"].cpu().numpy().view(np.uint64).reshape(world, args.nq, args.k)
+        merged_ok = bool(np.array_equal(merge_keys_host(gathered, args.k),
+                                        out["keys"].cpu().numpy().view(np.uint64).reshape(args.nq, args.k)))
 
     if rank == 0:
         total_rows = args.rows * world
@@ -1051,10 +1062,14 @@ def main():
                            if dist is not None else "none (one GPU)"),
             "rccl_world_size": (dist.get_world_size() if dist is not None else None),
         }
-        if planted_ok is not None:
-            line["multi_gpu_checks"] = {"planted_query_per_shard_returns_its_row": planted_ok}
-            if not all(planted_ok):
+        if planted_ok is not None or merged_ok is not None:
+            line["multi_gpu_checks"] = {"planted_query_per_shard_returns_its_row": planted_ok,
+                                        "device_merge_equals_host_merge_of_gathered_keys": merged_ok}
+            if planted_ok is not None and not all(planted_ok):
                 line["error"] = "a shard did not return its planted row"
+            if merged_ok is False:
+                line["error"] = (line.get("error", "") + "; " if line.get("error") else "") + \
+                    "the device merge differs from the host merge of the gathered keys"
         traffic_file = os.path.join(ROOT, "profiles", "scan_traffic.json")
         if os.path.exists(traffic_file):
             try:
