@@ -47,8 +47,7 @@ int main(int argc, char** argv) {
     fill_kernel<<<2048, 256>>>(A, (size_t)M * K * 2, 1);
     fill_kernel<<<2048, 256>>>(W, (size_t)N * K * 2, 2);
     hipMemset(bias, 0, N * 4); hipMemset(resid, 0, (size_t)M * N * 4);
-    const char* te = getenv("CS_GEMM_TILE");
-    const uint32_t bm = (te && (atoi(te) == 256 || atoi(te) == 257)) ? 256 : 128;
+    const uint32_t bm = 128;
     const uint32_t blocks = cs::sh_grid_blocks((M + bm - 1) / bm, N / 128);
     unsigned long long* d_st;
     hipMalloc(&d_st, (size_t)blocks * 4 * 8);

@@ -2,10 +2,7 @@
 // operands (split_f16.hpp), SURVEY.md §8a E3.  Replaces the MHA nodes of the ONNX graph that
 // /root/reference/src/embed/embedder.rs:286-289 runs through fastembed/ort.
 //
-// One block = one (sequence, head): K and V of the head are split once into LDS
-//   Kh/Kl  [key][32 d] f16, 80-B rows (conflict-free ds_read_b128 by the 16-lane groups)
-//   Vth/Vtl [d][key]  f16, rows of 2*Lp+8 bytes (conflict-free ds_read_b64 over d)
-// and every wave walks query tiles of 32 over all key tiles of 32:
+// Every wave walks query tiles of 32 over key tiles of 32 staged in LDS (layouts at each kernel):
 //   S^T (keys x queries) = K_tile (A: [key][d]) x Q^T (B: [d][query])      6 MFMAs (2 k-steps x hh, hl, lh)
 //   softmax in the lane: the query is the lane, its 16 keys of the tile are registers; online
 //   max / sum in the exp2 domain (scores pre-multiplied by log2 e), rescale only when a max moves
@@ -13,6 +10,8 @@
 // P^T is the S^T accumulator itself: its key index sits on (register, lane half) in exactly the
 // order the next MFMA's k index wants (cdna_hip_programming.md §3, "An accumulator tile as the next
 // MFMA's operand"), so probabilities are split to f16 pairs in registers and never touch LDS.
+// Input is the QKV GEMM's split-f16 output (SH_OUT_SPLIT); round 1's kernel that took an f32 qkv and split
+// K / V itself in a converting prologue (36 % of a block's life) is no longer built.
 #include <cstdlib>
 #include "encoder.hpp"
 #include "split_f16.hpp"
@@ -27,20 +26,8 @@ namespace cs {
 
 typedef __fp16 h16x2 __attribute__((ext_vector_type(2)));
 
-constexpr int AT_KROW = 80;                    // bytes per K row in LDS (64 data + 16 pad)
 constexpr float kLog2e = 1.4426950408889634f;
 constexpr float kMaskedLog2 = -3.0e38f;        // additive mask in the exp2 domain (finite: no NaN on all-masked rows)
-
-// Two probabilities -> packed (hi, hi) and (lo, lo).  Round-toward-zero packs two conversions into
-// one instruction; the low part takes up the residual exactly as in sh_split (2^-21 relative).
-__device__ __forceinline__ void split_pair_rtz(float a, float b, uint32_t& hi, uint32_t& lo) {
-    const float as = a < kShMinNormal ? 0.0f : a;  // p >= 0
-    const float bs = b < kShMinNormal ? 0.0f : b;
-    const h16x2 h = __builtin_amdgcn_cvt_pkrtz(as, bs);
-    const h16x2 l = __builtin_amdgcn_cvt_pkrtz((a - (float)h[0]) * kShLoScale, (b - (float)h[1]) * kShLoScale);
-    hi = __builtin_bit_cast(uint32_t, h);
-    lo = __builtin_bit_cast(uint32_t, l);
-}
 
 union Frag8 {
     f16x8 v;
@@ -48,222 +35,10 @@ union Frag8 {
     uint2 d[2];
 };
 
-template <bool SPLIT_OUT>
-__global__ void __launch_bounds__(256, 2)
-attention_sh_kernel(const float* __restrict__ qkv, const int32_t* __restrict__ mask, float* __restrict__ ctx,
-                    _Float16* __restrict__ ctxs, uint32_t* __restrict__ flag, uint32_t L, uint32_t H,
-                    float scale_log2e) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const uint32_t Lp = (L + 31) & ~31u;
-    const uint32_t VS = 2 * Lp + 8;            // bytes per V^T row
-    char* Kh = smem;                           // [Lp][80]
-    char* Kl = Kh + (size_t)Lp * AT_KROW;
-    char* Vth = Kl + (size_t)Lp * AT_KROW;     // [32][VS]
-    char* Vtl = Vth + (size_t)32 * VS;
-    float* madd = reinterpret_cast<float*>(Vtl + (size_t)32 * VS);  // [Lp]
-    int* last_valid_p = reinterpret_cast<int*>(madd + Lp);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int l31 = lane & 31, h = lane >> 5;
-    const uint32_t head = blockIdx.x, b = blockIdx.y;
-    const size_t row3 = (size_t)3 * H;
-    const float* base = qkv + (size_t)b * L * row3 + head * 32;
-    bool ovf = false;
-
-    AT_STAMP(0);
-    if (tid == 0) *last_valid_p = 0;
-    __syncthreads();
-    // K: thread -> (key, 4 consecutive d).  Loads are issued four iterations at a time before any
-    // of them is converted: one HBM round trip per batch instead of one per iteration.
-    for (uint32_t idx0 = tid; idx0 < Lp * 8; idx0 += 256 * 4) {
-        sh_f32x4 kv[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const uint32_t idx = idx0 + 256 * u, key = idx >> 3, c4 = idx & 7;
-            kv[u] = sh_f32x4{0.f, 0.f, 0.f, 0.f};
-            if (key < L) kv[u] = *reinterpret_cast<const sh_f32x4*>(base + key * row3 + H + c4 * 4);
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const uint32_t idx = idx0 + 256 * u, key = idx >> 3, c4 = idx & 7;
-            if (idx >= Lp * 8) break;
-            f16x4 hi, lo;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                _Float16 a, bb;
-                ovf |= sh_split(kv[u][e], a, bb);
-                hi[e] = a; lo[e] = bb;
-            }
-            *reinterpret_cast<f16x4*>(Kh + key * AT_KROW + c4 * 8) = hi;
-            *reinterpret_cast<f16x4*>(Kl + key * AT_KROW + c4 * 8) = lo;
-        }
-    }
-    // V^T: thread -> (key pair, 4 consecutive d); one 4-byte store per (d, plane); batched likewise
-    for (uint32_t idx0 = tid; idx0 < (Lp / 2) * 8; idx0 += 256 * 2) {
-        sh_f32x4 v0[2], v1[2];
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const uint32_t idx = idx0 + 256 * u, key = 2 * (idx >> 3), c4 = idx & 7;
-            v0[u] = sh_f32x4{0.f, 0.f, 0.f, 0.f};
-            v1[u] = sh_f32x4{0.f, 0.f, 0.f, 0.f};
-            if (key < L) v0[u] = *reinterpret_cast<const sh_f32x4*>(base + key * row3 + 2 * H + c4 * 4);
-            if (key + 1 < L) v1[u] = *reinterpret_cast<const sh_f32x4*>(base + (key + 1) * row3 + 2 * H + c4 * 4);
-        }
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const uint32_t idx = idx0 + 256 * u, key = 2 * (idx >> 3), c4 = idx & 7;
-            if (idx >= (Lp / 2) * 8) break;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                f16x2 hi, lo;
-                _Float16 a, bb;
-                ovf |= sh_split(v0[u][e], a, bb); hi[0] = a; lo[0] = bb;
-                ovf |= sh_split(v1[u][e], a, bb); hi[1] = a; lo[1] = bb;
-                const uint32_t d = c4 * 4 + e;
-                *reinterpret_cast<f16x2*>(Vth + d * VS + key * 2) = hi;
-                *reinterpret_cast<f16x2*>(Vtl + d * VS + key * 2) = lo;
-            }
-        }
-    }
-    for (uint32_t key = tid; key < Lp; key += 256) {
-        const bool ok = key < L && mask[(size_t)b * L + key] != 0;
-        madd[key] = ok ? 0.0f : kMaskedLog2;
-        if (ok) atomicMax(last_valid_p, (int)key);
-    }
-    __syncthreads();
-    const uint32_t ntiles = (uint32_t)(*last_valid_p) / 32 + 1;  // trailing all-masked tiles contribute exp2(-3e38 - m) = 0
-    AT_STAMP(1);
-
-    const char* kh_lane = Kh + l31 * AT_KROW + 16 * h;
-    const char* kl_lane = Kl + l31 * AT_KROW + 16 * h;
-    const char* vh_lane = Vth + l31 * VS + 8 * h;
-    const char* vl_lane = Vtl + l31 * VS + 8 * h;
-
-    for (uint32_t qb = 0; qb * 128 < L; ++qb) {
-        const uint32_t query = qb * 128 + wave * 32 + l31;
-        if (qb * 128 + wave * 32 >= L) break;  // wave-uniform: no query of this wave's tile exists
-        // Q^T fragments (B operand): element j of step s = d 16s + 8h + j
-        Frag8 qh[2], ql[2];
-        {
-            const bool ok = query < L;
-            const float* qp = base + (size_t)(ok ? query : 0) * row3 + 8 * h;
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const sh_f32x4 t0 = *reinterpret_cast<const sh_f32x4*>(qp + 16 * s);
-                const sh_f32x4 t1 = *reinterpret_cast<const sh_f32x4*>(qp + 16 * s + 4);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    _Float16 a, bb;
-                    ovf |= sh_split(ok ? t0[e] : 0.0f, a, bb);
-                    qh[s].v[e] = a; ql[s].v[e] = bb;
-                    ovf |= sh_split(ok ? t1[e] : 0.0f, a, bb);
-                    qh[s].v[4 + e] = a; ql[s].v[4 + e] = bb;
-                }
-            }
-        }
-        sh_f32x16 ohh, oxx;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { ohh[r] = 0.0f; oxx[r] = 0.0f; }
-        float m = -__builtin_huge_valf(), lsum = 0.0f;
-
-        for (uint32_t kt = 0; kt < ntiles; ++kt) {
-            sh_f32x16 hh, xx;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { hh[r] = 0.0f; xx[r] = 0.0f; }
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const f16x8 kh = *reinterpret_cast<const f16x8*>(kh_lane + (size_t)kt * 32 * AT_KROW + 32 * s);
-                const f16x8 kl = *reinterpret_cast<const f16x8*>(kl_lane + (size_t)kt * 32 * AT_KROW + 32 * s);
-                hh = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[s].v, hh, 0, 0, 0);
-                xx = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[s].v, xx, 0, 0, 0);
-                xx = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[s].v, xx, 0, 0, 0);
-            }
-            // t[r] = log2e * (scale * S^T[key = kt*32 + (r&3) + 8*(r>>2) + 4h][query] + mask)
-            float tmax = -__builtin_huge_valf();
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const sh_f32x4 ma = *reinterpret_cast<const sh_f32x4*>(madd + kt * 32 + 8 * g + 4 * h);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int r = 4 * g + e;
-                    hh[r] = fmaf(fmaf(xx[r], kShLoInv, hh[r]), scale_log2e, ma[e]);
-                    tmax = fmaxf(tmax, hh[r]);
-                }
-            }
-            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-            if (__any(tmax > m)) {  // a running max moved somewhere in the wave: rescale (exact no-op elsewhere)
-                const float mnew = fmaxf(m, tmax);
-                const float alpha = __builtin_amdgcn_exp2f(m - mnew);
-                lsum *= alpha;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) { ohh[r] *= alpha; oxx[r] *= alpha; }
-                m = mnew;
-            }
-            float psum = 0.0f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                hh[r] = __builtin_amdgcn_exp2f(hh[r] - m);
-                psum += hh[r];
-            }
-            lsum += psum;
-            // P^T fragments: element j of step s = register 8s + j  (key 16s + 8(j>>2) + 4h + (j&3))
-            Frag8 ph[2], pl[2];
-#pragma unroll
-            for (int s = 0; s < 2; ++s)
-#pragma unroll
-                for (int w2 = 0; w2 < 4; ++w2)
-                    split_pair_rtz(hh[8 * s + 2 * w2], hh[8 * s + 2 * w2 + 1], ph[s].u[w2], pl[s].u[w2]);
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                Frag8 vh, vl;
-                const size_t ko = (size_t)(kt * 32 + 16 * s) * 2;
-                vh.d[0] = *reinterpret_cast<const uint2*>(vh_lane + ko);
-                vh.d[1] = *reinterpret_cast<const uint2*>(vh_lane + ko + 16);
-                vl.d[0] = *reinterpret_cast<const uint2*>(vl_lane + ko);
-                vl.d[1] = *reinterpret_cast<const uint2*>(vl_lane + ko + 16);
-                ohh = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh.v, ph[s].v, ohh, 0, 0, 0);
-                oxx = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh.v, pl[s].v, oxx, 0, 0, 0);
-                oxx = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl.v, ph[s].v, oxx, 0, 0, 0);
-            }
-        }
-        lsum += __shfl_xor(lsum, 32, 64);
-        const float inv = 1.0f / lsum;
-        // O^T[d = (r&3) + 8*(r>>2) + 4h][query]: 4 consecutive d per register quad
-        if (query < L) {
-            if (SPLIT_OUT) {
-                // head_dim 32 = one k-chunk of the output projection: [row][head][32 hi | 32 lo]
-                _Float16* op = ctxs + (((size_t)b * L + query) * (H / 32) + head) * 64 + 4 * h;
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    f16x4 hi, lo;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        _Float16 a, bb;
-                        ovf |= sh_split(fmaf(oxx[4 * g + e], kShLoInv, ohh[4 * g + e]) * inv, a, bb);
-                        hi[e] = a; lo[e] = bb;
-                    }
-                    *reinterpret_cast<f16x4*>(op + 8 * g) = hi;
-                    *reinterpret_cast<f16x4*>(op + 32 + 8 * g) = lo;
-                }
-            } else {
-                float* op = ctx + ((size_t)b * L + query) * H + head * 32 + 4 * h;
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    sh_f32x4 o;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] = fmaf(oxx[4 * g + e], kShLoInv, ohh[4 * g + e]) * inv;
-                    *reinterpret_cast<sh_f32x4*>(op + 8 * g) = o;
-                }
-            }
-        }
-    }
-    AT_STAMP(2);
-    if (ovf && flag) atomicOr(flag, 1u);
-}
-
-// ---- the same attention on a split-f16 qkv (the QKV GEMM's SH_OUT_SPLIT output) ------------------
+// ---- whole sequence of one (sequence, head) resident in LDS (CS_ATTN_SHX1=0; head_dim 32) ----------
 // head_dim 32 = one k-chunk, so K and V of a (token, head) are one 128-B line [32 hi | 32 lo] each,
 // exactly the layout the matrix pipe wants for K: the prologue is pure LDS-DMA (no conversion, no
-// ds_write; it was 36 % of a block's life when it split f32 K/V itself).  V stays [key][d] in LDS
+// ds_write).  V stays [key][d] in LDS
 // and is consumed as the A operand V^T through the transposing read ds_read_b64_tr_b16: per
 // 16-lane group it turns a 4-key x 16-d block into "lane d holds its 4 keys" (verified on the
 // hardware with benchmarks/tr_probe).  LDS images: K pieces (16 B) at c ^ ((key >> 1) & 7) for
@@ -276,8 +51,9 @@ union FragTr {
     s16x4 q[2];
 };
 
-// Two probabilities -> packed (hi, hi) and (lo, lo), no subnormal guard (the f16 MFMA keeps
-// subnormal inputs; cs_embedder_create verifies that once per device).
+// Two probabilities -> packed (hi, hi) and (lo, lo).  Round-toward-zero packs two conversions into one
+// instruction; the low part takes up the residual exactly as in sh_split (2^-21 relative).  No subnormal
+// guard (the f16 MFMA keeps subnormal inputs; cs_embedder_create verifies that once per device).
 __device__ __forceinline__ void split_pair_rtz_ng(float a, float b, uint32_t& hi, uint32_t& lo) {
     const h16x2 h = __builtin_amdgcn_cvt_pkrtz(a, b);
     const h16x2 l = __builtin_amdgcn_cvt_pkrtz((a - (float)h[0]) * kShLoScale, (b - (float)h[1]) * kShLoScale);
@@ -755,37 +531,6 @@ int32_t launch_attention_sh2(const _Float16* qkv_split, const int32_t* mask, voi
     }));
     hipLaunchKernelGGL(attention_sh2_kernel, dim3(heads, B), dim3(256), lds, s, qkv_split, mask,
                        static_cast<_Float16*>(ctx_split), flag, L, H, (1.0f / sqrtf(32.0f)) * kLog2e);
-    CS_HIP(hipGetLastError());
-    return CS_OK;
-}
-
-size_t attention_sh_lds_bytes(uint32_t L) {
-    const size_t Lp = (L + 31) & ~31u;
-    return 2 * Lp * AT_KROW + 2 * 32 * (2 * Lp + 8) + Lp * sizeof(float) + 16;
-}
-
-int32_t launch_attention_sh(const float* qkv, const int32_t* mask, float* ctx, void* ctx_split, uint32_t* flag,
-                            uint32_t B, uint32_t L, uint32_t H, uint32_t heads, hipStream_t s) {
-    if (H / heads != 32 || H % heads)
-        return fail(CS_ERR_UNSUPPORTED, "head_dim %u not supported (32 only in this round)", heads ? H / heads : 0);
-    const size_t lds = attention_sh_lds_bytes(L);
-    if (lds > 160 * 1024 - 64) return fail(CS_ERR_UNSUPPORTED, "sequence length %u exceeds the LDS-resident K/V limit", L);
-    static PerDeviceOnce attr_set;  // function attributes are per device
-    CS_TRY(attr_set.run([&]() -> int32_t {
-        CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attention_sh_kernel<false>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
-        CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attention_sh_kernel<true>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
-        return CS_OK;
-    }));
-    dim3 grid(heads, B);
-    const float scale_log2e = (1.0f / sqrtf(32.0f)) * kLog2e;
-    if (ctx_split)
-        hipLaunchKernelGGL(attention_sh_kernel<true>, grid, dim3(256), lds, s, qkv, mask, ctx,
-                           static_cast<_Float16*>(ctx_split), flag, L, H, scale_log2e);
-    else
-        hipLaunchKernelGGL(attention_sh_kernel<false>, grid, dim3(256), lds, s, qkv, mask, ctx,
-                           static_cast<_Float16*>(nullptr), flag, L, H, scale_log2e);
     CS_HIP(hipGetLastError());
     return CS_OK;
 }

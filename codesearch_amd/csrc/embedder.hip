@@ -247,13 +247,7 @@ int32_t forward_range(cs_embedder* h, hipStream_t s, uint32_t b0, uint32_t nb, u
         const float* bqkv = h->d_bqkv + (size_t)l * 3 * H;
         if (split) {
             const _Float16* ws = h->d_wsplit + (size_t)l * sl.total;
-            static const bool attn_v1 = std::getenv("CS_ATTN_V1") != nullptr;  // A/B: f32 qkv + converting prologue
-            if (attn_v1) {
-                CS_TRY(launch_gemm_split(SH_OUT_F32, xs, ws + sl.qkv, bqkv, nullptr, qkv, nullptr, T, 3 * H, H, h->d_flag, s));
-                CS_TRY(mark(CS_STAGE_QKV));
-                CS_TRY(launch_attention_split(qkv, mask, ctxs, h->d_flag, nb, L, H, c.heads, s));
-                CS_TRY(mark(CS_STAGE_ATTENTION));
-            } else {
+            {
                 _Float16* qkvs = reinterpret_cast<_Float16*>(qkv);  // [T][3H/32][64] f16: same bytes as the f32 qkv
                 // CLS pooling reads ONE row per sequence of the last layer: its attention needs every key and value but
                 // only the CLS query, and everything behind it runs on nb rows instead of nb * L (cls_tail.hip).  Same

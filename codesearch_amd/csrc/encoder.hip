@@ -859,14 +859,12 @@ static int32_t launch_attention_impl(const float* qkv, const int32_t* mask, floa
     CS_TRY(attr_set.run([&]() -> int32_t {
         CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attention_kernel<false>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
-        CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attention_kernel<true>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
         return CS_OK;
     }));
     dim3 grid((L + 127) / 128, heads, B);
     const float scale = 1.0f / sqrtf(32.0f);
-    if (ctxs) hipLaunchKernelGGL(attention_kernel<true>, grid, dim3(256), lds, s, qkv, mask, ctx, ctxs, flag, L, H, scale);
-    else hipLaunchKernelGGL(attention_kernel<false>, grid, dim3(256), lds, s, qkv, mask, ctx, ctxs, flag, L, H, scale);
+    if (ctxs) return fail(CS_ERR_UNSUPPORTED, "the f32 attention kernel writes f32 context rows only");
+    hipLaunchKernelGGL(attention_kernel<false>, grid, dim3(256), lds, s, qkv, mask, ctx, ctxs, flag, L, H, scale);
     CS_HIP(hipGetLastError());
     return CS_OK;
 }
@@ -874,11 +872,6 @@ static int32_t launch_attention_impl(const float* qkv, const int32_t* mask, floa
 int32_t launch_attention(const float* qkv, const int32_t* mask, float* ctx, uint32_t B, uint32_t L,
                          uint32_t H, uint32_t heads, hipStream_t s) {
     return launch_attention_impl(qkv, mask, ctx, nullptr, nullptr, B, L, H, heads, s);
-}
-
-int32_t launch_attention_split(const float* qkv, const int32_t* mask, void* ctx_split, uint32_t* flag, uint32_t B,
-                               uint32_t L, uint32_t H, uint32_t heads, hipStream_t s) {
-    return launch_attention_sh(qkv, mask, nullptr, ctx_split, flag, B, L, H, heads, s);
 }
 
 int32_t launch_synth_params(float* d_out, const cs_bert_config& cfg, uint64_t seed, hipStream_t s) {

@@ -38,15 +38,8 @@ int32_t launch_gemm(int epi, const float* A, const float* W, const float* bias, 
 // qkv [B*L, 3H] (Q | K | V), mask [B, L] -> ctx [B*L, H]
 int32_t launch_attention(const float* qkv, const int32_t* mask, float* ctx, uint32_t B, uint32_t L,
                          uint32_t H, uint32_t heads, hipStream_t s);
-// ctx_split (optional, instead of ctx): the context in split-f16 form for the output projection
-int32_t launch_attention_split(const float* qkv, const int32_t* mask, void* ctx_split, uint32_t* flag, uint32_t B,
-                               uint32_t L, uint32_t H, uint32_t heads, hipStream_t s);
 size_t attention_lds_bytes(uint32_t L);
-// attention_split.hip: the same attention on the f16 MFMA with split-f16 operands; writes ctx (f32)
-// or, when ctx_split is given, the split form.
-int32_t launch_attention_sh(const float* qkv, const int32_t* mask, float* ctx, void* ctx_split, uint32_t* flag,
-                            uint32_t B, uint32_t L, uint32_t H, uint32_t heads, hipStream_t s);
-size_t attention_sh_lds_bytes(uint32_t L);
+// attention_split.hip: the same attention on the f16 MFMA with split-f16 operands:
 // attention on a split-f16 qkv [T][3H/32][64] (the QKV GEMM's SH_OUT_SPLIT output): K/V go to LDS by
 // LDS-DMA with no conversion, V is consumed through the transposing LDS read; writes ctx in split form.
 int32_t launch_attention_sh2(const _Float16* qkv_split, const int32_t* mask, void* ctx_split, uint32_t* flag,

@@ -19,11 +19,6 @@
 #define SH_STAMP(i)
 #endif
 
-// Diagnostic builds may pad the dynamic LDS request (-DSH_LDS_LAUNCH_BYTES=...) to force one block per CU.
-#ifndef SH_LDS_LAUNCH_BYTES
-#define SH_LDS_LAUNCH_BYTES SH_LDS_BYTES
-#endif
-
 namespace cs {
 
 // erf-GELU.  ocml's erff costs ~34 VALU instructions per element with both of its branches taken in
@@ -124,32 +119,6 @@ __device__ __forceinline__ void gemm_sh_epilogue(const float* ctile, const float
     }
 }
 
-template <int EPI>
-__global__ void __launch_bounds__(256, 2)
-gemm_sh_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ W,
-               const float* __restrict__ bias, const float* resid, float* C,
-               _Float16* __restrict__ Cs, uint32_t M, uint32_t N, uint32_t kchunks,
-               uint32_t* __restrict__ flag) {
-    extern __shared__ __attribute__((aligned(16))) char lds[];
-    uint32_t mt, nt;
-    if (!sh_tile_of_block(blockIdx.x, (M + SH_BM - 1) / SH_BM, N / SH_BN, mt, nt)) return;
-    const uint32_t m0 = mt * SH_BM, n0 = nt * SH_BN;
-    SH_STAMP(0);
-    ShAcc acc;
-    sh_acc_zero(acc);
-    sh_mainloop(A, M, m0, W, N, n0, kchunks, lds, acc, sh_kc_rot(nt, N / SH_BN, kchunks));
-    SH_STAMP(1);
-    float* ctile = reinterpret_cast<float*>(lds);
-    sh_acc_to_lds(acc, ctile);
-    SH_STAMP(2);
-
-    // Full tiles take a branch-free path (a per-row `if (row < M)` makes hipcc drain vmcnt
-    // around every store); the ragged last m-tile takes the guarded one.
-    if (m0 + SH_BM <= M) gemm_sh_epilogue<EPI, true, 2>(ctile, bias, resid, C, Cs, M, N, m0, n0, flag);
-    else gemm_sh_epilogue<EPI, false, 2>(ctile, bias, resid, C, Cs, M, N, m0, n0, flag);
-    SH_STAMP(3);
-}
-
 // 128 x 128 tiles on v_mfma_f32_16x16x32_f16 (sh_mainloop16), two blocks per CU.
 template <int EPI>
 __global__ void __launch_bounds__(256, 2)
@@ -177,32 +146,6 @@ gemm_sh16_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ W,
     SH_STAMP(2);
     if (m0 + SH_BM <= M) gemm_sh_epilogue<EPI, true, 2>(ctile, bias, resid, C, Cs, M, N, m0, n0, flag);
     else gemm_sh_epilogue<EPI, false, 2>(ctile, bias, resid, C, Cs, M, N, m0, n0, flag);
-    SH_STAMP(3);
-}
-
-// 256 x 128 tiles, 8 waves, 3-stage LDS-DMA ring (sh_mainloop3<4>), one block per CU.
-template <int EPI, bool IL = false>
-__global__ void __launch_bounds__(512, 2)
-gemm_sh3_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ W,
-                const float* __restrict__ bias, const float* resid, float* C,
-                _Float16* __restrict__ Cs, uint32_t M, uint32_t N, uint32_t kchunks,
-                uint32_t* __restrict__ flag) {
-    extern __shared__ __attribute__((aligned(16))) char lds[];
-    using G = ShGeom<4>;
-    uint32_t mt, nt;
-    if (!sh_tile_of_block(blockIdx.x, (M + G::BM - 1) / G::BM, N / SH_BN, mt, nt)) return;
-    const uint32_t m0 = mt * G::BM, n0 = nt * SH_BN;
-    SH_STAMP(0);
-    ShAcc acc;
-    sh_acc_zero(acc);
-    if (IL) sh_mainloop3i<4>(A, M, m0, W, N, n0, kchunks, lds, acc, sh_kc_rot(nt, N / SH_BN, kchunks));
-    else sh_mainloop3<4>(A, M, m0, W, N, n0, kchunks, lds, acc, sh_kc_rot(nt, N / SH_BN, kchunks));
-    SH_STAMP(1);
-    float* ctile = reinterpret_cast<float*>(lds);  // [256][128] f32 = 128 KiB of the 144 KiB ring
-    sh_acc_to_lds(acc, ctile);
-    SH_STAMP(2);
-    if (m0 + G::BM <= M) gemm_sh_epilogue<EPI, true, 4>(ctile, bias, resid, C, Cs, M, N, m0, n0, flag);
-    else gemm_sh_epilogue<EPI, false, 4>(ctile, bias, resid, C, Cs, M, N, m0, n0, flag);
     SH_STAMP(3);
 }
 
@@ -401,14 +344,6 @@ int32_t launch_gemm_split(int epi, const _Float16* A, const _Float16* W, const f
                           hipStream_t s) {
     if (N % SH_BN || K % 32) return fail(CS_ERR_UNSUPPORTED, "split GEMM N=%u K=%u must be multiples of 128/32", N, K);
     if (M == 0) return CS_OK;
-    static PerDeviceOnce attr_set;  // function attributes are per device
-    CS_TRY(attr_set.run([&]() -> int32_t {
-        CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_sh_kernel<SH_OUT_F32>), hipFuncAttributeMaxDynamicSharedMemorySize, SH_LDS_LAUNCH_BYTES));
-        CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_sh_kernel<SH_OUT_F32_RESID>), hipFuncAttributeMaxDynamicSharedMemorySize, SH_LDS_LAUNCH_BYTES));
-        CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_sh_kernel<SH_OUT_SPLIT_GELU>), hipFuncAttributeMaxDynamicSharedMemorySize, SH_LDS_LAUNCH_BYTES));
-        CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_sh_kernel<SH_OUT_SPLIT>), hipFuncAttributeMaxDynamicSharedMemorySize, SH_LDS_LAUNCH_BYTES));
-        return CS_OK;
-    }));
     const uint32_t kc = K / 32;
     static int skinny_max_m = -1;
     if (skinny_max_m < 0) {
@@ -438,15 +373,7 @@ int32_t launch_gemm_split(int epi, const _Float16* A, const _Float16* W, const f
         CS_HIP(hipGetLastError());
         return CS_OK;
     }
-    static int tile = -1;
-    if (tile < 0) {
-        // 16 (default): 128x128 tiles on v_mfma_f32_16x16x32_f16, 2 blocks/CU; 128: the same tiles on the 32x32x16
-        // MFMA; 256: 256x128, 3-stage ring; 257: the same with the DMA issue interleaved
-        const char* e = std::getenv("CS_GEMM_TILE");
-        const int v = e ? std::atoi(e) : 16;
-        tile = (v == 256 || v == 257 || v == 128) ? v : 16;
-    }
-    if (tile == 16) {  // 128 x 128 tiles on the 16x16x32 MFMA
+    {  // 128 x 128 tiles on the 16x16x32 MFMA
         static PerDeviceOnce attr16;  // function attributes are per device
         CS_TRY(attr16.run([&]() -> int32_t {
             CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_sh16_kernel<SH_OUT_F32>), hipFuncAttributeMaxDynamicSharedMemorySize, SH_LDS_BYTES));
@@ -463,49 +390,6 @@ int32_t launch_gemm_split(int epi, const _Float16* A, const _Float16* W, const f
         CS_HIP(hipGetLastError());
         return CS_OK;
     }
-    if (tile == 257) {  // 256 x 128 tiles, 3-stage ring, LDS-DMA issue spread through the MFMA stream
-        using G = ShGeom<4>;
-        static PerDeviceOnce attr3i;  // function attributes are per device
-        CS_TRY(attr3i.run([&]() -> int32_t {
-            CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_sh3_kernel<SH_OUT_F32, true>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
-            CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_sh3_kernel<SH_OUT_F32_RESID, true>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
-            CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_sh3_kernel<SH_OUT_SPLIT_GELU, true>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
-            CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_sh3_kernel<SH_OUT_SPLIT, true>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
-            return CS_OK;
-        }));
-        const dim3 grid3(sh_grid_blocks((M + G::BM - 1) / G::BM, N / SH_BN));
-        if (epi == SH_OUT_F32) hipLaunchKernelGGL((gemm_sh3_kernel<SH_OUT_F32, true>), grid3, dim3(G::THREADS), G::LDS, s, A, W, bias, resid, C, Cs, M, N, kc, d_flag);
-        else if (epi == SH_OUT_F32_RESID) hipLaunchKernelGGL((gemm_sh3_kernel<SH_OUT_F32_RESID, true>), grid3, dim3(G::THREADS), G::LDS, s, A, W, bias, resid, C, Cs, M, N, kc, d_flag);
-        else if (epi == SH_OUT_SPLIT) hipLaunchKernelGGL((gemm_sh3_kernel<SH_OUT_SPLIT, true>), grid3, dim3(G::THREADS), G::LDS, s, A, W, bias, resid, C, Cs, M, N, kc, d_flag);
-        else hipLaunchKernelGGL((gemm_sh3_kernel<SH_OUT_SPLIT_GELU, true>), grid3, dim3(G::THREADS), G::LDS, s, A, W, bias, resid, C, Cs, M, N, kc, d_flag);
-        CS_HIP(hipGetLastError());
-        return CS_OK;
-    }
-    if (tile == 256) {
-        using G = ShGeom<4>;
-        static PerDeviceOnce attr3;  // function attributes are per device
-        CS_TRY(attr3.run([&]() -> int32_t {
-            CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_sh3_kernel<SH_OUT_F32>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
-            CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_sh3_kernel<SH_OUT_F32_RESID>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
-            CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_sh3_kernel<SH_OUT_SPLIT_GELU>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
-            CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_sh3_kernel<SH_OUT_SPLIT>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
-            return CS_OK;
-        }));
-        const dim3 grid3(sh_grid_blocks((M + G::BM - 1) / G::BM, N / SH_BN));
-        if (epi == SH_OUT_F32) hipLaunchKernelGGL(gemm_sh3_kernel<SH_OUT_F32>, grid3, dim3(G::THREADS), G::LDS, s, A, W, bias, resid, C, Cs, M, N, kc, d_flag);
-        else if (epi == SH_OUT_F32_RESID) hipLaunchKernelGGL(gemm_sh3_kernel<SH_OUT_F32_RESID>, grid3, dim3(G::THREADS), G::LDS, s, A, W, bias, resid, C, Cs, M, N, kc, d_flag);
-        else if (epi == SH_OUT_SPLIT) hipLaunchKernelGGL(gemm_sh3_kernel<SH_OUT_SPLIT>, grid3, dim3(G::THREADS), G::LDS, s, A, W, bias, resid, C, Cs, M, N, kc, d_flag);
-        else hipLaunchKernelGGL(gemm_sh3_kernel<SH_OUT_SPLIT_GELU>, grid3, dim3(G::THREADS), G::LDS, s, A, W, bias, resid, C, Cs, M, N, kc, d_flag);
-        CS_HIP(hipGetLastError());
-        return CS_OK;
-    }
-    const dim3 grid(sh_grid_blocks((M + SH_BM - 1) / SH_BM, N / SH_BN));
-    if (epi == SH_OUT_F32) hipLaunchKernelGGL(gemm_sh_kernel<SH_OUT_F32>, grid, dim3(256), SH_LDS_LAUNCH_BYTES, s, A, W, bias, resid, C, Cs, M, N, kc, d_flag);
-    else if (epi == SH_OUT_F32_RESID) hipLaunchKernelGGL(gemm_sh_kernel<SH_OUT_F32_RESID>, grid, dim3(256), SH_LDS_LAUNCH_BYTES, s, A, W, bias, resid, C, Cs, M, N, kc, d_flag);
-    else if (epi == SH_OUT_SPLIT) hipLaunchKernelGGL(gemm_sh_kernel<SH_OUT_SPLIT>, grid, dim3(256), SH_LDS_LAUNCH_BYTES, s, A, W, bias, resid, C, Cs, M, N, kc, d_flag);
-    else hipLaunchKernelGGL(gemm_sh_kernel<SH_OUT_SPLIT_GELU>, grid, dim3(256), SH_LDS_LAUNCH_BYTES, s, A, W, bias, resid, C, Cs, M, N, kc, d_flag);
-    CS_HIP(hipGetLastError());
-    return CS_OK;
 }
 
 // Split-K form of C = A W^T for layers whose K walk is what bounds them (FFN-down at a few thousand token

@@ -193,7 +193,7 @@ gemm_wide_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ W,
     if (ABL == 7) { t_clk = __builtin_amdgcn_s_memtime(); t_real = __builtin_amdgcn_s_memrealtime(); t_mark = t_clk; }
     while (slot < total_slots) {
         const uint32_t m0 = mt * GW_BM, n0 = nt * GW_BN;
-        const uint32_t rot = sh_kc_rot(nt, ntiles, kchunks);  // see sh_mainloop: n-tiles of an m-tile walk K out of phase
+        const uint32_t rot = sh_kc_rot(nt, ntiles, kchunks);  // see sh_mainloop16: n-tiles of an m-tile walk K out of phase
         GwAcc acc;
         // The accumulators START at bias * 2^11 (LayerNorm: (bias + residual) * 2^11), the scale the products arrive on: the
         // epilogue needs neither registers nor loads for them.

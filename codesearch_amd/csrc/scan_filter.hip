@@ -324,7 +324,7 @@ unit_f16_rows_kernel(const float* __restrict__ src, const float* __restrict__ ro
 }
 
 // 128 x 128 x 64 tile main loop on plain f16 operands: the staging, LDS image and swizzle of
-// sh_mainloop (split_f16.hpp) — a stage is one 128-B line per row — but the line holds 64
+// sh_mainloop16 (split_f16.hpp) — a stage is one 128-B line per row — but the line holds 64
 // consecutive k of one f16 plane, so a stage is four MFMA k-steps into ONE accumulator set.
 __device__ __forceinline__ void uf_mainloop(const _Float16* __restrict__ A, uint32_t M, uint32_t m0,
                                             const _Float16* __restrict__ W, uint32_t N, uint32_t n0,
@@ -441,175 +441,18 @@ score_filter_kernel(const _Float16* __restrict__ corpus_h, uint64_t row_lo, uint
 // bounds these kernels, not the matrix pipe.  One block per CU (2 x 64 KiB stages).
 constexpr int UF2_BM = 256, UF2_BN = 256, UF2_TILE = 256 * 128, UF2_STAGE = 2 * UF2_TILE, UF2_LDS = 2 * UF2_STAGE;
 
-template <bool LEGACY>
-__global__ void __launch_bounds__(512, 2)
-score_filter256_kernel(const _Float16* __restrict__ corpus_h, uint64_t row_lo, uint64_t row_hi, uint32_t kchunks,
-                       const _Float16* __restrict__ queries_h, uint32_t nq, const float* __restrict__ tau,
-                       const uint32_t* __restrict__ dead, uint32_t* __restrict__ cand,
-                       uint32_t* __restrict__ cnt, uint32_t cap, float margin) {
-    extern __shared__ __attribute__((aligned(16))) char lds[];
-    const uint32_t M = (uint32_t)(row_hi - row_lo);
-    const uint32_t ntiles = (nq + UF2_BN - 1) / UF2_BN;
-    uint32_t mt, nt;
-    if (!sh_tile_of_block(blockIdx.x, (M + UF2_BM - 1) / UF2_BM, ntiles, mt, nt)) return;
-    const uint32_t m0 = mt * UF2_BM, n0 = nt * UF2_BN;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave >> 1, wc = wave & 1;
-    const int l31 = lane & 31, h = lane >> 5;
-    const _Float16* A = corpus_h + uf_tiled_off(row_lo, 0, kchunks);  // row_lo is a multiple of 128
-
-    const _Float16* asrc[4];
-    const _Float16* wsrc[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row = wave * 32 + i * 8 + (lane >> 3);
-        const int c = (lane & 7) ^ ((row >> 1) & 7);
-        const uint32_t wn = (n0 + row < nq) ? n0 + row : nq - 1;
-        asrc[i] = A + uf_tiled_off(m0 + row, 0, kchunks) + c * 8;  // padded tiles: no row clamp needed
-        wsrc[i] = queries_h + (size_t)wn * kchunks * 64 + c * 8;
-    }
-    auto stage = [&](uint32_t kc, char* buf) {
-        char* dst = buf + wave * 32 * 128;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            sh_glds16(asrc[i] + (size_t)kc * 128 * 64, dst + i * 1024);
-            sh_glds16(wsrc[i] + (size_t)kc * 64, dst + UF2_TILE + i * 1024);
-        }
-    };
-    const int swz = (l31 >> 1) & 7;
-    const int arow = (wr * 64 + l31) * 128, wrow = UF2_TILE + (wc * 128 + l31) * 128;
-    int sl[4];
-#pragma unroll
-    for (int s = 0; s < 4; ++s) sl[s] = ((2 * s + h) ^ swz) * 16;
-
-    sh_f32x16 acc[2][4];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-
-    uint32_t kr = sh_kc_rot(nt, ntiles, kchunks);
-    auto next_chunk = [&]() { const uint32_t c = kr; kr = kr + 1 == kchunks ? 0 : kr + 1; return c; };
-    stage(next_chunk(), lds);
-    __syncthreads();
-    if (LEGACY) {  // A/B (CS_FILTER256_LEGACY): every DMA of the next stage issued back to back at the top of the step
-    for (uint32_t kc = 0; kc < kchunks; ++kc) {
-        char* cur = lds + (kc & 1) * UF2_STAGE;
-        if (kc + 1 < kchunks) stage(next_chunk(), lds + ((kc + 1) & 1) * UF2_STAGE);
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            f16x8 a[2], w[4];
-#pragma unroll
-            for (int t = 0; t < 2; ++t) a[t] = *reinterpret_cast<const f16x8*>(cur + arow + t * 32 * 128 + sl[s]);
-#pragma unroll
-            for (int t = 0; t < 4; ++t) w[t] = *reinterpret_cast<const f16x8*>(cur + wrow + t * 32 * 128 + sl[s]);
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i], w[j], acc[i][j], 0, 0, 0);
-        }
-        __syncthreads();
-    }
-    } else {
-    // The wave's eight LDS-DMA instructions of the NEXT stage go out one at a time between the MFMAs of
-    // the first two k16 sub-steps of this one (an LDS-DMA costs its wave ~35+ cycles of issue while the
-    // CU's address path accepts it: issued back to back at the top of the step, with all eight waves doing
-    // the same, they hold the matrix pipe idle for about as long as the step's MFMAs take; see the ablation
-    // table in DESIGN.md §3.3).  Fragment reads are explicit asm with counted lgkmcnt, double-buffered
-    // across the sub-steps of a stage.
-    const uint32_t lds_base = (uint32_t)(uintptr_t)lds;
-    struct Frags { f16x8 a[2], w[4]; };
-    auto load_frags = [&](uint32_t stage_off, int s, Frags& f) {
-        const uint32_t aa = lds_base + stage_off + arow + sl[s], ww = lds_base + stage_off + wrow + sl[s];
-        asm volatile("ds_read_b128 %0, %1" : "=v"(f.a[0]) : "v"(aa));
-        asm volatile("ds_read_b128 %0, %1" : "=v"(f.w[0]) : "v"(ww));
-        asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(f.w[1]) : "v"(ww));
-        asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(f.a[1]) : "v"(aa));
-        asm volatile("ds_read_b128 %0, %1 offset:8192" : "=v"(f.w[2]) : "v"(ww));
-        asm volatile("ds_read_b128 %0, %1 offset:12288" : "=v"(f.w[3]) : "v"(ww));
-    };
-#define UF2_LGKM_WAIT(N)                                           \
-    do {                                                           \
-        asm volatile("s_waitcnt lgkmcnt(" #N ")" ::: "memory");    \
-        __builtin_amdgcn_sched_barrier(0);                         \
-    } while (0)
-    // eight MFMAs of one k16 sub-step; with `issue`, DMA pieces q0..q0+3 of the next stage after MFMAs 2, 4, 6, 8
-    auto mfma8 = [&](const Frags& f, bool issue, int q0, uint32_t kcn, char* nbuf) {
-        char* dst = nbuf + wave * 32 * 128;
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            const int i = p >> 1, j0 = (p & 1) * 2;
-            acc[i][j0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.a[i], f.w[j0], acc[i][j0], 0, 0, 0);
-            acc[i][j0 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.a[i], f.w[j0 + 1], acc[i][j0 + 1], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            if (issue) {
-                const int q = q0 + p;  // pieces 0..3: corpus rows, 4..7: queries
-                if (q < 4) sh_glds16(asrc[q] + (size_t)kcn * 128 * 64, dst + q * 1024);
-                else sh_glds16(wsrc[q - 4] + (size_t)kcn * 64, dst + UF2_TILE + (q - 4) * 1024);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    };
-    Frags f0, f1;
-    load_frags(0, 0, f0);
-    for (uint32_t kc = 0; kc < kchunks; ++kc) {
-        const uint32_t so = (kc & 1) * UF2_STAGE;
-        char* nbuf = lds + ((kc + 1) & 1) * UF2_STAGE;
-        const bool more = kc + 1 < kchunks;
-        const uint32_t kcn = more ? next_chunk() : 0;
-        load_frags(so, 1, f1);
-        UF2_LGKM_WAIT(6);
-        mfma8(f0, more, 0, kcn, nbuf);
-        load_frags(so, 2, f0);
-        UF2_LGKM_WAIT(6);
-        mfma8(f1, more, 4, kcn, nbuf);
-        load_frags(so, 3, f1);
-        UF2_LGKM_WAIT(6);
-        mfma8(f0, false, 0, 0, nbuf);
-        UF2_LGKM_WAIT(0);  // this wave's last reads of the stage are back
-        sh_wait_vmcnt<0>();  // ... and its pieces of the next stage have landed
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-        if (more) load_frags(so ^ UF2_STAGE, 0, f0);
-        __builtin_amdgcn_sched_barrier(0);
-        mfma8(f1, false, 0, 0, nbuf);
-    }
-#undef UF2_LGKM_WAIT
-    }
-
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const uint32_t q = n0 + wc * 128 + j * 32 + l31;
-        const bool qok = q < nq;
-        const float tq = qok ? tau[q] - margin : 0.0f;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const uint32_t m = m0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (qok && m < M && !(acc[i][j][r] <= tq)) {
-                    const uint64_t row = row_lo + m;
-                    if (!dead || !((dead[row >> 5] >> (row & 31)) & 1u)) {
-                        const uint32_t pos = atomicAdd(&cnt[(size_t)q * kCntStride], 1u);
-                        if (pos < cap) cand[2 * ((size_t)q * cap + pos)] = (uint32_t)row;  // low word of the 8-byte slot
-                    }
-                }
-            }
-        }
-    }
-}
-
 // ---- the 256 x 256 tiles as a persistent kernel with cross-tile prefetch ------------------------------
 // dim 384 is only six 64-k stages per tile, and with one block per CU (128 KiB of LDS) nothing covers a
 // tile's first stage (an HBM round trip when the corpus rows are cold) or its epilogue.  Here a block
 // walks tiles b, b + grid, ... (same XCD, consecutive tile slots: the XCD-shared walk of
 // sh_tile_of_block is kept) and issues stage 0 of its NEXT tile between the MFMAs of the current
 // tile's last stage, into the buffer that stage leaves free; the threshold epilogue then runs under
-// that load.  Main loop as in score_filter256_kernel<false> (DMA issue spread through the MFMAs).
+// that load.  The wave's eight LDS-DMA instructions of the NEXT stage go out one at a time between the MFMAs of
+// this one (an LDS-DMA costs its wave ~35+ cycles of issue while the CU's address path accepts it: issued back
+// to back at the top of the step, with all eight waves doing the same, they hold the matrix pipe idle for about
+// as long as the step's MFMAs take; see the ablation table in DESIGN.md §3.3).  Fragment reads are explicit asm
+// with counted lgkmcnt, double-buffered across the sub-steps of a stage.  (The one-block-per-tile form of this
+// kernel and its DMAs-at-step-start variant, rounds 1-2, are no longer built.)
 //
 // I8: the same kernel over the int8 copy ("int8 filter copy" above).  A 128-B line is 128 k instead of 64, the MFMA is
 // v_mfma_i32_16x16x64_i8 on the same 16-B fragments — every address below is unchanged, with kchunks = dim / 128 and
@@ -1619,10 +1462,6 @@ static int32_t scan_split_impl(const BatchedState& st, const SplitQueryWs& qw, c
     CS_TRY(attr_set.run([&]() -> int32_t {
         CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(score_filter_kernel),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, SH_LDS_BYTES));
-        CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(score_filter256_kernel<false>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, UF2_LDS));
-        CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(score_filter256_kernel<true>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, UF2_LDS));
         CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(score_filter256p_kernel<false>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, UF2_LDS));
         CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(score_filter256p_kernel<true>),
@@ -1878,30 +1717,19 @@ static int32_t scan_split_impl(const BatchedState& st, const SplitQueryWs& qw, c
 #undef CS_RW_LAUNCH
             } else if (wide) {
                 const uint32_t mt2 = (uint32_t)((hi - lo + UF2_BM - 1) / UF2_BM), nt2 = (nq + UF2_BN - 1) / UF2_BN;
-                static const bool legacy256 = std::getenv("CS_FILTER256_LEGACY") != nullptr;
-                static const bool tile256 = std::getenv("CS_FILTER256_TILEWISE") != nullptr;  // A/B: one block per tile
-                if (!legacy256 && !tile256) {
-                    static int cus = 0;
-                    if (!cus) {
-                        int dev = 0;
-                        hipDeviceProp_t prop;
-                        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
-                            cus = prop.multiProcessorCount;
-                        if (cus <= 0) cus = 256;
-                    }
-                    const uint32_t slots = sh_grid_blocks(mt2, nt2);
-                    const uint32_t grid = std::min<uint32_t>(slots, ((uint32_t)cus + 7) / 8 * 8);  // a multiple of 8: a block stays on its XCD slot
-                    hipLaunchKernelGGL(score_filter256p_kernel<false>, dim3(grid), dim3(512), UF2_LDS, stream, d_split, lo, hi,
-                                       dim / 64, qw.d_qsplit, nq, st.d_tau, d_dead, cand, st.d_cnt, cap, slots, margin,
-                                       (const float4*)nullptr, (const float4*)nullptr);
-                } else if (legacy256)
-                    hipLaunchKernelGGL(score_filter256_kernel<true>, dim3(sh_grid_blocks(mt2, nt2)), dim3(512), UF2_LDS,
-                                       stream, d_split, lo, hi, dim / 64, qw.d_qsplit, nq, st.d_tau, d_dead, cand,
-                                       st.d_cnt, cap, margin);
-                else
-                    hipLaunchKernelGGL(score_filter256_kernel<false>, dim3(sh_grid_blocks(mt2, nt2)), dim3(512), UF2_LDS,
-                                       stream, d_split, lo, hi, dim / 64, qw.d_qsplit, nq, st.d_tau, d_dead, cand,
-                                       st.d_cnt, cap, margin);
+                static int cus = 0;
+                if (!cus) {
+                    int dev = 0;
+                    hipDeviceProp_t prop;
+                    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+                        cus = prop.multiProcessorCount;
+                    if (cus <= 0) cus = 256;
+                }
+                const uint32_t slots = sh_grid_blocks(mt2, nt2);
+                const uint32_t grid = std::min<uint32_t>(slots, ((uint32_t)cus + 7) / 8 * 8);  // a multiple of 8: a block stays on its XCD slot
+                hipLaunchKernelGGL(score_filter256p_kernel<false>, dim3(grid), dim3(512), UF2_LDS, stream, d_split, lo, hi,
+                                   dim / 64, qw.d_qsplit, nq, st.d_tau, d_dead, cand, st.d_cnt, cap, slots, margin,
+                                   (const float4*)nullptr, (const float4*)nullptr);
             } else {
                 const uint32_t mtiles = (uint32_t)((hi - lo + SH_BM - 1) / SH_BM);
                 hipLaunchKernelGGL(score_filter_kernel, dim3(sh_grid_blocks(mtiles, ntiles)), dim3(256), SH_LDS_BYTES,
