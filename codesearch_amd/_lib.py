@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("CS_LIBCSGPU") or os.path.join(PKG_DIR, "libcsgpu.so")
 
 CS_OK, CS_ERR_BAD_ARG, CS_ERR_DIM_MISMATCH, CS_ERR_NOT_BUILT = 0, 1, 2, 3
 CS_ERR_CANCELLED, CS_ERR_OOM, CS_ERR_HIP, CS_ERR_UNSUPPORTED = 4, 5, 6, 7
-CS_GEMM_F32, CS_GEMM_SPLIT_F16 = 0, 1
+CS_GEMM_F32, CS_GEMM_SPLIT_F16, CS_GEMM_Q8_DYNAMIC = 0, 1, 2
 CS_MAX_K = 1024
 CS_MAX_QUERIES = 4096
 
@@ -107,6 +107,10 @@ SIGNATURES = {
     "cs_bert_config_bge_small": (None, [C.POINTER(BertConfig)]),
     "cs_bert_param_count": (C.c_uint64, [C.POINTER(BertConfig)]),
     "cs_embedder_create": (C.c_int32, [C.POINTER(BertConfig), f32p, C.c_uint64, C.c_int32, C.POINTER(vp)]),
+    "cs_embedder_create_quantized": (C.c_int32, [C.POINTER(BertConfig), f32p, f32p, C.c_uint64, C.c_int32, C.POINTER(vp)]),
+    "cs_bert_quant_columns": (C.c_uint64, [C.POINTER(BertConfig)]),
+    "cs_bert_params_from_onnx_q": (C.c_int32, [C.c_char_p, C.POINTER(BertConfig), f32p, C.c_uint64, f32p, C.c_uint64,
+                                               C.POINTER(C.c_int32)]),
     "cs_bert_config_from_dir": (C.c_int32, [C.c_char_p, C.c_int32, C.POINTER(BertConfig)]),
     "cs_bert_params_from_safetensors": (C.c_int32, [C.c_char_p, C.POINTER(BertConfig), f32p, C.c_uint64]),
     "cs_bert_params_from_onnx": (C.c_int32, [C.c_char_p, C.POINTER(BertConfig), f32p, C.c_uint64]),
@@ -154,6 +158,8 @@ SIGNATURES = {
     "cs_embedders_index_ids": (C.c_int32, [vp, vp, i32p, i32p, C.c_uint64, C.c_uint32, C.c_uint32, u32p, i32p]),
     "cs_debug_gemm_time": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                        C.c_int32, f64p]),
+    "cs_debug_gemm_q8": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32, f32p, f32p, f32p, f32p, f32p, f32p, C.c_uint32,
+                                     C.c_uint32, C.c_uint32, C.POINTER(C.c_uint8), f32p, i32p]),
     "cs_debug_gemm": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32, f32p, f32p, f32p, f32p, f32p,
                                   C.c_uint32, C.c_uint32, C.c_uint32, u32p]),
 }

@@ -160,3 +160,58 @@ def load_checkpoint(path: str, cfg: BertConfig) -> np.ndarray:
     else:
         raise ValueError("expected a .safetensors or .npz checkpoint")
     return from_state_dict(cfg, sd)
+
+
+# ---- dynamic-quantised Linear layers (the registry's *Q models) ------------------------------------
+
+LINEAR_ROLES = ("attention.self.query", "attention.self.key", "attention.self.value", "attention.output.dense",
+                "intermediate.dense", "output.dense")
+
+
+def quant_columns(cfg: BertConfig) -> int:
+    """Output columns of one layer's six Linear weights: query H | key H | value H | attention.output H |
+    intermediate I | output H (cs_bert_quant_columns, include/cs_bert_params.h)."""
+    return 5 * cfg.hidden + cfg.intermediate
+
+
+def quantize_linear_weights(cfg: BertConfig, flat: np.ndarray, per_channel: bool = False, unsigned: bool = True,
+                            reduce_range: bool = False) -> Tuple[np.ndarray, np.ndarray]:
+    """What onnxruntime's quantize_dynamic does to the Linear weights of a BERT export, applied to a flat f32 block:
+    every weight W [out, in] becomes (q - zero_point) * scale with q 8-bit (7-bit under reduce_range), one
+    (scale, zero_point) pair per tensor or per output channel, asymmetric for UINT8 and symmetric for INT8.
+    Returns (block with the dequantised weights in place, wscale [layers, 5H + I] float32) — the pair
+    cs_embedder_create_quantized and the oracle take.  Biases, LayerNorm and embedding tables stay f32 (the *Q files
+    may quantise their Gather tables too; the loader dequantises those, which is all the graph does with them)."""
+    out = np.array(flat, np.float32, copy=True)
+    H, I = cfg.hidden, cfg.intermediate
+    wscale = np.zeros((cfg.layers, quant_columns(cfg)), np.float32)
+    off = 0
+    col = {r: c for r, c in zip(LINEAR_ROLES, (0, H, 2 * H, 3 * H, 4 * H, 4 * H + I))}
+    if unsigned:
+        qmin, qmax = (0, 127) if reduce_range else (0, 255)
+    else:
+        qmin, qmax = (-64, 64) if reduce_range else (-127, 127)
+    for name, shape, _ in tensor_table(cfg):
+        n = int(np.prod(shape))
+        if name.endswith(".weight") and name.startswith("encoder.layer.") and len(shape) == 2:
+            parts = name.split(".")
+            layer, role = int(parts[2]), ".".join(parts[3:-1])
+            w = out[off:off + n].reshape(shape).astype(np.float32)
+            axis = 1 if per_channel else None
+            lo = np.minimum(w.min(axis=axis, keepdims=True), np.float32(0))
+            hi = np.maximum(w.max(axis=axis, keepdims=True), np.float32(0))
+            if unsigned:
+                scale = ((hi - lo) / np.float32(qmax - qmin)).astype(np.float32)
+                scale = np.where(scale == 0, np.float32(1), scale)
+                zp = np.clip(np.rint(np.float32(qmin) - lo / scale), qmin, qmax)
+            else:
+                scale = (np.maximum(np.abs(lo), np.abs(hi)) / np.float32(qmax)).astype(np.float32)
+                scale = np.where(scale == 0, np.float32(1), scale)
+                zp = np.zeros_like(scale)
+            q = np.clip(np.rint(w / scale) + zp, qmin, qmax)
+            out[off:off + n] = ((q - zp).astype(np.float32) * scale).astype(np.float32).reshape(-1)
+            c0 = col[role]
+            wscale[layer, c0:c0 + shape[0]] = np.broadcast_to(scale.reshape(-1), (shape[0],)) if per_channel \
+                else np.float32(scale.reshape(-1)[0])
+        off += n
+    return out, wscale

@@ -399,13 +399,20 @@ int32_t cs_embedder_create_from_dir(const char* model_dir, int32_t pooling, int3
     if (file_exists(st_path)) {
         CS_TRY(cs_bert_params_from_safetensors(st_path.c_str(), &cfg, params.data(), n));
     } else {
+        // (the *Q entries of the registry fetch onnx/model_quantized.onnx — Xenova/all-MiniLM-L6-v2, the reference's default
+        // model — or a model_optimized.onnx that holds quantised weights; hf-hub leaves only the file asked for)
         std::string onnx;
-        for (const char* rel : {"/onnx/model.onnx", "/model.onnx", "/model_optimized.onnx", "/onnx/model_optimized.onnx"})
+        for (const char* rel : {"/onnx/model.onnx", "/model.onnx", "/model_optimized.onnx", "/onnx/model_optimized.onnx",
+                                "/onnx/model_quantized.onnx", "/model_quantized.onnx"})
             if (file_exists(dir + rel)) { onnx = dir + rel; break; }
         if (onnx.empty())
             return fail(CS_ERR_BAD_ARG, "Failed to initialize embedding model: %s holds neither model.safetensors nor "
-                        "onnx/model.onnx, model.onnx or model_optimized.onnx", model_dir);
-        CS_TRY(cs_bert_params_from_onnx(onnx.c_str(), &cfg, params.data(), n));
+                        "onnx/model.onnx, model.onnx, model_optimized.onnx or model_quantized.onnx", model_dir);
+        std::vector<float> wscale((size_t)cfg.layers * cs_bert_quant_columns(&cfg));
+        int32_t quantized = 0;
+        CS_TRY(cs_bert_params_from_onnx_q(onnx.c_str(), &cfg, params.data(), n, wscale.data(), wscale.size(), &quantized));
+        if (quantized)  // every Linear behind MatMulInteger: run them as the graph does (CS_GEMM_Q8_DYNAMIC)
+            return cs_embedder_create_quantized(&cfg, params.data(), wscale.data(), wscale.size(), device, out);
     }
     return cs_embedder_create(&cfg, params.data(), 0, device, out);
 }

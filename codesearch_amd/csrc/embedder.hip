@@ -15,6 +15,7 @@
 #include "encoder.hpp"
 #include "scan.hpp"  // launch_synth_fill (cs_debug_gemm_time)
 #include "split_f16.hpp"
+#include "gemm_q8.hpp"
 
 using namespace cs;
 
@@ -67,11 +68,19 @@ struct cs_embedder {
     float* d_bqkv = nullptr;  // [layers][3H]
     _Float16* d_wsplit = nullptr;  // per layer: wqkv | attention-out | ffn-up | ffn-down, split-f16 rows
     uint32_t* d_flag = nullptr;    // split-f16 range flag
+    // dynamically quantised models (gemm_q8.hip): s8 weights per layer (q8_layer), their column metadata, the running
+    // (lo, hi) of every quantised tensor of a forward ([layers][4][q8_units][2]) and the rows' metadata
+    bool quantized = false;
+    int8_t* d_wq8 = nullptr;
+    Q8ColMeta* d_cmeta = nullptr;
+    uint32_t* d_range = nullptr;
+    uint32_t q8_units = 1;
+    Q8RowMeta* d_rmeta = nullptr;  // [cap_tokens] (workspace)
     int gemm_mode = CS_GEMM_SPLIT_F16;
     bool split_unavailable = false;  // device flushes f16 subnormals in the MFMA: exact-f32 kernels only
     bool wide_ok = false;            // every |w| < 31.98: the one-accumulator 128 x 384 kernels may run (gemm_wide.hip)
     int streams_in_flight = 1;       // slices of the current mini-batch running side by side (forward())
-    uint64_t split_forwards = 0, f32_forwards = 0, range_fallbacks = 0;
+    uint64_t split_forwards = 0, f32_forwards = 0, range_fallbacks = 0, q8_forwards = 0;
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;     // second half of a mini-batch runs here (see forward())
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -126,6 +135,8 @@ void free_workspace(cs_embedder* h) {
     if (h->d_mid) (void)hipFree(h->d_mid);
     if (h->d_pooled) (void)hipFree(h->d_pooled);
     if (h->d_perm) (void)hipFree(h->d_perm);
+    if (h->d_rmeta) (void)hipFree(h->d_rmeta);
+    h->d_rmeta = nullptr;
     h->d_perm = nullptr;
     h->d_ids = h->d_mask = nullptr;
     h->d_x = h->d_xs = h->d_qkv = h->d_ctx = h->d_mid = h->d_pooled = nullptr;
@@ -145,6 +156,7 @@ int32_t reserve(cs_embedder* h, size_t seqs, size_t tokens) {
     CS_HIP(hipMalloc(&h->d_mid, tokens * I * sizeof(float)));
     CS_HIP(hipMalloc(&h->d_pooled, seqs * H * sizeof(float)));
     CS_HIP(hipMalloc(&h->d_perm, seqs * sizeof(uint32_t)));
+    if (h->quantized) CS_HIP(hipMalloc(&h->d_rmeta, tokens * sizeof(Q8RowMeta)));
     h->cap_tokens = tokens;
     h->cap_seqs = seqs;
     return CS_OK;
@@ -171,7 +183,8 @@ int32_t forward_range(cs_embedder* h, hipStream_t s, uint32_t b0, uint32_t nb, u
     const uint32_t H = c.hidden, I = c.intermediate, T = nb * L;
     const size_t t0 = (size_t)b0 * L;
     const float* P = h->d_params;
-    const bool split = mode == CS_GEMM_SPLIT_F16;
+    const bool q8 = mode == CS_GEMM_Q8_DYNAMIC;
+    const bool split = mode == CS_GEMM_SPLIT_F16 || q8;  // q8: attention and the buffers as in split mode
     float* x = h->d_x + t0 * H;
     float* qkv = h->d_qkv + t0 * 3 * H;
     float* ctx = h->d_ctx + t0 * H;
@@ -183,7 +196,7 @@ int32_t forward_range(cs_embedder* h, hipStream_t s, uint32_t b0, uint32_t nb, u
     a.g = P + h->off.emb_ln_g; a.b = P + h->off.emb_ln_b;
     a.eps = c.layer_norm_eps; a.T = T; a.L = L; a.B = nb; a.vocab = c.vocab_size;
     a.pooling = c.pooling; a.x = x; a.out = h->d_pooled + (size_t)b0 * H;
-    a.xs = split ? (void*)(h->d_xs + t0 * H) : nullptr;
+    a.xs = (split && !q8) ? (void*)(h->d_xs + t0 * H) : nullptr;  // q8: the xs buffer holds the quantised rows instead
     a.flag = h->d_flag;
     _Float16* xs = reinterpret_cast<_Float16*>(h->d_xs + t0 * H);
     _Float16* ctxs = reinterpret_cast<_Float16*>(ctx);
@@ -245,7 +258,39 @@ int32_t forward_range(cs_embedder* h, hipStream_t s, uint32_t b0, uint32_t nb, u
         cs_bert_layer_offsets lo;
         cs_bert_layer_layout(&c, &h->off, l, &lo);
         const float* bqkv = h->d_bqkv + (size_t)l * 3 * H;
-        if (split) {
+        if (q8) {
+            // Every Linear as the quantised file's graph runs it: DynamicQuantizeLinear of its input (one range per
+            // call tensor), MatMulInteger on the int8 MFMA, * (x_scale * W_scale), + bias (gemm_q8.hip)
+            const Q8Layer ql = q8_layer(H, I);
+            const int8_t* wq = h->d_wq8 + (size_t)l * ql.total;
+            const Q8ColMeta* cm = h->d_cmeta + (size_t)l * (5 * (size_t)H + I);
+            uint32_t* rg = h->d_range + (size_t)l * 4 * 2 * h->q8_units;
+            const size_t rstep = (size_t)2 * h->q8_units;
+            int8_t* xq = reinterpret_cast<int8_t*>(h->d_xs + t0 * H);  // [T][<= 4H] bytes
+            Q8RowMeta* rm = h->d_rmeta + t0;
+            _Float16* qkvs = reinterpret_cast<_Float16*>(qkv);
+            CS_TRY(launch_q8_quantize(Q8_SRC_F32, x, T, H, rg, nullptr, xq, rm, s));
+            CS_TRY(launch_gemm_q8(SH_OUT_SPLIT, xq, rm, wq + ql.qkv, cm, bqkv, nullptr, nullptr, qkvs, T, 3 * H, H, h->d_flag, s));  // E2
+            CS_TRY(mark(CS_STAGE_QKV));
+            CS_TRY(launch_attention_sh2(qkvs, mask, ctxs, h->d_flag, nb, L, H, c.heads, s));  // E3
+            CS_TRY(mark(CS_STAGE_ATTENTION));
+            CS_TRY(launch_q8_quantize(Q8_SRC_SPLIT, ctxs, T, H, rg + rstep, nullptr, xq, rm, s));
+            CS_TRY(launch_gemm_q8(SH_OUT_F32_RESID, xq, rm, wq + ql.ao, cm + 3 * H, P + lo.ao_b, x, x, nullptr, T, H, H, h->d_flag, s));  // E4
+            CS_TRY(mark(CS_STAGE_OUT_PROJ));
+            a.g = P + lo.ao_ln_g; a.b = P + lo.ao_ln_b;
+            CS_TRY(launch_row_kernel(1, a, H, s));
+            CS_TRY(mark(CS_STAGE_LN_ATTN));
+            CS_TRY(launch_q8_quantize(Q8_SRC_F32, x, T, H, rg + 2 * rstep, nullptr, xq, rm, s));
+            CS_TRY(launch_gemm_q8(SH_OUT_SPLIT_GELU, xq, rm, wq + ql.up, cm + 4 * H, P + lo.up_b, nullptr, nullptr, mids, T, I, H, h->d_flag, s));  // E5
+            CS_TRY(mark(CS_STAGE_FFN_UP));
+            CS_TRY(launch_q8_quantize(Q8_SRC_SPLIT, mids, T, I, rg + 3 * rstep, nullptr, xq, rm, s));
+            CS_TRY(launch_gemm_q8(SH_OUT_F32_RESID, xq, rm, wq + ql.down, cm + 4 * H + I, P + lo.down_b, x, x, nullptr, T, H, I, h->d_flag, s));  // E6
+            CS_TRY(mark(CS_STAGE_FFN_DOWN));
+            a.g = P + lo.out_ln_g; a.b = P + lo.out_ln_b;
+            CS_TRY(launch_row_kernel(1, a, H, s));
+            CS_TRY(mark(CS_STAGE_LN_FFN));
+            if (l + 1 == c.layers) h->last_hidden_partial = false;
+        } else if (split) {
             const _Float16* ws = h->d_wsplit + (size_t)l * sl.total;
             {
                 _Float16* qkvs = reinterpret_cast<_Float16*>(qkv);  // [T][3H/32][64] f16: same bytes as the f32 qkv
@@ -376,7 +421,9 @@ int32_t forward_range(cs_embedder* h, hipStream_t s, uint32_t b0, uint32_t nb, u
 int32_t forward(cs_embedder* h, uint32_t B, uint32_t L, int mode) {
     hipStream_t s = h->stream;
     CS_HIP(hipEventRecord(h->ev0, s));
-    if (mode == CS_GEMM_SPLIT_F16) CS_HIP(hipMemsetAsync(h->d_flag, 0, sizeof(uint32_t), s));
+    if (mode != CS_GEMM_F32) CS_HIP(hipMemsetAsync(h->d_flag, 0, sizeof(uint32_t), s));
+    if (mode == CS_GEMM_Q8_DYNAMIC)  // every range starts from (+0, +0)
+        CS_HIP(hipMemsetAsync(h->d_range, 0, (size_t)h->cfg.layers * 4 * 2 * h->q8_units * sizeof(uint32_t), s));
     // Slicing pays from ~20,000 tokens (device us per forward, one stream / two: 16,384 tokens 3505 / 3542,
     // 24,576 5267 / 4916, 32,768 6517 / 6275, 49,152 9568 / 9437); below that it only multiplies launches
     // of kernels that already leave the chip part-empty.
@@ -397,7 +444,8 @@ int32_t forward(cs_embedder* h, uint32_t B, uint32_t L, int mode) {
         auto eff = [&](uint64_t tiles) { return cus > 0 ? (double)tiles / (double)(((tiles + cus - 1) / cus) * cus) : 0.0; };
         whole_rounds = h->cfg.hidden == 384 && mt >= 218 && eff(mt) >= 0.96 && eff(3 * mt) >= 0.96 && eff(4 * mt) >= 0.96;
     }
-    if (!h->stage_profile && !whole_rounds && h->n_streams >= 2 && B >= (uint32_t)h->n_streams &&
+    // (a quantised tensor is the WHOLE mini-batch: slices on several streams would each see their own range)
+    if (!h->stage_profile && !whole_rounds && mode != CS_GEMM_Q8_DYNAMIC && h->n_streams >= 2 && B >= (uint32_t)h->n_streams &&
         (uint64_t)B * L >= stream_min_tokens) {
         const uint32_t ns = (uint32_t)h->n_streams;
         h->streams_in_flight = (int)ns;
@@ -463,7 +511,15 @@ int32_t embed_impl(cs_embedder* h, const int32_t* ids, const int32_t* mask, uint
                               hipMemcpyHostToDevice, h->stream));
         int mode = h->gemm_mode;
         CS_TRY(forward(h, B, seq_len, mode));
-        if (mode == CS_GEMM_SPLIT_F16) {
+        if (mode == CS_GEMM_Q8_DYNAMIC) {
+            uint32_t flag = 0;
+            CS_HIP(hipMemcpyAsync(&flag, h->d_flag, sizeof(flag), hipMemcpyDeviceToHost, h->stream));
+            CS_HIP(hipStreamSynchronize(h->stream));
+            h->q8_forwards += 1;
+            if (flag)  // Q / K / V or a GELU output beyond 65504: the f32 kernels would run a different graph — refuse
+                return fail(CS_ERR_UNSUPPORTED, "Failed to generate embeddings: an activation of the quantised model left the "
+                            "f16 range of the attention / GELU hand-over (|x| > 65504)");
+        } else if (mode == CS_GEMM_SPLIT_F16) {
             uint32_t flag = 0;
             CS_HIP(hipMemcpyAsync(&flag, h->d_flag, sizeof(flag), hipMemcpyDeviceToHost, h->stream));
             CS_HIP(hipStreamSynchronize(h->stream));
@@ -554,7 +610,8 @@ int32_t run_window(cs_embedder* h, const std::vector<SeqView>& seqs, uint32_t ba
         const char* e = std::getenv("CS_EMBED_TOKEN_BATCH");
         return !(e && e[0] == '0');
     }();
-    const bool sorted = length_sort_enabled() && wn > batch;
+    // (a quantised model's tensors are the reference's call units: `batch` consecutive texts, padded to their longest)
+    const bool sorted = length_sort_enabled() && wn > batch && h->gemm_mode != CS_GEMM_Q8_DYNAMIC;
     const uint64_t budget = (uint64_t)batch * std::min<uint32_t>(256, h->cfg.max_position);
     const uint32_t max_rows = sorted && token_batches ? batch * 8 : batch;
     {   // workspace for the window's longest sequence once, not once per (growing) mini-batch
@@ -657,7 +714,8 @@ int32_t embed_ids_entry(cs_embedder* h, const int32_t* ids, const int32_t* mask,
     if (!h) return fail(CS_ERR_BAD_ARG, "null embedder handle");
     const uint32_t b = batch ? batch : default_batch(h);
     // a single mini-batch runs exactly as given (cs_embedder_last_hidden then has the caller's [n, seq_len] layout)
-    if (n <= b || !ids || !mask || !out || seq_len == 0 || seq_len > h->cfg.max_position || !length_sort_enabled())
+    if (n <= b || !ids || !mask || !out || seq_len == 0 || seq_len > h->cfg.max_position || !length_sort_enabled() ||
+        h->gemm_mode == CS_GEMM_Q8_DYNAMIC)
         return embed_impl(h, ids, mask, n, seq_len, batch, out, out_on_device, cancel);
     return embed_ids_windowed(h, ids, mask, n, seq_len, b, out, out_on_device, cancel);
 }
@@ -717,6 +775,20 @@ int32_t flush_queue(cs_embedder* h, const volatile int32_t* cancel) {
         const size_t window = (size_t)batch * 16;
         std::vector<uint32_t> order;
         std::vector<int32_t> ids, mask;
+        if (h->gemm_mode == CS_GEMM_Q8_DYNAMIC) {
+            // a quantised model's activations are quantised per CALL tensor (embedder.rs:286-289 hands ORT one submission
+            // at a time): each entry runs as its own mini-batches, in its own order
+            size_t lo = 0;
+            for (auto& e : todo) {
+                const size_t n = e->ids.size();
+                for (size_t b0 = 0; b0 < n; b0 += window) {
+                    const std::vector<SeqView> win(seqs.begin() + lo + b0, seqs.begin() + lo + std::min(n, b0 + window));
+                    CS_TRY(run_window(h, win, batch, 0, fl->d_rows + (lo + b0) * H, true, cancel, order, ids, mask));
+                }
+                lo += n;
+            }
+            return CS_OK;
+        }
         for (size_t lo = 0; lo < seqs.size(); lo += window) {
             const std::vector<SeqView> win(seqs.begin() + lo, seqs.begin() + std::min(seqs.size(), lo + window));
             CS_TRY(run_window(h, win, batch, 0, fl->d_rows + lo * H, true, cancel, order, ids, mask));
@@ -792,7 +864,7 @@ uint64_t cs_bert_param_count(const cs_bert_config* cfg) {
     return off.total;
 }
 
-int32_t cs_embedder_create(const cs_bert_config* cfg, const float* params, uint64_t seed,
+static int32_t create_impl(const cs_bert_config* cfg, const float* params, uint64_t seed, const float* wscale,
                            int32_t device, cs_embedder** out) {
     if (!out) return fail(CS_ERR_BAD_ARG, "out is null");
     *out = nullptr;
@@ -897,10 +969,72 @@ int32_t cs_embedder_create(const cs_bert_config* cfg, const float* params, uint6
                 break;
             }
     }
+    // dynamically quantised model: the s8 form of every Linear weight and its column metadata (gemm_q8.hip)
+    if (s == CS_OK && wscale) {
+        const size_t I = cfg->intermediate, cols = 5 * H + I;
+        const Q8Layer ql = q8_layer((uint32_t)H, (uint32_t)I);
+        float* d_ws = nullptr;
+        uint32_t* d_bad = nullptr;
+        if (I > 4 * H) s = fail(CS_ERR_UNSUPPORTED, "Failed to initialize embedding model: intermediate size above 4 x hidden");
+        if (s == CS_OK && (hipMalloc(&h->d_wq8, (size_t)cfg->layers * ql.total) != hipSuccess ||
+                           hipMalloc(&h->d_cmeta, (size_t)cfg->layers * cols * sizeof(Q8ColMeta)) != hipSuccess ||
+                           hipMalloc(&h->d_range, (size_t)cfg->layers * 4 * 2 * h->q8_units * sizeof(uint32_t)) != hipSuccess ||
+                           hipMalloc(&d_ws, (size_t)cfg->layers * cols * sizeof(float)) != hipSuccess ||
+                           hipMalloc(&d_bad, sizeof(uint32_t)) != hipSuccess))
+            s = fail(CS_ERR_OOM, "hipMalloc(quantised weights) failed");
+        if (s == CS_OK && (hipMemcpyAsync(d_ws, wscale, (size_t)cfg->layers * cols * sizeof(float), hipMemcpyHostToDevice, h->stream) != hipSuccess ||
+                           hipMemsetAsync(d_bad, 0, sizeof(uint32_t), h->stream) != hipSuccess))
+            s = fail(CS_ERR_HIP, "quantised weight setup failed");
+        for (uint32_t l = 0; l < cfg->layers && s == CS_OK; ++l) {
+            cs_bert_layer_offsets lo;
+            cs_bert_layer_layout(cfg, &h->off, l, &lo);
+            int8_t* wq = h->d_wq8 + (size_t)l * ql.total;
+            Q8ColMeta* cm = h->d_cmeta + (size_t)l * cols;
+            const float* sc = d_ws + (size_t)l * cols;
+            s = launch_q8_pack_weight(h->d_wqkv + (size_t)l * 3 * H * H, sc, (uint32_t)(3 * H), (uint32_t)H, wq + ql.qkv, cm, d_bad, h->stream);
+            if (s == CS_OK) s = launch_q8_pack_weight(h->d_params + lo.ao_w, sc + 3 * H, (uint32_t)H, (uint32_t)H, wq + ql.ao, cm + 3 * H, d_bad, h->stream);
+            if (s == CS_OK) s = launch_q8_pack_weight(h->d_params + lo.up_w, sc + 4 * H, (uint32_t)I, (uint32_t)H, wq + ql.up, cm + 4 * H, d_bad, h->stream);
+            if (s == CS_OK) s = launch_q8_pack_weight(h->d_params + lo.down_w, sc + 4 * H + I, (uint32_t)H, (uint32_t)I, wq + ql.down, cm + 4 * H + I, d_bad, h->stream);
+        }
+        uint32_t bad = 0;
+        if (s == CS_OK && (hipMemcpyAsync(&bad, d_bad, sizeof(bad), hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
+                           hipStreamSynchronize(h->stream) != hipSuccess))
+            s = fail(CS_ERR_HIP, "quantised weight setup failed");
+        if (d_ws) (void)hipFree(d_ws);
+        if (d_bad) (void)hipFree(d_bad);
+        if (s == CS_OK && bad)
+            s = fail(CS_ERR_BAD_ARG, "Failed to initialize embedding model: %s", (bad & 2)
+                         ? "a Linear weight is not an integer multiple of its column scale (not a quantised block)"
+                         : "the integers of a weight column span more than 8 bits");
+        if (s == CS_OK) {
+            h->quantized = true;
+            const char* env = std::getenv("CS_ENCODER_QUANT");  // "0": the f32 graph of the quantised weights
+            if (!h->split_unavailable && !(env && env[0] == '0')) h->gemm_mode = CS_GEMM_Q8_DYNAMIC;
+        }
+    }
     if (s == CS_OK && hipStreamSynchronize(h->stream) != hipSuccess) s = fail(CS_ERR_HIP, "parameter setup failed");
     if (s != CS_OK) return cleanup(s);
     *out = h;
     return CS_OK;
+}
+
+int32_t cs_embedder_create(const cs_bert_config* cfg, const float* params, uint64_t seed,
+                           int32_t device, cs_embedder** out) {
+    return create_impl(cfg, params, seed, nullptr, device, out);
+}
+
+uint64_t cs_bert_quant_columns(const cs_bert_config* cfg) {
+    return cfg ? 5 * (uint64_t)cfg->hidden + cfg->intermediate : 0;
+}
+
+int32_t cs_embedder_create_quantized(const cs_bert_config* cfg, const float* params, const float* wscale,
+                                     uint64_t n_wscale, int32_t device, cs_embedder** out) {
+    if (out) *out = nullptr;
+    if (!cfg || !params || !wscale) return fail(CS_ERR_BAD_ARG, "cs_embedder_create_quantized: null argument");
+    if (n_wscale != (uint64_t)cfg->layers * cs_bert_quant_columns(cfg))
+        return fail(CS_ERR_BAD_ARG, "cs_embedder_create_quantized: %llu column scales given, %llu expected (layers x (5 hidden + intermediate))",
+                    (unsigned long long)n_wscale, (unsigned long long)((uint64_t)cfg->layers * cs_bert_quant_columns(cfg)));
+    return create_impl(cfg, params, 0, wscale, device, out);
 }
 
 void cs_embedder_destroy(cs_embedder* h) {
@@ -918,6 +1052,9 @@ void cs_embedder_destroy(cs_embedder* h) {
     if (h->d_bqkv) (void)hipFree(h->d_bqkv);
     if (h->d_wsplit) (void)hipFree(h->d_wsplit);
     if (h->d_flag) (void)hipFree(h->d_flag);
+    if (h->d_wq8) (void)hipFree(h->d_wq8);
+    if (h->d_cmeta) (void)hipFree(h->d_cmeta);
+    if (h->d_range) (void)hipFree(h->d_range);
     for (hipEvent_t e : h->stage_ev) (void)hipEventDestroy(e);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -1067,8 +1204,10 @@ int32_t cs_embedder_profile_stages_read(cs_embedder* h, double* us_per_stage, ui
 
 int32_t cs_embedder_set_gemm_mode(cs_embedder* h, int32_t mode) {
     if (!h) return fail(CS_ERR_BAD_ARG, "null embedder handle");
-    if (mode != CS_GEMM_F32 && mode != CS_GEMM_SPLIT_F16) return fail(CS_ERR_BAD_ARG, "unknown gemm mode %d", mode);
-    if (mode == CS_GEMM_SPLIT_F16 && h->split_unavailable)
+    if (mode != CS_GEMM_F32 && mode != CS_GEMM_SPLIT_F16 && mode != CS_GEMM_Q8_DYNAMIC) return fail(CS_ERR_BAD_ARG, "unknown gemm mode %d", mode);
+    if (mode == CS_GEMM_Q8_DYNAMIC && !h->quantized)
+        return fail(CS_ERR_UNSUPPORTED, "dynamic-quantisation mode needs a quantised model (cs_embedder_create_quantized / a *Q model directory)");
+    if (mode != CS_GEMM_F32 && h->split_unavailable)
         return fail(CS_ERR_UNSUPPORTED, "split-f16 mode needs exact f16-subnormal MFMA inputs, which this device/mode lacks");
     h->gemm_mode = mode;
     return CS_OK;
@@ -1189,6 +1328,85 @@ int32_t cs_debug_gemm(int32_t device, int32_t mode, int32_t epilogue, const floa
     };
     st = run();
     for (void* p : {(void*)dA, (void*)dW, (void*)dB, (void*)dR, (void*)dC, (void*)sA, (void*)sW, (void*)sC, (void*)dF})
+        if (p) (void)hipFree(p);
+    return st;
+}
+
+int32_t cs_debug_gemm_q8(int32_t device, int32_t epilogue, int32_t a_split, const float* A, const float* W,
+                         const float* wscale, const float* bias, const float* resid, float* C, uint32_t M, uint32_t N,
+                         uint32_t K, uint8_t* xq_out, float* xparams, int32_t* acc_out) {
+    if (!A || !W || !wscale || !bias || !C || (epilogue == 2 && !resid)) return fail(CS_ERR_BAD_ARG, "null buffer");
+    if (epilogue != 0 && epilogue != 1 && epilogue != 2 && epilogue != 4) return fail(CS_ERR_BAD_ARG, "unknown epilogue %d", epilogue);
+    if (M == 0 || N % 128 || K % 128 || K == 0) return fail(CS_ERR_UNSUPPORTED, "cs_debug_gemm_q8 needs M > 0, N %% 128 == 0, K %% 128 == 0");
+    int ndev = 0;
+    CS_HIP(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) return fail(CS_ERR_HIP, "HIP device %d not available (%d visible)", device, ndev);
+    DeviceGuard g(device);
+    const size_t a_n = (size_t)M * K, w_n = (size_t)N * K, c_n = (size_t)M * N;
+    float *dA = nullptr, *dW = nullptr, *dS = nullptr, *dB = nullptr, *dR = nullptr, *dC = nullptr;
+    _Float16 *sA = nullptr, *sC = nullptr;
+    int8_t *dXq = nullptr, *dWq = nullptr;
+    Q8RowMeta* dRm = nullptr;
+    Q8ColMeta* dCm = nullptr;
+    uint32_t *dF = nullptr, *dRange = nullptr;
+    int32_t* dAcc = nullptr;
+    auto run = [&]() -> int32_t {
+        CS_HIP(hipMalloc(&dA, a_n * 4)); CS_HIP(hipMalloc(&dW, w_n * 4)); CS_HIP(hipMalloc(&dS, (size_t)N * 4));
+        CS_HIP(hipMalloc(&dB, (size_t)N * 4)); CS_HIP(hipMalloc(&dC, c_n * 4)); CS_HIP(hipMalloc(&dF, 16));
+        CS_HIP(hipMalloc(&dXq, a_n)); CS_HIP(hipMalloc(&dWq, w_n)); CS_HIP(hipMalloc(&dRm, (size_t)M * sizeof(Q8RowMeta)));
+        CS_HIP(hipMalloc(&dCm, (size_t)N * sizeof(Q8ColMeta))); CS_HIP(hipMalloc(&dRange, 8));
+        CS_HIP(hipMemcpy(dA, A, a_n * 4, hipMemcpyHostToDevice));
+        CS_HIP(hipMemcpy(dW, W, w_n * 4, hipMemcpyHostToDevice));
+        CS_HIP(hipMemcpy(dS, wscale, (size_t)N * 4, hipMemcpyHostToDevice));
+        CS_HIP(hipMemcpy(dB, bias, (size_t)N * 4, hipMemcpyHostToDevice));
+        CS_HIP(hipMemset(dF, 0, 16));
+        CS_HIP(hipMemset(dRange, 0, 8));
+        if (epilogue == 2) {
+            CS_HIP(hipMalloc(&dR, c_n * 4));
+            CS_HIP(hipMemcpy(dR, resid, c_n * 4, hipMemcpyHostToDevice));
+        }
+        if (acc_out) CS_HIP(hipMalloc(&dAcc, c_n * 4));
+        CS_TRY(launch_q8_pack_weight(dW, dS, N, K, dWq, dCm, dF + 1, nullptr));
+        if (a_split) {
+            CS_HIP(hipMalloc(&sA, a_n * 4));
+            CS_TRY(launch_split_rows(dA, sA, M, K, dF, nullptr));
+            CS_TRY(launch_q8_quantize(Q8_SRC_SPLIT, sA, M, K, dRange, nullptr, dXq, dRm, nullptr));
+        } else {
+            CS_TRY(launch_q8_quantize(Q8_SRC_F32, dA, M, K, dRange, nullptr, dXq, dRm, nullptr));
+        }
+        const int epi = epilogue == 0 ? SH_OUT_F32 : epilogue == 1 ? SH_OUT_SPLIT_GELU : epilogue == 2 ? SH_OUT_F32_RESID : SH_OUT_SPLIT;
+        if (epi == SH_OUT_SPLIT_GELU || epi == SH_OUT_SPLIT) CS_HIP(hipMalloc(&sC, c_n * 4));
+        CS_TRY(launch_gemm_q8(epi, dXq, dRm, dWq, dCm, dB, dR, dC, sC, M, N, K, dF, nullptr, dAcc));
+        CS_HIP(hipDeviceSynchronize());
+        uint32_t flags[2] = {0, 0};
+        CS_HIP(hipMemcpy(flags, dF, 8, hipMemcpyDeviceToHost));
+        if (flags[1]) return fail(CS_ERR_BAD_ARG, "cs_debug_gemm_q8: W is not a quantised matrix for these column scales (flag %u)", flags[1]);
+        if (sC) {
+            std::vector<_Float16> hs(c_n * 2);
+            CS_HIP(hipMemcpy(hs.data(), sC, c_n * 4, hipMemcpyDeviceToHost));
+            const size_t nch = N / 32;
+            for (size_t m = 0; m < M; ++m)
+                for (size_t n = 0; n < N; ++n) {
+                    const _Float16* line = hs.data() + (m * nch + n / 32) * 64;
+                    C[m * N + n] = (float)line[n % 32] + (float)line[32 + n % 32] * (1.0f / 2048.0f);
+                }
+        } else {
+            CS_HIP(hipMemcpy(C, dC, c_n * 4, hipMemcpyDeviceToHost));
+        }
+        if (acc_out) CS_HIP(hipMemcpy(acc_out, dAcc, c_n * 4, hipMemcpyDeviceToHost));
+        if (xq_out || xparams) {
+            std::vector<int8_t> hq(a_n);
+            Q8RowMeta rm0;
+            CS_HIP(hipMemcpy(hq.data(), dXq, a_n, hipMemcpyDeviceToHost));
+            CS_HIP(hipMemcpy(&rm0, dRm, sizeof(rm0), hipMemcpyDeviceToHost));
+            if (xq_out) for (size_t i = 0; i < a_n; ++i) xq_out[i] = (uint8_t)((int)hq[i] + 128);
+            if (xparams) { xparams[0] = rm0.xs; xparams[1] = (float)(rm0.za + 128); }
+        }
+        return CS_OK;
+    };
+    const int32_t st = run();
+    for (void* p : {(void*)dA, (void*)dW, (void*)dS, (void*)dB, (void*)dR, (void*)dC, (void*)sA, (void*)sC, (void*)dXq, (void*)dWq,
+                    (void*)dRm, (void*)dCm, (void*)dF, (void*)dRange, (void*)dAcc})
         if (p) (void)hipFree(p);
     return st;
 }

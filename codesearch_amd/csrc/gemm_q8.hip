@@ -1,0 +1,382 @@
+// gemm_q8.hip — the encoder's dense layers as onnxruntime's dynamic quantiser rewrites them (SURVEY.md §8a E2/E4/E5/E6 for
+// the registry's *Q models; the reference's DEFAULT model is one: ModelType::AllMiniLML6V2Q,
+// /root/reference/src/embed/embedder.rs:12-13,367-372 — fastembed runs its model_quantized.onnx through ONNX Runtime).
+// In those files every Linear is
+//     x -> DynamicQuantizeLinear -> MatMulInteger(x_q, W_q, x_zp, W_zp) -> Cast(f32) -> Mul(x_scale * W_scale) -> Add(bias)
+// with the published (ONNX opset 10 / 11) definitions
+//     DynamicQuantizeLinear, per tensor, uint8:  lo = min(0, min x), hi = max(0, max x),  x_scale = (hi - lo) / 255 (1 if hi == lo),
+//         x_zp = sat_u8(round_half_even(0 - lo / x_scale)),   x_q = sat_u8(round_half_even(x / x_scale) + x_zp)
+//     MatMulInteger:  acc[m][n] = sum_k (x_q[m][k] - x_zp) * (W_q[k][n] - W_zp[n])   in int32, exact
+// Here: a range pass (q8_minmax_kernel), a quantising pass (q8_quantize_kernel: the same f32 division and rounding, so the
+// same bytes from the same activations), and the product on v_mfma_i32_16x16x64_i8 — exact, so the int32 accumulators ARE
+// MatMulInteger's.  Both operands are kept as SIGNED bytes for the MFMA: a = x_q - 128, b = (W_q - W_zp) - c[n] with c[n]
+// chosen per column so the 8-bit span fits [-128, 127]; with za = x_zp - 128, zw = -c[n]
+//     sum_k (a - za)(b - zw)  =  sum_k a b  -  zw rowsum[m]  -  za colsum[n]  +  K za zw
+// puts the zero points back in the epilogue (int32 throughout).  One f16 MFMA product of the split-f16 kernels (three
+// MFMAs per 32 k) becomes one int8 MFMA per 64 k: a sixth of the matrix-pipe time, and a quarter of the operand bytes.
+// The tile leaves through the epilogue the split-f16 kernels use (gemm_epilogue.hpp).
+#include <cstdlib>
+
+#include "encoder.hpp"
+#include "gemm_epilogue.hpp"
+#include "gemm_q8.hpp"
+#include "split_f16.hpp"
+
+namespace cs {
+
+typedef int q8_i32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+// ---- the range of a quantisation unit ------------------------------------------------------------------------------
+// lo <= 0 <= hi always (the graph's range includes zero), so both start from +0.0f = all bits zero and move by integer
+// atomics on the float's bits: non-negative floats order like their bits (atomicMax), negative floats like their bits
+// reversed (atomicMax on the unsigned pattern finds the most negative).
+__device__ __forceinline__ void q8_range_update(uint32_t* slot, float lo, float hi) {
+    if (lo < 0.0f) atomicMax(slot, __float_as_uint(lo));
+    if (hi > 0.0f) atomicMax(slot + 1, __float_as_uint(hi));
+}
+
+// 16 bytes of the source -> up to 8 values.  f32 rows: unit u = 4 consecutive floats.  Split-f16 lines [rows][K/32][64]:
+// unit u = piece u % 4 of line u / 4: 8 hi halves at +0, their 8 lo halves 64 B further on; x = hi + lo / 2048.
+template <int SRC>
+struct Q8Unit {
+    static constexpr int N = SRC == Q8_SRC_F32 ? 4 : 8;
+    float v[N];
+    __device__ __forceinline__ void load(const void* src, uint64_t u) {
+        if (SRC == Q8_SRC_F32) {
+            const sh_f32x4 t = reinterpret_cast<const sh_f32x4*>(src)[u];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = t[e];
+        } else {
+            const _Float16* line = reinterpret_cast<const _Float16*>(src) + (u >> 2) * 64 + (u & 3) * 8;
+            const f16x8 h = *reinterpret_cast<const f16x8*>(line);
+            const f16x8 l = *reinterpret_cast<const f16x8*>(line + 32);
+#pragma unroll
+            for (int e = 0; e < N; ++e) v[e % N] = (float)h[e] + (float)l[e] * kShLoInv;
+        }
+    }
+};
+
+template <int SRC>
+__global__ void __launch_bounds__(256)
+q8_minmax_kernel(const void* __restrict__ src, uint32_t T, uint32_t K, uint32_t* __restrict__ range,
+                 const uint32_t* __restrict__ row_slot) {
+    constexpr int UN = Q8Unit<SRC>::N;
+    const uint32_t upr = K / UN;  // units per row
+    const uint64_t units = (uint64_t)T * upr;
+    constexpr uint32_t NONE = 0xffffffffu;
+    float lo = 0.0f, hi = 0.0f;
+    uint32_t mine = NONE;   // unit of the values this lane holds in lo / hi
+    bool single = true;     // ... and whether the lane has only ever seen that one
+    for (uint64_t u = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; u < units; u += (uint64_t)gridDim.x * blockDim.x) {
+        uint32_t slot = 0;
+        if (row_slot) {
+            slot = row_slot[u / upr];
+            if (slot >> 31) continue;  // the row is not part of the tensor the reference quantises
+        }
+        if (slot != mine) {
+            if (mine != NONE) {  // a new unit: flush what this lane holds
+                q8_range_update(range + 2 * (size_t)mine, lo, hi);
+                lo = hi = 0.0f;
+                single = false;
+            }
+            mine = slot;
+        }
+        Q8Unit<SRC> x;
+        x.load(src, u);
+#pragma unroll
+        for (int e = 0; e < UN; ++e) { lo = fminf(lo, x.v[e]); hi = fmaxf(hi, x.v[e]); }
+    }
+    // one unit for the whole wave (the common case): reduce across lanes first, two atomics per wave.  Lanes without
+    // work hold (0, 0), which every range contains.
+    const bool has = mine != NONE;
+    const uint64_t work = __ballot(has);
+    if (work == 0) return;
+    const int leader = __ffsll((unsigned long long)work) - 1;
+    const uint32_t lead = __shfl(mine, leader);
+    if (__all(!has || (single && mine == lead))) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            lo = fminf(lo, __shfl_xor(lo, o));
+            hi = fmaxf(hi, __shfl_xor(hi, o));
+        }
+        if ((int)(threadIdx.x & 63) == leader) q8_range_update(range + 2 * (size_t)lead, lo, hi);
+    } else if (has) {
+        q8_range_update(range + 2 * (size_t)mine, lo, hi);
+    }
+}
+
+// (x_scale, x_zp) of a unit from its range: DynamicQuantizeLinear's arithmetic, f32, one rounding per operation.
+__device__ __forceinline__ void q8_params(const uint32_t* slot, float& xs, float& xz) {
+    const float lo = __uint_as_float(slot[0]), hi = __uint_as_float(slot[1]);
+    xs = hi == lo ? 1.0f : __fdiv_rn(__fsub_rn(hi, lo), 255.0f);
+    const float z = __fsub_rn(0.0f, __fdiv_rn(lo, xs));
+    xz = rintf(fminf(fmaxf(z, 0.0f), 255.0f));  // round half to even
+}
+
+// A block owns Q8_RB whole rows, so a row's sum of stored bytes meets in LDS.
+constexpr int Q8_RB = 8;
+
+template <int SRC>
+__global__ void __launch_bounds__(256)
+q8_quantize_kernel(const void* __restrict__ src, uint32_t T, uint32_t K, const uint32_t* __restrict__ range,
+                   const uint32_t* __restrict__ row_slot, int8_t* __restrict__ xq, Q8RowMeta* __restrict__ rmeta) {
+    constexpr int UN = Q8Unit<SRC>::N;
+    __shared__ float r_xs[Q8_RB], r_xz[Q8_RB];
+    __shared__ int r_sum[Q8_RB];
+    const uint32_t row0 = blockIdx.x * Q8_RB;
+    const uint32_t rows = T - row0 < (uint32_t)Q8_RB ? T - row0 : (uint32_t)Q8_RB;
+    if (threadIdx.x < rows) {
+        const uint32_t slot = row_slot ? (row_slot[row0 + threadIdx.x] & 0x7fffffffu) : 0u;
+        float xs, xz;
+        q8_params(range + 2 * (size_t)slot, xs, xz);
+        r_xs[threadIdx.x] = xs;
+        r_xz[threadIdx.x] = xz;
+        r_sum[threadIdx.x] = 0;
+    }
+    __syncthreads();
+    const uint32_t upr = K / UN;
+    for (uint32_t c = threadIdx.x; c < rows * upr; c += 256) {
+        const uint32_t r = c / upr, cc = c - r * upr;
+        const uint64_t u = (uint64_t)(row0 + r) * upr + cc;
+        Q8Unit<SRC> x;
+        x.load(src, u);
+        const float xs = r_xs[r], xz = r_xz[r];
+        int sum = 0;
+        uint32_t packed[UN / 4];
+#pragma unroll
+        for (int w = 0; w < UN / 4; ++w) {
+            uint32_t p = 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                // x_q = sat_u8(round_half_even(x / x_scale) + x_zp); stored minus 128
+                const float q = fminf(fmaxf(__fadd_rn(rintf(__fdiv_rn(x.v[4 * w + e], xs)), xz), 0.0f), 255.0f);
+                const int a = (int)q - 128;
+                sum += a;
+                p |= (uint32_t)(a & 0xff) << (8 * e);
+            }
+            packed[w] = p;
+        }
+        // position of these UN bytes in the row: f32 source, unit cc = k 4cc..; split source, line cc / 4 (32 k), piece cc % 4 (8 k)
+        const size_t kbyte = SRC == Q8_SRC_F32 ? (size_t)cc * 4 : (size_t)(cc >> 2) * 32 + (cc & 3) * 8;
+        uint32_t* dst = reinterpret_cast<uint32_t*>(xq + (size_t)(row0 + r) * K + kbyte);
+#pragma unroll
+        for (int w = 0; w < UN / 4; ++w) dst[w] = packed[w];
+        atomicAdd(&r_sum[r], sum);
+    }
+    __syncthreads();
+    if (threadIdx.x < rows) {
+        Q8RowMeta m;
+        m.xs = r_xs[threadIdx.x];
+        m.za = (int)r_xz[threadIdx.x] - 128;
+        m.rowsum = r_sum[threadIdx.x];
+        m.pad = 0;
+        rmeta[row0 + threadIdx.x] = m;
+    }
+}
+
+// One wave per weight row n: the integers d = round(w / scale) (= W_q - W_zp of the file), re-centred so they fit s8.
+__global__ void __launch_bounds__(64)
+q8_pack_weight_kernel(const float* __restrict__ W, const float* __restrict__ scale, uint32_t N, uint32_t K,
+                      int8_t* __restrict__ wq, Q8ColMeta* __restrict__ cmeta, uint32_t* __restrict__ bad) {
+    const uint32_t n = blockIdx.x;
+    if (n >= N) return;
+    const int lane = threadIdx.x;
+    const float sc = scale[n];
+    const float* w = W + (size_t)n * K;
+    int dmin = 0x7fffffff, dmax = -0x7fffffff;
+    bool off_grid = false;
+    for (uint32_t k = lane; k < K; k += 64) {
+        const float t = sc != 0.0f ? __fdiv_rn(w[k], sc) : 0.0f;
+        const float d = rintf(t);
+        off_grid |= !(fabsf(t - d) <= 0.01f) || (sc == 0.0f && w[k] != 0.0f);
+        const int di = (int)fminf(fmaxf(d, -1.0e6f), 1.0e6f);
+        dmin = di < dmin ? di : dmin;
+        dmax = di > dmax ? di : dmax;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const int a = __shfl_xor(dmin, o), b = __shfl_xor(dmax, o);
+        dmin = a < dmin ? a : dmin;
+        dmax = b > dmax ? b : dmax;
+    }
+    if (__any(off_grid) && lane == 0) atomicOr(bad, 2u);
+    if (dmax - dmin > 255) {
+        if (lane == 0) atomicOr(bad, 1u);
+        return;
+    }
+    const int c = dmin + 128;  // b = d - c lies in [-128, 127]
+    int sum = 0;
+    for (uint32_t k = lane; k < K; k += 64) {
+        const int d = sc != 0.0f ? (int)rintf(__fdiv_rn(w[k], sc)) : 0;
+        const int b = d - c;
+        wq[(size_t)n * K + k] = (int8_t)b;
+        sum += b;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    if (lane == 0) {
+        Q8ColMeta m;
+        m.ws = sc;
+        m.zw = -c;
+        m.colsum = sum;
+        m.pad = 0;
+        cmeta[n] = m;
+    }
+}
+
+// ---- the product ----------------------------------------------------------------------------------------------------
+// 128 x 128 tiles, four waves as 2 x 2 (a wave owns 64 x 64 = 4 x 4 MFMA tiles of 16 x 16), two blocks per CU; stage =
+// one 128-B line (128 k) of 128 activation rows and 128 weight rows by LDS-DMA into the swizzled image of split_f16.hpp
+// (sh_mainloop16: same staging, same fragment addresses — a line's slots 0-3 are the first v_mfma_i32_16x16x64_i8 k-step,
+// slots 4-7 the second, where the split-f16 line holds its hi and lo planes).
+template <int EPI>
+__global__ void __launch_bounds__(256, 2)
+gemm_q8_kernel(const int8_t* __restrict__ A, const int8_t* __restrict__ W, const Q8RowMeta* __restrict__ rmeta,
+               const Q8ColMeta* __restrict__ cmeta, const float* __restrict__ bias, const float* resid, float* C,
+               _Float16* __restrict__ Cs, uint32_t M, uint32_t N, uint32_t K, uint32_t* __restrict__ flag,
+               int32_t* __restrict__ acc_dbg) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    uint32_t mt, nt;
+    if (!sh_tile_of_block(blockIdx.x, (M + SH_BM - 1) / SH_BM, N / SH_BN, mt, nt)) return;
+    const uint32_t m0 = mt * SH_BM, n0 = nt * SH_BN;
+    const uint32_t kchunks = K / 128;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    const int l15 = lane & 15, g = lane >> 4;
+    const int8_t* asrc[4];
+    const int8_t* wsrc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = wave * 32 + i * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((row >> 1) & 7);
+        const uint32_t am = (m0 + row < M) ? m0 + row : M - 1;  // rows past M re-read the last one: never stored
+        asrc[i] = A + (size_t)am * K + c * 16;
+        wsrc[i] = W + (size_t)(n0 + row) * K + c * 16;
+    }
+    auto stage = [&](uint32_t kc, char* buf) {
+        char* dst = buf + wave * 32 * 128;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            sh_glds16(asrc[i] + (size_t)kc * 128, dst + i * 1024);
+            sh_glds16(wsrc[i] + (size_t)kc * 128, dst + SH_TILE_BYTES + i * 1024);
+        }
+    };
+    const int swz = (l15 >> 1) & 7;
+    const int arow = (wr * 64 + l15) * 128, wrow = SH_TILE_BYTES + (wc * 64 + l15) * 128;
+    const int s0 = (g ^ swz) * 16, s1 = ((4 + g) ^ swz) * 16;
+    q8_i32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = q8_i32x4{0, 0, 0, 0};
+
+    uint32_t kr = sh_kc_rot(nt, N / SH_BN, kchunks);
+    auto next_chunk = [&]() { const uint32_t c = kr; kr = kr + 1 == kchunks ? 0 : kr + 1; return c; };
+    stage(next_chunk(), lds);
+    __syncthreads();
+    for (uint32_t kc = 0; kc < kchunks; ++kc) {
+        char* cur = lds + (kc & 1) * SH_STAGE_BYTES;
+        if (kc + 1 < kchunks) stage(next_chunk(), lds + ((kc + 1) & 1) * SH_STAGE_BYTES);
+        q8_i32x4 a0[4], a1[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            a0[i] = *reinterpret_cast<const q8_i32x4*>(cur + arow + i * 16 * 128 + s0);
+            a1[i] = *reinterpret_cast<const q8_i32x4*>(cur + arow + i * 16 * 128 + s1);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const q8_i32x4 w0 = *reinterpret_cast<const q8_i32x4*>(cur + wrow + j * 16 * 128 + s0);
+            const q8_i32x4 w1 = *reinterpret_cast<const q8_i32x4*>(cur + wrow + j * 16 * 128 + s1);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                acc[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0[i], w0, acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1[i], w1, acc[i][j], 0, 0, 0);
+            }
+        }
+        __syncthreads();  // stage kc+1 has landed (vmcnt(0) precedes the barrier); cur is free
+    }
+
+    // zero points back in, Cast + Mul(x_scale * W_scale): the tile as f32 into LDS (the stage buffers are free)
+    float* ctile = reinterpret_cast<float*>(lds);
+    Q8ColMeta cm[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) cm[j] = cmeta[n0 + wc * 64 + j * 16 + l15];
+    const int Ki = (int)K;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = wr * 64 + i * 16 + 4 * g + r;
+            const Q8RowMeta rm = rmeta[(m0 + m < M) ? m0 + m : M - 1];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int corr = acc[i][j][r] - cm[j].zw * rm.rowsum - rm.za * cm[j].colsum + Ki * rm.za * cm[j].zw;
+                ctile[m * 128 + wc * 64 + j * 16 + l15] = __fmul_rn((float)corr, __fmul_rn(rm.xs, cm[j].ws));
+                if (acc_dbg && m0 + m < M)  // cs_debug_gemm_q8: the MatMulInteger result itself
+                    acc_dbg[(size_t)(m0 + m) * N + n0 + wc * 64 + j * 16 + l15] = corr;
+            }
+        }
+    __syncthreads();
+    if (m0 + SH_BM <= M) gemm_sh_epilogue<EPI, true, 2>(ctile, bias, resid, C, Cs, M, N, m0, n0, flag);
+    else gemm_sh_epilogue<EPI, false, 2>(ctile, bias, resid, C, Cs, M, N, m0, n0, flag);
+}
+
+}  // namespace
+
+int32_t launch_q8_pack_weight(const float* d_W, const float* d_scale, uint32_t N, uint32_t K, int8_t* d_wq, Q8ColMeta* d_cmeta,
+                              uint32_t* d_bad, hipStream_t s) {
+    if (N == 0 || K == 0) return CS_OK;
+    hipLaunchKernelGGL(q8_pack_weight_kernel, dim3(N), dim3(64), 0, s, d_W, d_scale, N, K, d_wq, d_cmeta, d_bad);
+    CS_HIP(hipGetLastError());
+    return CS_OK;
+}
+
+int32_t launch_q8_quantize(int src_kind, const void* d_src, uint32_t T, uint32_t K, uint32_t* d_range, const uint32_t* d_row_slot,
+                           int8_t* d_xq, Q8RowMeta* d_rmeta, hipStream_t s) {
+    if (K % 32) return fail(CS_ERR_UNSUPPORTED, "dynamic quantisation needs K %% 32 == 0 (K = %u)", K);
+    if (T == 0) return CS_OK;
+    const uint64_t units = (uint64_t)T * (K / (src_kind == Q8_SRC_F32 ? 4 : 8));
+    const uint64_t want = (units + 255) / 256;
+    const dim3 grid_mm((uint32_t)(want < 4096 ? want : 4096));
+    const dim3 grid_q((T + Q8_RB - 1) / Q8_RB);
+    if (src_kind == Q8_SRC_F32) {
+        hipLaunchKernelGGL(q8_minmax_kernel<Q8_SRC_F32>, grid_mm, dim3(256), 0, s, d_src, T, K, d_range, d_row_slot);
+        hipLaunchKernelGGL(q8_quantize_kernel<Q8_SRC_F32>, grid_q, dim3(256), 0, s, d_src, T, K, d_range, d_row_slot, d_xq, d_rmeta);
+    } else {
+        hipLaunchKernelGGL(q8_minmax_kernel<Q8_SRC_SPLIT>, grid_mm, dim3(256), 0, s, d_src, T, K, d_range, d_row_slot);
+        hipLaunchKernelGGL(q8_quantize_kernel<Q8_SRC_SPLIT>, grid_q, dim3(256), 0, s, d_src, T, K, d_range, d_row_slot, d_xq, d_rmeta);
+    }
+    CS_HIP(hipGetLastError());
+    return CS_OK;
+}
+
+int32_t launch_gemm_q8(int epi, const int8_t* d_xq, const Q8RowMeta* d_rmeta, const int8_t* d_wq, const Q8ColMeta* d_cmeta,
+                       const float* bias, const float* resid, float* C, _Float16* Cs, uint32_t M, uint32_t N, uint32_t K,
+                       uint32_t* d_flag, hipStream_t s, int32_t* d_acc_dbg) {
+    if (N % SH_BN || K % 128 || K == 0)
+        return fail(CS_ERR_UNSUPPORTED, "quantised GEMM N=%u K=%u must be multiples of 128", N, K);
+    if (M == 0) return CS_OK;
+    static PerDeviceOnce attr;  // function attributes are per device
+    CS_TRY(attr.run([&]() -> int32_t {
+        CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_q8_kernel<SH_OUT_F32>), hipFuncAttributeMaxDynamicSharedMemorySize, SH_LDS_BYTES));
+        CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_q8_kernel<SH_OUT_F32_RESID>), hipFuncAttributeMaxDynamicSharedMemorySize, SH_LDS_BYTES));
+        CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_q8_kernel<SH_OUT_SPLIT_GELU>), hipFuncAttributeMaxDynamicSharedMemorySize, SH_LDS_BYTES));
+        CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_q8_kernel<SH_OUT_SPLIT>), hipFuncAttributeMaxDynamicSharedMemorySize, SH_LDS_BYTES));
+        return CS_OK;
+    }));
+    const dim3 grid(sh_grid_blocks((M + SH_BM - 1) / SH_BM, N / SH_BN));
+#define CS_Q8_LAUNCH(E) hipLaunchKernelGGL(gemm_q8_kernel<E>, grid, dim3(256), SH_LDS_BYTES, s, d_xq, d_wq, d_rmeta, d_cmeta, bias, resid, C, Cs, M, N, K, d_flag, d_acc_dbg)
+    if (epi == SH_OUT_F32) CS_Q8_LAUNCH(SH_OUT_F32);
+    else if (epi == SH_OUT_F32_RESID) CS_Q8_LAUNCH(SH_OUT_F32_RESID);
+    else if (epi == SH_OUT_SPLIT) CS_Q8_LAUNCH(SH_OUT_SPLIT);
+    else if (epi == SH_OUT_SPLIT_GELU) CS_Q8_LAUNCH(SH_OUT_SPLIT_GELU);
+    else return fail(CS_ERR_BAD_ARG, "quantised GEMM: unknown epilogue %d", epi);
+#undef CS_Q8_LAUNCH
+    CS_HIP(hipGetLastError());
+    return CS_OK;
+}
+
+}  // namespace cs

@@ -1,0 +1,46 @@
+// gemm_q8.hpp — launch interface of the dynamic-quantised dense layers (gemm_q8.hip).
+#pragma once
+#include "common.hpp"
+
+namespace cs {
+
+// What the GEMM needs to know about a row of activations / a column of weights (16 B each):
+//   activation row m:  x[m][k] = (a[m][k] - za) * xs      a = stored s8 (the graph's uint8 minus 128), za = x_zero_point - 128
+//   weight column n:   w[n][k] = (b[n][k] - zw) * ws      b = stored s8 (W_q - W_zp re-centred into [-128, 127])
+// rowsum / colsum are the plain sums of the stored s8 values over k.
+struct Q8RowMeta { float xs; int32_t za; int32_t rowsum; uint32_t pad; };
+struct Q8ColMeta { float ws; int32_t zw; int32_t colsum; uint32_t pad; };
+
+enum { Q8_SRC_F32 = 0, Q8_SRC_SPLIT = 1 };
+
+// One layer's quantised weights, bytes from the start of the layer's block: wqkv [3H][H] | ao [H][H] | up [I][H] | down [H][I]
+struct Q8Layer { size_t qkv, ao, up, down, total; };
+inline Q8Layer q8_layer(uint32_t H, uint32_t I) {
+    Q8Layer o;
+    o.qkv = 0;
+    o.ao = o.qkv + (size_t)3 * H * H;
+    o.up = o.ao + (size_t)H * H;
+    o.down = o.up + (size_t)I * H;
+    o.total = o.down + (size_t)H * I;
+    return o;
+}
+
+// W [N][K] f32 = (integer) * scale[n]  ->  wq [N][K] s8 + cmeta [N].  *d_bad (device u32, zeroed by the caller) is OR-ed
+// with 1 when a row's integers span more than 8 bits, with 2 when a weight is not a multiple of its scale.
+int32_t launch_q8_pack_weight(const float* d_W, const float* d_scale, uint32_t N, uint32_t K, int8_t* d_wq, Q8ColMeta* d_cmeta,
+                              uint32_t* d_bad, hipStream_t s);
+
+// DynamicQuantizeLinear of [T][K] activations (f32 rows, or split-f16 lines [T][K/32][64]):
+//   d_range [slots][2] u32: running (lo, hi) of each quantisation unit, all zero before the first call of a forward slot
+//   d_row_slot (may be null: one unit, slot 0): per row, the unit it belongs to; bit 31 set = the row lies outside its unit's
+//              own padded length (not part of the tensor the reference quantises): quantised, but kept out of the range
+// -> d_xq [T][K] s8, d_rmeta [T].
+int32_t launch_q8_quantize(int src_kind, const void* d_src, uint32_t T, uint32_t K, uint32_t* d_range, const uint32_t* d_row_slot,
+                           int8_t* d_xq, Q8RowMeta* d_rmeta, hipStream_t s);
+
+// C = MatMulInteger(xq, wq) * (xs * ws) + bias, then the epilogue `epi` (SH_OUT_*, encoder.hpp).  N % 128 == 0, K % 128 == 0.
+int32_t launch_gemm_q8(int epi, const int8_t* d_xq, const Q8RowMeta* d_rmeta, const int8_t* d_wq, const Q8ColMeta* d_cmeta,
+                       const float* bias, const float* resid, float* C, _Float16* Cs, uint32_t M, uint32_t N, uint32_t K,
+                       uint32_t* d_flag, hipStream_t s, int32_t* d_acc_dbg = nullptr);
+
+}  // namespace cs

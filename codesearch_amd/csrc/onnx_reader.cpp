@@ -25,10 +25,11 @@
 // downloads its model_quantized.onnx, written by onnxruntime's dynamic quantiser): every Linear weight W is stored as
 // W_quantized (INT8 / UINT8, [in, out]) + W_scale + W_zero_point — per tensor or per channel — and consumed by
 // DynamicQuantizeLinear -> MatMulInteger -> Cast -> Mul(scales) -> Add(bias); Gather tables may be quantised in place the
-// same way.  They are read as w = (q - zero_point) * scale into the f32 block: the encoder then runs the f32 GRAPH OF THE
-// QUANTISED WEIGHTS.  It does not re-quantise activations to 8 bits per call as ORT's MatMulInteger path does, so its
-// embeddings differ from the reference's by that activation-rounding noise (the weights, the dominant quantisation
-// error, are bit-for-bit the file's).
+// same way.  They are read as w = (q - zero_point) * scale into the f32 block, and cs_bert_params_from_onnx_q also hands out
+// every weight column's scale: with those the embedder runs each Linear as the file's graph does (activations re-quantised
+// to 8 bits per call, integer product: csrc/gemm_q8.hip, CS_GEMM_Q8_DYNAMIC).  Without them (CS_ENCODER_QUANT=0, or a file
+// only part of whose Linears are quantised) it runs the f32 GRAPH OF THE QUANTISED WEIGHTS, whose embeddings differ from
+// the reference's by the activation-rounding noise.
 #include <fcntl.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
@@ -375,7 +376,18 @@ const Tensor* weight_of_bias(const Model& m, const std::string& bias_name, uint6
 extern "C" {
 
 int32_t cs_bert_params_from_onnx(const char* path, const cs_bert_config* cfg, float* params, uint64_t n_params) {
+    return cs_bert_params_from_onnx_q(path, cfg, params, n_params, nullptr, 0, nullptr);
+}
+
+int32_t cs_bert_params_from_onnx_q(const char* path, const cs_bert_config* cfg, float* params, uint64_t n_params,
+                                   float* wscale, uint64_t n_wscale, int32_t* quantized) {
+    if (quantized) *quantized = 0;
     if (!path || !cfg || !params) return fail(CS_ERR_BAD_ARG, "null argument");
+    const uint64_t qcols = 5 * (uint64_t)cfg->hidden + cfg->intermediate;
+    if (wscale && n_wscale != (uint64_t)cfg->layers * qcols)
+        return fail(CS_ERR_BAD_ARG, "Failed to initialize embedding model: room for %llu column scales, %llu needed",
+                    (unsigned long long)n_wscale, (unsigned long long)((uint64_t)cfg->layers * qcols));
+    bool all_quantized = true;  // every Linear of every layer an INT8 / UINT8 initialiser behind MatMulInteger
     cs_bert_offsets o;
     cs_bert_layout(cfg, &o);
     if (n_params != o.total)
@@ -442,10 +454,13 @@ int32_t cs_bert_params_from_onnx(const char* path, const cs_bert_config* cfg, fl
         return copy_matrix(*t, rows, H, false, dst, name.c_str());
     };
     // a Linear layer: weight [out, in] + bias [out]
-    auto linear = [&](const std::string& prefix, uint64_t out, uint64_t in, float* w_dst, float* b_dst) -> int32_t {
+    // sc_dst (optional): the scale of each of the `out` columns when the weight is quantised per tensor or per output
+    // channel — the two forms MatMulInteger's b_zero_point allows; anything else clears all_quantized
+    auto linear = [&](const std::string& prefix, uint64_t out, uint64_t in, float* w_dst, float* b_dst, float* sc_dst) -> int32_t {
         const std::string bname = prefix + ".bias", wname = prefix + ".weight";
         CS_TRY(vec(bname, out, b_dst));
         if (const Tensor* w = named(wname)) {  // name kept (Gemm exports, hand-built files)
+            all_quantized = false;
             if (shape_is(*w, {out, in})) return copy_matrix(*w, out, in, false, w_dst, wname.c_str());
             return fail(CS_ERR_DIM_MISMATCH, "Failed to initialize embedding model: %s does not have shape [%llu, %llu]",
                         wname.c_str(), (unsigned long long)out, (unsigned long long)in);
@@ -456,6 +471,17 @@ int32_t cs_bert_params_from_onnx(const char* path, const cs_bert_config* cfg, fl
         if (!w)
             return fail(CS_ERR_BAD_ARG, "Failed to initialize embedding model: no MatMul/Gemm/MatMulInteger weight of shape [%llu, %llu] "
                         "feeds the Add of %s in %s", (unsigned long long)in, (unsigned long long)out, bname.c_str(), path);
+        bool per_column = false;
+        if (q.scale && tr && (w->dtype == 2 || w->dtype == 3)) {
+            Reader rs(*q.scale);
+            const uint64_t ns = q.scale->count();
+            if (rs.ok && (ns == 1 || ns == out)) {
+                per_column = true;
+                if (sc_dst)
+                    for (uint64_t c = 0; c < out; ++c) sc_dst[c] = rs.at(ns == 1 ? 0 : c);
+            }
+        }
+        if (!per_column) all_quantized = false;
         return copy_matrix(*w, out, in, tr, w_dst, wname.c_str(), q.scale ? &q : nullptr);
     };
 
@@ -473,11 +499,13 @@ int32_t cs_bert_params_from_onnx(const char* path, const cs_bert_config* cfg, fl
         cs_bert_layer_offsets lo;
         cs_bert_layer_layout(cfg, &o, l, &lo);
         const std::string p = "encoder.layer." + std::to_string(l) + ".";
+        float* sc = wscale ? wscale + (size_t)l * qcols : nullptr;  // query | key | value | attention.output | intermediate | output
         if (named(p + "attention.self.query.bias")) {
-            CS_TRY(linear(p + "attention.self.query", H, H, params + lo.q_w, params + lo.q_b));
-            CS_TRY(linear(p + "attention.self.key", H, H, params + lo.k_w, params + lo.k_b));
-            CS_TRY(linear(p + "attention.self.value", H, H, params + lo.v_w, params + lo.v_b));
+            CS_TRY(linear(p + "attention.self.query", H, H, params + lo.q_w, params + lo.q_b, sc));
+            CS_TRY(linear(p + "attention.self.key", H, H, params + lo.k_w, params + lo.k_b, sc ? sc + H : nullptr));
+            CS_TRY(linear(p + "attention.self.value", H, H, params + lo.v_w, params + lo.v_b, sc ? sc + 2 * H : nullptr));
         } else if (fused.size() == cfg->layers) {
+            all_quantized = false;
             const Tensor* w = m.resolve(fused[l]->in[1]);
             const Tensor* b = m.resolve(fused[l]->in[2]);
             if (!w || !b || !shape_is(*w, {H, 3 * H}) || b->count() != 3 * H)
@@ -500,14 +528,15 @@ int32_t cs_bert_params_from_onnx(const char* path, const cs_bert_config* cfg, fl
             return fail(CS_ERR_BAD_ARG, "Failed to initialize embedding model: %s has neither %sattention.self.query.bias nor "
                         "one fused Attention node per layer", path, p.c_str());
         }
-        CS_TRY(linear(p + "attention.output.dense", H, H, params + lo.ao_w, params + lo.ao_b));
+        CS_TRY(linear(p + "attention.output.dense", H, H, params + lo.ao_w, params + lo.ao_b, sc ? sc + 3 * H : nullptr));
         CS_TRY(vec(p + "attention.output.LayerNorm.weight", H, params + lo.ao_ln_g));
         CS_TRY(vec(p + "attention.output.LayerNorm.bias", H, params + lo.ao_ln_b));
-        CS_TRY(linear(p + "intermediate.dense", I, H, params + lo.up_w, params + lo.up_b));
-        CS_TRY(linear(p + "output.dense", H, I, params + lo.down_w, params + lo.down_b));
+        CS_TRY(linear(p + "intermediate.dense", I, H, params + lo.up_w, params + lo.up_b, sc ? sc + 4 * H : nullptr));
+        CS_TRY(linear(p + "output.dense", H, I, params + lo.down_w, params + lo.down_b, sc ? sc + 4 * H + I : nullptr));
         CS_TRY(vec(p + "output.LayerNorm.weight", H, params + lo.out_ln_g));
         CS_TRY(vec(p + "output.LayerNorm.bias", H, params + lo.out_ln_b));
     }
+    if (quantized) *quantized = all_quantized ? 1 : 0;
     return CS_OK;
 }
 

@@ -127,7 +127,7 @@ class FastEmbedder:
 
     def __init__(self, model_type: ModelType = None, cache_dir=None, *, config: BertConfig = None,
                  params: np.ndarray = None, seed: int = 0, device: int = 0, tokenizer=None,
-                 gemm_mode: Optional[str] = None):
+                 gemm_mode: Optional[str] = None, wscale: np.ndarray = None):
         self._lib = _lib.load()
         self._model_type = model_type or ModelType.default()
         self.config = config or self._model_type.bert_config()
@@ -144,14 +144,24 @@ class FastEmbedder:
                               f"Failed to initialize embedding model: expected {need} parameters, got {params.size}")
             pptr = params.ctypes.data_as(f32p)
         h = C.c_void_p()
-        _lib.check(self._lib.cs_embedder_create(C.byref(ccfg), pptr, seed, device, C.byref(h)))
+        if wscale is not None:
+            # a dynamically quantised model (bert_params.quantize_linear_weights / a *Q file): params hold integer
+            # multiples of the column scales wscale [layers, 5H + I]; runs as CS_GEMM_Q8_DYNAMIC ("q8") by default
+            if pptr is None:
+                raise CsError(_lib.CS_ERR_BAD_ARG, "Failed to initialize embedding model: a quantised model needs its parameters")
+            wscale = np.ascontiguousarray(wscale, np.float32)
+            _lib.check(self._lib.cs_embedder_create_quantized(C.byref(ccfg), pptr, wscale.ctypes.data_as(f32p), wscale.size,
+                                                              device, C.byref(h)))
+        else:
+            _lib.check(self._lib.cs_embedder_create(C.byref(ccfg), pptr, seed, device, C.byref(h)))
         self._h = h
         if gemm_mode is not None:
             self.set_gemm_mode(gemm_mode)
 
     def set_gemm_mode(self, mode: str) -> None:
-        """"split" (default: split-f16 operands on the f16 MFMA) or "f32" (exact-f32 MFMA)."""
-        m = {"f32": _lib.CS_GEMM_F32, "split": _lib.CS_GEMM_SPLIT_F16}[mode]
+        """"split" (default: split-f16 operands on the f16 MFMA), "f32" (exact-f32 MFMA) or, for a quantised model (and
+        its default), "q8": every Linear as onnxruntime's dynamic quantiser runs it (CS_GEMM_Q8_DYNAMIC)."""
+        m = {"f32": _lib.CS_GEMM_F32, "split": _lib.CS_GEMM_SPLIT_F16, "q8": _lib.CS_GEMM_Q8_DYNAMIC}[mode]
         _lib.check(self._lib.cs_embedder_set_gemm_mode(self._h, m))
 
     def debug_counters(self):

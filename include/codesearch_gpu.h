@@ -353,9 +353,11 @@ int32_t cs_embedder_create(const cs_bert_config* cfg, const float* params, uint6
  *     named parameters directly, Linear weights through the MatMul/Gemm feeding each bias's Add, the packed
  *     QKV of ORT-optimised files through their fused Attention nodes.
  * F32, F16 or BF16; pooler / position_ids / other extras ignored.  Dynamically quantised exports (the *Q models of
- * the registry, among them the reference's default AllMiniLML6V2Q, embedder.rs:12-13: INT8 / UINT8 weights with scale and
- * zero point behind MatMulInteger) are read as (q - zero_point) * scale: the encoder runs the f32 graph of the quantised
- * weights and does not re-quantise activations per call as ORT does.  All loaders are host-only. */
+ * the registry, among them the reference's default AllMiniLML6V2Q, embedder.rs:12-13: onnx/model_quantized.onnx — INT8 /
+ * UINT8 weights with scale and zero point behind MatMulInteger) are read as (q - zero_point) * scale into the f32 block and,
+ * when every Linear of every layer is quantised, the embedder runs them the way the file's graph does (CS_GEMM_Q8_DYNAMIC
+ * below: activations re-quantised to 8 bits per call, integer products); CS_ENCODER_QUANT=0 in the environment keeps the
+ * f32 graph of the quantised weights instead.  All loaders are host-only. */
 /* pooling: CS_POOL_CLS, CS_POOL_MEAN, or -1 = what <model_dir>/1_Pooling/config.json says (the
  * sentence-transformers module: mean for MiniLM / E5, CLS for BGE), CLS when that file is absent. */
 int32_t cs_bert_config_from_dir(const char* model_dir, int32_t pooling, cs_bert_config* cfg);
@@ -363,6 +365,19 @@ int32_t cs_bert_params_from_safetensors(const char* path, const cs_bert_config* 
                                         float* params, uint64_t n_params);
 int32_t cs_bert_params_from_onnx(const char* path, const cs_bert_config* cfg, float* params,
                                  uint64_t n_params);
+/* The same, also reporting the file's quantisation: wscale (optional, cs_bert_quant_columns(cfg) * layers floats) receives
+ * the scale of every output column of the six Linear weights of every layer (a per-tensor scale repeated over its columns),
+ * in the order query | key | value | attention.output | intermediate | output; *quantized = 1 when ALL of them are INT8 /
+ * UINT8 initialisers behind MatMulInteger (then `params` holds exact multiples of these scales), else 0. */
+int32_t cs_bert_params_from_onnx_q(const char* path, const cs_bert_config* cfg, float* params, uint64_t n_params,
+                                   float* wscale, uint64_t n_wscale, int32_t* quantized);
+/* Output columns of one layer's Linear weights: 5 * hidden + intermediate. */
+uint64_t cs_bert_quant_columns(const cs_bert_config* cfg);
+/* A dynamically quantised model (what onnxruntime's quantize_dynamic writes; see CS_GEMM_Q8_DYNAMIC).  `params` as for
+ * cs_embedder_create, with every Linear weight W[n][k] an integer multiple of wscale[layer][column n] whose integers span at
+ * most 8 bits per column (anything else -> CS_ERR_BAD_ARG); wscale: layers * cs_bert_quant_columns(cfg) floats. */
+int32_t cs_embedder_create_quantized(const cs_bert_config* cfg, const float* params, const float* wscale,
+                                     uint64_t n_wscale, int32_t device, cs_embedder** out);
 /* config.json + weights -> embedder on `device` (the tokenizer of the same directory comes from
  * cs_tokenizer_create_from_dir). */
 int32_t cs_embedder_create_from_dir(const char* model_dir, int32_t pooling, int32_t device,
@@ -532,8 +547,14 @@ int32_t cs_embedders_index_ids(cs_embedders* e, cs_shards* store, const int32_t*
  * CS_GEMM_F32: the exact-f32 MFMA (bit-for-bit an fmaf chain), 16/3 x the matrix-pipe time.
  * A mini-batch whose activations leave the f16 range (|x| > 65504) is recomputed with
  * CS_GEMM_F32 automatically; cs_embedder_debug_counters reports how often.
- * The environment variable CS_ENCODER_GEMM=f32|split sets the default at create time. */
-typedef enum cs_gemm_mode { CS_GEMM_F32 = 0, CS_GEMM_SPLIT_F16 = 1 } cs_gemm_mode;
+ * The environment variable CS_ENCODER_GEMM=f32|split sets the default at create time.
+ * CS_GEMM_Q8_DYNAMIC (embedders of quantised models only, and their default): every Linear as onnxruntime's dynamic
+ * quantiser rewrites it — DynamicQuantizeLinear of the layer's input (uint8, one range per call tensor, padding rows
+ * included) -> MatMulInteger -> * (x_scale * W_scale) -> + bias — with the integer product on the int8 MFMA (exact).  What
+ * "one call tensor" is: the sequences of ONE embed call's mini-batch (`batch` rows in the caller's order, padded to the
+ * longest of them, as fastembed hands them to ORT); length grouping, token-budget batches, stream slices and the CLS tail
+ * are off in this mode because each would change that tensor.  Attention, LayerNorm, GELU and pooling stay f32-class. */
+typedef enum cs_gemm_mode { CS_GEMM_F32 = 0, CS_GEMM_SPLIT_F16 = 1, CS_GEMM_Q8_DYNAMIC = 2 } cs_gemm_mode;
 int32_t cs_embedder_set_gemm_mode(cs_embedder* h, int32_t mode);
 int32_t cs_embedder_debug_counters(cs_embedder* h, uint64_t* split_forwards,
                                    uint64_t* f32_forwards, uint64_t* range_fallbacks);
@@ -547,6 +568,15 @@ int32_t cs_embedder_debug_counters(cs_embedder* h, uint64_t* split_forwards,
 int32_t cs_debug_gemm(int32_t device, int32_t mode, int32_t epilogue, const float* A,
                       const float* W, const float* bias, const float* resid, float* C,
                       uint32_t M, uint32_t N, uint32_t K, uint32_t* range_flag);
+
+/* Diagnostics: one dynamically quantised dense layer on host buffers (unit parity of csrc/gemm_q8.hip against the ONNX
+ * definitions of DynamicQuantizeLinear / MatMulInteger).  A [M,K] f32 activations (a_split != 0: staged through the
+ * split-f16 form first, as attention and GELU hand them over); W [N,K] f32 = integer multiples of wscale[n]; epilogue as
+ * cs_debug_gemm 0 / 1 / 2, 4 = bias -> split store.  Optional outputs: xq [M,K] the uint8 activations, xparams[2] =
+ * (x_scale, x_zero_point), acc [M,N] the int32 MatMulInteger result.  N % 128 == 0, K % 128 == 0. */
+int32_t cs_debug_gemm_q8(int32_t device, int32_t epilogue, int32_t a_split, const float* A, const float* W,
+                         const float* wscale, const float* bias, const float* resid, float* C, uint32_t M, uint32_t N,
+                         uint32_t K, uint8_t* xq, float* xparams, int32_t* acc);
 
 /* Diagnostics: device milliseconds per launch of one dense layer on synthetic operands resident in HBM.
  * mode 0 exact-f32 MFMA, 1 split-f16 (128 x 128 / skinny kernels), 2 split-f16 wide kernel (N % 384 == 0);

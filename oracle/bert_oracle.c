@@ -53,6 +53,60 @@ static void linear(const float* x, const float* w, const float* b, float* y, siz
     free(wt);
 }
 
+/* ---- dynamic quantisation (the registry's *Q models; the reference's DEFAULT model is one: ModelType::AllMiniLML6V2Q,
+ * /root/reference/src/embed/embedder.rs:12-13,367-372) -------------------------------------------------------------
+ * Their ONNX files come out of onnxruntime's quantize_dynamic: every Linear is
+ *   x -> DynamicQuantizeLinear -> MatMulInteger(x_q, W_q, x_zp, W_zp) -> Cast(f32) -> Mul(x_scale * W_scale) -> Add(bias)
+ * The ops are ONNX standard ops (opset 11 / 10); this restates their published definitions:
+ *   DynamicQuantizeLinear (per tensor, uint8):  lo = min(0, min x), hi = max(0, max x);
+ *       x_scale = (hi - lo) / 255   (1 when hi == lo);   x_zp = sat_u8(round_half_even(0 - lo / x_scale));
+ *       x_q = sat_u8(round_half_even(x / x_scale) + x_zp)
+ *   MatMulInteger:  acc[t][n] = sum_k (x_q[t][k] - x_zp) * (W_q[k][n] - W_zp[n])   in int32 (exact)
+ * `w` is the f32 block's dequantised weight (W_q - W_zp) * W_scale, [N][K]; the integers W_q - W_zp are recovered
+ * exactly as round(w / W_scale) (at most 255 in magnitude, one f32 rounding in w; a zero scale means a zero column), so
+ * the zero point itself is not needed.  wscale: one per output column n (a per-tensor file repeats its value).  PARITY UNPINNED against onnxruntime itself (not installed here; no model file offline). */
+static void linear_q8(const float* x, const float* w, const float* wscale, const float* b,
+                      float* y, size_t T, size_t K, size_t N) {
+    float lo = 0.0f, hi = 0.0f;
+    for (size_t i = 0; i < T * K; ++i) {
+        if (x[i] < lo) lo = x[i];
+        if (x[i] > hi) hi = x[i];
+    }
+    const float xs = hi == lo ? 1.0f : (hi - lo) / 255.0f;
+    float z = 0.0f - lo / xs;
+    if (z < 0.0f) z = 0.0f;
+    if (z > 255.0f) z = 255.0f;
+    const int32_t xz = (int32_t)nearbyintf(z); /* FE_TONEAREST: ties to even */
+    uint8_t* xq = (uint8_t*)malloc(T * K);
+    for (size_t i = 0; i < T * K; ++i) {
+        float v = nearbyintf(x[i] / xs) + (float)xz;
+        if (v < 0.0f) v = 0.0f;
+        if (v > 255.0f) v = 255.0f;
+        xq[i] = (uint8_t)v;
+    }
+    int32_t* wq = (int32_t*)malloc(sizeof(int32_t) * K * N); /* [K][N], already minus its zero point */
+    for (size_t n = 0; n < N; ++n)
+        for (size_t k = 0; k < K; ++k)
+            wq[k * N + n] = wscale[n] != 0.0f ? (int32_t)nearbyintf(w[n * K + k] / wscale[n]) : 0;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static)
+#endif
+    for (int64_t t = 0; t < (int64_t)T; ++t) {
+        int32_t* acc = (int32_t*)calloc(N, sizeof(int32_t));
+        const uint8_t* xt = xq + (size_t)t * K;
+        for (size_t k = 0; k < K; ++k) {
+            const int32_t xv = (int32_t)xt[k] - xz;
+            const int32_t* wr = wq + k * N;
+            for (size_t n = 0; n < N; ++n) acc[n] += xv * wr[n];
+        }
+        float* yt = y + (size_t)t * N;
+        for (size_t n = 0; n < N; ++n) yt[n] = (float)acc[n] * (xs * wscale[n]) + b[n];
+        free(acc);
+    }
+    free(wq);
+    free(xq);
+}
+
 static void layer_norm_rows(float* x, const float* g, const float* b, size_t T, size_t H, float eps) {
 #ifdef _OPENMP
 #pragma omp parallel for schedule(static)
@@ -75,9 +129,10 @@ static inline float gelu_erf(float v) { return 0.5f * v * (1.0f + erff(v * 0.707
 /* ids/mask: [B, L] int32.  hidden_out: optional [B*L*H] last_hidden_state.  pooled_out:
  * [B, H] pooled + L2-normalised.  layer_hidden_out: optional [layers+1][B*L*H] (embedding
  * output then every layer's output) for per-layer parity checks. */
-void cs_oracle_bert_forward(const cs_bert_config* cfg, const float* params, const int32_t* ids,
-                            const int32_t* mask, uint32_t B, uint32_t L, float* hidden_out,
-                            float* pooled_out, float* layer_hidden_out) {
+static void bert_forward_impl(const cs_bert_config* cfg, const float* params, const float* qscale,
+                              const int32_t* ids,
+                              const int32_t* mask, uint32_t B, uint32_t L, float* hidden_out,
+                              float* pooled_out, float* layer_hidden_out) {
     const size_t H = cfg->hidden, I = cfg->intermediate, NH = cfg->heads, DH = H / NH;
     const size_t T = (size_t)B * L;
     cs_bert_offsets off;
@@ -106,9 +161,19 @@ void cs_oracle_bert_forward(const cs_bert_config* cfg, const float* params, cons
     for (uint32_t l = 0; l < cfg->layers; ++l) {
         cs_bert_layer_offsets lo;
         cs_bert_layer_layout(cfg, &off, l, &lo);
-        linear(x, params + lo.q_w, params + lo.q_b, q, T, H, H);
-        linear(x, params + lo.k_w, params + lo.k_b, k, T, H, H);
-        linear(x, params + lo.v_w, params + lo.v_b, v, T, H, H);
+        /* quantised files: column scales of the layer, query | key | value | attention.output |
+         * intermediate | output (cs_bert_quant_columns, include/cs_bert_params.h) */
+        const size_t qcols = 5 * H + I;
+        const float* qs = qscale ? qscale + (size_t)l * qcols : NULL;
+#define DENSE(xin, W, Bv, yout, Kk, Nn, col0)                                                     \
+    do {                                                                                          \
+        if (qs) linear_q8(xin, params + (W), qs + (col0), params + (Bv), yout, T, Kk, Nn);           \
+        else linear(xin, params + (W), params + (Bv), yout, T, Kk, Nn);                           \
+    } while (0)
+        /* (the three projections share one DynamicQuantizeLinear of x in the graph: same x, same parameters) */
+        DENSE(x, lo.q_w, lo.q_b, q, H, H, 0);
+        DENSE(x, lo.k_w, lo.k_b, k, H, H, H);
+        DENSE(x, lo.v_w, lo.v_b, v, H, H, 2 * H);
         /* attention per (batch, head, query row) */
 #ifdef _OPENMP
 #pragma omp parallel for collapse(2) schedule(static)
@@ -142,12 +207,13 @@ void cs_oracle_bert_forward(const cs_bert_config* cfg, const float* params, cons
                 free(s);
             }
         }
-        linear(ctx, params + lo.ao_w, params + lo.ao_b, tmp, T, H, H);
+        DENSE(ctx, lo.ao_w, lo.ao_b, tmp, H, H, 3 * H);
         for (size_t i = 0; i < T * H; ++i) x[i] = tmp[i] + x[i]; /* BertSelfOutput: dense + residual */
         layer_norm_rows(x, params + lo.ao_ln_g, params + lo.ao_ln_b, T, H, cfg->layer_norm_eps);
-        linear(x, params + lo.up_w, params + lo.up_b, mid, T, H, I);
+        DENSE(x, lo.up_w, lo.up_b, mid, H, I, 4 * H);
         for (size_t i = 0; i < T * I; ++i) mid[i] = gelu_erf(mid[i]);
-        linear(mid, params + lo.down_w, params + lo.down_b, tmp, T, I, H);
+        DENSE(mid, lo.down_w, lo.down_b, tmp, I, H, 4 * H + I);
+#undef DENSE
         for (size_t i = 0; i < T * H; ++i) x[i] = tmp[i] + x[i];
         layer_norm_rows(x, params + lo.out_ln_g, params + lo.out_ln_b, T, H, cfg->layer_norm_eps);
         if (layer_hidden_out) memcpy(layer_hidden_out + (size_t)(l + 1) * T * H, x, sizeof(float) * T * H);
@@ -178,6 +244,20 @@ void cs_oracle_bert_forward(const cs_bert_config* cfg, const float* params, cons
         }
     }
     free(x); free(q); free(k); free(v); free(ctx); free(tmp); free(mid);
+}
+
+void cs_oracle_bert_forward(const cs_bert_config* cfg, const float* params, const int32_t* ids,
+                            const int32_t* mask, uint32_t B, uint32_t L, float* hidden_out,
+                            float* pooled_out, float* layer_hidden_out) {
+    bert_forward_impl(cfg, params, NULL, ids, mask, B, L, hidden_out, pooled_out, layer_hidden_out);
+}
+
+/* The same forward with every Linear run as onnxruntime's dynamic quantiser rewrites it (linear_q8 above): ONE
+ * quantisation of each activation tensor [B*L, K] per call — padding rows included, as the graph sees them. */
+void cs_oracle_bert_forward_q8(const cs_bert_config* cfg, const float* params, const float* wscale,
+                               const int32_t* ids, const int32_t* mask, uint32_t B,
+                               uint32_t L, float* hidden_out, float* pooled_out, float* layer_hidden_out) {
+    bert_forward_impl(cfg, params, wscale, ids, mask, B, L, hidden_out, pooled_out, layer_hidden_out);
 }
 
 void cs_oracle_bert_synth_params(const cs_bert_config* cfg, uint64_t seed, float* out) {

@@ -76,6 +76,13 @@ struct cs_bert_config; /* include/codesearch_gpu.h */
 void cs_oracle_bert_forward(const struct cs_bert_config* cfg, const float* params,
                             const int32_t* ids, const int32_t* mask, uint32_t B, uint32_t L,
                             float* hidden_out, float* pooled_out, float* layer_hidden_out);
+/* Dynamic-quantised Linear layers (the registry's *Q models, onnxruntime quantize_dynamic files): `params` holds the
+ * dequantised weights (W_q - W_zp) * W_scale; wscale [layers][5H + I] gives each output column's scale in the order
+ * query | key | value | attention.output | intermediate | output (include/cs_bert_params.h).  Every Linear
+ * = DynamicQuantizeLinear(x over the whole [B*L, K] tensor) -> MatMulInteger -> * (x_scale * w_scale) -> + bias. */
+void cs_oracle_bert_forward_q8(const struct cs_bert_config* cfg, const float* params, const float* wscale,
+                               const int32_t* ids, const int32_t* mask, uint32_t B, uint32_t L,
+                               float* hidden_out, float* pooled_out, float* layer_hidden_out);
 /* Flat parameter block from the synthetic rule of include/cs_bert_params.h. */
 void cs_oracle_bert_synth_params(const struct cs_bert_config* cfg, uint64_t seed, float* out);
 uint64_t cs_oracle_bert_param_count(const struct cs_bert_config* cfg);

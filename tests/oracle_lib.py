@@ -48,6 +48,8 @@ class Oracle:
         lib.cs_oracle_bert_forward.restype = None
         lib.cs_oracle_bert_forward.argtypes = [C.c_void_p, c_f32p, c_i32p, c_i32p, C.c_uint32, C.c_uint32, c_f32p, c_f32p, c_f32p]
         lib.cs_oracle_bert_synth_params.restype = None
+        lib.cs_oracle_bert_forward_q8.restype = None
+        lib.cs_oracle_bert_forward_q8.argtypes = [C.c_void_p, c_f32p, c_f32p, c_i32p, c_i32p, C.c_uint32, C.c_uint32, c_f32p, c_f32p, c_f32p]
         lib.cs_oracle_bert_synth_params.argtypes = [C.c_void_p, C.c_uint64, c_f32p]
         lib.cs_oracle_bert_param_count.restype = C.c_uint64
         lib.cs_oracle_bert_param_count.argtypes = [C.c_void_p]
@@ -113,8 +115,9 @@ class Oracle:
         self.lib.cs_oracle_bert_synth_params(C.byref(c), seed, _ptr(out, c_f32p))
         return out
 
-    def bert_forward(self, cfg, params, ids, mask, want_hidden=False, want_layers=False):
-        """-> dict(pooled [B,H], hidden [B,L,H]?, layers [layers+1,B,L,H]?)"""
+    def bert_forward(self, cfg, params, ids, mask, want_hidden=False, want_layers=False, wscale=None):
+        """-> dict(pooled [B,H], hidden [B,L,H]?, layers [layers+1,B,L,H]?).  wscale [layers, 5H + I]: run every
+        Linear as onnxruntime's dynamic quantiser rewrites it (cs_oracle_bert_forward_q8)."""
         c = cfg.to_c()
         params = np.ascontiguousarray(params, np.float32)
         ids = np.ascontiguousarray(ids, np.int32)
@@ -124,8 +127,15 @@ class Oracle:
         pooled = np.empty((B, H), np.float32)
         hidden = np.empty((B, L, H), np.float32) if want_hidden else None
         layers = np.empty((cfg.layers + 1, B, L, H), np.float32) if want_layers else None
-        self.lib.cs_oracle_bert_forward(C.byref(c), _ptr(params, c_f32p), _ptr(ids, c_i32p), _ptr(mask, c_i32p),
-                                        B, L, _ptr(hidden, c_f32p), _ptr(pooled, c_f32p), _ptr(layers, c_f32p))
+        if wscale is not None:
+            wscale = np.ascontiguousarray(wscale, np.float32)
+            assert wscale.shape == (cfg.layers, 5 * H + cfg.intermediate)
+            self.lib.cs_oracle_bert_forward_q8(C.byref(c), _ptr(params, c_f32p), _ptr(wscale, c_f32p), _ptr(ids, c_i32p),
+                                               _ptr(mask, c_i32p), B, L, _ptr(hidden, c_f32p), _ptr(pooled, c_f32p),
+                                               _ptr(layers, c_f32p))
+        else:
+            self.lib.cs_oracle_bert_forward(C.byref(c), _ptr(params, c_f32p), _ptr(ids, c_i32p), _ptr(mask, c_i32p),
+                                            B, L, _ptr(hidden, c_f32p), _ptr(pooled, c_f32p), _ptr(layers, c_f32p))
         return {"pooled": pooled, "hidden": hidden, "layers": layers}
 
     # ---- synthetic data --------------------------------------------------------

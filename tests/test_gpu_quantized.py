@@ -1,0 +1,213 @@
+"""Dynamically quantised models (the registry's *Q entries; the reference's DEFAULT model is one,
+/root/reference/src/embed/embedder.rs:12-13): csrc/gemm_q8.hip through the C ABI.
+
+Two bars.  (1) Operator level — the same activations in, the same integers out: DynamicQuantizeLinear's bytes and
+parameters and MatMulInteger's int32 results are compared EXACTLY with a numpy statement of the ONNX definitions, and
+the f32 scale / bias / residual stage bit for bit.  (2) Model level — against oracle/bert_oracle.c's quantised forward:
+an 8-bit rounding sits behind every Linear, so two f32-class evaluations of the same graph (different summation order in
+LayerNorm, another erf) disagree on a handful of activation bytes per tensor — a few 1e-4 on an embedding component;
+the bar is therefore statistical (cosine and max error), and the test shows the quantised forward is what was run by
+comparing against the f32 graph of the same weights, which sits an order of magnitude further away."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from codesearch_amd import _lib
+from codesearch_amd._lib import f32p
+from codesearch_amd.bert_params import (POOL_CLS, POOL_MEAN, BertConfig, quant_columns, quantize_linear_weights,
+                                        synth_params, synth_token_batch)
+
+pytestmark = pytest.mark.gpu
+
+
+def quantize_matrix(W, per_channel, unsigned):
+    """onnxruntime's weight quantisation of one [N, K] matrix -> (dequantised W, integers q - zp, scale [N])."""
+    W = np.asarray(W, np.float32)
+    axis = 1 if per_channel else None
+    lo = np.minimum(W.min(axis=axis, keepdims=True), np.float32(0))
+    hi = np.maximum(W.max(axis=axis, keepdims=True), np.float32(0))
+    if unsigned:
+        scale = ((hi - lo) / np.float32(255)).astype(np.float32)
+        zp = np.clip(np.rint(-lo / scale), 0, 255)
+        q = np.clip(np.rint(W / scale) + zp, 0, 255)
+    else:
+        scale = (np.maximum(np.abs(lo), np.abs(hi)) / np.float32(127)).astype(np.float32)
+        zp = np.zeros_like(scale)
+        q = np.clip(np.rint(W / scale), -127, 127)
+    d = (q - zp).astype(np.int64)
+    sc = np.broadcast_to(scale.reshape(-1), (W.shape[0],)).astype(np.float32) if per_channel \
+        else np.full(W.shape[0], scale.reshape(-1)[0], np.float32)
+    return (d.astype(np.float32) * sc[:, None]).astype(np.float32), d, sc
+
+
+def dynamic_quantize(x):
+    """ONNX DynamicQuantizeLinear (opset 11), float32 arithmetic -> (uint8 tensor, scale, zero point)."""
+    x = np.asarray(x, np.float32)
+    lo = np.minimum(np.float32(0), x.min())
+    hi = np.maximum(np.float32(0), x.max())
+    scale = np.float32(1) if hi == lo else np.float32((hi - lo) / np.float32(255))
+    zp = np.float32(np.rint(np.clip(np.float32(0) - np.float32(lo / scale), 0, 255)))
+    q = np.clip(np.rint((x / scale).astype(np.float32)) + zp, 0, 255).astype(np.uint8)
+    return q, scale, int(zp)
+
+
+def run_q8(lib, epi, A, W, sc, bias, resid=None, a_split=0):
+    M, K = A.shape
+    N = W.shape[0]
+    C_ = np.empty((M, N), np.float32)
+    xq = np.empty((M, K), np.uint8)
+    xp = np.empty(2, np.float32)
+    acc = np.empty((M, N), np.int32)
+    _lib.check(lib.cs_debug_gemm_q8(0, epi, a_split, A.ctypes.data_as(f32p), W.ctypes.data_as(f32p), sc.ctypes.data_as(f32p),
+                                    bias.ctypes.data_as(f32p), None if resid is None else resid.ctypes.data_as(f32p),
+                                    C_.ctypes.data_as(f32p), M, N, K, xq.ctypes.data_as(C.POINTER(C.c_uint8)),
+                                    xp.ctypes.data_as(f32p), acc.ctypes.data_as(C.POINTER(C.c_int32))))
+    return C_, xq, xp, acc
+
+
+def split_round_trip(A):
+    """What an f32 value becomes on its way through the split-f16 hand-over: hi + lo / 2048."""
+    A = np.asarray(A, np.float32)
+    hi = A.astype(np.float16)
+    lo = ((A - hi.astype(np.float32)) * np.float32(2048)).astype(np.float16)
+    return (hi.astype(np.float32) + lo.astype(np.float32) * np.float32(1 / 2048)).astype(np.float32)
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 384, 384), (128, 128, 128), (1, 1536, 384), (517, 384, 1536)])
+@pytest.mark.parametrize("per_channel,unsigned", [(False, True), (True, False), (True, True)])
+def test_operators_match_the_onnx_definitions_exactly(gpu_lib, M, N, K, per_channel, unsigned):
+    rng = np.random.default_rng(M * 7 + N + K + per_channel + 2 * unsigned)
+    A = (rng.standard_normal((M, K)) * rng.choice([0.3, 1.0, 4.0], size=(M, 1))).astype(np.float32)
+    A[rng.integers(0, M), rng.integers(0, K)] = 9.5   # an outlier sets the range, as in real activations
+    Wf = (rng.standard_normal((N, K)) * 0.05).astype(np.float32)
+    W, d, sc = quantize_matrix(Wf, per_channel, unsigned)
+    bias = (rng.standard_normal(N) * 0.1).astype(np.float32)
+    resid = rng.standard_normal((M, N)).astype(np.float32)
+    got, xq, xp, acc = run_q8(gpu_lib, 2, A, W, sc, bias, resid)
+    q, xs, xz = dynamic_quantize(A)
+    assert xp[0] == xs and int(xp[1]) == xz
+    assert np.array_equal(xq, q)                                             # DynamicQuantizeLinear, byte for byte
+    want_acc = (q.astype(np.int64) - xz) @ d.T                               # MatMulInteger
+    assert np.array_equal(acc.astype(np.int64), want_acc)
+    want = (want_acc.astype(np.float32) * (xs * sc)[None, :].astype(np.float32)).astype(np.float32)
+    want = ((want + bias[None, :]).astype(np.float32) + resid).astype(np.float32)   # Cast, Mul, Add(bias), + residual
+    assert np.array_equal(got, want)
+    # plain store and the two split-form stores (f32-class: one split round trip; the GELU is the kernels' own erf)
+    base = (want_acc.astype(np.float32) * (xs * sc)[None, :].astype(np.float32) + bias[None, :]).astype(np.float32)
+    assert np.array_equal(run_q8(gpu_lib, 0, A, W, sc, bias)[0], base)
+    np.testing.assert_allclose(run_q8(gpu_lib, 4, A, W, sc, bias)[0], base, rtol=3e-7, atol=1e-9)
+    from math import erf
+    gelu = 0.5 * base.astype(np.float64) * (1.0 + np.vectorize(erf)(base.astype(np.float64) / np.sqrt(2.0)))
+    np.testing.assert_allclose(run_q8(gpu_lib, 1, A, W, sc, bias)[0], gelu, rtol=2e-6, atol=2e-7)
+
+
+def test_split_form_activations_quantise_like_their_f32_values(gpu_lib):
+    """Attention and GELU hand their outputs over in split-f16 form: the quantiser reads hi + lo / 2048."""
+    rng = np.random.default_rng(5)
+    M, N, K = 200, 384, 1536
+    A = (rng.standard_normal((M, K)) * 2).astype(np.float32)
+    W, d, sc = quantize_matrix((rng.standard_normal((N, K)) * 0.03).astype(np.float32), True, True)
+    bias = np.zeros(N, np.float32)
+    _, xq, xp, acc = run_q8(gpu_lib, 0, A, W, sc, bias, a_split=1)
+    q, xs, xz = dynamic_quantize(split_round_trip(A))
+    assert xp[0] == xs and int(xp[1]) == xz and np.array_equal(xq, q)
+    assert np.array_equal(acc.astype(np.int64), (q.astype(np.int64) - xz) @ d.T)
+
+
+def test_degenerate_ranges_and_bad_blocks(gpu_lib):
+    M, N, K = 40, 128, 128
+    W, d, sc = quantize_matrix(np.random.default_rng(1).standard_normal((N, K)).astype(np.float32) * 0.1, False, True)
+    bias = np.arange(N, dtype=np.float32)
+    # all-zero activations: hi == lo -> scale 1, zero point 0, the output is the bias
+    got, xq, xp, _ = run_q8(gpu_lib, 0, np.zeros((M, K), np.float32), W, sc, bias)
+    assert xp[0] == 1.0 and xp[1] == 0.0 and not xq.any() and np.array_equal(got, np.tile(bias, (M, 1)))
+    # all-negative and all-positive tensors: the range still includes zero
+    for sign in (-1.0, 1.0):
+        A = (sign * (1.0 + np.random.default_rng(2).random((M, K)))).astype(np.float32)
+        _, xq, xp, _ = run_q8(gpu_lib, 0, A, W, sc, bias)
+        q, xs, xz = dynamic_quantize(A)
+        assert xp[0] == xs and int(xp[1]) == xz == (255 if sign < 0 else 0) and np.array_equal(xq, q)
+    # weights that are not multiples of their scales are refused, not silently re-quantised
+    with pytest.raises(_lib.CsError, match="not a quantised matrix"):
+        run_q8(gpu_lib, 0, np.ones((M, K), np.float32), (W + np.float32(0.37) * sc[:, None]).astype(np.float32), sc, bias)
+
+
+def small_cfg(pooling, layers=2):
+    return BertConfig(vocab_size=1500, hidden=384, layers=layers, heads=12, intermediate=1536, max_position=64, pooling=pooling)
+
+
+@pytest.mark.parametrize("per_channel,unsigned", [(False, True), (True, False), (True, True)])
+def test_one_quantised_layer_is_the_oracles_except_for_flipped_bytes(gpu_lib, oracle, per_channel, unsigned):
+    """One layer = four quantised Linears in a row.  Wherever no activation byte flips between the two f32-class
+    evaluations the hidden states agree to f32 rounding; a flipped byte moves its own token row by ~1e-3.  Measured:
+    0.6-1 % of the rows carry a flip."""
+    from codesearch_amd import FastEmbedder, ModelType
+
+    cfg = small_cfg(POOL_MEAN, layers=1)
+    params, wscale = quantize_linear_weights(cfg, synth_params(cfg, 11), per_channel=per_channel, unsigned=unsigned)
+    assert wscale.shape == (cfg.layers, quant_columns(cfg))
+    ids, mask = synth_token_batch(cfg, 4, 24, 48, True)
+    emb = FastEmbedder(ModelType.AllMiniLML6V2Q, config=cfg, params=params, wscale=wscale)
+    got = emb.embed_ids(ids, mask)
+    hid = emb.last_hidden(ids.size).reshape(ids.shape + (cfg.hidden,))
+    want = oracle.bert_forward(cfg, params, ids, mask, wscale=wscale, want_hidden=True)
+    f32_graph = oracle.bert_forward(cfg, params, ids, mask, want_hidden=True)
+    valid = mask.astype(bool)
+    err = np.abs(hid[valid] - want["hidden"][valid])
+    assert np.median(err) < 5e-7
+    assert (err.max(axis=1) > 1e-5).mean() < 0.04          # rows with a flipped byte
+    assert err.max() < 2e-2 and np.abs(got - want["pooled"]).max() < 1e-3
+    # not re-quantising the activations is a different function: every row moves, by thousands of times more
+    assert np.median(np.abs(f32_graph["hidden"][valid] - want["hidden"][valid])) > 1e-3
+    emb.close()
+
+
+@pytest.mark.parametrize("pooling", [POOL_MEAN, POOL_CLS])
+@pytest.mark.parametrize("per_channel,unsigned", [(False, True), (True, False)])
+def test_quantised_forward_against_the_oracle(gpu_lib, oracle, pooling, per_channel, unsigned):
+    """Two layers: a flipped byte in layer 1 reaches every token of its sequence through attention, and one that sits
+    on a tensor's extreme value moves that tensor's scale — dynamic quantisation is discontinuous, in the reference's
+    runtime as here.  The bar is the average distance, against what ignoring the activation quantisation would cost."""
+    from codesearch_amd import FastEmbedder, ModelType
+
+    cfg = small_cfg(pooling)
+    params, wscale = quantize_linear_weights(cfg, synth_params(cfg, 11), per_channel=per_channel, unsigned=unsigned)
+    ids, mask = synth_token_batch(cfg, 4, 24, 48, True)
+    emb = FastEmbedder(ModelType.AllMiniLML6V2Q, config=cfg, params=params, wscale=wscale)
+    got = emb.embed_ids(ids, mask)
+    want = oracle.bert_forward(cfg, params, ids, mask, wscale=wscale)["pooled"]
+    f32_graph = oracle.bert_forward(cfg, params, ids, mask)["pooled"]
+    err, noise = np.abs(got - want), np.abs(f32_graph - want)
+    assert err.max() < 3e-3 and (got * want).sum(1).min() > 0.99999
+    assert err.mean() < 0.5 * noise.mean(), (err.mean(), noise.mean())
+    np.testing.assert_allclose(np.linalg.norm(got, axis=1), 1.0, atol=1e-5)
+    # the f32 graph of the same (quantised) weights is still there on request, and is the other thing
+    emb.set_gemm_mode("split")
+    np.testing.assert_allclose(emb.embed_ids(ids, mask), f32_graph, atol=2e-5)
+    emb.set_gemm_mode("q8")
+    assert np.array_equal(emb.embed_ids(ids, mask), got)   # deterministic: integer atomics, fixed summation orders
+    emb.close()
+    # a model that is not quantised has no such mode
+    plain = FastEmbedder(ModelType.BGESmallENV15, config=cfg, seed=3)
+    with pytest.raises(_lib.CsError, match="needs a quantised model"):
+        plain.set_gemm_mode("q8")
+    plain.close()
+
+
+def test_a_call_is_one_tensor(gpu_lib, oracle):
+    """DynamicQuantizeLinear sees the whole call: the same text embeds differently beside an outlier sequence, exactly
+    as it does in the reference's runtime; batches are `batch` consecutive rows in the caller's order."""
+    from codesearch_amd import FastEmbedder, ModelType
+
+    cfg = small_cfg(POOL_MEAN)
+    params, wscale = quantize_linear_weights(cfg, synth_params(cfg, 2), per_channel=False, unsigned=True)
+    ids, mask = synth_token_batch(cfg, 9, 6, 32, True)
+    emb = FastEmbedder(ModelType.AllMiniLML6V2Q, config=cfg, params=params, wscale=wscale)
+    whole = emb.embed_ids(ids, mask, batch_size=6)
+    halves = emb.embed_ids(ids, mask, batch_size=3)
+    for name, got, parts in (("one call", whole, [slice(0, 6)]), ("two calls", halves, [slice(0, 3), slice(3, 6)])):
+        want = np.concatenate([oracle.bert_forward(cfg, params, ids[p], mask[p], wscale=wscale)["pooled"] for p in parts])
+        assert np.abs(got - want).max() < 3e-3, name
+    assert np.abs(whole - halves).max() > 1e-5   # the call boundary matters in this mode (and only in this mode)
+    emb.close()
