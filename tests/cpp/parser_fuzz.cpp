@@ -52,6 +52,11 @@ int32_t cs_embedder_create(const cs_bert_config*, const float*, uint64_t, int32_
     if (out) *out = nullptr;
     return cs::fail(CS_ERR_HIP, "stub: no device in the parser hardening driver");
 }
+uint64_t cs_bert_quant_columns(const cs_bert_config* cfg) { return cfg ? 5 * (uint64_t)cfg->hidden + cfg->intermediate : 0; }
+int32_t cs_embedder_create_quantized(const cs_bert_config*, const float*, const float*, uint64_t, int32_t, cs_embedder** out) {
+    if (out) *out = nullptr;
+    return cs::fail(CS_ERR_HIP, "stub: no device in the parser hardening driver");
+}
 }
 
 static std::vector<uint8_t> slurp(const std::string& path) {
@@ -102,7 +107,9 @@ int main(int argc, char** argv) {
         spit(target, bytes.data(), n);
         int32_t st = CS_OK;
         if (kind == "onnx") {
-            st = cs_bert_params_from_onnx(target.c_str(), &cfg, params.data(), n_params);
+            std::vector<float> wscale((size_t)cfg.layers * cs_bert_quant_columns(&cfg));
+            int32_t quantized = 0;
+            st = cs_bert_params_from_onnx_q(target.c_str(), &cfg, params.data(), n_params, wscale.data(), wscale.size(), &quantized);
         } else if (kind == "safetensors") {
             st = cs_bert_params_from_safetensors(target.c_str(), &cfg, params.data(), n_params);
         } else if (kind == "tokenizer_json") {
