@@ -211,3 +211,90 @@ def test_a_call_is_one_tensor(gpu_lib, oracle):
         assert np.abs(got - want).max() < 3e-3, name
     assert np.abs(whole - halves).max() > 1e-5   # the call boundary matters in this mode (and only in this mode)
     emb.close()
+
+
+@pytest.mark.parametrize("qdtype_name,per_channel", [("UINT8", False), ("INT8", True)])
+def test_quantised_model_directory(gpu_lib, oracle, tmp_path, qdtype_name, per_channel):
+    """What fastembed's cache holds for a *Q registry entry (the reference's default model among them): config.json and
+    onnx/model_quantized.onnx as onnxruntime's quantize_dynamic writes it.  FastEmbedder.from_dir must come up in the
+    dynamic-quantisation mode and embed as the oracle's quantised forward does on the block and scales read back from
+    the file; CS_ENCODER_QUANT=0 keeps the f32 graph of the same weights."""
+    import json
+    import os
+
+    from codesearch_amd import FastEmbedder
+    from codesearch_amd.bert_params import to_state_dict
+    from tests import onnx_writer
+    from tests.test_model_files import load_onnx_q
+
+    cfg = small_cfg(POOL_MEAN)
+    sd = to_state_dict(cfg, synth_params(cfg, 21))
+    config = {"model_type": "bert", "vocab_size": cfg.vocab_size, "hidden_size": 384, "num_hidden_layers": cfg.layers,
+              "num_attention_heads": 12, "intermediate_size": 1536, "max_position_embeddings": cfg.max_position,
+              "type_vocab_size": 2, "layer_norm_eps": 1e-12, "hidden_act": "gelu"}
+    cache = tmp_path / "models--Xenova--all-MiniLM-L6-v2" / "snapshots" / "abc"
+    (cache / "onnx").mkdir(parents=True)
+    (cache / "config.json").write_text(json.dumps(config))
+    path = cache / "onnx" / "model_quantized.onnx"
+    path.write_bytes(onnx_writer.bert_onnx(sd, cfg.layers, "quantized", qdtype=getattr(onnx_writer, qdtype_name),
+                                           per_channel=per_channel, quantize_tables=True))
+    params, wscale, quantized = load_onnx_q(gpu_lib, path, cfg)
+    assert quantized == 1
+    ids, mask = synth_token_batch(cfg, 6, 16, 40, True)
+    emb = FastEmbedder.from_dir(str(cache), pooling=POOL_MEAN)
+    got = emb.embed_ids(ids, mask)
+    want = oracle.bert_forward(cfg, params, ids, mask, wscale=wscale)["pooled"]
+    f32_graph = oracle.bert_forward(cfg, params, ids, mask)["pooled"]
+    err, noise = np.abs(got - want), np.abs(f32_graph - want)
+    assert err.max() < 3e-3 and err.mean() < 0.5 * noise.mean(), (err.max(), err.mean(), noise.mean())
+    emb.close()
+    os.environ["CS_ENCODER_QUANT"] = "0"
+    try:
+        emb = FastEmbedder.from_dir(str(cache), pooling=POOL_MEAN)
+        np.testing.assert_allclose(emb.embed_ids(ids, mask), f32_graph, atol=2e-5)
+        emb.close()
+    finally:
+        del os.environ["CS_ENCODER_QUANT"]
+
+
+def test_texts_and_queued_submissions_are_quantised_per_reference_call(gpu_lib, oracle):
+    """From strings a call tensor is `batch` CONSECUTIVE texts padded to their longest (fastembed's batches: no length
+    grouping, no token-budget batches in this mode); through the queue it is one submission (the reference hands ORT one
+    32-chunk slice at a time, /root/reference/src/embed/batch.rs:84-115) — coalescing submissions into one device batch
+    would change every range."""
+    import json
+    import os
+
+    from codesearch_amd import FastEmbedder, ModelType
+    from codesearch_amd.tokenizer import BertWordPieceTokenizer
+
+    G = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "tokenizer_golden.json")))
+    tok = BertWordPieceTokenizer(G["vocab"])
+    cfg = BertConfig(vocab_size=len(G["vocab"]), hidden=384, layers=2, heads=12, intermediate=1536, max_position=128,
+                     pooling=POOL_MEAN)
+    params, wscale = quantize_linear_weights(cfg, synth_params(cfg, 5), per_channel=True, unsigned=True)
+    emb = FastEmbedder(ModelType.AllMiniLML6V2Q, config=cfg, params=params, wscale=wscale, tokenizer=tok)
+    texts = ["fn main() { println!(\"hello world\"); }", "def calculate(a, b): return a", "struct", "x" * 150,
+             "impl Display for Point { fn fmt(&self, f: &mut Formatter) -> Result { write!(f, \"({}, {})\", self.x, self.y) } }",
+             "", "let v: Vec<u32> = (0..10).collect();", "class Foo(Bar): pass", "SELECT * FROM chunks WHERE id = 7",
+             "// comment only", "return"]
+
+    def per_call(groups):
+        out = []
+        for g in groups:
+            ids, mask = tok.encode_batch(g)
+            out.append(oracle.bert_forward(cfg, params, ids, mask, wscale=wscale)["pooled"])
+        return np.concatenate(out)
+
+    got = np.stack(emb.embed_batch_chunked(texts, 4))
+    want = per_call([texts[i:i + 4] for i in range(0, len(texts), 4)])
+    assert np.abs(got - want).max() < 3e-3 and np.abs(got - want).mean() < 1e-4
+    # grouped differently the same texts embed differently: the unit matters, and it is the caller's
+    assert np.abs(got - per_call([texts[:8], texts[8:]])).mean() > 2 * np.abs(got - want).mean()
+    # the queue: three submissions, one wait each, each its own tensor whatever else is queued
+    subs = [texts[:5], texts[5:6], texts[6:]]
+    tickets = [emb.submit_texts(s) for s in subs]
+    for s, t in zip(reversed(subs), reversed(tickets)):
+        e = np.abs(emb.wait(t) - per_call([s]))
+        assert e.max() < 3e-3 and e.mean() < 1e-4
+    emb.close()

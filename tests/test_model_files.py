@@ -24,6 +24,18 @@ def load_onnx(gpu_lib, path, cfg):
     return out
 
 
+def load_onnx_q(gpu_lib, path, cfg):
+    c = cfg.to_c()
+    n = int(gpu_lib.cs_bert_param_count(C.byref(c)))
+    cols = int(gpu_lib.cs_bert_quant_columns(C.byref(c)))
+    out = np.empty(n, np.float32)
+    wscale = np.zeros((cfg.layers, cols), np.float32)
+    quantized = C.c_int32(-1)
+    _lib.check(gpu_lib.cs_bert_params_from_onnx_q(str(path).encode(), C.byref(c), out.ctypes.data_as(_lib.f32p), n,
+                                                  wscale.ctypes.data_as(_lib.f32p), wscale.size, C.byref(quantized)))
+    return out, wscale, int(quantized.value)
+
+
 def test_reads_a_file_written_by_torchs_own_exporter(gpu_lib):
     """tests/golden/bert_tiny_export.onnx was produced by torch.onnx.export from transformers.BertModel
     (make_onnx_fixture.py): named embeddings / LayerNorms / biases, transposed `onnx::MatMul_N` Linear
@@ -54,6 +66,7 @@ def test_exporter_layouts_and_dtypes(gpu_lib, tmp_path, style, dtype, prefix):
     path = tmp_path / "model.onnx"
     path.write_bytes(onnx_writer.bert_onnx(sd, cfg.layers, style, dtype, prefix))
     got = load_onnx(gpu_lib, path, cfg)
+    assert load_onnx_q(gpu_lib, path, cfg)[2] == 0   # not a quantised file
     if dtype == onnx_writer.FLOAT:
         exp = flat
     else:
@@ -87,6 +100,23 @@ def test_dynamically_quantised_export(gpu_lib, tmp_path, qdtype, per_channel, ta
             assert 0 < rel < (0.02 if not per_channel else 0.01), (name, rel)   # it IS quantised, and sanely so
         else:
             assert np.array_equal(got[name], want), name
+    # ... and the column scales the dynamic-quantisation mode runs on (cs_bert_params_from_onnx_q): every Linear weight
+    # is an integer multiple of its column's scale, the integers spanning at most 8 bits
+    block, wscale, quantized = load_onnx_q(gpu_lib, path, cfg)
+    assert quantized == 1 and np.array_equal(to_state_dict(cfg, block)[next(iter(deq))], got[next(iter(deq))])
+    H, I = cfg.hidden, cfg.intermediate
+    roles = ("attention.self.query", "attention.self.key", "attention.self.value", "attention.output.dense",
+             "intermediate.dense", "output.dense")
+    for l in range(cfg.layers):
+        c0 = 0
+        for role in roles:
+            w = got[f"encoder.layer.{l}.{role}.weight"]
+            sc = wscale[l, c0:c0 + w.shape[0]]
+            c0 += w.shape[0]
+            d = w / sc[:, None]
+            assert np.abs(d - np.rint(d)).max() < 1e-3 and (np.rint(d).max(axis=1) - np.rint(d).min(axis=1)).max() <= 255
+            assert (np.unique(sc).size == 1) == (not per_channel)
+        assert c0 == 5 * H + I
     # a quantised weight whose scale is missing is refused with a message, not read as garbage
     broken = onnx_writer.bert_onnx(sd, cfg.layers, "quantized", qdtype=qdtype).replace(b"onnx::MatMul_1001_scale", b"onnx::MatMul_1001_scalX")
     (tmp_path / "broken.onnx").write_bytes(broken)
