@@ -20,6 +20,8 @@ def main():
     ap.add_argument("--ragged", action="store_true")
     ap.add_argument("--stages", action="store_true", help="also print per-kernel-class microseconds per layer (one stream)")
     ap.add_argument("--model", default="bge-small", help="registry short name: bge-small, bge-base, bge-large, minilm-l6, ...")
+    ap.add_argument("--quant", default="", help="u8 | s8 | u8c | s8c: quantise the Linear weights as onnxruntime's quantize_dynamic "
+                    "does (per tensor / per channel) and run the dynamic-quantisation mode (the *Q models)")
     args = ap.parse_args()
     import numpy as np
 
@@ -30,7 +32,14 @@ def main():
     if mt is None:
         raise SystemExit(f"unknown model {args.model!r}")
     cfg = mt.bert_config()
-    emb = FastEmbedder(mt, config=cfg, seed=202)
+    if args.quant:
+        from codesearch_amd.bert_params import quantize_linear_weights, synth_params
+
+        params, wscale = quantize_linear_weights(cfg, synth_params(cfg, 202), per_channel=args.quant.endswith("c"),
+                                                 unsigned=args.quant.startswith("u"))
+        emb = FastEmbedder(mt, config=cfg, params=params, wscale=wscale)
+    else:
+        emb = FastEmbedder(mt, config=cfg, seed=202)
     ids, mask = synth_token_batch(cfg, 999, args.batch, args.seq, args.ragged)
     emb.embed_ids(ids, mask)  # warm-up (allocates the workspace)
     emb.profile_read(reset=True)
@@ -57,7 +66,7 @@ def main():
     flops_tok = layers * (2 * (4 * H * H + 2 * H * I) + 4 * L * H)
     flops = flops_tok * args.batch * args.seq
     print(json.dumps({
-        "workload": f"{mt.name_str()} shape ({cfg.layers} x hidden {cfg.hidden}, {cfg.heads} heads), batch {args.batch} x seq {args.seq}, {'ragged' if args.ragged else 'full'} mask, fp32",
+        "workload": f"{mt.name_str()} shape ({cfg.layers} x hidden {cfg.hidden}, {cfg.heads} heads), batch {args.batch} x seq {args.seq}, {'ragged' if args.ragged else 'full'} mask, {'dynamic int8 Linears (' + args.quant + ')' if args.quant else 'fp32'}",
         "device_ms_per_batch": ms, "wall_ms_per_batch_incl_pcie": wall * 1e3,
         "chunks_per_s_device": args.batch / (ms * 1e-3), "tokens_per_s_device": args.batch * args.seq / (ms * 1e-3),
         "algorithmic_tflop_per_batch": flops / 1e12, "achieved_tflops": flops / (ms * 1e-3) / 1e12,

@@ -69,13 +69,14 @@ struct cs_embedder {
     _Float16* d_wsplit = nullptr;  // per layer: wqkv | attention-out | ffn-up | ffn-down, split-f16 rows
     uint32_t* d_flag = nullptr;    // split-f16 range flag
     // dynamically quantised models (gemm_q8.hip): s8 weights per layer (q8_layer), their column metadata, the running
-    // (lo, hi) of every quantised tensor of a forward ([layers][4][q8_units][2]) and the rows' metadata
+    // range slot of every quantised tensor of a forward ([layers][4][q8_units][Q8_RANGE_WORDS]) and the rows' metadata
     bool quantized = false;
     int8_t* d_wq8 = nullptr;
     Q8ColMeta* d_cmeta = nullptr;
     uint32_t* d_range = nullptr;
     uint32_t q8_units = 1;
-    Q8RowMeta* d_rmeta = nullptr;  // [cap_tokens] (workspace)
+    Q8RowMeta* d_rmeta = nullptr;  // [cap_tokens] (workspace): rows of the tensor being multiplied
+    Q8RowMeta* d_rmeta2 = nullptr; // [cap_tokens]: rows of the re-quantised FFN intermediate
     int gemm_mode = CS_GEMM_SPLIT_F16;
     bool split_unavailable = false;  // device flushes f16 subnormals in the MFMA: exact-f32 kernels only
     bool wide_ok = false;            // every |w| < 31.98: the one-accumulator 128 x 384 kernels may run (gemm_wide.hip)
@@ -136,7 +137,8 @@ void free_workspace(cs_embedder* h) {
     if (h->d_pooled) (void)hipFree(h->d_pooled);
     if (h->d_perm) (void)hipFree(h->d_perm);
     if (h->d_rmeta) (void)hipFree(h->d_rmeta);
-    h->d_rmeta = nullptr;
+    if (h->d_rmeta2) (void)hipFree(h->d_rmeta2);
+    h->d_rmeta = h->d_rmeta2 = nullptr;
     h->d_perm = nullptr;
     h->d_ids = h->d_mask = nullptr;
     h->d_x = h->d_xs = h->d_qkv = h->d_ctx = h->d_mid = h->d_pooled = nullptr;
@@ -156,7 +158,10 @@ int32_t reserve(cs_embedder* h, size_t seqs, size_t tokens) {
     CS_HIP(hipMalloc(&h->d_mid, tokens * I * sizeof(float)));
     CS_HIP(hipMalloc(&h->d_pooled, seqs * H * sizeof(float)));
     CS_HIP(hipMalloc(&h->d_perm, seqs * sizeof(uint32_t)));
-    if (h->quantized) CS_HIP(hipMalloc(&h->d_rmeta, tokens * sizeof(Q8RowMeta)));
+    if (h->quantized) {
+        CS_HIP(hipMalloc(&h->d_rmeta, tokens * sizeof(Q8RowMeta)));
+        CS_HIP(hipMalloc(&h->d_rmeta2, tokens * sizeof(Q8RowMeta)));
+    }
     h->cap_tokens = tokens;
     h->cap_seqs = seqs;
     return CS_OK;
@@ -264,8 +269,8 @@ int32_t forward_range(cs_embedder* h, hipStream_t s, uint32_t b0, uint32_t nb, u
             const Q8Layer ql = q8_layer(H, I);
             const int8_t* wq = h->d_wq8 + (size_t)l * ql.total;
             const Q8ColMeta* cm = h->d_cmeta + (size_t)l * (5 * (size_t)H + I);
-            uint32_t* rg = h->d_range + (size_t)l * 4 * 2 * h->q8_units;
-            const size_t rstep = (size_t)2 * h->q8_units;
+            uint32_t* rg = h->d_range + (size_t)l * 4 * Q8_RANGE_WORDS * h->q8_units;
+            const size_t rstep = (size_t)Q8_RANGE_WORDS * h->q8_units;
             int8_t* xq = reinterpret_cast<int8_t*>(h->d_xs + t0 * H);  // [T][<= 4H] bytes
             Q8RowMeta* rm = h->d_rmeta + t0;
             _Float16* qkvs = reinterpret_cast<_Float16*>(qkv);
@@ -281,10 +286,13 @@ int32_t forward_range(cs_embedder* h, hipStream_t s, uint32_t b0, uint32_t nb, u
             CS_TRY(launch_row_kernel(1, a, H, s));
             CS_TRY(mark(CS_STAGE_LN_ATTN));
             CS_TRY(launch_q8_quantize(Q8_SRC_F32, x, T, H, rg + 2 * rstep, nullptr, xq, rm, s));
-            CS_TRY(launch_gemm_q8(SH_OUT_SPLIT_GELU, xq, rm, wq + ql.up, cm + 4 * H, P + lo.up_b, nullptr, nullptr, mids, T, I, H, h->d_flag, s));  // E5
+            // E5: GELU(x W1^T + b1) leaves already re-quantised for E6 (two passes over the int8 product instead of 1.2 GB of
+            // f32-class hand-over at 65,536 rows: launch_gemm_q8_gelu_requant)
+            int8_t* midq = reinterpret_cast<int8_t*>(mid);
+            Q8RowMeta* rm2 = h->d_rmeta2 + t0;
+            CS_TRY(launch_gemm_q8_gelu_requant(xq, rm, wq + ql.up, cm + 4 * H, P + lo.up_b, T, I, H, rg + 3 * rstep, midq, rm2, s));
             CS_TRY(mark(CS_STAGE_FFN_UP));
-            CS_TRY(launch_q8_quantize(Q8_SRC_SPLIT, mids, T, I, rg + 3 * rstep, nullptr, xq, rm, s));
-            CS_TRY(launch_gemm_q8(SH_OUT_F32_RESID, xq, rm, wq + ql.down, cm + 4 * H + I, P + lo.down_b, x, x, nullptr, T, H, I, h->d_flag, s));  // E6
+            CS_TRY(launch_gemm_q8(SH_OUT_F32_RESID, midq, rm2, wq + ql.down, cm + 4 * H + I, P + lo.down_b, x, x, nullptr, T, H, I, h->d_flag, s));  // E6
             CS_TRY(mark(CS_STAGE_FFN_DOWN));
             a.g = P + lo.out_ln_g; a.b = P + lo.out_ln_b;
             CS_TRY(launch_row_kernel(1, a, H, s));
@@ -423,7 +431,7 @@ int32_t forward(cs_embedder* h, uint32_t B, uint32_t L, int mode) {
     CS_HIP(hipEventRecord(h->ev0, s));
     if (mode != CS_GEMM_F32) CS_HIP(hipMemsetAsync(h->d_flag, 0, sizeof(uint32_t), s));
     if (mode == CS_GEMM_Q8_DYNAMIC)  // every range starts from (+0, +0)
-        CS_HIP(hipMemsetAsync(h->d_range, 0, (size_t)h->cfg.layers * 4 * 2 * h->q8_units * sizeof(uint32_t), s));
+        CS_HIP(hipMemsetAsync(h->d_range, 0, (size_t)h->cfg.layers * 4 * Q8_RANGE_WORDS * h->q8_units * sizeof(uint32_t), s));
     // Slicing pays from ~20,000 tokens (device us per forward, one stream / two: 16,384 tokens 3505 / 3542,
     // 24,576 5267 / 4916, 32,768 6517 / 6275, 49,152 9568 / 9437); below that it only multiplies launches
     // of kernels that already leave the chip part-empty.
@@ -975,10 +983,10 @@ static int32_t create_impl(const cs_bert_config* cfg, const float* params, uint6
         const Q8Layer ql = q8_layer((uint32_t)H, (uint32_t)I);
         float* d_ws = nullptr;
         uint32_t* d_bad = nullptr;
-        if (I > 4 * H) s = fail(CS_ERR_UNSUPPORTED, "Failed to initialize embedding model: intermediate size above 4 x hidden");
+        if (I > 4 * H || I > 4096) s = fail(CS_ERR_UNSUPPORTED, "Failed to initialize embedding model: intermediate size above 4 x hidden or 4,096");
         if (s == CS_OK && (hipMalloc(&h->d_wq8, (size_t)cfg->layers * ql.total) != hipSuccess ||
                            hipMalloc(&h->d_cmeta, (size_t)cfg->layers * cols * sizeof(Q8ColMeta)) != hipSuccess ||
-                           hipMalloc(&h->d_range, (size_t)cfg->layers * 4 * 2 * h->q8_units * sizeof(uint32_t)) != hipSuccess ||
+                           hipMalloc(&h->d_range, (size_t)cfg->layers * 4 * Q8_RANGE_WORDS * h->q8_units * sizeof(uint32_t)) != hipSuccess ||
                            hipMalloc(&d_ws, (size_t)cfg->layers * cols * sizeof(float)) != hipSuccess ||
                            hipMalloc(&d_bad, sizeof(uint32_t)) != hipSuccess))
             s = fail(CS_ERR_OOM, "hipMalloc(quantised weights) failed");
@@ -1213,6 +1221,8 @@ int32_t cs_embedder_set_gemm_mode(cs_embedder* h, int32_t mode) {
     return CS_OK;
 }
 
+int32_t cs_embedder_gemm_mode(const cs_embedder* h) { return h ? h->gemm_mode : -1; }
+
 int32_t cs_embedder_debug_counters(cs_embedder* h, uint64_t* split_forwards, uint64_t* f32_forwards,
                                    uint64_t* range_fallbacks) {
     if (!h) return fail(CS_ERR_BAD_ARG, "null embedder handle");
@@ -1336,7 +1346,7 @@ int32_t cs_debug_gemm_q8(int32_t device, int32_t epilogue, int32_t a_split, cons
                          const float* wscale, const float* bias, const float* resid, float* C, uint32_t M, uint32_t N,
                          uint32_t K, uint8_t* xq_out, float* xparams, int32_t* acc_out) {
     if (!A || !W || !wscale || !bias || !C || (epilogue == 2 && !resid)) return fail(CS_ERR_BAD_ARG, "null buffer");
-    if (epilogue != 0 && epilogue != 1 && epilogue != 2 && epilogue != 4) return fail(CS_ERR_BAD_ARG, "unknown epilogue %d", epilogue);
+    if (epilogue != 0 && epilogue != 1 && epilogue != 2 && epilogue != 4 && epilogue != 5) return fail(CS_ERR_BAD_ARG, "unknown epilogue %d", epilogue);
     if (M == 0 || N % 128 || K % 128 || K == 0) return fail(CS_ERR_UNSUPPORTED, "cs_debug_gemm_q8 needs M > 0, N %% 128 == 0, K %% 128 == 0");
     int ndev = 0;
     CS_HIP(hipGetDeviceCount(&ndev));
@@ -1354,18 +1364,18 @@ int32_t cs_debug_gemm_q8(int32_t device, int32_t epilogue, int32_t a_split, cons
         CS_HIP(hipMalloc(&dA, a_n * 4)); CS_HIP(hipMalloc(&dW, w_n * 4)); CS_HIP(hipMalloc(&dS, (size_t)N * 4));
         CS_HIP(hipMalloc(&dB, (size_t)N * 4)); CS_HIP(hipMalloc(&dC, c_n * 4)); CS_HIP(hipMalloc(&dF, 16));
         CS_HIP(hipMalloc(&dXq, a_n)); CS_HIP(hipMalloc(&dWq, w_n)); CS_HIP(hipMalloc(&dRm, (size_t)M * sizeof(Q8RowMeta)));
-        CS_HIP(hipMalloc(&dCm, (size_t)N * sizeof(Q8ColMeta))); CS_HIP(hipMalloc(&dRange, 8));
+        CS_HIP(hipMalloc(&dCm, (size_t)N * sizeof(Q8ColMeta))); CS_HIP(hipMalloc(&dRange, Q8_RANGE_WORDS * 4));
         CS_HIP(hipMemcpy(dA, A, a_n * 4, hipMemcpyHostToDevice));
         CS_HIP(hipMemcpy(dW, W, w_n * 4, hipMemcpyHostToDevice));
         CS_HIP(hipMemcpy(dS, wscale, (size_t)N * 4, hipMemcpyHostToDevice));
         CS_HIP(hipMemcpy(dB, bias, (size_t)N * 4, hipMemcpyHostToDevice));
         CS_HIP(hipMemset(dF, 0, 16));
-        CS_HIP(hipMemset(dRange, 0, 8));
+        CS_HIP(hipMemset(dRange, 0, Q8_RANGE_WORDS * 4));
         if (epilogue == 2) {
             CS_HIP(hipMalloc(&dR, c_n * 4));
             CS_HIP(hipMemcpy(dR, resid, c_n * 4, hipMemcpyHostToDevice));
         }
-        if (acc_out) CS_HIP(hipMalloc(&dAcc, c_n * 4));
+        if (acc_out && epilogue != 5) CS_HIP(hipMalloc(&dAcc, c_n * 4));
         CS_TRY(launch_q8_pack_weight(dW, dS, N, K, dWq, dCm, dF + 1, nullptr));
         if (a_split) {
             CS_HIP(hipMalloc(&sA, a_n * 4));
@@ -1373,6 +1383,37 @@ int32_t cs_debug_gemm_q8(int32_t device, int32_t epilogue, int32_t a_split, cons
             CS_TRY(launch_q8_quantize(Q8_SRC_SPLIT, sA, M, K, dRange, nullptr, dXq, dRm, nullptr));
         } else {
             CS_TRY(launch_q8_quantize(Q8_SRC_F32, dA, M, K, dRange, nullptr, dXq, dRm, nullptr));
+        }
+        if (epilogue == 5) {  // GELU -> re-quantised (the two-pass FFN-up): C = the uint8 output, xparams[2..3] = its scale / zero point
+            int8_t* dOut = nullptr;
+            Q8RowMeta* dRm2 = nullptr;
+            uint32_t* dRange2 = nullptr;
+            CS_HIP(hipMalloc(&dOut, c_n)); CS_HIP(hipMalloc(&dRm2, (size_t)M * sizeof(Q8RowMeta))); CS_HIP(hipMalloc(&dRange2, Q8_RANGE_WORDS * 4));
+            CS_HIP(hipMemset(dRange2, 0, Q8_RANGE_WORDS * 4));
+            int32_t st5 = launch_gemm_q8_gelu_requant(dXq, dRm, dWq, dCm, dB, M, N, K, dRange2, dOut, dRm2, nullptr);
+            if (st5 == CS_OK && hipDeviceSynchronize() != hipSuccess) st5 = fail(CS_ERR_HIP, "requant GEMM failed");
+            std::vector<int8_t> ho(c_n);
+            std::vector<Q8RowMeta> hr(M);
+            if (st5 == CS_OK && (hipMemcpy(ho.data(), dOut, c_n, hipMemcpyDeviceToHost) != hipSuccess ||
+                                 hipMemcpy(hr.data(), dRm2, (size_t)M * sizeof(Q8RowMeta), hipMemcpyDeviceToHost) != hipSuccess))
+                st5 = fail(CS_ERR_HIP, "requant GEMM read-back failed");
+            (void)hipFree(dOut); (void)hipFree(dRm2); (void)hipFree(dRange2);
+            CS_TRY(st5);
+            for (size_t i = 0; i < c_n; ++i) C[i] = (float)((int)ho[i] + 128);
+            if (acc_out) for (size_t m = 0; m < M; ++m) acc_out[m] = hr[m].rowsum + 128 * (int32_t)N;  // row sums of the uint8 output
+            if (xparams) { xparams[2] = hr[0].xs; xparams[3] = (float)(hr[0].za + 128); }
+            uint32_t flags5[2] = {0, 0};
+            CS_HIP(hipMemcpy(flags5, dF, 8, hipMemcpyDeviceToHost));
+            if (flags5[1]) return fail(CS_ERR_BAD_ARG, "cs_debug_gemm_q8: W is not a quantised matrix for these column scales (flag %u)", flags5[1]);
+            if (xq_out || xparams) {
+                std::vector<int8_t> hq(a_n);
+                Q8RowMeta rm0;
+                CS_HIP(hipMemcpy(hq.data(), dXq, a_n, hipMemcpyDeviceToHost));
+                CS_HIP(hipMemcpy(&rm0, dRm, sizeof(rm0), hipMemcpyDeviceToHost));
+                if (xq_out) for (size_t i = 0; i < a_n; ++i) xq_out[i] = (uint8_t)((int)hq[i] + 128);
+                if (xparams) { xparams[0] = rm0.xs; xparams[1] = (float)(rm0.za + 128); }
+            }
+            return CS_OK;
         }
         const int epi = epilogue == 0 ? SH_OUT_F32 : epilogue == 1 ? SH_OUT_SPLIT_GELU : epilogue == 2 ? SH_OUT_F32_RESID : SH_OUT_SPLIT;
         if (epi == SH_OUT_SPLIT_GELU || epi == SH_OUT_SPLIT) CS_HIP(hipMalloc(&sC, c_n * 4));

@@ -32,9 +32,18 @@ namespace {
 // lo <= 0 <= hi always (the graph's range includes zero), so both start from +0.0f = all bits zero and move by integer
 // atomics on the float's bits: non-negative floats order like their bits (atomicMax), negative floats like their bits
 // reversed (atomicMax on the unsigned pattern finds the most negative).
+// A range only widens, so a value that does not beat what the slot already shows (a plain load, possibly stale) can be
+// dropped without the atomic (the load is agent-scope, so it is not served from another XCD's stale line): after the first few waves almost every update is — 32,768 waves hammering two addresses
+// took 380 us per tensor before this check.
 __device__ __forceinline__ void q8_range_update(uint32_t* slot, float lo, float hi) {
-    if (lo < 0.0f) atomicMax(slot, __float_as_uint(lo));
-    if (hi > 0.0f) atomicMax(slot + 1, __float_as_uint(hi));
+    if (lo < 0.0f) {
+        const uint32_t b = __float_as_uint(lo);
+        if (b > __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(slot, b);
+    }
+    if (hi > 0.0f) {
+        const uint32_t b = __float_as_uint(hi);
+        if (b > __hip_atomic_load(slot + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(slot + 1, b);
+    }
 }
 
 // 16 bytes of the source -> up to 8 values.  f32 rows: unit u = 4 consecutive floats.  Split-f16 lines [rows][K/32][64]:
@@ -65,6 +74,39 @@ q8_minmax_kernel(const void* __restrict__ src, uint32_t T, uint32_t K, uint32_t*
     constexpr int UN = Q8Unit<SRC>::N;
     const uint32_t upr = K / UN;  // units per row
     const uint64_t units = (uint64_t)T * upr;
+    if (!row_slot) {
+        // one unit (slot 0): four loads in flight per lane, the block's four waves meet in LDS, one update per block
+        __shared__ float s_lo[4], s_hi[4];
+        float lo = 0.0f, hi = 0.0f;
+        const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+        uint64_t u = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+        for (; u + 3 * stride < units; u += 4 * stride) {
+            Q8Unit<SRC> x[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) x[i].load(src, u + i * stride);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int e = 0; e < UN; ++e) { lo = fminf(lo, x[i].v[e]); hi = fmaxf(hi, x[i].v[e]); }
+        }
+        for (; u < units; u += stride) {
+            Q8Unit<SRC> x;
+            x.load(src, u);
+#pragma unroll
+            for (int e = 0; e < UN; ++e) { lo = fminf(lo, x.v[e]); hi = fmaxf(hi, x.v[e]); }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            lo = fminf(lo, __shfl_xor(lo, o));
+            hi = fmaxf(hi, __shfl_xor(hi, o));
+        }
+        if ((threadIdx.x & 63) == 0) { s_lo[threadIdx.x >> 6] = lo; s_hi[threadIdx.x >> 6] = hi; }
+        __syncthreads();
+        if (threadIdx.x == 0)
+            q8_range_update(range, fminf(fminf(s_lo[0], s_lo[1]), fminf(s_lo[2], s_lo[3])),
+                            fmaxf(fmaxf(s_hi[0], s_hi[1]), fmaxf(s_hi[2], s_hi[3])));
+        return;
+    }
     constexpr uint32_t NONE = 0xffffffffu;
     float lo = 0.0f, hi = 0.0f;
     uint32_t mine = NONE;   // unit of the values this lane holds in lo / hi
@@ -77,7 +119,7 @@ q8_minmax_kernel(const void* __restrict__ src, uint32_t T, uint32_t K, uint32_t*
         }
         if (slot != mine) {
             if (mine != NONE) {  // a new unit: flush what this lane holds
-                q8_range_update(range + 2 * (size_t)mine, lo, hi);
+                q8_range_update(range + Q8_RANGE_WORDS * (size_t)mine, lo, hi);
                 lo = hi = 0.0f;
                 single = false;
             }
@@ -101,18 +143,46 @@ q8_minmax_kernel(const void* __restrict__ src, uint32_t T, uint32_t K, uint32_t*
             lo = fminf(lo, __shfl_xor(lo, o));
             hi = fmaxf(hi, __shfl_xor(hi, o));
         }
-        if ((int)(threadIdx.x & 63) == leader) q8_range_update(range + 2 * (size_t)lead, lo, hi);
+        if ((int)(threadIdx.x & 63) == leader) q8_range_update(range + Q8_RANGE_WORDS * (size_t)lead, lo, hi);
     } else if (has) {
-        q8_range_update(range + 2 * (size_t)mine, lo, hi);
+        q8_range_update(range + Q8_RANGE_WORDS * (size_t)mine, lo, hi);
     }
 }
 
 // (x_scale, x_zp) of a unit from its range: DynamicQuantizeLinear's arithmetic, f32, one rounding per operation.
-__device__ __forceinline__ void q8_params(const uint32_t* slot, float& xs, float& xz) {
-    const float lo = __uint_as_float(slot[0]), hi = __uint_as_float(slot[1]);
+__device__ __forceinline__ void q8_params_of(float lo, float hi, float& xs, float& xz) {
     xs = hi == lo ? 1.0f : __fdiv_rn(__fsub_rn(hi, lo), 255.0f);
     const float z = __fsub_rn(0.0f, __fdiv_rn(lo, xs));
     xz = rintf(fminf(fmaxf(z, 0.0f), 255.0f));  // round half to even
+}
+__device__ __forceinline__ void q8_params(const uint32_t* slot, float& xs, float& xz) {
+    q8_params_of(__uint_as_float(slot[0]), __uint_as_float(slot[1]), xs, xz);
+}
+
+// ---- the range of GELU(y) from three extremes of y ---------------------------------------------------------------
+// x Phi(x) rises for x > c = -0.75179..., falls for x < c, and is <= 0 exactly where x <= 0.  So over a tensor
+//   hi = max(0, gelu(max y)),   lo = min(0, gelu(a), gelu(b)),  a = the largest y <= c,  b = the smallest y >= c
+// and the range pass of FFN-up only has to track max y, a and b (three compares per element) instead of evaluating
+// the GELU (~18 VALU slots per element, 100M elements per layer at 65,536 rows).  The three travel as order-preserving
+// unsigned keys, all "larger is better" (b negated), so an all-zero slot means "none yet" for each.
+constexpr float kGeluArgMin = -0.7517916f;
+__device__ __forceinline__ uint32_t q8_key(float x) {
+    const uint32_t b = __float_as_uint(x);
+    return b ^ (uint32_t)(((int32_t)b >> 31) | (int32_t)0x80000000);
+}
+__device__ __forceinline__ float q8_unkey(uint32_t k) {
+    return __uint_as_float(k ^ ((k >> 31) ? 0x80000000u : 0xffffffffu));
+}
+__device__ __forceinline__ void q8_key_update(uint32_t* word, float x) {
+    const uint32_t k = q8_key(x);
+    if (k > __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(word, k);
+}
+__device__ __forceinline__ void q8_params_gelu(const uint32_t* slot, float& xs, float& xz) {
+    float lo = 0.0f, hi = 0.0f;
+    if (slot[2]) hi = fmaxf(hi, sh_gelu_erf(q8_unkey(slot[2])));
+    if (slot[3]) lo = fminf(lo, sh_gelu_erf(q8_unkey(slot[3])));
+    if (slot[4]) lo = fminf(lo, sh_gelu_erf(-q8_unkey(slot[4])));
+    q8_params_of(lo, hi, xs, xz);
 }
 
 // A block owns Q8_RB whole rows, so a row's sum of stored bytes meets in LDS.
@@ -130,7 +200,7 @@ q8_quantize_kernel(const void* __restrict__ src, uint32_t T, uint32_t K, const u
     if (threadIdx.x < rows) {
         const uint32_t slot = row_slot ? (row_slot[row0 + threadIdx.x] & 0x7fffffffu) : 0u;
         float xs, xz;
-        q8_params(range + 2 * (size_t)slot, xs, xz);
+        q8_params(range + Q8_RANGE_WORDS * (size_t)slot, xs, xz);
         r_xs[threadIdx.x] = xs;
         r_xz[threadIdx.x] = xz;
         r_sum[threadIdx.x] = 0;
@@ -231,21 +301,48 @@ q8_pack_weight_kernel(const float* __restrict__ W, const float* __restrict__ sca
 // one 128-B line (128 k) of 128 activation rows and 128 weight rows by LDS-DMA into the swizzled image of split_f16.hpp
 // (sh_mainloop16: same staging, same fragment addresses — a line's slots 0-3 are the first v_mfma_i32_16x16x64_i8 k-step,
 // slots 4-7 the second, where the split-f16 line holds its hi and lo planes).
+// Two more ways out of the tile, for a layer whose output is GELU'd and then quantised again (FFN-up -> FFN-down): the
+// int8 product is a sixth of the split-f16 one on the matrix pipe, so computing it TWICE is cheaper than carrying the
+// f32-class GELU tensor through HBM (403 MB out, 403 MB back through a range pass, 403 MB back through a quantising
+// pass at 65,536 rows): pass 1 (Q8_EPI_GELU_RANGE) stores nothing and only widens the output tensor's range; pass 2
+// (Q8_EPI_GELU_Q8) recomputes the same values — same instruction sequence, same bits — and stores them already
+// quantised with that range, with their row sums: the next layer's operand (100 MB).
+enum { Q8_EPI_GELU_RANGE = 100, Q8_EPI_GELU_Q8 = 101 };
+struct Q8Requant {
+    uint32_t* range;       // (lo, hi) of the output tensor: widened by pass 1, read by pass 2
+    int8_t* out;           // [M][N] s8 (pass 2)
+    Q8RowMeta* rmeta_out;  // [M]: rowsum zeroed by pass 1, accumulated by pass 2; xs / za written by pass 2
+};
+
 template <int EPI>
 __global__ void __launch_bounds__(256, 2)
 gemm_q8_kernel(const int8_t* __restrict__ A, const int8_t* __restrict__ W, const Q8RowMeta* __restrict__ rmeta,
                const Q8ColMeta* __restrict__ cmeta, const float* __restrict__ bias, const float* resid, float* C,
                _Float16* __restrict__ Cs, uint32_t M, uint32_t N, uint32_t K, uint32_t* __restrict__ flag,
-               int32_t* __restrict__ acc_dbg) {
+               int32_t* __restrict__ acc_dbg, Q8Requant rq, uint32_t total_slots) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    uint32_t mt, nt;
-    if (!sh_tile_of_block(blockIdx.x, (M + SH_BM - 1) / SH_BM, N / SH_BN, mt, nt)) return;
-    const uint32_t m0 = mt * SH_BM, n0 = nt * SH_BN;
     const uint32_t kchunks = K / 128;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 1, wc = wave & 1;
     const int l15 = lane & 15, g = lane >> 4;
+    const int swz = (l15 >> 1) & 7;
+    const int arow = (wr * 64 + l15) * 128, wrow = SH_TILE_BYTES + (wc * 64 + l15) * 128;
+    const int s0 = (g ^ swz) * 16, s1 = ((4 + g) ^ swz) * 16;
+    const int Ki = (int)K;
+    // FFN-up passes: the output tensor's parameters (store pass) / this block's extremes of y over all its tiles (range pass)
+    float gs = 1.0f, gz = 0.0f, rgs = 1.0f;
+    if (EPI == Q8_EPI_GELU_Q8) {
+        q8_params_gelu(rq.range, gs, gz);
+        rgs = __fdiv_rn(1.0f, gs);
+    }
+    float ymax = -INFINITY, ya = -INFINITY, yb = INFINITY;  // max y, largest y <= c, smallest y >= c (q8_params_gelu)
+    // Persistent: a block walks tile slots b, b + grid, ... (a multiple of 8 apart: the same XCD, sh_tile_of_block) — a
+    // tile is three to twelve k-steps and a short epilogue, too little to pay a workgroup launch for.
+    for (uint32_t slot = blockIdx.x; slot < total_slots; slot += gridDim.x) {
+    uint32_t mt, nt;
+    if (!sh_tile_of_block(slot, (M + SH_BM - 1) / SH_BM, N / SH_BN, mt, nt)) continue;
+    const uint32_t m0 = mt * SH_BM, n0 = nt * SH_BN;
     const int8_t* asrc[4];
     const int8_t* wsrc[4];
 #pragma unroll
@@ -264,9 +361,6 @@ gemm_q8_kernel(const int8_t* __restrict__ A, const int8_t* __restrict__ W, const
             sh_glds16(wsrc[i] + (size_t)kc * 128, dst + SH_TILE_BYTES + i * 1024);
         }
     };
-    const int swz = (l15 >> 1) & 7;
-    const int arow = (wr * 64 + l15) * 128, wrow = SH_TILE_BYTES + (wc * 64 + l15) * 128;
-    const int s0 = (g ^ swz) * 16, s1 = ((4 + g) ^ swz) * 16;
     q8_i32x4 acc[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -299,29 +393,115 @@ gemm_q8_kernel(const int8_t* __restrict__ A, const int8_t* __restrict__ W, const
         __syncthreads();  // stage kc+1 has landed (vmcnt(0) precedes the barrier); cur is free
     }
 
-    // zero points back in, Cast + Mul(x_scale * W_scale): the tile as f32 into LDS (the stage buffers are free)
-    float* ctile = reinterpret_cast<float*>(lds);
     Q8ColMeta cm[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) cm[j] = cmeta[n0 + wc * 64 + j * 16 + l15];
-    const int Ki = (int)K;
+    if constexpr (EPI == Q8_EPI_GELU_RANGE || EPI == Q8_EPI_GELU_Q8) {
+        float bj[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bj[j] = bias[n0 + wc * 64 + j * 16 + l15];
+        int8_t* tile8 = reinterpret_cast<int8_t*>(lds);  // [128 m][128 n] s8 (the stage buffers are free)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = wr * 64 + i * 16 + 4 * g + r;
+                const Q8RowMeta rm = rmeta[(m0 + m < M) ? m0 + m : M - 1];
+                const int pm = rm.rowsum - Ki * rm.za;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int corr = acc[i][j][r] - __mul24(cm[j].zw, pm) - __mul24(rm.za, cm[j].colsum);
+                    const float y = __fadd_rn(__fmul_rn((float)corr, __fmul_rn(rm.xs, cm[j].ws)), bj[j]);
+                    if (EPI == Q8_EPI_GELU_RANGE) {
+                        ymax = fmaxf(ymax, y);
+                        ya = y <= kGeluArgMin ? fmaxf(ya, y) : ya;
+                        yb = y >= kGeluArgMin ? fminf(yb, y) : yb;
+                    } else {
+                        // sat_u8(round_half_even(v / scale) + zp): the quotient by a reciprocal, the true division only
+                        // where the two could round apart (|v / scale| <= ~255: they differ by < 1e-4)
+                        const float v = sh_gelu_erf(y);
+                        const float t = v * rgs;
+                        float rt = rintf(t);
+                        if (fabsf(fabsf(t - rt) - 0.5f) < 1.0e-3f) rt = rintf(__fdiv_rn(v, gs));
+                        const float q = fminf(fmaxf(__fadd_rn(rt, gz), 0.0f), 255.0f);
+                        tile8[m * 128 + wc * 64 + j * 16 + l15] = (int8_t)((int)q - 128);
+                    }
+                }
+            }
+        if (EPI == Q8_EPI_GELU_RANGE) {
+            // (rows past M repeat row M - 1: the same values once more, harmless in a range; reduced after the last tile)
+            if (nt == 0 && tid < SH_BM && m0 + tid < M) rq.rmeta_out[m0 + tid].rowsum = 0;
+        } else {
+            __syncthreads();
+            // 16 B per lane on consecutive lanes: a tile row is 8 lanes; their sum of bytes goes to the row's total
+#pragma unroll
+            for (int pass = 0; pass < 4; ++pass) {
+                const int row = (tid >> 3) + 32 * pass, c16 = tid & 7;
+                const q8_i32x4 v = *reinterpret_cast<const q8_i32x4*>(tile8 + row * 128 + c16 * 16);
+                int sum = 0;
+#pragma unroll
+                for (int w = 0; w < 4; ++w)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) sum += (int)(int8_t)(((uint32_t)v[w] >> (8 * e)) & 0xffu);
+                sum += __shfl_xor(sum, 1);
+                sum += __shfl_xor(sum, 2);
+                sum += __shfl_xor(sum, 4);
+                if (m0 + row < M) {
+                    *reinterpret_cast<q8_i32x4*>(rq.out + (size_t)(m0 + row) * N + n0 + c16 * 16) = v;
+                    if (c16 == 0) atomicAdd(&rq.rmeta_out[m0 + row].rowsum, sum);
+                }
+            }
+            if (nt == 0 && tid < SH_BM && m0 + tid < M) {
+                rq.rmeta_out[m0 + tid].xs = gs;
+                rq.rmeta_out[m0 + tid].za = (int)gz - 128;
+            }
+            __syncthreads();  // tile8 is read: the next tile may stage over it
+        }
+        continue;
+    }
+    // zero points back in, Cast + Mul(x_scale * W_scale): the tile as f32 into LDS (the stage buffers are free)
+    float* ctile = reinterpret_cast<float*>(lds);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int m = wr * 64 + i * 16 + 4 * g + r;
             const Q8RowMeta rm = rmeta[(m0 + m < M) ? m0 + m : M - 1];
+            const int pm = rm.rowsum - Ki * rm.za;  // -zw rowsum - za colsum + K za zw = -zw (rowsum - K za) - za colsum
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int corr = acc[i][j][r] - cm[j].zw * rm.rowsum - rm.za * cm[j].colsum + Ki * rm.za * cm[j].zw;
+                // (24-bit multiplies, full rate: |pm| <= 2^8 K, |colsum| <= 2^7 K, K <= 4,096 at create)
+                const int corr = acc[i][j][r] - __mul24(cm[j].zw, pm) - __mul24(rm.za, cm[j].colsum);
                 ctile[m * 128 + wc * 64 + j * 16 + l15] = __fmul_rn((float)corr, __fmul_rn(rm.xs, cm[j].ws));
                 if (acc_dbg && m0 + m < M)  // cs_debug_gemm_q8: the MatMulInteger result itself
                     acc_dbg[(size_t)(m0 + m) * N + n0 + wc * 64 + j * 16 + l15] = corr;
             }
         }
     __syncthreads();
-    if (m0 + SH_BM <= M) gemm_sh_epilogue<EPI, true, 2>(ctile, bias, resid, C, Cs, M, N, m0, n0, flag);
-    else gemm_sh_epilogue<EPI, false, 2>(ctile, bias, resid, C, Cs, M, N, m0, n0, flag);
+    constexpr int SEPI = (EPI == Q8_EPI_GELU_RANGE || EPI == Q8_EPI_GELU_Q8) ? SH_OUT_F32 : EPI;  // (never reached for those)
+    if (m0 + SH_BM <= M) gemm_sh_epilogue<SEPI, true, 2>(ctile, bias, resid, C, Cs, M, N, m0, n0, flag);
+    else gemm_sh_epilogue<SEPI, false, 2>(ctile, bias, resid, C, Cs, M, N, m0, n0, flag);
+    __syncthreads();  // ctile is read: the next tile may stage over it
+    }  // tile slots
+    if (EPI == Q8_EPI_GELU_RANGE) {
+        __shared__ float s_r[3][4];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            ymax = fmaxf(ymax, __shfl_xor(ymax, o));
+            ya = fmaxf(ya, __shfl_xor(ya, o));
+            yb = fminf(yb, __shfl_xor(yb, o));
+        }
+        if (lane == 0) { s_r[0][wave] = ymax; s_r[1][wave] = ya; s_r[2][wave] = yb; }
+        __syncthreads();
+        if (tid == 0) {
+            const float m3 = fmaxf(fmaxf(s_r[0][0], s_r[0][1]), fmaxf(s_r[0][2], s_r[0][3]));
+            const float a3 = fmaxf(fmaxf(s_r[1][0], s_r[1][1]), fmaxf(s_r[1][2], s_r[1][3]));
+            const float b3 = fminf(fminf(s_r[2][0], s_r[2][1]), fminf(s_r[2][2], s_r[2][3]));
+            if (m3 > -INFINITY) q8_key_update(rq.range + 2, m3);
+            if (a3 > -INFINITY) q8_key_update(rq.range + 3, a3);
+            if (b3 < INFINITY) q8_key_update(rq.range + 4, -b3);
+        }
+    }
 }
 
 }  // namespace
@@ -340,7 +520,7 @@ int32_t launch_q8_quantize(int src_kind, const void* d_src, uint32_t T, uint32_t
     if (T == 0) return CS_OK;
     const uint64_t units = (uint64_t)T * (K / (src_kind == Q8_SRC_F32 ? 4 : 8));
     const uint64_t want = (units + 255) / 256;
-    const dim3 grid_mm((uint32_t)(want < 4096 ? want : 4096));
+    const dim3 grid_mm((uint32_t)(want < 1024 ? want : 1024));  // four blocks per CU: enough loads in flight, few range updates
     const dim3 grid_q((T + Q8_RB - 1) / Q8_RB);
     if (src_kind == Q8_SRC_F32) {
         hipLaunchKernelGGL(q8_minmax_kernel<Q8_SRC_F32>, grid_mm, dim3(256), 0, s, d_src, T, K, d_range, d_row_slot);
@@ -351,6 +531,19 @@ int32_t launch_q8_quantize(int src_kind, const void* d_src, uint32_t T, uint32_t
     }
     CS_HIP(hipGetLastError());
     return CS_OK;
+}
+
+// two blocks per CU (64 KiB of LDS each), a multiple of 8 so that a block's slots stay on its XCD
+static uint32_t q8_persistent_grid(uint32_t slots) {
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+        if (cus <= 0) cus = 256;
+    }
+    const uint32_t want = (uint32_t)(2 * cus + 7) / 8 * 8;
+    return slots < want ? slots : want;
 }
 
 int32_t launch_gemm_q8(int epi, const int8_t* d_xq, const Q8RowMeta* d_rmeta, const int8_t* d_wq, const Q8ColMeta* d_cmeta,
@@ -367,14 +560,38 @@ int32_t launch_gemm_q8(int epi, const int8_t* d_xq, const Q8RowMeta* d_rmeta, co
         CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_q8_kernel<SH_OUT_SPLIT>), hipFuncAttributeMaxDynamicSharedMemorySize, SH_LDS_BYTES));
         return CS_OK;
     }));
-    const dim3 grid(sh_grid_blocks((M + SH_BM - 1) / SH_BM, N / SH_BN));
-#define CS_Q8_LAUNCH(E) hipLaunchKernelGGL(gemm_q8_kernel<E>, grid, dim3(256), SH_LDS_BYTES, s, d_xq, d_wq, d_rmeta, d_cmeta, bias, resid, C, Cs, M, N, K, d_flag, d_acc_dbg)
+    const uint32_t slots = sh_grid_blocks((M + SH_BM - 1) / SH_BM, N / SH_BN);
+    const dim3 grid(q8_persistent_grid(slots));
+#define CS_Q8_LAUNCH(E) hipLaunchKernelGGL(gemm_q8_kernel<E>, grid, dim3(256), SH_LDS_BYTES, s, d_xq, d_wq, d_rmeta, d_cmeta, bias, resid, C, Cs, M, N, K, d_flag, d_acc_dbg, Q8Requant{nullptr, nullptr, nullptr}, slots)
     if (epi == SH_OUT_F32) CS_Q8_LAUNCH(SH_OUT_F32);
     else if (epi == SH_OUT_F32_RESID) CS_Q8_LAUNCH(SH_OUT_F32_RESID);
     else if (epi == SH_OUT_SPLIT) CS_Q8_LAUNCH(SH_OUT_SPLIT);
     else if (epi == SH_OUT_SPLIT_GELU) CS_Q8_LAUNCH(SH_OUT_SPLIT_GELU);
     else return fail(CS_ERR_BAD_ARG, "quantised GEMM: unknown epilogue %d", epi);
 #undef CS_Q8_LAUNCH
+    CS_HIP(hipGetLastError());
+    return CS_OK;
+}
+
+int32_t launch_gemm_q8_gelu_requant(const int8_t* d_xq, const Q8RowMeta* d_rmeta, const int8_t* d_wq, const Q8ColMeta* d_cmeta,
+                                    const float* bias, uint32_t M, uint32_t N, uint32_t K, uint32_t* d_range_out, int8_t* d_out,
+                                    Q8RowMeta* d_rmeta_out, hipStream_t s) {
+    if (N % SH_BN || K % 128 || K == 0)
+        return fail(CS_ERR_UNSUPPORTED, "quantised GEMM N=%u K=%u must be multiples of 128", N, K);
+    if (M == 0) return CS_OK;
+    static PerDeviceOnce attr;  // function attributes are per device
+    CS_TRY(attr.run([&]() -> int32_t {
+        CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_q8_kernel<Q8_EPI_GELU_RANGE>), hipFuncAttributeMaxDynamicSharedMemorySize, SH_LDS_BYTES));
+        CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_q8_kernel<Q8_EPI_GELU_Q8>), hipFuncAttributeMaxDynamicSharedMemorySize, SH_LDS_BYTES));
+        return CS_OK;
+    }));
+    const uint32_t slots = sh_grid_blocks((M + SH_BM - 1) / SH_BM, N / SH_BN);
+    const dim3 grid(q8_persistent_grid(slots));
+    const Q8Requant rq{d_range_out, d_out, d_rmeta_out};
+    hipLaunchKernelGGL(gemm_q8_kernel<Q8_EPI_GELU_RANGE>, grid, dim3(256), SH_LDS_BYTES, s, d_xq, d_wq, d_rmeta, d_cmeta, bias,
+                       (const float*)nullptr, (float*)nullptr, (_Float16*)nullptr, M, N, K, (uint32_t*)nullptr, (int32_t*)nullptr, rq, slots);
+    hipLaunchKernelGGL(gemm_q8_kernel<Q8_EPI_GELU_Q8>, grid, dim3(256), SH_LDS_BYTES, s, d_xq, d_wq, d_rmeta, d_cmeta, bias,
+                       (const float*)nullptr, (float*)nullptr, (_Float16*)nullptr, M, N, K, (uint32_t*)nullptr, (int32_t*)nullptr, rq, slots);
     CS_HIP(hipGetLastError());
     return CS_OK;
 }

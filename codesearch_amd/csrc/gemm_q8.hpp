@@ -13,6 +13,10 @@ struct Q8ColMeta { float ws; int32_t zw; int32_t colsum; uint32_t pad; };
 
 enum { Q8_SRC_F32 = 0, Q8_SRC_SPLIT = 1 };
 
+// A quantisation unit's range slot: words 0, 1 = the bits of (lo, hi); 2..4 = scratch of the FFN-up range pass (gemm_q8.hip);
+// all zero before the unit's first kernel of a forward.
+constexpr uint32_t Q8_RANGE_WORDS = 8;
+
 // One layer's quantised weights, bytes from the start of the layer's block: wqkv [3H][H] | ao [H][H] | up [I][H] | down [H][I]
 struct Q8Layer { size_t qkv, ao, up, down, total; };
 inline Q8Layer q8_layer(uint32_t H, uint32_t I) {
@@ -31,7 +35,7 @@ int32_t launch_q8_pack_weight(const float* d_W, const float* d_scale, uint32_t N
                               uint32_t* d_bad, hipStream_t s);
 
 // DynamicQuantizeLinear of [T][K] activations (f32 rows, or split-f16 lines [T][K/32][64]):
-//   d_range [slots][2] u32: running (lo, hi) of each quantisation unit, all zero before the first call of a forward slot
+//   d_range [slots][Q8_RANGE_WORDS] u32: running (lo, hi) of each quantisation unit, all zero before the first call of a forward slot
 //   d_row_slot (may be null: one unit, slot 0): per row, the unit it belongs to; bit 31 set = the row lies outside its unit's
 //              own padded length (not part of the tensor the reference quantises): quantised, but kept out of the range
 // -> d_xq [T][K] s8, d_rmeta [T].
@@ -42,5 +46,12 @@ int32_t launch_q8_quantize(int src_kind, const void* d_src, uint32_t T, uint32_t
 int32_t launch_gemm_q8(int epi, const int8_t* d_xq, const Q8RowMeta* d_rmeta, const int8_t* d_wq, const Q8ColMeta* d_cmeta,
                        const float* bias, const float* resid, float* C, _Float16* Cs, uint32_t M, uint32_t N, uint32_t K,
                        uint32_t* d_flag, hipStream_t s, int32_t* d_acc_dbg = nullptr);
+
+// FFN-up of a quantised model in two passes over the same product: GELU(x W^T + b) re-quantised for FFN-down without the
+// f32-class tensor ever reaching HBM.  d_range_out (one slot, zero before the call) collects the output tensor's range;
+// d_out [M][N] s8 and d_rmeta_out [M] are the next launch_gemm_q8's operands.
+int32_t launch_gemm_q8_gelu_requant(const int8_t* d_xq, const Q8RowMeta* d_rmeta, const int8_t* d_wq, const Q8ColMeta* d_cmeta,
+                                    const float* bias, uint32_t M, uint32_t N, uint32_t K, uint32_t* d_range_out, int8_t* d_out,
+                                    Q8RowMeta* d_rmeta_out, hipStream_t s);
 
 }  // namespace cs

@@ -164,6 +164,11 @@ class FastEmbedder:
         m = {"f32": _lib.CS_GEMM_F32, "split": _lib.CS_GEMM_SPLIT_F16, "q8": _lib.CS_GEMM_Q8_DYNAMIC}[mode]
         _lib.check(self._lib.cs_embedder_set_gemm_mode(self._h, m))
 
+    def gemm_mode(self) -> str:
+        """The arithmetic of the dense layers in force: "split", "f32" or, for a quantised model, "q8"."""
+        return {_lib.CS_GEMM_F32: "f32", _lib.CS_GEMM_SPLIT_F16: "split", _lib.CS_GEMM_Q8_DYNAMIC: "q8"}[
+            int(self._lib.cs_embedder_gemm_mode(self._h))]
+
     def debug_counters(self):
         """-> (split_forwards, f32_forwards, range_fallbacks)"""
         a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()

@@ -556,6 +556,8 @@ int32_t cs_embedders_index_ids(cs_embedders* e, cs_shards* store, const int32_t*
  * are off in this mode because each would change that tensor.  Attention, LayerNorm, GELU and pooling stay f32-class. */
 typedef enum cs_gemm_mode { CS_GEMM_F32 = 0, CS_GEMM_SPLIT_F16 = 1, CS_GEMM_Q8_DYNAMIC = 2 } cs_gemm_mode;
 int32_t cs_embedder_set_gemm_mode(cs_embedder* h, int32_t mode);
+/* The mode in force (a cs_gemm_mode; -1 for a null handle): CS_GEMM_Q8_DYNAMIC for a quantised model unless switched off. */
+int32_t cs_embedder_gemm_mode(const cs_embedder* h);
 int32_t cs_embedder_debug_counters(cs_embedder* h, uint64_t* split_forwards,
                                    uint64_t* f32_forwards, uint64_t* range_fallbacks);
 
@@ -573,7 +575,10 @@ int32_t cs_debug_gemm(int32_t device, int32_t mode, int32_t epilogue, const floa
  * definitions of DynamicQuantizeLinear / MatMulInteger).  A [M,K] f32 activations (a_split != 0: staged through the
  * split-f16 form first, as attention and GELU hand them over); W [N,K] f32 = integer multiples of wscale[n]; epilogue as
  * cs_debug_gemm 0 / 1 / 2, 4 = bias -> split store.  Optional outputs: xq [M,K] the uint8 activations, xparams[2] =
- * (x_scale, x_zero_point), acc [M,N] the int32 MatMulInteger result.  N % 128 == 0, K % 128 == 0. */
+ * (x_scale, x_zero_point), acc [M,N] the int32 MatMulInteger result.  N % 128 == 0, K % 128 == 0.
+ * epilogue 5 = the FFN-up form (GELU, then quantised again for the next Linear, two passes over the product): C receives
+ * the uint8 output as floats, xparams (then FOUR floats) also its (scale, zero_point), the first M entries of acc each
+ * output row's sum of uint8 values. */
 int32_t cs_debug_gemm_q8(int32_t device, int32_t epilogue, int32_t a_split, const float* A, const float* W,
                          const float* wscale, const float* bias, const float* resid, float* C, uint32_t M, uint32_t N,
                          uint32_t K, uint8_t* xq, float* xparams, int32_t* acc);

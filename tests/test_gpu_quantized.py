@@ -102,6 +102,35 @@ def test_operators_match_the_onnx_definitions_exactly(gpu_lib, M, N, K, per_chan
     np.testing.assert_allclose(run_q8(gpu_lib, 1, A, W, sc, bias)[0], gelu, rtol=2e-6, atol=2e-7)
 
 
+@pytest.mark.parametrize("M,N,K", [(300, 1536, 384), (77, 128, 128)])
+def test_ffn_up_leaves_requantised(gpu_lib, M, N, K):
+    """FFN-up -> FFN-down: GELU(x W^T + b) is quantised again for the next Linear; the kernel computes the product twice
+    (range pass, store pass) and never writes the f32 tensor.  Its bytes against DynamicQuantizeLinear of the numpy GELU:
+    the kernels' own erf is 1.2e-7 off the exact one, so a value that sits on a rounding boundary may land on the other
+    side — a handful of bytes, by one step."""
+    from math import erf
+
+    rng = np.random.default_rng(M + N)
+    A = (rng.standard_normal((M, K)) * 1.5).astype(np.float32)
+    W, d, sc = quantize_matrix((rng.standard_normal((N, K)) * 0.05).astype(np.float32), True, True)
+    bias = (rng.standard_normal(N) * 0.1).astype(np.float32)
+    C_ = np.empty((M, N), np.float32)
+    xp = np.empty(4, np.float32)
+    rows = np.empty((M, N), np.int32)
+    _lib.check(gpu_lib.cs_debug_gemm_q8(0, 5, 0, A.ctypes.data_as(f32p), W.ctypes.data_as(f32p), sc.ctypes.data_as(f32p),
+                                        bias.ctypes.data_as(f32p), None, C_.ctypes.data_as(f32p), M, N, K, None,
+                                        xp.ctypes.data_as(f32p), rows.ctypes.data_as(C.POINTER(C.c_int32))))
+    q, xs, xz = dynamic_quantize(A)
+    assert xp[0] == xs and int(xp[1]) == xz
+    y = ((q.astype(np.int64) - xz) @ d.T).astype(np.float32) * (xs * sc)[None, :].astype(np.float32) + bias[None, :]
+    g = (0.5 * y.astype(np.float64) * (1.0 + np.vectorize(erf)(y.astype(np.float64) / np.sqrt(2.0)))).astype(np.float32)
+    gq, gs, gz = dynamic_quantize(g)
+    assert abs(float(xp[2]) - float(gs)) <= 2e-6 * float(gs) and int(xp[3]) == gz
+    diff = np.abs(C_.astype(np.int64) - gq.astype(np.int64))
+    assert diff.max() <= 1 and (diff != 0).mean() < 2e-3
+    assert np.array_equal(rows.reshape(-1)[:M], C_.astype(np.int64).sum(axis=1))   # the row sums the next product needs
+
+
 def test_split_form_activations_quantise_like_their_f32_values(gpu_lib):
     """Attention and GELU hand their outputs over in split-f16 form: the quantiser reads hi + lo / 2048."""
     rng = np.random.default_rng(5)
@@ -242,6 +271,7 @@ def test_quantised_model_directory(gpu_lib, oracle, tmp_path, qdtype_name, per_c
     assert quantized == 1
     ids, mask = synth_token_batch(cfg, 6, 16, 40, True)
     emb = FastEmbedder.from_dir(str(cache), pooling=POOL_MEAN)
+    assert emb.gemm_mode() == "q8"
     got = emb.embed_ids(ids, mask)
     want = oracle.bert_forward(cfg, params, ids, mask, wscale=wscale)["pooled"]
     f32_graph = oracle.bert_forward(cfg, params, ids, mask)["pooled"]
@@ -251,6 +281,7 @@ def test_quantised_model_directory(gpu_lib, oracle, tmp_path, qdtype_name, per_c
     os.environ["CS_ENCODER_QUANT"] = "0"
     try:
         emb = FastEmbedder.from_dir(str(cache), pooling=POOL_MEAN)
+        assert emb.gemm_mode() == "split"
         np.testing.assert_allclose(emb.embed_ids(ids, mask), f32_graph, atol=2e-5)
         emb.close()
     finally:
