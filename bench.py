@@ -278,6 +278,7 @@ def encoder_legs(shard, k, device, with_cpu=True):
     emb_mean.profile_stages(False)
     emb_mean.close()
     g5, a5 = _encoder_flops(cfg, B5, L5)
+    quantized_default = quantized_default_model_leg(ids, mask, d_q[0], device, iters)
     layers = cfg.layers
     stage_names = ("qkv_gemm", "attention", "out_proj_gemm", "layernorm_attn", "ffn_up_gemm", "ffn_down_gemm", "layernorm_ffn")
     Hh, Ii, BL = cfg.hidden, cfg.intermediate, B * L
@@ -349,6 +350,7 @@ def encoder_legs(shard, k, device, with_cpu=True):
             "per_kernel_us_per_layer": {kn: stages5[kn] / layers for kn in stage_names},
             "attention_executed_tflops": 3 * layers * 4 * L5 * Hh * B5 * L5 / (stages5["attention"] * 1e-6) / 1e12,
         },
+        "quantized_default_model": quantized_default,
         "reference_call_shape": {
             "workload": "32 chunks x 256 tokens per call (BatchEmbedder slices by 32, src/embed/batch.rs:70,94), CLS pooling",
             "device_ms_per_call": ms32, "wall_ms_per_call_incl_h2d": wall32 * 1e3, "chunks_per_s": 32 / (ms32 * 1e-3),
@@ -375,6 +377,49 @@ def encoder_legs(shard, k, device, with_cpu=True):
                             "free, and the forward itself runs slower beside a search (embed_ms_with_previous_search_in_flight)")
     es["cls_pool_variant"] = embed_search(cls)
     return {"encoder": enc, "embed_search": es}
+
+
+def quantized_default_model_leg(ids, mask, d_out, device, iters):
+    """The reference's DEFAULT model is a dynamically quantised one (ModelType::AllMiniLML6V2Q,
+    /root/reference/src/embed/embedder.rs:12-13): 6 layers, hidden 384, Linear weights as onnxruntime's quantize_dynamic
+    stores them, activations re-quantised to 8 bits per call.  Same batch (256 x 256 tokens, synthetic weights quantised
+    per tensor to uint8): the dynamic-quantisation mode (int8 MFMA, csrc/gemm_q8.hip) beside the f32 graph of the same
+    weights (split-f16 kernels)."""
+    import torch
+
+    from codesearch_amd import FastEmbedder, ModelType
+    from codesearch_amd.bert_params import quantize_linear_weights, synth_params
+
+    mt = ModelType.AllMiniLML6V2Q
+    cfg = mt.bert_config()
+    params, wscale = quantize_linear_weights(cfg, synth_params(cfg, 202), per_channel=False, unsigned=True)
+    emb = FastEmbedder(mt, config=cfg, params=params, wscale=wscale, device=device)
+    stage_names = ("qkv_gemm", "attention", "out_proj_gemm", "layernorm_attn", "ffn_up_gemm", "ffn_down_gemm", "layernorm_ffn")
+    out = {"workload": f"{mt.name_str()} shape ({cfg.layers} x hidden {cfg.hidden}), batch {ids.shape[0]} x seq {ids.shape[1]}, "
+                       "mean pooling, uint8 per-tensor Linear weights"}
+    for mode, key in (("q8", "dynamic_quantisation"), ("split", "f32_graph_of_the_quantised_weights")):
+        emb.set_gemm_mode(mode)
+        emb.embed_ids_to_device(ids, mask, d_out.data_ptr())
+        torch.cuda.synchronize()
+        emb.profile_read(reset=True)
+        for _ in range(iters):
+            emb.embed_ids_to_device(ids, mask, d_out.data_ptr())
+        torch.cuda.synchronize()
+        ms, n = emb.profile_read()
+        ms /= max(n, 1)
+        emb.profile_stages(True)
+        emb.embed_ids_to_device(ids, mask, d_out.data_ptr())
+        emb.profile_stages_read(reset=True)
+        for _ in range(3):
+            emb.embed_ids_to_device(ids, mask, d_out.data_ptr())
+        stages, _ = emb.profile_stages_read()
+        emb.profile_stages(False)
+        out[key] = {"ms_per_batch": ms, "chunks_per_s": ids.shape[0] / (ms * 1e-3),
+                    "per_kernel_us_per_layer": {kn: stages[kn] / cfg.layers for kn in stage_names}}
+    out["per_kernel_note"] = ("dynamic_quantisation: each Linear's time includes the range + quantising passes over its input; "
+                              "ffn_up_gemm is the two-pass product that leaves already re-quantised for ffn_down")
+    emb.close()
+    return out
 
 
 def e2e_leg(chunks, k, device):
