@@ -77,6 +77,8 @@ struct cs_embedder {
     uint32_t q8_units = 1;
     Q8RowMeta* d_rmeta = nullptr;  // [cap_tokens] (workspace): rows of the tensor being multiplied
     Q8RowMeta* d_rmeta2 = nullptr; // [cap_tokens]: rows of the re-quantised FFN intermediate
+    float* d_range_pairs = nullptr; // (lo, hi) per block / wave of the kernel that produced the tensor quantised next
+    size_t cap_range_pairs = 0;
     int gemm_mode = CS_GEMM_SPLIT_F16;
     bool split_unavailable = false;  // device flushes f16 subnormals in the MFMA: exact-f32 kernels only
     bool wide_ok = false;            // every |w| < 31.98: the one-accumulator 128 x 384 kernels may run (gemm_wide.hip)
@@ -138,7 +140,9 @@ void free_workspace(cs_embedder* h) {
     if (h->d_perm) (void)hipFree(h->d_perm);
     if (h->d_rmeta) (void)hipFree(h->d_rmeta);
     if (h->d_rmeta2) (void)hipFree(h->d_rmeta2);
+    if (h->d_range_pairs) (void)hipFree(h->d_range_pairs);
     h->d_rmeta = h->d_rmeta2 = nullptr;
+    h->d_range_pairs = nullptr;
     h->d_perm = nullptr;
     h->d_ids = h->d_mask = nullptr;
     h->d_x = h->d_xs = h->d_qkv = h->d_ctx = h->d_mid = h->d_pooled = nullptr;
@@ -161,6 +165,9 @@ int32_t reserve(cs_embedder* h, size_t seqs, size_t tokens) {
     if (h->quantized) {
         CS_HIP(hipMalloc(&h->d_rmeta, tokens * sizeof(Q8RowMeta)));
         CS_HIP(hipMalloc(&h->d_rmeta2, tokens * sizeof(Q8RowMeta)));
+        // LayerNorm: a pair per four rows; attention: four per (head group, sequence, 128 queries)
+        h->cap_range_pairs = std::max<size_t>(tokens / 4 + 1, (size_t)h->cfg.heads * 4 * (tokens / 128 + seqs));
+        CS_HIP(hipMalloc(&h->d_range_pairs, h->cap_range_pairs * 2 * sizeof(float)));
     }
     h->cap_tokens = tokens;
     h->cap_seqs = seqs;
@@ -203,6 +210,8 @@ int32_t forward_range(cs_embedder* h, hipStream_t s, uint32_t b0, uint32_t nb, u
     a.pooling = c.pooling; a.x = x; a.out = h->d_pooled + (size_t)b0 * H;
     a.xs = (split && !q8) ? (void*)(h->d_xs + t0 * H) : nullptr;  // q8: the xs buffer holds the quantised rows instead
     a.flag = h->d_flag;
+    if (q8) a.range_out = h->d_range_pairs;  // LayerNorm leaves its blocks' ranges for the quantising pass that follows
+    const uint32_t ln_pairs = (T + 3) / 4;
     _Float16* xs = reinterpret_cast<_Float16*>(h->d_xs + t0 * H);
     _Float16* ctxs = reinterpret_cast<_Float16*>(ctx);
     _Float16* mids = reinterpret_cast<_Float16*>(mid);
@@ -274,18 +283,21 @@ int32_t forward_range(cs_embedder* h, hipStream_t s, uint32_t b0, uint32_t nb, u
             int8_t* xq = reinterpret_cast<int8_t*>(h->d_xs + t0 * H);  // [T][<= 4H] bytes
             Q8RowMeta* rm = h->d_rmeta + t0;
             _Float16* qkvs = reinterpret_cast<_Float16*>(qkv);
-            CS_TRY(launch_q8_quantize(Q8_SRC_F32, x, T, H, rg, nullptr, xq, rm, s));
+            float* rp = h->d_range_pairs;
+            CS_TRY(launch_q8_quantize(Q8_SRC_F32, x, T, H, rg, nullptr, xq, rm, s, rp, ln_pairs));
             CS_TRY(launch_gemm_q8(SH_OUT_SPLIT, xq, rm, wq + ql.qkv, cm, bqkv, nullptr, nullptr, qkvs, T, 3 * H, H, h->d_flag, s));  // E2
             CS_TRY(mark(CS_STAGE_QKV));
-            CS_TRY(launch_attention_sh2(qkvs, mask, ctxs, h->d_flag, nb, L, H, c.heads, s));  // E3
+            uint32_t att_pairs = 0;
+            CS_TRY(launch_attention_sh2(qkvs, mask, ctxs, h->d_flag, nb, L, H, c.heads, s, rp, &att_pairs));  // E3
+            if (att_pairs > h->cap_range_pairs) return fail(CS_ERR_HIP, "range pair buffer too small (%u > %zu)", att_pairs, h->cap_range_pairs);
             CS_TRY(mark(CS_STAGE_ATTENTION));
-            CS_TRY(launch_q8_quantize(Q8_SRC_SPLIT, ctxs, T, H, rg + rstep, nullptr, xq, rm, s));
+            CS_TRY(launch_q8_quantize(Q8_SRC_SPLIT, ctxs, T, H, rg + rstep, nullptr, xq, rm, s, rp, att_pairs));
             CS_TRY(launch_gemm_q8(SH_OUT_F32_RESID, xq, rm, wq + ql.ao, cm + 3 * H, P + lo.ao_b, x, x, nullptr, T, H, H, h->d_flag, s));  // E4
             CS_TRY(mark(CS_STAGE_OUT_PROJ));
             a.g = P + lo.ao_ln_g; a.b = P + lo.ao_ln_b;
             CS_TRY(launch_row_kernel(1, a, H, s));
             CS_TRY(mark(CS_STAGE_LN_ATTN));
-            CS_TRY(launch_q8_quantize(Q8_SRC_F32, x, T, H, rg + 2 * rstep, nullptr, xq, rm, s));
+            CS_TRY(launch_q8_quantize(Q8_SRC_F32, x, T, H, rg + 2 * rstep, nullptr, xq, rm, s, rp, ln_pairs));
             // E5: GELU(x W1^T + b1) leaves already re-quantised for E6 (two passes over the int8 product instead of 1.2 GB of
             // f32-class hand-over at 65,536 rows: launch_gemm_q8_gelu_requant)
             int8_t* midq = reinterpret_cast<int8_t*>(mid);
@@ -999,10 +1011,10 @@ static int32_t create_impl(const cs_bert_config* cfg, const float* params, uint6
             int8_t* wq = h->d_wq8 + (size_t)l * ql.total;
             Q8ColMeta* cm = h->d_cmeta + (size_t)l * cols;
             const float* sc = d_ws + (size_t)l * cols;
-            s = launch_q8_pack_weight(h->d_wqkv + (size_t)l * 3 * H * H, sc, (uint32_t)(3 * H), (uint32_t)H, wq + ql.qkv, cm, d_bad, h->stream);
-            if (s == CS_OK) s = launch_q8_pack_weight(h->d_params + lo.ao_w, sc + 3 * H, (uint32_t)H, (uint32_t)H, wq + ql.ao, cm + 3 * H, d_bad, h->stream);
-            if (s == CS_OK) s = launch_q8_pack_weight(h->d_params + lo.up_w, sc + 4 * H, (uint32_t)I, (uint32_t)H, wq + ql.up, cm + 4 * H, d_bad, h->stream);
-            if (s == CS_OK) s = launch_q8_pack_weight(h->d_params + lo.down_w, sc + 4 * H + I, (uint32_t)H, (uint32_t)I, wq + ql.down, cm + 4 * H + I, d_bad, h->stream);
+            s = launch_q8_pack_weight(h->d_wqkv + (size_t)l * 3 * H * H, sc, h->d_bqkv + (size_t)l * 3 * H, (uint32_t)(3 * H), (uint32_t)H, wq + ql.qkv, cm, d_bad, h->stream);
+            if (s == CS_OK) s = launch_q8_pack_weight(h->d_params + lo.ao_w, sc + 3 * H, h->d_params + lo.ao_b, (uint32_t)H, (uint32_t)H, wq + ql.ao, cm + 3 * H, d_bad, h->stream);
+            if (s == CS_OK) s = launch_q8_pack_weight(h->d_params + lo.up_w, sc + 4 * H, h->d_params + lo.up_b, (uint32_t)I, (uint32_t)H, wq + ql.up, cm + 4 * H, d_bad, h->stream);
+            if (s == CS_OK) s = launch_q8_pack_weight(h->d_params + lo.down_w, sc + 4 * H + I, h->d_params + lo.down_b, (uint32_t)H, (uint32_t)I, wq + ql.down, cm + 4 * H + I, d_bad, h->stream);
         }
         uint32_t bad = 0;
         if (s == CS_OK && (hipMemcpyAsync(&bad, d_bad, sizeof(bad), hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
@@ -1376,7 +1388,7 @@ int32_t cs_debug_gemm_q8(int32_t device, int32_t epilogue, int32_t a_split, cons
             CS_HIP(hipMemcpy(dR, resid, c_n * 4, hipMemcpyHostToDevice));
         }
         if (acc_out && epilogue != 5) CS_HIP(hipMalloc(&dAcc, c_n * 4));
-        CS_TRY(launch_q8_pack_weight(dW, dS, N, K, dWq, dCm, dF + 1, nullptr));
+        CS_TRY(launch_q8_pack_weight(dW, dS, dB, N, K, dWq, dCm, dF + 1, nullptr));
         if (a_split) {
             CS_HIP(hipMalloc(&sA, a_n * 4));
             CS_TRY(launch_split_rows(dA, sA, M, K, dF, nullptr));

@@ -41,7 +41,7 @@ __device__ __forceinline__ int ln_col(int lane, int i) { return 2 * lane + 128 *
 template <int NPL>
 __device__ __forceinline__ bool ln_row(float (&v)[NPL], const float* __restrict__ g,
                                        const float* __restrict__ b, float eps, int lane,
-                                       float* __restrict__ out, _Float16* __restrict__ outs) {
+                                       float* __restrict__ out, _Float16* __restrict__ outs, float& lo, float& hi) {
     constexpr float invH = 1.0f / (64.0f * NPL);
     float s = 0.0f;
 #pragma unroll
@@ -62,6 +62,8 @@ __device__ __forceinline__ bool ln_row(float (&v)[NPL], const float* __restrict_
         o.x = (v[2 * p] - mean) * inv * gv.x + bv.x;
         o.y = (v[2 * p + 1] - mean) * inv * gv.y + bv.y;
         *reinterpret_cast<float2*>(out + c) = o;
+        lo = fminf(lo, fminf(o.x, o.y));  // (the row's range: see ln_range_out)
+        hi = fmaxf(hi, fmaxf(o.x, o.y));
         if (outs) {
             f16x2 hi, lo;
             _Float16 a, bb;
@@ -75,17 +77,36 @@ __device__ __forceinline__ bool ln_row(float (&v)[NPL], const float* __restrict_
     return ovf;
 }
 
+// Dynamic-quantised models quantise the LayerNorm output next (gemm_q8.hip): the block's (lo, hi) over its four rows,
+// zero included, goes to range_out[2 blockIdx.x ..] so that the range pass over the tensor (100 MB read at 65,536 rows)
+// is a reduction over one pair per block instead.  All 256 threads call.
+__device__ __forceinline__ void ln_range_out(float lo, float hi, float* __restrict__ range_out) {
+    __shared__ float s_lo[4], s_hi[4];
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        lo = fminf(lo, __shfl_xor(lo, m, 64));
+        hi = fmaxf(hi, __shfl_xor(hi, m, 64));
+    }
+    if ((threadIdx.x & 63) == 0) { s_lo[threadIdx.x >> 6] = lo; s_hi[threadIdx.x >> 6] = hi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        range_out[2 * (size_t)blockIdx.x] = fminf(fminf(s_lo[0], s_lo[1]), fminf(s_lo[2], s_lo[3]));
+        range_out[2 * (size_t)blockIdx.x + 1] = fmaxf(fmaxf(s_hi[0], s_hi[1]), fmaxf(s_hi[2], s_hi[3]));
+    }
+}
+
 template <int NPL>
 __global__ void __launch_bounds__(256)
 embed_ln_kernel(const int32_t* __restrict__ ids, const float* __restrict__ word,
                 const float* __restrict__ pos, const float* __restrict__ type0,
                 const float* __restrict__ g, const float* __restrict__ b, float eps, uint32_t T,
                 uint32_t L, uint32_t vocab, float* __restrict__ x, _Float16* __restrict__ xs,
-                uint32_t* __restrict__ flag) {
+                uint32_t* __restrict__ flag, float* __restrict__ range_out) {
     constexpr int H = 64 * NPL;
     const int lane = threadIdx.x & 63;
     const uint32_t t = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (t >= T) return;
+    float lo = 0.0f, hi = 0.0f;
+    if (t < T) {
     uint32_t id = (uint32_t)ids[t];
     if (id >= vocab) id = 0;  // host validates; never index out of the table
     const float* we = word + (size_t)id * H;
@@ -100,18 +121,22 @@ embed_ln_kernel(const int32_t* __restrict__ ids, const float* __restrict__ word,
         v[2 * p] = (w2.x + t2.x) + p2.x;  // BertEmbeddings: (inputs + token_type) + position
         v[2 * p + 1] = (w2.y + t2.y) + p2.y;
     }
-    const bool ovf = ln_row<NPL>(v, g, b, eps, lane, x + (size_t)t * H, xs ? xs + (size_t)t * H * 2 : nullptr);
+    const bool ovf = ln_row<NPL>(v, g, b, eps, lane, x + (size_t)t * H, xs ? xs + (size_t)t * H * 2 : nullptr, lo, hi);
     if (ovf && flag) atomicOr(flag, 1u);
+    }
+    if (range_out) ln_range_out(lo, hi, range_out);
 }
 
 template <int NPL>
 __global__ void __launch_bounds__(256)
 layernorm_kernel(float* __restrict__ x, const float* __restrict__ g, const float* __restrict__ b,
-                 float eps, uint32_t T, _Float16* __restrict__ xs, uint32_t* __restrict__ flag) {
+                 float eps, uint32_t T, _Float16* __restrict__ xs, uint32_t* __restrict__ flag,
+                 float* __restrict__ range_out) {
     constexpr int H = 64 * NPL;
     const int lane = threadIdx.x & 63;
     const uint32_t t = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (t >= T) return;
+    float lo = 0.0f, hi = 0.0f;
+    if (t < T) {
     float* row = x + (size_t)t * H;
     float v[NPL];
 #pragma unroll
@@ -120,8 +145,10 @@ layernorm_kernel(float* __restrict__ x, const float* __restrict__ g, const float
         v[2 * p] = r2.x;
         v[2 * p + 1] = r2.y;
     }
-    const bool ovf = ln_row<NPL>(v, g, b, eps, lane, row, xs ? xs + (size_t)t * H * 2 : nullptr);
+    const bool ovf = ln_row<NPL>(v, g, b, eps, lane, row, xs ? xs + (size_t)t * H * 2 : nullptr, lo, hi);
     if (ovf && flag) atomicOr(flag, 1u);
+    }
+    if (range_out) ln_range_out(lo, hi, range_out);
 }
 
 // LayerNorm over x + bias + sum of the split-K partial slabs (the epilogue of a launch_gemm_split_partial
@@ -151,7 +178,8 @@ layernorm_sum_kernel(float* __restrict__ x, const float* __restrict__ parts, uin
         v[2 * p] = (acc.x + bv.x) + r2.x;      // (A W^T + bias) + residual, as the fused epilogue computes it
         v[2 * p + 1] = (acc.y + bv.y) + r2.y;
     }
-    const bool ovf = ln_row<NPL>(v, g, b, eps, lane, row, xs ? xs + (size_t)t * H * 2 : nullptr);
+    float lo = 0.0f, hi = 0.0f;
+    const bool ovf = ln_row<NPL>(v, g, b, eps, lane, row, xs ? xs + (size_t)t * H * 2 : nullptr, lo, hi);
     if (ovf && flag) atomicOr(flag, 1u);
 }
 
@@ -770,10 +798,10 @@ static void launch_rows(int which, const EncoderLaunch& a, hipStream_t s) {
     const uint32_t T = a.T;
     if (which == 0)
         hipLaunchKernelGGL(embed_ln_kernel<NPL>, dim3((T + 3) / 4), dim3(256), 0, s, a.ids, a.word, a.pos,
-                           a.type0, a.g, a.b, a.eps, T, a.L, a.vocab, a.x, static_cast<_Float16*>(a.xs), a.flag);
+                           a.type0, a.g, a.b, a.eps, T, a.L, a.vocab, a.x, static_cast<_Float16*>(a.xs), a.flag, a.range_out);
     else if (which == 1)
         hipLaunchKernelGGL(layernorm_kernel<NPL>, dim3((T + 3) / 4), dim3(256), 0, s, a.x, a.g, a.b, a.eps, T,
-                           static_cast<_Float16*>(a.xs), a.flag);
+                           static_cast<_Float16*>(a.xs), a.flag, a.range_out);
     else if (which == 3)
         hipLaunchKernelGGL(layernorm_sum_kernel<NPL>, dim3((T + 3) / 4), dim3(256), 0, s, a.x, a.parts, a.nparts,
                            a.bias, a.g, a.b, a.eps, T, static_cast<_Float16*>(a.xs), a.flag);

@@ -149,6 +149,30 @@ q8_minmax_kernel(const void* __restrict__ src, uint32_t T, uint32_t K, uint32_t*
     }
 }
 
+// The producers of a tensor (LayerNorm, attention) leave one (lo, hi) per block or wave: their reduction is the range pass.
+__global__ void __launch_bounds__(1024)
+q8_range_reduce_kernel(const float* __restrict__ pairs, uint32_t n, uint32_t* __restrict__ slot) {
+    __shared__ float s_lo[16], s_hi[16];
+    float lo = 0.0f, hi = 0.0f;
+    for (uint32_t i = threadIdx.x; i < n; i += 1024) {
+        const float2 p = reinterpret_cast<const float2*>(pairs)[i];
+        lo = fminf(lo, p.x);
+        hi = fmaxf(hi, p.y);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        lo = fminf(lo, __shfl_xor(lo, o));
+        hi = fmaxf(hi, __shfl_xor(hi, o));
+    }
+    if ((threadIdx.x & 63) == 0) { s_lo[threadIdx.x >> 6] = lo; s_hi[threadIdx.x >> 6] = hi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 16; ++w) { lo = fminf(lo, s_lo[w]); hi = fmaxf(hi, s_hi[w]); }
+        slot[0] = __float_as_uint(lo);
+        slot[1] = __float_as_uint(hi);
+    }
+}
+
 // (x_scale, x_zp) of a unit from its range: DynamicQuantizeLinear's arithmetic, f32, one rounding per operation.
 __device__ __forceinline__ void q8_params_of(float lo, float hi, float& xs, float& xz) {
     xs = hi == lo ? 1.0f : __fdiv_rn(__fsub_rn(hi, lo), 255.0f);
@@ -248,8 +272,9 @@ q8_quantize_kernel(const void* __restrict__ src, uint32_t T, uint32_t K, const u
 
 // One wave per weight row n: the integers d = round(w / scale) (= W_q - W_zp of the file), re-centred so they fit s8.
 __global__ void __launch_bounds__(64)
-q8_pack_weight_kernel(const float* __restrict__ W, const float* __restrict__ scale, uint32_t N, uint32_t K,
-                      int8_t* __restrict__ wq, Q8ColMeta* __restrict__ cmeta, uint32_t* __restrict__ bad) {
+q8_pack_weight_kernel(const float* __restrict__ W, const float* __restrict__ scale, const float* __restrict__ bias,
+                      uint32_t N, uint32_t K, int8_t* __restrict__ wq, Q8ColMeta* __restrict__ cmeta,
+                      uint32_t* __restrict__ bad) {
     const uint32_t n = blockIdx.x;
     if (n >= N) return;
     const int lane = threadIdx.x;
@@ -291,7 +316,7 @@ q8_pack_weight_kernel(const float* __restrict__ W, const float* __restrict__ sca
         m.ws = sc;
         m.zw = -c;
         m.colsum = sum;
-        m.pad = 0;
+        m.bias = bias ? bias[n] : 0.0f;
         cmeta[n] = m;
     }
 }
@@ -504,29 +529,298 @@ gemm_q8_kernel(const int8_t* __restrict__ A, const int8_t* __restrict__ W, const
     }
 }
 
+
+// ---- K = 384 (hidden 384: MiniLM, BGE-small): activations in registers, weights streamed a whole n-tile ahead ------------
+// In gemm_q8_kernel a 128 x 128 tile with K = 384 is three k-steps, each waiting a full L2 round trip for the next stage
+// with two blocks per CU to cover it: 9 us per tile where the MFMAs are 0.8 (profiles/r04_q8_minilm_l6_kernel_stats.csv).
+// Here a block of eight waves owns a 128-row block of the activations and walks n-tiles: its A fragments — 64 rows x 384
+// k per wave = 96 registers — are loaded once per row block straight from global memory in MFMA operand order, and only
+// weights pass through LDS: one n-tile of W with ALL of K is 48 KiB, double-buffered, so tile t + 1 lands under the whole
+// of tile t (its MFMAs and its epilogue) and no k-step waits on memory; the tile's column metadata (with the bias in it)
+// rides along as two more DMA instructions, the row block's metadata sits in LDS too, so the loop issues no ordinary
+// load at all.  Wave tile 64 x 32 (waves as 2 x 4); the C tile leaves in two 64-row halves through 32 KiB of LDS (or as
+// the 16 KiB s8 tile of the re-quantising pass).  One block per CU (134 KiB of LDS, <= 256 registers at two waves per SIMD).
+constexpr int QR_KC = 3;
+constexpr int QR_WTILE = 128 * 128 * QR_KC;          // one n-tile of weights over all of K
+constexpr int QR_OUT_BYTES = 64 * 128 * 4;           // half a C tile in f32
+constexpr int QR_CM_BYTES = 128 * 16;                // an n-tile's column metadata (scale, zero point, column sum, bias)
+constexpr int QR_RM_BYTES = 128 * 16;                // the row block's metadata
+constexpr int QR_LDS = 2 * QR_WTILE + 2 * QR_CM_BYTES + QR_RM_BYTES + QR_OUT_BYTES;  // 137,216
+constexpr int QR_THREADS = 512;
+
+// rows [mrow0, mrow0 + 64) x columns [n0, n0 + 128) from ctile [64][128] f32 (bias already in), 512 threads
+template <int EPI, bool FULL>
+__device__ __forceinline__ void q8_rows_store(const float* ctile, const float* resid, float* C, _Float16* __restrict__ Cs,
+                                              uint32_t M, uint32_t N, uint32_t mrow0, uint32_t n0, uint32_t* __restrict__ flag) {
+    const int tid = threadIdx.x;
+    if (EPI == SH_OUT_SPLIT || EPI == SH_OUT_SPLIT_GELU) {
+        bool ovf = false;
+        const int c8 = tid & 15;
+        const size_t nchunks = N / 32;
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+            const int row = (tid >> 4) + 32 * pass;
+            const sh_f32x4 v0 = *reinterpret_cast<const sh_f32x4*>(ctile + row * 128 + c8 * 8);
+            const sh_f32x4 v1 = *reinterpret_cast<const sh_f32x4*>(ctile + row * 128 + c8 * 8 + 4);
+            f16x8 hi, lo;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                _Float16 a, b;
+                ovf |= sh_split(EPI == SH_OUT_SPLIT_GELU ? sh_gelu_erf(v0[e]) : v0[e], a, b);
+                hi[e] = a; lo[e] = b;
+                ovf |= sh_split(EPI == SH_OUT_SPLIT_GELU ? sh_gelu_erf(v1[e]) : v1[e], a, b);
+                hi[4 + e] = a; lo[4 + e] = b;
+            }
+            if (FULL || mrow0 + row < M) {
+                _Float16* dst = Cs + ((size_t)(mrow0 + row) * nchunks + (n0 >> 5) + (c8 >> 2)) * 64 + (c8 & 3) * 8;
+                __builtin_nontemporal_store(hi, reinterpret_cast<f16x8*>(dst));
+                __builtin_nontemporal_store(lo, reinterpret_cast<f16x8*>(dst + 32));
+            }
+        }
+        if (ovf && flag) atomicOr(flag, 1u);
+    } else {
+        const int c4 = tid & 31;
+        sh_f32x4 rs[4];
+        if (EPI == SH_OUT_F32_RESID) {
+#pragma unroll
+            for (int pass = 0; pass < 4; ++pass) {
+                const uint32_t row = mrow0 + (tid >> 5) + 16 * pass;
+                rs[pass] = *reinterpret_cast<const sh_f32x4*>(resid + (size_t)((FULL || row < M) ? row : M - 1) * N + n0 + c4 * 4);
+            }
+        }
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {
+            const int row = (tid >> 5) + 16 * pass;
+            sh_f32x4 v = *reinterpret_cast<const sh_f32x4*>(ctile + row * 128 + c4 * 4);
+            if (EPI == SH_OUT_F32_RESID) v += rs[pass];
+            if (FULL || mrow0 + row < M) *reinterpret_cast<sh_f32x4*>(C + (size_t)(mrow0 + row) * N + n0 + c4 * 4) = v;
+        }
+    }
+}
+
+template <int EPI>
+__global__ void __launch_bounds__(QR_THREADS, 2)
+gemm_q8_rows_kernel(const int8_t* __restrict__ A, const int8_t* __restrict__ W, const Q8RowMeta* __restrict__ rmeta,
+                    const Q8ColMeta* __restrict__ cmeta, const float* __restrict__ bias, const float* resid, float* C,
+                    _Float16* __restrict__ Cs, uint32_t M, uint32_t N, uint32_t* __restrict__ flag, Q8Requant rq,
+                    uint32_t parts, uint32_t total_units) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    constexpr uint32_t K = 128 * QR_KC;
+    constexpr bool REQ = EPI == Q8_EPI_GELU_RANGE || EPI == Q8_EPI_GELU_Q8;
+    char* cmbuf = lds + 2 * QR_WTILE;                          // [2][128] Q8ColMeta
+    Q8RowMeta* lrow = reinterpret_cast<Q8RowMeta*>(cmbuf + 2 * QR_CM_BYTES);  // [128]: xs, za, rowsum - K za
+    char* obuf = cmbuf + 2 * QR_CM_BYTES + QR_RM_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int l15 = lane & 15, g = lane >> 4;
+    const int swz = (l15 >> 1) & 7;
+    const int s0 = (g ^ swz) * 16, s1 = ((4 + g) ^ swz) * 16;
+    const int wrow = (wc * 32 + l15) * 128;
+    const uint32_t ntiles = N / 128, per = (ntiles + parts - 1) / parts;
+    // this wave's six LDS-DMA instructions of a W tile (of 48: chunk q / 16, rows 8 (q % 16) ..): per-lane source offsets
+    uint32_t woff[6];
+#pragma unroll
+    for (int t = 0; t < 6; ++t) {
+        const int q = wave * 6 + t, c = q >> 4, row = (q & 15) * 8 + (lane >> 3);
+        woff[t] = (uint32_t)row * K + c * 128 + (((lane & 7) ^ ((row >> 1) & 7)) * 16);
+    }
+    auto issue_w = [&](uint32_t nt, int b) {
+        const int8_t* src = W + (size_t)nt * 128 * K;
+        char* buf = lds + b * QR_WTILE;
+#pragma unroll
+        for (int t = 0; t < 6; ++t) sh_glds16(src + woff[t], buf + (wave * 6 + t) * 1024);
+        if (wave < 2)  // 128 columns x 16 B of metadata: lane l of wave w moves column 64 w + l
+            sh_glds16(reinterpret_cast<const char*>(cmeta + (size_t)nt * 128 + wave * 64) + lane * 16, cmbuf + b * QR_CM_BYTES + wave * 1024);
+    };
+    float gs = 1.0f, gz = 0.0f, rgs = 1.0f;
+    if (EPI == Q8_EPI_GELU_Q8) {
+        q8_params_gelu(rq.range, gs, gz);
+        rgs = __fdiv_rn(1.0f, gs);
+    }
+    float ymax = -INFINITY, ya = -INFINITY, yb = INFINITY;
+
+    for (uint32_t unit = blockIdx.x; unit < total_units; unit += gridDim.x) {
+        const uint32_t mt = unit / parts, nt0 = (unit % parts) * per;
+        const uint32_t nt1 = nt0 + per < ntiles ? nt0 + per : ntiles;
+        if (nt0 >= nt1) continue;
+        const uint32_t m0 = mt * 128;
+        // the wave's 64 rows x 384 k as MFMA A operands: row l15 of row group i, bytes 16 g .. of k-step s of chunk c
+        q8_i32x4 a0[QR_KC][4], a1[QR_KC][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t row = m0 + wr * 64 + i * 16 + l15;
+            const int8_t* p = A + (size_t)(row < M ? row : M - 1) * K + g * 16;
+#pragma unroll
+            for (int c = 0; c < QR_KC; ++c) {
+                a0[c][i] = *reinterpret_cast<const q8_i32x4*>(p + c * 128);
+                a1[c][i] = *reinterpret_cast<const q8_i32x4*>(p + c * 128 + 64);
+            }
+        }
+        // the row block's metadata into LDS: x_scale, x zero point, rowsum - K za
+        if (tid < 128) {
+            Q8RowMeta rm = rmeta[m0 + tid < M ? m0 + tid : M - 1];
+            rm.rowsum -= (int)K * rm.za;
+            lrow[tid] = rm;
+        }
+        issue_w(nt0, 0);
+        __syncthreads();  // W tile nt0 has landed (vmcnt(0) precedes the barrier); obuf and the other W buffer are free
+        for (uint32_t nt = nt0; nt < nt1; ++nt) {
+            const uint32_t n0 = nt * 128;
+            const int b = (nt - nt0) & 1;
+            char* cur = lds + b * QR_WTILE;
+            const Q8ColMeta* lcm = reinterpret_cast<const Q8ColMeta*>(cmbuf + b * QR_CM_BYTES);
+            if (nt + 1 < nt1) issue_w(nt + 1, b ^ 1);  // lands under this tile's MFMAs and epilogue
+            q8_i32x4 acc[4][2];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = q8_i32x4{0, 0, 0, 0};
+#pragma unroll
+            for (int c = 0; c < QR_KC; ++c) {
+                q8_i32x4 w0[2], w1[2];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    w0[j] = *reinterpret_cast<const q8_i32x4*>(cur + c * 16384 + wrow + j * 16 * 128 + s0);
+                    w1[j] = *reinterpret_cast<const q8_i32x4*>(cur + c * 16384 + wrow + j * 16 * 128 + s1);
+                }
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        acc[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0[c][i], w0[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1[c][i], w1[j], acc[i][j], 0, 0, 0);
+                    }
+            }
+            // y = float(acc with the zero points back in) * (x_scale * W_scale) + bias
+            Q8ColMeta cm[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) cm[j] = lcm[wc * 32 + j * 16 + l15];
+            auto y_of = [&](const Q8RowMeta& rm, int i, int r, int j) {
+                const int corr = acc[i][j][r] - __mul24(cm[j].zw, rm.rowsum) - __mul24(rm.za, cm[j].colsum);
+                return __fadd_rn(__fmul_rn((float)corr, __fmul_rn(rm.xs, cm[j].ws)), cm[j].bias);
+            };
+            if constexpr (REQ) {
+                int8_t* tile8 = reinterpret_cast<int8_t*>(obuf);  // [128 m][128 n] s8
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const Q8RowMeta rm = lrow[wr * 64 + i * 16 + 4 * g + r];
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            const float y = y_of(rm, i, r, j);
+                            if (EPI == Q8_EPI_GELU_RANGE) {
+                                ymax = fmaxf(ymax, y);
+                                ya = y <= kGeluArgMin ? fmaxf(ya, y) : ya;
+                                yb = y >= kGeluArgMin ? fminf(yb, y) : yb;
+                            } else {
+                                const float v = sh_gelu_erf(y);
+                                const float t = v * rgs;
+                                float rt = rintf(t);
+                                if (fabsf(fabsf(t - rt) - 0.5f) < 1.0e-3f) rt = rintf(__fdiv_rn(v, gs));
+                                const float q = fminf(fmaxf(__fadd_rn(rt, gz), 0.0f), 255.0f);
+                                tile8[(wr * 64 + i * 16 + 4 * g + r) * 128 + wc * 32 + j * 16 + l15] = (int8_t)((int)q - 128);
+                            }
+                        }
+                    }
+                if (EPI == Q8_EPI_GELU_RANGE) {
+                    if (nt == 0 && tid < 128 && m0 + tid < M) rq.rmeta_out[m0 + tid].rowsum = 0;
+                } else {
+                    __syncthreads();
+#pragma unroll
+                    for (int pass = 0; pass < 2; ++pass) {
+                        const int idx = tid + QR_THREADS * pass, row = idx >> 3, c16 = idx & 7;
+                        const q8_i32x4 v = *reinterpret_cast<const q8_i32x4*>(tile8 + row * 128 + c16 * 16);
+                        int sum = 0;
+#pragma unroll
+                        for (int w = 0; w < 4; ++w)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) sum += (int)(int8_t)(((uint32_t)v[w] >> (8 * e)) & 0xffu);
+                        sum += __shfl_xor(sum, 1);
+                        sum += __shfl_xor(sum, 2);
+                        sum += __shfl_xor(sum, 4);
+                        if (m0 + row < M) {
+                            *reinterpret_cast<q8_i32x4*>(rq.out + (size_t)(m0 + row) * N + n0 + c16 * 16) = v;
+                            if (c16 == 0) atomicAdd(&rq.rmeta_out[m0 + row].rowsum, sum);
+                        }
+                    }
+                    if (nt == 0 && tid < 128 && m0 + tid < M) {
+                        rq.rmeta_out[m0 + tid].xs = gs;
+                        rq.rmeta_out[m0 + tid].za = (int)gz - 128;
+                    }
+                }
+            } else {
+                float* ctile = reinterpret_cast<float*>(obuf);  // [64 m][128 n] f32: one half of the tile at a time
+                constexpr int SEPI = REQ ? SH_OUT_F32 : EPI;
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    if (half) __syncthreads();  // the first half has been read
+                    if (wr == half) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const Q8RowMeta rm = lrow[wr * 64 + i * 16 + 4 * g + r];
+#pragma unroll
+                                for (int j = 0; j < 2; ++j)
+                                    ctile[(i * 16 + 4 * g + r) * 128 + wc * 32 + j * 16 + l15] = y_of(rm, i, r, j);
+                            }
+                    }
+                    __syncthreads();
+                    const uint32_t mrow0 = m0 + half * 64;
+                    if (mrow0 + 64 <= M) q8_rows_store<SEPI, true>(ctile, resid, C, Cs, M, N, mrow0, n0, flag);
+                    else if (mrow0 < M) q8_rows_store<SEPI, false>(ctile, resid, C, Cs, M, N, mrow0, n0, flag);
+                }
+            }
+            __syncthreads();  // W tile nt + 1 has landed; every wave is done with this tile's weights and with obuf
+        }
+    }
+    if (EPI == Q8_EPI_GELU_RANGE) {
+        float* s_r = reinterpret_cast<float*>(obuf);  // [3][8]
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            ymax = fmaxf(ymax, __shfl_xor(ymax, o));
+            ya = fmaxf(ya, __shfl_xor(ya, o));
+            yb = fminf(yb, __shfl_xor(yb, o));
+        }
+        if (lane == 0) { s_r[wave] = ymax; s_r[8 + wave] = ya; s_r[16 + wave] = yb; }
+        __syncthreads();
+        if (tid == 0) {
+            float m3 = -INFINITY, a3 = -INFINITY, b3 = INFINITY;
+            for (int w = 0; w < 8; ++w) { m3 = fmaxf(m3, s_r[w]); a3 = fmaxf(a3, s_r[8 + w]); b3 = fminf(b3, s_r[16 + w]); }
+            if (m3 > -INFINITY) q8_key_update(rq.range + 2, m3);
+            if (a3 > -INFINITY) q8_key_update(rq.range + 3, a3);
+            if (b3 < INFINITY) q8_key_update(rq.range + 4, -b3);
+        }
+    }
+}
+
 }  // namespace
 
-int32_t launch_q8_pack_weight(const float* d_W, const float* d_scale, uint32_t N, uint32_t K, int8_t* d_wq, Q8ColMeta* d_cmeta,
-                              uint32_t* d_bad, hipStream_t s) {
+int32_t launch_q8_pack_weight(const float* d_W, const float* d_scale, const float* d_bias, uint32_t N, uint32_t K, int8_t* d_wq,
+                              Q8ColMeta* d_cmeta, uint32_t* d_bad, hipStream_t s) {
     if (N == 0 || K == 0) return CS_OK;
-    hipLaunchKernelGGL(q8_pack_weight_kernel, dim3(N), dim3(64), 0, s, d_W, d_scale, N, K, d_wq, d_cmeta, d_bad);
+    hipLaunchKernelGGL(q8_pack_weight_kernel, dim3(N), dim3(64), 0, s, d_W, d_scale, d_bias, N, K, d_wq, d_cmeta, d_bad);
     CS_HIP(hipGetLastError());
     return CS_OK;
 }
 
 int32_t launch_q8_quantize(int src_kind, const void* d_src, uint32_t T, uint32_t K, uint32_t* d_range, const uint32_t* d_row_slot,
-                           int8_t* d_xq, Q8RowMeta* d_rmeta, hipStream_t s) {
+                           int8_t* d_xq, Q8RowMeta* d_rmeta, hipStream_t s, const float* d_range_pairs, uint32_t n_pairs) {
     if (K % 32) return fail(CS_ERR_UNSUPPORTED, "dynamic quantisation needs K %% 32 == 0 (K = %u)", K);
     if (T == 0) return CS_OK;
     const uint64_t units = (uint64_t)T * (K / (src_kind == Q8_SRC_F32 ? 4 : 8));
     const uint64_t want = (units + 255) / 256;
     const dim3 grid_mm((uint32_t)(want < 1024 ? want : 1024));  // four blocks per CU: enough loads in flight, few range updates
     const dim3 grid_q((T + Q8_RB - 1) / Q8_RB);
+    const bool reduced = d_range_pairs && n_pairs && !d_row_slot;  // the tensor's producer already left per-block ranges
+    if (reduced) hipLaunchKernelGGL(q8_range_reduce_kernel, dim3(1), dim3(1024), 0, s, d_range_pairs, n_pairs, d_range);
     if (src_kind == Q8_SRC_F32) {
-        hipLaunchKernelGGL(q8_minmax_kernel<Q8_SRC_F32>, grid_mm, dim3(256), 0, s, d_src, T, K, d_range, d_row_slot);
+        if (!reduced) hipLaunchKernelGGL(q8_minmax_kernel<Q8_SRC_F32>, grid_mm, dim3(256), 0, s, d_src, T, K, d_range, d_row_slot);
         hipLaunchKernelGGL(q8_quantize_kernel<Q8_SRC_F32>, grid_q, dim3(256), 0, s, d_src, T, K, d_range, d_row_slot, d_xq, d_rmeta);
     } else {
-        hipLaunchKernelGGL(q8_minmax_kernel<Q8_SRC_SPLIT>, grid_mm, dim3(256), 0, s, d_src, T, K, d_range, d_row_slot);
+        if (!reduced) hipLaunchKernelGGL(q8_minmax_kernel<Q8_SRC_SPLIT>, grid_mm, dim3(256), 0, s, d_src, T, K, d_range, d_row_slot);
         hipLaunchKernelGGL(q8_quantize_kernel<Q8_SRC_SPLIT>, grid_q, dim3(256), 0, s, d_src, T, K, d_range, d_row_slot, d_xq, d_rmeta);
     }
     CS_HIP(hipGetLastError());
@@ -546,12 +840,56 @@ static uint32_t q8_persistent_grid(uint32_t slots) {
     return slots < want ? slots : want;
 }
 
+// The row-block kernel (gemm_q8_rows_kernel) takes K = 384 layers from rows_min_m rows on: below that a row block per CU
+// leaves most of the chip idle and the tile-per-block kernel spreads the same work over more CUs.  CS_Q8_ROWS=0: never.
+static bool q8_rows_takes(uint32_t M, uint32_t K) {
+    static const int min_m = [] { const char* e = std::getenv("CS_Q8_ROWS"); return e ? std::atoi(e) : 4096; }();
+    return K == 128 * QR_KC && min_m > 0 && M >= (uint32_t)min_m;
+}
+static int q8_cus() {
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+        if (cus <= 0) cus = 256;
+    }
+    return cus;
+}
+template <int EPI>
+static int32_t launch_rows(const int8_t* d_xq, const Q8RowMeta* d_rmeta, const int8_t* d_wq, const Q8ColMeta* d_cmeta,
+                           const float* bias, const float* resid, float* C, _Float16* Cs, uint32_t M, uint32_t N,
+                           uint32_t* d_flag, Q8Requant rq, hipStream_t s) {
+    static PerDeviceOnce attr;  // function attributes are per device
+    CS_TRY(attr.run([&]() -> int32_t {
+        CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_q8_rows_kernel<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, QR_LDS));
+        return CS_OK;
+    }));
+    const uint32_t mtiles = (M + 127) / 128, ntiles = N / 128, cus = (uint32_t)q8_cus();
+    // a unit = one row block x a range of its n-tiles: whole row blocks when there is one per CU, else cut so every CU has work
+    uint32_t parts = mtiles >= cus ? 1u : (cus + mtiles - 1) / mtiles;
+    if (parts > ntiles) parts = ntiles;
+    const uint32_t units = mtiles * parts;
+    hipLaunchKernelGGL(gemm_q8_rows_kernel<EPI>, dim3(units < cus ? units : cus), dim3(QR_THREADS), QR_LDS, s, d_xq, d_wq, d_rmeta,
+                       d_cmeta, bias, resid, C, Cs, M, N, d_flag, rq, parts, units);
+    CS_HIP(hipGetLastError());
+    return CS_OK;
+}
+
 int32_t launch_gemm_q8(int epi, const int8_t* d_xq, const Q8RowMeta* d_rmeta, const int8_t* d_wq, const Q8ColMeta* d_cmeta,
                        const float* bias, const float* resid, float* C, _Float16* Cs, uint32_t M, uint32_t N, uint32_t K,
                        uint32_t* d_flag, hipStream_t s, int32_t* d_acc_dbg) {
     if (N % SH_BN || K % 128 || K == 0)
         return fail(CS_ERR_UNSUPPORTED, "quantised GEMM N=%u K=%u must be multiples of 128", N, K);
     if (M == 0) return CS_OK;
+    if (q8_rows_takes(M, K) && !d_acc_dbg) {
+        const Q8Requant none{nullptr, nullptr, nullptr};
+        if (epi == SH_OUT_F32) return launch_rows<SH_OUT_F32>(d_xq, d_rmeta, d_wq, d_cmeta, bias, resid, C, Cs, M, N, d_flag, none, s);
+        if (epi == SH_OUT_F32_RESID) return launch_rows<SH_OUT_F32_RESID>(d_xq, d_rmeta, d_wq, d_cmeta, bias, resid, C, Cs, M, N, d_flag, none, s);
+        if (epi == SH_OUT_SPLIT) return launch_rows<SH_OUT_SPLIT>(d_xq, d_rmeta, d_wq, d_cmeta, bias, resid, C, Cs, M, N, d_flag, none, s);
+        if (epi == SH_OUT_SPLIT_GELU) return launch_rows<SH_OUT_SPLIT_GELU>(d_xq, d_rmeta, d_wq, d_cmeta, bias, resid, C, Cs, M, N, d_flag, none, s);
+        return fail(CS_ERR_BAD_ARG, "quantised GEMM: unknown epilogue %d", epi);
+    }
     static PerDeviceOnce attr;  // function attributes are per device
     CS_TRY(attr.run([&]() -> int32_t {
         CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_q8_kernel<SH_OUT_F32>), hipFuncAttributeMaxDynamicSharedMemorySize, SH_LDS_BYTES));
@@ -579,6 +917,11 @@ int32_t launch_gemm_q8_gelu_requant(const int8_t* d_xq, const Q8RowMeta* d_rmeta
     if (N % SH_BN || K % 128 || K == 0)
         return fail(CS_ERR_UNSUPPORTED, "quantised GEMM N=%u K=%u must be multiples of 128", N, K);
     if (M == 0) return CS_OK;
+    if (q8_rows_takes(M, K)) {
+        const Q8Requant rq{d_range_out, d_out, d_rmeta_out};
+        CS_TRY(launch_rows<Q8_EPI_GELU_RANGE>(d_xq, d_rmeta, d_wq, d_cmeta, bias, nullptr, nullptr, nullptr, M, N, nullptr, rq, s));
+        return launch_rows<Q8_EPI_GELU_Q8>(d_xq, d_rmeta, d_wq, d_cmeta, bias, nullptr, nullptr, nullptr, M, N, nullptr, rq, s);
+    }
     static PerDeviceOnce attr;  // function attributes are per device
     CS_TRY(attr.run([&]() -> int32_t {
         CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_q8_kernel<Q8_EPI_GELU_RANGE>), hipFuncAttributeMaxDynamicSharedMemorySize, SH_LDS_BYTES));

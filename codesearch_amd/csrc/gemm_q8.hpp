@@ -9,7 +9,7 @@ namespace cs {
 //   weight column n:   w[n][k] = (b[n][k] - zw) * ws      b = stored s8 (W_q - W_zp re-centred into [-128, 127])
 // rowsum / colsum are the plain sums of the stored s8 values over k.
 struct Q8RowMeta { float xs; int32_t za; int32_t rowsum; uint32_t pad; };
-struct Q8ColMeta { float ws; int32_t zw; int32_t colsum; uint32_t pad; };
+struct Q8ColMeta { float ws; int32_t zw; int32_t colsum; float bias; };  // bias: the layer's bias for this column (may be 0)
 
 enum { Q8_SRC_F32 = 0, Q8_SRC_SPLIT = 1 };
 
@@ -31,16 +31,19 @@ inline Q8Layer q8_layer(uint32_t H, uint32_t I) {
 
 // W [N][K] f32 = (integer) * scale[n]  ->  wq [N][K] s8 + cmeta [N].  *d_bad (device u32, zeroed by the caller) is OR-ed
 // with 1 when a row's integers span more than 8 bits, with 2 when a weight is not a multiple of its scale.
-int32_t launch_q8_pack_weight(const float* d_W, const float* d_scale, uint32_t N, uint32_t K, int8_t* d_wq, Q8ColMeta* d_cmeta,
-                              uint32_t* d_bad, hipStream_t s);
+int32_t launch_q8_pack_weight(const float* d_W, const float* d_scale, const float* d_bias, uint32_t N, uint32_t K, int8_t* d_wq,
+                              Q8ColMeta* d_cmeta, uint32_t* d_bad, hipStream_t s);
 
 // DynamicQuantizeLinear of [T][K] activations (f32 rows, or split-f16 lines [T][K/32][64]):
 //   d_range [slots][Q8_RANGE_WORDS] u32: running (lo, hi) of each quantisation unit, all zero before the first call of a forward slot
 //   d_row_slot (may be null: one unit, slot 0): per row, the unit it belongs to; bit 31 set = the row lies outside its unit's
 //              own padded length (not part of the tensor the reference quantises): quantised, but kept out of the range
 // -> d_xq [T][K] s8, d_rmeta [T].
+// d_range_pairs / n_pairs (optional): (lo, hi) float pairs the tensor's producer left per block or wave (LayerNorm,
+// attention): reduced instead of reading the tensor for its range.
 int32_t launch_q8_quantize(int src_kind, const void* d_src, uint32_t T, uint32_t K, uint32_t* d_range, const uint32_t* d_row_slot,
-                           int8_t* d_xq, Q8RowMeta* d_rmeta, hipStream_t s);
+                           int8_t* d_xq, Q8RowMeta* d_rmeta, hipStream_t s, const float* d_range_pairs = nullptr,
+                           uint32_t n_pairs = 0);
 
 // C = MatMulInteger(xq, wq) * (xs * ws) + bias, then the epilogue `epi` (SH_OUT_*, encoder.hpp).  N % 128 == 0, K % 128 == 0.
 int32_t launch_gemm_q8(int epi, const int8_t* d_xq, const Q8RowMeta* d_rmeta, const int8_t* d_wq, const Q8ColMeta* d_cmeta,
