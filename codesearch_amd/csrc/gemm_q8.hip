@@ -639,6 +639,7 @@ gemm_q8_rows_kernel(const int8_t* __restrict__ A, const int8_t* __restrict__ W, 
         rgs = __fdiv_rn(1.0f, gs);
     }
     float ymax = -INFINITY, ya = -INFINITY, yb = INFINITY;
+    float ycen = 0.0f, yhw = INFINITY;  // wave-uniform: centre and half-width (padded) of the wave's (a, b) so far
 
     for (uint32_t unit = blockIdx.x; unit < total_units; unit += gridDim.x) {
         const uint32_t mt = unit / parts, nt0 = (unit % parts) * per;
@@ -700,7 +701,41 @@ gemm_q8_rows_kernel(const int8_t* __restrict__ A, const int8_t* __restrict__ W, 
                 const int corr = acc[i][j][r] - __mul24(cm[j].zw, rm.rowsum) - __mul24(rm.za, cm[j].colsum);
                 return __fadd_rn(__fmul_rn((float)corr, __fmul_rn(rm.xs, cm[j].ws)), cm[j].bias);
             };
-            if constexpr (REQ) {
+            if constexpr (EPI == Q8_EPI_GELU_RANGE) {
+                // max y per element; the two neighbours a, b of the GELU's minimum (q8_params_gelu) only when this tile holds a
+                // value inside the window (a, b) the wave has so far — a handful of tiles per wave: three instructions per
+                // element instead of eight.  The window test is padded by 1e-5 (rounding of its centre): never misses.
+                float ys[32], off = INFINITY;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const Q8RowMeta rm = lrow[wr * 64 + i * 16 + 4 * g + r];
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            const float y = y_of(rm, i, r, j);
+                            ys[(i * 4 + r) * 2 + j] = y;
+                            ymax = fmaxf(ymax, y);
+                            off = fminf(off, fabsf(y - ycen));
+                        }
+                    }
+                if (!(yhw < INFINITY) || __any(off < yhw)) {
+#pragma unroll
+                    for (int e = 0; e < 32; ++e) {
+                        ya = ys[e] <= kGeluArgMin ? fmaxf(ya, ys[e]) : ya;
+                        yb = ys[e] >= kGeluArgMin ? fminf(yb, ys[e]) : yb;
+                    }
+                    float wa = ya, wb = yb;  // the wave's window
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) {
+                        wa = fmaxf(wa, __shfl_xor(wa, o));
+                        wb = fminf(wb, __shfl_xor(wb, o));
+                    }
+                    ycen = 0.5f * (wa + wb);             // (NaN / inf while a side is still empty: yhw stays inf)
+                    yhw = 0.5f * (wb - wa) + 1.0e-5f;
+                }
+                if (nt == 0 && tid < 128 && m0 + tid < M) rq.rmeta_out[m0 + tid].rowsum = 0;
+            } else if constexpr (REQ) {
                 int8_t* tile8 = reinterpret_cast<int8_t*>(obuf);  // [128 m][128 n] s8
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
@@ -710,11 +745,7 @@ gemm_q8_rows_kernel(const int8_t* __restrict__ A, const int8_t* __restrict__ W, 
 #pragma unroll
                         for (int j = 0; j < 2; ++j) {
                             const float y = y_of(rm, i, r, j);
-                            if (EPI == Q8_EPI_GELU_RANGE) {
-                                ymax = fmaxf(ymax, y);
-                                ya = y <= kGeluArgMin ? fmaxf(ya, y) : ya;
-                                yb = y >= kGeluArgMin ? fminf(yb, y) : yb;
-                            } else {
+                            {
                                 const float v = sh_gelu_erf(y);
                                 const float t = v * rgs;
                                 float rt = rintf(t);
@@ -724,9 +755,7 @@ gemm_q8_rows_kernel(const int8_t* __restrict__ A, const int8_t* __restrict__ W, 
                             }
                         }
                     }
-                if (EPI == Q8_EPI_GELU_RANGE) {
-                    if (nt == 0 && tid < 128 && m0 + tid < M) rq.rmeta_out[m0 + tid].rowsum = 0;
-                } else {
+                {
                     __syncthreads();
 #pragma unroll
                     for (int pass = 0; pass < 2; ++pass) {
