@@ -34,7 +34,9 @@ TEXTS = [
 def run_onnx(model_dir, ids, mask):
     import onnxruntime as ort
 
-    for rel in ("onnx/model.onnx", "model.onnx", "model_optimized.onnx"):
+    # (the *Q registry entries cache onnx/model_quantized.onnx: onnxruntime then runs the dynamically quantised graph, which
+    # is what the library's CS_GEMM_Q8_DYNAMIC mode restates; the transformers fallback below cannot stand in for it)
+    for rel in ("onnx/model.onnx", "model.onnx", "model_optimized.onnx", "onnx/model_quantized.onnx", "model_quantized.onnx"):
         p = os.path.join(model_dir, rel)
         if os.path.exists(p):
             break

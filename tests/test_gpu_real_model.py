@@ -2,7 +2,8 @@
 structural — the reference holds no embedding vector and no model file exists offline).
 
 Skipped unless CS_REAL_MODEL_DIR names a model directory as hf-hub leaves it in fastembed's cache (config.json; the
-weights as onnx/model.onnx | model.onnx | model_optimized.onnx | model.safetensors; tokenizer.json or vocab.txt), e.g.
+weights as onnx/model.onnx | model.onnx | model_optimized.onnx | onnx/model_quantized.onnx | model.safetensors;
+tokenizer.json or vocab.txt), e.g.
 the snapshot of Xenova/bge-small-en-v1.5 or BAAI/bge-small-en-v1.5:
 
     CS_REAL_MODEL_DIR=/path/to/snapshot python -m pytest tests/test_gpu_real_model.py -m gpu -q
@@ -81,7 +82,12 @@ def test_embeddings_match_the_cpu_runtime_golden(embedder):
     for i, t in enumerate(texts):
         n = int(mask[i].sum())
         assert ids[i][:n].tolist() == g["input_ids"][i][: int(g["lengths"][i])].tolist(), f"tokenisation differs: {t!r}"
-    assert np.abs(got - want).max() < 1e-4, np.abs(got - want).max()
+    # A dynamically quantised model (a *Q directory: model_quantized.onnx, run as CS_GEMM_Q8_DYNAMIC) has an 8-bit rounding
+    # behind every Linear: two f32-class evaluations of the same graph flip a few activation bytes (ORT on
+    # two CPUs differs from itself the same way), so the bound is the flip noise, not f32 rounding.  The golden must then
+    # have been made with the SAME call units (make_real_model_golden.py embeds its texts in one call, as this does).
+    tol = 3e-3 if embedder.gemm_mode() == "q8" else 1e-4
+    assert np.abs(got - want).max() < tol, np.abs(got - want).max()
     gn = got / np.linalg.norm(got, axis=1, keepdims=True)
     wn = want / np.linalg.norm(want, axis=1, keepdims=True)
-    assert np.abs(gn @ gn.T - wn @ wn.T).max() < 1e-4
+    assert np.abs(gn @ gn.T - wn @ wn.T).max() < tol
