@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""The reference's call shape on a quantised model (the default one): slices of 32 chunks x 256 tokens
+(/root/reference/src/embed/batch.rs:70,94), one call at a time vs eight submitted and collected through the queue
+(each slice stays its own quantisation unit inside the shared device batch)."""
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    import numpy as np
+
+    from codesearch_amd import FastEmbedder, ModelType
+    from codesearch_amd.bert_params import quantize_linear_weights, synth_params, synth_token_batch
+
+    mt = ModelType.AllMiniLML6V2Q
+    cfg = mt.bert_config()
+    params, wscale = quantize_linear_weights(cfg, synth_params(cfg, 202), per_channel=False, unsigned=True)
+    emb = FastEmbedder(mt, config=cfg, params=params, wscale=wscale)
+    ids, mask = synth_token_batch(cfg, 999, 256, 256, False)
+    out = {}
+    for mode in ("q8", "split"):
+        emb.set_gemm_mode(mode)
+        emb.embed_ids(ids[:32], mask[:32])
+        t0 = time.perf_counter()
+        for _ in range(10):
+            for lo in range(0, 256, 32):
+                emb.embed_ids(ids[lo:lo + 32], mask[lo:lo + 32])
+        one = (time.perf_counter() - t0) / 10
+
+        def queued():
+            ts = [emb.submit_ids(ids[lo:lo + 32], mask[lo:lo + 32]) for lo in range(0, 256, 32)]
+            return [emb.wait(t) for t in ts]
+
+        queued()
+        emb.profile_read(reset=True)
+        t0 = time.perf_counter()
+        for _ in range(10):
+            queued()
+        q = (time.perf_counter() - t0) / 10
+        ms, n = emb.profile_read()
+        out[mode] = {"one_call_at_a_time_chunks_per_s": 256 / one, "queued_chunks_per_s": 256 / q,
+                     "device_ms_per_8_calls_queued": ms / 10, "device_batches_per_8_calls": n / 10}
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

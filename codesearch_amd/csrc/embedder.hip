@@ -79,6 +79,12 @@ struct cs_embedder {
     Q8RowMeta* d_rmeta2 = nullptr; // [cap_tokens]: rows of the re-quantised FFN intermediate
     float* d_range_pairs = nullptr; // (lo, hi) per block / wave of the kernel that produced the tensor quantised next
     size_t cap_range_pairs = 0;
+    // several quantisation units (calls of the reference) in one device batch: per sequence its unit, per unit its own
+    // padded length, per row its range slot (gemm_q8.hpp); cur_units = units of the mini-batch being run (1: none of this)
+    uint32_t* d_seq_unit = nullptr;
+    uint32_t* d_unit_len = nullptr;
+    uint32_t* d_row_slot = nullptr;
+    uint32_t cur_units = 1;
     int gemm_mode = CS_GEMM_SPLIT_F16;
     bool split_unavailable = false;  // device flushes f16 subnormals in the MFMA: exact-f32 kernels only
     bool wide_ok = false;            // every |w| < 31.98: the one-accumulator 128 x 384 kernels may run (gemm_wide.hip)
@@ -141,8 +147,13 @@ void free_workspace(cs_embedder* h) {
     if (h->d_rmeta) (void)hipFree(h->d_rmeta);
     if (h->d_rmeta2) (void)hipFree(h->d_rmeta2);
     if (h->d_range_pairs) (void)hipFree(h->d_range_pairs);
+    if (h->d_seq_unit) (void)hipFree(h->d_seq_unit);
+    if (h->d_unit_len) (void)hipFree(h->d_unit_len);
+    if (h->d_row_slot) (void)hipFree(h->d_row_slot);
+    if (h->d_range) (void)hipFree(h->d_range);
     h->d_rmeta = h->d_rmeta2 = nullptr;
     h->d_range_pairs = nullptr;
+    h->d_seq_unit = h->d_unit_len = h->d_row_slot = h->d_range = nullptr;
     h->d_perm = nullptr;
     h->d_ids = h->d_mask = nullptr;
     h->d_x = h->d_xs = h->d_qkv = h->d_ctx = h->d_mid = h->d_pooled = nullptr;
@@ -168,6 +179,12 @@ int32_t reserve(cs_embedder* h, size_t seqs, size_t tokens) {
         // LayerNorm: a pair per four rows; attention: four per (head group, sequence, 128 queries)
         h->cap_range_pairs = std::max<size_t>(tokens / 4 + 1, (size_t)h->cfg.heads * 4 * (tokens / 128 + seqs));
         CS_HIP(hipMalloc(&h->d_range_pairs, h->cap_range_pairs * 2 * sizeof(float)));
+        CS_HIP(hipMalloc(&h->d_seq_unit, seqs * sizeof(uint32_t)));
+        CS_HIP(hipMalloc(&h->d_unit_len, seqs * sizeof(uint32_t)));
+        CS_HIP(hipMalloc(&h->d_row_slot, tokens * sizeof(uint32_t)));
+        // a range slot per (layer, quantised tensor, unit): at most one unit per sequence
+        h->q8_units = (uint32_t)seqs;
+        CS_HIP(hipMalloc(&h->d_range, (size_t)h->cfg.layers * 4 * Q8_RANGE_WORDS * h->q8_units * sizeof(uint32_t)));
     }
     h->cap_tokens = tokens;
     h->cap_seqs = seqs;
@@ -278,32 +295,45 @@ int32_t forward_range(cs_embedder* h, hipStream_t s, uint32_t b0, uint32_t nb, u
             const Q8Layer ql = q8_layer(H, I);
             const int8_t* wq = h->d_wq8 + (size_t)l * ql.total;
             const Q8ColMeta* cm = h->d_cmeta + (size_t)l * (5 * (size_t)H + I);
-            uint32_t* rg = h->d_range + (size_t)l * 4 * Q8_RANGE_WORDS * h->q8_units;
-            const size_t rstep = (size_t)Q8_RANGE_WORDS * h->q8_units;
+            const uint32_t U = h->cur_units;
+            uint32_t* rg = h->d_range + (size_t)l * 4 * Q8_RANGE_WORDS * U;
+            const size_t rstep = (size_t)Q8_RANGE_WORDS * U;
+            // several units in the batch: every row carries its unit's slot, ranges come from passes over the tensors
+            // (the producers' per-block ranges and the two-pass FFN-up assume one unit)
+            const uint32_t* rs = U > 1 ? h->d_row_slot : nullptr;
             int8_t* xq = reinterpret_cast<int8_t*>(h->d_xs + t0 * H);  // [T][<= 4H] bytes
             Q8RowMeta* rm = h->d_rmeta + t0;
             _Float16* qkvs = reinterpret_cast<_Float16*>(qkv);
             float* rp = h->d_range_pairs;
-            CS_TRY(launch_q8_quantize(Q8_SRC_F32, x, T, H, rg, nullptr, xq, rm, s, rp, ln_pairs));
+            if (rs && l == 0) CS_TRY(launch_q8_row_slots(h->d_seq_unit, h->d_unit_len, T, L, h->d_row_slot, s));
+            CS_TRY(launch_q8_quantize(Q8_SRC_F32, x, T, H, rg, rs, xq, rm, s, rp, ln_pairs));
             CS_TRY(launch_gemm_q8(SH_OUT_SPLIT, xq, rm, wq + ql.qkv, cm, bqkv, nullptr, nullptr, qkvs, T, 3 * H, H, h->d_flag, s));  // E2
             CS_TRY(mark(CS_STAGE_QKV));
             uint32_t att_pairs = 0;
             CS_TRY(launch_attention_sh2(qkvs, mask, ctxs, h->d_flag, nb, L, H, c.heads, s, rp, &att_pairs));  // E3
             if (att_pairs > h->cap_range_pairs) return fail(CS_ERR_HIP, "range pair buffer too small (%u > %zu)", att_pairs, h->cap_range_pairs);
             CS_TRY(mark(CS_STAGE_ATTENTION));
-            CS_TRY(launch_q8_quantize(Q8_SRC_SPLIT, ctxs, T, H, rg + rstep, nullptr, xq, rm, s, rp, att_pairs));
+            CS_TRY(launch_q8_quantize(Q8_SRC_SPLIT, ctxs, T, H, rg + rstep, rs, xq, rm, s, rp, att_pairs));
             CS_TRY(launch_gemm_q8(SH_OUT_F32_RESID, xq, rm, wq + ql.ao, cm + 3 * H, P + lo.ao_b, x, x, nullptr, T, H, H, h->d_flag, s));  // E4
             CS_TRY(mark(CS_STAGE_OUT_PROJ));
             a.g = P + lo.ao_ln_g; a.b = P + lo.ao_ln_b;
             CS_TRY(launch_row_kernel(1, a, H, s));
             CS_TRY(mark(CS_STAGE_LN_ATTN));
-            CS_TRY(launch_q8_quantize(Q8_SRC_F32, x, T, H, rg + 2 * rstep, nullptr, xq, rm, s, rp, ln_pairs));
+            CS_TRY(launch_q8_quantize(Q8_SRC_F32, x, T, H, rg + 2 * rstep, rs, xq, rm, s, rp, ln_pairs));
             // E5: GELU(x W1^T + b1) leaves already re-quantised for E6 (two passes over the int8 product instead of 1.2 GB of
             // f32-class hand-over at 65,536 rows: launch_gemm_q8_gelu_requant)
             int8_t* midq = reinterpret_cast<int8_t*>(mid);
             Q8RowMeta* rm2 = h->d_rmeta2 + t0;
-            CS_TRY(launch_gemm_q8_gelu_requant(xq, rm, wq + ql.up, cm + 4 * H, P + lo.up_b, T, I, H, rg + 3 * rstep, midq, rm2, s));
-            CS_TRY(mark(CS_STAGE_FFN_UP));
+            if (rs) {  // several units: GELU output in split form, then its own range + quantising passes (into the x_q buffer)
+                CS_TRY(launch_gemm_q8(SH_OUT_SPLIT_GELU, xq, rm, wq + ql.up, cm + 4 * H, P + lo.up_b, nullptr, nullptr, mids, T, I, H, h->d_flag, s));
+                CS_TRY(mark(CS_STAGE_FFN_UP));
+                CS_TRY(launch_q8_quantize(Q8_SRC_SPLIT, mids, T, I, rg + 3 * rstep, rs, xq, rm, s));
+                midq = xq;
+                rm2 = rm;
+            } else {
+                CS_TRY(launch_gemm_q8_gelu_requant(xq, rm, wq + ql.up, cm + 4 * H, P + lo.up_b, T, I, H, rg + 3 * rstep, midq, rm2, s));
+                CS_TRY(mark(CS_STAGE_FFN_UP));
+            }
             CS_TRY(launch_gemm_q8(SH_OUT_F32_RESID, midq, rm2, wq + ql.down, cm + 4 * H + I, P + lo.down_b, x, x, nullptr, T, H, I, h->d_flag, s));  // E6
             CS_TRY(mark(CS_STAGE_FFN_DOWN));
             a.g = P + lo.out_ln_g; a.b = P + lo.out_ln_b;
@@ -443,7 +473,7 @@ int32_t forward(cs_embedder* h, uint32_t B, uint32_t L, int mode) {
     CS_HIP(hipEventRecord(h->ev0, s));
     if (mode != CS_GEMM_F32) CS_HIP(hipMemsetAsync(h->d_flag, 0, sizeof(uint32_t), s));
     if (mode == CS_GEMM_Q8_DYNAMIC)  // every range starts from (+0, +0)
-        CS_HIP(hipMemsetAsync(h->d_range, 0, (size_t)h->cfg.layers * 4 * Q8_RANGE_WORDS * h->q8_units * sizeof(uint32_t), s));
+        CS_HIP(hipMemsetAsync(h->d_range, 0, (size_t)h->cfg.layers * 4 * Q8_RANGE_WORDS * h->cur_units * sizeof(uint32_t), s));
     // Slicing pays from ~20,000 tokens (device us per forward, one stream / two: 16,384 tokens 3505 / 3542,
     // 24,576 5267 / 4916, 32,768 6517 / 6275, 49,152 9568 / 9437); below that it only multiplies launches
     // of kernels that already leave the chip part-empty.
@@ -501,10 +531,19 @@ uint32_t default_batch(const cs_embedder* h) {
     return d <= 384 ? 256 : (d <= 768 ? 128 : 64);
 }
 
+// Several quantisation units in ONE mini-batch (dynamic-quantisation mode: calls of the reference embedded together, each
+// still quantised as the tensor it would have been on its own): the unit of every sequence, each unit's own padded length.
+struct UnitSpec {
+    const uint32_t* seq_unit = nullptr;  // [n]
+    const uint32_t* unit_len = nullptr;  // [units]
+    uint32_t units = 1;
+};
+
 // perm (optional, only with n <= batch): pooled row r of the mini-batch goes to out row perm[r].
+// units (optional, only with n <= batch and CS_GEMM_Q8_DYNAMIC): see UnitSpec.
 int32_t embed_impl(cs_embedder* h, const int32_t* ids, const int32_t* mask, uint64_t n,
                    uint32_t seq_len, uint32_t batch, float* out, bool out_on_device,
-                   const volatile int32_t* cancel, const uint32_t* perm = nullptr) {
+                   const volatile int32_t* cancel, const uint32_t* perm = nullptr, const UnitSpec* units = nullptr) {
     if (!h) return fail(CS_ERR_BAD_ARG, "null embedder handle");
     if (n == 0) return CS_OK;  // embedder.rs:271-273
     if (!ids || !mask || !out) return fail(CS_ERR_BAD_ARG, "null buffer");
@@ -530,6 +569,12 @@ int32_t embed_impl(cs_embedder* h, const int32_t* ids, const int32_t* mask, uint
         CS_HIP(hipMemcpyAsync(h->d_mask, mask + done * seq_len, tok * sizeof(int32_t),
                               hipMemcpyHostToDevice, h->stream));
         int mode = h->gemm_mode;
+        h->cur_units = 1;
+        if (units && units->units > 1 && mode == CS_GEMM_Q8_DYNAMIC && n <= batch) {
+            CS_HIP(hipMemcpyAsync(h->d_seq_unit, units->seq_unit, B * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
+            CS_HIP(hipMemcpyAsync(h->d_unit_len, units->unit_len, units->units * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
+            h->cur_units = units->units;
+        }
         CS_TRY(forward(h, B, seq_len, mode));
         if (mode == CS_GEMM_Q8_DYNAMIC) {
             uint32_t flag = 0;
@@ -796,16 +841,58 @@ int32_t flush_queue(cs_embedder* h, const volatile int32_t* cancel) {
         std::vector<uint32_t> order;
         std::vector<int32_t> ids, mask;
         if (h->gemm_mode == CS_GEMM_Q8_DYNAMIC) {
-            // a quantised model's activations are quantised per CALL tensor (embedder.rs:286-289 hands ORT one submission
-            // at a time): each entry runs as its own mini-batches, in its own order
+            // A quantised model's activations are quantised per CALL tensor (embedder.rs:286-289 hands ORT one submission
+            // at a time, fastembed cuts it into `batch` consecutive rows padded to their longest): those tensors stay the
+            // quantisation UNITS, but several of them share a device batch — each row carries its unit's range slot, and a
+            // unit's rows beyond its own padded length are kept out of its range (UnitSpec, gemm_q8.hpp).  A unit is
+            // never split over two device batches.
+            struct Unit { size_t first, rows; uint32_t len; };
+            std::vector<Unit> us;
             size_t lo = 0;
             for (auto& e : todo) {
                 const size_t n = e->ids.size();
-                for (size_t b0 = 0; b0 < n; b0 += window) {
-                    const std::vector<SeqView> win(seqs.begin() + lo + b0, seqs.begin() + lo + std::min(n, b0 + window));
-                    CS_TRY(run_window(h, win, batch, 0, fl->d_rows + (lo + b0) * H, true, cancel, order, ids, mask));
+                for (size_t b0 = 0; b0 < n; b0 += batch) {
+                    Unit u{lo + b0, std::min<size_t>(batch, n - b0), 1};
+                    for (size_t r = 0; r < u.rows; ++r) u.len = std::max(u.len, seqs[u.first + r].len);
+                    us.push_back(u);
                 }
                 lo += n;
+            }
+            const uint64_t budget = (uint64_t)batch * std::min<uint32_t>(256, h->cfg.max_position);  // as run_window's
+            std::vector<uint32_t> seq_unit, unit_len;
+            for (size_t u0 = 0; u0 < us.size();) {
+                if (cancel && *cancel) return fail(CS_ERR_CANCELLED, "Embedding interrupted by shutdown request");
+                size_t u1 = u0 + 1, rows = us[u0].rows;
+                uint32_t L = us[u0].len;
+                while (u1 < us.size() && us[u1].first == us[u1 - 1].first + us[u1 - 1].rows && rows + us[u1].rows <= batch &&
+                       (uint64_t)(rows + us[u1].rows) * std::max(L, us[u1].len) <= budget) {
+                    rows += us[u1].rows;
+                    L = std::max(L, us[u1].len);
+                    ++u1;
+                }
+                ids.assign(rows * L, 0);
+                mask.assign(rows * L, 0);
+                seq_unit.resize(rows);
+                unit_len.resize(u1 - u0);
+                size_t r = 0;
+                for (size_t u = u0; u < u1; ++u) {
+                    unit_len[u - u0] = us[u].len;
+                    for (size_t i = 0; i < us[u].rows; ++i, ++r) {
+                        const SeqView& v = seqs[us[u].first + i];
+                        std::copy(v.ids, v.ids + v.len, ids.begin() + r * L);
+                        if (v.mask) std::copy(v.mask, v.mask + v.len, mask.begin() + r * L);
+                        else std::fill(mask.begin() + r * L, mask.begin() + r * L + v.len, 1);
+                        seq_unit[r] = (uint32_t)(u - u0);
+                    }
+                }
+                {
+                    DeviceGuard g2(h->device);
+                    CS_TRY(reserve(h, std::max<size_t>(rows, h->cap_seqs), std::max<size_t>(rows * L, h->cap_tokens)));
+                }
+                UnitSpec spec{seq_unit.data(), unit_len.data(), (uint32_t)(u1 - u0)};
+                CS_TRY(embed_impl(h, ids.data(), mask.data(), rows, L, (uint32_t)rows, fl->d_rows + us[u0].first * H, true, nullptr,
+                                  nullptr, &spec));
+                u0 = u1;
             }
             return CS_OK;
         }
@@ -998,7 +1085,6 @@ static int32_t create_impl(const cs_bert_config* cfg, const float* params, uint6
         if (I > 4 * H || I > 4096) s = fail(CS_ERR_UNSUPPORTED, "Failed to initialize embedding model: intermediate size above 4 x hidden or 4,096");
         if (s == CS_OK && (hipMalloc(&h->d_wq8, (size_t)cfg->layers * ql.total) != hipSuccess ||
                            hipMalloc(&h->d_cmeta, (size_t)cfg->layers * cols * sizeof(Q8ColMeta)) != hipSuccess ||
-                           hipMalloc(&h->d_range, (size_t)cfg->layers * 4 * Q8_RANGE_WORDS * h->q8_units * sizeof(uint32_t)) != hipSuccess ||
                            hipMalloc(&d_ws, (size_t)cfg->layers * cols * sizeof(float)) != hipSuccess ||
                            hipMalloc(&d_bad, sizeof(uint32_t)) != hipSuccess))
             s = fail(CS_ERR_OOM, "hipMalloc(quantised weights) failed");
@@ -1074,7 +1160,6 @@ void cs_embedder_destroy(cs_embedder* h) {
     if (h->d_flag) (void)hipFree(h->d_flag);
     if (h->d_wq8) (void)hipFree(h->d_wq8);
     if (h->d_cmeta) (void)hipFree(h->d_cmeta);
-    if (h->d_range) (void)hipFree(h->d_range);
     for (hipEvent_t e : h->stage_ev) (void)hipEventDestroy(e);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);

@@ -74,79 +74,102 @@ q8_minmax_kernel(const void* __restrict__ src, uint32_t T, uint32_t K, uint32_t*
     constexpr int UN = Q8Unit<SRC>::N;
     const uint32_t upr = K / UN;  // units per row
     const uint64_t units = (uint64_t)T * upr;
-    if (!row_slot) {
-        // one unit (slot 0): four loads in flight per lane, the block's four waves meet in LDS, one update per block
-        __shared__ float s_lo[4], s_hi[4];
-        float lo = 0.0f, hi = 0.0f;
-        const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-        uint64_t u = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-        for (; u + 3 * stride < units; u += 4 * stride) {
-            Q8Unit<SRC> x[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) x[i].load(src, u + i * stride);
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int e = 0; e < UN; ++e) { lo = fminf(lo, x[i].v[e]); hi = fmaxf(hi, x[i].v[e]); }
-        }
-        for (; u < units; u += stride) {
-            Q8Unit<SRC> x;
-            x.load(src, u);
-#pragma unroll
-            for (int e = 0; e < UN; ++e) { lo = fminf(lo, x.v[e]); hi = fmaxf(hi, x.v[e]); }
-        }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            lo = fminf(lo, __shfl_xor(lo, o));
-            hi = fmaxf(hi, __shfl_xor(hi, o));
-        }
-        if ((threadIdx.x & 63) == 0) { s_lo[threadIdx.x >> 6] = lo; s_hi[threadIdx.x >> 6] = hi; }
-        __syncthreads();
-        if (threadIdx.x == 0)
-            q8_range_update(range, fminf(fminf(s_lo[0], s_lo[1]), fminf(s_lo[2], s_lo[3])),
-                            fmaxf(fmaxf(s_hi[0], s_hi[1]), fmaxf(s_hi[2], s_hi[3])));
-        return;
-    }
-    constexpr uint32_t NONE = 0xffffffffu;
+    // one unit (slot 0): four loads in flight per lane, the block's four waves meet in LDS, one update per block
+    __shared__ float s_lo[4], s_hi[4];
     float lo = 0.0f, hi = 0.0f;
-    uint32_t mine = NONE;   // unit of the values this lane holds in lo / hi
-    bool single = true;     // ... and whether the lane has only ever seen that one
-    for (uint64_t u = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; u < units; u += (uint64_t)gridDim.x * blockDim.x) {
-        uint32_t slot = 0;
-        if (row_slot) {
-            slot = row_slot[u / upr];
-            if (slot >> 31) continue;  // the row is not part of the tensor the reference quantises
-        }
-        if (slot != mine) {
-            if (mine != NONE) {  // a new unit: flush what this lane holds
-                q8_range_update(range + Q8_RANGE_WORDS * (size_t)mine, lo, hi);
-                lo = hi = 0.0f;
-                single = false;
-            }
-            mine = slot;
-        }
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    uint64_t u = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; u + 3 * stride < units; u += 4 * stride) {
+        Q8Unit<SRC> x[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) x[i].load(src, u + i * stride);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int e = 0; e < UN; ++e) { lo = fminf(lo, x[i].v[e]); hi = fmaxf(hi, x[i].v[e]); }
+    }
+    for (; u < units; u += stride) {
         Q8Unit<SRC> x;
         x.load(src, u);
 #pragma unroll
         for (int e = 0; e < UN; ++e) { lo = fminf(lo, x.v[e]); hi = fmaxf(hi, x.v[e]); }
     }
-    // one unit for the whole wave (the common case): reduce across lanes first, two atomics per wave.  Lanes without
-    // work hold (0, 0), which every range contains.
-    const bool has = mine != NONE;
-    const uint64_t work = __ballot(has);
-    if (work == 0) return;
-    const int leader = __ffsll((unsigned long long)work) - 1;
-    const uint32_t lead = __shfl(mine, leader);
-    if (__all(!has || (single && mine == lead))) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        lo = fminf(lo, __shfl_xor(lo, o));
+        hi = fmaxf(hi, __shfl_xor(hi, o));
+    }
+    if ((threadIdx.x & 63) == 0) { s_lo[threadIdx.x >> 6] = lo; s_hi[threadIdx.x >> 6] = hi; }
+    __syncthreads();
+    if (threadIdx.x == 0)
+        q8_range_update(range, fminf(fminf(s_lo[0], s_lo[1]), fminf(s_lo[2], s_lo[3])),
+                        fmaxf(fmaxf(s_hi[0], s_hi[1]), fmaxf(s_hi[2], s_hi[3])));
+}
+
+// Several units in the tensor (row_slot): a block owns 32 consecutive rows, a wave eight of them one after the other —
+// rows of one unit are contiguous, so a wave folds its rows into one (slot, lo, hi) and the block's four into mostly one
+// update.  (A grid-stride walk as above would hand every lane rows of every unit: millions of range updates, 50 ms.)
+template <int SRC>
+__global__ void __launch_bounds__(256)
+q8_minmax_units_kernel(const void* __restrict__ src, uint32_t T, uint32_t K, uint32_t* __restrict__ range,
+                       const uint32_t* __restrict__ row_slot) {
+    constexpr int UN = Q8Unit<SRC>::N;
+    constexpr uint32_t NONE = 0xffffffffu;
+    __shared__ uint32_t s_slot[4];
+    __shared__ float s_lo[4], s_hi[4];
+    const uint32_t upr = K / UN;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t cur = NONE;
+    float lo = 0.0f, hi = 0.0f;
+    for (int i = 0; i < 8; ++i) {
+        const uint32_t row = blockIdx.x * 32 + wave * 8 + i;
+        if (row >= T) break;
+        const uint32_t slot = row_slot[row];
+        if (slot >> 31) continue;  // outside its call's own padded length: not part of the tensor the reference quantises
+        float rlo = 0.0f, rhi = 0.0f;
+        for (uint32_t uu = lane; uu < upr; uu += 64) {
+            Q8Unit<SRC> x;
+            x.load(src, (uint64_t)row * upr + uu);
+#pragma unroll
+            for (int e = 0; e < UN; ++e) { rlo = fminf(rlo, x.v[e]); rhi = fmaxf(rhi, x.v[e]); }
+        }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
-            lo = fminf(lo, __shfl_xor(lo, o));
-            hi = fmaxf(hi, __shfl_xor(hi, o));
+            rlo = fminf(rlo, __shfl_xor(rlo, o));
+            rhi = fmaxf(rhi, __shfl_xor(rhi, o));
         }
-        if ((int)(threadIdx.x & 63) == leader) q8_range_update(range + Q8_RANGE_WORDS * (size_t)lead, lo, hi);
-    } else if (has) {
-        q8_range_update(range + Q8_RANGE_WORDS * (size_t)mine, lo, hi);
+        if (slot != cur) {
+            if (cur != NONE && lane == 0) q8_range_update(range + Q8_RANGE_WORDS * (size_t)cur, lo, hi);
+            cur = slot;
+            lo = rlo;
+            hi = rhi;
+        } else {
+            lo = fminf(lo, rlo);
+            hi = fmaxf(hi, rhi);
+        }
     }
+    if (lane == 0) { s_slot[wave] = cur; s_lo[wave] = lo; s_hi[wave] = hi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 0; w < 4; ++w) {
+            if (s_slot[w] == NONE) continue;
+            float l = s_lo[w], h = s_hi[w];
+            for (int v = w + 1; v < 4; ++v)
+                if (s_slot[v] == s_slot[w]) { l = fminf(l, s_lo[v]); h = fmaxf(h, s_hi[v]); s_slot[v] = NONE; }
+            q8_range_update(range + Q8_RANGE_WORDS * (size_t)s_slot[w], l, h);
+        }
+    }
+}
+
+// Quantisation units inside one device batch (several calls of the reference embedded together): row (b, t) belongs to
+// unit seq_unit[b]; positions t >= unit_len[unit] lie outside that call's own padded length (bit 31: quantised, never ranged).
+__global__ void __launch_bounds__(256)
+q8_row_slot_kernel(const uint32_t* __restrict__ seq_unit, const uint32_t* __restrict__ unit_len, uint32_t T, uint32_t L,
+                   uint32_t* __restrict__ row_slot) {
+    const uint32_t r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= T) return;
+    const uint32_t u = seq_unit[r / L];
+    row_slot[r] = u | ((r % L) >= unit_len[u] ? 0x80000000u : 0u);
 }
 
 // The producers of a tensor (LayerNorm, attention) leave one (lo, hi) per block or wave: their reduction is the range pass.
@@ -835,6 +858,14 @@ int32_t launch_q8_pack_weight(const float* d_W, const float* d_scale, const floa
     return CS_OK;
 }
 
+int32_t launch_q8_row_slots(const uint32_t* d_seq_unit, const uint32_t* d_unit_len, uint32_t T, uint32_t L, uint32_t* d_row_slot,
+                            hipStream_t s) {
+    if (T == 0 || L == 0) return CS_OK;
+    hipLaunchKernelGGL(q8_row_slot_kernel, dim3((T + 255) / 256), dim3(256), 0, s, d_seq_unit, d_unit_len, T, L, d_row_slot);
+    CS_HIP(hipGetLastError());
+    return CS_OK;
+}
+
 int32_t launch_q8_quantize(int src_kind, const void* d_src, uint32_t T, uint32_t K, uint32_t* d_range, const uint32_t* d_row_slot,
                            int8_t* d_xq, Q8RowMeta* d_rmeta, hipStream_t s, const float* d_range_pairs, uint32_t n_pairs) {
     if (K % 32) return fail(CS_ERR_UNSUPPORTED, "dynamic quantisation needs K %% 32 == 0 (K = %u)", K);
@@ -846,10 +877,12 @@ int32_t launch_q8_quantize(int src_kind, const void* d_src, uint32_t T, uint32_t
     const bool reduced = d_range_pairs && n_pairs && !d_row_slot;  // the tensor's producer already left per-block ranges
     if (reduced) hipLaunchKernelGGL(q8_range_reduce_kernel, dim3(1), dim3(1024), 0, s, d_range_pairs, n_pairs, d_range);
     if (src_kind == Q8_SRC_F32) {
-        if (!reduced) hipLaunchKernelGGL(q8_minmax_kernel<Q8_SRC_F32>, grid_mm, dim3(256), 0, s, d_src, T, K, d_range, d_row_slot);
+        if (!reduced && d_row_slot) hipLaunchKernelGGL(q8_minmax_units_kernel<Q8_SRC_F32>, dim3((T + 31) / 32), dim3(256), 0, s, d_src, T, K, d_range, d_row_slot);
+        else if (!reduced) hipLaunchKernelGGL(q8_minmax_kernel<Q8_SRC_F32>, grid_mm, dim3(256), 0, s, d_src, T, K, d_range, d_row_slot);
         hipLaunchKernelGGL(q8_quantize_kernel<Q8_SRC_F32>, grid_q, dim3(256), 0, s, d_src, T, K, d_range, d_row_slot, d_xq, d_rmeta);
     } else {
-        if (!reduced) hipLaunchKernelGGL(q8_minmax_kernel<Q8_SRC_SPLIT>, grid_mm, dim3(256), 0, s, d_src, T, K, d_range, d_row_slot);
+        if (!reduced && d_row_slot) hipLaunchKernelGGL(q8_minmax_units_kernel<Q8_SRC_SPLIT>, dim3((T + 31) / 32), dim3(256), 0, s, d_src, T, K, d_range, d_row_slot);
+        else if (!reduced) hipLaunchKernelGGL(q8_minmax_kernel<Q8_SRC_SPLIT>, grid_mm, dim3(256), 0, s, d_src, T, K, d_range, d_row_slot);
         hipLaunchKernelGGL(q8_quantize_kernel<Q8_SRC_SPLIT>, grid_q, dim3(256), 0, s, d_src, T, K, d_range, d_row_slot, d_xq, d_rmeta);
     }
     CS_HIP(hipGetLastError());

@@ -34,6 +34,11 @@ inline Q8Layer q8_layer(uint32_t H, uint32_t I) {
 int32_t launch_q8_pack_weight(const float* d_W, const float* d_scale, const float* d_bias, uint32_t N, uint32_t K, int8_t* d_wq,
                               Q8ColMeta* d_cmeta, uint32_t* d_bad, hipStream_t s);
 
+// d_row_slot [T] for a device batch of sequences of L positions each that holds several quantisation units (calls):
+// d_seq_unit [T / L] = the unit of each sequence, d_unit_len [units] = each unit's own padded length.
+int32_t launch_q8_row_slots(const uint32_t* d_seq_unit, const uint32_t* d_unit_len, uint32_t T, uint32_t L, uint32_t* d_row_slot,
+                            hipStream_t s);
+
 // DynamicQuantizeLinear of [T][K] activations (f32 rows, or split-f16 lines [T][K/32][64]):
 //   d_range [slots][Q8_RANGE_WORDS] u32: running (lo, hi) of each quantisation unit, all zero before the first call of a forward slot
 //   d_row_slot (may be null: one unit, slot 0): per row, the unit it belongs to; bit 31 set = the row lies outside its unit's

@@ -553,7 +553,10 @@ int32_t cs_embedders_index_ids(cs_embedders* e, cs_shards* store, const int32_t*
  * included) -> MatMulInteger -> * (x_scale * W_scale) -> + bias — with the integer product on the int8 MFMA (exact).  What
  * "one call tensor" is: the sequences of ONE embed call's mini-batch (`batch` rows in the caller's order, padded to the
  * longest of them, as fastembed hands them to ORT); length grouping, token-budget batches, stream slices and the CLS tail
- * are off in this mode because each would change that tensor.  Attention, LayerNorm, GELU and pooling stay f32-class. */
+ * are off in this mode because each would change that tensor.  The submission queue (cs_embedder_submit_*) still embeds
+ * several submissions in one device batch: each stays its own quantisation unit there (its own range per tensor, its rows
+ * beyond its own padded length kept out of it), so a ticket's rows are what the call alone would have produced.
+ * Attention, LayerNorm, GELU and pooling stay f32-class. */
 typedef enum cs_gemm_mode { CS_GEMM_F32 = 0, CS_GEMM_SPLIT_F16 = 1, CS_GEMM_Q8_DYNAMIC = 2 } cs_gemm_mode;
 int32_t cs_embedder_set_gemm_mode(cs_embedder* h, int32_t mode);
 /* The mode in force (a cs_gemm_mode; -1 for a null handle): CS_GEMM_Q8_DYNAMIC for a quantised model unless switched off. */

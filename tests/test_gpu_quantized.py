@@ -331,3 +331,45 @@ def test_texts_and_queued_submissions_are_quantised_per_reference_call(gpu_lib, 
         e = np.abs(emb.wait(t) - per_call([s]))
         assert e.max() < 3e-3 and e.mean() < 1e-4
     emb.close()
+
+
+def test_queued_submissions_share_a_device_batch_and_keep_their_own_ranges(gpu_lib, oracle):
+    """Several submissions embedded as ONE forward: every row carries its own call's quantisation range (and a call's
+    rows beyond its own padded length stay out of that range), so each submission's embeddings are those of the call
+    run alone — the throughput of the large batch without changing what a quantised model computes."""
+    from codesearch_amd import FastEmbedder, ModelType
+
+    cfg = small_cfg(POOL_MEAN)
+    params, wscale = quantize_linear_weights(cfg, synth_params(cfg, 31), per_channel=False, unsigned=True)
+    emb = FastEmbedder(ModelType.AllMiniLML6V2Q, config=cfg, params=params, wscale=wscale)
+    rng = np.random.default_rng(3)
+    subs = []
+    for n, L in ((5, 40), (1, 12), (9, 64), (3, 25), (7, 33)):   # different sizes, different longest rows
+        ids, mask = synth_token_batch(cfg, int(rng.integers(1, 1000)), n, L, True)
+        ids[0, -1], mask[0, -1] = 102, 1                         # one full-length row: L is the call's padded length
+        subs.append((ids, mask))
+    emb.profile_read(reset=True)
+    tickets = [emb.submit_ids(i, m) for i, m in subs]
+    got = [emb.wait(t) for t in tickets]
+    _, forwards = emb.profile_read()
+    assert forwards == 1, forwards                               # 25 rows, five units, one device batch
+    alone = []
+    for (ids, mask), g in zip(subs, got):
+        want = oracle.bert_forward(cfg, params, ids, mask, wscale=wscale)["pooled"]
+        e = np.abs(g - want)
+        assert e.max() < 3e-3 and e.mean() < 1.5e-4, (e.max(), e.mean())
+        alone.append(emb.embed_ids(ids, mask))                   # the same call on its own: one unit, other kernels
+    # sharing the batch is not what moves an embedding: against the call run alone the distance is the same flip noise,
+    # and embedding one call's rows with ANOTHER call's range would be far outside it
+    for g, a in zip(got, alone):
+        assert np.abs(g - a).max() < 3e-3 and np.abs(g - a).mean() < 1.5e-4
+    ids_all = np.zeros((25, 64), np.int32)
+    mask_all = np.zeros((25, 64), np.int32)
+    r = 0
+    for ids, mask in subs:
+        ids_all[r:r + len(ids), :ids.shape[1]] = ids
+        mask_all[r:r + len(ids), :ids.shape[1]] = mask
+        r += len(ids)
+    one_tensor = emb.embed_ids(ids_all, mask_all)                # what ignoring the units would compute
+    assert np.abs(one_tensor - np.concatenate(got)).mean() > 3 * np.abs(np.concatenate(got) - np.concatenate(alone)).mean()
+    emb.close()
