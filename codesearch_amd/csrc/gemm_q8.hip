@@ -69,8 +69,7 @@ struct Q8Unit {
 
 template <int SRC>
 __global__ void __launch_bounds__(256)
-q8_minmax_kernel(const void* __restrict__ src, uint32_t T, uint32_t K, uint32_t* __restrict__ range,
-                 const uint32_t* __restrict__ row_slot) {
+q8_minmax_kernel(const void* __restrict__ src, uint32_t T, uint32_t K, uint32_t* __restrict__ range) {
     constexpr int UN = Q8Unit<SRC>::N;
     const uint32_t upr = K / UN;  // units per row
     const uint64_t units = (uint64_t)T * upr;
@@ -624,7 +623,7 @@ __device__ __forceinline__ void q8_rows_store(const float* ctile, const float* r
 template <int EPI>
 __global__ void __launch_bounds__(QR_THREADS, 2)
 gemm_q8_rows_kernel(const int8_t* __restrict__ A, const int8_t* __restrict__ W, const Q8RowMeta* __restrict__ rmeta,
-                    const Q8ColMeta* __restrict__ cmeta, const float* __restrict__ bias, const float* resid, float* C,
+                    const Q8ColMeta* __restrict__ cmeta, const float* resid, float* C,
                     _Float16* __restrict__ Cs, uint32_t M, uint32_t N, uint32_t* __restrict__ flag, Q8Requant rq,
                     uint32_t parts, uint32_t total_units) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -878,11 +877,11 @@ int32_t launch_q8_quantize(int src_kind, const void* d_src, uint32_t T, uint32_t
     if (reduced) hipLaunchKernelGGL(q8_range_reduce_kernel, dim3(1), dim3(1024), 0, s, d_range_pairs, n_pairs, d_range);
     if (src_kind == Q8_SRC_F32) {
         if (!reduced && d_row_slot) hipLaunchKernelGGL(q8_minmax_units_kernel<Q8_SRC_F32>, dim3((T + 31) / 32), dim3(256), 0, s, d_src, T, K, d_range, d_row_slot);
-        else if (!reduced) hipLaunchKernelGGL(q8_minmax_kernel<Q8_SRC_F32>, grid_mm, dim3(256), 0, s, d_src, T, K, d_range, d_row_slot);
+        else if (!reduced) hipLaunchKernelGGL(q8_minmax_kernel<Q8_SRC_F32>, grid_mm, dim3(256), 0, s, d_src, T, K, d_range);
         hipLaunchKernelGGL(q8_quantize_kernel<Q8_SRC_F32>, grid_q, dim3(256), 0, s, d_src, T, K, d_range, d_row_slot, d_xq, d_rmeta);
     } else {
         if (!reduced && d_row_slot) hipLaunchKernelGGL(q8_minmax_units_kernel<Q8_SRC_SPLIT>, dim3((T + 31) / 32), dim3(256), 0, s, d_src, T, K, d_range, d_row_slot);
-        else if (!reduced) hipLaunchKernelGGL(q8_minmax_kernel<Q8_SRC_SPLIT>, grid_mm, dim3(256), 0, s, d_src, T, K, d_range, d_row_slot);
+        else if (!reduced) hipLaunchKernelGGL(q8_minmax_kernel<Q8_SRC_SPLIT>, grid_mm, dim3(256), 0, s, d_src, T, K, d_range);
         hipLaunchKernelGGL(q8_quantize_kernel<Q8_SRC_SPLIT>, grid_q, dim3(256), 0, s, d_src, T, K, d_range, d_row_slot, d_xq, d_rmeta);
     }
     CS_HIP(hipGetLastError());
@@ -932,8 +931,9 @@ static int32_t launch_rows(const int8_t* d_xq, const Q8RowMeta* d_rmeta, const i
     uint32_t parts = mtiles >= cus ? 1u : (cus + mtiles - 1) / mtiles;
     if (parts > ntiles) parts = ntiles;
     const uint32_t units = mtiles * parts;
+    (void)bias;  // the row-block kernel takes the bias from the column metadata (folded in at create time)
     hipLaunchKernelGGL(gemm_q8_rows_kernel<EPI>, dim3(units < cus ? units : cus), dim3(QR_THREADS), QR_LDS, s, d_xq, d_wq, d_rmeta,
-                       d_cmeta, bias, resid, C, Cs, M, N, d_flag, rq, parts, units);
+                       d_cmeta, resid, C, Cs, M, N, d_flag, rq, parts, units);
     CS_HIP(hipGetLastError());
     return CS_OK;
 }

@@ -379,8 +379,10 @@ class FastEmbedder {
     void discard(uint64_t ticket) { check(cs_embedder_discard(h_, ticket)); }
     size_t dimensions() const { return cs_embedder_dim(h_); }  // embedder.rs:307
     cs_embedder* handle() const { return h_; }
-    // CS_GEMM_SPLIT_F16 (default) or CS_GEMM_F32 (exact-f32 MFMA), include/codesearch_gpu.h
+    // CS_GEMM_SPLIT_F16 (default), CS_GEMM_F32 (exact-f32 MFMA) or, for a dynamically quantised model (a *Q registry
+    // entry's directory: what it comes up in), CS_GEMM_Q8_DYNAMIC — include/codesearch_gpu.h
     void set_gemm_mode(cs_gemm_mode mode) { check(cs_embedder_set_gemm_mode(h_, (int32_t)mode)); }
+    cs_gemm_mode gemm_mode() const { return (cs_gemm_mode)cs_embedder_gemm_mode(h_); }
 
   private:
     cs_embedder* h_ = nullptr;

@@ -107,6 +107,12 @@ static void linear_q8(const float* x, const float* w, const float* wscale, const
     free(xq);
 }
 
+/* One dynamically quantised Linear on its own (tests pin it against a numpy statement of the ONNX operators). */
+void cs_oracle_linear_q8(const float* x, const float* w, const float* wscale, const float* b, float* y, uint64_t T,
+                         uint64_t K, uint64_t N) {
+    linear_q8(x, w, wscale, b, y, (size_t)T, (size_t)K, (size_t)N);
+}
+
 static void layer_norm_rows(float* x, const float* g, const float* b, size_t T, size_t H, float eps) {
 #ifdef _OPENMP
 #pragma omp parallel for schedule(static)

@@ -83,6 +83,9 @@ void cs_oracle_bert_forward(const struct cs_bert_config* cfg, const float* param
 void cs_oracle_bert_forward_q8(const struct cs_bert_config* cfg, const float* params, const float* wscale,
                                const int32_t* ids, const int32_t* mask, uint32_t B, uint32_t L,
                                float* hidden_out, float* pooled_out, float* layer_hidden_out);
+/* y[T,N] = one such Linear: x [T,K] f32, w [N,K] the dequantised weight, wscale [N], b [N]. */
+void cs_oracle_linear_q8(const float* x, const float* w, const float* wscale, const float* b, float* y, uint64_t T,
+                         uint64_t K, uint64_t N);
 /* Flat parameter block from the synthetic rule of include/cs_bert_params.h. */
 void cs_oracle_bert_synth_params(const struct cs_bert_config* cfg, uint64_t seed, float* out);
 uint64_t cs_oracle_bert_param_count(const struct cs_bert_config* cfg);

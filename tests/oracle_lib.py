@@ -50,6 +50,8 @@ class Oracle:
         lib.cs_oracle_bert_synth_params.restype = None
         lib.cs_oracle_bert_forward_q8.restype = None
         lib.cs_oracle_bert_forward_q8.argtypes = [C.c_void_p, c_f32p, c_f32p, c_i32p, c_i32p, C.c_uint32, C.c_uint32, c_f32p, c_f32p, c_f32p]
+        lib.cs_oracle_linear_q8.restype = None
+        lib.cs_oracle_linear_q8.argtypes = [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_uint64, C.c_uint64, C.c_uint64]
         lib.cs_oracle_bert_synth_params.argtypes = [C.c_void_p, C.c_uint64, c_f32p]
         lib.cs_oracle_bert_param_count.restype = C.c_uint64
         lib.cs_oracle_bert_param_count.argtypes = [C.c_void_p]
@@ -137,6 +139,17 @@ class Oracle:
             self.lib.cs_oracle_bert_forward(C.byref(c), _ptr(params, c_f32p), _ptr(ids, c_i32p), _ptr(mask, c_i32p),
                                             B, L, _ptr(hidden, c_f32p), _ptr(pooled, c_f32p), _ptr(layers, c_f32p))
         return {"pooled": pooled, "hidden": hidden, "layers": layers}
+
+    def linear_q8(self, x, w, wscale, b):
+        """One dynamically quantised Linear (cs_oracle_linear_q8): x [T,K], w [N,K] dequantised, wscale [N], b [N] -> [T,N]."""
+        x = np.ascontiguousarray(x, np.float32)
+        w = np.ascontiguousarray(w, np.float32)
+        wscale = np.ascontiguousarray(wscale, np.float32)
+        b = np.ascontiguousarray(b, np.float32)
+        y = np.empty((x.shape[0], w.shape[0]), np.float32)
+        self.lib.cs_oracle_linear_q8(_ptr(x, c_f32p), _ptr(w, c_f32p), _ptr(wscale, c_f32p), _ptr(b, c_f32p), _ptr(y, c_f32p),
+                                     x.shape[0], x.shape[1], w.shape[0])
+        return y
 
     # ---- synthetic data --------------------------------------------------------
     def synth_rows(self, seed, first_row, n, dim):

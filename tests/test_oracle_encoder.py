@@ -190,3 +190,62 @@ def test_c_abi_checkpoint_loaders(tmp_path, gpu_lib):
     (bad / "model.safetensors").write_bytes(b"\x10\x00\x00\x00\x00\x00\x00\x00not json at all!")
     (bad / "config.json").write_text(json.dumps(hf))
     expect(lambda: load(bad), _lib.CS_ERR_BAD_ARG, "malformed header")
+
+
+# ---- dynamically quantised Linears (the registry's *Q models; oracle: linear_q8 / cs_oracle_bert_forward_q8) ----------
+
+def _onnx_dynamic_quantize(x):
+    """ONNX DynamicQuantizeLinear (opset 11) in float32, restated independently of the oracle."""
+    x = np.asarray(x, np.float32)
+    lo, hi = np.minimum(np.float32(0), x.min()), np.maximum(np.float32(0), x.max())
+    scale = np.float32(1) if hi == lo else np.float32((hi - lo) / np.float32(255))
+    zp = np.float32(np.rint(np.clip(np.float32(0) - np.float32(lo / scale), 0, 255)))
+    return np.clip(np.rint((x / scale).astype(np.float32)) + zp, 0, 255).astype(np.int64), scale, int(zp)
+
+
+@pytest.mark.parametrize("per_channel,unsigned", [(False, True), (True, False), (True, True), (False, False)])
+def test_quantised_linear_is_the_onnx_operator_chain(oracle, per_channel, unsigned):
+    """DynamicQuantizeLinear -> MatMulInteger -> Cast -> Mul(x_scale * W_scale) -> Add(bias), bit for bit: the integer
+    product is exact and the float stage is three roundings in a fixed order, so a numpy statement of the published operator
+    definitions must reproduce the oracle's output exactly (onnxruntime itself is not installed here: parity unpinned)."""
+    from codesearch_amd.bert_params import quantize_linear_weights
+
+    rng = np.random.default_rng(11 + per_channel + 2 * unsigned)
+    T, K, N = 37, 96, 40
+    cfg = BertConfig(vocab_size=8, hidden=K, layers=1, heads=2, intermediate=N, max_position=4)
+    # quantise a random [N, K] matrix the way the library's helper does it for every Linear (via a one-layer block)
+    flat = synth_params(cfg, 3)
+    sd = to_state_dict(cfg, flat)
+    sd["encoder.layer.0.intermediate.dense.weight"][:] = (rng.standard_normal((N, K)) * 0.07).astype(np.float32)
+    qflat, wscale = quantize_linear_weights(cfg, from_state_dict(cfg, sd), per_channel=per_channel, unsigned=unsigned)
+    W = to_state_dict(cfg, qflat)["encoder.layer.0.intermediate.dense.weight"]
+    sc = wscale[0, 4 * K:4 * K + N]
+    d = np.rint(W / sc[:, None]).astype(np.int64)                      # W_q - W_zp
+    assert np.abs(W / sc[:, None] - d).max() < 1e-3 and (d.max(axis=1) - d.min(axis=1)).max() <= 255
+    x = (rng.standard_normal((T, K)) * rng.choice([0.2, 1.0, 3.0], size=(T, 1))).astype(np.float32)
+    x[3, 5] = -7.25
+    b = (rng.standard_normal(N) * 0.1).astype(np.float32)
+    got = oracle.linear_q8(x, W, sc, b)
+    q, xs, xz = _onnx_dynamic_quantize(x)
+    acc = (q - xz) @ d.T
+    want = ((acc.astype(np.float32) * (xs * sc)[None, :].astype(np.float32)).astype(np.float32) + b[None, :]).astype(np.float32)
+    assert np.array_equal(got, want)
+    # degenerate tensor: all zeros -> scale 1, zero point 0, output = bias
+    assert np.array_equal(oracle.linear_q8(np.zeros((2, K), np.float32), W, sc, b), np.tile(b, (2, 1)))
+
+
+def test_quantised_forward_differs_from_the_f32_graph_and_is_call_dependent(oracle):
+    """The quantised forward is a different function from the f32 graph of the same weights, and — DynamicQuantizeLinear
+    ranging over the whole call — a sequence's embedding depends on what it was batched with."""
+    from codesearch_amd.bert_params import quant_columns, quantize_linear_weights
+
+    cfg = BertConfig(vocab_size=300, hidden=64, layers=2, heads=2, intermediate=128, max_position=32, pooling=POOL_MEAN)
+    params, wscale = quantize_linear_weights(cfg, synth_params(cfg, 5), per_channel=False, unsigned=True)
+    assert wscale.shape == (2, quant_columns(cfg)) and (wscale > 0).all()
+    ids, mask = synth_token_batch(cfg, 9, 6, 24, True)
+    q = oracle.bert_forward(cfg, params, ids, mask, wscale=wscale)["pooled"]
+    f = oracle.bert_forward(cfg, params, ids, mask)["pooled"]
+    assert 1e-5 < np.abs(q - f).max() < 5e-2
+    np.testing.assert_allclose(np.linalg.norm(q, axis=1), 1.0, atol=1e-5)
+    alone = oracle.bert_forward(cfg, params, ids[:3], mask[:3], wscale=wscale)["pooled"]
+    assert np.abs(alone - q[:3]).max() > 1e-6
