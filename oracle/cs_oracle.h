@@ -24,6 +24,9 @@
  *   encoder    : PARITY UNPINNED against the reference (it holds no embedding vectors,
  *                SURVEY.md §4); pinned instead against HF transformers BertModel run in
  *                the build container (tests/golden/make_encoder_golden.py).
+ *   quantised encoder (cs_oracle_bert_forward_q8): PARITY UNPINNED against onnxruntime (not installed here); its Linear is
+ *                pinned bit for bit to a numpy statement of ONNX DynamicQuantizeLinear / MatMulInteger
+ *                (tests/test_oracle_encoder.py).
  */
 #ifndef CS_ORACLE_H
 #define CS_ORACLE_H
