@@ -373,3 +373,33 @@ def test_queued_submissions_share_a_device_batch_and_keep_their_own_ranges(gpu_l
     one_tensor = emb.embed_ids(ids_all, mask_all)                # what ignoring the units would compute
     assert np.abs(one_tensor - np.concatenate(got)).mean() > 3 * np.abs(np.concatenate(got) - np.concatenate(alone)).mean()
     emb.close()
+
+
+def test_random_shapes_and_unit_mixes_stay_within_the_flip_noise(gpu_lib, oracle):
+    """Shapes the fixed cases do not visit: one-token rows, a single row, batches around the kernels' tile and row-block
+    thresholds, queued units of very different lengths (so most of a unit's rows lie beyond its own padded length)."""
+    from codesearch_amd import FastEmbedder, ModelType
+
+    cfg = BertConfig(vocab_size=900, hidden=384, layers=2, heads=12, intermediate=1536, max_position=160, pooling=POOL_MEAN)
+    params, wscale = quantize_linear_weights(cfg, synth_params(cfg, 77), per_channel=True, unsigned=True)
+    emb = FastEmbedder(ModelType.AllMiniLML6V2Q, config=cfg, params=params, wscale=wscale)
+    rng = np.random.default_rng(12)
+
+    def batch(n, L):
+        ids, mask = synth_token_batch(cfg, int(rng.integers(1, 10_000)), n, L, L > 2)
+        return ids, mask
+
+    def check(got, ids, mask, what):
+        want = oracle.bert_forward(cfg, params, ids, mask, wscale=wscale)["pooled"]
+        e = np.abs(got - want)
+        assert np.isfinite(got).all() and e.max() < 4e-3 and e.mean() < 2.5e-4, (what, e.max(), e.mean())
+
+    for n, L in ((1, 1), (1, 7), (3, 2), (2, 129), (33, 128), (40, 103), (64, 65)):   # 4,224 / 4,120 / 4,160 rows: row-block kernel
+        ids, mask = batch(n, L)
+        check(emb.embed_ids(ids, mask, batch_size=n), ids, mask, (n, L))
+    for _ in range(3):
+        subs = [batch(int(rng.integers(1, 12)), int(rng.choice([1, 3, 17, 64, 150]))) for _ in range(int(rng.integers(2, 7)))]
+        tickets = [emb.submit_ids(i, m) for i, m in subs]
+        for (ids, mask), t in zip(subs, tickets):
+            check(emb.wait(t), ids, mask, ("queued", ids.shape))
+    emb.close()
