@@ -18,8 +18,9 @@
 // weight into a constant, so `encoder.layer.N.….dense.weight` [out, in] arrives as an anonymous
 // initializer (`onnx::MatMul_1234`) of shape [in, out].  Those are found through the graph: the Add that
 // consumes the layer's bias, the MatMul feeding that Add, the MatMul's second input.  Gemm nodes (weight as
-// input 1, transB) and the fused com.microsoft Attention node of ORT-optimised files (packed [H, 3H] QKV
-// weight as input 1, packed [3H] bias as input 2) are understood as well.
+// input 1, transB) and what onnxruntime's transformer optimiser leaves (model_optimized.onnx) are understood as well: the
+// fused com.microsoft Attention / QAttention node (packed [H, 3H] QKV weight as input 1, packed [3H] bias as input 2)
+// and the nodes that swallow a bias Add — SkipLayerNormalization(input, skip, gamma, beta, bias), BiasGelu(x, bias).
 //
 // Quantised exports (the reference's DEFAULT model is one: ModelType::AllMiniLML6V2Q, embedder.rs:12-13,367-372 — fastembed
 // downloads its model_quantized.onnx, written by onnxruntime's dynamic quantiser): every Linear weight W is stored as
@@ -326,10 +327,42 @@ bool quant_of(const Model& m, const Tensor& wq, Quant& q) {
     return q.scale != nullptr;
 }
 
+// The weight behind the tensor `y` = x W (+ nothing yet): y's producer is the MatMul itself or, in a dynamically quantised
+// file, the Mul(Cast(MatMulInteger(..)), Mul(x_scale, W_scale)) that follows it — walk back to the product.
+const Tensor* weight_behind(const Model& m, const std::string& y, uint64_t out, uint64_t in, bool& transposed, Quant* quant) {
+    auto p = m.producer.find(y);
+    if (p == m.producer.end()) return nullptr;
+    const Node* mm = &m.nodes[p->second];
+    for (int hop = 0; hop < 4 && mm && (mm->op == "Mul" || mm->op == "Cast"); ++hop) {
+        const Node* next = nullptr;
+        for (const std::string& inp : mm->in) {
+            auto pp = m.producer.find(inp);
+            if (pp == m.producer.end()) continue;
+            const Node& cand = m.nodes[pp->second];
+            if (cand.op == "MatMulInteger" || cand.op == "Cast") { next = &cand; break; }
+            if (cand.op == "Mul" && !next) next = &cand;  // (the scale product is a Mul too: only if nothing better)
+        }
+        mm = next;
+    }
+    if (!mm) return nullptr;
+    if (mm->op == "MatMulInteger" && mm->in.size() >= 2 && quant) {
+        const Tensor* w = m.tensor(mm->in[1]);
+        if (w && shape_is(*w, {in, out}) && quant_of(m, *w, *quant)) { transposed = true; return w; }
+        return nullptr;
+    }
+    if (mm->op != "MatMul" || mm->in.size() != 2) return nullptr;
+    const Tensor* w = m.resolve(mm->in[1]);
+    if (w && shape_is(*w, {in, out})) { transposed = true; return w; }
+    return nullptr;
+}
+
 // The [out, in] weight that belongs to `bias_name` (see the header comment).  -> tensor + whether it is [in, out].
+// The bias is consumed by Gemm (with the weight), by the Add behind a MatMul, or — in files that went through
+// onnxruntime's transformer optimiser (model_optimized.onnx) — by the fused node that swallowed that Add:
+// com.microsoft SkipLayerNormalization(input, skip, gamma, beta, bias) or BiasGelu / FastGelu(x, bias).
 // Dynamic quantisation (the *Q models of the registry, e.g. Xenova/all-MiniLM-L6-v2's model_quantized.onnx) replaces
-// MatMul by DynamicQuantizeLinear -> MatMulInteger(x_q, W_quantized, x_zp, W_zero_point) -> Cast -> Mul(scales) before the
-// bias Add: the weight is then the INT8 / UINT8 second input of that MatMulInteger and *quant says how to read it.
+// MatMul by DynamicQuantizeLinear -> MatMulInteger(x_q, W_quantized, x_zp, W_zero_point) -> Cast -> Mul(scales): the weight
+// is then the INT8 / UINT8 second input of that MatMulInteger and *quant says how to read it.
 const Tensor* weight_of_bias(const Model& m, const std::string& bias_name, uint64_t out, uint64_t in, bool& transposed,
                              Quant* quant = nullptr) {
     auto range = m.consumers.equal_range(bias_name);
@@ -342,30 +375,12 @@ const Tensor* weight_of_bias(const Model& m, const std::string& bias_name, uint6
             if (!n.transB && shape_is(*w, {in, out})) { transposed = true; return w; }
         } else if (n.op == "Add" && n.in.size() == 2) {
             const std::string& other = n.in[0] == bias_name ? n.in[1] : n.in[0];
-            auto p = m.producer.find(other);
-            if (p == m.producer.end()) continue;
-            const Node* mm = &m.nodes[p->second];
-            // quantised layers: Add(bias, Mul(Cast(MatMulInteger(..)), Mul(x_scale, W_scale))) — walk back to the product
-            for (int hop = 0; hop < 4 && mm && (mm->op == "Mul" || mm->op == "Cast"); ++hop) {
-                const Node* next = nullptr;
-                for (const std::string& inp : mm->in) {
-                    auto pp = m.producer.find(inp);
-                    if (pp == m.producer.end()) continue;
-                    const Node& cand = m.nodes[pp->second];
-                    if (cand.op == "MatMulInteger" || cand.op == "Cast") { next = &cand; break; }
-                    if (cand.op == "Mul" && !next) next = &cand;  // (the scale product is a Mul too: only if nothing better)
-                }
-                mm = next;
-            }
-            if (!mm) continue;
-            if (mm->op == "MatMulInteger" && mm->in.size() >= 2 && quant) {
-                const Tensor* w = m.tensor(mm->in[1]);
-                if (w && shape_is(*w, {in, out}) && quant_of(m, *w, *quant)) { transposed = true; return w; }
-                continue;
-            }
-            if (mm->op != "MatMul" || mm->in.size() != 2) continue;
-            const Tensor* w = m.resolve(mm->in[1]);
-            if (w && shape_is(*w, {in, out})) { transposed = true; return w; }
+            if (const Tensor* w = weight_behind(m, other, out, in, transposed, quant)) return w;
+        } else if (n.op == "SkipLayerNormalization" && n.in.size() >= 5 && n.in[4] == bias_name) {
+            for (int k = 0; k < 2; ++k)  // input or skip: whichever the product feeds
+                if (const Tensor* w = weight_behind(m, n.in[k], out, in, transposed, quant)) return w;
+        } else if ((n.op == "BiasGelu" || n.op == "FastGelu") && n.in.size() >= 2 && n.in[1] == bias_name) {
+            if (const Tensor* w = weight_behind(m, n.in[0], out, in, transposed, quant)) return w;
         }
     }
     return nullptr;
@@ -491,10 +506,13 @@ int32_t cs_bert_params_from_onnx_q(const char* path, const cs_bert_config* cfg, 
     CS_TRY(vec("embeddings.LayerNorm.weight", H, params + o.emb_ln_g));
     CS_TRY(vec("embeddings.LayerNorm.bias", H, params + o.emb_ln_b));
 
-    // ORT-optimised files: one fused Attention node per layer, in layer order
+    // ORT-optimised files: one fused Attention node per layer, in layer order; their dynamically quantised form is
+    // com.microsoft QAttention(input_q, weight_q [H, 3H], bias [3H], input_scale, weight_scale, mask_index,
+    // input_zero_point, weight_zero_point): the same packed projection as integers (weight_scale / weight_zero_point
+    // per tensor or per output column)
     std::vector<const Node*> fused;
     for (const Node& n : m.nodes)
-        if (n.op == "Attention" && n.in.size() >= 3) fused.push_back(&n);
+        if ((n.op == "Attention" || n.op == "QAttention") && n.in.size() >= 3) fused.push_back(&n);
     for (uint32_t l = 0; l < cfg->layers; ++l) {
         cs_bert_layer_offsets lo;
         cs_bert_layer_layout(cfg, &o, l, &lo);
@@ -505,17 +523,35 @@ int32_t cs_bert_params_from_onnx_q(const char* path, const cs_bert_config* cfg, 
             CS_TRY(linear(p + "attention.self.key", H, H, params + lo.k_w, params + lo.k_b, sc ? sc + H : nullptr));
             CS_TRY(linear(p + "attention.self.value", H, H, params + lo.v_w, params + lo.v_b, sc ? sc + 2 * H : nullptr));
         } else if (fused.size() == cfg->layers) {
-            all_quantized = false;
-            const Tensor* w = m.resolve(fused[l]->in[1]);
-            const Tensor* b = m.resolve(fused[l]->in[2]);
+            const Node& an = *fused[l];
+            const bool qatt = an.op == "QAttention";
+            const Tensor* w = qatt ? m.tensor(an.in[1]) : m.resolve(an.in[1]);
+            const Tensor* b = m.resolve(an.in[2]);
             if (!w || !b || !shape_is(*w, {H, 3 * H}) || b->count() != 3 * H)
-                return fail(CS_ERR_BAD_ARG, "Failed to initialize embedding model: layer %u's fused Attention node lacks a "
-                            "[%llu, %llu] weight and [%llu] bias", l, (unsigned long long)H, (unsigned long long)(3 * H),
+                return fail(CS_ERR_BAD_ARG, "Failed to initialize embedding model: layer %u's fused %s node lacks a "
+                            "[%llu, %llu] weight and [%llu] bias", l, an.op.c_str(), (unsigned long long)H, (unsigned long long)(3 * H),
                             (unsigned long long)(3 * H));
-            Reader rw(*w), rb(*b);
+            Quant aq;
+            if (qatt) {
+                aq.scale = an.in.size() > 4 ? m.resolve(an.in[4]) : nullptr;
+                aq.zp = an.in.size() > 7 && !an.in[7].empty() ? m.tensor(an.in[7]) : nullptr;
+            }
+            Reader rw = qatt ? Reader(*w, aq, H, 3 * H) : Reader(*w);
+            Reader rb(*b);
             if (!rw.ok || !rb.ok || w->external || b->external)
                 return fail(CS_ERR_UNSUPPORTED, "Failed to initialize embedding model: layer %u's fused QKV weight has an "
-                            "unsupported data type (quantised exports are not read)", l);
+                            "unsupported data type or (QAttention) no usable weight_scale / weight_zero_point", l);
+            bool per_column = false;
+            if (qatt) {
+                Reader rs(*aq.scale);
+                const uint64_t ns = aq.scale->count();
+                if (rs.ok && (ns == 1 || ns == 3 * H)) {
+                    per_column = true;
+                    if (sc)
+                        for (uint64_t c = 0; c < 3 * H; ++c) sc[c] = rs.at(ns == 1 ? 0 : c);  // query | key | value columns
+                }
+            }
+            if (!per_column) all_quantized = false;
             float* wd[3] = {params + lo.q_w, params + lo.k_w, params + lo.v_w};
             float* bd[3] = {params + lo.q_b, params + lo.k_b, params + lo.v_b};
             for (int part = 0; part < 3; ++part) {

@@ -350,8 +350,9 @@ int32_t cs_embedder_create(const cs_bert_config* cfg, const float* params, uint6
  *   - model.safetensors (the PyTorch snapshot: HF BertModel tensor names, optional "bert." prefix), or
  *   - the ONNX export fastembed itself downloads and runs — onnx/model.onnx (Xenova/bge-small-en-v1.5),
  *     model.onnx or model_optimized.onnx: the graph's initialisers are read by hand (no protobuf library):
- *     named parameters directly, Linear weights through the MatMul/Gemm feeding each bias's Add, the packed
- *     QKV of ORT-optimised files through their fused Attention nodes.
+ *     named parameters directly, Linear weights through the MatMul/Gemm feeding each bias's Add — or, in files that went
+ *     through onnxruntime's transformer optimiser, the fused node that swallowed that Add (SkipLayerNormalization,
+ *     BiasGelu / FastGelu) — the packed QKV of such files through their fused Attention / QAttention nodes.
  * F32, F16 or BF16; pooler / position_ids / other extras ignored.  Dynamically quantised exports (the *Q models of
  * the registry, among them the reference's default AllMiniLML6V2Q, embedder.rs:12-13: onnx/model_quantized.onnx — INT8 /
  * UINT8 weights with scale and zero point behind MatMulInteger) are read as (q - zero_point) * scale into the f32 block and,

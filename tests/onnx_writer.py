@@ -94,20 +94,39 @@ def bert_onnx(sd: dict, layers: int, style: str = "matmul", dtype: int = FLOAT, 
        "quantized" — onnxruntime's dynamic quantisation of the "matmul" shape: W_quantized (qdtype, per tensor or per
                   output channel) + W_scale + W_zero_point consumed by DynamicQuantizeLinear -> MatMulInteger -> Cast ->
                   Mul(Mul(x_scale, W_scale)) -> Add(bias); with quantize_tables the word-embedding Gather table too.
-                  `dequantized` (a dict) receives name -> the f32 values a reader must reproduce."""
+                  `dequantized` (a dict) receives name -> the f32 values a reader must reproduce.
+       "optimized" / "optimized_quantized" — what onnxruntime's transformer optimiser leaves (model_optimized.onnx; the
+                  quantised form is e.g. the BGE-small *Q entry): the bias Adds are swallowed by fused com.microsoft nodes —
+                  SkipLayerNormalization(input, skip, gamma, beta, bias) behind attention.output / output.dense,
+                  BiasGelu(x, bias) behind intermediate.dense, Attention (QAttention when quantised: weight int8 [H, 3H],
+                  weight_scale, weight_zero_point) for Q / K / V, EmbedLayerNormalization for the three tables."""
     inits, nodes, counter = [], [], [1000]
+    optimized = style in ("optimized", "optimized_quantized")
+    quantized = style in ("quantized", "optimized_quantized")
 
     def keep(name):
         inits.append(tensor(prefix + name, sd[name], dtype))
 
-    def linear(base, x):
+    def linear(base, x, skip=None):
         w, b = sd[base + ".weight"], base + ".bias"
         keep(b)
         y = "/" + base + "/out"
+
+        def finish(mm):
+            """the node that consumes the bias: Add, or the fused node of an optimised file"""
+            if not optimized:
+                nodes.append(node("Add", [prefix + b, mm] if counter[0] % 3 else [mm, prefix + b], [y]))
+            elif skip is None:   # intermediate.dense
+                nodes.append(node("BiasGelu", [mm, prefix + b], [y]))
+            else:                # attention.output.dense / output.dense: + residual, LayerNorm, in one node
+                ln = base.replace(".dense", ".LayerNorm")
+                ins = [mm, skip] if counter[0] % 2 else [skip, mm]
+                nodes.append(node("SkipLayerNormalization", ins + [prefix + ln + ".weight", prefix + ln + ".bias", prefix + b], [y]))
+
         if style == "gemm":
             keep(base + ".weight")
             nodes.append(node("Gemm", [x, prefix + base + ".weight", prefix + b], [y], attrs=[("transB", 1)]))
-        elif style == "quantized":
+        elif quantized:
             counter[0] += 1
             anon = f"onnx::MatMul_{counter[0]}"
             q, sc, zp = quantize(w.T, qdtype, axis=1 if per_channel else None)   # stored [in, out]; channels = outputs
@@ -123,19 +142,19 @@ def bert_onnx(sd: dict, layers: int, style: str = "matmul", dtype: int = FLOAT, 
             nodes.append(node("Mul", [xs, anon + "_scale"], [f"/{base}/scales"]))
             nodes.append(node("Mul", [f"/{base}/mmi_f", f"/{base}/scales"] if counter[0] % 2 else [f"/{base}/scales", f"/{base}/mmi_f"],
                               [f"/{base}/mm"]))
-            nodes.append(node("Add", [prefix + b, f"/{base}/mm"] if counter[0] % 3 else [f"/{base}/mm", prefix + b], [y]))
+            finish(f"/{base}/mm")
         else:
             counter[0] += 1
             anon = f"onnx::MatMul_{counter[0]}"
             inits.append(tensor(anon, w.T, dtype, packed_float_data=(counter[0] % 2 == 0)))
             mm = "/" + base + "/MatMul_output_0"
             nodes.append(node("MatMul", [x, anon], [mm]))
-            nodes.append(node("Add", [prefix + b, mm] if counter[0] % 3 else [mm, prefix + b], [y]))
+            finish(mm)
         return y
 
     for n in ("embeddings.word_embeddings.weight", "embeddings.position_embeddings.weight",
               "embeddings.token_type_embeddings.weight", "embeddings.LayerNorm.weight", "embeddings.LayerNorm.bias"):
-        if style == "quantized" and quantize_tables and n == "embeddings.word_embeddings.weight":
+        if quantized and quantize_tables and n == "embeddings.word_embeddings.weight":
             q, sc, zp = quantize(sd[n], UINT8)
             inits.append(raw_tensor(prefix + n + "_quantized", q, UINT8))
             inits.append(tensor(prefix + n + "_scale", sc))
@@ -144,17 +163,41 @@ def bert_onnx(sd: dict, layers: int, style: str = "matmul", dtype: int = FLOAT, 
                 dequantized[n] = ((q.astype(np.float32) - zp.astype(np.float32)) * sc).astype(np.float32)
             continue
         keep(n)
-    nodes.append(node("Gather", [prefix + "embeddings.word_embeddings.weight", "input_ids"], ["/emb"]))
+    if optimized and not quantize_tables:
+        e = "embeddings."
+        nodes.append(node("EmbedLayerNormalization", ["input_ids", "token_type_ids", prefix + e + "word_embeddings.weight",
+                                                      prefix + e + "position_embeddings.weight", prefix + e + "token_type_embeddings.weight",
+                                                      prefix + e + "LayerNorm.weight", prefix + e + "LayerNorm.bias", "attention_mask"],
+                          ["/emb", "mask_index"]))
+    else:
+        nodes.append(node("Gather", [prefix + "embeddings.word_embeddings.weight", "input_ids"], ["/emb"]))
     x = "/emb"
     for l in range(layers):
         p = f"encoder.layer.{l}."
-        if style == "fused":
+        if style == "fused" or optimized:
             wq, wk, wv = (sd[p + f"attention.self.{n}.weight"] for n in ("query", "key", "value"))
             bq, bk, bv = (sd[p + f"attention.self.{n}.bias"] for n in ("query", "key", "value"))
-            inits.append(tensor(f"Attention_{l}_qkv_weight", np.concatenate([wq.T, wk.T, wv.T], axis=1), dtype))
+            packed = np.concatenate([wq.T, wk.T, wv.T], axis=1)   # [H, 3H]
             inits.append(tensor(f"Attention_{l}_qkv_bias", np.concatenate([bq, bk, bv]), dtype))
-            nodes.append(node("Attention", [x, f"Attention_{l}_qkv_weight", f"Attention_{l}_qkv_bias", "mask_index"],
-                              [f"/att{l}"], attrs=[("num_heads", 12)]))
+            if quantized:
+                q, sc, zp = quantize(packed, qdtype, axis=1 if per_channel else None)
+                inits.append(raw_tensor(f"Attention_{l}_qkv_weight_quantized", q, qdtype))
+                inits.append(tensor(f"Attention_{l}_qkv_weight_scale", sc))
+                inits.append(raw_tensor(f"Attention_{l}_qkv_weight_zero_point", zp, qdtype))
+                if dequantized is not None:
+                    deq = ((q.astype(np.float32) - zp.astype(np.float32)) * sc).astype(np.float32)
+                    H = wq.shape[0]
+                    for i, nme in enumerate(("query", "key", "value")):
+                        dequantized[p + f"attention.self.{nme}.weight"] = deq[:, i * H:(i + 1) * H].T.copy()
+                xq, xs, xz = (f"/att{l}/x_{t}" for t in ("quantized", "scale", "zero_point"))
+                nodes.append(node("DynamicQuantizeLinear", [x], [xq, xs, xz]))
+                nodes.append(node("QAttention", [xq, f"Attention_{l}_qkv_weight_quantized", f"Attention_{l}_qkv_bias", xs,
+                                                 f"Attention_{l}_qkv_weight_scale", "mask_index", xz,
+                                                 f"Attention_{l}_qkv_weight_zero_point"], [f"/att{l}"], attrs=[("num_heads", 12)]))
+            else:
+                inits.append(tensor(f"Attention_{l}_qkv_weight", packed, dtype))
+                nodes.append(node("Attention", [x, f"Attention_{l}_qkv_weight", f"Attention_{l}_qkv_bias", "mask_index"],
+                                  [f"/att{l}"], attrs=[("num_heads", 12)]))
             ctx = f"/att{l}"
         else:
             q = linear(p + "attention.self.query", x)
@@ -162,11 +205,11 @@ def bert_onnx(sd: dict, layers: int, style: str = "matmul", dtype: int = FLOAT, 
             v = linear(p + "attention.self.value", x)
             nodes.append(node("Softmax", [q, k, v], [f"/ctx{l}"]))
             ctx = f"/ctx{l}"
-        x = linear(p + "attention.output.dense", ctx)
+        x = linear(p + "attention.output.dense", ctx, skip=x)
         keep(p + "attention.output.LayerNorm.weight")
         keep(p + "attention.output.LayerNorm.bias")
-        x = linear(p + "intermediate.dense", x)
-        x = linear(p + "output.dense", x)
+        h = linear(p + "intermediate.dense", x)
+        x = linear(p + "output.dense", h, skip=x)
         keep(p + "output.LayerNorm.weight")
         keep(p + "output.LayerNorm.bias")
     return model(nodes, inits)

@@ -244,8 +244,10 @@ def test_a_call_is_one_tensor(gpu_lib, oracle):
     emb.close()
 
 
-@pytest.mark.parametrize("qdtype_name,per_channel", [("UINT8", False), ("INT8", True)])
-def test_quantised_model_directory(gpu_lib, oracle, tmp_path, qdtype_name, per_channel):
+@pytest.mark.parametrize("qdtype_name,per_channel,style,rel", [("UINT8", False, "quantized", "onnx/model_quantized.onnx"),
+                                                               ("INT8", True, "quantized", "onnx/model_quantized.onnx"),
+                                                               ("INT8", False, "optimized_quantized", "model_optimized.onnx")])
+def test_quantised_model_directory(gpu_lib, oracle, tmp_path, qdtype_name, per_channel, style, rel):
     """What fastembed's cache holds for a *Q registry entry (the reference's default model among them): config.json and
     onnx/model_quantized.onnx as onnxruntime's quantize_dynamic writes it.  FastEmbedder.from_dir must come up in the
     dynamic-quantisation mode and embed as the oracle's quantised forward does on the block and scales read back from
@@ -266,8 +268,8 @@ def test_quantised_model_directory(gpu_lib, oracle, tmp_path, qdtype_name, per_c
     cache = tmp_path / "models--Xenova--all-MiniLM-L6-v2" / "snapshots" / "abc"
     (cache / "onnx").mkdir(parents=True)
     (cache / "config.json").write_text(json.dumps(config))
-    path = cache / "onnx" / "model_quantized.onnx"
-    path.write_bytes(onnx_writer.bert_onnx(sd, cfg.layers, "quantized", qdtype=getattr(onnx_writer, qdtype_name),
+    path = cache / rel   # (the third case: the BGE-small *Q entry's file, through onnxruntime's transformer optimiser)
+    path.write_bytes(onnx_writer.bert_onnx(sd, cfg.layers, style, qdtype=getattr(onnx_writer, qdtype_name),
                                            per_channel=per_channel, quantize_tables=True))
     params, wscale, quantized = load_onnx_q(gpu_lib, path, cfg)
     assert quantized == 1

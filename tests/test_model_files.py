@@ -53,11 +53,13 @@ def test_reads_a_file_written_by_torchs_own_exporter(gpu_lib):
 @pytest.mark.parametrize("style,dtype,prefix", [("matmul", onnx_writer.FLOAT, ""), ("matmul", onnx_writer.FLOAT16, "bert."),
                                                 ("matmul", onnx_writer.BFLOAT16, "0.auto_model."),
                                                 ("gemm", onnx_writer.FLOAT, ""), ("fused", onnx_writer.FLOAT, ""),
-                                                ("fused", onnx_writer.FLOAT16, "")])
+                                                ("fused", onnx_writer.FLOAT16, ""), ("optimized", onnx_writer.FLOAT, ""),
+                                                ("optimized", onnx_writer.FLOAT16, "bert.")])
 def test_exporter_layouts_and_dtypes(gpu_lib, tmp_path, style, dtype, prefix):
     """The layouts exporters produce, at the BGE-small width (hidden 384, 2 layers): MatMul + Add with
     anonymous transposed weights (raw_data and packed float_data payloads, bias as either Add input), Gemm
-    with transB, the fused Attention node of ORT-optimised files; FLOAT / FLOAT16 / BFLOAT16."""
+    with transB, the fused Attention node of ORT-optimised files, and the fully optimised form (model_optimized.onnx:
+    every bias swallowed by SkipLayerNormalization / BiasGelu, EmbedLayerNormalization); FLOAT / FLOAT16 / BFLOAT16."""
     import torch
 
     cfg = BertConfig(vocab_size=300, layers=2, max_position=64, pooling=POOL_MEAN)
@@ -75,21 +77,24 @@ def test_exporter_layouts_and_dtypes(gpu_lib, tmp_path, style, dtype, prefix):
     assert np.array_equal(got, exp)
 
 
+@pytest.mark.parametrize("style", ["quantized", "optimized_quantized"])
 @pytest.mark.parametrize("qdtype,per_channel,tables,prefix", [(onnx_writer.INT8, False, False, ""),
                                                                (onnx_writer.UINT8, False, True, ""),
                                                                (onnx_writer.INT8, True, True, "0.auto_model.")])
-def test_dynamically_quantised_export(gpu_lib, tmp_path, qdtype, per_channel, tables, prefix):
+def test_dynamically_quantised_export(gpu_lib, tmp_path, qdtype, per_channel, tables, prefix, style):
     """The layout of the reference's DEFAULT model (ModelType::AllMiniLML6V2Q, embedder.rs:12-13: fastembed's
     model_quantized.onnx, written by onnxruntime's dynamic quantiser): W_quantized (INT8 symmetric / UINT8 asymmetric,
     per tensor or per output channel) + W_scale + W_zero_point behind DynamicQuantizeLinear -> MatMulInteger -> Cast ->
-    Mul -> Add(bias), optionally a quantised word-embedding table.  The loader must hand back exactly
-    (q - zero_point) * scale for those tensors and every other parameter bit for bit."""
+    Mul -> Add(bias), optionally a quantised word-embedding table — and the same through onnxruntime's transformer optimiser
+    ("optimized_quantized", the BGE-small *Q entry's model_optimized.onnx: QAttention with a packed int8 [H, 3H] weight, the
+    other biases inside SkipLayerNormalization / BiasGelu).  The loader must hand back exactly (q - zero_point) * scale
+    for those tensors and every other parameter bit for bit."""
     cfg = BertConfig(vocab_size=300, layers=2, max_position=64, pooling=POOL_MEAN)
     flat = synth_params(cfg, 78)
     sd = to_state_dict(cfg, flat)
     deq = {}
     path = tmp_path / "model_quantized.onnx"
-    path.write_bytes(onnx_writer.bert_onnx(sd, cfg.layers, "quantized", prefix=prefix, qdtype=qdtype, per_channel=per_channel,
+    path.write_bytes(onnx_writer.bert_onnx(sd, cfg.layers, style, prefix=prefix, qdtype=qdtype, per_channel=per_channel,
                                            quantize_tables=tables, dequantized=deq))
     got = to_state_dict(cfg, load_onnx(gpu_lib, path, cfg))
     assert len(deq) == 6 * cfg.layers + (1 if tables else 0)
@@ -115,7 +120,8 @@ def test_dynamically_quantised_export(gpu_lib, tmp_path, qdtype, per_channel, ta
             c0 += w.shape[0]
             d = w / sc[:, None]
             assert np.abs(d - np.rint(d)).max() < 1e-3 and (np.rint(d).max(axis=1) - np.rint(d).min(axis=1)).max() <= 255
-            assert (np.unique(sc).size == 1) == (not per_channel)
+            if not (style == "optimized_quantized" and role.startswith("attention.self.")):   # (one packed tensor there)
+                assert (np.unique(sc).size == 1) == (not per_channel)
         assert c0 == 5 * H + I
     # a quantised weight whose scale is missing is refused with a message, not read as garbage
     broken = onnx_writer.bert_onnx(sd, cfg.layers, "quantized", qdtype=qdtype).replace(b"onnx::MatMul_1001_scale", b"onnx::MatMul_1001_scalX")
