@@ -48,6 +48,10 @@ def test_quantised_onnx_survives_truncations_and_mutations(fuzz, tmp_path):
     p = tmp_path / "model_quantized.onnx"
     p.write_bytes(onnx_writer.bert_onnx(sd, 1, "quantized", qdtype=onnx_writer.UINT8, per_channel=True, quantize_tables=True))
     fuzz("onnx", p, seed=21, flips=600, aux="64 128 1 4 256 16")
+    # ... and the same through onnxruntime's transformer optimiser: QAttention, biases inside SkipLayerNormalization / BiasGelu
+    p2 = tmp_path / "model_optimized.onnx"
+    p2.write_bytes(onnx_writer.bert_onnx(sd, 1, "optimized_quantized", qdtype=onnx_writer.INT8, per_channel=False))
+    fuzz("onnx", p2, seed=22, flips=400, aux="64 128 1 4 256 16")
 
 
 def test_safetensors_reader_survives_truncations_and_mutations(fuzz, tmp_path):
