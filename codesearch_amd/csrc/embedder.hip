@@ -305,6 +305,35 @@ int32_t forward_range(cs_embedder* h, hipStream_t s, uint32_t b0, uint32_t nb, u
             Q8RowMeta* rm = h->d_rmeta + t0;
             _Float16* qkvs = reinterpret_cast<_Float16*>(qkv);
             float* rp = h->d_range_pairs;
+            if (!rs && q8_rows_from_source(T, H)) {
+                // one unit, K = 384, a row block per CU: the products quantise their own rows on the way in — per tensor only
+                // its range is needed first (a reduction of the pairs its producer left)
+                CS_TRY(launch_q8_range(Q8_SRC_F32, x, T, H, rg, s, rp, ln_pairs));
+                CS_TRY(launch_gemm_q8_from_source(SH_OUT_SPLIT, Q8_SRC_F32, x, rg, wq + ql.qkv, cm, bqkv, nullptr, nullptr, qkvs, T, 3 * H, H, h->d_flag, s));  // E2
+                CS_TRY(mark(CS_STAGE_QKV));
+                uint32_t att_pairs = 0;
+                CS_TRY(launch_attention_sh2(qkvs, mask, ctxs, h->d_flag, nb, L, H, c.heads, s, rp, &att_pairs));  // E3
+                CS_TRY(mark(CS_STAGE_ATTENTION));
+                CS_TRY(launch_q8_range(Q8_SRC_SPLIT, ctxs, T, H, rg + rstep, s, rp, att_pairs));
+                CS_TRY(launch_gemm_q8_from_source(SH_OUT_F32_RESID, Q8_SRC_SPLIT, ctxs, rg + rstep, wq + ql.ao, cm + 3 * H, P + lo.ao_b, x, x, nullptr, T, H, H,
+                                                  h->d_flag, s));  // E4
+                CS_TRY(mark(CS_STAGE_OUT_PROJ));
+                a.g = P + lo.ao_ln_g; a.b = P + lo.ao_ln_b;
+                CS_TRY(launch_row_kernel(1, a, H, s));
+                CS_TRY(mark(CS_STAGE_LN_ATTN));
+                CS_TRY(launch_q8_range(Q8_SRC_F32, x, T, H, rg + 2 * rstep, s, rp, ln_pairs));
+                int8_t* midq = reinterpret_cast<int8_t*>(mid);
+                Q8RowMeta* rm2 = h->d_rmeta2 + t0;
+                CS_TRY(launch_gemm_q8_gelu_requant_from_source(x, rg + 2 * rstep, wq + ql.up, cm + 4 * H, P + lo.up_b, T, I, H, rg + 3 * rstep, midq, rm2, s));  // E5
+                CS_TRY(mark(CS_STAGE_FFN_UP));
+                CS_TRY(launch_gemm_q8(SH_OUT_F32_RESID, midq, rm2, wq + ql.down, cm + 4 * H + I, P + lo.down_b, x, x, nullptr, T, H, I, h->d_flag, s));  // E6
+                CS_TRY(mark(CS_STAGE_FFN_DOWN));
+                a.g = P + lo.out_ln_g; a.b = P + lo.out_ln_b;
+                CS_TRY(launch_row_kernel(1, a, H, s));
+                CS_TRY(mark(CS_STAGE_LN_FFN));
+                if (l + 1 == c.layers) h->last_hidden_partial = false;
+                continue;
+            }
             if (rs && l == 0) CS_TRY(launch_q8_row_slots(h->d_seq_unit, h->d_unit_len, T, L, h->d_row_slot, s));
             CS_TRY(launch_q8_quantize(Q8_SRC_F32, x, T, H, rg, rs, xq, rm, s, rp, ln_pairs));
             CS_TRY(launch_gemm_q8(SH_OUT_SPLIT, xq, rm, wq + ql.qkv, cm, bqkv, nullptr, nullptr, qkvs, T, 3 * H, H, h->d_flag, s));  // E2
@@ -1474,7 +1503,7 @@ int32_t cs_debug_gemm_q8(int32_t device, int32_t epilogue, int32_t a_split, cons
         }
         if (acc_out && epilogue != 5) CS_HIP(hipMalloc(&dAcc, c_n * 4));
         CS_TRY(launch_q8_pack_weight(dW, dS, dB, N, K, dWq, dCm, dF + 1, nullptr));
-        if (a_split) {
+        if (a_split & 1) {
             CS_HIP(hipMalloc(&sA, a_n * 4));
             CS_TRY(launch_split_rows(dA, sA, M, K, dF, nullptr));
             CS_TRY(launch_q8_quantize(Q8_SRC_SPLIT, sA, M, K, dRange, nullptr, dXq, dRm, nullptr));
@@ -1487,7 +1516,8 @@ int32_t cs_debug_gemm_q8(int32_t device, int32_t epilogue, int32_t a_split, cons
             uint32_t* dRange2 = nullptr;
             CS_HIP(hipMalloc(&dOut, c_n)); CS_HIP(hipMalloc(&dRm2, (size_t)M * sizeof(Q8RowMeta))); CS_HIP(hipMalloc(&dRange2, Q8_RANGE_WORDS * 4));
             CS_HIP(hipMemset(dRange2, 0, Q8_RANGE_WORDS * 4));
-            int32_t st5 = launch_gemm_q8_gelu_requant(dXq, dRm, dWq, dCm, dB, M, N, K, dRange2, dOut, dRm2, nullptr);
+            int32_t st5 = (a_split & 8) ? launch_gemm_q8_gelu_requant_from_source(dA, dRange, dWq, dCm, dB, M, N, K, dRange2, dOut, dRm2, nullptr)
+                                        : launch_gemm_q8_gelu_requant(dXq, dRm, dWq, dCm, dB, M, N, K, dRange2, dOut, dRm2, nullptr);
             if (st5 == CS_OK && hipDeviceSynchronize() != hipSuccess) st5 = fail(CS_ERR_HIP, "requant GEMM failed");
             std::vector<int8_t> ho(c_n);
             std::vector<Q8RowMeta> hr(M);
@@ -1514,6 +1544,11 @@ int32_t cs_debug_gemm_q8(int32_t device, int32_t epilogue, int32_t a_split, cons
         }
         const int epi = epilogue == 0 ? SH_OUT_F32 : epilogue == 1 ? SH_OUT_SPLIT_GELU : epilogue == 2 ? SH_OUT_F32_RESID : SH_OUT_SPLIT;
         if (epi == SH_OUT_SPLIT_GELU || epi == SH_OUT_SPLIT) CS_HIP(hipMalloc(&sC, c_n * 4));
+        if (a_split & 8) {  // the products that quantise their own rows on the way in (row-block kernel; acc is not reported)
+            if (dAcc) CS_HIP(hipMemset(dAcc, 0, c_n * 4));
+            CS_TRY(launch_gemm_q8_from_source(epi, (a_split & 1) ? Q8_SRC_SPLIT : Q8_SRC_F32, (a_split & 1) ? (const void*)sA : (const void*)dA, dRange,
+                                              dWq, dCm, dB, dR, dC, sC, M, N, K, dF, nullptr));
+        } else
         CS_TRY(launch_gemm_q8(epi, dXq, dRm, dWq, dCm, dB, dR, dC, sC, M, N, K, dF, nullptr, dAcc));
         CS_HIP(hipDeviceSynchronize());
         uint32_t flags[2] = {0, 0};

@@ -620,12 +620,19 @@ __device__ __forceinline__ void q8_rows_store(const float* ctile, const float* r
     }
 }
 
-template <int EPI>
+// SRC = QR_PREQUANT: A is the quantised tensor (q8_quantize_kernel's output) with its row metadata.  SRC = Q8_SRC_F32 /
+// Q8_SRC_SPLIT: A is the f32-class tensor itself and in_range its range slot — the block quantises its own 128 rows on the
+// way in (cooperatively, into the W buffer the first tile does not use yet; every wave then takes its fragments from that
+// image): the quantising pass over the tensor, its 25 MB of output and their re-read disappear (25-28 us per Linear at
+// 65,536 rows).  One quantisation unit only.
+constexpr int QR_PREQUANT = -1;
+template <int EPI, int SRC = QR_PREQUANT>
 __global__ void __launch_bounds__(QR_THREADS, 2)
-gemm_q8_rows_kernel(const int8_t* __restrict__ A, const int8_t* __restrict__ W, const Q8RowMeta* __restrict__ rmeta,
+gemm_q8_rows_kernel(const void* __restrict__ Asrc, const int8_t* __restrict__ W, const Q8RowMeta* __restrict__ rmeta,
                     const Q8ColMeta* __restrict__ cmeta, const float* resid, float* C,
                     _Float16* __restrict__ Cs, uint32_t M, uint32_t N, uint32_t* __restrict__ flag, Q8Requant rq,
-                    uint32_t parts, uint32_t total_units) {
+                    uint32_t parts, uint32_t total_units, const uint32_t* __restrict__ in_range) {
+    const int8_t* A = reinterpret_cast<const int8_t*>(Asrc);
     extern __shared__ __attribute__((aligned(16))) char lds[];
     constexpr uint32_t K = 128 * QR_KC;
     constexpr bool REQ = EPI == Q8_EPI_GELU_RANGE || EPI == Q8_EPI_GELU_Q8;
@@ -662,6 +669,11 @@ gemm_q8_rows_kernel(const int8_t* __restrict__ A, const int8_t* __restrict__ W, 
     }
     float ymax = -INFINITY, ya = -INFINITY, yb = INFINITY;
     float ycen = 0.0f, yhw = INFINITY;  // wave-uniform: centre and half-width (padded) of the wave's (a, b) so far
+    float xs = 1.0f, xz = 0.0f, rxs = 1.0f;  // SRC >= 0: DynamicQuantizeLinear's parameters of the input tensor
+    if (SRC != QR_PREQUANT) {
+        q8_params(in_range, xs, xz);
+        rxs = __fdiv_rn(1.0f, xs);
+    }
 
     for (uint32_t unit = blockIdx.x; unit < total_units; unit += gridDim.x) {
         const uint32_t mt = unit / parts, nt0 = (unit % parts) * per;
@@ -670,24 +682,96 @@ gemm_q8_rows_kernel(const int8_t* __restrict__ A, const int8_t* __restrict__ W, 
         const uint32_t m0 = mt * 128;
         // the wave's 64 rows x 384 k as MFMA A operands: row l15 of row group i, bytes 16 g .. of k-step s of chunk c
         q8_i32x4 a0[QR_KC][4], a1[QR_KC][4];
+        if constexpr (SRC == QR_PREQUANT) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const uint32_t row = m0 + wr * 64 + i * 16 + l15;
-            const int8_t* p = A + (size_t)(row < M ? row : M - 1) * K + g * 16;
+            for (int i = 0; i < 4; ++i) {
+                const uint32_t row = m0 + wr * 64 + i * 16 + l15;
+                const int8_t* p = A + (size_t)(row < M ? row : M - 1) * K + g * 16;
 #pragma unroll
-            for (int c = 0; c < QR_KC; ++c) {
-                a0[c][i] = *reinterpret_cast<const q8_i32x4*>(p + c * 128);
-                a1[c][i] = *reinterpret_cast<const q8_i32x4*>(p + c * 128 + 64);
+                for (int c = 0; c < QR_KC; ++c) {
+                    a0[c][i] = *reinterpret_cast<const q8_i32x4*>(p + c * 128);
+                    a1[c][i] = *reinterpret_cast<const q8_i32x4*>(p + c * 128 + 64);
+                }
             }
+            // the row block's metadata into LDS: x_scale, x zero point, rowsum - K za
+            if (tid < 128) {
+                Q8RowMeta rm = rmeta[m0 + tid < M ? m0 + tid : M - 1];
+                rm.rowsum -= (int)K * rm.za;
+                lrow[tid] = rm;
+            }
+            issue_w(nt0, 0);
+            __syncthreads();  // W tile nt0 has landed (vmcnt(0) precedes the barrier); obuf and the other W buffer are free
+        } else {
+            if (tid < 128) lrow[tid].rowsum = 0;
+            issue_w(nt0, 0);
+            __syncthreads();
+            // 3 chunks x 128 rows x 8 slots of 16 k: six slots per thread, quantised into the image of W buffer 1
+            char* abuf = lds + QR_WTILE;
+#pragma unroll
+            for (int u = 0; u < 6; ++u) {
+                const int sidx = tid + QR_THREADS * u, c = sidx >> 10, row = (sidx & 1023) >> 3, sl = sidx & 7;
+                const uint32_t m = (m0 + row < M) ? m0 + row : M - 1;  // rows past M repeat the last one: never stored
+                float v[16];
+                if (SRC == Q8_SRC_F32) {
+                    const sh_f32x4* p = reinterpret_cast<const sh_f32x4*>(reinterpret_cast<const float*>(Asrc) + (size_t)m * K + c * 128 + sl * 16);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const sh_f32x4 t = p[q];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[4 * q + e] = t[e];
+                    }
+                } else {  // 16 k = half a 32-k line: 16 hi halves, their 16 lo halves 64 B further on
+                    const _Float16* p = reinterpret_cast<const _Float16*>(Asrc) + ((size_t)m * (K / 32) + c * 4 + (sl >> 1)) * 64 + (sl & 1) * 16;
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const f16x8 h = *reinterpret_cast<const f16x8*>(p + 8 * q);
+                        const f16x8 l = *reinterpret_cast<const f16x8*>(p + 32 + 8 * q);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[8 * q + e] = (float)h[e] + (float)l[e] * kShLoInv;
+                    }
+                }
+                q8_i32x4 packed;
+                int sum = 0;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    uint32_t pw = 0;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        // sat_u8(round_half_even(x / x_scale) + x_zp): the quotient by a reciprocal, the true division only where the
+                        // two could round apart (|x / x_scale| <= 255: they differ by < 1e-4)
+                        const float t = v[4 * w + e] * rxs;
+                        float rt = rintf(t);
+                        if (fabsf(fabsf(t - rt) - 0.5f) < 1.0e-3f) rt = rintf(__fdiv_rn(v[4 * w + e], xs));
+                        const float q = fminf(fmaxf(__fadd_rn(rt, xz), 0.0f), 255.0f);
+                        const int a = (int)q - 128;
+                        sum += a;
+                        pw |= (uint32_t)(a & 0xff) << (8 * e);
+                    }
+                    packed[w] = (int)pw;
+                }
+                *reinterpret_cast<q8_i32x4*>(abuf + c * 16384 + row * 128 + ((sl ^ ((row >> 1) & 7)) * 16)) = packed;
+                atomicAdd(&lrow[row].rowsum, sum);
+            }
+            __syncthreads();  // the image and the row sums are complete (and W tile nt0 has landed)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int c = 0; c < QR_KC; ++c) {
+                    const char* p = abuf + c * 16384 + (wr * 64 + i * 16 + l15) * 128;
+                    a0[c][i] = *reinterpret_cast<const q8_i32x4*>(p + s0);
+                    a1[c][i] = *reinterpret_cast<const q8_i32x4*>(p + s1);
+                }
+            const int za = (int)xz - 128;
+            int pm = 0;
+            if (tid < 128) pm = lrow[tid].rowsum - (int)K * za;
+            __syncthreads();  // fragments are in registers (W buffer 1 is free for tile nt0 + 1), row sums read
+            if (tid < 128) {
+                Q8RowMeta rm;
+                rm.xs = xs; rm.za = za; rm.rowsum = pm; rm.pad = 0;
+                lrow[tid] = rm;
+            }
+            __syncthreads();
         }
-        // the row block's metadata into LDS: x_scale, x zero point, rowsum - K za
-        if (tid < 128) {
-            Q8RowMeta rm = rmeta[m0 + tid < M ? m0 + tid : M - 1];
-            rm.rowsum -= (int)K * rm.za;
-            lrow[tid] = rm;
-        }
-        issue_w(nt0, 0);
-        __syncthreads();  // W tile nt0 has landed (vmcnt(0) precedes the barrier); obuf and the other W buffer are free
         for (uint32_t nt = nt0; nt < nt1; ++nt) {
             const uint32_t n0 = nt * 128;
             const int b = (nt - nt0) & 1;
@@ -917,13 +1001,13 @@ static int q8_cus() {
     }
     return cus;
 }
-template <int EPI>
-static int32_t launch_rows(const int8_t* d_xq, const Q8RowMeta* d_rmeta, const int8_t* d_wq, const Q8ColMeta* d_cmeta,
+template <int EPI, int SRC = QR_PREQUANT>
+static int32_t launch_rows(const void* d_xq, const Q8RowMeta* d_rmeta, const int8_t* d_wq, const Q8ColMeta* d_cmeta,
                            const float* bias, const float* resid, float* C, _Float16* Cs, uint32_t M, uint32_t N,
-                           uint32_t* d_flag, Q8Requant rq, hipStream_t s) {
+                           uint32_t* d_flag, Q8Requant rq, hipStream_t s, const uint32_t* d_in_range = nullptr) {
     static PerDeviceOnce attr;  // function attributes are per device
     CS_TRY(attr.run([&]() -> int32_t {
-        CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_q8_rows_kernel<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, QR_LDS));
+        CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_q8_rows_kernel<EPI, SRC>), hipFuncAttributeMaxDynamicSharedMemorySize, QR_LDS));
         return CS_OK;
     }));
     const uint32_t mtiles = (M + 127) / 128, ntiles = N / 128, cus = (uint32_t)q8_cus();
@@ -932,8 +1016,8 @@ static int32_t launch_rows(const int8_t* d_xq, const Q8RowMeta* d_rmeta, const i
     if (parts > ntiles) parts = ntiles;
     const uint32_t units = mtiles * parts;
     (void)bias;  // the row-block kernel takes the bias from the column metadata (folded in at create time)
-    hipLaunchKernelGGL(gemm_q8_rows_kernel<EPI>, dim3(units < cus ? units : cus), dim3(QR_THREADS), QR_LDS, s, d_xq, d_wq, d_rmeta,
-                       d_cmeta, resid, C, Cs, M, N, d_flag, rq, parts, units);
+    hipLaunchKernelGGL((gemm_q8_rows_kernel<EPI, SRC>), dim3(units < cus ? units : cus), dim3(QR_THREADS), QR_LDS, s, d_xq, d_wq, d_rmeta,
+                       d_cmeta, resid, C, Cs, M, N, d_flag, rq, parts, units, d_in_range);
     CS_HIP(hipGetLastError());
     return CS_OK;
 }
@@ -971,6 +1055,48 @@ int32_t launch_gemm_q8(int epi, const int8_t* d_xq, const Q8RowMeta* d_rmeta, co
 #undef CS_Q8_LAUNCH
     CS_HIP(hipGetLastError());
     return CS_OK;
+}
+
+bool q8_rows_from_source(uint32_t M, uint32_t K) {
+    static const bool on = [] { const char* e = std::getenv("CS_Q8_ROWS_SRC"); return !(e && e[0] == '0'); }();
+    return on && q8_rows_takes(M, K);
+}
+
+int32_t launch_q8_range(int src_kind, const void* d_src, uint32_t T, uint32_t K, uint32_t* d_range, hipStream_t s,
+                        const float* d_range_pairs, uint32_t n_pairs) {
+    if (T == 0) return CS_OK;
+    if (d_range_pairs && n_pairs) {
+        hipLaunchKernelGGL(q8_range_reduce_kernel, dim3(1), dim3(1024), 0, s, d_range_pairs, n_pairs, d_range);
+    } else {
+        const uint64_t units = (uint64_t)T * (K / (src_kind == Q8_SRC_F32 ? 4 : 8));
+        const uint64_t want = (units + 255) / 256;
+        const dim3 grid_mm((uint32_t)(want < 1024 ? want : 1024));
+        if (src_kind == Q8_SRC_F32) hipLaunchKernelGGL(q8_minmax_kernel<Q8_SRC_F32>, grid_mm, dim3(256), 0, s, d_src, T, K, d_range);
+        else hipLaunchKernelGGL(q8_minmax_kernel<Q8_SRC_SPLIT>, grid_mm, dim3(256), 0, s, d_src, T, K, d_range);
+    }
+    CS_HIP(hipGetLastError());
+    return CS_OK;
+}
+
+int32_t launch_gemm_q8_from_source(int epi, int src_kind, const void* d_src, const uint32_t* d_in_range, const int8_t* d_wq,
+                                   const Q8ColMeta* d_cmeta, const float* bias, const float* resid, float* C, _Float16* Cs,
+                                   uint32_t M, uint32_t N, uint32_t K, uint32_t* d_flag, hipStream_t s) {
+    if (!q8_rows_takes(M, K) || N % 128) return fail(CS_ERR_UNSUPPORTED, "quantise-on-load product: M=%u N=%u K=%u not taken by the row-block kernel", M, N, K);
+    const Q8Requant none{nullptr, nullptr, nullptr};
+    if (epi == SH_OUT_SPLIT && src_kind == Q8_SRC_F32)
+        return launch_rows<SH_OUT_SPLIT, Q8_SRC_F32>(d_src, nullptr, d_wq, d_cmeta, bias, resid, C, Cs, M, N, d_flag, none, s, d_in_range);
+    if (epi == SH_OUT_F32_RESID && src_kind == Q8_SRC_SPLIT)
+        return launch_rows<SH_OUT_F32_RESID, Q8_SRC_SPLIT>(d_src, nullptr, d_wq, d_cmeta, bias, resid, C, Cs, M, N, d_flag, none, s, d_in_range);
+    return fail(CS_ERR_UNSUPPORTED, "quantise-on-load product: epilogue %d from source kind %d is not built", epi, src_kind);
+}
+
+int32_t launch_gemm_q8_gelu_requant_from_source(const float* d_x, const uint32_t* d_in_range, const int8_t* d_wq, const Q8ColMeta* d_cmeta,
+                                                const float* bias, uint32_t M, uint32_t N, uint32_t K, uint32_t* d_range_out,
+                                                int8_t* d_out, Q8RowMeta* d_rmeta_out, hipStream_t s) {
+    if (!q8_rows_takes(M, K) || N % 128) return fail(CS_ERR_UNSUPPORTED, "quantise-on-load product: M=%u N=%u K=%u not taken by the row-block kernel", M, N, K);
+    const Q8Requant rq{d_range_out, d_out, d_rmeta_out};
+    CS_TRY((launch_rows<Q8_EPI_GELU_RANGE, Q8_SRC_F32>(d_x, nullptr, d_wq, d_cmeta, bias, nullptr, nullptr, nullptr, M, N, nullptr, rq, s, d_in_range)));
+    return launch_rows<Q8_EPI_GELU_Q8, Q8_SRC_F32>(d_x, nullptr, d_wq, d_cmeta, bias, nullptr, nullptr, nullptr, M, N, nullptr, rq, s, d_in_range);
 }
 
 int32_t launch_gemm_q8_gelu_requant(const int8_t* d_xq, const Q8RowMeta* d_rmeta, const int8_t* d_wq, const Q8ColMeta* d_cmeta,

@@ -55,6 +55,19 @@ int32_t launch_gemm_q8(int epi, const int8_t* d_xq, const Q8RowMeta* d_rmeta, co
                        const float* bias, const float* resid, float* C, _Float16* Cs, uint32_t M, uint32_t N, uint32_t K,
                        uint32_t* d_flag, hipStream_t s, int32_t* d_acc_dbg = nullptr);
 
+// From 4,096 rows a K = 384 layer can take the f32-class tensor itself (q8_rows_from_source): the product kernel's
+// blocks quantise their own rows on the way in, only the tensor's range (launch_q8_range: a reduction of the producer's
+// pairs, or a pass over the tensor) is needed first.  One quantisation unit only.  CS_Q8_ROWS_SRC=0: never.
+bool q8_rows_from_source(uint32_t M, uint32_t K);
+int32_t launch_q8_range(int src_kind, const void* d_src, uint32_t T, uint32_t K, uint32_t* d_range, hipStream_t s,
+                        const float* d_range_pairs = nullptr, uint32_t n_pairs = 0);
+int32_t launch_gemm_q8_from_source(int epi, int src_kind, const void* d_src, const uint32_t* d_in_range, const int8_t* d_wq,
+                                   const Q8ColMeta* d_cmeta, const float* bias, const float* resid, float* C, _Float16* Cs,
+                                   uint32_t M, uint32_t N, uint32_t K, uint32_t* d_flag, hipStream_t s);
+int32_t launch_gemm_q8_gelu_requant_from_source(const float* d_x, const uint32_t* d_in_range, const int8_t* d_wq, const Q8ColMeta* d_cmeta,
+                                                const float* bias, uint32_t M, uint32_t N, uint32_t K, uint32_t* d_range_out,
+                                                int8_t* d_out, Q8RowMeta* d_rmeta_out, hipStream_t s);
+
 // FFN-up of a quantised model in two passes over the same product: GELU(x W^T + b) re-quantised for FFN-down without the
 // f32-class tensor ever reaching HBM.  d_range_out (one slot, zero before the call) collects the output tensor's range;
 // d_out [M][N] s8 and d_rmeta_out [M] are the next launch_gemm_q8's operands.

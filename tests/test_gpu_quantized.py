@@ -133,6 +133,44 @@ def test_ffn_up_leaves_requantised(gpu_lib, M, N, K):
     assert np.array_equal(rows.reshape(-1)[:M], C_.astype(np.int64).sum(axis=1))   # the row sums the next product needs
 
 
+def test_row_block_products_quantise_their_own_rows(gpu_lib):
+    """From 4,096 rows a K = 384 Linear takes the f32-class tensor itself: each block of the product kernel quantises its
+    128 rows on the way in (reciprocal multiply, the true division where the two could round apart).  Same bytes, same
+    integers, so the same outputs bit for bit as the separate quantising pass."""
+    from scipy.special import erf
+
+    rng = np.random.default_rng(8)
+    M, K = 4300, 384
+    A = (rng.standard_normal((M, K)) * rng.choice([0.3, 1.0, 3.0], size=(M, 1))).astype(np.float32)
+    for N, epi, a_split in ((1152, 4, 8), (384, 2, 9)):
+        W, d, sc = quantize_matrix((rng.standard_normal((N, K)) * 0.05).astype(np.float32), True, True)
+        bias = (rng.standard_normal(N) * 0.1).astype(np.float32)
+        resid = rng.standard_normal((M, N)).astype(np.float32)
+        got = run_q8(gpu_lib, epi, A, W, sc, bias, resid if epi == 2 else None, a_split=a_split)[0]
+        ref = run_q8(gpu_lib, epi, A, W, sc, bias, resid if epi == 2 else None, a_split=a_split & 1)[0]
+        assert np.array_equal(got, ref)
+        q, xs, xz = dynamic_quantize(split_round_trip(A) if a_split & 1 else A)
+        base = (((q.astype(np.int64) - xz) @ d.T).astype(np.float32) * (xs * sc)[None, :].astype(np.float32) + bias[None, :]).astype(np.float32)
+        if epi == 2:
+            assert np.array_equal(got, (base + resid).astype(np.float32))
+        else:
+            np.testing.assert_allclose(got, base, rtol=3e-7, atol=1e-9)
+    # FFN-up (two passes, re-quantised output) from the f32 tensor
+    N = 1536
+    W, d, sc = quantize_matrix((rng.standard_normal((N, K)) * 0.05).astype(np.float32), False, True)
+    bias = (rng.standard_normal(N) * 0.1).astype(np.float32)
+    outs = []
+    for a_split in (8, 0):
+        C_ = np.empty((M, N), np.float32)
+        xp = np.empty(4, np.float32)
+        rows = np.empty((M, N), np.int32)
+        _lib.check(gpu_lib.cs_debug_gemm_q8(0, 5, a_split, A.ctypes.data_as(f32p), W.ctypes.data_as(f32p), sc.ctypes.data_as(f32p),
+                                            bias.ctypes.data_as(f32p), None, C_.ctypes.data_as(f32p), M, N, K, None,
+                                            xp.ctypes.data_as(f32p), rows.ctypes.data_as(C.POINTER(C.c_int32))))
+        outs.append((C_, xp.copy(), rows.reshape(-1)[:M].copy()))
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1][2:], outs[1][1][2:]) and np.array_equal(outs[0][2], outs[1][2])
+
+
 def test_split_form_activations_quantise_like_their_f32_values(gpu_lib):
     """Attention and GELU hand their outputs over in split-f16 form: the quantiser reads hi + lo / 2048."""
     rng = np.random.default_rng(5)
