@@ -443,3 +443,32 @@ def test_random_shapes_and_unit_mixes_stay_within_the_flip_noise(gpu_lib, oracle
         for (ids, mask), t in zip(subs, tickets):
             check(emb.wait(t), ids, mask, ("queued", ids.shape))
     emb.close()
+
+
+@pytest.mark.parametrize("hidden,heads,inter", [(768, 12, 3072), (1024, 16, 4096)])
+def test_quantised_wider_models(gpu_lib, oracle, hidden, heads, inter):
+    """hidden 768 / 1,024 (head_dim 64; K = 768 ... 4,096 in the products: the tile-per-block kernel, 24-bit zero-point
+    arithmetic at its widest).  Wider rows carry more activation bytes each: 2-15 % of the rows hold a flipped one after a
+    single layer and, in about one input in four, one of them is a tensor's extreme, which moves that tensor's scale and
+    with it every row by ~2e-3 (benchmarks/q8_wide_probe.py) — so the bar is the distance against what ignoring the
+    activation quantisation costs, as for the two-layer model."""
+    from codesearch_amd import FastEmbedder, ModelType
+
+    cfg = BertConfig(vocab_size=600, hidden=hidden, layers=1, heads=heads, intermediate=inter, max_position=64, pooling=POOL_CLS)
+    params, wscale = quantize_linear_weights(cfg, synth_params(cfg, 41), per_channel=True, unsigned=True)
+    emb = FastEmbedder(ModelType.BGEBaseENV15, config=cfg, params=params, wscale=wscale)
+    assert emb.gemm_mode() == "q8"
+    clean = 0
+    for iseed in (14, 55, 56):
+        ids, mask = synth_token_batch(cfg, iseed, 20, 48, True)
+        got = emb.embed_ids(ids, mask)
+        hid = emb.last_hidden(ids.size).reshape(ids.shape + (hidden,))
+        want = oracle.bert_forward(cfg, params, ids, mask, wscale=wscale, want_hidden=True)
+        f32_graph = oracle.bert_forward(cfg, params, ids, mask, want_hidden=True)
+        valid = mask.astype(bool)
+        err = np.abs(hid[valid] - want["hidden"][valid])
+        noise = np.abs(f32_graph["hidden"][valid] - want["hidden"][valid])
+        assert err.mean() < 0.5 * noise.mean() and np.abs(got - want["pooled"]).max() < 5e-3, (iseed, err.mean(), noise.mean())
+        clean += int(np.median(err) < 1e-6)
+    assert clean >= 1   # where no extreme moved, the rows agree to f32 rounding
+    emb.close()
