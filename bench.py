@@ -429,8 +429,40 @@ def quantized_default_model_leg(ids, mask, d_out, device, iters):
         emb.profile_stages(False)
         out[key] = {"ms_per_batch": ms, "chunks_per_s": ids.shape[0] / (ms * 1e-3),
                     "per_kernel_us_per_layer": {kn: stages[kn] / cfg.layers for kn in stage_names}}
-    out["per_kernel_note"] = ("dynamic_quantisation: each Linear's time includes the range + quantising passes over its input; "
-                              "ffn_up_gemm is the two-pass product that leaves already re-quantised for ffn_down")
+    out["per_kernel_note"] = ("dynamic_quantisation: each Linear's time includes the range reduction (and, below 4,096 rows, the "
+                              "quantising pass) over its input; ffn_up_gemm is the two-pass product that leaves already "
+                              "re-quantised for ffn_down")
+    # the reference's call shape on its default model: 32 chunks per embed call (src/embed/batch.rs:70,94), one call at a
+    # time and eight of them through the submission queue — each stays its own quantisation unit inside the shared batch
+    emb.set_gemm_mode("q8")
+    B = ids.shape[0]
+    emb.embed_ids(ids[:32], mask[:32])
+    t0 = time.perf_counter()
+    for _ in range(5):
+        for lo in range(0, B, 32):
+            emb.embed_ids(ids[lo:lo + 32], mask[lo:lo + 32])
+    one = (time.perf_counter() - t0) / 5
+
+    def queued_round():
+        ts = [emb.submit_ids(ids[lo:lo + 32], mask[lo:lo + 32]) for lo in range(0, B, 32)]
+        return [emb.wait(t) for t in ts]
+
+    queued_round()
+    emb.profile_read(reset=True)
+    walls = []
+    for _ in range(7):
+        t0 = time.perf_counter()
+        queued_round()
+        walls.append(time.perf_counter() - t0)
+    ms_q, n_q = emb.profile_read()
+    out["reference_call_shape"] = {
+        "workload": f"{B // 32} calls of 32 chunks x {ids.shape[1]} tokens, dynamic quantisation",
+        "one_call_at_a_time_chunks_per_s": B / one,
+        "queued_chunks_per_s": B / sorted(walls)[3], "queued_wall_is": "median of 7 rounds",
+        "queued_device_ms_per_round": ms_q / 7, "queued_device_batches_per_round": n_q / 7,
+        "note": "queued: one device batch, one quantisation unit per call (its own range per tensor; rows beyond a call's own "
+                "padded length stay out of it)",
+    }
     emb.close()
     return out
 
