@@ -517,6 +517,9 @@ typedef struct cs_embedders cs_embedders;
 /* One replica per entry of `devices` (a device may appear twice: two replicas share it). */
 int32_t cs_embedders_create(const cs_bert_config* cfg, const float* params, uint64_t seed, const int32_t* devices,
                             uint32_t n, cs_embedders** out);
+/* (a dynamically quantised model directory brings every replica up in CS_GEMM_Q8_DYNAMIC: a call tensor is then what ONE
+ * replica receives — cs_embedders_embed_* hand each replica whole mini-batches of the caller's order; in the index loop a
+ * replica's mini-batch is the chunks of ITS shards, not the reference's contiguous slice.) */
 int32_t cs_embedders_create_from_dir(const char* model_dir, int32_t pooling, const int32_t* devices, uint32_t n,
                                      cs_embedders** out);
 void cs_embedders_destroy(cs_embedders* e);
