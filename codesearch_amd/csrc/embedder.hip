@@ -78,7 +78,7 @@ struct cs_embedder {
     Q8RowMeta* d_rmeta = nullptr;  // [cap_tokens] (workspace): rows of the tensor being multiplied
     Q8RowMeta* d_rmeta2 = nullptr; // [cap_tokens]: rows of the re-quantised FFN intermediate
     float* d_range_pairs = nullptr; // (lo, hi) per block / wave of the kernel that produced the tensor quantised next
-    size_t cap_range_pairs = 0;
+    size_t cap_range_pairs = 0, cap_range_pairs2 = 0;
     // several quantisation units (calls of the reference) in one device batch: per sequence its unit, per unit its own
     // padded length, per row its range slot (gemm_q8.hpp); cur_units = units of the mini-batch being run (1: none of this)
     uint32_t* d_seq_unit = nullptr;
@@ -178,7 +178,9 @@ int32_t reserve(cs_embedder* h, size_t seqs, size_t tokens) {
         CS_HIP(hipMalloc(&h->d_rmeta2, tokens * sizeof(Q8RowMeta)));
         // LayerNorm: a pair per four rows; attention: four per (head group, sequence, 128 queries)
         h->cap_range_pairs = std::max<size_t>(tokens / 4 + 1, (size_t)h->cfg.heads * 4 * (tokens / 128 + seqs));
-        CS_HIP(hipMalloc(&h->d_range_pairs, h->cap_range_pairs * 2 * sizeof(float)));
+        // (+ a second set for the few-rows path: FFN-up leaves a pair per 16 x 16 output tile while it reads the first set)
+        h->cap_range_pairs2 = (size_t)(I / 16) * (tokens / 16 + 1);
+        CS_HIP(hipMalloc(&h->d_range_pairs, (h->cap_range_pairs + h->cap_range_pairs2) * 2 * sizeof(float)));
         CS_HIP(hipMalloc(&h->d_seq_unit, seqs * sizeof(uint32_t)));
         CS_HIP(hipMalloc(&h->d_unit_len, seqs * sizeof(uint32_t)));
         CS_HIP(hipMalloc(&h->d_row_slot, tokens * sizeof(uint32_t)));
@@ -305,6 +307,34 @@ int32_t forward_range(cs_embedder* h, hipStream_t s, uint32_t b0, uint32_t nb, u
             Q8RowMeta* rm = h->d_rmeta + t0;
             _Float16* qkvs = reinterpret_cast<_Float16*>(qkv);
             float* rp = h->d_range_pairs;
+            if (!rs && T <= q8_skinny_max_m() && I <= 3072 && (uint64_t)(I / 16) * ((T + 15) / 16) <= h->cap_range_pairs2) {
+                // a few token rows (queries): one launch per Linear — range reduction and quantisation inside the product
+                float* rp2 = rp + 2 * h->cap_range_pairs;
+                CS_TRY(launch_gemm_q8_skinny(SH_OUT_SPLIT, Q8_SRC_F32, x, rp, ln_pairs, wq + ql.qkv, cm, nullptr, nullptr, qkvs, T, 3 * H, H, h->d_flag,
+                                             nullptr, nullptr, s));  // E2
+                CS_TRY(mark(CS_STAGE_QKV));
+                uint32_t att_pairs = 0, up_pairs = 0;
+                CS_TRY(launch_attention_sh2(qkvs, mask, ctxs, h->d_flag, nb, L, H, c.heads, s, rp, &att_pairs));  // E3
+                CS_TRY(mark(CS_STAGE_ATTENTION));
+                if (!att_pairs) return fail(CS_ERR_UNSUPPORTED, "attention kernel without range pairs in the few-rows quantised path");
+                CS_TRY(launch_gemm_q8_skinny(SH_OUT_F32_RESID, Q8_SRC_SPLIT, ctxs, rp, att_pairs, wq + ql.ao, cm + 3 * H, x, x, nullptr, T, H, H,
+                                             h->d_flag, nullptr, nullptr, s));  // E4
+                CS_TRY(mark(CS_STAGE_OUT_PROJ));
+                a.g = P + lo.ao_ln_g; a.b = P + lo.ao_ln_b;
+                CS_TRY(launch_row_kernel(1, a, H, s));
+                CS_TRY(mark(CS_STAGE_LN_ATTN));
+                CS_TRY(launch_gemm_q8_skinny(SH_OUT_SPLIT_GELU, Q8_SRC_F32, x, rp, ln_pairs, wq + ql.up, cm + 4 * H, nullptr, nullptr, mids, T, I, H,
+                                             h->d_flag, rp2, &up_pairs, s));  // E5
+                CS_TRY(mark(CS_STAGE_FFN_UP));
+                CS_TRY(launch_gemm_q8_skinny(SH_OUT_F32_RESID, Q8_SRC_SPLIT, mids, rp2, up_pairs, wq + ql.down, cm + 4 * H + I, x, x, nullptr, T, H, I,
+                                             h->d_flag, nullptr, nullptr, s));  // E6
+                CS_TRY(mark(CS_STAGE_FFN_DOWN));
+                a.g = P + lo.out_ln_g; a.b = P + lo.out_ln_b;
+                CS_TRY(launch_row_kernel(1, a, H, s));
+                CS_TRY(mark(CS_STAGE_LN_FFN));
+                if (l + 1 == c.layers) h->last_hidden_partial = false;
+                continue;
+            }
             if (!rs && q8_rows_from_source(T, H)) {
                 // one unit, K = 384, a row block per CU: the products quantise their own rows on the way in — per tensor only
                 // its range is needed first (a reduction of the pairs its producer left)
@@ -1544,7 +1574,11 @@ int32_t cs_debug_gemm_q8(int32_t device, int32_t epilogue, int32_t a_split, cons
         }
         const int epi = epilogue == 0 ? SH_OUT_F32 : epilogue == 1 ? SH_OUT_SPLIT_GELU : epilogue == 2 ? SH_OUT_F32_RESID : SH_OUT_SPLIT;
         if (epi == SH_OUT_SPLIT_GELU || epi == SH_OUT_SPLIT) CS_HIP(hipMalloc(&sC, c_n * 4));
-        if (a_split & 8) {  // the products that quantise their own rows on the way in (row-block kernel; acc is not reported)
+        if (a_split & 4) {  // the few-rows kernel: its "pairs" are the one (lo, hi) in the slot (the words are the floats' bits)
+            if (dAcc) CS_HIP(hipMemset(dAcc, 0, c_n * 4));
+            CS_TRY(launch_gemm_q8_skinny(epi, (a_split & 1) ? Q8_SRC_SPLIT : Q8_SRC_F32, (a_split & 1) ? (const void*)sA : (const void*)dA,
+                                         reinterpret_cast<const float*>(dRange), 1, dWq, dCm, dR, dC, sC, M, N, K, dF, nullptr, nullptr, nullptr));
+        } else if (a_split & 8) {  // the products that quantise their own rows on the way in (row-block kernel; acc is not reported)
             if (dAcc) CS_HIP(hipMemset(dAcc, 0, c_n * 4));
             CS_TRY(launch_gemm_q8_from_source(epi, (a_split & 1) ? Q8_SRC_SPLIT : Q8_SRC_F32, (a_split & 1) ? (const void*)sA : (const void*)dA, dRange,
                                               dWq, dCm, dB, dR, dC, sC, M, N, K, dF, nullptr));

@@ -552,6 +552,165 @@ gemm_q8_kernel(const int8_t* __restrict__ A, const int8_t* __restrict__ W, const
 }
 
 
+// ---- a few token rows (query-side forwards): one launch per Linear --------------------------------------------------------
+// A one-query forward is latency-bound: range reduction, quantising pass and product are three dependent launches per
+// Linear, seventeen per layer (0.55 ms against 0.20 for the split-f16 path's skinny kernels; 0.25 with this kernel).  Here a block owns ONE
+// 16 x 16 output tile (as gemm_sh_skinny_kernel): it reduces the (lo, hi) pairs its input's producer left, quantises
+// its 16 activation rows over all of K into LDS — the same division and rounding, so the same bytes as
+// q8_quantize_kernel — and its four waves split K between them, weights global -> VGPR in MFMA operand order, every load of
+// a wave in flight at once; the four partial tiles meet in LDS.  With the FFN-up launch leaving the (lo, hi) of what each
+// block stored, a layer is seven launches.  One quantisation unit only.
+template <int EPI, int SRC>
+__global__ void __launch_bounds__(256)
+gemm_q8_skinny_kernel(const void* __restrict__ src, const float* __restrict__ range_pairs, uint32_t n_pairs,
+                      const int8_t* __restrict__ W, const Q8ColMeta* __restrict__ cmeta, const float* resid, float* C,
+                      _Float16* __restrict__ Cs, uint32_t M, uint32_t N, uint32_t K, uint32_t* __restrict__ flag,
+                      float* __restrict__ range_out) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];  // [16][K + 16] s8: the block's quantised rows
+    __shared__ float s_lo[4], s_hi[4];
+    __shared__ int s_rowsum[16];
+    __shared__ int red[4][16][17];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, g = lane >> 4;
+    const uint32_t n0 = blockIdx.x * 16, m0 = blockIdx.y * 16;
+    const uint32_t astride = K + 16;
+    // this wave's weight fragments first: k-steps wave, wave + 4, ... of 64 (they do not depend on the activations)
+    const uint32_t ksteps = K / 64;
+    const uint32_t mine = ksteps > (uint32_t)wave ? (ksteps - wave + 3) / 4 : 0;
+    const int8_t* wp = W + (size_t)(n0 + l15) * K + g * 16;
+    constexpr int U = 6;  // K = 1536: six steps per wave; beyond that the loop runs again
+    q8_i32x4 wf[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const uint32_t i = (uint32_t)u < mine ? u : (mine ? mine - 1 : 0);
+        wf[u] = mine ? *reinterpret_cast<const q8_i32x4*>(wp + (size_t)(wave + 4 * i) * 64) : q8_i32x4{0, 0, 0, 0};
+    }
+    // the tensor's range from its producer's pairs
+    float lo = 0.0f, hi = 0.0f;
+    for (uint32_t i = tid; i < n_pairs; i += 256) {
+        const float2 p = reinterpret_cast<const float2*>(range_pairs)[i];
+        lo = fminf(lo, p.x);
+        hi = fmaxf(hi, p.y);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        lo = fminf(lo, __shfl_xor(lo, o));
+        hi = fmaxf(hi, __shfl_xor(hi, o));
+    }
+    if (lane == 0) { s_lo[wave] = lo; s_hi[wave] = hi; }
+    if (tid < 16) s_rowsum[tid] = 0;
+    __syncthreads();
+    float xs, xz;
+    q8_params_of(fminf(fminf(s_lo[0], s_lo[1]), fminf(s_lo[2], s_lo[3])), fmaxf(fmaxf(s_hi[0], s_hi[1]), fmaxf(s_hi[2], s_hi[3])), xs, xz);
+    const int za = (int)xz - 128;
+    // 16 rows x K / 16 slots of 16 k
+    const uint32_t spr = K / 16;
+    for (uint32_t sidx = tid; sidx < 16 * spr; sidx += 256) {
+        const uint32_t row = sidx / spr, sl = sidx - row * spr;
+        const uint32_t m = (m0 + row < M) ? m0 + row : M - 1;  // rows past M repeat the last one: never stored
+        float v[16];
+        if (SRC == Q8_SRC_F32) {
+            const sh_f32x4* p = reinterpret_cast<const sh_f32x4*>(reinterpret_cast<const float*>(src) + (size_t)m * K + sl * 16);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const sh_f32x4 t = p[q];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[4 * q + e] = t[e];
+            }
+        } else {  // 16 k = half a 32-k line: 16 hi halves, their 16 lo halves 64 B further on
+            const _Float16* p = reinterpret_cast<const _Float16*>(src) + ((size_t)m * (K / 32) + (sl >> 1)) * 64 + (sl & 1) * 16;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const f16x8 h = *reinterpret_cast<const f16x8*>(p + 8 * q);
+                const f16x8 l = *reinterpret_cast<const f16x8*>(p + 32 + 8 * q);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[8 * q + e] = (float)h[e] + (float)l[e] * kShLoInv;
+            }
+        }
+        q8_i32x4 packed;
+        int sum = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            uint32_t pw = 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float q = fminf(fmaxf(__fadd_rn(rintf(__fdiv_rn(v[4 * w + e], xs)), xz), 0.0f), 255.0f);
+                const int a = (int)q - 128;
+                sum += a;
+                pw |= (uint32_t)(a & 0xff) << (8 * e);
+            }
+            packed[w] = (int)pw;
+        }
+        *reinterpret_cast<q8_i32x4*>(lds + row * astride + sl * 16) = packed;
+        atomicAdd(&s_rowsum[row], sum);
+    }
+    __syncthreads();
+    q8_i32x4 acc = {0, 0, 0, 0};
+    for (uint32_t i0 = 0; i0 < mine; i0 += U) {
+        if (i0) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint32_t i = i0 + u < mine ? i0 + u : mine - 1;
+                wf[u] = *reinterpret_cast<const q8_i32x4*>(wp + (size_t)(wave + 4 * i) * 64);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (i0 + u < mine) {  // wave-uniform
+                const q8_i32x4 a = *reinterpret_cast<const q8_i32x4*>(lds + l15 * astride + (size_t)(wave + 4 * (i0 + u)) * 64 + g * 16);
+                acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, wf[u], acc, 0, 0, 0);
+            }
+        }
+    }
+    // C/D layout of the 16x16 MFMA: n = lane & 15, m = 4 (lane >> 4) + r
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[wave][4 * g + r][l15] = acc[r];
+    __syncthreads();
+    const int m = tid >> 4, n = tid & 15;
+    const uint32_t row = m0 + m, col = n0 + n;
+    const Q8ColMeta cm = cmeta[col];
+    const int total = (red[0][m][n] + red[1][m][n]) + (red[2][m][n] + red[3][m][n]);
+    const int corr = total - __mul24(cm.zw, s_rowsum[m] - (int)K * za) - __mul24(za, cm.colsum);
+    float v = __fadd_rn(__fmul_rn((float)corr, __fmul_rn(xs, cm.ws)), cm.bias);
+    float rlo = 0.0f, rhi = 0.0f;
+    bool ovf = false;
+    if (EPI == SH_OUT_F32 || EPI == SH_OUT_F32_RESID) {
+        if (row < M) {
+            if (EPI == SH_OUT_F32_RESID) v += resid[(size_t)row * N + col];
+            C[(size_t)row * N + col] = v;
+        }
+    } else {
+        if (EPI == SH_OUT_SPLIT_GELU) v = sh_gelu_erf(v);
+        _Float16 h16, l16;
+        ovf = sh_split(v, h16, l16);
+        if (row < M) {
+            _Float16* dst = Cs + ((size_t)row * (N / 32) + (col >> 5)) * 64 + (col & 31);
+            dst[0] = h16;
+            dst[32] = l16;
+            const float stored = fmaf((float)l16, kShLoInv, (float)h16);  // what the next Linear's quantiser will read
+            rlo = fminf(rlo, stored);
+            rhi = fmaxf(rhi, stored);
+        }
+        if (ovf && flag) atomicOr(flag, 1u);
+    }
+    if (range_out) {  // this block's (lo, hi) of what it stored, for the Linear that follows
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            rlo = fminf(rlo, __shfl_xor(rlo, o));
+            rhi = fmaxf(rhi, __shfl_xor(rhi, o));
+        }
+        __syncthreads();
+        if (lane == 0) { s_lo[wave] = rlo; s_hi[wave] = rhi; }
+        __syncthreads();
+        if (tid == 0) {
+            const size_t b = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+            range_out[2 * b] = fminf(fminf(s_lo[0], s_lo[1]), fminf(s_lo[2], s_lo[3]));
+            range_out[2 * b + 1] = fmaxf(fmaxf(s_hi[0], s_hi[1]), fmaxf(s_hi[2], s_hi[3]));
+        }
+    }
+}
+
 // ---- K = 384 (hidden 384: MiniLM, BGE-small): activations in registers, weights streamed a whole n-tile ahead ------------
 // In gemm_q8_kernel a 128 x 128 tile with K = 384 is three k-steps, each waiting a full L2 round trip for the next stage
 // with two blocks per CU to cover it: 9 us per tile where the MFMAs are 0.8 (profiles/r04_q8_minilm_l6_kernel_stats.csv).
@@ -1088,6 +1247,35 @@ int32_t launch_gemm_q8_from_source(int epi, int src_kind, const void* d_src, con
     if (epi == SH_OUT_F32_RESID && src_kind == Q8_SRC_SPLIT)
         return launch_rows<SH_OUT_F32_RESID, Q8_SRC_SPLIT>(d_src, nullptr, d_wq, d_cmeta, bias, resid, C, Cs, M, N, d_flag, none, s, d_in_range);
     return fail(CS_ERR_UNSUPPORTED, "quantise-on-load product: epilogue %d from source kind %d is not built", epi, src_kind);
+}
+
+uint32_t q8_skinny_max_m() {
+    static const uint32_t v = [] { const char* e = std::getenv("CS_Q8_SKINNY_MAX_M"); return e ? (uint32_t)std::atoll(e) : 512u; }();
+    return v;
+}
+
+int32_t launch_gemm_q8_skinny(int epi, int src_kind, const void* d_src, const float* d_range_pairs, uint32_t n_pairs,
+                              const int8_t* d_wq, const Q8ColMeta* d_cmeta, const float* resid, float* C, _Float16* Cs, uint32_t M,
+                              uint32_t N, uint32_t K, uint32_t* d_flag, float* d_range_out, uint32_t* out_pairs, hipStream_t s) {
+    if (out_pairs) *out_pairs = 0;
+    if (N % 32 || K % 64 || K == 0) return fail(CS_ERR_UNSUPPORTED, "quantised GEMM N=%u K=%u must be multiples of 32 / 64", N, K);
+    if (M == 0) return CS_OK;
+    const dim3 grid(N / 16, (M + 15) / 16);
+    const size_t lds = (size_t)16 * (K + 16);
+#define CS_Q8S(E, S) hipLaunchKernelGGL((gemm_q8_skinny_kernel<E, S>), grid, dim3(256), lds, s, d_src, d_range_pairs, n_pairs, d_wq, d_cmeta, \
+                                        resid, C, Cs, M, N, K, d_flag, d_range_out)
+    const bool f32src = src_kind == Q8_SRC_F32;
+    if (epi == SH_OUT_SPLIT && f32src) CS_Q8S(SH_OUT_SPLIT, Q8_SRC_F32);
+    else if (epi == SH_OUT_SPLIT_GELU && f32src) CS_Q8S(SH_OUT_SPLIT_GELU, Q8_SRC_F32);
+    else if (epi == SH_OUT_F32_RESID && !f32src) CS_Q8S(SH_OUT_F32_RESID, Q8_SRC_SPLIT);
+    else if (epi == SH_OUT_F32 && f32src) CS_Q8S(SH_OUT_F32, Q8_SRC_F32);
+    else if (epi == SH_OUT_F32_RESID && f32src) CS_Q8S(SH_OUT_F32_RESID, Q8_SRC_F32);
+    else if (epi == SH_OUT_SPLIT && !f32src) CS_Q8S(SH_OUT_SPLIT, Q8_SRC_SPLIT);
+    else return fail(CS_ERR_UNSUPPORTED, "few-rows quantised product: epilogue %d from source kind %d is not built", epi, src_kind);
+#undef CS_Q8S
+    CS_HIP(hipGetLastError());
+    if (out_pairs && d_range_out) *out_pairs = grid.x * grid.y;
+    return CS_OK;
 }
 
 int32_t launch_gemm_q8_gelu_requant_from_source(const float* d_x, const uint32_t* d_in_range, const int8_t* d_wq, const Q8ColMeta* d_cmeta,

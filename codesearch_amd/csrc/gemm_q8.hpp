@@ -68,6 +68,14 @@ int32_t launch_gemm_q8_gelu_requant_from_source(const float* d_x, const uint32_t
                                                 const float* bias, uint32_t M, uint32_t N, uint32_t K, uint32_t* d_range_out,
                                                 int8_t* d_out, Q8RowMeta* d_rmeta_out, hipStream_t s);
 
+// A few token rows (up to q8_skinny_max_m; CS_Q8_SKINNY_MAX_M, 0 = never): one launch per Linear — each block reduces
+// the (lo, hi) pairs its input's producer left, quantises its 16 rows into LDS and multiplies one 16 x 16 tile with K
+// split over its waves.  With d_range_out every block leaves the (lo, hi) of what it stored (*out_pairs of them).
+uint32_t q8_skinny_max_m();
+int32_t launch_gemm_q8_skinny(int epi, int src_kind, const void* d_src, const float* d_range_pairs, uint32_t n_pairs,
+                              const int8_t* d_wq, const Q8ColMeta* d_cmeta, const float* resid, float* C, _Float16* Cs, uint32_t M,
+                              uint32_t N, uint32_t K, uint32_t* d_flag, float* d_range_out, uint32_t* out_pairs, hipStream_t s);
+
 // FFN-up of a quantised model in two passes over the same product: GELU(x W^T + b) re-quantised for FFN-down without the
 // f32-class tensor ever reaching HBM.  d_range_out (one slot, zero before the call) collects the output tensor's range;
 // d_out [M][N] s8 and d_rmeta_out [M] are the next launch_gemm_q8's operands.

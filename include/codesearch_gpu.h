@@ -580,7 +580,8 @@ int32_t cs_debug_gemm(int32_t device, int32_t mode, int32_t epilogue, const floa
 
 /* Diagnostics: one dynamically quantised dense layer on host buffers (unit parity of csrc/gemm_q8.hip against the ONNX
  * definitions of DynamicQuantizeLinear / MatMulInteger).  A [M,K] f32 activations (a_split & 1: staged through the
- * split-f16 form first, as attention and GELU hand them over; a_split & 8: the row-block products that quantise their own
+ * split-f16 form first, as attention and GELU hand them over; a_split & 4: the few-rows kernel (one launch: range from
+ * pairs, quantisation and product; epilogues 0 / 1 / 2 / 4 as built for the encoder's chain, acc not reported); a_split & 8: the row-block products that quantise their own
  * rows on the way in — K = 384, M >= 4,096, epilogues 4 (f32 source), 2 (split source) and 5; acc then not reported); W [N,K] f32 = integer multiples of wscale[n]; epilogue as
  * cs_debug_gemm 0 / 1 / 2, 4 = bias -> split store.  Optional outputs: xq [M,K] the uint8 activations, xparams[2] =
  * (x_scale, x_zero_point), acc [M,N] the int32 MatMulInteger result.  N % 128 == 0, K % 128 == 0.

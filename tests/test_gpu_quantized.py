@@ -133,6 +133,21 @@ def test_ffn_up_leaves_requantised(gpu_lib, M, N, K):
     assert np.array_equal(rows.reshape(-1)[:M], C_.astype(np.int64).sum(axis=1))   # the row sums the next product needs
 
 
+@pytest.mark.parametrize("M,N,K,epi,a_split", [(16, 1152, 384, 4, 4), (9, 384, 384, 2, 5), (200, 1536, 384, 1, 4),
+                                               (33, 384, 1536, 2, 5), (1, 384, 384, 0, 4)])
+def test_few_rows_kernel_is_one_launch_with_the_same_bits(gpu_lib, M, N, K, epi, a_split):
+    """Query-side forwards run one launch per Linear (gemm_q8_skinny_kernel: range from the producer's pairs, the
+    block's 16 rows quantised into LDS, K split over the waves): the same bytes and integers as the three-launch form."""
+    rng = np.random.default_rng(M + N + K)
+    A = (rng.standard_normal((M, K)) * 1.3).astype(np.float32)
+    W, d, sc = quantize_matrix((rng.standard_normal((N, K)) * 0.05).astype(np.float32), True, False)
+    bias = (rng.standard_normal(N) * 0.1).astype(np.float32)
+    resid = rng.standard_normal((M, N)).astype(np.float32) if epi == 2 else None
+    got = run_q8(gpu_lib, epi, A, W, sc, bias, resid, a_split=a_split)[0]
+    ref = run_q8(gpu_lib, epi, A, W, sc, bias, resid, a_split=a_split & 1)[0]
+    assert np.array_equal(got, ref)
+
+
 def test_row_block_products_quantise_their_own_rows(gpu_lib):
     """From 4,096 rows a K = 384 Linear takes the f32-class tensor itself: each block of the product kernel quantises its
     128 rows on the way in (reciprocal multiply, the true division where the two could round apart).  Same bytes, same
