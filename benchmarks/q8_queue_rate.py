@@ -44,6 +44,16 @@ def main():
         ms, n = emb.profile_read()
         out[mode] = {"one_call_at_a_time_chunks_per_s": 256 / one, "queued_chunks_per_s": 256 / q,
                      "device_ms_per_8_calls_queued": ms / 10, "device_batches_per_8_calls": n / 10}
+        if "--stages" in sys.argv:  # per-kernel-class microseconds per layer of the shared device batch (8 units)
+            emb.profile_stages(True)
+            queued()
+            emb.profile_stages_read(reset=True)
+            for _ in range(3):
+                queued()
+            st, nf = emb.profile_stages_read()
+            emb.profile_stages(False)
+            out[mode]["queued_stages_us_per_layer"] = {
+                k: round(v / (cfg.layers if k not in ("embed_ln", "pool_normalize") else 1), 1) for k, v in st.items()}
     print(json.dumps(out))
 
 

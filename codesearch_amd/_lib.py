@@ -161,6 +161,8 @@ SIGNATURES = {
                                        C.c_int32, f64p]),
     "cs_debug_gemm_q8": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32, f32p, f32p, f32p, f32p, f32p, f32p, C.c_uint32,
                                      C.c_uint32, C.c_uint32, C.POINTER(C.c_uint8), f32p, i32p]),
+    "cs_debug_gemm_q8_units": (C.c_int32, [C.c_int32, C.c_int32, f32p, f32p, f32p, f32p, f32p, f32p, C.c_uint32, C.c_uint32,
+                                           C.c_uint32, u32p, C.c_uint32, f32p, i32p]),
     "cs_debug_gemm": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32, f32p, f32p, f32p, f32p, f32p,
                                   C.c_uint32, C.c_uint32, C.c_uint32, u32p]),
 }

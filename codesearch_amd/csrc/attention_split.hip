@@ -225,7 +225,8 @@ template <int NC>
 __global__ void __launch_bounds__(256, 2)
 attention_shx_kernel(const _Float16* __restrict__ qkvs, const int32_t* __restrict__ mask,
                      _Float16* __restrict__ ctxs, uint32_t* __restrict__ flag, uint32_t L, uint32_t H,
-                     float scale_log2e, uint32_t HB, float* __restrict__ range_out) {
+                     float scale_log2e, uint32_t HB, float* __restrict__ range_out,
+                     const uint32_t* __restrict__ seq_unit, const uint32_t* __restrict__ unit_len) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int KT = 128;                        // keys per super-tile
     const uint32_t Lp = (L + 31) & ~31u;
@@ -479,15 +480,17 @@ attention_shx_kernel(const _Float16* __restrict__ qkvs, const int32_t* __restric
     AT_STAMP(2);
     if (ovf && flag) atomicOr(flag, 1u);
     // Dynamic-quantised models quantise this tensor next (gemm_q8.hip): one (lo, hi) per wave instead of a range pass
-    // over the stored tensor — range_out [blocks][4 waves][2]
+    // over the stored tensor — range_out [sequence][query block][head group][4 waves][2].  With several quantisation units
+    // in the batch a query row beyond its unit's own padded length is not part of the tensor the reference quantises.
     if (range_out) {
+        if (unit_len && query >= unit_len[seq_unit[b]]) rlo = rhi = 0.0f;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
             rlo = fminf(rlo, __shfl_xor(rlo, o, 64));
             rhi = fmaxf(rhi, __shfl_xor(rhi, o, 64));
         }
         if (lane == 0) {
-            const size_t blk = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+            const size_t blk = ((size_t)blockIdx.y * gridDim.z + blockIdx.z) * gridDim.x + blockIdx.x;
             _Float16 a, bb;
             (void)sh_split(rlo, a, bb);
             range_out[(blk * 4 + wave) * 2] = fmaf((float)bb, kShLoInv, (float)a);
@@ -499,7 +502,7 @@ attention_shx_kernel(const _Float16* __restrict__ qkvs, const int32_t* __restric
 
 int32_t launch_attention_sh2(const _Float16* qkv_split, const int32_t* mask, void* ctx_split, uint32_t* flag,
                              uint32_t B, uint32_t L, uint32_t H, uint32_t heads, hipStream_t s, float* range_out,
-                             uint32_t* range_pairs) {
+                             uint32_t* range_pairs, const uint32_t* seq_unit, const uint32_t* unit_len) {
     if (range_pairs) *range_pairs = 0;
     const uint32_t dh = heads ? H / heads : 0;
     if ((dh != 32 && dh != 64) || H % heads)
@@ -514,7 +517,7 @@ int32_t launch_attention_sh2(const _Float16* qkv_split, const int32_t* mask, voi
             return CS_OK;
         }));
         hipLaunchKernelGGL(attention_shx_kernel<2>, dim3(heads, B, (L + 127) / 128), dim3(256), lds, s, qkv_split, mask,
-                           static_cast<_Float16*>(ctx_split), flag, L, H, (1.0f / sqrtf(64.0f)) * kLog2e, 1u, range_out);
+                           static_cast<_Float16*>(ctx_split), flag, L, H, (1.0f / sqrtf(64.0f)) * kLog2e, 1u, range_out, seq_unit, unit_len);
         if (range_pairs) *range_pairs = heads * B * ((L + 127) / 128) * 4;
         CS_HIP(hipGetLastError());
         return CS_OK;
@@ -541,7 +544,7 @@ int32_t launch_attention_sh2(const _Float16* qkv_split, const int32_t* mask, voi
         uint32_t hb = !pack_heads ? 1u : (Lp <= 32 ? 4u : (Lp <= 64 ? 2u : 1u));  // heads per block (kernel comment)
         while (heads % hb) hb >>= 1;
         hipLaunchKernelGGL(attention_shx_kernel<1>, dim3(heads / hb, B, (L + 127) / 128), dim3(256), lds1, s, qkv_split, mask,
-                           static_cast<_Float16*>(ctx_split), flag, L, H, (1.0f / sqrtf(32.0f)) * kLog2e, hb, range_out);
+                           static_cast<_Float16*>(ctx_split), flag, L, H, (1.0f / sqrtf(32.0f)) * kLog2e, hb, range_out, seq_unit, unit_len);
         if (range_pairs) *range_pairs = (heads / hb) * B * ((L + 127) / 128) * 4;
         CS_HIP(hipGetLastError());
         return CS_OK;

@@ -176,8 +176,9 @@ int32_t reserve(cs_embedder* h, size_t seqs, size_t tokens) {
     if (h->quantized) {
         CS_HIP(hipMalloc(&h->d_rmeta, tokens * sizeof(Q8RowMeta)));
         CS_HIP(hipMalloc(&h->d_rmeta2, tokens * sizeof(Q8RowMeta)));
-        // LayerNorm: a pair per four rows; attention: four per (head group, sequence, 128 queries)
-        h->cap_range_pairs = std::max<size_t>(tokens / 4 + 1, (size_t)h->cfg.heads * 4 * (tokens / 128 + seqs));
+        // LayerNorm: a pair per four rows (per row with several units in the batch); attention: four per (head group,
+        // sequence, 128 queries)
+        h->cap_range_pairs = std::max<size_t>(tokens + 1, (size_t)h->cfg.heads * 4 * (tokens / 128 + seqs));
         // (+ a second set for the few-rows path: FFN-up leaves a pair per 16 x 16 output tile while it reads the first set)
         h->cap_range_pairs2 = (size_t)(I / 16) * (tokens / 16 + 1);
         CS_HIP(hipMalloc(&h->d_range_pairs, (h->cap_range_pairs + h->cap_range_pairs2) * 2 * sizeof(float)));
@@ -231,6 +232,11 @@ int32_t forward_range(cs_embedder* h, hipStream_t s, uint32_t b0, uint32_t nb, u
     a.flag = h->d_flag;
     if (q8) a.range_out = h->d_range_pairs;  // LayerNorm leaves its blocks' ranges for the quantising pass that follows
     const uint32_t ln_pairs = (T + 3) / 4;
+    // several quantisation units in a batch the row-block kernels take: every product quantises its own rows with their
+    // unit's parameters, the producers' pairs are reduced per unit (LayerNorm: a pair per row)
+    static const bool q8_mu_on = [] { const char* e = std::getenv("CS_Q8_ROWS_UNITS"); return !(e && e[0] == '0'); }();
+    const bool q8_mu = q8 && q8_mu_on && h->cur_units > 1 && q8_rows_from_source(T, H) && T <= h->cap_range_pairs;
+    a.range_rows = q8_mu;
     _Float16* xs = reinterpret_cast<_Float16*>(h->d_xs + t0 * H);
     _Float16* ctxs = reinterpret_cast<_Float16*>(ctx);
     _Float16* mids = reinterpret_cast<_Float16*>(mid);
@@ -365,6 +371,37 @@ int32_t forward_range(cs_embedder* h, hipStream_t s, uint32_t b0, uint32_t nb, u
                 continue;
             }
             if (rs && l == 0) CS_TRY(launch_q8_row_slots(h->d_seq_unit, h->d_unit_len, T, L, h->d_row_slot, s));
+            if (q8_mu) {
+                // the one-unit path above with every range kept per unit
+                const uint32_t* su = h->d_seq_unit + b0;
+                CS_TRY(launch_q8_range_units(rp, L, true, su, h->d_unit_len, nb, U, rg, s));
+                CS_TRY(launch_gemm_q8_from_source(SH_OUT_SPLIT, Q8_SRC_F32, x, rg, wq + ql.qkv, cm, bqkv, nullptr, nullptr, qkvs, T, 3 * H, H, h->d_flag, s, rs));  // E2
+                CS_TRY(mark(CS_STAGE_QKV));
+                uint32_t att_pairs = 0;
+                CS_TRY(launch_attention_sh2(qkvs, mask, ctxs, h->d_flag, nb, L, H, c.heads, s, rp, &att_pairs, su, h->d_unit_len));  // E3
+                CS_TRY(mark(CS_STAGE_ATTENTION));
+                if (!att_pairs || att_pairs > h->cap_range_pairs)
+                    return fail(CS_ERR_HIP, "attention range pairs (%u) do not fit the pair buffer (%zu)", att_pairs, h->cap_range_pairs);
+                CS_TRY(launch_q8_range_units(rp, att_pairs / nb, false, su, h->d_unit_len, nb, U, rg + rstep, s));
+                CS_TRY(launch_gemm_q8_from_source(SH_OUT_F32_RESID, Q8_SRC_SPLIT, ctxs, rg + rstep, wq + ql.ao, cm + 3 * H, P + lo.ao_b, x, x, nullptr, T, H, H,
+                                                  h->d_flag, s, rs));  // E4
+                CS_TRY(mark(CS_STAGE_OUT_PROJ));
+                a.g = P + lo.ao_ln_g; a.b = P + lo.ao_ln_b;
+                CS_TRY(launch_row_kernel(1, a, H, s));
+                CS_TRY(mark(CS_STAGE_LN_ATTN));
+                CS_TRY(launch_q8_range_units(rp, L, true, su, h->d_unit_len, nb, U, rg + 2 * rstep, s));
+                int8_t* midq = reinterpret_cast<int8_t*>(mid);
+                Q8RowMeta* rm2 = h->d_rmeta2 + t0;
+                CS_TRY(launch_gemm_q8_gelu_requant_from_source(x, rg + 2 * rstep, wq + ql.up, cm + 4 * H, P + lo.up_b, T, I, H, rg + 3 * rstep, midq, rm2, s, rs));  // E5
+                CS_TRY(mark(CS_STAGE_FFN_UP));
+                CS_TRY(launch_gemm_q8(SH_OUT_F32_RESID, midq, rm2, wq + ql.down, cm + 4 * H + I, P + lo.down_b, x, x, nullptr, T, H, I, h->d_flag, s));  // E6
+                CS_TRY(mark(CS_STAGE_FFN_DOWN));
+                a.g = P + lo.out_ln_g; a.b = P + lo.out_ln_b;
+                CS_TRY(launch_row_kernel(1, a, H, s));
+                CS_TRY(mark(CS_STAGE_LN_FFN));
+                if (l + 1 == c.layers) h->last_hidden_partial = false;
+                continue;
+            }
             CS_TRY(launch_q8_quantize(Q8_SRC_F32, x, T, H, rg, rs, xq, rm, s, rp, ln_pairs));
             CS_TRY(launch_gemm_q8(SH_OUT_SPLIT, xq, rm, wq + ql.qkv, cm, bqkv, nullptr, nullptr, qkvs, T, 3 * H, H, h->d_flag, s));  // E2
             CS_TRY(mark(CS_STAGE_QKV));
@@ -1614,6 +1651,107 @@ int32_t cs_debug_gemm_q8(int32_t device, int32_t epilogue, int32_t a_split, cons
     const int32_t st = run();
     for (void* p : {(void*)dA, (void*)dW, (void*)dS, (void*)dB, (void*)dR, (void*)dC, (void*)sA, (void*)sC, (void*)dXq, (void*)dWq,
                     (void*)dRm, (void*)dCm, (void*)dF, (void*)dRange, (void*)dAcc})
+        if (p) (void)hipFree(p);
+    return st;
+}
+
+// Diagnostics: the row-block products over a tensor of SEVERAL quantisation units (queued calls in one device batch):
+// row_slot [M] as launch_q8_quantize takes it.  epilogue 4 (f32 source -> split store), 2 (split source, + residual) or
+// 5 (FFN-up: GELU, quantised again per unit).  row_params [M][4] = per row (x_scale, x_zero_point, out_scale,
+// out_zero_point) — the last two only for epilogue 5, where rowsums [M] receives each output row's sum of uint8 values.
+int32_t cs_debug_gemm_q8_units(int32_t device, int32_t epilogue, const float* A, const float* W, const float* wscale,
+                               const float* bias, const float* resid, float* C, uint32_t M, uint32_t N, uint32_t K,
+                               const uint32_t* row_slot, uint32_t units, float* row_params, int32_t* rowsums) {
+    if (!A || !W || !wscale || !bias || !C || !row_slot || (epilogue == 2 && !resid)) return fail(CS_ERR_BAD_ARG, "null buffer");
+    if (epilogue != 2 && epilogue != 4 && epilogue != 5) return fail(CS_ERR_BAD_ARG, "unknown epilogue %d", epilogue);
+    if (M == 0 || units == 0 || N % 128 || !q8_rows_from_source(M, K))
+        return fail(CS_ERR_UNSUPPORTED, "cs_debug_gemm_q8_units: M=%u N=%u K=%u is not a row-block product", M, N, K);
+    for (uint32_t m = 0; m < M; ++m)
+        if ((row_slot[m] & 0x7fffffffu) >= units || (m && (row_slot[m] & 0x7fffffffu) < (row_slot[m - 1] & 0x7fffffffu)))
+            return fail(CS_ERR_BAD_ARG, "row_slot[%u]: units must be consecutive runs of rows, in order", m);
+    int ndev = 0;
+    CS_HIP(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) return fail(CS_ERR_HIP, "HIP device %d not available (%d visible)", device, ndev);
+    DeviceGuard g(device);
+    const size_t a_n = (size_t)M * K, w_n = (size_t)N * K, c_n = (size_t)M * N;
+    float *dA = nullptr, *dW = nullptr, *dS = nullptr, *dB = nullptr, *dR = nullptr, *dC = nullptr;
+    _Float16 *sA = nullptr, *sC = nullptr;
+    int8_t *dXq = nullptr, *dWq = nullptr, *dOut = nullptr;
+    Q8RowMeta *dRm = nullptr, *dRm2 = nullptr;
+    Q8ColMeta* dCm = nullptr;
+    uint32_t *dF = nullptr, *dRange = nullptr, *dRange2 = nullptr, *dSlot = nullptr;
+    auto run = [&]() -> int32_t {
+        const size_t rbytes = (size_t)units * Q8_RANGE_WORDS * 4;
+        CS_HIP(hipMalloc(&dA, a_n * 4)); CS_HIP(hipMalloc(&dW, w_n * 4)); CS_HIP(hipMalloc(&dS, (size_t)N * 4));
+        CS_HIP(hipMalloc(&dB, (size_t)N * 4)); CS_HIP(hipMalloc(&dC, c_n * 4)); CS_HIP(hipMalloc(&dF, 16));
+        CS_HIP(hipMalloc(&dXq, a_n)); CS_HIP(hipMalloc(&dWq, w_n)); CS_HIP(hipMalloc(&dRm, (size_t)M * sizeof(Q8RowMeta)));
+        CS_HIP(hipMalloc(&dCm, (size_t)N * sizeof(Q8ColMeta))); CS_HIP(hipMalloc(&dRange, rbytes)); CS_HIP(hipMalloc(&dRange2, rbytes));
+        CS_HIP(hipMalloc(&dSlot, (size_t)M * 4));
+        CS_HIP(hipMemcpy(dA, A, a_n * 4, hipMemcpyHostToDevice));
+        CS_HIP(hipMemcpy(dW, W, w_n * 4, hipMemcpyHostToDevice));
+        CS_HIP(hipMemcpy(dS, wscale, (size_t)N * 4, hipMemcpyHostToDevice));
+        CS_HIP(hipMemcpy(dB, bias, (size_t)N * 4, hipMemcpyHostToDevice));
+        CS_HIP(hipMemcpy(dSlot, row_slot, (size_t)M * 4, hipMemcpyHostToDevice));
+        CS_HIP(hipMemset(dF, 0, 16));
+        CS_HIP(hipMemset(dRange, 0, rbytes));
+        CS_HIP(hipMemset(dRange2, 0, rbytes));
+        CS_TRY(launch_q8_pack_weight(dW, dS, dB, N, K, dWq, dCm, dF + 1, nullptr));
+        // the units' ranges by a pass over the tensor (the quantised rows this also writes only serve row_params)
+        if (epilogue == 2) {
+            CS_HIP(hipMalloc(&sA, a_n * 4));
+            CS_HIP(hipMalloc(&dR, c_n * 4));
+            CS_HIP(hipMemcpy(dR, resid, c_n * 4, hipMemcpyHostToDevice));
+            CS_TRY(launch_split_rows(dA, sA, M, K, dF, nullptr));
+            CS_TRY(launch_q8_quantize(Q8_SRC_SPLIT, sA, M, K, dRange, dSlot, dXq, dRm, nullptr));
+            CS_TRY(launch_gemm_q8_from_source(SH_OUT_F32_RESID, Q8_SRC_SPLIT, sA, dRange, dWq, dCm, dB, dR, dC, nullptr, M, N, K, dF, nullptr, dSlot));
+        } else {
+            CS_TRY(launch_q8_quantize(Q8_SRC_F32, dA, M, K, dRange, dSlot, dXq, dRm, nullptr));
+            if (epilogue == 4) {
+                CS_HIP(hipMalloc(&sC, c_n * 4));
+                CS_TRY(launch_gemm_q8_from_source(SH_OUT_SPLIT, Q8_SRC_F32, dA, dRange, dWq, dCm, dB, nullptr, nullptr, sC, M, N, K, dF, nullptr, dSlot));
+            } else {
+                CS_HIP(hipMalloc(&dOut, c_n));
+                CS_HIP(hipMalloc(&dRm2, (size_t)M * sizeof(Q8RowMeta)));
+                CS_TRY(launch_gemm_q8_gelu_requant_from_source(dA, dRange, dWq, dCm, dB, M, N, K, dRange2, dOut, dRm2, nullptr, dSlot));
+            }
+        }
+        CS_HIP(hipDeviceSynchronize());
+        uint32_t flags[2] = {0, 0};
+        CS_HIP(hipMemcpy(flags, dF, 8, hipMemcpyDeviceToHost));
+        if (flags[1]) return fail(CS_ERR_BAD_ARG, "cs_debug_gemm_q8_units: W is not a quantised matrix for these column scales (flag %u)", flags[1]);
+        std::vector<Q8RowMeta> hr(M), hr2;
+        CS_HIP(hipMemcpy(hr.data(), dRm, (size_t)M * sizeof(Q8RowMeta), hipMemcpyDeviceToHost));
+        if (epilogue == 5) {
+            std::vector<int8_t> ho(c_n);
+            hr2.resize(M);
+            CS_HIP(hipMemcpy(ho.data(), dOut, c_n, hipMemcpyDeviceToHost));
+            CS_HIP(hipMemcpy(hr2.data(), dRm2, (size_t)M * sizeof(Q8RowMeta), hipMemcpyDeviceToHost));
+            for (size_t i = 0; i < c_n; ++i) C[i] = (float)((int)ho[i] + 128);
+            if (rowsums) for (size_t m = 0; m < M; ++m) rowsums[m] = hr2[m].rowsum + 128 * (int32_t)N;
+        } else if (sC) {
+            std::vector<_Float16> hs(c_n * 2);
+            CS_HIP(hipMemcpy(hs.data(), sC, c_n * 4, hipMemcpyDeviceToHost));
+            const size_t nch = N / 32;
+            for (size_t m = 0; m < M; ++m)
+                for (size_t n = 0; n < N; ++n) {
+                    const _Float16* line = hs.data() + (m * nch + n / 32) * 64;
+                    C[m * N + n] = (float)line[n % 32] + (float)line[32 + n % 32] * (1.0f / 2048.0f);
+                }
+        } else {
+            CS_HIP(hipMemcpy(C, dC, c_n * 4, hipMemcpyDeviceToHost));
+        }
+        if (row_params)
+            for (size_t m = 0; m < M; ++m) {
+                row_params[4 * m] = hr[m].xs;
+                row_params[4 * m + 1] = (float)(hr[m].za + 128);
+                row_params[4 * m + 2] = epilogue == 5 ? hr2[m].xs : 0.0f;
+                row_params[4 * m + 3] = epilogue == 5 ? (float)(hr2[m].za + 128) : 0.0f;
+            }
+        return CS_OK;
+    };
+    const int32_t st = run();
+    for (void* p : {(void*)dA, (void*)dW, (void*)dS, (void*)dB, (void*)dR, (void*)dC, (void*)sA, (void*)sC, (void*)dXq, (void*)dWq,
+                    (void*)dOut, (void*)dRm, (void*)dRm2, (void*)dCm, (void*)dF, (void*)dRange, (void*)dRange2, (void*)dSlot})
         if (p) (void)hipFree(p);
     return st;
 }

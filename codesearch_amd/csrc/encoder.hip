@@ -79,13 +79,21 @@ __device__ __forceinline__ bool ln_row(float (&v)[NPL], const float* __restrict_
 
 // Dynamic-quantised models quantise the LayerNorm output next (gemm_q8.hip): the block's (lo, hi) over its four rows,
 // zero included, goes to range_out[2 blockIdx.x ..] so that the range pass over the tensor (100 MB read at 65,536 rows)
-// is a reduction over one pair per block instead.  All 256 threads call.
-__device__ __forceinline__ void ln_range_out(float lo, float hi, float* __restrict__ range_out) {
+// is a reduction over one pair per block instead.  All 256 threads call.  rows != 0 (several quantisation units in the
+// batch, whose borders fall on any row): one pair per token ROW, range_out[2 t ..].
+__device__ __forceinline__ void ln_range_out(float lo, float hi, float* __restrict__ range_out, uint32_t rows, uint32_t t, uint32_t T) {
     __shared__ float s_lo[4], s_hi[4];
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) {
         lo = fminf(lo, __shfl_xor(lo, m, 64));
         hi = fmaxf(hi, __shfl_xor(hi, m, 64));
+    }
+    if (rows) {
+        if ((threadIdx.x & 63) == 0 && t < T) {
+            range_out[2 * (size_t)t] = lo;
+            range_out[2 * (size_t)t + 1] = hi;
+        }
+        return;
     }
     if ((threadIdx.x & 63) == 0) { s_lo[threadIdx.x >> 6] = lo; s_hi[threadIdx.x >> 6] = hi; }
     __syncthreads();
@@ -101,7 +109,7 @@ embed_ln_kernel(const int32_t* __restrict__ ids, const float* __restrict__ word,
                 const float* __restrict__ pos, const float* __restrict__ type0,
                 const float* __restrict__ g, const float* __restrict__ b, float eps, uint32_t T,
                 uint32_t L, uint32_t vocab, float* __restrict__ x, _Float16* __restrict__ xs,
-                uint32_t* __restrict__ flag, float* __restrict__ range_out) {
+                uint32_t* __restrict__ flag, float* __restrict__ range_out, uint32_t range_rows) {
     constexpr int H = 64 * NPL;
     const int lane = threadIdx.x & 63;
     const uint32_t t = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -124,14 +132,14 @@ embed_ln_kernel(const int32_t* __restrict__ ids, const float* __restrict__ word,
     const bool ovf = ln_row<NPL>(v, g, b, eps, lane, x + (size_t)t * H, xs ? xs + (size_t)t * H * 2 : nullptr, lo, hi);
     if (ovf && flag) atomicOr(flag, 1u);
     }
-    if (range_out) ln_range_out(lo, hi, range_out);
+    if (range_out) ln_range_out(lo, hi, range_out, range_rows, t, T);
 }
 
 template <int NPL>
 __global__ void __launch_bounds__(256)
 layernorm_kernel(float* __restrict__ x, const float* __restrict__ g, const float* __restrict__ b,
                  float eps, uint32_t T, _Float16* __restrict__ xs, uint32_t* __restrict__ flag,
-                 float* __restrict__ range_out) {
+                 float* __restrict__ range_out, uint32_t range_rows) {
     constexpr int H = 64 * NPL;
     const int lane = threadIdx.x & 63;
     const uint32_t t = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -148,7 +156,7 @@ layernorm_kernel(float* __restrict__ x, const float* __restrict__ g, const float
     const bool ovf = ln_row<NPL>(v, g, b, eps, lane, row, xs ? xs + (size_t)t * H * 2 : nullptr, lo, hi);
     if (ovf && flag) atomicOr(flag, 1u);
     }
-    if (range_out) ln_range_out(lo, hi, range_out);
+    if (range_out) ln_range_out(lo, hi, range_out, range_rows, t, T);
 }
 
 // LayerNorm over x + bias + sum of the split-K partial slabs (the epilogue of a launch_gemm_split_partial
@@ -798,10 +806,10 @@ static void launch_rows(int which, const EncoderLaunch& a, hipStream_t s) {
     const uint32_t T = a.T;
     if (which == 0)
         hipLaunchKernelGGL(embed_ln_kernel<NPL>, dim3((T + 3) / 4), dim3(256), 0, s, a.ids, a.word, a.pos,
-                           a.type0, a.g, a.b, a.eps, T, a.L, a.vocab, a.x, static_cast<_Float16*>(a.xs), a.flag, a.range_out);
+                           a.type0, a.g, a.b, a.eps, T, a.L, a.vocab, a.x, static_cast<_Float16*>(a.xs), a.flag, a.range_out, a.range_rows ? 1u : 0u);
     else if (which == 1)
         hipLaunchKernelGGL(layernorm_kernel<NPL>, dim3((T + 3) / 4), dim3(256), 0, s, a.x, a.g, a.b, a.eps, T,
-                           static_cast<_Float16*>(a.xs), a.flag, a.range_out);
+                           static_cast<_Float16*>(a.xs), a.flag, a.range_out, a.range_rows ? 1u : 0u);
     else if (which == 3)
         hipLaunchKernelGGL(layernorm_sum_kernel<NPL>, dim3((T + 3) / 4), dim3(256), 0, s, a.x, a.parts, a.nparts,
                            a.bias, a.g, a.b, a.eps, T, static_cast<_Float16*>(a.xs), a.flag);

@@ -28,6 +28,7 @@ struct EncoderLaunch {
     uint32_t nparts = 0;
     uint32_t* flag = nullptr;   // split-f16 overflow flag (device)
     float* range_out = nullptr; // which 0 / 1, optional: [ceil(T / 4)][2] — each block's (lo, hi) of the rows it wrote
+    bool range_rows = false;    //   ... or [T][2], a pair per token row (several quantisation units in the batch)
 };
 
 enum { GEMM_BIAS = 0, GEMM_GELU = 1, GEMM_RESID = 2 };
@@ -43,11 +44,14 @@ size_t attention_lds_bytes(uint32_t L);
 // attention_split.hip: the same attention on the f16 MFMA with split-f16 operands:
 // attention on a split-f16 qkv [T][3H/32][64] (the QKV GEMM's SH_OUT_SPLIT output): K/V go to LDS by
 // LDS-DMA with no conversion, V is consumed through the transposing LDS read; writes ctx in split form.
-// range_out (optional, with range_pairs): every wave's (lo, hi) of the values it stored — *range_pairs pairs are written
-// (0 when the kernel that ran does not report them: the caller then takes its own range pass).
+// range_out (optional, with range_pairs): every wave's (lo, hi) of the values it stored — *range_pairs pairs are written,
+// sequence by sequence (*range_pairs / B each; 0 when the kernel that ran does not report them: the caller then takes its
+// own range pass).  seq_unit / unit_len (optional, device): sequence b belongs to quantisation unit seq_unit[b], whose own
+// padded length is unit_len[unit] — query rows at or beyond it are kept out of the pairs.
 int32_t launch_attention_sh2(const _Float16* qkv_split, const int32_t* mask, void* ctx_split, uint32_t* flag,
                              uint32_t B, uint32_t L, uint32_t H, uint32_t heads, hipStream_t s, float* range_out = nullptr,
-                             uint32_t* range_pairs = nullptr);
+                             uint32_t* range_pairs = nullptr, const uint32_t* seq_unit = nullptr,
+                             const uint32_t* unit_len = nullptr);
 
 // Split-f16 GEMM (gemm_split.hip): A [M][K/32][64] f16, W [N][K/32][64] f16 (split_f16.hpp).
 enum { SH_OUT_F32 = 0, SH_OUT_F32_RESID = 1, SH_OUT_SPLIT_GELU = 2, SH_OUT_SPLIT = 3,

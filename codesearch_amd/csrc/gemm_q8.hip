@@ -195,6 +195,46 @@ q8_range_reduce_kernel(const float* __restrict__ pairs, uint32_t n, uint32_t* __
     }
 }
 
+// The same with several units in the batch: the pairs lie sequence by sequence (pps per sequence), the sequences of a unit
+// are consecutive; block u reduces unit u's.  rows != 0: a pair is a token ROW (pps = the batch's padded length) and only
+// positions below the unit's own padded length belong to its tensor.
+__global__ void __launch_bounds__(256)
+q8_range_reduce_units_kernel(const float* __restrict__ pairs, uint32_t pps, uint32_t rows, const uint32_t* __restrict__ seq_unit,
+                             const uint32_t* __restrict__ unit_len, uint32_t B, uint32_t* __restrict__ range) {
+    __shared__ uint32_t s_first, s_end;
+    __shared__ float s_lo[4], s_hi[4];
+    const uint32_t u = blockIdx.x;
+    if (threadIdx.x == 0) { s_first = B; s_end = 0; }
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < B; b += 256)
+        if (seq_unit[b] == u) { atomicMin(&s_first, b); atomicMax(&s_end, b + 1); }
+    __syncthreads();
+    const uint32_t first = s_first, end = s_end;
+    float lo = 0.0f, hi = 0.0f;
+    if (first < end) {
+        const uint32_t own = rows ? unit_len[u] : pps;
+        const uint64_t n = (uint64_t)(end - first) * pps;
+        for (uint64_t i = threadIdx.x; i < n; i += 256) {
+            if (rows && (uint32_t)(i % pps) >= own) continue;
+            const float2 p = reinterpret_cast<const float2*>(pairs)[(uint64_t)first * pps + i];
+            lo = fminf(lo, p.x);
+            hi = fmaxf(hi, p.y);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        lo = fminf(lo, __shfl_xor(lo, o));
+        hi = fmaxf(hi, __shfl_xor(hi, o));
+    }
+    if ((threadIdx.x & 63) == 0) { s_lo[threadIdx.x >> 6] = lo; s_hi[threadIdx.x >> 6] = hi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t* slot = range + Q8_RANGE_WORDS * (size_t)u;
+        slot[0] = __float_as_uint(fminf(fminf(s_lo[0], s_lo[1]), fminf(s_lo[2], s_lo[3])));
+        slot[1] = __float_as_uint(fmaxf(fmaxf(s_hi[0], s_hi[1]), fmaxf(s_hi[2], s_hi[3])));
+    }
+}
+
 // (x_scale, x_zp) of a unit from its range: DynamicQuantizeLinear's arithmetic, f32, one rounding per operation.
 __device__ __forceinline__ void q8_params_of(float lo, float hi, float& xs, float& xz) {
     xs = hi == lo ? 1.0f : __fdiv_rn(__fsub_rn(hi, lo), 255.0f);
@@ -783,14 +823,23 @@ __device__ __forceinline__ void q8_rows_store(const float* ctile, const float* r
 // Q8_SRC_SPLIT: A is the f32-class tensor itself and in_range its range slot — the block quantises its own 128 rows on the
 // way in (cooperatively, into the W buffer the first tile does not use yet; every wave then takes its fragments from that
 // image): the quantising pass over the tensor, its 25 MB of output and their re-read disappear (25-28 us per Linear at
-// 65,536 rows).  One quantisation unit only.
+// 65,536 rows).
+// MU (with SRC >= 0): the tensor holds SEVERAL quantisation units (queued calls sharing a device batch): row_slot [M]
+// names each row's unit (bit 31: the row lies beyond its call's own padded length — quantised with the unit's
+// parameters, never part of a range), in_range and rq.range are the units' slot arrays.  Every row is quantised with its
+// own unit's parameters; the FFN-up range pass keeps ONE unit's extremes per wave at a time and hands them to that unit's
+// slot whenever the rows it walks change unit (row blocks of one unit — the usual case — cost one compare per row).
 constexpr int QR_PREQUANT = -1;
-template <int EPI, int SRC = QR_PREQUANT>
+struct Q8RowOut { float gs, gz, rgs; uint32_t slot; };  // MU: a row's output parameters (FFN-up store pass) and slot word
+constexpr int QR_LDS_MU = QR_LDS + 128 * 16;
+template <int EPI, int SRC = QR_PREQUANT, bool MU = false>
 __global__ void __launch_bounds__(QR_THREADS, 2)
 gemm_q8_rows_kernel(const void* __restrict__ Asrc, const int8_t* __restrict__ W, const Q8RowMeta* __restrict__ rmeta,
                     const Q8ColMeta* __restrict__ cmeta, const float* resid, float* C,
                     _Float16* __restrict__ Cs, uint32_t M, uint32_t N, uint32_t* __restrict__ flag, Q8Requant rq,
-                    uint32_t parts, uint32_t total_units, const uint32_t* __restrict__ in_range) {
+                    uint32_t parts, uint32_t total_units, const uint32_t* __restrict__ in_range,
+                    const uint32_t* __restrict__ row_slot) {
+    static_assert(!MU || SRC != QR_PREQUANT, "several units: quantise-on-load only");
     const int8_t* A = reinterpret_cast<const int8_t*>(Asrc);
     extern __shared__ __attribute__((aligned(16))) char lds[];
     constexpr uint32_t K = 128 * QR_KC;
@@ -798,6 +847,7 @@ gemm_q8_rows_kernel(const void* __restrict__ Asrc, const int8_t* __restrict__ W,
     char* cmbuf = lds + 2 * QR_WTILE;                          // [2][128] Q8ColMeta
     Q8RowMeta* lrow = reinterpret_cast<Q8RowMeta*>(cmbuf + 2 * QR_CM_BYTES);  // [128]: xs, za, rowsum - K za
     char* obuf = cmbuf + 2 * QR_CM_BYTES + QR_RM_BYTES;
+    Q8RowOut* lout = reinterpret_cast<Q8RowOut*>(lds + QR_LDS);  // [128], MU only
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;
@@ -822,17 +872,49 @@ gemm_q8_rows_kernel(const void* __restrict__ Asrc, const int8_t* __restrict__ W,
             sh_glds16(reinterpret_cast<const char*>(cmeta + (size_t)nt * 128 + wave * 64) + lane * 16, cmbuf + b * QR_CM_BYTES + wave * 1024);
     };
     float gs = 1.0f, gz = 0.0f, rgs = 1.0f;
-    if (EPI == Q8_EPI_GELU_Q8) {
+    if (EPI == Q8_EPI_GELU_Q8 && !MU) {
         q8_params_gelu(rq.range, gs, gz);
         rgs = __fdiv_rn(1.0f, gs);
     }
     float ymax = -INFINITY, ya = -INFINITY, yb = INFINITY;
     float ycen = 0.0f, yhw = INFINITY;  // wave-uniform: centre and half-width (padded) of the wave's (a, b) so far
     float xs = 1.0f, xz = 0.0f, rxs = 1.0f;  // SRC >= 0: DynamicQuantizeLinear's parameters of the input tensor
-    if (SRC != QR_PREQUANT) {
+    if (SRC != QR_PREQUANT && !MU) {
         q8_params(in_range, xs, xz);
         rxs = __fdiv_rn(1.0f, xs);
     }
+    // MU, range pass: the unit whose extremes (ymax, ya, yb) the wave is holding; they go to its slot when the unit changes
+    constexpr uint32_t NO_SLOT = 0xffffffffu;
+    uint32_t cur_slot = NO_SLOT;
+    uint32_t blk_first = 0, blk_last = 0;
+    // (block-uniform: every wave of the block is at the same unit — the eight meet in LDS and one thread updates the slot;
+    // with an update per wave, 2,048 waves read the same two cache lines at the same moment: 137 us per launch instead of
+    // 116 at 65,536 rows, eight units)
+    auto flush_slot = [&]() {
+        if (cur_slot != NO_SLOT) {
+            float* s_r = reinterpret_cast<float*>(obuf);  // [3][8] (the range pass stages nothing in obuf)
+            float m3 = ymax, a3 = ya, b3 = yb;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                m3 = fmaxf(m3, __shfl_xor(m3, o));
+                a3 = fmaxf(a3, __shfl_xor(a3, o));
+                b3 = fminf(b3, __shfl_xor(b3, o));
+            }
+            if (lane == 0) { s_r[wave] = m3; s_r[8 + wave] = a3; s_r[16 + wave] = b3; }
+            __syncthreads();
+            if (tid == 0) {
+                m3 = -INFINITY; a3 = -INFINITY; b3 = INFINITY;
+                for (int w = 0; w < 8; ++w) { m3 = fmaxf(m3, s_r[w]); a3 = fmaxf(a3, s_r[8 + w]); b3 = fminf(b3, s_r[16 + w]); }
+                uint32_t* slot = rq.range + Q8_RANGE_WORDS * (size_t)cur_slot;
+                if (m3 > -INFINITY) q8_key_update(slot + 2, m3);
+                if (a3 > -INFINITY) q8_key_update(slot + 3, a3);
+                if (b3 < INFINITY) q8_key_update(slot + 4, -b3);
+            }
+            __syncthreads();
+        }
+        ymax = -INFINITY; ya = -INFINITY; yb = INFINITY;
+        ycen = 0.0f; yhw = INFINITY;
+    };
 
     for (uint32_t unit = blockIdx.x; unit < total_units; unit += gridDim.x) {
         const uint32_t mt = unit / parts, nt0 = (unit % parts) * per;
@@ -861,8 +943,31 @@ gemm_q8_rows_kernel(const void* __restrict__ Asrc, const int8_t* __restrict__ W,
             issue_w(nt0, 0);
             __syncthreads();  // W tile nt0 has landed (vmcnt(0) precedes the barrier); obuf and the other W buffer are free
         } else {
-            if (tid < 128) lrow[tid].rowsum = 0;
-            issue_w(nt0, 0);
+            if constexpr (MU) {
+                const bool live = m0 + tid < M;
+                uint32_t sw = 0;
+                if (tid < 128) sw = row_slot[live ? m0 + tid : M - 1];
+                issue_w(nt0, 0);  // (behind the slot load, ahead of the loads that depend on it)
+                if (tid < 128) {  // the row's unit: its input parameters (and, store pass, its output parameters)
+                    const uint32_t sl = sw & 0x7fffffffu;
+                    float rxs_, rxz_;
+                    q8_params(in_range + Q8_RANGE_WORDS * (size_t)sl, rxs_, rxz_);
+                    Q8RowMeta rm;
+                    rm.xs = rxs_; rm.za = (int)rxz_ - 128; rm.rowsum = 0; rm.pad = __float_as_uint(__fdiv_rn(1.0f, rxs_));
+                    lrow[tid] = rm;
+                    Q8RowOut ro;
+                    ro.gs = 1.0f; ro.gz = 0.0f; ro.rgs = 1.0f;
+                    ro.slot = live ? sw : NO_SLOT;  // rows past M: in no unit's range
+                    if (EPI == Q8_EPI_GELU_Q8) {
+                        q8_params_gelu(rq.range + Q8_RANGE_WORDS * (size_t)sl, ro.gs, ro.gz);
+                        ro.rgs = __fdiv_rn(1.0f, ro.gs);
+                    }
+                    lout[tid] = ro;
+                }
+            } else {
+                if (tid < 128) lrow[tid].rowsum = 0;
+                issue_w(nt0, 0);
+            }
             __syncthreads();
             // 3 chunks x 128 rows x 8 slots of 16 k: six slots per thread, quantised into the image of W buffer 1
             char* abuf = lds + QR_WTILE;
@@ -889,6 +994,12 @@ gemm_q8_rows_kernel(const void* __restrict__ Asrc, const int8_t* __restrict__ W,
                         for (int e = 0; e < 8; ++e) v[8 * q + e] = (float)h[e] + (float)l[e] * kShLoInv;
                     }
                 }
+                if constexpr (MU) {  // this row's unit
+                    const Q8RowMeta rq_ = lrow[row];
+                    xs = rq_.xs;
+                    xz = (float)(rq_.za + 128);
+                    rxs = __uint_as_float(rq_.pad);
+                }
                 q8_i32x4 packed;
                 int sum = 0;
 #pragma unroll
@@ -912,6 +1023,15 @@ gemm_q8_rows_kernel(const void* __restrict__ Asrc, const int8_t* __restrict__ W,
                 atomicAdd(&lrow[row].rowsum, sum);
             }
             __syncthreads();  // the image and the row sums are complete (and W tile nt0 has landed)
+            if constexpr (MU && EPI == Q8_EPI_GELU_RANGE) {  // the units this row block holds (almost always one)
+                const uint32_t last_row = M - 1 - m0 < 127u ? M - 1 - m0 : 127u;
+                blk_first = __builtin_amdgcn_readfirstlane(lout[0].slot & 0x7fffffffu);
+                blk_last = __builtin_amdgcn_readfirstlane(lout[last_row].slot & 0x7fffffffu);
+                if (blk_first == blk_last && cur_slot != blk_first) {
+                    flush_slot();
+                    cur_slot = blk_first;
+                }
+            }
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -920,15 +1040,25 @@ gemm_q8_rows_kernel(const void* __restrict__ Asrc, const int8_t* __restrict__ W,
                     a0[c][i] = *reinterpret_cast<const q8_i32x4*>(p + s0);
                     a1[c][i] = *reinterpret_cast<const q8_i32x4*>(p + s1);
                 }
-            const int za = (int)xz - 128;
-            int pm = 0;
-            if (tid < 128) pm = lrow[tid].rowsum - (int)K * za;
-            __syncthreads();  // fragments are in registers (W buffer 1 is free for tile nt0 + 1), row sums read
+            Q8RowMeta rmine;
             if (tid < 128) {
-                Q8RowMeta rm;
-                rm.xs = xs; rm.za = za; rm.rowsum = pm; rm.pad = 0;
-                lrow[tid] = rm;
+                if constexpr (MU) {
+                    rmine = lrow[tid];
+                } else {
+                    rmine.xs = xs; rmine.za = (int)xz - 128; rmine.rowsum = lrow[tid].rowsum; rmine.pad = 0;
+                }
+                rmine.rowsum -= (int)K * rmine.za;
+                if constexpr (MU && EPI == Q8_EPI_GELU_RANGE) {
+                    // range pass: a row that is not part of the row block's (one) unit — beyond its call's own padded length, or past
+                    // M — yields NaN; with several units in the block the marks are set per unit and tile (below)
+                    const uint32_t last_row = M - 1 - m0 < 127u ? M - 1 - m0 : 127u;
+                    const uint32_t bf = lout[0].slot & 0x7fffffffu, bl = lout[last_row].slot & 0x7fffffffu;
+                    lout[tid].gs = rmine.xs;
+                    if (bf == bl && lout[tid].slot != bf) rmine.xs = __builtin_nanf("");
+                }
             }
+            __syncthreads();  // fragments are in registers (W buffer 1 is free for tile nt0 + 1), row sums read
+            if (tid < 128) lrow[tid] = rmine;
             __syncthreads();
         }
         for (uint32_t nt = nt0; nt < nt1; ++nt) {
@@ -970,34 +1100,58 @@ gemm_q8_rows_kernel(const void* __restrict__ Asrc, const int8_t* __restrict__ W,
                 // max y per element; the two neighbours a, b of the GELU's minimum (q8_params_gelu) only when this tile holds a
                 // value inside the window (a, b) the wave has so far — a handful of tiles per wave: three instructions per
                 // element instead of eight.  The window test is padded by 1e-5 (rounding of its centre): never misses.
-                float ys[32], off = INFINITY;
+                // MU: the rows that are not the folded unit's carry x_scale = NaN in the row metadata (set at the head of the row
+                // block): their y is NaN, which fmaxf / fminf and both comparisons drop — no maximum, neither side of c, outside
+                // the window — so the fold itself is the one-unit code.
+                auto fold = [&]() {
+                    float ys[32], off = INFINITY;
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+                    for (int i = 0; i < 4; ++i)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const Q8RowMeta rm = lrow[wr * 64 + i * 16 + 4 * g + r];
+                        for (int r = 0; r < 4; ++r) {
+                            const Q8RowMeta rm = lrow[wr * 64 + i * 16 + 4 * g + r];
 #pragma unroll
-                        for (int j = 0; j < 2; ++j) {
-                            const float y = y_of(rm, i, r, j);
-                            ys[(i * 4 + r) * 2 + j] = y;
-                            ymax = fmaxf(ymax, y);
-                            off = fminf(off, fabsf(y - ycen));
+                            for (int j = 0; j < 2; ++j) {
+                                const float y = y_of(rm, i, r, j);
+                                ys[(i * 4 + r) * 2 + j] = y;
+                                ymax = fmaxf(ymax, y);
+                                off = fminf(off, fabsf(y - ycen));
+                            }
                         }
-                    }
-                if (!(yhw < INFINITY) || __any(off < yhw)) {
+                    if (!(yhw < INFINITY) || __any(off < yhw)) {
 #pragma unroll
-                    for (int e = 0; e < 32; ++e) {
-                        ya = ys[e] <= kGeluArgMin ? fmaxf(ya, ys[e]) : ya;
-                        yb = ys[e] >= kGeluArgMin ? fminf(yb, ys[e]) : yb;
-                    }
-                    float wa = ya, wb = yb;  // the wave's window
+                        for (int e = 0; e < 32; ++e) {
+                            ya = ys[e] <= kGeluArgMin ? fmaxf(ya, ys[e]) : ya;
+                            yb = ys[e] >= kGeluArgMin ? fminf(yb, ys[e]) : yb;
+                        }
+                        float wa = ya, wb = yb;  // the wave's window
 #pragma unroll
-                    for (int o = 32; o > 0; o >>= 1) {
-                        wa = fmaxf(wa, __shfl_xor(wa, o));
-                        wb = fminf(wb, __shfl_xor(wb, o));
+                        for (int o = 32; o > 0; o >>= 1) {
+                            wa = fmaxf(wa, __shfl_xor(wa, o));
+                            wb = fminf(wb, __shfl_xor(wb, o));
+                        }
+                        ycen = 0.5f * (wa + wb);             // (NaN / inf while a side is still empty: yhw stays inf)
+                        yhw = 0.5f * (wb - wa) + 1.0e-5f;
                     }
-                    ycen = 0.5f * (wa + wb);             // (NaN / inf while a side is still empty: yhw stays inf)
-                    yhw = 0.5f * (wb - wa) + 1.0e-5f;
+                };
+                if constexpr (MU) {
+                    for (uint32_t su = blk_first;; ++su) {  // almost always ONE round: a row block holds one unit
+                        if (blk_first != blk_last) {
+                            // several units in this row block (rare): a round per unit, the row metadata re-marked for each
+                            // (block-uniform, so the barriers are safe)
+                            if (su != cur_slot) {
+                                flush_slot();
+                                cur_slot = su;
+                            }
+                            __syncthreads();
+                            if (tid < 128) lrow[tid].xs = lout[tid].slot == su ? lout[tid].gs : __builtin_nanf("");
+                            __syncthreads();
+                        }
+                        fold();
+                        if (su == blk_last) break;
+                    }
+                } else {
+                    fold();
                 }
                 if (nt == 0 && tid < 128 && m0 + tid < M) rq.rmeta_out[m0 + tid].rowsum = 0;
             } else if constexpr (REQ) {
@@ -1007,6 +1161,10 @@ gemm_q8_rows_kernel(const void* __restrict__ Asrc, const int8_t* __restrict__ W,
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const Q8RowMeta rm = lrow[wr * 64 + i * 16 + 4 * g + r];
+                        if constexpr (MU) {  // the row's unit's output parameters
+                            const Q8RowOut ro = lout[wr * 64 + i * 16 + 4 * g + r];
+                            gs = ro.gs; gz = ro.gz; rgs = ro.rgs;
+                        }
 #pragma unroll
                         for (int j = 0; j < 2; ++j) {
                             const float y = y_of(rm, i, r, j);
@@ -1040,6 +1198,7 @@ gemm_q8_rows_kernel(const void* __restrict__ Asrc, const int8_t* __restrict__ W,
                         }
                     }
                     if (nt == 0 && tid < 128 && m0 + tid < M) {
+                        if constexpr (MU) { gs = lout[tid].gs; gz = lout[tid].gz; }
                         rq.rmeta_out[m0 + tid].xs = gs;
                         rq.rmeta_out[m0 + tid].za = (int)gz - 128;
                     }
@@ -1070,7 +1229,9 @@ gemm_q8_rows_kernel(const void* __restrict__ Asrc, const int8_t* __restrict__ W,
             __syncthreads();  // W tile nt + 1 has landed; every wave is done with this tile's weights and with obuf
         }
     }
-    if (EPI == Q8_EPI_GELU_RANGE) {
+    if (EPI == Q8_EPI_GELU_RANGE && MU) {
+        flush_slot();
+    } else if (EPI == Q8_EPI_GELU_RANGE) {
         float* s_r = reinterpret_cast<float*>(obuf);  // [3][8]
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
@@ -1160,13 +1321,15 @@ static int q8_cus() {
     }
     return cus;
 }
-template <int EPI, int SRC = QR_PREQUANT>
+template <int EPI, int SRC = QR_PREQUANT, bool MU = false>
 static int32_t launch_rows(const void* d_xq, const Q8RowMeta* d_rmeta, const int8_t* d_wq, const Q8ColMeta* d_cmeta,
                            const float* bias, const float* resid, float* C, _Float16* Cs, uint32_t M, uint32_t N,
-                           uint32_t* d_flag, Q8Requant rq, hipStream_t s, const uint32_t* d_in_range = nullptr) {
+                           uint32_t* d_flag, Q8Requant rq, hipStream_t s, const uint32_t* d_in_range = nullptr,
+                           const uint32_t* d_row_slot = nullptr) {
+    constexpr int LDS = MU ? QR_LDS_MU : QR_LDS;
     static PerDeviceOnce attr;  // function attributes are per device
     CS_TRY(attr.run([&]() -> int32_t {
-        CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_q8_rows_kernel<EPI, SRC>), hipFuncAttributeMaxDynamicSharedMemorySize, QR_LDS));
+        CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_q8_rows_kernel<EPI, SRC, MU>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
         return CS_OK;
     }));
     const uint32_t mtiles = (M + 127) / 128, ntiles = N / 128, cus = (uint32_t)q8_cus();
@@ -1175,8 +1338,8 @@ static int32_t launch_rows(const void* d_xq, const Q8RowMeta* d_rmeta, const int
     if (parts > ntiles) parts = ntiles;
     const uint32_t units = mtiles * parts;
     (void)bias;  // the row-block kernel takes the bias from the column metadata (folded in at create time)
-    hipLaunchKernelGGL((gemm_q8_rows_kernel<EPI, SRC>), dim3(units < cus ? units : cus), dim3(QR_THREADS), QR_LDS, s, d_xq, d_wq, d_rmeta,
-                       d_cmeta, resid, C, Cs, M, N, d_flag, rq, parts, units, d_in_range);
+    hipLaunchKernelGGL((gemm_q8_rows_kernel<EPI, SRC, MU>), dim3(units < cus ? units : cus), dim3(QR_THREADS), LDS, s, d_xq, d_wq, d_rmeta,
+                       d_cmeta, resid, C, Cs, M, N, d_flag, rq, parts, units, d_in_range, d_row_slot);
     CS_HIP(hipGetLastError());
     return CS_OK;
 }
@@ -1237,11 +1400,24 @@ int32_t launch_q8_range(int src_kind, const void* d_src, uint32_t T, uint32_t K,
     return CS_OK;
 }
 
+int32_t launch_q8_range_units(const float* d_range_pairs, uint32_t pairs_per_seq, bool pairs_are_rows, const uint32_t* d_seq_unit,
+                              const uint32_t* d_unit_len, uint32_t B, uint32_t units, uint32_t* d_range, hipStream_t s) {
+    if (B == 0 || units == 0 || pairs_per_seq == 0) return CS_OK;
+    hipLaunchKernelGGL(q8_range_reduce_units_kernel, dim3(units), dim3(256), 0, s, d_range_pairs, pairs_per_seq, pairs_are_rows ? 1u : 0u,
+                       d_seq_unit, d_unit_len, B, d_range);
+    CS_HIP(hipGetLastError());
+    return CS_OK;
+}
+
 int32_t launch_gemm_q8_from_source(int epi, int src_kind, const void* d_src, const uint32_t* d_in_range, const int8_t* d_wq,
                                    const Q8ColMeta* d_cmeta, const float* bias, const float* resid, float* C, _Float16* Cs,
-                                   uint32_t M, uint32_t N, uint32_t K, uint32_t* d_flag, hipStream_t s) {
+                                   uint32_t M, uint32_t N, uint32_t K, uint32_t* d_flag, hipStream_t s, const uint32_t* d_row_slot) {
     if (!q8_rows_takes(M, K) || N % 128) return fail(CS_ERR_UNSUPPORTED, "quantise-on-load product: M=%u N=%u K=%u not taken by the row-block kernel", M, N, K);
     const Q8Requant none{nullptr, nullptr, nullptr};
+    if (epi == SH_OUT_SPLIT && src_kind == Q8_SRC_F32 && d_row_slot)
+        return launch_rows<SH_OUT_SPLIT, Q8_SRC_F32, true>(d_src, nullptr, d_wq, d_cmeta, bias, resid, C, Cs, M, N, d_flag, none, s, d_in_range, d_row_slot);
+    if (epi == SH_OUT_F32_RESID && src_kind == Q8_SRC_SPLIT && d_row_slot)
+        return launch_rows<SH_OUT_F32_RESID, Q8_SRC_SPLIT, true>(d_src, nullptr, d_wq, d_cmeta, bias, resid, C, Cs, M, N, d_flag, none, s, d_in_range, d_row_slot);
     if (epi == SH_OUT_SPLIT && src_kind == Q8_SRC_F32)
         return launch_rows<SH_OUT_SPLIT, Q8_SRC_F32>(d_src, nullptr, d_wq, d_cmeta, bias, resid, C, Cs, M, N, d_flag, none, s, d_in_range);
     if (epi == SH_OUT_F32_RESID && src_kind == Q8_SRC_SPLIT)
@@ -1280,9 +1456,13 @@ int32_t launch_gemm_q8_skinny(int epi, int src_kind, const void* d_src, const fl
 
 int32_t launch_gemm_q8_gelu_requant_from_source(const float* d_x, const uint32_t* d_in_range, const int8_t* d_wq, const Q8ColMeta* d_cmeta,
                                                 const float* bias, uint32_t M, uint32_t N, uint32_t K, uint32_t* d_range_out,
-                                                int8_t* d_out, Q8RowMeta* d_rmeta_out, hipStream_t s) {
+                                                int8_t* d_out, Q8RowMeta* d_rmeta_out, hipStream_t s, const uint32_t* d_row_slot) {
     if (!q8_rows_takes(M, K) || N % 128) return fail(CS_ERR_UNSUPPORTED, "quantise-on-load product: M=%u N=%u K=%u not taken by the row-block kernel", M, N, K);
     const Q8Requant rq{d_range_out, d_out, d_rmeta_out};
+    if (d_row_slot) {
+        CS_TRY((launch_rows<Q8_EPI_GELU_RANGE, Q8_SRC_F32, true>(d_x, nullptr, d_wq, d_cmeta, bias, nullptr, nullptr, nullptr, M, N, nullptr, rq, s, d_in_range, d_row_slot)));
+        return launch_rows<Q8_EPI_GELU_Q8, Q8_SRC_F32, true>(d_x, nullptr, d_wq, d_cmeta, bias, nullptr, nullptr, nullptr, M, N, nullptr, rq, s, d_in_range, d_row_slot);
+    }
     CS_TRY((launch_rows<Q8_EPI_GELU_RANGE, Q8_SRC_F32>(d_x, nullptr, d_wq, d_cmeta, bias, nullptr, nullptr, nullptr, M, N, nullptr, rq, s, d_in_range)));
     return launch_rows<Q8_EPI_GELU_Q8, Q8_SRC_F32>(d_x, nullptr, d_wq, d_cmeta, bias, nullptr, nullptr, nullptr, M, N, nullptr, rq, s, d_in_range);
 }

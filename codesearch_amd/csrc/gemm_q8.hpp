@@ -61,12 +61,21 @@ int32_t launch_gemm_q8(int epi, const int8_t* d_xq, const Q8RowMeta* d_rmeta, co
 bool q8_rows_from_source(uint32_t M, uint32_t K);
 int32_t launch_q8_range(int src_kind, const void* d_src, uint32_t T, uint32_t K, uint32_t* d_range, hipStream_t s,
                         const float* d_range_pairs = nullptr, uint32_t n_pairs = 0);
+// d_row_slot (optional): SEVERAL units in the tensor — d_in_range / d_range_out are then the units' slot arrays and every
+// row is quantised with its own unit's parameters (row_slot as for launch_q8_quantize).
 int32_t launch_gemm_q8_from_source(int epi, int src_kind, const void* d_src, const uint32_t* d_in_range, const int8_t* d_wq,
                                    const Q8ColMeta* d_cmeta, const float* bias, const float* resid, float* C, _Float16* Cs,
-                                   uint32_t M, uint32_t N, uint32_t K, uint32_t* d_flag, hipStream_t s);
+                                   uint32_t M, uint32_t N, uint32_t K, uint32_t* d_flag, hipStream_t s,
+                                   const uint32_t* d_row_slot = nullptr);
 int32_t launch_gemm_q8_gelu_requant_from_source(const float* d_x, const uint32_t* d_in_range, const int8_t* d_wq, const Q8ColMeta* d_cmeta,
                                                 const float* bias, uint32_t M, uint32_t N, uint32_t K, uint32_t* d_range_out,
-                                                int8_t* d_out, Q8RowMeta* d_rmeta_out, hipStream_t s);
+                                                int8_t* d_out, Q8RowMeta* d_rmeta_out, hipStream_t s,
+                                                const uint32_t* d_row_slot = nullptr);
+// The units' ranges from what the tensor's producer left: pairs_per_seq (lo, hi) pairs per sequence, sequence by sequence
+// (attention: its waves' pairs; LayerNorm with EncoderLaunch::range_rows: one pair per token row — pairs_are_rows, and
+// only positions below the unit's own padded length count).  Writes words 0, 1 of every unit's slot.
+int32_t launch_q8_range_units(const float* d_range_pairs, uint32_t pairs_per_seq, bool pairs_are_rows, const uint32_t* d_seq_unit,
+                              const uint32_t* d_unit_len, uint32_t B, uint32_t units, uint32_t* d_range, hipStream_t s);
 
 // A few token rows (up to q8_skinny_max_m; CS_Q8_SKINNY_MAX_M, 0 = never): one launch per Linear — each block reduces
 // the (lo, hi) pairs its input's producer left, quantises its 16 rows into LDS and multiplies one 16 x 16 tile with K

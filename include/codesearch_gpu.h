@@ -592,6 +592,16 @@ int32_t cs_debug_gemm_q8(int32_t device, int32_t epilogue, int32_t a_split, cons
                          const float* wscale, const float* bias, const float* resid, float* C, uint32_t M, uint32_t N,
                          uint32_t K, uint8_t* xq, float* xparams, int32_t* acc);
 
+/* Diagnostics: the same products over a tensor that holds SEVERAL quantisation units (queued calls sharing a device
+ * batch, cs_embedder_submit_*): row_slot [M] = each row's unit (consecutive runs of rows, in order), bit 31 set where the
+ * row lies beyond its call's own padded length (quantised with the unit's parameters, never part of a range).  Row-block
+ * products only (K = 384, M >= 4,096); epilogue 4 (f32 source -> split store), 2 (split source, + residual), 5 (FFN-up:
+ * GELU, quantised again per unit; C = the uint8 output as floats).  row_params [M][4] = per row (x_scale, x_zero_point,
+ * out_scale, out_zero_point) (the last two: epilogue 5), rowsums [M] (epilogue 5) each output row's sum of uint8 values. */
+int32_t cs_debug_gemm_q8_units(int32_t device, int32_t epilogue, const float* A, const float* W, const float* wscale,
+                               const float* bias, const float* resid, float* C, uint32_t M, uint32_t N, uint32_t K,
+                               const uint32_t* row_slot, uint32_t units, float* row_params, int32_t* rowsums);
+
 /* Diagnostics: device milliseconds per launch of one dense layer on synthetic operands resident in HBM.
  * mode 0 exact-f32 MFMA, 1 split-f16 (128 x 128 / skinny kernels), 2 split-f16 wide kernel (N % 384 == 0);
  * epilogue 0 f32, 1 GELU -> split, 2 + residual, 3 LayerNorm-fused (mode 2, N = 384), 4 bias -> split (QKV);

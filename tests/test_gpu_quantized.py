@@ -186,6 +186,85 @@ def test_row_block_products_quantise_their_own_rows(gpu_lib):
     assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1][2:], outs[1][1][2:]) and np.array_equal(outs[0][2], outs[1][2])
 
 
+def _unit_rows(rng, L, units):
+    """row_slot of a device batch of sequences of L positions: units = [(sequences, own padded length)], in order."""
+    slots = []
+    for u, (n, own) in enumerate(units):
+        for _ in range(n):
+            slots += [u | (0x80000000 if t >= own else 0) for t in range(L)]
+    return np.array(slots, np.uint32)
+
+
+def _quantize_with(x, lo, hi):
+    scale = np.float32(1) if hi == lo else np.float32((np.float32(hi) - np.float32(lo)) / np.float32(255))
+    zp = np.float32(np.rint(np.clip(np.float32(0) - np.float32(np.float32(lo) / scale), 0, 255)))
+    return np.clip(np.rint((x / scale).astype(np.float32)) + zp, 0, 255).astype(np.uint8), scale, int(zp)
+
+
+@pytest.mark.parametrize("L,units", [(50, [(30, 50), (2, 7), (40, 33), (18, 50)]),        # borders inside row blocks
+                                     (128, [(8, 128), (8, 70), (16, 128), (4, 1)]),        # whole row blocks per unit
+                                     (37, [(1, 37)] * 5 + [(110, 20), (1, 36)])])          # many units inside one row block
+def test_row_block_products_over_several_units(gpu_lib, L, units):
+    """Queued calls share a device batch but stay their own quantisation units: the row-block products quantise every row
+    with its OWN unit's (scale, zero point), a unit's range covers only the rows inside its own padded length, and the
+    FFN-up range pass keeps the units' extremes apart — against numpy unit by unit: same bytes, same integers."""
+    from scipy.special import erf
+
+    rng = np.random.default_rng(L)
+    slot = _unit_rows(rng, L, units)
+    M, K = len(slot), 384
+    assert M >= 4096
+    U = len(units)
+    su = slot & 0x7fffffff
+    inc = (slot >> 31) == 0
+    # every unit at its own magnitude (and rows outside a unit's own length larger still: they must not widen its range)
+    A = (rng.standard_normal((M, K)) * rng.choice([0.2, 1.0, 4.0], size=U)[su][:, None]).astype(np.float32)
+    A[~inc] *= np.float32(3)
+
+    def run(epi, N, resid=None):
+        W, d, sc = quantize_matrix((rng.standard_normal((N, K)) * 0.05).astype(np.float32), True, True)
+        bias = (rng.standard_normal(N) * 0.1).astype(np.float32)
+        C_ = np.empty((M, N), np.float32)
+        rp = np.empty((M, 4), np.float32)
+        sums = np.empty(M, np.int32)
+        _lib.check(gpu_lib.cs_debug_gemm_q8_units(0, epi, A.ctypes.data_as(f32p), W.ctypes.data_as(f32p), sc.ctypes.data_as(f32p),
+                                                  bias.ctypes.data_as(f32p), None if resid is None else resid.ctypes.data_as(f32p),
+                                                  C_.ctypes.data_as(f32p), M, N, K, slot.ctypes.data_as(C.POINTER(C.c_uint32)), U,
+                                                  rp.ctypes.data_as(f32p), sums.ctypes.data_as(C.POINTER(C.c_int32))))
+        return C_, rp, sums, d, sc, bias
+
+    def base_of(src, d, sc, bias, rp):
+        base = np.empty((M, d.shape[0]), np.float32)
+        for u in range(U):
+            rows = su == u
+            own = rows & inc
+            lo = min(np.float32(0), src[own].min()) if own.any() else np.float32(0)
+            hi = max(np.float32(0), src[own].max()) if own.any() else np.float32(0)
+            q, xs, xz = _quantize_with(src[rows], lo, hi)
+            assert (rp[rows, 0] == xs).all() and (rp[rows, 1] == xz).all(), u
+            base[rows] = ((q.astype(np.int64) - xz) @ d.T).astype(np.float32) * (xs * sc)[None, :].astype(np.float32) + bias[None, :]
+        return base
+
+    got, rp, _, d, sc, bias = run(4, 1152)                                   # QKV: f32 source -> split store
+    np.testing.assert_allclose(got, base_of(A, d, sc, bias, rp), rtol=3e-7, atol=1e-9)
+    resid = rng.standard_normal((M, 384)).astype(np.float32)
+    got, rp, _, d, sc, bias = run(2, 384, resid)                             # out-proj: split source, + residual
+    assert np.array_equal(got, (base_of(split_round_trip(A), d, sc, bias, rp) + resid).astype(np.float32))
+    got, rp, sums, d, sc, bias = run(5, 1536)                                # FFN-up: GELU, quantised again per unit
+    y = base_of(A, d, sc, bias, rp)
+    gl = (0.5 * y.astype(np.float64) * (1.0 + erf(y.astype(np.float64) / np.sqrt(2.0)))).astype(np.float32)
+    for u in range(U):
+        rows = su == u
+        own = rows & inc
+        lo = min(np.float32(0), gl[own].min()) if own.any() else np.float32(0)
+        hi = max(np.float32(0), gl[own].max()) if own.any() else np.float32(0)
+        gq, gs, gz = _quantize_with(gl[rows], lo, hi)
+        assert (np.abs(rp[rows, 2] - gs) <= 2e-6 * gs).all() and (rp[rows, 3] == gz).all(), u
+        diff = np.abs(got[rows].astype(np.int64) - gq.astype(np.int64))
+        assert diff.max() <= 1 and (diff != 0).mean() < 2e-3, (u, diff.max(), (diff != 0).mean())
+    assert np.array_equal(sums, got.astype(np.int64).sum(axis=1))
+
+
 def test_split_form_activations_quantise_like_their_f32_values(gpu_lib):
     """Attention and GELU hand their outputs over in split-f16 form: the quantiser reads hi + lo / 2048."""
     rng = np.random.default_rng(5)
