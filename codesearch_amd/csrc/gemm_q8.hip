@@ -845,7 +845,7 @@ gemm_q8_rows_kernel(const void* __restrict__ Asrc, const int8_t* __restrict__ W,
     constexpr uint32_t K = 128 * QR_KC;
     constexpr bool REQ = EPI == Q8_EPI_GELU_RANGE || EPI == Q8_EPI_GELU_Q8;
     char* cmbuf = lds + 2 * QR_WTILE;                          // [2][128] Q8ColMeta
-    Q8RowMeta* lrow = reinterpret_cast<Q8RowMeta*>(cmbuf + 2 * QR_CM_BYTES);  // [128]: xs, za, rowsum - K za
+    Q8RowMeta* lrow = reinterpret_cast<Q8RowMeta*>(cmbuf + 2 * QR_CM_BYTES);  // [128]: xs, -za, rowsum - K za
     char* obuf = cmbuf + 2 * QR_CM_BYTES + QR_RM_BYTES;
     Q8RowOut* lout = reinterpret_cast<Q8RowOut*>(lds + QR_LDS);  // [128], MU only
     const int tid = threadIdx.x, lane = tid & 63;
@@ -938,6 +938,7 @@ gemm_q8_rows_kernel(const void* __restrict__ Asrc, const int8_t* __restrict__ W,
             if (tid < 128) {
                 Q8RowMeta rm = rmeta[m0 + tid < M ? m0 + tid : M - 1];
                 rm.rowsum -= (int)K * rm.za;
+                rm.za = -rm.za;  // (as y_of takes it)
                 lrow[tid] = rm;
             }
             issue_w(nt0, 0);
@@ -1048,6 +1049,7 @@ gemm_q8_rows_kernel(const void* __restrict__ Asrc, const int8_t* __restrict__ W,
                     rmine.xs = xs; rmine.za = (int)xz - 128; rmine.rowsum = lrow[tid].rowsum; rmine.pad = 0;
                 }
                 rmine.rowsum -= (int)K * rmine.za;
+                rmine.za = -rmine.za;  // (as y_of takes it)
                 if constexpr (MU && EPI == Q8_EPI_GELU_RANGE) {
                     // range pass: a row that is not part of the row block's (one) unit — beyond its call's own padded length, or past
                     // M — yields NaN; with several units in the block the marks are set per unit and tile (below)
@@ -1088,13 +1090,29 @@ gemm_q8_rows_kernel(const void* __restrict__ Asrc, const int8_t* __restrict__ W,
                         acc[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1[c][i], w1[j], acc[i][j], 0, 0, 0);
                     }
             }
+            // y_of reads the accumulators through inline asm, which the compiler's hazard recogniser does not pad: an MFMA's
+            // result must not be read for up to 12 wait states (8-pass XDL; cdna_hip_programming.md 5.7).  Every later read of
+            // acc goes through this statement's outputs, so none is scheduled above it.
+            asm volatile("s_nop 15"
+                         : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]), "+v"(acc[2][0]), "+v"(acc[2][1]),
+                           "+v"(acc[3][0]), "+v"(acc[3][1]));
             // y = float(acc with the zero points back in) * (x_scale * W_scale) + bias
             Q8ColMeta cm[2];
+            float csc[2];  // one unit, parameters known to the kernel: x_scale * W_scale per column, once per tile
 #pragma unroll
-            for (int j = 0; j < 2; ++j) cm[j] = lcm[wc * 32 + j * 16 + l15];
+            for (int j = 0; j < 2; ++j) {
+                cm[j] = lcm[wc * 32 + j * 16 + l15];
+                cm[j].zw = -cm[j].zw;
+                csc[j] = __fmul_rn(xs, cm[j].ws);
+            }
+            // the zero points back in: acc - zw rowsum' - za colsum as two v_mad_i32_i24 (|operands| < 2^17; lrow holds -za, cm
+            // -zw) — through __mul24 the compiler spent five instructions per element on this, three of them sign extensions
             auto y_of = [&](const Q8RowMeta& rm, int i, int r, int j) {
-                const int corr = acc[i][j][r] - __mul24(cm[j].zw, rm.rowsum) - __mul24(rm.za, cm[j].colsum);
-                return __fadd_rn(__fmul_rn((float)corr, __fmul_rn(rm.xs, cm[j].ws)), cm[j].bias);
+                int corr;
+                asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(corr) : "v"(cm[j].zw), "v"(rm.rowsum), "v"(acc[i][j][r]));
+                asm("v_mad_i32_i24 %0, %1, %2, %0" : "+v"(corr) : "v"(rm.za), "v"(cm[j].colsum));
+                const float sc = (SRC != QR_PREQUANT && !MU) ? csc[j] : __fmul_rn(rm.xs, cm[j].ws);
+                return __fadd_rn(__fmul_rn((float)corr, sc), cm[j].bias);
             };
             if constexpr (EPI == Q8_EPI_GELU_RANGE) {
                 // max y per element; the two neighbours a, b of the GELU's minimum (q8_params_gelu) only when this tile holds a
@@ -1165,17 +1183,16 @@ gemm_q8_rows_kernel(const void* __restrict__ Asrc, const int8_t* __restrict__ W,
                             const Q8RowOut ro = lout[wr * 64 + i * 16 + 4 * g + r];
                             gs = ro.gs; gz = ro.gz; rgs = ro.rgs;
                         }
+                        const float gz128 = gz - 128.0f;  // (the stored byte is the uint8 minus 128: folded into the zero point, exact)
 #pragma unroll
                         for (int j = 0; j < 2; ++j) {
-                            const float y = y_of(rm, i, r, j);
-                            {
-                                const float v = sh_gelu_erf(y);
-                                const float t = v * rgs;
-                                float rt = rintf(t);
-                                if (fabsf(fabsf(t - rt) - 0.5f) < 1.0e-3f) rt = rintf(__fdiv_rn(v, gs));
-                                const float q = fminf(fmaxf(__fadd_rn(rt, gz), 0.0f), 255.0f);
-                                tile8[(wr * 64 + i * 16 + 4 * g + r) * 128 + wc * 32 + j * 16 + l15] = (int8_t)((int)q - 128);
-                            }
+                            const float v = sh_gelu_erf(y_of(rm, i, r, j));
+                            const float t = v * rgs;
+                            float rt = rintf(t);
+                            // |t - rint(t)| <= 0.5: within 1e-3 of a tie exactly when it exceeds 0.499
+                            if (fabsf(t - rt) > 0.499f) rt = rintf(__fdiv_rn(v, gs));
+                            const float q = fminf(fmaxf(__fadd_rn(rt, gz128), -128.0f), 127.0f);
+                            tile8[(wr * 64 + i * 16 + 4 * g + r) * 128 + wc * 32 + j * 16 + l15] = (int8_t)(int)q;
                         }
                     }
                 {
