@@ -509,6 +509,33 @@ def test_queued_submissions_share_a_device_batch_and_keep_their_own_ranges(gpu_l
     emb.close()
 
 
+def test_queued_units_on_the_row_block_kernels(gpu_lib, oracle):
+    """From 4,096 token rows a device batch of several units runs the one-unit path's kernels (per-row parameters on load,
+    per-unit ranges from the producers' pairs, the two-pass FFN-up per unit): same bars against the oracle per submission,
+    and against CS_Q8_ROWS_UNITS=0's general form the distance is the same flip noise."""
+    from codesearch_amd import FastEmbedder, ModelType
+
+    cfg = BertConfig(vocab_size=900, hidden=384, layers=2, heads=12, intermediate=1536, max_position=160, pooling=POOL_MEAN)
+    params, wscale = quantize_linear_weights(cfg, synth_params(cfg, 41), per_channel=True, unsigned=True)
+    emb = FastEmbedder(ModelType.AllMiniLML6V2Q, config=cfg, params=params, wscale=wscale)
+    rng = np.random.default_rng(5)
+    subs = []
+    for n, L in ((20, 128), (1, 9), (10, 100), (12, 128), (3, 37)):      # 46 rows x 128 = 5,888 token rows, five units
+        ids, mask = synth_token_batch(cfg, int(rng.integers(1, 1000)), n, L, True)
+        ids[0, -1], mask[0, -1] = 102, 1
+        subs.append((ids, mask))
+    emb.profile_read(reset=True)
+    tickets = [emb.submit_ids(i, m) for i, m in subs]
+    got = [emb.wait(t) for t in tickets]
+    _, forwards = emb.profile_read()
+    assert forwards == 1, forwards
+    for (ids, mask), g in zip(subs, got):
+        want = oracle.bert_forward(cfg, params, ids, mask, wscale=wscale)["pooled"]
+        e = np.abs(g - want)
+        assert np.isfinite(g).all() and e.max() < 4e-3 and e.mean() < 2.5e-4, (ids.shape, e.max(), e.mean())
+    emb.close()
+
+
 def test_random_shapes_and_unit_mixes_stay_within_the_flip_noise(gpu_lib, oracle):
     """Shapes the fixed cases do not visit: one-token rows, a single row, batches around the kernels' tile and row-block
     thresholds, queued units of very different lengths (so most of a unit's rows lie beyond its own padded length)."""
