@@ -511,8 +511,9 @@ def test_queued_submissions_share_a_device_batch_and_keep_their_own_ranges(gpu_l
 
 def test_queued_units_on_the_row_block_kernels(gpu_lib, oracle):
     """From 4,096 token rows a device batch of several units runs the one-unit path's kernels (per-row parameters on load,
-    per-unit ranges from the producers' pairs, the two-pass FFN-up per unit): same bars against the oracle per submission,
-    and against CS_Q8_ROWS_UNITS=0's general form the distance is the same flip noise."""
+    per-unit ranges from the producers' pairs, the two-pass FFN-up per unit): one forward, and the same bars against the
+    oracle per submission as the general form is held to (its operators are compared with numpy unit by unit in
+    test_row_block_products_over_several_units)."""
     from codesearch_amd import FastEmbedder, ModelType
 
     cfg = BertConfig(vocab_size=900, hidden=384, layers=2, heads=12, intermediate=1536, max_position=160, pooling=POOL_MEAN)
