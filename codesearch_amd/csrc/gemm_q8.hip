@@ -828,7 +828,9 @@ __device__ __forceinline__ void q8_rows_store(const float* ctile, const float* r
 // names each row's unit (bit 31: the row lies beyond its call's own padded length — quantised with the unit's
 // parameters, never part of a range), in_range and rq.range are the units' slot arrays.  Every row is quantised with its
 // own unit's parameters; the FFN-up range pass keeps ONE unit's extremes per wave at a time and hands them to that unit's
-// slot whenever the rows it walks change unit (row blocks of one unit — the usual case — cost one compare per row).
+// slot whenever the rows it walks change unit.  Rows that are not the current unit's are marked in the LDS row metadata
+// (x_scale = NaN: their y drops out of every max, min and comparison), so a row block of one unit — the usual case — runs
+// the one-unit code per element.
 constexpr int QR_PREQUANT = -1;
 struct Q8RowOut { float gs, gz, rgs; uint32_t slot; };  // MU: a row's output parameters (FFN-up store pass) and slot word
 constexpr int QR_LDS_MU = QR_LDS + 128 * 16;
