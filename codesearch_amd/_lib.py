@@ -133,6 +133,7 @@ SIGNATURES = {
     "cs_tokenizer_destroy": (None, [vp]),
     "cs_tokenizer_vocab_size": (C.c_uint32, [vp]),
     "cs_tokenizer_max_length": (C.c_uint32, [vp]),
+    "cs_tokenizer_pad_id": (C.c_int32, [vp]),
     "cs_tokenizer_token_to_id": (C.c_int32, [vp, C.c_char_p]),
     "cs_tokenizer_encode_batch": (C.c_int32, [vp, C.c_char_p, u64p, C.c_uint32, C.c_uint32, i32p, i32p,
                                               C.c_uint32, u32p]),

@@ -23,6 +23,7 @@
 
 #include "../../include/cs_bert_params.h"
 #include "common.hpp"
+#include "unigram.hpp"
 
 namespace {
 
@@ -417,6 +418,220 @@ int32_t cs_embedder_create_from_dir(const char* model_dir, int32_t pooling, int3
     return cs_embedder_create(&cfg, params.data(), 0, device, out);
 }
 
+// ---- tokenizer.json with a SentencePiece-unigram model (the XLM-R vocabulary of the registry's multilingual entries) ----
+// Read into a cs::UnigramSpec (unigram.hpp) — every component must be one unigram.cpp restates, anything else is refused:
+//   model        type Unigram, unk_id, vocab [[piece, score], ...], byte_fallback false
+//   normalizer   null | Precompiled | Replace | Strip | Sequence of those; Replace patterns: Regex " {2,}" or a String
+//   pre_tokenizer  WhitespaceSplit | Metaspace | Sequence of those
+//   post_processor TemplateProcessing whose `single` is <bos> $A <eos>
+//   added_tokens   special, not normalized, not single_word (matched in the raw text)
+static bool base64_decode(const std::string& in, std::string& out) {
+    out.clear();
+    uint32_t acc = 0;
+    int bits = 0;
+    for (unsigned char c : in) {
+        int v;
+        if (c >= 'A' && c <= 'Z') v = c - 'A';
+        else if (c >= 'a' && c <= 'z') v = c - 'a' + 26;
+        else if (c >= '0' && c <= '9') v = c - '0' + 52;
+        else if (c == '+' || c == '-') v = 62;
+        else if (c == '/' || c == '_') v = 63;
+        else if (c == '=' || c == '\n' || c == '\r') continue;
+        else return false;
+        acc = (acc << 6) | (uint32_t)v;
+        bits += 6;
+        if (bits >= 8) {
+            bits -= 8;
+            out.push_back((char)((acc >> bits) & 0xFF));
+        }
+    }
+    return true;
+}
+
+static int32_t unigram_norm(const Json& nz, std::vector<cs::UnigramSpec::Norm>& out) {
+    if (nz.kind == Json::Null) return CS_OK;
+    if (nz.kind != Json::Obj) return fail(CS_ERR_BAD_ARG, "Failed to initialize embedding model: tokenizer.json normalizer is not an object");
+    const Json* ty = nz.get("type");
+    const std::string t = ty && ty->kind == Json::Str ? ty->str : "";
+    cs::UnigramSpec::Norm n;
+    if (t == "Sequence") {
+        const Json* list = nz.get("normalizers");
+        if (!list || list->kind != Json::Arr) return fail(CS_ERR_BAD_ARG, "Failed to initialize embedding model: normalizer Sequence without a list");
+        for (const Json& e : list->arr) CS_TRY(unigram_norm(e, out));
+        return CS_OK;
+    }
+    if (t == "Precompiled") {
+        const Json* b = nz.get("precompiled_charsmap");
+        n.kind = cs::UnigramSpec::Norm::PRECOMPILED;
+        if (b && b->kind == Json::Str && !base64_decode(b->str, n.blob))
+            return fail(CS_ERR_BAD_ARG, "Failed to initialize embedding model: precompiled_charsmap is not base64");
+        out.push_back(std::move(n));
+        return CS_OK;
+    }
+    if (t == "Replace") {
+        const Json* pat = nz.get("pattern");
+        const Json* content = nz.get("content");
+        if (!pat || pat->kind != Json::Obj || !content || content->kind != Json::Str)
+            return fail(CS_ERR_BAD_ARG, "Failed to initialize embedding model: normalizer Replace without pattern / content");
+        n.content = content->str;
+        if (const Json* re = pat->get("Regex")) {
+            if (re->kind != Json::Str || re->str != " {2,}")
+                return fail(CS_ERR_UNSUPPORTED, "Failed to initialize embedding model: normalizer Replace with the regular expression \"%s\" "
+                            "(only \" {2,}\" is built)", re->kind == Json::Str ? re->str.c_str() : "?");
+            n.kind = cs::UnigramSpec::Norm::REPLACE_SPACES;
+        } else if (const Json* st = pat->get("String")) {
+            if (st->kind != Json::Str) return fail(CS_ERR_BAD_ARG, "Failed to initialize embedding model: normalizer Replace pattern is not a string");
+            n.kind = cs::UnigramSpec::Norm::REPLACE_STRING;
+            n.pattern = st->str;
+        } else {
+            return fail(CS_ERR_UNSUPPORTED, "Failed to initialize embedding model: normalizer Replace pattern kind is not built");
+        }
+        out.push_back(std::move(n));
+        return CS_OK;
+    }
+    if (t == "Strip") {
+        n.kind = cs::UnigramSpec::Norm::STRIP;
+        const Json* l = nz.get("strip_left");
+        const Json* r = nz.get("strip_right");
+        n.left = l && l->kind == Json::Bool && l->b;
+        n.right = r && r->kind == Json::Bool && r->b;
+        out.push_back(std::move(n));
+        return CS_OK;
+    }
+    return fail(CS_ERR_UNSUPPORTED, "Failed to initialize embedding model: normalizer \"%s\" is not built for unigram tokenizers", t.c_str());
+}
+
+static int32_t unigram_pre(const Json& pj, std::vector<cs::UnigramSpec::Pre>& out) {
+    if (pj.kind == Json::Null) return CS_OK;
+    if (pj.kind != Json::Obj) return fail(CS_ERR_BAD_ARG, "Failed to initialize embedding model: tokenizer.json pre_tokenizer is not an object");
+    const Json* ty = pj.get("type");
+    const std::string t = ty && ty->kind == Json::Str ? ty->str : "";
+    cs::UnigramSpec::Pre p;
+    if (t == "Sequence") {
+        const Json* list = pj.get("pretokenizers");
+        if (!list || list->kind != Json::Arr) return fail(CS_ERR_BAD_ARG, "Failed to initialize embedding model: pre_tokenizer Sequence without a list");
+        for (const Json& e : list->arr) CS_TRY(unigram_pre(e, out));
+        return CS_OK;
+    }
+    if (t == "WhitespaceSplit") {
+        p.kind = cs::UnigramSpec::Pre::WHITESPACE_SPLIT;
+        out.push_back(p);
+        return CS_OK;
+    }
+    if (t == "Metaspace") {
+        p.kind = cs::UnigramSpec::Pre::METASPACE;
+        const Json* rep = pj.get("replacement");
+        p.replacement = rep && rep->kind == Json::Str ? rep->str : "\xE2\x96\x81";
+        if (p.replacement.empty() || p.replacement == " ")
+            return fail(CS_ERR_UNSUPPORTED, "Failed to initialize embedding model: Metaspace replacement must be one non-space character");
+        p.prepend = 1;
+        if (const Json* ps = pj.get("prepend_scheme")) {
+            if (ps->kind == Json::Str) {
+                if (ps->str == "always") p.prepend = 1;
+                else if (ps->str == "never") p.prepend = 0;
+                else if (ps->str == "first") p.prepend = 2;
+                else return fail(CS_ERR_UNSUPPORTED, "Failed to initialize embedding model: Metaspace prepend_scheme \"%s\"", ps->str.c_str());
+            }
+        } else if (const Json* aps = pj.get("add_prefix_space")) {  // the older serialisation
+            if (aps->kind == Json::Bool) p.prepend = aps->b ? 1 : 0;
+        }
+        const Json* sp = pj.get("split");
+        p.split = !(sp && sp->kind == Json::Bool && !sp->b);
+        out.push_back(p);
+        return CS_OK;
+    }
+    return fail(CS_ERR_UNSUPPORTED, "Failed to initialize embedding model: pre_tokenizer \"%s\" is not built for unigram tokenizers", t.c_str());
+}
+
+static int32_t unigram_from_json(const Json& root, const Json& model, const char* json_path, uint32_t max_length, cs_tokenizer** out) {
+    cs::UnigramSpec spec;
+    const Json* vocab = model.get("vocab");
+    if (!vocab || vocab->kind != Json::Arr || vocab->arr.empty())
+        return fail(CS_ERR_BAD_ARG, "Failed to initialize embedding model: %s has no unigram vocabulary", json_path);
+    spec.vocab.reserve(vocab->arr.size());
+    for (const Json& e : vocab->arr) {
+        if (e.kind != Json::Arr || e.arr.size() != 2 || e.arr[0].kind != Json::Str || e.arr[1].kind != Json::Num)
+            return fail(CS_ERR_BAD_ARG, "Failed to initialize embedding model: a unigram vocabulary entry is not [piece, score]");
+        spec.vocab.emplace_back(e.arr[0].str, e.arr[1].num);
+    }
+    const Json* unk = model.get("unk_id");
+    if (!unk || unk->kind != Json::Num || !(unk->num >= 0 && unk->num < (double)spec.vocab.size()))
+        return fail(CS_ERR_UNSUPPORTED, "Failed to initialize embedding model: unigram model without a valid unk_id");
+    spec.unk_id = (int32_t)unk->num;
+    if (const Json* bf = model.get("byte_fallback"))
+        if (bf->kind == Json::Bool && bf->b) return fail(CS_ERR_UNSUPPORTED, "Failed to initialize embedding model: unigram byte_fallback is not built");
+    if (const Json* nz = root.get("normalizer")) CS_TRY(unigram_norm(*nz, spec.norms));
+    if (const Json* pj = root.get("pre_tokenizer")) CS_TRY(unigram_pre(*pj, spec.pres));
+    auto id_of = [&](const std::string& piece) -> int32_t {
+        int32_t id = -1;
+        for (size_t i = 0; i < spec.vocab.size(); ++i)
+            if (spec.vocab[i].first == piece) id = (int32_t)i;
+        return id;
+    };
+    if (const Json* at = root.get("added_tokens")) {
+        if (at->kind == Json::Arr)
+            for (const Json& e : at->arr) {
+                if (e.kind != Json::Obj) continue;
+                const Json* content = e.get("content");
+                const Json* id = e.get("id");
+                if (!content || content->kind != Json::Str || !id || id->kind != Json::Num || content->str.empty()) continue;
+                auto flag = [&](const char* k) { const Json* v = e.get(k); return v && v->kind == Json::Bool && v->b; };
+                if (flag("single_word") || flag("normalized"))
+                    return fail(CS_ERR_UNSUPPORTED, "Failed to initialize embedding model: added token \"%s\" is single_word / normalized (not built)",
+                                content->str.c_str());
+                if (!(id->num >= 0 && id->num < (double)spec.vocab.size()))
+                    return fail(CS_ERR_UNSUPPORTED, "Failed to initialize embedding model: added token \"%s\" lies outside the unigram vocabulary",
+                                content->str.c_str());
+                cs::UnigramSpec::Added a;
+                a.text = content->str;
+                a.id = (int32_t)id->num;
+                a.lstrip = flag("lstrip");
+                a.rstrip = flag("rstrip");
+                spec.added.push_back(std::move(a));
+            }
+    }
+    // TemplateProcessing: single = [SpecialToken bos, Sequence A, SpecialToken eos]
+    std::string bos = "<s>", eos = "</s>";
+    if (const Json* pp = root.get("post_processor")) {
+        if (pp->kind == Json::Obj) {
+            const Json* ty = pp->get("type");
+            if (!ty || ty->kind != Json::Str || ty->str != "TemplateProcessing")
+                return fail(CS_ERR_UNSUPPORTED, "Failed to initialize embedding model: post_processor \"%s\" is not built for unigram tokenizers",
+                            ty && ty->kind == Json::Str ? ty->str.c_str() : "?");
+            const Json* single = pp->get("single");
+            if (!single || single->kind != Json::Arr || single->arr.size() != 3)
+                return fail(CS_ERR_UNSUPPORTED, "Failed to initialize embedding model: TemplateProcessing `single` is not <bos> $A <eos>");
+            auto special = [&](const Json& e, std::string& name) {
+                const Json* st = e.kind == Json::Obj ? e.get("SpecialToken") : nullptr;
+                const Json* id = st && st->kind == Json::Obj ? st->get("id") : nullptr;
+                if (!id || id->kind != Json::Str) return false;
+                name = id->str;
+                return true;
+            };
+            const Json* seq = single->arr[1].kind == Json::Obj ? single->arr[1].get("Sequence") : nullptr;
+            if (!special(single->arr[0], bos) || !special(single->arr[2], eos) || !seq)
+                return fail(CS_ERR_UNSUPPORTED, "Failed to initialize embedding model: TemplateProcessing `single` is not <bos> $A <eos>");
+        }
+    } else {
+        return fail(CS_ERR_UNSUPPORTED, "Failed to initialize embedding model: unigram tokenizer.json without a post_processor");
+    }
+    spec.bos = id_of(bos);
+    spec.eos = id_of(eos);
+    spec.pad = id_of("<pad>");
+    if (const Json* pad = root.get("padding"))
+        if (pad->kind == Json::Obj)
+            if (const Json* pid = pad->get("pad_id"))
+                if (pid->kind == Json::Num && pid->num >= 0 && pid->num < (double)spec.vocab.size()) spec.pad = (int32_t)pid->num;
+    if (max_length == 0) {
+        max_length = 512;  // fastembed's default truncation length
+        if (const Json* tr = root.get("truncation"))
+            if (tr->kind == Json::Obj)
+                if (const Json* ml = tr->get("max_length"))
+                    if (ml->kind == Json::Num && ml->num >= 2 && ml->num <= 1e6) max_length = (uint32_t)ml->num;
+    }
+    return cs::tokenizer_from_unigram(std::move(spec), max_length, out);
+}
+
 // ---- tokenizer.json (the `tokenizers` crate's serialisation; what fastembed loads) ------------------
 // Read: model.type == "WordPiece", model.vocab {token: id}, model.unk_token / continuing_subword_prefix /
 // max_input_chars_per_word (must be the BERT values cs_tokenizer implements), normalizer BertNormalizer
@@ -437,8 +652,9 @@ int32_t cs_tokenizer_create_from_json(const char* json_path, uint32_t max_length
     if (!model || model->kind != Json::Obj)
         return fail(CS_ERR_BAD_ARG, "Failed to initialize embedding model: %s has no \"model\" object", json_path);
     const Json* type = model->get("type");
+    if (type && type->kind == Json::Str && type->str == "Unigram") return unigram_from_json(root, *model, json_path, max_length, out);
     if (type && type->kind == Json::Str && type->str != "WordPiece")
-        return fail(CS_ERR_UNSUPPORTED, "Failed to initialize embedding model: tokenizer model \"%s\" (only WordPiece is built)",
+        return fail(CS_ERR_UNSUPPORTED, "Failed to initialize embedding model: tokenizer model \"%s\" (WordPiece and Unigram are built)",
                     type->str.c_str());
     const Json* vocab = model->get("vocab");
     if (!vocab || vocab->kind != Json::Obj || vocab->obj.empty())

@@ -819,7 +819,7 @@ int32_t embed_texts_impl(cs_embedder* h, const cs_tokenizer* t, const char* utf8
         if (offsets[i + 1] < offsets[i]) return fail(CS_ERR_BAD_ARG, "text offsets must be non-decreasing");
     if (batch == 0) batch = default_batch(h);
     const uint32_t max_length = h->cfg.max_position;
-    const int32_t pad = cs_tokenizer_token_to_id(t, "[PAD]");
+    const int32_t pad = cs_tokenizer_pad_id(t);  // [PAD], or <pad> of a unigram tokenizer.json
     const uint32_t H = h->cfg.hidden;
     const uint64_t window = (uint64_t)batch * 16;
     auto span = [&](uint64_t lo) { return (uint32_t)std::min<uint64_t>(window, n - lo); };

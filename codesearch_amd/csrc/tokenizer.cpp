@@ -23,11 +23,14 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
+#include <new>
 #include <string>
 #include <thread>
 #include <vector>
 
 #include "common.hpp"
+#include "unigram.hpp"
 
 namespace {
 
@@ -133,6 +136,9 @@ struct cs_tokenizer {
     uint32_t max_token_bytes = 0;
     struct Special { std::string text; int32_t id; };
     std::vector<Special> specials;  // matched verbatim in the raw text, longest first
+    // a SentencePiece-unigram tokenizer.json (unigram.cpp) instead of the WordPiece tables above: cls / sep / pad are then
+    // its <s> / </s> / <pad>, size its vocabulary
+    std::shared_ptr<cs::UnigramEngine> unigram;
 
     int32_t find(uint64_t h, const char* a, uint32_t alen, const char* b, uint32_t blen) const {
         // key = a ++ b (a is the optional "##")
@@ -349,6 +355,10 @@ void tokenize_texts(const cs_tokenizer* t, const char* utf8, const uint64_t* off
     auto work = [&](uint32_t lo, uint32_t hi) {
         for (uint32_t i = lo; i < hi; ++i) {
             std::vector<int32_t>& ids = out[i];
+            if (t->unigram) {
+                t->unigram->encode(utf8 + offsets[i], (size_t)(offsets[i + 1] - offsets[i]), body, ids);
+                continue;
+            }
             ids.push_back(t->cls);
             Encoder enc(*t, ids, body + 1);
             enc.encode(reinterpret_cast<const unsigned char*>(utf8) + offsets[i], (size_t)(offsets[i + 1] - offsets[i]));
@@ -369,6 +379,26 @@ void tokenize_texts(const cs_tokenizer* t, const char* utf8, const uint64_t* off
             }
         });
     for (auto& x : th) x.join();
+}
+
+int32_t tokenizer_from_unigram(UnigramSpec&& spec, uint32_t max_length, cs_tokenizer** out) {
+    if (!out) return fail(CS_ERR_BAD_ARG, "null out pointer");
+    *out = nullptr;
+    if (max_length < 2) return fail(CS_ERR_BAD_ARG, "max_length %u leaves no room for <s> and </s>", max_length);
+    std::shared_ptr<UnigramEngine> eng;
+    CS_TRY(UnigramEngine::create(std::move(spec), &eng));
+    cs_tokenizer* t = new (std::nothrow) cs_tokenizer();
+    if (!t) return fail(CS_ERR_OOM, "out of host memory");
+    t->unigram = eng;
+    t->lowercase = false;
+    t->max_length = max_length;
+    t->size = eng->vocab_size();
+    t->cls = eng->bos();
+    t->sep = eng->eos();
+    t->pad = eng->pad();
+    t->unk = -1;
+    *out = t;
+    return CS_OK;
 }
 
 }  // namespace cs
@@ -426,8 +456,10 @@ void cs_tokenizer_destroy(cs_tokenizer* t) { delete t; }
 
 uint32_t cs_tokenizer_vocab_size(const cs_tokenizer* t) { return t ? t->size : 0; }
 uint32_t cs_tokenizer_max_length(const cs_tokenizer* t) { return t ? t->max_length : 0; }
+int32_t cs_tokenizer_pad_id(const cs_tokenizer* t) { return t ? t->pad : -1; }
 
 int32_t cs_tokenizer_token_to_id(const cs_tokenizer* t, const char* token) {
+    if (t && token && t->unigram) return t->unigram->token_to_id(std::string(token));
     return (t && token) ? t->find(std::string(token)) : -1;
 }
 

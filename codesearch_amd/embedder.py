@@ -79,13 +79,12 @@ class ModelType(enum.Enum):
             return BertConfig(pooling=POOL_CLS)
         if self in (ModelType.AllMiniLML6V2, ModelType.AllMiniLML6V2Q):
             return BertConfig(layers=6, pooling=POOL_MEAN)
-        if self is ModelType.ParaphraseMLMiniLML12V2:
-            # embedder.rs:58 maps this entry to fastembed's ParaphraseMLMiniLML12V2 = paraphrase-multilingual-
-            # MiniLM-L12-v2 (12 layers, a ~250k-entry SentencePiece/unigram vocabulary) whatever name() says
-            # (embedder.rs:103): a WordPiece tokenizer would embed a different model.
-            raise CsError(_lib.CS_ERR_UNSUPPORTED,
-                          f"Failed to initialize embedding model: {self.name_str()} needs a unigram (SentencePiece) "
-                          "tokenizer, which is not built")
+        if self in (ModelType.ParaphraseMLMiniLML12V2, ModelType.MultilingualE5Small):
+            # embedder.rs:58 maps the first entry to fastembed's ParaphraseMLMiniLML12V2 = paraphrase-multilingual-
+            # MiniLM-L12-v2 whatever name() says (embedder.rs:103); both are BERT encoders (12 x 384, absolute positions)
+            # over the ~250k-piece XLM-R SentencePiece vocabulary [3P-MEM: their config.json], mean pooling: the
+            # tokenizer.json they ship is a unigram model, which csrc/unigram.cpp runs (cs_tokenizer_create_from_json)
+            return BertConfig(vocab_size=250037, layers=12, pooling=POOL_MEAN)
         if self in (ModelType.AllMiniLML12V2, ModelType.AllMiniLML12V2Q):
             return BertConfig(layers=12, pooling=POOL_MEAN)
         if self is ModelType.BGEBaseENV15:     # BERT-base: 12 x 768, 12 heads of 64
@@ -94,7 +93,7 @@ class ModelType(enum.Enum):
             return BertConfig(hidden=1024, layers=24, heads=16, intermediate=4096, pooling=POOL_CLS)
         raise CsError(_lib.CS_ERR_UNSUPPORTED,
                       f"Failed to initialize embedding model: {self.name_str()} is not a BERT encoder with absolute "
-                      "positions (rotary / ALiBi / XLM-R families are not built)")
+                      "positions (the rotary, ALiBi and ModernBERT families are not built)")
 
 
 # second spellings accepted by ModelType::parse (embedder.rs:178-195), verbatim

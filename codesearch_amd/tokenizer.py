@@ -31,7 +31,9 @@ def pack_texts(texts: Sequence[str]):
 class WordPieceTokenizer:
     """The product tokenizer: cs_tokenizer_* of libcsgpu.so (csrc/tokenizer.cpp), the C++
     restatement of the `tokenizers` 0.22.2 BERT pipeline fastembed runs.  `vocab` is a
-    {token: id} dict with contiguous ids, or use from_vocab_file for a vocab.txt."""
+    {token: id} dict with contiguous ids, or use from_vocab_file for a vocab.txt.  A tokenizer.json
+    (from_tokenizer_json / from_dir) may also hold a SentencePiece-unigram model — the XLM-R vocabulary of
+    the registry's multilingual entries — which csrc/unigram.cpp runs behind the same handle."""
 
     def __init__(self, vocab: Dict[str, int] = None, lowercase: bool = True, max_length: int = 512,
                  vocab_file: str = None, tokenizer_json: str = None, model_dir: str = None):
@@ -56,7 +58,7 @@ class WordPieceTokenizer:
         if not max_length:  # the handle's own truncation length (from the json / directory)
             max_length = int(self._lib.cs_tokenizer_max_length(h))
         self.max_length = max_length
-        self.pad_id = self.token_to_id("[PAD]")
+        self.pad_id = int(self._lib.cs_tokenizer_pad_id(h))  # [PAD], or <pad> of a unigram tokenizer.json
 
     @classmethod
     def from_vocab_file(cls, path: str, **kw) -> "WordPieceTokenizer":

@@ -458,6 +458,7 @@ int32_t cs_tokenizer_create_from_dir(const char* model_dir, uint32_t max_length,
 void cs_tokenizer_destroy(cs_tokenizer* t);
 uint32_t cs_tokenizer_vocab_size(const cs_tokenizer* t);
 uint32_t cs_tokenizer_max_length(const cs_tokenizer* t);  /* the handle's truncation length */
+int32_t cs_tokenizer_pad_id(const cs_tokenizer* t);       /* [PAD] (WordPiece) or <pad> (unigram): what encode_batch pads with */
 int32_t cs_tokenizer_token_to_id(const cs_tokenizer* t, const char* token); /* -1 = absent */
 /* Tokenizer::encode_batch.  Text i is utf8[offsets[i] .. offsets[i+1]) (n+1 offsets).
  * max_length 0 = the handle's.  *out_len = the batch's longest sequence L (<= max_length).

@@ -340,6 +340,40 @@ def test_text_entry_points_with_tokenizer(FE, oracle):
     assert ei.value.code == CS_ERR_UNSUPPORTED
 
 
+def test_text_entry_points_with_a_unigram_tokenizer(FE, oracle, tmp_path):
+    """The registry's multilingual entries (multilingual-e5-small, paraphrase-multilingual-MiniLM: embedder.rs:58,70) are
+    BERT encoders over a SentencePiece-unigram vocabulary: strings -> csrc/unigram.cpp on the host -> the encoder on the
+    GPU, against the `tokenizers` library's ids through the encoder oracle (a small unigram model trained here:
+    tests/golden/make_unigram_golden.py)."""
+    pytest.importorskip("sentencepiece")
+    tokenizers = pytest.importorskip("tokenizers")
+    import sys
+
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    import make_unigram_golden as G
+
+    from codesearch_amd.tokenizer import WordPieceTokenizer
+
+    path = str(tmp_path / "tokenizer.json")
+    hf = G.build(path, "published")
+    tok = WordPieceTokenizer.from_tokenizer_json(path)
+    assert tok.vocab_size() == hf.get_vocab_size() and tok.pad_id == hf.token_to_id("<pad>")
+    cfg = BertConfig(vocab_size=tok.vocab_size(), layers=2, pooling=POOL_MEAN)
+    emb = FE(cfg, seed=29, tokenizer=tok)
+    texts = G.MULTI[:8] + ["fn main() { println!(\"hello\"); }", "", "x" * 90]
+    got = np.stack(emb.embed_batch(texts))
+    enc = hf.encode_batch(texts)
+    L = max(len(e.ids) for e in enc)
+    ids = np.full((len(texts), L), hf.token_to_id("<pad>"), np.int32)
+    mask = np.zeros((len(texts), L), np.int32)
+    for i, e in enumerate(enc):
+        ids[i, :len(e.ids)] = e.ids
+        mask[i, :len(e.ids)] = 1
+    ref = oracle.bert_forward(cfg, synth_params(cfg, 29), ids, mask)["pooled"]
+    np.testing.assert_allclose(got, ref, atol=TOL_ORACLE)
+    emb.close()
+
+
 def test_text_pipeline_index_and_search(FE):
     """pipeline.index_text_chunks / search_text_queries: strings -> cs_embedder_embed_texts_device ->
     cs_index_add_device -> batched search; a prefix of a chunk must retrieve that chunk, and the result

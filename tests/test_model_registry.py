@@ -60,9 +60,11 @@ def test_gpu_runnable_architectures():
     for m in (M.BGELargeENV15, M.MxbaiEmbedLargeV1):
         c = m.bert_config()
         assert (c.hidden, c.layers, c.heads, c.intermediate) == (1024, 24, 16, 4096)
-    for m in (M.NomicEmbedTextV1, M.NomicEmbedTextV15, M.JinaEmbeddingsV2BaseCode, M.MultilingualE5Small,
-              M.ModernBertEmbedLarge, M.ParaphraseMLMiniLML12V2):  # the last: unigram tokenizer (embedder.rs:58)
-        with pytest.raises(CsError):
+    for m in (M.MultilingualE5Small, M.ParaphraseMLMiniLML12V2):  # BERT encoders over the XLM-R unigram vocabulary (embedder.rs:58,70)
+        c = m.bert_config()
+        assert (c.hidden, c.layers, c.heads, c.intermediate, c.vocab_size, c.pooling) == (384, 12, 12, 1536, 250037, POOL_MEAN)
+    for m in (M.NomicEmbedTextV1, M.NomicEmbedTextV15, M.NomicEmbedTextV15Q, M.JinaEmbeddingsV2BaseCode, M.ModernBertEmbedLarge):
+        with pytest.raises(CsError):  # rotary / ALiBi / ModernBERT: other encoders
             m.bert_config()
     for m in M.all():  # what the configs produce is what the registry promises
         try:

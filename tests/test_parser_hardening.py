@@ -90,6 +90,26 @@ def test_tokenizer_json_and_vocab_readers_survive(fuzz, tmp_path):
     fuzz("vocab", v, seed=16)
 
 
+def test_unigram_tokenizer_json_reader_survives(fuzz, tmp_path):
+    """A tokenizer.json with a SentencePiece-unigram model (csrc/unigram.cpp): the piece list, the base64 precompiled
+    character map (a double-array trie walked with indices taken from the file) and the component lists, mutated."""
+    pytest.importorskip("sentencepiece")
+    import sys
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import make_unigram_golden as G
+
+    p = tmp_path / "tokenizer.json"
+    G.build(str(p), "published")
+    fuzz("tokenizer_json", p, seed=21, flips=200)
+    # without the (large) character map the mutations land on the pieces, scores and component objects
+    d = json.load(open(p, encoding="utf-8"))
+    d["normalizer"]["normalizers"][0]["precompiled_charsmap"] = ""  # (an empty map normalises nothing)
+    small = tmp_path / "small.json"
+    small.write_text(json.dumps(d), encoding="utf-8")
+    fuzz("tokenizer_json", small, seed=22, flips=300)
+
+
 def test_config_json_reader_survives(fuzz, tmp_path):
     cfg = {"model_type": "bert", "hidden_act": "gelu", "vocab_size": 48, "hidden_size": 384, "num_hidden_layers": 2,
            "num_attention_heads": 12, "intermediate_size": 1536, "max_position_embeddings": 16, "type_vocab_size": 2,
