@@ -449,7 +449,12 @@ int32_t cs_tokenizer_create_from_file(const char* vocab_path, int32_t lowercase,
 /* tokenizer.json of the `tokenizers` crate — the file fastembed builds its tokenizer from: WordPiece
  * model.vocab, BertNormalizer.lowercase, truncation.max_length.  max_length 0 = the file's truncation
  * length, 512 (fastembed's default) when it has none.  Anything that is not the BERT pipeline
- * cs_tokenizer implements (another model type, prefix, unk token or normalizer) is refused. */
+ * cs_tokenizer implements (another model type, prefix, unk token or normalizer) is refused.
+ * A file whose model.type is "Unigram" (SentencePiece vocabularies: the registry's multilingual entries,
+ * /root/reference/src/embed/embedder.rs:58,70) is read by csrc/unigram.cpp instead: model.vocab [[piece, score]],
+ * unk_id; normalizer Precompiled / Replace(Regex " {2,}" or a String) / Strip (or a Sequence of them);
+ * pre_tokenizer WhitespaceSplit / Metaspace; post_processor TemplateProcessing <bos> $A <eos>; special added
+ * tokens.  The handle then encodes <s> ... </s> and pads with <pad>; any other component is refused. */
 int32_t cs_tokenizer_create_from_json(const char* tokenizer_json_path, uint32_t max_length,
                                       cs_tokenizer** out);
 /* A model directory: tokenizer.json when present, else vocab.txt with tokenizer_config.json's
