@@ -62,6 +62,38 @@ def test_random_strings_match_the_library(lib):
     assert bad == 0, (bad, total)
 
 
+def test_a_vocabulary_of_xlmr_size(lib, files, tmp_path):
+    """XLM-R's vocabulary has 250,002 pieces: the same file with 120,000 more pieces (random lower-case strings, half of
+    them word-initial, among them repeats of existing pieces with other scores) loads in a fraction of a second and
+    still segments exactly as the library does."""
+    import random
+    import time
+
+    from tokenizers import Tokenizer
+
+    path, _ = files["published"]
+    d = json.load(open(path, encoding="utf-8"))
+    rng = random.Random(5)
+    alpha = "abcdefghijklmnopqrstuvwxyz"
+    extra = []
+    for _ in range(120_000):
+        w = ("▁" if rng.random() < 0.5 else "") + "".join(rng.choice(alpha) for _ in range(rng.randint(1, 9)))
+        extra.append([w, -8.0 - rng.random() * 6])      # (repeats happen: a later entry wins, as in the library's map)
+    mask = d["model"]["vocab"].pop()                     # <mask> stays last
+    d["model"]["vocab"] += extra + [mask]
+    for a in d["added_tokens"]:
+        if a["content"] == "<mask>":
+            a["id"] = len(d["model"]["vocab"]) - 1
+    big = str(tmp_path / "big.json")
+    json.dump(d, open(big, "w", encoding="utf-8"), ensure_ascii=False)
+    texts = [" ".join("".join(rng.choice(alpha) for _ in range(rng.randint(1, 10))) for _ in range(100)) for _ in range(200)]
+    want = [e.ids for e in Tokenizer.from_file(big).encode_batch(texts)]
+    t0 = time.time()
+    got = F.encode_all(lib, big, texts)
+    assert got == want
+    assert time.time() - t0 < 20.0
+
+
 def test_truncation_and_handle_properties(lib, files):
     """max_length counts <s> and </s>; 0 takes the file's truncation.max_length; padding is <pad>; lookups by piece."""
     path, tok = files["published"]
