@@ -116,7 +116,9 @@ int main(int argc, char** argv) {
             cs_tokenizer* t = nullptr;
             st = cs_tokenizer_create_from_json(target.c_str(), 0, &t);
             if (st == CS_OK && t) {  // a tokenizer that loads must also tokenise
-                const char text[] = "fn main() { let caf\xc3\xa9 = [SEP] 42; }";
+                // (accents composed and combining, CJK, an emoji ZWJ sequence, width variants, special tokens of both kinds)
+                const char text[] = "fn main() { let caf\xc3\xa9 = [SEP] 42; } e\xcc\x81\xcc\x82 \xe4\xb8\x96\xe7\x95\x8c  <mask> </s>"
+                                    " \xf0\x9f\x91\xa8\xe2\x80\x8d\xf0\x9f\x91\xa9 \xef\xbd\x86\xef\xbd\x95 \xd8\x80\xd9\xa1 \r\n\t end";
                 const uint64_t off[2] = {0, sizeof text - 1};
                 uint32_t L = 0;
                 (void)cs_tokenizer_encode_batch(t, text, off, 1, 0, nullptr, nullptr, 0, &L);
