@@ -20,19 +20,25 @@ def main():
     cfg = mt.bert_config()
     params, wscale = quantize_linear_weights(cfg, synth_params(cfg, 202), per_channel=False, unsigned=True)
     emb = FastEmbedder(mt, config=cfg, params=params, wscale=wscale)
-    ids, mask = synth_token_batch(cfg, 999, 256, 256, False)
-    out = {}
+    # --shape CALLS,CHUNKS,TOKENS: other call shapes (default: the reference's, 8 calls of 32 chunks x 256 tokens)
+    calls, per, L = 8, 32, 256
+    for a in sys.argv[1:]:
+        if a.startswith("--shape="):
+            calls, per, L = (int(x) for x in a[len("--shape="):].split(","))
+    total = calls * per
+    ids, mask = synth_token_batch(cfg, 999, total, L, False)
+    out = {"shape": {"calls": calls, "chunks_per_call": per, "tokens": L}}
     for mode in ("q8", "split"):
         emb.set_gemm_mode(mode)
-        emb.embed_ids(ids[:32], mask[:32])
+        emb.embed_ids(ids[:per], mask[:per])
         t0 = time.perf_counter()
         for _ in range(10):
-            for lo in range(0, 256, 32):
-                emb.embed_ids(ids[lo:lo + 32], mask[lo:lo + 32])
+            for lo in range(0, total, per):
+                emb.embed_ids(ids[lo:lo + per], mask[lo:lo + per])
         one = (time.perf_counter() - t0) / 10
 
         def queued():
-            ts = [emb.submit_ids(ids[lo:lo + 32], mask[lo:lo + 32]) for lo in range(0, 256, 32)]
+            ts = [emb.submit_ids(ids[lo:lo + per], mask[lo:lo + per]) for lo in range(0, total, per)]
             return [emb.wait(t) for t in ts]
 
         queued()
@@ -42,7 +48,7 @@ def main():
             queued()
         q = (time.perf_counter() - t0) / 10
         ms, n = emb.profile_read()
-        out[mode] = {"one_call_at_a_time_chunks_per_s": 256 / one, "queued_chunks_per_s": 256 / q,
+        out[mode] = {"one_call_at_a_time_chunks_per_s": total / one, "queued_chunks_per_s": total / q,
                      "device_ms_per_8_calls_queued": ms / 10, "device_batches_per_8_calls": n / 10}
         if "--stages" in sys.argv:  # per-kernel-class microseconds per layer of the shared device batch (8 units)
             emb.profile_stages(True)
