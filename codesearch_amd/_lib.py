@@ -37,6 +37,8 @@ class BertConfig(C.Structure):
         ("type_vocab_size", C.c_uint32),
         ("layer_norm_eps", C.c_float),
         ("pooling", C.c_int32),
+        ("arch", C.c_uint32),
+        ("rotary_base", C.c_float),
     ]
 
 

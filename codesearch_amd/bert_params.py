@@ -11,6 +11,7 @@ import numpy as np
 from .synth import synth_below, synth_int
 
 POOL_CLS, POOL_MEAN = 0, 1
+ARCH_BERT, ARCH_NOMIC = 0, 1  # cs_encoder_arch
 
 # kind -> (shift, base); cs_bert_synth_rule
 _RULE = {
@@ -30,6 +31,8 @@ class BertConfig:
     type_vocab_size: int = 2
     layer_norm_eps: float = 1e-12
     pooling: int = POOL_CLS
+    arch: int = ARCH_BERT          # ARCH_NOMIC: rotary positions on Q / K, fc2(fc11(x) * silu(fc12(x))), no position table
+    rotary_base: float = 0.0
 
     @staticmethod
     def bge_small() -> "BertConfig":
@@ -40,15 +43,19 @@ class BertConfig:
         from ._lib import BertConfig as CBert
 
         return CBert(self.vocab_size, self.hidden, self.layers, self.heads, self.intermediate,
-                     self.max_position, self.type_vocab_size, self.layer_norm_eps, self.pooling)
+                     self.max_position, self.type_vocab_size, self.layer_norm_eps, self.pooling, self.arch,
+                     self.rotary_base)
 
 
 def tensor_table(cfg: BertConfig) -> List[Tuple[str, Tuple[int, ...], str]]:
-    """[(hf_name, shape, kind)] in flat order (= BertModel(add_pooling_layer=False).state_dict())."""
+    """[(hf_name, shape, kind)] in flat order (= BertModel(add_pooling_layer=False).state_dict()).  ARCH_NOMIC: the same
+    order without the position table and with the gate projection behind the up projection (cs_bert_params.h); the names
+    are this table's own — `nomic_state_dict_names` maps a NomicBert checkpoint onto them."""
     H, I = cfg.hidden, cfg.intermediate
+    nomic = cfg.arch == ARCH_NOMIC
     t = [
         ("embeddings.word_embeddings.weight", (cfg.vocab_size, H), "emb"),
-        ("embeddings.position_embeddings.weight", (cfg.max_position, H), "emb"),
+    ] + ([] if nomic else [("embeddings.position_embeddings.weight", (cfg.max_position, H), "emb")]) + [
         ("embeddings.token_type_embeddings.weight", (cfg.type_vocab_size, H), "emb"),
         ("embeddings.LayerNorm.weight", (H,), "ln_g"),
         ("embeddings.LayerNorm.bias", (H,), "ln_b"),
@@ -62,6 +69,7 @@ def tensor_table(cfg: BertConfig) -> List[Tuple[str, Tuple[int, ...], str]]:
             (p + "attention.output.dense.weight", (H, H), "ao_w"), (p + "attention.output.dense.bias", (H,), "bias"),
             (p + "attention.output.LayerNorm.weight", (H,), "ln_g"), (p + "attention.output.LayerNorm.bias", (H,), "ln_b"),
             (p + "intermediate.dense.weight", (I, H), "up_w"), (p + "intermediate.dense.bias", (I,), "bias"),
+        ] + ([(p + "intermediate.gate.weight", (I, H), "up_w"), (p + "intermediate.gate.bias", (I,), "bias")] if nomic else []) + [
             (p + "output.dense.weight", (H, I), "down_w"), (p + "output.dense.bias", (H,), "bias"),
             (p + "output.LayerNorm.weight", (H,), "ln_g"), (p + "output.LayerNorm.bias", (H,), "ln_b"),
         ]
@@ -134,8 +142,80 @@ def synth_token_batch(cfg: BertConfig, seed: int, B: int, L: int, ragged: bool):
 
 # ---- real checkpoints ----------------------------------------------------------
 
+def nomic_config_from_hf(cfg_json: dict, max_length: int = 512) -> BertConfig:
+    """config.json of a NomicBert checkpoint (nomic-ai/nomic-embed-text-v1 / v1.5: model_type "nomic_bert", GPT-2 style
+    key names) -> BertConfig(arch=ARCH_NOMIC).  Only the published configuration is taken: full rotary fraction,
+    non-interleaved, no scale base, swiglu, post-norm — anything else is refused.  max_position is the sequence bound
+    the tokenizer truncates to (there is no position table to size)."""
+    if cfg_json.get("model_type") != "nomic_bert":
+        raise ValueError(f"model_type {cfg_json.get('model_type')!r} is not nomic_bert")
+    want = {"rotary_emb_fraction": 1.0, "rotary_emb_interleaved": False, "rotary_emb_scale_base": None,
+            "activation_function": "swiglu", "prenorm": False}
+    for key, val in want.items():
+        if key in cfg_json and cfg_json[key] != val:
+            raise ValueError(f"nomic_bert with {key} = {cfg_json[key]!r} is not built (only {val!r})")
+    if cfg_json.get("rotary_scaling_factor") not in (None, 1, 1.0):
+        raise ValueError("nomic_bert with a rotary scaling factor is not built")
+    return BertConfig(vocab_size=cfg_json["vocab_size"], hidden=cfg_json["n_embd"], layers=cfg_json["n_layer"],
+                      heads=cfg_json["n_head"], intermediate=cfg_json.get("n_inner") or 4 * cfg_json["n_embd"],
+                      max_position=min(max_length, cfg_json.get("n_positions", max_length)),
+                      type_vocab_size=cfg_json.get("type_vocab_size", 2),
+                      layer_norm_eps=cfg_json.get("layer_norm_epsilon", 1e-12), pooling=POOL_MEAN, arch=ARCH_NOMIC,
+                      rotary_base=float(cfg_json.get("rotary_emb_base", 10000.0)))
+
+
+def from_nomic_state_dict(cfg: BertConfig, sd) -> np.ndarray:
+    """A NomicBert state dict (names of the model repository's modeling file: emb_ln, encoder.layers.N.attn.Wqkv /
+    out_proj, norm1, mlp.fc11 / fc12 / fc2, norm2) -> the flat block of an ARCH_NOMIC config.  The fused Wqkv is cut into
+    its query / key / value thirds; Linear biases the checkpoint does not hold (the published ones hold none) are zero."""
+    assert cfg.arch == ARCH_NOMIC
+    H = cfg.hidden
+
+    def get(name):
+        for key in (name, "bert." + name, "model." + name):
+            if key in sd:
+                a = sd[key]
+                return a.detach().cpu().numpy() if hasattr(a, "detach") else np.asarray(a)
+        return None
+
+    mapped = {
+        "embeddings.word_embeddings.weight": get("embeddings.word_embeddings.weight"),
+        "embeddings.token_type_embeddings.weight": get("embeddings.token_type_embeddings.weight"),
+        "embeddings.LayerNorm.weight": get("emb_ln.weight"), "embeddings.LayerNorm.bias": get("emb_ln.bias"),
+    }
+    for l in range(cfg.layers):
+        src, dst = f"encoder.layers.{l}.", f"encoder.layer.{l}."
+        wqkv, bqkv = get(src + "attn.Wqkv.weight"), get(src + "attn.Wqkv.bias")
+        if wqkv is None or tuple(wqkv.shape) != (3 * H, H):
+            raise ValueError(f"{src}attn.Wqkv.weight: expected {(3 * H, H)}")
+        for i, role in enumerate(("query", "key", "value")):
+            mapped[dst + f"attention.self.{role}.weight"] = wqkv[i * H:(i + 1) * H]
+            mapped[dst + f"attention.self.{role}.bias"] = None if bqkv is None else bqkv[i * H:(i + 1) * H]
+        for ours, theirs in (("attention.output.dense", "attn.out_proj"), ("attention.output.LayerNorm", "norm1"),
+                             ("intermediate.dense", "mlp.fc11"), ("intermediate.gate", "mlp.fc12"),
+                             ("output.dense", "mlp.fc2"), ("output.LayerNorm", "norm2")):
+            mapped[dst + ours + ".weight"] = get(src + theirs + ".weight")
+            mapped[dst + ours + ".bias"] = get(src + theirs + ".bias")
+    out = np.zeros(param_count(cfg), np.float32)
+    off = 0
+    for name, shape, kind in tensor_table(cfg):
+        n = int(np.prod(shape))
+        a = mapped.get(name)
+        if a is None:
+            if kind != "bias":
+                raise ValueError(f"the checkpoint holds nothing for {name}")
+        else:
+            if tuple(a.shape) != tuple(shape):
+                raise ValueError(f"{name}: expected {shape}, got {a.shape}")
+            out[off:off + n] = a.astype(np.float32).reshape(-1)
+        off += n
+    return out
+
+
 def config_from_hf(cfg_json: dict, pooling: int = POOL_CLS) -> BertConfig:
-    """HF config.json -> BertConfig (BERT family only)."""
+    """HF config.json -> BertConfig (BERT family; nomic_bert through nomic_config_from_hf)."""
+    if cfg_json.get("model_type") == "nomic_bert":
+        return nomic_config_from_hf(cfg_json)
     if cfg_json.get("model_type", "bert") != "bert":
         raise ValueError(f"model_type {cfg_json.get('model_type')!r} is not a BERT encoder")
     if cfg_json.get("hidden_act", "gelu") != "gelu":
@@ -159,7 +239,7 @@ def load_checkpoint(path: str, cfg: BertConfig) -> np.ndarray:
         sd = dict(np.load(path))
     else:
         raise ValueError("expected a .safetensors or .npz checkpoint")
-    return from_state_dict(cfg, sd)
+    return from_nomic_state_dict(cfg, sd) if cfg.arch == ARCH_NOMIC else from_state_dict(cfg, sd)
 
 
 # ---- dynamic-quantised Linear layers (the registry's *Q models) ------------------------------------

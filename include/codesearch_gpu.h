@@ -322,6 +322,13 @@ typedef struct cs_embedder cs_embedder;
 
 typedef enum cs_pooling { CS_POOL_CLS = 0, CS_POOL_MEAN = 1 } cs_pooling;
 
+/* Encoder family.  CS_ARCH_BERT: absolute position embeddings, GELU feed-forward (every BERT / MiniLM / BGE / E5 entry of
+ * the reference's registry, embedder.rs:7-48).  CS_ARCH_NOMIC: the NomicBert encoder of the registry's three Nomic entries
+ * (embedder.rs:30-35: nomic-embed-text-v1 / v1.5 / v1.5-Q) — no position table; rotary angles on Q and K (non-interleaved
+ * halves, pos * base^(-2i/d)); a gated feed-forward  fc2( fc11(x) * silu(fc12(x)) );  post-LayerNorm and everything else as
+ * BERT.  Flat parameter order: cs_bert_params.h. */
+typedef enum cs_encoder_arch { CS_ARCH_BERT = 0, CS_ARCH_NOMIC = 1 } cs_encoder_arch;
+
 typedef struct cs_bert_config {
     uint32_t vocab_size;        /* 30522 for bge-small-en-v1.5 */
     uint32_t hidden;            /* 384  (== ModelType::dimensions, embedder.rs:76-96) */
@@ -332,6 +339,8 @@ typedef struct cs_bert_config {
     uint32_t type_vocab_size;   /* 2 */
     float layer_norm_eps;       /* 1e-12 */
     int32_t pooling;            /* cs_pooling */
+    uint32_t arch;              /* cs_encoder_arch; 0 = BERT (every field above means what it did before this field existed) */
+    float rotary_base;          /* CS_ARCH_NOMIC: base of the rotary angles (1000 for nomic-embed-text-v1 / v1.5); else ignored */
 } cs_bert_config;
 
 /* Fills *cfg with the BAAI/bge-small-en-v1.5 architecture (CLS pooling). */

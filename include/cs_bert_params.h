@@ -20,6 +20,13 @@
  *     output.dense.weight / .bias                [H, I] [H]
  *     output.LayerNorm.weight / .bias            [H] [H]
  *
+ * CS_ARCH_NOMIC (NomicBert: the registry's nomic-embed-text entries) keeps this order with two differences: there is NO
+ * position table (`pos` == `type`: zero floats), and every layer carries a second up-projection behind the first —
+ *     intermediate.dense.weight / .bias          [I, H] [I]     = mlp.fc11 (the value branch)
+ *     intermediate.gate.weight / .bias           [I, H] [I]     = mlp.fc12 (the gate: y = fc11(x) * silu(fc12(x)))
+ * — so that the two are ONE [2I, H] weight for the up-projection GEMM.  The published checkpoints have no Linear biases
+ * (their slots are zero); the encoder applies whatever the slots hold.
+ *
  * Synthetic weights (no checkpoint is reachable from the build/GPU boxes): element at flat
  * offset e of a tensor of kind K is  base(K) + cs_synth_weight(seed, e, shift(K))  — see
  * cs_bert_synth_rule().  Shifts keep activations O(1) and attention non-degenerate.
@@ -54,6 +61,7 @@ CS_SYNTH_FN void cs_bert_synth_rule(int kind, int* shift, float* base) {
 typedef struct cs_bert_layer_offsets {
     uint64_t q_w, q_b, k_w, k_b, v_w, v_b, ao_w, ao_b, ao_ln_g, ao_ln_b;
     uint64_t up_w, up_b, down_w, down_b, out_ln_g, out_ln_b;
+    uint64_t gate_w, gate_b; /* CS_ARCH_NOMIC only (else == down_w) */
 } cs_bert_layer_offsets;
 
 typedef struct cs_bert_offsets {
@@ -67,12 +75,13 @@ CS_SYNTH_FN void cs_bert_layout(const cs_bert_config* c, cs_bert_offsets* o) {
     const uint64_t H = c->hidden, I = c->intermediate;
     uint64_t p = 0;
     o->word = p; p += (uint64_t)c->vocab_size * H;
-    o->pos = p; p += (uint64_t)c->max_position * H;
+    o->pos = p; if (c->arch != CS_ARCH_NOMIC) p += (uint64_t)c->max_position * H;
     o->type = p; p += (uint64_t)c->type_vocab_size * H;
     o->emb_ln_g = p; p += H;
     o->emb_ln_b = p; p += H;
     o->layer0 = p;
     o->layer_stride = 4 * (H * H + H) + 2 * H + (I * H + I) + (H * I + H) + 2 * H;
+    if (c->arch == CS_ARCH_NOMIC) o->layer_stride += I * H + I;
     o->total = p + (uint64_t)c->layers * o->layer_stride;
 }
 
@@ -86,6 +95,8 @@ CS_SYNTH_FN void cs_bert_layer_layout(const cs_bert_config* c, const cs_bert_off
     l->ao_w = p; p += H * H; l->ao_b = p; p += H;
     l->ao_ln_g = p; p += H; l->ao_ln_b = p; p += H;
     l->up_w = p; p += I * H; l->up_b = p; p += I;
+    l->gate_w = p; l->gate_b = p;
+    if (c->arch == CS_ARCH_NOMIC) { p += I * H; l->gate_b = p; p += I; }
     l->down_w = p; p += H * I; l->down_b = p; p += H;
     l->out_ln_g = p; p += H; l->out_ln_b = p; p += H;
 }
@@ -110,6 +121,11 @@ CS_SYNTH_FN int cs_bert_kind_at(const cs_bert_config* c, const cs_bert_offsets* 
     if (r < I * H) return CS_T_FFN_UP_W;
     if (r < I * H + I) return CS_T_BIAS;
     r -= I * H + I;
+    if (c->arch == CS_ARCH_NOMIC) {
+        if (r < I * H) return CS_T_FFN_UP_W;
+        if (r < I * H + I) return CS_T_BIAS;
+        r -= I * H + I;
+    }
     if (r < H * I) return CS_T_FFN_DOWN_W;
     if (r < H * I + H) return CS_T_BIAS;
     r -= H * I + H;

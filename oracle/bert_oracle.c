@@ -12,6 +12,14 @@
  *          x = LayerNorm(x + gelu_erf(x W_1^T + b_1) W_2^T + b_2) }
  * followed by fastembed's pooling (CLS for the BGE family, mean for MiniLM/E5/...) and
  * L2 normalisation v / (|v| + 1e-12).
+ * CS_ARCH_NOMIC (cs_bert_config.arch; the registry's three Nomic entries, /root/reference/src/embed/embedder.rs:30-35,
+ * :64-66 -> fastembed's NomicEmbedTextV1 / V15 / V15Q) restates the NomicBert encoder those files export
+ * (nomic-ai/nomic-embed-text-v1*, `modeling_hf_nomic_bert.py` of the model repository; third-party code, absent here —
+ * restated from its published definition): no position table; Q and K of every head rotated by the non-interleaved
+ * rotary map (x1, x2) -> (x1 cos - x2 sin, x2 cos + x1 sin) over the head's two halves, angle = pos * base^(-2i/d_h)
+ * (f32 throughout, as the module computes its cos / sin cache); the feed-forward is  fc2( fc11(x) * silu(fc12(x)) );
+ * post-LayerNorm, masking, mean pooling and normalisation as above.  Pinned against a float64 torch statement that takes
+ * its rotary map from transformers' own `rotate_half` / `apply_rotary_pos_emb` (tests/golden/make_nomic_golden.py).
  * PARITY UNPINNED against the reference itself (it ships no embedding vectors,
  * SURVEY.md §4, §8c); pinned against HF transformers BertModel (float64) by
  * tests/golden/make_encoder_golden.py -> tests/golden/encoder_golden.npz.
@@ -131,6 +139,29 @@ static void layer_norm_rows(float* x, const float* g, const float* b, size_t T, 
 }
 
 static inline float gelu_erf(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
+static inline float silu(float v) { return v / (1.0f + expf(-v)); }
+
+/* NomicBert: rotary position map on the [T, H] tensor of queries (or keys), head by head, in place.  The cos / sin cache
+ * as the module builds it: inv_freq_i = 1 / base^(2i / d_h), angle = pos * inv_freq_i, all in f32. */
+static void rotary_rows(float* qk, size_t T, size_t L, size_t NH, size_t DH, float base) {
+    const size_t half = DH / 2;
+    float* inv_freq = (float*)malloc(sizeof(float) * half);
+    for (size_t i = 0; i < half; ++i) inv_freq[i] = 1.0f / powf(base, (float)(2 * i) / (float)DH);
+    for (size_t t = 0; t < T; ++t) {
+        const float pos = (float)(t % L);
+        for (size_t h = 0; h < NH; ++h) {
+            float* r = qk + t * NH * DH + h * DH;
+            for (size_t i = 0; i < half; ++i) {
+                const float ang = pos * inv_freq[i];
+                const float c = cosf(ang), s = sinf(ang);
+                const float x1 = r[i], x2 = r[i + half];
+                r[i] = x1 * c - x2 * s;
+                r[i + half] = x2 * c + x1 * s;
+            }
+        }
+    }
+    free(inv_freq);
+}
 
 /* ids/mask: [B, L] int32.  hidden_out: optional [B*L*H] last_hidden_state.  pooled_out:
  * [B, H] pooled + L2-normalised.  layer_hidden_out: optional [layers+1][B*L*H] (embedding
@@ -150,6 +181,8 @@ static void bert_forward_impl(const cs_bert_config* cfg, const float* params, co
     float* ctx = (float*)malloc(sizeof(float) * T * H);
     float* tmp = (float*)malloc(sizeof(float) * T * H);
     float* mid = (float*)malloc(sizeof(float) * T * I);
+    const int nomic = cfg->arch == CS_ARCH_NOMIC;
+    float* gate = nomic ? (float*)malloc(sizeof(float) * T * I) : NULL;
 
     /* embeddings: word + token_type(0) + position, then LayerNorm (HF BertEmbeddings order:
      * inputs_embeds + token_type_embeddings, then + position_embeddings) */
@@ -158,6 +191,10 @@ static void bert_forward_impl(const cs_bert_config* cfg, const float* params, co
         const float* we = params + off.word + (size_t)ids[t] * H;
         const float* pe = params + off.pos + pos * H;
         const float* te = params + off.type; /* token_type_ids = 0 */
+        if (nomic) { /* NomicBertEmbeddings: word + token_type, no position table */
+            for (size_t i = 0; i < H; ++i) x[t * H + i] = we[i] + te[i];
+            continue;
+        }
         for (size_t i = 0; i < H; ++i) x[t * H + i] = (we[i] + te[i]) + pe[i];
     }
     layer_norm_rows(x, params + off.emb_ln_g, params + off.emb_ln_b, T, H, cfg->layer_norm_eps);
@@ -180,6 +217,10 @@ static void bert_forward_impl(const cs_bert_config* cfg, const float* params, co
         DENSE(x, lo.q_w, lo.q_b, q, H, H, 0);
         DENSE(x, lo.k_w, lo.k_b, k, H, H, H);
         DENSE(x, lo.v_w, lo.v_b, v, H, H, 2 * H);
+        if (nomic) {
+            rotary_rows(q, T, L, NH, DH, cfg->rotary_base);
+            rotary_rows(k, T, L, NH, DH, cfg->rotary_base);
+        }
         /* attention per (batch, head, query row) */
 #ifdef _OPENMP
 #pragma omp parallel for collapse(2) schedule(static)
@@ -217,7 +258,12 @@ static void bert_forward_impl(const cs_bert_config* cfg, const float* params, co
         for (size_t i = 0; i < T * H; ++i) x[i] = tmp[i] + x[i]; /* BertSelfOutput: dense + residual */
         layer_norm_rows(x, params + lo.ao_ln_g, params + lo.ao_ln_b, T, H, cfg->layer_norm_eps);
         DENSE(x, lo.up_w, lo.up_b, mid, H, I, 4 * H);
-        for (size_t i = 0; i < T * I; ++i) mid[i] = gelu_erf(mid[i]);
+        if (nomic) { /* NomicBertGatedMLP, activation swiglu: y = fc11(x) * silu(fc12(x)) */
+            linear(x, params + lo.gate_w, params + lo.gate_b, gate, T, H, I);
+            for (size_t i = 0; i < T * I; ++i) mid[i] = mid[i] * silu(gate[i]);
+        } else {
+            for (size_t i = 0; i < T * I; ++i) mid[i] = gelu_erf(mid[i]);
+        }
         DENSE(mid, lo.down_w, lo.down_b, tmp, I, H, 4 * H + I);
 #undef DENSE
         for (size_t i = 0; i < T * H; ++i) x[i] = tmp[i] + x[i];
@@ -249,7 +295,7 @@ static void bert_forward_impl(const cs_bert_config* cfg, const float* params, co
             for (size_t i = 0; i < H; ++i) p[i] /= den;
         }
     }
-    free(x); free(q); free(k); free(v); free(ctx); free(tmp); free(mid);
+    free(x); free(q); free(k); free(v); free(ctx); free(tmp); free(mid); free(gate);
 }
 
 void cs_oracle_bert_forward(const cs_bert_config* cfg, const float* params, const int32_t* ids,

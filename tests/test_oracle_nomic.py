@@ -1,0 +1,115 @@
+"""Pins the CS_ARCH_NOMIC branch of the encoder oracle (oracle/bert_oracle.c: rotary Q / K, swiglu feed-forward, no
+position table) to the committed golden vectors of tests/golden/make_nomic_golden.py (a float64 torch statement built on
+transformers' rotate_half / apply_rotary_pos_emb), and the NomicBert checkpoint-name mapping.  CPU only."""
+import os
+
+import numpy as np
+import pytest
+
+from codesearch_amd.bert_params import (ARCH_NOMIC, POOL_MEAN, BertConfig, from_nomic_state_dict, nomic_config_from_hf,
+                                        param_count, synth_params, synth_token_batch, tensor_table, to_state_dict)
+
+GOLD = np.load(os.path.join(os.path.dirname(__file__), "golden", "nomic_golden.npz"))
+
+
+def case_cfg(name):
+    m = GOLD[name + "/meta"]
+    cfg = BertConfig(vocab_size=int(m[0]), hidden=int(m[1]), layers=int(m[2]), heads=int(m[3]), intermediate=int(m[4]),
+                     max_position=int(m[5]), pooling=POOL_MEAN, arch=ARCH_NOMIC, rotary_base=1000.0)
+    return cfg, int(m[6]), int(m[7]), int(m[8]), int(m[9]), bool(m[10])
+
+
+def test_nomic_layout_and_generator_identity(oracle):
+    cfg = BertConfig(vocab_size=512, hidden=128, layers=2, heads=2, intermediate=256, pooling=POOL_MEAN, arch=ARCH_NOMIC,
+                     rotary_base=1000.0)
+    H, I = cfg.hidden, cfg.intermediate
+    # no position table; one more [I, H] + [I] per layer than BERT
+    bert = BertConfig(vocab_size=512, hidden=128, layers=2, heads=2, intermediate=256)
+    assert param_count(cfg) == param_count(bert) - bert.max_position * H + cfg.layers * (I * H + I)
+    assert oracle.bert_param_count(cfg) == param_count(cfg)
+    assert np.array_equal(oracle.bert_synth_params(cfg, 9), synth_params(cfg, 9))
+    names = [n for n, _, _ in tensor_table(cfg)]
+    assert "embeddings.position_embeddings.weight" not in names
+    assert names.index("encoder.layer.0.intermediate.gate.weight") == names.index("encoder.layer.0.intermediate.dense.bias") + 1
+
+
+@pytest.mark.parametrize("name", [str(n) for n in GOLD["names"] if str(n) != "nomic_shape"])
+def test_oracle_matches_the_torch_statement(oracle, name):
+    cfg, wseed, iseed, B, L, ragged = case_cfg(name)
+    params = synth_params(cfg, wseed)
+    ids, mask = synth_token_batch(cfg, iseed, B, L, ragged)
+    r = oracle.bert_forward(cfg, params, ids, mask, want_hidden=True, want_layers=True)
+    np.testing.assert_allclose(r["pooled"], GOLD[name + "/mean"], atol=2e-6)
+    np.testing.assert_allclose(np.linalg.norm(r["pooled"], axis=1), 1.0, atol=1e-6)
+    valid = mask.astype(bool)
+    absmean = np.array([np.abs(h[valid]).mean() for h in r["layers"]])
+    np.testing.assert_allclose(absmean, GOLD[name + "/layer_absmean"], rtol=1e-5)
+    H = cfg.hidden
+    probe = np.array([[h[0, 0, 0], h[B - 1, 1, 7], h[0, mask[0].sum() - 1, H - 1]] for h in r["layers"]])
+    np.testing.assert_allclose(probe, GOLD[name + "/layer_probe"], atol=2e-5)
+    np.testing.assert_allclose(r["hidden"][0, 0], GOLD[name + "/last_row0"], atol=2e-5)
+
+
+def test_oracle_matches_at_the_published_shape(oracle):
+    """12 x 768, 12 heads of 64, n_inner 3072, rotary base 1000 (nomic-embed-text-v1.5's config.json), 4 x 128 tokens."""
+    cfg, wseed, iseed, B, L, ragged = case_cfg("nomic_shape")
+    params = oracle.bert_synth_params(cfg, wseed)
+    ids, mask = synth_token_batch(cfg, iseed, B, L, ragged)
+    r = oracle.bert_forward(cfg, params, ids, mask, want_hidden=True)
+    np.testing.assert_allclose(r["pooled"], GOLD["nomic_shape/mean"], atol=1e-5)
+    np.testing.assert_allclose(r["hidden"][0, 0], GOLD["nomic_shape/last_row0"], atol=1e-4)
+    mean = GOLD["nomic_shape/mean"]
+    assert (mean @ mean.T)[~np.eye(len(mean), dtype=bool)].max() < 0.999  # the synthetic model tells sequences apart
+
+
+def test_positions_matter_and_padding_does_not_leak(oracle):
+    cfg, wseed, iseed, B, L, _ = case_cfg("dh64_L48")
+    params = synth_params(cfg, wseed)
+    ids, mask = synth_token_batch(cfg, iseed, B, L, True)
+    base = oracle.bert_forward(cfg, params, ids, mask)["pooled"]
+    # garbage in the padded positions changes nothing
+    ids2 = np.where(mask == 1, ids, 77).astype(np.int32)
+    assert np.abs(oracle.bert_forward(cfg, params, ids2, mask)["pooled"] - base).max() < 1e-6
+    # with no position table, the rotary map is the only thing that sees token order: swapping two inner tokens of a
+    # full row must move the embedding
+    b = int(np.argmax(mask.sum(1)))
+    ids3 = ids.copy()
+    ids3[b, 3], ids3[b, 9] = ids[b, 9], ids[b, 3]
+    assert ids3[b, 3] != ids[b, 3]
+    moved = np.abs(oracle.bert_forward(cfg, params, ids3, mask)["pooled"][b] - base[b]).max()
+    assert moved > 1e-4, moved
+
+
+def test_nomic_checkpoint_names_map_onto_the_flat_block():
+    """The model repository's parameter names (emb_ln, encoder.layers.N.attn.Wqkv / out_proj, norm1, mlp.fc11 / fc12 / fc2,
+    norm2; no Linear biases) and its config.json keys."""
+    hf = {"model_type": "nomic_bert", "vocab_size": 512, "n_embd": 128, "n_head": 2, "n_layer": 2, "n_inner": 256,
+          "n_positions": 8192, "type_vocab_size": 2, "layer_norm_epsilon": 1e-12, "rotary_emb_base": 1000,
+          "rotary_emb_fraction": 1.0, "rotary_emb_interleaved": False, "rotary_emb_scale_base": None,
+          "activation_function": "swiglu", "prenorm": False, "qkv_proj_bias": False, "mlp_fc1_bias": False}
+    cfg = nomic_config_from_hf(hf)
+    assert (cfg.arch, cfg.rotary_base, cfg.hidden, cfg.heads, cfg.intermediate, cfg.max_position, cfg.pooling) == \
+        (ARCH_NOMIC, 1000.0, 128, 2, 256, 512, POOL_MEAN)
+    flat = synth_params(cfg, 5)
+    ours = to_state_dict(cfg, flat)
+    sd = {"embeddings.word_embeddings.weight": ours["embeddings.word_embeddings.weight"],
+          "embeddings.token_type_embeddings.weight": ours["embeddings.token_type_embeddings.weight"],
+          "emb_ln.weight": ours["embeddings.LayerNorm.weight"], "emb_ln.bias": ours["embeddings.LayerNorm.bias"]}
+    for l in range(cfg.layers):
+        a, b = f"encoder.layer.{l}.", f"encoder.layers.{l}."
+        sd[b + "attn.Wqkv.weight"] = np.concatenate([ours[a + f"attention.self.{r}.weight"] for r in ("query", "key", "value")])
+        sd[b + "attn.out_proj.weight"] = ours[a + "attention.output.dense.weight"]
+        sd[b + "mlp.fc11.weight"] = ours[a + "intermediate.dense.weight"]
+        sd[b + "mlp.fc12.weight"] = ours[a + "intermediate.gate.weight"]
+        sd[b + "mlp.fc2.weight"] = ours[a + "output.dense.weight"]
+        for n, o in (("norm1", "attention.output.LayerNorm"), ("norm2", "output.LayerNorm")):
+            sd[b + n + ".weight"], sd[b + n + ".bias"] = ours[a + o + ".weight"], ours[a + o + ".bias"]
+    got = to_state_dict(cfg, from_nomic_state_dict(cfg, sd))
+    for name, _, kind in tensor_table(cfg):
+        if kind == "bias":
+            assert not got[name].any(), name  # the checkpoint holds no Linear bias
+        else:
+            assert np.array_equal(got[name], ours[name]), name
+    for bad in ({"rotary_emb_interleaved": True}, {"activation_function": "gelu"}, {"prenorm": True}, {"rotary_emb_fraction": 0.5}):
+        with pytest.raises(ValueError):
+            nomic_config_from_hf({**hf, **bad})
