@@ -156,6 +156,9 @@ def nomic_config_from_hf(cfg_json: dict, max_length: int = 512) -> BertConfig:
             raise ValueError(f"nomic_bert with {key} = {cfg_json[key]!r} is not built (only {val!r})")
     if cfg_json.get("rotary_scaling_factor") not in (None, 1, 1.0):
         raise ValueError("nomic_bert with a rotary scaling factor is not built")
+    for key in ("vocab_size", "n_embd", "n_layer", "n_head"):
+        if key not in cfg_json:
+            raise ValueError(f"nomic_bert config.json lacks {key}")
     return BertConfig(vocab_size=cfg_json["vocab_size"], hidden=cfg_json["n_embd"], layers=cfg_json["n_layer"],
                       heads=cfg_json["n_head"], intermediate=cfg_json.get("n_inner") or 4 * cfg_json["n_embd"],
                       max_position=min(max_length, cfg_json.get("n_positions", max_length)),

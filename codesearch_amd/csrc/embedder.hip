@@ -76,6 +76,10 @@ struct cs_embedder {
     float* d_params = nullptr;
     float* d_wqkv = nullptr;  // [layers][3H][H]  (query | key | value rows)
     float* d_bqkv = nullptr;  // [layers][3H]
+    // CS_ARCH_NOMIC: the up projection's bias as one [2I] vector per layer (fc11 | fc12) and the rotary table
+    // [max_position][d_h / 2] (cos, sin)
+    float* d_bup = nullptr;
+    float2* d_rope = nullptr;
     _Float16* d_wsplit = nullptr;  // per layer: wqkv | attention-out | ffn-up | ffn-down, split-f16 rows
     uint32_t* d_flag = nullptr;    // split-f16 range flag
     // dynamically quantised models (gemm_q8.hip): s8 weights per layer (q8_layer), their column metadata, the running
@@ -144,6 +148,9 @@ scatter_rows_kernel(const float* __restrict__ src, const uint32_t* __restrict__ 
     reinterpret_cast<float4*>(dst)[(size_t)perm[r] * h4 + c] = reinterpret_cast<const float4*>(src)[(size_t)r * h4 + c];
 }
 
+// Floats per token row of the feed-forward workspace: [I]; CS_ARCH_NOMIC: [2I] (value | gate) + [I] (their product)
+size_t mid_width(const cs_bert_config& c) { return (size_t)c.intermediate * (c.arch == CS_ARCH_NOMIC ? 3 : 1); }
+
 void free_workspace(cs_embedder* h) {
     if (h->d_ids) (void)hipFree(h->d_ids);
     if (h->d_mask) (void)hipFree(h->d_mask);
@@ -180,7 +187,7 @@ int32_t reserve(cs_embedder* h, size_t seqs, size_t tokens) {
     CS_HIP(hipMalloc(&h->d_xs, tokens * H * sizeof(float)));
     CS_HIP(hipMalloc(&h->d_qkv, tokens * 3 * H * sizeof(float)));
     CS_HIP(hipMalloc(&h->d_ctx, tokens * H * sizeof(float)));
-    CS_HIP(hipMalloc(&h->d_mid, tokens * I * sizeof(float)));
+    CS_HIP(hipMalloc(&h->d_mid, tokens * mid_width(h->cfg) * sizeof(float)));
     CS_HIP(hipMalloc(&h->d_pooled, seqs * H * sizeof(float)));
     CS_HIP(hipMalloc(&h->d_perm, seqs * sizeof(uint32_t)));
     if (h->quantized) {
@@ -204,7 +211,7 @@ int32_t reserve(cs_embedder* h, size_t seqs, size_t tokens) {
     return CS_OK;
 }
 
-// Offsets (in f16 elements) of one layer's split weights inside d_wsplit.
+// Offsets (in f16 elements) of one layer's split weights inside d_wsplit.  CS_ARCH_NOMIC: `up` holds fc11 | fc12, [2I][H].
 struct SplitLayer { size_t qkv, ao, up, down, total; };
 SplitLayer split_layer(const cs_bert_config& c) {
     const size_t H = c.hidden, I = c.intermediate;
@@ -212,7 +219,7 @@ SplitLayer split_layer(const cs_bert_config& c) {
     o.qkv = 0;
     o.ao = o.qkv + 3 * H * H * 2;
     o.up = o.ao + H * H * 2;
-    o.down = o.up + I * H * 2;
+    o.down = o.up + (c.arch == CS_ARCH_NOMIC ? 2 : 1) * I * H * 2;
     o.total = o.down + H * I * 2;
     return o;
 }
@@ -230,11 +237,12 @@ int32_t forward_range(cs_embedder* h, hipStream_t s, uint32_t b0, uint32_t nb, u
     float* x = h->d_x + t0 * H;
     float* qkv = h->d_qkv + t0 * 3 * H;
     float* ctx = h->d_ctx + t0 * H;
-    float* mid = h->d_mid + t0 * I;
+    const bool nomic = c.arch == CS_ARCH_NOMIC;
+    float* mid = h->d_mid + t0 * mid_width(c);
     const int32_t* mask = h->d_mask + t0;
     EncoderLaunch a;
     a.ids = h->d_ids + t0; a.mask = mask;
-    a.word = P + h->off.word; a.pos = P + h->off.pos; a.type0 = P + h->off.type;
+    a.word = P + h->off.word; a.pos = nomic ? nullptr : P + h->off.pos; a.type0 = P + h->off.type;
     a.g = P + h->off.emb_ln_g; a.b = P + h->off.emb_ln_b;
     a.eps = c.layer_norm_eps; a.T = T; a.L = L; a.B = nb; a.vocab = c.vocab_size;
     a.pooling = c.pooling; a.x = x; a.out = h->d_pooled + (size_t)b0 * H;
@@ -462,7 +470,7 @@ int32_t forward_range(cs_embedder* h, hipStream_t s, uint32_t b0, uint32_t nb, u
                 const bool cls_tail_fits = L <= 512 && (dh_tail == 32 || dh_tail == 64) && H % c.heads == 0 &&
                                            (uint64_t)(L - 1) * I >= (uint64_t)4 * H;
                 if (l + 1 == c.layers) h->last_hidden_partial = false;
-                if (cls_tail_on && cls_tail_fits && c.pooling == CS_POOL_CLS && l + 1 == c.layers && T >= cls_tail_min && L >= 16) {
+                if (cls_tail_on && cls_tail_fits && !nomic && c.pooling == CS_POOL_CLS && l + 1 == c.layers && T >= cls_tail_min && L >= 16) {
                     h->last_hidden_partial = true;
                     float* x_cls = mid;                                            // [nb, H] f32
                     _Float16* xs_cls = reinterpret_cast<_Float16*>(mid + (size_t)nb * H);       // [nb][H/32][64]
@@ -495,6 +503,7 @@ int32_t forward_range(cs_embedder* h, hipStream_t s, uint32_t b0, uint32_t nb, u
                     return CS_OK;
                 }
                 CS_TRY(dense(SH_OUT_SPLIT, xs, ws + sl.qkv, bqkv, nullptr, nullptr, qkvs, T, 3 * H, H));  // E2
+                if (nomic) CS_TRY(launch_rope_split(qkvs, h->d_rope, T, L, H, c.heads, h->d_flag, s));  // rotary map on Q and K (nomic.hip)
                 CS_TRY(mark(CS_STAGE_QKV));
                 CS_TRY(launch_attention_sh2(qkvs, mask, ctxs, h->d_flag, nb, L, H, c.heads, s));                                 // E3
                 CS_TRY(mark(CS_STAGE_ATTENTION));
@@ -523,10 +532,20 @@ int32_t forward_range(cs_embedder* h, hipStream_t s, uint32_t b0, uint32_t nb, u
             }
             CS_TRY(mark(CS_STAGE_LN_ATTN));
             a.g = P + lo.out_ln_g; a.b = P + lo.out_ln_b;
-            CS_TRY(dense(SH_OUT_SPLIT_GELU, xs, ws + sl.up, P + lo.up_b, nullptr, nullptr, mids, T, I, H));    // E5
+            const _Float16* ffn_in = mids;  // E6's operand
+            if (nomic) {
+                // E5 of the gated feed-forward: ONE product over fc11 | fc12 ([2I, H]) into the first 2I columns of the
+                // workspace, then value * silu(gate) into its last I columns — the operand of E6
+                _Float16* gated = reinterpret_cast<_Float16*>(mid + (size_t)T * 2 * I);
+                CS_TRY(dense(SH_OUT_SPLIT, xs, ws + sl.up, h->d_bup + (size_t)l * 2 * I, nullptr, nullptr, mids, T, 2 * I, H));
+                CS_TRY(launch_swiglu_split(mids, gated, T, I, h->d_flag, s));
+                ffn_in = gated;
+            } else {
+                CS_TRY(dense(SH_OUT_SPLIT_GELU, xs, ws + sl.up, P + lo.up_b, nullptr, nullptr, mids, T, I, H));    // E5
+            }
             CS_TRY(mark(CS_STAGE_FFN_UP));
             if (fuse_ln) {
-                CS_TRY(launch_gemm_wide_ln(mids, ws + sl.down, P + lo.down_b, x, a.g, a.b, c.layer_norm_eps,
+                CS_TRY(launch_gemm_wide_ln(ffn_in, ws + sl.down, P + lo.down_b, x, a.g, a.b, c.layer_norm_eps,
                                            (split_resid && l + 1 < c.layers) ? nullptr : x, xs, T, I, h->d_flag, s,
                                            split_resid ? xs : nullptr));  // E6
                 CS_TRY(mark(CS_STAGE_FFN_DOWN));
@@ -535,12 +554,12 @@ int32_t forward_range(cs_embedder* h, hipStream_t s, uint32_t b0, uint32_t nb, u
                 // latency each; three K slices per tile (two from 6,144 rows: still one round of blocks), partial
                 // slabs in the qkv buffer (free by now), summed with bias and residual by the LayerNorm that follows
                 const uint32_t ks = T <= split_k_max ? 3 : 2;
-                CS_TRY(launch_gemm_split_partial(mids, ws + sl.down, qkv, T, H, I, ks, s));  // E6
+                CS_TRY(launch_gemm_split_partial(ffn_in, ws + sl.down, qkv, T, H, I, ks, s));  // E6
                 CS_TRY(mark(CS_STAGE_FFN_DOWN));
                 a.parts = qkv; a.nparts = ks; a.bias = P + lo.down_b;
                 CS_TRY(launch_row_kernel(3, a, H, s));
             } else {
-                CS_TRY(dense(SH_OUT_F32_RESID, mids, ws + sl.down, P + lo.down_b, x, x, nullptr, T, H, I)); // E6
+                CS_TRY(dense(SH_OUT_F32_RESID, ffn_in, ws + sl.down, P + lo.down_b, x, x, nullptr, T, H, I)); // E6
                 CS_TRY(mark(CS_STAGE_FFN_DOWN));
                 CS_TRY(launch_row_kernel(1, a, H, s));
             }
@@ -548,6 +567,7 @@ int32_t forward_range(cs_embedder* h, hipStream_t s, uint32_t b0, uint32_t nb, u
         } else {
             const float* wqkv = h->d_wqkv + (size_t)l * 3 * H * H;
             CS_TRY(launch_gemm(GEMM_BIAS, x, wqkv, bqkv, nullptr, qkv, T, 3 * H, H, s));        // E2
+            if (nomic) CS_TRY(launch_rope_f32(qkv, h->d_rope, T, L, H, c.heads, s));
             CS_TRY(mark(CS_STAGE_QKV));
             CS_TRY(launch_attention(qkv, mask, ctx, nb, L, H, c.heads, s));                     // E3
             CS_TRY(mark(CS_STAGE_ATTENTION));
@@ -556,7 +576,14 @@ int32_t forward_range(cs_embedder* h, hipStream_t s, uint32_t b0, uint32_t nb, u
             a.g = P + lo.ao_ln_g; a.b = P + lo.ao_ln_b;
             CS_TRY(launch_row_kernel(1, a, H, s));
             CS_TRY(mark(CS_STAGE_LN_ATTN));
-            CS_TRY(launch_gemm(GEMM_GELU, x, P + lo.up_w, P + lo.up_b, nullptr, mid, T, I, H, s)); // E5
+            if (nomic) {  // value and gate as two products, value *= silu(gate)
+                float* gate = mid + (size_t)T * I;
+                CS_TRY(launch_gemm(GEMM_BIAS, x, P + lo.up_w, P + lo.up_b, nullptr, mid, T, I, H, s));
+                CS_TRY(launch_gemm(GEMM_BIAS, x, P + lo.gate_w, P + lo.gate_b, nullptr, gate, T, I, H, s));
+                CS_TRY(launch_swiglu_f32(mid, gate, T, I, s));
+            } else {
+                CS_TRY(launch_gemm(GEMM_GELU, x, P + lo.up_w, P + lo.up_b, nullptr, mid, T, I, H, s)); // E5
+            }
             CS_TRY(mark(CS_STAGE_FFN_UP));
             CS_TRY(launch_gemm(GEMM_RESID, mid, P + lo.down_w, P + lo.down_b, x, x, T, H, I, s));  // E6
             CS_TRY(mark(CS_STAGE_FFN_DOWN));
@@ -1093,6 +1120,7 @@ void cs_bert_config_bge_small(cs_bert_config* cfg) {
     cfg->vocab_size = 30522; cfg->hidden = 384; cfg->layers = 12; cfg->heads = 12;
     cfg->intermediate = 1536; cfg->max_position = 512; cfg->type_vocab_size = 2;
     cfg->layer_norm_eps = 1e-12f; cfg->pooling = CS_POOL_CLS;
+    cfg->arch = CS_ARCH_BERT; cfg->rotary_base = 0.0f;
 }
 
 uint64_t cs_bert_param_count(const cs_bert_config* cfg) {
@@ -1120,6 +1148,15 @@ static int32_t create_impl(const cs_bert_config* cfg, const float* params, uint6
         return fail(CS_ERR_UNSUPPORTED, "Failed to initialize embedding model: sizes must be multiples of 128");
     if (cfg->pooling != CS_POOL_CLS && cfg->pooling != CS_POOL_MEAN)
         return fail(CS_ERR_BAD_ARG, "Failed to initialize embedding model: unknown pooling %d", cfg->pooling);
+    if (cfg->arch != CS_ARCH_BERT && cfg->arch != CS_ARCH_NOMIC)
+        return fail(CS_ERR_UNSUPPORTED, "Failed to initialize embedding model: unknown encoder family %u", cfg->arch);
+    if (cfg->arch == CS_ARCH_NOMIC) {
+        if (!(cfg->rotary_base > 1.0f) || !(cfg->rotary_base < 1.0e9f))
+            return fail(CS_ERR_BAD_ARG, "Failed to initialize embedding model: rotary base %g", (double)cfg->rotary_base);
+        // the quantised export's graph quantises the rotated and gated tensors in places of its own: not restated
+        if (wscale) return fail(CS_ERR_UNSUPPORTED, "Failed to initialize embedding model: the dynamic-quantisation mode is not built for "
+                                "the Nomic encoder (create it from the dequantised weights: cs_embedder_create)");
+    }
     int ndev = 0;
     CS_HIP(hipGetDeviceCount(&ndev));
     if (device < 0 || device >= ndev)
@@ -1162,6 +1199,31 @@ static int32_t create_impl(const cs_bert_config* cfg, const float* params, uint6
                 s = fail(CS_ERR_HIP, "QKV packing failed");
         }
     }
+    if (s == CS_OK && cfg->arch == CS_ARCH_NOMIC) {
+        const size_t I = cfg->intermediate, half = H / cfg->heads / 2;
+        if (hipMalloc(&h->d_bup, (size_t)cfg->layers * 2 * I * sizeof(float)) != hipSuccess ||
+            hipMalloc(&h->d_rope, (size_t)cfg->max_position * half * sizeof(float2)) != hipSuccess)
+            return cleanup(fail(CS_ERR_OOM, "hipMalloc(parameters) failed"));
+        for (uint32_t l = 0; l < cfg->layers && s == CS_OK; ++l) {
+            cs_bert_layer_offsets lo;
+            cs_bert_layer_layout(cfg, &h->off, l, &lo);
+            if (hipMemcpyAsync(h->d_bup + (size_t)l * 2 * I, h->d_params + lo.up_b, I * sizeof(float), hipMemcpyDeviceToDevice, h->stream) != hipSuccess ||
+                hipMemcpyAsync(h->d_bup + (size_t)l * 2 * I + I, h->d_params + lo.gate_b, I * sizeof(float), hipMemcpyDeviceToDevice, h->stream) != hipSuccess)
+                s = fail(CS_ERR_HIP, "feed-forward bias packing failed");
+        }
+        // the module's cos / sin cache, formed as it forms it: inv_freq_i = 1 / base^(2i / d_h) and pos * inv_freq_i in f32
+        std::vector<float2> rope((size_t)cfg->max_position * half);
+        const float dh = (float)(2 * half);
+        for (size_t i = 0; i < half; ++i) {
+            const float inv_freq = 1.0f / powf(cfg->rotary_base, (float)(2 * i) / dh);
+            for (size_t p = 0; p < cfg->max_position; ++p) {
+                const float ang = (float)p * inv_freq;
+                rope[p * half + i] = make_float2(cosf(ang), sinf(ang));
+            }
+        }
+        if (s == CS_OK && hipMemcpy(h->d_rope, rope.data(), rope.size() * sizeof(float2), hipMemcpyHostToDevice) != hipSuccess)
+            s = fail(CS_ERR_HIP, "rotary table upload failed");
+    }
     // split-f16 copies of the four dense weights of every layer (split_f16.hpp)
     if (s == CS_OK) {
         const SplitLayer sl = split_layer(*cfg);
@@ -1177,6 +1239,8 @@ static int32_t create_impl(const cs_bert_config* cfg, const float* params, uint6
             s = launch_split_rows(h->d_wqkv + (size_t)l * 3 * H * H, ws + sl.qkv, 3 * H, (uint32_t)H, h->d_flag, h->stream);
             if (s == CS_OK) s = launch_split_rows(h->d_params + lo.ao_w, ws + sl.ao, H, (uint32_t)H, h->d_flag, h->stream);
             if (s == CS_OK) s = launch_split_rows(h->d_params + lo.up_w, ws + sl.up, I, (uint32_t)H, h->d_flag, h->stream);
+            if (s == CS_OK && cfg->arch == CS_ARCH_NOMIC)  // fc12's rows behind fc11's: one [2I, H] weight
+                s = launch_split_rows(h->d_params + lo.gate_w, ws + sl.up + I * H * 2, I, (uint32_t)H, h->d_flag, h->stream);
             if (s == CS_OK) s = launch_split_rows(h->d_params + lo.down_w, ws + sl.down, H, (uint32_t)I, h->d_flag, h->stream);
         }
         uint32_t wflag = 0;
@@ -1287,6 +1351,8 @@ void cs_embedder_destroy(cs_embedder* h) {
     if (h->d_params) (void)hipFree(h->d_params);
     if (h->d_wqkv) (void)hipFree(h->d_wqkv);
     if (h->d_bqkv) (void)hipFree(h->d_bqkv);
+    if (h->d_bup) (void)hipFree(h->d_bup);
+    if (h->d_rope) (void)hipFree(h->d_rope);
     if (h->d_wsplit) (void)hipFree(h->d_wsplit);
     if (h->d_flag) (void)hipFree(h->d_flag);
     if (h->d_wq8) (void)hipFree(h->d_wq8);

@@ -118,14 +118,14 @@ embed_ln_kernel(const int32_t* __restrict__ ids, const float* __restrict__ word,
     uint32_t id = (uint32_t)ids[t];
     if (id >= vocab) id = 0;  // host validates; never index out of the table
     const float* we = word + (size_t)id * H;
-    const float* pe = pos + (size_t)(t % L) * H;
+    const float* pe = pos ? pos + (size_t)(t % L) * H : nullptr;  // null: no position table (CS_ARCH_NOMIC)
     float v[NPL];
 #pragma unroll
     for (int p = 0; p < NPL / 2; ++p) {
         const int c = ln_col(lane, 2 * p);
         const float2 w2 = *reinterpret_cast<const float2*>(we + c);
         const float2 t2 = *reinterpret_cast<const float2*>(type0 + c);
-        const float2 p2 = *reinterpret_cast<const float2*>(pe + c);
+        const float2 p2 = pe ? *reinterpret_cast<const float2*>(pe + c) : make_float2(0.0f, 0.0f);
         v[2 * p] = (w2.x + t2.x) + p2.x;  // BertEmbeddings: (inputs + token_type) + position
         v[2 * p + 1] = (w2.y + t2.y) + p2.y;
     }

@@ -78,6 +78,14 @@ int32_t launch_gemm_wide_ln(const _Float16* A, const _Float16* W, const float* b
 int32_t launch_attention_cls(const _Float16* q_cls, const _Float16* kv_split, const int32_t* mask, _Float16* ctxs_cls,
                              uint32_t* flag, uint32_t B, uint32_t L, uint32_t H, uint32_t heads, hipStream_t s);
 int32_t launch_gather_cls(const _Float16* xs, float* x_cls, _Float16* xs_cls, uint32_t B, uint32_t L, uint32_t H, hipStream_t s);
+// nomic.hip (CS_ARCH_NOMIC): the rotary position map on the Q and K columns of a QKV tensor, in place — split form
+// [T][3H/32][64] or f32 [T][3H]; rope [L_max][d_h / 2] (cos, sin) — and the feed-forward gate value * silu(gate): up2
+// [T][2I/32][64] (value lines, then gate lines) -> out [T][I/32][64], or value [T][I] *= silu(gate [T][I]).
+int32_t launch_rope_split(_Float16* qkvs, const float2* rope, uint32_t T, uint32_t L, uint32_t H, uint32_t heads,
+                          uint32_t* flag, hipStream_t s);
+int32_t launch_rope_f32(float* qkv, const float2* rope, uint32_t T, uint32_t L, uint32_t H, uint32_t heads, hipStream_t s);
+int32_t launch_swiglu_split(const _Float16* up2, _Float16* out, uint32_t T, uint32_t I, uint32_t* flag, hipStream_t s);
+int32_t launch_swiglu_f32(float* value, const float* gate, uint32_t T, uint32_t I, hipStream_t s);
 extern int g_gemm_wide_ablation;  // diagnostics (cs_debug_gemm_time)
 extern int g_gemm_wide_shape;      // diagnostics: block shape override (192 | 384), 0 = default
 double gemm_wide_read_clock_ghz(double* main_cycles, double* epi_cycles);  // after an ablation-7 launch: median in-kernel clock

@@ -18,7 +18,7 @@ import numpy as np
 
 from . import _lib
 from ._lib import CsError, f32p, i32p
-from .bert_params import POOL_CLS, POOL_MEAN, BertConfig
+from .bert_params import ARCH_NOMIC, POOL_CLS, POOL_MEAN, BertConfig
 from .tokenizer import pack_texts
 
 
@@ -91,9 +91,16 @@ class ModelType(enum.Enum):
             return BertConfig(hidden=768, layers=12, heads=12, intermediate=3072, pooling=POOL_CLS)
         if self in (ModelType.BGELargeENV15, ModelType.MxbaiEmbedLargeV1):  # BERT-large: 24 x 1024, 16 heads of 64
             return BertConfig(hidden=1024, layers=24, heads=16, intermediate=4096, pooling=POOL_CLS)
+        if self in (ModelType.NomicEmbedTextV1, ModelType.NomicEmbedTextV15, ModelType.NomicEmbedTextV15Q):
+            # NomicBert [3P-MEM: the model repositories' config.json]: 12 x 768, 12 heads of 64, n_inner 3072, vocab 30528
+            # (bert-base-uncased's WordPiece vocabulary padded to a multiple of 64), rotary base 1000, swiglu, no position
+            # table; mean pooling.  max_position = the 512 tokens fastembed's default InitOptions truncate to
+            # (embedder.rs:238).  The quantised entry runs the f32 graph of its dequantised weights (encoder.hpp).
+            return BertConfig(vocab_size=30528, hidden=768, layers=12, heads=12, intermediate=3072, max_position=512,
+                              pooling=POOL_MEAN, arch=ARCH_NOMIC, rotary_base=1000.0)
         raise CsError(_lib.CS_ERR_UNSUPPORTED,
-                      f"Failed to initialize embedding model: {self.name_str()} is not a BERT encoder with absolute "
-                      "positions (the rotary, ALiBi and ModernBERT families are not built)")
+                      f"Failed to initialize embedding model: {self.name_str()} is not a BERT or NomicBert encoder "
+                      "(the ALiBi and ModernBERT families are not built)")
 
 
 # second spellings accepted by ModelType::parse (embedder.rs:178-195), verbatim

@@ -1,0 +1,133 @@
+"""Parity tests for the NomicBert encoder family (cs_bert_config.arch = CS_ARCH_NOMIC: the reference registry's three
+nomic-embed-text entries, /root/reference/src/embed/embedder.rs:30-35): HIP kernels through the C ABI — the BERT dense
+layers and attention plus the rotary map and the feed-forward gate of csrc/nomic.hip — against the CPU oracle and the
+committed float64 golden vectors (tests/golden/make_nomic_golden.py).  Needs an MI355X.
+
+Bar as for the BERT encoders: within 2e-5 of the fp32 oracle, 3e-5 of the float64 golden (north_star: 1e-4)."""
+import os
+
+import numpy as np
+import pytest
+
+from codesearch_amd.bert_params import ARCH_NOMIC, POOL_CLS, POOL_MEAN, BertConfig, synth_params, synth_token_batch
+
+pytestmark = pytest.mark.gpu
+
+GOLD = np.load(os.path.join(os.path.dirname(__file__), "golden", "nomic_golden.npz"))
+TOL_ORACLE = 2e-5
+TOL_GOLDEN = 3e-5
+
+
+def case_cfg(name):
+    m = GOLD[name + "/meta"]
+    cfg = BertConfig(vocab_size=int(m[0]), hidden=int(m[1]), layers=int(m[2]), heads=int(m[3]), intermediate=int(m[4]),
+                     max_position=int(m[5]), pooling=POOL_MEAN, arch=ARCH_NOMIC, rotary_base=1000.0)
+    return cfg, int(m[6]), int(m[7]), int(m[8]), int(m[9]), bool(m[10])
+
+
+@pytest.fixture(scope="module")
+def FE(gpu_lib):
+    from codesearch_amd import FastEmbedder, ModelType
+
+    assert gpu_lib.cs_device_count() >= 1
+    return lambda cfg, **kw: FastEmbedder(ModelType.NomicEmbedTextV15, config=cfg, **kw)
+
+
+@pytest.mark.parametrize("gemm_mode", ["split", "f32"])
+@pytest.mark.parametrize("name", [str(n) for n in GOLD["names"] if str(n) != "nomic_shape"])
+def test_small_cases_vs_golden_and_oracle(FE, oracle, name, gemm_mode):
+    """Both arithmetic modes: split-f16 operands on the f16 MFMA (the default) and the exact-f32 kernels (the fallback the
+    split path takes when a value leaves the f16 range)."""
+    cfg, wseed, iseed, B, L, ragged = case_cfg(name)
+    ids, mask = synth_token_batch(cfg, iseed, B, L, ragged)
+    params = synth_params(cfg, wseed)
+    emb = FE(cfg, seed=wseed, gemm_mode=gemm_mode)
+    got = emb.embed_ids(ids, mask)
+    ref = oracle.bert_forward(cfg, params, ids, mask, want_hidden=True)
+    np.testing.assert_allclose(got, ref["pooled"], atol=TOL_ORACLE)
+    np.testing.assert_allclose(got, GOLD[name + "/mean"], atol=TOL_GOLDEN)
+    np.testing.assert_allclose(np.linalg.norm(got, axis=1), 1.0, atol=1e-5)
+    hid = emb.last_hidden(B * L).reshape(B, L, cfg.hidden)
+    valid = mask.astype(bool)
+    np.testing.assert_allclose(hid[valid], ref["hidden"][valid], atol=2e-4)
+    split, f32, _ = emb.debug_counters()
+    assert (split, f32) == ((1, 0) if gemm_mode == "split" else (0, 1))
+    emb.close()
+
+
+def test_published_shape_vs_golden_and_oracle(FE, oracle):
+    """nomic-embed-text-v1.5's own shape (12 x 768, 12 heads of 64, n_inner 3072, vocab 30528, rotary base 1000)."""
+    cfg, wseed, iseed, B, L, ragged = case_cfg("nomic_shape")
+    ids, mask = synth_token_batch(cfg, iseed, B, L, ragged)
+    emb = FE(cfg, seed=wseed)
+    got = emb.embed_ids(ids, mask)
+    ref = oracle.bert_forward(cfg, oracle.bert_synth_params(cfg, wseed), ids, mask)
+    np.testing.assert_allclose(got, ref["pooled"], atol=TOL_ORACLE)
+    np.testing.assert_allclose(got, GOLD["nomic_shape/mean"], atol=TOL_GOLDEN)
+    assert emb.debug_counters()[:2] == (1, 0)
+    emb.close()
+
+
+def test_registry_entry_builds_and_runs(FE, oracle):
+    """ModelType::NomicEmbedTextV1 / V15 / V15Q -> the NomicBert config (embedder.rs:64-66, :84-86: 768 dimensions); two
+    layers of it here, every dense-layer route by batch size: a few rows (skinny kernels), the reference's 32-chunk call
+    (mid-size tiles), an indexing batch (persistent wide kernels, N = 2I = 6,144 for the gated up projection)."""
+    from codesearch_amd import ModelType
+
+    for m in (ModelType.NomicEmbedTextV1, ModelType.NomicEmbedTextV15, ModelType.NomicEmbedTextV15Q):
+        assert (m.dimensions(), m.bert_config().arch) == (768, ARCH_NOMIC)
+    cfg = ModelType.NomicEmbedTextV15.bert_config()
+    cfg.layers, cfg.vocab_size = 2, 2048
+    emb = FE(cfg, seed=411)
+    params = synth_params(cfg, 411)
+    for B, L, ragged in ((1, 12, False), (32, 96, True), (128, 128, True)):
+        ids, mask = synth_token_batch(cfg, 500 + B, B, L, ragged)
+        got = emb.embed_ids(ids, mask)
+        ref = oracle.bert_forward(cfg, params, ids, mask)["pooled"]
+        np.testing.assert_allclose(got, ref, atol=TOL_ORACLE)
+    assert emb.debug_counters()[1] == 0  # no exact-f32 fallback
+    emb.close()
+
+
+def test_minibatches_and_padding_do_not_change_an_embedding(FE, oracle):
+    """A row's rotary angles are its own positions: embedding it alone, in a longer padded batch, or behind other rows
+    gives the same vector (the length-grouped runner relies on it)."""
+    cfg, wseed, iseed, B, L, _ = case_cfg("dh64_L48")
+    ids, mask = synth_token_batch(cfg, iseed, B, L, True)
+    emb = FE(cfg, seed=wseed)
+    base = emb.embed_ids(ids, mask)
+    pad = 16
+    ids2 = np.concatenate([ids, np.zeros((B, pad), np.int32)], axis=1)
+    mask2 = np.concatenate([mask, np.zeros((B, pad), np.int32)], axis=1)
+    np.testing.assert_allclose(emb.embed_ids(ids2, mask2), base, atol=2e-6)
+    for b in range(B):
+        np.testing.assert_allclose(emb.embed_ids(ids[b:b + 1], mask[b:b + 1])[0], base[b], atol=2e-6)
+    emb.close()
+
+
+def test_cls_pooling_and_refusals(FE, oracle):
+    """CLS pooling on this family takes the full last layer (the CLS tail is BERT's); a quantised Nomic model is refused
+    with a worded error, and so are a missing rotary base and an unknown family."""
+    from codesearch_amd import CsError
+    from codesearch_amd.bert_params import quantize_linear_weights
+
+    cfg, wseed, iseed, B, L, _ = case_cfg("dh32_L64")
+    cfg.pooling = POOL_CLS
+    ids, mask = synth_token_batch(cfg, iseed, 80, L, False)  # 5,120 token rows: where BERT would take the CLS tail
+    emb = FE(cfg, seed=wseed)
+    got = emb.embed_ids(ids, mask)
+    ref = oracle.bert_forward(cfg, synth_params(cfg, wseed), ids, mask)["pooled"]
+    np.testing.assert_allclose(got, ref, atol=TOL_ORACLE)
+    emb.last_hidden(80 * L)  # the whole last layer was computed
+    emb.close()
+    cfg.pooling = POOL_MEAN
+    bad = BertConfig(**{**cfg.__dict__, "rotary_base": 0.0})
+    with pytest.raises(CsError, match="rotary base"):
+        FE(bad, seed=1)
+    with pytest.raises(CsError, match="unknown encoder family"):
+        FE(BertConfig(**{**cfg.__dict__, "arch": 7}), seed=1)
+    small = BertConfig(vocab_size=512, hidden=384, layers=1, heads=12, intermediate=1536, pooling=POOL_MEAN)
+    p, wscale = quantize_linear_weights(small, synth_params(small, 3))
+    with pytest.raises(CsError, match="dynamic-quantisation mode is not built"):
+        nomic_small = BertConfig(**{**small.__dict__, "arch": ARCH_NOMIC, "rotary_base": 1000.0})
+        FE(nomic_small, params=synth_params(nomic_small, 3), wscale=wscale)

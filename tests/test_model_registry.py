@@ -3,7 +3,7 @@
 import pytest
 
 from codesearch_amd import CsError, ModelType
-from codesearch_amd.bert_params import POOL_CLS, POOL_MEAN
+from codesearch_amd.bert_params import ARCH_NOMIC, POOL_CLS, POOL_MEAN
 
 M = ModelType
 
@@ -63,8 +63,12 @@ def test_gpu_runnable_architectures():
     for m in (M.MultilingualE5Small, M.ParaphraseMLMiniLML12V2):  # BERT encoders over the XLM-R unigram vocabulary (embedder.rs:58,70)
         c = m.bert_config()
         assert (c.hidden, c.layers, c.heads, c.intermediate, c.vocab_size, c.pooling) == (384, 12, 12, 1536, 250037, POOL_MEAN)
-    for m in (M.NomicEmbedTextV1, M.NomicEmbedTextV15, M.NomicEmbedTextV15Q, M.JinaEmbeddingsV2BaseCode, M.ModernBertEmbedLarge):
-        with pytest.raises(CsError):  # rotary / ALiBi / ModernBERT: other encoders
+    for m in (M.NomicEmbedTextV1, M.NomicEmbedTextV15, M.NomicEmbedTextV15Q):  # NomicBert: rotary positions, gated feed-forward
+        c = m.bert_config()
+        assert (c.arch, c.hidden, c.layers, c.heads, c.intermediate, c.vocab_size, c.rotary_base, c.pooling) == \
+            (ARCH_NOMIC, 768, 12, 12, 3072, 30528, 1000.0, POOL_MEAN)
+    for m in (M.JinaEmbeddingsV2BaseCode, M.ModernBertEmbedLarge):
+        with pytest.raises(CsError):  # ALiBi / ModernBERT: other encoders
             m.bert_config()
     for m in M.all():  # what the configs produce is what the registry promises
         try:
