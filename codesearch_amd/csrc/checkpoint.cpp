@@ -187,8 +187,50 @@ float half_to_float(uint16_t h) {
 struct TensorRef { std::string dtype; std::vector<uint64_t> shape; uint64_t begin = 0, end = 0; };
 
 // name -> (shape, offset in the flat block) for every tensor of the layout, in layout order
-struct Want { std::string name; std::vector<uint64_t> shape; uint64_t off; };
+// src_rows != 0: the file's tensor is [src_rows, shape[1]] and rows [row0, row0 + shape[0]) of it are wanted (a fused
+// projection); optional: a tensor the file may lack (its slot stays zero)
+struct Want { std::string name; std::vector<uint64_t> shape; uint64_t off; uint64_t src_rows = 0, row0 = 0; bool optional = false; };
+
+// NomicBert checkpoints (nomic-ai/nomic-embed-text-v1 / v1.5, the model repository's modeling file): emb_ln,
+// encoder.layers.N.{attn.Wqkv, attn.out_proj, norm1, mlp.fc11, mlp.fc12, mlp.fc2, norm2}; no Linear biases in the
+// published files (taken when present)
+std::vector<Want> nomic_layout_table(const cs_bert_config& c) {
+    cs_bert_offsets o;
+    cs_bert_layout(&c, &o);
+    const uint64_t H = c.hidden, I = c.intermediate;
+    std::vector<Want> t = {
+        {"embeddings.word_embeddings.weight", {c.vocab_size, H}, o.word},
+        {"embeddings.token_type_embeddings.weight", {c.type_vocab_size, H}, o.type},
+        {"emb_ln.weight", {H}, o.emb_ln_g},
+        {"emb_ln.bias", {H}, o.emb_ln_b},
+    };
+    for (uint32_t l = 0; l < c.layers; ++l) {
+        cs_bert_layer_offsets lo;
+        cs_bert_layer_layout(&c, &o, l, &lo);
+        const std::string p = "encoder.layers." + std::to_string(l) + ".";
+        const uint64_t qw[3] = {lo.q_w, lo.k_w, lo.v_w}, qb[3] = {lo.q_b, lo.k_b, lo.v_b};
+        for (uint64_t i = 0; i < 3; ++i) {
+            t.push_back({p + "attn.Wqkv.weight", {H, H}, qw[i], 3 * H, i * H, false});
+            t.push_back({p + "attn.Wqkv.bias", {H}, qb[i], 3 * H, i * H, true});
+        }
+        t.push_back({p + "attn.out_proj.weight", {H, H}, lo.ao_w});
+        t.push_back({p + "attn.out_proj.bias", {H}, lo.ao_b, 0, 0, true});
+        t.push_back({p + "norm1.weight", {H}, lo.ao_ln_g});
+        t.push_back({p + "norm1.bias", {H}, lo.ao_ln_b});
+        t.push_back({p + "mlp.fc11.weight", {I, H}, lo.up_w});
+        t.push_back({p + "mlp.fc11.bias", {I}, lo.up_b, 0, 0, true});
+        t.push_back({p + "mlp.fc12.weight", {I, H}, lo.gate_w});
+        t.push_back({p + "mlp.fc12.bias", {I}, lo.gate_b, 0, 0, true});
+        t.push_back({p + "mlp.fc2.weight", {H, I}, lo.down_w});
+        t.push_back({p + "mlp.fc2.bias", {H}, lo.down_b, 0, 0, true});
+        t.push_back({p + "norm2.weight", {H}, lo.out_ln_g});
+        t.push_back({p + "norm2.bias", {H}, lo.out_ln_b});
+    }
+    return t;
+}
+
 std::vector<Want> layout_table(const cs_bert_config& c) {
+    if (c.arch == CS_ARCH_NOMIC) return nomic_layout_table(c);
     cs_bert_offsets o;
     cs_bert_layout(&c, &o);
     const uint64_t H = c.hidden, I = c.intermediate;
@@ -236,10 +278,13 @@ extern "C" {
 
 int32_t cs_bert_config_from_dir(const char* model_dir, int32_t pooling, cs_bert_config* cfg) {
     if (!model_dir || !cfg) return fail(CS_ERR_BAD_ARG, "null argument");
+    const bool pooling_given = pooling != -1;
+    bool pooling_file = false;
     if (pooling == -1) {  // auto: the sentence-transformers pooling module of the snapshot, CLS when there is none
         pooling = CS_POOL_CLS;
         std::string ptext;
         if (read_file(std::string(model_dir) + "/1_Pooling/config.json", ptext, 1 << 20)) {
+            pooling_file = true;
             JsonParser pj{ptext.data(), ptext.data() + ptext.size()};
             const Json proot = pj.value();
             if (pj.ok && proot.kind == Json::Obj) {
@@ -259,6 +304,37 @@ int32_t cs_bert_config_from_dir(const char* model_dir, int32_t pooling, cs_bert_
     const Json root = jp.value();
     if (!jp.ok || root.kind != Json::Obj)
         return fail(CS_ERR_BAD_ARG, "Failed to initialize embedding model: %s is not a JSON object", path.c_str());
+    if (const Json* mt = root.get("model_type"))
+        if (mt->kind == Json::Str && mt->str == "nomic_bert") {
+            // NomicBert (the registry's nomic-embed-text entries): GPT-2 style keys.  Only the published configuration is
+            // built — full rotary fraction, non-interleaved, no scale base / scaling factor, swiglu, post-norm.
+            auto is = [&](const char* key, auto pred) { const Json* j = root.get(key); return !j || pred(*j); };
+            if (!is("rotary_emb_fraction", [](const Json& j) { return j.kind == Json::Num && j.num == 1.0; }) ||
+                !is("rotary_emb_interleaved", [](const Json& j) { return j.kind == Json::Bool && !j.b; }) ||
+                !is("rotary_emb_scale_base", [](const Json& j) { return j.kind == Json::Null; }) ||
+                !is("rotary_scaling_factor", [](const Json& j) { return j.kind == Json::Null || (j.kind == Json::Num && j.num == 1.0); }) ||
+                !is("activation_function", [](const Json& j) { return j.kind == Json::Str && j.str == "swiglu"; }) ||
+                !is("prenorm", [](const Json& j) { return j.kind == Json::Bool && !j.b; }))
+                return fail(CS_ERR_UNSUPPORTED, "Failed to initialize embedding model: this nomic_bert configuration is not built "
+                            "(only full non-interleaved rotary positions without scaling, swiglu, post-norm)");
+            cs_bert_config c{};
+            if (!json_u32(root, "vocab_size", c.vocab_size) || !json_u32(root, "n_embd", c.hidden) ||
+                !json_u32(root, "n_layer", c.layers) || !json_u32(root, "n_head", c.heads))
+                return fail(CS_ERR_BAD_ARG, "Failed to initialize embedding model: %s lacks a nomic_bert size field", path.c_str());
+            if (!json_u32(root, "n_inner", c.intermediate)) c.intermediate = 4 * c.hidden;
+            // no position table to size: the bound is what fastembed's default InitOptions truncate to (embedder.rs:238)
+            uint32_t npos = 0;
+            c.max_position = (json_u32(root, "n_positions", npos) && npos && npos < 512) ? npos : 512;
+            if (!json_u32(root, "type_vocab_size", c.type_vocab_size)) c.type_vocab_size = 2;
+            const Json* eps = root.get("layer_norm_epsilon");
+            c.layer_norm_eps = (eps && eps->kind == Json::Num) ? (float)eps->num : 1e-12f;
+            const Json* rb = root.get("rotary_emb_base");
+            c.rotary_base = (rb && rb->kind == Json::Num) ? (float)rb->num : 10000.0f;
+            c.arch = CS_ARCH_NOMIC;
+            c.pooling = pooling_given ? pooling : (pooling_file ? pooling : CS_POOL_MEAN);  // fastembed pools the family by mean
+            *cfg = c;
+            return CS_OK;
+        }
     if (const Json* mt = root.get("model_type"))
         if (mt->kind == Json::Str && mt->str != "bert")
             return fail(CS_ERR_UNSUPPORTED, "Failed to initialize embedding model: model_type \"%s\" is not a BERT encoder",
@@ -337,26 +413,37 @@ int32_t cs_bert_params_from_safetensors(const char* path, const cs_bert_config* 
     for (const Want& w : layout_table(*cfg)) {
         auto it = have.find(w.name);
         if (it == have.end()) it = have.find("bert." + w.name);
-        if (it == have.end())
+        if (it == have.end()) it = have.find("model." + w.name);
+        uint64_t count = 1;
+        for (uint64_t d : w.shape) count *= d;
+        if (it == have.end()) {
+            if (w.optional) {
+                std::memset(params + w.off, 0, count * sizeof(float));
+                continue;
+            }
             return fail(CS_ERR_BAD_ARG, "Failed to initialize embedding model: tensor %s is missing from %s",
                         w.name.c_str(), path);
+        }
         const TensorRef& t = it->second;
-        if (t.shape != w.shape) {
+        std::vector<uint64_t> file_shape = w.shape;
+        if (w.src_rows) file_shape[0] = w.src_rows;
+        const uint64_t skip = w.src_rows ? w.row0 * (count / w.shape[0]) : 0;  // elements in front of the wanted rows
+        uint64_t file_count = 1;
+        for (uint64_t d : file_shape) file_count *= d;
+        if (t.shape != file_shape) {
             std::string got, exp;
             for (uint64_t d : t.shape) got += (got.empty() ? "" : ", ") + std::to_string(d);
-            for (uint64_t d : w.shape) exp += (exp.empty() ? "" : ", ") + std::to_string(d);
+            for (uint64_t d : file_shape) exp += (exp.empty() ? "" : ", ") + std::to_string(d);
             return fail(CS_ERR_DIM_MISMATCH, "Failed to initialize embedding model: %s has shape [%s], config.json implies [%s]",
                         w.name.c_str(), got.c_str(), exp.c_str());
         }
-        uint64_t count = 1;
-        for (uint64_t d : w.shape) count *= d;
         const uint32_t esz = t.dtype == "F32" ? 4 : (t.dtype == "F16" || t.dtype == "BF16") ? 2 : 0;
         if (!esz)
             return fail(CS_ERR_UNSUPPORTED, "Failed to initialize embedding model: %s has dtype %s (F32, F16, BF16 only)",
                         w.name.c_str(), t.dtype.c_str());
-        if (t.end < t.begin || t.end - t.begin != count * esz)
+        if (t.end < t.begin || t.end - t.begin != file_count * esz)
             return fail(CS_ERR_BAD_ARG, "Failed to initialize embedding model: %s has inconsistent data_offsets", w.name.c_str());
-        if (fseeko(f, (off_t)(data0 + t.begin), SEEK_SET) != 0)
+        if (fseeko(f, (off_t)(data0 + t.begin + skip * esz), SEEK_SET) != 0)
             return fail(CS_ERR_BAD_ARG, "Failed to initialize embedding model: %s is truncated", path);
         float* dst = params + w.off;
         if (esz == 4) {
@@ -409,6 +496,9 @@ int32_t cs_embedder_create_from_dir(const char* model_dir, int32_t pooling, int3
         if (onnx.empty())
             return fail(CS_ERR_BAD_ARG, "Failed to initialize embedding model: %s holds neither model.safetensors nor "
                         "onnx/model.onnx, model.onnx, model_optimized.onnx or model_quantized.onnx", model_dir);
+        if (cfg.arch == CS_ARCH_NOMIC)
+            return fail(CS_ERR_UNSUPPORTED, "Failed to initialize embedding model: the ONNX export of a nomic_bert model is not read "
+                        "(%s): place the repository's model.safetensors in %s", onnx.c_str(), model_dir);
         std::vector<float> wscale((size_t)cfg.layers * cs_bert_quant_columns(&cfg));
         int32_t quantized = 0;
         CS_TRY(cs_bert_params_from_onnx_q(onnx.c_str(), &cfg, params.data(), n, wscale.data(), wscale.size(), &quantized));

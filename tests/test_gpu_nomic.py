@@ -131,3 +131,34 @@ def test_cls_pooling_and_refusals(FE, oracle):
     with pytest.raises(CsError, match="dynamic-quantisation mode is not built"):
         nomic_small = BertConfig(**{**small.__dict__, "arch": ARCH_NOMIC, "rotary_base": 1000.0})
         FE(nomic_small, params=synth_params(nomic_small, 3), wscale=wscale)
+
+
+def test_embedder_from_a_nomic_snapshot_directory(FE, oracle, tmp_path):
+    """FastEmbedder.from_dir = cs_embedder_create_from_dir + the directory's WordPiece vocabulary (the Nomic models use
+    bert-base-uncased's): a NomicBert snapshot written here — config.json with the repository's keys, model.safetensors
+    with its tensor names (fused Wqkv, no Linear biases), vocab.txt — embeds texts like an embedder handed the mapped
+    flat block, and like the oracle."""
+    from codesearch_amd import FastEmbedder
+    from codesearch_amd.bert_params import from_nomic_state_dict
+    from codesearch_amd.pipeline import synth_code_texts, synth_vocab
+    from codesearch_amd.tokenizer import WordPieceTokenizer
+    from tests.test_oracle_nomic import nomic_snapshot
+
+    vocab = synth_vocab(1024)
+    cfg = BertConfig(vocab_size=1024, hidden=768, layers=2, heads=12, intermediate=3072, max_position=512, pooling=POOL_MEAN,
+                     arch=ARCH_NOMIC, rotary_base=1000.0)
+    d = tmp_path / "snapshot"
+    nomic_snapshot(d, cfg, synth_params(cfg, 78))
+    (d / "vocab.txt").write_text("\n".join(sorted(vocab, key=vocab.get)) + "\n")
+    emb = FastEmbedder.from_dir(str(d))
+    assert (emb.config.arch, emb.config.rotary_base, emb.dimensions(), emb.config.pooling) == (ARCH_NOMIC, 1000.0, 768, POOL_MEAN)
+    from safetensors.numpy import load_file
+    flat = from_nomic_state_dict(cfg, load_file(str(d / "model.safetensors")))  # the file's Linear biases: none -> zero
+    texts = synth_code_texts(vocab, 9, 3, mean_words=20) + ["fn main() { [SEP] }", ""]
+    got = np.stack(emb.embed_batch(texts))
+    ref_emb = FE(cfg, params=flat, tokenizer=WordPieceTokenizer(vocab, max_length=512))
+    assert np.array_equal(got, np.stack(ref_emb.embed_batch(texts)))
+    ids, mask = emb.tokenizer.encode_batch(texts)
+    np.testing.assert_allclose(got, oracle.bert_forward(cfg, flat, ids, mask)["pooled"], atol=TOL_ORACLE)
+    emb.close()
+    ref_emb.close()

@@ -99,6 +99,8 @@ def test_checkpoint_loader_roundtrip(tmp_path):
     save_file(sd, path)
     assert np.array_equal(load_checkpoint(path, cfg), flat)
     with pytest.raises(ValueError):
+        config_from_hf({**hf, "model_type": "modernbert"})
+    with pytest.raises(ValueError):  # NomicBert has its own keys (tests/test_oracle_nomic.py)
         config_from_hf({**hf, "model_type": "nomic_bert"})
 
 
@@ -167,7 +169,7 @@ def test_c_abi_checkpoint_loaders(tmp_path, gpu_lib):
     bad = tmp_path / "bad"
     bad.mkdir()
     expect(lambda: load(bad), _lib.CS_ERR_BAD_ARG, "cannot open")
-    (bad / "config.json").write_text(json.dumps({**hf, "model_type": "nomic_bert"}))
+    (bad / "config.json").write_text(json.dumps({**hf, "model_type": "modernbert"}))
     expect(lambda: load(bad), _lib.CS_ERR_UNSUPPORTED, "is not a BERT encoder")
     (bad / "config.json").write_text(json.dumps({**hf, "num_hidden_layers": 3}))
     save_file({k: np.ascontiguousarray(v) for k, v in sd.items()}, str(bad / "model.safetensors"))

@@ -113,3 +113,105 @@ def test_nomic_checkpoint_names_map_onto_the_flat_block():
     for bad in ({"rotary_emb_interleaved": True}, {"activation_function": "gelu"}, {"prenorm": True}, {"rotary_emb_fraction": 0.5}):
         with pytest.raises(ValueError):
             nomic_config_from_hf({**hf, **bad})
+
+
+def nomic_snapshot(tmp, cfg, flat, dtype=None, with_biases=False):
+    """A NomicBert HF snapshot directory (config.json with the repository's keys + model.safetensors with its names)."""
+    import json
+
+    from safetensors.numpy import save_file
+
+    ours = to_state_dict(cfg, flat)
+    sd = {"embeddings.word_embeddings.weight": ours["embeddings.word_embeddings.weight"],
+          "embeddings.token_type_embeddings.weight": ours["embeddings.token_type_embeddings.weight"],
+          "emb_ln.weight": ours["embeddings.LayerNorm.weight"], "emb_ln.bias": ours["embeddings.LayerNorm.bias"]}
+    for l in range(cfg.layers):
+        a, b = f"encoder.layer.{l}.", f"encoder.layers.{l}."
+        sd[b + "attn.Wqkv.weight"] = np.concatenate([ours[a + f"attention.self.{r}.weight"] for r in ("query", "key", "value")])
+        if with_biases:
+            sd[b + "attn.Wqkv.bias"] = np.concatenate([ours[a + f"attention.self.{r}.bias"] for r in ("query", "key", "value")])
+        for theirs, mine in (("attn.out_proj", "attention.output.dense"), ("mlp.fc11", "intermediate.dense"),
+                             ("mlp.fc12", "intermediate.gate"), ("mlp.fc2", "output.dense")):
+            sd[b + theirs + ".weight"] = ours[a + mine + ".weight"]
+            if with_biases:
+                sd[b + theirs + ".bias"] = ours[a + mine + ".bias"]
+        for n, o in (("norm1", "attention.output.LayerNorm"), ("norm2", "output.LayerNorm")):
+            sd[b + n + ".weight"], sd[b + n + ".bias"] = ours[a + o + ".weight"], ours[a + o + ".bias"]
+    hf = {"model_type": "nomic_bert", "architectures": ["NomicBertModel"], "vocab_size": cfg.vocab_size, "n_embd": cfg.hidden,
+          "n_head": cfg.heads, "n_layer": cfg.layers, "n_inner": cfg.intermediate, "n_positions": 8192,
+          "type_vocab_size": cfg.type_vocab_size, "layer_norm_epsilon": cfg.layer_norm_eps, "rotary_emb_base": int(cfg.rotary_base),
+          "rotary_emb_fraction": 1.0, "rotary_emb_interleaved": False, "rotary_emb_scale_base": None,
+          "rotary_scaling_factor": None, "activation_function": "swiglu", "prenorm": False, "qkv_proj_bias": with_biases,
+          "mlp_fc1_bias": with_biases, "mlp_fc2_bias": with_biases}
+    tmp.mkdir(exist_ok=True)
+    (tmp / "config.json").write_text(json.dumps(hf))
+    save_file({k: np.ascontiguousarray(v if dtype is None else v.astype(dtype)) for k, v in sd.items()},
+              str(tmp / "model.safetensors"), metadata={"format": "pt"})
+    return hf
+
+
+def test_c_abi_loader_reads_a_nomic_snapshot(tmp_path, gpu_lib):
+    """cs_bert_config_from_dir / cs_bert_params_from_safetensors (csrc/checkpoint.cpp, host-only) on a NomicBert snapshot:
+    the repository's config keys and tensor names (fused Wqkv cut into thirds, absent Linear biases left zero) give the
+    config and flat block of the Python mapping; refusals are worded."""
+    import ctypes as C
+    import json
+
+    from codesearch_amd import _lib
+
+    cfg = BertConfig(vocab_size=300, hidden=384, layers=2, heads=12, intermediate=1536, max_position=512, pooling=POOL_MEAN,
+                     arch=ARCH_NOMIC, rotary_base=1000.0)
+    flat = synth_params(cfg, 21)
+
+    def load(d, pooling=-1):
+        c = _lib.BertConfig()
+        _lib.check(gpu_lib.cs_bert_config_from_dir(str(d).encode(), pooling, C.byref(c)))
+        n = int(gpu_lib.cs_bert_param_count(C.byref(c)))
+        out = np.full(n, np.nan, np.float32)
+        _lib.check(gpu_lib.cs_bert_params_from_safetensors(str(d / "model.safetensors").encode(), C.byref(c),
+                                                          out.ctypes.data_as(_lib.f32p), n))
+        return c, out
+
+    hf = nomic_snapshot(tmp_path / "plain", cfg, flat)
+    c, got = load(tmp_path / "plain")
+    assert (c.arch, c.vocab_size, c.hidden, c.layers, c.heads, c.intermediate, c.max_position, c.type_vocab_size, c.pooling) == \
+        (ARCH_NOMIC, 300, 384, 2, 12, 1536, 512, 2, POOL_MEAN)  # mean pooling without a 1_Pooling module: fastembed's choice
+    assert c.rotary_base == 1000.0 and int(gpu_lib.cs_bert_param_count(C.byref(c))) == param_count(cfg)
+    # what the Python mapping gives for the same file: Linear biases zero, everything else bit for bit
+    from safetensors.numpy import load_file
+    exp = from_nomic_state_dict(cfg, load_file(str(tmp_path / "plain" / "model.safetensors")))
+    assert np.array_equal(got, exp)
+    # a checkpoint that does hold Linear biases: taken
+    nomic_snapshot(tmp_path / "biased", cfg, flat, with_biases=True)
+    _, got = load(tmp_path / "biased")
+    assert np.array_equal(got, flat)
+    # f16 file
+    nomic_snapshot(tmp_path / "f16", cfg, flat, dtype=np.float16)
+    _, got16 = load(tmp_path / "f16")
+    keep = exp != 0
+    assert np.array_equal(got16[keep], exp.astype(np.float16).astype(np.float32)[keep])
+    assert load(tmp_path / "plain", pooling=0)[0].pooling == 0  # an explicit pooling wins
+
+    def expect(d, code, text):
+        try:
+            load(d)
+        except _lib.CsError as e:
+            assert e.code == code and text in str(e), str(e)
+        else:
+            raise AssertionError("expected " + text)
+
+    bad = tmp_path / "bad"
+    for change, text in (({"rotary_emb_interleaved": True}, "this nomic_bert configuration is not built"),
+                         ({"activation_function": "gelu"}, "this nomic_bert configuration is not built"),
+                         ({"rotary_scaling_factor": 2}, "this nomic_bert configuration is not built"),
+                         ({"prenorm": True}, "this nomic_bert configuration is not built")):
+        nomic_snapshot(bad, cfg, flat)
+        (bad / "config.json").write_text(json.dumps({**hf, **change}))
+        expect(bad, _lib.CS_ERR_UNSUPPORTED, text)
+    nomic_snapshot(bad, cfg, flat)
+    (bad / "config.json").write_text(json.dumps({k: v for k, v in hf.items() if k != "n_head"}))
+    expect(bad, _lib.CS_ERR_BAD_ARG, "lacks a nomic_bert size field")
+    (bad / "config.json").write_text(json.dumps({**hf, "n_inner": 1024}))
+    expect(bad, _lib.CS_ERR_DIM_MISMATCH, "encoder.layers.0.mlp.fc11.weight has shape [1536, 384], config.json implies [1024, 384]")
+    (bad / "config.json").write_text(json.dumps({**hf, "n_layer": 3}))
+    expect(bad, _lib.CS_ERR_BAD_ARG, "encoder.layers.2.attn.Wqkv.weight is missing")
