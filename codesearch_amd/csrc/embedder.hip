@@ -534,11 +534,18 @@ int32_t forward_range(cs_embedder* h, hipStream_t s, uint32_t b0, uint32_t nb, u
             a.g = P + lo.out_ln_g; a.b = P + lo.out_ln_b;
             const _Float16* ffn_in = mids;  // E6's operand
             if (nomic) {
-                // E5 of the gated feed-forward: ONE product over fc11 | fc12 ([2I, H]) into the first 2I columns of the
-                // workspace, then value * silu(gate) into its last I columns — the operand of E6
+                // E5 of the gated feed-forward: ONE product over fc11's and fc12's rows ([2I, H], interleaved in groups of 16)
+                // into the first 2I columns of the workspace, then value * silu(gate) into its last I columns — E6's operand
                 _Float16* gated = reinterpret_cast<_Float16*>(mid + (size_t)T * 2 * I);
-                CS_TRY(dense(SH_OUT_SPLIT, xs, ws + sl.up, h->d_bup + (size_t)l * 2 * I, nullptr, nullptr, mids, T, 2 * I, H));
-                CS_TRY(launch_swiglu_split(mids, gated, T, I, h->d_flag, s));
+                const float* bup = h->d_bup + (size_t)l * 2 * I;
+                static const bool gate_fused = [] { const char* e = std::getenv("CS_NOMIC_GATE_FUSED"); return !(e && e[0] == '0'); }();
+                const bool w384 = takes_wide(T, 2 * I, H), w192 = !w384 && takes_192(T, 2 * I, H);
+                if (gate_fused && (w384 || w192)) {  // the gate as the product's epilogue: the raw [T, 2I] tensor never exists
+                    CS_TRY(launch_gemm_wide(GW_OUT_SWIGLU, xs, ws + sl.up, bup, nullptr, nullptr, gated, T, 2 * I, H, h->d_flag, s, w192 ? 192 : 0));
+                } else {
+                    CS_TRY(dense(SH_OUT_SPLIT, xs, ws + sl.up, bup, nullptr, nullptr, mids, T, 2 * I, H));
+                    CS_TRY(launch_swiglu_split(mids, gated, T, I, h->d_flag, s));
+                }
                 ffn_in = gated;
             } else {
                 CS_TRY(dense(SH_OUT_SPLIT_GELU, xs, ws + sl.up, P + lo.up_b, nullptr, nullptr, mids, T, I, H));    // E5
@@ -1207,8 +1214,12 @@ static int32_t create_impl(const cs_bert_config* cfg, const float* params, uint6
         for (uint32_t l = 0; l < cfg->layers && s == CS_OK; ++l) {
             cs_bert_layer_offsets lo;
             cs_bert_layer_layout(cfg, &h->off, l, &lo);
-            if (hipMemcpyAsync(h->d_bup + (size_t)l * 2 * I, h->d_params + lo.up_b, I * sizeof(float), hipMemcpyDeviceToDevice, h->stream) != hipSuccess ||
-                hipMemcpyAsync(h->d_bup + (size_t)l * 2 * I + I, h->d_params + lo.gate_b, I * sizeof(float), hipMemcpyDeviceToDevice, h->stream) != hipSuccess)
+            // value and gate interleaved in groups of 16 columns, the order of the packed weight (GW_OUT_SWIGLU, encoder.hpp)
+            float* bl = h->d_bup + (size_t)l * 2 * I;
+            if (hipMemcpy2DAsync(bl, 32 * sizeof(float), h->d_params + lo.up_b, 16 * sizeof(float), 16 * sizeof(float), I / 16,
+                                 hipMemcpyDeviceToDevice, h->stream) != hipSuccess ||
+                hipMemcpy2DAsync(bl + 16, 32 * sizeof(float), h->d_params + lo.gate_b, 16 * sizeof(float), 16 * sizeof(float), I / 16,
+                                 hipMemcpyDeviceToDevice, h->stream) != hipSuccess)
                 s = fail(CS_ERR_HIP, "feed-forward bias packing failed");
         }
         // the module's cos / sin cache, formed as it forms it: inv_freq_i = 1 / base^(2i / d_h) and pos * inv_freq_i in f32
@@ -1232,16 +1243,31 @@ static int32_t create_impl(const cs_bert_config* cfg, const float* params, uint6
             hipMalloc(&h->d_flag, sizeof(uint32_t)) != hipSuccess)
             return cleanup(fail(CS_ERR_OOM, "hipMalloc(split weights) failed"));
         if (hipMemsetAsync(h->d_flag, 0, sizeof(uint32_t), h->stream) != hipSuccess) s = fail(CS_ERR_HIP, "memset failed");
+        float* d_updown = nullptr;  // CS_ARCH_NOMIC: one layer's fc11 / fc12 rows interleaved in groups of 16, [2I][H]
+        if (cfg->arch == CS_ARCH_NOMIC && hipMalloc(&d_updown, 2 * I * H * sizeof(float)) != hipSuccess)
+            return cleanup(fail(CS_ERR_OOM, "hipMalloc(split weights) failed"));
         for (uint32_t l = 0; l < cfg->layers && s == CS_OK; ++l) {
             cs_bert_layer_offsets lo;
             cs_bert_layer_layout(cfg, &h->off, l, &lo);
             _Float16* ws = h->d_wsplit + (size_t)l * sl.total;
             s = launch_split_rows(h->d_wqkv + (size_t)l * 3 * H * H, ws + sl.qkv, 3 * H, (uint32_t)H, h->d_flag, h->stream);
             if (s == CS_OK) s = launch_split_rows(h->d_params + lo.ao_w, ws + sl.ao, H, (uint32_t)H, h->d_flag, h->stream);
-            if (s == CS_OK) s = launch_split_rows(h->d_params + lo.up_w, ws + sl.up, I, (uint32_t)H, h->d_flag, h->stream);
-            if (s == CS_OK && cfg->arch == CS_ARCH_NOMIC)  // fc12's rows behind fc11's: one [2I, H] weight
-                s = launch_split_rows(h->d_params + lo.gate_w, ws + sl.up + I * H * 2, I, (uint32_t)H, h->d_flag, h->stream);
+            if (s == CS_OK && cfg->arch == CS_ARCH_NOMIC) {
+                // one [2I, H] weight: raw output columns 32 u .. 32 u + 15 = fc11's rows 16 u .., the next sixteen fc12's, so that
+                // a value and its gate meet in one lane of the product's epilogue (GW_OUT_SWIGLU) and in one line of its output
+                const size_t grp = 16 * H * sizeof(float);
+                if (hipMemcpy2DAsync(d_updown, 2 * grp, h->d_params + lo.up_w, grp, grp, I / 16, hipMemcpyDeviceToDevice, h->stream) != hipSuccess ||
+                    hipMemcpy2DAsync(d_updown + 16 * H, 2 * grp, h->d_params + lo.gate_w, grp, grp, I / 16, hipMemcpyDeviceToDevice, h->stream) != hipSuccess)
+                    s = fail(CS_ERR_HIP, "feed-forward weight packing failed");
+                if (s == CS_OK) s = launch_split_rows(d_updown, ws + sl.up, 2 * I, (uint32_t)H, h->d_flag, h->stream);
+            } else if (s == CS_OK) {
+                s = launch_split_rows(h->d_params + lo.up_w, ws + sl.up, I, (uint32_t)H, h->d_flag, h->stream);
+            }
             if (s == CS_OK) s = launch_split_rows(h->d_params + lo.down_w, ws + sl.down, H, (uint32_t)I, h->d_flag, h->stream);
+        }
+        if (d_updown) {
+            (void)hipStreamSynchronize(h->stream);
+            (void)hipFree(d_updown);
         }
         uint32_t wflag = 0;
         if (s == CS_OK && (hipMemcpyAsync(&wflag, h->d_flag, sizeof(wflag), hipMemcpyDeviceToHost, h->stream) != hipSuccess ||

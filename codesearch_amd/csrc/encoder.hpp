@@ -64,6 +64,9 @@ int32_t launch_gemm_split(int epi, const _Float16* A, const _Float16* W, const f
 // gemm_wide.hip: the same product as a persistent kernel over 128 x 384 tiles with one accumulator per output
 // (w_hi scaled by 2^11 in registers).  N % 384 == 0; weights must pass sh_weights_fit_wide (|w| < 31.98).
 bool gemm_wide_supported(uint32_t N, uint32_t K);
+// epilogue of launch_gemm_wide only: W = value and gate rows interleaved in groups of 16 ([N][K], N = 2 x gated width);
+// Cs [M][N/64][64] = value * silu(gate) in split form (gemm_wide.hip; nomic.hip holds the stand-alone form)
+constexpr int GW_OUT_SWIGLU = 17;
 // shape: 0 = CS_GEMM_WIDE_SHAPE / default (128 x 384 where N allows), 192 = the 128 x 192 two-blocks-per-CU shape, 384
 int32_t launch_gemm_wide(int epi, const _Float16* A, const _Float16* W, const float* bias, const float* resid, float* C,
                          _Float16* Cs, uint32_t M, uint32_t N, uint32_t K, uint32_t* d_flag, hipStream_t s, int shape = 0);
@@ -80,7 +83,8 @@ int32_t launch_attention_cls(const _Float16* q_cls, const _Float16* kv_split, co
 int32_t launch_gather_cls(const _Float16* xs, float* x_cls, _Float16* xs_cls, uint32_t B, uint32_t L, uint32_t H, hipStream_t s);
 // nomic.hip (CS_ARCH_NOMIC): the rotary position map on the Q and K columns of a QKV tensor, in place — split form
 // [T][3H/32][64] or f32 [T][3H]; rope [L_max][d_h / 2] (cos, sin) — and the feed-forward gate value * silu(gate): up2
-// [T][2I/32][64] (value lines, then gate lines) -> out [T][I/32][64], or value [T][I] *= silu(gate [T][I]).
+// [T][2I/32][64] (every 128-byte line: 16 values | 16 gates, the interleaved row order of GW_OUT_SWIGLU's weight) -> out
+// [T][I/32][64], or value [T][I] *= silu(gate [T][I]).
 int32_t launch_rope_split(_Float16* qkvs, const float2* rope, uint32_t T, uint32_t L, uint32_t H, uint32_t heads,
                           uint32_t* flag, hipStream_t s);
 int32_t launch_rope_f32(float* qkv, const float2* rope, uint32_t T, uint32_t L, uint32_t H, uint32_t heads, hipStream_t s);

@@ -63,6 +63,12 @@ struct GwGeom {
 };
 constexpr uint32_t GW_LN_RESID_SPLIT = 1u, GW_LN_NO_F32 = 2u;  // ln_flags of the LayerNorm epilogue (launch_gemm_wide_ln)
 constexpr int GW_OUT_LN = 16;  // epilogue: + bias + residual, LayerNorm over the 384 columns, store f32 AND split form
+// GW_OUT_SWIGLU (encoder.hpp): the gated up projection of a NomicBert feed-forward.  W's rows (and the bias) are value and gate
+// rows interleaved in groups of 16 — raw columns 32 u .. 32 u + 15 are fc11's rows 16 u .. 16 u + 15, the next sixteen
+// fc12's — so a wave's six 16-column MFMA tiles are value, gate, value, gate, value, gate of the SAME 48 gated columns and a
+// lane holds a value and its gate in the same register slot of neighbouring tiles: the epilogue stores
+// value * silu(gate) in split form, [M][N/64][64], and the 2 x 4 bytes per element of the raw projection never reach HBM.
+// (A wave owns 48 gated columns = one and a half 128-byte lines: a third of the lines are completed by two waves.)
 
 namespace {
 
@@ -82,6 +88,10 @@ __device__ __forceinline__ float gw_erf_fast(float x) {  // gemm_split.hip sh_er
     return __builtin_copysignf(e, x);
 }
 __device__ __forceinline__ float gw_gelu(float v) { return 0.5f * v * (1.0f + gw_erf_fast(v * 0.70710678118654752440f)); }
+// v * sigmoid(v): hardware exp2 and reciprocal (~1 ulp each)
+__device__ __forceinline__ float gw_silu(float v) {
+    return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v * -1.44269504088896340736f));
+}
 
 struct GwAcc { sh_f32x4v c[4][6]; };
 
@@ -381,6 +391,40 @@ gemm_wide_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ W,
             // gamma / beta per strip from the block's LDS copy (held in registers across the strips they would cost the 48
             // registers the accumulators need; as global loads each strip's would sit behind the previous strip's stores
             // in the vmcnt queue and wait for them)
+            if constexpr (EPI == GW_OUT_SWIGLU) {
+#pragma unroll
+                for (int jj = 0; jj < 3; ++jj) {
+                    sh_f32x4 v;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        v[r] = (acc.c[i][2 * jj][r] * kShLoInv) * gw_silu(acc.c[i][2 * jj + 1][r] * kShLoInv);
+                    *reinterpret_cast<sh_f32x4*>(patch + l15 * PS + 16 * jj + 4 * g) = v;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                // 16 rows x 6 pieces of 8 gated columns = 96 pieces
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const int pidx = lane + 64 * t;
+                    if (pidx < 96) {
+                        const int prow = pidx / 6, q = pidx - prow * 6;
+                        const sh_f32x4 v0 = *reinterpret_cast<const sh_f32x4*>(patch + prow * PS + q * 8);
+                        const sh_f32x4 v1 = *reinterpret_cast<const sh_f32x4*>(patch + prow * PS + q * 8 + 4);
+                        const uint32_t m = wr * 64 + 16 * i + prow;
+                        const uint32_t col = (n0 >> 1) + wc * 48 + q * 8;  // gated column
+                        f16x8 hi, lo;
+                        sh_split8(v0, v1, hi, lo, mx);
+                        if (full || m0 + m < M) {
+                            _Float16* dst = Cs + ((size_t)(m0 + m) * (N / 64) + (col >> 5)) * 64 + (col & 31);
+                            __builtin_nontemporal_store(hi, reinterpret_cast<f16x8*>(dst));
+                            __builtin_nontemporal_store(lo, reinterpret_cast<f16x8*>(dst + 32));
+                        }
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                continue;
+            }
 #pragma unroll
             for (int j = 0; j < 6; ++j) {
                 sh_f32x4 v;
@@ -540,6 +584,7 @@ static int32_t gemm_wide_launch(int epi, const _Float16* A, const _Float16* W, c
         CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wide_kernel<SH_OUT_F32_RESID, 0, WCN>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
         CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wide_kernel<SH_OUT_SPLIT_GELU, 0, WCN>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
         CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wide_kernel<SH_OUT_SPLIT, 0, WCN>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
+        CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wide_kernel<GW_OUT_SWIGLU, 0, WCN>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
         if constexpr (WCN == 4)
             CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wide_kernel<GW_OUT_LN, 0, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
         int dev = 0, n = 0;
@@ -595,6 +640,7 @@ static int32_t gemm_wide_launch(int epi, const _Float16* A, const _Float16* W, c
     else if (epi == SH_OUT_F32_RESID) GW_LAUNCH(SH_OUT_F32_RESID, 0);
     else if (epi == SH_OUT_SPLIT) GW_LAUNCH(SH_OUT_SPLIT, 0);
     else if (epi == SH_OUT_SPLIT_GELU) GW_LAUNCH(SH_OUT_SPLIT_GELU, 0);
+    else if (epi == GW_OUT_SWIGLU) GW_LAUNCH(GW_OUT_SWIGLU, 0);
     else if (epi == GW_OUT_LN) {
         if constexpr (WCN == 4) GW_LAUNCH(GW_OUT_LN, 0);
         else return fail(CS_ERR_BAD_ARG, "the LayerNorm epilogue needs the 128 x 384 block");

@@ -1,8 +1,9 @@
 // nomic.hip — what the NomicBert encoder (cs_bert_config.arch == CS_ARCH_NOMIC: the reference registry's nomic-embed-text
 // entries, /root/reference/src/embed/embedder.rs:30-35, :64-66) does that BERT does not: the rotary position map on Q and K
 // behind the QKV projection, and the gate of its feed-forward,  fc2( fc11(x) * silu(fc12(x)) ).  Both are element-wise passes
-// between the dense layers of gemm_wide.hip / gemm_split.hip, which run unchanged (the up projection is ONE GEMM over the
-// [2I, H] weight fc11 | fc12); each exists for the split-f16 tensors of the default path (split_f16.hpp: a 32-column chunk
+// between the dense layers of gemm_wide.hip / gemm_split.hip (the up projection is ONE GEMM over the [2I, H] weight of
+// fc11's and fc12's rows interleaved in groups of 16; at indexing batch sizes the gate is that GEMM's epilogue,
+// GW_OUT_SWIGLU, and the stand-alone kernel below serves the smaller launches); each exists for the split-f16 tensors of the default path (split_f16.hpp: a 32-column chunk
 // of a row is one 128-B line, 32 hi then 32 lo) and for the plain f32 tensors of the exact path.  HBM-bound: 16-byte
 // accesses, one thread per eight neighbouring elements.
 //
@@ -97,7 +98,9 @@ rope_f32_kernel(float* __restrict__ qkv, const float2* __restrict__ rope, uint32
 
 __device__ __forceinline__ float silu(float v) { return v / (1.0f + expf(-v)); }
 
-// up2 [T][2I/32][64]: value lines 0 .. I/32 - 1 (fc11), gate lines I/32 .. 2I/32 - 1 (fc12) -> out [T][I/32][64]
+// up2 [T][2I/32][64], columns interleaved in groups of 16 (GW_OUT_SWIGLU's weight order, encoder.hpp): line u of a row holds
+// values 16 u .. 16 u + 15 and their gates — hi: [16 v | 16 g], lo: [16 v | 16 g] -> out [T][I/32][64].  One thread: eight
+// gated columns.
 __global__ void __launch_bounds__(256)
 swiglu_split_kernel(const _Float16* __restrict__ up2, _Float16* __restrict__ out, uint32_t T, uint32_t I,
                     uint32_t* __restrict__ flag) {
@@ -105,9 +108,9 @@ swiglu_split_kernel(const _Float16* __restrict__ up2, _Float16* __restrict__ out
     const uint64_t gid = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (gid >= (uint64_t)T * per_row) return;
     const uint64_t t = gid / per_row;
-    const uint32_t col = (uint32_t)(gid % per_row) * 8;
-    const _Float16* pv = up2 + t * (uint64_t)(2 * I) * 2 + (col >> 5) * 64 + (col & 31);
-    const _Float16* pg = pv + (size_t)(I >> 5) * 64;
+    const uint32_t col = (uint32_t)(gid % per_row) * 8;  // gated column: line col / 16 of the raw row, offset col % 16
+    const _Float16* pv = up2 + t * (uint64_t)(2 * I) * 2 + (size_t)(col >> 4) * 64 + (col & 15);
+    const _Float16* pg = pv + 16;
     sh_f32x4 va, vb, ga, gb;
     unsplit8(*reinterpret_cast<const f16x8*>(pv), *reinterpret_cast<const f16x8*>(pv + 32), va, vb);
     unsplit8(*reinterpret_cast<const f16x8*>(pg), *reinterpret_cast<const f16x8*>(pg + 32), ga, gb);

@@ -162,3 +162,39 @@ def test_embedder_from_a_nomic_snapshot_directory(FE, oracle, tmp_path):
     np.testing.assert_allclose(got, oracle.bert_forward(cfg, flat, ids, mask)["pooled"], atol=TOL_ORACLE)
     emb.close()
     ref_emb.close()
+
+
+@pytest.mark.parametrize("hidden,heads,inter,B,L", [(384, 12, 1536, 96, 96), (768, 12, 3072, 48, 128), (384, 12, 1536, 40, 200)])
+def test_gate_in_the_product_epilogue_equals_the_separate_kernel(FE, oracle, hidden, heads, inter, B, L):
+    """At indexing batch sizes the gate is the up projection's epilogue (gemm_wide.hip GW_OUT_SWIGLU: the 128 x 384 block
+    shape for 2I <= 4,096 columns, the 128 x 192 one above; a ragged last row tile in the third case).  Against the
+    oracle, and against the same library with the stand-alone gate kernel (CS_NOMIC_GATE_FUSED=0 is read once per process,
+    so the comparison runs in a child process through the C ABI as well)."""
+    import subprocess
+    import sys
+
+    cfg = BertConfig(vocab_size=512, hidden=hidden, layers=2, heads=heads, intermediate=inter, max_position=512,
+                     pooling=POOL_MEAN, arch=ARCH_NOMIC, rotary_base=1000.0)
+    ids, mask = synth_token_batch(cfg, 600 + B, B, L, True)
+    emb = FE(cfg, seed=412)
+    got = emb.embed_ids(ids, mask)
+    emb.close()
+    ref = oracle.bert_forward(cfg, synth_params(cfg, 412), ids, mask)["pooled"]
+    np.testing.assert_allclose(got, ref, atol=TOL_ORACLE)
+    code = (
+        "import numpy as np, sys\n"
+        "from codesearch_amd import FastEmbedder, ModelType\n"
+        "from codesearch_amd.bert_params import ARCH_NOMIC, POOL_MEAN, BertConfig, synth_token_batch\n"
+        f"cfg = BertConfig(vocab_size=512, hidden={hidden}, layers=2, heads={heads}, intermediate={inter}, max_position=512,"
+        " pooling=POOL_MEAN, arch=ARCH_NOMIC, rotary_base=1000.0)\n"
+        f"ids, mask = synth_token_batch(cfg, {600 + B}, {B}, {L}, True)\n"
+        "emb = FastEmbedder(ModelType.NomicEmbedTextV15, config=cfg, seed=412)\n"
+        "np.save(sys.argv[1], emb.embed_ids(ids, mask))\n")
+    out = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"nomic_unfused_{hidden}_{B}_{L}.npy")
+    env = dict(os.environ, CS_NOMIC_GATE_FUSED="0")
+    subprocess.run([sys.executable, "-c", code, out], check=True, env=env, cwd=os.path.dirname(os.path.dirname(__file__)))
+    unfused = np.load(out)
+    os.remove(out)
+    # the two routes differ by the silu's last bits (hardware exp2 / rcp against expf and a division)
+    np.testing.assert_allclose(got, unfused, atol=2e-6)
+    np.testing.assert_allclose(unfused, ref, atol=TOL_ORACLE)
