@@ -291,6 +291,7 @@ def encoder_legs(shard, k, device, with_cpu=True):
     emb_mean.close()
     g5, a5 = _encoder_flops(cfg, B5, L5)
     quantized_default = quantized_default_model_leg(ids, mask, d_q[0], device, iters)
+    nomic = nomic_model_leg(device, iters)
     layers = cfg.layers
     stage_names = ("qkv_gemm", "attention", "out_proj_gemm", "layernorm_attn", "ffn_up_gemm", "ffn_down_gemm", "layernorm_ffn")
     Hh, Ii, BL = cfg.hidden, cfg.intermediate, B * L
@@ -363,6 +364,7 @@ def encoder_legs(shard, k, device, with_cpu=True):
             "attention_executed_tflops": 3 * layers * 4 * L5 * Hh * B5 * L5 / (stages5["attention"] * 1e-6) / 1e12,
         },
         "quantized_default_model": quantized_default,
+        "nomic_model": nomic,
         "reference_call_shape": {
             "workload": "32 chunks x 256 tokens per call (BatchEmbedder slices by 32, src/embed/batch.rs:70,94), CLS pooling",
             "device_ms_per_call": ms32, "wall_ms_per_call_incl_h2d": wall32 * 1e3, "chunks_per_s": 32 / (ms32 * 1e-3),
@@ -390,6 +392,58 @@ def encoder_legs(shard, k, device, with_cpu=True):
                             "free, and the forward itself runs slower beside a search (embed_ms_with_previous_search_in_flight)")
     es["cls_pool_variant"] = embed_search(cls)
     return {"encoder": enc, "embed_search": es}
+
+
+def nomic_model_leg(device, iters):
+    """The registry's Nomic entries (ModelType::NomicEmbedTextV1 / V15 / V15Q, /root/reference/src/embed/embedder.rs:30-35) are
+    NomicBert encoders: 12 x 768, 12 heads of 64, rotary positions on Q / K, fc2(fc11(x) * silu(fc12(x))) with n_inner 3072
+    (cs_bert_config.arch = CS_ARCH_NOMIC, csrc/nomic.hip).  The reference's mini-batch for a 768-d model (128 sequences,
+    embedder.rs:251-261) at 256 tokens, synthetic weights, mean pooling; flops = 16 H^2 multiply-adds per token and layer in
+    the dense layers (3 + 1 + 8 + 4) against BERT's 12."""
+    import torch
+
+    from codesearch_amd import FastEmbedder, ModelType
+    from codesearch_amd.bert_params import synth_token_batch
+
+    mt = ModelType.NomicEmbedTextV15
+    cfg = mt.bert_config()
+    Bn, Ln = 128, 256
+    ids, mask = synth_token_batch(cfg, 997, Bn, Ln, False)
+    emb = FastEmbedder(mt, config=cfg, seed=203, device=device)
+    d_out = torch.empty((Bn, cfg.hidden), dtype=torch.float32, device=f"cuda:{device}")
+    emb.embed_ids_to_device(ids, mask, d_out.data_ptr())
+    torch.cuda.synchronize()
+    emb.profile_read(reset=True)
+    for _ in range(iters):
+        emb.embed_ids_to_device(ids, mask, d_out.data_ptr())
+    torch.cuda.synchronize()
+    ms, n = emb.profile_read()
+    ms /= max(n, 1)
+    emb.profile_stages(True)
+    emb.embed_ids_to_device(ids, mask, d_out.data_ptr())
+    emb.profile_stages_read(reset=True)
+    for _ in range(3):
+        emb.embed_ids_to_device(ids, mask, d_out.data_ptr())
+    stages, _ = emb.profile_stages_read()
+    emb.profile_stages(False)
+    split_fw, f32_fw, _ = emb.debug_counters()
+    emb.close()
+    H, I, T = cfg.hidden, cfg.intermediate, Bn * Ln
+    dense = 2.0 * T * (3 * H * H + H * H + 2 * I * H + H * I) * cfg.layers
+    attn = 4.0 * Bn * Ln * Ln * H * cfg.layers
+    stage_names = ("qkv_gemm", "attention", "out_proj_gemm", "layernorm_attn", "ffn_up_gemm", "ffn_down_gemm", "layernorm_ffn")
+    return {
+        "workload": f"{mt.name_str()} shape ({cfg.layers} x hidden {H}, {cfg.heads} heads of {H // cfg.heads}, n_inner {I}, rotary base "
+                    f"{cfg.rotary_base:g}), batch {Bn} x seq {Ln}, synthetic weights, mean pooling",
+        "ms_per_batch": ms, "chunks_per_s": Bn / (ms * 1e-3), "tokens_per_s": T / (ms * 1e-3),
+        "algorithmic_tflops": (dense + attn) / (ms * 1e-3) / 1e12,
+        "executed_tflops": 3 * (dense + attn) / (ms * 1e-3) / 1e12,
+        "frac_of_f16_mfma_peak": 3 * (dense + attn) / (ms * 1e-3) / 1e12 / MFMA_F16_PEAK_TFLOPS,
+        "split_forwards": split_fw, "f32_fallbacks": f32_fw,
+        "per_kernel_us_per_layer": {kn: stages[kn] / cfg.layers for kn in stage_names},
+        "per_kernel_note": "qkv_gemm includes the rotary map on Q and K (nomic.hip rope_split_kernel); ffn_up_gemm is ONE product over "
+                           "fc11 | fc12 whose epilogue stores value * silu(gate) (gemm_wide.hip GW_OUT_SWIGLU)",
+    }
 
 
 def quantized_default_model_leg(ids, mask, d_out, device, iters):
