@@ -19,7 +19,11 @@ TINY = "48 64 2 2 128 16"  # vocab hidden layers heads intermediate max_position
 
 @pytest.fixture(scope="module")
 def fuzz():
-    subprocess.run(["make", "-s", "-C", CPP, "asan"], check=True)
+    import fcntl
+
+    with open(os.path.join(CPP, ".asan_build.lock"), "w") as lock:  # pytest-xdist workers build one at a time
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        subprocess.run(["make", "-s", "-C", CPP, "asan"], check=True)
     exe = os.path.join(CPP, "parser_fuzz_asan")
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=1:allocator_may_return_null=1:max_allocation_size_mb=4096",
                UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1")
