@@ -198,3 +198,23 @@ def test_gate_in_the_product_epilogue_equals_the_separate_kernel(FE, oracle, hid
     # the two routes differ by the silu's last bits (hardware exp2 / rcp against expf and a division)
     np.testing.assert_allclose(got, unfused, atol=2e-6)
     np.testing.assert_allclose(unfused, ref, atol=TOL_ORACLE)
+
+
+def test_two_stream_slices_and_the_longest_sequences(FE, oracle):
+    """From 20,000 tokens a forward runs as two half-batches on two streams (embedder.hip forward()): each slice has its
+    own [T, 2I | I] stretch of the feed-forward workspace.  And 512 positions — every row of the rotary table."""
+    cfg = BertConfig(vocab_size=512, hidden=768, layers=1, heads=12, intermediate=3072, max_position=512, pooling=POOL_MEAN,
+                     arch=ARCH_NOMIC, rotary_base=1000.0)
+    emb = FE(cfg, seed=413)
+    params = synth_params(cfg, 413)
+    ids, mask = synth_token_batch(cfg, 700, 96, 256, True)  # 24,576 tokens
+    got = emb.embed_ids(ids, mask, batch_size=96)
+    np.testing.assert_allclose(got, oracle.bert_forward(cfg, params, ids, mask)["pooled"], atol=TOL_ORACLE)
+    ids, mask = synth_token_batch(cfg, 701, 3, 512, True)
+    got = emb.embed_ids(ids, mask)
+    np.testing.assert_allclose(got, oracle.bert_forward(cfg, params, ids, mask)["pooled"], atol=TOL_ORACLE)
+    from codesearch_amd import CsError
+    with pytest.raises(CsError):  # beyond max_position: no rotary row (and no truncation behind the tokenizer's back)
+        emb.embed_ids(np.ones((1, 513), np.int32), np.ones((1, 513), np.int32))
+    assert emb.debug_counters()[1] == 0
+    emb.close()
