@@ -367,9 +367,16 @@ int32_t cs_embedder_create(const cs_bert_config* cfg, const float* params, uint6
  * UINT8 weights with scale and zero point behind MatMulInteger) are read as (q - zero_point) * scale into the f32 block and,
  * when every Linear of every layer is quantised, the embedder runs them the way the file's graph does (CS_GEMM_Q8_DYNAMIC
  * below: activations re-quantised to 8 bits per call, integer products); CS_ENCODER_QUANT=0 in the environment keeps the
- * f32 graph of the quantised weights instead.  All loaders are host-only. */
+ * f32 graph of the quantised weights instead.  All loaders are host-only.
+ * A NomicBert directory (config.json with model_type "nomic_bert": nomic-ai/nomic-embed-text-v1 / v1.5, the registry's
+ * Nomic entries) is read too — its GPT-2 style keys (n_embd, n_head, n_layer, n_inner, rotary_emb_base, ...; only the
+ * published arrangement: full non-interleaved rotary positions without scaling, swiglu, post-norm) into a CS_ARCH_NOMIC
+ * config, and its model.safetensors by the model repository's tensor names (emb_ln, encoder.layers.N.attn.Wqkv cut into
+ * query | key | value, attn.out_proj, norm1, mlp.fc11 / fc12 / fc2, norm2; absent Linear biases are zero).  Its ONNX
+ * export is not read (CS_ERR_UNSUPPORTED). */
 /* pooling: CS_POOL_CLS, CS_POOL_MEAN, or -1 = what <model_dir>/1_Pooling/config.json says (the
- * sentence-transformers module: mean for MiniLM / E5, CLS for BGE), CLS when that file is absent. */
+ * sentence-transformers module: mean for MiniLM / E5, CLS for BGE), CLS when that file is absent (mean for a
+ * nomic_bert directory: fastembed's pooling for the family). */
 int32_t cs_bert_config_from_dir(const char* model_dir, int32_t pooling, cs_bert_config* cfg);
 int32_t cs_bert_params_from_safetensors(const char* path, const cs_bert_config* cfg,
                                         float* params, uint64_t n_params);
