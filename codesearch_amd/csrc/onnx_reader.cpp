@@ -398,6 +398,8 @@ int32_t cs_bert_params_from_onnx_q(const char* path, const cs_bert_config* cfg, 
                                    float* wscale, uint64_t n_wscale, int32_t* quantized) {
     if (quantized) *quantized = 0;
     if (!path || !cfg || !params) return fail(CS_ERR_BAD_ARG, "null argument");
+    if (cfg->arch != CS_ARCH_BERT)  // the names and graph shapes below are a BERT export's
+        return fail(CS_ERR_UNSUPPORTED, "Failed to initialize embedding model: only BERT exports are read from ONNX files (%s)", path);
     const uint64_t qcols = 5 * (uint64_t)cfg->hidden + cfg->intermediate;
     if (wscale && n_wscale != (uint64_t)cfg->layers * qcols)
         return fail(CS_ERR_BAD_ARG, "Failed to initialize embedding model: room for %llu column scales, %llu needed",

@@ -215,3 +215,25 @@ def test_c_abi_loader_reads_a_nomic_snapshot(tmp_path, gpu_lib):
     expect(bad, _lib.CS_ERR_DIM_MISMATCH, "encoder.layers.0.mlp.fc11.weight has shape [1536, 384], config.json implies [1024, 384]")
     (bad / "config.json").write_text(json.dumps({**hf, "n_layer": 3}))
     expect(bad, _lib.CS_ERR_BAD_ARG, "encoder.layers.2.attn.Wqkv.weight is missing")
+
+
+def test_onnx_reader_refuses_a_nomic_config(tmp_path, gpu_lib):
+    """The ONNX reader's names and graph shapes are a BERT export's: a CS_ARCH_NOMIC config is refused before the file is
+    opened, and a nomic_bert directory that holds only an ONNX file says what it needs."""
+    import ctypes as C
+
+    from codesearch_amd import _lib
+
+    cfg = BertConfig(vocab_size=300, hidden=384, layers=1, heads=12, intermediate=1536, pooling=POOL_MEAN, arch=ARCH_NOMIC,
+                     rotary_base=1000.0)
+    c = cfg.to_c()
+    out = np.zeros(param_count(cfg), np.float32)
+    rc = gpu_lib.cs_bert_params_from_onnx(str(tmp_path / "model.onnx").encode(), C.byref(c), out.ctypes.data_as(_lib.f32p), out.size)
+    assert rc == _lib.CS_ERR_UNSUPPORTED and "only BERT exports" in gpu_lib.cs_last_error().decode()
+    d = tmp_path / "snap"
+    nomic_snapshot(d, cfg, synth_params(cfg, 1))
+    (d / "model.safetensors").rename(d / "elsewhere.bin")
+    (d / "model.onnx").write_bytes(b"\x08\x07")
+    h = C.c_void_p()
+    rc = gpu_lib.cs_embedder_create_from_dir(str(d).encode(), -1, 0, C.byref(h))
+    assert rc == _lib.CS_ERR_UNSUPPORTED and "model.safetensors" in gpu_lib.cs_last_error().decode()
