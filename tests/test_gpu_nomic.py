@@ -218,3 +218,24 @@ def test_two_stream_slices_and_the_longest_sequences(FE, oracle):
         emb.embed_ids(np.ones((1, 513), np.int32), np.ones((1, 513), np.int32))
     assert emb.debug_counters()[1] == 0
     emb.close()
+
+
+def test_randomised_shapes_against_the_oracle(FE, oracle):
+    """Twelve seeded (batch, length, raggedness) draws over both head widths — odd lengths, single rows, lengths around the
+    attention kernels' 32 / 64 / 128-key boundaries — one embedder per width, every draw against the oracle."""
+    rng = np.random.default_rng(20261004)
+    for hidden, heads, inter in ((384, 12, 1536), (768, 12, 3072)):
+        cfg = BertConfig(vocab_size=512, hidden=hidden, layers=2, heads=heads, intermediate=inter, max_position=512,
+                         pooling=POOL_MEAN, arch=ARCH_NOMIC, rotary_base=1000.0)
+        emb = FE(cfg, seed=414)
+        params = synth_params(cfg, 414)
+        for draw in range(6):
+            L = int(rng.choice([1, 2, 5, 31, 33, 63, 65, 100, 127, 129, 200, 257]))
+            B = int(rng.integers(1, 40 if L <= 129 else 12))
+            ragged = bool(rng.integers(0, 2)) and L >= 16
+            ids, mask = synth_token_batch(cfg, 800 + 13 * draw + hidden, B, L, ragged)
+            got = emb.embed_ids(ids, mask)
+            ref = oracle.bert_forward(cfg, params, ids, mask)["pooled"]
+            np.testing.assert_allclose(got, ref, atol=TOL_ORACLE, err_msg=f"hidden {hidden} B {B} L {L} ragged {ragged}")
+        assert emb.debug_counters()[1] == 0
+        emb.close()
