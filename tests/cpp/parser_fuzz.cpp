@@ -70,7 +70,7 @@ static void spit(const std::string& path, const uint8_t* p, size_t n) {
 
 int main(int argc, char** argv) {
     if (argc < 5) {
-        fprintf(stderr, "usage: parser_fuzz <onnx|safetensors|tokenizer_json|vocab|config_dir> <file> <seed> <flips> [aux]\n");
+        fprintf(stderr, "usage: parser_fuzz <onnx|safetensors|tokenizer_json|vocab|config_dir> <file> <seed> <flips> [\"vocab hidden layers heads intermediate maxpos [arch]\"]\n");
         return 2;
     }
     const std::string kind = argv[1], src = argv[2];
@@ -87,9 +87,11 @@ int main(int argc, char** argv) {
     cfg.vocab_size = 64; cfg.hidden = 384; cfg.layers = 1; cfg.heads = 12; cfg.intermediate = 1536; cfg.max_position = 32;
     cfg.type_vocab_size = 2; cfg.layer_norm_eps = 1e-12f; cfg.pooling = 0;
     if (argc > 5) {
-        unsigned v[6] = {0, 0, 0, 0, 0, 0};
-        if (sscanf(argv[5], "%u %u %u %u %u %u", &v[0], &v[1], &v[2], &v[3], &v[4], &v[5]) == 6) {
+        unsigned v[7] = {0, 0, 0, 0, 0, 0, 0};  // an optional seventh field: the encoder family (1 = NomicBert, rotary base 1000)
+        const int got = sscanf(argv[5], "%u %u %u %u %u %u %u", &v[0], &v[1], &v[2], &v[3], &v[4], &v[5], &v[6]);
+        if (got >= 6) {
             cfg.vocab_size = v[0]; cfg.hidden = v[1]; cfg.layers = v[2]; cfg.heads = v[3]; cfg.intermediate = v[4]; cfg.max_position = v[5];
+            if (got == 7 && v[6] == 1) { cfg.arch = CS_ARCH_NOMIC; cfg.rotary_base = 1000.0f; }
         }
     }
     const uint64_t n_params = cs_bert_param_count(&cfg);

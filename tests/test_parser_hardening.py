@@ -71,6 +71,23 @@ def test_safetensors_reader_survives_truncations_and_mutations(fuzz, tmp_path):
     fuzz("safetensors", p, seed=13, flips=300)
 
 
+def test_nomic_snapshot_readers_survive_truncations_and_mutations(fuzz, tmp_path):
+    """The NomicBert branches of the same readers: config.json with the model repository's keys, model.safetensors with its
+    names (rows of the fused Wqkv read at an offset, Linear biases optional)."""
+    from codesearch_amd.bert_params import ARCH_NOMIC, POOL_MEAN, BertConfig, synth_params
+    from tests.test_oracle_nomic import nomic_snapshot
+
+    cfg = BertConfig(vocab_size=64, hidden=128, heads=4, intermediate=256, layers=1, max_position=512, pooling=POOL_MEAN,
+                     arch=ARCH_NOMIC, rotary_base=1000.0)
+    d = tmp_path / "nomic"
+    nomic_snapshot(d, cfg, synth_params(cfg, 6))
+    fuzz("safetensors", d / "model.safetensors", seed=31, flips=600, aux="64 128 1 4 256 512 1")
+    nomic_snapshot(d, cfg, synth_params(cfg, 6), dtype=np.float16, with_biases=True)
+    fuzz("safetensors", d / "model.safetensors", seed=32, flips=300, aux="64 128 1 4 256 512 1")
+    out = fuzz("config_dir", d / "config.json", seed=33, flips=1500)
+    assert "0 crashes" in out
+
+
 def test_tokenizer_json_and_vocab_readers_survive(fuzz, tmp_path):
     from tokenizers import Tokenizer, models, normalizers, pre_tokenizers, processors
 
