@@ -76,8 +76,8 @@ struct cs_embedder {
     float* d_params = nullptr;
     float* d_wqkv = nullptr;  // [layers][3H][H]  (query | key | value rows)
     float* d_bqkv = nullptr;  // [layers][3H]
-    // CS_ARCH_NOMIC: the up projection's bias as one [2I] vector per layer (fc11 | fc12) and the rotary table
-    // [max_position][d_h / 2] (cos, sin)
+    // CS_ARCH_NOMIC: the up projection's bias as one [2I] vector per layer (fc11's and fc12's entries interleaved in groups
+    // of 16, like the rows of the packed weight) and the rotary table [max_position][d_h / 2] (cos, sin)
     float* d_bup = nullptr;
     float2* d_rope = nullptr;
     _Float16* d_wsplit = nullptr;  // per layer: wqkv | attention-out | ffn-up | ffn-down, split-f16 rows
@@ -118,7 +118,7 @@ struct cs_embedder {
     float* d_xs = nullptr;      // [T, H/32, 64] f16: x in split form (same bytes as f32)
     float* d_qkv = nullptr;     // [T, 3H]
     float* d_ctx = nullptr;     // [T, H]   (f32, or split form: same bytes)
-    float* d_mid = nullptr;     // [T, I]   (f32, or split form: same bytes)
+    float* d_mid = nullptr;     // [T, I]   (f32, or split form: same bytes); CS_ARCH_NOMIC: [T, 3I] per slice (mid_width)
     float* d_pooled = nullptr;  // [B, H]
     uint32_t* d_perm = nullptr; // [B] destination row of each pooled row (length-sorted text mini-batches)
     std::vector<float> h_pooled; // host staging of a mini-batch's rows when they are scattered
