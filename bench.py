@@ -68,7 +68,7 @@ def parse_args():
     ap.add_argument("--e2e-chunks", type=int, default=100_000)
     ap.add_argument("--route", choices=("stream", "cost", "filter"), default="stream",
                     help="one query per step: stream = the f32 streaming scan (the north-star kernel `value` is quoted on; "
-                         "default), cost = the library's default route (int8 filter + exact refine from 150,000 rows on), filter")
+                         "default), cost = the library's default route (int8 filter + exact refine from 32,768 rows on at k < 48, 300,000 above), filter")
     ap.add_argument("--no-rccl-child", action="store_true",
                     help="--gpus N without a launcher: do not run the one-rank-per-GPU RCCL form as child processes first")
     ap.add_argument("--no-config5", action="store_true", help="--gpus N without a launcher: skip the 1,000-query leg")
@@ -619,7 +619,7 @@ def scan_1m_leg(dim, k, device, store_cls):
            "hbm_GBps": gbps, "frac_of_hbm_peak": gbps / HBM_PEAK_GBPS,
            "default_routing": {"ms_per_search": wall_def * 1e3, "chunks_per_s": rows / wall_def,
                                "bit_identical_to_streaming_scan": same,
-                               "note": "CS_ROUTE_COST: int8 filter + exact refine from 150,000 rows on; the figures above "
+                               "note": "CS_ROUTE_COST: int8 filter + exact refine from 32,768 rows on (k < 48; 300,000 from k = 48); the figures above "
                                        "select CS_ROUTE_STREAM (the HIP scan kernel configs[1] names)"}}
     del st
     return out
@@ -1106,7 +1106,7 @@ def main():
         achieved = alg_bytes / (scan_us * 1e-6) / 1e9
         # the scan is HBM-bound below ~39 queries per pass and fp32-MFMA-bound above
         wants_filter = (args.nq >= int(os.environ.get("CS_FILTER_MIN_Q", "2"))  # one query: --route (default: streaming scan)
-                        or (args.nq == 1 and args.route != "stream" and (args.route == "filter" or args.rows >= 150_000)))
+                        or (args.nq == 1 and args.route != "stream" and (args.route == "filter" or args.rows >= (32_768 if args.k < 48 else 300_000))))
         filter_path = wants_filter and args.dim in (384, 768, 1024) and os.environ.get("CS_INDEX_SPLIT", "1")[0] != "0"
         alg_flops = 2.0 * args.rows * args.nq * args.dim
         int8_path = filter_path and os.environ.get("CS_FILTER_INT8", "1")[0] != "0"
@@ -1231,7 +1231,7 @@ def main():
             line["recall_at_10"] = recall
             line["max_abs_cos_err_vs_cpu"] = err
         if world == 1 and args.nq == 1 and args.route == "stream" and not args.only_scan:
-            # The DEFAULT route of the same search (CS_ROUTE_COST, index.hip run_search): one query over >= 150,000 rows goes
+            # The DEFAULT route of the same search (CS_ROUTE_COST, index.hip run_search): one query over >= 32,768 rows (k < 48; 300,000 from k = 48) goes
             # through the MFMA filter over the int8 copy (a quarter of the f32 bytes) + exact f32 re-score — the shape of the
             # reference's MCP and HTTP searches (src/mcp/mod.rs:252, src/server/mod.rs:547).  Same bits as the streaming scan.
             def timed_single(kk, reps=50):
@@ -1263,7 +1263,7 @@ def main():
             has8, has16, fbytes = shard.store.filter_copies()
             line["default_routing_ms_per_search"] = route[f"k{args.k}"]["default_ms_per_search"]
             line["default_routing"] = {
-                "route": "CS_ROUTE_COST (default): int8 filter + exact f32 refine for one query over >= 150,000 rows",
+                "route": "CS_ROUTE_COST (default): int8 filter + exact f32 refine for one query over >= 32,768 rows at k < 48, >= 300,000 rows from k = 48",
                 "per_k": route,
                 "chunks_per_s": args.rows / (route[f"k{args.k}"]["default_ms_per_search"] * 1e-3),
                 "filter_copy": {2: "int8", 1: "f16", 0: "none"}[copy], "copies_in_hbm": {"int8": has8, "f16": has16},

@@ -290,10 +290,14 @@ struct cs_index {
     // kernel: bench.py selects it for `value`); CS_ROUTE_FILTER takes the filter whenever a copy can serve.
     int single_route = CS_ROUTE_COST;
     uint64_t single_filter_min_rows = 2000000;  // ... with the f16 copy (and k >= single_filter_min_k)
-    // ... with the int8 copy: measured crossover of the two routes at k = 10 / 25 (profiles/r04_route_crossover.log,
-    // us per search, stream / filter): 50k rows 67 / 80, 100k 83 / 81-87, 200k 109 / 90, 400k 158 / 100, 1M 263 / 154,
-    // 2M 473 / 210, 4M 889 / 320 — the filter's fixed rounds cost ~80 us, then it streams a quarter of the bytes
-    uint64_t single_int8_min_rows = 150000;
+    // ... with the int8 copy: the measured crossover of the two routes, which depends on the list length because the
+    // filter's round plan does (scan_filter.hip: growth up to 24 - one round up to 60 x 3,072 rows - below k = 48, 5.5 from
+    // there on).  profiles/r04_route_crossover_by_k.log, us per search, stream / filter: k = 10: 20k rows 54 / 57, 35k 63 / 58,
+    // 100k 83 / 65, 184k 105 / 72; k = 25: 35k 71 / 63, 100k 104 / 86; k = 40: 200k 158 / 102 — k = 50: 150k 97 / 114, 300k 129 / 127,
+    // 400k 150 / 131; k = 75: 300k 141 / 135; k = 99: 300k 142 / 141.  (Round 4's first figure, 150,000 rows for every k, was
+    // taken before the phase plan and the one-round phase 0.)
+    uint64_t single_int8_min_rows = 32768;        // k < 48 (CS_FILTER_SINGLE_MIN_ROWS)
+    uint64_t single_int8_min_rows_long = 300000;  // k >= 48 (CS_FILTER_SINGLE_MIN_ROWS_LONG)
     uint64_t few_queries_min_rows = 50000;  // 2-4 queries: rows from which they take the filter (CS_FILTER_FEW_MIN_ROWS)
     uint64_t single_batched_max_rows = 1024;  // ... and one query over at most this many rows (0 = never; CS_SINGLE_BATCHED_MAX_ROWS)
     // primed streaming scan (scan.hip PRIME mode): from this k and this many rows on, a pass over
@@ -544,7 +548,7 @@ int32_t run_search(cs_index* h, Workspace* w, const ScanPlan& plan, const float*
     const bool single_filter =
         nq == 1 && h->single_route != CS_ROUTE_STREAM &&
         (h->single_route == CS_ROUTE_FILTER ||
-         (q8_serves(h) && h->n_rows >= h->single_int8_min_rows) ||
+         (q8_serves(h) && h->n_rows >= (k < 48 ? h->single_int8_min_rows : h->single_int8_min_rows_long)) ||
          (h->n_rows >= h->single_filter_min_rows && h->single_filter_min_k && k >= h->single_filter_min_k));
     // Two to four queries over a corpus between one phase 0 and ~50,000 rows: the streaming scan (one pass per query
     // tile) is ahead of the filter's fixed rounds (profiles/r04_batched_route_by_size.log, us per search at nq = 2, k = 25,
@@ -774,6 +778,7 @@ int32_t cs_index_create(uint32_t dim, uint64_t capacity_rows, int32_t device, ui
             if (h->single_filter_min_k == 0) h->single_route = CS_ROUTE_STREAM;
         }
         if (const char* e = std::getenv("CS_FILTER_SINGLE_MIN_ROWS")) h->single_int8_min_rows = (uint64_t)std::atoll(e);
+        if (const char* e = std::getenv("CS_FILTER_SINGLE_MIN_ROWS_LONG")) h->single_int8_min_rows_long = (uint64_t)std::atoll(e);
         if (const char* e = std::getenv("CS_FILTER_FEW_MIN_ROWS")) h->few_queries_min_rows = (uint64_t)std::atoll(e);
         if (const char* e = std::getenv("CS_SINGLE_BATCHED_MAX_ROWS")) h->single_batched_max_rows = (uint64_t)std::atoll(e);
         if (const char* e = std::getenv("CS_SCAN_PRIME_MIN_K")) h->prime_min_k = (uint32_t)std::atol(e);  // 0 = off

@@ -267,9 +267,10 @@ int32_t cs_index_set_filter_min_queries(cs_index* h, uint32_t min_queries);
 /* How ONE query is answered over a large index.  The reference's commonest searches are exactly that shape: MCP
  * (src/mcp/mod.rs:252: one query, k = limit * 3) and the HTTP handler (src/server/mod.rs:547: k = 25).  Every route
  * returns the same bits (exact f32 re-score of the filter's candidates; tests/test_gpu_scan.py).
- *   CS_ROUTE_COST   (default) over >= 150,000 rows (CS_FILTER_SINGLE_MIN_ROWS: the measured crossover) the filter +
- *                   refine path whenever the int8 copy serves (it streams 1 byte per element instead of 4: 0.154 vs
- *                   0.263 ms over 1M x 384, 0.66 vs 2.16 ms over 10M at k = 10), and from k = 100 on over >= 2M rows
+ *   CS_ROUTE_COST   (default) over >= 32,768 rows below k = 48 and >= 300,000 rows from there on (CS_FILTER_SINGLE_MIN_ROWS,
+ *                   CS_FILTER_SINGLE_MIN_ROWS_LONG: the measured crossovers) the filter + refine path whenever the int8
+ *                   copy serves (it streams 1 byte per element instead of 4: 0.065 vs 0.083 ms over 100,000 x 384, 0.13
+ *                   vs 0.26 ms over 1M, 0.64 vs 2.16 ms over 10M at k = 10), and from k = 100 on over >= 2M rows
  *                   (CS_FILTER_SINGLE_MIN_K) when only the f16 copy does; else the streaming scan;
  *   CS_ROUTE_STREAM always the f32 streaming scan (scan.hip — the kernel BASELINE.json's roofline target is quoted
  *                   on; bench.py selects it for `value`);  CS_FILTER_SINGLE_MIN_K=0 makes it a handle's default;

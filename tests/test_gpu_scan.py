@@ -458,7 +458,7 @@ def test_config1_1m_single_query_against_oracle(VS, oracle):
             streamed[(kk, i)] = (c1[0].copy(), i1[0].copy())
     assert st.debug_counters() == (0, 0)
     assert st.search_raw(qs[3], 10)[1][0][0] == 999_998
-    # the default route at this size (CS_ROUTE_COST: the int8 filter from 150,000 rows on): same bits, 0.15 vs 0.26 ms
+    # the default route at this size (CS_ROUTE_COST: the int8 filter from 32,768 rows on at k < 48): same bits, 0.13 vs 0.26 ms
     st.set_single_query_route(st.ROUTE_COST)
     for (kk, i), (sc, si) in sorted(streamed.items()):
         c1, i1, n1 = st.search_raw(qs[i], kk)
@@ -693,7 +693,8 @@ def test_persistent_store_round_trip(VS, oracle, tmp_path):
 
 
 def test_single_query_through_filter_is_bit_identical(VS):
-    """One query may take filter + refine — by default (CS_ROUTE_COST) from 150,000 rows on when the int8 copy serves, at
+    """One query may take filter + refine — by default (CS_ROUTE_COST) from 32,768 rows on below k = 48 and from 300,000 rows
+    on above (the measured crossovers, index.hip) when the int8 copy serves, at
     any size with CS_ROUTE_FILTER or cs_index_set_filter_min_queries(1); CS_ROUTE_STREAM pins the streaming scan.  Same
     bits on every route; the debug counters prove which route ran."""
     dim, n, k = 384, 200_000, 10
@@ -709,8 +710,16 @@ def test_single_query_through_filter_is_bit_identical(VS):
         c1, i1, n1 = st.search_raw(q, k)
         assert n1[0] == n0[0] and i1.tolist() == i0.tolist() and c1.tobytes() == c0.tobytes()
     assert st.debug_counters() == (5, 0)
+    for kk, filtered in ((47, 1), (48, 0), (75, 0)):  # a long list over 200,000 rows is still ahead on the streaming scan
+        before = st.debug_counters()[0]
+        c1, i1, n1 = st.search_raw(qs[0], kk)
+        assert st.debug_counters()[0] - before == filtered, kk
+        st.set_single_query_route(st.ROUTE_STREAM)
+        c0, i0, n0 = st.search_raw(qs[0], kk)
+        st.set_single_query_route(st.ROUTE_COST)
+        assert n1[0] == n0[0] and i1.tolist() == i0.tolist() and c1.tobytes() == c0.tobytes()
     small = VS(None, dim)
-    small.insert_synthetic(60_000, 99, 0)         # below the crossover the default route streams ...
+    small.insert_synthetic(20_000, 99, 0)         # below the crossover the default route streams ...
     small.build_index()
     sbase = [small.search_raw(q, k) for q in qs]
     assert small.debug_counters() == (0, 0)
