@@ -298,7 +298,8 @@ struct cs_index {
     // taken before the phase plan and the one-round phase 0.)
     uint64_t single_int8_min_rows = 32768;        // k < 48 (CS_FILTER_SINGLE_MIN_ROWS)
     uint64_t single_int8_min_rows_long = 300000;  // k >= 48 (CS_FILTER_SINGLE_MIN_ROWS_LONG)
-    uint64_t few_queries_min_rows = 50000;  // 2-4 queries: rows from which they take the filter (CS_FILTER_FEW_MIN_ROWS)
+    uint64_t few_queries_min_rows = 40000;        // two queries: rows from which they take the filter (CS_FILTER_FEW_MIN_ROWS) ...
+    uint64_t few_queries_min_rows_short = 16384;  // ... with k <= 16 (both follow CS_FILTER_FEW_MIN_ROWS when it is set)
     uint64_t single_batched_max_rows = 1024;  // ... and one query over at most this many rows (0 = never; CS_SINGLE_BATCHED_MAX_ROWS)
     // primed streaming scan (scan.hip PRIME mode): from this k and this many rows on, a pass over
     // the first prime_rows rows bounds the list inserts of the full scan
@@ -550,11 +551,17 @@ int32_t run_search(cs_index* h, Workspace* w, const ScanPlan& plan, const float*
         (h->single_route == CS_ROUTE_FILTER ||
          (q8_serves(h) && h->n_rows >= (k < 48 ? h->single_int8_min_rows : h->single_int8_min_rows_long)) ||
          (h->n_rows >= h->single_filter_min_rows && h->single_filter_min_k && k >= h->single_filter_min_k));
-    // Two to four queries over a corpus between one phase 0 and ~50,000 rows: the streaming scan (one pass per query
+    // (First measurement, round 4:) two to four queries over a corpus between one phase 0 and ~50,000 rows: the streaming scan (one pass per query
     // tile) is ahead of the filter's fixed rounds (profiles/r04_batched_route_by_size.log, us per search at nq = 2, k = 25,
     // filter / stream: 2,000 rows 37 / 45; 5,000 63 / 45; 20,000 71 / 60; 100,000 97 / 117); from five queries on the filter
     // wins at every size (9 x 200: 41 ... 277 us against 81 ... 600 on the exact-f32 MFMA path).
-    const bool few_small = nq >= 2 && nq <= 4 && h->filter_min_q == 2 && h->n_rows > kFilterPhase0 && h->n_rows < h->few_queries_min_rows;
+    // Re-measured behind the one-round phase 0 and the one-round plan of small corpora (profiles/r04_few_queries_crossover.log,
+    // us per search, stream / filter): FOUR queries are ahead on the filter from 5,000 rows on (k = 10: 5k 63 / 54, 20k 78 / 61,
+    // 50k 119 / 67; k = 25: 5k 64 / 58, 50k 95 / 76) — three share their pass of the streaming scan and their filter rounds,
+    // so they follow; TWO stream up to ~16,000 rows with a short list (k = 10: 10k 47 / 56, 20k 66 / 61) and up to ~40,000
+    // rows above (k = 25: 20k 60 / 65, 35k 66 / 69, 50k 82 / 73).
+    const uint64_t few_min = k <= 16 ? h->few_queries_min_rows_short : h->few_queries_min_rows;
+    const bool few_small = nq == 2 && h->filter_min_q == 2 && h->n_rows > kFilterPhase0 && h->n_rows < few_min;
     const bool wants_filter = ((int)nq >= h->filter_min_q && !few_small) || single_filter ||
                               (nq == 1 && h->n_rows <= h->single_batched_max_rows);
     const bool normed = h->n_rows > 0 && h->normed_rows >= h->n_rows;
@@ -779,7 +786,7 @@ int32_t cs_index_create(uint32_t dim, uint64_t capacity_rows, int32_t device, ui
         }
         if (const char* e = std::getenv("CS_FILTER_SINGLE_MIN_ROWS")) h->single_int8_min_rows = (uint64_t)std::atoll(e);
         if (const char* e = std::getenv("CS_FILTER_SINGLE_MIN_ROWS_LONG")) h->single_int8_min_rows_long = (uint64_t)std::atoll(e);
-        if (const char* e = std::getenv("CS_FILTER_FEW_MIN_ROWS")) h->few_queries_min_rows = (uint64_t)std::atoll(e);
+        if (const char* e = std::getenv("CS_FILTER_FEW_MIN_ROWS")) h->few_queries_min_rows = h->few_queries_min_rows_short = (uint64_t)std::atoll(e);
         if (const char* e = std::getenv("CS_SINGLE_BATCHED_MAX_ROWS")) h->single_batched_max_rows = (uint64_t)std::atoll(e);
         if (const char* e = std::getenv("CS_SCAN_PRIME_MIN_K")) h->prime_min_k = (uint32_t)std::atol(e);  // 0 = off
         if (const char* e = std::getenv("CS_SCAN_PRIME_MIN_ROWS")) h->prime_min_rows = (uint64_t)std::atoll(e);
