@@ -1588,12 +1588,17 @@ static int32_t scan_split_impl(const BatchedState& st, const SplitQueryWs& qw, c
         // exp(z band / sigma) = 3.3 at the 25th best of 175k isotropic rows) into a 4,096-slot buffer — r = 57 overflowed
         // at k = 25 and fell back to the exact scan (profiles/r04_filter_gmax_ab.log); 24, capped by 900 / k, keeps a
         // factor of 4.5 in hand and lets 1M rows take two rounds instead of three (153 -> 138 us at k = 10)
-        // ... except where ONE round reaches the last row: up to four queries with k <= 16 over at most 60 x 3,072 rows expect
-        // ~k r 3.3 <= 3,200 candidates (r <= 60), and should the buffer overflow after all, the exact rerun behind it costs
-        // what a streaming scan of so few rows costs (~100 us), not the 2.2 ms of a 10M-row corpus: 100,000 rows 76 -> 55 us
+        // ... except where ONE round reaches the last row: up to four queries over at most min(60, 970 / k) x 3,072 rows expect
+        // ~k r 3.3 <= 3,200 candidates, and should the buffer overflow after all, the exact rerun behind it costs what a
+        // streaming scan of so few rows costs (~100 us), not the 2.2 ms of a 10M-row corpus: one query over 100,000 rows 77 -> 65 us
+        // at k = 10, 84 -> 74 at k = 20, 86 -> 78 at k = 25.  (Five to ten queries gain 5 % at 100,000 rows and lose 7 % at
+        // 184,000 — their candidates multiply the refine: they keep the capped plan; profiles/r04_filter_one_round_ab.log.)
         static const double g1_env = [] { const char* e = std::getenv("CS_FILTER_G1MAX"); return e ? std::atof(e) : 60.0; }();
-        const bool one_round = nq <= 4 && k <= 16 && (double)n_rows <= g1_env * (double)phase;
-        const double gshort = one_round ? g1_env : std::min(24.0, 900.0 / (double)k);
+        static const uint32_t g1_maxq = [] { const char* e = std::getenv("CS_FILTER_G1_MAXQ"); return e ? (uint32_t)std::atoi(e) : 4u; }();
+        static const double g1_cand = [] { const char* e = std::getenv("CS_FILTER_G1_CAND"); return e ? std::atof(e) : 970.0; }();
+        const double g1 = std::min(g1_env, g1_cand / (double)k);  // 60 up to k = 16, 38.8 at k = 25, no more than the cap of 24 from k = 40
+        const bool one_round = nq <= g1_maxq && g1 > 24.0 && (double)n_rows <= g1 * (double)phase;
+        const double gshort = one_round ? g1 : std::min(24.0, 900.0 / (double)k);
         const double gmax = gmax_env > 1.0 ? gmax_env : (k >= 48 ? 5.5 : gshort), span = (double)n_rows / (double)phase;
         const double nph = std::ceil(std::log(span) / std::log(gmax) - 1e-9);
         ratio = std::pow(span, 1.0 / (nph < 1.0 ? 1.0 : nph));
