@@ -298,7 +298,7 @@ struct cs_index {
     // taken before the phase plan and the one-round phase 0.)
     uint64_t single_int8_min_rows = 32768;        // k < 48 (CS_FILTER_SINGLE_MIN_ROWS)
     uint64_t single_int8_min_rows_long = 300000;  // k >= 48 (CS_FILTER_SINGLE_MIN_ROWS_LONG)
-    uint64_t few_queries_min_rows = 40000;        // two queries: rows from which they take the filter (CS_FILTER_FEW_MIN_ROWS) ...
+    uint64_t few_queries_min_rows = 40000;        // two or three queries: rows from which they take the filter (CS_FILTER_FEW_MIN_ROWS) ...
     uint64_t few_queries_min_rows_short = 16384;  // ... with k <= 16 (both follow CS_FILTER_FEW_MIN_ROWS when it is set)
     uint64_t single_batched_max_rows = 1024;  // ... and one query over at most this many rows (0 = never; CS_SINGLE_BATCHED_MAX_ROWS)
     // primed streaming scan (scan.hip PRIME mode): from this k and this many rows on, a pass over
@@ -557,11 +557,12 @@ int32_t run_search(cs_index* h, Workspace* w, const ScanPlan& plan, const float*
     // wins at every size (9 x 200: 41 ... 277 us against 81 ... 600 on the exact-f32 MFMA path).
     // Re-measured behind the one-round phase 0 and the one-round plan of small corpora (profiles/r04_few_queries_crossover.log,
     // us per search, stream / filter): FOUR queries are ahead on the filter from 5,000 rows on (k = 10: 5k 63 / 54, 20k 78 / 61,
-    // 50k 119 / 67; k = 25: 5k 64 / 58, 50k 95 / 76) — three share their pass of the streaming scan and their filter rounds,
-    // so they follow; TWO stream up to ~16,000 rows with a short list (k = 10: 10k 47 / 56, 20k 66 / 61) and up to ~40,000
-    // rows above (k = 25: 20k 60 / 65, 35k 66 / 69, 50k 82 / 73).
+    // 50k 119 / 67; k = 25: 5k 64 / 58, 50k 95 / 76); TWO stream up to ~16,000 rows with a short list (k = 10: 10k 47 / 56,
+    // 20k 66 / 61) and up to ~40,000 rows above (k = 25: 20k 60 / 65, 35k 66 / 69, 50k 82 / 73), and THREE cost the streaming
+    // scan what two do (one pass: 5k rows 44 / 55, 10k 48 / 57, 20k at k = 25 60 / 66; four take a second pass: 63), so they
+    // follow two.
     const uint64_t few_min = k <= 16 ? h->few_queries_min_rows_short : h->few_queries_min_rows;
-    const bool few_small = nq == 2 && h->filter_min_q == 2 && h->n_rows > kFilterPhase0 && h->n_rows < few_min;
+    const bool few_small = nq >= 2 && nq <= 3 && h->filter_min_q == 2 && h->n_rows > kFilterPhase0 && h->n_rows < few_min;
     const bool wants_filter = ((int)nq >= h->filter_min_q && !few_small) || single_filter ||
                               (nq == 1 && h->n_rows <= h->single_batched_max_rows);
     const bool normed = h->n_rows > 0 && h->normed_rows >= h->n_rows;
