@@ -72,6 +72,9 @@ def parse_args():
     ap.add_argument("--no-rccl-child", action="store_true",
                     help="--gpus N without a launcher: do not run the one-rank-per-GPU RCCL form as child processes first")
     ap.add_argument("--no-config5", action="store_true", help="--gpus N without a launcher: skip the 1,000-query leg")
+    ap.add_argument("--rccl-child-timeout", type=float, default=200.0,
+                    help="--gpus N without a launcher: seconds the RCCL child run may take before its process group is ended "
+                         "(well under the driver's own limit: the one-process line must still be printed)")
     ap.add_argument("--only-scan", action="store_true",
                     help="timed loop only: no CPU baseline, no 1M / filter / encoder / e2e legs, no recall sample")
     a = ap.parse_args()
@@ -740,9 +743,35 @@ def rccl_child_record(args, nproc, force_dist):
            "--gpus", str(nproc), "--steps", str(min(args.steps, 50)), "--warmup", str(min(args.warmup, 10)),
            "--rows", str(args.rows), "--dim", str(args.dim), "--nq", str(args.nq), "--k", str(args.k), "--only-scan"]
     t0 = time.perf_counter()
+    budget = float(args.rccl_child_timeout)
     try:
-        r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
-    except Exception as e:  # a timeout, a missing launcher: recorded, never fatal for the one-process line
+        # own session: a child that hangs in RCCL initialisation is ended as a whole process GROUP (the launcher and every
+        # rank), by the ids this call created — never by name
+        import signal
+
+        p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, cwd=ROOT,
+                             start_new_session=True)
+        try:
+            out_s, err_s = p.communicate(timeout=budget)
+        except subprocess.TimeoutExpired:
+            for sig in (signal.SIGTERM, signal.SIGKILL):
+                try:
+                    os.killpg(p.pid, sig)
+                except ProcessLookupError:
+                    break
+                try:
+                    p.communicate(timeout=10)
+                    break
+                except subprocess.TimeoutExpired:
+                    continue
+            return {"error": f"the RCCL child processes did not finish within {budget:.0f} s and were ended (process group "
+                             f"{p.pid}); the one-process line below does not depend on them",
+                    "wall_s": time.perf_counter() - t0}
+
+        class _R:  # the fields of subprocess.CompletedProcess used below
+            stdout, stderr, returncode = out_s, err_s, p.returncode
+        r = _R
+    except Exception as e:  # a missing launcher: recorded, never fatal for the one-process line
         return {"error": f"{type(e).__name__}: {e}"}
     rec = None
     for ln in reversed(r.stdout.splitlines()):
@@ -774,9 +803,19 @@ def main_one_process(args):
     rehearsal = bool(os.environ.get("CS_BENCH_SHARD_DEVICES"))
     devices = [int(x) for x in os.environ["CS_BENCH_SHARD_DEVICES"].split(",")] if rehearsal else list(range(N))
     rccl = None
+    phases = {}  # wall seconds per phase of this run, carried in the line
+    t_ph = time.perf_counter()
+
+    def phase(name):
+        nonlocal t_ph
+        now = time.perf_counter()
+        phases[name] = round(now - t_ph, 3)
+        t_ph = now
+
     if not args.no_rccl_child:
         distinct = len(set(devices))
         rccl = rccl_child_record(args, distinct, force_dist=(distinct == 1))
+    phase("rccl_child_s")
 
     import numpy as np
     import torch
@@ -790,9 +829,16 @@ def main_one_process(args):
     if len(devices) != N or max(devices) >= ndev:
         raise SystemExit(f"--gpus {N}: only {ndev} HIP device(s) visible")
     dim, rows, nq, k = args.dim, args.rows, args.nq, args.k
+    phase("import_s")
     st = VectorStore(None, dim, devices=devices, rows_per_stripe=rows, capacity=N * rows)
     st.insert_synthetic(N * rows, SEED, 0)
+    for d in sorted(set(devices)):
+        torch.cuda.synchronize(d)
+    phase("fill_s")
     st.build_index()
+    for d in sorted(set(devices)):
+        torch.cuda.synchronize(d)
+    phase("build_s")
     assert st.shard_lens() == [rows] * N
     # `value` is quoted on the f32 streaming scan (the north-star kernel) when a step is one query; the default route of
     # such a search (int8 filter + exact refine, same bits) is timed beside it
@@ -865,33 +911,7 @@ def main_one_process(args):
     exp_cos, exp_ids = host_merge(q_host, nq)
     merged_ok = bool(np.array_equal(got_ids.astype(np.uint64), exp_ids) and got_cos.tobytes() == exp_cos.tobytes())
 
-    # (3) the gather form NOT in use, for the record (opt-in CS_SHARDS_DIRECT): a disagreement is reported below, it does
-    # not fail the default path's line
-    other = "0" if bool(lib.cs_shards_direct_gather(st.handle)) else "1"
-    os.environ["CS_SHARDS_DIRECT"], prev = other, os.environ.get("CS_SHARDS_DIRECT")
-    alt_same, alt_direct, alt_error = None, None, None
-    try:
-        st2 = VectorStore(None, dim, devices=devices, rows_per_stripe=1 << 16, capacity=N << 16)
-        st2.insert_synthetic(N << 16, SEED, 0)
-        st2.build_index()
-        alt_direct = bool(lib.cs_shards_direct_gather(st2.handle))
-        c_alt, i_alt, _ = st2.search_raw(q_host, k)
-        st2.close()
-    except Exception as e:
-        alt_error = f"{type(e).__name__}: {e}"
-    finally:
-        if prev is None:
-            del os.environ["CS_SHARDS_DIRECT"]
-        else:
-            os.environ["CS_SHARDS_DIRECT"] = prev
-    if alt_error is None:
-        st3 = VectorStore(None, dim, devices=devices, rows_per_stripe=1 << 16, capacity=N << 16)
-        st3.insert_synthetic(N << 16, SEED, 0)
-        st3.build_index()
-        c_def, i_def, _ = st3.search_raw(q_host, k)
-        alt_same = bool(np.array_equal(i_alt, i_def) and c_alt.tobytes() == c_def.tobytes())
-        st3.close()
-
+    phase("checks_s")
     for _ in range(args.warmup):
         step()
     sync_all()
@@ -903,6 +923,7 @@ def main_one_process(args):
     _lib.check(lib.cs_index_profile_read(sh0, C.byref(s_ms), C.byref(n_l), C.byref(m_ms), 1))
     _lib.check(lib.cs_index_profile(sh0, 0))
     timed_same = bool(torch.equal(keys, ref_keys))
+    phase("warmup_and_timed_s")
     scan_us = s_ms.value * 1e3 / max(n_l.value, 1)
     alg_bytes = rows * dim * 4
     achieved = alg_bytes / (scan_us * 1e-6) / 1e9 if scan_us else 0.0
@@ -940,12 +961,55 @@ def main_one_process(args):
             "planted_query_per_shard_returns_its_row": planted_ok,
             "merged_topk_equals_host_merge_of_per_shard_searches": merged_ok,
             "timed_searches_equal_the_first": timed_same,
-            "opt_in_gather_mode_agrees": alt_same,
-            "opt_in_gather_mode": "direct" if alt_direct else "copy",
-            "opt_in_gather_mode_error": alt_error,
         },
         "rccl": rccl,
+        "phases_wall_s": phases,
     }
+    failed = []
+    if not all(planted_ok):
+        failed.append("a shard did not return its planted row")
+    if not merged_ok:
+        failed.append("the merged top-k differs from the host merge of the per-shard searches")
+    if not timed_same:
+        failed.append("timed searches disagree with the first one")
+    if failed:
+        line["error"] = "; ".join(failed)
+    # The record is on stdout BEFORE any optional leg runs (the opt-in gather mode, the default route, configs[4]'s
+    # 1,000-query step): a leg that hangs or is ended from outside cannot take the measured line with it.  The complete
+    # line — the same keys plus the legs' — follows as the LAST line when they finish.
+    pending = ["opt_in_gather_mode"] + (["default_routing"] if nq == 1 else []) + ([] if args.no_config5 else ["config_5"])
+    print(json.dumps(dict(line, legs_pending=pending)), flush=True)
+    # the gather form NOT in use, for the record (opt-in CS_SHARDS_DIRECT): a disagreement is reported below, it does
+    # not fail the default path's line
+    other = "0" if bool(lib.cs_shards_direct_gather(st.handle)) else "1"
+    os.environ["CS_SHARDS_DIRECT"], prev = other, os.environ.get("CS_SHARDS_DIRECT")
+    alt_same, alt_direct, alt_error = None, None, None
+    try:
+        st2 = VectorStore(None, dim, devices=devices, rows_per_stripe=1 << 16, capacity=N << 16)
+        st2.insert_synthetic(N << 16, SEED, 0)
+        st2.build_index()
+        alt_direct = bool(lib.cs_shards_direct_gather(st2.handle))
+        c_alt, i_alt, _ = st2.search_raw(q_host, k)
+        st2.close()
+    except Exception as e:
+        alt_error = f"{type(e).__name__}: {e}"
+    finally:
+        if prev is None:
+            del os.environ["CS_SHARDS_DIRECT"]
+        else:
+            os.environ["CS_SHARDS_DIRECT"] = prev
+    if alt_error is None:
+        st3 = VectorStore(None, dim, devices=devices, rows_per_stripe=1 << 16, capacity=N << 16)
+        st3.insert_synthetic(N << 16, SEED, 0)
+        st3.build_index()
+        c_def, i_def, _ = st3.search_raw(q_host, k)
+        alt_same = bool(np.array_equal(i_alt, i_def) and c_alt.tobytes() == c_def.tobytes())
+        st3.close()
+
+    line["multi_gpu_checks"].update({"opt_in_gather_mode_agrees": alt_same,
+                                     "opt_in_gather_mode": "direct" if alt_direct else "copy",
+                                     "opt_in_gather_mode_error": alt_error})
+    phase("opt_in_gather_s")
     # the default route of the same search (CS_ROUTE_COST): one query per shard through the int8 filter + exact refine
     if nq == 1:
         st.set_single_query_route(st.ROUTE_COST)
@@ -958,6 +1022,7 @@ def main_one_process(args):
                                    "note": "cs_index_set_single_query_route(CS_ROUTE_COST): what a caller gets without asking; "
                                            "`value` selects CS_ROUTE_STREAM"}
         st.set_single_query_route(st.ROUTE_STREAM)
+        phase("default_routing_s")
     # BASELINE.json configs[4] as worded: 1,000 batched queries per step over the resident shards (int8 MFMA filter +
     # exact f32 refine per shard, one merge of N lists per query)
     if not args.no_config5:
@@ -989,15 +1054,7 @@ def main_one_process(args):
                          "note": "per GPU, over the whole step (filter phases, re-score, select, gather, merge): the filter "
                                  "kernel alone is reported by the N = 1 line's --nq 1000 run"},
         }
-    failed = []
-    if not all(planted_ok):
-        failed.append("a shard did not return its planted row")
-    if not merged_ok:
-        failed.append("the merged top-k differs from the host merge of the per-shard searches")
-    if not timed_same:
-        failed.append("timed searches disagree with the first one")
-    if failed:
-        line["error"] = "; ".join(failed)
+        phase("config_5_s")
     print(json.dumps(line), flush=True)
     st.close()
     if failed:  # the DEFAULT path only: the opt-in gather mode and the RCCL child are reported, never fatal

@@ -1925,6 +1925,12 @@ int32_t cs_debug_gemm_time(int32_t device, int32_t mode, int32_t epilogue, uint3
         };
         // ablation >= 100: DMA schedule ablation - 100 of the product kernel (gemm_wide.hip gw_dma_slot), any epilogue
         // ablation 192 / 384: that block shape of the product kernel, any epilogue
+        // ablation 3192 / 3384: that block shape with the main loop on the 32 x 32 x 16 MFMA (gemm_wide32.hip); 1192 / 1384:
+        // the 16 x 16 x 32 form whatever CS_GEMM_WIDE_MFMA says
+        if (mode == 2 && (ablation == 3192 || ablation == 3384 || ablation == 1192 || ablation == 1384)) {
+            cs::g_gemm_wide_mfma = ablation >= 3000 ? 32 : 16;
+            ablation %= 1000;
+        }
         cs::g_gemm_wide_shape = (mode == 2 && (ablation == 192 || ablation == 384)) ? ablation : 0;
         cs::g_gemm_wide_ablation = (mode == 2 && epilogue == 4 && ablation < 100) ? ablation : 0;
         for (int i = 0; i < 3; ++i) CS_TRY(once());
@@ -1947,6 +1953,7 @@ int32_t cs_debug_gemm_time(int32_t device, int32_t mode, int32_t epilogue, uint3
     const int32_t st = run();
     cs::g_gemm_wide_ablation = 0;
     cs::g_gemm_wide_shape = 0;
+    cs::g_gemm_wide_mfma = 0;
     (void)hipDeviceSynchronize();
     for (void* p : {(void*)dA, (void*)dW, (void*)dB, (void*)dR, (void*)dC, (void*)sA, (void*)sW, (void*)sC, (void*)dF})
         if (p) (void)hipFree(p);

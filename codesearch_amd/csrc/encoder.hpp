@@ -92,6 +92,7 @@ int32_t launch_swiglu_split(const _Float16* up2, _Float16* out, uint32_t T, uint
 int32_t launch_swiglu_f32(float* value, const float* gate, uint32_t T, uint32_t I, hipStream_t s);
 extern int g_gemm_wide_ablation;  // diagnostics (cs_debug_gemm_time)
 extern int g_gemm_wide_shape;      // diagnostics: block shape override (192 | 384), 0 = default
+extern int g_gemm_wide_mfma;       // diagnostics: MFMA shape of the wide kernel's main loop (16 | 32), 0 = default
 double gemm_wide_read_clock_ghz(double* main_cycles, double* epi_cycles);  // after an ablation-7 launch: median in-kernel clock
 int32_t sh_weights_fit_wide(const _Float16* d_wsplit, uint64_t n_f16, uint32_t* d_scratch_flag, bool* ok, hipStream_t s);
 int32_t launch_synth_params(float* d_out, const cs_bert_config& cfg, uint64_t seed, hipStream_t s);

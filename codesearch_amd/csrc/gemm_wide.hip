@@ -32,37 +32,10 @@
 #include <algorithm>
 #include <type_traits>
 #include <vector>
-#include "split_f16.hpp"
+#include "gemm_wide.hpp"
 
 namespace cs {
 
-
-
-constexpr int GW_BM = 128, GW_BN = 384;
-constexpr int GW_A_BYTES = GW_BM * 128;            // one k-chunk (32 k, hi + lo) of 128 A rows
-constexpr int GW_PARAM_FLOATS = 4096;                // bias of up to 4,096 columns (LayerNorm: bias | gamma | beta of 384)
-constexpr int GW_STATS = 5 * GW_BM * 4;            // LayerNorm epilogue: [4 column groups][128 rows] f32 partial sums + [128] row statistic
-// Two block shapes share the kernel: WCN = 4 column waves -> 8 waves, 128 x 384 outputs, one block per CU (whole rows
-// at N = 384: the LayerNorm epilogue); WCN = 2 -> 4 waves, 128 x 192 outputs, 80 KiB of LDS, TWO blocks per CU, so
-// one block's epilogue (VALU conversions + stores) runs under the other's MFMAs.
-template <int WCN>
-struct GwGeom {
-    static constexpr int BN = 96 * WCN;
-    static constexpr int WAVES = 2 * WCN;
-    static constexpr int THREADS = 64 * WAVES;
-    static constexpr int W_BYTES = BN * 128;
-    static constexpr int STAGE = GW_A_BYTES + W_BYTES;           // 65,536 | 40,960
-    // WCN == 4 keeps the layer's bias (and the LayerNorm's gamma / beta) in LDS for the block's lifetime: the epilogue then
-    // issues no global LOAD, so nothing in it waits on vmcnt (which retires in issue order: a load issued behind the
-    // previous strip's stores, or behind the next tile's first DMAs, waits for all of them)
-    static constexpr int PARAMS = WCN == 4 ? GW_PARAM_FLOATS * 4 : 0;
-    static constexpr int LDS = 2 * STAGE + (WCN == 4 ? GW_STATS : 0) + PARAMS;
-    static constexpr int A_PIECES = 16 / WAVES;                  // LDS-DMA pieces (8 rows x 128 B) of A per wave and stage: 2 | 4
-    static constexpr int W_PIECES = (BN / 8) / WAVES;            // ... of W: 6
-    static constexpr int PIECES = A_PIECES + W_PIECES;           // 8 | 10
-};
-constexpr uint32_t GW_LN_RESID_SPLIT = 1u, GW_LN_NO_F32 = 2u;  // ln_flags of the LayerNorm epilogue (launch_gemm_wide_ln)
-constexpr int GW_OUT_LN = 16;  // epilogue: + bias + residual, LayerNorm over the 384 columns, store f32 AND split form
 // GW_OUT_SWIGLU (encoder.hpp): the gated up projection of a NomicBert feed-forward.  W's rows (and the bias) are value and gate
 // rows interleaved in groups of 16 — raw columns 32 u .. 32 u + 15 are fc11's rows 16 u .. 16 u + 15, the next sixteen
 // fc12's — so a wave's six 16-column MFMA tiles are value, gate, value, gate, value, gate of the SAME 48 gated columns and a
@@ -72,35 +45,7 @@ constexpr int GW_OUT_LN = 16;  // epilogue: + bias + residual, LayerNorm over th
 
 namespace {
 
-__device__ __forceinline__ float gw_erf_fast(float x) {  // gemm_split.hip sh_erf_fast
-    const float t = fminf(fabsf(x), 4.0f);
-    float q = 7.569788067485206e-07f;
-    q = fmaf(q, t, -1.6365151168429293e-05f);
-    q = fmaf(q, t, 0.00015192339196801186f);
-    q = fmaf(q, t, -0.0007679605041630566f);
-    q = fmaf(q, t, 0.002005203627049923f);
-    q = fmaf(q, t, 0.0003252939786761999f);
-    q = fmaf(q, t, -0.028044508770108223f);
-    q = fmaf(q, t, 0.1484302133321762f);
-    q = fmaf(q, t, 0.9184240698814392f);
-    q = fmaf(q, t, 1.6279078722000122f);
-    const float e = 1.0f - __builtin_amdgcn_exp2f(-(q * t));
-    return __builtin_copysignf(e, x);
-}
-__device__ __forceinline__ float gw_gelu(float v) { return 0.5f * v * (1.0f + gw_erf_fast(v * 0.70710678118654752440f)); }
-// v * sigmoid(v): hardware exp2 and reciprocal (~1 ulp each)
-__device__ __forceinline__ float gw_silu(float v) {
-    return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v * -1.44269504088896340736f));
-}
-
 struct GwAcc { sh_f32x4v c[4][6]; };
-
-// this wave's eight LDS-DMA pieces of a stage: p = 0, 1 -> A rows, p = 2..7 -> W rows
-template <int WCN>
-struct GwSrc {  // element offsets from A / W (32 bits: a [65536, 1536] operand is 2^27.6 elements)
-    uint32_t a[GwGeom<WCN>::A_PIECES];
-    uint32_t w[GwGeom<WCN>::W_PIECES];
-};
 
 }  // namespace
 
@@ -571,6 +516,7 @@ bool gemm_wide_supported(uint32_t N, uint32_t K) { return N % 192 == 0 && K % 32
 
 int g_gemm_wide_ablation = 0;  // diagnostics only (cs_debug_gemm_time)
 int g_gemm_wide_shape = 0;     // diagnostics only: 192 / 384 overrides CS_GEMM_WIDE_SHAPE
+int g_gemm_wide_mfma = 0;      // diagnostics only: 16 / 32 overrides CS_GEMM_WIDE_MFMA
 
 template <int WCN>
 static int32_t gemm_wide_launch(int epi, const _Float16* A, const _Float16* W, const float* bias, const float* resid, float* C,
@@ -664,6 +610,11 @@ static int32_t gemm_wide_impl(int epi, const _Float16* A, const _Float16* W, con
     // r04_gemm_stagger_by_cu_ab.log code 1000, r04_gemm_role_split_ab.log)
     const int want = shape ? shape : g_gemm_wide_shape ? g_gemm_wide_shape : shape_env ? shape_env : (epi == SH_OUT_SPLIT ? 192 : 384);
     const bool big = epi == GW_OUT_LN || g_gemm_wide_ablation || (want == 384 && N % 384 == 0 && N <= (uint32_t)GW_PARAM_FLOATS);
+    // MFMA shape of the main loop: 16 x 16 x 32 (this file) | 32 x 32 x 16 (gemm_wide32.hip; CS_GEMM_WIDE_MFMA=32)
+    static const int mfma_env = [] { const char* e = std::getenv("CS_GEMM_WIDE_MFMA"); return e ? std::atoi(e) : 0; }();
+    const int mfma = g_gemm_wide_mfma ? g_gemm_wide_mfma : mfma_env;
+    if (mfma == 32 && !g_gemm_wide_ablation && epi != GW_OUT_SWIGLU)
+        return gemm_wide32_launch(big ? 4 : 2, epi, A, W, bias, resid, C, Cs, M, N, K, d_flag, s, ln_g, ln_b, ln_eps, ln_flags);
     if (big) return gemm_wide_launch<4>(epi, A, W, bias, resid, C, Cs, M, N, K, d_flag, s, ln_g, ln_b, ln_eps, ln_flags);
     return gemm_wide_launch<2>(epi, A, W, bias, resid, C, Cs, M, N, K, d_flag, s, ln_g, ln_b, ln_eps, ln_flags);
 }
@@ -685,7 +636,7 @@ int32_t launch_gemm_wide_ln(const _Float16* A, const _Float16* W, const float* b
     if (!resid && !resid_split) return fail(CS_ERR_BAD_ARG, "the LayerNorm epilogue needs a residual");
     const uint32_t flags = (resid_split ? GW_LN_RESID_SPLIT : 0u) | (X ? 0u : GW_LN_NO_F32);
     const float* r = resid_split ? reinterpret_cast<const float*>(resid_split) : resid;
-    return gemm_wide_impl(GW_OUT_LN, A, W, bias, r, X, Xs, M, GW_BN, K, d_flag, s, gamma, beta, eps, 0, flags);
+    return gemm_wide_impl(GW_OUT_LN, A, W, bias, r, X, Xs, M, 384, K, d_flag, s, gamma, beta, eps, 0, flags);
 }
 
 }  // namespace cs
