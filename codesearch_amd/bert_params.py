@@ -154,8 +154,12 @@ def nomic_config_from_hf(cfg_json: dict, max_length: int = 512) -> BertConfig:
     for key, val in want.items():
         if key in cfg_json and cfg_json[key] != val:
             raise ValueError(f"nomic_bert with {key} = {cfg_json[key]!r} is not built (only {val!r})")
-    if cfg_json.get("rotary_scaling_factor") not in (None, 1, 1.0):
-        raise ValueError("nomic_bert with a rotary scaling factor is not built")
+    # dynamic-NTK scaling changes the rotary base only beyond max_trained_positions (2,048 by default): with the sequence
+    # bound below that the table is the unscaled one whatever the factor (checkpoint.cpp nomic branch)
+    factor = cfg_json.get("rotary_scaling_factor")
+    trained = cfg_json.get("max_trained_positions") or 2048
+    if factor not in (None, 1, 1.0) and min(max_length, cfg_json.get("n_positions", max_length)) > trained:
+        raise ValueError("nomic_bert with a rotary scaling factor that applies at this length is not built")
     for key in ("vocab_size", "n_embd", "n_layer", "n_head"):
         if key not in cfg_json:
             raise ValueError(f"nomic_bert config.json lacks {key}")

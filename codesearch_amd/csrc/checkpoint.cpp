@@ -312,7 +312,7 @@ int32_t cs_bert_config_from_dir(const char* model_dir, int32_t pooling, cs_bert_
             if (!is("rotary_emb_fraction", [](const Json& j) { return j.kind == Json::Num && j.num == 1.0; }) ||
                 !is("rotary_emb_interleaved", [](const Json& j) { return j.kind == Json::Bool && !j.b; }) ||
                 !is("rotary_emb_scale_base", [](const Json& j) { return j.kind == Json::Null; }) ||
-                !is("rotary_scaling_factor", [](const Json& j) { return j.kind == Json::Null || (j.kind == Json::Num && j.num == 1.0); }) ||
+                !is("rotary_scaling_factor", [](const Json& j) { return j.kind == Json::Null || (j.kind == Json::Num && j.num >= 1.0); }) ||
                 !is("activation_function", [](const Json& j) { return j.kind == Json::Str && j.str == "swiglu"; }) ||
                 !is("prenorm", [](const Json& j) { return j.kind == Json::Bool && !j.b; }))
                 return fail(CS_ERR_UNSUPPORTED, "Failed to initialize embedding model: this nomic_bert configuration is not built "
@@ -325,6 +325,18 @@ int32_t cs_bert_config_from_dir(const char* model_dir, int32_t pooling, cs_bert_
             // no position table to size: the bound is what fastembed's default InitOptions truncate to (embedder.rs:238)
             uint32_t npos = 0;
             c.max_position = (json_u32(root, "n_positions", npos) && npos && npos < 512) ? npos : 512;
+            // rotary_scaling_factor (dynamic NTK): the factor changes the rotary base only for sequences LONGER than
+            // max_trained_positions (2,048 by default); this loader never runs more than 512 positions, so the table is the
+            // unscaled one whatever the factor says (the 8k-context checkpoints carry a factor of 2) — refused
+            // only where the scaling would actually apply
+            {
+                uint32_t trained = 0;
+                if (!json_u32(root, "max_trained_positions", trained) || trained == 0) trained = 2048;
+                const Json* rf = root.get("rotary_scaling_factor");
+                if (rf && rf->kind == Json::Num && rf->num != 1.0 && c.max_position > trained)
+                    return fail(CS_ERR_UNSUPPORTED, "Failed to initialize embedding model: this nomic_bert configuration is not built "
+                                "(rotary scaling factor %g applies from %u positions on, %u are run)", rf->num, trained, c.max_position);
+            }
             if (!json_u32(root, "type_vocab_size", c.type_vocab_size)) c.type_vocab_size = 2;
             const Json* eps = root.get("layer_norm_epsilon");
             c.layer_norm_eps = (eps && eps->kind == Json::Num) ? (float)eps->num : 1e-12f;

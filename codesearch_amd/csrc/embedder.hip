@@ -1336,7 +1336,10 @@ static int32_t create_impl(const cs_bert_config* cfg, const float* params, uint6
         if (s == CS_OK) {
             h->quantized = true;
             const char* env = std::getenv("CS_ENCODER_QUANT");  // "0": the f32 graph of the quantised weights
-            if (!h->split_unavailable && !(env && env[0] == '0')) h->gemm_mode = CS_GEMM_Q8_DYNAMIC;
+            // an explicit CS_ENCODER_GEMM is honoured for quantised models too: "f32" / "split" select the f32
+            // graph of the dequantised weights on that arithmetic, exactly as CS_ENCODER_QUANT=0 does
+            const bool explicit_gemm = std::getenv("CS_ENCODER_GEMM") != nullptr;
+            if (!h->split_unavailable && !explicit_gemm && !(env && env[0] == '0')) h->gemm_mode = CS_GEMM_Q8_DYNAMIC;
         }
     }
     if (s == CS_OK && hipStreamSynchronize(h->stream) != hipSuccess) s = fail(CS_ERR_HIP, "parameter setup failed");

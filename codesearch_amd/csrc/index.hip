@@ -345,88 +345,116 @@ int32_t drain_appends(cs_index* h) {
     return CS_OK;
 }
 
+// New buffers of a grow(), freed on every path that does not commit them (a failing copy between the
+// allocations and the pointer swap used to return with nc / nd / nn / n8 / nm still allocated).
+struct GrowBuffers {
+    float* nc = nullptr;      // corpus
+    uint32_t* nd = nullptr;   // tombstone bitmap
+    float* nn = nullptr;      // row norms
+    _Float16* ns = nullptr;   // f16 filter copy
+    int8_t* n8 = nullptr;     // int8 filter copy
+    float4* nm = nullptr;     // its tile metadata
+    ~GrowBuffers() {
+        for (void* p : {(void*)nc, (void*)nd, (void*)nn, (void*)ns, (void*)n8, (void*)nm})
+            if (p) (void)hipFree(p);
+    }
+};
+
+// CS_FAULT_GROW_COPY=<stage> (tests): the copy of that stage reports a failure — 1 f16 copy, 2 int8 copy, 3 bitmap clear,
+// 4 norms, 5 corpus, 6 bitmap upload
+static bool grow_fault(int stage, const cs_index* h) {
+    const char* e = std::getenv("CS_FAULT_GROW_COPY");  // (read per call: a grow is rare, and tests set it mid-process)
+    return e && std::atoi(e) == stage && h->capacity != 0;
+}
+#define CS_GROW_COPY(stage, call)                                                                            \
+    do {                                                                                                     \
+        const hipError_t _e = grow_fault(stage, h) ? hipErrorUnknown : (call);                               \
+        if (_e != hipSuccess)                                                                                \
+            return fail(CS_ERR_HIP, "growing the index: copy stage %d failed: %s", stage, hipGetErrorString(_e)); \
+    } while (0)
+
+// Transactional: every new buffer is allocated and filled first; the handle's pointers are swapped (and the old buffers
+// freed) only after the last copy succeeded.  A failure leaves the index exactly as it was and frees what was allocated.
+// Two degradations are not failures: without room for a larger f16 / int8 filter copy that copy is dropped (searches
+// rebuild the f16 copy on demand or stay on the exact paths).
 int32_t grow(cs_index* h, uint64_t need_rows) {
     if (need_rows <= h->capacity) return CS_OK;
     // drain the device before the old buffers are copied and freed, or rows of an unfinished append would be lost
     if (h->n_rows) CS_TRY(drain_appends(h));
     uint64_t cap = h->capacity ? h->capacity * 2 : 1024;
     if (cap < need_rows) cap = need_rows;
-    float* nc = nullptr;
-    uint32_t* nd = nullptr;
+    GrowBuffers nb;
     const size_t words = (size_t)((cap + 31) / 32);
-    CS_HIP(hipMalloc(&nc, (size_t)cap * h->dim * sizeof(float)));
-    hipError_t e = hipMalloc(&nd, words * sizeof(uint32_t));
-    if (e != hipSuccess) {
-        (void)hipFree(nc);
-        return fail(CS_ERR_OOM, "hipMalloc(dead bitmap) failed: %s", hipGetErrorString(e));
-    }
-    float* nn = nullptr;
-    e = hipMalloc(&nn, (size_t)cap * sizeof(float));
-    if (e != hipSuccess) {
-        (void)hipFree(nc);
-        (void)hipFree(nd);
-        return fail(CS_ERR_OOM, "hipMalloc(row norms) failed: %s", hipGetErrorString(e));
-    }
+    hipError_t e = hipMalloc(&nb.nc, (size_t)cap * h->dim * sizeof(float));
+    if (e != hipSuccess) return fail(CS_ERR_OOM, "hipMalloc(corpus, %llu rows) failed: %s", (unsigned long long)cap, hipGetErrorString(e));
+    e = hipMalloc(&nb.nd, words * sizeof(uint32_t));
+    if (e != hipSuccess) return fail(CS_ERR_OOM, "hipMalloc(dead bitmap) failed: %s", hipGetErrorString(e));
+    e = hipMalloc(&nb.nn, (size_t)cap * sizeof(float));
+    if (e != hipSuccess) return fail(CS_ERR_OOM, "hipMalloc(row norms) failed: %s", hipGetErrorString(e));
+    bool drop_split = false, drop_q8 = false;
+    size_t cap256 = 0;
     if (h->d_split) {
         // the f16 copy exists (the int8 copy does not serve): it grows with the corpus.  Without room for it, it is
         // dropped — searches then build it again on demand or stay on the exact paths; the int8 copy below does not
         // depend on it (whole 128-row tiles, an even number of them: 256-row blocks)
-        _Float16* ns = nullptr;
-        const size_t cap256 = ((size_t)cap + 255) / 256 * 256;
-        if (hipMalloc(&ns, cap256 * h->dim * sizeof(_Float16)) != hipSuccess) {
+        cap256 = ((size_t)cap + 255) / 256 * 256;
+        if (hipMalloc(&nb.ns, cap256 * h->dim * sizeof(_Float16)) != hipSuccess) {
             (void)hipGetLastError();
-            (void)hipFree(h->d_split);
-            h->d_split = nullptr;
-            h->split_rows = 0;
-            h->split_cap = 0;
-        } else {
-            if (h->split_rows)
-                CS_HIP(hipMemcpy(ns, h->d_split, ((size_t)h->split_rows + 127) / 128 * 128 * h->dim * sizeof(_Float16),
-                                 hipMemcpyDeviceToDevice));
-            (void)hipFree(h->d_split);
-            h->d_split = ns;
-            h->split_cap = cap256;
+            nb.ns = nullptr;
+            drop_split = true;
+        } else if (h->split_rows) {
+            CS_GROW_COPY(1, hipMemcpy(nb.ns, h->d_split, ((size_t)h->split_rows + 127) / 128 * 128 * h->dim * sizeof(_Float16),
+                                      hipMemcpyDeviceToDevice));
         }
     }
     if (h->use_q8) {
-        int8_t* n8 = nullptr;
-        float4* nm = nullptr;
         const size_t tiles = ((size_t)cap + 255) / 256 * 2;  // an even number: the 256-row tile kernel reads whole pairs
         const bool fault = std::getenv("CS_FAULT_INT8_ALLOC") != nullptr && h->capacity != 0;  // tests: the failure path
-        if (fault || hipMalloc(&n8, tiles * 128 * h->dim) != hipSuccess || hipMalloc(&nm, tiles * sizeof(float4)) != hipSuccess) {
+        if (fault || hipMalloc(&nb.n8, tiles * 128 * h->dim) != hipSuccess || hipMalloc(&nb.nm, tiles * sizeof(float4)) != hipSuccess) {
             (void)hipGetLastError();  // no room: no int8 copy from here on (the f16 copy, or the exact paths, serve)
-            if (n8) (void)hipFree(n8);
-            n8 = nullptr; nm = nullptr;
-            h->use_q8 = false;
-            h->q8_rows = 0;
+            if (nb.n8) (void)hipFree(nb.n8);
+            nb.n8 = nullptr; nb.nm = nullptr;
+            drop_q8 = true;
         } else if (h->q8_rows) {
-            CS_HIP(hipMemcpy(n8, h->d_q8, (size_t)h->q8_rows * h->dim, hipMemcpyDeviceToDevice));
-            CS_HIP(hipMemcpy(nm, h->d_tmeta, (size_t)(h->q8_rows / 128) * sizeof(float4), hipMemcpyDeviceToDevice));
+            CS_GROW_COPY(2, hipMemcpy(nb.n8, h->d_q8, (size_t)h->q8_rows * h->dim, hipMemcpyDeviceToDevice));
+            CS_GROW_COPY(2, hipMemcpy(nb.nm, h->d_tmeta, (size_t)(h->q8_rows / 128) * sizeof(float4), hipMemcpyDeviceToDevice));
         }
+    }
+    CS_GROW_COPY(3, hipMemset(nb.nd, 0, words * sizeof(uint32_t)));
+    if (h->normed_rows)
+        CS_GROW_COPY(4, hipMemcpy(nb.nn, h->d_norms, (size_t)h->normed_rows * sizeof(float), hipMemcpyDeviceToDevice));
+    if (h->n_rows) {
+        CS_GROW_COPY(5, hipMemcpy(nb.nc, h->d_corpus, (size_t)h->n_rows * h->dim * sizeof(float), hipMemcpyDeviceToDevice));
+        CS_GROW_COPY(6, hipMemcpy(nb.nd, h->h_dead.data(), h->h_dead.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    }
+    // ---- commit: nothing below can fail ----
+    if (h->d_split) {
+        (void)hipFree(h->d_split);
+        h->d_split = nb.ns;
+        nb.ns = nullptr;
+        if (drop_split) { h->split_rows = 0; h->split_cap = 0; }
+        else h->split_cap = cap256;
+    }
+    if (h->use_q8) {
         // the old, smaller buffers never survive a grow: a build that found them would convert tiles past their end
         if (h->d_q8) (void)hipFree(h->d_q8);
         if (h->d_tmeta) (void)hipFree(h->d_tmeta);
-        h->d_q8 = n8;
-        h->d_tmeta = nm;
+        h->d_q8 = nb.n8;
+        h->d_tmeta = nb.nm;
+        nb.n8 = nullptr; nb.nm = nullptr;
+        if (drop_q8) { h->use_q8 = false; h->q8_rows = 0; }
     }
-    CS_HIP(hipMemset(nd, 0, words * sizeof(uint32_t)));
-    if (h->normed_rows)
-        CS_HIP(hipMemcpy(nn, h->d_norms, (size_t)h->normed_rows * sizeof(float), hipMemcpyDeviceToDevice));
     if (h->d_norms) (void)hipFree(h->d_norms);
-    h->d_norms = nn;
-    if (h->n_rows) {
-        CS_HIP(hipMemcpy(nc, h->d_corpus, (size_t)h->n_rows * h->dim * sizeof(float),
-                         hipMemcpyDeviceToDevice));
-        CS_HIP(hipMemcpy(nd, h->h_dead.data(), h->h_dead.size() * sizeof(uint32_t),
-                         hipMemcpyHostToDevice));
-    }
+    h->d_norms = nb.nn;
     if (h->d_corpus) (void)hipFree(h->d_corpus);
     if (h->d_dead) (void)hipFree(h->d_dead);
-    h->d_corpus = nc;
-    h->d_dead = nd;
+    h->d_corpus = nb.nc;
+    h->d_dead = nb.nd;
+    nb.nn = nullptr; nb.nc = nullptr; nb.nd = nullptr;
     h->capacity = cap;
     return CS_OK;
 }
+#undef CS_GROW_COPY
 
 // the int8 copy is the filter's operand: it exists, was not retired, and reaches past phase 0's rows
 bool q8_serves(const cs_index* h) {

@@ -79,6 +79,37 @@ std::string sanitize(const char* s, size_t n) {
     return out;
 }
 
+// true when the bytes are well-formed UTF-8 (what sanitize would leave unchanged)
+bool valid_utf8(const char* s, size_t n) {
+    const unsigned char* u = reinterpret_cast<const unsigned char*>(s);
+    size_t i = 0;
+    while (i < n) {
+        const unsigned char b = u[i];
+        size_t len = 0;
+        if (b < 0x80) len = 1;
+        else if (b >= 0xC2 && b <= 0xDF) len = 2;
+        else if (b >= 0xE0 && b <= 0xEF) len = 3;
+        else if (b >= 0xF0 && b <= 0xF4) len = 4;
+        if (len == 0 || i + len > n) return false;
+        for (size_t k = 1; k < len; ++k)
+            if ((u[i + k] & 0xC0) != 0x80) return false;
+        if (len == 3) {
+            const uint32_t cp = u8_cp(s + i, 3);
+            if (cp < 0x800 || (cp >= 0xD800 && cp <= 0xDFFF)) return false;
+        }
+        if (len == 4) {
+            const uint32_t cp = u8_cp(s + i, 4);
+            if (cp < 0x10000 || cp > 0x10FFFF) return false;
+        }
+        i += len;
+    }
+    return true;
+}
+bool valid_utf8(const std::string& s) { return valid_utf8(s.data(), s.size()); }
+// length of the character at s[i], never past the end of the string (the strings below are valid UTF-8 by construction —
+// sanitize() for the text, UnigramEngine::create for everything a tokenizer.json can splice into it — this is the belt)
+inline size_t u8_len_at(const std::string& s, size_t i) { return std::min(u8_len((unsigned char)s[i]), s.size() - i); }
+
 enum Gcb { G_OTHER, G_CONTROL, G_EXTEND, G_SPACING, G_PREPEND };
 Gcb gcb(uint32_t cp) {
     if (cp < 0x300) {  // the fast path of ordinary text: only controls below U+0300 (plus U+00AD, in the table)
@@ -101,6 +132,21 @@ int32_t UnigramEngine::create(UnigramSpec&& spec, std::shared_ptr<UnigramEngine>
     for (int32_t id : {spec.bos, spec.eos, spec.pad})
         if (id < 0 || (size_t)id >= spec.vocab.size())
             return fail(CS_ERR_BAD_ARG, "Failed to initialize embedding model: <s> / </s> / <pad> missing from the unigram vocabulary");
+    // Everything the file can splice INTO a text after sanitize() has run must itself be well-formed UTF-8: the pipeline
+    // below walks strings character by character and trusts their lead bytes (a Replace content of one byte
+    // 0xE2 made Strip run past the end of the string on a tokenizer worker thread).
+    for (const auto& nz : spec.norms)
+        if (!valid_utf8(nz.content) || !valid_utf8(nz.pattern))
+            return fail(CS_ERR_BAD_ARG, "Failed to initialize embedding model: a Replace normalizer's pattern or content is not valid UTF-8");
+    for (const auto& pre : spec.pres)
+        if (!valid_utf8(pre.replacement))
+            return fail(CS_ERR_BAD_ARG, "Failed to initialize embedding model: the Metaspace replacement is not valid UTF-8");
+    for (size_t i = 0; i < spec.vocab.size(); ++i)
+        if (!valid_utf8(spec.vocab[i].first))
+            return fail(CS_ERR_BAD_ARG, "Failed to initialize embedding model: unigram piece %zu is not valid UTF-8", i);
+    for (const auto& a : spec.added)
+        if (!valid_utf8(a.text))
+            return fail(CS_ERR_BAD_ARG, "Failed to initialize embedding model: added token %d is not valid UTF-8", a.id);
     auto eng = std::make_shared<UnigramEngine>();
     eng->spec_ = std::move(spec);
     double mn = std::numeric_limits<double>::infinity();
@@ -119,6 +165,16 @@ int32_t UnigramEngine::create(UnigramSpec&& spec, std::shared_ptr<UnigramEngine>
             m.trie.resize(tsize / 4);
             if (tsize) std::memcpy(m.trie.data(), b.data() + 4, tsize);
             m.normalized.assign(b.data() + 4 + tsize, b.size() - 4 - tsize);
+            // every NUL-terminated replacement of the pool (transform() hands out [idx, next NUL) for an idx the trie
+            // chooses: a replacement that starts inside a character is caught by checking every suffix start the trie
+            // can name, i.e. the whole pool piecewise AND, at lookup time, the piece handed out)
+            for (size_t lo = 0; lo < m.normalized.size();) {
+                size_t hi = lo;
+                while (hi < m.normalized.size() && m.normalized[hi] != '\0') ++hi;
+                if (!valid_utf8(m.normalized.data() + lo, hi - lo))
+                    return fail(CS_ERR_BAD_ARG, "Failed to initialize embedding model: precompiled_charsmap holds a replacement that is not valid UTF-8");
+                lo = hi + 1;
+            }
         }
         eng->maps_.push_back(std::move(m));
     }
@@ -198,6 +254,7 @@ bool UnigramEngine::transform(const Charsmap& m, const char* chunk, size_t n, co
             if (idx > m.normalized.size()) return false;
             size_t end = idx;
             while (end < m.normalized.size() && m.normalized[end] != '\0') ++end;
+            if (!valid_utf8(m.normalized.data() + idx, end - idx)) return false;  // an index into the middle of a character
             *out = m.normalized.data() + idx;
             *out_n = end - idx;
             return true;
@@ -221,7 +278,7 @@ void UnigramEngine::normalize(std::string& s) const {
                     // one grapheme cluster [i, j).  Only clusters under six bytes are looked up whole, and the walk below is
                     // character by character otherwise, so the rules that only ever build longer clusters (Hangul
                     // sequences, regional-indicator pairs, emoji ZWJ sequences, Indic conjuncts) do not change the result
-                    size_t len = u8_len((unsigned char)s[i]);
+                    size_t len = u8_len_at(s, i);
                     uint32_t cp = u8_cp(s.data() + i, len);
                     size_t j = i + len;
                     Gcb g = gcb(cp);
@@ -229,7 +286,7 @@ void UnigramEngine::normalize(std::string& s) const {
                         j += 1;
                     } else if (g != G_CONTROL) {
                         while (g == G_PREPEND && j < n) {  // GB9b: Prepend x (anything but a control)
-                            const size_t l2 = u8_len((unsigned char)s[j]);
+                            const size_t l2 = u8_len_at(s, j);
                             const uint32_t c2 = u8_cp(s.data() + j, l2);
                             const Gcb g2 = gcb(c2);
                             if (g2 == G_CONTROL) break;
@@ -237,7 +294,7 @@ void UnigramEngine::normalize(std::string& s) const {
                             g = g2;
                         }
                         while (j < n) {  // GB9 / GB9a: x (Extend | ZWJ | SpacingMark)
-                            const size_t l2 = u8_len((unsigned char)s[j]);
+                            const size_t l2 = u8_len_at(s, j);
                             const Gcb g2 = gcb(u8_cp(s.data() + j, l2));
                             if (g2 != G_EXTEND && g2 != G_SPACING) break;
                             j += l2;
@@ -249,7 +306,7 @@ void UnigramEngine::normalize(std::string& s) const {
                         out.append(rep, rep_n);
                     } else {
                         for (size_t k = i; k < j;) {
-                            const size_t l2 = u8_len((unsigned char)s[k]);
+                            const size_t l2 = std::min(u8_len((unsigned char)s[k]), j - k);
                             if (transform(m, s.data() + k, l2, &rep, &rep_n)) out.append(rep, rep_n);
                             else out.append(s.data() + k, l2);
                             k += l2;
@@ -295,7 +352,7 @@ void UnigramEngine::normalize(std::string& s) const {
                 size_t lo = 0, hi = s.size();
                 if (nz.left)
                     while (lo < hi) {
-                        const size_t l = u8_len((unsigned char)s[lo]);
+                        const size_t l = std::min(u8_len((unsigned char)s[lo]), hi - lo);
                         if (!is_space(u8_cp(s.data() + lo, l))) break;
                         lo += l;
                     }
@@ -303,10 +360,10 @@ void UnigramEngine::normalize(std::string& s) const {
                     while (hi > lo) {
                         size_t k = hi - 1;
                         while (k > lo && ((unsigned char)s[k] & 0xC0) == 0x80) --k;
-                        if (!is_space(u8_cp(s.data() + k, hi - k))) break;
+                        if (hi - k > 4 || !is_space(u8_cp(s.data() + k, hi - k))) break;
                         hi = k;
                     }
-                s = s.substr(lo, hi - lo);
+                s = s.substr(lo, hi - lo);  // lo <= hi <= size by the clamps above
                 break;
             }
         }
@@ -384,7 +441,7 @@ void UnigramEngine::encode_segment(const char* p, size_t n, bool at_text_start, 
                     first = false;
                 };
                 while (i < t.size()) {
-                    const size_t l = u8_len((unsigned char)t[i]);
+                    const size_t l = u8_len_at(t, i);
                     if (is_space(u8_cp(t.data() + i, l))) {
                         if (i > start) flush(start, i);
                         start = i + l;
@@ -410,7 +467,7 @@ void UnigramEngine::encode_segment(const char* p, size_t n, bool at_text_start, 
                         start = i;
                         i += pre.replacement.size();
                     } else {
-                        i += u8_len((unsigned char)m[i]);
+                        i += u8_len_at(m, i);
                     }
                 }
                 if (m.size() > start) next.push_back({m.substr(start), false});
@@ -436,18 +493,18 @@ void UnigramEngine::encode(const char* utf8, size_t n, uint32_t body_max, std::v
         if (!spec_.added.empty())
             for (const auto& a : spec_.added)
                 if (!a.text.empty() && text.compare(i, a.text.size(), a.text) == 0) { hit = &a; break; }
-        if (!hit) { i += u8_len((unsigned char)text[i]); continue; }
+        if (!hit) { i += u8_len_at(text, i); continue; }
         size_t lo = i, hi = i + hit->text.size();
         if (hit->lstrip)  // the token takes the whitespace in front of it
             while (lo > seg) {
                 size_t k = lo - 1;
                 while (k > seg && ((unsigned char)text[k] & 0xC0) == 0x80) --k;
-                if (!is_space(u8_cp(text.data() + k, lo - k))) break;
+                if (lo - k > 4 || !is_space(u8_cp(text.data() + k, lo - k))) break;
                 lo = k;
             }
         if (hit->rstrip)
             while (hi < text.size()) {
-                const size_t l = u8_len((unsigned char)text[hi]);
+                const size_t l = u8_len_at(text, hi);
                 if (!is_space(u8_cp(text.data() + hi, l))) break;
                 hi += l;
             }

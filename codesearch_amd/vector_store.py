@@ -561,7 +561,9 @@ class VectorStore:
 
     def set_single_query_route(self, route: int) -> None:
         """How one query over a large index is answered (cs_index_set_single_query_route): ROUTE_COST (default: the int8
-        filter + exact refine from 150,000 rows on), ROUTE_STREAM (always the f32 streaming scan), ROUTE_FILTER.  Same bits."""
+        filter + exact refine from 32,768 rows on for lists of k < 48 and from 300,000 rows on from k = 48 — the measured
+        crossovers, index.hip single_int8_min_rows / single_int8_min_rows_long; CS_FILTER_SINGLE_MIN_ROWS /
+        CS_FILTER_SINGLE_MIN_ROWS_LONG override them), ROUTE_STREAM (always the f32 streaming scan), ROUTE_FILTER.  Same bits."""
         if self.sharded:
             for g in range(int(self._lib.cs_shards_count(self._h))):
                 _lib.check(self._lib.cs_index_set_single_query_route(self.shard_handle(g), int(route)))

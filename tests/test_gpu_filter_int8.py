@@ -367,3 +367,39 @@ def test_filter_copy_allocation_failures_fall_back_without_corruption(VS, monkey
         c1, i1, _ = bare.search_raw(qs[i], k)
         assert ids[i].tolist() == i1[0].tolist(), i
         np.testing.assert_allclose(cos[i], c1[0], atol=1e-6)
+
+
+@pytest.mark.parametrize("stage", [2, 3, 4, 5, 6])
+def test_a_failing_copy_inside_grow_leaves_the_index_as_it_was(VS, monkeypatch, stage):
+    """VERDICT r4 #13 (index.hip grow): a copy that fails between the new buffers' allocation and the pointer swap must
+    neither leak them nor leave the index half-moved.  CS_FAULT_GROW_COPY=<stage> makes that stage's copy report a failure:
+    the insert returns an error, free device memory is what it was, the index still answers from its old rows with the same
+    bits, and the same insert succeeds once the fault is gone."""
+    import torch
+
+    from codesearch_amd import _lib
+
+    dim, k = 384, 10
+    st = VS(None, dim)
+    st.insert_synthetic(5_000, 21, 0)
+    st.build_index()
+    q = synth_rows(22, 0, 1, dim)[0]
+    cos0, ids0, _ = st.search_raw(q, k)
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    monkeypatch.setenv("CS_FAULT_GROW_COPY", str(stage))
+    with pytest.raises(_lib.CsError) as ei:
+        st.insert_synthetic(120_000, 21, 5_000)   # grows past the first capacity
+    assert "growing the index" in str(ei.value) and f"stage {stage}" in str(ei.value)
+    monkeypatch.delenv("CS_FAULT_GROW_COPY")
+    torch.cuda.synchronize()
+    assert abs(torch.cuda.mem_get_info()[0] - free0) < (8 << 20), (torch.cuda.mem_get_info()[0], free0)  # nothing leaked
+    assert len(st) == 5_000
+    cos1, ids1, _ = st.search_raw(q, k)
+    assert ids1.tolist() == ids0.tolist() and cos1.tobytes() == cos0.tobytes()
+    st.insert_synthetic(120_000, 21, 5_000)
+    st.build_index()
+    assert len(st) == 125_000
+    pq = synth_rows(21, 100_000, 1, dim)[0]
+    _, ids2, _ = st.search_raw(pq, k)
+    assert ids2[0][0] == 100_000

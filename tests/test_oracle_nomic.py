@@ -203,11 +203,17 @@ def test_c_abi_loader_reads_a_nomic_snapshot(tmp_path, gpu_lib):
     bad = tmp_path / "bad"
     for change, text in (({"rotary_emb_interleaved": True}, "this nomic_bert configuration is not built"),
                          ({"activation_function": "gelu"}, "this nomic_bert configuration is not built"),
-                         ({"rotary_scaling_factor": 2}, "this nomic_bert configuration is not built"),
+                         ({"rotary_scaling_factor": 2, "max_trained_positions": 64}, "this nomic_bert configuration is not built"),
                          ({"prenorm": True}, "this nomic_bert configuration is not built")):
         nomic_snapshot(bad, cfg, flat)
         (bad / "config.json").write_text(json.dumps({**hf, **change}))
         expect(bad, _lib.CS_ERR_UNSUPPORTED, text)
+    # the 8k-context checkpoints' dynamic-NTK factor only changes the rotary base beyond max_trained_positions (2,048):
+    # at the 512 positions this loader runs the table is the same, so such a config loads
+    nomic_snapshot(bad, cfg, flat)
+    (bad / "config.json").write_text(json.dumps({**hf, "rotary_scaling_factor": 2}))
+    c2, got2 = load(bad)
+    assert c2.max_position == 512 and np.array_equal(got2, exp)
     nomic_snapshot(bad, cfg, flat)
     (bad / "config.json").write_text(json.dumps({k: v for k, v in hf.items() if k != "n_head"}))
     expect(bad, _lib.CS_ERR_BAD_ARG, "lacks a nomic_bert size field")

@@ -170,3 +170,55 @@ def test_components_that_are_not_built_are_refused(lib, files, tmp_path):
     refuses(lambda d: d["model"].__setitem__("unk_id", 99999), _lib.CS_ERR_UNSUPPORTED)
     refuses(lambda d: d["model"].__setitem__("vocab", [["a", "x"]]), _lib.CS_ERR_BAD_ARG)
     refuses(lambda d: d["normalizer"]["normalizers"][0].__setitem__("precompiled_charsmap", "AAAA"), _lib.CS_ERR_BAD_ARG)
+
+
+def _raw_json_with(path_in, path_out, marker, raw):
+    """Re-writes a tokenizer.json with the ASCII `marker` replaced by the raw bytes `raw` (a JSON writer would never
+    emit them; a downloaded file can hold anything, and checkpoint.cpp's JSON reader passes string bytes through)."""
+    data = open(path_in, "rb").read()
+    assert data.count(marker) >= 1
+    open(path_out, "wb").write(data.replace(marker, raw))
+
+
+@pytest.mark.parametrize("where", ["replace_content", "metaspace", "piece", "added", "charsmap"])
+def test_ill_formed_utf8_in_the_file_is_refused_at_load_time(lib, files, tmp_path, where):
+    """bytes the file splices into a text AFTER the input was sanitised (a Replace content, the Metaspace
+    replacement, a vocabulary piece, an added token, a replacement string of the precompiled character map) must be
+    well-formed UTF-8 themselves — a lone 0xE2 as Replace content made Strip walk past the end of the string at ENCODE
+    time.  Such a file is refused when it is loaded, with the reference's wording."""
+    import base64
+
+    path, _ = files["converter"]  # Precompiled, Strip(right), Replace -> U+2581; Metaspace
+    d = json.load(open(path, encoding="utf-8"))
+    if where == "replace_content":
+        d["normalizer"]["normalizers"].append({"type": "Replace", "pattern": {"String": "a"}, "content": "QQMARKQQ"})
+        d["normalizer"]["normalizers"].append({"type": "Strip", "strip_left": True, "strip_right": True})
+    elif where == "metaspace":
+        pt = d["pre_tokenizer"]
+        (pt["pretokenizers"][-1] if pt["type"] == "Sequence" else pt)["replacement"] = "QQMARKQQ"
+    elif where == "piece":
+        d["model"]["vocab"][10][0] = "QQMARKQQ"
+    elif where == "added":
+        d["added_tokens"].append({"id": 11, "content": "QQMARKQQ", "single_word": False, "lstrip": False, "rstrip": False,
+                                  "normalized": False, "special": True})
+    else:
+        blob = bytearray(base64.b64decode(d["normalizer"]["normalizers"][0]["precompiled_charsmap"]))
+        tsize = int.from_bytes(blob[:4], "little")
+        pool = 4 + tsize
+        # the first byte of the first multi-byte replacement in the pool becomes a lone continuation byte
+        i = next(k for k in range(pool, len(blob)) if blob[k] >= 0xC2)
+        blob[i] = 0x80
+        d["normalizer"]["normalizers"][0]["precompiled_charsmap"] = base64.b64encode(bytes(blob)).decode()
+    good = tmp_path / "good.json"
+    good.write_text(json.dumps(d), encoding="utf-8")
+    bad = tmp_path / "bad.json"
+    if where == "charsmap":
+        bad = good
+    else:
+        _raw_json_with(good, bad, b"QQMARKQQ", b"\xe2")
+    h = C.c_void_p()
+    st = lib.cs_tokenizer_create_from_json(str(bad).encode(), 0, C.byref(h))
+    assert st == _lib.CS_ERR_BAD_ARG, (where, st)
+    msg = _lib.last_error()
+    assert msg.startswith("Failed to initialize embedding model") and "UTF-8" in msg, msg
+    assert not h.value
