@@ -9,6 +9,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 fetch_csv, write_csv, tag = sys.argv[1:4]
+commit = sys.argv[4] if len(sys.argv) > 4 else os.environ.get("CS_MEASURED_AT_COMMIT")  # the GPU box has no .git
 
 
 def rows(f):
@@ -31,7 +32,7 @@ write = sum(float(W[i][1]["Counter_Value"]) for i in big) / len(big)
 pf = sum(float(F[i][0]["Counter_Value"]) for i in big) / len(big)
 pw = sum(float(W[i][0]["Counter_Value"]) for i in big) / len(big)
 name = F[big[0]][1]["Kernel_Name"].split("(")[0].replace("void ", "")
-doc = {"rows": 10000000, "dim": 384, "hbm_bytes_per_launch": (fetch * 2 + write) * 1024,
+doc = {"rows": 10000000, "dim": 384, "measured_at_commit": commit, "hbm_bytes_per_launch": (fetch * 2 + write) * 1024,
        "fetch_size_kb_raw": fetch, "write_size_kb_raw": write, "prime_pass_hbm_bytes": (pf * 2 + pw) * 1024,
        "source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only), "
                  f"profiles/{tag}_scan_pmc_fetch.csv and {tag}_scan_pmc_write.csv, {name} over 10M rows "

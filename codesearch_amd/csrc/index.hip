@@ -314,7 +314,10 @@ struct cs_index {
     // streams of OTHER devices that carry unfinished appends into this corpus (index_append_from: an encoder replica on
     // another GPU writing its rows over xGMI); hipDeviceSynchronize on this device does not wait for them
     // (an EVENT recorded on that stream behind the copy, not the stream handle: the caller may destroy its stream)
-    std::vector<std::pair<int, hipEvent_t>> foreign_appends;
+    // peer appends in flight: ONE event per (source device, stream), re-recorded by every append on that stream (a later
+    // record covers the stream's earlier copies), so an ingest of millions of rows in mini-batches keeps a handful of events
+    struct ForeignAppend { int device; hipStream_t stream; hipEvent_t done; };
+    std::vector<ForeignAppend> foreign_appends;
 
     std::mutex mu;  // guards the pools below (search is re-entrant)
     std::vector<Workspace*> pool;
@@ -334,15 +337,16 @@ namespace {
 int32_t drain_appends(cs_index* h) {
     int32_t st = CS_OK;
     for (const auto& fe : h->foreign_appends) {
-        DeviceGuard g(fe.first);
-        if (hipEventSynchronize(fe.second) != hipSuccess && st == CS_OK)
+        DeviceGuard g(fe.device);
+        if (hipEventSynchronize(fe.done) != hipSuccess && st == CS_OK)
             st = fail(CS_ERR_HIP, "a peer append into the index did not complete: %s", hipGetErrorString(hipGetLastError()));
-        (void)hipEventDestroy(fe.second);
+        (void)hipEventDestroy(fe.done);
     }
     h->foreign_appends.clear();
-    CS_TRY(st);
-    CS_HIP(hipDeviceSynchronize());
-    return CS_OK;
+    // (the index's own device is drained whether or not a peer reported a failure)
+    if (hipDeviceSynchronize() != hipSuccess && st == CS_OK)
+        st = fail(CS_ERR_HIP, "hipDeviceSynchronize failed: %s", hipGetErrorString(hipGetLastError()));
+    return st;
 }
 
 // New buffers of a grow(), freed on every path that does not commit them (a failing copy between the
@@ -1196,15 +1200,20 @@ int32_t cs::index_append_from(cs_index* h, const float* d_rows, int src_device, 
     if (src_device == h->device) CS_HIP(hipMemcpyAsync(dst, d_rows, bytes, hipMemcpyDeviceToDevice, stream));
     else {
         CS_HIP(hipMemcpyPeerAsync(dst, h->device, d_rows, src_device, bytes, stream));
-        hipEvent_t done = nullptr;
-        CS_HIP(hipEventCreateWithFlags(&done, hipEventDisableTiming));
-        if (hipEventRecord(done, stream) != hipSuccess) {
-            (void)hipEventDestroy(done);
-            return fail(CS_ERR_HIP, "hipEventRecord on the peer stream failed");
+        cs_index::ForeignAppend* slot = nullptr;
+        for (auto& fe : h->foreign_appends)
+            if (fe.device == src_device && fe.stream == stream) { slot = &fe; break; }
+        if (slot) {  // the same stream again: re-recording its event covers this copy and every earlier one
+            if (hipEventRecord(slot->done, stream) != hipSuccess) return fail(CS_ERR_HIP, "hipEventRecord on the peer stream failed");
+        } else {
+            hipEvent_t done = nullptr;
+            CS_HIP(hipEventCreateWithFlags(&done, hipEventDisableTiming));
+            if (hipEventRecord(done, stream) != hipSuccess) {
+                (void)hipEventDestroy(done);
+                return fail(CS_ERR_HIP, "hipEventRecord on the peer stream failed");
+            }
+            h->foreign_appends.push_back({src_device, stream, done});
         }
-        // one event per source device is enough: a later record on the same stream covers the earlier copies only if
-        // it is the same stream, which the index cannot know — so every append keeps its own event until the next drain
-        h->foreign_appends.emplace_back(src_device, done);
     }
     finish_append(h, n, nullptr);
     return CS_OK;
