@@ -128,6 +128,7 @@ SIGNATURES = {
     "cs_embedder_set_gemm_mode": (C.c_int32, [vp, C.c_int32]),
     "cs_embedder_gemm_mode": (C.c_int32, [vp]),
     "cs_embedder_debug_counters": (C.c_int32, [vp, u64p, u64p, u64p]),
+    "cs_embedder_small_forward_counters": (C.c_int32, [vp, u64p, u64p]),
     "cs_tokenizer_create": (C.c_int32, [C.c_char_p, C.c_uint64, C.c_int32, C.c_uint32, C.POINTER(vp)]),
     "cs_tokenizer_create_from_file": (C.c_int32, [C.c_char_p, C.c_int32, C.c_uint32, C.POINTER(vp)]),
     "cs_tokenizer_create_from_json": (C.c_int32, [C.c_char_p, C.c_uint32, C.POINTER(vp)]),

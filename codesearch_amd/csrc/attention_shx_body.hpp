@@ -1,0 +1,361 @@
+// attention_shx_body.hpp — the body of attention_shx_kernel (attention_split.hip) as a device function, so that the
+// one-launch forward of short queries (small_forward.hip) runs the SAME arithmetic as the stand-alone kernel: only how
+// the qkv tensor is read and the context written differs (a memory policy).
+#pragma once
+
+#include "encoder.hpp"
+#include "split_f16.hpp"
+
+#ifndef AT_STAMP
+#define AT_STAMP(i)
+#endif
+
+namespace cs {
+
+typedef __fp16 h16x2 __attribute__((ext_vector_type(2)));
+
+constexpr float kLog2e = 1.4426950408889634f;
+constexpr float kMaskedLog2 = -3.0e38f;        // additive mask in the exp2 domain (finite: no NaN on all-masked rows)
+
+union Frag8 {
+    f16x8 v;
+    uint32_t u[4];
+    uint2 d[2];
+};
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+union FragTr {
+    f16x8 v;
+    s16x4 q[2];
+};
+
+// Two probabilities -> packed (hi, hi) and (lo, lo).  Round-toward-zero packs two conversions into one
+// instruction; the low part takes up the residual exactly as in sh_split (2^-21 relative).  No subnormal
+// guard (the f16 MFMA keeps subnormal inputs; cs_embedder_create verifies that once per device).
+__device__ __forceinline__ void split_pair_rtz_ng(float a, float b, uint32_t& hi, uint32_t& lo) {
+    const h16x2 h = __builtin_amdgcn_cvt_pkrtz(a, b);
+    const h16x2 l = __builtin_amdgcn_cvt_pkrtz((a - (float)h[0]) * kShLoScale, (b - (float)h[1]) * kShLoScale);
+    hi = __builtin_bit_cast(uint32_t, h);
+    lo = __builtin_bit_cast(uint32_t, l);
+}
+
+// The stand-alone kernel's accesses: plain 16-byte loads, K / V pieces (8 keys x 128 B) by LDS-DMA, plain 8-byte stores.
+struct AttnMemPlain {
+    __device__ __forceinline__ f16x8 ld16(const _Float16* p) const { return *reinterpret_cast<const f16x8*>(p); }
+    // a piece of K / V (8 keys x 128 B) into its lane-linear LDS image: the DMA is issued by stage_load, stage_store has
+    // nothing left to do
+    __device__ __forceinline__ f16x8 stage_load(const _Float16* src, char* lds_piece) const { sh_glds16(src, lds_piece); return f16x8{}; }
+    __device__ __forceinline__ void stage_store(char*, int, f16x8) const {}
+    __device__ __forceinline__ void st8(_Float16* p, f16x4 v) const { *reinterpret_cast<f16x4*>(p) = v; }
+};
+
+// ---- head_dim 32 * NC (NC = 2: BGE-base / BGE-large / mxbai-large): keys in super-tiles of 128 ------------
+// A (token, head) is NC 128-B lines [32 hi | 32 lo] of the split qkv row.  Each line of K and of V gets its
+// own LDS image with exactly the layout of attention_sh2_kernel (K pieces at c ^ ((key >> 1) & 7), V pieces
+// at c ^ (4 * ((key >> 1) & 1)) for the transposing read), so S sums NC images and O^T has NC 32-row tiles of
+// d.  At 512 B per key (NC = 2) a whole 512-token sequence no longer fits LDS: keys are staged 128 at a time
+// (64 KiB, two blocks per CU), the online softmax state carrying over.  Block = (head, sequence, 128 queries).
+// MQ / MO: how the qkv tensor is read and the context tensor written (AttnMemPlain: plain loads, K / V by LDS-DMA, plain
+// stores — the stand-alone kernel; small_forward.hip passes a policy whose every access carries sc1, K / V through
+// registers).  bx / by / bz: the block's coordinates, gx / gz: the grid's extents (the kernel form passes its own).
+template <int NC, class MQ, class MO>
+__device__ __forceinline__ void
+attention_shx_body(char* smem, const MQ& mq, const MO& mo, const _Float16* qkvs, const int32_t* __restrict__ mask,
+                   _Float16* ctxs, uint32_t* __restrict__ flag, uint32_t L, uint32_t H,
+                   float scale_log2e, uint32_t HB, float* __restrict__ range_out,
+                   const uint32_t* __restrict__ seq_unit, const uint32_t* __restrict__ unit_len,
+                   uint32_t bx, uint32_t by, uint32_t bz, uint32_t gx, uint32_t gz) {
+    constexpr int KT = 128;                        // keys per super-tile
+    const uint32_t Lp = (L + 31) & ~31u;
+    char* Kt = smem;                               // [NC][KT][128 B]
+    char* Vt = Kt + (size_t)NC * KT * 128;         // [NC][KT][128 B]
+    float* madd = reinterpret_cast<float*>(Vt + (size_t)NC * KT * 128);  // [Lp]
+    int* last_valid_p = reinterpret_cast<int*>(madd + Lp);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, h = lane >> 5;
+    // Short sequences: a block of four waves serves HB heads (4 up to 32 tokens, 2 up to 64, else 1), wq = 4 / HB query
+    // tiles each — one head per block left three (one) of the four waves without a query tile, and the per-block
+    // overheads set the rate (2,048 x 32 tokens took 144 us per layer where the flops of 256 x 256 take 150).  Each
+    // head has KT / HB rows of the K and V images, staged by its own waves.
+    const uint32_t wq = 4 / HB, hsub = (uint32_t)wave / wq, qt = (uint32_t)wave % wq;
+    const uint32_t head = bx * HB + hsub, b = by, qb = bz;
+    Kt += (size_t)hsub * (KT / HB) * 128;
+    Vt += (size_t)hsub * (KT / HB) * 128;
+    const uint32_t nh = H / (32 * NC), nch = 3 * nh * NC;  // chunks per token row: Q heads | K heads | V heads
+    const _Float16* base = qkvs + (size_t)b * L * nch * 64;
+    bool ovf = false;
+
+    AT_STAMP(0);
+    if (tid == 0) *last_valid_p = 0;
+
+    const int kswz = (l31 >> 1) & 7;
+    int k_hi[2], k_lo[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        k_hi[s] = ((2 * s + h) ^ kswz) * 16;
+        k_lo[s] = ((4 + 2 * s + h) ^ kswz) * 16;
+    }
+    const int vq = (lane & 15) >> 2, vp = lane & 3, vg = (lane >> 4) & 1;
+    const int vfv = 4 * ((vq >> 1) & 1);
+    const int v_hi = (4 * h + vq) * 128 + (((2 * vg + (vp >> 1)) ^ vfv) * 16) + 8 * (vp & 1);
+    const int v_lo = v_hi ^ 64;
+
+    const bool wave_live = qb * 128 + qt * 32 < L;  // wave-uniform: some query of this wave's tile exists
+    const uint32_t query = qb * 128 + qt * 32 + l31;
+    const uint32_t qsrc = query < L ? query : L - 1;
+    f16x8 qh[NC][2], ql[NC][2];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const _Float16* qp = base + ((size_t)qsrc * nch + head * NC + c) * 64 + 8 * h;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            qh[c][s] = mq.ld16(qp + 16 * s);
+            ql[c][s] = mq.ld16(qp + 32 + 16 * s);
+        }
+    }
+    sh_f32x16 ohh[NC], oxx[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { ohh[c][r] = 0.0f; oxx[c][r] = 0.0f; }
+    float m = -__builtin_huge_valf(), lsum = 0.0f;
+
+    // stage keys [128 st, 128 st + 128): 8 keys x 128 B per instruction and image
+    auto stage = [&](uint32_t st) {
+        // only the groups of 8 keys that exist (padded to whole 32-key tiles): a 32-token sequence stages 4 of the 16
+        const uint32_t live = Lp - st * KT < (uint32_t)KT ? Lp - st * KT : (uint32_t)KT;  // <= KT / HB when HB > 1
+        // (four groups per round: a policy that stages through registers has all of a round's loads in flight before the
+        // first LDS write; the LDS-DMA policy issues its pieces in the same order as one group at a time would)
+        for (uint32_t i0 = qt; i0 < live / 8; i0 += 4 * wq) {
+            f16x8 rk[4][NC], rv[4][NC];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const uint32_t ii = i0 + u * wq;
+                if (ii < live / 8) {
+                    const uint32_t row = ii * 8 + (lane >> 3);            // key inside the super-tile
+                    const uint32_t gk = st * KT + row;
+                    const uint32_t key = gk < L ? gk : L - 1;             // keys past L are masked; read a valid line
+                    const uint32_t ck = (lane & 7) ^ ((row >> 1) & 7);
+                    const uint32_t cv = (lane & 7) ^ (4 * ((row >> 1) & 1));
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) {
+                        rk[u][c] = mq.stage_load(base + ((size_t)key * nch + (nh + head) * NC + c) * 64 + ck * 8, Kt + (size_t)c * KT * 128 + ii * 1024);
+                        rv[u][c] = mq.stage_load(base + ((size_t)key * nch + (2 * nh + head) * NC + c) * 64 + cv * 8, Vt + (size_t)c * KT * 128 + ii * 1024);
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const uint32_t ii = i0 + u * wq;
+                if (ii < live / 8) {
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) {
+                        mq.stage_store(Kt + (size_t)c * KT * 128 + ii * 1024, lane, rk[u][c]);
+                        mq.stage_store(Vt + (size_t)c * KT * 128 + ii * 1024, lane, rv[u][c]);
+                    }
+                }
+            }
+        }
+    };
+    // A block's first round trips all leave together: the query fragments (above), the first super-tile's K / V, and the
+    // mask — waiting for the mask before the staging was issued put two memory latencies in front of every block
+    // (63 of the kernel's 150 us per layer were per-block overhead: 107 us at 128 tokens per sequence against 150 at 256).
+    stage(0);
+    __syncthreads();  // last_valid_p = 0 is visible
+    for (uint32_t key = tid; key < Lp; key += 256) {
+        const bool ok = key < L && mask[(size_t)b * L + key] != 0;
+        madd[key] = ok ? 0.0f : kMaskedLog2;
+        if (ok) atomicMax(last_valid_p, (int)key);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const uint32_t ntiles = (uint32_t)(*last_valid_p) / 32 + 1;  // 32-key tiles that hold a valid key
+
+    for (uint32_t st = 0; st * 4 < ntiles; ++st) {
+        if (st > 0) {
+            __syncthreads();  // every wave is done with the previous super-tile
+            stage(st);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+        if (!wave_live) continue;  // (still takes part in the staging and the barriers)
+        const uint32_t kt_end = ntiles - st * 4 < 4 ? ntiles - st * 4 : 4;
+        for (uint32_t kl = 0; kl < kt_end; ++kl) {
+            const uint32_t kt = st * 4 + kl;  // global 32-key tile
+            sh_f32x16 hh, xx;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { hh[r] = 0.0f; xx[r] = 0.0f; }
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const char* kr = Kt + (size_t)c * KT * 128 + (size_t)(kl * 32 + l31) * 128;
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const f16x8 kh = *reinterpret_cast<const f16x8*>(kr + k_hi[s]);
+                    const f16x8 kl8 = *reinterpret_cast<const f16x8*>(kr + k_lo[s]);
+                    hh = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[c][s], hh, 0, 0, 0);
+                    xx = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[c][s], xx, 0, 0, 0);
+                    xx = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl8, qh[c][s], xx, 0, 0, 0);
+                }
+            }
+#ifndef CS_ATTN_SCALAR_SOFTMAX
+            // The softmax of a tile is 172 VALU instructions per wave against 12 MFMAs when written element by element
+            // — the kernel is VALU-bound (2.3 x the MFMAs' cycles) — so everything that is the same operation on two
+            // neighbouring keys is a packed-f32 instruction (v_pk_fma_f32 / v_pk_add_f32 / v_pk_mul_f32): 124.
+            // Same operations, same roundings; only the order of the row sum changes (two partial sums).
+            sh_f32x2 p2[8];
+            float tmax = -__builtin_huge_valf();
+            const sh_f32x2 lo_inv2 = {kShLoInv, kShLoInv}, scale2 = {scale_log2e, scale_log2e};
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const sh_f32x4 ma = *reinterpret_cast<const sh_f32x4*>(madd + kt * 32 + 8 * g + 4 * h);
+#pragma unroll
+                for (int e2 = 0; e2 < 2; ++e2) {
+                    const int r = 4 * g + 2 * e2;
+                    const sh_f32x2 x2 = {xx[r], xx[r + 1]}, h2 = {hh[r], hh[r + 1]}, m2 = {ma[2 * e2], ma[2 * e2 + 1]};
+                    const sh_f32x2 s2 = __builtin_elementwise_fma(__builtin_elementwise_fma(x2, lo_inv2, h2), scale2, m2);
+                    p2[r / 2] = s2;
+                    tmax = fmaxf(tmax, fmaxf(s2[0], s2[1]));
+                }
+            }
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+            if (__any(tmax > m)) {
+                const float mnew = fmaxf(m, tmax);
+                const float alpha = __builtin_amdgcn_exp2f(m - mnew);
+                lsum *= alpha;
+#pragma unroll
+                for (int c = 0; c < NC; ++c)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) { ohh[c][r] *= alpha; oxx[c][r] *= alpha; }
+                m = mnew;
+            }
+            const sh_f32x2 m2v = {m, m};
+            sh_f32x2 ps2 = {0.0f, 0.0f};
+            Frag8 ph[2], pl[2];
+            const sh_f32x2 lo_scale2 = {kShLoScale, kShLoScale};
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const sh_f32x2 d2 = p2[i] - m2v;
+                const sh_f32x2 e2 = {__builtin_amdgcn_exp2f(d2[0]), __builtin_amdgcn_exp2f(d2[1])};
+                ps2 += e2;
+                const h16x2 hi = __builtin_amdgcn_cvt_pkrtz(e2[0], e2[1]);
+                const sh_f32x2 back = {(float)hi[0], (float)hi[1]};
+                const sh_f32x2 r2 = (e2 - back) * lo_scale2;
+                const h16x2 lo = __builtin_amdgcn_cvt_pkrtz(r2[0], r2[1]);
+                ph[i >> 2].u[i & 3] = __builtin_bit_cast(uint32_t, hi);
+                pl[i >> 2].u[i & 3] = __builtin_bit_cast(uint32_t, lo);
+            }
+            lsum += ps2[0] + ps2[1];
+#else
+            float tmax = -__builtin_huge_valf();
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const sh_f32x4 ma = *reinterpret_cast<const sh_f32x4*>(madd + kt * 32 + 8 * g + 4 * h);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int r = 4 * g + e;
+                    hh[r] = fmaf(fmaf(xx[r], kShLoInv, hh[r]), scale_log2e, ma[e]);
+                    tmax = fmaxf(tmax, hh[r]);
+                }
+            }
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+            if (__any(tmax > m)) {
+                const float mnew = fmaxf(m, tmax);
+                const float alpha = __builtin_amdgcn_exp2f(m - mnew);
+                lsum *= alpha;
+#pragma unroll
+                for (int c = 0; c < NC; ++c)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) { ohh[c][r] *= alpha; oxx[c][r] *= alpha; }
+                m = mnew;
+            }
+            float psum = 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                hh[r] = __builtin_amdgcn_exp2f(hh[r] - m);
+                psum += hh[r];
+            }
+            lsum += psum;
+            Frag8 ph[2], pl[2];
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int w2 = 0; w2 < 4; ++w2) {
+#ifdef CS_ATTN_P_HI_ONLY  // experiment (VERDICT r2 #4 ii): P as ONE f16, round to nearest; no p_lo * v_hi product
+                    const f16x2 pr = __builtin_convertvector(sh_f32x2{hh[8 * s + 2 * w2], hh[8 * s + 2 * w2 + 1]}, f16x2);
+                    ph[s].u[w2] = __builtin_bit_cast(uint32_t, pr);
+                    pl[s].u[w2] = 0u;
+#else
+                    split_pair_rtz_ng(hh[8 * s + 2 * w2], hh[8 * s + 2 * w2 + 1], ph[s].u[w2], pl[s].u[w2]);
+#endif
+                }
+#endif
+            typedef __attribute__((address_space(3))) s16x4* lds_s16x4_p;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const char* vr = Vt + (size_t)c * KT * 128 + (size_t)kl * 32 * 128;
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    FragTr vh, vl;
+                    vh.q[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(vr + s * 16 * 128 + v_hi));
+                    vh.q[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(vr + s * 16 * 128 + 8 * 128 + v_hi));
+                    vl.q[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(vr + s * 16 * 128 + v_lo));
+                    vl.q[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(vr + s * 16 * 128 + 8 * 128 + v_lo));
+                    ohh[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh.v, ph[s].v, ohh[c], 0, 0, 0);
+#ifndef CS_ATTN_P_HI_ONLY
+                    oxx[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh.v, pl[s].v, oxx[c], 0, 0, 0);
+#endif
+                    oxx[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl.v, ph[s].v, oxx[c], 0, 0, 0);
+                }
+            }
+        }
+    }
+    lsum += __shfl_xor(lsum, 32, 64);
+    const float inv = 1.0f / lsum;
+    float rlo = 0.0f, rhi = 0.0f;  // range of what this wave stores, zero included
+    if (wave_live && query < L) {
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            _Float16* op = ctxs + (((size_t)b * L + query) * nh + head) * NC * 64 + c * 64 + 4 * h;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f16x4 hi, lo;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    _Float16 a, bb;
+                    const float o = fmaf(oxx[c][4 * g + e], kShLoInv, ohh[c][4 * g + e]) * inv;
+                    ovf |= sh_split(o, a, bb);
+                    hi[e] = a; lo[e] = bb;
+                    rlo = fminf(rlo, o);  // (splitting is monotone: the extremes of what is stored are the split extremes)
+                    rhi = fmaxf(rhi, o);
+                }
+                mo.st8(op + 8 * g, hi);
+                mo.st8(op + 32 + 8 * g, lo);
+            }
+        }
+    }
+    AT_STAMP(2);
+    if (ovf && flag) atomicOr(flag, 1u);
+    // Dynamic-quantised models quantise this tensor next (gemm_q8.hip): one (lo, hi) per wave instead of a range pass
+    // over the stored tensor — range_out [sequence][query block][head group][4 waves][2].  With several quantisation units
+    // in the batch a query row beyond its unit's own padded length is not part of the tensor the reference quantises.
+    if (range_out) {
+        if (unit_len && query >= unit_len[seq_unit[b]]) rlo = rhi = 0.0f;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            rlo = fminf(rlo, __shfl_xor(rlo, o, 64));
+            rhi = fmaxf(rhi, __shfl_xor(rhi, o, 64));
+        }
+        if (lane == 0) {
+            const size_t blk = ((size_t)by * gz + bz) * gx + bx;
+            _Float16 a, bb;
+            (void)sh_split(rlo, a, bb);
+            range_out[(blk * 4 + wave) * 2] = fmaf((float)bb, kShLoInv, (float)a);
+            (void)sh_split(rhi, a, bb);
+            range_out[(blk * 4 + wave) * 2 + 1] = fmaf((float)bb, kShLoInv, (float)a);
+        }
+    }
+}
+
+}  // namespace cs

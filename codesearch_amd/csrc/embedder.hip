@@ -14,6 +14,7 @@
 
 #include "encoder.hpp"
 #include "scan.hpp"  // launch_synth_fill (cs_debug_gemm_time)
+#include "small_forward.hpp"
 #include "split_f16.hpp"
 #include "gemm_q8.hpp"
 
@@ -82,6 +83,13 @@ struct cs_embedder {
     float2* d_rope = nullptr;
     _Float16* d_wsplit = nullptr;  // per layer: wqkv | attention-out | ffn-up | ffn-down, split-f16 rows
     uint32_t* d_flag = nullptr;    // split-f16 range flag
+    // the one-launch forward of short queries (small_forward.hip): the layers' pointers on the device, its barrier words,
+    // whether this mini-batch ran it (embed_impl then reads the give-up word), how often it ran / gave up
+    SfLayer* d_sf_layers = nullptr;
+    uint32_t* d_sf_sync = nullptr;
+    uint64_t* d_sf_dbg = nullptr;   // CS_SMALL_FORWARD_DEBUG: per-block tick sums of the last launch (printed to stderr)
+    bool sf_ran = false, sf_off = false;
+    uint64_t sf_forwards = 0, sf_fallbacks = 0;
     // dynamically quantised models (gemm_q8.hip): s8 weights per layer (q8_layer), their column metadata, the running
     // range slot of every quantised tensor of a forward ([layers][4][q8_units][Q8_RANGE_WORDS]) and the rows' metadata
     bool quantized = false;
@@ -308,6 +316,33 @@ int32_t forward_range(cs_embedder* h, hipStream_t s, uint32_t b0, uint32_t nb, u
         if (takes_192(Mr, Nn, Kk)) return launch_gemm_wide(epi, Ain, Wt, bias, resid, Cf, Csp, Mr, Nn, Kk, h->d_flag, s, 192);
         return launch_gemm_split(epi, Ain, Wt, bias, resid, Cf, Csp, Mr, Nn, Kk, h->d_flag, s);
     };
+    // A few short sequences (the query side): everything up to the last LayerNorm as ONE launch (small_forward.hip; same
+    // bits as the launches below).  CS_SMALL_FORWARD=0 switches it off; CS_SMALL_FORWARD_MAX_ROWS moves its upper bound.
+    h->sf_ran = false;
+    if (mode == CS_GEMM_SPLIT_F16 && h->d_sf_layers && !h->sf_off && !h->stage_profile && !nomic && b0 == 0 &&
+        small_forward_supported(H, I, c.heads, T, L)) {
+        const char* e = std::getenv("CS_SMALL_FORWARD");  // (read per forward: tests and A/B runs flip it mid-process)
+        const char* em = std::getenv("CS_SMALL_FORWARD_MAX_ROWS");
+        const uint32_t max_rows = em ? (uint32_t)std::atoi(em) : 192u;
+        if (!(e && e[0] == '0') && T <= max_rows) {
+            uint32_t hb = L <= 32 ? 4u : (L <= 64 ? 2u : 1u);  // heads per attention block, as launch_attention_sh2 packs them
+            if (const char* ph = std::getenv("CS_ATTN_PACK_HEADS")) if (ph[0] == '0') hb = 1;
+            while (c.heads % hb) hb >>= 1;
+            SfArgs sa{};
+            sa.ids = a.ids; sa.mask = mask; sa.word = a.word; sa.pos = a.pos; sa.type0 = a.type0; sa.emb_g = a.g; sa.emb_b = a.b;
+            sa.layers = h->d_sf_layers; sa.n_layers = c.layers; sa.eps = c.layer_norm_eps;
+            sa.T = T; sa.L = L; sa.B = nb; sa.vocab = c.vocab_size; sa.heads = c.heads; sa.hb = hb;
+            sa.X = x; sa.Y = h->d_xs + t0 * H; sa.QKVS = reinterpret_cast<_Float16*>(qkv); sa.CTXS = reinterpret_cast<_Float16*>(ctx);
+            sa.MIDS = reinterpret_cast<_Float16*>(mid); sa.flag = h->d_flag; sa.sync = h->d_sf_sync;
+            sa.dbg = h->d_sf_dbg;
+            CS_HIP(hipMemsetAsync(h->d_sf_sync, 0, 16, s));
+            CS_TRY(launch_small_forward(sa, s));
+            h->sf_ran = true;
+            h->last_hidden_partial = false;
+            CS_TRY(launch_row_kernel(2, a, H, s));  // E7 + E8
+            return CS_OK;
+        }
+    }
     CS_TRY(mark(-1));
     CS_TRY(launch_row_kernel(0, a, H, s));  // E1
     CS_TRY(mark(CS_STAGE_EMBED_LN));
@@ -727,6 +762,35 @@ int32_t embed_impl(cs_embedder* h, const int32_t* ids, const int32_t* mask, uint
         } else if (mode == CS_GEMM_SPLIT_F16) {
             uint32_t flag = 0;
             CS_HIP(hipMemcpyAsync(&flag, h->d_flag, sizeof(flag), hipMemcpyDeviceToHost, h->stream));
+            if (h->sf_ran) {  // the one-launch forward: did it reach its end?
+                uint32_t sync[4] = {0, 0, 0, 0};
+                CS_HIP(hipMemcpyAsync(sync, h->d_sf_sync, sizeof sync, hipMemcpyDeviceToHost, h->stream));
+                CS_HIP(hipStreamSynchronize(h->stream));
+                h->sf_forwards += 1;
+                if (h->d_sf_dbg && !sync[1]) {  // diagnostics: where the blocks' time went (medians over the 96 blocks, us)
+                    std::vector<uint64_t> d(96 * 3 + 8);
+                    CS_HIP(hipMemcpy(d.data(), h->d_sf_dbg, d.size() * sizeof(uint64_t), hipMemcpyDeviceToHost));
+                    double med[3];
+                    for (int k = 0; k < 3; ++k) {
+                        std::vector<uint64_t> v;
+                        for (int b = 0; b < 96; ++b) v.push_back(d[3 * b + k]);
+                        std::sort(v.begin(), v.end());
+                        med[k] = v[48] * 0.01;
+                    }
+                    fprintf(stderr, "small_forward B=%u L=%u: per block (median) compute %.1f us, store drain %.1f us, grid barriers %.1f us; "
+                                    "block 0: %.1f / %.1f / %.1f; block 0's compute by phase kind: QKV %.1f attention %.1f out-proj %.1f FFN-up %.1f FFN-down %.1f\n",
+                            B, seq_len, med[0], med[1], med[2], d[0] * 0.01, d[1] * 0.01, d[2] * 0.01, d[288] * 0.01, d[289] * 0.01,
+                            d[290] * 0.01, d[291] * 0.01, d[292] * 0.01);
+                }
+                if (sync[1]) {  // a grid barrier gave up (blocks not co-resident): this mini-batch again, kernel by kernel
+                    h->sf_fallbacks += 1;
+                    h->sf_off = true;
+                    const int32_t st = forward(h, B, seq_len, mode);
+                    h->sf_off = false;
+                    CS_TRY(st);
+                    CS_HIP(hipMemcpyAsync(&flag, h->d_flag, sizeof(flag), hipMemcpyDeviceToHost, h->stream));
+                }
+            }
             CS_HIP(hipStreamSynchronize(h->stream));
             h->split_forwards += 1;
             if (flag) {  // an activation left the f16 range: redo this mini-batch on the exact-f32 MFMA
@@ -1285,6 +1349,24 @@ static int32_t create_impl(const cs_bert_config* cfg, const float* params, uint6
         bool denorm_ok = false;  // the split format relies on exact f16-subnormal MFMA inputs
         if (s == CS_OK) s = sh_denorm_selftest(&denorm_ok, h->stream);
         if (s == CS_OK && !denorm_ok) { h->gemm_mode = CS_GEMM_F32; h->split_unavailable = true; }
+        // the one-launch forward of short queries (small_forward.hip) reads the layers' pointers from a device table
+        if (s == CS_OK && cfg->arch != CS_ARCH_NOMIC && small_forward_supported((uint32_t)H, (uint32_t)I, cfg->heads, 1, 1)) {
+            std::vector<SfLayer> tab(cfg->layers);
+            for (uint32_t l = 0; l < cfg->layers; ++l) {
+                cs_bert_layer_offsets lo;
+                cs_bert_layer_layout(cfg, &h->off, l, &lo);
+                const _Float16* wl = h->d_wsplit + (size_t)l * sl.total;
+                const float* P = h->d_params;
+                tab[l] = SfLayer{wl + sl.qkv, wl + sl.ao, wl + sl.up, wl + sl.down, h->d_bqkv + (size_t)l * 3 * H, P + lo.ao_b, P + lo.up_b,
+                                 P + lo.down_b, P + lo.ao_ln_g, P + lo.ao_ln_b, P + lo.out_ln_g, P + lo.out_ln_b};
+            }
+            if (hipMalloc(&h->d_sf_layers, tab.size() * sizeof(SfLayer)) != hipSuccess || hipMalloc(&h->d_sf_sync, 16) != hipSuccess ||
+                hipMemcpyAsync(h->d_sf_layers, tab.data(), tab.size() * sizeof(SfLayer), hipMemcpyHostToDevice, h->stream) != hipSuccess ||
+                hipStreamSynchronize(h->stream) != hipSuccess)
+                s = fail(CS_ERR_OOM, "the one-launch forward's layer table could not be set up");
+            if (s == CS_OK && std::getenv("CS_SMALL_FORWARD_DEBUG") && hipMalloc(&h->d_sf_dbg, (96 * 3 + 8) * sizeof(uint64_t)) != hipSuccess)
+                h->d_sf_dbg = nullptr;
+        }
         if (const char* env = std::getenv("CS_ENCODER_STREAMS")) {
             h->streams_forced = true;
             const int v = std::atoi(env);
@@ -1384,6 +1466,9 @@ void cs_embedder_destroy(cs_embedder* h) {
     if (h->d_rope) (void)hipFree(h->d_rope);
     if (h->d_wsplit) (void)hipFree(h->d_wsplit);
     if (h->d_flag) (void)hipFree(h->d_flag);
+    if (h->d_sf_layers) (void)hipFree(h->d_sf_layers);
+    if (h->d_sf_sync) (void)hipFree(h->d_sf_sync);
+    if (h->d_sf_dbg) (void)hipFree(h->d_sf_dbg);
     if (h->d_wq8) (void)hipFree(h->d_wq8);
     if (h->d_cmeta) (void)hipFree(h->d_cmeta);
     for (hipEvent_t e : h->stage_ev) (void)hipEventDestroy(e);
@@ -1552,6 +1637,13 @@ int32_t cs_embedder_debug_counters(cs_embedder* h, uint64_t* split_forwards, uin
     if (split_forwards) *split_forwards = h->split_forwards;
     if (f32_forwards) *f32_forwards = h->f32_forwards;
     if (range_fallbacks) *range_fallbacks = h->range_fallbacks;
+    return CS_OK;
+}
+
+int32_t cs_embedder_small_forward_counters(cs_embedder* h, uint64_t* forwards, uint64_t* fallbacks) {
+    if (!h) return fail(CS_ERR_BAD_ARG, "null embedder handle");
+    if (forwards) *forwards = h->sf_forwards;
+    if (fallbacks) *fallbacks = h->sf_fallbacks;
     return CS_OK;
 }
 

@@ -15,6 +15,7 @@
 // All arithmetic is fp32: the f32-input MFMA is bit-for-bit an fmaf chain
 // (cdna_hip_programming.md §3), which keeps the 1e-4 embedding tolerance with margin.
 #include "encoder.hpp"
+#include "encoder_rows.hpp"
 #include "split_f16.hpp"
 
 #include <cstdlib>
@@ -26,41 +27,23 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr float kMaskMin = -3.4028234663852886e38f;  // HF get_extended_attention_mask
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
-    return v;
-}
-
 // ---- E1: embeddings + LayerNorm; E4/E6: LayerNorm -------------------------------------------
 // One wave per token row; NPL = H / 64 values per lane, held as pairs of consecutive columns
 // (v[2p], v[2p+1] = columns 2*lane + 128*p + {0,1}) so the row can also be written in split-f16
-// form (split_f16.hpp) with one 4-byte store per pair and plane.
-__device__ __forceinline__ int ln_col(int lane, int i) { return 2 * lane + 128 * (i >> 1) + (i & 1); }
-
+// form (split_f16.hpp) with one 4-byte store per pair and plane.  The arithmetic is ln_row_core (encoder_rows.hpp).
 template <int NPL>
 __device__ __forceinline__ bool ln_row(float (&v)[NPL], const float* __restrict__ g,
                                        const float* __restrict__ b, float eps, int lane,
                                        float* __restrict__ out, _Float16* __restrict__ outs, float& lo, float& hi) {
-    constexpr float invH = 1.0f / (64.0f * NPL);
-    float s = 0.0f;
-#pragma unroll
-    for (int i = 0; i < NPL; ++i) s += v[i];
-    const float mean = wave_sum(s) * invH;
-    float q = 0.0f;
-#pragma unroll
-    for (int i = 0; i < NPL; ++i) { const float d = v[i] - mean; q = fmaf(d, d, q); }
-    const float var = wave_sum(q) * invH;
-    const float inv = 1.0f / sqrtf(var + eps);
+    float ov[NPL];
+    ln_row_core<NPL>(v, g, b, eps, lane, ov);
     bool ovf = false;
 #pragma unroll
     for (int p = 0; p < NPL / 2; ++p) {
         const int c = ln_col(lane, 2 * p);
-        const float2 gv = *reinterpret_cast<const float2*>(g + c);
-        const float2 bv = *reinterpret_cast<const float2*>(b + c);
         float2 o;
-        o.x = (v[2 * p] - mean) * inv * gv.x + bv.x;
-        o.y = (v[2 * p + 1] - mean) * inv * gv.y + bv.y;
+        o.x = ov[2 * p];
+        o.y = ov[2 * p + 1];
         *reinterpret_cast<float2*>(out + c) = o;
         lo = fminf(lo, fminf(o.x, o.y));  // (the row's range: see ln_range_out)
         hi = fmaxf(hi, fmaxf(o.x, o.y));

@@ -181,6 +181,13 @@ class FastEmbedder:
         _lib.check(self._lib.cs_embedder_debug_counters(self._h, C.byref(a), C.byref(b), C.byref(c)))
         return int(a.value), int(b.value), int(c.value)
 
+    def small_forward_counters(self):
+        """-> (mini-batches that ran as ONE kernel launch (csrc/small_forward.hip: a few short sequences, the query side),
+        how many of those gave up at a grid barrier and were re-run kernel by kernel)"""
+        a, b = C.c_uint64(), C.c_uint64()
+        _lib.check(self._lib.cs_embedder_small_forward_counters(self._h, C.byref(a), C.byref(b)))
+        return int(a.value), int(b.value)
+
     @classmethod
     def from_dir(cls, model_dir: str, model_type: ModelType = None, pooling: int = -1, device: int = 0,
                  lowercase: Optional[bool] = None) -> "FastEmbedder":

@@ -590,6 +590,11 @@ int32_t cs_embedder_set_gemm_mode(cs_embedder* h, int32_t mode);
 int32_t cs_embedder_gemm_mode(const cs_embedder* h);
 int32_t cs_embedder_debug_counters(cs_embedder* h, uint64_t* split_forwards,
                                    uint64_t* f32_forwards, uint64_t* range_fallbacks);
+/* The one-launch forward of short queries (embed_one / embed_queries_batch: src/embed/mod.rs:164-226; csrc/small_forward.hip:
+ * mini-batches of a 384-d BERT model with at most CS_SMALL_FORWARD_MAX_ROWS (192) token rows in split-f16 mode run as ONE
+ * kernel, bit-identical to the kernel-by-kernel path): how many mini-batches took it, and how many of those gave up at a
+ * grid barrier and were re-run kernel by kernel.  CS_SMALL_FORWARD=0 switches it off. */
+int32_t cs_embedder_small_forward_counters(cs_embedder* h, uint64_t* forwards, uint64_t* fallbacks);
 
 /* Diagnostics: one dense layer of the encoder on host buffers, for unit parity tests of the
  * GEMM kernels (E2/E4/E5/E6).  C[M,N] = A[M,K] W[N,K]^T + bias, epilogue 0 = none,
