@@ -13,9 +13,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 def report(d):
     f = glob.glob(d + "/*/*_kernel_trace.csv")[0]
     rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
-    # the last forward: from the last embed_ln_kernel on
-    start = max(i for i, r in enumerate(rows) if "embed_ln_kernel" in r["Kernel_Name"] or "small_forward" in r["Kernel_Name"])
-    fwd = rows[start:]
+    # the last forward: the kernels between the last two pooling kernels
+    pools = [i for i, r in enumerate(rows) if "pool_normalize" in r["Kernel_Name"]]
+    fwd = [r for r in rows[pools[-2] + 1:pools[-1] + 1] if "copyBuffer" not in r["Kernel_Name"] and "fillBuffer" not in r["Kernel_Name"]]
     t0, prev_end = int(fwd[0]["Start_Timestamp"]), None
     tot_k = tot_gap = 0.0
     for r in fwd:

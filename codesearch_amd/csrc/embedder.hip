@@ -15,6 +15,7 @@
 #include "encoder.hpp"
 #include "scan.hpp"  // launch_synth_fill (cs_debug_gemm_time)
 #include "small_forward.hpp"
+#include "small_path.hpp"
 #include "split_f16.hpp"
 #include "gemm_q8.hpp"
 
@@ -88,6 +89,9 @@ struct cs_embedder {
     SfLayer* d_sf_layers = nullptr;
     uint32_t* d_sf_sync = nullptr;
     uint64_t* d_sf_dbg = nullptr;   // CS_SMALL_FORWARD_DEBUG: per-block tick sums of the last launch (printed to stderr)
+    // small_path.hip / small_forward.hip workspace: [4][SP_MAX_ROWS][H] FFN-down K-slice slabs | [SP_MAX_ROWS][H] the residual
+    // stream behind a layer's last LayerNorm (d_x holds it behind the attention block's)
+    float* d_sp_ws = nullptr;
     bool sf_ran = false, sf_off = false;
     uint64_t sf_forwards = 0, sf_fallbacks = 0;
     // dynamically quantised models (gemm_q8.hip): s8 weights per layer (q8_layer), their column metadata, the running
@@ -316,15 +320,22 @@ int32_t forward_range(cs_embedder* h, hipStream_t s, uint32_t b0, uint32_t nb, u
         if (takes_192(Mr, Nn, Kk)) return launch_gemm_wide(epi, Ain, Wt, bias, resid, Cf, Csp, Mr, Nn, Kk, h->d_flag, s, 192);
         return launch_gemm_split(epi, Ain, Wt, bias, resid, Cf, Csp, Mr, Nn, Kk, h->d_flag, s);
     };
-    // A few short sequences (the query side): everything up to the last LayerNorm as ONE launch (small_forward.hip; same
-    // bits as the launches below).  CS_SMALL_FORWARD=0 switches it off; CS_SMALL_FORWARD_MAX_ROWS moves its upper bound.
+    // ---- a few short sequences (under 200 token rows: the query side) ----
+    // small_path.hip: LayerNorm as the prologue of the dense layer that reads it, FFN-down as four K slices summed by the
+    // LayerNorm that follows: 62 launches per 12-layer forward instead of 86, none of them pulling 196 KB through one CU
+    // (CS_SMALL_PATH=0: the general small-batch kernels below).  CS_SMALL_FORWARD=1: the same arithmetic as ONE launch
+    // (small_forward.hip) — bit-identical, measured slower than the launches: opt-in.
     h->sf_ran = false;
-    if (mode == CS_GEMM_SPLIT_F16 && h->d_sf_layers && !h->sf_off && !h->stage_profile && !nomic && b0 == 0 &&
-        small_forward_supported(H, I, c.heads, T, L)) {
-        const char* e = std::getenv("CS_SMALL_FORWARD");  // (read per forward: tests and A/B runs flip it mid-process)
-        const char* em = std::getenv("CS_SMALL_FORWARD_MAX_ROWS");
-        const uint32_t max_rows = em ? (uint32_t)std::atoi(em) : 192u;
-        if (!(e && e[0] == '0') && T <= max_rows) {
+    const char* e0 = std::getenv("CS_SMALL_PATH");  // (read per forward: tests flip it mid-process)
+    const bool sp_on = !(e0 && e0[0] == '0');
+    if (mode == CS_GEMM_SPLIT_F16 && sp_on && !nomic && b0 == 0 && T < 200 && small_path_supported(H, I, T)) {
+        if (!h->d_sp_ws) CS_HIP(hipMalloc(&h->d_sp_ws, (size_t)5 * SP_MAX_ROWS * H * sizeof(float)));
+        float* parts = h->d_sp_ws;                                   // [4][T][H]
+        float* xa = h->d_sp_ws + (size_t)4 * SP_MAX_ROWS * H;        // [T][H]
+        float* y = h->d_xs + t0 * H;                                  // [T][H] (the split copy of x is not used on this path)
+        _Float16* qkvs = reinterpret_cast<_Float16*>(qkv);
+        const char* e1 = std::getenv("CS_SMALL_FORWARD");  // (read per forward: tests and A/B runs flip it mid-process)
+        if (e1 && e1[0] == '1' && h->d_sf_layers && !h->sf_off && !h->stage_profile && small_forward_supported(H, I, c.heads, T, L)) {
             uint32_t hb = L <= 32 ? 4u : (L <= 64 ? 2u : 1u);  // heads per attention block, as launch_attention_sh2 packs them
             if (const char* ph = std::getenv("CS_ATTN_PACK_HEADS")) if (ph[0] == '0') hb = 1;
             while (c.heads % hb) hb >>= 1;
@@ -332,7 +343,7 @@ int32_t forward_range(cs_embedder* h, hipStream_t s, uint32_t b0, uint32_t nb, u
             sa.ids = a.ids; sa.mask = mask; sa.word = a.word; sa.pos = a.pos; sa.type0 = a.type0; sa.emb_g = a.g; sa.emb_b = a.b;
             sa.layers = h->d_sf_layers; sa.n_layers = c.layers; sa.eps = c.layer_norm_eps;
             sa.T = T; sa.L = L; sa.B = nb; sa.vocab = c.vocab_size; sa.heads = c.heads; sa.hb = hb;
-            sa.X = x; sa.Y = h->d_xs + t0 * H; sa.QKVS = reinterpret_cast<_Float16*>(qkv); sa.CTXS = reinterpret_cast<_Float16*>(ctx);
+            sa.X = x; sa.XA = xa; sa.Y = y; sa.PARTS = parts; sa.QKVS = qkvs; sa.CTXS = ctxs;
             sa.MIDS = reinterpret_cast<_Float16*>(mid); sa.flag = h->d_flag; sa.sync = h->d_sf_sync;
             sa.dbg = h->d_sf_dbg;
             CS_HIP(hipMemsetAsync(h->d_sf_sync, 0, 16, s));
@@ -342,6 +353,43 @@ int32_t forward_range(cs_embedder* h, hipStream_t s, uint32_t b0, uint32_t nb, u
             CS_TRY(launch_row_kernel(2, a, H, s));  // E7 + E8
             return CS_OK;
         }
+        _Float16* ctxs2 = ctxs;
+        _Float16* mids2 = reinterpret_cast<_Float16*>(mid);
+        const SplitLayer sl2 = split_layer(c);
+        CS_TRY(mark(-1));
+        for (uint32_t l = 0; l < c.layers; ++l) {
+            cs_bert_layer_offsets lo, lp;
+            cs_bert_layer_layout(&c, &h->off, l, &lo);
+            if (l) cs_bert_layer_layout(&c, &h->off, l - 1, &lp);
+            const _Float16* ws = h->d_wsplit + (size_t)l * sl2.total;
+            SpLnGemmArgs g1{};
+            g1.Y = y; g1.parts = parts; g1.parts_bias = l ? P + lp.down_b : nullptr; g1.X = x;
+            g1.ids = a.ids; g1.word = a.word; g1.pos = a.pos; g1.type0 = a.type0; g1.L = L; g1.vocab = c.vocab_size;
+            g1.ln_g = l ? P + lp.out_ln_g : a.g; g1.ln_b = l ? P + lp.out_ln_b : a.b; g1.eps = c.layer_norm_eps;
+            g1.Xout = xa; g1.W = ws + sl2.qkv; g1.bias = h->d_bqkv + (size_t)l * 3 * H; g1.Cs = qkvs; g1.T = T; g1.N = 3 * H; g1.flag = h->d_flag;
+            CS_TRY(launch_sp_ln_gemm(SH_OUT_SPLIT, l ? 1 : 2, g1, H, s));                                        // (E1 | LN) + E2
+            CS_TRY(mark(CS_STAGE_QKV));
+            CS_TRY(launch_attention_sh2(qkvs, mask, ctxs2, h->d_flag, nb, L, H, c.heads, s));                      // E3
+            CS_TRY(mark(CS_STAGE_ATTENTION));
+            CS_TRY(launch_gemm_split(SH_OUT_F32_RESID, ctxs2, ws + sl2.ao, P + lo.ao_b, xa, y, nullptr, T, H, H, h->d_flag, s));  // E4 -> y
+            CS_TRY(mark(CS_STAGE_OUT_PROJ));
+            SpLnGemmArgs g4 = g1;
+            g4.ln_g = P + lo.ao_ln_g; g4.ln_b = P + lo.ao_ln_b; g4.Xout = x; g4.W = ws + sl2.up; g4.bias = P + lo.up_b; g4.Cs = mids2; g4.N = I;
+            CS_TRY(launch_sp_ln_gemm(SH_OUT_SPLIT_GELU, 0, g4, H, s));                                           // LN + E5
+            CS_TRY(mark(CS_STAGE_FFN_UP));
+            CS_TRY(launch_sp_partial(mids2, ws + sl2.down, parts, T, H, H, s));                                  // E6, four K slices
+            CS_TRY(mark(CS_STAGE_FFN_DOWN));
+        }
+        cs_bert_layer_offsets ll;
+        cs_bert_layer_layout(&c, &h->off, c.layers - 1, &ll);
+        a.parts = parts; a.nparts = 4; a.bias = P + ll.down_b; a.g = P + ll.out_ln_g; a.b = P + ll.out_ln_b;
+        a.xs = nullptr;
+        CS_TRY(launch_row_kernel(3, a, H, s));  // the last LayerNorm: (slabs + bias) + x -> x
+        CS_TRY(mark(CS_STAGE_LN_FFN));
+        h->last_hidden_partial = false;
+        CS_TRY(launch_row_kernel(2, a, H, s));  // E7 + E8
+        CS_TRY(mark(CS_STAGE_POOL));
+        return CS_OK;
     }
     CS_TRY(mark(-1));
     CS_TRY(launch_row_kernel(0, a, H, s));  // E1
@@ -1469,6 +1517,7 @@ void cs_embedder_destroy(cs_embedder* h) {
     if (h->d_sf_layers) (void)hipFree(h->d_sf_layers);
     if (h->d_sf_sync) (void)hipFree(h->d_sf_sync);
     if (h->d_sf_dbg) (void)hipFree(h->d_sf_dbg);
+    if (h->d_sp_ws) (void)hipFree(h->d_sp_ws);
     if (h->d_wq8) (void)hipFree(h->d_wq8);
     if (h->d_cmeta) (void)hipFree(h->d_cmeta);
     for (hipEvent_t e : h->stage_ev) (void)hipEventDestroy(e);

@@ -43,13 +43,13 @@ typedef unsigned int sf_u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int sf_u32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int SF_GRID = 96;                         // resident blocks: the widest phase (FFN-up: 1536 / 16 column tiles)
-constexpr int SF_W_BYTES = 16 * 48 * 128;           // one 16-row weight tile of K <= 1536: [chunk][16 rows][128 B], swizzled
+constexpr int SF_W_BYTES = 16 * 12 * 128;           // one 16-row weight tile of 12 k-chunks: [chunk][16 rows][128 B], swizzled
 constexpr int SF_AROW = 384 * 4 + 16;               // a split row of the A image (12 lines) + 16 B: conflict-free ds_read_b128
 constexpr int SF_AIMG = 16 * SF_AROW;               // 24,832
 constexpr int SF_RED = 4 * 16 * 17 * 4;             // the four waves' partial tiles
 constexpr int SF_ATT = 2 * 128 * 128 + 512 * 4 + 16;  // attention_shx_body<1>: K | V images of 128 keys, mask of <= 512 keys
 constexpr int SF_OFF_AIMG = SF_W_BYTES, SF_OFF_RED = SF_W_BYTES + SF_AIMG, SF_OFF_ATT = SF_W_BYTES;
-constexpr int SF_LDS = SF_W_BYTES + (SF_ATT > SF_AIMG + SF_RED ? SF_ATT : SF_AIMG + SF_RED);  // 133,136
+constexpr int SF_LDS = SF_W_BYTES + (SF_ATT > SF_AIMG + SF_RED ? SF_ATT : SF_AIMG + SF_RED);  // 59,408
 constexpr int SC1 = 16;                             // aux of the raw buffer intrinsics: sc1
 
 // One tensor other blocks write or read inside the launch: every access is a buffer instruction with sc1.
@@ -95,13 +95,15 @@ struct SfMap {
 // [chunk][row][128 B], 16-B slot c at c ^ ((row >> 1) & 7) (permutation on the SOURCE address: the DMA destination is
 // lane-linear).  Pieces of 8 rows x 128 B = 2 kchunks of them, dealt to waves 1..3 (wave 0's lane 0 polls the grid
 // barrier behind this: its queue stays empty).
-__device__ __forceinline__ void sf_w_prefetch(char* lds, const _Float16* __restrict__ W, uint32_t nt, uint32_t kchunks, int wave, int lane) {
+// c0, nc: the window of k-chunks brought in (image chunk c = row chunk c0 + c); kchunks: chunks per row of W.
+__device__ __forceinline__ void sf_w_prefetch(char* lds, const _Float16* __restrict__ W, uint32_t nt, uint32_t kchunks, uint32_t c0,
+                                              uint32_t nc, int wave, int lane) {
     if (wave == 0) return;
-    const uint32_t pieces = 2 * kchunks;
+    const uint32_t pieces = 2 * nc;
     for (uint32_t p = wave - 1; p < pieces; p += 3) {
         const uint32_t c = p >> 1, row = (p & 1) * 8 + (lane >> 3);
         const uint32_t slot = (lane & 7) ^ ((row >> 1) & 7);
-        sh_glds16(W + ((size_t)(16 * nt + row) * kchunks + c) * 64 + slot * 8, lds + p * 1024);
+        sh_glds16(W + ((size_t)(16 * nt + row) * kchunks + c0 + c) * 64 + slot * 8, lds + p * 1024);
     }
 }
 
@@ -136,8 +138,8 @@ small_forward_kernel(SfArgs a) {
     float (*red)[16][17] = reinterpret_cast<float (*)[16][17]>(lds + SF_OFF_RED);
     __shared__ int s_abort;
 
-    const Sc1Buf bX(a.X, (size_t)T * H * 4), bY(a.Y, (size_t)T * H * 4), bQ(a.QKVS, (size_t)T * 3 * H * 4),
-        bC(a.CTXS, (size_t)T * H * 4), bM(a.MIDS, (size_t)T * I * 4);
+    const Sc1Buf bX(a.X, (size_t)T * H * 4), bXA(a.XA, (size_t)T * H * 4), bY(a.Y, (size_t)T * H * 4), bP(a.PARTS, (size_t)4 * T * H * 4),
+        bQ(a.QKVS, (size_t)T * 3 * H * 4), bC(a.CTXS, (size_t)T * H * 4), bM(a.MIDS, (size_t)T * I * 4);
 
     uint32_t target = 0;
     bool ovf = false;
@@ -151,7 +153,9 @@ small_forward_kernel(SfArgs a) {
     };
 
     // ---- grid barrier + the prefetch of the next phase's weight tile ----
-    auto barrier = [&](const _Float16* Wnext, uint32_t NTnext, uint32_t kc_next, uint32_t code) -> bool {
+    // Wnext: the next phase's weight ([NTnext * 16][kc_next chunks per row]); kslices != 0: that phase cuts K into four
+    // slices by block group (FFN-down), each block needing only its slice of the tile's rows
+    auto barrier = [&](const _Float16* Wnext, uint32_t NTnext, uint32_t kc_next, uint32_t code, bool kslices = false) -> bool {
         if (a.dbg) { const uint64_t t = __builtin_amdgcn_s_memrealtime(); t_ph[(code - 1) % 5 < 5 ? (code - 1) % 5 : 0] += t - t_mark; }
         stamp(t_compute);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // EVERY wave drains its write-through stores (R1)
@@ -160,7 +164,10 @@ small_forward_kernel(SfArgs a) {
         __syncthreads();                                  // ... and is done with this phase's LDS
         if (Wnext) {
             const SfMap m(NTnext, blk);
-            if (m.active) sf_w_prefetch(lds_w, Wnext, m.nt, kc_next, wave, lane);
+            if (m.active) {
+                if (kslices) sf_w_prefetch(lds_w, Wnext, m.nt, kc_next, m.mt0 * (kc_next / 4), kc_next / 4, wave, lane);
+                else sf_w_prefetch(lds_w, Wnext, m.nt, kc_next, 0, kc_next, wave, lane);
+            }
         }
         target += SF_GRID;
         if (tid == 0) {
@@ -185,13 +192,16 @@ small_forward_kernel(SfArgs a) {
 
     // ---- LayerNorm prologue: the 16 rows of m-tile mt -> the A image in LDS (split form); the leader also writes X ----
     // emb != 0: the rows are the embedding gather (word + type + position), else Y's.
-    auto ln_prologue = [&](uint32_t mt, const float* gw, const float* bw, bool emb, bool leader) {
+    // src 0: Y's rows; 1: (the four FFN-down slabs in order + pbias) + X's row (layernorm_sum_kernel's order); 2: the embedding
+    // gather.  The leader writes the normalised rows to `xout` / its accessor (never the buffer src 1 reads its residual from).
+    auto ln_prologue = [&](uint32_t mt, const float* gw, const float* bw, int src, const float* pbias, bool leader, float* xout,
+                           const Sc1Buf& bout) {
         // this wave's four rows: every load of all four in flight before the first is used (one memory latency, not four)
         float v[4][NPL];
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
             const uint32_t t_raw = 16 * mt + 4 * wave + rr, t = t_raw < T ? t_raw : T - 1;
-            if (emb) {
+            if (src == 2) {
                 uint32_t id = (uint32_t)a.ids[t];
                 if (id >= a.vocab) id = 0;
                 const float* we = a.word + (size_t)id * H;
@@ -204,6 +214,15 @@ small_forward_kernel(SfArgs a) {
                     const float2 p2 = *reinterpret_cast<const float2*>(pe + c);
                     v[rr][2 * p] = (w2.x + t2.x) + p2.x;
                     v[rr][2 * p + 1] = (w2.y + t2.y) + p2.y;
+                }
+            } else if (src == 1) {
+#pragma unroll
+                for (int i = 0; i < NPL; ++i) {
+                    const int c = ln_col(lane, i);
+                    float acc = bP.ld4(a.PARTS + (size_t)t * H + c);
+#pragma unroll
+                    for (uint32_t sl = 1; sl < 4; ++sl) acc += bP.ld4(a.PARTS + ((size_t)sl * T + t) * H + c);
+                    v[rr][i] = (acc + pbias[c]) + bX.ld4(a.X + (size_t)t * H + c);
                 }
             } else {
 #pragma unroll
@@ -227,7 +246,7 @@ small_forward_kernel(SfArgs a) {
                 ovf |= sh_split(o[2 * p + 1], x0, x1); hi[1] = x0; lo[1] = x1;
                 *reinterpret_cast<f16x2*>(irow + (c >> 5) * 128 + (c & 31) * 2) = hi;
                 *reinterpret_cast<f16x2*>(irow + (c >> 5) * 128 + 64 + (c & 31) * 2) = lo;
-                if (leader && t_raw < T) bX.st8(a.X + (size_t)t * H + c, make_float2(o[2 * p], o[2 * p + 1]));
+                if (leader && t_raw < T) bout.st8(xout + (size_t)t * H + c, make_float2(o[2 * p], o[2 * p + 1]));
             }
         }
         __syncthreads();
@@ -235,9 +254,12 @@ small_forward_kernel(SfArgs a) {
 
     // ---- one 16 x 16 output tile: gemm_sh_skinny_kernel<EPI, 1, 1> with W from the LDS image ----
     // PRO: A from the LDS image the prologue left; else from `Ag` (split rows, sc1).  U = kchunks / 4.
-    auto tile = [&](auto u_tag, auto epi_tag, bool a_from_img, const Sc1Buf* bA, const _Float16* Ag, uint32_t kchunks, uint32_t mt,
-                    uint32_t nt, const float* bias, const Sc1Buf* bOut, uint32_t N, float* Cf, _Float16* Cs) {
-        constexpr int U = decltype(u_tag)::value;
+    // EPI: SH_OUT_SPLIT | SH_OUT_SPLIT_GELU (split rows -> Cs) | SH_OUT_F32_RESID (+ bias + XA's row -> Cf) | SH_OUT_PARTIAL (raw
+    // sums of K slice `ks` -> slab ks of Cf: no bias).  A: the LDS image the prologue left (a_from_img) or split rows `Ag` of
+    // akc chunks each, read from chunk ac0 on.  Three k-chunks per wave (K = 384, or a quarter of K = 1536).
+    auto tile = [&](auto epi_tag, bool a_from_img, const Sc1Buf* bA, const _Float16* Ag, uint32_t akc, uint32_t ac0, uint32_t mt,
+                    uint32_t nt, const float* bias, const Sc1Buf* bOut, uint32_t N, float* Cf, _Float16* Cs, uint32_t ks) {
+        constexpr int U = 3;
         constexpr int EPI = decltype(epi_tag)::value;
         const uint32_t m0 = 16 * mt, n0 = 16 * nt;
         f16x8 ah[U], al[U];
@@ -250,7 +272,7 @@ small_forward_kernel(SfArgs a) {
             }
         } else {
             const uint32_t r = m0 + l15;
-            const _Float16* ap = Ag + (size_t)(r < T ? r : T - 1) * kchunks * 64 + 8 * g;
+            const _Float16* ap = Ag + ((size_t)(r < T ? r : T - 1) * akc + ac0) * 64 + 8 * g;
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 ah[u] = bA->ld16(ap + (size_t)(wave + 4 * u) * 64);
@@ -261,22 +283,22 @@ small_forward_kernel(SfArgs a) {
         // more dependent memory round trips per tile)
         const int m = tid >> 4, n = tid & 15;
         const uint32_t row = m0 + m, col = n0 + n;
-        const float bias_v = bias[col];
-        float resid_v = 0.0f;
-        if constexpr (EPI == SH_OUT_F32_RESID) resid_v = bX.ld4(a.X + (size_t)(row < T ? row : T - 1) * N + col);
+        float bias_v = 0.0f, resid_v = 0.0f;
+        if constexpr (EPI != SH_OUT_PARTIAL) bias_v = bias[col];
+        if constexpr (EPI == SH_OUT_F32_RESID) resid_v = bXA.ld4(a.XA + (size_t)(row < T ? row : T - 1) * N + col);
         sh_f32x4v hh = {0.f, 0.f, 0.f, 0.f}, xx = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int u = 0; u < U; ++u) sf_chunk_mma(lds_w, wave + 4 * u, l15, g, ah[u], al[u], hh, xx);
 #pragma unroll
         for (int r = 0; r < 4; ++r) red[wave][4 * g + r][l15] = fmaf(xx[r], kShLoInv, hh[r]);
         __syncthreads();
-        float v = (red[0][m][n] + red[1][m][n]) + (red[2][m][n] + red[3][m][n]) + bias_v;
-        if constexpr (EPI == SH_OUT_F32_RESID) {
-            if (row < T) {
-                v += resid_v;
-                bOut->st4(Cf + (size_t)row * N + col, v);
-            }
+        float v = (red[0][m][n] + red[1][m][n]) + (red[2][m][n] + red[3][m][n]);
+        if constexpr (EPI == SH_OUT_PARTIAL) {
+            if (row < T) bOut->st4(Cf + ((size_t)ks * T + row) * N + col, v);
+        } else if constexpr (EPI == SH_OUT_F32_RESID) {
+            if (row < T) bOut->st4(Cf + (size_t)row * N + col, (v + bias_v) + resid_v);
         } else {
+            v += bias_v;
             if (EPI == SH_OUT_SPLIT_GELU) v = sh_gelu_erf(v);
             _Float16 hi, lo;
             ovf |= sh_split(v, hi, lo);
@@ -292,11 +314,10 @@ small_forward_kernel(SfArgs a) {
         __syncthreads();  // `red` (and the A image) are reused by the block's next tile
     };
 
-    using U3 = std::integral_constant<int, 3>;
-    using U12 = std::integral_constant<int, 12>;
     using E_SPLIT = std::integral_constant<int, SH_OUT_SPLIT>;
     using E_GELU = std::integral_constant<int, SH_OUT_SPLIT_GELU>;
     using E_RESID = std::integral_constant<int, SH_OUT_F32_RESID>;
+    using E_PART = std::integral_constant<int, SH_OUT_PARTIAL>;
 
     constexpr uint32_t NT_QKV = 3 * H / 16, NT_H = H / 16, NT_I = I / 16;
     const float scale_log2e = (1.0f / sqrtf(32.0f)) * kLog2e;
@@ -304,22 +325,24 @@ small_forward_kernel(SfArgs a) {
     // the first phase's weight tile
     {
         const SfMap m(NT_QKV, blk);
-        if (m.active) sf_w_prefetch(lds_w, a.layers[0].wqkv, m.nt, KC_H, wave, lane);
+        if (m.active) sf_w_prefetch(lds_w, a.layers[0].wqkv, m.nt, KC_H, 0, KC_H, wave, lane);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
 
     for (uint32_t l = 0; l < a.n_layers; ++l) {
         const SfLayer ly = a.layers[l];
-        // ---- E2: LayerNorm (or the embedding) as prologue, QKV projection -> QKVS ----
+        // ---- E2: the previous layer's last LayerNorm (over its FFN-down slabs + bias + residual) — or the embedding — as
+        // prologue, QKV projection -> QKVS; the leader leaves the normalised rows in XA ----
         {
             const SfMap m(NT_QKV, blk);
             if (m.active) {
                 const float* gw = l ? a.layers[l - 1].ln2_g : a.emb_g;
                 const float* bw = l ? a.layers[l - 1].ln2_b : a.emb_b;
+                const float* pb = l ? a.layers[l - 1].bdown : nullptr;
                 for (uint32_t mt = m.mt0; mt < MT; mt += m.mt_step) {
-                    ln_prologue(mt, gw, bw, l == 0, m.nt == 0);
-                    tile(U3{}, E_SPLIT{}, true, nullptr, nullptr, KC_H, mt, m.nt, ly.bqkv, &bQ, 3 * H, nullptr, a.QKVS);
+                    ln_prologue(mt, gw, bw, l ? 1 : 2, pb, m.nt == 0, a.XA, bXA);
+                    tile(E_SPLIT{}, true, nullptr, nullptr, 0, 0, mt, m.nt, ly.bqkv, &bQ, 3 * H, nullptr, a.QKVS, 0);
                 }
             }
         }
@@ -336,41 +359,47 @@ small_forward_kernel(SfArgs a) {
             }
         }
         if (!barrier(nullptr, 0, 0, 5 * l + 2)) return;
-        // ---- E4: out-proj + bias + residual -> Y ----
+        // ---- E4: out-proj + bias + residual (XA) -> Y ----
         {
             const SfMap m(NT_H, blk);
             if (m.active)
                 for (uint32_t mt = m.mt0; mt < MT; mt += m.mt_step)
-                    tile(U3{}, E_RESID{}, false, &bC, a.CTXS, KC_H, mt, m.nt, ly.bo, &bY, H, a.Y, nullptr);
+                    tile(E_RESID{}, false, &bC, a.CTXS, KC_H, 0, mt, m.nt, ly.bo, &bY, H, a.Y, nullptr, 0);
         }
         if (!barrier(ly.wup, NT_I, KC_H, 5 * l + 3)) return;
-        // ---- E5: LayerNorm as prologue, FFN-up + GELU -> MIDS ----
+        // ---- E5: the attention block's LayerNorm as prologue (the leader leaves the rows in X), FFN-up + GELU -> MIDS ----
         {
             const SfMap m(NT_I, blk);
             if (m.active)
                 for (uint32_t mt = m.mt0; mt < MT; mt += m.mt_step) {
-                    ln_prologue(mt, ly.ln1_g, ly.ln1_b, false, m.nt == 0);
-                    tile(U3{}, E_GELU{}, true, nullptr, nullptr, KC_H, mt, m.nt, ly.bup, &bM, I, nullptr, a.MIDS);
+                    ln_prologue(mt, ly.ln1_g, ly.ln1_b, 0, nullptr, m.nt == 0, a.X, bX);
+                    tile(E_GELU{}, true, nullptr, nullptr, 0, 0, mt, m.nt, ly.bup, &bM, I, nullptr, a.MIDS, 0);
                 }
         }
-        if (!barrier(ly.wdown, NT_H, KC_I, 5 * l + 4)) return;
-        // ---- E6: FFN-down + bias + residual -> Y ----
+        if (!barrier(ly.wdown, NT_H, KC_I, 5 * l + 4, true)) return;
+        // ---- E6: FFN-down as four K slices (block group = slice) -> PARTS; summed by the next LayerNorm ----
         {
-            const SfMap m(NT_H, blk);
+            const SfMap m(NT_H, blk);  // groups = 4: m.mt0 is the K slice here, every block walks all row tiles
             if (m.active)
-                for (uint32_t mt = m.mt0; mt < MT; mt += m.mt_step)
-                    tile(U12{}, E_RESID{}, false, &bM, a.MIDS, KC_I, mt, m.nt, ly.bdown, &bY, H, a.Y, nullptr);
+                for (uint32_t mt = 0; mt < MT; ++mt)
+                    tile(E_PART{}, false, &bM, a.MIDS, KC_I, m.mt0 * (KC_I / 4), mt, m.nt, nullptr, &bP, H, a.PARTS, nullptr, m.mt0);
         }
         const bool last = l + 1 == a.n_layers;
         if (!barrier(last ? nullptr : a.layers[l + 1].wqkv, NT_QKV, KC_H, 5 * l + 5)) return;
     }
-    // ---- the last LayerNorm: Y -> X (the last hidden state the pooling kernel reads) ----
+    // ---- the last LayerNorm: (slabs + bias) + X -> X, in place (the last hidden state the pooling kernel reads) ----
     {
         const SfLayer ly = a.layers[a.n_layers - 1];
         for (uint32_t t = 4 * blk + wave; t < T; t += 4 * SF_GRID) {
             float v[NPL], o[NPL];
 #pragma unroll
-            for (int i = 0; i < NPL; ++i) v[i] = bY.ld4(a.Y + (size_t)t * H + ln_col(lane, i));
+            for (int i = 0; i < NPL; ++i) {
+                const int c = ln_col(lane, i);
+                float acc = bP.ld4(a.PARTS + (size_t)t * H + c);
+#pragma unroll
+                for (uint32_t sl = 1; sl < 4; ++sl) acc += bP.ld4(a.PARTS + ((size_t)sl * T + t) * H + c);
+                v[i] = (acc + ly.bdown[c]) + bX.ld4(a.X + (size_t)t * H + c);
+            }
             ln_row_core<NPL>(v, ly.ln2_g, ly.ln2_b, a.eps, lane, o);
 #pragma unroll
             for (int p = 0; p < NPL / 2; ++p)

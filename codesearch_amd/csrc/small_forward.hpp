@@ -19,8 +19,10 @@ struct SfArgs {
     uint32_t n_layers;
     float eps;
     uint32_t T, L, B, vocab, heads, hb;
-    float* X;          // [T, H] f32: the residual stream behind each LayerNorm
-    float* Y;          // [T, H] f32: dense layer + bias + residual in front of each LayerNorm
+    float* X;          // [T, H] f32: the residual stream behind the attention block's LayerNorm (and, at the end, the last hidden state)
+    float* XA;         // [T, H] f32: the residual stream behind a layer's last LayerNorm (the next layer's input)
+    float* Y;          // [T, H] f32: out-proj + bias + residual, in front of the attention block's LayerNorm
+    float* PARTS;      // [4][T][H] f32: FFN-down's four K slices (summed, with bias and residual, by the LayerNorm that follows)
     _Float16* QKVS;    // [T][3H/32][64]
     _Float16* CTXS;    // [T][H/32][64]
     _Float16* MIDS;    // [T][I/32][64]

@@ -1,11 +1,12 @@
-"""The one-launch forward of short queries (csrc/small_forward.hip) against the kernel-by-kernel path it replaces for
-mini-batches of a few short sequences — the query side of `codesearch search` (EmbeddingService::embed_query /
-embed_queries_batch, /root/reference/src/embed/mod.rs:164-226: one query and up to eight variants).
+"""Mini-batches of a few short sequences — the query side of `codesearch search` (EmbeddingService::embed_query /
+embed_queries_batch, /root/reference/src/embed/mod.rs:164-226: one query and up to eight variants) — take the small path
+(csrc/small_path.hip: LayerNorm as the dense layers' prologue, FFN-down in four K slices; default under 200 token rows) or,
+opt-in (CS_SMALL_FORWARD=1), the same arithmetic as ONE kernel launch (csrc/small_forward.hip).
 
-Bar: the SAME BITS.  The persistent kernel runs the same arithmetic (dense-layer tiles of gemm_sh_skinny_kernel, LayerNorm
-of ln_row_core, attention of attention_shx_body) behind grid barriers with write-through (sc1) hand-offs instead of kernel
-boundaries; any stale read of another block's data would show as a differing embedding.  Both paths are also held to the
-oracle at the usual 2e-5."""
+Bars: the small path against the oracle at the usual 2e-5 (and against the general small-batch kernels, CS_SMALL_PATH=0,
+which sum FFN-down in another order); the one-launch form against the small path BIT FOR BIT — it runs the same arithmetic
+behind grid barriers with write-through (sc1) hand-offs instead of kernel boundaries, so any stale read of another block's
+data would show as a differing embedding."""
 import os
 import threading
 
@@ -41,19 +42,29 @@ def test_one_launch_forward_gives_the_bits_of_the_kernel_by_kernel_path(monkeypa
     emb.close()
 
 
-def test_one_launch_forward_matches_the_oracle(monkeypatch):
+@pytest.mark.parametrize("hidden,heads,B,L", [(384, 12, 9, 16), (384, 12, 1, 7), (768, 12, 3, 20), (1024, 16, 2, 33)])
+def test_small_path_and_one_launch_forward_match_the_oracle(monkeypatch, hidden, heads, B, L):
+    """384-, 768- and 1024-wide models (head_dim 32 and 64): the small path against the oracle and against the general
+    small-batch kernels; the one-launch form (384-wide models only: elsewhere the switch changes nothing) the same bits."""
     from codesearch_amd import BertConfig, FastEmbedder, ModelType
     from codesearch_amd.bert_params import POOL_MEAN, synth_token_batch
     from tests.oracle_lib import load_oracle
 
     oracle = load_oracle()
-    cfg = BertConfig(vocab_size=1024, layers=6, pooling=POOL_MEAN)
-    emb = FastEmbedder(ModelType.AllMiniLML6V2, config=cfg, seed=77, device=0)
-    ids, mask = synth_token_batch(cfg, 78, 9, 16, True)
-    got = _embed(emb, ids, mask, True, monkeypatch)
-    assert emb.small_forward_counters() == (1, 0)
+    cfg = BertConfig(vocab_size=1024, hidden=hidden, heads=heads, intermediate=4 * hidden, layers=3, pooling=POOL_MEAN)
+    mt = {384: ModelType.AllMiniLML6V2, 768: ModelType.BGEBaseENV15, 1024: ModelType.BGELargeENV15}[hidden]
+    emb = FastEmbedder(mt, config=cfg, seed=77, device=0)
+    ids, mask = synth_token_batch(cfg, 78, B, L, True)
     exp = oracle.bert_forward(cfg, oracle.bert_synth_params(cfg, 77), ids, mask)["pooled"]
-    assert float(np.abs(got - exp).max()) < 2e-5
+    small = _embed(emb, ids, mask, False, monkeypatch)
+    assert float(np.abs(small - exp).max()) < 2e-5
+    one = _embed(emb, ids, mask, True, monkeypatch)
+    assert one.tobytes() == small.tobytes()
+    assert emb.small_forward_counters() == ((1, 0) if hidden == 384 else (0, 0))
+    monkeypatch.setenv("CS_SMALL_PATH", "0")
+    general = _embed(emb, ids, mask, False, monkeypatch)
+    monkeypatch.delenv("CS_SMALL_PATH")
+    assert float(np.abs(general - exp).max()) < 2e-5 and float(np.abs(general - small).max()) < 2e-6
     emb.close()
 
 
@@ -96,19 +107,21 @@ def test_one_launch_forward_under_other_gpu_work(monkeypatch):
     store.close()
 
 
-def test_more_rows_than_the_bound_take_the_kernel_by_kernel_path(monkeypatch):
+def test_200_rows_and_more_take_the_general_kernels(monkeypatch):
     from codesearch_amd import BertConfig, FastEmbedder, ModelType
     from codesearch_amd.bert_params import POOL_CLS, synth_token_batch
 
     cfg = BertConfig(vocab_size=512, layers=2, pooling=POOL_CLS)
     emb = FastEmbedder(ModelType.BGESmallENV15, config=cfg, seed=3, device=0)
     ids, mask = synth_token_batch(cfg, 4, 16, 64, False)  # 1,024 rows
-    _embed(emb, ids, mask, True, monkeypatch)
+    big = _embed(emb, ids, mask, True, monkeypatch)
     assert emb.small_forward_counters() == (0, 0)
-    monkeypatch.setenv("CS_SMALL_FORWARD_MAX_ROWS", "64")
-    ids, mask = synth_token_batch(cfg, 4, 4, 16, False)   # 64 rows: taken
+    monkeypatch.setenv("CS_SMALL_PATH", "0")
+    assert _embed(emb, ids, mask, True, monkeypatch).tobytes() == big.tobytes()  # the switch changes nothing up there
+    monkeypatch.delenv("CS_SMALL_PATH")
+    ids, mask = synth_token_batch(cfg, 4, 12, 16, False)  # 192 rows: the small path, and its one-launch form on request
     _embed(emb, ids, mask, True, monkeypatch)
-    ids, mask = synth_token_batch(cfg, 4, 5, 16, False)   # 80 rows: not
+    ids, mask = synth_token_batch(cfg, 4, 13, 16, False)  # 208 rows: not
     _embed(emb, ids, mask, True, monkeypatch)
     assert emb.small_forward_counters() == (1, 0)
     emb.close()
