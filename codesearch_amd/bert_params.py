@@ -11,7 +11,8 @@ import numpy as np
 from .synth import synth_below, synth_int
 
 POOL_CLS, POOL_MEAN = 0, 1
-ARCH_BERT, ARCH_NOMIC = 0, 1  # cs_encoder_arch
+ARCH_BERT, ARCH_NOMIC, ARCH_JINA, ARCH_JINA_QKNORM = 0, 1, 2, 3  # cs_encoder_arch
+GATED_ARCHS = (ARCH_NOMIC, ARCH_JINA, ARCH_JINA_QKNORM)      # no position table, a gate projection per layer
 
 # kind -> (shift, base); cs_bert_synth_rule
 _RULE = {
@@ -32,6 +33,8 @@ class BertConfig:
     layer_norm_eps: float = 1e-12
     pooling: int = POOL_CLS
     arch: int = ARCH_BERT          # ARCH_NOMIC: rotary positions on Q / K, fc2(fc11(x) * silu(fc12(x))), no position table
+    #                                ARCH_JINA[_QKNORM]: ALiBi on the scores, down(value * gelu(gate)), no position table
+    #                                (_QKNORM: LayerNorm on the whole query / key rows)
     rotary_base: float = 0.0
 
     @staticmethod
@@ -52,7 +55,8 @@ def tensor_table(cfg: BertConfig) -> List[Tuple[str, Tuple[int, ...], str]]:
     order without the position table and with the gate projection behind the up projection (cs_bert_params.h); the names
     are this table's own — `nomic_state_dict_names` maps a NomicBert checkpoint onto them."""
     H, I = cfg.hidden, cfg.intermediate
-    nomic = cfg.arch == ARCH_NOMIC
+    nomic = cfg.arch in GATED_ARCHS
+    qkn = cfg.arch == ARCH_JINA_QKNORM
     t = [
         ("embeddings.word_embeddings.weight", (cfg.vocab_size, H), "emb"),
     ] + ([] if nomic else [("embeddings.position_embeddings.weight", (cfg.max_position, H), "emb")]) + [
@@ -66,6 +70,9 @@ def tensor_table(cfg: BertConfig) -> List[Tuple[str, Tuple[int, ...], str]]:
             (p + "attention.self.query.weight", (H, H), "qk_w"), (p + "attention.self.query.bias", (H,), "bias"),
             (p + "attention.self.key.weight", (H, H), "qk_w"), (p + "attention.self.key.bias", (H,), "bias"),
             (p + "attention.self.value.weight", (H, H), "v_w"), (p + "attention.self.value.bias", (H,), "bias"),
+        ] + ([(p + "attention.self.layer_norm_q.weight", (H,), "ln_g"), (p + "attention.self.layer_norm_q.bias", (H,), "ln_b"),
+              (p + "attention.self.layer_norm_k.weight", (H,), "ln_g"), (p + "attention.self.layer_norm_k.bias", (H,), "ln_b")]
+             if qkn else []) + [
             (p + "attention.output.dense.weight", (H, H), "ao_w"), (p + "attention.output.dense.bias", (H,), "bias"),
             (p + "attention.output.LayerNorm.weight", (H,), "ln_g"), (p + "attention.output.LayerNorm.bias", (H,), "ln_b"),
             (p + "intermediate.dense.weight", (I, H), "up_w"), (p + "intermediate.dense.bias", (I,), "bias"),
@@ -171,6 +178,93 @@ def nomic_config_from_hf(cfg_json: dict, max_length: int = 512) -> BertConfig:
                       rotary_base=float(cfg_json.get("rotary_emb_base", 10000.0)))
 
 
+def jina_config_from_hf(cfg_json: dict, max_length: int = 512, qk_norm: bool = True) -> BertConfig:
+    """config.json of a JinaBert checkpoint (jinaai/jina-embeddings-v2-base-code: model_type "bert" with
+    position_embedding_type "alibi" and feed_forward_type "geglu") -> BertConfig(arch=ARCH_JINA[_QKNORM]).  Whether the
+    attention carries layer_norm_q / layer_norm_k is a property of the modelling file the config's auto_map names
+    ("...qk-post-norm..."), else of the checkpoint's tensors: `qk_norm` is the fallback.  max_position is the sequence
+    bound the tokenizer truncates to (ALiBi has no table to size; the reference's chunks end at 512 tokens)."""
+    if cfg_json.get("position_embedding_type") != "alibi":
+        raise ValueError("not a JinaBert (alibi) configuration")
+    if cfg_json.get("feed_forward_type", "original") != "geglu":
+        raise ValueError(f"JinaBert with feed_forward_type {cfg_json.get('feed_forward_type')!r} is not built (only 'geglu')")
+    if cfg_json.get("hidden_act", "gelu") != "gelu":
+        raise ValueError("only erf-GELU encoders are supported")
+    am = " ".join(str(v) for v in (cfg_json.get("auto_map") or {}).values())
+    if am:
+        qk_norm = "qk-post-norm" in am
+    return BertConfig(vocab_size=cfg_json["vocab_size"], hidden=cfg_json["hidden_size"],
+                      layers=cfg_json["num_hidden_layers"], heads=cfg_json["num_attention_heads"],
+                      intermediate=cfg_json["intermediate_size"],
+                      max_position=min(max_length, cfg_json.get("max_position_embeddings", max_length)),
+                      type_vocab_size=cfg_json.get("type_vocab_size", 2),
+                      layer_norm_eps=cfg_json.get("layer_norm_eps", 1e-12), pooling=POOL_MEAN,
+                      arch=ARCH_JINA_QKNORM if qk_norm else ARCH_JINA)
+
+
+def from_jina_state_dict(cfg: BertConfig, sd) -> np.ndarray:
+    """A JinaBert state dict -> the flat block of an ARCH_JINA[_QKNORM] config.  BERT names throughout, except the
+    feed-forward: `mlp.up_gated_layer` [2I, H] (qk-post-norm file: rows [0, I) are the value, rows [I, 2I) go through GELU)
+    or `mlp.gated_layers` (the first modelling file: rows [0, I) go through GELU, rows [I, 2I) are the value), `mlp.down_layer`
+    / `mlp.wo`, `mlp.layernorm`.  The up projection has no bias (zero slots)."""
+    assert cfg.arch in (ARCH_JINA, ARCH_JINA_QKNORM)
+    I = cfg.intermediate
+
+    def get(name):
+        for key in (name, "bert." + name, "model." + name):
+            if key in sd:
+                a = sd[key]
+                return a.detach().cpu().numpy() if hasattr(a, "detach") else np.asarray(a)
+        return None
+
+    mapped = {}
+    for l in range(cfg.layers):
+        p = f"encoder.layer.{l}."
+        up = get(p + "mlp.up_gated_layer.weight")
+        if up is not None:
+            value, gate = up[:I], up[I:]
+            down = "mlp.down_layer"
+        else:
+            up = get(p + "mlp.gated_layers.weight")
+            if up is None:
+                raise ValueError(f"the checkpoint holds no gated up projection for layer {l}")
+            gate, value = up[:I], up[I:]
+            down = "mlp.wo"
+        if tuple(up.shape) != (2 * I, cfg.hidden):
+            raise ValueError(f"{p}mlp up projection: expected {(2 * I, cfg.hidden)}, got {up.shape}")
+        mapped[p + "intermediate.dense.weight"], mapped[p + "intermediate.gate.weight"] = value, gate
+        mapped[p + "output.dense.weight"], mapped[p + "output.dense.bias"] = get(p + down + ".weight"), get(p + down + ".bias")
+        mapped[p + "output.LayerNorm.weight"], mapped[p + "output.LayerNorm.bias"] = get(p + "mlp.layernorm.weight"), get(p + "mlp.layernorm.bias")
+    out = np.zeros(param_count(cfg), np.float32)
+    off = 0
+    for name, shape, kind in tensor_table(cfg):
+        n = int(np.prod(shape))
+        a = mapped[name] if name in mapped else get(name)
+        if a is None:
+            if not (kind == "bias" and ".intermediate." in name):
+                raise ValueError(f"the checkpoint holds nothing for {name}")
+        else:
+            if tuple(a.shape) != tuple(shape):
+                raise ValueError(f"{name}: expected {shape}, got {a.shape}")
+            out[off:off + n] = a.astype(np.float32).reshape(-1)
+        off += n
+    return out
+
+
+def alibi_slopes(heads: int) -> np.ndarray:
+    """JinaBert's `_get_alibi_head_slopes`: Python floats, then an f32 tensor."""
+    import math
+
+    def pow2(n):
+        start = 2 ** (-(2 ** -(math.log2(n) - 3)))
+        return [start * start ** i for i in range(n)]
+
+    if math.log2(heads).is_integer():
+        return np.asarray(pow2(heads), np.float32)
+    closest = 2 ** math.floor(math.log2(heads))
+    return np.asarray(pow2(closest) + pow2(2 * closest)[0::2][:heads - closest], np.float32)
+
+
 def from_nomic_state_dict(cfg: BertConfig, sd) -> np.ndarray:
     """A NomicBert state dict (names of the model repository's modeling file: emb_ln, encoder.layers.N.attn.Wqkv /
     out_proj, norm1, mlp.fc11 / fc12 / fc2, norm2) -> the flat block of an ARCH_NOMIC config.  The fused Wqkv is cut into
@@ -223,6 +317,8 @@ def config_from_hf(cfg_json: dict, pooling: int = POOL_CLS) -> BertConfig:
     """HF config.json -> BertConfig (BERT family; nomic_bert through nomic_config_from_hf)."""
     if cfg_json.get("model_type") == "nomic_bert":
         return nomic_config_from_hf(cfg_json)
+    if cfg_json.get("position_embedding_type") == "alibi":
+        return jina_config_from_hf(cfg_json)
     if cfg_json.get("model_type", "bert") != "bert":
         raise ValueError(f"model_type {cfg_json.get('model_type')!r} is not a BERT encoder")
     if cfg_json.get("hidden_act", "gelu") != "gelu":
@@ -246,6 +342,8 @@ def load_checkpoint(path: str, cfg: BertConfig) -> np.ndarray:
         sd = dict(np.load(path))
     else:
         raise ValueError("expected a .safetensors or .npz checkpoint")
+    if cfg.arch in (ARCH_JINA, ARCH_JINA_QKNORM):
+        return from_jina_state_dict(cfg, sd)
     return from_nomic_state_dict(cfg, sd) if cfg.arch == ARCH_NOMIC else from_state_dict(cfg, sd)
 
 

@@ -328,7 +328,10 @@ typedef enum cs_pooling { CS_POOL_CLS = 0, CS_POOL_MEAN = 1 } cs_pooling;
  * (embedder.rs:30-35: nomic-embed-text-v1 / v1.5 / v1.5-Q) — no position table; rotary angles on Q and K (non-interleaved
  * halves, pos * base^(-2i/d)); a gated feed-forward  fc2( fc11(x) * silu(fc12(x)) );  post-LayerNorm and everything else as
  * BERT.  Flat parameter order: cs_bert_params.h. */
-typedef enum cs_encoder_arch { CS_ARCH_BERT = 0, CS_ARCH_NOMIC = 1 } cs_encoder_arch;
+/* CS_ARCH_JINA / CS_ARCH_JINA_QKNORM: JinaBert (embedder.rs:40-41,69: JinaEmbeddingsV2BaseCode) — no position table, the
+ * symmetric ALiBi bias -slope_h |i - j| on the attention scores, a GELU-gated feed-forward; _QKNORM adds the LayerNorm on the
+ * whole query and key rows that the "qk-post-norm" modelling file (the one jina-embeddings-v2-base-code names) applies. */
+typedef enum cs_encoder_arch { CS_ARCH_BERT = 0, CS_ARCH_NOMIC = 1, CS_ARCH_JINA = 2, CS_ARCH_JINA_QKNORM = 3 } cs_encoder_arch;
 
 typedef struct cs_bert_config {
     uint32_t vocab_size;        /* 30522 for bge-small-en-v1.5 */

@@ -61,7 +61,8 @@ CS_SYNTH_FN void cs_bert_synth_rule(int kind, int* shift, float* base) {
 typedef struct cs_bert_layer_offsets {
     uint64_t q_w, q_b, k_w, k_b, v_w, v_b, ao_w, ao_b, ao_ln_g, ao_ln_b;
     uint64_t up_w, up_b, down_w, down_b, out_ln_g, out_ln_b;
-    uint64_t gate_w, gate_b; /* CS_ARCH_NOMIC only (else == down_w) */
+    uint64_t gate_w, gate_b; /* gated feed-forwards only (else == down_w) */
+    uint64_t qln_g, qln_b, kln_g, kln_b; /* CS_ARCH_JINA_QKNORM only (else == ao_w) */
 } cs_bert_layer_offsets;
 
 typedef struct cs_bert_offsets {
@@ -71,17 +72,24 @@ typedef struct cs_bert_offsets {
     uint64_t total;
 } cs_bert_offsets;
 
+/* families without a position table and with a gated feed-forward (a second [I, H] up-projection per layer) */
+CS_SYNTH_FN int cs_arch_gated(uint32_t arch) {
+    return arch == CS_ARCH_NOMIC || arch == CS_ARCH_JINA || arch == CS_ARCH_JINA_QKNORM;
+}
+CS_SYNTH_FN int cs_arch_alibi(uint32_t arch) { return arch == CS_ARCH_JINA || arch == CS_ARCH_JINA_QKNORM; }
+
 CS_SYNTH_FN void cs_bert_layout(const cs_bert_config* c, cs_bert_offsets* o) {
     const uint64_t H = c->hidden, I = c->intermediate;
     uint64_t p = 0;
     o->word = p; p += (uint64_t)c->vocab_size * H;
-    o->pos = p; if (c->arch != CS_ARCH_NOMIC) p += (uint64_t)c->max_position * H;
+    o->pos = p; if (!cs_arch_gated(c->arch)) p += (uint64_t)c->max_position * H;
     o->type = p; p += (uint64_t)c->type_vocab_size * H;
     o->emb_ln_g = p; p += H;
     o->emb_ln_b = p; p += H;
     o->layer0 = p;
     o->layer_stride = 4 * (H * H + H) + 2 * H + (I * H + I) + (H * I + H) + 2 * H;
-    if (c->arch == CS_ARCH_NOMIC) o->layer_stride += I * H + I;
+    if (cs_arch_gated(c->arch)) o->layer_stride += I * H + I;
+    if (c->arch == CS_ARCH_JINA_QKNORM) o->layer_stride += 4 * H;
     o->total = p + (uint64_t)c->layers * o->layer_stride;
 }
 
@@ -92,11 +100,13 @@ CS_SYNTH_FN void cs_bert_layer_layout(const cs_bert_config* c, const cs_bert_off
     l->q_w = p; p += H * H; l->q_b = p; p += H;
     l->k_w = p; p += H * H; l->k_b = p; p += H;
     l->v_w = p; p += H * H; l->v_b = p; p += H;
+    l->qln_g = l->qln_b = l->kln_g = l->kln_b = p;
+    if (c->arch == CS_ARCH_JINA_QKNORM) { l->qln_g = p; p += H; l->qln_b = p; p += H; l->kln_g = p; p += H; l->kln_b = p; p += H; }
     l->ao_w = p; p += H * H; l->ao_b = p; p += H;
     l->ao_ln_g = p; p += H; l->ao_ln_b = p; p += H;
     l->up_w = p; p += I * H; l->up_b = p; p += I;
     l->gate_w = p; l->gate_b = p;
-    if (c->arch == CS_ARCH_NOMIC) { p += I * H; l->gate_b = p; p += I; }
+    if (cs_arch_gated(c->arch)) { p += I * H; l->gate_b = p; p += I; }
     l->down_w = p; p += H * I; l->down_b = p; p += H;
     l->out_ln_g = p; p += H; l->out_ln_b = p; p += H;
 }
@@ -113,6 +123,10 @@ CS_SYNTH_FN int cs_bert_kind_at(const cs_bert_config* c, const cs_bert_offsets* 
     const uint64_t lin = H * H + H;
     if (r < 2 * lin) return (r % lin) < H * H ? CS_T_QK_W : CS_T_BIAS;          /* q, k */
     if (r < 3 * lin) return (r - 2 * lin) < H * H ? CS_T_V_W : CS_T_BIAS;       /* v */
+    if (c->arch == CS_ARCH_JINA_QKNORM) { /* layer_norm_q, layer_norm_k: gamma, beta, gamma, beta */
+        if (r < 3 * lin + 4 * H) return (((r - 3 * lin) / H) & 1) ? CS_T_LN_BETA : CS_T_LN_GAMMA;
+        r -= 4 * H;
+    }
     if (r < 4 * lin) return (r - 3 * lin) < H * H ? CS_T_ATTN_OUT_W : CS_T_BIAS;
     r -= 4 * lin;
     if (r < H) return CS_T_LN_GAMMA;
@@ -121,7 +135,7 @@ CS_SYNTH_FN int cs_bert_kind_at(const cs_bert_config* c, const cs_bert_offsets* 
     if (r < I * H) return CS_T_FFN_UP_W;
     if (r < I * H + I) return CS_T_BIAS;
     r -= I * H + I;
-    if (c->arch == CS_ARCH_NOMIC) {
+    if (cs_arch_gated(c->arch)) {
         if (r < I * H) return CS_T_FFN_UP_W;
         if (r < I * H + I) return CS_T_BIAS;
         r -= I * H + I;

@@ -20,6 +20,16 @@
  * (f32 throughout, as the module computes its cos / sin cache); the feed-forward is  fc2( fc11(x) * silu(fc12(x)) );
  * post-LayerNorm, masking, mean pooling and normalisation as above.  Pinned against a float64 torch statement that takes
  * its rotary map from transformers' own `rotate_half` / `apply_rotary_pos_emb` (tests/golden/make_nomic_golden.py).
+ * CS_ARCH_JINA / CS_ARCH_JINA_QKNORM (the registry's JinaEmbeddingsV2BaseCode, /root/reference/src/embed/embedder.rs:40-41,
+ * :69, :92, :112 -> fastembed's JinaEmbeddingsV2BaseCode) restate JinaBert (jinaai/jina-bert-implementation and
+ * jinaai/jina-bert-v2-qk-post-norm `modeling_bert.py`; third-party code, absent here — restated from its published
+ * definition): embeddings = word + token_type -> LayerNorm (no position table); scores
+ *   softmax(Q K^T / sqrt(d_h) + mask + alibi),  alibi[h][i][j] = -slope_h |i - j|  (the symmetric, encoder form),
+ * slopes the geometric sequence of the ALiBi paper (closest power of two, then every second slope of the doubled set);
+ * _QKNORM: LayerNorm over the WHOLE query row and the whole key row (H columns, own gamma / beta each) before the cut into
+ * heads; the feed-forward is  down( value * gelu_erf(gate) )  over the two halves of one bias-free [2I, H] projection;
+ * post-LayerNorm, mean pooling, normalisation as above.  Pinned against a float64 torch statement written from the same
+ * definition (tests/golden/make_jina_golden.py) — PARITY UNPINNED against the model itself.
  * PARITY UNPINNED against the reference itself (it ships no embedding vectors,
  * SURVEY.md §4, §8c); pinned against HF transformers BertModel (float64) by
  * tests/golden/make_encoder_golden.py -> tests/golden/encoder_golden.npz.
@@ -163,6 +173,27 @@ static void rotary_rows(float* qk, size_t T, size_t L, size_t NH, size_t DH, flo
     free(inv_freq);
 }
 
+/* ALiBi head slopes as JinaBert's `_get_alibi_head_slopes` forms them (Python floats = doubles, then an f32 tensor). */
+static void alibi_pow2(size_t n, double* out) {
+    const double start = pow(2.0, -pow(2.0, -(log2((double)n) - 3.0)));
+    for (size_t i = 0; i < n; ++i) out[i] = start * pow(start, (double)i);
+}
+static void alibi_slopes(size_t n, float* out) {
+    double* tmp = (double*)malloc(sizeof(double) * 2 * n + 16);
+    size_t closest = 1;
+    while (closest * 2 <= n) closest *= 2;
+    if (closest == n) {
+        alibi_pow2(n, tmp);
+        for (size_t i = 0; i < n; ++i) out[i] = (float)tmp[i];
+    } else {
+        alibi_pow2(closest, tmp);
+        for (size_t i = 0; i < closest; ++i) out[i] = (float)tmp[i];
+        alibi_pow2(2 * closest, tmp); /* (2 * closest is a power of two: the recursion ends here) */
+        for (size_t i = 0; i < n - closest; ++i) out[closest + i] = (float)tmp[2 * i];
+    }
+    free(tmp);
+}
+
 /* ids/mask: [B, L] int32.  hidden_out: optional [B*L*H] last_hidden_state.  pooled_out:
  * [B, H] pooled + L2-normalised.  layer_hidden_out: optional [layers+1][B*L*H] (embedding
  * output then every layer's output) for per-layer parity checks. */
@@ -182,7 +213,10 @@ static void bert_forward_impl(const cs_bert_config* cfg, const float* params, co
     float* tmp = (float*)malloc(sizeof(float) * T * H);
     float* mid = (float*)malloc(sizeof(float) * T * I);
     const int nomic = cfg->arch == CS_ARCH_NOMIC;
-    float* gate = nomic ? (float*)malloc(sizeof(float) * T * I) : NULL;
+    const int gated = cs_arch_gated(cfg->arch), alibi = cs_arch_alibi(cfg->arch);
+    float* gate = gated ? (float*)malloc(sizeof(float) * T * I) : NULL;
+    float* slopes = (float*)malloc(sizeof(float) * NH);
+    if (alibi) alibi_slopes(NH, slopes);
 
     /* embeddings: word + token_type(0) + position, then LayerNorm (HF BertEmbeddings order:
      * inputs_embeds + token_type_embeddings, then + position_embeddings) */
@@ -191,7 +225,7 @@ static void bert_forward_impl(const cs_bert_config* cfg, const float* params, co
         const float* we = params + off.word + (size_t)ids[t] * H;
         const float* pe = params + off.pos + pos * H;
         const float* te = params + off.type; /* token_type_ids = 0 */
-        if (nomic) { /* NomicBertEmbeddings: word + token_type, no position table */
+        if (gated) { /* NomicBertEmbeddings / JinaBertEmbeddings (alibi): word + token_type, no position table */
             for (size_t i = 0; i < H; ++i) x[t * H + i] = we[i] + te[i];
             continue;
         }
@@ -221,6 +255,10 @@ static void bert_forward_impl(const cs_bert_config* cfg, const float* params, co
             rotary_rows(q, T, L, NH, DH, cfg->rotary_base);
             rotary_rows(k, T, L, NH, DH, cfg->rotary_base);
         }
+        if (cfg->arch == CS_ARCH_JINA_QKNORM) { /* layer_norm_q / layer_norm_k over the whole rows, before the heads */
+            layer_norm_rows(q, params + lo.qln_g, params + lo.qln_b, T, H, cfg->layer_norm_eps);
+            layer_norm_rows(k, params + lo.kln_g, params + lo.kln_b, T, H, cfg->layer_norm_eps);
+        }
         /* attention per (batch, head, query row) */
 #ifdef _OPENMP
 #pragma omp parallel for collapse(2) schedule(static)
@@ -238,6 +276,8 @@ static void bert_forward_impl(const cs_bert_config* cfg, const float* params, co
                         d *= scale;
                         /* additive mask: (1 - m) * finfo(f32).min, as HF get_extended_attention_mask */
                         if (!mask[(size_t)b * L + j]) d += -3.4028234663852886e38f;
+                        /* JinaBert: softmax(scores + bias), bias = slopes * -|i - j| (an f32 tensor product) */
+                        if (alibi) d += slopes[h] * -(float)(i > j ? i - j : j - i);
                         s[j] = d;
                         if (d > mx) mx = d;
                     }
@@ -261,6 +301,9 @@ static void bert_forward_impl(const cs_bert_config* cfg, const float* params, co
         if (nomic) { /* NomicBertGatedMLP, activation swiglu: y = fc11(x) * silu(fc12(x)) */
             linear(x, params + lo.gate_w, params + lo.gate_b, gate, T, H, I);
             for (size_t i = 0; i < T * I; ++i) mid[i] = mid[i] * silu(gate[i]);
+        } else if (gated) { /* JinaBertGLUMLP (geglu): y = value * gelu(gate) over the halves of one [2I, H] projection */
+            linear(x, params + lo.gate_w, params + lo.gate_b, gate, T, H, I);
+            for (size_t i = 0; i < T * I; ++i) mid[i] = mid[i] * gelu_erf(gate[i]);
         } else {
             for (size_t i = 0; i < T * I; ++i) mid[i] = gelu_erf(mid[i]);
         }
@@ -295,7 +338,7 @@ static void bert_forward_impl(const cs_bert_config* cfg, const float* params, co
             for (size_t i = 0; i < H; ++i) p[i] /= den;
         }
     }
-    free(x); free(q); free(k); free(v); free(ctx); free(tmp); free(mid); free(gate);
+    free(x); free(q); free(k); free(v); free(ctx); free(tmp); free(mid); free(gate); free(slopes);
 }
 
 void cs_oracle_bert_forward(const cs_bert_config* cfg, const float* params, const int32_t* ids,
@@ -311,6 +354,8 @@ void cs_oracle_bert_forward_q8(const cs_bert_config* cfg, const float* params, c
                                uint32_t L, float* hidden_out, float* pooled_out, float* layer_hidden_out) {
     bert_forward_impl(cfg, params, wscale, ids, mask, B, L, hidden_out, pooled_out, layer_hidden_out);
 }
+
+void cs_oracle_alibi_slopes(uint32_t n, float* out) { alibi_slopes((size_t)n, out); }
 
 void cs_oracle_bert_synth_params(const cs_bert_config* cfg, uint64_t seed, float* out) {
     cs_bert_offsets off;

@@ -90,6 +90,8 @@ void cs_oracle_bert_forward_q8(const struct cs_bert_config* cfg, const float* pa
 void cs_oracle_linear_q8(const float* x, const float* w, const float* wscale, const float* b, float* y, uint64_t T,
                          uint64_t K, uint64_t N);
 /* Flat parameter block from the synthetic rule of include/cs_bert_params.h. */
+/* JinaBert's ALiBi head slopes (CS_ARCH_JINA*), n floats. */
+void cs_oracle_alibi_slopes(uint32_t n, float* out);
 void cs_oracle_bert_synth_params(const struct cs_bert_config* cfg, uint64_t seed, float* out);
 uint64_t cs_oracle_bert_param_count(const struct cs_bert_config* cfg);
 

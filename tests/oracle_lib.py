@@ -55,6 +55,8 @@ class Oracle:
         lib.cs_oracle_bert_synth_params.argtypes = [C.c_void_p, C.c_uint64, c_f32p]
         lib.cs_oracle_bert_param_count.restype = C.c_uint64
         lib.cs_oracle_bert_param_count.argtypes = [C.c_void_p]
+        lib.cs_oracle_alibi_slopes.restype = None
+        lib.cs_oracle_alibi_slopes.argtypes = [C.c_uint32, c_f32p]
         lib.cs_oracle_synth_rows.restype = None
         lib.cs_oracle_synth_rows.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, c_f32p]
         lib.cs_oracle_synth_planted.restype = None
@@ -110,6 +112,11 @@ class Oracle:
     def bert_param_count(self, cfg) -> int:
         c = cfg.to_c()
         return int(self.lib.cs_oracle_bert_param_count(C.byref(c)))
+
+    def alibi_slopes(self, heads: int):
+        out = np.empty(heads, np.float32)
+        self.lib.cs_oracle_alibi_slopes(heads, _ptr(out, c_f32p))
+        return out
 
     def bert_synth_params(self, cfg, seed):
         c = cfg.to_c()

@@ -1,0 +1,140 @@
+"""Pins the CS_ARCH_JINA / CS_ARCH_JINA_QKNORM branch of the encoder oracle (oracle/bert_oracle.c: ALiBi on the scores, a
+GELU-gated feed-forward, optional LayerNorm on the query / key rows, no position table) to the committed golden vectors of
+tests/golden/make_jina_golden.py (a float64 torch statement whose head slopes come from transformers' MPT ALiBi builder),
+and the JinaBert checkpoint-name / config.json mapping.  CPU only."""
+import os
+
+import numpy as np
+import pytest
+
+from codesearch_amd.bert_params import (ARCH_JINA, ARCH_JINA_QKNORM, POOL_MEAN, BertConfig, alibi_slopes, config_from_hf,
+                                        from_jina_state_dict, param_count, synth_params, synth_token_batch, tensor_table,
+                                        to_state_dict)
+
+GOLD = np.load(os.path.join(os.path.dirname(__file__), "golden", "jina_golden.npz"))
+
+
+def case_cfg(name):
+    m = GOLD[name + "/meta"]
+    cfg = BertConfig(vocab_size=int(m[0]), hidden=int(m[1]), layers=int(m[2]), heads=int(m[3]), intermediate=int(m[4]),
+                     max_position=int(m[5]), pooling=POOL_MEAN, arch=int(m[11]))
+    return cfg, int(m[6]), int(m[7]), int(m[8]), int(m[9]), bool(m[10])
+
+
+def test_jina_layout_and_generator_identity(oracle):
+    bert = BertConfig(vocab_size=512, hidden=128, layers=2, heads=2, intermediate=256)
+    H, I = bert.hidden, bert.intermediate
+    for arch, extra in ((ARCH_JINA, 0), (ARCH_JINA_QKNORM, 4 * H)):
+        cfg = BertConfig(vocab_size=512, hidden=128, layers=2, heads=2, intermediate=256, pooling=POOL_MEAN, arch=arch)
+        # no position table; one more [I, H] + [I] per layer than BERT (+ four [H] vectors with the query / key LayerNorms)
+        assert param_count(cfg) == param_count(bert) - bert.max_position * H + cfg.layers * (I * H + I + extra)
+        assert oracle.bert_param_count(cfg) == param_count(cfg)
+        assert np.array_equal(oracle.bert_synth_params(cfg, 9), synth_params(cfg, 9))
+        names = [n for n, _, _ in tensor_table(cfg)]
+        assert "embeddings.position_embeddings.weight" not in names
+        assert ("encoder.layer.1.attention.self.layer_norm_k.bias" in names) == (arch == ARCH_JINA_QKNORM)
+    # the LayerNorm slots are generated as LayerNorm parameters (gamma around 1)
+    cfg = BertConfig(vocab_size=512, hidden=128, layers=1, heads=2, intermediate=256, pooling=POOL_MEAN, arch=ARCH_JINA_QKNORM)
+    sd = to_state_dict(cfg, synth_params(cfg, 3))
+    assert abs(float(sd["encoder.layer.0.attention.self.layer_norm_q.weight"].mean()) - 1.0) < 0.05
+    assert abs(float(sd["encoder.layer.0.attention.self.layer_norm_k.bias"].mean())) < 0.05
+
+
+@pytest.mark.parametrize("heads", [8, 12, 16])
+def test_alibi_slopes_match_the_library_builder(oracle, heads):
+    want = GOLD[f"slopes/{heads}"]
+    assert np.array_equal(oracle.alibi_slopes(heads), want)
+    assert np.array_equal(alibi_slopes(heads), want)
+    if heads == 12:  # 2^-1 .. 2^-8, then 2^-0.5, 2^-1.5, 2^-2.5, 2^-3.5
+        np.testing.assert_allclose(want, [2.0 ** -(i + 1) for i in range(8)] + [2.0 ** -(i + 0.5) for i in range(4)], rtol=1e-7)
+
+
+@pytest.mark.parametrize("name", [str(n) for n in GOLD["names"] if str(n) != "jina_code_shape"])
+def test_oracle_matches_the_torch_statement(oracle, name):
+    cfg, wseed, iseed, B, L, ragged = case_cfg(name)
+    params = synth_params(cfg, wseed)
+    ids, mask = synth_token_batch(cfg, iseed, B, L, ragged)
+    r = oracle.bert_forward(cfg, params, ids, mask, want_hidden=True, want_layers=True)
+    np.testing.assert_allclose(r["pooled"], GOLD[name + "/mean"], atol=2e-6)
+    np.testing.assert_allclose(np.linalg.norm(r["pooled"], axis=1), 1.0, atol=1e-6)
+    valid = mask.astype(bool)
+    absmean = np.array([np.abs(h[valid]).mean() for h in r["layers"]])
+    np.testing.assert_allclose(absmean, GOLD[name + "/layer_absmean"], rtol=1e-5)
+    H = cfg.hidden
+    probe = np.array([[h[0, 0, 0], h[B - 1, 1, 7], h[0, mask[0].sum() - 1, H - 1]] for h in r["layers"]])
+    np.testing.assert_allclose(probe, GOLD[name + "/layer_probe"], atol=2e-5)
+    np.testing.assert_allclose(r["hidden"][0, 0], GOLD[name + "/last_row0"], atol=2e-5)
+
+
+def test_oracle_matches_at_the_published_shape(oracle):
+    """12 x 768, 12 heads of 64, intermediate 3072, vocab 61056 (jina-embeddings-v2-base-code's config.json), 4 x 128 tokens."""
+    cfg, wseed, iseed, B, L, ragged = case_cfg("jina_code_shape")
+    params = oracle.bert_synth_params(cfg, wseed)
+    ids, mask = synth_token_batch(cfg, iseed, B, L, ragged)
+    r = oracle.bert_forward(cfg, params, ids, mask, want_hidden=True)
+    np.testing.assert_allclose(r["pooled"], GOLD["jina_code_shape/mean"], atol=1e-5)
+    np.testing.assert_allclose(r["hidden"][0, 0], GOLD["jina_code_shape/last_row0"], atol=1e-4)
+    mean = GOLD["jina_code_shape/mean"]
+    assert (mean @ mean.T)[~np.eye(len(mean), dtype=bool)].max() < 0.999  # the synthetic model tells sequences apart
+
+
+def test_positions_matter_and_padding_does_not_leak(oracle):
+    cfg, wseed, iseed, B, L, _ = case_cfg("dh64_L48")
+    params = synth_params(cfg, wseed)
+    ids, mask = synth_token_batch(cfg, iseed, B, L, True)
+    base = oracle.bert_forward(cfg, params, ids, mask)["pooled"]
+    ids2 = np.where(mask == 1, ids, 77).astype(np.int32)  # garbage in the padded positions changes nothing
+    assert np.abs(oracle.bert_forward(cfg, params, ids2, mask)["pooled"] - base).max() < 1e-6
+    # with no position table, the ALiBi bias is the only thing that sees token order
+    b = int(np.argmax(mask.sum(1)))
+    ids3 = ids.copy()
+    ids3[b, 3], ids3[b, 29] = ids[b, 29], ids[b, 3]
+    assert ids3[b, 3] != ids[b, 3]
+    moved = np.abs(oracle.bert_forward(cfg, params, ids3, mask)["pooled"][b] - base[b]).max()
+    assert moved > 1e-5, moved
+
+
+def test_jina_checkpoint_names_map_onto_the_flat_block():
+    """config.json keys and parameter names of the two JinaBert modelling files: `mlp.up_gated_layer` (value rows first,
+    qk-post-norm file) against `mlp.gated_layers` (activated rows first), and where the QK LayerNorm comes from."""
+    hf = {"model_type": "bert", "position_embedding_type": "alibi", "feed_forward_type": "geglu", "hidden_act": "gelu",
+          "vocab_size": 512, "hidden_size": 128, "num_attention_heads": 2, "num_hidden_layers": 2, "intermediate_size": 256,
+          "max_position_embeddings": 8192, "type_vocab_size": 2, "layer_norm_eps": 1e-12,
+          "auto_map": {"AutoModel": "jinaai/jina-bert-v2-qk-post-norm--modeling_bert.JinaBertModel"}}
+    cfg = config_from_hf(hf)
+    assert (cfg.arch, cfg.pooling, cfg.max_position, cfg.hidden, cfg.intermediate) == (ARCH_JINA_QKNORM, POOL_MEAN, 512, 128, 256)
+    hf2 = dict(hf, auto_map={"AutoModel": "jinaai/jina-bert-implementation--modeling_bert.JinaBertModel"})
+    cfg2 = config_from_hf(hf2)
+    assert cfg2.arch == ARCH_JINA
+    with pytest.raises(ValueError):
+        config_from_hf(dict(hf, feed_forward_type="original"))
+    rng = np.random.default_rng(5)
+    for c, up_name, down_name, value_first in ((cfg, "mlp.up_gated_layer", "mlp.down_layer", True),
+                                               (cfg2, "mlp.gated_layers", "mlp.wo", False)):
+        flat = rng.standard_normal(param_count(c)).astype(np.float32)
+        ours = to_state_dict(c, flat)
+        theirs = {}
+        for name, a in ours.items():
+            if ".intermediate." in name or ".output.dense." in name or ".output.LayerNorm." in name:
+                if "attention" in name:
+                    theirs[name] = a
+                continue
+            theirs[name] = a
+        for l in range(c.layers):
+            p = f"encoder.layer.{l}."
+            v, g = ours[p + "intermediate.dense.weight"], ours[p + "intermediate.gate.weight"]
+            theirs[p + up_name + ".weight"] = np.concatenate([v, g] if value_first else [g, v])
+            theirs[p + down_name + ".weight"] = ours[p + "output.dense.weight"]
+            theirs[p + down_name + ".bias"] = ours[p + "output.dense.bias"]
+            theirs[p + "mlp.layernorm.weight"] = ours[p + "output.LayerNorm.weight"]
+            theirs[p + "mlp.layernorm.bias"] = ours[p + "output.LayerNorm.bias"]
+        back = to_state_dict(c, from_jina_state_dict(c, theirs))
+        for name, a in ours.items():
+            if ".intermediate." in name and name.endswith(".bias"):
+                assert not back[name].any()  # the checkpoint's up projection has no bias
+            else:
+                assert np.array_equal(back[name], a), name
+        broken = dict(theirs)
+        del broken["encoder.layer.1." + up_name + ".weight"]
+        with pytest.raises(ValueError):
+            from_jina_state_dict(c, broken)
