@@ -59,13 +59,16 @@ struct AttnMemPlain {
 // MQ / MO: how the qkv tensor is read and the context tensor written (AttnMemPlain: plain loads, K / V by LDS-DMA, plain
 // stores — the stand-alone kernel; small_forward.hip passes a policy whose every access carries sc1, K / V through
 // registers).  bx / by / bz: the block's coordinates, gx / gz: the grid's extents (the kernel form passes its own).
-template <int NC, class MQ, class MO>
+// ALIBI (JinaBert, CS_ARCH_JINA*): the score of (query i, key j) of head h also gets -slope_h |i - j|; alibi_log2 [heads] holds
+// the slopes times log2 e (the softmax runs in the exp2 domain).  BERT / NomicBert instantiate ALIBI = false: the same code as
+// before the parameter existed.
+template <int NC, class MQ, class MO, bool ALIBI = false>
 __device__ __forceinline__ void
 attention_shx_body(char* smem, const MQ& mq, const MO& mo, const _Float16* qkvs, const int32_t* __restrict__ mask,
                    _Float16* ctxs, uint32_t* __restrict__ flag, uint32_t L, uint32_t H,
                    float scale_log2e, uint32_t HB, float* __restrict__ range_out,
                    const uint32_t* __restrict__ seq_unit, const uint32_t* __restrict__ unit_len,
-                   uint32_t bx, uint32_t by, uint32_t bz, uint32_t gx, uint32_t gz) {
+                   uint32_t bx, uint32_t by, uint32_t bz, uint32_t gx, uint32_t gz, const float* __restrict__ alibi_log2 = nullptr) {
     constexpr int KT = 128;                        // keys per super-tile
     const uint32_t Lp = (L + 31) & ~31u;
     char* Kt = smem;                               // [NC][KT][128 B]
@@ -105,6 +108,9 @@ attention_shx_body(char* smem, const MQ& mq, const MO& mo, const _Float16* qkvs,
     const bool wave_live = qb * 128 + qt * 32 < L;  // wave-uniform: some query of this wave's tile exists
     const uint32_t query = qb * 128 + qt * 32 + l31;
     const uint32_t qsrc = query < L ? query : L - 1;
+    float neg_slope = 0.0f;                        // ALIBI: -slope_head * log2 e
+    const float qpos = (float)query - (float)(4 * h);  // query position minus the lane half's key offset inside a group of 8
+    if constexpr (ALIBI) neg_slope = -alibi_log2[head];
     f16x8 qh[NC][2], ql[NC][2];
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
@@ -213,7 +219,13 @@ attention_shx_body(char* smem, const MQ& mq, const MO& mo, const _Float16* qkvs,
 #pragma unroll
                 for (int e2 = 0; e2 < 2; ++e2) {
                     const int r = 4 * g + 2 * e2;
-                    const sh_f32x2 x2 = {xx[r], xx[r + 1]}, h2 = {hh[r], hh[r + 1]}, m2 = {ma[2 * e2], ma[2 * e2 + 1]};
+                    const sh_f32x2 x2 = {xx[r], xx[r + 1]}, h2 = {hh[r], hh[r + 1]};
+                    sh_f32x2 m2 = {ma[2 * e2], ma[2 * e2 + 1]};
+                    if constexpr (ALIBI) {  // key = 32 kt + 8 g + 4 h + 2 e2 (+ 1)
+                        const float d0 = qpos - (float)(kt * 32 + 8 * g + 2 * e2);
+                        m2[0] = fmaf(neg_slope, fabsf(d0), m2[0]);
+                        m2[1] = fmaf(neg_slope, fabsf(d0 - 1.0f), m2[1]);
+                    }
                     const sh_f32x2 s2 = __builtin_elementwise_fma(__builtin_elementwise_fma(x2, lo_inv2, h2), scale2, m2);
                     p2[r / 2] = s2;
                     tmax = fmaxf(tmax, fmaxf(s2[0], s2[1]));
@@ -255,7 +267,9 @@ attention_shx_body(char* smem, const MQ& mq, const MO& mo, const _Float16* qkvs,
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int r = 4 * g + e;
-                    hh[r] = fmaf(fmaf(xx[r], kShLoInv, hh[r]), scale_log2e, ma[e]);
+                    float me = ma[e];
+                    if constexpr (ALIBI) me = fmaf(neg_slope, fabsf(qpos - (float)(kt * 32 + 8 * g + e)), me);
+                    hh[r] = fmaf(fmaf(xx[r], kShLoInv, hh[r]), scale_log2e, me);
                     tmax = fmaxf(tmax, hh[r]);
                 }
             }

@@ -229,8 +229,58 @@ std::vector<Want> nomic_layout_table(const cs_bert_config& c) {
     return t;
 }
 
-std::vector<Want> layout_table(const cs_bert_config& c) {
+// JinaBert checkpoints (jinaai/jina-embeddings-v2-base-code; the two modelling files of the family): BERT names for the
+// embeddings and the attention block (+ attention.self.layer_norm_q / layer_norm_k with CS_ARCH_JINA_QKNORM), the
+// feed-forward as mlp.up_gated_layer [2I, H] (rows [0, I) the value, rows [I, 2I) through GELU), mlp.down_layer,
+// mlp.layernorm — or, `first_file`, mlp.gated_layers (rows [0, I) through GELU, rows [I, 2I) the value), mlp.wo.  The up
+// projection has no bias (zero slots).
+std::vector<Want> jina_layout_table(const cs_bert_config& c, bool first_file) {
+    cs_bert_offsets o;
+    cs_bert_layout(&c, &o);
+    const uint64_t H = c.hidden, I = c.intermediate;
+    std::vector<Want> t = {
+        {"embeddings.word_embeddings.weight", {c.vocab_size, H}, o.word},
+        {"embeddings.token_type_embeddings.weight", {c.type_vocab_size, H}, o.type},
+        {"embeddings.LayerNorm.weight", {H}, o.emb_ln_g},
+        {"embeddings.LayerNorm.bias", {H}, o.emb_ln_b},
+    };
+    for (uint32_t l = 0; l < c.layers; ++l) {
+        cs_bert_layer_offsets lo;
+        cs_bert_layer_layout(&c, &o, l, &lo);
+        const std::string p = "encoder.layer." + std::to_string(l) + ".";
+        t.push_back({p + "attention.self.query.weight", {H, H}, lo.q_w});
+        t.push_back({p + "attention.self.query.bias", {H}, lo.q_b});
+        t.push_back({p + "attention.self.key.weight", {H, H}, lo.k_w});
+        t.push_back({p + "attention.self.key.bias", {H}, lo.k_b});
+        t.push_back({p + "attention.self.value.weight", {H, H}, lo.v_w});
+        t.push_back({p + "attention.self.value.bias", {H}, lo.v_b});
+        if (c.arch == CS_ARCH_JINA_QKNORM) {
+            t.push_back({p + "attention.self.layer_norm_q.weight", {H}, lo.qln_g});
+            t.push_back({p + "attention.self.layer_norm_q.bias", {H}, lo.qln_b});
+            t.push_back({p + "attention.self.layer_norm_k.weight", {H}, lo.kln_g});
+            t.push_back({p + "attention.self.layer_norm_k.bias", {H}, lo.kln_b});
+        }
+        t.push_back({p + "attention.output.dense.weight", {H, H}, lo.ao_w});
+        t.push_back({p + "attention.output.dense.bias", {H}, lo.ao_b});
+        t.push_back({p + "attention.output.LayerNorm.weight", {H}, lo.ao_ln_g});
+        t.push_back({p + "attention.output.LayerNorm.bias", {H}, lo.ao_ln_b});
+        const std::string up = p + (first_file ? "mlp.gated_layers" : "mlp.up_gated_layer");
+        const std::string down = p + (first_file ? "mlp.wo" : "mlp.down_layer");
+        t.push_back({up + ".weight", {I, H}, lo.up_w, 2 * I, first_file ? I : 0, false});
+        t.push_back({up + ".weight", {I, H}, lo.gate_w, 2 * I, first_file ? 0 : I, false});
+        t.push_back({up + ".bias", {I}, lo.up_b, 2 * I, first_file ? I : 0, true});
+        t.push_back({up + ".bias", {I}, lo.gate_b, 2 * I, first_file ? 0 : I, true});
+        t.push_back({down + ".weight", {H, I}, lo.down_w});
+        t.push_back({down + ".bias", {H}, lo.down_b});
+        t.push_back({p + "mlp.layernorm.weight", {H}, lo.out_ln_g});
+        t.push_back({p + "mlp.layernorm.bias", {H}, lo.out_ln_b});
+    }
+    return t;
+}
+
+std::vector<Want> layout_table(const cs_bert_config& c, bool jina_first_file = false) {
     if (c.arch == CS_ARCH_NOMIC) return nomic_layout_table(c);
+    if (cs_arch_alibi(c.arch)) return jina_layout_table(c, jina_first_file);
     cs_bert_offsets o;
     cs_bert_layout(&c, &o);
     const uint64_t H = c.hidden, I = c.intermediate;
@@ -355,10 +405,20 @@ int32_t cs_bert_config_from_dir(const char* model_dir, int32_t pooling, cs_bert_
         if (act->kind == Json::Str && act->str != "gelu")
             return fail(CS_ERR_UNSUPPORTED, "Failed to initialize embedding model: hidden_act \"%s\" (only erf-GELU)",
                         act->str.c_str());
-    if (const Json* pe = root.get("position_embedding_type"))
-        if (pe->kind == Json::Str && pe->str != "absolute")
+    bool jina = false;
+    if (const Json* pe = root.get("position_embedding_type")) {
+        if (pe->kind == Json::Str && pe->str == "alibi") {
+            // JinaBert (the registry's jina-embeddings-v2-base-code): only the published arrangement — GELU-gated feed-forward
+            const Json* ff = root.get("feed_forward_type");
+            if (!ff || ff->kind != Json::Str || ff->str != "geglu")
+                return fail(CS_ERR_UNSUPPORTED, "Failed to initialize embedding model: this JinaBert configuration is not built "
+                            "(feed_forward_type \"%s\"; only \"geglu\")", (ff && ff->kind == Json::Str) ? ff->str.c_str() : "original");
+            jina = true;
+        } else if (pe->kind == Json::Str && pe->str != "absolute") {
             return fail(CS_ERR_UNSUPPORTED, "Failed to initialize embedding model: position_embedding_type \"%s\"",
                         pe->str.c_str());
+        }
+    }
     cs_bert_config c{};
     if (!json_u32(root, "vocab_size", c.vocab_size) || !json_u32(root, "hidden_size", c.hidden) ||
         !json_u32(root, "num_hidden_layers", c.layers) || !json_u32(root, "num_attention_heads", c.heads) ||
@@ -369,6 +429,21 @@ int32_t cs_bert_config_from_dir(const char* model_dir, int32_t pooling, cs_bert_
     const Json* eps = root.get("layer_norm_eps");
     c.layer_norm_eps = (eps && eps->kind == Json::Num) ? (float)eps->num : 1e-12f;
     c.pooling = pooling;
+    if (jina) {
+        // no position table to size: the bound is what fastembed's default InitOptions truncate to (embedder.rs:238)
+        if (c.max_position > 512) c.max_position = 512;
+        // the modelling file the config names decides whether Q and K rows are LayerNorm'ed ("...qk-post-norm..."); a
+        // checkpoint that says otherwise overrides it (cs_embedder_create_from_dir looks at the tensors)
+        bool qkn = true;
+        if (const Json* am = root.get("auto_map"))
+            if (am->kind == Json::Obj && !am->obj.empty()) {
+                qkn = false;
+                for (const auto& kv : am->obj)
+                    if (kv.second.kind == Json::Str && kv.second.str.find("qk-post-norm") != std::string::npos) qkn = true;
+            }
+        c.arch = qkn ? CS_ARCH_JINA_QKNORM : CS_ARCH_JINA;
+        c.pooling = pooling_given ? pooling : (pooling_file ? pooling : CS_POOL_MEAN);  // fastembed pools the model by mean
+    }
     *cfg = c;
     return CS_OK;
 }
@@ -422,7 +497,11 @@ int32_t cs_bert_params_from_safetensors(const char* path, const cs_bert_config* 
     }
     const uint64_t data0 = 8 + hlen;
     std::vector<unsigned char> raw;
-    for (const Want& w : layout_table(*cfg)) {
+    bool jina_first_file = false;
+    if (cs_arch_alibi(cfg->arch))
+        for (const auto& kv : have)
+            if (kv.first.find("mlp.gated_layers.weight") != std::string::npos) { jina_first_file = true; break; }
+    for (const Want& w : layout_table(*cfg, jina_first_file)) {
         auto it = have.find(w.name);
         if (it == have.end()) it = have.find("bert." + w.name);
         if (it == have.end()) it = have.find("model." + w.name);
@@ -480,11 +559,33 @@ int32_t cs_bert_params_from_safetensors(const char* path, const cs_bert_config* 
     return CS_OK;
 }
 
+// Does the JSON header of a safetensors file mention `needle` (a tensor-name fragment)?  -1: the file cannot be read.
+static int safetensors_header_mentions(const std::string& path, const char* needle) {
+    FILE* f = std::fopen(path.c_str(), "rb");
+    if (!f) return -1;
+    unsigned char lenb[8];
+    uint64_t hlen = 0;
+    int r = -1;
+    if (std::fread(lenb, 1, 8, f) == 8) {
+        for (int i = 7; i >= 0; --i) hlen = (hlen << 8) | lenb[i];
+        if (hlen >= 2 && hlen <= (100ull << 20)) {
+            std::string header(hlen, '\0');
+            if (std::fread(&header[0], 1, hlen, f) == hlen) r = header.find(needle) != std::string::npos ? 1 : 0;
+        }
+    }
+    std::fclose(f);
+    return r;
+}
+
 int32_t cs_embedder_create_from_dir(const char* model_dir, int32_t pooling, int32_t device, cs_embedder** out) {
     if (!out) return fail(CS_ERR_BAD_ARG, "null out pointer");
     *out = nullptr;
     cs_bert_config cfg;
     CS_TRY(cs_bert_config_from_dir(model_dir, pooling, &cfg));
+    if (cs_arch_alibi(cfg.arch)) {  // JinaBert: the checkpoint's own tensors say whether Q and K rows are LayerNorm'ed
+        const int m = safetensors_header_mentions(std::string(model_dir) + "/model.safetensors", "attention.self.layer_norm_q.");
+        if (m >= 0) cfg.arch = m ? CS_ARCH_JINA_QKNORM : CS_ARCH_JINA;
+    }
     const uint64_t n = cs_bert_param_count(&cfg);
     std::vector<float> params;
     try {
@@ -510,6 +611,9 @@ int32_t cs_embedder_create_from_dir(const char* model_dir, int32_t pooling, int3
                         "onnx/model.onnx, model.onnx, model_optimized.onnx or model_quantized.onnx", model_dir);
         if (cfg.arch == CS_ARCH_NOMIC)
             return fail(CS_ERR_UNSUPPORTED, "Failed to initialize embedding model: the ONNX export of a nomic_bert model is not read "
+                        "(%s): place the repository's model.safetensors in %s", onnx.c_str(), model_dir);
+        if (cs_arch_alibi(cfg.arch))
+            return fail(CS_ERR_UNSUPPORTED, "Failed to initialize embedding model: the ONNX export of a JinaBert model is not read "
                         "(%s): place the repository's model.safetensors in %s", onnx.c_str(), model_dir);
         std::vector<float> wscale((size_t)cfg.layers * cs_bert_quant_columns(&cfg));
         int32_t quantized = 0;

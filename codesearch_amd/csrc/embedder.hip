@@ -82,6 +82,8 @@ struct cs_embedder {
     // of 16, like the rows of the packed weight) and the rotary table [max_position][d_h / 2] (cos, sin)
     float* d_bup = nullptr;
     float2* d_rope = nullptr;
+    // CS_ARCH_JINA*: the ALiBi head slopes, [2][heads]: as they are | times log2 e (attention_split.hip adds in the exp2 domain)
+    float* d_alibi = nullptr;
     _Float16* d_wsplit = nullptr;  // per layer: wqkv | attention-out | ffn-up | ffn-down, split-f16 rows
     uint32_t* d_flag = nullptr;    // split-f16 range flag
     // the one-launch forward of short queries (small_forward.hip): the layers' pointers on the device, its barrier words,
@@ -161,7 +163,7 @@ scatter_rows_kernel(const float* __restrict__ src, const uint32_t* __restrict__ 
 }
 
 // Floats per token row of the feed-forward workspace: [I]; CS_ARCH_NOMIC: [2I] (value | gate) + [I] (their product)
-size_t mid_width(const cs_bert_config& c) { return (size_t)c.intermediate * (c.arch == CS_ARCH_NOMIC ? 3 : 1); }
+size_t mid_width(const cs_bert_config& c) { return (size_t)c.intermediate * (cs_arch_gated(c.arch) ? 3 : 1); }
 
 void free_workspace(cs_embedder* h) {
     if (h->d_ids) (void)hipFree(h->d_ids);
@@ -231,7 +233,7 @@ SplitLayer split_layer(const cs_bert_config& c) {
     o.qkv = 0;
     o.ao = o.qkv + 3 * H * H * 2;
     o.up = o.ao + H * H * 2;
-    o.down = o.up + (c.arch == CS_ARCH_NOMIC ? 2 : 1) * I * H * 2;
+    o.down = o.up + (cs_arch_gated(c.arch) ? 2 : 1) * I * H * 2;
     o.total = o.down + H * I * 2;
     return o;
 }
@@ -249,7 +251,11 @@ int32_t forward_range(cs_embedder* h, hipStream_t s, uint32_t b0, uint32_t nb, u
     float* x = h->d_x + t0 * H;
     float* qkv = h->d_qkv + t0 * 3 * H;
     float* ctx = h->d_ctx + t0 * H;
-    const bool nomic = c.arch == CS_ARCH_NOMIC;
+    // `nomic`: every family with a gated feed-forward and no position table (NomicBert, JinaBert); `rotary` / `jina` what
+    // only one of them does (rotary map on Q / K | ALiBi on the scores, GELU gate, optional LayerNorm on Q / K rows)
+    const bool nomic = cs_arch_gated(c.arch), rotary = c.arch == CS_ARCH_NOMIC, jina = cs_arch_alibi(c.arch);
+    const bool qknorm = c.arch == CS_ARCH_JINA_QKNORM;
+    const float* alibi = jina ? h->d_alibi : nullptr;
     float* mid = h->d_mid + t0 * mid_width(c);
     const int32_t* mask = h->d_mask + t0;
     EncoderLaunch a;
@@ -586,9 +592,10 @@ int32_t forward_range(cs_embedder* h, hipStream_t s, uint32_t b0, uint32_t nb, u
                     return CS_OK;
                 }
                 CS_TRY(dense(SH_OUT_SPLIT, xs, ws + sl.qkv, bqkv, nullptr, nullptr, qkvs, T, 3 * H, H));  // E2
-                if (nomic) CS_TRY(launch_rope_split(qkvs, h->d_rope, T, L, H, c.heads, h->d_flag, s));  // rotary map on Q and K (nomic.hip)
+                if (rotary) CS_TRY(launch_rope_split(qkvs, h->d_rope, T, L, H, c.heads, h->d_flag, s));  // rotary map on Q and K (nomic.hip)
+                if (qknorm) CS_TRY(launch_qk_layernorm_split(qkvs, P + lo.qln_g, c.layer_norm_eps, T, H, h->d_flag, s));  // JinaBert qk-post-norm
                 CS_TRY(mark(CS_STAGE_QKV));
-                CS_TRY(launch_attention_sh2(qkvs, mask, ctxs, h->d_flag, nb, L, H, c.heads, s));                                 // E3
+                CS_TRY(launch_attention_sh2(qkvs, mask, ctxs, h->d_flag, nb, L, H, c.heads, s, nullptr, nullptr, nullptr, nullptr, alibi));  // E3
                 CS_TRY(mark(CS_STAGE_ATTENTION));
             }
             a.g = P + lo.ao_ln_g; a.b = P + lo.ao_ln_b;
@@ -624,10 +631,10 @@ int32_t forward_range(cs_embedder* h, hipStream_t s, uint32_t b0, uint32_t nb, u
                 static const bool gate_fused = [] { const char* e = std::getenv("CS_NOMIC_GATE_FUSED"); return !(e && e[0] == '0'); }();
                 const bool w384 = takes_wide(T, 2 * I, H), w192 = !w384 && takes_192(T, 2 * I, H);
                 if (gate_fused && (w384 || w192)) {  // the gate as the product's epilogue: the raw [T, 2I] tensor never exists
-                    CS_TRY(launch_gemm_wide(GW_OUT_SWIGLU, xs, ws + sl.up, bup, nullptr, nullptr, gated, T, 2 * I, H, h->d_flag, s, w192 ? 192 : 0));
+                    CS_TRY(launch_gemm_wide(jina ? GW_OUT_GEGLU : GW_OUT_SWIGLU, xs, ws + sl.up, bup, nullptr, nullptr, gated, T, 2 * I, H, h->d_flag, s, w192 ? 192 : 0));
                 } else {
                     CS_TRY(dense(SH_OUT_SPLIT, xs, ws + sl.up, bup, nullptr, nullptr, mids, T, 2 * I, H));
-                    CS_TRY(launch_swiglu_split(mids, gated, T, I, h->d_flag, s));
+                    CS_TRY(launch_swiglu_split(mids, gated, T, I, h->d_flag, s, jina));
                 }
                 ffn_in = gated;
             } else {
@@ -657,9 +664,10 @@ int32_t forward_range(cs_embedder* h, hipStream_t s, uint32_t b0, uint32_t nb, u
         } else {
             const float* wqkv = h->d_wqkv + (size_t)l * 3 * H * H;
             CS_TRY(launch_gemm(GEMM_BIAS, x, wqkv, bqkv, nullptr, qkv, T, 3 * H, H, s));        // E2
-            if (nomic) CS_TRY(launch_rope_f32(qkv, h->d_rope, T, L, H, c.heads, s));
+            if (rotary) CS_TRY(launch_rope_f32(qkv, h->d_rope, T, L, H, c.heads, s));
+            if (qknorm) CS_TRY(launch_qk_layernorm_f32(qkv, P + lo.qln_g, c.layer_norm_eps, T, H, s));
             CS_TRY(mark(CS_STAGE_QKV));
-            CS_TRY(launch_attention(qkv, mask, ctx, nb, L, H, c.heads, s));                     // E3
+            CS_TRY(launch_attention(qkv, mask, ctx, nb, L, H, c.heads, s, alibi));              // E3
             CS_TRY(mark(CS_STAGE_ATTENTION));
             CS_TRY(launch_gemm(GEMM_RESID, ctx, P + lo.ao_w, P + lo.ao_b, x, x, T, H, H, s));   // E4
             CS_TRY(mark(CS_STAGE_OUT_PROJ));
@@ -670,7 +678,7 @@ int32_t forward_range(cs_embedder* h, hipStream_t s, uint32_t b0, uint32_t nb, u
                 float* gate = mid + (size_t)T * I;
                 CS_TRY(launch_gemm(GEMM_BIAS, x, P + lo.up_w, P + lo.up_b, nullptr, mid, T, I, H, s));
                 CS_TRY(launch_gemm(GEMM_BIAS, x, P + lo.gate_w, P + lo.gate_b, nullptr, gate, T, I, H, s));
-                CS_TRY(launch_swiglu_f32(mid, gate, T, I, s));
+                CS_TRY(launch_swiglu_f32(mid, gate, T, I, s, jina));
             } else {
                 CS_TRY(launch_gemm(GEMM_GELU, x, P + lo.up_w, P + lo.up_b, nullptr, mid, T, I, H, s)); // E5
             }
@@ -1267,8 +1275,11 @@ static int32_t create_impl(const cs_bert_config* cfg, const float* params, uint6
         return fail(CS_ERR_UNSUPPORTED, "Failed to initialize embedding model: sizes must be multiples of 128");
     if (cfg->pooling != CS_POOL_CLS && cfg->pooling != CS_POOL_MEAN)
         return fail(CS_ERR_BAD_ARG, "Failed to initialize embedding model: unknown pooling %d", cfg->pooling);
-    if (cfg->arch != CS_ARCH_BERT && cfg->arch != CS_ARCH_NOMIC)
+    if (cfg->arch != CS_ARCH_BERT && !cs_arch_gated(cfg->arch))
         return fail(CS_ERR_UNSUPPORTED, "Failed to initialize embedding model: unknown encoder family %u", cfg->arch);
+    if (cs_arch_alibi(cfg->arch) && wscale)
+        return fail(CS_ERR_UNSUPPORTED, "Failed to initialize embedding model: the dynamic-quantisation mode is not built for "
+                    "the JinaBert encoder (create it from the dequantised weights: cs_embedder_create)");
     if (cfg->arch == CS_ARCH_NOMIC) {
         if (!(cfg->rotary_base > 1.0f) || !(cfg->rotary_base < 1.0e9f))
             return fail(CS_ERR_BAD_ARG, "Failed to initialize embedding model: rotary base %g", (double)cfg->rotary_base);
@@ -1318,10 +1329,24 @@ static int32_t create_impl(const cs_bert_config* cfg, const float* params, uint6
                 s = fail(CS_ERR_HIP, "QKV packing failed");
         }
     }
-    if (s == CS_OK && cfg->arch == CS_ARCH_NOMIC) {
+    if (s == CS_OK && cs_arch_alibi(cfg->arch)) {
+        // JinaBert's `_get_alibi_head_slopes`: the geometric sequence from 2^(-8 / n) for the closest power of two n below the
+        // head count, then every second slope of the doubled set — formed in double as the module forms them in Python floats
+        const uint32_t nh = cfg->heads;
+        std::vector<float> sl(2 * (size_t)nh);
+        uint32_t closest = 1;
+        while (closest * 2 <= nh) closest *= 2;
+        auto slope = [](uint32_t n, uint32_t i) { const double start = std::exp2(-8.0 / (double)n); return start * std::pow(start, (double)i); };
+        for (uint32_t i = 0; i < nh; ++i) sl[i] = (float)(i < closest ? slope(closest, i) : slope(2 * closest, 2 * (i - closest)));
+        for (uint32_t i = 0; i < nh; ++i) sl[nh + i] = sl[i] * 1.4426950408889634f;
+        if (hipMalloc(&h->d_alibi, sl.size() * sizeof(float)) != hipSuccess) return cleanup(fail(CS_ERR_OOM, "hipMalloc(parameters) failed"));
+        if (hipMemcpy(h->d_alibi, sl.data(), sl.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess)
+            s = fail(CS_ERR_HIP, "ALiBi slope upload failed");
+    }
+    if (s == CS_OK && cs_arch_gated(cfg->arch)) {
         const size_t I = cfg->intermediate, half = H / cfg->heads / 2;
         if (hipMalloc(&h->d_bup, (size_t)cfg->layers * 2 * I * sizeof(float)) != hipSuccess ||
-            hipMalloc(&h->d_rope, (size_t)cfg->max_position * half * sizeof(float2)) != hipSuccess)
+            (cfg->arch == CS_ARCH_NOMIC && hipMalloc(&h->d_rope, (size_t)cfg->max_position * half * sizeof(float2)) != hipSuccess))
             return cleanup(fail(CS_ERR_OOM, "hipMalloc(parameters) failed"));
         for (uint32_t l = 0; l < cfg->layers && s == CS_OK; ++l) {
             cs_bert_layer_offsets lo;
@@ -1335,16 +1360,16 @@ static int32_t create_impl(const cs_bert_config* cfg, const float* params, uint6
                 s = fail(CS_ERR_HIP, "feed-forward bias packing failed");
         }
         // the module's cos / sin cache, formed as it forms it: inv_freq_i = 1 / base^(2i / d_h) and pos * inv_freq_i in f32
-        std::vector<float2> rope((size_t)cfg->max_position * half);
+        std::vector<float2> rope(cfg->arch == CS_ARCH_NOMIC ? (size_t)cfg->max_position * half : 0);
         const float dh = (float)(2 * half);
-        for (size_t i = 0; i < half; ++i) {
+        for (size_t i = 0; i < half && !rope.empty(); ++i) {
             const float inv_freq = 1.0f / powf(cfg->rotary_base, (float)(2 * i) / dh);
             for (size_t p = 0; p < cfg->max_position; ++p) {
                 const float ang = (float)p * inv_freq;
                 rope[p * half + i] = make_float2(cosf(ang), sinf(ang));
             }
         }
-        if (s == CS_OK && hipMemcpy(h->d_rope, rope.data(), rope.size() * sizeof(float2), hipMemcpyHostToDevice) != hipSuccess)
+        if (s == CS_OK && !rope.empty() && hipMemcpy(h->d_rope, rope.data(), rope.size() * sizeof(float2), hipMemcpyHostToDevice) != hipSuccess)
             s = fail(CS_ERR_HIP, "rotary table upload failed");
     }
     // split-f16 copies of the four dense weights of every layer (split_f16.hpp)
@@ -1356,7 +1381,7 @@ static int32_t create_impl(const cs_bert_config* cfg, const float* params, uint6
             return cleanup(fail(CS_ERR_OOM, "hipMalloc(split weights) failed"));
         if (hipMemsetAsync(h->d_flag, 0, sizeof(uint32_t), h->stream) != hipSuccess) s = fail(CS_ERR_HIP, "memset failed");
         float* d_updown = nullptr;  // CS_ARCH_NOMIC: one layer's fc11 / fc12 rows interleaved in groups of 16, [2I][H]
-        if (cfg->arch == CS_ARCH_NOMIC && hipMalloc(&d_updown, 2 * I * H * sizeof(float)) != hipSuccess)
+        if (cs_arch_gated(cfg->arch) && hipMalloc(&d_updown, 2 * I * H * sizeof(float)) != hipSuccess)
             return cleanup(fail(CS_ERR_OOM, "hipMalloc(split weights) failed"));
         for (uint32_t l = 0; l < cfg->layers && s == CS_OK; ++l) {
             cs_bert_layer_offsets lo;
@@ -1364,7 +1389,7 @@ static int32_t create_impl(const cs_bert_config* cfg, const float* params, uint6
             _Float16* ws = h->d_wsplit + (size_t)l * sl.total;
             s = launch_split_rows(h->d_wqkv + (size_t)l * 3 * H * H, ws + sl.qkv, 3 * H, (uint32_t)H, h->d_flag, h->stream);
             if (s == CS_OK) s = launch_split_rows(h->d_params + lo.ao_w, ws + sl.ao, H, (uint32_t)H, h->d_flag, h->stream);
-            if (s == CS_OK && cfg->arch == CS_ARCH_NOMIC) {
+            if (s == CS_OK && cs_arch_gated(cfg->arch)) {
                 // one [2I, H] weight: raw output columns 32 u .. 32 u + 15 = fc11's rows 16 u .., the next sixteen fc12's, so that
                 // a value and its gate meet in one lane of the product's epilogue (GW_OUT_SWIGLU) and in one line of its output
                 const size_t grp = 16 * H * sizeof(float);
@@ -1398,7 +1423,7 @@ static int32_t create_impl(const cs_bert_config* cfg, const float* params, uint6
         if (s == CS_OK) s = sh_denorm_selftest(&denorm_ok, h->stream);
         if (s == CS_OK && !denorm_ok) { h->gemm_mode = CS_GEMM_F32; h->split_unavailable = true; }
         // the one-launch forward of short queries (small_forward.hip) reads the layers' pointers from a device table
-        if (s == CS_OK && cfg->arch != CS_ARCH_NOMIC && small_forward_supported((uint32_t)H, (uint32_t)I, cfg->heads, 1, 1)) {
+        if (s == CS_OK && !cs_arch_gated(cfg->arch) && small_forward_supported((uint32_t)H, (uint32_t)I, cfg->heads, 1, 1)) {
             std::vector<SfLayer> tab(cfg->layers);
             for (uint32_t l = 0; l < cfg->layers; ++l) {
                 cs_bert_layer_offsets lo;
@@ -1512,6 +1537,7 @@ void cs_embedder_destroy(cs_embedder* h) {
     if (h->d_bqkv) (void)hipFree(h->d_bqkv);
     if (h->d_bup) (void)hipFree(h->d_bup);
     if (h->d_rope) (void)hipFree(h->d_rope);
+    if (h->d_alibi) (void)hipFree(h->d_alibi);
     if (h->d_wsplit) (void)hipFree(h->d_wsplit);
     if (h->d_flag) (void)hipFree(h->d_flag);
     if (h->d_sf_layers) (void)hipFree(h->d_sf_layers);

@@ -423,7 +423,7 @@ template <bool SPLIT>
 __global__ void __launch_bounds__(256)
 attention_kernel(const float* __restrict__ qkv, const int32_t* __restrict__ mask,
                  float* __restrict__ ctx, _Float16* __restrict__ ctxs, uint32_t* __restrict__ flag,
-                 uint32_t L, uint32_t H, float scale) {
+                 uint32_t L, uint32_t H, float scale, const float* __restrict__ alibi) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const uint32_t Lp = (L + 31) & ~31u;
     float* Ks = smem;                 // [Lp][36]
@@ -492,6 +492,7 @@ attention_kernel(const float* __restrict__ qkv, const int32_t* __restrict__ mask
         for (int r = 0; r < 16; ++r) {
             const uint32_t key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
             st[r] = st[r] * scale + madd[key];
+            if (alibi) st[r] += alibi[head] * -fabsf((float)query - (float)key);  // JinaBert: -slope_h |i - j|
             tmax = fmaxf(tmax, st[r]);
         }
         tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
@@ -554,7 +555,7 @@ constexpr int AKT64 = 128; // keys per super-tile
 
 __global__ void __launch_bounds__(256)
 attention64_kernel(const float* __restrict__ qkv, const int32_t* __restrict__ mask, float* __restrict__ ctx,
-                   uint32_t L, uint32_t H, float scale) {
+                   uint32_t L, uint32_t H, float scale, const float* __restrict__ alibi) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const uint32_t Lp = (L + 31) & ~31u;
     float* Ks = smem;                          // [128][68]
@@ -628,6 +629,7 @@ attention64_kernel(const float* __restrict__ qkv, const int32_t* __restrict__ ma
             for (int r = 0; r < 16; ++r) {
                 const uint32_t key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
                 stt[r] = stt[r] * scale + madd[key];
+                if (alibi) stt[r] += alibi[head] * -fabsf((float)query - (float)key);  // JinaBert: -slope_h |i - j|
                 tmax = fmaxf(tmax, stt[r]);
             }
             tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
@@ -855,7 +857,7 @@ size_t attention_lds_bytes(uint32_t L) {
 
 static int32_t launch_attention_impl(const float* qkv, const int32_t* mask, float* ctx, _Float16* ctxs,
                                      uint32_t* flag, uint32_t B, uint32_t L, uint32_t H, uint32_t heads,
-                                     hipStream_t s) {
+                                     hipStream_t s, const float* alibi) {
     if (heads && H % heads == 0 && H / heads == 64 && !ctxs) {  // exact-f32 mode, 64-wide heads
         const size_t Lp = (L + 31) & ~31u;
         const size_t lds64 = ((size_t)AKT64 * (AKS64 + 64) + Lp + 4) * sizeof(float);
@@ -866,7 +868,7 @@ static int32_t launch_attention_impl(const float* qkv, const int32_t* mask, floa
             return CS_OK;
         }));
         hipLaunchKernelGGL(attention64_kernel, dim3((L + 127) / 128, heads, B), dim3(256), lds64, s, qkv, mask, ctx, L, H,
-                           1.0f / sqrtf(64.0f));
+                           1.0f / sqrtf(64.0f), alibi);
         CS_HIP(hipGetLastError());
         return CS_OK;
     }
@@ -883,14 +885,14 @@ static int32_t launch_attention_impl(const float* qkv, const int32_t* mask, floa
     dim3 grid((L + 127) / 128, heads, B);
     const float scale = 1.0f / sqrtf(32.0f);
     if (ctxs) return fail(CS_ERR_UNSUPPORTED, "the f32 attention kernel writes f32 context rows only");
-    hipLaunchKernelGGL(attention_kernel<false>, grid, dim3(256), lds, s, qkv, mask, ctx, ctxs, flag, L, H, scale);
+    hipLaunchKernelGGL(attention_kernel<false>, grid, dim3(256), lds, s, qkv, mask, ctx, ctxs, flag, L, H, scale, alibi);
     CS_HIP(hipGetLastError());
     return CS_OK;
 }
 
 int32_t launch_attention(const float* qkv, const int32_t* mask, float* ctx, uint32_t B, uint32_t L,
-                         uint32_t H, uint32_t heads, hipStream_t s) {
-    return launch_attention_impl(qkv, mask, ctx, nullptr, nullptr, B, L, H, heads, s);
+                         uint32_t H, uint32_t heads, hipStream_t s, const float* alibi) {
+    return launch_attention_impl(qkv, mask, ctx, nullptr, nullptr, B, L, H, heads, s, alibi);
 }
 
 int32_t launch_synth_params(float* d_out, const cs_bert_config& cfg, uint64_t seed, hipStream_t s) {

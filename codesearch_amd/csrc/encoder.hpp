@@ -38,8 +38,9 @@ int32_t launch_row_kernel(int which, const EncoderLaunch& a, uint32_t H, hipStre
 int32_t launch_gemm(int epi, const float* A, const float* W, const float* bias, const float* resid,
                     float* C, uint32_t M, uint32_t N, uint32_t K, hipStream_t s);
 // qkv [B*L, 3H] (Q | K | V), mask [B, L] -> ctx [B*L, H]
+// alibi (optional, device, [heads]): JinaBert's head slopes — the score of (query i, key j) gets -slope_h |i - j|
 int32_t launch_attention(const float* qkv, const int32_t* mask, float* ctx, uint32_t B, uint32_t L,
-                         uint32_t H, uint32_t heads, hipStream_t s);
+                         uint32_t H, uint32_t heads, hipStream_t s, const float* alibi = nullptr);
 size_t attention_lds_bytes(uint32_t L);
 // attention_split.hip: the same attention on the f16 MFMA with split-f16 operands:
 // attention on a split-f16 qkv [T][3H/32][64] (the QKV GEMM's SH_OUT_SPLIT output): K/V go to LDS by
@@ -51,7 +52,7 @@ size_t attention_lds_bytes(uint32_t L);
 int32_t launch_attention_sh2(const _Float16* qkv_split, const int32_t* mask, void* ctx_split, uint32_t* flag,
                              uint32_t B, uint32_t L, uint32_t H, uint32_t heads, hipStream_t s, float* range_out = nullptr,
                              uint32_t* range_pairs = nullptr, const uint32_t* seq_unit = nullptr,
-                             const uint32_t* unit_len = nullptr);
+                             const uint32_t* unit_len = nullptr, const float* alibi = nullptr);
 
 // Split-f16 GEMM (gemm_split.hip): A [M][K/32][64] f16, W [N][K/32][64] f16 (split_f16.hpp).
 enum { SH_OUT_F32 = 0, SH_OUT_F32_RESID = 1, SH_OUT_SPLIT_GELU = 2, SH_OUT_SPLIT = 3,
@@ -67,6 +68,7 @@ bool gemm_wide_supported(uint32_t N, uint32_t K);
 // epilogue of launch_gemm_wide only: W = value and gate rows interleaved in groups of 16 ([N][K], N = 2 x gated width);
 // Cs [M][N/64][64] = value * silu(gate) in split form (gemm_wide.hip; nomic.hip holds the stand-alone form)
 constexpr int GW_OUT_SWIGLU = 17;
+constexpr int GW_OUT_GEGLU = 18;   // the same with value * gelu_erf(gate): JinaBert's feed-forward
 // shape: 0 = CS_GEMM_WIDE_SHAPE / default (128 x 384 where N allows), 192 = the 128 x 192 two-blocks-per-CU shape, 384
 int32_t launch_gemm_wide(int epi, const _Float16* A, const _Float16* W, const float* bias, const float* resid, float* C,
                          _Float16* Cs, uint32_t M, uint32_t N, uint32_t K, uint32_t* d_flag, hipStream_t s, int shape = 0);
@@ -88,8 +90,14 @@ int32_t launch_gather_cls(const _Float16* xs, float* x_cls, _Float16* xs_cls, ui
 int32_t launch_rope_split(_Float16* qkvs, const float2* rope, uint32_t T, uint32_t L, uint32_t H, uint32_t heads,
                           uint32_t* flag, hipStream_t s);
 int32_t launch_rope_f32(float* qkv, const float2* rope, uint32_t T, uint32_t L, uint32_t H, uint32_t heads, hipStream_t s);
-int32_t launch_swiglu_split(const _Float16* up2, _Float16* out, uint32_t T, uint32_t I, uint32_t* flag, hipStream_t s);
-int32_t launch_swiglu_f32(float* value, const float* gate, uint32_t T, uint32_t I, hipStream_t s);
+// gelu_gate: value * gelu_erf(gate) instead (CS_ARCH_JINA*)
+int32_t launch_swiglu_split(const _Float16* up2, _Float16* out, uint32_t T, uint32_t I, uint32_t* flag, hipStream_t s,
+                            bool gelu_gate = false);
+int32_t launch_swiglu_f32(float* value, const float* gate, uint32_t T, uint32_t I, hipStream_t s, bool gelu_gate = false);
+// CS_ARCH_JINA_QKNORM: LayerNorm over the whole query row and the whole key row of a QKV tensor, in place (split form
+// [T][3H/32][64] or f32 [T][3H]); ln = gamma_q | beta_q | gamma_k | beta_k, [4][H]
+int32_t launch_qk_layernorm_split(_Float16* qkvs, const float* ln, float eps, uint32_t T, uint32_t H, uint32_t* flag, hipStream_t s);
+int32_t launch_qk_layernorm_f32(float* qkv, const float* ln, float eps, uint32_t T, uint32_t H, hipStream_t s);
 extern int g_gemm_wide_ablation;  // diagnostics (cs_debug_gemm_time)
 extern int g_gemm_wide_shape;      // diagnostics: block shape override (192 | 384), 0 = default
 extern int g_gemm_wide_mfma;       // diagnostics: MFMA shape of the wide kernel's main loop (16 | 32), 0 = default

@@ -36,7 +36,7 @@
 
 namespace cs {
 
-// GW_OUT_SWIGLU (encoder.hpp): the gated up projection of a NomicBert feed-forward.  W's rows (and the bias) are value and gate
+// GW_OUT_SWIGLU / GW_OUT_GEGLU (encoder.hpp): the gated up projection of a NomicBert (silu gate) / JinaBert (erf-GELU gate) feed-forward.  W's rows (and the bias) are value and gate
 // rows interleaved in groups of 16 — raw columns 32 u .. 32 u + 15 are fc11's rows 16 u .. 16 u + 15, the next sixteen
 // fc12's — so a wave's six 16-column MFMA tiles are value, gate, value, gate, value, gate of the SAME 48 gated columns and a
 // lane holds a value and its gate in the same register slot of neighbouring tiles: the epilogue stores
@@ -336,13 +336,15 @@ gemm_wide_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ W,
             // gamma / beta per strip from the block's LDS copy (held in registers across the strips they would cost the 48
             // registers the accumulators need; as global loads each strip's would sit behind the previous strip's stores
             // in the vmcnt queue and wait for them)
-            if constexpr (EPI == GW_OUT_SWIGLU) {
+            if constexpr (EPI == GW_OUT_SWIGLU || EPI == GW_OUT_GEGLU) {
 #pragma unroll
                 for (int jj = 0; jj < 3; ++jj) {
                     sh_f32x4 v;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        v[r] = (acc.c[i][2 * jj][r] * kShLoInv) * gw_silu(acc.c[i][2 * jj + 1][r] * kShLoInv);
+                    for (int r = 0; r < 4; ++r) {
+                        const float gt = acc.c[i][2 * jj + 1][r] * kShLoInv;
+                        v[r] = (acc.c[i][2 * jj][r] * kShLoInv) * (EPI == GW_OUT_GEGLU ? gw_gelu(gt) : gw_silu(gt));
+                    }
                     *reinterpret_cast<sh_f32x4*>(patch + l15 * PS + 16 * jj + 4 * g) = v;
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -531,6 +533,7 @@ static int32_t gemm_wide_launch(int epi, const _Float16* A, const _Float16* W, c
         CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wide_kernel<SH_OUT_SPLIT_GELU, 0, WCN>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
         CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wide_kernel<SH_OUT_SPLIT, 0, WCN>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
         CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wide_kernel<GW_OUT_SWIGLU, 0, WCN>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
+        CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wide_kernel<GW_OUT_GEGLU, 0, WCN>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
         if constexpr (WCN == 4)
             CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wide_kernel<GW_OUT_LN, 0, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
         int dev = 0, n = 0;
@@ -587,6 +590,7 @@ static int32_t gemm_wide_launch(int epi, const _Float16* A, const _Float16* W, c
     else if (epi == SH_OUT_SPLIT) GW_LAUNCH(SH_OUT_SPLIT, 0);
     else if (epi == SH_OUT_SPLIT_GELU) GW_LAUNCH(SH_OUT_SPLIT_GELU, 0);
     else if (epi == GW_OUT_SWIGLU) GW_LAUNCH(GW_OUT_SWIGLU, 0);
+    else if (epi == GW_OUT_GEGLU) GW_LAUNCH(GW_OUT_GEGLU, 0);
     else if (epi == GW_OUT_LN) {
         if constexpr (WCN == 4) GW_LAUNCH(GW_OUT_LN, 0);
         else return fail(CS_ERR_BAD_ARG, "the LayerNorm epilogue needs the 128 x 384 block");
@@ -613,7 +617,7 @@ static int32_t gemm_wide_impl(int epi, const _Float16* A, const _Float16* W, con
     // MFMA shape of the main loop: 16 x 16 x 32 (this file) | 32 x 32 x 16 (gemm_wide32.hip; CS_GEMM_WIDE_MFMA=32)
     static const int mfma_env = [] { const char* e = std::getenv("CS_GEMM_WIDE_MFMA"); return e ? std::atoi(e) : 0; }();
     const int mfma = g_gemm_wide_mfma ? g_gemm_wide_mfma : mfma_env;
-    if (mfma == 32 && !g_gemm_wide_ablation && epi != GW_OUT_SWIGLU)
+    if (mfma == 32 && !g_gemm_wide_ablation && epi != GW_OUT_SWIGLU && epi != GW_OUT_GEGLU)
         return gemm_wide32_launch(big ? 4 : 2, epi, A, W, bias, resid, C, Cs, M, N, K, d_flag, s, ln_g, ln_b, ln_eps, ln_flags);
     if (big) return gemm_wide_launch<4>(epi, A, W, bias, resid, C, Cs, M, N, K, d_flag, s, ln_g, ln_b, ln_eps, ln_flags);
     return gemm_wide_launch<2>(epi, A, W, bias, resid, C, Cs, M, N, K, d_flag, s, ln_g, ln_b, ln_eps, ln_flags);

@@ -11,6 +11,10 @@
 //   (x1_i, x2_i) -> (x1_i cos a - x2_i sin a,  x2_i cos a + x1_i sin a),   a = pos * base^(-2i / d_h),  i < d_h / 2
 // with cos / sin from a table the host fills in f32 exactly as the module builds its cache (cs_embedder_create).  With
 // d_h = 64 the two halves are two neighbouring lines of the split tensor, with d_h = 32 the two halves of one line.
+//
+// CS_ARCH_JINA / CS_ARCH_JINA_QKNORM (JinaBert: the registry's jina-embeddings-v2-base-code, embedder.rs:40-41) share the gate
+// kernels with the erf-GELU in the silu's place ( down( value * gelu(gate) ) ), and _QKNORM adds the LayerNorm its attention
+// applies to the whole query row and the whole key row before they are cut into heads: one wave per (token, Q | K).
 #include "encoder.hpp"
 #include "split_f16.hpp"
 
@@ -97,10 +101,13 @@ rope_f32_kernel(float* __restrict__ qkv, const float2* __restrict__ rope, uint32
 }
 
 __device__ __forceinline__ float silu(float v) { return v / (1.0f + expf(-v)); }
+__device__ __forceinline__ float gelu_exact(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
+template <bool GELU> __device__ __forceinline__ float gate_act(float v) { return GELU ? gelu_exact(v) : silu(v); }
 
 // up2 [T][2I/32][64], columns interleaved in groups of 16 (GW_OUT_SWIGLU's weight order, encoder.hpp): line u of a row holds
 // values 16 u .. 16 u + 15 and their gates — hi: [16 v | 16 g], lo: [16 v | 16 g] -> out [T][I/32][64].  One thread: eight
 // gated columns.
+template <bool GELU>
 __global__ void __launch_bounds__(256)
 swiglu_split_kernel(const _Float16* __restrict__ up2, _Float16* __restrict__ out, uint32_t T, uint32_t I,
                     uint32_t* __restrict__ flag) {
@@ -116,8 +123,8 @@ swiglu_split_kernel(const _Float16* __restrict__ up2, _Float16* __restrict__ out
     unsplit8(*reinterpret_cast<const f16x8*>(pg), *reinterpret_cast<const f16x8*>(pg + 32), ga, gb);
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-        va[e] = va[e] * silu(ga[e]);
-        vb[e] = vb[e] * silu(gb[e]);
+        va[e] = va[e] * gate_act<GELU>(ga[e]);
+        vb[e] = vb[e] * gate_act<GELU>(gb[e]);
     }
     f16x8 oh, ol;
     uint32_t mx = 0;
@@ -129,6 +136,7 @@ swiglu_split_kernel(const _Float16* __restrict__ up2, _Float16* __restrict__ out
 }
 
 // value [T][I] *= silu(gate [T][I])
+template <bool GELU>
 __global__ void __launch_bounds__(256)
 swiglu_f32_kernel(float* __restrict__ value, const float* __restrict__ gate, uint64_t n4) {
     const uint64_t gid = (uint64_t)blockIdx.x * 256 + threadIdx.x;
@@ -136,8 +144,88 @@ swiglu_f32_kernel(float* __restrict__ value, const float* __restrict__ gate, uin
     sh_f32x4 v = reinterpret_cast<const sh_f32x4*>(value)[gid];
     const sh_f32x4 g = reinterpret_cast<const sh_f32x4*>(gate)[gid];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = v[e] * silu(g[e]);
+    for (int e = 0; e < 4; ++e) v[e] = v[e] * gate_act<GELU>(g[e]);
     reinterpret_cast<sh_f32x4*>(value)[gid] = v;
+}
+
+// LayerNorm over the H query (which = 0) or key (which = 1) columns of one token row of the QKV tensor, in place.  One wave
+// per (token, which); a lane holds eight neighbouring columns per round (H <= 1024: two rounds).  Two-pass statistics as
+// the row kernels of encoder.hip (mean, then the variance of the deviations).  ln = gamma_q | beta_q | gamma_k | beta_k.
+template <bool SPLIT>
+__global__ void __launch_bounds__(256)
+qk_layernorm_kernel(void* __restrict__ qkv, const float* __restrict__ ln, float eps, uint32_t T, uint32_t H, uint32_t* __restrict__ flag) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint64_t job = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (job >= (uint64_t)T * 2) return;
+    const uint64_t t = job >> 1;
+    const uint32_t which = (uint32_t)(job & 1);
+    const float* gamma = ln + (size_t)which * 2 * H;
+    const float* beta = gamma + H;
+    sh_f32x4 va[2], vb[2];
+    float sum = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const uint32_t c = (lane + 64 * r) * 8;  // first of eight columns inside the Q (K) part
+        va[r] = sh_f32x4{0.f, 0.f, 0.f, 0.f}; vb[r] = va[r];
+        if (c < H) {
+            const uint32_t col = which * H + c;
+            if (SPLIT) {
+                const _Float16* p = static_cast<const _Float16*>(qkv) + t * (uint64_t)(3 * H) * 2 + (size_t)(col >> 5) * 64 + (col & 31);
+                unsplit8(*reinterpret_cast<const f16x8*>(p), *reinterpret_cast<const f16x8*>(p + 32), va[r], vb[r]);
+            } else {
+                const float* p = static_cast<const float*>(qkv) + t * (uint64_t)(3 * H) + col;
+                va[r] = *reinterpret_cast<const sh_f32x4*>(p);
+                vb[r] = *reinterpret_cast<const sh_f32x4*>(p + 4);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) sum += va[r][e] + vb[r][e];
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+    const float mean = sum / (float)H;
+    float var = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        if ((lane + 64 * r) * 8 < H) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float da = va[r][e] - mean, db = vb[r][e] - mean;
+                var += da * da + db * db;
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) var += __shfl_xor(var, o, 64);
+    const float inv = 1.0f / sqrtf(var / (float)H + eps);
+    uint32_t mx = 0;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const uint32_t c = (lane + 64 * r) * 8;
+        if (c < H) {
+            const sh_f32x4 g0 = *reinterpret_cast<const sh_f32x4*>(gamma + c), g1 = *reinterpret_cast<const sh_f32x4*>(gamma + c + 4);
+            const sh_f32x4 b0 = *reinterpret_cast<const sh_f32x4*>(beta + c), b1 = *reinterpret_cast<const sh_f32x4*>(beta + c + 4);
+            sh_f32x4 oa, ob;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                oa[e] = (va[r][e] - mean) * inv * g0[e] + b0[e];
+                ob[e] = (vb[r][e] - mean) * inv * g1[e] + b1[e];
+            }
+            const uint32_t col = which * H + c;
+            if (SPLIT) {
+                _Float16* p = static_cast<_Float16*>(qkv) + t * (uint64_t)(3 * H) * 2 + (size_t)(col >> 5) * 64 + (col & 31);
+                f16x8 oh, ol;
+                sh_split8(oa, ob, oh, ol, mx);
+                *reinterpret_cast<f16x8*>(p) = oh;
+                *reinterpret_cast<f16x8*>(p + 32) = ol;
+            } else {
+                float* p = static_cast<float*>(qkv) + t * (uint64_t)(3 * H) + col;
+                *reinterpret_cast<sh_f32x4*>(p) = oa;
+                *reinterpret_cast<sh_f32x4*>(p + 4) = ob;
+            }
+        }
+    }
+    if (SPLIT && sh_split_overflowed(mx) && flag) atomicOr(flag, 1u);
 }
 
 }  // namespace
@@ -165,19 +253,39 @@ int32_t launch_rope_f32(float* qkv, const float2* rope, uint32_t T, uint32_t L, 
     return CS_OK;
 }
 
-int32_t launch_swiglu_split(const _Float16* up2, _Float16* out, uint32_t T, uint32_t I, uint32_t* flag, hipStream_t s) {
+int32_t launch_swiglu_split(const _Float16* up2, _Float16* out, uint32_t T, uint32_t I, uint32_t* flag, hipStream_t s, bool gelu_gate) {
     if (!T) return CS_OK;
     if (I % 32) return fail(CS_ERR_UNSUPPORTED, "gated feed-forward: intermediate size %u is not a multiple of 32", I);
     const uint64_t threads = (uint64_t)T * (I / 8);
-    hipLaunchKernelGGL(swiglu_split_kernel, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, s, up2, out, T, I, flag);
+    const dim3 grid((uint32_t)((threads + 255) / 256));
+    if (gelu_gate) hipLaunchKernelGGL(swiglu_split_kernel<true>, grid, dim3(256), 0, s, up2, out, T, I, flag);
+    else hipLaunchKernelGGL(swiglu_split_kernel<false>, grid, dim3(256), 0, s, up2, out, T, I, flag);
     CS_HIP(hipGetLastError());
     return CS_OK;
 }
 
-int32_t launch_swiglu_f32(float* value, const float* gate, uint32_t T, uint32_t I, hipStream_t s) {
+int32_t launch_swiglu_f32(float* value, const float* gate, uint32_t T, uint32_t I, hipStream_t s, bool gelu_gate) {
     if (!T) return CS_OK;
     const uint64_t n4 = (uint64_t)T * I / 4;
-    hipLaunchKernelGGL(swiglu_f32_kernel, dim3((uint32_t)((n4 + 255) / 256)), dim3(256), 0, s, value, gate, n4);
+    const dim3 grid((uint32_t)((n4 + 255) / 256));
+    if (gelu_gate) hipLaunchKernelGGL(swiglu_f32_kernel<true>, grid, dim3(256), 0, s, value, gate, n4);
+    else hipLaunchKernelGGL(swiglu_f32_kernel<false>, grid, dim3(256), 0, s, value, gate, n4);
+    CS_HIP(hipGetLastError());
+    return CS_OK;
+}
+
+int32_t launch_qk_layernorm_split(_Float16* qkvs, const float* ln, float eps, uint32_t T, uint32_t H, uint32_t* flag, hipStream_t s) {
+    if (!T) return CS_OK;
+    if (H % 32 || H > 1024) return fail(CS_ERR_UNSUPPORTED, "query / key LayerNorm: hidden size %u not supported (multiples of 32 up to 1024)", H);
+    hipLaunchKernelGGL(qk_layernorm_kernel<true>, dim3((uint32_t)(((uint64_t)T * 2 + 3) / 4)), dim3(256), 0, s, (void*)qkvs, ln, eps, T, H, flag);
+    CS_HIP(hipGetLastError());
+    return CS_OK;
+}
+
+int32_t launch_qk_layernorm_f32(float* qkv, const float* ln, float eps, uint32_t T, uint32_t H, hipStream_t s) {
+    if (!T) return CS_OK;
+    if (H % 8 || H > 1024) return fail(CS_ERR_UNSUPPORTED, "query / key LayerNorm: hidden size %u not supported (multiples of 8 up to 1024)", H);
+    hipLaunchKernelGGL(qk_layernorm_kernel<false>, dim3((uint32_t)(((uint64_t)T * 2 + 3) / 4)), dim3(256), 0, s, (void*)qkv, ln, eps, T, H, (uint32_t*)nullptr);
     CS_HIP(hipGetLastError());
     return CS_OK;
 }

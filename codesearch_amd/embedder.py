@@ -18,7 +18,7 @@ import numpy as np
 
 from . import _lib
 from ._lib import CsError, f32p, i32p
-from .bert_params import ARCH_NOMIC, POOL_CLS, POOL_MEAN, BertConfig
+from .bert_params import ARCH_JINA_QKNORM, ARCH_NOMIC, POOL_CLS, POOL_MEAN, BertConfig
 from .tokenizer import pack_texts
 
 
@@ -98,9 +98,15 @@ class ModelType(enum.Enum):
             # (embedder.rs:238).  The quantised entry runs the f32 graph of its dequantised weights (encoder.hpp).
             return BertConfig(vocab_size=30528, hidden=768, layers=12, heads=12, intermediate=3072, max_position=512,
                               pooling=POOL_MEAN, arch=ARCH_NOMIC, rotary_base=1000.0)
+        if self is ModelType.JinaEmbeddingsV2BaseCode:
+            # JinaBert [3P-MEM: the model repository's config.json]: 12 x 768, 12 heads of 64, intermediate 3072, vocab 61056
+            # (its own BPE vocabulary over code), ALiBi instead of a position table, GELU-gated feed-forward, LayerNorm on
+            # the query / key rows (its auto_map names the "qk-post-norm" modelling file); mean pooling; 512 tokens as above.
+            return BertConfig(vocab_size=61056, hidden=768, layers=12, heads=12, intermediate=3072, max_position=512,
+                              pooling=POOL_MEAN, arch=ARCH_JINA_QKNORM)
         raise CsError(_lib.CS_ERR_UNSUPPORTED,
-                      f"Failed to initialize embedding model: {self.name_str()} is not a BERT or NomicBert encoder "
-                      "(the ALiBi and ModernBERT families are not built)")
+                      f"Failed to initialize embedding model: {self.name_str()} is not a BERT, NomicBert or JinaBert encoder "
+                      "(the ModernBERT family is not built)")
 
 
 # second spellings accepted by ModelType::parse (embedder.rs:178-195), verbatim

@@ -3,7 +3,7 @@
 import pytest
 
 from codesearch_amd import CsError, ModelType
-from codesearch_amd.bert_params import ARCH_NOMIC, POOL_CLS, POOL_MEAN
+from codesearch_amd.bert_params import ARCH_JINA_QKNORM, ARCH_NOMIC, POOL_CLS, POOL_MEAN
 
 M = ModelType
 
@@ -67,9 +67,11 @@ def test_gpu_runnable_architectures():
         c = m.bert_config()
         assert (c.arch, c.hidden, c.layers, c.heads, c.intermediate, c.vocab_size, c.rotary_base, c.pooling) == \
             (ARCH_NOMIC, 768, 12, 12, 3072, 30528, 1000.0, POOL_MEAN)
-    for m in (M.JinaEmbeddingsV2BaseCode, M.ModernBertEmbedLarge):
-        with pytest.raises(CsError):  # ALiBi / ModernBERT: other encoders
-            m.bert_config()
+    c = M.JinaEmbeddingsV2BaseCode.bert_config()  # JinaBert: ALiBi, GELU-gated feed-forward, LayerNorm on Q / K rows
+    assert (c.arch, c.hidden, c.layers, c.heads, c.intermediate, c.vocab_size, c.pooling) == \
+        (ARCH_JINA_QKNORM, 768, 12, 12, 3072, 61056, POOL_MEAN)
+    with pytest.raises(CsError):  # ModernBERT: another encoder
+        M.ModernBertEmbedLarge.bert_config()
     for m in M.all():  # what the configs produce is what the registry promises
         try:
             assert m.bert_config().hidden == m.dimensions()
