@@ -594,3 +594,63 @@ def test_quantised_wider_models(gpu_lib, oracle, hidden, heads, inter):
         clean += int(np.median(err) < 1e-6)
     assert clean >= 1   # where no extreme moved, the rows agree to f32 rounding
     emb.close()
+
+
+def test_search_results_are_stable_under_quantisation_noise(gpu_lib, oracle):
+    """What a USER of the default (quantised) model sees: 20,480 chunks and 64 queries embedded in the
+    dynamic-quantisation mode by the GPU and by the quantised oracle (the same 256-row call tensors), each side searched
+    for its top-10.  The two evaluations disagree on a few activation bytes per tensor, so an embedding moves by up to
+    `delta` (L2; measured here, asserted below its bound); a unit-vector cosine then moves by at most delta_q + delta_x.
+    The bar: every id the two top-10 lists do not share sits within that band of the oracle's 10th cosine — nothing outside
+    the noise band ever changes rank — planted near-duplicates are found first by both, and the lists agree on at least 9
+    of 10 ids on average."""
+    from codesearch_amd import FastEmbedder, ModelType, VectorStore
+
+    cfg = BertConfig(vocab_size=2048, hidden=384, layers=2, heads=12, intermediate=1536, max_position=64, pooling=POOL_MEAN)
+    params, wscale = quantize_linear_weights(cfg, synth_params(cfg, 31), per_channel=False, unsigned=True)
+    N, L, Q, K, CALL = 20480, 16, 64, 10, 256
+    ids, mask = synth_token_batch(cfg, 77, N, L, False)
+    rng = np.random.default_rng(5)
+    planted = rng.choice(N, Q, replace=False)
+    qids, qmask = ids[planted].copy(), mask[planted].copy()
+    for i in range(Q):  # a query = its chunk with three inner tokens replaced
+        for p in rng.choice(np.arange(1, L - 1), 3, replace=False):
+            qids[i, p] = int(rng.integers(1000, cfg.vocab_size))
+    emb = FastEmbedder(ModelType.AllMiniLML6V2Q, config=cfg, params=params, wscale=wscale)
+    assert emb.gemm_mode() == "q8"
+    g_rows = emb.embed_ids(ids, mask, batch_size=CALL)
+    g_q = emb.embed_ids(qids, qmask, batch_size=Q)
+    emb.close()
+    o_rows = np.concatenate([oracle.bert_forward(cfg, params, ids[i:i + CALL], mask[i:i + CALL], wscale=wscale)["pooled"]
+                             for i in range(0, N, CALL)])
+    o_q = oracle.bert_forward(cfg, params, qids, qmask, wscale=wscale)["pooled"]
+    d_rows = np.linalg.norm(g_rows - o_rows, axis=1)
+    d_q = np.linalg.norm(g_q - o_q, axis=1)
+    # the flip noise: median row far below its worst (most rows carry no flipped byte that matters)
+    assert d_rows.max() < 1e-2 and np.median(d_rows) < 1e-3, (d_rows.max(), np.median(d_rows))
+    assert np.abs(g_rows - o_rows).max() < 3e-3
+    store = VectorStore(None, cfg.hidden, device=0)
+    store.insert_embeddings(g_rows)
+    store.build_index()
+    g_cos, g_ids, cnt = store.search_raw(g_q, K)
+    assert (cnt == K).all()
+    o_cos_all = o_q @ o_rows.T                                     # [Q, N] oracle-side cosines of the oracle's embeddings
+    shared, worst_excess, top1_same = 0, 0.0, 0
+    for i in range(Q):
+        o_ids = np.lexsort((np.arange(N), -o_cos_all[i]))[:K]       # (cosine desc, id asc)
+        kth = o_cos_all[i, o_ids[-1]]
+        band = d_q[i] + d_rows.max()
+        gi, oi = set(g_ids[i].tolist()), set(o_ids.tolist())
+        shared += len(gi & oi)
+        for r in gi ^ oi:                                           # in one list only: inside the noise band of the k-th cosine
+            worst_excess = max(worst_excess, abs(o_cos_all[i, r] - kth) - 2 * band)
+        top1_same += int(g_ids[i][0] == o_ids[0])
+        # the planted chunk is found by both whenever its margin over the runner-up exceeds the band
+        margin = o_cos_all[i, planted[i]] - np.partition(np.delete(o_cos_all[i], planted[i]), -1)[-1]
+        if margin > 2 * band:
+            assert g_ids[i][0] == planted[i] == o_ids[0], (i, margin, band)
+    assert worst_excess <= 0.0, worst_excess
+    assert shared >= 0.9 * Q * K, shared / (Q * K)
+    print(f"q8 top-{K} stability over {N} chunks, {Q} queries: {shared / (Q * K):.4f} of ids shared, top-1 equal {top1_same}/{Q}, "
+          f"row noise L2 median {np.median(d_rows):.2e} max {d_rows.max():.2e}, query noise max {d_q.max():.2e}")
+    store.close()
