@@ -15,7 +15,7 @@ sys.path.insert(0, ROOT)
 def main():
     from codesearch_amd import _lib
 
-    lib = _lib.load()
+    lib = _lib.load_diag()  # cs_debug_*: libcsgpu_diag.so (include/codesearch_gpu_diag.h)
     M = int(os.environ.get("M", 65536))
     rounds = int(os.environ.get("ROUNDS", 5))
     iters = int(os.environ.get("ITERS", 30))
@@ -24,7 +24,7 @@ def main():
 
     def t(epi, N, K, code):
         ms = C.c_double()
-        _lib.check(lib.cs_debug_gemm_time(0, 2, epi, M, N, K, iters, code, C.byref(ms)))
+        _lib.check_diag(lib.cs_debug_gemm_time(0, 2, epi, M, N, K, iters, code, C.byref(ms)))
         return ms.value * 1e3
 
     shapes = [("qkv      N=1152 K=384  bias->split", 4, 1152, 384), ("ffn_up   N=1536 K=384  GELU->split", 1, 1536, 384),

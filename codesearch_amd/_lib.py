@@ -11,6 +11,8 @@ import os
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 # CS_LIBCSGPU: another build of the same library (A/B scripts under benchmarks/)
 LIB_PATH = os.environ.get("CS_LIBCSGPU") or os.path.join(PKG_DIR, "libcsgpu.so")
+# the diagnostic build of the same sources (csrc/Makefile): everything above plus cs_debug_*
+DIAG_LIB_PATH = os.environ.get("CS_LIBCSGPU_DIAG") or os.path.join(PKG_DIR, "libcsgpu_diag.so")
 
 CS_OK, CS_ERR_BAD_ARG, CS_ERR_DIM_MISMATCH, CS_ERR_NOT_BUILT = 0, 1, 2, 3
 CS_ERR_CANCELLED, CS_ERR_OOM, CS_ERR_HIP, CS_ERR_UNSUPPORTED = 4, 5, 6, 7
@@ -161,6 +163,10 @@ SIGNATURES = {
     "cs_embedders_embed_ids": (C.c_int32, [vp, i32p, i32p, C.c_uint64, C.c_uint32, C.c_uint32, f32p, i32p]),
     "cs_embedders_index_texts": (C.c_int32, [vp, vp, vp, C.c_char_p, u64p, C.c_uint64, C.c_uint32, u32p, i32p]),
     "cs_embedders_index_ids": (C.c_int32, [vp, vp, i32p, i32p, C.c_uint64, C.c_uint32, C.c_uint32, u32p, i32p]),
+}
+
+# include/codesearch_gpu_diag.h: exported by libcsgpu_diag.so only (operator-level parity tests, benchmarks/)
+DIAG_SIGNATURES = {
     "cs_debug_gemm_time": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                        C.c_int32, f64p]),
     "cs_debug_gemm_q8": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32, f32p, f32p, f32p, f32p, f32p, f32p, C.c_uint32,
@@ -172,6 +178,7 @@ SIGNATURES = {
 }
 
 _LIB = None
+_DIAG = None
 
 
 def load() -> C.CDLL:
@@ -197,6 +204,30 @@ def load() -> C.CDLL:
         fn.argtypes = args
     _LIB = lib
     return lib
+
+
+def load_diag() -> C.CDLL:
+    """Load libcsgpu_diag.so once: its own copy of the library (linked -Bsymbolic, loaded RTLD_LOCAL, so it coexists
+    with libcsgpu.so in one process) with the cs_debug_* entry points bound.  Errors of its calls are read with
+    check_diag."""
+    global _DIAG
+    if _DIAG is not None:
+        return _DIAG
+    if not os.path.exists(DIAG_LIB_PATH):
+        raise FileNotFoundError(f"{DIAG_LIB_PATH} is missing: build it with `make -C codesearch_amd/csrc`")
+    load()  # (torch's HIP runtime first, as above)
+    lib = C.CDLL(DIAG_LIB_PATH, mode=C.RTLD_LOCAL)
+    for name, (res, args) in {**SIGNATURES, **DIAG_SIGNATURES}.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _DIAG = lib
+    return lib
+
+
+def check_diag(status: int) -> None:
+    if status != CS_OK:
+        raise CsError(status, load_diag().cs_last_error().decode("utf-8", "replace"))
 
 
 def last_error() -> str:

@@ -98,10 +98,14 @@ int32_t launch_swiglu_f32(float* value, const float* gate, uint32_t T, uint32_t 
 // [T][3H/32][64] or f32 [T][3H]); ln = gamma_q | beta_q | gamma_k | beta_k, [4][H]
 int32_t launch_qk_layernorm_split(_Float16* qkvs, const float* ln, float eps, uint32_t T, uint32_t H, uint32_t* flag, hipStream_t s);
 int32_t launch_qk_layernorm_f32(float* qkv, const float* ln, float eps, uint32_t T, uint32_t H, hipStream_t s);
-extern int g_gemm_wide_ablation;  // diagnostics (cs_debug_gemm_time)
-extern int g_gemm_wide_shape;      // diagnostics: block shape override (192 | 384), 0 = default
-extern int g_gemm_wide_mfma;       // diagnostics: MFMA shape of the wide kernel's main loop (16 | 32), 0 = default
+#ifdef CS_DIAGNOSTICS  // libcsgpu_diag.so only (diagnostics.hip: cs_debug_gemm_time)
+extern int g_gemm_wide_ablation;  // ablation instantiation of the wide kernel to launch, 0 = the product kernel
+extern int g_gemm_wide_shape;      // block shape override (192 | 384), 0 = default
+extern int g_gemm_wide_mfma;       // MFMA shape of the wide kernel's main loop (16 | 32), 0 = default
 double gemm_wide_read_clock_ghz(double* main_cycles, double* epi_cycles);  // after an ablation-7 launch: median in-kernel clock
+#else
+constexpr int g_gemm_wide_ablation = 0, g_gemm_wide_shape = 0, g_gemm_wide_mfma = 0;
+#endif
 int32_t sh_weights_fit_wide(const _Float16* d_wsplit, uint64_t n_f16, uint32_t* d_scratch_flag, bool* ok, hipStream_t s);
 int32_t launch_synth_params(float* d_out, const cs_bert_config& cfg, uint64_t seed, hipStream_t s);
 

@@ -55,7 +55,11 @@ struct GwAcc { sh_f32x4v c[4][6]; };
 // reads hoisted out of the k loop (the pure MFMA rate); 6 = 1 without the epilogue's stores.
 // ABL 7: the product kernel plus one (s_memtime, s_memrealtime) pair per block at its first and after its last tile,
 // written to a buffer nothing else reads: the in-kernel clock (MI355X_MICROARCH.md, DVFS give-back item 6).
+// Only libcsgpu_diag.so (-DCS_DIAGNOSTICS) instantiates ABL != 0 and holds the stamp buffer; the product library compiles
+// the ABL = 0 kernels alone.
+#ifdef CS_DIAGNOSTICS
 __device__ uint64_t g_gw_stamps[8 * 512];  // per block: clk0, real0, clk1, real1, main-loop cycles, epilogue cycles, tiles
+#endif
 
 // Round 4 measured, and did not keep, three re-arrangements of WHEN this kernel's memory instructions issue (diagnostic
 // builds of commit "Wide GEMM experiments", logs profiles/r04_gemm_dma_schedule_ab.log, r04_gemm_stagger_by_cu_ab.log,
@@ -144,7 +148,7 @@ gemm_wide_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ W,
 #pragma unroll
     for (int p = 0; p < NP; ++p) dma(src, p, sh_kc_rot(nt, ntiles, kchunks), 0);
 
-    uint64_t t_clk = 0, t_real = 0, t_main = 0, t_epi = 0, t_mark = 0, n_tiles = 0;
+    [[maybe_unused]] uint64_t t_clk = 0, t_real = 0, t_main = 0, t_epi = 0, t_mark = 0, n_tiles = 0;
     if (ABL == 7) { t_clk = __builtin_amdgcn_s_memtime(); t_real = __builtin_amdgcn_s_memrealtime(); t_mark = t_clk; }
     while (slot < total_slots) {
         const uint32_t m0 = mt * GW_BM, n0 = nt * GW_BN;
@@ -456,6 +460,7 @@ gemm_wide_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ W,
         mt = nmt;
         nt = nnt;
     }
+#ifdef CS_DIAGNOSTICS
     if (ABL == 7 && tid == 0 && blockIdx.x < 512) {
         g_gw_stamps[8 * blockIdx.x + 0] = t_clk;
         g_gw_stamps[8 * blockIdx.x + 1] = t_real;
@@ -465,8 +470,10 @@ gemm_wide_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ W,
         g_gw_stamps[8 * blockIdx.x + 5] = t_epi;
         g_gw_stamps[8 * blockIdx.x + 6] = n_tiles;
     }
+#endif
 }
 
+#ifdef CS_DIAGNOSTICS
 // median over blocks of (shader cycles) / (100 MHz reference ticks) of the last ABL 7 launch, in GHz; main_cycles /
 // epi_cycles: wave 0's cycles per tile in the k loop (first barrier to last) and in the epilogue (next tile's first
 // DMAs + conversions + stores), medians over blocks
@@ -488,6 +495,7 @@ double gemm_wide_read_clock_ghz(double* main_cycles, double* epi_cycles) {
     if (epi_cycles) *epi_cycles = e[e.size() / 2];
     return v[v.size() / 2];
 }
+#endif  // CS_DIAGNOSTICS
 
 // true when every w_hi of a split weight matrix times 2^11 stays finite in f16 (|w_hi| <= 31.98)
 __global__ void __launch_bounds__(256)
@@ -516,9 +524,11 @@ int32_t sh_weights_fit_wide(const _Float16* d_wsplit, uint64_t n_f16, uint32_t* 
 
 bool gemm_wide_supported(uint32_t N, uint32_t K) { return N % 192 == 0 && K % 32 == 0 && N > 0 && K > 0; }
 
+#ifdef CS_DIAGNOSTICS
 int g_gemm_wide_ablation = 0;  // diagnostics only (cs_debug_gemm_time)
 int g_gemm_wide_shape = 0;     // diagnostics only: 192 / 384 overrides CS_GEMM_WIDE_SHAPE
 int g_gemm_wide_mfma = 0;      // diagnostics only: 16 / 32 overrides CS_GEMM_WIDE_MFMA
+#endif
 
 template <int WCN>
 static int32_t gemm_wide_launch(int epi, const _Float16* A, const _Float16* W, const float* bias, const float* resid, float* C,
@@ -553,6 +563,7 @@ static int32_t gemm_wide_launch(int epi, const _Float16* A, const _Float16* W, c
     const uint32_t grid = slots < resident ? slots : resident;
     const uint32_t kc = K / 32;
 #define GW_LAUNCH(E, V) hipLaunchKernelGGL((gemm_wide_kernel<E, V, WCN>), dim3(grid), dim3(G::THREADS), G::LDS, s, A, W, bias, resid, C, Cs, M, N, kc, d_flag, slots, ln_g, ln_b, ln_eps, ln_flags)
+#ifdef CS_DIAGNOSTICS
     if constexpr (WCN == 4) {
         if (g_gemm_wide_ablation && epi == SH_OUT_SPLIT) {
             static PerDeviceOnce abl_attr;  // function attributes are per device
@@ -585,6 +596,7 @@ static int32_t gemm_wide_launch(int epi, const _Float16* A, const _Float16* W, c
             return CS_OK;
         }
     }
+#endif  // CS_DIAGNOSTICS
     if (epi == SH_OUT_F32) GW_LAUNCH(SH_OUT_F32, 0);
     else if (epi == SH_OUT_F32_RESID) GW_LAUNCH(SH_OUT_F32_RESID, 0);
     else if (epi == SH_OUT_SPLIT) GW_LAUNCH(SH_OUT_SPLIT, 0);

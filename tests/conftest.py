@@ -60,3 +60,12 @@ def gpu_lib():
     from codesearch_amd import _lib
 
     return _lib.load()
+
+
+@pytest.fixture(scope="session")
+def diag_lib():
+    """libcsgpu_diag.so: the product sources built with -DCS_DIAGNOSTICS, which adds the operator-level cs_debug_* entry
+    points (include/codesearch_gpu_diag.h) the unit parity tests of single kernels go through."""
+    from codesearch_amd import _lib
+
+    return _lib.load_diag()

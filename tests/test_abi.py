@@ -7,8 +7,8 @@ import re
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def declared_symbols():
-    text = open(os.path.join(ROOT, "include", "codesearch_gpu.h")).read()
+def declared_symbols(header="codesearch_gpu.h"):
+    text = open(os.path.join(ROOT, "include", header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     names = set(re.findall(r"\b(cs_[a-z0-9_]+)\s*\(", text))
     inline = set(re.findall(r"static inline [a-z0-9_ ]+?\b(cs_[a-z0-9_]+)\s*\(", text))
@@ -24,6 +24,24 @@ def test_library_exports_every_declared_symbol(gpu_lib):
     for s in sorted(syms):
         assert hasattr(raw, s), f"{s} declared in include/codesearch_gpu.h but not exported"
     assert syms == set(_lib.SIGNATURES), syms ^ set(_lib.SIGNATURES)
+
+
+def test_diagnostics_live_in_their_own_library(gpu_lib):
+    """cs_debug_* (include/codesearch_gpu_diag.h) are exported by libcsgpu_diag.so — which also exports the whole product
+    ABI — and by nothing a deployment ships: libcsgpu.so holds no debug entry point and no ablation state."""
+    import subprocess
+
+    from codesearch_amd import _lib
+
+    diag = declared_symbols("codesearch_gpu_diag.h")
+    assert diag == set(_lib.DIAG_SIGNATURES) and all(s.startswith("cs_debug_") for s in diag), diag
+    raw = ctypes.CDLL(_lib.DIAG_LIB_PATH, mode=ctypes.RTLD_LOCAL)
+    for s in sorted(diag | declared_symbols()):
+        assert hasattr(raw, s), f"{s} not exported by libcsgpu_diag.so"
+    exported = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], check=True, capture_output=True, text=True).stdout
+    for needle in ("cs_debug_", "g_gw_stamps", "g_gemm_wide_ablation"):
+        assert needle not in exported, f"{needle} leaked into libcsgpu.so"
+    assert not (set(_lib.SIGNATURES) & set(_lib.DIAG_SIGNATURES))
 
 
 def test_no_gpu_means_loud_failure_not_fallback(gpu_lib):

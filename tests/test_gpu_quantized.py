@@ -59,7 +59,7 @@ def run_q8(lib, epi, A, W, sc, bias, resid=None, a_split=0):
     xq = np.empty((M, K), np.uint8)
     xp = np.empty(2, np.float32)
     acc = np.empty((M, N), np.int32)
-    _lib.check(lib.cs_debug_gemm_q8(0, epi, a_split, A.ctypes.data_as(f32p), W.ctypes.data_as(f32p), sc.ctypes.data_as(f32p),
+    _lib.check_diag(lib.cs_debug_gemm_q8(0, epi, a_split, A.ctypes.data_as(f32p), W.ctypes.data_as(f32p), sc.ctypes.data_as(f32p),
                                     bias.ctypes.data_as(f32p), None if resid is None else resid.ctypes.data_as(f32p),
                                     C_.ctypes.data_as(f32p), M, N, K, xq.ctypes.data_as(C.POINTER(C.c_uint8)),
                                     xp.ctypes.data_as(f32p), acc.ctypes.data_as(C.POINTER(C.c_int32))))
@@ -78,7 +78,7 @@ def split_round_trip(A):
 @pytest.mark.parametrize("M,N,K", [(300, 384, 384), (128, 128, 128), (1, 1536, 384), (517, 384, 1536),
                                    (4500, 384, 384), (4100, 1152, 384), (4224, 1536, 384)])
 @pytest.mark.parametrize("per_channel,unsigned", [(False, True), (True, False), (True, True)])
-def test_operators_match_the_onnx_definitions_exactly(gpu_lib, M, N, K, per_channel, unsigned):
+def test_operators_match_the_onnx_definitions_exactly(diag_lib, M, N, K, per_channel, unsigned):
     rng = np.random.default_rng(M * 7 + N + K + per_channel + 2 * unsigned)
     A = (rng.standard_normal((M, K)) * rng.choice([0.3, 1.0, 4.0], size=(M, 1))).astype(np.float32)
     A[rng.integers(0, M), rng.integers(0, K)] = 9.5   # an outlier sets the range, as in real activations
@@ -86,7 +86,7 @@ def test_operators_match_the_onnx_definitions_exactly(gpu_lib, M, N, K, per_chan
     W, d, sc = quantize_matrix(Wf, per_channel, unsigned)
     bias = (rng.standard_normal(N) * 0.1).astype(np.float32)
     resid = rng.standard_normal((M, N)).astype(np.float32)
-    got, xq, xp, acc = run_q8(gpu_lib, 2, A, W, sc, bias, resid)
+    got, xq, xp, acc = run_q8(diag_lib, 2, A, W, sc, bias, resid)
     q, xs, xz = dynamic_quantize(A)
     assert xp[0] == xs and int(xp[1]) == xz
     assert np.array_equal(xq, q)                                             # DynamicQuantizeLinear, byte for byte
@@ -97,15 +97,15 @@ def test_operators_match_the_onnx_definitions_exactly(gpu_lib, M, N, K, per_chan
     assert np.array_equal(got, want)
     # plain store and the two split-form stores (f32-class: one split round trip; the GELU is the kernels' own erf)
     base = (want_acc.astype(np.float32) * (xs * sc)[None, :].astype(np.float32) + bias[None, :]).astype(np.float32)
-    assert np.array_equal(run_q8(gpu_lib, 0, A, W, sc, bias)[0], base)
-    np.testing.assert_allclose(run_q8(gpu_lib, 4, A, W, sc, bias)[0], base, rtol=3e-7, atol=1e-9)
+    assert np.array_equal(run_q8(diag_lib, 0, A, W, sc, bias)[0], base)
+    np.testing.assert_allclose(run_q8(diag_lib, 4, A, W, sc, bias)[0], base, rtol=3e-7, atol=1e-9)
     from scipy.special import erf
     gelu = 0.5 * base.astype(np.float64) * (1.0 + erf(base.astype(np.float64) / np.sqrt(2.0)))
-    np.testing.assert_allclose(run_q8(gpu_lib, 1, A, W, sc, bias)[0], gelu, rtol=2e-6, atol=2e-7)
+    np.testing.assert_allclose(run_q8(diag_lib, 1, A, W, sc, bias)[0], gelu, rtol=2e-6, atol=2e-7)
 
 
 @pytest.mark.parametrize("M,N,K", [(300, 1536, 384), (77, 128, 128), (4500, 1536, 384)])
-def test_ffn_up_leaves_requantised(gpu_lib, M, N, K):
+def test_ffn_up_leaves_requantised(diag_lib, M, N, K):
     """FFN-up -> FFN-down: GELU(x W^T + b) is quantised again for the next Linear; the kernel computes the product twice
     (range pass, store pass) and never writes the f32 tensor.  Its bytes against DynamicQuantizeLinear of the numpy GELU:
     the kernels' own erf is 1.2e-7 off the exact one, so a value that sits on a rounding boundary may land on the other
@@ -119,7 +119,7 @@ def test_ffn_up_leaves_requantised(gpu_lib, M, N, K):
     C_ = np.empty((M, N), np.float32)
     xp = np.empty(4, np.float32)
     rows = np.empty((M, N), np.int32)
-    _lib.check(gpu_lib.cs_debug_gemm_q8(0, 5, 0, A.ctypes.data_as(f32p), W.ctypes.data_as(f32p), sc.ctypes.data_as(f32p),
+    _lib.check_diag(diag_lib.cs_debug_gemm_q8(0, 5, 0, A.ctypes.data_as(f32p), W.ctypes.data_as(f32p), sc.ctypes.data_as(f32p),
                                         bias.ctypes.data_as(f32p), None, C_.ctypes.data_as(f32p), M, N, K, None,
                                         xp.ctypes.data_as(f32p), rows.ctypes.data_as(C.POINTER(C.c_int32))))
     q, xs, xz = dynamic_quantize(A)
@@ -135,7 +135,7 @@ def test_ffn_up_leaves_requantised(gpu_lib, M, N, K):
 
 @pytest.mark.parametrize("M,N,K,epi,a_split", [(16, 1152, 384, 4, 4), (9, 384, 384, 2, 5), (200, 1536, 384, 1, 4),
                                                (33, 384, 1536, 2, 5), (1, 384, 384, 0, 4)])
-def test_few_rows_kernel_is_one_launch_with_the_same_bits(gpu_lib, M, N, K, epi, a_split):
+def test_few_rows_kernel_is_one_launch_with_the_same_bits(diag_lib, M, N, K, epi, a_split):
     """Query-side forwards run one launch per Linear (gemm_q8_skinny_kernel: range from the producer's pairs, the
     block's 16 rows quantised into LDS, K split over the waves): the same bytes and integers as the three-launch form."""
     rng = np.random.default_rng(M + N + K)
@@ -143,12 +143,12 @@ def test_few_rows_kernel_is_one_launch_with_the_same_bits(gpu_lib, M, N, K, epi,
     W, d, sc = quantize_matrix((rng.standard_normal((N, K)) * 0.05).astype(np.float32), True, False)
     bias = (rng.standard_normal(N) * 0.1).astype(np.float32)
     resid = rng.standard_normal((M, N)).astype(np.float32) if epi == 2 else None
-    got = run_q8(gpu_lib, epi, A, W, sc, bias, resid, a_split=a_split)[0]
-    ref = run_q8(gpu_lib, epi, A, W, sc, bias, resid, a_split=a_split & 1)[0]
+    got = run_q8(diag_lib, epi, A, W, sc, bias, resid, a_split=a_split)[0]
+    ref = run_q8(diag_lib, epi, A, W, sc, bias, resid, a_split=a_split & 1)[0]
     assert np.array_equal(got, ref)
 
 
-def test_row_block_products_quantise_their_own_rows(gpu_lib):
+def test_row_block_products_quantise_their_own_rows(diag_lib):
     """From 4,096 rows a K = 384 Linear takes the f32-class tensor itself: each block of the product kernel quantises its
     128 rows on the way in (reciprocal multiply, the true division where the two could round apart).  Same bytes, same
     integers, so the same outputs bit for bit as the separate quantising pass."""
@@ -161,8 +161,8 @@ def test_row_block_products_quantise_their_own_rows(gpu_lib):
         W, d, sc = quantize_matrix((rng.standard_normal((N, K)) * 0.05).astype(np.float32), True, True)
         bias = (rng.standard_normal(N) * 0.1).astype(np.float32)
         resid = rng.standard_normal((M, N)).astype(np.float32)
-        got = run_q8(gpu_lib, epi, A, W, sc, bias, resid if epi == 2 else None, a_split=a_split)[0]
-        ref = run_q8(gpu_lib, epi, A, W, sc, bias, resid if epi == 2 else None, a_split=a_split & 1)[0]
+        got = run_q8(diag_lib, epi, A, W, sc, bias, resid if epi == 2 else None, a_split=a_split)[0]
+        ref = run_q8(diag_lib, epi, A, W, sc, bias, resid if epi == 2 else None, a_split=a_split & 1)[0]
         assert np.array_equal(got, ref)
         q, xs, xz = dynamic_quantize(split_round_trip(A) if a_split & 1 else A)
         base = (((q.astype(np.int64) - xz) @ d.T).astype(np.float32) * (xs * sc)[None, :].astype(np.float32) + bias[None, :]).astype(np.float32)
@@ -179,7 +179,7 @@ def test_row_block_products_quantise_their_own_rows(gpu_lib):
         C_ = np.empty((M, N), np.float32)
         xp = np.empty(4, np.float32)
         rows = np.empty((M, N), np.int32)
-        _lib.check(gpu_lib.cs_debug_gemm_q8(0, 5, a_split, A.ctypes.data_as(f32p), W.ctypes.data_as(f32p), sc.ctypes.data_as(f32p),
+        _lib.check_diag(diag_lib.cs_debug_gemm_q8(0, 5, a_split, A.ctypes.data_as(f32p), W.ctypes.data_as(f32p), sc.ctypes.data_as(f32p),
                                             bias.ctypes.data_as(f32p), None, C_.ctypes.data_as(f32p), M, N, K, None,
                                             xp.ctypes.data_as(f32p), rows.ctypes.data_as(C.POINTER(C.c_int32))))
         outs.append((C_, xp.copy(), rows.reshape(-1)[:M].copy()))
@@ -204,7 +204,7 @@ def _quantize_with(x, lo, hi):
 @pytest.mark.parametrize("L,units", [(50, [(30, 50), (2, 7), (40, 33), (18, 50)]),        # borders inside row blocks
                                      (128, [(8, 128), (8, 70), (16, 128), (4, 1)]),        # whole row blocks per unit
                                      (37, [(1, 37)] * 5 + [(110, 20), (1, 36)])])          # many units inside one row block
-def test_row_block_products_over_several_units(gpu_lib, L, units):
+def test_row_block_products_over_several_units(diag_lib, L, units):
     """Queued calls share a device batch but stay their own quantisation units: the row-block products quantise every row
     with its OWN unit's (scale, zero point), a unit's range covers only the rows inside its own padded length, and the
     FFN-up range pass keeps the units' extremes apart — against numpy unit by unit: same bytes, same integers."""
@@ -227,7 +227,7 @@ def test_row_block_products_over_several_units(gpu_lib, L, units):
         C_ = np.empty((M, N), np.float32)
         rp = np.empty((M, 4), np.float32)
         sums = np.empty(M, np.int32)
-        _lib.check(gpu_lib.cs_debug_gemm_q8_units(0, epi, A.ctypes.data_as(f32p), W.ctypes.data_as(f32p), sc.ctypes.data_as(f32p),
+        _lib.check_diag(diag_lib.cs_debug_gemm_q8_units(0, epi, A.ctypes.data_as(f32p), W.ctypes.data_as(f32p), sc.ctypes.data_as(f32p),
                                                   bias.ctypes.data_as(f32p), None if resid is None else resid.ctypes.data_as(f32p),
                                                   C_.ctypes.data_as(f32p), M, N, K, slot.ctypes.data_as(C.POINTER(C.c_uint32)), U,
                                                   rp.ctypes.data_as(f32p), sums.ctypes.data_as(C.POINTER(C.c_int32))))
@@ -265,35 +265,35 @@ def test_row_block_products_over_several_units(gpu_lib, L, units):
     assert np.array_equal(sums, got.astype(np.int64).sum(axis=1))
 
 
-def test_split_form_activations_quantise_like_their_f32_values(gpu_lib):
+def test_split_form_activations_quantise_like_their_f32_values(diag_lib):
     """Attention and GELU hand their outputs over in split-f16 form: the quantiser reads hi + lo / 2048."""
     rng = np.random.default_rng(5)
     M, N, K = 200, 384, 1536
     A = (rng.standard_normal((M, K)) * 2).astype(np.float32)
     W, d, sc = quantize_matrix((rng.standard_normal((N, K)) * 0.03).astype(np.float32), True, True)
     bias = np.zeros(N, np.float32)
-    _, xq, xp, acc = run_q8(gpu_lib, 0, A, W, sc, bias, a_split=1)
+    _, xq, xp, acc = run_q8(diag_lib, 0, A, W, sc, bias, a_split=1)
     q, xs, xz = dynamic_quantize(split_round_trip(A))
     assert xp[0] == xs and int(xp[1]) == xz and np.array_equal(xq, q)
     assert np.array_equal(acc.astype(np.int64), (q.astype(np.int64) - xz) @ d.T)
 
 
-def test_degenerate_ranges_and_bad_blocks(gpu_lib):
+def test_degenerate_ranges_and_bad_blocks(diag_lib):
     M, N, K = 40, 128, 128
     W, d, sc = quantize_matrix(np.random.default_rng(1).standard_normal((N, K)).astype(np.float32) * 0.1, False, True)
     bias = np.arange(N, dtype=np.float32)
     # all-zero activations: hi == lo -> scale 1, zero point 0, the output is the bias
-    got, xq, xp, _ = run_q8(gpu_lib, 0, np.zeros((M, K), np.float32), W, sc, bias)
+    got, xq, xp, _ = run_q8(diag_lib, 0, np.zeros((M, K), np.float32), W, sc, bias)
     assert xp[0] == 1.0 and xp[1] == 0.0 and not xq.any() and np.array_equal(got, np.tile(bias, (M, 1)))
     # all-negative and all-positive tensors: the range still includes zero
     for sign in (-1.0, 1.0):
         A = (sign * (1.0 + np.random.default_rng(2).random((M, K)))).astype(np.float32)
-        _, xq, xp, _ = run_q8(gpu_lib, 0, A, W, sc, bias)
+        _, xq, xp, _ = run_q8(diag_lib, 0, A, W, sc, bias)
         q, xs, xz = dynamic_quantize(A)
         assert xp[0] == xs and int(xp[1]) == xz == (255 if sign < 0 else 0) and np.array_equal(xq, q)
     # weights that are not multiples of their scales are refused, not silently re-quantised
     with pytest.raises(_lib.CsError, match="not a quantised matrix"):
-        run_q8(gpu_lib, 0, np.ones((M, K), np.float32), (W + np.float32(0.37) * sc[:, None]).astype(np.float32), sc, bias)
+        run_q8(diag_lib, 0, np.ones((M, K), np.float32), (W + np.float32(0.37) * sc[:, None]).astype(np.float32), sc, bias)
 
 
 def small_cfg(pooling, layers=2):
