@@ -386,6 +386,140 @@ const Tensor* weight_of_bias(const Model& m, const std::string& bias_name, uint6
     return nullptr;
 }
 
+// ---- NomicBert exports (the registry's nomic-embed-text entries: what fastembed caches is onnx/model.onnx, or
+// onnx/model_quantized.onnx for the *Q entry) ------------------------------------------------------------------------------
+// The Linear layers of the published checkpoints have NO bias, so there is no named bias whose Add leads to the weight (the
+// anchor of the BERT reader above): a torch export leaves every such weight as an anonymous transposed initialiser
+// (`onnx::MatMul_N`, [in, out]) on the second input of a MatMul — MatMulInteger behind DynamicQuantizeLinear in the
+// quantised file.  They are therefore taken by STRUCTURE: the MatMul / MatMulInteger nodes whose second input is a 2-D
+// initialiser, in graph (= execution) order, are per layer  Wqkv [H, 3H] | out_proj [H, H] | fc11, fc12 [H, I] | fc2 [I, H]
+// (the products between activations — Q K^T, P V — have no initialiser and drop out); of the two [H, I] products the gate
+// (fc12) is the one whose result reaches a Sigmoid (silu(g) = g * sigmoid(g)) — the order decides only where no Sigmoid
+// is found.  LayerNorm parameters and the embedding tables keep their module names (emb_ln, encoder.layers.N.norm1 /
+// norm2).  A quantised file is read as (q - zero_point) * scale into the f32 block: the Nomic encoder runs the f32 graph of
+// those weights (the dynamic-quantisation mode is BERT's, embedder.hip).  Restated from how torch.onnx lays such a module
+// out; no Nomic export is on disk here (parity unpinned).
+struct WeightProduct { const Node* node; const Tensor* w; Quant q; bool quantised; };
+
+// does the float result of product node `n` reach a Sigmoid through at most `depth` Cast / Mul nodes?
+bool reaches_sigmoid(const Model& m, const std::string& name, int depth) {
+    auto range = m.consumers.equal_range(name);
+    for (auto it = range.first; it != range.second; ++it) {
+        const Node& c = m.nodes[it->second];
+        if (c.op == "Sigmoid") return true;
+    }
+    if (depth <= 0) return false;
+    for (auto it = range.first; it != range.second; ++it) {
+        const Node& c = m.nodes[it->second];
+        if ((c.op == "Cast" || c.op == "Mul") && !c.out.empty() && reaches_sigmoid(m, c.out[0], depth - 1)) return true;
+    }
+    return false;
+}
+
+int32_t nomic_params_from_onnx(const Model& m, const cs_bert_config* cfg, const cs_bert_offsets& o, float* params, const char* path) {
+    const uint64_t H = cfg->hidden, I = cfg->intermediate;
+    std::string mod_prefix;
+    {
+        static const std::string anchor = "embeddings.word_embeddings.weight";
+        for (const auto& kv : m.init) {
+            const std::string& nm = kv.first;
+            if (nm.size() >= anchor.size() && nm.compare(nm.size() - anchor.size(), anchor.size(), anchor) == 0) {
+                mod_prefix = nm.substr(0, nm.size() - anchor.size());
+                break;
+            }
+        }
+    }
+    auto named = [&](const std::string& name) -> const Tensor* { return m.tensor(mod_prefix + name); };
+    auto vec = [&](const std::string& name, uint64_t n, float* dst, bool optional) -> int32_t {
+        const Tensor* t = named(name);
+        if (!t) {
+            if (optional) { std::memset(dst, 0, n * sizeof(float)); return CS_OK; }
+            return fail(CS_ERR_BAD_ARG, "Failed to initialize embedding model: tensor %s is missing from %s", name.c_str(), path);
+        }
+        if (t->count() != n || t->dims.size() > 2)
+            return fail(CS_ERR_DIM_MISMATCH, "Failed to initialize embedding model: %s has %llu elements, config.json implies %llu",
+                        name.c_str(), (unsigned long long)t->count(), (unsigned long long)n);
+        return copy_matrix(*t, 1, n, false, dst, name.c_str());
+    };
+    auto table = [&](const std::string& name, uint64_t rows, float* dst) -> int32_t {
+        const Tensor* t = named(name);
+        if (!t) return fail(CS_ERR_BAD_ARG, "Failed to initialize embedding model: tensor %s is missing from %s", name.c_str(), path);
+        if (!shape_is(*t, {rows, H}))
+            return fail(CS_ERR_DIM_MISMATCH, "Failed to initialize embedding model: %s does not have shape [%llu, %llu]",
+                        name.c_str(), (unsigned long long)rows, (unsigned long long)H);
+        return copy_matrix(*t, rows, H, false, dst, name.c_str());
+    };
+    CS_TRY(table("embeddings.word_embeddings.weight", cfg->vocab_size, params + o.word));
+    CS_TRY(table("embeddings.token_type_embeddings.weight", cfg->type_vocab_size, params + o.type));
+    CS_TRY(vec("emb_ln.weight", H, params + o.emb_ln_g, false));
+    CS_TRY(vec("emb_ln.bias", H, params + o.emb_ln_b, false));
+
+    std::vector<WeightProduct> prods;
+    for (const Node& n : m.nodes) {
+        if (n.op == "MatMul" && n.in.size() == 2) {
+            const Tensor* w = m.resolve(n.in[1]);
+            if (w && w->dims.size() == 2) prods.push_back({&n, w, Quant{}, false});
+        } else if (n.op == "MatMulInteger" && n.in.size() >= 2) {
+            const Tensor* w = m.tensor(n.in[1]);
+            Quant q;
+            if (w && w->dims.size() == 2 && (w->dtype == 2 || w->dtype == 3) && quant_of(m, *w, q)) prods.push_back({&n, w, q, true});
+        }
+    }
+    if (prods.size() != (size_t)5 * cfg->layers)
+        return fail(CS_ERR_BAD_ARG, "Failed to initialize embedding model: %s holds %zu weight products (MatMul / MatMulInteger with a "
+                    "2-D initialiser), a nomic_bert export of %u layers holds %u", path, prods.size(), cfg->layers, 5 * cfg->layers);
+    std::vector<float> packed((size_t)3 * H * H);
+    for (uint32_t l = 0; l < cfg->layers; ++l) {
+        cs_bert_layer_offsets lo;
+        cs_bert_layer_layout(cfg, &o, l, &lo);
+        const WeightProduct* e = &prods[(size_t)5 * l];
+        auto want = [&](int i, uint64_t in, uint64_t out, const char* what) -> int32_t {
+            if (!shape_is(*e[i].w, {in, out}))
+                return fail(CS_ERR_DIM_MISMATCH, "Failed to initialize embedding model: layer %u's %s product does not hold a [%llu, %llu] "
+                            "weight (%s)", l, what, (unsigned long long)in, (unsigned long long)out, e[i].w->name.c_str());
+            return CS_OK;
+        };
+        CS_TRY(want(0, H, 3 * H, "Wqkv"));
+        CS_TRY(want(1, H, H, "out_proj"));
+        CS_TRY(want(2, H, I, "fc11 / fc12"));
+        CS_TRY(want(3, H, I, "fc11 / fc12"));
+        CS_TRY(want(4, I, H, "fc2"));
+        auto copy = [&](int i, uint64_t out, uint64_t in, float* dst, const char* what) -> int32_t {
+            return copy_matrix(*e[i].w, out, in, true, dst, what, e[i].quantised ? &e[i].q : nullptr);
+        };
+        CS_TRY(copy(0, 3 * H, H, packed.data(), "Wqkv"));
+        std::memcpy(params + lo.q_w, packed.data(), H * H * sizeof(float));
+        std::memcpy(params + lo.k_w, packed.data() + H * H, H * H * sizeof(float));
+        std::memcpy(params + lo.v_w, packed.data() + 2 * H * H, H * H * sizeof(float));
+        CS_TRY(copy(1, H, H, params + lo.ao_w, "out_proj"));
+        const bool g2 = !e[2].node->out.empty() && reaches_sigmoid(m, e[2].node->out[0], 3);
+        const bool g3 = !e[3].node->out.empty() && reaches_sigmoid(m, e[3].node->out[0], 3);
+        if (g2 && g3)
+            return fail(CS_ERR_UNSUPPORTED, "Failed to initialize embedding model: both feed-forward up projections of layer %u reach a "
+                        "Sigmoid in %s (not the swiglu arrangement)", l, path);
+        const int gate = g2 ? 2 : 3, value = g2 ? 3 : 2;  // (no Sigmoid found: the module's own order, fc11 then fc12)
+        CS_TRY(copy(value, I, H, params + lo.up_w, "fc11"));
+        CS_TRY(copy(gate, I, H, params + lo.gate_w, "fc12"));
+        CS_TRY(copy(4, H, I, params + lo.down_w, "fc2"));
+        const std::string p = "encoder.layers." + std::to_string(l) + ".";
+        // Linear biases: none in the published files (zero slots); taken by name where an export kept one
+        std::vector<float> b3((size_t)3 * H);
+        CS_TRY(vec(p + "attn.Wqkv.bias", 3 * H, b3.data(), true));
+        std::memcpy(params + lo.q_b, b3.data(), H * sizeof(float));
+        std::memcpy(params + lo.k_b, b3.data() + H, H * sizeof(float));
+        std::memcpy(params + lo.v_b, b3.data() + 2 * H, H * sizeof(float));
+        CS_TRY(vec(p + "attn.out_proj.bias", H, params + lo.ao_b, true));
+        CS_TRY(vec(p + "mlp.fc11.bias", I, params + lo.up_b, true));
+        CS_TRY(vec(p + "mlp.fc12.bias", I, params + lo.gate_b, true));
+        CS_TRY(vec(p + "mlp.fc2.bias", H, params + lo.down_b, true));
+        CS_TRY(vec(p + "norm1.weight", H, params + lo.ao_ln_g, false));
+        CS_TRY(vec(p + "norm1.bias", H, params + lo.ao_ln_b, false));
+        CS_TRY(vec(p + "norm2.weight", H, params + lo.out_ln_g, false));
+        CS_TRY(vec(p + "norm2.bias", H, params + lo.out_ln_b, false));
+    }
+    return CS_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -398,8 +532,8 @@ int32_t cs_bert_params_from_onnx_q(const char* path, const cs_bert_config* cfg, 
                                    float* wscale, uint64_t n_wscale, int32_t* quantized) {
     if (quantized) *quantized = 0;
     if (!path || !cfg || !params) return fail(CS_ERR_BAD_ARG, "null argument");
-    if (cfg->arch != CS_ARCH_BERT)  // the names and graph shapes below are a BERT export's
-        return fail(CS_ERR_UNSUPPORTED, "Failed to initialize embedding model: only BERT exports are read from ONNX files (%s)", path);
+    if (cfg->arch != CS_ARCH_BERT && cfg->arch != CS_ARCH_NOMIC)  // the names and graph shapes below are a BERT export's
+        return fail(CS_ERR_UNSUPPORTED, "Failed to initialize embedding model: only BERT and NomicBert exports are read from ONNX files (%s)", path);
     const uint64_t qcols = 5 * (uint64_t)cfg->hidden + cfg->intermediate;
     if (wscale && n_wscale != (uint64_t)cfg->layers * qcols)
         return fail(CS_ERR_BAD_ARG, "Failed to initialize embedding model: room for %llu column scales, %llu needed",
@@ -424,6 +558,7 @@ int32_t cs_bert_params_from_onnx_q(const char* path, const cs_bert_config* cfg, 
 
     Model m;
     CS_TRY(parse_model(Span{(const uint8_t*)map, (const uint8_t*)map + sb.st_size}, m, path));
+    if (cfg->arch == CS_ARCH_NOMIC) return nomic_params_from_onnx(m, cfg, o, params, path);  // (*quantized stays 0: f32 graph)
     const uint64_t H = cfg->hidden, I = cfg->intermediate;
 
     // a tensor whose state-dict name survived the export, under whatever module prefix the exported model was

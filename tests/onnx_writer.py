@@ -213,3 +213,78 @@ def bert_onnx(sd: dict, layers: int, style: str = "matmul", dtype: int = FLOAT, 
         keep(p + "output.LayerNorm.weight")
         keep(p + "output.LayerNorm.bias")
     return model(nodes, inits)
+
+
+def nomic_onnx(sd: dict, layers: int, quantized: bool = False, qdtype: int = UINT8, per_channel: bool = False,
+               gate_first: bool = False, dtype: int = FLOAT, prefix: str = "", dequantized: dict = None) -> bytes:
+    """sd: a NomicBert state dict under the model repository's names (emb_ln, encoder.layers.N.attn.Wqkv / out_proj, norm1,
+    mlp.fc11 / fc12 / fc2, norm2; no Linear biases).  The layout torch's exporter gives such a module (the real thing:
+    tests/golden/nomic_tiny_export.onnx): embedding tables and LayerNorm parameters under their names, every Linear weight an
+    anonymous transposed `onnx::MatMul_N` on a MatMul's second input, the attention products as MatMuls between
+    activations, silu as Sigmoid + Mul.  quantized: onnxruntime's dynamic quantisation of it (DynamicQuantizeLinear ->
+    MatMulInteger -> Cast -> Mul(scales); `dequantized` receives name -> the f32 weights a reader must reproduce).
+    gate_first: fc12's product is emitted before fc11's (a reader must find the gate by its Sigmoid, not by position)."""
+    inits, nodes, counter = [], [], [2000]
+
+    def keep(name):
+        inits.append(tensor(prefix + name, sd[name], dtype))
+
+    def product(base, x):
+        w = sd[base + ".weight"]
+        counter[0] += 1
+        anon = f"onnx::MatMul_{counter[0]}"
+        y = f"/{base}/MatMul_output_0"
+        if not quantized:
+            inits.append(tensor(anon, w.T, dtype, packed_float_data=(counter[0] % 2 == 0)))
+            nodes.append(node("MatMul", [x, anon], [y]))
+            return y
+        q, sc, zp = quantize(w.T, qdtype, axis=1 if per_channel else None)   # stored [in, out]; channels = outputs
+        inits.append(raw_tensor(anon + "_quantized", q, qdtype))
+        inits.append(tensor(anon + "_scale", sc))
+        inits.append(raw_tensor(anon + "_zero_point", zp, qdtype))
+        if dequantized is not None:
+            dequantized[base + ".weight"] = ((q.astype(np.float32) - zp.astype(np.float32)) * sc).T.astype(np.float32)
+        xq, xs, xz = (f"/{base}/x_{t}" for t in ("quantized", "scale", "zero_point"))
+        nodes.append(node("DynamicQuantizeLinear", [x], [xq, xs, xz]))
+        nodes.append(node("MatMulInteger", [xq, anon + "_quantized", xz, anon + "_zero_point"], [f"/{base}/mmi"]))
+        nodes.append(node("Cast", [f"/{base}/mmi"], [f"/{base}/mmi_f"], attrs=[("to", 1)]))
+        nodes.append(node("Mul", [xs, anon + "_scale"], [f"/{base}/scales"]))
+        nodes.append(node("Mul", [f"/{base}/mmi_f", f"/{base}/scales"] if counter[0] % 2 else [f"/{base}/scales", f"/{base}/mmi_f"], [y]))
+        return y
+
+    for n in ("embeddings.word_embeddings.weight", "embeddings.token_type_embeddings.weight", "emb_ln.weight", "emb_ln.bias"):
+        keep(n)
+    nodes.append(node("Gather", [prefix + "embeddings.word_embeddings.weight", "input_ids"], ["/we"]))
+    nodes.append(node("Gather", [prefix + "embeddings.token_type_embeddings.weight", "token_type_ids"], ["/te"]))
+    nodes.append(node("Add", ["/we", "/te"], ["/emb"]))
+    nodes.append(node("LayerNormalization", ["/emb", prefix + "emb_ln.weight", prefix + "emb_ln.bias"], ["/x0"]))
+    x = "/x0"
+    for l in range(layers):
+        p = f"encoder.layers.{l}."
+        qkv = product(p + "attn.Wqkv", x)
+        nodes.append(node("Split", [qkv], [f"/q{l}", f"/k{l}", f"/v{l}"]))
+        nodes.append(node("MatMul", [f"/q{l}", f"/k{l}"], [f"/s{l}"]))          # products between activations: no initialiser
+        nodes.append(node("Softmax", [f"/s{l}"], [f"/p{l}"]))
+        nodes.append(node("MatMul", [f"/p{l}", f"/v{l}"], [f"/ctx{l}"]))
+        ao = product(p + "attn.out_proj", f"/ctx{l}")
+        nodes.append(node("Add", [ao, x], [f"/r1_{l}"]))
+        keep(p + "norm1.weight")
+        keep(p + "norm1.bias")
+        nodes.append(node("LayerNormalization", [f"/r1_{l}", prefix + p + "norm1.weight", prefix + p + "norm1.bias"], [f"/x1_{l}"]))
+        x = f"/x1_{l}"
+        if gate_first:
+            g = product(p + "mlp.fc12", x)
+            v = product(p + "mlp.fc11", x)
+        else:
+            v = product(p + "mlp.fc11", x)
+            g = product(p + "mlp.fc12", x)
+        nodes.append(node("Sigmoid", [g], [f"/sig{l}"]))
+        nodes.append(node("Mul", [g, f"/sig{l}"], [f"/silu{l}"]))
+        nodes.append(node("Mul", [v, f"/silu{l}"], [f"/gated{l}"]))
+        down = product(p + "mlp.fc2", f"/gated{l}")
+        nodes.append(node("Add", [down, x], [f"/r2_{l}"]))
+        keep(p + "norm2.weight")
+        keep(p + "norm2.bias")
+        nodes.append(node("LayerNormalization", [f"/r2_{l}", prefix + p + "norm2.weight", prefix + p + "norm2.bias"], [f"/x2_{l}"]))
+        x = f"/x2_{l}"
+    return model(nodes, inits)

@@ -223,23 +223,102 @@ def test_c_abi_loader_reads_a_nomic_snapshot(tmp_path, gpu_lib):
     expect(bad, _lib.CS_ERR_BAD_ARG, "encoder.layers.2.attn.Wqkv.weight is missing")
 
 
-def test_onnx_reader_refuses_a_nomic_config(tmp_path, gpu_lib):
-    """The ONNX reader's names and graph shapes are a BERT export's: a CS_ARCH_NOMIC config is refused before the file is
-    opened, and a nomic_bert directory that holds only an ONNX file says what it needs."""
+def nomic_state_dict(cfg, flat):
+    """The flat block under the model repository's tensor names (what nomic_snapshot writes into model.safetensors)."""
+    ours = to_state_dict(cfg, flat)
+    sd = {"embeddings.word_embeddings.weight": ours["embeddings.word_embeddings.weight"],
+          "embeddings.token_type_embeddings.weight": ours["embeddings.token_type_embeddings.weight"],
+          "emb_ln.weight": ours["embeddings.LayerNorm.weight"], "emb_ln.bias": ours["embeddings.LayerNorm.bias"]}
+    for l in range(cfg.layers):
+        a, b = f"encoder.layer.{l}.", f"encoder.layers.{l}."
+        sd[b + "attn.Wqkv.weight"] = np.concatenate([ours[a + f"attention.self.{r}.weight"] for r in ("query", "key", "value")])
+        for theirs, mine in (("attn.out_proj", "attention.output.dense"), ("mlp.fc11", "intermediate.dense"),
+                             ("mlp.fc12", "intermediate.gate"), ("mlp.fc2", "output.dense")):
+            sd[b + theirs + ".weight"] = ours[a + mine + ".weight"]
+        for n, o in (("norm1", "attention.output.LayerNorm"), ("norm2", "output.LayerNorm")):
+            sd[b + n + ".weight"], sd[b + n + ".bias"] = ours[a + o + ".weight"], ours[a + o + ".bias"]
+    return sd
+
+
+def load_nomic_onnx(gpu_lib, path, cfg):
     import ctypes as C
 
     from codesearch_amd import _lib
 
+    c = cfg.to_c()
+    out = np.full(param_count(cfg), np.nan, np.float32)
+    rc = gpu_lib.cs_bert_params_from_onnx(str(path).encode(), C.byref(c), out.ctypes.data_as(_lib.f32p), out.size)
+    return rc, out, gpu_lib.cs_last_error().decode()
+
+
+def test_onnx_reader_reads_a_nomic_export_written_by_torchs_own_exporter(gpu_lib):
+    """tests/golden/nomic_tiny_export.onnx (make_nomic_onnx_fixture.py): a NomicBert-shaped module through torch.onnx's
+    TorchScript exporter — bias-free Linear weights as anonymous transposed initialisers, silu as Sigmoid + Mul, the
+    attention products as MatMuls between activations.  The flat block must equal the one built from the state dict it was
+    exported from, bit for bit (what fastembed caches for the registry's Nomic entries is such a file, embedder.rs:36-37)."""
+    from codesearch_amd import _lib
+
+    gold = os.path.join(os.path.dirname(__file__), "golden")
+    cfg = BertConfig(vocab_size=48, hidden=64, layers=2, heads=2, intermediate=128, max_position=512, pooling=POOL_MEAN,
+                     arch=ARCH_NOMIC, rotary_base=1000.0)
+    rc, got, err = load_nomic_onnx(gpu_lib, os.path.join(gold, "nomic_tiny_export.onnx"), cfg)
+    assert rc == _lib.CS_OK, err
+    assert np.array_equal(got, from_nomic_state_dict(cfg, dict(np.load(os.path.join(gold, "nomic_tiny_export_state.npz")))))
+    # a config with another layer count does not match the file's weight products
+    rc, _, err = load_nomic_onnx(gpu_lib, os.path.join(gold, "nomic_tiny_export.onnx"), BertConfig(**{**cfg.__dict__, "layers": 3}))
+    assert rc == _lib.CS_ERR_BAD_ARG and "weight products" in err
+
+
+@pytest.mark.parametrize("quantized,per_channel,gate_first", [(False, False, False), (False, False, True), (True, False, False),
+                                                              (True, True, True)])
+def test_onnx_reader_finds_nomic_weights_by_graph_structure(tmp_path, gpu_lib, quantized, per_channel, gate_first):
+    """The same layout at the models' width from tests/onnx_writer.py: f32 and dynamically quantised (the *Q entry's
+    model_quantized.onnx: read as (q - zero_point) * scale, per tensor or per output channel), the gate found by the Sigmoid
+    its product feeds whichever of fc11 / fc12 comes first in the file, F16 initialisers, a module prefix."""
+    from codesearch_amd import _lib
+    from tests import onnx_writer
+
+    cfg = BertConfig(vocab_size=300, hidden=384, layers=2, heads=12, intermediate=1536, max_position=512, pooling=POOL_MEAN,
+                     arch=ARCH_NOMIC, rotary_base=1000.0)
+    flat = synth_params(cfg, 5)
+    sd = nomic_state_dict(cfg, flat)
+    deq = {}
+    p = tmp_path / "model.onnx"
+    p.write_bytes(onnx_writer.nomic_onnx(sd, cfg.layers, quantized=quantized, per_channel=per_channel, gate_first=gate_first,
+                                         prefix="model." if gate_first else "", dequantized=deq))
+    rc, got, err = load_nomic_onnx(gpu_lib, p, cfg)
+    assert rc == _lib.CS_OK, err
+    want_sd = dict(sd)
+    want_sd.update(deq)
+    want = from_nomic_state_dict(cfg, want_sd)   # (Linear biases: none in the file -> zero slots)
+    assert np.array_equal(got, want)
+    if quantized:
+        assert np.abs(got - from_nomic_state_dict(cfg, sd)).max() < 2e-3 and not np.array_equal(got, from_nomic_state_dict(cfg, sd))
+    if not quantized and not gate_first:  # F16 payloads
+        p.write_bytes(onnx_writer.nomic_onnx(sd, cfg.layers, dtype=onnx_writer.FLOAT16))
+        rc, got16, err = load_nomic_onnx(gpu_lib, p, cfg)
+        assert rc == _lib.CS_OK, err
+        h = {k: v.astype(np.float16).astype(np.float32) for k, v in sd.items()}
+        assert np.array_equal(got16, from_nomic_state_dict(cfg, h))
+
+
+def test_onnx_reader_refusals_for_nomic(tmp_path, gpu_lib):
+    """A file that is not an ONNX graph, a BERT export under a nomic_bert config, and an encoder family the reader has no
+    branch for are refused with worded errors."""
+    import ctypes as C
+
+    from codesearch_amd import _lib
+    from codesearch_amd.bert_params import ARCH_JINA
+
     cfg = BertConfig(vocab_size=300, hidden=384, layers=1, heads=12, intermediate=1536, pooling=POOL_MEAN, arch=ARCH_NOMIC,
                      rotary_base=1000.0)
-    c = cfg.to_c()
-    out = np.zeros(param_count(cfg), np.float32)
-    rc = gpu_lib.cs_bert_params_from_onnx(str(tmp_path / "model.onnx").encode(), C.byref(c), out.ctypes.data_as(_lib.f32p), out.size)
-    assert rc == _lib.CS_ERR_UNSUPPORTED and "only BERT exports" in gpu_lib.cs_last_error().decode()
     d = tmp_path / "snap"
     nomic_snapshot(d, cfg, synth_params(cfg, 1))
     (d / "model.safetensors").rename(d / "elsewhere.bin")
     (d / "model.onnx").write_bytes(b"\x08\x07")
     h = C.c_void_p()
     rc = gpu_lib.cs_embedder_create_from_dir(str(d).encode(), -1, 0, C.byref(h))
-    assert rc == _lib.CS_ERR_UNSUPPORTED and "model.safetensors" in gpu_lib.cs_last_error().decode()
+    assert rc == _lib.CS_ERR_BAD_ARG and "holds no graph" in gpu_lib.cs_last_error().decode()
+    jina = BertConfig(vocab_size=300, hidden=384, layers=1, heads=12, intermediate=1536, pooling=POOL_MEAN, arch=ARCH_JINA)
+    rc, _, err = load_nomic_onnx(gpu_lib, d / "model.onnx", jina)
+    assert rc == _lib.CS_ERR_UNSUPPORTED and "only BERT and NomicBert exports" in err
