@@ -376,8 +376,17 @@ int32_t cs_embedder_create(const cs_bert_config* cfg, const float* params, uint6
  * Nomic entries) is read too — its GPT-2 style keys (n_embd, n_head, n_layer, n_inner, rotary_emb_base, ...; only the
  * published arrangement: full non-interleaved rotary positions without scaling, swiglu, post-norm) into a CS_ARCH_NOMIC
  * config, and its model.safetensors by the model repository's tensor names (emb_ln, encoder.layers.N.attn.Wqkv cut into
- * query | key | value, attn.out_proj, norm1, mlp.fc11 / fc12 / fc2, norm2; absent Linear biases are zero).  Its ONNX
- * export is not read (CS_ERR_UNSUPPORTED). */
+ * query | key | value, attn.out_proj, norm1, mlp.fc11 / fc12 / fc2, norm2; absent Linear biases are zero) — or its ONNX export,
+ * which is what fastembed caches for the registry's Nomic entries (onnx/model.onnx; onnx/model_quantized.onnx for the *Q
+ * entry, read as (q - zero_point) * scale and run as the f32 graph of those weights): the bias-free Linear weights are
+ * anonymous there and are taken by graph structure — the MatMul / MatMulInteger nodes with a 2-D initialiser, in order
+ * Wqkv | out_proj | fc11, fc12 | fc2 per layer, the gate being the [H, I] product whose result reaches a Sigmoid.
+ * A JinaBert directory (config.json with position_embedding_type "alibi" and feed_forward_type "geglu":
+ * jinaai/jina-embeddings-v2-base-code, the registry's JinaEmbeddingsV2BaseCode) is read from model.safetensors by either
+ * modelling file's tensor names (mlp.up_gated_layer / down_layer / layernorm with the value rows first, or mlp.gated_layers /
+ * wo with the activated rows first; attention.self.layer_norm_q / _k present or not decides CS_ARCH_JINA_QKNORM against
+ * CS_ARCH_JINA, the config's auto_map where there is no checkpoint to ask); max_position is capped at the 512 tokens
+ * fastembed truncates to.  Its ONNX export is not read (CS_ERR_UNSUPPORTED). */
 /* pooling: CS_POOL_CLS, CS_POOL_MEAN, or -1 = what <model_dir>/1_Pooling/config.json says (the
  * sentence-transformers module: mean for MiniLM / E5, CLS for BGE), CLS when that file is absent (mean for a
  * nomic_bert directory: fastembed's pooling for the family). */

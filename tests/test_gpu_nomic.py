@@ -239,3 +239,43 @@ def test_randomised_shapes_against_the_oracle(FE, oracle):
             np.testing.assert_allclose(got, ref, atol=TOL_ORACLE, err_msg=f"hidden {hidden} B {B} L {L} ragged {ragged}")
         assert emb.debug_counters()[1] == 0
         emb.close()
+
+
+@pytest.mark.parametrize("quantized", [False, True])
+def test_embedder_from_a_fastembed_cache_of_a_nomic_export(FE, oracle, tmp_path, quantized):
+    """What `FastEmbedder::with_cache_dir` (embedder.rs:218-245) leaves on disk for a Nomic entry is the model's ONNX export
+    (onnx/model.onnx; onnx/model_quantized.onnx for NomicEmbedTextV15Q, embedder.rs:36-37), not a safetensors snapshot:
+    cs_embedder_create_from_dir reads the bias-free Linear weights off the graph's structure (csrc/onnx_reader.cpp).  The
+    embedder from such a directory embeds like the one handed the same block, and like the oracle; the quantised file runs
+    the f32 graph of its dequantised weights (the oracle is given those)."""
+    import json
+
+    from codesearch_amd import FastEmbedder
+    from codesearch_amd.bert_params import from_nomic_state_dict
+    from tests import onnx_writer
+    from tests.test_oracle_nomic import nomic_snapshot, nomic_state_dict
+
+    cfg = BertConfig(vocab_size=1024, hidden=768, layers=2, heads=12, intermediate=3072, max_position=512, pooling=POOL_MEAN,
+                     arch=ARCH_NOMIC, rotary_base=1000.0)
+    flat = synth_params(cfg, 81)
+    cache = tmp_path / "models--nomic-ai--nomic-embed-text-v1.5" / "snapshots" / "abc"
+    cache.mkdir(parents=True)
+    nomic_snapshot(cache, cfg, flat)                     # config.json with the repository's keys ...
+    (cache / "model.safetensors").unlink()               # ... but no PyTorch weights: fastembed fetched the ONNX file only
+    (cache / "onnx").mkdir()
+    sd = nomic_state_dict(cfg, flat)
+    deq = {}
+    rel = "onnx/model_quantized.onnx" if quantized else "onnx/model.onnx"
+    (cache / rel).write_bytes(onnx_writer.nomic_onnx(sd, cfg.layers, quantized=quantized, per_channel=quantized, dequantized=deq))
+    want_sd = dict(sd)
+    want_sd.update(deq)
+    block = from_nomic_state_dict(cfg, want_sd)
+    ids, mask = synth_token_batch(cfg, 910, 6, 40, True)
+    emb = FastEmbedder.from_dir(str(cache))
+    assert (emb.config.arch, emb.dimensions(), emb.gemm_mode()) == (ARCH_NOMIC, 768, "split")
+    got = emb.embed_ids(ids, mask)
+    ref_emb = FE(cfg, params=block)
+    assert np.array_equal(got, ref_emb.embed_ids(ids, mask))
+    np.testing.assert_allclose(got, oracle.bert_forward(cfg, block, ids, mask)["pooled"], atol=TOL_ORACLE)
+    emb.close()
+    ref_emb.close()

@@ -88,6 +88,30 @@ def test_nomic_snapshot_readers_survive_truncations_and_mutations(fuzz, tmp_path
     assert "0 crashes" in out
 
 
+def test_nomic_onnx_and_jina_snapshot_readers_survive_truncations_and_mutations(fuzz, tmp_path):
+    """Round 5's reader branches: the structural NomicBert ONNX reader (a real exporter's file and the quantised layout of
+    tests/onnx_writer.py) and the JinaBert safetensors names (rows of the [2I, H] up projection read at an offset) with its
+    config.json keys."""
+    from codesearch_amd.bert_params import ARCH_JINA_QKNORM, ARCH_NOMIC, POOL_MEAN, BertConfig, synth_params
+    from tests import onnx_writer
+    from tests.test_gpu_jina import jina_snapshot
+    from tests.test_oracle_nomic import nomic_state_dict
+
+    fuzz("onnx", os.path.join(GOLD, "nomic_tiny_export.onnx"), seed=41, aux="48 64 2 2 128 512 1")
+    cfg = BertConfig(vocab_size=64, hidden=128, heads=4, intermediate=256, layers=1, max_position=512, pooling=POOL_MEAN,
+                     arch=ARCH_NOMIC, rotary_base=1000.0)
+    p = tmp_path / "model_quantized.onnx"
+    p.write_bytes(onnx_writer.nomic_onnx(nomic_state_dict(cfg, synth_params(cfg, 7)), cfg.layers, quantized=True, per_channel=True))
+    fuzz("onnx", p, seed=42, flips=600, aux="64 128 1 4 256 512 1")
+    jcfg = BertConfig(vocab_size=64, hidden=128, heads=4, intermediate=256, layers=1, max_position=512, pooling=POOL_MEAN,
+                      arch=ARCH_JINA_QKNORM)
+    d = tmp_path / "jina"
+    jina_snapshot(str(d), jcfg, synth_params(jcfg, 8))
+    fuzz("safetensors", d / "model.safetensors", seed=43, flips=600, aux="64 128 1 4 256 512 3")
+    out = fuzz("config_dir", d / "config.json", seed=44, flips=1500)
+    assert "0 crashes" in out
+
+
 def test_tokenizer_json_and_vocab_readers_survive(fuzz, tmp_path):
     from tokenizers import Tokenizer, models, normalizers, pre_tokenizers, processors
 
