@@ -399,7 +399,12 @@ struct Q8Requant {
     uint32_t* range;       // (lo, hi) of the output tensor: widened by pass 1, read by pass 2
     int8_t* out;           // [M][N] s8 (pass 2)
     Q8RowMeta* rmeta_out;  // [M]: rowsum zeroed by pass 1, accumulated by pass 2; xs / za written by pass 2
+    uint32_t use_table;    // pass 2 of the row-block kernel, one unit: the output byte by table lookup (CS_Q8_GELU_TABLE=0: direct)
 };
+static uint32_t q8_gelu_table_on() {
+    const char* e = std::getenv("CS_Q8_GELU_TABLE");  // (read per launch: A/B scripts and tests flip it mid-process)
+    return !(e && e[0] == '0');
+}
 
 template <int EPI>
 __global__ void __launch_bounds__(256, 2)
@@ -751,6 +756,79 @@ gemm_q8_skinny_kernel(const void* __restrict__ src, const float* __restrict__ ra
     }
 }
 
+// ---- FFN-up store pass: the re-quantised GELU byte as a table lookup in the y domain ----------------------------------------
+// Per output the store pass evaluated erf-GELU, a reciprocal multiply, the tie test, rint, clamp: ~43 of the ~48 VALU
+// instructions it spends per element, on a kernel whose vector issue is busy 0.72 of its time
+// (profiles/r04_q8_sq_counters.txt).  With ONE quantisation unit the output parameters (g_scale, g_zp) are the same for the
+// whole launch, so the byte is a FUNCTION of y alone:  B(y) = clamp(rint(gelu(y) / g_scale) + g_zp - 128)  — a step function,
+// falling one step at a time up to the GELU's minimum at c = -0.7518 and rising one step at a time behind it, and two steps
+// are never closer than g_scale / max|gelu'| = g_scale / 1.13 in y.  Every block therefore builds, once, a table over
+// buckets of width 0.8 g_scale: { thr, byte_left | byte_right << 8 } — at most one step per bucket, its threshold found by
+// bisection on B ITSELF (the function below: the arithmetic the direct form runs), so a lookup returns what the direct form
+// returns except inside the few-ulp neighbourhood of a threshold where the f32 pipeline is not monotone (a 1e-5 fraction
+// of values, two orders below the boundary flips between any two erf implementations).  Lookup: one fma, a conversion, an
+// unsigned min, a shift-add, ds_read_b64, a shift, a compare, a select.  The table covers [QG_YL, max y]; everything below
+// QG_YL reads the last entry (checked constant by the builder); a configuration the table cannot represent (more than
+// QG_NB buckets: a degenerate range; two steps in one bucket: the bucket around c when a rounding boundary falls inside its
+// 1e-4-wide dip) makes the builder return 0 and the block runs the direct form.
+constexpr int QG_NB = 2048;
+constexpr float QG_YL = -16.0f;
+struct Q8GeluEntry { float thr; uint32_t w; };  // byte = low 8 bits of (y >= thr ? w >> 8 : w)
+constexpr int QG_LDS = QG_NB * (int)sizeof(Q8GeluEntry);
+
+__device__ __forceinline__ int q8_gelu_byte(float y, float gs, float rgs, float gz128) {  // the direct form (s8: uint8 - 128)
+    const float v = sh_gelu_erf(y);
+    const float t = v * rgs;
+    float rt = rintf(t);
+    // |t - rint(t)| <= 0.5: within 1e-3 of a tie exactly when it exceeds 0.499
+    if (fabsf(t - rt) > 0.499f) rt = rintf(__fdiv_rn(v, gs));
+    return (int)fminf(fmaxf(__fadd_rn(rt, gz128), -128.0f), 127.0f);
+}
+
+// All `nthreads` threads of the block.  Returns 1 / bucket width, or 0 when the block must run the direct form.  `ok` is a
+// word of LDS the caller has zeroed (behind a barrier).
+__device__ __forceinline__ float q8_build_gelu_table(Q8GeluEntry* tbl, uint32_t* ok_bad, float gs, float rgs, float gz128, float ymax,
+                                                     int nthreads) {
+    const float w = gs * 0.8f, span = ymax - QG_YL;
+    if (!(w > 0.0f) || !(span > 0.0f) || !(span / w < (float)(QG_NB - 4))) return 0.0f;   // (block-uniform)
+    const float inv_w = __fdiv_rn(1.0f, w);
+    const int nb = (int)(span * inv_w) + 2;          // buckets a value <= ymax can index
+    bool bad = false;
+    for (int i = threadIdx.x; i < nb; i += nthreads) {
+        // a value indexes bucket i when floor((y - YL) inv_w) == i in f32: inside [left, right] with room for those roundings
+        const float left = QG_YL + ((float)i - 0.02f) * w, right = QG_YL + ((float)i + 1.02f) * w;
+        const int bl = q8_gelu_byte(left, gs, rgs, gz128), br = q8_gelu_byte(right, gs, rgs, gz128);
+        Q8GeluEntry e;
+        e.thr = INFINITY;
+        e.w = (uint32_t)(bl & 0xff) | ((uint32_t)(bl & 0xff) << 8);
+        if (left <= kGeluArgMin && right >= kGeluArgMin) {   // the turning point: flat unless a rounding boundary sits in the dip
+            if (bl != br || q8_gelu_byte(kGeluArgMin, gs, rgs, gz128) != bl) bad = true;
+        } else if (bl != br) {
+            if (br - bl != 1 && bl - br != 1) bad = true;
+            float lo = left, hi = right;                      // B(lo) == bl, B(hi) == br
+            for (int it = 0; it < 40; ++it) {
+                const float mid = 0.5f * (lo + hi);
+                if (!(mid > lo && mid < hi)) break;
+                if (q8_gelu_byte(mid, gs, rgs, gz128) == bl) lo = mid; else hi = mid;
+            }
+            e.thr = hi;
+            e.w = (uint32_t)(bl & 0xff) | ((uint32_t)(br & 0xff) << 8);
+        }
+        tbl[i] = e;
+    }
+    if (threadIdx.x == 0) {  // everything below QG_YL: one byte (gelu(y) is -0.5 |y| 1.5e-8 there: far inside one step)
+        const int b0 = q8_gelu_byte(QG_YL, gs, rgs, gz128);
+        if (q8_gelu_byte(-3.0e4f, gs, rgs, gz128) != b0 || q8_gelu_byte(QG_YL - 1.0f, gs, rgs, gz128) != b0) bad = true;
+        Q8GeluEntry e;
+        e.thr = INFINITY;
+        e.w = (uint32_t)(b0 & 0xff) | ((uint32_t)(b0 & 0xff) << 8);
+        tbl[QG_NB - 1] = e;
+    }
+    if (bad) atomicOr(ok_bad, 1u);
+    __syncthreads();
+    return *ok_bad ? 0.0f : inv_w;
+}
+
 // ---- K = 384 (hidden 384: MiniLM, BGE-small): activations in registers, weights streamed a whole n-tile ahead ------------
 // In gemm_q8_kernel a 128 x 128 tile with K = 384 is three k-steps, each waiting a full L2 round trip for the next stage
 // with two blocks per CU to cover it: 9 us per tile where the MFMAs are 0.8 (profiles/r04_q8_minilm_l6_kernel_stats.csv).
@@ -874,9 +952,20 @@ gemm_q8_rows_kernel(const void* __restrict__ Asrc, const int8_t* __restrict__ W,
             sh_glds16(reinterpret_cast<const char*>(cmeta + (size_t)nt * 128 + wave * 64) + lane * 16, cmbuf + b * QR_CM_BYTES + wave * 1024);
     };
     float gs = 1.0f, gz = 0.0f, rgs = 1.0f;
+    // one unit's store pass: the output byte by table (q8_build_gelu_table); tb_inv_w == 0: the direct form
+    Q8GeluEntry* gtbl = reinterpret_cast<Q8GeluEntry*>(lds + QR_LDS);
+    float tb_inv_w = 0.0f, tb_c0 = 0.0f;
     if (EPI == Q8_EPI_GELU_Q8 && !MU) {
         q8_params_gelu(rq.range, gs, gz);
         rgs = __fdiv_rn(1.0f, gs);
+        if (rq.use_table && rq.range[2]) {
+            uint32_t* ok_bad = reinterpret_cast<uint32_t*>(lds);  // (W buffer 0: nothing has been issued into it yet)
+            if (threadIdx.x == 0) *ok_bad = 0u;
+            __syncthreads();
+            tb_inv_w = q8_build_gelu_table(gtbl, ok_bad, gs, rgs, gz - 128.0f, q8_unkey(rq.range[2]), QR_THREADS);
+            tb_c0 = -QG_YL * tb_inv_w;
+            __syncthreads();  // (ok_bad has been read by every thread before the first W tile lands on it)
+        }
     }
     float ymax = -INFINITY, ya = -INFINITY, yb = INFINITY;
     float ycen = 0.0f, yhw = INFINITY;  // wave-uniform: centre and half-width (padded) of the wave's (a, b) so far
@@ -1176,6 +1265,23 @@ gemm_q8_rows_kernel(const void* __restrict__ Asrc, const int8_t* __restrict__ W,
                 if (nt == 0 && tid < 128 && m0 + tid < M) rq.rmeta_out[m0 + tid].rowsum = 0;
             } else if constexpr (REQ) {
                 int8_t* tile8 = reinterpret_cast<int8_t*>(obuf);  // [128 m][128 n] s8
+                if (!MU && tb_inv_w != 0.0f) {  // (block-uniform) one unit: the byte by table
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const Q8RowMeta rm = lrow[wr * 64 + i * 16 + 4 * g + r];
+#pragma unroll
+                            for (int j = 0; j < 2; ++j) {
+                                const float y = y_of(rm, i, r, j);
+                                uint32_t idx = (uint32_t)(int)fmaf(y, tb_inv_w, tb_c0);   // y < QG_YL: negative -> the last entry
+                                idx = idx < (uint32_t)(QG_NB - 1) ? idx : (uint32_t)(QG_NB - 1);
+                                const Q8GeluEntry e = gtbl[idx];
+                                const uint32_t sel = y >= e.thr ? e.w >> 8 : e.w;
+                                tile8[(wr * 64 + i * 16 + 4 * g + r) * 128 + wc * 32 + j * 16 + l15] = (int8_t)sel;
+                            }
+                        }
+                } else
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -1345,7 +1451,7 @@ static int32_t launch_rows(const void* d_xq, const Q8RowMeta* d_rmeta, const int
                            const float* bias, const float* resid, float* C, _Float16* Cs, uint32_t M, uint32_t N,
                            uint32_t* d_flag, Q8Requant rq, hipStream_t s, const uint32_t* d_in_range = nullptr,
                            const uint32_t* d_row_slot = nullptr) {
-    constexpr int LDS = MU ? QR_LDS_MU : QR_LDS;
+    constexpr int LDS = MU ? QR_LDS_MU : (EPI == Q8_EPI_GELU_Q8 ? QR_LDS + QG_LDS : QR_LDS);
     static PerDeviceOnce attr;  // function attributes are per device
     CS_TRY(attr.run([&]() -> int32_t {
         CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_q8_rows_kernel<EPI, SRC, MU>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
@@ -1370,7 +1476,7 @@ int32_t launch_gemm_q8(int epi, const int8_t* d_xq, const Q8RowMeta* d_rmeta, co
         return fail(CS_ERR_UNSUPPORTED, "quantised GEMM N=%u K=%u must be multiples of 128", N, K);
     if (M == 0) return CS_OK;
     if (q8_rows_takes(M, K) && !d_acc_dbg) {
-        const Q8Requant none{nullptr, nullptr, nullptr};
+        const Q8Requant none{nullptr, nullptr, nullptr, 0u};
         if (epi == SH_OUT_F32) return launch_rows<SH_OUT_F32>(d_xq, d_rmeta, d_wq, d_cmeta, bias, resid, C, Cs, M, N, d_flag, none, s);
         if (epi == SH_OUT_F32_RESID) return launch_rows<SH_OUT_F32_RESID>(d_xq, d_rmeta, d_wq, d_cmeta, bias, resid, C, Cs, M, N, d_flag, none, s);
         if (epi == SH_OUT_SPLIT) return launch_rows<SH_OUT_SPLIT>(d_xq, d_rmeta, d_wq, d_cmeta, bias, resid, C, Cs, M, N, d_flag, none, s);
@@ -1387,7 +1493,7 @@ int32_t launch_gemm_q8(int epi, const int8_t* d_xq, const Q8RowMeta* d_rmeta, co
     }));
     const uint32_t slots = sh_grid_blocks((M + SH_BM - 1) / SH_BM, N / SH_BN);
     const dim3 grid(q8_persistent_grid(slots));
-#define CS_Q8_LAUNCH(E) hipLaunchKernelGGL(gemm_q8_kernel<E>, grid, dim3(256), SH_LDS_BYTES, s, d_xq, d_wq, d_rmeta, d_cmeta, bias, resid, C, Cs, M, N, K, d_flag, d_acc_dbg, Q8Requant{nullptr, nullptr, nullptr}, slots)
+#define CS_Q8_LAUNCH(E) hipLaunchKernelGGL(gemm_q8_kernel<E>, grid, dim3(256), SH_LDS_BYTES, s, d_xq, d_wq, d_rmeta, d_cmeta, bias, resid, C, Cs, M, N, K, d_flag, d_acc_dbg, Q8Requant{nullptr, nullptr, nullptr, 0u}, slots)
     if (epi == SH_OUT_F32) CS_Q8_LAUNCH(SH_OUT_F32);
     else if (epi == SH_OUT_F32_RESID) CS_Q8_LAUNCH(SH_OUT_F32_RESID);
     else if (epi == SH_OUT_SPLIT) CS_Q8_LAUNCH(SH_OUT_SPLIT);
@@ -1432,7 +1538,7 @@ int32_t launch_gemm_q8_from_source(int epi, int src_kind, const void* d_src, con
                                    const Q8ColMeta* d_cmeta, const float* bias, const float* resid, float* C, _Float16* Cs,
                                    uint32_t M, uint32_t N, uint32_t K, uint32_t* d_flag, hipStream_t s, const uint32_t* d_row_slot) {
     if (!q8_rows_takes(M, K) || N % 128) return fail(CS_ERR_UNSUPPORTED, "quantise-on-load product: M=%u N=%u K=%u not taken by the row-block kernel", M, N, K);
-    const Q8Requant none{nullptr, nullptr, nullptr};
+    const Q8Requant none{nullptr, nullptr, nullptr, 0u};
     if (epi == SH_OUT_SPLIT && src_kind == Q8_SRC_F32 && d_row_slot)
         return launch_rows<SH_OUT_SPLIT, Q8_SRC_F32, true>(d_src, nullptr, d_wq, d_cmeta, bias, resid, C, Cs, M, N, d_flag, none, s, d_in_range, d_row_slot);
     if (epi == SH_OUT_F32_RESID && src_kind == Q8_SRC_SPLIT && d_row_slot)
@@ -1477,7 +1583,7 @@ int32_t launch_gemm_q8_gelu_requant_from_source(const float* d_x, const uint32_t
                                                 const float* bias, uint32_t M, uint32_t N, uint32_t K, uint32_t* d_range_out,
                                                 int8_t* d_out, Q8RowMeta* d_rmeta_out, hipStream_t s, const uint32_t* d_row_slot) {
     if (!q8_rows_takes(M, K) || N % 128) return fail(CS_ERR_UNSUPPORTED, "quantise-on-load product: M=%u N=%u K=%u not taken by the row-block kernel", M, N, K);
-    const Q8Requant rq{d_range_out, d_out, d_rmeta_out};
+    const Q8Requant rq{d_range_out, d_out, d_rmeta_out, q8_gelu_table_on()};
     if (d_row_slot) {
         CS_TRY((launch_rows<Q8_EPI_GELU_RANGE, Q8_SRC_F32, true>(d_x, nullptr, d_wq, d_cmeta, bias, nullptr, nullptr, nullptr, M, N, nullptr, rq, s, d_in_range, d_row_slot)));
         return launch_rows<Q8_EPI_GELU_Q8, Q8_SRC_F32, true>(d_x, nullptr, d_wq, d_cmeta, bias, nullptr, nullptr, nullptr, M, N, nullptr, rq, s, d_in_range, d_row_slot);
@@ -1493,7 +1599,7 @@ int32_t launch_gemm_q8_gelu_requant(const int8_t* d_xq, const Q8RowMeta* d_rmeta
         return fail(CS_ERR_UNSUPPORTED, "quantised GEMM N=%u K=%u must be multiples of 128", N, K);
     if (M == 0) return CS_OK;
     if (q8_rows_takes(M, K)) {
-        const Q8Requant rq{d_range_out, d_out, d_rmeta_out};
+        const Q8Requant rq{d_range_out, d_out, d_rmeta_out, q8_gelu_table_on()};
         CS_TRY(launch_rows<Q8_EPI_GELU_RANGE>(d_xq, d_rmeta, d_wq, d_cmeta, bias, nullptr, nullptr, nullptr, M, N, nullptr, rq, s));
         return launch_rows<Q8_EPI_GELU_Q8>(d_xq, d_rmeta, d_wq, d_cmeta, bias, nullptr, nullptr, nullptr, M, N, nullptr, rq, s);
     }
@@ -1505,7 +1611,7 @@ int32_t launch_gemm_q8_gelu_requant(const int8_t* d_xq, const Q8RowMeta* d_rmeta
     }));
     const uint32_t slots = sh_grid_blocks((M + SH_BM - 1) / SH_BM, N / SH_BN);
     const dim3 grid(q8_persistent_grid(slots));
-    const Q8Requant rq{d_range_out, d_out, d_rmeta_out};
+    const Q8Requant rq{d_range_out, d_out, d_rmeta_out, 0u};
     hipLaunchKernelGGL(gemm_q8_kernel<Q8_EPI_GELU_RANGE>, grid, dim3(256), SH_LDS_BYTES, s, d_xq, d_wq, d_rmeta, d_cmeta, bias,
                        (const float*)nullptr, (float*)nullptr, (_Float16*)nullptr, M, N, K, (uint32_t*)nullptr, (int32_t*)nullptr, rq, slots);
     hipLaunchKernelGGL(gemm_q8_kernel<Q8_EPI_GELU_Q8>, grid, dim3(256), SH_LDS_BYTES, s, d_xq, d_wq, d_rmeta, d_cmeta, bias,
