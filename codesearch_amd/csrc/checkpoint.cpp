@@ -23,6 +23,7 @@
 
 #include "../../include/cs_bert_params.h"
 #include "common.hpp"
+#include "bpe.hpp"
 #include "unigram.hpp"
 
 namespace {
@@ -835,6 +836,186 @@ static int32_t unigram_from_json(const Json& root, const Json& model, const char
     return cs::tokenizer_from_unigram(std::move(spec), max_length, out);
 }
 
+// ---- tokenizer.json with a byte-level BPE model (the registry's JinaEmbeddingsV2BaseCode) -----------------------------------
+// Read into a cs::BpeSpec (bpe.hpp) — every component must be one bpe.cpp restates, anything else is refused:
+//   model          type BPE, vocab {token: id}, merges ["a b", ...] or [["a", "b"], ...], unk_token, fuse_unk, ignore_merges;
+//                  no dropout, no continuing_subword_prefix / end_of_word_suffix, no byte_fallback
+//   normalizer     null
+//   pre_tokenizer  ByteLevel | Digits | Sequence of those ending in ByteLevel
+//   post_processor RobertaProcessing (cls, sep) | TemplateProcessing whose `single` is <bos> $A <eos> | ByteLevel (no template)
+//                  | Sequence of those
+//   added_tokens   special, not normalized, not single_word (matched in the raw text)
+static int32_t bpe_pre(const Json& pj, std::vector<cs::BpeSpec::Pre>& out) {
+    if (pj.kind == Json::Null) return CS_OK;
+    if (pj.kind != Json::Obj) return fail(CS_ERR_BAD_ARG, "Failed to initialize embedding model: tokenizer.json pre_tokenizer is not an object");
+    const Json* ty = pj.get("type");
+    const std::string t = ty && ty->kind == Json::Str ? ty->str : "";
+    auto flag = [&](const char* k, bool dflt) { const Json* v = pj.get(k); return v && v->kind == Json::Bool ? v->b : dflt; };
+    if (t == "Sequence") {
+        const Json* list = pj.get("pretokenizers");
+        if (!list || list->kind != Json::Arr) return fail(CS_ERR_BAD_ARG, "Failed to initialize embedding model: pre_tokenizer Sequence without a list");
+        for (const Json& e : list->arr) CS_TRY(bpe_pre(e, out));
+        return CS_OK;
+    }
+    cs::BpeSpec::Pre p;
+    if (t == "ByteLevel") {
+        p.kind = cs::BpeSpec::Pre::BYTE_LEVEL;
+        p.add_prefix_space = flag("add_prefix_space", true);
+        p.use_regex = flag("use_regex", true);
+    } else if (t == "Digits") {
+        p.kind = cs::BpeSpec::Pre::DIGITS;
+        p.individual_digits = flag("individual_digits", false);
+    } else {
+        return fail(CS_ERR_UNSUPPORTED, "Failed to initialize embedding model: pre_tokenizer \"%s\" is not built for BPE tokenizers (ByteLevel, Digits)", t.c_str());
+    }
+    out.push_back(p);
+    return CS_OK;
+}
+
+static int32_t bpe_post(const Json& pp, std::string& bos, std::string& eos) {
+    if (pp.kind == Json::Null) return CS_OK;
+    if (pp.kind != Json::Obj) return fail(CS_ERR_BAD_ARG, "Failed to initialize embedding model: tokenizer.json post_processor is not an object");
+    const Json* ty = pp.get("type");
+    const std::string t = ty && ty->kind == Json::Str ? ty->str : "";
+    if (t == "ByteLevel") return CS_OK;  // offsets only
+    if (t == "Sequence") {
+        const Json* list = pp.get("processors");
+        if (!list || list->kind != Json::Arr) return fail(CS_ERR_BAD_ARG, "Failed to initialize embedding model: post_processor Sequence without a list");
+        for (const Json& e : list->arr) CS_TRY(bpe_post(e, bos, eos));
+        return CS_OK;
+    }
+    if (t == "RobertaProcessing" || t == "BertProcessing") {
+        auto first = [&](const char* k, std::string& name) {
+            const Json* v = pp.get(k);
+            if (!v || v->kind != Json::Arr || v->arr.size() != 2 || v->arr[0].kind != Json::Str) return false;
+            name = v->arr[0].str;
+            return true;
+        };
+        if (!first("cls", bos) || !first("sep", eos))
+            return fail(CS_ERR_BAD_ARG, "Failed to initialize embedding model: %s without cls / sep", t.c_str());
+        return CS_OK;
+    }
+    if (t == "TemplateProcessing") {
+        const Json* single = pp.get("single");
+        if (!single || single->kind != Json::Arr)
+            return fail(CS_ERR_UNSUPPORTED, "Failed to initialize embedding model: TemplateProcessing without `single`");
+        auto special = [&](const Json& e, std::string& name) {
+            const Json* st = e.kind == Json::Obj ? e.get("SpecialToken") : nullptr;
+            const Json* id = st && st->kind == Json::Obj ? st->get("id") : nullptr;
+            if (!id || id->kind != Json::Str) return false;
+            name = id->str;
+            return true;
+        };
+        auto is_seq = [&](const Json& e) { return e.kind == Json::Obj && e.get("Sequence") != nullptr; };
+        const auto& a = single->arr;
+        bool ok = false;
+        if (a.size() == 1 && is_seq(a[0])) ok = true;                                                  // $A
+        else if (a.size() == 2 && special(a[0], bos) && is_seq(a[1])) ok = true;                       // <bos> $A
+        else if (a.size() == 2 && is_seq(a[0]) && special(a[1], eos)) ok = true;                       // $A <eos>
+        else if (a.size() == 3 && special(a[0], bos) && is_seq(a[1]) && special(a[2], eos)) ok = true; // <bos> $A <eos>
+        if (!ok) return fail(CS_ERR_UNSUPPORTED, "Failed to initialize embedding model: TemplateProcessing `single` is not [<bos>] $A [<eos>]");
+        return CS_OK;
+    }
+    return fail(CS_ERR_UNSUPPORTED, "Failed to initialize embedding model: post_processor \"%s\" is not built for BPE tokenizers", t.c_str());
+}
+
+static int32_t bpe_from_json(const Json& root, const Json& model, const char* json_path, uint32_t max_length, cs_tokenizer** out) {
+    cs::BpeSpec spec;
+    const Json* vocab = model.get("vocab");
+    if (!vocab || vocab->kind != Json::Obj || vocab->obj.empty())
+        return fail(CS_ERR_BAD_ARG, "Failed to initialize embedding model: %s has no BPE vocabulary", json_path);
+    for (const auto& kv : vocab->obj) {
+        if (kv.second.kind != Json::Num || !(kv.second.num >= 0 && kv.second.num < 2147483647.0))
+            return fail(CS_ERR_BAD_ARG, "Failed to initialize embedding model: BPE vocabulary entry \"%s\" has no valid id", kv.first.c_str());
+        spec.vocab.emplace_back(kv.first, (int32_t)kv.second.num);
+    }
+    const Json* merges = model.get("merges");
+    if (!merges || merges->kind != Json::Arr)
+        return fail(CS_ERR_BAD_ARG, "Failed to initialize embedding model: %s has no BPE merges", json_path);
+    for (const Json& m : merges->arr) {
+        if (m.kind == Json::Str) {  // "left right"
+            const size_t sp = m.str.find(' ');
+            if (sp == std::string::npos || m.str.find(' ', sp + 1) != std::string::npos)
+                return fail(CS_ERR_BAD_ARG, "Failed to initialize embedding model: merge \"%s\" is not two tokens", m.str.c_str());
+            spec.merges.emplace_back(m.str.substr(0, sp), m.str.substr(sp + 1));
+        } else if (m.kind == Json::Arr && m.arr.size() == 2 && m.arr[0].kind == Json::Str && m.arr[1].kind == Json::Str) {
+            spec.merges.emplace_back(m.arr[0].str, m.arr[1].str);
+        } else {
+            return fail(CS_ERR_BAD_ARG, "Failed to initialize embedding model: a BPE merge is neither \"a b\" nor [a, b]");
+        }
+    }
+    auto refuse_set = [&](const char* key, const char* what) -> int32_t {
+        const Json* v = model.get(key);
+        if (!v || v->kind == Json::Null) return CS_OK;
+        if (v->kind == Json::Str && v->str.empty()) return CS_OK;
+        if (v->kind == Json::Bool && !v->b) return CS_OK;
+        return fail(CS_ERR_UNSUPPORTED, "Failed to initialize embedding model: BPE %s is not built", what);
+    };
+    CS_TRY(refuse_set("dropout", "dropout"));
+    CS_TRY(refuse_set("continuing_subword_prefix", "continuing_subword_prefix"));
+    CS_TRY(refuse_set("end_of_word_suffix", "end_of_word_suffix"));
+    CS_TRY(refuse_set("byte_fallback", "byte_fallback"));
+    if (const Json* u = model.get("unk_token"))
+        if (u->kind == Json::Str) spec.unk_token = u->str;
+    auto mflag = [&](const char* k) { const Json* v = model.get(k); return v && v->kind == Json::Bool && v->b; };
+    spec.fuse_unk = mflag("fuse_unk");
+    spec.ignore_merges = mflag("ignore_merges");
+    if (const Json* nz = root.get("normalizer"))
+        if (nz->kind != Json::Null)
+            return fail(CS_ERR_UNSUPPORTED, "Failed to initialize embedding model: a normalizer in front of a BPE model is not built");
+    if (const Json* pj = root.get("pre_tokenizer")) CS_TRY(bpe_pre(*pj, spec.pres));
+    std::map<std::string, int32_t> added_ids;
+    if (const Json* at = root.get("added_tokens"))
+        if (at->kind == Json::Arr)
+            for (const Json& e : at->arr) {
+                if (e.kind != Json::Obj) continue;
+                const Json* content = e.get("content");
+                const Json* id = e.get("id");
+                if (!content || content->kind != Json::Str || !id || id->kind != Json::Num || content->str.empty()) continue;
+                auto flag = [&](const char* k) { const Json* v = e.get(k); return v && v->kind == Json::Bool && v->b; };
+                if (flag("single_word") || flag("normalized"))
+                    return fail(CS_ERR_UNSUPPORTED, "Failed to initialize embedding model: added token \"%s\" is single_word / normalized (not built)",
+                                content->str.c_str());
+                if (!(id->num >= 0 && id->num < 2147483647.0))
+                    return fail(CS_ERR_BAD_ARG, "Failed to initialize embedding model: added token \"%s\" has no valid id", content->str.c_str());
+                cs::BpeSpec::Added a;
+                a.text = content->str;
+                a.id = (int32_t)id->num;
+                a.lstrip = flag("lstrip");
+                a.rstrip = flag("rstrip");
+                added_ids[a.text] = a.id;
+                spec.added.push_back(std::move(a));
+            }
+    std::string bos, eos;
+    if (const Json* pp = root.get("post_processor")) CS_TRY(bpe_post(*pp, bos, eos));
+    auto id_of = [&](const std::string& tok) -> int32_t {
+        if (tok.empty()) return -1;
+        auto it = added_ids.find(tok);
+        if (it != added_ids.end()) return it->second;
+        for (const auto& kv : spec.vocab)
+            if (kv.first == tok) return kv.second;
+        return -2;
+    };
+    spec.bos = id_of(bos);
+    spec.eos = id_of(eos);
+    if (spec.bos == -2 || spec.eos == -2)
+        return fail(CS_ERR_BAD_ARG, "Failed to initialize embedding model: the post_processor's special tokens are not in the vocabulary");
+    spec.pad = id_of("<pad>");
+    if (spec.pad == -2) spec.pad = -1;
+    if (const Json* pad = root.get("padding"))
+        if (pad->kind == Json::Obj)
+            if (const Json* pid = pad->get("pad_id"))
+                if (pid->kind == Json::Num && pid->num >= 0 && pid->num < 2147483647.0) spec.pad = (int32_t)pid->num;
+    if (max_length == 0) {
+        max_length = 512;  // fastembed's default truncation length
+        if (const Json* tr = root.get("truncation"))
+            if (tr->kind == Json::Obj)
+                if (const Json* ml = tr->get("max_length"))
+                    if (ml->kind == Json::Num && ml->num >= 2 && ml->num <= 1e6) max_length = (uint32_t)ml->num;
+    }
+    return cs::tokenizer_from_bpe(std::move(spec), max_length, out);
+}
+
 // ---- tokenizer.json (the `tokenizers` crate's serialisation; what fastembed loads) ------------------
 // Read: model.type == "WordPiece", model.vocab {token: id}, model.unk_token / continuing_subword_prefix /
 // max_input_chars_per_word (must be the BERT values cs_tokenizer implements), normalizer BertNormalizer
@@ -856,8 +1037,9 @@ int32_t cs_tokenizer_create_from_json(const char* json_path, uint32_t max_length
         return fail(CS_ERR_BAD_ARG, "Failed to initialize embedding model: %s has no \"model\" object", json_path);
     const Json* type = model->get("type");
     if (type && type->kind == Json::Str && type->str == "Unigram") return unigram_from_json(root, *model, json_path, max_length, out);
+    if (type && type->kind == Json::Str && type->str == "BPE") return bpe_from_json(root, *model, json_path, max_length, out);
     if (type && type->kind == Json::Str && type->str != "WordPiece")
-        return fail(CS_ERR_UNSUPPORTED, "Failed to initialize embedding model: tokenizer model \"%s\" (WordPiece and Unigram are built)",
+        return fail(CS_ERR_UNSUPPORTED, "Failed to initialize embedding model: tokenizer model \"%s\" (WordPiece, Unigram and BPE are built)",
                     type->str.c_str());
     const Json* vocab = model->get("vocab");
     if (!vocab || vocab->kind != Json::Obj || vocab->obj.empty())

@@ -30,6 +30,7 @@
 #include <vector>
 
 #include "common.hpp"
+#include "bpe.hpp"
 #include "unigram.hpp"
 
 namespace {
@@ -139,6 +140,8 @@ struct cs_tokenizer {
     // a SentencePiece-unigram tokenizer.json (unigram.cpp) instead of the WordPiece tables above: cls / sep / pad are then
     // its <s> / </s> / <pad>, size its vocabulary
     std::shared_ptr<cs::UnigramEngine> unigram;
+    // ... or a byte-level BPE tokenizer.json (bpe.cpp): cls / sep are its <bos> / <eos> (-1: the file's template has none)
+    std::shared_ptr<cs::BpeEngine> bpe;
 
     int32_t find(uint64_t h, const char* a, uint32_t alen, const char* b, uint32_t blen) const {
         // key = a ++ b (a is the optional "##")
@@ -359,6 +362,11 @@ void tokenize_texts(const cs_tokenizer* t, const char* utf8, const uint64_t* off
                 t->unigram->encode(utf8 + offsets[i], (size_t)(offsets[i + 1] - offsets[i]), body, ids);
                 continue;
             }
+            if (t->bpe) {
+                const uint32_t sp = t->bpe->specials();
+                t->bpe->encode(utf8 + offsets[i], (size_t)(offsets[i + 1] - offsets[i]), max_length >= sp ? max_length - sp : 0, ids);
+                continue;
+            }
             ids.push_back(t->cls);
             Encoder enc(*t, ids, body + 1);
             enc.encode(reinterpret_cast<const unsigned char*>(utf8) + offsets[i], (size_t)(offsets[i + 1] - offsets[i]));
@@ -379,6 +387,26 @@ void tokenize_texts(const cs_tokenizer* t, const char* utf8, const uint64_t* off
             }
         });
     for (auto& x : th) x.join();
+}
+
+int32_t tokenizer_from_bpe(BpeSpec&& spec, uint32_t max_length, cs_tokenizer** out) {
+    if (!out) return fail(CS_ERR_BAD_ARG, "null out pointer");
+    *out = nullptr;
+    if (max_length < 2) return fail(CS_ERR_BAD_ARG, "max_length %u leaves no room for <s> and </s>", max_length);
+    std::shared_ptr<BpeEngine> eng;
+    CS_TRY(BpeEngine::create(std::move(spec), &eng));
+    cs_tokenizer* t = new (std::nothrow) cs_tokenizer();
+    if (!t) return fail(CS_ERR_OOM, "out of host memory");
+    t->bpe = eng;
+    t->lowercase = false;
+    t->max_length = max_length;
+    t->size = eng->vocab_size();
+    t->cls = eng->bos();
+    t->sep = eng->eos();
+    t->pad = eng->pad() >= 0 ? eng->pad() : 0;
+    t->unk = -1;
+    *out = t;
+    return CS_OK;
 }
 
 int32_t tokenizer_from_unigram(UnigramSpec&& spec, uint32_t max_length, cs_tokenizer** out) {
@@ -460,6 +488,7 @@ int32_t cs_tokenizer_pad_id(const cs_tokenizer* t) { return t ? t->pad : -1; }
 
 int32_t cs_tokenizer_token_to_id(const cs_tokenizer* t, const char* token) {
     if (t && token && t->unigram) return t->unigram->token_to_id(std::string(token));
+    if (t && token && t->bpe) return t->bpe->token_to_id(std::string(token));
     return (t && token) ? t->find(std::string(token)) : -1;
 }
 

@@ -234,3 +234,39 @@ def test_randomised_shapes_against_the_oracle(FE, oracle):
             np.testing.assert_allclose(got, ref, atol=TOL_ORACLE, err_msg=f"hidden {hidden} B {B} L {L} ragged {ragged}")
         assert emb.debug_counters()[1] == 0
         emb.close()
+
+
+def test_texts_through_the_models_own_kind_of_tokenizer(FE, oracle, tmp_path):
+    """jina-embeddings-v2-base-code ships a byte-level BPE tokenizer.json (not WordPiece): FastEmbedder.from_dir on a snapshot
+    with such a file (trained here by the `tokenizers` library itself) tokenises with csrc/bpe.cpp — the ids the library
+    gives — and embeds like the oracle on those ids: strings in, vectors out, for the registry's code model."""
+    pytest.importorskip("tokenizers")
+    from codesearch_amd import FastEmbedder
+    from tests.test_bpe_tokenizer import build as build_bpe
+
+    cfg = BertConfig(vocab_size=704, hidden=768, layers=2, heads=12, intermediate=3072, max_position=512, pooling=POOL_MEAN,
+                     arch=ARCH_JINA_QKNORM)
+    flat = synth_params(cfg, 83)
+    for l in range(cfg.layers):
+        sd = to_state_dict(cfg, flat)
+        sd[f"encoder.layer.{l}.intermediate.dense.bias"][:] = 0
+        sd[f"encoder.layer.{l}.intermediate.gate.bias"][:] = 0
+    d = tmp_path / "snapshot"
+    jina_snapshot(str(d), cfg, flat)
+    tok = build_bpe(str(d / "tokenizer.json"), post="roberta")
+    assert tok.get_vocab_size() <= cfg.vocab_size
+    emb = FastEmbedder.from_dir(str(d))
+    texts = ["def authenticate(user, password):\n    return check_hash(user.password_hash, password)",
+             "fn main() { println!(\"{}\", 42); }", "SELECT id FROM users WHERE age >= 18;", "it's a naïve café", "", "x"]
+    got = np.stack(emb.embed_batch(texts))
+    encs = [tok.encode(t).ids for t in texts]
+    L = max(len(e) for e in encs)
+    ids = np.full((len(texts), L), tok.token_to_id("<pad>"), np.int32)
+    mask = np.zeros((len(texts), L), np.int32)
+    for i, e in enumerate(encs):
+        ids[i, :len(e)] = e
+        mask[i, :len(e)] = 1
+    my_ids, my_mask = emb.tokenizer.encode_batch(texts)
+    assert np.array_equal(my_ids, ids) and np.array_equal(my_mask, mask)
+    np.testing.assert_allclose(got, oracle.bert_forward(cfg, flat, ids, mask)["pooled"], atol=TOL_ORACLE)
+    emb.close()

@@ -130,6 +130,12 @@ def test_tokenizer_json_and_vocab_readers_survive(fuzz, tmp_path):
     esc = tmp_path / "escaped.json"
     esc.write_text(json.dumps(json.load(open(p, encoding="utf-8")), ensure_ascii=True))
     fuzz("tokenizer_json", esc, seed=15, flips=300)
+    # a byte-level BPE tokenizer.json (bpe.cpp: merges, pre-tokenizer / post-processor objects, added tokens)
+    from tests.test_bpe_tokenizer import build as build_bpe
+
+    bp = tmp_path / "bpe.json"
+    build_bpe(str(bp), post="template", digits=True)
+    fuzz("tokenizer_json", bp, seed=16, flips=400)
     v = tmp_path / "vocab.txt"
     v.write_text("\n".join(t for t, _ in sorted(vocab.items(), key=lambda kv: kv[1])) + "\n", encoding="utf-8")
     fuzz("vocab", v, seed=16)
