@@ -41,6 +41,9 @@ class BertConfig(C.Structure):
         ("pooling", C.c_int32),
         ("arch", C.c_uint32),
         ("rotary_base", C.c_float),
+        ("rotary_base_local", C.c_float),
+        ("local_window", C.c_uint32),
+        ("global_every", C.c_uint32),
     ]
 
 

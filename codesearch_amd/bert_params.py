@@ -11,8 +11,8 @@ import numpy as np
 from .synth import synth_below, synth_int
 
 POOL_CLS, POOL_MEAN = 0, 1
-ARCH_BERT, ARCH_NOMIC, ARCH_JINA, ARCH_JINA_QKNORM = 0, 1, 2, 3  # cs_encoder_arch
-GATED_ARCHS = (ARCH_NOMIC, ARCH_JINA, ARCH_JINA_QKNORM)      # no position table, a gate projection per layer
+ARCH_BERT, ARCH_NOMIC, ARCH_JINA, ARCH_JINA_QKNORM, ARCH_MODERN = 0, 1, 2, 3, 4  # cs_encoder_arch
+GATED_ARCHS = (ARCH_NOMIC, ARCH_JINA, ARCH_JINA_QKNORM, ARCH_MODERN)      # no position table, a gate projection per layer
 
 # kind -> (shift, base); cs_bert_synth_rule
 _RULE = {
@@ -36,6 +36,12 @@ class BertConfig:
     #                                ARCH_JINA[_QKNORM]: ALiBi on the scores, down(value * gelu(gate)), no position table
     #                                (_QKNORM: LayerNorm on the whole query / key rows)
     rotary_base: float = 0.0
+    #                                ARCH_MODERN: pre-norm layers, rotary positions (rotary_base on the global layers — every
+    #                                global_every-th from 0 —, rotary_base_local on the others, which see |i - j| <= local_window),
+    #                                Wo(gelu(Wi_a x) * Wi_b x), a final LayerNorm, no position / token-type table
+    rotary_base_local: float = 0.0
+    local_window: int = 0
+    global_every: int = 0
 
     @staticmethod
     def bge_small() -> "BertConfig":
@@ -47,7 +53,7 @@ class BertConfig:
 
         return CBert(self.vocab_size, self.hidden, self.layers, self.heads, self.intermediate,
                      self.max_position, self.type_vocab_size, self.layer_norm_eps, self.pooling, self.arch,
-                     self.rotary_base)
+                     self.rotary_base, self.rotary_base_local, self.local_window, self.global_every)
 
 
 def tensor_table(cfg: BertConfig) -> List[Tuple[str, Tuple[int, ...], str]]:
@@ -59,8 +65,8 @@ def tensor_table(cfg: BertConfig) -> List[Tuple[str, Tuple[int, ...], str]]:
     qkn = cfg.arch == ARCH_JINA_QKNORM
     t = [
         ("embeddings.word_embeddings.weight", (cfg.vocab_size, H), "emb"),
-    ] + ([] if nomic else [("embeddings.position_embeddings.weight", (cfg.max_position, H), "emb")]) + [
-        ("embeddings.token_type_embeddings.weight", (cfg.type_vocab_size, H), "emb"),
+    ] + ([] if nomic else [("embeddings.position_embeddings.weight", (cfg.max_position, H), "emb")]) + (
+        [] if cfg.arch == ARCH_MODERN else [("embeddings.token_type_embeddings.weight", (cfg.type_vocab_size, H), "emb")]) + [
         ("embeddings.LayerNorm.weight", (H,), "ln_g"),
         ("embeddings.LayerNorm.bias", (H,), "ln_b"),
     ]
@@ -80,6 +86,8 @@ def tensor_table(cfg: BertConfig) -> List[Tuple[str, Tuple[int, ...], str]]:
             (p + "output.dense.weight", (H, I), "down_w"), (p + "output.dense.bias", (H,), "bias"),
             (p + "output.LayerNorm.weight", (H,), "ln_g"), (p + "output.LayerNorm.bias", (H,), "ln_b"),
         ]
+    if cfg.arch == ARCH_MODERN:
+        t += [("final_norm.weight", (H,), "ln_g"), ("final_norm.bias", (H,), "ln_b")]
     return t
 
 
@@ -145,6 +153,18 @@ def synth_token_batch(cfg: BertConfig, seed: int, B: int, L: int, ragged: bool):
         ids[b, lens[b] - 1] = 102 % cfg.vocab_size
     ids = ids * mask
     return ids, mask
+
+
+def token_batch_with_lens(cfg: BertConfig, seed: int, lens, L: int):
+    """synth_token_batch with the rows' lengths given (tests of the local-attention family pick paddings that leave every
+    padded position a valid key inside its window)."""
+    B = len(lens)
+    ids, _ = synth_token_batch(cfg, seed, B, L, False)
+    lens = np.asarray(lens, np.int64)
+    mask = (np.arange(L)[None, :] < lens[:, None]).astype(np.int32)
+    for b in range(B):
+        ids[b, lens[b] - 1] = 102 % cfg.vocab_size
+    return ids * mask, mask
 
 
 # ---- real checkpoints (SURVEY.md §8f-2) ----------------------------------------------------------

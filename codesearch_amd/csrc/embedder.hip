@@ -16,6 +16,7 @@ void cs_bert_config_bge_small(cs_bert_config* cfg) {
     cfg->intermediate = 1536; cfg->max_position = 512; cfg->type_vocab_size = 2;
     cfg->layer_norm_eps = 1e-12f; cfg->pooling = CS_POOL_CLS;
     cfg->arch = CS_ARCH_BERT; cfg->rotary_base = 0.0f;
+    cfg->rotary_base_local = 0.0f; cfg->local_window = 0; cfg->global_every = 0;
 }
 
 uint64_t cs_bert_param_count(const cs_bert_config* cfg) {

@@ -775,7 +775,7 @@ int32_t check_search(const cs_index* h, uint32_t nq, uint32_t dim, uint32_t k) {
 extern "C" {
 
 const char* cs_last_error(void) { return last_error_ref().c_str(); }
-uint32_t cs_abi_version(void) { return 5; }  // 5: cs_bert_config gained arch, rotary_base
+uint32_t cs_abi_version(void) { return 6; }  // 5: cs_bert_config gained arch, rotary_base; 6: rotary_base_local, local_window, global_every
 
 int32_t cs_device_count(void) {
     int n = 0;

@@ -212,7 +212,9 @@ class FastEmbedder:
         self.config = BertConfig(vocab_size=ccfg.vocab_size, hidden=ccfg.hidden, layers=ccfg.layers, heads=ccfg.heads,
                                  intermediate=ccfg.intermediate, max_position=ccfg.max_position,
                                  type_vocab_size=ccfg.type_vocab_size, layer_norm_eps=ccfg.layer_norm_eps,
-                                 pooling=ccfg.pooling, arch=ccfg.arch, rotary_base=ccfg.rotary_base)
+                                 pooling=ccfg.pooling, arch=ccfg.arch, rotary_base=ccfg.rotary_base,
+                                 rotary_base_local=ccfg.rotary_base_local, local_window=ccfg.local_window,
+                                 global_every=ccfg.global_every)
         h = C.c_void_p()
         _lib.check(self._lib.cs_embedder_create_from_dir(str(model_dir).encode(), pooling, device, C.byref(h)))
         self._h = h

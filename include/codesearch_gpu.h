@@ -330,8 +330,12 @@ typedef enum cs_pooling { CS_POOL_CLS = 0, CS_POOL_MEAN = 1 } cs_pooling;
  * BERT.  Flat parameter order: cs_bert_params.h. */
 /* CS_ARCH_JINA / CS_ARCH_JINA_QKNORM: JinaBert (embedder.rs:40-41,69: JinaEmbeddingsV2BaseCode) — no position table, the
  * symmetric ALiBi bias -slope_h |i - j| on the attention scores, a GELU-gated feed-forward; _QKNORM adds the LayerNorm on the
- * whole query and key rows that the "qk-post-norm" modelling file (the one jina-embeddings-v2-base-code names) applies. */
-typedef enum cs_encoder_arch { CS_ARCH_BERT = 0, CS_ARCH_NOMIC = 1, CS_ARCH_JINA = 2, CS_ARCH_JINA_QKNORM = 3 } cs_encoder_arch;
+ * whole query and key rows that the "qk-post-norm" modelling file (the one jina-embeddings-v2-base-code names) applies.
+ * CS_ARCH_MODERN: ModernBERT (embedder.rs:47, :72: ModernBertEmbedLarge) — PRE-norm layers (x += attn(LN(x)); x += mlp(LN(x)),
+ * layer 0 without its first LayerNorm, a final LayerNorm), no position or token-type table, rotary positions on Q / K with one
+ * base for the global-attention layers (every `global_every`-th, from layer 0) and another for the local ones, whose scores
+ * are masked outside |i - j| <= local_window, and the feed-forward  Wo( gelu(Wi_a x) * Wi_b x ). */
+typedef enum cs_encoder_arch { CS_ARCH_BERT = 0, CS_ARCH_NOMIC = 1, CS_ARCH_JINA = 2, CS_ARCH_JINA_QKNORM = 3, CS_ARCH_MODERN = 4 } cs_encoder_arch;
 
 typedef struct cs_bert_config {
     uint32_t vocab_size;        /* 30522 for bge-small-en-v1.5 */
@@ -344,7 +348,12 @@ typedef struct cs_bert_config {
     float layer_norm_eps;       /* 1e-12 */
     int32_t pooling;            /* cs_pooling */
     uint32_t arch;              /* cs_encoder_arch; 0 = BERT (every field above means what it did before this field existed) */
-    float rotary_base;          /* CS_ARCH_NOMIC: base of the rotary angles (1000 for nomic-embed-text-v1 / v1.5); else ignored */
+    float rotary_base;          /* CS_ARCH_NOMIC: base of the rotary angles (1000 for nomic-embed-text-v1 / v1.5); CS_ARCH_MODERN: of
+                                 * the global-attention layers (160000); else ignored */
+    /* CS_ARCH_MODERN only (zero for every other family; ABI 6): */
+    float rotary_base_local;    /* base of the rotary angles of the local-attention layers (10000) */
+    uint32_t local_window;      /* local layers attend to keys with |i - j| <= local_window (64 = local_attention / 2) */
+    uint32_t global_every;      /* layer l attends globally when l % global_every == 0 (3) */
 } cs_bert_config;
 
 /* Fills *cfg with the BAAI/bge-small-en-v1.5 architecture (CLS pooling). */

@@ -27,6 +27,14 @@
  * — so that the two are ONE [2I, H] weight for the up-projection GEMM.  The published checkpoints have no Linear biases
  * (their slots are zero); the encoder applies whatever the slots hold.
  *
+ * CS_ARCH_MODERN (ModernBERT: the registry's ModernBertEmbedLarge) keeps the gated order too — no position AND no token-type
+ * table; per layer query | key | value (the thirds of the fused Wqkv) with their biases, attention.output.dense (= attn.Wo),
+ * attention.output.LayerNorm (= the layer's attn_norm, applied BEFORE attention; layer 0's slot is never read),
+ * intermediate.dense (= the half of mlp.Wi that is NOT activated: rows [I, 2I)), intermediate.gate (= rows [0, I), through
+ * GELU), output.dense (= mlp.Wo), output.LayerNorm (= mlp_norm, applied BEFORE the feed-forward) — and behind the last layer
+ *     final_norm.weight / .bias                  [H] [H]
+ * The published checkpoints have no biases at all (attention_bias, mlp_bias, norm_bias false: zero slots).
+ *
  * Synthetic weights (no checkpoint is reachable from the build/GPU boxes): element at flat
  * offset e of a tensor of kind K is  base(K) + cs_synth_weight(seed, e, shift(K))  — see
  * cs_bert_synth_rule().  Shifts keep activations O(1) and attention non-degenerate.
@@ -69,12 +77,13 @@ typedef struct cs_bert_offsets {
     uint64_t word, pos, type, emb_ln_g, emb_ln_b;
     uint64_t layer0;       /* offset of layer 0 */
     uint64_t layer_stride; /* floats per layer */
+    uint64_t final_ln_g, final_ln_b; /* CS_ARCH_MODERN only (else == total) */
     uint64_t total;
 } cs_bert_offsets;
 
 /* families without a position table and with a gated feed-forward (a second [I, H] up-projection per layer) */
 CS_SYNTH_FN int cs_arch_gated(uint32_t arch) {
-    return arch == CS_ARCH_NOMIC || arch == CS_ARCH_JINA || arch == CS_ARCH_JINA_QKNORM;
+    return arch == CS_ARCH_NOMIC || arch == CS_ARCH_JINA || arch == CS_ARCH_JINA_QKNORM || arch == CS_ARCH_MODERN;
 }
 CS_SYNTH_FN int cs_arch_alibi(uint32_t arch) { return arch == CS_ARCH_JINA || arch == CS_ARCH_JINA_QKNORM; }
 
@@ -83,7 +92,7 @@ CS_SYNTH_FN void cs_bert_layout(const cs_bert_config* c, cs_bert_offsets* o) {
     uint64_t p = 0;
     o->word = p; p += (uint64_t)c->vocab_size * H;
     o->pos = p; if (!cs_arch_gated(c->arch)) p += (uint64_t)c->max_position * H;
-    o->type = p; p += (uint64_t)c->type_vocab_size * H;
+    o->type = p; if (c->arch != CS_ARCH_MODERN) p += (uint64_t)c->type_vocab_size * H;
     o->emb_ln_g = p; p += H;
     o->emb_ln_b = p; p += H;
     o->layer0 = p;
@@ -91,6 +100,8 @@ CS_SYNTH_FN void cs_bert_layout(const cs_bert_config* c, cs_bert_offsets* o) {
     if (cs_arch_gated(c->arch)) o->layer_stride += I * H + I;
     if (c->arch == CS_ARCH_JINA_QKNORM) o->layer_stride += 4 * H;
     o->total = p + (uint64_t)c->layers * o->layer_stride;
+    o->final_ln_g = o->final_ln_b = o->total;
+    if (c->arch == CS_ARCH_MODERN) { o->final_ln_g = o->total; o->final_ln_b = o->total + H; o->total += 2 * H; }
 }
 
 CS_SYNTH_FN void cs_bert_layer_layout(const cs_bert_config* c, const cs_bert_offsets* o,
@@ -119,6 +130,7 @@ CS_SYNTH_FN int cs_bert_kind_at(const cs_bert_config* c, const cs_bert_offsets* 
     if (e < o->emb_ln_g) return CS_T_TYPE_EMB;
     if (e < o->emb_ln_b) return CS_T_LN_GAMMA;
     if (e < o->layer0) return CS_T_LN_BETA;
+    if (e >= o->final_ln_g && o->final_ln_g != o->total) return e < o->final_ln_b ? CS_T_LN_GAMMA : CS_T_LN_BETA;
     uint64_t r = (e - o->layer0) % o->layer_stride;
     const uint64_t lin = H * H + H;
     if (r < 2 * lin) return (r % lin) < H * H ? CS_T_QK_W : CS_T_BIAS;          /* q, k */

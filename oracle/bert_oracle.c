@@ -30,6 +30,13 @@
  * heads; the feed-forward is  down( value * gelu_erf(gate) )  over the two halves of one bias-free [2I, H] projection;
  * post-LayerNorm, mean pooling, normalisation as above.  Pinned against a float64 torch statement written from the same
  * definition (tests/golden/make_jina_golden.py) — PARITY UNPINNED against the model itself.
+ * CS_ARCH_MODERN (the registry's ModernBertEmbedLarge, /root/reference/src/embed/embedder.rs:47, :72 -> fastembed's
+ * ModernBertEmbedLarge = lightonai/modernbert-embed-large) restates HF transformers' `ModernBertModel` (modeling_modernbert.py,
+ * installed here as a library and read as its published definition): tok_embeddings -> LayerNorm; per layer
+ *   x = x + Wo( attention( rope( Wqkv LN_attn(x) ) ) )      (layer 0: no LN_attn; rope base per layer type; local layers mask
+ *   x = x + Wo_mlp( gelu_erf(Wi_a LN_mlp(x)) * Wi_b LN_mlp(x) )                         |i - j| > local_window)
+ * then final_norm, mean pooling, L2 normalisation.  Pinned against HF's own ModernBertModel in float64
+ * (tests/golden/make_modern_golden.py).
  * PARITY UNPINNED against the reference itself (it ships no embedding vectors,
  * SURVEY.md §4, §8c); pinned against HF transformers BertModel (float64) by
  * tests/golden/make_encoder_golden.py -> tests/golden/encoder_golden.npz.
@@ -197,10 +204,117 @@ static void alibi_slopes(size_t n, float* out) {
 /* ids/mask: [B, L] int32.  hidden_out: optional [B*L*H] last_hidden_state.  pooled_out:
  * [B, H] pooled + L2-normalised.  layer_hidden_out: optional [layers+1][B*L*H] (embedding
  * output then every layer's output) for per-layer parity checks. */
+/* ModernBERT (CS_ARCH_MODERN): pre-norm layers, see the header comment. */
+static void modern_forward_impl(const cs_bert_config* cfg, const float* params, const int32_t* ids, const int32_t* mask,
+                                uint32_t B, uint32_t L, float* hidden_out, float* pooled_out, float* layer_hidden_out) {
+    const size_t H = cfg->hidden, I = cfg->intermediate, NH = cfg->heads, DH = H / NH;
+    const size_t T = (size_t)B * L;
+    cs_bert_offsets off;
+    cs_bert_layout(cfg, &off);
+    float* x = (float*)malloc(sizeof(float) * T * H);
+    float* n = (float*)malloc(sizeof(float) * T * H);
+    float* q = (float*)malloc(sizeof(float) * T * H);
+    float* k = (float*)malloc(sizeof(float) * T * H);
+    float* v = (float*)malloc(sizeof(float) * T * H);
+    float* ctx = (float*)malloc(sizeof(float) * T * H);
+    float* tmp = (float*)malloc(sizeof(float) * T * H);
+    float* mid = (float*)malloc(sizeof(float) * T * I);
+    float* gate = (float*)malloc(sizeof(float) * T * I);
+    for (size_t t = 0; t < T; ++t) memcpy(x + t * H, params + off.word + (size_t)ids[t] * H, sizeof(float) * H);
+    layer_norm_rows(x, params + off.emb_ln_g, params + off.emb_ln_b, T, H, cfg->layer_norm_eps);
+    if (layer_hidden_out) memcpy(layer_hidden_out, x, sizeof(float) * T * H);
+    const float scale = 1.0f / sqrtf((float)DH);  /* head_dim ** -0.5 */
+    for (uint32_t l = 0; l < cfg->layers; ++l) {
+        cs_bert_layer_offsets lo;
+        cs_bert_layer_layout(cfg, &off, l, &lo);
+        const int global = cfg->global_every ? (l % cfg->global_every == 0) : 1;
+        memcpy(n, x, sizeof(float) * T * H);
+        if (l) layer_norm_rows(n, params + lo.ao_ln_g, params + lo.ao_ln_b, T, H, cfg->layer_norm_eps); /* attn_norm; Identity in layer 0 */
+        linear(n, params + lo.q_w, params + lo.q_b, q, T, H, H);
+        linear(n, params + lo.k_w, params + lo.k_b, k, T, H, H);
+        linear(n, params + lo.v_w, params + lo.v_b, v, T, H, H);
+        rotary_rows(q, T, L, NH, DH, global ? cfg->rotary_base : cfg->rotary_base_local);
+        rotary_rows(k, T, L, NH, DH, global ? cfg->rotary_base : cfg->rotary_base_local);
+#ifdef _OPENMP
+#pragma omp parallel for collapse(2) schedule(static)
+#endif
+        for (int64_t b = 0; b < (int64_t)B; ++b) {
+            for (int64_t h = 0; h < (int64_t)NH; ++h) {
+                float* s = (float*)malloc(sizeof(float) * L);
+                for (size_t i = 0; i < L; ++i) {
+                    const float* qi = q + ((size_t)b * L + i) * H + (size_t)h * DH;
+                    float mx = -INFINITY;
+                    for (size_t j = 0; j < L; ++j) {
+                        const float* kj = k + ((size_t)b * L + j) * H + (size_t)h * DH;
+                        float d = 0.0f;
+                        for (size_t e = 0; e < DH; ++e) d += qi[e] * kj[e];
+                        d *= scale;
+                        const size_t dist = i > j ? i - j : j - i;
+                        /* additive mask, finfo(f32).min: padded keys, and keys outside the local window */
+                        if (!mask[(size_t)b * L + j] || (!global && dist > cfg->local_window)) d += -3.4028234663852886e38f;
+                        s[j] = d;
+                        if (d > mx) mx = d;
+                    }
+                    float sum = 0.0f;
+                    for (size_t j = 0; j < L; ++j) { s[j] = expf(s[j] - mx); sum += s[j]; }
+                    float* o = ctx + ((size_t)b * L + i) * H + (size_t)h * DH;
+                    for (size_t e = 0; e < DH; ++e) o[e] = 0.0f;
+                    for (size_t j = 0; j < L; ++j) {
+                        const float p = s[j] / sum;
+                        const float* vj = v + ((size_t)b * L + j) * H + (size_t)h * DH;
+                        for (size_t e = 0; e < DH; ++e) o[e] += p * vj[e];
+                    }
+                }
+                free(s);
+            }
+        }
+        linear(ctx, params + lo.ao_w, params + lo.ao_b, tmp, T, H, H);
+        for (size_t i = 0; i < T * H; ++i) x[i] = x[i] + tmp[i];
+        memcpy(n, x, sizeof(float) * T * H);
+        layer_norm_rows(n, params + lo.out_ln_g, params + lo.out_ln_b, T, H, cfg->layer_norm_eps); /* mlp_norm */
+        linear(n, params + lo.gate_w, params + lo.gate_b, gate, T, H, I); /* Wi rows [0, I): through the activation */
+        linear(n, params + lo.up_w, params + lo.up_b, mid, T, H, I);      /* Wi rows [I, 2I) */
+        for (size_t i = 0; i < T * I; ++i) mid[i] = gelu_erf(gate[i]) * mid[i];
+        linear(mid, params + lo.down_w, params + lo.down_b, tmp, T, I, H);
+        for (size_t i = 0; i < T * H; ++i) x[i] = x[i] + tmp[i];
+        if (layer_hidden_out) memcpy(layer_hidden_out + (size_t)(l + 1) * T * H, x, sizeof(float) * T * H);
+    }
+    layer_norm_rows(x, params + off.final_ln_g, params + off.final_ln_b, T, H, cfg->layer_norm_eps);
+    if (hidden_out) memcpy(hidden_out, x, sizeof(float) * T * H);
+    if (pooled_out) {
+        for (size_t b = 0; b < B; ++b) {
+            float* p = pooled_out + b * H;
+            if (cfg->pooling == CS_POOL_CLS) {
+                memcpy(p, x + b * L * H, sizeof(float) * H);
+            } else {
+                float cnt = 0.0f;
+                for (size_t i = 0; i < H; ++i) p[i] = 0.0f;
+                for (size_t t = 0; t < L; ++t) {
+                    if (!mask[b * L + t]) continue;
+                    cnt += 1.0f;
+                    const float* r = x + (b * L + t) * H;
+                    for (size_t i = 0; i < H; ++i) p[i] += r[i];
+                }
+                if (cnt < 1e-9f) cnt = 1e-9f;
+                for (size_t i = 0; i < H; ++i) p[i] /= cnt;
+            }
+            float ss = 0.0f;
+            for (size_t i = 0; i < H; ++i) ss += p[i] * p[i];
+            const float den = sqrtf(ss) + 1e-12f;
+            for (size_t i = 0; i < H; ++i) p[i] /= den;
+        }
+    }
+    free(x); free(n); free(q); free(k); free(v); free(ctx); free(tmp); free(mid); free(gate);
+}
+
 static void bert_forward_impl(const cs_bert_config* cfg, const float* params, const float* qscale,
                               const int32_t* ids,
                               const int32_t* mask, uint32_t B, uint32_t L, float* hidden_out,
                               float* pooled_out, float* layer_hidden_out) {
+    if (cfg->arch == CS_ARCH_MODERN) {
+        modern_forward_impl(cfg, params, ids, mask, B, L, hidden_out, pooled_out, layer_hidden_out);
+        return;
+    }
     const size_t H = cfg->hidden, I = cfg->intermediate, NH = cfg->heads, DH = H / NH;
     const size_t T = (size_t)B * L;
     cs_bert_offsets off;
