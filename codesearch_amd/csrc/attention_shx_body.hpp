@@ -59,16 +59,19 @@ struct AttnMemPlain {
 // MQ / MO: how the qkv tensor is read and the context tensor written (AttnMemPlain: plain loads, K / V by LDS-DMA, plain
 // stores — the stand-alone kernel; small_forward.hip passes a policy whose every access carries sc1, K / V through
 // registers).  bx / by / bz: the block's coordinates, gx / gz: the grid's extents (the kernel form passes its own).
-// ALIBI (JinaBert, CS_ARCH_JINA*): the score of (query i, key j) of head h also gets -slope_h |i - j|; alibi_log2 [heads] holds
-// the slopes times log2 e (the softmax runs in the exp2 domain).  BERT / NomicBert instantiate ALIBI = false: the same code as
-// before the parameter existed.
-template <int NC, class MQ, class MO, bool ALIBI = false>
+// POS = 1 (JinaBert, CS_ARCH_JINA*): the score of (query i, key j) of head h also gets -slope_h |i - j|; alibi_log2 [heads] holds
+// the slopes times log2 e (the softmax runs in the exp2 domain).  POS = 2 (ModernBERT's local layers, CS_ARCH_MODERN): keys with
+// |i - j| > window are masked like padding.  BERT / NomicBert instantiate POS = 0: the same code as before the parameter existed.
+template <int NC, class MQ, class MO, int POS = 0>
 __device__ __forceinline__ void
 attention_shx_body(char* smem, const MQ& mq, const MO& mo, const _Float16* qkvs, const int32_t* __restrict__ mask,
                    _Float16* ctxs, uint32_t* __restrict__ flag, uint32_t L, uint32_t H,
                    float scale_log2e, uint32_t HB, float* __restrict__ range_out,
                    const uint32_t* __restrict__ seq_unit, const uint32_t* __restrict__ unit_len,
-                   uint32_t bx, uint32_t by, uint32_t bz, uint32_t gx, uint32_t gz, const float* __restrict__ alibi_log2 = nullptr) {
+                   uint32_t bx, uint32_t by, uint32_t bz, uint32_t gx, uint32_t gz, const float* __restrict__ alibi_log2 = nullptr,
+                   uint32_t window = 0) {
+    constexpr bool ALIBI = POS == 1, WINDOW = POS == 2;
+    const float wlimit = (float)window;
     constexpr int KT = 128;                        // keys per super-tile
     const uint32_t Lp = (L + 31) & ~31u;
     char* Kt = smem;                               // [NC][KT][128 B]
@@ -226,6 +229,11 @@ attention_shx_body(char* smem, const MQ& mq, const MO& mo, const _Float16* qkvs,
                         m2[0] = fmaf(neg_slope, fabsf(d0), m2[0]);
                         m2[1] = fmaf(neg_slope, fabsf(d0 - 1.0f), m2[1]);
                     }
+                    if constexpr (WINDOW) {
+                        const float d0 = qpos - (float)(kt * 32 + 8 * g + 2 * e2);
+                        m2[0] = fabsf(d0) > wlimit ? kMaskedLog2 : m2[0];
+                        m2[1] = fabsf(d0 - 1.0f) > wlimit ? kMaskedLog2 : m2[1];
+                    }
                     const sh_f32x2 s2 = __builtin_elementwise_fma(__builtin_elementwise_fma(x2, lo_inv2, h2), scale2, m2);
                     p2[r / 2] = s2;
                     tmax = fmaxf(tmax, fmaxf(s2[0], s2[1]));
@@ -269,6 +277,7 @@ attention_shx_body(char* smem, const MQ& mq, const MO& mo, const _Float16* qkvs,
                     const int r = 4 * g + e;
                     float me = ma[e];
                     if constexpr (ALIBI) me = fmaf(neg_slope, fabsf(qpos - (float)(kt * 32 + 8 * g + e)), me);
+                    if constexpr (WINDOW) me = fabsf(qpos - (float)(kt * 32 + 8 * g + e)) > wlimit ? kMaskedLog2 : me;
                     hh[r] = fmaf(fmaf(xx[r], kShLoInv, hh[r]), scale_log2e, me);
                     tmax = fmaxf(tmax, hh[r]);
                 }

@@ -190,23 +190,25 @@ attention_sh2_kernel(const _Float16* __restrict__ qkvs, const int32_t* __restric
 
 // ---- head_dim 32 * NC (NC = 2: BGE-base / BGE-large / mxbai-large): keys in super-tiles of 128 ------------
 // The body lives in attention_shx_body.hpp (shared with small_forward.hip).
-template <int NC, bool ALIBI = false>
+template <int NC, int POS = 0>
 __global__ void __launch_bounds__(256, 2)
 attention_shx_kernel(const _Float16* __restrict__ qkvs, const int32_t* __restrict__ mask,
                      _Float16* __restrict__ ctxs, uint32_t* __restrict__ flag, uint32_t L, uint32_t H,
                      float scale_log2e, uint32_t HB, float* __restrict__ range_out,
                      const uint32_t* __restrict__ seq_unit, const uint32_t* __restrict__ unit_len,
-                     const float* __restrict__ alibi_log2) {
+                     const float* __restrict__ alibi_log2, uint32_t window) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const AttnMemPlain mem;
-    attention_shx_body<NC, AttnMemPlain, AttnMemPlain, ALIBI>(smem, mem, mem, qkvs, mask, ctxs, flag, L, H, scale_log2e, HB, range_out,
-                                                              seq_unit, unit_len, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x,
-                                                              gridDim.z, alibi_log2);
+    attention_shx_body<NC, AttnMemPlain, AttnMemPlain, POS>(smem, mem, mem, qkvs, mask, ctxs, flag, L, H, scale_log2e, HB, range_out,
+                                                            seq_unit, unit_len, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x,
+                                                            gridDim.z, alibi_log2, window);
 }
 
 int32_t launch_attention_sh2(const _Float16* qkv_split, const int32_t* mask, void* ctx_split, uint32_t* flag,
                              uint32_t B, uint32_t L, uint32_t H, uint32_t heads, hipStream_t s, float* range_out,
-                             uint32_t* range_pairs, const uint32_t* seq_unit, const uint32_t* unit_len, const float* alibi) {
+                             uint32_t* range_pairs, const uint32_t* seq_unit, const uint32_t* unit_len, const float* alibi,
+                             uint32_t window) {
+    if (alibi && window) return fail(CS_ERR_BAD_ARG, "attention: ALiBi and a local window together are not built");
     // alibi (CS_ARCH_JINA*): [2][heads] — the slopes, then the slopes times log2 e (what these kernels add in the exp2 domain)
     const float* alibi_log2 = alibi ? alibi + heads : nullptr;
     if (range_pairs) *range_pairs = 0;
@@ -220,16 +222,21 @@ int32_t launch_attention_sh2(const _Float16* qkv_split, const int32_t* mask, voi
         CS_TRY(attr64.run([&]() -> int32_t {
             CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attention_shx_kernel<2>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
-            CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attention_shx_kernel<2, true>),
+            CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attention_shx_kernel<2, 1>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+            CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attention_shx_kernel<2, 2>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
             return CS_OK;
         }));
         if (alibi_log2)
-            hipLaunchKernelGGL((attention_shx_kernel<2, true>), dim3(heads, B, (L + 127) / 128), dim3(256), lds, s, qkv_split, mask,
-                               static_cast<_Float16*>(ctx_split), flag, L, H, (1.0f / sqrtf(64.0f)) * kLog2e, 1u, range_out, seq_unit, unit_len, alibi_log2);
+            hipLaunchKernelGGL((attention_shx_kernel<2, 1>), dim3(heads, B, (L + 127) / 128), dim3(256), lds, s, qkv_split, mask,
+                               static_cast<_Float16*>(ctx_split), flag, L, H, (1.0f / sqrtf(64.0f)) * kLog2e, 1u, range_out, seq_unit, unit_len, alibi_log2, 0u);
+        else if (window)
+            hipLaunchKernelGGL((attention_shx_kernel<2, 2>), dim3(heads, B, (L + 127) / 128), dim3(256), lds, s, qkv_split, mask,
+                               static_cast<_Float16*>(ctx_split), flag, L, H, (1.0f / sqrtf(64.0f)) * kLog2e, 1u, range_out, seq_unit, unit_len, alibi_log2, window);
         else
         hipLaunchKernelGGL(attention_shx_kernel<2>, dim3(heads, B, (L + 127) / 128), dim3(256), lds, s, qkv_split, mask,
-                           static_cast<_Float16*>(ctx_split), flag, L, H, (1.0f / sqrtf(64.0f)) * kLog2e, 1u, range_out, seq_unit, unit_len, alibi_log2);
+                           static_cast<_Float16*>(ctx_split), flag, L, H, (1.0f / sqrtf(64.0f)) * kLog2e, 1u, range_out, seq_unit, unit_len, alibi_log2, 0u);
         if (range_pairs) *range_pairs = heads * B * ((L + 127) / 128) * 4;
         CS_HIP(hipGetLastError());
         return CS_OK;
@@ -239,7 +246,7 @@ int32_t launch_attention_sh2(const _Float16* qkv_split, const int32_t* mask, voi
     // the others) — 256 x 256 tokens 12.75 -> 12.54 ms per forward although K/V are staged once per query
     // block.  CS_ATTN_SHX1=0 selects the whole-sequence kernel (attention_sh2_kernel) for A/B.
     static const bool shx1 = [] { const char* e = std::getenv("CS_ATTN_SHX1"); return !(e && e[0] == '0'); }();
-    if (shx1 || alibi_log2) {
+    if (shx1 || alibi_log2 || window) {
         // CS_ATTN_LDS_PAD (diagnostics): extra dynamic LDS per block, i.e. fewer co-resident blocks per CU — how the kernel's
         // time moves with occupancy says whether a tile's dependent chain (latency) or issue slots bound it
         static const size_t lds_pad = [] { const char* e = std::getenv("CS_ATTN_LDS_PAD"); return e ? (size_t)std::atol(e) : (size_t)0; }();
@@ -256,11 +263,14 @@ int32_t launch_attention_sh2(const _Float16* qkv_split, const int32_t* mask, voi
         uint32_t hb = !pack_heads ? 1u : (Lp <= 32 ? 4u : (Lp <= 64 ? 2u : 1u));  // heads per block (kernel comment)
         while (heads % hb) hb >>= 1;
         if (alibi_log2)
-            hipLaunchKernelGGL((attention_shx_kernel<1, true>), dim3(heads / hb, B, (L + 127) / 128), dim3(256), lds1, s, qkv_split, mask,
-                               static_cast<_Float16*>(ctx_split), flag, L, H, (1.0f / sqrtf(32.0f)) * kLog2e, hb, range_out, seq_unit, unit_len, alibi_log2);
+            hipLaunchKernelGGL((attention_shx_kernel<1, 1>), dim3(heads / hb, B, (L + 127) / 128), dim3(256), lds1, s, qkv_split, mask,
+                               static_cast<_Float16*>(ctx_split), flag, L, H, (1.0f / sqrtf(32.0f)) * kLog2e, hb, range_out, seq_unit, unit_len, alibi_log2, 0u);
+        else if (window)
+            hipLaunchKernelGGL((attention_shx_kernel<1, 2>), dim3(heads / hb, B, (L + 127) / 128), dim3(256), lds1, s, qkv_split, mask,
+                               static_cast<_Float16*>(ctx_split), flag, L, H, (1.0f / sqrtf(32.0f)) * kLog2e, hb, range_out, seq_unit, unit_len, alibi_log2, window);
         else
         hipLaunchKernelGGL(attention_shx_kernel<1>, dim3(heads / hb, B, (L + 127) / 128), dim3(256), lds1, s, qkv_split, mask,
-                           static_cast<_Float16*>(ctx_split), flag, L, H, (1.0f / sqrtf(32.0f)) * kLog2e, hb, range_out, seq_unit, unit_len, alibi_log2);
+                           static_cast<_Float16*>(ctx_split), flag, L, H, (1.0f / sqrtf(32.0f)) * kLog2e, hb, range_out, seq_unit, unit_len, alibi_log2, 0u);
         if (range_pairs) *range_pairs = (heads / hb) * B * ((L + 127) / 128) * 4;
         CS_HIP(hipGetLastError());
         return CS_OK;

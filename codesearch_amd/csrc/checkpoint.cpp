@@ -279,6 +279,120 @@ std::vector<Want> jina_layout_table(const cs_bert_config& c, bool first_file) {
     return t;
 }
 
+// ModernBERT checkpoints (lightonai/modernbert-embed-large; HF ModernBertModel's names, optional "model." prefix):
+// embeddings.tok_embeddings / norm, layers.N.{attn_norm (N >= 1), attn.Wqkv, attn.Wo, mlp_norm, mlp.Wi [2 I_f, H], mlp.Wo
+// [H, I_f]}, final_norm; biases optional everywhere (the published files have none: zero slots).  The file's intermediate
+// size I_f may be smaller than the config's (2,624 against the 2,688 = 21 x 128 the kernels tile): the extra rows of Wi and
+// columns of Wo are zero — the same function.
+int32_t modern_params_from_safetensors(FILE* f, const std::map<std::string, TensorRef>& have, uint64_t data0, const cs_bert_config& c,
+                                       float* params, const char* path) {
+    cs_bert_offsets o;
+    cs_bert_layout(&c, &o);
+    const uint64_t H = c.hidden, I = c.intermediate;
+    std::memset(params, 0, o.total * sizeof(float));
+    std::vector<unsigned char> raw;
+    // the tensor `name` as f32 (empty + CS_OK when it is absent and optional)
+    auto fetch = [&](const std::string& name, bool optional, std::vector<float>& out, std::vector<uint64_t>& shape) -> int32_t {
+        out.clear();
+        auto it = have.find(name);
+        if (it == have.end()) it = have.find("model." + name);
+        if (it == have.end()) {
+            if (optional) return CS_OK;
+            return fail(CS_ERR_BAD_ARG, "Failed to initialize embedding model: tensor %s is missing from %s", name.c_str(), path);
+        }
+        const TensorRef& t = it->second;
+        uint64_t count = 1;
+        for (uint64_t d : t.shape) {
+            if (d != 0 && count > (1ull << 40) / d) return fail(CS_ERR_BAD_ARG, "Failed to initialize embedding model: %s has an implausible shape", name.c_str());
+            count *= d;
+        }
+        const uint32_t esz = t.dtype == "F32" ? 4 : (t.dtype == "F16" || t.dtype == "BF16") ? 2 : 0;
+        if (!esz) return fail(CS_ERR_UNSUPPORTED, "Failed to initialize embedding model: %s has dtype %s (F32, F16, BF16 only)", name.c_str(), t.dtype.c_str());
+        if (t.end < t.begin || t.end - t.begin != count * esz || count > o.total)
+            return fail(CS_ERR_BAD_ARG, "Failed to initialize embedding model: %s has inconsistent data_offsets", name.c_str());
+        if (fseeko(f, (off_t)(data0 + t.begin), SEEK_SET) != 0) return fail(CS_ERR_BAD_ARG, "Failed to initialize embedding model: %s is truncated", path);
+        out.resize(count);
+        if (esz == 4) {
+            if (std::fread(out.data(), 4, count, f) != count) return fail(CS_ERR_BAD_ARG, "Failed to initialize embedding model: %s is truncated", path);
+        } else {
+            raw.resize(count * 2);
+            if (std::fread(raw.data(), 2, count, f) != count) return fail(CS_ERR_BAD_ARG, "Failed to initialize embedding model: %s is truncated", path);
+            const bool bf = t.dtype == "BF16";
+            for (uint64_t i = 0; i < count; ++i) {
+                const uint16_t v = (uint16_t)(raw[2 * i] | (raw[2 * i + 1] << 8));
+                if (bf) { const uint32_t bits = (uint32_t)v << 16; std::memcpy(&out[i], &bits, 4); }
+                else out[i] = half_to_float(v);
+            }
+        }
+        shape = t.shape;
+        return CS_OK;
+    };
+    auto bad_shape = [&](const std::string& name) {
+        return fail(CS_ERR_DIM_MISMATCH, "Failed to initialize embedding model: %s does not have the shape config.json implies", name.c_str());
+    };
+    std::vector<float> v;
+    std::vector<uint64_t> sh;
+    auto vec = [&](const std::string& name, uint64_t n, uint64_t off, bool optional) -> int32_t {
+        CS_TRY(fetch(name, optional, v, sh));
+        if (v.empty()) return CS_OK;
+        if (v.size() != n) return bad_shape(name);
+        std::memcpy(params + off, v.data(), n * sizeof(float));
+        return CS_OK;
+    };
+    CS_TRY(fetch("embeddings.tok_embeddings.weight", false, v, sh));
+    if (sh != std::vector<uint64_t>{c.vocab_size, H}) return bad_shape("embeddings.tok_embeddings.weight");
+    std::memcpy(params + o.word, v.data(), v.size() * sizeof(float));
+    CS_TRY(vec("embeddings.norm.weight", H, o.emb_ln_g, false));
+    CS_TRY(vec("embeddings.norm.bias", H, o.emb_ln_b, true));
+    CS_TRY(vec("final_norm.weight", H, o.final_ln_g, false));
+    CS_TRY(vec("final_norm.bias", H, o.final_ln_b, true));
+    for (uint32_t l = 0; l < c.layers; ++l) {
+        cs_bert_layer_offsets lo;
+        cs_bert_layer_layout(&c, &o, l, &lo);
+        const std::string p = "layers." + std::to_string(l) + ".";
+        if (l) {
+            CS_TRY(vec(p + "attn_norm.weight", H, lo.ao_ln_g, false));
+            CS_TRY(vec(p + "attn_norm.bias", H, lo.ao_ln_b, true));
+        } else {
+            for (uint64_t i = 0; i < H; ++i) params[lo.ao_ln_g + i] = 1.0f;  // (never read: layer 0's attn_norm is the identity)
+        }
+        CS_TRY(fetch(p + "attn.Wqkv.weight", false, v, sh));
+        if (sh != std::vector<uint64_t>{3 * H, H}) return bad_shape(p + "attn.Wqkv.weight");
+        std::memcpy(params + lo.q_w, v.data(), H * H * sizeof(float));
+        std::memcpy(params + lo.k_w, v.data() + H * H, H * H * sizeof(float));
+        std::memcpy(params + lo.v_w, v.data() + 2 * H * H, H * H * sizeof(float));
+        CS_TRY(fetch(p + "attn.Wqkv.bias", true, v, sh));
+        if (!v.empty()) {
+            if (v.size() != 3 * H) return bad_shape(p + "attn.Wqkv.bias");
+            std::memcpy(params + lo.q_b, v.data(), H * sizeof(float));
+            std::memcpy(params + lo.k_b, v.data() + H, H * sizeof(float));
+            std::memcpy(params + lo.v_b, v.data() + 2 * H, H * sizeof(float));
+        }
+        CS_TRY(fetch(p + "attn.Wo.weight", false, v, sh));
+        if (sh != std::vector<uint64_t>{H, H}) return bad_shape(p + "attn.Wo.weight");
+        std::memcpy(params + lo.ao_w, v.data(), H * H * sizeof(float));
+        CS_TRY(vec(p + "attn.Wo.bias", H, lo.ao_b, true));
+        CS_TRY(vec(p + "mlp_norm.weight", H, lo.out_ln_g, false));
+        CS_TRY(vec(p + "mlp_norm.bias", H, lo.out_ln_b, true));
+        CS_TRY(fetch(p + "mlp.Wi.weight", false, v, sh));
+        if (sh.size() != 2 || sh[1] != H || sh[0] % 2 || sh[0] / 2 > I || sh[0] == 0) return bad_shape(p + "mlp.Wi.weight");
+        const uint64_t If = sh[0] / 2;  // rows [0, I_f): through the activation (our gate); rows [I_f, 2 I_f): our value
+        std::memcpy(params + lo.gate_w, v.data(), If * H * sizeof(float));
+        std::memcpy(params + lo.up_w, v.data() + If * H, If * H * sizeof(float));
+        CS_TRY(fetch(p + "mlp.Wi.bias", true, v, sh));
+        if (!v.empty()) {
+            if (v.size() != 2 * If) return bad_shape(p + "mlp.Wi.bias");
+            std::memcpy(params + lo.gate_b, v.data(), If * sizeof(float));
+            std::memcpy(params + lo.up_b, v.data() + If, If * sizeof(float));
+        }
+        CS_TRY(fetch(p + "mlp.Wo.weight", false, v, sh));
+        if (sh != std::vector<uint64_t>{H, If}) return bad_shape(p + "mlp.Wo.weight");
+        for (uint64_t r = 0; r < H; ++r) std::memcpy(params + lo.down_w + r * I, v.data() + r * If, If * sizeof(float));
+        CS_TRY(vec(p + "mlp.Wo.bias", H, lo.down_b, true));
+    }
+    return CS_OK;
+}
+
 std::vector<Want> layout_table(const cs_bert_config& c, bool jina_first_file = false) {
     if (c.arch == CS_ARCH_NOMIC) return nomic_layout_table(c);
     if (cs_arch_alibi(c.arch)) return jina_layout_table(c, jina_first_file);
@@ -399,6 +513,49 @@ int32_t cs_bert_config_from_dir(const char* model_dir, int32_t pooling, cs_bert_
             return CS_OK;
         }
     if (const Json* mt = root.get("model_type"))
+        if (mt->kind == Json::Str && mt->str == "modernbert") {
+            // ModernBERT (the registry's modernbert-embed-large): only the published arrangement — erf-GELU gate, default rotary
+            // positions (no scaling), full / sliding layers by global_attn_every_n_layers
+            if (const Json* act = root.get("hidden_activation"))
+                if (act->kind == Json::Str && act->str != "gelu")
+                    return fail(CS_ERR_UNSUPPORTED, "Failed to initialize embedding model: this ModernBERT configuration is not built "
+                                "(hidden_activation \"%s\"; only \"gelu\")", act->str.c_str());
+            cs_bert_config c{};
+            if (!json_u32(root, "vocab_size", c.vocab_size) || !json_u32(root, "hidden_size", c.hidden) ||
+                !json_u32(root, "num_hidden_layers", c.layers) || !json_u32(root, "num_attention_heads", c.heads) ||
+                !json_u32(root, "intermediate_size", c.intermediate))
+                return fail(CS_ERR_BAD_ARG, "Failed to initialize embedding model: %s lacks a ModernBERT size field", path.c_str());
+            c.intermediate = (c.intermediate + 127) / 128 * 128;  // the kernels' tile: zero rows / columns fill the difference
+            uint32_t npos = 0;
+            c.max_position = (json_u32(root, "max_position_embeddings", npos) && npos && npos < 512) ? npos : 512;  // (fastembed truncates to 512)
+            c.type_vocab_size = 1;  // (no token-type table in this family; the field only has to be non-zero)
+            const Json* eps = root.get("norm_eps");
+            c.layer_norm_eps = (eps && eps->kind == Json::Num) ? (float)eps->num : 1e-5f;
+            if (!json_u32(root, "global_attn_every_n_layers", c.global_every) || c.global_every == 0) c.global_every = 3;
+            uint32_t local = 0;
+            if (!json_u32(root, "local_attention", local) || local < 2) local = 128;
+            c.local_window = local / 2;
+            auto num = [&](const Json* j, float dflt) { return (j && j->kind == Json::Num && j->num > 1.0) ? (float)j->num : dflt; };
+            c.rotary_base = num(root.get("global_rope_theta"), 160000.0f);
+            c.rotary_base_local = num(root.get("local_rope_theta"), 10000.0f);
+            if (const Json* rp = root.get("rope_parameters"))  // the newer serialisation: {full_attention: {rope_theta, rope_type}, sliding_attention: {...}}
+                if (rp->kind == Json::Obj)
+                    for (const char* which : {"full_attention", "sliding_attention"}) {
+                        const Json* e = rp->get(which);
+                        if (!e || e->kind != Json::Obj) continue;
+                        if (const Json* ty = e->get("rope_type"))
+                            if (ty->kind == Json::Str && ty->str != "default")
+                                return fail(CS_ERR_UNSUPPORTED, "Failed to initialize embedding model: this ModernBERT configuration is not built "
+                                            "(rope_type \"%s\")", ty->str.c_str());
+                        float& dst = which[0] == 'f' ? c.rotary_base : c.rotary_base_local;
+                        dst = num(e->get("rope_theta"), dst);
+                    }
+            c.arch = CS_ARCH_MODERN;
+            c.pooling = pooling_given ? pooling : (pooling_file ? pooling : CS_POOL_MEAN);  // fastembed pools the model by mean
+            *cfg = c;
+            return CS_OK;
+        }
+    if (const Json* mt = root.get("model_type"))
         if (mt->kind == Json::Str && mt->str != "bert")
             return fail(CS_ERR_UNSUPPORTED, "Failed to initialize embedding model: model_type \"%s\" is not a BERT encoder",
                         mt->str.c_str());
@@ -497,6 +654,7 @@ int32_t cs_bert_params_from_safetensors(const char* path, const cs_bert_config* 
         have[kv.first] = std::move(t);
     }
     const uint64_t data0 = 8 + hlen;
+    if (cfg->arch == CS_ARCH_MODERN) return modern_params_from_safetensors(f, have, data0, *cfg, params, path);
     std::vector<unsigned char> raw;
     bool jina_first_file = false;
     if (cs_arch_alibi(cfg->arch))
@@ -610,6 +768,9 @@ int32_t cs_embedder_create_from_dir(const char* model_dir, int32_t pooling, int3
         if (onnx.empty())
             return fail(CS_ERR_BAD_ARG, "Failed to initialize embedding model: %s holds neither model.safetensors nor "
                         "onnx/model.onnx, model.onnx, model_optimized.onnx or model_quantized.onnx", model_dir);
+        if (cfg.arch == CS_ARCH_MODERN)
+            return fail(CS_ERR_UNSUPPORTED, "Failed to initialize embedding model: the ONNX export of a ModernBERT model is not read "
+                        "(%s): place the repository's model.safetensors in %s", onnx.c_str(), model_dir);
         if (cs_arch_alibi(cfg.arch))
             return fail(CS_ERR_UNSUPPORTED, "Failed to initialize embedding model: the ONNX export of a JinaBert model is not read "
                         "(%s): place the repository's model.safetensors in %s", onnx.c_str(), model_dir);

@@ -49,6 +49,15 @@ static int32_t create_impl(const cs_bert_config* cfg, const float* params, uint6
     if (cs_arch_alibi(cfg->arch) && wscale)
         return fail(CS_ERR_UNSUPPORTED, "Failed to initialize embedding model: the dynamic-quantisation mode is not built for "
                     "the JinaBert encoder (create it from the dequantised weights: cs_embedder_create)");
+    if (cfg->arch == CS_ARCH_MODERN) {
+        if (!(cfg->rotary_base > 1.0f) || !(cfg->rotary_base < 1.0e9f) || !(cfg->rotary_base_local > 1.0f) || !(cfg->rotary_base_local < 1.0e9f))
+            return fail(CS_ERR_BAD_ARG, "Failed to initialize embedding model: rotary bases %g / %g", (double)cfg->rotary_base,
+                        (double)cfg->rotary_base_local);
+        if (cfg->global_every == 0 || cfg->local_window == 0)
+            return fail(CS_ERR_BAD_ARG, "Failed to initialize embedding model: ModernBERT needs global_every and local_window");
+        if (wscale) return fail(CS_ERR_UNSUPPORTED, "Failed to initialize embedding model: the dynamic-quantisation mode is not built for "
+                                "the ModernBERT encoder (create it from the dequantised weights: cs_embedder_create)");
+    }
     if (cfg->arch == CS_ARCH_NOMIC) {
         if (!(cfg->rotary_base > 1.0f) || !(cfg->rotary_base < 1.0e9f))
             return fail(CS_ERR_BAD_ARG, "Failed to initialize embedding model: rotary base %g", (double)cfg->rotary_base);
@@ -114,8 +123,12 @@ static int32_t create_impl(const cs_bert_config* cfg, const float* params, uint6
     }
     if (s == CS_OK && cs_arch_gated(cfg->arch)) {
         const size_t I = cfg->intermediate, half = H / cfg->heads / 2;
+        const bool rotary = cfg->arch == CS_ARCH_NOMIC || cfg->arch == CS_ARCH_MODERN;
         if (hipMalloc(&h->d_bup, (size_t)cfg->layers * 2 * I * sizeof(float)) != hipSuccess ||
-            (cfg->arch == CS_ARCH_NOMIC && hipMalloc(&h->d_rope, (size_t)cfg->max_position * half * sizeof(float2)) != hipSuccess))
+            (rotary && hipMalloc(&h->d_rope, (size_t)cfg->max_position * half * sizeof(float2)) != hipSuccess) ||
+            (cfg->arch == CS_ARCH_MODERN && (hipMalloc(&h->d_rope_local, (size_t)cfg->max_position * half * sizeof(float2)) != hipSuccess ||
+                                             hipMalloc(&h->d_zero_row, H * sizeof(float)) != hipSuccess ||
+                                             hipMemsetAsync(h->d_zero_row, 0, H * sizeof(float), h->stream) != hipSuccess)))
             return cleanup(fail(CS_ERR_OOM, "hipMalloc(parameters) failed"));
         for (uint32_t l = 0; l < cfg->layers && s == CS_OK; ++l) {
             cs_bert_layer_offsets lo;
@@ -129,17 +142,20 @@ static int32_t create_impl(const cs_bert_config* cfg, const float* params, uint6
                 s = fail(CS_ERR_HIP, "feed-forward bias packing failed");
         }
         // the module's cos / sin cache, formed as it forms it: inv_freq_i = 1 / base^(2i / d_h) and pos * inv_freq_i in f32
-        std::vector<float2> rope(cfg->arch == CS_ARCH_NOMIC ? (size_t)cfg->max_position * half : 0);
+        std::vector<float2> rope(rotary ? (size_t)cfg->max_position * half : 0);
         const float dh = (float)(2 * half);
-        for (size_t i = 0; i < half && !rope.empty(); ++i) {
-            const float inv_freq = 1.0f / powf(cfg->rotary_base, (float)(2 * i) / dh);
-            for (size_t p = 0; p < cfg->max_position; ++p) {
-                const float ang = (float)p * inv_freq;
-                rope[p * half + i] = make_float2(cosf(ang), sinf(ang));
+        for (int which = 0; which < (cfg->arch == CS_ARCH_MODERN ? 2 : 1) && !rope.empty() && s == CS_OK; ++which) {
+            const float base = which ? cfg->rotary_base_local : cfg->rotary_base;
+            for (size_t i = 0; i < half; ++i) {
+                const float inv_freq = 1.0f / powf(base, (float)(2 * i) / dh);
+                for (size_t p = 0; p < cfg->max_position; ++p) {
+                    const float ang = (float)p * inv_freq;
+                    rope[p * half + i] = make_float2(cosf(ang), sinf(ang));
+                }
             }
+            if (hipMemcpy(which ? h->d_rope_local : h->d_rope, rope.data(), rope.size() * sizeof(float2), hipMemcpyHostToDevice) != hipSuccess)
+                s = fail(CS_ERR_HIP, "rotary table upload failed");
         }
-        if (s == CS_OK && !rope.empty() && hipMemcpy(h->d_rope, rope.data(), rope.size() * sizeof(float2), hipMemcpyHostToDevice) != hipSuccess)
-            s = fail(CS_ERR_HIP, "rotary table upload failed");
     }
     // split-f16 copies of the four dense weights of every layer (split_f16.hpp)
     if (s == CS_OK) {
@@ -307,6 +323,8 @@ void cs_embedder_destroy(cs_embedder* h) {
     if (h->d_bup) (void)hipFree(h->d_bup);
     if (h->d_rope) (void)hipFree(h->d_rope);
     if (h->d_alibi) (void)hipFree(h->d_alibi);
+    if (h->d_rope_local) (void)hipFree(h->d_rope_local);
+    if (h->d_zero_row) (void)hipFree(h->d_zero_row);
     if (h->d_wsplit) (void)hipFree(h->d_wsplit);
     if (h->d_flag) (void)hipFree(h->d_flag);
     if (h->d_sf_layers) (void)hipFree(h->d_sf_layers);

@@ -168,6 +168,88 @@ int32_t forward_range(cs_embedder* h, hipStream_t s, uint32_t b0, uint32_t nb, u
         if (takes_192(Mr, Nn, Kk)) return launch_gemm_wide(epi, Ain, Wt, bias, resid, Cf, Csp, Mr, Nn, Kk, h->d_flag, s, 192);
         return launch_gemm_split(epi, Ain, Wt, bias, resid, Cf, Csp, Mr, Nn, Kk, h->d_flag, s);
     };
+    // ---- ModernBERT (CS_ARCH_MODERN): pre-norm layers -----------------------------------------------------------------------------
+    // x is the residual stream and is only ever added to: x += Wo attention(rope(Wqkv LN_attn(x))) (layer 0 takes the embedding
+    // LayerNorm's output as it is); x += Wo_mlp(gelu(Wi_a LN_mlp(x)) * Wi_b LN_mlp(x)); a final LayerNorm in front of the
+    // pooling.  The LayerNorm outputs go to the context buffer (f32, free at both points) and to xs in split form; the rotary
+    // table and the attention window follow the layer's type (global every `global_every`-th layer, local otherwise); the
+    // gate is the up projection's epilogue at indexing sizes (GW_OUT_GEGLU, as for JinaBert: value = the half of Wi that is
+    // not activated).  The same kernels as every other family; exact-f32 mode included.
+    if (c.arch == CS_ARCH_MODERN) {
+        if (q8) return fail(CS_ERR_UNSUPPORTED, "the dynamic-quantisation mode is not built for the ModernBERT encoder");
+        a.pos = nullptr; a.type0 = h->d_zero_row;
+        if (!split) a.xs = nullptr;
+        CS_TRY(mark(-1));
+        CS_TRY(launch_row_kernel(0, a, H, s));  // E1 (its split copy is layer 0's operand: attn_norm is the identity there)
+        CS_TRY(mark(CS_STAGE_EMBED_LN));
+        _Float16* qkvs = reinterpret_cast<_Float16*>(qkv);
+        EncoderLaunch n = a;   // LayerNorm of the residual stream into the context buffer (+ xs)
+        n.src = x; n.x = ctx;
+        for (uint32_t l = 0; l < c.layers; ++l) {
+            cs_bert_layer_offsets lo;
+            cs_bert_layer_layout(&c, &h->off, l, &lo);
+            const bool global = c.global_every == 0 || l % c.global_every == 0;
+            const float2* rope = global ? h->d_rope : h->d_rope_local;
+            const uint32_t window = global ? 0u : c.local_window;
+            const float* bqkv = h->d_bqkv + (size_t)l * 3 * H;
+            if (l) {
+                n.g = P + lo.ao_ln_g; n.b = P + lo.ao_ln_b;
+                CS_TRY(launch_row_kernel(4, n, H, s));  // attn_norm
+            }
+            if (split) {
+                const _Float16* ws = h->d_wsplit + (size_t)l * sl.total;
+                CS_TRY(dense(SH_OUT_SPLIT, xs, ws + sl.qkv, bqkv, nullptr, nullptr, qkvs, T, 3 * H, H));  // E2
+                CS_TRY(launch_rope_split(qkvs, rope, T, L, H, c.heads, h->d_flag, s));
+                CS_TRY(mark(CS_STAGE_QKV));
+                CS_TRY(launch_attention_sh2(qkvs, mask, ctxs, h->d_flag, nb, L, H, c.heads, s, nullptr, nullptr, nullptr, nullptr, nullptr, window));  // E3
+                CS_TRY(mark(CS_STAGE_ATTENTION));
+                CS_TRY(dense(SH_OUT_F32_RESID, ctxs, ws + sl.ao, P + lo.ao_b, x, x, nullptr, T, H, H));  // E4: x += Wo ctx
+                CS_TRY(mark(CS_STAGE_OUT_PROJ));
+                n.g = P + lo.out_ln_g; n.b = P + lo.out_ln_b;
+                CS_TRY(launch_row_kernel(4, n, H, s));  // mlp_norm
+                CS_TRY(mark(CS_STAGE_LN_ATTN));
+                _Float16* gated = reinterpret_cast<_Float16*>(mid + (size_t)T * 2 * I);
+                const float* bup = h->d_bup + (size_t)l * 2 * I;
+                const bool w384 = takes_wide(T, 2 * I, H), w192 = !w384 && takes_192(T, 2 * I, H);
+                if (w384 || w192) {
+                    CS_TRY(launch_gemm_wide(GW_OUT_GEGLU, xs, ws + sl.up, bup, nullptr, nullptr, gated, T, 2 * I, H, h->d_flag, s, w192 ? 192 : 0));
+                } else {
+                    CS_TRY(dense(SH_OUT_SPLIT, xs, ws + sl.up, bup, nullptr, nullptr, mids, T, 2 * I, H));
+                    CS_TRY(launch_swiglu_split(mids, gated, T, I, h->d_flag, s, true));
+                }
+                CS_TRY(mark(CS_STAGE_FFN_UP));
+                CS_TRY(dense(SH_OUT_F32_RESID, gated, ws + sl.down, P + lo.down_b, x, x, nullptr, T, H, I));  // E6: x += Wo_mlp(...)
+                CS_TRY(mark(CS_STAGE_FFN_DOWN));
+            } else {
+                const float* nin = l ? ctx : x;  // layer 0: the embedding LayerNorm's output itself
+                const float* wqkv = h->d_wqkv + (size_t)l * 3 * H * H;
+                CS_TRY(launch_gemm(GEMM_BIAS, nin, wqkv, bqkv, nullptr, qkv, T, 3 * H, H, s));
+                CS_TRY(launch_rope_f32(qkv, rope, T, L, H, c.heads, s));
+                CS_TRY(mark(CS_STAGE_QKV));
+                CS_TRY(launch_attention(qkv, mask, ctx, nb, L, H, c.heads, s, nullptr, window));
+                CS_TRY(mark(CS_STAGE_ATTENTION));
+                CS_TRY(launch_gemm(GEMM_RESID, ctx, P + lo.ao_w, P + lo.ao_b, x, x, T, H, H, s));
+                CS_TRY(mark(CS_STAGE_OUT_PROJ));
+                n.g = P + lo.out_ln_g; n.b = P + lo.out_ln_b;
+                CS_TRY(launch_row_kernel(4, n, H, s));
+                CS_TRY(mark(CS_STAGE_LN_ATTN));
+                float* gate = mid + (size_t)T * I;
+                CS_TRY(launch_gemm(GEMM_BIAS, ctx, P + lo.up_w, P + lo.up_b, nullptr, mid, T, I, H, s));
+                CS_TRY(launch_gemm(GEMM_BIAS, ctx, P + lo.gate_w, P + lo.gate_b, nullptr, gate, T, I, H, s));
+                CS_TRY(launch_swiglu_f32(mid, gate, T, I, s, true));
+                CS_TRY(mark(CS_STAGE_FFN_UP));
+                CS_TRY(launch_gemm(GEMM_RESID, mid, P + lo.down_w, P + lo.down_b, x, x, T, H, I, s));
+                CS_TRY(mark(CS_STAGE_FFN_DOWN));
+            }
+        }
+        a.g = P + h->off.final_ln_g; a.b = P + h->off.final_ln_b; a.xs = nullptr;
+        CS_TRY(launch_row_kernel(1, a, H, s));  // final_norm, in place
+        CS_TRY(mark(CS_STAGE_LN_FFN));
+        h->last_hidden_partial = false;
+        CS_TRY(launch_row_kernel(2, a, H, s));  // E7 + E8
+        CS_TRY(mark(CS_STAGE_POOL));
+        return CS_OK;
+    }
     // ---- a few short sequences (under 200 token rows: the query side) ----
     // small_path.hip: LayerNorm as the prologue of the dense layer that reads it, FFN-down as four K slices summed by the
     // LayerNorm that follows: 62 launches per 12-layer forward instead of 86, none of them pulling 196 KB through one CU

@@ -82,6 +82,10 @@ struct cs_embedder {
     // of 16, like the rows of the packed weight) and the rotary table [max_position][d_h / 2] (cos, sin)
     float* d_bup = nullptr;
     float2* d_rope = nullptr;
+    // CS_ARCH_MODERN: the rotary table of the local-attention layers (d_rope: of the global ones) and a row of H zeros (the
+    // token-type row the embedding kernel adds: this family has none)
+    float2* d_rope_local = nullptr;
+    float* d_zero_row = nullptr;
     // CS_ARCH_JINA*: the ALiBi head slopes, [2][heads]: as they are | times log2 e (attention_split.hip adds in the exp2 domain)
     float* d_alibi = nullptr;
     _Float16* d_wsplit = nullptr;  // per layer: wqkv | attention-out | ffn-up | ffn-down, split-f16 rows

@@ -142,6 +142,28 @@ layernorm_kernel(float* __restrict__ x, const float* __restrict__ g, const float
     if (range_out) ln_range_out(lo, hi, range_out, range_rows, t, T);
 }
 
+// LayerNorm of src into dst (and its split form): the pre-norm families keep src, the residual stream, as it is
+template <int NPL>
+__global__ void __launch_bounds__(256)
+layernorm_to_kernel(const float* __restrict__ src, float* __restrict__ dst, const float* __restrict__ g, const float* __restrict__ b,
+                    float eps, uint32_t T, _Float16* __restrict__ xs, uint32_t* __restrict__ flag) {
+    constexpr int H = 64 * NPL;
+    const int lane = threadIdx.x & 63;
+    const uint32_t t = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= T) return;
+    const float* row = src + (size_t)t * H;
+    float v[NPL];
+#pragma unroll
+    for (int p = 0; p < NPL / 2; ++p) {
+        const float2 r2 = *reinterpret_cast<const float2*>(row + ln_col(lane, 2 * p));
+        v[2 * p] = r2.x;
+        v[2 * p + 1] = r2.y;
+    }
+    float lo = 0.0f, hi = 0.0f;
+    const bool ovf = ln_row<NPL>(v, g, b, eps, lane, dst + (size_t)t * H, xs ? xs + (size_t)t * H * 2 : nullptr, lo, hi);
+    if (ovf && flag) atomicOr(flag, 1u);
+}
+
 // LayerNorm over x + bias + sum of the split-K partial slabs (the epilogue of a launch_gemm_split_partial
 // GEMM moved here: slab order is fixed, so the sum is deterministic).
 template <int NPL>
@@ -423,7 +445,7 @@ template <bool SPLIT>
 __global__ void __launch_bounds__(256)
 attention_kernel(const float* __restrict__ qkv, const int32_t* __restrict__ mask,
                  float* __restrict__ ctx, _Float16* __restrict__ ctxs, uint32_t* __restrict__ flag,
-                 uint32_t L, uint32_t H, float scale, const float* __restrict__ alibi) {
+                 uint32_t L, uint32_t H, float scale, const float* __restrict__ alibi, uint32_t window) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const uint32_t Lp = (L + 31) & ~31u;
     float* Ks = smem;                 // [Lp][36]
@@ -493,6 +515,7 @@ attention_kernel(const float* __restrict__ qkv, const int32_t* __restrict__ mask
             const uint32_t key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
             st[r] = st[r] * scale + madd[key];
             if (alibi) st[r] += alibi[head] * -fabsf((float)query - (float)key);  // JinaBert: -slope_h |i - j|
+            if (window && (query > key ? query - key : key - query) > window) st[r] = kMaskMin;  // ModernBERT: a local layer
             tmax = fmaxf(tmax, st[r]);
         }
         tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
@@ -555,7 +578,7 @@ constexpr int AKT64 = 128; // keys per super-tile
 
 __global__ void __launch_bounds__(256)
 attention64_kernel(const float* __restrict__ qkv, const int32_t* __restrict__ mask, float* __restrict__ ctx,
-                   uint32_t L, uint32_t H, float scale, const float* __restrict__ alibi) {
+                   uint32_t L, uint32_t H, float scale, const float* __restrict__ alibi, uint32_t window) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const uint32_t Lp = (L + 31) & ~31u;
     float* Ks = smem;                          // [128][68]
@@ -630,6 +653,7 @@ attention64_kernel(const float* __restrict__ qkv, const int32_t* __restrict__ ma
                 const uint32_t key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
                 stt[r] = stt[r] * scale + madd[key];
                 if (alibi) stt[r] += alibi[head] * -fabsf((float)query - (float)key);  // JinaBert: -slope_h |i - j|
+                if (window && (query > key ? query - key : key - query) > window) stt[r] = kMaskMin;  // ModernBERT: a local layer
                 tmax = fmaxf(tmax, stt[r]);
             }
             tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
@@ -795,6 +819,9 @@ static void launch_rows(int which, const EncoderLaunch& a, hipStream_t s) {
     else if (which == 1)
         hipLaunchKernelGGL(layernorm_kernel<NPL>, dim3((T + 3) / 4), dim3(256), 0, s, a.x, a.g, a.b, a.eps, T,
                            static_cast<_Float16*>(a.xs), a.flag, a.range_out, a.range_rows ? 1u : 0u);
+    else if (which == 4)
+        hipLaunchKernelGGL(layernorm_to_kernel<NPL>, dim3((T + 3) / 4), dim3(256), 0, s, a.src, a.x, a.g, a.b, a.eps, T,
+                           static_cast<_Float16*>(a.xs), a.flag);
     else if (which == 3)
         hipLaunchKernelGGL(layernorm_sum_kernel<NPL>, dim3((T + 3) / 4), dim3(256), 0, s, a.x, a.parts, a.nparts,
                            a.bias, a.g, a.b, a.eps, T, static_cast<_Float16*>(a.xs), a.flag);
@@ -857,7 +884,7 @@ size_t attention_lds_bytes(uint32_t L) {
 
 static int32_t launch_attention_impl(const float* qkv, const int32_t* mask, float* ctx, _Float16* ctxs,
                                      uint32_t* flag, uint32_t B, uint32_t L, uint32_t H, uint32_t heads,
-                                     hipStream_t s, const float* alibi) {
+                                     hipStream_t s, const float* alibi, uint32_t window) {
     if (heads && H % heads == 0 && H / heads == 64 && !ctxs) {  // exact-f32 mode, 64-wide heads
         const size_t Lp = (L + 31) & ~31u;
         const size_t lds64 = ((size_t)AKT64 * (AKS64 + 64) + Lp + 4) * sizeof(float);
@@ -868,7 +895,7 @@ static int32_t launch_attention_impl(const float* qkv, const int32_t* mask, floa
             return CS_OK;
         }));
         hipLaunchKernelGGL(attention64_kernel, dim3((L + 127) / 128, heads, B), dim3(256), lds64, s, qkv, mask, ctx, L, H,
-                           1.0f / sqrtf(64.0f), alibi);
+                           1.0f / sqrtf(64.0f), alibi, window);
         CS_HIP(hipGetLastError());
         return CS_OK;
     }
@@ -885,14 +912,14 @@ static int32_t launch_attention_impl(const float* qkv, const int32_t* mask, floa
     dim3 grid((L + 127) / 128, heads, B);
     const float scale = 1.0f / sqrtf(32.0f);
     if (ctxs) return fail(CS_ERR_UNSUPPORTED, "the f32 attention kernel writes f32 context rows only");
-    hipLaunchKernelGGL(attention_kernel<false>, grid, dim3(256), lds, s, qkv, mask, ctx, ctxs, flag, L, H, scale, alibi);
+    hipLaunchKernelGGL(attention_kernel<false>, grid, dim3(256), lds, s, qkv, mask, ctx, ctxs, flag, L, H, scale, alibi, window);
     CS_HIP(hipGetLastError());
     return CS_OK;
 }
 
 int32_t launch_attention(const float* qkv, const int32_t* mask, float* ctx, uint32_t B, uint32_t L,
-                         uint32_t H, uint32_t heads, hipStream_t s, const float* alibi) {
-    return launch_attention_impl(qkv, mask, ctx, nullptr, nullptr, B, L, H, heads, s, alibi);
+                         uint32_t H, uint32_t heads, hipStream_t s, const float* alibi, uint32_t window) {
+    return launch_attention_impl(qkv, mask, ctx, nullptr, nullptr, B, L, H, heads, s, alibi, window);
 }
 
 int32_t launch_synth_params(float* d_out, const cs_bert_config& cfg, uint64_t seed, hipStream_t s) {

@@ -26,6 +26,7 @@ struct EncoderLaunch {
     const float* parts = nullptr;  // which == 3: [nparts][T][H] partial sums of a split-K GEMM
     const float* bias = nullptr;   //             the layer's bias ([H])
     uint32_t nparts = 0;
+    const float* src = nullptr;    // which == 4: LayerNorm of src -> x (and xs), src left as it is (pre-norm families)
     uint32_t* flag = nullptr;   // split-f16 overflow flag (device)
     float* range_out = nullptr; // which 0 / 1, optional: [ceil(T / 4)][2] — each block's (lo, hi) of the rows it wrote
     bool range_rows = false;    //   ... or [T][2], a pair per token row (several quantisation units in the batch)
@@ -39,8 +40,9 @@ int32_t launch_gemm(int epi, const float* A, const float* W, const float* bias, 
                     float* C, uint32_t M, uint32_t N, uint32_t K, hipStream_t s);
 // qkv [B*L, 3H] (Q | K | V), mask [B, L] -> ctx [B*L, H]
 // alibi (optional, device, [heads]): JinaBert's head slopes — the score of (query i, key j) gets -slope_h |i - j|
+// window (0 = none): ModernBERT's local layers — keys with |i - j| > window are masked like padding
 int32_t launch_attention(const float* qkv, const int32_t* mask, float* ctx, uint32_t B, uint32_t L,
-                         uint32_t H, uint32_t heads, hipStream_t s, const float* alibi = nullptr);
+                         uint32_t H, uint32_t heads, hipStream_t s, const float* alibi = nullptr, uint32_t window = 0);
 size_t attention_lds_bytes(uint32_t L);
 // attention_split.hip: the same attention on the f16 MFMA with split-f16 operands:
 // attention on a split-f16 qkv [T][3H/32][64] (the QKV GEMM's SH_OUT_SPLIT output): K/V go to LDS by
@@ -52,7 +54,7 @@ size_t attention_lds_bytes(uint32_t L);
 int32_t launch_attention_sh2(const _Float16* qkv_split, const int32_t* mask, void* ctx_split, uint32_t* flag,
                              uint32_t B, uint32_t L, uint32_t H, uint32_t heads, hipStream_t s, float* range_out = nullptr,
                              uint32_t* range_pairs = nullptr, const uint32_t* seq_unit = nullptr,
-                             const uint32_t* unit_len = nullptr, const float* alibi = nullptr);
+                             const uint32_t* unit_len = nullptr, const float* alibi = nullptr, uint32_t window = 0);
 
 // Split-f16 GEMM (gemm_split.hip): A [M][K/32][64] f16, W [N][K/32][64] f16 (split_f16.hpp).
 enum { SH_OUT_F32 = 0, SH_OUT_F32_RESID = 1, SH_OUT_SPLIT_GELU = 2, SH_OUT_SPLIT = 3,

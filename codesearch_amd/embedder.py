@@ -18,7 +18,7 @@ import numpy as np
 
 from . import _lib
 from ._lib import CsError, f32p, i32p
-from .bert_params import ARCH_JINA_QKNORM, ARCH_NOMIC, POOL_CLS, POOL_MEAN, BertConfig
+from .bert_params import ARCH_JINA_QKNORM, ARCH_MODERN, ARCH_NOMIC, POOL_CLS, POOL_MEAN, BertConfig
 from .tokenizer import pack_texts
 
 
@@ -104,9 +104,15 @@ class ModelType(enum.Enum):
             # the query / key rows (its auto_map names the "qk-post-norm" modelling file); mean pooling; 512 tokens as above.
             return BertConfig(vocab_size=61056, hidden=768, layers=12, heads=12, intermediate=3072, max_position=512,
                               pooling=POOL_MEAN, arch=ARCH_JINA_QKNORM)
-        raise CsError(_lib.CS_ERR_UNSUPPORTED,
-                      f"Failed to initialize embedding model: {self.name_str()} is not a BERT, NomicBert or JinaBert encoder "
-                      "(the ModernBERT family is not built)")
+        if self is ModelType.ModernBertEmbedLarge:
+            # ModernBERT-large [3P-MEM: lightonai/modernbert-embed-large's config.json]: 28 x 1024, 16 heads of 64, intermediate
+            # 2624 — carried as 2688 = 21 x 128, the kernels' tile: the extra rows / columns are zero —, vocab 50368, pre-norm,
+            # rotary positions (base 160000 on every third layer, which attends globally; 10000 on the others, which see
+            # 64 tokens either side), GELU-gated feed-forward, eps 1e-5; mean pooling; 512 tokens as above.
+            return BertConfig(vocab_size=50368, hidden=1024, layers=28, heads=16, intermediate=2688, max_position=512,
+                              type_vocab_size=1, layer_norm_eps=1e-5, pooling=POOL_MEAN, arch=ARCH_MODERN, rotary_base=160000.0,
+                              rotary_base_local=10000.0, local_window=64, global_every=3)
+        raise CsError(_lib.CS_ERR_UNSUPPORTED, f"Failed to initialize embedding model: {self.name_str()} has no encoder configuration")
 
 
 # second spellings accepted by ModelType::parse (embedder.rs:178-195), verbatim

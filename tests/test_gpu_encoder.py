@@ -131,8 +131,8 @@ def test_cancel_and_errors(FE):
         emb.embed_ids(np.zeros((1, 513), np.int32), np.ones((1, 513), np.int32))
     assert emb.embed_ids(ids[:0], mask[:0]).shape == (0, 384)  # embedder.rs:271-273
     assert emb.dimensions() == 384 and emb.model_name() == "BAAI/bge-small-en-v1.5"
-    with pytest.raises(CsError):  # the one model family that is not built
-        FastEmbedder(ModelType.ModernBertEmbedLarge)
+    with pytest.raises(CsError):  # an encoder family the library does not know
+        FastEmbedder(ModelType.BGESmallENV15, config=BertConfig(arch=9), seed=1)
     assert ModelType.BGEBaseENV15.bert_config().hidden == 768 and ModelType.MxbaiEmbedLargeV1.bert_config().heads == 16
 
 

@@ -3,7 +3,7 @@
 import pytest
 
 from codesearch_amd import CsError, ModelType
-from codesearch_amd.bert_params import ARCH_JINA_QKNORM, ARCH_NOMIC, POOL_CLS, POOL_MEAN
+from codesearch_amd.bert_params import ARCH_JINA_QKNORM, ARCH_MODERN, ARCH_NOMIC, POOL_CLS, POOL_MEAN
 
 M = ModelType
 
@@ -70,8 +70,11 @@ def test_gpu_runnable_architectures():
     c = M.JinaEmbeddingsV2BaseCode.bert_config()  # JinaBert: ALiBi, GELU-gated feed-forward, LayerNorm on Q / K rows
     assert (c.arch, c.hidden, c.layers, c.heads, c.intermediate, c.vocab_size, c.pooling) == \
         (ARCH_JINA_QKNORM, 768, 12, 12, 3072, 61056, POOL_MEAN)
-    with pytest.raises(CsError):  # ModernBERT: another encoder
-        M.ModernBertEmbedLarge.bert_config()
+    c = M.ModernBertEmbedLarge.bert_config()  # ModernBERT: pre-norm, two rotary bases, local / global layers, padded feed-forward width
+    assert (c.arch, c.hidden, c.layers, c.heads, c.intermediate, c.vocab_size, c.rotary_base, c.rotary_base_local, c.local_window,
+            c.global_every, c.layer_norm_eps, c.pooling) == (ARCH_MODERN, 1024, 28, 16, 2688, 50368, 160000.0, 10000.0, 64, 3, 1e-5, POOL_MEAN)
+    for m in M.all():  # every registry entry has an encoder configuration
+        m.bert_config()
     for m in M.all():  # what the configs produce is what the registry promises
         try:
             assert m.bert_config().hidden == m.dimensions()
