@@ -395,7 +395,13 @@ int32_t cs_embedder_create(const cs_bert_config* cfg, const float* params, uint6
  * modelling file's tensor names (mlp.up_gated_layer / down_layer / layernorm with the value rows first, or mlp.gated_layers /
  * wo with the activated rows first; attention.self.layer_norm_q / _k present or not decides CS_ARCH_JINA_QKNORM against
  * CS_ARCH_JINA, the config's auto_map where there is no checkpoint to ask); max_position is capped at the 512 tokens
- * fastembed truncates to.  Its ONNX export is not read (CS_ERR_UNSUPPORTED). */
+ * fastembed truncates to.  Its ONNX export is not read (CS_ERR_UNSUPPORTED).
+ * A ModernBERT directory (config.json with model_type "modernbert": lightonai/modernbert-embed-large, the registry's
+ * ModernBertEmbedLarge) is read from model.safetensors by HF ModernBertModel's names (embeddings.tok_embeddings / norm,
+ * layers.N.attn_norm / attn.Wqkv / attn.Wo / mlp_norm / mlp.Wi / mlp.Wo, final_norm; optional "model." prefix; biases optional):
+ * config keys global_attn_every_n_layers, local_attention, global_rope_theta / local_rope_theta (or rope_parameters), norm_eps;
+ * intermediate_size is rounded up to a multiple of 128 in the cs_bert_config (2,624 -> 2,688) and the loader fills the
+ * difference with zero rows / columns.  Its ONNX export is not read (CS_ERR_UNSUPPORTED). */
 /* pooling: CS_POOL_CLS, CS_POOL_MEAN, or -1 = what <model_dir>/1_Pooling/config.json says (the
  * sentence-transformers module: mean for MiniLM / E5, CLS for BGE), CLS when that file is absent (mean for a
  * nomic_bert directory: fastembed's pooling for the family). */

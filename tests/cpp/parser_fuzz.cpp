@@ -93,6 +93,10 @@ int main(int argc, char** argv) {
             cfg.vocab_size = v[0]; cfg.hidden = v[1]; cfg.layers = v[2]; cfg.heads = v[3]; cfg.intermediate = v[4]; cfg.max_position = v[5];
             if (got == 7 && v[6] == 1) { cfg.arch = CS_ARCH_NOMIC; cfg.rotary_base = 1000.0f; }
             if (got == 7 && (v[6] == 2 || v[6] == 3)) cfg.arch = v[6] == 2 ? CS_ARCH_JINA : CS_ARCH_JINA_QKNORM;
+            if (got == 7 && v[6] == 4) {
+                cfg.arch = CS_ARCH_MODERN; cfg.rotary_base = 160000.0f; cfg.rotary_base_local = 10000.0f; cfg.local_window = 64;
+                cfg.global_every = 3; cfg.type_vocab_size = 1;
+            }
         }
     }
     const uint64_t n_params = cs_bert_param_count(&cfg);

@@ -110,6 +110,18 @@ def test_nomic_onnx_and_jina_snapshot_readers_survive_truncations_and_mutations(
     fuzz("safetensors", d / "model.safetensors", seed=43, flips=600, aux="64 128 1 4 256 512 3")
     out = fuzz("config_dir", d / "config.json", seed=44, flips=1500)
     assert "0 crashes" in out
+    # ModernBERT: its own safetensors reader (whole tensors fetched, the feed-forward zero-padded) and config.json branch
+    from codesearch_amd.bert_params import ARCH_MODERN
+    from tests.test_gpu_modern import modern_snapshot
+
+    mcfg = BertConfig(vocab_size=64, hidden=128, heads=4, intermediate=256, layers=2, max_position=512, type_vocab_size=1,
+                      pooling=POOL_MEAN, arch=ARCH_MODERN, layer_norm_eps=1e-5, rotary_base=160000.0, rotary_base_local=10000.0,
+                      global_every=3, local_window=64)
+    md = tmp_path / "modern"
+    modern_snapshot(str(md), mcfg, synth_params(mcfg, 9), file_intermediate=200)
+    fuzz("safetensors", md / "model.safetensors", seed=45, flips=600, aux="64 128 2 4 256 512 4")
+    out = fuzz("config_dir", md / "config.json", seed=46, flips=1500)
+    assert "0 crashes" in out
 
 
 def test_tokenizer_json_and_vocab_readers_survive(fuzz, tmp_path):
