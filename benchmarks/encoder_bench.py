@@ -63,7 +63,7 @@ def main():
         stages = {k: round(v / (cfg.layers if k not in ("embed_ln", "pool_normalize") else 1), 1) for k, v in st.items()}
         stages["one_stream_ms_per_forward"] = round(ms1 / max(n1, 1), 3)
     L, H, I, layers = args.seq, cfg.hidden, cfg.intermediate, cfg.layers
-    up = 3 if getattr(cfg, "arch", 0) == 1 else 2  # NomicBert: value and gate projections in front of fc2
+    up = 3 if getattr(cfg, "arch", 0) in (1, 2, 3, 4) else 2  # gated feed-forwards (NomicBert, JinaBert, ModernBERT): value and gate projections in front of the down projection
     flops_tok = layers * (2 * (4 * H * H + up * H * I) + 4 * L * H)
     flops = flops_tok * args.batch * args.seq
     print(json.dumps({

@@ -183,6 +183,9 @@ attention_shx_body(char* smem, const MQ& mq, const MO& mo, const _Float16* qkvs,
     const uint32_t ntiles = (uint32_t)(*last_valid_p) / 32 + 1;  // 32-key tiles that hold a valid key
 
     for (uint32_t st = 0; st * 4 < ntiles; ++st) {
+        if constexpr (WINDOW) {  // (block-uniform) a super-tile of 128 keys no query of this block can see: not staged, not walked
+            if (st * KT > qb * 128 + 127 + window || st * KT + (KT - 1) + window < qb * 128) continue;
+        }
         if (st > 0) {
             __syncthreads();  // every wave is done with the previous super-tile
             stage(st);
@@ -193,6 +196,10 @@ attention_shx_body(char* smem, const MQ& mq, const MO& mo, const _Float16* qkvs,
         const uint32_t kt_end = ntiles - st * 4 < 4 ? ntiles - st * 4 : 4;
         for (uint32_t kl = 0; kl < kt_end; ++kl) {
             const uint32_t kt = st * 4 + kl;  // global 32-key tile
+            if constexpr (WINDOW) {  // (wave-uniform) a key tile outside the window of every query of this wave's tile
+                const uint32_t q0 = qb * 128 + qt * 32;
+                if (kt * 32 > q0 + 31 + window || kt * 32 + 31 + window < q0) continue;
+            }
             sh_f32x16 hh, xx;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { hh[r] = 0.0f; xx[r] = 0.0f; }
