@@ -227,7 +227,9 @@ def test_tokenizer_json_refusals(gpu_lib, tmp_path):
     p = tmp_path / "ok.json"
     p.write_text(json.dumps(base))
     assert WordPieceTokenizer.from_tokenizer_json(str(p)).max_length == 512  # fastembed's default truncation
-    expect({**base, "model": {**base["model"], "type": "BPE"}}, _lib.CS_ERR_UNSUPPORTED, "WordPiece and Unigram are built")
+    expect({**base, "model": {**base["model"], "type": "WordLevel"}}, _lib.CS_ERR_UNSUPPORTED, "WordPiece, Unigram and BPE are built")
+    # (a BPE model is read by its own rules, tests/test_bpe_tokenizer.py: this file has no merges)
+    expect({**base, "model": {**base["model"], "type": "BPE"}}, _lib.CS_ERR_BAD_ARG, "no BPE merges")
     # (a Unigram model is read by its own rules, tests/test_unigram_tokenizer.py: this vocabulary is not a [piece, score] list)
     expect({**base, "model": {**base["model"], "type": "Unigram"}}, _lib.CS_ERR_BAD_ARG, "no unigram vocabulary")
     expect({**base, "model": {**base["model"], "continuing_subword_prefix": "@@"}}, _lib.CS_ERR_UNSUPPORTED, "expected ##")

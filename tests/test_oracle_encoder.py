@@ -169,7 +169,7 @@ def test_c_abi_checkpoint_loaders(tmp_path, gpu_lib):
     bad = tmp_path / "bad"
     bad.mkdir()
     expect(lambda: load(bad), _lib.CS_ERR_BAD_ARG, "cannot open")
-    (bad / "config.json").write_text(json.dumps({**hf, "model_type": "modernbert"}))
+    (bad / "config.json").write_text(json.dumps({**hf, "model_type": "deberta-v2"}))
     expect(lambda: load(bad), _lib.CS_ERR_UNSUPPORTED, "is not a BERT encoder")
     (bad / "config.json").write_text(json.dumps({**hf, "num_hidden_layers": 3}))
     save_file({k: np.ascontiguousarray(v) for k, v in sd.items()}, str(bad / "model.safetensors"))
