@@ -117,6 +117,7 @@ struct cs_embedder {
     uint32_t* d_unit_len = nullptr;
     uint32_t* d_row_slot = nullptr;
     uint32_t cur_units = 1;
+    uint32_t q8_x_pairs = 0;        // (lo, hi) pairs the kernel that last wrote the residual stream left in d_range_pairs
     int gemm_mode = CS_GEMM_SPLIT_F16;
     bool split_unavailable = false;  // device flushes f16 subnormals in the MFMA: exact-f32 kernels only
     bool wide_ok = false;            // every |w| < 31.98: the one-accumulator 128 x 384 kernels may run (gemm_wide.hip)

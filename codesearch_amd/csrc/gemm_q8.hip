@@ -1376,6 +1376,214 @@ gemm_q8_rows_kernel(const void* __restrict__ Asrc, const int8_t* __restrict__ W,
     }
 }
 
+// ---- N = 384 layers (out-proj, FFN-down of the 384-wide models) with their residual add and LayerNorm in the epilogue --------
+// The row-block kernel above hands a row's 384 outputs to eight waves and three n-tiles: the LayerNorm behind E4 / E6 had to be
+// its own kernel (34 us per layer each at 65,536 rows: 100 MB read, 100 MB written — the two of them a tenth of the forward).
+// Here a WAVE owns 16 whole rows: W is the MFMA's first operand, so a lane holds, for each of the 24 column tiles, four
+// CONSECUTIVE columns of ONE row (row l15, columns 16 j + 4 g ..) — 96 accumulators; the four lanes of a row meet by two
+// shuffles for its statistics and the row leaves normalised in 16-byte stores, with the (lo, hi) the next quantisation wants.
+// A block = 8 waves = 128 rows; its activations are loaded (SRC = Q8_SRC_SPLIT: from the split-f16 tensor, quantised on the
+// way in with the tensor's parameters; QR_PREQUANT: the s8 tensor FFN-up left, with its row metadata) ONCE into registers in
+// MFMA operand order — K / 64 x 16 bytes per lane — and W streams through a ring of four 24-KiB stages ([384 n][64 k], one
+// MFMA k-step for all 24 tiles) by LDS-DMA with one barrier per stage.  y, y + residual are the row-block kernel's bits
+// (same operations in the same order); the LayerNorm sums a row in another order than layernorm_kernel (in-lane over 96
+// values, then across four lanes), so its output may differ from the two-kernel path in the last bit.
+// One quantisation unit only (several units: the two-kernel path).  CS_Q8_LN_FUSED=0 restores it.
+constexpr int QN_N = 384, QN_THREADS = 512, QN_NST = 4;
+constexpr int QN_STAGE = QN_N * 64;                    // 24,576 B
+// (the metadata sits at the bottom of LDS: every read of it is then one base register + an immediate offset; above 64 KiB the
+// offsets do not fit the instruction and the compiler keeps — and spills — an address register per (array, tile))
+constexpr int QN_OFF_CM = 0;                           // ws [384] | -zw [384] | colsum [384] | bias [384]
+constexpr int QN_OFF_LN = QN_OFF_CM + 4 * QN_N * 4;    // gamma [384] | beta [384]
+constexpr int QN_OFF_W = QN_OFF_LN + 2 * QN_N * 4;     // 9,216: the ring of weight stages
+constexpr int QN_LDS = QN_OFF_W + QN_NST * QN_STAGE;   // 107,520
+
+template <int SRC, int KS>  // KS = K / 64 stages: 6 (K = 384) | 24 (K = 1536)
+__global__ void __launch_bounds__(QN_THREADS, 2)
+gemm_q8_ln_kernel(const void* __restrict__ Asrc, const Q8RowMeta* __restrict__ rmeta, const uint32_t* __restrict__ in_range,
+                  const int8_t* __restrict__ W, const Q8ColMeta* __restrict__ cmeta, float* X, const float* __restrict__ ln_g,
+                  const float* __restrict__ ln_b, float eps, uint32_t M, float* __restrict__ range_out) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    constexpr uint32_t K = 64 * KS;
+    float* l_ws = reinterpret_cast<float*>(lds + QN_OFF_CM);
+    int* l_nzw = reinterpret_cast<int*>(l_ws + QN_N);
+    int* l_cs = l_nzw + QN_N;
+    float* l_bias = reinterpret_cast<float*>(l_cs + QN_N);
+    float* l_g = reinterpret_cast<float*>(lds + QN_OFF_LN);
+    float* l_b = l_g + QN_N;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, g = lane >> 4;
+    for (int n = tid; n < QN_N; n += QN_THREADS) {
+        const Q8ColMeta cm = cmeta[n];
+        l_ws[n] = cm.ws; l_nzw[n] = -cm.zw; l_cs[n] = cm.colsum; l_bias[n] = cm.bias;
+        l_g[n] = ln_g[n]; l_b[n] = ln_b[n];
+    }
+    float xs = 1.0f, xz = 0.0f, rxs = 1.0f;
+    if (SRC == Q8_SRC_SPLIT) {
+        q8_params(in_range, xs, xz);
+        rxs = __fdiv_rn(1.0f, xs);
+    }
+    // this wave's three LDS-DMA instructions of a stage: 16 rows x 64 B each; piece p of row n sits at slot p ^ ((n >> 2) & 3)
+    uint32_t woff[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        const int row = (wave * 3 + t) * 16 + (lane >> 2);
+        woff[t] = (uint32_t)row * K + (((lane & 3) ^ ((row >> 2) & 3)) * 16);
+    }
+    auto issue = [&](uint32_t st) {
+        char* buf = lds + QN_OFF_W + (st % QN_NST) * QN_STAGE;
+#pragma unroll
+        for (int t = 0; t < 3; ++t) sh_glds16(W + woff[t] + st * 64, buf + (wave * 3 + t) * 1024);
+    };
+    const int frag = l15 * 64 + ((g ^ ((l15 >> 2) & 3)) * 16);  // this lane's 16 bytes of tile j of a stage: + 1024 j
+    const uint32_t groups = (M + 127) / 128;
+    for (uint32_t grp = blockIdx.x; grp < groups; grp += gridDim.x) {
+        const uint32_t row = grp * 128 + wave * 16 + l15;          // this lane's row (the four lanes l15 + 16 g share it)
+        const uint32_t rowc = row < M ? row : M - 1;
+        __syncthreads();  // every wave is done with the previous group's last stages (and the metadata is in LDS)
+        // (opaque to the optimiser: otherwise the 3 x KS DMA source addresses are loop invariants it keeps — and spills — as
+        // 64-bit registers; recomputing one costs an add)
+        asm volatile("" : "+v"(woff[0]), "+v"(woff[1]), "+v"(woff[2]));
+#pragma unroll
+        for (int st = 0; st < QN_NST - 1; ++st) issue(st);
+        // the row's activations as MFMA operands: bytes 64 st + 16 g .. of the row, for every stage
+        q8_i32x4 a[KS];
+        int rowsum = 0;
+        float rxs_row = xs;
+        int za = 0;
+        if constexpr (SRC == Q8_SRC_SPLIT) {
+            const _Float16* src = reinterpret_cast<const _Float16*>(Asrc) + (size_t)rowc * (K / 32) * 64;
+#pragma unroll
+            for (int st = 0; st < KS; ++st) {
+                const _Float16* p = src + (2 * st + (g >> 1)) * 64 + (g & 1) * 16;
+                const f16x8 h0 = *reinterpret_cast<const f16x8*>(p), h1 = *reinterpret_cast<const f16x8*>(p + 8);
+                const f16x8 o0 = *reinterpret_cast<const f16x8*>(p + 32), o1 = *reinterpret_cast<const f16x8*>(p + 40);
+                q8_i32x4 packed;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    uint32_t pw = 0;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int idx = 4 * w + e;
+                        const float v = idx < 8 ? (float)h0[idx] + (float)o0[idx] * kShLoInv : (float)h1[idx - 8] + (float)o1[idx - 8] * kShLoInv;
+                        const float t = v * rxs;
+                        float rt = rintf(t);
+                        if (fabsf(fabsf(t - rt) - 0.5f) < 1.0e-3f) rt = rintf(__fdiv_rn(v, xs));
+                        const float q = fminf(fmaxf(__fadd_rn(rt, xz), 0.0f), 255.0f);
+                        const int b = (int)q - 128;
+                        rowsum += b;
+                        pw |= (uint32_t)(b & 0xff) << (8 * e);
+                    }
+                    packed[w] = (int)pw;
+                }
+                a[st] = packed;
+            }
+            rowsum += __shfl_xor(rowsum, 16);
+            rowsum += __shfl_xor(rowsum, 32);
+            za = (int)xz - 128;
+        } else {
+            const int8_t* src = reinterpret_cast<const int8_t*>(Asrc) + (size_t)rowc * K + g * 16;
+#pragma unroll
+            for (int st = 0; st < KS; ++st) a[st] = *reinterpret_cast<const q8_i32x4*>(src + st * 64);
+            const Q8RowMeta rm = rmeta[rowc];
+            rxs_row = rm.xs; za = rm.za; rowsum = rm.rowsum;
+        }
+        const int rowsum_c = rowsum - (int)K * za, nza = -za;
+        q8_i32x4 acc[24];
+#pragma unroll
+        for (int j = 0; j < 24; ++j) acc[j] = q8_i32x4{0, 0, 0, 0};
+#pragma unroll
+        for (uint32_t st = 0; st < (uint32_t)KS; ++st) {  // (fully unrolled: a[] must stay in registers)
+            // this wave's share of stage st has landed: of the stages it has in flight only the younger ones may remain
+            if (st + QN_NST - 1 <= (uint32_t)KS) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * (QN_NST - 2)) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();  // ... and everyone's; everyone is done with stage st - 1, whose slot the next issue overwrites
+            if (st + QN_NST - 1 < (uint32_t)KS) issue(st + QN_NST - 1);
+            const char* buf = lds + QN_OFF_W + (st % QN_NST) * QN_STAGE + frag;
+            const q8_i32x4 av = a[st];
+#pragma unroll
+            for (int j = 0; j < 24; ++j) {
+                const q8_i32x4 w = *reinterpret_cast<const q8_i32x4*>(buf + j * 1024);
+                acc[j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(w, av, acc[j], 0, 0, 0);
+                // (at most six fragment reads in flight: unrestrained, the scheduler hoists all 24 — 96 registers — and spills)
+                if (j % 6 == 5) __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        // (the accumulators are read through inline asm below: see the row-block kernel's note on MFMA results and s_nop)
+        asm volatile("s_nop 15"
+                     : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]), "+v"(acc[7]),
+                       "+v"(acc[8]), "+v"(acc[9]), "+v"(acc[10]), "+v"(acc[11]), "+v"(acc[12]), "+v"(acc[13]), "+v"(acc[14]), "+v"(acc[15]),
+                       "+v"(acc[16]), "+v"(acc[17]), "+v"(acc[18]), "+v"(acc[19]), "+v"(acc[20]), "+v"(acc[21]), "+v"(acc[22]), "+v"(acc[23]));
+        // y = float(acc with the zero points back in) * (x_scale * W_scale) + bias, + residual: kept in the accumulator registers
+        float* xrow = X + (size_t)rowc * QN_N + 4 * g;
+        float vf[96];  // the row's values this lane holds (scalars: partial updates of the accumulator tuples made the allocator spill)
+        float sum = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 24; ++j) {
+            const int c0 = 16 * j + 4 * g;
+            const sh_f32x4 ws4 = *reinterpret_cast<const sh_f32x4*>(l_ws + c0);
+            const q8_i32x4 nzw4 = *reinterpret_cast<const q8_i32x4*>(l_nzw + c0);
+            const q8_i32x4 cs4 = *reinterpret_cast<const q8_i32x4*>(l_cs + c0);
+            const sh_f32x4 b4 = *reinterpret_cast<const sh_f32x4*>(l_bias + c0);
+            const sh_f32x4 r4 = *reinterpret_cast<const sh_f32x4*>(xrow + 16 * j);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                int corr;
+                asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(corr) : "v"(nzw4[r]), "v"(rowsum_c), "v"(acc[j][r]));
+                asm("v_mad_i32_i24 %0, %1, %2, %0" : "+v"(corr) : "v"(nza), "v"(cs4[r]));
+                const float y = __fadd_rn(__fmul_rn((float)corr, __fmul_rn(rxs_row, ws4[r])), b4[r]);
+                const float v = y + r4[r];
+                sum += v;
+                vf[4 * j + r] = v;
+            }
+            // (the tile's values are pinned here: left alone, the optimiser runs the integer half and the loads of all 24 tiles
+            // first and the float half behind them, and the allocator spills ~160 values per lane)
+            asm volatile("" : "+v"(sum), "+v"(vf[4 * j]), "+v"(vf[4 * j + 1]), "+v"(vf[4 * j + 2]), "+v"(vf[4 * j + 3]));
+            if (j % 2 == 1) __builtin_amdgcn_sched_barrier(0);
+        }
+        sum += __shfl_xor(sum, 16);
+        sum += __shfl_xor(sum, 32);
+        const float mean = sum * (1.0f / (float)QN_N);
+        float qv = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 24; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { const float d = vf[4 * j + r] - mean; qv = fmaf(d, d, qv); }
+        qv += __shfl_xor(qv, 16);
+        qv += __shfl_xor(qv, 32);
+        const float inv = 1.0f / sqrtf(qv * (1.0f / (float)QN_N) + eps);
+        float lo = 0.0f, hi = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 24; ++j) {
+            const int c0 = 16 * j + 4 * g;
+            const sh_f32x4 g4 = *reinterpret_cast<const sh_f32x4*>(l_g + c0);
+            const sh_f32x4 b4 = *reinterpret_cast<const sh_f32x4*>(l_b + c0);
+            sh_f32x4 o;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                o[r] = (vf[4 * j + r] - mean) * inv * g4[r] + b4[r];
+                lo = fminf(lo, o[r]);
+                hi = fmaxf(hi, o[r]);
+            }
+            if (row < M) *reinterpret_cast<sh_f32x4*>(xrow + 16 * j) = o;
+            if (j % 2 == 1) __builtin_amdgcn_sched_barrier(0);
+        }
+        if (range_out) {  // one (lo, hi) pair per wave = 16 rows (rows past M: none of theirs)
+            if (row >= M) { lo = 0.0f; hi = 0.0f; }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                lo = fminf(lo, __shfl_xor(lo, o));
+                hi = fmaxf(hi, __shfl_xor(hi, o));
+            }
+            if (lane == 0) {
+                range_out[2 * ((size_t)grp * 8 + wave)] = lo;
+                range_out[2 * ((size_t)grp * 8 + wave) + 1] = hi;
+            }
+        }
+    }
+}
+
 }  // namespace
 
 int32_t launch_q8_pack_weight(const float* d_W, const float* d_scale, const float* d_bias, uint32_t N, uint32_t K, int8_t* d_wq,
@@ -1466,6 +1674,42 @@ static int32_t launch_rows(const void* d_xq, const Q8RowMeta* d_rmeta, const int
     hipLaunchKernelGGL((gemm_q8_rows_kernel<EPI, SRC, MU>), dim3(units < cus ? units : cus), dim3(QR_THREADS), LDS, s, d_xq, d_wq, d_rmeta,
                        d_cmeta, resid, C, Cs, M, N, d_flag, rq, parts, units, d_in_range, d_row_slot);
     CS_HIP(hipGetLastError());
+    return CS_OK;
+}
+
+// N = 384, one quantisation unit, from 4,096 rows: the product with its residual add and LayerNorm in one kernel
+// (gemm_q8_ln_kernel).  src_kind Q8_SRC_SPLIT (d_src = the split-f16 tensor, d_in_range its range slot) or -1 (d_src = the s8
+// tensor, d_rmeta its rows).  X [M][384]: the residual on entry, LayerNorm(product + bias + residual) on return; *out_pairs
+// (lo, hi) pairs are left in d_range_pairs for the quantisation that follows.
+bool q8_ln_fused_takes(uint32_t M, uint32_t N, uint32_t K) {
+    const char* e = std::getenv("CS_Q8_LN_FUSED");  // (read per call: tests and A/B scripts flip it mid-process)
+    return !(e && e[0] == '0') && N == (uint32_t)QN_N && (K == 384 || K == 1536) && q8_rows_takes(M, 384);
+}
+int32_t launch_gemm_q8_ln(int src_kind, const void* d_src, const Q8RowMeta* d_rmeta, const uint32_t* d_in_range, const int8_t* d_wq,
+                          const Q8ColMeta* d_cmeta, float* X, const float* ln_g, const float* ln_b, float eps, uint32_t M, uint32_t K,
+                          float* d_range_pairs, uint32_t* out_pairs, hipStream_t s) {
+    if (out_pairs) *out_pairs = 0;
+    if (M == 0) return CS_OK;
+    if (K != 384 && K != 1536) return fail(CS_ERR_UNSUPPORTED, "LayerNorm-fused quantised product: K=%u not built (384, 1536)", K);
+    if (src_kind != Q8_SRC_SPLIT && src_kind != QR_PREQUANT) return fail(CS_ERR_BAD_ARG, "LayerNorm-fused quantised product: bad source kind");
+    if (src_kind == Q8_SRC_SPLIT && K != 384) return fail(CS_ERR_UNSUPPORTED, "LayerNorm-fused quantised product: quantise-on-load is built for K = 384");
+    static PerDeviceOnce attr;  // function attributes are per device
+    CS_TRY(attr.run([&]() -> int32_t {
+        CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_q8_ln_kernel<Q8_SRC_SPLIT, 6>), hipFuncAttributeMaxDynamicSharedMemorySize, QN_LDS));
+        CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_q8_ln_kernel<QR_PREQUANT, 6>), hipFuncAttributeMaxDynamicSharedMemorySize, QN_LDS));
+        CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_q8_ln_kernel<QR_PREQUANT, 24>), hipFuncAttributeMaxDynamicSharedMemorySize, QN_LDS));
+        return CS_OK;
+    }));
+    const uint32_t groups = (M + 127) / 128, cus = (uint32_t)q8_cus();
+    const dim3 grid(groups < cus ? groups : cus);
+    if (src_kind == Q8_SRC_SPLIT)
+        hipLaunchKernelGGL((gemm_q8_ln_kernel<Q8_SRC_SPLIT, 6>), grid, dim3(QN_THREADS), QN_LDS, s, d_src, d_rmeta, d_in_range, d_wq, d_cmeta, X, ln_g, ln_b, eps, M, d_range_pairs);
+    else if (K == 384)
+        hipLaunchKernelGGL((gemm_q8_ln_kernel<QR_PREQUANT, 6>), grid, dim3(QN_THREADS), QN_LDS, s, d_src, d_rmeta, d_in_range, d_wq, d_cmeta, X, ln_g, ln_b, eps, M, d_range_pairs);
+    else
+        hipLaunchKernelGGL((gemm_q8_ln_kernel<QR_PREQUANT, 24>), grid, dim3(QN_THREADS), QN_LDS, s, d_src, d_rmeta, d_in_range, d_wq, d_cmeta, X, ln_g, ln_b, eps, M, d_range_pairs);
+    CS_HIP(hipGetLastError());
+    if (out_pairs) *out_pairs = groups * 8;
     return CS_OK;
 }
 

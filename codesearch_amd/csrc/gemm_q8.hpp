@@ -71,6 +71,15 @@ int32_t launch_gemm_q8_gelu_requant_from_source(const float* d_x, const uint32_t
                                                 const float* bias, uint32_t M, uint32_t N, uint32_t K, uint32_t* d_range_out,
                                                 int8_t* d_out, Q8RowMeta* d_rmeta_out, hipStream_t s,
                                                 const uint32_t* d_row_slot = nullptr);
+// N = 384 layers of a one-unit batch from 4,096 rows: product + bias + residual + LayerNorm in ONE kernel (gemm_q8_ln_kernel; a
+// wave owns 16 whole rows).  src_kind: Q8_SRC_SPLIT (d_src split-f16 [M][K/32][64], d_in_range its range slot; K = 384) or
+// Q8_SRC_PREQUANT (d_src s8 [M][K], d_rmeta its rows; K = 384 | 1536).  X [M][384]: the residual on entry, the normalised rows on
+// return; d_range_pairs receives *out_pairs (lo, hi) pairs (one per 16 rows) for the quantisation that follows.
+constexpr int Q8_SRC_PREQUANT = -1;
+bool q8_ln_fused_takes(uint32_t M, uint32_t N, uint32_t K);
+int32_t launch_gemm_q8_ln(int src_kind, const void* d_src, const Q8RowMeta* d_rmeta, const uint32_t* d_in_range, const int8_t* d_wq,
+                          const Q8ColMeta* d_cmeta, float* X, const float* ln_g, const float* ln_b, float eps, uint32_t M, uint32_t K,
+                          float* d_range_pairs, uint32_t* out_pairs, hipStream_t s);
 // The units' ranges from what the tensor's producer left: pairs_per_seq (lo, hi) pairs per sequence, sequence by sequence
 // (attention: its waves' pairs; LayerNorm with EncoderLaunch::range_rows: one pair per token row — pairs_are_rows, and
 // only positions below the unit's own padded length count).  Writes words 0, 1 of every unit's slot.
