@@ -20,6 +20,7 @@ namespace cs {
 namespace {
 
 #include "bytelevel_tables.inc"
+#include "nfc_tables.inc"
 
 bool in_ranges(const uint32_t (*t)[2], uint32_t n, uint32_t cp) {
     uint32_t lo = 0, hi = n;
@@ -88,6 +89,102 @@ std::string sanitize(const char* s, size_t n) {
         else { out.append("\xEF\xBF\xBD"); ++i; }
     }
     return out;
+}
+
+
+// ---- NFC (the normaliser ModernBERT's tokenizer.json puts in front of its BPE model) ----------------------------------------
+// Canonical decomposition (tables: the wheel's own NFD per code point; Hangul arithmetically), canonical reordering by
+// combining class, canonical composition (the wheel's primary composites; Hangul arithmetically) — UAX #15.
+uint32_t nfc_ccc(uint32_t cp) {
+    if (cp < 0x300) return 0;
+    uint32_t lo = 0, hi = kNfcCcc_N;
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) / 2;
+        if (kNfcCcc[mid].cp < cp) lo = mid + 1; else hi = mid;
+    }
+    return (lo < kNfcCcc_N && kNfcCcc[lo].cp == cp) ? kNfcCcc[lo].ccc : 0;
+}
+void nfc_decompose(uint32_t cp, std::vector<uint32_t>& out) {
+    if (cp >= 0xAC00 && cp <= 0xD7A3) {  // Hangul syllable -> L V (T)
+        const uint32_t s = cp - 0xAC00;
+        out.push_back(0x1100 + s / 588);
+        out.push_back(0x1161 + (s % 588) / 28);
+        if (s % 28) out.push_back(0x11A7 + s % 28);
+        return;
+    }
+    if (cp >= 0xC0) {
+        uint32_t lo = 0, hi = kNfcDecomp_N;
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi) / 2;
+            if (kNfcDecomp[mid].cp < cp) lo = mid + 1; else hi = mid;
+        }
+        if (lo < kNfcDecomp_N && kNfcDecomp[lo].cp == cp) {
+            for (uint32_t i = 0; i < kNfcDecomp[lo].len; ++i) out.push_back(kNfcDecompPool[kNfcDecomp[lo].off + i]);
+            return;
+        }
+    }
+    out.push_back(cp);
+}
+uint32_t nfc_compose(uint32_t a, uint32_t b) {  // 0: the pair does not compose
+    if (a >= 0x1100 && a <= 0x1112 && b >= 0x1161 && b <= 0x1175) return 0xAC00 + ((a - 0x1100) * 21 + (b - 0x1161)) * 28;
+    if (a >= 0xAC00 && a <= 0xD7A3 && (a - 0xAC00) % 28 == 0 && b > 0x11A7 && b <= 0x11C2) return a + (b - 0x11A7);
+    uint32_t lo = 0, hi = kNfcPairs_N;
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) / 2;
+        const NfcPair& p = kNfcPairs[mid];
+        if (p.first < a || (p.first == a && p.second < b)) lo = mid + 1; else hi = mid;
+    }
+    return (lo < kNfcPairs_N && kNfcPairs[lo].first == a && kNfcPairs[lo].second == b) ? kNfcPairs[lo].composite : 0;
+}
+// s: valid UTF-8.  Text whose every code point lies below U+0300 is in NFC as it stands (no combining mark, nothing that
+// decomposes to one... composes only with what follows): the common case of source code returns at the scan.
+void nfc_normalize(std::string& s) {
+    bool plain = true;
+    for (size_t i = 0; i < s.size() && plain; ++i) {
+        const unsigned char b = (unsigned char)s[i];
+        if (b >= 0xCC) plain = false;  // lead bytes 0xCC.. start code points >= U+0300
+    }
+    if (plain) return;
+    std::vector<uint32_t> d;
+    d.reserve(s.size());
+    for (size_t i = 0; i < s.size();) {
+        const size_t l = std::min(u8_len((unsigned char)s[i]), s.size() - i);
+        nfc_decompose(u8_cp(s.data() + i, l), d);
+        i += l;
+    }
+    // canonical ordering: every run of non-starters sorted by class, stably
+    for (size_t i = 0; i < d.size();) {
+        if (nfc_ccc(d[i]) == 0) { ++i; continue; }
+        size_t j = i;
+        while (j < d.size() && nfc_ccc(d[j]) != 0) ++j;
+        std::stable_sort(d.begin() + i, d.begin() + j, [](uint32_t x, uint32_t y) { return nfc_ccc(x) < nfc_ccc(y); });
+        i = j;
+    }
+    // canonical composition (UAX #15 sample algorithm)
+    std::vector<uint32_t> c;
+    c.reserve(d.size());
+    if (!d.empty()) {
+        size_t starter_pos = 0;
+        uint32_t starter = d[0];
+        int last_class = (int)nfc_ccc(starter);
+        if (last_class != 0) last_class = 256;  // a leading non-starter never composes with what follows
+        c.push_back(starter);
+        for (size_t i = 1; i < d.size(); ++i) {
+            const uint32_t ch = d[i];
+            const int cls = (int)nfc_ccc(ch);
+            const uint32_t comp = nfc_compose(starter, ch);
+            if (comp && (last_class < cls || last_class == 0)) {
+                c[starter_pos] = comp;
+                starter = comp;
+            } else {
+                if (cls == 0) { starter_pos = c.size(); starter = ch; }
+                last_class = cls;
+                c.push_back(ch);
+            }
+        }
+    }
+    s.clear();
+    for (uint32_t cp : c) append_cp(s, cp);
 }
 
 // GPT-2's bytes_to_unicode: printable bytes stand for themselves, the others for U+0100 + n in order of appearance
@@ -273,6 +370,7 @@ void BpeEngine::encode_word(const std::string& bytes, std::vector<int32_t>& ids)
 // A stretch of text between added tokens: the pre-tokenizer steps, then every pre-token through the model
 void BpeEngine::encode_segment(const char* p, size_t n, bool, std::vector<int32_t>& ids) const {
     std::vector<std::string> pieces(1, std::string(p, n));
+    if (spec_.nfc) nfc_normalize(pieces[0]);
     for (const auto& pre : spec_.pres) {
         std::vector<std::string> next;
         for (std::string& t : pieces) {

@@ -19,6 +19,7 @@ struct BpeSpec {
     std::vector<std::pair<std::string, std::string>> merges;       // model.merges, in rank order
     std::string unk_token;                                         // "" = none (an unknown symbol is dropped, as the library does)
     bool fuse_unk = false, ignore_merges = false;
+    bool nfc = false;                                              // normalizer {"type": "NFC"}: applied to the text between added tokens
     struct Pre {
         enum Kind { BYTE_LEVEL, DIGITS } kind = BYTE_LEVEL;
         bool add_prefix_space = false, use_regex = true;           // BYTE_LEVEL

@@ -1122,8 +1122,20 @@ static int32_t bpe_from_json(const Json& root, const Json& model, const char* js
     spec.fuse_unk = mflag("fuse_unk");
     spec.ignore_merges = mflag("ignore_merges");
     if (const Json* nz = root.get("normalizer"))
-        if (nz->kind != Json::Null)
-            return fail(CS_ERR_UNSUPPORTED, "Failed to initialize embedding model: a normalizer in front of a BPE model is not built");
+        if (nz->kind != Json::Null) {
+            // NFC (ModernBERT's file), alone or as the one member of a Sequence; anything else is refused
+            const Json* one = nz;
+            if (nz->kind == Json::Obj)
+                if (const Json* ty = nz->get("type"))
+                    if (ty->kind == Json::Str && ty->str == "Sequence")
+                        if (const Json* list = nz->get("normalizers"))
+                            if (list->kind == Json::Arr && list->arr.size() == 1) one = &list->arr[0];
+            const Json* ty = one->kind == Json::Obj ? one->get("type") : nullptr;
+            if (!ty || ty->kind != Json::Str || ty->str != "NFC")
+                return fail(CS_ERR_UNSUPPORTED, "Failed to initialize embedding model: normalizer \"%s\" in front of a BPE model is not built (NFC is)",
+                            ty && ty->kind == Json::Str ? ty->str.c_str() : "?");
+            spec.nfc = true;
+        }
     if (const Json* pj = root.get("pre_tokenizer")) CS_TRY(bpe_pre(*pj, spec.pres));
     std::map<std::string, int32_t> added_ids;
     if (const Json* at = root.get("added_tokens"))

@@ -501,7 +501,7 @@ int32_t cs_tokenizer_create_from_file(const char* vocab_path, int32_t lowercase,
  * tokens.  The handle then encodes <s> ... </s> and pads with <pad>; any other component is refused.
  * A file whose model.type is "BPE" (byte-level BPE: the registry's JinaEmbeddingsV2BaseCode,
  * /root/reference/src/embed/embedder.rs:40-41) is read by csrc/bpe.cpp: model.vocab {token: id}, model.merges ("a b" or
- * [a, b]), unk_token, fuse_unk, ignore_merges; no normalizer; pre_tokenizer ByteLevel (add_prefix_space, use_regex: the
+ * [a, b]), unk_token, fuse_unk, ignore_merges; normalizer none or NFC (ModernBERT's file); pre_tokenizer ByteLevel (add_prefix_space, use_regex: the
  * GPT-2 pattern) optionally behind Digits; post_processor RobertaProcessing / TemplateProcessing [<bos>] $A [<eos>] /
  * ByteLevel; special added tokens (lstrip / rstrip honoured).  Dropout, word prefixes / suffixes and byte_fallback are
  * refused.  Merges run in the crate's own queue order (lowest rank, then leftmost), so ids equal the crate's. */

@@ -44,14 +44,21 @@ TEXTS = [
     " \n", "x \n y", "<s>literal specials</s> in <mask> the <pad> text<unk>", "before<mask>after", "a <mask> b", "<s><s>", "</s>",
     "def f(x):\n    return x ** 2  # square\n", "std::vector<std::pair<int, float>> v{{1, 2.0f}};", "#include <stdio.h>\nint main(void){return 0;}",
     "a" * 300, "ab " * 200, "9" * 50, "'" * 7 + "s't're", "end with apostrophe'", "\x00\x01\x7f control", "� replacement ﻿ bom",
+    # canonical (de)composition for the NFC variants: decomposed accents, reordering of marks, Hangul jamo, singletons, exclusions
+    "cafe\u0301 nai\u0308ve A\u030a \u212b \u2126 \u1e9b\u0323 q\u0307\u0323 q\u0323\u0307", "\u1100\u1161\u11a8 \u1112\u1161\u11ab\uae00 \u1100\u1161 \u11a8",
+    "\u0958 \u0915\u093c \u0f43 \u0f42\u0fb7 \ufb1f \u05f2\u05b7 \u2adc \u0344 \u0308\u0301", "a\u0301\u0301\u0328 e\u0328\u0301 \u0301a o\u0302\u0303 \u1ed7 D\u0307\u0323 \u1e0c\u0307",
 ]
 
 
 def build(path, *, post="roberta", add_prefix_space=False, digits=None, use_regex=True, ignore_merges=False, legacy_merges=False,
-          trim=True):
-    from tokenizers import Tokenizer, decoders, models, pre_tokenizers, processors, trainers
+          trim=True, nfc=False):
+    from tokenizers import Tokenizer, decoders, models, normalizers, pre_tokenizers, processors, trainers
 
     tok = Tokenizer(models.BPE())
+    if nfc == "sequence":
+        tok.normalizer = normalizers.Sequence([normalizers.NFC()])
+    elif nfc:
+        tok.normalizer = normalizers.NFC()   # ModernBERT's arrangement
     bl = pre_tokenizers.ByteLevel(add_prefix_space=add_prefix_space, use_regex=use_regex)
     tok.pre_tokenizer = bl if digits is None else pre_tokenizers.Sequence([pre_tokenizers.Digits(individual_digits=digits), bl])
     tok.decoder = decoders.ByteLevel()
@@ -93,6 +100,8 @@ VARIANTS = {
     "digits_contiguous_prefix": dict(post="template", digits=False, add_prefix_space=True),
     "no_regex": dict(post="roberta", use_regex=False),
     "ignore_merges": dict(post="roberta", ignore_merges=True),
+    "nfc_template": dict(post="template", nfc=True),
+    "nfc_sequence_prefix": dict(post="roberta", nfc="sequence", add_prefix_space=True),
 }
 
 
@@ -178,7 +187,7 @@ def test_refusals_are_worded(lib, tmp_path):
     expect(lambda d: d["model"].__setitem__("dropout", 0.1), _lib.CS_ERR_UNSUPPORTED, "dropout")
     expect(lambda d: d["model"].__setitem__("byte_fallback", True), _lib.CS_ERR_UNSUPPORTED, "byte_fallback")
     expect(lambda d: d["model"].__setitem__("end_of_word_suffix", "</w>"), _lib.CS_ERR_UNSUPPORTED, "end_of_word_suffix")
-    expect(lambda d: d.__setitem__("normalizer", {"type": "NFC"}), _lib.CS_ERR_UNSUPPORTED, "normalizer")
+    expect(lambda d: d.__setitem__("normalizer", {"type": "NFKC"}), _lib.CS_ERR_UNSUPPORTED, "normalizer")
     expect(lambda d: d.__setitem__("pre_tokenizer", {"type": "Whitespace"}), _lib.CS_ERR_UNSUPPORTED, "pre_tokenizer")
     expect(lambda d: d["model"]["merges"].append(["zz", "qq"]), _lib.CS_ERR_BAD_ARG, "outside the vocabulary")
     expect(lambda d: d["model"].__setitem__("merges", ["a b c"]), _lib.CS_ERR_BAD_ARG, "not two tokens")
