@@ -8,7 +8,7 @@ cd "$(dirname "$0")/../codesearch_amd/csrc"
 make -s
 mkdir -p ../variants/obj_$name
 objs=""
-for o in *.o; do
+for o in $(ls *.o | grep -v "\.diag\.o$"); do
   src=${o%.o}.hip
   use=$o
   for f in "$@"; do

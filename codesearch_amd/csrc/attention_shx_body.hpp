@@ -9,6 +9,9 @@
 #ifndef AT_STAMP
 #define AT_STAMP(i)
 #endif
+#ifndef CS_ATTN_PIPE_FENCE
+#define CS_ATTN_PIPE_FENCE __builtin_amdgcn_sched_barrier(0)
+#endif
 
 namespace cs {
 
@@ -40,6 +43,16 @@ __device__ __forceinline__ void split_pair_rtz_ng(float a, float b, uint32_t& hi
     lo = __builtin_bit_cast(uint32_t, l);
 }
 
+// max of a value with its partner's in the other half of the wave (lane ^ 32) on the VALU: v_permlane32_swap exchanges the upper
+// half of one register with the lower half of another, so the pair (t, copy of t) comes back as (own, partner's) in every lane —
+// no LDS round trip (ds_bpermute) in the tile's dependent chain.
+__device__ __forceinline__ float xhalf_max_swap(float t) {
+    const uint32_t u = __builtin_bit_cast(uint32_t, t);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    const uint32_t a = r[0], b = r[1];
+    return fmaxf(__builtin_bit_cast(float, a), __builtin_bit_cast(float, b));
+}
+
 // The stand-alone kernel's accesses: plain 16-byte loads, K / V pieces (8 keys x 128 B) by LDS-DMA, plain 8-byte stores.
 struct AttnMemPlain {
     __device__ __forceinline__ f16x8 ld16(const _Float16* p) const { return *reinterpret_cast<const f16x8*>(p); }
@@ -62,7 +75,7 @@ struct AttnMemPlain {
 // POS = 1 (JinaBert, CS_ARCH_JINA*): the score of (query i, key j) of head h also gets -slope_h |i - j|; alibi_log2 [heads] holds
 // the slopes times log2 e (the softmax runs in the exp2 domain).  POS = 2 (ModernBERT's local layers, CS_ARCH_MODERN): keys with
 // |i - j| > window are masked like padding.  BERT / NomicBert instantiate POS = 0: the same code as before the parameter existed.
-template <int NC, class MQ, class MO, int POS = 0>
+template <int NC, class MQ, class MO, int POS = 0, int PIPE = 0>
 __device__ __forceinline__ void
 attention_shx_body(char* smem, const MQ& mq, const MO& mo, const _Float16* qkvs, const int32_t* __restrict__ mask,
                    _Float16* ctxs, uint32_t* __restrict__ flag, uint32_t L, uint32_t H,
@@ -71,6 +84,8 @@ attention_shx_body(char* smem, const MQ& mq, const MO& mo, const _Float16* qkvs,
                    uint32_t bx, uint32_t by, uint32_t bz, uint32_t gx, uint32_t gz, const float* __restrict__ alibi_log2 = nullptr,
                    uint32_t window = 0) {
     constexpr bool ALIBI = POS == 1, WINDOW = POS == 2;
+    constexpr bool IMM = PIPE >= 2;    // the super-tile's tiles written out over pinned lane addresses (below)
+    constexpr bool EARLY = PIPE == 3;  // + a tile's K fragments all requested before its first MFMA, its V fragments before the exponentials
     const float wlimit = (float)window;
     constexpr int KT = 128;                        // keys per super-tile
     const uint32_t Lp = (L + 31) & ~31u;
@@ -182,6 +197,24 @@ attention_shx_body(char* smem, const MQ& mq, const MO& mo, const _Float16* qkvs,
     __syncthreads();
     const uint32_t ntiles = (uint32_t)(*last_valid_p) / 32 + 1;  // 32-key tiles that hold a valid key
 
+    // PIPE = 2: the lane's LDS byte addresses, held in registers for the whole walk (pinned: left alone the compiler
+    // re-adds base and lane offset at every access); a tile's reads are these plus immediates
+    typedef __attribute__((address_space(3))) char* lds_char_p;
+    typedef __attribute__((address_space(3))) const f16x8* lds_f16x8_cp;
+    typedef __attribute__((address_space(3))) const sh_f32x4* lds_f32x4_cp;
+    uint32_t ka[4] = {0, 0, 0, 0}, va[2] = {0, 0}, ma0 = 0;
+    if constexpr (IMM) {
+        const uint32_t k0 = (uint32_t)(uintptr_t)(lds_char_p)Kt + (uint32_t)l31 * 128u, v0 = (uint32_t)(uintptr_t)(lds_char_p)Vt;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) { ka[s] = k0 + (uint32_t)k_hi[s]; ka[2 + s] = k0 + (uint32_t)k_lo[s]; }
+        va[0] = v0 + (uint32_t)v_hi;
+        va[1] = v0 + (uint32_t)v_lo;
+        ma0 = (uint32_t)(uintptr_t)(lds_char_p)reinterpret_cast<char*>(madd) + 16u * (uint32_t)h;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(ka[i]));
+        asm volatile("" : "+v"(va[0]), "+v"(va[1]), "+v"(ma0));
+    }
+
     for (uint32_t st = 0; st * 4 < ntiles; ++st) {
         if constexpr (WINDOW) {  // (block-uniform) a super-tile of 128 keys no query of this block can see: not staged, not walked
             if (st * KT > qb * 128 + 127 + window || st * KT + (KT - 1) + window < qb * 128) continue;
@@ -194,27 +227,58 @@ attention_shx_body(char* smem, const MQ& mq, const MO& mo, const _Float16* qkvs,
         }
         if (!wave_live) continue;  // (still takes part in the staging and the barriers)
         const uint32_t kt_end = ntiles - st * 4 < 4 ? ntiles - st * 4 : 4;
-        for (uint32_t kl = 0; kl < kt_end; ++kl) {
-            const uint32_t kt = st * 4 + kl;  // global 32-key tile
-            if constexpr (WINDOW) {  // (wave-uniform) a key tile outside the window of every query of this wave's tile
-                const uint32_t q0 = qb * 128 + qt * 32;
-                if (kt * 32 > q0 + 31 + window || kt * 32 + 31 + window < q0) continue;
-            }
-            sh_f32x16 hh, xx;
+        const uint32_t ma_st = ma0 + st * 512u;  // (PIPE = 2) the mask floats of this super-tile's keys
+        uint32_t kl_lo = 0, kl_hi = kt_end;
+        if constexpr (WINDOW) {  // (wave-uniform) the key tiles some query of this wave's tile can see: 32 kt <= q0 + 31 + window, 32 kt + 31 + window >= q0
+            const int q0 = (int)(qb * 128 + qt * 32), w = (int)window, t0 = (int)(st * 4);
+            const int first = q0 - 31 - w > 0 ? (q0 - 31 - w + 31) / 32 : 0, past = (q0 + 31 + w) / 32 + 1;
+            kl_lo = (uint32_t)(first > t0 ? first - t0 : 0);
+            kl_hi = past - t0 < (int)kt_end ? (uint32_t)(past - t0 > 0 ? past - t0 : 0) : kt_end;
+        }
+        // S^T of key tile kl of the staged super-tile: the two accumulators of the split product (hi x hi | hi x lo + lo x hi)
+        auto compute_s = [&](uint32_t kl, sh_f32x16& hh, sh_f32x16& xx) __attribute__((always_inline)) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) { hh[r] = 0.0f; xx[r] = 0.0f; }
+            if constexpr (EARLY) {
+                // one LDS round trip in front of the tile's MFMAs instead of one per reused fragment register
+                f16x8 kf[NC][4];
+#pragma unroll
+                for (int c = 0; c < NC; ++c)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) kf[c][i] = *(lds_f16x8_cp)(uintptr_t)(ka[i] + (uint32_t)(c * KT * 128) + kl * 4096u);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int c = 0; c < NC; ++c)
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) {
+                        hh = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[c][s], qh[c][s], hh, 0, 0, 0);
+                        xx = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[c][s], ql[c][s], xx, 0, 0, 0);
+                        xx = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[c][2 + s], qh[c][s], xx, 0, 0, 0);
+                    }
+                return;
+            }
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
                 const char* kr = Kt + (size_t)c * KT * 128 + (size_t)(kl * 32 + l31) * 128;
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
-                    const f16x8 kh = *reinterpret_cast<const f16x8*>(kr + k_hi[s]);
-                    const f16x8 kl8 = *reinterpret_cast<const f16x8*>(kr + k_lo[s]);
+                    f16x8 kh, kl8;
+                    if constexpr (IMM) {
+                        kh = *(lds_f16x8_cp)(uintptr_t)(ka[s] + (uint32_t)(c * KT * 128) + kl * 4096u);
+                        kl8 = *(lds_f16x8_cp)(uintptr_t)(ka[2 + s] + (uint32_t)(c * KT * 128) + kl * 4096u);
+                    } else {
+                        kh = *reinterpret_cast<const f16x8*>(kr + k_hi[s]);
+                        kl8 = *reinterpret_cast<const f16x8*>(kr + k_lo[s]);
+                    }
                     hh = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[c][s], hh, 0, 0, 0);
                     xx = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[c][s], xx, 0, 0, 0);
                     xx = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl8, qh[c][s], xx, 0, 0, 0);
                 }
             }
+        };
+        // the tile's softmax and O^T += V^T P^T
+        auto finish_tile = [&](uint32_t kl, sh_f32x16& hh, sh_f32x16& xx) __attribute__((always_inline)) {
+            const uint32_t kt = st * 4 + kl;  // global 32-key tile
 #ifndef CS_ATTN_SCALAR_SOFTMAX
             // The softmax of a tile is 172 VALU instructions per wave against 12 MFMAs when written element by element
             // — the kernel is VALU-bound (2.3 x the MFMAs' cycles) — so everything that is the same operation on two
@@ -225,7 +289,9 @@ attention_shx_body(char* smem, const MQ& mq, const MO& mo, const _Float16* qkvs,
             const sh_f32x2 lo_inv2 = {kShLoInv, kShLoInv}, scale2 = {scale_log2e, scale_log2e};
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const sh_f32x4 ma = *reinterpret_cast<const sh_f32x4*>(madd + kt * 32 + 8 * g + 4 * h);
+                sh_f32x4 ma;
+                if constexpr (IMM) ma = *(lds_f32x4_cp)(uintptr_t)(ma_st + (kl * 32u + 8u * g) * 4u);
+                else ma = *reinterpret_cast<const sh_f32x4*>(madd + kt * 32 + 8 * g + 4 * h);
 #pragma unroll
                 for (int e2 = 0; e2 < 2; ++e2) {
                     const int r = 4 * g + 2 * e2;
@@ -246,7 +312,8 @@ attention_shx_body(char* smem, const MQ& mq, const MO& mo, const _Float16* qkvs,
                     tmax = fmaxf(tmax, fmaxf(s2[0], s2[1]));
                 }
             }
-            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+            if constexpr (IMM) tmax = xhalf_max_swap(tmax);
+            else tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
             if (__any(tmax > m)) {
                 const float mnew = fmaxf(m, tmax);
                 const float alpha = __builtin_amdgcn_exp2f(m - mnew);
@@ -256,6 +323,21 @@ attention_shx_body(char* smem, const MQ& mq, const MO& mo, const _Float16* qkvs,
 #pragma unroll
                     for (int r = 0; r < 16; ++r) { ohh[c][r] *= alpha; oxx[c][r] *= alpha; }
                 m = mnew;
+            }
+            typedef __attribute__((address_space(3))) s16x4* lds_s16x4_p;
+            FragTr vhe[NC][2], vle[NC][2];
+            if constexpr (EARLY) {  // the scores' 32 accumulator registers died into p2: room for the tile's V fragments
+#pragma unroll
+                for (int c = 0; c < NC; ++c)
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) {
+                        const uint32_t off = (uint32_t)(c * KT * 128) + kl * 4096u + (uint32_t)(s * 16 * 128);
+                        vhe[c][s].q[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(uintptr_t)(va[0] + off));
+                        vhe[c][s].q[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(uintptr_t)(va[0] + off + 1024u));
+                        vle[c][s].q[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(uintptr_t)(va[1] + off));
+                        vle[c][s].q[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(uintptr_t)(va[1] + off + 1024u));
+                    }
+                __builtin_amdgcn_sched_barrier(0);
             }
             const sh_f32x2 m2v = {m, m};
             sh_f32x2 ps2 = {0.0f, 0.0f};
@@ -321,22 +403,73 @@ attention_shx_body(char* smem, const MQ& mq, const MO& mo, const _Float16* qkvs,
 #endif
                 }
 #endif
+#ifdef CS_ATTN_SCALAR_SOFTMAX
             typedef __attribute__((address_space(3))) s16x4* lds_s16x4_p;
+            FragTr vhe[NC][2], vle[NC][2];
+#endif
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
                 const char* vr = Vt + (size_t)c * KT * 128 + (size_t)kl * 32 * 128;
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
                     FragTr vh, vl;
+                    if constexpr (EARLY) {
+                        vh = vhe[c][s];
+                        vl = vle[c][s];
+                    } else if constexpr (IMM) {
+                        const uint32_t off = (uint32_t)(c * KT * 128) + kl * 4096u + (uint32_t)(s * 16 * 128);
+                        vh.q[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(uintptr_t)(va[0] + off));
+                        vh.q[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(uintptr_t)(va[0] + off + 1024u));
+                        vl.q[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(uintptr_t)(va[1] + off));
+                        vl.q[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(uintptr_t)(va[1] + off + 1024u));
+                    } else {
                     vh.q[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(vr + s * 16 * 128 + v_hi));
                     vh.q[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(vr + s * 16 * 128 + 8 * 128 + v_hi));
                     vl.q[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(vr + s * 16 * 128 + v_lo));
                     vl.q[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(vr + s * 16 * 128 + 8 * 128 + v_lo));
+                    }
                     ohh[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh.v, ph[s].v, ohh[c], 0, 0, 0);
 #ifndef CS_ATTN_P_HI_ONLY
                     oxx[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh.v, pl[s].v, oxx[c], 0, 0, 0);
 #endif
                     oxx[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl.v, ph[s].v, oxx[c], 0, 0, 0);
+                }
+            }
+        };
+        if constexpr (PIPE == 0) {
+            for (uint32_t kl = kl_lo; kl < kl_hi; ++kl) {
+                sh_f32x16 hh, xx;
+                compute_s(kl, hh, xx);
+                finish_tile(kl, hh, xx);
+            }
+        } else if constexpr (IMM) {
+            // The super-tile's four key tiles written out: every LDS address of a tile is then a lane constant plus an
+            // immediate (the rolled loop carries seven address registers and bumps each per tile: 15 of its 149 vector
+            // instructions), and the cross-half max stays on the VALU.  Same arithmetic, same order: bit-identical.
+#pragma unroll
+            for (uint32_t kl = 0; kl < 4; ++kl) {
+                if (kl >= kl_lo && kl < kl_hi) {
+                    sh_f32x16 hh, xx;
+                    compute_s(kl, hh, xx);
+                    finish_tile(kl, hh, xx);
+                }
+            }
+        } else {
+            // Two key tiles in flight: the S MFMAs of tile kl + 1 are issued before the softmax of tile kl, so the matrix
+            // pipe works through them (and their K fragments arrive from LDS) while this wave's VALU runs the softmax —
+            // the tile's chain K read -> 6 MFMAs -> softmax -> 6 MFMAs loses its first two links.  Same arithmetic in the
+            // same order per tile: results are bit-identical to PIPE = 0.  The pipeline drains at a super-tile's end (the
+            // next one's K is not staged yet).  Unrolled by two so that the accumulators swap roles without copies.
+            sh_f32x16 hhA, xxA, hhB, xxB;
+            if (kl_lo < kl_hi) compute_s(kl_lo, hhA, xxA);
+            for (uint32_t kl = kl_lo; kl < kl_hi; kl += 2) {
+                if (kl + 1 < kl_hi) compute_s(kl + 1, hhB, xxB);
+                CS_ATTN_PIPE_FENCE;
+                finish_tile(kl, hhA, xxA);
+                if (kl + 1 < kl_hi) {
+                    if (kl + 2 < kl_hi) compute_s(kl + 2, hhA, xxA);
+                    CS_ATTN_PIPE_FENCE;
+                    finish_tile(kl + 1, hhB, xxB);
                 }
             }
         }

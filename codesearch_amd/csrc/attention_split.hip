@@ -25,6 +25,13 @@
 
 namespace cs {
 
+#ifndef CS_ATTN_PIPE_WAVES
+#define CS_ATTN_PIPE_WAVES 3   // waves per SIMD the head_dim-32 two-tile kernel is compiled for (168 registers)
+#endif
+
+// defaults of CS_ATTN_PIPE per head width (same-box A/B of the four forms: profiles/r05_attention_loop_forms_ab.log)
+constexpr int kAttnPipeDefault32 = 2, kAttnPipeDefault64 = 3;
+
 // ---- whole sequence of one (sequence, head) resident in LDS (CS_ATTN_SHX1=0; head_dim 32) ----------
 // head_dim 32 = one k-chunk, so K and V of a (token, head) are one 128-B line [32 hi | 32 lo] each,
 // exactly the layout the matrix pipe wants for K: the prologue is pure LDS-DMA (no conversion, no
@@ -190,8 +197,8 @@ attention_sh2_kernel(const _Float16* __restrict__ qkvs, const int32_t* __restric
 
 // ---- head_dim 32 * NC (NC = 2: BGE-base / BGE-large / mxbai-large): keys in super-tiles of 128 ------------
 // The body lives in attention_shx_body.hpp (shared with small_forward.hip).
-template <int NC, int POS = 0>
-__global__ void __launch_bounds__(256, 2)
+template <int NC, int POS = 0, int PIPE = 0>
+__global__ void __launch_bounds__(256, NC == 1 ? (PIPE == 1 ? CS_ATTN_PIPE_WAVES : (PIPE >= 2 ? 4 : 2)) : 2)
 attention_shx_kernel(const _Float16* __restrict__ qkvs, const int32_t* __restrict__ mask,
                      _Float16* __restrict__ ctxs, uint32_t* __restrict__ flag, uint32_t L, uint32_t H,
                      float scale_log2e, uint32_t HB, float* __restrict__ range_out,
@@ -199,10 +206,57 @@ attention_shx_kernel(const _Float16* __restrict__ qkvs, const int32_t* __restric
                      const float* __restrict__ alibi_log2, uint32_t window) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const AttnMemPlain mem;
-    attention_shx_body<NC, AttnMemPlain, AttnMemPlain, POS>(smem, mem, mem, qkvs, mask, ctxs, flag, L, H, scale_log2e, HB, range_out,
+    attention_shx_body<NC, AttnMemPlain, AttnMemPlain, POS, PIPE>(smem, mem, mem, qkvs, mask, ctxs, flag, L, H, scale_log2e, HB, range_out,
                                                             seq_unit, unit_len, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x,
                                                             gridDim.z, alibi_log2, window);
 }
+
+namespace {
+
+struct ShxArgs {
+    const _Float16* qkv; const int32_t* mask; _Float16* ctx; uint32_t* flag; uint32_t L, H; float scale_log2e; uint32_t hb;
+    float* range_out; const uint32_t* seq_unit; const uint32_t* unit_len; const float* alibi_log2; uint32_t window;
+};
+
+template <int NC, int POS, int PIPE>
+int32_t launch_shx_one(dim3 grid, size_t lds, hipStream_t s, const ShxArgs& a) {
+    if (lds > 64 * 1024 - 256) {  // above the default dynamic-LDS limit: the attribute is per function and per device
+        static PerDeviceOnce attr;
+        CS_TRY(attr.run([&]() -> int32_t {
+            CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attention_shx_kernel<NC, POS, PIPE>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
+            return CS_OK;
+        }));
+    }
+    hipLaunchKernelGGL((attention_shx_kernel<NC, POS, PIPE>), grid, dim3(256), lds, s, a.qkv, a.mask, a.ctx, a.flag, a.L, a.H,
+                       a.scale_log2e, a.hb, a.range_out, a.seq_unit, a.unit_len, a.alibi_log2, a.window);
+    CS_HIP(hipGetLastError());
+    return CS_OK;
+}
+
+template <int NC>
+int32_t launch_shx(int pos, int pipe, dim3 grid, size_t lds, hipStream_t s, const ShxArgs& a) {
+    if (pipe == 3) {
+        if (pos == 1) return launch_shx_one<NC, 1, 3>(grid, lds, s, a);
+        if (pos == 2) return launch_shx_one<NC, 2, 3>(grid, lds, s, a);
+        return launch_shx_one<NC, 0, 3>(grid, lds, s, a);
+    }
+    if (pipe == 2) {
+        if (pos == 1) return launch_shx_one<NC, 1, 2>(grid, lds, s, a);
+        if (pos == 2) return launch_shx_one<NC, 2, 2>(grid, lds, s, a);
+        return launch_shx_one<NC, 0, 2>(grid, lds, s, a);
+    }
+    if (pipe == 1) {
+        if (pos == 1) return launch_shx_one<NC, 1, 1>(grid, lds, s, a);
+        if (pos == 2) return launch_shx_one<NC, 2, 1>(grid, lds, s, a);
+        return launch_shx_one<NC, 0, 1>(grid, lds, s, a);
+    }
+    if (pos == 1) return launch_shx_one<NC, 1, 0>(grid, lds, s, a);
+    if (pos == 2) return launch_shx_one<NC, 2, 0>(grid, lds, s, a);
+    return launch_shx_one<NC, 0, 0>(grid, lds, s, a);
+}
+
+}  // namespace
 
 int32_t launch_attention_sh2(const _Float16* qkv_split, const int32_t* mask, void* ctx_split, uint32_t* flag,
                              uint32_t B, uint32_t L, uint32_t H, uint32_t heads, hipStream_t s, float* range_out,
@@ -211,34 +265,22 @@ int32_t launch_attention_sh2(const _Float16* qkv_split, const int32_t* mask, voi
     if (alibi && window) return fail(CS_ERR_BAD_ARG, "attention: ALiBi and a local window together are not built");
     // alibi (CS_ARCH_JINA*): [2][heads] — the slopes, then the slopes times log2 e (what these kernels add in the exp2 domain)
     const float* alibi_log2 = alibi ? alibi + heads : nullptr;
+    const int pos = alibi_log2 ? 1 : (window ? 2 : 0);
     if (range_pairs) *range_pairs = 0;
     const uint32_t dh = heads ? H / heads : 0;
     if ((dh != 32 && dh != 64) || H % heads)
         return fail(CS_ERR_UNSUPPORTED, "head_dim %u not supported (32 or 64)", dh);
     const size_t Lp = (L + 31) & ~31u;
+    // CS_ATTN_PIPE (attention_shx_body.hpp, PIPE): 0 the rolled tile loop, 1 two key tiles in flight per wave, 2 the super-tile's
+    // four tiles written out (immediate LDS offsets, cross-half max on the VALU)
+    static const int pipe_env = [] { const char* e = std::getenv("CS_ATTN_PIPE"); return e && e[0] >= '0' && e[0] <= '3' ? e[0] - '0' : -1; }();
+    ShxArgs a{qkv_split, mask, static_cast<_Float16*>(ctx_split), flag, L, H, 0.0f, 1u, range_out, seq_unit, unit_len, alibi_log2, window};
     if (dh == 64) {  // two 128-B lines per (token, head): keys staged 128 at a time
         const size_t lds = 2 * 2 * 128 * 128 + Lp * sizeof(float) + 16;
-        static PerDeviceOnce attr64;  // function attributes are per device
-        CS_TRY(attr64.run([&]() -> int32_t {
-            CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attention_shx_kernel<2>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
-            CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attention_shx_kernel<2, 1>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
-            CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attention_shx_kernel<2, 2>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
-            return CS_OK;
-        }));
-        if (alibi_log2)
-            hipLaunchKernelGGL((attention_shx_kernel<2, 1>), dim3(heads, B, (L + 127) / 128), dim3(256), lds, s, qkv_split, mask,
-                               static_cast<_Float16*>(ctx_split), flag, L, H, (1.0f / sqrtf(64.0f)) * kLog2e, 1u, range_out, seq_unit, unit_len, alibi_log2, 0u);
-        else if (window)
-            hipLaunchKernelGGL((attention_shx_kernel<2, 2>), dim3(heads, B, (L + 127) / 128), dim3(256), lds, s, qkv_split, mask,
-                               static_cast<_Float16*>(ctx_split), flag, L, H, (1.0f / sqrtf(64.0f)) * kLog2e, 1u, range_out, seq_unit, unit_len, alibi_log2, window);
-        else
-        hipLaunchKernelGGL(attention_shx_kernel<2>, dim3(heads, B, (L + 127) / 128), dim3(256), lds, s, qkv_split, mask,
-                           static_cast<_Float16*>(ctx_split), flag, L, H, (1.0f / sqrtf(64.0f)) * kLog2e, 1u, range_out, seq_unit, unit_len, alibi_log2, 0u);
+        a.scale_log2e = (1.0f / sqrtf(64.0f)) * kLog2e;
+        const int pipe = pipe_env < 0 ? kAttnPipeDefault64 : pipe_env;
+        CS_TRY(launch_shx<2>(pos, pipe, dim3(heads, B, (L + 127) / 128), lds, s, a));
         if (range_pairs) *range_pairs = heads * B * ((L + 127) / 128) * 4;
-        CS_HIP(hipGetLastError());
         return CS_OK;
     }
     // head_dim 32 also runs on the 128-key super-tile kernel by default: 32 KiB of LDS per block instead of
@@ -246,33 +288,19 @@ int32_t launch_attention_sh2(const _Float16* qkv_split, const int32_t* mask, voi
     // the others) — 256 x 256 tokens 12.75 -> 12.54 ms per forward although K/V are staged once per query
     // block.  CS_ATTN_SHX1=0 selects the whole-sequence kernel (attention_sh2_kernel) for A/B.
     static const bool shx1 = [] { const char* e = std::getenv("CS_ATTN_SHX1"); return !(e && e[0] == '0'); }();
-    if (shx1 || alibi_log2 || window) {
+    if (shx1 || pos) {
         // CS_ATTN_LDS_PAD (diagnostics): extra dynamic LDS per block, i.e. fewer co-resident blocks per CU — how the kernel's
         // time moves with occupancy says whether a tile's dependent chain (latency) or issue slots bound it
         static const size_t lds_pad = [] { const char* e = std::getenv("CS_ATTN_LDS_PAD"); return e ? (size_t)std::atol(e) : (size_t)0; }();
         const size_t lds1 = 2 * 1 * 128 * 128 + Lp * sizeof(float) + 16 + lds_pad;
-        if (lds_pad) {
-            static PerDeviceOnce pad_attr;
-            CS_TRY(pad_attr.run([&]() -> int32_t {
-                CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attention_shx_kernel<1>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
-                return CS_OK;
-            }));
-        }
         static const bool pack_heads = [] { const char* e = std::getenv("CS_ATTN_PACK_HEADS"); return !(e && e[0] == '0'); }();
         uint32_t hb = !pack_heads ? 1u : (Lp <= 32 ? 4u : (Lp <= 64 ? 2u : 1u));  // heads per block (kernel comment)
         while (heads % hb) hb >>= 1;
-        if (alibi_log2)
-            hipLaunchKernelGGL((attention_shx_kernel<1, 1>), dim3(heads / hb, B, (L + 127) / 128), dim3(256), lds1, s, qkv_split, mask,
-                               static_cast<_Float16*>(ctx_split), flag, L, H, (1.0f / sqrtf(32.0f)) * kLog2e, hb, range_out, seq_unit, unit_len, alibi_log2, 0u);
-        else if (window)
-            hipLaunchKernelGGL((attention_shx_kernel<1, 2>), dim3(heads / hb, B, (L + 127) / 128), dim3(256), lds1, s, qkv_split, mask,
-                               static_cast<_Float16*>(ctx_split), flag, L, H, (1.0f / sqrtf(32.0f)) * kLog2e, hb, range_out, seq_unit, unit_len, alibi_log2, window);
-        else
-        hipLaunchKernelGGL(attention_shx_kernel<1>, dim3(heads / hb, B, (L + 127) / 128), dim3(256), lds1, s, qkv_split, mask,
-                           static_cast<_Float16*>(ctx_split), flag, L, H, (1.0f / sqrtf(32.0f)) * kLog2e, hb, range_out, seq_unit, unit_len, alibi_log2, 0u);
+        a.scale_log2e = (1.0f / sqrtf(32.0f)) * kLog2e;
+        a.hb = hb;
+        const int pipe = pipe_env < 0 ? kAttnPipeDefault32 : pipe_env;
+        CS_TRY(launch_shx<1>(pos, pipe, dim3(heads / hb, B, (L + 127) / 128), lds1, s, a));
         if (range_pairs) *range_pairs = (heads / hb) * B * ((L + 127) / 128) * 4;
-        CS_HIP(hipGetLastError());
         return CS_OK;
     }
     const size_t lds = 2 * Lp * 128 + Lp * sizeof(float) + 16;

@@ -768,9 +768,6 @@ int32_t cs_embedder_create_from_dir(const char* model_dir, int32_t pooling, int3
         if (onnx.empty())
             return fail(CS_ERR_BAD_ARG, "Failed to initialize embedding model: %s holds neither model.safetensors nor "
                         "onnx/model.onnx, model.onnx, model_optimized.onnx or model_quantized.onnx", model_dir);
-        if (cfg.arch == CS_ARCH_MODERN)
-            return fail(CS_ERR_UNSUPPORTED, "Failed to initialize embedding model: the ONNX export of a ModernBERT model is not read "
-                        "(%s): place the repository's model.safetensors in %s", onnx.c_str(), model_dir);
         if (cs_arch_alibi(cfg.arch))
             return fail(CS_ERR_UNSUPPORTED, "Failed to initialize embedding model: the ONNX export of a JinaBert model is not read "
                         "(%s): place the repository's model.safetensors in %s", onnx.c_str(), model_dir);

@@ -400,6 +400,7 @@ const Tensor* weight_of_bias(const Model& m, const std::string& bias_name, uint6
 // those weights (the dynamic-quantisation mode is BERT's, embedder.hip).  Restated from how torch.onnx lays such a module
 // out; no Nomic export is on disk here (parity unpinned).
 struct WeightProduct { const Node* node; const Tensor* w; Quant q; bool quantised; };
+std::vector<WeightProduct> weight_products(const Model& m);
 
 // does the float result of product node `n` reach a Sigmoid through at most `depth` Cast / Mul nodes?
 bool reaches_sigmoid(const Model& m, const std::string& name, int depth) {
@@ -454,17 +455,7 @@ int32_t nomic_params_from_onnx(const Model& m, const cs_bert_config* cfg, const 
     CS_TRY(vec("emb_ln.weight", H, params + o.emb_ln_g, false));
     CS_TRY(vec("emb_ln.bias", H, params + o.emb_ln_b, false));
 
-    std::vector<WeightProduct> prods;
-    for (const Node& n : m.nodes) {
-        if (n.op == "MatMul" && n.in.size() == 2) {
-            const Tensor* w = m.resolve(n.in[1]);
-            if (w && w->dims.size() == 2) prods.push_back({&n, w, Quant{}, false});
-        } else if (n.op == "MatMulInteger" && n.in.size() >= 2) {
-            const Tensor* w = m.tensor(n.in[1]);
-            Quant q;
-            if (w && w->dims.size() == 2 && (w->dtype == 2 || w->dtype == 3) && quant_of(m, *w, q)) prods.push_back({&n, w, q, true});
-        }
-    }
+    const std::vector<WeightProduct> prods = weight_products(m);
     if (prods.size() != (size_t)5 * cfg->layers)
         return fail(CS_ERR_BAD_ARG, "Failed to initialize embedding model: %s holds %zu weight products (MatMul / MatMulInteger with a "
                     "2-D initialiser), a nomic_bert export of %u layers holds %u", path, prods.size(), cfg->layers, 5 * cfg->layers);
@@ -520,6 +511,171 @@ int32_t nomic_params_from_onnx(const Model& m, const cs_bert_config* cfg, const 
     return CS_OK;
 }
 
+// the weight products of a graph, in node order: MatMul with a 2-D initialiser as its second input, or MatMulInteger with an INT8 /
+// UINT8 one that has a scale — what a bias-free Linear leaves behind in an export (the weight transposed and anonymous)
+std::vector<WeightProduct> weight_products(const Model& m) {
+    std::vector<WeightProduct> prods;
+    for (const Node& n : m.nodes) {
+        if (n.op == "MatMul" && n.in.size() == 2) {
+            const Tensor* w = m.resolve(n.in[1]);
+            if (w && w->dims.size() == 2) prods.push_back({&n, w, Quant{}, false});
+        } else if (n.op == "MatMulInteger" && n.in.size() >= 2) {
+            const Tensor* w = m.tensor(n.in[1]);
+            Quant q;
+            if (w && w->dims.size() == 2 && (w->dtype == 2 || w->dtype == 3) && quant_of(m, *w, q)) prods.push_back({&n, w, q, true});
+        }
+    }
+    return prods;
+}
+
+// does `name` reach an `op` node through at most `depth` element-wise nodes (Cast / Mul / Div / Add)?
+bool reaches_op(const Model& m, const std::string& name, const char* op, int depth) {
+    auto range = m.consumers.equal_range(name);
+    for (auto it = range.first; it != range.second; ++it)
+        if (m.nodes[it->second].op == op) return true;
+    if (depth <= 0) return false;
+    for (auto it = range.first; it != range.second; ++it) {
+        const Node& c = m.nodes[it->second];
+        if ((c.op == "Cast" || c.op == "Mul" || c.op == "Div" || c.op == "Add") && !c.out.empty() && reaches_op(m, c.out[0], op, depth - 1))
+            return true;
+    }
+    return false;
+}
+
+// ---- ModernBERT exports (CS_ARCH_MODERN; the registry's modernbert-embed-large entry, /root/reference/src/embed/embedder.rs:47,
+// :72: fastembed caches onnx/model.onnx) ------------------------------------------------------------------------------------
+// The modelling code's Linears carry no bias in the published configuration (attention_bias / mlp_bias / norm_bias false), so
+// an export holds, per layer and in this order, four weight products with anonymous transposed initialisers — Wqkv [H, 3H],
+// attn.Wo [H, H], mlp.Wi [H, 2 I_f] (columns [0, I_f) go through the GELU: our gate; the rest multiply it: our value) and
+// mlp.Wo [I_f, H] — while the LayerNorm weights keep their state-dict names (embeddings.norm, layers.N.attn_norm for N > 0,
+// layers.N.mlp_norm, final_norm; a .bias is taken where one exists).  I_f is the file's width (2,624); the parameter block's
+// (cfg->intermediate, 2,688) is zero-padded exactly as the safetensors reader pads it (checkpoint.cpp).  Pinned on a file
+// written by torch.onnx's exporter from transformers' own ModernBertModel (tests/golden/make_modern_onnx_fixture.py).
+int32_t modern_params_from_onnx(const Model& m, const cs_bert_config* cfg, const cs_bert_offsets& o, float* params, const char* path) {
+    const uint64_t H = cfg->hidden, I = cfg->intermediate;
+    std::memset(params, 0, o.total * sizeof(float));
+    std::string mod_prefix;
+    bool anchored = false;
+    {
+        static const std::string anchor = "embeddings.tok_embeddings.weight";
+        for (const auto& kv : m.init) {
+            const std::string& nm = kv.first;
+            if (nm.size() >= anchor.size() && nm.compare(nm.size() - anchor.size(), anchor.size(), anchor) == 0) {
+                mod_prefix = nm.substr(0, nm.size() - anchor.size());
+                anchored = true;
+                break;
+            }
+        }
+    }
+    if (!anchored)
+        return fail(CS_ERR_BAD_ARG, "Failed to initialize embedding model: tensor embeddings.tok_embeddings.weight is missing from %s", path);
+    auto named = [&](const std::string& name) -> const Tensor* { return m.tensor(mod_prefix + name); };
+    auto vec = [&](const std::string& name, uint64_t n, float* dst, bool optional) -> int32_t {
+        const Tensor* t = named(name);
+        if (!t) {
+            if (optional) return CS_OK;  // (the block is zeroed)
+            return fail(CS_ERR_BAD_ARG, "Failed to initialize embedding model: tensor %s is missing from %s", name.c_str(), path);
+        }
+        if (t->count() != n || t->dims.size() > 2)
+            return fail(CS_ERR_DIM_MISMATCH, "Failed to initialize embedding model: %s has %llu elements, config.json implies %llu",
+                        name.c_str(), (unsigned long long)t->count(), (unsigned long long)n);
+        return copy_matrix(*t, 1, n, false, dst, name.c_str());
+    };
+    {
+        const Tensor* t = named("embeddings.tok_embeddings.weight");
+        if (!shape_is(*t, {cfg->vocab_size, H}))
+            return fail(CS_ERR_DIM_MISMATCH, "Failed to initialize embedding model: embeddings.tok_embeddings.weight does not have shape "
+                        "[%u, %llu]", cfg->vocab_size, (unsigned long long)H);
+        CS_TRY(copy_matrix(*t, cfg->vocab_size, H, false, params + o.word, "embeddings.tok_embeddings.weight"));
+    }
+    CS_TRY(vec("embeddings.norm.weight", H, params + o.emb_ln_g, false));
+    CS_TRY(vec("embeddings.norm.bias", H, params + o.emb_ln_b, true));
+    CS_TRY(vec("final_norm.weight", H, params + o.final_ln_g, false));
+    CS_TRY(vec("final_norm.bias", H, params + o.final_ln_b, true));
+
+    const std::vector<WeightProduct> prods = weight_products(m);
+    if (prods.size() != (size_t)4 * cfg->layers)
+        return fail(CS_ERR_BAD_ARG, "Failed to initialize embedding model: %s holds %zu weight products (MatMul / MatMulInteger with a "
+                    "2-D initialiser), a modernbert export of %u layers holds %u", path, prods.size(), cfg->layers, 4 * cfg->layers);
+    std::vector<float> packed;
+    for (uint32_t l = 0; l < cfg->layers; ++l) {
+        cs_bert_layer_offsets lo;
+        cs_bert_layer_layout(cfg, &o, l, &lo);
+        const WeightProduct* e = &prods[(size_t)4 * l];
+        const std::string p = "layers." + std::to_string(l) + ".";
+        auto bad = [&](const char* what, const Tensor& w) {
+            return fail(CS_ERR_DIM_MISMATCH, "Failed to initialize embedding model: layer %u's %s product does not hold the weight "
+                        "config.json implies (%s)", l, what, w.name.c_str());
+        };
+        auto copy = [&](int i, uint64_t out, uint64_t in, float* dst, const char* what) -> int32_t {
+            return copy_matrix(*e[i].w, out, in, true, dst, what, e[i].quantised ? &e[i].q : nullptr);
+        };
+        if (!shape_is(*e[0].w, {H, 3 * H})) return bad("attn.Wqkv", *e[0].w);
+        if (!shape_is(*e[1].w, {H, H})) return bad("attn.Wo", *e[1].w);
+        const uint64_t wi = e[2].w->dims.size() == 2 ? e[2].w->dims[1] : 0;
+        if (e[2].w->dims[0] != H || wi == 0 || wi % 2 || wi / 2 > I) return bad("mlp.Wi", *e[2].w);
+        const uint64_t If = wi / 2;
+        if (!shape_is(*e[3].w, {If, H})) return bad("mlp.Wo", *e[3].w);
+
+        if (l) {
+            CS_TRY(vec(p + "attn_norm.weight", H, params + lo.ao_ln_g, false));
+            CS_TRY(vec(p + "attn_norm.bias", H, params + lo.ao_ln_b, true));
+        } else {
+            for (uint64_t i = 0; i < H; ++i) params[lo.ao_ln_g + i] = 1.0f;  // (never read: layer 0's attn_norm is the identity)
+        }
+        CS_TRY(vec(p + "mlp_norm.weight", H, params + lo.out_ln_g, false));
+        CS_TRY(vec(p + "mlp_norm.bias", H, params + lo.out_ln_b, true));
+
+        packed.resize((size_t)3 * H * H);
+        CS_TRY(copy(0, 3 * H, H, packed.data(), "attn.Wqkv"));
+        std::memcpy(params + lo.q_w, packed.data(), H * H * sizeof(float));
+        std::memcpy(params + lo.k_w, packed.data() + H * H, H * H * sizeof(float));
+        std::memcpy(params + lo.v_w, packed.data() + 2 * H * H, H * H * sizeof(float));
+        CS_TRY(copy(1, H, H, params + lo.ao_w, "attn.Wo"));
+
+        // which half of Wi's output meets the activation: the module's order is [through GELU | multiplier]; an export that
+        // splits the product is checked (the half whose Split output reaches the Erf of an exact GELU is the gate)
+        bool gate_first = true;
+        if (!e[2].node->out.empty()) {
+            auto range = m.consumers.equal_range(e[2].node->out[0]);
+            for (auto it = range.first; it != range.second; ++it) {
+                const Node& c = m.nodes[it->second];
+                if (c.op == "Split" && c.out.size() == 2) {
+                    const bool g0 = reaches_op(m, c.out[0], "Erf", 3), g1 = reaches_op(m, c.out[1], "Erf", 3);
+                    if (g0 && g1)
+                        return fail(CS_ERR_UNSUPPORTED, "Failed to initialize embedding model: both halves of layer %u's mlp.Wi reach an "
+                                    "Erf in %s (not the gated arrangement)", l, path);
+                    if (g1) gate_first = false;
+                }
+            }
+        }
+        packed.resize((size_t)2 * If * H);
+        CS_TRY(copy(2, 2 * If, H, packed.data(), "mlp.Wi"));
+        std::memcpy(params + (gate_first ? lo.gate_w : lo.up_w), packed.data(), If * H * sizeof(float));
+        std::memcpy(params + (gate_first ? lo.up_w : lo.gate_w), packed.data() + If * H, If * H * sizeof(float));
+        packed.resize((size_t)H * If);
+        CS_TRY(copy(3, H, If, packed.data(), "mlp.Wo"));
+        for (uint64_t r = 0; r < H; ++r) std::memcpy(params + lo.down_w + r * I, packed.data() + r * If, If * sizeof(float));
+
+        // Linear biases: none in the published files (zero slots); taken by name where an export kept one
+        std::vector<float> b3((size_t)3 * H, 0.0f);
+        CS_TRY(vec(p + "attn.Wqkv.bias", 3 * H, b3.data(), true));
+        std::memcpy(params + lo.q_b, b3.data(), H * sizeof(float));
+        std::memcpy(params + lo.k_b, b3.data() + H, H * sizeof(float));
+        std::memcpy(params + lo.v_b, b3.data() + 2 * H, H * sizeof(float));
+        CS_TRY(vec(p + "attn.Wo.bias", H, params + lo.ao_b, true));
+        if (const Tensor* wb = named(p + "mlp.Wi.bias")) {
+            if (wb->count() != 2 * If) return bad("mlp.Wi.bias", *wb);
+            std::vector<float> b2((size_t)2 * If);
+            CS_TRY(copy_matrix(*wb, 1, 2 * If, false, b2.data(), "mlp.Wi.bias"));
+            std::memcpy(params + (gate_first ? lo.gate_b : lo.up_b), b2.data(), If * sizeof(float));
+            std::memcpy(params + (gate_first ? lo.up_b : lo.gate_b), b2.data() + If, If * sizeof(float));
+        }
+        CS_TRY(vec(p + "mlp.Wo.bias", H, params + lo.down_b, true));
+    }
+    return CS_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -532,8 +688,8 @@ int32_t cs_bert_params_from_onnx_q(const char* path, const cs_bert_config* cfg, 
                                    float* wscale, uint64_t n_wscale, int32_t* quantized) {
     if (quantized) *quantized = 0;
     if (!path || !cfg || !params) return fail(CS_ERR_BAD_ARG, "null argument");
-    if (cfg->arch != CS_ARCH_BERT && cfg->arch != CS_ARCH_NOMIC)  // the names and graph shapes below are a BERT export's
-        return fail(CS_ERR_UNSUPPORTED, "Failed to initialize embedding model: only BERT and NomicBert exports are read from ONNX files (%s)", path);
+    if (cfg->arch != CS_ARCH_BERT && cfg->arch != CS_ARCH_NOMIC && cfg->arch != CS_ARCH_MODERN)  // the names and graph shapes below are a BERT export's
+        return fail(CS_ERR_UNSUPPORTED, "Failed to initialize embedding model: only BERT, NomicBert and ModernBERT exports are read from ONNX files (%s)", path);
     const uint64_t qcols = 5 * (uint64_t)cfg->hidden + cfg->intermediate;
     if (wscale && n_wscale != (uint64_t)cfg->layers * qcols)
         return fail(CS_ERR_BAD_ARG, "Failed to initialize embedding model: room for %llu column scales, %llu needed",
@@ -559,6 +715,7 @@ int32_t cs_bert_params_from_onnx_q(const char* path, const cs_bert_config* cfg, 
     Model m;
     CS_TRY(parse_model(Span{(const uint8_t*)map, (const uint8_t*)map + sb.st_size}, m, path));
     if (cfg->arch == CS_ARCH_NOMIC) return nomic_params_from_onnx(m, cfg, o, params, path);  // (*quantized stays 0: f32 graph)
+    if (cfg->arch == CS_ARCH_MODERN) return modern_params_from_onnx(m, cfg, o, params, path);
     const uint64_t H = cfg->hidden, I = cfg->intermediate;
 
     // a tensor whose state-dict name survived the export, under whatever module prefix the exported model was

@@ -77,3 +77,70 @@ def test_local_layers_are_local_and_padding_does_not_leak(oracle):
     # one that is global throughout: the window is really applied
     all_global = BertConfig(**{**cfg.__dict__, "global_every": 1})
     assert np.abs(oracle.bert_forward(all_global, params, ids, mask)["pooled"] - base).max() > 1e-4
+
+
+# ---- the ONNX export (what fastembed caches for the registry entry) -------------------------------------------------------
+
+ONNX_CFG = BertConfig(vocab_size=48, hidden=64, layers=3, heads=2, intermediate=128, max_position=64, type_vocab_size=1,
+                      pooling=POOL_MEAN, arch=ARCH_MODERN, layer_norm_eps=1e-5, rotary_base=160000.0, rotary_base_local=10000.0,
+                      global_every=3, local_window=8)
+
+
+def block_from_modernbert_state(cfg, sd):
+    """The flat parameter block of `cfg` from a ModernBertModel state dict whose feed-forward is I_f <= cfg.intermediate wide:
+    zero padding, zero biases, layer 0's (never read) attn_norm slot at one."""
+    from codesearch_amd.bert_params import to_state_dict
+
+    flat = np.zeros(param_count(cfg), np.float32)
+    ours = to_state_dict(cfg, flat)  # views into flat
+    H = cfg.hidden
+    ours["embeddings.word_embeddings.weight"][:] = sd["embeddings.tok_embeddings.weight"]
+    ours["embeddings.LayerNorm.weight"][:] = sd["embeddings.norm.weight"]
+    ours["final_norm.weight"][:] = sd["final_norm.weight"]
+    for l in range(cfg.layers):
+        a, b = f"encoder.layer.{l}.", f"layers.{l}."
+        ours[a + "attention.output.LayerNorm.weight"][:] = sd[b + "attn_norm.weight"] if l else 1.0
+        for i, r in enumerate(("query", "key", "value")):
+            ours[a + f"attention.self.{r}.weight"][:] = sd[b + "attn.Wqkv.weight"][i * H:(i + 1) * H]
+        ours[a + "attention.output.dense.weight"][:] = sd[b + "attn.Wo.weight"]
+        ours[a + "output.LayerNorm.weight"][:] = sd[b + "mlp_norm.weight"]
+        If = sd[b + "mlp.Wi.weight"].shape[0] // 2
+        ours[a + "intermediate.gate.weight"][:If] = sd[b + "mlp.Wi.weight"][:If]
+        ours[a + "intermediate.dense.weight"][:If] = sd[b + "mlp.Wi.weight"][If:]
+        ours[a + "output.dense.weight"][:, :If] = sd[b + "mlp.Wo.weight"]
+    return flat
+
+
+def load_onnx(gpu_lib, path, cfg):
+    import ctypes as C
+
+    from codesearch_amd import _lib
+
+    c = cfg.to_c()
+    out = np.full(param_count(cfg), np.nan, np.float32)
+    rc = gpu_lib.cs_bert_params_from_onnx(str(path).encode(), C.byref(c), out.ctypes.data_as(_lib.f32p), out.size)
+    return rc, out, gpu_lib.cs_last_error().decode()
+
+
+def test_onnx_reader_reads_a_modernbert_export_written_by_torchs_own_exporter(gpu_lib, oracle):
+    """tests/golden/modern_tiny_export.onnx (make_modern_onnx_fixture.py): transformers' own ModernBertModel through torch.onnx's
+    TorchScript exporter — the four bias-free Linear weights of a layer as anonymous transposed initialisers in module order,
+    LayerNorm weights under their state-dict names, the feed-forward 80 wide inside a block padded to 128.  The flat block must
+    equal the one built from the state dict the file was exported from, bit for bit; and the CPU oracle run on that block
+    must reproduce the exporting model's own output (stored with the state)."""
+    from codesearch_amd import _lib
+
+    gold = os.path.join(os.path.dirname(__file__), "golden")
+    state = dict(np.load(os.path.join(gold, "modern_tiny_export_state.npz")))
+    rc, got, err = load_onnx(gpu_lib, os.path.join(gold, "modern_tiny_export.onnx"), ONNX_CFG)
+    assert rc == _lib.CS_OK, err
+    assert np.array_equal(got, block_from_modernbert_state(ONNX_CFG, state))
+    pooled = oracle.bert_forward(ONNX_CFG, got, state["query_ids"], state["query_mask"])["pooled"]
+    np.testing.assert_allclose(pooled, state["query_pooled"], atol=2e-6)
+    # a config with another layer count, or another width, does not match the file
+    rc, _, err = load_onnx(gpu_lib, os.path.join(gold, "modern_tiny_export.onnx"), BertConfig(**{**ONNX_CFG.__dict__, "layers": 4}))
+    assert rc == _lib.CS_ERR_BAD_ARG and "weight products" in err
+    rc, _, err = load_onnx(gpu_lib, os.path.join(gold, "modern_tiny_export.onnx"), BertConfig(**{**ONNX_CFG.__dict__, "intermediate": 64}))
+    assert rc == _lib.CS_ERR_DIM_MISMATCH and "mlp.Wi" in err
+    rc, _, err = load_onnx(gpu_lib, os.path.join(gold, "bert_tiny_export.onnx"), ONNX_CFG)
+    assert rc == _lib.CS_ERR_BAD_ARG and "tok_embeddings" in err
