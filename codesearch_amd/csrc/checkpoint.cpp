@@ -441,6 +441,26 @@ bool json_u32(const Json& root, const char* key, uint32_t& out) {
 
 extern "C" {
 
+static int safetensors_header_mentions(const std::string& path, const char* needle);
+
+// the weight files cs_embedder_create_from_dir reads, in its order of preference ("" when the directory holds none)
+static std::string model_file_in(const std::string& dir, bool& safetensors) {
+    safetensors = file_exists(dir + "/model.safetensors");
+    if (safetensors) return dir + "/model.safetensors";
+    for (const char* rel : {"/onnx/model.onnx", "/model.onnx", "/model_optimized.onnx", "/onnx/model_optimized.onnx",
+                            "/onnx/model_quantized.onnx", "/model_quantized.onnx"})
+        if (file_exists(dir + rel)) return dir + rel;
+    return "";
+}
+
+// JinaBert: 1 when the directory's weights hold query / key LayerNorm tensors, 0 when they do not, -1 when there is no readable file
+static int jina_variant_from_files(const char* model_dir) {
+    bool st = false;
+    const std::string f = model_file_in(model_dir, st);
+    if (f.empty()) return -1;
+    return st ? safetensors_header_mentions(f, "attention.self.layer_norm_q.") : cs::onnx_initializer_mentions(f.c_str(), "attention.self.layer_norm_q.");
+}
+
 int32_t cs_bert_config_from_dir(const char* model_dir, int32_t pooling, cs_bert_config* cfg) {
     if (!model_dir || !cfg) return fail(CS_ERR_BAD_ARG, "null argument");
     const bool pooling_given = pooling != -1;
@@ -590,8 +610,7 @@ int32_t cs_bert_config_from_dir(const char* model_dir, int32_t pooling, cs_bert_
     if (jina) {
         // no position table to size: the bound is what fastembed's default InitOptions truncate to (embedder.rs:238)
         if (c.max_position > 512) c.max_position = 512;
-        // the modelling file the config names decides whether Q and K rows are LayerNorm'ed ("...qk-post-norm..."); a
-        // checkpoint that says otherwise overrides it (cs_embedder_create_from_dir looks at the tensors)
+        // the modelling file the config names decides whether Q and K rows are LayerNorm'ed ("...qk-post-norm...")
         bool qkn = true;
         if (const Json* am = root.get("auto_map"))
             if (am->kind == Json::Obj && !am->obj.empty()) {
@@ -599,6 +618,9 @@ int32_t cs_bert_config_from_dir(const char* model_dir, int32_t pooling, cs_bert_
                 for (const auto& kv : am->obj)
                     if (kv.second.kind == Json::Str && kv.second.str.find("qk-post-norm") != std::string::npos) qkn = true;
             }
+        // ... and the weights file next to it has the last word: its own tensors say whether the query / key LayerNorms exist
+        const int in_file = jina_variant_from_files(model_dir);
+        if (in_file >= 0) qkn = in_file != 0;
         c.arch = qkn ? CS_ARCH_JINA_QKNORM : CS_ARCH_JINA;
         c.pooling = pooling_given ? pooling : (pooling_file ? pooling : CS_POOL_MEAN);  // fastembed pools the model by mean
     }
@@ -741,10 +763,17 @@ int32_t cs_embedder_create_from_dir(const char* model_dir, int32_t pooling, int3
     *out = nullptr;
     cs_bert_config cfg;
     CS_TRY(cs_bert_config_from_dir(model_dir, pooling, &cfg));
-    if (cs_arch_alibi(cfg.arch)) {  // JinaBert: the checkpoint's own tensors say whether Q and K rows are LayerNorm'ed
-        const int m = safetensors_header_mentions(std::string(model_dir) + "/model.safetensors", "attention.self.layer_norm_q.");
-        if (m >= 0) cfg.arch = m ? CS_ARCH_JINA_QKNORM : CS_ARCH_JINA;
-    }
+    // hf-hub snapshot of the PyTorch model (model.safetensors) or fastembed's cache of the ONNX export
+    // (onnx/model.onnx for Xenova/bge-small-en-v1.5; model.onnx / model_optimized.onnx for other entries; the *Q entries of the
+    // registry fetch onnx/model_quantized.onnx — Xenova/all-MiniLM-L6-v2, the reference's default model — or a
+    // model_optimized.onnx that holds quantised weights; hf-hub leaves only the file asked for)
+    bool have_st = false;
+    const std::string file = model_file_in(model_dir, have_st);
+    if (file.empty())
+        return fail(CS_ERR_BAD_ARG, "Failed to initialize embedding model: %s holds neither model.safetensors nor "
+                    "onnx/model.onnx, model.onnx, model_optimized.onnx or model_quantized.onnx", model_dir);
+    const std::string& st_path = file;
+    const std::string& onnx = file;
     const uint64_t n = cs_bert_param_count(&cfg);
     std::vector<float> params;
     try {
@@ -752,25 +781,9 @@ int32_t cs_embedder_create_from_dir(const char* model_dir, int32_t pooling, int3
     } catch (const std::bad_alloc&) {
         return fail(CS_ERR_OOM, "out of host memory for %llu parameters", (unsigned long long)n);
     }
-    // hf-hub snapshot of the PyTorch model (model.safetensors) or fastembed's cache of the ONNX export
-    // (onnx/model.onnx for Xenova/bge-small-en-v1.5; model.onnx / model_optimized.onnx for other entries)
-    const std::string dir(model_dir);
-    const std::string st_path = dir + "/model.safetensors";
-    if (file_exists(st_path)) {
+    if (have_st) {
         CS_TRY(cs_bert_params_from_safetensors(st_path.c_str(), &cfg, params.data(), n));
     } else {
-        // (the *Q entries of the registry fetch onnx/model_quantized.onnx — Xenova/all-MiniLM-L6-v2, the reference's default
-        // model — or a model_optimized.onnx that holds quantised weights; hf-hub leaves only the file asked for)
-        std::string onnx;
-        for (const char* rel : {"/onnx/model.onnx", "/model.onnx", "/model_optimized.onnx", "/onnx/model_optimized.onnx",
-                                "/onnx/model_quantized.onnx", "/model_quantized.onnx"})
-            if (file_exists(dir + rel)) { onnx = dir + rel; break; }
-        if (onnx.empty())
-            return fail(CS_ERR_BAD_ARG, "Failed to initialize embedding model: %s holds neither model.safetensors nor "
-                        "onnx/model.onnx, model.onnx, model_optimized.onnx or model_quantized.onnx", model_dir);
-        if (cs_arch_alibi(cfg.arch))
-            return fail(CS_ERR_UNSUPPORTED, "Failed to initialize embedding model: the ONNX export of a JinaBert model is not read "
-                        "(%s): place the repository's model.safetensors in %s", onnx.c_str(), model_dir);
         std::vector<float> wscale((size_t)cfg.layers * cs_bert_quant_columns(&cfg));
         int32_t quantized = 0;
         CS_TRY(cs_bert_params_from_onnx_q(onnx.c_str(), &cfg, params.data(), n, wscale.data(), wscale.size(), &quantized));

@@ -17,6 +17,8 @@ namespace cs {
 // ---- error plumbing: status code + thread-local message (cs_last_error) ---------------
 std::string& last_error_ref();
 int32_t fail(int32_t code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
+// onnx_reader.cpp: 1 when an initialiser's name contains `needle`, 0 when none does, -1 when the file cannot be read
+int onnx_initializer_mentions(const char* path, const char* needle);
 
 #define CS_HIP(expr)                                                                      \
     do {                                                                                  \

@@ -678,6 +678,28 @@ int32_t modern_params_from_onnx(const Model& m, const cs_bert_config* cfg, const
 
 }  // namespace
 
+namespace cs {
+
+// 1 when some initialiser's name contains `needle`, 0 when none does, -1 when the file cannot be read (checkpoint.cpp: which
+// JinaBert variant wrote an export)
+int onnx_initializer_mentions(const char* path, const char* needle) {
+    const int fd = open(path, O_RDONLY);
+    if (fd < 0) return -1;
+    struct stat sb;
+    if (fstat(fd, &sb) != 0 || sb.st_size <= 0) { close(fd); return -1; }
+    void* map = mmap(nullptr, (size_t)sb.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+    close(fd);
+    if (map == MAP_FAILED) return -1;
+    struct Unmap { void* p; size_t n; ~Unmap() { munmap(p, n); } } unmap{map, (size_t)sb.st_size};
+    Model m;
+    if (parse_model(Span{(const uint8_t*)map, (const uint8_t*)map + sb.st_size}, m, path) != CS_OK) return -1;
+    for (const auto& kv : m.init)
+        if (kv.first.find(needle) != std::string::npos) return 1;
+    return 0;
+}
+
+}  // namespace cs
+
 extern "C" {
 
 int32_t cs_bert_params_from_onnx(const char* path, const cs_bert_config* cfg, float* params, uint64_t n_params) {
@@ -688,8 +710,8 @@ int32_t cs_bert_params_from_onnx_q(const char* path, const cs_bert_config* cfg, 
                                    float* wscale, uint64_t n_wscale, int32_t* quantized) {
     if (quantized) *quantized = 0;
     if (!path || !cfg || !params) return fail(CS_ERR_BAD_ARG, "null argument");
-    if (cfg->arch != CS_ARCH_BERT && cfg->arch != CS_ARCH_NOMIC && cfg->arch != CS_ARCH_MODERN)  // the names and graph shapes below are a BERT export's
-        return fail(CS_ERR_UNSUPPORTED, "Failed to initialize embedding model: only BERT, NomicBert and ModernBERT exports are read from ONNX files (%s)", path);
+    if (cfg->arch != CS_ARCH_BERT && cfg->arch != CS_ARCH_NOMIC && cfg->arch != CS_ARCH_MODERN && !cs_arch_alibi(cfg->arch))
+        return fail(CS_ERR_UNSUPPORTED, "Failed to initialize embedding model: only BERT, NomicBert, JinaBert and ModernBERT exports are read from ONNX files (%s)", path);
     const uint64_t qcols = 5 * (uint64_t)cfg->hidden + cfg->intermediate;
     if (wscale && n_wscale != (uint64_t)cfg->layers * qcols)
         return fail(CS_ERR_BAD_ARG, "Failed to initialize embedding model: room for %llu column scales, %llu needed",
@@ -795,7 +817,8 @@ int32_t cs_bert_params_from_onnx_q(const char* path, const cs_bert_config* cfg, 
     };
 
     CS_TRY(table("embeddings.word_embeddings.weight", cfg->vocab_size, params + o.word));
-    CS_TRY(table("embeddings.position_embeddings.weight", cfg->max_position, params + o.pos));
+    const bool jina = cs_arch_alibi(cfg->arch);  // JinaBert: BERT's names for the attention block, no position table (ALiBi)
+    if (!jina) CS_TRY(table("embeddings.position_embeddings.weight", cfg->max_position, params + o.pos));
     CS_TRY(table("embeddings.token_type_embeddings.weight", cfg->type_vocab_size, params + o.type));
     CS_TRY(vec("embeddings.LayerNorm.weight", H, params + o.emb_ln_g));
     CS_TRY(vec("embeddings.LayerNorm.bias", H, params + o.emb_ln_b));
@@ -807,6 +830,19 @@ int32_t cs_bert_params_from_onnx_q(const char* path, const cs_bert_config* cfg, 
     std::vector<const Node*> fused;
     for (const Node& n : m.nodes)
         if ((n.op == "Attention" || n.op == "QAttention") && n.in.size() >= 3) fused.push_back(&n);
+    // JinaBert's gated up projection carries no bias (mlp.gated_layers in jinaai/jina-bert-implementation, mlp.up_gated_layer in
+    // jina-bert-v2-qk-post-norm): an anonymous transposed [H, 2I] initialiser behind a MatMul — the only weight products of that
+    // shape in the graph, one per layer in layer order
+    std::vector<WeightProduct> gated;
+    if (jina) {
+        all_quantized = false;
+        for (const WeightProduct& wp : weight_products(m))
+            if (shape_is(*wp.w, {H, 2 * I})) gated.push_back(wp);
+        const bool has_qln = named("encoder.layer.0.attention.self.layer_norm_q.weight") != nullptr;
+        if (has_qln != (cfg->arch == CS_ARCH_JINA_QKNORM))
+            return fail(CS_ERR_DIM_MISMATCH, "Failed to initialize embedding model: %s %s query / key LayerNorm weights, the configuration "
+                        "says the opposite", path, has_qln ? "holds" : "holds no");
+    }
     for (uint32_t l = 0; l < cfg->layers; ++l) {
         cs_bert_layer_offsets lo;
         cs_bert_layer_layout(cfg, &o, l, &lo);
@@ -861,6 +897,38 @@ int32_t cs_bert_params_from_onnx_q(const char* path, const cs_bert_config* cfg, 
         CS_TRY(linear(p + "attention.output.dense", H, H, params + lo.ao_w, params + lo.ao_b, sc ? sc + 3 * H : nullptr));
         CS_TRY(vec(p + "attention.output.LayerNorm.weight", H, params + lo.ao_ln_g));
         CS_TRY(vec(p + "attention.output.LayerNorm.bias", H, params + lo.ao_ln_b));
+        if (jina) {
+            if (cfg->arch == CS_ARCH_JINA_QKNORM) {
+                CS_TRY(vec(p + "attention.self.layer_norm_q.weight", H, params + lo.qln_g));
+                CS_TRY(vec(p + "attention.self.layer_norm_q.bias", H, params + lo.qln_b));
+                CS_TRY(vec(p + "attention.self.layer_norm_k.weight", H, params + lo.kln_g));
+                CS_TRY(vec(p + "attention.self.layer_norm_k.bias", H, params + lo.kln_b));
+            }
+            // which modelling file wrote the graph: mlp.gated_layers + mlp.wo ([through GELU | multiplier]) or mlp.up_gated_layer +
+            // mlp.down_layer ([multiplier | through GELU]) — told apart by the down projection's bias name
+            const bool first_file = named(p + "mlp.wo.bias") != nullptr;
+            const std::string up = p + (first_file ? "mlp.gated_layers" : "mlp.up_gated_layer"), down = p + (first_file ? "mlp.wo" : "mlp.down_layer");
+            std::vector<float> packed((size_t)2 * I * H), b2((size_t)2 * I, 0.0f);
+            if (named(up + ".bias")) {  // an export of a variant that kept the bias: the weight is the one behind its Add
+                CS_TRY(linear(up, 2 * I, H, packed.data(), b2.data(), nullptr));
+            } else {
+                if (gated.size() != cfg->layers)
+                    return fail(CS_ERR_BAD_ARG, "Failed to initialize embedding model: %s holds %zu bias-free [%llu, %llu] weight products, "
+                                "a JinaBert export of %u layers holds %u (the gated up projections)", path, gated.size(),
+                                (unsigned long long)H, (unsigned long long)(2 * I), cfg->layers, cfg->layers);
+                CS_TRY(copy_matrix(*gated[l].w, 2 * I, H, true, packed.data(), up.c_str(), gated[l].quantised ? &gated[l].q : nullptr));
+            }
+            const size_t gate0 = first_file ? 0 : I, up0 = first_file ? I : 0;
+            std::memcpy(params + lo.gate_w, packed.data() + gate0 * H, I * H * sizeof(float));
+            std::memcpy(params + lo.up_w, packed.data() + up0 * H, I * H * sizeof(float));
+            std::memcpy(params + lo.gate_b, b2.data() + gate0, I * sizeof(float));
+            std::memcpy(params + lo.up_b, b2.data() + up0, I * sizeof(float));
+            CS_TRY(linear(down, H, I, params + lo.down_w, params + lo.down_b, nullptr));
+            CS_TRY(vec(p + "mlp.layernorm.weight", H, params + lo.out_ln_g));
+            CS_TRY(vec(p + "mlp.layernorm.bias", H, params + lo.out_ln_b));
+            all_quantized = false;
+            continue;
+        }
         CS_TRY(linear(p + "intermediate.dense", I, H, params + lo.up_w, params + lo.up_b, sc ? sc + 4 * H : nullptr));
         CS_TRY(linear(p + "output.dense", H, I, params + lo.down_w, params + lo.down_b, sc ? sc + 4 * H + I : nullptr));
         CS_TRY(vec(p + "output.LayerNorm.weight", H, params + lo.out_ln_g));

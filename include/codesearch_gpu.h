@@ -395,13 +395,16 @@ int32_t cs_embedder_create(const cs_bert_config* cfg, const float* params, uint6
  * modelling file's tensor names (mlp.up_gated_layer / down_layer / layernorm with the value rows first, or mlp.gated_layers /
  * wo with the activated rows first; attention.self.layer_norm_q / _k present or not decides CS_ARCH_JINA_QKNORM against
  * CS_ARCH_JINA, the config's auto_map where there is no checkpoint to ask); max_position is capped at the 512 tokens
- * fastembed truncates to.  Its ONNX export is not read (CS_ERR_UNSUPPORTED).
+ * fastembed truncates to.  Its ONNX export (onnx/model.onnx: what fastembed caches) is read as well: BERT's names for the
+ * embeddings and the attention block (weights behind the Add of their named bias), the bias-free gated up projection as the
+ * one [H, 2I] weight product of each layer, mlp.wo / mlp.down_layer telling the two modelling files apart.
  * A ModernBERT directory (config.json with model_type "modernbert": lightonai/modernbert-embed-large, the registry's
  * ModernBertEmbedLarge) is read from model.safetensors by HF ModernBertModel's names (embeddings.tok_embeddings / norm,
  * layers.N.attn_norm / attn.Wqkv / attn.Wo / mlp_norm / mlp.Wi / mlp.Wo, final_norm; optional "model." prefix; biases optional):
  * config keys global_attn_every_n_layers, local_attention, global_rope_theta / local_rope_theta (or rope_parameters), norm_eps;
  * intermediate_size is rounded up to a multiple of 128 in the cs_bert_config (2,624 -> 2,688) and the loader fills the
- * difference with zero rows / columns.  Its ONNX export is not read (CS_ERR_UNSUPPORTED). */
+ * difference with zero rows / columns.  Its ONNX export (onnx/model.onnx) is read as well: the LayerNorm weights by name, the
+ * four bias-free Linear weights of a layer (Wqkv, attn.Wo, mlp.Wi, mlp.Wo) as the graph's weight products in order. */
 /* pooling: CS_POOL_CLS, CS_POOL_MEAN, or -1 = what <model_dir>/1_Pooling/config.json says (the
  * sentence-transformers module: mean for MiniLM / E5, CLS for BGE), CLS when that file is absent (mean for a
  * nomic_bert directory: fastembed's pooling for the family). */

@@ -23,14 +23,16 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 H, NH, LAYERS, INNER, VOCAB = 64, 2, 3, 80, 48
 
 
-def main():
+def write(out_dir, stem, dims=None, local_attention=16):
+    """dims = (hidden, heads, layers, intermediate, vocabulary): the GPU tests export at a width the kernels run (384)"""
     from torch.onnx._internal.torchscript_exporter import onnx_proto_utils
     from transformers import ModernBertConfig, ModernBertModel
 
+    H, NH, LAYERS, INNER, VOCAB = dims or (globals()["H"], globals()["NH"], globals()["LAYERS"], globals()["INNER"], globals()["VOCAB"])
     onnx_proto_utils._add_onnxscript_fn = lambda proto, *a, **k: proto
     hc = ModernBertConfig(vocab_size=VOCAB, hidden_size=H, intermediate_size=INNER, num_hidden_layers=LAYERS, num_attention_heads=NH,
                           max_position_embeddings=64, norm_eps=1e-5, norm_bias=False, attention_bias=False, mlp_bias=False,
-                          local_attention=16, global_attn_every_n_layers=3, global_rope_theta=160000.0, local_rope_theta=10000.0,
+                          local_attention=local_attention, global_attn_every_n_layers=3, global_rope_theta=160000.0, local_rope_theta=10000.0,
                           pad_token_id=0, bos_token_id=1, eos_token_id=2, cls_token_id=1, sep_token_id=2)
     hc._attn_implementation = "eager"
     torch.manual_seed(20261005)
@@ -40,7 +42,7 @@ def main():
             p.copy_(torch.randn_like(p) * 0.08 + (1.0 if name.endswith("norm.weight") else 0.0))
     ids = torch.randint(3, VOCAB, (2, 12))
     mask = torch.ones(2, 12, dtype=torch.long)
-    out = os.path.join(HERE, "modern_tiny_export.onnx")
+    out = os.path.join(out_dir, stem + ".onnx")
     axes = {n: {0: "batch", 1: "seq"} for n in ("input_ids", "attention_mask")}
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
@@ -60,9 +62,14 @@ def main():
     pooled = (hidden * w).sum(1) / w.sum(1)
     pooled = pooled / pooled.norm(dim=1, keepdim=True)
     state = {k: v.numpy() for k, v in model.state_dict().items()}
-    np.savez_compressed(os.path.join(HERE, "modern_tiny_export_state.npz"), query_ids=qids.numpy().astype(np.int32),
+    np.savez_compressed(os.path.join(out_dir, stem + "_state.npz"), query_ids=qids.numpy().astype(np.int32),
                         query_mask=qmask.numpy().astype(np.int32), query_pooled=pooled.numpy().astype(np.float32), **state)
     print("wrote", out, os.path.getsize(out), "bytes")
+    return out
+
+
+def main():
+    write(HERE, "modern_tiny_export")
 
 
 if __name__ == "__main__":

@@ -270,3 +270,38 @@ def test_texts_through_the_models_own_kind_of_tokenizer(FE, oracle, tmp_path):
     assert np.array_equal(my_ids, ids) and np.array_equal(my_mask, mask)
     np.testing.assert_allclose(got, oracle.bert_forward(cfg, flat, ids, mask)["pooled"], atol=TOL_ORACLE)
     emb.close()
+
+
+def _fixture_module(name):
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location(name, os.path.join(os.path.dirname(__file__), "golden", name + ".py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_embedder_from_a_fastembed_cache_of_the_onnx_export(FE, tmp_path):
+    """What fastembed leaves on disk for the registry entry: config.json + onnx/model.onnx (no safetensors).  The file is
+    written here by torch.onnx's exporter from the JinaBert-shaped module of tests/golden/make_jina_onnx_fixture.py at a width
+    the kernels run (hidden 384, 12 heads, 2 layers); the embedder loaded from it — the variant (query / key LayerNorm) read
+    off the file's own tensors, against a config.json that names the other modelling file — must reproduce the EXPORTING
+    MODULE's own pooled output."""
+    from codesearch_amd import FastEmbedder
+
+    d = tmp_path / "cache"
+    (d / "onnx").mkdir(parents=True)
+    _fixture_module("make_jina_onnx_fixture").write(str(d / "onnx"), "model", dims=(384, 12, 2, 256, 64))
+    state = np.load(str(d / "onnx" / "model_state.npz"))
+    repo = "jinaai/jina-bert-implementation"   # (the config names the FIRST modelling file: the file's tensors decide)
+    hf = {"model_type": "bert", "position_embedding_type": "alibi", "feed_forward_type": "geglu", "hidden_act": "gelu", "vocab_size": 64,
+          "hidden_size": 384, "num_attention_heads": 12, "num_hidden_layers": 2, "intermediate_size": 256, "max_position_embeddings": 8192,
+          "type_vocab_size": 2, "layer_norm_eps": 1e-12, "emb_pooler": "mean",
+          "auto_map": {"AutoConfig": repo + "--configuration_bert.JinaBertConfig", "AutoModel": repo + "--modeling_bert.JinaBertModel"}}
+    (d / "config.json").write_text(json.dumps(hf))
+    (d / "vocab.txt").write_text("\n".join(["[PAD]", "[UNK]", "[CLS]", "[SEP]", "[MASK]"] + [f"w{i}" for i in range(59)]) + "\n")
+    emb = FastEmbedder.from_dir(str(d))
+    assert (emb.config.arch, emb.dimensions(), emb.config.intermediate, emb.config.pooling) == (ARCH_JINA_QKNORM, 384, 256, POOL_MEAN)
+    got = emb.embed_ids(state["query_ids"], state["query_mask"])
+    np.testing.assert_allclose(got, state["query_pooled"], atol=TOL_GOLDEN)
+    emb.close()

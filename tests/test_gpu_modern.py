@@ -183,27 +183,29 @@ def test_embedder_from_a_modernbert_snapshot_directory(FE, oracle, tmp_path):
 
 def test_embedder_from_a_fastembed_cache_of_the_onnx_export(FE, tmp_path):
     """What fastembed leaves on disk for the registry entry: config.json + onnx/model.onnx (no safetensors).  The file is
-    tests/golden/modern_tiny_export.onnx — transformers' own ModernBertModel through torch.onnx's exporter — and the embedder
-    loaded from it must reproduce the EXPORTING MODEL's own pooled output on a padded batch longer than the local window."""
-    import shutil
+    written here by torch.onnx's exporter from transformers' own ModernBertModel (tests/golden/make_modern_onnx_fixture.py) at
+    a width the kernels run (hidden 384, 12 heads, 3 layers, feed-forward 200 inside a block padded to 256, local window 8
+    either side); the embedder loaded from it must reproduce the EXPORTING MODEL's own pooled output on a padded batch
+    longer than the local window."""
+    import importlib.util
 
     from codesearch_amd import FastEmbedder
-    from codesearch_amd.pipeline import synth_vocab
 
-    gold = os.path.join(os.path.dirname(__file__), "golden")
-    state = np.load(os.path.join(gold, "modern_tiny_export_state.npz"))
+    spec = importlib.util.spec_from_file_location("make_modern_onnx_fixture", os.path.join(os.path.dirname(__file__), "golden", "make_modern_onnx_fixture.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
     d = tmp_path / "cache"
     (d / "onnx").mkdir(parents=True)
-    shutil.copy(os.path.join(gold, "modern_tiny_export.onnx"), d / "onnx" / "model.onnx")
-    hf = {"model_type": "modernbert", "architectures": ["ModernBertModel"], "vocab_size": 48, "hidden_size": 64, "num_hidden_layers": 3,
-          "num_attention_heads": 2, "intermediate_size": 80, "max_position_embeddings": 64, "norm_eps": 1e-5, "norm_bias": False,
+    mod.write(str(d / "onnx"), "model", dims=(384, 12, 3, 200, 64), local_attention=16)
+    state = np.load(str(d / "onnx" / "model_state.npz"))
+    hf = {"model_type": "modernbert", "architectures": ["ModernBertModel"], "vocab_size": 64, "hidden_size": 384, "num_hidden_layers": 3,
+          "num_attention_heads": 12, "intermediate_size": 200, "max_position_embeddings": 64, "norm_eps": 1e-5, "norm_bias": False,
           "attention_bias": False, "mlp_bias": False, "hidden_activation": "gelu", "global_attn_every_n_layers": 3, "local_attention": 16,
           "global_rope_theta": 160000.0, "local_rope_theta": 10000.0, "classifier_pooling": "mean"}
     (d / "config.json").write_text(json.dumps(hf))
-    vocab = synth_vocab(48)
-    (d / "vocab.txt").write_text("\n".join(sorted(vocab, key=vocab.get)) + "\n")
+    (d / "vocab.txt").write_text("\n".join(["[PAD]", "[UNK]", "[CLS]", "[SEP]", "[MASK]"] + [f"w{i}" for i in range(59)]) + "\n")
     emb = FastEmbedder.from_dir(str(d))
-    assert (emb.config.arch, emb.dimensions(), emb.config.intermediate, emb.config.local_window, emb.config.pooling) == (ARCH_MODERN, 64, 128, 8, POOL_MEAN)
+    assert (emb.config.arch, emb.dimensions(), emb.config.intermediate, emb.config.local_window, emb.config.pooling) == (ARCH_MODERN, 384, 256, 8, POOL_MEAN)
     got = emb.embed_ids(state["query_ids"], state["query_mask"])
     np.testing.assert_allclose(got, state["query_pooled"], atol=TOL_GOLDEN)
     emb.close()

@@ -138,3 +138,67 @@ def test_jina_checkpoint_names_map_onto_the_flat_block():
         del broken["encoder.layer.1." + up_name + ".weight"]
         with pytest.raises(ValueError):
             from_jina_state_dict(c, broken)
+
+
+# ---- the ONNX export (what fastembed caches for the registry entry) -------------------------------------------------------
+
+ONNX_CFG = BertConfig(vocab_size=48, hidden=64, layers=2, heads=2, intermediate=128, max_position=512, pooling=POOL_MEAN,
+                      arch=ARCH_JINA_QKNORM)
+
+
+def load_onnx(gpu_lib, path, cfg):
+    import ctypes as C
+
+    from codesearch_amd import _lib
+
+    c = cfg.to_c()
+    out = np.full(param_count(cfg), np.nan, np.float32)
+    rc = gpu_lib.cs_bert_params_from_onnx(str(path).encode(), C.byref(c), out.ctypes.data_as(_lib.f32p), out.size)
+    return rc, out, gpu_lib.cs_last_error().decode()
+
+
+def test_onnx_reader_reads_a_jinabert_export_written_by_torchs_own_exporter(gpu_lib, oracle):
+    """tests/golden/jina_tiny_export.onnx (make_jina_onnx_fixture.py): a JinaBert-shaped module (the qk-post-norm modelling
+    file's names) through torch.onnx's TorchScript exporter — Linear weights as anonymous transposed initialisers behind the
+    Add of their named bias, the bias-free up_gated_layer identified only by its [H, 2I] shape and its position.  The flat
+    block must equal the one built from the state dict the file was exported from, bit for bit, and the CPU oracle run on it
+    must reproduce the exporting module's own output (stored with the state)."""
+    from codesearch_amd import _lib
+
+    gold = os.path.join(os.path.dirname(__file__), "golden")
+    state = dict(np.load(os.path.join(gold, "jina_tiny_export_state.npz")))
+    path = os.path.join(gold, "jina_tiny_export.onnx")
+    rc, got, err = load_onnx(gpu_lib, path, ONNX_CFG)
+    assert rc == _lib.CS_OK, err
+    assert np.array_equal(got, from_jina_state_dict(ONNX_CFG, state))
+    pooled = oracle.bert_forward(ONNX_CFG, got, state["query_ids"], state["query_mask"])["pooled"]
+    np.testing.assert_allclose(pooled, state["query_pooled"], atol=2e-6)
+    # the file's own tensors contradict a configuration without the query / key LayerNorms; another depth or width does not fit
+    rc, _, err = load_onnx(gpu_lib, path, BertConfig(**{**ONNX_CFG.__dict__, "arch": ARCH_JINA}))
+    assert rc == _lib.CS_ERR_DIM_MISMATCH and "query / key LayerNorm" in err
+    rc, _, err = load_onnx(gpu_lib, path, BertConfig(**{**ONNX_CFG.__dict__, "layers": 3}))
+    assert rc != _lib.CS_OK
+    rc, _, err = load_onnx(gpu_lib, path, BertConfig(**{**ONNX_CFG.__dict__, "intermediate": 256}))
+    assert rc == _lib.CS_ERR_BAD_ARG and "gated up projections" in err
+
+
+def test_onnx_reader_reads_the_first_modelling_files_arrangement(gpu_lib, oracle, tmp_path):
+    """jinaai/jina-bert-implementation's names (no query / key LayerNorm, mlp.gated_layers whose FIRST half goes through the GELU,
+    mlp.wo), exported here by the fixture script's module in that arrangement."""
+    import importlib.util
+
+    from codesearch_amd import _lib
+
+    spec = importlib.util.spec_from_file_location("make_jina_onnx_fixture", os.path.join(os.path.dirname(__file__), "golden", "make_jina_onnx_fixture.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    path = mod.write(str(tmp_path), "first_file", first_file=True)
+    state = dict(np.load(os.path.join(str(tmp_path), "first_file_state.npz")))
+    cfg = BertConfig(**{**ONNX_CFG.__dict__, "arch": ARCH_JINA})
+    rc, got, err = load_onnx(gpu_lib, path, cfg)
+    assert rc == _lib.CS_OK, err
+    assert np.array_equal(got, from_jina_state_dict(cfg, state))
+    pooled = oracle.bert_forward(cfg, got, state["query_ids"], state["query_mask"])["pooled"]
+    np.testing.assert_allclose(pooled, state["query_pooled"], atol=2e-6)
+    rc, _, err = load_onnx(gpu_lib, path, ONNX_CFG)
+    assert rc == _lib.CS_ERR_DIM_MISMATCH and "holds no query / key LayerNorm" in err

@@ -308,8 +308,6 @@ def test_onnx_reader_refusals_for_nomic(tmp_path, gpu_lib):
     import ctypes as C
 
     from codesearch_amd import _lib
-    from codesearch_amd.bert_params import ARCH_JINA
-
     cfg = BertConfig(vocab_size=300, hidden=384, layers=1, heads=12, intermediate=1536, pooling=POOL_MEAN, arch=ARCH_NOMIC,
                      rotary_base=1000.0)
     d = tmp_path / "snap"
@@ -319,6 +317,6 @@ def test_onnx_reader_refusals_for_nomic(tmp_path, gpu_lib):
     h = C.c_void_p()
     rc = gpu_lib.cs_embedder_create_from_dir(str(d).encode(), -1, 0, C.byref(h))
     assert rc == _lib.CS_ERR_BAD_ARG and "holds no graph" in gpu_lib.cs_last_error().decode()
-    jina = BertConfig(vocab_size=300, hidden=384, layers=1, heads=12, intermediate=1536, pooling=POOL_MEAN, arch=ARCH_JINA)
-    rc, _, err = load_nomic_onnx(gpu_lib, d / "model.onnx", jina)
-    assert rc == _lib.CS_ERR_UNSUPPORTED and "only BERT and NomicBert exports" in err
+    other = BertConfig(vocab_size=300, hidden=384, layers=1, heads=12, intermediate=1536, pooling=POOL_MEAN, arch=9)
+    rc, _, err = load_nomic_onnx(gpu_lib, d / "model.onnx", other)
+    assert rc == _lib.CS_ERR_UNSUPPORTED and "exports are read from ONNX files" in err

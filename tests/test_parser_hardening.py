@@ -180,3 +180,13 @@ def test_config_json_reader_survives(fuzz, tmp_path):
     p = tmp_path / "config.json"
     p.write_text(json.dumps(cfg, indent=1))
     fuzz("config_dir", p, seed=17)
+
+
+def test_jina_and_modernbert_onnx_exports_survive_truncations_and_mutations(fuzz):
+    """The JinaBert and ModernBERT branches of the ONNX reader on files a real exporter wrote (tests/golden/make_jina_onnx_fixture.py,
+    make_modern_onnx_fixture.py): named tensors, anonymous weight products found by shape and position, the zero-padded
+    feed-forward of the ModernBERT block (the file is 80 wide, the configuration 128)."""
+    out = fuzz("onnx", os.path.join(GOLD, "jina_tiny_export.onnx"), seed=51, flips=800, aux="48 64 2 2 128 512 3")
+    assert "0 crashes" in out
+    out = fuzz("onnx", os.path.join(GOLD, "modern_tiny_export.onnx"), seed=52, flips=800, aux="48 64 3 2 128 64 4")
+    assert "0 crashes" in out
