@@ -9,6 +9,11 @@
 #ifndef AT_STAMP
 #define AT_STAMP(i)
 #endif
+// CS_ATTN_ARITH=2 (default): one accumulator per score tile and the probabilities' low plane as an UNSCALED residual (below);
+// =1: the split product's two accumulators and the 2^11-scaled low plane of split_f16.hpp on both sides (rounds 1-4)
+#ifndef CS_ATTN_ARITH
+#define CS_ATTN_ARITH 2
+#endif
 #ifndef CS_ATTN_PIPE_FENCE
 #define CS_ATTN_PIPE_FENCE __builtin_amdgcn_sched_barrier(0)
 #endif
@@ -41,6 +46,20 @@ __device__ __forceinline__ void split_pair_rtz_ng(float a, float b, uint32_t& hi
     const h16x2 l = __builtin_amdgcn_cvt_pkrtz((a - (float)h[0]) * kShLoScale, (b - (float)h[1]) * kShLoScale);
     hi = __builtin_bit_cast(uint32_t, h);
     lo = __builtin_bit_cast(uint32_t, l);
+}
+
+// e - (float)h for the low / high half h of a packed f16 pair in ONE instruction: v_fma_mix_f32 reads an f16 source in place
+// (op_sel_hi marks it 16-bit, op_sel picks the half).  The compiler selects it for one in ten of these and converts the rest
+// (v_cvt_f32_f16 + subtract), so it is written out.
+__device__ __forceinline__ float mix_residual_lo(float e, uint32_t hpair) {
+    float r;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(hpair), "v"(e));
+    return r;
+}
+__device__ __forceinline__ float mix_residual_hi(float e, uint32_t hpair) {
+    float r;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(hpair), "v"(e));
+    return r;
 }
 
 // max of a value with its partner's in the other half of the wave (lane ^ 32) on the VALU: v_permlane32_swap exchanges the upper
@@ -139,6 +158,21 @@ attention_shx_body(char* smem, const MQ& mq, const MO& mo, const _Float16* qkvs,
             ql[c][s] = mq.ld16(qp + 32 + 16 * s);
         }
     }
+#if CS_ATTN_ARITH == 2 && !defined(CS_ATTN_SCALAR_SOFTMAX)
+    // S = k_hi q_hi + k_hi (q_lo' 2^-11) + k_lo' (q_hi 2^-11)  (x = x_hi + x_lo' 2^-11, split_f16.hpp): with the two factors 2^-11
+    // applied to the QUERY fragments — once per block, exact powers of two — all three products land in ONE accumulator at
+    // the same scale: 16 registers and the per-tile combine (8 packed FMAs of ~126 vector instructions) less.  Where a scaled
+    // half drops below 2^-14 it is an f16 subnormal (kept by the VALU and by the MFMA: cs_embedder_create checks the latter):
+    // absolute precision 2^-24 on a term that is itself 2^-11 of the score.
+    f16x8 qhs[NC][2];
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            qhs[c][s] = qh[c][s] * (_Float16)kShLoInv;
+            ql[c][s] = ql[c][s] * (_Float16)kShLoInv;
+        }
+#endif
     sh_f32x16 ohh[NC], oxx[NC];
 #pragma unroll
     for (int c = 0; c < NC; ++c)
@@ -252,8 +286,13 @@ attention_shx_body(char* smem, const MQ& mq, const MO& mo, const _Float16* qkvs,
 #pragma unroll
                     for (int s = 0; s < 2; ++s) {
                         hh = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[c][s], qh[c][s], hh, 0, 0, 0);
+#if CS_ATTN_ARITH == 2 && !defined(CS_ATTN_SCALAR_SOFTMAX)
+                        hh = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[c][s], ql[c][s], hh, 0, 0, 0);
+                        hh = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[c][2 + s], qhs[c][s], hh, 0, 0, 0);
+#else
                         xx = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[c][s], ql[c][s], xx, 0, 0, 0);
                         xx = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[c][2 + s], qh[c][s], xx, 0, 0, 0);
+#endif
                     }
                 return;
             }
@@ -271,8 +310,13 @@ attention_shx_body(char* smem, const MQ& mq, const MO& mo, const _Float16* qkvs,
                         kl8 = *reinterpret_cast<const f16x8*>(kr + k_lo[s]);
                     }
                     hh = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[c][s], hh, 0, 0, 0);
+#if CS_ATTN_ARITH == 2 && !defined(CS_ATTN_SCALAR_SOFTMAX)
+                    hh = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[c][s], hh, 0, 0, 0);
+                    hh = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl8, qhs[c][s], hh, 0, 0, 0);
+#else
                     xx = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[c][s], xx, 0, 0, 0);
                     xx = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl8, qh[c][s], xx, 0, 0, 0);
+#endif
                 }
             }
         };
@@ -307,7 +351,12 @@ attention_shx_body(char* smem, const MQ& mq, const MO& mo, const _Float16* qkvs,
                         m2[0] = fabsf(d0) > wlimit ? kMaskedLog2 : m2[0];
                         m2[1] = fabsf(d0 - 1.0f) > wlimit ? kMaskedLog2 : m2[1];
                     }
+#if CS_ATTN_ARITH == 2
+                    (void)x2; (void)lo_inv2;
+                    const sh_f32x2 s2 = __builtin_elementwise_fma(h2, scale2, m2);
+#else
                     const sh_f32x2 s2 = __builtin_elementwise_fma(__builtin_elementwise_fma(x2, lo_inv2, h2), scale2, m2);
+#endif
                     p2[r / 2] = s2;
                     tmax = fmaxf(tmax, fmaxf(s2[0], s2[1]));
                 }
@@ -339,7 +388,17 @@ attention_shx_body(char* smem, const MQ& mq, const MO& mo, const _Float16* qkvs,
                     }
                 __builtin_amdgcn_sched_barrier(0);
             }
+#if CS_ATTN_ARITH == 2
+            // Probabilities travel as E = 2^11 e (the exponent's bias moved by 11: no instruction): P_hi' = rtz_f16(E) and the
+            // UNSCALED residual P_lo'' = rtz_f16(E - P_hi') carry E to 21+ bits, and
+            //   2^11 O^T = v_hi (P_hi' + P_lo'') + (v_lo' P_hi') 2^-11
+            // — the residual's product joins the high accumulator instead of being scaled by 2^11 first (8 packed multiplies per
+            // tile less), E - P_hi' is one mixed-precision FMA per element (v_fma_mix_f32) instead of two conversions and a packed
+            // subtract.  The row sum runs over E too, so the final division is unchanged.
+            const sh_f32x2 m2v = {m - 11.0f, m - 11.0f};
+#else
             const sh_f32x2 m2v = {m, m};
+#endif
             sh_f32x2 ps2 = {0.0f, 0.0f};
             Frag8 ph[2], pl[2];
             const sh_f32x2 lo_scale2 = {kShLoScale, kShLoScale};
@@ -349,9 +408,15 @@ attention_shx_body(char* smem, const MQ& mq, const MO& mo, const _Float16* qkvs,
                 const sh_f32x2 e2 = {__builtin_amdgcn_exp2f(d2[0]), __builtin_amdgcn_exp2f(d2[1])};
                 ps2 += e2;
                 const h16x2 hi = __builtin_amdgcn_cvt_pkrtz(e2[0], e2[1]);
+#if CS_ATTN_ARITH == 2
+                (void)lo_scale2;
+                const uint32_t hib = __builtin_bit_cast(uint32_t, hi);
+                const h16x2 lo = __builtin_amdgcn_cvt_pkrtz(mix_residual_lo(e2[0], hib), mix_residual_hi(e2[1], hib));
+#else
                 const sh_f32x2 back = {(float)hi[0], (float)hi[1]};
                 const sh_f32x2 r2 = (e2 - back) * lo_scale2;
                 const h16x2 lo = __builtin_amdgcn_cvt_pkrtz(r2[0], r2[1]);
+#endif
                 ph[i >> 2].u[i & 3] = __builtin_bit_cast(uint32_t, hi);
                 pl[i >> 2].u[i & 3] = __builtin_bit_cast(uint32_t, lo);
             }
@@ -429,7 +494,9 @@ attention_shx_body(char* smem, const MQ& mq, const MO& mo, const _Float16* qkvs,
                     vl.q[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(vr + s * 16 * 128 + 8 * 128 + v_lo));
                     }
                     ohh[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh.v, ph[s].v, ohh[c], 0, 0, 0);
-#ifndef CS_ATTN_P_HI_ONLY
+#if CS_ATTN_ARITH == 2 && !defined(CS_ATTN_SCALAR_SOFTMAX)
+                    ohh[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh.v, pl[s].v, ohh[c], 0, 0, 0);
+#elif !defined(CS_ATTN_P_HI_ONLY)
                     oxx[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh.v, pl[s].v, oxx[c], 0, 0, 0);
 #endif
                     oxx[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl.v, ph[s].v, oxx[c], 0, 0, 0);
