@@ -1389,22 +1389,27 @@ gemm_q8_rows_kernel(const void* __restrict__ Asrc, const int8_t* __restrict__ W,
 // (same operations in the same order); the LayerNorm sums a row in another order than layernorm_kernel (in-lane over 96
 // values, then across four lanes), so its output may differ from the two-kernel path in the last bit.
 // One quantisation unit only (several units: the two-kernel path).  CS_Q8_LN_FUSED=0 restores it.
-constexpr int QN_N = 384, QN_THREADS = 512, QN_NST = 4;
+constexpr int QN_N = 384;
 constexpr int QN_STAGE = QN_N * 64;                    // 24,576 B
 // (the metadata sits at the bottom of LDS: every read of it is then one base register + an immediate offset; above 64 KiB the
 // offsets do not fit the instruction and the compiler keeps — and spills — an address register per (array, tile))
 constexpr int QN_OFF_CM = 0;                           // ws [384] | -zw [384] | colsum [384] | bias [384]
 constexpr int QN_OFF_LN = QN_OFF_CM + 4 * QN_N * 4;    // gamma [384] | beta [384]
 constexpr int QN_OFF_W = QN_OFF_LN + 2 * QN_N * 4;     // 9,216: the ring of weight stages
-constexpr int QN_LDS = QN_OFF_W + QN_NST * QN_STAGE;   // 107,520
+constexpr int qn_lds(int nst) { return QN_OFF_W + nst * QN_STAGE; }  // 4 stages: 107,520; 2 stages: 58,368 (two blocks per CU)
 
-template <int SRC, int KS>  // KS = K / 64 stages: 6 (K = 384) | 24 (K = 1536)
-__global__ void __launch_bounds__(QN_THREADS, 2)
+// NW waves per block (8, the default: 128 rows, ONE block per CU, a ring of NST = 4 stages; 4: 64 rows, TWO blocks per CU with a
+// double buffer — the same eight waves per CU as two independent blocks; measured slower, see launch_gemm_q8_ln)
+template <int SRC, int KS, int NW, int NST>  // KS = K / 64 stages: 6 (K = 384) | 24 (K = 1536)
+__global__ void __launch_bounds__(64 * NW, 2)
 gemm_q8_ln_kernel(const void* __restrict__ Asrc, const Q8RowMeta* __restrict__ rmeta, const uint32_t* __restrict__ in_range,
                   const int8_t* __restrict__ W, const Q8ColMeta* __restrict__ cmeta, float* X, const float* __restrict__ ln_g,
                   const float* __restrict__ ln_b, float eps, uint32_t M, float* __restrict__ range_out) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     constexpr uint32_t K = 64 * KS;
+    constexpr int QN_THREADS = 64 * NW, QN_NST = NST;
+    constexpr int DPW = 24 / NW;       // LDS-DMA instructions of a stage per wave (16 weight rows x 64 B each)
+    constexpr uint32_t RG = 16 * NW;   // rows per group
     float* l_ws = reinterpret_cast<float*>(lds + QN_OFF_CM);
     int* l_nzw = reinterpret_cast<int*>(l_ws + QN_N);
     int* l_cs = l_nzw + QN_N;
@@ -1424,27 +1429,28 @@ gemm_q8_ln_kernel(const void* __restrict__ Asrc, const Q8RowMeta* __restrict__ r
         q8_params(in_range, xs, xz);
         rxs = __fdiv_rn(1.0f, xs);
     }
-    // this wave's three LDS-DMA instructions of a stage: 16 rows x 64 B each; piece p of row n sits at slot p ^ ((n >> 2) & 3)
-    uint32_t woff[3];
+    // this wave's DPW LDS-DMA instructions of a stage: 16 rows x 64 B each; piece p of row n sits at slot p ^ ((n >> 2) & 3)
+    uint32_t woff[DPW];
 #pragma unroll
-    for (int t = 0; t < 3; ++t) {
-        const int row = (wave * 3 + t) * 16 + (lane >> 2);
+    for (int t = 0; t < DPW; ++t) {
+        const int row = (wave * DPW + t) * 16 + (lane >> 2);
         woff[t] = (uint32_t)row * K + (((lane & 3) ^ ((row >> 2) & 3)) * 16);
     }
     auto issue = [&](uint32_t st) {
         char* buf = lds + QN_OFF_W + (st % QN_NST) * QN_STAGE;
 #pragma unroll
-        for (int t = 0; t < 3; ++t) sh_glds16(W + woff[t] + st * 64, buf + (wave * 3 + t) * 1024);
+        for (int t = 0; t < DPW; ++t) sh_glds16(W + woff[t] + st * 64, buf + (wave * DPW + t) * 1024);
     };
     const int frag = l15 * 64 + ((g ^ ((l15 >> 2) & 3)) * 16);  // this lane's 16 bytes of tile j of a stage: + 1024 j
-    const uint32_t groups = (M + 127) / 128;
+    const uint32_t groups = (M + RG - 1) / RG;
     for (uint32_t grp = blockIdx.x; grp < groups; grp += gridDim.x) {
-        const uint32_t row = grp * 128 + wave * 16 + l15;          // this lane's row (the four lanes l15 + 16 g share it)
+        const uint32_t row = grp * RG + wave * 16 + l15;           // this lane's row (the four lanes l15 + 16 g share it)
         const uint32_t rowc = row < M ? row : M - 1;
         __syncthreads();  // every wave is done with the previous group's last stages (and the metadata is in LDS)
         // (opaque to the optimiser: otherwise the 3 x KS DMA source addresses are loop invariants it keeps — and spills — as
         // 64-bit registers; recomputing one costs an add)
-        asm volatile("" : "+v"(woff[0]), "+v"(woff[1]), "+v"(woff[2]));
+#pragma unroll
+        for (int t = 0; t < DPW; ++t) asm volatile("" : "+v"(woff[t]));
 #pragma unroll
         for (int st = 0; st < QN_NST - 1; ++st) issue(st);
         // the row's activations as MFMA operands: bytes 64 st + 16 g .. of the row, for every stage
@@ -1496,7 +1502,7 @@ gemm_q8_ln_kernel(const void* __restrict__ Asrc, const Q8RowMeta* __restrict__ r
 #pragma unroll
         for (uint32_t st = 0; st < (uint32_t)KS; ++st) {  // (fully unrolled: a[] must stay in registers)
             // this wave's share of stage st has landed: of the stages it has in flight only the younger ones may remain
-            if (st + QN_NST - 1 <= (uint32_t)KS) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * (QN_NST - 2)) : "memory");
+            if (st + QN_NST - 1 <= (uint32_t)KS) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DPW * (QN_NST - 2)) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();  // ... and everyone's; everyone is done with stage st - 1, whose slot the next issue overwrites
             if (st + QN_NST - 1 < (uint32_t)KS) issue(st + QN_NST - 1);
@@ -1577,8 +1583,8 @@ gemm_q8_ln_kernel(const void* __restrict__ Asrc, const Q8RowMeta* __restrict__ r
                 hi = fmaxf(hi, __shfl_xor(hi, o));
             }
             if (lane == 0) {
-                range_out[2 * ((size_t)grp * 8 + wave)] = lo;
-                range_out[2 * ((size_t)grp * 8 + wave) + 1] = hi;
+                range_out[2 * ((size_t)grp * NW + wave)] = lo;
+                range_out[2 * ((size_t)grp * NW + wave) + 1] = hi;
             }
         }
     }
@@ -1693,24 +1699,39 @@ int32_t launch_gemm_q8_ln(int src_kind, const void* d_src, const Q8RowMeta* d_rm
     if (K != 384 && K != 1536) return fail(CS_ERR_UNSUPPORTED, "LayerNorm-fused quantised product: K=%u not built (384, 1536)", K);
     if (src_kind != Q8_SRC_SPLIT && src_kind != QR_PREQUANT) return fail(CS_ERR_BAD_ARG, "LayerNorm-fused quantised product: bad source kind");
     if (src_kind == Q8_SRC_SPLIT && K != 384) return fail(CS_ERR_UNSUPPORTED, "LayerNorm-fused quantised product: quantise-on-load is built for K = 384");
+    // CS_Q8_LN_WAVES=4: two blocks of four waves per CU (64 rows, double buffer) instead of one block of eight (128 rows, four-stage
+    // ring).  Measured (profiles/r05_q8_ln_waves_ab.log): out-proj 97.7 -> 101.9 us, FFN-down 103 -> 107.7: two independent blocks do
+    // not overlap what eight lockstep waves leave exposed — the double buffer loses more than the independence returns.  Opt-in.
+    const char* we = std::getenv("CS_Q8_LN_WAVES");
+    const bool four = we && we[0] == '4';
     static PerDeviceOnce attr;  // function attributes are per device
     CS_TRY(attr.run([&]() -> int32_t {
-        CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_q8_ln_kernel<Q8_SRC_SPLIT, 6>), hipFuncAttributeMaxDynamicSharedMemorySize, QN_LDS));
-        CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_q8_ln_kernel<QR_PREQUANT, 6>), hipFuncAttributeMaxDynamicSharedMemorySize, QN_LDS));
-        CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_q8_ln_kernel<QR_PREQUANT, 24>), hipFuncAttributeMaxDynamicSharedMemorySize, QN_LDS));
+        auto allow = [](auto kernel, int nst) { return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, qn_lds(nst)); };
+        CS_HIP(allow(gemm_q8_ln_kernel<Q8_SRC_SPLIT, 6, 4, 2>, 2));
+        CS_HIP(allow(gemm_q8_ln_kernel<QR_PREQUANT, 6, 4, 2>, 2));
+        CS_HIP(allow(gemm_q8_ln_kernel<QR_PREQUANT, 24, 4, 2>, 2));
+        CS_HIP(allow(gemm_q8_ln_kernel<Q8_SRC_SPLIT, 6, 8, 4>, 4));
+        CS_HIP(allow(gemm_q8_ln_kernel<QR_PREQUANT, 6, 8, 4>, 4));
+        CS_HIP(allow(gemm_q8_ln_kernel<QR_PREQUANT, 24, 8, 4>, 4));
         return CS_OK;
     }));
-    const uint32_t groups = (M + 127) / 128, cus = (uint32_t)q8_cus();
-    const dim3 grid(groups < cus ? groups : cus);
-    if (src_kind == Q8_SRC_SPLIT)
-        hipLaunchKernelGGL((gemm_q8_ln_kernel<Q8_SRC_SPLIT, 6>), grid, dim3(QN_THREADS), QN_LDS, s, d_src, d_rmeta, d_in_range, d_wq, d_cmeta, X, ln_g, ln_b, eps, M, d_range_pairs);
-    else if (K == 384)
-        hipLaunchKernelGGL((gemm_q8_ln_kernel<QR_PREQUANT, 6>), grid, dim3(QN_THREADS), QN_LDS, s, d_src, d_rmeta, d_in_range, d_wq, d_cmeta, X, ln_g, ln_b, eps, M, d_range_pairs);
-    else
-        hipLaunchKernelGGL((gemm_q8_ln_kernel<QR_PREQUANT, 24>), grid, dim3(QN_THREADS), QN_LDS, s, d_src, d_rmeta, d_in_range, d_wq, d_cmeta, X, ln_g, ln_b, eps, M, d_range_pairs);
-    CS_HIP(hipGetLastError());
-    if (out_pairs) *out_pairs = groups * 8;
-    return CS_OK;
+    auto go = [&](auto kernel, uint32_t nw, int nst) -> int32_t {
+        const size_t ldsb = (size_t)qn_lds(nst);
+        const uint32_t groups = (M + 16 * nw - 1) / (16 * nw), slots = (uint32_t)q8_cus() * (nw == 4 ? 2u : 1u);
+        hipLaunchKernelGGL(kernel, dim3(groups < slots ? groups : slots), dim3(64 * nw), ldsb, s, d_src, d_rmeta, d_in_range, d_wq, d_cmeta, X, ln_g, ln_b,
+                           eps, M, d_range_pairs);
+        CS_HIP(hipGetLastError());
+        if (out_pairs) *out_pairs = groups * nw;
+        return CS_OK;
+    };
+    if (four) {
+        if (src_kind == Q8_SRC_SPLIT) return go(gemm_q8_ln_kernel<Q8_SRC_SPLIT, 6, 4, 2>, 4, 2);
+        if (K == 384) return go(gemm_q8_ln_kernel<QR_PREQUANT, 6, 4, 2>, 4, 2);
+        return go(gemm_q8_ln_kernel<QR_PREQUANT, 24, 4, 2>, 4, 2);
+    }
+    if (src_kind == Q8_SRC_SPLIT) return go(gemm_q8_ln_kernel<Q8_SRC_SPLIT, 6, 8, 4>, 8, 4);
+    if (K == 384) return go(gemm_q8_ln_kernel<QR_PREQUANT, 6, 8, 4>, 8, 4);
+    return go(gemm_q8_ln_kernel<QR_PREQUANT, 24, 8, 4>, 8, 4);
 }
 
 int32_t launch_gemm_q8(int epi, const int8_t* d_xq, const Q8RowMeta* d_rmeta, const int8_t* d_wq, const Q8ColMeta* d_cmeta,
