@@ -376,8 +376,12 @@ int32_t forward_range(cs_embedder* h, hipStream_t s, uint32_t b0, uint32_t nb, u
                 // one unit, K = 384, a row block per CU: the products quantise their own rows on the way in — per tensor only
                 // its range is needed first (a reduction of the pairs its producer left).  x_pairs: how many pairs the
                 // kernel that wrote x left (LayerNorm: one per four rows; the LayerNorm-fused products: one per sixteen)
+                // (q8_x_pairs == 0: the LayerNorm-fused product that wrote x widened this tensor's slot itself — CS_Q8_LN_SLOT=1; measured:
+                // what the consumers save on the reduction launch, 4 us each, the producers pay for the block's meeting and its
+                // agent-scope update, profiles/r05_q8_ln_epilogue_ab.log: opt-in.  Default: pairs + a reduction launch)
+                static const bool ln_slot = [] { const char* e = std::getenv("CS_Q8_LN_SLOT"); return e && e[0] == '1'; }();
                 if (l == 0) h->q8_x_pairs = ln_pairs;
-                CS_TRY(launch_q8_range(Q8_SRC_F32, x, T, H, rg, s, rp, h->q8_x_pairs));
+                if (h->q8_x_pairs) CS_TRY(launch_q8_range(Q8_SRC_F32, x, T, H, rg, s, rp, h->q8_x_pairs));
                 CS_TRY(launch_gemm_q8_from_source(SH_OUT_SPLIT, Q8_SRC_F32, x, rg, wq + ql.qkv, cm, bqkv, nullptr, nullptr, qkvs, T, 3 * H, H, h->d_flag, s));  // E2
                 CS_TRY(mark(CS_STAGE_QKV));
                 uint32_t att_pairs = 0;
@@ -386,7 +390,7 @@ int32_t forward_range(cs_embedder* h, hipStream_t s, uint32_t b0, uint32_t nb, u
                 CS_TRY(launch_q8_range(Q8_SRC_SPLIT, ctxs, T, H, rg + rstep, s, rp, att_pairs));
                 if (q8_ln_fused_takes(T, H, H)) {  // E4 with its residual add and LayerNorm in one kernel (gemm_q8_ln_kernel)
                     CS_TRY(launch_gemm_q8_ln(Q8_SRC_SPLIT, ctxs, nullptr, rg + rstep, wq + ql.ao, cm + 3 * H, x, P + lo.ao_ln_g, P + lo.ao_ln_b,
-                                             c.layer_norm_eps, T, H, rp, &h->q8_x_pairs, s));
+                                             c.layer_norm_eps, T, H, rp, &h->q8_x_pairs, s, ln_slot ? rg + 2 * rstep : nullptr));
                     CS_TRY(mark(CS_STAGE_OUT_PROJ));
                 } else {
                     CS_TRY(launch_gemm_q8_from_source(SH_OUT_F32_RESID, Q8_SRC_SPLIT, ctxs, rg + rstep, wq + ql.ao, cm + 3 * H, P + lo.ao_b, x, x, nullptr, T, H, H,
@@ -397,14 +401,15 @@ int32_t forward_range(cs_embedder* h, hipStream_t s, uint32_t b0, uint32_t nb, u
                     h->q8_x_pairs = ln_pairs;
                 }
                 CS_TRY(mark(CS_STAGE_LN_ATTN));
-                CS_TRY(launch_q8_range(Q8_SRC_F32, x, T, H, rg + 2 * rstep, s, rp, h->q8_x_pairs));
+                if (h->q8_x_pairs) CS_TRY(launch_q8_range(Q8_SRC_F32, x, T, H, rg + 2 * rstep, s, rp, h->q8_x_pairs));
                 int8_t* midq = reinterpret_cast<int8_t*>(mid);
                 Q8RowMeta* rm2 = h->d_rmeta2 + t0;
                 CS_TRY(launch_gemm_q8_gelu_requant_from_source(x, rg + 2 * rstep, wq + ql.up, cm + 4 * H, P + lo.up_b, T, I, H, rg + 3 * rstep, midq, rm2, s));  // E5
                 CS_TRY(mark(CS_STAGE_FFN_UP));
                 if (q8_ln_fused_takes(T, H, I)) {  // E6 likewise
+                    // (the next layer's first slot; the last layer's output is not quantised again: pairs nobody reads)
                     CS_TRY(launch_gemm_q8_ln(Q8_SRC_PREQUANT, midq, rm2, nullptr, wq + ql.down, cm + 4 * H + I, x, P + lo.out_ln_g, P + lo.out_ln_b,
-                                             c.layer_norm_eps, T, I, rp, &h->q8_x_pairs, s));
+                                             c.layer_norm_eps, T, I, rp, &h->q8_x_pairs, s, ln_slot && l + 1 < c.layers ? rg + 4 * rstep : nullptr));
                     CS_TRY(mark(CS_STAGE_FFN_DOWN));
                 } else {
                     CS_TRY(launch_gemm_q8(SH_OUT_F32_RESID, midq, rm2, wq + ql.down, cm + 4 * H + I, P + lo.down_b, x, x, nullptr, T, H, I, h->d_flag, s));  // E6

@@ -1396,7 +1396,7 @@ constexpr int QN_STAGE = QN_N * 64;                    // 24,576 B
 constexpr int QN_OFF_CM = 0;                           // ws [384] | -zw [384] | colsum [384] | bias [384]
 constexpr int QN_OFF_LN = QN_OFF_CM + 4 * QN_N * 4;    // gamma [384] | beta [384]
 constexpr int QN_OFF_W = QN_OFF_LN + 2 * QN_N * 4;     // 9,216: the ring of weight stages
-constexpr int qn_lds(int nst) { return QN_OFF_W + nst * QN_STAGE; }  // 4 stages: 107,520; 2 stages: 58,368 (two blocks per CU)
+constexpr int qn_lds(int nst) { return QN_OFF_W + nst * QN_STAGE + 64; }  // 4 stages: 107,584; 2 stages: 58,432 (two blocks per CU); the last 64 B: the waves' (lo, hi)
 
 // NW waves per block (8, the default: 128 rows, ONE block per CU, a ring of NST = 4 stages; 4: 64 rows, TWO blocks per CU with a
 // double buffer — the same eight waves per CU as two independent blocks; measured slower, see launch_gemm_q8_ln)
@@ -1404,7 +1404,7 @@ template <int SRC, int KS, int NW, int NST>  // KS = K / 64 stages: 6 (K = 384) 
 __global__ void __launch_bounds__(64 * NW, 2)
 gemm_q8_ln_kernel(const void* __restrict__ Asrc, const Q8RowMeta* __restrict__ rmeta, const uint32_t* __restrict__ in_range,
                   const int8_t* __restrict__ W, const Q8ColMeta* __restrict__ cmeta, float* X, const float* __restrict__ ln_g,
-                  const float* __restrict__ ln_b, float eps, uint32_t M, float* __restrict__ range_out) {
+                  const float* __restrict__ ln_b, float eps, uint32_t M, float* __restrict__ range_out, uint32_t* __restrict__ range_slot) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     constexpr uint32_t K = 64 * KS;
     constexpr int QN_THREADS = 64 * NW, QN_NST = NST;
@@ -1523,6 +1523,18 @@ gemm_q8_ln_kernel(const void* __restrict__ Asrc, const Q8RowMeta* __restrict__ r
                        "+v"(acc[16]), "+v"(acc[17]), "+v"(acc[18]), "+v"(acc[19]), "+v"(acc[20]), "+v"(acc[21]), "+v"(acc[22]), "+v"(acc[23]));
         // y = float(acc with the zero points back in) * (x_scale * W_scale) + bias, + residual: kept in the accumulator registers
         float* xrow = X + (size_t)rowc * QN_N + 4 * g;
+        // The row's residual, all 24 tiles requested at once: the activations' registers are free from here on, and read tile by
+        // tile inside the loop below (whose scheduling fences keep two tiles' loads in flight) the epilogue paid a memory round
+        // trip per pair of tiles, twelve in a row.  (CS_Q8_LN_RESID_PREFETCH=0 at compile time restores that form.)
+#ifndef CS_Q8_LN_RESID_PREFETCH
+#define CS_Q8_LN_RESID_PREFETCH 1
+#endif
+#if CS_Q8_LN_RESID_PREFETCH
+        sh_f32x4 rpre[24];
+#pragma unroll
+        for (int j = 0; j < 24; ++j) rpre[j] = *reinterpret_cast<const sh_f32x4*>(xrow + 16 * j);
+        __builtin_amdgcn_sched_barrier(0);
+#endif
         float vf[96];  // the row's values this lane holds (scalars: partial updates of the accumulator tuples made the allocator spill)
         float sum = 0.0f;
 #pragma unroll
@@ -1532,7 +1544,11 @@ gemm_q8_ln_kernel(const void* __restrict__ Asrc, const Q8RowMeta* __restrict__ r
             const q8_i32x4 nzw4 = *reinterpret_cast<const q8_i32x4*>(l_nzw + c0);
             const q8_i32x4 cs4 = *reinterpret_cast<const q8_i32x4*>(l_cs + c0);
             const sh_f32x4 b4 = *reinterpret_cast<const sh_f32x4*>(l_bias + c0);
+#if CS_Q8_LN_RESID_PREFETCH
+            const sh_f32x4 r4 = rpre[j];
+#else
             const sh_f32x4 r4 = *reinterpret_cast<const sh_f32x4*>(xrow + 16 * j);
+#endif
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 int corr;
@@ -1575,14 +1591,27 @@ gemm_q8_ln_kernel(const void* __restrict__ Asrc, const Q8RowMeta* __restrict__ r
             if (row < M) *reinterpret_cast<sh_f32x4*>(xrow + 16 * j) = o;
             if (j % 2 == 1) __builtin_amdgcn_sched_barrier(0);
         }
-        if (range_out) {  // one (lo, hi) pair per wave = 16 rows (rows past M: none of theirs)
+        if (range_out || range_slot) {  // the (lo, hi) of this wave's 16 rows (rows past M: none of theirs)
             if (row >= M) { lo = 0.0f; hi = 0.0f; }
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) {
                 lo = fminf(lo, __shfl_xor(lo, o));
                 hi = fmaxf(hi, __shfl_xor(hi, o));
             }
-            if (lane == 0) {
+            if (range_slot) {
+                // straight into the range slot of the tensor's next quantisation: no pair buffer, no reduction launch behind the
+                // kernel.  One update per BLOCK (the waves meet in LDS): a wave each — 4,096 contended atomics on two addresses —
+                // cost the kernel 36 us.
+                float* s_r = reinterpret_cast<float*>(lds + QN_OFF_W + QN_NST * QN_STAGE);  // [NW][2], behind the ring
+                if (lane == 0) { s_r[2 * wave] = lo; s_r[2 * wave + 1] = hi; }
+                __syncthreads();
+                if (tid == 0) {
+#pragma unroll
+                    for (int w = 1; w < NW; ++w) { lo = fminf(lo, s_r[2 * w]); hi = fmaxf(hi, s_r[2 * w + 1]); }
+                    q8_range_update(range_slot, lo, hi);
+                }
+                // (the next group's first barrier stands between these reads and the next writes of s_r)
+            } else if (lane == 0) {
                 range_out[2 * ((size_t)grp * NW + wave)] = lo;
                 range_out[2 * ((size_t)grp * NW + wave) + 1] = hi;
             }
@@ -1686,14 +1715,15 @@ static int32_t launch_rows(const void* d_xq, const Q8RowMeta* d_rmeta, const int
 // N = 384, one quantisation unit, from 4,096 rows: the product with its residual add and LayerNorm in one kernel
 // (gemm_q8_ln_kernel).  src_kind Q8_SRC_SPLIT (d_src = the split-f16 tensor, d_in_range its range slot) or -1 (d_src = the s8
 // tensor, d_rmeta its rows).  X [M][384]: the residual on entry, LayerNorm(product + bias + residual) on return; *out_pairs
-// (lo, hi) pairs are left in d_range_pairs for the quantisation that follows.
+// (lo, hi) pairs are left in d_range_pairs for the quantisation that follows — or, with d_out_slot, the waves widen that range
+// slot themselves (zeroed by the caller at the start of the forward) and *out_pairs = 0: no reduction launch behind the kernel.
 bool q8_ln_fused_takes(uint32_t M, uint32_t N, uint32_t K) {
     const char* e = std::getenv("CS_Q8_LN_FUSED");  // (read per call: tests and A/B scripts flip it mid-process)
     return !(e && e[0] == '0') && N == (uint32_t)QN_N && (K == 384 || K == 1536) && q8_rows_takes(M, 384);
 }
 int32_t launch_gemm_q8_ln(int src_kind, const void* d_src, const Q8RowMeta* d_rmeta, const uint32_t* d_in_range, const int8_t* d_wq,
                           const Q8ColMeta* d_cmeta, float* X, const float* ln_g, const float* ln_b, float eps, uint32_t M, uint32_t K,
-                          float* d_range_pairs, uint32_t* out_pairs, hipStream_t s) {
+                          float* d_range_pairs, uint32_t* out_pairs, hipStream_t s, uint32_t* d_out_slot) {
     if (out_pairs) *out_pairs = 0;
     if (M == 0) return CS_OK;
     if (K != 384 && K != 1536) return fail(CS_ERR_UNSUPPORTED, "LayerNorm-fused quantised product: K=%u not built (384, 1536)", K);
@@ -1719,9 +1749,9 @@ int32_t launch_gemm_q8_ln(int src_kind, const void* d_src, const Q8RowMeta* d_rm
         const size_t ldsb = (size_t)qn_lds(nst);
         const uint32_t groups = (M + 16 * nw - 1) / (16 * nw), slots = (uint32_t)q8_cus() * (nw == 4 ? 2u : 1u);
         hipLaunchKernelGGL(kernel, dim3(groups < slots ? groups : slots), dim3(64 * nw), ldsb, s, d_src, d_rmeta, d_in_range, d_wq, d_cmeta, X, ln_g, ln_b,
-                           eps, M, d_range_pairs);
+                           eps, M, d_range_pairs, d_out_slot);
         CS_HIP(hipGetLastError());
-        if (out_pairs) *out_pairs = groups * nw;
+        if (out_pairs) *out_pairs = d_out_slot ? 0 : groups * nw;
         return CS_OK;
     };
     if (four) {
