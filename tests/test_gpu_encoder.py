@@ -568,3 +568,32 @@ def test_head_dim_64_models(FE, oracle, hidden, heads, inter, L):
     got32 = emb.embed_ids(ids, mask)
     np.testing.assert_allclose(got32, ref, atol=TOL_ORACLE)
     assert np.abs(got32 - got).max() < 5e-6
+
+
+@pytest.mark.parametrize("hidden,heads,inter", [(384, 12, 1536), (768, 12, 3072)])
+@pytest.mark.parametrize("qscale,kscale", [(8.0, 8.0), (30.0, 1.0), (0.02, 0.02), (1.0, 0.001)])
+def test_attention_arithmetic_under_wide_and_narrow_scores(FE, oracle, hidden, heads, inter, qscale, kscale):
+    """The attention kernel's round-5 arithmetic at its edges: query / key projections scaled so that the scores spread over
+    hundreds of units (the running reference jumps by far more than the 4 the lazy rescaling tolerates, tile after tile, and the
+    probabilities between rescales reach 2^4) or shrink to 1e-3 (the 2^-11-scaled query halves and the unscaled residual of the
+    probabilities are f16 subnormals) — 512 tokens = four super-tiles per query block, ragged masks, both head widths, the
+    whole forward against the oracle at the usual 2e-5."""
+    from codesearch_amd.bert_params import to_state_dict
+
+    cfg = BertConfig(vocab_size=512, hidden=hidden, heads=heads, intermediate=inter, layers=2, pooling=POOL_MEAN)
+    flat = synth_params(cfg, 77)
+    sd = to_state_dict(cfg, flat)  # views into flat
+    for l in range(cfg.layers):
+        p = f"encoder.layer.{l}.attention.self."
+        sd[p + "query.weight"] *= qscale
+        sd[p + "query.bias"] *= qscale
+        sd[p + "key.weight"] *= kscale
+        sd[p + "key.bias"] *= kscale
+    ids, mask = synth_token_batch(cfg, 515, 3, 512, True)
+    emb = FE(cfg, params=flat)
+    got = emb.embed_ids(ids, mask)
+    ref = oracle.bert_forward(cfg, flat, ids, mask)["pooled"]
+    np.testing.assert_allclose(got, ref, atol=TOL_ORACLE)
+    short = emb.embed_ids(ids[:, :40], mask[:, :40])  # the few-rows path over the same weights
+    np.testing.assert_allclose(short, oracle.bert_forward(cfg, flat, ids[:, :40], mask[:, :40])["pooled"], atol=TOL_ORACLE)
+    emb.close()
