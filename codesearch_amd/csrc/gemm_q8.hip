@@ -1389,6 +1389,9 @@ gemm_q8_rows_kernel(const void* __restrict__ Asrc, const int8_t* __restrict__ W,
 // (same operations in the same order); the LayerNorm sums a row in another order than layernorm_kernel (in-lane over 96
 // values, then across four lanes), so its output may differ from the two-kernel path in the last bit.
 // One quantisation unit only (several units: the two-kernel path).  CS_Q8_LN_FUSED=0 restores it.
+#ifndef CS_Q8_LN_RESID_PREFETCH
+#define CS_Q8_LN_RESID_PREFETCH 1   // (0: the residual read tile by tile inside the epilogue loop, for A/B)
+#endif
 constexpr int QN_N = 384;
 constexpr int QN_STAGE = QN_N * 64;                    // 24,576 B
 // (the metadata sits at the bottom of LDS: every read of it is then one base register + an immediate offset; above 64 KiB the
@@ -1526,9 +1529,6 @@ gemm_q8_ln_kernel(const void* __restrict__ Asrc, const Q8RowMeta* __restrict__ r
         // The row's residual, all 24 tiles requested at once: the activations' registers are free from here on, and read tile by
         // tile inside the loop below (whose scheduling fences keep two tiles' loads in flight) the epilogue paid a memory round
         // trip per pair of tiles, twelve in a row.  (CS_Q8_LN_RESID_PREFETCH=0 at compile time restores that form.)
-#ifndef CS_Q8_LN_RESID_PREFETCH
-#define CS_Q8_LN_RESID_PREFETCH 1
-#endif
 #if CS_Q8_LN_RESID_PREFETCH
         sh_f32x4 rpre[24];
 #pragma unroll
