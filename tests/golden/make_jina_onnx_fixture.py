@@ -146,7 +146,7 @@ class JinaTiny(nn.Module):
         return x
 
 
-def write(out_dir, stem, first_file=False, dims=None):
+def write(out_dir, stem, first_file=False, dims=None, opset=14):
     """dims = (hidden, heads, layers, intermediate, vocabulary): the GPU tests export at a width the kernels run (384)"""
     global FIRST_FILE, H, NH, LAYERS, INNER, VOCAB
     from torch.onnx._internal.torchscript_exporter import onnx_proto_utils
@@ -169,7 +169,7 @@ def write(out_dir, stem, first_file=False, dims=None):
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         torch.onnx.export(model, (ids, mask, tt), out, input_names=list(axes), output_names=["last_hidden_state"], dynamic_axes=axes,
-                          opset_version=14, dynamo=False)
+                          opset_version=opset, dynamo=False)
     g = torch.Generator().manual_seed(11)
     qids = torch.randint(0, VOCAB, (3, 24), generator=g)
     lens = [24, 17, 9]

@@ -23,7 +23,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 H, NH, LAYERS, INNER, VOCAB = 64, 2, 3, 80, 48
 
 
-def write(out_dir, stem, dims=None, local_attention=16):
+def write(out_dir, stem, dims=None, local_attention=16, opset=14):
     """dims = (hidden, heads, layers, intermediate, vocabulary): the GPU tests export at a width the kernels run (384)"""
     from torch.onnx._internal.torchscript_exporter import onnx_proto_utils
     from transformers import ModernBertConfig, ModernBertModel
@@ -47,7 +47,7 @@ def write(out_dir, stem, dims=None, local_attention=16):
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         torch.onnx.export(model, (ids, mask), out, input_names=list(axes), output_names=["last_hidden_state"], dynamic_axes=axes,
-                          opset_version=14, dynamo=False)
+                          opset_version=opset, dynamo=False)
     # the exporting model's own answer: 3 sequences of 40 tokens (longer than the local window), the last two padded
     g = torch.Generator().manual_seed(7)
     qids = torch.randint(3, VOCAB, (3, 40), generator=g)

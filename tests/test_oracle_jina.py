@@ -202,3 +202,21 @@ def test_onnx_reader_reads_the_first_modelling_files_arrangement(gpu_lib, oracle
     np.testing.assert_allclose(pooled, state["query_pooled"], atol=2e-6)
     rc, _, err = load_onnx(gpu_lib, path, ONNX_CFG)
     assert rc == _lib.CS_ERR_DIM_MISMATCH and "holds no query / key LayerNorm" in err
+
+
+def test_onnx_reader_reads_an_opset_17_export(gpu_lib, tmp_path):
+    """Opset 17: LayerNormalization nodes instead of the decomposed chain; the Linear weights still anonymous behind their biases."""
+    import importlib.util
+
+    from codesearch_amd import _lib
+    from tests.onnx_dump import read
+
+    spec = importlib.util.spec_from_file_location("make_jina_onnx_fixture", os.path.join(os.path.dirname(__file__), "golden", "make_jina_onnx_fixture.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    path = mod.write(str(tmp_path), "opset17", opset=17)
+    assert any(op == "LayerNormalization" for op, _, _, _ in read(path)["nodes"])
+    state = dict(np.load(os.path.join(str(tmp_path), "opset17_state.npz")))
+    rc, got, err = load_onnx(gpu_lib, path, ONNX_CFG)
+    assert rc == _lib.CS_OK, err
+    assert np.array_equal(got, from_jina_state_dict(ONNX_CFG, state))

@@ -144,3 +144,23 @@ def test_onnx_reader_reads_a_modernbert_export_written_by_torchs_own_exporter(gp
     assert rc == _lib.CS_ERR_DIM_MISMATCH and "mlp.Wi" in err
     rc, _, err = load_onnx(gpu_lib, os.path.join(gold, "bert_tiny_export.onnx"), ONNX_CFG)
     assert rc == _lib.CS_ERR_BAD_ARG and "tok_embeddings" in err
+
+
+def test_onnx_reader_reads_an_opset_17_export(gpu_lib, tmp_path):
+    """The same model exported at opset 17: LayerNorm arrives as ONE LayerNormalization node instead of the ReduceMean / Sub / Pow
+    chain — the reader goes by initialiser names and weight products, not by how a norm is spelt."""
+    import importlib.util
+
+    from codesearch_amd import _lib
+
+    spec = importlib.util.spec_from_file_location("make_modern_onnx_fixture", os.path.join(os.path.dirname(__file__), "golden", "make_modern_onnx_fixture.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    path = mod.write(str(tmp_path), "opset17", opset=17)
+    from tests.onnx_dump import read
+
+    assert any(op == "LayerNormalization" for op, _, _, _ in read(path)["nodes"])
+    state = dict(np.load(os.path.join(str(tmp_path), "opset17_state.npz")))
+    rc, got, err = load_onnx(gpu_lib, path, ONNX_CFG)
+    assert rc == _lib.CS_OK, err
+    assert np.array_equal(got, block_from_modernbert_state(ONNX_CFG, state))
