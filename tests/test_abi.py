@@ -71,3 +71,31 @@ def test_inline_key_helpers_match_python_mirror():
     order = np.argsort(keys)[::-1]
     assert order.tolist() == [0, 1, 5, 2, 3, 4, 6]  # cos desc, then id asc on the tie at 0.0
     assert (keys != 0).all()
+
+
+def test_integration_md_binds_what_the_header_declares():
+    """The Rust `extern "C"` block of INTEGRATION.md — what a maintainer of the reference would paste — names only functions
+    the header declares, with the header's argument counts, and its CsBertConfig has the header's fields in the header's
+    order (cs_bert_config_from_dir writes the whole struct: a stale binding is a buffer overrun)."""
+    import re
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    md = open(os.path.join(root, "INTEGRATION.md")).read()
+    hdr = open(os.path.join(root, "include", "codesearch_gpu.h")).read()
+    hdr_nc = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+
+    def count(args):
+        args = re.sub(r"//[^\n]*", "", args).strip()
+        return 0 if args in ("", "void") else len([a for a in args.split(",") if a.strip()])
+
+    bound = re.findall(r"pub fn (cs_[a-z0-9_]+)\(([^;]*?)\)\s*(?:->[^;]*)?;", md, re.S)
+    assert len(bound) >= 40
+    for name, args in bound:
+        m = re.search(r"\b" + name + r"\s*\(([^;]*?)\)\s*;", hdr_nc, re.S)
+        assert m, f"INTEGRATION.md binds {name}, the header does not declare it"
+        assert count(args) == count(m.group(1)), f"{name}: {count(args)} arguments in INTEGRATION.md, {count(m.group(1))} in the header"
+    c_fields = re.findall(r"^\s*(?:uint32_t|int32_t|float)\s+([a-z_]+);", re.search(r"typedef struct cs_bert_config \{(.*?)\} cs_bert_config;", hdr_nc, re.S).group(1), re.M)
+    rs_body = re.sub(r"//[^\n]*", "", re.search(r"pub struct CsBertConfig \{(.*?)\n\}", md, re.S).group(1))
+    rs_fields = re.findall(r"pub ([a-z_]+):", rs_body)
+    assert rs_fields == c_fields, (rs_fields, c_fields)
+    assert "cs_abi_version() -> u32" in md
