@@ -597,3 +597,41 @@ def test_attention_arithmetic_under_wide_and_narrow_scores(FE, oracle, hidden, h
     short = emb.embed_ids(ids[:, :40], mask[:, :40])  # the few-rows path over the same weights
     np.testing.assert_allclose(short, oracle.bert_forward(cfg, flat, ids[:, :40], mask[:, :40])["pooled"], atol=TOL_ORACLE)
     emb.close()
+
+
+def test_attention_loop_forms_are_bit_identical():
+    """The attention tile loop's four forms (CS_ATTN_PIPE=0..3: rolled, two key tiles in flight, the super-tile written out,
+    + early fragment requests) compute the same arithmetic in the same order: one process per form (the knob is read once),
+    the same embeddings bit for bit — head_dim 32 and 64, an ALiBi model, a local-window model, ragged 300-token batches."""
+    import hashlib
+    import subprocess
+    import sys
+
+    script = r'''
+import hashlib, sys
+import numpy as np
+sys.path.insert(0, %r)
+from codesearch_amd import FastEmbedder, ModelType
+from codesearch_amd.bert_params import (ARCH_JINA_QKNORM, ARCH_MODERN, POOL_MEAN, BertConfig, synth_token_batch, token_batch_with_lens)
+h = hashlib.sha256()
+cfgs = [BertConfig(vocab_size=512, layers=2),
+        BertConfig(vocab_size=512, hidden=768, heads=12, intermediate=3072, layers=1),
+        BertConfig(vocab_size=512, hidden=768, heads=12, intermediate=3072, layers=1, pooling=POOL_MEAN, arch=ARCH_JINA_QKNORM),
+        BertConfig(vocab_size=512, hidden=1024, heads=16, intermediate=1536, layers=3, max_position=512, type_vocab_size=1, pooling=POOL_MEAN,
+                   arch=ARCH_MODERN, layer_norm_eps=1e-5, rotary_base=160000.0, rotary_base_local=10000.0, global_every=3, local_window=64)]
+for i, cfg in enumerate(cfgs):
+    emb = FastEmbedder(ModelType.BGESmallENV15, config=cfg, seed=31 + i)
+    if cfg.arch == ARCH_MODERN:
+        ids, mask = token_batch_with_lens(cfg, 7, [300, 280, 255], 300)
+    else:
+        ids, mask = synth_token_batch(cfg, 7, 3, 300, True)
+    h.update(np.ascontiguousarray(emb.embed_ids(ids, mask)).tobytes())
+    emb.close()
+print("DIGEST", h.hexdigest())
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    digests = {}
+    for form in "0123":
+        r = subprocess.run([sys.executable, "-c", script], env=dict(os.environ, CS_ATTN_PIPE=form), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        digests[form] = [l for l in r.stdout.splitlines() if l.startswith("DIGEST")][0]
+    assert len(set(digests.values())) == 1, digests
