@@ -220,3 +220,47 @@ def test_onnx_reader_reads_an_opset_17_export(gpu_lib, tmp_path):
     rc, got, err = load_onnx(gpu_lib, path, ONNX_CFG)
     assert rc == _lib.CS_OK, err
     assert np.array_equal(got, from_jina_state_dict(ONNX_CFG, state))
+
+
+def test_config_from_dir_takes_the_variant_from_the_weights_file(gpu_lib, tmp_path):
+    """cs_bert_config_from_dir on a JinaBert directory: with no weights file the modelling file named by auto_map decides whether
+    the query / key rows are LayerNorm'ed; a model.safetensors or an ONNX export next to config.json overrides it with what its own
+    tensors say (host-only: no GPU involved)."""
+    import ctypes as C
+    import json
+    import shutil
+
+    from safetensors.numpy import save_file
+
+    from codesearch_amd import _lib
+
+    def arch_of(d):
+        c = _lib.BertConfig()
+        _lib.check(gpu_lib.cs_bert_config_from_dir(str(d).encode(), -1, C.byref(c)))
+        return c.arch, c.pooling, c.max_position
+
+    def config(repo):
+        return {"model_type": "bert", "position_embedding_type": "alibi", "feed_forward_type": "geglu", "hidden_act": "gelu", "vocab_size": 48,
+                "hidden_size": 64, "num_attention_heads": 2, "num_hidden_layers": 2, "intermediate_size": 128, "max_position_embeddings": 8192,
+                "type_vocab_size": 2, "layer_norm_eps": 1e-12,
+                "auto_map": {"AutoModel": repo + "--modeling_bert.JinaBertModel"}}
+
+    gold = os.path.join(os.path.dirname(__file__), "golden")
+    d = tmp_path / "m"
+    d.mkdir()
+    (d / "config.json").write_text(json.dumps(config("jinaai/jina-bert-implementation")))
+    assert arch_of(d) == (ARCH_JINA, POOL_MEAN, 512)                      # the config alone
+    (d / "config.json").write_text(json.dumps(config("jinaai/jina-bert-v2-qk-post-norm")))
+    assert arch_of(d)[0] == ARCH_JINA_QKNORM
+    # a safetensors file without the query / key LayerNorms overrides the qk-post-norm config ...
+    save_file({"encoder.layer.0.attention.self.query.weight": np.zeros((64, 64), np.float32)}, str(d / "model.safetensors"))
+    assert arch_of(d)[0] == ARCH_JINA
+    # ... and the exported graph, whose initialisers hold them, overrides the first modelling file's config
+    (d / "model.safetensors").unlink()
+    (d / "config.json").write_text(json.dumps(config("jinaai/jina-bert-implementation")))
+    (d / "onnx").mkdir()
+    shutil.copy(os.path.join(gold, "jina_tiny_export.onnx"), d / "onnx" / "model.onnx")
+    assert arch_of(d)[0] == ARCH_JINA_QKNORM
+    # an unreadable weights file leaves the decision with the config
+    (d / "onnx" / "model.onnx").write_bytes(b"\x00\x01garbage")
+    assert arch_of(d)[0] == ARCH_JINA
