@@ -1399,10 +1399,11 @@ constexpr int QN_STAGE = QN_N * 64;                    // 24,576 B
 constexpr int QN_OFF_CM = 0;                           // ws [384] | -zw [384] | colsum [384] | bias [384]
 constexpr int QN_OFF_LN = QN_OFF_CM + 4 * QN_N * 4;    // gamma [384] | beta [384]
 constexpr int QN_OFF_W = QN_OFF_LN + 2 * QN_N * 4;     // 9,216: the ring of weight stages
-constexpr int qn_lds(int nst) { return QN_OFF_W + nst * QN_STAGE + 64; }  // 4 stages: 107,584; 2 stages: 58,432 (two blocks per CU); the last 64 B: the waves' (lo, hi)
+// (lng: gamma / beta read from global memory in the last pass instead of from LDS — three stages then fit twice into a CU's 160 KiB)
+constexpr int qn_lds(int nst, bool lng = false) { return (lng ? QN_OFF_LN : QN_OFF_W) + nst * QN_STAGE + 64; }  // 8 waves, 4 stages: 107,584; 4 waves, 3 stages: 79,936; the last 64 B: the waves' (lo, hi)
 
-// NW waves per block (8, the default: 128 rows, ONE block per CU, a ring of NST = 4 stages; 4: 64 rows, TWO blocks per CU with a
-// double buffer — the same eight waves per CU as two independent blocks; measured slower, see launch_gemm_q8_ln)
+// NW waves per block (8, the default: 128 rows, ONE block per CU, a ring of NST = 4 stages; 4: 64 rows, TWO blocks per CU with
+// three stages each — the same eight waves per CU as two independent blocks; measured slower, see launch_gemm_q8_ln)
 template <int SRC, int KS, int NW, int NST>  // KS = K / 64 stages: 6 (K = 384) | 24 (K = 1536)
 __global__ void __launch_bounds__(64 * NW, 2)
 gemm_q8_ln_kernel(const void* __restrict__ Asrc, const Q8RowMeta* __restrict__ rmeta, const uint32_t* __restrict__ in_range,
@@ -1411,6 +1412,8 @@ gemm_q8_ln_kernel(const void* __restrict__ Asrc, const Q8RowMeta* __restrict__ r
     extern __shared__ __attribute__((aligned(16))) char lds[];
     constexpr uint32_t K = 64 * KS;
     constexpr int QN_THREADS = 64 * NW, QN_NST = NST;
+    constexpr bool LNG = NW == 4;      // gamma / beta from global memory (their LDS goes to the third weight stage)
+    constexpr int OFF_W = LNG ? QN_OFF_LN : QN_OFF_W;
     constexpr int DPW = 24 / NW;       // LDS-DMA instructions of a stage per wave (16 weight rows x 64 B each)
     constexpr uint32_t RG = 16 * NW;   // rows per group
     float* l_ws = reinterpret_cast<float*>(lds + QN_OFF_CM);
@@ -1425,7 +1428,7 @@ gemm_q8_ln_kernel(const void* __restrict__ Asrc, const Q8RowMeta* __restrict__ r
     for (int n = tid; n < QN_N; n += QN_THREADS) {
         const Q8ColMeta cm = cmeta[n];
         l_ws[n] = cm.ws; l_nzw[n] = -cm.zw; l_cs[n] = cm.colsum; l_bias[n] = cm.bias;
-        l_g[n] = ln_g[n]; l_b[n] = ln_b[n];
+        if (!LNG) { l_g[n] = ln_g[n]; l_b[n] = ln_b[n]; }
     }
     float xs = 1.0f, xz = 0.0f, rxs = 1.0f;
     if (SRC == Q8_SRC_SPLIT) {
@@ -1440,7 +1443,7 @@ gemm_q8_ln_kernel(const void* __restrict__ Asrc, const Q8RowMeta* __restrict__ r
         woff[t] = (uint32_t)row * K + (((lane & 3) ^ ((row >> 2) & 3)) * 16);
     }
     auto issue = [&](uint32_t st) {
-        char* buf = lds + QN_OFF_W + (st % QN_NST) * QN_STAGE;
+        char* buf = lds + OFF_W + (st % QN_NST) * QN_STAGE;
 #pragma unroll
         for (int t = 0; t < DPW; ++t) sh_glds16(W + woff[t] + st * 64, buf + (wave * DPW + t) * 1024);
     };
@@ -1509,7 +1512,7 @@ gemm_q8_ln_kernel(const void* __restrict__ Asrc, const Q8RowMeta* __restrict__ r
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();  // ... and everyone's; everyone is done with stage st - 1, whose slot the next issue overwrites
             if (st + QN_NST - 1 < (uint32_t)KS) issue(st + QN_NST - 1);
-            const char* buf = lds + QN_OFF_W + (st % QN_NST) * QN_STAGE + frag;
+            const char* buf = lds + OFF_W + (st % QN_NST) * QN_STAGE + frag;
             const q8_i32x4 av = a[st];
 #pragma unroll
             for (int j = 0; j < 24; ++j) {
@@ -1579,8 +1582,8 @@ gemm_q8_ln_kernel(const void* __restrict__ Asrc, const Q8RowMeta* __restrict__ r
 #pragma unroll
         for (int j = 0; j < 24; ++j) {
             const int c0 = 16 * j + 4 * g;
-            const sh_f32x4 g4 = *reinterpret_cast<const sh_f32x4*>(l_g + c0);
-            const sh_f32x4 b4 = *reinterpret_cast<const sh_f32x4*>(l_b + c0);
+            const sh_f32x4 g4 = *reinterpret_cast<const sh_f32x4*>((LNG ? ln_g : l_g) + c0);
+            const sh_f32x4 b4 = *reinterpret_cast<const sh_f32x4*>((LNG ? ln_b : l_b) + c0);
             sh_f32x4 o;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -1602,7 +1605,7 @@ gemm_q8_ln_kernel(const void* __restrict__ Asrc, const Q8RowMeta* __restrict__ r
                 // straight into the range slot of the tensor's next quantisation: no pair buffer, no reduction launch behind the
                 // kernel.  One update per BLOCK (the waves meet in LDS): a wave each — 4,096 contended atomics on two addresses —
                 // cost the kernel 36 us.
-                float* s_r = reinterpret_cast<float*>(lds + QN_OFF_W + QN_NST * QN_STAGE);  // [NW][2], behind the ring
+                float* s_r = reinterpret_cast<float*>(lds + OFF_W + QN_NST * QN_STAGE);  // [NW][2], behind the ring
                 if (lane == 0) { s_r[2 * wave] = lo; s_r[2 * wave + 1] = hi; }
                 __syncthreads();
                 if (tid == 0) {
@@ -1729,24 +1732,25 @@ int32_t launch_gemm_q8_ln(int src_kind, const void* d_src, const Q8RowMeta* d_rm
     if (K != 384 && K != 1536) return fail(CS_ERR_UNSUPPORTED, "LayerNorm-fused quantised product: K=%u not built (384, 1536)", K);
     if (src_kind != Q8_SRC_SPLIT && src_kind != QR_PREQUANT) return fail(CS_ERR_BAD_ARG, "LayerNorm-fused quantised product: bad source kind");
     if (src_kind == Q8_SRC_SPLIT && K != 384) return fail(CS_ERR_UNSUPPORTED, "LayerNorm-fused quantised product: quantise-on-load is built for K = 384");
-    // CS_Q8_LN_WAVES=4: two blocks of four waves per CU (64 rows, double buffer) instead of one block of eight (128 rows, four-stage
-    // ring).  Measured (profiles/r05_q8_ln_waves_ab.log): out-proj 97.7 -> 101.9 us, FFN-down 103 -> 107.7: two independent blocks do
-    // not overlap what eight lockstep waves leave exposed — the double buffer loses more than the independence returns.  Opt-in.
+    // CS_Q8_LN_WAVES=4: two blocks of four waves per CU (64 rows, three-stage ring, gamma / beta from global memory) instead of one
+    // block of eight (128 rows, four-stage ring).  Measured twice (profiles/r05_q8_ln_waves_ab.log; with a double buffer, then with
+    // three stages): out-proj 88.3 -> 92.5 us, FFN-down 95.0 -> 103.4 — two independent blocks do not overlap what eight waves in
+    // step leave exposed.  Opt-in.
     const char* we = std::getenv("CS_Q8_LN_WAVES");
     const bool four = we && we[0] == '4';
     static PerDeviceOnce attr;  // function attributes are per device
     CS_TRY(attr.run([&]() -> int32_t {
-        auto allow = [](auto kernel, int nst) { return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, qn_lds(nst)); };
-        CS_HIP(allow(gemm_q8_ln_kernel<Q8_SRC_SPLIT, 6, 4, 2>, 2));
-        CS_HIP(allow(gemm_q8_ln_kernel<QR_PREQUANT, 6, 4, 2>, 2));
-        CS_HIP(allow(gemm_q8_ln_kernel<QR_PREQUANT, 24, 4, 2>, 2));
+        auto allow = [](auto kernel, int nst) { return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, qn_lds(nst, nst == 3)); };
+        CS_HIP(allow(gemm_q8_ln_kernel<Q8_SRC_SPLIT, 6, 4, 3>, 3));
+        CS_HIP(allow(gemm_q8_ln_kernel<QR_PREQUANT, 6, 4, 3>, 3));
+        CS_HIP(allow(gemm_q8_ln_kernel<QR_PREQUANT, 24, 4, 3>, 3));
         CS_HIP(allow(gemm_q8_ln_kernel<Q8_SRC_SPLIT, 6, 8, 4>, 4));
         CS_HIP(allow(gemm_q8_ln_kernel<QR_PREQUANT, 6, 8, 4>, 4));
         CS_HIP(allow(gemm_q8_ln_kernel<QR_PREQUANT, 24, 8, 4>, 4));
         return CS_OK;
     }));
     auto go = [&](auto kernel, uint32_t nw, int nst) -> int32_t {
-        const size_t ldsb = (size_t)qn_lds(nst);
+        const size_t ldsb = (size_t)qn_lds(nst, nst == 3);
         const uint32_t groups = (M + 16 * nw - 1) / (16 * nw), slots = (uint32_t)q8_cus() * (nw == 4 ? 2u : 1u);
         hipLaunchKernelGGL(kernel, dim3(groups < slots ? groups : slots), dim3(64 * nw), ldsb, s, d_src, d_rmeta, d_in_range, d_wq, d_cmeta, X, ln_g, ln_b,
                            eps, M, d_range_pairs, d_out_slot);
@@ -1755,9 +1759,9 @@ int32_t launch_gemm_q8_ln(int src_kind, const void* d_src, const Q8RowMeta* d_rm
         return CS_OK;
     };
     if (four) {
-        if (src_kind == Q8_SRC_SPLIT) return go(gemm_q8_ln_kernel<Q8_SRC_SPLIT, 6, 4, 2>, 4, 2);
-        if (K == 384) return go(gemm_q8_ln_kernel<QR_PREQUANT, 6, 4, 2>, 4, 2);
-        return go(gemm_q8_ln_kernel<QR_PREQUANT, 24, 4, 2>, 4, 2);
+        if (src_kind == Q8_SRC_SPLIT) return go(gemm_q8_ln_kernel<Q8_SRC_SPLIT, 6, 4, 3>, 4, 3);
+        if (K == 384) return go(gemm_q8_ln_kernel<QR_PREQUANT, 6, 4, 3>, 4, 3);
+        return go(gemm_q8_ln_kernel<QR_PREQUANT, 24, 4, 3>, 4, 3);
     }
     if (src_kind == Q8_SRC_SPLIT) return go(gemm_q8_ln_kernel<Q8_SRC_SPLIT, 6, 8, 4>, 8, 4);
     if (K == 384) return go(gemm_q8_ln_kernel<QR_PREQUANT, 6, 8, 4>, 8, 4);
