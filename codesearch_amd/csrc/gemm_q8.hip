@@ -172,11 +172,15 @@ q8_row_slot_kernel(const uint32_t* __restrict__ seq_unit, const uint32_t* __rest
 }
 
 // The producers of a tensor (LayerNorm, attention) leave one (lo, hi) per block or wave: their reduction is the range pass.
-__global__ void __launch_bounds__(1024)
+// Several blocks, each folding a slice of the pairs and widening the slot with at most two atomics (the slot starts from
+// (+0, +0): the forward zeroes every range slot before its first kernel) — one block of 1,024 threads took 7.3 us on
+// 16-24 thousand pairs, three times per layer.
+constexpr int Q8_RR_BLOCKS = 32;
+__global__ void __launch_bounds__(256)
 q8_range_reduce_kernel(const float* __restrict__ pairs, uint32_t n, uint32_t* __restrict__ slot) {
-    __shared__ float s_lo[16], s_hi[16];
+    __shared__ float s_lo[4], s_hi[4];
     float lo = 0.0f, hi = 0.0f;
-    for (uint32_t i = threadIdx.x; i < n; i += 1024) {
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
         const float2 p = reinterpret_cast<const float2*>(pairs)[i];
         lo = fminf(lo, p.x);
         hi = fmaxf(hi, p.y);
@@ -189,9 +193,8 @@ q8_range_reduce_kernel(const float* __restrict__ pairs, uint32_t n, uint32_t* __
     if ((threadIdx.x & 63) == 0) { s_lo[threadIdx.x >> 6] = lo; s_hi[threadIdx.x >> 6] = hi; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        for (int w = 1; w < 16; ++w) { lo = fminf(lo, s_lo[w]); hi = fmaxf(hi, s_hi[w]); }
-        slot[0] = __float_as_uint(lo);
-        slot[1] = __float_as_uint(hi);
+        for (int w = 1; w < 4; ++w) { lo = fminf(lo, s_lo[w]); hi = fmaxf(hi, s_hi[w]); }
+        q8_range_update(slot, lo, hi);
     }
 }
 
@@ -1649,7 +1652,7 @@ int32_t launch_q8_quantize(int src_kind, const void* d_src, uint32_t T, uint32_t
     const dim3 grid_mm((uint32_t)(want < 1024 ? want : 1024));  // four blocks per CU: enough loads in flight, few range updates
     const dim3 grid_q((T + Q8_RB - 1) / Q8_RB);
     const bool reduced = d_range_pairs && n_pairs && !d_row_slot;  // the tensor's producer already left per-block ranges
-    if (reduced) hipLaunchKernelGGL(q8_range_reduce_kernel, dim3(1), dim3(1024), 0, s, d_range_pairs, n_pairs, d_range);
+    if (reduced) hipLaunchKernelGGL(q8_range_reduce_kernel, dim3(Q8_RR_BLOCKS), dim3(256), 0, s, d_range_pairs, n_pairs, d_range);
     if (src_kind == Q8_SRC_F32) {
         if (!reduced && d_row_slot) hipLaunchKernelGGL(q8_minmax_units_kernel<Q8_SRC_F32>, dim3((T + 31) / 32), dim3(256), 0, s, d_src, T, K, d_range, d_row_slot);
         else if (!reduced) hipLaunchKernelGGL(q8_minmax_kernel<Q8_SRC_F32>, grid_mm, dim3(256), 0, s, d_src, T, K, d_range);
@@ -1812,7 +1815,7 @@ int32_t launch_q8_range(int src_kind, const void* d_src, uint32_t T, uint32_t K,
                         const float* d_range_pairs, uint32_t n_pairs) {
     if (T == 0) return CS_OK;
     if (d_range_pairs && n_pairs) {
-        hipLaunchKernelGGL(q8_range_reduce_kernel, dim3(1), dim3(1024), 0, s, d_range_pairs, n_pairs, d_range);
+        hipLaunchKernelGGL(q8_range_reduce_kernel, dim3(Q8_RR_BLOCKS), dim3(256), 0, s, d_range_pairs, n_pairs, d_range);
     } else {
         const uint64_t units = (uint64_t)T * (K / (src_kind == Q8_SRC_F32 ? 4 : 8));
         const uint64_t want = (units + 255) / 256;
