@@ -135,7 +135,7 @@ int32_t cs_debug_gemm_q8(int32_t device, int32_t epilogue, int32_t a_split, cons
     int8_t *dXq = nullptr, *dWq = nullptr;
     Q8RowMeta* dRm = nullptr;
     Q8ColMeta* dCm = nullptr;
-    uint32_t *dF = nullptr, *dRange = nullptr;
+    uint32_t *dF = nullptr, *dRange = nullptr, *dCmT = nullptr;
     int32_t* dAcc = nullptr;
     auto run = [&]() -> int32_t {
         CS_HIP(hipMalloc(&dA, a_n * 4)); CS_HIP(hipMalloc(&dW, w_n * 4)); CS_HIP(hipMalloc(&dS, (size_t)N * 4));
@@ -154,6 +154,11 @@ int32_t cs_debug_gemm_q8(int32_t device, int32_t epilogue, int32_t a_split, cons
         }
         if (acc_out && epilogue != 5) CS_HIP(hipMalloc(&dAcc, c_n * 4));
         CS_TRY(launch_q8_pack_weight(dW, dS, dB, N, K, dWq, dCm, dF + 1, nullptr));
+        if (a_split & 16) {
+            if ((a_split & 1) || K != 384 || (epilogue != 4 && epilogue != 5)) return fail(CS_ERR_UNSUPPORTED, "cs_debug_gemm_q8: the slab kernel takes f32 rows, K = 384, epilogue 4 | 5");
+            CS_HIP(hipMalloc(&dCmT, (size_t)N * sizeof(Q8ColMeta)));
+            CS_TRY(launch_q8_cmeta_tiles(dCm, N, dCmT, nullptr));
+        }
         if (a_split & 1) {
             CS_HIP(hipMalloc(&sA, a_n * 4));
             CS_TRY(launch_split_rows(dA, sA, M, K, dF, nullptr));
@@ -167,7 +172,9 @@ int32_t cs_debug_gemm_q8(int32_t device, int32_t epilogue, int32_t a_split, cons
             uint32_t* dRange2 = nullptr;
             CS_HIP(hipMalloc(&dOut, c_n)); CS_HIP(hipMalloc(&dRm2, (size_t)M * sizeof(Q8RowMeta))); CS_HIP(hipMalloc(&dRange2, Q8_RANGE_WORDS * 4));
             CS_HIP(hipMemset(dRange2, 0, Q8_RANGE_WORDS * 4));
-            int32_t st5 = (a_split & 8) ? launch_gemm_q8_gelu_requant_from_source(dA, dRange, dWq, dCm, dB, M, N, K, dRange2, dOut, dRm2, nullptr)
+            // (a_split & 16: the slab kernel, whatever M — gemm_q8_slab.hip)
+            int32_t st5 = (a_split & 16) ? launch_gemm_q8_slab_gelu_requant(dA, dRange, dWq, dCmT, M, N, K, dRange2, dOut, dRm2, q8_gelu_table_on(), nullptr)
+                        : (a_split & 8) ? launch_gemm_q8_gelu_requant_from_source(dA, dRange, dWq, dCm, dB, M, N, K, dRange2, dOut, dRm2, nullptr)
                                         : launch_gemm_q8_gelu_requant(dXq, dRm, dWq, dCm, dB, M, N, K, dRange2, dOut, dRm2, nullptr);
             if (st5 == CS_OK && hipDeviceSynchronize() != hipSuccess) st5 = fail(CS_ERR_HIP, "requant GEMM failed");
             std::vector<int8_t> ho(c_n);
@@ -199,6 +206,9 @@ int32_t cs_debug_gemm_q8(int32_t device, int32_t epilogue, int32_t a_split, cons
             if (dAcc) CS_HIP(hipMemset(dAcc, 0, c_n * 4));
             CS_TRY(launch_gemm_q8_skinny(epi, (a_split & 1) ? Q8_SRC_SPLIT : Q8_SRC_F32, (a_split & 1) ? (const void*)sA : (const void*)dA,
                                          reinterpret_cast<const float*>(dRange), 1, dWq, dCm, dR, dC, sC, M, N, K, dF, nullptr, nullptr, nullptr));
+        } else if (a_split & 16) {  // the slab kernel (acc is not reported)
+            if (dAcc) CS_HIP(hipMemset(dAcc, 0, c_n * 4));
+            CS_TRY(launch_gemm_q8_slab_split(dA, dRange, dWq, dCmT, sC, M, N, K, dF, nullptr));
         } else if (a_split & 8) {  // the products that quantise their own rows on the way in (row-block kernel; acc is not reported)
             if (dAcc) CS_HIP(hipMemset(dAcc, 0, c_n * 4));
             CS_TRY(launch_gemm_q8_from_source(epi, (a_split & 1) ? Q8_SRC_SPLIT : Q8_SRC_F32, (a_split & 1) ? (const void*)sA : (const void*)dA, dRange,
@@ -234,7 +244,7 @@ int32_t cs_debug_gemm_q8(int32_t device, int32_t epilogue, int32_t a_split, cons
     };
     const int32_t st = run();
     for (void* p : {(void*)dA, (void*)dW, (void*)dS, (void*)dB, (void*)dR, (void*)dC, (void*)sA, (void*)sC, (void*)dXq, (void*)dWq,
-                    (void*)dRm, (void*)dCm, (void*)dF, (void*)dRange, (void*)dAcc})
+                    (void*)dRm, (void*)dCm, (void*)dF, (void*)dRange, (void*)dAcc, (void*)dCmT})
         if (p) (void)hipFree(p);
     return st;
 }

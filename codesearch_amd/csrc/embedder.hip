@@ -246,6 +246,7 @@ static int32_t create_impl(const cs_bert_config* cfg, const float* params, uint6
         if (I > 4 * H || I > 4096) s = fail(CS_ERR_UNSUPPORTED, "Failed to initialize embedding model: intermediate size above 4 x hidden or 4,096");
         if (s == CS_OK && (hipMalloc(&h->d_wq8, (size_t)cfg->layers * ql.total) != hipSuccess ||
                            hipMalloc(&h->d_cmeta, (size_t)cfg->layers * cols * sizeof(Q8ColMeta)) != hipSuccess ||
+                           hipMalloc(&h->d_cmeta_tiles, (size_t)cfg->layers * cols * sizeof(Q8ColMeta)) != hipSuccess ||
                            hipMalloc(&d_ws, (size_t)cfg->layers * cols * sizeof(float)) != hipSuccess ||
                            hipMalloc(&d_bad, sizeof(uint32_t)) != hipSuccess))
             s = fail(CS_ERR_OOM, "hipMalloc(quantised weights) failed");
@@ -262,6 +263,10 @@ static int32_t create_impl(const cs_bert_config* cfg, const float* params, uint6
             if (s == CS_OK) s = launch_q8_pack_weight(h->d_params + lo.ao_w, sc + 3 * H, h->d_params + lo.ao_b, (uint32_t)H, (uint32_t)H, wq + ql.ao, cm + 3 * H, d_bad, h->stream);
             if (s == CS_OK) s = launch_q8_pack_weight(h->d_params + lo.up_w, sc + 4 * H, h->d_params + lo.up_b, (uint32_t)I, (uint32_t)H, wq + ql.up, cm + 4 * H, d_bad, h->stream);
             if (s == CS_OK) s = launch_q8_pack_weight(h->d_params + lo.down_w, sc + 4 * H + I, h->d_params + lo.down_b, (uint32_t)H, (uint32_t)I, wq + ql.down, cm + 4 * H + I, d_bad, h->stream);
+            // QKV's and FFN-up's columns once more as structure-of-arrays tiles (the slab kernel's layout; column n of the layer at word 4 n)
+            uint32_t* ct = h->d_cmeta_tiles + ((size_t)l * cols) * 4;
+            if (s == CS_OK && (3 * H) % 128 == 0) s = launch_q8_cmeta_tiles(cm, (uint32_t)(3 * H), ct, h->stream);
+            if (s == CS_OK && I % 128 == 0 && H % 128 == 0) s = launch_q8_cmeta_tiles(cm + 4 * H, (uint32_t)I, ct + 4 * 4 * H, h->stream);
         }
         uint32_t bad = 0;
         if (s == CS_OK && (hipMemcpyAsync(&bad, d_bad, sizeof(bad), hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
@@ -333,6 +338,7 @@ void cs_embedder_destroy(cs_embedder* h) {
     if (h->d_sp_ws) (void)hipFree(h->d_sp_ws);
     if (h->d_wq8) (void)hipFree(h->d_wq8);
     if (h->d_cmeta) (void)hipFree(h->d_cmeta);
+    if (h->d_cmeta_tiles) (void)hipFree(h->d_cmeta_tiles);
     for (hipEvent_t e : h->stage_ev) (void)hipEventDestroy(e);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);

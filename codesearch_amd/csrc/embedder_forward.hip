@@ -334,6 +334,7 @@ int32_t forward_range(cs_embedder* h, hipStream_t s, uint32_t b0, uint32_t nb, u
             const Q8Layer ql = q8_layer(H, I);
             const int8_t* wq = h->d_wq8 + (size_t)l * ql.total;
             const Q8ColMeta* cm = h->d_cmeta + (size_t)l * (5 * (size_t)H + I);
+            const uint32_t* cmt = (H % 128 == 0 && I % 128 == 0) ? h->d_cmeta_tiles + (size_t)l * (5 * (size_t)H + I) * 4 : nullptr;  // (slab kernel)
             const uint32_t U = h->cur_units;
             uint32_t* rg = h->d_range + (size_t)l * 4 * Q8_RANGE_WORDS * U;
             const size_t rstep = (size_t)Q8_RANGE_WORDS * U;
@@ -382,7 +383,7 @@ int32_t forward_range(cs_embedder* h, hipStream_t s, uint32_t b0, uint32_t nb, u
                 static const bool ln_slot = [] { const char* e = std::getenv("CS_Q8_LN_SLOT"); return e && e[0] == '1'; }();
                 if (l == 0) h->q8_x_pairs = ln_pairs;
                 if (h->q8_x_pairs) CS_TRY(launch_q8_range(Q8_SRC_F32, x, T, H, rg, s, rp, h->q8_x_pairs));
-                CS_TRY(launch_gemm_q8_from_source(SH_OUT_SPLIT, Q8_SRC_F32, x, rg, wq + ql.qkv, cm, bqkv, nullptr, nullptr, qkvs, T, 3 * H, H, h->d_flag, s));  // E2
+                CS_TRY(launch_gemm_q8_from_source(SH_OUT_SPLIT, Q8_SRC_F32, x, rg, wq + ql.qkv, cm, bqkv, nullptr, nullptr, qkvs, T, 3 * H, H, h->d_flag, s, nullptr, cmt));  // E2
                 CS_TRY(mark(CS_STAGE_QKV));
                 uint32_t att_pairs = 0;
                 CS_TRY(launch_attention_sh2(qkvs, mask, ctxs, h->d_flag, nb, L, H, c.heads, s, rp, &att_pairs));  // E3
@@ -404,7 +405,8 @@ int32_t forward_range(cs_embedder* h, hipStream_t s, uint32_t b0, uint32_t nb, u
                 if (h->q8_x_pairs) CS_TRY(launch_q8_range(Q8_SRC_F32, x, T, H, rg + 2 * rstep, s, rp, h->q8_x_pairs));
                 int8_t* midq = reinterpret_cast<int8_t*>(mid);
                 Q8RowMeta* rm2 = h->d_rmeta2 + t0;
-                CS_TRY(launch_gemm_q8_gelu_requant_from_source(x, rg + 2 * rstep, wq + ql.up, cm + 4 * H, P + lo.up_b, T, I, H, rg + 3 * rstep, midq, rm2, s));  // E5
+                CS_TRY(launch_gemm_q8_gelu_requant_from_source(x, rg + 2 * rstep, wq + ql.up, cm + 4 * H, P + lo.up_b, T, I, H, rg + 3 * rstep, midq, rm2, s, nullptr,
+                                                               cmt ? cmt + 4 * 4 * H : nullptr));  // E5
                 CS_TRY(mark(CS_STAGE_FFN_UP));
                 if (q8_ln_fused_takes(T, H, I)) {  // E6 likewise
                     // (the next layer's first slot; the last layer's output is not quantised again: pairs nobody reads)

@@ -186,6 +186,41 @@ def test_row_block_products_quantise_their_own_rows(diag_lib):
     assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1][2:], outs[1][1][2:]) and np.array_equal(outs[0][2], outs[1][2])
 
 
+@pytest.mark.parametrize("M,N", [(300, 1152), (4500, 1536), (1, 128), (66000, 256), (513, 384)])
+def test_slab_kernel_leaves_the_row_block_kernels_bits(diag_lib, M, N, monkeypatch):
+    """At indexing batch sizes QKV and FFN-up run on gemm_q8_slab_kernel (a block owns 256 rows, W is the MFMA's first
+    operand, the tile leaves from registers in 16-byte stores after half-wave exchanges): the same integers and the same
+    f32 operations in the same order, so the same bits as the separate quantising pass + tile kernel — ragged slabs, n-tile
+    ranges cut between blocks (few slabs) and blocks that walk several slabs (66,000 rows) included."""
+    rng = np.random.default_rng(M + N)
+    K = 384
+    A = (rng.standard_normal((M, K)) * rng.choice([0.3, 1.0, 3.0], size=(M, 1))).astype(np.float32)
+    W, d, sc = quantize_matrix((rng.standard_normal((N, K)) * 0.05).astype(np.float32), True, True)
+    bias = (rng.standard_normal(N) * 0.1).astype(np.float32)
+    # (below 4,096 rows the comparison path is the tile kernel, whose store pass computes the GELU byte directly: the slab
+    # kernel is put on its direct form too — the table form differs from it inside a few ulps of a rounding threshold)
+    if M < 4096:
+        monkeypatch.setenv("CS_Q8_GELU_TABLE", "0")
+    # QKV: bias, split-f16 store
+    got = run_q8(diag_lib, 4, A, W, sc, bias, None, a_split=16)[0]
+    ref = run_q8(diag_lib, 4, A, W, sc, bias, None, a_split=0)[0]
+    assert np.array_equal(got, ref)
+    # FFN-up: range pass + re-quantising store pass (bytes, output parameters, row sums)
+    outs = []
+    for a_split in (16, 0):
+        C_ = np.empty((M, N), np.float32)
+        xp = np.empty(4, np.float32)
+        rows = np.empty((M, N), np.int32)
+        _lib.check_diag(diag_lib.cs_debug_gemm_q8(0, 5, a_split, A.ctypes.data_as(f32p), W.ctypes.data_as(f32p), sc.ctypes.data_as(f32p),
+                                            bias.ctypes.data_as(f32p), None, C_.ctypes.data_as(f32p), M, N, K, None,
+                                            xp.ctypes.data_as(f32p), rows.ctypes.data_as(C.POINTER(C.c_int32))))
+        outs.append((C_, xp.copy(), rows.reshape(-1)[:M].copy()))
+    assert np.array_equal(outs[0][1][2:], outs[1][1][2:])        # the output tensor's (scale, zero point)
+    assert np.array_equal(outs[0][2], outs[1][2])                # the row sums FFN-down needs
+    assert np.array_equal(outs[0][0], outs[1][0])
+    assert np.array_equal(outs[0][2], outs[0][0].astype(np.int64).sum(axis=1))
+
+
 def _unit_rows(rng, L, units):
     """row_slot of a device batch of sequences of L positions: units = [(sequences, own padded length)], in order."""
     slots = []
