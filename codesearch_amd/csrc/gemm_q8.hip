@@ -1345,19 +1345,29 @@ gemm_q8_ln_kernel(const void* __restrict__ Asrc, const Q8RowMeta* __restrict__ r
                 q8_i32x4 packed;
 #pragma unroll
                 for (int w = 0; w < 4; ++w) {
-                    uint32_t pw = 0;
+                    // four values -> one dword (gemm_q8_slab.hip's form of the same arithmetic: the reciprocal quotient lies within
+                    // 255 * 2^-23 of the true one, so only within 1e-4 of a tie does the true division decide; the integer in [0, 255]
+                    // converts and packs in one instruction, the row sum is a dot product with ones)
+                    float v[4], rt[4], d[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const int idx = 4 * w + e;
-                        const float v = idx < 8 ? (float)h0[idx] + (float)o0[idx] * kShLoInv : (float)h1[idx - 8] + (float)o1[idx - 8] * kShLoInv;
-                        const float t = v * rxs;
-                        float rt = rintf(t);
-                        if (fabsf(fabsf(t - rt) - 0.5f) < 1.0e-3f) rt = rintf(__fdiv_rn(v, xs));
-                        const float q = fminf(fmaxf(__fadd_rn(rt, xz), 0.0f), 255.0f);
-                        const int b = (int)q - 128;
-                        rowsum += b;
-                        pw |= (uint32_t)(b & 0xff) << (8 * e);
+                        v[e] = idx < 8 ? (float)h0[idx] + (float)o0[idx] * kShLoInv : (float)h1[idx - 8] + (float)o1[idx - 8] * kShLoInv;
+                        const float t = v[e] * rxs;
+                        rt[e] = rintf(t);
+                        d[e] = t - rt[e];
                     }
+                    if (fmaxf(fmaxf(fabsf(d[0]), fabsf(d[1])), fmaxf(fabsf(d[2]), fabsf(d[3]))) > 0.4999f) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (fabsf(d[e]) > 0.4999f) rt[e] = rintf(__fdiv_rn(v[e], xs));
+                    }
+                    uint32_t pw = 0;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        pw = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_amdgcn_fmed3f(__fadd_rn(rt[e], xz), 0.0f, 255.0f), e, pw);
+                    pw ^= 0x80808080u;
+                    rowsum = __builtin_amdgcn_sdot4((int)pw, 0x01010101, rowsum, false);
                     packed[w] = (int)pw;
                 }
                 a[st] = packed;

@@ -21,7 +21,7 @@
 //  * an n-tile's column metadata rides with its weights as a 2-KiB structure-of-arrays image (ws | -zw | colsum | bias: built once
 //    at create time, launch_q8_cmeta_tiles), read as 16-byte vectors for the lane's four columns; za * colsum is the accumulators'
 //    initial value, so the zero points cost one v_mad_i32_i24 per output.
-// LDS: 2 x 48 KiB weights + 2 x 2 KiB metadata (+ 16 KiB GELU byte table in the store pass): one block per CU.
+// LDS: 2 x 48 KiB weights + 3 x 2 KiB metadata (+ 16 KiB GELU byte table in the store pass): one block per CU.
 #include <cstdlib>
 
 #include "encoder.hpp"
@@ -39,7 +39,7 @@ constexpr int QS_THREADS = 512;
 constexpr int QS_WTILE = 128 * 128 * QS_KC;   // one n-tile of weights over all of K: 49,152 B
 constexpr int QS_CM_BYTES = 4 * 128 * 4;      // ws [128] | -zw [128] | colsum [128] | bias [128]
 constexpr int QS_OFF_CM = 2 * QS_WTILE;
-constexpr int QS_OFF_TBL = QS_OFF_CM + 2 * QS_CM_BYTES;
+constexpr int QS_OFF_TBL = QS_OFF_CM + 3 * QS_CM_BYTES;  // (three metadata buffers: the late waves read tile t's while tile t + 2's lands)
 constexpr int qs_lds(bool table) { return QS_OFF_TBL + (table ? QG_LDS : 0) + 128; }  // the last 128 B: the waves' extremes
 
 __global__ void __launch_bounds__(256)
@@ -85,6 +85,26 @@ __device__ __forceinline__ void qs_swap16(uint32_t& a, uint32_t& b) {  // a's od
 
 typedef uint32_t qs_u32x4 __attribute__((ext_vector_type(4)));
 
+// -DCS_Q8_STAMPS (benchmarks/build_variant.sh): wave 0 of block 3 reads the shader clock at a unit's start, behind the quantising
+// prologue, and per tile behind the MFMAs, behind the epilogue and behind the end barrier; the sums are printed at the kernel's end.
+#ifdef CS_Q8_STAMPS
+#define QS_STAMP(v)                                                                      \
+    do {                                                                                 \
+        __builtin_amdgcn_sched_barrier(0);                                               \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : : "memory");     \
+        __builtin_amdgcn_sched_barrier(0);                                               \
+    } while (0)
+#else
+#define QS_STAMP(v) do { } while (0)
+#endif
+// fragments of W requested ahead of the MFMAs that use them (left to the compiler: two reads, a full wait, four MFMAs)
+#ifndef CS_Q8_SLAB_PF
+#define CS_Q8_SLAB_PF 4
+#endif
+#ifndef CS_Q8_SLAB_NT
+#define CS_Q8_SLAB_NT 0   // (1: the split-f16 planes leave with the non-temporal policy, for A/B)
+#endif
+
 // EPI: SH_OUT_SPLIT (QKV: bias, split-f16 store) | Q8_EPI_GELU_RANGE | Q8_EPI_GELU_Q8 (the two passes of FFN-up, gemm_q8.hip)
 template <int EPI>
 __global__ void __launch_bounds__(QS_THREADS, 2)
@@ -109,7 +129,7 @@ gemm_q8_slab_kernel(const float* __restrict__ X, const int8_t* __restrict__ W, c
         const int q = wave * 6 + t, c = q >> 4, row = (q & 15) * 8 + (lane >> 3);
         woff[t] = (uint32_t)row * K + c * 128 + (((lane & 7) ^ ((row >> 1) & 7)) * 16);
     }
-    auto issue_w = [&](uint32_t nt, int b) {
+    auto issue_w = [&](uint32_t nt, int b, int cb) {
         const int8_t* src = W + (size_t)nt * 128 * K;
         char* buf = lds + b * QS_WTILE;
 #pragma unroll
@@ -120,7 +140,7 @@ gemm_q8_slab_kernel(const float* __restrict__ X, const int8_t* __restrict__ W, c
         }
         if (wave < 2)  // the tile's 2 KiB of column metadata: lane l of wave w moves bytes 1024 w + 16 l ..
             sh_glds16(reinterpret_cast<const char*>(cmt) + (size_t)nt * QS_CM_BYTES + wave * 1024 + lane * 16,
-                      lds + QS_OFF_CM + b * QS_CM_BYTES + wave * 1024);
+                      lds + QS_OFF_CM + cb * QS_CM_BYTES + wave * 1024);
     };
     // DynamicQuantizeLinear's parameters of the input tensor
     float xs, xz;
@@ -147,13 +167,25 @@ gemm_q8_slab_kernel(const float* __restrict__ X, const int8_t* __restrict__ W, c
     float ymax = -INFINITY, ya = -INFINITY, yb = INFINITY;
     float ycen = 0.0f, yhw = INFINITY;  // wave-uniform: centre and half-width (padded) of the wave's (a, b) so far
     uint32_t mx = 0;                    // packed maximum of |hi| bit patterns (sh_split_overflowed)
+#ifdef CS_Q8_STAMPS
+    unsigned long long st0 = 0, st1 = 0, st2 = 0, st3 = 0, st4 = 0, c_pro = 0, c_mfma = 0, c_epi = 0, c_bar = 0;
+    (void)st2; (void)st3; (void)st4;
+    uint32_t c_tiles = 0;
+#endif
 
+    // Waves 0-3 and waves 4-7 (a pair per SIMD) walk the tiles half a tile apart: between two barriers the first four run a tile's
+    // MFMAs and then its epilogue, the other four the PREVIOUS tile's epilogue and then this tile's MFMAs — the matrix pipe works
+    // for one wave of a SIMD while the vector pipe works for the other (run in step, both waited for the pipe together and then
+    // left it idle through both epilogues: stamps in profiles/r06_q8_slab_stamps.log).
+    const int late = wave >> 2;
+    q8_i32x4 acc[2][8];
     for (uint32_t unit = blockIdx.x; unit < total_units; unit += gridDim.x) {
         const uint32_t mt = unit / parts, nt0 = (unit % parts) * per;
         const uint32_t nt1 = nt0 + per < ntiles ? nt0 + per : ntiles;
         if (nt0 >= nt1) continue;
         const uint32_t m0 = mt * QS_ROWS + wave * 32;  // this wave's first row
-        issue_w(nt0, 0);
+        QS_STAMP(st0);
+        issue_w(nt0, 0, 0);
         // the wave's 32 rows x 384 k as MFMA operands, quantised on the way in: fragment (c, s, i) = row 16 i + l15, k 128 c + 64 s + 16 g ..
         q8_i32x4 a[QS_KC][2][2];
         int rowsum[2] = {0, 0};
@@ -176,20 +208,29 @@ gemm_q8_slab_kernel(const float* __restrict__ X, const int8_t* __restrict__ W, c
                     q8_i32x4 packed;
 #pragma unroll
                     for (int w = 0; w < 4; ++w) {
-                        uint32_t pw = 0;
+                        // sat_u8(round_half_even(x / x_scale) + x_zp) - 128, four values -> one dword.  The quotient by a reciprocal:
+                        // |x / x_scale| <= 255 and two roundings (the reciprocal, the product) put it within 255 * 2^-23 = 3.1e-5 of the
+                        // true quotient, so its rint IS the true quotient's unless it lies within 1e-4 of a tie — there (a few dwords in
+                        // a hundred, wave-wide) the true division decides.  Same bytes as q8_quantize_kernel.
+                        const sh_f32x4 x = v[s][i][w];
+                        float rt[4], d[4];
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            // sat_u8(round_half_even(x / x_scale) + x_zp): the quotient by a reciprocal, the true division only where the
-                            // two could round apart (|x / x_scale| <= 255: they differ by < 1e-4) — gemm_q8_rows_kernel's arithmetic
-                            const float x = v[s][i][w][e];
-                            const float t = x * rxs;
-                            float rt = rintf(t);
-                            if (fabsf(fabsf(t - rt) - 0.5f) < 1.0e-3f) rt = rintf(__fdiv_rn(x, xs));
-                            const float q = fminf(fmaxf(__fadd_rn(rt, xz), 0.0f), 255.0f);
-                            const int b = (int)q - 128;
-                            rowsum[i] += b;
-                            pw |= (uint32_t)(b & 0xff) << (8 * e);
+                            const float t = x[e] * rxs;
+                            rt[e] = rintf(t);
+                            d[e] = t - rt[e];
                         }
+                        if (fmaxf(fmaxf(fabsf(d[0]), fabsf(d[1])), fmaxf(fabsf(d[2]), fabsf(d[3]))) > 0.4999f) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                if (fabsf(d[e]) > 0.4999f) rt[e] = rintf(__fdiv_rn(x[e], xs));
+                        }
+                        uint32_t pw = 0;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)  // (the operand is an integer in [0, 255]: the conversion is exact)
+                            pw = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_amdgcn_fmed3f(__fadd_rn(rt[e], xz), 0.0f, 255.0f), e, pw);
+                        pw ^= 0x80808080u;
+                        rowsum[i] = __builtin_amdgcn_sdot4((int)pw, 0x01010101, rowsum[i], false);
                         packed[w] = (int)pw;
                     }
                     a[c][s][i] = packed;
@@ -205,75 +246,114 @@ gemm_q8_slab_kernel(const float* __restrict__ X, const int8_t* __restrict__ W, c
         int osum[2] = {0, 0};  // store pass: the row's sum of stored bytes over this unit's tiles (this lane's columns)
         if (EPI == Q8_EPI_GELU_RANGE && nt0 == 0 && tid < QS_ROWS && mt * QS_ROWS + tid < M) rq.rmeta_out[mt * QS_ROWS + tid].rowsum = 0;
         __syncthreads();  // W tile nt0 has landed (vmcnt(0) precedes the barrier)
+        QS_STAMP(st1);
+#ifdef CS_Q8_STAMPS
+        c_pro += st1 - st0;
+#endif
 
-        for (uint32_t nt = nt0; nt < nt1; ++nt) {
-            const uint32_t n0 = nt * 128;
-            const int b = (nt - nt0) & 1;
-            const char* cur = lds + b * QS_WTILE;
-            const char* cmb = lds + QS_OFF_CM + b * QS_CM_BYTES + g * 16;  // + 64 j: this lane's four columns of tile j; + 512 per array
-            if (nt + 1 < nt1) issue_w(nt + 1, b ^ 1);  // lands under this tile's MFMAs and epilogue
-            q8_i32x4 acc[2][8];
+        // y = float(acc with the zero points back in) * (x_scale * W_scale) + bias for tile j, both row groups: four consecutive columns
+        // each (one set of metadata reads for the two)
+        auto y8_of = [&](const char* cmb, int j, sh_f32x4& y0, sh_f32x4& y1) {
+            const sh_f32x4 ws4 = *reinterpret_cast<const sh_f32x4*>(cmb + 64 * j);
+            const q8_i32x4 nzw4 = *reinterpret_cast<const q8_i32x4*>(cmb + 512 + 64 * j);
+            const sh_f32x4 b4 = *reinterpret_cast<const sh_f32x4*>(cmb + 1536 + 64 * j);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {  // za * colsum: the accumulators' start
-                const q8_i32x4 cs4 = *reinterpret_cast<const q8_i32x4*>(cmb + 1024 + 64 * j);
-                q8_i32x4 u;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) asm("v_mul_i32_i24 %0, %1, %2" : "=v"(u[r]) : "v"(nza), "v"(cs4[r]));
-                acc[0][j] = u;
-                acc[1][j] = u;
+            for (int r = 0; r < 4; ++r) {
+                const float sc = __fmul_rn(xs, ws4[r]);
+                int c0, c1;
+                asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(c0) : "v"(nzw4[r]), "v"(rowsum_c[0]), "v"(acc[0][j][r]));
+                asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(c1) : "v"(nzw4[r]), "v"(rowsum_c[1]), "v"(acc[1][j][r]));
+                y0[r] = __fadd_rn(__fmul_rn((float)c0, sc), b4[r]);
+                y1[r] = __fadd_rn(__fmul_rn((float)c1, sc), b4[r]);
             }
+        };
+        const uint32_t T = nt1 - nt0;
+        // (the accumulators carry nothing from the previous unit or through the prologue: said so, or the register allocator keeps them live there)
 #pragma unroll
-            for (int c = 0; c < QS_KC; ++c)
+        for (int j = 0; j < 8; ++j) acc[0][j] = acc[1][j] = q8_i32x4{0, 0, 0, 0};
+        // sub-step u: the early waves run tile t's MFMAs at u = 2 t and its epilogue at 2 t + 1, the late waves one sub-step behind;
+        // a barrier after every odd u (W tile t + 1, issued at u = 2 t, has landed; both halves are done with W tile t)
+        for (uint32_t u = 0; u <= 2 * T; ++u) {
+            if (!(u & 1) && (u >> 1) + 1 < T) issue_w(nt0 + (u >> 1) + 1, ((u >> 1) + 1) & 1, ((u >> 1) + 1) % 3);
+            const uint32_t v = u - (uint32_t)late;  // (late waves at u = 0: nothing yet)
+            const uint32_t t = v >> 1;
+            if (v <= 2 * T - 1 && !(v & 1)) {
+                // ---- tile t's MFMAs
+                const char* cur = lds + (t & 1) * QS_WTILE;
+                const char* cmb = lds + QS_OFF_CM + (t % 3) * QS_CM_BYTES + g * 16;  // + 64 j: this lane's four columns of tile j; + 512 per array
 #pragma unroll
-                for (int s = 0; s < 2; ++s) {
-                    const char* wp = cur + c * 16384 + (s ? f1 : f0);
+                for (int j = 0; j < 8; ++j) {  // za * colsum: the accumulators' start
+                    const q8_i32x4 cs4 = *reinterpret_cast<const q8_i32x4*>(cmb + 1024 + 64 * j);
+                    q8_i32x4 uu;
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const q8_i32x4 w = *reinterpret_cast<const q8_i32x4*>(wp + j * 2048);
+                    for (int r = 0; r < 4; ++r) asm("v_mul_i32_i24 %0, %1, %2" : "=v"(uu[r]) : "v"(nza), "v"(cs4[r]));
+                    acc[0][j] = uu;
+                    acc[1][j] = uu;
+                }
+                {
+                    // fragment f = (chunk f / 16, k-step (f / 8) % 2, tile f % 8): one read feeds two MFMAs; PF reads stay in flight ahead of
+                    // the MFMAs that use them (the scheduling groups below pin that order)
+                    constexpr int PF = CS_Q8_SLAB_PF;
+                    auto wfrag = [&](int f) {
+                        return *reinterpret_cast<const q8_i32x4*>(cur + (f >> 4) * 16384 + (((f >> 3) & 1) ? f1 : f0) + (f & 7) * 2048);
+                    };
+                    __builtin_amdgcn_sched_barrier(0);
+                    q8_i32x4 wq[PF];
+#pragma unroll
+                    for (int f = 0; f < PF; ++f) wq[f] = wfrag(f);
+#pragma unroll
+                    for (int f = 0; f < 48; ++f) {
+                        const int c = f >> 4, s = (f >> 3) & 1, j = f & 7;
+                        const q8_i32x4 w = wq[f % PF];
+                        if (f + PF < 48) wq[f % PF] = wfrag(f + PF);
                         acc[0][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(w, a[c][s][0], acc[0][j], 0, 0, 0);
                         acc[1][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(w, a[c][s][1], acc[1][j], 0, 0, 0);
                     }
-                }
-            // The accumulators are read through inline asm below, which the compiler's hazard recogniser does not pad: an MFMA's
-            // result must not be read for up to 12 wait states (cdna_hip_programming.md 5.7).  Every later read of acc goes through
-            // this statement's outputs, so none is scheduled above it.
-            asm volatile("s_nop 15"
-                         : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[0][2]), "+v"(acc[0][3]), "+v"(acc[0][4]), "+v"(acc[0][5]),
-                           "+v"(acc[0][6]), "+v"(acc[0][7]), "+v"(acc[1][0]), "+v"(acc[1][1]), "+v"(acc[1][2]), "+v"(acc[1][3]),
-                           "+v"(acc[1][4]), "+v"(acc[1][5]), "+v"(acc[1][6]), "+v"(acc[1][7]));
-            // y = float(acc with the zero points back in) * (x_scale * W_scale) + bias for row group i, tile j: four consecutive columns
-            auto y4_of = [&](int i, int j) {
-                const sh_f32x4 ws4 = *reinterpret_cast<const sh_f32x4*>(cmb + 64 * j);
-                const q8_i32x4 nzw4 = *reinterpret_cast<const q8_i32x4*>(cmb + 512 + 64 * j);
-                const sh_f32x4 b4 = *reinterpret_cast<const sh_f32x4*>(cmb + 1536 + 64 * j);
-                sh_f32x4 y;
+                    __builtin_amdgcn_sched_group_barrier(0x100, PF, 0);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    int corr;
-                    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(corr) : "v"(nzw4[r]), "v"(rowsum_c[i]), "v"(acc[i][j][r]));
-                    y[r] = __fadd_rn(__fmul_rn((float)corr, __fmul_rn(xs, ws4[r])), b4[r]);
+                    for (int f = 0; f < 48; ++f) {
+                        if (f + PF < 48) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
-                return y;
-            };
-            if constexpr (EPI == Q8_EPI_GELU_RANGE) {
-                // max y per element; the two neighbours a, b of the GELU's minimum (q8_params_gelu) only when this row group holds a
-                // value inside the window (a, b) the wave has so far (gemm_q8_rows_kernel's fold)
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    float ys[32], off = INFINITY;
+                // The accumulators are read through inline asm in the epilogue, which the compiler's hazard recogniser does not pad: an
+                // MFMA's result must not be read for up to 12 wait states (cdna_hip_programming.md 5.7).  Every later read of acc goes
+                // through this statement's outputs, so none is scheduled above it.
+                asm volatile("s_nop 15"
+                             : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[0][2]), "+v"(acc[0][3]), "+v"(acc[0][4]), "+v"(acc[0][5]),
+                               "+v"(acc[0][6]), "+v"(acc[0][7]), "+v"(acc[1][0]), "+v"(acc[1][1]), "+v"(acc[1][2]), "+v"(acc[1][3]),
+                               "+v"(acc[1][4]), "+v"(acc[1][5]), "+v"(acc[1][6]), "+v"(acc[1][7]));
+#ifdef CS_Q8_STAMPS
+                QS_STAMP(st2);
+                c_mfma += st2 - st1; st1 = st2;
+#endif
+            } else if (v <= 2 * T - 1) {
+                // ---- tile t's epilogue
+                const uint32_t n0 = (nt0 + t) * 128;
+                const char* cmb = lds + QS_OFF_CM + (t % 3) * QS_CM_BYTES + g * 16;
+                if constexpr (EPI == Q8_EPI_GELU_RANGE) {
+                    // max y per element; the two neighbours a, b of the GELU's minimum (q8_params_gelu) only when this tile holds a
+                    // value inside the window (a, b) the wave has so far (gemm_q8_rows_kernel's fold).  v_max3 / v_min3 by hand: through
+                    // fmaxf / fminf the compiler quiets every operand first (a v_max_f32 x, x per value: 330 of the fold's 1,000
+                    // instructions); a NaN y is dropped by the hardware min / max all the same.
+                    float ys[64], off = INFINITY;
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
-                        const sh_f32x4 y = y4_of(i, j);
+                        sh_f32x4 y0, y1;
+                        y8_of(cmb, j, y0, y1);
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            ys[4 * j + r] = y[r];
-                            ymax = fmaxf(ymax, y[r]);
-                            off = fminf(off, fabsf(y[r] - ycen));
+                            ys[8 * j + r] = y0[r];
+                            ys[8 * j + 4 + r] = y1[r];
+                            const float d0 = y0[r] - ycen, d1 = y1[r] - ycen;
+                            asm("v_max3_f32 %0, %0, %1, %2" : "+v"(ymax) : "v"(y0[r]), "v"(y1[r]));
+                            asm("v_min3_f32 %0, %0, |%1|, |%2|" : "+v"(off) : "v"(d0), "v"(d1));
                         }
                     }
                     if (!(yhw < INFINITY) || __any(off < yhw)) {
 #pragma unroll
-                        for (int e = 0; e < 32; ++e) {
+                        for (int e = 0; e < 64; ++e) {
                             ya = ys[e] <= kGeluArgMin ? fmaxf(ya, ys[e]) : ya;
                             yb = ys[e] >= kGeluArgMin ? fminf(yb, ys[e]) : yb;
                         }
@@ -286,66 +366,110 @@ gemm_q8_slab_kernel(const float* __restrict__ X, const int8_t* __restrict__ W, c
                         ycen = 0.5f * (wa + wb);             // (NaN / inf while a side is still empty: yhw stays inf)
                         yhw = 0.5f * (wb - wa) + 1.0e-5f;
                     }
-                }
-            } else if constexpr (EPI == Q8_EPI_GELU_Q8) {
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    uint32_t d[8];
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const sh_f32x4 y = y4_of(i, j);
-                        uint32_t sel[4];
-                        if (tb_inv_w != 0.0f) {  // (block-uniform) the byte by table
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                uint32_t idx = (uint32_t)(int)fmaf(y[r], tb_inv_w, tb_c0);   // y < QG_YL: negative -> the last entry
-                                idx = idx < (uint32_t)(QG_NB - 1) ? idx : (uint32_t)(QG_NB - 1);
-                                const Q8GeluEntry e = gtbl[idx];
-                                sel[r] = y[r] >= e.thr ? e.w >> 8 : e.w;
-                            }
-                        } else {
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) sel[r] = (uint32_t)q8_gelu_byte(y[r], gs, rgs, gz128);
-                        }
-                        // the four low bytes -> one dword (columns 16 j + 4 g .. + 3 of the row)
+                } else if constexpr (EPI == Q8_EPI_GELU_Q8) {
+                    uint32_t d0[8], d1[8];
+                    // the four low bytes -> one dword (columns 16 j + 4 g .. + 3 of the row)
+                    auto pack4 = [](const uint32_t (&sel)[4]) {
                         const uint32_t p01 = __builtin_amdgcn_perm(sel[1], sel[0], 0x0c0c0400u);
                         const uint32_t p23 = __builtin_amdgcn_perm(sel[3], sel[2], 0x0c0c0400u);
-                        d[j] = __builtin_amdgcn_perm(p23, p01, 0x05040100u);
-                        osum[i] = __builtin_amdgcn_sdot4((int)d[j], 0x01010101, osum[i], false);
-                    }
-                    // 4 x 4 transpose over the row's four lanes: lane g ends with tile g's 16 bytes in d[0..3], tile 4 + g's in d[4..7]
-                    qs_swap32(d[0], d[2]); qs_swap32(d[1], d[3]); qs_swap32(d[4], d[6]); qs_swap32(d[5], d[7]);
-                    qs_swap16(d[0], d[1]); qs_swap16(d[2], d[3]); qs_swap16(d[4], d[5]); qs_swap16(d[6], d[7]);
-                    const uint32_t row = m0 + i * 16 + l15;
-                    if (row < M) {
-                        int8_t* dst = rq.out + (size_t)row * N + n0 + 16 * g;
-                        *reinterpret_cast<qs_u32x4*>(dst) = qs_u32x4{d[0], d[1], d[2], d[3]};
-                        *reinterpret_cast<qs_u32x4*>(dst + 64) = qs_u32x4{d[4], d[5], d[6], d[7]};
-                    }
-                }
-            } else {
+                        return __builtin_amdgcn_perm(p23, p01, 0x05040100u);
+                    };
+                    if (tb_inv_w != 0.0f) {  // (block-uniform) the byte by table
 #pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    const uint32_t row = m0 + i * 16 + l15;
-                    _Float16* line = Cs + ((size_t)row * (N / 32) + (n0 >> 5)) * 64;  // + 64 per 32 columns; hi [32] | lo [32]
+                        for (int j = 0; j < 8; ++j) {
+                            sh_f32x4 y0, y1;
+                            y8_of(cmb, j, y0, y1);
+                            uint32_t s0[4], s1[4];
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                uint32_t i0 = (uint32_t)(int)fmaf(y0[r], tb_inv_w, tb_c0), i1 = (uint32_t)(int)fmaf(y1[r], tb_inv_w, tb_c0);
+                                i0 = i0 < (uint32_t)(QG_NB - 1) ? i0 : (uint32_t)(QG_NB - 1);   // y < QG_YL: negative -> the last entry
+                                i1 = i1 < (uint32_t)(QG_NB - 1) ? i1 : (uint32_t)(QG_NB - 1);
+                                const Q8GeluEntry e0 = gtbl[i0], e1 = gtbl[i1];
+                                s0[r] = y0[r] >= e0.thr ? e0.w >> 8 : e0.w;
+                                s1[r] = y1[r] >= e1.thr ? e1.w >> 8 : e1.w;
+                            }
+                            d0[j] = pack4(s0);
+                            d1[j] = pack4(s1);
+                            if (j & 1) __builtin_amdgcn_sched_barrier(0);  // (two tiles' reads in flight: unrestrained, all eight are hoisted and spill)
+                        }
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            sh_f32x4 y0, y1;
+                            y8_of(cmb, j, y0, y1);
+                            uint32_t s0[4], s1[4];
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                s0[r] = (uint32_t)q8_gelu_byte(y0[r], gs, rgs, gz128);
+                                s1[r] = (uint32_t)q8_gelu_byte(y1[r], gs, rgs, gz128);
+                            }
+                            d0[j] = pack4(s0);
+                            d1[j] = pack4(s1);
+                        }
+                    }
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        uint32_t (&d)[8] = i ? d1 : d0;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) osum[i] = __builtin_amdgcn_sdot4((int)d[j], 0x01010101, osum[i], false);
+                        // 4 x 4 transpose over the row's four lanes: lane g ends with tile g's 16 bytes in d[0..3], tile 4 + g's in d[4..7]
+                        qs_swap32(d[0], d[2]); qs_swap32(d[1], d[3]); qs_swap32(d[4], d[6]); qs_swap32(d[5], d[7]);
+                        qs_swap16(d[0], d[1]); qs_swap16(d[2], d[3]); qs_swap16(d[4], d[5]); qs_swap16(d[6], d[7]);
+                        const uint32_t row = m0 + i * 16 + l15;
+                        if (row < M) {
+                            int8_t* dst = rq.out + (size_t)row * N + n0 + 16 * g;
+                            *reinterpret_cast<qs_u32x4*>(dst) = qs_u32x4{d[0], d[1], d[2], d[3]};
+                            *reinterpret_cast<qs_u32x4*>(dst + 64) = qs_u32x4{d[4], d[5], d[6], d[7]};
+                        }
+                    }
+                } else {
+                    const uint32_t row0 = m0 + l15, row1 = m0 + 16 + l15;
+                    // + 64 per 32 columns; hi [32] | lo [32]
+                    _Float16* line0 = Cs + ((size_t)row0 * (N / 32) + (n0 >> 5)) * 64 + ((g & 1) ? 16 + 4 * (g - 1) : 4 * g);
+                    _Float16* line1 = line0 + (size_t)16 * (N / 32) * 64;
+                    auto put = [&](_Float16* dst, bool live, const uint32_t (&a0)[2], const uint32_t (&a1)[2]) {
+                        if (!live) return;
+                        // (plain stores: an instruction writes 16 rows x 64 B — half lines — and the non-temporal policy nearly halves the
+                        // write rate of that shape, 5.9 -> 3.4 TB/s: profiles/r02_hbm_write_probe.log; QKV 116 -> 89 us)
+#if CS_Q8_SLAB_NT
+                        __builtin_nontemporal_store(qs_u32x4{a0[0], a0[1], a1[0], a1[1]}, reinterpret_cast<qs_u32x4*>(dst));
+#else
+                        *reinterpret_cast<qs_u32x4*>(dst) = qs_u32x4{a0[0], a0[1], a1[0], a1[1]};
+#endif
+                    };
 #pragma unroll
                     for (int jp = 0; jp < 4; ++jp) {  // a line = tiles 2 jp, 2 jp + 1
-                        uint32_t h0[2], l0[2], h1[2], l1[2];
-                        qs_split4(y4_of(i, 2 * jp), h0, l0, mx);
-                        qs_split4(y4_of(i, 2 * jp + 1), h1, l1, mx);
-                        // one exchange between the lane pairs (g, g ^ 1): even g ends with columns 4 g .. 4 g + 7 of the line's first tile,
-                        // odd g with columns 4 (g - 1) .. of its second tile — 16 bytes per lane and plane
-                        qs_swap16(h0[0], h1[0]); qs_swap16(h0[1], h1[1]);
-                        qs_swap16(l0[0], l1[0]); qs_swap16(l0[1], l1[1]);
-                        if (row < M) {
-                            _Float16* dst = line + 64 * jp + ((g & 1) ? 16 + 4 * (g - 1) : 4 * g);
-                            __builtin_nontemporal_store(qs_u32x4{h0[0], h0[1], h1[0], h1[1]}, reinterpret_cast<qs_u32x4*>(dst));
-                            __builtin_nontemporal_store(qs_u32x4{l0[0], l0[1], l1[0], l1[1]}, reinterpret_cast<qs_u32x4*>(dst + 32));
+                        sh_f32x4 ya0, ya1, yb0, yb1;
+                        y8_of(cmb, 2 * jp, ya0, ya1);
+                        y8_of(cmb, 2 * jp + 1, yb0, yb1);
+#pragma unroll
+                        for (int i = 0; i < 2; ++i) {
+                            uint32_t h0[2], l0[2], h1[2], l1[2];
+                            qs_split4(i ? ya1 : ya0, h0, l0, mx);
+                            qs_split4(i ? yb1 : yb0, h1, l1, mx);
+                            // one exchange between the lane pairs (g, g ^ 1): even g ends with columns 4 g .. 4 g + 7 of the line's first tile,
+                            // odd g with columns 4 (g - 1) .. of its second tile — 16 bytes per lane and plane
+                            qs_swap16(h0[0], h1[0]); qs_swap16(h0[1], h1[1]);
+                            qs_swap16(l0[0], l1[0]); qs_swap16(l0[1], l1[1]);
+                            _Float16* dst = (i ? line1 : line0) + 64 * jp;
+                            put(dst, (i ? row1 : row0) < M, h0, h1);
+                            put(dst + 32, (i ? row1 : row0) < M, l0, l1);
                         }
                     }
                 }
+#ifdef CS_Q8_STAMPS
+                QS_STAMP(st3);
+                c_epi += st3 - st1; st1 = st3; ++c_tiles;
+#endif
             }
-            __syncthreads();  // W tile nt + 1 has landed; every wave is done with this tile's weights and metadata
+            if (u & 1) {
+                __syncthreads();
+#ifdef CS_Q8_STAMPS
+                QS_STAMP(st4);
+                c_bar += st4 - st1; st1 = st4;
+#endif
+            }
         }
         if constexpr (EPI == Q8_EPI_GELU_Q8) {
 #pragma unroll
@@ -363,6 +487,7 @@ gemm_q8_slab_kernel(const float* __restrict__ X, const int8_t* __restrict__ W, c
                 }
             }
         }
+        __syncthreads();  // the late waves' last epilogue has read its metadata: the next unit may stage over it
     }
     if (EPI == Q8_EPI_GELU_RANGE) {
 #pragma unroll
@@ -382,6 +507,10 @@ gemm_q8_slab_kernel(const float* __restrict__ X, const int8_t* __restrict__ W, c
         }
     }
     if (EPI == SH_OUT_SPLIT && flag && sh_split_overflowed(mx)) atomicOr(flag, 1u);
+#ifdef CS_Q8_STAMPS
+    if (blockIdx.x == 3 && (tid == 0 || tid == 256))
+        printf("q8 slab EPI %d N %u wave %d: %u tiles, prologue %llu  mfma %llu  epilogue %llu  end barrier %llu\n", EPI, N, wave, c_tiles, c_pro, c_mfma, c_epi, c_bar);
+#endif
 }
 
 int qs_cus() {
