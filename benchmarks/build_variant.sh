@@ -8,16 +8,16 @@ cd "$(dirname "$0")/../codesearch_amd/csrc"
 make -s
 mkdir -p ../variants/obj_$name
 objs=""
-for o in $(ls *.o | grep -v "\.diag\.o$"); do
+for o in $(make -s objs); do
   src=${o%.o}.hip
   use=$o
   for f in "$@"; do
     if [ "$f" == "$src" ]; then
-      /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function -ffp-contract=on -fno-fast-math $extra -c $src -o ../variants/obj_$name/$o
+      /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function -ffp-contract=on -fno-fast-math -fvisibility=hidden -fvisibility-inlines-hidden $extra -c $src -o ../variants/obj_$name/$o
       use=../variants/obj_$name/$o
     fi
   done
   objs="$objs $use"
 done
-/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o ../variants/libcsgpu_$name.so $objs
+/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -Wl,--version-script=exports.map -o ../variants/libcsgpu_$name.so $objs
 echo built codesearch_amd/variants/libcsgpu_$name.so

@@ -133,7 +133,6 @@ SIGNATURES = {
     "cs_embedder_set_gemm_mode": (C.c_int32, [vp, C.c_int32]),
     "cs_embedder_gemm_mode": (C.c_int32, [vp]),
     "cs_embedder_debug_counters": (C.c_int32, [vp, u64p, u64p, u64p]),
-    "cs_embedder_small_forward_counters": (C.c_int32, [vp, u64p, u64p]),
     "cs_tokenizer_create": (C.c_int32, [C.c_char_p, C.c_uint64, C.c_int32, C.c_uint32, C.POINTER(vp)]),
     "cs_tokenizer_create_from_file": (C.c_int32, [C.c_char_p, C.c_int32, C.c_uint32, C.POINTER(vp)]),
     "cs_tokenizer_create_from_json": (C.c_int32, [C.c_char_p, C.c_uint32, C.POINTER(vp)]),
@@ -170,6 +169,7 @@ SIGNATURES = {
 
 # include/codesearch_gpu_diag.h: exported by libcsgpu_diag.so only (operator-level parity tests, benchmarks/)
 DIAG_SIGNATURES = {
+    "cs_debug_small_forward_counters": (C.c_int32, [vp, u64p, u64p]),
     "cs_debug_gemm_time": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                        C.c_int32, f64p]),
     "cs_debug_gemm_q8": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32, f32p, f32p, f32p, f32p, f32p, f32p, C.c_uint32,

@@ -32,6 +32,7 @@ namespace cs {
 // defaults of CS_ATTN_PIPE per head width (same-box A/B of the four forms: profiles/r05_attention_loop_forms_ab.log)
 constexpr int kAttnPipeDefault32 = 2, kAttnPipeDefault64 = 3;
 
+#ifdef CS_DIAGNOSTICS  // (the whole-sequence kernel: CS_ATTN_SHX1=0, A/B only — the product library runs the super-tile kernel below)
 // ---- whole sequence of one (sequence, head) resident in LDS (CS_ATTN_SHX1=0; head_dim 32) ----------
 // head_dim 32 = one k-chunk, so K and V of a (token, head) are one 128-B line [32 hi | 32 lo] each,
 // exactly the layout the matrix pipe wants for K: the prologue is pure LDS-DMA (no conversion, no
@@ -194,6 +195,7 @@ attention_sh2_kernel(const _Float16* __restrict__ qkvs, const int32_t* __restric
     AT_STAMP(2);
     if (ovf && flag) atomicOr(flag, 1u);
 }
+#endif  // CS_DIAGNOSTICS
 
 // ---- head_dim 32 * NC (NC = 2: BGE-base / BGE-large / mxbai-large): keys in super-tiles of 128 ------------
 // The body lives in attention_shx_body.hpp (shared with small_forward.hip).
@@ -236,6 +238,15 @@ int32_t launch_shx_one(dim3 grid, size_t lds, hipStream_t s, const ShxArgs& a) {
 
 template <int NC>
 int32_t launch_shx(int pos, int pipe, dim3 grid, size_t lds, hipStream_t s, const ShxArgs& a) {
+#ifndef CS_DIAGNOSTICS
+    // the product library holds each head width's default form only (the other tile-loop forms are bit-identical and slower:
+    // profiles/r05_attention_loop_forms_ab.log; the diagnostic library keeps them for CS_ATTN_PIPE)
+    constexpr int P = NC == 1 ? kAttnPipeDefault32 : kAttnPipeDefault64;
+    (void)pipe;
+    if (pos == 1) return launch_shx_one<NC, 1, P>(grid, lds, s, a);
+    if (pos == 2) return launch_shx_one<NC, 2, P>(grid, lds, s, a);
+    return launch_shx_one<NC, 0, P>(grid, lds, s, a);
+#else
     if (pipe == 3) {
         if (pos == 1) return launch_shx_one<NC, 1, 3>(grid, lds, s, a);
         if (pos == 2) return launch_shx_one<NC, 2, 3>(grid, lds, s, a);
@@ -254,6 +265,7 @@ int32_t launch_shx(int pos, int pipe, dim3 grid, size_t lds, hipStream_t s, cons
     if (pos == 1) return launch_shx_one<NC, 1, 0>(grid, lds, s, a);
     if (pos == 2) return launch_shx_one<NC, 2, 0>(grid, lds, s, a);
     return launch_shx_one<NC, 0, 0>(grid, lds, s, a);
+#endif
 }
 
 }  // namespace
@@ -273,7 +285,7 @@ int32_t launch_attention_sh2(const _Float16* qkv_split, const int32_t* mask, voi
     const size_t Lp = (L + 31) & ~31u;
     // CS_ATTN_PIPE (attention_shx_body.hpp, PIPE): 0 the rolled tile loop, 1 two key tiles in flight per wave, 2 the super-tile's
     // four tiles written out (immediate LDS offsets, cross-half max on the VALU)
-    static const int pipe_env = [] { const char* e = std::getenv("CS_ATTN_PIPE"); return e && e[0] >= '0' && e[0] <= '3' ? e[0] - '0' : -1; }();
+    static const int pipe_env = [] { const char* e = cs_lab_env("CS_ATTN_PIPE"); return e && e[0] >= '0' && e[0] <= '3' ? e[0] - '0' : -1; }();
     ShxArgs a{qkv_split, mask, static_cast<_Float16*>(ctx_split), flag, L, H, 0.0f, 1u, range_out, seq_unit, unit_len, alibi_log2, window};
     if (dh == 64) {  // two 128-B lines per (token, head): keys staged 128 at a time
         const size_t lds = 2 * 2 * 128 * 128 + Lp * sizeof(float) + 16;
@@ -287,13 +299,13 @@ int32_t launch_attention_sh2(const _Float16* qkv_split, const int32_t* mask, voi
     // 64 (four blocks per CU, one per 128 queries, so K/V staging of one block hides behind the softmax of
     // the others) — 256 x 256 tokens 12.75 -> 12.54 ms per forward although K/V are staged once per query
     // block.  CS_ATTN_SHX1=0 selects the whole-sequence kernel (attention_sh2_kernel) for A/B.
-    static const bool shx1 = [] { const char* e = std::getenv("CS_ATTN_SHX1"); return !(e && e[0] == '0'); }();
+    static const bool shx1 = [] { const char* e = cs_lab_env("CS_ATTN_SHX1"); return !(e && e[0] == '0'); }();
     if (shx1 || pos) {
         // CS_ATTN_LDS_PAD (diagnostics): extra dynamic LDS per block, i.e. fewer co-resident blocks per CU — how the kernel's
         // time moves with occupancy says whether a tile's dependent chain (latency) or issue slots bound it
-        static const size_t lds_pad = [] { const char* e = std::getenv("CS_ATTN_LDS_PAD"); return e ? (size_t)std::atol(e) : (size_t)0; }();
+        static const size_t lds_pad = [] { const char* e = cs_lab_env("CS_ATTN_LDS_PAD"); return e ? (size_t)std::atol(e) : (size_t)0; }();
         const size_t lds1 = 2 * 1 * 128 * 128 + Lp * sizeof(float) + 16 + lds_pad;
-        static const bool pack_heads = [] { const char* e = std::getenv("CS_ATTN_PACK_HEADS"); return !(e && e[0] == '0'); }();
+        static const bool pack_heads = [] { const char* e = cs_lab_env("CS_ATTN_PACK_HEADS"); return !(e && e[0] == '0'); }();
         uint32_t hb = !pack_heads ? 1u : (Lp <= 32 ? 4u : (Lp <= 64 ? 2u : 1u));  // heads per block (kernel comment)
         while (heads % hb) hb >>= 1;
         a.scale_log2e = (1.0f / sqrtf(32.0f)) * kLog2e;
@@ -303,6 +315,9 @@ int32_t launch_attention_sh2(const _Float16* qkv_split, const int32_t* mask, voi
         if (range_pairs) *range_pairs = (heads / hb) * B * ((L + 127) / 128) * 4;
         return CS_OK;
     }
+#ifndef CS_DIAGNOSTICS
+    return fail(CS_ERR_UNSUPPORTED, "attention: no kernel for head_dim %u", dh);  // (not reached: shx1 is constant here)
+#else
     const size_t lds = 2 * Lp * 128 + Lp * sizeof(float) + 16;
     if (lds > 160 * 1024 - 64) return fail(CS_ERR_UNSUPPORTED, "sequence length %u exceeds the LDS-resident K/V limit", L);
     static PerDeviceOnce attr_set;  // function attributes are per device
@@ -315,6 +330,7 @@ int32_t launch_attention_sh2(const _Float16* qkv_split, const int32_t* mask, voi
                        static_cast<_Float16*>(ctx_split), flag, L, H, (1.0f / sqrtf(32.0f)) * kLog2e);
     CS_HIP(hipGetLastError());
     return CS_OK;
+#endif
 }
 
 }  // namespace cs

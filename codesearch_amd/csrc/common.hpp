@@ -6,6 +6,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -19,6 +20,19 @@ std::string& last_error_ref();
 int32_t fail(int32_t code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
 // onnx_reader.cpp: 1 when an initialiser's name contains `needle`, 0 when none does, -1 when the file cannot be read
 int onnx_initializer_mentions(const char* path, const char* needle);
+
+// Environment knobs.  A deployment's knobs (CODESEARCH_BATCH_SIZE, CS_ENCODER_*, CS_INDEX_SPLIT, the routing
+// thresholds ...) are read with std::getenv in every build.  LABORATORY knobs — tile shapes, rejected kernel variants, fault
+// injection, A/B switches of experiments that are decided — exist only in the diagnostic build (libcsgpu_diag.so,
+// -DCS_DIAGNOSTICS): in the product library cs_lab_env is a constant null and the branches behind it compile away.
+inline const char* cs_lab_env(const char* name) {
+#ifdef CS_DIAGNOSTICS
+    return std::getenv(name);
+#else
+    (void)name;
+    return nullptr;
+#endif
+}
 
 #define CS_HIP(expr)                                                                      \
     do {                                                                                  \

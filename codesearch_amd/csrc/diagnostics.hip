@@ -374,7 +374,7 @@ int32_t cs_debug_gemm_time(int32_t device, int32_t mode, int32_t epilogue, uint3
         CS_TRY(launch_synth_fill(dA, M, K, 11, 0, nullptr));
         CS_TRY(launch_synth_fill(dW, N, K, 12, 0, nullptr));
         CS_TRY(launch_synth_fill(dR, M, N, 13, 0, nullptr));
-        if (std::getenv("CS_DEBUG_GEMM_ZERO")) {  // all-zero operands: what the clock (DVFS), not the schedule, is worth
+        if (cs_lab_env("CS_DEBUG_GEMM_ZERO")) {  // all-zero operands: what the clock (DVFS), not the schedule, is worth
             CS_HIP(hipMemset(dA, 0, a_n * 4)); CS_HIP(hipMemset(dW, 0, w_n * 4)); CS_HIP(hipMemset(dR, 0, c_n * 4));
         }
         CS_HIP(hipMemset(dB, 0, (size_t)N * 4));

@@ -4,6 +4,9 @@
 // embeddings.  Mini-batching and the shutdown poll follow embed_batch_chunked
 // (embedder.rs:266-295).
 #include "embedder_state.hpp"
+#ifdef CS_DIAGNOSTICS
+#include "../../include/codesearch_gpu_diag.h"
+#endif
 
 using namespace cs;
 using namespace cs::emb;
@@ -201,13 +204,15 @@ static int32_t create_impl(const cs_bert_config* cfg, const float* params, uint6
         if (s == CS_OK && !wflag) {  // may the one-accumulator kernels scale w_hi by 2^11 in f16?
             bool fit = false;
             s = sh_weights_fit_wide(h->d_wsplit, (uint64_t)cfg->layers * sl.total, h->d_flag, &fit, h->stream);
-            const char* e = std::getenv("CS_GEMM_WIDE");  // "0": never
+            const char* e = cs_lab_env("CS_GEMM_WIDE");  // "0": never
             h->wide_ok = fit && !(e && e[0] == '0');
         }
         bool denorm_ok = false;  // the split format relies on exact f16-subnormal MFMA inputs
         if (s == CS_OK) s = sh_denorm_selftest(&denorm_ok, h->stream);
         if (s == CS_OK && !denorm_ok) { h->gemm_mode = CS_GEMM_F32; h->split_unavailable = true; }
-        // the one-launch forward of short queries (small_forward.hip) reads the layers' pointers from a device table
+#ifdef CS_DIAGNOSTICS
+        // the one-launch forward of short queries (small_forward.hip: bit-identical to the launch chain and slower, so it lives in the
+        // diagnostic library only) reads the layers' pointers from a device table
         if (s == CS_OK && !cs_arch_gated(cfg->arch) && small_forward_supported((uint32_t)H, (uint32_t)I, cfg->heads, 1, 1)) {
             std::vector<SfLayer> tab(cfg->layers);
             for (uint32_t l = 0; l < cfg->layers; ++l) {
@@ -222,9 +227,10 @@ static int32_t create_impl(const cs_bert_config* cfg, const float* params, uint6
                 hipMemcpyAsync(h->d_sf_layers, tab.data(), tab.size() * sizeof(SfLayer), hipMemcpyHostToDevice, h->stream) != hipSuccess ||
                 hipStreamSynchronize(h->stream) != hipSuccess)
                 s = fail(CS_ERR_OOM, "the one-launch forward's layer table could not be set up");
-            if (s == CS_OK && std::getenv("CS_SMALL_FORWARD_DEBUG") && hipMalloc(&h->d_sf_dbg, (96 * 3 + 8) * sizeof(uint64_t)) != hipSuccess)
+            if (s == CS_OK && cs_lab_env("CS_SMALL_FORWARD_DEBUG") && hipMalloc(&h->d_sf_dbg, (96 * 3 + 8) * sizeof(uint64_t)) != hipSuccess)
                 h->d_sf_dbg = nullptr;
         }
+#endif
         if (const char* env = std::getenv("CS_ENCODER_STREAMS")) {
             h->streams_forced = true;
             const int v = std::atoi(env);
@@ -436,11 +442,13 @@ int32_t cs_embedder_debug_counters(cs_embedder* h, uint64_t* split_forwards, uin
     return CS_OK;
 }
 
-int32_t cs_embedder_small_forward_counters(cs_embedder* h, uint64_t* forwards, uint64_t* fallbacks) {
+#ifdef CS_DIAGNOSTICS
+int32_t cs_debug_small_forward_counters(cs_embedder* h, uint64_t* forwards, uint64_t* fallbacks) {
     if (!h) return fail(CS_ERR_BAD_ARG, "null embedder handle");
     if (forwards) *forwards = h->sf_forwards;
     if (fallbacks) *fallbacks = h->sf_fallbacks;
     return CS_OK;
 }
+#endif
 
 }  // extern "C"

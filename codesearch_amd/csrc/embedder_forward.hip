@@ -112,20 +112,20 @@ int32_t forward_range(cs_embedder* h, hipStream_t s, uint32_t b0, uint32_t nb, u
     const uint32_t ln_pairs = (T + 3) / 4;
     // several quantisation units in a batch the row-block kernels take: every product quantises its own rows with their
     // unit's parameters, the producers' pairs are reduced per unit (LayerNorm: a pair per row)
-    static const bool q8_mu_on = [] { const char* e = std::getenv("CS_Q8_ROWS_UNITS"); return !(e && e[0] == '0'); }();
+    static const bool q8_mu_on = [] { const char* e = cs_lab_env("CS_Q8_ROWS_UNITS"); return !(e && e[0] == '0'); }();
     const bool q8_mu = q8 && q8_mu_on && h->cur_units > 1 && q8_rows_from_source(T, H) && T <= h->cap_range_pairs;
     a.range_rows = q8_mu;
     _Float16* xs = reinterpret_cast<_Float16*>(h->d_xs + t0 * H);
     _Float16* ctxs = reinterpret_cast<_Float16*>(ctx);
     _Float16* mids = reinterpret_cast<_Float16*>(mid);
     const SplitLayer sl = split_layer(c);
-    static const uint32_t split_k_min = [] { const char* e = std::getenv("CS_GEMM_SPLITK_MIN_M"); return e ? (uint32_t)std::atoi(e) : 1100u; }();
-    static const uint32_t split_k_max = [] { const char* e = std::getenv("CS_GEMM_SPLITK_MAX_M"); return e ? (uint32_t)std::atoi(e) : 6144u; }();
+    static const uint32_t split_k_min = [] { const char* e = cs_lab_env("CS_GEMM_SPLITK_MIN_M"); return e ? (uint32_t)std::atoi(e) : 1100u; }();
+    static const uint32_t split_k_max = [] { const char* e = cs_lab_env("CS_GEMM_SPLITK_MAX_M"); return e ? (uint32_t)std::atoi(e) : 6144u; }();
     // device us per forward, fused / FFN-down in 3 K slices / out-proj too: 1,280 rows 1320 / 1020 / 971, 2,048
     // 1331 / 1052 / 1021, 4,096 1538 / 1311 / 1328, 6,144 1841 / 1619 / 1654, 8,192 2210 / 2264 / -
     // two slices up to 10,240 rows: 7,168 rows 2048 -> 1891 us, 8,192 2203 -> 2060, 10,240 2443 -> 2369, 12,288 3034 -> 3167
-    static const uint32_t split_k_max2 = [] { const char* e = std::getenv("CS_GEMM_SPLITK_MAX2_M"); return e ? (uint32_t)std::atoi(e) : 10240u; }();
-    static const uint32_t split_k_ao_max = [] { const char* e = std::getenv("CS_GEMM_SPLITK_AO_MAX_M"); return e ? (uint32_t)std::atoi(e) : 2560u; }();
+    static const uint32_t split_k_max2 = [] { const char* e = cs_lab_env("CS_GEMM_SPLITK_MAX2_M"); return e ? (uint32_t)std::atoi(e) : 10240u; }();
+    static const uint32_t split_k_ao_max = [] { const char* e = cs_lab_env("CS_GEMM_SPLITK_AO_MAX_M"); return e ? (uint32_t)std::atoi(e) : 2560u; }();
     // stage profile: an event after each kernel (only on the one-stream path, see forward())
     auto mark = [&](int tag) -> int32_t {
         if (!h->stage_profile) return CS_OK;
@@ -147,7 +147,7 @@ int32_t forward_range(cs_embedder* h, hipStream_t s, uint32_t b0, uint32_t nb, u
     // runs beside it on the second stream (measured, device ms per forward, wide / 128 x 128: 32 x 256 tokens 2.67 /
     // 2.08, 64 x 256 4.01 / 3.57 — one stream, N = 384 layers leave half the chip idle — 128 x 256 5.95 / 6.40,
     // 256 x 256 11.4 / 12.5).
-    static const uint32_t wide_min_m = [] { const char* e = std::getenv("CS_GEMM_WIDE_MIN_M"); return e ? (uint32_t)std::atoll(e) : 12288u; }();
+    static const uint32_t wide_min_m = [] { const char* e = cs_lab_env("CS_GEMM_WIDE_MIN_M"); return e ? (uint32_t)std::atoll(e) : 12288u; }();
     auto takes_wide = [&](uint32_t Mr, uint32_t Nn, uint32_t Kk) {
         if (!h->wide_ok || !wide_min_m || !gemm_wide_supported(Nn, Kk) || Nn % 384) return false;
         const uint32_t tiles = ((Mr + 127) / 128) * (Nn / 384);
@@ -156,7 +156,7 @@ int32_t forward_range(cs_embedder* h, hipStream_t s, uint32_t b0, uint32_t nb, u
     // Mid-size launches (the reference's 32-chunk calls: 8,192 token rows): the 128 x 128 grid is 1.1 rounds of
     // blocks for QKV (576 tiles on 512 slots); 128 x 192 tiles at two blocks per CU make it ONE round (384 tiles for
     // QKV, 512 for FFN-up).  Taken when that single round is at least 70 % full.
-    static const bool mid192 = [] { const char* e = std::getenv("CS_GEMM_WIDE_MID"); return !(e && e[0] == '0'); }();
+    static const bool mid192 = [] { const char* e = cs_lab_env("CS_GEMM_WIDE_MID"); return !(e && e[0] == '0'); }();
     auto takes_192 = [&](uint32_t Mr, uint32_t Nn, uint32_t Kk) {
         if (!mid192 || !h->wide_ok || !gemm_wide_supported(Nn, Kk) || h->streams_in_flight >= 2) return false;
         const uint32_t tiles = ((Mr + 127) / 128) * (Nn / 192);
@@ -253,8 +253,8 @@ int32_t forward_range(cs_embedder* h, hipStream_t s, uint32_t b0, uint32_t nb, u
     // ---- a few short sequences (under 200 token rows: the query side) ----
     // small_path.hip: LayerNorm as the prologue of the dense layer that reads it, FFN-down as four K slices summed by the
     // LayerNorm that follows: 62 launches per 12-layer forward instead of 86, none of them pulling 196 KB through one CU
-    // (CS_SMALL_PATH=0: the general small-batch kernels below).  CS_SMALL_FORWARD=1: the same arithmetic as ONE launch
-    // (small_forward.hip) — bit-identical, measured slower than the launches: opt-in.
+    // (CS_SMALL_PATH=0: the general small-batch kernels below).  Diagnostic library, CS_SMALL_FORWARD=1: the same arithmetic as ONE
+    // launch (small_forward.hip) — bit-identical, measured slower than the launches.
     h->sf_ran = false;
     const char* e0 = std::getenv("CS_SMALL_PATH");  // (read per forward: tests flip it mid-process)
     const bool sp_on = !(e0 && e0[0] == '0');
@@ -264,10 +264,11 @@ int32_t forward_range(cs_embedder* h, hipStream_t s, uint32_t b0, uint32_t nb, u
         float* xa = h->d_sp_ws + (size_t)4 * SP_MAX_ROWS * H;        // [T][H]
         float* y = h->d_xs + t0 * H;                                  // [T][H] (the split copy of x is not used on this path)
         _Float16* qkvs = reinterpret_cast<_Float16*>(qkv);
-        const char* e1 = std::getenv("CS_SMALL_FORWARD");  // (read per forward: tests and A/B runs flip it mid-process)
+#ifdef CS_DIAGNOSTICS
+        const char* e1 = cs_lab_env("CS_SMALL_FORWARD");  // (read per forward: tests and A/B runs flip it mid-process)
         if (e1 && e1[0] == '1' && h->d_sf_layers && !h->sf_off && !h->stage_profile && small_forward_supported(H, I, c.heads, T, L)) {
             uint32_t hb = L <= 32 ? 4u : (L <= 64 ? 2u : 1u);  // heads per attention block, as launch_attention_sh2 packs them
-            if (const char* ph = std::getenv("CS_ATTN_PACK_HEADS")) if (ph[0] == '0') hb = 1;
+            if (const char* ph = cs_lab_env("CS_ATTN_PACK_HEADS")) if (ph[0] == '0') hb = 1;
             while (c.heads % hb) hb >>= 1;
             SfArgs sa{};
             sa.ids = a.ids; sa.mask = mask; sa.word = a.word; sa.pos = a.pos; sa.type0 = a.type0; sa.emb_g = a.g; sa.emb_b = a.b;
@@ -283,6 +284,7 @@ int32_t forward_range(cs_embedder* h, hipStream_t s, uint32_t b0, uint32_t nb, u
             CS_TRY(launch_row_kernel(2, a, H, s));  // E7 + E8
             return CS_OK;
         }
+#endif
         _Float16* ctxs2 = ctxs;
         _Float16* mids2 = reinterpret_cast<_Float16*>(mid);
         const SplitLayer sl2 = split_layer(c);
@@ -380,7 +382,7 @@ int32_t forward_range(cs_embedder* h, hipStream_t s, uint32_t b0, uint32_t nb, u
                 // (q8_x_pairs == 0: the LayerNorm-fused product that wrote x widened this tensor's slot itself — CS_Q8_LN_SLOT=1; measured:
                 // what the consumers save on the reduction launch, 4 us each, the producers pay for the block's meeting and its
                 // agent-scope update, profiles/r05_q8_ln_epilogue_ab.log: opt-in.  Default: pairs + a reduction launch)
-                static const bool ln_slot = [] { const char* e = std::getenv("CS_Q8_LN_SLOT"); return e && e[0] == '1'; }();
+                static const bool ln_slot = [] { const char* e = cs_lab_env("CS_Q8_LN_SLOT"); return e && e[0] == '1'; }();
                 if (l == 0) h->q8_x_pairs = ln_pairs;
                 if (h->q8_x_pairs) CS_TRY(launch_q8_range(Q8_SRC_F32, x, T, H, rg, s, rp, h->q8_x_pairs));
                 CS_TRY(launch_gemm_q8_from_source(SH_OUT_SPLIT, Q8_SRC_F32, x, rg, wq + ql.qkv, cm, bqkv, nullptr, nullptr, qkvs, T, 3 * H, H, h->d_flag, s, nullptr, cmt));  // E2
@@ -547,9 +549,9 @@ int32_t forward_range(cs_embedder* h, hipStream_t s, uint32_t b0, uint32_t nb, u
             }
             a.g = P + lo.ao_ln_g; a.b = P + lo.ao_ln_b;
             // N = 384 at indexing batch sizes: dense layer + residual + LayerNorm in one kernel (gemm_wide.hip)
-            static const bool ln_fuse_on = [] { const char* e = std::getenv("CS_GEMM_WIDE_LN"); return !(e && e[0] == '0'); }();
+            static const bool ln_fuse_on = [] { const char* e = cs_lab_env("CS_GEMM_WIDE_LN"); return !(e && e[0] == '0'); }();
             const bool fuse_ln = ln_fuse_on && H == 384 && takes_wide(T, H, H);
-            static const bool split_resid_on = [] { const char* e = std::getenv("CS_GEMM_WIDE_LN_SPLIT_RESID"); return !(e && e[0] == '0'); }();
+            static const bool split_resid_on = [] { const char* e = cs_lab_env("CS_GEMM_WIDE_LN_SPLIT_RESID"); return !(e && e[0] == '0'); }();
             const bool split_resid = fuse_ln && split_resid_on;  // every N = 384 layer of this forward is fused or none is
             if (fuse_ln) {
                 // the residual stream is carried in split form alone between the fused layers (read from xs, no f32
@@ -575,7 +577,7 @@ int32_t forward_range(cs_embedder* h, hipStream_t s, uint32_t b0, uint32_t nb, u
                 // into the first 2I columns of the workspace, then value * silu(gate) into its last I columns — E6's operand
                 _Float16* gated = reinterpret_cast<_Float16*>(mid + (size_t)T * 2 * I);
                 const float* bup = h->d_bup + (size_t)l * 2 * I;
-                static const bool gate_fused = [] { const char* e = std::getenv("CS_NOMIC_GATE_FUSED"); return !(e && e[0] == '0'); }();
+                static const bool gate_fused = [] { const char* e = cs_lab_env("CS_NOMIC_GATE_FUSED"); return !(e && e[0] == '0'); }();
                 const bool w384 = takes_wide(T, 2 * I, H), w192 = !w384 && takes_192(T, 2 * I, H);
                 if (gate_fused && (w384 || w192)) {  // the gate as the product's epilogue: the raw [T, 2I] tensor never exists
                     CS_TRY(launch_gemm_wide(jina ? GW_OUT_GEGLU : GW_OUT_SWIGLU, xs, ws + sl.up, bup, nullptr, nullptr, gated, T, 2 * I, H, h->d_flag, s, w192 ? 192 : 0));
@@ -656,7 +658,7 @@ int32_t forward(cs_embedder* h, uint32_t B, uint32_t L, int mode) {
     // 24,576 5267 / 4916, 32,768 6517 / 6275, 49,152 9568 / 9437); below that it only multiplies launches
     // of kernels that already leave the chip part-empty.
     static const uint64_t stream_min_tokens = [] {
-        const char* e = std::getenv("CS_ENCODER_STREAM_MIN_TOKENS");
+        const char* e = cs_lab_env("CS_ENCODER_STREAM_MIN_TOKENS");
         return e ? (uint64_t)std::atoll(e) : (uint64_t)20000;
     }();
     h->stage_tag.clear();

@@ -846,7 +846,7 @@ int32_t launch_row_kernel(int which, const EncoderLaunch& a, uint32_t H, hipStre
 static int gemm_variant() {
     static int v = -1;
     if (v < 0) {
-        const char* e = std::getenv("CS_GEMM_VARIANT");  // 0 = plain, 1 = pipelined (default)
+        const char* e = cs_lab_env("CS_GEMM_VARIANT");  // 0 = plain, 1 = pipelined (default)
         v = e ? std::atoi(e) : 1;
     }
     return v;

@@ -345,7 +345,7 @@ q8_pack_weight_kernel(const float* __restrict__ W, const float* __restrict__ sca
 // (Q8_EPI_GELU_Q8) recomputes the same values — same instruction sequence, same bits — and stores them already
 // quantised with that range, with their row sums: the next layer's operand (100 MB).
 static uint32_t gelu_table_on_env() {
-    const char* e = std::getenv("CS_Q8_GELU_TABLE");  // (read per launch: A/B scripts and tests flip it mid-process)
+    const char* e = cs_lab_env("CS_Q8_GELU_TABLE");  // (read per launch: A/B scripts and tests flip it mid-process)
     return !(e && e[0] == '0');
 }
 
@@ -1562,7 +1562,7 @@ static uint32_t q8_persistent_grid(uint32_t slots) {
 // The row-block kernel (gemm_q8_rows_kernel) takes K = 384 layers from rows_min_m rows on: below that a row block per CU
 // leaves most of the chip idle and the tile-per-block kernel spreads the same work over more CUs.  CS_Q8_ROWS=0: never.
 static bool q8_rows_takes(uint32_t M, uint32_t K) {
-    static const int min_m = [] { const char* e = std::getenv("CS_Q8_ROWS"); return e ? std::atoi(e) : 4096; }();
+    static const int min_m = [] { const char* e = cs_lab_env("CS_Q8_ROWS"); return e ? std::atoi(e) : 4096; }();
     return K == 128 * QR_KC && min_m > 0 && M >= (uint32_t)min_m;
 }
 static int q8_cus() {
@@ -1604,7 +1604,7 @@ static int32_t launch_rows(const void* d_xq, const Q8RowMeta* d_rmeta, const int
 // (lo, hi) pairs are left in d_range_pairs for the quantisation that follows — or, with d_out_slot, the waves widen that range
 // slot themselves (zeroed by the caller at the start of the forward) and *out_pairs = 0: no reduction launch behind the kernel.
 bool q8_ln_fused_takes(uint32_t M, uint32_t N, uint32_t K) {
-    const char* e = std::getenv("CS_Q8_LN_FUSED");  // (read per call: tests and A/B scripts flip it mid-process)
+    const char* e = cs_lab_env("CS_Q8_LN_FUSED");  // (read per call: tests and A/B scripts flip it mid-process)
     return !(e && e[0] == '0') && N == (uint32_t)QN_N && (K == 384 || K == 1536) && q8_rows_takes(M, 384);
 }
 int32_t launch_gemm_q8_ln(int src_kind, const void* d_src, const Q8RowMeta* d_rmeta, const uint32_t* d_in_range, const int8_t* d_wq,
@@ -1618,15 +1618,19 @@ int32_t launch_gemm_q8_ln(int src_kind, const void* d_src, const Q8RowMeta* d_rm
     // CS_Q8_LN_WAVES=4: two blocks of four waves per CU (64 rows, three-stage ring, gamma / beta from global memory) instead of one
     // block of eight (128 rows, four-stage ring).  Measured twice (profiles/r05_q8_ln_waves_ab.log; with a double buffer, then with
     // three stages): out-proj 88.3 -> 92.5 us, FFN-down 95.0 -> 103.4 — two independent blocks do not overlap what eight waves in
-    // step leave exposed.  Opt-in.
-    const char* we = std::getenv("CS_Q8_LN_WAVES");
+    // step leave exposed.  Diagnostic library only.
+#ifdef CS_DIAGNOSTICS
+    const char* we = cs_lab_env("CS_Q8_LN_WAVES");
     const bool four = we && we[0] == '4';
+#endif
     static PerDeviceOnce attr;  // function attributes are per device
     CS_TRY(attr.run([&]() -> int32_t {
         auto allow = [](auto kernel, int nst) { return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, qn_lds(nst, nst == 3)); };
+#ifdef CS_DIAGNOSTICS
         CS_HIP(allow(gemm_q8_ln_kernel<Q8_SRC_SPLIT, 6, 4, 3>, 3));
         CS_HIP(allow(gemm_q8_ln_kernel<QR_PREQUANT, 6, 4, 3>, 3));
         CS_HIP(allow(gemm_q8_ln_kernel<QR_PREQUANT, 24, 4, 3>, 3));
+#endif
         CS_HIP(allow(gemm_q8_ln_kernel<Q8_SRC_SPLIT, 6, 8, 4>, 4));
         CS_HIP(allow(gemm_q8_ln_kernel<QR_PREQUANT, 6, 8, 4>, 4));
         CS_HIP(allow(gemm_q8_ln_kernel<QR_PREQUANT, 24, 8, 4>, 4));
@@ -1641,11 +1645,13 @@ int32_t launch_gemm_q8_ln(int src_kind, const void* d_src, const Q8RowMeta* d_rm
         if (out_pairs) *out_pairs = d_out_slot ? 0 : groups * nw;
         return CS_OK;
     };
+#ifdef CS_DIAGNOSTICS
     if (four) {
         if (src_kind == Q8_SRC_SPLIT) return go(gemm_q8_ln_kernel<Q8_SRC_SPLIT, 6, 4, 3>, 4, 3);
         if (K == 384) return go(gemm_q8_ln_kernel<QR_PREQUANT, 6, 4, 3>, 4, 3);
         return go(gemm_q8_ln_kernel<QR_PREQUANT, 24, 4, 3>, 4, 3);
     }
+#endif
     if (src_kind == Q8_SRC_SPLIT) return go(gemm_q8_ln_kernel<Q8_SRC_SPLIT, 6, 8, 4>, 8, 4);
     if (K == 384) return go(gemm_q8_ln_kernel<QR_PREQUANT, 6, 8, 4>, 8, 4);
     return go(gemm_q8_ln_kernel<QR_PREQUANT, 24, 8, 4>, 8, 4);
@@ -1687,7 +1693,7 @@ int32_t launch_gemm_q8(int epi, const int8_t* d_xq, const Q8RowMeta* d_rmeta, co
 }
 
 bool q8_rows_from_source(uint32_t M, uint32_t K) {
-    static const bool on = [] { const char* e = std::getenv("CS_Q8_ROWS_SRC"); return !(e && e[0] == '0'); }();
+    static const bool on = [] { const char* e = cs_lab_env("CS_Q8_ROWS_SRC"); return !(e && e[0] == '0'); }();
     return on && q8_rows_takes(M, K);
 }
 
@@ -1736,7 +1742,7 @@ int32_t launch_gemm_q8_from_source(int epi, int src_kind, const void* d_src, con
 }
 
 uint32_t q8_skinny_max_m() {
-    static const uint32_t v = [] { const char* e = std::getenv("CS_Q8_SKINNY_MAX_M"); return e ? (uint32_t)std::atoll(e) : 512u; }();
+    static const uint32_t v = [] { const char* e = cs_lab_env("CS_Q8_SKINNY_MAX_M"); return e ? (uint32_t)std::atoll(e) : 512u; }();
     return v;
 }
 

@@ -556,7 +556,7 @@ int32_t launch_q8_cmeta_tiles(const Q8ColMeta* d_cmeta, uint32_t N, uint32_t* d_
 
 bool q8_slab_takes(uint32_t M, uint32_t N, uint32_t K) {
     // below ~8k rows the slabs x n-tile parts no longer cover the chip and the 128-row blocks spread the same work over more CUs
-    static const int min_m = [] { const char* e = std::getenv("CS_Q8_SLAB_MIN_M"); return e ? std::atoi(e) : 8192; }();
+    static const int min_m = [] { const char* e = cs_lab_env("CS_Q8_SLAB_MIN_M"); return e ? std::atoi(e) : 8192; }();
     return K == 128 * QS_KC && N % 128 == 0 && N > 0 && min_m > 0 && M >= (uint32_t)min_m;
 }
 

@@ -250,7 +250,7 @@ int32_t launch_gemm_split(int epi, const _Float16* A, const _Float16* W, const f
     const uint32_t kc = K / 32;
     static int skinny_max_m = -1;
     if (skinny_max_m < 0) {
-        const char* e = std::getenv("CS_GEMM_SKINNY_MAX_M");  // 0 disables the small-M kernel
+        const char* e = cs_lab_env("CS_GEMM_SKINNY_MAX_M");  // 0 disables the small-M kernel
         skinny_max_m = e ? std::atoi(e) : 1100;
     }
     if ((int64_t)M <= skinny_max_m) {
@@ -267,7 +267,7 @@ int32_t launch_gemm_split(int epi, const _Float16* A, const _Float16* W, const f
         // (4 x 4 tiles per block: 1017 at 512 rows, 1297 at 1024: never the fastest)
         static int wide_from = -1;
         if (wide_from < 0) {
-            const char* e = std::getenv("CS_GEMM_SKINNY_WIDE_M");  // rows from which a block owns 2 x 2 tiles
+            const char* e = cs_lab_env("CS_GEMM_SKINNY_WIDE_M");  // rows from which a block owns 2 x 2 tiles
             wide_from = e ? std::atoi(e) : 200;
         }
         if ((int64_t)M < wide_from) CS_SKINNY(1, 1);

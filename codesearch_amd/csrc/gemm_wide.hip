@@ -550,7 +550,7 @@ static int32_t gemm_wide_launch(int epi, const _Float16* A, const _Float16* W, c
         if (hipGetDevice(&dev) == hipSuccess &&
             hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n >= 8)
             cus = n / 8 * 8;  // whole XCD octets: slot -> XCD mapping survives the persistent stride
-        if (std::getenv("CS_GEMM_WIDE_DEBUG")) {
+        if (cs_lab_env("CS_GEMM_WIDE_DEBUG")) {
             int nb = -1;
             (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, gemm_wide_kernel<SH_OUT_SPLIT, 0, WCN>, G::THREADS, G::LDS);
             fprintf(stderr, "gemm_wide<WCN=%d>: %d threads, %d B LDS, occupancy %d blocks per CU\n", WCN, G::THREADS, G::LDS, nb);
@@ -620,17 +620,20 @@ static int32_t gemm_wide_impl(int epi, const _Float16* A, const _Float16* W, con
                               const float* ln_g, const float* ln_b, float ln_eps, int shape = 0, uint32_t ln_flags = 0) {
     if (!gemm_wide_supported(N, K)) return fail(CS_ERR_UNSUPPORTED, "wide split GEMM needs N %% 192 == 0 and K %% 32 == 0 (N=%u K=%u)", N, K);
     if (M == 0) return CS_OK;
-    static const int shape_env = [] { const char* e = std::getenv("CS_GEMM_WIDE_SHAPE"); return e ? std::atoi(e) : 0; }();
+    static const int shape_env = [] { const char* e = cs_lab_env("CS_GEMM_WIDE_SHAPE"); return e ? std::atoi(e) : 0; }();
     // default: 128 x 384, except the bias -> split-store layer (the QKV projection), which four boxes measured 3-4 % faster
     // as 128 x 192 tiles, two blocks per CU (169-173 vs 175-181 us at 65,536 x 1,152 x 384; FFN-up level: profiles/
     // r04_gemm_stagger_by_cu_ab.log code 1000, r04_gemm_role_split_ab.log)
     const int want = shape ? shape : g_gemm_wide_shape ? g_gemm_wide_shape : shape_env ? shape_env : (epi == SH_OUT_SPLIT ? 192 : 384);
     const bool big = epi == GW_OUT_LN || g_gemm_wide_ablation || (want == 384 && N % 384 == 0 && N <= (uint32_t)GW_PARAM_FLOATS);
-    // MFMA shape of the main loop: 16 x 16 x 32 (this file) | 32 x 32 x 16 (gemm_wide32.hip; CS_GEMM_WIDE_MFMA=32)
-    static const int mfma_env = [] { const char* e = std::getenv("CS_GEMM_WIDE_MFMA"); return e ? std::atoi(e) : 0; }();
+#ifdef CS_DIAGNOSTICS
+    // MFMA shape of the main loop: 16 x 16 x 32 (this file) | 32 x 32 x 16 (gemm_wide32.hip, diagnostic library only: parity-green,
+    // 2-8 % slower per layer, profiles/r05_gemm_mfma_shape_ab.log; CS_GEMM_WIDE_MFMA=32)
+    static const int mfma_env = [] { const char* e = cs_lab_env("CS_GEMM_WIDE_MFMA"); return e ? std::atoi(e) : 0; }();
     const int mfma = g_gemm_wide_mfma ? g_gemm_wide_mfma : mfma_env;
     if (mfma == 32 && !g_gemm_wide_ablation && epi != GW_OUT_SWIGLU && epi != GW_OUT_GEGLU)
         return gemm_wide32_launch(big ? 4 : 2, epi, A, W, bias, resid, C, Cs, M, N, K, d_flag, s, ln_g, ln_b, ln_eps, ln_flags);
+#endif
     if (big) return gemm_wide_launch<4>(epi, A, W, bias, resid, C, Cs, M, N, K, d_flag, s, ln_g, ln_b, ln_eps, ln_flags);
     return gemm_wide_launch<2>(epi, A, W, bias, resid, C, Cs, M, N, K, d_flag, s, ln_g, ln_b, ln_eps, ln_flags);
 }

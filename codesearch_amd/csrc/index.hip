@@ -367,7 +367,7 @@ struct GrowBuffers {
 // CS_FAULT_GROW_COPY=<stage> (tests): the copy of that stage reports a failure — 1 f16 copy, 2 int8 copy, 3 bitmap clear,
 // 4 norms, 5 corpus, 6 bitmap upload
 static bool grow_fault(int stage, const cs_index* h) {
-    const char* e = std::getenv("CS_FAULT_GROW_COPY");  // (read per call: a grow is rare, and tests set it mid-process)
+    const char* e = cs_lab_env("CS_FAULT_GROW_COPY");  // (read per call: a grow is rare, and tests set it mid-process)
     return e && std::atoi(e) == stage && h->capacity != 0;
 }
 #define CS_GROW_COPY(stage, call)                                                                            \
@@ -413,7 +413,7 @@ int32_t grow(cs_index* h, uint64_t need_rows) {
     }
     if (h->use_q8) {
         const size_t tiles = ((size_t)cap + 255) / 256 * 2;  // an even number: the 256-row tile kernel reads whole pairs
-        const bool fault = std::getenv("CS_FAULT_INT8_ALLOC") != nullptr && h->capacity != 0;  // tests: the failure path
+        const bool fault = cs_lab_env("CS_FAULT_INT8_ALLOC") != nullptr && h->capacity != 0;  // tests: the failure path
         if (fault || hipMalloc(&nb.n8, tiles * 128 * h->dim) != hipSuccess || hipMalloc(&nb.nm, tiles * sizeof(float4)) != hipSuccess) {
             (void)hipGetLastError();  // no room: no int8 copy from here on (the f16 copy, or the exact paths, serve)
             if (nb.n8) (void)hipFree(nb.n8);
@@ -477,7 +477,7 @@ bool ensure_f16(cs_index* h) {
     if (!h->d_split || h->split_cap < cap256) {
         if (h->d_split) (void)hipFree(h->d_split);
         h->d_split = nullptr; h->split_rows = 0; h->split_cap = 0;
-        if (std::getenv("CS_FAULT_F16_ALLOC") != nullptr || hipMalloc(&h->d_split, cap256 * h->dim * sizeof(_Float16)) != hipSuccess) {
+        if (cs_lab_env("CS_FAULT_F16_ALLOC") != nullptr || hipMalloc(&h->d_split, cap256 * h->dim * sizeof(_Float16)) != hipSuccess) {
             (void)hipGetLastError();
             h->d_split = nullptr;
             h->f16_failed = true;
@@ -807,7 +807,7 @@ int32_t cs_index_create(uint32_t dim, uint64_t capacity_rows, int32_t device, ui
         const char* e8 = std::getenv("CS_FILTER_INT8");  // "0": filter on the f16 copy only
         h->use_q8 = h->use_split && !(e8 && e8[0] == '0');
         const char* ee = std::getenv("CS_FILTER_F16_EAGER");  // "1": keep the f16 copy beside a serving int8 copy
-        h->f16_eager = (ee && ee[0] == '1') || std::getenv("CS_FILTER_INT8_MAX_Q") != nullptr;
+        h->f16_eager = (ee && ee[0] == '1') || cs_lab_env("CS_FILTER_INT8_MAX_Q") != nullptr;
         if (const char* e = std::getenv("CS_FILTER_INT8_MAX_SPREAD")) h->q8_max_spread = (float)std::atof(e);
         if (const char* e = std::getenv("CS_FILTER_MIN_Q")) {
             h->filter_min_q = std::atoi(e);
@@ -819,7 +819,7 @@ int32_t cs_index_create(uint32_t dim, uint64_t capacity_rows, int32_t device, ui
         }
         if (const char* e = std::getenv("CS_FILTER_SINGLE_MIN_ROWS")) h->single_int8_min_rows = (uint64_t)std::atoll(e);
         if (const char* e = std::getenv("CS_FILTER_SINGLE_MIN_ROWS_LONG")) h->single_int8_min_rows_long = (uint64_t)std::atoll(e);
-        if (const char* e = std::getenv("CS_FILTER_FEW_MIN_ROWS")) h->few_queries_min_rows = h->few_queries_min_rows_short = (uint64_t)std::atoll(e);
+        if (const char* e = cs_lab_env("CS_FILTER_FEW_MIN_ROWS")) h->few_queries_min_rows = h->few_queries_min_rows_short = (uint64_t)std::atoll(e);
         if (const char* e = std::getenv("CS_SINGLE_BATCHED_MAX_ROWS")) h->single_batched_max_rows = (uint64_t)std::atoll(e);
         if (const char* e = std::getenv("CS_SCAN_PRIME_MIN_K")) h->prime_min_k = (uint32_t)std::atol(e);  // 0 = off
         if (const char* e = std::getenv("CS_SCAN_PRIME_MIN_ROWS")) h->prime_min_rows = (uint64_t)std::atoll(e);

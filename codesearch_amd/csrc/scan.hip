@@ -635,7 +635,7 @@ static int blocks_per_cu(uint32_t dim, uint32_t qtile, uint32_t kpad, bool deep)
     // 1 %; 3 and 4 blocks are no better than 5, 1 block is 6 % worse.  Four queries per pass are VALU-heavy and
     // keep the full occupancy (2.67 vs 3.22 ms).  CS_SCAN_BLOCKS_PER_CU overrides (A/B).
     static const int forced = [] {
-        const char* e = std::getenv("CS_SCAN_BLOCKS_PER_CU");
+        const char* e = cs_lab_env("CS_SCAN_BLOCKS_PER_CU");
         return e ? std::atoi(e) : 0;
     }();
     nb = nb > 8 ? 8 : nb;
@@ -653,9 +653,9 @@ static int blocks_per_cu(uint32_t dim, uint32_t qtile, uint32_t kpad, bool deep)
 // k = 128: 2.250 vs 2.270) and behind at 1M rows (330 vs 320 us), hence the second limit.
 static bool scan_deep(uint32_t dim, uint32_t qtile, uint32_t k, uint64_t n_rows) {
     static const int max_k = [] {
-        const char* off = std::getenv("CS_SCAN_DEEP");
+        const char* off = cs_lab_env("CS_SCAN_DEEP");
         if (off && off[0] == '0') return 0;
-        const char* e = std::getenv("CS_SCAN_DEEP_MAX_K");
+        const char* e = cs_lab_env("CS_SCAN_DEEP_MAX_K");
         return e ? std::atoi(e) : 64;
     }();
     if (!fast_dim(dim) || qtile != 1 || max_k == 0) return false;
@@ -780,7 +780,7 @@ static uint32_t merge_group(uint32_t k) {
     // sorted everything it loaded, short lists went through 512-key groups and a second level: 20 us for the two
     // launches against 36 us for one 4,096-key sort.)  Never fewer than 2.  CS_MERGE_GROUP_KEYS overrides (A/B).
     static const uint32_t cap = [] {
-        const char* e = std::getenv("CS_MERGE_GROUP_KEYS");
+        const char* e = cs_lab_env("CS_MERGE_GROUP_KEYS");
         const int v = e ? std::atoi(e) : 0;
         return (v >= 64 && v <= kMergeCap) ? (uint32_t)v : (uint32_t)kMergeCap;
     }();

@@ -50,7 +50,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // cosine units; bound derived in the header comment
 float filter_margin(uint32_t dim, bool subnormals_exact) {
     static const float forced = [] {
-        const char* e = std::getenv("CS_FILTER_MARGIN");
+        const char* e = cs_lab_env("CS_FILTER_MARGIN");
         return e ? (float)std::atof(e) : 0.0f;
     }();
     if (forced > 0.0f) return forced;
@@ -1508,11 +1508,11 @@ static int32_t scan_split_impl(const BatchedState& st, const SplitQueryWs& qw, c
     }));
     // int8 copy: the filter's operand whenever one exists and covers at least one tile behind phase 0
     static const uint32_t q8_max_env = [] {
-        const char* e = std::getenv("CS_FILTER_INT8_MAX_Q");  // A/B: query count up to which the int8 copy is the operand
+        const char* e = cs_lab_env("CS_FILTER_INT8_MAX_Q");  // A/B: query count up to which the int8 copy is the operand
         return e ? (uint32_t)std::atoi(e) : 0u;
     }();
     static const uint32_t q8_rw_env = [] {
-        const char* e = std::getenv("CS_FILTER_INT8_RW_MAX_Q");  // A/B: ... and up to which its resident-query kernel runs
+        const char* e = cs_lab_env("CS_FILTER_INT8_RW_MAX_Q");  // A/B: ... and up to which its resident-query kernel runs
         return e ? (uint32_t)std::atoi(e) : 0u;
     }();
     // one persistent block per (query tile, row group) slot of an XCD: at most 32 query tiles
@@ -1521,7 +1521,7 @@ static int32_t scan_split_impl(const BatchedState& st, const SplitQueryWs& qw, c
     // the same tile kernel on int8 2.30 / 2.45 / 4.36 / 7.98 (LDS traffic, not MFMA rate, paces it), the resident-query
     // kernel on int8 1.61 / 1.82 / 3.20 / 5.95 — so the tile kernel only takes what exceeds 32 query tiles.
     const uint32_t q8_rw_max = q8_rw_env ? std::min(q8_rw_env, q8_rw_limit) : q8_rw_limit;
-    static const bool rq8_on = [] { const char* e = std::getenv("CS_FILTER_INT8_RQ"); return !(e && e[0] == '0'); }();
+    static const bool rq8_on = [] { const char* e = cs_lab_env("CS_FILTER_INT8_RQ"); return !(e && e[0] == '0'); }();
     // phase 0 re-scores its rows once PER QUERY (L2 traffic nq x rows x dim x 4): 3,072 rows up to 32 queries, 1,024 above
     const uint32_t phase0 = nq <= 32 ? kFilterPhase0 : 1024u;
     const bool use_q8 = q8 && q8->d_q8 && q8->rows > kFilterPhase0 && (!q8_max_env || nq <= q8_max_env) && qw.d_q8q && qw.d_qmeta;
@@ -1531,7 +1531,7 @@ static int32_t scan_split_impl(const BatchedState& st, const SplitQueryWs& qw, c
     // second MFMA is not free even where the kernel streams — same-box A/B over 10M rows: 9 x 200 0.877 -> 0.863 ms,
     // 1 x 200 0.836 -> 0.811, but 8 x 10 0.681 -> 0.712 and 64 x 10 0.81 -> 1.04 — so short lists and more than 32
     // queries keep one plane.  CS_FILTER_INT8_Q2=0: never; =2: whenever the kernel exists (<= 64 queries).
-    static const int q2_mode = [] { const char* e = std::getenv("CS_FILTER_INT8_Q2"); return e ? std::atoi(e) : 1; }();
+    static const int q2_mode = [] { const char* e = cs_lab_env("CS_FILTER_INT8_Q2"); return e ? std::atoi(e) : 1; }();
     const bool two_planes = use_q8 && q2_mode > 0 && J <= 6 && qw.d_q8q_hi && qw.d_q8q_lo &&
                             (q2_mode >= 2 ? nq <= 64 : (nq <= 32 && k >= 48));
     hipLaunchKernelGGL(prep_queries_kernel<J>, dim3((nq + 7) / 8), dim3(256), 0, stream,
@@ -1544,13 +1544,13 @@ static int32_t scan_split_impl(const BatchedState& st, const SplitQueryWs& qw, c
     const uint32_t ntiles = (nq + SH_BN - 1) / SH_BN;
     static int wide_min = -1;  // query count from which the 256 x 256 tile kernel is used
     if (wide_min < 0) {
-        const char* e = std::getenv("CS_FILTER_WIDE_MIN_Q");
+        const char* e = cs_lab_env("CS_FILTER_WIDE_MIN_Q");
         wide_min = e ? std::atoi(e) : 129;
     }
     const bool wide = (int)nq >= wide_min;
     static int rw_mode = -1;  // resident-query / deep-ring kernel: <= 64 queries at dim 384 / 768, <= 32 at 1024
     if (rw_mode < 0) {
-        const char* e = std::getenv("CS_FILTER_RW");
+        const char* e = cs_lab_env("CS_FILTER_RW");
         rw_mode = e ? std::atoi(e) : 1;
     }
     // resident-query kernel: up to 64 queries always; above that when CS_FILTER_RW=2 (128-query tiles)
@@ -1571,19 +1571,19 @@ static int32_t scan_split_impl(const BatchedState& st, const SplitQueryWs& qw, c
     // take 5 filter phases at k = 200 (was 6) and 3 at k = 10 (was 4), 1M rows 2 at k = 10.  CS_FILTER_GROWTH / CS_FILTER_GROWTH1 restore fixed growth.
     static int growth_env = -1;
     if (growth_env < 0) {
-        const char* e = std::getenv("CS_FILTER_GROWTH");
+        const char* e = cs_lab_env("CS_FILTER_GROWTH");
         growth_env = e ? std::atoi(e) : 0;
         if (growth_env == 1) growth_env = 2;
     }
     static const uint32_t growth1_env = [] {
-        const char* e = std::getenv("CS_FILTER_GROWTH1");
+        const char* e = cs_lab_env("CS_FILTER_GROWTH1");
         return e ? (uint32_t)std::atoi(e) : 0u;
     }();
     const bool fixed_growth = growth_env > 0 || growth1_env > 1;
     const uint32_t growth = growth_env > 0 ? (uint32_t)growth_env : (k >= 48 ? 4u : 8u);
     double ratio = 0.0;  // planned D_next / D
     if (!fixed_growth && n_rows > phase) {
-        static const double gmax_env = [] { const char* e = std::getenv("CS_FILTER_GMAX"); return e ? std::atof(e) : 0.0; }();
+        static const double gmax_env = [] { const char* e = cs_lab_env("CS_FILTER_GMAX"); return e ? std::atof(e) : 0.0; }();
         // Short lists: a round from D to r D rows brings ~k r candidates times the band's factor (the tail just below tau:
         // exp(z band / sigma) = 3.3 at the 25th best of 175k isotropic rows) into a 4,096-slot buffer — r = 57 overflowed
         // at k = 25 and fell back to the exact scan (profiles/r04_filter_gmax_ab.log); 24, capped by 900 / k, keeps a
@@ -1593,9 +1593,9 @@ static int32_t scan_split_impl(const BatchedState& st, const SplitQueryWs& qw, c
         // streaming scan of so few rows costs (~100 us), not the 2.2 ms of a 10M-row corpus: one query over 100,000 rows 77 -> 65 us
         // at k = 10, 84 -> 74 at k = 20, 86 -> 78 at k = 25.  (Five to ten queries gain 5 % at 100,000 rows and lose 7 % at
         // 184,000 — their candidates multiply the refine: they keep the capped plan; profiles/r04_filter_one_round_ab.log.)
-        static const double g1_env = [] { const char* e = std::getenv("CS_FILTER_G1MAX"); return e ? std::atof(e) : 60.0; }();
-        static const uint32_t g1_maxq = [] { const char* e = std::getenv("CS_FILTER_G1_MAXQ"); return e ? (uint32_t)std::atoi(e) : 4u; }();
-        static const double g1_cand = [] { const char* e = std::getenv("CS_FILTER_G1_CAND"); return e ? std::atof(e) : 970.0; }();
+        static const double g1_env = [] { const char* e = cs_lab_env("CS_FILTER_G1MAX"); return e ? std::atof(e) : 60.0; }();
+        static const uint32_t g1_maxq = [] { const char* e = cs_lab_env("CS_FILTER_G1_MAXQ"); return e ? (uint32_t)std::atoi(e) : 4u; }();
+        static const double g1_cand = [] { const char* e = cs_lab_env("CS_FILTER_G1_CAND"); return e ? std::atof(e) : 970.0; }();
         const double g1 = std::min(g1_env, g1_cand / (double)k);  // 60 up to k = 16, 38.8 at k = 25, no more than the cap of 24 from k = 40
         const bool one_round = nq <= g1_maxq && g1 > 24.0 && (double)n_rows <= g1 * (double)phase;
         const double gshort = one_round ? g1 : std::min(24.0, 900.0 / (double)k);
@@ -1650,7 +1650,7 @@ static int32_t scan_split_impl(const BatchedState& st, const SplitQueryWs& qw, c
                     // above 128 queries at dim 384: 256 resident queries per block — half the query tiles re-reading the
                     // corpus through L2 (1,000 queries over 10M rows: 7.21 -> 5.95 ms; 129: 1.97 -> 1.61); "0" = A/B
                     static const bool rw8_256 = [] {
-                        const char* e = std::getenv("CS_FILTER_INT8_RW256");
+                        const char* e = cs_lab_env("CS_FILTER_INT8_RW256");
                         return !(e && e[0] == '0');
                     }();
                     const uint32_t per = nq <= 32 ? 32 : (nq <= 64 || J > 6) ? 64 : (J == 3 && rw8_256 && nq > 128) ? 256 : 128;
@@ -1661,7 +1661,7 @@ static int32_t scan_split_impl(const BatchedState& st, const SplitQueryWs& qw, c
                     if (slots < qtiles) slots = qtiles;
                     const uint32_t blocks = (uint32_t)slots * 8;
                     static const uint32_t nt_stream8 = [] {
-                        const char* e = std::getenv("CS_FILTER_NT");
+                        const char* e = cs_lab_env("CS_FILTER_NT");
                         return (uint32_t)!(e && e[0] == '0');
                     }();
 #define CS_RW8_LAUNCH(NQT_)                                                                                        \
@@ -1704,7 +1704,7 @@ static int32_t scan_split_impl(const BatchedState& st, const SplitQueryWs& qw, c
                 if (slots < qtiles) slots = qtiles;
                 const uint32_t blocks = (uint32_t)slots * 8;
                 static const uint32_t nt_stream = [] {
-                    const char* e = std::getenv("CS_FILTER_NT");  // "0": default cache policy on the corpus stream
+                    const char* e = cs_lab_env("CS_FILTER_NT");  // "0": default cache policy on the corpus stream
                     return (uint32_t)!(e && e[0] == '0');
                 }();
 #define CS_RW_LAUNCH(NQT_)                                                                                   \
@@ -1753,7 +1753,7 @@ static int32_t scan_split_impl(const BatchedState& st, const SplitQueryWs& qw, c
         // refine: exact keys in place (each query's rows spread over rk_blocks CUs), then the select
         // phase 0 of a few queries: its 3,072 rows in ONE round of 32 rows per block (96 blocks per query instead of three
         // rounds on 32: the phase is a dependent launch in front of every filter search, 12 -> 7 us for one query)
-        static const uint32_t rk0_env = [] { const char* e = std::getenv("CS_FILTER_PHASE0_BLOCKS"); return e ? (uint32_t)std::atoi(e) : 96u; }();
+        static const uint32_t rk0_env = [] { const char* e = cs_lab_env("CS_FILTER_PHASE0_BLOCKS"); return e ? (uint32_t)std::atoi(e) : 96u; }();
         const uint32_t rk_now = (first && nq * rk0_env <= 1024 && rk0_env > rk_blocks) ? rk0_env : rk_blocks;  // up to ten queries
         hipLaunchKernelGGL(rescore_keys_kernel<J>, dim3(rk_now, nq), dim3(RK_THREADS), 0, stream, d_corpus, d_queries,
                            qw.d_qmag, st.d_cand, st.d_cnt, cap, id_base, first ? (uint32_t)hi : 0u, d_dead);

@@ -195,9 +195,13 @@ class FastEmbedder:
 
     def small_forward_counters(self):
         """-> (mini-batches that ran as ONE kernel launch (csrc/small_forward.hip: a few short sequences, the query side),
-        how many of those gave up at a grid barrier and were re-run kernel by kernel)"""
+        how many of those gave up at a grid barrier and were re-run kernel by kernel).  The one-launch forward is built into
+        the diagnostic library only (include/codesearch_gpu_diag.h): an embedder created through libcsgpu.so has no such path."""
+        fn = getattr(self._lib, "cs_debug_small_forward_counters", None)
+        if fn is None or fn.argtypes is None:
+            raise RuntimeError("the one-launch forward lives in libcsgpu_diag.so only (tests: the lab_lib fixture)")
         a, b = C.c_uint64(), C.c_uint64()
-        _lib.check(self._lib.cs_embedder_small_forward_counters(self._h, C.byref(a), C.byref(b)))
+        _lib.check(fn(self._h, C.byref(a), C.byref(b)))
         return int(a.value), int(b.value)
 
     @classmethod

@@ -34,6 +34,11 @@
 extern "C" {
 #endif
 
+/* The library is built with -fvisibility=hidden: CS_API marks the entry points — the only symbols it exports. */
+#ifndef CS_API
+#define CS_API __attribute__((visibility("default")))
+#endif
+
 typedef enum cs_status {
     CS_OK = 0,
     CS_ERR_BAD_ARG = 1,
@@ -55,11 +60,11 @@ typedef enum cs_status {
  * most 9, src/search/mod.rs:263-388). */
 #define CS_MAX_VARIANTS 16u
 
-const char* cs_last_error(void);
+CS_API const char* cs_last_error(void);
 /* ABI version of this header; bumped on any signature change. */
-uint32_t cs_abi_version(void);
+CS_API uint32_t cs_abi_version(void);
 /* Number of visible HIP devices (0 if none / no driver). */
-int32_t cs_device_count(void);
+CS_API int32_t cs_device_count(void);
 
 /* ------------------------------------------------------------------------------------
  * Vector index  — the vector half of VectorStore.  Chunk metadata (store.rs:19-85) stays
@@ -72,47 +77,47 @@ typedef struct cs_index cs_index;
  * reservation hint (the matrix grows by doubling); `device` is the HIP ordinal;
  * `id_base` is the first id this shard hands out (0 for a single-GPU store; the row
  * offset of the shard for a row-sharded store). */
-int32_t cs_index_create(uint32_t dim, uint64_t capacity_rows, int32_t device,
+CS_API int32_t cs_index_create(uint32_t dim, uint64_t capacity_rows, int32_t device,
                         uint32_t id_base, cs_index** out);
-void cs_index_destroy(cs_index* h);
+CS_API void cs_index_destroy(cs_index* h);
 
 /* insert_chunks_with_ids — store.rs:618-686 (vector half: writer.add_item, :674).
  * Appends n rows of `dim` floats (host memory); ids are contiguous from next_id
  * (store.rs:659-685).  dim != index dim -> CS_ERR_DIM_MISMATCH with the reference text
  * "Embedding dimension mismatch: expected {}, got {}".  Marks the index not-built
  * (store.rs:682).  out_ids may be NULL. */
-int32_t cs_index_add(cs_index* h, const float* rows, uint64_t n, uint32_t dim,
+CS_API int32_t cs_index_add(cs_index* h, const float* rows, uint64_t n, uint32_t dim,
                      uint32_t* out_ids);
 /* Same, rows already in HBM on the index's device (zero-copy hand-off from the
  * encoder's pooled+normalised output).  The copy is asynchronous on `stream`: d_rows must stay
  * alive and unmodified until that stream has passed this point (cs_index_build drains the
  * device, and so does a later append that has to grow the matrix). */
-int32_t cs_index_add_device(cs_index* h, const float* d_rows, uint64_t n, uint32_t dim,
+CS_API int32_t cs_index_add_device(cs_index* h, const float* d_rows, uint64_t n, uint32_t dim,
                             uint32_t* out_ids, void* stream);
 /* Appends n rows produced in place by the counter-based generator of
  * include/cs_synth.h (row r, col c -> cs_synth_value(seed, (first_row + r)*dim + c)).
  * Exists so 10M..80M-row corpora never cross PCIe; not a reference method. */
-int32_t cs_index_add_synthetic(cs_index* h, uint64_t n, uint64_t seed, uint64_t first_row,
+CS_API int32_t cs_index_add_synthetic(cs_index* h, uint64_t n, uint64_t seed, uint64_t first_row,
                                uint32_t* out_first_id);
 
 /* delete_chunks — store.rs:548-610.  Tombstones the ids (a deleted row can never be
  * returned again); *removed counts ids that were live.  Unknown ids are ignored like
  * `del_item(..).is_ok()` failing (store.rs:594).  Marks not-built if any was removed
  * (store.rs:604-606). */
-int32_t cs_index_remove(cs_index* h, const uint32_t* ids, uint64_t n, uint64_t* removed);
+CS_API int32_t cs_index_remove(cs_index* h, const uint32_t* ids, uint64_t n, uint64_t* removed);
 
 /* build_index — store.rs:386-430.  The exact scan needs no tree; this publishes the
  * appended rows to searchers and sets `indexed` (store.rs:428). */
-int32_t cs_index_build(cs_index* h);
+CS_API int32_t cs_index_build(cs_index* h);
 /* clear — store.rs:690-707. */
-int32_t cs_index_clear(cs_index* h);
+CS_API int32_t cs_index_clear(cs_index* h);
 
 /* is_indexed (store.rs:745), stats().total_chunks (store.rs:488-523), next_id, dims. */
-int32_t cs_index_is_built(const cs_index* h);
-uint64_t cs_index_len(const cs_index* h);      /* live rows (appended - removed) */
-uint32_t cs_index_next_id(const cs_index* h);  /* store.rs:101 */
-uint32_t cs_index_dim(const cs_index* h);
-int32_t cs_index_device(const cs_index* h);
+CS_API int32_t cs_index_is_built(const cs_index* h);
+CS_API uint64_t cs_index_len(const cs_index* h);      /* live rows (appended - removed) */
+CS_API uint32_t cs_index_next_id(const cs_index* h);  /* store.rs:101 */
+CS_API uint32_t cs_index_dim(const cs_index* h);
+CS_API int32_t cs_index_device(const cs_index* h);
 
 /* search — store.rs:431-486, for nq queries at once (the caller's par_iter over query
  * variants, src/search/mod.rs:508-511, becomes one call).
@@ -124,7 +129,7 @@ int32_t cs_index_device(const cs_index* h);
  * (store.rs:432-438); not built -> "Index not built. Call build_index() after
  * inserting chunks." (store.rs:440-444).  The reference's distance/score pair is
  * derived from the cosine by cs_cos_to_distance()/cs_cos_to_score(). */
-int32_t cs_index_search(cs_index* h, const float* queries, uint32_t nq, uint32_t dim,
+CS_API int32_t cs_index_search(cs_index* h, const float* queries, uint32_t nq, uint32_t dim,
                         uint32_t k, float* out_cos, uint32_t* out_ids,
                         uint32_t* out_counts);
 /* Same with queries and outputs in HBM; asynchronous on `stream`: the call only enqueues work and
@@ -139,7 +144,7 @@ int32_t cs_index_search(cs_index* h, const float* queries, uint32_t nq, uint32_t
  * report an overflow through cs_index_search_status() instead: check it once the results are needed and
  * rerun an overflowed search (in slices of <= 16 queries, or through cs_index_search, which reruns by
  * itself). */
-int32_t cs_index_search_device(cs_index* h, const float* d_queries, uint32_t nq,
+CS_API int32_t cs_index_search_device(cs_index* h, const float* d_queries, uint32_t nq,
                                uint32_t dim, uint32_t k, uint64_t* d_out_keys,
                                float* d_out_cos, uint32_t* d_out_ids,
                                uint32_t* d_out_counts, void* stream);
@@ -151,28 +156,28 @@ int32_t cs_index_search_device(cs_index* h, const float* d_queries, uint32_t nq,
  * runs on the device behind the searches (scan.hip merge_variants_kernel): k results and two scalars cross
  * PCIe instead of nq lists.  out_cos / out_ids: [k]; *out_count <= k valid entries.  nq <= CS_MAX_VARIANTS.
  * Equal scores are ordered (cosine desc, id asc), where the reference's HashMap order is unspecified. */
-int32_t cs_index_search_variants(cs_index* h, const float* queries, uint32_t nq, uint32_t dim, uint32_t k,
+CS_API int32_t cs_index_search_variants(cs_index* h, const float* queries, uint32_t nq, uint32_t dim, uint32_t k,
                                  float* out_cos, uint32_t* out_ids, uint32_t* out_count,
                                  int32_t* out_high_confidence);
 /* The merge alone, on device buffers: d_keys [nv, k] packed keys as cs_index_search_device (or the shard
  * merge) leaves them -> the best `limit` distinct ids.  Asynchronous on `stream`; outputs optional. */
-int32_t cs_merge_variants_device(int32_t device, const uint64_t* d_keys, uint32_t nv, uint32_t k, uint32_t limit,
+CS_API int32_t cs_merge_variants_device(int32_t device, const uint64_t* d_keys, uint32_t nv, uint32_t k, uint32_t limit,
                                  uint64_t* d_out_keys, float* d_out_cos, uint32_t* d_out_ids,
                                  uint32_t* d_out_count, uint32_t* d_out_high_confidence, void* stream);
 
 /* Synchronises `stream` and reports in *overflowed whether any cs_index_search_device call of more
  * than 16 queries issued by this thread on it since the previous status call overflowed a candidate buffer
  * (its results are then incomplete); clears the condition. */
-int32_t cs_index_search_status(cs_index* h, void* stream, uint32_t* overflowed);
+CS_API int32_t cs_index_search_status(cs_index* h, void* stream, uint32_t* overflowed);
 /* Frees the device-API scratch (partial lists, candidate buffers, split queries, merge ping-pong) the handle keeps
  * per (stream, calling thread) for `stream`, for every thread that used it; synchronises the stream first.  Call it
  * before destroying a stream that searched, or from a request thread that is about to exit: scratch is otherwise
  * kept for the life of the index (cs_index_destroy frees all of it). */
-int32_t cs_index_release_stream(cs_index* h, void* stream);
+CS_API int32_t cs_index_release_stream(cs_index* h, void* stream);
 
 /* Shard merge: given `nlists` per-shard key lists [nlists, nq, k]
  * (as all-gathered over RCCL), write the merged best-k per query.  Device pointers. */
-int32_t cs_merge_topk_device(int32_t device, const uint64_t* d_keys, uint32_t nlists,
+CS_API int32_t cs_merge_topk_device(int32_t device, const uint64_t* d_keys, uint32_t nlists,
                              uint32_t nq, uint32_t k, uint64_t* d_out_keys,
                              float* d_out_cos, uint32_t* d_out_ids,
                              uint32_t* d_out_counts, void* stream);
@@ -191,39 +196,39 @@ int32_t cs_merge_topk_device(int32_t device, const uint64_t* d_keys, uint32_t nl
  * cs_index_* (add/remove/build/clear need external exclusion; search is re-entrant).
  * ---------------------------------------------------------------------------------- */
 typedef struct cs_shards cs_shards;
-int32_t cs_shards_create(uint32_t dim, uint32_t nshards, const int32_t* devices, uint64_t rows_per_stripe,
+CS_API int32_t cs_shards_create(uint32_t dim, uint32_t nshards, const int32_t* devices, uint64_t rows_per_stripe,
                          uint64_t capacity_rows /* whole store, reservation hint */, cs_shards** out);
-void cs_shards_destroy(cs_shards* h);
-int32_t cs_shards_add(cs_shards* h, const float* rows, uint64_t n, uint32_t dim, uint32_t* out_ids);
+CS_API void cs_shards_destroy(cs_shards* h);
+CS_API int32_t cs_shards_add(cs_shards* h, const float* rows, uint64_t n, uint32_t dim, uint32_t* out_ids);
 /* Same with the rows in HBM of device `src_device` (an encoder replica's output): each run of rows goes to its
  * shard by one asynchronous copy on `stream` (a stream of src_device; in place when the shard lives there, over
  * xGMI otherwise) — the multi-GPU form of cs_index_add_device, src/index/mod.rs:692-723.  Appends are
  * all-or-nothing: capacity is reserved on every touched shard before any row moves. */
-int32_t cs_shards_add_device(cs_shards* h, const float* d_rows, int32_t src_device, uint64_t n, uint32_t dim,
+CS_API int32_t cs_shards_add_device(cs_shards* h, const float* d_rows, int32_t src_device, uint64_t n, uint32_t dim,
                              uint32_t* out_ids, void* stream);
 /* Where the next n appended rows will live (ids are contiguous from next_id, so this is known before the rows exist):
  * run i = rows [first[i], first[i] + count[i]) of the append, all on shard[i]; runs ascend and cover [0, n).
  * *n_runs = the number of runs; the arrays are filled only when max_runs >= *n_runs (call with 0 to size them). */
-int32_t cs_shards_plan_append(const cs_shards* h, uint64_t n, uint32_t max_runs, uint32_t* shard, uint64_t* first,
+CS_API int32_t cs_shards_plan_append(const cs_shards* h, uint64_t n, uint32_t max_runs, uint32_t* shard, uint64_t* first,
                               uint64_t* count, uint32_t* n_runs);
 /* cs_shards_add_device with the rows in several buffers: part i = the next counts[i] rows, at d_rows[i] in HBM of
  * src_devices[i]; the parts must be the runs of cs_shards_plan_append for their total, in order.  One asynchronous
  * copy per part on the null stream of its source device. */
-int32_t cs_shards_add_device_parts(cs_shards* h, uint32_t nparts, const float* const* d_rows,
+CS_API int32_t cs_shards_add_device_parts(cs_shards* h, uint32_t nparts, const float* const* d_rows,
                                    const int32_t* src_devices, const uint64_t* counts, uint32_t dim, uint32_t* out_ids);
-int32_t cs_shards_add_synthetic(cs_shards* h, uint64_t n, uint64_t seed, uint64_t first_row,
+CS_API int32_t cs_shards_add_synthetic(cs_shards* h, uint64_t n, uint64_t seed, uint64_t first_row,
                                 uint32_t* out_first_id);
-int32_t cs_shards_remove(cs_shards* h, const uint32_t* ids, uint64_t n, uint64_t* removed);
-int32_t cs_shards_build(cs_shards* h);
-int32_t cs_shards_clear(cs_shards* h);
-int32_t cs_shards_is_built(const cs_shards* h);
-uint64_t cs_shards_len(const cs_shards* h);
-uint32_t cs_shards_next_id(const cs_shards* h);
-uint32_t cs_shards_dim(const cs_shards* h);
-uint32_t cs_shards_count(const cs_shards* h);                        /* number of shards */
-uint64_t cs_shards_shard_len(const cs_shards* h, uint32_t shard);    /* live rows on one shard */
-int32_t cs_shards_direct_gather(const cs_shards* h);                 /* 1 = shards write into the root's buffer (CS_SHARDS_DIRECT=1) */
-int32_t cs_shards_search(cs_shards* h, const float* queries, uint32_t nq, uint32_t dim, uint32_t k,
+CS_API int32_t cs_shards_remove(cs_shards* h, const uint32_t* ids, uint64_t n, uint64_t* removed);
+CS_API int32_t cs_shards_build(cs_shards* h);
+CS_API int32_t cs_shards_clear(cs_shards* h);
+CS_API int32_t cs_shards_is_built(const cs_shards* h);
+CS_API uint64_t cs_shards_len(const cs_shards* h);
+CS_API uint32_t cs_shards_next_id(const cs_shards* h);
+CS_API uint32_t cs_shards_dim(const cs_shards* h);
+CS_API uint32_t cs_shards_count(const cs_shards* h);                        /* number of shards */
+CS_API uint64_t cs_shards_shard_len(const cs_shards* h, uint32_t shard);    /* live rows on one shard */
+CS_API int32_t cs_shards_direct_gather(const cs_shards* h);                 /* 1 = shards write into the root's buffer (CS_SHARDS_DIRECT=1) */
+CS_API int32_t cs_shards_search(cs_shards* h, const float* queries, uint32_t nq, uint32_t dim, uint32_t k,
                          float* out_cos, uint32_t* out_ids, uint32_t* out_counts);
 /* Device-pointer form (cs_index_search_device's counterpart): d_queries [nq, dim] and the outputs live in HBM of the
  * store's FIRST device (cs_shards_root_device); asynchronous on `stream`, a stream of that device — the call only
@@ -231,30 +236,30 @@ int32_t cs_shards_search(cs_shards* h, const float* queries, uint32_t nq, uint32
  * back, and `stream` waits for one event per shard before the merge.  Nothing waits for the host, so consecutive
  * searches overlap their launch cost with the previous scan.  Exactness above 16 queries per call as for
  * cs_index_search_device: ask cs_shards_search_status once the results are needed. */
-int32_t cs_shards_search_device(cs_shards* h, const float* d_queries, uint32_t nq, uint32_t dim, uint32_t k,
+CS_API int32_t cs_shards_search_device(cs_shards* h, const float* d_queries, uint32_t nq, uint32_t dim, uint32_t k,
                                 uint64_t* d_out_keys, float* d_out_cos, uint32_t* d_out_ids, uint32_t* d_out_counts,
                                 void* stream);
-int32_t cs_shards_search_status(cs_shards* h, void* stream, uint32_t* overflowed);
-int32_t cs_shards_root_device(const cs_shards* h);
-int32_t cs_shards_shard_device(const cs_shards* h, uint32_t shard);
+CS_API int32_t cs_shards_search_status(cs_shards* h, void* stream, uint32_t* overflowed);
+CS_API int32_t cs_shards_root_device(const cs_shards* h);
+CS_API int32_t cs_shards_shard_device(const cs_shards* h, uint32_t shard);
 /* Borrowed handle of one shard's cs_index, for diagnostics only (cs_index_profile*, cs_index_debug_counters,
  * cs_index_search* of that shard alone: local row numbers, not ids).  Never mutate or destroy it. */
-cs_index* cs_shards_shard_index(cs_shards* h, uint32_t shard);
+CS_API cs_index* cs_shards_shard_index(cs_shards* h, uint32_t shard);
 /* cs_index_search_variants over the sharded store: per-variant searches on every shard, the shard merge, then the
  * variant merge (src/search/mod.rs:513-611) on the first device. */
-int32_t cs_shards_search_variants(cs_shards* h, const float* queries, uint32_t nq, uint32_t dim, uint32_t k,
+CS_API int32_t cs_shards_search_variants(cs_shards* h, const float* queries, uint32_t nq, uint32_t dim, uint32_t k,
                                   float* out_cos, uint32_t* out_ids, uint32_t* out_count, int32_t* out_high_confidence);
-int32_t cs_shards_read_rows(cs_shards* h, uint64_t first_id, uint64_t n, float* out_rows);
+CS_API int32_t cs_shards_read_rows(cs_shards* h, uint64_t first_id, uint64_t n, float* out_rows);
 
 /* Copy rows [first_row, first_row + n) of the matrix back to host memory (test and
  * persistence aid; VectorStore has no direct counterpart). */
-int32_t cs_index_read_rows(cs_index* h, uint64_t first_row, uint64_t n, float* out_rows);
+CS_API int32_t cs_index_read_rows(cs_index* h, uint64_t first_row, uint64_t n, float* out_rows);
 
 /* Kernel timing for bench.py: when enabled, every scan launch is bracketed by HIP
  * events on the launching stream.  read() synchronises and returns accumulated
  * milliseconds and launch count since the last reset. */
-int32_t cs_index_profile(cs_index* h, int32_t enable);
-int32_t cs_index_profile_read(cs_index* h, double* scan_ms, uint64_t* scan_launches,
+CS_API int32_t cs_index_profile(cs_index* h, int32_t enable);
+CS_API int32_t cs_index_profile_read(cs_index* h, double* scan_ms, uint64_t* scan_launches,
                               double* merge_ms, int32_t reset);
 
 /* Diagnostics: how many searches took the batched-query (MFMA) path, and how many of those
@@ -263,7 +268,7 @@ int32_t cs_index_profile_read(cs_index* h, double* scan_ms, uint64_t* scan_launc
  * over the half-size unit-vector copy built at cs_index_build, then an exact f32 re-score of the
  * candidates: results bit-identical to the streaming f32 scan).  Default 2 (CS_FILTER_MIN_Q); 1
  * routes single queries through it too (1.45 ms instead of 2.26 ms over 10M x 384). */
-int32_t cs_index_set_filter_min_queries(cs_index* h, uint32_t min_queries);
+CS_API int32_t cs_index_set_filter_min_queries(cs_index* h, uint32_t min_queries);
 /* How ONE query is answered over a large index.  The reference's commonest searches are exactly that shape: MCP
  * (src/mcp/mod.rs:252: one query, k = limit * 3) and the HTTP handler (src/server/mod.rs:547: k = 25).  Every route
  * returns the same bits (exact f32 re-score of the filter's candidates; tests/test_gpu_scan.py).
@@ -276,8 +281,8 @@ int32_t cs_index_set_filter_min_queries(cs_index* h, uint32_t min_queries);
  *                   on; bench.py selects it for `value`);  CS_FILTER_SINGLE_MIN_K=0 makes it a handle's default;
  *   CS_ROUTE_FILTER the filter path whenever a filter copy can serve, whatever the row count. */
 enum { CS_ROUTE_COST = 0, CS_ROUTE_STREAM = 1, CS_ROUTE_FILTER = 2 };
-int32_t cs_index_set_single_query_route(cs_index* h, int32_t route);
-int32_t cs_index_debug_counters(cs_index* h, uint64_t* batched_searches,
+CS_API int32_t cs_index_set_single_query_route(cs_index* h, int32_t route);
+CS_API int32_t cs_index_debug_counters(cs_index* h, uint64_t* batched_searches,
                                 uint64_t* batched_fallbacks);
 /* Diagnostics: which copy of the corpus feeds the filter of batched searches right now — 0 none (no filter copy:
  * CS_INDEX_SPLIT=0 or unsupported width), 1 the f16 unit rows, 2 the int8 unit rows — the spread
@@ -286,14 +291,14 @@ int32_t cs_index_debug_counters(cs_index* h, uint64_t* batched_searches,
  * overflowed and were answered by the f16 copy instead (the int8 copy is retired until cs_index_clear once two searches
  * through it have overflowed and they are more than one in sixteen of its searches).
  * Results are exact and bit-identical whichever copy filters. */
-int32_t cs_index_filter_state(cs_index* h, int32_t* copy, float* spread, uint64_t* int8_reruns);
+CS_API int32_t cs_index_filter_state(cs_index* h, int32_t* copy, float* spread, uint64_t* int8_reruns);
 /* Which filter copies exist in HBM right now, and the bytes they occupy.  The int8 copy (1 byte per element) is kept by
  * every index of a supported width; the f16 copy (2 bytes per element) only where the int8 copy does not serve — no int8
  * copy (CS_FILTER_INT8=0, no room), retired at a build by its spread or later by two overflowed searches, or at most
  * 1,024 rows — and is then built by cs_index_build, or by the first search after a retirement (that one search waits
  * ~5 ms per 10M x 384 for the conversion; if there is no room for it the search takes the exact paths, no error).
  * CS_FILTER_F16_EAGER=1 keeps both at every build (round 3's behaviour: 7 bytes per element instead of 5). */
-int32_t cs_index_filter_copies(cs_index* h, int32_t* has_int8, int32_t* has_f16, uint64_t* filter_bytes);
+CS_API int32_t cs_index_filter_copies(cs_index* h, int32_t* has_int8, int32_t* has_f16, uint64_t* filter_bytes);
 
 /* Score mapping.  store.rs:477-478: score = 1 - distance, distance = arroy 0.5.0
  * Cosine = (1 - cos) / 2  (third-party). */
@@ -357,15 +362,15 @@ typedef struct cs_bert_config {
 } cs_bert_config;
 
 /* Fills *cfg with the BAAI/bge-small-en-v1.5 architecture (CLS pooling). */
-void cs_bert_config_bge_small(cs_bert_config* cfg);
+CS_API void cs_bert_config_bge_small(cs_bert_config* cfg);
 /* Number of f32 parameters a config needs, in the flat order documented in
  * codesearch_amd/csrc/bert_params.h (HF BertModel tensor order). */
-uint64_t cs_bert_param_count(const cs_bert_config* cfg);
+CS_API uint64_t cs_bert_param_count(const cs_bert_config* cfg);
 
 /* FastEmbedder::with_cache_dir — embedder.rs:218-245.  `params` = flat f32 parameter
  * block (host memory, cs_bert_param_count floats); NULL => weights are generated on the
  * device from `seed` by the counter-based generator of include/cs_synth.h (synthetic-weight mode). */
-int32_t cs_embedder_create(const cs_bert_config* cfg, const float* params, uint64_t seed,
+CS_API int32_t cs_embedder_create(const cs_bert_config* cfg, const float* params, uint64_t seed,
                            int32_t device, cs_embedder** out);
 /* Real checkpoints (the model-loading half of with_cache_dir).  `model_dir` is a model directory as hf-hub
  * caches it: config.json (BERT family, erf-GELU, absolute positions) and the weights as EITHER
@@ -408,30 +413,30 @@ int32_t cs_embedder_create(const cs_bert_config* cfg, const float* params, uint6
 /* pooling: CS_POOL_CLS, CS_POOL_MEAN, or -1 = what <model_dir>/1_Pooling/config.json says (the
  * sentence-transformers module: mean for MiniLM / E5, CLS for BGE), CLS when that file is absent (mean for a
  * nomic_bert directory: fastembed's pooling for the family). */
-int32_t cs_bert_config_from_dir(const char* model_dir, int32_t pooling, cs_bert_config* cfg);
-int32_t cs_bert_params_from_safetensors(const char* path, const cs_bert_config* cfg,
+CS_API int32_t cs_bert_config_from_dir(const char* model_dir, int32_t pooling, cs_bert_config* cfg);
+CS_API int32_t cs_bert_params_from_safetensors(const char* path, const cs_bert_config* cfg,
                                         float* params, uint64_t n_params);
-int32_t cs_bert_params_from_onnx(const char* path, const cs_bert_config* cfg, float* params,
+CS_API int32_t cs_bert_params_from_onnx(const char* path, const cs_bert_config* cfg, float* params,
                                  uint64_t n_params);
 /* The same, also reporting the file's quantisation: wscale (optional, cs_bert_quant_columns(cfg) * layers floats) receives
  * the scale of every output column of the six Linear weights of every layer (a per-tensor scale repeated over its columns),
  * in the order query | key | value | attention.output | intermediate | output; *quantized = 1 when ALL of them are INT8 /
  * UINT8 initialisers behind MatMulInteger (then `params` holds exact multiples of these scales), else 0. */
-int32_t cs_bert_params_from_onnx_q(const char* path, const cs_bert_config* cfg, float* params, uint64_t n_params,
+CS_API int32_t cs_bert_params_from_onnx_q(const char* path, const cs_bert_config* cfg, float* params, uint64_t n_params,
                                    float* wscale, uint64_t n_wscale, int32_t* quantized);
 /* Output columns of one layer's Linear weights: 5 * hidden + intermediate. */
-uint64_t cs_bert_quant_columns(const cs_bert_config* cfg);
+CS_API uint64_t cs_bert_quant_columns(const cs_bert_config* cfg);
 /* A dynamically quantised model (what onnxruntime's quantize_dynamic writes; see CS_GEMM_Q8_DYNAMIC).  `params` as for
  * cs_embedder_create, with every Linear weight W[n][k] an integer multiple of wscale[layer][column n] whose integers span at
  * most 8 bits per column (anything else -> CS_ERR_BAD_ARG); wscale: layers * cs_bert_quant_columns(cfg) floats. */
-int32_t cs_embedder_create_quantized(const cs_bert_config* cfg, const float* params, const float* wscale,
+CS_API int32_t cs_embedder_create_quantized(const cs_bert_config* cfg, const float* params, const float* wscale,
                                      uint64_t n_wscale, int32_t device, cs_embedder** out);
 /* config.json + weights -> embedder on `device` (the tokenizer of the same directory comes from
  * cs_tokenizer_create_from_dir). */
-int32_t cs_embedder_create_from_dir(const char* model_dir, int32_t pooling, int32_t device,
+CS_API int32_t cs_embedder_create_from_dir(const char* model_dir, int32_t pooling, int32_t device,
                                     cs_embedder** out);
-void cs_embedder_destroy(cs_embedder* h);
-uint32_t cs_embedder_dim(const cs_embedder* h);   /* dimensions(), embedder.rs:307 */
+CS_API void cs_embedder_destroy(cs_embedder* h);
+CS_API uint32_t cs_embedder_dim(const cs_embedder* h);   /* dimensions(), embedder.rs:307 */
 
 /* embed_batch_chunked — embedder.rs:266-295, from token ids.
  *   ids, mask : [n, seq_len] i32 row-major (mask 1 = token, 0 = pad)
@@ -440,12 +445,12 @@ uint32_t cs_embedder_dim(const cs_embedder* h);   /* dimensions(), embedder.rs:3
  *   out       : [n, dim] f32 — L2-normalised pooled embeddings
  *   cancel    : optional flag polled between mini-batches (embedder.rs:280); non-zero
  *               -> CS_ERR_CANCELLED "Embedding interrupted by shutdown request". */
-int32_t cs_embedder_embed_ids(cs_embedder* h, const int32_t* ids, const int32_t* mask,
+CS_API int32_t cs_embedder_embed_ids(cs_embedder* h, const int32_t* ids, const int32_t* mask,
                               uint64_t n, uint32_t seq_len, uint32_t batch, float* out,
                               const volatile int32_t* cancel);
 /* Same, but leaves the [n, dim] result in HBM at d_out (e.g. to feed
  * cs_index_add_device without a PCIe round trip). */
-int32_t cs_embedder_embed_ids_device(cs_embedder* h, const int32_t* ids,
+CS_API int32_t cs_embedder_embed_ids_device(cs_embedder* h, const int32_t* ids,
                                      const int32_t* mask, uint64_t n, uint32_t seq_len,
                                      uint32_t batch, float* d_out,
                                      const volatile int32_t* cancel);
@@ -454,8 +459,8 @@ int32_t cs_embedder_embed_ids_device(cs_embedder* h, const int32_t* ids,
  * only the CLS rows of its LAST layer (the only rows the embedding reads; csrc/cls_tail.hip): this call then returns
  * CS_ERR_UNSUPPORTED (the buffer holds the layer before outside the CLS rows).  CS_ENCODER_CLS_TAIL=0 in the environment
  * restores the full last layer; rows longer than 512 tokens always run it. */
-int32_t cs_embedder_last_hidden(cs_embedder* h, float* out, uint64_t n_tokens);
-int32_t cs_embedder_profile_read(cs_embedder* h, double* forward_ms, uint64_t* forwards,
+CS_API int32_t cs_embedder_last_hidden(cs_embedder* h, float* out, uint64_t n_tokens);
+CS_API int32_t cs_embedder_profile_read(cs_embedder* h, double* forward_ms, uint64_t* forwards,
                                  int32_t reset);
 /* Per-kernel-class timing for bench.py's encoder roofline: while enabled, a forward runs on ONE
  * stream with a HIP event after every kernel.  read() returns the summed
@@ -472,8 +477,8 @@ enum {
     CS_STAGE_POOL = 8,      /* E7 + E8 */
     CS_ENCODER_STAGES = 9
 };
-int32_t cs_embedder_profile_stages(cs_embedder* h, int32_t enable);
-int32_t cs_embedder_profile_stages_read(cs_embedder* h, double* us_per_stage /*[CS_ENCODER_STAGES]*/,
+CS_API int32_t cs_embedder_profile_stages(cs_embedder* h, int32_t enable);
+CS_API int32_t cs_embedder_profile_stages_read(cs_embedder* h, double* us_per_stage /*[CS_ENCODER_STAGES]*/,
                                         uint64_t* forwards, int32_t reset);
 
 /* ------------------------------------------------------------------------------------
@@ -489,9 +494,9 @@ typedef struct cs_tokenizer cs_tokenizer;
  * is BertNormalizer's flag (strip_accents follows it, as in tokenizer.json's null);
  * `max_length` the truncation length (512 for bge-small).  The vocabulary must hold
  * [PAD] [UNK] [CLS] [SEP]. */
-int32_t cs_tokenizer_create(const char* vocab, uint64_t vocab_bytes, int32_t lowercase,
+CS_API int32_t cs_tokenizer_create(const char* vocab, uint64_t vocab_bytes, int32_t lowercase,
                             uint32_t max_length, cs_tokenizer** out);
-int32_t cs_tokenizer_create_from_file(const char* vocab_path, int32_t lowercase,
+CS_API int32_t cs_tokenizer_create_from_file(const char* vocab_path, int32_t lowercase,
                                       uint32_t max_length, cs_tokenizer** out);
 /* tokenizer.json of the `tokenizers` crate — the file fastembed builds its tokenizer from: WordPiece
  * model.vocab, BertNormalizer.lowercase, truncation.max_length.  max_length 0 = the file's truncation
@@ -508,21 +513,21 @@ int32_t cs_tokenizer_create_from_file(const char* vocab_path, int32_t lowercase,
  * GPT-2 pattern) optionally behind Digits; post_processor RobertaProcessing / TemplateProcessing [<bos>] $A [<eos>] /
  * ByteLevel; special added tokens (lstrip / rstrip honoured).  Dropout, word prefixes / suffixes and byte_fallback are
  * refused.  Merges run in the crate's own queue order (lowest rank, then leftmost), so ids equal the crate's. */
-int32_t cs_tokenizer_create_from_json(const char* tokenizer_json_path, uint32_t max_length,
+CS_API int32_t cs_tokenizer_create_from_json(const char* tokenizer_json_path, uint32_t max_length,
                                       cs_tokenizer** out);
 /* A model directory: tokenizer.json when present, else vocab.txt with tokenizer_config.json's
  * do_lower_case; truncation at min(max_length or 512, tokenizer_config.json's model_max_length). */
-int32_t cs_tokenizer_create_from_dir(const char* model_dir, uint32_t max_length, cs_tokenizer** out);
-void cs_tokenizer_destroy(cs_tokenizer* t);
-uint32_t cs_tokenizer_vocab_size(const cs_tokenizer* t);
-uint32_t cs_tokenizer_max_length(const cs_tokenizer* t);  /* the handle's truncation length */
-int32_t cs_tokenizer_pad_id(const cs_tokenizer* t);       /* [PAD] (WordPiece) or <pad> (unigram): what encode_batch pads with */
-int32_t cs_tokenizer_token_to_id(const cs_tokenizer* t, const char* token); /* -1 = absent */
+CS_API int32_t cs_tokenizer_create_from_dir(const char* model_dir, uint32_t max_length, cs_tokenizer** out);
+CS_API void cs_tokenizer_destroy(cs_tokenizer* t);
+CS_API uint32_t cs_tokenizer_vocab_size(const cs_tokenizer* t);
+CS_API uint32_t cs_tokenizer_max_length(const cs_tokenizer* t);  /* the handle's truncation length */
+CS_API int32_t cs_tokenizer_pad_id(const cs_tokenizer* t);       /* [PAD] (WordPiece) or <pad> (unigram): what encode_batch pads with */
+CS_API int32_t cs_tokenizer_token_to_id(const cs_tokenizer* t, const char* token); /* -1 = absent */
 /* Tokenizer::encode_batch.  Text i is utf8[offsets[i] .. offsets[i+1]) (n+1 offsets).
  * max_length 0 = the handle's.  *out_len = the batch's longest sequence L (<= max_length).
  * ids/mask: [n, row_stride] i32 with row_stride >= L, padded with [PAD] / 0; pass both NULL
  * to query L only.  Re-entrant. */
-int32_t cs_tokenizer_encode_batch(const cs_tokenizer* t, const char* utf8,
+CS_API int32_t cs_tokenizer_encode_batch(const cs_tokenizer* t, const char* utf8,
                                   const uint64_t* offsets, uint32_t n, uint32_t max_length,
                                   int32_t* ids, int32_t* mask, uint32_t row_stride,
                                   uint32_t* out_len);
@@ -536,11 +541,11 @@ int32_t cs_tokenizer_encode_batch(const cs_tokenizer* t, const char* utf8,
  * batch-mates beyond f32 rounding; CS_EMBED_LENGTH_SORT=0 keeps consecutive texts together).
  * Row i of `out` is always text i.  `cancel` is polled between mini-batches.
  * out: [n, dim] f32 host memory. */
-int32_t cs_embedder_embed_texts(cs_embedder* h, const cs_tokenizer* t, const char* utf8,
+CS_API int32_t cs_embedder_embed_texts(cs_embedder* h, const cs_tokenizer* t, const char* utf8,
                                 const uint64_t* offsets, uint64_t n, uint32_t batch,
                                 float* out, const volatile int32_t* cancel);
 /* Same, result left in HBM at d_out. */
-int32_t cs_embedder_embed_texts_device(cs_embedder* h, const cs_tokenizer* t, const char* utf8,
+CS_API int32_t cs_embedder_embed_texts_device(cs_embedder* h, const cs_tokenizer* t, const char* utf8,
                                        const uint64_t* offsets, uint64_t n, uint32_t batch,
                                        float* d_out, const volatile int32_t* cancel);
 
@@ -556,14 +561,14 @@ int32_t cs_embedder_embed_texts_device(cs_embedder* h, const cs_tokenizer* t, co
  * behind an Arc<Mutex<..>>); they must not overlap the handle's other entry points.  A wait interrupted through
  * `cancel` returns CS_ERR_CANCELLED and leaves the queue intact; a ticket is consumed by the wait that returns its
  * rows (or its error) and by discard. */
-int32_t cs_embedder_submit_texts(cs_embedder* h, const cs_tokenizer* t, const char* utf8, const uint64_t* offsets,
+CS_API int32_t cs_embedder_submit_texts(cs_embedder* h, const cs_tokenizer* t, const char* utf8, const uint64_t* offsets,
                                  uint64_t n, uint64_t* ticket);
-int32_t cs_embedder_submit_ids(cs_embedder* h, const int32_t* ids, const int32_t* mask, uint64_t n, uint32_t seq_len,
+CS_API int32_t cs_embedder_submit_ids(cs_embedder* h, const int32_t* ids, const int32_t* mask, uint64_t n, uint32_t seq_len,
                                uint64_t* ticket);
-int32_t cs_embedder_wait(cs_embedder* h, uint64_t ticket, float* out, const volatile int32_t* cancel);
-int32_t cs_embedder_wait_device(cs_embedder* h, uint64_t ticket, float* d_out, const volatile int32_t* cancel);
-int32_t cs_embedder_discard(cs_embedder* h, uint64_t ticket);
-uint64_t cs_embedder_queued_rows(cs_embedder* h);   /* rows submitted and not yet embedded */
+CS_API int32_t cs_embedder_wait(cs_embedder* h, uint64_t ticket, float* out, const volatile int32_t* cancel);
+CS_API int32_t cs_embedder_wait_device(cs_embedder* h, uint64_t ticket, float* d_out, const volatile int32_t* cancel);
+CS_API int32_t cs_embedder_discard(cs_embedder* h, uint64_t ticket);
+CS_API uint64_t cs_embedder_queued_rows(cs_embedder* h);   /* rows submitted and not yet embedded */
 
 /* ------------------------------------------------------------------------------------
  * Encoder replicas: one cs_embedder per GPU inside ONE process, and the reference's index loop
@@ -574,23 +579,23 @@ uint64_t cs_embedder_queued_rows(cs_embedder* h);   /* rows submitted and not ye
  * ---------------------------------------------------------------------------------- */
 typedef struct cs_embedders cs_embedders;
 /* One replica per entry of `devices` (a device may appear twice: two replicas share it). */
-int32_t cs_embedders_create(const cs_bert_config* cfg, const float* params, uint64_t seed, const int32_t* devices,
+CS_API int32_t cs_embedders_create(const cs_bert_config* cfg, const float* params, uint64_t seed, const int32_t* devices,
                             uint32_t n, cs_embedders** out);
 /* (a dynamically quantised model directory brings every replica up in CS_GEMM_Q8_DYNAMIC: a call tensor is then what ONE
  * replica receives — cs_embedders_embed_* hand each replica whole mini-batches of the caller's order; in the index loop a
  * replica's mini-batch is the chunks of ITS shards, not the reference's contiguous slice.) */
-int32_t cs_embedders_create_from_dir(const char* model_dir, int32_t pooling, const int32_t* devices, uint32_t n,
+CS_API int32_t cs_embedders_create_from_dir(const char* model_dir, int32_t pooling, const int32_t* devices, uint32_t n,
                                      cs_embedders** out);
-void cs_embedders_destroy(cs_embedders* e);
-uint32_t cs_embedders_count(const cs_embedders* e);
-uint32_t cs_embedders_dim(const cs_embedders* e);
-cs_embedder* cs_embedders_replica(cs_embedders* e, uint32_t i);   /* borrowed: never destroy it */
-int32_t cs_embedders_device(const cs_embedders* e, uint32_t i);
+CS_API void cs_embedders_destroy(cs_embedders* e);
+CS_API uint32_t cs_embedders_count(const cs_embedders* e);
+CS_API uint32_t cs_embedders_dim(const cs_embedders* e);
+CS_API cs_embedder* cs_embedders_replica(cs_embedders* e, uint32_t i);   /* borrowed: never destroy it */
+CS_API int32_t cs_embedders_device(const cs_embedders* e, uint32_t i);
 /* embed_batch over all replicas: the inputs are cut into one contiguous range of whole mini-batches per replica, each
  * embedded on its own device by its own host thread; row i of `out` (host memory) is input i. */
-int32_t cs_embedders_embed_texts(cs_embedders* e, const cs_tokenizer* t, const char* utf8, const uint64_t* offsets,
+CS_API int32_t cs_embedders_embed_texts(cs_embedders* e, const cs_tokenizer* t, const char* utf8, const uint64_t* offsets,
                                  uint64_t n, uint32_t batch, float* out, const volatile int32_t* cancel);
-int32_t cs_embedders_embed_ids(cs_embedders* e, const int32_t* ids, const int32_t* mask, uint64_t n, uint32_t seq_len,
+CS_API int32_t cs_embedders_embed_ids(cs_embedders* e, const int32_t* ids, const int32_t* mask, uint64_t n, uint32_t seq_len,
                                uint32_t batch, float* out, const volatile int32_t* cancel);
 /* Embed and append in one call: every replica embeds the inputs whose ids fall on the shards it serves (the shards on
  * its own device; a shard whose device has no replica is served by replica shard %% count, its rows crossing xGMI
@@ -598,10 +603,10 @@ int32_t cs_embedders_embed_ids(cs_embedders* e, const int32_t* ids, const int32_
  * (cs_shards_add_device_parts).  out_ids (optional): the n assigned ids, contiguous from next_id (store.rs:659-685).
  * An error or a shutdown request leaves the store as it was.  Use a stripe of one mini-batch (256 rows) or a few
  * for an even spread of one call's inputs over the GPUs. */
-int32_t cs_embedders_index_texts(cs_embedders* e, const cs_tokenizer* t, cs_shards* store, const char* utf8,
+CS_API int32_t cs_embedders_index_texts(cs_embedders* e, const cs_tokenizer* t, cs_shards* store, const char* utf8,
                                  const uint64_t* offsets, uint64_t n, uint32_t batch, uint32_t* out_ids,
                                  const volatile int32_t* cancel);
-int32_t cs_embedders_index_ids(cs_embedders* e, cs_shards* store, const int32_t* ids, const int32_t* mask, uint64_t n,
+CS_API int32_t cs_embedders_index_ids(cs_embedders* e, cs_shards* store, const int32_t* ids, const int32_t* mask, uint64_t n,
                                uint32_t seq_len, uint32_t batch, uint32_t* out_ids, const volatile int32_t* cancel);
 
 /* Arithmetic of the dense layers.  CS_GEMM_SPLIT_F16 (default): every f32 operand as two f16
@@ -619,18 +624,15 @@ int32_t cs_embedders_index_ids(cs_embedders* e, cs_shards* store, const int32_t*
  * are off in this mode because each would change that tensor.  The submission queue (cs_embedder_submit_*) still embeds
  * several submissions in one device batch: each stays its own quantisation unit there (its own range per tensor, its rows
  * beyond its own padded length kept out of it), so a ticket's rows are what the call alone would have produced.
- * Attention, LayerNorm, GELU and pooling stay f32-class. */
+ * Attention, LayerNorm, GELU and pooling stay f32-class.  A mini-batch whose Q / K / V, attention output or GELU output
+ * leaves the f16 range of that hand-over is run again as the f32 graph of the dequantised weights (CS_GEMM_F32) and
+ * counted in range_fallbacks: onnxruntime has no such limit, so the call never fails for it. */
 typedef enum cs_gemm_mode { CS_GEMM_F32 = 0, CS_GEMM_SPLIT_F16 = 1, CS_GEMM_Q8_DYNAMIC = 2 } cs_gemm_mode;
-int32_t cs_embedder_set_gemm_mode(cs_embedder* h, int32_t mode);
+CS_API int32_t cs_embedder_set_gemm_mode(cs_embedder* h, int32_t mode);
 /* The mode in force (a cs_gemm_mode; -1 for a null handle): CS_GEMM_Q8_DYNAMIC for a quantised model unless switched off. */
-int32_t cs_embedder_gemm_mode(const cs_embedder* h);
-int32_t cs_embedder_debug_counters(cs_embedder* h, uint64_t* split_forwards,
+CS_API int32_t cs_embedder_gemm_mode(const cs_embedder* h);
+CS_API int32_t cs_embedder_debug_counters(cs_embedder* h, uint64_t* split_forwards,
                                    uint64_t* f32_forwards, uint64_t* range_fallbacks);
-/* The one-launch forward of short queries (embed_one / embed_queries_batch: src/embed/mod.rs:164-226; csrc/small_forward.hip:
- * mini-batches of a 384-d BERT model with at most CS_SMALL_FORWARD_MAX_ROWS (192) token rows in split-f16 mode run as ONE
- * kernel, bit-identical to the kernel-by-kernel path): how many mini-batches took it, and how many of those gave up at a
- * grid barrier and were re-run kernel by kernel.  CS_SMALL_FORWARD=0 switches it off. */
-int32_t cs_embedder_small_forward_counters(cs_embedder* h, uint64_t* forwards, uint64_t* fallbacks);
 
 /* Operator-level diagnostics (cs_debug_*: single dense layers on host buffers for the kernels' unit parity tests, timed
  * launches and ablations for the A/B scripts under benchmarks/) are NOT part of this library: they are declared in

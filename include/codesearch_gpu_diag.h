@@ -21,7 +21,7 @@ extern "C" {
  * Wide kernel, N = 384 only: 3 = + resid, then LayerNorm (gamma = bias + 1, beta = -bias) in the same kernel, f32 and
  * split outputs; 4 = the same with the residual handed over in split form in the output buffer and no f32 output (how
  * the encoder runs it).  *range_flag (optional) is set when a split-f16 operand left the f16 range. */
-int32_t cs_debug_gemm(int32_t device, int32_t mode, int32_t epilogue, const float* A,
+CS_API int32_t cs_debug_gemm(int32_t device, int32_t mode, int32_t epilogue, const float* A,
                       const float* W, const float* bias, const float* resid, float* C,
                       uint32_t M, uint32_t N, uint32_t K, uint32_t* range_flag);
 
@@ -35,7 +35,7 @@ int32_t cs_debug_gemm(int32_t device, int32_t mode, int32_t epilogue, const floa
  * epilogue 5 = the FFN-up form (GELU, then quantised again for the next Linear, two passes over the product): C receives
  * the uint8 output as floats, xparams (then FOUR floats) also its (scale, zero_point), the first M entries of acc each
  * output row's sum of uint8 values. */
-int32_t cs_debug_gemm_q8(int32_t device, int32_t epilogue, int32_t a_split, const float* A, const float* W,
+CS_API int32_t cs_debug_gemm_q8(int32_t device, int32_t epilogue, int32_t a_split, const float* A, const float* W,
                          const float* wscale, const float* bias, const float* resid, float* C, uint32_t M, uint32_t N,
                          uint32_t K, uint8_t* xq, float* xparams, int32_t* acc);
 
@@ -45,9 +45,16 @@ int32_t cs_debug_gemm_q8(int32_t device, int32_t epilogue, int32_t a_split, cons
  * products only (K = 384, M >= 4,096); epilogue 4 (f32 source -> split store), 2 (split source, + residual), 5 (FFN-up:
  * GELU, quantised again per unit; C = the uint8 output as floats).  row_params [M][4] = per row (x_scale, x_zero_point,
  * out_scale, out_zero_point) (the last two: epilogue 5), rowsums [M] (epilogue 5) each output row's sum of uint8 values. */
-int32_t cs_debug_gemm_q8_units(int32_t device, int32_t epilogue, const float* A, const float* W, const float* wscale,
+CS_API int32_t cs_debug_gemm_q8_units(int32_t device, int32_t epilogue, const float* A, const float* W, const float* wscale,
                                const float* bias, const float* resid, float* C, uint32_t M, uint32_t N, uint32_t K,
                                const uint32_t* row_slot, uint32_t units, float* row_params, int32_t* rowsums);
+
+/* Diagnostics: the one-launch forward of short queries (csrc/small_forward.hip; embed_one / embed_queries_batch,
+ * src/embed/mod.rs:164-226) — mini-batches of a 384-d BERT model with at most 192 token rows in split-f16 mode as ONE kernel,
+ * bit-identical to the kernel-by-kernel path and measured slower than it (profiles/r05_small_forward_ab.log), so it is built
+ * into this library only and taken with CS_SMALL_FORWARD=1: how many mini-batches took it, and how many of those gave up at
+ * a grid barrier and were re-run kernel by kernel. */
+CS_API int32_t cs_debug_small_forward_counters(cs_embedder* h, uint64_t* forwards, uint64_t* fallbacks);
 
 /* Diagnostics: device milliseconds per launch of one dense layer on synthetic operands resident in HBM.
  * mode 0 exact-f32 MFMA, 1 split-f16 (128 x 128 / skinny kernels), 2 split-f16 wide kernel (N % 384 == 0);
@@ -55,7 +62,7 @@ int32_t cs_debug_gemm_q8_units(int32_t device, int32_t epilogue, const float* A,
  * ablation (mode 2): 0 none; epilogue 4 only: 1 no LDS-DMA, 2 no MFMA, 3 DMAs issued at the start of a k-step, 4-10 see
  * gemm_wide.hip; any epilogue: 192 / 384 = that block shape of the product kernel.  CS_DEBUG_GEMM_ZERO=1: all-zero operands
  * (the same instruction stream at the clock the chip holds on trivial data). */
-int32_t cs_debug_gemm_time(int32_t device, int32_t mode, int32_t epilogue, uint32_t M, uint32_t N, uint32_t K,
+CS_API int32_t cs_debug_gemm_time(int32_t device, int32_t mode, int32_t epilogue, uint32_t M, uint32_t N, uint32_t K,
                            uint32_t iters, int32_t ablation, double* ms_per_launch);
 
 #ifdef __cplusplus

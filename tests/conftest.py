@@ -62,6 +62,19 @@ def gpu_lib():
     return _lib.load()
 
 
+@pytest.fixture
+def lab_lib(monkeypatch):
+    """libcsgpu_diag.so standing in for the product library for ONE test: FastEmbedder / VectorStore objects created
+    inside the test bind to it.  Laboratory knobs (cs_lab_env in csrc/common.hpp: tile shapes, rejected kernel variants,
+    fault injection) and the variants themselves (the one-launch forward, the 32x32x16 wide GEMM, the non-default
+    attention loops) exist only there; the product library reads none of them."""
+    from codesearch_amd import _lib
+
+    diag = _lib.load_diag()
+    monkeypatch.setattr(_lib, "_LIB", diag)
+    return diag
+
+
 @pytest.fixture(scope="session")
 def diag_lib():
     """libcsgpu_diag.so: the product sources built with -DCS_DIAGNOSTICS, which adds the operator-level cs_debug_* entry

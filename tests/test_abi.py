@@ -34,13 +34,22 @@ def test_diagnostics_live_in_their_own_library(gpu_lib):
     from codesearch_amd import _lib
 
     diag = declared_symbols("codesearch_gpu_diag.h")
-    assert diag == set(_lib.DIAG_SIGNATURES) and all(s.startswith("cs_debug_") for s in diag), diag
+    assert diag == set(_lib.DIAG_SIGNATURES) and all(s.startswith("cs_debug_") for s in diag), diag ^ set(_lib.DIAG_SIGNATURES)
     raw = ctypes.CDLL(_lib.DIAG_LIB_PATH, mode=ctypes.RTLD_LOCAL)
     for s in sorted(diag | declared_symbols()):
         assert hasattr(raw, s), f"{s} not exported by libcsgpu_diag.so"
     exported = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], check=True, capture_output=True, text=True).stdout
-    for needle in ("cs_debug_", "g_gw_stamps", "g_gemm_wide_ablation"):
+    for needle in ("cs_debug_", "g_gw_stamps", "g_gemm_wide_ablation", "gemm_wide32", "small_forward"):
         assert needle not in exported, f"{needle} leaked into libcsgpu.so"
+    # built with -fvisibility=hidden behind a version script: the dynamic symbol table IS the C ABI — no cs:: function, no
+    # kernel stub, no template instantiation beside the entry points the header declares
+    names = [l.split()[-1] for l in exported.splitlines() if l.strip()]
+    assert sorted(names) == sorted(declared_symbols()), set(names) ^ declared_symbols()
+    # the rejected variants are not merely unexported: their kernels are not in the product's code object at all
+    blob = open(_lib.LIB_PATH, "rb").read()
+    for needle in (b"gemm_wide32_kernel", b"small_forward_kernel", b"attention_sh2_kernel"):
+        assert needle not in blob, needle
+        assert needle in open(_lib.DIAG_LIB_PATH, "rb").read(), needle
     assert not (set(_lib.SIGNATURES) & set(_lib.DIAG_SIGNATURES))
 
 

@@ -629,9 +629,14 @@ for i, cfg in enumerate(cfgs):
     emb.close()
 print("DIGEST", h.hexdigest())
 ''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    from codesearch_amd import _lib
+
+    # the four forms live in the diagnostic library (CS_ATTN_PIPE is a laboratory knob); the product library holds each head
+    # width's default form only — run last, through libcsgpu.so itself: the same bits again
     digests = {}
-    for form in "0123":
-        r = subprocess.run([sys.executable, "-c", script], env=dict(os.environ, CS_ATTN_PIPE=form), capture_output=True, text=True, timeout=600)
+    for form in ["0", "1", "2", "3", "product"]:
+        env = dict(os.environ) if form == "product" else dict(os.environ, CS_ATTN_PIPE=form, CS_LIBCSGPU=_lib.DIAG_LIB_PATH)
+        r = subprocess.run([sys.executable, "-c", script], env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         digests[form] = [l for l in r.stdout.splitlines() if l.startswith("DIGEST")][0]
     assert len(set(digests.values())) == 1, digests

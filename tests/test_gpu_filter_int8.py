@@ -55,9 +55,10 @@ def test_filter_copy_choice_does_not_change_a_bit(VS, monkeypatch, int8, dim, n,
 
 @pytest.mark.parametrize("dim,n,nq,k", [(384, 50_000, 300, 10), (384, 33_000, 1000, 10), (768, 20_100, 260, 25),
                                         (1024, 10_000, 257, 10)])
-def test_int8_tile_kernel_for_query_counts_past_the_resident_limit(VS, monkeypatch, dim, n, nq, k):
+def test_int8_tile_kernel_for_query_counts_past_the_resident_limit(lab_lib, VS, monkeypatch, dim, n, nq, k):
     """Past 32 query tiles the int8 copy goes through the 256 x 256 tile kernel (score_filter256p_kernel<true>);
-    CS_FILTER_INT8_RW_MAX_Q lowers the switch-over so that a few hundred queries reach it.  Odd tile counts: the last
+    CS_FILTER_INT8_RW_MAX_Q (a laboratory knob: the diagnostic library, lab_lib) lowers the switch-over so that a few hundred
+    queries reach it.  Odd tile counts: the last
     256-row block holds one real 128-row tile."""
     monkeypatch.setenv("CS_FILTER_INT8_RW_MAX_Q", "128")
     monkeypatch.setenv("CS_FILTER_SINGLE_MIN_K", "0")
@@ -76,7 +77,7 @@ def test_int8_tile_kernel_for_query_counts_past_the_resident_limit(VS, monkeypat
 
 @pytest.mark.parametrize("rq", ["1", "0"])
 @pytest.mark.parametrize("n,nq,k", [(70_000, 129, 10), (50_000, 257, 64), (33_000, 700, 10)])
-def test_many_queries_both_resident_query_kernels(VS, monkeypatch, rq, n, nq, k):
+def test_many_queries_both_resident_query_kernels(lab_lib, VS, monkeypatch, rq, n, nq, k):
     """Above 128 queries at dim 384 the int8 copy is scored by score_filter_rq8_kernel (eight waves per block, corpus
     fragments through registers); CS_FILTER_INT8_RQ=0 keeps score_filter_rw8_kernel<8, 3>.  Odd tile counts: the last
     256-row unit holds one real 128-row tile."""
@@ -99,7 +100,7 @@ def test_many_queries_both_resident_query_kernels(VS, monkeypatch, rq, n, nq, k)
 @pytest.mark.parametrize("q2", ["2", "0"])
 @pytest.mark.parametrize("dim,n,nq,k", [(384, 200_000, 9, 200), (384, 150_000, 33, 10), (384, 120_000, 64, 100),
                                         (768, 60_000, 8, 200), (768, 50_000, 40, 25)])
-def test_two_plane_queries_do_not_change_a_bit(VS, monkeypatch, q2, dim, n, nq, k):
+def test_two_plane_queries_do_not_change_a_bit(lab_lib, VS, monkeypatch, q2, dim, n, nq, k):
     """CS_FILTER_INT8_Q2=2 takes every search of up to 64 queries through the two-plane query kernels (default: long
     lists of up to 32 queries only), =0 none: same bits either way; adversarial magnitudes ride along."""
     monkeypatch.setenv("CS_FILTER_INT8_Q2", q2)
@@ -332,7 +333,7 @@ def test_two_overflows_through_the_int8_copy_retire_it(VS, oracle, monkeypatch):
     assert st.filter_copies()[1]         # ... built by the first search that overflowed
 
 
-def test_filter_copy_allocation_failures_fall_back_without_corruption(VS, monkeypatch):
+def test_filter_copy_allocation_failures_fall_back_without_corruption(lab_lib, VS, monkeypatch):
     """ADVICE r3 (index.hip grow): when a filter copy cannot be (re)allocated while the corpus grows, the stale smaller
     buffer must not survive.  CS_FAULT_INT8_ALLOC makes the int8 reallocation of a grow fail: the index drops the int8
     copy, the next build makes the f16 one, answers stay bit-identical to the single-query scans.  With the f16 allocation
@@ -370,7 +371,7 @@ def test_filter_copy_allocation_failures_fall_back_without_corruption(VS, monkey
 
 
 @pytest.mark.parametrize("stage", [2, 3, 4, 5, 6])
-def test_a_failing_copy_inside_grow_leaves_the_index_as_it_was(VS, monkeypatch, stage):
+def test_a_failing_copy_inside_grow_leaves_the_index_as_it_was(lab_lib, VS, monkeypatch, stage):
     """VERDICT r4 #13 (index.hip grow): a copy that fails between the new buffers' allocation and the pointer swap must
     neither leak them nor leave the index half-moved.  CS_FAULT_GROW_COPY=<stage> makes that stage's copy report a failure:
     the insert returns an error, free device memory is what it was, the index still answers from its old rows with the same

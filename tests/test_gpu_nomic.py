@@ -191,7 +191,10 @@ def test_gate_in_the_product_epilogue_equals_the_separate_kernel(FE, oracle, hid
         "emb = FastEmbedder(ModelType.NomicEmbedTextV15, config=cfg, seed=412)\n"
         "np.save(sys.argv[1], emb.embed_ids(ids, mask))\n")
     out = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"nomic_unfused_{hidden}_{B}_{L}.npy")
-    env = dict(os.environ, CS_NOMIC_GATE_FUSED="0")
+    from codesearch_amd import _lib
+
+    # (a laboratory knob: read by the diagnostic library only)
+    env = dict(os.environ, CS_NOMIC_GATE_FUSED="0", CS_LIBCSGPU=_lib.DIAG_LIB_PATH)
     subprocess.run([sys.executable, "-c", code, out], check=True, env=env, cwd=os.path.dirname(os.path.dirname(__file__)))
     unfused = np.load(out)
     os.remove(out)

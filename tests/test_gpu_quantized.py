@@ -361,6 +361,38 @@ def test_one_quantised_layer_is_the_oracles_except_for_flipped_bytes(gpu_lib, or
     emb.close()
 
 
+def test_activations_beyond_the_f16_range_degrade_instead_of_failing(gpu_lib, oracle):
+    """onnxruntime embeds whatever the activations are (/root/reference/src/embed/embedder.rs:286-289); this mode hands Q / K / V
+    and the attention output over in split-f16 form, which ends at 65504.  A value-bias block of 1e5 trips that: the
+    mini-batch is then run again as the f32 graph of the dequantised weights (the same model without the 8-bit rounding of
+    the activations) and counted — not refused.  The result against the oracle's f32 evaluation of those weights, and a
+    mini-batch that stays in range against the quantised oracle as always."""
+    from codesearch_amd import FastEmbedder, ModelType
+    from codesearch_amd.bert_params import to_state_dict, from_state_dict
+
+    cfg = small_cfg(POOL_MEAN)
+    params, wscale = quantize_linear_weights(cfg, synth_params(cfg, 31), per_channel=False, unsigned=True)
+    sd = to_state_dict(cfg, params)
+    sd["encoder.layer.0.attention.self.value.bias"] = sd["encoder.layer.0.attention.self.value.bias"] + np.float32(1.0e5)
+    big = from_state_dict(cfg, sd)
+    ids, mask = synth_token_batch(cfg, 6, 16, 40, True)
+    emb = FastEmbedder(ModelType.AllMiniLML6V2Q, config=cfg, params=big, wscale=wscale)
+    assert emb.gemm_mode() == "q8"
+    got = emb.embed_ids(ids, mask)                     # (before: CS_ERR_UNSUPPORTED "left the f16 range")
+    _, f32_forwards, fallbacks = emb.debug_counters()
+    assert fallbacks == 1 and f32_forwards == 1
+    want = oracle.bert_forward(cfg, big, ids, mask)["pooled"]          # the f32 graph of the dequantised weights
+    assert np.isfinite(got).all() and np.abs(got - want).max() < 1e-4
+    emb.close()
+    # the same weights without the block: no fallback, the quantised graph
+    emb = FastEmbedder(ModelType.AllMiniLML6V2Q, config=cfg, params=params, wscale=wscale)
+    got = emb.embed_ids(ids, mask)
+    assert emb.debug_counters()[2] == 0
+    want = oracle.bert_forward(cfg, params, ids, mask, wscale=wscale)["pooled"]
+    assert np.abs(got - want).max() < 3e-3
+    emb.close()
+
+
 @pytest.mark.parametrize("pooling", [POOL_MEAN, POOL_CLS])
 @pytest.mark.parametrize("per_channel,unsigned", [(False, True), (True, False)])
 def test_quantised_forward_against_the_oracle(gpu_lib, oracle, pooling, per_channel, unsigned):

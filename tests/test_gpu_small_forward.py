@@ -16,6 +16,13 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def _one_launch_forward_lives_in_the_diagnostic_library(lab_lib):
+    """small_forward.hip is built into libcsgpu_diag.so only (it is bit-identical to the launch chain and slower): every
+    embedder of this module is created through that library."""
+    yield
+
+
 def _embed(emb, ids, mask, on, monkeypatch):
     monkeypatch.setenv("CS_SMALL_FORWARD", "1" if on else "0")
     return emb.embed_ids(ids, mask)
