@@ -70,6 +70,7 @@ SIGNATURES = {
     "cs_index_clear": (C.c_int32, [vp]),
     "cs_index_is_built": (C.c_int32, [vp]),
     "cs_index_len": (C.c_uint64, [vp]),
+    "cs_index_stored_rows": (C.c_uint64, [vp]),
     "cs_index_next_id": (C.c_uint32, [vp]),
     "cs_index_dim": (C.c_uint32, [vp]),
     "cs_index_device": (C.c_int32, [vp]),
@@ -90,6 +91,7 @@ SIGNATURES = {
     "cs_shards_clear": (C.c_int32, [vp]),
     "cs_shards_is_built": (C.c_int32, [vp]),
     "cs_shards_len": (C.c_uint64, [vp]),
+    "cs_shards_stored_rows": (C.c_uint64, [vp]),
     "cs_shards_next_id": (C.c_uint32, [vp]),
     "cs_shards_dim": (C.c_uint32, [vp]),
     "cs_shards_count": (C.c_uint32, [vp]),

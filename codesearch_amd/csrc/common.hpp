@@ -82,6 +82,17 @@ struct DeviceGuard {
 };
 
 // ---- packed sort key (mirrors cs_key_* in the public header) ------------------------------
+// The id of a corpus row.  A never-compacted index numbers its rows in storage order (id = base + row, store.rs:659-685); once
+// cs_index_build has squeezed deleted rows out, the surviving rows keep their ids through a row -> id table in HBM (ascending, so
+// "(cosine desc, id asc)" and the strict-> insert rule are untouched).  The table is read on the candidate path only — a few
+// rows per search, never per row scanned.
+struct RowIds {
+    uint32_t base;
+    const uint32_t* ids;  // [rows] or null (identity)
+    __host__ __device__ RowIds(uint32_t b = 0, const uint32_t* t = nullptr) : base(b), ids(t) {}
+    __device__ __forceinline__ uint32_t of(uint64_t row) const { return ids ? ids[row] : base + (uint32_t)row; }
+};
+
 __host__ __device__ __forceinline__ uint64_t key_pack(float c, uint32_t id) {
     c = c + 0.0f;  // -0 -> +0
 #if defined(__HIP_DEVICE_COMPILE__)

@@ -248,8 +248,20 @@ struct cs_index {
     uint32_t dim = 0;
     uint32_t id_base = 0;
     uint64_t capacity = 0;   // rows allocated
-    uint64_t n_rows = 0;     // rows appended (next_id - id_base)
-    uint64_t n_removed = 0;
+    uint64_t n_rows = 0;     // rows in storage
+    uint64_t n_ids = 0;      // ids issued (next_id - id_base): n_rows until cs_index_build first reclaims deleted rows
+    uint64_t n_removed = 0;  // tombstoned rows still in storage
+    // Reclaiming deleted rows (store.rs:548-610: arroy drops deleted items at the next build; the incremental `index` deletes a
+    // changed file's chunks and re-inserts them, src/index/mod.rs:525,544 — a store re-indexed daily would otherwise only grow):
+    // when at least compact_dead_pct % of the stored rows are tombstones, cs_index_build rewrites corpus (norms and the filter
+    // copies are rebuilt from it) without them.  Ids stay what they were: h_ids / d_ids = the id of each stored row,
+    // ascending; empty = never compacted, id = id_base + row.  (CS_INDEX_COMPACT_DEAD_PCT, default 10; 0 = never.)
+    std::vector<uint32_t> h_ids;
+    uint32_t* d_ids = nullptr;
+    uint64_t ids_cap = 0, ids_uploaded = 0;
+    uint32_t compact_dead_pct = 10;
+    uint64_t compactions = 0;
+    RowIds row_ids() const { return RowIds(id_base, h_ids.empty() ? nullptr : d_ids); }
     float* d_corpus = nullptr;
     uint32_t* d_dead = nullptr;  // bitmap over rows, sized for `capacity`
     float* d_norms = nullptr;    // |row| for rows [0, normed_rows) (batched-query path)
@@ -495,20 +507,91 @@ bool ensure_f16(cs_index* h) {
     return true;
 }
 
+// rows idx[0 .. n) of src (relative to it) -> dst rows 0 .. n, `dim` floats each
+__global__ void __launch_bounds__(256)
+gather_rows_kernel(const float* __restrict__ src, const uint32_t* __restrict__ idx, uint64_t n, uint32_t dim, float* __restrict__ dst) {
+    const uint64_t total = n * dim;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (uint64_t)gridDim.x * 256) {
+        const uint64_t r = i / dim;
+        dst[i] = src[(size_t)idx[r] * dim + (i - r * dim)];
+    }
+}
+
+// cs_index_build, when enough of the stored rows are tombstones: the live rows move to the front of the corpus in their order
+// (chunk by chunk: a chunk's survivors are gathered straight into place when their destination lies wholly before the chunk,
+// through a bounded staging buffer otherwise — never a second corpus), the row -> id table keeps their ids, and everything
+// derived from the rows (norms, mean unit row, int8 / f16 filter copies) is rebuilt by the build that called this.  A search
+// afterwards streams only live rows, and returns what it returned before: the same ids, the same cosines, bit for bit.
+int32_t compact(cs_index* h) {
+    const uint64_t live = h->n_rows - h->n_removed;
+    constexpr uint64_t CH = 1u << 18;  // rows per chunk (staging: 403 MB at dim 384)
+    const uint64_t chunk = std::min<uint64_t>(CH, h->n_rows);
+    struct Tmp {
+        float* rows = nullptr; uint32_t* idx = nullptr;
+        ~Tmp() { if (rows) (void)hipFree(rows); if (idx) (void)hipFree(idx); }
+    } t;
+    CS_HIP(hipMalloc(&t.rows, (size_t)chunk * h->dim * sizeof(float)));
+    CS_HIP(hipMalloc(&t.idx, (size_t)chunk * sizeof(uint32_t)));
+    std::vector<uint32_t> nid;
+    nid.reserve((size_t)live);
+    std::vector<uint32_t> idx;
+    idx.reserve((size_t)chunk);
+    const bool ident = h->h_ids.empty();
+    uint64_t dst = 0;
+    for (uint64_t c0 = 0; c0 < h->n_rows; c0 += chunk) {
+        const uint64_t c1 = std::min(h->n_rows, c0 + chunk);
+        idx.clear();
+        for (uint64_t r = c0; r < c1; ++r)
+            if (!((h->h_dead[(size_t)(r >> 5)] >> (r & 31)) & 1u)) {
+                idx.push_back((uint32_t)(r - c0));
+                nid.push_back(ident ? h->id_base + (uint32_t)r : h->h_ids[(size_t)r]);
+            }
+        const uint64_t cnt = idx.size();
+        if (cnt == 0) continue;
+        if (dst == c0 && cnt == c1 - c0) { dst += cnt; continue; }  // nothing deleted up to here: the rows are in place
+        CS_HIP(hipMemcpyAsync(t.idx, idx.data(), (size_t)cnt * sizeof(uint32_t), hipMemcpyHostToDevice, nullptr));
+        const uint32_t blocks = (uint32_t)std::min<uint64_t>((cnt * h->dim + 255) / 256, (uint64_t)h->num_cus * 16);
+        const bool direct = dst + cnt <= c0;  // the destination does not reach into the chunk being read
+        hipLaunchKernelGGL(gather_rows_kernel, dim3(blocks), dim3(256), 0, nullptr, h->d_corpus + (size_t)c0 * h->dim, t.idx, cnt, h->dim,
+                           direct ? h->d_corpus + (size_t)dst * h->dim : t.rows);
+        CS_HIP(hipGetLastError());
+        if (!direct)
+            CS_HIP(hipMemcpyAsync(h->d_corpus + (size_t)dst * h->dim, t.rows, (size_t)cnt * h->dim * sizeof(float), hipMemcpyDeviceToDevice, nullptr));
+        CS_HIP(hipStreamSynchronize(nullptr));  // (idx is reused by the next chunk)
+        dst += cnt;
+    }
+    if (dst != live) return fail(CS_ERR_HIP, "compaction moved %llu rows, expected %llu", (unsigned long long)dst, (unsigned long long)live);
+    h->n_rows = live;
+    h->n_removed = 0;
+    h->h_dead.assign((size_t)((live + 31) / 32), 0u);
+    if (h->d_dead && h->capacity) CS_HIP(hipMemset(h->d_dead, 0, (size_t)((h->capacity + 31) / 32) * sizeof(uint32_t)));
+    h->h_ids.swap(nid);
+    h->ids_uploaded = 0;
+    // everything derived from the rows is rebuilt over the new storage order by the build that follows
+    h->normed_rows = 0;
+    h->q8_rows = 0;
+    h->split_rows = 0;
+    h->compactions += 1;
+    return CS_OK;
+}
+
 int32_t check_append(cs_index* h, uint64_t n, uint32_t dim) {
     if (!h) return fail(CS_ERR_BAD_ARG, "null index handle");
     if (dim != h->dim)  // store.rs:667-671
         return fail(CS_ERR_DIM_MISMATCH, "Embedding dimension mismatch: expected %u, got %u",
                     h->dim, dim);
-    if ((uint64_t)h->id_base + h->n_rows + n > 0xffffffffull)
+    if ((uint64_t)h->id_base + h->n_ids + n > 0xffffffffull)
         return fail(CS_ERR_BAD_ARG, "id space exhausted: ids are u32 (store.rs:97)");
     return CS_OK;
 }
 
 void finish_append(cs_index* h, uint64_t n, uint32_t* out_ids) {
-    const uint32_t start = h->id_base + (uint32_t)h->n_rows;
+    const uint32_t start = h->id_base + (uint32_t)h->n_ids;   // ids are never reused (store.rs:101)
     if (out_ids)
         for (uint64_t i = 0; i < n; ++i) out_ids[i] = start + (uint32_t)i;  // store.rs:684
+    if (!h->h_ids.empty())  // a compacted index: the new rows' ids join the row -> id table (uploaded by the next build)
+        for (uint64_t i = 0; i < n; ++i) h->h_ids.push_back(start + (uint32_t)i);
+    h->n_ids += n;
     h->n_rows += n;
     h->h_dead.resize((size_t)((h->n_rows + 31) / 32), 0u);
     if (n) h->built = false;  // store.rs:682
@@ -643,12 +726,12 @@ int32_t run_search(cs_index* h, Workspace* w, const ScanPlan& plan, const float*
                 h->q8_searches.fetch_add(1);
             }
             CS_TRY(launch_scan_split(w->bs, w->qw, h->d_corpus, h->d_split, h->n_rows, h->dim,
-                                     d_queries, nq, k, h->n_removed ? h->d_dead : nullptr, h->id_base, d_keys,
+                                     d_queries, nq, k, h->n_removed ? h->d_dead : nullptr, h->row_ids(), d_keys,
                                      d_cos, d_ids, d_counts, stream, h->filter_margin, &q8));
         } else {
             w->last_via_q8 = false;
             CS_TRY(launch_scan_batched(w->bs, h->d_corpus, h->d_norms, h->n_rows, h->dim, d_queries, nq, k,
-                                       h->n_removed ? h->d_dead : nullptr, h->id_base, h->num_cus, d_keys, d_cos,
+                                       h->n_removed ? h->d_dead : nullptr, h->row_ids(), h->num_cus, d_keys, d_cos,
                                        d_ids, d_counts, stream));
         }
         if (timed) CS_HIP(hipEventRecord(ev.e1, stream));
@@ -665,7 +748,7 @@ int32_t run_search(cs_index* h, Workspace* w, const ScanPlan& plan, const float*
             if (can_overflow && nq <= kGatedMaxQ) {
                 const uint32_t* gate = w->bs.d_overflow;
                 CS_TRY(launch_scan(plan, h->d_corpus, h->n_rows, h->dim, d_queries, nq, k,
-                                   h->n_removed ? h->d_dead : nullptr, h->id_base, w->d_partial, stream, nullptr, false,
+                                   h->n_removed ? h->d_dead : nullptr, h->row_ids(), w->d_partial, stream, nullptr, false,
                                    gate));
                 CS_TRY(launch_merge(w->d_partial, plan.blocks, nq, k, false, w->d_tmp_a, w->d_tmp_b, d_keys, d_cos, d_ids,
                                     d_counts, stream, gate));
@@ -689,7 +772,7 @@ int32_t run_search(cs_index* h, Workspace* w, const ScanPlan& plan, const float*
                 // before the exact list-based scan is asked to
                 w->last_via_q8 = false;
                 CS_TRY(launch_scan_split(w->bs, w->qw, h->d_corpus, h->d_split, h->n_rows, h->dim, d_queries, nq, k,
-                                         h->n_removed ? h->d_dead : nullptr, h->id_base, d_keys, d_cos, d_ids, d_counts,
+                                         h->n_removed ? h->d_dead : nullptr, h->row_ids(), d_keys, d_cos, d_ids, d_counts,
                                          stream, h->filter_margin, nullptr));
                 CS_HIP(hipMemcpyAsync(w->h_overflow, w->bs.d_overflow, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
                 CS_HIP(hipStreamSynchronize(stream));
@@ -715,7 +798,7 @@ int32_t run_search(cs_index* h, Workspace* w, const ScanPlan& plan, const float*
         ev = none;
         return [&]() -> int32_t {
             CS_TRY(launch_scan(plan, h->d_corpus, h->n_rows, h->dim, d_queries, nq, k,
-                               h->n_removed ? h->d_dead : nullptr, h->id_base, w->d_partial, stream));
+                               h->n_removed ? h->d_dead : nullptr, h->row_ids(), w->d_partial, stream));
             return launch_merge(w->d_partial, plan.blocks, nq, k, false, w->d_tmp_a, w->d_tmp_b, d_keys, d_cos,
                                 d_ids, d_counts, stream);
         }();
@@ -738,11 +821,11 @@ int32_t run_search(cs_index* h, Workspace* w, const ScanPlan& plan, const float*
         h->n_rows >= 4 * prime_rows && scan_prime_supported(h->dim)) {
         const ScanPlan pp = plan_prime(prime_rows, h->dim, nq, k, h->num_cus);
         CS_TRY(w->reserve_prime(pp, nq));
-        CS_TRY(launch_scan(pp, h->d_corpus, prime_rows, h->dim, d_queries, nq, k, d_dead, h->id_base,
+        CS_TRY(launch_scan(pp, h->d_corpus, prime_rows, h->dim, d_queries, nq, k, d_dead, h->row_ids(),
                            nullptr, stream, &w->prime, true));
         prime = &w->prime;
     }
-    CS_TRY(launch_scan(plan, h->d_corpus, h->n_rows, h->dim, d_queries, nq, k, d_dead, h->id_base,
+    CS_TRY(launch_scan(plan, h->d_corpus, h->n_rows, h->dim, d_queries, nq, k, d_dead, h->row_ids(),
                        w->d_partial, stream, prime));
     if (timed) CS_HIP(hipEventRecord(ev.e1, stream));
     CS_TRY(launch_merge(w->d_partial, plan.blocks, nq, k, false, w->d_tmp_a, w->d_tmp_b, d_keys, d_cos,
@@ -817,6 +900,7 @@ int32_t cs_index_create(uint32_t dim, uint64_t capacity_rows, int32_t device, ui
             h->single_filter_min_k = (uint32_t)std::atol(e);
             if (h->single_filter_min_k == 0) h->single_route = CS_ROUTE_STREAM;
         }
+        if (const char* e = std::getenv("CS_INDEX_COMPACT_DEAD_PCT")) h->compact_dead_pct = (uint32_t)std::max(0, std::min(100, std::atoi(e)));
         if (const char* e = std::getenv("CS_FILTER_SINGLE_MIN_ROWS")) h->single_int8_min_rows = (uint64_t)std::atoll(e);
         if (const char* e = std::getenv("CS_FILTER_SINGLE_MIN_ROWS_LONG")) h->single_int8_min_rows_long = (uint64_t)std::atoll(e);
         if (const char* e = cs_lab_env("CS_FILTER_FEW_MIN_ROWS")) h->few_queries_min_rows = h->few_queries_min_rows_short = (uint64_t)std::atoll(e);
@@ -863,6 +947,7 @@ void cs_index_destroy(cs_index* h) {
     if (h->d_q8) (void)hipFree(h->d_q8);
     if (h->d_tmeta) (void)hipFree(h->d_tmeta);
     if (h->d_mu) (void)hipFree(h->d_mu);
+    if (h->d_ids) (void)hipFree(h->d_ids);
     delete h;
 }
 
@@ -900,7 +985,7 @@ int32_t cs_index_add_synthetic(cs_index* h, uint64_t n, uint64_t seed, uint64_t 
     CS_TRY(launch_synth_fill(h->d_corpus + (size_t)h->n_rows * h->dim, n, h->dim, seed, first_row,
                              nullptr));
     CS_HIP(hipStreamSynchronize(nullptr));
-    if (out_first_id) *out_first_id = h->id_base + (uint32_t)h->n_rows;
+    if (out_first_id) *out_first_id = h->id_base + (uint32_t)h->n_ids;
     finish_append(h, n, nullptr);
     return CS_OK;
 }
@@ -913,7 +998,12 @@ int32_t cs_index_remove(cs_index* h, const uint32_t* ids, uint64_t n, uint64_t* 
     uint64_t cnt = 0;
     for (uint64_t i = 0; i < n; ++i) {
         if (ids[i] < h->id_base) continue;
-        const uint64_t row = (uint64_t)ids[i] - h->id_base;
+        uint64_t row = (uint64_t)ids[i] - h->id_base;
+        if (!h->h_ids.empty()) {  // compacted: the id's row by bisection of the ascending row -> id table
+            const auto it = std::lower_bound(h->h_ids.begin(), h->h_ids.end(), ids[i]);
+            if (it == h->h_ids.end() || *it != ids[i]) continue;  // never issued, or deleted and reclaimed: not counted
+            row = (uint64_t)(it - h->h_ids.begin());
+        }
         if (row >= h->n_rows) continue;  // del_item fails -> not counted (store.rs:594)
         uint32_t& w = h->h_dead[(size_t)(row >> 5)];
         const uint32_t bit = 1u << (row & 31);
@@ -936,6 +1026,21 @@ int32_t cs_index_build(cs_index* h) {
     if (!h) return fail(CS_ERR_BAD_ARG, "null index handle");
     DeviceGuard g(h->device);
     CS_TRY(drain_appends(h));  // appended rows (incl. async device appends) are now visible
+    if (h->compact_dead_pct && h->n_removed && h->n_removed * 100 >= (uint64_t)h->compact_dead_pct * h->n_rows) CS_TRY(compact(h));
+    if (!h->h_ids.empty() && h->ids_uploaded < h->n_rows) {  // the row -> id table of a compacted index, for the rows that are new
+        if (h->ids_cap < h->n_rows) {
+            uint32_t* nt = nullptr;
+            const uint64_t cap = std::max<uint64_t>(h->capacity, h->n_rows);
+            CS_HIP(hipMalloc(&nt, (size_t)cap * sizeof(uint32_t)));
+            if (h->d_ids) (void)hipFree(h->d_ids);
+            h->d_ids = nt;
+            h->ids_cap = cap;
+            h->ids_uploaded = 0;
+        }
+        CS_HIP(hipMemcpy(h->d_ids + h->ids_uploaded, h->h_ids.data() + h->ids_uploaded,
+                         (size_t)(h->n_rows - h->ids_uploaded) * sizeof(uint32_t), hipMemcpyHostToDevice));
+        h->ids_uploaded = h->n_rows;
+    }
     if ((batched_supported(h->dim) || h->use_split) && h->normed_rows < h->n_rows) {
         CS_TRY(launch_row_norms(h->d_corpus, h->normed_rows, h->n_rows - h->normed_rows, h->dim,
                                 h->d_norms, nullptr));
@@ -993,6 +1098,9 @@ int32_t cs_index_clear(cs_index* h) {
     if (h->d_dead && h->capacity)
         CS_HIP(hipMemset(h->d_dead, 0, (size_t)((h->capacity + 31) / 32) * sizeof(uint32_t)));
     h->n_rows = 0;  // store.rs:701 next_id = 0
+    h->n_ids = 0;
+    h->h_ids.clear();
+    h->ids_uploaded = 0;
     h->normed_rows = 0;
     h->split_rows = 0;
     h->f16_failed = false;
@@ -1008,7 +1116,8 @@ int32_t cs_index_clear(cs_index* h) {
 
 int32_t cs_index_is_built(const cs_index* h) { return h && h->built ? 1 : 0; }
 uint64_t cs_index_len(const cs_index* h) { return h ? h->n_rows - h->n_removed : 0; }
-uint32_t cs_index_next_id(const cs_index* h) { return h ? h->id_base + (uint32_t)h->n_rows : 0; }
+uint64_t cs_index_stored_rows(const cs_index* h) { return h ? h->n_rows : 0; }
+uint32_t cs_index_next_id(const cs_index* h) { return h ? h->id_base + (uint32_t)h->n_ids : 0; }
 uint32_t cs_index_dim(const cs_index* h) { return h ? h->dim : 0; }
 int32_t cs_index_device(const cs_index* h) { return h ? h->device : -1; }
 
@@ -1252,13 +1361,29 @@ extern "C" {
 
 int32_t cs_index_read_rows(cs_index* h, uint64_t first_row, uint64_t n, float* out_rows) {
     if (!h || !out_rows) return fail(CS_ERR_BAD_ARG, "null argument");
-    if (first_row + n > h->n_rows)
+    if (first_row + n > h->n_ids)
         return fail(CS_ERR_BAD_ARG, "rows [%llu, %llu) out of range (have %llu)",
                     (unsigned long long)first_row, (unsigned long long)(first_row + n),
-                    (unsigned long long)h->n_rows);
+                    (unsigned long long)h->n_ids);
     if (n == 0) return CS_OK;
     DeviceGuard g(h->device);
     CS_TRY(drain_appends(h));
+    if (!h->h_ids.empty()) {  // compacted: rows are named by their ids (first_row = id - id_base); runs of neighbours in one copy
+        uint64_t i = 0;
+        while (i < n) {
+            const uint32_t id = h->id_base + (uint32_t)(first_row + i);
+            const auto it = std::lower_bound(h->h_ids.begin(), h->h_ids.end(), id);
+            if (it == h->h_ids.end() || *it != id)
+                return fail(CS_ERR_BAD_ARG, "row of id %u was deleted and reclaimed by cs_index_build", id);
+            const uint64_t row = (uint64_t)(it - h->h_ids.begin());
+            uint64_t run = 1;
+            while (i + run < n && row + run < h->n_rows && h->h_ids[(size_t)(row + run)] == id + run) ++run;
+            CS_HIP(hipMemcpy(out_rows + (size_t)i * h->dim, h->d_corpus + (size_t)row * h->dim, (size_t)run * h->dim * sizeof(float),
+                             hipMemcpyDeviceToHost));
+            i += run;
+        }
+        return CS_OK;
+    }
     CS_HIP(hipMemcpy(out_rows, h->d_corpus + (size_t)first_row * h->dim,
                      (size_t)n * h->dim * sizeof(float), hipMemcpyDeviceToHost));
     return CS_OK;

@@ -148,7 +148,7 @@ template <int J, int U, int QT, bool NT, bool PRIME = false>
 __global__ void __launch_bounds__(kBlock)
 scan_topk_kernel(const float* __restrict__ corpus, uint64_t n_rows,
                  const float* __restrict__ queries, uint32_t nq, uint32_t k, uint32_t kpad,
-                 const uint32_t* __restrict__ dead, uint32_t id_base,
+                 const uint32_t* __restrict__ dead, RowIds id_base,
                  uint64_t* __restrict__ partial, const float* __restrict__ floor_in,
                  float* __restrict__ wave_max, uint32_t* __restrict__ done_ctr,
                  float* __restrict__ floor_out, const uint32_t* __restrict__ gate) {
@@ -260,7 +260,7 @@ scan_topk_kernel(const float* __restrict__ corpus, uint64_t n_rows,
                         const float cc = __shfl(c, src, 64);
                         const uint64_t rr = row0 + 2 * u + (src >> 5);
                         if (cc > thr[qi] && !row_is_dead(dead, rr))
-                            wave_list_insert(list, k, lane, cc, id_base + (uint32_t)rr, thr[qi],
+                            wave_list_insert(list, k, lane, cc, id_base.of(rr), thr[qi],
                                              wpos[qi], floor[qi]);
                     }
                 }
@@ -340,7 +340,7 @@ scan_topk_kernel(const float* __restrict__ corpus, uint64_t n_rows,
 __global__ void __launch_bounds__(kBlock)
 scan_topk_generic_kernel(const float* __restrict__ corpus, uint64_t n_rows, uint32_t dim,
                          const float* __restrict__ queries, uint32_t nq, uint32_t k,
-                         uint32_t kpad, const uint32_t* __restrict__ dead, uint32_t id_base,
+                         uint32_t kpad, const uint32_t* __restrict__ dead, RowIds id_base,
                          uint64_t* __restrict__ partial, const uint32_t* __restrict__ gate) {
     if (gate && *gate == 0u) return;
     extern __shared__ __attribute__((aligned(16))) uint64_t lds_keys[];  // [kWaves][kpad]
@@ -369,7 +369,7 @@ scan_topk_generic_kernel(const float* __restrict__ corpus, uint64_t n_rows, uint
         const float d = wave_allreduce_sum(dot);
         const float c = (qmag == 0.0f || xmag == 0.0f) ? 0.0f : d / (qmag * xmag);
         if (c > thr && !row_is_dead(dead, r))  // wave-uniform
-            wave_list_insert(list, k, lane, c, id_base + (uint32_t)r, thr, wpos);
+            wave_list_insert(list, k, lane, c, id_base.of(r), thr, wpos);
     }
     __syncthreads();
     const uint32_t nsort = kWaves * kpad;
@@ -720,7 +720,7 @@ ScanPlan plan_prime(uint64_t sample_rows, uint32_t dim, uint32_t nq, uint32_t k,
 template <int J, int U, int QT>
 static void launch_fast(const ScanPlan& plan, const float* d_corpus, uint64_t n_rows,
                         const float* d_queries, uint32_t nq, uint32_t k, const uint32_t* d_dead,
-                        uint32_t id_base, uint64_t* d_partial, const ScanPrime* prime,
+                        RowIds id_base, uint64_t* d_partial, const ScanPrime* prime,
                         bool prime_pass, hipStream_t stream, const uint32_t* gate) {
     const size_t lds = (size_t)QT * kWaves * plan.kpad * sizeof(uint64_t);
     dim3 grid(plan.blocks, plan.passes);
@@ -737,7 +737,7 @@ static void launch_fast(const ScanPlan& plan, const float* d_corpus, uint64_t n_
 template <int J, int U>
 static void launch_fast_q(const ScanPlan& plan, const float* d_corpus, uint64_t n_rows,
                           const float* d_queries, uint32_t nq, uint32_t k,
-                          const uint32_t* d_dead, uint32_t id_base, uint64_t* d_partial,
+                          const uint32_t* d_dead, RowIds id_base, uint64_t* d_partial,
                           const ScanPrime* prime, bool prime_pass, hipStream_t stream, const uint32_t* gate) {
     switch (plan.qtile) {
         case 4: launch_fast<J, U, 4>(plan, d_corpus, n_rows, d_queries, nq, k, d_dead, id_base, d_partial, prime, prime_pass, stream, gate); break;
@@ -748,7 +748,7 @@ static void launch_fast_q(const ScanPlan& plan, const float* d_corpus, uint64_t 
 
 int32_t launch_scan(const ScanPlan& plan, const float* d_corpus, uint64_t n_rows, uint32_t dim,
                     const float* d_queries, uint32_t nq, uint32_t k, const uint32_t* d_dead,
-                    uint32_t id_base, uint64_t* d_partial, hipStream_t stream,
+                    RowIds id_base, uint64_t* d_partial, hipStream_t stream,
                     const ScanPrime* prime, bool prime_pass, const uint32_t* gate) {
     if (prime_pass && (!prime || !fast_dim(dim) || n_rows == 0))
         return fail(CS_ERR_BAD_ARG, "prime pass needs a 384/768/1024-d corpus prefix and its buffers");

@@ -35,7 +35,7 @@ ScanPlan plan_prime(uint64_t sample_rows, uint32_t dim, uint32_t nq, uint32_t k,
 // partial lists written);  prime alone: start the lists from prime->d_floor.
 int32_t launch_scan(const ScanPlan& plan, const float* d_corpus, uint64_t n_rows, uint32_t dim,
                     const float* d_queries, uint32_t nq, uint32_t k, const uint32_t* d_dead,
-                    uint32_t id_base, uint64_t* d_partial, hipStream_t stream,
+                    RowIds id_base, uint64_t* d_partial, hipStream_t stream,
                     const ScanPrime* prime = nullptr, bool prime_pass = false, const uint32_t* gate = nullptr);
 // `gate` (launch_scan and launch_merge): device word; when non-null every block of the launch exits at
 // once unless *gate != 0 — the exact rerun enqueued behind a batched search on the device API.
@@ -110,7 +110,7 @@ int32_t launch_row_norms(const float* d_corpus, uint64_t first, uint64_t n, uint
 // Exact unless *st.d_overflow != 0 afterwards (then rerun on the list-based scan).
 int32_t launch_scan_batched(const BatchedState& st, const float* d_corpus, const float* d_norms,
                             uint64_t n_rows, uint32_t dim, const float* d_queries, uint32_t nq, uint32_t k,
-                            const uint32_t* d_dead, uint32_t id_base, int num_cus, uint64_t* d_out_keys,
+                            const uint32_t* d_dead, RowIds id_base, int num_cus, uint64_t* d_out_keys,
                             float* d_out_cos, uint32_t* d_out_ids, uint32_t* d_out_counts,
                             hipStream_t stream);
 
@@ -151,7 +151,7 @@ int32_t launch_corpus_split(const float* d_corpus, const float* d_norms, _Float1
 // Exact (bit-identical to launch_scan + launch_merge) unless *st.d_overflow != 0 afterwards.
 int32_t launch_scan_split(const BatchedState& st, const SplitQueryWs& qw, const float* d_corpus,
                           const _Float16* d_split, uint64_t n_rows, uint32_t dim, const float* d_queries, uint32_t nq, uint32_t k, const uint32_t* d_dead,
-                          uint32_t id_base, uint64_t* d_out_keys, float* d_out_cos, uint32_t* d_out_ids,
+                          RowIds id_base, uint64_t* d_out_keys, float* d_out_cos, uint32_t* d_out_ids,
                           uint32_t* d_out_counts, hipStream_t stream, float margin, const Q8View* q8 = nullptr);
 // Proven bound of |filter cosine - exact cosine| for unit vectors of this width (scan_filter.hip header);
 // `subnormals_exact` = the f16 MFMA consumes subnormal inputs exactly (sh_denorm_selftest).

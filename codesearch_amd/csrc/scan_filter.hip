@@ -852,7 +852,7 @@ template <int J>
 __global__ void __launch_bounds__(RK_THREADS)
 rescore_keys_kernel(const float* __restrict__ corpus, const float* __restrict__ queries,
                     const float* __restrict__ qmag, uint64_t* __restrict__ cand,
-                    const uint32_t* __restrict__ cnt, uint32_t cap, uint32_t id_base,
+                    const uint32_t* __restrict__ cnt, uint32_t cap, RowIds id_base,
                     uint32_t first_rows, const uint32_t* __restrict__ dead) {
     constexpr int DIM = 128 * J;
     constexpr int RU = J <= 3 ? 4 : 2;          // rows per half-wave per round, loads issued together
@@ -908,7 +908,7 @@ rescore_keys_kernel(const float* __restrict__ corpus, const float* __restrict__ 
                 // NaN/Inf scores are never returned
                 const bool live = !(first_rows && dead) || !((dead[row[u] >> 5] >> (row[u] & 31)) & 1u);
                 if (l32 == 0)
-                    slots[i] = (live && c > -__builtin_huge_valf() && c < __builtin_huge_valf()) ? key_pack(c, id_base + row[u]) : 0ull;
+                    slots[i] = (live && c > -__builtin_huge_valf() && c < __builtin_huge_valf()) ? key_pack(c, id_base.of(row[u])) : 0ull;
             }
         }
     }
@@ -1453,7 +1453,7 @@ int32_t launch_corpus_q8(const float* d_corpus, const float* d_norms, int8_t* d_
 template <int J>
 static int32_t scan_split_impl(const BatchedState& st, const SplitQueryWs& qw, const float* d_corpus,
                                const _Float16* d_split, uint64_t n_rows, const float* d_queries, uint32_t nq, uint32_t k, const uint32_t* d_dead,
-                               uint32_t id_base, uint64_t* d_out_keys, float* d_out_cos,
+                               RowIds id_base, uint64_t* d_out_keys, float* d_out_cos,
                                uint32_t* d_out_ids, uint32_t* d_out_counts, hipStream_t stream, float margin,
                                const Q8View* q8) {
     constexpr uint32_t dim = 128 * J;
@@ -1778,7 +1778,7 @@ static int32_t scan_split_impl(const BatchedState& st, const SplitQueryWs& qw, c
 
 int32_t launch_scan_split(const BatchedState& st, const SplitQueryWs& qw, const float* d_corpus,
                           const _Float16* d_split, uint64_t n_rows, uint32_t dim, const float* d_queries, uint32_t nq, uint32_t k, const uint32_t* d_dead,
-                          uint32_t id_base, uint64_t* d_out_keys, float* d_out_cos, uint32_t* d_out_ids,
+                          RowIds id_base, uint64_t* d_out_keys, float* d_out_cos, uint32_t* d_out_ids,
                           uint32_t* d_out_counts, hipStream_t stream, float margin, const Q8View* q8) {
 #define CS_SPLIT_ARGS st, qw, d_corpus, d_split, n_rows, d_queries, nq, k, d_dead, id_base, d_out_keys, \
                       d_out_cos, d_out_ids, d_out_counts, stream, margin, q8

@@ -72,7 +72,7 @@ score_append_kernel(const float* __restrict__ corpus, const float* __restrict__ 
                     uint64_t row_lo, uint64_t row_hi, uint32_t dim,
                     const float* __restrict__ queries, uint32_t nq,
                     const float* __restrict__ tau, const uint32_t* __restrict__ dead,
-                    uint32_t id_base, uint64_t* __restrict__ cand, uint32_t* __restrict__ cnt,
+                    RowIds id_base, uint64_t* __restrict__ cand, uint32_t* __restrict__ cnt,
                     uint32_t cap) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const uint32_t QS = dim + 4;  // (dim+4) % 64 == 4 for dim in {384, 768, 1024}: conflict-free b128
@@ -187,7 +187,7 @@ score_append_kernel(const float* __restrict__ corpus, const float* __restrict__ 
                 if (c > thr[t] && row < row_hi) {  // rare, divergent, short
                     if (!dead || !((dead[row >> 5] >> (row & 31)) & 1u)) {
                         const uint32_t pos = atomicAdd(&cnt[(size_t)q * kCntStride], 1u);
-                        if (pos < cap) cand[(size_t)q * cap + pos] = key_pack(c, id_base + (uint32_t)row);
+                        if (pos < cap) cand[(size_t)q * cap + pos] = key_pack(c, id_base.of(row));
                     }
                 }
             }
@@ -319,7 +319,7 @@ int32_t launch_row_norms(const float* d_corpus, uint64_t first, uint64_t n, uint
 
 int32_t launch_scan_batched(const BatchedState& st, const float* d_corpus, const float* d_norms,
                             uint64_t n_rows, uint32_t dim, const float* d_queries, uint32_t nq, uint32_t k,
-                            const uint32_t* d_dead, uint32_t id_base, int num_cus, uint64_t* d_out_keys,
+                            const uint32_t* d_dead, RowIds id_base, int num_cus, uint64_t* d_out_keys,
                             float* d_out_cos, uint32_t* d_out_ids, uint32_t* d_out_counts,
                             hipStream_t stream) {
     const uint32_t cap = batched_cap(k);

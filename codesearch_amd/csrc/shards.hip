@@ -591,6 +591,11 @@ uint32_t cs_shards_next_id(const cs_shards* h) { return h ? (uint32_t)h->next : 
 uint32_t cs_shards_dim(const cs_shards* h) { return h ? h->dim : 0; }
 uint32_t cs_shards_count(const cs_shards* h) { return h ? h->n : 0; }
 int32_t cs_shards_direct_gather(const cs_shards* h) { return h && h->direct ? 1 : 0; }
+uint64_t cs_shards_stored_rows(const cs_shards* h) {
+    uint64_t n = 0;
+    if (h) for (cs_index* ix : h->idx) n += cs_index_stored_rows(ix);
+    return n;
+}
 uint64_t cs_shards_shard_len(const cs_shards* h, uint32_t shard) {
     return h && shard < h->n ? cs_index_len(h->idx[shard]) : 0;
 }

@@ -249,10 +249,25 @@ class VectorStore:
             f.seek(0, 2)
             step = max(1, (256 << 20) // (4 * self.dimensions))
             for lo in range(self._persisted_rows, n, step):
-                f.write(self.read_rows(lo, min(step, n - lo)).astype("<f4").tobytes())
+                f.write(self._read_rows_for_file(lo, min(step, n - lo)).astype("<f4").tobytes())
         self._write_chunks(chunks)
         self._write_meta(meta, built=True)  # the meta file is the commit point
         self._persisted_rows = n
+
+    def _read_rows_for_file(self, lo: int, cnt: int) -> np.ndarray:
+        """Rows of ids [id_base + lo, + cnt) for the flat vector file, which stays indexed by id: a deleted id's row may
+        have been reclaimed by the build (cs_index_build) — its slot in the file is zeros, and the meta file's removed
+        list keeps it dead on reopening."""
+        gone = sorted(i - self.id_base - lo for i in self._removed if lo <= i - self.id_base < lo + cnt)
+        if not gone:
+            return self.read_rows(lo, cnt)
+        out = np.zeros((cnt, self.dimensions), np.float32)
+        start = 0
+        for g in gone + [cnt]:
+            if g > start:
+                out[start:g] = self.read_rows(lo + start, g - start)
+            start = g + 1
+        return out
 
     def _write_chunks(self, chunks: str) -> None:
         """chunks.jsonl: appended to when only new chunks arrived (the reference builds per file: rewriting N lines per
@@ -454,6 +469,11 @@ class VectorStore:
 
     def __len__(self) -> int:
         return int(self._fn("len")(self._h))
+
+    def stored_rows(self) -> int:
+        """Rows the corpus matrix physically holds, tombstoned ones included: len(self) right after a build that reclaimed
+        the deleted rows (cs_index_build, from 10 % dead rows on), more in between."""
+        return int(self._fn("stored_rows")(self._h))
 
     def search_raw(self, queries, limit: int):
         """-> (cos [nq, limit] f32, ids [nq, limit] u32, counts [nq] u32); rows best-first."""

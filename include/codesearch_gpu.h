@@ -107,8 +107,15 @@ CS_API int32_t cs_index_add_synthetic(cs_index* h, uint64_t n, uint64_t seed, ui
 CS_API int32_t cs_index_remove(cs_index* h, const uint32_t* ids, uint64_t n, uint64_t* removed);
 
 /* build_index — store.rs:386-430.  The exact scan needs no tree; this publishes the
- * appended rows to searchers and sets `indexed` (store.rs:428). */
+ * appended rows to searchers and sets `indexed` (store.rs:428).  It is also where deleted rows are reclaimed, as arroy
+ * drops deleted items at its next build (the incremental `index` deletes a changed file's chunks and re-inserts them,
+ * src/index/mod.rs:525,544): when at least 10 % of the stored rows are tombstones (CS_INDEX_COMPACT_DEAD_PCT; 0 = never) the
+ * live rows are moved together in HBM, in their order, and the filter copies are rebuilt over them.  Ids do not change
+ * (a row -> id table in HBM, read for the few candidate rows of a search only), next_id does not go back (ids are never
+ * reused, store.rs:101), and searches return the same ids and cosines bit for bit — they just no longer stream the dead
+ * rows.  cs_index_stored_rows tells how many rows the matrix physically holds. */
 CS_API int32_t cs_index_build(cs_index* h);
+CS_API uint64_t cs_index_stored_rows(const cs_index* h);  /* rows held in HBM, tombstoned ones included (== len after a reclaiming build) */
 /* clear — store.rs:690-707. */
 CS_API int32_t cs_index_clear(cs_index* h);
 
@@ -223,6 +230,7 @@ CS_API int32_t cs_shards_build(cs_shards* h);
 CS_API int32_t cs_shards_clear(cs_shards* h);
 CS_API int32_t cs_shards_is_built(const cs_shards* h);
 CS_API uint64_t cs_shards_len(const cs_shards* h);
+CS_API uint64_t cs_shards_stored_rows(const cs_shards* h);   /* over all shards (cs_index_stored_rows; every shard reclaims its own deleted rows at cs_shards_build) */
 CS_API uint32_t cs_shards_next_id(const cs_shards* h);
 CS_API uint32_t cs_shards_dim(const cs_shards* h);
 CS_API uint32_t cs_shards_count(const cs_shards* h);                        /* number of shards */
@@ -251,8 +259,9 @@ CS_API int32_t cs_shards_search_variants(cs_shards* h, const float* queries, uin
                                   float* out_cos, uint32_t* out_ids, uint32_t* out_count, int32_t* out_high_confidence);
 CS_API int32_t cs_shards_read_rows(cs_shards* h, uint64_t first_id, uint64_t n, float* out_rows);
 
-/* Copy rows [first_row, first_row + n) of the matrix back to host memory (test and
- * persistence aid; VectorStore has no direct counterpart). */
+/* Copy the rows of ids [id_base + first_row, id_base + first_row + n) back to host memory (test and
+ * persistence aid; VectorStore has no direct counterpart).  Rows are named by their ids' offsets, wherever a reclaiming
+ * build has moved them; an id whose row was deleted and reclaimed is CS_ERR_BAD_ARG. */
 CS_API int32_t cs_index_read_rows(cs_index* h, uint64_t first_row, uint64_t n, float* out_rows);
 
 /* Kernel timing for bench.py: when enabled, every scan launch is bracketed by HIP
