@@ -296,6 +296,13 @@ int32_t BpeEngine::create(BpeSpec&& spec, std::shared_ptr<BpeEngine>* out) {
         ++rank;
     }
     e->spec_ = std::move(spec);
+    // a normalized added token is matched in normalised text: its own content goes through the normaliser once, here
+    for (auto& a : e->spec_.added)
+        if (a.normalized) {
+            if (e->spec_.nfc) nfc_normalize(a.text);
+            if (a.text.empty()) return fail(CS_ERR_BAD_ARG, "Failed to initialize embedding model: malformed added token");
+            e->has_normalized_added_ = true;
+        }
     // added tokens: longest first, so the scan below is leftmost-longest
     std::stable_sort(e->spec_.added.begin(), e->spec_.added.end(),
                      [](const BpeSpec::Added& x, const BpeSpec::Added& y) { return x.text.size() > y.text.size(); });
@@ -367,10 +374,9 @@ void BpeEngine::encode_word(const std::string& bytes, std::vector<int32_t>& ids)
         if (s.len != 0) ids.push_back(s.c);
 }
 
-// A stretch of text between added tokens: the pre-tokenizer steps, then every pre-token through the model
-void BpeEngine::encode_segment(const char* p, size_t n, bool, std::vector<int32_t>& ids) const {
-    std::vector<std::string> pieces(1, std::string(p, n));
-    if (spec_.nfc) nfc_normalize(pieces[0]);
+// A stretch of text between added tokens, normalised: the pre-tokenizer steps, then every pre-token through the model
+void BpeEngine::encode_piece(std::string&& text, std::vector<int32_t>& ids) const {
+    std::vector<std::string> pieces(1, std::move(text));
     for (const auto& pre : spec_.pres) {
         std::vector<std::string> next;
         for (std::string& t : pieces) {
@@ -402,17 +408,13 @@ void BpeEngine::encode_segment(const char* p, size_t n, bool, std::vector<int32_
     for (const std::string& w : pieces) encode_word(w, ids);
 }
 
-void BpeEngine::encode(const char* utf8, size_t n, uint32_t body_max, std::vector<int32_t>& ids) const {
-    if (spec_.bos >= 0) ids.push_back(spec_.bos);
-    const size_t base = ids.size();
-    const std::string text = sanitize(utf8, n);
+template <class F>
+void BpeEngine::split_on_added(const std::string& text, bool normalized, std::vector<int32_t>& ids, F&& piece) const {
     size_t seg = 0, i = 0;
-    auto run_segment = [&](size_t lo, size_t hi) { if (hi > lo) encode_segment(text.data() + lo, hi - lo, lo == 0, ids); };
     while (i < text.size()) {
         const BpeSpec::Added* hit = nullptr;
-        if (!spec_.added.empty())
-            for (const auto& a : spec_.added)  // (longest first)
-                if (text.compare(i, a.text.size(), a.text) == 0) { hit = &a; break; }
+        for (const auto& a : spec_.added)  // (longest first)
+            if (a.normalized == normalized && text.compare(i, a.text.size(), a.text) == 0) { hit = &a; break; }
         if (!hit) { i += std::min(u8_len((unsigned char)text[i]), text.size() - i); continue; }
         size_t lo = i, hi = i + hit->text.size();
         if (hit->lstrip)  // the token takes the whitespace in front of it
@@ -428,11 +430,30 @@ void BpeEngine::encode(const char* utf8, size_t n, uint32_t body_max, std::vecto
                 if (!is_space(u8_cp(text.data() + hi, l))) break;
                 hi += l;
             }
-        run_segment(seg, lo);
+        if (lo > seg) piece(seg, lo);
         ids.push_back(hit->id);
         seg = i = hi;
     }
-    run_segment(seg, text.size());
+    if (text.size() > seg) piece(seg, text.size());
+}
+
+// A stretch of raw text between the verbatim (non-normalized) added tokens: normalised, cut at the normalized added tokens, the
+// rest through the pre-tokenizer and the model
+void BpeEngine::encode_segment(const char* p, size_t n, bool, std::vector<int32_t>& ids) const {
+    std::string text(p, n);
+    if (spec_.nfc) nfc_normalize(text);
+    if (!has_normalized_added_) {
+        encode_piece(std::move(text), ids);
+        return;
+    }
+    split_on_added(text, true, ids, [&](size_t lo, size_t hi) { encode_piece(text.substr(lo, hi - lo), ids); });
+}
+
+void BpeEngine::encode(const char* utf8, size_t n, uint32_t body_max, std::vector<int32_t>& ids) const {
+    if (spec_.bos >= 0) ids.push_back(spec_.bos);
+    const size_t base = ids.size();
+    const std::string text = sanitize(utf8, n);
+    split_on_added(text, false, ids, [&](size_t lo, size_t hi) { encode_segment(text.data() + lo, hi - lo, lo == 0, ids); });
     if (ids.size() - base > body_max) ids.resize(base + body_max);  // truncation: on the right, before the template
     if (spec_.eos >= 0) ids.push_back(spec_.eos);
 }

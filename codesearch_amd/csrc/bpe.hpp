@@ -26,8 +26,11 @@ struct BpeSpec {
         bool individual_digits = false;                            // DIGITS
     };
     std::vector<Pre> pres;                                         // must end in (or be) a BYTE_LEVEL step
-    struct Added { std::string text; int32_t id = -1; bool lstrip = false, rstrip = false; };
-    std::vector<Added> added;                                      // special tokens, matched verbatim in the raw text
+    // added tokens (AddedVocabulary of the library).  normalized = false (special tokens as a rule): matched verbatim in the RAW
+    // text, first.  normalized = true (ModernBERT's |||IP_ADDRESS||| ... and its runs of 2-24 spaces — plain tokens that indented
+    // code is full of): matched in what is left, AFTER that text's normalisation (split_normalized_trie), leftmost-longest.
+    struct Added { std::string text; int32_t id = -1; bool lstrip = false, rstrip = false, normalized = false; };
+    std::vector<Added> added;
     int32_t bos = -1, eos = -1, pad = -1;                          // <bos> $A <eos> (RobertaProcessing / TemplateProcessing); -1 = none
 };
 
@@ -53,6 +56,10 @@ private:
 
     void encode_word(const std::string& bytes, std::vector<int32_t>& ids) const;
     void encode_segment(const char* p, size_t n, bool at_text_start, std::vector<int32_t>& ids) const;
+    void encode_piece(std::string&& text, std::vector<int32_t>& ids) const;
+    // `text` cut at its leftmost-longest added tokens of one kind: piece(lo, hi) for every stretch between them, the token's id behind it
+    template <class F> void split_on_added(const std::string& text, bool normalized, std::vector<int32_t>& ids, F&& piece) const;
+    bool has_normalized_added_ = false;
 };
 
 // a cs_tokenizer handle (tokenizer.cpp) around an engine built from `spec`

@@ -951,8 +951,8 @@ static int32_t unigram_from_json(const Json& root, const Json& model, const char
                 const Json* id = e.get("id");
                 if (!content || content->kind != Json::Str || !id || id->kind != Json::Num || content->str.empty()) continue;
                 auto flag = [&](const char* k) { const Json* v = e.get(k); return v && v->kind == Json::Bool && v->b; };
-                if (flag("single_word") || flag("normalized"))
-                    return fail(CS_ERR_UNSUPPORTED, "Failed to initialize embedding model: added token \"%s\" is single_word / normalized (not built)",
+                if (flag("single_word"))
+                    return fail(CS_ERR_UNSUPPORTED, "Failed to initialize embedding model: added token \"%s\" is single_word (not built)",
                                 content->str.c_str());
                 if (!(id->num >= 0 && id->num < (double)spec.vocab.size()))
                     return fail(CS_ERR_UNSUPPORTED, "Failed to initialize embedding model: added token \"%s\" lies outside the unigram vocabulary",
@@ -1156,8 +1156,8 @@ static int32_t bpe_from_json(const Json& root, const Json& model, const char* js
                 const Json* id = e.get("id");
                 if (!content || content->kind != Json::Str || !id || id->kind != Json::Num || content->str.empty()) continue;
                 auto flag = [&](const char* k) { const Json* v = e.get(k); return v && v->kind == Json::Bool && v->b; };
-                if (flag("single_word") || flag("normalized"))
-                    return fail(CS_ERR_UNSUPPORTED, "Failed to initialize embedding model: added token \"%s\" is single_word / normalized (not built)",
+                if (flag("single_word"))
+                    return fail(CS_ERR_UNSUPPORTED, "Failed to initialize embedding model: added token \"%s\" is single_word (not built)",
                                 content->str.c_str());
                 if (!(id->num >= 0 && id->num < 2147483647.0))
                     return fail(CS_ERR_BAD_ARG, "Failed to initialize embedding model: added token \"%s\" has no valid id", content->str.c_str());
@@ -1166,6 +1166,7 @@ static int32_t bpe_from_json(const Json& root, const Json& model, const char* js
                 a.id = (int32_t)id->num;
                 a.lstrip = flag("lstrip");
                 a.rstrip = flag("rstrip");
+                a.normalized = flag("normalized");  // matched in the normalised text, behind the verbatim ones (bpe.hpp)
                 added_ids[a.text] = a.id;
                 spec.added.push_back(std::move(a));
             }

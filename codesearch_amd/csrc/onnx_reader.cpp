@@ -394,11 +394,12 @@ const Tensor* weight_of_bias(const Model& m, const std::string& bias_name, uint6
 // quantised file.  They are therefore taken by STRUCTURE: the MatMul / MatMulInteger nodes whose second input is a 2-D
 // initialiser, in graph (= execution) order, are per layer  Wqkv [H, 3H] | out_proj [H, H] | fc11, fc12 [H, I] | fc2 [I, H]
 // (the products between activations — Q K^T, P V — have no initialiser and drop out); of the two [H, I] products the gate
-// (fc12) is the one whose result reaches a Sigmoid (silu(g) = g * sigmoid(g)) — the order decides only where no Sigmoid
-// is found.  LayerNorm parameters and the embedding tables keep their module names (emb_ln, encoder.layers.N.norm1 /
+// (fc12) is the one whose result reaches a Sigmoid (silu(g) = g * sigmoid(g)); a file in which neither does (a fused
+// activation op) is refused rather than guessed at.  LayerNorm parameters and the embedding tables keep their module names (emb_ln, encoder.layers.N.norm1 /
 // norm2).  A quantised file is read as (q - zero_point) * scale into the f32 block: the Nomic encoder runs the f32 graph of
 // those weights (the dynamic-quantisation mode is BERT's, embedder.hip).  Restated from how torch.onnx lays such a module
-// out; no Nomic export is on disk here (parity unpinned).
+// out and pinned on a file torch's own exporter wrote (tests/golden/nomic_tiny_export.onnx); the hub's own export is not
+// on disk here.
 struct WeightProduct { const Node* node; const Tensor* w; Quant q; bool quantised; };
 std::vector<WeightProduct> weight_products(const Model& m);
 
@@ -488,7 +489,10 @@ int32_t nomic_params_from_onnx(const Model& m, const cs_bert_config* cfg, const 
         if (g2 && g3)
             return fail(CS_ERR_UNSUPPORTED, "Failed to initialize embedding model: both feed-forward up projections of layer %u reach a "
                         "Sigmoid in %s (not the swiglu arrangement)", l, path);
-        const int gate = g2 ? 2 : 3, value = g2 ? 3 : 2;  // (no Sigmoid found: the module's own order, fc11 then fc12)
+        if (!g2 && !g3)  // (a fused or contrib activation, a deeper Cast chain: guessing would swap value and gate silently — ADVICE r5)
+            return fail(CS_ERR_UNSUPPORTED, "Failed to initialize embedding model: neither feed-forward up projection of layer %u reaches a "
+                        "Sigmoid in %s: which one is the SwiGLU gate cannot be read off this export", l, path);
+        const int gate = g2 ? 2 : 3, value = g2 ? 3 : 2;
         CS_TRY(copy(value, I, H, params + lo.up_w, "fc11"));
         CS_TRY(copy(gate, I, H, params + lo.gate_w, "fc12"));
         CS_TRY(copy(4, H, I, params + lo.down_w, "fc2"));

@@ -43,6 +43,9 @@ TEXTS = [
     "१२३ ٤٥٦ Ⅷ ½ ²", "a b c　de f", "line1\n\n\n   line2\n \n\t x", "trailing newline\n", "\n", "\n\n x",
     " \n", "x \n y", "<s>literal specials</s> in <mask> the <pad> text<unk>", "before<mask>after", "a <mask> b", "<s><s>", "</s>",
     "def f(x):\n    return x ** 2  # square\n", "std::vector<std::pair<int, float>> v{{1, 2.0f}};", "#include <stdio.h>\nint main(void){return 0;}",
+    # runs of spaces and the placeholder tokens (the normalized added tokens of the ModernBERT arrangement)
+    "class A:\n    def f(self):\n        if x:\n            return  y\n" + " " * 27 + "z" + " " * 24 + "|" + " " * 25,
+    "ping |||IP_ADDRESS||| from|||EMAIL_ADDRESS|||  |||PHONE_NUMBER|||||| ||IP_ADDRESS|||", "   <mask>  x   </s>    ", "\t  \t   \n  \n   x",
     "a" * 300, "ab " * 200, "9" * 50, "'" * 7 + "s't're", "end with apostrophe'", "\x00\x01\x7f control", "� replacement ﻿ bom",
     # canonical (de)composition for the NFC variants: decomposed accents, reordering of marks, Hangul jamo, singletons, exclusions
     "cafe\u0301 nai\u0308ve A\u030a \u212b \u2126 \u1e9b\u0323 q\u0307\u0323 q\u0323\u0307", "\u1100\u1161\u11a8 \u1112\u1161\u11ab\uae00 \u1100\u1161 \u11a8",
@@ -50,8 +53,13 @@ TEXTS = [
 ]
 
 
+# what the published ModernBERT tokenizer.json holds beside its specials (GPT-NeoX / OLMo lineage): plain added tokens,
+# normalized and not special — three placeholders and the runs of 2 .. 24 spaces indented code is made of
+MODERN_ADDED = ["|||IP_ADDRESS|||", "|||EMAIL_ADDRESS|||", "|||PHONE_NUMBER|||"] + [" " * n for n in range(24, 1, -1)]
+
+
 def build(path, *, post="roberta", add_prefix_space=False, digits=None, use_regex=True, ignore_merges=False, legacy_merges=False,
-          trim=True, nfc=False):
+          trim=True, nfc=False, modern_added=False):
     from tokenizers import Tokenizer, decoders, models, normalizers, pre_tokenizers, processors, trainers
 
     tok = Tokenizer(models.BPE())
@@ -65,6 +73,10 @@ def build(path, *, post="roberta", add_prefix_space=False, digits=None, use_rege
     trainer = trainers.BpeTrainer(vocab_size=700, special_tokens=SPECIALS, initial_alphabet=pre_tokenizers.ByteLevel.alphabet(),
                                   show_progress=False)
     tok.train_from_iterator(CORPUS, trainer)
+    if modern_added:
+        from tokenizers import AddedToken
+
+        tok.add_tokens([AddedToken(t, normalized=True, special=False) for t in MODERN_ADDED])
     if post == "roberta":
         tok.post_processor = processors.RobertaProcessing(sep=("</s>", tok.token_to_id("</s>")), cls=("<s>", tok.token_to_id("<s>")),
                                                            trim_offsets=trim, add_prefix_space=add_prefix_space)
@@ -102,6 +114,8 @@ VARIANTS = {
     "ignore_merges": dict(post="roberta", ignore_merges=True),
     "nfc_template": dict(post="template", nfc=True),
     "nfc_sequence_prefix": dict(post="roberta", nfc="sequence", add_prefix_space=True),
+    "modernbert_added_tokens": dict(post="template", nfc=True, modern_added=True),
+    "normalized_added_no_normalizer": dict(post="roberta", modern_added=True),
 }
 
 
