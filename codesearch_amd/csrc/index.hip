@@ -325,9 +325,11 @@ struct cs_index {
     bool built = false;
     // streams of OTHER devices that carry unfinished appends into this corpus (index_append_from: an encoder replica on
     // another GPU writing its rows over xGMI); hipDeviceSynchronize on this device does not wait for them
-    // (an EVENT recorded on that stream behind the copy, not the stream handle: the caller may destroy its stream)
     // peer appends in flight: ONE event per (source device, stream), re-recorded by every append on that stream (a later
-    // record covers the stream's earlier copies), so an ingest of millions of rows in mini-batches keeps a handful of events
+    // record covers the stream's earlier copies), so an ingest of millions of rows in mini-batches keeps a handful of events.
+    // CONTRACT (include/codesearch_gpu.h, cs_shards_add_device / cs_embedders_index_*): a stream that carried an append must
+    // stay alive until the next build / search / read of this index has drained it — a destroyed stream whose handle value is
+    // handed out again would have its slot's event re-recorded on the NEW stream and the old copies would go untracked
     struct ForeignAppend { int device; hipStream_t stream; hipEvent_t done; };
     std::vector<ForeignAppend> foreign_appends;
 

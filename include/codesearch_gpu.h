@@ -210,7 +210,8 @@ CS_API int32_t cs_shards_add(cs_shards* h, const float* rows, uint64_t n, uint32
 /* Same with the rows in HBM of device `src_device` (an encoder replica's output): each run of rows goes to its
  * shard by one asynchronous copy on `stream` (a stream of src_device; in place when the shard lives there, over
  * xGMI otherwise) — the multi-GPU form of cs_index_add_device, src/index/mod.rs:692-723.  Appends are
- * all-or-nothing: capacity is reserved on every touched shard before any row moves. */
+ * all-or-nothing: capacity is reserved on every touched shard before any row moves.  `stream` must stay alive until
+ * the store's next build, search or read has drained it (the store tracks one event per source stream). */
 CS_API int32_t cs_shards_add_device(cs_shards* h, const float* d_rows, int32_t src_device, uint64_t n, uint32_t dim,
                              uint32_t* out_ids, void* stream);
 /* Where the next n appended rows will live (ids are contiguous from next_id, so this is known before the rows exist):
