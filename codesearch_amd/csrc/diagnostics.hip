@@ -173,7 +173,7 @@ int32_t cs_debug_gemm_q8(int32_t device, int32_t epilogue, int32_t a_split, cons
             CS_HIP(hipMalloc(&dOut, c_n)); CS_HIP(hipMalloc(&dRm2, (size_t)M * sizeof(Q8RowMeta))); CS_HIP(hipMalloc(&dRange2, Q8_RANGE_WORDS * 4));
             CS_HIP(hipMemset(dRange2, 0, Q8_RANGE_WORDS * 4));
             // (a_split & 16: the slab kernel, whatever M — gemm_q8_slab.hip)
-            int32_t st5 = (a_split & 16) ? launch_gemm_q8_slab_gelu_requant(dA, dRange, dWq, dCmT, M, N, K, dRange2, dOut, dRm2, q8_gelu_table_on(), nullptr)
+            int32_t st5 = (a_split & 16) ? launch_gemm_q8_slab_gelu_requant(dA, dRange, dWq, dCmT, M, N, K, dRange2, dOut, dRm2, q8_gelu_table_on(), nullptr, (a_split & 32) ? dXq : nullptr)
                         : (a_split & 8) ? launch_gemm_q8_gelu_requant_from_source(dA, dRange, dWq, dCm, dB, M, N, K, dRange2, dOut, dRm2, nullptr)
                                         : launch_gemm_q8_gelu_requant(dXq, dRm, dWq, dCm, dB, M, N, K, dRange2, dOut, dRm2, nullptr);
             if (st5 == CS_OK && hipDeviceSynchronize() != hipSuccess) st5 = fail(CS_ERR_HIP, "requant GEMM failed");

@@ -408,7 +408,7 @@ int32_t forward_range(cs_embedder* h, hipStream_t s, uint32_t b0, uint32_t nb, u
                 int8_t* midq = reinterpret_cast<int8_t*>(mid);
                 Q8RowMeta* rm2 = h->d_rmeta2 + t0;
                 CS_TRY(launch_gemm_q8_gelu_requant_from_source(x, rg + 2 * rstep, wq + ql.up, cm + 4 * H, P + lo.up_b, T, I, H, rg + 3 * rstep, midq, rm2, s, nullptr,
-                                                               cmt ? cmt + 4 * 4 * H : nullptr));  // E5
+                                                               cmt ? cmt + 4 * 4 * H : nullptr, xq));  // E5 (xq: the range pass's quantised rows for the store pass)
                 CS_TRY(mark(CS_STAGE_FFN_UP));
                 if (q8_ln_fused_takes(T, H, I)) {  // E6 likewise
                     // (the next layer's first slot; the last layer's output is not quantised again: pairs nobody reads)

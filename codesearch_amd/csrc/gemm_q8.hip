@@ -1773,9 +1773,10 @@ int32_t launch_gemm_q8_skinny(int epi, int src_kind, const void* d_src, const fl
 int32_t launch_gemm_q8_gelu_requant_from_source(const float* d_x, const uint32_t* d_in_range, const int8_t* d_wq, const Q8ColMeta* d_cmeta,
                                                 const float* bias, uint32_t M, uint32_t N, uint32_t K, uint32_t* d_range_out,
                                                 int8_t* d_out, Q8RowMeta* d_rmeta_out, hipStream_t s, const uint32_t* d_row_slot,
-                                                const uint32_t* d_cmeta_tiles) {
+                                                const uint32_t* d_cmeta_tiles, int8_t* d_xq_scratch) {
     if (d_cmeta_tiles && !d_row_slot && q8_slab_takes(M, N, K))
-        return launch_gemm_q8_slab_gelu_requant(d_x, d_in_range, d_wq, d_cmeta_tiles, M, N, K, d_range_out, d_out, d_rmeta_out, q8_gelu_table_on(), s);
+        return launch_gemm_q8_slab_gelu_requant(d_x, d_in_range, d_wq, d_cmeta_tiles, M, N, K, d_range_out, d_out, d_rmeta_out, q8_gelu_table_on(), s,
+                                                d_xq_scratch);
     if (!q8_rows_takes(M, K) || N % 128) return fail(CS_ERR_UNSUPPORTED, "quantise-on-load product: M=%u N=%u K=%u not taken by the row-block kernel", M, N, K);
     const Q8Requant rq{d_range_out, d_out, d_rmeta_out, q8_gelu_table_on()};
     if (d_row_slot) {

@@ -70,7 +70,8 @@ int32_t launch_gemm_q8_from_source(int epi, int src_kind, const void* d_src, con
 int32_t launch_gemm_q8_gelu_requant_from_source(const float* d_x, const uint32_t* d_in_range, const int8_t* d_wq, const Q8ColMeta* d_cmeta,
                                                 const float* bias, uint32_t M, uint32_t N, uint32_t K, uint32_t* d_range_out,
                                                 int8_t* d_out, Q8RowMeta* d_rmeta_out, hipStream_t s,
-                                                const uint32_t* d_row_slot = nullptr, const uint32_t* d_cmeta_tiles = nullptr);
+                                                const uint32_t* d_row_slot = nullptr, const uint32_t* d_cmeta_tiles = nullptr,
+                                                int8_t* d_xq_scratch = nullptr);
 // The same two products at indexing batch sizes (gemm_q8_slab.hip: a block owns 256 rows, W the MFMA's first operand, the tile
 // leaves from registers): taken by the two calls above when d_cmeta_tiles — the weight's column metadata as 2-KiB
 // structure-of-arrays tiles (ws | -zw | colsum | bias per 128 columns; launch_q8_cmeta_tiles, N * 16 bytes) — is given, the
@@ -82,7 +83,7 @@ int32_t launch_gemm_q8_slab_split(const float* d_x, const uint32_t* d_in_range, 
                                   _Float16* Cs, uint32_t M, uint32_t N, uint32_t K, uint32_t* d_flag, hipStream_t s);
 int32_t launch_gemm_q8_slab_gelu_requant(const float* d_x, const uint32_t* d_in_range, const int8_t* d_wq, const uint32_t* d_cmeta_tiles,
                                          uint32_t M, uint32_t N, uint32_t K, uint32_t* d_range_out, int8_t* d_out, Q8RowMeta* d_rmeta_out,
-                                         uint32_t use_table, hipStream_t s);
+                                         uint32_t use_table, hipStream_t s, int8_t* d_xq_scratch = nullptr);
 // N = 384 layers of a one-unit batch from 4,096 rows: product + bias + residual + LayerNorm in ONE kernel (gemm_q8_ln_kernel; a
 // wave owns 16 whole rows).  src_kind: Q8_SRC_SPLIT (d_src split-f16 [M][K/32][64], d_in_range its range slot; K = 384) or
 // Q8_SRC_PREQUANT (d_src s8 [M][K], d_rmeta its rows; K = 384 | 1536).  X [M][384]: the residual on entry, the normalised rows on

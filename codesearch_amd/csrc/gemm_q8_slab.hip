@@ -106,11 +106,15 @@ typedef uint32_t qs_u32x4 __attribute__((ext_vector_type(4)));
 #endif
 
 // EPI: SH_OUT_SPLIT (QKV: bias, split-f16 store) | Q8_EPI_GELU_RANGE | Q8_EPI_GELU_Q8 (the two passes of FFN-up, gemm_q8.hip)
-template <int EPI>
+// PREQ: X is the s8 tensor [M][384] the range pass left in xq_out (the store pass of FFN-up: a quarter of the f32 rows' bytes —
+// the prologue is bound by what a CU can take in, ~10 B per cycle — and no second quantisation)
+template <int EPI, bool PREQ = false>
 __global__ void __launch_bounds__(QS_THREADS, 2)
-gemm_q8_slab_kernel(const float* __restrict__ X, const int8_t* __restrict__ W, const uint32_t* __restrict__ cmt,
+gemm_q8_slab_kernel(const void* __restrict__ Xv, const int8_t* __restrict__ W, const uint32_t* __restrict__ cmt,
                     _Float16* __restrict__ Cs, uint32_t M, uint32_t N, uint32_t* __restrict__ flag, Q8Requant rq, uint32_t parts,
-                    uint32_t total_units, const uint32_t* __restrict__ in_range) {
+                    uint32_t total_units, const uint32_t* __restrict__ in_range, int8_t* __restrict__ xq_out) {
+    const float* X = reinterpret_cast<const float*>(Xv);
+    const int8_t* Xq = reinterpret_cast<const int8_t*>(Xv);
     extern __shared__ __attribute__((aligned(16))) char lds[];
     constexpr uint32_t K = 128 * QS_KC;
     constexpr bool TABLE = EPI == Q8_EPI_GELU_Q8;
@@ -189,6 +193,25 @@ gemm_q8_slab_kernel(const float* __restrict__ X, const int8_t* __restrict__ W, c
         // the wave's 32 rows x 384 k as MFMA operands, quantised on the way in: fragment (c, s, i) = row 16 i + l15, k 128 c + 64 s + 16 g ..
         q8_i32x4 a[QS_KC][2][2];
         int rowsum[2] = {0, 0};
+        if constexpr (PREQ) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const uint32_t row = m0 + i * 16 + l15;
+                const int8_t* p = Xq + (size_t)(row < M ? row : M - 1) * K + g * 16;
+#pragma unroll
+                for (int c = 0; c < QS_KC; ++c)
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) a[c][s][i] = *reinterpret_cast<const q8_i32x4*>(p + c * 128 + s * 64);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int c = 0; c < QS_KC; ++c)
+#pragma unroll
+                    for (int s = 0; s < 2; ++s)
+#pragma unroll
+                        for (int w = 0; w < 4; ++w) rowsum[i] = __builtin_amdgcn_sdot4(a[c][s][i][w], 0x01010101, rowsum[i], false);
+        } else
 #pragma unroll
         for (int c = 0; c < QS_KC; ++c) {
             sh_f32x4 v[2][2][4];
@@ -234,6 +257,10 @@ gemm_q8_slab_kernel(const float* __restrict__ X, const int8_t* __restrict__ W, c
                         packed[w] = (int)pw;
                     }
                     a[c][s][i] = packed;
+                    if (xq_out && nt0 == 0) {  // (range pass) the quantised rows, for the store pass
+                        const uint32_t row = m0 + i * 16 + l15;
+                        if (row < M) *reinterpret_cast<q8_i32x4*>(xq_out + (size_t)row * K + c * 128 + s * 64 + g * 16) = packed;
+                    }
                 }
         }
         int rowsum_c[2];
@@ -524,13 +551,13 @@ int qs_cus() {
     return cus;
 }
 
-template <int EPI>
-int32_t launch_slab(const float* d_x, const uint32_t* d_in_range, const int8_t* d_wq, const uint32_t* d_cmt, _Float16* Cs, uint32_t M,
-                    uint32_t N, uint32_t* d_flag, Q8Requant rq, hipStream_t s) {
+template <int EPI, bool PREQ = false>
+int32_t launch_slab(const void* d_x, const uint32_t* d_in_range, const int8_t* d_wq, const uint32_t* d_cmt, _Float16* Cs, uint32_t M,
+                    uint32_t N, uint32_t* d_flag, Q8Requant rq, hipStream_t s, int8_t* d_xq_out = nullptr) {
     constexpr int LDS = qs_lds(EPI == Q8_EPI_GELU_Q8);
     static PerDeviceOnce attr;  // function attributes are per device
     CS_TRY(attr.run([&]() -> int32_t {
-        CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_q8_slab_kernel<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_q8_slab_kernel<EPI, PREQ>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
         return CS_OK;
     }));
     const uint32_t slabs = (M + QS_ROWS - 1) / QS_ROWS, ntiles = N / 128, cus = (uint32_t)qs_cus();
@@ -538,8 +565,8 @@ int32_t launch_slab(const float* d_x, const uint32_t* d_in_range, const int8_t* 
     uint32_t parts = slabs >= cus ? 1u : (cus + slabs - 1) / slabs;
     if (parts > ntiles) parts = ntiles;
     const uint32_t units = slabs * parts;
-    hipLaunchKernelGGL(gemm_q8_slab_kernel<EPI>, dim3(units < cus ? units : cus), dim3(QS_THREADS), LDS, s, d_x, d_wq, d_cmt, Cs, M, N, d_flag,
-                       rq, parts, units, d_in_range);
+    hipLaunchKernelGGL((gemm_q8_slab_kernel<EPI, PREQ>), dim3(units < cus ? units : cus), dim3(QS_THREADS), LDS, s, d_x, d_wq, d_cmt, Cs, M, N, d_flag,
+                       rq, parts, units, d_in_range, d_xq_out);
     CS_HIP(hipGetLastError());
     return CS_OK;
 }
@@ -569,11 +596,13 @@ int32_t launch_gemm_q8_slab_split(const float* d_x, const uint32_t* d_in_range, 
 
 int32_t launch_gemm_q8_slab_gelu_requant(const float* d_x, const uint32_t* d_in_range, const int8_t* d_wq, const uint32_t* d_cmeta_tiles,
                                          uint32_t M, uint32_t N, uint32_t K, uint32_t* d_range_out, int8_t* d_out, Q8RowMeta* d_rmeta_out,
-                                         uint32_t use_table, hipStream_t s) {
+                                         uint32_t use_table, hipStream_t s, int8_t* d_xq_scratch) {
     if (K != 128 * QS_KC || N % 128 || N == 0) return fail(CS_ERR_UNSUPPORTED, "slab product: N=%u K=%u not built (K = 384, N %% 128 == 0)", N, K);
     if (M == 0) return CS_OK;
     const Q8Requant rq{d_range_out, d_out, d_rmeta_out, use_table};
-    CS_TRY(launch_slab<Q8_EPI_GELU_RANGE>(d_x, d_in_range, d_wq, d_cmeta_tiles, nullptr, M, N, nullptr, rq, s));
+    // d_xq_scratch [M][384] s8 (optional): the range pass leaves the rows it quantised there and the store pass takes them from it
+    CS_TRY(launch_slab<Q8_EPI_GELU_RANGE>(d_x, d_in_range, d_wq, d_cmeta_tiles, nullptr, M, N, nullptr, rq, s, d_xq_scratch));
+    if (d_xq_scratch) return (launch_slab<Q8_EPI_GELU_Q8, true>(d_xq_scratch, d_in_range, d_wq, d_cmeta_tiles, nullptr, M, N, nullptr, rq, s));
     return launch_slab<Q8_EPI_GELU_Q8>(d_x, d_in_range, d_wq, d_cmeta_tiles, nullptr, M, N, nullptr, rq, s);
 }
 

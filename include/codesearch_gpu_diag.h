@@ -29,7 +29,9 @@ CS_API int32_t cs_debug_gemm(int32_t device, int32_t mode, int32_t epilogue, con
  * definitions of DynamicQuantizeLinear / MatMulInteger).  A [M,K] f32 activations (a_split & 1: staged through the
  * split-f16 form first, as attention and GELU hand them over; a_split & 4: the few-rows kernel (one launch: range from
  * pairs, quantisation and product; epilogues 0 / 1 / 2 / 4 as built for the encoder's chain, acc not reported); a_split & 8: the row-block products that quantise their own
- * rows on the way in — K = 384, M >= 4,096, epilogues 4 (f32 source), 2 (split source) and 5; acc then not reported); W [N,K] f32 = integer multiples of wscale[n]; epilogue as
+ * rows on the way in — K = 384, M >= 4,096, epilogues 4 (f32 source), 2 (split source) and 5; acc then not reported; a_split & 16:
+ * the slab kernel (csrc/gemm_q8_slab.hip: f32 rows, K = 384, epilogues 4 and 5, any M; | 32: its FFN-up store pass takes the s8
+ * rows its range pass left instead of quantising again)); W [N,K] f32 = integer multiples of wscale[n]; epilogue as
  * cs_debug_gemm 0 / 1 / 2, 4 = bias -> split store.  Optional outputs: xq [M,K] the uint8 activations, xparams[2] =
  * (x_scale, x_zero_point), acc [M,N] the int32 MatMulInteger result.  N % 128 == 0, K % 128 == 0.
  * epilogue 5 = the FFN-up form (GELU, then quantised again for the next Linear, two passes over the product): C receives

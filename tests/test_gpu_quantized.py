@@ -207,7 +207,7 @@ def test_slab_kernel_leaves_the_row_block_kernels_bits(diag_lib, M, N, monkeypat
     assert np.array_equal(got, ref)
     # FFN-up: range pass + re-quantising store pass (bytes, output parameters, row sums)
     outs = []
-    for a_split in (16, 0):
+    for a_split in (16, 48, 0):   # 48 = 16 | 32: the store pass takes the rows the range pass quantised (s8) instead of quantising again
         C_ = np.empty((M, N), np.float32)
         xp = np.empty(4, np.float32)
         rows = np.empty((M, N), np.int32)
@@ -215,10 +215,11 @@ def test_slab_kernel_leaves_the_row_block_kernels_bits(diag_lib, M, N, monkeypat
                                             bias.ctypes.data_as(f32p), None, C_.ctypes.data_as(f32p), M, N, K, None,
                                             xp.ctypes.data_as(f32p), rows.ctypes.data_as(C.POINTER(C.c_int32))))
         outs.append((C_, xp.copy(), rows.reshape(-1)[:M].copy()))
-    assert np.array_equal(outs[0][1][2:], outs[1][1][2:])        # the output tensor's (scale, zero point)
-    assert np.array_equal(outs[0][2], outs[1][2])                # the row sums FFN-down needs
-    assert np.array_equal(outs[0][0], outs[1][0])
-    assert np.array_equal(outs[0][2], outs[0][0].astype(np.int64).sum(axis=1))
+    for o in outs[:2]:
+        assert np.array_equal(o[1][2:], outs[2][1][2:])          # the output tensor's (scale, zero point)
+        assert np.array_equal(o[2], outs[2][2])                  # the row sums FFN-down needs
+        assert np.array_equal(o[0], outs[2][0])
+        assert np.array_equal(o[2], o[0].astype(np.int64).sum(axis=1))
 
 
 def _unit_rows(rng, L, units):
