@@ -64,6 +64,8 @@ SIGNATURES = {
     "cs_index_destroy": (None, [vp]),
     "cs_index_add": (C.c_int32, [vp, f32p, C.c_uint64, C.c_uint32, u32p]),
     "cs_index_add_device": (C.c_int32, [vp, vp, C.c_uint64, C.c_uint32, u32p, vp]),
+    "cs_index_reserve_rows": (C.c_int32, [vp, C.c_uint64, C.c_uint32, C.POINTER(vp)]),
+    "cs_index_commit_rows": (C.c_int32, [vp, C.c_uint64, u32p]),
     "cs_index_add_synthetic": (C.c_int32, [vp, C.c_uint64, C.c_uint64, C.c_uint64, u32p]),
     "cs_index_remove": (C.c_int32, [vp, u32p, C.c_uint64, u64p]),
     "cs_index_build": (C.c_int32, [vp]),

@@ -60,6 +60,10 @@ int32_t embed_impl(cs_embedder* h, const int32_t* ids, const int32_t* mask, uint
                               hipMemcpyHostToDevice, h->stream));
         int mode = h->gemm_mode;
         h->cur_units = 1;
+        // results wanted in device memory in input order: the pooling kernel stores them there itself (E8 in place when `out`
+        // is a corpus region, cs_index_reserve_rows) — no [B, H] copy behind the forward
+        struct DstGuard { cs_embedder* e; ~DstGuard() { e->pooled_dst = nullptr; } } dst_guard{h};
+        h->pooled_dst = (out_on_device && !perm) ? out + done * H : nullptr;
         if (units && units->units > 1 && mode == CS_GEMM_Q8_DYNAMIC && n <= batch) {
             CS_HIP(hipMemcpyAsync(h->d_seq_unit, units->seq_unit, B * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
             CS_HIP(hipMemcpyAsync(h->d_unit_len, units->unit_len, units->units * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
@@ -125,8 +129,9 @@ int32_t embed_impl(cs_embedder* h, const int32_t* ids, const int32_t* mask, uint
         }
         if (mode == CS_GEMM_F32) h->f32_forwards += 1;
         if (!perm) {
-            CS_HIP(hipMemcpyAsync(out + done * H, h->d_pooled, (size_t)B * H * sizeof(float),
-                                  out_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, h->stream));
+            if (!h->pooled_dst)
+                CS_HIP(hipMemcpyAsync(out + done * H, h->d_pooled, (size_t)B * H * sizeof(float),
+                                      out_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, h->stream));
             CS_HIP(hipStreamSynchronize(h->stream));
         } else if (out_on_device) {
             CS_HIP(hipMemcpyAsync(h->d_perm, perm, B * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));

@@ -105,7 +105,7 @@ int32_t forward_range(cs_embedder* h, hipStream_t s, uint32_t b0, uint32_t nb, u
     a.word = P + h->off.word; a.pos = nomic ? nullptr : P + h->off.pos; a.type0 = P + h->off.type;
     a.g = P + h->off.emb_ln_g; a.b = P + h->off.emb_ln_b;
     a.eps = c.layer_norm_eps; a.T = T; a.L = L; a.B = nb; a.vocab = c.vocab_size;
-    a.pooling = c.pooling; a.x = x; a.out = h->d_pooled + (size_t)b0 * H;
+    a.pooling = c.pooling; a.x = x; a.out = (h->pooled_dst ? h->pooled_dst : h->d_pooled) + (size_t)b0 * H;
     a.xs = (split && !q8) ? (void*)(h->d_xs + t0 * H) : nullptr;  // q8: the xs buffer holds the quantised rows instead
     a.flag = h->d_flag;
     if (q8) a.range_out = h->d_range_pairs;  // LayerNorm leaves its blocks' ranges for the quantising pass that follows

@@ -140,6 +140,7 @@ struct cs_embedder {
     float* d_ctx = nullptr;     // [T, H]   (f32, or split form: same bytes)
     float* d_mid = nullptr;     // [T, I]   (f32, or split form: same bytes); CS_ARCH_NOMIC: [T, 3I] per slice (mid_width)
     float* d_pooled = nullptr;  // [B, H]
+    float* pooled_dst = nullptr;  // set around a forward whose pooled rows go straight to the caller's device buffer (a corpus region: E8 in place)
     uint32_t* d_perm = nullptr; // [B] destination row of each pooled row (length-sorted text mini-batches)
     std::vector<float> h_pooled; // host staging of a mini-batch's rows when they are scattered
     uint32_t last_B = 0, last_L = 0;

@@ -979,6 +979,28 @@ int32_t cs_index_add_device(cs_index* h, const float* d_rows, uint64_t n, uint32
     return CS_OK;
 }
 
+// E8 in place ("optionally write straight into corpus matrix row"): room for n more rows is made, *d_rows is where
+// they go — the caller has them WRITTEN there (cs_embedder_embed_*_device with this address as its output: the pooling kernel's
+// own stores land in the corpus) — and cs_index_commit_rows makes them rows of the index with the next n ids.  No staging buffer,
+// no device-to-device copy.  Between the two calls the handle must see no other mutating call (&mut self, as insert_chunks).
+int32_t cs_index_reserve_rows(cs_index* h, uint64_t n, uint32_t dim, float** d_rows) {
+    CS_TRY(check_append(h, n, dim));
+    if (!d_rows) return fail(CS_ERR_BAD_ARG, "d_rows is null");
+    DeviceGuard g(h->device);
+    CS_TRY(grow(h, h->n_rows + n));
+    *d_rows = h->d_corpus + (size_t)h->n_rows * h->dim;
+    return CS_OK;
+}
+
+int32_t cs_index_commit_rows(cs_index* h, uint64_t n, uint32_t* out_ids) {
+    CS_TRY(check_append(h, n, h ? h->dim : 0));
+    if (h->n_rows + n > h->capacity)
+        return fail(CS_ERR_BAD_ARG, "cs_index_commit_rows: %llu rows were not reserved (capacity %llu, stored %llu)", (unsigned long long)n,
+                    (unsigned long long)h->capacity, (unsigned long long)h->n_rows);
+    finish_append(h, n, out_ids);
+    return CS_OK;
+}
+
 int32_t cs_index_add_synthetic(cs_index* h, uint64_t n, uint64_t seed, uint64_t first_row,
                                uint32_t* out_first_id) {
     CS_TRY(check_append(h, n, h ? h->dim : 0));

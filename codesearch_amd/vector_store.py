@@ -410,6 +410,22 @@ class VectorStore:
                                           ids.ctypes.data_as(u32p)))
         return ids
 
+    def reserve_rows(self, n: int) -> int:
+        """Room for n more rows -> the device address they are to be written at (cs_index_reserve_rows: E8 in place — an
+        embedder's *_to_device call with this address stores its pooled rows straight into the corpus).  commit_rows(n)
+        then makes them rows with the next n ids.  One cs_index only (a sharded store plans placement: cs_shards_plan_append)."""
+        self._writable()
+        if self.sharded:
+            raise CsError(_lib.CS_ERR_UNSUPPORTED, "reserve_rows: a sharded store appends through cs_shards_add_device")
+        p = C.c_void_p()
+        _lib.check(self._lib.cs_index_reserve_rows(self._h, int(n), self.dimensions, C.byref(p)))
+        return int(p.value or 0)
+
+    def commit_rows(self, n: int) -> np.ndarray:
+        ids = np.zeros(int(n), np.uint32)
+        _lib.check(self._lib.cs_index_commit_rows(self._h, int(n), ids.ctypes.data_as(u32p)))
+        return ids
+
     def insert_synthetic(self, n: int, seed: int, first_row: int = 0) -> int:
         """Generate n rows in HBM with include/cs_synth.h -> first id."""
         first = C.c_uint32()

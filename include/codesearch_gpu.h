@@ -97,6 +97,11 @@ CS_API int32_t cs_index_add_device(cs_index* h, const float* d_rows, uint64_t n,
 /* Appends n rows produced in place by the counter-based generator of
  * include/cs_synth.h (row r, col c -> cs_synth_value(seed, (first_row + r)*dim + c)).
  * Exists so 10M..80M-row corpora never cross PCIe; not a reference method. */
+/* The same without the copy (the encoder's pooling kernel writes straight into corpus rows): reserve room for
+ * n rows, have them written at *d_rows (cs_embedder_embed_ids_device / _texts_device with that address as output), then
+ * commit — they become rows with the next n ids (store.rs:659-685).  No other mutating call on the handle in between. */
+CS_API int32_t cs_index_reserve_rows(cs_index* h, uint64_t n, uint32_t dim, float** d_rows);
+CS_API int32_t cs_index_commit_rows(cs_index* h, uint64_t n, uint32_t* out_ids);
 CS_API int32_t cs_index_add_synthetic(cs_index* h, uint64_t n, uint64_t seed, uint64_t first_row,
                                uint32_t* out_first_id);
 
