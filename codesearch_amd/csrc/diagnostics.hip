@@ -398,7 +398,7 @@ int32_t cs_debug_gemm_time(int32_t device, int32_t mode, int32_t epilogue, uint3
             cs::g_gemm_wide_mfma = ablation >= 3000 ? 32 : 16;
             ablation %= 1000;
         }
-        cs::g_gemm_wide_shape = (mode == 2 && (ablation == 192 || ablation == 384)) ? ablation : 0;
+        cs::g_gemm_wide_shape = (mode == 2 && (ablation == 192 || ablation == 384 || ablation == 256)) ? ablation : 0;  // (256: the 256 x 192 block)
         cs::g_gemm_wide_ablation = (mode == 2 && epilogue == 4 && ablation < 100) ? ablation : 0;
         for (int i = 0; i < 3; ++i) CS_TRY(once());
         CS_HIP(hipEventRecord(e0, nullptr));

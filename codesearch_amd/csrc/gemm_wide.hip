@@ -69,21 +69,22 @@ __device__ uint64_t g_gw_stamps[8 * 512];  // per block: clk0, real0, clk1, real
 // store beside storing waves that never wait on vmcnt (+7 %).  The no-DMA ablation already runs as fast as the full
 // kernel; on all-zero operands the same instruction stream is 15-20 % faster (r04_gemm_zero_vs_random.log): the rest
 // is the clock the chip holds under this load, not the schedule.
-template <int EPI, int ABL = 0, int WCN = 4>
-__global__ void __launch_bounds__(GwGeom<WCN>::THREADS, 2)
+template <int EPI, int ABL = 0, int WCN = 4, int WRN = 2>
+__global__ void __launch_bounds__((GwGeom<WCN, WRN>::THREADS), 2)
 gemm_wide_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ W, const float* __restrict__ bias,
                  const float* resid, float* C, _Float16* __restrict__ Cs, uint32_t M, uint32_t N, uint32_t kchunks,
                  uint32_t* __restrict__ flag, uint32_t total_slots, const float* __restrict__ ln_g,
                  const float* __restrict__ ln_b, float ln_eps, uint32_t ln_flags) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    using G = GwGeom<WCN>;
-    static_assert(EPI != GW_OUT_LN || WCN == 4, "the LayerNorm epilogue needs whole rows in one block");
+    using G = GwGeom<WCN, WRN>;
+    static_assert(EPI != GW_OUT_LN || (WCN == 4 && WRN == 2), "the LayerNorm epilogue needs whole rows in one block");
+    constexpr int BM = G::BM, A_BYTES = G::A_BYTES;
     constexpr int GW_BN = G::BN, GW_STAGE = G::STAGE, AP = G::A_PIECES, WP = G::W_PIECES, NP = G::PIECES;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave / WCN, wc = wave % WCN;
     const int l15 = lane & 15, g = lane >> 4;
-    const uint32_t mtiles = (M + GW_BM - 1) / GW_BM, ntiles = N / GW_BN;
+    const uint32_t mtiles = (M + BM - 1) / BM, ntiles = N / GW_BN;
 
     // LDS image of a stage: row r of a tile = one 128-B line, logical 16-B slot c at physical slot c ^ ((r >> 1) & 7)
     // (split_f16.hpp); the LDS-DMA destination is lane-linear, so the permutation goes into the source address.
@@ -92,7 +93,7 @@ gemm_wide_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ W,
         const int c = (lane & 7) ^ ((row_in_tile >> 1) & 7);
         return grow * kchunks * 64 + c * 8;
     };
-    auto tile_src = [&](uint32_t m0, uint32_t n0, GwSrc<WCN>& s) {
+    auto tile_src = [&](uint32_t m0, uint32_t n0, GwSrc<WCN, WRN>& s) {
 #pragma unroll
         for (int p = 0; p < AP; ++p) {
             const uint32_t r = (wave * AP + p) * 8 + drow;
@@ -104,13 +105,13 @@ gemm_wide_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ W,
             s.w[p] = src_of(r, n0 + r);
         }
     };
-    auto dma = [&](const GwSrc<WCN>& s, int p, uint32_t kc, uint32_t bufoff) {
+    auto dma = [&](const GwSrc<WCN, WRN>& s, int p, uint32_t kc, uint32_t bufoff) {
         if (p < AP) sh_glds16(A + (s.a[p < AP ? p : 0] + kc * 64), lds + bufoff + (wave * AP + p) * 1024);
-        else sh_glds16(W + (s.w[p >= AP ? p - AP : 0] + kc * 64), lds + bufoff + GW_A_BYTES + (wave * WP + (p - AP)) * 1024);
+        else sh_glds16(W + (s.w[p >= AP ? p - AP : 0] + kc * 64), lds + bufoff + A_BYTES + (wave * WP + (p - AP)) * 1024);
     };
 
     const int swz = (l15 >> 1) & 7;
-    const uint32_t a_off = (wr * 64 + l15) * 128, w_off = GW_A_BYTES + (wc * 96 + l15) * 128;
+    const uint32_t a_off = (wr * 64 + l15) * 128, w_off = A_BYTES + (wc * 96 + l15) * 128;
     const uint32_t s_hi = (g ^ swz) * 16, s_lo = ((4 + g) ^ swz) * 16;
 
     auto valid = [&](uint32_t slot, uint32_t& mt, uint32_t& nt) { return sh_tile_of_block(slot, mtiles, ntiles, mt, nt); };
@@ -142,8 +143,8 @@ gemm_wide_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ W,
         if constexpr (lds_params) return *reinterpret_cast<const sh_f32x4*>(pbias + c);
         else return *reinterpret_cast<const sh_f32x4*>(bias + c);
     };
-    GwSrc<WCN> src;
-    tile_src(mt * GW_BM, nt * GW_BN, src);
+    GwSrc<WCN, WRN> src;
+    tile_src(mt * BM, nt * GW_BN, src);
     uint32_t buf = 0;  // stage buffer (0 | 1) that holds stage 0 of the current tile
 #pragma unroll
     for (int p = 0; p < NP; ++p) dma(src, p, sh_kc_rot(nt, ntiles, kchunks), 0);
@@ -151,7 +152,7 @@ gemm_wide_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ W,
     [[maybe_unused]] uint64_t t_clk = 0, t_real = 0, t_main = 0, t_epi = 0, t_mark = 0, n_tiles = 0;
     if (ABL == 7) { t_clk = __builtin_amdgcn_s_memtime(); t_real = __builtin_amdgcn_s_memrealtime(); t_mark = t_clk; }
     while (slot < total_slots) {
-        const uint32_t m0 = mt * GW_BM, n0 = nt * GW_BN;
+        const uint32_t m0 = mt * BM, n0 = nt * GW_BN;
         const uint32_t rot = sh_kc_rot(nt, ntiles, kchunks);  // see sh_mainloop16: n-tiles of an m-tile walk K out of phase
         GwAcc acc;
         // The accumulators START at bias * 2^11 (LayerNorm: (bias + residual) * 2^11), the scale the products arrive on: the
@@ -277,7 +278,7 @@ gemm_wide_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ W,
         uint32_t nmt = 0, nnt = 0;
         const uint32_t nslot = next_valid(slot + gridDim.x, nmt, nnt);
         if (nslot < total_slots) {
-            tile_src(nmt * GW_BM, nnt * GW_BN, src);
+            tile_src(nmt * BM, nnt * GW_BN, src);
 #pragma unroll
             for (int p = 0; p < NP; ++p) dma(src, p, sh_kc_rot(nnt, ntiles, kchunks), (ebuf ^ 1) * GW_STAGE);
         }
@@ -290,9 +291,9 @@ gemm_wide_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ W,
         // buffer (ds_write_b128, rows padded to 400 B: conflict-free) and reads them back in line order, 8 consecutive
         // columns per lane, so every global store is 16 B per lane on consecutive lanes of a line.  (Storing straight
         // from the accumulators, 8 B per lane and plane, was measured: 2.4x slower — partial-line writes.)
-        const bool full = m0 + GW_BM <= M;
+        const bool full = m0 + BM <= M;
         uint32_t mx = 0;  // packed maximum of |hi| bit patterns (sh_split8)
-        float* patch = reinterpret_cast<float*>(lds + ebuf * GW_STAGE + wave * 8192);  // [16 rows][100 floats]
+        float* patch = reinterpret_cast<float*>(lds + ebuf * GW_STAGE + wave * G::PATCH);  // [16 rows][100 floats]
         constexpr int PS = 100;
         float mean[4] = {0.f, 0.f, 0.f, 0.f};
         float* rowstat = reinterpret_cast<float*>(lds + 2 * GW_STAGE) + 4 * GW_BM;
@@ -530,21 +531,21 @@ int g_gemm_wide_shape = 0;     // diagnostics only: 192 / 384 overrides CS_GEMM_
 int g_gemm_wide_mfma = 0;      // diagnostics only: 16 / 32 overrides CS_GEMM_WIDE_MFMA
 #endif
 
-template <int WCN>
+template <int WCN, int WRN = 2>
 static int32_t gemm_wide_launch(int epi, const _Float16* A, const _Float16* W, const float* bias, const float* resid, float* C,
                                 _Float16* Cs, uint32_t M, uint32_t N, uint32_t K, uint32_t* d_flag, hipStream_t s,
                                 const float* ln_g, const float* ln_b, float ln_eps, uint32_t ln_flags) {
-    using G = GwGeom<WCN>;
+    using G = GwGeom<WCN, WRN>;
     static PerDeviceOnce attr_set;  // function attributes are per device
     static int cus = 256;
     CS_TRY(attr_set.run([&]() -> int32_t {
-        CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wide_kernel<SH_OUT_F32, 0, WCN>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
-        CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wide_kernel<SH_OUT_F32_RESID, 0, WCN>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
-        CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wide_kernel<SH_OUT_SPLIT_GELU, 0, WCN>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
-        CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wide_kernel<SH_OUT_SPLIT, 0, WCN>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
-        CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wide_kernel<GW_OUT_SWIGLU, 0, WCN>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
-        CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wide_kernel<GW_OUT_GEGLU, 0, WCN>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
-        if constexpr (WCN == 4)
+        CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wide_kernel<SH_OUT_F32, 0, WCN, WRN>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
+        CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wide_kernel<SH_OUT_F32_RESID, 0, WCN, WRN>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
+        CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wide_kernel<SH_OUT_SPLIT_GELU, 0, WCN, WRN>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
+        CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wide_kernel<SH_OUT_SPLIT, 0, WCN, WRN>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
+        CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wide_kernel<GW_OUT_SWIGLU, 0, WCN, WRN>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
+        CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wide_kernel<GW_OUT_GEGLU, 0, WCN, WRN>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
+        if constexpr (WCN == 4 && WRN == 2)
             CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wide_kernel<GW_OUT_LN, 0, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
         int dev = 0, n = 0;
         if (hipGetDevice(&dev) == hipSuccess &&
@@ -552,19 +553,19 @@ static int32_t gemm_wide_launch(int epi, const _Float16* A, const _Float16* W, c
             cus = n / 8 * 8;  // whole XCD octets: slot -> XCD mapping survives the persistent stride
         if (cs_lab_env("CS_GEMM_WIDE_DEBUG")) {
             int nb = -1;
-            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, gemm_wide_kernel<SH_OUT_SPLIT, 0, WCN>, G::THREADS, G::LDS);
-            fprintf(stderr, "gemm_wide<WCN=%d>: %d threads, %d B LDS, occupancy %d blocks per CU\n", WCN, G::THREADS, G::LDS, nb);
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, gemm_wide_kernel<SH_OUT_SPLIT, 0, WCN, WRN>, G::THREADS, G::LDS);
+            fprintf(stderr, "gemm_wide<WCN=%d, WRN=%d>: %d threads, %d B LDS, occupancy %d blocks per CU\n", WCN, WRN, G::THREADS, G::LDS, nb);
         }
         return CS_OK;
     }));
-    const uint32_t mtiles = (M + GW_BM - 1) / GW_BM, ntiles = N / G::BN;
+    const uint32_t mtiles = (M + G::BM - 1) / G::BM, ntiles = N / G::BN;
     const uint32_t slots = sh_grid_blocks(mtiles, ntiles);
-    const uint32_t resident = (uint32_t)cus * (WCN == 4 ? 1u : 2u);  // persistent grid: every block resident
+    const uint32_t resident = (uint32_t)cus * ((WCN == 4 || WRN == 4) ? 1u : 2u);  // persistent grid: every block resident
     const uint32_t grid = slots < resident ? slots : resident;
     const uint32_t kc = K / 32;
-#define GW_LAUNCH(E, V) hipLaunchKernelGGL((gemm_wide_kernel<E, V, WCN>), dim3(grid), dim3(G::THREADS), G::LDS, s, A, W, bias, resid, C, Cs, M, N, kc, d_flag, slots, ln_g, ln_b, ln_eps, ln_flags)
+#define GW_LAUNCH(E, V) hipLaunchKernelGGL((gemm_wide_kernel<E, V, WCN, WRN>), dim3(grid), dim3(G::THREADS), G::LDS, s, A, W, bias, resid, C, Cs, M, N, kc, d_flag, slots, ln_g, ln_b, ln_eps, ln_flags)
 #ifdef CS_DIAGNOSTICS
-    if constexpr (WCN == 4) {
+    if constexpr (WCN == 4 && WRN == 2) {
         if (g_gemm_wide_ablation && epi == SH_OUT_SPLIT) {
             static PerDeviceOnce abl_attr;  // function attributes are per device
             CS_TRY(abl_attr.run([&]() -> int32_t {
@@ -604,7 +605,7 @@ static int32_t gemm_wide_launch(int epi, const _Float16* A, const _Float16* W, c
     else if (epi == GW_OUT_SWIGLU) GW_LAUNCH(GW_OUT_SWIGLU, 0);
     else if (epi == GW_OUT_GEGLU) GW_LAUNCH(GW_OUT_GEGLU, 0);
     else if (epi == GW_OUT_LN) {
-        if constexpr (WCN == 4) GW_LAUNCH(GW_OUT_LN, 0);
+        if constexpr (WCN == 4 && WRN == 2) GW_LAUNCH(GW_OUT_LN, 0);
         else return fail(CS_ERR_BAD_ARG, "the LayerNorm epilogue needs the 128 x 384 block");
     } else return fail(CS_ERR_BAD_ARG, "unknown epilogue %d", epi);
 #undef GW_LAUNCH
@@ -635,6 +636,12 @@ static int32_t gemm_wide_impl(int epi, const _Float16* A, const _Float16* W, con
         return gemm_wide32_launch(big ? 4 : 2, epi, A, W, bias, resid, C, Cs, M, N, K, d_flag, s, ln_g, ln_b, ln_eps, ln_flags);
 #endif
     if (big) return gemm_wide_launch<4>(epi, A, W, bias, resid, C, Cs, M, N, K, d_flag, s, ln_g, ln_b, ln_eps, ln_flags);
+#ifdef CS_DIAGNOSTICS
+    // 256 x 192, one block per CU (GwGeom<2, 4>; diagnostic library only): 0.875x / 0.70x the operand bytes per flop of the default
+    // shapes, parity-green, and level with them on every layer shape (profiles/r06_gemm_tall_block_ab.log) — the wide GEMMs are not
+    // bound by what L2 can deliver to LDS
+    if (want == 256) return gemm_wide_launch<2, 4>(epi, A, W, bias, resid, C, Cs, M, N, K, d_flag, s, ln_g, ln_b, ln_eps, ln_flags);
+#endif
     return gemm_wide_launch<2>(epi, A, W, bias, resid, C, Cs, M, N, K, d_flag, s, ln_g, ln_b, ln_eps, ln_flags);
 }
 

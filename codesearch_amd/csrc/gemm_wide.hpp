@@ -14,30 +14,40 @@ constexpr int GW_STATS = 5 * GW_BM * 4;            // LayerNorm epilogue: [4 col
 // Two block shapes share the kernel: WCN = 4 column waves -> 8 waves, 128 x 384 outputs, one block per CU (whole rows
 // at N = 384: the LayerNorm epilogue); WCN = 2 -> 4 waves, 128 x 192 outputs, 80 KiB of LDS, TWO blocks per CU, so
 // one block's epilogue (VALU conversions + stores) runs under the other's MFMAs.
-template <int WCN>
+// WRN = 4 (with WCN = 2; r06, diagnostic library only): 8 waves as 4 x 2, 256 x 192 outputs, one block per CU — a k-step stages
+// 32 KiB of A + 24 KiB of W for the outputs the 128 x 384 block stages 64 KiB for (and two 128 x 192 blocks 80 KiB).  Built to test
+// whether the 5 GB of operand tiles an encoder layer's four products pull from L2 into LDS bound them (748 us per layer = 6.7 TB/s,
+// the rate MI355X_MICROARCH.md gives that path): they do not — the block is level with the others (profiles/r06_gemm_tall_block_ab.log).
+template <int WCN, int WRN = 2>
 struct GwGeom {
+    static constexpr int BM = 64 * WRN;
+    static constexpr int A_BYTES = BM * 128;                     // one k-chunk (32 k, hi + lo) of the block's A rows
     static constexpr int BN = 96 * WCN;
-    static constexpr int WAVES = 2 * WCN;
+    static constexpr int WAVES = WRN * WCN;
     static constexpr int THREADS = 64 * WAVES;
     static constexpr int W_BYTES = BN * 128;
-    static constexpr int STAGE = GW_A_BYTES + W_BYTES;           // 65,536 | 40,960
+    static constexpr int STAGE = A_BYTES + W_BYTES;              // 65,536 | 40,960 | 57,344 (256 x 192)
     // WCN == 4 keeps the layer's bias (and the LayerNorm's gamma / beta) in LDS for the block's lifetime: the epilogue then
     // issues no global LOAD, so nothing in it waits on vmcnt (which retires in issue order: a load issued behind the
     // previous strip's stores, or behind the next tile's first DMAs, waits for all of them)
     static constexpr int PARAMS = WCN == 4 ? GW_PARAM_FLOATS * 4 : 0;
     static constexpr int LDS = 2 * STAGE + (WCN == 4 ? GW_STATS : 0) + PARAMS;
-    static constexpr int A_PIECES = 16 / WAVES;                  // LDS-DMA pieces (8 rows x 128 B) of A per wave and stage: 2 | 4
-    static constexpr int W_PIECES = (BN / 8) / WAVES;            // ... of W: 6
-    static constexpr int PIECES = A_PIECES + W_PIECES;           // 8 | 10
+    static constexpr int A_PIECES = (BM / 8) / WAVES;            // LDS-DMA pieces (8 rows x 128 B) of A per wave and stage: 2 | 4 | 4
+    static constexpr int W_PIECES = (BN / 8) / WAVES;            // ... of W: 6 | 6 | 3
+    static constexpr int PIECES = A_PIECES + W_PIECES;           // 8 | 10 | 7
+    // a wave's private epilogue patch inside the free stage buffer ([16 rows][100 floats] = 6,400 B used)
+    static constexpr int PATCH = WAVES * 8192 <= STAGE ? 8192 : STAGE / WAVES / 16 * 16;
+    static_assert(PATCH >= 6400, "the stage buffer must hold every wave's epilogue patch");
+    static_assert(WRN == 2 || WCN == 2, "256-row blocks are built 192 columns wide");
 };
 constexpr uint32_t GW_LN_RESID_SPLIT = 1u, GW_LN_NO_F32 = 2u;  // ln_flags of the LayerNorm epilogue (launch_gemm_wide_ln)
 constexpr int GW_OUT_LN = 16;  // epilogue: + bias + residual, LayerNorm over the 384 columns, store f32 AND split form
 
 // this wave's LDS-DMA pieces of a stage: element offsets from A / W (32 bits: a [65536, 1536] operand is 2^27.6 elements)
-template <int WCN>
+template <int WCN, int WRN = 2>
 struct GwSrc {
-    uint32_t a[GwGeom<WCN>::A_PIECES];
-    uint32_t w[GwGeom<WCN>::W_PIECES];
+    uint32_t a[GwGeom<WCN, WRN>::A_PIECES];
+    uint32_t w[GwGeom<WCN, WRN>::W_PIECES];
 };
 
 __device__ __forceinline__ float gw_erf_fast(float x) {  // gemm_epilogue.hpp sh_erf_fast
