@@ -664,6 +664,41 @@ def test_quantised_wider_models(gpu_lib, oracle, hidden, heads, inter):
     emb.close()
 
 
+def test_slab_kernels_inside_a_forward(gpu_lib, oracle, tmp_path):
+    """From 8,192 token rows a quantised forward runs QKV and FFN-up on gemm_q8_slab_kernel (the store pass taking the rows
+    the range pass quantised).  A 320 x 40-token call (12,800 rows, two layers): against the quantised oracle at the model
+    level's usual bar, and BIT FOR BIT against the same call on the row-block kernels (CS_Q8_SLAB_MIN_M=0 — a laboratory
+    knob read once per process: a child process on the diagnostic library)."""
+    import os
+    import subprocess
+    import sys
+
+    from codesearch_amd import FastEmbedder, ModelType, _lib
+
+    cfg = small_cfg(POOL_MEAN)
+    params, wscale = quantize_linear_weights(cfg, synth_params(cfg, 41), per_channel=False, unsigned=True)
+    ids, mask = synth_token_batch(cfg, 42, 320, 40, True)
+    emb = FastEmbedder(ModelType.AllMiniLML6V2Q, config=cfg, params=params, wscale=wscale)
+    got = emb.embed_ids(ids, mask, batch_size=320)
+    emb.close()
+    want = oracle.bert_forward(cfg, params, ids, mask, wscale=wscale)["pooled"]
+    err = np.abs(got - want)
+    assert err.max() < 3e-3 and np.median(err) < 2e-5, (err.max(), np.median(err))
+    code = (
+        "import numpy as np, sys\n"
+        "from codesearch_amd import FastEmbedder, ModelType\n"
+        "from codesearch_amd.bert_params import POOL_MEAN, BertConfig, quantize_linear_weights, synth_params, synth_token_batch\n"
+        "cfg = BertConfig(vocab_size=1500, hidden=384, layers=2, heads=12, intermediate=1536, max_position=64, pooling=POOL_MEAN)\n"
+        "params, wscale = quantize_linear_weights(cfg, synth_params(cfg, 41), per_channel=False, unsigned=True)\n"
+        "ids, mask = synth_token_batch(cfg, 42, 320, 40, True)\n"
+        "emb = FastEmbedder(ModelType.AllMiniLML6V2Q, config=cfg, params=params, wscale=wscale)\n"
+        "np.save(sys.argv[1], emb.embed_ids(ids, mask, batch_size=320))\n")
+    out = str(tmp_path / "rowblock.npy")
+    env = dict(os.environ, CS_Q8_SLAB_MIN_M="0", CS_LIBCSGPU=_lib.DIAG_LIB_PATH)
+    subprocess.run([sys.executable, "-c", code, out], check=True, env=env, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert np.load(out).tobytes() == got.tobytes()
+
+
 def test_search_results_are_stable_under_quantisation_noise(gpu_lib, oracle):
     """What a USER of the default (quantised) model sees: 20,480 chunks and 64 queries embedded in the
     dynamic-quantisation mode by the GPU and by the quantised oracle (the same 256-row call tensors), each side searched
