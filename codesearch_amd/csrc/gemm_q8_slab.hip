@@ -172,7 +172,7 @@ gemm_q8_slab_kernel(const void* __restrict__ Xv, const int8_t* __restrict__ W, c
     float ycen = 0.0f, yhw = INFINITY;  // wave-uniform: centre and half-width (padded) of the wave's (a, b) so far
     uint32_t mx = 0;                    // packed maximum of |hi| bit patterns (sh_split_overflowed)
 #ifdef CS_Q8_STAMPS
-    unsigned long long st0 = 0, st1 = 0, st2 = 0, st3 = 0, st4 = 0, c_pro = 0, c_mfma = 0, c_epi = 0, c_bar = 0;
+    unsigned long long st0 = 0, st1 = 0, st2 = 0, st3 = 0, st4 = 0, c_pro = 0, c_mfma = 0, c_epi = 0, c_bar = 0, c_dma = 0, c_epi_a = 0;
     (void)st2; (void)st3; (void)st4;
     uint32_t c_tiles = 0;
 #endif
@@ -302,6 +302,9 @@ gemm_q8_slab_kernel(const void* __restrict__ Xv, const int8_t* __restrict__ W, c
         // a barrier after every odd u (W tile t + 1, issued at u = 2 t, has landed; both halves are done with W tile t)
         for (uint32_t u = 0; u <= 2 * T; ++u) {
             if (!(u & 1) && (u >> 1) + 1 < T) issue_w(nt0 + (u >> 1) + 1, ((u >> 1) + 1) & 1, ((u >> 1) + 1) % 3);
+#ifdef CS_Q8_STAMPS
+            { unsigned long long td; QS_STAMP(td); c_dma += td - st1; st1 = td; }
+#endif
             const uint32_t v = u - (uint32_t)late;  // (late waves at u = 0: nothing yet)
             const uint32_t t = v >> 1;
             if (v <= 2 * T - 1 && !(v & 1)) {
@@ -377,6 +380,9 @@ gemm_q8_slab_kernel(const void* __restrict__ Xv, const int8_t* __restrict__ W, c
                             asm("v_max3_f32 %0, %0, %1, %2" : "+v"(ymax) : "v"(y0[r]), "v"(y1[r]));
                             asm("v_min3_f32 %0, %0, |%1|, |%2|" : "+v"(off) : "v"(d0), "v"(d1));
                         }
+#ifdef CS_Q8_STAMPS
+                        if (j == 3) { unsigned long long th; QS_STAMP(th); c_epi_a += th - st1; }
+#endif
                     }
                     if (!(yhw < INFINITY) || __any(off < yhw)) {
 #pragma unroll
@@ -536,7 +542,7 @@ gemm_q8_slab_kernel(const void* __restrict__ Xv, const int8_t* __restrict__ W, c
     if (EPI == SH_OUT_SPLIT && flag && sh_split_overflowed(mx)) atomicOr(flag, 1u);
 #ifdef CS_Q8_STAMPS
     if (blockIdx.x == 3 && (tid == 0 || tid == 256))
-        printf("q8 slab EPI %d N %u wave %d: %u tiles, prologue %llu  mfma %llu  epilogue %llu  end barrier %llu\n", EPI, N, wave, c_tiles, c_pro, c_mfma, c_epi, c_bar);
+        printf("q8 slab EPI %d N %u wave %d: %u tiles, prologue %llu  dma issue %llu  mfma %llu  epilogue %llu (first half %llu)  end barrier %llu\n", EPI, N, wave, c_tiles, c_pro, c_dma, c_mfma, c_epi, c_epi_a, c_bar);
 #endif
 }
 
