@@ -169,7 +169,17 @@ gemm_q8_slab_kernel(const void* __restrict__ Xv, const int8_t* __restrict__ W, c
     }
     const float gz128 = gz - 128.0f;
     float ymax = -INFINITY, ya = -INFINITY, yb = INFINITY;
-    float ycen = 0.0f, yhw = INFINITY;  // wave-uniform: centre and half-width (padded) of the wave's (a, b) so far
+    float ycen = 0.0f, yhw = INFINITY;  // wave-uniform: centre and half-width (padded) of the (a, b) window in force
+    float wwa = -INFINITY, wwb = INFINITY;  // the wave's own window so far
+    // The block's waves share their windows through two ordered keys in LDS (0 = none yet): a wave alone sees 4,096 values per tile
+    // and its window shrinks like 1 / tiles, so the window update below ran on about half of its tiles (stamps, profiles/
+    // r06_q8_slab_ab.log (8)); with eight waves' values behind the window it runs on one tile in sixteen.  Never misses: a value
+    // outside ANY wave's (a, b) cannot be the tensor's a or b.
+    uint32_t* s_win = reinterpret_cast<uint32_t*>(s_r + 24);
+    if (EPI == Q8_EPI_GELU_RANGE) {
+        if (tid < 2) s_win[tid] = 0u;
+        __syncthreads();
+    }
     uint32_t mx = 0;                    // packed maximum of |hi| bit patterns (sh_split_overflowed)
 #ifdef CS_Q8_STAMPS
     unsigned long long st0 = 0, st1 = 0, st2 = 0, st3 = 0, st4 = 0, c_pro = 0, c_mfma = 0, c_epi = 0, c_bar = 0, c_dma = 0, c_epi_a = 0;
@@ -368,6 +378,12 @@ gemm_q8_slab_kernel(const void* __restrict__ Xv, const int8_t* __restrict__ W, c
                     // fmaxf / fminf the compiler quiets every operand first (a v_max_f32 x, x per value: 330 of the fold's 1,000
                     // instructions); a NaN y is dropped by the hardware min / max all the same.
                     float ys[64], off = INFINITY;
+                    {
+                        const uint32_t k0 = s_win[0], k1 = s_win[1];  // (the same address in every lane: wave-uniform)
+                        const float ba = k0 ? fmaxf(wwa, q8_unkey(k0)) : wwa, bb = k1 ? fminf(wwb, -q8_unkey(k1)) : wwb;
+                        ycen = 0.5f * (ba + bb);             // (NaN / inf while a side is still empty: yhw stays inf)
+                        yhw = 0.5f * (bb - ba) + 1.0e-5f;
+                    }
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
                         sh_f32x4 y0, y1;
@@ -396,8 +412,12 @@ gemm_q8_slab_kernel(const void* __restrict__ Xv, const int8_t* __restrict__ W, c
                             wa = fmaxf(wa, __shfl_xor(wa, o));
                             wb = fminf(wb, __shfl_xor(wb, o));
                         }
-                        ycen = 0.5f * (wa + wb);             // (NaN / inf while a side is still empty: yhw stays inf)
-                        yhw = 0.5f * (wb - wa) + 1.0e-5f;
+                        wwa = wa;
+                        wwb = wb;
+                        if (lane == 0) {
+                            if (wa > -INFINITY) atomicMax(&s_win[0], q8_key(wa));
+                            if (wb < INFINITY) atomicMax(&s_win[1], q8_key(-wb));
+                        }
                     }
                 } else if constexpr (EPI == Q8_EPI_GELU_Q8) {
                     uint32_t d0[8], d1[8];
