@@ -1263,6 +1263,29 @@ gemm_q8_rows_kernel(const void* __restrict__ Asrc, const int8_t* __restrict__ W,
 #ifndef CS_Q8_LN_RESID_PREFETCH
 #define CS_Q8_LN_RESID_PREFETCH 1   // (0: the residual read tile by tile inside the epilogue loop, for A/B)
 #endif
+#ifdef CS_Q8_STAMPS
+#define QN_STAMP(v)                                                                      \
+    do {                                                                                 \
+        __builtin_amdgcn_sched_barrier(0);                                               \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : : "memory");     \
+        __builtin_amdgcn_sched_barrier(0);                                               \
+    } while (0)
+#else
+#define QN_STAMP(v) do { } while (0)
+#endif
+#ifndef CS_Q8_LN_PF
+#define CS_Q8_LN_PF 8   // weight fragments requested ahead of their MFMA (4 registers each)
+#endif
+// s_waitcnt vmcnt(n) for an n that is a constant only after unrolling (the instruction wants an immediate)
+__device__ __forceinline__ void qn_wait_vmcnt(int n) {
+    switch (n) {
+#define QN_W(i) case i: asm volatile("s_waitcnt vmcnt(" #i ")" ::: "memory"); break;
+        QN_W(0) QN_W(1) QN_W(2) QN_W(3) QN_W(4) QN_W(5) QN_W(6) QN_W(7) QN_W(8) QN_W(9) QN_W(10) QN_W(11) QN_W(12) QN_W(13) QN_W(14)
+        QN_W(15) QN_W(16) QN_W(17) QN_W(18) QN_W(19) QN_W(20)
+#undef QN_W
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+}
 constexpr int QN_N = 384;
 constexpr int QN_STAGE = QN_N * 64;                    // 24,576 B
 // (the metadata sits at the bottom of LDS: every read of it is then one base register + an immediate offset; above 64 KiB the
@@ -1306,21 +1329,35 @@ gemm_q8_ln_kernel(const void* __restrict__ Asrc, const Q8RowMeta* __restrict__ r
         q8_params(in_range, xs, xz);
         rxs = __fdiv_rn(1.0f, xs);
     }
-    // this wave's DPW LDS-DMA instructions of a stage: 16 rows x 64 B each; piece p of row n sits at slot p ^ ((n >> 2) & 3)
+    // this wave's DPW LDS-DMA instructions of a stage: 16 rows x 64 B each; piece p of row n sits at slot p ^ ((n >> 2) & 2).
+    // (ds_read_b128 is served in the lane groups {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, + 32 — MI355X_MICROARCH.md, LDS table:
+    // with 64-byte rows the 16 lanes of a group are rows r, r + 12 of one 16-byte column and rows r + 4, r + 8 of the next; flipping
+    // bit 1 of the slot on rows 8-15 puts the four on four different slots.  The r04-r06 form, p ^ ((n >> 2) & 3), left two of them on
+    // the same banks: every fragment read took eight LDS cycles instead of four.)
     uint32_t woff[DPW];
 #pragma unroll
     for (int t = 0; t < DPW; ++t) {
         const int row = (wave * DPW + t) * 16 + (lane >> 2);
-        woff[t] = (uint32_t)row * K + (((lane & 3) ^ ((row >> 2) & 3)) * 16);
+        woff[t] = (uint32_t)row * K + (((lane & 3) ^ ((row >> 2) & 2)) * 16);
     }
+    // (a buffer load, not global_load_lds: the compiler files the latter under FLAT — "may touch LDS or memory, may complete out of
+    // order" — and from then on answers every wait it inserts itself, the fragment reads' lgkmcnt included, with a full drain)
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<int8_t*>(W), 0, (int)(QN_N * K), 0x00020000);
     auto issue = [&](uint32_t st) {
         char* buf = lds + OFF_W + (st % QN_NST) * QN_STAGE;
 #pragma unroll
-        for (int t = 0; t < DPW; ++t) sh_glds16(W + woff[t] + st * 64, buf + (wave * DPW + t) * 1024);
+        for (int t = 0; t < DPW; ++t)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (__attribute__((address_space(3))) void*)(buf + (wave * DPW + t) * 1024), 16, (int)woff[t],
+                                                     (int)(st * 64), 0, 0);
     };
-    const int frag = l15 * 64 + ((g ^ ((l15 >> 2) & 3)) * 16);  // this lane's 16 bytes of tile j of a stage: + 1024 j
+    const int frag = l15 * 64 + ((g ^ ((l15 >> 2) & 2)) * 16);  // this lane's 16 bytes of tile j of a stage: + 1024 j
     const uint32_t groups = (M + RG - 1) / RG;
+#ifdef CS_Q8_STAMPS
+    unsigned long long c_pro = 0, c_wait = 0, c_loop = 0, c_e1 = 0, c_e2 = 0, c_e3 = 0, t0 = 0, t1 = 0, t2 = 0;
+    uint32_t c_groups = 0;
+#endif
     for (uint32_t grp = blockIdx.x; grp < groups; grp += gridDim.x) {
+        QN_STAMP(t0);
         const uint32_t row = grp * RG + wave * 16 + l15;           // this lane's row (the four lanes l15 + 16 g share it)
         const uint32_t rowc = row < M ? row : M - 1;
         __syncthreads();  // every wave is done with the previous group's last stages (and the metadata is in LDS)
@@ -1328,13 +1365,29 @@ gemm_q8_ln_kernel(const void* __restrict__ Asrc, const Q8RowMeta* __restrict__ r
         // 64-bit registers; recomputing one costs an add)
 #pragma unroll
         for (int t = 0; t < DPW; ++t) asm volatile("" : "+v"(woff[t]));
-#pragma unroll
-        for (int st = 0; st < QN_NST - 1; ++st) issue(st);
-        // the row's activations as MFMA operands: bytes 64 st + 16 g .. of the row, for every stage
+        // The weight ring: stage s lives in slot s % NST; AH = NST - 2 stages are requested ahead of the one being read, so the
+        // request made at "top of stage s" overwrites stage s - 2, whose last fragment every wave had consumed before it arrived
+        // at that barrier (only reads of stage s - 1 are still in flight there).  The barrier of stage s stands PF tiles BEFORE the stage's first MFMA (its first fragment read
+        // is the next instruction), is a bare s_barrier behind a counted vmcnt wait — __syncthreads() carries a fence the
+        // compiler answers with vmcnt(0), which through round 5 drained every request in flight at every stage — and the fragment
+        // reads run PF tiles ahead of their MFMAs across it.  (Rounds 4-5: six reads, a full wait, six MFMAs where registers
+        // allowed, else — K = 1536, whose 24 activation fragments were all loaded up front — one read, a full wait, one MFMA:
+        // an LDS round trip per MFMA, 2,200 cycles per stage against the 770 of its MFMAs.)
+        constexpr int AH = QN_NST - 2;
+        constexpr int PF = CS_Q8_LN_PF;
+        constexpr int T = 24 * KS;
+        constexpr bool ROLL = SRC != Q8_SRC_SPLIT;  // the s8 row arrives stage by stage, AH stages ahead of its MFMAs
         q8_i32x4 a[KS];
         int rowsum = 0;
         float rxs_row = xs;
         int za = 0;
+        const int8_t* a8 = reinterpret_cast<const int8_t*>(Asrc) + (size_t)rowc * K + g * 16;
+        if constexpr (ROLL) {  // (first: the oldest request in flight, nothing waits behind it)
+            const Q8RowMeta rm = rmeta[rowc];
+            rxs_row = rm.xs; za = rm.za; rowsum = rm.rowsum;
+        }
+#pragma unroll
+        for (int st = 0; st < AH && st < KS; ++st) issue(st);
         if constexpr (SRC == Q8_SRC_SPLIT) {
             const _Float16* src = reinterpret_cast<const _Float16*>(Asrc) + (size_t)rowc * (K / 32) * 64;
 #pragma unroll
@@ -1376,38 +1429,74 @@ gemm_q8_ln_kernel(const void* __restrict__ Asrc, const Q8RowMeta* __restrict__ r
             rowsum += __shfl_xor(rowsum, 32);
             za = (int)xz - 128;
         } else {
-            const int8_t* src = reinterpret_cast<const int8_t*>(Asrc) + (size_t)rowc * K + g * 16;
 #pragma unroll
-            for (int st = 0; st < KS; ++st) a[st] = *reinterpret_cast<const q8_i32x4*>(src + st * 64);
-            const Q8RowMeta rm = rmeta[rowc];
-            rxs_row = rm.xs; za = rm.za; rowsum = rm.rowsum;
+            for (int st = 0; st < AH && st < KS; ++st) a[st] = *reinterpret_cast<const q8_i32x4*>(a8 + st * 64);
         }
         const int rowsum_c = rowsum - (int)K * za, nza = -za;
         q8_i32x4 acc[24];
 #pragma unroll
         for (int j = 0; j < 24; ++j) acc[j] = q8_i32x4{0, 0, 0, 0};
+#ifdef CS_Q8_STAMPS
+        asm volatile("" : "+v"(a[0]));
+        QN_STAMP(t1);
+        c_pro += t1 - t0; ++c_groups;
+#endif
+        // top of stage st: this wave's share of it has landed (requests are served in order: behind the LAST of stage st's DPW
+        // there are at most AH - 1 younger stages, each with — ROLL — one activation load that the compiler places anywhere among
+        // its stage's DPW; the prologue's activation loads may all stand in front of stage 0's last request), then everyone's;
+        // request stage st + AH and its activations
+        auto top = [&](int st) {
+            __builtin_amdgcn_sched_barrier(0);
+#ifdef CS_Q8_STAMPS
+            QN_STAMP(t2);
+#endif
+            const int younger = KS - 1 - st < AH - 1 ? KS - 1 - st : AH - 1;
+            qn_wait_vmcnt(DPW * younger + (ROLL ? (st < younger ? st : younger) : 0));
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+#ifdef CS_Q8_STAMPS
+            { unsigned long long tw; QN_STAMP(tw); c_wait += tw - t2; }
+#endif
+            if (st + AH < KS) {
+                issue(st + AH);
+                if constexpr (ROLL) a[st + AH] = *reinterpret_cast<const q8_i32x4*>(a8 + (st + AH) * 64);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        auto wfrag = [&](int u) {  // tile u % 24 of stage u / 24
+            return *reinterpret_cast<const q8_i32x4*>(lds + OFF_W + ((u / 24) % QN_NST) * QN_STAGE + frag + (u % 24) * 1024);
+        };
+        top(0);
+        q8_i32x4 wq[PF];
 #pragma unroll
-        for (uint32_t st = 0; st < (uint32_t)KS; ++st) {  // (fully unrolled: a[] must stay in registers)
-            // this wave's share of stage st has landed: of the stages it has in flight only the younger ones may remain
-            if (st + QN_NST - 1 <= (uint32_t)KS) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DPW * (QN_NST - 2)) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();  // ... and everyone's; everyone is done with stage st - 1, whose slot the next issue overwrites
-            if (st + QN_NST - 1 < (uint32_t)KS) issue(st + QN_NST - 1);
-            const char* buf = lds + OFF_W + (st % QN_NST) * QN_STAGE + frag;
-            const q8_i32x4 av = a[st];
+        for (int u = 0; u < PF; ++u) wq[u] = wfrag(u);
+        __builtin_amdgcn_sched_group_barrier(0x100, PF, 0);
+#pragma unroll
+        for (int st = 0; st < KS; ++st) {  // (both loops fully unrolled: a[], wq[] and acc[] are registers)
 #pragma unroll
             for (int j = 0; j < 24; ++j) {
-                const q8_i32x4 w = *reinterpret_cast<const q8_i32x4*>(buf + j * 1024);
-                acc[j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(w, av, acc[j], 0, 0, 0);
-                // (at most six fragment reads in flight: unrestrained, the scheduler hoists all 24 — 96 registers — and spills)
-                if (j % 6 == 5) __builtin_amdgcn_sched_barrier(0);
+                const int t = 24 * st + j, u = t + PF;
+                const q8_i32x4 w = wq[t % PF];
+                if (u < T) {
+                    if (u % 24 == 0) top(u / 24);
+                    wq[t % PF] = wfrag(u);
+                }
+                acc[j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(w, a[st], acc[j], 0, 0, 0);
+                // (pinned: one read, one MFMA — left alone the scheduler gathers the reads, 4 registers each, in front)
+                if (u < T) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
             }
         }
+        __builtin_amdgcn_sched_barrier(0);
         // (the accumulators are read through inline asm below: see the row-block kernel's note on MFMA results and s_nop)
         asm volatile("s_nop 15"
                      : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]), "+v"(acc[7]),
                        "+v"(acc[8]), "+v"(acc[9]), "+v"(acc[10]), "+v"(acc[11]), "+v"(acc[12]), "+v"(acc[13]), "+v"(acc[14]), "+v"(acc[15]),
                        "+v"(acc[16]), "+v"(acc[17]), "+v"(acc[18]), "+v"(acc[19]), "+v"(acc[20]), "+v"(acc[21]), "+v"(acc[22]), "+v"(acc[23]));
+#ifdef CS_Q8_STAMPS
+        QN_STAMP(t2);
+        c_loop += t2 - t1;
+#endif
         // y = float(acc with the zero points back in) * (x_scale * W_scale) + bias, + residual: kept in the accumulator registers
         float* xrow = X + (size_t)rowc * QN_N + 4 * g;
         // The row's residual, all 24 tiles requested at once: the activations' registers are free from here on, and read tile by
@@ -1450,6 +1539,11 @@ gemm_q8_ln_kernel(const void* __restrict__ Asrc, const Q8RowMeta* __restrict__ r
         }
         sum += __shfl_xor(sum, 16);
         sum += __shfl_xor(sum, 32);
+#ifdef CS_Q8_STAMPS
+        asm volatile("" : "+v"(sum));
+        QN_STAMP(t1);
+        c_e1 += t1 - t2;
+#endif
         const float mean = sum * (1.0f / (float)QN_N);
         float qv = 0.0f;
 #pragma unroll
@@ -1459,6 +1553,11 @@ gemm_q8_ln_kernel(const void* __restrict__ Asrc, const Q8RowMeta* __restrict__ r
         qv += __shfl_xor(qv, 16);
         qv += __shfl_xor(qv, 32);
         const float inv = 1.0f / sqrtf(qv * (1.0f / (float)QN_N) + eps);
+#ifdef CS_Q8_STAMPS
+        { float iv = inv; asm volatile("" : "+v"(iv)); }
+        QN_STAMP(t2);
+        c_e2 += t2 - t1;
+#endif
         float lo = 0.0f, hi = 0.0f;
 #pragma unroll
         for (int j = 0; j < 24; ++j) {
@@ -1500,7 +1599,17 @@ gemm_q8_ln_kernel(const void* __restrict__ Asrc, const Q8RowMeta* __restrict__ r
                 range_out[2 * ((size_t)grp * NW + wave) + 1] = hi;
             }
         }
+#ifdef CS_Q8_STAMPS
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        QN_STAMP(t1);
+        c_e3 += t1 - t2;
+#endif
     }
+#ifdef CS_Q8_STAMPS
+    if (blockIdx.x == 3 && (tid == 0 || tid == 64 * (NW - 1)))
+        printf("q8 ln SRC %d KS %d wave %d: %u groups, prologue %llu  k loop %llu (of it waiting %llu)  y+resid %llu  variance %llu  normalise+store %llu\n", SRC, KS, wave,
+               c_groups, c_pro, c_loop, c_wait, c_e1, c_e2, c_e3);
+#endif
 }
 
 }  // namespace
@@ -1631,9 +1740,9 @@ int32_t launch_gemm_q8_ln(int src_kind, const void* d_src, const Q8RowMeta* d_rm
         CS_HIP(allow(gemm_q8_ln_kernel<QR_PREQUANT, 6, 4, 3>, 3));
         CS_HIP(allow(gemm_q8_ln_kernel<QR_PREQUANT, 24, 4, 3>, 3));
 #endif
-        CS_HIP(allow(gemm_q8_ln_kernel<Q8_SRC_SPLIT, 6, 8, 4>, 4));
-        CS_HIP(allow(gemm_q8_ln_kernel<QR_PREQUANT, 6, 8, 4>, 4));
-        CS_HIP(allow(gemm_q8_ln_kernel<QR_PREQUANT, 24, 8, 4>, 4));
+        CS_HIP(allow(gemm_q8_ln_kernel<Q8_SRC_SPLIT, 6, 8, 5>, 5));
+        CS_HIP(allow(gemm_q8_ln_kernel<QR_PREQUANT, 6, 8, 5>, 5));
+        CS_HIP(allow(gemm_q8_ln_kernel<QR_PREQUANT, 24, 8, 5>, 5));
         return CS_OK;
     }));
     auto go = [&](auto kernel, uint32_t nw, int nst) -> int32_t {
@@ -1652,9 +1761,9 @@ int32_t launch_gemm_q8_ln(int src_kind, const void* d_src, const Q8RowMeta* d_rm
         return go(gemm_q8_ln_kernel<QR_PREQUANT, 24, 4, 3>, 4, 3);
     }
 #endif
-    if (src_kind == Q8_SRC_SPLIT) return go(gemm_q8_ln_kernel<Q8_SRC_SPLIT, 6, 8, 4>, 8, 4);
-    if (K == 384) return go(gemm_q8_ln_kernel<QR_PREQUANT, 6, 8, 4>, 8, 4);
-    return go(gemm_q8_ln_kernel<QR_PREQUANT, 24, 8, 4>, 8, 4);
+    if (src_kind == Q8_SRC_SPLIT) return go(gemm_q8_ln_kernel<Q8_SRC_SPLIT, 6, 8, 5>, 8, 5);
+    if (K == 384) return go(gemm_q8_ln_kernel<QR_PREQUANT, 6, 8, 5>, 8, 5);
+    return go(gemm_q8_ln_kernel<QR_PREQUANT, 24, 8, 5>, 8, 5);
 }
 
 int32_t launch_gemm_q8(int epi, const int8_t* d_xq, const Q8RowMeta* d_rmeta, const int8_t* d_wq, const Q8ColMeta* d_cmeta,
