@@ -253,6 +253,7 @@ static int32_t create_impl(const cs_bert_config* cfg, const float* params, uint6
         if (s == CS_OK && (hipMalloc(&h->d_wq8, (size_t)cfg->layers * ql.total) != hipSuccess ||
                            hipMalloc(&h->d_cmeta, (size_t)cfg->layers * cols * sizeof(Q8ColMeta)) != hipSuccess ||
                            hipMalloc(&h->d_cmeta_tiles, (size_t)cfg->layers * cols * sizeof(Q8ColMeta)) != hipSuccess ||
+                           (H % 64 == 0 && I % 64 == 0 && hipMalloc(&h->d_wq8_stages, (size_t)cfg->layers * (H * H + H * I)) != hipSuccess) ||
                            hipMalloc(&d_ws, (size_t)cfg->layers * cols * sizeof(float)) != hipSuccess ||
                            hipMalloc(&d_bad, sizeof(uint32_t)) != hipSuccess))
             s = fail(CS_ERR_OOM, "hipMalloc(quantised weights) failed");
@@ -273,6 +274,12 @@ static int32_t create_impl(const cs_bert_config* cfg, const float* params, uint6
             uint32_t* ct = h->d_cmeta_tiles + ((size_t)l * cols) * 4;
             if (s == CS_OK && (3 * H) % 128 == 0) s = launch_q8_cmeta_tiles(cm, (uint32_t)(3 * H), ct, h->stream);
             if (s == CS_OK && I % 128 == 0 && H % 128 == 0) s = launch_q8_cmeta_tiles(cm + 4 * H, (uint32_t)I, ct + 4 * 4 * H, h->stream);
+            // out-proj and FFN-down once more, stage-major (the LayerNorm-fused products' weight stream)
+            if (s == CS_OK && h->d_wq8_stages) {
+                int8_t* ws = h->d_wq8_stages + (size_t)l * (H * H + H * I);
+                s = launch_q8_stage_major(wq + ql.ao, (uint32_t)H, (uint32_t)H, ws, h->stream);
+                if (s == CS_OK) s = launch_q8_stage_major(wq + ql.down, (uint32_t)H, (uint32_t)I, ws + H * H, h->stream);
+            }
         }
         uint32_t bad = 0;
         if (s == CS_OK && (hipMemcpyAsync(&bad, d_bad, sizeof(bad), hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
@@ -345,6 +352,7 @@ void cs_embedder_destroy(cs_embedder* h) {
     if (h->d_wq8) (void)hipFree(h->d_wq8);
     if (h->d_cmeta) (void)hipFree(h->d_cmeta);
     if (h->d_cmeta_tiles) (void)hipFree(h->d_cmeta_tiles);
+    if (h->d_wq8_stages) (void)hipFree(h->d_wq8_stages);
     for (hipEvent_t e : h->stage_ev) (void)hipEventDestroy(e);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);

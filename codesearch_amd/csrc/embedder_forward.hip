@@ -336,6 +336,7 @@ int32_t forward_range(cs_embedder* h, hipStream_t s, uint32_t b0, uint32_t nb, u
             const Q8Layer ql = q8_layer(H, I);
             const int8_t* wq = h->d_wq8 + (size_t)l * ql.total;
             const Q8ColMeta* cm = h->d_cmeta + (size_t)l * (5 * (size_t)H + I);
+            const int8_t* wst = h->d_wq8_stages ? h->d_wq8_stages + (size_t)l * ((size_t)H * H + (size_t)H * I) : nullptr;  // (out-proj | FFN-down, stage-major)
             const uint32_t* cmt = (H % 128 == 0 && I % 128 == 0) ? h->d_cmeta_tiles + (size_t)l * (5 * (size_t)H + I) * 4 : nullptr;  // (slab kernel)
             const uint32_t U = h->cur_units;
             uint32_t* rg = h->d_range + (size_t)l * 4 * Q8_RANGE_WORDS * U;
@@ -392,8 +393,8 @@ int32_t forward_range(cs_embedder* h, hipStream_t s, uint32_t b0, uint32_t nb, u
                 CS_TRY(mark(CS_STAGE_ATTENTION));
                 CS_TRY(launch_q8_range(Q8_SRC_SPLIT, ctxs, T, H, rg + rstep, s, rp, att_pairs));
                 if (q8_ln_fused_takes(T, H, H)) {  // E4 with its residual add and LayerNorm in one kernel (gemm_q8_ln_kernel)
-                    CS_TRY(launch_gemm_q8_ln(Q8_SRC_SPLIT, ctxs, nullptr, rg + rstep, wq + ql.ao, cm + 3 * H, x, P + lo.ao_ln_g, P + lo.ao_ln_b,
-                                             c.layer_norm_eps, T, H, rp, &h->q8_x_pairs, s, ln_slot ? rg + 2 * rstep : nullptr));
+                    CS_TRY(launch_gemm_q8_ln(Q8_SRC_SPLIT, ctxs, nullptr, rg + rstep, wst ? wst : wq + ql.ao, cm + 3 * H, x, P + lo.ao_ln_g, P + lo.ao_ln_b,
+                                             c.layer_norm_eps, T, H, rp, &h->q8_x_pairs, s, ln_slot ? rg + 2 * rstep : nullptr, wst != nullptr));
                     CS_TRY(mark(CS_STAGE_OUT_PROJ));
                 } else {
                     CS_TRY(launch_gemm_q8_from_source(SH_OUT_F32_RESID, Q8_SRC_SPLIT, ctxs, rg + rstep, wq + ql.ao, cm + 3 * H, P + lo.ao_b, x, x, nullptr, T, H, H,
@@ -412,8 +413,8 @@ int32_t forward_range(cs_embedder* h, hipStream_t s, uint32_t b0, uint32_t nb, u
                 CS_TRY(mark(CS_STAGE_FFN_UP));
                 if (q8_ln_fused_takes(T, H, I)) {  // E6 likewise
                     // (the next layer's first slot; the last layer's output is not quantised again: pairs nobody reads)
-                    CS_TRY(launch_gemm_q8_ln(Q8_SRC_PREQUANT, midq, rm2, nullptr, wq + ql.down, cm + 4 * H + I, x, P + lo.out_ln_g, P + lo.out_ln_b,
-                                             c.layer_norm_eps, T, I, rp, &h->q8_x_pairs, s, ln_slot && l + 1 < c.layers ? rg + 4 * rstep : nullptr));
+                    CS_TRY(launch_gemm_q8_ln(Q8_SRC_PREQUANT, midq, rm2, nullptr, wst ? wst + (size_t)H * H : wq + ql.down, cm + 4 * H + I, x, P + lo.out_ln_g, P + lo.out_ln_b,
+                                             c.layer_norm_eps, T, I, rp, &h->q8_x_pairs, s, ln_slot && l + 1 < c.layers ? rg + 4 * rstep : nullptr, wst != nullptr));
                     CS_TRY(mark(CS_STAGE_FFN_DOWN));
                 } else {
                     CS_TRY(launch_gemm_q8(SH_OUT_F32_RESID, midq, rm2, wq + ql.down, cm + 4 * H + I, P + lo.down_b, x, x, nullptr, T, H, I, h->d_flag, s));  // E6

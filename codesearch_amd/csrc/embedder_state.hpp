@@ -105,6 +105,7 @@ struct cs_embedder {
     bool quantized = false;
     int8_t* d_wq8 = nullptr;
     Q8ColMeta* d_cmeta = nullptr;
+    int8_t* d_wq8_stages = nullptr;     // [layers][H * H + H * I]: out-proj and FFN-down once more in the order gemm_q8_ln_kernel streams them (384-wide models)
     uint32_t* d_cmeta_tiles = nullptr;  // the same columns as 2-KiB structure-of-arrays tiles (gemm_q8_slab.hip), 16 B per column
     uint32_t* d_range = nullptr;
     uint32_t q8_units = 1;

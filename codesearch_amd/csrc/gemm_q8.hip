@@ -16,6 +16,7 @@
 // MFMAs per 32 k) becomes one int8 MFMA per 64 k: a sixth of the matrix-pipe time, and a quarter of the operand bytes.
 // The tile leaves through the epilogue the split-f16 kernels use (gemm_epilogue.hpp).
 #include <cstdlib>
+#include <utility>
 
 #include "encoder.hpp"
 #include "gemm_epilogue.hpp"
@@ -1247,6 +1248,15 @@ gemm_q8_rows_kernel(const void* __restrict__ Asrc, const int8_t* __restrict__ W,
     }
 }
 
+// W [N][K] -> [K / 64][N][64]: the order gemm_q8_ln_kernel streams it in (one thread per 16-byte piece)
+__global__ void __launch_bounds__(256)
+q8_stage_major_kernel(const int8_t* __restrict__ w, int8_t* __restrict__ out, uint32_t N, uint32_t K) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x, per_row = K / 16;
+    if (i >= N * per_row) return;
+    const uint32_t n = i / per_row, p = i % per_row;
+    *reinterpret_cast<q8_i32x4*>(out + ((size_t)(p / 4) * N + n) * 64 + (p % 4) * 16) = *reinterpret_cast<const q8_i32x4*>(w + (size_t)n * K + p * 16);
+}
+
 // ---- N = 384 layers (out-proj, FFN-down of the 384-wide models) with their residual add and LayerNorm in the epilogue --------
 // The row-block kernel above hands a row's 384 outputs to eight waves and three n-tiles: the LayerNorm behind E4 / E6 had to be
 // its own kernel (34 us per layer each at 65,536 rows: 100 MB read, 100 MB written — the two of them a tenth of the forward).
@@ -1276,15 +1286,39 @@ gemm_q8_rows_kernel(const void* __restrict__ Asrc, const int8_t* __restrict__ W,
 #ifndef CS_Q8_LN_PF
 #define CS_Q8_LN_PF 8   // weight fragments requested ahead of their MFMA (4 registers each)
 #endif
-// s_waitcnt vmcnt(n) for an n that is a constant only after unrolling (the instruction wants an immediate)
-__device__ __forceinline__ void qn_wait_vmcnt(int n) {
-    switch (n) {
-#define QN_W(i) case i: asm volatile("s_waitcnt vmcnt(" #i ")" ::: "memory"); break;
-        QN_W(0) QN_W(1) QN_W(2) QN_W(3) QN_W(4) QN_W(5) QN_W(6) QN_W(7) QN_W(8) QN_W(9) QN_W(10) QN_W(11) QN_W(12) QN_W(13) QN_W(14)
-        QN_W(15) QN_W(16) QN_W(17) QN_W(18) QN_W(19) QN_W(20)
-#undef QN_W
-        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-    }
+#ifndef CS_Q8_LN_DIAG
+#define CS_Q8_LN_DIAG 0
+#endif
+#ifndef CS_Q8_LN_RPRE
+#define CS_Q8_LN_RPRE 16  // of the 24 residual tiles of a row, those requested inside the k loop (4 registers each; the rest behind it)
+#endif
+// the vector-memory requests made at the top of stage i (i < 0: the prologue's weight stages): what the counted waits add up
+// residual tiles requested before stage i's top.  K = 384: evenly from stage 0 on (the loop is short); K = 1536: half of them over
+// stages ks / 3 .. ks - 4 and half over the last three, where the activation fragments' registers have drained (requested evenly,
+// ten tiles already make the allocator spill freshly loaded ones — a wait for memory in the middle of the loop)
+constexpr int qn_rpre_upto(int i, int ks) {
+    constexpr int R = CS_Q8_LN_RPRE;
+    if (i <= 0) return 0;
+    if (i >= ks) return R;
+    if (ks <= 6) return i * R / ks;
+    const int i0 = ks / 3, i1 = ks - 3;
+    if (i <= i0) return 0;
+    if (i <= i1) return (i - i0) * (R / 2) / (i1 - i0);
+    return R / 2 + (i - i1) * (R - R / 2) / 3;
+}
+constexpr int qn_top_requests(int i, int ks, int ah, int dpw, bool roll) {
+    return i < 0 ? dpw : (i + ah < ks ? dpw + (roll ? 1 : 0) : 0) + (qn_rpre_upto(i + 1, ks) - qn_rpre_upto(i, ks));
+}
+constexpr int qn_younger_requests(int st, int ks, int ah, int dpw, bool roll) {  // those certainly behind stage st's last weight request
+    int n = 0;
+    for (int i = st - ah + 1; i <= st - 1; ++i) n += qn_top_requests(i, ks, ah, dpw, roll);
+    return n;
+}
+// a loop whose index is a constant expression in its body (immediates of s_waitcnt, bounds of inner loops): the stage loop is
+// too large for "#pragma unroll" to be relied on, and left rolled it indexes the register arrays dynamically (scratch memory)
+template <class F, int... I>
+__device__ __forceinline__ void qn_static_for(std::integer_sequence<int, I...>, F&& f) {
+    (f(std::integral_constant<int, I>{}), ...);
 }
 constexpr int QN_N = 384;
 constexpr int QN_STAGE = QN_N * 64;                    // 24,576 B
@@ -1302,7 +1336,8 @@ template <int SRC, int KS, int NW, int NST>  // KS = K / 64 stages: 6 (K = 384) 
 __global__ void __launch_bounds__(64 * NW, 2)
 gemm_q8_ln_kernel(const void* __restrict__ Asrc, const Q8RowMeta* __restrict__ rmeta, const uint32_t* __restrict__ in_range,
                   const int8_t* __restrict__ W, const Q8ColMeta* __restrict__ cmeta, float* X, const float* __restrict__ ln_g,
-                  const float* __restrict__ ln_b, float eps, uint32_t M, float* __restrict__ range_out, uint32_t* __restrict__ range_slot) {
+                  const float* __restrict__ ln_b, float eps, uint32_t M, float* __restrict__ range_out, uint32_t* __restrict__ range_slot,
+                  uint32_t stage_major) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     constexpr uint32_t K = 64 * KS;
     constexpr int QN_THREADS = 64 * NW, QN_NST = NST;
@@ -1338,8 +1373,12 @@ gemm_q8_ln_kernel(const void* __restrict__ Asrc, const Q8RowMeta* __restrict__ r
 #pragma unroll
     for (int t = 0; t < DPW; ++t) {
         const int row = (wave * DPW + t) * 16 + (lane >> 2);
-        woff[t] = (uint32_t)row * K + (((lane & 3) ^ ((row >> 2) & 2)) * 16);
+        woff[t] = (uint32_t)row * (stage_major ? 64u : K) + (((lane & 3) ^ ((row >> 2) & 2)) * 16);
     }
+    // W as launch_q8_stage_major leaves it ([K / 64][384][64]: a stage is 24 KiB in a row and every request of 16 rows x 64 B one
+    // KiB of whole 128-byte lines) or row-major ([384][K]: the same request takes 64 B out of each of 16 lines — the L2 moves
+    // twice the bytes, and the k loop of K = 1536 ran at the rate its weight stream arrived, 16 B per cycle and CU)
+    const uint32_t st_stride = stage_major ? (uint32_t)QN_N * 64u : 64u;
     // (a buffer load, not global_load_lds: the compiler files the latter under FLAT — "may touch LDS or memory, may complete out of
     // order" — and from then on answers every wait it inserts itself, the fragment reads' lgkmcnt included, with a full drain)
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<int8_t*>(W), 0, (int)(QN_N * K), 0x00020000);
@@ -1348,7 +1387,7 @@ gemm_q8_ln_kernel(const void* __restrict__ Asrc, const Q8RowMeta* __restrict__ r
 #pragma unroll
         for (int t = 0; t < DPW; ++t)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (__attribute__((address_space(3))) void*)(buf + (wave * DPW + t) * 1024), 16, (int)woff[t],
-                                                     (int)(st * 64), 0, 0);
+                                                     (int)(st * st_stride), 0, 0);
     };
     const int frag = l15 * 64 + ((g ^ ((l15 >> 2) & 2)) * 16);  // this lane's 16 bytes of tile j of a stage: + 1024 j
     const uint32_t groups = (M + RG - 1) / RG;
@@ -1441,52 +1480,72 @@ gemm_q8_ln_kernel(const void* __restrict__ Asrc, const Q8RowMeta* __restrict__ r
         QN_STAMP(t1);
         c_pro += t1 - t0; ++c_groups;
 #endif
+        // The row's residual: CS_Q8_LN_RPRE of its 24 tiles are requested stage by stage inside the k loop (their registers are
+        // the ones the up-front activation fragments held through round 5), the rest behind it — the epilogue used to begin with
+        // a memory round trip for all 24 (15-20 thousand cycles per group of the stamps' 70).
+        float* xrow = X + (size_t)rowc * QN_N + 4 * g;
+#if CS_Q8_LN_RESID_PREFETCH
+        sh_f32x4 rpre[24];
+#endif
         // top of stage st: this wave's share of it has landed (requests are served in order: behind the LAST of stage st's DPW
         // there are at most AH - 1 younger stages, each with — ROLL — one activation load that the compiler places anywhere among
         // its stage's DPW; the prologue's activation loads may all stand in front of stage 0's last request), then everyone's;
         // request stage st + AH and its activations
-        auto top = [&](int st) {
+        auto top = [&](auto st_) {
+            constexpr int st = decltype(st_)::value;
             __builtin_amdgcn_sched_barrier(0);
 #ifdef CS_Q8_STAMPS
             QN_STAMP(t2);
 #endif
-            const int younger = KS - 1 - st < AH - 1 ? KS - 1 - st : AH - 1;
-            qn_wait_vmcnt(DPW * younger + (ROLL ? (st < younger ? st : younger) : 0));
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(qn_younger_requests(st, KS, AH, DPW, ROLL)) : "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
 #ifdef CS_Q8_STAMPS
             { unsigned long long tw; QN_STAMP(tw); c_wait += tw - t2; }
 #endif
-            if (st + AH < KS) {
+            if constexpr (st + AH < KS) {
+#if !(defined(CS_Q8_STAMPS) && CS_Q8_LN_DIAG == 1)  // (diagnostic: 1 = no weight requests inside the loop)
                 issue(st + AH);
+#endif
                 if constexpr (ROLL) a[st + AH] = *reinterpret_cast<const q8_i32x4*>(a8 + (st + AH) * 64);
             }
+#if CS_Q8_LN_RESID_PREFETCH
+#pragma unroll
+            for (int j = qn_rpre_upto(st, KS); j < qn_rpre_upto(st + 1, KS); ++j) rpre[j] = *reinterpret_cast<const sh_f32x4*>(xrow + 16 * j);
+#endif
             __builtin_amdgcn_sched_barrier(0);
         };
         auto wfrag = [&](int u) {  // tile u % 24 of stage u / 24
             return *reinterpret_cast<const q8_i32x4*>(lds + OFF_W + ((u / 24) % QN_NST) * QN_STAGE + frag + (u % 24) * 1024);
         };
-        top(0);
+        top(std::integral_constant<int, 0>{});
         q8_i32x4 wq[PF];
 #pragma unroll
         for (int u = 0; u < PF; ++u) wq[u] = wfrag(u);
         __builtin_amdgcn_sched_group_barrier(0x100, PF, 0);
+        auto tile = [&](int st, int j) {  // MFMA of tile j of stage st, behind the request for the fragment PF tiles on
+            const int t = 24 * st + j, u = t + PF;
+            const q8_i32x4 w = wq[t % PF];
+#if defined(CS_Q8_STAMPS) && CS_Q8_LN_DIAG == 2  // (diagnostic: 2 = neither fragment reads nor MFMAs, 3 = no fragment reads)
+            return;
+#elif defined(CS_Q8_STAMPS) && CS_Q8_LN_DIAG == 3
+            if (u < PF) wq[t % PF] = wfrag(u);
+#else
+            if (u < T) wq[t % PF] = wfrag(u);
+#endif
+            acc[j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(w, a[st], acc[j], 0, 0, 0);
+            // (pinned: one read, one MFMA — left alone the scheduler gathers the reads, 4 registers each, in front)
+            if (u < T) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        };
+        qn_static_for(std::make_integer_sequence<int, KS>{}, [&](auto st_) {
+            constexpr int st = decltype(st_)::value;
 #pragma unroll
-        for (int st = 0; st < KS; ++st) {  // (both loops fully unrolled: a[], wq[] and acc[] are registers)
+            for (int j = 0; j < 24 - PF; ++j) tile(st, j);
+            if constexpr (st + 1 < KS) top(std::integral_constant<int, st + 1>{});  // the next fragment requested is the next stage's first
 #pragma unroll
-            for (int j = 0; j < 24; ++j) {
-                const int t = 24 * st + j, u = t + PF;
-                const q8_i32x4 w = wq[t % PF];
-                if (u < T) {
-                    if (u % 24 == 0) top(u / 24);
-                    wq[t % PF] = wfrag(u);
-                }
-                acc[j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(w, a[st], acc[j], 0, 0, 0);
-                // (pinned: one read, one MFMA — left alone the scheduler gathers the reads, 4 registers each, in front)
-                if (u < T) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            }
-        }
+            for (int j = 24 - PF; j < 24; ++j) tile(st, j);
+        });
         __builtin_amdgcn_sched_barrier(0);
         // (the accumulators are read through inline asm below: see the row-block kernel's note on MFMA results and s_nop)
         asm volatile("s_nop 15"
@@ -1498,14 +1557,12 @@ gemm_q8_ln_kernel(const void* __restrict__ Asrc, const Q8RowMeta* __restrict__ r
         c_loop += t2 - t1;
 #endif
         // y = float(acc with the zero points back in) * (x_scale * W_scale) + bias, + residual: kept in the accumulator registers
-        float* xrow = X + (size_t)rowc * QN_N + 4 * g;
-        // The row's residual, all 24 tiles requested at once: the activations' registers are free from here on, and read tile by
-        // tile inside the loop below (whose scheduling fences keep two tiles' loads in flight) the epilogue paid a memory round
-        // trip per pair of tiles, twelve in a row.  (CS_Q8_LN_RESID_PREFETCH=0 at compile time restores that form.)
+        // (the residual tiles not requested inside the k loop, all at once: read tile by tile inside the loop below — whose
+        // scheduling fences keep two tiles' loads in flight — the epilogue paid a memory round trip per pair of tiles.
+        // CS_Q8_LN_RESID_PREFETCH=0 at compile time restores that form.)
 #if CS_Q8_LN_RESID_PREFETCH
-        sh_f32x4 rpre[24];
 #pragma unroll
-        for (int j = 0; j < 24; ++j) rpre[j] = *reinterpret_cast<const sh_f32x4*>(xrow + 16 * j);
+        for (int j = CS_Q8_LN_RPRE; j < 24; ++j) rpre[j] = *reinterpret_cast<const sh_f32x4*>(xrow + 16 * j);
         __builtin_amdgcn_sched_barrier(0);
 #endif
         float vf[96];  // the row's values this lane holds (scalars: partial updates of the accumulator tuples made the allocator spill)
@@ -1712,13 +1769,21 @@ static int32_t launch_rows(const void* d_xq, const Q8RowMeta* d_rmeta, const int
 // tensor, d_rmeta its rows).  X [M][384]: the residual on entry, LayerNorm(product + bias + residual) on return; *out_pairs
 // (lo, hi) pairs are left in d_range_pairs for the quantisation that follows — or, with d_out_slot, the waves widen that range
 // slot themselves (zeroed by the caller at the start of the forward) and *out_pairs = 0: no reduction launch behind the kernel.
+int32_t launch_q8_stage_major(const int8_t* d_wq, uint32_t N, uint32_t K, int8_t* d_out, hipStream_t s) {
+    if (K % 64) return fail(CS_ERR_UNSUPPORTED, "stage-major weight copy: K=%u is not a multiple of 64", K);
+    if (N == 0 || K == 0) return CS_OK;
+    hipLaunchKernelGGL(q8_stage_major_kernel, dim3((N * (K / 16) + 255) / 256), dim3(256), 0, s, d_wq, d_out, N, K);
+    CS_HIP(hipGetLastError());
+    return CS_OK;
+}
+
 bool q8_ln_fused_takes(uint32_t M, uint32_t N, uint32_t K) {
     const char* e = cs_lab_env("CS_Q8_LN_FUSED");  // (read per call: tests and A/B scripts flip it mid-process)
     return !(e && e[0] == '0') && N == (uint32_t)QN_N && (K == 384 || K == 1536) && q8_rows_takes(M, 384);
 }
 int32_t launch_gemm_q8_ln(int src_kind, const void* d_src, const Q8RowMeta* d_rmeta, const uint32_t* d_in_range, const int8_t* d_wq,
                           const Q8ColMeta* d_cmeta, float* X, const float* ln_g, const float* ln_b, float eps, uint32_t M, uint32_t K,
-                          float* d_range_pairs, uint32_t* out_pairs, hipStream_t s, uint32_t* d_out_slot) {
+                          float* d_range_pairs, uint32_t* out_pairs, hipStream_t s, uint32_t* d_out_slot, bool w_stage_major) {
     if (out_pairs) *out_pairs = 0;
     if (M == 0) return CS_OK;
     if (K != 384 && K != 1536) return fail(CS_ERR_UNSUPPORTED, "LayerNorm-fused quantised product: K=%u not built (384, 1536)", K);
@@ -1749,7 +1814,7 @@ int32_t launch_gemm_q8_ln(int src_kind, const void* d_src, const Q8RowMeta* d_rm
         const size_t ldsb = (size_t)qn_lds(nst, nst == 3);
         const uint32_t groups = (M + 16 * nw - 1) / (16 * nw), slots = (uint32_t)q8_cus() * (nw == 4 ? 2u : 1u);
         hipLaunchKernelGGL(kernel, dim3(groups < slots ? groups : slots), dim3(64 * nw), ldsb, s, d_src, d_rmeta, d_in_range, d_wq, d_cmeta, X, ln_g, ln_b,
-                           eps, M, d_range_pairs, d_out_slot);
+                           eps, M, d_range_pairs, d_out_slot, w_stage_major ? 1u : 0u);
         CS_HIP(hipGetLastError());
         if (out_pairs) *out_pairs = d_out_slot ? 0 : groups * nw;
         return CS_OK;

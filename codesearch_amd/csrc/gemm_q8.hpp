@@ -92,7 +92,10 @@ constexpr int Q8_SRC_PREQUANT = -1;
 bool q8_ln_fused_takes(uint32_t M, uint32_t N, uint32_t K);
 int32_t launch_gemm_q8_ln(int src_kind, const void* d_src, const Q8RowMeta* d_rmeta, const uint32_t* d_in_range, const int8_t* d_wq,
                           const Q8ColMeta* d_cmeta, float* X, const float* ln_g, const float* ln_b, float eps, uint32_t M, uint32_t K,
-                          float* d_range_pairs, uint32_t* out_pairs, hipStream_t s, uint32_t* d_out_slot = nullptr);
+                          float* d_range_pairs, uint32_t* out_pairs, hipStream_t s, uint32_t* d_out_slot = nullptr, bool w_stage_major = false);
+// d_out [K / 64][N][64] from d_wq [N][K]: the order launch_gemm_q8_ln streams a weight in (w_stage_major: every request whole
+// 128-byte lines; row-major it takes 64 B out of each line it touches)
+int32_t launch_q8_stage_major(const int8_t* d_wq, uint32_t N, uint32_t K, int8_t* d_out, hipStream_t s);
 // The units' ranges from what the tensor's producer left: pairs_per_seq (lo, hi) pairs per sequence, sequence by sequence
 // (attention: its waves' pairs; LayerNorm with EncoderLaunch::range_rows: one pair per token row — pairs_are_rows, and
 // only positions below the unit's own padded length count).  Writes words 0, 1 of every unit's slot.
