@@ -133,18 +133,14 @@ gemm_q8_slab_kernel(const void* __restrict__ Xv, const int8_t* __restrict__ W, c
         const int q = wave * 6 + t, c = q >> 4, row = (q & 15) * 8 + (lane >> 3);
         woff[t] = (uint32_t)row * K + c * 128 + (((lane & 7) ^ ((row >> 1) & 7)) * 16);
     }
+    // (buffer loads: split_f16.hpp, sh_blds16 — the fragment reads' waits stay counted while the next tile is on its way)
+    const sh_rsrc w_rsrc = sh_make_rsrc(W, N * K), cm_rsrc = sh_make_rsrc(cmt, ntiles * (uint32_t)QS_CM_BYTES);
     auto issue_w = [&](uint32_t nt, int b, int cb) {
-        const int8_t* src = W + (size_t)nt * 128 * K;
         char* buf = lds + b * QS_WTILE;
 #pragma unroll
-        for (int t = 0; t < 6; ++t) {
-            uint32_t o = woff[t];
-            asm volatile("" : "+v"(o));  // (opaque: otherwise the six source addresses are kept — and spilled — as 64-bit loop invariants)
-            sh_glds16(src + o, buf + (wave * 6 + t) * 1024);
-        }
+        for (int t = 0; t < 6; ++t) sh_blds16(w_rsrc, woff[t], nt * 128 * K, buf + (wave * 6 + t) * 1024);
         if (wave < 2)  // the tile's 2 KiB of column metadata: lane l of wave w moves bytes 1024 w + 16 l ..
-            sh_glds16(reinterpret_cast<const char*>(cmt) + (size_t)nt * QS_CM_BYTES + wave * 1024 + lane * 16,
-                      lds + QS_OFF_CM + cb * QS_CM_BYTES + wave * 1024);
+            sh_blds16(cm_rsrc, (uint32_t)(wave * 1024 + lane * 16), nt * (uint32_t)QS_CM_BYTES, lds + QS_OFF_CM + cb * QS_CM_BYTES + wave * 1024);
     };
     // DynamicQuantizeLinear's parameters of the input tensor
     float xs, xz;

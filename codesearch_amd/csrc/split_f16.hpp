@@ -103,6 +103,18 @@ __device__ __forceinline__ void sh_glds16(const void* gsrc, void* lds_dst) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
                                      (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
 }
+// The same request as a BUFFER load (buffer_load_dwordx4 ... lds): base + a 32-bit per-lane offset + a wave-uniform offset.  Worth
+// the descriptor wherever other waits stand between the request and its covering vmcnt: the compiler files global_load_lds
+// under FLAT ("may touch LDS or memory, may complete out of order") and, until a vmcnt wait has covered it, answers every wait it
+// inserts itself — the lgkmcnt in front of each MFMA's fragment reads included — with a full drain; buffer loads are counted.
+// (Reads past the descriptor's size return zeros instead of faulting.)
+typedef __amdgpu_buffer_rsrc_t sh_rsrc;
+__device__ __forceinline__ sh_rsrc sh_make_rsrc(const void* base, uint32_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ void sh_blds16(sh_rsrc r, uint32_t lane_off, uint32_t wave_off, void* lds_dst) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds_dst, 16, (int)lane_off, (int)wave_off, 0, 0);
+}
 // The same with the non-temporal cache policy (aux = 2): for bytes ONE CU reads once (a streamed corpus);
 // never for operands other CUs re-read from L2 (MI355X_MICROARCH.md, price list row nt-weights).
 __device__ __forceinline__ void sh_glds16_nt(const void* gsrc, void* lds_dst) {
