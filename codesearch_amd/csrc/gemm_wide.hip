@@ -91,7 +91,7 @@ gemm_wide_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ W,
     const int drow = lane >> 3;                  // row of a piece (8 rows x 128 B) this lane fetches
     auto src_of = [&](uint32_t row_in_tile, uint32_t grow) {
         const int c = (lane & 7) ^ ((row_in_tile >> 1) & 7);
-        return grow * kchunks * 64 + c * 8;
+        return (grow * kchunks * 64 + c * 8) * 2;  // bytes from the tensor's start
     };
     auto tile_src = [&](uint32_t m0, uint32_t n0, GwSrc<WCN, WRN>& s) {
 #pragma unroll
@@ -105,9 +105,11 @@ gemm_wide_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ W,
             s.w[p] = src_of(r, n0 + r);
         }
     };
+    // (buffer loads: split_f16.hpp, sh_blds16 — the operand reads' waits stay counted while the next k-step is on its way)
+    const sh_rsrc a_rsrc = sh_make_rsrc(A, M * kchunks * 128u), w_rsrc = sh_make_rsrc(W, N * kchunks * 128u);
     auto dma = [&](const GwSrc<WCN, WRN>& s, int p, uint32_t kc, uint32_t bufoff) {
-        if (p < AP) sh_glds16(A + (s.a[p < AP ? p : 0] + kc * 64), lds + bufoff + (wave * AP + p) * 1024);
-        else sh_glds16(W + (s.w[p >= AP ? p - AP : 0] + kc * 64), lds + bufoff + A_BYTES + (wave * WP + (p - AP)) * 1024);
+        if (p < AP) sh_blds16(a_rsrc, s.a[p < AP ? p : 0], kc * 128, lds + bufoff + (wave * AP + p) * 1024);
+        else sh_blds16(w_rsrc, s.w[p >= AP ? p - AP : 0], kc * 128, lds + bufoff + A_BYTES + (wave * WP + (p - AP)) * 1024);
     };
 
     const int swz = (l15 >> 1) & 7;
@@ -620,6 +622,8 @@ static int32_t gemm_wide_impl(int epi, const _Float16* A, const _Float16* W, con
                               _Float16* Cs, uint32_t M, uint32_t N, uint32_t K, uint32_t* d_flag, hipStream_t s,
                               const float* ln_g, const float* ln_b, float ln_eps, int shape = 0, uint32_t ln_flags = 0) {
     if (!gemm_wide_supported(N, K)) return fail(CS_ERR_UNSUPPORTED, "wide split GEMM needs N %% 192 == 0 and K %% 32 == 0 (N=%u K=%u)", N, K);
+    if ((uint64_t)M * (K / 32) * 128 >= (1ull << 32) || (uint64_t)N * (K / 32) * 128 >= (1ull << 32))  // (32-bit buffer offsets in the kernel)
+        return fail(CS_ERR_UNSUPPORTED, "wide split GEMM: an operand of 4 GiB or more (M=%u N=%u K=%u)", M, N, K);
     if (M == 0) return CS_OK;
     static const int shape_env = [] { const char* e = cs_lab_env("CS_GEMM_WIDE_SHAPE"); return e ? std::atoi(e) : 0; }();
     // default: 128 x 384, except the bias -> split-store layer (the QKV projection), which four boxes measured 3-4 % faster
