@@ -1263,10 +1263,11 @@ q8_stage_major_kernel(const int8_t* __restrict__ w, int8_t* __restrict__ out, ui
 // Here a WAVE owns 16 whole rows: W is the MFMA's first operand, so a lane holds, for each of the 24 column tiles, four
 // CONSECUTIVE columns of ONE row (row l15, columns 16 j + 4 g ..) — 96 accumulators; the four lanes of a row meet by two
 // shuffles for its statistics and the row leaves normalised in 16-byte stores, with the (lo, hi) the next quantisation wants.
-// A block = 8 waves = 128 rows; its activations are loaded (SRC = Q8_SRC_SPLIT: from the split-f16 tensor, quantised on the
-// way in with the tensor's parameters; QR_PREQUANT: the s8 tensor FFN-up left, with its row metadata) ONCE into registers in
-// MFMA operand order — K / 64 x 16 bytes per lane — and W streams through a ring of four 24-KiB stages ([384 n][64 k], one
-// MFMA k-step for all 24 tiles) by LDS-DMA with one barrier per stage.  y, y + residual are the row-block kernel's bits
+// A block = 8 waves = 128 rows; its activations are MFMA operands in registers — K / 64 x 16 bytes per lane (SRC = Q8_SRC_SPLIT:
+// loaded from the split-f16 tensor and quantised on the way in with the tensor's parameters; QR_PREQUANT: the s8 tensor FFN-up
+// left, with its row metadata, loaded stage by stage three stages ahead) — and W streams through a ring of five 24-KiB stages
+// ([384 n][64 k], one MFMA k-step for all 24 tiles) by LDS-DMA with one bare barrier per stage; fragment reads run eight tiles
+// ahead of their MFMAs across those barriers (the loop's notes; profiles/r06_q8_ln_kernel.log).  y, y + residual are the row-block kernel's bits
 // (same operations in the same order); the LayerNorm sums a row in another order than layernorm_kernel (in-lane over 96
 // values, then across four lanes), so its output may differ from the two-kernel path in the last bit.
 // One quantisation unit only (several units: the two-kernel path).  CS_Q8_LN_FUSED=0 restores it.
@@ -1328,9 +1329,9 @@ constexpr int QN_OFF_CM = 0;                           // ws [384] | -zw [384] |
 constexpr int QN_OFF_LN = QN_OFF_CM + 4 * QN_N * 4;    // gamma [384] | beta [384]
 constexpr int QN_OFF_W = QN_OFF_LN + 2 * QN_N * 4;     // 9,216: the ring of weight stages
 // (lng: gamma / beta read from global memory in the last pass instead of from LDS — three stages then fit twice into a CU's 160 KiB)
-constexpr int qn_lds(int nst, bool lng = false) { return (lng ? QN_OFF_LN : QN_OFF_W) + nst * QN_STAGE + 64; }  // 8 waves, 4 stages: 107,584; 4 waves, 3 stages: 79,936; the last 64 B: the waves' (lo, hi)
+constexpr int qn_lds(int nst, bool lng = false) { return (lng ? QN_OFF_LN : QN_OFF_W) + nst * QN_STAGE + 64; }  // 8 waves, 5 stages: 132,160; 4 waves, 3 stages: 79,936; the last 64 B: the waves' (lo, hi)
 
-// NW waves per block (8, the default: 128 rows, ONE block per CU, a ring of NST = 4 stages; 4: 64 rows, TWO blocks per CU with
+// NW waves per block (8, the default: 128 rows, ONE block per CU, a ring of NST = 5 stages; 4: 64 rows, TWO blocks per CU with
 // three stages each — the same eight waves per CU as two independent blocks; measured slower, see launch_gemm_q8_ln)
 template <int SRC, int KS, int NW, int NST>  // KS = K / 64 stages: 6 (K = 384) | 24 (K = 1536)
 __global__ void __launch_bounds__(64 * NW, 2)
@@ -1790,7 +1791,7 @@ int32_t launch_gemm_q8_ln(int src_kind, const void* d_src, const Q8RowMeta* d_rm
     if (src_kind != Q8_SRC_SPLIT && src_kind != QR_PREQUANT) return fail(CS_ERR_BAD_ARG, "LayerNorm-fused quantised product: bad source kind");
     if (src_kind == Q8_SRC_SPLIT && K != 384) return fail(CS_ERR_UNSUPPORTED, "LayerNorm-fused quantised product: quantise-on-load is built for K = 384");
     // CS_Q8_LN_WAVES=4: two blocks of four waves per CU (64 rows, three-stage ring, gamma / beta from global memory) instead of one
-    // block of eight (128 rows, four-stage ring).  Measured twice (profiles/r05_q8_ln_waves_ab.log; with a double buffer, then with
+    // block of eight (128 rows, five-stage ring).  Measured three times (profiles/r05_q8_ln_waves_ab.log; r06_q8_ln_kernel.log (8); with a double buffer, then with
     // three stages): out-proj 88.3 -> 92.5 us, FFN-down 95.0 -> 103.4 — two independent blocks do not overlap what eight waves in
     // step leave exposed.  Diagnostic library only.
 #ifdef CS_DIAGNOSTICS
