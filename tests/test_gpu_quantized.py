@@ -699,6 +699,31 @@ def test_slab_kernels_inside_a_forward(gpu_lib, oracle, tmp_path):
     assert np.load(out).tobytes() == got.tobytes()
 
 
+@pytest.mark.parametrize("B,L", [(256, 16), (264, 16), (320, 40), (512, 64), (1024, 64)])
+def test_layernorm_fused_products_repeat_their_bits(gpu_lib, oracle, B, L):
+    """A race screen for the LayerNorm-fused products (gemm_q8_ln_kernel: weight stages by LDS-DMA behind COUNTED vmcnt waits
+    and bare barriers, fragment reads in flight across them, MI355X guide: "place reads by the vmcnt / barrier count, never
+    by clean runs").  Token-row counts with one 128-row group per block (4,096), a ragged last group (4,224), several
+    groups per block (32,768; 65,536 = two per block on 256 CUs): the same call eight times must leave the same bytes
+    (a stage read before it landed shows as a run that differs), and the first run meets the quantised oracle at the
+    model level's bar."""
+    from codesearch_amd import FastEmbedder, ModelType
+
+    cfg = small_cfg(POOL_MEAN)
+    params, wscale = quantize_linear_weights(cfg, synth_params(cfg, 51), per_channel=False, unsigned=True)
+    ids, mask = synth_token_batch(cfg, 52 + B, B, L, True)
+    emb = FastEmbedder(ModelType.AllMiniLML6V2Q, config=cfg, params=params, wscale=wscale)
+    assert emb.gemm_mode() == "q8"
+    first = emb.embed_ids(ids, mask, batch_size=B)
+    for _ in range(7):
+        assert emb.embed_ids(ids, mask, batch_size=B).tobytes() == first.tobytes()
+    emb.close()
+    if B * L <= 16384:  # (the C oracle's forward is seconds per 10k token rows)
+        want = oracle.bert_forward(cfg, params, ids, mask, wscale=wscale)["pooled"]
+        err = np.abs(first - want)
+        assert err.max() < 3e-3 and np.median(err) < 2e-5, (err.max(), np.median(err))
+
+
 def test_search_results_are_stable_under_quantisation_noise(gpu_lib, oracle):
     """What a USER of the default (quantised) model sees: 20,480 chunks and 64 queries embedded in the
     dynamic-quantisation mode by the GPU and by the quantised oracle (the same 256-row call tensors), each side searched
