@@ -175,7 +175,7 @@ small_forward_kernel(SfArgs a) {
             uint32_t spins = 0;
             while (__hip_atomic_load(a.sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
                 __builtin_amdgcn_s_sleep(2);
-                if (++spins > (1u << 21) || __hip_atomic_load(a.sync + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+                if (++spins > (1u << 16) || __hip_atomic_load(a.sync + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
                     __hip_atomic_store(a.sync + 1, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // give up: every block leaves
                     s_abort = 1;
                     break;
@@ -428,7 +428,9 @@ int32_t launch_small_forward(const SfArgs& a, hipStream_t s) {
         CS_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
         return CS_OK;
     }));
-    // every block must be resident (one per CU: 133 KB of LDS each) or the grid barrier cannot complete
+    // every block must be resident (SF_LDS = 59,408 B each; checked here only as one CU per block — another stream, replica or
+    // process holding CUs can still leave blocks unscheduled: each barrier then gives up after 2^16 polls, ~0.1 s, and the caller
+    // falls back to the launch-per-operator path) or the grid barrier cannot complete
     if (cus < SF_GRID) return fail(CS_ERR_UNSUPPORTED, "the one-launch forward needs %d compute units (device has %d)", SF_GRID, cus);
     hipLaunchKernelGGL(small_forward_kernel<6>, dim3(SF_GRID), dim3(256), SF_LDS, s, a);
     CS_HIP(hipGetLastError());
