@@ -231,6 +231,17 @@ int32_t run_window(cs_embedder* h, const std::vector<SeqView>& seqs, uint32_t ba
         while (b0 + B < wn && B < max_rows && (uint64_t)(B + 1) * seqs[order[b0 + B]].len <= budget) ++B;
         uint32_t L = 1;
         for (uint32_t r = 0; r < B; ++r) L = std::max(L, seqs[order[b0 + r]].len);
+        // (the wide GEMM addresses an operand with 32-bit byte offsets: a mini-batch's largest split-f16 tensor — token rows x
+        // max(intermediate, 3 hidden) x 4 B — stays under 4 GiB; only a CODESEARCH_BATCH_SIZE far above the reference's 256 gets here.
+        // Not for a quantised model's call tensors: they are the reference's units, and their tensors are a quarter the size)
+        if (h->gemm_mode != CS_GEMM_Q8_DYNAMIC) {
+            const uint64_t tok_cap = ((1ull << 32) - 1) / (4ull * std::max<uint64_t>(h->cfg.intermediate, 3ull * h->cfg.hidden));
+            while (B > 1 && (uint64_t)B * L > tok_cap) {
+                --B;
+                L = 1;
+                for (uint32_t r = 0; r < B; ++r) L = std::max(L, seqs[order[b0 + r]].len);
+            }
+        }
         ids.assign((size_t)B * L, pad);
         mask.assign((size_t)B * L, 0);
         for (uint32_t r = 0; r < B; ++r) {
