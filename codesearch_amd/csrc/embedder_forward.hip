@@ -287,6 +287,10 @@ int32_t forward_range(cs_embedder* h, hipStream_t s, uint32_t b0, uint32_t nb, u
 #endif
         _Float16* ctxs2 = ctxs;
         _Float16* mids2 = reinterpret_cast<_Float16*>(mid);
+        // sequences of up to 32 tokens (a query and its variants) of a 384-wide model: attention inside the out-projection's blocks, 50
+        // instead of 62 launches per 12-layer forward.  CS_SMALL_FUSE=0 (read per forward: the tests compare the two): the two launches.
+        const char* e2 = std::getenv("CS_SMALL_FUSE");
+        const bool sp_fused = !(e2 && e2[0] == '0') && sp_attn_proj_supported(H, c.heads, T, L);
         const SplitLayer sl2 = split_layer(c);
         CS_TRY(mark(-1));
         for (uint32_t l = 0; l < c.layers; ++l) {
@@ -301,9 +305,14 @@ int32_t forward_range(cs_embedder* h, hipStream_t s, uint32_t b0, uint32_t nb, u
             g1.Xout = xa; g1.W = ws + sl2.qkv; g1.bias = h->d_bqkv + (size_t)l * 3 * H; g1.Cs = qkvs; g1.T = T; g1.N = 3 * H; g1.flag = h->d_flag;
             CS_TRY(launch_sp_ln_gemm(SH_OUT_SPLIT, l ? 1 : 2, g1, H, s));                                        // (E1 | LN) + E2
             CS_TRY(mark(CS_STAGE_QKV));
-            CS_TRY(launch_attention_sh2(qkvs, mask, ctxs2, h->d_flag, nb, L, H, c.heads, s));                      // E3
-            CS_TRY(mark(CS_STAGE_ATTENTION));
-            CS_TRY(launch_gemm_split(SH_OUT_F32_RESID, ctxs2, ws + sl2.ao, P + lo.ao_b, xa, y, nullptr, T, H, H, h->d_flag, s));  // E4 -> y
+            if (sp_fused) {  // E3 + E4 -> y in one launch: every out-projection block computes its rows' attention itself (small_path.hip)
+                CS_TRY(mark(CS_STAGE_ATTENTION));
+                CS_TRY(launch_sp_attn_proj(qkvs, mask, ws + sl2.ao, P + lo.ao_b, xa, y, T, L, H, c.heads, h->d_flag, s));
+            } else {
+                CS_TRY(launch_attention_sh2(qkvs, mask, ctxs2, h->d_flag, nb, L, H, c.heads, s));                      // E3
+                CS_TRY(mark(CS_STAGE_ATTENTION));
+                CS_TRY(launch_gemm_split(SH_OUT_F32_RESID, ctxs2, ws + sl2.ao, P + lo.ao_b, xa, y, nullptr, T, H, H, h->d_flag, s));  // E4 -> y
+            }
             CS_TRY(mark(CS_STAGE_OUT_PROJ));
             SpLnGemmArgs g4 = g1;
             g4.ln_g = P + lo.ao_ln_g; g4.ln_b = P + lo.ao_ln_b; g4.Xout = x; g4.W = ws + sl2.up; g4.bias = P + lo.up_b; g4.Cs = mids2; g4.N = I;

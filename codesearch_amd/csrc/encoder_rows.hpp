@@ -46,6 +46,15 @@ template <int NPL, int R>
 __device__ __forceinline__ void ln_rows_core(const float (&v)[R][NPL], const float* __restrict__ g, const float* __restrict__ b,
                                              float eps, int lane, float (&o)[R][NPL]) {
     constexpr float invH = 1.0f / (64.0f * NPL);
+    // (gamma / beta requested before the reductions: left in the last loop, where they are used, their memory round trip stood
+    // behind the two shuffle chains of every short kernel that normalises a row as its prologue)
+    float2 gv[NPL / 2], bv[NPL / 2];
+#pragma unroll
+    for (int p = 0; p < NPL / 2; ++p) {
+        gv[p] = *reinterpret_cast<const float2*>(g + ln_col(lane, 2 * p));
+        bv[p] = *reinterpret_cast<const float2*>(b + ln_col(lane, 2 * p));
+    }
+    asm volatile("" : : "v"(gv[0].x), "v"(bv[0].x));  // (keeps the requests up here)
     float s[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
@@ -75,11 +84,8 @@ __device__ __forceinline__ void ln_rows_core(const float (&v)[R][NPL], const flo
         const float inv = 1.0f / sqrtf(var + eps);
 #pragma unroll
         for (int p = 0; p < NPL / 2; ++p) {
-            const int c = ln_col(lane, 2 * p);
-            const float2 gv = *reinterpret_cast<const float2*>(g + c);
-            const float2 bv = *reinterpret_cast<const float2*>(b + c);
-            o[r][2 * p] = (v[r][2 * p] - mean[r]) * inv * gv.x + bv.x;
-            o[r][2 * p + 1] = (v[r][2 * p + 1] - mean[r]) * inv * gv.y + bv.y;
+            o[r][2 * p] = (v[r][2 * p] - mean[r]) * inv * gv[p].x + bv[p].x;
+            o[r][2 * p + 1] = (v[r][2 * p + 1] - mean[r]) * inv * gv[p].y + bv[p].y;
         }
     }
 }

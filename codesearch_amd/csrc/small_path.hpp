@@ -36,4 +36,11 @@ int32_t launch_sp_ln_gemm(int epi, int pro, const SpLnGemmArgs& a, uint32_t H, h
 // parts[ks][T][N] = A[:, K slice ks] W[:, K slice ks]^T for the four quarters of K = 4 H (A [T][K/32][64], W [N][K/32][64])
 int32_t launch_sp_partial(const _Float16* A, const _Float16* W, float* parts, uint32_t T, uint32_t N, uint32_t H, hipStream_t s);
 
+// E3 + E4 in one launch for sequences of up to 32 tokens of a 384-wide, 12-head model (sp_attn_proj_kernel): C [T][384] =
+// attention(qkvs) W^T + bias + resid; qkvs [T][36][64] split form (Q heads | K heads | V heads), mask [T] (row-major [B][L]),
+// W [384][12][64] split form
+bool sp_attn_proj_supported(uint32_t H, uint32_t heads, uint32_t T, uint32_t L);
+int32_t launch_sp_attn_proj(const _Float16* qkvs, const int32_t* mask, const _Float16* W, const float* bias, const float* resid, float* C,
+                            uint32_t T, uint32_t L, uint32_t H, uint32_t heads, uint32_t* flag, hipStream_t s);
+
 }  // namespace cs

@@ -23,9 +23,49 @@ def _one_launch_forward_lives_in_the_diagnostic_library(lab_lib):
     yield
 
 
+@pytest.fixture(scope="module")
+def oracle_lib_fixture():
+    from tests.oracle_lib import load_oracle
+
+    return load_oracle()
+
+
 def _embed(emb, ids, mask, on, monkeypatch):
+    # (the one-launch form repeats the bits of the launch chain with attention as its own launch: CS_SMALL_FUSE=0)
+    monkeypatch.setenv("CS_SMALL_FUSE", "0")
     monkeypatch.setenv("CS_SMALL_FORWARD", "1" if on else "0")
     return emb.embed_ids(ids, mask)
+
+
+@pytest.mark.parametrize("B,L,ragged", [(1, 16, False), (1, 5, False), (2, 16, True), (4, 8, True), (1, 32, False), (1, 1, False),
+                                        (3, 10, True), (2, 7, True), (8, 4, True), (1, 17, False), (9, 16, True), (12, 16, False),
+                                        (6, 11, True), (5, 31, True), (6, 32, False), (17, 11, True), (7, 21, True), (19, 10, True)])
+@pytest.mark.parametrize("pooling", ["cls", "mean"])
+def test_attention_inside_the_out_projection_matches_the_two_launches(monkeypatch, oracle_lib_fixture, B, L, ragged, pooling):
+    """Sequences of up to 32 tokens of a 384-wide, 12-head model run E3 + E4 as ONE launch (sp_attn_proj_kernel: every
+    out-projection block computes its rows' attention itself, 16 x 16 x 32 tiles, another summation order than
+    attention_shx_kernel): within 2e-6 of the two-launch chain (CS_SMALL_FUSE=0) and within 2e-5 of the oracle — rows of
+    several short sequences in one 16-row tile (a key counts only inside the query's sequence), padded keys, tiles whose
+    sequences span 33 and more token rows (6 x 11: the four-tile form), sequences of 17-32 tokens, up to 190 rows."""
+    from codesearch_amd import BertConfig, FastEmbedder, ModelType
+    from codesearch_amd.bert_params import POOL_CLS, POOL_MEAN, synth_token_batch
+
+    oracle = oracle_lib_fixture
+    cfg = BertConfig(vocab_size=2048, layers=4, pooling=POOL_CLS if pooling == "cls" else POOL_MEAN)
+    emb = FastEmbedder(ModelType.BGESmallENV15, config=cfg, seed=312, device=0)
+    ids, mask = synth_token_batch(cfg, 2000 + B * 64 + L, B, L, ragged)
+    monkeypatch.setenv("CS_SMALL_FORWARD", "0")
+    monkeypatch.setenv("CS_SMALL_FUSE", "0")
+    two = emb.embed_ids(ids, mask)
+    monkeypatch.setenv("CS_SMALL_FUSE", "1")
+    one = emb.embed_ids(ids, mask)
+    again = emb.embed_ids(ids, mask)
+    assert one.tobytes() == again.tobytes()
+    assert float(np.abs(one - two).max()) < 2e-6, float(np.abs(one - two).max())
+    exp = oracle.bert_forward(cfg, oracle.bert_synth_params(cfg, 312), ids, mask)["pooled"]
+    assert float(np.abs(one - exp).max()) < 2e-5
+    assert emb.debug_counters()[2] == 0
+    emb.close()
 
 
 @pytest.mark.parametrize("B,L,ragged", [(1, 16, False), (1, 5, False), (9, 16, True), (3, 33, True), (2, 64, False),
