@@ -360,27 +360,51 @@ int32_t forward_range(cs_embedder* h, hipStream_t s, uint32_t b0, uint32_t nb, u
             if (!rs && T <= q8_skinny_max_m() && I <= 3072 && (uint64_t)(I / 16) * ((T + 15) / 16) <= h->cap_range_pairs2) {
                 // a few token rows (queries): one launch per Linear — range reduction and quantisation inside the product
                 float* rp2 = rp + 2 * h->cap_range_pairs;
-                CS_TRY(launch_gemm_q8_skinny(SH_OUT_SPLIT, Q8_SRC_F32, x, rp, ln_pairs, wq + ql.qkv, cm, nullptr, nullptr, qkvs, T, 3 * H, H, h->d_flag,
-                                             nullptr, nullptr, s));  // E2
+                // Up to 16 rows of a 384-wide model (one short query): the two LayerNorms of a layer are the prologues of the products
+                // that read them (Q8_SRC_LN: the block's 16 rows are the whole tensor, so it knows the range) — five launches per layer
+                // instead of seven.  The products behind attention and GELU then write the PRE-norm rows to ybuf and add the
+                // normalised ones (x, written by the prologue's column-tile-0 blocks) as their residual.  Same arithmetic, same bits.
+                // CS_Q8_SKINNY_LN=0 (read per forward: the tests compare the two): the LayerNorm launches.
+                const char* e3 = std::getenv("CS_Q8_SKINNY_LN");
+                const bool fold = !(e3 && e3[0] == '0') && T <= 16 && H == 384;
+                float* ybuf = h->d_xs + t0 * H;              // [T][H] f32 (the split copy of x is not used on this path)
+                const bool last = l + 1 == c.layers;
+                if (fold && l) {
+                    cs_bert_layer_offsets lp;
+                    cs_bert_layer_layout(&c, &h->off, l - 1, &lp);
+                    CS_TRY(launch_gemm_q8_skinny_ln(SH_OUT_SPLIT, ybuf, P + lp.out_ln_g, P + lp.out_ln_b, c.layer_norm_eps, x, wq + ql.qkv, cm, qkvs, T, 3 * H,
+                                                    h->d_flag, nullptr, nullptr, s));  // LN (layer l - 1's second) + E2
+                } else {
+                    CS_TRY(launch_gemm_q8_skinny(SH_OUT_SPLIT, Q8_SRC_F32, x, rp, ln_pairs, wq + ql.qkv, cm, nullptr, nullptr, qkvs, T, 3 * H, H, h->d_flag,
+                                                 nullptr, nullptr, s));  // E2
+                }
                 CS_TRY(mark(CS_STAGE_QKV));
                 uint32_t att_pairs = 0, up_pairs = 0;
                 CS_TRY(launch_attention_sh2(qkvs, mask, ctxs, h->d_flag, nb, L, H, c.heads, s, rp, &att_pairs));  // E3
                 CS_TRY(mark(CS_STAGE_ATTENTION));
                 if (!att_pairs) return fail(CS_ERR_UNSUPPORTED, "attention kernel without range pairs in the few-rows quantised path");
-                CS_TRY(launch_gemm_q8_skinny(SH_OUT_F32_RESID, Q8_SRC_SPLIT, ctxs, rp, att_pairs, wq + ql.ao, cm + 3 * H, x, x, nullptr, T, H, H,
+                CS_TRY(launch_gemm_q8_skinny(SH_OUT_F32_RESID, Q8_SRC_SPLIT, ctxs, rp, att_pairs, wq + ql.ao, cm + 3 * H, x, fold ? ybuf : x, nullptr, T, H, H,
                                              h->d_flag, nullptr, nullptr, s));  // E4
                 CS_TRY(mark(CS_STAGE_OUT_PROJ));
-                a.g = P + lo.ao_ln_g; a.b = P + lo.ao_ln_b;
-                CS_TRY(launch_row_kernel(1, a, H, s));
-                CS_TRY(mark(CS_STAGE_LN_ATTN));
-                CS_TRY(launch_gemm_q8_skinny(SH_OUT_SPLIT_GELU, Q8_SRC_F32, x, rp, ln_pairs, wq + ql.up, cm + 4 * H, nullptr, nullptr, mids, T, I, H,
-                                             h->d_flag, rp2, &up_pairs, s));  // E5
+                if (fold) {
+                    CS_TRY(mark(CS_STAGE_LN_ATTN));
+                    CS_TRY(launch_gemm_q8_skinny_ln(SH_OUT_SPLIT_GELU, ybuf, P + lo.ao_ln_g, P + lo.ao_ln_b, c.layer_norm_eps, x, wq + ql.up, cm + 4 * H, mids, T, I,
+                                                    h->d_flag, rp2, &up_pairs, s));  // LN + E5
+                } else {
+                    a.g = P + lo.ao_ln_g; a.b = P + lo.ao_ln_b;
+                    CS_TRY(launch_row_kernel(1, a, H, s));
+                    CS_TRY(mark(CS_STAGE_LN_ATTN));
+                    CS_TRY(launch_gemm_q8_skinny(SH_OUT_SPLIT_GELU, Q8_SRC_F32, x, rp, ln_pairs, wq + ql.up, cm + 4 * H, nullptr, nullptr, mids, T, I, H,
+                                                 h->d_flag, rp2, &up_pairs, s));  // E5
+                }
                 CS_TRY(mark(CS_STAGE_FFN_UP));
-                CS_TRY(launch_gemm_q8_skinny(SH_OUT_F32_RESID, Q8_SRC_SPLIT, mids, rp2, up_pairs, wq + ql.down, cm + 4 * H + I, x, x, nullptr, T, H, I,
-                                             h->d_flag, nullptr, nullptr, s));  // E6
+                CS_TRY(launch_gemm_q8_skinny(SH_OUT_F32_RESID, Q8_SRC_SPLIT, mids, rp2, up_pairs, wq + ql.down, cm + 4 * H + I, x, fold && !last ? ybuf : x, nullptr,
+                                             T, H, I, h->d_flag, nullptr, nullptr, s));  // E6
                 CS_TRY(mark(CS_STAGE_FFN_DOWN));
-                a.g = P + lo.out_ln_g; a.b = P + lo.out_ln_b;
-                CS_TRY(launch_row_kernel(1, a, H, s));
+                if (!fold || last) {  // (folded: the next layer's first product normalises ybuf)
+                    a.g = P + lo.out_ln_g; a.b = P + lo.out_ln_b;
+                    CS_TRY(launch_row_kernel(1, a, H, s));
+                }
                 CS_TRY(mark(CS_STAGE_LN_FFN));
                 if (l + 1 == c.layers) h->last_hidden_partial = false;
                 continue;

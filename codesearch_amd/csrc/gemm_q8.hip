@@ -19,6 +19,7 @@
 #include <utility>
 
 #include "encoder.hpp"
+#include "encoder_rows.hpp"
 #include "gemm_epilogue.hpp"
 #include "gemm_q8.hpp"
 #include "gemm_q8_dev.hpp"
@@ -554,7 +555,8 @@ __global__ void __launch_bounds__(256)
 gemm_q8_skinny_kernel(const void* __restrict__ src, const float* __restrict__ range_pairs, uint32_t n_pairs,
                       const int8_t* __restrict__ W, const Q8ColMeta* __restrict__ cmeta, const float* resid, float* C,
                       _Float16* __restrict__ Cs, uint32_t M, uint32_t N, uint32_t K, uint32_t* __restrict__ flag,
-                      float* __restrict__ range_out) {
+                      float* __restrict__ range_out, const float* __restrict__ ln_g = nullptr, const float* __restrict__ ln_b = nullptr,
+                      float ln_eps = 0.0f, float* __restrict__ ln_xout = nullptr) {
     extern __shared__ __attribute__((aligned(16))) char lds[];  // [16][K + 16] s8: the block's quantised rows
     __shared__ float s_lo[4], s_hi[4];
     __shared__ int s_rowsum[16];
@@ -575,12 +577,77 @@ gemm_q8_skinny_kernel(const void* __restrict__ src, const float* __restrict__ ra
         const uint32_t i = (uint32_t)u < mine ? u : (mine ? mine - 1 : 0);
         wf[u] = mine ? *reinterpret_cast<const q8_i32x4*>(wp + (size_t)(wave + 4 * i) * 64) : q8_i32x4{0, 0, 0, 0};
     }
+    // the epilogue's operands and the block's raw activation rows are requested NOW, with the weights and the pairs: the range, the
+    // quantising pass and the epilogue used to wait for memory one after the other (three round trips per launch, ~1.5 us each, in a
+    // path that is seven dependent launches per layer)
+    const int em = tid >> 4, en = tid & 15;
+    const uint32_t erow = m0 + em, ecol = n0 + en;
+    const Q8ColMeta cm = cmeta[ecol];
+    float e_resid = 0.0f;
+    if (EPI == SH_OUT_F32_RESID) e_resid = resid[(size_t)(erow < M ? erow : M - 1) * N + ecol];
+    // 16 rows x K / 16 slots of 16 k; slot sidx = tid + 256 s (s < 6: K <= 1536; beyond, the loop below reads the rest as before)
+    const uint32_t spr = K / 16, nslots = 16 * spr;
+    constexpr int PS = SRC == Q8_SRC_LN ? 1 : 6;
+    sh_f32x4 raw[PS][4];   // Q8_SRC_F32: 16 floats | split source: (hi 0-7, hi 8-15, lo 0-7, lo 8-15) as 4 x 16 bytes
+    // Q8_SRC_LN (K = 384, M <= 16: the block's rows are the whole tensor): the rows are normalised here — a wave takes four of them,
+    // layernorm_kernel's arithmetic (ln_rows_core) — their range is the tensor's, the blocks of column tile 0 write them to ln_xout
+    float lnv[4][6];
+    if constexpr (SRC == Q8_SRC_LN) {
+        float v[4][6];
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const uint32_t t_raw = m0 + 4 * wave + rr, t = t_raw < M ? t_raw : M - 1;
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                const float2 r2 = *reinterpret_cast<const float2*>(reinterpret_cast<const float*>(src) + (size_t)t * 384 + ln_col(lane, 2 * p));
+                v[rr][2 * p] = r2.x;
+                v[rr][2 * p + 1] = r2.y;
+            }
+        }
+        ln_rows_core<6, 4>(v, ln_g, ln_b, ln_eps, lane, lnv);
+    }
+#pragma unroll
+    for (int ps = 0; ps < (SRC == Q8_SRC_LN ? 0 : PS); ++ps) {
+        const uint32_t sidx = tid + 256 * ps;
+        if (sidx < nslots) {
+            const uint32_t row = sidx / spr, sl = sidx - row * spr;
+            const uint32_t m = (m0 + row < M) ? m0 + row : M - 1;  // rows past M repeat the last one: never stored
+            if (SRC == Q8_SRC_F32) {
+                const sh_f32x4* p = reinterpret_cast<const sh_f32x4*>(reinterpret_cast<const float*>(src) + (size_t)m * K + sl * 16);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) raw[ps][q] = p[q];
+            } else {  // 16 k = half a 32-k line: 16 hi halves, their 16 lo halves 64 B further on
+                const _Float16* p = reinterpret_cast<const _Float16*>(src) + ((size_t)m * (K / 32) + (sl >> 1)) * 64 + (sl & 1) * 16;
+                raw[ps][0] = *reinterpret_cast<const sh_f32x4*>(p);
+                raw[ps][1] = *reinterpret_cast<const sh_f32x4*>(p + 8);
+                raw[ps][2] = *reinterpret_cast<const sh_f32x4*>(p + 32);
+                raw[ps][3] = *reinterpret_cast<const sh_f32x4*>(p + 40);
+            }
+        }
+    }
     // the tensor's range from its producer's pairs
     float lo = 0.0f, hi = 0.0f;
-    for (uint32_t i = tid; i < n_pairs; i += 256) {
-        const float2 p = reinterpret_cast<const float2*>(range_pairs)[i];
-        lo = fminf(lo, p.x);
-        hi = fmaxf(hi, p.y);
+    if constexpr (SRC == Q8_SRC_LN) {
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const uint32_t t = m0 + 4 * wave + rr;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {  // (rows past M are copies of row M - 1: they widen nothing)
+                lo = fminf(lo, lnv[rr][i]);
+                hi = fmaxf(hi, lnv[rr][i]);
+            }
+            if (blockIdx.x == 0 && t < M) {
+#pragma unroll
+                for (int p = 0; p < 3; ++p)
+                    *reinterpret_cast<float2*>(ln_xout + (size_t)t * 384 + ln_col(lane, 2 * p)) = make_float2(lnv[rr][2 * p], lnv[rr][2 * p + 1]);
+            }
+        }
+    } else {
+        for (uint32_t i = tid; i < n_pairs; i += 256) {
+            const float2 p = reinterpret_cast<const float2*>(range_pairs)[i];
+            lo = fminf(lo, p.x);
+            hi = fmaxf(hi, p.y);
+        }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -593,26 +660,19 @@ gemm_q8_skinny_kernel(const void* __restrict__ src, const float* __restrict__ ra
     float xs, xz;
     q8_params_of(fminf(fminf(s_lo[0], s_lo[1]), fminf(s_lo[2], s_lo[3])), fmaxf(fmaxf(s_hi[0], s_hi[1]), fmaxf(s_hi[2], s_hi[3])), xs, xz);
     const int za = (int)xz - 128;
-    // 16 rows x K / 16 slots of 16 k
-    const uint32_t spr = K / 16;
-    for (uint32_t sidx = tid; sidx < 16 * spr; sidx += 256) {
+    auto quantise_slot = [&](uint32_t sidx, const sh_f32x4 (&r4)[4]) {
         const uint32_t row = sidx / spr, sl = sidx - row * spr;
-        const uint32_t m = (m0 + row < M) ? m0 + row : M - 1;  // rows past M repeat the last one: never stored
         float v[16];
         if (SRC == Q8_SRC_F32) {
-            const sh_f32x4* p = reinterpret_cast<const sh_f32x4*>(reinterpret_cast<const float*>(src) + (size_t)m * K + sl * 16);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const sh_f32x4 t = p[q];
+            for (int q = 0; q < 4; ++q)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[4 * q + e] = t[e];
-            }
-        } else {  // 16 k = half a 32-k line: 16 hi halves, their 16 lo halves 64 B further on
-            const _Float16* p = reinterpret_cast<const _Float16*>(src) + ((size_t)m * (K / 32) + (sl >> 1)) * 64 + (sl & 1) * 16;
+                for (int e = 0; e < 4; ++e) v[4 * q + e] = r4[q][e];
+        } else {
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
-                const f16x8 h = *reinterpret_cast<const f16x8*>(p + 8 * q);
-                const f16x8 l = *reinterpret_cast<const f16x8*>(p + 32 + 8 * q);
+                const f16x8 h = __builtin_bit_cast(f16x8, r4[q]);
+                const f16x8 l = __builtin_bit_cast(f16x8, r4[2 + q]);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[8 * q + e] = (float)h[e] + (float)l[e] * kShLoInv;
             }
@@ -633,6 +693,48 @@ gemm_q8_skinny_kernel(const void* __restrict__ src, const float* __restrict__ ra
         }
         *reinterpret_cast<q8_i32x4*>(lds + row * astride + sl * 16) = packed;
         atomicAdd(&s_rowsum[row], sum);
+    };
+    if constexpr (SRC == Q8_SRC_LN) {  // the normalised rows from registers: columns 2 lane + 128 p + {0, 1} of row 4 wave + rr
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int row = 4 * wave + rr;
+            int sum = 0;
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                uint32_t pw = 0;
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const float q = fminf(fmaxf(__fadd_rn(rintf(__fdiv_rn(lnv[rr][2 * p + e], xs)), xz), 0.0f), 255.0f);
+                    const int a = (int)q - 128;
+                    sum += a;
+                    pw |= (uint32_t)(a & 0xff) << (8 * e);
+                }
+                *reinterpret_cast<uint16_t*>(lds + row * astride + ln_col(lane, 2 * p)) = (uint16_t)pw;
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+            if (lane == 0) s_rowsum[row] = sum;
+        }
+    }
+#pragma unroll
+    for (int ps = 0; ps < (SRC == Q8_SRC_LN ? 0 : PS); ++ps)
+        if (tid + 256 * ps < nslots) quantise_slot(tid + 256 * ps, raw[ps]);
+    for (uint32_t sidx = tid + 256 * PS; SRC != Q8_SRC_LN && sidx < nslots; sidx += 256) {  // (K > 1536)
+        const uint32_t row = sidx / spr, sl = sidx - row * spr;
+        const uint32_t m = (m0 + row < M) ? m0 + row : M - 1;
+        sh_f32x4 r4[4];
+        if (SRC == Q8_SRC_F32) {
+            const sh_f32x4* p = reinterpret_cast<const sh_f32x4*>(reinterpret_cast<const float*>(src) + (size_t)m * K + sl * 16);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) r4[q] = p[q];
+        } else {
+            const _Float16* p = reinterpret_cast<const _Float16*>(src) + ((size_t)m * (K / 32) + (sl >> 1)) * 64 + (sl & 1) * 16;
+            r4[0] = *reinterpret_cast<const sh_f32x4*>(p);
+            r4[1] = *reinterpret_cast<const sh_f32x4*>(p + 8);
+            r4[2] = *reinterpret_cast<const sh_f32x4*>(p + 32);
+            r4[3] = *reinterpret_cast<const sh_f32x4*>(p + 40);
+        }
+        quantise_slot(sidx, r4);
     }
     __syncthreads();
     q8_i32x4 acc = {0, 0, 0, 0};
@@ -656,9 +758,8 @@ gemm_q8_skinny_kernel(const void* __restrict__ src, const float* __restrict__ ra
 #pragma unroll
     for (int r = 0; r < 4; ++r) red[wave][4 * g + r][l15] = acc[r];
     __syncthreads();
-    const int m = tid >> 4, n = tid & 15;
-    const uint32_t row = m0 + m, col = n0 + n;
-    const Q8ColMeta cm = cmeta[col];
+    const int m = em, n = en;
+    const uint32_t row = erow, col = ecol;
     const int total = (red[0][m][n] + red[1][m][n]) + (red[2][m][n] + red[3][m][n]);
     const int corr = total - __mul24(cm.zw, s_rowsum[m] - (int)K * za) - __mul24(za, cm.colsum);
     float v = __fadd_rn(__fmul_rn((float)corr, __fmul_rn(xs, cm.ws)), cm.bias);
@@ -666,7 +767,7 @@ gemm_q8_skinny_kernel(const void* __restrict__ src, const float* __restrict__ ra
     bool ovf = false;
     if (EPI == SH_OUT_F32 || EPI == SH_OUT_F32_RESID) {
         if (row < M) {
-            if (EPI == SH_OUT_F32_RESID) v += resid[(size_t)row * N + col];
+            if (EPI == SH_OUT_F32_RESID) v += e_resid;
             C[(size_t)row * N + col] = v;
         }
     } else {
@@ -1942,6 +2043,28 @@ int32_t launch_gemm_q8_skinny(int epi, int src_kind, const void* d_src, const fl
 #undef CS_Q8S
     CS_HIP(hipGetLastError());
     if (out_pairs && d_range_out) *out_pairs = grid.x * grid.y;
+    return CS_OK;
+}
+
+int32_t launch_gemm_q8_skinny_ln(int epi, const float* d_y, const float* ln_g, const float* ln_b, float eps, float* d_xout,
+                                 const int8_t* d_wq, const Q8ColMeta* d_cmeta, _Float16* Cs, uint32_t M, uint32_t N, uint32_t* d_flag,
+                                 float* d_range_out, uint32_t* out_pairs, hipStream_t s) {
+    if (out_pairs) *out_pairs = 0;
+    if (M == 0) return CS_OK;
+    if (M > 16 || N % 32 || !d_xout || d_xout == d_y)
+        return fail(CS_ERR_UNSUPPORTED, "few-rows quantised product with a LayerNorm prologue: %u rows (<= 16), N = %u", M, N);
+    const dim3 grid(N / 16, 1);
+    const size_t lds = (size_t)16 * (384 + 16);
+    const float* none = nullptr;
+    if (epi == SH_OUT_SPLIT)
+        hipLaunchKernelGGL((gemm_q8_skinny_kernel<SH_OUT_SPLIT, Q8_SRC_LN>), grid, dim3(256), lds, s, d_y, none, 0u, d_wq, d_cmeta, none, nullptr, Cs, M, N,
+                           384u, d_flag, d_range_out, ln_g, ln_b, eps, d_xout);
+    else if (epi == SH_OUT_SPLIT_GELU)
+        hipLaunchKernelGGL((gemm_q8_skinny_kernel<SH_OUT_SPLIT_GELU, Q8_SRC_LN>), grid, dim3(256), lds, s, d_y, none, 0u, d_wq, d_cmeta, none, nullptr, Cs, M,
+                           N, 384u, d_flag, d_range_out, ln_g, ln_b, eps, d_xout);
+    else return fail(CS_ERR_UNSUPPORTED, "few-rows quantised product with a LayerNorm prologue: epilogue %d is not built", epi);
+    CS_HIP(hipGetLastError());
+    if (out_pairs && d_range_out) *out_pairs = grid.x;
     return CS_OK;
 }
 

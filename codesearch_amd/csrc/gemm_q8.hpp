@@ -11,7 +11,7 @@ namespace cs {
 struct Q8RowMeta { float xs; int32_t za; int32_t rowsum; uint32_t pad; };
 struct Q8ColMeta { float ws; int32_t zw; int32_t colsum; float bias; };  // bias: the layer's bias for this column (may be 0)
 
-enum { Q8_SRC_F32 = 0, Q8_SRC_SPLIT = 1 };
+enum { Q8_SRC_F32 = 0, Q8_SRC_SPLIT = 1, Q8_SRC_LN = 2 };  // (Q8_SRC_LN: launch_gemm_q8_skinny_ln only)
 
 // A quantisation unit's range slot: words 0, 1 = the bits of (lo, hi); 2..4 = scratch of the FFN-up range pass (gemm_q8.hip);
 // all zero before the unit's first kernel of a forward.
@@ -109,6 +109,13 @@ uint32_t q8_skinny_max_m();
 int32_t launch_gemm_q8_skinny(int epi, int src_kind, const void* d_src, const float* d_range_pairs, uint32_t n_pairs,
                               const int8_t* d_wq, const Q8ColMeta* d_cmeta, const float* resid, float* C, _Float16* Cs, uint32_t M,
                               uint32_t N, uint32_t K, uint32_t* d_flag, float* d_range_out, uint32_t* out_pairs, hipStream_t s);
+
+// The same for up to 16 token rows of a 384-wide tensor that still wants its LayerNorm: d_y [M][384] f32 is normalised by every
+// block itself (the block's 16 rows ARE the tensor: its range is theirs), quantised and multiplied; the blocks of column tile 0
+// write the normalised rows to d_xout (the residual the next product adds; never d_y).  epi: SH_OUT_SPLIT | SH_OUT_SPLIT_GELU.
+int32_t launch_gemm_q8_skinny_ln(int epi, const float* d_y, const float* ln_g, const float* ln_b, float eps, float* d_xout,
+                                 const int8_t* d_wq, const Q8ColMeta* d_cmeta, _Float16* Cs, uint32_t M, uint32_t N, uint32_t* d_flag,
+                                 float* d_range_out, uint32_t* out_pairs, hipStream_t s);
 
 // FFN-up of a quantised model in two passes over the same product: GELU(x W^T + b) re-quantised for FFN-down without the
 // f32-class tensor ever reaching HBM.  d_range_out (one slot, zero before the call) collects the output tensor's range;

@@ -699,6 +699,33 @@ def test_slab_kernels_inside_a_forward(gpu_lib, oracle, tmp_path):
     assert np.load(out).tobytes() == got.tobytes()
 
 
+@pytest.mark.parametrize("B,L,ragged", [(1, 16, False), (1, 5, False), (2, 8, True), (1, 1, False), (3, 5, True), (1, 12, False)])
+@pytest.mark.parametrize("pooling", [POOL_MEAN, POOL_CLS])
+def test_one_short_query_folds_its_layernorms_into_the_products(gpu_lib, oracle, monkeypatch, B, L, ragged, pooling):
+    """Up to 16 token rows of a 384-wide quantised model (one short query — `codesearch search` on the reference's default
+    model): the two LayerNorms of a layer run as the prologues of the products that read them (Q8_SRC_LN: the block's 16
+    rows are the whole call tensor, so it knows its range), five launches per layer instead of seven.  The same arithmetic
+    (layernorm_kernel's), so the SAME BITS as the chain with LayerNorm launches (CS_Q8_SKINNY_LN=0), and the quantised
+    oracle's embedding at the model level's bar."""
+    from codesearch_amd import FastEmbedder, ModelType
+
+    cfg = small_cfg(pooling, layers=3)
+    params, wscale = quantize_linear_weights(cfg, synth_params(cfg, 61), per_channel=False, unsigned=True)
+    ids, mask = synth_token_batch(cfg, 62 + B * 8 + L, B, L, ragged)
+    emb = FastEmbedder(ModelType.AllMiniLML6V2Q, config=cfg, params=params, wscale=wscale)
+    assert emb.gemm_mode() == "q8"
+    monkeypatch.setenv("CS_Q8_SKINNY_LN", "0")
+    chain = emb.embed_ids(ids, mask, batch_size=B)
+    monkeypatch.setenv("CS_Q8_SKINNY_LN", "1")
+    folded = emb.embed_ids(ids, mask, batch_size=B)
+    assert folded.tobytes() == chain.tobytes(), float(np.abs(folded - chain).max())
+    assert emb.embed_ids(ids, mask, batch_size=B).tobytes() == folded.tobytes()
+    emb.close()
+    want = oracle.bert_forward(cfg, params, ids, mask, wscale=wscale)["pooled"]
+    err = np.abs(folded - want)
+    assert err.max() < 3e-3, (err.max(), np.median(err))
+
+
 @pytest.mark.parametrize("B,L", [(256, 16), (264, 16), (320, 40), (512, 64), (1024, 64)])
 def test_layernorm_fused_products_repeat_their_bits(gpu_lib, oracle, B, L):
     """A race screen for the LayerNorm-fused products (gemm_q8_ln_kernel: weight stages by LDS-DMA behind COUNTED vmcnt waits
