@@ -87,6 +87,19 @@ gemm_sh_skinny_kernel(const _Float16* __restrict__ A, const _Float16* __restrict
     for (int i = 0; i < RT; ++i)
 #pragma unroll
         for (int j = 0; j < CT; ++j) { hh[i][j] = sh_f32x4v{0.f, 0.f, 0.f, 0.f}; xx[i][j] = sh_f32x4v{0.f, 0.f, 0.f, 0.f}; }
+    // the epilogue's operands — bias and residual of this thread's output elements — are requested with the tile's operands: read
+    // behind the partial tiles' meeting they were a second memory round trip in a kernel that lives for one or two
+    const int em = tid >> 4, en = tid & 15;
+    float e_bias[CT], e_res[RT][CT];
+#pragma unroll
+    for (int j = 0; j < CT; ++j) e_bias[j] = bias[n0 + 16 * j + en];
+#pragma unroll
+    for (int i = 0; i < RT; ++i)
+#pragma unroll
+        for (int j = 0; j < CT; ++j) {
+            const uint32_t row = m0 + 16 * i + em;
+            e_res[i][j] = EPI == SH_OUT_F32_RESID ? resid[(size_t)(row < M ? row : M - 1) * N + n0 + 16 * j + en] : 0.0f;
+        }
     // groups of U of this wave's chunks: every 16-B load of a group in flight before its MFMAs.  With one
     // tile per block K = 384 is one group of 3 chunks per wave and K = 1536 one group of 12: one memory
     // latency per GEMM.
@@ -135,7 +148,7 @@ gemm_sh_skinny_kernel(const _Float16* __restrict__ A, const _Float16* __restrict
 #pragma unroll
             for (int r = 0; r < 4; ++r) red[wave][i][j][4 * g + r][l15] = fmaf(xx[i][j][r], kShLoInv, hh[i][j][r]);
     __syncthreads();
-    const int m = tid >> 4, n = tid & 15;
+    const int m = em, n = en;
     bool ovf = false;
 #pragma unroll
     for (int i = 0; i < RT; ++i) {
@@ -144,9 +157,9 @@ gemm_sh_skinny_kernel(const _Float16* __restrict__ A, const _Float16* __restrict
 #pragma unroll
         for (int j = 0; j < CT; ++j) {
             const uint32_t col = n0 + 16 * j + n;
-            float v = (red[0][i][j][m][n] + red[1][i][j][m][n]) + (red[2][i][j][m][n] + red[3][i][j][m][n]) + bias[col];
+            float v = (red[0][i][j][m][n] + red[1][i][j][m][n]) + (red[2][i][j][m][n] + red[3][i][j][m][n]) + e_bias[j];
             if (EPI == SH_OUT_F32 || EPI == SH_OUT_F32_RESID) {
-                if (EPI == SH_OUT_F32_RESID) v += resid[(size_t)row * N + col];
+                if (EPI == SH_OUT_F32_RESID) v += e_res[i][j];
                 C[(size_t)row * N + col] = v;
             } else {
                 if (EPI == SH_OUT_SPLIT_GELU) v = sh_gelu_erf(v);
