@@ -168,6 +168,9 @@ static int32_t create_impl(const cs_bert_config* cfg, const float* params, uint6
             hipMalloc(&h->d_flag, sizeof(uint32_t)) != hipSuccess)
             return cleanup(fail(CS_ERR_OOM, "hipMalloc(split weights) failed"));
         if (hipMemsetAsync(h->d_flag, 0, sizeof(uint32_t), h->stream) != hipSuccess) s = fail(CS_ERR_HIP, "memset failed");
+        // (a query's transfers from / to pageable memory are staged by the runtime, each a wait of its own: a few pinned KiB instead;
+        // without them the pageable path below is taken)
+        if (hipHostMalloc(reinterpret_cast<void**>(&h->h_pin), 128 << 10, hipHostMallocDefault) != hipSuccess) { h->h_pin = nullptr; (void)hipGetLastError(); }
         float* d_updown = nullptr;  // CS_ARCH_NOMIC: one layer's fc11 / fc12 rows interleaved in groups of 16, [2I][H]
         if (cs_arch_gated(cfg->arch) && hipMalloc(&d_updown, 2 * I * H * sizeof(float)) != hipSuccess)
             return cleanup(fail(CS_ERR_OOM, "hipMalloc(split weights) failed"));
@@ -345,6 +348,7 @@ void cs_embedder_destroy(cs_embedder* h) {
     if (h->d_zero_row) (void)hipFree(h->d_zero_row);
     if (h->d_wsplit) (void)hipFree(h->d_wsplit);
     if (h->d_flag) (void)hipFree(h->d_flag);
+    if (h->h_pin) (void)hipHostFree(h->h_pin);
     if (h->d_sf_layers) (void)hipFree(h->d_sf_layers);
     if (h->d_sf_sync) (void)hipFree(h->d_sf_sync);
     if (h->d_sf_dbg) (void)hipFree(h->d_sf_dbg);

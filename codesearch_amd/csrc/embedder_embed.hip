@@ -55,9 +55,24 @@ int32_t embed_impl(cs_embedder* h, const int32_t* ids, const int32_t* mask, uint
             if (bi[i] < 0 || (uint32_t)bi[i] >= h->cfg.vocab_size)
                 return fail(CS_ERR_BAD_ARG, "Failed to generate embeddings: token id %d outside vocabulary of %u",
                             bi[i], h->cfg.vocab_size);
-        CS_HIP(hipMemcpyAsync(h->d_ids, bi, tok * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
-        CS_HIP(hipMemcpyAsync(h->d_mask, mask + done * seq_len, tok * sizeof(int32_t),
-                              hipMemcpyHostToDevice, h->stream));
+        // a small mini-batch (a query and its variants) goes through 128 KiB of pinned memory: ids | mask in, the range flag and the
+        // rows out behind ONE wait — from pageable memory every transfer is staged by the runtime and waits on its own
+        constexpr size_t kPinHalf = 64 << 10;
+        const bool pin_in = h->h_pin && tok * 2 * sizeof(int32_t) <= kPinHalf;
+        if (pin_in) {  // (the stream is idle: the previous mini-batch ended with a wait)
+            std::memcpy(h->h_pin, bi, tok * sizeof(int32_t));
+            std::memcpy(h->h_pin + tok * sizeof(int32_t), mask + done * seq_len, tok * sizeof(int32_t));
+            CS_HIP(hipMemcpyAsync(h->d_ids, h->h_pin, tok * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+            CS_HIP(hipMemcpyAsync(h->d_mask, h->h_pin + tok * sizeof(int32_t), tok * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+        } else {
+            CS_HIP(hipMemcpyAsync(h->d_ids, bi, tok * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+            CS_HIP(hipMemcpyAsync(h->d_mask, mask + done * seq_len, tok * sizeof(int32_t),
+                                  hipMemcpyHostToDevice, h->stream));
+        }
+        const bool pin_out = h->h_pin && !perm && !out_on_device && (size_t)B * H * sizeof(float) + 64 <= kPinHalf;
+        uint32_t* pin_flag = reinterpret_cast<uint32_t*>(h->h_pin + kPinHalf);
+        float* pin_rows = reinterpret_cast<float*>(h->h_pin + kPinHalf + 64);
+        bool fetched = false;  // the rows are in pin_rows already
         int mode = h->gemm_mode;
         h->cur_units = 1;
         // results wanted in device memory in input order: the pooling kernel stores them there itself (E8 in place when `out`
@@ -72,8 +87,16 @@ int32_t embed_impl(cs_embedder* h, const int32_t* ids, const int32_t* mask, uint
         CS_TRY(forward(h, B, seq_len, mode));
         if (mode == CS_GEMM_Q8_DYNAMIC) {
             uint32_t flag = 0;
-            CS_HIP(hipMemcpyAsync(&flag, h->d_flag, sizeof(flag), hipMemcpyDeviceToHost, h->stream));
-            CS_HIP(hipStreamSynchronize(h->stream));
+            if (pin_out) {
+                CS_HIP(hipMemcpyAsync(pin_flag, h->d_flag, sizeof(flag), hipMemcpyDeviceToHost, h->stream));
+                CS_HIP(hipMemcpyAsync(pin_rows, h->d_pooled, (size_t)B * H * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+                CS_HIP(hipStreamSynchronize(h->stream));
+                flag = *pin_flag;
+                fetched = !flag;
+            } else {
+                CS_HIP(hipMemcpyAsync(&flag, h->d_flag, sizeof(flag), hipMemcpyDeviceToHost, h->stream));
+                CS_HIP(hipStreamSynchronize(h->stream));
+            }
             h->q8_forwards += 1;
             if (flag) {
                 // Q / K / V, an attention output or a GELU output beyond 65504 does not fit the split-f16 hand-over.  onnxruntime has
@@ -87,7 +110,16 @@ int32_t embed_impl(cs_embedder* h, const int32_t* ids, const int32_t* mask, uint
             }
         } else if (mode == CS_GEMM_SPLIT_F16) {
             uint32_t flag = 0;
-            CS_HIP(hipMemcpyAsync(&flag, h->d_flag, sizeof(flag), hipMemcpyDeviceToHost, h->stream));
+            bool pinned_here = pin_out;
+#ifdef CS_DIAGNOSTICS
+            if (h->sf_ran) pinned_here = false;  // (the one-launch forward's own hand-shake below)
+#endif
+            if (pinned_here) {
+                CS_HIP(hipMemcpyAsync(pin_flag, h->d_flag, sizeof(flag), hipMemcpyDeviceToHost, h->stream));
+                CS_HIP(hipMemcpyAsync(pin_rows, h->d_pooled, (size_t)B * H * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+            } else {
+                CS_HIP(hipMemcpyAsync(&flag, h->d_flag, sizeof(flag), hipMemcpyDeviceToHost, h->stream));
+            }
 #ifdef CS_DIAGNOSTICS
             if (h->sf_ran) {  // the one-launch forward: did it reach its end?
                 uint32_t sync[4] = {0, 0, 0, 0};
@@ -120,6 +152,7 @@ int32_t embed_impl(cs_embedder* h, const int32_t* ids, const int32_t* mask, uint
             }
 #endif
             CS_HIP(hipStreamSynchronize(h->stream));
+            if (pinned_here) { flag = *pin_flag; fetched = !flag; }
             h->split_forwards += 1;
             if (flag) {  // an activation left the f16 range: redo this mini-batch on the exact-f32 MFMA
                 h->range_fallbacks += 1;
@@ -128,7 +161,9 @@ int32_t embed_impl(cs_embedder* h, const int32_t* ids, const int32_t* mask, uint
             }
         }
         if (mode == CS_GEMM_F32) h->f32_forwards += 1;
-        if (!perm) {
+        if (fetched) {
+            std::memcpy(out + done * H, pin_rows, (size_t)B * H * sizeof(float));
+        } else if (!perm) {
             if (!h->pooled_dst)
                 CS_HIP(hipMemcpyAsync(out + done * H, h->d_pooled, (size_t)B * H * sizeof(float),
                                       out_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, h->stream));

@@ -144,6 +144,7 @@ struct cs_embedder {
     float* pooled_dst = nullptr;  // set around a forward whose pooled rows go straight to the caller's device buffer (a corpus region: E8 in place)
     uint32_t* d_perm = nullptr; // [B] destination row of each pooled row (length-sorted text mini-batches)
     std::vector<float> h_pooled; // host staging of a mini-batch's rows when they are scattered
+    char* h_pin = nullptr;       // 128 KiB of pinned host memory: a small mini-batch's ids | mask going in, its range flag + rows coming out
     uint32_t last_B = 0, last_L = 0;
     bool last_hidden_partial = false;  // the last forward ran the CLS tail: d_x holds the previous layer outside the CLS rows
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
