@@ -293,6 +293,7 @@ def encoder_legs(shard, k, device, with_cpu=True):
         emb_mean.embed_ids_to_device(ids5, mask5, d5.data_ptr())
     stages5, _ = emb_mean.profile_stages_read()
     emb_mean.profile_stages(False)
+    query_embed = query_embed_latency(emb_mean, ids, mask)  # the query side on the BGE-small shape (benchmarks/query_latency.py's first line)
     emb_mean.close()
     g5, a5 = _encoder_flops(cfg, B5, L5)
     quantized_default = quantized_default_model_leg(ids, mask, d_q[0], device, iters)
@@ -369,6 +370,7 @@ def encoder_legs(shard, k, device, with_cpu=True):
             "attention_executed_tflops": 3 * layers * 4 * L5 * Hh * B5 * L5 / (stages5["attention"] * 1e-6) / 1e12,
         },
         "quantized_default_model": quantized_default,
+        "query_embed": query_embed,
         "nomic_model": nomic,
         "reference_call_shape": {
             "workload": "32 chunks x 256 tokens per call (BatchEmbedder slices by 32, src/embed/batch.rs:70,94), CLS pooling",
@@ -451,6 +453,22 @@ def nomic_model_leg(device, iters):
     }
 
 
+def query_embed_latency(emb, ids, mask, reps=60):
+    """One short query (1 x 16 tokens) through `emb`: device time of the forward (HIP events) and wall time of the host call."""
+    q_ids, q_mask = ids[:1, :16].copy(), mask[:1, :16].copy()
+    q_mask[:] = 1
+    for _ in range(10):
+        emb.embed_ids(q_ids, q_mask)
+    emb.profile_read(reset=True)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        emb.embed_ids(q_ids, q_mask)
+    wall = (time.perf_counter() - t0) / reps
+    ms, n = emb.profile_read()
+    emb.profile_read(reset=True)
+    return {"tokens": "1 x 16", "device_us": ms / max(n, 1) * 1e3, "host_call_us": wall * 1e6}
+
+
 def quantized_default_model_leg(ids, mask, d_out, device, iters):
     """The reference's DEFAULT model is a dynamically quantised one (ModelType::AllMiniLML6V2Q,
     /root/reference/src/embed/embedder.rs:12-13): 6 layers, hidden 384, Linear weights as onnxruntime's quantize_dynamic
@@ -494,6 +512,7 @@ def quantized_default_model_leg(ids, mask, d_out, device, iters):
     # the reference's call shape on its default model: 32 chunks per embed call (src/embed/batch.rs:70,94), one call at a
     # time and eight of them through the submission queue — each stays its own quantisation unit inside the shared batch
     emb.set_gemm_mode("q8")
+    out["query_embed"] = query_embed_latency(emb, ids, mask)  # `codesearch search`: one short query (src/embed/mod.rs:164-181)
     B = ids.shape[0]
     emb.embed_ids(ids[:32], mask[:32])
     t0 = time.perf_counter()
@@ -1375,6 +1394,8 @@ def main():
             line["encoder_ms_per_batch"] = line["encoder"].get("ms_per_batch")  # BGE-small shape, 256 x 256 tokens, mean pooling (configs[2])
             qd = (line["encoder"].get("quantized_default_model") or {}).get("dynamic_quantisation") or {}
             line["q8_default_model_ms_per_batch"] = qd.get("ms_per_batch")      # AllMiniLML6V2Q shape, 256 x 256 tokens (the reference's default model)
+            line["query_embed_device_us"] = (line["encoder"].get("query_embed") or {}).get("device_us")  # one 16-token query, BGE-small shape
+            line["query_embed_default_model_device_us"] = ((line["encoder"].get("quantized_default_model") or {}).get("query_embed") or {}).get("device_us")
             line["embedded_and_searched_chunks_per_s"] = line["embed_search"]["chunks_embedded_and_searched_per_s"]
             # BASELINE's metric as worded ("chunks embedded+searched/sec over 10M x 384"): the literal figure beside
             # `value`, which is its search half alone at the north-star target
