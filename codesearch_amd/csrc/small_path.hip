@@ -15,6 +15,7 @@
 #include "small_path.hpp"
 
 #include <algorithm>
+#include <cstdlib>
 
 #include "encoder_rows.hpp"
 #include "gemm_epilogue.hpp"
@@ -34,31 +35,37 @@ struct SpGeom {
 }  // namespace
 
 // PRO: 0 LayerNorm of Y's rows | 1 LayerNorm of (slab sum + bias) + residual | 2 embedding gather + LayerNorm
-template <int NPL, int EPI, int PRO>
+// WIDE (many row tiles: a query AND its variants): a block = 16 rows x 64 columns, a wave = one 16-column tile over ALL of K — a
+// quarter of the blocks, so a quarter of the redundant LayerNorm prologues (at 144 rows the 72 column tiles of a row tile read the
+// same four partial slabs 72 times: 80 MB per launch).  The wave keeps the four partial sums the four waves of the narrow form hold
+// (chunks v, v + 4, ... for v = 0..3, in that order) and adds them the same way: the same bits.
+template <int NPL, int EPI, int PRO, bool WIDE = false>
 __global__ void __launch_bounds__(256)
 sp_ln_gemm_kernel(SpLnGemmArgs a) {
     using G = SpGeom<NPL>;
     constexpr int H = G::H, U = G::U;
     __shared__ __attribute__((aligned(16))) char aimg[16 * G::AROW];
-    __shared__ float red[4][16][17];
+    __shared__ float red[WIDE ? 1 : 4][16][17];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l15 = lane & 15, g = lane >> 4;
-    const uint32_t n0 = blockIdx.x * 16, m0 = blockIdx.y * 16, T = a.T;
+    const uint32_t n0 = WIDE ? blockIdx.x * 64 + wave * 16 : blockIdx.x * 16, m0 = blockIdx.y * 16, T = a.T;
     const bool leader = blockIdx.x == 0;
     bool ovf = false;
 
     // this wave's W fragments leave first: they depend on nothing
     constexpr uint32_t kchunks = H / 32;
+    constexpr int NWF = WIDE ? 4 * U : U;  // narrow: chunks wave, wave + 4, ...; wide: every chunk, fragment v * U + u = chunk v + 4 u
     const _Float16* wp = a.W + (size_t)(n0 + l15) * kchunks * 64 + 8 * g;
-    f16x8 wh[U], wl[U];
+    f16x8 wh[NWF], wl[NWF];
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-        wh[u] = *reinterpret_cast<const f16x8*>(wp + (size_t)(wave + 4 * u) * 64);
-        wl[u] = *reinterpret_cast<const f16x8*>(wp + (size_t)(wave + 4 * u) * 64 + 32);
+    for (int i = 0; i < NWF; ++i) {
+        const int chunk = WIDE ? (i / U) + 4 * (i % U) : wave + 4 * i;
+        wh[i] = *reinterpret_cast<const f16x8*>(wp + (size_t)chunk * 64);
+        wl[i] = *reinterpret_cast<const f16x8*>(wp + (size_t)chunk * 64 + 32);
     }
     const int em = tid >> 4, en = tid & 15;
-    const float bias_v = a.bias[n0 + en];
+    const float bias_v = WIDE ? a.bias[n0 + l15] : a.bias[n0 + en];
 
     // ---- prologue: the tile's 16 rows -> LayerNorm -> split form in LDS (4 rows per wave) ----
     float v[4][NPL];
@@ -128,8 +135,41 @@ sp_ln_gemm_kernel(SpLnGemmArgs a) {
     __syncthreads();
 
     // ---- the tile ----
-    sh_f32x4v hh = {0.f, 0.f, 0.f, 0.f}, xx = {0.f, 0.f, 0.f, 0.f};
     const char* irow = aimg + l15 * G::AROW + g * 16;
+    if constexpr (WIDE) {
+        float part[4][4];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            sh_f32x4v hh = {0.f, 0.f, 0.f, 0.f}, xx = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const f16x8 ah = *reinterpret_cast<const f16x8*>(irow + (v + 4 * u) * 128);
+                const f16x8 al = *reinterpret_cast<const f16x8*>(irow + (v + 4 * u) * 128 + 64);
+                hh = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, wh[v * U + u], hh, 0, 0, 0);
+                xx = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, wl[v * U + u], xx, 0, 0, 0);
+                xx = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, wh[v * U + u], xx, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) part[v][r] = fmaf(xx[r], kShLoInv, hh[r]);
+        }
+        // C/D layout: column n0 + l15, rows m0 + 4 g + r
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const uint32_t row = m0 + 4 * g + r, col = n0 + l15;
+            if (row < T) {
+                float o = (part[0][r] + part[1][r]) + (part[2][r] + part[3][r]) + bias_v;
+                if (EPI == SH_OUT_SPLIT_GELU) o = sh_gelu_erf(o);
+                _Float16 hi, lo;
+                ovf |= sh_split(o, hi, lo);
+                _Float16* dst = a.Cs + ((size_t)row * (a.N / 32) + (col >> 5)) * 64 + (col & 31);
+                dst[0] = hi;
+                dst[32] = lo;
+            }
+        }
+        if (ovf && a.flag) atomicOr(a.flag, 1u);
+        return;
+    }
+    sh_f32x4v hh = {0.f, 0.f, 0.f, 0.f}, xx = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         const f16x8 ah = *reinterpret_cast<const f16x8*>(irow + (wave + 4 * u) * 128);
@@ -155,27 +195,52 @@ sp_ln_gemm_kernel(SpLnGemmArgs a) {
 }
 
 // One K slice (a quarter of K = 4 H) of a 16 x 16 tile of C = A W^T: raw sums into slab blockIdx.z of parts[4][T][N].
-template <int NPL>
+// WIDE (sp_ln_gemm_kernel's note): a block = 16 rows x 64 columns, a wave = one column tile over the whole slice, keeping the four
+// partial sums of the narrow form's four waves and adding them the same way.
+template <int NPL, bool WIDE = false>
 __global__ void __launch_bounds__(256)
 sp_partial_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ W, float* __restrict__ parts, uint32_t T, uint32_t N) {
     constexpr int U = SpGeom<NPL>::U;
     constexpr uint32_t kchunks = 8 * NPL, kq = kchunks / 4;  // K = 4 H = 256 NPL
-    __shared__ float red[4][16][17];
+    __shared__ float red[WIDE ? 1 : 4][16][17];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l15 = lane & 15, g = lane >> 4;
-    const uint32_t n0 = blockIdx.x * 16, m0 = blockIdx.y * 16, ks = blockIdx.z;
+    const uint32_t n0 = WIDE ? blockIdx.x * 64 + wave * 16 : blockIdx.x * 16, m0 = blockIdx.y * 16, ks = blockIdx.z;
     const uint32_t r = m0 + l15;
     const _Float16* ap = A + (size_t)(r < T ? r : T - 1) * kchunks * 64 + 8 * g;
     const _Float16* wp = W + (size_t)(n0 + l15) * kchunks * 64 + 8 * g;
-    f16x8 ah[U], al[U], wh[U], wl[U];
+    constexpr int NF = WIDE ? 4 * U : U;  // narrow: chunks wave, wave + 4, ... of the slice; wide: all, fragment v * U + u = chunk v + 4 u
+    f16x8 ah[NF], al[NF], wh[NF], wl[NF];
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-        const size_t off = (size_t)(ks * kq + wave + 4 * u) * 64;
-        wh[u] = *reinterpret_cast<const f16x8*>(wp + off);
-        wl[u] = *reinterpret_cast<const f16x8*>(wp + off + 32);
-        ah[u] = *reinterpret_cast<const f16x8*>(ap + off);
-        al[u] = *reinterpret_cast<const f16x8*>(ap + off + 32);
+    for (int i = 0; i < NF; ++i) {
+        const int chunk = WIDE ? (i / U) + 4 * (i % U) : wave + 4 * i;
+        const size_t off = (size_t)(ks * kq + chunk) * 64;
+        wh[i] = *reinterpret_cast<const f16x8*>(wp + off);
+        wl[i] = *reinterpret_cast<const f16x8*>(wp + off + 32);
+        ah[i] = *reinterpret_cast<const f16x8*>(ap + off);
+        al[i] = *reinterpret_cast<const f16x8*>(ap + off + 32);
+    }
+    if constexpr (WIDE) {
+        float part[4][4];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            sh_f32x4v hh = {0.f, 0.f, 0.f, 0.f}, xx = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                hh = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[v * U + u], wh[v * U + u], hh, 0, 0, 0);
+                xx = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[v * U + u], wl[v * U + u], xx, 0, 0, 0);
+                xx = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[v * U + u], wh[v * U + u], xx, 0, 0, 0);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) part[v][q] = fmaf(xx[q], kShLoInv, hh[q]);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {  // C/D layout: column n0 + l15, rows m0 + 4 g + q
+            const uint32_t row = m0 + 4 * g + q;
+            if (row < T) parts[((size_t)ks * T + row) * N + n0 + l15] = (part[0][q] + part[1][q]) + (part[2][q] + part[3][q]);
+        }
+        return;
     }
     sh_f32x4v hh = {0.f, 0.f, 0.f, 0.f}, xx = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -404,8 +469,22 @@ bool small_path_supported(uint32_t H, uint32_t I, uint32_t T) {
     return (H == 384 || H == 768 || H == 1024) && I == 4 * H && T >= 1 && T <= SP_MAX_ROWS;
 }
 
+// rows from which the dense layers take the wide form (a block = 16 x 64): CS_SMALL_WIDE_MIN_ROWS (laboratory knob; 0 = never)
+static uint32_t sp_wide_min_rows() {
+    static const uint32_t v = [] { const char* e = cs_lab_env("CS_SMALL_WIDE_MIN_ROWS"); return e ? (uint32_t)std::atol(e) : 128u; }();
+    return v;
+}
+
 template <int NPL>
 static void sp_launch_ln_gemm(int epi, int pro, const SpLnGemmArgs& a, hipStream_t s) {
+    if (NPL == 6 && sp_wide_min_rows() && a.T >= sp_wide_min_rows() && a.N % 64 == 0) {
+        const dim3 grid(a.N / 64, (a.T + 15) / 16);
+#define SP_W(E, P) hipLaunchKernelGGL((sp_ln_gemm_kernel<6, E, P, true>), grid, dim3(256), 0, s, a)
+        if (epi == SH_OUT_SPLIT) { if (pro == 0) SP_W(SH_OUT_SPLIT, 0); else if (pro == 1) SP_W(SH_OUT_SPLIT, 1); else SP_W(SH_OUT_SPLIT, 2); }
+        else { if (pro == 0) SP_W(SH_OUT_SPLIT_GELU, 0); else if (pro == 1) SP_W(SH_OUT_SPLIT_GELU, 1); else SP_W(SH_OUT_SPLIT_GELU, 2); }
+#undef SP_W
+        return;
+    }
     const dim3 grid(a.N / 16, (a.T + 15) / 16);
 #define SP_L(E, P) hipLaunchKernelGGL((sp_ln_gemm_kernel<NPL, E, P>), grid, dim3(256), 0, s, a)
     if (epi == SH_OUT_SPLIT) { if (pro == 0) SP_L(SH_OUT_SPLIT, 0); else if (pro == 1) SP_L(SH_OUT_SPLIT, 1); else SP_L(SH_OUT_SPLIT, 2); }
@@ -427,6 +506,11 @@ int32_t launch_sp_ln_gemm(int epi, int pro, const SpLnGemmArgs& a, uint32_t H, h
 }
 
 int32_t launch_sp_partial(const _Float16* A, const _Float16* W, float* parts, uint32_t T, uint32_t N, uint32_t H, hipStream_t s) {
+    if (H == 384 && sp_wide_min_rows() && T >= sp_wide_min_rows() && N % 64 == 0) {
+        hipLaunchKernelGGL((sp_partial_kernel<6, true>), dim3(N / 64, (T + 15) / 16, 4), dim3(256), 0, s, A, W, parts, T, N);
+        CS_HIP(hipGetLastError());
+        return CS_OK;
+    }
     const dim3 grid(N / 16, (T + 15) / 16, 4);
     switch (H) {
         case 384: hipLaunchKernelGGL(sp_partial_kernel<6>, grid, dim3(256), 0, s, A, W, parts, T, N); break;
