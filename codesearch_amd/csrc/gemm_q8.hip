@@ -550,7 +550,9 @@ gemm_q8_kernel(const int8_t* __restrict__ A, const int8_t* __restrict__ W, const
 // q8_quantize_kernel — and its four waves split K between them, weights global -> VGPR in MFMA operand order, every load of
 // a wave in flight at once; the four partial tiles meet in LDS.  With the FFN-up launch leaving the (lo, hi) of what each
 // block stored, a layer is seven launches.  One quantisation unit only.
-template <int EPI, int SRC>
+// WIDE (many row tiles: a query and its variants, N >= 1024): a block = 16 rows x 64 columns, a wave = one column tile over all of K —
+// a quarter of the blocks redo the range reduction and the quantising pass of the same 16 rows.  Integer sums: the same bits.
+template <int EPI, int SRC, bool WIDE = false>
 __global__ void __launch_bounds__(256)
 gemm_q8_skinny_kernel(const void* __restrict__ src, const float* __restrict__ range_pairs, uint32_t n_pairs,
                       const int8_t* __restrict__ W, const Q8ColMeta* __restrict__ cmeta, const float* resid, float* C,
@@ -564,27 +566,33 @@ gemm_q8_skinny_kernel(const void* __restrict__ src, const float* __restrict__ ra
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l15 = lane & 15, g = lane >> 4;
-    const uint32_t n0 = blockIdx.x * 16, m0 = blockIdx.y * 16;
+    const uint32_t n0 = WIDE ? blockIdx.x * 64 + wave * 16 : blockIdx.x * 16, m0 = blockIdx.y * 16;
     const uint32_t astride = K + 16;
-    // this wave's weight fragments first: k-steps wave, wave + 4, ... of 64 (they do not depend on the activations)
+    // this wave's weight fragments first: k-steps wave, wave + 4, ... of 64 — WIDE: every k-step — (they do not depend on the activations)
     const uint32_t ksteps = K / 64;
-    const uint32_t mine = ksteps > (uint32_t)wave ? (ksteps - wave + 3) / 4 : 0;
+    const uint32_t mine = WIDE ? ksteps : (ksteps > (uint32_t)wave ? (ksteps - wave + 3) / 4 : 0);
+    const uint32_t kfirst = WIDE ? 0u : (uint32_t)wave, kstride = WIDE ? 1u : 4u;
     const int8_t* wp = W + (size_t)(n0 + l15) * K + g * 16;
     constexpr int U = 6;  // K = 1536: six steps per wave; beyond that the loop runs again
     q8_i32x4 wf[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         const uint32_t i = (uint32_t)u < mine ? u : (mine ? mine - 1 : 0);
-        wf[u] = mine ? *reinterpret_cast<const q8_i32x4*>(wp + (size_t)(wave + 4 * i) * 64) : q8_i32x4{0, 0, 0, 0};
+        wf[u] = mine ? *reinterpret_cast<const q8_i32x4*>(wp + (size_t)(kfirst + kstride * i) * 64) : q8_i32x4{0, 0, 0, 0};
     }
     // the epilogue's operands and the block's raw activation rows are requested NOW, with the weights and the pairs: the range, the
     // quantising pass and the epilogue used to wait for memory one after the other (three round trips per launch, ~1.5 us each, in a
     // path that is seven dependent launches per layer)
     const int em = tid >> 4, en = tid & 15;
-    const uint32_t erow = m0 + em, ecol = n0 + en;
-    const Q8ColMeta cm = cmeta[ecol];
-    float e_resid = 0.0f;
-    if (EPI == SH_OUT_F32_RESID) e_resid = resid[(size_t)(erow < M ? erow : M - 1) * N + ecol];
+    constexpr int ET = WIDE ? 4 : 1;  // column tiles of the block: thread (em, en) finishes element (em, en) of each
+    const uint32_t erow = m0 + em, ecol0 = (WIDE ? blockIdx.x * 64 : blockIdx.x * 16) + en;
+    Q8ColMeta cmv[ET];
+    float e_residv[ET];
+#pragma unroll
+    for (int t = 0; t < ET; ++t) {
+        cmv[t] = cmeta[ecol0 + 16 * t];
+        e_residv[t] = EPI == SH_OUT_F32_RESID ? resid[(size_t)(erow < M ? erow : M - 1) * N + ecol0 + 16 * t] : 0.0f;
+    }
     // 16 rows x K / 16 slots of 16 k; slot sidx = tid + 256 s (s < 6: K <= 1536; beyond, the loop below reads the rest as before)
     const uint32_t spr = K / 16, nslots = 16 * spr;
     constexpr int PS = SRC == Q8_SRC_LN ? 1 : 6;
@@ -743,13 +751,13 @@ gemm_q8_skinny_kernel(const void* __restrict__ src, const float* __restrict__ ra
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const uint32_t i = i0 + u < mine ? i0 + u : mine - 1;
-                wf[u] = *reinterpret_cast<const q8_i32x4*>(wp + (size_t)(wave + 4 * i) * 64);
+                wf[u] = *reinterpret_cast<const q8_i32x4*>(wp + (size_t)(kfirst + kstride * i) * 64);
             }
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             if (i0 + u < mine) {  // wave-uniform
-                const q8_i32x4 a = *reinterpret_cast<const q8_i32x4*>(lds + l15 * astride + (size_t)(wave + 4 * (i0 + u)) * 64 + g * 16);
+                const q8_i32x4 a = *reinterpret_cast<const q8_i32x4*>(lds + l15 * astride + (size_t)(kfirst + kstride * (i0 + u)) * 64 + g * 16);
                 acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, wf[u], acc, 0, 0, 0);
             }
         }
@@ -759,31 +767,36 @@ gemm_q8_skinny_kernel(const void* __restrict__ src, const float* __restrict__ ra
     for (int r = 0; r < 4; ++r) red[wave][4 * g + r][l15] = acc[r];
     __syncthreads();
     const int m = em, n = en;
-    const uint32_t row = erow, col = ecol;
-    const int total = (red[0][m][n] + red[1][m][n]) + (red[2][m][n] + red[3][m][n]);
-    const int corr = total - __mul24(cm.zw, s_rowsum[m] - (int)K * za) - __mul24(za, cm.colsum);
-    float v = __fadd_rn(__fmul_rn((float)corr, __fmul_rn(xs, cm.ws)), cm.bias);
+    const uint32_t row = erow;
     float rlo = 0.0f, rhi = 0.0f;
     bool ovf = false;
-    if (EPI == SH_OUT_F32 || EPI == SH_OUT_F32_RESID) {
-        if (row < M) {
-            if (EPI == SH_OUT_F32_RESID) v += e_resid;
-            C[(size_t)row * N + col] = v;
+#pragma unroll
+    for (int t = 0; t < ET; ++t) {
+        const uint32_t col = ecol0 + 16 * t;
+        const Q8ColMeta cm = cmv[t];
+        const int total = WIDE ? red[t][m][n] : (red[0][m][n] + red[1][m][n]) + (red[2][m][n] + red[3][m][n]);
+        const int corr = total - __mul24(cm.zw, s_rowsum[m] - (int)K * za) - __mul24(za, cm.colsum);
+        float v = __fadd_rn(__fmul_rn((float)corr, __fmul_rn(xs, cm.ws)), cm.bias);
+        if (EPI == SH_OUT_F32 || EPI == SH_OUT_F32_RESID) {
+            if (row < M) {
+                if (EPI == SH_OUT_F32_RESID) v += e_residv[t];
+                C[(size_t)row * N + col] = v;
+            }
+        } else {
+            if (EPI == SH_OUT_SPLIT_GELU) v = sh_gelu_erf(v);
+            _Float16 h16, l16;
+            ovf |= sh_split(v, h16, l16);
+            if (row < M) {
+                _Float16* dst = Cs + ((size_t)row * (N / 32) + (col >> 5)) * 64 + (col & 31);
+                dst[0] = h16;
+                dst[32] = l16;
+                const float stored = fmaf((float)l16, kShLoInv, (float)h16);  // what the next Linear's quantiser will read
+                rlo = fminf(rlo, stored);
+                rhi = fmaxf(rhi, stored);
+            }
         }
-    } else {
-        if (EPI == SH_OUT_SPLIT_GELU) v = sh_gelu_erf(v);
-        _Float16 h16, l16;
-        ovf = sh_split(v, h16, l16);
-        if (row < M) {
-            _Float16* dst = Cs + ((size_t)row * (N / 32) + (col >> 5)) * 64 + (col & 31);
-            dst[0] = h16;
-            dst[32] = l16;
-            const float stored = fmaf((float)l16, kShLoInv, (float)h16);  // what the next Linear's quantiser will read
-            rlo = fminf(rlo, stored);
-            rhi = fmaxf(rhi, stored);
-        }
-        if (ovf && flag) atomicOr(flag, 1u);
     }
+    if (EPI != SH_OUT_F32 && EPI != SH_OUT_F32_RESID && ovf && flag) atomicOr(flag, 1u);
     if (range_out) {  // this block's (lo, hi) of what it stored, for the Linear that follows
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
@@ -2028,11 +2041,25 @@ int32_t launch_gemm_q8_skinny(int epi, int src_kind, const void* d_src, const fl
     if (out_pairs) *out_pairs = 0;
     if (N % 32 || K % 64 || K == 0) return fail(CS_ERR_UNSUPPORTED, "quantised GEMM N=%u K=%u must be multiples of 32 / 64", N, K);
     if (M == 0) return CS_OK;
-    const dim3 grid(N / 16, (M + 15) / 16);
     const size_t lds = (size_t)16 * (K + 16);
+    const bool f32src = src_kind == Q8_SRC_F32;
+    // many row tiles of a wide layer (QKV, FFN-up of a query and its variants): 16 x 64 blocks (CS_Q8_SKINNY_WIDE_MIN_M, laboratory knob; 0 = never)
+    static const uint32_t wide_min = [] { const char* e = cs_lab_env("CS_Q8_SKINNY_WIDE_MIN_M"); return e ? (uint32_t)std::atol(e) : 128u; }();
+    if (wide_min && M >= wide_min && K == 384 && N >= 1024 && N % 64 == 0 && f32src && (epi == SH_OUT_SPLIT || epi == SH_OUT_SPLIT_GELU)) {
+        const dim3 wgrid(N / 64, (M + 15) / 16);
+        if (epi == SH_OUT_SPLIT)
+            hipLaunchKernelGGL((gemm_q8_skinny_kernel<SH_OUT_SPLIT, Q8_SRC_F32, true>), wgrid, dim3(256), lds, s, d_src, d_range_pairs, n_pairs, d_wq, d_cmeta,
+                               resid, C, Cs, M, N, K, d_flag, d_range_out);
+        else
+            hipLaunchKernelGGL((gemm_q8_skinny_kernel<SH_OUT_SPLIT_GELU, Q8_SRC_F32, true>), wgrid, dim3(256), lds, s, d_src, d_range_pairs, n_pairs, d_wq,
+                               d_cmeta, resid, C, Cs, M, N, K, d_flag, d_range_out);
+        CS_HIP(hipGetLastError());
+        if (out_pairs && d_range_out) *out_pairs = wgrid.x * wgrid.y;
+        return CS_OK;
+    }
+    const dim3 grid(N / 16, (M + 15) / 16);
 #define CS_Q8S(E, S) hipLaunchKernelGGL((gemm_q8_skinny_kernel<E, S>), grid, dim3(256), lds, s, d_src, d_range_pairs, n_pairs, d_wq, d_cmeta, \
                                         resid, C, Cs, M, N, K, d_flag, d_range_out)
-    const bool f32src = src_kind == Q8_SRC_F32;
     if (epi == SH_OUT_SPLIT && f32src) CS_Q8S(SH_OUT_SPLIT, Q8_SRC_F32);
     else if (epi == SH_OUT_SPLIT_GELU && f32src) CS_Q8S(SH_OUT_SPLIT_GELU, Q8_SRC_F32);
     else if (epi == SH_OUT_F32_RESID && !f32src) CS_Q8S(SH_OUT_F32_RESID, Q8_SRC_SPLIT);

@@ -726,6 +726,45 @@ def test_one_short_query_folds_its_layernorms_into_the_products(gpu_lib, oracle,
     assert err.max() < 3e-3, (err.max(), np.median(err))
 
 
+def test_a_query_and_its_variants_on_wide_blocks(gpu_lib, oracle, tmp_path):
+    """From 128 token rows the few-rows quantised products of the wide layers (QKV, FFN-up) run on 16 x 64 blocks (a wave =
+    one column tile over all of K; gemm_q8_skinny_kernel WIDE).  Nine and twelve 16-token sequences: the quantised oracle's
+    embedding at the model level's bar, and BIT FOR BIT the embedding of the 16 x 16 blocks (CS_Q8_SKINNY_WIDE_MIN_M=0 — a
+    laboratory knob read once per process: a child process on the diagnostic library)."""
+    import os
+    import subprocess
+    import sys
+
+    from codesearch_amd import FastEmbedder, ModelType, _lib
+
+    cfg = small_cfg(POOL_MEAN, layers=3)
+    params, wscale = quantize_linear_weights(cfg, synth_params(cfg, 71), per_channel=False, unsigned=True)
+    outs = {}
+    for B in (9, 12):
+        ids, mask = synth_token_batch(cfg, 72 + B, B, 16, True)
+        emb = FastEmbedder(ModelType.AllMiniLML6V2Q, config=cfg, params=params, wscale=wscale)
+        outs[B] = emb.embed_ids(ids, mask, batch_size=B)
+        emb.close()
+        want = oracle.bert_forward(cfg, params, ids, mask, wscale=wscale)["pooled"]
+        assert np.abs(outs[B] - want).max() < 3e-3
+    code = (
+        "import numpy as np, sys\n"
+        "from codesearch_amd import FastEmbedder, ModelType\n"
+        "from codesearch_amd.bert_params import POOL_MEAN, BertConfig, quantize_linear_weights, synth_params, synth_token_batch\n"
+        "cfg = BertConfig(vocab_size=1500, hidden=384, layers=3, heads=12, intermediate=1536, max_position=64, pooling=POOL_MEAN)\n"
+        "params, wscale = quantize_linear_weights(cfg, synth_params(cfg, 71), per_channel=False, unsigned=True)\n"
+        "for B in (9, 12):\n"
+        "    ids, mask = synth_token_batch(cfg, 72 + B, B, 16, True)\n"
+        "    emb = FastEmbedder(ModelType.AllMiniLML6V2Q, config=cfg, params=params, wscale=wscale)\n"
+        "    np.save(sys.argv[1] + str(B) + '.npy', emb.embed_ids(ids, mask, batch_size=B))\n"
+        "    emb.close()\n")
+    env = dict(os.environ, CS_Q8_SKINNY_WIDE_MIN_M="0", CS_LIBCSGPU=_lib.DIAG_LIB_PATH)
+    subprocess.run([sys.executable, "-c", code, str(tmp_path / "narrow")], check=True, env=env,
+                   cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    for B in (9, 12):
+        assert np.load(str(tmp_path / "narrow") + f"{B}.npy").tobytes() == outs[B].tobytes()
+
+
 @pytest.mark.parametrize("B,L", [(256, 16), (264, 16), (320, 40), (512, 64), (1024, 64)])
 def test_layernorm_fused_products_repeat_their_bits(gpu_lib, oracle, B, L):
     """A race screen for the LayerNorm-fused products (gemm_q8_ln_kernel: weight stages by LDS-DMA behind COUNTED vmcnt waits
