@@ -454,19 +454,25 @@ def nomic_model_leg(device, iters):
 
 
 def query_embed_latency(emb, ids, mask, reps=60):
-    """One short query (1 x 16 tokens) through `emb`: device time of the forward (HIP events) and wall time of the host call."""
-    q_ids, q_mask = ids[:1, :16].copy(), mask[:1, :16].copy()
-    q_mask[:] = 1
-    for _ in range(10):
-        emb.embed_ids(q_ids, q_mask)
-    emb.profile_read(reset=True)
-    t0 = time.perf_counter()
-    for _ in range(reps):
-        emb.embed_ids(q_ids, q_mask)
-    wall = (time.perf_counter() - t0) / reps
-    ms, n = emb.profile_read()
-    emb.profile_read(reset=True)
-    return {"tokens": "1 x 16", "device_us": ms / max(n, 1) * 1e3, "host_call_us": wall * 1e6}
+    """One short query (1 x 16 tokens) through `emb`, and a query with its eight variants (9 x 16: what the reference embeds per search,
+    src/search/mod.rs:508-611): device time of the forward (HIP events) and wall time of the host call."""
+    out = {}
+    for B, key in ((1, ""), (9, "variants_")):
+        q_ids, q_mask = ids[:B, :16].copy(), mask[:B, :16].copy()
+        q_mask[:] = 1
+        for _ in range(10):
+            emb.embed_ids(q_ids, q_mask)
+        emb.profile_read(reset=True)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            emb.embed_ids(q_ids, q_mask)
+        wall = (time.perf_counter() - t0) / reps
+        ms, n = emb.profile_read()
+        emb.profile_read(reset=True)
+        out[key + "tokens"] = f"{B} x 16"
+        out[key + "device_us"] = ms / max(n, 1) * 1e3
+        out[key + "host_call_us"] = wall * 1e6
+    return out
 
 
 def quantized_default_model_leg(ids, mask, d_out, device, iters):
