@@ -419,7 +419,8 @@ int32_t forward_range(cs_embedder* h, hipStream_t s, uint32_t b0, uint32_t nb, u
                 static const bool ln_slot = [] { const char* e = cs_lab_env("CS_Q8_LN_SLOT"); return e && e[0] == '1'; }();
                 if (l == 0) h->q8_x_pairs = ln_pairs;
                 if (h->q8_x_pairs) CS_TRY(launch_q8_range(Q8_SRC_F32, x, T, H, rg, s, rp, h->q8_x_pairs));
-                CS_TRY(launch_gemm_q8_from_source(SH_OUT_SPLIT, Q8_SRC_F32, x, rg, wq + ql.qkv, cm, bqkv, nullptr, nullptr, qkvs, T, 3 * H, H, h->d_flag, s, nullptr, cmt));  // E2
+                CS_TRY(launch_gemm_q8_from_source(SH_OUT_SPLIT, Q8_SRC_F32, x, rg, wq + ql.qkv, cm, bqkv, nullptr, nullptr, qkvs, T, 3 * H, H, h->d_flag, s, nullptr, cmt,
+                                                  xq));  // E2 (xq: scratch for the quantised rows of a call of few slabs)
                 CS_TRY(mark(CS_STAGE_QKV));
                 uint32_t att_pairs = 0;
                 CS_TRY(launch_attention_sh2(qkvs, mask, ctxs, h->d_flag, nb, L, H, c.heads, s, rp, &att_pairs));  // E3

@@ -2014,9 +2014,9 @@ int32_t launch_q8_range_units(const float* d_range_pairs, uint32_t pairs_per_seq
 int32_t launch_gemm_q8_from_source(int epi, int src_kind, const void* d_src, const uint32_t* d_in_range, const int8_t* d_wq,
                                    const Q8ColMeta* d_cmeta, const float* bias, const float* resid, float* C, _Float16* Cs,
                                    uint32_t M, uint32_t N, uint32_t K, uint32_t* d_flag, hipStream_t s, const uint32_t* d_row_slot,
-                                   const uint32_t* d_cmeta_tiles) {
+                                   const uint32_t* d_cmeta_tiles, int8_t* d_xq_scratch) {
     if (d_cmeta_tiles && !d_row_slot && epi == SH_OUT_SPLIT && src_kind == Q8_SRC_F32 && q8_slab_takes(M, N, K))
-        return launch_gemm_q8_slab_split(reinterpret_cast<const float*>(d_src), d_in_range, d_wq, d_cmeta_tiles, Cs, M, N, K, d_flag, s);
+        return launch_gemm_q8_slab_split(reinterpret_cast<const float*>(d_src), d_in_range, d_wq, d_cmeta_tiles, Cs, M, N, K, d_flag, s, d_xq_scratch);
     if (!q8_rows_takes(M, K) || N % 128) return fail(CS_ERR_UNSUPPORTED, "quantise-on-load product: M=%u N=%u K=%u not taken by the row-block kernel", M, N, K);
     const Q8Requant none{nullptr, nullptr, nullptr, 0u};
     if (epi == SH_OUT_SPLIT && src_kind == Q8_SRC_F32 && d_row_slot)

@@ -66,7 +66,7 @@ int32_t launch_q8_range(int src_kind, const void* d_src, uint32_t T, uint32_t K,
 int32_t launch_gemm_q8_from_source(int epi, int src_kind, const void* d_src, const uint32_t* d_in_range, const int8_t* d_wq,
                                    const Q8ColMeta* d_cmeta, const float* bias, const float* resid, float* C, _Float16* Cs,
                                    uint32_t M, uint32_t N, uint32_t K, uint32_t* d_flag, hipStream_t s,
-                                   const uint32_t* d_row_slot = nullptr, const uint32_t* d_cmeta_tiles = nullptr);
+                                   const uint32_t* d_row_slot = nullptr, const uint32_t* d_cmeta_tiles = nullptr, int8_t* d_xq_scratch = nullptr);
 int32_t launch_gemm_q8_gelu_requant_from_source(const float* d_x, const uint32_t* d_in_range, const int8_t* d_wq, const Q8ColMeta* d_cmeta,
                                                 const float* bias, uint32_t M, uint32_t N, uint32_t K, uint32_t* d_range_out,
                                                 int8_t* d_out, Q8RowMeta* d_rmeta_out, hipStream_t s,
@@ -80,7 +80,7 @@ bool q8_slab_takes(uint32_t M, uint32_t N, uint32_t K);
 uint32_t q8_gelu_table_on();  // CS_Q8_GELU_TABLE=0: the store pass computes the re-quantised GELU byte directly (read per launch)
 int32_t launch_q8_cmeta_tiles(const Q8ColMeta* d_cmeta, uint32_t N, uint32_t* d_tiles, hipStream_t s);
 int32_t launch_gemm_q8_slab_split(const float* d_x, const uint32_t* d_in_range, const int8_t* d_wq, const uint32_t* d_cmeta_tiles,
-                                  _Float16* Cs, uint32_t M, uint32_t N, uint32_t K, uint32_t* d_flag, hipStream_t s);
+                                  _Float16* Cs, uint32_t M, uint32_t N, uint32_t K, uint32_t* d_flag, hipStream_t s, int8_t* d_xq_scratch = nullptr);
 int32_t launch_gemm_q8_slab_gelu_requant(const float* d_x, const uint32_t* d_in_range, const int8_t* d_wq, const uint32_t* d_cmeta_tiles,
                                          uint32_t M, uint32_t N, uint32_t K, uint32_t* d_range_out, int8_t* d_out, Q8RowMeta* d_rmeta_out,
                                          uint32_t use_table, hipStream_t s, int8_t* d_xq_scratch = nullptr);

@@ -573,6 +573,46 @@ int qs_cus() {
     return cus;
 }
 
+// X [M][384] f32 -> xq [M][384] s8 with the tensor's parameters: the slab kernel's own quantising arithmetic (reciprocal quotient, the true
+// division inside the tie window: the bytes of q8_quantize_kernel), one thread per 16 values.  For calls of few slabs, whose units
+// (slab x a range of n-tiles) would otherwise each quantise the slab's 256 rows again.
+__global__ void __launch_bounds__(256)
+qs_prequant_kernel(const float* __restrict__ X, const uint32_t* __restrict__ in_range, int8_t* __restrict__ xq, uint64_t n16) {
+    float xs, xz;
+    q8_params(in_range, xs, xz);
+    const float rxs = __fdiv_rn(1.0f, xs);
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n16) return;
+    const sh_f32x4* p = reinterpret_cast<const sh_f32x4*>(X + i * 16);
+    q8_i32x4 packed;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        const sh_f32x4 x = p[w];
+        float rt[4], d[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float t = x[e] * rxs;
+            rt[e] = rintf(t);
+            d[e] = t - rt[e];
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (fabsf(d[e]) > 0.4999f) rt[e] = rintf(__fdiv_rn(x[e], xs));
+        uint32_t pw = 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) pw = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_amdgcn_fmed3f(__fadd_rn(rt[e], xz), 0.0f, 255.0f), e, pw);
+        packed[w] = (int)(pw ^ 0x80808080u);
+    }
+    *reinterpret_cast<q8_i32x4*>(xq + i * 16) = packed;
+}
+
+// units per slab the launch below cuts (1 when every CU has a slab of its own)
+static uint32_t qs_parts(uint32_t M, uint32_t N) {
+    const uint32_t slabs = (M + QS_ROWS - 1) / QS_ROWS, ntiles = N / 128, cus = (uint32_t)qs_cus();
+    uint32_t parts = slabs >= cus ? 1u : (cus + slabs - 1) / slabs;
+    return parts > ntiles ? ntiles : parts;
+}
+
 template <int EPI, bool PREQ = false>
 int32_t launch_slab(const void* d_x, const uint32_t* d_in_range, const int8_t* d_wq, const uint32_t* d_cmt, _Float16* Cs, uint32_t M,
                     uint32_t N, uint32_t* d_flag, Q8Requant rq, hipStream_t s, int8_t* d_xq_out = nullptr) {
@@ -610,9 +650,17 @@ bool q8_slab_takes(uint32_t M, uint32_t N, uint32_t K) {
 }
 
 int32_t launch_gemm_q8_slab_split(const float* d_x, const uint32_t* d_in_range, const int8_t* d_wq, const uint32_t* d_cmeta_tiles,
-                                  _Float16* Cs, uint32_t M, uint32_t N, uint32_t K, uint32_t* d_flag, hipStream_t s) {
+                                  _Float16* Cs, uint32_t M, uint32_t N, uint32_t K, uint32_t* d_flag, hipStream_t s, int8_t* d_xq_scratch) {
     if (K != 128 * QS_KC || N % 128 || N == 0) return fail(CS_ERR_UNSUPPORTED, "slab product: N=%u K=%u not built (K = 384, N %% 128 == 0)", N, K);
     if (M == 0) return CS_OK;
+    // few slabs (a call of 32 chunks: the reference's own call shape, src/embed/batch.rs:70): three and more units share a slab and
+    // each would quantise its 256 rows again (16 of a unit's ~30 us) — quantise once, the units read the bytes
+    if (d_xq_scratch && qs_parts(M, N) >= 3) {
+        const uint64_t n16 = (uint64_t)M * K / 16;
+        hipLaunchKernelGGL(qs_prequant_kernel, dim3((uint32_t)((n16 + 255) / 256)), dim3(256), 0, s, d_x, d_in_range, d_xq_scratch, n16);
+        CS_HIP(hipGetLastError());
+        return launch_slab<SH_OUT_SPLIT, true>(d_xq_scratch, d_in_range, d_wq, d_cmeta_tiles, Cs, M, N, d_flag, Q8Requant{nullptr, nullptr, nullptr, 0u}, s);
+    }
     return launch_slab<SH_OUT_SPLIT>(d_x, d_in_range, d_wq, d_cmeta_tiles, Cs, M, N, d_flag, Q8Requant{nullptr, nullptr, nullptr, 0u}, s);
 }
 
@@ -623,6 +671,13 @@ int32_t launch_gemm_q8_slab_gelu_requant(const float* d_x, const uint32_t* d_in_
     if (M == 0) return CS_OK;
     const Q8Requant rq{d_range_out, d_out, d_rmeta_out, use_table};
     // d_xq_scratch [M][384] s8 (optional): the range pass leaves the rows it quantised there and the store pass takes them from it
+    if (d_xq_scratch && qs_parts(M, N) >= 3) {  // (few slabs: launch_gemm_q8_slab_split's note) both passes read bytes quantised once
+        const uint64_t n16 = (uint64_t)M * K / 16;
+        hipLaunchKernelGGL(qs_prequant_kernel, dim3((uint32_t)((n16 + 255) / 256)), dim3(256), 0, s, d_x, d_in_range, d_xq_scratch, n16);
+        CS_HIP(hipGetLastError());
+        CS_TRY((launch_slab<Q8_EPI_GELU_RANGE, true>(d_xq_scratch, d_in_range, d_wq, d_cmeta_tiles, nullptr, M, N, nullptr, rq, s)));
+        return (launch_slab<Q8_EPI_GELU_Q8, true>(d_xq_scratch, d_in_range, d_wq, d_cmeta_tiles, nullptr, M, N, nullptr, rq, s));
+    }
     CS_TRY(launch_slab<Q8_EPI_GELU_RANGE>(d_x, d_in_range, d_wq, d_cmeta_tiles, nullptr, M, N, nullptr, rq, s, d_xq_scratch));
     if (d_xq_scratch) return (launch_slab<Q8_EPI_GELU_Q8, true>(d_xq_scratch, d_in_range, d_wq, d_cmeta_tiles, nullptr, M, N, nullptr, rq, s));
     return launch_slab<Q8_EPI_GELU_Q8>(d_x, d_in_range, d_wq, d_cmeta_tiles, nullptr, M, N, nullptr, rq, s);
